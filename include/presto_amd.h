@@ -1,0 +1,310 @@
+/*
+ * presto_amd.h -- C ABI of the MI355X-native page-processing library (libpresto_amd.so).
+ *
+ * This is the drop-in boundary for Trino's vectorized page-processing hot path
+ * (SURVEY.md section 8b).  Every entry point is extern "C", takes plain pointers and
+ * sizes, returns an int32 status (0 / positive = OK, negative = pa_status error class)
+ * and never lets a C++ exception cross.  A JNI shim binds one `native` method per
+ * export; tests bind the same symbols through ctypes.
+ *
+ * Reference interfaces replaced (all paths under /root/reference/core):
+ *   Operator protocol           trino-main/src/main/java/io/trino/operator/Operator.java:21-103
+ *   OperatorFactory             trino-main/src/main/java/io/trino/operator/OperatorFactory.java:18-50
+ *   Page / Block data model     trino-spi/src/main/java/io/trino/spi/Page.java:33-398,
+ *                               trino-spi/src/main/java/io/trino/spi/block/LongArrayBlock.java:32-130,
+ *                               .../IntArrayBlock.java, .../ByteArrayBlock.java,
+ *                               .../VariableWidthBlock.java:34-110, .../DictionaryBlock.java,
+ *                               .../RunLengthEncodedBlock.java
+ *   RowExpression tree          trino-main/src/main/java/io/trino/sql/relational/{CallExpression,
+ *                               ConstantExpression,InputReferenceExpression,SpecialForm}.java
+ */
+#ifndef PRESTO_AMD_H
+#define PRESTO_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PA_ABI_VERSION 1
+
+/* ---- status codes (negative = error).  Mapped by the JNI shim onto TrinoException
+ *      StandardErrorCode (trino-spi/.../StandardErrorCode.java). ---- */
+typedef enum pa_status {
+    PA_OK = 0,
+    PA_ERR_INVALID_ARGUMENT = -1,        /* IllegalArgumentException / checkArgument */
+    PA_ERR_ILLEGAL_STATE = -2,           /* checkState: addInput when !needsInput, after finish ... */
+    PA_ERR_NOT_SUPPORTED = -3,           /* expression / type outside the device subset: caller falls back to Java */
+    PA_ERR_NUMERIC_VALUE_OUT_OF_RANGE = -4, /* BigintOperators.java:47-55 (Math.addExact etc.) */
+    PA_ERR_DIVISION_BY_ZERO = -5,        /* BigintOperators.java:88-110 */
+    PA_ERR_INSUFFICIENT_RESOURCES = -6,  /* BigintGroupByHash.java:264-267 (table > 2^30) / HBM exhausted */
+    PA_ERR_DEVICE = -7,                  /* HIP / RCCL runtime error */
+    PA_ERR_COMPILER = -8,                /* COMPILER_ERROR: device code generation failed */
+    PA_ERR_NO_DEVICE = -9                /* no gfx950 device / HIP extension unusable: fail loudly, never fall back */
+} pa_status;
+
+/* ---- SQL types on the path (physical layout follows SURVEY.md section 8 preamble) ---- */
+typedef enum pa_type {
+    PA_BIGINT = 0,   /* LongArrayBlock, 8 B */
+    PA_INTEGER = 1,  /* IntArrayBlock, 4 B */
+    PA_DATE = 2,     /* IntArrayBlock, 4 B, days since 1970-01-01 */
+    PA_DOUBLE = 3,   /* LongArrayBlock holding doubleToLongBits, 8 B */
+    PA_BOOLEAN = 4,  /* ByteArrayBlock, 1 B */
+    PA_VARCHAR = 5   /* VariableWidthBlock: bytes + int32 offsets[positionCount+1] */
+} pa_type;
+
+typedef enum pa_encoding {
+    PA_FLAT = 0,        /* values[] (+array_offset), optional nulls[] */
+    PA_VARWIDTH = 1,    /* values = bytes, offsets[positionCount+1] (already shifted by array_offset) */
+    PA_DICTIONARY = 2,  /* ids[positionCount] into *dictionary */
+    PA_RLE = 3          /* *dictionary holds exactly one position, repeated positionCount times */
+} pa_encoding;
+
+typedef enum pa_mem {
+    PA_MEM_HOST = 0,    /* pointers are host addresses (JVM-copied / pinned staging) */
+    PA_MEM_DEVICE = 1   /* pointers are HBM addresses on the operator's device */
+} pa_mem;
+
+/* One Block.  nulls is Trino's boolean[] valueIsNull: 1 byte per position, non-zero = NULL,
+ * may be NULL pointer when the block has no nulls (LongArrayBlock.java:37-41). */
+typedef struct pa_column {
+    int32_t type;                       /* pa_type */
+    int32_t encoding;                   /* pa_encoding */
+    const void* values;                 /* FLAT: element array; VARWIDTH: byte array */
+    const int32_t* offsets;             /* VARWIDTH only */
+    const uint8_t* nulls;               /* optional */
+    const int32_t* ids;                 /* DICTIONARY only */
+    const struct pa_column* dictionary; /* DICTIONARY / RLE */
+    int32_t dictionary_size;            /* positions in *dictionary */
+    int32_t reserved;
+} pa_column;
+
+/* One Page: Block[] + positionCount (Page.java:33-60). */
+typedef struct pa_page {
+    int32_t position_count;
+    int32_t channel_count;
+    pa_column* columns;
+    int32_t mem;                        /* pa_mem: where every pointer of every column lives */
+    int32_t reserved;
+} pa_page;
+
+/* ---- RowExpression tree, flattened (TM/sql/relational package) ---- */
+typedef enum pa_expr_kind {
+    PA_EXPR_INPUT_REF = 0,   /* InputReferenceExpression(field) */
+    PA_EXPR_CONSTANT = 1,    /* ConstantExpression(value, type) */
+    PA_EXPR_CALL = 2,        /* CallExpression(resolvedFunction, args) */
+    PA_EXPR_SPECIAL = 3      /* SpecialForm(form, args)  (SpecialForm.java:137-152) */
+} pa_expr_kind;
+
+typedef enum pa_call_op {    /* operator / function of a CALL node; operand types from children */
+    PA_OP_ADD = 0, PA_OP_SUBTRACT = 1, PA_OP_MULTIPLY = 2, PA_OP_DIVIDE = 3, PA_OP_MODULUS = 4,
+    PA_OP_NEGATE = 5,
+    PA_OP_EQUAL = 6, PA_OP_NOT_EQUAL = 7, PA_OP_LESS_THAN = 8, PA_OP_LESS_THAN_OR_EQUAL = 9,
+    PA_OP_GREATER_THAN = 10, PA_OP_GREATER_THAN_OR_EQUAL = 11,
+    PA_OP_NOT = 12,          /* $not */
+    PA_OP_CAST = 13          /* to node type; INTEGER/DATE->BIGINT, BIGINT/INTEGER->DOUBLE */
+} pa_call_op;
+
+typedef enum pa_special_form {
+    PA_FORM_AND = 0, PA_FORM_OR = 1, PA_FORM_BETWEEN = 2, PA_FORM_IS_NULL = 3,
+    PA_FORM_IF = 4, PA_FORM_COALESCE = 5, PA_FORM_IN = 6
+} pa_special_form;
+
+typedef struct pa_expr_node {
+    int32_t kind;       /* pa_expr_kind */
+    int32_t op;         /* pa_call_op or pa_special_form */
+    int32_t type;       /* result pa_type */
+    int32_t channel;    /* INPUT_REF: page channel */
+    int32_t is_null;    /* CONSTANT: typed NULL */
+    int32_t nargs;
+    int32_t first_arg;  /* index of first child id in pa_expr.args */
+    int32_t str_len;    /* CONSTANT VARCHAR */
+    int64_t i64;        /* CONSTANT BIGINT/INTEGER/DATE/BOOLEAN */
+    double f64;         /* CONSTANT DOUBLE */
+    const char* str;    /* CONSTANT VARCHAR bytes (not NUL terminated) */
+} pa_expr_node;
+
+typedef struct pa_expr {
+    int32_t node_count;
+    int32_t root;
+    const pa_expr_node* nodes;
+    int32_t arg_count;
+    int32_t reserved;
+    const int32_t* args;
+} pa_expr;
+
+/* ---- aggregate functions (TM/operator/aggregation package) ---- */
+typedef enum pa_agg_fn {
+    PA_AGG_COUNT_STAR = 0,   /* CountAggregation.java:33-55 */
+    PA_AGG_COUNT = 1,        /* count(x): non-null inputs */
+    PA_AGG_SUM = 2,          /* DoubleSumAggregation / LongSumAggregation by input type */
+    PA_AGG_AVG = 3,          /* AverageAggregations.java:34-80 */
+    PA_AGG_MIN = 4,
+    PA_AGG_MAX = 5
+} pa_agg_fn;
+
+typedef struct pa_aggregate {
+    int32_t fn;              /* pa_agg_fn */
+    int32_t input_channel;   /* -1 for count(*) */
+    int32_t mask_channel;    /* BOOLEAN channel or -1 (CompilerOperations.java:65-74 semantics) */
+    int32_t input_type;      /* pa_type of the input channel */
+} pa_aggregate;
+
+typedef enum pa_agg_step { PA_STEP_SINGLE = 0, PA_STEP_PARTIAL = 1, PA_STEP_FINAL = 2 } pa_agg_step;
+
+/* ---- operator descriptors (what the planner hands to an OperatorFactory) ---- */
+
+/* FilterAndProjectOperator.createOperatorFactory (FilterAndProjectOperator.java:73-178):
+ * PageProcessor(Optional<PageFilter>, List<PageProjection>).  Projections are expressions over the
+ * INPUT page channels; an INPUT_REF root is InputPageProjection (identity/gather). */
+typedef struct pa_filter_project_desc {
+    int32_t input_channel_count;
+    const int32_t* input_types;          /* pa_type per input channel */
+    const pa_expr* filter;               /* NULL = no filter */
+    int32_t projection_count;
+    const pa_expr* projections;
+    int32_t output_mem;                  /* pa_mem of pages returned by get_output */
+    void* stream;                        /* hipStream_t to launch on; NULL = library-owned stream */
+} pa_filter_project_desc;
+
+/* AggregationOperator (AggregationOperator.java:40-140): global aggregates, Step.SINGLE. */
+typedef struct pa_aggregation_desc {
+    int32_t input_channel_count;
+    const int32_t* input_types;
+    int32_t aggregate_count;
+    const pa_aggregate* aggregates;
+    int32_t output_mem;
+    void* stream;
+} pa_aggregation_desc;
+
+/* HashAggregationOperatorFactory (HashAggregationOperator.java:120-202). */
+typedef struct pa_hash_aggregation_desc {
+    int32_t input_channel_count;
+    const int32_t* input_types;
+    int32_t group_by_count;
+    const int32_t* group_by_channels;
+    int32_t hash_channel;                /* precomputed $hashvalue channel or -1 */
+    int32_t step;                        /* pa_agg_step; SINGLE supported */
+    int32_t aggregate_count;
+    const pa_aggregate* aggregates;
+    int32_t expected_groups;
+    int32_t output_mem;
+    void* stream;
+} pa_hash_aggregation_desc;
+
+/* Fused pipeline: [Scan]FilterAndProject -> (Hash)AggregationOperator collapsed into one device
+ * pass.  Semantically the composition of the two descriptors: the aggregation's channels index the
+ * projection outputs.  group_by_count == 0 selects the global AggregationOperator form (Q6);
+ * otherwise HashAggregationOperator (Q1). */
+typedef struct pa_fused_aggregation_desc {
+    pa_filter_project_desc filter_project;
+    pa_hash_aggregation_desc aggregation;   /* input_* fields describe the projected page */
+} pa_fused_aggregation_desc;
+
+/* HashBuilderOperator + LookupJoinOperator (join/HashBuilderOperator.java:56-330,
+ * join/LookupJoinOperatorFactory.java; OperatorFactories.innerJoin, OperatorFactories.java:27-45). */
+typedef struct pa_hash_builder_desc {
+    int32_t input_channel_count;
+    const int32_t* input_types;
+    int32_t join_channel_count;
+    const int32_t* join_channels;
+    int32_t hash_channel;                /* precomputed hash channel or -1 */
+    int32_t output_channel_count;
+    const int32_t* output_channels;      /* build columns copied to the join output */
+    int32_t expected_positions;
+    void* stream;
+} pa_hash_builder_desc;
+
+typedef struct pa_lookup_join_desc {
+    int32_t probe_channel_count;
+    const int32_t* probe_types;
+    int32_t join_channel_count;
+    const int32_t* probe_join_channels;
+    int32_t probe_hash_channel;          /* or -1 */
+    int32_t probe_output_channel_count;
+    const int32_t* probe_output_channels;
+    int32_t output_mem;
+    void* stream;
+} pa_lookup_join_desc;
+
+typedef struct pa_operator pa_operator;             /* opaque operator handle */
+typedef struct pa_lookup_source pa_lookup_source;   /* opaque: JoinBridge / LookupSourceFactory */
+
+/* ---- library lifecycle ---- */
+int32_t pa_abi_version(void);
+/* Binds the calling thread (and operators it creates) to HIP device `device`; -1 keeps the
+ * current device.  Fails with PA_ERR_NO_DEVICE when no gfx950 device is usable. */
+int32_t pa_init(int32_t device);
+int32_t pa_shutdown(void);
+/* Message of the last failing call on this thread ("" if none). */
+const char* pa_last_error(void);
+int32_t pa_device_count(void);
+
+/* ---- device memory plumbing for hosts without their own allocator (JNI shim, tests) ---- */
+int32_t pa_device_malloc(void** ptr, int64_t bytes);
+int32_t pa_device_free(void* ptr);
+int32_t pa_host_malloc_pinned(void** ptr, int64_t bytes);
+int32_t pa_host_free_pinned(void* ptr);
+int32_t pa_memcpy_h2d(void* dst, const void* src, int64_t bytes, void* stream);
+int32_t pa_memcpy_d2h(void* dst, const void* src, int64_t bytes, void* stream);
+int32_t pa_stream_synchronize(void* stream);
+
+/* ---- operator factories ---- */
+int32_t pa_filter_project_create(const pa_filter_project_desc* desc, pa_operator** out);
+int32_t pa_aggregation_create(const pa_aggregation_desc* desc, pa_operator** out);
+int32_t pa_hash_aggregation_create(const pa_hash_aggregation_desc* desc, pa_operator** out);
+int32_t pa_fused_aggregation_create(const pa_fused_aggregation_desc* desc, pa_operator** out);
+int32_t pa_lookup_source_create(pa_lookup_source** out);
+int32_t pa_lookup_source_destroy(pa_lookup_source* ls);
+int32_t pa_hash_builder_create(const pa_hash_builder_desc* desc, pa_lookup_source* bridge, pa_operator** out);
+int32_t pa_lookup_join_create(const pa_lookup_join_desc* desc, pa_lookup_source* bridge, pa_operator** out);
+
+/* ---- Operator protocol (Operator.java:21-103; call order Driver.java:355-457) ---- */
+int32_t pa_op_needs_input(pa_operator* op);                 /* 1 / 0 */
+int32_t pa_op_add_input(pa_operator* op, const pa_page* page);
+/* Returns 1 and fills *out when a page is available, 0 when none.  The page's buffers are owned by
+ * the operator and stay valid until the next get_output / close on the same handle. */
+int32_t pa_op_get_output(pa_operator* op, pa_page* out);
+int32_t pa_op_finish(pa_operator* op);
+int32_t pa_op_is_finished(pa_operator* op);                 /* 1 / 0 */
+int32_t pa_op_is_blocked(pa_operator* op);                  /* 1 = device work still in flight */
+int64_t pa_op_memory_bytes(pa_operator* op);                /* HBM held (OperatorContext memory accounting) */
+int32_t pa_op_close(pa_operator* op);
+/* Device time (ms) of the kernels the operator launched since creation, measured with HIP events
+ * on the operator's stream; *launches = number of timed launches of its dominant kernel. */
+int32_t pa_op_kernel_time(pa_operator* op, double* total_ms, int64_t* launches);
+
+/* ---- stand-alone kernels of the path (used by exchange / tests; all device pointers) ---- */
+/* rawHash per position = InterpretedHashGenerator.hashPosition over `channels`
+ * (InterpretedHashGenerator.java:62-70, CombineHashFunction.java:26-29). */
+int32_t pa_hash_page(const pa_page* page, int32_t channel_count, const int32_t* channels,
+                     int64_t* out_raw_hash, void* stream);
+/* partition = (int) XxHash64.hash(Long.reverse(rawHash)) & (count-1)   (LocalPartitionGenerator.java:45-65)
+ * or (rawHash & MAX_LONG) % count when local == 0                      (HashGenerator.java:24-35). */
+int32_t pa_partition_ids(const int64_t* raw_hash, int32_t position_count, int32_t partition_count,
+                         int32_t local, int32_t* out_partition, void* stream);
+/* Stable partition of positions by partition id: out_positions grouped by partition in ascending
+ * position order inside each partition (PartitioningExchanger.java:59-82), out_counts[partition_count]. */
+int32_t pa_partition_positions(const int32_t* partition, int32_t position_count, int32_t partition_count,
+                               int32_t* out_positions, int64_t* out_counts_host, void* stream);
+/* Block.copyPositions for a flat column: dst[i] = src[positions[i]]. */
+int32_t pa_gather_flat(const void* src, int32_t elem_bytes, const int32_t* positions, int32_t count,
+                       void* dst, void* stream);
+
+/* ---- synthetic TPC-H-shaped column generator, on device ---- */
+typedef enum pa_tpch_column {
+    PA_L_ORDERKEY = 0, PA_L_QUANTITY = 1, PA_L_EXTENDEDPRICE = 2, PA_L_DISCOUNT = 3, PA_L_TAX = 4,
+    PA_L_SHIPDATE = 5, PA_L_RETURNFLAG = 6, PA_L_LINESTATUS = 7,
+    PA_O_ORDERKEY = 8, PA_O_CUSTKEY = 9, PA_O_ORDERDATE = 10, PA_O_SHIPPRIORITY = 11,
+    PA_C_CUSTKEY = 12, PA_C_MKTSEGMENT = 13
+} pa_tpch_column;
+/* Fills rows [first_row, first_row+row_count) of the column into `values` (and `offsets`
+ * [row_count+1] for VARCHAR columns).  Row r of a column depends only on (seed, column, r, scale). */
+int32_t pa_tpch_generate(int32_t column, double scale_factor, int64_t first_row, int64_t row_count,
+                         uint64_t seed, void* values, int32_t* offsets, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PRESTO_AMD_H */

@@ -1,0 +1,358 @@
+"""ctypes binding of the CPU oracle (oracle/liboracle.so).
+
+TEST INFRASTRUCTURE ONLY -- imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+leg, never by anything under presto_amd/.  See oracle/presto_oracle.h.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from presto_amd import abi
+from presto_amd.expr import serialize, serialize_many
+from presto_amd.page import Page, page_from_c
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _HERE])
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_HERE, "liboracle.so")
+        if not os.path.exists(path):
+            build()
+        L = C.CDLL(path)
+        L.orc_last_error.restype = C.c_char_p
+        L.orc_xxh64.restype = C.c_uint64
+        L.orc_xxh64.argtypes = [C.c_void_p, C.c_int64, C.c_uint64]
+        for name in ("orc_xxh64_long", "orc_hash_bigint", "orc_murmur3_fmix"):
+            getattr(L, name).restype = C.c_int64
+            getattr(L, name).argtypes = [C.c_int64]
+        L.orc_hash_integer.restype = C.c_int64
+        L.orc_hash_integer.argtypes = [C.c_int32]
+        L.orc_hash_boolean.restype = C.c_int64
+        L.orc_hash_boolean.argtypes = [C.c_int32]
+        L.orc_hash_double.restype = C.c_int64
+        L.orc_hash_double.argtypes = [C.c_double]
+        L.orc_combine_hash.restype = C.c_int64
+        L.orc_combine_hash.argtypes = [C.c_int64, C.c_int64]
+        L.orc_array_size.argtypes = [C.c_int32, C.c_float]
+        L.orc_hash_agg_create.restype = C.c_void_p
+        L.orc_hash_agg_create.argtypes = [C.POINTER(abi.pa_hash_aggregation_desc)]
+        L.orc_hash_agg_add_page.argtypes = [C.c_void_p, C.POINTER(abi.pa_page), C.c_void_p]
+        L.orc_hash_agg_group_count.argtypes = [C.c_void_p]
+        L.orc_hash_agg_capacity.argtypes = [C.c_void_p]
+        L.orc_hash_agg_contains.argtypes = [C.c_void_p, C.POINTER(abi.pa_page), C.c_int32]
+        L.orc_hash_agg_build_result.argtypes = [C.c_void_p, C.POINTER(abi.pa_page)]
+        L.orc_hash_agg_destroy.argtypes = [C.c_void_p]
+        L.orc_join_create.restype = C.c_void_p
+        L.orc_join_create.argtypes = [C.POINTER(abi.pa_hash_builder_desc)]
+        L.orc_join_add_build_page.argtypes = [C.c_void_p, C.POINTER(abi.pa_page)]
+        L.orc_join_build.argtypes = [C.c_void_p]
+        L.orc_join_build_positions.argtypes = [C.c_void_p]
+        L.orc_join_tables.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.c_void_p, C.c_void_p]
+        L.orc_join_probe.argtypes = [C.c_void_p, C.POINTER(abi.pa_lookup_join_desc), C.POINTER(abi.pa_page),
+                                     C.POINTER(abi.pa_page), C.POINTER(C.POINTER(C.c_int32)),
+                                     C.POINTER(C.POINTER(C.c_int32)), C.POINTER(C.c_int32)]
+        L.orc_join_destroy.argtypes = [C.c_void_p]
+        L.orc_free.argtypes = [C.c_void_p]
+        L.orc_free_page.argtypes = [C.POINTER(abi.pa_page)]
+        L.orc_filter.argtypes = [C.POINTER(abi.pa_page), C.POINTER(abi.pa_expr), C.c_void_p,
+                                 C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+        L.orc_filter_project.argtypes = [C.POINTER(abi.pa_page), C.POINTER(abi.pa_expr), C.c_int32,
+                                         C.POINTER(abi.pa_expr), C.POINTER(abi.pa_page)]
+        L.orc_hash_page.argtypes = [C.POINTER(abi.pa_page), C.c_int32, C.POINTER(C.c_int32), C.c_void_p]
+        L.orc_partition_ids.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
+        L.orc_partition_positions.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
+        L.orc_tpch_generate.argtypes = [C.c_int32, C.c_double, C.c_int64, C.c_int64, C.c_uint64, C.c_void_p,
+                                        C.c_void_p]
+        L.orc_q6.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_double),
+                             C.POINTER(C.c_int64)]
+        _LIB = L
+    return _LIB
+
+
+class OracleError(Exception):
+    def __init__(self, status, message):
+        super().__init__("%s: %s" % (abi.STATUS_NAMES.get(status, status), message))
+        self.status = status
+
+
+def _check(rc):
+    if rc < 0:
+        raise OracleError(rc, lib().orc_last_error().decode())
+    return rc
+
+
+# ---- hashes ---------------------------------------------------------------------------------
+def xxh64(data, seed=0):
+    buf = C.create_string_buffer(bytes(data), max(len(data), 1))
+    return lib().orc_xxh64(buf, len(data), seed)
+
+
+def _s64(v):
+    v &= (1 << 64) - 1
+    return v - (1 << 64) if v >= (1 << 63) else v
+
+
+def xxh64_long(v): return lib().orc_xxh64_long(_s64(v))
+def hash_bigint(v): return lib().orc_hash_bigint(_s64(v))
+def hash_integer(v): return lib().orc_hash_integer(v)
+def hash_double(v): return lib().orc_hash_double(v)
+def hash_boolean(v): return lib().orc_hash_boolean(1 if v else 0)
+def murmur3_fmix(v): return lib().orc_murmur3_fmix(_s64(v))
+def combine_hash(a, b): return lib().orc_combine_hash(_s64(a), _s64(b))
+def array_size(expected, fill=0.75): return lib().orc_array_size(expected, fill)
+
+
+def hash_page(page, channels):
+    cpage, keep = page.to_c()
+    out = np.zeros(page.position_count, dtype=np.int64)
+    ch = abi.int32_array(channels)
+    _check(lib().orc_hash_page(C.byref(cpage), len(channels), ch, out.ctypes.data))
+    return out
+
+
+def partition_ids(raw_hash, partition_count, local=True):
+    raw_hash = np.ascontiguousarray(raw_hash, dtype=np.int64)
+    out = np.zeros(len(raw_hash), dtype=np.int32)
+    _check(lib().orc_partition_ids(raw_hash.ctypes.data, len(raw_hash), partition_count, 1 if local else 0,
+                                   out.ctypes.data))
+    return out
+
+
+def partition_positions(partition, partition_count):
+    partition = np.ascontiguousarray(partition, dtype=np.int32)
+    pos = np.zeros(len(partition), dtype=np.int32)
+    counts = np.zeros(partition_count, dtype=np.int64)
+    _check(lib().orc_partition_positions(partition.ctypes.data, len(partition), partition_count, pos.ctypes.data,
+                                         counts.ctypes.data))
+    return pos, counts
+
+
+# ---- filter / project -------------------------------------------------------------------------
+def filter_positions(page, filter_expr):
+    """PageFilter.filter -> SelectedPositions: returns (is_list, positions ndarray | range count)."""
+    cpage, keep = page.to_c()
+    e, k2 = serialize(filter_expr)
+    pos = np.zeros(max(page.position_count, 1), dtype=np.int32)
+    count = C.c_int32()
+    is_list = C.c_int32()
+    _check(lib().orc_filter(C.byref(cpage), C.byref(e), pos.ctypes.data, C.byref(count), C.byref(is_list)))
+    if is_list.value:
+        return True, pos[:count.value].copy()
+    return False, count.value
+
+
+def filter_project(page, filter_expr, projections):
+    """PageProcessor over one page -> Page or None."""
+    cpage, keep = page.to_c()
+    fe = None
+    if filter_expr is not None:
+        f, kf = serialize(filter_expr)
+        fe = C.byref(f)
+    arr, kp = serialize_many(projections)
+    out = abi.pa_page()
+    rc = _check(lib().orc_filter_project(C.byref(cpage), fe, len(projections), arr, C.byref(out)))
+    if rc == 0:
+        return None
+    result = page_from_c(out)
+    lib().orc_free_page(C.byref(out))
+    return result
+
+
+# ---- aggregation --------------------------------------------------------------------------------
+def make_aggregates(aggregates):
+    """aggregates: list of (fn, input_channel, input_type[, mask_channel])."""
+    arr = (abi.pa_aggregate * max(len(aggregates), 1))()
+    for i, a in enumerate(aggregates):
+        arr[i].fn = a[0]
+        arr[i].input_channel = a[1]
+        arr[i].input_type = a[2] if a[2] is not None else 0
+        arr[i].mask_channel = a[3] if len(a) > 3 else -1
+    return arr
+
+
+def make_hash_agg_desc(input_types, group_by_channels, aggregates, hash_channel=-1, expected_groups=10000,
+                       step=abi.STEP_SINGLE, output_mem=abi.MEM_HOST, stream=None):
+    d = abi.pa_hash_aggregation_desc()
+    keep = []
+    types = abi.int32_array(input_types)
+    gb = abi.int32_array(group_by_channels)
+    aggs = make_aggregates(aggregates)
+    d.input_channel_count = len(input_types)
+    d.input_types = C.cast(types, C.POINTER(C.c_int32))
+    d.group_by_count = len(group_by_channels)
+    d.group_by_channels = C.cast(gb, C.POINTER(C.c_int32))
+    d.hash_channel = hash_channel
+    d.step = step
+    d.aggregate_count = len(aggregates)
+    d.aggregates = C.cast(aggs, C.POINTER(abi.pa_aggregate))
+    d.expected_groups = expected_groups
+    d.output_mem = output_mem
+    d.stream = stream
+    keep += [types, gb, aggs]
+    return d, keep
+
+
+class HashAggregation:
+    """InMemoryHashAggregationBuilder (+ GroupByHash) / AggregationOperator restatement."""
+
+    def __init__(self, input_types, group_by_channels, aggregates, hash_channel=-1, expected_groups=10000):
+        self._desc, self._keep = make_hash_agg_desc(input_types, group_by_channels, aggregates, hash_channel,
+                                                    expected_groups)
+        self._h = lib().orc_hash_agg_create(C.byref(self._desc))
+
+    def add_page(self, page, want_group_ids=False):
+        cpage, keep = page.to_c()
+        gids = None
+        ptr = None
+        if want_group_ids:
+            gids = np.zeros(max(page.position_count, 1), dtype=np.int32)
+            ptr = gids.ctypes.data
+        _check(lib().orc_hash_agg_add_page(self._h, C.byref(cpage), ptr))
+        return gids[:page.position_count] if want_group_ids else None
+
+    def group_count(self): return lib().orc_hash_agg_group_count(self._h)
+    def capacity(self): return lib().orc_hash_agg_capacity(self._h)
+
+    def contains(self, page, position):
+        cpage, keep = page.to_c()
+        return bool(lib().orc_hash_agg_contains(self._h, C.byref(cpage), position))
+
+    def build_result(self):
+        out = abi.pa_page()
+        _check(lib().orc_hash_agg_build_result(self._h, C.byref(out)))
+        result = page_from_c(out)
+        lib().orc_free_page(C.byref(out))
+        return result
+
+    def close(self):
+        if self._h:
+            lib().orc_hash_agg_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+
+# ---- join -----------------------------------------------------------------------------------------
+def make_hash_builder_desc(input_types, join_channels, output_channels, hash_channel=-1, expected_positions=0,
+                           stream=None):
+    d = abi.pa_hash_builder_desc()
+    types = abi.int32_array(input_types)
+    jc = abi.int32_array(join_channels)
+    oc = abi.int32_array(output_channels)
+    d.input_channel_count = len(input_types)
+    d.input_types = C.cast(types, C.POINTER(C.c_int32))
+    d.join_channel_count = len(join_channels)
+    d.join_channels = C.cast(jc, C.POINTER(C.c_int32))
+    d.hash_channel = hash_channel
+    d.output_channel_count = len(output_channels)
+    d.output_channels = C.cast(oc, C.POINTER(C.c_int32))
+    d.expected_positions = expected_positions
+    d.stream = stream
+    return d, [types, jc, oc]
+
+
+def make_lookup_join_desc(probe_types, probe_join_channels, probe_output_channels, probe_hash_channel=-1,
+                          output_mem=abi.MEM_HOST, stream=None):
+    d = abi.pa_lookup_join_desc()
+    types = abi.int32_array(probe_types)
+    jc = abi.int32_array(probe_join_channels)
+    oc = abi.int32_array(probe_output_channels)
+    d.probe_channel_count = len(probe_types)
+    d.probe_types = C.cast(types, C.POINTER(C.c_int32))
+    d.join_channel_count = len(probe_join_channels)
+    d.probe_join_channels = C.cast(jc, C.POINTER(C.c_int32))
+    d.probe_hash_channel = probe_hash_channel
+    d.probe_output_channel_count = len(probe_output_channels)
+    d.probe_output_channels = C.cast(oc, C.POINTER(C.c_int32))
+    d.output_mem = output_mem
+    d.stream = stream
+    return d, [types, jc, oc]
+
+
+class HashJoin:
+    """PagesIndex + PagesHash + ArrayPositionLinks + DefaultPageJoiner restatement (inner join)."""
+
+    def __init__(self, build_types, join_channels, output_channels, hash_channel=-1):
+        self._desc, self._keep = make_hash_builder_desc(build_types, join_channels, output_channels, hash_channel)
+        self._h = lib().orc_join_create(C.byref(self._desc))
+
+    def add_build_page(self, page):
+        cpage, keep = page.to_c()
+        _check(lib().orc_join_add_build_page(self._h, C.byref(cpage)))
+
+    def build(self):
+        _check(lib().orc_join_build(self._h))
+
+    def tables(self):
+        hs = C.c_int32()
+        lib().orc_join_tables(self._h, C.byref(hs), None, None)
+        key = np.zeros(hs.value, dtype=np.int32)
+        links = np.zeros(max(lib().orc_join_build_positions(self._h), 1), dtype=np.int32)
+        lib().orc_join_tables(self._h, C.byref(hs), key.ctypes.data, links.ctypes.data)
+        return key, links[:lib().orc_join_build_positions(self._h)]
+
+    def probe(self, page, probe_types, probe_join_channels, probe_output_channels, probe_hash_channel=-1):
+        """Returns (output Page, probe indices, build positions) in the reference's emission order."""
+        d, keep = make_lookup_join_desc(probe_types, probe_join_channels, probe_output_channels, probe_hash_channel)
+        cpage, k2 = page.to_c()
+        out = abi.pa_page()
+        pi = C.POINTER(C.c_int32)()
+        bi = C.POINTER(C.c_int32)()
+        cnt = C.c_int32()
+        _check(lib().orc_join_probe(self._h, C.byref(d), C.byref(cpage), C.byref(out), C.byref(pi), C.byref(bi),
+                                    C.byref(cnt)))
+        n = cnt.value
+        p = np.ctypeslib.as_array(pi, shape=(max(n, 1),))[:n].copy()
+        b = np.ctypeslib.as_array(bi, shape=(max(n, 1),))[:n].copy()
+        lib().orc_free(pi)
+        lib().orc_free(bi)
+        result = page_from_c(out)
+        lib().orc_free_page(C.byref(out))
+        return result, p, b
+
+    def close(self):
+        if self._h:
+            lib().orc_join_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+
+# ---- synthetic TPC-H ---------------------------------------------------------------------------------
+def tpch_column(column, scale_factor, first_row, row_count, seed=0x5EED0000):
+    """Returns (values ndarray, offsets ndarray | None)."""
+    t = abi.TPCH_COLUMN_TYPE[column]
+    offsets = None
+    if t == abi.VARCHAR:
+        values = np.zeros(max(row_count * 10, 1), dtype=np.uint8)
+        offsets = np.zeros(row_count + 1, dtype=np.int32)
+    elif t in (abi.BIGINT,):
+        values = np.zeros(row_count, dtype=np.int64)
+    elif t == abi.DOUBLE:
+        values = np.zeros(row_count, dtype=np.float64)
+    else:
+        values = np.zeros(row_count, dtype=np.int32)
+    _check(lib().orc_tpch_generate(column, scale_factor, first_row, row_count, seed, values.ctypes.data,
+                                   offsets.ctypes.data if offsets is not None else None))
+    if offsets is not None:
+        values = values[:max(int(offsets[-1]), 1)].copy()
+    return values, offsets
+
+
+def q6(shipdate, discount, quantity, extendedprice):
+    s = C.c_double()
+    c = C.c_int64()
+    lib().orc_q6(shipdate.ctypes.data, discount.ctypes.data, quantity.ctypes.data, extendedprice.ctypes.data,
+                 len(shipdate), C.byref(s), C.byref(c))
+    return s.value, c.value

@@ -1,0 +1,96 @@
+/*
+ * presto_oracle.h -- CPU restatement of Trino's page-processing hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing in presto_amd/ (the product) may include, link or call this;
+ * only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg do, and only as the checker.
+ *
+ * The reference (Trino 359, 100 % Java) cannot be built in the authoring container (no JDK, no
+ * Maven cache, no network), so this is a scalar, row-at-a-time C restatement
+ * that follows the reference files cited next to every function.  It is pinned by the reference's
+ * own behavioural tests restated in tests/  and, for the third-party XXH64
+ * (io.airlift:slice XxHash64, version managed by io.airlift:airbase:110), by the public xxHash
+ * vectors computed with the independent python `xxhash` package (tests/golden/).
+ *
+ * It shares only the *struct definitions* of include/presto_amd.h (the boundary spec), no code.
+ */
+#ifndef PRESTO_ORACLE_H
+#define PRESTO_ORACLE_H
+
+#include "../include/presto_amd.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- hash arithmetic ---- */
+uint64_t orc_xxh64(const void* data, int64_t len, uint64_t seed);
+int64_t orc_xxh64_long(int64_t value);
+int64_t orc_hash_bigint(int64_t value);
+int64_t orc_hash_integer(int32_t value);
+int64_t orc_hash_double(double value);
+int64_t orc_hash_boolean(int32_t value);
+int64_t orc_murmur3_fmix(int64_t x);
+int64_t orc_combine_hash(int64_t previous, int64_t value);
+int32_t orc_array_size(int32_t expected, float fill);
+int32_t orc_hash_page(const pa_page* page, int32_t channel_count, const int32_t* channels, int64_t* out);
+int32_t orc_partition_ids(const int64_t* raw_hash, int32_t n, int32_t partition_count, int32_t local, int32_t* out);
+int32_t orc_partition_positions(const int32_t* partition, int32_t n, int32_t partition_count,
+                                int32_t* out_positions, int64_t* out_counts);
+
+/* ---- filter / projection ---- */
+const char* orc_last_error(void);
+/* PageFilter.filter + positionsArrayToSelectedPositions.  positions must hold position_count ints.
+ * *is_list = 0 means the result is positionsRange(0, *count). */
+int32_t orc_filter(const pa_page* page, const pa_expr* filter, int32_t* positions, int32_t* count, int32_t* is_list);
+/* PageProcessor over one page: concatenation of all output batches.  *out is malloc'ed; free with
+ * orc_free_page.  Returns 1 if an output page exists, 0 if the processor yields nothing (no selected
+ * rows), negative pa_status on error. */
+int32_t orc_filter_project(const pa_page* page, const pa_expr* filter, int32_t projection_count,
+                           const pa_expr* projections, pa_page* out);
+void orc_free_page(pa_page* page);
+/* ---- aggregation ---- */
+typedef struct orc_hash_agg orc_hash_agg;
+/* group_by_count == 0: AggregationOperator (one global group).  Otherwise
+ * InMemoryHashAggregationBuilder over BigintGroupByHash / MultiChannelGroupByHash
+ * (GroupByHash.createGroupByHash picks Bigint for exactly one BIGINT key). */
+orc_hash_agg* orc_hash_agg_create(const pa_hash_aggregation_desc* desc);
+/* processPage; when group_ids != NULL also returns the group id of every position. */
+int32_t orc_hash_agg_add_page(orc_hash_agg* agg, const pa_page* page, int32_t* group_ids);
+int32_t orc_hash_agg_group_count(const orc_hash_agg* agg);
+int32_t orc_hash_agg_capacity(const orc_hash_agg* agg);
+/* GroupByHash.contains(position, page) */
+int32_t orc_hash_agg_contains(const orc_hash_agg* agg, const pa_page* page, int32_t position);
+/* buildResult: rows for group id 0..n-1 in order: [keys..., ($hashvalue), aggregates...]. */
+int32_t orc_hash_agg_build_result(orc_hash_agg* agg, pa_page* out);
+void orc_hash_agg_destroy(orc_hash_agg* agg);
+
+/* ---- hash join ---- */
+typedef struct orc_join orc_join;
+orc_join* orc_join_create(const pa_hash_builder_desc* desc);
+int32_t orc_join_add_build_page(orc_join* j, const pa_page* page);     /* PagesIndex.addPage */
+int32_t orc_join_build(orc_join* j);                                    /* new PagesHash(...) */
+int32_t orc_join_build_positions(const orc_join* j);
+/* copies key[] (hash_size ints) and positionLinks[] (positions ints) when the pointers are non-NULL */
+int32_t orc_join_tables(const orc_join* j, int32_t* hash_size, int32_t* key, int32_t* position_links);
+/* DefaultPageJoiner.processProbe for an inner join, whole probe page, no page-size flushes:
+ * out = probe output channels gathered by probe index ++ build output channels; also returns the
+ * (probe index, build position) pairs in emission order (malloc'ed, free with orc_free). */
+int32_t orc_join_probe(const orc_join* j, const pa_lookup_join_desc* desc, const pa_page* probe,
+                       pa_page* out, int32_t** probe_indices, int32_t** build_positions, int32_t* match_count);
+void orc_join_destroy(orc_join* j);
+void orc_free(void* p);
+
+/* ---- synthetic TPC-H-shaped columns ---- */
+int32_t orc_tpch_generate(int32_t column, double scale_factor, int64_t first_row, int64_t row_count,
+                          uint64_t seed, void* values, int32_t* offsets);
+
+/* ---- hand-written query twins used by the CPU baseline (BM/HandTpchQuery6.java:95-141,
+ *      BM/HandTpchQuery1.java:241-330 + HashAggregationOperator), one Driver thread each ---- */
+/* Q6 over columns; returns sum and count of selected rows */
+int32_t orc_q6(const int32_t* shipdate, const double* discount, const double* quantity,
+               const double* extendedprice, int64_t n, double* sum, int64_t* count);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

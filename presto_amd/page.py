@@ -1,0 +1,256 @@
+"""Host-side mirror of the reference's Page / Block data model.
+
+Mirrors io.trino.spi.Page (core/trino-spi/src/main/java/io/trino/spi/Page.java:33-398) and the
+flat / variable-width / dictionary / RLE blocks (core/trino-spi/src/main/java/io/trino/spi/block/
+LongArrayBlock.java:32-130, IntArrayBlock.java, ByteArrayBlock.java, VariableWidthBlock.java:34-110,
+DictionaryBlock.java, RunLengthEncodedBlock.java).  A Block only *describes* buffers (numpy arrays on
+the host, raw HBM pointers on the device); no arithmetic happens here.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import abi
+
+_NP_DTYPE = {abi.BIGINT: np.int64, abi.INTEGER: np.int32, abi.DATE: np.int32, abi.DOUBLE: np.float64,
+             abi.BOOLEAN: np.uint8}
+
+
+class DeviceBuffer:
+    """A span of HBM described by (pointer, bytes); `owner` keeps the allocation alive
+    (a torch tensor, or a presto_amd._lib.DeviceAllocation)."""
+
+    def __init__(self, ptr, nbytes, owner=None):
+        self.ptr = int(ptr)
+        self.nbytes = int(nbytes)
+        self.owner = owner
+
+
+def _ptr(buf):
+    if buf is None:
+        return None
+    if isinstance(buf, DeviceBuffer):
+        return buf.ptr
+    if isinstance(buf, np.ndarray):
+        return buf.ctypes.data
+    if hasattr(buf, "data_ptr"):  # torch tensor
+        return buf.data_ptr()
+    raise TypeError(type(buf))
+
+
+class Block:
+    def __init__(self, type_, encoding, position_count, values=None, offsets=None, nulls=None, ids=None,
+                 dictionary=None):
+        self.type = type_
+        self.encoding = encoding
+        self.position_count = int(position_count)
+        self.values = values
+        self.offsets = offsets
+        self.nulls = nulls
+        self.ids = ids
+        self.dictionary = dictionary
+
+    # ---- host constructors -------------------------------------------------------------
+    @staticmethod
+    def flat(type_, values, nulls=None):
+        arr = np.ascontiguousarray(np.asarray(values, dtype=_NP_DTYPE[type_]))
+        nl = None
+        if nulls is not None:
+            nl = np.ascontiguousarray(np.asarray(nulls, dtype=np.uint8))
+            if not nl.any():
+                nl = None  # LongArrayBlock: valueIsNull == null when mayHaveNull is false
+        return Block(type_, abi.FLAT, len(arr), values=arr, nulls=nl)
+
+    @staticmethod
+    def bigint(values, nulls=None):
+        return Block.flat(abi.BIGINT, values, nulls)
+
+    @staticmethod
+    def integer(values, nulls=None):
+        return Block.flat(abi.INTEGER, values, nulls)
+
+    @staticmethod
+    def date(values, nulls=None):
+        return Block.flat(abi.DATE, values, nulls)
+
+    @staticmethod
+    def double(values, nulls=None):
+        return Block.flat(abi.DOUBLE, values, nulls)
+
+    @staticmethod
+    def boolean(values, nulls=None):
+        return Block.flat(abi.BOOLEAN, np.asarray(values, dtype=np.uint8), nulls)
+
+    @staticmethod
+    def varchar(strings):
+        """strings: iterable of bytes / str / None (None = NULL)."""
+        data = bytearray()
+        offsets = [0]
+        nulls = []
+        for s in strings:
+            if s is None:
+                nulls.append(1)
+            else:
+                if isinstance(s, str):
+                    s = s.encode("utf-8")
+                data += s
+                nulls.append(0)
+            offsets.append(len(data))
+        vals = np.frombuffer(bytes(data) if data else b"\0", dtype=np.uint8).copy()
+        nl = np.asarray(nulls, dtype=np.uint8)
+        return Block(abi.VARCHAR, abi.VARWIDTH, len(nulls), values=vals,
+                     offsets=np.asarray(offsets, dtype=np.int32), nulls=nl if nl.any() else None)
+
+    @staticmethod
+    def varwidth(values_bytes, offsets, nulls=None):
+        offsets = np.ascontiguousarray(np.asarray(offsets, dtype=np.int32))
+        return Block(abi.VARCHAR, abi.VARWIDTH, len(offsets) - 1,
+                     values=np.ascontiguousarray(np.asarray(values_bytes, dtype=np.uint8)), offsets=offsets,
+                     nulls=nulls)
+
+    @staticmethod
+    def dictionary_block(dictionary, ids):
+        ids = np.ascontiguousarray(np.asarray(ids, dtype=np.int32))
+        return Block(dictionary.type, abi.DICTIONARY, len(ids), ids=ids, dictionary=dictionary)
+
+    @staticmethod
+    def rle(value_block, position_count):
+        assert value_block.position_count == 1
+        return Block(value_block.type, abi.RLE, position_count, dictionary=value_block)
+
+    # ---- materialisation (host blocks only) ----------------------------------------------
+    def to_pylist(self):
+        """Decoded python values (None for NULL); VARCHAR as bytes."""
+        if self.encoding == abi.DICTIONARY:
+            d = self.dictionary.to_pylist()
+            return [d[i] for i in self.ids.tolist()]
+        if self.encoding == abi.RLE:
+            return self.dictionary.to_pylist() * self.position_count
+        n = self.position_count
+        nulls = self.nulls
+        if self.type == abi.VARCHAR:
+            raw = self.values.tobytes()
+            off = self.offsets.tolist()
+            out = [raw[off[i]:off[i + 1]] for i in range(n)]
+        else:
+            out = self.values[:n].tolist()
+            if self.type == abi.BOOLEAN:
+                out = [bool(v) for v in out]
+        if nulls is not None:
+            out = [None if nulls[i] else out[i] for i in range(n)]
+        return out
+
+    def fill_c(self, col, keep):
+        col.type = self.type
+        col.encoding = self.encoding
+        col.values = _ptr(self.values)
+        col.offsets = _ptr(self.offsets)
+        col.nulls = _ptr(self.nulls)
+        col.ids = _ptr(self.ids)
+        col.dictionary_size = 0
+        if self.dictionary is not None:
+            d = abi.pa_column()
+            self.dictionary.fill_c(d, keep)
+            keep.append(d)
+            col.dictionary = C.pointer(d)
+            col.dictionary_size = self.dictionary.position_count
+        keep.append(self)
+
+
+class Page:
+    def __init__(self, blocks, position_count=None, mem=abi.MEM_HOST):
+        self.blocks = list(blocks)
+        if position_count is None:
+            position_count = self.blocks[0].position_count if self.blocks else 0
+        for b in self.blocks:
+            assert b.position_count == position_count, (b.position_count, position_count)
+        self.position_count = int(position_count)
+        self.mem = mem
+
+    @property
+    def channel_count(self):
+        return len(self.blocks)
+
+    def to_c(self):
+        """Returns (pa_page, keepalive list)."""
+        keep = []
+        cols = (abi.pa_column * max(len(self.blocks), 1))()
+        for i, b in enumerate(self.blocks):
+            b.fill_c(cols[i], keep)
+        page = abi.pa_page()
+        page.position_count = self.position_count
+        page.channel_count = len(self.blocks)
+        page.columns = C.cast(cols, C.POINTER(abi.pa_column))
+        page.mem = self.mem
+        keep.append(cols)
+        return page, keep
+
+    def to_rows(self):
+        cols = [b.to_pylist() for b in self.blocks]
+        return [tuple(c[i] for c in cols) for i in range(self.position_count)]
+
+    def get_region(self, offset, length):
+        """Page.getRegion for flat / varwidth host blocks (views, no copy)."""
+        out = []
+        for b in self.blocks:
+            nulls = None if b.nulls is None else b.nulls[offset:offset + length]
+            if b.encoding == abi.FLAT:
+                out.append(Block(b.type, abi.FLAT, length, values=b.values[offset:offset + length], nulls=nulls))
+            elif b.encoding == abi.VARWIDTH:
+                out.append(Block(b.type, abi.VARWIDTH, length, values=b.values,
+                                 offsets=b.offsets[offset:offset + length + 1], nulls=nulls))
+            else:
+                raise NotImplementedError
+        return Page(out, length, self.mem)
+
+
+def page_from_c(cpage, copy=True):
+    """Builds a host Page from a pa_page whose pointers are host addresses (copies by default)."""
+    n = cpage.position_count
+    blocks = []
+    for i in range(cpage.channel_count):
+        col = cpage.columns[i]
+        nulls = None
+        if col.nulls:
+            nulls = np.ctypeslib.as_array(C.cast(col.nulls, C.POINTER(C.c_uint8)), shape=(max(n, 1),))[:n]
+            nulls = nulls.copy() if copy else nulls
+        if col.encoding == abi.VARWIDTH:
+            off = np.ctypeslib.as_array(C.cast(col.offsets, C.POINTER(C.c_int32)), shape=(n + 1,))
+            off = off.copy() if copy else off
+            total = int(off[n]) if n > 0 else 0
+            if total > 0:
+                vals = np.ctypeslib.as_array(C.cast(col.values, C.POINTER(C.c_uint8)), shape=(total,))
+                vals = vals.copy() if copy else vals
+            else:
+                vals = np.zeros(1, dtype=np.uint8)
+            blocks.append(Block(col.type, abi.VARWIDTH, n, values=vals, offsets=off, nulls=nulls))
+        elif col.encoding == abi.FLAT:
+            dt = np.dtype(_NP_DTYPE[col.type])
+            if n > 0:
+                ctype = {8: C.c_int64, 4: C.c_int32, 1: C.c_uint8}[dt.itemsize]
+                raw = np.ctypeslib.as_array(C.cast(col.values, C.POINTER(ctype)), shape=(n,))
+                vals = raw.view(dt)
+                vals = vals.copy() if copy else vals
+            else:
+                vals = np.zeros(0, dtype=dt)
+            blocks.append(Block(col.type, abi.FLAT, n, values=vals, nulls=nulls))
+        else:
+            raise NotImplementedError("dictionary output")
+    return Page(blocks, n, abi.MEM_HOST)
+
+
+def sequence_page(length, columns):
+    """SequencePageBuilder.createSequencePage (core/trino-main/src/test/java/io/trino/
+    SequencePageBuilder.java:44-84): column i = start_i .. start_i+length-1; VARCHAR = decimal string."""
+    blocks = []
+    for type_, start in columns:
+        seq = np.arange(start, start + length)
+        if type_ == abi.VARCHAR:
+            blocks.append(Block.varchar([str(v) for v in seq.tolist()]))
+        elif type_ == abi.DOUBLE:
+            blocks.append(Block.double(seq.astype(np.float64)))
+        elif type_ == abi.BOOLEAN:
+            blocks.append(Block.boolean((seq % 2) == 0))
+        else:
+            blocks.append(Block.flat(type_, seq))
+    return Page(blocks, length)
