@@ -161,6 +161,7 @@ typedef enum pa_agg_step { PA_STEP_SINGLE = 0, PA_STEP_PARTIAL = 1, PA_STEP_FINA
 typedef struct pa_filter_project_desc {
     int32_t input_channel_count;
     const int32_t* input_types;          /* pa_type per input channel */
+    const int32_t* input_type_params;    /* per channel: VarcharType.getLength() bound, 0 = unbounded; NULL = all 0 */
     const pa_expr* filter;               /* NULL = no filter */
     int32_t projection_count;
     const pa_expr* projections;
@@ -182,6 +183,7 @@ typedef struct pa_aggregation_desc {
 typedef struct pa_hash_aggregation_desc {
     int32_t input_channel_count;
     const int32_t* input_types;
+    const int32_t* input_type_params;    /* as in pa_filter_project_desc; may be NULL */
     int32_t group_by_count;
     const int32_t* group_by_channels;
     int32_t hash_channel;                /* precomputed $hashvalue channel or -1 */

@@ -74,6 +74,7 @@ def lib():
                                         C.c_void_p]
         L.orc_q6.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_double),
                              C.POINTER(C.c_int64)]
+        L.orc_q1_add.argtypes = [C.c_void_p] + [C.c_void_p] * 9 + [C.c_int64]
         _LIB = L
     return _LIB
 
@@ -356,3 +357,13 @@ def q6(shipdate, discount, quantity, extendedprice):
     lib().orc_q6(shipdate.ctypes.data, discount.ctypes.data, quantity.ctypes.data, extendedprice.ctypes.data,
                  len(shipdate), C.byref(s), C.byref(c))
     return s.value, c.value
+
+
+def q1(columns, chunks=1):
+    """Hand-written Q1 pipeline twin over whole columns (returnflag bytes, rf offsets, linestatus bytes, ls offsets,
+    quantity, extendedprice, discount, tax, shipdate); returns the result rows."""
+    from presto_amd import tpch
+    agg = HashAggregation([p.type for p in tpch.q1_projections()], tpch.Q1_GROUP_BY, tpch.Q1_AGGREGATES)
+    n = len(columns[8])
+    _check(lib().orc_q1_add(agg._h, *[c.ctypes.data for c in columns], n))
+    return agg.build_result().to_rows()

@@ -1863,3 +1863,66 @@ int32_t orc_q6(const int32_t* shipdate, const double* discount, const double* qu
     *count = c;
     return 0;
 }
+
+/* =====================================================================================
+ * Q1 twin for the CPU baseline: TpchQuery1Operator.filterAndProjectRowOriented
+ * (BM/HandTpchQuery1.java:241-330, with the SQL form's 8 aggregates of BM/SqlTpchQuery1.java:29-36)
+ * feeding HashAggregationOperator -> InMemoryHashAggregationBuilder -> MultiChannelGroupByHash in
+ * pages of up to 8192 projected rows, exactly as one Driver thread does.  `agg` must have been created
+ * for the projected layout (VARCHAR, VARCHAR, DOUBLE x5) with group-by channels {0,1}.
+ * ===================================================================================== */
+int32_t orc_q1_add(orc_hash_agg* agg, const uint8_t* returnflag, const int32_t* rf_offsets, const uint8_t* linestatus,
+                   const int32_t* ls_offsets, const double* quantity, const double* extendedprice, const double* discount,
+                   const double* tax, const int32_t* shipdate, int64_t n)
+{
+    enum { BATCH = 8192 };
+    uint8_t rf[BATCH * 4], ls[BATCH * 4];
+    int32_t rfo[BATCH + 1], lso[BATCH + 1];
+    static __thread double qty[BATCH], price[BATCH], disc_price[BATCH], charge[BATCH], disc[BATCH];
+    int64_t i = 0;
+    while (i < n) {
+        int32_t m = 0;
+        int32_t rfb = 0, lsb = 0;
+        rfo[0] = 0;
+        lso[0] = 0;
+        for (; i < n && m < BATCH; i++) {
+            if (shipdate[i] <= 10471) {
+                int32_t l1 = rf_offsets[i + 1] - rf_offsets[i], l2 = ls_offsets[i + 1] - ls_offsets[i];
+                if (l1 > 4 || l2 > 4) {
+                    return fail(PA_ERR_NOT_SUPPORTED, "q1 twin expects VARCHAR(1..4) flags");
+                }
+                memcpy(rf + rfb, returnflag + rf_offsets[i], (size_t)l1);
+                rfb += l1;
+                rfo[m + 1] = rfb;
+                memcpy(ls + lsb, linestatus + ls_offsets[i], (size_t)l2);
+                lsb += l2;
+                lso[m + 1] = lsb;
+                qty[m] = quantity[i];
+                price[m] = extendedprice[i];
+                disc_price[m] = extendedprice[i] * (1 - discount[i]);
+                charge[m] = extendedprice[i] * (1 - discount[i]) * (1 + tax[i]);
+                disc[m] = discount[i];
+                m++;
+            }
+        }
+        if (m == 0) {
+            continue;
+        }
+        pa_column cols[7];
+        memset(cols, 0, sizeof cols);
+        cols[0].type = PA_VARCHAR; cols[0].encoding = PA_VARWIDTH; cols[0].values = rf; cols[0].offsets = rfo;
+        cols[1].type = PA_VARCHAR; cols[1].encoding = PA_VARWIDTH; cols[1].values = ls; cols[1].offsets = lso;
+        const double* d[5] = {qty, price, disc_price, charge, disc};
+        for (int c = 0; c < 5; c++) {
+            cols[2 + c].type = PA_DOUBLE;
+            cols[2 + c].encoding = PA_FLAT;
+            cols[2 + c].values = d[c];
+        }
+        pa_page page = {m, 7, cols, PA_MEM_HOST, 0};
+        int32_t rc = orc_hash_agg_add_page(agg, &page, NULL);
+        if (rc < 0) {
+            return rc;
+        }
+    }
+    return 0;
+}

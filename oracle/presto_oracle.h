@@ -90,6 +90,11 @@ int32_t orc_tpch_generate(int32_t column, double scale_factor, int64_t first_row
 int32_t orc_q6(const int32_t* shipdate, const double* discount, const double* quantity,
                const double* extendedprice, int64_t n, double* sum, int64_t* count);
 
+/* Q1: filter + project in 8192-row pages into `agg` (created for the projected 7-channel layout) */
+int32_t orc_q1_add(orc_hash_agg* agg, const uint8_t* returnflag, const int32_t* rf_offsets, const uint8_t* linestatus,
+                   const int32_t* ls_offsets, const double* quantity, const double* extendedprice, const double* discount,
+                   const double* tax, const int32_t* shipdate, int64_t n);
+
 #ifdef __cplusplus
 }
 #endif

@@ -122,6 +122,7 @@ class pa_filter_project_desc(C.Structure):
     _fields_ = [
         ("input_channel_count", C.c_int32),
         ("input_types", C.POINTER(C.c_int32)),
+        ("input_type_params", C.POINTER(C.c_int32)),
         ("filter", C.POINTER(pa_expr)),
         ("projection_count", C.c_int32),
         ("projections", C.POINTER(pa_expr)),
@@ -145,6 +146,7 @@ class pa_hash_aggregation_desc(C.Structure):
     _fields_ = [
         ("input_channel_count", C.c_int32),
         ("input_types", C.POINTER(C.c_int32)),
+        ("input_type_params", C.POINTER(C.c_int32)),
         ("group_by_count", C.c_int32),
         ("group_by_channels", C.POINTER(C.c_int32)),
         ("hash_channel", C.c_int32),

@@ -1,0 +1,457 @@
+// abi.cpp -- the extern "C" surface declared in include/presto_amd.h.  Thin: argument checks, the
+// exception -> status translation, and dispatch to the operator objects.  No arithmetic lives here.
+#include <mutex>
+
+#include "exprgen.hpp"
+#include "jit.hpp"
+#include "operator.hpp"
+#include "static_kernels.hpp"
+
+namespace pa {
+
+static thread_local std::string g_last_error;
+void set_last_error(const std::string& msg) { g_last_error = msg; }
+
+static int g_cu_count = 0;
+static std::once_flag g_device_once;
+static int32_t g_device_status = PA_OK;
+static std::string g_device_message;
+
+static void probe_device()
+{
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) {
+        g_device_status = PA_ERR_NO_DEVICE;
+        g_device_message = "no HIP device visible: libpresto_amd.so needs an MI355X (gfx950); there is no CPU fallback";
+        return;
+    }
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) {
+        g_device_status = PA_ERR_NO_DEVICE;
+        g_device_message = "hipGetDeviceProperties failed";
+        return;
+    }
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        g_device_status = PA_ERR_NO_DEVICE;
+        g_device_message = std::string("device is ") + prop.gcnArchName + ", but this library is built for gfx950 only";
+        return;
+    }
+    g_cu_count = prop.multiProcessorCount;
+}
+
+void require_device()
+{
+    std::call_once(g_device_once, probe_device);
+    if (g_device_status != PA_OK) throw Error(g_device_status, g_device_message);
+}
+
+int device_cu_count()
+{
+    require_device();
+    return g_cu_count > 0 ? g_cu_count : 256;
+}
+
+template <typename F>
+static int32_t guarded(F&& f)
+{
+    try {
+        return f();
+    }
+    catch (const Error& e) {
+        set_last_error(e.what());
+        return e.code;
+    }
+    catch (const std::bad_alloc&) {
+        set_last_error("host allocation failed");
+        return PA_ERR_INSUFFICIENT_RESOURCES;
+    }
+    catch (const std::exception& e) {
+        set_last_error(e.what());
+        return PA_ERR_DEVICE;
+    }
+    catch (...) {
+        set_last_error("unknown failure");
+        return PA_ERR_DEVICE;
+    }
+}
+
+}  // namespace pa
+
+using namespace pa;
+
+struct pa_lookup_source {
+    std::shared_ptr<void> impl;  // filled by the hash builder (op_join.cpp)
+};
+
+extern "C" {
+
+int32_t pa_abi_version(void) { return PA_ABI_VERSION; }
+
+int32_t pa_init(int32_t device)
+{
+    return guarded([&]() -> int32_t {
+        int count = 0;
+        if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
+            throw Error(PA_ERR_NO_DEVICE, "no HIP device visible: libpresto_amd.so needs an MI355X (gfx950); there is no CPU fallback");
+        }
+        if (device >= 0) {
+            PA_REQUIRE(device < count, PA_ERR_INVALID_ARGUMENT, "device ordinal out of range");
+            PA_HIP(hipSetDevice(device));
+        }
+        require_device();
+        return PA_OK;
+    });
+}
+
+int32_t pa_shutdown(void) { return PA_OK; }
+
+const char* pa_last_error(void) { return g_last_error.c_str(); }
+
+int32_t pa_device_count(void)
+{
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess) return 0;
+    return count;
+}
+
+int32_t pa_device_malloc(void** ptr, int64_t bytes)
+{
+    return guarded([&]() -> int32_t {
+        PA_REQUIRE(ptr != nullptr && bytes >= 0, PA_ERR_INVALID_ARGUMENT, "bad arguments");
+        require_device();
+        PA_HIP(hipMalloc(ptr, (size_t)(bytes > 0 ? bytes : 1)));
+        return PA_OK;
+    });
+}
+int32_t pa_device_free(void* ptr)
+{
+    return guarded([&]() -> int32_t {
+        if (ptr) PA_HIP(hipFree(ptr));
+        return PA_OK;
+    });
+}
+int32_t pa_host_malloc_pinned(void** ptr, int64_t bytes)
+{
+    return guarded([&]() -> int32_t {
+        PA_REQUIRE(ptr != nullptr && bytes >= 0, PA_ERR_INVALID_ARGUMENT, "bad arguments");
+        require_device();
+        PA_HIP(hipHostMalloc(ptr, (size_t)(bytes > 0 ? bytes : 1), hipHostMallocDefault));
+        return PA_OK;
+    });
+}
+int32_t pa_host_free_pinned(void* ptr)
+{
+    return guarded([&]() -> int32_t {
+        if (ptr) PA_HIP(hipHostFree(ptr));
+        return PA_OK;
+    });
+}
+int32_t pa_memcpy_h2d(void* dst, const void* src, int64_t bytes, void* stream)
+{
+    return guarded([&]() -> int32_t {
+        if (bytes > 0) PA_HIP(hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+        PA_HIP(hipStreamSynchronize((hipStream_t)stream));
+        return PA_OK;
+    });
+}
+int32_t pa_memcpy_d2h(void* dst, const void* src, int64_t bytes, void* stream)
+{
+    return guarded([&]() -> int32_t {
+        if (bytes > 0) PA_HIP(hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
+        PA_HIP(hipStreamSynchronize((hipStream_t)stream));
+        return PA_OK;
+    });
+}
+int32_t pa_stream_synchronize(void* stream)
+{
+    return guarded([&]() -> int32_t {
+        PA_HIP(hipStreamSynchronize((hipStream_t)stream));
+        return PA_OK;
+    });
+}
+
+// ---- factories ----
+int32_t pa_fused_aggregation_create(const pa_fused_aggregation_desc* desc, pa_operator** out)
+{
+    return guarded([&]() -> int32_t {
+        PA_REQUIRE(out != nullptr, PA_ERR_INVALID_ARGUMENT, "out is null");
+        *out = make_fused_aggregation(desc);
+        return PA_OK;
+    });
+}
+
+// AggregationOperator / HashAggregationOperator on their own = the fused operator with an empty filter
+// and identity projections over the input channels.
+static int32_t create_plain_aggregation(const pa_hash_aggregation_desc* agg, pa_operator** out)
+{
+    PA_REQUIRE(agg != nullptr && out != nullptr, PA_ERR_INVALID_ARGUMENT, "null argument");
+    int n = agg->input_channel_count;
+    PA_REQUIRE(n > 0, PA_ERR_INVALID_ARGUMENT, "aggregation needs input channels");
+    std::vector<pa_expr_node> nodes(n);
+    std::vector<pa_expr> exprs(n);
+    for (int c = 0; c < n; c++) {
+        memset(&nodes[c], 0, sizeof(pa_expr_node));
+        nodes[c].kind = PA_EXPR_INPUT_REF;
+        nodes[c].type = agg->input_types[c];
+        nodes[c].channel = c;
+        exprs[c].node_count = 1;
+        exprs[c].root = 0;
+        exprs[c].nodes = &nodes[c];
+        exprs[c].arg_count = 0;
+        exprs[c].args = nullptr;
+    }
+    pa_fused_aggregation_desc d;
+    memset(&d, 0, sizeof d);
+    d.filter_project.input_channel_count = n;
+    d.filter_project.input_types = agg->input_types;
+    d.filter_project.input_type_params = agg->input_type_params;
+    d.filter_project.filter = nullptr;
+    d.filter_project.projection_count = n;
+    d.filter_project.projections = exprs.data();
+    d.filter_project.output_mem = agg->output_mem;
+    d.filter_project.stream = agg->stream;
+    d.aggregation = *agg;
+    *out = make_fused_aggregation(&d);
+    return PA_OK;
+}
+
+int32_t pa_hash_aggregation_create(const pa_hash_aggregation_desc* desc, pa_operator** out)
+{
+    return guarded([&]() -> int32_t { return create_plain_aggregation(desc, out); });
+}
+
+int32_t pa_aggregation_create(const pa_aggregation_desc* desc, pa_operator** out)
+{
+    return guarded([&]() -> int32_t {
+        PA_REQUIRE(desc != nullptr, PA_ERR_INVALID_ARGUMENT, "descriptor is null");
+        pa_hash_aggregation_desc h;
+        memset(&h, 0, sizeof h);
+        h.input_channel_count = desc->input_channel_count;
+        h.input_types = desc->input_types;
+        h.group_by_count = 0;
+        h.hash_channel = -1;
+        h.step = PA_STEP_SINGLE;
+        h.aggregate_count = desc->aggregate_count;
+        h.aggregates = desc->aggregates;
+        h.output_mem = desc->output_mem;
+        h.stream = desc->stream;
+        return create_plain_aggregation(&h, out);
+    });
+}
+
+int32_t pa_filter_project_create(const pa_filter_project_desc* desc, pa_operator** out)
+{
+    return guarded([&]() -> int32_t {
+        PA_REQUIRE(out != nullptr, PA_ERR_INVALID_ARGUMENT, "out is null");
+        *out = make_filter_project(desc);
+        return PA_OK;
+    });
+}
+
+int32_t pa_lookup_source_create(pa_lookup_source** out)
+{
+    return guarded([&]() -> int32_t {
+        PA_REQUIRE(out != nullptr, PA_ERR_INVALID_ARGUMENT, "out is null");
+        *out = new pa_lookup_source();
+        return PA_OK;
+    });
+}
+int32_t pa_lookup_source_destroy(pa_lookup_source* ls)
+{
+    delete ls;
+    return PA_OK;
+}
+int32_t pa_hash_builder_create(const pa_hash_builder_desc* desc, pa_lookup_source* bridge, pa_operator** out)
+{
+    return guarded([&]() -> int32_t {
+        PA_REQUIRE(out != nullptr && bridge != nullptr, PA_ERR_INVALID_ARGUMENT, "null argument");
+        *out = make_hash_builder(desc, bridge);
+        return PA_OK;
+    });
+}
+int32_t pa_lookup_join_create(const pa_lookup_join_desc* desc, pa_lookup_source* bridge, pa_operator** out)
+{
+    return guarded([&]() -> int32_t {
+        PA_REQUIRE(out != nullptr && bridge != nullptr, PA_ERR_INVALID_ARGUMENT, "null argument");
+        *out = make_lookup_join(desc, bridge);
+        return PA_OK;
+    });
+}
+
+// ---- Operator protocol ----
+int32_t pa_op_needs_input(pa_operator* op)
+{
+    return guarded([&]() -> int32_t {
+        PA_REQUIRE(op != nullptr, PA_ERR_INVALID_ARGUMENT, "operator is null");
+        return op->needs_input() ? 1 : 0;
+    });
+}
+int32_t pa_op_add_input(pa_operator* op, const pa_page* page)
+{
+    return guarded([&]() -> int32_t {
+        PA_REQUIRE(op != nullptr, PA_ERR_INVALID_ARGUMENT, "operator is null");
+        PA_REQUIRE(op->needs_input(), PA_ERR_ILLEGAL_STATE, "Operator does not need input");
+        op->add_input(page);
+        return PA_OK;
+    });
+}
+int32_t pa_op_get_output(pa_operator* op, pa_page* out)
+{
+    return guarded([&]() -> int32_t {
+        PA_REQUIRE(op != nullptr && out != nullptr, PA_ERR_INVALID_ARGUMENT, "null argument");
+        return op->get_output(out) ? 1 : 0;
+    });
+}
+int32_t pa_op_finish(pa_operator* op)
+{
+    return guarded([&]() -> int32_t {
+        PA_REQUIRE(op != nullptr, PA_ERR_INVALID_ARGUMENT, "operator is null");
+        op->finish();
+        return PA_OK;
+    });
+}
+int32_t pa_op_is_finished(pa_operator* op)
+{
+    return guarded([&]() -> int32_t {
+        PA_REQUIRE(op != nullptr, PA_ERR_INVALID_ARGUMENT, "operator is null");
+        return op->is_finished() ? 1 : 0;
+    });
+}
+int32_t pa_op_is_blocked(pa_operator* op)
+{
+    return guarded([&]() -> int32_t {
+        PA_REQUIRE(op != nullptr, PA_ERR_INVALID_ARGUMENT, "operator is null");
+        return op->is_blocked() ? 1 : 0;
+    });
+}
+int64_t pa_op_memory_bytes(pa_operator* op)
+{
+    int64_t bytes = 0;
+    int32_t rc = guarded([&]() -> int32_t {
+        PA_REQUIRE(op != nullptr, PA_ERR_INVALID_ARGUMENT, "operator is null");
+        bytes = op->memory_bytes();
+        return PA_OK;
+    });
+    return rc < 0 ? rc : bytes;
+}
+int32_t pa_op_close(pa_operator* op)
+{
+    return guarded([&]() -> int32_t {
+        if (op) {
+            op->close();
+            delete op;
+        }
+        return PA_OK;
+    });
+}
+int32_t pa_op_kernel_time(pa_operator* op, double* total_ms, int64_t* launches)
+{
+    return guarded([&]() -> int32_t {
+        PA_REQUIRE(op != nullptr, PA_ERR_INVALID_ARGUMENT, "operator is null");
+        op->timer.drain();
+        if (total_ms) *total_ms = op->timer.total_ms();
+        if (launches) *launches = op->timer.launches();
+        return PA_OK;
+    });
+}
+
+// ---- stand-alone kernels ----
+int32_t pa_hash_page(const pa_page* page, int32_t channel_count, const int32_t* channels, int64_t* out_raw_hash, void* stream)
+{
+    return guarded([&]() -> int32_t {
+        PA_REQUIRE(page != nullptr && channels != nullptr && out_raw_hash != nullptr, PA_ERR_INVALID_ARGUMENT, "null argument");
+        PA_REQUIRE(page->mem == PA_MEM_DEVICE, PA_ERR_INVALID_ARGUMENT, "pa_hash_page takes a device-resident page");
+        PA_REQUIRE(channel_count >= 0 && channel_count <= 16, PA_ERR_NOT_SUPPORTED, "at most 16 hash channels");
+        require_device();
+        HashPageArgs a;
+        memset(&a, 0, sizeof a);
+        for (int32_t i = 0; i < channel_count; i++) {
+            int32_t c = channels[i];
+            PA_REQUIRE(c >= 0 && c < page->channel_count, PA_ERR_INVALID_ARGUMENT, "hash channel out of range");
+            const pa_column& col = page->columns[c];
+            PA_REQUIRE(col.encoding == PA_FLAT || col.encoding == PA_VARWIDTH, PA_ERR_NOT_SUPPORTED, "hash of an encoded block");
+            a.col[i].values = col.values;
+            a.col[i].offsets = col.offsets;
+            a.col[i].nulls = col.nulls;
+            a.col[i].type = col.type;
+        }
+        a.ncols = channel_count;
+        a.n = page->position_count;
+        a.out = out_raw_hash;
+        launch_hash_page(a, (hipStream_t)stream);
+        return PA_OK;
+    });
+}
+
+int32_t pa_partition_ids(const int64_t* raw_hash, int32_t position_count, int32_t partition_count, int32_t local,
+                         int32_t* out_partition, void* stream)
+{
+    return guarded([&]() -> int32_t {
+        PA_REQUIRE(raw_hash != nullptr && out_partition != nullptr, PA_ERR_INVALID_ARGUMENT, "null argument");
+        PA_REQUIRE(partition_count > 0, PA_ERR_INVALID_ARGUMENT, "partitionCount must be positive");
+        PA_REQUIRE(!local || (partition_count & (partition_count - 1)) == 0, PA_ERR_INVALID_ARGUMENT, "partitionCount must be a power of 2");
+        require_device();
+        launch_partition_ids(raw_hash, position_count, partition_count, local, out_partition, (hipStream_t)stream);
+        return PA_OK;
+    });
+}
+
+int32_t pa_gather_flat(const void* src, int32_t elem_bytes, const int32_t* positions, int32_t count, void* dst, void* stream)
+{
+    return guarded([&]() -> int32_t {
+        require_device();
+        launch_gather_flat(src, elem_bytes, positions, count, dst, (hipStream_t)stream);
+        return PA_OK;
+    });
+}
+
+int32_t pa_tpch_generate(int32_t column, double scale_factor, int64_t first_row, int64_t row_count, uint64_t seed, void* values,
+                         int32_t* offsets, void* stream)
+{
+    return guarded([&]() -> int32_t {
+        PA_REQUIRE(values != nullptr && row_count >= 0, PA_ERR_INVALID_ARGUMENT, "bad arguments");
+        require_device();
+        launch_tpch(column, scale_factor, first_row, row_count, seed, values, offsets, (hipStream_t)stream);
+        return PA_OK;
+    });
+}
+
+// ---- code generation without a device (build(), CPU-side tests) ----
+// Writes the generated translation unit of a fused descriptor into buf (NUL terminated) and its cache
+// key into key[17]; returns the needed buffer size.  variant: -1 default, 0 GLOBAL, 1 LDS, 2 GT.
+int64_t pa_codegen_fused(const pa_fused_aggregation_desc* desc, int32_t variant, char* buf, int64_t buf_size, char* key)
+{
+    int64_t need = 0;
+    int32_t rc = guarded([&]() -> int32_t {
+        std::string entry;
+        std::string src = fused_source_for_desc(desc, variant, &entry);
+        std::string tu = jit_translation_unit(src);
+        need = (int64_t)tu.size() + 1;
+        if (buf && buf_size >= need) memcpy(buf, tu.c_str(), (size_t)need);
+        if (key) {
+            std::string k = jit_key(src);
+            memcpy(key, k.c_str(), k.size() + 1);
+        }
+        return PA_OK;
+    });
+    return rc < 0 ? rc : need;
+}
+
+// Compiles a fused descriptor's kernel with hiprtc for gfx950 (no device needed); returns the code
+// object size or a negative status.
+int64_t pa_codegen_compile_fused(const pa_fused_aggregation_desc* desc, int32_t variant)
+{
+    int64_t size = 0;
+    int32_t rc = guarded([&]() -> int32_t {
+        std::string entry;
+        std::string src = fused_source_for_desc(desc, variant, &entry);
+        size = (int64_t)jit_compile_only(src).size();
+        return PA_OK;
+    });
+    return rc < 0 ? rc : size;
+}
+
+}  // extern "C"

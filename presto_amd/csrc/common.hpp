@@ -1,0 +1,227 @@
+// common.hpp -- host-side plumbing of libpresto_amd.so: error model, HIP RAII helpers, streams.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/presto_amd.h"
+
+namespace pa {
+
+// Internal error; converted into (status, thread-local message) at the C ABI, never crosses it.
+struct Error : std::runtime_error {
+    int32_t code;
+    Error(int32_t c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+
+void set_last_error(const std::string& msg);
+
+#define PA_HIP(expr)                                                                                   \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess) {                                                                        \
+            throw ::pa::Error(PA_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));       \
+        }                                                                                              \
+    } while (0)
+
+#define PA_REQUIRE(cond, code, msg)                   \
+    do {                                              \
+        if (!(cond)) throw ::pa::Error((code), (msg)); \
+    } while (0)
+
+inline int type_width(int32_t t)
+{
+    switch (t) {
+        case PA_BIGINT:
+        case PA_DOUBLE:
+            return 8;
+        case PA_INTEGER:
+        case PA_DATE:
+            return 4;
+        case PA_BOOLEAN:
+            return 1;
+        default:
+            return 0;
+    }
+}
+
+// Growable HBM allocation (never shrinks; reused across pages).
+class DevBuf {
+public:
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    DevBuf(DevBuf&& o) noexcept : p_(o.p_), cap_(o.cap_) { o.p_ = nullptr; o.cap_ = 0; }
+    DevBuf& operator=(DevBuf&& o) noexcept
+    {
+        if (this != &o) { release(); p_ = o.p_; cap_ = o.cap_; o.p_ = nullptr; o.cap_ = 0; }
+        return *this;
+    }
+    ~DevBuf() { release(); }
+    void* ensure(size_t bytes)
+    {
+        if (bytes > cap_) {
+            release();
+            size_t want = bytes < 256 ? 256 : bytes;
+            PA_HIP(hipMalloc(&p_, want));
+            cap_ = want;
+        }
+        return p_;
+    }
+    // grow keeping contents (stream-ordered copy)
+    void* grow(size_t bytes, hipStream_t s)
+    {
+        if (bytes <= cap_) return p_;
+        void* np = nullptr;
+        size_t want = bytes < 2 * cap_ ? 2 * cap_ : bytes;
+        PA_HIP(hipMalloc(&np, want));
+        if (p_ && cap_) {
+            PA_HIP(hipMemcpyAsync(np, p_, cap_, hipMemcpyDeviceToDevice, s));
+            PA_HIP(hipStreamSynchronize(s));
+            (void)hipFree(p_);
+        }
+        p_ = np;
+        cap_ = want;
+        return p_;
+    }
+    void release()
+    {
+        if (p_) (void)hipFree(p_);
+        p_ = nullptr;
+        cap_ = 0;
+    }
+    void* ptr() const { return p_; }
+    template <typename T> T* as() const { return static_cast<T*>(p_); }
+    size_t capacity() const { return cap_; }
+
+private:
+    void* p_ = nullptr;
+    size_t cap_ = 0;
+};
+
+// Growable pinned host allocation (D2H landing zone / H2D staging).
+class PinnedBuf {
+public:
+    PinnedBuf() = default;
+    PinnedBuf(const PinnedBuf&) = delete;
+    PinnedBuf& operator=(const PinnedBuf&) = delete;
+    PinnedBuf(PinnedBuf&& o) noexcept : p_(o.p_), cap_(o.cap_) { o.p_ = nullptr; o.cap_ = 0; }
+    PinnedBuf& operator=(PinnedBuf&& o) noexcept
+    {
+        if (this != &o) { release(); p_ = o.p_; cap_ = o.cap_; o.p_ = nullptr; o.cap_ = 0; }
+        return *this;
+    }
+    ~PinnedBuf() { release(); }
+    void* ensure(size_t bytes)
+    {
+        if (bytes > cap_) {
+            release();
+            size_t want = bytes < 256 ? 256 : bytes;
+            PA_HIP(hipHostMalloc(&p_, want, hipHostMallocDefault));
+            cap_ = want;
+        }
+        return p_;
+    }
+    void release()
+    {
+        if (p_) (void)hipHostFree(p_);
+        p_ = nullptr;
+        cap_ = 0;
+    }
+    void* ptr() const { return p_; }
+    template <typename T> T* as() const { return static_cast<T*>(p_); }
+    size_t capacity() const { return cap_; }
+
+private:
+    void* p_ = nullptr;
+    size_t cap_ = 0;
+};
+
+// A stream either borrowed from the host (desc.stream) or owned by the operator.
+class Stream {
+public:
+    explicit Stream(void* borrowed)
+    {
+        if (borrowed) {
+            s_ = static_cast<hipStream_t>(borrowed);
+            owned_ = false;
+        }
+        else {
+            PA_HIP(hipStreamCreateWithFlags(&s_, hipStreamNonBlocking));
+            owned_ = true;
+        }
+    }
+    Stream(const Stream&) = delete;
+    Stream& operator=(const Stream&) = delete;
+    ~Stream()
+    {
+        if (owned_ && s_) (void)hipStreamDestroy(s_);
+    }
+    hipStream_t get() const { return s_; }
+    void sync() const { PA_HIP(hipStreamSynchronize(s_)); }
+
+private:
+    hipStream_t s_ = nullptr;
+    bool owned_ = false;
+};
+
+// HIP-event stopwatch around the launches of an operator's dominant kernel (pa_op_kernel_time).
+class KernelTimer {
+public:
+    ~KernelTimer()
+    {
+        for (auto& p : pairs_) {
+            (void)hipEventDestroy(p.first);
+            (void)hipEventDestroy(p.second);
+        }
+    }
+    void begin(hipStream_t s)
+    {
+        if (next_ == pairs_.size()) {
+            if (pairs_.size() >= 4096) { drain(); }
+            else {
+                hipEvent_t a, b;
+                PA_HIP(hipEventCreate(&a));
+                PA_HIP(hipEventCreate(&b));
+                pairs_.emplace_back(a, b);
+            }
+        }
+        PA_HIP(hipEventRecord(pairs_[next_].first, s));
+    }
+    void end(hipStream_t s)
+    {
+        PA_HIP(hipEventRecord(pairs_[next_].second, s));
+        next_++;
+    }
+    void drain()
+    {
+        for (size_t i = 0; i < next_; i++) {
+            PA_HIP(hipEventSynchronize(pairs_[i].second));
+            float ms = 0;
+            PA_HIP(hipEventElapsedTime(&ms, pairs_[i].first, pairs_[i].second));
+            total_ms_ += ms;
+            launches_++;
+        }
+        next_ = 0;
+    }
+    double total_ms() const { return total_ms_; }
+    int64_t launches() const { return launches_; }
+
+private:
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pairs_;
+    size_t next_ = 0;
+    double total_ms_ = 0;
+    int64_t launches_ = 0;
+};
+
+int device_cu_count();
+void require_device();
+
+}  // namespace pa

@@ -1,0 +1,161 @@
+// device_page.cpp -- see device_page.hpp.
+#include "device_page.hpp"
+
+namespace pa {
+
+void* PageStager::arena(size_t index, size_t bytes)
+{
+    if (index >= bufs_.size()) bufs_.resize(index + 1);
+    return bufs_[index].ensure(bytes);
+}
+
+size_t PageStager::bytes() const
+{
+    size_t total = 0;
+    for (const auto& b : bufs_) total += b.capacity();
+    return total;
+}
+
+static const void* to_device(const void* src, size_t bytes, bool is_device, void* dst, hipStream_t stream)
+{
+    if (src == nullptr) return nullptr;
+    if (is_device) return src;
+    if (bytes > 0) PA_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stream));
+    return dst;
+}
+
+DevPage PageStager::stage(const pa_page* page, const std::vector<bool>* needed, hipStream_t stream)
+{
+    PA_REQUIRE(page != nullptr, PA_ERR_INVALID_ARGUMENT, "page is null");
+    PA_REQUIRE(page->position_count >= 0 && page->channel_count >= 0, PA_ERR_INVALID_ARGUMENT, "negative page dimensions");
+    PA_REQUIRE(page->channel_count == 0 || page->columns != nullptr, PA_ERR_INVALID_ARGUMENT, "page columns is null");
+    const bool dev = page->mem == PA_MEM_DEVICE;
+    const int64_t n = page->position_count;
+    DevPage out;
+    out.n = page->position_count;
+    out.cols.resize(page->channel_count);
+    next_ = 0;
+    for (int32_t c = 0; c < page->channel_count; c++) {
+        const pa_column& col = page->columns[c];
+        DevColumn& d = out.cols[c];
+        d.type = col.type;
+        if (needed && (c >= (int32_t)needed->size() || !(*needed)[c])) {
+            next_ += 6;
+            continue;
+        }
+        size_t slot = next_;
+        next_ += 6;
+        if (col.encoding == PA_FLAT) {
+            int w = type_width(col.type);
+            PA_REQUIRE(w > 0, PA_ERR_NOT_SUPPORTED, "FLAT block of a variable-width type");
+            PA_REQUIRE(col.values != nullptr || n == 0, PA_ERR_INVALID_ARGUMENT, "block values is null");
+            d.values = to_device(col.values, (size_t)n * w, dev, dev ? nullptr : arena(slot, (size_t)n * w), stream);
+            d.nulls = static_cast<const uint8_t*>(
+                to_device(col.nulls, (size_t)n, dev, (dev || !col.nulls) ? nullptr : arena(slot + 1, (size_t)n), stream));
+        }
+        else if (col.encoding == PA_VARWIDTH) {
+            PA_REQUIRE(col.type == PA_VARCHAR, PA_ERR_NOT_SUPPORTED, "VARWIDTH block of a fixed-width type");
+            PA_REQUIRE(col.offsets != nullptr, PA_ERR_INVALID_ARGUMENT, "VARWIDTH block without offsets");
+            d.varwidth = true;
+            if (dev) {
+                d.values = col.values;
+                d.offsets = col.offsets;
+                d.nulls = col.nulls;
+            }
+            else {
+                size_t total = (size_t)col.offsets[n];
+                d.offsets = static_cast<const int32_t*>(
+                    to_device(col.offsets, (size_t)(n + 1) * 4, false, arena(slot, (size_t)(n + 1) * 4), stream));
+                d.values = to_device(col.values, total, false, arena(slot + 1, total ? total : 1), stream);
+                d.nulls = static_cast<const uint8_t*>(
+                    to_device(col.nulls, (size_t)n, false, col.nulls ? arena(slot + 2, (size_t)n) : nullptr, stream));
+            }
+        }
+        else if (col.encoding == PA_DICTIONARY || col.encoding == PA_RLE) {
+            // decode (DictionaryBlock / RunLengthEncodedBlock -> flat) with a gather kernel
+            PA_REQUIRE(col.dictionary != nullptr, PA_ERR_INVALID_ARGUMENT, "dictionary block without dictionary");
+            const pa_column& dict = *col.dictionary;
+            PA_REQUIRE(dict.encoding == PA_FLAT, PA_ERR_NOT_SUPPORTED,
+                       "dictionary / RLE over variable-width or nested blocks is decoded on the Java side");
+            int w = type_width(dict.type);
+            PA_REQUIRE(w > 0, PA_ERR_NOT_SUPPORTED, "dictionary of a variable-width type");
+            d.type = dict.type;
+            int64_t dn = col.encoding == PA_RLE ? 1 : col.dictionary_size;
+            PA_REQUIRE(dn > 0 || n == 0, PA_ERR_INVALID_ARGUMENT, "empty dictionary");
+            const void* dvals = to_device(dict.values, (size_t)dn * w, dev, dev ? nullptr : arena(slot, (size_t)dn * w), stream);
+            const uint8_t* dnulls = static_cast<const uint8_t*>(
+                to_device(dict.nulls, (size_t)dn, dev, (dev || !dict.nulls) ? nullptr : arena(slot + 1, (size_t)dn), stream));
+            void* flat = arena(slot + 2, (size_t)(n > 0 ? n : 1) * w);
+            uint8_t* fnulls = dnulls ? static_cast<uint8_t*>(arena(slot + 3, (size_t)(n > 0 ? n : 1))) : nullptr;
+            if (col.encoding == PA_RLE) {
+                launch_fill_flat(flat, w, dvals, n, stream);
+                if (dnulls) launch_fill_flat(fnulls, 1, dnulls, n, stream);
+            }
+            else {
+                PA_REQUIRE(col.ids != nullptr, PA_ERR_INVALID_ARGUMENT, "dictionary block without ids");
+                const int32_t* ids = static_cast<const int32_t*>(
+                    to_device(col.ids, (size_t)n * 4, dev, dev ? nullptr : arena(slot + 4, (size_t)(n > 0 ? n : 1) * 4), stream));
+                launch_gather_flat(dvals, w, ids, n, flat, stream);
+                if (dnulls) launch_gather_nulls(dnulls, ids, n, fnulls, stream);
+            }
+            d.values = flat;
+            d.nulls = fnulls;
+        }
+        else {
+            throw Error(PA_ERR_NOT_SUPPORTED, "unknown block encoding");
+        }
+    }
+    return out;
+}
+
+void publish_output(std::vector<OutColumn>& cols, int32_t n, int32_t mem, hipStream_t stream, pa_page* out,
+                    std::vector<pa_column>& storage)
+{
+    storage.assign(cols.size() ? cols.size() : 1, pa_column{});
+    bool need_sync = false;
+    for (size_t c = 0; c < cols.size(); c++) {
+        OutColumn& o = cols[c];
+        pa_column& p = storage[c];
+        p.type = o.type;
+        p.encoding = o.varwidth ? PA_VARWIDTH : PA_FLAT;
+        const void* dv = o.is_view ? o.view_values : o.values.ptr();
+        const int32_t* doff = o.is_view ? o.view_offsets : o.offsets.as<int32_t>();
+        const uint8_t* dn = o.is_view ? o.view_nulls : (o.has_nulls ? o.nulls.as<uint8_t>() : nullptr);
+        if (mem == PA_MEM_DEVICE) {
+            p.values = dv;
+            p.offsets = o.varwidth ? doff : nullptr;
+            p.nulls = dn;
+            continue;
+        }
+        if (o.varwidth) {
+            int32_t* ho = static_cast<int32_t*>(o.h_offsets.ensure((size_t)(n + 1) * 4));
+            PA_HIP(hipMemcpyAsync(ho, doff, (size_t)(n + 1) * 4, hipMemcpyDeviceToHost, stream));
+            PA_HIP(hipStreamSynchronize(stream));
+            size_t total = (size_t)ho[n];
+            void* hv = o.h_values.ensure(total ? total : 1);
+            if (total) PA_HIP(hipMemcpyAsync(hv, dv, total, hipMemcpyDeviceToHost, stream));
+            p.values = hv;
+            p.offsets = ho;
+        }
+        else {
+            size_t bytes = (size_t)n * type_width(o.type);
+            void* hv = o.h_values.ensure(bytes ? bytes : 1);
+            if (bytes) PA_HIP(hipMemcpyAsync(hv, dv, bytes, hipMemcpyDeviceToHost, stream));
+            p.values = hv;
+        }
+        if (dn) {
+            void* hn = o.h_nulls.ensure((size_t)(n > 0 ? n : 1));
+            if (n) PA_HIP(hipMemcpyAsync(hn, dn, (size_t)n, hipMemcpyDeviceToHost, stream));
+            p.nulls = static_cast<const uint8_t*>(hn);
+        }
+        need_sync = true;
+    }
+    if (need_sync) PA_HIP(hipStreamSynchronize(stream));
+    out->position_count = n;
+    out->channel_count = (int32_t)cols.size();
+    out->columns = storage.data();
+    out->mem = mem;
+    out->reserved = 0;
+}
+
+}  // namespace pa

@@ -1,0 +1,67 @@
+// device_page.hpp -- Pages as columnar HBM buffers.
+//
+// An input pa_page is normalised into a DevPage whose columns are FLAT or VARWIDTH device arrays:
+//   * PA_MEM_DEVICE pages are used in place (zero copy);
+//   * PA_MEM_HOST pages (what the JNI shim hands over after copying out of the JVM heap, SURVEY 8b
+//     "Ownership") are copied column by column into the operator's staging arena on its stream;
+//   * DICTIONARY / RLE blocks are decoded by a gather kernel (DictionaryBlock.getLoadedBlock semantics).
+// Output pages are produced in HBM and, for PA_MEM_HOST consumers, landed in pinned host memory.
+#pragma once
+
+#include <vector>
+
+#include "common.hpp"
+
+namespace pa {
+
+struct DevColumn {
+    int32_t type = PA_BIGINT;
+    bool varwidth = false;
+    const void* values = nullptr;
+    const int32_t* offsets = nullptr;
+    const uint8_t* nulls = nullptr;  // nullptr = no nulls
+};
+
+struct DevPage {
+    int32_t n = 0;
+    std::vector<DevColumn> cols;
+};
+
+class PageStager {
+public:
+    // `needed` (may be null) limits staging to the channels an operator actually reads.
+    DevPage stage(const pa_page* page, const std::vector<bool>* needed, hipStream_t stream);
+    size_t bytes() const;
+
+private:
+    void* arena(size_t index, size_t bytes);
+    std::vector<DevBuf> bufs_;
+    size_t next_ = 0;
+};
+
+// One output Block under construction in HBM.
+struct OutColumn {
+    int32_t type = PA_BIGINT;
+    bool varwidth = false;
+    bool has_nulls = false;
+    DevBuf values, offsets, nulls;
+    // host landing zone (PA_MEM_HOST outputs)
+    PinnedBuf h_values, h_offsets, h_nulls;
+    // zero-copy view of an input column (identity projection of a fully selected device page)
+    const void* view_values = nullptr;
+    const int32_t* view_offsets = nullptr;
+    const uint8_t* view_nulls = nullptr;
+    bool is_view = false;
+};
+
+// Fills `out` (whose `columns` array has room for cols.size() entries) from device columns; for
+// PA_MEM_HOST copies the first `n` positions to pinned memory and synchronises the stream.
+void publish_output(std::vector<OutColumn>& cols, int32_t n, int32_t mem, hipStream_t stream, pa_page* out,
+                    std::vector<pa_column>& storage);
+
+// static kernels used by staging (static_kernels.hip)
+void launch_gather_flat(const void* src, int elem_bytes, const int32_t* positions, int64_t count, void* dst, hipStream_t s);
+void launch_gather_nulls(const uint8_t* src, const int32_t* positions, int64_t count, uint8_t* dst, hipStream_t s);
+void launch_fill_flat(void* dst, int elem_bytes, const void* src_one, int64_t count, hipStream_t s);
+
+}  // namespace pa

@@ -1,0 +1,410 @@
+// pa_device.h -- device-side building blocks for gfx950 (CDNA4, wave64) shared by the statically
+// compiled kernels and by the kernels generated per query (exprgen.cpp + hiprtc).
+//
+// Everything here is integer / f64 streaming work bounded by HBM: no MFMA.  Wave width is
+// hard-coded to 64 (cdna_hip_programming.md section 1).
+#pragma once
+
+typedef long long i64;
+typedef unsigned long long u64;
+typedef int i32;
+typedef unsigned int u32;
+typedef unsigned char u8;
+
+#define PA_WAVE 64
+
+// pa_status values raised from device code (include/presto_amd.h)
+#define PA_DEV_ERR_OUT_OF_RANGE (-4)
+#define PA_DEV_ERR_DIV_ZERO (-5)
+#define PA_DEV_ERR_RESOURCES (-6)
+
+typedef i32 pa_i32x4 __attribute__((ext_vector_type(4)));
+typedef double pa_f64x2 __attribute__((ext_vector_type(2)));
+typedef i64 pa_i64x2 __attribute__((ext_vector_type(2)));
+typedef u32 pa_u32x4 __attribute__((ext_vector_type(4)));
+
+// ---------------------------------------------------------------------------------------------
+// hash arithmetic -- bit-exact with the reference
+// ---------------------------------------------------------------------------------------------
+#define PA_P1 0x9E3779B185EBCA87ULL
+#define PA_P2 0xC2B2AE3D27D4EB4FULL
+#define PA_P3 0x165667B19E3779F9ULL
+#define PA_P4 0x85EBCA77C2B2AE63ULL
+#define PA_P5 0x27D4EB2F165667C5ULL
+
+__device__ __forceinline__ u64 pa_rotl64(u64 x, int r) { return (x << r) | (x >> (64 - r)); }
+
+// AbstractLongType.hash (core/trino-spi/.../type/AbstractLongType.java:126-130)
+__device__ __forceinline__ i64 pa_hash_bigint(i64 v) { return (i64)(pa_rotl64((u64)v * PA_P2, 31) * PA_P1); }
+// DoubleType.hashCodeOperator (core/trino-spi/.../type/DoubleType.java:163-170)
+__device__ __forceinline__ i64 pa_hash_double(double v)
+{
+    if (v == 0) v = 0;
+    i64 bits = (v != v) ? 0x7ff8000000000000LL : __double_as_longlong(v);
+    return pa_hash_bigint(bits);
+}
+// fastutil HashCommon.murmurHash3 == PagesHash.getHashPosition mix (…/operator/join/PagesHash.java:225-241)
+__device__ __forceinline__ u64 pa_murmur3_fmix(u64 h)
+{
+    h ^= h >> 33;
+    h *= 0xff51afd7ed558ccdULL;
+    h ^= h >> 33;
+    h *= 0xc4ceb9fe1a85ec53ULL;
+    h ^= h >> 33;
+    return h;
+}
+// CombineHashFunction.getHash (…/operator/scalar/CombineHashFunction.java:26-29)
+__device__ __forceinline__ i64 pa_combine_hash(i64 prev, i64 v) { return (i64)(31ULL * (u64)prev + (u64)v); }
+
+__device__ __forceinline__ u64 pa_xxh_round(u64 acc, u64 in) { return pa_rotl64(acc + in * PA_P2, 31) * PA_P1; }
+__device__ __forceinline__ u64 pa_xxh_merge(u64 h, u64 v) { return (h ^ pa_xxh_round(0, v)) * PA_P1 + PA_P4; }
+__device__ __forceinline__ u64 pa_rd64(const u8* p)
+{
+    u64 v = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) v |= (u64)p[i] << (8 * i);
+    return v;
+}
+__device__ __forceinline__ u32 pa_rd32(const u8* p)
+{
+    return (u32)p[0] | ((u32)p[1] << 8) | ((u32)p[2] << 16) | ((u32)p[3] << 24);
+}
+__device__ __forceinline__ u64 pa_xxh_avalanche(u64 h)
+{
+    h ^= h >> 33;
+    h *= PA_P2;
+    h ^= h >> 29;
+    h *= PA_P3;
+    h ^= h >> 32;
+    return h;
+}
+// XXH64 seed 0 of a byte string == io.airlift.slice.XxHash64.hash(Slice) (VARCHAR hash,
+// core/trino-spi/.../block/AbstractVariableWidthBlock.java:92-96)
+__device__ inline u64 pa_xxh64(const u8* p, i32 len)
+{
+    const u8* end = p + len;
+    u64 h;
+    if (len >= 32) {
+        u64 v1 = PA_P1 + PA_P2, v2 = PA_P2, v3 = 0, v4 = 0ULL - PA_P1;
+        do {
+            v1 = pa_xxh_round(v1, pa_rd64(p));
+            v2 = pa_xxh_round(v2, pa_rd64(p + 8));
+            v3 = pa_xxh_round(v3, pa_rd64(p + 16));
+            v4 = pa_xxh_round(v4, pa_rd64(p + 24));
+            p += 32;
+        } while (p + 32 <= end);
+        h = pa_rotl64(v1, 1) + pa_rotl64(v2, 7) + pa_rotl64(v3, 12) + pa_rotl64(v4, 18);
+        h = pa_xxh_merge(h, v1);
+        h = pa_xxh_merge(h, v2);
+        h = pa_xxh_merge(h, v3);
+        h = pa_xxh_merge(h, v4);
+    }
+    else {
+        h = PA_P5;
+    }
+    h += (u64)len;
+    while (p + 8 <= end) {
+        h ^= pa_xxh_round(0, pa_rd64(p));
+        h = pa_rotl64(h, 27) * PA_P1 + PA_P4;
+        p += 8;
+    }
+    if (p + 4 <= end) {
+        h ^= (u64)pa_rd32(p) * PA_P1;
+        h = pa_rotl64(h, 23) * PA_P2 + PA_P3;
+        p += 4;
+    }
+    while (p < end) {
+        h ^= (u64)(*p) * PA_P5;
+        h = pa_rotl64(h, 11) * PA_P1;
+        p++;
+    }
+    return pa_xxh_avalanche(h);
+}
+// XxHash64.hash(long): XXH64 of the 8 little-endian bytes
+__device__ __forceinline__ u64 pa_xxh64_long(u64 v)
+{
+    u64 h = PA_P5 + 8;
+    h ^= pa_xxh_round(0, v);
+    h = pa_rotl64(h, 27) * PA_P1 + PA_P4;
+    return pa_xxh_avalanche(h);
+}
+
+// ---------------------------------------------------------------------------------------------
+// VARCHAR helpers (Slice.equals / Slice.compareTo: unsigned bytes, then length)
+// ---------------------------------------------------------------------------------------------
+__device__ inline bool pa_str_eq(const u8* a, i32 alen, const u8* b, i32 blen)
+{
+    if (alen != blen) return false;
+    for (i32 i = 0; i < alen; i++)
+        if (a[i] != b[i]) return false;
+    return true;
+}
+__device__ inline int pa_str_cmp(const u8* a, i32 alen, const u8* b, i32 blen)
+{
+    i32 n = alen < blen ? alen : blen;
+    for (i32 i = 0; i < n; i++) {
+        if (a[i] != b[i]) return a[i] < b[i] ? -1 : 1;
+    }
+    return (alen > blen) - (alen < blen);
+}
+
+// ---------------------------------------------------------------------------------------------
+// exact integer arithmetic (BigintOperators.java:47-121 / IntegerOperators.java): overflow -> *err
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void pa_raise(i32* err, i32 code)
+{
+    if (*err == 0) atomicCAS(err, 0, code);
+}
+__device__ __forceinline__ i64 pa_add_exact(i64 a, i64 b, i32* err)
+{
+    i64 r;
+    if (__builtin_add_overflow(a, b, &r)) pa_raise(err, PA_DEV_ERR_OUT_OF_RANGE);
+    return r;
+}
+__device__ __forceinline__ i64 pa_sub_exact(i64 a, i64 b, i32* err)
+{
+    i64 r;
+    if (__builtin_sub_overflow(a, b, &r)) pa_raise(err, PA_DEV_ERR_OUT_OF_RANGE);
+    return r;
+}
+__device__ __forceinline__ i64 pa_mul_exact(i64 a, i64 b, i32* err)
+{
+    i64 r;
+    if (__builtin_mul_overflow(a, b, &r)) pa_raise(err, PA_DEV_ERR_OUT_OF_RANGE);
+    return r;
+}
+__device__ __forceinline__ i64 pa_div_exact(i64 a, i64 b, i32* err)
+{
+    if (b == 0) { pa_raise(err, PA_DEV_ERR_DIV_ZERO); return 0; }
+    if (a == (-9223372036854775807LL - 1) && b == -1) { pa_raise(err, PA_DEV_ERR_OUT_OF_RANGE); return 0; }
+    return a / b;
+}
+__device__ __forceinline__ i64 pa_mod_exact(i64 a, i64 b, i32* err)
+{
+    if (b == 0) { pa_raise(err, PA_DEV_ERR_DIV_ZERO); return 0; }
+    if (b == -1) return 0;
+    return a % b;
+}
+__device__ __forceinline__ i64 pa_int_range(i64 v, i32* err)
+{
+    if (v > 2147483647LL || v < -2147483648LL) pa_raise(err, PA_DEV_ERR_OUT_OF_RANGE);
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// wave64 / workgroup reductions in a fixed order (bitwise reproducible run to run)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double pa_wave_sum_f64(double v)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v = v + __shfl_xor(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ i64 pa_wave_sum_i64(i64 v)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v = v + __shfl_xor(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ i64 pa_wave_sum_i64_exact(i64 v, i32* err)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        i64 o = __shfl_xor(v, off, 64);
+        i64 r;
+        if (__builtin_add_overflow(v, o, &r)) pa_raise(err, PA_DEV_ERR_OUT_OF_RANGE);
+        v = r;
+    }
+    return v;
+}
+__device__ __forceinline__ double pa_wave_min_f64(double v)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) { double o = __shfl_xor(v, off, 64); v = o < v ? o : v; }
+    return v;
+}
+__device__ __forceinline__ double pa_wave_max_f64(double v)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) { double o = __shfl_xor(v, off, 64); v = o > v ? o : v; }
+    return v;
+}
+__device__ __forceinline__ i64 pa_wave_min_i64(i64 v)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) { i64 o = __shfl_xor(v, off, 64); v = o < v ? o : v; }
+    return v;
+}
+__device__ __forceinline__ i64 pa_wave_max_i64(i64 v)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) { i64 o = __shfl_xor(v, off, 64); v = o > v ? o : v; }
+    return v;
+}
+
+// exclusive prefix count of `pred` among the lanes of the wave below this one, plus the wave total
+__device__ __forceinline__ u32 pa_wave_prefix(bool pred, u32* total)
+{
+    u64 mask = __ballot(pred);
+    u32 lane = threadIdx.x & 63;
+    *total = (u32)__popcll(mask);
+    return (u32)__popcll(mask & ((1ULL << lane) - 1ULL));
+}
+
+// packed-key hashing for the group tables (any good mix; not part of results parity)
+__device__ __forceinline__ u32 pa_mix32(u64 k)
+{
+    u32 x = (u32)k ^ (u32)(k >> 32);
+    x *= 0x9E3779B1u;
+    x ^= x >> 15;
+    x *= 0x85EBCA77u;
+    x ^= x >> 13;
+    return x;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Group tables.  Keys are packed into W 64-bit words (exprgen); equality is word equality.
+// ---------------------------------------------------------------------------------------------
+#define PA_MAX_CHANNELS 32
+
+// Kernel argument block of the fused scan-filter-project-aggregate kernels (op_fused.cpp keeps the
+// host mirror `FusedArgs` in sync).
+struct PaFusedArgs {
+    const void* v[PA_MAX_CHANNELS];   // column values (FLAT) / bytes (VARWIDTH)
+    const i32* o[PA_MAX_CHANNELS];    // VARWIDTH offsets
+    const u8* nl[PA_MAX_CHANNELS];    // nulls (1 B / row) or nullptr
+    i64 n;                            // rows in this page
+    i32 vec;                          // 1: every used buffer is 16-B aligned -> 4 rows / lane / step
+    i32 pad;
+    u64* slab;                        // per-workgroup partial states of this launch
+    u64* gt_tag;                      // global group table: 0 empty | hash<<2|1 busy | hash<<2|3 ready
+    u64* gt_keys;                     // [capacity][W]
+    u64* gt_words;                    // [NW][capacity] accumulator words
+    u32 gt_mask;                      // capacity - 1
+    i32 gt_max_fill;
+    i32* gt_count;                    // groups in the table
+    i32* err;                         // first device-raised pa_status
+    u64* overflow_rows;               // rows that missed the LDS table (drives mode escalation)
+};
+
+// Wave-private LDS table lookup/insert for a one-wave workgroup.  Every active lane must call it
+// (lanes with active == false just ride along).  Returns the slot, or -1 when all C slots hold other
+// keys.  LDS operations of one wave execute in program order, so a key written in iteration j is
+// visible to every lane from iteration j+1 on; a lane that loses the claim re-reads the same slot
+// in the next iteration and never compares in the iteration of the claim.
+template <int W, int C>
+__device__ __forceinline__ int pa_lds_find(bool active, volatile u32* st, volatile u64* kw, u32 h, const u64 (&k)[W])
+{
+    bool done = !active;
+    int g = -1;
+    u32 i = h & (C - 1);
+    int probes = 0;
+    while (__ballot(!done) != 0ULL) {
+        if (!done) {
+            u32 s = st[i];
+            if (s == 0u) {
+                if (atomicCAS((u32*)&st[i], 0u, 1u) == 0u) {
+#pragma unroll
+                    for (int w = 0; w < W; w++) kw[i * W + w] = k[w];
+                    g = (int)i;
+                    done = true;
+                }
+            }
+            else {
+                bool eq = true;
+#pragma unroll
+                for (int w = 0; w < W; w++) eq = eq && (kw[i * W + w] == k[w]);
+                if (eq) {
+                    g = (int)i;
+                    done = true;
+                }
+                else {
+                    i = (i + 1) & (C - 1);
+                    if (++probes >= C) done = true;
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    return g;
+}
+
+// Global (HBM) group table upsert.  Table memory is only ever touched with agent-scope atomic
+// accesses (sc1: coherent across the 8 XCD L2s); key words are published by: sc1 stores ->
+// s_waitcnt vmcnt(0) -> sc1 tag store (MI355X_MICROARCH.md "handoff-flag", drained-sc1 form).
+// A lane that finds the slot busy with its own hash re-polls it in the next loop iteration; the
+// claiming lane finishes its publication inside the iteration of the claim, so lanes of one wave
+// cannot wait on each other.
+__device__ __forceinline__ int pa_gt_upsert_n(u64* tag, u64* keys, u32 mask, u32 h, const u64* k, const int W, i32* count,
+                                              i32 max_fill, i32* err)
+{
+    const u64 busy = ((u64)h << 2) | 1ULL, ready = ((u64)h << 2) | 3ULL;
+    u32 i = h & mask;
+    u32 probes = 0;
+    int spins = 0;
+    while (probes <= mask) {
+        u64 t = __hip_atomic_load(&tag[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (t == 0ULL) {
+            u64 old = atomicCAS(&tag[i], 0ULL, busy);
+            if (old == 0ULL) {
+                for (int w = 0; w < W; w++)
+                    __hip_atomic_store(&keys[(u64)i * W + w], k[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_store(&tag[i], ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                i32 c = atomicAdd(count, 1);
+                if (c >= max_fill) pa_raise(err, PA_DEV_ERR_RESOURCES);
+                return (int)i;
+            }
+            t = old;
+        }
+        if ((t | 2ULL) == ready) {
+            if (t == busy) {
+                if (++spins > (1 << 22)) break;  // bounded: a stuck publisher surfaces as an error
+                __builtin_amdgcn_s_sleep(1);
+                continue;
+            }
+            bool eq = true;
+            for (int w = 0; w < W; w++)
+                eq = eq && (__hip_atomic_load(&keys[(u64)i * W + w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == k[w]);
+            if (eq) return (int)i;
+        }
+        i = (i + 1) & mask;
+        probes++;
+    }
+    pa_raise(err, PA_DEV_ERR_RESOURCES);
+    return -1;
+}
+template <int W>
+__device__ __forceinline__ int pa_gt_upsert(u64* tag, u64* keys, u32 mask, u32 h, const u64 (&k)[W], i32* count,
+                                            i32 max_fill, i32* err)
+{
+    return pa_gt_upsert_n(tag, keys, mask, h, k, W, count, max_fill, err);
+}
+
+// hash of a packed key (identical in the generated kernels and in the merge / rehash kernels)
+__device__ __forceinline__ u32 pa_key_hash(const u64* k, const int W)
+{
+    u64 hk = k[0];
+    for (int i = 1; i < W; i++) hk = (hk ^ (hk >> 29)) * 0x9E3779B97F4A7C15ULL + k[i];
+    return pa_mix32(hk);
+}
+
+// accumulator word kinds (op_fused.cpp)
+#define PA_W_CNT 0
+#define PA_W_SUMF 1
+#define PA_W_SUMI 2
+
+__device__ __forceinline__ void pa_gt_add_f64(u64* words, u64 idx, double v)
+{
+    unsafeAtomicAdd((double*)&words[idx], v);  // global_atomic_add_f64
+}
+__device__ __forceinline__ void pa_gt_add_u64(u64* words, u64 idx, u64 v)
+{
+    atomicAdd((unsigned long long*)&words[idx], (unsigned long long)v);
+}
+__device__ __forceinline__ void pa_gt_add_i64_exact(u64* words, u64 idx, i64 v, i32* err)
+{
+    i64 old = (i64)atomicAdd((unsigned long long*)&words[idx], (unsigned long long)v);
+    i64 r;
+    if (__builtin_add_overflow(old, v, &r)) pa_raise(err, PA_DEV_ERR_OUT_OF_RANGE);
+}

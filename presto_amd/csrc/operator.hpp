@@ -1,0 +1,34 @@
+// operator.hpp -- the Operator protocol of the reference, as seen from behind the C ABI.
+// (core/trino-main/src/main/java/io/trino/operator/Operator.java:21-103; call order as driven by
+//  Driver.processInternal, core/trino-main/src/main/java/io/trino/operator/Driver.java:355-457)
+#pragma once
+
+#include "common.hpp"
+#include "device_page.hpp"
+
+struct pa_operator {
+    virtual ~pa_operator() = default;
+    virtual bool needs_input() = 0;
+    virtual void add_input(const pa_page* page) = 0;
+    virtual bool get_output(pa_page* out) = 0;
+    virtual void finish() = 0;
+    virtual bool is_finished() = 0;
+    virtual bool is_blocked() { return false; }
+    virtual int64_t memory_bytes() { return 0; }
+    virtual void close() {}
+    pa::KernelTimer timer;
+};
+
+namespace pa {
+
+pa_operator* make_fused_aggregation(const pa_fused_aggregation_desc* desc);
+pa_operator* make_filter_project(const pa_filter_project_desc* desc);
+pa_operator* make_hash_builder(const pa_hash_builder_desc* desc, pa_lookup_source* bridge);
+pa_operator* make_lookup_join(const pa_lookup_join_desc* desc, pa_lookup_source* bridge);
+
+// code-object source for a fused descriptor under the "no nulls, aligned" layout; used by build() to
+// pre-compile the TPC-H shapes and by the CPU-side codegen tests
+std::string fused_source_for_desc(const pa_fused_aggregation_desc* desc, int variant, std::string* entry);
+std::string filter_project_source_for_desc(const pa_filter_project_desc* desc, std::string* entry);
+
+}  // namespace pa

@@ -1,0 +1,345 @@
+// static_kernels.hip -- query-independent gfx950 kernels of the page-processing path: dictionary decode,
+// partial-state merges, group-table rehash, row hashing / partitioning, synthetic TPC-H column
+// generation.  Expression-bearing kernels are generated per query (op_fused.cpp, op_filter_project.cpp).
+#include <hip/hip_runtime.h>
+
+#include "common.hpp"
+#include "kernels/pa_device.h"
+#include "static_kernels.hpp"
+
+namespace pa {
+
+static inline int grid_for(int64_t work, int block, int max_blocks = 256 * 8)
+{
+    int64_t g = (work + block - 1) / block;
+    if (g < 1) g = 1;
+    if (g > max_blocks) g = max_blocks;
+    return (int)g;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Block.copyPositions / dictionary decode
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void k_gather(const T* __restrict__ src, const i32* __restrict__ pos, i64 n, T* __restrict__ dst)
+{
+    for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < n; i += (i64)gridDim.x * 256) dst[i] = src[pos[i]];
+}
+template <typename T>
+__global__ __launch_bounds__(256) void k_fill(T* __restrict__ dst, const T* __restrict__ one, i64 n)
+{
+    T v = *one;
+    for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < n; i += (i64)gridDim.x * 256) dst[i] = v;
+}
+
+void launch_gather_flat(const void* src, int elem_bytes, const int32_t* positions, int64_t count, void* dst, hipStream_t s)
+{
+    if (count <= 0) return;
+    int g = grid_for(count, 256);
+    switch (elem_bytes) {
+        case 8: hipLaunchKernelGGL(k_gather<u64>, g, 256, 0, s, (const u64*)src, positions, count, (u64*)dst); break;
+        case 4: hipLaunchKernelGGL(k_gather<u32>, g, 256, 0, s, (const u32*)src, positions, count, (u32*)dst); break;
+        case 1: hipLaunchKernelGGL(k_gather<u8>, g, 256, 0, s, (const u8*)src, positions, count, (u8*)dst); break;
+        default: throw Error(PA_ERR_INVALID_ARGUMENT, "gather: unsupported element width");
+    }
+    PA_HIP(hipGetLastError());
+}
+void launch_gather_nulls(const uint8_t* src, const int32_t* positions, int64_t count, uint8_t* dst, hipStream_t s)
+{
+    launch_gather_flat(src, 1, positions, count, dst, s);
+}
+void launch_fill_flat(void* dst, int elem_bytes, const void* src_one, int64_t count, hipStream_t s)
+{
+    if (count <= 0) return;
+    int g = grid_for(count, 256);
+    switch (elem_bytes) {
+        case 8: hipLaunchKernelGGL(k_fill<u64>, g, 256, 0, s, (u64*)dst, (const u64*)src_one, count); break;
+        case 4: hipLaunchKernelGGL(k_fill<u32>, g, 256, 0, s, (u32*)dst, (const u32*)src_one, count); break;
+        case 1: hipLaunchKernelGGL(k_fill<u8>, g, 256, 0, s, (u8*)dst, (const u8*)src_one, count); break;
+        default: throw Error(PA_ERR_INVALID_ARGUMENT, "fill: unsupported element width");
+    }
+    PA_HIP(hipGetLastError());
+}
+
+// ---------------------------------------------------------------------------------------------
+// merge of the per-workgroup partial states of the GLOBAL variant: one workgroup, word w handled by
+// wave-strided lanes in a fixed order => the result does not depend on scheduling.
+// state[w] (+)= sum over blocks b (ascending) of slab[b][w]
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_merge_global_slab(const u64* __restrict__ slab, int blocks, int nw,
+                                                           const i32* __restrict__ kinds, u64* __restrict__ state, i32* err)
+{
+    __shared__ u64 part[256];
+    for (int w = 0; w < nw; w++) {
+        const int kind = kinds[w];
+        // lane t accumulates blocks t, t+256, ... in ascending order
+        if (kind == PA_W_SUMF) {
+            double acc = 0.0;
+            for (int b = threadIdx.x; b < blocks; b += 256) acc = acc + __longlong_as_double((i64)slab[(u64)b * nw + w]);
+            part[threadIdx.x] = (u64)__double_as_longlong(acc);
+        }
+        else {
+            i64 acc = 0;
+            for (int b = threadIdx.x; b < blocks; b += 256) {
+                i64 v = (i64)slab[(u64)b * nw + w];
+                if (kind == PA_W_SUMI) acc = pa_add_exact(acc, v, err);
+                else acc += v;
+            }
+            part[threadIdx.x] = (u64)acc;
+        }
+        __syncthreads();
+        for (int stride = 128; stride >= 1; stride >>= 1) {
+            if ((int)threadIdx.x < stride) {
+                if (kind == PA_W_SUMF) {
+                    double a = __longlong_as_double((i64)part[threadIdx.x]) + __longlong_as_double((i64)part[threadIdx.x + stride]);
+                    part[threadIdx.x] = (u64)__double_as_longlong(a);
+                }
+                else if (kind == PA_W_SUMI) {
+                    part[threadIdx.x] = (u64)pa_add_exact((i64)part[threadIdx.x], (i64)part[threadIdx.x + stride], err);
+                }
+                else {
+                    part[threadIdx.x] += part[threadIdx.x + stride];
+                }
+            }
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+            if (kind == PA_W_SUMF) state[w] = (u64)__double_as_longlong(__longlong_as_double((i64)state[w]) + __longlong_as_double((i64)part[0]));
+            else if (kind == PA_W_SUMI) state[w] = (u64)pa_add_exact((i64)state[w], (i64)part[0], err);
+            else state[w] += part[0];
+        }
+        __syncthreads();
+    }
+}
+
+void launch_merge_global_slab(const uint64_t* slab, int blocks, int nw, const int32_t* kinds_dev, uint64_t* state, int32_t* err,
+                              hipStream_t s)
+{
+    hipLaunchKernelGGL(k_merge_global_slab, 1, 256, 0, s, (const u64*)slab, blocks, nw, kinds_dev, (u64*)state, err);
+    PA_HIP(hipGetLastError());
+}
+
+// ---------------------------------------------------------------------------------------------
+// merge of the per-wave partial tables of the LDS variant into the HBM group table.
+// One lane per (wave, slot) entry: upsert the key, then add every word atomically.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_merge_lds_slab(const u64* __restrict__ slab, i64 entries, int W, int NW,
+                                                        const i32* __restrict__ kinds, u64* tag, u64* keys, u64* words, u32 mask,
+                                                        i32 max_fill, i32* count, i32* err)
+{
+    const int stride = 1 + W + NW;
+    for (i64 e = (i64)blockIdx.x * 256 + threadIdx.x; e < entries; e += (i64)gridDim.x * 256) {
+        const u64* ent = slab + e * stride;
+        if (ent[0] == 0ULL) continue;
+        u64 k[8];
+        for (int w = 0; w < W; w++) k[w] = ent[1 + w];
+        u32 h = pa_key_hash(k, W);
+        int g = pa_gt_upsert_n(tag, keys, mask, h, k, W, count, max_fill, err);
+        if (g < 0) continue;
+        const u64 cap = (u64)mask + 1ULL;
+        for (int w = 0; w < NW; w++) {
+            u64 v = ent[1 + W + w];
+            if (kinds[w] == PA_W_SUMF) pa_gt_add_f64(words, (u64)w * cap + g, __longlong_as_double((i64)v));
+            else if (kinds[w] == PA_W_SUMI) pa_gt_add_i64_exact(words, (u64)w * cap + g, (i64)v, err);
+            else pa_gt_add_u64(words, (u64)w * cap + g, v);
+        }
+    }
+}
+
+void launch_merge_lds_slab(const uint64_t* slab, int waves, int c, int w, int nw, const int32_t* kinds_dev, uint64_t* gt_tag,
+                           uint64_t* gt_keys, uint64_t* gt_words, uint32_t gt_mask, int32_t gt_max_fill, int32_t* gt_count,
+                           int32_t* err, hipStream_t s)
+{
+    int64_t entries = (int64_t)waves * c;
+    hipLaunchKernelGGL(k_merge_lds_slab, grid_for(entries, 256), 256, 0, s, (const u64*)slab, entries, w, nw, kinds_dev, (u64*)gt_tag,
+                       (u64*)gt_keys, (u64*)gt_words, gt_mask, gt_max_fill, gt_count, err);
+    PA_HIP(hipGetLastError());
+}
+
+// re-insert every group of the old table into a larger one (GroupByHash.tryRehash counterpart)
+__global__ __launch_bounds__(256) void k_gt_rehash(const u64* __restrict__ old_tag, const u64* __restrict__ old_keys,
+                                                   const u64* __restrict__ old_words, u32 old_cap, int W, int NW, u64* tag, u64* keys,
+                                                   u64* words, u32 mask, i32 max_fill, i32* count, i32* err)
+{
+    for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < (i64)old_cap; i += (i64)gridDim.x * 256) {
+        if (old_tag[i] == 0ULL) continue;
+        u64 k[8];
+        for (int w = 0; w < W; w++) k[w] = old_keys[(u64)i * W + w];
+        u32 h = pa_key_hash(k, W);
+        int g = pa_gt_upsert_n(tag, keys, mask, h, k, W, count, max_fill, err);
+        if (g < 0) continue;
+        const u64 cap = (u64)mask + 1ULL;
+        // each old group maps to exactly one new slot, so plain stores suffice
+        for (int w = 0; w < NW; w++) words[(u64)w * cap + g] = old_words[(u64)w * old_cap + i];
+    }
+}
+
+void launch_gt_rehash(const uint64_t* old_tag, const uint64_t* old_keys, const uint64_t* old_words, uint32_t old_cap, int w, int nw,
+                      uint64_t* tag, uint64_t* keys, uint64_t* words, uint32_t mask, int32_t max_fill, int32_t* count, int32_t* err,
+                      hipStream_t s)
+{
+    hipLaunchKernelGGL(k_gt_rehash, grid_for(old_cap, 256), 256, 0, s, (const u64*)old_tag, (const u64*)old_keys, (const u64*)old_words,
+                       old_cap, w, nw, (u64*)tag, (u64*)keys, (u64*)words, mask, max_fill, count, err);
+    PA_HIP(hipGetLastError());
+}
+
+// ---------------------------------------------------------------------------------------------
+// InterpretedHashGenerator.hashPosition over typed columns (…/operator/InterpretedHashGenerator.java:62-70)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_hash_page(HashPageArgs a)
+{
+    for (i64 r = (i64)blockIdx.x * 256 + threadIdx.x; r < a.n; r += (i64)gridDim.x * 256) {
+        i64 result = 0;
+        for (int c = 0; c < a.ncols; c++) {
+            const HashCol& col = a.col[c];
+            i64 h = 0;  // NULL -> 0 (BlockTypeOperators.java:102-108)
+            if (!(col.nulls && col.nulls[r])) {
+                switch (col.type) {
+                    case PA_BIGINT: h = pa_hash_bigint(((const i64*)col.values)[r]); break;
+                    case PA_INTEGER:
+                    case PA_DATE: h = pa_hash_bigint((i64)((const i32*)col.values)[r]); break;
+                    case PA_DOUBLE: h = pa_hash_double(((const double*)col.values)[r]); break;
+                    case PA_BOOLEAN: h = (i64)pa_xxh64_long(((const u8*)col.values)[r] ? 1ULL : 0ULL); break;
+                    case PA_VARCHAR: {
+                        i32 o = col.offsets[r];
+                        h = (i64)pa_xxh64((const u8*)col.values + o, col.offsets[r + 1] - o);
+                        break;
+                    }
+                    default: break;
+                }
+            }
+            result = pa_combine_hash(result, h);
+        }
+        a.out[r] = result;
+    }
+}
+
+void launch_hash_page(const HashPageArgs& args, hipStream_t s)
+{
+    if (args.n <= 0) return;
+    hipLaunchKernelGGL(k_hash_page, grid_for(args.n, 256), 256, 0, s, args);
+    PA_HIP(hipGetLastError());
+}
+
+// LocalPartitionGenerator.getPartition (…/operator/exchange/LocalPartitionGenerator.java:45-65) /
+// HashGenerator.getPartition (…/operator/HashGenerator.java:24-35)
+__global__ __launch_bounds__(256) void k_partition_ids(const i64* __restrict__ raw_hash, i64 n, i32 partition_count, i32 local,
+                                                       i32* __restrict__ out)
+{
+    for (i64 r = (i64)blockIdx.x * 256 + threadIdx.x; r < n; r += (i64)gridDim.x * 256) {
+        u64 h = (u64)raw_hash[r];
+        i32 p;
+        if (local) {
+            u64 rev = __brevll(h);  // Long.reverse
+            p = (i32)(u32)pa_xxh64_long(rev) & (partition_count - 1);
+        }
+        else {
+            p = (i32)((i64)(h & 0x7fffffffffffffffULL) % (i64)partition_count);
+        }
+        out[r] = p;
+    }
+}
+
+void launch_partition_ids(const int64_t* raw_hash, int64_t n, int32_t partition_count, int32_t local, int32_t* out, hipStream_t s)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_partition_ids, grid_for(n, 256), 256, 0, s, (const i64*)raw_hash, (i64)n, partition_count, local, out);
+    PA_HIP(hipGetLastError());
+}
+
+// ---------------------------------------------------------------------------------------------
+// synthetic TPC-H-shaped columns: row r of a column depends only on (seed, column, r, sf)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ u64 g_mix64(u64 z)
+{
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+__device__ __forceinline__ u64 g_rnd(u64 seed, u32 stream, u64 row)
+{
+    return g_mix64(seed + (u64)stream * 0xD1342543DE82EF95ULL + (row + 1) * 0x9E3779B97F4A7C15ULL);
+}
+enum { S_QTY = 1, S_PRICE = 2, S_DISC = 3, S_TAX = 4, S_SHIP = 5, S_RECEIPT = 6, S_FLAG = 7, S_CUST = 8, S_ODATE = 9, S_SEG = 10 };
+
+__device__ __forceinline__ i64 g_sparse_orderkey(i64 o) { return (o >> 3) * 32 + (o & 7) + 1; }
+__device__ __forceinline__ i32 g_shipdate(u64 seed, i64 r) { return 8036 + (i32)(g_rnd(seed, S_SHIP, (u64)r) % 2526ULL); }
+__device__ __forceinline__ i32 g_segment(u64 seed, i64 r)
+{
+    u64 u = g_rnd(seed, S_SEG, (u64)(r / 5));
+    i32 start = (i32)(u % 5ULL);
+    i32 stride = 1 + (i32)((u >> 8) % 4ULL);
+    return (start + stride * (i32)(r % 5)) % 5;
+}
+__constant__ char g_segments[5][11] = {"AUTOMOBILE", "BUILDING", "FURNITURE", "HOUSEHOLD", "MACHINERY"};
+__constant__ i32 g_segment_len[5] = {10, 8, 9, 9, 9};
+__constant__ signed char g_order_in_block[28] = {0, 1, 1, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 4, 5, 5, 5, 5, 5, 5, 6, 6, 6, 6, 6, 6, 6};
+
+__global__ __launch_bounds__(256) void k_tpch(i32 column, i64 orders, u64 customers, i64 first_row, i64 n, u64 seed, void* values,
+                                              i32* offsets)
+{
+    for (i64 k = (i64)blockIdx.x * 256 + threadIdx.x; k < n; k += (i64)gridDim.x * 256) {
+        const i64 r = first_row + k;
+        switch (column) {
+            case PA_L_ORDERKEY: {
+                i64 o = (r / 28) * 7 + g_order_in_block[r % 28];
+                if (o >= orders) o = orders - 1;
+                ((i64*)values)[k] = g_sparse_orderkey(o);
+                break;
+            }
+            case PA_L_QUANTITY: ((double*)values)[k] = (double)(1 + g_rnd(seed, S_QTY, (u64)r) % 50ULL); break;
+            case PA_L_EXTENDEDPRICE: ((double*)values)[k] = (double)(90100ULL + g_rnd(seed, S_PRICE, (u64)r) % 10404851ULL) / 100.0; break;
+            case PA_L_DISCOUNT: ((double*)values)[k] = (double)(g_rnd(seed, S_DISC, (u64)r) % 11ULL) / 100.0; break;
+            case PA_L_TAX: ((double*)values)[k] = (double)(g_rnd(seed, S_TAX, (u64)r) % 9ULL) / 100.0; break;
+            case PA_L_SHIPDATE: ((i32*)values)[k] = g_shipdate(seed, r); break;
+            case PA_L_RETURNFLAG: {
+                i32 receipt = g_shipdate(seed, r) + 1 + (i32)(g_rnd(seed, S_RECEIPT, (u64)r) % 30ULL);
+                char f = 'N';
+                if (receipt <= 9298) f = (g_rnd(seed, S_FLAG, (u64)r) & 1ULL) ? 'R' : 'A';
+                ((u8*)values)[k] = (u8)f;
+                offsets[k] = (i32)k;
+                if (k == n - 1) offsets[n] = (i32)n;
+                break;
+            }
+            case PA_L_LINESTATUS:
+                ((u8*)values)[k] = (u8)(g_shipdate(seed, r) > 9298 ? 'O' : 'F');
+                offsets[k] = (i32)k;
+                if (k == n - 1) offsets[n] = (i32)n;
+                break;
+            case PA_O_ORDERKEY: ((i64*)values)[k] = g_sparse_orderkey(r); break;
+            case PA_O_CUSTKEY: {
+                u64 usable = customers - customers / 3ULL;
+                u64 u = g_rnd(seed, S_CUST, (u64)r) % usable;
+                ((i64*)values)[k] = (i64)((u / 2ULL) * 3ULL + (u % 2ULL) + 1ULL);
+                break;
+            }
+            case PA_O_ORDERDATE: ((i32*)values)[k] = 8035 + (i32)(g_rnd(seed, S_ODATE, (u64)r) % 2406ULL); break;
+            case PA_O_SHIPPRIORITY: ((i32*)values)[k] = 0; break;
+            case PA_C_CUSTKEY: ((i64*)values)[k] = r + 1; break;
+            case PA_C_MKTSEGMENT: {
+                i64 off = (r / 5 - first_row / 5) * 45;
+                for (i64 q = (r / 5) * 5; q < r; q++) off += g_segment_len[g_segment(seed, q)];
+                i32 sgm = g_segment(seed, r);
+                i32 len = g_segment_len[sgm];
+                for (i32 b = 0; b < len; b++) ((u8*)values)[off + b] = (u8)g_segments[sgm][b];
+                offsets[k] = (i32)off;
+                if (k == n - 1) offsets[n] = (i32)(off + len);
+                break;
+            }
+            default: break;
+        }
+    }
+}
+
+void launch_tpch(int32_t column, double sf, int64_t first_row, int64_t n, uint64_t seed, void* values, int32_t* offsets, hipStream_t s)
+{
+    if (n <= 0) return;
+    PA_REQUIRE(column >= PA_L_ORDERKEY && column <= PA_C_MKTSEGMENT, PA_ERR_INVALID_ARGUMENT, "unknown tpch column");
+    PA_REQUIRE(column != PA_C_MKTSEGMENT || first_row % 5 == 0, PA_ERR_INVALID_ARGUMENT, "mktsegment first_row must be a multiple of 5");
+    int64_t orders = (int64_t)(1500000.0 * sf);
+    uint64_t customers = (uint64_t)(150000.0 * sf);
+    hipLaunchKernelGGL(k_tpch, grid_for(n, 256), 256, 0, s, column, (i64)orders, (u64)customers, (i64)first_row, (i64)n, (u64)seed, values, offsets);
+    PA_HIP(hipGetLastError());
+}
+
+}  // namespace pa

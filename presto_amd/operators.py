@@ -1,0 +1,346 @@
+"""Host-side mirror of the reference's Operator / OperatorFactory interfaces over the C ABI.
+
+Mirrors io.trino.operator.Operator (core/trino-main/src/main/java/io/trino/operator/Operator.java:21-103)
+with the same method names and call protocol (needsInput / addInput / getOutput / finish / isFinished /
+close), so that the parity tests read like the reference's operator tests
+(core/trino-main/src/test/java/io/trino/operator/OperatorAssertion.java:62-138).  Each class is what the
+Java `GpuOperator implements Operator` of INTEGRATION.md would be: a handle plus one native call per method.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import abi
+from ._lib import DeviceAllocation, check, lib
+from .expr import serialize, serialize_many
+from .page import Block, DeviceBuffer, Page, page_from_c
+
+
+class Operator:
+    """Operator.java:21-103"""
+
+    def __init__(self, handle, keep):
+        self._h = handle
+        self._keep = keep
+
+    def needsInput(self):
+        return bool(check(lib().pa_op_needs_input(self._h)))
+
+    def addInput(self, page):
+        cpage, keep = page.to_c()
+        check(lib().pa_op_add_input(self._h, C.byref(cpage)))
+        self._last_input = keep  # Pages may be retained by the operator until its work is done
+
+    def getOutput(self):
+        """Returns a host Page (copy) for PA_MEM_HOST operators, a device Page view otherwise, or None."""
+        out = abi.pa_page()
+        if not check(lib().pa_op_get_output(self._h, C.byref(out))):
+            return None
+        if out.mem == abi.MEM_HOST:
+            return page_from_c(out)
+        return device_page_from_c(out, owner=self)
+
+    def finish(self):
+        check(lib().pa_op_finish(self._h))
+
+    def isFinished(self):
+        return bool(check(lib().pa_op_is_finished(self._h)))
+
+    def isBlocked(self):
+        return bool(check(lib().pa_op_is_blocked(self._h)))
+
+    def memoryBytes(self):
+        return lib().pa_op_memory_bytes(self._h)
+
+    def kernelTime(self):
+        """(total ms, launches) of the operator's dominant kernel, from HIP events on its stream."""
+        ms = C.c_double()
+        n = C.c_int64()
+        check(lib().pa_op_kernel_time(self._h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def close(self):
+        if self._h:
+            lib().pa_op_close(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def device_page_from_c(cpage, owner=None):
+    blocks = []
+    n = cpage.position_count
+    for i in range(cpage.channel_count):
+        col = cpage.columns[i]
+        w = abi.TYPE_WIDTH[col.type]
+        nulls = DeviceBuffer(col.nulls, n, owner) if col.nulls else None
+        if col.encoding == abi.VARWIDTH:
+            blocks.append(Block(col.type, abi.VARWIDTH, n, values=DeviceBuffer(col.values, 0, owner),
+                                offsets=DeviceBuffer(col.offsets, 4 * (n + 1), owner), nulls=nulls))
+        else:
+            blocks.append(Block(col.type, abi.FLAT, n, values=DeviceBuffer(col.values, w * n, owner), nulls=nulls))
+    return Page(blocks, n, abi.MEM_DEVICE)
+
+
+# ---- descriptors -----------------------------------------------------------------------------------
+def _filter_project_desc(input_types, filter_expr, projections, output_mem, stream, type_params=None):
+    keep = []
+    d = abi.pa_filter_project_desc()
+    types = abi.int32_array(input_types)
+    d.input_channel_count = len(input_types)
+    d.input_types = C.cast(types, C.POINTER(C.c_int32))
+    keep.append(types)
+    if type_params is not None:
+        tp = abi.int32_array(type_params)
+        d.input_type_params = C.cast(tp, C.POINTER(C.c_int32))
+        keep.append(tp)
+    if filter_expr is not None:
+        f, kf = serialize(filter_expr)
+        keep += [f, kf]
+        d.filter = C.pointer(f)
+    arr, kp = serialize_many(projections)
+    keep += [arr, kp]
+    d.projection_count = len(projections)
+    d.projections = C.cast(arr, C.POINTER(abi.pa_expr))
+    d.output_mem = output_mem
+    d.stream = stream
+    return d, keep
+
+
+def _aggregates(aggregates):
+    arr = (abi.pa_aggregate * max(len(aggregates), 1))()
+    for i, a in enumerate(aggregates):
+        arr[i].fn = a[0]
+        arr[i].input_channel = a[1]
+        arr[i].input_type = a[2] if a[2] is not None else 0
+        arr[i].mask_channel = a[3] if len(a) > 3 else -1
+    return arr
+
+
+def _hash_agg_desc(input_types, group_by_channels, aggregates, hash_channel, expected_groups, output_mem, stream,
+                   type_params=None):
+    keep = []
+    d = abi.pa_hash_aggregation_desc()
+    types = abi.int32_array(input_types)
+    gb = abi.int32_array(group_by_channels)
+    aggs = _aggregates(aggregates)
+    d.input_channel_count = len(input_types)
+    d.input_types = C.cast(types, C.POINTER(C.c_int32))
+    if type_params is not None:
+        tp = abi.int32_array(type_params)
+        d.input_type_params = C.cast(tp, C.POINTER(C.c_int32))
+        keep.append(tp)
+    d.group_by_count = len(group_by_channels)
+    d.group_by_channels = C.cast(gb, C.POINTER(C.c_int32))
+    d.hash_channel = hash_channel
+    d.step = abi.STEP_SINGLE
+    d.aggregate_count = len(aggregates)
+    d.aggregates = C.cast(aggs, C.POINTER(abi.pa_aggregate))
+    d.expected_groups = expected_groups
+    d.output_mem = output_mem
+    d.stream = stream
+    keep += [types, gb, aggs]
+    return d, keep
+
+
+def fused_aggregation_desc(input_types, filter_expr, projections, group_by_channels, aggregates, hash_channel=-1,
+                           expected_groups=10000, output_mem=abi.MEM_HOST, stream=None, type_params=None):
+    """aggregates: list of (fn, projection index, input type[, mask projection index])."""
+    fp, k1 = _filter_project_desc(input_types, filter_expr, projections, output_mem, stream, type_params)
+    ag, k2 = _hash_agg_desc([p.type for p in projections], group_by_channels, aggregates, hash_channel, expected_groups,
+                            output_mem, stream)
+    d = abi.pa_fused_aggregation_desc()
+    d.filter_project = fp
+    d.aggregation = ag
+    return d, [k1, k2, fp, ag]
+
+
+# ---- factories (OperatorFactory.createOperator) ----------------------------------------------------------
+def FilterAndProjectOperator(input_types, filter_expr, projections, output_mem=abi.MEM_HOST, stream=None,
+                             type_params=None):
+    """FilterAndProjectOperator.createOperatorFactory (…/operator/FilterAndProjectOperator.java:73-178) with
+    PageProcessor(Optional<PageFilter>, List<PageProjection>)."""
+    d, keep = _filter_project_desc(input_types, filter_expr, projections, output_mem, stream, type_params)
+    h = C.c_void_p()
+    check(lib().pa_filter_project_create(C.byref(d), C.byref(h)))
+    return Operator(h, keep)
+
+
+def AggregationOperator(input_types, aggregates, output_mem=abi.MEM_HOST, stream=None):
+    """AggregationOperator.AggregationOperatorFactory (…/operator/AggregationOperator.java:40-95), Step.SINGLE."""
+    d = abi.pa_aggregation_desc()
+    types = abi.int32_array(input_types)
+    aggs = _aggregates(aggregates)
+    d.input_channel_count = len(input_types)
+    d.input_types = C.cast(types, C.POINTER(C.c_int32))
+    d.aggregate_count = len(aggregates)
+    d.aggregates = C.cast(aggs, C.POINTER(abi.pa_aggregate))
+    d.output_mem = output_mem
+    d.stream = stream
+    h = C.c_void_p()
+    check(lib().pa_aggregation_create(C.byref(d), C.byref(h)))
+    return Operator(h, [types, aggs])
+
+
+def HashAggregationOperator(input_types, group_by_channels, aggregates, hash_channel=-1, expected_groups=10000,
+                            output_mem=abi.MEM_HOST, stream=None, type_params=None):
+    """HashAggregationOperatorFactory (…/operator/HashAggregationOperator.java:120-202), Step.SINGLE."""
+    d, keep = _hash_agg_desc(input_types, group_by_channels, aggregates, hash_channel, expected_groups, output_mem, stream,
+                             type_params)
+    h = C.c_void_p()
+    check(lib().pa_hash_aggregation_create(C.byref(d), C.byref(h)))
+    return Operator(h, keep)
+
+
+def FusedAggregationOperator(input_types, filter_expr, projections, group_by_channels, aggregates, **kw):
+    """[Scan]FilterAndProject -> (Hash)Aggregation collapsed into one device pass."""
+    d, keep = fused_aggregation_desc(input_types, filter_expr, projections, group_by_channels, aggregates, **kw)
+    h = C.c_void_p()
+    check(lib().pa_fused_aggregation_create(C.byref(d), C.byref(h)))
+    return Operator(h, keep)
+
+
+class LookupSourceFactory:
+    """JoinBridge between a HashBuilderOperator and its LookupJoinOperators
+    (…/operator/join/PartitionedLookupSourceFactory.java, JoinBridgeManager.java)."""
+
+    def __init__(self):
+        h = C.c_void_p()
+        check(lib().pa_lookup_source_create(C.byref(h)))
+        self._h = h
+
+    def destroy(self):
+        if self._h:
+            lib().pa_lookup_source_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+
+def HashBuilderOperator(bridge, input_types, join_channels, output_channels, hash_channel=-1, expected_positions=0,
+                        stream=None):
+    """HashBuilderOperator.HashBuilderOperatorFactory (…/operator/join/HashBuilderOperator.java:56-180)."""
+    d = abi.pa_hash_builder_desc()
+    types = abi.int32_array(input_types)
+    jc = abi.int32_array(join_channels)
+    oc = abi.int32_array(output_channels)
+    d.input_channel_count = len(input_types)
+    d.input_types = C.cast(types, C.POINTER(C.c_int32))
+    d.join_channel_count = len(join_channels)
+    d.join_channels = C.cast(jc, C.POINTER(C.c_int32))
+    d.hash_channel = hash_channel
+    d.output_channel_count = len(output_channels)
+    d.output_channels = C.cast(oc, C.POINTER(C.c_int32))
+    d.expected_positions = expected_positions
+    d.stream = stream
+    h = C.c_void_p()
+    check(lib().pa_hash_builder_create(C.byref(d), bridge._h, C.byref(h)))
+    return Operator(h, [types, jc, oc, bridge])
+
+
+def LookupJoinOperator(bridge, probe_types, probe_join_channels, probe_output_channels, probe_hash_channel=-1,
+                       output_mem=abi.MEM_HOST, stream=None):
+    """OperatorFactories.innerJoin (…/operator/OperatorFactories.java:27-45) -> LookupJoinOperator."""
+    d = abi.pa_lookup_join_desc()
+    types = abi.int32_array(probe_types)
+    jc = abi.int32_array(probe_join_channels)
+    oc = abi.int32_array(probe_output_channels)
+    d.probe_channel_count = len(probe_types)
+    d.probe_types = C.cast(types, C.POINTER(C.c_int32))
+    d.join_channel_count = len(probe_join_channels)
+    d.probe_join_channels = C.cast(jc, C.POINTER(C.c_int32))
+    d.probe_hash_channel = probe_hash_channel
+    d.probe_output_channel_count = len(probe_output_channels)
+    d.probe_output_channels = C.cast(oc, C.POINTER(C.c_int32))
+    d.output_mem = output_mem
+    d.stream = stream
+    h = C.c_void_p()
+    check(lib().pa_lookup_join_create(C.byref(d), bridge._h, C.byref(h)))
+    return Operator(h, [types, jc, oc, bridge])
+
+
+# ---- driver loop ---------------------------------------------------------------------------------------
+def to_pages(operator, input_pages):
+    """OperatorAssertion.toPages (core/trino-main/src/test/java/io/trino/operator/OperatorAssertion.java:62-138):
+    feed while needsInput, drain getOutput, then finish and drain until isFinished."""
+    out = []
+    it = iter(input_pages)
+    pending = next(it, None)
+    for _ in range(1 << 20):
+        progressed = False
+        if pending is not None and operator.needsInput():
+            if pending.position_count > 0:  # Driver.java:391 never hands over empty pages
+                operator.addInput(pending)
+            pending = next(it, None)
+            progressed = True
+        page = operator.getOutput()
+        if page is not None:
+            if page.position_count > 0:
+                out.append(page)
+            progressed = True
+        if pending is None and not progressed:
+            break
+    operator.finish()
+    for _ in range(1 << 20):
+        if operator.isFinished():
+            break
+        page = operator.getOutput()
+        if page is not None and page.position_count > 0:
+            out.append(page)
+    assert operator.isFinished(), "operator did not finish"
+    return out
+
+
+# ---- device pages without torch (JNI-style hosts, tests) -----------------------------------------------
+def upload_page(page):
+    """Copies a host Page into HBM through the C ABI; returns a PA_MEM_DEVICE Page."""
+    blocks = []
+
+    def up(arr):
+        if arr is None:
+            return None
+        arr = np.ascontiguousarray(arr)
+        alloc = DeviceAllocation(max(arr.nbytes, 16))
+        check(lib().pa_memcpy_h2d(alloc.ptr, arr.ctypes.data, arr.nbytes, None))
+        return DeviceBuffer(alloc.ptr, arr.nbytes, alloc)
+
+    for b in page.blocks:
+        if b.encoding not in (abi.FLAT, abi.VARWIDTH):
+            raise NotImplementedError("upload of encoded blocks")
+        blocks.append(Block(b.type, b.encoding, b.position_count, values=up(b.values), offsets=up(b.offsets),
+                            nulls=up(b.nulls)))
+    return Page(blocks, page.position_count, abi.MEM_DEVICE)
+
+
+def download(buf, dtype, count):
+    """DeviceBuffer -> numpy array."""
+    out = np.zeros(count, dtype=dtype)
+    if count:
+        check(lib().pa_memcpy_d2h(out.ctypes.data, buf.ptr, out.nbytes, None))
+    return out
+
+
+def download_page(page):
+    """PA_MEM_DEVICE Page (flat / varwidth blocks) -> host Page."""
+    n = page.position_count
+    blocks = []
+    for b in page.blocks:
+        nulls = download(b.nulls, np.uint8, n) if b.nulls is not None else None
+        if b.encoding == abi.VARWIDTH:
+            off = download(b.offsets, np.int32, n + 1)
+            total = int(off[n]) if n else 0
+            vals = download(b.values, np.uint8, total) if total else np.zeros(1, np.uint8)
+            blocks.append(Block(b.type, abi.VARWIDTH, n, values=vals, offsets=off, nulls=nulls))
+        else:
+            dt = {abi.BIGINT: np.int64, abi.INTEGER: np.int32, abi.DATE: np.int32, abi.DOUBLE: np.float64,
+                  abi.BOOLEAN: np.uint8}[b.type]
+            blocks.append(Block(b.type, abi.FLAT, n, values=download(b.values, dt, n), nulls=nulls))
+    return Page(blocks, n, abi.MEM_HOST)

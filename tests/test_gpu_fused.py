@@ -1,0 +1,180 @@
+"""GPU parity of the fused scan-filter-project-aggregate operator (Q6 / Q1 shapes) against the oracle.
+
+DOUBLE tolerance: the reference adds f64 values strictly left to right (DoubleSumAggregation.java:33-38);
+the device adds per lane / wave / workgroup partials, so sums agree to rounding only.  Stated tolerance
+(BASELINE.md section 3): |gpu - cpu| <= 1e-9 * max(|gpu|, |cpu|) against the sequential CPU sum -- whose own
+rounding error grows with the row count -- and, tighter, |gpu - exact| <= 1e-12 * |exact| against the correctly
+rounded sum (math.fsum) of the same projected values.  The reference's own tests compare 5 significant digits.
+Counts, group keys and row selection are bit-exact.
+"""
+import math
+
+import numpy as np
+import pytest
+
+from presto_amd import abi, tpch
+from presto_amd.expr import and_, constant, field
+from presto_amd.operators import (AggregationOperator, FusedAggregationOperator, HashAggregationOperator, download_page,
+                                  to_pages, upload_page)
+from presto_amd.page import Block, Page, sequence_page
+from tests.util import rows_equal_ignore_order
+
+pytestmark = pytest.mark.gpu
+REL = 1e-9
+REL_EXACT = 1e-12
+
+
+def host_lineitem(oracle, columns, sf, first, n):
+    blocks = []
+    for col in columns:
+        v, o = oracle.tpch_column(col, sf, first, n)
+        t = abi.TPCH_COLUMN_TYPE[col]
+        blocks.append(Block.varwidth(v, o) if t == abi.VARCHAR else Block.flat(t, v))
+    return Page(blocks, n)
+
+
+@pytest.mark.parametrize("column", list(range(14)))
+def test_tpch_generator_matches_oracle(gpu, oracle, column):
+    n, first = 10007 if column != abi.C_MKTSEGMENT else 10005, 12345
+    dev = tpch.DeviceColumns([column], 0.05, first + n)
+    page = download_page(dev.page(first, n))
+    v, o = oracle.tpch_column(column, 0.05, first, n)
+    b = page.blocks[0]
+    if o is None:
+        assert np.array_equal(b.values.view(np.uint8), v.view(np.uint8))
+    else:
+        # device offsets are relative to row 0 of the generated table, oracle's to `first`
+        base = int(b.offsets[0])
+        assert np.array_equal(b.offsets - base, o)
+        assert bytes(b.values[base:base + int(o[-1])]) == bytes(v[:int(o[-1])])
+
+
+def q6_operator(**kw):
+    aggs = tpch.Q6_AGGREGATES + [(abi.AGG_COUNT_STAR, -1, None)]
+    return FusedAggregationOperator(tpch.Q6_TYPES, tpch.q6_filter(), tpch.q6_projections(), [], aggs, **kw)
+
+
+@pytest.mark.parametrize("n", [1, 3, 4, 5, 1000, 250003])
+def test_q6_fused_matches_oracle(gpu, oracle, n):
+    sf = 0.1
+    host = host_lineitem(oracle, tpch.Q6_COLUMNS, sf, 0, n)
+    ref_sum, ref_count = oracle.q6(*(b.values for b in host.blocks))
+    dev = tpch.DeviceColumns(tpch.Q6_COLUMNS, sf, n)
+    op = q6_operator()
+    out = to_pages(op, list(dev.pages(100000)))
+    assert len(out) == 1
+    (revenue, count), = out[0].to_rows()
+    assert count == ref_count
+    if ref_count == 0:
+        assert revenue is None  # DoubleSumAggregation.output: NULL when no input row
+    else:
+        assert abs(revenue - ref_sum) <= REL * abs(ref_sum)
+    # and through the generic oracle operators (PageProcessor -> AggregationOperator)
+    projected = oracle.filter_project(host, tpch.q6_filter(), tpch.q6_projections())
+    agg = oracle.HashAggregation([abi.DOUBLE], [], [(abi.AGG_SUM, 0, abi.DOUBLE), (abi.AGG_COUNT_STAR, -1, None)])
+    if projected is not None:
+        agg.add_page(projected)
+    (osum, ocount), = agg.build_result().to_rows()
+    assert ocount == ref_count and (osum is None) == (ref_count == 0)
+    if ref_count:
+        assert osum == ref_sum  # the two oracle paths add in the same order: bit-exact
+        exact = math.fsum(projected.blocks[0].values.tolist())
+        assert abs(revenue - exact) <= REL_EXACT * abs(exact)
+    op.close()
+
+
+def test_q6_host_pages_with_nulls(gpu, oracle):
+    rng = np.random.default_rng(7)
+    n = 40001
+    host = host_lineitem(oracle, tpch.Q6_COLUMNS, 0.1, 0, n)
+    blocks = []
+    for b in host.blocks:
+        nulls = (rng.random(n) < 0.1).astype(np.uint8)
+        blocks.append(Block(b.type, abi.FLAT, n, values=b.values, nulls=nulls))
+    host = Page(blocks, n)
+    op = q6_operator()
+    pages = [host.get_region(0, 12345), host.get_region(12345, n - 12345)]  # second region is unaligned
+    out = to_pages(op, pages)
+    (revenue, count), = out[0].to_rows()
+    projected = oracle.filter_project(host, tpch.q6_filter(), tpch.q6_projections())
+    agg = oracle.HashAggregation([abi.DOUBLE], [], [(abi.AGG_SUM, 0, abi.DOUBLE), (abi.AGG_COUNT_STAR, -1, None)])
+    agg.add_page(projected)
+    (osum, ocount), = agg.build_result().to_rows()
+    assert count == ocount
+    assert abs(revenue - osum) <= REL * abs(osum)
+
+
+def q1_reference(oracle, host):
+    projected = oracle.filter_project(host, tpch.q1_filter(), tpch.q1_projections())
+    agg = oracle.HashAggregation([p.type for p in tpch.q1_projections()], tpch.Q1_GROUP_BY, tpch.Q1_AGGREGATES)
+    agg.add_page(projected)
+    return agg.build_result().to_rows()
+
+
+@pytest.mark.parametrize("n", [5, 1000, 300001])
+def test_q1_fused_matches_oracle(gpu, oracle, n):
+    sf = 0.1
+    host = host_lineitem(oracle, tpch.Q1_COLUMNS, sf, 0, n)
+    expected = q1_reference(oracle, host)
+    dev = tpch.DeviceColumns(tpch.Q1_COLUMNS, sf, n)
+    op = FusedAggregationOperator(tpch.Q1_TYPES, tpch.q1_filter(), tpch.q1_projections(), tpch.Q1_GROUP_BY, tpch.Q1_AGGREGATES,
+                                  type_params=tpch.Q1_TYPE_PARAMS)
+    out = to_pages(op, list(dev.pages(65536)))
+    rows = [r for p in out for r in p.to_rows()]
+    rows_equal_ignore_order(rows, expected, rel=REL)
+    # against correctly rounded per-group sums of the projected values
+    projected = oracle.filter_project(host, tpch.q1_filter(), tpch.q1_projections())
+    cols = [b.to_pylist() if b.type == abi.VARCHAR else b.values for b in projected.blocks]
+    for row in rows:
+        sel = np.array([a == row[0] and b == row[1] for a, b in zip(cols[0], cols[1])])
+        assert int(sel.sum()) == row[9]
+        for out_col, src in ((2, 2), (3, 3), (4, 4), (5, 5)):
+            exact = math.fsum(cols[src][sel].tolist())
+            assert abs(row[out_col] - exact) <= REL_EXACT * abs(exact)
+        for out_col, src in ((6, 2), (7, 3), (8, 6)):
+            exact = math.fsum(cols[src][sel].tolist()) / row[9]
+            assert abs(row[out_col] - exact) <= REL_EXACT * abs(exact)
+    op.close()
+
+
+def test_q1_without_type_params_uses_two_word_keys(gpu, oracle):
+    n = 50000
+    host = host_lineitem(oracle, tpch.Q1_COLUMNS, 0.1, 0, n)
+    expected = q1_reference(oracle, host)
+    op = FusedAggregationOperator(tpch.Q1_TYPES, tpch.q1_filter(), tpch.q1_projections(), tpch.Q1_GROUP_BY, tpch.Q1_AGGREGATES)
+    rows = [r for p in to_pages(op, [host]) for r in p.to_rows()]
+    rows_equal_ignore_order(rows, expected, rel=REL)
+
+
+def test_hash_aggregation_many_groups_escalates_to_hbm_table(gpu, oracle):
+    """TestHashAggregationOperator.testHashAggregation shape (…/TestHashAggregationOperator.java:160-219):
+    3 pages x 40 000 rows, BIGINT key -> count 3, sum 3i, avg i per key."""
+    pages = [sequence_page(40000, [(abi.BIGINT, 0), (abi.BIGINT, 0)]) for _ in range(3)]
+    aggs = [(abi.AGG_COUNT_STAR, -1, None), (abi.AGG_SUM, 1, abi.BIGINT), (abi.AGG_AVG, 1, abi.BIGINT)]
+    op = HashAggregationOperator([abi.BIGINT, abi.BIGINT], [0], aggs, expected_groups=100000)
+    rows = [r for p in to_pages(op, pages) for r in p.to_rows()]
+    assert len(rows) == 40000
+    assert sorted(rows) == [(i, 3, 3 * i, float(i)) for i in range(40000)]
+    ref = oracle.HashAggregation([abi.BIGINT, abi.BIGINT], [0], aggs, expected_groups=100000)
+    for p in pages:
+        ref.add_page(p)
+    rows_equal_ignore_order(rows, ref.build_result().to_rows(), rel=0.0)
+
+
+def test_aggregation_operator_kat(gpu, oracle):
+    """TestAggregationOperator.testAggregation subset (…/TestAggregationOperator.java:119-156): 100-row
+    sequence page -> count 100, sum(bigint) 4950, avg 49.5, sum(double @500) 54950.0."""
+    page = sequence_page(100, [(abi.BIGINT, 0), (abi.DOUBLE, 500)])
+    aggs = [(abi.AGG_COUNT_STAR, -1, None), (abi.AGG_SUM, 0, abi.BIGINT), (abi.AGG_AVG, 0, abi.BIGINT), (abi.AGG_SUM, 1, abi.DOUBLE)]
+    op = AggregationOperator([abi.BIGINT, abi.DOUBLE], aggs)
+    out = to_pages(op, [page])
+    assert out[0].to_rows() == [(100, 4950, 49.5, 54950.0)]
+
+
+def test_bigint_sum_overflow_raises(gpu):
+    from presto_amd._lib import PrestoAmdError
+    page = Page([Block.bigint([2 ** 62, 2 ** 62, 5])])
+    op = AggregationOperator([abi.BIGINT], [(abi.AGG_SUM, 0, abi.BIGINT)])
+    with pytest.raises(PrestoAmdError) as e:
+        to_pages(op, [page])
+    assert e.value.status == abi.ERR_NUMERIC_VALUE_OUT_OF_RANGE
