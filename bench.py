@@ -151,8 +151,8 @@ def main():
         op.finish()
         out = op.getOutput()
         results[name] = out.to_rows()
+        ms, n = op.kernelTime()  # also during warm-up: the first event query of a process pays a one-off cost
         if timed:
-            ms, n = op.kernelTime()
             ktime[name][0] += ms
             ktime[name][1] += n
         op.close()
@@ -163,14 +163,25 @@ def main():
 
     for _ in range(args.warmup):
         step(False)
+    # a full collection over torch's import graph takes tens of ms: keep the cyclic GC out of the timed region
+    import gc
+    gc.collect()
+    gc.freeze()
+    gc.disable()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    step_times = []
     for _ in range(args.steps):
+        ts0 = time.perf_counter()
         step(True)
+        step_times.append(time.perf_counter() - ts0)
+    te = time.perf_counter()
     torch.cuda.synchronize()
+    if os.environ.get("BENCH_DEBUG"):
+        print("step ms:", ["%.2f" % (x * 1e3) for x in step_times], "final sync ms: %.2f" % ((time.perf_counter() - te) * 1e3), file=sys.stderr)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()

@@ -52,6 +52,14 @@ inline int type_width(int32_t t)
     }
 }
 
+// size-class caches (pool.cpp)
+void* pool_device_alloc(size_t bytes, size_t* granted);
+void pool_device_free(void* ptr, size_t granted);
+void* pool_pinned_alloc(size_t bytes, size_t* granted);
+void pool_pinned_free(void* ptr, size_t granted);
+hipStream_t pool_stream_acquire();
+void pool_stream_release(hipStream_t s);
+
 // Growable HBM allocation (never shrinks; reused across pages).
 class DevBuf {
 public:
@@ -69,31 +77,13 @@ public:
     {
         if (bytes > cap_) {
             release();
-            size_t want = bytes < 256 ? 256 : bytes;
-            PA_HIP(hipMalloc(&p_, want));
-            cap_ = want;
+            p_ = pool_device_alloc(bytes, &cap_);
         }
-        return p_;
-    }
-    // grow keeping contents (stream-ordered copy)
-    void* grow(size_t bytes, hipStream_t s)
-    {
-        if (bytes <= cap_) return p_;
-        void* np = nullptr;
-        size_t want = bytes < 2 * cap_ ? 2 * cap_ : bytes;
-        PA_HIP(hipMalloc(&np, want));
-        if (p_ && cap_) {
-            PA_HIP(hipMemcpyAsync(np, p_, cap_, hipMemcpyDeviceToDevice, s));
-            PA_HIP(hipStreamSynchronize(s));
-            (void)hipFree(p_);
-        }
-        p_ = np;
-        cap_ = want;
         return p_;
     }
     void release()
     {
-        if (p_) (void)hipFree(p_);
+        if (p_) pool_device_free(p_, cap_);
         p_ = nullptr;
         cap_ = 0;
     }
@@ -123,15 +113,13 @@ public:
     {
         if (bytes > cap_) {
             release();
-            size_t want = bytes < 256 ? 256 : bytes;
-            PA_HIP(hipHostMalloc(&p_, want, hipHostMallocDefault));
-            cap_ = want;
+            p_ = pool_pinned_alloc(bytes, &cap_);
         }
         return p_;
     }
     void release()
     {
-        if (p_) (void)hipHostFree(p_);
+        if (p_) pool_pinned_free(p_, cap_);
         p_ = nullptr;
         cap_ = 0;
     }
@@ -154,7 +142,7 @@ public:
             owned_ = false;
         }
         else {
-            PA_HIP(hipStreamCreateWithFlags(&s_, hipStreamNonBlocking));
+            s_ = pool_stream_acquire();
             owned_ = true;
         }
     }
@@ -162,7 +150,7 @@ public:
     Stream& operator=(const Stream&) = delete;
     ~Stream()
     {
-        if (owned_ && s_) (void)hipStreamDestroy(s_);
+        if (owned_ && s_) pool_stream_release(s_);
     }
     hipStream_t get() const { return s_; }
     void sync() const { PA_HIP(hipStreamSynchronize(s_)); }

@@ -127,6 +127,12 @@ void publish_output(std::vector<OutColumn>& cols, int32_t n, int32_t mem, hipStr
             p.nulls = dn;
             continue;
         }
+        if (o.host_ready) {
+            p.values = o.h_values.ptr();
+            p.offsets = o.varwidth ? o.h_offsets.as<int32_t>() : nullptr;
+            p.nulls = o.has_nulls ? o.h_nulls.as<uint8_t>() : nullptr;
+            continue;
+        }
         if (o.varwidth) {
             int32_t* ho = static_cast<int32_t*>(o.h_offsets.ensure((size_t)(n + 1) * 4));
             PA_HIP(hipMemcpyAsync(ho, doff, (size_t)(n + 1) * 4, hipMemcpyDeviceToHost, stream));

@@ -52,6 +52,8 @@ struct OutColumn {
     const int32_t* view_offsets = nullptr;
     const uint8_t* view_nulls = nullptr;
     bool is_view = false;
+    // the h_* buffers already hold the block (operators that assemble small results on the host)
+    bool host_ready = false;
 };
 
 // Fills `out` (whose `columns` array has room for cols.size() entries) from device columns; for

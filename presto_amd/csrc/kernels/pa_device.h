@@ -287,46 +287,24 @@ struct PaFusedArgs {
     u64* overflow_rows;               // rows that missed the LDS table (drives mode escalation)
 };
 
-// Wave-private LDS table lookup/insert for a one-wave workgroup.  Every active lane must call it
-// (lanes with active == false just ride along).  Returns the slot, or -1 when all C slots hold other
-// keys.  LDS operations of one wave execute in program order, so a key written in iteration j is
-// visible to every lane from iteration j+1 on; a lane that loses the claim re-reads the same slot
-// in the next iteration and never compares in the iteration of the claim.
-template <int W, int C>
-__device__ __forceinline__ int pa_lds_find(bool active, volatile u32* st, volatile u64* kw, u32 h, const u64 (&k)[W])
+// 64-bit value of lane `lane` (wave-uniform) broadcast to the wave
+__device__ __forceinline__ u64 pa_readlane_u64(u64 v, int lane)
 {
-    bool done = !active;
-    int g = -1;
-    u32 i = h & (C - 1);
-    int probes = 0;
-    while (__ballot(!done) != 0ULL) {
-        if (!done) {
-            u32 s = st[i];
-            if (s == 0u) {
-                if (atomicCAS((u32*)&st[i], 0u, 1u) == 0u) {
-#pragma unroll
-                    for (int w = 0; w < W; w++) kw[i * W + w] = k[w];
-                    g = (int)i;
-                    done = true;
-                }
-            }
-            else {
-                bool eq = true;
-#pragma unroll
-                for (int w = 0; w < W; w++) eq = eq && (kw[i * W + w] == k[w]);
-                if (eq) {
-                    g = (int)i;
-                    done = true;
-                }
-                else {
-                    i = (i + 1) & (C - 1);
-                    if (++probes >= C) done = true;
-                }
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
+    u32 lo = (u32)__builtin_amdgcn_readlane((int)(u32)v, lane);
+    u32 hi = (u32)__builtin_amdgcn_readlane((int)(u32)(v >> 32), lane);
+    return ((u64)hi << 32) | (u64)lo;
+}
+
+// bytes of a short VARCHAR (declared bound <= 7) packed little-endian into one word
+__device__ __forceinline__ u64 pa_short_bytes(const u8* p, i32 len, i32 bound, i32* err)
+{
+    if (len > bound) {
+        pa_raise(err, -3);
+        len = bound;
     }
-    return g;
+    u64 v = 0;
+    for (i32 b = 0; b < len; b++) v |= (u64)p[b] << (8 * b);
+    return v;
 }
 
 // Global (HBM) group table upsert.  Table memory is only ever touched with agent-scope atomic

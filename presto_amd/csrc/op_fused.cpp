@@ -34,7 +34,7 @@ void launch_merge_global_slab(const uint64_t* slab, int blocks, int nw, const in
                               hipStream_t s);
 void launch_merge_lds_slab(const uint64_t* slab, int waves, int c, int w, int nw, const int32_t* kinds_dev, uint64_t* gt_tag,
                            uint64_t* gt_keys, uint64_t* gt_words, uint32_t gt_mask, int32_t gt_max_fill, int32_t* gt_count,
-                           int32_t* err, hipStream_t s);
+                           int32_t* err, const uint64_t* overflow_rows, hipStream_t s);
 void launch_gt_rehash(const uint64_t* old_tag, const uint64_t* old_keys, const uint64_t* old_words, uint32_t old_cap, int w, int nw,
                       uint64_t* tag, uint64_t* keys, uint64_t* words, uint32_t mask, int32_t max_fill, int32_t* count, int32_t* err,
                       hipStream_t s);
@@ -67,11 +67,15 @@ enum WordKind { W_CNT = 0, W_SUMF = 1, W_SUMI = 2 };
 
 constexpr int kLdsSlots = 8;  // C of the LDS variant: 8 groups x NW words x 64 lanes x 8 B of LDS per wave
 
+// Group keys are bit-packed into as few 64-bit words as possible (Q1: two VARCHAR(1) keys -> one word).
 struct KeyPart {
-    int32_t type;
-    int word;        // first key word
-    int nwords;      // 1 or 2
-    int null_bit;    // bit in the null-mask word, or -1
+    int32_t type = PA_BIGINT;
+    int word = 0;        // word holding the value (first of two for long VARCHAR)
+    int shift = 0;       // bit offset inside the word
+    int bits = 64;       // value bits (long VARCHAR: 128 = two dedicated words)
+    int bound = 0;       // short VARCHAR: declared length bound (1..7)
+    int null_word = -1;  // position of the IS NULL flag, or -1
+    int null_shift = 0;
 };
 
 struct Spec {
@@ -86,6 +90,7 @@ struct Spec {
     int expected_groups = 0;
     int output_mem = PA_MEM_HOST;
     std::vector<bool> used_channel;
+    std::vector<int> short_bound;  // per channel: > 0 when the channel is a short VARCHAR group key (packed bytes passed as cs<c>)
 };
 
 struct KernelInfo {
@@ -95,7 +100,6 @@ struct KernelInfo {
     std::vector<int32_t> word_kind;
     std::vector<std::pair<int, int>> agg_words;  // per aggregate: (count word, value word or -1)
     std::vector<KeyPart> keys;
-    int null_word = -1;
 };
 
 Spec make_spec(const pa_fused_aggregation_desc* d)
@@ -153,6 +157,14 @@ Spec make_spec(const pa_fused_aggregation_desc* d)
         PA_REQUIRE(c >= 0 && c < s.n_in, PA_ERR_INVALID_ARGUMENT, "expression references a channel outside the page");
         s.used_channel[c] = true;
     }
+    s.short_bound.assign(s.n_in, 0);
+    for (int j : s.group_proj) {
+        const OwnedExpr& pe = s.proj[j];
+        if (pe.is_input_ref() && pe.root_type() == PA_VARCHAR) {
+            int c = pe.node(pe.root).channel;
+            if (s.in_params[c] >= 1 && s.in_params[c] <= 7) s.short_bound[c] = s.in_params[c];
+        }
+    }
     return s;
 }
 
@@ -165,6 +177,7 @@ std::string row_params(const Spec& s, const std::vector<ChannelLayout>& layout)
         if (!s.used_channel[c]) continue;
         p << ", " << RowCodegen::ctype(layout[c].type) << " c" << c;
         if (layout[c].type == PA_VARCHAR) p << ", i32 cl" << c;
+        if (s.short_bound[c] > 0) p << ", u64 cs" << c;
         if (layout[c].nullable) p << ", bool cn" << c;
     }
     return p.str();
@@ -173,10 +186,10 @@ std::string row_params(const Spec& s, const std::vector<ChannelLayout>& layout)
 // vector loads of row quad q and the 4 argument lists
 void emit_vector_loads(const Spec& s, const std::vector<ChannelLayout>& layout, std::ostringstream& o, std::string args[4])
 {
+    static const char* xyzw[4] = {"x", "y", "z", "w"};
     for (int c = 0; c < s.n_in; c++) {
         if (!s.used_channel[c]) continue;
         std::string C = std::to_string(c);
-        static const char* xyzw[4] = {"x", "y", "z", "w"};
         switch (layout[c].type) {
             case PA_BIGINT:
                 o << "        pa_i64x2 A" << C << " = ((const pa_i64x2*)a.v[" << C << "])[2 * q], B" << C << " = ((const pa_i64x2*)a.v[" << C
@@ -197,14 +210,38 @@ void emit_vector_loads(const Spec& s, const std::vector<ChannelLayout>& layout, 
                 o << "        u32 A" << C << " = ((const u32*)a.v[" << C << "])[q];\n";
                 for (int r = 0; r < 4; r++) args[r] += ", ((A" + C + " >> " + std::to_string(8 * r) + ") & 0xffu) != 0u";
                 break;
-            case PA_VARCHAR:
+            case PA_VARCHAR: {
                 o << "        pa_i32x4 O" << C << " = ((const pa_i32x4*)a.o[" << C << "])[q]; i32 E" << C << " = a.o[" << C << "][4 * q + 4];\n";
+                std::string lo[4], len[4];
                 for (int r = 0; r < 4; r++) {
-                    std::string lo = "O" + C + "." + xyzw[r];
-                    std::string hi = r < 3 ? "O" + C + "." + xyzw[r + 1] : "E" + C;
-                    args[r] += ", (const u8*)a.v[" + C + "] + " + lo + ", " + hi + " - " + lo;
+                    lo[r] = "O" + C + "." + xyzw[r];
+                    len[r] = (r < 3 ? "O" + C + "." + xyzw[r + 1] : "E" + C) + " - " + lo[r];
+                }
+                if (s.short_bound[c] > 0) {
+                    // packed bytes of short VARCHAR keys; VARCHAR(1) rows that all hold one byte are read
+                    // with a single (unaligned) dword load
+                    o << "        u64 S" << C << "0, S" << C << "1, S" << C << "2, S" << C << "3;\n";
+                    if (s.short_bound[c] == 1) {
+                        o << "        if (E" << C << " - " << lo[0] << " == 4) {\n            u32 pk; __builtin_memcpy(&pk, (const u8*)a.v[" << C
+                          << "] + " << lo[0] << ", 4);\n";
+                        for (int r = 0; r < 4; r++) o << "            S" << C << r << " = (pk >> " << 8 * r << ") & 0xffu;\n";
+                        o << "        } else {\n";
+                    }
+                    else {
+                        o << "        {\n";
+                    }
+                    for (int r = 0; r < 4; r++) {
+                        o << "            S" << C << r << " = pa_short_bytes((const u8*)a.v[" << C << "] + " << lo[r] << ", " << len[r] << ", "
+                          << s.short_bound[c] << ", a.err);\n";
+                    }
+                    o << "        }\n";
+                }
+                for (int r = 0; r < 4; r++) {
+                    args[r] += ", (const u8*)a.v[" + C + "] + " + lo[r] + ", " + len[r];
+                    if (s.short_bound[c] > 0) args[r] += ", S" + C + std::to_string(r);
                 }
                 break;
+            }
             default:
                 throw Error(PA_ERR_NOT_SUPPORTED, "column type not supported on device");
         }
@@ -227,13 +264,37 @@ std::string scalar_args(const Spec& s, const std::vector<ChannelLayout>& layout)
             case PA_INTEGER:
             case PA_DATE: a += ", (i64)((const i32*)a.v[" + C + "])[r]"; break;
             case PA_BOOLEAN: a += ", ((const u8*)a.v[" + C + "])[r] != 0"; break;
-            case PA_VARCHAR: a += ", (const u8*)a.v[" + C + "] + a.o[" + C + "][r], a.o[" + C + "][r + 1] - a.o[" + C + "][r]"; break;
+            case PA_VARCHAR:
+                a += ", (const u8*)a.v[" + C + "] + a.o[" + C + "][r], a.o[" + C + "][r + 1] - a.o[" + C + "][r]";
+                if (s.short_bound[c] > 0) {
+                    a += ", pa_short_bytes((const u8*)a.v[" + C + "] + a.o[" + C + "][r], a.o[" + C + "][r + 1] - a.o[" + C + "][r], " +
+                         std::to_string(s.short_bound[c]) + ", a.err)";
+                }
+                break;
             default: throw Error(PA_ERR_NOT_SUPPORTED, "column type not supported on device");
         }
         if (layout[c].nullable) a += ", a.nl[" + C + "][r] != 0";
     }
     return a;
 }
+
+// first-fit bit packing of the key parts into 64-bit words
+struct KeyPacker {
+    std::vector<int> used;  // bits used per word
+    int place(int bits, int* shift)
+    {
+        for (size_t w = 0; w < used.size(); w++) {
+            if (used[w] + bits <= 64) {
+                *shift = used[w];
+                used[w] += bits;
+                return (int)w;
+            }
+        }
+        used.push_back(bits);
+        *shift = 0;
+        return (int)used.size() - 1;
+    }
+};
 
 KernelInfo generate(const Spec& s, const std::vector<ChannelLayout>& layout, int variant)
 {
@@ -263,76 +324,83 @@ KernelInfo generate(const Spec& s, const std::vector<ChannelLayout>& layout, int
         return it->second;
     };
 
-    // 3. group keys -> packed words
-    std::vector<std::string> key_words;
-    std::vector<std::string> null_bits;
+    // 3. group keys -> bit-packed words
+    KeyPacker packer;
+    std::vector<std::vector<std::string>> word_terms;  // per word: OR-ed terms
+    auto add_term = [&](int word, const std::string& term) {
+        if ((int)word_terms.size() <= word) word_terms.resize(word + 1);
+        word_terms[word].push_back(term);
+    };
     for (size_t gi = 0; gi < s.group_proj.size(); gi++) {
         const GenValue& kv = proj_value(s.group_proj[gi]);
+        const OwnedExpr& pe = s.proj[s.group_proj[gi]];
         KeyPart part;
         part.type = kv.type;
-        part.word = (int)key_words.size();
-        part.nwords = 1;
-        part.null_bit = -1;
-        std::string nn = kv.n;
-        std::string guard = kv.nullable() ? "(" + nn + ") ? 0ULL : " : "";
+        std::string value;  // u64 expression already confined to `bits` bits
         switch (kv.type) {
             case PA_BIGINT:
+                part.bits = 64;
+                value = "(u64)" + kv.v;
+                break;
             case PA_INTEGER:
             case PA_DATE:
-                key_words.push_back(guard + "(u64)" + kv.v);
+                part.bits = 32;
+                value = "(u64)(u32)(i32)" + kv.v;
                 break;
             case PA_BOOLEAN:
-                key_words.push_back(guard + "(" + kv.v + " ? 1ULL : 0ULL)");
+                part.bits = 1;
+                value = "(" + kv.v + " ? 1ULL : 0ULL)";
                 break;
             case PA_DOUBLE:
                 // IS NOT DISTINCT semantics of the group key: -0 == +0, NaN == NaN (DoubleType.java:163-184)
-                key_words.push_back(guard + "((" + kv.v + " == 0.0) ? 0ULL : ((" + kv.v + " != " + kv.v +
-                                    ") ? 0x7ff8000000000000ULL : (u64)__double_as_longlong(" + kv.v + ")))");
+                part.bits = 64;
+                value = "((" + kv.v + " == 0.0) ? 0ULL : ((" + kv.v + " != " + kv.v + ") ? 0x7ff8000000000000ULL : (u64)__double_as_longlong(" +
+                        kv.v + ")))";
                 break;
             case PA_VARCHAR: {
-                // short strings packed little-endian with the length in the top byte
-                int bound = 0;
-                const OwnedExpr& pe = s.proj[s.group_proj[gi]];
-                if (pe.is_input_ref()) bound = s.in_params[pe.node(pe.root).channel];
-                part.nwords = (bound > 0 && bound <= 7) ? 1 : 2;
-                std::string id = "ks" + std::to_string(gi);
-                inner << "u64 " << id << "a = 0, " << id << "b = 0;\n";
-                inner << "if (" << (kv.nullable() ? "!" + nn + " && " : "") << "true) {\n";
-                inner << "  if (" << kv.len << " > " << (part.nwords == 1 ? 7 : 15) << ") pa_raise(a.err, -3);\n";
-                inner << "  for (i32 b = 0; b < " << kv.len << " && b < " << (part.nwords == 1 ? 7 : 15) << "; b++) {\n";
-                if (part.nwords == 1) {
-                    inner << "    " << id << "a |= (u64)" << kv.v << "[b] << (8 * b);\n  }\n";
-                    inner << "  " << id << "a |= (u64)" << kv.len << " << 56;\n}\n";
-                    key_words.push_back(id + "a");
+                int ch = pe.is_input_ref() ? pe.node(pe.root).channel : -1;
+                if (ch >= 0 && s.short_bound[ch] > 0) {
+                    part.bound = s.short_bound[ch];
+                    part.bits = 8 * part.bound + 4;
+                    value = "(cs" + std::to_string(ch) + " | ((u64)" + kv.len + " << " + std::to_string(8 * part.bound) + "))";
                 }
                 else {
-                    inner << "    if (b < 8) " << id << "a |= (u64)" << kv.v << "[b] << (8 * b); else " << id << "b |= (u64)" << kv.v
-                          << "[b] << (8 * (b - 8));\n  }\n";
-                    inner << "  " << id << "b |= (u64)" << kv.len << " << 56;\n}\n";
-                    key_words.push_back(id + "a");
-                    key_words.push_back(id + "b");
+                    part.bits = 128;
                 }
                 break;
             }
             default:
                 throw Error(PA_ERR_NOT_SUPPORTED, "group key type not supported on device");
         }
+        std::string guard = kv.nullable() ? "(" + kv.n + ") ? 0ULL : " : "";
+        if (part.bits == 128) {
+            // up to 15 bytes in two dedicated words, length in the top byte of the second
+            int sh;
+            part.word = packer.place(64, &sh);
+            int w2 = packer.place(64, &sh);
+            PA_REQUIRE(w2 == part.word + 1, PA_ERR_NOT_SUPPORTED, "internal: long VARCHAR key words not adjacent");
+            std::string id = "ks" + std::to_string(gi);
+            inner << "u64 " << id << "a = 0, " << id << "b = 0;\n";
+            inner << "if (" << (kv.nullable() ? "!" + kv.n : "true") << ") {\n";
+            inner << "  if (" << kv.len << " > 15) pa_raise(a.err, -3);\n";
+            inner << "  for (i32 b = 0; b < " << kv.len << " && b < 15; b++) {\n";
+            inner << "    if (b < 8) " << id << "a |= (u64)" << kv.v << "[b] << (8 * b); else " << id << "b |= (u64)" << kv.v
+                  << "[b] << (8 * (b - 8));\n  }\n";
+            inner << "  " << id << "b |= (u64)" << kv.len << " << 56;\n}\n";
+            add_term(part.word, id + "a");
+            add_term(part.word + 1, id + "b");
+        }
+        else {
+            part.word = packer.place(part.bits, &part.shift);
+            add_term(part.word, "((" + guard + value + ") << " + std::to_string(part.shift) + ")");
+        }
         if (kv.nullable()) {
-            part.null_bit = (int)null_bits.size();
-            null_bits.push_back(nn);
+            part.null_word = packer.place(1, &part.null_shift);
+            add_term(part.null_word, "((" + kv.n + ") ? " + std::to_string(1ULL << part.null_shift) + "ULL : 0ULL)");
         }
         k.keys.push_back(part);
     }
-    if (!null_bits.empty()) {
-        k.null_word = (int)key_words.size();
-        std::string w;
-        for (size_t b = 0; b < null_bits.size(); b++) {
-            if (b) w += " | ";
-            w += "((" + null_bits[b] + ") ? " + std::to_string(1ULL << b) + "ULL : 0ULL)";
-        }
-        key_words.push_back(w);
-    }
-    k.w = (int)key_words.size();
+    k.w = (int)packer.used.size();
     PA_REQUIRE(k.w <= 8, PA_ERR_NOT_SUPPORTED, "group key wider than 8 words");
 
     // 4. accumulator words, shared between aggregates over the same (input, mask)
@@ -383,8 +451,7 @@ KernelInfo generate(const Spec& s, const std::vector<ChannelLayout>& layout, int
     }
     for (const auto& w : words) k.word_kind.push_back(w.kind);
     if (variant == V_LDS) {
-        PA_REQUIRE((size_t)k.nw * kLdsSlots * 64 * 8 + kLdsSlots * (4 + 8 * k.w) <= 64 * 1024, PA_ERR_NOT_SUPPORTED,
-                   "too many accumulator words for the LDS variant");
+        PA_REQUIRE((size_t)k.nw * kLdsSlots * 64 * 8 <= 64 * 1024, PA_ERR_NOT_SUPPORTED, "too many accumulator words for the LDS variant");
     }
 
     // ---- assemble the translation unit ----
@@ -396,7 +463,10 @@ KernelInfo generate(const Spec& s, const std::vector<ChannelLayout>& layout, int
         src << " };\n";
     }
     else if (variant == V_LDS) {
-        src << "struct PaAcc { volatile u32* st; volatile u64* kw; u64* acc; u32 lane; };\n";
+        // key table of the wave in (scalar) registers; accumulators lane-private in LDS: word w of group g
+        // of lane l lives at pa_accw[(w * C + g) * 64 + l], so no two lanes ever share an address
+        src << "__shared__ u64 pa_accw[PA_NW * PA_C * 64];\n";
+        src << "struct PaAcc { u64 tk[PA_C][PA_KW]; int tcount; u32 lane; };\n";
     }
     else {
         src << "struct PaAcc { int unused; };\n";
@@ -407,14 +477,13 @@ KernelInfo generate(const Spec& s, const std::vector<ChannelLayout>& layout, int
     for (int w = 0; w < k.nw; w++) {
         src << "bool u" << w << " = false; " << (words[w].kind == W_SUMF ? "double" : "i64") << " x" << w << " = 0;\n";
     }
-    if (k.w > 0) {
-        src << "u64 key[PA_KW];\n#pragma unroll\nfor (int i = 0; i < PA_KW; i++) key[i] = 0;\nu32 h = 0;\n";
-    }
+    if (k.w > 0) src << "u64 key[PA_KW];\n#pragma unroll\nfor (int i = 0; i < PA_KW; i++) key[i] = 0;\n";
     src << "if (sel) {\n" << inner.str();
     for (int w = 0; w < k.nw; w++) src << "u" << w << " = " << words[w].cond << "; x" << w << " = " << words[w].val << ";\n";
-    if (k.w > 0) {
-        for (int i = 0; i < k.w; i++) src << "key[" << i << "] = " << key_words[i] << ";\n";
-        src << "h = pa_key_hash(key, PA_KW);\n";
+    for (int i = 0; i < k.w; i++) {
+        src << "key[" << i << "] = ";
+        for (size_t t = 0; t < word_terms[i].size(); t++) src << (t ? " | " : "") << word_terms[i][t];
+        src << ";\n";
     }
     src << "}\n";
     if (variant == V_GLOBAL) {
@@ -427,18 +496,33 @@ KernelInfo generate(const Spec& s, const std::vector<ChannelLayout>& layout, int
         src << "}\n";
     }
     else if (variant == V_LDS) {
-        src << "int g = pa_lds_find<PA_KW, PA_C>(sel, acc.st, acc.kw, h, key);\n";
+        src << "int g = -1;\nif (sel) {\n#pragma unroll\n  for (int s = 0; s < PA_C; s++) {\n    bool eq = s < acc.tcount;\n#pragma unroll\n"
+               "    for (int w = 0; w < PA_KW; w++) eq = eq && (key[w] == acc.tk[s][w]);\n    if (eq) g = s;\n  }\n}\n";
+        // first occurrences: append the missing keys to the wave's table one at a time (wave-uniform loop)
+        src << "u64 miss = __ballot(sel && g < 0);\nwhile (miss != 0ULL) {\n  const int src_lane = __builtin_amdgcn_readfirstlane(__ffsll((long long)miss) - 1);\n"
+               "  u64 nk[PA_KW];\n#pragma unroll\n  for (int w = 0; w < PA_KW; w++) nk[w] = pa_readlane_u64(key[w], src_lane);\n"
+               "  const int slot = acc.tcount;\n  if (slot < PA_C) {\n#pragma unroll\n    for (int s = 0; s < PA_C; s++) {\n      if (s == slot) {\n#pragma unroll\n"
+               "        for (int w = 0; w < PA_KW; w++) acc.tk[s][w] = nk[w];\n      }\n    }\n    acc.tcount = slot + 1;\n  }\n"
+               "  bool mine = sel && g == -1;\n#pragma unroll\n  for (int w = 0; w < PA_KW; w++) mine = mine && (key[w] == nk[w]);\n"
+               "  if (mine) g = slot < PA_C ? slot : -2;\n  miss = __ballot(sel && g == -1);\n}\n";
         src << "if (sel) {\n  if (g >= 0) {\n";
         for (int w = 0; w < k.nw; w++) {
-            std::string idx = "acc.acc[(" + std::to_string(w) + " * PA_C + g) * 64 + acc.lane]";
-            if (words[w].kind == W_SUMF) src << "    if (u" << w << ") { double* p = (double*)&" << idx << "; *p = *p + x" << w << "; }\n";
-            else if (words[w].kind == W_SUMI) src << "    if (u" << w << ") { i64* p = (i64*)&" << idx << "; *p = pa_add_exact(*p, x" << w << ", a.err); }\n";
-            else src << "    if (u" << w << ") { " << idx << " += 1ULL; }\n";
+            std::string idx = "pa_accw[(" + std::to_string(w) + " * PA_C + g) * 64 + acc.lane]";
+            if (words[w].kind == W_SUMF) {
+                src << "    if (u" << w << ") __hip_atomic_fetch_add((double*)&" << idx << ", x" << w << ", __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);\n";
+            }
+            else if (words[w].kind == W_SUMI) {
+                src << "    if (u" << w << ") { i64* p = (i64*)&" << idx << "; *p = pa_add_exact(*p, x" << w << ", a.err); }\n";
+            }
+            else {
+                src << "    if (u" << w << ") __hip_atomic_fetch_add(&" << idx << ", 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);\n";
+            }
         }
         src << "  } else {\n    atomicAdd((unsigned long long*)a.overflow_rows, 1ULL);\n  }\n}\n";
     }
     else {
-        src << "if (sel) {\n  int g = pa_gt_upsert<PA_KW>(a.gt_tag, a.gt_keys, a.gt_mask, h, key, a.gt_count, a.gt_max_fill, a.err);\n";
+        src << "if (sel) {\n  const u32 h = pa_key_hash(key, PA_KW);\n"
+               "  int g = pa_gt_upsert<PA_KW>(a.gt_tag, a.gt_keys, a.gt_mask, h, key, a.gt_count, a.gt_max_fill, a.err);\n";
         src << "  if (g >= 0) {\n    const u64 cap = (u64)a.gt_mask + 1ULL;\n";
         for (int w = 0; w < k.nw; w++) {
             std::string idx = std::to_string(w) + "ULL * cap + (u64)g";
@@ -458,11 +542,10 @@ KernelInfo generate(const Spec& s, const std::vector<ChannelLayout>& layout, int
         for (int w = 0; w < k.nw; w++) src << "    acc.w" << w << " = 0;\n";
     }
     else if (variant == V_LDS) {
-        src << "    __shared__ u32 st[PA_C];\n    __shared__ u64 kw[PA_C * PA_KW];\n    __shared__ u64 accw[PA_NW * PA_C * 64];\n";
-        src << "    for (int i = threadIdx.x; i < PA_C; i += 64) st[i] = 0u;\n";
-        src << "    for (int i = threadIdx.x; i < PA_NW * PA_C * 64; i += 64) accw[i] = 0ULL;\n";
+        src << "    for (int i = threadIdx.x; i < PA_NW * PA_C * 64; i += 64) pa_accw[i] = 0ULL;\n";
         src << "    __syncthreads();\n";
-        src << "    PaAcc acc; acc.st = st; acc.kw = kw; acc.acc = accw; acc.lane = threadIdx.x;\n";
+        src << "    PaAcc acc; acc.tcount = 0; acc.lane = threadIdx.x;\n";
+        src << "#pragma unroll\n    for (int s = 0; s < PA_C; s++) {\n#pragma unroll\n        for (int w = 0; w < PA_KW; w++) acc.tk[s][w] = 0ULL;\n    }\n";
     }
     else {
         src << "    PaAcc acc; acc.unused = 0;\n";
@@ -497,16 +580,16 @@ KernelInfo generate(const Spec& s, const std::vector<ChannelLayout>& layout, int
         // per-wave partial table -> slab entry [occupied, keys(W), words(NW)]
         src << "    __syncthreads();\n";
         src << "    u64* out = a.slab + (u64)blockIdx.x * PA_C * (1 + PA_KW + PA_NW);\n";
-        src << "    for (int i = 0; i < PA_C; i++) {\n        u64* e = out + (u64)i * (1 + PA_KW + PA_NW);\n";
-        src << "        const u32 occ = st[i];\n        if (threadIdx.x == 0) e[0] = occ;\n        if (occ == 0u) continue;\n";
-        src << "        if (threadIdx.x < PA_KW) e[1 + threadIdx.x] = kw[i * PA_KW + threadIdx.x];\n";
+        src << "#pragma unroll\n    for (int i = 0; i < PA_C; i++) {\n        u64* e = out + (u64)i * (1 + PA_KW + PA_NW);\n";
+        src << "        const bool occ = i < acc.tcount;\n        if (threadIdx.x == 0) e[0] = occ ? 1ULL : 0ULL;\n        if (occ) {\n";
+        src << "#pragma unroll\n            for (int w = 0; w < PA_KW; w++) { if (threadIdx.x == 0) e[1 + w] = acc.tk[i][w]; }\n";
         for (int w = 0; w < k.nw; w++) {
-            std::string idx = "accw[(" + std::to_string(w) + " * PA_C + i) * 64 + threadIdx.x]";
-            if (words[w].kind == W_SUMF) src << "        { double v = pa_wave_sum_f64(__longlong_as_double((i64)" << idx << ")); if (threadIdx.x == 0) e[1 + PA_KW + " << w << "] = (u64)__double_as_longlong(v); }\n";
-            else if (words[w].kind == W_SUMI) src << "        { i64 v = pa_wave_sum_i64_exact((i64)" << idx << ", a.err); if (threadIdx.x == 0) e[1 + PA_KW + " << w << "] = (u64)v; }\n";
-            else src << "        { i64 v = pa_wave_sum_i64((i64)" << idx << "); if (threadIdx.x == 0) e[1 + PA_KW + " << w << "] = (u64)v; }\n";
+            std::string idx = "pa_accw[(" + std::to_string(w) + " * PA_C + i) * 64 + threadIdx.x]";
+            if (words[w].kind == W_SUMF) src << "            { double v = pa_wave_sum_f64(__longlong_as_double((i64)" << idx << ")); if (threadIdx.x == 0) e[1 + PA_KW + " << w << "] = (u64)__double_as_longlong(v); }\n";
+            else if (words[w].kind == W_SUMI) src << "            { i64 v = pa_wave_sum_i64_exact((i64)" << idx << ", a.err); if (threadIdx.x == 0) e[1 + PA_KW + " << w << "] = (u64)v; }\n";
+            else src << "            { i64 v = pa_wave_sum_i64((i64)" << idx << "); if (threadIdx.x == 0) e[1 + PA_KW + " << w << "] = (u64)v; }\n";
         }
-        src << "    }\n";
+        src << "        }\n    }\n";
     }
     src << "}\n";
     k.source = src.str();
@@ -524,20 +607,22 @@ uint32_t next_pow2(uint64_t v)
 
 class FusedAggregationOperator : public pa_operator {
 public:
-    explicit FusedAggregationOperator(const pa_fused_aggregation_desc* d) : spec_(make_spec(d)), stream_(d->aggregation.stream ? d->aggregation.stream : d->filter_project.stream)
+    explicit FusedAggregationOperator(const pa_fused_aggregation_desc* d)
+        : spec_(make_spec(d)), stream_(d->aggregation.stream ? d->aggregation.stream : d->filter_project.stream)
     {
         require_device();
         grouped_ = !spec_.group_proj.empty();
         mode_ = grouped_ ? V_LDS : V_GLOBAL;
         cus_ = device_cu_count();
-        PA_HIP(hipMalloc((void**)&ctl_, 64));  // [0] err  [1] gt_count  [2..3] overflow rows
+        ctl_ = static_cast<int32_t*>(ctl_buf_.ensure(64));  // [0] err  [1] gt_count  [2..3] overflow rows
         PA_HIP(hipMemsetAsync(ctl_, 0, 64, stream_.get()));
-        PA_HIP(hipHostMalloc((void**)&h_ctl_, 64, hipHostMallocDefault));
+        h_ctl_ = static_cast<int32_t*>(h_ctl_buf_.ensure(64));
+        memset(h_ctl_, 0, 64);
     }
     ~FusedAggregationOperator() override
     {
-        if (ctl_) (void)hipFree(ctl_);
-        if (h_ctl_) (void)hipHostFree(h_ctl_);
+        // pooled buffers go back to the caches in the member destructors: all device work must be done first
+        (void)hipStreamSynchronize(stream_.get());
     }
 
     bool needs_input() override { return !finishing_; }
@@ -564,13 +649,11 @@ public:
             }
             sig += layout[c].nullable ? 'n' : '-';
         }
-        rows_in_ += dp.n;
         for (;;) {
             const Compiled& ck = kernel_for(sig, layout, mode_);
             if (run_page(ck, dp, vec)) break;
-            mode_ = V_GT;  // the page held more groups than the LDS tables: redo it (and every later page) on the HBM table
+            mode_ = V_GT;  // the page held more groups than the register tables: redo it (and every later page) on the HBM table
         }
-        check_device_error();
     }
 
     void finish() override { finishing_ = true; }
@@ -585,7 +668,7 @@ public:
             publish_output(out_cols_, out_rows_, spec_.output_mem, stream_.get(), out, out_storage_);
             return true;
         }
-        return false;  // HashAggregationOperator emits nothing for an empty input (no global default row, SINGLE step with keys)
+        return false;  // HashAggregationOperator emits nothing for an empty input (SINGLE step with keys)
     }
 
     int64_t memory_bytes() override
@@ -616,8 +699,8 @@ private:
             w_ = c->info.w;
             layout_fixed_ = true;
         }
-        // every signature of one operator yields the same accumulator layout except for nullable
-        // inputs gaining their own count words; states of different layouts cannot be merged
+        // every signature of one operator must yield the same state layout: nullable inputs add count
+        // words / null flags, and states of different layouts cannot be merged
         PA_REQUIRE(c->info.nw == nw_ && c->info.w == w_, PA_ERR_NOT_SUPPORTED,
                    "pages of one operator changed nullability in a way that changes the accumulator layout");
         const Compiled& ref = *c;
@@ -642,7 +725,7 @@ private:
             PA_HIP(hipMemsetAsync(ctl_ + 1, 0, 4, s));
             launch_gt_rehash(gt_tag_.as<uint64_t>(), gt_keys_.as<uint64_t>(), gt_words_.as<uint64_t>(), gt_cap_, std::max(w_, 1), nw_,
                              tag.as<uint64_t>(), keys.as<uint64_t>(), words.as<uint64_t>(), cap - 1, (int32_t)(cap - cap / 4), ctl_ + 1, ctl_, s);
-            PA_HIP(hipStreamSynchronize(s));
+            PA_HIP(hipStreamSynchronize(s));  // the old arrays return to the pool below
         }
         gt_tag_ = std::move(tag);
         gt_keys_ = std::move(keys);
@@ -673,8 +756,7 @@ private:
         const int64_t chunk = ki.variant == V_GT ? (int64_t)1 << 26 : total;
         while (offset < total) {
             int64_t n = std::min(chunk, total - offset);
-            if (offset > 0 || n < total) {
-                PA_REQUIRE(offset % 4 == 0, PA_ERR_DEVICE, "internal: unaligned chunk");
+            if (offset > 0) {
                 for (int c = 0; c < spec_.n_in; c++) {
                     if (!spec_.used_channel[c]) continue;
                     const DevColumn& col = dp.cols[c];
@@ -687,7 +769,7 @@ private:
             int64_t work = (n + 3) / 4;
             int grid;
             if (ki.variant == V_LDS) {
-                int per_cu = std::max(1, std::min(8, (int)(160 * 1024 / ((size_t)ki.nw * ki.c * 64 * 8 + 1024))));
+                int per_cu = std::max(1, std::min(16, (int)(160 * 1024 / ((size_t)ki.nw * ki.c * 64 * 8 + 512))));
                 grid = (int)std::min<int64_t>((work + 63) / 64, (int64_t)cus_ * per_cu);
             }
             else {
@@ -703,7 +785,8 @@ private:
             }
             else if (ki.variant == V_LDS) {
                 a.slab = static_cast<uint64_t*>(slab_.ensure((size_t)grid * ki.c * (1 + ki.w + ki.nw) * 8));
-                PA_HIP(hipMemsetAsync(ctl_ + 2, 0, 8, s));
+                // the merge of this launch adds at most grid * C groups to those already known
+                ensure_table(groups_upper_ + (uint64_t)grid * ki.c);
             }
             else {
                 ensure_table(groups_upper_ + (uint64_t)n);
@@ -721,38 +804,30 @@ private:
                 launch_merge_global_slab(a.slab, grid, ki.nw, ck.kinds.as<int32_t>(), state_.as<uint64_t>(), ctl_, s);
             }
             else if (ki.variant == V_LDS) {
+                // the merge skips itself when the launch overflowed (overflow_rows != 0); the host learns about
+                // it from the control block, which it reads once per page
+                launch_merge_lds_slab(a.slab, grid, ki.c, ki.w, ki.nw, ck.kinds.as<int32_t>(), a.gt_tag, a.gt_keys, a.gt_words, a.gt_mask,
+                                      a.gt_max_fill, a.gt_count, ctl_, a.overflow_rows, s);
                 PA_HIP(hipMemcpyAsync(h_ctl_, ctl_, 16, hipMemcpyDeviceToHost, s));
                 PA_HIP(hipStreamSynchronize(s));
                 uint64_t overflow;
                 memcpy(&overflow, h_ctl_ + 2, 8);
-                if (overflow != 0) return false;
-                // h_ctl_[1] = groups after the previous merges; this merge adds at most grid * C more
-                ensure_table((uint64_t)h_ctl_[1] + (uint64_t)grid * ki.c);
-                a.gt_tag = gt_tag_.as<uint64_t>();
-                a.gt_keys = gt_keys_.as<uint64_t>();
-                a.gt_words = gt_words_.as<uint64_t>();
-                a.gt_mask = gt_cap_ - 1;
-                a.gt_max_fill = (int32_t)(gt_cap_ - gt_cap_ / 4);
-                launch_merge_lds_slab(a.slab, grid, ki.c, ki.w, ki.nw, ck.kinds.as<int32_t>(), a.gt_tag, a.gt_keys, a.gt_words, a.gt_mask,
-                                      a.gt_max_fill, a.gt_count, ctl_, s);
-                groups_upper_ = (uint64_t)h_ctl_[1] + (uint64_t)grid * ki.c;
+                if (overflow != 0) {
+                    PA_HIP(hipMemsetAsync(ctl_ + 2, 0, 8, s));
+                    return false;
+                }
+                raise_if(h_ctl_[0]);
+                groups_upper_ = (uint64_t)h_ctl_[1];
             }
             else {
                 PA_HIP(hipMemcpyAsync(h_ctl_, ctl_, 8, hipMemcpyDeviceToHost, s));
                 PA_HIP(hipStreamSynchronize(s));
+                raise_if(h_ctl_[0]);
                 groups_upper_ = (uint64_t)h_ctl_[1];
             }
             offset += n;
         }
         return true;
-    }
-
-    void check_device_error()
-    {
-        // the LDS / GT variants already synchronised and copied ctl; the GLOBAL variant defers the check
-        // to get_output so that add_input stays asynchronous
-        if (mode_ == V_GLOBAL) return;
-        raise_if(h_ctl_[0]);
     }
 
     static void raise_if(int32_t code)
@@ -762,7 +837,7 @@ private:
             case PA_ERR_NUMERIC_VALUE_OUT_OF_RANGE: throw Error(code, "numeric value out of range (bigint/integer arithmetic overflow)");
             case PA_ERR_DIVISION_BY_ZERO: throw Error(code, "Division by zero");
             case PA_ERR_INSUFFICIENT_RESOURCES: throw Error(code, "group table capacity exceeded");
-            case PA_ERR_NOT_SUPPORTED: throw Error(code, "VARCHAR group key longer than the device key packing supports");
+            case PA_ERR_NOT_SUPPORTED: throw Error(code, "VARCHAR group key longer than its declared bound / the device key packing supports");
             default: throw Error(code, "device-side error");
         }
     }
@@ -775,7 +850,8 @@ private:
     std::map<std::string, std::unique_ptr<Compiled>> compiled_;
     bool grouped_ = false, finishing_ = false, output_done_ = false, layout_fixed_ = false;
     int mode_ = V_GLOBAL, cus_ = 256, nw_ = 0, w_ = 0;
-    int64_t rows_in_ = 0;
+    DevBuf ctl_buf_;
+    PinnedBuf h_ctl_buf_, h_table_;
     int32_t* ctl_ = nullptr;
     int32_t* h_ctl_ = nullptr;
     DevBuf slab_, state_, gt_tag_, gt_keys_, gt_words_;
@@ -784,9 +860,6 @@ private:
     std::vector<OutColumn> out_cols_;
     std::vector<pa_column> out_storage_;
     int32_t out_rows_ = 0;
-    // host staging of the output page
-    std::vector<std::vector<uint8_t>> host_cols_, host_nulls_;
-    std::vector<std::vector<int32_t>> host_offsets_;
 };
 
 // Final values: InMemoryHashAggregationBuilder.buildResult (…/InMemoryHashAggregationBuilder.java:244-298) /
@@ -801,32 +874,42 @@ void FusedAggregationOperator::build_output()
     if (compiled_.empty()) {
         std::vector<ChannelLayout> layout(spec_.n_in);
         for (int c = 0; c < spec_.n_in; c++) layout[c].type = spec_.in_types[c];
-        KernelInfo ki = generate(spec_, layout, grouped_ ? V_GT : V_GLOBAL);
         auto c = std::make_unique<Compiled>();
-        c->info = ki;
-        nw_ = ki.nw;
-        w_ = ki.w;
+        c->info = generate(spec_, layout, grouped_ ? V_GT : V_GLOBAL);
+        nw_ = c->info.nw;
+        w_ = c->info.w;
         compiled_["-"] = std::move(c);
     }
     const KernelInfo& ki = compiled_.begin()->second->info;
-    PA_HIP(hipMemcpyAsync(h_ctl_, ctl_, 16, hipMemcpyDeviceToHost, s));
-    PA_HIP(hipStreamSynchronize(s));
-    raise_if(h_ctl_[0]);
 
-    std::vector<uint64_t> tag, keys, words;  // dense per group after compaction
+    // one pinned landing zone: [ctl 64 B][state | tag, keys, words]
+    const size_t table_words = grouped_ ? (size_t)gt_cap_ * (1 + std::max(w_, 1) + nw_) : (size_t)nw_;
+    uint8_t* land = static_cast<uint8_t*>(h_table_.ensure(64 + table_words * 8 + 8));
+    uint64_t* h_words = reinterpret_cast<uint64_t*>(land + 64);
+    PA_HIP(hipMemcpyAsync(land, ctl_, 16, hipMemcpyDeviceToHost, s));
+    if (!grouped_) {
+        if (state_.ptr()) PA_HIP(hipMemcpyAsync(h_words, state_.ptr(), (size_t)nw_ * 8, hipMemcpyDeviceToHost, s));
+        else memset(h_words, 0, (size_t)nw_ * 8);
+    }
+    else if (gt_cap_ > 0) {
+        PA_HIP(hipMemcpyAsync(h_words, gt_tag_.ptr(), (size_t)gt_cap_ * 8, hipMemcpyDeviceToHost, s));
+        PA_HIP(hipMemcpyAsync(h_words + gt_cap_, gt_keys_.ptr(), (size_t)gt_cap_ * 8 * std::max(w_, 1), hipMemcpyDeviceToHost, s));
+        PA_HIP(hipMemcpyAsync(h_words + (size_t)gt_cap_ * (1 + std::max(w_, 1)), gt_words_.ptr(), (size_t)gt_cap_ * 8 * nw_, hipMemcpyDeviceToHost, s));
+    }
+    PA_HIP(hipStreamSynchronize(s));
+    raise_if(reinterpret_cast<int32_t*>(land)[0]);
+
+    // dense (keys, words) per group
+    std::vector<uint64_t> keys, words;
     int64_t groups = 0;
     if (!grouped_) {
         groups = 1;
-        words.assign(nw_, 0);
-        if (state_.ptr()) {
-            PA_HIP(hipMemcpy(words.data(), state_.ptr(), (size_t)nw_ * 8, hipMemcpyDeviceToHost));
-        }
+        words.assign(h_words, h_words + nw_);
     }
-    else if (gt_cap_ > 0) {
-        std::vector<uint64_t> t(gt_cap_), kk((size_t)gt_cap_ * std::max(w_, 1)), ww((size_t)gt_cap_ * nw_);
-        PA_HIP(hipMemcpy(t.data(), gt_tag_.ptr(), t.size() * 8, hipMemcpyDeviceToHost));
-        PA_HIP(hipMemcpy(kk.data(), gt_keys_.ptr(), kk.size() * 8, hipMemcpyDeviceToHost));
-        PA_HIP(hipMemcpy(ww.data(), gt_words_.ptr(), ww.size() * 8, hipMemcpyDeviceToHost));
+    else {
+        const uint64_t* t = h_words;
+        const uint64_t* kk = h_words + gt_cap_;
+        const uint64_t* ww = h_words + (size_t)gt_cap_ * (1 + std::max(w_, 1));
         for (uint32_t i = 0; i < gt_cap_; i++) {
             if (t[i] == 0) continue;
             for (int w = 0; w < w_; w++) keys.push_back(kk[(size_t)i * w_ + w]);
@@ -842,9 +925,8 @@ void FusedAggregationOperator::build_output()
     const int ncols = nkeys + (has_hash ? 1 : 0) + (int)spec_.aggs.size();
     out_cols_.clear();
     out_cols_.resize(ncols);
-    host_cols_.assign(ncols, {});
-    host_nulls_.assign(ncols, {});
-    host_offsets_.assign(ncols, {});
+    std::vector<std::vector<uint8_t>> host_cols(ncols), host_nulls(ncols);
+    std::vector<std::vector<int32_t>> host_offsets(ncols);
     std::vector<int64_t> row_hash(groups, 0);
     int col = 0;
     for (int gi = 0; gi < nkeys; gi++, col++) {
@@ -852,21 +934,22 @@ void FusedAggregationOperator::build_output()
         OutColumn& oc = out_cols_[col];
         oc.type = kp.type;
         oc.varwidth = kp.type == PA_VARCHAR;
-        auto& data = host_cols_[col];
-        auto& nulls = host_nulls_[col];
-        auto& offs = host_offsets_[col];
+        auto& data = host_cols[col];
+        auto& nulls = host_nulls[col];
+        auto& offs = host_offsets[col];
         nulls.assign(groups ? groups : 1, 0);
         bool any_null = false;
         if (oc.varwidth) offs.push_back(0);
+        const uint64_t mask = kp.bits >= 64 ? ~0ULL : ((1ULL << kp.bits) - 1ULL);
         for (int64_t g = 0; g < groups; g++) {
             const uint64_t* kw = &keys[(size_t)g * w_];
-            bool is_null = kp.null_bit >= 0 && ((kw[ki.null_word] >> kp.null_bit) & 1ULL);
+            bool is_null = kp.null_word >= 0 && ((kw[kp.null_word] >> kp.null_shift) & 1ULL);
             int64_t h = 0;
             if (is_null) {
                 nulls[g] = 1;
                 any_null = true;
             }
-            uint64_t w0 = kw[kp.word];
+            uint64_t w0 = (kw[kp.word] >> kp.shift) & mask;
             switch (kp.type) {
                 case PA_BIGINT: {
                     int64_t v = is_null ? 0 : (int64_t)w0;
@@ -876,7 +959,7 @@ void FusedAggregationOperator::build_output()
                 }
                 case PA_INTEGER:
                 case PA_DATE: {
-                    int32_t v = is_null ? 0 : (int32_t)(int64_t)w0;
+                    int32_t v = is_null ? 0 : (int32_t)(uint32_t)w0;
                     data.insert(data.end(), (uint8_t*)&v, (uint8_t*)&v + 4);
                     if (!is_null) h = host_hash_bigint((int64_t)v);
                     break;
@@ -897,10 +980,14 @@ void FusedAggregationOperator::build_output()
                     uint8_t bytes[16];
                     int len = 0;
                     if (!is_null) {
-                        uint64_t last = kw[kp.word + kp.nwords - 1];
-                        len = (int)(last >> 56);
-                        for (int b = 0; b < len; b++) {
-                            bytes[b] = b < 8 ? (uint8_t)(w0 >> (8 * b)) : (uint8_t)(kw[kp.word + 1] >> (8 * (b - 8)));
+                        if (kp.bits == 128) {
+                            uint64_t a0 = kw[kp.word], b0 = kw[kp.word + 1];
+                            len = (int)(b0 >> 56);
+                            for (int b = 0; b < len; b++) bytes[b] = b < 8 ? (uint8_t)(a0 >> (8 * b)) : (uint8_t)(b0 >> (8 * (b - 8)));
+                        }
+                        else {
+                            len = (int)(w0 >> (8 * kp.bound));
+                            for (int b = 0; b < len; b++) bytes[b] = (uint8_t)(w0 >> (8 * b));
                         }
                         h = (int64_t)host_xxh64(bytes, len);
                     }
@@ -920,10 +1007,10 @@ void FusedAggregationOperator::build_output()
         // (HashGenerationOptimizer.java:867-890 defines the precomputed channel as the same function)
         OutColumn& oc = out_cols_[col];
         oc.type = PA_BIGINT;
-        auto& data = host_cols_[col];
+        auto& data = host_cols[col];
         data.resize((size_t)groups * 8);
         if (groups) memcpy(data.data(), row_hash.data(), (size_t)groups * 8);
-        host_nulls_[col].assign(groups ? groups : 1, 0);
+        host_nulls[col].assign(groups ? groups : 1, 0);
         col++;
     }
     for (size_t k = 0; k < spec_.aggs.size(); k++, col++) {
@@ -932,8 +1019,8 @@ void FusedAggregationOperator::build_output()
         OutColumn& oc = out_cols_[col];
         bool as_double = ag.fn == PA_AGG_AVG || (ag.fn == PA_AGG_SUM && vw >= 0 && ki.word_kind[vw] == W_SUMF);
         oc.type = as_double ? PA_DOUBLE : ((ag.fn == PA_AGG_SUM) ? spec_.proj[ag.input_channel].root_type() : PA_BIGINT);
-        auto& data = host_cols_[col];
-        auto& nulls = host_nulls_[col];
+        auto& data = host_cols[col];
+        auto& nulls = host_nulls[col];
         nulls.assign(groups ? groups : 1, 0);
         bool any_null = false;
         const int width = type_width(oc.type);
@@ -971,22 +1058,36 @@ void FusedAggregationOperator::build_output()
         }
         oc.has_nulls = any_null;
     }
-    // place the assembled blocks in HBM (device consumers) / they are copied back by publish_output (host consumers)
+    // hand the assembled blocks over: pinned host memory for PA_MEM_HOST consumers, HBM otherwise
+    const bool to_device = spec_.output_mem == PA_MEM_DEVICE;
     for (int c = 0; c < ncols; c++) {
         OutColumn& oc = out_cols_[c];
-        size_t bytes = host_cols_[c].size();
-        oc.values.ensure(bytes ? bytes : 1);
-        if (bytes) PA_HIP(hipMemcpyAsync(oc.values.ptr(), host_cols_[c].data(), bytes, hipMemcpyHostToDevice, s));
+        size_t bytes = host_cols[c].size();
+        void* hv = oc.h_values.ensure(bytes ? bytes : 1);
+        if (bytes) memcpy(hv, host_cols[c].data(), bytes);
         if (oc.varwidth) {
-            oc.offsets.ensure(host_offsets_[c].size() * 4);
-            PA_HIP(hipMemcpyAsync(oc.offsets.ptr(), host_offsets_[c].data(), host_offsets_[c].size() * 4, hipMemcpyHostToDevice, s));
+            void* ho = oc.h_offsets.ensure(host_offsets[c].size() * 4);
+            memcpy(ho, host_offsets[c].data(), host_offsets[c].size() * 4);
         }
         if (oc.has_nulls) {
-            oc.nulls.ensure(host_nulls_[c].size());
-            PA_HIP(hipMemcpyAsync(oc.nulls.ptr(), host_nulls_[c].data(), host_nulls_[c].size(), hipMemcpyHostToDevice, s));
+            void* hn = oc.h_nulls.ensure(host_nulls[c].size());
+            memcpy(hn, host_nulls[c].data(), host_nulls[c].size());
+        }
+        oc.host_ready = true;
+        if (to_device) {
+            oc.values.ensure(bytes ? bytes : 1);
+            if (bytes) PA_HIP(hipMemcpyAsync(oc.values.ptr(), hv, bytes, hipMemcpyHostToDevice, s));
+            if (oc.varwidth) {
+                oc.offsets.ensure(host_offsets[c].size() * 4);
+                PA_HIP(hipMemcpyAsync(oc.offsets.ptr(), oc.h_offsets.ptr(), host_offsets[c].size() * 4, hipMemcpyHostToDevice, s));
+            }
+            if (oc.has_nulls) {
+                oc.nulls.ensure(host_nulls[c].size());
+                PA_HIP(hipMemcpyAsync(oc.nulls.ptr(), oc.h_nulls.ptr(), host_nulls[c].size(), hipMemcpyHostToDevice, s));
+            }
         }
     }
-    PA_HIP(hipStreamSynchronize(s));
+    if (to_device) PA_HIP(hipStreamSynchronize(s));
 }
 
 }  // namespace

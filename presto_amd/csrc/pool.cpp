@@ -1,0 +1,146 @@
+// pool.cpp -- size-class caches for HBM, pinned host memory and streams.  hipMalloc / hipHostMalloc /
+// hipStreamCreate cost 0.1-several ms each; an operator instance lives for one query, so without reuse
+// the allocator would dominate short queries (a fresh operator per query is the reference's model too:
+// OperatorFactory.createOperator, …/operator/OperatorFactory.java:18-50).
+#include <map>
+#include <mutex>
+
+#include "common.hpp"
+
+namespace pa {
+namespace {
+
+struct Pools {
+    std::mutex mu;
+    // key: (device, size class)
+    std::multimap<std::pair<int, size_t>, void*> device_free;
+    std::multimap<size_t, void*> pinned_free;
+    std::multimap<int, hipStream_t> stream_free;
+    size_t device_cached = 0, pinned_cached = 0;
+};
+Pools& pools()
+{
+    static Pools* p = new Pools();  // leaked on purpose: HIP may already be torn down at static destruction
+    return *p;
+}
+
+size_t size_class(size_t bytes)
+{
+    size_t c = 256;
+    while (c < bytes) c <<= 1;
+    return c;
+}
+
+constexpr size_t kMaxCachedDevice = 8ULL << 30;  // of 288 GB
+constexpr size_t kMaxCachedPinned = 1ULL << 30;
+
+}  // namespace
+
+void* pool_device_alloc(size_t bytes, size_t* granted)
+{
+    size_t c = size_class(bytes);
+    int dev = 0;
+    PA_HIP(hipGetDevice(&dev));
+    {
+        Pools& p = pools();
+        std::lock_guard<std::mutex> lock(p.mu);
+        auto it = p.device_free.find({dev, c});
+        if (it != p.device_free.end()) {
+            void* ptr = it->second;
+            p.device_free.erase(it);
+            p.device_cached -= c;
+            *granted = c;
+            return ptr;
+        }
+    }
+    void* ptr = nullptr;
+    PA_HIP(hipMalloc(&ptr, c));
+    *granted = c;
+    return ptr;
+}
+
+void pool_device_free(void* ptr, size_t granted)
+{
+    if (!ptr) return;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return;
+    Pools& p = pools();
+    {
+        std::lock_guard<std::mutex> lock(p.mu);
+        if (p.device_cached + granted <= kMaxCachedDevice) {
+            p.device_free.emplace(std::make_pair(dev, granted), ptr);
+            p.device_cached += granted;
+            return;
+        }
+    }
+    (void)hipFree(ptr);
+}
+
+void* pool_pinned_alloc(size_t bytes, size_t* granted)
+{
+    size_t c = size_class(bytes);
+    {
+        Pools& p = pools();
+        std::lock_guard<std::mutex> lock(p.mu);
+        auto it = p.pinned_free.find(c);
+        if (it != p.pinned_free.end()) {
+            void* ptr = it->second;
+            p.pinned_free.erase(it);
+            p.pinned_cached -= c;
+            *granted = c;
+            return ptr;
+        }
+    }
+    void* ptr = nullptr;
+    PA_HIP(hipHostMalloc(&ptr, c, hipHostMallocDefault));
+    *granted = c;
+    return ptr;
+}
+
+void pool_pinned_free(void* ptr, size_t granted)
+{
+    if (!ptr) return;
+    Pools& p = pools();
+    {
+        std::lock_guard<std::mutex> lock(p.mu);
+        if (p.pinned_cached + granted <= kMaxCachedPinned) {
+            p.pinned_free.emplace(granted, ptr);
+            p.pinned_cached += granted;
+            return;
+        }
+    }
+    (void)hipHostFree(ptr);
+}
+
+hipStream_t pool_stream_acquire()
+{
+    int dev = 0;
+    PA_HIP(hipGetDevice(&dev));
+    {
+        Pools& p = pools();
+        std::lock_guard<std::mutex> lock(p.mu);
+        auto it = p.stream_free.find(dev);
+        if (it != p.stream_free.end()) {
+            hipStream_t s = it->second;
+            p.stream_free.erase(it);
+            return s;
+        }
+    }
+    hipStream_t s = nullptr;
+    PA_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    return s;
+}
+
+void pool_stream_release(hipStream_t s)
+{
+    if (!s) return;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return;
+    // everything enqueued by the previous owner must be done before its buffers are recycled
+    (void)hipStreamSynchronize(s);
+    Pools& p = pools();
+    std::lock_guard<std::mutex> lock(p.mu);
+    p.stream_free.emplace(dev, s);
+}
+
+}  // namespace pa

@@ -125,8 +125,10 @@ void launch_merge_global_slab(const uint64_t* slab, int blocks, int nw, const in
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_merge_lds_slab(const u64* __restrict__ slab, i64 entries, int W, int NW,
                                                         const i32* __restrict__ kinds, u64* tag, u64* keys, u64* words, u32 mask,
-                                                        i32 max_fill, i32* count, i32* err)
+                                                        i32 max_fill, i32* count, i32* err, const u64* overflow_rows)
 {
+    // a launch whose register tables overflowed is discarded as a whole: the page is redone on the HBM table
+    if (*overflow_rows != 0ULL) return;
     const int stride = 1 + W + NW;
     for (i64 e = (i64)blockIdx.x * 256 + threadIdx.x; e < entries; e += (i64)gridDim.x * 256) {
         const u64* ent = slab + e * stride;
@@ -148,11 +150,11 @@ __global__ __launch_bounds__(256) void k_merge_lds_slab(const u64* __restrict__ 
 
 void launch_merge_lds_slab(const uint64_t* slab, int waves, int c, int w, int nw, const int32_t* kinds_dev, uint64_t* gt_tag,
                            uint64_t* gt_keys, uint64_t* gt_words, uint32_t gt_mask, int32_t gt_max_fill, int32_t* gt_count,
-                           int32_t* err, hipStream_t s)
+                           int32_t* err, const uint64_t* overflow_rows, hipStream_t s)
 {
     int64_t entries = (int64_t)waves * c;
     hipLaunchKernelGGL(k_merge_lds_slab, grid_for(entries, 256), 256, 0, s, (const u64*)slab, entries, w, nw, kinds_dev, (u64*)gt_tag,
-                       (u64*)gt_keys, (u64*)gt_words, gt_mask, gt_max_fill, gt_count, err);
+                       (u64*)gt_keys, (u64*)gt_words, gt_mask, gt_max_fill, gt_count, err, (const u64*)overflow_rows);
     PA_HIP(hipGetLastError());
 }
 
