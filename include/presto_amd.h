@@ -266,7 +266,8 @@ int32_t pa_lookup_join_create(const pa_lookup_join_desc* desc, pa_lookup_source*
 int32_t pa_op_needs_input(pa_operator* op);                 /* 1 / 0 */
 int32_t pa_op_add_input(pa_operator* op, const pa_page* page);
 /* Returns 1 and fills *out when a page is available, 0 when none.  The page's buffers are owned by
- * the operator and stay valid until the next get_output / close on the same handle. */
+ * the operator (or, for zero-copy identity projections, are the caller's own input buffers) and stay valid
+ * until the next add_input / get_output / close on the same handle. */
 int32_t pa_op_get_output(pa_operator* op, pa_page* out);
 int32_t pa_op_finish(pa_operator* op);
 int32_t pa_op_is_finished(pa_operator* op);                 /* 1 / 0 */
@@ -276,6 +277,19 @@ int32_t pa_op_close(pa_operator* op);
 /* Device time (ms) of the kernels the operator launched since creation, measured with HIP events
  * on the operator's stream; *launches = number of timed launches of its dominant kernel. */
 int32_t pa_op_kernel_time(pa_operator* op, double* total_ms, int64_t* launches);
+
+/* (probe position, build position) pairs of the probe page a LookupJoin operator joined last, in emission
+ * order (DefaultPageJoiner.java:236-320), valid after its get_output; device pointers. */
+int32_t pa_lookup_join_match_pairs(pa_operator* op, const int32_t** probe_positions, const int32_t** build_positions, int32_t* count);
+/* PagesHash.key[] (hash_size ints, -1 = empty) and ArrayPositionLinks.positionLinks[] (positions ints) of a built
+ * lookup source; device pointers. */
+int32_t pa_lookup_source_tables(pa_lookup_source* ls, const int32_t** key, int32_t* hash_size, const int32_t** position_links,
+                                int32_t* positions);
+
+/* SelectedPositions of the page a FilterAndProject operator processed last (valid after its get_output):
+ * *is_list == 0 means positionsRange(0, *count) (PageFilter.java:37-39: no or every row selected); otherwise
+ * *dev_positions points at *count ascending positions in HBM (PageFilter.java:41-49). */
+int32_t pa_filter_project_selected_positions(pa_operator* op, const int32_t** dev_positions, int32_t* count, int32_t* is_list);
 
 /* ---- stand-alone kernels of the path (used by exchange / tests; all device pointers) ---- */
 /* rawHash per position = InterpretedHashGenerator.hashPosition over `channels`
@@ -305,6 +319,16 @@ typedef enum pa_tpch_column {
  * [row_count+1] for VARCHAR columns).  Row r of a column depends only on (seed, column, r, scale). */
 int32_t pa_tpch_generate(int32_t column, double scale_factor, int64_t first_row, int64_t row_count,
                          uint64_t seed, void* values, int32_t* offsets, void* stream);
+
+/* ---- query-time code generation without a device (build step, CPU-side tests) ----
+ * pa_codegen_*: writes the generated gfx950 translation unit of a descriptor (all-non-null, aligned column
+ * layout) into buf (NUL terminated) and its cache key into key[17]; returns the needed buffer size.
+ * pa_codegen_compile_*: compiles it with hiprtc; returns the code-object size.  Negative = pa_status.
+ * variant: -1 default, 0 GLOBAL (no keys), 1 LDS (few groups), 2 GT (HBM table). */
+int64_t pa_codegen_fused(const pa_fused_aggregation_desc* desc, int32_t variant, char* buf, int64_t buf_size, char* key);
+int64_t pa_codegen_compile_fused(const pa_fused_aggregation_desc* desc, int32_t variant);
+int64_t pa_codegen_filter_project(const pa_filter_project_desc* desc, char* buf, int64_t buf_size, char* key);
+int64_t pa_codegen_compile_filter_project(const pa_filter_project_desc* desc);
 
 #ifdef __cplusplus
 }

@@ -70,6 +70,9 @@ def lib():
     L.pa_codegen_filter_project.restype = C.c_int64
     L.pa_codegen_compile_filter_project.argtypes = [C.POINTER(abi.pa_filter_project_desc)]
     L.pa_codegen_compile_filter_project.restype = C.c_int64
+    L.pa_filter_project_selected_positions.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    L.pa_lookup_join_match_pairs.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_int32)]
+    L.pa_lookup_source_tables.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_int32), C.POINTER(vp), C.POINTER(C.c_int32)]
     if L.pa_abi_version() != abi.ABI_VERSION:
         raise ImportError("libpresto_amd.so ABI version %d != %d" % (L.pa_abi_version(), abi.ABI_VERSION))
     _LIB = L

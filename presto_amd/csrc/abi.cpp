@@ -5,6 +5,7 @@
 #include "exprgen.hpp"
 #include "jit.hpp"
 #include "operator.hpp"
+#include "scan_kernels.hpp"
 #include "static_kernels.hpp"
 
 namespace pa {
@@ -80,11 +81,17 @@ static int32_t guarded(F&& f)
 
 }  // namespace pa
 
+namespace pa {
+int32_t filter_project_last_positions(pa_operator* op, const int32_t** dev_positions, int32_t* count, int32_t* is_list);
+}
 using namespace pa;
 
-struct pa_lookup_source {
-    std::shared_ptr<void> impl;  // filled by the hash builder (op_join.cpp)
-};
+namespace pa {
+pa_lookup_source* lookup_source_new();
+void lookup_source_delete(pa_lookup_source* ls);
+int32_t lookup_join_last_pairs(pa_operator* op, const int32_t** probe_idx, const int32_t** build_pos, int32_t* count);
+int32_t lookup_source_tables(pa_lookup_source* ls, const int32_t** key, int32_t* hash_size, const int32_t** links, int32_t* positions);
+}
 
 extern "C" {
 
@@ -255,14 +262,30 @@ int32_t pa_lookup_source_create(pa_lookup_source** out)
 {
     return guarded([&]() -> int32_t {
         PA_REQUIRE(out != nullptr, PA_ERR_INVALID_ARGUMENT, "out is null");
-        *out = new pa_lookup_source();
+        *out = lookup_source_new();
         return PA_OK;
     });
 }
 int32_t pa_lookup_source_destroy(pa_lookup_source* ls)
 {
-    delete ls;
-    return PA_OK;
+    return guarded([&]() -> int32_t {
+        if (ls) lookup_source_delete(ls);
+        return PA_OK;
+    });
+}
+int32_t pa_lookup_join_match_pairs(pa_operator* op, const int32_t** probe_positions, const int32_t** build_positions, int32_t* count)
+{
+    return guarded([&]() -> int32_t {
+        PA_REQUIRE(op && probe_positions && build_positions && count, PA_ERR_INVALID_ARGUMENT, "null argument");
+        return lookup_join_last_pairs(op, probe_positions, build_positions, count);
+    });
+}
+int32_t pa_lookup_source_tables(pa_lookup_source* ls, const int32_t** key, int32_t* hash_size, const int32_t** position_links, int32_t* positions)
+{
+    return guarded([&]() -> int32_t {
+        PA_REQUIRE(ls && key && hash_size && position_links && positions, PA_ERR_INVALID_ARGUMENT, "null argument");
+        return lookup_source_tables(ls, key, hash_size, position_links, positions);
+    });
 }
 int32_t pa_hash_builder_create(const pa_hash_builder_desc* desc, pa_lookup_source* bridge, pa_operator** out)
 {
@@ -419,6 +442,31 @@ int32_t pa_tpch_generate(int32_t column, double scale_factor, int64_t first_row,
     });
 }
 
+int32_t pa_filter_project_selected_positions(pa_operator* op, const int32_t** dev_positions, int32_t* count, int32_t* is_list)
+{
+    return guarded([&]() -> int32_t {
+        PA_REQUIRE(op != nullptr && dev_positions != nullptr && count != nullptr && is_list != nullptr, PA_ERR_INVALID_ARGUMENT, "null argument");
+        return filter_project_last_positions(op, dev_positions, count, is_list);
+    });
+}
+
+int32_t pa_partition_positions(const int32_t* partition, int32_t position_count, int32_t partition_count, int32_t* out_positions,
+                               int64_t* out_counts_host, void* stream)
+{
+    return guarded([&]() -> int32_t {
+        PA_REQUIRE(partition != nullptr && out_positions != nullptr && out_counts_host != nullptr, PA_ERR_INVALID_ARGUMENT, "null argument");
+        require_device();
+        hipStream_t s = (hipStream_t)stream;
+        DevBuf temp, counts;
+        temp.ensure(partition_temp_bytes(position_count, partition_count));
+        counts.ensure((size_t)partition_count * 8);
+        launch_partition_positions(partition, position_count, partition_count, out_positions, counts.as<int64_t>(), temp.ptr(), s);
+        PA_HIP(hipMemcpyAsync(out_counts_host, counts.ptr(), (size_t)partition_count * 8, hipMemcpyDeviceToHost, s));
+        PA_HIP(hipStreamSynchronize(s));
+        return PA_OK;
+    });
+}
+
 // ---- code generation without a device (build(), CPU-side tests) ----
 // Writes the generated translation unit of a fused descriptor into buf (NUL terminated) and its cache
 // key into key[17]; returns the needed buffer size.  variant: -1 default, 0 GLOBAL, 1 LDS, 2 GT.
@@ -448,6 +496,36 @@ int64_t pa_codegen_compile_fused(const pa_fused_aggregation_desc* desc, int32_t 
     int32_t rc = guarded([&]() -> int32_t {
         std::string entry;
         std::string src = fused_source_for_desc(desc, variant, &entry);
+        size = (int64_t)jit_compile_only(src).size();
+        return PA_OK;
+    });
+    return rc < 0 ? rc : size;
+}
+
+int64_t pa_codegen_filter_project(const pa_filter_project_desc* desc, char* buf, int64_t buf_size, char* key)
+{
+    int64_t need = 0;
+    int32_t rc = guarded([&]() -> int32_t {
+        std::string entry;
+        std::string src = filter_project_source_for_desc(desc, &entry);
+        std::string tu = jit_translation_unit(src);
+        need = (int64_t)tu.size() + 1;
+        if (buf && buf_size >= need) memcpy(buf, tu.c_str(), (size_t)need);
+        if (key) {
+            std::string k = jit_key(src);
+            memcpy(key, k.c_str(), k.size() + 1);
+        }
+        return PA_OK;
+    });
+    return rc < 0 ? rc : need;
+}
+
+int64_t pa_codegen_compile_filter_project(const pa_filter_project_desc* desc)
+{
+    int64_t size = 0;
+    int32_t rc = guarded([&]() -> int32_t {
+        std::string entry;
+        std::string src = filter_project_source_for_desc(desc, &entry);
         size = (int64_t)jit_compile_only(src).size();
         return PA_OK;
     });

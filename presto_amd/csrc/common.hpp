@@ -81,6 +81,22 @@ public:
         }
         return p_;
     }
+    // grows keeping the first `used` bytes; the old allocation is recycled only after the copy completed
+    void* reserve_keep(size_t bytes, size_t used, hipStream_t s)
+    {
+        if (bytes <= cap_) return p_;
+        size_t ncap = 0;
+        size_t want = bytes > 2 * cap_ ? bytes : 2 * cap_;
+        void* np = pool_device_alloc(want, &ncap);
+        if (p_ && used) {
+            PA_HIP(hipMemcpyAsync(np, p_, used, hipMemcpyDeviceToDevice, s));
+            PA_HIP(hipStreamSynchronize(s));
+        }
+        release();
+        p_ = np;
+        cap_ = ncap;
+        return p_;
+    }
     void release()
     {
         if (p_) pool_device_free(p_, cap_);

@@ -1,0 +1,205 @@
+// join_kernels.hip -- hash join build and probe on device.
+//
+// Layout follows the reference's PagesHash: key[hashSize] (int32, -1 = empty) holds a *build position*,
+// positionLinks[n] chains equal keys, the head of a chain is the LAST inserted (= highest) position and
+// the chain descends, so a probe row emits its matches in descending build position
+// (…/operator/join/PagesHash.java:77-120, …/ArrayPositionLinks.java:45-50).
+// Build pages are concatenated into flat columns, so address == position.
+// The probe is random access into key[] and the build key columns: transaction-bound, not streaming.
+#include <hip/hip_runtime.h>
+
+#include "join_kernels.hpp"
+#include "kernels/pa_device.h"
+
+namespace pa {
+
+static inline int grid_for(int64_t work)
+{
+    int64_t g = (work + 255) / 256;
+    if (g < 1) g = 1;
+    if (g > 256 * 16) g = 256 * 16;
+    return (int)g;
+}
+
+__device__ __forceinline__ bool jcol_is_null(const JoinCol& c, i32 r) { return c.nulls && c.nulls[r]; }
+
+// positionEqualsRowIgnoreNulls: plain EQUAL on non-null values (DOUBLE: ==, so NaN never matches)
+__device__ __forceinline__ bool jcol_equal(const JoinCol& a, i32 ra, const JoinCol& b, i32 rb)
+{
+    switch (a.type) {
+        case PA_BIGINT: return ((const i64*)a.values)[ra] == ((const i64*)b.values)[rb];
+        case PA_INTEGER:
+        case PA_DATE: return ((const i32*)a.values)[ra] == ((const i32*)b.values)[rb];
+        case PA_DOUBLE: return ((const double*)a.values)[ra] == ((const double*)b.values)[rb];
+        case PA_BOOLEAN: return (((const u8*)a.values)[ra] != 0) == (((const u8*)b.values)[rb] != 0);
+        case PA_VARCHAR: {
+            i32 oa = a.offsets[ra], ob = b.offsets[rb];
+            return pa_str_eq((const u8*)a.values + oa, a.offsets[ra + 1] - oa, (const u8*)b.values + ob, b.offsets[rb + 1] - ob);
+        }
+        default: return false;
+    }
+}
+__device__ __forceinline__ bool keys_equal(const JoinKeys& a, i32 ra, const JoinKeys& b, i32 rb)
+{
+    for (int c = 0; c < a.ncols; c++) {
+        if (!jcol_equal(a.col[c], ra, b.col[c], rb)) return false;
+    }
+    return true;
+}
+__device__ __forceinline__ bool keys_have_null(const JoinKeys& k, i32 r)
+{
+    for (int c = 0; c < k.ncols; c++) {
+        if (jcol_is_null(k.col[c], r)) return true;
+    }
+    return false;
+}
+
+// Phase A: every non-null build position finds / claims the slot of its key; the slot ends up holding the
+// highest position of the key (atomicMax), exactly the head the reference's sequential insertion leaves.
+__global__ __launch_bounds__(256) void k_join_build_slots(JoinKeys build, const i64* __restrict__ raw_hash, i32 n, i32* key, u32 mask,
+                                                          i32* __restrict__ slot_of, i32* err)
+{
+    for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < n; i += (i64)gridDim.x * 256) {
+        const i32 p = (i32)i;
+        if (keys_have_null(build, p)) {  // PagesHash.java:95-97: rows with a NULL key are not inserted
+            slot_of[p] = -1;
+            continue;
+        }
+        u32 pos = (u32)pa_murmur3_fmix((u64)raw_hash[p]) & mask;
+        u32 probes = 0;
+        for (;;) {
+            i32 cur = __hip_atomic_load(&key[pos], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (cur == -1) {
+                i32 old = atomicCAS(&key[pos], -1, p);
+                if (old == -1) break;
+                cur = old;
+            }
+            // build columns are immutable: any position ever stored in this slot carries the slot's key
+            if (raw_hash[cur] == raw_hash[p] && keys_equal(build, cur, build, p)) {
+                atomicMax(&key[pos], p);
+                break;
+            }
+            pos = (pos + 1) & mask;
+            if (++probes > mask) {
+                pa_raise(err, PA_DEV_ERR_RESOURCES);
+                break;
+            }
+        }
+        slot_of[p] = (i32)pos;
+    }
+}
+
+// Phase B: positionLinks.  Each key's chain is a list sorted by descending position starting at the head
+// (= key[slot]).  A non-head position inserts itself with a lock-free sorted-list insertion (no deletions):
+// publication order = links[p] store (sc1) -> s_waitcnt vmcnt(0) -> CAS on the predecessor.
+__global__ __launch_bounds__(256) void k_join_build_links(i32 n, const i32* __restrict__ key, const i32* __restrict__ slot_of, i32* links)
+{
+    for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < n; i += (i64)gridDim.x * 256) {
+        const i32 p = (i32)i;
+        const i32 slot = slot_of[p];
+        if (slot < 0) continue;
+        i32 a = key[slot];
+        if (a == p) continue;  // the head; its link is set by whoever inserts right after it
+        for (;;) {
+            i32 nxt = __hip_atomic_load(&links[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (nxt > p) {
+                a = nxt;
+                continue;
+            }
+            __hip_atomic_store(&links[p], nxt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (atomicCAS(&links[a], nxt, p) == nxt) break;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_fill_i32(i32* __restrict__ dst, i32 v, i64 n)
+{
+    for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < n; i += (i64)gridDim.x * 256) dst[i] = v;
+}
+void launch_fill_i32(int32_t* dst, int32_t value, int64_t n, hipStream_t s)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_fill_i32, grid_for(n), 256, 0, s, dst, value, (i64)n);
+    PA_HIP(hipGetLastError());
+}
+
+__global__ __launch_bounds__(256) void k_rebase_offsets(const i32* __restrict__ in, i32 in_base, i32 out_base, i64 n, i32* __restrict__ out)
+{
+    for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < n; i += (i64)gridDim.x * 256) out[i] = in[i] - in_base + out_base;
+}
+void launch_rebase_offsets(const int32_t* in, int32_t in_base, int32_t out_base, int64_t n_plus_1, int32_t* out, hipStream_t s)
+{
+    if (n_plus_1 <= 0) return;
+    hipLaunchKernelGGL(k_rebase_offsets, grid_for(n_plus_1), 256, 0, s, in, in_base, out_base, (i64)n_plus_1, out);
+    PA_HIP(hipGetLastError());
+}
+
+void launch_join_build(const JoinKeys& build, const int64_t* raw_hash, int32_t n, int32_t* key, uint32_t mask, int32_t* slot_of,
+                       int32_t* links, int32_t* err, hipStream_t s)
+{
+    launch_fill_i32(key, -1, (int64_t)mask + 1, s);
+    if (n <= 0) return;
+    launch_fill_i32(links, -1, n, s);
+    hipLaunchKernelGGL(k_join_build_slots, grid_for(n), 256, 0, s, build, (const i64*)raw_hash, n, key, mask, slot_of, err);
+    hipLaunchKernelGGL(k_join_build_links, grid_for(n), 256, 0, s, n, (const i32*)key, (const i32*)slot_of, links);
+    PA_HIP(hipGetLastError());
+}
+
+__global__ __launch_bounds__(256) void k_join_probe_count(JoinKeys build, JoinKeys probe, const i64* __restrict__ probe_hash, i32 n_probe,
+                                                          const i32* __restrict__ key, u32 mask, const i32* __restrict__ links,
+                                                          i32* __restrict__ head, i32* __restrict__ counts)
+{
+    for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < n_probe; i += (i64)gridDim.x * 256) {
+        const i32 r = (i32)i;
+        i32 h = -1;
+        if (!keys_have_null(probe, r)) {  // JoinProbe.java:89-91
+            u32 pos = (u32)pa_murmur3_fmix((u64)probe_hash[r]) & mask;
+            for (u32 probes = 0; probes <= mask; probes++) {
+                i32 cur = key[pos];
+                if (cur == -1) break;
+                if (keys_equal(build, cur, probe, r)) {
+                    h = cur;
+                    break;
+                }
+                pos = (pos + 1) & mask;
+            }
+        }
+        head[r] = h;
+        i32 c = 0;
+        for (i32 j = h; j != -1; j = links[j]) c++;
+        counts[r] = c;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_join_probe_emit(const i32* __restrict__ head, const i32* __restrict__ offsets, i32 n_probe,
+                                                         const i32* __restrict__ links, i32* __restrict__ probe_idx, i32* __restrict__ build_pos)
+{
+    for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < n_probe; i += (i64)gridDim.x * 256) {
+        const i32 r = (i32)i;
+        i32 o = offsets[r];
+        for (i32 j = head[r]; j != -1; j = links[j]) {
+            probe_idx[o] = r;
+            build_pos[o] = j;
+            o++;
+        }
+    }
+}
+
+void launch_join_probe_count(const JoinKeys& build, const JoinKeys& probe, const int64_t* probe_hash, int32_t n_probe, const int32_t* key,
+                             uint32_t mask, const int32_t* links, int32_t* head, int32_t* counts, hipStream_t s)
+{
+    if (n_probe <= 0) return;
+    hipLaunchKernelGGL(k_join_probe_count, grid_for(n_probe), 256, 0, s, build, probe, (const i64*)probe_hash, n_probe, key, mask, links, head,
+                       counts);
+    PA_HIP(hipGetLastError());
+}
+void launch_join_probe_emit(const int32_t* head, const int32_t* offsets, int32_t n_probe, const int32_t* links, int32_t* probe_idx,
+                            int32_t* build_pos, hipStream_t s)
+{
+    if (n_probe <= 0) return;
+    hipLaunchKernelGGL(k_join_probe_emit, grid_for(n_probe), 256, 0, s, head, offsets, n_probe, links, probe_idx, build_pos);
+    PA_HIP(hipGetLastError());
+}
+
+}  // namespace pa

@@ -1,0 +1,35 @@
+// join_kernels.hpp -- launchers of join_kernels.hip.
+#pragma once
+
+#include "common.hpp"
+
+namespace pa {
+
+constexpr int kMaxJoinChannels = 8;
+
+struct JoinCol {
+    const void* values;
+    const int32_t* offsets;
+    const uint8_t* nulls;
+    int32_t type;
+    int32_t pad;
+};
+struct JoinKeys {
+    JoinCol col[kMaxJoinChannels];
+    int32_t ncols;
+    int32_t pad;
+};
+
+// PagesHash constructor (…/operator/join/PagesHash.java:54-126) + ArrayPositionLinks (…/ArrayPositionLinks.java:38-50)
+void launch_join_build(const JoinKeys& build, const int64_t* raw_hash, int32_t n, int32_t* key, uint32_t mask, int32_t* slot_of,
+                       int32_t* links, int32_t* err, hipStream_t s);
+// PagesHash.getAddressIndex + chain length per probe row (…/PagesHash.java:158-170, JoinProbe.java:87-117)
+void launch_join_probe_count(const JoinKeys& build, const JoinKeys& probe, const int64_t* probe_hash, int32_t n_probe, const int32_t* key,
+                             uint32_t mask, const int32_t* links, int32_t* head, int32_t* counts, hipStream_t s);
+// DefaultPageJoiner.joinCurrentPosition: (probe position, build position) pairs in emission order
+void launch_join_probe_emit(const int32_t* head, const int32_t* offsets, int32_t n_probe, const int32_t* links, int32_t* probe_idx,
+                            int32_t* build_pos, hipStream_t s);
+void launch_fill_i32(int32_t* dst, int32_t value, int64_t n, hipStream_t s);
+void launch_rebase_offsets(const int32_t* in, int32_t in_base, int32_t out_base, int64_t n_plus_1, int32_t* out, hipStream_t s);
+
+}  // namespace pa

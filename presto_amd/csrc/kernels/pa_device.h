@@ -386,3 +386,47 @@ __device__ __forceinline__ void pa_gt_add_i64_exact(u64* words, u64 idx, i64 v, 
     i64 r;
     if (__builtin_add_overflow(old, v, &r)) pa_raise(err, PA_DEV_ERR_OUT_OF_RANGE);
 }
+
+// ---------------------------------------------------------------------------------------------
+// workgroup (256 threads) exclusive scan of small per-thread counts: wave shuffles + LDS
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ i32 pa_block_exclusive_scan_256(i32 v, i32* total)
+{
+    __shared__ i32 pa_scan_wave_sums[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    i32 inc = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        i32 o = __shfl_up(inc, off, 64);
+        if (lane >= off) inc += o;
+    }
+    if (lane == 63) pa_scan_wave_sums[wave] = inc;
+    __syncthreads();
+    i32 base = 0, all = 0;
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        i32 s = pa_scan_wave_sums[w];
+        if (w < wave) base += s;
+        all += s;
+    }
+    __syncthreads();
+    *total = all;
+    return base + inc - v;
+}
+
+// Kernel argument block of the generated FilterAndProject kernels (op_filter_project.cpp mirrors it).
+struct PaFpArgs {
+    const void* v[PA_MAX_CHANNELS];
+    const i32* o[PA_MAX_CHANNELS];
+    const u8* nl[PA_MAX_CHANNELS];
+    void* out_v[PA_MAX_CHANNELS];   // per projection: output values (worst case n entries)
+    u8* out_nl[PA_MAX_CHANNELS];    // per projection: output nulls or nullptr
+    i64 n;
+    i32 vec;
+    i32 pad;
+    u8* sel4;                       // 4 selection bits per row quad (filter result, PageFilter.filter)
+    i32* tile_counts;               // selected rows per 1024-row tile
+    const i32* tile_offsets;        // exclusive scan of tile_counts
+    i32* positions;                 // SelectedPositions.positions (ascending), worst case n entries
+    i32* err;
+};

@@ -1,0 +1,411 @@
+// op_filter_project.cpp -- FilterAndProjectOperator on device: one input Page -> at most one output Page
+// holding the projections of the selected rows in input order.
+//
+// Reference path replaced:
+//   FilterAndProjectOperator (…/operator/FilterAndProjectOperator.java:37-71)
+//   PageProcessor.createWorkProcessor / ProjectSelectedPositions (…/operator/project/PageProcessor.java:111-137, 180-263)
+//   generated PageFilter.filter + PageFilter.positionsArrayToSelectedPositions (…/sql/gen/PageFunctionCompiler.java:459-544,
+//     …/operator/project/PageFilter.java:27-50)
+//   generated PageProjectionWork.process (…/sql/gen/PageFunctionCompiler.java:283-320), InputPageProjection.project
+//     (…/operator/project/InputPageProjection.java:57-70: identity = getRegion / copyPositions)
+// Batch boundaries of the reference (adaptive 1..8192-row batches, MergePages re-chunking) are not part of the
+// result: the device operator emits the whole page's output at once.
+//
+// Kernels (generated per expression set and column-layout signature):
+//   pa_fp_count    filter per row -> 4 selection bits per row quad + selected rows per 1024-row tile
+//   (scan)         exclusive scan of the tile counts (scan_kernels.hip)
+//   pa_fp_scatter  ranks inside the tile by workgroup scan, evaluates the projections of the selected rows and
+//                  writes them (and the ascending positions list) compacted
+// Both are HBM-bound: filter columns are read once, projection inputs once, outputs written once.
+#include <map>
+#include <sstream>
+
+#include "exprgen.hpp"
+#include "jit.hpp"
+#include "operator.hpp"
+#include "rowgen.hpp"
+#include "scan_kernels.hpp"
+
+namespace pa {
+namespace {
+
+constexpr int kMaxChannels = 32;
+constexpr int kTileRows = 1024;
+
+struct FpArgs {  // host mirror of PaFpArgs
+    const void* v[kMaxChannels];
+    const int32_t* o[kMaxChannels];
+    const uint8_t* nl[kMaxChannels];
+    void* out_v[kMaxChannels];
+    uint8_t* out_nl[kMaxChannels];
+    int64_t n;
+    int32_t vec;
+    int32_t pad;
+    uint8_t* sel4;
+    int32_t* tile_counts;
+    const int32_t* tile_offsets;
+    int32_t* positions;
+    int32_t* err;
+};
+
+struct FpSpec {
+    int n_in = 0;
+    std::vector<int32_t> in_types;
+    bool has_filter = false;
+    OwnedExpr filter;
+    std::vector<OwnedExpr> proj;
+    int output_mem = PA_MEM_HOST;
+    std::vector<bool> used_channel;
+};
+
+struct FpKernelInfo {
+    std::string source;
+    std::vector<bool> proj_nullable;
+};
+
+FpSpec make_fp_spec(const pa_filter_project_desc* d)
+{
+    PA_REQUIRE(d != nullptr, PA_ERR_INVALID_ARGUMENT, "descriptor is null");
+    FpSpec s;
+    PA_REQUIRE(d->input_channel_count >= 0 && d->input_channel_count <= kMaxChannels, PA_ERR_NOT_SUPPORTED, "at most 32 input channels");
+    PA_REQUIRE(d->projection_count >= 0 && d->projection_count <= kMaxChannels, PA_ERR_NOT_SUPPORTED, "at most 32 projections");
+    s.n_in = d->input_channel_count;
+    if (s.n_in) s.in_types.assign(d->input_types, d->input_types + s.n_in);
+    s.has_filter = d->filter != nullptr;
+    if (s.has_filter) {
+        s.filter = OwnedExpr::copy(*d->filter);
+        PA_REQUIRE(s.filter.root_type() == PA_BOOLEAN, PA_ERR_INVALID_ARGUMENT, "filter must be BOOLEAN");
+    }
+    for (int32_t j = 0; j < d->projection_count; j++) {
+        s.proj.push_back(OwnedExpr::copy(d->projections[j]));
+        const OwnedExpr& e = s.proj.back();
+        PA_REQUIRE(e.root_type() != PA_VARCHAR || e.is_input_ref(), PA_ERR_NOT_SUPPORTED,
+                   "VARCHAR projections other than plain input references are not on the device path");
+    }
+    s.output_mem = d->output_mem;
+    std::set<int32_t> used;
+    if (s.has_filter) s.filter.collect_channels(&used);
+    for (const auto& e : s.proj) e.collect_channels(&used);
+    s.used_channel.assign(s.n_in, false);
+    for (int32_t c : used) {
+        PA_REQUIRE(c >= 0 && c < s.n_in, PA_ERR_INVALID_ARGUMENT, "expression references a channel outside the page");
+        s.used_channel[c] = true;
+    }
+    return s;
+}
+
+FpKernelInfo generate_fp(const FpSpec& s, const std::vector<ChannelLayout>& layout)
+{
+    FpKernelInfo k;
+    RowInputs ri;
+    ri.n_in = s.n_in;
+    ri.used = s.used_channel;
+    ri.short_bound.assign(s.n_in, 0);
+    std::ostringstream src;
+    const std::string params = row_params(ri, layout);
+
+    // filter: bool pa_sel(args, row...)
+    src << "__device__ __forceinline__ bool pa_sel(const PaFpArgs& a" << params << ")\n{\n";
+    if (s.has_filter) {
+        RowCodegen gen(layout, "a.err");
+        std::ostringstream body;
+        GenValue f = gen.emit(s.filter, body);
+        src << body.str() << "return " << (f.nullable() ? "(!" + f.n + " && " + f.v + ")" : f.v) << ";\n";  // PageFunctionCompiler.java:539-542
+    }
+    else {
+        src << "return true;\n";
+    }
+    src << "}\n";
+
+    // projections of one selected row written at output position `rank`
+    src << "__device__ __forceinline__ void pa_out(const PaFpArgs& a, i64 rank, i32 row" << params << ")\n{\n";
+    src << "if (a.positions) a.positions[rank] = row;\n";
+    {
+        RowCodegen gen(layout, "a.err");
+        std::ostringstream body;
+        for (size_t j = 0; j < s.proj.size(); j++) {
+            const OwnedExpr& e = s.proj[j];
+            if (e.root_type() == PA_VARCHAR) {  // gathered afterwards through the positions list
+                k.proj_nullable.push_back(layout[e.node(e.root).channel].nullable);
+                continue;
+            }
+            GenValue v = gen.emit(e, body);
+            const char* ct = nullptr;
+            std::string val = v.v;
+            switch (e.root_type()) {
+                case PA_BIGINT: ct = "i64"; break;
+                case PA_INTEGER:
+                case PA_DATE: ct = "i32"; val = "(i32)" + val; break;
+                case PA_DOUBLE: ct = "double"; break;
+                case PA_BOOLEAN: ct = "u8"; val = "(" + val + " ? (u8)1 : (u8)0)"; break;
+                default: throw Error(PA_ERR_NOT_SUPPORTED, "projection type not supported on device");
+            }
+            // NULL rows store a zero value, as BlockBuilder.appendNull does
+            std::string stored = v.nullable() ? "(" + v.n + ") ? (" + ct + ")0 : (" + ct + ")(" + val + ")" : val;
+            body << "((" << ct << "*)a.out_v[" << j << "])[rank] = " << stored << ";\n";
+            if (v.nullable()) body << "a.out_nl[" << j << "][rank] = (" << v.n << ") ? (u8)1 : (u8)0;\n";
+            k.proj_nullable.push_back(v.nullable());
+        }
+        src << body.str();
+    }
+    src << "}\n\n";
+
+    std::string vargs[4];
+    std::ostringstream vloads;
+    emit_vector_loads(ri, layout, vloads, vargs);
+    const std::string sargs = scalar_args(ri, layout);
+
+    if (s.has_filter) {
+        src << "extern \"C\" __global__ __launch_bounds__(256) void pa_fp_count(PaFpArgs a)\n{\n";
+        src << "    const i64 q = (i64)blockIdx.x * 256 + threadIdx.x;\n    const i64 row0 = q << 2;\n    u32 bits = 0;\n";
+        src << "    if (a.vec && row0 + 4 <= a.n) {\n" << vloads.str();
+        for (int r = 0; r < 4; r++) src << "        if (pa_sel(a" << vargs[r] << ")) bits |= " << (1 << r) << "u;\n";
+        src << "    } else {\n        for (int i = 0; i < 4; i++) {\n            const i64 r = row0 + i;\n"
+               "            if (r < a.n) { if (pa_sel(a" << sargs << ")) bits |= 1u << i; }\n        }\n    }\n";
+        src << "    if (row0 < a.n) a.sel4[q] = (u8)bits;\n";
+        src << "    i32 total;\n    (void)pa_block_exclusive_scan_256((i32)__popc(bits), &total);\n";
+        src << "    if (threadIdx.x == 0) a.tile_counts[blockIdx.x] = total;\n}\n\n";
+    }
+    src << "extern \"C\" __global__ __launch_bounds__(256) void pa_fp_scatter(PaFpArgs a)\n{\n";
+    src << "    const i64 q = (i64)blockIdx.x * 256 + threadIdx.x;\n    const i64 row0 = q << 2;\n";
+    if (s.has_filter) {
+        src << "    const u32 bits = row0 < a.n ? (u32)a.sel4[q] : 0u;\n";
+        src << "    i32 total;\n    i64 rank = (i64)a.tile_offsets[blockIdx.x] + pa_block_exclusive_scan_256((i32)__popc(bits), &total);\n";
+        src << "    if (bits == 0u) return;\n";
+    }
+    else {
+        src << "    if (row0 >= a.n) return;\n    const i64 left = a.n - row0;\n    const u32 bits = left >= 4 ? 15u : ((1u << left) - 1u);\n    i64 rank = row0;\n";
+    }
+    src << "    if (a.vec && row0 + 4 <= a.n) {\n" << vloads.str();
+    for (int r = 0; r < 4; r++) {
+        src << "        if (bits & " << (1 << r) << "u) { pa_out(a, rank, (i32)(row0 + " << r << ")" << vargs[r] << "); rank++; }\n";
+    }
+    src << "    } else {\n        for (int i = 0; i < 4; i++) {\n            const i64 r = row0 + i;\n"
+           "            if (r < a.n && (bits & (1u << i))) { pa_out(a, rank, (i32)r" << sargs << "); rank++; }\n        }\n    }\n}\n";
+    k.source = src.str();
+    return k;
+}
+
+class FilterProjectOperator : public pa_operator {
+public:
+    explicit FilterProjectOperator(const pa_filter_project_desc* d) : spec_(make_fp_spec(d)), stream_(d->stream)
+    {
+        require_device();
+        ctl_ = static_cast<int32_t*>(ctl_buf_.ensure(64));  // [0] err [1] selected count
+        PA_HIP(hipMemsetAsync(ctl_, 0, 64, stream_.get()));
+        h_ctl_ = static_cast<int32_t*>(h_ctl_buf_.ensure(64));
+        out_cols_.resize(spec_.proj.size());
+    }
+    ~FilterProjectOperator() override { (void)hipStreamSynchronize(stream_.get()); }
+
+    bool needs_input() override { return !finishing_ && !pending_; }
+
+    void add_input(const pa_page* page) override
+    {
+        PA_REQUIRE(!finishing_, PA_ERR_ILLEGAL_STATE, "Operator is already finishing");
+        PA_REQUIRE(!pending_, PA_ERR_ILLEGAL_STATE, "Operator still holds an output page");
+        PA_REQUIRE(page != nullptr, PA_ERR_INVALID_ARGUMENT, "page is null");
+        PA_REQUIRE(page->channel_count == spec_.n_in, PA_ERR_INVALID_ARGUMENT, "page channel count does not match the operator's input types");
+        if (page->position_count == 0) return;  // PageProcessor.java:113-115
+        hipStream_t s = stream_.get();
+        in_ = stager_.stage(page, &spec_.used_channel, s);
+        in_device_ = page->mem == PA_MEM_DEVICE;
+        const int64_t n = in_.n;
+        std::vector<ChannelLayout> layout(spec_.n_in);
+        std::string sig;
+        bool vec = true;
+        for (int c = 0; c < spec_.n_in; c++) {
+            layout[c].type = spec_.used_channel[c] ? in_.cols[c].type : spec_.in_types[c];
+            layout[c].nullable = spec_.used_channel[c] && in_.cols[c].nulls != nullptr;
+            if (spec_.used_channel[c]) {
+                PA_REQUIRE(in_.cols[c].type == spec_.in_types[c], PA_ERR_INVALID_ARGUMENT, "page block type does not match the declared input type");
+                vec = vec && ((uintptr_t)in_.cols[c].values % 16 == 0) && ((uintptr_t)in_.cols[c].offsets % 16 == 0) &&
+                      ((uintptr_t)in_.cols[c].nulls % 4 == 0);
+            }
+            sig += layout[c].nullable ? 'n' : '-';
+        }
+        Compiled& ck = kernel_for(sig, layout);
+        cur_ = &ck;
+        const int64_t tiles = (n + kTileRows - 1) / kTileRows;
+        FpArgs a;
+        memset(&a, 0, sizeof a);
+        for (int c = 0; c < spec_.n_in; c++) {
+            if (!spec_.used_channel[c]) continue;
+            a.v[c] = in_.cols[c].values;
+            a.o[c] = in_.cols[c].offsets;
+            a.nl[c] = in_.cols[c].nulls;
+        }
+        a.n = n;
+        a.vec = vec ? 1 : 0;
+        a.err = ctl_;
+        need_positions_ = false;
+        for (size_t j = 0; j < spec_.proj.size(); j++) {
+            OutColumn& oc = out_cols_[j];
+            const OwnedExpr& e = spec_.proj[j];
+            oc.type = e.root_type();
+            oc.varwidth = oc.type == PA_VARCHAR;
+            oc.has_nulls = ck.info.proj_nullable[j];
+            oc.is_view = false;
+            oc.host_ready = false;
+            if (oc.varwidth) {
+                need_positions_ = need_positions_ || spec_.has_filter;
+                continue;
+            }
+            a.out_v[j] = oc.values.ensure((size_t)n * type_width(oc.type));
+            if (oc.has_nulls) a.out_nl[j] = static_cast<uint8_t*>(oc.nulls.ensure((size_t)n));
+        }
+        if (spec_.has_filter) {
+            a.sel4 = static_cast<uint8_t*>(sel4_.ensure((size_t)(n + 3) / 4));
+            a.tile_counts = static_cast<int32_t*>(tile_counts_.ensure((size_t)tiles * 4));
+            a.positions = static_cast<int32_t*>(positions_.ensure((size_t)n * 4));
+            a.tile_offsets = a.tile_counts;  // scanned in place
+            void* params[] = {&a};
+            timer.begin(s);
+            PA_HIP(hipModuleLaunchKernel(ck.count_fn, (unsigned)tiles, 1, 1, 256, 1, 1, 0, s, params, nullptr));
+            launch_exclusive_scan_i32(a.tile_counts, a.tile_counts, tiles, ctl_ + 1, scan_temp_.ensure(scan_temp_bytes(tiles)), s);
+            PA_HIP(hipModuleLaunchKernel(ck.scatter_fn, (unsigned)tiles, 1, 1, 256, 1, 1, 0, s, params, nullptr));
+            timer.end(s);
+        }
+        else {
+            void* params[] = {&a};
+            timer.begin(s);
+            if (!spec_.proj.empty()) PA_HIP(hipModuleLaunchKernel(ck.scatter_fn, (unsigned)tiles, 1, 1, 256, 1, 1, 0, s, params, nullptr));
+            timer.end(s);
+        }
+        PA_HIP(hipMemcpyAsync(h_ctl_, ctl_, 8, hipMemcpyDeviceToHost, s));
+        pending_ = true;
+    }
+
+    bool get_output(pa_page* out) override
+    {
+        if (!pending_) return false;
+        pending_ = false;
+        hipStream_t s = stream_.get();
+        PA_HIP(hipStreamSynchronize(s));
+        const int32_t err = h_ctl_[0];
+        if (err != 0) {
+            PA_HIP(hipMemsetAsync(ctl_, 0, 4, s));
+            switch (err) {
+                case PA_ERR_NUMERIC_VALUE_OUT_OF_RANGE: throw Error(err, "numeric value out of range (bigint/integer arithmetic overflow)");
+                case PA_ERR_DIVISION_BY_ZERO: throw Error(err, "Division by zero");
+                default: throw Error(err, "device-side error");
+            }
+        }
+        const int32_t n = in_.n;
+        const int32_t count = spec_.has_filter ? h_ctl_[1] : n;
+        last_count_ = count;
+        last_is_list_ = count != 0 && count != n;  // PageFilter.java:37-39: range when none or all rows pass
+        if (count == 0) return false;  // PageProcessor.java:127-129
+        for (size_t j = 0; j < spec_.proj.size(); j++) {
+            OutColumn& oc = out_cols_[j];
+            const OwnedExpr& e = spec_.proj[j];
+            const bool identity = e.is_input_ref();
+            if (identity && count == n) {
+                // positionsRange(0, n): InputPageProjection returns block.getRegion -> zero copy
+                const DevColumn& src = in_.cols[e.node(e.root).channel];
+                oc.is_view = true;
+                oc.view_values = src.values;
+                oc.view_offsets = src.offsets;
+                oc.view_nulls = src.nulls;
+                oc.has_nulls = src.nulls != nullptr;
+                continue;
+            }
+            if (oc.varwidth) {
+                // Block.copyPositions for a VariableWidthBlock: lengths -> exclusive scan -> byte copy
+                const DevColumn& src = in_.cols[e.node(e.root).channel];
+                int32_t* lens = static_cast<int32_t*>(oc.offsets.ensure((size_t)(count + 1) * 4));
+                launch_varwidth_lengths(positions_.as<int32_t>(), count, src.offsets, src.nulls, lens, s);
+                launch_exclusive_scan_i32(lens, lens, count, ctl_ + 2, scan_temp_.ensure(scan_temp_bytes(count)), s);
+                PA_HIP(hipMemcpyAsync(h_ctl_ + 2, ctl_ + 2, 4, hipMemcpyDeviceToHost, s));
+                PA_HIP(hipStreamSynchronize(s));
+                int32_t total = h_ctl_[2];
+                uint8_t* bytes = static_cast<uint8_t*>(oc.values.ensure((size_t)(total > 0 ? total : 1)));
+                launch_varwidth_copy(positions_.as<int32_t>(), count, src.offsets, static_cast<const uint8_t*>(src.values), src.nulls, lens, bytes,
+                                     ctl_ + 2, s);
+                if (src.nulls) {
+                    launch_gather_nulls(src.nulls, positions_.as<int32_t>(), count, static_cast<uint8_t*>(oc.nulls.ensure((size_t)count)), s);
+                    oc.has_nulls = true;
+                }
+                else {
+                    oc.has_nulls = false;
+                }
+            }
+        }
+        publish_output(out_cols_, count, spec_.output_mem, s, out, out_storage_);
+        return true;
+    }
+
+    void finish() override { finishing_ = true; }
+    bool is_finished() override { return finishing_ && !pending_; }
+    bool is_blocked() override { return false; }
+    int64_t memory_bytes() override { return (int64_t)(stager_.bytes() + sel4_.capacity() + positions_.capacity() + tile_counts_.capacity()); }
+
+    // SelectedPositions of the last processed page (after its get_output)
+    void last_positions(const int32_t** dev_positions, int32_t* count, int32_t* is_list) const
+    {
+        *dev_positions = positions_.as<int32_t>();
+        *count = last_count_;
+        *is_list = last_is_list_ ? 1 : 0;
+    }
+
+private:
+    struct Compiled {
+        FpKernelInfo info;
+        hipFunction_t count_fn = nullptr, scatter_fn = nullptr;
+    };
+
+    Compiled& kernel_for(const std::string& sig, const std::vector<ChannelLayout>& layout)
+    {
+        auto it = compiled_.find(sig);
+        if (it != compiled_.end()) return *it->second;
+        auto c = std::make_unique<Compiled>();
+        c->info = generate_fp(spec_, layout);
+        if (spec_.has_filter) c->count_fn = jit_get(c->info.source, "pa_fp_count").fn;
+        c->scatter_fn = jit_get(c->info.source, "pa_fp_scatter").fn;
+        Compiled& ref = *c;
+        compiled_[sig] = std::move(c);
+        return ref;
+    }
+
+    FpSpec spec_;
+    Stream stream_;
+    PageStager stager_;
+    std::map<std::string, std::unique_ptr<Compiled>> compiled_;
+    Compiled* cur_ = nullptr;
+    DevPage in_;
+    bool in_device_ = false, finishing_ = false, pending_ = false, need_positions_ = false;
+    DevBuf ctl_buf_, sel4_, tile_counts_, positions_, scan_temp_;
+    PinnedBuf h_ctl_buf_;
+    int32_t* ctl_ = nullptr;
+    int32_t* h_ctl_ = nullptr;
+    int32_t last_count_ = 0;
+    bool last_is_list_ = false;
+    std::vector<OutColumn> out_cols_;
+    std::vector<pa_column> out_storage_;
+};
+
+}  // namespace
+
+pa_operator* make_filter_project(const pa_filter_project_desc* desc)
+{
+    return new FilterProjectOperator(desc);
+}
+
+std::string filter_project_source_for_desc(const pa_filter_project_desc* desc, std::string* entry)
+{
+    FpSpec s = make_fp_spec(desc);
+    std::vector<ChannelLayout> layout(s.n_in);
+    for (int c = 0; c < s.n_in; c++) layout[c].type = s.in_types[c];
+    if (entry) *entry = "pa_fp_scatter";
+    return generate_fp(s, layout).source;
+}
+
+int32_t filter_project_last_positions(pa_operator* op, const int32_t** dev_positions, int32_t* count, int32_t* is_list)
+{
+    auto* fp = dynamic_cast<FilterProjectOperator*>(op);
+    PA_REQUIRE(fp != nullptr, PA_ERR_INVALID_ARGUMENT, "not a FilterAndProject operator");
+    fp->last_positions(dev_positions, count, is_list);
+    return PA_OK;
+}
+
+}  // namespace pa

@@ -26,6 +26,7 @@
 #include "host_hash.hpp"
 #include "jit.hpp"
 #include "operator.hpp"
+#include "rowgen.hpp"
 
 namespace pa {
 
@@ -170,114 +171,6 @@ Spec make_spec(const pa_fused_aggregation_desc* d)
 
 // ---- source generation -------------------------------------------------------------------------
 
-std::string row_params(const Spec& s, const std::vector<ChannelLayout>& layout)
-{
-    std::ostringstream p;
-    for (int c = 0; c < s.n_in; c++) {
-        if (!s.used_channel[c]) continue;
-        p << ", " << RowCodegen::ctype(layout[c].type) << " c" << c;
-        if (layout[c].type == PA_VARCHAR) p << ", i32 cl" << c;
-        if (s.short_bound[c] > 0) p << ", u64 cs" << c;
-        if (layout[c].nullable) p << ", bool cn" << c;
-    }
-    return p.str();
-}
-
-// vector loads of row quad q and the 4 argument lists
-void emit_vector_loads(const Spec& s, const std::vector<ChannelLayout>& layout, std::ostringstream& o, std::string args[4])
-{
-    static const char* xyzw[4] = {"x", "y", "z", "w"};
-    for (int c = 0; c < s.n_in; c++) {
-        if (!s.used_channel[c]) continue;
-        std::string C = std::to_string(c);
-        switch (layout[c].type) {
-            case PA_BIGINT:
-                o << "        pa_i64x2 A" << C << " = ((const pa_i64x2*)a.v[" << C << "])[2 * q], B" << C << " = ((const pa_i64x2*)a.v[" << C
-                  << "])[2 * q + 1];\n";
-                for (int r = 0; r < 4; r++) args[r] += ", " + std::string(r < 2 ? "A" : "B") + C + "." + xyzw[r & 1];
-                break;
-            case PA_DOUBLE:
-                o << "        pa_f64x2 A" << C << " = ((const pa_f64x2*)a.v[" << C << "])[2 * q], B" << C << " = ((const pa_f64x2*)a.v[" << C
-                  << "])[2 * q + 1];\n";
-                for (int r = 0; r < 4; r++) args[r] += ", " + std::string(r < 2 ? "A" : "B") + C + "." + xyzw[r & 1];
-                break;
-            case PA_INTEGER:
-            case PA_DATE:
-                o << "        pa_i32x4 A" << C << " = ((const pa_i32x4*)a.v[" << C << "])[q];\n";
-                for (int r = 0; r < 4; r++) args[r] += ", (i64)A" + C + "." + xyzw[r];
-                break;
-            case PA_BOOLEAN:
-                o << "        u32 A" << C << " = ((const u32*)a.v[" << C << "])[q];\n";
-                for (int r = 0; r < 4; r++) args[r] += ", ((A" + C + " >> " + std::to_string(8 * r) + ") & 0xffu) != 0u";
-                break;
-            case PA_VARCHAR: {
-                o << "        pa_i32x4 O" << C << " = ((const pa_i32x4*)a.o[" << C << "])[q]; i32 E" << C << " = a.o[" << C << "][4 * q + 4];\n";
-                std::string lo[4], len[4];
-                for (int r = 0; r < 4; r++) {
-                    lo[r] = "O" + C + "." + xyzw[r];
-                    len[r] = (r < 3 ? "O" + C + "." + xyzw[r + 1] : "E" + C) + " - " + lo[r];
-                }
-                if (s.short_bound[c] > 0) {
-                    // packed bytes of short VARCHAR keys; VARCHAR(1) rows that all hold one byte are read
-                    // with a single (unaligned) dword load
-                    o << "        u64 S" << C << "0, S" << C << "1, S" << C << "2, S" << C << "3;\n";
-                    if (s.short_bound[c] == 1) {
-                        o << "        if (E" << C << " - " << lo[0] << " == 4) {\n            u32 pk; __builtin_memcpy(&pk, (const u8*)a.v[" << C
-                          << "] + " << lo[0] << ", 4);\n";
-                        for (int r = 0; r < 4; r++) o << "            S" << C << r << " = (pk >> " << 8 * r << ") & 0xffu;\n";
-                        o << "        } else {\n";
-                    }
-                    else {
-                        o << "        {\n";
-                    }
-                    for (int r = 0; r < 4; r++) {
-                        o << "            S" << C << r << " = pa_short_bytes((const u8*)a.v[" << C << "] + " << lo[r] << ", " << len[r] << ", "
-                          << s.short_bound[c] << ", a.err);\n";
-                    }
-                    o << "        }\n";
-                }
-                for (int r = 0; r < 4; r++) {
-                    args[r] += ", (const u8*)a.v[" + C + "] + " + lo[r] + ", " + len[r];
-                    if (s.short_bound[c] > 0) args[r] += ", S" + C + std::to_string(r);
-                }
-                break;
-            }
-            default:
-                throw Error(PA_ERR_NOT_SUPPORTED, "column type not supported on device");
-        }
-        if (layout[c].nullable) {
-            o << "        u32 N" << C << " = ((const u32*)a.nl[" << C << "])[q];\n";
-            for (int r = 0; r < 4; r++) args[r] += ", ((N" + C + " >> " + std::to_string(8 * r) + ") & 0xffu) != 0u";
-        }
-    }
-}
-
-std::string scalar_args(const Spec& s, const std::vector<ChannelLayout>& layout)
-{
-    std::string a;
-    for (int c = 0; c < s.n_in; c++) {
-        if (!s.used_channel[c]) continue;
-        std::string C = std::to_string(c);
-        switch (layout[c].type) {
-            case PA_BIGINT: a += ", ((const i64*)a.v[" + C + "])[r]"; break;
-            case PA_DOUBLE: a += ", ((const double*)a.v[" + C + "])[r]"; break;
-            case PA_INTEGER:
-            case PA_DATE: a += ", (i64)((const i32*)a.v[" + C + "])[r]"; break;
-            case PA_BOOLEAN: a += ", ((const u8*)a.v[" + C + "])[r] != 0"; break;
-            case PA_VARCHAR:
-                a += ", (const u8*)a.v[" + C + "] + a.o[" + C + "][r], a.o[" + C + "][r + 1] - a.o[" + C + "][r]";
-                if (s.short_bound[c] > 0) {
-                    a += ", pa_short_bytes((const u8*)a.v[" + C + "] + a.o[" + C + "][r], a.o[" + C + "][r + 1] - a.o[" + C + "][r], " +
-                         std::to_string(s.short_bound[c]) + ", a.err)";
-                }
-                break;
-            default: throw Error(PA_ERR_NOT_SUPPORTED, "column type not supported on device");
-        }
-        if (layout[c].nullable) a += ", a.nl[" + C + "][r] != 0";
-    }
-    return a;
-}
-
 // first-fit bit packing of the key parts into 64-bit words
 struct KeyPacker {
     std::vector<int> used;  // bits used per word
@@ -304,6 +197,10 @@ KernelInfo generate(const Spec& s, const std::vector<ChannelLayout>& layout, int
     k.block = variant == V_LDS ? 64 : 256;
     k.c = variant == V_LDS ? kLdsSlots : 0;
 
+    RowInputs ri;
+    ri.n_in = s.n_in;
+    ri.used = s.used_channel;
+    ri.short_bound = s.short_bound;
     std::ostringstream body;  // inside pa_row
     RowCodegen gen(layout, "a.err");
 
@@ -471,7 +368,7 @@ KernelInfo generate(const Spec& s, const std::vector<ChannelLayout>& layout, int
     else {
         src << "struct PaAcc { int unused; };\n";
     }
-    src << "__device__ __forceinline__ void pa_row(const PaFusedArgs& a, PaAcc& acc" << row_params(s, layout) << ")\n{\n";
+    src << "__device__ __forceinline__ void pa_row(const PaFusedArgs& a, PaAcc& acc" << row_params(ri, layout) << ")\n{\n";
     src << body.str();
     // values needed after the selected-only block are declared up front
     for (int w = 0; w < k.nw; w++) {
@@ -554,10 +451,10 @@ KernelInfo generate(const Spec& s, const std::vector<ChannelLayout>& layout, int
     src << "    const i64 nq = a.vec ? (a.n >> 2) : 0;\n";
     src << "    for (i64 q = t; q < nq; q += T) {\n";
     std::string args[4];
-    emit_vector_loads(s, layout, src, args);
+    emit_vector_loads(ri, layout, src, args);
     for (int r = 0; r < 4; r++) src << "        pa_row(a, acc" << args[r] << ");\n";
     src << "    }\n";
-    src << "    for (i64 r = (nq << 2) + t; r < a.n; r += T) {\n        pa_row(a, acc" << scalar_args(s, layout) << ");\n    }\n";
+    src << "    for (i64 r = (nq << 2) + t; r < a.n; r += T) {\n        pa_row(a, acc" << scalar_args(ri, layout) << ");\n    }\n";
     if (variant == V_GLOBAL) {
         src << "    __shared__ u64 red[" << (B / 64) << " * PA_NW];\n    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;\n";
         for (int w = 0; w < k.nw; w++) {

@@ -1,0 +1,429 @@
+// op_join.cpp -- HashBuilderOperator + LookupJoinOperator (inner equi-join) on device.
+//
+// Reference path replaced:
+//   HashBuilderOperator.addInput / finish -> PagesIndex.addPage / createLookupSourceSupplier
+//     (…/operator/join/HashBuilderOperator.java:332-364, 492-510; …/operator/PagesIndex.java:212, 492-536)
+//   PagesHash ctor / getAddressIndex, ArrayPositionLinks (…/operator/join/PagesHash.java:54-126, 158-170;
+//     …/operator/join/ArrayPositionLinks.java:38-50, 90-100)
+//   LookupJoinOperator / DefaultPageJoiner.processProbe / JoinProbe / LookupJoinPageBuilder
+//     (…/operator/join/LookupJoinOperator.java:46-125; DefaultPageJoiner.java:236-320; JoinProbe.java:56-117;
+//      LookupJoinPageBuilder.java:76-139)
+// Output rows come out exactly in the reference's order: ascending probe position, and for one probe row its
+// matches in descending build position (the chain order).  The whole probe page is joined at once; the
+// reference's 1 MB / 8192-row output flushes only move page boundaries.
+#include <atomic>
+#include <mutex>
+
+#include "join_kernels.hpp"
+#include "operator.hpp"
+#include "scan_kernels.hpp"
+#include "static_kernels.hpp"
+
+namespace pa {
+
+struct BuildColumn {
+    int32_t type = PA_BIGINT;
+    bool varwidth = false;
+    DevBuf values, offsets, nulls;
+    bool has_nulls = false;
+    int64_t bytes = 0;  // VARWIDTH: bytes used
+};
+
+// The lookup source shared between the build operator and its probe operators
+// (LookupSourceFactory / JoinBridge; PartitionedLookupSourceFactory.java:179-206).
+struct LookupSourceImpl {
+    std::vector<BuildColumn> cols;
+    int32_t n = 0;
+    std::vector<int> join_channels, output_channels;
+    int hash_channel = -1;
+    DevBuf key, links, raw_hash, slot_of;
+    uint32_t mask = 0;
+    std::atomic<bool> built{false};
+    std::atomic<int32_t> error{0};
+
+    JoinKeys build_keys() const
+    {
+        JoinKeys k;
+        memset(&k, 0, sizeof k);
+        k.ncols = (int32_t)join_channels.size();
+        for (int i = 0; i < k.ncols; i++) {
+            const BuildColumn& c = cols[join_channels[i]];
+            k.col[i].values = c.values.ptr();
+            k.col[i].offsets = c.offsets.as<int32_t>();
+            k.col[i].nulls = c.has_nulls ? c.nulls.as<uint8_t>() : nullptr;
+            k.col[i].type = c.type;
+        }
+        return k;
+    }
+};
+
+}  // namespace pa
+
+struct pa_lookup_source {
+    std::shared_ptr<pa::LookupSourceImpl> impl;
+};
+
+namespace pa {
+namespace {
+
+// fastutil HashCommon.arraySize(expected, 0.75f) as used by PagesHash.java:64
+uint32_t array_size(int64_t expected)
+{
+    uint64_t need = (uint64_t)((expected + 0.75 - 1e-9) / 0.75);  // ceil(expected / 0.75)
+    while ((double)need * 0.75 < (double)expected) need++;
+    uint64_t s = 2;
+    while (s < need) s <<= 1;
+    PA_REQUIRE(s <= (1ULL << 30), PA_ERR_INSUFFICIENT_RESOURCES, "Size of hash table cannot exceed 1 billion entries");
+    return (uint32_t)s;
+}
+
+class HashBuilderOperator : public pa_operator {
+public:
+    HashBuilderOperator(const pa_hash_builder_desc* d, pa_lookup_source* bridge) : stream_(d->stream)
+    {
+        PA_REQUIRE(d != nullptr, PA_ERR_INVALID_ARGUMENT, "descriptor is null");
+        require_device();
+        PA_REQUIRE(d->input_channel_count > 0 && d->input_channel_count <= 32, PA_ERR_NOT_SUPPORTED, "1..32 build channels");
+        PA_REQUIRE(d->join_channel_count > 0 && d->join_channel_count <= kMaxJoinChannels, PA_ERR_NOT_SUPPORTED, "1..8 join channels");
+        ls_ = std::make_shared<LookupSourceImpl>();
+        ls_->cols.resize(d->input_channel_count);
+        for (int c = 0; c < d->input_channel_count; c++) {
+            ls_->cols[c].type = d->input_types[c];
+            ls_->cols[c].varwidth = d->input_types[c] == PA_VARCHAR;
+        }
+        for (int i = 0; i < d->join_channel_count; i++) {
+            PA_REQUIRE(d->join_channels[i] >= 0 && d->join_channels[i] < d->input_channel_count, PA_ERR_INVALID_ARGUMENT, "join channel out of range");
+            ls_->join_channels.push_back(d->join_channels[i]);
+        }
+        for (int i = 0; i < d->output_channel_count; i++) {
+            PA_REQUIRE(d->output_channels[i] >= 0 && d->output_channels[i] < d->input_channel_count, PA_ERR_INVALID_ARGUMENT, "output channel out of range");
+            ls_->output_channels.push_back(d->output_channels[i]);
+        }
+        ls_->hash_channel = d->hash_channel;
+        PA_REQUIRE(ls_->hash_channel < d->input_channel_count, PA_ERR_INVALID_ARGUMENT, "hash channel out of range");
+        PA_REQUIRE(ls_->hash_channel < 0 || d->input_types[ls_->hash_channel] == PA_BIGINT, PA_ERR_INVALID_ARGUMENT, "hash channel must be BIGINT");
+        expected_ = d->expected_positions;
+        bridge->impl = ls_;
+        ctl_ = static_cast<int32_t*>(ctl_buf_.ensure(64));
+        PA_HIP(hipMemsetAsync(ctl_, 0, 64, stream_.get()));
+    }
+    ~HashBuilderOperator() override { (void)hipStreamSynchronize(stream_.get()); }
+
+    bool needs_input() override { return !finishing_; }
+
+    // PagesIndex.addPage: append every channel to the flat build columns
+    void add_input(const pa_page* page) override
+    {
+        PA_REQUIRE(!finishing_, PA_ERR_ILLEGAL_STATE, "Operator is already finishing");
+        PA_REQUIRE(page != nullptr, PA_ERR_INVALID_ARGUMENT, "page is null");
+        PA_REQUIRE(page->channel_count == (int32_t)ls_->cols.size(), PA_ERR_INVALID_ARGUMENT, "page channel count does not match the build types");
+        const int64_t m = page->position_count;
+        if (m == 0) return;
+        PA_REQUIRE((int64_t)ls_->n + m <= INT32_MAX, PA_ERR_INSUFFICIENT_RESOURCES, "build side exceeds 2^31 positions");
+        hipStream_t s = stream_.get();
+        DevPage dp = stager_.stage(page, nullptr, s);
+        const int64_t n0 = ls_->n;
+        const int64_t want = std::max<int64_t>(n0 + m, expected_);
+        for (size_t c = 0; c < ls_->cols.size(); c++) {
+            BuildColumn& bc = ls_->cols[c];
+            const DevColumn& in = dp.cols[c];
+            PA_REQUIRE(in.type == bc.type, PA_ERR_INVALID_ARGUMENT, "page block type does not match the declared build type");
+            if (bc.varwidth) {
+                int32_t ends[2] = {0, 0};
+                PA_HIP(hipMemcpyAsync(&ends[0], in.offsets, 4, hipMemcpyDeviceToHost, s));
+                PA_HIP(hipMemcpyAsync(&ends[1], in.offsets + m, 4, hipMemcpyDeviceToHost, s));
+                PA_HIP(hipStreamSynchronize(s));
+                int64_t add = (int64_t)ends[1] - ends[0];
+                PA_REQUIRE(bc.bytes + add <= INT32_MAX, PA_ERR_INSUFFICIENT_RESOURCES, "build VARCHAR column exceeds 2 GB");
+                bc.offsets.reserve_keep((size_t)(want + 1) * 4, (size_t)(n0 + 1) * 4, s);
+                bc.values.reserve_keep((size_t)std::max<int64_t>(bc.bytes + add, 16), (size_t)bc.bytes, s);
+                launch_rebase_offsets(in.offsets, ends[0], (int32_t)bc.bytes, m + 1, bc.offsets.as<int32_t>() + n0, s);
+                if (add) PA_HIP(hipMemcpyAsync(bc.values.as<char>() + bc.bytes, static_cast<const char*>(in.values) + ends[0], (size_t)add, hipMemcpyDeviceToDevice, s));
+                bc.bytes += add;
+            }
+            else {
+                int w = type_width(bc.type);
+                bc.values.reserve_keep((size_t)want * w, (size_t)n0 * w, s);
+                PA_HIP(hipMemcpyAsync(bc.values.as<char>() + n0 * w, in.values, (size_t)m * w, hipMemcpyDeviceToDevice, s));
+            }
+            if (in.nulls || bc.has_nulls) {
+                bc.nulls.reserve_keep((size_t)want, bc.has_nulls ? (size_t)n0 : 0, s);
+                if (!bc.has_nulls && n0) PA_HIP(hipMemsetAsync(bc.nulls.ptr(), 0, (size_t)n0, s));
+                if (in.nulls) PA_HIP(hipMemcpyAsync(bc.nulls.as<char>() + n0, in.nulls, (size_t)m, hipMemcpyDeviceToDevice, s));
+                else PA_HIP(hipMemsetAsync(bc.nulls.as<char>() + n0, 0, (size_t)m, s));
+                bc.has_nulls = true;
+            }
+        }
+        ls_->n = (int32_t)(n0 + m);
+        // staged host pages live in the stager's arena, which the next add_input overwrites
+        PA_HIP(hipStreamSynchronize(s));
+    }
+
+    // finishInput -> buildLookupSource -> new PagesHash(...)
+    void finish() override
+    {
+        if (finishing_) return;
+        finishing_ = true;
+        hipStream_t s = stream_.get();
+        const int32_t n = ls_->n;
+        const uint32_t hash_size = array_size(n);
+        ls_->mask = hash_size - 1;
+        ls_->key.ensure((size_t)hash_size * 4);
+        ls_->links.ensure((size_t)std::max(n, 1) * 4);
+        ls_->slot_of.ensure((size_t)std::max(n, 1) * 4);
+        ls_->raw_hash.ensure((size_t)std::max(n, 1) * 8);
+        JoinKeys bk = ls_->build_keys();
+        if (n > 0) {
+            if (ls_->hash_channel >= 0) {
+                PA_HIP(hipMemcpyAsync(ls_->raw_hash.ptr(), ls_->cols[ls_->hash_channel].values.ptr(), (size_t)n * 8, hipMemcpyDeviceToDevice, s));
+            }
+            else {
+                HashPageArgs ha;
+                memset(&ha, 0, sizeof ha);
+                for (int i = 0; i < bk.ncols; i++) {
+                    ha.col[i].values = bk.col[i].values;
+                    ha.col[i].offsets = bk.col[i].offsets;
+                    ha.col[i].nulls = bk.col[i].nulls;
+                    ha.col[i].type = bk.col[i].type;
+                }
+                ha.ncols = bk.ncols;
+                ha.n = n;
+                ha.out = ls_->raw_hash.as<int64_t>();
+                launch_hash_page(ha, s);
+            }
+        }
+        timer.begin(s);
+        launch_join_build(bk, ls_->raw_hash.as<int64_t>(), n, ls_->key.as<int32_t>(), ls_->mask, ls_->slot_of.as<int32_t>(), ls_->links.as<int32_t>(),
+                          ctl_, s);
+        timer.end(s);
+        int32_t err = 0;
+        PA_HIP(hipMemcpyAsync(&err, ctl_, 4, hipMemcpyDeviceToHost, s));
+        PA_HIP(hipStreamSynchronize(s));
+        ls_->error.store(err);
+        ls_->built.store(true);  // lendPartitionLookupSource: probes may proceed
+        if (err) throw Error(err, "hash build failed on device");
+    }
+
+    bool get_output(pa_page*) override { return false; }
+    bool is_finished() override { return finishing_; }
+    int64_t memory_bytes() override
+    {
+        int64_t b = (int64_t)(ls_->key.capacity() + ls_->links.capacity() + ls_->raw_hash.capacity() + ls_->slot_of.capacity());
+        for (const auto& c : ls_->cols) b += (int64_t)(c.values.capacity() + c.offsets.capacity() + c.nulls.capacity());
+        return b;
+    }
+
+private:
+    Stream stream_;
+    PageStager stager_;
+    std::shared_ptr<LookupSourceImpl> ls_;
+    DevBuf ctl_buf_;
+    int32_t* ctl_ = nullptr;
+    int64_t expected_ = 0;
+    bool finishing_ = false;
+};
+
+class LookupJoinOperator : public pa_operator {
+public:
+    LookupJoinOperator(const pa_lookup_join_desc* d, pa_lookup_source* bridge) : stream_(d->stream)
+    {
+        PA_REQUIRE(d != nullptr, PA_ERR_INVALID_ARGUMENT, "descriptor is null");
+        require_device();
+        PA_REQUIRE(bridge->impl != nullptr, PA_ERR_ILLEGAL_STATE, "lookup source has no build operator yet");
+        ls_ = bridge->impl;
+        PA_REQUIRE(d->join_channel_count == (int32_t)ls_->join_channels.size(), PA_ERR_INVALID_ARGUMENT, "probe and build join channel counts differ");
+        n_probe_channels_ = d->probe_channel_count;
+        probe_types_.assign(d->probe_types, d->probe_types + d->probe_channel_count);
+        for (int i = 0; i < d->join_channel_count; i++) {
+            int c = d->probe_join_channels[i];
+            PA_REQUIRE(c >= 0 && c < n_probe_channels_, PA_ERR_INVALID_ARGUMENT, "probe join channel out of range");
+            PA_REQUIRE(probe_types_[c] == ls_->cols[ls_->join_channels[i]].type, PA_ERR_INVALID_ARGUMENT, "probe / build join key types differ");
+            join_channels_.push_back(c);
+        }
+        hash_channel_ = d->probe_hash_channel;
+        for (int i = 0; i < d->probe_output_channel_count; i++) {
+            int c = d->probe_output_channels[i];
+            PA_REQUIRE(c >= 0 && c < n_probe_channels_, PA_ERR_INVALID_ARGUMENT, "probe output channel out of range");
+            output_channels_.push_back(c);
+        }
+        output_mem_ = d->output_mem;
+        needed_.assign(n_probe_channels_, false);
+        for (int c : join_channels_) needed_[c] = true;
+        for (int c : output_channels_) needed_[c] = true;
+        if (hash_channel_ >= 0) needed_[hash_channel_] = true;
+        ctl_ = static_cast<int32_t*>(ctl_buf_.ensure(64));
+        h_ctl_ = static_cast<int32_t*>(h_ctl_buf_.ensure(64));
+        out_cols_.resize(output_channels_.size() + ls_->output_channels.size());
+    }
+    ~LookupJoinOperator() override { (void)hipStreamSynchronize(stream_.get()); }
+
+    // LookupJoinOperator.needsInput: only once the lookup source is ready, one probe page at a time
+    bool needs_input() override { return !finishing_ && !pending_ && ls_->built.load(); }
+    bool is_blocked() override { return !ls_->built.load(); }
+
+    void add_input(const pa_page* page) override
+    {
+        PA_REQUIRE(ls_->built.load(), PA_ERR_ILLEGAL_STATE, "lookup source is not built yet");
+        PA_REQUIRE(!finishing_ && !pending_, PA_ERR_ILLEGAL_STATE, "Operator does not need input");
+        PA_REQUIRE(page != nullptr && page->channel_count == n_probe_channels_, PA_ERR_INVALID_ARGUMENT, "probe page does not match the probe types");
+        if (page->position_count == 0) return;
+        hipStream_t s = stream_.get();
+        in_ = stager_.stage(page, &needed_, s);
+        const int32_t n = in_.n;
+        JoinKeys pk;
+        memset(&pk, 0, sizeof pk);
+        pk.ncols = (int32_t)join_channels_.size();
+        for (int i = 0; i < pk.ncols; i++) {
+            const DevColumn& c = in_.cols[join_channels_[i]];
+            PA_REQUIRE(c.type == probe_types_[join_channels_[i]], PA_ERR_INVALID_ARGUMENT, "page block type does not match the declared probe type");
+            pk.col[i].values = c.values;
+            pk.col[i].offsets = c.offsets;
+            pk.col[i].nulls = c.nulls;
+            pk.col[i].type = c.type;
+        }
+        const int64_t* probe_hash;
+        if (hash_channel_ >= 0) {
+            probe_hash = static_cast<const int64_t*>(in_.cols[hash_channel_].values);
+        }
+        else {
+            HashPageArgs ha;
+            memset(&ha, 0, sizeof ha);
+            for (int i = 0; i < pk.ncols; i++) {
+                ha.col[i].values = pk.col[i].values;
+                ha.col[i].offsets = pk.col[i].offsets;
+                ha.col[i].nulls = pk.col[i].nulls;
+                ha.col[i].type = pk.col[i].type;
+            }
+            ha.ncols = pk.ncols;
+            ha.n = n;
+            ha.out = static_cast<int64_t*>(hash_.ensure((size_t)n * 8));
+            launch_hash_page(ha, s);
+            probe_hash = ha.out;
+        }
+        int32_t* head = static_cast<int32_t*>(head_.ensure((size_t)n * 4));
+        int32_t* counts = static_cast<int32_t*>(counts_.ensure((size_t)n * 4));
+        timer.begin(s);
+        launch_join_probe_count(ls_->build_keys(), pk, probe_hash, n, ls_->key.as<int32_t>(), ls_->mask, ls_->links.as<int32_t>(), head, counts, s);
+        launch_exclusive_scan_i32(counts, counts, n, ctl_, scan_temp_.ensure(scan_temp_bytes(n)), s);
+        timer.end(s);
+        PA_HIP(hipMemcpyAsync(h_ctl_, ctl_, 4, hipMemcpyDeviceToHost, s));
+        pending_ = true;
+    }
+
+    bool get_output(pa_page* out) override
+    {
+        if (!pending_) return false;
+        pending_ = false;
+        hipStream_t s = stream_.get();
+        PA_HIP(hipStreamSynchronize(s));
+        const int32_t total = h_ctl_[0];
+        last_matches_ = total;
+        if (total == 0) return false;
+        const int32_t n = in_.n;
+        int32_t* probe_idx = static_cast<int32_t*>(probe_idx_.ensure((size_t)total * 4));
+        int32_t* build_pos = static_cast<int32_t*>(build_pos_.ensure((size_t)total * 4));
+        launch_join_probe_emit(head_.as<int32_t>(), counts_.as<int32_t>(), n, ls_->links.as<int32_t>(), probe_idx, build_pos, s);
+        // LookupJoinPageBuilder.build: probe output channels by probe index ++ build output channels by build position
+        size_t oc = 0;
+        for (int c : output_channels_) {
+            const DevColumn& src = in_.cols[c];
+            gather_column(src.type, src.varwidth, src.values, src.offsets, src.nulls, probe_idx, total, out_cols_[oc++], s);
+        }
+        for (int c : ls_->output_channels) {
+            const BuildColumn& src = ls_->cols[c];
+            gather_column(src.type, src.varwidth, src.values.ptr(), src.offsets.as<int32_t>(), src.has_nulls ? src.nulls.as<uint8_t>() : nullptr,
+                          build_pos, total, out_cols_[oc++], s);
+        }
+        publish_output(out_cols_, total, output_mem_, s, out, out_storage_);
+        return true;
+    }
+
+    void finish() override { finishing_ = true; }
+    bool is_finished() override { return finishing_ && !pending_; }
+    int64_t memory_bytes() override { return (int64_t)(stager_.bytes() + head_.capacity() + counts_.capacity() + probe_idx_.capacity() + build_pos_.capacity()); }
+
+    void last_pairs(const int32_t** probe_idx, const int32_t** build_pos, int32_t* count) const
+    {
+        *probe_idx = probe_idx_.as<int32_t>();
+        *build_pos = build_pos_.as<int32_t>();
+        *count = last_matches_;
+    }
+
+private:
+    void gather_column(int32_t type, bool varwidth, const void* values, const int32_t* offsets, const uint8_t* nulls, const int32_t* positions,
+                       int32_t count, OutColumn& oc, hipStream_t s)
+    {
+        oc.type = type;
+        oc.varwidth = varwidth;
+        oc.is_view = false;
+        oc.host_ready = false;
+        oc.has_nulls = nulls != nullptr;
+        if (varwidth) {
+            int32_t* lens = static_cast<int32_t*>(oc.offsets.ensure((size_t)(count + 1) * 4));
+            launch_varwidth_lengths(positions, count, offsets, nulls, lens, s);
+            launch_exclusive_scan_i32(lens, lens, count, ctl_ + 2, scan_temp_.ensure(scan_temp_bytes(count)), s);
+            PA_HIP(hipMemcpyAsync(h_ctl_ + 2, ctl_ + 2, 4, hipMemcpyDeviceToHost, s));
+            PA_HIP(hipStreamSynchronize(s));
+            int32_t bytes = h_ctl_[2];
+            uint8_t* dst = static_cast<uint8_t*>(oc.values.ensure((size_t)(bytes > 0 ? bytes : 1)));
+            launch_varwidth_copy(positions, count, offsets, static_cast<const uint8_t*>(values), nulls, lens, dst, ctl_ + 2, s);
+        }
+        else {
+            int w = type_width(type);
+            launch_gather_flat(values, w, positions, count, oc.values.ensure((size_t)count * w), s);
+        }
+        if (nulls) launch_gather_nulls(nulls, positions, count, static_cast<uint8_t*>(oc.nulls.ensure((size_t)count)), s);
+    }
+
+    Stream stream_;
+    PageStager stager_;
+    std::shared_ptr<LookupSourceImpl> ls_;
+    int n_probe_channels_ = 0;
+    std::vector<int32_t> probe_types_;
+    std::vector<int> join_channels_, output_channels_;
+    std::vector<bool> needed_;
+    int hash_channel_ = -1, output_mem_ = PA_MEM_HOST;
+    DevPage in_;
+    DevBuf ctl_buf_, hash_, head_, counts_, probe_idx_, build_pos_, scan_temp_;
+    PinnedBuf h_ctl_buf_;
+    int32_t* ctl_ = nullptr;
+    int32_t* h_ctl_ = nullptr;
+    int32_t last_matches_ = 0;
+    bool finishing_ = false, pending_ = false;
+    std::vector<OutColumn> out_cols_;
+    std::vector<pa_column> out_storage_;
+};
+
+}  // namespace
+
+pa_operator* make_hash_builder(const pa_hash_builder_desc* desc, pa_lookup_source* bridge)
+{
+    return new HashBuilderOperator(desc, bridge);
+}
+pa_operator* make_lookup_join(const pa_lookup_join_desc* desc, pa_lookup_source* bridge)
+{
+    return new LookupJoinOperator(desc, bridge);
+}
+pa_lookup_source* lookup_source_new() { return new pa_lookup_source(); }
+void lookup_source_delete(pa_lookup_source* ls) { delete ls; }
+
+int32_t lookup_join_last_pairs(pa_operator* op, const int32_t** probe_idx, const int32_t** build_pos, int32_t* count)
+{
+    auto* j = dynamic_cast<LookupJoinOperator*>(op);
+    PA_REQUIRE(j != nullptr, PA_ERR_INVALID_ARGUMENT, "not a LookupJoin operator");
+    j->last_pairs(probe_idx, build_pos, count);
+    return PA_OK;
+}
+
+// key[] / positionLinks[] of a built lookup source (tests: chain order parity with the reference)
+int32_t lookup_source_tables(pa_lookup_source* ls, const int32_t** key, int32_t* hash_size, const int32_t** links, int32_t* positions)
+{
+    PA_REQUIRE(ls != nullptr && ls->impl != nullptr && ls->impl->built.load(), PA_ERR_ILLEGAL_STATE, "lookup source is not built");
+    *key = ls->impl->key.as<int32_t>();
+    *hash_size = (int32_t)(ls->impl->mask + 1);
+    *links = ls->impl->links.as<int32_t>();
+    *positions = ls->impl->n;
+    return PA_OK;
+}
+
+}  // namespace pa

@@ -1,0 +1,116 @@
+// rowgen.cpp -- shared pieces of the generated kernels: how the columns of a page reach the per-row
+// function (4 rows per lane per step with 16-byte loads when every buffer is aligned, scalar otherwise).
+// Kernel argument blocks expose the columns as a.v[c] / a.o[c] / a.nl[c] and the error word as a.err.
+#include "rowgen.hpp"
+
+namespace pa {
+
+std::string row_params(const RowInputs& s, const std::vector<ChannelLayout>& layout)
+{
+    std::ostringstream p;
+    for (int c = 0; c < s.n_in; c++) {
+        if (!s.used[c]) continue;
+        p << ", " << RowCodegen::ctype(layout[c].type) << " c" << c;
+        if (layout[c].type == PA_VARCHAR) p << ", i32 cl" << c;
+        if (s.short_bound[c] > 0) p << ", u64 cs" << c;
+        if (layout[c].nullable) p << ", bool cn" << c;
+    }
+    return p.str();
+}
+
+// vector loads of row quad q and the 4 argument lists
+void emit_vector_loads(const RowInputs& s, const std::vector<ChannelLayout>& layout, std::ostringstream& o, std::string args[4])
+{
+    static const char* xyzw[4] = {"x", "y", "z", "w"};
+    for (int c = 0; c < s.n_in; c++) {
+        if (!s.used[c]) continue;
+        std::string C = std::to_string(c);
+        switch (layout[c].type) {
+            case PA_BIGINT:
+                o << "        pa_i64x2 A" << C << " = ((const pa_i64x2*)a.v[" << C << "])[2 * q], B" << C << " = ((const pa_i64x2*)a.v[" << C
+                  << "])[2 * q + 1];\n";
+                for (int r = 0; r < 4; r++) args[r] += ", " + std::string(r < 2 ? "A" : "B") + C + "." + xyzw[r & 1];
+                break;
+            case PA_DOUBLE:
+                o << "        pa_f64x2 A" << C << " = ((const pa_f64x2*)a.v[" << C << "])[2 * q], B" << C << " = ((const pa_f64x2*)a.v[" << C
+                  << "])[2 * q + 1];\n";
+                for (int r = 0; r < 4; r++) args[r] += ", " + std::string(r < 2 ? "A" : "B") + C + "." + xyzw[r & 1];
+                break;
+            case PA_INTEGER:
+            case PA_DATE:
+                o << "        pa_i32x4 A" << C << " = ((const pa_i32x4*)a.v[" << C << "])[q];\n";
+                for (int r = 0; r < 4; r++) args[r] += ", (i64)A" + C + "." + xyzw[r];
+                break;
+            case PA_BOOLEAN:
+                o << "        u32 A" << C << " = ((const u32*)a.v[" << C << "])[q];\n";
+                for (int r = 0; r < 4; r++) args[r] += ", ((A" + C + " >> " + std::to_string(8 * r) + ") & 0xffu) != 0u";
+                break;
+            case PA_VARCHAR: {
+                o << "        pa_i32x4 O" << C << " = ((const pa_i32x4*)a.o[" << C << "])[q]; i32 E" << C << " = a.o[" << C << "][4 * q + 4];\n";
+                std::string lo[4], len[4];
+                for (int r = 0; r < 4; r++) {
+                    lo[r] = "O" + C + "." + xyzw[r];
+                    len[r] = (r < 3 ? "O" + C + "." + xyzw[r + 1] : "E" + C) + " - " + lo[r];
+                }
+                if (s.short_bound[c] > 0) {
+                    // packed bytes of short VARCHAR keys; VARCHAR(1) rows that all hold one byte are read
+                    // with a single (unaligned) dword load
+                    o << "        u64 S" << C << "0, S" << C << "1, S" << C << "2, S" << C << "3;\n";
+                    if (s.short_bound[c] == 1) {
+                        o << "        if (E" << C << " - " << lo[0] << " == 4) {\n            u32 pk; __builtin_memcpy(&pk, (const u8*)a.v[" << C
+                          << "] + " << lo[0] << ", 4);\n";
+                        for (int r = 0; r < 4; r++) o << "            S" << C << r << " = (pk >> " << 8 * r << ") & 0xffu;\n";
+                        o << "        } else {\n";
+                    }
+                    else {
+                        o << "        {\n";
+                    }
+                    for (int r = 0; r < 4; r++) {
+                        o << "            S" << C << r << " = pa_short_bytes((const u8*)a.v[" << C << "] + " << lo[r] << ", " << len[r] << ", "
+                          << s.short_bound[c] << ", a.err);\n";
+                    }
+                    o << "        }\n";
+                }
+                for (int r = 0; r < 4; r++) {
+                    args[r] += ", (const u8*)a.v[" + C + "] + " + lo[r] + ", " + len[r];
+                    if (s.short_bound[c] > 0) args[r] += ", S" + C + std::to_string(r);
+                }
+                break;
+            }
+            default:
+                throw Error(PA_ERR_NOT_SUPPORTED, "column type not supported on device");
+        }
+        if (layout[c].nullable) {
+            o << "        u32 N" << C << " = ((const u32*)a.nl[" << C << "])[q];\n";
+            for (int r = 0; r < 4; r++) args[r] += ", ((N" + C + " >> " + std::to_string(8 * r) + ") & 0xffu) != 0u";
+        }
+    }
+}
+
+std::string scalar_args(const RowInputs& s, const std::vector<ChannelLayout>& layout)
+{
+    std::string a;
+    for (int c = 0; c < s.n_in; c++) {
+        if (!s.used[c]) continue;
+        std::string C = std::to_string(c);
+        switch (layout[c].type) {
+            case PA_BIGINT: a += ", ((const i64*)a.v[" + C + "])[r]"; break;
+            case PA_DOUBLE: a += ", ((const double*)a.v[" + C + "])[r]"; break;
+            case PA_INTEGER:
+            case PA_DATE: a += ", (i64)((const i32*)a.v[" + C + "])[r]"; break;
+            case PA_BOOLEAN: a += ", ((const u8*)a.v[" + C + "])[r] != 0"; break;
+            case PA_VARCHAR:
+                a += ", (const u8*)a.v[" + C + "] + a.o[" + C + "][r], a.o[" + C + "][r + 1] - a.o[" + C + "][r]";
+                if (s.short_bound[c] > 0) {
+                    a += ", pa_short_bytes((const u8*)a.v[" + C + "] + a.o[" + C + "][r], a.o[" + C + "][r + 1] - a.o[" + C + "][r], " +
+                         std::to_string(s.short_bound[c]) + ", a.err)";
+                }
+                break;
+            default: throw Error(PA_ERR_NOT_SUPPORTED, "column type not supported on device");
+        }
+        if (layout[c].nullable) a += ", a.nl[" + C + "][r] != 0";
+    }
+    return a;
+}
+
+}  // namespace pa

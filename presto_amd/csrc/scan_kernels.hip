@@ -1,0 +1,260 @@
+// scan_kernels.hip -- exclusive prefix sums, variable-width gathers and the stable partition used by
+// the compaction paths (FilterAndProject output, join output, exchange partitioning).  HBM-bound integer
+// work: wave64 shuffles + LDS inside a workgroup, two-level block sums across workgroups.
+#include <hip/hip_runtime.h>
+
+#include "common.hpp"
+#include "kernels/pa_device.h"
+#include "scan_kernels.hpp"
+
+namespace pa {
+
+static inline int blocks_for(int64_t n, int per_block)
+{
+    int64_t b = (n + per_block - 1) / per_block;
+    return (int)(b < 1 ? 1 : b);
+}
+
+constexpr int kScanBlock = 256;
+constexpr int kScanItems = 4;                        // items per thread
+constexpr int kScanTile = kScanBlock * kScanItems;   // 1024 items per workgroup
+
+// inclusive wave scan with shuffles
+__device__ __forceinline__ i32 wave_inclusive_scan(i32 v)
+{
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        i32 o = __shfl_up(v, off, 64);
+        if (lane >= off) v += o;
+    }
+    return v;
+}
+
+// exclusive prefix of `v` over the 256 threads of the workgroup; *total = workgroup sum
+__device__ __forceinline__ i32 block_exclusive_scan(i32 v, i32* total)
+{
+    __shared__ i32 wave_sums[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    i32 inc = wave_inclusive_scan(v);
+    if (lane == 63) wave_sums[wave] = inc;
+    __syncthreads();
+    i32 base = 0, all = 0;
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        i32 s = wave_sums[w];
+        if (w < wave) base += s;
+        all += s;
+    }
+    __syncthreads();
+    *total = all;
+    return base + inc - v;
+}
+
+__global__ __launch_bounds__(kScanBlock) void k_scan_tile_sums(const i32* __restrict__ in, i64 n, i32* __restrict__ sums)
+{
+    i64 base = (i64)blockIdx.x * kScanTile + (i64)threadIdx.x * kScanItems;
+    i32 s = 0;
+#pragma unroll
+    for (int i = 0; i < kScanItems; i++) {
+        if (base + i < n) s += in[base + i];
+    }
+    i32 total;
+    (void)block_exclusive_scan(s, &total);
+    if (threadIdx.x == 0) sums[blockIdx.x] = total;
+}
+
+// single workgroup: in-place exclusive scan of up to any length (sequential over 1024-item chunks)
+__global__ __launch_bounds__(kScanBlock) void k_scan_single(i32* __restrict__ data, i64 n, i32* __restrict__ total_out)
+{
+    i32 carry = 0;
+    for (i64 chunk = 0; chunk < n; chunk += kScanTile) {
+        i64 base = chunk + (i64)threadIdx.x * kScanItems;
+        i32 v[kScanItems];
+        i32 s = 0;
+#pragma unroll
+        for (int i = 0; i < kScanItems; i++) {
+            v[i] = (base + i < n) ? data[base + i] : 0;
+            s += v[i];
+        }
+        i32 total;
+        i32 ex = block_exclusive_scan(s, &total) + carry;
+#pragma unroll
+        for (int i = 0; i < kScanItems; i++) {
+            if (base + i < n) data[base + i] = ex;
+            ex += v[i];
+        }
+        carry += total;
+    }
+    if (threadIdx.x == 0 && total_out) *total_out = carry;
+}
+
+__global__ __launch_bounds__(kScanBlock) void k_scan_apply(const i32* __restrict__ in, i64 n, const i32* __restrict__ tile_offsets,
+                                                           i32* __restrict__ out)
+{
+    i64 base = (i64)blockIdx.x * kScanTile + (i64)threadIdx.x * kScanItems;
+    i32 v[kScanItems];
+    i32 s = 0;
+#pragma unroll
+    for (int i = 0; i < kScanItems; i++) {
+        v[i] = (base + i < n) ? in[base + i] : 0;
+        s += v[i];
+    }
+    i32 total;
+    i32 ex = block_exclusive_scan(s, &total) + tile_offsets[blockIdx.x];
+#pragma unroll
+    for (int i = 0; i < kScanItems; i++) {
+        if (base + i < n) out[base + i] = ex;
+        ex += v[i];
+    }
+}
+
+size_t scan_temp_bytes(int64_t n)
+{
+    int64_t tiles = (n + kScanTile - 1) / kScanTile;
+    int64_t tiles2 = (tiles + kScanTile - 1) / kScanTile;
+    return (size_t)(tiles + tiles2 + 8) * 4;
+}
+
+// out[i] = sum(in[0..i)), *total_out = sum(in[0..n)); out may alias in; out has room for n entries.
+// The caller guarantees the sum fits int32 (positions / byte offsets of one Block).
+void launch_exclusive_scan_i32(const int32_t* in, int32_t* out, int64_t n, int32_t* total_out, void* temp, hipStream_t s)
+{
+    if (n <= 0) {
+        if (total_out) PA_HIP(hipMemsetAsync(total_out, 0, 4, s));
+        return;
+    }
+    int64_t tiles = (n + kScanTile - 1) / kScanTile;
+    if (tiles == 1) {
+        if (out != in) PA_HIP(hipMemcpyAsync(out, in, (size_t)n * 4, hipMemcpyDeviceToDevice, s));
+        hipLaunchKernelGGL(k_scan_single, 1, kScanBlock, 0, s, out, (i64)n, total_out);
+        PA_HIP(hipGetLastError());
+        return;
+    }
+    i32* sums = static_cast<i32*>(temp);
+    hipLaunchKernelGGL(k_scan_tile_sums, (int)tiles, kScanBlock, 0, s, in, (i64)n, sums);
+    hipLaunchKernelGGL(k_scan_single, 1, kScanBlock, 0, s, sums, (i64)tiles, total_out);
+    hipLaunchKernelGGL(k_scan_apply, (int)tiles, kScanBlock, 0, s, in, (i64)n, (const i32*)sums, out);
+    PA_HIP(hipGetLastError());
+}
+
+// ---------------------------------------------------------------------------------------------
+// VariableWidthBlock.copyPositions: lengths -> (scan) -> bytes
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_varwidth_lengths(const i32* __restrict__ positions, i64 count, const i32* __restrict__ offsets,
+                                                          const u8* __restrict__ nulls, i32* __restrict__ out_len)
+{
+    for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < count; i += (i64)gridDim.x * 256) {
+        i32 p = positions ? positions[i] : (i32)i;
+        out_len[i] = (nulls && nulls[p]) ? 0 : offsets[p + 1] - offsets[p];
+    }
+}
+__global__ __launch_bounds__(256) void k_varwidth_copy(const i32* __restrict__ positions, i64 count, const i32* __restrict__ offsets,
+                                                       const u8* __restrict__ bytes, const u8* __restrict__ nulls,
+                                                       i32* __restrict__ out_offsets, u8* __restrict__ out_bytes, i32* total)
+{
+    for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < count; i += (i64)gridDim.x * 256) {
+        i32 p = positions ? positions[i] : (i32)i;
+        i32 len = (nulls && nulls[p]) ? 0 : offsets[p + 1] - offsets[p];
+        const u8* src = bytes + offsets[p];
+        u8* dst = out_bytes + out_offsets[i];
+        for (i32 b = 0; b < len; b++) dst[b] = src[b];
+        if (i == count - 1) out_offsets[count] = *total;
+    }
+}
+
+void launch_varwidth_lengths(const int32_t* positions, int64_t count, const int32_t* offsets, const uint8_t* nulls, int32_t* out_len,
+                             hipStream_t s)
+{
+    if (count <= 0) return;
+    hipLaunchKernelGGL(k_varwidth_lengths, blocks_for(count, 256) > 2048 ? 2048 : blocks_for(count, 256), 256, 0, s, positions, (i64)count, offsets,
+                       nulls, out_len);
+    PA_HIP(hipGetLastError());
+}
+void launch_varwidth_copy(const int32_t* positions, int64_t count, const int32_t* offsets, const uint8_t* bytes, const uint8_t* nulls,
+                          int32_t* out_offsets, uint8_t* out_bytes, int32_t* total, hipStream_t s)
+{
+    if (count <= 0) return;
+    hipLaunchKernelGGL(k_varwidth_copy, blocks_for(count, 256) > 2048 ? 2048 : blocks_for(count, 256), 256, 0, s, positions, (i64)count, offsets,
+                       bytes, nulls, out_offsets, out_bytes, total);
+    PA_HIP(hipGetLastError());
+}
+
+// ---------------------------------------------------------------------------------------------
+// Stable partition of positions by partition id (PartitioningExchanger.java:59-82): positions of
+// partition p keep ascending order; partitions are laid out one after the other.
+// counts[p * tiles + t] = rows of partition p in tile t  ->  exclusive scan  ->  scatter
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_partition_count(const i32* __restrict__ part, i64 n, i32 P, i64 tiles, i32* __restrict__ counts)
+{
+    __shared__ i32 hist[1024];
+    for (int i = threadIdx.x; i < P; i += 256) hist[i] = 0;
+    __syncthreads();
+    i64 base = (i64)blockIdx.x * kScanTile + (i64)threadIdx.x * kScanItems;
+#pragma unroll
+    for (int i = 0; i < kScanItems; i++) {
+        if (base + i < n) atomicAdd(&hist[part[base + i]], 1);
+    }
+    __syncthreads();
+    for (int p = threadIdx.x; p < P; p += 256) counts[(i64)p * tiles + blockIdx.x] = hist[p];
+}
+
+__global__ __launch_bounds__(256) void k_partition_scatter(const i32* __restrict__ part, i64 n, i32 P, i64 tiles,
+                                                           const i32* __restrict__ offsets, i32* __restrict__ out_positions)
+{
+    // rank of a row inside its (tile, partition) = rows of the same partition before it in the tile,
+    // obtained partition by partition with a workgroup scan; P is small (number of GPUs / drivers)
+    i64 base = (i64)blockIdx.x * kScanTile + (i64)threadIdx.x * kScanItems;
+    i32 mine[kScanItems];
+#pragma unroll
+    for (int i = 0; i < kScanItems; i++) mine[i] = (base + i < n) ? part[base + i] : -1;
+    for (i32 p = 0; p < P; p++) {
+        i32 c = 0;
+#pragma unroll
+        for (int i = 0; i < kScanItems; i++) c += (mine[i] == p) ? 1 : 0;
+        i32 total;
+        i32 ex = block_exclusive_scan(c, &total);
+        if (total == 0) continue;
+        i32 dst = offsets[(i64)p * tiles + blockIdx.x] + ex;
+#pragma unroll
+        for (int i = 0; i < kScanItems; i++) {
+            if (mine[i] == p) out_positions[dst++] = (i32)(base + i);
+        }
+    }
+}
+
+__global__ void k_partition_totals(const i32* __restrict__ offsets, i64 tiles, i32 P, i64 n, i64* __restrict__ out_counts)
+{
+    int p = threadIdx.x;
+    if (p < P) {
+        i64 start = offsets[(i64)p * tiles];
+        i64 end = (p + 1 < P) ? (i64)offsets[(i64)(p + 1) * tiles] : n;
+        out_counts[p] = end - start;
+    }
+}
+
+size_t partition_temp_bytes(int64_t n, int32_t partition_count)
+{
+    int64_t tiles = (n + kScanTile - 1) / kScanTile;
+    return (size_t)(tiles * partition_count) * 4 + scan_temp_bytes(tiles * partition_count) + 64;
+}
+
+void launch_partition_positions(const int32_t* partition, int64_t n, int32_t partition_count, int32_t* out_positions,
+                                int64_t* out_counts_dev, void* temp, hipStream_t s)
+{
+    PA_REQUIRE(partition_count >= 1 && partition_count <= 1024, PA_ERR_NOT_SUPPORTED, "1..1024 partitions");
+    if (n <= 0) {
+        PA_HIP(hipMemsetAsync(out_counts_dev, 0, (size_t)partition_count * 8, s));
+        return;
+    }
+    int64_t tiles = (n + kScanTile - 1) / kScanTile;
+    i32* counts = static_cast<i32*>(temp);
+    void* scan_temp = counts + tiles * partition_count;
+    hipLaunchKernelGGL(k_partition_count, (int)tiles, 256, 0, s, partition, (i64)n, partition_count, (i64)tiles, counts);
+    launch_exclusive_scan_i32(counts, counts, tiles * partition_count, nullptr, scan_temp, s);
+    hipLaunchKernelGGL(k_partition_scatter, (int)tiles, 256, 0, s, partition, (i64)n, partition_count, (i64)tiles, (const i32*)counts, out_positions);
+    hipLaunchKernelGGL(k_partition_totals, 1, 1024, 0, s, (const i32*)counts, (i64)tiles, partition_count, (i64)n, (i64*)out_counts_dev);
+    PA_HIP(hipGetLastError());
+}
+
+}  // namespace pa

@@ -1,0 +1,18 @@
+// scan_kernels.hpp -- launchers of scan_kernels.hip.
+#pragma once
+
+#include "common.hpp"
+
+namespace pa {
+
+size_t scan_temp_bytes(int64_t n);
+void launch_exclusive_scan_i32(const int32_t* in, int32_t* out, int64_t n, int32_t* total_out, void* temp, hipStream_t s);
+void launch_varwidth_lengths(const int32_t* positions, int64_t count, const int32_t* offsets, const uint8_t* nulls, int32_t* out_len,
+                             hipStream_t s);
+void launch_varwidth_copy(const int32_t* positions, int64_t count, const int32_t* offsets, const uint8_t* bytes, const uint8_t* nulls,
+                          int32_t* out_offsets, uint8_t* out_bytes, int32_t* total, hipStream_t s);
+size_t partition_temp_bytes(int64_t n, int32_t partition_count);
+void launch_partition_positions(const int32_t* partition, int64_t n, int32_t partition_count, int32_t* out_positions,
+                                int64_t* out_counts_dev, void* temp, hipStream_t s);
+
+}  // namespace pa

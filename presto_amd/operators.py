@@ -59,6 +59,23 @@ class Operator:
         check(lib().pa_op_kernel_time(self._h, C.byref(ms), C.byref(n)))
         return ms.value, n.value
 
+    def selectedPositions(self):
+        """FilterAndProject only: SelectedPositions of the last page -> (is_list, ndarray | count)."""
+        ptr, count, is_list = C.c_void_p(), C.c_int32(), C.c_int32()
+        check(lib().pa_filter_project_selected_positions(self._h, C.byref(ptr), C.byref(count), C.byref(is_list)))
+        if not is_list.value:
+            return False, count.value
+        return True, download(DeviceBuffer(ptr.value, 4 * count.value), np.int32, count.value)
+
+    def matchPairs(self):
+        """LookupJoin only: (probe positions, build positions) of the last probe page in emission order."""
+        p, b, count = C.c_void_p(), C.c_void_p(), C.c_int32()
+        check(lib().pa_lookup_join_match_pairs(self._h, C.byref(p), C.byref(b), C.byref(count)))
+        n = count.value
+        if n == 0:
+            return np.zeros(0, np.int32), np.zeros(0, np.int32)
+        return (download(DeviceBuffer(p.value, 4 * n), np.int32, n), download(DeviceBuffer(b.value, 4 * n), np.int32, n))
+
     def close(self):
         if self._h:
             lib().pa_op_close(self._h)
@@ -212,6 +229,13 @@ class LookupSourceFactory:
         h = C.c_void_p()
         check(lib().pa_lookup_source_create(C.byref(h)))
         self._h = h
+
+    def tables(self):
+        """(key[], positionLinks[]) of the built PagesHash."""
+        key, links, hs, n = C.c_void_p(), C.c_void_p(), C.c_int32(), C.c_int32()
+        check(lib().pa_lookup_source_tables(self._h, C.byref(key), C.byref(hs), C.byref(links), C.byref(n)))
+        return (download(DeviceBuffer(key.value, 4 * hs.value), np.int32, hs.value),
+                download(DeviceBuffer(links.value, 4 * n.value), np.int32, n.value))
 
     def destroy(self):
         if self._h:
