@@ -148,11 +148,15 @@ private:
     size_t cap_ = 0;
 };
 
+int device_cu_count();
+void require_device();
+
 // A stream either borrowed from the host (desc.stream) or owned by the operator.
 class Stream {
 public:
     explicit Stream(void* borrowed)
     {
+        require_device();  // operators construct their stream first: no device => PA_ERR_NO_DEVICE, loudly
         if (borrowed) {
             s_ = static_cast<hipStream_t>(borrowed);
             owned_ = false;

@@ -1,6 +1,6 @@
 // host_hash.hpp -- host-side copies of the reference's hash arithmetic, used where an operator has to
 // emit a $hashvalue column for a handful of result rows.  Product code; the test oracle
-// has its own independent restatement in oracle/presto_oracle.c.
+// has its own independent restatement under oracle/.
 #pragma once
 
 #include <cstdint>

@@ -1,0 +1,110 @@
+"""Hash-partitioned exchange between the GPUs of one node: the RCCL counterpart of the reference's page shuffle.
+
+Reference: rows are routed by
+    partition = (int) XxHash64.hash(Long.reverse(rawHash)) & (P - 1)     local exchange / PartitionedLookupSource
+                (core/trino-main/src/main/java/io/trino/operator/exchange/LocalPartitionGenerator.java:45-65,
+                 core/trino-main/src/main/java/io/trino/operator/join/PartitionedLookupSource.java:143-152)
+    partition = (rawHash & MAX_LONG) % P                                  remote exchange
+                (core/trino-main/src/main/java/io/trino/operator/HashGenerator.java:24-35,
+                 core/trino-main/src/main/java/io/trino/operator/PartitionedOutputOperator.java:411-431)
+with rawHash = InterpretedHashGenerator over the partition channels, appended per partition in ascending position
+order (core/trino-main/src/main/java/io/trino/operator/exchange/PartitioningExchanger.java:59-82), then serialised
+and pulled over HTTP.  Here: one rank per GPU, P = world size; the per-row work (hash, partition id, stable
+partition, gather into per-destination send buffers) runs in HIP kernels behind the C ABI, and the transfer is one
+all-to-all per column over xGMI (torch.distributed `nccl` == RCCL): raw column bytes, no serialisation, no
+compression.  Row order inside what a rank receives = (source rank, source position), i.e. what a consumer that
+drains the producers in rank order would see.
+
+The `ops` object supplies the per-row kernels so that the exchange logic can be exercised on CPU ranks (gloo) in
+the tests with a checker implementation; the product implementation is DeviceOps.
+"""
+import ctypes as C
+
+import torch
+import torch.distributed as dist
+
+from . import abi
+from .page import Block, DeviceBuffer, Page
+
+_TORCH_DTYPE = {abi.BIGINT: torch.int64, abi.INTEGER: torch.int32, abi.DATE: torch.int32, abi.DOUBLE: torch.float64,
+                abi.BOOLEAN: torch.uint8}
+
+
+class DeviceOps:
+    """Per-row exchange kernels on this rank's GPU through libpresto_amd.so; columns are torch CUDA tensors."""
+
+    def __init__(self):
+        from ._lib import check, lib
+        self._check, self._lib = check, lib()
+
+    @staticmethod
+    def _stream():
+        return torch.cuda.current_stream().cuda_stream or None
+
+    @staticmethod
+    def _page(columns, types):
+        n = int(columns[0].shape[0]) if columns else 0
+        blocks = [Block(t, abi.FLAT, n, values=DeviceBuffer(c.data_ptr(), c.numel() * c.element_size(), c))
+                  for c, t in zip(columns, types)]
+        return Page(blocks, n, abi.MEM_DEVICE)
+
+    def hash_rows(self, columns, types, channels):
+        page = self._page(columns, types)
+        cpage, keep = page.to_c()
+        out = torch.empty(page.position_count, dtype=torch.int64, device=columns[0].device)
+        ch = abi.int32_array(channels)
+        self._check(self._lib.pa_hash_page(C.byref(cpage), len(channels), ch, out.data_ptr(), self._stream()))
+        return out
+
+    def partition_ids(self, raw_hash, partition_count, local):
+        out = torch.empty(raw_hash.numel(), dtype=torch.int32, device=raw_hash.device)
+        self._check(self._lib.pa_partition_ids(raw_hash.data_ptr(), raw_hash.numel(), partition_count, 1 if local else 0,
+                                               out.data_ptr(), self._stream()))
+        return out
+
+    def partition_positions(self, partition, partition_count):
+        pos = torch.empty(partition.numel(), dtype=torch.int32, device=partition.device)
+        counts = (C.c_int64 * partition_count)()
+        self._check(self._lib.pa_partition_positions(partition.data_ptr(), partition.numel(), partition_count, pos.data_ptr(),
+                                                     counts, self._stream()))
+        return pos, [int(c) for c in counts]
+
+    def gather(self, column, positions):
+        out = torch.empty(positions.numel(), dtype=column.dtype, device=column.device)
+        self._check(self._lib.pa_gather_flat(column.data_ptr(), column.element_size(), positions.data_ptr(), positions.numel(),
+                                             out.data_ptr(), self._stream()))
+        return out
+
+
+def partition_rows(ops, columns, types, hash_channels, partition_count, local=True, raw_hash=None):
+    """Returns (positions grouped by partition, rows per partition)."""
+    if raw_hash is None:
+        raw_hash = ops.hash_rows(columns, types, hash_channels)
+    part = ops.partition_ids(raw_hash, partition_count, local)
+    return ops.partition_positions(part, partition_count)
+
+
+def exchange_columns(ops, columns, types, hash_channels, group=None, local=None, raw_hash=None):
+    """All-to-all of the rows of `columns` (1-D tensors of equal length) by the hash of `hash_channels`.
+
+    Returns (received columns, rows received from every source rank)."""
+    world = dist.get_world_size(group)
+    for t in types:
+        if t == abi.VARCHAR:
+            raise NotImplementedError("VARCHAR columns are not shuffled on device yet (fixed-width columns only)")
+    if local is None:
+        local = (world & (world - 1)) == 0  # LocalPartitionGenerator needs a power of two
+    positions, send_counts = partition_rows(ops, columns, types, hash_channels, world, local, raw_hash)
+    device = columns[0].device
+    # 8 x 8 count matrix: every rank learns how much it receives from each source
+    sc = torch.tensor(send_counts, dtype=torch.int64, device=device)
+    rc = torch.empty(world, dtype=torch.int64, device=device)
+    dist.all_to_all_single(rc, sc, group=group)
+    recv_counts = [int(x) for x in rc.tolist()]
+    received = []
+    for col in columns:
+        send = ops.gather(col, positions)
+        recv = torch.empty(sum(recv_counts), dtype=col.dtype, device=device)
+        dist.all_to_all_single(recv, send, output_split_sizes=recv_counts, input_split_sizes=send_counts, group=group)
+        received.append(recv)
+    return received, recv_counts

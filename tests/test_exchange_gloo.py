@@ -1,0 +1,119 @@
+"""world_size-2 gloo test of the exchange logic (presto_amd/exchange.py) on CPU ranks.
+
+The per-row kernels are supplied by the oracle here (checker implementation of the `ops` interface); what is under
+test is the sharded path itself: partition -> count exchange -> all-to-all per column -> per-rank build/probe,
+which must reproduce the single-process join as a multiset and keep every key on exactly one rank
+(PartitionedLookupSource semantics, …/operator/join/PartitionedLookupSource.java:143-152)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class OracleOps:
+    """CPU checker implementation of the exchange `ops` interface."""
+
+    def __init__(self):
+        from oracle import oracle as O
+        self.O = O
+
+    def _page(self, columns, types):
+        from presto_amd.page import Block, Page
+        return Page([Block.flat(t, c.numpy()) for c, t in zip(columns, types)], int(columns[0].shape[0]))
+
+    def hash_rows(self, columns, types, channels):
+        return torch.from_numpy(self.O.hash_page(self._page(columns, types), channels))
+
+    def partition_ids(self, raw_hash, partition_count, local):
+        return torch.from_numpy(self.O.partition_ids(raw_hash.numpy(), partition_count, local))
+
+    def partition_positions(self, partition, partition_count):
+        pos, counts = self.O.partition_positions(partition.numpy(), partition_count)
+        return torch.from_numpy(pos), [int(c) for c in counts]
+
+    def gather(self, column, positions):
+        return column[positions.long()]
+
+
+def make_tables(seed):
+    from presto_amd import abi
+    rng = np.random.default_rng(seed)
+    nb, npr = 3000, 8000
+    build = [rng.integers(0, 2000, nb).astype(np.int64), rng.random(nb), np.arange(nb, dtype=np.int32)]
+    probe = [rng.integers(-50, 2200, npr).astype(np.int64), np.arange(npr, dtype=np.int32)]
+    return build, [abi.BIGINT, abi.DOUBLE, abi.INTEGER], probe, [abi.BIGINT, abi.INTEGER]
+
+
+def oracle_join_rows(O, build, btypes, probe, ptypes):
+    from presto_amd.page import Block, Page
+    j = O.HashJoin(btypes, [0], [1, 2])
+    j.add_build_page(Page([Block.flat(t, c) for c, t in zip(build, btypes)], len(build[0])))
+    j.build()
+    out, pi, bi = j.probe(Page([Block.flat(t, c) for c, t in zip(probe, ptypes)], len(probe[0])), ptypes, [0], [0, 1])
+    return out.to_rows()
+
+
+def worker(rank, world, port, result_queue):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import oracle as O
+    from presto_amd.exchange import exchange_columns
+    ops = OracleOps()
+    build, btypes, probe, ptypes = make_tables(1234)
+    # every rank starts with a contiguous row range of both tables (the scan shards by row range)
+    def shard(cols):
+        n = len(cols[0])
+        lo, hi = n * rank // world, n * (rank + 1) // world
+        return [torch.from_numpy(np.ascontiguousarray(c[lo:hi])) for c in cols]
+    b_recv, b_counts = exchange_columns(ops, shard(build), btypes, [0])
+    p_recv, p_counts = exchange_columns(ops, shard(probe), ptypes, [0])
+    rows = oracle_join_rows(O, [c.numpy() for c in b_recv], btypes, [c.numpy() for c in p_recv], ptypes)
+    keys = sorted(set(b_recv[0].tolist()))
+    result_queue.put((rank, rows, keys, b_counts, p_counts))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def test_partitioned_join_over_two_gloo_ranks(oracle):
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=worker, args=(r, world, port, q)) for r in range(world)]
+    [p.start() for p in procs]
+    results = [q.get(timeout=120) for _ in range(world)]
+    [p.join(timeout=60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    results.sort()
+    build, btypes, probe, ptypes = make_tables(1234)
+    expected = oracle_join_rows(oracle, build, btypes, probe, ptypes)
+    got = [r for _, rows, _, _, _ in results for r in rows]
+    assert sorted(got) == sorted(expected) and len(got) > 0
+    # every build key lives on exactly one rank, and that rank is the one the reference's local rule names
+    k0, k1 = set(results[0][2]), set(results[1][2])
+    assert not (k0 & k1)
+    from presto_amd.page import Block, Page
+    allkeys = np.array(sorted(k0 | k1), dtype=np.int64)
+    h = oracle.hash_page(Page([Block.bigint(allkeys)], len(allkeys)), [0])
+    part = oracle.partition_ids(h, world, local=True)
+    assert set(allkeys[part == 0].tolist()) == k0 and set(allkeys[part == 1].tolist()) == k1
+    # counts are consistent: what rank r received from s is what s sent to r
+    assert sum(results[0][3]) + sum(results[1][3]) == len(build[0])
+    assert sum(results[0][4]) + sum(results[1][4]) == len(probe[0])

@@ -1,0 +1,216 @@
+"""The reference's own behavioural known-answer tests restated against the oracle.  These are
+what pins the CPU restatement: inputs are SequencePageBuilder pages, expected values are copied from the cited
+reference tests."""
+import numpy as np
+import pytest
+
+from presto_amd import abi
+from presto_amd.expr import and_, constant, field
+from presto_amd.page import Block, Page, sequence_page
+
+
+def test_fp1_filter_and_project(oracle):
+    """TestFilterAndProjectOperator.test (…/operator/TestFilterAndProjectOperator.java:80-124)"""
+    page = sequence_page(100, [(abi.VARCHAR, 0), (abi.BIGINT, 0)])
+    out = oracle.filter_project(page, field(1, abi.BIGINT).between(0, 9), [field(0, abi.VARCHAR), field(1, abi.BIGINT) + 5])
+    assert out.to_rows() == [(str(i).encode(), i + 5) for i in range(10)]
+
+
+def test_fp2_same_value_pages(oracle):
+    """…/TestFilterAndProjectOperator.java:126-161: 4 x the same page, filter c1 = 10, project c1 -> [10,10,10,10]"""
+    page = sequence_page(100, [(abi.VARCHAR, 0), (abi.BIGINT, 0)])
+    rows = []
+    for _ in range(4):
+        out = oracle.filter_project(page, field(1, abi.BIGINT).eq(10), [field(1, abi.BIGINT)])
+        rows += out.to_rows()
+    assert rows == [(10,)] * 4
+
+
+def test_page_processor_selection_shapes(oracle):
+    """TestPageProcessor partial / all / none / projection-less (…/operator/project/TestPageProcessor.java:90-200)"""
+    page = sequence_page(100, [(abi.BIGINT, 0)])
+    c0 = field(0, abi.BIGINT)
+    rng = and_(c0 >= 25, c0 < 75)
+    assert oracle.filter_positions(page, rng)[0] is True
+    assert oracle.filter_positions(page, rng)[1].tolist() == list(range(25, 75))
+    assert [r[0] for r in oracle.filter_project(page, rng, [c0]).to_rows()] == list(range(25, 75))
+    assert oracle.filter_positions(page, c0 >= 0) == (False, 100)      # positionsRange(0, 100)
+    assert oracle.filter_positions(page, c0 < 0) == (False, 0)          # positionsRange(0, 0)
+    assert oracle.filter_project(page, c0 < 0, [c0]) is None             # no page
+    out = oracle.filter_project(page, rng, [])
+    assert out.channel_count == 0 and out.position_count == 50
+    empty = Page([Block.bigint([])], 0)
+    assert oracle.filter_project(empty, None, [c0]) is None
+
+
+def test_agg1_global_aggregates(oracle):
+    """TestAggregationOperator.testAggregation (…/operator/TestAggregationOperator.java:119-156), the aggregates on
+    the device path: count 100, sum(bigint@0) 4950, avg 49.5, count(varchar) 100, sum(bigint@500) 54950, sum(double@500) 54950.0"""
+    page = sequence_page(100, [(abi.VARCHAR, 0), (abi.BIGINT, 0), (abi.VARCHAR, 300), (abi.BIGINT, 500), (abi.DOUBLE, 500), (abi.VARCHAR, 500)])
+    types = [abi.VARCHAR, abi.BIGINT, abi.VARCHAR, abi.BIGINT, abi.DOUBLE, abi.VARCHAR]
+    agg = oracle.HashAggregation(types, [], [(abi.AGG_COUNT_STAR, -1, None), (abi.AGG_SUM, 1, abi.BIGINT), (abi.AGG_AVG, 1, abi.BIGINT),
+                                             (abi.AGG_COUNT, 0, abi.VARCHAR), (abi.AGG_SUM, 3, abi.BIGINT), (abi.AGG_SUM, 4, abi.DOUBLE)])
+    agg.add_page(page)
+    assert agg.build_result().to_rows() == [(100, 4950, 49.5, 100, 54950, 54950.0)]
+
+
+def test_agg_mask_with_dirty_nulls(oracle):
+    """TestAggregationOperator.testMaskWithDirtyNulls (…/TestAggregationOperator.java:91-117): values {1,2,3,4},
+    mask bytes {0,27,0,75} with nulls {T,T,F,F} -> count = 1"""
+    mask = Block(abi.BOOLEAN, abi.FLAT, 4, values=np.array([0, 27, 0, 75], dtype=np.uint8), nulls=np.array([1, 1, 0, 0], dtype=np.uint8))
+    page = Page([Block.bigint([1, 2, 3, 4]), mask], 4)
+    agg = oracle.HashAggregation([abi.BIGINT, abi.BOOLEAN], [], [(abi.AGG_COUNT_STAR, -1, None, 1)])
+    agg.add_page(page)
+    assert agg.build_result().to_rows() == [(1,)]
+
+
+def test_agg_empty_input_default_row(oracle):
+    """AggregationOperator emits one row even without input: count 0, sum NULL (DoubleSumAggregation.java:54-63)"""
+    agg = oracle.HashAggregation([abi.DOUBLE], [], [(abi.AGG_COUNT_STAR, -1, None), (abi.AGG_SUM, 0, abi.DOUBLE), (abi.AGG_AVG, 0, abi.DOUBLE)])
+    assert agg.build_result().to_rows() == [(0, None, None)]
+
+
+@pytest.mark.parametrize("hashed", [False, True])
+def test_hagg1_hash_aggregation(oracle, hashed):
+    """TestHashAggregationOperator.testHashAggregation (…/TestHashAggregationOperator.java:160-219): 3 pages x 40 000
+    rows keyed by VARCHAR seq; per key count(*) 3, sum(bigint) 3i, avg i, count(varchar) 3"""
+    pages = [sequence_page(40000, [(abi.VARCHAR, 0), (abi.BIGINT, 0)]) for _ in range(3)]
+    types = [abi.VARCHAR, abi.BIGINT]
+    hc = -1
+    if hashed:
+        pages = [Page(p.blocks + [Block.bigint(oracle.hash_page(p, [0]))], 40000) for p in pages]
+        types, hc = types + [abi.BIGINT], 2
+    agg = oracle.HashAggregation(types, [0], [(abi.AGG_COUNT_STAR, -1, None), (abi.AGG_SUM, 1, abi.BIGINT), (abi.AGG_AVG, 1, abi.BIGINT),
+                                              (abi.AGG_COUNT, 0, abi.VARCHAR)], hash_channel=hc, expected_groups=100000)
+    for p in pages:
+        agg.add_page(p)
+    rows = agg.build_result().to_rows()
+    assert len(rows) == 40000
+    # group ids are first-seen ordinals, so the result is already in key order here
+    for i, r in enumerate(rows):
+        key, rest = r[0], r[1:]
+        if hashed:
+            assert rest[0] == oracle.combine_hash(0, oracle._s64(oracle.xxh64(key)))
+            rest = rest[1:]
+        assert key == str(i).encode() and rest == (3, 3 * i, float(i), 3)
+
+
+def test_gbh1_group_ids_are_first_seen_ordinals(oracle):
+    """TestGroupByHash.testAddPage / testGetGroupIds (…/operator/TestGroupByHash.java:69-140): values 0..499 one page at a
+    time, twice, each page added 10 times -> group id == value, count stable on re-add"""
+    gbh = oracle.HashAggregation([abi.BIGINT], [0], [], expected_groups=100)
+    for tries in range(2):
+        for value in range(500):
+            page = Page([Block.bigint([value])], 1)
+            for _ in range(3):
+                ids = gbh.add_page(page, want_group_ids=True)
+                assert ids.tolist() == [value]
+                assert gbh.group_count() == (value + 1 if tries == 0 else 500)
+
+
+def test_gbh_null_group_and_rehash(oracle):
+    """TestGroupByHash.testNullGroup (…/TestGroupByHash.java:98-118): NULL, then 1..132747 forces rehashes; contains(0) false"""
+    gbh = oracle.HashAggregation([abi.BIGINT], [0], [], expected_groups=100)
+    gbh.add_page(Page([Block.bigint([0], [1])], 1))
+    gbh.add_page(Page([Block.bigint(np.arange(1, 132748))], 132747))
+    assert gbh.group_count() == 132748
+    assert not gbh.contains(Page([Block.bigint([0])], 1), 0)
+    assert gbh.contains(Page([Block.bigint([5])], 1), 0) and gbh.contains(Page([Block.bigint([0], [1])], 1), 0)
+    assert gbh.capacity() == 262144  # 256 doubled while groups >= 0.75 * capacity
+
+
+def test_gbh_force_rehash_multichannel(oracle):
+    """TestGroupByHash.testForceRehash (…/TestGroupByHash.java:238-253): 100 VARCHAR keys into a table sized for 4"""
+    page = sequence_page(100, [(abi.VARCHAR, 0)])
+    gbh = oracle.HashAggregation([abi.VARCHAR], [0], [], expected_groups=4)
+    ids = gbh.add_page(page, want_group_ids=True)
+    assert ids.tolist() == list(range(100))
+    assert all(gbh.contains(page, i) for i in range(100))
+    assert gbh.capacity() == 256
+
+
+def test_gbh_contains_multiple_columns(oracle):
+    """TestGroupByHash.testContainsMultipleColumns (…/TestGroupByHash.java:218-235)"""
+    page = Page([Block.double(np.arange(10, dtype=np.float64)), Block.varchar([str(i) for i in range(10)])], 10)
+    gbh = oracle.HashAggregation([abi.DOUBLE, abi.VARCHAR], [0, 1], [], expected_groups=100)
+    gbh.add_page(page)
+    assert gbh.contains(Page([Block.double([3.0]), Block.varchar(["3"])], 1), 0)
+    assert not gbh.contains(Page([Block.double([3.0]), Block.varchar(["4"])], 1), 0)
+
+
+def test_links1_position_links_chain_order(oracle):
+    """TestPositionLinks.testArrayPositionLinks (…/join/TestPositionLinks.java:39-64): link(new, head) chains descend"""
+    keys = [7, 7, 7, 7, 1, 2, 3, 4, 5, 6, 9, 9, 9]  # positions 0..3 share a key, 10..12 share a key
+    j = oracle.HashJoin([abi.BIGINT], [0], [0])
+    j.add_build_page(Page([Block.bigint(keys)], len(keys)))
+    j.build()
+    key, links = j.tables()
+    assert links.tolist() == [-1, 0, 1, 2, -1, -1, -1, -1, -1, -1, -1, 10, 11]
+    assert sorted(k for k in key.tolist() if k >= 0) == [3, 4, 5, 6, 7, 8, 9, 12]  # heads = last inserted of each key
+
+
+@pytest.mark.parametrize("probe_hash,build_hash", [(False, False), (True, False), (False, True), (True, True)])
+def test_join1_inner_join(oracle, probe_hash, build_hash):
+    """TestHashJoinOperator.testInnerJoin (…/join/TestHashJoinOperator.java:192-229)"""
+    btypes = ptypes = [abi.VARCHAR, abi.BIGINT, abi.BIGINT]
+    build = sequence_page(10, [(abi.VARCHAR, 20), (abi.BIGINT, 30), (abi.BIGINT, 40)])
+    probe = sequence_page(1000, [(abi.VARCHAR, 0), (abi.BIGINT, 1000), (abi.BIGINT, 2000)])
+    bh = ph = -1
+    if build_hash:
+        build, btypes, bh = Page(build.blocks + [Block.bigint(oracle.hash_page(build, [0]))], 10), btypes + [abi.BIGINT], 3
+    if probe_hash:
+        probe, ptypes, ph = Page(probe.blocks + [Block.bigint(oracle.hash_page(probe, [0]))], 1000), ptypes + [abi.BIGINT], 3
+    j = oracle.HashJoin(btypes, [0], [0, 1, 2], hash_channel=bh)
+    j.add_build_page(build)
+    j.build()
+    out, pi, bi = j.probe(probe, ptypes, [0], [0, 1, 2], ph)
+    assert out.to_rows() == [(str(20 + i).encode(), 1020 + i, 2020 + i, str(20 + i).encode(), 30 + i, 40 + i) for i in range(10)]
+    assert pi.tolist() == list(range(20, 30)) and bi.tolist() == list(range(10))
+
+
+def test_join_nulls_never_match(oracle):
+    """TestHashJoinOperator NULL cases (…/join/TestHashJoinOperator.java:694-850): NULL keys on either side never match"""
+    build = Page([Block.varchar(["a", None, None, "a", "b"])], 5)
+    probe = Page([Block.varchar(["a", None, "b", "c"])], 4)
+    j = oracle.HashJoin([abi.VARCHAR], [0], [0])
+    j.add_build_page(build)
+    j.build()
+    out, pi, bi = j.probe(probe, [abi.VARCHAR], [0], [0])
+    assert out.to_rows() == [(b"a", b"a"), (b"a", b"a"), (b"b", b"b")]
+    assert pi.tolist() == [0, 0, 2] and bi.tolist() == [3, 0, 4]  # chain: last inserted first
+
+
+def test_join_rle_probe(oracle):
+    """…/TestHashJoinOperator.java:232-267: an RLE probe block replicates its matches"""
+    build = Page([Block.bigint([5, 6, 5])], 3)
+    probe = Page([Block.rle(Block.bigint([5]), 3)], 3)
+    j = oracle.HashJoin([abi.BIGINT], [0], [0])
+    j.add_build_page(build)
+    j.build()
+    out, pi, bi = j.probe(probe, [abi.BIGINT], [0], [0])
+    assert pi.tolist() == [0, 0, 1, 1, 2, 2] and bi.tolist() == [2, 0, 2, 0, 2, 0]
+
+
+def test_bigint_sum_overflow_is_an_error(oracle):
+    agg = oracle.HashAggregation([abi.BIGINT], [], [(abi.AGG_SUM, 0, abi.BIGINT)])
+    with pytest.raises(oracle.OracleError) as e:
+        agg.add_page(Page([Block.bigint([2 ** 62, 2 ** 62])], 2))
+    assert e.value.status == abi.ERR_NUMERIC_VALUE_OUT_OF_RANGE
+
+
+def test_q1_group_structure_against_sf1_answers(oracle):
+    """Distribution sanity of the synthetic generator against the reference's SF1 answers (tests/golden/tpch_sf1_answers.json):
+    the same 4 (returnflag, linestatus) groups with matching proportions."""
+    import json, os
+    from presto_amd import tpch
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "tpch_sf1_answers.json")))
+    n = 400000
+    cols = [oracle.tpch_column(c, 1.0, 0, n) for c in tpch.Q1_COLUMNS]
+    args = [cols[0][0], cols[0][1], cols[1][0], cols[1][1]] + [c[0] for c in cols[2:]]
+    rows = oracle.q1(args)
+    got = {(r[0].decode(), r[1].decode()): r[9] for r in rows}
+    ref = {(x["returnflag"], x["linestatus"]): x["count_order"] for x in g["q01_groups"]}
+    assert set(got) == set(ref)
+    tg, tr = sum(got.values()), sum(ref.values())
+    for k in ref:
+        assert abs(got[k] / tg - ref[k] / tr) < 0.03, (k, got[k] / tg, ref[k] / tr)
