@@ -151,12 +151,14 @@ FpKernelInfo generate_fp(const FpSpec& s, const std::vector<ChannelLayout>& layo
     src << "}\n\n";
 
     std::string vargs[4];
-    std::ostringstream vloads;
+    std::ostringstream vloads, prologue;
     emit_vector_loads(ri, layout, vloads, vargs);
+    emit_prologue(ri, layout, prologue);
     const std::string sargs = scalar_args(ri, layout);
 
     if (s.has_filter) {
         src << "extern \"C\" __global__ __launch_bounds__(256) void pa_fp_count(PaFpArgs a)\n{\n";
+        src << prologue.str();
         src << "    const i64 q = (i64)blockIdx.x * 256 + threadIdx.x;\n    const i64 row0 = q << 2;\n    u32 bits = 0;\n";
         src << "    if (a.vec && row0 + 4 <= a.n) {\n" << vloads.str();
         for (int r = 0; r < 4; r++) src << "        if (pa_sel(a" << vargs[r] << ")) bits |= " << (1 << r) << "u;\n";
@@ -167,6 +169,7 @@ FpKernelInfo generate_fp(const FpSpec& s, const std::vector<ChannelLayout>& layo
         src << "    if (threadIdx.x == 0) a.tile_counts[blockIdx.x] = total;\n}\n\n";
     }
     src << "extern \"C\" __global__ __launch_bounds__(256) void pa_fp_scatter(PaFpArgs a)\n{\n";
+    src << prologue.str();
     src << "    const i64 q = (i64)blockIdx.x * 256 + threadIdx.x;\n    const i64 row0 = q << 2;\n";
     if (s.has_filter) {
         src << "    const u32 bits = row0 < a.n ? (u32)a.sel4[q] : 0u;\n";

@@ -447,6 +447,7 @@ KernelInfo generate(const Spec& s, const std::vector<ChannelLayout>& layout, int
     else {
         src << "    PaAcc acc; acc.unused = 0;\n";
     }
+    emit_prologue(ri, layout, src);
     src << "    const i64 t = (i64)blockIdx.x * " << B << " + threadIdx.x, T = (i64)gridDim.x * " << B << ";\n";
     src << "    const i64 nq = a.vec ? (a.n >> 2) : 0;\n";
     src << "    for (i64 q = t; q < nq; q += T) {\n";

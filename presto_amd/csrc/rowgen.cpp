@@ -18,10 +18,24 @@ std::string row_params(const RowInputs& s, const std::vector<ChannelLayout>& lay
     return p.str();
 }
 
-// vector loads of row quad q and the 4 argument lists
+// Kernel prologue: wave-uniform facts about the page used by the speculative VARCHAR(1) path.
+void emit_prologue(const RowInputs& s, const std::vector<ChannelLayout>& layout, std::ostringstream& o)
+{
+    for (int c = 0; c < s.n_in; c++) {
+        if (!s.used[c] || layout[c].type != PA_VARCHAR || s.short_bound[c] != 1) continue;
+        o << "    const i32 P" << c << " = a.n > 0 ? a.o[" << c << "][0] : 0;\n";
+        o << "    const i64 PB" << c << " = a.n > 0 ? (i64)a.o[" << c << "][a.n] - P" << c << " : 0;\n";
+    }
+}
+
+// vector loads of row quad q and the 4 argument lists.  All independent loads are issued first (one HBM
+// round trip per step); work that depends on loaded offsets follows.  VARCHAR(1) keys read their 4 bytes
+// speculatively at the position they have when every earlier string of the page is one byte long, and
+// fall back to the offset-dependent path otherwise.
 void emit_vector_loads(const RowInputs& s, const std::vector<ChannelLayout>& layout, std::ostringstream& o, std::string args[4])
 {
     static const char* xyzw[4] = {"x", "y", "z", "w"};
+    std::ostringstream post;
     for (int c = 0; c < s.n_in; c++) {
         if (!s.used[c]) continue;
         std::string C = std::to_string(c);
@@ -53,23 +67,24 @@ void emit_vector_loads(const RowInputs& s, const std::vector<ChannelLayout>& lay
                     len[r] = (r < 3 ? "O" + C + "." + xyzw[r + 1] : "E" + C) + " - " + lo[r];
                 }
                 if (s.short_bound[c] > 0) {
-                    // packed bytes of short VARCHAR keys; VARCHAR(1) rows that all hold one byte are read
-                    // with a single (unaligned) dword load
-                    o << "        u64 S" << C << "0, S" << C << "1, S" << C << "2, S" << C << "3;\n";
+                    post << "        u64 S" << C << "0, S" << C << "1, S" << C << "2, S" << C << "3;\n";
                     if (s.short_bound[c] == 1) {
-                        o << "        if (E" << C << " - " << lo[0] << " == 4) {\n            u32 pk; __builtin_memcpy(&pk, (const u8*)a.v[" << C
-                          << "] + " << lo[0] << ", 4);\n";
-                        for (int r = 0; r < 4; r++) o << "            S" << C << r << " = (pk >> " << 8 * r << ") & 0xffu;\n";
-                        o << "        } else {\n";
+                        o << "        u32 K" << C << " = 0u; if (4 * q + 4 <= PB" << C << ") __builtin_memcpy(&K" << C << ", (const u8*)a.v[" << C
+                          << "] + P" << C << " + 4 * q, 4);\n";
+                        post << "        if (E" << C << " - " << lo[0] << " == 4) {\n            u32 pk = K" << C << ";\n            if (" << lo[0]
+                             << " != P" << C << " + (i32)(4 * q) || 4 * q + 4 > PB" << C << ") __builtin_memcpy(&pk, (const u8*)a.v[" << C << "] + "
+                             << lo[0] << ", 4);\n";
+                        for (int r = 0; r < 4; r++) post << "            S" << C << r << " = (pk >> " << 8 * r << ") & 0xffu;\n";
+                        post << "        } else {\n";
                     }
                     else {
-                        o << "        {\n";
+                        post << "        {\n";
                     }
                     for (int r = 0; r < 4; r++) {
-                        o << "            S" << C << r << " = pa_short_bytes((const u8*)a.v[" << C << "] + " << lo[r] << ", " << len[r] << ", "
-                          << s.short_bound[c] << ", a.err);\n";
+                        post << "            S" << C << r << " = pa_short_bytes((const u8*)a.v[" << C << "] + " << lo[r] << ", " << len[r] << ", "
+                             << s.short_bound[c] << ", a.err);\n";
                     }
-                    o << "        }\n";
+                    post << "        }\n";
                 }
                 for (int r = 0; r < 4; r++) {
                     args[r] += ", (const u8*)a.v[" + C + "] + " + lo[r] + ", " + len[r];
@@ -85,6 +100,7 @@ void emit_vector_loads(const RowInputs& s, const std::vector<ChannelLayout>& lay
             for (int r = 0; r < 4; r++) args[r] += ", ((N" + C + " >> " + std::to_string(8 * r) + ") & 0xffu) != 0u";
         }
     }
+    o << post.str();
 }
 
 std::string scalar_args(const RowInputs& s, const std::vector<ChannelLayout>& layout)
