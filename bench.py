@@ -194,6 +194,13 @@ def main():
     rows_per_step = rows * len(queries)
     value = rows_per_step * args.steps * world / elapsed
 
+    # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command (profiles/pmc_traffic.json,
+    # written by scripts/summarize_profile.py); only valid for the default workload shape they were collected on
+    pmc = {}
+    pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(pmc_path) and args.sf == 100.0 and args.page_rows == 1 << 26:
+        pmc = json.load(open(pmc_path)).get("kernels", {})
+
     def roof(name, bytes_per_row, pages):
         ms, n = ktime[name]
         if n == 0:
@@ -202,8 +209,10 @@ def main():
         rows_per_launch = sum(p.position_count for p in pages) / len(pages)
         achieved = rows_per_launch * bytes_per_row / avg_s / 1e9
         return {"bound": "hbm", "kernel": "pa_fused (%s)" % name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": ms / n, "launches": n,
-                "algorithmic_bytes_per_launch": rows_per_launch * bytes_per_row}
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": pmc.get({"q1": "q1_lds", "q6": "q6_global"}[name], {}).get("hbm_bytes_per_launch"),
+                "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE x2 on gfx950)" if pmc else None,
+                "avg_launch_ms": ms / n, "launches": n, "algorithmic_bytes_per_launch": rows_per_launch * bytes_per_row}
 
     if rank == 0:
         line = {
