@@ -35,7 +35,7 @@ void launch_merge_global_slab(const uint64_t* slab, int blocks, int nw, const in
                               hipStream_t s);
 void launch_merge_lds_slab(const uint64_t* slab, int waves, int c, int w, int nw, const int32_t* kinds_dev, uint64_t* gt_tag,
                            uint64_t* gt_keys, uint64_t* gt_words, uint32_t gt_mask, int32_t gt_max_fill, int32_t* gt_count,
-                           int32_t* err, const uint64_t* overflow_rows, hipStream_t s);
+                           int32_t* err, const uint64_t* overflow_rows, int32_t* entry_slot, hipStream_t s);
 void launch_gt_rehash(const uint64_t* old_tag, const uint64_t* old_keys, const uint64_t* old_words, uint32_t old_cap, int w, int nw,
                       uint64_t* tag, uint64_t* keys, uint64_t* words, uint32_t mask, int32_t max_fill, int32_t* count, int32_t* err,
                       hipStream_t s);
@@ -475,17 +475,18 @@ KernelInfo generate(const Spec& s, const std::vector<ChannelLayout>& layout, int
         src << "            }\n        }\n        a.slab[(u64)blockIdx.x * PA_NW + w] = r;\n    }\n";
     }
     else if (variant == V_LDS) {
-        // per-wave partial table -> slab entry [occupied, keys(W), words(NW)]
+        // per-wave partial table -> slab, field-major: field f of entry e = blockIdx.x * C + i at slab[f * E + e]
         src << "    __syncthreads();\n";
-        src << "    u64* out = a.slab + (u64)blockIdx.x * PA_C * (1 + PA_KW + PA_NW);\n";
-        src << "#pragma unroll\n    for (int i = 0; i < PA_C; i++) {\n        u64* e = out + (u64)i * (1 + PA_KW + PA_NW);\n";
+        src << "    const u64 E = (u64)gridDim.x * PA_C;\n";
+        src << "#pragma unroll\n    for (int i = 0; i < PA_C; i++) {\n        u64* e = a.slab + (u64)blockIdx.x * PA_C + i;\n";
         src << "        const bool occ = i < acc.tcount;\n        if (threadIdx.x == 0) e[0] = occ ? 1ULL : 0ULL;\n        if (occ) {\n";
-        src << "#pragma unroll\n            for (int w = 0; w < PA_KW; w++) { if (threadIdx.x == 0) e[1 + w] = acc.tk[i][w]; }\n";
+        src << "#pragma unroll\n            for (int w = 0; w < PA_KW; w++) { if (threadIdx.x == 0) e[(u64)(1 + w) * E] = acc.tk[i][w]; }\n";
         for (int w = 0; w < k.nw; w++) {
             std::string idx = "pa_accw[(" + std::to_string(w) + " * PA_C + i) * 64 + threadIdx.x]";
-            if (words[w].kind == W_SUMF) src << "            { double v = pa_wave_sum_f64(__longlong_as_double((i64)" << idx << ")); if (threadIdx.x == 0) e[1 + PA_KW + " << w << "] = (u64)__double_as_longlong(v); }\n";
-            else if (words[w].kind == W_SUMI) src << "            { i64 v = pa_wave_sum_i64_exact((i64)" << idx << ", a.err); if (threadIdx.x == 0) e[1 + PA_KW + " << w << "] = (u64)v; }\n";
-            else src << "            { i64 v = pa_wave_sum_i64((i64)" << idx << "); if (threadIdx.x == 0) e[1 + PA_KW + " << w << "] = (u64)v; }\n";
+            std::string dst = "e[(u64)(1 + PA_KW + " + std::to_string(w) + ") * E]";
+            if (words[w].kind == W_SUMF) src << "            { double v = pa_wave_sum_f64(__longlong_as_double((i64)" << idx << ")); if (threadIdx.x == 0) " << dst << " = (u64)__double_as_longlong(v); }\n";
+            else if (words[w].kind == W_SUMI) src << "            { i64 v = pa_wave_sum_i64_exact((i64)" << idx << ", a.err); if (threadIdx.x == 0) " << dst << " = (u64)v; }\n";
+            else src << "            { i64 v = pa_wave_sum_i64((i64)" << idx << "); if (threadIdx.x == 0) " << dst << " = (u64)v; }\n";
         }
         src << "        }\n    }\n";
     }
@@ -521,6 +522,11 @@ public:
     {
         // pooled buffers go back to the caches in the member destructors: all device work must be done first
         (void)hipStreamSynchronize(stream_.get());
+        if (merge_stream_) pool_stream_release(merge_stream_);  // synchronises it
+        for (int b = 0; b < 2; b++) {
+            if (ev_main_[b]) (void)hipEventDestroy(ev_main_[b]);
+            if (ev_merge_[b]) (void)hipEventDestroy(ev_merge_[b]);
+        }
     }
 
     bool needs_input() override { return !finishing_; }
@@ -613,6 +619,7 @@ private:
         uint32_t cap = next_pow2(want);
         if (cap <= gt_cap_) return;
         hipStream_t s = stream_.get();
+        drain_merges();  // in-flight merges still write the old table
         DevBuf tag, keys, words;
         tag.ensure((size_t)cap * 8);
         keys.ensure((size_t)cap * 8 * std::max(w_, 1));
@@ -629,6 +636,12 @@ private:
         gt_keys_ = std::move(keys);
         gt_words_ = std::move(words);
         gt_cap_ = cap;
+    }
+
+    void drain_merges()
+    {
+        if (merge_stream_) PA_HIP(hipStreamSynchronize(merge_stream_));
+        merge_pending_[0] = merge_pending_[1] = false;
     }
 
     // returns false when the LDS variant overflowed and the page must be redone with the HBM table
@@ -682,11 +695,23 @@ private:
                 }
             }
             else if (ki.variant == V_LDS) {
-                a.slab = static_cast<uint64_t*>(slab_.ensure((size_t)grid * ki.c * (1 + ki.w + ki.nw) * 8));
-                // the merge of this launch adds at most grid * C groups to those already known
-                ensure_table(groups_upper_ + (uint64_t)grid * ki.c);
+                const int b = lds_page_ & 1;
+                if (!merge_stream_) {
+                    merge_stream_ = pool_stream_acquire();
+                    for (int i = 0; i < 2; i++) {
+                        PA_HIP(hipEventCreateWithFlags(&ev_main_[i], hipEventDisableTiming));
+                        PA_HIP(hipEventCreateWithFlags(&ev_merge_[i], hipEventDisableTiming));
+                    }
+                }
+                // slab b was last read by the merge of page k-2
+                if (merge_pending_[b]) PA_HIP(hipStreamWaitEvent(s, ev_merge_[b], 0));
+                a.slab = static_cast<uint64_t*>(lds_slab_[b].ensure((size_t)grid * ki.c * (1 + ki.w + ki.nw) * 8));
+                a.overflow_rows = reinterpret_cast<uint64_t*>(ctl_ + 2 + 2 * b);
+                // the merges of this launch and of the one still in flight add at most 2 * grid * C groups
+                ensure_table(groups_upper_ + 2 * (uint64_t)grid * ki.c);
             }
             else {
+                drain_merges();
                 ensure_table(groups_upper_ + (uint64_t)n);
             }
             a.gt_tag = gt_tag_.as<uint64_t>();
@@ -702,20 +727,29 @@ private:
                 launch_merge_global_slab(a.slab, grid, ki.nw, ck.kinds.as<int32_t>(), state_.as<uint64_t>(), ctl_, s);
             }
             else if (ki.variant == V_LDS) {
-                // the merge skips itself when the launch overflowed (overflow_rows != 0); the host learns about
-                // it from the control block, which it reads once per page
+                // The merge skips itself when the launch overflowed (overflow_rows != 0).  It runs on the merge
+                // stream, overlapped with the next page's fused kernel; the host only waits for the fused kernel
+                // and the control block (error word, group count, overflow counters).
+                const int b = lds_page_ & 1;
+                PA_HIP(hipMemcpyAsync(h_ctl_, ctl_, 32, hipMemcpyDeviceToHost, s));
+                PA_HIP(hipEventRecord(ev_main_[b], s));
+                PA_HIP(hipStreamWaitEvent(merge_stream_, ev_main_[b], 0));
                 launch_merge_lds_slab(a.slab, grid, ki.c, ki.w, ki.nw, ck.kinds.as<int32_t>(), a.gt_tag, a.gt_keys, a.gt_words, a.gt_mask,
-                                      a.gt_max_fill, a.gt_count, ctl_, a.overflow_rows, s);
-                PA_HIP(hipMemcpyAsync(h_ctl_, ctl_, 16, hipMemcpyDeviceToHost, s));
-                PA_HIP(hipStreamSynchronize(s));
+                                      a.gt_max_fill, a.gt_count, ctl_, a.overflow_rows,
+                                      static_cast<int32_t*>(entry_slot_[b].ensure((size_t)grid * ki.c * 4)), merge_stream_);
+                PA_HIP(hipEventRecord(ev_merge_[b], merge_stream_));
+                merge_pending_[b] = true;
+                PA_HIP(hipEventSynchronize(ev_main_[b]));
                 uint64_t overflow;
-                memcpy(&overflow, h_ctl_ + 2, 8);
+                memcpy(&overflow, h_ctl_ + 2 + 2 * b, 8);
                 if (overflow != 0) {
-                    PA_HIP(hipMemsetAsync(ctl_ + 2, 0, 8, s));
+                    drain_merges();
+                    PA_HIP(hipMemsetAsync(ctl_ + 2 + 2 * b, 0, 8, s));
                     return false;
                 }
                 raise_if(h_ctl_[0]);
-                groups_upper_ = (uint64_t)h_ctl_[1];
+                groups_upper_ = (uint64_t)h_ctl_[1];  // groups merged so far (the in-flight merges are bounded above)
+                lds_page_++;
             }
             else {
                 PA_HIP(hipMemcpyAsync(h_ctl_, ctl_, 8, hipMemcpyDeviceToHost, s));
@@ -753,6 +787,12 @@ private:
     int32_t* ctl_ = nullptr;
     int32_t* h_ctl_ = nullptr;
     DevBuf slab_, state_, gt_tag_, gt_keys_, gt_words_;
+    // LDS variant: the merge of page k runs on a second stream while the fused kernel of page k+1 streams
+    DevBuf lds_slab_[2], entry_slot_[2];
+    hipStream_t merge_stream_ = nullptr;
+    hipEvent_t ev_main_[2] = {nullptr, nullptr}, ev_merge_[2] = {nullptr, nullptr};
+    bool merge_pending_[2] = {false, false};
+    int lds_page_ = 0;
     uint32_t gt_cap_ = 0;
     uint64_t groups_upper_ = 0;
     std::vector<OutColumn> out_cols_;
@@ -767,6 +807,7 @@ private:
 void FusedAggregationOperator::build_output()
 {
     hipStream_t s = stream_.get();
+    drain_merges();
     // any signature works for the layout (all share nw_/w_): take the first compiled kernel, or build
     // one for the all-non-null layout when no page ever arrived
     if (compiled_.empty()) {

@@ -120,41 +120,102 @@ void launch_merge_global_slab(const uint64_t* slab, int blocks, int nw, const in
 }
 
 // ---------------------------------------------------------------------------------------------
-// merge of the per-wave partial tables of the LDS variant into the HBM group table.
-// One lane per (wave, slot) entry: upsert the key, then add every word atomically.
+// merge of the per-wave partial tables of the LDS variant into the HBM group table, in two launches:
+//   1. one lane per (wave, slot) entry upserts the entry's key and records its table slot;
+//   2. one workgroup per occupied table slot adds the words of its entries in a fixed (lane-strided,
+//      then tree) order -- no atomics on the accumulators, bitwise reproducible for a fixed grid.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_merge_lds_slab(const u64* __restrict__ slab, i64 entries, int W, int NW,
-                                                        const i32* __restrict__ kinds, u64* tag, u64* keys, u64* words, u32 mask,
-                                                        i32 max_fill, i32* count, i32* err, const u64* overflow_rows)
+__global__ __launch_bounds__(256) void k_merge_lds_keys(const u64* __restrict__ slab, i64 entries, int W, int NW, u64* tag, u64* keys,
+                                                        u32 mask, i32 max_fill, i32* count, i32* err, const u64* overflow_rows,
+                                                        i32* __restrict__ entry_slot)
 {
+    // slab is field-major: field f of entry e at slab[f * entries + e]; fields = occupied, W key words, NW words
     // a launch whose register tables overflowed is discarded as a whole: the page is redone on the HBM table
-    if (*overflow_rows != 0ULL) return;
-    const int stride = 1 + W + NW;
+    const bool discard = *overflow_rows != 0ULL;
     for (i64 e = (i64)blockIdx.x * 256 + threadIdx.x; e < entries; e += (i64)gridDim.x * 256) {
-        const u64* ent = slab + e * stride;
-        if (ent[0] == 0ULL) continue;
-        u64 k[8];
-        for (int w = 0; w < W; w++) k[w] = ent[1 + w];
-        u32 h = pa_key_hash(k, W);
-        int g = pa_gt_upsert_n(tag, keys, mask, h, k, W, count, max_fill, err);
-        if (g < 0) continue;
-        const u64 cap = (u64)mask + 1ULL;
+        i32 g = -1;
+        if (!discard && slab[e] != 0ULL) {
+            u64 k[8];
+            for (int w = 0; w < W; w++) k[w] = slab[(i64)(1 + w) * entries + e];
+            g = pa_gt_upsert_n(tag, keys, mask, pa_key_hash(k, W), k, W, count, max_fill, err);
+        }
+        entry_slot[e] = g;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_merge_lds_words(const u64* __restrict__ slab, i64 entries, int W, int NW,
+                                                         const i32* __restrict__ kinds, const u64* __restrict__ tag, u64* words, u32 cap,
+                                                         const i32* __restrict__ entry_slot, i32* err)
+{
+    __shared__ u64 part[256];
+    __shared__ u32 occupied[256];
+    __shared__ u32 n_occupied;
+    // one coalesced look at this workgroup's 256 table slots; the (few) occupied ones are then handled in turn
+    if (threadIdx.x == 0) n_occupied = 0;
+    __syncthreads();
+    {
+        const u32 s = blockIdx.x * 256 + threadIdx.x;
+        if (s < cap && tag[s] != 0ULL) occupied[atomicAdd(&n_occupied, 1u)] = s;
+    }
+    __syncthreads();
+    const u32 n_occ = n_occupied;
+    for (u32 oi = 0; oi < n_occ; oi++) {
+        // ascending slot order keeps the workgroup's work list independent of the atomicAdd arrival order
+        u32 slot = 0xffffffffu;
+        {
+            // k-th smallest occupied slot: n_occ is tiny, a linear selection is enough
+            u32 best = 0xffffffffu;
+            for (u32 j = 0; j < n_occ; j++) {
+                u32 cand = occupied[j];
+                u32 rank = 0;
+                for (u32 i2 = 0; i2 < n_occ; i2++) rank += occupied[i2] < cand ? 1u : 0u;
+                if (rank == oi) best = cand;
+            }
+            slot = best;
+        }
         for (int w = 0; w < NW; w++) {
-            u64 v = ent[1 + W + w];
-            if (kinds[w] == PA_W_SUMF) pa_gt_add_f64(words, (u64)w * cap + g, __longlong_as_double((i64)v));
-            else if (kinds[w] == PA_W_SUMI) pa_gt_add_i64_exact(words, (u64)w * cap + g, (i64)v, err);
-            else pa_gt_add_u64(words, (u64)w * cap + g, v);
+            const int kind = kinds[w];
+            const u64* col = slab + (i64)(1 + W + w) * entries;
+            double accf = 0.0;
+            i64 acci = 0;
+            // coalesced, branch-free: entries of other slots contribute an exact zero
+            for (i64 e = threadIdx.x; e < entries; e += 256) {
+                const bool mine = entry_slot[e] == (i32)slot;
+                const u64 v = col[e];
+                if (kind == PA_W_SUMF) accf = accf + (mine ? __longlong_as_double((i64)v) : 0.0);
+                else if (kind == PA_W_SUMI) acci = pa_add_exact(acci, mine ? (i64)v : 0, err);
+                else acci += mine ? (i64)v : 0;
+            }
+            part[threadIdx.x] = kind == PA_W_SUMF ? (u64)__double_as_longlong(accf) : (u64)acci;
+            __syncthreads();
+            for (int s = 128; s >= 1; s >>= 1) {
+                if ((int)threadIdx.x < s) {
+                    if (kind == PA_W_SUMF) part[threadIdx.x] = (u64)__double_as_longlong(__longlong_as_double((i64)part[threadIdx.x]) + __longlong_as_double((i64)part[threadIdx.x + s]));
+                    else if (kind == PA_W_SUMI) part[threadIdx.x] = (u64)pa_add_exact((i64)part[threadIdx.x], (i64)part[threadIdx.x + s], err);
+                    else part[threadIdx.x] += part[threadIdx.x + s];
+                }
+                __syncthreads();
+            }
+            if (threadIdx.x == 0) {
+                u64* dst = &words[(u64)w * cap + slot];
+                if (kind == PA_W_SUMF) *dst = (u64)__double_as_longlong(__longlong_as_double((i64)*dst) + __longlong_as_double((i64)part[0]));
+                else if (kind == PA_W_SUMI) *dst = (u64)pa_add_exact((i64)*dst, (i64)part[0], err);
+                else *dst += part[0];
+            }
+            __syncthreads();
         }
     }
 }
 
 void launch_merge_lds_slab(const uint64_t* slab, int waves, int c, int w, int nw, const int32_t* kinds_dev, uint64_t* gt_tag,
                            uint64_t* gt_keys, uint64_t* gt_words, uint32_t gt_mask, int32_t gt_max_fill, int32_t* gt_count,
-                           int32_t* err, const uint64_t* overflow_rows, hipStream_t s)
+                           int32_t* err, const uint64_t* overflow_rows, int32_t* entry_slot, hipStream_t s)
 {
     int64_t entries = (int64_t)waves * c;
-    hipLaunchKernelGGL(k_merge_lds_slab, grid_for(entries, 256), 256, 0, s, (const u64*)slab, entries, w, nw, kinds_dev, (u64*)gt_tag,
-                       (u64*)gt_keys, (u64*)gt_words, gt_mask, gt_max_fill, gt_count, err, (const u64*)overflow_rows);
+    hipLaunchKernelGGL(k_merge_lds_keys, grid_for(entries, 256), 256, 0, s, (const u64*)slab, entries, w, nw, (u64*)gt_tag, (u64*)gt_keys,
+                       gt_mask, gt_max_fill, gt_count, err, (const u64*)overflow_rows, entry_slot);
+    hipLaunchKernelGGL(k_merge_lds_words, (gt_mask + 256) / 256, 256, 0, s, (const u64*)slab, entries, w, nw, kinds_dev, (const u64*)gt_tag,
+                       (u64*)gt_words, gt_mask + 1, (const i32*)entry_slot, err);
     PA_HIP(hipGetLastError());
 }
 
