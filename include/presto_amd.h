@@ -251,6 +251,11 @@ int32_t pa_host_free_pinned(void* ptr);
 int32_t pa_memcpy_h2d(void* dst, const void* src, int64_t bytes, void* stream);
 int32_t pa_memcpy_d2h(void* dst, const void* src, int64_t bytes, void* stream);
 int32_t pa_stream_synchronize(void* stream);
+/* One HIP stream per Driver: operators chained through PA_MEM_DEVICE pages must be created with the same
+ * desc.stream (stream order is what makes a producer's buffer reuse safe), as a Driver runs its operators on
+ * one thread (Driver.java:284,317,357). */
+int32_t pa_stream_create(void** stream);
+int32_t pa_stream_destroy(void* stream);
 
 /* ---- operator factories ---- */
 int32_t pa_filter_project_create(const pa_filter_project_desc* desc, pa_operator** out);

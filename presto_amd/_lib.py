@@ -42,6 +42,8 @@ def lib():
     L.pa_memcpy_h2d.argtypes = [vp, vp, C.c_int64, vp]
     L.pa_memcpy_d2h.argtypes = [vp, vp, C.c_int64, vp]
     L.pa_stream_synchronize.argtypes = [vp]
+    L.pa_stream_create.argtypes = [C.POINTER(vp)]
+    L.pa_stream_destroy.argtypes = [vp]
     L.pa_filter_project_create.argtypes = [C.POINTER(abi.pa_filter_project_desc), C.POINTER(vp)]
     L.pa_aggregation_create.argtypes = [C.POINTER(abi.pa_aggregation_desc), C.POINTER(vp)]
     L.pa_hash_aggregation_create.argtypes = [C.POINTER(abi.pa_hash_aggregation_desc), C.POINTER(vp)]
@@ -109,3 +111,20 @@ class DeviceAllocation:
             self.free()
         except Exception:
             pass
+
+
+class DeviceStream:
+    """A HIP stream owned through the C ABI: one per Driver, shared by the operators of its pipeline."""
+
+    def __init__(self):
+        p = C.c_void_p()
+        check(lib().pa_stream_create(C.byref(p)))
+        self.handle = p.value
+
+    def synchronize(self):
+        check(lib().pa_stream_synchronize(self.handle))
+
+    def destroy(self):
+        if self.handle:
+            lib().pa_stream_destroy(self.handle)
+            self.handle = None

@@ -180,6 +180,25 @@ int32_t pa_stream_synchronize(void* stream)
     });
 }
 
+int32_t pa_stream_create(void** stream)
+{
+    return guarded([&]() -> int32_t {
+        PA_REQUIRE(stream != nullptr, PA_ERR_INVALID_ARGUMENT, "stream is null");
+        require_device();
+        hipStream_t s;
+        PA_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        *stream = s;
+        return PA_OK;
+    });
+}
+int32_t pa_stream_destroy(void* stream)
+{
+    return guarded([&]() -> int32_t {
+        if (stream) PA_HIP(hipStreamDestroy((hipStream_t)stream));
+        return PA_OK;
+    });
+}
+
 // ---- factories ----
 int32_t pa_fused_aggregation_create(const pa_fused_aggregation_desc* desc, pa_operator** out)
 {

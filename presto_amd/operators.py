@@ -323,6 +323,57 @@ def to_pages(operator, input_pages):
     return out
 
 
+class Driver:
+    """Single-threaded operator pipeline, the shape of Driver.processInternal
+    (core/trino-main/src/main/java/io/trino/operator/Driver.java:355-457): a page source feeding operators[0], every
+    pass moves at most one page between each adjacent pair, finish() propagates downstream once an operator is
+    finished; the pages of the last operator are collected."""
+
+    def __init__(self, source_pages, operators):
+        self.source = iter(source_pages)
+        self.operators = list(operators)
+        self.output = []
+
+    def run(self):
+        ops = self.operators
+        pending = next(self.source, None)
+        source_done = pending is None
+        if source_done:
+            ops[0].finish()
+        for _ in range(1 << 22):
+            moved = False
+            if pending is not None and ops[0].needsInput():
+                if pending.position_count > 0:
+                    ops[0].addInput(pending)
+                pending = next(self.source, None)
+                moved = True
+                if pending is None and not source_done:
+                    source_done = True
+                    ops[0].finish()
+            for i in range(len(ops) - 1):
+                cur, nxt = ops[i], ops[i + 1]
+                if not cur.isFinished() and nxt.needsInput():
+                    page = cur.getOutput()
+                    if page is not None and page.position_count > 0:
+                        nxt.addInput(page)
+                        moved = True
+                if cur.isFinished():
+                    nxt.finish()  # idempotent (Driver.java:365-372)
+            last = ops[-1]
+            page = last.getOutput()
+            if page is not None:
+                if page.position_count > 0:
+                    self.output.append(page)
+                moved = True
+            if last.isFinished():
+                return self.output
+            if not moved and pending is None:
+                # nothing moved and nothing is left to feed: operators must be draining (finish already sent)
+                if all(op.isFinished() for op in ops):
+                    return self.output
+        raise RuntimeError("pipeline did not finish")
+
+
 # ---- device pages without torch (JNI-style hosts, tests) -----------------------------------------------
 def upload_page(page):
     """Copies a host Page into HBM through the C ABI; returns a PA_MEM_DEVICE Page."""

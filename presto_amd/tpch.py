@@ -134,3 +134,39 @@ def _ptr_of(buf):
 
 def lineitem_rows(scale_factor):
     return int(LINEITEM_ROWS_PER_SF * scale_factor)
+
+
+# ---- Q3 ------------------------------------------------------------------------------------------------
+# testing/trino-benchto-benchmarks/src/main/resources/sql/presto/tpch/q03.sql; plan shape lineitem JOIN (orders JOIN customer)
+CUSTOMER_COLUMNS = [abi.C_CUSTKEY, abi.C_MKTSEGMENT]
+CUSTOMER_TYPES = [abi.BIGINT, abi.VARCHAR]
+ORDERS_COLUMNS = [abi.O_ORDERKEY, abi.O_CUSTKEY, abi.O_ORDERDATE, abi.O_SHIPPRIORITY]
+ORDERS_TYPES = [abi.BIGINT, abi.BIGINT, abi.DATE, abi.INTEGER]
+Q3_LINEITEM_COLUMNS = [abi.L_ORDERKEY, abi.L_EXTENDEDPRICE, abi.L_DISCOUNT, abi.L_SHIPDATE]
+Q3_LINEITEM_TYPES = [abi.BIGINT, abi.DOUBLE, abi.DOUBLE, abi.DATE]
+Q3_DATE = 9204  # 1995-03-15
+
+
+def q3_customer_filter():
+    return field(1, abi.VARCHAR).eq(constant("BUILDING", abi.VARCHAR))
+
+
+def q3_orders_filter():
+    return field(2, abi.DATE) < constant(Q3_DATE, abi.DATE)
+
+
+def q3_lineitem_filter():
+    return field(3, abi.DATE) > constant(Q3_DATE, abi.DATE)
+
+
+def q3_lineitem_projections():
+    return [field(0, abi.BIGINT), field(1, abi.DOUBLE) * (constant(1.0, abi.DOUBLE) - field(2, abi.DOUBLE))]
+
+
+def customer_rows(scale_factor):
+    n = int(CUSTOMER_ROWS_PER_SF * scale_factor)
+    return n - n % 5
+
+
+def orders_rows(scale_factor):
+    return int(ORDERS_ROWS_PER_SF * scale_factor)
