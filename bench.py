@@ -33,9 +33,11 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--sf", type=float, default=100.0, help="TPC-H scale factor of the lineitem shard per GPU")
-    ap.add_argument("--page-rows", type=int, default=1 << 26, help="rows per device-resident page")
+    ap.add_argument("--page-rows", type=int, default=1 << 28, help="rows per device-resident page")
     ap.add_argument("--cpu-rows", type=int, default=16_000_000, help="rows of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--queries", default="q1,q6")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend; 'gloo' only to rehearse the multi-rank "
+                    "control flow with several ranks on one GPU (RCCL refuses two ranks on one device)")
     return ap.parse_args()
 
 
@@ -103,14 +105,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch
     import torch.distributed as dist
-    torch.cuda.set_device(local_rank)
+    device = local_rank if args.backend == "nccl" else local_rank % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(device)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device))
+        else:
+            dist.init_process_group(args.backend)
 
     from presto_amd import _lib, abi, tpch
     from presto_amd.operators import FusedAggregationOperator
-    _lib.init(local_rank)
+    _lib.init(device)
 
     rows = tpch.lineitem_rows(args.sf)
     queries = args.queries.split(",")
@@ -187,7 +193,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -198,7 +204,7 @@ def main():
     # written by scripts/summarize_profile.py); only valid for the default workload shape they were collected on
     pmc = {}
     pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(pmc_path) and args.sf == 100.0 and args.page_rows == 1 << 26:
+    if os.path.exists(pmc_path) and args.sf == 100.0 and args.page_rows == 1 << 28:
         pmc = json.load(open(pmc_path)).get("kernels", {})
 
     def roof(name, bytes_per_row, pages):

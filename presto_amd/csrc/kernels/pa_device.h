@@ -285,6 +285,10 @@ struct PaFusedArgs {
     i32* gt_count;                    // groups in the table
     i32* err;                         // first device-raised pa_status
     u64* overflow_rows;               // rows that missed the LDS table (drives mode escalation)
+    const i32* row_list;              // GT variant: process these rows (of this launch's range) instead of all n
+    i64 n_list;
+    i32* spill_rows;                  // GT variant: rows whose group did not fit the table (redone after a rehash)
+    u32* spill_count;
 };
 
 // 64-bit value of lane `lane` (wave-uniform) broadcast to the wave
@@ -320,37 +324,74 @@ __device__ __forceinline__ int pa_gt_upsert_n(u64* tag, u64* keys, u32 mask, u32
     u32 i = h & mask;
     u32 probes = 0;
     int spins = 0;
-    while (probes <= mask) {
-        u64 t = __hip_atomic_load(&tag[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (t == 0ULL) {
-            u64 old = atomicCAS(&tag[i], 0ULL, busy);
-            if (old == 0ULL) {
-                for (int w = 0; w < W; w++)
-                    __hip_atomic_store(&keys[(u64)i * W + w], k[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __hip_atomic_store(&tag[i], ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                i32 c = atomicAdd(count, 1);
-                if (c >= max_fill) pa_raise(err, PA_DEV_ERR_RESOURCES);
-                return (int)i;
+    int result = -2;  // -2 = still searching, -1 = no room, >= 0 = slot
+    // Fast path for groups that already exist (the common case once a table is warm): ordinary cached loads.
+    // Tags only ever go empty -> busy -> ready and key words are written once, before the tag turns ready, so a
+    // (possibly stale) cached view can at worst miss a group that exists -- never match a wrong one.  Hot groups
+    // are then served from L1/L2 instead of hammering one memory channel with device-scope loads.
+    {
+        u32 j = i;
+        for (int probe = 0; probe < 8; probe++) {
+            const u64 t = tag[j];
+            if (t == 0ULL) break;
+            if (t == ready) {
+                bool eq = true;
+                for (int w = 0; w < W; w++) eq = eq && (keys[(u64)j * W + w] == k[w]);
+                if (eq) return (int)j;
             }
-            t = old;
+            j = (j + 1) & mask;
         }
-        if ((t | 2ULL) == ready) {
-            if (t == busy) {
-                if (++spins > (1 << 22)) break;  // bounded: a stuck publisher surfaces as an error
-                __builtin_amdgcn_s_sleep(1);
-                continue;
-            }
-            bool eq = true;
-            for (int w = 0; w < W; w++)
-                eq = eq && (__hip_atomic_load(&keys[(u64)i * W + w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == k[w]);
-            if (eq) return (int)i;
-        }
-        i = (i + 1) & mask;
-        probes++;
     }
-    pa_raise(err, PA_DEV_ERR_RESOURCES);
-    return -1;
+    // Wave-uniform loop: every lane of the wave stays in the loop until all of them are done, so a lane that
+    // claims a slot publishes its key INSIDE the iteration of the claim.  (With an early `return` the compiler
+    // may sink the publication behind the loop, and lanes of the same wave waiting for that very slot would
+    // spin until their bound: SIMT forward-progress hazard.)
+    while (__ballot(result == -2) != 0ULL) {
+        if (result == -2) {
+            u64 t = __hip_atomic_load(&tag[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            bool advance = false;
+            if (t == 0ULL) {
+                // a new group: refuse it once the table holds max_fill groups (the caller spills the row and the
+                // host rehashes into a larger table); concurrent inserts may overshoot by the lanes in flight
+                if (__hip_atomic_load(count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= max_fill) {
+                    result = -1;
+                }
+                else {
+                    u64 old = atomicCAS(&tag[i], 0ULL, busy);
+                    if (old == 0ULL) {
+                        for (int w = 0; w < W; w++)
+                            __hip_atomic_store(&keys[(u64)i * W + w], k[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        __hip_atomic_store(&tag[i], ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        atomicAdd(count, 1);
+                        result = (int)i;
+                    }
+                    // else: someone else claimed it between the load and the CAS: look at it again next iteration
+                }
+            }
+            else if ((t | 2ULL) == ready) {
+                if (t == busy) {
+                    // being published by another lane (possibly of this wave, which finishes inside its iteration)
+                    if (++spins > (1 << 20)) result = -1;  // bounded: a stuck publisher surfaces as a spilled row
+                }
+                else {
+                    bool eq = true;
+                    for (int w = 0; w < W; w++)
+                        eq = eq && (__hip_atomic_load(&keys[(u64)i * W + w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == k[w]);
+                    if (eq) result = (int)i;
+                    else advance = true;
+                }
+            }
+            else {
+                advance = true;
+            }
+            if (advance) {
+                i = (i + 1) & mask;
+                if (++probes > mask) result = -1;  // every slot holds another key
+            }
+        }
+    }
+    return result;
 }
 template <int W>
 __device__ __forceinline__ int pa_gt_upsert(u64* tag, u64* keys, u32 mask, u32 h, const u64 (&k)[W], i32* count,

@@ -40,6 +40,9 @@ void launch_gt_rehash(const uint64_t* old_tag, const uint64_t* old_keys, const u
                       uint64_t* tag, uint64_t* keys, uint64_t* words, uint32_t mask, int32_t max_fill, int32_t* count, int32_t* err,
                       hipStream_t s);
 
+void launch_gt_compact(const uint64_t* tag, const uint64_t* keys, const uint64_t* words, uint32_t cap, int w, int nw, uint64_t* out_keys,
+                       uint64_t* out_words, uint32_t* counter, hipStream_t s);
+
 namespace {
 
 constexpr int kMaxChannels = 32;  // PA_MAX_CHANNELS in pa_device.h
@@ -61,6 +64,10 @@ struct FusedArgs {
     int32_t* gt_count;
     int32_t* err;
     uint64_t* overflow_rows;
+    const int32_t* row_list;
+    int64_t n_list;
+    int32_t* spill_rows;
+    uint32_t* spill_count;
 };
 
 enum Variant { V_GLOBAL = 0, V_LDS = 1, V_GT = 2 };
@@ -368,7 +375,7 @@ KernelInfo generate(const Spec& s, const std::vector<ChannelLayout>& layout, int
     else {
         src << "struct PaAcc { int unused; };\n";
     }
-    src << "__device__ __forceinline__ void pa_row(const PaFusedArgs& a, PaAcc& acc" << row_params(ri, layout) << ")\n{\n";
+    src << "__device__ __forceinline__ void pa_row(const PaFusedArgs& a, PaAcc& acc, const i32 row" << row_params(ri, layout) << ")\n{\n";
     src << body.str();
     // values needed after the selected-only block are declared up front
     for (int w = 0; w < k.nw; w++) {
@@ -427,7 +434,8 @@ KernelInfo generate(const Spec& s, const std::vector<ChannelLayout>& layout, int
             else if (words[w].kind == W_SUMI) src << "    if (u" << w << ") pa_gt_add_i64_exact(a.gt_words, " << idx << ", x" << w << ", a.err);\n";
             else src << "    if (u" << w << ") pa_gt_add_u64(a.gt_words, " << idx << ", 1ULL);\n";
         }
-        src << "  }\n}\n";
+        // no room for this row's group: spill the row; the host rehashes and replays the spilled rows
+        src << "  } else {\n    a.spill_rows[atomicAdd(a.spill_count, 1u)] = row;\n  }\n}\n";
     }
     src << "}\n\n";
 
@@ -453,9 +461,13 @@ KernelInfo generate(const Spec& s, const std::vector<ChannelLayout>& layout, int
     src << "    for (i64 q = t; q < nq; q += T) {\n";
     std::string args[4];
     emit_vector_loads(ri, layout, src, args);
-    for (int r = 0; r < 4; r++) src << "        pa_row(a, acc" << args[r] << ");\n";
+    for (int r = 0; r < 4; r++) src << "        pa_row(a, acc, (i32)(4 * q + " << r << ")" << args[r] << ");\n";
     src << "    }\n";
-    src << "    for (i64 r = (nq << 2) + t; r < a.n; r += T) {\n        pa_row(a, acc" << scalar_args(ri, layout) << ");\n    }\n";
+    src << "    for (i64 r = (nq << 2) + t; r < a.n; r += T) {\n        pa_row(a, acc, (i32)r" << scalar_args(ri, layout) << ");\n    }\n";
+    if (variant == V_GT) {
+        src << "    for (i64 i = t; i < a.n_list; i += T) {\n        const i64 r = a.row_list[i];\n        pa_row(a, acc, (i32)r" << scalar_args(ri, layout)
+            << ");\n    }\n";
+    }
     if (variant == V_GLOBAL) {
         src << "    __shared__ u64 red[" << (B / 64) << " * PA_NW];\n    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;\n";
         for (int w = 0; w < k.nw; w++) {
@@ -612,6 +624,7 @@ private:
         return ref;
     }
 
+    // makes room for at least min_groups groups at a load factor of one half
     void ensure_table(uint64_t min_groups)
     {
         uint64_t want = std::max<uint64_t>(1024, 2 * min_groups);
@@ -712,13 +725,19 @@ private:
             }
             else {
                 drain_merges();
-                ensure_table(groups_upper_ + (uint64_t)n);
+                // sized by the groups seen so far, not by the rows: rows whose new group does not fit are spilled and
+                // replayed after a rehash (see below)
+                ensure_table(std::max<uint64_t>({(uint64_t)32768, 2 * groups_upper_, (uint64_t)std::max(spec_.expected_groups, 0)}));
+                a.spill_rows = static_cast<int32_t*>(spill_[0].ensure((size_t)n * 4));
+                a.spill_count = reinterpret_cast<uint32_t*>(ctl_ + 6);
+                a.row_list = nullptr;
+                a.n_list = 0;
             }
             a.gt_tag = gt_tag_.as<uint64_t>();
             a.gt_keys = gt_keys_.as<uint64_t>();
             a.gt_words = gt_words_.as<uint64_t>();
             a.gt_mask = gt_cap_ ? gt_cap_ - 1 : 0;
-            a.gt_max_fill = (int32_t)(gt_cap_ - gt_cap_ / 4);
+            a.gt_max_fill = ki.variant == V_GT ? (int32_t)(gt_cap_ / 2) : (int32_t)(gt_cap_ - gt_cap_ / 4);
             void* params[] = {&a};
             timer.begin(s);
             PA_HIP(hipModuleLaunchKernel(ck.kernel.fn, grid, 1, 1, ki.block, 1, 1, 0, s, params, nullptr));
@@ -752,10 +771,34 @@ private:
                 lds_page_++;
             }
             else {
-                PA_HIP(hipMemcpyAsync(h_ctl_, ctl_, 8, hipMemcpyDeviceToHost, s));
-                PA_HIP(hipStreamSynchronize(s));
-                raise_if(h_ctl_[0]);
-                groups_upper_ = (uint64_t)h_ctl_[1];
+                // replay loop: grow the table until every row of the launch found room for its group
+                int cur = 0;
+                for (;;) {
+                    PA_HIP(hipMemcpyAsync(h_ctl_, ctl_, 32, hipMemcpyDeviceToHost, s));
+                    PA_HIP(hipStreamSynchronize(s));
+                    raise_if(h_ctl_[0]);
+                    groups_upper_ = (uint64_t)h_ctl_[1];
+                    const uint32_t spilled = (uint32_t)h_ctl_[6];
+                    if (spilled == 0) break;
+                    PA_HIP(hipMemsetAsync(ctl_ + 6, 0, 4, s));
+                    ensure_table(std::max<uint64_t>((uint64_t)gt_cap_ * 2, 2 * (groups_upper_ + spilled)));
+                    FusedArgs r = a;
+                    r.n = 0;
+                    r.row_list = spill_[cur].as<int32_t>();
+                    r.n_list = spilled;
+                    r.spill_rows = static_cast<int32_t*>(spill_[cur ^ 1].ensure((size_t)spilled * 4));
+                    r.gt_tag = gt_tag_.as<uint64_t>();
+                    r.gt_keys = gt_keys_.as<uint64_t>();
+                    r.gt_words = gt_words_.as<uint64_t>();
+                    r.gt_mask = gt_cap_ - 1;
+                    r.gt_max_fill = (int32_t)(gt_cap_ / 2);
+                    void* rparams[] = {&r};
+                    int rgrid = (int)std::max<int64_t>(1, std::min<int64_t>(((int64_t)spilled + 255) / 256, (int64_t)cus_ * 8));
+                    timer.begin(s);
+                    PA_HIP(hipModuleLaunchKernel(ck.kernel.fn, rgrid, 1, 1, ki.block, 1, 1, 0, s, rparams, nullptr));
+                    timer.end(s);
+                    cur ^= 1;
+                }
             }
             offset += n;
         }
@@ -788,7 +831,7 @@ private:
     int32_t* h_ctl_ = nullptr;
     DevBuf slab_, state_, gt_tag_, gt_keys_, gt_words_;
     // LDS variant: the merge of page k runs on a second stream while the fused kernel of page k+1 streams
-    DevBuf lds_slab_[2], entry_slot_[2];
+    DevBuf lds_slab_[2], entry_slot_[2], spill_[2], dense_keys_, dense_words_;
     hipStream_t merge_stream_ = nullptr;
     hipEvent_t ev_main_[2] = {nullptr, nullptr}, ev_merge_[2] = {nullptr, nullptr};
     bool merge_pending_[2] = {false, false};
@@ -821,39 +864,37 @@ void FusedAggregationOperator::build_output()
     }
     const KernelInfo& ki = compiled_.begin()->second->info;
 
-    // one pinned landing zone: [ctl 64 B][state | tag, keys, words]
-    const size_t table_words = grouped_ ? (size_t)gt_cap_ * (1 + std::max(w_, 1) + nw_) : (size_t)nw_;
-    uint8_t* land = static_cast<uint8_t*>(h_table_.ensure(64 + table_words * 8 + 8));
-    uint64_t* h_words = reinterpret_cast<uint64_t*>(land + 64);
-    PA_HIP(hipMemcpyAsync(land, ctl_, 16, hipMemcpyDeviceToHost, s));
-    if (!grouped_) {
-        if (state_.ptr()) PA_HIP(hipMemcpyAsync(h_words, state_.ptr(), (size_t)nw_ * 8, hipMemcpyDeviceToHost, s));
-        else memset(h_words, 0, (size_t)nw_ * 8);
-    }
-    else if (gt_cap_ > 0) {
-        PA_HIP(hipMemcpyAsync(h_words, gt_tag_.ptr(), (size_t)gt_cap_ * 8, hipMemcpyDeviceToHost, s));
-        PA_HIP(hipMemcpyAsync(h_words + gt_cap_, gt_keys_.ptr(), (size_t)gt_cap_ * 8 * std::max(w_, 1), hipMemcpyDeviceToHost, s));
-        PA_HIP(hipMemcpyAsync(h_words + (size_t)gt_cap_ * (1 + std::max(w_, 1)), gt_words_.ptr(), (size_t)gt_cap_ * 8 * nw_, hipMemcpyDeviceToHost, s));
-    }
+    // the error word and, for grouped results, the dense (keys, words) rows of the occupied table slots
+    PA_HIP(hipMemcpyAsync(h_ctl_, ctl_, 32, hipMemcpyDeviceToHost, s));
     PA_HIP(hipStreamSynchronize(s));
-    raise_if(reinterpret_cast<int32_t*>(land)[0]);
-
-    // dense (keys, words) per group
+    raise_if(h_ctl_[0]);
     std::vector<uint64_t> keys, words;
     int64_t groups = 0;
     if (!grouped_) {
         groups = 1;
-        words.assign(h_words, h_words + nw_);
+        words.assign(nw_, 0);
+        if (state_.ptr()) PA_HIP(hipMemcpy(words.data(), state_.ptr(), (size_t)nw_ * 8, hipMemcpyDeviceToHost));
     }
-    else {
-        const uint64_t* t = h_words;
-        const uint64_t* kk = h_words + gt_cap_;
-        const uint64_t* ww = h_words + (size_t)gt_cap_ * (1 + std::max(w_, 1));
-        for (uint32_t i = 0; i < gt_cap_; i++) {
-            if (t[i] == 0) continue;
-            for (int w = 0; w < w_; w++) keys.push_back(kk[(size_t)i * w_ + w]);
-            for (int w = 0; w < nw_; w++) words.push_back(ww[(size_t)w * gt_cap_ + i]);
-            groups++;
+    else if (gt_cap_ > 0) {
+        groups = h_ctl_[1];
+        if (groups > 0) {
+            const int kw = std::max(w_, 1);
+            dense_keys_.ensure((size_t)groups * kw * 8);
+            dense_words_.ensure((size_t)groups * nw_ * 8);
+            PA_HIP(hipMemsetAsync(ctl_ + 7, 0, 4, s));
+            launch_gt_compact(gt_tag_.as<uint64_t>(), gt_keys_.as<uint64_t>(), gt_words_.as<uint64_t>(), gt_cap_, kw, nw_,
+                              dense_keys_.as<uint64_t>(), dense_words_.as<uint64_t>(), reinterpret_cast<uint32_t*>(ctl_ + 7), s);
+            uint8_t* land = static_cast<uint8_t*>(h_table_.ensure((size_t)groups * (kw + nw_) * 8));
+            PA_HIP(hipMemcpyAsync(land, dense_keys_.ptr(), (size_t)groups * kw * 8, hipMemcpyDeviceToHost, s));
+            PA_HIP(hipMemcpyAsync(land + (size_t)groups * kw * 8, dense_words_.ptr(), (size_t)groups * nw_ * 8, hipMemcpyDeviceToHost, s));
+            PA_HIP(hipStreamSynchronize(s));
+            const uint64_t* hk = reinterpret_cast<const uint64_t*>(land);
+            const uint64_t* hw = hk + (size_t)groups * kw;
+            keys.resize((size_t)groups * w_);
+            for (int64_t g = 0; g < groups; g++) {
+                for (int w = 0; w < w_; w++) keys[(size_t)g * w_ + w] = hk[(size_t)g * kw + w];
+            }
+            words.assign(hw, hw + (size_t)groups * nw_);
         }
     }
     PA_REQUIRE(groups <= INT32_MAX, PA_ERR_INSUFFICIENT_RESOURCES, "too many groups for one output page");

@@ -138,6 +138,7 @@ __global__ __launch_bounds__(256) void k_merge_lds_keys(const u64* __restrict__ 
             u64 k[8];
             for (int w = 0; w < W; w++) k[w] = slab[(i64)(1 + w) * entries + e];
             g = pa_gt_upsert_n(tag, keys, mask, pa_key_hash(k, W), k, W, count, max_fill, err);
+            if (g < 0) pa_raise(err, PA_DEV_ERR_RESOURCES);  // the host sized the table for every entry of the slab
         }
         entry_slot[e] = g;
     }
@@ -230,7 +231,10 @@ __global__ __launch_bounds__(256) void k_gt_rehash(const u64* __restrict__ old_t
         for (int w = 0; w < W; w++) k[w] = old_keys[(u64)i * W + w];
         u32 h = pa_key_hash(k, W);
         int g = pa_gt_upsert_n(tag, keys, mask, h, k, W, count, max_fill, err);
-        if (g < 0) continue;
+        if (g < 0) {
+            pa_raise(err, PA_DEV_ERR_RESOURCES);  // cannot happen: the new table is larger than the old one
+            continue;
+        }
         const u64 cap = (u64)mask + 1ULL;
         // each old group maps to exactly one new slot, so plain stores suffice
         for (int w = 0; w < NW; w++) words[(u64)w * cap + g] = old_words[(u64)w * old_cap + i];
@@ -243,6 +247,25 @@ void launch_gt_rehash(const uint64_t* old_tag, const uint64_t* old_keys, const u
 {
     hipLaunchKernelGGL(k_gt_rehash, grid_for(old_cap, 256), 256, 0, s, (const u64*)old_tag, (const u64*)old_keys, (const u64*)old_words,
                        old_cap, w, nw, (u64*)tag, (u64*)keys, (u64*)words, mask, max_fill, count, err);
+    PA_HIP(hipGetLastError());
+}
+
+// dense (keys, words) rows of the occupied slots, for the output blocks (order = arrival at the counter)
+__global__ __launch_bounds__(256) void k_gt_compact(const u64* __restrict__ tag, const u64* __restrict__ keys, const u64* __restrict__ words,
+                                                    u32 cap, int W, int NW, u64* __restrict__ out_keys, u64* __restrict__ out_words, u32* counter)
+{
+    for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < (i64)cap; i += (i64)gridDim.x * 256) {
+        if (tag[i] == 0ULL) continue;
+        u32 idx = atomicAdd(counter, 1u);
+        for (int w = 0; w < W; w++) out_keys[(u64)idx * W + w] = keys[(u64)i * W + w];
+        for (int w = 0; w < NW; w++) out_words[(u64)idx * NW + w] = words[(u64)w * cap + i];
+    }
+}
+void launch_gt_compact(const uint64_t* tag, const uint64_t* keys, const uint64_t* words, uint32_t cap, int w, int nw, uint64_t* out_keys,
+                       uint64_t* out_words, uint32_t* counter, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_gt_compact, grid_for(cap, 256), 256, 0, s, (const u64*)tag, (const u64*)keys, (const u64*)words, cap, w, nw,
+                       (u64*)out_keys, (u64*)out_words, (u32*)counter);
     PA_HIP(hipGetLastError());
 }
 

@@ -1,0 +1,105 @@
+"""Operator micro-benchmarks on device-resident pages (dev tool; numbers quoted in DESIGN.md):
+FilterAndProject (Q6 shape), HashAggregation at several cardinalities (BenchmarkGroupByHash shape), hash join build /
+probe (BenchmarkHashBuildAndJoinOperators shape).  rows/s = input rows / wall time including the final sync."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from presto_amd import _lib, abi, tpch
+from presto_amd.expr import field
+from presto_amd.operators import (FilterAndProjectOperator, HashAggregationOperator, HashBuilderOperator, LookupJoinOperator,
+                                  LookupSourceFactory)
+from presto_amd.page import Block, DeviceBuffer, Page
+torch.cuda.set_device(0)
+_lib.init(0)
+which = sys.argv[1:] or ["fp", "agg", "join"]
+
+
+def dev_block(type_, t):
+    return Block(type_, abi.FLAT, t.numel(), values=DeviceBuffer(t.data_ptr(), t.numel() * t.element_size(), t))
+
+
+def timeit(fn, reps=5):
+    torch.cuda.synchronize()  # inputs were produced on torch's stream; operators run on their own
+    fn()
+    torch.cuda.synchronize()
+    best = 1e9
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        fn()
+        torch.cuda.synchronize()
+        best = min(best, time.perf_counter() - t0)
+    return best
+
+
+if "fp" in which:
+    rows = 1 << 27
+    dev = tpch.DeviceColumns(tpch.Q6_COLUMNS, 100.0, rows)
+    pages = list(dev.pages(1 << 26))
+    for name, f in (("q6 filter (1.9% pass)", tpch.q6_filter()), ("q1 filter (96% pass)", field(0, abi.DATE) <= 10471)):
+        def run():
+            op = FilterAndProjectOperator(tpch.Q6_TYPES, f, tpch.q6_projections() + [field(0, abi.DATE)], output_mem=abi.MEM_DEVICE)
+            for p in pages:
+                op.addInput(p)
+                op.getOutput()
+            op.finish()
+            ms, n = op.kernelTime()
+            op.close()
+            return ms
+        dt = timeit(run)
+        print("FilterAndProject %-24s %.3g rows/s  (%.1f GB/s of the 28 B/row inputs)" % (name, rows / dt, rows * 28 / dt / 1e9))
+
+if "agg" in which:
+    rows = 1 << 26
+    g = torch.Generator(device="cuda").manual_seed(1)
+    vals = torch.rand(rows, dtype=torch.float64, device="cuda", generator=g)
+    for groups in [int(x) for x in os.environ.get("AGG_GROUPS", "4,64,1000,100000,3000000").split(",")]:
+        keys = torch.randint(0, groups, (rows,), dtype=torch.int64, device="cuda", generator=g)
+        page = Page([dev_block(abi.BIGINT, keys), dev_block(abi.DOUBLE, vals)], rows, abi.MEM_DEVICE)
+        sub = [Page([Block(abi.BIGINT, abi.FLAT, 1 << 24, values=DeviceBuffer(keys.data_ptr() + 8 * i, 8 << 24, keys)),
+                     Block(abi.DOUBLE, abi.FLAT, 1 << 24, values=DeviceBuffer(vals.data_ptr() + 8 * i, 8 << 24, vals))], 1 << 24, abi.MEM_DEVICE)
+               for i in range(0, rows, 1 << 24)]
+        def run():
+            op = HashAggregationOperator([abi.BIGINT, abi.DOUBLE], [0], [(abi.AGG_SUM, 1, abi.DOUBLE), (abi.AGG_COUNT_STAR, -1, None)],
+                                         expected_groups=groups, output_mem=abi.MEM_DEVICE)
+            for p in sub:
+                op.addInput(p)
+            op.finish()
+            out = op.getOutput()
+            n = out.position_count
+            op.close()
+            return n
+        dt = timeit(run, reps=3)
+        print("HashAggregation %8d groups: %.3g rows/s (%.1f GB/s of the 16 B/row inputs), %d groups out" % (groups, rows / dt, rows * 16 / dt / 1e9, run()))
+
+if "join" in which:
+    g = torch.Generator(device="cuda").manual_seed(2)
+    for nb, npr in ((1 << 20, 1 << 26), (15_000_000, 1 << 26)):
+        bkeys = torch.randperm(nb, device="cuda", generator=g).to(torch.int64) * 4
+        bpay = torch.arange(nb, dtype=torch.int32, device="cuda")
+        pkeys = torch.randint(0, nb * 8, (npr,), dtype=torch.int64, device="cuda", generator=g)  # ~50 % match
+        pval = torch.rand(npr, dtype=torch.float64, device="cuda", generator=g)
+        build = Page([dev_block(abi.BIGINT, bkeys), dev_block(abi.INTEGER, bpay)], nb, abi.MEM_DEVICE)
+        probes = [Page([Block(abi.BIGINT, abi.FLAT, 1 << 24, values=DeviceBuffer(pkeys.data_ptr() + 8 * i, 8 << 24, pkeys)),
+                        Block(abi.DOUBLE, abi.FLAT, 1 << 24, values=DeviceBuffer(pval.data_ptr() + 8 * i, 8 << 24, pval))], 1 << 24, abi.MEM_DEVICE)
+                  for i in range(0, npr, 1 << 24)]
+        bridge = LookupSourceFactory()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        b = HashBuilderOperator(bridge, [abi.BIGINT, abi.INTEGER], [0], [1], expected_positions=nb)
+        b.addInput(build)
+        b.finish()
+        torch.cuda.synchronize()
+        tb = time.perf_counter() - t0
+        def run():
+            j = LookupJoinOperator(bridge, [abi.BIGINT, abi.DOUBLE], [0], [0, 1], output_mem=abi.MEM_DEVICE)
+            total = 0
+            for p in probes:
+                j.addInput(p)
+                out = j.getOutput()
+                total += out.position_count if out is not None else 0
+            j.finish()
+            j.close()
+            return total
+        dt = timeit(run, reps=3)
+        print("HashJoin build %9d rows: %.3g rows/s (incl. allocation); probe %d rows: %.3g rows/s, %d matches" % (nb, nb / tb, npr, npr / dt, run()))
