@@ -169,12 +169,21 @@ typedef struct pa_filter_project_desc {
     void* stream;                        /* hipStream_t to launch on; NULL = library-owned stream */
 } pa_filter_project_desc;
 
-/* AggregationOperator (AggregationOperator.java:40-140): global aggregates, Step.SINGLE. */
+/* Intermediate states of Step.PARTIAL / Step.FINAL (AggregationNode.Step): the reference serialises LongState /
+ * LongDoubleState / LongLongState rows; here they are flattened into plain channels, per aggregate
+ *   count(*), count(x)  ->  [count BIGINT]
+ *   sum(x), avg(x)      ->  [count BIGINT, sum DOUBLE]   (sum BIGINT for sum over BIGINT/INTEGER)
+ * PARTIAL emits keys, ($hashvalue), then these channels; FINAL takes them as input: pa_aggregate.input_channel names
+ * the aggregate's count channel (the sum channel follows it), input_type the type of the sum, and it combines with the
+ * @CombineFunction of the aggregate (DoubleSumAggregation.java:47-52 etc.). */
+
+/* AggregationOperator (AggregationOperator.java:40-140): global aggregates. */
 typedef struct pa_aggregation_desc {
     int32_t input_channel_count;
     const int32_t* input_types;
     int32_t aggregate_count;
     const pa_aggregate* aggregates;
+    int32_t step;                        /* pa_agg_step */
     int32_t output_mem;
     void* stream;
 } pa_aggregation_desc;
@@ -187,7 +196,7 @@ typedef struct pa_hash_aggregation_desc {
     int32_t group_by_count;
     const int32_t* group_by_channels;
     int32_t hash_channel;                /* precomputed $hashvalue channel or -1 */
-    int32_t step;                        /* pa_agg_step; SINGLE supported */
+    int32_t step;                        /* pa_agg_step */
     int32_t aggregate_count;
     const pa_aggregate* aggregates;
     int32_t expected_groups;

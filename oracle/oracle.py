@@ -205,9 +205,10 @@ def make_hash_agg_desc(input_types, group_by_channels, aggregates, hash_channel=
 class HashAggregation:
     """InMemoryHashAggregationBuilder (+ GroupByHash) / AggregationOperator restatement."""
 
-    def __init__(self, input_types, group_by_channels, aggregates, hash_channel=-1, expected_groups=10000):
+    def __init__(self, input_types, group_by_channels, aggregates, hash_channel=-1, expected_groups=10000,
+                 step=abi.STEP_SINGLE):
         self._desc, self._keep = make_hash_agg_desc(input_types, group_by_channels, aggregates, hash_channel,
-                                                    expected_groups)
+                                                    expected_groups, step)
         self._h = lib().orc_hash_agg_create(C.byref(self._desc))
 
     def add_page(self, page, want_group_ids=False):

@@ -1236,6 +1236,37 @@ static void accumulate(orc_hash_agg* a, int32_t k, const pa_page* page, const in
 {
     const pa_aggregate* ag = &a->aggs[k];
     acc_state* st = a->states + (size_t)k * a->state_cap;
+    if (a->desc.step == PA_STEP_FINAL) {
+        /* Step.FINAL: the input channels are intermediate states [count BIGINT] (+ [sum]); the @CombineFunction of
+         * every aggregate adds them (DoubleSumAggregation.java:47-52, AverageAggregations.java:60-65,
+         * CountAggregation.java:45-49, LongSumAggregation.java:48-53) */
+        for (int32_t pos = 0; pos < page->position_count; pos++) {
+            acc_state* s = &st[gids ? gids[pos] : 0];
+            orc_val c = col_get(&page->columns[ag->input_channel], pos);
+            if (c.is_null) {
+                continue;
+            }
+            s->count += c.i;
+            if (ag->fn == PA_AGG_SUM || ag->fn == PA_AGG_AVG) {
+                orc_val v = col_get(&page->columns[ag->input_channel + 1], pos);
+                if (v.is_null) {
+                    continue;
+                }
+                if (v.type == PA_DOUBLE) {
+                    s->dsum = s->dsum + v.d;
+                }
+                else {
+                    int64_t r;
+                    if (__builtin_add_overflow(s->lsum, v.i, &r)) {
+                        a->error = PA_ERR_NUMERIC_VALUE_OUT_OF_RANGE;
+                        return;
+                    }
+                    s->lsum = r;
+                }
+            }
+        }
+        return;
+    }
     for (int32_t pos = 0; pos < page->position_count; pos++) {
         if (!mask_passes(page, ag->mask_channel, pos)) {
             continue;
@@ -1343,7 +1374,12 @@ int32_t orc_hash_agg_build_result(orc_hash_agg* a, pa_page* out)
     int32_t groups = a->next_group_id;
     int32_t nkeys = a->desc.group_by_count;
     int32_t has_hash = nkeys > 0 && a->desc.hash_channel >= 0;
-    int32_t ncols = nkeys + has_hash + a->desc.aggregate_count;
+    int32_t partial = a->desc.step == PA_STEP_PARTIAL;
+    int32_t agg_cols = 0;
+    for (int32_t k = 0; k < a->desc.aggregate_count; k++) {
+        agg_cols += (partial && (a->aggs[k].fn == PA_AGG_SUM || a->aggs[k].fn == PA_AGG_AVG)) ? 2 : 1;
+    }
+    int32_t ncols = nkeys + has_hash + agg_cols;
     memset(out, 0, sizeof *out);
     out->position_count = groups;
     out->channel_count = ncols;
@@ -1407,6 +1443,24 @@ int32_t orc_hash_agg_build_result(orc_hash_agg* a, pa_page* out)
     for (int32_t k = 0; k < a->desc.aggregate_count; k++) {
         const pa_aggregate* ag = &a->aggs[k];
         const acc_state* st = a->states + (size_t)k * a->state_cap;
+        if (partial) {
+            /* Step.PARTIAL: the states themselves, flattened: [count BIGINT] (+ [sum DOUBLE | BIGINT]) */
+            int value_double = ag->fn == PA_AGG_AVG || ag->input_type == PA_DOUBLE;
+            for (int part = 0; part < ((ag->fn == PA_AGG_SUM || ag->fn == PA_AGG_AVG) ? 2 : 1); part++) {
+                col_builder b;
+                cb_init(&b, part == 0 ? PA_BIGINT : (value_double ? PA_DOUBLE : PA_BIGINT), groups);
+                for (int32_t g = 0; g < groups; g++) {
+                    orc_val v;
+                    memset(&v, 0, sizeof v);
+                    v.type = b.type;
+                    if (part == 0) v.i = st[g].count;
+                    else { v.d = st[g].dsum; v.i = st[g].lsum; }
+                    cb_append(&b, &v);
+                }
+                cb_finish(&b, &out->columns[c++]);
+            }
+            continue;
+        }
         int32_t out_type;
         switch (ag->fn) {
             case PA_AGG_COUNT_STAR:

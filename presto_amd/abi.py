@@ -137,6 +137,7 @@ class pa_aggregation_desc(C.Structure):
         ("input_types", C.POINTER(C.c_int32)),
         ("aggregate_count", C.c_int32),
         ("aggregates", C.POINTER(pa_aggregate)),
+        ("step", C.c_int32),
         ("output_mem", C.c_int32),
         ("stream", C.c_void_p),
     ]

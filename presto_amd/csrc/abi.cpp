@@ -259,7 +259,7 @@ int32_t pa_aggregation_create(const pa_aggregation_desc* desc, pa_operator** out
         h.input_types = desc->input_types;
         h.group_by_count = 0;
         h.hash_channel = -1;
-        h.step = PA_STEP_SINGLE;
+        h.step = desc->step;
         h.aggregate_count = desc->aggregate_count;
         h.aggregates = desc->aggregates;
         h.output_mem = desc->output_mem;

@@ -96,6 +96,7 @@ struct Spec {
     int hash_channel = -1;
     std::vector<pa_aggregate> aggs;
     int expected_groups = 0;
+    int step = PA_STEP_SINGLE;
     int output_mem = PA_MEM_HOST;
     std::vector<bool> used_channel;
     std::vector<int> short_bound;  // per channel: > 0 when the channel is a short VARCHAR group key (packed bytes passed as cs<c>)
@@ -129,7 +130,8 @@ Spec make_spec(const pa_fused_aggregation_desc* d)
     for (int32_t j = 0; j < fp.projection_count; j++) s.proj.push_back(OwnedExpr::copy(fp.projections[j]));
     PA_REQUIRE(ag.input_channel_count == fp.projection_count, PA_ERR_INVALID_ARGUMENT,
                "aggregation input channels must be the projection outputs");
-    PA_REQUIRE(ag.step == PA_STEP_SINGLE, PA_ERR_NOT_SUPPORTED, "only Step.SINGLE runs on device");
+    PA_REQUIRE(ag.step == PA_STEP_SINGLE || ag.step == PA_STEP_PARTIAL || ag.step == PA_STEP_FINAL, PA_ERR_INVALID_ARGUMENT, "unknown aggregation step");
+    s.step = ag.step;
     for (int32_t g = 0; g < ag.group_by_count; g++) {
         int ch = ag.group_by_channels[g];
         PA_REQUIRE(ch >= 0 && ch < fp.projection_count, PA_ERR_INVALID_ARGUMENT, "group-by channel out of range");
@@ -142,7 +144,18 @@ Spec make_spec(const pa_fused_aggregation_desc* d)
                    "aggregate input channel out of range");
         PA_REQUIRE(a.mask_channel < fp.projection_count, PA_ERR_INVALID_ARGUMENT, "aggregate mask channel out of range");
         PA_REQUIRE(a.fn != PA_AGG_MIN && a.fn != PA_AGG_MAX, PA_ERR_NOT_SUPPORTED, "min/max are not on the device path yet");
-        if (a.fn != PA_AGG_COUNT_STAR) {
+        if (s.step == PA_STEP_FINAL) {
+            // intermediate input: [count BIGINT] for count / count(*), [count BIGINT, sum] for sum / avg
+            PA_REQUIRE(a.input_channel >= 0 && s.proj[a.input_channel].root_type() == PA_BIGINT, PA_ERR_INVALID_ARGUMENT,
+                       "FINAL step: the aggregate's first state channel must be the BIGINT count");
+            PA_REQUIRE(a.mask_channel < 0, PA_ERR_INVALID_ARGUMENT, "FINAL step takes no mask");
+            if (a.fn == PA_AGG_SUM || a.fn == PA_AGG_AVG) {
+                PA_REQUIRE(a.input_channel + 1 < fp.projection_count, PA_ERR_INVALID_ARGUMENT, "FINAL step: missing sum state channel");
+                int32_t t = s.proj[a.input_channel + 1].root_type();
+                PA_REQUIRE(t == PA_DOUBLE || (a.fn == PA_AGG_SUM && t == PA_BIGINT), PA_ERR_INVALID_ARGUMENT, "FINAL step: bad sum state type");
+            }
+        }
+        else if (a.fn != PA_AGG_COUNT_STAR) {
             int32_t t = s.proj[a.input_channel].root_type();
             PA_REQUIRE(a.fn == PA_AGG_COUNT || t == PA_DOUBLE || t == PA_BIGINT || t == PA_INTEGER, PA_ERR_NOT_SUPPORTED,
                        "sum/avg input type not supported on device");
@@ -156,7 +169,8 @@ Spec make_spec(const pa_fused_aggregation_desc* d)
     if (s.has_filter) s.filter.collect_channels(&used);
     std::set<int> used_proj(s.group_proj.begin(), s.group_proj.end());
     for (const auto& a : s.aggs) {
-        if (a.fn != PA_AGG_COUNT_STAR) used_proj.insert(a.input_channel);
+        if (a.fn != PA_AGG_COUNT_STAR || s.step == PA_STEP_FINAL) used_proj.insert(a.input_channel);
+        if (s.step == PA_STEP_FINAL && (a.fn == PA_AGG_SUM || a.fn == PA_AGG_AVG)) used_proj.insert(a.input_channel + 1);
         if (a.mask_channel >= 0) used_proj.insert(a.mask_channel);
     }
     for (int j : used_proj) s.proj[j].collect_channels(&used);
@@ -217,7 +231,7 @@ KernelInfo generate(const Spec& s, const std::vector<ChannelLayout>& layout, int
         GenValue f = gen.emit(s.filter, body);
         sel = f.nullable() ? "(!" + f.n + " && " + f.v + ")" : f.v;  // PageFunctionCompiler.java:539-542
     }
-    body << "const bool sel = " << sel << ";\n";
+    body << "const bool sel = live && " << sel << ";\n";
 
     // 2. projections used downstream, evaluated once, only for selected rows
     std::ostringstream inner;
@@ -319,6 +333,22 @@ KernelInfo generate(const Spec& s, const std::vector<ChannelLayout>& layout, int
         return (int)words.size() - 1;
     };
     for (const auto& ag : s.aggs) {
+        if (s.step == PA_STEP_FINAL) {
+            // combine functions (DoubleSumAggregation.combine, AverageAggregations.combine, CountAggregation.combine,
+            // LongSumAggregation.combine: SURVEY a15): counts and sums of the partial states add up
+            const GenValue& c = proj_value(ag.input_channel);
+            std::string ch = std::to_string(ag.input_channel);
+            std::string ccond = c.nullable() ? "(!" + c.n + ")" : "true";
+            int cw = word(W_CNT, ccond, c.v, "fcnt|" + ch);
+            int vw = -1;
+            if (ag.fn == PA_AGG_SUM || ag.fn == PA_AGG_AVG) {
+                const GenValue& v = proj_value(ag.input_channel + 1);
+                std::string vcond = v.nullable() ? "(" + ccond + " && !" + v.n + ")" : ccond;
+                vw = word(v.type == PA_DOUBLE ? W_SUMF : W_SUMI, vcond, v.v, "fsum|" + ch);
+            }
+            k.agg_words.emplace_back(cw, vw);
+            continue;
+        }
         std::string cond = "true", ckey = "m" + std::to_string(ag.mask_channel);
         if (ag.mask_channel >= 0) {
             const GenValue& m = proj_value(ag.mask_channel);
@@ -375,7 +405,7 @@ KernelInfo generate(const Spec& s, const std::vector<ChannelLayout>& layout, int
     else {
         src << "struct PaAcc { int unused; };\n";
     }
-    src << "__device__ __forceinline__ void pa_row(const PaFusedArgs& a, PaAcc& acc, const i32 row" << row_params(ri, layout) << ")\n{\n";
+    src << "__device__ __forceinline__ void pa_row(const PaFusedArgs& a, PaAcc& acc, const bool live, const i32 row" << row_params(ri, layout) << ")\n{\n";
     src << body.str();
     // values needed after the selected-only block are declared up front
     for (int w = 0; w < k.nw; w++) {
@@ -395,7 +425,7 @@ KernelInfo generate(const Spec& s, const std::vector<ChannelLayout>& layout, int
         for (int w = 0; w < k.nw; w++) {
             if (words[w].kind == W_SUMF) src << "if (u" << w << ") acc.w" << w << " = acc.w" << w << " + x" << w << ";\n";
             else if (words[w].kind == W_SUMI) src << "if (u" << w << ") acc.w" << w << " = pa_add_exact(acc.w" << w << ", x" << w << ", a.err);\n";
-            else src << "if (u" << w << ") acc.w" << w << " += 1;\n";
+            else src << "if (u" << w << ") acc.w" << w << " += x" << w << ";\n";
         }
         src << "}\n";
     }
@@ -419,7 +449,7 @@ KernelInfo generate(const Spec& s, const std::vector<ChannelLayout>& layout, int
                 src << "    if (u" << w << ") { i64* p = (i64*)&" << idx << "; *p = pa_add_exact(*p, x" << w << ", a.err); }\n";
             }
             else {
-                src << "    if (u" << w << ") __hip_atomic_fetch_add(&" << idx << ", 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);\n";
+                src << "    if (u" << w << ") __hip_atomic_fetch_add(&" << idx << ", (u64)x" << w << ", __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);\n";
             }
         }
         src << "  } else {\n    atomicAdd((unsigned long long*)a.overflow_rows, 1ULL);\n  }\n}\n";
@@ -432,7 +462,7 @@ KernelInfo generate(const Spec& s, const std::vector<ChannelLayout>& layout, int
             std::string idx = std::to_string(w) + "ULL * cap + (u64)g";
             if (words[w].kind == W_SUMF) src << "    if (u" << w << ") pa_gt_add_f64(a.gt_words, " << idx << ", x" << w << ");\n";
             else if (words[w].kind == W_SUMI) src << "    if (u" << w << ") pa_gt_add_i64_exact(a.gt_words, " << idx << ", x" << w << ", a.err);\n";
-            else src << "    if (u" << w << ") pa_gt_add_u64(a.gt_words, " << idx << ", 1ULL);\n";
+            else src << "    if (u" << w << ") pa_gt_add_u64(a.gt_words, " << idx << ", (u64)x" << w << ");\n";
         }
         // no room for this row's group: spill the row; the host rehashes and replays the spilled rows
         src << "  } else {\n    a.spill_rows[atomicAdd(a.spill_count, 1u)] = row;\n  }\n}\n";
@@ -458,14 +488,27 @@ KernelInfo generate(const Spec& s, const std::vector<ChannelLayout>& layout, int
     emit_prologue(ri, layout, src);
     src << "    const i64 t = (i64)blockIdx.x * " << B << " + threadIdx.x, T = (i64)gridDim.x * " << B << ";\n";
     src << "    const i64 nq = a.vec ? (a.n >> 2) : 0;\n";
-    src << "    for (i64 q = t; q < nq; q += T) {\n";
     std::string args[4];
-    emit_vector_loads(ri, layout, src, args);
-    for (int r = 0; r < 4; r++) src << "        pa_row(a, acc, (i32)(4 * q + " << r << ")" << args[r] << ");\n";
-    src << "    }\n";
-    src << "    for (i64 r = (nq << 2) + t; r < a.n; r += T) {\n        pa_row(a, acc, (i32)r" << scalar_args(ri, layout) << ");\n    }\n";
+    if (variant == V_LDS) {
+        // The wave's key table is wave-uniform state: every lane must take part in every pa_row call, so the loops
+        // run until the LAST lane of the wave is done and finished lanes ride along with live == false (their loads
+        // are clamped to a valid row).
+        src << "    for (i64 qi = t; __ballot(qi < nq) != 0ULL; qi += T) {\n        const bool live = qi < nq;\n        const i64 q = live ? qi : 0;\n";
+        emit_vector_loads(ri, layout, src, args);
+        for (int r = 0; r < 4; r++) src << "        pa_row(a, acc, live, (i32)(4 * q + " << r << ")" << args[r] << ");\n";
+        src << "    }\n";
+        src << "    for (i64 ri = (nq << 2) + t; __ballot(ri < a.n) != 0ULL; ri += T) {\n        const bool live = ri < a.n;\n        const i64 r = live ? ri : a.n - 1;\n"
+               "        pa_row(a, acc, live, (i32)r" << scalar_args(ri, layout) << ");\n    }\n";
+    }
+    else {
+        src << "    for (i64 q = t; q < nq; q += T) {\n";
+        emit_vector_loads(ri, layout, src, args);
+        for (int r = 0; r < 4; r++) src << "        pa_row(a, acc, true, (i32)(4 * q + " << r << ")" << args[r] << ");\n";
+        src << "    }\n";
+        src << "    for (i64 r = (nq << 2) + t; r < a.n; r += T) {\n        pa_row(a, acc, true, (i32)r" << scalar_args(ri, layout) << ");\n    }\n";
+    }
     if (variant == V_GT) {
-        src << "    for (i64 i = t; i < a.n_list; i += T) {\n        const i64 r = a.row_list[i];\n        pa_row(a, acc, (i32)r" << scalar_args(ri, layout)
+        src << "    for (i64 i = t; i < a.n_list; i += T) {\n        const i64 r = a.row_list[i];\n        pa_row(a, acc, true, (i32)r" << scalar_args(ri, layout)
             << ");\n    }\n";
     }
     if (variant == V_GLOBAL) {
@@ -902,7 +945,10 @@ void FusedAggregationOperator::build_output()
 
     const int nkeys = (int)spec_.group_proj.size();
     const bool has_hash = nkeys > 0 && spec_.hash_channel >= 0;
-    const int ncols = nkeys + (has_hash ? 1 : 0) + (int)spec_.aggs.size();
+    const bool partial = spec_.step == PA_STEP_PARTIAL;
+    int agg_cols = 0;
+    for (const auto& ag : spec_.aggs) agg_cols += (partial && (ag.fn == PA_AGG_SUM || ag.fn == PA_AGG_AVG)) ? 2 : 1;
+    const int ncols = nkeys + (has_hash ? 1 : 0) + agg_cols;
     out_cols_.clear();
     out_cols_.resize(ncols);
     std::vector<std::vector<uint8_t>> host_cols(ncols), host_nulls(ncols);
@@ -993,12 +1039,28 @@ void FusedAggregationOperator::build_output()
         host_nulls[col].assign(groups ? groups : 1, 0);
         col++;
     }
-    for (size_t k = 0; k < spec_.aggs.size(); k++, col++) {
+    for (size_t k = 0; k < spec_.aggs.size(); k++) {
         const pa_aggregate& ag = spec_.aggs[k];
         int cw = ki.agg_words[k].first, vw = ki.agg_words[k].second;
+        const bool value_is_double = vw >= 0 && ki.word_kind[vw] == W_SUMF;
+        if (partial) {
+            // Step.PARTIAL: the accumulator states themselves -- [count BIGINT] (+ [sum]) per aggregate, the flattened form
+            // of the reference's LongState / LongDoubleState / LongLongState intermediate rows
+            for (int part = 0; part < ((ag.fn == PA_AGG_SUM || ag.fn == PA_AGG_AVG) ? 2 : 1); part++, col++) {
+                OutColumn& oc = out_cols_[col];
+                oc.type = part == 0 ? PA_BIGINT : (value_is_double ? PA_DOUBLE : PA_BIGINT);
+                auto& data = host_cols[col];
+                host_nulls[col].assign(groups ? groups : 1, 0);
+                data.resize((size_t)groups * 8);
+                for (int64_t g = 0; g < groups; g++) memcpy(&data[(size_t)g * 8], &words[(size_t)g * nw_ + (part == 0 ? cw : vw)], 8);
+                oc.has_nulls = false;
+            }
+            continue;
+        }
         OutColumn& oc = out_cols_[col];
-        bool as_double = ag.fn == PA_AGG_AVG || (ag.fn == PA_AGG_SUM && vw >= 0 && ki.word_kind[vw] == W_SUMF);
-        oc.type = as_double ? PA_DOUBLE : ((ag.fn == PA_AGG_SUM) ? spec_.proj[ag.input_channel].root_type() : PA_BIGINT);
+        bool as_double = ag.fn == PA_AGG_AVG || (ag.fn == PA_AGG_SUM && value_is_double);
+        const int value_proj = spec_.step == PA_STEP_FINAL ? ag.input_channel + 1 : ag.input_channel;
+        oc.type = as_double ? PA_DOUBLE : ((ag.fn == PA_AGG_SUM) ? spec_.proj[value_proj].root_type() : PA_BIGINT);
         auto& data = host_cols[col];
         auto& nulls = host_nulls[col];
         nulls.assign(groups ? groups : 1, 0);
@@ -1037,6 +1099,7 @@ void FusedAggregationOperator::build_output()
             }
         }
         oc.has_nulls = any_null;
+        col++;
     }
     // hand the assembled blocks over: pinned host memory for PA_MEM_HOST consumers, HBM otherwise
     const bool to_device = spec_.output_mem == PA_MEM_DEVICE;

@@ -179,13 +179,25 @@ __global__ __launch_bounds__(256) void k_merge_lds_words(const u64* __restrict__
             const u64* col = slab + (i64)(1 + W + w) * entries;
             double accf = 0.0;
             i64 acci = 0;
-            // coalesced, branch-free: entries of other slots contribute an exact zero
-            for (i64 e = threadIdx.x; e < entries; e += 256) {
-                const bool mine = entry_slot[e] == (i32)slot;
-                const u64 v = col[e];
-                if (kind == PA_W_SUMF) accf = accf + (mine ? __longlong_as_double((i64)v) : 0.0);
-                else if (kind == PA_W_SUMI) acci = pa_add_exact(acci, mine ? (i64)v : 0, err);
-                else acci += mine ? (i64)v : 0;
+            // coalesced and branch-free: entries of other slots contribute an exact zero.  8 entries per lane are
+            // loaded before the first use so that the loop is not one HBM round trip per entry.
+            for (i64 e0 = threadIdx.x; e0 < entries; e0 += 256 * 8) {
+                u64 v[8];
+                i32 es[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const i64 e = e0 + (i64)j * 256;
+                    const bool in = e < entries;
+                    es[j] = in ? entry_slot[e] : -1;
+                    v[j] = in ? col[e] : 0ULL;
+                }
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const bool mine = es[j] == (i32)slot;
+                    if (kind == PA_W_SUMF) accf = accf + (mine ? __longlong_as_double((i64)v[j]) : 0.0);
+                    else if (kind == PA_W_SUMI) acci = pa_add_exact(acci, mine ? (i64)v[j] : 0, err);
+                    else acci += mine ? (i64)v[j] : 0;
+                }
             }
             part[threadIdx.x] = kind == PA_W_SUMF ? (u64)__double_as_longlong(accf) : (u64)acci;
             __syncthreads();

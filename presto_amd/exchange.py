@@ -108,3 +108,54 @@ def exchange_columns(ops, columns, types, hash_channels, group=None, local=None,
         dist.all_to_all_single(recv, send, output_split_sizes=recv_counts, input_split_sizes=send_counts, group=group)
         received.append(recv)
     return received, recv_counts
+
+
+# ---- partial -> final aggregation across ranks --------------------------------------------------------------------
+def partial_layout(key_types, aggregates):
+    """Channel types of a Step.PARTIAL output page and the aggregate list of the matching Step.FINAL operator.
+
+    aggregates: list of (fn, input_channel, input_type[, mask]) of the SINGLE-step aggregation.  The intermediate
+    channels follow include/presto_amd.h: [count] for count / count(*), [count, sum] for sum / avg."""
+    types = list(key_types)
+    final = []
+    for a in aggregates:
+        fn, in_type = a[0], a[2]
+        first = len(types)
+        types.append(abi.BIGINT)
+        if fn in (abi.AGG_SUM, abi.AGG_AVG):
+            value_type = abi.DOUBLE if (fn == abi.AGG_AVG or in_type == abi.DOUBLE) else abi.BIGINT
+            types.append(value_type)
+            final.append((fn, first, value_type))
+        else:
+            final.append((fn, first, abi.BIGINT))
+    return types, final
+
+
+def merge_partial_aggregations(partial_page, make_final_operator, group=None, dst=0):
+    """The FINAL step of a row-range-sharded aggregation (HashAggregationOperator Step.PARTIAL on every rank ->
+    Step.FINAL on one; the reference ships the partial pages through its exchange).  `partial_page` is this rank's
+    host Page of intermediate states (or None when the rank produced no group); the pages are tiny (Q1: 4 rows), so
+    they travel as objects.  Returns the final host Page on rank `dst`, None elsewhere."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    payload = None
+    if partial_page is not None and partial_page.position_count > 0:
+        payload = [(b.type, b.to_pylist()) for b in partial_page.blocks]
+    gathered = [None] * world
+    dist.all_gather_object(gathered, payload, group=group)
+    if rank != dst:
+        return None
+    op = make_final_operator()
+    for cols in gathered:  # rank order: a fixed combine order
+        if cols is None:
+            continue
+        blocks = []
+        for t, values in cols:
+            nulls = [v is None for v in values]
+            if t == abi.VARCHAR:
+                blocks.append(Block.varchar(values))
+            else:
+                blocks.append(Block.flat(t, [0 if v is None else v for v in values], nulls))
+        op.addInput(Page(blocks, len(cols[0][1]) if cols else 0))
+    op.finish()
+    return op.getOutput()

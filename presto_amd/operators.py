@@ -139,7 +139,7 @@ def _aggregates(aggregates):
 
 
 def _hash_agg_desc(input_types, group_by_channels, aggregates, hash_channel, expected_groups, output_mem, stream,
-                   type_params=None):
+                   type_params=None, step=abi.STEP_SINGLE):
     keep = []
     d = abi.pa_hash_aggregation_desc()
     types = abi.int32_array(input_types)
@@ -154,7 +154,7 @@ def _hash_agg_desc(input_types, group_by_channels, aggregates, hash_channel, exp
     d.group_by_count = len(group_by_channels)
     d.group_by_channels = C.cast(gb, C.POINTER(C.c_int32))
     d.hash_channel = hash_channel
-    d.step = abi.STEP_SINGLE
+    d.step = step
     d.aggregate_count = len(aggregates)
     d.aggregates = C.cast(aggs, C.POINTER(abi.pa_aggregate))
     d.expected_groups = expected_groups
@@ -165,11 +165,11 @@ def _hash_agg_desc(input_types, group_by_channels, aggregates, hash_channel, exp
 
 
 def fused_aggregation_desc(input_types, filter_expr, projections, group_by_channels, aggregates, hash_channel=-1,
-                           expected_groups=10000, output_mem=abi.MEM_HOST, stream=None, type_params=None):
+                           expected_groups=10000, output_mem=abi.MEM_HOST, stream=None, type_params=None, step=abi.STEP_SINGLE):
     """aggregates: list of (fn, projection index, input type[, mask projection index])."""
     fp, k1 = _filter_project_desc(input_types, filter_expr, projections, output_mem, stream, type_params)
     ag, k2 = _hash_agg_desc([p.type for p in projections], group_by_channels, aggregates, hash_channel, expected_groups,
-                            output_mem, stream)
+                            output_mem, stream, None, step)
     d = abi.pa_fused_aggregation_desc()
     d.filter_project = fp
     d.aggregation = ag
@@ -187,8 +187,8 @@ def FilterAndProjectOperator(input_types, filter_expr, projections, output_mem=a
     return Operator(h, keep)
 
 
-def AggregationOperator(input_types, aggregates, output_mem=abi.MEM_HOST, stream=None):
-    """AggregationOperator.AggregationOperatorFactory (…/operator/AggregationOperator.java:40-95), Step.SINGLE."""
+def AggregationOperator(input_types, aggregates, output_mem=abi.MEM_HOST, stream=None, step=abi.STEP_SINGLE):
+    """AggregationOperator.AggregationOperatorFactory (…/operator/AggregationOperator.java:40-95)."""
     d = abi.pa_aggregation_desc()
     types = abi.int32_array(input_types)
     aggs = _aggregates(aggregates)
@@ -196,6 +196,7 @@ def AggregationOperator(input_types, aggregates, output_mem=abi.MEM_HOST, stream
     d.input_types = C.cast(types, C.POINTER(C.c_int32))
     d.aggregate_count = len(aggregates)
     d.aggregates = C.cast(aggs, C.POINTER(abi.pa_aggregate))
+    d.step = step
     d.output_mem = output_mem
     d.stream = stream
     h = C.c_void_p()
@@ -204,10 +205,10 @@ def AggregationOperator(input_types, aggregates, output_mem=abi.MEM_HOST, stream
 
 
 def HashAggregationOperator(input_types, group_by_channels, aggregates, hash_channel=-1, expected_groups=10000,
-                            output_mem=abi.MEM_HOST, stream=None, type_params=None):
-    """HashAggregationOperatorFactory (…/operator/HashAggregationOperator.java:120-202), Step.SINGLE."""
+                            output_mem=abi.MEM_HOST, stream=None, type_params=None, step=abi.STEP_SINGLE):
+    """HashAggregationOperatorFactory (…/operator/HashAggregationOperator.java:120-202)."""
     d, keep = _hash_agg_desc(input_types, group_by_channels, aggregates, hash_channel, expected_groups, output_mem, stream,
-                             type_params)
+                             type_params, step)
     h = C.c_void_p()
     check(lib().pa_hash_aggregation_create(C.byref(d), C.byref(h)))
     return Operator(h, keep)

@@ -61,7 +61,7 @@ for k in dur:
         "hbm_bytes_per_launch": (2.0 * fetch_kib + write_kib) * 1024.0,
         "correction": "FETCH_SIZE x2 (gfx950 wide streaming reads), WRITE_SIZE x1; KiB -> bytes",
     }
-json.dump({"tag": tag, "command": "python3 bench.py --steps N --warmup W --cpu-rows 0 (SF100, 2^26-row pages)", "kernels": traffic},
+json.dump({"tag": tag, "command": "python3 bench.py --steps N --warmup W --cpu-rows 0 (SF100, 2^28-row pages)", "kernels": traffic},
           open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)
 
 with open(os.path.join(out, tag + "_summary.md"), "w") as f:
@@ -70,7 +70,7 @@ with open(os.path.join(out, tag + "_summary.md"), "w") as f:
     f.write("## kernel stats (all kernels of the run)\n\n| kernel | calls | total ms | avg us | % |\n|---|---|---|---|---|\n")
     for r in stats:
         f.write("| `%s` | %s | %.3f | %.1f | %s |\n" % (r["Name"][:70], r["Calls"], int(r["TotalDurationNs"]) / 1e6, float(r["AverageNs"]) / 1e3, r["Percentage"]))
-    f.write("\n## fused kernels (per launch = one 2^26-row page)\n\n| kernel | launches | avg ms | FETCH_SIZE KiB (raw) | WRITE_SIZE KiB | HBM bytes / launch (corrected) |\n|---|---|---|---|---|---|\n")
+    f.write("\n## fused kernels (per launch = one 2^28-row page (the last page of the table is shorter))\n\n| kernel | launches | avg ms | FETCH_SIZE KiB (raw) | WRITE_SIZE KiB | HBM bytes / launch (corrected) |\n|---|---|---|---|---|---|\n")
     for k, t in traffic.items():
         f.write("| pa_fused %s | %d | %.4f | %.0f | %.1f | %.4g |\n" % (k, t["launches"], t["avg_launch_ms"], t["fetch_size_kib_raw"], t["write_size_kib"], t["hbm_bytes_per_launch"]))
     if bench_json and os.path.exists(bench_json):

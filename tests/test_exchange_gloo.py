@@ -83,6 +83,75 @@ def worker(rank, world, port, result_queue):
     dist.destroy_process_group()
 
 
+class OracleFinalOperator:
+    """Operator-protocol adapter over the oracle's Step.FINAL aggregation (checker side of merge_partial_aggregations)."""
+
+    def __init__(self, O, types, group_by, aggregates):
+        from presto_amd import abi
+        self.agg = O.HashAggregation(types, group_by, aggregates, step=abi.STEP_FINAL)
+
+    def addInput(self, page):
+        self.agg.add_page(page)
+
+    def finish(self):
+        pass
+
+    def getOutput(self):
+        return self.agg.build_result()
+
+
+def agg_worker(rank, world, port, result_queue):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import oracle as O
+    from presto_amd import abi
+    from presto_amd.exchange import merge_partial_aggregations, partial_layout
+    from presto_amd.page import Block, Page
+    keys, vals = agg_table()
+    n = len(keys)
+    lo, hi = n * rank // world, n * (rank + 1) // world
+    aggs = [(abi.AGG_SUM, 1, abi.DOUBLE), (abi.AGG_AVG, 1, abi.DOUBLE), (abi.AGG_COUNT_STAR, -1, None)]
+    part = O.HashAggregation([abi.BIGINT, abi.DOUBLE], [0], aggs, step=abi.STEP_PARTIAL)
+    part.add_page(Page([Block.bigint(keys[lo:hi]), Block.double(vals[lo:hi])], hi - lo))
+    ptypes, faggs = partial_layout([abi.BIGINT], aggs)
+    out = merge_partial_aggregations(part.build_result(), lambda: OracleFinalOperator(O, ptypes, [0], faggs))
+    result_queue.put((rank, None if out is None else out.to_rows()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def agg_table():
+    rng = np.random.default_rng(77)
+    return rng.integers(0, 11, 5000).astype(np.int64), rng.random(5000)
+
+
+def test_partial_final_aggregation_over_two_gloo_ranks(oracle):
+    from presto_amd import abi
+    from presto_amd.page import Block, Page
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=agg_worker, args=(r, world, port, q)) for r in range(world)]
+    [p.start() for p in procs]
+    results = dict(q.get(timeout=120) for _ in range(world))
+    [p.join(timeout=60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    assert results[1] is None
+    keys, vals = agg_table()
+    aggs = [(abi.AGG_SUM, 1, abi.DOUBLE), (abi.AGG_AVG, 1, abi.DOUBLE), (abi.AGG_COUNT_STAR, -1, None)]
+    single = oracle.HashAggregation([abi.BIGINT, abi.DOUBLE], [0], aggs)
+    single.add_page(Page([Block.bigint(keys), Block.double(vals)], len(keys)))
+    expected = sorted(single.build_result().to_rows())
+    got = sorted(results[0])
+    assert len(got) == len(expected) == 11
+    for g, e in zip(got, expected):
+        assert g[0] == e[0] and g[3] == e[3]
+        assert abs(g[1] - e[1]) <= 1e-12 * abs(e[1]) and abs(g[2] - e[2]) <= 1e-12 * abs(e[2])
+
+
 def free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))

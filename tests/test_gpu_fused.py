@@ -178,3 +178,19 @@ def test_bigint_sum_overflow_raises(gpu):
     with pytest.raises(PrestoAmdError) as e:
         to_pages(op, [page])
     assert e.value.status == abi.ERR_NUMERIC_VALUE_OUT_OF_RANGE
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 5, 6, 7, 8, 9, 63, 64, 65, 257, 1027])
+def test_new_groups_in_partial_waves(gpu, oracle, n):
+    """Regression: first occurrences of a group in a wave iteration where only some lanes have a row (tiny pages, page
+    tails) must update the wave's key table consistently."""
+    keys = (np.arange(n) * 7) % 8
+    vals = np.arange(n, dtype=np.float64) + 0.5
+    pages = [Page([Block.bigint(keys), Block.double(vals)], n), Page([Block.bigint(keys[::-1].copy()), Block.double(vals)], n)]
+    aggs = [(abi.AGG_SUM, 1, abi.DOUBLE), (abi.AGG_COUNT_STAR, -1, None)]
+    op = HashAggregationOperator([abi.BIGINT, abi.DOUBLE], [0], aggs)
+    rows = [r for p in to_pages(op, pages) for r in p.to_rows()]
+    ref = oracle.HashAggregation([abi.BIGINT, abi.DOUBLE], [0], aggs)
+    for p in pages:
+        ref.add_page(p)
+    rows_equal_ignore_order(rows, ref.build_result().to_rows(), rel=1e-12)
