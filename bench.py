@@ -211,14 +211,15 @@ def main():
         ms, n = ktime[name]
         if n == 0:
             return None
-        avg_s = ms / n / 1e3
-        rows_per_launch = sum(p.position_count for p in pages) / len(pages)
-        achieved = rows_per_launch * bytes_per_row / avg_s / 1e9
+        # all launches of the operator's dominant kernel in the timed region (a page whose row count is not a multiple
+        # of 256 adds one tiny tail launch): algorithmic bytes of the timed region / their summed duration
+        total_bytes = sum(p.position_count for p in pages) * bytes_per_row * args.steps
+        achieved = total_bytes / (ms / 1e3) / 1e9
+        traffic = pmc.get({"q1": "q1_lds", "q6": "q6_global"}[name], {}).get("hbm_bytes_per_launch")
         return {"bound": "hbm", "kernel": "pa_fused (%s)" % name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
-                "traffic": pmc.get({"q1": "q1_lds", "q6": "q6_global"}[name], {}).get("hbm_bytes_per_launch"),
-                "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE x2 on gfx950)" if pmc else None,
-                "avg_launch_ms": ms / n, "launches": n, "algorithmic_bytes_per_launch": rows_per_launch * bytes_per_row}
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE x2 on gfx950), average per launch" if pmc else None,
+                "avg_launch_ms": ms / n, "launches": n, "algorithmic_bytes_per_launch": total_bytes / n}
 
     if rank == 0:
         line = {

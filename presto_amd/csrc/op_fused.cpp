@@ -449,7 +449,8 @@ KernelInfo generate(const Spec& s, const std::vector<ChannelLayout>& layout, int
                 src << "    if (u" << w << ") { i64* p = (i64*)&" << idx << "; *p = pa_add_exact(*p, x" << w << ", a.err); }\n";
             }
             else {
-                src << "    if (u" << w << ") __hip_atomic_fetch_add(&" << idx << ", (u64)x" << w << ", __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);\n";
+                src << "    if (u" << w << ") __hip_atomic_fetch_add(&" << idx << ", " << (words[w].val == "1" ? std::string("1ULL") : "(u64)x" + std::to_string(w))
+                    << ", __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);\n";
             }
         }
         src << "  } else {\n    atomicAdd((unsigned long long*)a.overflow_rows, 1ULL);\n  }\n}\n";
@@ -469,83 +470,97 @@ KernelInfo generate(const Spec& s, const std::vector<ChannelLayout>& layout, int
     }
     src << "}\n\n";
 
-    // kernel
+    // kernels.  mode 0: one kernel walks the page (GLOBAL / GT).  LDS variant: the wave's key table is wave-uniform
+    // state, so every lane must take part in every pa_row call; the host splits the page and `pa_fused` (mode 1) takes the
+    // leading multiple of 256 rows -- whole groups of 64 quads per wave, all lanes live, 16-byte loads -- while
+    // `pa_fused_tail` (mode 2) takes the remaining < 256 rows (or everything when a buffer is unaligned) row by row with a
+    // wave-uniform trip count, finished lanes riding along with live == false on a clamped row.  Two entry points keep the
+    // tail's code out of the hot loop's register allocation.
     const int B = k.block;
-    src << "extern \"C\" __global__ __launch_bounds__(" << B << ") void pa_fused(PaFusedArgs a)\n{\n";
-    if (variant == V_GLOBAL) {
-        src << "    PaAcc acc;\n";
-        for (int w = 0; w < k.nw; w++) src << "    acc.w" << w << " = 0;\n";
-    }
-    else if (variant == V_LDS) {
-        src << "    for (int i = threadIdx.x; i < PA_NW * PA_C * 64; i += 64) pa_accw[i] = 0ULL;\n";
-        src << "    __syncthreads();\n";
-        src << "    PaAcc acc; acc.tcount = 0; acc.lane = threadIdx.x;\n";
-        src << "#pragma unroll\n    for (int s = 0; s < PA_C; s++) {\n#pragma unroll\n        for (int w = 0; w < PA_KW; w++) acc.tk[s][w] = 0ULL;\n    }\n";
-    }
-    else {
-        src << "    PaAcc acc; acc.unused = 0;\n";
-    }
-    emit_prologue(ri, layout, src);
-    src << "    const i64 t = (i64)blockIdx.x * " << B << " + threadIdx.x, T = (i64)gridDim.x * " << B << ";\n";
-    src << "    const i64 nq = a.vec ? (a.n >> 2) : 0;\n";
-    std::string args[4];
+    auto emit_kernel = [&](const char* name, int mode) {
+        src << "extern \"C\" __global__ __launch_bounds__(" << B << ") void " << name << "(PaFusedArgs a)\n{\n";
+        if (variant == V_GLOBAL) {
+            src << "    PaAcc acc;\n";
+            for (int w = 0; w < k.nw; w++) src << "    acc.w" << w << " = 0;\n";
+        }
+        else if (variant == V_LDS) {
+            src << "    for (int i = threadIdx.x; i < PA_NW * PA_C * 64; i += 64) pa_accw[i] = 0ULL;\n";
+            src << "    __syncthreads();\n";
+            src << "    PaAcc acc; acc.tcount = 0; acc.lane = threadIdx.x;\n";
+            src << "#pragma unroll\n    for (int s = 0; s < PA_C; s++) {\n#pragma unroll\n        for (int w = 0; w < PA_KW; w++) acc.tk[s][w] = 0ULL;\n    }\n";
+        }
+        else {
+            src << "    PaAcc acc; acc.unused = 0;\n";
+        }
+        if (mode != 2) emit_prologue(ri, layout, src);
+        src << "    const i64 t = (i64)blockIdx.x * " << B << " + threadIdx.x, T = (i64)gridDim.x * " << B << ";\n";
+        std::string args[4];
+        if (mode == 1) {
+            src << "    const i64 nq = a.n >> 2;  // the host passes a multiple of 256 rows\n";
+            src << "    for (i64 q = t; q < nq; q += T) {\n";
+            emit_vector_loads(ri, layout, src, args);
+            for (int r = 0; r < 4; r++) src << "        pa_row(a, acc, true, (i32)(4 * q + " << r << ")" << args[r] << ");\n";
+            src << "    }\n";
+        }
+        else if (mode == 2) {
+            src << "    for (i64 rb = (i64)blockIdx.x * 64; rb < a.n; rb += T) {\n        const bool live = rb + threadIdx.x < a.n;\n"
+                   "        const i64 r = live ? rb + threadIdx.x : a.n - 1;\n        pa_row(a, acc, live, (i32)r" << scalar_args(ri, layout) << ");\n    }\n";
+        }
+        else {
+            src << "    const i64 nq = a.vec ? (a.n >> 2) : 0;\n";
+            src << "    for (i64 q = t; q < nq; q += T) {\n";
+            emit_vector_loads(ri, layout, src, args);
+            for (int r = 0; r < 4; r++) src << "        pa_row(a, acc, true, (i32)(4 * q + " << r << ")" << args[r] << ");\n";
+            src << "    }\n";
+            src << "    for (i64 r = (nq << 2) + t; r < a.n; r += T) {\n        pa_row(a, acc, true, (i32)r" << scalar_args(ri, layout) << ");\n    }\n";
+        }
+        if (variant == V_GT) {
+            src << "    for (i64 i = t; i < a.n_list; i += T) {\n        const i64 r = a.row_list[i];\n        pa_row(a, acc, true, (i32)r" << scalar_args(ri, layout)
+                << ");\n    }\n";
+        }
+        if (variant == V_GLOBAL) {
+            src << "    __shared__ u64 red[" << (B / 64) << " * PA_NW];\n    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;\n";
+            for (int w = 0; w < k.nw; w++) {
+                if (words[w].kind == W_SUMF) src << "    { double v = pa_wave_sum_f64(acc.w" << w << "); if (lane == 0) red[wave * PA_NW + " << w << "] = (u64)__double_as_longlong(v); }\n";
+                else if (words[w].kind == W_SUMI) src << "    { i64 v = pa_wave_sum_i64_exact(acc.w" << w << ", a.err); if (lane == 0) red[wave * PA_NW + " << w << "] = (u64)v; }\n";
+                else src << "    { i64 v = pa_wave_sum_i64(acc.w" << w << "); if (lane == 0) red[wave * PA_NW + " << w << "] = (u64)v; }\n";
+            }
+            src << "    __syncthreads();\n    if (threadIdx.x < PA_NW) {\n        const int w = threadIdx.x;\n        u64 r = red[w];\n";
+            src << "        for (int i = 1; i < " << (B / 64) << "; i++) {\n            u64 o = red[i * PA_NW + w];\n";
+            src << "            switch (w) {\n";
+            for (int w = 0; w < k.nw; w++) {
+                src << "                case " << w << ": ";
+                if (words[w].kind == W_SUMF) src << "r = (u64)__double_as_longlong(__longlong_as_double((i64)r) + __longlong_as_double((i64)o)); break;\n";
+                else if (words[w].kind == W_SUMI) src << "r = (u64)pa_add_exact((i64)r, (i64)o, a.err); break;\n";
+                else src << "r = r + o; break;\n";
+            }
+            src << "            }\n        }\n        a.slab[(u64)blockIdx.x * PA_NW + w] = r;\n    }\n";
+        }
+        else if (variant == V_LDS) {
+            // per-wave partial table -> slab, field-major: field f of entry e = blockIdx.x * C + i at slab[f * E + e]
+            src << "    __syncthreads();\n";
+            src << "    const u64 E = (u64)gridDim.x * PA_C;\n";
+            src << "#pragma unroll\n    for (int i = 0; i < PA_C; i++) {\n        u64* e = a.slab + (u64)blockIdx.x * PA_C + i;\n";
+            src << "        const bool occ = i < acc.tcount;\n        if (threadIdx.x == 0) e[0] = occ ? 1ULL : 0ULL;\n        if (occ) {\n";
+            src << "#pragma unroll\n            for (int w = 0; w < PA_KW; w++) { if (threadIdx.x == 0) e[(u64)(1 + w) * E] = acc.tk[i][w]; }\n";
+            for (int w = 0; w < k.nw; w++) {
+                std::string idx = "pa_accw[(" + std::to_string(w) + " * PA_C + i) * 64 + threadIdx.x]";
+                std::string dst = "e[(u64)(1 + PA_KW + " + std::to_string(w) + ") * E]";
+                if (words[w].kind == W_SUMF) src << "            { double v = pa_wave_sum_f64(__longlong_as_double((i64)" << idx << ")); if (threadIdx.x == 0) " << dst << " = (u64)__double_as_longlong(v); }\n";
+                else if (words[w].kind == W_SUMI) src << "            { i64 v = pa_wave_sum_i64_exact((i64)" << idx << ", a.err); if (threadIdx.x == 0) " << dst << " = (u64)v; }\n";
+                else src << "            { i64 v = pa_wave_sum_i64((i64)" << idx << "); if (threadIdx.x == 0) " << dst << " = (u64)v; }\n";
+            }
+            src << "        }\n    }\n";
+        }
+        src << "}\n\n";
+    };
     if (variant == V_LDS) {
-        // The wave's key table is wave-uniform state: every lane must take part in every pa_row call, so the loops
-        // run until the LAST lane of the wave is done and finished lanes ride along with live == false (their loads
-        // are clamped to a valid row).
-        src << "    for (i64 qi = t; __ballot(qi < nq) != 0ULL; qi += T) {\n        const bool live = qi < nq;\n        const i64 q = live ? qi : 0;\n";
-        emit_vector_loads(ri, layout, src, args);
-        for (int r = 0; r < 4; r++) src << "        pa_row(a, acc, live, (i32)(4 * q + " << r << ")" << args[r] << ");\n";
-        src << "    }\n";
-        src << "    for (i64 ri = (nq << 2) + t; __ballot(ri < a.n) != 0ULL; ri += T) {\n        const bool live = ri < a.n;\n        const i64 r = live ? ri : a.n - 1;\n"
-               "        pa_row(a, acc, live, (i32)r" << scalar_args(ri, layout) << ");\n    }\n";
+        emit_kernel("pa_fused", 1);
+        emit_kernel("pa_fused_tail", 2);
     }
     else {
-        src << "    for (i64 q = t; q < nq; q += T) {\n";
-        emit_vector_loads(ri, layout, src, args);
-        for (int r = 0; r < 4; r++) src << "        pa_row(a, acc, true, (i32)(4 * q + " << r << ")" << args[r] << ");\n";
-        src << "    }\n";
-        src << "    for (i64 r = (nq << 2) + t; r < a.n; r += T) {\n        pa_row(a, acc, true, (i32)r" << scalar_args(ri, layout) << ");\n    }\n";
+        emit_kernel("pa_fused", 0);
     }
-    if (variant == V_GT) {
-        src << "    for (i64 i = t; i < a.n_list; i += T) {\n        const i64 r = a.row_list[i];\n        pa_row(a, acc, true, (i32)r" << scalar_args(ri, layout)
-            << ");\n    }\n";
-    }
-    if (variant == V_GLOBAL) {
-        src << "    __shared__ u64 red[" << (B / 64) << " * PA_NW];\n    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;\n";
-        for (int w = 0; w < k.nw; w++) {
-            if (words[w].kind == W_SUMF) src << "    { double v = pa_wave_sum_f64(acc.w" << w << "); if (lane == 0) red[wave * PA_NW + " << w << "] = (u64)__double_as_longlong(v); }\n";
-            else if (words[w].kind == W_SUMI) src << "    { i64 v = pa_wave_sum_i64_exact(acc.w" << w << ", a.err); if (lane == 0) red[wave * PA_NW + " << w << "] = (u64)v; }\n";
-            else src << "    { i64 v = pa_wave_sum_i64(acc.w" << w << "); if (lane == 0) red[wave * PA_NW + " << w << "] = (u64)v; }\n";
-        }
-        src << "    __syncthreads();\n    if (threadIdx.x < PA_NW) {\n        const int w = threadIdx.x;\n        u64 r = red[w];\n";
-        src << "        for (int i = 1; i < " << (B / 64) << "; i++) {\n            u64 o = red[i * PA_NW + w];\n";
-        src << "            switch (w) {\n";
-        for (int w = 0; w < k.nw; w++) {
-            src << "                case " << w << ": ";
-            if (words[w].kind == W_SUMF) src << "r = (u64)__double_as_longlong(__longlong_as_double((i64)r) + __longlong_as_double((i64)o)); break;\n";
-            else if (words[w].kind == W_SUMI) src << "r = (u64)pa_add_exact((i64)r, (i64)o, a.err); break;\n";
-            else src << "r = r + o; break;\n";
-        }
-        src << "            }\n        }\n        a.slab[(u64)blockIdx.x * PA_NW + w] = r;\n    }\n";
-    }
-    else if (variant == V_LDS) {
-        // per-wave partial table -> slab, field-major: field f of entry e = blockIdx.x * C + i at slab[f * E + e]
-        src << "    __syncthreads();\n";
-        src << "    const u64 E = (u64)gridDim.x * PA_C;\n";
-        src << "#pragma unroll\n    for (int i = 0; i < PA_C; i++) {\n        u64* e = a.slab + (u64)blockIdx.x * PA_C + i;\n";
-        src << "        const bool occ = i < acc.tcount;\n        if (threadIdx.x == 0) e[0] = occ ? 1ULL : 0ULL;\n        if (occ) {\n";
-        src << "#pragma unroll\n            for (int w = 0; w < PA_KW; w++) { if (threadIdx.x == 0) e[(u64)(1 + w) * E] = acc.tk[i][w]; }\n";
-        for (int w = 0; w < k.nw; w++) {
-            std::string idx = "pa_accw[(" + std::to_string(w) + " * PA_C + i) * 64 + threadIdx.x]";
-            std::string dst = "e[(u64)(1 + PA_KW + " + std::to_string(w) + ") * E]";
-            if (words[w].kind == W_SUMF) src << "            { double v = pa_wave_sum_f64(__longlong_as_double((i64)" << idx << ")); if (threadIdx.x == 0) " << dst << " = (u64)__double_as_longlong(v); }\n";
-            else if (words[w].kind == W_SUMI) src << "            { i64 v = pa_wave_sum_i64_exact((i64)" << idx << ", a.err); if (threadIdx.x == 0) " << dst << " = (u64)v; }\n";
-            else src << "            { i64 v = pa_wave_sum_i64((i64)" << idx << "); if (threadIdx.x == 0) " << dst << " = (u64)v; }\n";
-        }
-        src << "        }\n    }\n";
-    }
-    src << "}\n";
     k.source = src.str();
     return k;
 }
@@ -638,7 +653,7 @@ public:
 private:
     struct Compiled {
         KernelInfo info;
-        JitKernel kernel;
+        JitKernel kernel, tail_kernel;
         DevBuf kinds;
     };
 
@@ -650,6 +665,7 @@ private:
         auto c = std::make_unique<Compiled>();
         c->info = generate(spec_, layout, variant);
         c->kernel = jit_get(c->info.source, c->info.entry);
+        if (variant == V_LDS) c->tail_kernel = jit_get(c->info.source, "pa_fused_tail");
         c->kinds.ensure(sizeof(int32_t) * c->info.word_kind.size());
         PA_HIP(hipMemcpyAsync(c->kinds.ptr(), c->info.word_kind.data(), sizeof(int32_t) * c->info.word_kind.size(), hipMemcpyHostToDevice, stream_.get()));
         PA_HIP(hipStreamSynchronize(stream_.get()));
@@ -721,8 +737,15 @@ private:
         const int64_t total = dp.n;
         // the HBM-table variant bounds the groups one launch can add so that the table can be sized first
         const int64_t chunk = ki.variant == V_GT ? (int64_t)1 << 26 : total;
+        // LDS variant: head = leading multiple of 256 rows through the vector kernel, tail = the rest through the scalar one
+        const int64_t lds_head = (ki.variant == V_LDS && vec) ? (total & ~(int64_t)255) : 0;
         while (offset < total) {
             int64_t n = std::min(chunk, total - offset);
+            bool use_tail = false;
+            if (ki.variant == V_LDS) {
+                if (offset < lds_head) n = lds_head - offset;
+                else use_tail = true;
+            }
             if (offset > 0) {
                 for (int c = 0; c < spec_.n_in; c++) {
                     if (!spec_.used_channel[c]) continue;
@@ -733,7 +756,7 @@ private:
                 }
             }
             a.n = n;
-            int64_t work = (n + 3) / 4;
+            int64_t work = use_tail ? n : (n + 3) / 4;
             int grid;
             if (ki.variant == V_LDS) {
                 int per_cu = std::max(1, std::min(16, (int)(160 * 1024 / ((size_t)ki.nw * ki.c * 64 * 8 + 512))));
@@ -783,7 +806,7 @@ private:
             a.gt_max_fill = ki.variant == V_GT ? (int32_t)(gt_cap_ / 2) : (int32_t)(gt_cap_ - gt_cap_ / 4);
             void* params[] = {&a};
             timer.begin(s);
-            PA_HIP(hipModuleLaunchKernel(ck.kernel.fn, grid, 1, 1, ki.block, 1, 1, 0, s, params, nullptr));
+            PA_HIP(hipModuleLaunchKernel(use_tail ? ck.tail_kernel.fn : ck.kernel.fn, grid, 1, 1, ki.block, 1, 1, 0, s, params, nullptr));
             timer.end(s);
             if (ki.variant == V_GLOBAL) {
                 launch_merge_global_slab(a.slab, grid, ki.nw, ck.kinds.as<int32_t>(), state_.as<uint64_t>(), ctl_, s);
