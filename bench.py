@@ -211,8 +211,9 @@ def main():
         ms, n = ktime[name]
         if n == 0:
             return None
-        # all launches of the operator's dominant kernel in the timed region (a page whose row count is not a multiple
-        # of 256 adds one tiny tail launch): algorithmic bytes of the timed region / their summed duration
+        # algorithmic bytes of the timed region / summed duration of the operator's kernel launches; n counts the
+        # launches of the dominant kernel `pa_fused` only (a page whose row count is not a multiple of 256 adds one
+        # <256-row `pa_fused_tail` launch: its ~10 us are in `ms`, it is not a launch of the dominant kernel)
         total_bytes = sum(p.position_count for p in pages) * bytes_per_row * args.steps
         achieved = total_bytes / (ms / 1e3) / 1e9
         traffic = pmc.get({"q1": "q1_lds", "q6": "q6_global"}[name], {}).get("hbm_bytes_per_launch")

@@ -203,9 +203,12 @@ public:
         }
         PA_HIP(hipEventRecord(pairs_[next_].first, s));
     }
-    void end(hipStream_t s)
+    // dominant = false: the time still counts, the launch does not (e.g. the few-row tail launch of a page)
+    void end(hipStream_t s, bool dominant = true)
     {
         PA_HIP(hipEventRecord(pairs_[next_].second, s));
+        if (minor_.size() <= next_) minor_.resize(next_ + 1);
+        minor_[next_] = !dominant;
         next_++;
     }
     void drain()
@@ -215,7 +218,7 @@ public:
             float ms = 0;
             PA_HIP(hipEventElapsedTime(&ms, pairs_[i].first, pairs_[i].second));
             total_ms_ += ms;
-            launches_++;
+            if (!minor_[i]) launches_++;
         }
         next_ = 0;
     }
@@ -224,6 +227,7 @@ public:
 
 private:
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pairs_;
+    std::vector<char> minor_;
     size_t next_ = 0;
     double total_ms_ = 0;
     int64_t launches_ = 0;

@@ -807,7 +807,7 @@ private:
             void* params[] = {&a};
             timer.begin(s);
             PA_HIP(hipModuleLaunchKernel(use_tail ? ck.tail_kernel.fn : ck.kernel.fn, grid, 1, 1, ki.block, 1, 1, 0, s, params, nullptr));
-            timer.end(s);
+            timer.end(s, !use_tail);
             if (ki.variant == V_GLOBAL) {
                 launch_merge_global_slab(a.slab, grid, ki.nw, ck.kinds.as<int32_t>(), state_.as<uint64_t>(), ctl_, s);
             }

@@ -18,14 +18,24 @@ out = os.path.join(root, "profiles")
 os.makedirs(out, exist_ok=True)
 
 
-def one(pattern):
-    return glob.glob(pattern)[0]
+def one(directory, *patterns):
+    """First file under `directory` (any depth) matching one of the patterns: rocprofv3 writes CSVs directly, or a
+    rocpd database that `rocpd2csv` / `rocpd2summary --format csv` turn into the same tables."""
+    for pattern in patterns:
+        hits = sorted(glob.glob(os.path.join(directory, "**", pattern), recursive=True))
+        if hits:
+            return hits[0]
+    raise SystemExit("no %s under %s" % (" / ".join(patterns), directory))
 
 
-stats_src = one(os.path.join(trace_dir, "*", "*_kernel_stats.csv"))
+stats_src = one(trace_dir, "*_kernel_stats.csv", "kernels_summary.csv")
 shutil.copy(stats_src, os.path.join(out, tag + "_kernel_stats.csv"))
-stats = list(csv.DictReader(open(stats_src)))
-trace = list(csv.DictReader(open(one(os.path.join(trace_dir, "*", "*_kernel_trace.csv")))))
+stats = []
+for r in csv.DictReader(open(stats_src)):  # column names differ between the two producers
+    stats.append({"Name": r["Name"], "Calls": r["Calls"], "TotalDurationNs": r.get("TotalDurationNs") or r["Duration (Nsec)"],
+                  "AverageNs": r.get("AverageNs") or r["Average (Nsec)"],
+                  "Percentage": "%.2f" % float(r.get("Percentage") or r["Percent (Inc)"])})
+trace = list(csv.DictReader(open(one(trace_dir, "*kernel_trace.csv"))))
 
 
 def kernel_class(r):
@@ -43,7 +53,7 @@ for r in trace:
 
 pmc = {}
 for name, d in (("FETCH_SIZE", fetch_dir), ("WRITE_SIZE", write_dir)):
-    rows = list(csv.DictReader(open(one(os.path.join(d, "*", "*_counter_collection.csv")))))
+    rows = list(csv.DictReader(open(one(d, "*counter_collection*.csv"))))
     acc = collections.defaultdict(list)
     for r in rows:
         k = kernel_class(r)

@@ -1,0 +1,197 @@
+// C++ driver test: runs the reference's operator known-answer cases through include/presto_amd.hpp (the C++ host
+// mirror) on the GPU, and checks them against the oracle (liboracle.so) on the same pages.
+//   fp-1   TestFilterAndProjectOperator.test   core/trino-main/src/test/java/io/trino/operator/TestFilterAndProjectOperator.java:71-112
+//   hagg   TestHashAggregationOperator (count/sum/avg over grouped sequence pages), :150-215
+// plus a two-operator Driver pipeline FilterAndProject -> HashAggregation (Driver.java:355-457 call order).
+// Built by __graft_entry__.build(); executed by tests/test_gpu_cpp_driver.py.  Exit code 0 = all cases pass.
+#include <cmath>
+#include <cstdio>
+#include <map>
+
+#include "presto_amd.hpp"
+#include "presto_oracle.h"
+
+using namespace presto_amd;
+
+static int failures = 0;
+#define EXPECT(cond, ...)                              \
+    do {                                               \
+        if (!(cond)) {                                 \
+            failures++;                                \
+            fprintf(stderr, "FAIL %s:%d: ", __FILE__, __LINE__); \
+            fprintf(stderr, __VA_ARGS__);              \
+            fprintf(stderr, "\n");                     \
+        }                                              \
+    } while (0)
+
+static Page sequencePage(int32_t length, int64_t start)
+{
+    std::vector<std::string> s;
+    std::vector<int64_t> v;
+    for (int32_t i = 0; i < length; i++) {
+        s.push_back(std::to_string(start + i));
+        v.push_back(start + i);
+    }
+    return Page({Block::varchar(s), Block::bigint(v)});
+}
+
+static Expr between(Expr value, Expr lo, Expr hi) { return specialForm(PA_FORM_BETWEEN, PA_BOOLEAN, {value, lo, hi}); }
+
+// fp-1: filter field1 BETWEEN 10 AND 19, projections (field0, field1 + 5) over sequence pages of 100 rows
+static void testFilterAndProject()
+{
+    std::vector<int32_t> types = {PA_VARCHAR, PA_BIGINT};
+    Expr filter = between(field(1, PA_BIGINT), constantLong(10), constantLong(19));
+    std::vector<Expr> projections = {field(0, PA_VARCHAR), call(PA_OP_ADD, PA_BIGINT, {field(1, PA_BIGINT), constantLong(5)})};
+    auto op = createFilterAndProjectOperator(types, filter, projections);
+    std::vector<Page> input = {sequencePage(100, 0), sequencePage(100, 0)};
+    auto out = runDriver(input, {op.get()});
+    int64_t rows = 0;
+    for (const auto& p : out) {
+        for (int32_t i = 0; i < p.getPositionCount(); i++, rows++) {
+            int64_t expect = 10 + (rows % 10);
+            EXPECT(p.getBlock(0).getSlice(i) == std::to_string(expect), "fp-1 row %ld varchar %s", (long)rows, p.getBlock(0).getSlice(i).c_str());
+            EXPECT(p.getBlock(1).getLong(i) == expect + 5, "fp-1 row %ld bigint %ld", (long)rows, (long)p.getBlock(1).getLong(i));
+        }
+    }
+    EXPECT(rows == 20, "fp-1 expected 20 rows, got %ld", (long)rows);
+
+    // the same pages through the oracle's PageProcessor restatement
+    SerializedExpression f(filter);
+    std::vector<std::unique_ptr<SerializedExpression>> ps;
+    std::vector<pa_expr> pe;
+    for (auto& p : projections) {
+        ps.push_back(std::make_unique<SerializedExpression>(p));
+        pe.push_back(*ps.back()->get());
+    }
+    pa_page in;
+    std::vector<pa_column> cols;
+    input[0].toNative(&in, cols);
+    pa_page ref{};
+    int32_t rc = orc_filter_project(&in, f.get(), (int32_t)pe.size(), pe.data(), &ref);
+    EXPECT(rc >= 0, "oracle filter_project: %s", orc_last_error());
+    Page expected = Page::fromNative(ref);
+    orc_free_page(&ref);
+    EXPECT(!out.empty() && expected.getPositionCount() == out[0].getPositionCount(), "fp-1 oracle row count");
+    for (int32_t i = 0; !out.empty() && i < expected.getPositionCount() && i < out[0].getPositionCount(); i++) {
+        EXPECT(expected.getBlock(0).getSlice(i) == out[0].getBlock(0).getSlice(i), "fp-1 oracle varchar row %d", i);
+        EXPECT(expected.getBlock(1).getLong(i) == out[0].getBlock(1).getLong(i), "fp-1 oracle bigint row %d", i);
+    }
+}
+
+// division by zero must surface as the reference's DIVISION_BY_ZERO, not as a value
+static void testDivisionByZero()
+{
+    std::vector<int32_t> types = {PA_VARCHAR, PA_BIGINT};
+    std::vector<Expr> projections = {call(PA_OP_DIVIDE, PA_BIGINT, {constantLong(100), field(1, PA_BIGINT)})};
+    auto op = createFilterAndProjectOperator(types, nullptr, projections);
+    bool thrown = false;
+    try {
+        op->addInput(sequencePage(10, 0));
+        op->getOutput();
+    }
+    catch (const TrinoException& e) {
+        thrown = e.status == PA_ERR_DIVISION_BY_ZERO;
+    }
+    EXPECT(thrown, "expected DIVISION_BY_ZERO");
+}
+
+struct GroupState {
+    int64_t count;
+    int64_t sum;
+    double avg;
+};
+
+static std::map<int64_t, GroupState> collect(const std::vector<Page>& pages)
+{
+    std::map<int64_t, GroupState> groups;
+    for (const auto& p : pages) {
+        for (int32_t i = 0; i < p.getPositionCount(); i++) {
+            int64_t key = p.getBlock(0).getLong(i);
+            EXPECT(!groups.count(key), "duplicate group %ld", (long)key);
+            groups[key] = GroupState{p.getBlock(1).getLong(i), p.getBlock(2).getLong(i), p.getBlock(3).getDouble(i)};
+        }
+    }
+    return groups;
+}
+
+// FilterAndProject (key = field1 % 7, value = field1) -> HashAggregation(count(*), sum(value), avg(value)) by key
+static void testPipeline()
+{
+    std::vector<int32_t> types = {PA_VARCHAR, PA_BIGINT};
+    Expr filter = call(PA_OP_GREATER_THAN_OR_EQUAL, PA_BOOLEAN, {field(1, PA_BIGINT), constantLong(3)});
+    std::vector<Expr> projections = {call(PA_OP_MODULUS, PA_BIGINT, {field(1, PA_BIGINT), constantLong(7)}), field(1, PA_BIGINT)};
+    auto fp = createFilterAndProjectOperator(types, filter, projections);
+    std::vector<int32_t> aggTypes = {PA_BIGINT, PA_BIGINT};
+    std::vector<pa_aggregate> aggs = {{PA_AGG_COUNT_STAR, -1, -1, PA_BIGINT}, {PA_AGG_SUM, 1, -1, PA_BIGINT}, {PA_AGG_AVG, 1, -1, PA_BIGINT}};
+    auto agg = createHashAggregationOperator(aggTypes, {0}, aggs);
+    std::vector<Page> input;
+    for (int i = 0; i < 8; i++) input.push_back(sequencePage(1000, 1000 * i));
+    auto got = collect(runDriver(input, {fp.get(), agg.get()}));
+
+    // oracle: the same filter/projection and GroupByHash + accumulators page by page
+    SerializedExpression f(filter);
+    std::vector<std::unique_ptr<SerializedExpression>> ps;
+    std::vector<pa_expr> pe;
+    for (auto& p : projections) {
+        ps.push_back(std::make_unique<SerializedExpression>(p));
+        pe.push_back(*ps.back()->get());
+    }
+    std::vector<int32_t> gb = {0};
+    pa_hash_aggregation_desc d{};
+    d.input_channel_count = 2;
+    d.input_types = aggTypes.data();
+    d.group_by_count = 1;
+    d.group_by_channels = gb.data();
+    d.hash_channel = -1;
+    d.aggregate_count = (int32_t)aggs.size();
+    d.aggregates = aggs.data();
+    d.expected_groups = 10000;
+    orc_hash_agg* ref = orc_hash_agg_create(&d);
+    for (const auto& page : input) {
+        pa_page in;
+        std::vector<pa_column> cols;
+        page.toNative(&in, cols);
+        pa_page projected{};
+        EXPECT(orc_filter_project(&in, f.get(), (int32_t)pe.size(), pe.data(), &projected) >= 0, "oracle: %s", orc_last_error());
+        std::vector<int32_t> ids((size_t)projected.position_count + 1);
+        EXPECT(orc_hash_agg_add_page(ref, &projected, ids.data()) >= 0, "oracle: %s", orc_last_error());
+        orc_free_page(&projected);
+    }
+    pa_page result{};
+    EXPECT(orc_hash_agg_build_result(ref, &result) >= 0, "oracle: %s", orc_last_error());
+    auto expected = collect({Page::fromNative(result)});
+    orc_free_page(&result);
+    orc_hash_agg_destroy(ref);
+
+    EXPECT(got.size() == 7 && expected.size() == got.size(), "groups: got %zu expected %zu", got.size(), expected.size());
+    for (const auto& [key, e] : expected) {
+        auto it = got.find(key);
+        EXPECT(it != got.end(), "missing group %ld", (long)key);
+        if (it == got.end()) continue;
+        EXPECT(it->second.count == e.count, "group %ld count %ld != %ld", (long)key, (long)it->second.count, (long)e.count);
+        EXPECT(it->second.sum == e.sum, "group %ld sum %ld != %ld", (long)key, (long)it->second.sum, (long)e.sum);
+        EXPECT(std::fabs(it->second.avg - e.avg) <= 1e-9 * std::fabs(e.avg), "group %ld avg %.17g != %.17g", (long)key, it->second.avg, e.avg);
+    }
+}
+
+int main()
+{
+    try {
+        check(pa_init(0));
+        testFilterAndProject();
+        testDivisionByZero();
+        testPipeline();
+        pa_shutdown();
+    }
+    catch (const std::exception& e) {
+        fprintf(stderr, "exception: %s\n", e.what());
+        return 2;
+    }
+    if (failures) {
+        fprintf(stderr, "%d failure(s)\n", failures);
+        return 1;
+    }
+    printf("cpp driver: all cases pass\n");
+    return 0;
+}
