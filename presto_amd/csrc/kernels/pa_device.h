@@ -317,7 +317,32 @@ __device__ __forceinline__ u64 pa_short_bytes(const u8* p, i32 len, i32 bound, i
 // A lane that finds the slot busy with its own hash re-polls it in the next loop iteration; the
 // claiming lane finishes its publication inside the iteration of the claim, so lanes of one wave
 // cannot wait on each other.
-__device__ __forceinline__ int pa_gt_upsert_n(u64* tag, u64* keys, u32 mask, u32 h, const u64* k, const int W, i32* count,
+// Group counting without a hot address: a kernel reads the table's group count once (base), every wave keeps its own
+// tally of the slots it claimed and adds it to the global counter once, at the end of the kernel (pa_gt_ctr_flush).
+// The fill check inside a launch uses the estimate base + (claims this lane has seen in its wave) x (waves of the
+// grid): loads and atomics on ONE address from every insert retire at well under 1 G/s on this part and used to bound
+// launches that create millions of groups.  The estimate only decides when rows start to be spilled; a probe-length
+// bound backs it up, and the exact count is known to the host after every launch.
+struct PaGtCtr {
+    i32 base;   // groups in the table when the kernel started
+    i32 scale;  // waves in the grid
+    i32 seen;   // claims made by this wave while this lane was searching
+    i32 mine;   // claims this lane accounts for (each claim is counted by exactly one lane)
+    u32 max_probes;
+};
+// spilling = true: the caller can spill a row that finds no room (fill estimate and probe bound apply);
+// false: the host sized the table for everything the kernel inserts (merge, rehash): only a full table fails.
+__device__ __forceinline__ PaGtCtr pa_gt_ctr_init(const i32* count, bool spilling)
+{
+    PaGtCtr c;
+    c.base = *count;
+    c.scale = spilling ? (i32)(gridDim.x * (blockDim.x >> 6)) : 0;
+    c.seen = 0;
+    c.mine = 0;
+    c.max_probes = spilling ? 512u : 0xffffffffu;
+    return c;
+}
+__device__ __forceinline__ int pa_gt_upsert_n(u64* tag, u64* keys, u32 mask, u32 h, const u64* k, const int W, PaGtCtr& ctr,
                                               i32 max_fill, i32* err)
 {
     const u64 busy = ((u64)h << 2) | 1ULL, ready = ((u64)h << 2) | 3ULL;
@@ -346,14 +371,19 @@ __device__ __forceinline__ int pa_gt_upsert_n(u64* tag, u64* keys, u32 mask, u32
     // claims a slot publishes its key INSIDE the iteration of the claim.  (With an early `return` the compiler
     // may sink the publication behind the loop, and lanes of the same wave waiting for that very slot would
     // spin until their bound: SIMT forward-progress hazard.)
+    const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
     while (__ballot(result == -2) != 0ULL) {
-        if (result == -2) {
-            u64 t = __hip_atomic_load(&tag[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const bool searching = result == -2;
+        u64 t = 1ULL;
+        if (searching) t = __hip_atomic_load(&tag[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const i32 filled = ctr.base + ctr.seen * ctr.scale;
+        bool claimed = false;
+        if (searching) {
             bool advance = false;
             if (t == 0ULL) {
                 // a new group: refuse it once the table holds max_fill groups (the caller spills the row and the
                 // host rehashes into a larger table); concurrent inserts may overshoot by the lanes in flight
-                if (__hip_atomic_load(count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= max_fill) {
+                if (filled >= max_fill) {
                     result = -1;
                 }
                 else {
@@ -363,7 +393,7 @@ __device__ __forceinline__ int pa_gt_upsert_n(u64* tag, u64* keys, u32 mask, u32
                             __hip_atomic_store(&keys[(u64)i * W + w], k[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                         __hip_atomic_store(&tag[i], ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        atomicAdd(count, 1);
+                        claimed = true;
                         result = (int)i;
                     }
                     // else: someone else claimed it between the load and the CAS: look at it again next iteration
@@ -387,17 +417,30 @@ __device__ __forceinline__ int pa_gt_upsert_n(u64* tag, u64* keys, u32 mask, u32
             }
             if (advance) {
                 i = (i + 1) & mask;
-                if (++probes > mask) result = -1;  // every slot holds another key
+                if (++probes > ctr.max_probes || probes > mask) result = -1;  // a cluster this long means the table is (nearly) full
             }
+        }
+        const u64 claims = __ballot(claimed);
+        if (claims != 0ULL) {
+            const i32 c = (i32)__popcll(claims);
+            ctr.seen += c;
+            if (lane == __ffsll((long long)claims) - 1) ctr.mine += c;
         }
     }
     return result;
 }
 template <int W>
-__device__ __forceinline__ int pa_gt_upsert(u64* tag, u64* keys, u32 mask, u32 h, const u64 (&k)[W], i32* count,
+__device__ __forceinline__ int pa_gt_upsert(u64* tag, u64* keys, u32 mask, u32 h, const u64 (&k)[W], PaGtCtr& ctr,
                                             i32 max_fill, i32* err)
 {
-    return pa_gt_upsert_n(tag, keys, mask, h, k, W, count, max_fill, err);
+    return pa_gt_upsert_n(tag, keys, mask, h, k, W, ctr, max_fill, err);
+}
+
+// end of kernel, all lanes of the wave: one atomic per wave publishes its claims
+__device__ __forceinline__ void pa_gt_ctr_flush(const PaGtCtr& ctr, i32* count)
+{
+    const i64 total = pa_wave_sum_i64((i64)ctr.mine);
+    if ((threadIdx.x & 63) == 0 && total != 0) atomicAdd(count, (i32)total);
 }
 
 // hash of a packed key (identical in the generated kernels and in the merge / rehash kernels)

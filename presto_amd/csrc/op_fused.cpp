@@ -27,6 +27,7 @@
 #include "jit.hpp"
 #include "operator.hpp"
 #include "rowgen.hpp"
+#include "static_kernels.hpp"
 
 namespace pa {
 
@@ -403,7 +404,7 @@ KernelInfo generate(const Spec& s, const std::vector<ChannelLayout>& layout, int
         src << "struct PaAcc { u64 tk[PA_C][PA_KW]; int tcount; u32 lane; };\n";
     }
     else {
-        src << "struct PaAcc { int unused; };\n";
+        src << "struct PaAcc { PaGtCtr gt; };\n";
     }
     src << "__device__ __forceinline__ void pa_row(const PaFusedArgs& a, PaAcc& acc, const bool live, const i32 row" << row_params(ri, layout) << ")\n{\n";
     src << body.str();
@@ -457,7 +458,7 @@ KernelInfo generate(const Spec& s, const std::vector<ChannelLayout>& layout, int
     }
     else {
         src << "if (sel) {\n  const u32 h = pa_key_hash(key, PA_KW);\n"
-               "  int g = pa_gt_upsert<PA_KW>(a.gt_tag, a.gt_keys, a.gt_mask, h, key, a.gt_count, a.gt_max_fill, a.err);\n";
+               "  int g = pa_gt_upsert<PA_KW>(a.gt_tag, a.gt_keys, a.gt_mask, h, key, acc.gt, a.gt_max_fill, a.err);\n";
         src << "  if (g >= 0) {\n    const u64 cap = (u64)a.gt_mask + 1ULL;\n";
         for (int w = 0; w < k.nw; w++) {
             std::string idx = std::to_string(w) + "ULL * cap + (u64)g";
@@ -490,7 +491,7 @@ KernelInfo generate(const Spec& s, const std::vector<ChannelLayout>& layout, int
             src << "#pragma unroll\n    for (int s = 0; s < PA_C; s++) {\n#pragma unroll\n        for (int w = 0; w < PA_KW; w++) acc.tk[s][w] = 0ULL;\n    }\n";
         }
         else {
-            src << "    PaAcc acc; acc.unused = 0;\n";
+            src << "    PaAcc acc; acc.gt = pa_gt_ctr_init(a.gt_count, true);\n";
         }
         if (mode != 2) emit_prologue(ri, layout, src);
         src << "    const i64 t = (i64)blockIdx.x * " << B << " + threadIdx.x, T = (i64)gridDim.x * " << B << ";\n";
@@ -517,6 +518,7 @@ KernelInfo generate(const Spec& s, const std::vector<ChannelLayout>& layout, int
         if (variant == V_GT) {
             src << "    for (i64 i = t; i < a.n_list; i += T) {\n        const i64 r = a.row_list[i];\n        pa_row(a, acc, true, (i32)r" << scalar_args(ri, layout)
                 << ");\n    }\n";
+            src << "    pa_gt_ctr_flush(acc.gt, a.gt_count);\n";
         }
         if (variant == V_GLOBAL) {
             src << "    __shared__ u64 red[" << (B / 64) << " * PA_NW];\n    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;\n";
@@ -793,7 +795,8 @@ private:
                 drain_merges();
                 // sized by the groups seen so far, not by the rows: rows whose new group does not fit are spilled and
                 // replayed after a rehash (see below)
-                ensure_table(std::max<uint64_t>({(uint64_t)32768, 2 * groups_upper_, (uint64_t)std::max(spec_.expected_groups, 0)}));
+                // (ensure_table doubles its argument: the table is kept at most half full)
+                ensure_table(std::max<uint64_t>({(uint64_t)16384, groups_upper_ + groups_upper_ / 4, (uint64_t)std::max(spec_.expected_groups, 0)}));
                 a.spill_rows = static_cast<int32_t*>(spill_[0].ensure((size_t)n * 4));
                 a.spill_count = reinterpret_cast<uint32_t*>(ctl_ + 6);
                 a.row_list = nullptr;
@@ -884,6 +887,7 @@ private:
     }
 
     void build_output();
+    bool emit_on_device(const KernelInfo& ki, int64_t groups);
 
     Spec spec_;
     Stream stream_;
@@ -897,7 +901,7 @@ private:
     int32_t* h_ctl_ = nullptr;
     DevBuf slab_, state_, gt_tag_, gt_keys_, gt_words_;
     // LDS variant: the merge of page k runs on a second stream while the fused kernel of page k+1 streams
-    DevBuf lds_slab_[2], entry_slot_[2], spill_[2], dense_keys_, dense_words_;
+    DevBuf lds_slab_[2], entry_slot_[2], spill_[2], dense_keys_, dense_words_, null_flags_;
     hipStream_t merge_stream_ = nullptr;
     hipEvent_t ev_main_[2] = {nullptr, nullptr}, ev_merge_[2] = {nullptr, nullptr};
     bool merge_pending_[2] = {false, false};
@@ -908,6 +912,100 @@ private:
     std::vector<pa_column> out_storage_;
     int32_t out_rows_ = 0;
 };
+
+// Large grouped results (Q3: millions of groups) never visit the host: k_gt_emit compacts the table and writes the output
+// blocks in one pass.  Small results and VARCHAR keys take the host assembly of build_output below.
+bool FusedAggregationOperator::emit_on_device(const KernelInfo& ki, int64_t groups)
+{
+    constexpr int64_t kMinGroups = 4096;
+    const int nkeys = (int)spec_.group_proj.size();
+    const bool has_hash = nkeys > 0 && spec_.hash_channel >= 0;
+    const bool partial = spec_.step == PA_STEP_PARTIAL;
+    if (groups < kMinGroups || groups > INT32_MAX) return false;
+    for (int gi = 0; gi < nkeys; gi++) {
+        if (ki.keys[gi].type == PA_VARCHAR) return false;
+    }
+    GtEmitArgs a{};
+    int n = 0;
+    auto add = [&](int kind, int type) -> GtEmitCol* {
+        if (n >= GT_EMIT_MAX_COLS) return nullptr;
+        GtEmitCol& c = a.col[n++];
+        c.kind = kind;
+        c.type = type;
+        c.null_word = -1;
+        c.width = type_width(type);
+        return &c;
+    };
+    std::vector<bool> nullable;
+    for (int gi = 0; gi < nkeys; gi++) {
+        const KeyPart& kp = ki.keys[gi];
+        GtEmitCol* c = add(GT_EMIT_KEY, kp.type);
+        if (!c) return false;
+        c->word = kp.word;
+        c->shift = kp.shift;
+        c->bits = kp.bits;
+        c->null_word = kp.null_word;
+        c->null_shift = kp.null_shift;
+        nullable.push_back(kp.null_word >= 0);
+    }
+    if (has_hash) {
+        if (!add(GT_EMIT_HASH, PA_BIGINT)) return false;
+        nullable.push_back(false);
+    }
+    for (size_t k = 0; k < spec_.aggs.size(); k++) {
+        const pa_aggregate& ag = spec_.aggs[k];
+        const int cw = ki.agg_words[k].first, vw = ki.agg_words[k].second;
+        const bool value_is_double = vw >= 0 && ki.word_kind[vw] == W_SUMF;
+        if (partial) {
+            for (int part = 0; part < ((ag.fn == PA_AGG_SUM || ag.fn == PA_AGG_AVG) ? 2 : 1); part++) {
+                GtEmitCol* c = add(GT_EMIT_STATE, part == 0 ? PA_BIGINT : (value_is_double ? PA_DOUBLE : PA_BIGINT));
+                if (!c) return false;
+                c->word = part == 0 ? cw : vw;
+                nullable.push_back(false);
+            }
+            continue;
+        }
+        const bool as_double = ag.fn == PA_AGG_AVG || (ag.fn == PA_AGG_SUM && value_is_double);
+        const int value_proj = spec_.step == PA_STEP_FINAL ? ag.input_channel + 1 : ag.input_channel;
+        const int type = as_double ? PA_DOUBLE : ((ag.fn == PA_AGG_SUM) ? spec_.proj[value_proj].root_type() : PA_BIGINT);
+        const int kind = ag.fn == PA_AGG_SUM ? GT_EMIT_SUM : (ag.fn == PA_AGG_AVG ? GT_EMIT_AVG : GT_EMIT_COUNT);
+        if (ag.fn != PA_AGG_SUM && ag.fn != PA_AGG_AVG && ag.fn != PA_AGG_COUNT && ag.fn != PA_AGG_COUNT_STAR) return false;
+        GtEmitCol* c = add(kind, type);
+        if (!c) return false;
+        c->cw = cw;
+        c->vw = vw;
+        nullable.push_back(kind != GT_EMIT_COUNT);
+    }
+    hipStream_t s = stream_.get();
+    out_cols_.clear();
+    out_cols_.resize(n);
+    for (int c = 0; c < n; c++) {
+        OutColumn& oc = out_cols_[c];
+        oc.type = a.col[c].type;
+        a.col[c].values = oc.values.ensure((size_t)groups * a.col[c].width);
+        a.col[c].nulls = nullable[c] ? static_cast<uint8_t*>(oc.nulls.ensure((size_t)groups)) : nullptr;
+    }
+    a.tag = gt_tag_.as<uint64_t>();
+    a.keys = gt_keys_.as<uint64_t>();
+    a.words = gt_words_.as<uint64_t>();
+    a.cap = gt_cap_;
+    a.W = std::max(w_, 1);
+    a.NW = nw_;
+    a.ncols = n;
+    a.counter = reinterpret_cast<uint32_t*>(ctl_ + 7);
+    a.null_flags = static_cast<uint32_t*>(null_flags_.ensure(GT_EMIT_MAX_COLS * 4));
+    PA_HIP(hipMemsetAsync(ctl_ + 7, 0, 4, s));
+    PA_HIP(hipMemsetAsync(a.null_flags, 0, GT_EMIT_MAX_COLS * 4, s));
+    launch_gt_emit(a, s);
+    uint32_t flags[GT_EMIT_MAX_COLS];
+    PA_HIP(hipMemcpyAsync(flags, a.null_flags, sizeof(flags), hipMemcpyDeviceToHost, s));
+    PA_HIP(hipMemcpyAsync(h_ctl_, ctl_, 32, hipMemcpyDeviceToHost, s));
+    PA_HIP(hipStreamSynchronize(s));
+    PA_REQUIRE((int64_t)(uint32_t)h_ctl_[7] == groups, PA_ERR_DEVICE, "group table and group count disagree");
+    for (int c = 0; c < n; c++) out_cols_[c].has_nulls = flags[c] != 0;
+    out_rows_ = (int32_t)groups;
+    return true;
+}
 
 // Final values: InMemoryHashAggregationBuilder.buildResult (…/InMemoryHashAggregationBuilder.java:244-298) /
 // AggregationOperator.getOutput (…/AggregationOperator.java:164-186) with the output functions of SURVEY a15.
@@ -943,6 +1041,7 @@ void FusedAggregationOperator::build_output()
     }
     else if (gt_cap_ > 0) {
         groups = h_ctl_[1];
+        if (emit_on_device(ki, groups)) return;
         if (groups > 0) {
             const int kw = std::max(w_, 1);
             dense_keys_.ensure((size_t)groups * kw * 8);

@@ -2,8 +2,10 @@
 // hipStreamCreate cost 0.1-several ms each; an operator instance lives for one query, so without reuse
 // the allocator would dominate short queries (a fresh operator per query is the reference's model too:
 // OperatorFactory.createOperator, …/operator/OperatorFactory.java:18-50).
+#include <cstdlib>
 #include <map>
 #include <mutex>
+#include <vector>
 
 #include "common.hpp"
 
@@ -24,14 +26,26 @@ Pools& pools()
     return *p;
 }
 
+// powers of two below 1 MiB; above, four steps per octave (<= 25 % slack on the multi-GB page buffers)
 size_t size_class(size_t bytes)
 {
     size_t c = 256;
     while (c < bytes) c <<= 1;
-    return c;
+    if (c <= (1ULL << 20)) return c;
+    const size_t step = c >> 3;  // c/2 < bytes <= c: classes c/2 + k * c/8
+    return (bytes + step - 1) / step * step;
 }
 
-constexpr size_t kMaxCachedDevice = 8ULL << 30;  // of 288 GB
+// Freed blocks kept for the next operator.  A Q3 pipeline over 2^28-row pages holds tens of GB of transient page
+// buffers, and re-creating them with hipMalloc costs hundreds of ms; the card has 288 GB.
+size_t max_cached_device()
+{
+    static const size_t v = [] {
+        const char* e = getenv("PRESTO_AMD_POOL_BYTES");
+        return e ? (size_t)strtoull(e, nullptr, 10) : (size_t)(96ULL << 30);
+    }();
+    return v;
+}
 constexpr size_t kMaxCachedPinned = 1ULL << 30;
 
 }  // namespace
@@ -54,7 +68,28 @@ void* pool_device_alloc(size_t bytes, size_t* granted)
         }
     }
     void* ptr = nullptr;
-    PA_HIP(hipMalloc(&ptr, c));
+    hipError_t e = hipMalloc(&ptr, c);
+    if (e == hipErrorOutOfMemory) {
+        // give the cached blocks back to the driver and try once more
+        (void)hipGetLastError();
+        std::vector<void*> cached;
+        {
+            Pools& p = pools();
+            std::lock_guard<std::mutex> lock(p.mu);
+            for (auto it = p.device_free.begin(); it != p.device_free.end();) {
+                if (it->first.first == dev) {
+                    cached.push_back(it->second);
+                    p.device_cached -= it->first.second;
+                    it = p.device_free.erase(it);
+                }
+                else ++it;
+            }
+        }
+        PA_HIP(hipDeviceSynchronize());
+        for (void* q : cached) (void)hipFree(q);
+        e = hipMalloc(&ptr, c);
+    }
+    PA_HIP(e);
     *granted = c;
     return ptr;
 }
@@ -67,7 +102,7 @@ void pool_device_free(void* ptr, size_t granted)
     Pools& p = pools();
     {
         std::lock_guard<std::mutex> lock(p.mu);
-        if (p.device_cached + granted <= kMaxCachedDevice) {
+        if (p.device_cached + granted <= max_cached_device()) {
             p.device_free.emplace(std::make_pair(dev, granted), ptr);
             p.device_cached += granted;
             return;

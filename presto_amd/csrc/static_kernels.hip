@@ -132,16 +132,18 @@ __global__ __launch_bounds__(256) void k_merge_lds_keys(const u64* __restrict__ 
     // slab is field-major: field f of entry e at slab[f * entries + e]; fields = occupied, W key words, NW words
     // a launch whose register tables overflowed is discarded as a whole: the page is redone on the HBM table
     const bool discard = *overflow_rows != 0ULL;
+    PaGtCtr ctr = pa_gt_ctr_init(count, false);
     for (i64 e = (i64)blockIdx.x * 256 + threadIdx.x; e < entries; e += (i64)gridDim.x * 256) {
         i32 g = -1;
         if (!discard && slab[e] != 0ULL) {
             u64 k[8];
             for (int w = 0; w < W; w++) k[w] = slab[(i64)(1 + w) * entries + e];
-            g = pa_gt_upsert_n(tag, keys, mask, pa_key_hash(k, W), k, W, count, max_fill, err);
+            g = pa_gt_upsert_n(tag, keys, mask, pa_key_hash(k, W), k, W, ctr, max_fill, err);
             if (g < 0) pa_raise(err, PA_DEV_ERR_RESOURCES);  // the host sized the table for every entry of the slab
         }
         entry_slot[e] = g;
     }
+    pa_gt_ctr_flush(ctr, count);
 }
 
 __global__ __launch_bounds__(256) void k_merge_lds_words(const u64* __restrict__ slab, i64 entries, int W, int NW,
@@ -237,12 +239,13 @@ __global__ __launch_bounds__(256) void k_gt_rehash(const u64* __restrict__ old_t
                                                    const u64* __restrict__ old_words, u32 old_cap, int W, int NW, u64* tag, u64* keys,
                                                    u64* words, u32 mask, i32 max_fill, i32* count, i32* err)
 {
+    PaGtCtr ctr = pa_gt_ctr_init(count, false);
     for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < (i64)old_cap; i += (i64)gridDim.x * 256) {
         if (old_tag[i] == 0ULL) continue;
         u64 k[8];
         for (int w = 0; w < W; w++) k[w] = old_keys[(u64)i * W + w];
         u32 h = pa_key_hash(k, W);
-        int g = pa_gt_upsert_n(tag, keys, mask, h, k, W, count, max_fill, err);
+        int g = pa_gt_upsert_n(tag, keys, mask, h, k, W, ctr, max_fill, err);
         if (g < 0) {
             pa_raise(err, PA_DEV_ERR_RESOURCES);  // cannot happen: the new table is larger than the old one
             continue;
@@ -251,6 +254,7 @@ __global__ __launch_bounds__(256) void k_gt_rehash(const u64* __restrict__ old_t
         // each old group maps to exactly one new slot, so plain stores suffice
         for (int w = 0; w < NW; w++) words[(u64)w * cap + g] = old_words[(u64)w * old_cap + i];
     }
+    pa_gt_ctr_flush(ctr, count);
 }
 
 void launch_gt_rehash(const uint64_t* old_tag, const uint64_t* old_keys, const uint64_t* old_words, uint32_t old_cap, int w, int nw,
@@ -278,6 +282,96 @@ void launch_gt_compact(const uint64_t* tag, const uint64_t* keys, const uint64_t
 {
     hipLaunchKernelGGL(k_gt_compact, grid_for(cap, 256), 256, 0, s, (const u64*)tag, (const u64*)keys, (const u64*)words, cap, w, nw,
                        (u64*)out_keys, (u64*)out_words, (u32*)counter);
+    PA_HIP(hipGetLastError());
+}
+
+// keys -> output blocks, states -> final values, in the pass that compacts the table (see static_kernels.hpp).
+// A workgroup takes 4096 consecutive slots: occupancy bits -> workgroup scan -> ONE counter atomic per tile (atomics
+// on a single address retire at only ~0.25 G/s on this part, so per-wave or per-slot counting would bound the kernel).
+__device__ __forceinline__ void gt_emit_slot(const GtEmitArgs& a, u64 i, u64 g)
+{
+    const u64* kw = (const u64*)a.keys + i * (u64)a.W;
+    const u64* wd = (const u64*)a.words;
+    i64 row_hash = 0;
+    for (int c = 0; c < a.ncols; c++) {
+        const GtEmitCol& col = a.col[c];
+        u64 bits = 0;
+        bool is_null = false;
+        switch (col.kind) {
+            case GT_EMIT_KEY: {
+                is_null = col.null_word >= 0 && ((kw[col.null_word] >> col.null_shift) & 1ULL);
+                const u64 mask = col.bits >= 64 ? ~0ULL : ((1ULL << col.bits) - 1ULL);
+                const u64 w0 = (kw[col.word] >> col.shift) & mask;
+                i64 h = 0;  // NULL hashes to 0
+                if (!is_null) {
+                    switch (col.type) {
+                        case PA_BIGINT: bits = w0; h = pa_hash_bigint((i64)w0); break;
+                        case PA_INTEGER:
+                        case PA_DATE: bits = (u64)(u32)w0; h = pa_hash_bigint((i64)(i32)(u32)w0); break;
+                        case PA_BOOLEAN: bits = w0 != 0 ? 1ULL : 0ULL; h = (i64)pa_xxh64_long(bits); break;
+                        default: bits = w0; h = pa_hash_bigint((i64)w0); break;  // DOUBLE: canonical bits
+                    }
+                }
+                row_hash = pa_combine_hash(row_hash, h);
+                break;
+            }
+            case GT_EMIT_HASH: bits = (u64)row_hash; break;
+            case GT_EMIT_STATE: bits = wd[(u64)col.word * a.cap + i]; break;
+            case GT_EMIT_COUNT: bits = wd[(u64)col.cw * a.cap + i]; break;
+            case GT_EMIT_SUM:
+                if (wd[(u64)col.cw * a.cap + i] == 0ULL) is_null = true;
+                else bits = wd[(u64)col.vw * a.cap + i];
+                break;
+            case GT_EMIT_AVG: {
+                const i64 count = (i64)wd[(u64)col.cw * a.cap + i];
+                if (count == 0) is_null = true;
+                else {
+                    double avg = __longlong_as_double((i64)wd[(u64)col.vw * a.cap + i]) / (double)count;
+                    bits = (u64)__double_as_longlong(avg);
+                }
+                break;
+            }
+            default: break;
+        }
+        if (col.width == 8) ((u64*)col.values)[g] = bits;
+        else if (col.width == 4) ((u32*)col.values)[g] = (u32)bits;
+        else ((u8*)col.values)[g] = (u8)bits;
+        if (col.nulls) {
+            col.nulls[g] = is_null ? 1 : 0;
+            if (is_null) a.null_flags[c] = 1u;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_gt_emit(GtEmitArgs a)
+{
+    __shared__ u32 tile_base;
+    const i64 cap = (i64)a.cap;
+    const i64 tiles = (cap + 4095) >> 12;
+    const u64* tag = (const u64*)a.tag;
+    for (i64 tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        const i64 first = (tile << 12) + threadIdx.x;
+        u32 occ = 0;
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const i64 i = first + (i64)j * 256;
+            if (i < cap && tag[i] != 0ULL) occ |= 1u << j;
+        }
+        i32 total = 0;
+        const i32 before = pa_block_exclusive_scan_256((i32)__popc(occ), &total);
+        if (total == 0) continue;  // workgroup-uniform
+        if (threadIdx.x == 0) tile_base = atomicAdd(a.counter, (u32)total);
+        __syncthreads();
+        u64 g = (u64)tile_base + (u64)before;
+        for (int j = 0; j < 16; j++) {
+            if ((occ >> j) & 1u) gt_emit_slot(a, (u64)(first + (i64)j * 256), g++);
+        }
+    }
+}
+void launch_gt_emit(const GtEmitArgs& args, hipStream_t s)
+{
+    const int64_t tiles = ((int64_t)args.cap + 4095) >> 12;
+    hipLaunchKernelGGL(k_gt_emit, (int)std::max<int64_t>(1, std::min<int64_t>(tiles, 256 * 8)), 256, 0, s, args);
     PA_HIP(hipGetLastError());
 }
 

@@ -24,4 +24,30 @@ void launch_hash_page(const HashPageArgs& args, hipStream_t s);
 void launch_partition_ids(const int64_t* raw_hash, int64_t n, int32_t partition_count, int32_t local, int32_t* out, hipStream_t s);
 void launch_tpch(int32_t column, double sf, int64_t first_row, int64_t n, uint64_t seed, void* values, int32_t* offsets, hipStream_t s);
 
+// Grouped output assembled on device (InMemoryHashAggregationBuilder.buildResult): one pass over the table slots
+// compacts the occupied ones (one counter atomic per wave) and writes every output block -- unpacked key columns,
+// $hashvalue, final aggregate values or PARTIAL states -- directly.
+enum GtEmitKind { GT_EMIT_KEY = 0, GT_EMIT_HASH = 1, GT_EMIT_COUNT = 2, GT_EMIT_SUM = 3, GT_EMIT_AVG = 4, GT_EMIT_STATE = 5 };
+struct GtEmitCol {
+    int32_t kind, type;          // GtEmitKind, pa_type of the output block
+    int32_t word, shift, bits;   // KEY: packed position; STATE: accumulator word
+    int32_t null_word, null_shift;
+    int32_t cw, vw;              // aggregates: count word, value word
+    int32_t width;               // bytes per output element
+    void* values;
+    uint8_t* nulls;              // may be null when the column cannot hold NULLs
+};
+constexpr int GT_EMIT_MAX_COLS = 32;
+struct GtEmitArgs {
+    const uint64_t* tag;
+    const uint64_t* keys;
+    const uint64_t* words;
+    uint32_t cap;
+    int32_t W, NW, ncols;
+    uint32_t* counter;
+    uint32_t* null_flags;        // [ncols]: set to 1 when the column wrote a NULL
+    GtEmitCol col[GT_EMIT_MAX_COLS];
+};
+void launch_gt_emit(const GtEmitArgs& args, hipStream_t s);
+
 }  // namespace pa

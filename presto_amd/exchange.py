@@ -94,8 +94,12 @@ def exchange_columns(ops, columns, types, hash_channels, group=None, local=None,
             raise NotImplementedError("VARCHAR columns are not shuffled on device yet (fixed-width columns only)")
     if local is None:
         local = (world & (world - 1)) == 0  # LocalPartitionGenerator needs a power of two
-    positions, send_counts = partition_rows(ops, columns, types, hash_channels, world, local, raw_hash)
     device = columns[0].device
+    rows = int(columns[0].shape[0])
+    if rows > 0:
+        positions, send_counts = partition_rows(ops, columns, types, hash_channels, world, local, raw_hash)
+    else:  # a rank with nothing to send still takes part in the collectives
+        positions, send_counts = None, [0] * world
     # 8 x 8 count matrix: every rank learns how much it receives from each source
     sc = torch.tensor(send_counts, dtype=torch.int64, device=device)
     rc = torch.empty(world, dtype=torch.int64, device=device)
@@ -103,7 +107,7 @@ def exchange_columns(ops, columns, types, hash_channels, group=None, local=None,
     recv_counts = [int(x) for x in rc.tolist()]
     received = []
     for col in columns:
-        send = ops.gather(col, positions)
+        send = ops.gather(col, positions) if rows > 0 else col
         recv = torch.empty(sum(recv_counts), dtype=col.dtype, device=device)
         dist.all_to_all_single(recv, send, output_split_sizes=recv_counts, input_split_sizes=send_counts, group=group)
         received.append(recv)

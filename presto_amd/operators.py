@@ -238,6 +238,12 @@ class LookupSourceFactory:
         return (download(DeviceBuffer(key.value, 4 * hs.value), np.int32, hs.value),
                 download(DeviceBuffer(links.value, 4 * n.value), np.int32, n.value))
 
+    def positionCount(self):
+        """Build positions of the published lookup source (LookupSource.getJoinPositionCount)."""
+        key, links, hs, n = C.c_void_p(), C.c_void_p(), C.c_int32(), C.c_int32()
+        check(lib().pa_lookup_source_tables(self._h, C.byref(key), C.byref(hs), C.byref(links), C.byref(n)))
+        return n.value
+
     def destroy(self):
         if self._h:
             lib().pa_lookup_source_destroy(self._h)

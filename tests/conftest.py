@@ -2,6 +2,8 @@ import os
 import sys
 
 import pytest
+import torch  # noqa: F401  -- before libpresto_amd.so: the torch wheel bundles its own HIP/HSA runtime, and a process that
+#                 loads torch's after /opt/rocm's (through libpresto_amd.so) finds no GPU from torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:

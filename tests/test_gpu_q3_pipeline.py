@@ -8,8 +8,6 @@ import pytest
 
 from presto_amd import abi, tpch
 from presto_amd._lib import DeviceStream
-from presto_amd.operators import (Driver, FilterAndProjectOperator, HashAggregationOperator, HashBuilderOperator, LookupJoinOperator,
-                                  LookupSourceFactory)
 from presto_amd.expr import field
 from presto_amd.page import Block, Page
 from tests.util import rows_equal_ignore_order
@@ -44,42 +42,57 @@ def oracle_q3(oracle, customer, orders, lineitem):
     return agg.build_result().to_rows(), oc.position_count, joined.position_count
 
 
+def _device_tables(sf):
+    nc, no, nl = tpch.customer_rows(sf), tpch.orders_rows(sf), tpch.lineitem_rows(sf)
+    return (tpch.DeviceColumns(tpch.CUSTOMER_COLUMNS, sf, nc), tpch.DeviceColumns(tpch.ORDERS_COLUMNS, sf, no),
+            tpch.DeviceColumns(tpch.Q3_LINEITEM_COLUMNS, sf, nl))
+
+
+def _expected(oracle, sf):
+    nc, no, nl = tpch.customer_rows(sf), tpch.orders_rows(sf), tpch.lineitem_rows(sf)
+    return oracle_q3(oracle, host_table(oracle, tpch.CUSTOMER_COLUMNS, sf, nc), host_table(oracle, tpch.ORDERS_COLUMNS, sf, no),
+                     host_table(oracle, tpch.Q3_LINEITEM_COLUMNS, sf, nl))
+
+
 @pytest.mark.parametrize("sf,page_rows", [(0.02, 1 << 14), (0.1, 1 << 17)])
 def test_q3_pipeline_matches_oracle(gpu, oracle, sf, page_rows):
-    nc, no, nl = tpch.customer_rows(sf), tpch.orders_rows(sf), tpch.lineitem_rows(sf)
-    expected, exp_orders, exp_joined = oracle_q3(oracle, host_table(oracle, tpch.CUSTOMER_COLUMNS, sf, nc),
-                                                 host_table(oracle, tpch.ORDERS_COLUMNS, sf, no),
-                                                 host_table(oracle, tpch.Q3_LINEITEM_COLUMNS, sf, nl))
+    from presto_amd import q3
+    expected, exp_orders, exp_joined = _expected(oracle, sf)
     stream = DeviceStream()
-    s = stream.handle
-    dev = abi.MEM_DEVICE
-    customer = tpch.DeviceColumns(tpch.CUSTOMER_COLUMNS, sf, nc)
-    orders = tpch.DeviceColumns(tpch.ORDERS_COLUMNS, sf, no)
-    lineitem = tpch.DeviceColumns(tpch.Q3_LINEITEM_COLUMNS, sf, nl)
-
-    # pipeline 1: customer -> FilterAndProject -> HashBuilder (JoinBridge b1)
-    b1 = LookupSourceFactory()
-    Driver(customer.pages(page_rows - page_rows % 20), [
-        FilterAndProjectOperator(tpch.CUSTOMER_TYPES, tpch.q3_customer_filter(), [field(0, abi.BIGINT)], output_mem=dev, stream=s),
-        HashBuilderOperator(b1, [abi.BIGINT], [0], [], stream=s)]).run()
-    # pipeline 2: orders -> FilterAndProject -> LookupJoin(b1) -> HashBuilder (b2)
-    b2 = LookupSourceFactory()
-    join1 = LookupJoinOperator(b1, tpch.ORDERS_TYPES, [1], [0, 2, 3], output_mem=dev, stream=s)
-    Driver(orders.pages(page_rows), [
-        FilterAndProjectOperator(tpch.ORDERS_TYPES, tpch.q3_orders_filter(), [field(i, t) for i, t in enumerate(tpch.ORDERS_TYPES)], output_mem=dev, stream=s),
-        join1,
-        HashBuilderOperator(b2, [abi.BIGINT, abi.DATE, abi.INTEGER], [0], [1, 2], stream=s)]).run()
-    # pipeline 3: lineitem -> FilterAndProject -> LookupJoin(b2) -> HashAggregation
-    agg = HashAggregationOperator([abi.BIGINT, abi.DOUBLE, abi.DATE, abi.INTEGER], [0, 2, 3], [(abi.AGG_SUM, 1, abi.DOUBLE), (abi.AGG_COUNT_STAR, -1, None)],
-                                  expected_groups=100000, stream=s)
-    out = Driver(lineitem.pages(page_rows), [
-        FilterAndProjectOperator(tpch.Q3_LINEITEM_TYPES, tpch.q3_lineitem_filter(), tpch.q3_lineitem_projections(), output_mem=dev, stream=s),
-        LookupJoinOperator(b2, [abi.BIGINT, abi.DOUBLE], [0], [0, 1], output_mem=dev, stream=s),
-        agg]).run()
+    customer, orders, lineitem = _device_tables(sf)
+    out, counters = q3.run(customer.pages(page_rows - page_rows % 20), orders.pages(page_rows), lineitem.pages(page_rows), stream.handle,
+                           distributed=False)
     rows = [r for p in out for r in p.to_rows()]
     assert len(expected) > 100
     rows_equal_ignore_order(rows, expected, rel=1e-9)
-    key, links = b2.tables()
-    assert len(links) == exp_orders  # orders JOIN customer rows that reached the second build side
+    assert counters["build2_rows"] == exp_orders  # orders JOIN customer rows that reached the second build side
     assert sum(r[4] for r in rows) == exp_joined
     stream.destroy()
+
+
+def test_q3_with_exchange_steps_on_one_rank_over_rccl(gpu, oracle):
+    """The multi-GPU form of the pipelines (an ExchangeOperator before every build and probe) with a one-rank RCCL
+    group: every all-to-all is a self copy, so the result must equal the oracle's, and every row must come back."""
+    import os
+    import torch
+    import torch.distributed as dist
+    from presto_amd import q3
+    sf, page_rows = 0.05, 1 << 16
+    expected, exp_orders, exp_joined = _expected(oracle, sf)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    torch.zeros(1, device="cuda")  # initialise torch's view of the device before the process group asks for it
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        stream = DeviceStream()
+        customer, orders, lineitem = _device_tables(sf)
+        out, counters = q3.run(customer.pages(page_rows - page_rows % 20), orders.pages(page_rows), lineitem.pages(page_rows),
+                               stream.handle, distributed=True)
+        torch.cuda.synchronize()
+        rows = [r for p in out for r in p.to_rows()]
+        rows_equal_ignore_order(rows, expected, rel=1e-9)
+        assert counters["build2_rows"] == exp_orders
+        assert sum(r[4] for r in rows) == exp_joined
+        stream.destroy()
+    finally:
+        dist.destroy_process_group()
