@@ -71,7 +71,7 @@ struct FusedArgs {
     uint32_t* spill_count;
 };
 
-enum Variant { V_GLOBAL = 0, V_LDS = 1, V_GT = 2 };
+enum Variant { V_GLOBAL = 0, V_LDS = 1, V_GT = 2, V_LDSH = 3 };
 enum WordKind { W_CNT = 0, W_SUMF = 1, W_SUMI = 2 };
 
 constexpr int kLdsSlots = 8;  // C of the LDS variant: 8 groups x NW words x 64 lanes x 8 B of LDS per wave
@@ -107,6 +107,7 @@ struct KernelInfo {
     std::string source, entry;
     int variant = V_GLOBAL;
     int nw = 0, w = 0, c = 0, block = 256;
+    int lc = 0;  // V_LDSH: slots of the workgroup's LDS table
     std::vector<int32_t> word_kind;
     std::vector<std::pair<int, int>> agg_words;  // per aggregate: (count word, value word or -1)
     std::vector<KeyPart> keys;
@@ -388,6 +389,15 @@ KernelInfo generate(const Spec& s, const std::vector<ChannelLayout>& layout, int
     if (variant == V_LDS) {
         PA_REQUIRE((size_t)k.nw * kLdsSlots * 64 * 8 <= 64 * 1024, PA_ERR_NOT_SUPPORTED, "too many accumulator words for the LDS variant");
     }
+    if (variant == V_LDSH) {
+        // one table per 512-thread workgroup in 64 KB of LDS (two workgroups per CU): tag + key words + accumulator words per slot
+        const size_t slot_bytes = 8 * (size_t)(1 + std::max(k.w, 1) + k.nw);
+        int lc = 2048;
+        while (lc > 32 && (size_t)lc * slot_bytes > 62 * 1024) lc >>= 1;
+        PA_REQUIRE((size_t)lc * slot_bytes <= 62 * 1024, PA_ERR_NOT_SUPPORTED, "group state too wide for the LDS-table variant");
+        k.lc = lc;
+        k.block = 512;
+    }
 
     // ---- assemble the translation unit ----
     std::ostringstream src;
@@ -402,6 +412,41 @@ KernelInfo generate(const Spec& s, const std::vector<ChannelLayout>& layout, int
         // of lane l lives at pa_accw[(w * C + g) * 64 + l], so no two lanes ever share an address
         src << "__shared__ u64 pa_accw[PA_NW * PA_C * 64];\n";
         src << "struct PaAcc { u64 tk[PA_C][PA_KW]; int tcount; u32 lane; };\n";
+    }
+    else if (variant == V_LDSH) {
+        // Medium cardinality: the workgroup aggregates into an open-addressing table in LDS (ds_cmpst / ds_add: no HBM
+        // atomics in the row loop -- atomics of many rows on a few HBM addresses retire at ~16 M/s per address on this
+        // part), and adds its table to the HBM table once, at the end of the kernel.  A row whose group finds no room
+        // in the LDS table (more than PA_LC / 2 groups seen by the workgroup) goes to the HBM table directly.
+        src << "#define PA_LC " << k.lc << "\n";
+        src << "__shared__ u64 pa_lt_tag[PA_LC];\n__shared__ u64 pa_lt_key[PA_LC * PA_KW];\n__shared__ u64 pa_lt_acc[PA_LC * PA_NW];\n"
+               "__shared__ i32 pa_lt_count;\n";
+        src << "struct PaAcc { PaGtCtr gt; PaGtCtr flush; i64 fell; };\n";
+        // same claim / publish protocol as pa_gt_upsert_n, on LDS: tag 0 -> busy -> ready, wave-uniform loop so that a
+        // lane waiting for a slot another lane of its wave is publishing cannot starve it
+        src << "__device__ __forceinline__ int pa_lt_upsert(const u32 h, const u64 (&k)[PA_KW])\n{\n"
+               "    const u64 busy = ((u64)h << 2) | 1ULL, ready = ((u64)h << 2) | 3ULL;\n"
+               "    u32 i = h & (PA_LC - 1);\n    u32 probes = 0;\n    int spins = 0;\n    int result = -2;\n"
+               "    while (__ballot(result == -2) != 0ULL) {\n        if (result == -2) {\n"
+               "            const u64 t = __hip_atomic_load(&pa_lt_tag[i], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);\n"
+               "            bool advance = false;\n"
+               "            if (t == 0ULL) {\n"
+               "                if (__hip_atomic_load(&pa_lt_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= PA_LC / 2) result = -1;\n"
+               "                else {\n"
+               "                    u64 expected = 0ULL;\n"
+               "                    if (__hip_atomic_compare_exchange_strong(&pa_lt_tag[i], &expected, busy, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {\n"
+               "#pragma unroll\n                        for (int w = 0; w < PA_KW; w++) pa_lt_key[i * PA_KW + w] = k[w];\n"
+               "                        __hip_atomic_store(&pa_lt_tag[i], ready, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);\n"
+               "                        __hip_atomic_fetch_add(&pa_lt_count, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);\n"
+               "                        result = (int)i;\n                    }\n                }\n            }\n"
+               "            else if ((t | 2ULL) == ready) {\n"
+               "                if (t == busy) { if (++spins > (1 << 20)) result = -1; }\n"
+               "                else {\n                    bool eq = true;\n#pragma unroll\n"
+               "                    for (int w = 0; w < PA_KW; w++) eq = eq && (pa_lt_key[i * PA_KW + w] == k[w]);\n"
+               "                    if (eq) result = (int)i; else advance = true;\n                }\n            }\n"
+               "            else advance = true;\n"
+               "            if (advance) { i = (i + 1) & (PA_LC - 1); if (++probes >= PA_LC) result = -1; }\n"
+               "        }\n    }\n    return result;\n}\n";
     }
     else {
         src << "struct PaAcc { PaGtCtr gt; };\n";
@@ -457,8 +502,27 @@ KernelInfo generate(const Spec& s, const std::vector<ChannelLayout>& layout, int
         src << "  } else {\n    atomicAdd((unsigned long long*)a.overflow_rows, 1ULL);\n  }\n}\n";
     }
     else {
-        src << "if (sel) {\n  const u32 h = pa_key_hash(key, PA_KW);\n"
-               "  int g = pa_gt_upsert<PA_KW>(a.gt_tag, a.gt_keys, a.gt_mask, h, key, acc.gt, a.gt_max_fill, a.err);\n";
+        src << "if (sel) {\n  const u32 h = pa_key_hash(key, PA_KW);\n";
+        if (variant == V_LDSH) {
+            src << "  const int ls = pa_lt_upsert(h, key);\n  if (ls >= 0) {\n";
+            for (int w = 0; w < k.nw; w++) {
+                std::string idx = "pa_lt_acc[ls * PA_NW + " + std::to_string(w) + "]";
+                if (words[w].kind == W_SUMF) {
+                    src << "    if (u" << w << ") __hip_atomic_fetch_add((double*)&" << idx << ", x" << w << ", __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);\n";
+                }
+                else if (words[w].kind == W_SUMI) {
+                    src << "    if (u" << w << ") { i64 o = (i64)__hip_atomic_fetch_add(&" << idx << ", (u64)x" << w
+                        << ", __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); i64 r; if (__builtin_add_overflow(o, x" << w
+                        << ", &r)) pa_raise(a.err, PA_DEV_ERR_OUT_OF_RANGE); }\n";
+                }
+                else {
+                    src << "    if (u" << w << ") __hip_atomic_fetch_add(&" << idx << ", " << (words[w].val == "1" ? std::string("1ULL") : "(u64)x" + std::to_string(w))
+                        << ", __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);\n";
+                }
+            }
+            src << "  } else {\n  acc.fell++;\n";
+        }
+        src << "  int g = pa_gt_upsert<PA_KW>(a.gt_tag, a.gt_keys, a.gt_mask, h, key, acc.gt, a.gt_max_fill, a.err);\n";
         src << "  if (g >= 0) {\n    const u64 cap = (u64)a.gt_mask + 1ULL;\n";
         for (int w = 0; w < k.nw; w++) {
             std::string idx = std::to_string(w) + "ULL * cap + (u64)g";
@@ -467,7 +531,9 @@ KernelInfo generate(const Spec& s, const std::vector<ChannelLayout>& layout, int
             else src << "    if (u" << w << ") pa_gt_add_u64(a.gt_words, " << idx << ", (u64)x" << w << ");\n";
         }
         // no room for this row's group: spill the row; the host rehashes and replays the spilled rows
-        src << "  } else {\n    a.spill_rows[atomicAdd(a.spill_count, 1u)] = row;\n  }\n}\n";
+        src << "  } else {\n    a.spill_rows[atomicAdd(a.spill_count, 1u)] = row;\n  }\n";
+        if (variant == V_LDSH) src << "  }\n";
+        src << "}\n";
     }
     src << "}\n\n";
 
@@ -489,6 +555,12 @@ KernelInfo generate(const Spec& s, const std::vector<ChannelLayout>& layout, int
             src << "    __syncthreads();\n";
             src << "    PaAcc acc; acc.tcount = 0; acc.lane = threadIdx.x;\n";
             src << "#pragma unroll\n    for (int s = 0; s < PA_C; s++) {\n#pragma unroll\n        for (int w = 0; w < PA_KW; w++) acc.tk[s][w] = 0ULL;\n    }\n";
+        }
+        else if (variant == V_LDSH) {
+            src << "    for (int i = threadIdx.x; i < PA_LC; i += " << B << ") pa_lt_tag[i] = 0ULL;\n";
+            src << "    for (int i = threadIdx.x; i < PA_LC * PA_NW; i += " << B << ") pa_lt_acc[i] = 0ULL;\n";
+            src << "    if (threadIdx.x == 0) pa_lt_count = 0;\n    __syncthreads();\n";
+            src << "    PaAcc acc; acc.gt = pa_gt_ctr_init(a.gt_count, true); acc.flush = pa_gt_ctr_init(a.gt_count, false); acc.fell = 0;\n";
         }
         else {
             src << "    PaAcc acc; acc.gt = pa_gt_ctr_init(a.gt_count, true);\n";
@@ -515,11 +587,28 @@ KernelInfo generate(const Spec& s, const std::vector<ChannelLayout>& layout, int
             src << "    }\n";
             src << "    for (i64 r = (nq << 2) + t; r < a.n; r += T) {\n        pa_row(a, acc, true, (i32)r" << scalar_args(ri, layout) << ");\n    }\n";
         }
-        if (variant == V_GT) {
+        if (variant == V_GT || variant == V_LDSH) {
             src << "    for (i64 i = t; i < a.n_list; i += T) {\n        const i64 r = a.row_list[i];\n        pa_row(a, acc, true, (i32)r" << scalar_args(ri, layout)
                 << ");\n    }\n";
-            src << "    pa_gt_ctr_flush(acc.gt, a.gt_count);\n";
         }
+        if (variant == V_LDSH) {
+            // the workgroup's table -> HBM table: one upsert and PA_NW atomics per group and workgroup
+            src << "    __syncthreads();\n    const u64 cap = (u64)a.gt_mask + 1ULL;\n";
+            src << "    for (int sl = threadIdx.x; sl < PA_LC; sl += " << B << ") {\n        if (pa_lt_tag[sl] == 0ULL) continue;\n"
+                   "        u64 fk[PA_KW];\n#pragma unroll\n        for (int w = 0; w < PA_KW; w++) fk[w] = pa_lt_key[sl * PA_KW + w];\n"
+                   "        const int g = pa_gt_upsert<PA_KW>(a.gt_tag, a.gt_keys, a.gt_mask, pa_key_hash(fk, PA_KW), fk, acc.flush, 0x7fffffff, a.err);\n"
+                   "        if (g < 0) { pa_raise(a.err, PA_DEV_ERR_RESOURCES); continue; }\n";
+            for (int w = 0; w < k.nw; w++) {
+                std::string idx = std::to_string(w) + "ULL * cap + (u64)g";
+                std::string v = "pa_lt_acc[sl * PA_NW + " + std::to_string(w) + "]";
+                if (words[w].kind == W_SUMF) src << "        pa_gt_add_f64(a.gt_words, " << idx << ", __longlong_as_double((i64)" << v << "));\n";
+                else if (words[w].kind == W_SUMI) src << "        pa_gt_add_i64_exact(a.gt_words, " << idx << ", (i64)" << v << ", a.err);\n";
+                else src << "        pa_gt_add_u64(a.gt_words, " << idx << ", " << v << ");\n";
+            }
+            src << "    }\n    pa_gt_ctr_flush(acc.flush, a.gt_count);\n";
+            src << "    { const i64 f = pa_wave_sum_i64(acc.fell); if ((threadIdx.x & 63) == 0 && f != 0) atomicAdd((unsigned long long*)a.overflow_rows, (unsigned long long)f); }\n";
+        }
+        if (variant == V_GT || variant == V_LDSH) src << "    pa_gt_ctr_flush(acc.gt, a.gt_count);\n";
         if (variant == V_GLOBAL) {
             src << "    __shared__ u64 red[" << (B / 64) << " * PA_NW];\n    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;\n";
             for (int w = 0; w < k.nw; w++) {
@@ -583,7 +672,9 @@ public:
     {
         require_device();
         grouped_ = !spec_.group_proj.empty();
-        mode_ = grouped_ ? V_LDS : V_GLOBAL;
+        // the planner's estimate decides where a grouped aggregation starts: the few-groups register/LDS variant (a page
+        // that overflows it is redone on the HBM table), or directly the HBM table when many groups are expected
+        mode_ = grouped_ ? (spec_.expected_groups > (1 << 20) ? V_GT : V_LDS) : V_GLOBAL;
         cus_ = device_cu_count();
         ctl_ = static_cast<int32_t*>(ctl_buf_.ensure(64));  // [0] err  [1] gt_count  [2..3] overflow rows
         PA_HIP(hipMemsetAsync(ctl_, 0, 64, stream_.get()));
@@ -626,9 +717,20 @@ public:
             sig += layout[c].nullable ? 'n' : '-';
         }
         for (;;) {
-            const Compiled& ck = kernel_for(sig, layout, mode_);
+            const Compiled* compiled = nullptr;
+            try {
+                compiled = &kernel_for(sig, layout, mode_);
+            }
+            catch (const Error& e) {
+                if (mode_ != V_LDSH || e.code != PA_ERR_NOT_SUPPORTED) throw;
+                mode_ = V_GT;  // group state too wide for a workgroup's LDS table
+                continue;
+            }
+            const Compiled& ck = *compiled;
             if (run_page(ck, dp, vec)) break;
-            mode_ = V_GT;  // the page held more groups than the register tables: redo it (and every later page) on the HBM table
+            // the page held more groups than the wave's register table: redo it (and every later page) with the
+            // workgroup-level LDS table, which itself hands rows it has no room for to the HBM table
+            mode_ = V_LDSH;
         }
     }
 
@@ -738,7 +840,7 @@ private:
         int64_t offset = 0;
         const int64_t total = dp.n;
         // the HBM-table variant bounds the groups one launch can add so that the table can be sized first
-        const int64_t chunk = ki.variant == V_GT ? (int64_t)1 << 26 : total;
+        const int64_t chunk = (ki.variant == V_GT || ki.variant == V_LDSH) ? (int64_t)1 << 26 : total;
         // LDS variant: head = leading multiple of 256 rows through the vector kernel, tail = the rest through the scalar one
         const int64_t lds_head = (ki.variant == V_LDS && vec) ? (total & ~(int64_t)255) : 0;
         while (offset < total) {
@@ -764,10 +866,15 @@ private:
                 int per_cu = std::max(1, std::min(16, (int)(160 * 1024 / ((size_t)ki.nw * ki.c * 64 * 8 + 512))));
                 grid = (int)std::min<int64_t>((work + 63) / 64, (int64_t)cus_ * per_cu);
             }
+            else if (ki.variant == V_LDSH) {
+                grid = (int)std::min<int64_t>((work + ki.block - 1) / ki.block, (int64_t)cus_ * 2);  // 64 KB of LDS each
+            }
             else {
                 grid = (int)std::min<int64_t>((work + 255) / 256, (int64_t)cus_ * 8);
             }
             grid = std::max(grid, 1);
+            // V_LDSH: every workgroup adds up to lc / 2 groups of its LDS table at the end of the launch, and must find room
+            const uint64_t flush_room = ki.variant == V_LDSH ? (uint64_t)grid * (uint64_t)(ki.lc / 2) : 0;
             if (ki.variant == V_GLOBAL) {
                 a.slab = static_cast<uint64_t*>(slab_.ensure((size_t)grid * ki.nw * 8));
                 if (!state_.ptr()) {
@@ -796,7 +903,7 @@ private:
                 // sized by the groups seen so far, not by the rows: rows whose new group does not fit are spilled and
                 // replayed after a rehash (see below)
                 // (ensure_table doubles its argument: the table is kept at most half full)
-                ensure_table(std::max<uint64_t>({(uint64_t)16384, groups_upper_ + groups_upper_ / 4, (uint64_t)std::max(spec_.expected_groups, 0)}));
+                ensure_table(std::max<uint64_t>({(uint64_t)16384, groups_upper_ + groups_upper_ / 4, (uint64_t)std::max(spec_.expected_groups, 0)}) + flush_room);
                 a.spill_rows = static_cast<int32_t*>(spill_[0].ensure((size_t)n * 4));
                 a.spill_count = reinterpret_cast<uint32_t*>(ctl_ + 6);
                 a.row_list = nullptr;
@@ -806,7 +913,7 @@ private:
             a.gt_keys = gt_keys_.as<uint64_t>();
             a.gt_words = gt_words_.as<uint64_t>();
             a.gt_mask = gt_cap_ ? gt_cap_ - 1 : 0;
-            a.gt_max_fill = ki.variant == V_GT ? (int32_t)(gt_cap_ / 2) : (int32_t)(gt_cap_ - gt_cap_ / 4);
+            a.gt_max_fill = ki.variant == V_LDS ? (int32_t)(gt_cap_ - gt_cap_ / 4) : (int32_t)(gt_cap_ / 2 - flush_room);
             void* params[] = {&a};
             timer.begin(s);
             PA_HIP(hipModuleLaunchKernel(use_tail ? ck.tail_kernel.fn : ck.kernel.fn, grid, 1, 1, ki.block, 1, 1, 0, s, params, nullptr));
@@ -848,9 +955,18 @@ private:
                     raise_if(h_ctl_[0]);
                     groups_upper_ = (uint64_t)h_ctl_[1];
                     const uint32_t spilled = (uint32_t)h_ctl_[6];
+                    if (ki.variant == V_LDSH) {
+                        // rows that found no room in the workgroups' LDS tables: when they are a large part of the
+                        // page, the cardinality is beyond this variant and later pages go to the HBM table directly
+                        uint64_t fell;
+                        memcpy(&fell, h_ctl_ + 2, 8);
+                        if (fell != 0) PA_HIP(hipMemsetAsync(ctl_ + 2, 0, 8, s));
+                        if (fell > (uint64_t)n / 4) mode_ = V_GT;
+                    }
                     if (spilled == 0) break;
                     PA_HIP(hipMemsetAsync(ctl_ + 6, 0, 4, s));
-                    ensure_table(std::max<uint64_t>((uint64_t)gt_cap_ * 2, 2 * (groups_upper_ + spilled)));
+                    // at least twice the slots (ensure_table doubles its argument)
+                    ensure_table(std::max<uint64_t>((uint64_t)gt_cap_ / 2 + 1, groups_upper_ + spilled) + flush_room);
                     FusedArgs r = a;
                     r.n = 0;
                     r.row_list = spill_[cur].as<int32_t>();
@@ -860,9 +976,10 @@ private:
                     r.gt_keys = gt_keys_.as<uint64_t>();
                     r.gt_words = gt_words_.as<uint64_t>();
                     r.gt_mask = gt_cap_ - 1;
-                    r.gt_max_fill = (int32_t)(gt_cap_ / 2);
+                    r.gt_max_fill = (int32_t)(gt_cap_ / 2 - flush_room);
                     void* rparams[] = {&r};
-                    int rgrid = (int)std::max<int64_t>(1, std::min<int64_t>(((int64_t)spilled + 255) / 256, (int64_t)cus_ * 8));
+                    // (never more workgroups than the launch the table was sized for: V_LDSH flushes per workgroup)
+                    int rgrid = (int)std::max<int64_t>(1, std::min<int64_t>(((int64_t)spilled + ki.block - 1) / ki.block, (int64_t)grid));
                     timer.begin(s);
                     PA_HIP(hipModuleLaunchKernel(ck.kernel.fn, rgrid, 1, 1, ki.block, 1, 1, 0, s, rparams, nullptr));
                     timer.end(s);

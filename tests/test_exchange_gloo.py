@@ -186,3 +186,84 @@ def test_partitioned_join_over_two_gloo_ranks(oracle):
     # counts are consistent: what rank r received from s is what s sent to r
     assert sum(results[0][3]) + sum(results[1][3]) == len(build[0])
     assert sum(results[0][4]) + sum(results[1][4]) == len(probe[0])
+
+
+class CollectOperator:
+    """Sink with the Operator protocol: keeps the pages it is given."""
+
+    def __init__(self):
+        self.pages, self._finished = [], False
+
+    def needsInput(self):
+        return not self._finished
+
+    def addInput(self, page):
+        self.pages.append(page)
+
+    def getOutput(self):
+        return None
+
+    def finish(self):
+        self._finished = True
+
+    def isFinished(self):
+        return self._finished
+
+
+def exchange_operator_worker(rank, world, port, result_queue):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from presto_amd import abi
+    from presto_amd.operators import Driver
+    from presto_amd.q3 import ExchangeOperator, page_of, tensor_of
+    keys, vals = exchange_operator_table()
+    # uneven page counts: rank 0 feeds three pages, rank 1 one page -- rank 1 must keep answering rank 0's rounds
+    n = len(keys)
+    bounds = [0, n // 4, n // 2, 3 * n // 4] if rank == 0 else [3 * n // 4, n]
+    if rank == 0:
+        ranges = list(zip(bounds[:-1], bounds[1:]))
+    else:
+        ranges = [(bounds[0], bounds[1])]
+    types = [abi.BIGINT, abi.DOUBLE]
+    pages = [page_of([torch.from_numpy(np.ascontiguousarray(keys[lo:hi])), torch.from_numpy(np.ascontiguousarray(vals[lo:hi]))], types)
+             for lo, hi in ranges]
+    ex = ExchangeOperator(types, [0], None, ops=OracleOps(), device=torch.device("cpu"))
+    sink = CollectOperator()
+    Driver(pages, [ex, sink]).run()
+    cpu = torch.device("cpu")
+    got_keys = np.concatenate([tensor_of(p.blocks[0], cpu).numpy() for p in sink.pages]) if sink.pages else np.zeros(0, np.int64)
+    got_vals = np.concatenate([tensor_of(p.blocks[1], cpu).numpy() for p in sink.pages]) if sink.pages else np.zeros(0)
+    result_queue.put((rank, got_keys.tolist(), got_vals.tolist(), ex.rows_sent, ex.rows_received, len(sink.pages)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def exchange_operator_table():
+    rng = np.random.default_rng(5)
+    return rng.integers(0, 10 ** 6, 4000).astype(np.int64), rng.random(4000)
+
+
+def test_exchange_operator_with_uneven_page_counts(oracle):
+    """ExchangeOperator (the exchange step of the multi-GPU Q3 pipelines): collective rounds stay matched when the
+    ranks feed different numbers of pages; every row arrives exactly once, on the rank its key hashes to."""
+    from presto_amd.page import Block, Page
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=exchange_operator_worker, args=(r, world, port, q)) for r in range(world)]
+    [p.start() for p in procs]
+    results = sorted(q.get(timeout=120) for _ in range(world))
+    [p.join(timeout=60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    keys, vals = exchange_operator_table()
+    h = oracle.hash_page(Page([Block.bigint(keys)], len(keys)), [0])
+    part = oracle.partition_ids(h, world, local=True)
+    for rank, got_keys, got_vals, sent, received, pages in results:
+        mine = part == rank
+        assert sorted(zip(got_keys, got_vals)) == sorted(zip(keys[mine].tolist(), vals[mine].tolist()))
+        assert received == int(mine.sum())
+        assert pages == 3  # one output page per collective round (rank 0 fed three pages)
+    assert results[0][3] == 3000 and results[1][3] == 1000

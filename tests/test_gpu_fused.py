@@ -194,3 +194,32 @@ def test_new_groups_in_partial_waves(gpu, oracle, n):
     for p in pages:
         ref.add_page(p)
     rows_equal_ignore_order(rows, ref.build_result().to_rows(), rel=1e-12)
+
+
+@pytest.mark.parametrize("groups,pages,rows", [(9, 2, 5000), (64, 3, 70001), (700, 2, 200003), (3000, 3, 150001), (50000, 2, 300007)])
+def test_hash_aggregation_across_cardinalities(gpu, oracle, groups, pages, rows):
+    """Every tier of the grouped aggregation against the oracle: the wave-register table (<= 8 groups), the workgroup's
+    LDS table (tens to ~1000 groups; rows beyond its capacity go to the HBM table), the HBM table.  Nullable key and
+    value, a second key column, a mask channel; BIGINT sums and counts bit-exact, DOUBLE within 1e-9."""
+    rng = np.random.default_rng(groups)
+    plist = []
+    for p in range(pages):
+        k1 = rng.integers(0, groups, rows).astype(np.int64) * 1000003 - 17
+        k1_null = rng.random(rows) < 0.01
+        k2 = (k1 % 3).astype(np.int32)
+        v = rng.random(rows) * 100 - 50
+        v_null = rng.random(rows) < 0.05
+        b = rng.integers(-1000, 1000, rows).astype(np.int64)
+        m = rng.random(rows) < 0.7
+        plist.append(Page([Block.bigint(k1, k1_null), Block.integer(k2), Block.double(v, v_null), Block.bigint(b), Block.boolean(m)], rows))
+    types = [abi.BIGINT, abi.INTEGER, abi.DOUBLE, abi.BIGINT, abi.BOOLEAN]
+    aggs = [(abi.AGG_SUM, 2, abi.DOUBLE), (abi.AGG_AVG, 2, abi.DOUBLE), (abi.AGG_COUNT, 2, abi.DOUBLE), (abi.AGG_SUM, 3, abi.BIGINT),
+            (abi.AGG_COUNT_STAR, -1, None), (abi.AGG_SUM, 3, abi.BIGINT, 4)]
+    op = HashAggregationOperator(types, [0, 1], aggs)
+    got = [r for p in to_pages(op, plist) for r in p.to_rows()]
+    ref = oracle.HashAggregation(types, [0, 1], aggs)
+    for p in plist:
+        ref.add_page(p)
+    expected = ref.build_result().to_rows()
+    assert len(expected) >= min(groups, 9)
+    rows_equal_ignore_order(got, expected, rel=1e-9)
