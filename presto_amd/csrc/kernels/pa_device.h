@@ -289,7 +289,33 @@ struct PaFusedArgs {
     i64 n_list;
     i32* spill_rows;                  // GT variant: rows whose group did not fit the table (redone after a rehash)
     u32* spill_count;
+    // Replicas of the group table: workgroup b works on replica b & gt_rep_mask (each a full table of gt_mask + 1 slots,
+    // laid out one after the other in gt_tag / gt_keys / gt_words).  Atomics of many rows on few addresses retire at
+    // ~0.15 M/s per address on this part; R replicas divide the pressure per address by R.  The host folds the
+    // replicas into one table before the result is read.
+    u32 gt_rep_mask;
+    u32 pad2;
+    i32* gt_rep_count;                // groups of replica r >= 1 at [r]; replica 0 counts in gt_count
 };
+
+// the replica of the group table this workgroup works on
+struct PaGtView {
+    u64* tag;
+    u64* keys;
+    u64* words;
+    i32* count;
+};
+__device__ __forceinline__ PaGtView pa_gt_view(const PaFusedArgs& a, const int W, const int NW)
+{
+    const u32 r = blockIdx.x & a.gt_rep_mask;
+    const u64 cap = (u64)a.gt_mask + 1ULL;
+    PaGtView v;
+    v.tag = a.gt_tag + (u64)r * cap;
+    v.keys = a.gt_keys + (u64)r * cap * (u64)W;
+    v.words = a.gt_words + (u64)r * cap * (u64)NW;
+    v.count = r ? a.gt_rep_count + r : a.gt_count;
+    return v;
+}
 
 // 64-bit value of lane `lane` (wave-uniform) broadcast to the wave
 __device__ __forceinline__ u64 pa_readlane_u64(u64 v, int lane)
@@ -332,11 +358,11 @@ struct PaGtCtr {
 };
 // spilling = true: the caller can spill a row that finds no room (fill estimate and probe bound apply);
 // false: the host sized the table for everything the kernel inserts (merge, rehash): only a full table fails.
-__device__ __forceinline__ PaGtCtr pa_gt_ctr_init(const i32* count, bool spilling)
+__device__ __forceinline__ PaGtCtr pa_gt_ctr_init(const i32* count, bool spilling, u32 replicas = 1)
 {
     PaGtCtr c;
     c.base = *count;
-    c.scale = spilling ? (i32)(gridDim.x * (blockDim.x >> 6)) : 0;
+    c.scale = spilling ? (i32)((gridDim.x * (blockDim.x >> 6) + replicas - 1) / replicas) : 0;  // waves working on this table
     c.seen = 0;
     c.mine = 0;
     c.max_probes = spilling ? 512u : 0xffffffffu;

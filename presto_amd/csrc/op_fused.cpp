@@ -37,9 +37,9 @@ void launch_merge_global_slab(const uint64_t* slab, int blocks, int nw, const in
 void launch_merge_lds_slab(const uint64_t* slab, int waves, int c, int w, int nw, const int32_t* kinds_dev, uint64_t* gt_tag,
                            uint64_t* gt_keys, uint64_t* gt_words, uint32_t gt_mask, int32_t gt_max_fill, int32_t* gt_count,
                            int32_t* err, const uint64_t* overflow_rows, int32_t* entry_slot, hipStream_t s);
-void launch_gt_rehash(const uint64_t* old_tag, const uint64_t* old_keys, const uint64_t* old_words, uint32_t old_cap, int w, int nw,
-                      uint64_t* tag, uint64_t* keys, uint64_t* words, uint32_t mask, int32_t max_fill, int32_t* count, int32_t* err,
-                      hipStream_t s);
+void launch_gt_fold(const uint64_t* old_tag, const uint64_t* old_keys, const uint64_t* old_words, uint32_t old_cap, uint32_t old_reps, int w,
+                    int nw, const int32_t* kinds_dev, uint64_t* tag, uint64_t* keys, uint64_t* words, uint32_t mask, uint32_t new_reps,
+                    int32_t* count0, int32_t* rep_count, int32_t* err, hipStream_t s);
 
 void launch_gt_compact(const uint64_t* tag, const uint64_t* keys, const uint64_t* words, uint32_t cap, int w, int nw, uint64_t* out_keys,
                        uint64_t* out_words, uint32_t* counter, hipStream_t s);
@@ -69,6 +69,9 @@ struct FusedArgs {
     int64_t n_list;
     int32_t* spill_rows;
     uint32_t* spill_count;
+    uint32_t gt_rep_mask;
+    uint32_t pad2;
+    int32_t* gt_rep_count;
 };
 
 enum Variant { V_GLOBAL = 0, V_LDS = 1, V_GT = 2, V_LDSH = 3 };
@@ -421,7 +424,7 @@ KernelInfo generate(const Spec& s, const std::vector<ChannelLayout>& layout, int
         src << "#define PA_LC " << k.lc << "\n";
         src << "__shared__ u64 pa_lt_tag[PA_LC];\n__shared__ u64 pa_lt_key[PA_LC * PA_KW];\n__shared__ u64 pa_lt_acc[PA_LC * PA_NW];\n"
                "__shared__ i32 pa_lt_count;\n";
-        src << "struct PaAcc { PaGtCtr gt; PaGtCtr flush; i64 fell; };\n";
+        src << "struct PaAcc { PaGtView tv; PaGtCtr gt; PaGtCtr flush; i64 fell; };\n";
         // same claim / publish protocol as pa_gt_upsert_n, on LDS: tag 0 -> busy -> ready, wave-uniform loop so that a
         // lane waiting for a slot another lane of its wave is publishing cannot starve it
         src << "__device__ __forceinline__ int pa_lt_upsert(const u32 h, const u64 (&k)[PA_KW])\n{\n"
@@ -449,7 +452,7 @@ KernelInfo generate(const Spec& s, const std::vector<ChannelLayout>& layout, int
                "        }\n    }\n    return result;\n}\n";
     }
     else {
-        src << "struct PaAcc { PaGtCtr gt; };\n";
+        src << "struct PaAcc { PaGtView tv; PaGtCtr gt; };\n";
     }
     src << "__device__ __forceinline__ void pa_row(const PaFusedArgs& a, PaAcc& acc, const bool live, const i32 row" << row_params(ri, layout) << ")\n{\n";
     src << body.str();
@@ -522,13 +525,13 @@ KernelInfo generate(const Spec& s, const std::vector<ChannelLayout>& layout, int
             }
             src << "  } else {\n  acc.fell++;\n";
         }
-        src << "  int g = pa_gt_upsert<PA_KW>(a.gt_tag, a.gt_keys, a.gt_mask, h, key, acc.gt, a.gt_max_fill, a.err);\n";
+        src << "  int g = pa_gt_upsert<PA_KW>(acc.tv.tag, acc.tv.keys, a.gt_mask, h, key, acc.gt, a.gt_max_fill, a.err);\n";
         src << "  if (g >= 0) {\n    const u64 cap = (u64)a.gt_mask + 1ULL;\n";
         for (int w = 0; w < k.nw; w++) {
             std::string idx = std::to_string(w) + "ULL * cap + (u64)g";
-            if (words[w].kind == W_SUMF) src << "    if (u" << w << ") pa_gt_add_f64(a.gt_words, " << idx << ", x" << w << ");\n";
-            else if (words[w].kind == W_SUMI) src << "    if (u" << w << ") pa_gt_add_i64_exact(a.gt_words, " << idx << ", x" << w << ", a.err);\n";
-            else src << "    if (u" << w << ") pa_gt_add_u64(a.gt_words, " << idx << ", (u64)x" << w << ");\n";
+            if (words[w].kind == W_SUMF) src << "    if (u" << w << ") pa_gt_add_f64(acc.tv.words, " << idx << ", x" << w << ");\n";
+            else if (words[w].kind == W_SUMI) src << "    if (u" << w << ") pa_gt_add_i64_exact(acc.tv.words, " << idx << ", x" << w << ", a.err);\n";
+            else src << "    if (u" << w << ") pa_gt_add_u64(acc.tv.words, " << idx << ", (u64)x" << w << ");\n";
         }
         // no room for this row's group: spill the row; the host rehashes and replays the spilled rows
         src << "  } else {\n    a.spill_rows[atomicAdd(a.spill_count, 1u)] = row;\n  }\n";
@@ -560,10 +563,11 @@ KernelInfo generate(const Spec& s, const std::vector<ChannelLayout>& layout, int
             src << "    for (int i = threadIdx.x; i < PA_LC; i += " << B << ") pa_lt_tag[i] = 0ULL;\n";
             src << "    for (int i = threadIdx.x; i < PA_LC * PA_NW; i += " << B << ") pa_lt_acc[i] = 0ULL;\n";
             src << "    if (threadIdx.x == 0) pa_lt_count = 0;\n    __syncthreads();\n";
-            src << "    PaAcc acc; acc.gt = pa_gt_ctr_init(a.gt_count, true); acc.flush = pa_gt_ctr_init(a.gt_count, false); acc.fell = 0;\n";
+            src << "    PaAcc acc; acc.tv = pa_gt_view(a, PA_KW, PA_NW); acc.gt = pa_gt_ctr_init(acc.tv.count, true, a.gt_rep_mask + 1u);\n"
+                   "    acc.flush = pa_gt_ctr_init(acc.tv.count, false); acc.fell = 0;\n";
         }
         else {
-            src << "    PaAcc acc; acc.gt = pa_gt_ctr_init(a.gt_count, true);\n";
+            src << "    PaAcc acc; acc.tv = pa_gt_view(a, PA_KW, PA_NW); acc.gt = pa_gt_ctr_init(acc.tv.count, true, a.gt_rep_mask + 1u);\n";
         }
         if (mode != 2) emit_prologue(ri, layout, src);
         src << "    const i64 t = (i64)blockIdx.x * " << B << " + threadIdx.x, T = (i64)gridDim.x * " << B << ";\n";
@@ -596,19 +600,19 @@ KernelInfo generate(const Spec& s, const std::vector<ChannelLayout>& layout, int
             src << "    __syncthreads();\n    const u64 cap = (u64)a.gt_mask + 1ULL;\n";
             src << "    for (int sl = threadIdx.x; sl < PA_LC; sl += " << B << ") {\n        if (pa_lt_tag[sl] == 0ULL) continue;\n"
                    "        u64 fk[PA_KW];\n#pragma unroll\n        for (int w = 0; w < PA_KW; w++) fk[w] = pa_lt_key[sl * PA_KW + w];\n"
-                   "        const int g = pa_gt_upsert<PA_KW>(a.gt_tag, a.gt_keys, a.gt_mask, pa_key_hash(fk, PA_KW), fk, acc.flush, 0x7fffffff, a.err);\n"
+                   "        const int g = pa_gt_upsert<PA_KW>(acc.tv.tag, acc.tv.keys, a.gt_mask, pa_key_hash(fk, PA_KW), fk, acc.flush, 0x7fffffff, a.err);\n"
                    "        if (g < 0) { pa_raise(a.err, PA_DEV_ERR_RESOURCES); continue; }\n";
             for (int w = 0; w < k.nw; w++) {
                 std::string idx = std::to_string(w) + "ULL * cap + (u64)g";
                 std::string v = "pa_lt_acc[sl * PA_NW + " + std::to_string(w) + "]";
-                if (words[w].kind == W_SUMF) src << "        pa_gt_add_f64(a.gt_words, " << idx << ", __longlong_as_double((i64)" << v << "));\n";
-                else if (words[w].kind == W_SUMI) src << "        pa_gt_add_i64_exact(a.gt_words, " << idx << ", (i64)" << v << ", a.err);\n";
-                else src << "        pa_gt_add_u64(a.gt_words, " << idx << ", " << v << ");\n";
+                if (words[w].kind == W_SUMF) src << "        pa_gt_add_f64(acc.tv.words, " << idx << ", __longlong_as_double((i64)" << v << "));\n";
+                else if (words[w].kind == W_SUMI) src << "        pa_gt_add_i64_exact(acc.tv.words, " << idx << ", (i64)" << v << ", a.err);\n";
+                else src << "        pa_gt_add_u64(acc.tv.words, " << idx << ", " << v << ");\n";
             }
-            src << "    }\n    pa_gt_ctr_flush(acc.flush, a.gt_count);\n";
+            src << "    }\n    pa_gt_ctr_flush(acc.flush, acc.tv.count);\n";
             src << "    { const i64 f = pa_wave_sum_i64(acc.fell); if ((threadIdx.x & 63) == 0 && f != 0) atomicAdd((unsigned long long*)a.overflow_rows, (unsigned long long)f); }\n";
         }
-        if (variant == V_GT || variant == V_LDSH) src << "    pa_gt_ctr_flush(acc.gt, a.gt_count);\n";
+        if (variant == V_GT || variant == V_LDSH) src << "    pa_gt_ctr_flush(acc.gt, acc.tv.count);\n";
         if (variant == V_GLOBAL) {
             src << "    __shared__ u64 red[" << (B / 64) << " * PA_NW];\n    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;\n";
             for (int w = 0; w < k.nw; w++) {
@@ -773,6 +777,7 @@ private:
         c->kinds.ensure(sizeof(int32_t) * c->info.word_kind.size());
         PA_HIP(hipMemcpyAsync(c->kinds.ptr(), c->info.word_kind.data(), sizeof(int32_t) * c->info.word_kind.size(), hipMemcpyHostToDevice, stream_.get()));
         PA_HIP(hipStreamSynchronize(stream_.get()));
+        if (!kinds_dev_) kinds_dev_ = c->kinds.as<int32_t>();
         if (!layout_fixed_) {
             nw_ = c->info.nw;
             w_ = c->info.w;
@@ -787,31 +792,70 @@ private:
         return ref;
     }
 
-    // makes room for at least min_groups groups at a load factor of one half
-    void ensure_table(uint64_t min_groups)
+    // replicas wanted for a table of g groups: enough distinct accumulator addresses (>= ~2^17) for the atomics of a
+    // launch not to queue on a few of them; none needed once the groups themselves are that many
+    static uint32_t desired_replicas(uint64_t g)
     {
+        uint64_t r = (1ULL << 17) / std::max<uint64_t>(g, 1);
+        uint32_t p = 1;
+        while (p * 2 <= r && p < 128) p <<= 1;
+        return p;
+    }
+
+    // makes room for at least min_groups groups per replica at a load factor of one half; reps = 0 keeps the replica count
+    void ensure_table(uint64_t min_groups, uint32_t reps = 0)
+    {
+        if (reps == 0) reps = gt_rep_;
+        if (reps < gt_rep_) min_groups = std::max(min_groups, groups_sum_);  // replicas fold into fewer tables
         uint64_t want = std::max<uint64_t>(1024, 2 * min_groups);
         PA_REQUIRE(want <= (1ULL << 30), PA_ERR_INSUFFICIENT_RESOURCES, "Size of hash table cannot exceed 1 billion entries");
-        uint32_t cap = next_pow2(want);
-        if (cap <= gt_cap_) return;
+        uint32_t cap = std::max(next_pow2(want), gt_cap_);
+        const size_t slot_bytes = 8 * (size_t)(1 + std::max(w_, 1) + nw_);
+        while (reps > 1 && (size_t)reps * cap * slot_bytes > (8ULL << 30)) reps >>= 1;
+        if (cap == gt_cap_ && reps == gt_rep_) return;
         hipStream_t s = stream_.get();
         drain_merges();  // in-flight merges still write the old table
-        DevBuf tag, keys, words;
-        tag.ensure((size_t)cap * 8);
-        keys.ensure((size_t)cap * 8 * std::max(w_, 1));
-        words.ensure((size_t)cap * 8 * nw_);
-        PA_HIP(hipMemsetAsync(tag.ptr(), 0, (size_t)cap * 8, s));
-        PA_HIP(hipMemsetAsync(words.ptr(), 0, (size_t)cap * 8 * nw_, s));
+        DevBuf tag, keys, words, rc;
+        const size_t slots = (size_t)reps * cap;
+        tag.ensure(slots * 8);
+        keys.ensure(slots * 8 * std::max(w_, 1));
+        words.ensure(slots * 8 * nw_);
+        rc.ensure(128 * 4);
+        PA_HIP(hipMemsetAsync(tag.ptr(), 0, slots * 8, s));
+        PA_HIP(hipMemsetAsync(words.ptr(), 0, slots * 8 * nw_, s));
+        PA_HIP(hipMemsetAsync(rc.ptr(), 0, 128 * 4, s));
         if (gt_cap_ > 0) {
+            PA_REQUIRE(kinds_dev_ != nullptr, PA_ERR_ILLEGAL_STATE, "group table without a compiled kernel");
             PA_HIP(hipMemsetAsync(ctl_ + 1, 0, 4, s));
-            launch_gt_rehash(gt_tag_.as<uint64_t>(), gt_keys_.as<uint64_t>(), gt_words_.as<uint64_t>(), gt_cap_, std::max(w_, 1), nw_,
-                             tag.as<uint64_t>(), keys.as<uint64_t>(), words.as<uint64_t>(), cap - 1, (int32_t)(cap - cap / 4), ctl_ + 1, ctl_, s);
+            launch_gt_fold(gt_tag_.as<uint64_t>(), gt_keys_.as<uint64_t>(), gt_words_.as<uint64_t>(), gt_cap_, gt_rep_, std::max(w_, 1), nw_,
+                           kinds_dev_, tag.as<uint64_t>(), keys.as<uint64_t>(), words.as<uint64_t>(), cap - 1, reps, ctl_ + 1,
+                           rc.as<int32_t>(), ctl_, s);
             PA_HIP(hipStreamSynchronize(s));  // the old arrays return to the pool below
         }
         gt_tag_ = std::move(tag);
         gt_keys_ = std::move(keys);
         gt_words_ = std::move(words);
+        rep_count_ = std::move(rc);
         gt_cap_ = cap;
+        gt_rep_ = reps;
+    }
+
+    // group counts of all replicas after a launch: groups_upper_ = the fullest replica (what every replica must have
+    // room for), groups_sum_ = upper bound of the distinct groups
+    void read_group_counts(hipStream_t s)
+    {
+        int32_t* h = static_cast<int32_t*>(h_rep_.ensure(128 * 4));
+        h[0] = 0;
+        if (gt_rep_ > 1) PA_HIP(hipMemcpyAsync(h, rep_count_.ptr(), (size_t)gt_rep_ * 4, hipMemcpyDeviceToHost, s));
+        PA_HIP(hipMemcpyAsync(h_ctl_, ctl_, 32, hipMemcpyDeviceToHost, s));
+        PA_HIP(hipStreamSynchronize(s));
+        uint64_t mx = (uint64_t)h_ctl_[1], sum = (uint64_t)h_ctl_[1];
+        for (uint32_t r = 1; r < gt_rep_; r++) {
+            mx = std::max<uint64_t>(mx, (uint64_t)h[r]);
+            sum += (uint64_t)h[r];
+        }
+        groups_upper_ = mx;
+        groups_sum_ = sum;
     }
 
     void drain_merges()
@@ -845,6 +889,9 @@ private:
         const int64_t lds_head = (ki.variant == V_LDS && vec) ? (total & ~(int64_t)255) : 0;
         while (offset < total) {
             int64_t n = std::min(chunk, total - offset);
+            // the first launch on the HBM table is a short one: it tells how many groups there are, which decides the
+            // number of table replicas for the rest
+            if ((ki.variant == V_GT || ki.variant == V_LDSH) && !gt_probed_) n = std::min<int64_t>(n, (int64_t)1 << 22);
             bool use_tail = false;
             if (ki.variant == V_LDS) {
                 if (offset < lds_head) n = lds_head - offset;
@@ -874,7 +921,15 @@ private:
             }
             grid = std::max(grid, 1);
             // V_LDSH: every workgroup adds up to lc / 2 groups of its LDS table at the end of the launch, and must find room
-            const uint64_t flush_room = ki.variant == V_LDSH ? (uint64_t)grid * (uint64_t)(ki.lc / 2) : 0;
+            uint32_t reps = 1;
+            if (ki.variant == V_GT || ki.variant == V_LDSH) {
+                const uint32_t want = desired_replicas(gt_probed_ ? groups_upper_ : std::max<uint64_t>(groups_upper_, (uint64_t)std::max(spec_.expected_groups, 1)));
+                // change the layout only when it pays: much more replication needed, or far too much held
+                reps = (want >= 2 * gt_rep_ || want * 4 <= gt_rep_) ? want : gt_rep_;
+                reps = std::min<uint32_t>(reps, next_pow2((uint64_t)grid));
+            }
+            auto room_for_flush = [&](uint32_t r) { return ki.variant == V_LDSH ? (uint64_t)((grid + r - 1) / r) * (uint64_t)(ki.lc / 2) : (uint64_t)0; };
+            uint64_t flush_room = room_for_flush(reps);
             if (ki.variant == V_GLOBAL) {
                 a.slab = static_cast<uint64_t*>(slab_.ensure((size_t)grid * ki.nw * 8));
                 if (!state_.ptr()) {
@@ -903,7 +958,12 @@ private:
                 // sized by the groups seen so far, not by the rows: rows whose new group does not fit are spilled and
                 // replayed after a rehash (see below)
                 // (ensure_table doubles its argument: the table is kept at most half full)
-                ensure_table(std::max<uint64_t>({(uint64_t)16384, groups_upper_ + groups_upper_ / 4, (uint64_t)std::max(spec_.expected_groups, 0)}) + flush_room);
+                const uint64_t expected = (uint64_t)std::max(spec_.expected_groups, 0);
+                ensure_table(std::max<uint64_t>({(uint64_t)16384 / reps, groups_upper_ + groups_upper_ / 4, expected}) + flush_room, reps);
+                if (gt_rep_ != reps) {  // the memory bound reduced the replicas
+                    flush_room = room_for_flush(gt_rep_);
+                    ensure_table(std::max<uint64_t>({(uint64_t)16384 / gt_rep_, groups_upper_ + groups_upper_ / 4, expected}) + flush_room);
+                }
                 a.spill_rows = static_cast<int32_t*>(spill_[0].ensure((size_t)n * 4));
                 a.spill_count = reinterpret_cast<uint32_t*>(ctl_ + 6);
                 a.row_list = nullptr;
@@ -914,6 +974,8 @@ private:
             a.gt_words = gt_words_.as<uint64_t>();
             a.gt_mask = gt_cap_ ? gt_cap_ - 1 : 0;
             a.gt_max_fill = ki.variant == V_LDS ? (int32_t)(gt_cap_ - gt_cap_ / 4) : (int32_t)(gt_cap_ / 2 - flush_room);
+            a.gt_rep_mask = (ki.variant == V_GT || ki.variant == V_LDSH) ? gt_rep_ - 1 : 0;
+            a.gt_rep_count = rep_count_.as<int32_t>();
             void* params[] = {&a};
             timer.begin(s);
             PA_HIP(hipModuleLaunchKernel(use_tail ? ck.tail_kernel.fn : ck.kernel.fn, grid, 1, 1, ki.block, 1, 1, 0, s, params, nullptr));
@@ -950,10 +1012,9 @@ private:
                 // replay loop: grow the table until every row of the launch found room for its group
                 int cur = 0;
                 for (;;) {
-                    PA_HIP(hipMemcpyAsync(h_ctl_, ctl_, 32, hipMemcpyDeviceToHost, s));
-                    PA_HIP(hipStreamSynchronize(s));
+                    read_group_counts(s);
                     raise_if(h_ctl_[0]);
-                    groups_upper_ = (uint64_t)h_ctl_[1];
+                    gt_probed_ = true;
                     const uint32_t spilled = (uint32_t)h_ctl_[6];
                     if (ki.variant == V_LDSH) {
                         // rows that found no room in the workgroups' LDS tables: when they are a large part of the
@@ -1018,7 +1079,12 @@ private:
     int32_t* h_ctl_ = nullptr;
     DevBuf slab_, state_, gt_tag_, gt_keys_, gt_words_;
     // LDS variant: the merge of page k runs on a second stream while the fused kernel of page k+1 streams
-    DevBuf lds_slab_[2], entry_slot_[2], spill_[2], dense_keys_, dense_words_, null_flags_;
+    DevBuf lds_slab_[2], entry_slot_[2], spill_[2], dense_keys_, dense_words_, null_flags_, rep_count_;
+    PinnedBuf h_rep_;
+    uint32_t gt_rep_ = 1;
+    uint64_t groups_sum_ = 0;
+    bool gt_probed_ = false;
+    const int32_t* kinds_dev_ = nullptr;
     hipStream_t merge_stream_ = nullptr;
     hipEvent_t ev_main_[2] = {nullptr, nullptr}, ev_merge_[2] = {nullptr, nullptr};
     bool merge_pending_[2] = {false, false};
@@ -1157,6 +1223,14 @@ void FusedAggregationOperator::build_output()
         if (state_.ptr()) PA_HIP(hipMemcpy(words.data(), state_.ptr(), (size_t)nw_ * 8, hipMemcpyDeviceToHost));
     }
     else if (gt_cap_ > 0) {
+        if (gt_rep_ > 1) {
+            // fold the replicas into one table: states of one key combine with the aggregates' combine functions
+            read_group_counts(s);
+            ensure_table(groups_sum_, 1);
+            PA_HIP(hipMemcpyAsync(h_ctl_, ctl_, 32, hipMemcpyDeviceToHost, s));
+            PA_HIP(hipStreamSynchronize(s));
+            raise_if(h_ctl_[0]);
+        }
         groups = h_ctl_[1];
         if (emit_on_device(ki, groups)) return;
         if (groups > 0) {

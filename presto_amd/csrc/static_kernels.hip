@@ -234,35 +234,54 @@ void launch_merge_lds_slab(const uint64_t* slab, int waves, int c, int w, int nw
     PA_HIP(hipGetLastError());
 }
 
-// re-insert every group of the old table into a larger one (GroupByHash.tryRehash counterpart)
-__global__ __launch_bounds__(256) void k_gt_rehash(const u64* __restrict__ old_tag, const u64* __restrict__ old_keys,
-                                                   const u64* __restrict__ old_words, u32 old_cap, int W, int NW, u64* tag, u64* keys,
-                                                   u64* words, u32 mask, i32 max_fill, i32* count, i32* err)
+// Re-insert every group of the old table(s) into new ones (GroupByHash.tryRehash counterpart), folding replicas:
+// blockIdx.y = old replica r, its groups go to new replica r & new_rep_mask; states of one key arriving from several old
+// replicas are combined with the aggregates' combine functions (adds), so the same kernel grows a table, changes the
+// number of replicas and folds all replicas into one before the result is read.
+__global__ __launch_bounds__(256) void k_gt_fold(const u64* __restrict__ old_tag, const u64* __restrict__ old_keys,
+                                                 const u64* __restrict__ old_words, u32 old_cap, int W, int NW, const i32* __restrict__ kinds,
+                                                 u64* tag, u64* keys, u64* words, u32 mask, u32 new_rep_mask, i32* count0, i32* rep_count,
+                                                 i32* err)
 {
+    const u64 cap = (u64)mask + 1ULL;
+    const u32 r_old = blockIdx.y, r_new = r_old & new_rep_mask;
+    old_tag += (u64)r_old * old_cap;
+    old_keys += (u64)r_old * old_cap * (u64)W;
+    old_words += (u64)r_old * old_cap * (u64)NW;
+    tag += (u64)r_new * cap;
+    keys += (u64)r_new * cap * (u64)W;
+    words += (u64)r_new * cap * (u64)NW;
+    i32* count = r_new ? rep_count + r_new : count0;
     PaGtCtr ctr = pa_gt_ctr_init(count, false);
     for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < (i64)old_cap; i += (i64)gridDim.x * 256) {
         if (old_tag[i] == 0ULL) continue;
         u64 k[8];
         for (int w = 0; w < W; w++) k[w] = old_keys[(u64)i * W + w];
         u32 h = pa_key_hash(k, W);
-        int g = pa_gt_upsert_n(tag, keys, mask, h, k, W, ctr, max_fill, err);
+        int g = pa_gt_upsert_n(tag, keys, mask, h, k, W, ctr, 0x7fffffff, err);
         if (g < 0) {
-            pa_raise(err, PA_DEV_ERR_RESOURCES);  // cannot happen: the new table is larger than the old one
+            pa_raise(err, PA_DEV_ERR_RESOURCES);  // cannot happen: the host sized the new tables for all groups
             continue;
         }
-        const u64 cap = (u64)mask + 1ULL;
-        // each old group maps to exactly one new slot, so plain stores suffice
-        for (int w = 0; w < NW; w++) words[(u64)w * cap + g] = old_words[(u64)w * old_cap + i];
+        for (int w = 0; w < NW; w++) {
+            const u64 v = old_words[(u64)w * old_cap + i];
+            const u64 idx = (u64)w * cap + (u64)g;
+            const int kind = kinds[w];
+            if (kind == PA_W_SUMF) pa_gt_add_f64(words, idx, __longlong_as_double((i64)v));
+            else if (kind == PA_W_SUMI) pa_gt_add_i64_exact(words, idx, (i64)v, err);
+            else pa_gt_add_u64(words, idx, v);
+        }
     }
     pa_gt_ctr_flush(ctr, count);
 }
 
-void launch_gt_rehash(const uint64_t* old_tag, const uint64_t* old_keys, const uint64_t* old_words, uint32_t old_cap, int w, int nw,
-                      uint64_t* tag, uint64_t* keys, uint64_t* words, uint32_t mask, int32_t max_fill, int32_t* count, int32_t* err,
-                      hipStream_t s)
+void launch_gt_fold(const uint64_t* old_tag, const uint64_t* old_keys, const uint64_t* old_words, uint32_t old_cap, uint32_t old_reps, int w,
+                    int nw, const int32_t* kinds_dev, uint64_t* tag, uint64_t* keys, uint64_t* words, uint32_t mask, uint32_t new_reps,
+                    int32_t* count0, int32_t* rep_count, int32_t* err, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_gt_rehash, grid_for(old_cap, 256), 256, 0, s, (const u64*)old_tag, (const u64*)old_keys, (const u64*)old_words,
-                       old_cap, w, nw, (u64*)tag, (u64*)keys, (u64*)words, mask, max_fill, count, err);
+    dim3 grid((unsigned)std::max(1, std::min(grid_for(old_cap, 256), 2048 / (int)std::max(1u, std::min(old_reps, 8u)))), old_reps, 1);
+    hipLaunchKernelGGL(k_gt_fold, grid, dim3(256, 1, 1), 0, s, (const u64*)old_tag, (const u64*)old_keys, (const u64*)old_words, old_cap, w, nw,
+                       kinds_dev, (u64*)tag, (u64*)keys, (u64*)words, mask, new_reps - 1, count0, rep_count, err);
     PA_HIP(hipGetLastError());
 }
 
