@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PA_ABI_VERSION 1
+#define PA_ABI_VERSION 2
 
 /* ---- status codes (negative = error).  Mapped by the JNI shim onto TrinoException
  *      StandardErrorCode (trino-spi/.../StandardErrorCode.java). ---- */
@@ -167,6 +167,14 @@ typedef struct pa_filter_project_desc {
     const pa_expr* projections;
     int32_t output_mem;                  /* pa_mem of pages returned by get_output */
     void* stream;                        /* hipStream_t to launch on; NULL = library-owned stream */
+    /* MergePages behind the PageProcessor (FilterAndProjectOperator.java:60-66, MergePages.java:112-172): an output
+     * page with fewer than min_output_page_rows rows AND fewer than min_output_page_bytes bytes (Block.getSizeInBytes
+     * accounting: value width + 1 per position, VARCHAR bytes + 5 per position) is buffered and emitted merged once the
+     * buffer reaches max_output_page_bytes (0 = PageBuilderStatus.DEFAULT_MAX_PAGE_SIZE_IN_BYTES, 1 MiB), a big page
+     * arrives, or the input ends.  Both thresholds 0 = pass every page through (the reference's tests). */
+    int64_t min_output_page_bytes;
+    int32_t min_output_page_rows;
+    int32_t max_output_page_bytes;
 } pa_filter_project_desc;
 
 /* Intermediate states of Step.PARTIAL / Step.FINAL (AggregationNode.Step): the reference serialises LongState /

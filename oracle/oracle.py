@@ -368,3 +368,71 @@ def q1(columns, chunks=1):
     n = len(columns[8])
     _check(lib().orc_q1_add(agg._h, *[c.ctypes.data for c in columns], n))
     return agg.build_result().to_rows()
+
+
+# ---- MergePages ---------------------------------------------------------------------------------------------------
+def block_size_in_bytes(block):
+    """Block.getSizeInBytes of the flat block kinds: LongArrayBlock / IntArrayBlock / ByteArrayBlock
+    (core/trino-spi/src/main/java/io/trino/spi/block/LongArrayBlock.java:55-57: (value width + 1) * positions) and
+    VariableWidthBlock (VariableWidthBlock.java:66-68: bytes + (4 + 1) * positions)."""
+    from presto_amd import abi
+    n = block.position_count
+    if block.type == abi.VARCHAR:
+        off = block.offsets
+        return int(off[n]) - int(off[0]) + 5 * n
+    return (abi.TYPE_WIDTH[block.type] + 1) * n
+
+
+def page_size_in_bytes(page):
+    return sum(block_size_in_bytes(b) for b in page.blocks)
+
+
+def concat_pages(pages):
+    """PageBuilder contents after appendPage of every page (MergePages.java:155-164)."""
+    import numpy as np
+    from presto_amd import abi
+    from presto_amd.page import Block, Page
+    blocks = []
+    for c in range(pages[0].channel_count):
+        t = pages[0].blocks[c].type
+        vals = [v for p in pages for v in p.blocks[c].to_pylist()]
+        if t == abi.VARCHAR:
+            blocks.append(Block.varchar(vals))
+        else:
+            blocks.append(Block.flat(t, [0 if v is None else v for v in vals], [v is None for v in vals]))
+    return Page(blocks, sum(p.position_count for p in pages))
+
+
+class MergePages:
+    """MergePages.MergePagesTransformation (core/trino-main/src/main/java/io/trino/operator/project/MergePages.java:
+    86-172) as a push-style state machine: process(page) / finish() return the pages that come out."""
+
+    DEFAULT_MAX_PAGE_SIZE_IN_BYTES = 1024 * 1024  # PageBuilderStatus.java:18
+
+    def __init__(self, min_page_size_in_bytes, min_row_count, max_page_size_in_bytes=0):
+        self.min_bytes = min_page_size_in_bytes
+        self.min_rows = min_row_count
+        self.max_bytes = max_page_size_in_bytes or self.DEFAULT_MAX_PAGE_SIZE_IN_BYTES
+        self.buffered = []
+        self.buffered_bytes = 0
+
+    def _flush(self):
+        out = concat_pages(self.buffered)
+        self.buffered, self.buffered_bytes = [], 0
+        return out
+
+    def process(self, page):
+        out = []
+        if page.position_count >= self.min_rows or page_size_in_bytes(page) >= self.min_bytes:  # :128
+            if self.buffered:
+                out.append(self._flush())  # :133-138: the buffered rows first, the big page on the next call
+            out.append(page)
+            return out
+        self.buffered.append(page)  # :141
+        self.buffered_bytes += page_size_in_bytes(page)
+        if self.buffered_bytes >= self.max_bytes:  # :143 pageBuilder.isFull(), PageBuilderStatus.java:49-52
+            out.append(self._flush())
+        return out
+
+    def finish(self):
+        return [self._flush()] if self.buffered else []  # :117-124

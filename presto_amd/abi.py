@@ -5,7 +5,7 @@ test-only oracle binding (oracle/oracle.py), exactly as both C sides share the h
 """
 import ctypes as C
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 # pa_status
 OK = 0
@@ -128,6 +128,9 @@ class pa_filter_project_desc(C.Structure):
         ("projections", C.POINTER(pa_expr)),
         ("output_mem", C.c_int32),
         ("stream", C.c_void_p),
+        ("min_output_page_bytes", C.c_int64),
+        ("min_output_page_rows", C.c_int32),
+        ("max_output_page_bytes", C.c_int32),
     ]
 
 

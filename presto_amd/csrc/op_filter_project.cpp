@@ -198,10 +198,19 @@ public:
         PA_HIP(hipMemsetAsync(ctl_, 0, 64, stream_.get()));
         h_ctl_ = static_cast<int32_t*>(h_ctl_buf_.ensure(64));
         out_cols_.resize(spec_.proj.size());
+        var_first_.assign(spec_.proj.size(), 0);
+        var_bytes_.assign(spec_.proj.size(), 0);
+        PA_REQUIRE(d->min_output_page_bytes >= 0 && d->min_output_page_rows >= 0 && d->max_output_page_bytes >= 0, PA_ERR_INVALID_ARGUMENT,
+                   "MergePages thresholds must not be negative");  // MergePages.java:101-105
+        merge_min_bytes_ = d->min_output_page_bytes;
+        merge_min_rows_ = d->min_output_page_rows;
+        if (d->max_output_page_bytes > 0) merge_max_bytes_ = d->max_output_page_bytes;
+        PA_REQUIRE(merge_max_bytes_ >= merge_min_bytes_, PA_ERR_INVALID_ARGUMENT, "maxPageSizeInBytes must be greater or equal than minPageSizeInBytes");
+        merging_ = merge_min_bytes_ > 0 || merge_min_rows_ > 0;
     }
     ~FilterProjectOperator() override { (void)hipStreamSynchronize(stream_.get()); }
 
-    bool needs_input() override { return !finishing_ && !pending_; }
+    bool needs_input() override { return !finishing_ && !pending_ && !big_queued_; }
 
     void add_input(const pa_page* page) override
     {
@@ -279,9 +288,44 @@ public:
         pending_ = true;
     }
 
+    // MergePages.MergePagesTransformation.process (MergePages.java:112-153) around the page the PageProcessor made
     bool get_output(pa_page* out) override
     {
-        if (!pending_) return false;
+        hipStream_t s = stream_.get();
+        if (big_queued_) {  // :114-119 the big page that followed a flush
+            big_queued_ = false;
+            publish_output(out_cols_, big_count_, spec_.output_mem, s, out, out_storage_);
+            return true;
+        }
+        if (pending_) {
+            int32_t count = 0;
+            const bool have = process_pending(&count);
+            if (have && !merging_) {
+                publish_output(out_cols_, count, spec_.output_mem, s, out, out_storage_);
+                return true;
+            }
+            if (have) {
+                const int64_t bytes = page_size_in_bytes(count);
+                if (count >= merge_min_rows_ || bytes >= merge_min_bytes_) {  // :128
+                    if (m_rows_ == 0) {
+                        publish_output(out_cols_, count, spec_.output_mem, s, out, out_storage_);
+                        return true;
+                    }
+                    big_queued_ = true;  // :133-138
+                    big_count_ = count;
+                    return flush_merged(out);
+                }
+                append_merged(count, bytes);  // :141
+                if (m_size_ >= merge_max_bytes_) return flush_merged(out);  // :143-145
+            }
+        }
+        if (finishing_ && m_rows_ > 0) return flush_merged(out);  // :121-124
+        return false;
+    }
+
+    // the PageProcessor part: fills out_cols_ for the page added last; false when no row was selected
+    bool process_pending(int32_t* out_count)
+    {
         pending_ = false;
         hipStream_t s = stream_.get();
         PA_HIP(hipStreamSynchronize(s));
@@ -334,12 +378,93 @@ public:
                 }
             }
         }
-        publish_output(out_cols_, count, spec_.output_mem, s, out, out_storage_);
+        *out_count = count;
+        return true;
+    }
+
+    // Page.getSizeInBytes of the output page with the reference's block accounting (see include/presto_amd.h)
+    int64_t page_size_in_bytes(int32_t count)
+    {
+        hipStream_t s = stream_.get();
+        int64_t bytes = 0;
+        for (size_t j = 0; j < out_cols_.size(); j++) {
+            OutColumn& oc = out_cols_[j];
+            if (!oc.varwidth) {
+                bytes += (int64_t)(type_width(oc.type) + 1) * count;
+                continue;
+            }
+            const int32_t* off = oc.is_view ? oc.view_offsets : oc.offsets.as<int32_t>();
+            int32_t ends[2];
+            PA_HIP(hipMemcpyAsync(&ends[0], off, 4, hipMemcpyDeviceToHost, s));
+            PA_HIP(hipMemcpyAsync(&ends[1], off + count, 4, hipMemcpyDeviceToHost, s));
+            PA_HIP(hipStreamSynchronize(s));
+            var_first_[j] = ends[0];
+            var_bytes_[j] = ends[1] - ends[0];
+            bytes += (int64_t)var_bytes_[j] + 5LL * count;
+        }
+        return bytes;
+    }
+
+    // PageBuilder.appendPage (MergePages.java:155-164): the page's blocks behind the buffered ones, on device
+    void append_merged(int32_t count, int64_t bytes)
+    {
+        hipStream_t s = stream_.get();
+        if (merge_cols_.size() != out_cols_.size()) {
+            merge_cols_.clear();
+            merge_cols_.resize(out_cols_.size());
+            m_var_bytes_.assign(out_cols_.size(), 0);
+        }
+        for (size_t j = 0; j < out_cols_.size(); j++) {
+            OutColumn& oc = out_cols_[j];
+            OutColumn& mc = merge_cols_[j];
+            const void* sv = oc.is_view ? oc.view_values : oc.values.ptr();
+            const uint8_t* sn = oc.is_view ? oc.view_nulls : (oc.has_nulls ? oc.nulls.as<uint8_t>() : nullptr);
+            mc.type = oc.type;
+            mc.varwidth = oc.varwidth;
+            if (oc.varwidth) {
+                const int32_t* so = oc.is_view ? oc.view_offsets : oc.offsets.as<int32_t>();
+                int32_t* mo = static_cast<int32_t*>(mc.offsets.reserve_keep((size_t)(m_rows_ + count + 1) * 4, (size_t)(m_rows_ ? m_rows_ + 1 : 0) * 4, s));
+                launch_offsets_append(so, count, (int32_t)m_var_bytes_[j], mo + m_rows_, m_rows_ == 0, s);
+                char* mv = static_cast<char*>(mc.values.reserve_keep((size_t)(m_var_bytes_[j] + var_bytes_[j] + 1), (size_t)m_var_bytes_[j], s));
+                if (var_bytes_[j] > 0)
+                    PA_HIP(hipMemcpyAsync(mv + m_var_bytes_[j], static_cast<const char*>(sv) + var_first_[j], (size_t)var_bytes_[j], hipMemcpyDeviceToDevice, s));
+                m_var_bytes_[j] += var_bytes_[j];
+            }
+            else {
+                const size_t w = (size_t)type_width(oc.type);
+                char* mv = static_cast<char*>(mc.values.reserve_keep((size_t)(m_rows_ + count) * w, (size_t)m_rows_ * w, s));
+                PA_HIP(hipMemcpyAsync(mv + (size_t)m_rows_ * w, sv, (size_t)count * w, hipMemcpyDeviceToDevice, s));
+            }
+            if (sn || mc.has_nulls) {
+                uint8_t* mn = static_cast<uint8_t*>(mc.nulls.reserve_keep((size_t)(m_rows_ + count), mc.has_nulls ? (size_t)m_rows_ : 0, s));
+                if (!mc.has_nulls && m_rows_ > 0) PA_HIP(hipMemsetAsync(mn, 0, (size_t)m_rows_, s));  // earlier pages had no NULL
+                if (sn) PA_HIP(hipMemcpyAsync(mn + m_rows_, sn, (size_t)count, hipMemcpyDeviceToDevice, s));
+                else PA_HIP(hipMemsetAsync(mn + m_rows_, 0, (size_t)count, s));
+                mc.has_nulls = true;
+            }
+        }
+        m_rows_ += count;
+        m_size_ += bytes;
+    }
+
+    // pageBuilder.build() + reset(): the buffered rows leave as one page (valid until the next add_input / get_output)
+    bool flush_merged(pa_page* out)
+    {
+        const int32_t n = (int32_t)m_rows_;
+        for (auto& mc : merge_cols_) {
+            mc.is_view = false;
+            mc.host_ready = false;
+        }
+        publish_output(merge_cols_, n, spec_.output_mem, stream_.get(), out, merge_storage_);
+        m_rows_ = 0;
+        m_size_ = 0;
+        for (auto& mc : merge_cols_) mc.has_nulls = false;  // the pointers of the published page are already taken
+        std::fill(m_var_bytes_.begin(), m_var_bytes_.end(), 0);
         return true;
     }
 
     void finish() override { finishing_ = true; }
-    bool is_finished() override { return finishing_ && !pending_; }
+    bool is_finished() override { return finishing_ && !pending_ && !big_queued_ && m_rows_ == 0; }
     bool is_blocked() override { return false; }
     int64_t memory_bytes() override { return (int64_t)(stager_.bytes() + sel4_.capacity() + positions_.capacity() + tile_counts_.capacity()); }
 
@@ -385,6 +510,14 @@ private:
     bool last_is_list_ = false;
     std::vector<OutColumn> out_cols_;
     std::vector<pa_column> out_storage_;
+    // MergePages state
+    bool merging_ = false, big_queued_ = false;
+    int32_t merge_min_rows_ = 0, big_count_ = 0;
+    int64_t merge_min_bytes_ = 0, merge_max_bytes_ = 1 << 20, m_rows_ = 0, m_size_ = 0;
+    std::vector<OutColumn> merge_cols_;
+    std::vector<pa_column> merge_storage_;
+    std::vector<int64_t> m_var_bytes_;
+    std::vector<int32_t> var_first_, var_bytes_;
 };
 
 }  // namespace

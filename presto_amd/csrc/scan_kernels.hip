@@ -257,4 +257,18 @@ void launch_partition_positions(const int32_t* partition, int64_t n, int32_t par
     PA_HIP(hipGetLastError());
 }
 
+__global__ __launch_bounds__(256) void k_offsets_append(const i32* __restrict__ src, i64 count, i32 dst_base, i32* __restrict__ dst, int write_first)
+{
+    const i32 first = src[0];
+    for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < count; i += (i64)gridDim.x * 256) dst[i + 1] = dst_base + (src[i + 1] - first);
+    if (write_first && blockIdx.x == 0 && threadIdx.x == 0) dst[0] = dst_base;
+}
+void launch_offsets_append(const int32_t* src, int64_t count, int32_t dst_base, int32_t* dst, bool write_first, hipStream_t s)
+{
+    if (count <= 0) return;
+    int grid = (int)std::min<int64_t>((count + 255) / 256, 2048);
+    hipLaunchKernelGGL(k_offsets_append, grid, 256, 0, s, (const i32*)src, (i64)count, (i32)dst_base, (i32*)dst, write_first ? 1 : 0);
+    PA_HIP(hipGetLastError());
+}
+
 }  // namespace pa

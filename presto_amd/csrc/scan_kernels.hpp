@@ -11,6 +11,9 @@ void launch_varwidth_lengths(const int32_t* positions, int64_t count, const int3
                              hipStream_t s);
 void launch_varwidth_copy(const int32_t* positions, int64_t count, const int32_t* offsets, const uint8_t* bytes, const uint8_t* nulls,
                           int32_t* out_offsets, uint8_t* out_bytes, int32_t* total, hipStream_t s);
+// dst[i + 1] = dst_base + src[i + 1] - src[0] for i in [0, count); dst[0] = dst_base when write_first (appending a
+// VariableWidthBlock's offsets behind others, MergePages' PageBuilder)
+void launch_offsets_append(const int32_t* src, int64_t count, int32_t dst_base, int32_t* dst, bool write_first, hipStream_t s);
 size_t partition_temp_bytes(int64_t n, int32_t partition_count);
 void launch_partition_positions(const int32_t* partition, int64_t n, int32_t partition_count, int32_t* out_positions,
                                 int64_t* out_counts_dev, void* temp, hipStream_t s);

@@ -178,10 +178,14 @@ def fused_aggregation_desc(input_types, filter_expr, projections, group_by_chann
 
 # ---- factories (OperatorFactory.createOperator) ----------------------------------------------------------
 def FilterAndProjectOperator(input_types, filter_expr, projections, output_mem=abi.MEM_HOST, stream=None,
-                             type_params=None):
+                             type_params=None, min_output_page_size=0, min_output_page_row_count=0, max_output_page_size=0):
     """FilterAndProjectOperator.createOperatorFactory (…/operator/FilterAndProjectOperator.java:73-178) with
-    PageProcessor(Optional<PageFilter>, List<PageProjection>)."""
+    PageProcessor(Optional<PageFilter>, List<PageProjection>); minOutputPageSize / minOutputPageRowCount configure
+    the MergePages step behind it (0, 0 = every page passes through, as in the reference's operator tests)."""
     d, keep = _filter_project_desc(input_types, filter_expr, projections, output_mem, stream, type_params)
+    d.min_output_page_bytes = int(min_output_page_size)
+    d.min_output_page_rows = int(min_output_page_row_count)
+    d.max_output_page_bytes = int(max_output_page_size)
     h = C.c_void_p()
     check(lib().pa_filter_project_create(C.byref(d), C.byref(h)))
     return Operator(h, keep)

@@ -174,3 +174,81 @@ def test_dictionary_and_rle_inputs(gpu, oracle):
     op = FilterAndProjectOperator([abi.BIGINT, abi.DOUBLE], f, proj)
     rows = [r for p in to_pages(op, [page]) for r in p.to_rows()]
     assert rows == oracle_rows(oracle, [page], f, proj)
+
+
+# ---- MergePages behind the PageProcessor (a7) ------------------------------------------------------------------------
+def merged_reference(oracle, pages, f, projections, min_bytes, min_rows, max_bytes=0):
+    m = oracle.MergePages(min_bytes, min_rows, max_bytes)
+    out = []
+    for p in pages:
+        q = oracle.filter_project(p, f, projections)
+        if q is not None and q.position_count > 0:
+            out += m.process(q)
+    return [p.to_rows() for p in out + m.finish()]
+
+
+@pytest.mark.parametrize("device_output", [False, True])
+def test_merge_pages_kats_on_device(gpu, oracle, device_output):
+    """TestMergePages.java:44-163 through FilterAndProjectOperator(minOutputPageSize, minOutputPageRowCount): identity
+    projections, no filter, so the PageProcessor hands the input pages to MergePages unchanged."""
+    from presto_amd.operators import download_page
+    types = [abi.VARCHAR, abi.BIGINT, abi.DOUBLE]
+    cols = [(abi.VARCHAR, 0), (abi.BIGINT, 0), (abi.DOUBLE, 0)]
+    proj = [field(i, t) for i, t in enumerate(types)]
+    mem = abi.MEM_DEVICE if device_output else abi.MEM_HOST
+
+    def go(pages, min_bytes, min_rows, max_bytes=0, ptypes=types, pproj=proj):
+        op = FilterAndProjectOperator(ptypes, None, pproj, output_mem=mem, min_output_page_size=min_bytes, min_output_page_row_count=min_rows,
+                                      max_output_page_size=max_bytes)
+        got = []
+        for p in pages:  # Driver order: addInput, then getOutput until none
+            assert op.needsInput()
+            op.addInput(p)
+            while True:
+                o = op.getOutput()
+                if o is None:
+                    break
+                got.append((download_page(o) if device_output else o).to_rows())
+        op.finish()
+        while not op.isFinished():
+            o = op.getOutput()
+            if o is not None:
+                got.append((download_page(o) if device_output else o).to_rows())
+        assert got == merged_reference(oracle, pages, None, pproj, min_bytes, min_rows, max_bytes)
+        return got
+
+    page = sequence_page(10, cols)
+    assert go([page], oracle.page_size_in_bytes(page), 2 ** 31 - 1) == [page.to_rows()]
+    assert go([page], 1024 * 1024, 10) == [page.to_rows()]
+    whole = sequence_page(20, cols)
+    assert go([whole.get_region(0, 10), whole.get_region(10, 10)], oracle.page_size_in_bytes(whole) + 1, 21) == [whole.to_rows()]
+    small, big = sequence_page(10, cols), sequence_page(100, cols)
+    assert go([small, big], oracle.page_size_in_bytes(big), 100) == [small.to_rows(), big.to_rows()]
+    w1 = sequence_page(20, [(abi.BIGINT, 0)])
+    halves = [w1.get_region(0, 10), w1.get_region(10, 10)]
+    size = oracle.page_size_in_bytes(w1)
+    assert go(halves + halves, size // 2 + 1, 11, size, [abi.BIGINT], [field(0, abi.BIGINT)]) == [w1.to_rows(), w1.to_rows()]
+
+
+def test_merge_pages_selective_filter_with_nulls_and_varchar(gpu, oracle):
+    """The shape MergePages exists for: a selective filter over many small pages (8192-row connector pages, ~2 % pass);
+    defaults of the session properties (500 kB / 256 rows, SystemSessionProperties.java:106-107) and a small maximum so
+    that full-buffer flushes happen; nullable and VARCHAR columns; expressions and identity projections mixed."""
+    rng = np.random.default_rng(11)
+    words = [b"", b"a", b"BUILDING", b"MACHINERY", None]
+    pages = []
+    for i in range(40):
+        n = int(rng.integers(1, 4000))
+        pages.append(Page([Block.bigint(rng.integers(0, 1000, n), rng.random(n) < 0.1), Block.double(rng.random(n)),
+                           Block.varchar([words[j] for j in rng.integers(0, len(words), n)]), Block.integer(rng.integers(-5, 5, n))], n))
+    types = [abi.BIGINT, abi.DOUBLE, abi.VARCHAR, abi.INTEGER]
+    f = field(1, abi.DOUBLE) < constant(0.03, abi.DOUBLE)
+    proj = [field(0, abi.BIGINT), field(2, abi.VARCHAR), field(1, abi.DOUBLE) * constant(2.0, abi.DOUBLE), field(3, abi.INTEGER)]
+    for min_bytes, min_rows, max_bytes in [(500 * 1000, 256, 0), (3000, 120, 6000), (1, 1, 0)]:
+        op = FilterAndProjectOperator(types, f, proj, min_output_page_size=min_bytes, min_output_page_row_count=min_rows,
+                                      max_output_page_size=max_bytes)
+        got = [p.to_rows() for p in to_pages(op, pages)]
+        expected = merged_reference(oracle, pages, f, proj, min_bytes, min_rows, max_bytes)
+        assert len(got) == len(expected)
+        assert bits([r for p in got for r in p]) == bits([r for p in expected for r in p])
+        assert [len(p) for p in got] == [len(p) for p in expected]

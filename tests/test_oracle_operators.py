@@ -214,3 +214,42 @@ def test_q1_group_structure_against_sf1_answers(oracle):
     tg, tr = sum(got.values()), sum(ref.values())
     for k in ref:
         assert abs(got[k] / tg - ref[k] / tr) < 0.03, (k, got[k] / tg, ref[k] / tr)
+
+
+# ---- MergePages (core/trino-main/src/test/java/io/trino/operator/project/TestMergePages.java) ------------------------
+MERGE_TYPES = [(abi.VARCHAR, 0), (abi.BIGINT, 0), (abi.DOUBLE, 0)]
+
+
+def merge_all(m, pages):
+    out = []
+    for p in pages:
+        out += m.process(p)
+    return out + m.finish()
+
+
+def test_merge_pages_kats(oracle):
+    from presto_amd.page import sequence_page
+    page = sequence_page(10, MERGE_TYPES)
+    size = oracle.page_size_in_bytes(page)
+    assert size == (10 + 5 * 10) + 9 * 10 + 9 * 10  # "0".."9" + (4 + 1) per position; (8 + 1) per position twice
+    # testMinPageSizeThreshold (:44-59): a page of exactly minPageSizeInBytes passes through
+    out = merge_all(oracle.MergePages(size, 2 ** 31 - 1, 2 ** 31 - 1), [page])
+    assert len(out) == 1 and out[0] is page
+    # testMinRowCountThreshold (:61-76)
+    out = merge_all(oracle.MergePages(1024 * 1024, 10, 2 ** 31 - 1), [page])
+    assert len(out) == 1 and out[0] is page
+    # testBufferSmallPages (:106-123): two halves come out as the whole
+    whole = sequence_page(20, MERGE_TYPES)
+    halves = [whole.get_region(0, 10), whole.get_region(10, 10)]
+    out = merge_all(oracle.MergePages(oracle.page_size_in_bytes(whole) + 1, 21, 2 ** 31 - 1), halves)
+    assert [p.to_rows() for p in out] == [whole.to_rows()]
+    # testFlushOnBigPage (:125-142): the buffered small page first, then the big one
+    small, big = sequence_page(10, MERGE_TYPES), sequence_page(100, MERGE_TYPES)
+    out = merge_all(oracle.MergePages(oracle.page_size_in_bytes(big), 100, 2 ** 31 - 1), [small, big])
+    assert [p.to_rows() for p in out] == [small.to_rows(), big.to_rows()]
+    # testFlushOnFullPage (:144-163): BIGINT halves, max page size = the whole page: two whole pages
+    whole = sequence_page(20, [(abi.BIGINT, 0)])
+    halves = [whole.get_region(0, 10), whole.get_region(10, 10)]
+    size = oracle.page_size_in_bytes(whole)
+    out = merge_all(oracle.MergePages(size // 2 + 1, 11, size), halves + halves)
+    assert [p.to_rows() for p in out] == [whole.to_rows(), whole.to_rows()]
