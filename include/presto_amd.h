@@ -247,6 +247,23 @@ typedef struct pa_lookup_join_desc {
     void* stream;
 } pa_lookup_join_desc;
 
+/* TopNOperator.createOperatorFactory (TopNOperator.java:43-90): keep the n best rows under (sort_channels, sort_orders)
+ * and emit them, ordered, as one page after finish.  Ties between fully equal sort keys come out in arrival order (the
+ * reference leaves their order unspecified). */
+typedef enum pa_sort_order {             /* io.trino.spi.connector.SortOrder */
+    PA_ASC_NULLS_FIRST = 0, PA_ASC_NULLS_LAST = 1, PA_DESC_NULLS_FIRST = 2, PA_DESC_NULLS_LAST = 3
+} pa_sort_order;
+typedef struct pa_topn_desc {
+    int32_t input_channel_count;
+    const int32_t* input_types;
+    int32_t n;
+    int32_t sort_channel_count;
+    const int32_t* sort_channels;
+    const int32_t* sort_orders;          /* pa_sort_order per sort channel */
+    int32_t output_mem;
+    void* stream;
+} pa_topn_desc;
+
 typedef struct pa_operator pa_operator;             /* opaque operator handle */
 typedef struct pa_lookup_source pa_lookup_source;   /* opaque: JoinBridge / LookupSourceFactory */
 
@@ -279,6 +296,7 @@ int32_t pa_filter_project_create(const pa_filter_project_desc* desc, pa_operator
 int32_t pa_aggregation_create(const pa_aggregation_desc* desc, pa_operator** out);
 int32_t pa_hash_aggregation_create(const pa_hash_aggregation_desc* desc, pa_operator** out);
 int32_t pa_fused_aggregation_create(const pa_fused_aggregation_desc* desc, pa_operator** out);
+int32_t pa_topn_create(const pa_topn_desc* desc, pa_operator** out);
 int32_t pa_lookup_source_create(pa_lookup_source** out);
 int32_t pa_lookup_source_destroy(pa_lookup_source* ls);
 int32_t pa_hash_builder_create(const pa_hash_builder_desc* desc, pa_lookup_source* bridge, pa_operator** out);

@@ -436,3 +436,47 @@ class MergePages:
 
     def finish(self):
         return [self._flush()] if self.buffered else []  # :117-124
+
+
+# ---- TopN ---------------------------------------------------------------------------------------------------------
+def topn(pages, n, sort_channels, sort_orders):
+    """TopNOperator / TopNProcessor / GroupedTopNBuilder with one group (core/trino-main/src/main/java/io/trino/operator/
+    TopNProcessor.java:35-110): the n first rows under SimplePageWithPositionComparator (…/SimplePageWithPositionComparator.java:
+    45-70) with SortOrder.compareBlockValue (core/trino-spi/src/main/java/io/trino/spi/connector/SortOrder.java:58-84), as
+    rows.  Fully tied rows keep arrival order here (the reference leaves it open).  Type orders: BIGINT / INTEGER / DATE
+    numeric, DOUBLE Double.compare (-0.0 < 0.0, NaN last), VARCHAR unsigned bytes (Slice.compareTo), BOOLEAN false < true."""
+    import functools
+    import math
+    import struct
+    from presto_amd import abi
+    rows = [r for p in pages for r in p.to_rows()]
+    types = [b.type for b in pages[0].blocks] if pages else []
+
+    def value_cmp(t, a, b):
+        if t == abi.DOUBLE:
+            def image(d):
+                bits = 0x7ff8000000000000 if math.isnan(d) else struct.unpack("<Q", struct.pack("<d", d))[0]
+                return (~bits) & 0xFFFFFFFFFFFFFFFF if bits >> 63 else bits | 0x8000000000000000
+            a, b = image(a), image(b)
+        return -1 if a < b else (1 if a > b else 0)
+
+    def cmp(x, y):
+        for ch, order in zip(sort_channels, sort_orders):
+            a, b = x[ch], y[ch]
+            ascending, nulls_first = order < 2, (order & 1) == 0
+            if a is None and b is None:
+                c = 0
+            elif a is None:
+                c = -1 if nulls_first else 1
+            elif b is None:
+                c = 1 if nulls_first else -1
+            else:
+                c = value_cmp(types[ch], a, b)
+                c = c if ascending else -c
+            if c:
+                return c
+        return 0
+
+    if n == 0:
+        return []
+    return sorted(rows, key=functools.cmp_to_key(cmp))[:n]

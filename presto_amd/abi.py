@@ -134,6 +134,22 @@ class pa_filter_project_desc(C.Structure):
     ]
 
 
+ASC_NULLS_FIRST, ASC_NULLS_LAST, DESC_NULLS_FIRST, DESC_NULLS_LAST = 0, 1, 2, 3  # io.trino.spi.connector.SortOrder
+
+
+class pa_topn_desc(C.Structure):
+    _fields_ = [
+        ("input_channel_count", C.c_int32),
+        ("input_types", C.POINTER(C.c_int32)),
+        ("n", C.c_int32),
+        ("sort_channel_count", C.c_int32),
+        ("sort_channels", C.POINTER(C.c_int32)),
+        ("sort_orders", C.POINTER(C.c_int32)),
+        ("output_mem", C.c_int32),
+        ("stream", C.c_void_p),
+    ]
+
+
 class pa_aggregation_desc(C.Structure):
     _fields_ = [
         ("input_channel_count", C.c_int32),

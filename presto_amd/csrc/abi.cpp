@@ -306,6 +306,14 @@ int32_t pa_lookup_source_tables(pa_lookup_source* ls, const int32_t** key, int32
         return lookup_source_tables(ls, key, hash_size, position_links, positions);
     });
 }
+int32_t pa_topn_create(const pa_topn_desc* desc, pa_operator** out)
+{
+    return guarded([&]() -> int32_t {
+        PA_REQUIRE(out != nullptr, PA_ERR_INVALID_ARGUMENT, "null argument");
+        *out = make_topn(desc);
+        return PA_OK;
+    });
+}
 int32_t pa_hash_builder_create(const pa_hash_builder_desc* desc, pa_lookup_source* bridge, pa_operator** out)
 {
     return guarded([&]() -> int32_t {

@@ -1,0 +1,361 @@
+// op_topn.cpp -- TopNOperator (core/trino-main/src/main/java/io/trino/operator/TopNOperator.java:30-160; TopNProcessor.java:
+// 35-110; GroupedTopNBuilder.java with a single group): keep the N best rows under (sortChannels, sortOrders), emit them
+// in order once the input is finished.
+//
+// The reference compares every input row with the root of an N-row heap (SimplePageWithPositionComparator.java:45-70).
+// Device side here: every page is cut down to the rows whose FIRST sort key is not beyond the N-th best first key seen
+// so far (topn_kernels.hip: order-preserving 64-bit key, radix selection, stable compaction + gathers); only those rows
+// -- at least N per page at first, fewer and fewer later -- cross to the host, which holds the survivors and does the
+// exact multi-channel comparison (all sort channels, NULL placement, ties in arrival order) at the end.  Rows tied with
+// the N-th on the first key are kept, so the result is exact; the reference leaves the order of fully tied rows open.
+#include <algorithm>
+#include <cstring>
+#include <numeric>
+
+#include "operator.hpp"
+#include "scan_kernels.hpp"
+#include "topn_kernels.hpp"
+
+namespace pa {
+
+namespace {
+
+struct HostColumn {
+    int32_t type = PA_BIGINT;
+    std::vector<uint8_t> values;    // fixed width elements, or VARCHAR bytes
+    std::vector<int32_t> offsets;   // VARCHAR: rows + 1 entries
+    std::vector<uint8_t> nulls;     // one per row
+};
+
+class TopNOperator : public pa_operator {
+public:
+    explicit TopNOperator(const pa_topn_desc* d) : stream_(d->stream)
+    {
+        require_device();
+        PA_REQUIRE(d->input_channel_count > 0 && d->input_types, PA_ERR_INVALID_ARGUMENT, "TopN needs input types");
+        PA_REQUIRE(d->n >= 0, PA_ERR_INVALID_ARGUMENT, "n must be positive");  // TopNOperator.java:62
+        PA_REQUIRE(d->sort_channel_count > 0 && d->sort_channels && d->sort_orders, PA_ERR_INVALID_ARGUMENT, "TopN needs sort channels");
+        types_.assign(d->input_types, d->input_types + d->input_channel_count);
+        sort_channels_.assign(d->sort_channels, d->sort_channels + d->sort_channel_count);
+        sort_orders_.assign(d->sort_orders, d->sort_orders + d->sort_channel_count);
+        for (size_t i = 0; i < sort_channels_.size(); i++) {
+            PA_REQUIRE(sort_channels_[i] >= 0 && sort_channels_[i] < (int)types_.size(), PA_ERR_INVALID_ARGUMENT, "sort channel out of range");
+            PA_REQUIRE(sort_orders_[i] >= 0 && sort_orders_[i] <= 3, PA_ERR_INVALID_ARGUMENT, "unknown sort order");
+        }
+        n_ = d->n;
+        output_mem_ = d->output_mem;
+        store_.resize(types_.size());
+        for (size_t c = 0; c < types_.size(); c++) {
+            store_[c].type = types_[c];
+            if (types_[c] == PA_VARCHAR) store_[c].offsets.push_back(0);
+        }
+        h_hist_ = static_cast<uint32_t*>(h_hist_buf_.ensure(256 * 4 + 64));
+        finishing_ = n_ == 0;  // TopNOperator.java:93-95: LIMIT 0 is finished from the start
+        output_done_ = n_ == 0;
+    }
+    ~TopNOperator() override { (void)hipStreamSynchronize(stream_.get()); }
+
+    bool needs_input() override { return !finishing_; }
+
+    void add_input(const pa_page* page) override
+    {
+        PA_REQUIRE(!finishing_, PA_ERR_ILLEGAL_STATE, "Operator is already finishing");
+        PA_REQUIRE(page != nullptr, PA_ERR_INVALID_ARGUMENT, "page is null");
+        PA_REQUIRE(page->channel_count == (int32_t)types_.size(), PA_ERR_INVALID_ARGUMENT, "page channel count does not match the operator's input types");
+        if (page->position_count == 0) return;
+        hipStream_t s = stream_.get();
+        DevPage dp = stager_.stage(page, nullptr, s);
+        const int64_t n = dp.n;
+        for (size_t c = 0; c < types_.size(); c++) PA_REQUIRE(dp.cols[c].type == types_[c], PA_ERR_INVALID_ARGUMENT, "page block type does not match the declared input type");
+        const DevColumn& first = dp.cols[sort_channels_[0]];
+        uint64_t* keys = static_cast<uint64_t*>(keys_.ensure((size_t)n * 8));
+        timer.begin(s);
+        launch_topn_keys(first.type, first.values, first.offsets, first.nulls, n, sort_orders_[0], keys, s);
+        // the N-th best first key of this page alone bounds the N-th best overall
+        if (n >= n_) threshold_ = std::min(threshold_, topn_select_kth(keys, n, n_, select_temp_.ensure(topn_select_temp_bytes()), h_hist_, s));
+        const int32_t* positions = nullptr;
+        int64_t count = n;
+        if (threshold_ != ~0ULL) {
+            int32_t* part = static_cast<int32_t*>(part_.ensure((size_t)n * 4));
+            int32_t* pos = static_cast<int32_t*>(pos_.ensure((size_t)n * 4));
+            int64_t* counts = static_cast<int64_t*>(counts_.ensure(64));
+            launch_topn_flag(keys, n, threshold_, part, s);
+            launch_partition_positions(part, n, 2, pos, counts, part_temp_.ensure(partition_temp_bytes(n, 2)), s);
+            int64_t h_counts[2];
+            PA_HIP(hipMemcpyAsync(h_counts, counts, 16, hipMemcpyDeviceToHost, s));
+            PA_HIP(hipStreamSynchronize(s));
+            count = h_counts[0];
+            positions = pos;
+        }
+        timer.end(s);
+        if (count == 0) return;
+        append_rows(dp, keys, positions, count);
+        prune();
+    }
+
+    void finish() override { finishing_ = true; }
+    bool is_finished() override { return finishing_ && output_done_; }
+
+    bool get_output(pa_page* out) override
+    {
+        if (!finishing_ || output_done_) return false;
+        output_done_ = true;
+        const int64_t rows = (int64_t)store_keys_.size();
+        if (rows == 0) return false;
+        std::vector<int64_t> order((size_t)rows);
+        std::iota(order.begin(), order.end(), 0);
+        std::stable_sort(order.begin(), order.end(), [&](int64_t a, int64_t b) { return compare_rows(a, b) < 0; });
+        const int64_t m = std::min<int64_t>(rows, n_);
+        build_output(order, m);
+        publish_output(out_cols_, (int32_t)m, output_mem_, stream_.get(), out, out_storage_);
+        return true;
+    }
+
+    int64_t memory_bytes() override { return (int64_t)(stager_.bytes() + keys_.capacity() + part_.capacity() + pos_.capacity()); }
+
+private:
+    // selected rows of the page -> host store (Block.copyPositions on device, then one D2H per column)
+    void append_rows(const DevPage& dp, const uint64_t* keys, const int32_t* positions, int64_t count)
+    {
+        hipStream_t s = stream_.get();
+        const int64_t n = dp.n;
+        auto fetch = [&](const void* dev, size_t bytes, std::vector<uint8_t>& dst) {
+            void* land = land_.ensure(bytes ? bytes : 1);
+            if (bytes) PA_HIP(hipMemcpyAsync(land, dev, bytes, hipMemcpyDeviceToHost, s));
+            PA_HIP(hipStreamSynchronize(s));
+            dst.insert(dst.end(), static_cast<uint8_t*>(land), static_cast<uint8_t*>(land) + bytes);
+        };
+        // keys
+        {
+            const void* src = keys;
+            if (positions) {
+                launch_gather_flat(keys, 8, positions, count, gather_.ensure((size_t)count * 8), s);
+                src = gather_.ptr();
+            }
+            std::vector<uint8_t> raw;
+            fetch(src, (size_t)count * 8, raw);
+            const size_t old = store_keys_.size();
+            store_keys_.resize(old + (size_t)count);
+            memcpy(store_keys_.data() + old, raw.data(), raw.size());
+        }
+        for (size_t c = 0; c < types_.size(); c++) {
+            const DevColumn& col = dp.cols[c];
+            HostColumn& hc = store_[c];
+            if (col.nulls) {
+                const void* src = col.nulls;
+                if (positions) {
+                    launch_gather_nulls(col.nulls, positions, count, static_cast<uint8_t*>(gather_.ensure((size_t)count)), s);
+                    src = gather_.ptr();
+                }
+                fetch(src, (size_t)count, hc.nulls);
+            }
+            else {
+                hc.nulls.insert(hc.nulls.end(), (size_t)count, 0);
+            }
+            if (!col.varwidth) {
+                const int w = type_width(col.type);
+                const void* src = col.values;
+                if (positions) {
+                    launch_gather_flat(col.values, w, positions, count, gather_.ensure((size_t)count * w), s);
+                    src = gather_.ptr();
+                }
+                fetch(src, (size_t)count * w, hc.values);
+                continue;
+            }
+            // VARCHAR: lengths -> exclusive scan -> byte copy (as FilterAndProject's copyPositions), or the whole block
+            std::vector<uint8_t> raw_off, raw_bytes;
+            if (positions) {
+                int32_t* lens = static_cast<int32_t*>(var_off_.ensure((size_t)(count + 1) * 4));
+                int32_t* total = static_cast<int32_t*>(counts_.ensure(64)) + 8;
+                launch_varwidth_lengths(positions, count, col.offsets, col.nulls, lens, s);
+                launch_exclusive_scan_i32(lens, lens, count, total, scan_temp_.ensure(scan_temp_bytes(count)), s);
+                int32_t h_total = 0;
+                PA_HIP(hipMemcpyAsync(&h_total, total, 4, hipMemcpyDeviceToHost, s));
+                PA_HIP(hipStreamSynchronize(s));
+                uint8_t* bytes = static_cast<uint8_t*>(var_bytes_.ensure((size_t)(h_total > 0 ? h_total : 1)));
+                launch_varwidth_copy(positions, count, col.offsets, static_cast<const uint8_t*>(col.values), col.nulls, lens, bytes, total, s);
+                fetch(lens, (size_t)(count + 1) * 4, raw_off);
+                fetch(bytes, (size_t)h_total, raw_bytes);
+            }
+            else {
+                fetch(col.offsets, (size_t)(n + 1) * 4, raw_off);
+                const int32_t* o = reinterpret_cast<const int32_t*>(raw_off.data());
+                const int32_t lo = o[0], hi = o[n];
+                fetch(static_cast<const uint8_t*>(col.values) + lo, (size_t)(hi - lo), raw_bytes);
+            }
+            const int32_t* o = reinterpret_cast<const int32_t*>(raw_off.data());
+            const int32_t base = (int32_t)hc.values.size() - o[0];
+            for (int64_t i = 1; i <= count; i++) hc.offsets.push_back(o[i] + base);
+            hc.values.insert(hc.values.end(), raw_bytes.begin(), raw_bytes.end());
+        }
+    }
+
+    // keeps the host store bounded: the N-th smallest first key of the survivors tightens the threshold
+    void prune()
+    {
+        const size_t rows = store_keys_.size();
+        if ((int64_t)rows < std::max<int64_t>(8 * n_, 1 << 20)) return;
+        std::vector<uint64_t> k(store_keys_);
+        std::nth_element(k.begin(), k.begin() + (n_ - 1), k.end());
+        threshold_ = std::min(threshold_, k[(size_t)n_ - 1]);
+        std::vector<int64_t> keep;
+        for (size_t i = 0; i < rows; i++) {
+            if (store_keys_[i] <= threshold_) keep.push_back((int64_t)i);
+        }
+        if (keep.size() == rows) return;
+        std::vector<uint64_t> nk(keep.size());
+        for (size_t i = 0; i < keep.size(); i++) nk[i] = store_keys_[(size_t)keep[i]];
+        store_keys_.swap(nk);
+        for (auto& hc : store_) {
+            HostColumn out;
+            out.type = hc.type;
+            copy_rows(hc, keep, (int64_t)keep.size(), out);
+            hc = std::move(out);
+        }
+    }
+
+    static void copy_rows(const HostColumn& src, const std::vector<int64_t>& rows, int64_t m, HostColumn& dst)
+    {
+        dst.nulls.resize((size_t)m);
+        if (src.type == PA_VARCHAR) {
+            dst.offsets.assign(1, 0);
+            for (int64_t i = 0; i < m; i++) {
+                const size_t r = (size_t)rows[(size_t)i];
+                dst.nulls[(size_t)i] = src.nulls[r];
+                dst.values.insert(dst.values.end(), src.values.begin() + src.offsets[r], src.values.begin() + src.offsets[r + 1]);
+                dst.offsets.push_back((int32_t)dst.values.size());
+            }
+            return;
+        }
+        const size_t w = (size_t)type_width(src.type);
+        dst.values.resize((size_t)m * w);
+        for (int64_t i = 0; i < m; i++) {
+            const size_t r = (size_t)rows[(size_t)i];
+            dst.nulls[(size_t)i] = src.nulls[r];
+            memcpy(&dst.values[(size_t)i * w], &src.values[r * w], w);
+        }
+    }
+
+    // SimplePageWithPositionComparator.compareTo (…/operator/SimplePageWithPositionComparator.java:45-70) with
+    // SortOrder.compareBlockValue (core/trino-spi/src/main/java/io/trino/spi/connector/SortOrder.java:58-84)
+    int compare_rows(int64_t a, int64_t b) const
+    {
+        for (size_t i = 0; i < sort_channels_.size(); i++) {
+            const HostColumn& hc = store_[(size_t)sort_channels_[i]];
+            const int order = sort_orders_[i];
+            const bool ascending = order < 2, nulls_first = (order & 1) == 0;
+            const bool an = hc.nulls[(size_t)a] != 0, bn = hc.nulls[(size_t)b] != 0;
+            int c = 0;
+            if (an && bn) c = 0;
+            else if (an) c = nulls_first ? -1 : 1;
+            else if (bn) c = nulls_first ? 1 : -1;
+            else {
+                c = compare_values(hc, a, b);
+                if (!ascending) c = -c;
+            }
+            if (c != 0) return c;
+        }
+        return 0;
+    }
+
+    static int compare_values(const HostColumn& hc, int64_t a, int64_t b)
+    {
+        switch (hc.type) {
+            case PA_BIGINT: {
+                int64_t x, y;
+                memcpy(&x, &hc.values[(size_t)a * 8], 8);
+                memcpy(&y, &hc.values[(size_t)b * 8], 8);
+                return x < y ? -1 : (x > y ? 1 : 0);
+            }
+            case PA_INTEGER:
+            case PA_DATE: {
+                int32_t x, y;
+                memcpy(&x, &hc.values[(size_t)a * 4], 4);
+                memcpy(&y, &hc.values[(size_t)b * 4], 4);
+                return x < y ? -1 : (x > y ? 1 : 0);
+            }
+            case PA_BOOLEAN: return (int)(hc.values[(size_t)a] != 0) - (int)(hc.values[(size_t)b] != 0);
+            case PA_DOUBLE: {
+                // Double.compare: numeric order, -0.0 < 0.0, NaN (one value) above everything
+                auto image = [&](int64_t r) {
+                    double d;
+                    memcpy(&d, &hc.values[(size_t)r * 8], 8);
+                    uint64_t bits;
+                    if (d != d) bits = 0x7ff8000000000000ULL;
+                    else memcpy(&bits, &d, 8);
+                    return (bits >> 63) ? ~bits : (bits | 0x8000000000000000ULL);
+                };
+                const uint64_t x = image(a), y = image(b);
+                return x < y ? -1 : (x > y ? 1 : 0);
+            }
+            case PA_VARCHAR: {
+                const int32_t ao = hc.offsets[(size_t)a], al = hc.offsets[(size_t)a + 1] - ao;
+                const int32_t bo = hc.offsets[(size_t)b], bl = hc.offsets[(size_t)b + 1] - bo;
+                const int c = memcmp(hc.values.data() + ao, hc.values.data() + bo, (size_t)std::min(al, bl));  // Slice.compareTo
+                if (c != 0) return c < 0 ? -1 : 1;
+                return al < bl ? -1 : (al > bl ? 1 : 0);
+            }
+            default: return 0;
+        }
+    }
+
+    void build_output(const std::vector<int64_t>& order, int64_t m)
+    {
+        hipStream_t s = stream_.get();
+        out_cols_.clear();
+        out_cols_.resize(types_.size());
+        const bool to_device = output_mem_ == PA_MEM_DEVICE;
+        for (size_t c = 0; c < types_.size(); c++) {
+            HostColumn hc;
+            hc.type = types_[c];
+            copy_rows(store_[c], order, m, hc);
+            OutColumn& oc = out_cols_[c];
+            oc.type = types_[c];
+            oc.varwidth = types_[c] == PA_VARCHAR;
+            oc.has_nulls = std::any_of(hc.nulls.begin(), hc.nulls.end(), [](uint8_t v) { return v != 0; });
+            const size_t bytes = hc.values.size();
+            memcpy(oc.h_values.ensure(bytes ? bytes : 1), hc.values.data(), bytes);
+            if (oc.varwidth) memcpy(oc.h_offsets.ensure(hc.offsets.size() * 4), hc.offsets.data(), hc.offsets.size() * 4);
+            if (oc.has_nulls) memcpy(oc.h_nulls.ensure(hc.nulls.size()), hc.nulls.data(), hc.nulls.size());
+            oc.host_ready = true;
+            if (to_device) {
+                oc.values.ensure(bytes ? bytes : 1);
+                if (bytes) PA_HIP(hipMemcpyAsync(oc.values.ptr(), oc.h_values.ptr(), bytes, hipMemcpyHostToDevice, s));
+                if (oc.varwidth) {
+                    oc.offsets.ensure(hc.offsets.size() * 4);
+                    PA_HIP(hipMemcpyAsync(oc.offsets.ptr(), oc.h_offsets.ptr(), hc.offsets.size() * 4, hipMemcpyHostToDevice, s));
+                }
+                if (oc.has_nulls) {
+                    oc.nulls.ensure(hc.nulls.size());
+                    PA_HIP(hipMemcpyAsync(oc.nulls.ptr(), oc.h_nulls.ptr(), hc.nulls.size(), hipMemcpyHostToDevice, s));
+                }
+            }
+        }
+        if (to_device) PA_HIP(hipStreamSynchronize(s));
+    }
+
+    Stream stream_;
+    PageStager stager_;
+    std::vector<int32_t> types_, sort_channels_, sort_orders_;
+    int64_t n_ = 0;
+    int32_t output_mem_ = PA_MEM_HOST;
+    bool finishing_ = false, output_done_ = false;
+    uint64_t threshold_ = ~0ULL;  // rows whose first-channel key is above it cannot be among the N best
+    DevBuf keys_, part_, pos_, counts_, part_temp_, select_temp_, gather_, var_off_, var_bytes_, scan_temp_;
+    PinnedBuf land_, h_hist_buf_;
+    uint32_t* h_hist_ = nullptr;
+    std::vector<HostColumn> store_;
+    std::vector<uint64_t> store_keys_;
+    std::vector<OutColumn> out_cols_;
+    std::vector<pa_column> out_storage_;
+};
+
+}  // namespace
+
+pa_operator* make_topn(const pa_topn_desc* desc)
+{
+    PA_REQUIRE(desc != nullptr, PA_ERR_INVALID_ARGUMENT, "descriptor is null");
+    return new TopNOperator(desc);
+}
+
+}  // namespace pa

@@ -1,0 +1,135 @@
+// topn_kernels.hip -- device side of TopNOperator (core/trino-main/src/main/java/io/trino/operator/TopNOperator.java,
+// TopNProcessor.java, GroupedTopNBuilder.java): the reference keeps a heap of N rows and compares every input row with
+// its root.  Here a page is reduced to the rows that can still be among the N best -- rows whose first sort key is not
+// beyond the N-th best seen so far -- by an order-preserving 64-bit key, a radix selection of the N-th smallest key and
+// a stable compaction; the exact multi-channel comparison of the few survivors is the host's (op_topn.cpp).
+#include <hip/hip_runtime.h>
+
+#include "common.hpp"
+#include "kernels/pa_device.h"
+#include "topn_kernels.hpp"
+
+namespace pa {
+
+namespace {
+
+constexpr int kHistGrid = 1024;
+
+// SortOrder.java: ASC_NULLS_FIRST(0), ASC_NULLS_LAST(1), DESC_NULLS_FIRST(2), DESC_NULLS_LAST(3)
+__device__ __forceinline__ u64 order_key(u64 ascending_image, bool is_null, int sort_order)
+{
+    const bool descending = sort_order >= 2, nulls_first = (sort_order & 1) == 0;
+    if (is_null) return nulls_first ? 0ULL : ~0ULL;
+    return descending ? ~ascending_image : ascending_image;
+}
+
+__global__ __launch_bounds__(256) void k_topn_keys(i32 type, const void* __restrict__ values, const i32* __restrict__ offsets,
+                                                   const u8* __restrict__ nulls, i64 n, i32 sort_order, u64* __restrict__ keys)
+{
+    for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < n; i += (i64)gridDim.x * 256) {
+        const bool is_null = nulls && nulls[i];
+        u64 img = 0;
+        if (!is_null) {
+            switch (type) {
+                case PA_BIGINT: img = (u64)((const i64*)values)[i] ^ 0x8000000000000000ULL; break;
+                case PA_INTEGER:
+                case PA_DATE: img = (u64)(i64)((const i32*)values)[i] ^ 0x8000000000000000ULL; break;
+                case PA_BOOLEAN: img = ((const u8*)values)[i] ? 1ULL : 0ULL; break;
+                case PA_DOUBLE: {
+                    // Double.compare order (DoubleType.compareTo): -0.0 < 0.0, NaN above everything, one NaN
+                    double d = ((const double*)values)[i];
+                    u64 b = d != d ? 0x7ff8000000000000ULL : (u64)__double_as_longlong(d);
+                    img = (b >> 63) ? ~b : (b | 0x8000000000000000ULL);
+                    break;
+                }
+                case PA_VARCHAR: {
+                    // Slice.compareTo = unsigned bytes, shorter first: the first 8 bytes big-endian are a monotone image
+                    const i32 o = offsets[i], len = offsets[i + 1] - o;
+                    const u8* p = (const u8*)values + o;
+                    for (int b = 0; b < 8; b++) img = (img << 8) | (b < len ? (u64)p[b] : 0ULL);
+                    break;
+                }
+                default: break;
+            }
+        }
+        keys[i] = order_key(img, is_null, sort_order);
+    }
+}
+
+// digit histogram of the keys that share the already selected prefix; one 256-bin row per workgroup
+__global__ __launch_bounds__(256) void k_topn_hist(const u64* __restrict__ keys, i64 n, u64 prefix, int shift, int first, u32* __restrict__ slab)
+{
+    __shared__ u32 hist[256];
+    hist[threadIdx.x] = 0;
+    __syncthreads();
+    for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < n; i += (i64)gridDim.x * 256) {
+        const u64 k = keys[i];
+        if (first || (k >> (shift + 8)) == prefix) atomicAdd(&hist[(k >> shift) & 255ULL], 1u);
+    }
+    __syncthreads();
+    slab[(u64)blockIdx.x * 256 + threadIdx.x] = hist[threadIdx.x];
+}
+
+__global__ __launch_bounds__(256) void k_topn_hist_reduce(const u32* __restrict__ slab, int rows, u32* __restrict__ out)
+{
+    u32 sum = 0;
+    for (int r = 0; r < rows; r++) sum += slab[(u64)r * 256 + threadIdx.x];
+    out[threadIdx.x] = sum;
+}
+
+__global__ __launch_bounds__(256) void k_topn_flag(const u64* __restrict__ keys, i64 n, u64 threshold, i32* __restrict__ partition)
+{
+    for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < n; i += (i64)gridDim.x * 256) partition[i] = keys[i] <= threshold ? 0 : 1;
+}
+
+int grid_of(int64_t n) { return (int)std::max<int64_t>(1, std::min<int64_t>((n + 255) / 256, 2048)); }
+
+}  // namespace
+
+void launch_topn_keys(int32_t type, const void* values, const int32_t* offsets, const uint8_t* nulls, int64_t n, int32_t sort_order,
+                      uint64_t* keys, hipStream_t s)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_topn_keys, grid_of(n), 256, 0, s, type, values, (const i32*)offsets, (const u8*)nulls, (i64)n, sort_order, (u64*)keys);
+    PA_HIP(hipGetLastError());
+}
+
+size_t topn_select_temp_bytes() { return (size_t)(kHistGrid + 1) * 256 * 4; }
+
+uint64_t topn_select_kth(const uint64_t* keys, int64_t n, int64_t k, void* temp, uint32_t* host_hist, hipStream_t s)
+{
+    PA_REQUIRE(k >= 1 && k <= n, PA_ERR_INVALID_ARGUMENT, "selection rank out of range");
+    u32* slab = static_cast<u32*>(temp);
+    u32* total = slab + (size_t)kHistGrid * 256;
+    const int grid = (int)std::min<int64_t>(kHistGrid, std::max<int64_t>(1, (n + 255) / 256));
+    uint64_t prefix = 0;
+    int64_t remaining = k;
+    for (int shift = 56; shift >= 0; shift -= 8) {
+        hipLaunchKernelGGL(k_topn_hist, grid, 256, 0, s, (const u64*)keys, (i64)n, (u64)prefix, shift, shift == 56 ? 1 : 0, slab);
+        hipLaunchKernelGGL(k_topn_hist_reduce, 1, 256, 0, s, (const u32*)slab, grid, total);
+        PA_HIP(hipGetLastError());
+        PA_HIP(hipMemcpyAsync(host_hist, total, 256 * 4, hipMemcpyDeviceToHost, s));
+        PA_HIP(hipStreamSynchronize(s));
+        int digit = 255;
+        int64_t before = 0;
+        for (int d = 0; d < 256; d++) {
+            if (before + (int64_t)host_hist[d] >= remaining) {
+                digit = d;
+                break;
+            }
+            before += host_hist[d];
+        }
+        remaining -= before;
+        prefix = (prefix << 8) | (uint64_t)digit;
+    }
+    return prefix;
+}
+
+void launch_topn_flag(const uint64_t* keys, int64_t n, uint64_t threshold, int32_t* partition, hipStream_t s)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_topn_flag, grid_of(n), 256, 0, s, (const u64*)keys, (i64)n, (u64)threshold, partition);
+    PA_HIP(hipGetLastError());
+}
+
+}  // namespace pa

@@ -226,6 +226,25 @@ def FusedAggregationOperator(input_types, filter_expr, projections, group_by_cha
     return Operator(h, keep)
 
 
+def TopNOperator(input_types, n, sort_channels, sort_orders, output_mem=abi.MEM_HOST, stream=None):
+    """TopNOperator.createOperatorFactory (…/operator/TopNOperator.java:43-90)."""
+    d = abi.pa_topn_desc()
+    types = abi.int32_array(input_types)
+    sc = abi.int32_array(sort_channels)
+    so = abi.int32_array(sort_orders)
+    d.input_channel_count = len(input_types)
+    d.input_types = C.cast(types, C.POINTER(C.c_int32))
+    d.n = n
+    d.sort_channel_count = len(sort_channels)
+    d.sort_channels = C.cast(sc, C.POINTER(C.c_int32))
+    d.sort_orders = C.cast(so, C.POINTER(C.c_int32))
+    d.output_mem = output_mem
+    d.stream = stream
+    h = C.c_void_p()
+    check(lib().pa_topn_create(C.byref(d), C.byref(h)))
+    return Operator(h, [types, sc, so])
+
+
 class LookupSourceFactory:
     """JoinBridge between a HashBuilderOperator and its LookupJoinOperators
     (…/operator/join/PartitionedLookupSourceFactory.java, JoinBridgeManager.java)."""

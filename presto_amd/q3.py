@@ -5,6 +5,7 @@
                                                     [-> exchange by orderkey] -> HashBuilder(b2)
     lineitem -> FilterAndProject(shipdate > DATE; orderkey, revenue) [-> exchange by orderkey] -> LookupJoin(b2)
              -> HashAggregation(orderkey, orderdate, shippriority; sum(revenue), count(*))
+             [-> TopN(10; revenue DESC, orderdate ASC)]      the query's ORDER BY ... LIMIT 10, when asked for
 
 The bracketed steps exist when the process group has more than one rank: they are the reference's hash-partitioned
 exchange between the stages of a distributed join (PartitionedOutputOperator.java:411-431 routing rule,
@@ -22,7 +23,7 @@ from . import abi, tpch
 from .exchange import DeviceOps, exchange_columns
 from .expr import field
 from .operators import (Driver, FilterAndProjectOperator, HashAggregationOperator, HashBuilderOperator, LookupJoinOperator,
-                        LookupSourceFactory)
+                        LookupSourceFactory, TopNOperator)
 from .page import Block, DeviceBuffer, Page
 
 _TORCH_DTYPE = {abi.BIGINT: torch.int64, abi.INTEGER: torch.int32, abi.DATE: torch.int32, abi.DOUBLE: torch.float64,
@@ -134,13 +135,15 @@ AGG_TYPES = [abi.BIGINT, abi.DOUBLE, abi.DATE, abi.INTEGER]       # lineitem JOI
 AGG_GROUP_BY = [0, 2, 3]
 AGG_AGGREGATES = [(abi.AGG_SUM, 1, abi.DOUBLE), (abi.AGG_COUNT_STAR, -1, None)]
 ORDERS_JOINED_TYPES = [abi.BIGINT, abi.DATE, abi.INTEGER]           # orders JOIN customer: orderkey, orderdate, shippriority
+RESULT_TYPES = [abi.BIGINT, abi.DATE, abi.INTEGER, abi.DOUBLE, abi.BIGINT]  # orderkey, orderdate, shippriority, revenue, count
 
 
 def run(customer_pages, orders_pages, lineitem_pages, stream, group=None, ops=None, device=None, expected_groups=100000,
-        distributed=None, result_mem=abi.MEM_HOST):
+        distributed=None, result_mem=abi.MEM_HOST, top_n=0):
     """Runs the three pipelines on this rank's pages; returns (result pages, counters).  `stream` is the HIP stream
     handle every operator (and the exchange) runs on; result_mem = where the grouped result is left (PA_MEM_DEVICE
-    when a device operator, e.g. the TopN of the full query, consumes it)."""
+    when a device operator consumes it).  top_n > 0 appends the query's TopN (revenue DESC, orderdate ASC): every rank then
+    returns its own top_n rows -- the groups of different ranks are disjoint, so the query result is the top_n of their union."""
     if distributed is None:
         distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
     dev = abi.MEM_DEVICE
@@ -181,12 +184,14 @@ def run(customer_pages, orders_pages, lineitem_pages, stream, group=None, ops=No
     # pipeline 3
     # orderkey is unique on the build side, so its row count bounds the groups (what the planner's stats estimate)
     expected_groups = max(expected_groups, min(b2.positionCount(), 1 << 28))
-    agg = HashAggregationOperator(AGG_TYPES, AGG_GROUP_BY, AGG_AGGREGATES, expected_groups=expected_groups, output_mem=result_mem, stream=s)
+    agg = HashAggregationOperator(AGG_TYPES, AGG_GROUP_BY, AGG_AGGREGATES, expected_groups=expected_groups,
+                                  output_mem=dev if top_n else result_mem, stream=s)
     out = Driver(lineitem_pages, [
         FilterAndProjectOperator(tpch.Q3_LINEITEM_TYPES, tpch.q3_lineitem_filter(), tpch.q3_lineitem_projections(), output_mem=dev, stream=s),
         *exchange([abi.BIGINT, abi.DOUBLE], [0]),
         LookupJoinOperator(b2, [abi.BIGINT, abi.DOUBLE], [0], [0, 1], output_mem=dev, stream=s),
-        agg]).run()
+        agg,
+        *([TopNOperator(RESULT_TYPES, top_n, [3, 1], [abi.DESC_NULLS_LAST, abi.ASC_NULLS_LAST], output_mem=result_mem, stream=s)] if top_n else [])]).run()
     lap("lineitem_pipeline")
     counters["build1_rows"] = b1.positionCount()
     counters["build2_rows"] = b2.positionCount()

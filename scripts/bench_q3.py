@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--backend", default="nccl")
     ap.add_argument("--force-exchange", action="store_true", help="run the exchange steps even with one rank")
+    ap.add_argument("--top-n", type=int, default=10, help="the query's ORDER BY revenue DESC, orderdate LIMIT n (0 = stop at the grouped result)")
     args = ap.parse_args()
 
     import torch
@@ -50,7 +51,8 @@ def main():
 
     def step():
         out, counters = q3.run(customer.pages(args.page_rows - args.page_rows % 20), orders.pages(args.page_rows),
-                               lineitem.pages(args.page_rows), stream.handle, distributed=distributed, result_mem=abi.MEM_DEVICE)
+                               lineitem.pages(args.page_rows), stream.handle, distributed=distributed,
+                               result_mem=abi.MEM_HOST if args.top_n else abi.MEM_DEVICE, top_n=args.top_n)
         groups = sum(p.position_count for p in out)
         return groups, counters
 
@@ -82,10 +84,10 @@ def main():
             "metric": "rows/s through the TPC-H Q3 operator pipelines (customer+orders+lineitem input rows)",
             "value": rows * world * args.steps / elapsed, "unit": "rows/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "scaling": "weak", "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "TPC-H SF%g Q3: 2 hash joins + grouped sum, %d-row pages, exchange steps %s" %
-                                   (args.sf, args.page_rows, "on" if distributed else "off (one rank)"),
+            "config": {"workload": "TPC-H SF%g Q3: 2 hash joins + grouped sum%s, %d-row pages, exchange steps %s" %
+                                   (args.sf, " + top %d" % args.top_n if args.top_n else "", args.page_rows, "on" if distributed else "off (one rank)"),
                        "rows_per_gpu": {"customer": nc, "orders": no, "lineitem": nl}},
-            "rank0": {"groups": groups, **counters}}))
+            "rank0": {"result_rows": groups, **counters}}))
     stream.destroy()
     if dist.is_initialized():
         dist.destroy_process_group()

@@ -252,3 +252,12 @@ def test_merge_pages_selective_filter_with_nulls_and_varchar(gpu, oracle):
         assert len(got) == len(expected)
         assert bits([r for p in got for r in p]) == bits([r for p in expected for r in p])
         assert [len(p) for p in got] == [len(p) for p in expected]
+
+
+def test_fp2_merge_output_kat(gpu):
+    """TestFilterAndProjectOperator.testMergeOutput (…/TestFilterAndProjectOperator.java:126-161)"""
+    page = sequence_page(100, [(abi.VARCHAR, 0), (abi.BIGINT, 0)])
+    op = FilterAndProjectOperator([abi.VARCHAR, abi.BIGINT], field(1, abi.BIGINT).eq(10), [field(1, abi.BIGINT)],
+                                  min_output_page_size=64 * 1024, min_output_page_row_count=2)
+    out = to_pages(op, [page] * 4)
+    assert [p.to_rows() for p in out] == [[(10,)] * 4]

@@ -96,3 +96,24 @@ def test_q3_with_exchange_steps_on_one_rank_over_rccl(gpu, oracle):
         stream.destroy()
     finally:
         dist.destroy_process_group()
+
+
+def test_q3_with_topn(gpu, oracle):
+    """The whole query: ... GROUP BY ... ORDER BY revenue DESC, orderdate LIMIT 10 (TopNOperator behind the aggregation)."""
+    from presto_amd import q3
+    sf, page_rows = 0.1, 1 << 17
+    expected, _, _ = _expected(oracle, sf)
+    # oracle TopN over the oracle's grouped result: rows are (orderkey, orderdate, shippriority, revenue, count)
+    from presto_amd.page import Block, Page
+    cols = list(zip(*expected))
+    page = Page([Block.bigint(cols[0]), Block.date(cols[1]), Block.integer(cols[2]), Block.double(cols[3]), Block.bigint(cols[4])], len(expected))
+    top = oracle.topn([page], 10, [3, 1], [abi.DESC_NULLS_LAST, abi.ASC_NULLS_LAST])
+    stream = DeviceStream()
+    customer, orders, lineitem = _device_tables(sf)
+    out, _ = q3.run(customer.pages(page_rows - page_rows % 20), orders.pages(page_rows), lineitem.pages(page_rows), stream.handle,
+                    distributed=False, top_n=10)
+    rows = [r for p in out for r in p.to_rows()]
+    assert len(rows) == 10
+    for g, e in zip(rows, top):
+        assert g[:3] == e[:3] and g[4] == e[4] and abs(g[3] - e[3]) <= 1e-9 * abs(e[3])
+    stream.destroy()

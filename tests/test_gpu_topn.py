@@ -1,0 +1,85 @@
+"""TopNOperator on device against the reference's known answers (core/trino-main/src/test/java/io/trino/operator/
+TestTopNOperator.java:77-182) and the oracle's restatement on random pages (every type as first sort key, NULL
+placement, ties on the first key resolved by the second)."""
+import numpy as np
+import pytest
+
+from presto_amd import abi
+from presto_amd.operators import TopNOperator, download_page, to_pages
+from presto_amd.page import Block, Page
+
+pytestmark = pytest.mark.gpu
+
+
+def rows_of(pages):
+    return [r for p in pages for r in p.to_rows()]
+
+
+def test_topn_kats(gpu, oracle):
+    pages = [Page([Block.bigint([1, 2]), Block.double([0.1, 0.2])]), Page([Block.bigint([-1, 4]), Block.double([-0.1, 0.4])]),
+             Page([Block.bigint([5, 4, 6]), Block.double([0.5, 0.41, 0.6])])]
+    types = [abi.BIGINT, abi.DOUBLE]
+    # testSingleFieldKey (:77-104)
+    assert rows_of(to_pages(TopNOperator(types, 2, [0], [abi.DESC_NULLS_LAST]), pages)) == [(6, 0.6), (5, 0.5)]
+    # testReverseOrder (:136-164)
+    assert rows_of(to_pages(TopNOperator(types, 2, [0], [abi.ASC_NULLS_LAST]), pages)) == [(-1, -0.1), (1, 0.1)]
+    # testMultiFieldKey (:106-134)
+    vp = [Page([Block.varchar(["a", "b"]), Block.bigint([1, 2])]), Page([Block.varchar(["f", "a"]), Block.bigint([3, 4])]),
+          Page([Block.varchar(["d", "d", "e"]), Block.bigint([5, 7, 6])])]
+    got = rows_of(to_pages(TopNOperator([abi.VARCHAR, abi.BIGINT], 3, [0, 1], [abi.DESC_NULLS_LAST, abi.DESC_NULLS_LAST]), vp))
+    assert got == [(b"f", 3), (b"e", 6), (b"d", 7)]
+    # testLimitZero (:166-182)
+    op = TopNOperator([abi.BIGINT], 0, [0], [abi.DESC_NULLS_LAST])
+    assert op.getOutput() is None and op.isFinished() and not op.needsInput() and op.getOutput() is None
+    # the oracle agrees on the same inputs
+    assert oracle.topn(pages, 2, [0], [abi.DESC_NULLS_LAST]) == [(6, 0.6), (5, 0.5)]
+    assert oracle.topn(vp, 3, [0, 1], [abi.DESC_NULLS_LAST] * 2) == got
+
+
+@pytest.mark.parametrize("first", ["bigint", "double", "varchar", "date", "boolean"])
+@pytest.mark.parametrize("order", [abi.ASC_NULLS_FIRST, abi.ASC_NULLS_LAST, abi.DESC_NULLS_FIRST, abi.DESC_NULLS_LAST])
+def test_topn_matches_oracle(gpu, oracle, first, order):
+    rng = np.random.default_rng(hash((first, order)) % 2 ** 32)
+    words = [b"", b"a", b"ab", b"abcdefgh", b"abcdefghX", b"abcdefghY", b"zz", b"\xc3\xa9", None]
+    pages = []
+    for _ in range(5):
+        n = int(rng.integers(1, 30000))
+        nulls = rng.random(n) < 0.02
+        if first == "bigint":
+            k = Block.bigint(rng.integers(-2 ** 62, 2 ** 62, n), nulls)
+        elif first == "double":
+            v = rng.standard_normal(n) * 1e3
+            v[rng.random(n) < 0.01] = np.nan
+            v[rng.random(n) < 0.01] = -0.0
+            v[rng.random(n) < 0.01] = 0.0
+            k = Block.double(v, nulls)
+        elif first == "varchar":
+            k = Block.varchar([words[j] for j in rng.integers(0, len(words), n)])
+        elif first == "date":
+            k = Block.date(rng.integers(8000, 8100, n), nulls)     # few distinct values: many ties on the first key
+        else:
+            k = Block.boolean(rng.random(n) < 0.5, nulls)
+        pages.append(Page([k, Block.integer(rng.permutation(n).astype(np.int32) + 1000000 * len(pages)), Block.double(rng.random(n))], n))
+    types = [pages[0].blocks[0].type, abi.INTEGER, abi.DOUBLE]
+    for limit in (1, 10, 2500):
+        orders = [order, abi.DESC_NULLS_LAST]   # the second channel is unique: no fully tied rows
+        expected = oracle.topn(pages, limit, [0, 1], orders)
+        got = rows_of(to_pages(TopNOperator(types, limit, [0, 1], orders), pages))
+        assert len(got) == len(expected)
+        for g, e in zip(got, expected):
+            assert g[1] == e[1] and g[2] == e[2], (g, e)
+            assert g[0] == e[0] or (isinstance(e[0], float) and np.isnan(e[0]) and np.isnan(g[0]))
+
+
+def test_topn_device_pages_and_device_output(gpu, oracle):
+    from presto_amd.operators import upload_page
+    rng = np.random.default_rng(3)
+    pages = [Page([Block.double(rng.random(200000)), Block.bigint(np.arange(200000) + 200000 * i)], 200000) for i in range(3)]
+    op = TopNOperator([abi.DOUBLE, abi.BIGINT], 10, [0, 1], [abi.DESC_NULLS_LAST, abi.ASC_NULLS_LAST], output_mem=abi.MEM_DEVICE)
+    dev_pages = [upload_page(p) for p in pages]
+    for p in dev_pages:
+        op.addInput(p)
+    op.finish()
+    out = download_page(op.getOutput())
+    assert out.to_rows() == oracle.topn(pages, 10, [0, 1], [abi.DESC_NULLS_LAST, abi.ASC_NULLS_LAST])
+    assert op.isFinished()

@@ -16,14 +16,16 @@ def test_fp1_filter_and_project(oracle):
     assert out.to_rows() == [(str(i).encode(), i + 5) for i in range(10)]
 
 
-def test_fp2_same_value_pages(oracle):
-    """…/TestFilterAndProjectOperator.java:126-161: 4 x the same page, filter c1 = 10, project c1 -> [10,10,10,10]"""
+def test_fp2_merge_output(oracle):
+    """TestFilterAndProjectOperator.testMergeOutput (…/TestFilterAndProjectOperator.java:126-161): 4 x the same page,
+    filter c1 = 10, project c1, minOutputPageSize 64 kB / minOutputPageRowCount 2 -> ONE page [10,10,10,10]"""
     page = sequence_page(100, [(abi.VARCHAR, 0), (abi.BIGINT, 0)])
-    rows = []
+    merge = oracle.MergePages(64 * 1024, 2)
+    out = []
     for _ in range(4):
-        out = oracle.filter_project(page, field(1, abi.BIGINT).eq(10), [field(1, abi.BIGINT)])
-        rows += out.to_rows()
-    assert rows == [(10,)] * 4
+        out += merge.process(oracle.filter_project(page, field(1, abi.BIGINT).eq(10), [field(1, abi.BIGINT)]))
+    out += merge.finish()
+    assert [p.to_rows() for p in out] == [[(10,)] * 4]
 
 
 def test_page_processor_selection_shapes(oracle):
