@@ -146,19 +146,33 @@ void launch_join_build(const JoinKeys& build, const int64_t* raw_hash, int32_t n
     PA_HIP(hipGetLastError());
 }
 
+// Probe-side copy of PagesHash.key[] with the upper half of the mixed hash next to the build position: a probe that
+// meets another key's slot moves on without touching the build rows (the reference's positionToHashes byte filter,
+// PagesHash.java:85-90,182-196, kept inside the slot so that a mismatch costs no second random access).
+__global__ __launch_bounds__(256) void k_join_tag_slots(const i32* __restrict__ key, i64 hash_size, const i64* __restrict__ raw_hash,
+                                                        u64* __restrict__ tagged)
+{
+    for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < hash_size; i += (i64)gridDim.x * 256) {
+        const i32 p = key[i];
+        tagged[i] = p == -1 ? ~0ULL : (((u64)pa_murmur3_fmix((u64)raw_hash[p]) & 0xffffffff00000000ULL) | (u64)(u32)p);
+    }
+}
+
 __global__ __launch_bounds__(256) void k_join_probe_count(JoinKeys build, JoinKeys probe, const i64* __restrict__ probe_hash, i32 n_probe,
-                                                          const i32* __restrict__ key, u32 mask, const i32* __restrict__ links,
+                                                          const u64* __restrict__ tagged, u32 mask, const i32* __restrict__ links,
                                                           i32* __restrict__ head, i32* __restrict__ counts)
 {
     for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < n_probe; i += (i64)gridDim.x * 256) {
         const i32 r = (i32)i;
         i32 h = -1;
         if (!keys_have_null(probe, r)) {  // JoinProbe.java:89-91
-            u32 pos = (u32)pa_murmur3_fmix((u64)probe_hash[r]) & mask;
+            const u64 mixed = (u64)pa_murmur3_fmix((u64)probe_hash[r]);
+            u32 pos = (u32)mixed & mask;
             for (u32 probes = 0; probes <= mask; probes++) {
-                i32 cur = key[pos];
+                const u64 t = tagged[pos];
+                const i32 cur = (i32)(u32)t;
                 if (cur == -1) break;
-                if (keys_equal(build, cur, probe, r)) {
+                if (((t ^ mixed) >> 32) == 0ULL && keys_equal(build, cur, probe, r)) {
                     h = cur;
                     break;
                 }
@@ -186,12 +200,17 @@ __global__ __launch_bounds__(256) void k_join_probe_emit(const i32* __restrict__
     }
 }
 
-void launch_join_probe_count(const JoinKeys& build, const JoinKeys& probe, const int64_t* probe_hash, int32_t n_probe, const int32_t* key,
+void launch_join_tag_slots(const int32_t* key, int64_t hash_size, const int64_t* raw_hash, uint64_t* tagged, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_join_tag_slots, grid_for(hash_size), 256, 0, s, key, (i64)hash_size, (const i64*)raw_hash, (u64*)tagged);
+    PA_HIP(hipGetLastError());
+}
+void launch_join_probe_count(const JoinKeys& build, const JoinKeys& probe, const int64_t* probe_hash, int32_t n_probe, const uint64_t* tagged,
                              uint32_t mask, const int32_t* links, int32_t* head, int32_t* counts, hipStream_t s)
 {
     if (n_probe <= 0) return;
-    hipLaunchKernelGGL(k_join_probe_count, grid_for(n_probe), 256, 0, s, build, probe, (const i64*)probe_hash, n_probe, key, mask, links, head,
-                       counts);
+    hipLaunchKernelGGL(k_join_probe_count, grid_for(n_probe), 256, 0, s, build, probe, (const i64*)probe_hash, n_probe, (const u64*)tagged, mask,
+                       links, head, counts);
     PA_HIP(hipGetLastError());
 }
 void launch_join_probe_emit(const int32_t* head, const int32_t* offsets, int32_t n_probe, const int32_t* links, int32_t* probe_idx,

@@ -36,7 +36,7 @@ struct LookupSourceImpl {
     int32_t n = 0;
     std::vector<int> join_channels, output_channels;
     int hash_channel = -1;
-    DevBuf key, links, raw_hash, slot_of;
+    DevBuf key, links, raw_hash, slot_of, tagged;
     uint32_t mask = 0;
     std::atomic<bool> built{false};
     std::atomic<int32_t> error{0};
@@ -195,6 +195,8 @@ public:
         timer.begin(s);
         launch_join_build(bk, ls_->raw_hash.as<int64_t>(), n, ls_->key.as<int32_t>(), ls_->mask, ls_->slot_of.as<int32_t>(), ls_->links.as<int32_t>(),
                           ctl_, s);
+        launch_join_tag_slots(ls_->key.as<int32_t>(), (int64_t)hash_size, ls_->raw_hash.as<int64_t>(),
+                              static_cast<uint64_t*>(ls_->tagged.ensure((size_t)hash_size * 8)), s);
         timer.end(s);
         int32_t err = 0;
         PA_HIP(hipMemcpyAsync(&err, ctl_, 4, hipMemcpyDeviceToHost, s));
@@ -208,7 +210,7 @@ public:
     bool is_finished() override { return finishing_; }
     int64_t memory_bytes() override
     {
-        int64_t b = (int64_t)(ls_->key.capacity() + ls_->links.capacity() + ls_->raw_hash.capacity() + ls_->slot_of.capacity());
+        int64_t b = (int64_t)(ls_->key.capacity() + ls_->links.capacity() + ls_->raw_hash.capacity() + ls_->slot_of.capacity() + ls_->tagged.capacity());
         for (const auto& c : ls_->cols) b += (int64_t)(c.values.capacity() + c.offsets.capacity() + c.nulls.capacity());
         return b;
     }
@@ -303,7 +305,7 @@ public:
         int32_t* head = static_cast<int32_t*>(head_.ensure((size_t)n * 4));
         int32_t* counts = static_cast<int32_t*>(counts_.ensure((size_t)n * 4));
         timer.begin(s);
-        launch_join_probe_count(ls_->build_keys(), pk, probe_hash, n, ls_->key.as<int32_t>(), ls_->mask, ls_->links.as<int32_t>(), head, counts, s);
+        launch_join_probe_count(ls_->build_keys(), pk, probe_hash, n, ls_->tagged.as<uint64_t>(), ls_->mask, ls_->links.as<int32_t>(), head, counts, s);
         launch_exclusive_scan_i32(counts, counts, n, ctl_, scan_temp_.ensure(scan_temp_bytes(n)), s);
         timer.end(s);
         PA_HIP(hipMemcpyAsync(h_ctl_, ctl_, 4, hipMemcpyDeviceToHost, s));
