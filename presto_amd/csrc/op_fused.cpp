@@ -485,7 +485,7 @@ KernelInfo generate(const Spec& s, const std::vector<ChannelLayout>& layout, int
         src << "u64 miss = __ballot(sel && g < 0);\nwhile (miss != 0ULL) {\n  const int src_lane = __builtin_amdgcn_readfirstlane(__ffsll((long long)miss) - 1);\n"
                "  u64 nk[PA_KW];\n#pragma unroll\n  for (int w = 0; w < PA_KW; w++) nk[w] = pa_readlane_u64(key[w], src_lane);\n"
                "  const int slot = acc.tcount;\n  if (slot < PA_C) {\n#pragma unroll\n    for (int s = 0; s < PA_C; s++) {\n      if (s == slot) {\n#pragma unroll\n"
-               "        for (int w = 0; w < PA_KW; w++) acc.tk[s][w] = nk[w];\n      }\n    }\n    acc.tcount = slot + 1;\n  }\n"
+               "        for (int w = 0; w < PA_KW; w++) acc.tk[s][w] = nk[w];\n      }\n    }\n    acc.tcount = slot + 1;\n  } else {\n    acc.tcount = PA_C + 1;\n  }\n"
                "  bool mine = sel && g == -1;\n#pragma unroll\n  for (int w = 0; w < PA_KW; w++) mine = mine && (key[w] == nk[w]);\n"
                "  if (mine) g = slot < PA_C ? slot : -2;\n  miss = __ballot(sel && g == -1);\n}\n";
         src << "if (sel) {\n  if (g >= 0) {\n";
@@ -502,7 +502,10 @@ KernelInfo generate(const Spec& s, const std::vector<ChannelLayout>& layout, int
                     << ", __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);\n";
             }
         }
-        src << "  } else {\n    atomicAdd((unsigned long long*)a.overflow_rows, 1ULL);\n  }\n}\n";
+        // a row whose group found no slot: the wave has marked its table as overflowed (tcount = PA_C + 1, set in the loop
+        // above) and reports once at the end of the kernel; the launch is discarded as a whole.  (A per-row atomic on the
+        // one overflow counter would serialise the useless pass on a single address: 3 ms instead of 0.25 ms per 64 M rows.)
+        src << "  }\n}\n";
     }
     else {
         src << "if (sel) {\n  const u32 h = pa_key_hash(key, PA_KW);\n";
@@ -634,6 +637,7 @@ KernelInfo generate(const Spec& s, const std::vector<ChannelLayout>& layout, int
         else if (variant == V_LDS) {
             // per-wave partial table -> slab, field-major: field f of entry e = blockIdx.x * C + i at slab[f * E + e]
             src << "    __syncthreads();\n";
+            src << "    if (acc.tcount > PA_C && threadIdx.x == 0) atomicAdd((unsigned long long*)a.overflow_rows, 1ULL);\n";
             src << "    const u64 E = (u64)gridDim.x * PA_C;\n";
             src << "#pragma unroll\n    for (int i = 0; i < PA_C; i++) {\n        u64* e = a.slab + (u64)blockIdx.x * PA_C + i;\n";
             src << "        const bool occ = i < acc.tcount;\n        if (threadIdx.x == 0) e[0] = occ ? 1ULL : 0ULL;\n        if (occ) {\n";
