@@ -573,7 +573,16 @@ KernelInfo generate(const Spec& s, const std::vector<ChannelLayout>& layout, int
             src << "    PaAcc acc; acc.tv = pa_gt_view(a, PA_KW, PA_NW); acc.gt = pa_gt_ctr_init(acc.tv.count, true, a.gt_rep_mask + 1u);\n";
         }
         if (mode != 2) emit_prologue(ri, layout, src);
-        src << "    const i64 t = (i64)blockIdx.x * " << B << " + threadIdx.x, T = (i64)gridDim.x * " << B << ";\n";
+        if (variant == V_GLOBAL) {
+            // XCD-aware block -> tile mapping: consecutive workgroup ids go round-robin to the 8 XCDs, so give the
+            // workgroups of one XCD consecutive tiles (each XCD's L2 / TLB then walks one contiguous eighth of every grid
+            // stride).  Measured on Q6: 0.75 -> 0.79 of the HBM peak; neutral for the one-wave workgroups of the LDS variant.
+            src << "    const u32 bsw = (gridDim.x & 7u) == 0u ? (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x;\n"
+                   "    const i64 t = (i64)bsw * " << B << " + threadIdx.x, T = (i64)gridDim.x * " << B << ";\n";
+        }
+        else {
+            src << "    const i64 t = (i64)blockIdx.x * " << B << " + threadIdx.x, T = (i64)gridDim.x * " << B << ";\n";
+        }
         std::string args[4];
         if (mode == 1) {
             src << "    const i64 nq = a.n >> 2;  // the host passes a multiple of 256 rows\n";
