@@ -115,7 +115,7 @@ def main():
             dist.init_process_group(args.backend)
 
     from presto_amd import _lib, abi, tpch
-    from presto_amd.operators import FusedAggregationOperator
+    from presto_amd.operators import FusedAggregationOperatorFactory
     _lib.init(device)
 
     rows = tpch.lineitem_rows(args.sf)
@@ -144,14 +144,17 @@ def main():
     ktime = {"q6": [0.0, 0], "q1": [0.0, 0]}
     results = {}
 
+    # the planner's part, once per query plan: OperatorFactory objects holding the serialised descriptors
+    # (LocalExecutionPlanner builds the factories; every Driver then calls createOperator)
+    factories = {
+        "q6": FusedAggregationOperatorFactory(tpch.Q6_TYPES, tpch.q6_filter(), tpch.q6_projections(), [], tpch.Q6_AGGREGATES),
+        "q1": FusedAggregationOperatorFactory(tpch.Q1_TYPES, tpch.q1_filter(), tpch.q1_projections(), tpch.Q1_GROUP_BY,
+                                              tpch.Q1_AGGREGATES, type_params=tpch.Q1_TYPE_PARAMS),
+    }
+
     def run_query(name, timed):
-        if name == "q6":
-            op = FusedAggregationOperator(tpch.Q6_TYPES, tpch.q6_filter(), tpch.q6_projections(), [], tpch.Q6_AGGREGATES)
-            pages = q6_pages
-        else:
-            op = FusedAggregationOperator(tpch.Q1_TYPES, tpch.q1_filter(), tpch.q1_projections(), tpch.Q1_GROUP_BY,
-                                          tpch.Q1_AGGREGATES, type_params=tpch.Q1_TYPE_PARAMS)
-            pages = q1_pages
+        op = factories[name].createOperator()  # a fresh operator per pass: operators are single-use
+        pages = q6_pages if name == "q6" else q1_pages
         for p in pages:
             op.addInput(p)
         op.finish()

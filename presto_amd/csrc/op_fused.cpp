@@ -20,6 +20,8 @@
 #include <algorithm>
 #include <cmath>
 #include <map>
+#include <memory>
+#include <mutex>
 #include <sstream>
 
 #include "exprgen.hpp"
@@ -688,6 +690,17 @@ public:
         : spec_(make_spec(d)), stream_(d->aggregation.stream ? d->aggregation.stream : d->filter_project.stream)
     {
         require_device();
+        {
+            std::ostringstream f;
+            for (int c = 0; c < spec_.n_in; c++) f << spec_.in_types[c] << ',' << spec_.in_params[c] << ';';
+            f << '|' << (spec_.has_filter ? spec_.filter.fingerprint() : std::string("-")) << '|';
+            for (const auto& p : spec_.proj) f << p.fingerprint() << '#';
+            f << '|';
+            for (int g : spec_.group_proj) f << g << ',';
+            f << '|' << spec_.hash_channel << '|' << spec_.step << '|';
+            for (const auto& a : spec_.aggs) f << a.fn << ',' << a.input_channel << ',' << a.mask_channel << ',' << a.input_type << ';';
+            plan_fingerprint_ = f.str();
+        }
         grouped_ = !spec_.group_proj.empty();
         // the planner's estimate decides where a grouped aggregation starts: the few-groups register/LDS variant (a page
         // that overflows it is redone on the HBM table), or directly the HBM table when many groups are expected
@@ -772,37 +785,73 @@ public:
     }
 
 private:
+    // One code object + word-kind table per (plan fingerprint, column-layout signature, variant, device), shared by every
+    // operator instance of the process: an operator lives for one query (OperatorFactory.createOperator), the generated
+    // code for its plan node does not change -- re-generating ~30 KB of source and hashing it per instance cost ~0.1 ms.
     struct Compiled {
         KernelInfo info;
         JitKernel kernel, tail_kernel;
         DevBuf kinds;
     };
+    static std::shared_ptr<const Compiled> shared_lookup(const std::string& key)
+    {
+        std::lock_guard<std::mutex> lock(shared_mutex());
+        auto it = shared_cache().find(key);
+        return it == shared_cache().end() ? nullptr : it->second;
+    }
+    static std::mutex& shared_mutex()
+    {
+        static std::mutex* m = new std::mutex();
+        return *m;
+    }
+    static std::map<std::string, std::shared_ptr<const Compiled>>& shared_cache()
+    {
+        static auto* c = new std::map<std::string, std::shared_ptr<const Compiled>>();  // leaked: HIP may be gone at exit
+        return *c;
+    }
 
     const Compiled& kernel_for(const std::string& sig, const std::vector<ChannelLayout>& layout, int variant)
     {
         std::string key = sig + "|" + std::to_string(variant);
         auto it = compiled_.find(key);
         if (it != compiled_.end()) return *it->second;
-        auto c = std::make_unique<Compiled>();
+        int dev = 0;
+        PA_HIP(hipGetDevice(&dev));
+        const std::string shared_key = std::to_string(dev) + "|" + key + "|" + plan_fingerprint_;
+        if (auto hit = shared_lookup(shared_key)) {
+            adopt_layout(*hit);
+            compiled_[key] = hit;
+            return *hit;
+        }
+        auto c = std::make_shared<Compiled>();
         c->info = generate(spec_, layout, variant);
         c->kernel = jit_get(c->info.source, c->info.entry);
         if (variant == V_LDS) c->tail_kernel = jit_get(c->info.source, "pa_fused_tail");
         c->kinds.ensure(sizeof(int32_t) * c->info.word_kind.size());
         PA_HIP(hipMemcpyAsync(c->kinds.ptr(), c->info.word_kind.data(), sizeof(int32_t) * c->info.word_kind.size(), hipMemcpyHostToDevice, stream_.get()));
         PA_HIP(hipStreamSynchronize(stream_.get()));
-        if (!kinds_dev_) kinds_dev_ = c->kinds.as<int32_t>();
+        adopt_layout(*c);
+        {
+            std::lock_guard<std::mutex> lock(shared_mutex());
+            shared_cache()[shared_key] = c;
+        }
+        const Compiled& ref = *c;
+        compiled_[key] = std::move(c);
+        return ref;
+    }
+
+    void adopt_layout(const Compiled& c)
+    {
+        if (!kinds_dev_) kinds_dev_ = c.kinds.as<int32_t>();
         if (!layout_fixed_) {
-            nw_ = c->info.nw;
-            w_ = c->info.w;
+            nw_ = c.info.nw;
+            w_ = c.info.w;
             layout_fixed_ = true;
         }
         // every signature of one operator must yield the same state layout: nullable inputs add count
         // words / null flags, and states of different layouts cannot be merged
-        PA_REQUIRE(c->info.nw == nw_ && c->info.w == w_, PA_ERR_NOT_SUPPORTED,
+        PA_REQUIRE(c.info.nw == nw_ && c.info.w == w_, PA_ERR_NOT_SUPPORTED,
                    "pages of one operator changed nullability in a way that changes the accumulator layout");
-        const Compiled& ref = *c;
-        compiled_[key] = std::move(c);
-        return ref;
     }
 
     // replicas wanted for a table of g groups: enough distinct accumulator addresses (>= ~2^17) for the atomics of a
@@ -1083,7 +1132,8 @@ private:
     Spec spec_;
     Stream stream_;
     PageStager stager_;
-    std::map<std::string, std::unique_ptr<Compiled>> compiled_;
+    std::map<std::string, std::shared_ptr<const Compiled>> compiled_;
+    std::string plan_fingerprint_;
     bool grouped_ = false, finishing_ = false, output_done_ = false, layout_fixed_ = false;
     int mode_ = V_GLOBAL, cus_ = 256, nw_ = 0, w_ = 0;
     DevBuf ctl_buf_;
@@ -1216,7 +1266,7 @@ void FusedAggregationOperator::build_output()
     if (compiled_.empty()) {
         std::vector<ChannelLayout> layout(spec_.n_in);
         for (int c = 0; c < spec_.n_in; c++) layout[c].type = spec_.in_types[c];
-        auto c = std::make_unique<Compiled>();
+        auto c = std::make_shared<Compiled>();
         c->info = generate(spec_, layout, grouped_ ? V_GT : V_GLOBAL);
         nw_ = c->info.nw;
         w_ = c->info.w;

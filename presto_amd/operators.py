@@ -218,12 +218,28 @@ def HashAggregationOperator(input_types, group_by_channels, aggregates, hash_cha
     return Operator(h, keep)
 
 
+class OperatorFactory:
+    """OperatorFactory (core/trino-main/src/main/java/io/trino/operator/OperatorFactory.java:18-50): built once per plan
+    node by the planner -- the descriptor (types, serialised RowExpressions, aggregates) is made here, once --
+    createOperator() is then called per Driver and only hands the descriptor to the native factory."""
+
+    def __init__(self, create, desc, keep):
+        self._create, self._desc, self._keep = create, desc, keep
+
+    def createOperator(self):
+        h = C.c_void_p()
+        check(self._create(C.byref(self._desc), C.byref(h)))
+        return Operator(h, self._keep)
+
+
+def FusedAggregationOperatorFactory(input_types, filter_expr, projections, group_by_channels, aggregates, **kw):
+    d, keep = fused_aggregation_desc(input_types, filter_expr, projections, group_by_channels, aggregates, **kw)
+    return OperatorFactory(lib().pa_fused_aggregation_create, d, keep)
+
+
 def FusedAggregationOperator(input_types, filter_expr, projections, group_by_channels, aggregates, **kw):
     """[Scan]FilterAndProject -> (Hash)Aggregation collapsed into one device pass."""
-    d, keep = fused_aggregation_desc(input_types, filter_expr, projections, group_by_channels, aggregates, **kw)
-    h = C.c_void_p()
-    check(lib().pa_fused_aggregation_create(C.byref(d), C.byref(h)))
-    return Operator(h, keep)
+    return FusedAggregationOperatorFactory(input_types, filter_expr, projections, group_by_channels, aggregates, **kw).createOperator()
 
 
 def TopNOperator(input_types, n, sort_channels, sort_orders, output_mem=abi.MEM_HOST, stream=None):
