@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PA_ABI_VERSION 2
+#define PA_ABI_VERSION 3
 
 /* ---- status codes (negative = error).  Mapped by the JNI shim onto TrinoException
  *      StandardErrorCode (trino-spi/.../StandardErrorCode.java). ---- */
@@ -235,6 +235,14 @@ typedef struct pa_hash_builder_desc {
     void* stream;
 } pa_hash_builder_desc;
 
+/* The four join methods of OperatorFactories (OperatorFactories.java:27-84; LookupJoinOperators.JoinType). */
+typedef enum pa_join_type {
+    PA_JOIN_INNER = 0,
+    PA_JOIN_PROBE_OUTER = 1,    /* LEFT:  a probe row without a match comes out once, build channels NULL (DefaultPageJoiner.java:296-303) */
+    PA_JOIN_LOOKUP_OUTER = 2,   /* RIGHT: build rows never appended to an output are emitted by pa_lookup_outer_create's operator */
+    PA_JOIN_FULL_OUTER = 3      /* both */
+} pa_join_type;
+
 typedef struct pa_lookup_join_desc {
     int32_t probe_channel_count;
     const int32_t* probe_types;
@@ -245,6 +253,8 @@ typedef struct pa_lookup_join_desc {
     const int32_t* probe_output_channels;
     int32_t output_mem;
     void* stream;
+    int32_t join_type;                   /* pa_join_type */
+    int32_t reserved;
 } pa_lookup_join_desc;
 
 /* TopNOperator.createOperatorFactory (TopNOperator.java:43-90): keep the n best rows under (sort_channels, sort_orders)
@@ -301,6 +311,12 @@ int32_t pa_lookup_source_create(pa_lookup_source** out);
 int32_t pa_lookup_source_destroy(pa_lookup_source* ls);
 int32_t pa_hash_builder_create(const pa_hash_builder_desc* desc, pa_lookup_source* bridge, pa_operator** out);
 int32_t pa_lookup_join_create(const pa_lookup_join_desc* desc, pa_lookup_source* bridge, pa_operator** out);
+/* LookupOuterOperator (join/LookupOuterOperator.java:40-215): a source operator (never needs input) that, once every probe
+ * operator of the bridge is finished (the caller creates it / pulls from it after they are), emits the build rows no probe
+ * row was joined with -- ascending build position, probe output channels NULL (types from desc), then the build output
+ * channels (OuterLookupSource.java:120-160).  desc->join_type must be LOOKUP_OUTER or FULL_OUTER, as for the probe operators
+ * of the same bridge (they mark the visited positions). */
+int32_t pa_lookup_outer_create(const pa_lookup_join_desc* desc, pa_lookup_source* bridge, pa_operator** out);
 
 /* ---- Operator protocol (Operator.java:21-103; call order Driver.java:355-457) ---- */
 int32_t pa_op_needs_input(pa_operator* op);                 /* 1 / 0 */

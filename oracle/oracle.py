@@ -60,6 +60,7 @@ def lib():
         L.orc_join_probe.argtypes = [C.c_void_p, C.POINTER(abi.pa_lookup_join_desc), C.POINTER(abi.pa_page),
                                      C.POINTER(abi.pa_page), C.POINTER(C.POINTER(C.c_int32)),
                                      C.POINTER(C.POINTER(C.c_int32)), C.POINTER(C.c_int32)]
+        L.orc_join_outer.argtypes = [C.c_void_p, C.POINTER(abi.pa_lookup_join_desc), C.POINTER(abi.pa_page)]
         L.orc_join_destroy.argtypes = [C.c_void_p]
         L.orc_free.argtypes = [C.c_void_p]
         L.orc_free_page.argtypes = [C.POINTER(abi.pa_page)]
@@ -264,7 +265,7 @@ def make_hash_builder_desc(input_types, join_channels, output_channels, hash_cha
 
 
 def make_lookup_join_desc(probe_types, probe_join_channels, probe_output_channels, probe_hash_channel=-1,
-                          output_mem=abi.MEM_HOST, stream=None):
+                          output_mem=abi.MEM_HOST, stream=None, join_type=abi.JOIN_INNER):
     d = abi.pa_lookup_join_desc()
     types = abi.int32_array(probe_types)
     jc = abi.int32_array(probe_join_channels)
@@ -278,6 +279,7 @@ def make_lookup_join_desc(probe_types, probe_join_channels, probe_output_channel
     d.probe_output_channels = C.cast(oc, C.POINTER(C.c_int32))
     d.output_mem = output_mem
     d.stream = stream
+    d.join_type = join_type
     return d, [types, jc, oc]
 
 
@@ -303,9 +305,10 @@ class HashJoin:
         lib().orc_join_tables(self._h, C.byref(hs), key.ctypes.data, links.ctypes.data)
         return key, links[:lib().orc_join_build_positions(self._h)]
 
-    def probe(self, page, probe_types, probe_join_channels, probe_output_channels, probe_hash_channel=-1):
-        """Returns (output Page, probe indices, build positions) in the reference's emission order."""
-        d, keep = make_lookup_join_desc(probe_types, probe_join_channels, probe_output_channels, probe_hash_channel)
+    def probe(self, page, probe_types, probe_join_channels, probe_output_channels, probe_hash_channel=-1, join_type=abi.JOIN_INNER):
+        """Returns (output Page, probe indices, build positions) in the reference's emission order; build position -1 =
+        the NULL-extended row of a probe-outer join."""
+        d, keep = make_lookup_join_desc(probe_types, probe_join_channels, probe_output_channels, probe_hash_channel, join_type=join_type)
         cpage, k2 = page.to_c()
         out = abi.pa_page()
         pi = C.POINTER(C.c_int32)()
@@ -321,6 +324,15 @@ class HashJoin:
         result = page_from_c(out)
         lib().orc_free_page(C.byref(out))
         return result, p, b
+
+    def outer(self, probe_types, probe_output_channels):
+        """LookupOuterOperator: the build rows no probe row was joined with (after LOOKUP_OUTER / FULL_OUTER probes)."""
+        d, keep = make_lookup_join_desc(probe_types, [], probe_output_channels, join_type=abi.JOIN_LOOKUP_OUTER)
+        out = abi.pa_page()
+        _check(lib().orc_join_outer(self._h, C.byref(d), C.byref(out)))
+        result = page_from_c(out)
+        lib().orc_free_page(C.byref(out))
+        return result
 
     def close(self):
         if self._h:

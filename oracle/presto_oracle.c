@@ -1515,6 +1515,7 @@ struct orc_join {
     int32_t* key;
     uint8_t* position_to_hashes;
     int32_t* position_links;
+    uint8_t* visited; /* OuterLookupSource.OuterPositionTracker.visitedPositions (OuterLookupSource.java:162-215) */
 };
 
 orc_join* orc_join_create(const pa_hash_builder_desc* d)
@@ -1553,6 +1554,7 @@ void orc_join_destroy(orc_join* j)
     free(j->key);
     free(j->position_to_hashes);
     free(j->position_links);
+    free(j->visited);
     free(j);
 }
 
@@ -1609,6 +1611,7 @@ int32_t orc_join_build(orc_join* j)
     }
     j->position_to_hashes = (uint8_t*)malloc((size_t)(n > 0 ? n : 1));
     j->position_links = (int32_t*)malloc(sizeof(int32_t) * (size_t)(n > 0 ? n : 1));
+    j->visited = (uint8_t*)calloc((size_t)(n > 0 ? n : 1), 1);
     for (int32_t i = 0; i < n; i++) {
         j->position_links[i] = -1;
     }
@@ -1697,7 +1700,19 @@ int32_t orc_join_probe(const orc_join* j, const pa_lookup_join_desc* d, const pa
                 has_null = 1;
             }
         }
+        const int probe_outer = d->join_type == PA_JOIN_PROBE_OUTER || d->join_type == PA_JOIN_FULL_OUTER;
+        const int track = d->join_type == PA_JOIN_LOOKUP_OUTER || d->join_type == PA_JOIN_FULL_OUTER;
         if (has_null) {
+            if (probe_outer) { /* DefaultPageJoiner.outerJoinCurrentPosition -> appendNullForBuild (:296-303) */
+                if (cnt == cap) {
+                    cap *= 2;
+                    pi = (int32_t*)realloc(pi, sizeof(int32_t) * (size_t)cap);
+                    bi = (int32_t*)realloc(bi, sizeof(int32_t) * (size_t)cap);
+                }
+                pi[cnt] = position;
+                bi[cnt] = -1;
+                cnt++;
+            }
             continue;
         }
         int64_t raw_hash;
@@ -1708,15 +1723,23 @@ int32_t orc_join_probe(const orc_join* j, const pa_lookup_join_desc* d, const pa
             raw_hash = hash_position(probe, d->join_channel_count, d->probe_join_channels, position);
         }
         int32_t join_position = join_address_index(j, probe, d->probe_join_channels, position, raw_hash);
-        while (join_position >= 0) {
+        int produced = 0;
+        while (join_position >= 0 || (probe_outer && !produced)) {
             if (cnt == cap) {
                 cap *= 2;
                 pi = (int32_t*)realloc(pi, sizeof(int32_t) * (size_t)cap);
                 bi = (int32_t*)realloc(bi, sizeof(int32_t) * (size_t)cap);
             }
             pi[cnt] = position;
-            bi[cnt] = join_position;
+            bi[cnt] = join_position >= 0 ? join_position : -1;
             cnt++;
+            produced = 1;
+            if (join_position < 0) {
+                break;
+            }
+            if (track) {
+                ((orc_join*)j)->visited[join_position] = 1; /* OuterLookupSource.appendTo -> positionVisited */
+            }
             join_position = j->position_links[join_position]; /* ArrayPositionLinks.next */
         }
     }
@@ -1749,7 +1772,15 @@ int32_t orc_join_probe(const orc_join* j, const pa_lookup_join_desc* d, const pa
             col_builder b;
             cb_init(&b, src->type, cnt);
             for (int32_t k = 0; k < cnt; k++) {
-                orc_val v = builder_get(src, bi[k]);
+                orc_val v;
+                if (bi[k] >= 0) {
+                    v = builder_get(src, bi[k]);
+                }
+                else { /* LookupJoinPageBuilder.appendNullForBuild (:84-99) */
+                    memset(&v, 0, sizeof v);
+                    v.is_null = 1;
+                    v.type = src->type;
+                }
                 cb_append(&b, &v);
             }
             cb_finish(&b, &out->columns[c++]);
@@ -1766,6 +1797,49 @@ int32_t orc_join_probe(const orc_join* j, const pa_lookup_join_desc* d, const pa
     }
     else {
         free(bi);
+    }
+    return 0;
+}
+
+/* LookupOuterOperator (TM/operator/join/LookupOuterOperator.java:150-215) over the shared OuterPositionIterator
+ * (TM/operator/join/OuterLookupSource.java:120-160): the build positions no probe row was joined with, ascending; probe
+ * output channels NULL, then the build output channels. */
+int32_t orc_join_outer(const orc_join* j, const pa_lookup_join_desc* d, pa_page* out)
+{
+    int32_t cnt = 0;
+    for (int32_t p = 0; p < j->positions; p++) {
+        cnt += j->visited[p] ? 0 : 1;
+    }
+    int32_t ncols = d->probe_output_channel_count + j->desc.output_channel_count;
+    memset(out, 0, sizeof *out);
+    out->position_count = cnt;
+    out->channel_count = ncols;
+    out->mem = PA_MEM_HOST;
+    out->columns = (pa_column*)calloc((size_t)(ncols > 0 ? ncols : 1), sizeof(pa_column));
+    int32_t c = 0;
+    for (int32_t i = 0; i < d->probe_output_channel_count; i++) {
+        col_builder b;
+        cb_init(&b, d->probe_types[d->probe_output_channels[i]], cnt);
+        for (int32_t k = 0; k < cnt; k++) {
+            orc_val v;
+            memset(&v, 0, sizeof v);
+            v.is_null = 1;
+            v.type = b.type;
+            cb_append(&b, &v);
+        }
+        cb_finish(&b, &out->columns[c++]);
+    }
+    for (int32_t i = 0; i < j->desc.output_channel_count; i++) {
+        const col_builder* src = &j->cols[j->output_channels[i]];
+        col_builder b;
+        cb_init(&b, src->type, cnt);
+        for (int32_t p = 0; p < j->positions; p++) {
+            if (!j->visited[p]) {
+                orc_val v = builder_get(src, p);
+                cb_append(&b, &v);
+            }
+        }
+        cb_finish(&b, &out->columns[c++]);
     }
     return 0;
 }

@@ -77,6 +77,8 @@ int32_t orc_join_tables(const orc_join* j, int32_t* hash_size, int32_t* key, int
  * (probe index, build position) pairs in emission order (malloc'ed, free with orc_free). */
 int32_t orc_join_probe(const orc_join* j, const pa_lookup_join_desc* desc, const pa_page* probe,
                        pa_page* out, int32_t** probe_indices, int32_t** build_positions, int32_t* match_count);
+/* LookupOuterOperator: build rows never joined by a LOOKUP_OUTER / FULL_OUTER probe so far */
+int32_t orc_join_outer(const orc_join* j, const pa_lookup_join_desc* desc, pa_page* out);
 void orc_join_destroy(orc_join* j);
 void orc_free(void* p);
 

@@ -5,7 +5,7 @@ test-only oracle binding (oracle/oracle.py), exactly as both C sides share the h
 """
 import ctypes as C
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 # pa_status
 OK = 0
@@ -211,7 +211,12 @@ class pa_lookup_join_desc(C.Structure):
         ("probe_output_channels", C.POINTER(C.c_int32)),
         ("output_mem", C.c_int32),
         ("stream", C.c_void_p),
+        ("join_type", C.c_int32),
+        ("reserved", C.c_int32),
     ]
+
+
+JOIN_INNER, JOIN_PROBE_OUTER, JOIN_LOOKUP_OUTER, JOIN_FULL_OUTER = 0, 1, 2, 3  # LookupJoinOperators.JoinType
 
 
 def int32_array(values):

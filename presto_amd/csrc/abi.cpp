@@ -331,6 +331,15 @@ int32_t pa_lookup_join_create(const pa_lookup_join_desc* desc, pa_lookup_source*
     });
 }
 
+int32_t pa_lookup_outer_create(const pa_lookup_join_desc* desc, pa_lookup_source* bridge, pa_operator** out)
+{
+    return guarded([&]() -> int32_t {
+        PA_REQUIRE(out != nullptr && bridge != nullptr, PA_ERR_INVALID_ARGUMENT, "null argument");
+        *out = make_lookup_outer(desc, bridge);
+        return PA_OK;
+    });
+}
+
 // ---- Operator protocol ----
 int32_t pa_op_needs_input(pa_operator* op)
 {

@@ -64,6 +64,9 @@ void publish_output(std::vector<OutColumn>& cols, int32_t n, int32_t mem, hipStr
 // static kernels used by staging (static_kernels.hip)
 void launch_gather_flat(const void* src, int elem_bytes, const int32_t* positions, int64_t count, void* dst, hipStream_t s);
 void launch_gather_nulls(const uint8_t* src, const int32_t* positions, int64_t count, uint8_t* dst, hipStream_t s);
+// positions may hold -1 = NULL row; elem_bytes 0 = only the NULL flags (VARCHAR columns)
+void launch_gather_or_null(const void* src, int elem_bytes, const uint8_t* src_nulls, const int32_t* positions, int64_t count, void* dst,
+                           uint8_t* dst_nulls, hipStream_t s);
 void launch_fill_flat(void* dst, int elem_bytes, const void* src_one, int64_t count, hipStream_t s);
 
 }  // namespace pa

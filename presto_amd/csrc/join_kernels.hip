@@ -160,7 +160,7 @@ __global__ __launch_bounds__(256) void k_join_tag_slots(const i32* __restrict__ 
 
 __global__ __launch_bounds__(256) void k_join_probe_count(JoinKeys build, JoinKeys probe, const i64* __restrict__ probe_hash, i32 n_probe,
                                                           const u64* __restrict__ tagged, u32 mask, const i32* __restrict__ links,
-                                                          i32* __restrict__ head, i32* __restrict__ counts)
+                                                          i32* __restrict__ head, i32* __restrict__ counts, int probe_outer)
 {
     for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < n_probe; i += (i64)gridDim.x * 256) {
         const i32 r = (i32)i;
@@ -182,22 +182,36 @@ __global__ __launch_bounds__(256) void k_join_probe_count(JoinKeys build, JoinKe
         head[r] = h;
         i32 c = 0;
         for (i32 j = h; j != -1; j = links[j]) c++;
-        counts[r] = c;
+        counts[r] = (c == 0 && probe_outer) ? 1 : c;  // DefaultPageJoiner.outerJoinCurrentPosition: one NULL-extended row
     }
 }
 
 __global__ __launch_bounds__(256) void k_join_probe_emit(const i32* __restrict__ head, const i32* __restrict__ offsets, i32 n_probe,
-                                                         const i32* __restrict__ links, i32* __restrict__ probe_idx, i32* __restrict__ build_pos)
+                                                         const i32* __restrict__ links, i32* __restrict__ probe_idx, i32* __restrict__ build_pos,
+                                                         int probe_outer, u8* __restrict__ visited)
 {
     for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < n_probe; i += (i64)gridDim.x * 256) {
         const i32 r = (i32)i;
         i32 o = offsets[r];
-        for (i32 j = head[r]; j != -1; j = links[j]) {
+        const i32 h = head[r];
+        if (h == -1 && probe_outer) {  // LookupJoinPageBuilder.appendNullForBuild
+            probe_idx[o] = r;
+            build_pos[o] = -1;
+            continue;
+        }
+        for (i32 j = h; j != -1; j = links[j]) {
             probe_idx[o] = r;
             build_pos[o] = j;
+            if (visited) visited[j] = 1;  // OuterLookupSource.appendTo -> positionVisited (same value from every writer)
             o++;
         }
     }
+}
+
+// partition 0 = build positions never visited (the rows LookupOuterOperator emits), 1 = visited
+__global__ __launch_bounds__(256) void k_join_unvisited_flag(const u8* __restrict__ visited, i64 n, i32* __restrict__ partition)
+{
+    for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < n; i += (i64)gridDim.x * 256) partition[i] = visited[i] ? 1 : 0;
 }
 
 void launch_join_tag_slots(const int32_t* key, int64_t hash_size, const int64_t* raw_hash, uint64_t* tagged, hipStream_t s)
@@ -206,18 +220,25 @@ void launch_join_tag_slots(const int32_t* key, int64_t hash_size, const int64_t*
     PA_HIP(hipGetLastError());
 }
 void launch_join_probe_count(const JoinKeys& build, const JoinKeys& probe, const int64_t* probe_hash, int32_t n_probe, const uint64_t* tagged,
-                             uint32_t mask, const int32_t* links, int32_t* head, int32_t* counts, hipStream_t s)
+                             uint32_t mask, const int32_t* links, int32_t* head, int32_t* counts, bool probe_outer, hipStream_t s)
 {
     if (n_probe <= 0) return;
     hipLaunchKernelGGL(k_join_probe_count, grid_for(n_probe), 256, 0, s, build, probe, (const i64*)probe_hash, n_probe, (const u64*)tagged, mask,
-                       links, head, counts);
+                       links, head, counts, probe_outer ? 1 : 0);
+    PA_HIP(hipGetLastError());
+}
+void launch_join_unvisited_flag(const uint8_t* visited, int64_t n, int32_t* partition, hipStream_t s)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_join_unvisited_flag, grid_for(n), 256, 0, s, visited, (i64)n, partition);
     PA_HIP(hipGetLastError());
 }
 void launch_join_probe_emit(const int32_t* head, const int32_t* offsets, int32_t n_probe, const int32_t* links, int32_t* probe_idx,
-                            int32_t* build_pos, hipStream_t s)
+                            int32_t* build_pos, bool probe_outer, uint8_t* visited, hipStream_t s)
 {
     if (n_probe <= 0) return;
-    hipLaunchKernelGGL(k_join_probe_emit, grid_for(n_probe), 256, 0, s, head, offsets, n_probe, links, probe_idx, build_pos);
+    hipLaunchKernelGGL(k_join_probe_emit, grid_for(n_probe), 256, 0, s, head, offsets, n_probe, links, probe_idx, build_pos, probe_outer ? 1 : 0,
+                       visited);
     PA_HIP(hipGetLastError());
 }
 

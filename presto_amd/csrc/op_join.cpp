@@ -37,6 +37,7 @@ struct LookupSourceImpl {
     std::vector<int> join_channels, output_channels;
     int hash_channel = -1;
     DevBuf key, links, raw_hash, slot_of, tagged;
+    DevBuf visited;  // OuterPositionTracker.visitedPositions: 1 B per build position, written by LOOKUP_OUTER / FULL_OUTER probes
     uint32_t mask = 0;
     std::atomic<bool> built{false};
     std::atomic<int32_t> error{0};
@@ -197,6 +198,7 @@ public:
                           ctl_, s);
         launch_join_tag_slots(ls_->key.as<int32_t>(), (int64_t)hash_size, ls_->raw_hash.as<int64_t>(),
                               static_cast<uint64_t*>(ls_->tagged.ensure((size_t)hash_size * 8)), s);
+        PA_HIP(hipMemsetAsync(ls_->visited.ensure((size_t)std::max(n, 1)), 0, (size_t)std::max(n, 1), s));
         timer.end(s);
         int32_t err = 0;
         PA_HIP(hipMemcpyAsync(&err, ctl_, 4, hipMemcpyDeviceToHost, s));
@@ -249,6 +251,9 @@ public:
             output_channels_.push_back(c);
         }
         output_mem_ = d->output_mem;
+        PA_REQUIRE(d->join_type >= PA_JOIN_INNER && d->join_type <= PA_JOIN_FULL_OUTER, PA_ERR_INVALID_ARGUMENT, "unknown join type");
+        probe_outer_ = d->join_type == PA_JOIN_PROBE_OUTER || d->join_type == PA_JOIN_FULL_OUTER;
+        track_visited_ = d->join_type == PA_JOIN_LOOKUP_OUTER || d->join_type == PA_JOIN_FULL_OUTER;
         needed_.assign(n_probe_channels_, false);
         for (int c : join_channels_) needed_[c] = true;
         for (int c : output_channels_) needed_[c] = true;
@@ -305,7 +310,7 @@ public:
         int32_t* head = static_cast<int32_t*>(head_.ensure((size_t)n * 4));
         int32_t* counts = static_cast<int32_t*>(counts_.ensure((size_t)n * 4));
         timer.begin(s);
-        launch_join_probe_count(ls_->build_keys(), pk, probe_hash, n, ls_->tagged.as<uint64_t>(), ls_->mask, ls_->links.as<int32_t>(), head, counts, s);
+        launch_join_probe_count(ls_->build_keys(), pk, probe_hash, n, ls_->tagged.as<uint64_t>(), ls_->mask, ls_->links.as<int32_t>(), head, counts, probe_outer_, s);
         launch_exclusive_scan_i32(counts, counts, n, ctl_, scan_temp_.ensure(scan_temp_bytes(n)), s);
         timer.end(s);
         PA_HIP(hipMemcpyAsync(h_ctl_, ctl_, 4, hipMemcpyDeviceToHost, s));
@@ -324,7 +329,8 @@ public:
         const int32_t n = in_.n;
         int32_t* probe_idx = static_cast<int32_t*>(probe_idx_.ensure((size_t)total * 4));
         int32_t* build_pos = static_cast<int32_t*>(build_pos_.ensure((size_t)total * 4));
-        launch_join_probe_emit(head_.as<int32_t>(), counts_.as<int32_t>(), n, ls_->links.as<int32_t>(), probe_idx, build_pos, s);
+        launch_join_probe_emit(head_.as<int32_t>(), counts_.as<int32_t>(), n, ls_->links.as<int32_t>(), probe_idx, build_pos, probe_outer_,
+                               track_visited_ ? ls_->visited.as<uint8_t>() : nullptr, s);
         // LookupJoinPageBuilder.build: probe output channels by probe index ++ build output channels by build position
         size_t oc = 0;
         for (int c : output_channels_) {
@@ -334,7 +340,7 @@ public:
         for (int c : ls_->output_channels) {
             const BuildColumn& src = ls_->cols[c];
             gather_column(src.type, src.varwidth, src.values.ptr(), src.offsets.as<int32_t>(), src.has_nulls ? src.nulls.as<uint8_t>() : nullptr,
-                          build_pos, total, out_cols_[oc++], s);
+                          build_pos, total, out_cols_[oc++], s, probe_outer_);
         }
         publish_output(out_cols_, total, output_mem_, s, out, out_storage_);
         return true;
@@ -352,14 +358,15 @@ public:
     }
 
 private:
+    // null_rows: positions may hold -1 = a NULL row (build side of a probe-outer join)
     void gather_column(int32_t type, bool varwidth, const void* values, const int32_t* offsets, const uint8_t* nulls, const int32_t* positions,
-                       int32_t count, OutColumn& oc, hipStream_t s)
+                       int32_t count, OutColumn& oc, hipStream_t s, bool null_rows = false)
     {
         oc.type = type;
         oc.varwidth = varwidth;
         oc.is_view = false;
         oc.host_ready = false;
-        oc.has_nulls = nulls != nullptr;
+        oc.has_nulls = nulls != nullptr || null_rows;
         if (varwidth) {
             int32_t* lens = static_cast<int32_t*>(oc.offsets.ensure((size_t)(count + 1) * 4));
             launch_varwidth_lengths(positions, count, offsets, nulls, lens, s);
@@ -370,11 +377,17 @@ private:
             uint8_t* dst = static_cast<uint8_t*>(oc.values.ensure((size_t)(bytes > 0 ? bytes : 1)));
             launch_varwidth_copy(positions, count, offsets, static_cast<const uint8_t*>(values), nulls, lens, dst, ctl_ + 2, s);
         }
+        else if (null_rows) {
+            int w = type_width(type);
+            launch_gather_or_null(values, w, nulls, positions, count, oc.values.ensure((size_t)count * w), static_cast<uint8_t*>(oc.nulls.ensure((size_t)count)), s);
+            return;
+        }
         else {
             int w = type_width(type);
             launch_gather_flat(values, w, positions, count, oc.values.ensure((size_t)count * w), s);
         }
-        if (nulls) launch_gather_nulls(nulls, positions, count, static_cast<uint8_t*>(oc.nulls.ensure((size_t)count)), s);
+        if (null_rows) launch_gather_or_null(nullptr, 0, nulls, positions, count, nullptr, static_cast<uint8_t*>(oc.nulls.ensure((size_t)count)), s);
+        else if (nulls) launch_gather_nulls(nulls, positions, count, static_cast<uint8_t*>(oc.nulls.ensure((size_t)count)), s);
     }
 
     Stream stream_;
@@ -391,7 +404,112 @@ private:
     int32_t* ctl_ = nullptr;
     int32_t* h_ctl_ = nullptr;
     int32_t last_matches_ = 0;
-    bool finishing_ = false, pending_ = false;
+    bool finishing_ = false, pending_ = false, probe_outer_ = false, track_visited_ = false;
+    std::vector<OutColumn> out_cols_;
+    std::vector<pa_column> out_storage_;
+};
+
+// LookupOuterOperator (…/operator/join/LookupOuterOperator.java:40-215): after the probe operators of the bridge are
+// finished, the build rows whose position was never appended to a join output, in ascending position
+// (OuterLookupSource.SharedLookupOuterPositionIterator, OuterLookupSource.java:120-160); probe channels NULL.
+class LookupOuterOperator : public pa_operator {
+public:
+    LookupOuterOperator(const pa_lookup_join_desc* d, pa_lookup_source* bridge) : stream_(d->stream)
+    {
+        PA_REQUIRE(d != nullptr, PA_ERR_INVALID_ARGUMENT, "descriptor is null");
+        require_device();
+        PA_REQUIRE(bridge->impl != nullptr, PA_ERR_ILLEGAL_STATE, "lookup source has no build operator yet");
+        PA_REQUIRE(d->join_type == PA_JOIN_LOOKUP_OUTER || d->join_type == PA_JOIN_FULL_OUTER, PA_ERR_INVALID_ARGUMENT,
+                   "LookupOuterOperator belongs to a lookup-outer or full-outer join");
+        ls_ = bridge->impl;
+        for (int i = 0; i < d->probe_output_channel_count; i++) {
+            int c = d->probe_output_channels[i];
+            PA_REQUIRE(c >= 0 && c < d->probe_channel_count, PA_ERR_INVALID_ARGUMENT, "probe output channel out of range");
+            probe_output_types_.push_back(d->probe_types[c]);
+        }
+        output_mem_ = d->output_mem;
+        ctl_ = static_cast<int32_t*>(ctl_buf_.ensure(64));
+        h_ctl_ = static_cast<int32_t*>(h_ctl_buf_.ensure(64));
+    }
+    ~LookupOuterOperator() override { (void)hipStreamSynchronize(stream_.get()); }
+
+    bool needs_input() override { return false; }  // LookupOuterOperator.java:135-138
+    void add_input(const pa_page*) override { throw Error(PA_ERR_ILLEGAL_STATE, "LookupOuterOperator does not take input"); }
+    bool is_blocked() override { return !ls_->built.load(); }
+    void finish() override {}
+    bool is_finished() override { return done_; }
+
+    bool get_output(pa_page* out) override
+    {
+        if (done_ || !ls_->built.load()) return false;
+        done_ = true;
+        hipStream_t s = stream_.get();
+        const int64_t n = ls_->n;
+        if (n == 0) return false;
+        int32_t* part = static_cast<int32_t*>(part_.ensure((size_t)n * 4));
+        int32_t* pos = static_cast<int32_t*>(pos_.ensure((size_t)n * 4));
+        int64_t* counts = static_cast<int64_t*>(counts_.ensure(64));
+        launch_join_unvisited_flag(ls_->visited.as<uint8_t>(), n, part, s);
+        launch_partition_positions(part, n, 2, pos, counts, part_temp_.ensure(partition_temp_bytes(n, 2)), s);
+        int64_t h_counts[2];
+        PA_HIP(hipMemcpyAsync(h_counts, counts, 16, hipMemcpyDeviceToHost, s));
+        PA_HIP(hipStreamSynchronize(s));
+        const int32_t count = (int32_t)h_counts[0];
+        if (count == 0) return false;
+        out_cols_.clear();
+        out_cols_.resize(probe_output_types_.size() + ls_->output_channels.size());
+        size_t oc = 0;
+        for (int32_t t : probe_output_types_) {  // appendNullForProbe: LookupOuterOperator.java:178-186
+            OutColumn& o = out_cols_[oc++];
+            o.type = t;
+            o.varwidth = t == PA_VARCHAR;
+            o.has_nulls = true;
+            PA_HIP(hipMemsetAsync(o.nulls.ensure((size_t)count), 1, (size_t)count, s));
+            if (o.varwidth) {
+                PA_HIP(hipMemsetAsync(o.offsets.ensure((size_t)(count + 1) * 4), 0, (size_t)(count + 1) * 4, s));
+                o.values.ensure(1);
+            }
+            else {
+                PA_HIP(hipMemsetAsync(o.values.ensure((size_t)count * type_width(t)), 0, (size_t)count * type_width(t), s));
+            }
+        }
+        for (int c : ls_->output_channels) {
+            const BuildColumn& src = ls_->cols[c];
+            OutColumn& o = out_cols_[oc++];
+            o.type = src.type;
+            o.varwidth = src.varwidth;
+            const uint8_t* nulls = src.has_nulls ? src.nulls.as<uint8_t>() : nullptr;
+            o.has_nulls = nulls != nullptr;
+            if (src.varwidth) {
+                int32_t* lens = static_cast<int32_t*>(o.offsets.ensure((size_t)(count + 1) * 4));
+                launch_varwidth_lengths(pos, count, src.offsets.as<int32_t>(), nulls, lens, s);
+                launch_exclusive_scan_i32(lens, lens, count, ctl_ + 2, scan_temp_.ensure(scan_temp_bytes(count)), s);
+                PA_HIP(hipMemcpyAsync(h_ctl_ + 2, ctl_ + 2, 4, hipMemcpyDeviceToHost, s));
+                PA_HIP(hipStreamSynchronize(s));
+                const int32_t bytes = h_ctl_[2];
+                launch_varwidth_copy(pos, count, src.offsets.as<int32_t>(), src.values.as<uint8_t>(), nulls, lens,
+                                     static_cast<uint8_t*>(o.values.ensure((size_t)(bytes > 0 ? bytes : 1))), ctl_ + 2, s);
+            }
+            else {
+                const int w = type_width(src.type);
+                launch_gather_flat(src.values.ptr(), w, pos, count, o.values.ensure((size_t)count * w), s);
+            }
+            if (nulls) launch_gather_nulls(nulls, pos, count, static_cast<uint8_t*>(o.nulls.ensure((size_t)count)), s);
+        }
+        publish_output(out_cols_, count, output_mem_, s, out, out_storage_);
+        return true;
+    }
+
+private:
+    Stream stream_;
+    std::shared_ptr<LookupSourceImpl> ls_;
+    std::vector<int32_t> probe_output_types_;
+    int output_mem_ = PA_MEM_HOST;
+    bool done_ = false;
+    DevBuf ctl_buf_, part_, pos_, counts_, part_temp_, scan_temp_;
+    PinnedBuf h_ctl_buf_;
+    int32_t* ctl_ = nullptr;
+    int32_t* h_ctl_ = nullptr;
     std::vector<OutColumn> out_cols_;
     std::vector<pa_column> out_storage_;
 };
@@ -405,6 +523,10 @@ pa_operator* make_hash_builder(const pa_hash_builder_desc* desc, pa_lookup_sourc
 pa_operator* make_lookup_join(const pa_lookup_join_desc* desc, pa_lookup_source* bridge)
 {
     return new LookupJoinOperator(desc, bridge);
+}
+pa_operator* make_lookup_outer(const pa_lookup_join_desc* desc, pa_lookup_source* bridge)
+{
+    return new LookupOuterOperator(desc, bridge);
 }
 pa_lookup_source* lookup_source_new() { return new pa_lookup_source(); }
 void lookup_source_delete(pa_lookup_source* ls) { delete ls; }

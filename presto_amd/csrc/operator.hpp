@@ -26,6 +26,7 @@ pa_operator* make_filter_project(const pa_filter_project_desc* desc);
 pa_operator* make_hash_builder(const pa_hash_builder_desc* desc, pa_lookup_source* bridge);
 pa_operator* make_lookup_join(const pa_lookup_join_desc* desc, pa_lookup_source* bridge);
 pa_operator* make_topn(const pa_topn_desc* desc);
+pa_operator* make_lookup_outer(const pa_lookup_join_desc* desc, pa_lookup_source* bridge);
 
 // code-object source for a fused descriptor under the "no nulls, aligned" layout; used by build() to
 // pre-compile the TPC-H shapes and by the CPU-side codegen tests

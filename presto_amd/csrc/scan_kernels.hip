@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256) void k_varwidth_lengths(const i32* __restrict_
 {
     for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < count; i += (i64)gridDim.x * 256) {
         i32 p = positions ? positions[i] : (i32)i;
-        out_len[i] = (nulls && nulls[p]) ? 0 : offsets[p + 1] - offsets[p];
+        out_len[i] = (p < 0 || (nulls && nulls[p])) ? 0 : offsets[p + 1] - offsets[p];  // p < 0: NULL-extended row of an outer join
     }
 }
 __global__ __launch_bounds__(256) void k_varwidth_copy(const i32* __restrict__ positions, i64 count, const i32* __restrict__ offsets,
@@ -155,8 +155,8 @@ __global__ __launch_bounds__(256) void k_varwidth_copy(const i32* __restrict__ p
 {
     for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < count; i += (i64)gridDim.x * 256) {
         i32 p = positions ? positions[i] : (i32)i;
-        i32 len = (nulls && nulls[p]) ? 0 : offsets[p + 1] - offsets[p];
-        const u8* src = bytes + offsets[p];
+        i32 len = (p < 0 || (nulls && nulls[p])) ? 0 : offsets[p + 1] - offsets[p];
+        const u8* src = bytes + (p < 0 ? 0 : offsets[p]);
         u8* dst = out_bytes + out_offsets[i];
         for (i32 b = 0; b < len; b++) dst[b] = src[b];
         if (i == count - 1) out_offsets[count] = *total;

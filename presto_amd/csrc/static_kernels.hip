@@ -32,6 +32,33 @@ __global__ __launch_bounds__(256) void k_fill(T* __restrict__ dst, const T* __re
     for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < n; i += (i64)gridDim.x * 256) dst[i] = v;
 }
 
+// Block.copyPositions where position -1 stands for a NULL row (the build side of an outer join's unmatched probe rows):
+// value 0 and NULL flag 1 there; elsewhere the source value and the source's NULL flag (or 0)
+template <typename T>
+__global__ __launch_bounds__(256) void k_gather_or_null(const T* __restrict__ src, const u8* __restrict__ src_nulls, const i32* __restrict__ pos, i64 n,
+                                                        T* __restrict__ dst, u8* __restrict__ dst_nulls)
+{
+    for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < n; i += (i64)gridDim.x * 256) {
+        const i32 p = pos[i];
+        if (dst) dst[i] = p < 0 ? (T)0 : src[p];
+        dst_nulls[i] = p < 0 ? (u8)1 : (src_nulls ? src_nulls[p] : (u8)0);
+    }
+}
+void launch_gather_or_null(const void* src, int elem_bytes, const uint8_t* src_nulls, const int32_t* positions, int64_t count, void* dst,
+                           uint8_t* dst_nulls, hipStream_t s)
+{
+    if (count <= 0) return;
+    int g = grid_for(count, 256);
+    switch (elem_bytes) {
+        case 8: hipLaunchKernelGGL(k_gather_or_null<u64>, g, 256, 0, s, (const u64*)src, src_nulls, positions, count, (u64*)dst, dst_nulls); break;
+        case 4: hipLaunchKernelGGL(k_gather_or_null<u32>, g, 256, 0, s, (const u32*)src, src_nulls, positions, count, (u32*)dst, dst_nulls); break;
+        case 1: hipLaunchKernelGGL(k_gather_or_null<u8>, g, 256, 0, s, (const u8*)src, src_nulls, positions, count, (u8*)dst, dst_nulls); break;
+        case 0: hipLaunchKernelGGL(k_gather_or_null<u8>, g, 256, 0, s, (const u8*)nullptr, src_nulls, positions, count, (u8*)nullptr, dst_nulls); break;
+        default: throw Error(PA_ERR_INVALID_ARGUMENT, "unsupported element width");
+    }
+    PA_HIP(hipGetLastError());
+}
+
 void launch_gather_flat(const void* src, int elem_bytes, const int32_t* positions, int64_t count, void* dst, hipStream_t s)
 {
     if (count <= 0) return;

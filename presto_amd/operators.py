@@ -316,9 +316,7 @@ def HashBuilderOperator(bridge, input_types, join_channels, output_channels, has
     return Operator(h, [types, jc, oc, bridge])
 
 
-def LookupJoinOperator(bridge, probe_types, probe_join_channels, probe_output_channels, probe_hash_channel=-1,
-                       output_mem=abi.MEM_HOST, stream=None):
-    """OperatorFactories.innerJoin (…/operator/OperatorFactories.java:27-45) -> LookupJoinOperator."""
+def _lookup_join_desc(probe_types, probe_join_channels, probe_output_channels, probe_hash_channel, output_mem, stream, join_type):
     d = abi.pa_lookup_join_desc()
     types = abi.int32_array(probe_types)
     jc = abi.int32_array(probe_join_channels)
@@ -332,6 +330,37 @@ def LookupJoinOperator(bridge, probe_types, probe_join_channels, probe_output_ch
     d.probe_output_channels = C.cast(oc, C.POINTER(C.c_int32))
     d.output_mem = output_mem
     d.stream = stream
+    d.join_type = join_type
+    return d, [types, jc, oc]
+
+
+def LookupOuterOperator(bridge, probe_types, probe_output_channels, join_type=abi.JOIN_LOOKUP_OUTER, output_mem=abi.MEM_HOST, stream=None):
+    """LookupOuterOperator (…/operator/join/LookupOuterOperator.java:40-215): created by OperatorFactories.lookupOuterJoin /
+    fullOuterJoin next to the probe operators; pull from it once they are finished."""
+    d, keep = _lookup_join_desc(probe_types, [], probe_output_channels, -1, output_mem, stream, join_type)
+    h = C.c_void_p()
+    check(lib().pa_lookup_outer_create(C.byref(d), bridge._h, C.byref(h)))
+    return Operator(h, keep + [bridge])
+
+
+def LookupJoinOperator(bridge, probe_types, probe_join_channels, probe_output_channels, probe_hash_channel=-1,
+                       output_mem=abi.MEM_HOST, stream=None, join_type=abi.JOIN_INNER):
+    """OperatorFactories.innerJoin / probeOuterJoin / lookupOuterJoin / fullOuterJoin (…/operator/OperatorFactories.java:27-84)
+    -> LookupJoinOperator; join_type = abi.JOIN_*."""
+    d = abi.pa_lookup_join_desc()
+    types = abi.int32_array(probe_types)
+    jc = abi.int32_array(probe_join_channels)
+    oc = abi.int32_array(probe_output_channels)
+    d.probe_channel_count = len(probe_types)
+    d.probe_types = C.cast(types, C.POINTER(C.c_int32))
+    d.join_channel_count = len(probe_join_channels)
+    d.probe_join_channels = C.cast(jc, C.POINTER(C.c_int32))
+    d.probe_hash_channel = probe_hash_channel
+    d.probe_output_channel_count = len(probe_output_channels)
+    d.probe_output_channels = C.cast(oc, C.POINTER(C.c_int32))
+    d.output_mem = output_mem
+    d.stream = stream
+    d.join_type = join_type
     h = C.c_void_p()
     check(lib().pa_lookup_join_create(C.byref(d), bridge._h, C.byref(h)))
     return Operator(h, [types, jc, oc, bridge])

@@ -255,3 +255,51 @@ def test_merge_pages_kats(oracle):
     size = oracle.page_size_in_bytes(whole)
     out = merge_all(oracle.MergePages(size // 2 + 1, 11, size), halves + halves)
     assert [p.to_rows() for p in out] == [whole.to_rows(), whole.to_rows()]
+
+
+# ---- outer joins (core/trino-main/src/test/java/io/trino/operator/join/TestHashJoinOperator.java:850-1390) ------------
+def _varchar_join(oracle, build, probe, join_type):
+    j = oracle.HashJoin([abi.VARCHAR], [0], [0])
+    if build:
+        j.add_build_page(Page([Block.varchar(build)], len(build)))
+    j.build()
+    out, pi, bi = j.probe(Page([Block.varchar(probe)], len(probe)), [abi.VARCHAR], [0], [0], join_type=join_type)
+    return j, out.to_rows()
+
+
+def test_probe_outer_join_kats(oracle):
+    # testProbeOuterJoin (:850-894): build seq 10 rows @20,30,40; probe seq 15 rows @20,1020,2020
+    types = [abi.VARCHAR, abi.BIGINT, abi.BIGINT]
+    j = oracle.HashJoin(types, [0], [0, 1, 2])
+    j.add_build_page(sequence_page(10, [(abi.VARCHAR, 20), (abi.BIGINT, 30), (abi.BIGINT, 40)]))
+    j.build()
+    out, _, _ = j.probe(sequence_page(15, [(abi.VARCHAR, 20), (abi.BIGINT, 1020), (abi.BIGINT, 2020)]), types, [0], [0, 1, 2],
+                        join_type=abi.JOIN_PROBE_OUTER)
+    expected = [(str(20 + i).encode(), 1020 + i, 2020 + i, str(20 + i).encode(), 30 + i, 40 + i) for i in range(10)]
+    expected += [(str(30 + i).encode(), 1030 + i, 2030 + i, None, None, None) for i in range(5)]
+    assert out.to_rows() == expected
+    # testOuterJoinWithNullProbe (:945-985)
+    assert _varchar_join(oracle, ["a", "b", "c"], ["a", None, None, "a", "b"], abi.JOIN_PROBE_OUTER)[1] == \
+        [(b"a", b"a"), (None, None), (None, None), (b"a", b"a"), (b"b", b"b")]
+    # testOuterJoinWithNullBuild (:1032-1071)
+    assert _varchar_join(oracle, ["a", None, None, "a", "b"], ["a", "b", "c"], abi.JOIN_PROBE_OUTER)[1] == \
+        [(b"a", b"a"), (b"a", b"a"), (b"b", b"b"), (b"c", None)]
+    # testOuterJoinWithNullOnBothSides (:1118-1158)
+    assert _varchar_join(oracle, ["a", None, None, "a", "b"], ["a", "b", None, "c"], abi.JOIN_PROBE_OUTER)[1] == \
+        [(b"a", b"a"), (b"a", b"a"), (b"b", b"b"), (None, None), (b"c", None)]
+    # testProbeOuterJoinWithEmptyLookupSource (:1297-1343) / testFullOuterJoinWithEmptyLookupSource (:1345-1390)
+    for jt in (abi.JOIN_PROBE_OUTER, abi.JOIN_FULL_OUTER):
+        assert _varchar_join(oracle, [], ["a", "b", None, "c"], jt)[1] == [(b"a", None), (b"b", None), (None, None), (b"c", None)]
+
+
+def test_lookup_outer_and_full_outer(oracle):
+    # the build rows no probe row joined with come out afterwards, ascending, probe side NULL
+    # (OuterLookupSource.java:120-160; testLookupOuterJoinWithEmptyLookupSource :1258-1295 for the empty case)
+    j, rows = _varchar_join(oracle, ["a", None, "x", "a", "b", "y"], ["a", "c", None], abi.JOIN_FULL_OUTER)
+    assert rows == [(b"a", b"a"), (b"a", b"a"), (b"c", None), (None, None)]
+    assert j.outer([abi.VARCHAR], [0]).to_rows() == [(None, None), (None, b"x"), (None, b"b"), (None, b"y")]
+    j, rows = _varchar_join(oracle, ["a", "b"], ["b", "z"], abi.JOIN_LOOKUP_OUTER)
+    assert rows == [(b"b", b"b")]
+    assert j.outer([abi.VARCHAR], [0]).to_rows() == [(None, b"a")]
+    j, rows = _varchar_join(oracle, [], ["test"], abi.JOIN_LOOKUP_OUTER)
+    assert rows == [] and j.outer([abi.VARCHAR], [0]).position_count == 0
