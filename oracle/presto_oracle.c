@@ -1230,6 +1230,40 @@ static int mask_passes(const pa_page* page, int32_t mask_channel, int32_t pos)
     return ((const uint8_t*)c->values)[p] != 0;
 }
 
+/* DoubleType's COMPARISON operator = Double.compare (SPI/type/DoubleType.java:194-198): numeric order, -0.0 < 0.0,
+ * NaN equal to itself and above everything */
+static int double_compare(double a, double b)
+{
+    if (a < b) return -1;
+    if (a > b) return 1;
+    uint64_t x, y;
+    memcpy(&x, &a, 8);
+    memcpy(&y, &b, 8);
+    if (a != a) x = 0x7ff8000000000000ULL; /* doubleToLongBits: one NaN */
+    if (b != b) y = 0x7ff8000000000000ULL;
+    int64_t sx = (int64_t)x, sy = (int64_t)y; /* Double.compare falls back to the order of doubleToLongBits */
+    return sx == sy ? 0 : (sx < sy ? -1 : 1);
+}
+
+/* AbstractMinMaxAggregationFunction.compareAndUpdateState (TM/operator/aggregation/AbstractMinMaxAggregationFunction.java:
+ * 274-330): the first value is taken as is, later ones when the type's comparison says smaller (min) / larger (max) */
+static void min_max_update(acc_state* s, int is_min, const orc_val* v)
+{
+    int take;
+    if (!s->has_value) {
+        take = 1;
+    }
+    else {
+        int c = v->type == PA_DOUBLE ? double_compare(v->d, s->dsum) : (v->i < s->lsum ? -1 : (v->i > s->lsum ? 1 : 0));
+        take = is_min ? c < 0 : c > 0;
+    }
+    if (take) {
+        s->has_value = 1;
+        s->dsum = v->d;
+        s->lsum = v->i;
+    }
+}
+
 /* generated GroupedAccumulator.addInput loop (TM/operator/aggregation/AccumulatorCompiler.java:490-569)
  * calling the input functions of SURVEY a15 */
 static void accumulate(orc_hash_agg* a, int32_t k, const pa_page* page, const int32_t* gids)
@@ -1247,6 +1281,13 @@ static void accumulate(orc_hash_agg* a, int32_t k, const pa_page* page, const in
                 continue;
             }
             s->count += c.i;
+            if (ag->fn == PA_AGG_MIN || ag->fn == PA_AGG_MAX) { /* combine = compareAndUpdateState with the other state's value */
+                orc_val v = col_get(&page->columns[ag->input_channel + 1], pos);
+                if (!v.is_null) {
+                    min_max_update(s, ag->fn == PA_AGG_MIN, &v);
+                }
+                continue;
+            }
             if (ag->fn == PA_AGG_SUM || ag->fn == PA_AGG_AVG) {
                 orc_val v = col_get(&page->columns[ag->input_channel + 1], pos);
                 if (v.is_null) {
@@ -1303,25 +1344,10 @@ static void accumulate(orc_hash_agg* a, int32_t k, const pa_page* page, const in
                 s->dsum = s->dsum + (v.type == PA_DOUBLE ? v.d : (double)v.i);
                 break;
             case PA_AGG_MIN:
-            case PA_AGG_MAX: {
-                int take;
-                if (!s->has_value) {
-                    take = 1;
-                }
-                else if (v.type == PA_DOUBLE) { /* MinAggregationFunction/MaxAggregationFunction: comparison operator */
-                    take = ag->fn == PA_AGG_MIN ? (v.d < s->dsum) : (v.d > s->dsum);
-                }
-                else {
-                    take = ag->fn == PA_AGG_MIN ? (v.i < s->lsum) : (v.i > s->lsum);
-                }
-                if (take) {
-                    s->has_value = 1;
-                    s->dsum = v.d;
-                    s->lsum = v.i;
-                }
+            case PA_AGG_MAX:
+                min_max_update(s, ag->fn == PA_AGG_MIN, &v);
                 s->count++;
                 break;
-            }
             default:
                 break;
         }
@@ -1377,7 +1403,7 @@ int32_t orc_hash_agg_build_result(orc_hash_agg* a, pa_page* out)
     int32_t partial = a->desc.step == PA_STEP_PARTIAL;
     int32_t agg_cols = 0;
     for (int32_t k = 0; k < a->desc.aggregate_count; k++) {
-        agg_cols += (partial && (a->aggs[k].fn == PA_AGG_SUM || a->aggs[k].fn == PA_AGG_AVG)) ? 2 : 1;
+        agg_cols += (partial && a->aggs[k].fn != PA_AGG_COUNT && a->aggs[k].fn != PA_AGG_COUNT_STAR) ? 2 : 1;
     }
     int32_t ncols = nkeys + has_hash + agg_cols;
     memset(out, 0, sizeof *out);
@@ -1446,14 +1472,17 @@ int32_t orc_hash_agg_build_result(orc_hash_agg* a, pa_page* out)
         if (partial) {
             /* Step.PARTIAL: the states themselves, flattened: [count BIGINT] (+ [sum DOUBLE | BIGINT]) */
             int value_double = ag->fn == PA_AGG_AVG || ag->input_type == PA_DOUBLE;
-            for (int part = 0; part < ((ag->fn == PA_AGG_SUM || ag->fn == PA_AGG_AVG) ? 2 : 1); part++) {
+            int min_max = ag->fn == PA_AGG_MIN || ag->fn == PA_AGG_MAX;
+            for (int part = 0; part < ((ag->fn == PA_AGG_COUNT || ag->fn == PA_AGG_COUNT_STAR) ? 1 : 2); part++) {
                 col_builder b;
-                cb_init(&b, part == 0 ? PA_BIGINT : (value_double ? PA_DOUBLE : PA_BIGINT), groups);
+                /* min / max: [count BIGINT, value of the input type (NULL while no value was seen)] */
+                cb_init(&b, part == 0 ? PA_BIGINT : (min_max ? ag->input_type : (value_double ? PA_DOUBLE : PA_BIGINT)), groups);
                 for (int32_t g = 0; g < groups; g++) {
                     orc_val v;
                     memset(&v, 0, sizeof v);
                     v.type = b.type;
                     if (part == 0) v.i = st[g].count;
+                    else if (min_max && !st[g].has_value) v.is_null = 1;
                     else { v.d = st[g].dsum; v.i = st[g].lsum; }
                     cb_append(&b, &v);
                 }

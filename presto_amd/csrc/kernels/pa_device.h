@@ -206,6 +206,15 @@ __device__ __forceinline__ i64 pa_wave_sum_i64(i64 v)
     for (int off = 32; off >= 1; off >>= 1) v = v + __shfl_xor(v, off, 64);
     return v;
 }
+__device__ __forceinline__ u64 pa_wave_max_u64(u64 v)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const u64 o = ((u64)(u32)__shfl_xor((int)(u32)(v >> 32), off, 64) << 32) | (u64)(u32)__shfl_xor((int)(u32)v, off, 64);
+        v = o > v ? o : v;
+    }
+    return v;
+}
 __device__ __forceinline__ i64 pa_wave_sum_i64_exact(i64 v, i32* err)
 {
 #pragma unroll
@@ -481,6 +490,19 @@ __device__ __forceinline__ u32 pa_key_hash(const u64* k, const int W)
 #define PA_W_CNT 0
 #define PA_W_SUMF 1
 #define PA_W_SUMI 2
+#define PA_W_MAXU 3   // min / max: unsigned maximum of an order-preserving image of the value (identity 0)
+
+// Order-preserving 64-bit images (a < b in the type's COMPARISON order <=> image(a) < image(b)): min / max become one
+// unsigned maximum (min over x = max over ~image(x)) whose identity is the zero the tables are cleared to.
+__device__ __forceinline__ u64 pa_img_i64(i64 v) { return (u64)v ^ 0x8000000000000000ULL; }
+__device__ __forceinline__ u64 pa_img_f64(double d)
+{
+    // Double.compare (DoubleType.java:194-198): -0.0 < 0.0, one NaN above everything
+    const u64 b = d != d ? 0x7ff8000000000000ULL : (u64)__double_as_longlong(d);
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ULL);
+}
+__device__ __forceinline__ i64 pa_unimg_i64(u64 img) { return (i64)(img ^ 0x8000000000000000ULL); }
+__device__ __forceinline__ u64 pa_unimg_f64_bits(u64 img) { return (img >> 63) ? (img & 0x7fffffffffffffffULL) : ~img; }
 
 __device__ __forceinline__ void pa_gt_add_f64(u64* words, u64 idx, double v)
 {
@@ -489,6 +511,10 @@ __device__ __forceinline__ void pa_gt_add_f64(u64* words, u64 idx, double v)
 __device__ __forceinline__ void pa_gt_add_u64(u64* words, u64 idx, u64 v)
 {
     atomicAdd((unsigned long long*)&words[idx], (unsigned long long)v);
+}
+__device__ __forceinline__ void pa_gt_max_u64(u64* words, u64 idx, u64 v)
+{
+    atomicMax((unsigned long long*)&words[idx], (unsigned long long)v);
 }
 __device__ __forceinline__ void pa_gt_add_i64_exact(u64* words, u64 idx, i64 v, i32* err)
 {

@@ -77,7 +77,7 @@ struct FusedArgs {
 };
 
 enum Variant { V_GLOBAL = 0, V_LDS = 1, V_GT = 2, V_LDSH = 3 };
-enum WordKind { W_CNT = 0, W_SUMF = 1, W_SUMI = 2 };
+enum WordKind { W_CNT = 0, W_SUMF = 1, W_SUMI = 2, W_MAXU = 3 };
 
 constexpr int kLdsSlots = 8;  // C of the LDS variant: 8 groups x NW words x 64 lanes x 8 B of LDS per wave
 
@@ -150,12 +150,18 @@ Spec make_spec(const pa_fused_aggregation_desc* d)
         PA_REQUIRE(a.fn == PA_AGG_COUNT_STAR || (a.input_channel >= 0 && a.input_channel < fp.projection_count), PA_ERR_INVALID_ARGUMENT,
                    "aggregate input channel out of range");
         PA_REQUIRE(a.mask_channel < fp.projection_count, PA_ERR_INVALID_ARGUMENT, "aggregate mask channel out of range");
-        PA_REQUIRE(a.fn != PA_AGG_MIN && a.fn != PA_AGG_MAX, PA_ERR_NOT_SUPPORTED, "min/max are not on the device path yet");
+        if (a.fn == PA_AGG_MIN || a.fn == PA_AGG_MAX) {
+            PA_REQUIRE(a.input_type != PA_VARCHAR, PA_ERR_NOT_SUPPORTED, "min/max over VARCHAR are not on the device path yet");
+        }
         if (s.step == PA_STEP_FINAL) {
             // intermediate input: [count BIGINT] for count / count(*), [count BIGINT, sum] for sum / avg
             PA_REQUIRE(a.input_channel >= 0 && s.proj[a.input_channel].root_type() == PA_BIGINT, PA_ERR_INVALID_ARGUMENT,
                        "FINAL step: the aggregate's first state channel must be the BIGINT count");
             PA_REQUIRE(a.mask_channel < 0, PA_ERR_INVALID_ARGUMENT, "FINAL step takes no mask");
+            if (a.fn == PA_AGG_MIN || a.fn == PA_AGG_MAX) {
+                PA_REQUIRE(a.input_channel + 1 < fp.projection_count, PA_ERR_INVALID_ARGUMENT, "FINAL step: missing value state channel");
+                PA_REQUIRE(s.proj[a.input_channel + 1].root_type() != PA_VARCHAR, PA_ERR_NOT_SUPPORTED, "min/max over VARCHAR are not on the device path yet");
+            }
             if (a.fn == PA_AGG_SUM || a.fn == PA_AGG_AVG) {
                 PA_REQUIRE(a.input_channel + 1 < fp.projection_count, PA_ERR_INVALID_ARGUMENT, "FINAL step: missing sum state channel");
                 int32_t t = s.proj[a.input_channel + 1].root_type();
@@ -164,8 +170,9 @@ Spec make_spec(const pa_fused_aggregation_desc* d)
         }
         else if (a.fn != PA_AGG_COUNT_STAR) {
             int32_t t = s.proj[a.input_channel].root_type();
-            PA_REQUIRE(a.fn == PA_AGG_COUNT || t == PA_DOUBLE || t == PA_BIGINT || t == PA_INTEGER, PA_ERR_NOT_SUPPORTED,
-                       "sum/avg input type not supported on device");
+            const bool min_max = a.fn == PA_AGG_MIN || a.fn == PA_AGG_MAX;
+            PA_REQUIRE(a.fn == PA_AGG_COUNT || t == PA_DOUBLE || t == PA_BIGINT || t == PA_INTEGER || (min_max && (t == PA_DATE || t == PA_BOOLEAN)),
+                       PA_ERR_NOT_SUPPORTED, "aggregate input type not supported on device");
         }
         s.aggs.push_back(a);
     }
@@ -177,7 +184,7 @@ Spec make_spec(const pa_fused_aggregation_desc* d)
     std::set<int> used_proj(s.group_proj.begin(), s.group_proj.end());
     for (const auto& a : s.aggs) {
         if (a.fn != PA_AGG_COUNT_STAR || s.step == PA_STEP_FINAL) used_proj.insert(a.input_channel);
-        if (s.step == PA_STEP_FINAL && (a.fn == PA_AGG_SUM || a.fn == PA_AGG_AVG)) used_proj.insert(a.input_channel + 1);
+        if (s.step == PA_STEP_FINAL && a.fn != PA_AGG_COUNT && a.fn != PA_AGG_COUNT_STAR) used_proj.insert(a.input_channel + 1);  // the value state
         if (a.mask_channel >= 0) used_proj.insert(a.mask_channel);
     }
     for (int j : used_proj) s.proj[j].collect_channels(&used);
@@ -339,6 +346,19 @@ KernelInfo generate(const Spec& s, const std::vector<ChannelLayout>& layout, int
         word_index[key] = (int)words.size() - 1;
         return (int)words.size() - 1;
     };
+    // min / max: u64 maximum of an order-preserving image (pa_img_*; min takes the complement), see pa_device.h
+    auto minmax_image = [&](const GenValue& x, bool is_min) {
+        std::string img;
+        switch (x.type) {
+            case PA_BIGINT:
+            case PA_INTEGER:
+            case PA_DATE: img = "pa_img_i64((i64)" + x.v + ")"; break;
+            case PA_DOUBLE: img = "pa_img_f64(" + x.v + ")"; break;
+            case PA_BOOLEAN: img = "(" + x.v + " ? 1ULL : 0ULL)"; break;
+            default: throw Error(PA_ERR_NOT_SUPPORTED, "min/max input type not supported on device");
+        }
+        return is_min ? "(~" + img + ")" : img;
+    };
     for (const auto& ag : s.aggs) {
         if (s.step == PA_STEP_FINAL) {
             // combine functions (DoubleSumAggregation.combine, AverageAggregations.combine, CountAggregation.combine,
@@ -352,6 +372,12 @@ KernelInfo generate(const Spec& s, const std::vector<ChannelLayout>& layout, int
                 const GenValue& v = proj_value(ag.input_channel + 1);
                 std::string vcond = v.nullable() ? "(" + ccond + " && !" + v.n + ")" : ccond;
                 vw = word(v.type == PA_DOUBLE ? W_SUMF : W_SUMI, vcond, v.v, "fsum|" + ch);
+            }
+            else if (ag.fn == PA_AGG_MIN || ag.fn == PA_AGG_MAX) {
+                // AbstractMinMaxAggregationFunction.combine: compare-and-update with the other state's value
+                const GenValue& v = proj_value(ag.input_channel + 1);
+                std::string vcond = v.nullable() ? "(" + ccond + " && !" + v.n + ")" : ccond;
+                vw = word(W_MAXU, vcond, minmax_image(v, ag.fn == PA_AGG_MIN), std::string(ag.fn == PA_AGG_MIN ? "fmin|" : "fmax|") + ch);
             }
             k.agg_words.emplace_back(cw, vw);
             continue;
@@ -382,6 +408,9 @@ KernelInfo generate(const Spec& s, const std::vector<ChannelLayout>& layout, int
             std::string v = x.type == PA_DOUBLE ? x.v : "((double)" + x.v + ")";  // AverageAggregations.java:34-39
             vw = word(W_SUMF, ccond, v, std::string("sumf|") + (x.type == PA_DOUBLE ? "d|" : "i|") + xkey + "|" + ckey);
         }
+        else if (ag.fn == PA_AGG_MIN || ag.fn == PA_AGG_MAX) {
+            vw = word(W_MAXU, ccond, minmax_image(x, ag.fn == PA_AGG_MIN), std::string(ag.fn == PA_AGG_MIN ? "min|" : "max|") + xkey + "|" + ckey);
+        }
         k.agg_words.emplace_back(cw, vw);
     }
     k.nw = (int)words.size();
@@ -409,7 +438,7 @@ KernelInfo generate(const Spec& s, const std::vector<ChannelLayout>& layout, int
     src << "#define PA_NW " << k.nw << "\n#define PA_KW " << (k.w > 0 ? k.w : 1) << "\n#define PA_C " << (k.c > 0 ? k.c : 1) << "\n";
     if (variant == V_GLOBAL) {
         src << "struct PaAcc {";
-        for (int w = 0; w < k.nw; w++) src << (words[w].kind == W_SUMF ? " double" : " i64") << " w" << w << ";";
+        for (int w = 0; w < k.nw; w++) src << (words[w].kind == W_SUMF ? " double" : (words[w].kind == W_MAXU ? " u64" : " i64")) << " w" << w << ";";
         src << " };\n";
     }
     else if (variant == V_LDS) {
@@ -460,7 +489,7 @@ KernelInfo generate(const Spec& s, const std::vector<ChannelLayout>& layout, int
     src << body.str();
     // values needed after the selected-only block are declared up front
     for (int w = 0; w < k.nw; w++) {
-        src << "bool u" << w << " = false; " << (words[w].kind == W_SUMF ? "double" : "i64") << " x" << w << " = 0;\n";
+        src << "bool u" << w << " = false; " << (words[w].kind == W_SUMF ? "double" : (words[w].kind == W_MAXU ? "u64" : "i64")) << " x" << w << " = 0;\n";
     }
     if (k.w > 0) src << "u64 key[PA_KW];\n#pragma unroll\nfor (int i = 0; i < PA_KW; i++) key[i] = 0;\n";
     src << "if (sel) {\n" << inner.str();
@@ -476,6 +505,7 @@ KernelInfo generate(const Spec& s, const std::vector<ChannelLayout>& layout, int
         for (int w = 0; w < k.nw; w++) {
             if (words[w].kind == W_SUMF) src << "if (u" << w << ") acc.w" << w << " = acc.w" << w << " + x" << w << ";\n";
             else if (words[w].kind == W_SUMI) src << "if (u" << w << ") acc.w" << w << " = pa_add_exact(acc.w" << w << ", x" << w << ", a.err);\n";
+            else if (words[w].kind == W_MAXU) src << "if (u" << w << ") acc.w" << w << " = x" << w << " > acc.w" << w << " ? x" << w << " : acc.w" << w << ";\n";
             else src << "if (u" << w << ") acc.w" << w << " += x" << w << ";\n";
         }
         src << "}\n";
@@ -498,6 +528,9 @@ KernelInfo generate(const Spec& s, const std::vector<ChannelLayout>& layout, int
             }
             else if (words[w].kind == W_SUMI) {
                 src << "    if (u" << w << ") { i64* p = (i64*)&" << idx << "; *p = pa_add_exact(*p, x" << w << ", a.err); }\n";
+            }
+            else if (words[w].kind == W_MAXU) {
+                src << "    if (u" << w << ") { u64* p = &" << idx << "; if (x" << w << " > *p) *p = x" << w << "; }\n";
             }
             else {
                 src << "    if (u" << w << ") __hip_atomic_fetch_add(&" << idx << ", " << (words[w].val == "1" ? std::string("1ULL") : "(u64)x" + std::to_string(w))
@@ -523,6 +556,9 @@ KernelInfo generate(const Spec& s, const std::vector<ChannelLayout>& layout, int
                         << ", __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); i64 r; if (__builtin_add_overflow(o, x" << w
                         << ", &r)) pa_raise(a.err, PA_DEV_ERR_OUT_OF_RANGE); }\n";
                 }
+                else if (words[w].kind == W_MAXU) {
+                    src << "    if (u" << w << ") __hip_atomic_fetch_max(&" << idx << ", x" << w << ", __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);\n";
+                }
                 else {
                     src << "    if (u" << w << ") __hip_atomic_fetch_add(&" << idx << ", " << (words[w].val == "1" ? std::string("1ULL") : "(u64)x" + std::to_string(w))
                         << ", __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);\n";
@@ -536,6 +572,7 @@ KernelInfo generate(const Spec& s, const std::vector<ChannelLayout>& layout, int
             std::string idx = std::to_string(w) + "ULL * cap + (u64)g";
             if (words[w].kind == W_SUMF) src << "    if (u" << w << ") pa_gt_add_f64(acc.tv.words, " << idx << ", x" << w << ");\n";
             else if (words[w].kind == W_SUMI) src << "    if (u" << w << ") pa_gt_add_i64_exact(acc.tv.words, " << idx << ", x" << w << ", a.err);\n";
+            else if (words[w].kind == W_MAXU) src << "    if (u" << w << ") pa_gt_max_u64(acc.tv.words, " << idx << ", x" << w << ");\n";
             else src << "    if (u" << w << ") pa_gt_add_u64(acc.tv.words, " << idx << ", (u64)x" << w << ");\n";
         }
         // no room for this row's group: spill the row; the host rehashes and replays the spilled rows
@@ -621,6 +658,7 @@ KernelInfo generate(const Spec& s, const std::vector<ChannelLayout>& layout, int
                 std::string v = "pa_lt_acc[sl * PA_NW + " + std::to_string(w) + "]";
                 if (words[w].kind == W_SUMF) src << "        pa_gt_add_f64(acc.tv.words, " << idx << ", __longlong_as_double((i64)" << v << "));\n";
                 else if (words[w].kind == W_SUMI) src << "        pa_gt_add_i64_exact(acc.tv.words, " << idx << ", (i64)" << v << ", a.err);\n";
+                else if (words[w].kind == W_MAXU) src << "        pa_gt_max_u64(acc.tv.words, " << idx << ", " << v << ");\n";
                 else src << "        pa_gt_add_u64(acc.tv.words, " << idx << ", " << v << ");\n";
             }
             src << "    }\n    pa_gt_ctr_flush(acc.flush, acc.tv.count);\n";
@@ -632,6 +670,7 @@ KernelInfo generate(const Spec& s, const std::vector<ChannelLayout>& layout, int
             for (int w = 0; w < k.nw; w++) {
                 if (words[w].kind == W_SUMF) src << "    { double v = pa_wave_sum_f64(acc.w" << w << "); if (lane == 0) red[wave * PA_NW + " << w << "] = (u64)__double_as_longlong(v); }\n";
                 else if (words[w].kind == W_SUMI) src << "    { i64 v = pa_wave_sum_i64_exact(acc.w" << w << ", a.err); if (lane == 0) red[wave * PA_NW + " << w << "] = (u64)v; }\n";
+                else if (words[w].kind == W_MAXU) src << "    { u64 v = pa_wave_max_u64(acc.w" << w << "); if (lane == 0) red[wave * PA_NW + " << w << "] = v; }\n";
                 else src << "    { i64 v = pa_wave_sum_i64(acc.w" << w << "); if (lane == 0) red[wave * PA_NW + " << w << "] = (u64)v; }\n";
             }
             src << "    __syncthreads();\n    if (threadIdx.x < PA_NW) {\n        const int w = threadIdx.x;\n        u64 r = red[w];\n";
@@ -641,6 +680,7 @@ KernelInfo generate(const Spec& s, const std::vector<ChannelLayout>& layout, int
                 src << "                case " << w << ": ";
                 if (words[w].kind == W_SUMF) src << "r = (u64)__double_as_longlong(__longlong_as_double((i64)r) + __longlong_as_double((i64)o)); break;\n";
                 else if (words[w].kind == W_SUMI) src << "r = (u64)pa_add_exact((i64)r, (i64)o, a.err); break;\n";
+                else if (words[w].kind == W_MAXU) src << "r = o > r ? o : r; break;\n";
                 else src << "r = r + o; break;\n";
             }
             src << "            }\n        }\n        a.slab[(u64)blockIdx.x * PA_NW + w] = r;\n    }\n";
@@ -658,6 +698,7 @@ KernelInfo generate(const Spec& s, const std::vector<ChannelLayout>& layout, int
                 std::string dst = "e[(u64)(1 + PA_KW + " + std::to_string(w) + ") * E]";
                 if (words[w].kind == W_SUMF) src << "            { double v = pa_wave_sum_f64(__longlong_as_double((i64)" << idx << ")); if (threadIdx.x == 0) " << dst << " = (u64)__double_as_longlong(v); }\n";
                 else if (words[w].kind == W_SUMI) src << "            { i64 v = pa_wave_sum_i64_exact((i64)" << idx << ", a.err); if (threadIdx.x == 0) " << dst << " = (u64)v; }\n";
+                else if (words[w].kind == W_MAXU) src << "            { u64 v = pa_wave_max_u64(" << idx << "); if (threadIdx.x == 0) " << dst << " = v; }\n";
                 else src << "            { i64 v = pa_wave_sum_i64((i64)" << idx << "); if (threadIdx.x == 0) " << dst << " = (u64)v; }\n";
             }
             src << "        }\n    }\n";
@@ -752,8 +793,10 @@ public:
                 compiled = &kernel_for(sig, layout, mode_);
             }
             catch (const Error& e) {
-                if (mode_ != V_LDSH || e.code != PA_ERR_NOT_SUPPORTED) throw;
-                mode_ = V_GT;  // group state too wide for a workgroup's LDS table
+                // the group state may be too wide for the wave's / the workgroup's LDS budget: move on to the next tier
+                // (anything else that is not supported fails again there and surfaces)
+                if (e.code != PA_ERR_NOT_SUPPORTED || (mode_ != V_LDS && mode_ != V_LDSH)) throw;
+                mode_ = mode_ == V_LDS ? V_LDSH : V_GT;
                 continue;
             }
             const Compiled& ck = *compiled;
@@ -1202,6 +1245,23 @@ bool FusedAggregationOperator::emit_on_device(const KernelInfo& ki, int64_t grou
         const pa_aggregate& ag = spec_.aggs[k];
         const int cw = ki.agg_words[k].first, vw = ki.agg_words[k].second;
         const bool value_is_double = vw >= 0 && ki.word_kind[vw] == W_SUMF;
+        const bool min_max = ag.fn == PA_AGG_MIN || ag.fn == PA_AGG_MAX;
+        const int value_proj = spec_.step == PA_STEP_FINAL ? ag.input_channel + 1 : ag.input_channel;
+        if (partial && min_max) {
+            GtEmitCol* c = add(GT_EMIT_STATE, PA_BIGINT);
+            if (!c) return false;
+            c->word = cw;
+            nullable.push_back(false);
+        }
+        if (min_max) {  // the value itself (final result, or the value half of the PARTIAL state): NULL while no input was seen
+            GtEmitCol* c = add(GT_EMIT_MINMAX, spec_.proj[value_proj].root_type());
+            if (!c) return false;
+            c->cw = cw;
+            c->vw = vw;
+            c->shift = ag.fn == PA_AGG_MIN ? 1 : 0;
+            nullable.push_back(true);
+            continue;
+        }
         if (partial) {
             for (int part = 0; part < ((ag.fn == PA_AGG_SUM || ag.fn == PA_AGG_AVG) ? 2 : 1); part++) {
                 GtEmitCol* c = add(GT_EMIT_STATE, part == 0 ? PA_BIGINT : (value_is_double ? PA_DOUBLE : PA_BIGINT));
@@ -1212,7 +1272,6 @@ bool FusedAggregationOperator::emit_on_device(const KernelInfo& ki, int64_t grou
             continue;
         }
         const bool as_double = ag.fn == PA_AGG_AVG || (ag.fn == PA_AGG_SUM && value_is_double);
-        const int value_proj = spec_.step == PA_STEP_FINAL ? ag.input_channel + 1 : ag.input_channel;
         const int type = as_double ? PA_DOUBLE : ((ag.fn == PA_AGG_SUM) ? spec_.proj[value_proj].root_type() : PA_BIGINT);
         const int kind = ag.fn == PA_AGG_SUM ? GT_EMIT_SUM : (ag.fn == PA_AGG_AVG ? GT_EMIT_AVG : GT_EMIT_COUNT);
         if (ag.fn != PA_AGG_SUM && ag.fn != PA_AGG_AVG && ag.fn != PA_AGG_COUNT && ag.fn != PA_AGG_COUNT_STAR) return false;
@@ -1323,7 +1382,7 @@ void FusedAggregationOperator::build_output()
     const bool has_hash = nkeys > 0 && spec_.hash_channel >= 0;
     const bool partial = spec_.step == PA_STEP_PARTIAL;
     int agg_cols = 0;
-    for (const auto& ag : spec_.aggs) agg_cols += (partial && (ag.fn == PA_AGG_SUM || ag.fn == PA_AGG_AVG)) ? 2 : 1;
+    for (const auto& ag : spec_.aggs) agg_cols += (partial && ag.fn != PA_AGG_COUNT && ag.fn != PA_AGG_COUNT_STAR) ? 2 : 1;
     const int ncols = nkeys + (has_hash ? 1 : 0) + agg_cols;
     out_cols_.clear();
     out_cols_.resize(ncols);
@@ -1419,6 +1478,44 @@ void FusedAggregationOperator::build_output()
         const pa_aggregate& ag = spec_.aggs[k];
         int cw = ki.agg_words[k].first, vw = ki.agg_words[k].second;
         const bool value_is_double = vw >= 0 && ki.word_kind[vw] == W_SUMF;
+        if (ag.fn == PA_AGG_MIN || ag.fn == PA_AGG_MAX) {
+            // the value back from its order-preserving image (pa_img_*); PARTIAL = [count BIGINT, value], NULL while count == 0
+            if (partial) {
+                OutColumn& cc = out_cols_[col];
+                cc.type = PA_BIGINT;
+                host_nulls[col].assign(groups ? groups : 1, 0);
+                host_cols[col].resize((size_t)groups * 8);
+                for (int64_t g = 0; g < groups; g++) memcpy(&host_cols[col][(size_t)g * 8], &words[(size_t)g * nw_ + cw], 8);
+                cc.has_nulls = false;
+                col++;
+            }
+            const int value_proj = spec_.step == PA_STEP_FINAL ? ag.input_channel + 1 : ag.input_channel;
+            OutColumn& oc = out_cols_[col];
+            oc.type = spec_.proj[value_proj].root_type();
+            const int width = type_width(oc.type);
+            auto& data = host_cols[col];
+            auto& nulls = host_nulls[col];
+            nulls.assign(groups ? groups : 1, 0);
+            data.assign((size_t)groups * width, 0);
+            bool any_null = false;
+            for (int64_t g = 0; g < groups; g++) {
+                const uint64_t* ww = &words[(size_t)g * nw_];
+                if (ww[cw] == 0) {
+                    nulls[g] = 1;
+                    any_null = true;
+                    continue;
+                }
+                uint64_t img = ag.fn == PA_AGG_MIN ? ~ww[vw] : ww[vw];
+                uint64_t bits;
+                if (oc.type == PA_DOUBLE) bits = (img >> 63) ? (img & 0x7fffffffffffffffULL) : ~img;
+                else if (oc.type == PA_BOOLEAN) bits = img;
+                else bits = img ^ 0x8000000000000000ULL;
+                memcpy(&data[(size_t)g * width], &bits, (size_t)width);  // little endian: the low bytes are the narrower value
+            }
+            oc.has_nulls = any_null;
+            col++;
+            continue;
+        }
         if (partial) {
             // Step.PARTIAL: the accumulator states themselves -- [count BIGINT] (+ [sum]) per aggregate, the flattened form
             // of the reference's LongState / LongDoubleState / LongLongState intermediate rows

@@ -105,6 +105,14 @@ __global__ __launch_bounds__(256) void k_merge_global_slab(const u64* __restrict
             for (int b = threadIdx.x; b < blocks; b += 256) acc = acc + __longlong_as_double((i64)slab[(u64)b * nw + w]);
             part[threadIdx.x] = (u64)__double_as_longlong(acc);
         }
+        else if (kind == PA_W_MAXU) {
+            u64 acc = 0;
+            for (int b = threadIdx.x; b < blocks; b += 256) {
+                const u64 v = slab[(u64)b * nw + w];
+                acc = v > acc ? v : acc;
+            }
+            part[threadIdx.x] = acc;
+        }
         else {
             i64 acc = 0;
             for (int b = threadIdx.x; b < blocks; b += 256) {
@@ -124,6 +132,9 @@ __global__ __launch_bounds__(256) void k_merge_global_slab(const u64* __restrict
                 else if (kind == PA_W_SUMI) {
                     part[threadIdx.x] = (u64)pa_add_exact((i64)part[threadIdx.x], (i64)part[threadIdx.x + stride], err);
                 }
+                else if (kind == PA_W_MAXU) {
+                    part[threadIdx.x] = part[threadIdx.x + stride] > part[threadIdx.x] ? part[threadIdx.x + stride] : part[threadIdx.x];
+                }
                 else {
                     part[threadIdx.x] += part[threadIdx.x + stride];
                 }
@@ -133,6 +144,7 @@ __global__ __launch_bounds__(256) void k_merge_global_slab(const u64* __restrict
         if (threadIdx.x == 0) {
             if (kind == PA_W_SUMF) state[w] = (u64)__double_as_longlong(__longlong_as_double((i64)state[w]) + __longlong_as_double((i64)part[0]));
             else if (kind == PA_W_SUMI) state[w] = (u64)pa_add_exact((i64)state[w], (i64)part[0], err);
+            else if (kind == PA_W_MAXU) state[w] = part[0] > state[w] ? part[0] : state[w];
             else state[w] += part[0];
         }
         __syncthreads();
@@ -208,6 +220,7 @@ __global__ __launch_bounds__(256) void k_merge_lds_words(const u64* __restrict__
             const u64* col = slab + (i64)(1 + W + w) * entries;
             double accf = 0.0;
             i64 acci = 0;
+            u64 accm = 0;
             // coalesced and branch-free: entries of other slots contribute an exact zero.  8 entries per lane are
             // loaded before the first use so that the loop is not one HBM round trip per entry.
             for (i64 e0 = threadIdx.x; e0 < entries; e0 += 256 * 8) {
@@ -225,15 +238,17 @@ __global__ __launch_bounds__(256) void k_merge_lds_words(const u64* __restrict__
                     const bool mine = es[j] == (i32)slot;
                     if (kind == PA_W_SUMF) accf = accf + (mine ? __longlong_as_double((i64)v[j]) : 0.0);
                     else if (kind == PA_W_SUMI) acci = pa_add_exact(acci, mine ? (i64)v[j] : 0, err);
+                    else if (kind == PA_W_MAXU) accm = (mine && v[j] > accm) ? v[j] : accm;
                     else acci += mine ? (i64)v[j] : 0;
                 }
             }
-            part[threadIdx.x] = kind == PA_W_SUMF ? (u64)__double_as_longlong(accf) : (u64)acci;
+            part[threadIdx.x] = kind == PA_W_SUMF ? (u64)__double_as_longlong(accf) : (kind == PA_W_MAXU ? accm : (u64)acci);
             __syncthreads();
             for (int s = 128; s >= 1; s >>= 1) {
                 if ((int)threadIdx.x < s) {
                     if (kind == PA_W_SUMF) part[threadIdx.x] = (u64)__double_as_longlong(__longlong_as_double((i64)part[threadIdx.x]) + __longlong_as_double((i64)part[threadIdx.x + s]));
                     else if (kind == PA_W_SUMI) part[threadIdx.x] = (u64)pa_add_exact((i64)part[threadIdx.x], (i64)part[threadIdx.x + s], err);
+                    else if (kind == PA_W_MAXU) part[threadIdx.x] = part[threadIdx.x + s] > part[threadIdx.x] ? part[threadIdx.x + s] : part[threadIdx.x];
                     else part[threadIdx.x] += part[threadIdx.x + s];
                 }
                 __syncthreads();
@@ -242,6 +257,7 @@ __global__ __launch_bounds__(256) void k_merge_lds_words(const u64* __restrict__
                 u64* dst = &words[(u64)w * cap + slot];
                 if (kind == PA_W_SUMF) *dst = (u64)__double_as_longlong(__longlong_as_double((i64)*dst) + __longlong_as_double((i64)part[0]));
                 else if (kind == PA_W_SUMI) *dst = (u64)pa_add_exact((i64)*dst, (i64)part[0], err);
+                else if (kind == PA_W_MAXU) *dst = part[0] > *dst ? part[0] : *dst;
                 else *dst += part[0];
             }
             __syncthreads();
@@ -296,6 +312,7 @@ __global__ __launch_bounds__(256) void k_gt_fold(const u64* __restrict__ old_tag
             const int kind = kinds[w];
             if (kind == PA_W_SUMF) pa_gt_add_f64(words, idx, __longlong_as_double((i64)v));
             else if (kind == PA_W_SUMI) pa_gt_add_i64_exact(words, idx, (i64)v, err);
+            else if (kind == PA_W_MAXU) pa_gt_max_u64(words, idx, v);
             else pa_gt_add_u64(words, idx, v);
         }
     }
@@ -368,6 +385,17 @@ __device__ __forceinline__ void gt_emit_slot(const GtEmitArgs& a, u64 i, u64 g)
                 if (wd[(u64)col.cw * a.cap + i] == 0ULL) is_null = true;
                 else bits = wd[(u64)col.vw * a.cap + i];
                 break;
+            case GT_EMIT_MINMAX: {
+                if (wd[(u64)col.cw * a.cap + i] == 0ULL) is_null = true;
+                else {
+                    u64 img = wd[(u64)col.vw * a.cap + i];
+                    if (col.shift) img = ~img;  // min is kept as the maximum of the complement
+                    if (col.type == PA_DOUBLE) bits = pa_unimg_f64_bits(img);
+                    else if (col.type == PA_BOOLEAN) bits = img;
+                    else bits = (u64)pa_unimg_i64(img);
+                }
+                break;
+            }
             case GT_EMIT_AVG: {
                 const i64 count = (i64)wd[(u64)col.cw * a.cap + i];
                 if (count == 0) is_null = true;

@@ -27,10 +27,10 @@ void launch_tpch(int32_t column, double sf, int64_t first_row, int64_t n, uint64
 // Grouped output assembled on device (InMemoryHashAggregationBuilder.buildResult): one pass over the table slots
 // compacts the occupied ones (one counter atomic per wave) and writes every output block -- unpacked key columns,
 // $hashvalue, final aggregate values or PARTIAL states -- directly.
-enum GtEmitKind { GT_EMIT_KEY = 0, GT_EMIT_HASH = 1, GT_EMIT_COUNT = 2, GT_EMIT_SUM = 3, GT_EMIT_AVG = 4, GT_EMIT_STATE = 5 };
+enum GtEmitKind { GT_EMIT_KEY = 0, GT_EMIT_HASH = 1, GT_EMIT_COUNT = 2, GT_EMIT_SUM = 3, GT_EMIT_AVG = 4, GT_EMIT_STATE = 5, GT_EMIT_MINMAX = 6 };
 struct GtEmitCol {
     int32_t kind, type;          // GtEmitKind, pa_type of the output block
-    int32_t word, shift, bits;   // KEY: packed position; STATE: accumulator word
+    int32_t word, shift, bits;   // KEY: packed position; STATE: accumulator word; MINMAX: shift = 1 for min
     int32_t null_word, null_shift;
     int32_t cw, vw;              // aggregates: count word, value word
     int32_t width;               // bytes per output element

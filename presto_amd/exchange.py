@@ -119,7 +119,7 @@ def partial_layout(key_types, aggregates):
     """Channel types of a Step.PARTIAL output page and the aggregate list of the matching Step.FINAL operator.
 
     aggregates: list of (fn, input_channel, input_type[, mask]) of the SINGLE-step aggregation.  The intermediate
-    channels follow include/presto_amd.h: [count] for count / count(*), [count, sum] for sum / avg."""
+    channels follow include/presto_amd.h: [count] for count / count(*), [count, sum] for sum / avg, [count, value] for min / max."""
     types = list(key_types)
     final = []
     for a in aggregates:
@@ -130,6 +130,9 @@ def partial_layout(key_types, aggregates):
             value_type = abi.DOUBLE if (fn == abi.AGG_AVG or in_type == abi.DOUBLE) else abi.BIGINT
             types.append(value_type)
             final.append((fn, first, value_type))
+        elif fn in (abi.AGG_MIN, abi.AGG_MAX):
+            types.append(in_type)  # [count, value of the input type]
+            final.append((fn, first, in_type))
         else:
             final.append((fn, first, abi.BIGINT))
     return types, final

@@ -223,3 +223,51 @@ def test_hash_aggregation_across_cardinalities(gpu, oracle, groups, pages, rows)
     expected = ref.build_result().to_rows()
     assert len(expected) >= min(groups, 9)
     rows_equal_ignore_order(got, expected, rel=1e-9)
+
+
+@pytest.mark.parametrize("groups,rows", [(0, 30001), (5, 20000), (200, 100003), (5000, 200001), (60000, 200003)])
+def test_min_max_across_variants_and_types(gpu, oracle, groups, rows):
+    """min / max (AbstractMinMaxAggregationFunction: the type's COMPARISON operator; Double.compare for DOUBLE, so NaN is the
+    maximum and -0.0 < 0.0) over BIGINT / INTEGER / DATE / DOUBLE / BOOLEAN in every variant of the aggregation -- global,
+    wave-register table, workgroup LDS table, HBM table -- with nullable inputs and a mask; bit-exact against the oracle."""
+    rng = np.random.default_rng(groups + 1)
+    plist = []
+    for p in range(2):
+        d = rng.standard_normal(rows) * 100
+        d[rng.random(rows) < 0.002] = np.nan
+        d[rng.random(rows) < 0.01] = -0.0
+        d[rng.random(rows) < 0.01] = 0.0
+        plist.append(Page([Block.bigint(rng.integers(0, max(groups, 1), rows)), Block.double(d, rng.random(rows) < 0.2),
+                           Block.bigint(rng.integers(-2 ** 62, 2 ** 62, rows), rng.random(rows) < 0.5), Block.integer(rng.integers(-1000, 1000, rows)),
+                           Block.date(rng.integers(8000, 12000, rows)), Block.boolean(rng.random(rows) < 0.5, rng.random(rows) < 0.3),
+                           Block.boolean(rng.random(rows) < 0.6)], rows))
+    types = [abi.BIGINT, abi.DOUBLE, abi.BIGINT, abi.INTEGER, abi.DATE, abi.BOOLEAN, abi.BOOLEAN]
+    aggs = [(abi.AGG_MIN, 1, abi.DOUBLE), (abi.AGG_MAX, 1, abi.DOUBLE), (abi.AGG_MIN, 2, abi.BIGINT), (abi.AGG_MAX, 2, abi.BIGINT),
+            (abi.AGG_MIN, 3, abi.INTEGER), (abi.AGG_MAX, 4, abi.DATE), (abi.AGG_MIN, 5, abi.BOOLEAN), (abi.AGG_MAX, 5, abi.BOOLEAN),
+            (abi.AGG_MAX, 1, abi.DOUBLE, 6), (abi.AGG_SUM, 3, abi.INTEGER), (abi.AGG_COUNT_STAR, -1, None)]
+    keys = [0] if groups else []
+    make = (lambda **kw: HashAggregationOperator(types, keys, aggs, **kw)) if groups else (lambda **kw: AggregationOperator(types, aggs, **kw))
+    got = [r for p in to_pages(make(), plist) for r in p.to_rows()]
+    ref = oracle.HashAggregation(types, keys, aggs)
+    for p in plist:
+        ref.add_page(p)
+    expected = ref.build_result().to_rows()
+    assert bits_of(sorted(got, key=lambda r: r[0] if groups else 0)) == bits_of(sorted(expected, key=lambda r: r[0] if groups else 0))
+    # PARTIAL per page, FINAL over the partial pages == SINGLE
+    from presto_amd.exchange import partial_layout
+    ptypes, faggs = partial_layout([abi.BIGINT] if groups else [], aggs)
+    partial_pages = []
+    for p in plist:
+        partial_pages += to_pages(make(step=abi.STEP_PARTIAL), [p])
+    fkeys = [0] if groups else []
+    final = HashAggregationOperator(ptypes, fkeys, faggs, step=abi.STEP_FINAL) if groups else AggregationOperator(ptypes, faggs, step=abi.STEP_FINAL)
+    got2 = [r for p in to_pages(final, partial_pages) for r in p.to_rows()]
+    assert bits_of(sorted(got2, key=lambda r: r[0] if groups else 0)) == bits_of(sorted(expected, key=lambda r: r[0] if groups else 0))
+
+
+def bits_of(rows):
+    import struct
+    out = []
+    for r in rows:
+        out.append(tuple(("nan" if v != v else struct.pack("<d", v)) if isinstance(v, float) else v for v in r))
+    return out
