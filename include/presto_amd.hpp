@@ -304,6 +304,74 @@ inline std::unique_ptr<Operator> createHashAggregationOperator(const std::vector
     return std::make_unique<Operator>(h);
 }
 
+inline std::unique_ptr<Operator> createTopNOperator(const std::vector<int32_t>& inputTypes, int32_t n, const std::vector<int32_t>& sortChannels,
+                                                    const std::vector<int32_t>& sortOrders)
+{
+    pa_topn_desc d{};
+    d.input_channel_count = (int32_t)inputTypes.size();
+    d.input_types = inputTypes.data();
+    d.n = n;
+    d.sort_channel_count = (int32_t)sortChannels.size();
+    d.sort_channels = sortChannels.data();
+    d.sort_orders = sortOrders.data();
+    d.output_mem = PA_MEM_HOST;
+    pa_operator* h = nullptr;
+    check(pa_topn_create(&d, &h));
+    return std::make_unique<Operator>(h);
+}
+
+// JoinBridge shared by the build operator and its probe operators (JoinBridgeManager / PartitionedLookupSourceFactory)
+class LookupSourceFactory {
+public:
+    LookupSourceFactory() { check(pa_lookup_source_create(&h_)); }
+    LookupSourceFactory(const LookupSourceFactory&) = delete;
+    LookupSourceFactory& operator=(const LookupSourceFactory&) = delete;
+    ~LookupSourceFactory()
+    {
+        if (h_) pa_lookup_source_destroy(h_);
+    }
+    pa_lookup_source* handle() { return h_; }
+
+private:
+    pa_lookup_source* h_ = nullptr;
+};
+
+inline std::unique_ptr<Operator> createHashBuilderOperator(LookupSourceFactory& bridge, const std::vector<int32_t>& inputTypes,
+                                                           const std::vector<int32_t>& joinChannels, const std::vector<int32_t>& outputChannels)
+{
+    pa_hash_builder_desc d{};
+    d.input_channel_count = (int32_t)inputTypes.size();
+    d.input_types = inputTypes.data();
+    d.join_channel_count = (int32_t)joinChannels.size();
+    d.join_channels = joinChannels.data();
+    d.hash_channel = -1;
+    d.output_channel_count = (int32_t)outputChannels.size();
+    d.output_channels = outputChannels.data();
+    pa_operator* h = nullptr;
+    check(pa_hash_builder_create(&d, bridge.handle(), &h));
+    return std::make_unique<Operator>(h);
+}
+
+// OperatorFactories.innerJoin / probeOuterJoin / lookupOuterJoin / fullOuterJoin: joinType = pa_join_type
+inline std::unique_ptr<Operator> createLookupJoinOperator(LookupSourceFactory& bridge, const std::vector<int32_t>& probeTypes,
+                                                          const std::vector<int32_t>& probeJoinChannels, const std::vector<int32_t>& probeOutputChannels,
+                                                          int32_t joinType = PA_JOIN_INNER)
+{
+    pa_lookup_join_desc d{};
+    d.probe_channel_count = (int32_t)probeTypes.size();
+    d.probe_types = probeTypes.data();
+    d.join_channel_count = (int32_t)probeJoinChannels.size();
+    d.probe_join_channels = probeJoinChannels.data();
+    d.probe_hash_channel = -1;
+    d.probe_output_channel_count = (int32_t)probeOutputChannels.size();
+    d.probe_output_channels = probeOutputChannels.data();
+    d.output_mem = PA_MEM_HOST;
+    d.join_type = joinType;
+    pa_operator* h = nullptr;
+    check(pa_lookup_join_create(&d, bridge.handle(), &h));
+    return std::make_unique<Operator>(h);
+}
+
 // ---- Driver (Driver.processInternal): page source -> operators[0] -> ... -> collected output -----------------------
 inline std::vector<Page> runDriver(const std::vector<Page>& source, const std::vector<Operator*>& operators)
 {

@@ -175,6 +175,49 @@ static void testPipeline()
     }
 }
 
+// join-1: TestHashJoinOperator.testInnerJoin (core/trino-main/src/test/java/io/trino/operator/join/TestHashJoinOperator.java:192-229):
+// build (VARCHAR, BIGINT, BIGINT) sequence 10 rows @20,30,40; probe sequence 1000 rows @0,1000,2000; key channel 0.  Then the
+// same build probed with a probe-outer join, and a TopN over the join output (TestTopNOperator-style ordering).
+static Page sequencePage3(int32_t length, int64_t a, int64_t b, int64_t c)
+{
+    std::vector<std::string> s;
+    std::vector<int64_t> x, y;
+    for (int32_t i = 0; i < length; i++) {
+        s.push_back(std::to_string(a + i));
+        x.push_back(b + i);
+        y.push_back(c + i);
+    }
+    return Page({Block::varchar(s), Block::bigint(x), Block::bigint(y)});
+}
+
+static void testJoinAndTopN()
+{
+    std::vector<int32_t> types = {PA_VARCHAR, PA_BIGINT, PA_BIGINT};
+    LookupSourceFactory bridge;
+    auto build = createHashBuilderOperator(bridge, types, {0}, {0, 1, 2});
+    runDriver({sequencePage3(10, 20, 30, 40)}, {build.get()});
+    auto join = createLookupJoinOperator(bridge, types, {0}, {0, 1, 2});
+    std::vector<int32_t> joined = {PA_VARCHAR, PA_BIGINT, PA_BIGINT, PA_VARCHAR, PA_BIGINT, PA_BIGINT};
+    auto topn = createTopNOperator(joined, 3, {1}, {PA_DESC_NULLS_LAST});
+    auto out = runDriver({sequencePage3(1000, 0, 1000, 2000)}, {join.get(), topn.get()});
+    EXPECT(out.size() == 1 && out[0].getPositionCount() == 3, "join-1 + TopN: expected one page of 3 rows");
+    for (int32_t i = 0; !out.empty() && i < out[0].getPositionCount(); i++) {
+        const int64_t k = 29 - i;  // the 10 matches are probe rows "20".."29"; top 3 by probe column 1 descending
+        EXPECT(out[0].getBlock(0).getSlice(i) == std::to_string(k) && out[0].getBlock(3).getSlice(i) == std::to_string(k), "join-1 keys row %d", i);
+        EXPECT(out[0].getBlock(1).getLong(i) == 1000 + k && out[0].getBlock(2).getLong(i) == 2000 + k, "join-1 probe columns row %d", i);
+        EXPECT(out[0].getBlock(4).getLong(i) == 30 + (k - 20) && out[0].getBlock(5).getLong(i) == 40 + (k - 20), "join-1 build columns row %d", i);
+    }
+    // testProbeOuterJoin (:850-894): 15 probe rows @20: 10 matches, then 5 rows with NULL build columns
+    auto outer = createLookupJoinOperator(bridge, types, {0}, {0, 1, 2}, PA_JOIN_PROBE_OUTER);
+    auto rows = runDriver({sequencePage3(15, 20, 1020, 2020)}, {outer.get()});
+    EXPECT(rows.size() == 1 && rows[0].getPositionCount() == 15, "probe outer: expected 15 rows");
+    for (int32_t i = 0; !rows.empty() && i < rows[0].getPositionCount(); i++) {
+        EXPECT(rows[0].getBlock(1).getLong(i) == 1020 + i, "probe outer probe column row %d", i);
+        EXPECT(rows[0].getBlock(4).isNull(i) == (i >= 10), "probe outer NULL build side row %d", i);
+        if (i < 10) EXPECT(rows[0].getBlock(4).getLong(i) == 30 + i, "probe outer build column row %d", i);
+    }
+}
+
 int main()
 {
     try {
@@ -182,6 +225,7 @@ int main()
         testFilterAndProject();
         testDivisionByZero();
         testPipeline();
+        testJoinAndTopN();
         pa_shutdown();
     }
     catch (const std::exception& e) {
