@@ -64,7 +64,7 @@ std::string double_literal(double v)
     if (v != v) return "__longlong_as_double(0x7ff8000000000000LL)";
     if (std::isinf(v)) return v > 0 ? "__longlong_as_double(0x7ff0000000000000LL)" : "__longlong_as_double(0xfff0000000000000LL)";
     char buf[64];
-    snprintf(buf, sizeof buf, "%a", v);  // exact hexadecimal floating literal (C++17)
+    snprintf(buf, sizeof buf, v < 0 || (v == 0 && std::signbit(v)) ? "(%a)" : "%a", v);  // exact hexadecimal floating literal (C++17)
     return buf;
 }
 
@@ -195,7 +195,7 @@ GenValue RowCodegen::emit_node(const OwnedExpr& e, int32_t id, std::ostringstrea
                     char buf[40];
                     int64_t v = n.is_null ? 0 : n.i64;
                     if (v == INT64_MIN) snprintf(buf, sizeof buf, "(-9223372036854775807LL - 1)");
-                    else snprintf(buf, sizeof buf, "%" PRId64 "LL", v);
+                    else snprintf(buf, sizeof buf, v < 0 ? "(%" PRId64 "LL)" : "%" PRId64 "LL", v);
                     r.v = buf;
                 }
             }
@@ -248,7 +248,7 @@ GenValue RowCodegen::emit_node(const OwnedExpr& e, int32_t id, std::ostringstrea
                     case PA_OP_MULTIPLY: out << x.v << " * " << y.v; break;
                     case PA_OP_DIVIDE: out << x.v << " / " << y.v; break;
                     case PA_OP_MODULUS: out << "fmod(" << x.v << ", " << y.v << ")"; break;
-                    default: out << "-" << x.v; break;
+                    default: out << "-(" << x.v << ")"; break;  // (a negative literal operand would read as `--`)
                 }
                 out << ";\n";
                 return r;
