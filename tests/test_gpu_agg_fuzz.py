@@ -1,0 +1,92 @@
+"""Randomised group-by shapes against the oracle: 1-3 key columns drawn from every key type (nullable BIGINT, INTEGER, DATE,
+nullable BOOLEAN, DOUBLE with -0.0 / NaN, short VARCHAR with a declared length bound, longer VARCHAR), random aggregates
+(count(*), count, sum, avg, min, max; masks; nullable inputs), cardinalities from a handful to tens of thousands -- so the
+key packing (bit fields, two-word strings, NULL flags) and every tier of the aggregation see shapes nobody wrote by hand."""
+import numpy as np
+import pytest
+
+from presto_amd import abi
+from presto_amd.operators import HashAggregationOperator, to_pages
+from presto_amd.page import Block, Page
+
+pytestmark = pytest.mark.gpu
+
+WORDS_SHORT = [b"", b"A", b"F", b"N", b"ab", b"abc", b"xyzw", b"1234567", None]
+WORDS_LONG = [b"", b"BUILDING", b"AUTOMOBILE", b"MACHINERY", b"0123456789abcde", b"x", None, b"HOUSEHOLD"]
+
+
+def key_column(rng, kind, n, card):
+    if kind == "bigint":
+        return abi.BIGINT, Block.bigint(rng.integers(0, card, n) * 1000003 - 5, rng.random(n) < 0.02), 0
+    if kind == "integer":
+        return abi.INTEGER, Block.integer(rng.integers(-card // 2, card // 2 + 1, n)), 0
+    if kind == "date":
+        return abi.DATE, Block.date(rng.integers(8000, 8000 + max(card, 1), n)), 0
+    if kind == "boolean":
+        return abi.BOOLEAN, Block.boolean(rng.random(n) < 0.5, rng.random(n) < 0.1), 0
+    if kind == "double":
+        pool = np.concatenate([rng.standard_normal(max(card, 4)), [0.0, -0.0, np.nan, np.inf]])
+        return abi.DOUBLE, Block.double(pool[rng.integers(0, len(pool), n)], rng.random(n) < 0.02), 0
+    if kind == "short":
+        return abi.VARCHAR, Block.varchar([WORDS_SHORT[i] for i in rng.integers(0, len(WORDS_SHORT), n)]), 7
+    return abi.VARCHAR, Block.varchar([WORDS_LONG[i] for i in rng.integers(0, len(WORDS_LONG), n)]), 0
+
+
+@pytest.mark.parametrize("seed", list(range(24)))
+def test_random_group_by_shapes(gpu, oracle, seed):
+    rng = np.random.default_rng(7000 + seed)
+    kinds = ["bigint", "integer", "date", "boolean", "double", "short", "long"]
+    nkeys = int(rng.integers(1, 4))
+    chosen = [kinds[i] for i in rng.choice(len(kinds), nkeys, replace=False)]
+    card = int([3, 40, 700, 20000][seed % 4])
+    pages = []
+    types, params = None, None
+    for _ in range(int(rng.integers(1, 4))):
+        n = int(rng.integers(1, 60000))
+        blocks, types, params = [], [], []
+        state = rng.bit_generator.state
+        for kind in chosen:
+            t, b, p = key_column(rng, kind, n, card)
+            blocks.append(b)
+            types.append(t)
+            params.append(p)
+        # value columns: nullable DOUBLE, BIGINT, INTEGER, and a nullable mask
+        blocks += [Block.double(rng.random(n) * 200 - 100, rng.random(n) < 0.1), Block.bigint(rng.integers(-10 ** 6, 10 ** 6, n), rng.random(n) < 0.1),
+                   Block.integer(rng.integers(-500, 500, n)), Block.boolean(rng.random(n) < 0.7, rng.random(n) < 0.05)]
+        types += [abi.DOUBLE, abi.BIGINT, abi.INTEGER, abi.BOOLEAN]
+        params += [0, 0, 0, 0]
+        pages.append(Page(blocks, n))
+    v0 = nkeys
+    pool = [(abi.AGG_COUNT_STAR, -1, None), (abi.AGG_COUNT, v0, abi.DOUBLE), (abi.AGG_SUM, v0, abi.DOUBLE), (abi.AGG_AVG, v0, abi.DOUBLE),
+            (abi.AGG_SUM, v0 + 1, abi.BIGINT), (abi.AGG_AVG, v0 + 1, abi.BIGINT), (abi.AGG_MIN, v0, abi.DOUBLE), (abi.AGG_MAX, v0 + 1, abi.BIGINT),
+            (abi.AGG_MIN, v0 + 2, abi.INTEGER), (abi.AGG_SUM, v0 + 2, abi.INTEGER), (abi.AGG_SUM, v0, abi.DOUBLE, v0 + 3), (abi.AGG_COUNT_STAR, -1, None, v0 + 3),
+            (abi.AGG_MAX, v0, abi.DOUBLE, v0 + 3)]
+    aggs = [pool[i] for i in sorted(rng.choice(len(pool), int(rng.integers(1, 7)), replace=False))]
+    keys = list(range(nkeys))
+    op = HashAggregationOperator(types, keys, aggs, type_params=params)
+    got = [r for p in to_pages(op, pages) for r in p.to_rows()]
+    ref = oracle.HashAggregation(types, keys, aggs)
+    for p in pages:
+        ref.add_page(p)
+    expected = ref.build_result().to_rows()
+
+    def key_of(r):  # group keys are exact; a DOUBLE key of -0.0 comes out as +0.0 on the device (same group; DESIGN)
+        out = []
+        for v in r[:nkeys]:
+            if isinstance(v, float):
+                out.append("nan" if v != v else repr(0.0 if v == 0.0 else v))
+            else:
+                out.append(repr(v))
+        return tuple(out)
+
+    assert len(got) == len(expected)
+    g, e = {key_of(r): r for r in got}, {key_of(r): r for r in expected}
+    assert len(g) == len(got) and set(g) == set(e)
+    for k, er in e.items():
+        for gv, ev in zip(g[k][nkeys:], er[nkeys:]):
+            if isinstance(ev, float) and ev == ev:
+                assert gv == ev or abs(gv - ev) <= 1e-9 * max(abs(gv), abs(ev)), (k, g[k], er)
+            elif isinstance(ev, float):
+                assert gv != gv, (k, g[k], er)
+            else:
+                assert gv == ev, (k, g[k], er)
