@@ -155,25 +155,30 @@ FpKernelInfo generate_fp(const FpSpec& s, const std::vector<ChannelLayout>& layo
     emit_vector_loads(ri, layout, vloads, vargs);
     emit_prologue(ri, layout, prologue);
     const std::string sargs = scalar_args(ri, layout);
+    // tile handled by this workgroup: consecutive workgroup ids go round-robin to the 8 XCDs, so inside every window of
+    // 2048 tiles the workgroups of one XCD take 256 consecutive tiles (+2-3 % on the page -> page path)
+    const std::string tile_decl =
+        "    const u32 pa_w = blockIdx.x & ~2047u, pa_i = blockIdx.x & 2047u;\n"
+        "    const u32 pa_tile = (pa_w + 2048u <= gridDim.x) ? pa_w + ((pa_i & 7u) << 8) + (pa_i >> 3) : blockIdx.x;\n";
 
     if (s.has_filter) {
         src << "extern \"C\" __global__ __launch_bounds__(256) void pa_fp_count(PaFpArgs a)\n{\n";
         src << prologue.str();
-        src << "    const i64 q = (i64)blockIdx.x * 256 + threadIdx.x;\n    const i64 row0 = q << 2;\n    u32 bits = 0;\n";
+        src << tile_decl << "    const i64 q = (i64)pa_tile * 256 + threadIdx.x;\n    const i64 row0 = q << 2;\n    u32 bits = 0;\n";
         src << "    if (a.vec && row0 + 4 <= a.n) {\n" << vloads.str();
         for (int r = 0; r < 4; r++) src << "        if (pa_sel(a" << vargs[r] << ")) bits |= " << (1 << r) << "u;\n";
         src << "    } else {\n        for (int i = 0; i < 4; i++) {\n            const i64 r = row0 + i;\n"
                "            if (r < a.n) { if (pa_sel(a" << sargs << ")) bits |= 1u << i; }\n        }\n    }\n";
         src << "    if (row0 < a.n) a.sel4[q] = (u8)bits;\n";
         src << "    i32 total;\n    (void)pa_block_exclusive_scan_256((i32)__popc(bits), &total);\n";
-        src << "    if (threadIdx.x == 0) a.tile_counts[blockIdx.x] = total;\n}\n\n";
+        src << "    if (threadIdx.x == 0) a.tile_counts[pa_tile] = total;\n}\n\n";
     }
     src << "extern \"C\" __global__ __launch_bounds__(256) void pa_fp_scatter(PaFpArgs a)\n{\n";
     src << prologue.str();
-    src << "    const i64 q = (i64)blockIdx.x * 256 + threadIdx.x;\n    const i64 row0 = q << 2;\n";
+    src << tile_decl << "    const i64 q = (i64)pa_tile * 256 + threadIdx.x;\n    const i64 row0 = q << 2;\n";
     if (s.has_filter) {
         src << "    const u32 bits = row0 < a.n ? (u32)a.sel4[q] : 0u;\n";
-        src << "    i32 total;\n    i64 rank = (i64)a.tile_offsets[blockIdx.x] + pa_block_exclusive_scan_256((i32)__popc(bits), &total);\n";
+        src << "    i32 total;\n    i64 rank = (i64)a.tile_offsets[pa_tile] + pa_block_exclusive_scan_256((i32)__popc(bits), &total);\n";
         src << "    if (bits == 0u) return;\n";
     }
     else {
