@@ -365,6 +365,21 @@ int32_t pa_partition_positions(const int32_t* partition, int32_t position_count,
 int32_t pa_gather_flat(const void* src, int32_t elem_bytes, const int32_t* positions, int32_t count,
                        void* dst, void* stream);
 
+/* ---- page wire format (PagesSerde, uncompressed / unencrypted / no checksum) ----
+ * pa_page_serialize writes the SerializedPage frame (PagesSerdeUtil.java:66-74: positionCount int, markers byte = 0,
+ * uncompressedSize int, size int) and the writeRawPage payload (PagesSerdeUtil.java:45-52; LONG_ARRAY / INT_ARRAY /
+ * BYTE_ARRAY / VARIABLE_WIDTH block encodings, nulls as bits) of a host or device page into host memory; returns the
+ * bytes written (negative = pa_status; PA_ERR_INSUFFICIENT_RESOURCES when capacity is too small).  DOUBLE travels as
+ * LONG_ARRAY and DATE as INT_ARRAY, as in the reference, so pa_page_deserialize types the blocks BIGINT / INTEGER /
+ * BOOLEAN / VARCHAR: the consumer's declared column types tell DOUBLE from BIGINT and DATE from INTEGER.
+ * pa_page_deserialize builds a PA_MEM_DEVICE page owned by the returned buffer (NULL positions of fixed-width blocks
+ * hold 0). */
+typedef struct pa_page_buffer pa_page_buffer;
+int64_t pa_page_serialize(const pa_page* page, void* out_host, int64_t capacity, void* stream);
+int32_t pa_page_deserialize(const void* bytes_host, int64_t size, void* stream, pa_page_buffer** out);
+int32_t pa_page_buffer_page(pa_page_buffer* buffer, pa_page* out);
+int32_t pa_page_buffer_free(pa_page_buffer* buffer);
+
 /* ---- synthetic TPC-H-shaped column generator, on device ---- */
 typedef enum pa_tpch_column {
     PA_L_ORDERKEY = 0, PA_L_QUANTITY = 1, PA_L_EXTENDEDPRICE = 2, PA_L_DISCOUNT = 3, PA_L_TAX = 4,

@@ -492,3 +492,96 @@ def topn(pages, n, sort_channels, sort_orders):
     if n == 0:
         return []
     return sorted(rows, key=functools.cmp_to_key(cmp))[:n]
+
+
+# ---- page wire format -------------------------------------------------------------------------------------------------
+_ENCODING = {abi.BIGINT: (b"LONG_ARRAY", "<i8"), abi.DOUBLE: (b"LONG_ARRAY", "<f8"), abi.INTEGER: (b"INT_ARRAY", "<i4"), abi.DATE: (b"INT_ARRAY", "<i4"),
+             abi.BOOLEAN: (b"BYTE_ARRAY", "u1"), abi.VARCHAR: (b"VARIABLE_WIDTH", None)}
+
+
+def serialize_page(page):
+    """PagesSerde.serialize without compression / encryption / checksum: the SerializedPage frame of
+    PagesSerdeUtil.writeSerializedPage (core/trino-main/src/main/java/io/trino/execution/buffer/PagesSerdeUtil.java:66-74)
+    around writeRawPage (:45-52); per block the length-prefixed encoding name (InternalBlockEncodingSerde.java:56-80) and
+    LongArrayBlockEncoding.writeBlock (core/trino-spi/.../block/LongArrayBlockEncoding.java:38-61; Int / Byte alike),
+    VariableWidthBlockEncoding.writeBlock (:37-58), EncoderUtil.encodeNullsAsBits (:35-72).  Little endian (Slice)."""
+    import struct
+    n = page.position_count
+    payload = bytearray(struct.pack("<i", page.channel_count))
+    for b in page.blocks:
+        name, dtype = _ENCODING[b.type]
+        payload += struct.pack("<i", len(name)) + name + struct.pack("<i", n)
+        nulls = None if b.nulls is None else np.asarray(b.nulls[:n], dtype=np.uint8)
+
+        def null_bits():
+            out = bytearray([0 if nulls is None else 1])
+            if nulls is not None:
+                out += np.packbits(nulls != 0, bitorder="big").tobytes()
+            return out
+        if b.type == abi.VARCHAR:
+            off = np.asarray(b.offsets[:n + 1], dtype=np.int64)
+            payload += (off[1:] - off[0]).astype("<i4").tobytes()
+            payload += null_bits()
+            total = int(off[n] - off[0])
+            payload += struct.pack("<i", total) + np.asarray(b.values, dtype=np.uint8)[int(off[0]):int(off[0]) + total].tobytes()
+            continue
+        payload += null_bits()
+        values = np.asarray(b.values[:n]).astype(dtype)
+        if nulls is None:
+            payload += values.tobytes()
+        else:
+            keep = values[nulls == 0]
+            payload += struct.pack("<i", len(keep)) + keep.tobytes()
+    return struct.pack("<ibii", n, 0, len(payload), len(payload)) + bytes(payload)
+
+
+def deserialize_page(data):
+    """PagesSerde.deserialize of serialize_page's form -> host Page (LONG_ARRAY -> BIGINT, INT_ARRAY -> INTEGER, BYTE_ARRAY ->
+    BOOLEAN blocks: LongArrayBlockEncoding.readBlock :63-95 leaves 0 at NULL positions)."""
+    import struct
+    from presto_amd.page import Block, Page
+    n, markers, uncompressed, size = struct.unpack_from("<ibii", data, 0)
+    assert markers == 0 and uncompressed == size
+    pos = 13
+    (channels,) = struct.unpack_from("<i", data, pos)
+    pos += 4
+    blocks = []
+    for _ in range(channels):
+        (ln,) = struct.unpack_from("<i", data, pos)
+        name = data[pos + 4:pos + 4 + ln]
+        pos += 4 + ln
+        (count,) = struct.unpack_from("<i", data, pos)
+        pos += 4
+        assert count == n
+        ends = None
+        if name == b"VARIABLE_WIDTH":
+            ends = np.frombuffer(data, dtype="<i4", count=n, offset=pos)
+            pos += 4 * n
+        has_null = data[pos] != 0
+        pos += 1
+        nulls = None
+        if has_null:
+            nb = (n + 7) // 8
+            nulls = np.unpackbits(np.frombuffer(data, dtype=np.uint8, count=nb, offset=pos), bitorder="big")[:n].astype(np.uint8)
+            pos += nb
+        if name == b"VARIABLE_WIDTH":
+            (total,) = struct.unpack_from("<i", data, pos)
+            pos += 4
+            raw = np.frombuffer(data, dtype=np.uint8, count=total, offset=pos).copy() if total else np.zeros(1, np.uint8)
+            pos += total
+            blocks.append(Block(abi.VARCHAR, abi.VARWIDTH, n, values=raw, offsets=np.concatenate([[0], ends]).astype(np.int32), nulls=nulls))
+            continue
+        t, dtype = {b"LONG_ARRAY": (abi.BIGINT, "<i8"), b"INT_ARRAY": (abi.INTEGER, "<i4"), b"BYTE_ARRAY": (abi.BOOLEAN, "u1")}[name]
+        width = np.dtype(dtype).itemsize
+        if not has_null:
+            values = np.frombuffer(data, dtype=dtype, count=n, offset=pos).copy()
+            pos += n * width
+        else:
+            (nn,) = struct.unpack_from("<i", data, pos)
+            pos += 4
+            values = np.zeros(n, dtype=dtype)
+            values[nulls == 0] = np.frombuffer(data, dtype=dtype, count=nn, offset=pos)
+            pos += nn * width
+        blocks.append(Block(t, abi.FLAT, n, values=values, nulls=nulls))
+    assert pos == len(data)
+    return Page(blocks, n)

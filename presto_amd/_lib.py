@@ -75,6 +75,11 @@ def lib():
     L.pa_filter_project_selected_positions.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     L.pa_lookup_join_match_pairs.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_int32)]
     L.pa_lookup_source_tables.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_int32), C.POINTER(vp), C.POINTER(C.c_int32)]
+    L.pa_page_serialize.argtypes = [C.POINTER(abi.pa_page), vp, C.c_int64, vp]
+    L.pa_page_serialize.restype = C.c_int64
+    L.pa_page_deserialize.argtypes = [vp, C.c_int64, vp, C.POINTER(vp)]
+    L.pa_page_buffer_page.argtypes = [vp, C.POINTER(abi.pa_page)]
+    L.pa_page_buffer_free.argtypes = [vp]
     if L.pa_abi_version() != abi.ABI_VERSION:
         raise ImportError("libpresto_amd.so ABI version %d != %d" % (L.pa_abi_version(), abi.ABI_VERSION))
     _LIB = L

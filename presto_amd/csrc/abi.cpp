@@ -340,6 +340,40 @@ int32_t pa_lookup_outer_create(const pa_lookup_join_desc* desc, pa_lookup_source
     });
 }
 
+// ---- page wire format ----
+int64_t pa_page_serialize(const pa_page* page, void* out_host, int64_t capacity, void* stream)
+{
+    int64_t written = 0;
+    int32_t rc = guarded([&]() -> int32_t {
+        written = serialize_page(page, out_host, capacity, static_cast<hipStream_t>(stream));
+        return PA_OK;
+    });
+    return rc < 0 ? (int64_t)rc : written;
+}
+int32_t pa_page_deserialize(const void* bytes_host, int64_t size, void* stream, pa_page_buffer** out)
+{
+    return guarded([&]() -> int32_t {
+        PA_REQUIRE(out != nullptr, PA_ERR_INVALID_ARGUMENT, "null argument");
+        *out = deserialize_page(bytes_host, size, static_cast<hipStream_t>(stream));
+        return PA_OK;
+    });
+}
+int32_t pa_page_buffer_page(pa_page_buffer* buffer, pa_page* out)
+{
+    return guarded([&]() -> int32_t {
+        PA_REQUIRE(buffer != nullptr && out != nullptr, PA_ERR_INVALID_ARGUMENT, "null argument");
+        page_buffer_page(buffer, out);
+        return PA_OK;
+    });
+}
+int32_t pa_page_buffer_free(pa_page_buffer* buffer)
+{
+    return guarded([&]() -> int32_t {
+        page_buffer_free(buffer);
+        return PA_OK;
+    });
+}
+
 // ---- Operator protocol ----
 int32_t pa_op_needs_input(pa_operator* op)
 {

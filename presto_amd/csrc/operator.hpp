@@ -28,6 +28,12 @@ pa_operator* make_lookup_join(const pa_lookup_join_desc* desc, pa_lookup_source*
 pa_operator* make_topn(const pa_topn_desc* desc);
 pa_operator* make_lookup_outer(const pa_lookup_join_desc* desc, pa_lookup_source* bridge);
 
+// page wire format (page_serde.cpp)
+int64_t serialize_page(const pa_page* page, void* out_host, int64_t capacity, hipStream_t s);
+pa_page_buffer* deserialize_page(const void* bytes, int64_t size, hipStream_t s);
+void page_buffer_page(pa_page_buffer* buffer, pa_page* out);
+void page_buffer_free(pa_page_buffer* buffer);
+
 // code-object source for a fused descriptor under the "no nulls, aligned" layout; used by build() to
 // pre-compile the TPC-H shapes and by the CPU-side codegen tests
 std::string fused_source_for_desc(const pa_fused_aggregation_desc* desc, int variant, std::string* entry);

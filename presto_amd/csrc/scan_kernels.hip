@@ -271,4 +271,85 @@ void launch_offsets_append(const int32_t* src, int64_t count, int32_t dst_base, 
     PA_HIP(hipGetLastError());
 }
 
+// ---------------------------------------------------------------------------------------------
+// page serde helpers (PagesSerde block encodings)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pack_null_bits(const u8* __restrict__ nulls, i64 n, u8* __restrict__ packed)
+{
+    const i64 bytes = (n + 7) >> 3;
+    for (i64 b = (i64)blockIdx.x * 256 + threadIdx.x; b < bytes; b += (i64)gridDim.x * 256) {
+        u32 v = 0;
+        for (int k = 0; k < 8; k++) {
+            const i64 p = b * 8 + k;
+            if (p < n && nulls[p]) v |= 0x80u >> k;
+        }
+        packed[b] = (u8)v;
+    }
+}
+__global__ __launch_bounds__(256) void k_unpack_null_bits(const u8* __restrict__ packed, i64 n, u8* __restrict__ nulls)
+{
+    for (i64 p = (i64)blockIdx.x * 256 + threadIdx.x; p < n; p += (i64)gridDim.x * 256) nulls[p] = (packed[p >> 3] >> (7 - (p & 7))) & 1u;
+}
+__global__ __launch_bounds__(256) void k_null_flag(const u8* __restrict__ nulls, i64 n, i32* __restrict__ partition)
+{
+    for (i64 p = (i64)blockIdx.x * 256 + threadIdx.x; p < n; p += (i64)gridDim.x * 256) partition[p] = nulls[p] ? 1 : 0;
+}
+template <typename T>
+__global__ __launch_bounds__(256) void k_scatter(const T* __restrict__ src, const i32* __restrict__ pos, i64 n, T* __restrict__ dst)
+{
+    for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < n; i += (i64)gridDim.x * 256) dst[pos[i]] = src[i];
+}
+__global__ __launch_bounds__(256) void k_varwidth_ends(const i32* __restrict__ offsets, i64 n, i32* __restrict__ ends)
+{
+    const i32 first = offsets[0];
+    for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < n; i += (i64)gridDim.x * 256) ends[i] = offsets[i + 1] - first;
+}
+__global__ __launch_bounds__(256) void k_varwidth_from_ends(const i32* __restrict__ ends, i64 n, i32* __restrict__ offsets)
+{
+    for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < n; i += (i64)gridDim.x * 256) offsets[i + 1] = ends[i];
+    if (blockIdx.x == 0 && threadIdx.x == 0) offsets[0] = 0;
+}
+static int serde_grid(int64_t n) { return (int)std::max<int64_t>(1, std::min<int64_t>((n + 255) / 256, 2048)); }
+void launch_pack_null_bits(const uint8_t* nulls, int64_t n, uint8_t* packed, hipStream_t s)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_pack_null_bits, serde_grid((n + 7) / 8), 256, 0, s, nulls, (i64)n, packed);
+    PA_HIP(hipGetLastError());
+}
+void launch_unpack_null_bits(const uint8_t* packed, int64_t n, uint8_t* nulls, hipStream_t s)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_unpack_null_bits, serde_grid(n), 256, 0, s, packed, (i64)n, nulls);
+    PA_HIP(hipGetLastError());
+}
+void launch_null_flag(const uint8_t* nulls, int64_t n, int32_t* partition, hipStream_t s)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_null_flag, serde_grid(n), 256, 0, s, nulls, (i64)n, partition);
+    PA_HIP(hipGetLastError());
+}
+void launch_scatter_flat(const void* src, int elem_bytes, const int32_t* positions, int64_t count, void* dst, hipStream_t s)
+{
+    if (count <= 0) return;
+    const int g = serde_grid(count);
+    switch (elem_bytes) {
+        case 8: hipLaunchKernelGGL(k_scatter<u64>, g, 256, 0, s, (const u64*)src, positions, (i64)count, (u64*)dst); break;
+        case 4: hipLaunchKernelGGL(k_scatter<u32>, g, 256, 0, s, (const u32*)src, positions, (i64)count, (u32*)dst); break;
+        case 1: hipLaunchKernelGGL(k_scatter<u8>, g, 256, 0, s, (const u8*)src, positions, (i64)count, (u8*)dst); break;
+        default: throw Error(PA_ERR_INVALID_ARGUMENT, "unsupported element width");
+    }
+    PA_HIP(hipGetLastError());
+}
+void launch_varwidth_ends(const int32_t* offsets, int64_t n, int32_t* ends, hipStream_t s)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_varwidth_ends, serde_grid(n), 256, 0, s, offsets, (i64)n, ends);
+    PA_HIP(hipGetLastError());
+}
+void launch_varwidth_from_ends(const int32_t* ends, int64_t n, int32_t* offsets, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_varwidth_from_ends, serde_grid(std::max<int64_t>(n, 1)), 256, 0, s, ends, (i64)n, offsets);
+    PA_HIP(hipGetLastError());
+}
+
 }  // namespace pa

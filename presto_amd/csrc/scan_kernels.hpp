@@ -14,6 +14,17 @@ void launch_varwidth_copy(const int32_t* positions, int64_t count, const int32_t
 // dst[i + 1] = dst_base + src[i + 1] - src[0] for i in [0, count); dst[0] = dst_base when write_first (appending a
 // VariableWidthBlock's offsets behind others, MergePages' PageBuilder)
 void launch_offsets_append(const int32_t* src, int64_t count, int32_t dst_base, int32_t* dst, bool write_first, hipStream_t s);
+// EncoderUtil.encodeNullsAsBits / decodeNullBits (core/trino-spi/.../block/EncoderUtil.java:35-110): 1 B / position <-> bits,
+// most significant bit first
+void launch_pack_null_bits(const uint8_t* nulls, int64_t n, uint8_t* packed, hipStream_t s);
+void launch_unpack_null_bits(const uint8_t* packed, int64_t n, uint8_t* nulls, hipStream_t s);
+// partition[i] = nulls[i] ? 1 : 0 (non-null positions first under the stable partition)
+void launch_null_flag(const uint8_t* nulls, int64_t n, int32_t* partition, hipStream_t s);
+// dst[positions[i]] = src[i] (inverse of Block.copyPositions: the values of the non-null positions back in place)
+void launch_scatter_flat(const void* src, int elem_bytes, const int32_t* positions, int64_t count, void* dst, hipStream_t s);
+// VariableWidthBlockEncoding offsets: ends[i] = offsets[i + 1] - offsets[0]; and back: offsets[0] = 0, offsets[i + 1] = ends[i]
+void launch_varwidth_ends(const int32_t* offsets, int64_t n, int32_t* ends, hipStream_t s);
+void launch_varwidth_from_ends(const int32_t* ends, int64_t n, int32_t* offsets, hipStream_t s);
 size_t partition_temp_bytes(int64_t n, int32_t partition_count);
 void launch_partition_positions(const int32_t* partition, int64_t n, int32_t partition_count, int32_t* out_positions,
                                 int64_t* out_counts_dev, void* temp, hipStream_t s);

@@ -254,3 +254,48 @@ def sequence_page(length, columns):
         else:
             blocks.append(Block.flat(type_, seq))
     return Page(blocks, length)
+
+
+# ---- wire format (PagesSerde) through the C ABI ------------------------------------------------------------------------
+def serialize_page(page, stream=None):
+    """SerializedPage bytes (frame + payload, uncompressed) of a host or device Page: pa_page_serialize."""
+    from ._lib import check, lib
+    cpage, keep = page.to_c()
+    n = page.position_count
+    cap = 64 + sum(64 + 13 * n + (int(b.offsets[n]) - int(b.offsets[0]) if (b.type == abi.VARCHAR and page.mem == abi.MEM_HOST and b.encoding == abi.VARWIDTH) else 0)
+                   for b in page.blocks)
+    for _ in range(8):
+        buf = (C.c_uint8 * cap)()
+        rc = lib().pa_page_serialize(C.byref(cpage), buf, cap, stream)
+        if rc == abi.ERR_INSUFFICIENT_RESOURCES:
+            cap *= 4  # device VARCHAR bytes are only known to the library
+            continue
+        check(rc if rc < 0 else 0)
+        return bytes(bytearray(buf)[:rc])
+    raise MemoryError("serialized page does not fit")
+
+
+class _PageBuffer:
+    def __init__(self, handle):
+        self.handle = handle
+
+    def __del__(self):
+        try:
+            from ._lib import lib
+            lib().pa_page_buffer_free(self.handle)
+        except Exception:
+            pass
+
+
+def deserialize_page(data, stream=None):
+    """PA_MEM_DEVICE Page from SerializedPage bytes: pa_page_deserialize (DOUBLE / DATE columns come back as BIGINT / INTEGER
+    blocks of the same bits: the wire format carries encodings, not types)."""
+    from ._lib import check, lib
+    from .operators import device_page_from_c
+    raw = (C.c_uint8 * max(len(data), 1)).from_buffer_copy(bytes(data) if data else b"\0")
+    h = C.c_void_p()
+    check(lib().pa_page_deserialize(raw, len(data), stream, C.byref(h)))
+    owner = _PageBuffer(h)
+    cpage = abi.pa_page()
+    check(lib().pa_page_buffer_page(h, C.byref(cpage)))
+    return device_page_from_c(cpage, owner=owner)

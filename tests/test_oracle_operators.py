@@ -303,3 +303,25 @@ def test_lookup_outer_and_full_outer(oracle):
     assert j.outer([abi.VARCHAR], [0]).to_rows() == [(None, b"a")]
     j, rows = _varchar_join(oracle, [], ["test"], abi.JOIN_LOOKUP_OUTER)
     assert rows == [] and j.outer([abi.VARCHAR], [0]).position_count == 0
+
+
+def test_page_wire_format_known_frame(oracle):
+    """The reference's tests only round-trip PagesSerde (core/trino-main/src/test/java/io/trino/execution/buffer/TestPagesSerde.java),
+    they hold no golden bytes; this frame is computed by hand from the cited encodings (PagesSerdeUtil.java:45-74,
+    LongArrayBlockEncoding.java:38-61, VariableWidthBlockEncoding.java:37-58, EncoderUtil.java:35-72): (BIGINT 1, NULL, 3),
+    (VARCHAR 'ab', '', NULL)."""
+    import struct
+    page = Page([Block.bigint([1, 0, 3], [0, 1, 0]), Block.varchar([b"ab", b"", None])], 3)
+    payload = struct.pack("<i", 2)
+    payload += struct.pack("<i", 10) + b"LONG_ARRAY" + struct.pack("<i", 3) + bytes([1, 0b01000000]) + struct.pack("<iqq", 2, 1, 3)
+    payload += struct.pack("<i", 14) + b"VARIABLE_WIDTH" + struct.pack("<i", 3) + struct.pack("<iii", 2, 2, 2) + bytes([1, 0b00100000]) + struct.pack("<i", 2) + b"ab"
+    frame = struct.pack("<ibii", 3, 0, len(payload), len(payload)) + payload
+    assert oracle.serialize_page(page) == frame
+    assert oracle.deserialize_page(frame).to_rows() == [(1, b"ab"), (None, b""), (3, None)]
+    rng = np.random.default_rng(3)
+    n = 1001
+    big = Page([Block.double(rng.random(n), rng.random(n) < 0.2), Block.integer(rng.integers(-5, 5, n)), Block.boolean(rng.random(n) < 0.5, rng.random(n) < 0.5)], n)
+    back = oracle.deserialize_page(oracle.serialize_page(big))
+    assert back.blocks[1].to_pylist() == big.blocks[1].to_pylist()
+    assert [None if v is None else int(v) for v in back.blocks[2].to_pylist()] == [None if v is None else int(v) for v in big.blocks[2].to_pylist()]
+    assert [None if v is None else np.int64(v).view(np.float64) for v in back.blocks[0].to_pylist()] == big.blocks[0].to_pylist()
