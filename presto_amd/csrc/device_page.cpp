@@ -1,5 +1,6 @@
 // device_page.cpp -- see device_page.hpp.
 #include "device_page.hpp"
+#include "scan_kernels.hpp"
 
 namespace pa {
 
@@ -40,11 +41,11 @@ DevPage PageStager::stage(const pa_page* page, const std::vector<bool>* needed, 
         DevColumn& d = out.cols[c];
         d.type = col.type;
         if (needed && (c >= (int32_t)needed->size() || !(*needed)[c])) {
-            next_ += 6;
+            next_ += 9;
             continue;
         }
         size_t slot = next_;
-        next_ += 6;
+        next_ += 9;
         if (col.encoding == PA_FLAT) {
             int w = type_width(col.type);
             PA_REQUIRE(w > 0, PA_ERR_NOT_SUPPORTED, "FLAT block of a variable-width type");
@@ -75,8 +76,62 @@ DevPage PageStager::stage(const pa_page* page, const std::vector<bool>* needed, 
             // decode (DictionaryBlock / RunLengthEncodedBlock -> flat) with a gather kernel
             PA_REQUIRE(col.dictionary != nullptr, PA_ERR_INVALID_ARGUMENT, "dictionary block without dictionary");
             const pa_column& dict = *col.dictionary;
-            PA_REQUIRE(dict.encoding == PA_FLAT, PA_ERR_NOT_SUPPORTED,
-                       "dictionary / RLE over variable-width or nested blocks is decoded on the Java side");
+            if (dict.encoding == PA_VARWIDTH) {
+                // DictionaryBlock / RLE over a VariableWidthBlock (what ORC / Parquet readers hand over for strings):
+                // Block.copyPositions by the ids -- lengths, exclusive scan, byte copy
+                PA_REQUIRE(dict.type == PA_VARCHAR && dict.offsets != nullptr, PA_ERR_INVALID_ARGUMENT, "bad variable-width dictionary");
+                const int64_t dn = col.encoding == PA_RLE ? 1 : col.dictionary_size;
+                PA_REQUIRE(dn > 0 || n == 0, PA_ERR_INVALID_ARGUMENT, "empty dictionary");
+                d.type = PA_VARCHAR;
+                d.varwidth = true;
+                const int32_t* doff;
+                const void* dvals;
+                const uint8_t* dnulls;
+                if (dev) {
+                    doff = dict.offsets;
+                    dvals = dict.values;
+                    dnulls = dict.nulls;
+                }
+                else {
+                    const size_t bytes = (size_t)dict.offsets[dn];
+                    doff = static_cast<const int32_t*>(to_device(dict.offsets, (size_t)(dn + 1) * 4, false, arena(slot, (size_t)(dn + 1) * 4), stream));
+                    dvals = to_device(dict.values, bytes, false, arena(slot + 1, bytes ? bytes : 1), stream);
+                    dnulls = static_cast<const uint8_t*>(to_device(dict.nulls, (size_t)dn, false, dict.nulls ? arena(slot + 2, (size_t)dn) : nullptr, stream));
+                }
+                const size_t rows = (size_t)(n > 0 ? n : 1);
+                int32_t* ids = static_cast<int32_t*>(arena(slot + 4, rows * 4));
+                if (col.encoding == PA_RLE) {
+                    PA_HIP(hipMemsetAsync(ids, 0, rows * 4, stream));
+                }
+                else {
+                    PA_REQUIRE(col.ids != nullptr, PA_ERR_INVALID_ARGUMENT, "dictionary block without ids");
+                    if (dev) ids = const_cast<int32_t*>(col.ids);
+                    else PA_HIP(hipMemcpyAsync(ids, col.ids, (size_t)n * 4, hipMemcpyHostToDevice, stream));
+                }
+                int32_t* out_off = static_cast<int32_t*>(arena(slot + 3, (rows + 1) * 4));
+                int32_t* total = static_cast<int32_t*>(arena(slot + 6, 64));
+                PA_HIP(hipMemsetAsync(out_off, 0, (rows + 1) * 4, stream));
+                PA_HIP(hipMemsetAsync(total, 0, 4, stream));
+                int32_t h_total = 0;
+                if (n > 0) {
+                    launch_varwidth_lengths(ids, n, doff, dnulls, out_off, stream);
+                    launch_exclusive_scan_i32(out_off, out_off, n, total, arena(slot + 7, scan_temp_bytes(n)), stream);
+                    PA_HIP(hipMemcpyAsync(&h_total, total, 4, hipMemcpyDeviceToHost, stream));
+                    PA_HIP(hipStreamSynchronize(stream));
+                }
+                uint8_t* out_bytes = static_cast<uint8_t*>(arena(slot + 5, (size_t)(h_total > 0 ? h_total : 1)));
+                if (n > 0) launch_varwidth_copy(ids, n, doff, static_cast<const uint8_t*>(dvals), dnulls, out_off, out_bytes, total, stream);
+                uint8_t* fnulls = nullptr;
+                if (dnulls) {
+                    fnulls = static_cast<uint8_t*>(arena(slot + 8, rows));
+                    if (n > 0) launch_gather_nulls(dnulls, ids, n, fnulls, stream);
+                }
+                d.values = out_bytes;
+                d.offsets = out_off;
+                d.nulls = fnulls;
+                continue;
+            }
+            PA_REQUIRE(dict.encoding == PA_FLAT, PA_ERR_NOT_SUPPORTED, "dictionary / RLE over nested blocks is decoded on the Java side");
             int w = type_width(dict.type);
             PA_REQUIRE(w > 0, PA_ERR_NOT_SUPPORTED, "dictionary of a variable-width type");
             d.type = dict.type;

@@ -176,6 +176,27 @@ def test_dictionary_and_rle_inputs(gpu, oracle):
     assert rows == oracle_rows(oracle, [page], f, proj)
 
 
+def test_varchar_dictionary_and_rle_inputs(gpu, oracle):
+    """DictionaryBlock / RunLengthEncodedBlock over a VariableWidthBlock (what ORC / Parquet readers produce for strings):
+    filter on the string, project it, group by it."""
+    from presto_amd.operators import HashAggregationOperator
+    rng = np.random.default_rng(8)
+    n = 20000
+    d = Block.varchar([b"BUILDING", b"", None, b"AUTOMOBILE", b"x", b"MACHINERY"])
+    ids = rng.integers(0, 6, n).astype(np.int32)
+    page = Page([Block.dictionary_block(d, ids), Block.rle(Block.varchar([b"const"]), n), Block.bigint(np.arange(n))], n)
+    types = [abi.VARCHAR, abi.VARCHAR, abi.BIGINT]
+    f = or_(field(0, abi.VARCHAR).eq(constant(b"BUILDING", abi.VARCHAR)), field(0, abi.VARCHAR) > constant(b"M", abi.VARCHAR))
+    proj = [field(0, abi.VARCHAR), field(1, abi.VARCHAR), field(2, abi.BIGINT)]
+    rows = [r for p in to_pages(FilterAndProjectOperator(types, f, proj), [page]) for r in p.to_rows()]
+    assert rows == oracle_rows(oracle, [page], f, proj) and len(rows) > 1000
+    aggs = [(abi.AGG_COUNT_STAR, -1, None), (abi.AGG_SUM, 2, abi.BIGINT)]
+    got = sorted((r for p in to_pages(HashAggregationOperator(types, [0, 1], aggs), [page]) for r in p.to_rows()), key=repr)
+    ref = oracle.HashAggregation(types, [0, 1], aggs)
+    ref.add_page(page)
+    assert got == sorted(ref.build_result().to_rows(), key=repr) and len(got) == 6
+
+
 # ---- MergePages behind the PageProcessor (a7) ------------------------------------------------------------------------
 def merged_reference(oracle, pages, f, projections, min_bytes, min_rows, max_bytes=0):
     m = oracle.MergePages(min_bytes, min_rows, max_bytes)
