@@ -199,6 +199,10 @@ Spec make_spec(const pa_fused_aggregation_desc* d)
         if (pe.is_input_ref() && pe.root_type() == PA_VARCHAR) {
             int c = pe.node(pe.root).channel;
             if (s.in_params[c] >= 1 && s.in_params[c] <= 7) s.short_bound[c] = s.in_params[c];
+            // a declared bound the packed key cannot hold is refused now, so that the planner keeps the Java operator; for an
+            // undeclared bound (0) the operator is optimistic: a key longer than 15 bytes fails the query at run time
+            // (offload VARCHAR group keys only for VARCHAR(n), n <= 15)
+            PA_REQUIRE(s.in_params[c] <= 15, PA_ERR_NOT_SUPPORTED, "VARCHAR group keys longer than 15 bytes are not on the device path");
         }
     }
     return s;
