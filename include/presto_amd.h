@@ -380,6 +380,16 @@ int32_t pa_page_deserialize(const void* bytes_host, int64_t size, void* stream, 
 int32_t pa_page_buffer_page(pa_page_buffer* buffer, pa_page* out);
 int32_t pa_page_buffer_free(pa_page_buffer* buffer);
 
+/* Block.copyPositions for a VariableWidthBlock, in two calls (the byte total sizes the second one's output):
+ * pa_varwidth_gather_offsets: out_lengths[i] = length of row positions[i]; out_offsets[count + 1] = their exclusive scan
+ * (out_offsets[count] = total); *total_bytes_host = total.  pa_varwidth_gather_bytes copies the bytes behind those offsets.
+ * pa_offsets_from_lengths: exclusive scan of per-row lengths into count + 1 offsets (what a receiver of shuffled rows does). */
+int32_t pa_varwidth_gather_offsets(const int32_t* offsets, const int32_t* positions, int32_t count, int32_t* out_lengths,
+                                   int32_t* out_offsets, int64_t* total_bytes_host, void* stream);
+int32_t pa_varwidth_gather_bytes(const void* values, const int32_t* offsets, const int32_t* positions, int32_t count,
+                                 const int32_t* out_offsets, void* out_values, void* stream);
+int32_t pa_offsets_from_lengths(const int32_t* lengths, int32_t count, int32_t* out_offsets, int64_t* total_bytes_host, void* stream);
+
 /* ---- synthetic TPC-H-shaped column generator, on device ---- */
 typedef enum pa_tpch_column {
     PA_L_ORDERKEY = 0, PA_L_QUANTITY = 1, PA_L_EXTENDEDPRICE = 2, PA_L_DISCOUNT = 3, PA_L_TAX = 4,

@@ -75,6 +75,9 @@ def lib():
     L.pa_filter_project_selected_positions.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     L.pa_lookup_join_match_pairs.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_int32)]
     L.pa_lookup_source_tables.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_int32), C.POINTER(vp), C.POINTER(C.c_int32)]
+    L.pa_varwidth_gather_offsets.argtypes = [vp, vp, C.c_int32, vp, vp, C.POINTER(C.c_int64), vp]
+    L.pa_varwidth_gather_bytes.argtypes = [vp, vp, vp, C.c_int32, vp, vp, vp]
+    L.pa_offsets_from_lengths.argtypes = [vp, C.c_int32, vp, C.POINTER(C.c_int64), vp]
     L.pa_page_serialize.argtypes = [C.POINTER(abi.pa_page), vp, C.c_int64, vp]
     L.pa_page_serialize.restype = C.c_int64
     L.pa_page_deserialize.argtypes = [vp, C.c_int64, vp, C.POINTER(vp)]

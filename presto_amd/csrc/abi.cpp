@@ -501,6 +501,71 @@ int32_t pa_gather_flat(const void* src, int32_t elem_bytes, const int32_t* posit
     });
 }
 
+namespace {
+// exclusive scan of n lengths already sitting in offs[0..n) into offs[0..n], total to the host
+int64_t scan_lengths_in_place(int32_t* offs, int32_t n, hipStream_t s)
+{
+    pa::DevBuf temp, total;
+    int32_t* t = static_cast<int32_t*>(total.ensure(64));
+    PA_HIP(hipMemsetAsync(t, 0, 4, s));
+    int32_t h = 0;
+    if (n > 0) {
+        pa::launch_exclusive_scan_i32(offs, offs, n, t, temp.ensure(pa::scan_temp_bytes(n)), s);
+        PA_HIP(hipMemcpyAsync(offs + n, t, 4, hipMemcpyDeviceToDevice, s));
+        PA_HIP(hipMemcpyAsync(&h, t, 4, hipMemcpyDeviceToHost, s));
+    }
+    else {
+        PA_HIP(hipMemsetAsync(offs, 0, 4, s));
+    }
+    PA_HIP(hipStreamSynchronize(s));  // temp / total go back to the pool
+    return h;
+}
+}  // namespace
+
+int32_t pa_varwidth_gather_offsets(const int32_t* offsets, const int32_t* positions, int32_t count, int32_t* out_lengths,
+                                   int32_t* out_offsets, int64_t* total_bytes_host, void* stream)
+{
+    return guarded([&]() -> int32_t {
+        PA_REQUIRE(offsets && out_offsets && total_bytes_host && count >= 0, PA_ERR_INVALID_ARGUMENT, "bad arguments");
+        require_device();
+        hipStream_t s = (hipStream_t)stream;
+        if (count > 0) {
+            launch_varwidth_lengths(positions, count, offsets, nullptr, out_offsets, s);
+            if (out_lengths) PA_HIP(hipMemcpyAsync(out_lengths, out_offsets, (size_t)count * 4, hipMemcpyDeviceToDevice, s));
+        }
+        *total_bytes_host = scan_lengths_in_place(out_offsets, count, s);
+        return PA_OK;
+    });
+}
+int32_t pa_varwidth_gather_bytes(const void* values, const int32_t* offsets, const int32_t* positions, int32_t count,
+                                 const int32_t* out_offsets, void* out_values, void* stream)
+{
+    return guarded([&]() -> int32_t {
+        PA_REQUIRE(offsets && out_offsets && count >= 0, PA_ERR_INVALID_ARGUMENT, "bad arguments");
+        require_device();
+        if (count == 0) return PA_OK;
+        pa::DevBuf total;
+        int32_t* t = static_cast<int32_t*>(total.ensure(64));
+        hipStream_t s = (hipStream_t)stream;
+        PA_HIP(hipMemcpyAsync(t, out_offsets + count, 4, hipMemcpyDeviceToDevice, s));
+        launch_varwidth_copy(positions, count, offsets, static_cast<const uint8_t*>(values), nullptr, const_cast<int32_t*>(out_offsets),
+                             static_cast<uint8_t*>(out_values), t, s);
+        PA_HIP(hipStreamSynchronize(s));
+        return PA_OK;
+    });
+}
+int32_t pa_offsets_from_lengths(const int32_t* lengths, int32_t count, int32_t* out_offsets, int64_t* total_bytes_host, void* stream)
+{
+    return guarded([&]() -> int32_t {
+        PA_REQUIRE(out_offsets && total_bytes_host && count >= 0 && (lengths || count == 0), PA_ERR_INVALID_ARGUMENT, "bad arguments");
+        require_device();
+        hipStream_t s = (hipStream_t)stream;
+        if (count > 0) PA_HIP(hipMemcpyAsync(out_offsets, lengths, (size_t)count * 4, hipMemcpyDeviceToDevice, s));
+        *total_bytes_host = scan_lengths_in_place(out_offsets, count, s);
+        return PA_OK;
+    });
+}
+
 int32_t pa_tpch_generate(int32_t column, double scale_factor, int64_t first_row, int64_t row_count, uint64_t seed, void* values,
                          int32_t* offsets, void* stream)
 {

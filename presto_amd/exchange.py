@@ -43,9 +43,14 @@ class DeviceOps:
 
     @staticmethod
     def _page(columns, types):
-        n = int(columns[0].shape[0]) if columns else 0
-        blocks = [Block(t, abi.FLAT, n, values=DeviceBuffer(c.data_ptr(), c.numel() * c.element_size(), c))
-                  for c, t in zip(columns, types)]
+        n = rows_of(columns[0]) if columns else 0
+        blocks = []
+        for c, t in zip(columns, types):
+            if t == abi.VARCHAR:  # (bytes uint8, offsets int32[n + 1])
+                v, o = c
+                blocks.append(Block(t, abi.VARWIDTH, n, values=DeviceBuffer(v.data_ptr(), v.numel(), v), offsets=DeviceBuffer(o.data_ptr(), o.numel() * 4, o)))
+            else:
+                blocks.append(Block(t, abi.FLAT, n, values=DeviceBuffer(c.data_ptr(), c.numel() * c.element_size(), c)))
         return Page(blocks, n, abi.MEM_DEVICE)
 
     def hash_rows(self, columns, types, channels):
@@ -69,11 +74,36 @@ class DeviceOps:
                                                      counts, self._stream()))
         return pos, [int(c) for c in counts]
 
+    def gather_varwidth(self, values, offsets, positions):
+        """Block.copyPositions for a VARCHAR column -> (bytes, offsets, per-row lengths)."""
+        n = positions.numel()
+        lengths = torch.empty(n, dtype=torch.int32, device=values.device)
+        out_offsets = torch.empty(n + 1, dtype=torch.int32, device=values.device)
+        total = C.c_int64()
+        self._check(self._lib.pa_varwidth_gather_offsets(offsets.data_ptr(), positions.data_ptr(), n, lengths.data_ptr(), out_offsets.data_ptr(),
+                                                         C.byref(total), self._stream()))
+        out = torch.empty(max(total.value, 1), dtype=torch.uint8, device=values.device)
+        self._check(self._lib.pa_varwidth_gather_bytes(values.data_ptr(), offsets.data_ptr(), positions.data_ptr(), n, out_offsets.data_ptr(),
+                                                       out.data_ptr(), self._stream()))
+        return out[:total.value], out_offsets, lengths
+
+    def offsets_from_lengths(self, lengths):
+        n = lengths.numel()
+        out = torch.empty(n + 1, dtype=torch.int32, device=lengths.device)
+        total = C.c_int64()
+        self._check(self._lib.pa_offsets_from_lengths(lengths.data_ptr() if n else None, n, out.data_ptr(), C.byref(total), self._stream()))
+        return out, total.value
+
     def gather(self, column, positions):
         out = torch.empty(positions.numel(), dtype=column.dtype, device=column.device)
         self._check(self._lib.pa_gather_flat(column.data_ptr(), column.element_size(), positions.data_ptr(), positions.numel(),
                                              out.data_ptr(), self._stream()))
         return out
+
+
+def rows_of(column):
+    """rows of a column: a 1-D tensor, or (bytes, offsets[n + 1]) for VARCHAR"""
+    return int(column[1].shape[0]) - 1 if isinstance(column, (tuple, list)) else int(column.shape[0])
 
 
 def partition_rows(ops, columns, types, hash_channels, partition_count, local=True, raw_hash=None):
@@ -85,17 +115,16 @@ def partition_rows(ops, columns, types, hash_channels, partition_count, local=Tr
 
 
 def exchange_columns(ops, columns, types, hash_channels, group=None, local=None, raw_hash=None):
-    """All-to-all of the rows of `columns` (1-D tensors of equal length) by the hash of `hash_channels`.
+    """All-to-all of the rows of `columns` by the hash of `hash_channels`.  A column is a 1-D tensor, or for VARCHAR the pair
+    (bytes uint8, offsets int32[n + 1]): its rows travel as per-row lengths (split by rows) plus the bytes (split by the byte
+    totals of the destinations), and the receiver rebuilds the offsets with a scan.
 
     Returns (received columns, rows received from every source rank)."""
     world = dist.get_world_size(group)
-    for t in types:
-        if t == abi.VARCHAR:
-            raise NotImplementedError("VARCHAR columns are not shuffled on device yet (fixed-width columns only)")
     if local is None:
         local = (world & (world - 1)) == 0  # LocalPartitionGenerator needs a power of two
-    device = columns[0].device
-    rows = int(columns[0].shape[0])
+    device = (columns[0][0] if isinstance(columns[0], (tuple, list)) else columns[0]).device
+    rows = rows_of(columns[0])
     if rows > 0:
         positions, send_counts = partition_rows(ops, columns, types, hash_channels, world, local, raw_hash)
     else:  # a rank with nothing to send still takes part in the collectives
@@ -106,7 +135,30 @@ def exchange_columns(ops, columns, types, hash_channels, group=None, local=None,
     dist.all_to_all_single(rc, sc, group=group)
     recv_counts = [int(x) for x in rc.tolist()]
     received = []
-    for col in columns:
+    for col, t in zip(columns, types):
+        if t == abi.VARCHAR:
+            values, offsets = col
+            if rows > 0:
+                send_bytes, send_offsets, send_lengths = ops.gather_varwidth(values, offsets, positions)
+                bounds = torch.tensor([0] + list(torch.tensor(send_counts).cumsum(0).tolist()), dtype=torch.int64, device=device)
+                ends = send_offsets.index_select(0, bounds).tolist()  # byte offset at every destination boundary
+                send_byte_counts = [int(ends[i + 1] - ends[i]) for i in range(world)]
+            else:
+                send_bytes = torch.empty(0, dtype=torch.uint8, device=device)
+                send_lengths = torch.empty(0, dtype=torch.int32, device=device)
+                send_byte_counts = [0] * world
+            sb = torch.tensor(send_byte_counts, dtype=torch.int64, device=device)
+            rb = torch.empty(world, dtype=torch.int64, device=device)
+            dist.all_to_all_single(rb, sb, group=group)
+            recv_byte_counts = [int(x) for x in rb.tolist()]
+            recv_lengths = torch.empty(sum(recv_counts), dtype=torch.int32, device=device)
+            dist.all_to_all_single(recv_lengths, send_lengths, output_split_sizes=recv_counts, input_split_sizes=send_counts, group=group)
+            recv_bytes = torch.empty(sum(recv_byte_counts), dtype=torch.uint8, device=device)
+            dist.all_to_all_single(recv_bytes, send_bytes.contiguous(), output_split_sizes=recv_byte_counts, input_split_sizes=send_byte_counts, group=group)
+            recv_offsets, total = ops.offsets_from_lengths(recv_lengths)
+            assert total == sum(recv_byte_counts)
+            received.append((recv_bytes, recv_offsets))
+            continue
         send = ops.gather(col, positions) if rows > 0 else col
         recv = torch.empty(sum(recv_counts), dtype=col.dtype, device=device)
         dist.all_to_all_single(recv, send, output_split_sizes=recv_counts, input_split_sizes=send_counts, group=group)

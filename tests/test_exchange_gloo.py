@@ -25,8 +25,11 @@ class OracleOps:
         self.O = O
 
     def _page(self, columns, types):
+        from presto_amd import abi
+        from presto_amd.exchange import rows_of
         from presto_amd.page import Block, Page
-        return Page([Block.flat(t, c.numpy()) for c, t in zip(columns, types)], int(columns[0].shape[0]))
+        blocks = [Block.varwidth(c[0].numpy(), c[1].numpy()) if t == abi.VARCHAR else Block.flat(t, c.numpy()) for c, t in zip(columns, types)]
+        return Page(blocks, rows_of(columns[0]))
 
     def hash_rows(self, columns, types, channels):
         return torch.from_numpy(self.O.hash_page(self._page(columns, types), channels))
@@ -40,6 +43,17 @@ class OracleOps:
 
     def gather(self, column, positions):
         return column[positions.long()]
+
+    def gather_varwidth(self, values, offsets, positions):
+        v, o, p = values.numpy(), offsets.numpy().astype(np.int64), positions.numpy().astype(np.int64)
+        lengths = (o[p + 1] - o[p]).astype(np.int32)
+        out_off = np.concatenate([[0], np.cumsum(lengths)]).astype(np.int32)
+        out = np.concatenate([v[o[i]:o[i + 1]] for i in p]) if len(p) else np.zeros(0, np.uint8)
+        return torch.from_numpy(np.ascontiguousarray(out.astype(np.uint8))), torch.from_numpy(out_off), torch.from_numpy(lengths)
+
+    def offsets_from_lengths(self, lengths):
+        out = np.concatenate([[0], np.cumsum(lengths.numpy().astype(np.int64))]).astype(np.int32)
+        return torch.from_numpy(out), int(out[-1])
 
 
 def make_tables(seed):
@@ -267,3 +281,57 @@ def test_exchange_operator_with_uneven_page_counts(oracle):
         assert received == int(mine.sum())
         assert pages == 3  # one output page per collective round (rank 0 fed three pages)
     assert results[0][3] == 3000 and results[1][3] == 1000
+
+
+def varchar_worker(rank, world, port, result_queue):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from presto_amd import abi
+    from presto_amd.exchange import exchange_columns
+    from presto_amd.page import Block
+    keys, names = varchar_table()
+    n = len(keys)
+    lo, hi = (0, n // 3) if rank == 0 else (n // 3, n)   # uneven shards
+    b = Block.varchar(names[lo:hi])
+    cols = [torch.from_numpy(np.ascontiguousarray(keys[lo:hi])), (torch.from_numpy(b.values.copy()), torch.from_numpy(b.offsets.copy()))]
+    recv, counts = exchange_columns(OracleOps(), cols, [abi.BIGINT, abi.VARCHAR], [1])   # partitioned BY THE STRING
+    rk = recv[0].numpy().tolist()
+    rb, ro = recv[1][0].numpy().tobytes(), recv[1][1].numpy().tolist()
+    rows = [(rk[i], rb[ro[i]:ro[i + 1]]) for i in range(len(rk))]
+    result_queue.put((rank, rows, counts))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def varchar_table():
+    rng = np.random.default_rng(21)
+    words = [b"", b"a", b"BUILDING", b"AUTOMOBILE", b"0123456789abcdefghijklmnopqrstuvwxyz", b"\xc3\xa9", b"zz"]
+    n = 3001
+    return rng.integers(0, 10 ** 6, n).astype(np.int64), [words[i] + str(int(j)).encode() for i, j in zip(rng.integers(0, len(words), n), rng.integers(0, 50, n))]
+
+
+def test_varchar_columns_travel_through_the_exchange(oracle):
+    """VARCHAR columns (and a VARCHAR partitioning key): per-row lengths split by rows, bytes split by the byte totals of
+    the destinations, offsets rebuilt by the receiver; every row arrives once, on the rank its string hashes to."""
+    from presto_amd.page import Block, Page
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=varchar_worker, args=(r, world, port, q)) for r in range(world)]
+    [p.start() for p in procs]
+    results = sorted(q.get(timeout=120) for _ in range(world))
+    [p.join(timeout=60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    keys, names = varchar_table()
+    h = oracle.hash_page(Page([Block.varchar(names)], len(names)), [0])
+    part = oracle.partition_ids(h, world, local=True)
+    for rank, rows, counts in results:
+        mine = [(int(k), nm) for k, nm, p in zip(keys, names, part) if p == rank]
+        assert sorted(rows) == sorted(mine) and len(rows) == sum(counts)
+        # source-rank order, then source position: rank 0's rows first, each run in ascending source position
+        split = counts[0]
+        first = [(int(k), nm) for k, nm, p in zip(keys[:len(keys) // 3], names[:len(keys) // 3], part[:len(keys) // 3]) if p == rank]
+        assert rows[:split] == first

@@ -72,3 +72,33 @@ def test_exchange_on_one_rank_over_rccl(gpu, oracle):
         assert np.array_equal(recv[0].cpu().numpy(), keys) and np.array_equal(recv[1].cpu().numpy(), vals)
     finally:
         dist.destroy_process_group()
+
+
+def test_varchar_exchange_on_one_rank_over_rccl(gpu, oracle):
+    """VARCHAR column + VARCHAR partitioning key through the device ops and a one-rank RCCL group (self copy): rows come back
+    grouped by partition, strings intact."""
+    import torch.distributed as dist
+    from presto_amd.exchange import DeviceOps, exchange_columns
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29537")
+    torch.zeros(1, device="cuda")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        rng = np.random.default_rng(9)
+        n = 40001
+        words = [b"", b"a", b"BUILDING", b"0123456789abcdefghijklmnopqrstuvwxyz", b"zz"]
+        names = [words[i] + str(int(j)).encode() for i, j in zip(rng.integers(0, len(words), n), rng.integers(0, 1000, n))]
+        b = Block.varchar(names)
+        keys = rng.integers(0, 10 ** 9, n).astype(np.int64)
+        cols = [torch.from_numpy(keys).cuda(), (torch.from_numpy(b.values.copy()).cuda(), torch.from_numpy(b.offsets.copy()).cuda())]
+        recv, counts = exchange_columns(DeviceOps(), cols, [abi.BIGINT, abi.VARCHAR], [1])
+        torch.cuda.synchronize()
+        assert counts == [n]
+        rb, ro = recv[1][0].cpu().numpy().tobytes(), recv[1][1].cpu().numpy().tolist()
+        got = [(int(k), rb[ro[i]:ro[i + 1]]) for i, k in enumerate(recv[0].cpu().numpy().tolist())]
+        assert got == list(zip(keys.tolist(), names))   # one partition: the stable order is the input order
+        # the row hash of the string column equals the oracle's (what routes the rows)
+        h = DeviceOps().hash_rows(cols, [abi.BIGINT, abi.VARCHAR], [1]).cpu().numpy()
+        assert np.array_equal(h, oracle.hash_page(Page([Block.bigint(keys), Block.varchar(names)], n), [1]))
+    finally:
+        dist.destroy_process_group()
