@@ -275,6 +275,20 @@ typedef struct pa_topn_desc {
     void* stream;
 } pa_topn_desc;
 
+/* OrderByOperator.OrderByOperatorFactory (OrderByOperator.java:45-120): collect the input, sort it by (sort_channels,
+ * sort_orders) when it ends, emit output_channels in order (one page).  Fully tied rows keep arrival order. */
+typedef struct pa_order_by_desc {
+    int32_t input_channel_count;
+    const int32_t* input_types;
+    int32_t output_channel_count;
+    const int32_t* output_channels;
+    int32_t sort_channel_count;
+    const int32_t* sort_channels;
+    const int32_t* sort_orders;          /* pa_sort_order per sort channel */
+    int32_t output_mem;
+    void* stream;
+} pa_order_by_desc;
+
 typedef struct pa_operator pa_operator;             /* opaque operator handle */
 typedef struct pa_lookup_source pa_lookup_source;   /* opaque: JoinBridge / LookupSourceFactory */
 
@@ -308,6 +322,7 @@ int32_t pa_aggregation_create(const pa_aggregation_desc* desc, pa_operator** out
 int32_t pa_hash_aggregation_create(const pa_hash_aggregation_desc* desc, pa_operator** out);
 int32_t pa_fused_aggregation_create(const pa_fused_aggregation_desc* desc, pa_operator** out);
 int32_t pa_topn_create(const pa_topn_desc* desc, pa_operator** out);
+int32_t pa_order_by_create(const pa_order_by_desc* desc, pa_operator** out);
 int32_t pa_lookup_source_create(pa_lookup_source** out);
 int32_t pa_lookup_source_destroy(pa_lookup_source* ls);
 int32_t pa_hash_builder_create(const pa_hash_builder_desc* desc, pa_lookup_source* bridge, pa_operator** out);
@@ -324,7 +339,9 @@ int32_t pa_op_needs_input(pa_operator* op);                 /* 1 / 0 */
 int32_t pa_op_add_input(pa_operator* op, const pa_page* page);
 /* Returns 1 and fills *out when a page is available, 0 when none.  The page's buffers are owned by
  * the operator (or, for zero-copy identity projections, are the caller's own input buffers) and stay valid
- * until the next add_input / get_output / close on the same handle. */
+ * until the next add_input / get_output / close on the same handle.  PA_MEM_DEVICE pages: when the operator runs on a
+ * caller-provided desc.stream the page is valid in that stream's order; when the library owns the stream (desc.stream ==
+ * NULL) the page is complete on return. */
 int32_t pa_op_get_output(pa_operator* op, pa_page* out);
 int32_t pa_op_finish(pa_operator* op);
 int32_t pa_op_is_finished(pa_operator* op);                 /* 1 / 0 */

@@ -491,7 +491,14 @@ def topn(pages, n, sort_channels, sort_orders):
 
     if n == 0:
         return []
-    return sorted(rows, key=functools.cmp_to_key(cmp))[:n]
+    ordered = sorted(rows, key=functools.cmp_to_key(cmp))
+    return ordered if n is None else ordered[:n]
+
+
+def order_by(pages, output_channels, sort_channels, sort_orders):
+    """OrderByOperator (core/trino-main/src/main/java/io/trino/operator/OrderByOperator.java:45-330): PagesIndex.sort with the same
+    comparator as TopN (SimplePagesIndexComparator / SortOrder.compareBlockValue), every row kept; output channels only."""
+    return [tuple(r[c] for c in output_channels) for r in topn(pages, None, sort_channels, sort_orders)]
 
 
 # ---- page wire format -------------------------------------------------------------------------------------------------

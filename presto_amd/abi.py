@@ -150,6 +150,20 @@ class pa_topn_desc(C.Structure):
     ]
 
 
+class pa_order_by_desc(C.Structure):
+    _fields_ = [
+        ("input_channel_count", C.c_int32),
+        ("input_types", C.POINTER(C.c_int32)),
+        ("output_channel_count", C.c_int32),
+        ("output_channels", C.POINTER(C.c_int32)),
+        ("sort_channel_count", C.c_int32),
+        ("sort_channels", C.POINTER(C.c_int32)),
+        ("sort_orders", C.POINTER(C.c_int32)),
+        ("output_mem", C.c_int32),
+        ("stream", C.c_void_p),
+    ]
+
+
 class pa_aggregation_desc(C.Structure):
     _fields_ = [
         ("input_channel_count", C.c_int32),

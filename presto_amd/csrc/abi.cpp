@@ -314,6 +314,14 @@ int32_t pa_topn_create(const pa_topn_desc* desc, pa_operator** out)
         return PA_OK;
     });
 }
+int32_t pa_order_by_create(const pa_order_by_desc* desc, pa_operator** out)
+{
+    return guarded([&]() -> int32_t {
+        PA_REQUIRE(out != nullptr, PA_ERR_INVALID_ARGUMENT, "null argument");
+        *out = make_order_by(desc);
+        return PA_OK;
+    });
+}
 int32_t pa_hash_builder_create(const pa_hash_builder_desc* desc, pa_lookup_source* bridge, pa_operator** out)
 {
     return guarded([&]() -> int32_t {
@@ -395,7 +403,11 @@ int32_t pa_op_get_output(pa_operator* op, pa_page* out)
 {
     return guarded([&]() -> int32_t {
         PA_REQUIRE(op != nullptr && out != nullptr, PA_ERR_INVALID_ARGUMENT, "null argument");
-        return op->get_output(out) ? 1 : 0;
+        if (!op->get_output(out)) return 0;
+        if (out->mem == PA_MEM_DEVICE) {
+            if (hipStream_t s = op->private_stream()) PA_HIP(hipStreamSynchronize(s));
+        }
+        return 1;
     });
 }
 int32_t pa_op_finish(pa_operator* op)

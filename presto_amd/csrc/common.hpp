@@ -173,6 +173,7 @@ public:
         if (owned_ && s_) pool_stream_release(s_);
     }
     hipStream_t get() const { return s_; }
+    bool owned() const { return owned_; }
     void sync() const { PA_HIP(hipStreamSynchronize(s_)); }
 
 private:

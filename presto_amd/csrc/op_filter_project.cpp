@@ -214,6 +214,7 @@ public:
         merging_ = merge_min_bytes_ > 0 || merge_min_rows_ > 0;
     }
     ~FilterProjectOperator() override { (void)hipStreamSynchronize(stream_.get()); }
+    hipStream_t private_stream() override { return stream_.owned() ? stream_.get() : nullptr; }
 
     bool needs_input() override { return !finishing_ && !pending_ && !big_queued_; }
 

@@ -766,6 +766,7 @@ public:
             if (ev_merge_[b]) (void)hipEventDestroy(ev_merge_[b]);
         }
     }
+    hipStream_t private_stream() override { return stream_.owned() ? stream_.get() : nullptr; }
 
     bool needs_input() override { return !finishing_; }
 

@@ -263,6 +263,7 @@ public:
         out_cols_.resize(output_channels_.size() + ls_->output_channels.size());
     }
     ~LookupJoinOperator() override { (void)hipStreamSynchronize(stream_.get()); }
+    hipStream_t private_stream() override { return stream_.owned() ? stream_.get() : nullptr; }
 
     // LookupJoinOperator.needsInput: only once the lookup source is ready, one probe page at a time
     bool needs_input() override { return !finishing_ && !pending_ && ls_->built.load(); }
@@ -432,6 +433,7 @@ public:
         h_ctl_ = static_cast<int32_t*>(h_ctl_buf_.ensure(64));
     }
     ~LookupOuterOperator() override { (void)hipStreamSynchronize(stream_.get()); }
+    hipStream_t private_stream() override { return stream_.owned() ? stream_.get() : nullptr; }
 
     bool needs_input() override { return false; }  // LookupOuterOperator.java:135-138
     void add_input(const pa_page*) override { throw Error(PA_ERR_ILLEGAL_STATE, "LookupOuterOperator does not take input"); }

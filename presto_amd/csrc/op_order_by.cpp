@@ -1,0 +1,232 @@
+// op_order_by.cpp -- OrderByOperator (core/trino-main/src/main/java/io/trino/operator/OrderByOperator.java:45-330): collect every
+// input page (PagesIndex.addPage), sort by (sortChannels, sortOrders) when the input ends (PagesIndex.sort ->
+// PagesIndexOrdering with SimplePagesIndexComparator), emit the output channels in order.
+//
+// The reference quick-sorts row addresses with a multi-channel comparator.  Here: a stable least-significant-digit radix
+// sort of a row permutation on device.  Every sort channel is turned into order-preserving 64-bit images
+// (topn_kernels.hip: integers, DATE, BOOLEAN, DOUBLE in Double.compare order; a VARCHAR as its 8-byte chunks, zero padded,
+// with the length as the least significant key -- Slice.compareTo: unsigned bytes, a proper prefix sorts first) plus a
+// one-bit NULL digit above them (SortOrder: NULLS FIRST / LAST, independent of ASC / DESC); channels are processed from the
+// last sort channel to the first, each image in eight 8-bit passes of the stable partition the exchange already uses
+// (digit -> partition id -> positions grouped by digit in arrival order).  Fully tied rows keep arrival order.
+#include <algorithm>
+#include <cstring>
+
+#include "operator.hpp"
+#include "scan_kernels.hpp"
+#include "topn_kernels.hpp"
+
+namespace pa {
+
+void launch_sort_digits(const uint64_t* keys, const int32_t* perm, int64_t n, int shift, int bits, int32_t* digits, hipStream_t s);
+void launch_sort_null_digits(const uint8_t* nulls, const int32_t* perm, int64_t n, int nulls_first, int32_t* digits, hipStream_t s);
+void launch_varchar_chunk_keys(const void* values, const int32_t* offsets, const uint8_t* nulls, int64_t n, int chunk, int descending,
+                               uint64_t* keys, hipStream_t s);
+void launch_iota_i32(int32_t* dst, int64_t n, hipStream_t s);
+int32_t varchar_max_length(const int32_t* offsets, int64_t n, void* temp_dev_8, hipStream_t s);
+
+namespace {
+
+// all rows of the input so far, column by column (PagesIndex.addPage; flat device arrays: address == position)
+struct Accumulated {
+    int32_t type = PA_BIGINT;
+    bool varwidth = false, has_nulls = false;
+    DevBuf values, offsets, nulls;
+    int64_t bytes = 0;  // VARCHAR bytes used
+};
+
+class OrderByOperator : public pa_operator {
+public:
+    explicit OrderByOperator(const pa_order_by_desc* d) : stream_(d->stream)
+    {
+        require_device();
+        PA_REQUIRE(d->input_channel_count > 0 && d->input_types, PA_ERR_INVALID_ARGUMENT, "OrderBy needs input types");
+        PA_REQUIRE(d->sort_channel_count > 0 && d->sort_channels && d->sort_orders, PA_ERR_INVALID_ARGUMENT, "OrderBy needs sort channels");
+        types_.assign(d->input_types, d->input_types + d->input_channel_count);
+        if (d->output_channels) output_channels_.assign(d->output_channels, d->output_channels + d->output_channel_count);
+        sort_channels_.assign(d->sort_channels, d->sort_channels + d->sort_channel_count);
+        sort_orders_.assign(d->sort_orders, d->sort_orders + d->sort_channel_count);
+        for (int c : output_channels_) PA_REQUIRE(c >= 0 && c < (int)types_.size(), PA_ERR_INVALID_ARGUMENT, "output channel out of range");
+        for (size_t i = 0; i < sort_channels_.size(); i++) {
+            PA_REQUIRE(sort_channels_[i] >= 0 && sort_channels_[i] < (int)types_.size(), PA_ERR_INVALID_ARGUMENT, "sort channel out of range");
+            PA_REQUIRE(sort_orders_[i] >= 0 && sort_orders_[i] <= 3, PA_ERR_INVALID_ARGUMENT, "unknown sort order");
+        }
+        output_mem_ = d->output_mem;
+        cols_.resize(types_.size());
+        needed_.assign(types_.size(), false);
+        for (int c : output_channels_) needed_[(size_t)c] = true;
+        for (int c : sort_channels_) needed_[(size_t)c] = true;
+        for (size_t c = 0; c < types_.size(); c++) {
+            cols_[c].type = types_[c];
+            cols_[c].varwidth = types_[c] == PA_VARCHAR;
+        }
+    }
+    ~OrderByOperator() override { (void)hipStreamSynchronize(stream_.get()); }
+    hipStream_t private_stream() override { return stream_.owned() ? stream_.get() : nullptr; }
+
+    bool needs_input() override { return !finishing_; }
+
+    void add_input(const pa_page* page) override
+    {
+        PA_REQUIRE(!finishing_, PA_ERR_ILLEGAL_STATE, "Operator is already finishing");
+        PA_REQUIRE(page != nullptr && page->channel_count == (int32_t)types_.size(), PA_ERR_INVALID_ARGUMENT, "page does not match the operator's input types");
+        if (page->position_count == 0) return;
+        hipStream_t s = stream_.get();
+        DevPage dp = stager_.stage(page, &needed_, s);
+        const int64_t m = dp.n;
+        PA_REQUIRE(rows_ + m <= INT32_MAX, PA_ERR_INSUFFICIENT_RESOURCES, "too many rows for one sort");
+        for (size_t c = 0; c < types_.size(); c++) {
+            if (!needed_[c]) continue;
+            const DevColumn& in = dp.cols[c];
+            PA_REQUIRE(in.type == types_[c], PA_ERR_INVALID_ARGUMENT, "page block type does not match the declared input type");
+            Accumulated& a = cols_[c];
+            if (a.varwidth) {
+                int32_t ends[2];
+                PA_HIP(hipMemcpyAsync(&ends[0], in.offsets, 4, hipMemcpyDeviceToHost, s));
+                PA_HIP(hipMemcpyAsync(&ends[1], in.offsets + m, 4, hipMemcpyDeviceToHost, s));
+                PA_HIP(hipStreamSynchronize(s));
+                const int64_t add = ends[1] - ends[0];
+                PA_REQUIRE(a.bytes + add <= INT32_MAX, PA_ERR_INSUFFICIENT_RESOURCES, "VARCHAR column exceeds 2 GB");
+                int32_t* off = static_cast<int32_t*>(a.offsets.reserve_keep((size_t)(rows_ + m + 1) * 4, (size_t)(rows_ ? rows_ + 1 : 0) * 4, s));
+                launch_offsets_append(in.offsets, m, (int32_t)a.bytes, off + rows_, rows_ == 0, s);
+                char* v = static_cast<char*>(a.values.reserve_keep((size_t)(a.bytes + add + 1), (size_t)a.bytes, s));
+                if (add) PA_HIP(hipMemcpyAsync(v + a.bytes, static_cast<const char*>(in.values) + ends[0], (size_t)add, hipMemcpyDeviceToDevice, s));
+                a.bytes += add;
+            }
+            else {
+                const size_t w = (size_t)type_width(a.type);
+                char* v = static_cast<char*>(a.values.reserve_keep((size_t)(rows_ + m) * w, (size_t)rows_ * w, s));
+                PA_HIP(hipMemcpyAsync(v + (size_t)rows_ * w, in.values, (size_t)m * w, hipMemcpyDeviceToDevice, s));
+            }
+            if (in.nulls || a.has_nulls) {
+                uint8_t* nl = static_cast<uint8_t*>(a.nulls.reserve_keep((size_t)(rows_ + m), a.has_nulls ? (size_t)rows_ : 0, s));
+                if (!a.has_nulls && rows_ > 0) PA_HIP(hipMemsetAsync(nl, 0, (size_t)rows_, s));
+                if (in.nulls) PA_HIP(hipMemcpyAsync(nl + rows_, in.nulls, (size_t)m, hipMemcpyDeviceToDevice, s));
+                else PA_HIP(hipMemsetAsync(nl + rows_, 0, (size_t)m, s));
+                a.has_nulls = true;
+            }
+        }
+        PA_HIP(hipStreamSynchronize(s));  // the stager's buffers are reused by the next page
+        rows_ += m;
+    }
+
+    void finish() override { finishing_ = true; }
+    bool is_finished() override { return finishing_ && output_done_; }
+
+    bool get_output(pa_page* out) override
+    {
+        if (!finishing_ || output_done_) return false;
+        output_done_ = true;
+        if (rows_ == 0) return false;
+        hipStream_t s = stream_.get();
+        const int64_t n = rows_;
+        int32_t* perm = static_cast<int32_t*>(perm_[0].ensure((size_t)n * 4));
+        int32_t* next = static_cast<int32_t*>(perm_[1].ensure((size_t)n * 4));
+        int32_t* digits = static_cast<int32_t*>(digits_.ensure((size_t)n * 4));
+        int32_t* pos = static_cast<int32_t*>(pos_.ensure((size_t)n * 4));
+        int64_t* counts = static_cast<int64_t*>(counts_.ensure(256 * 8));
+        uint64_t* keys = static_cast<uint64_t*>(keys_.ensure((size_t)n * 8));
+        void* temp = part_temp_.ensure(partition_temp_bytes(n, 256));
+        launch_iota_i32(perm, n, s);
+        timer.begin(s);
+        auto pass = [&](int partitions) {
+            // one stable radix pass: rows grouped by digit, arrival order kept inside a digit; perm' = perm o pos
+            launch_partition_positions(digits, n, partitions, pos, counts, temp, s);
+            launch_gather_flat(perm, 4, pos, n, next, s);
+            std::swap(perm, next);
+        };
+        auto sort_by_image = [&]() {
+            for (int shift = 0; shift < 64; shift += 8) {
+                launch_sort_digits(keys, perm, n, shift, 8, digits, s);
+                pass(256);
+            }
+        };
+        for (int i = (int)sort_channels_.size() - 1; i >= 0; i--) {
+            const Accumulated& a = cols_[(size_t)sort_channels_[i]];
+            const int order = sort_orders_[i];
+            const bool descending = order >= 2, nulls_first = (order & 1) == 0;
+            const uint8_t* nulls = a.has_nulls ? a.nulls.as<uint8_t>() : nullptr;
+            if (a.varwidth) {
+                // least significant first: the length, then the 8-byte chunks from the last to the first
+                const int32_t max_len = varchar_max_length(a.offsets.as<int32_t>(), n, counts, s);
+                const int chunks = (max_len + 7) / 8;
+                for (int chunk = chunks; chunk >= 0; chunk--) {
+                    launch_varchar_chunk_keys(a.values.ptr(), a.offsets.as<int32_t>(), nulls, n, chunk == chunks ? -1 : chunk, descending ? 1 : 0, keys, s);
+                    sort_by_image();
+                }
+            }
+            else {
+                // value image; NULL rows get one constant image (they keep arrival order among themselves) and their place
+                // relative to the values is decided by the separate NULL digit below
+                launch_topn_keys(a.type, a.values.ptr(), nullptr, nulls, n, descending ? PA_DESC_NULLS_LAST : PA_ASC_NULLS_LAST, keys, s);
+                sort_by_image();
+            }
+            if (nulls) {
+                launch_sort_null_digits(nulls, perm, n, nulls_first ? 1 : 0, digits, s);
+                pass(2);
+            }
+        }
+        timer.end(s);
+        // output channels in sorted order (PagesIndex.appendTo)
+        const std::vector<int>& outs = output_channels_;
+        out_cols_.clear();
+        out_cols_.resize(outs.size());
+        for (size_t j = 0; j < outs.size(); j++) {
+            const Accumulated& a = cols_[(size_t)outs[j]];
+            OutColumn& oc = out_cols_[j];
+            oc.type = a.type;
+            oc.varwidth = a.varwidth;
+            const uint8_t* nulls = a.has_nulls ? a.nulls.as<uint8_t>() : nullptr;
+            oc.has_nulls = nulls != nullptr;
+            if (a.varwidth) {
+                int32_t* lens = static_cast<int32_t*>(oc.offsets.ensure((size_t)(n + 1) * 4));
+                int32_t* total = reinterpret_cast<int32_t*>(counts);
+                launch_varwidth_lengths(perm, n, a.offsets.as<int32_t>(), nulls, lens, s);
+                launch_exclusive_scan_i32(lens, lens, n, total, scan_temp_.ensure(scan_temp_bytes(n)), s);
+                int32_t h_total = 0;
+                PA_HIP(hipMemcpyAsync(&h_total, total, 4, hipMemcpyDeviceToHost, s));
+                PA_HIP(hipStreamSynchronize(s));
+                launch_varwidth_copy(perm, n, a.offsets.as<int32_t>(), a.values.as<uint8_t>(), nulls, lens,
+                                     static_cast<uint8_t*>(oc.values.ensure((size_t)(h_total > 0 ? h_total : 1))), total, s);
+            }
+            else {
+                const int w = type_width(a.type);
+                launch_gather_flat(a.values.ptr(), w, perm, n, oc.values.ensure((size_t)n * w), s);
+            }
+            if (nulls) launch_gather_nulls(nulls, perm, n, static_cast<uint8_t*>(oc.nulls.ensure((size_t)n)), s);
+        }
+        publish_output(out_cols_, (int32_t)n, output_mem_, s, out, out_storage_);
+        return true;
+    }
+
+    int64_t memory_bytes() override
+    {
+        int64_t b = 0;
+        for (const auto& a : cols_) b += (int64_t)(a.values.capacity() + a.offsets.capacity() + a.nulls.capacity());
+        return b;
+    }
+
+private:
+    Stream stream_;
+    PageStager stager_;
+    std::vector<int32_t> types_, sort_orders_;
+    std::vector<int> output_channels_, sort_channels_;
+    std::vector<bool> needed_;
+    std::vector<Accumulated> cols_;
+    int64_t rows_ = 0;
+    int32_t output_mem_ = PA_MEM_HOST;
+    bool finishing_ = false, output_done_ = false;
+    DevBuf perm_[2], digits_, pos_, counts_, keys_, part_temp_, scan_temp_;
+    std::vector<OutColumn> out_cols_;
+    std::vector<pa_column> out_storage_;
+};
+
+}  // namespace
+
+pa_operator* make_order_by(const pa_order_by_desc* desc)
+{
+    PA_REQUIRE(desc != nullptr, PA_ERR_INVALID_ARGUMENT, "descriptor is null");
+    return new OrderByOperator(desc);
+}
+
+}  // namespace pa

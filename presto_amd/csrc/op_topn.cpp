@@ -54,6 +54,7 @@ public:
         output_done_ = n_ == 0;
     }
     ~TopNOperator() override { (void)hipStreamSynchronize(stream_.get()); }
+    hipStream_t private_stream() override { return stream_.owned() ? stream_.get() : nullptr; }
 
     bool needs_input() override { return !finishing_; }
 

@@ -16,6 +16,9 @@ struct pa_operator {
     virtual bool is_blocked() { return false; }
     virtual int64_t memory_bytes() { return 0; }
     virtual void close() {}
+    // the operator's stream when the library owns it (desc.stream == NULL), else nullptr: nobody outside can order work
+    // against an owned stream, so device output pages are completed before pa_op_get_output returns them
+    virtual hipStream_t private_stream() { return nullptr; }
     pa::KernelTimer timer;
 };
 
@@ -26,6 +29,7 @@ pa_operator* make_filter_project(const pa_filter_project_desc* desc);
 pa_operator* make_hash_builder(const pa_hash_builder_desc* desc, pa_lookup_source* bridge);
 pa_operator* make_lookup_join(const pa_lookup_join_desc* desc, pa_lookup_source* bridge);
 pa_operator* make_topn(const pa_topn_desc* desc);
+pa_operator* make_order_by(const pa_order_by_desc* desc);
 pa_operator* make_lookup_outer(const pa_lookup_join_desc* desc, pa_lookup_source* bridge);
 
 // page wire format (page_serde.cpp)

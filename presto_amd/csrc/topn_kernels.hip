@@ -132,4 +132,88 @@ void launch_topn_flag(const uint64_t* keys, int64_t n, uint64_t threshold, int32
     PA_HIP(hipGetLastError());
 }
 
+// ---- OrderByOperator (op_order_by.cpp): digits of a radix pass, taken through the current permutation --------------------
+namespace {
+__global__ __launch_bounds__(256) void k_sort_digits(const u64* __restrict__ keys, const i32* __restrict__ perm, i64 n, int shift, u32 mask,
+                                                     i32* __restrict__ digits)
+{
+    for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < n; i += (i64)gridDim.x * 256) digits[i] = (i32)((keys[perm[i]] >> shift) & mask);
+}
+__global__ __launch_bounds__(256) void k_sort_null_digits(const u8* __restrict__ nulls, const i32* __restrict__ perm, i64 n, int nulls_first,
+                                                          i32* __restrict__ digits)
+{
+    for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < n; i += (i64)gridDim.x * 256) {
+        const int is_null = nulls[perm[i]] ? 1 : 0;
+        digits[i] = nulls_first ? 1 - is_null : is_null;
+    }
+}
+// chunk >= 0: bytes [8 chunk, 8 chunk + 8) big-endian, zero padded; chunk < 0: the length.  NULL rows get image 0 (their
+// place is decided by the NULL digit); descending = complement.
+__global__ __launch_bounds__(256) void k_varchar_chunk_keys(const u8* __restrict__ values, const i32* __restrict__ offsets, const u8* __restrict__ nulls,
+                                                            i64 n, int chunk, int descending, u64* __restrict__ keys)
+{
+    for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < n; i += (i64)gridDim.x * 256) {
+        u64 img = 0;
+        if (!(nulls && nulls[i])) {
+            const i32 o = offsets[i], len = offsets[i + 1] - o;
+            if (chunk < 0) img = (u64)(u32)len;
+            else {
+                const u8* p = values + o + 8 * chunk;
+                const i32 left = len - 8 * chunk;
+                for (int b = 0; b < 8; b++) img = (img << 8) | (b < left ? (u64)p[b] : 0ULL);
+            }
+            if (descending) img = ~img;
+        }
+        keys[i] = img;
+    }
+}
+__global__ __launch_bounds__(256) void k_iota_i32(i32* dst, i64 n)
+{
+    for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < n; i += (i64)gridDim.x * 256) dst[i] = (i32)i;
+}
+__global__ __launch_bounds__(256) void k_varchar_max_length(const i32* __restrict__ offsets, i64 n, i32* out)
+{
+    i32 m = 0;
+    for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < n; i += (i64)gridDim.x * 256) m = max(m, offsets[i + 1] - offsets[i]);
+    for (int off = 32; off >= 1; off >>= 1) m = max(m, __shfl_xor(m, off, 64));
+    if ((threadIdx.x & 63) == 0 && m > 0) atomicMax(out, m);
+}
+}  // namespace
+
+void launch_sort_digits(const uint64_t* keys, const int32_t* perm, int64_t n, int shift, int bits, int32_t* digits, hipStream_t s)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_sort_digits, grid_of(n), 256, 0, s, (const u64*)keys, perm, (i64)n, shift, (u32)((1u << bits) - 1u), digits);
+    PA_HIP(hipGetLastError());
+}
+void launch_sort_null_digits(const uint8_t* nulls, const int32_t* perm, int64_t n, int nulls_first, int32_t* digits, hipStream_t s)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_sort_null_digits, grid_of(n), 256, 0, s, nulls, perm, (i64)n, nulls_first, digits);
+    PA_HIP(hipGetLastError());
+}
+void launch_varchar_chunk_keys(const void* values, const int32_t* offsets, const uint8_t* nulls, int64_t n, int chunk, int descending,
+                               uint64_t* keys, hipStream_t s)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_varchar_chunk_keys, grid_of(n), 256, 0, s, (const u8*)values, offsets, nulls, (i64)n, chunk, descending, (u64*)keys);
+    PA_HIP(hipGetLastError());
+}
+void launch_iota_i32(int32_t* dst, int64_t n, hipStream_t s)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_iota_i32, grid_of(n), 256, 0, s, dst, (i64)n);
+    PA_HIP(hipGetLastError());
+}
+int32_t varchar_max_length(const int32_t* offsets, int64_t n, void* temp_dev_8, hipStream_t s)
+{
+    int32_t* out = static_cast<int32_t*>(temp_dev_8);
+    PA_HIP(hipMemsetAsync(out, 0, 4, s));
+    if (n > 0) hipLaunchKernelGGL(k_varchar_max_length, grid_of(n), 256, 0, s, offsets, (i64)n, out);
+    int32_t h = 0;
+    PA_HIP(hipMemcpyAsync(&h, out, 4, hipMemcpyDeviceToHost, s));
+    PA_HIP(hipStreamSynchronize(s));
+    return h;
+}
+
 }  // namespace pa

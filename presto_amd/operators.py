@@ -261,6 +261,27 @@ def TopNOperator(input_types, n, sort_channels, sort_orders, output_mem=abi.MEM_
     return Operator(h, [types, sc, so])
 
 
+def OrderByOperator(input_types, output_channels, sort_channels, sort_orders, output_mem=abi.MEM_HOST, stream=None):
+    """OrderByOperator.OrderByOperatorFactory (…/operator/OrderByOperator.java:45-120)."""
+    d = abi.pa_order_by_desc()
+    types = abi.int32_array(input_types)
+    oc = abi.int32_array(output_channels)
+    sc = abi.int32_array(sort_channels)
+    so = abi.int32_array(sort_orders)
+    d.input_channel_count = len(input_types)
+    d.input_types = C.cast(types, C.POINTER(C.c_int32))
+    d.output_channel_count = len(output_channels)
+    d.output_channels = C.cast(oc, C.POINTER(C.c_int32))
+    d.sort_channel_count = len(sort_channels)
+    d.sort_channels = C.cast(sc, C.POINTER(C.c_int32))
+    d.sort_orders = C.cast(so, C.POINTER(C.c_int32))
+    d.output_mem = output_mem
+    d.stream = stream
+    h = C.c_void_p()
+    check(lib().pa_order_by_create(C.byref(d), C.byref(h)))
+    return Operator(h, [types, oc, sc, so])
+
+
 class LookupSourceFactory:
     """JoinBridge between a HashBuilderOperator and its LookupJoinOperators
     (…/operator/join/PartitionedLookupSourceFactory.java, JoinBridgeManager.java)."""
