@@ -303,8 +303,11 @@ struct PaFusedArgs {
     // ~0.15 M/s per address on this part; R replicas divide the pressure per address by R.  The host folds the
     // replicas into one table before the result is read.
     u32 gt_rep_mask;
-    u32 pad2;
+    u32 part_mask;                    // hash-partitioning pass: partitions - 1 (partition id part_mask + 1 = row filtered out)
     i32* gt_rep_count;                // groups of replica r >= 1 at [r]; replica 0 counts in gt_count
+    i32* part_ids;                    // hash-partitioning pass: partition of every row of the launch
+    i32 list_blocked;                 // row_list is cut into one contiguous slice per workgroup (partition-ordered lists)
+    i32 pad3;
 };
 
 // the replica of the group table this workgroup works on

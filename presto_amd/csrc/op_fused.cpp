@@ -29,6 +29,7 @@
 #include "jit.hpp"
 #include "operator.hpp"
 #include "rowgen.hpp"
+#include "scan_kernels.hpp"
 #include "static_kernels.hpp"
 
 namespace pa {
@@ -72,11 +73,14 @@ struct FusedArgs {
     int32_t* spill_rows;
     uint32_t* spill_count;
     uint32_t gt_rep_mask;
-    uint32_t pad2;
+    uint32_t part_mask;
     int32_t* gt_rep_count;
+    int32_t* part_ids;
+    int32_t list_blocked;
+    int32_t pad3;
 };
 
-enum Variant { V_GLOBAL = 0, V_LDS = 1, V_GT = 2, V_LDSH = 3 };
+enum Variant { V_GLOBAL = 0, V_LDS = 1, V_GT = 2, V_LDSH = 3, V_HASH = 4 };
 enum WordKind { W_CNT = 0, W_SUMF = 1, W_SUMI = 2, W_MAXU = 3 };
 
 constexpr int kLdsSlots = 8;  // C of the LDS variant: 8 groups x NW words x 64 lanes x 8 B of LDS per wave
@@ -486,6 +490,12 @@ KernelInfo generate(const Spec& s, const std::vector<ChannelLayout>& layout, int
                "            if (advance) { i = (i + 1) & (PA_LC - 1); if (++probes >= PA_LC) result = -1; }\n"
                "        }\n    }\n    return result;\n}\n";
     }
+    else if (variant == V_HASH) {
+        // Hash-partitioning pass in front of the LDS-table variant at medium cardinality (hundreds to ~10^5 groups): it only
+        // computes every row's partition = hash(key) mod P (P + 1 for rows the filter drops).  The rows are then taken in
+        // partition order, a contiguous slice per workgroup, so that a workgroup's LDS table meets a few partitions' groups only.
+        src << "struct PaAcc { int unused; };\n";
+    }
     else {
         src << "struct PaAcc { PaGtView tv; PaGtCtr gt; };\n";
     }
@@ -504,7 +514,10 @@ KernelInfo generate(const Spec& s, const std::vector<ChannelLayout>& layout, int
         src << ";\n";
     }
     src << "}\n";
-    if (variant == V_GLOBAL) {
+    if (variant == V_HASH) {
+        src << "if (live) a.part_ids[row] = sel ? (i32)(pa_key_hash(key, PA_KW) & a.part_mask) : (i32)(a.part_mask + 1u);\n";
+    }
+    else if (variant == V_GLOBAL) {
         src << "if (sel) {\n";
         for (int w = 0; w < k.nw; w++) {
             if (words[w].kind == W_SUMF) src << "if (u" << w << ") acc.w" << w << " = acc.w" << w << " + x" << w << ";\n";
@@ -612,6 +625,9 @@ KernelInfo generate(const Spec& s, const std::vector<ChannelLayout>& layout, int
             src << "    PaAcc acc; acc.tv = pa_gt_view(a, PA_KW, PA_NW); acc.gt = pa_gt_ctr_init(acc.tv.count, true, a.gt_rep_mask + 1u);\n"
                    "    acc.flush = pa_gt_ctr_init(acc.tv.count, false); acc.fell = 0;\n";
         }
+        else if (variant == V_HASH) {
+            src << "    PaAcc acc; acc.unused = 0;\n";
+        }
         else {
             src << "    PaAcc acc; acc.tv = pa_gt_view(a, PA_KW, PA_NW); acc.gt = pa_gt_ctr_init(acc.tv.count, true, a.gt_rep_mask + 1u);\n";
         }
@@ -647,8 +663,14 @@ KernelInfo generate(const Spec& s, const std::vector<ChannelLayout>& layout, int
             src << "    for (i64 r = (nq << 2) + t; r < a.n; r += T) {\n        pa_row(a, acc, true, (i32)r" << scalar_args(ri, layout) << ");\n    }\n";
         }
         if (variant == V_GT || variant == V_LDSH) {
+            // rows given by a list: grid-stride (spill replays), or one contiguous slice per workgroup (partition-ordered lists:
+            // the workgroup's LDS table then meets the groups of a few partitions only)
+            src << "    if (a.list_blocked) {\n        const i64 per = (a.n_list + gridDim.x - 1) / gridDim.x;\n"
+                   "        const i64 b0 = (i64)blockIdx.x * per, b1 = b0 + per < a.n_list ? b0 + per : a.n_list;\n"
+                   "        for (i64 i = b0 + threadIdx.x; i < b1; i += " << B << ") {\n            const i64 r = a.row_list[i];\n            pa_row(a, acc, true, (i32)r"
+                << scalar_args(ri, layout) << ");\n        }\n    } else {\n";
             src << "    for (i64 i = t; i < a.n_list; i += T) {\n        const i64 r = a.row_list[i];\n        pa_row(a, acc, true, (i32)r" << scalar_args(ri, layout)
-                << ");\n    }\n";
+                << ");\n    }\n    }\n";
         }
         if (variant == V_LDSH) {
             // the workgroup's table -> HBM table: one upsert and PA_NW atomics per group and workgroup
@@ -793,6 +815,11 @@ public:
             sig += layout[c].nullable ? 'n' : '-';
         }
         for (;;) {
+            int partitions = 0;
+            if (mode_ == V_GT && partitioned_wanted(sig, layout, &partitions)) {
+                run_page_partitioned(sig, layout, dp, vec, partitions);
+                break;
+            }
             const Compiled* compiled = nullptr;
             try {
                 compiled = &kernel_for(sig, layout, mode_);
@@ -974,8 +1001,79 @@ private:
         merge_pending_[0] = merge_pending_[1] = false;
     }
 
+    // rows of one chunk of a page in a given order (the hash-partitioned path)
+    struct RowList {
+        const int32_t* rows;   // positions relative to the chunk's first row
+        int64_t count;
+        int64_t first_row;     // of the chunk in the page
+        int64_t chunk_rows;
+    };
+
+    // Medium cardinality on the HBM-table tier (G groups, lc / 2 < G <= 8 K): partition the rows by hash(key) mod P so that
+    // a partition holds ~lc / 8 groups, then run the LDS-table kernel over the rows in partition order, one contiguous slice
+    // per workgroup -- the atomics per row move from HBM (~20 G/s for the whole chip) into LDS.
+    bool partitioned_wanted(const std::string& sig, const std::vector<ChannelLayout>& layout, int* partitions)
+    {
+        if (!gt_probed_ || getenv("PRESTO_AMD_NO_PARTITIONED")) return false;
+        const uint64_t g = groups_upper_;
+        // measured (64 M rows, 16 B/row): 1 K groups 9 -> 20 G rows/s, 4 K 6 -> 14 G; from ~20 K groups on the rows of one partition
+        // are spread over so many cache lines of the page that gathering them costs more than the HBM atomics it saves
+        if (g < 256 || g > 8192) return false;
+        const Compiled* ldsh = nullptr;
+        try {
+            ldsh = &kernel_for(sig, layout, V_LDSH);
+        }
+        catch (const Error& e) {
+            if (e.code != PA_ERR_NOT_SUPPORTED) throw;
+            return false;
+        }
+        const uint64_t per = std::max(ldsh->info.lc / 8, 8);
+        uint64_t p = next_pow2((g + per - 1) / per);
+        *partitions = (int)std::min<uint64_t>(std::max<uint64_t>(p, 2), 1023);  // + 1 partition for filtered rows <= 1024
+        if (*partitions == 1023) *partitions = 512;
+        return true;
+    }
+
+    void run_page_partitioned(const std::string& sig, const std::vector<ChannelLayout>& layout, const DevPage& dp, bool vec, int partitions)
+    {
+        hipStream_t s = stream_.get();
+        const Compiled& hk = kernel_for(sig, layout, V_HASH);
+        const Compiled& lk = kernel_for(sig, layout, V_LDSH);
+        const int64_t chunk = (int64_t)1 << 26;
+        for (int64_t offset = 0; offset < dp.n; offset += chunk) {
+            const int64_t n = std::min(chunk, dp.n - offset);
+            FusedArgs a;
+            memset(&a, 0, sizeof a);
+            for (int c = 0; c < spec_.n_in; c++) {
+                if (!spec_.used_channel[c]) continue;
+                const DevColumn& col = dp.cols[c];
+                a.v[c] = col.varwidth ? col.values : static_cast<const char*>(col.values) + offset * type_width(col.type);
+                a.o[c] = col.offsets ? col.offsets + offset : nullptr;
+                a.nl[c] = col.nulls ? col.nulls + offset : nullptr;
+            }
+            a.n = n;
+            a.vec = (vec && offset % 4 == 0) ? 1 : 0;
+            a.err = ctl_;
+            a.part_ids = static_cast<int32_t*>(part_ids_.ensure((size_t)n * 4));
+            a.part_mask = (uint32_t)partitions - 1;
+            void* params[] = {&a};
+            const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(((n + 3) / 4 + 255) / 256, (int64_t)cus_ * 8));
+            timer.begin(s);
+            PA_HIP(hipModuleLaunchKernel(hk.kernel.fn, grid, 1, 1, hk.info.block, 1, 1, 0, s, params, nullptr));
+            int32_t* positions = static_cast<int32_t*>(part_pos_.ensure((size_t)n * 4));
+            int64_t* counts = static_cast<int64_t*>(part_counts_.ensure((size_t)(partitions + 1) * 8));
+            launch_partition_positions(a.part_ids, n, partitions + 1, positions, counts, part_temp_.ensure(partition_temp_bytes(n, partitions + 1)), s);
+            timer.end(s, false);
+            int64_t dropped = 0;
+            PA_HIP(hipMemcpyAsync(&dropped, counts + partitions, 8, hipMemcpyDeviceToHost, s));
+            PA_HIP(hipStreamSynchronize(s));
+            RowList list{positions, n - dropped, offset, n};
+            if (list.count > 0) run_page(lk, dp, vec, &list);
+        }
+    }
+
     // returns false when the LDS variant overflowed and the page must be redone with the HBM table
-    bool run_page(const Compiled& ck, const DevPage& dp, bool vec)
+    bool run_page(const Compiled& ck, const DevPage& dp, bool vec, const RowList* list = nullptr)
     {
         hipStream_t s = stream_.get();
         const KernelInfo& ki = ck.info;
@@ -991,8 +1089,8 @@ private:
         a.err = ctl_;
         a.gt_count = ctl_ + 1;
         a.overflow_rows = reinterpret_cast<uint64_t*>(ctl_ + 2);
-        int64_t offset = 0;
-        const int64_t total = dp.n;
+        int64_t offset = list ? list->first_row : 0;
+        const int64_t total = list ? list->first_row + list->chunk_rows : dp.n;
         // the HBM-table variant bounds the groups one launch can add so that the table can be sized first
         const int64_t chunk = (ki.variant == V_GT || ki.variant == V_LDSH) ? (int64_t)1 << 26 : total;
         // LDS variant: head = leading multiple of 256 rows through the vector kernel, tail = the rest through the scalar one
@@ -1001,7 +1099,7 @@ private:
             int64_t n = std::min(chunk, total - offset);
             // the first launch on the HBM table is a short one: it tells how many groups there are, which decides the
             // number of table replicas for the rest
-            if ((ki.variant == V_GT || ki.variant == V_LDSH) && !gt_probed_) n = std::min<int64_t>(n, (int64_t)1 << 22);
+            if ((ki.variant == V_GT || ki.variant == V_LDSH) && !gt_probed_ && !list) n = std::min<int64_t>(n, (int64_t)1 << 22);
             bool use_tail = false;
             if (ki.variant == V_LDS) {
                 if (offset < lds_head) n = lds_head - offset;
@@ -1016,8 +1114,14 @@ private:
                     if (col.nulls) a.nl[c] = col.nulls + offset;
                 }
             }
-            a.n = n;
+            a.n = list ? 0 : n;
             int64_t work = use_tail ? n : (n + 3) / 4;
+            if (list) {
+                a.row_list = list->rows;
+                a.n_list = list->count;
+                a.list_blocked = 1;
+                work = list->count;
+            }
             int grid;
             if (ki.variant == V_LDS) {
                 int per_cu = std::max(1, std::min(16, (int)(160 * 1024 / ((size_t)ki.nw * ki.c * 64 * 8 + 512))));
@@ -1076,8 +1180,10 @@ private:
                 }
                 a.spill_rows = static_cast<int32_t*>(spill_[0].ensure((size_t)n * 4));
                 a.spill_count = reinterpret_cast<uint32_t*>(ctl_ + 6);
-                a.row_list = nullptr;
-                a.n_list = 0;
+                if (!list) {
+                    a.row_list = nullptr;
+                    a.n_list = 0;
+                }
             }
             a.gt_tag = gt_tag_.as<uint64_t>();
             a.gt_keys = gt_keys_.as<uint64_t>();
@@ -1191,6 +1297,7 @@ private:
     DevBuf slab_, state_, gt_tag_, gt_keys_, gt_words_;
     // LDS variant: the merge of page k runs on a second stream while the fused kernel of page k+1 streams
     DevBuf lds_slab_[2], entry_slot_[2], spill_[2], dense_keys_, dense_words_, null_flags_, rep_count_;
+    DevBuf part_ids_, part_pos_, part_counts_, part_temp_;
     PinnedBuf h_rep_;
     uint32_t gt_rep_ = 1;
     uint64_t groups_sum_ = 0;
