@@ -460,7 +460,11 @@ KernelInfo generate(const Spec& s, const std::vector<ChannelLayout>& layout, int
         // atomics in the row loop -- atomics of many rows on a few HBM addresses retire at ~16 M/s per address on this
         // part), and adds its table to the HBM table once, at the end of the kernel.  A row whose group finds no room
         // in the LDS table (more than PA_LC / 2 groups seen by the workgroup) goes to the HBM table directly.
-        src << "#define PA_LC " << k.lc << "\n";
+        int lc_bits = 0;
+        while ((1 << lc_bits) < k.lc) lc_bits++;
+        // the LDS table is indexed by the TOP bits of the 32-bit key hash: the low bits choose the partition (hash-partitioned
+        // path) and the HBM-table slot, so rows of one partition would otherwise share their home slots
+        src << "#define PA_LC " << k.lc << "\n#define PA_LC_SHIFT " << (32 - lc_bits) << "\n";
         src << "__shared__ u64 pa_lt_tag[PA_LC];\n__shared__ u64 pa_lt_key[PA_LC * PA_KW];\n__shared__ u64 pa_lt_acc[PA_LC * PA_NW];\n"
                "__shared__ i32 pa_lt_count;\n";
         src << "struct PaAcc { PaGtView tv; PaGtCtr gt; PaGtCtr flush; i64 fell; };\n";
@@ -468,7 +472,7 @@ KernelInfo generate(const Spec& s, const std::vector<ChannelLayout>& layout, int
         // lane waiting for a slot another lane of its wave is publishing cannot starve it
         src << "__device__ __forceinline__ int pa_lt_upsert(const u32 h, const u64 (&k)[PA_KW])\n{\n"
                "    const u64 busy = ((u64)h << 2) | 1ULL, ready = ((u64)h << 2) | 3ULL;\n"
-               "    u32 i = h & (PA_LC - 1);\n    u32 probes = 0;\n    int spins = 0;\n    int result = -2;\n"
+               "    u32 i = h >> PA_LC_SHIFT;\n    u32 probes = 0;\n    int spins = 0;\n    int result = -2;\n"
                "    while (__ballot(result == -2) != 0ULL) {\n        if (result == -2) {\n"
                "            const u64 t = __hip_atomic_load(&pa_lt_tag[i], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);\n"
                "            bool advance = false;\n"
@@ -498,6 +502,49 @@ KernelInfo generate(const Spec& s, const std::vector<ChannelLayout>& layout, int
     }
     else {
         src << "struct PaAcc { PaGtView tv; PaGtCtr gt; };\n";
+    }
+    if (variant == V_GT || variant == V_LDSH) {
+        // accumulation of one row into the workgroup's LDS table / the HBM table
+        src << "__device__ __forceinline__ void pa_acc(const PaFusedArgs& a, PaAcc& acc, const bool sel, const i32 row, const u64 (&key)[PA_KW]";
+        for (int w = 0; w < k.nw; w++) src << ", const bool u" << w << ", const " << (words[w].kind == W_SUMF ? "double" : (words[w].kind == W_MAXU ? "u64" : "i64")) << " x" << w;
+        src << ")\n{\n";
+        src << "if (sel) {\n  const u32 h = pa_key_hash(key, PA_KW);\n";
+        if (variant == V_LDSH) {
+            src << "  const int ls = pa_lt_upsert(h, key);\n  if (ls >= 0) {\n";
+            for (int w = 0; w < k.nw; w++) {
+                std::string idx = "pa_lt_acc[ls * PA_NW + " + std::to_string(w) + "]";
+                if (words[w].kind == W_SUMF) {
+                    src << "    if (u" << w << ") __hip_atomic_fetch_add((double*)&" << idx << ", x" << w << ", __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);\n";
+                }
+                else if (words[w].kind == W_SUMI) {
+                    src << "    if (u" << w << ") { i64 o = (i64)__hip_atomic_fetch_add(&" << idx << ", (u64)x" << w
+                        << ", __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); i64 r; if (__builtin_add_overflow(o, x" << w
+                        << ", &r)) pa_raise(a.err, PA_DEV_ERR_OUT_OF_RANGE); }\n";
+                }
+                else if (words[w].kind == W_MAXU) {
+                    src << "    if (u" << w << ") __hip_atomic_fetch_max(&" << idx << ", x" << w << ", __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);\n";
+                }
+                else {
+                    src << "    if (u" << w << ") __hip_atomic_fetch_add(&" << idx << ", " << ("(u64)x" + std::to_string(w))
+                        << ", __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);\n";
+                }
+            }
+            src << "  } else {\n  acc.fell++;\n";
+        }
+        src << "  int g = pa_gt_upsert<PA_KW>(acc.tv.tag, acc.tv.keys, a.gt_mask, h, key, acc.gt, a.gt_max_fill, a.err);\n";
+        src << "  if (g >= 0) {\n    const u64 cap = (u64)a.gt_mask + 1ULL;\n";
+        for (int w = 0; w < k.nw; w++) {
+            std::string idx = std::to_string(w) + "ULL * cap + (u64)g";
+            if (words[w].kind == W_SUMF) src << "    if (u" << w << ") pa_gt_add_f64(acc.tv.words, " << idx << ", x" << w << ");\n";
+            else if (words[w].kind == W_SUMI) src << "    if (u" << w << ") pa_gt_add_i64_exact(acc.tv.words, " << idx << ", x" << w << ", a.err);\n";
+            else if (words[w].kind == W_MAXU) src << "    if (u" << w << ") pa_gt_max_u64(acc.tv.words, " << idx << ", x" << w << ");\n";
+            else src << "    if (u" << w << ") pa_gt_add_u64(acc.tv.words, " << idx << ", (u64)x" << w << ");\n";
+        }
+        // no room for this row's group: spill the row; the host rehashes and replays the spilled rows
+        src << "  } else {\n    a.spill_rows[atomicAdd(a.spill_count, 1u)] = row;\n  }\n";
+        if (variant == V_LDSH) src << "  }\n";
+        src << "}\n";
+        src << "}\n\n";
     }
     src << "__device__ __forceinline__ void pa_row(const PaFusedArgs& a, PaAcc& acc, const bool live, const i32 row" << row_params(ri, layout) << ")\n{\n";
     src << body.str();
@@ -560,42 +607,9 @@ KernelInfo generate(const Spec& s, const std::vector<ChannelLayout>& layout, int
         src << "  }\n}\n";
     }
     else {
-        src << "if (sel) {\n  const u32 h = pa_key_hash(key, PA_KW);\n";
-        if (variant == V_LDSH) {
-            src << "  const int ls = pa_lt_upsert(h, key);\n  if (ls >= 0) {\n";
-            for (int w = 0; w < k.nw; w++) {
-                std::string idx = "pa_lt_acc[ls * PA_NW + " + std::to_string(w) + "]";
-                if (words[w].kind == W_SUMF) {
-                    src << "    if (u" << w << ") __hip_atomic_fetch_add((double*)&" << idx << ", x" << w << ", __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);\n";
-                }
-                else if (words[w].kind == W_SUMI) {
-                    src << "    if (u" << w << ") { i64 o = (i64)__hip_atomic_fetch_add(&" << idx << ", (u64)x" << w
-                        << ", __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); i64 r; if (__builtin_add_overflow(o, x" << w
-                        << ", &r)) pa_raise(a.err, PA_DEV_ERR_OUT_OF_RANGE); }\n";
-                }
-                else if (words[w].kind == W_MAXU) {
-                    src << "    if (u" << w << ") __hip_atomic_fetch_max(&" << idx << ", x" << w << ", __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);\n";
-                }
-                else {
-                    src << "    if (u" << w << ") __hip_atomic_fetch_add(&" << idx << ", " << (words[w].val == "1" ? std::string("1ULL") : "(u64)x" + std::to_string(w))
-                        << ", __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);\n";
-                }
-            }
-            src << "  } else {\n  acc.fell++;\n";
-        }
-        src << "  int g = pa_gt_upsert<PA_KW>(acc.tv.tag, acc.tv.keys, a.gt_mask, h, key, acc.gt, a.gt_max_fill, a.err);\n";
-        src << "  if (g >= 0) {\n    const u64 cap = (u64)a.gt_mask + 1ULL;\n";
-        for (int w = 0; w < k.nw; w++) {
-            std::string idx = std::to_string(w) + "ULL * cap + (u64)g";
-            if (words[w].kind == W_SUMF) src << "    if (u" << w << ") pa_gt_add_f64(acc.tv.words, " << idx << ", x" << w << ");\n";
-            else if (words[w].kind == W_SUMI) src << "    if (u" << w << ") pa_gt_add_i64_exact(acc.tv.words, " << idx << ", x" << w << ", a.err);\n";
-            else if (words[w].kind == W_MAXU) src << "    if (u" << w << ") pa_gt_max_u64(acc.tv.words, " << idx << ", x" << w << ");\n";
-            else src << "    if (u" << w << ") pa_gt_add_u64(acc.tv.words, " << idx << ", (u64)x" << w << ");\n";
-        }
-        // no room for this row's group: spill the row; the host rehashes and replays the spilled rows
-        src << "  } else {\n    a.spill_rows[atomicAdd(a.spill_count, 1u)] = row;\n  }\n";
-        if (variant == V_LDSH) src << "  }\n";
-        src << "}\n";
+        src << "pa_acc(a, acc, sel, row, key";
+        for (int w = 0; w < k.nw; w++) src << ", u" << w << ", x" << w;
+        src << ");\n";
     }
     src << "}\n\n";
 
@@ -814,10 +828,11 @@ public:
             }
             sig += layout[c].nullable ? 'n' : '-';
         }
+        int64_t start_row = 0;
         for (;;) {
             int partitions = 0;
             if (mode_ == V_GT && partitioned_wanted(sig, layout, &partitions)) {
-                run_page_partitioned(sig, layout, dp, vec, partitions);
+                run_page_partitioned(sig, layout, dp, vec, partitions, start_row);
                 break;
             }
             const Compiled* compiled = nullptr;
@@ -832,7 +847,14 @@ public:
                 continue;
             }
             const Compiled& ck = *compiled;
-            if (run_page(ck, dp, vec)) break;
+            resume_from_ = -1;
+            if (run_page(ck, dp, vec, nullptr, start_row)) break;
+            if (resume_from_ >= 0) {
+                // the LDS-table variant found, on the first rows of the page, that most rows miss its table: the rows from
+                // resume_from_ on go to the tier mode_ now names (hash-partitioned or plain HBM table)
+                start_row = resume_from_;
+                continue;
+            }
             // the page held more groups than the wave's register table: redo it (and every later page) with the
             // workgroup-level LDS table, which itself hands rows it has no room for to the HBM table
             mode_ = V_LDSH;
@@ -1015,10 +1037,10 @@ private:
     bool partitioned_wanted(const std::string& sig, const std::vector<ChannelLayout>& layout, int* partitions)
     {
         if (!gt_probed_ || getenv("PRESTO_AMD_NO_PARTITIONED")) return false;
+        // measured (64 M rows, 16 B/row, uniform keys; steady state per page): 1 K groups 9 -> 26 G rows/s, 8 K 6 -> 18 G,
+        // 100 K 8 -> 11.6 G; beyond ~128 K groups a workgroup's slice holds more groups than its table
         const uint64_t g = groups_upper_;
-        // measured (64 M rows, 16 B/row): 1 K groups 9 -> 20 G rows/s, 4 K 6 -> 14 G; from ~20 K groups on the rows of one partition
-        // are spread over so many cache lines of the page that gathering them costs more than the HBM atomics it saves
-        if (g < 256 || g > 8192) return false;
+        if (g < 256 || g > (1ULL << 17)) return false;
         const Compiled* ldsh = nullptr;
         try {
             ldsh = &kernel_for(sig, layout, V_LDSH);
@@ -1034,13 +1056,17 @@ private:
         return true;
     }
 
-    void run_page_partitioned(const std::string& sig, const std::vector<ChannelLayout>& layout, const DevPage& dp, bool vec, int partitions)
+    void run_page_partitioned(const std::string& sig, const std::vector<ChannelLayout>& layout, const DevPage& dp, bool vec, int partitions,
+                              int64_t start_row)
     {
         hipStream_t s = stream_.get();
+        // (A variant that also wrote every row's packed key / input words, put them in partition order and let the kernel read
+        // them contiguously was measured slower at every cardinality -- 8 K groups 14.8 vs 17.9 G rows/s, 100 K 10.5 vs 11.6 --
+        // than letting the LDS-table kernel gather the page rows of its slice, and was removed.)
         const Compiled& hk = kernel_for(sig, layout, V_HASH);
         const Compiled& lk = kernel_for(sig, layout, V_LDSH);
         const int64_t chunk = (int64_t)1 << 26;
-        for (int64_t offset = 0; offset < dp.n; offset += chunk) {
+        for (int64_t offset = start_row; offset < dp.n; offset += chunk) {
             const int64_t n = std::min(chunk, dp.n - offset);
             FusedArgs a;
             memset(&a, 0, sizeof a);
@@ -1073,7 +1099,7 @@ private:
     }
 
     // returns false when the LDS variant overflowed and the page must be redone with the HBM table
-    bool run_page(const Compiled& ck, const DevPage& dp, bool vec, const RowList* list = nullptr)
+    bool run_page(const Compiled& ck, const DevPage& dp, bool vec, const RowList* list = nullptr, int64_t start_row = 0)
     {
         hipStream_t s = stream_.get();
         const KernelInfo& ki = ck.info;
@@ -1089,7 +1115,7 @@ private:
         a.err = ctl_;
         a.gt_count = ctl_ + 1;
         a.overflow_rows = reinterpret_cast<uint64_t*>(ctl_ + 2);
-        int64_t offset = list ? list->first_row : 0;
+        int64_t offset = list ? list->first_row : start_row;
         const int64_t total = list ? list->first_row + list->chunk_rows : dp.n;
         // the HBM-table variant bounds the groups one launch can add so that the table can be sized first
         const int64_t chunk = (ki.variant == V_GT || ki.variant == V_LDSH) ? (int64_t)1 << 26 : total;
@@ -1102,7 +1128,12 @@ private:
             if ((ki.variant == V_GT || ki.variant == V_LDSH) && !gt_probed_ && !list) n = std::min<int64_t>(n, (int64_t)1 << 22);
             bool use_tail = false;
             if (ki.variant == V_LDS) {
-                if (offset < lds_head) n = lds_head - offset;
+                if (offset < lds_head) {
+                    n = lds_head - offset;
+                    // nothing is known about the cardinality yet: a short first launch decides whether the register-table
+                    // variant fits, instead of a whole wasted pass over a large page
+                    if (!lds_probed_ && n > ((int64_t)1 << 22)) n = (int64_t)1 << 20;
+                }
                 else use_tail = true;
             }
             if (offset > 0) {
@@ -1223,6 +1254,7 @@ private:
                 raise_if(h_ctl_[0]);
                 groups_upper_ = (uint64_t)h_ctl_[1];  // groups merged so far (the in-flight merges are bounded above)
                 lds_page_++;
+                lds_probed_ = true;
             }
             else {
                 // replay loop: grow the table until every row of the launch found room for its group
@@ -1238,7 +1270,10 @@ private:
                         uint64_t fell;
                         memcpy(&fell, h_ctl_ + 2, 8);
                         if (fell != 0) PA_HIP(hipMemsetAsync(ctl_ + 2, 0, 8, s));
-                        if (fell > (uint64_t)n / 4) mode_ = V_GT;
+                        if (fell > (uint64_t)n / 4) {
+                            mode_ = V_GT;
+                            if (!list && spilled == 0 && offset + n < total) resume_from_ = offset + n;
+                        }
                     }
                     if (spilled == 0) break;
                     PA_HIP(hipMemsetAsync(ctl_ + 6, 0, 4, s));
@@ -1264,6 +1299,7 @@ private:
                 }
             }
             offset += n;
+            if (resume_from_ >= 0) return false;  // the rest of the page goes to another tier (see add_input)
         }
         return true;
     }
@@ -1301,7 +1337,8 @@ private:
     PinnedBuf h_rep_;
     uint32_t gt_rep_ = 1;
     uint64_t groups_sum_ = 0;
-    bool gt_probed_ = false;
+    bool gt_probed_ = false, lds_probed_ = false;
+    int64_t resume_from_ = -1;
     const int32_t* kinds_dev_ = nullptr;
     hipStream_t merge_stream_ = nullptr;
     hipEvent_t ev_main_[2] = {nullptr, nullptr}, ev_merge_[2] = {nullptr, nullptr};

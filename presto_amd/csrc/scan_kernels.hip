@@ -202,24 +202,45 @@ __global__ __launch_bounds__(256) void k_partition_count(const i32* __restrict__
 __global__ __launch_bounds__(256) void k_partition_scatter(const i32* __restrict__ part, i64 n, i32 P, i64 tiles,
                                                            const i32* __restrict__ offsets, i32* __restrict__ out_positions)
 {
-    // rank of a row inside its (tile, partition) = rows of the same partition before it in the tile,
-    // obtained partition by partition with a workgroup scan; P is small (number of GPUs / drivers)
-    i64 base = (i64)blockIdx.x * kScanTile + (i64)threadIdx.x * kScanItems;
-    i32 mine[kScanItems];
-#pragma unroll
-    for (int i = 0; i < kScanItems; i++) mine[i] = (base + i < n) ? part[base + i] : -1;
-    for (i32 p = 0; p < P; p++) {
-        i32 c = 0;
-#pragma unroll
-        for (int i = 0; i < kScanItems; i++) c += (mine[i] == p) ? 1 : 0;
-        i32 total;
-        i32 ex = block_exclusive_scan(c, &total);
-        if (total == 0) continue;
-        i32 dst = offsets[(i64)p * tiles + blockIdx.x] + ex;
-#pragma unroll
-        for (int i = 0; i < kScanItems; i++) {
-            if (mine[i] == p) out_positions[dst++] = (i32)(base + i);
+    // Stable rank of a row inside its (tile, partition) = rows of the same partition before it in the tile.  Cost independent
+    // of P (the radix passes of OrderBy and the hash-partitioned aggregation use P = 256 .. 1024): the tile is walked in four
+    // slots of 256 consecutive rows; inside a slot a lane finds the lanes of its wave with the same partition by matching the
+    // id bit by bit (ballots), the first of them publishes the wave's count for that partition in LDS, and the counts of the
+    // earlier waves plus the running total of the earlier slots give the rank.
+    __shared__ i32 running[1024];      // rows of partition p in the slots done so far
+    __shared__ i32 wave_count[4][1024];
+    for (int p = threadIdx.x; p < P; p += 256) {
+        running[p] = 0;
+        wave_count[0][p] = wave_count[1][p] = wave_count[2][p] = wave_count[3][p] = 0;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const i64 tile0 = (i64)blockIdx.x * kScanTile;
+    for (int slot = 0; slot < kScanItems; slot++) {
+        const i64 row = tile0 + (i64)slot * 256 + threadIdx.x;
+        const bool live = row < n;
+        const i32 p = live ? part[row] : -1;
+        // lanes of this wave with the same partition id
+        u64 peers = __ballot(live);
+        for (int bit = 0; bit < 10; bit++) {
+            const u64 b = __ballot(live && ((p >> bit) & 1));
+            peers &= ((p >> bit) & 1) ? b : ~b;
         }
+        const int before = __popcll(peers & ((1ULL << lane) - 1ULL));
+        const bool leader = live && before == 0;
+        if (leader) wave_count[wave][p] = (i32)__popcll(peers);
+        __syncthreads();
+        if (live) {
+            i32 rank = running[p] + before;
+            for (int w = 0; w < wave; w++) rank += wave_count[w][p];
+            out_positions[offsets[(i64)p * tiles + blockIdx.x] + rank] = (i32)row;
+        }
+        __syncthreads();
+        if (leader) {
+            atomicAdd(&running[p], wave_count[wave][p]);
+            wave_count[wave][p] = 0;
+        }
+        __syncthreads();
     }
 }
 
