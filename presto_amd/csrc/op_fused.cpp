@@ -31,6 +31,7 @@
 #include "rowgen.hpp"
 #include "scan_kernels.hpp"
 #include "static_kernels.hpp"
+#include "intern_kernels.hpp"
 
 namespace pa {
 
@@ -110,6 +111,9 @@ struct Spec {
     int output_mem = PA_MEM_HOST;
     std::vector<bool> used_channel;
     std::vector<int> short_bound;  // per channel: > 0 when the channel is a short VARCHAR group key (packed bytes passed as cs<c>)
+    // per channel: VARCHAR group key of unknown or long (> 15 bytes) bound, replaced by its interned id before the kernels
+    // see the page (intern_kernels.hpp); in_types / the projection's type say INTEGER for such a channel
+    std::vector<bool> interned;
 };
 
 struct KernelInfo {
@@ -198,15 +202,42 @@ Spec make_spec(const pa_fused_aggregation_desc* d)
         s.used_channel[c] = true;
     }
     s.short_bound.assign(s.n_in, 0);
+    s.interned.assign(s.n_in, false);
     for (int j : s.group_proj) {
         const OwnedExpr& pe = s.proj[j];
         if (pe.is_input_ref() && pe.root_type() == PA_VARCHAR) {
             int c = pe.node(pe.root).channel;
             if (s.in_params[c] >= 1 && s.in_params[c] <= 7) s.short_bound[c] = s.in_params[c];
+            if (s.in_params[c] >= 1 && s.in_params[c] <= 15) continue;  // fits the packed key: bytes in the key words
+            // unknown or long bound: the key is compared through its interned id -- possible when nothing but the grouping
+            // (and count(), which only looks at the NULL flag) reads the channel
+            bool only_key = !(s.has_filter && [&] { std::set<int32_t> f; s.filter.collect_channels(&f); return f.count(c) != 0; }());
+            for (size_t q = 0; q < s.proj.size() && only_key; q++) {
+                std::set<int32_t> ch;
+                s.proj[q].collect_channels(&ch);
+                if (!ch.count(c)) continue;
+                only_key = s.proj[q].is_input_ref();
+                for (const pa_aggregate& a : s.aggs) {
+                    if (a.mask_channel == (int32_t)q) only_key = false;
+                    if (a.input_channel == (int32_t)q && a.fn != PA_AGG_COUNT && a.fn != PA_AGG_COUNT_STAR) only_key = false;
+                    if (s.step == PA_STEP_FINAL && (a.input_channel == (int32_t)q || a.input_channel + 1 == (int32_t)q)) only_key = false;
+                }
+            }
+            if (only_key) {
+                s.interned[c] = true;
+                continue;
+            }
             // a declared bound the packed key cannot hold is refused now, so that the planner keeps the Java operator; for an
             // undeclared bound (0) the operator is optimistic: a key longer than 15 bytes fails the query at run time
-            // (offload VARCHAR group keys only for VARCHAR(n), n <= 15)
-            PA_REQUIRE(s.in_params[c] <= 15, PA_ERR_NOT_SUPPORTED, "VARCHAR group keys longer than 15 bytes are not on the device path");
+            PA_REQUIRE(s.in_params[c] <= 15, PA_ERR_NOT_SUPPORTED,
+                       "VARCHAR group keys longer than 15 bytes that other expressions read are not on the device path");
+        }
+    }
+    for (int c = 0; c < s.n_in; c++) {
+        if (!s.interned[c]) continue;
+        s.in_types[c] = PA_INTEGER;
+        for (OwnedExpr& pe : s.proj) {
+            if (pe.is_input_ref() && pe.node(pe.root).channel == c) pe.nodes[pe.root].type = PA_INTEGER;
         }
     }
     return s;
@@ -814,6 +845,7 @@ public:
         if (page->position_count == 0) return;
         hipStream_t s = stream_.get();
         DevPage dp = stager_.stage(page, &spec_.used_channel, s);
+        intern_keys(dp, s);
         // layout signature of this page
         std::vector<ChannelLayout> layout(spec_.n_in);
         std::string sig;
@@ -869,6 +901,7 @@ public:
         if (!finishing_ || output_done_) return false;
         output_done_ = true;
         build_output();
+        if (grouped_ && out_rows_ > 0) decode_interned_keys();
         if (!grouped_ || out_rows_ > 0) {
             publish_output(out_cols_, out_rows_, spec_.output_mem, stream_.get(), out, out_storage_);
             return true;
@@ -1318,6 +1351,16 @@ private:
 
     void build_output();
     bool emit_on_device(const KernelInfo& ki, int64_t groups);
+    void intern_keys(DevPage& dp, hipStream_t s);
+    void decode_interned_keys();
+    // channel of group key gi when that channel is interned, else -1
+    int interned_channel(int gi) const
+    {
+        const OwnedExpr& pe = spec_.proj[spec_.group_proj[gi]];
+        if (!pe.is_input_ref()) return -1;
+        const int c = pe.node(pe.root).channel;
+        return spec_.interned[c] ? c : -1;
+    }
 
     Spec spec_;
     Stream stream_;
@@ -1349,7 +1392,61 @@ private:
     std::vector<OutColumn> out_cols_;
     std::vector<pa_column> out_storage_;
     int32_t out_rows_ = 0;
+    std::vector<std::unique_ptr<StringInterner>> interners_;  // per input channel, for Spec::interned channels
 };
+
+// VARCHAR group keys without a short bound: the page's strings become ids of the channel's dictionary, and the kernels
+// group by the id column (equal strings <=> equal ids, so the grouping is MultiChannelGroupByHash's, exactly).
+void FusedAggregationOperator::intern_keys(DevPage& dp, hipStream_t s)
+{
+    for (int c = 0; c < spec_.n_in; c++) {
+        if (!spec_.interned[c]) continue;
+        DevColumn& col = dp.cols[c];
+        PA_REQUIRE(col.type == PA_VARCHAR && col.varwidth && col.offsets != nullptr, PA_ERR_INVALID_ARGUMENT,
+                   "page block type does not match the declared input type");
+        if (interners_.empty()) interners_.resize(spec_.n_in);
+        if (!interners_[c]) interners_[c] = std::make_unique<StringInterner>();
+        const int32_t* ids = interners_[c]->intern(col.values, col.offsets, col.nulls, dp.n, s);
+        col.type = PA_INTEGER;
+        col.varwidth = false;
+        col.values = ids;
+        col.offsets = nullptr;
+    }
+}
+
+// The id key columns of the assembled output back to VariableWidthBlocks.
+void FusedAggregationOperator::decode_interned_keys()
+{
+    hipStream_t s = stream_.get();
+    for (int gi = 0; gi < (int)spec_.group_proj.size(); gi++) {
+        const int c = interned_channel(gi);
+        if (c < 0) continue;
+        OutColumn& oc = out_cols_[gi];
+        const int64_t n = out_rows_;
+        if (oc.host_ready && spec_.output_mem != PA_MEM_DEVICE) {  // assembled on the host and not uploaded yet
+            oc.values.ensure((size_t)std::max<int64_t>(n, 1) * 4);
+            if (n) PA_HIP(hipMemcpyAsync(oc.values.ptr(), oc.h_values.ptr(), (size_t)n * 4, hipMemcpyHostToDevice, s));
+            if (oc.has_nulls) {
+                oc.nulls.ensure((size_t)std::max<int64_t>(n, 1));
+                if (n) PA_HIP(hipMemcpyAsync(oc.nulls.ptr(), oc.h_nulls.ptr(), (size_t)n, hipMemcpyHostToDevice, s));
+            }
+        }
+        DevBuf values, offsets;
+        if (n == 0 || interners_.empty() || !interners_[c]) {  // no page ever arrived
+            PA_HIP(hipMemsetAsync(offsets.ensure(4), 0, 4, s));
+            values.ensure(1);
+        }
+        else {
+            interners_[c]->decode(oc.values.as<int32_t>(), oc.has_nulls ? oc.nulls.as<uint8_t>() : nullptr, n, &values, &offsets, s);
+        }
+        PA_HIP(hipStreamSynchronize(s));  // the id column goes back to the pool
+        oc.values = std::move(values);
+        oc.offsets = std::move(offsets);
+        oc.type = PA_VARCHAR;
+        oc.varwidth = true;
+        oc.host_ready = false;
+    }
+}
 
 // Large grouped results (Q3: millions of groups) never visit the host: k_gt_emit compacts the table and writes the output
 // blocks in one pass.  Small results and VARCHAR keys take the host assembly of build_output below.
@@ -1384,6 +1481,8 @@ bool FusedAggregationOperator::emit_on_device(const KernelInfo& ki, int64_t grou
         c->bits = kp.bits;
         c->null_word = kp.null_word;
         c->null_shift = kp.null_shift;
+        const int ic = interned_channel(gi);  // the key's share of $hashvalue is the hash of the string, not of its id
+        c->dict_hash = (ic >= 0 && !interners_.empty() && interners_[ic]) ? interners_[ic]->hashes() : nullptr;
         nullable.push_back(kp.null_word >= 0);
     }
     if (has_hash) {
@@ -1542,6 +1641,15 @@ void FusedAggregationOperator::build_output()
     for (int gi = 0; gi < nkeys; gi++, col++) {
         const KeyPart& kp = ki.keys[gi];
         OutColumn& oc = out_cols_[col];
+        // interned key: the id column is assembled here, decode_interned_keys turns it into strings; the string hashes
+        // come from the dictionary
+        std::vector<uint64_t> dict_hash;
+        const int ic = interned_channel(gi);
+        if (ic >= 0 && has_hash && groups > 0 && !interners_.empty() && interners_[ic] && interners_[ic]->size()) {
+            dict_hash.resize(interners_[ic]->size());
+            PA_HIP(hipMemcpyAsync(dict_hash.data(), interners_[ic]->hashes(), dict_hash.size() * 8, hipMemcpyDeviceToHost, s));
+            PA_HIP(hipStreamSynchronize(s));
+        }
         oc.type = kp.type;
         oc.varwidth = kp.type == PA_VARCHAR;
         auto& data = host_cols[col];
@@ -1571,7 +1679,7 @@ void FusedAggregationOperator::build_output()
                 case PA_DATE: {
                     int32_t v = is_null ? 0 : (int32_t)(uint32_t)w0;
                     data.insert(data.end(), (uint8_t*)&v, (uint8_t*)&v + 4);
-                    if (!is_null) h = host_hash_bigint((int64_t)v);
+                    if (!is_null) h = (ic >= 0 && (size_t)(uint32_t)v < dict_hash.size()) ? (int64_t)dict_hash[(uint32_t)v] : host_hash_bigint((int64_t)v);
                     break;
                 }
                 case PA_BOOLEAN: {

@@ -370,7 +370,10 @@ __device__ __forceinline__ void gt_emit_slot(const GtEmitArgs& a, u64 i, u64 g)
                     switch (col.type) {
                         case PA_BIGINT: bits = w0; h = pa_hash_bigint((i64)w0); break;
                         case PA_INTEGER:
-                        case PA_DATE: bits = (u64)(u32)w0; h = pa_hash_bigint((i64)(i32)(u32)w0); break;
+                        case PA_DATE:
+                            bits = (u64)(u32)w0;
+                            h = col.dict_hash ? (i64)col.dict_hash[(u32)w0] : pa_hash_bigint((i64)(i32)(u32)w0);
+                            break;
                         case PA_BOOLEAN: bits = w0 != 0 ? 1ULL : 0ULL; h = (i64)pa_xxh64_long(bits); break;
                         default: bits = w0; h = pa_hash_bigint((i64)w0); break;  // DOUBLE: canonical bits
                     }

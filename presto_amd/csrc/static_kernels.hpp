@@ -36,6 +36,7 @@ struct GtEmitCol {
     int32_t width;               // bytes per output element
     void* values;
     uint8_t* nulls;              // may be null when the column cannot hold NULLs
+    const uint64_t* dict_hash;   // KEY of an interned VARCHAR channel: per id the hash of the string ($hashvalue), else null
 };
 constexpr int GT_EMIT_MAX_COLS = 32;
 struct GtEmitArgs {

@@ -74,6 +74,38 @@ if "agg" in which:
         print("HashAggregation %8d groups: %.3g rows/s (%.1f GB/s of the 16 B/row inputs), %d groups out; wall %.2f ms, fused kernels %.2f ms in %d launches"
               % (groups, rows / dt, rows * 16 / dt / 1e9, run(), dt * 1e3, run.kernel_ms, run.launches))
 
+if "vagg" in which:
+    # VARCHAR(25) keys ("Customer#%09d" + padding, c_name / s_name shape): interned on the device, then grouped by id
+    rows, width = 1 << 25, 24
+    g = torch.Generator(device="cuda").manual_seed(3)
+    vals = torch.rand(rows, dtype=torch.float64, device="cuda", generator=g)
+    for groups in [int(x) for x in os.environ.get("AGG_GROUPS", "4,1000,100000,3000000").split(",")]:
+        ids = torch.randint(0, groups, (rows,), dtype=torch.int64, device="cuda", generator=g)
+        digits = torch.stack([(ids // 10 ** k) % 10 + 48 for k in range(8, -1, -1)], dim=1).to(torch.uint8)
+        text = torch.cat([torch.tensor(list(b"Customer#"), dtype=torch.uint8, device="cuda").expand(rows, 9), digits,
+                          torch.full((rows, width - 18), 120, dtype=torch.uint8, device="cuda")], dim=1).contiguous()
+        offs = (torch.arange(rows + 1, dtype=torch.int64, device="cuda") * width).to(torch.int32)
+        chunk = 1 << 23
+        sub = []
+        for i in range(0, rows, chunk):
+            o = offs[i:i + chunk + 1].contiguous()
+            kb = Block(abi.VARCHAR, abi.VARWIDTH, chunk, values=DeviceBuffer(text.data_ptr(), text.numel(), text), offsets=DeviceBuffer(o.data_ptr(), o.numel() * 4, o))
+            sub.append(Page([kb, Block(abi.DOUBLE, abi.FLAT, chunk, values=DeviceBuffer(vals.data_ptr() + 8 * i, 8 * chunk, vals))], chunk, abi.MEM_DEVICE))
+        def run():
+            op = HashAggregationOperator([abi.VARCHAR, abi.DOUBLE], [0], [(abi.AGG_SUM, 1, abi.DOUBLE), (abi.AGG_COUNT_STAR, -1, None)],
+                                         expected_groups=groups, output_mem=abi.MEM_DEVICE, type_params=[25, 0])
+            for p in sub:
+                op.addInput(p)
+            op.finish()
+            out = op.getOutput()
+            n = out.position_count
+            run.kernel_ms, run.launches = op.kernelTime()
+            op.close()
+            return n
+        dt = timeit(run, reps=3)
+        print("HashAggregation VARCHAR(25) key %8d groups: %.3g rows/s (%.1f GB/s of the 36 B/row inputs), %d groups out; wall %.2f ms, fused kernels %.2f ms"
+              % (groups, rows / dt, rows * 36 / dt / 1e9, run(), dt * 1e3, run.kernel_ms))
+
 if "join" in which:
     g = torch.Generator(device="cuda").manual_seed(2)
     for nb, npr in ((1 << 20, 1 << 26), (15_000_000, 1 << 26)):

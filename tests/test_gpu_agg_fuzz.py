@@ -1,5 +1,5 @@
 """Randomised group-by shapes against the oracle: 1-3 key columns drawn from every key type (nullable BIGINT, INTEGER, DATE,
-nullable BOOLEAN, DOUBLE with -0.0 / NaN, short VARCHAR with a declared length bound, longer VARCHAR), random aggregates
+nullable BOOLEAN, DOUBLE with -0.0 / NaN, short VARCHAR with a declared length bound, longer VARCHAR, interned text), random aggregates
 (count(*), count, sum, avg, min, max; masks; nullable inputs), cardinalities from a handful to tens of thousands -- so the
 key packing (bit fields, two-word strings, NULL flags) and every tier of the aggregation see shapes nobody wrote by hand."""
 import numpy as np
@@ -29,13 +29,17 @@ def key_column(rng, kind, n, card):
         return abi.DOUBLE, Block.double(pool[rng.integers(0, len(pool), n)], rng.random(n) < 0.02), 0
     if kind == "short":
         return abi.VARCHAR, Block.varchar([WORDS_SHORT[i] for i in rng.integers(0, len(WORDS_SHORT), n)]), 7
+    if kind == "text":  # longer than the packed key holds: interned on the device
+        ids = rng.integers(0, max(card, 1), n)
+        nulls = rng.random(n) < 0.02
+        return abi.VARCHAR, Block.varchar([None if z else b"Customer#%09d %s" % (i, b"y" * (i % 19)) for i, z in zip(ids, nulls)]), int(rng.choice([0, 64]))
     return abi.VARCHAR, Block.varchar([WORDS_LONG[i] for i in rng.integers(0, len(WORDS_LONG), n)]), 0
 
 
 @pytest.mark.parametrize("seed", list(range(24)))
 def test_random_group_by_shapes(gpu, oracle, seed):
     rng = np.random.default_rng(7000 + seed)
-    kinds = ["bigint", "integer", "date", "boolean", "double", "short", "long"]
+    kinds = ["bigint", "integer", "date", "boolean", "double", "short", "long", "text"]
     nkeys = int(rng.integers(1, 4))
     chosen = [kinds[i] for i in rng.choice(len(kinds), nkeys, replace=False)]
     card = int([3, 40, 700, 20000][seed % 4])

@@ -1,0 +1,152 @@
+"""VARCHAR group keys of any length (MultiChannelGroupByHash compares the bytes, …/MultiChannelGroupByHash.java:441-452).
+Keys whose declared bound fits 15 bytes travel inside the packed key words; every other VARCHAR key is interned on the
+device (string -> dense id, byte-exact) and grouped by id.  These tests drive the interned path through every tier of
+the aggregation, with NULLs, empty strings, strings that differ only in their last byte or only in length, PARTIAL /
+FINAL, the $hashvalue channel and device-resident output -- all against the oracle."""
+import numpy as np
+import pytest
+
+from presto_amd import abi
+from presto_amd.exchange import partial_layout
+from presto_amd.operators import FusedAggregationOperator, HashAggregationOperator, download_page, to_pages
+from presto_amd.page import Block, Page
+from presto_amd.expr import constant, field
+
+pytestmark = pytest.mark.gpu
+
+TRICKY = [b"", b"a", b"a\0", b"a\0\0", b"12345678", b"12345678\0", b"123456789", b"1234567812345678", b"1234567812345679",
+          b"1234567812345678x", b"Customer#000000001 special requests", b"Customer#000000001 special requestt",
+          b"Customer#000000001 special request", "zażółć gęślą jaźń".encode(), b"\xff" * 40, b"\xff" * 41, None]
+
+
+def long_keys(rng, n, card, null_share=0.01):
+    ids = rng.integers(0, card, n)
+    base = [("supplier#%09d--%s" % (i, "x" * (i % 23))).encode() for i in range(card)]
+    keys = [base[i] for i in ids]
+    for i in np.nonzero(rng.random(n) < null_share)[0]:
+        keys[i] = None
+    return keys
+
+
+def run_both(oracle, types, keys, aggs, pages, **kw):
+    op = HashAggregationOperator(types, keys, aggs, **kw)
+    got = [r for p in to_pages(op, pages) for r in p.to_rows()]
+    ref = oracle.HashAggregation(types, keys, aggs, hash_channel=kw.get("hash_channel", -1))
+    for p in pages:
+        ref.add_page(p)
+    return got, ref.build_result().to_rows()
+
+
+def assert_same(got, expected, nkeys=1):
+    assert len(got) == len(expected)
+    g = {r[:nkeys]: r for r in got}
+    e = {r[:nkeys]: r for r in expected}
+    assert len(g) == len(got) and set(g) == set(e)
+    for k, er in e.items():
+        for gv, ev in zip(g[k][nkeys:], er[nkeys:]):
+            if isinstance(ev, float):
+                assert gv == ev or abs(gv - ev) <= 1e-9 * max(abs(gv), abs(ev)), (k, g[k], er)  # DOUBLE sums: DESIGN tolerance
+            else:
+                assert gv == ev, (k, g[k], er)
+
+
+def test_tricky_strings_are_distinct_groups(gpu, oracle):
+    rng = np.random.default_rng(1)
+    n = 50000
+    pick = rng.integers(0, len(TRICKY), n)
+    page = Page([Block.varchar([TRICKY[i] for i in pick]), Block.bigint(rng.integers(0, 100, n))], n)
+    types = [abi.VARCHAR, abi.BIGINT]
+    aggs = [(abi.AGG_COUNT_STAR, -1, None), (abi.AGG_SUM, 1, abi.BIGINT), (abi.AGG_COUNT, 0, abi.VARCHAR)]
+    got, expected = run_both(oracle, types, [0], aggs, [page, page])
+    assert len(expected) == len(TRICKY)
+    assert_same(got, expected)
+
+
+@pytest.mark.parametrize("card,rows,pages", [(6, 30000, 2), (300, 100000, 2), (20000, 150000, 3), (400000, 500000, 2)])
+def test_long_keys_through_every_tier(gpu, oracle, card, rows, pages):
+    rng = np.random.default_rng(card)
+    plist = []
+    for _ in range(pages):
+        plist.append(Page([Block.varchar(long_keys(rng, rows, card)), Block.double(rng.random(rows), rng.random(rows) < 0.1),
+                           Block.bigint(rng.integers(-1000, 1000, rows))], rows))
+    types = [abi.VARCHAR, abi.DOUBLE, abi.BIGINT]
+    aggs = [(abi.AGG_COUNT_STAR, -1, None), (abi.AGG_SUM, 1, abi.DOUBLE), (abi.AGG_AVG, 2, abi.BIGINT), (abi.AGG_MIN, 2, abi.BIGINT),
+            (abi.AGG_COUNT, 0, abi.VARCHAR)]
+    got, expected = run_both(oracle, types, [0], aggs, plist, expected_groups=card)
+    assert_same(got, expected)
+
+
+@pytest.mark.parametrize("card", [50, 100000])
+def test_hash_channel_and_second_key(gpu, oracle, card):
+    """$hashvalue of an interned key is the hash of the string (VarcharType.hash = XxHash64 of the bytes), combined with
+    the other key's hash as InterpretedHashGenerator does."""
+    rng = np.random.default_rng(card + 5)
+    rows = 200000
+    plist = []
+    for _ in range(2):
+        p = Page([Block.varchar(long_keys(rng, rows, card)), Block.integer(rng.integers(0, 3, rows)), Block.bigint(rng.integers(0, 10, rows))], rows)
+        plist.append(Page(p.blocks + [Block.bigint(oracle.hash_page(p, [0, 1]))], rows))
+    types = [abi.VARCHAR, abi.INTEGER, abi.BIGINT, abi.BIGINT]
+    aggs = [(abi.AGG_SUM, 2, abi.BIGINT), (abi.AGG_COUNT_STAR, -1, None)]
+    got, expected = run_both(oracle, types, [0, 1], aggs, plist, hash_channel=3, expected_groups=card * 3)
+    assert_same(got, expected, nkeys=2)
+    for r in got[:2000]:
+        h = 0 if r[0] is None else oracle._s64(oracle.xxh64(r[0]))
+        assert r[2] == oracle.combine_hash(oracle.combine_hash(0, h), oracle.hash_integer(r[1]))
+
+
+@pytest.mark.parametrize("card", [40, 30000])
+def test_partial_final_with_long_keys(gpu, oracle, card):
+    rng = np.random.default_rng(card + 9)
+    rows = 120000
+    plist = [Page([Block.varchar(long_keys(rng, rows, card)), Block.double(rng.random(rows))], rows) for _ in range(3)]
+    types = [abi.VARCHAR, abi.DOUBLE]
+    aggs = [(abi.AGG_SUM, 1, abi.DOUBLE), (abi.AGG_AVG, 1, abi.DOUBLE), (abi.AGG_COUNT_STAR, -1, None), (abi.AGG_MAX, 1, abi.DOUBLE)]
+    ref = oracle.HashAggregation(types, [0], aggs)
+    for p in plist:
+        ref.add_page(p)
+    expected = ref.build_result().to_rows()
+    ptypes, faggs = partial_layout([abi.VARCHAR], aggs)
+    partial_pages = []
+    for p in plist:
+        partial_pages += to_pages(HashAggregationOperator(types, [0], aggs, step=abi.STEP_PARTIAL, expected_groups=card), [p])
+    assert all(p.blocks[0].type == abi.VARCHAR for p in partial_pages)
+    final = HashAggregationOperator(ptypes, [0], faggs, step=abi.STEP_FINAL, expected_groups=card)
+    got = [r for p in to_pages(final, partial_pages) for r in p.to_rows()]
+    assert_same(got, expected)
+
+
+def test_declared_long_bound_and_fused_filter(gpu, oracle):
+    """VARCHAR(40) keys behind a filter and projections on other channels (the fused ScanFilterAndProject -> HashAggregation);
+    a long key that the filter itself reads stays with the Java operators."""
+    rng = np.random.default_rng(77)
+    rows, card = 200000, 1500
+    page = Page([Block.varchar(long_keys(rng, rows, card, 0.0)), Block.double(rng.random(rows) * 10), Block.bigint(rng.integers(0, 50, rows))], rows)
+    types = [abi.VARCHAR, abi.DOUBLE, abi.BIGINT]
+    x, q = field(1, abi.DOUBLE), field(2, abi.BIGINT)
+    filt = q < constant(25, abi.BIGINT)
+    proj = [field(0, abi.VARCHAR), x * constant(2.0, abi.DOUBLE), q + 1]
+    aggs = [(abi.AGG_SUM, 1, abi.DOUBLE), (abi.AGG_SUM, 2, abi.BIGINT), (abi.AGG_COUNT_STAR, -1, None)]
+    op = FusedAggregationOperator(types, filt, proj, [0], aggs, type_params=[40, 0, 0])
+    got = [r for p in to_pages(op, [page]) for r in p.to_rows()]
+    fp = oracle.filter_project(page, filt, proj)
+    ref = oracle.HashAggregation([abi.VARCHAR, abi.DOUBLE, abi.BIGINT], [0], aggs)
+    ref.add_page(fp)
+    assert_same(got, ref.build_result().to_rows())
+    from presto_amd._lib import PrestoAmdError
+    with pytest.raises(PrestoAmdError) as e:
+        FusedAggregationOperator(types, field(0, abi.VARCHAR).eq(constant("supplier#000000001--x", abi.VARCHAR)), proj, [0], aggs, type_params=[40, 0, 0])
+    assert e.value.status == abi.ERR_NOT_SUPPORTED
+
+
+def test_device_resident_output(gpu, oracle):
+    rng = np.random.default_rng(3)
+    rows, card = 300000, 50000
+    page = Page([Block.varchar(long_keys(rng, rows, card)), Block.bigint(rng.integers(0, 9, rows))], rows)
+    types = [abi.VARCHAR, abi.BIGINT]
+    aggs = [(abi.AGG_SUM, 1, abi.BIGINT)]
+    op = HashAggregationOperator(types, [0], aggs, output_mem=abi.MEM_DEVICE, expected_groups=card)
+    got = [r for p in to_pages(op, [page]) for r in download_page(p).to_rows()]
+    ref = oracle.HashAggregation(types, [0], aggs)
+    ref.add_page(page)
+    assert_same(got, ref.build_result().to_rows())
