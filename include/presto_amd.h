@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PA_ABI_VERSION 3
+#define PA_ABI_VERSION 4
 
 /* ---- status codes (negative = error).  Mapped by the JNI shim onto TrinoException
  *      StandardErrorCode (trino-spi/.../StandardErrorCode.java). ---- */
@@ -289,6 +289,36 @@ typedef struct pa_order_by_desc {
     void* stream;
 } pa_order_by_desc;
 
+/* DynamicFilterSourceOperator.DynamicFilterSourceOperatorFactory (DynamicFilterSourceOperator.java:74-139): on the build
+ * side of a join; passes every page through unchanged (the output page IS the input page: same buffers, which the caller
+ * keeps alive until it has consumed the output) and collects per filter channel the distinct values (at most
+ * max_distinct_values per channel and max_filter_size_bytes over all channels), else the min / max of the orderable,
+ * non-floating-point channels while no more than min_max_collection_limit rows were seen, else nothing.  The size of a
+ * set is counted as its values' bytes; the reference counts TypedSet.getRetainedSizeInBytes(), a JVM-layout figure. */
+typedef struct pa_dynamic_filter_source_desc {
+    int32_t input_channel_count;
+    const int32_t* input_types;
+    int32_t filter_channel_count;
+    const int32_t* filter_channels;      /* DynamicFilterSourceOperator.Channel.index per dynamic filter */
+    int32_t max_distinct_values;
+    int32_t min_max_collection_limit;
+    int64_t max_filter_size_bytes;
+    void* stream;
+} pa_dynamic_filter_source_desc;
+
+/* One column's Domain of the TupleDomain handed to dynamicPredicateConsumer (nullAllowed is always false). */
+typedef enum pa_domain_kind {
+    PA_DOMAIN_ALL = 0,                   /* channel absent from the TupleDomain: unconstrained */
+    PA_DOMAIN_NONE = 1,                  /* Domain.none(type): no build value (all NULL / NaN, or no rows) */
+    PA_DOMAIN_VALUES = 2,                /* discrete set: value_count distinct non-NULL, non-NaN values, ascending */
+    PA_DOMAIN_RANGE = 3                  /* value_count = 2: [values[0], values[1]], both inclusive */
+} pa_domain_kind;
+typedef struct pa_domain {
+    int32_t kind;                        /* pa_domain_kind */
+    int32_t value_count;
+    pa_column values;                    /* host memory owned by the operator (valid until it is destroyed), no NULLs */
+} pa_domain;
+
 typedef struct pa_operator pa_operator;             /* opaque operator handle */
 typedef struct pa_lookup_source pa_lookup_source;   /* opaque: JoinBridge / LookupSourceFactory */
 
@@ -323,6 +353,11 @@ int32_t pa_hash_aggregation_create(const pa_hash_aggregation_desc* desc, pa_oper
 int32_t pa_fused_aggregation_create(const pa_fused_aggregation_desc* desc, pa_operator** out);
 int32_t pa_topn_create(const pa_topn_desc* desc, pa_operator** out);
 int32_t pa_order_by_create(const pa_order_by_desc* desc, pa_operator** out);
+int32_t pa_dynamic_filter_source_create(const pa_dynamic_filter_source_desc* desc, pa_operator** out);
+/* The dynamicPredicateConsumer call of a DynamicFilterSourceOperator: returns 0 while the consumer has not been called
+ * (it is called by finish(), or earlier when the operator gives up collecting), 1 once it has; then *is_all != 0 means
+ * TupleDomain.all(), else domains[i] (i < filter_channel_count <= domain_capacity) is filter channel i's Domain. */
+int32_t pa_dynamic_filter_poll(pa_operator* op, int32_t* is_all, pa_domain* domains, int32_t domain_capacity);
 int32_t pa_lookup_source_create(pa_lookup_source** out);
 int32_t pa_lookup_source_destroy(pa_lookup_source* ls);
 int32_t pa_hash_builder_create(const pa_hash_builder_desc* desc, pa_lookup_source* bridge, pa_operator** out);

@@ -320,6 +320,24 @@ inline std::unique_ptr<Operator> createTopNOperator(const std::vector<int32_t>& 
     return std::make_unique<Operator>(h);
 }
 
+// DynamicFilterSourceOperatorFactory: the returned operator passes pages through; poll the collected predicate with
+// pa_dynamic_filter_poll(op->handle(), ...) after finish()
+inline std::unique_ptr<Operator> createDynamicFilterSourceOperator(const std::vector<int32_t>& inputTypes, const std::vector<int32_t>& filterChannels,
+                                                                   int32_t maxDistinctValues, int64_t maxFilterSizeBytes, int32_t minMaxCollectionLimit)
+{
+    pa_dynamic_filter_source_desc d{};
+    d.input_channel_count = (int32_t)inputTypes.size();
+    d.input_types = inputTypes.data();
+    d.filter_channel_count = (int32_t)filterChannels.size();
+    d.filter_channels = filterChannels.data();
+    d.max_distinct_values = maxDistinctValues;
+    d.max_filter_size_bytes = maxFilterSizeBytes;
+    d.min_max_collection_limit = minMaxCollectionLimit;
+    pa_operator* h = nullptr;
+    check(pa_dynamic_filter_source_create(&d, &h));
+    return std::make_unique<Operator>(h);
+}
+
 // JoinBridge shared by the build operator and its probe operators (JoinBridgeManager / PartitionedLookupSourceFactory)
 class LookupSourceFactory {
 public:

@@ -501,6 +501,101 @@ def order_by(pages, output_channels, sort_channels, sort_orders):
     return [tuple(r[c] for c in output_channels) for r in topn(pages, None, sort_channels, sort_orders)]
 
 
+# ---- dynamic filter source -----------------------------------------------------------------------------------------
+class DynamicFilterSource:
+    """DynamicFilterSourceOperator (core/trino-main/src/main/java/io/trino/operator/DynamicFilterSourceOperator.java:164-418)
+    as a row-at-a-time restatement: TypedSet per channel -> min / max of the orderable non-floating channels -> give up.
+    `predicate` is what dynamicPredicateConsumer received (None while not called): "all", or one entry per channel:
+    ("all",) | ("none",) | ("values", ascending list) | ("range", low, high).  As in the device operator the size of a
+    value set is its values' bytes (VARCHAR: 8-byte padded + 4 B offsets); the reference's figure
+    (TypedSet.getRetainedSizeInBytes) depends on the JVM's object layout and has no portable restatement."""
+
+    def __init__(self, input_types, filter_channels, max_distinct_values, max_filter_size_bytes, min_max_collection_limit):
+        self.types = [input_types[c] for c in filter_channels]
+        self.channels = list(filter_channels)
+        self.max_distinct, self.max_bytes, self.limit = max_distinct_values, max_filter_size_bytes, min_max_collection_limit
+        # :183-203
+        self.min_max_channels = [i for i, t in enumerate(self.types) if min_max_collection_limit > 0 and t != abi.DOUBLE]
+        self.sets = [dict() for _ in self.types]  # canonical key -> first seen value (TypedSet keeps the first of equal values)
+        self.has_null = [False] * len(self.types)
+        self.min = [None] * len(self.types) if self.min_max_channels else None
+        self.max = [None] * len(self.types)
+        self.predicate = None
+        self.finished = False
+
+    @staticmethod
+    def _key(t, v):
+        if t == abi.DOUBLE:  # IS DISTINCT FROM: NaN equals NaN, -0.0 equals 0.0
+            return "nan" if v != v else (0.0 if v == 0.0 else v)
+        return v
+
+    def _update_min_max(self, i, values):  # updateMinMaxValues :303-347 (comparison operator of the type)
+        vals = [v for v in values if v is not None]
+        if not vals:
+            return
+        lo, hi = min(vals), max(vals)
+        self.min[i] = lo if self.min[i] is None else min(self.min[i], lo)
+        self.max[i] = hi if self.max[i] is None else max(self.max[i], hi)
+
+    def add_page(self, page):  # addInput :225-267; the page itself passes through
+        assert not self.finished
+        cols = [page.blocks[c].to_pylist() for c in self.channels]
+        if self.sets is None:
+            if self.min is None:
+                return page
+            self.limit -= page.position_count
+            if self.limit < 0:
+                self.predicate, self.min = "all", None  # handleMinMaxCollectionLimitExceeded
+                return page
+            for i in self.min_max_channels:
+                self._update_min_max(i, cols[i])
+            return page
+        self.limit -= page.position_count
+        size_bytes, most = 0, 0
+        for i, (t, col) in enumerate(zip(self.types, cols)):
+            for v in col:
+                if v is None:
+                    self.has_null[i] = True
+                else:
+                    self.sets[i].setdefault(self._key(t, v), v)
+            n = len(self.sets[i])
+            if t == abi.VARCHAR:
+                size_bytes += sum(-(-len(v) // 8) * 8 for v in self.sets[i]) + 4 * n
+            else:
+                size_bytes += n * {abi.BIGINT: 8, abi.DOUBLE: 8, abi.INTEGER: 4, abi.DATE: 4, abi.BOOLEAN: 1}[t]
+            most = max(most, n + (1 if self.has_null[i] else 0))
+        if most > self.max_distinct or size_bytes > self.max_bytes:  # handleTooLargePredicate :268-292
+            if not self.min_max_channels:
+                self.predicate = "all"
+            elif self.limit < 0:
+                self.predicate, self.min = "all", None
+            else:
+                for i in self.min_max_channels:
+                    self._update_min_max(i, list(self.sets[i].values()))
+            self.sets = None
+        return page
+
+    def finish(self):  # :358-401
+        if self.finished:
+            return
+        self.finished = True
+        if self.sets is None:
+            if self.min is None:
+                return
+            out = [("all",)] * len(self.types)
+            for i in self.min_max_channels:
+                out[i] = ("none",) if self.min[i] is None else ("range", self.min[i], self.max[i])
+            self.predicate = out
+            return
+        out = []
+        for t, values in zip(self.types, self.sets):  # convertToDomain :403-418: no NULL, no NaN
+            vals = [v for k, v in values.items() if k != "nan"]
+            if t == abi.DOUBLE:
+                vals = [0.0 if v == 0.0 else v for v in vals]  # the device keeps +0.0 for the {-0.0, 0.0} element (DESIGN)
+            out.append(("values", sorted(vals)) if vals else ("none",))
+        self.predicate = out
+
+
 # ---- page wire format -------------------------------------------------------------------------------------------------
 _ENCODING = {abi.BIGINT: (b"LONG_ARRAY", "<i8"), abi.DOUBLE: (b"LONG_ARRAY", "<f8"), abi.INTEGER: (b"INT_ARRAY", "<i4"), abi.DATE: (b"INT_ARRAY", "<i4"),
              abi.BOOLEAN: (b"BYTE_ARRAY", "u1"), abi.VARCHAR: (b"VARIABLE_WIDTH", None)}

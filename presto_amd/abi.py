@@ -5,7 +5,7 @@ test-only oracle binding (oracle/oracle.py), exactly as both C sides share the h
 """
 import ctypes as C
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 # pa_status
 OK = 0
@@ -162,6 +162,26 @@ class pa_order_by_desc(C.Structure):
         ("output_mem", C.c_int32),
         ("stream", C.c_void_p),
     ]
+
+
+class pa_dynamic_filter_source_desc(C.Structure):
+    _fields_ = [
+        ("input_channel_count", C.c_int32),
+        ("input_types", C.POINTER(C.c_int32)),
+        ("filter_channel_count", C.c_int32),
+        ("filter_channels", C.POINTER(C.c_int32)),
+        ("max_distinct_values", C.c_int32),
+        ("min_max_collection_limit", C.c_int32),
+        ("max_filter_size_bytes", C.c_int64),
+        ("stream", C.c_void_p),
+    ]
+
+
+DOMAIN_ALL, DOMAIN_NONE, DOMAIN_VALUES, DOMAIN_RANGE = 0, 1, 2, 3
+
+
+class pa_domain(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("value_count", C.c_int32), ("values", pa_column)]
 
 
 class pa_aggregation_desc(C.Structure):

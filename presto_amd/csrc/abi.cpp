@@ -314,6 +314,21 @@ int32_t pa_topn_create(const pa_topn_desc* desc, pa_operator** out)
         return PA_OK;
     });
 }
+int32_t pa_dynamic_filter_source_create(const pa_dynamic_filter_source_desc* desc, pa_operator** out)
+{
+    return guarded([&]() -> int32_t {
+        PA_REQUIRE(out != nullptr, PA_ERR_INVALID_ARGUMENT, "null argument");
+        *out = make_dynamic_filter_source(desc);
+        return PA_OK;
+    });
+}
+int32_t pa_dynamic_filter_poll(pa_operator* op, int32_t* is_all, pa_domain* domains, int32_t domain_capacity)
+{
+    return guarded([&]() -> int32_t {
+        PA_REQUIRE(op != nullptr && is_all != nullptr, PA_ERR_INVALID_ARGUMENT, "null argument");
+        return dynamic_filter_poll(op, is_all, domains, domain_capacity);
+    });
+}
 int32_t pa_order_by_create(const pa_order_by_desc* desc, pa_operator** out)
 {
     return guarded([&]() -> int32_t {

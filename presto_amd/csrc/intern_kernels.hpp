@@ -38,6 +38,7 @@ public:
     void decode(const int32_t* ids, const uint8_t* nulls, int64_t n, DevBuf* values, DevBuf* offsets, hipStream_t s);
     const uint64_t* hashes() const { return id_hash_.as<uint64_t>(); }
     uint32_t size() const { return ids_; }
+    uint64_t bytes() const { return (uint64_t)words_ * 8; }  // arena in use (strings padded to 8 bytes)
 
 private:
     InternTable view() const;

@@ -31,6 +31,8 @@ pa_operator* make_lookup_join(const pa_lookup_join_desc* desc, pa_lookup_source*
 pa_operator* make_topn(const pa_topn_desc* desc);
 pa_operator* make_order_by(const pa_order_by_desc* desc);
 pa_operator* make_lookup_outer(const pa_lookup_join_desc* desc, pa_lookup_source* bridge);
+pa_operator* make_dynamic_filter_source(const pa_dynamic_filter_source_desc* desc);
+int32_t dynamic_filter_poll(pa_operator* op, int32_t* is_all, pa_domain* domains, int32_t capacity);
 
 // page wire format (page_serde.cpp)
 int64_t serialize_page(const pa_page* page, void* out_host, int64_t capacity, hipStream_t s);

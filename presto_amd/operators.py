@@ -282,6 +282,65 @@ def OrderByOperator(input_types, output_channels, sort_channels, sort_orders, ou
     return Operator(h, [types, oc, sc, so])
 
 
+class DynamicFilterSourceOperator(Operator):
+    """DynamicFilterSourceOperator.DynamicFilterSourceOperatorFactory (…/operator/DynamicFilterSourceOperator.java:74-139):
+    pass-through on the build side of a join that collects the build values of `filter_channels`."""
+
+    def __init__(self, input_types, filter_channels, max_distinct_values, max_filter_size_bytes, min_max_collection_limit, stream=None):
+        d = abi.pa_dynamic_filter_source_desc()
+        types = abi.int32_array(input_types)
+        fc = abi.int32_array(filter_channels)
+        d.input_channel_count = len(input_types)
+        d.input_types = C.cast(types, C.POINTER(C.c_int32))
+        d.filter_channel_count = len(filter_channels)
+        d.filter_channels = C.cast(fc, C.POINTER(C.c_int32))
+        d.max_distinct_values = max_distinct_values
+        d.min_max_collection_limit = min_max_collection_limit
+        d.max_filter_size_bytes = max_filter_size_bytes
+        d.stream = stream
+        h = C.c_void_p()
+        check(lib().pa_dynamic_filter_source_create(C.byref(d), C.byref(h)))
+        super().__init__(h, [types, fc])
+        self._filters = len(filter_channels)
+
+    def getOutput(self):
+        """The page handed to addInput (the reference returns the same Page object)."""
+        out = abi.pa_page()
+        if not check(lib().pa_op_get_output(self._h, C.byref(out))):
+            return None
+        return self._last_page
+
+    def addInput(self, page):
+        super().addInput(page)
+        self._last_page = page
+
+    def predicate(self):
+        """What dynamicPredicateConsumer received: None while it has not been called, "all" for TupleDomain.all(), else one
+        entry per filter channel: ("all",) | ("none",) | ("values", [..ascending..]) | ("range", low, high)."""
+        is_all = C.c_int32()
+        doms = (abi.pa_domain * self._filters)()
+        if not check(lib().pa_dynamic_filter_poll(self._h, C.byref(is_all), doms, self._filters)):
+            return None
+        if is_all.value:
+            return "all"
+        out = []
+        for d in doms:
+            if d.kind == abi.DOMAIN_ALL:
+                out.append(("all",))
+                continue
+            if d.kind == abi.DOMAIN_NONE:
+                out.append(("none",))
+                continue
+            page = abi.pa_page()
+            page.position_count = d.value_count
+            page.channel_count = 1
+            page.columns = C.pointer(d.values)
+            page.mem = abi.MEM_HOST
+            vals = [r[0] for r in page_from_c(page).to_rows()]
+            out.append(("values", vals) if d.kind == abi.DOMAIN_VALUES else ("range", vals[0], vals[1]))
+        return out
+
+
 class LookupSourceFactory:
     """JoinBridge between a HashBuilderOperator and its LookupJoinOperators
     (…/operator/join/PartitionedLookupSourceFactory.java, JoinBridgeManager.java)."""

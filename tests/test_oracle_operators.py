@@ -325,3 +325,65 @@ def test_page_wire_format_known_frame(oracle):
     assert back.blocks[1].to_pylist() == big.blocks[1].to_pylist()
     assert [None if v is None else int(v) for v in back.blocks[2].to_pylist()] == [None if v is None else int(v) for v in big.blocks[2].to_pylist()]
     assert [None if v is None else np.int64(v).view(np.float64) for v in back.blocks[0].to_pylist()] == big.blocks[0].to_pylist()
+
+
+# ---- DynamicFilterSourceOperator KATs (TestDynamicFilterSourceOperator.java; defaults :121-124: 100 distinct values, 10 kB,
+# 1 000 000 rows for min / max) ------------------------------------------------------------------------------------------
+def dynamic_filter_kats():
+    """(name, types, filter channels, pages as column lists, (max distinct, max bytes, min/max row limit), expected)"""
+    seq = lambda a, b: list(range(a, b))
+    nan = float("nan")
+    B, I, D, BO, V = abi.BIGINT, abi.INTEGER, abi.DOUBLE, abi.BOOLEAN, abi.VARCHAR
+    dflt = (100, 10240, 1000000)
+    text = b"A" * 10241
+    ta, tb = b"A" * 5121, b"B" * 5121
+    return [
+        ("multiple operators 1", [B], [0], [[[1, 2]], [[3, 5]]], dflt, [("values", [1, 2, 3, 5])]),  # :181-207
+        ("multiple operators 2", [B], [0], [[[2, 3]], [[1, 4]]], dflt, [("values", [1, 2, 3, 4])]),
+        ("multiple columns", [BO, D], [0, 1], [[[True, True], [1.5, 3.0]], [[False], [4.5]]], dflt,
+         [("values", [False, True]), ("values", [1.5, 3.0, 4.5])]),  # :209-223
+        ("only first column", [BO, D], [0], [[[True, True], [1.5, 3.0]], [[False], [4.5]]], dflt, [("values", [False, True])]),
+        ("only last column", [BO, D], [1], [[[True, True], [1.5, 3.0]], [[False], [4.5]]], dflt, [("values", [1.5, 3.0, 4.5])]),
+        ("nulls", [I], [0], [[[1, 2, 3]], [[3, None, 4]], [[4, 5]]], dflt, [("values", [1, 2, 3, 4, 5])]),  # :255-276
+        ("double NaN", [D], [0], [[[42.0, nan]]], dflt, [("values", [42.0])]),  # :278-294
+        ("too many rows double", [D], [0], [[[float(i) for i in seq(0, 101)]], [[nan] * 101]], dflt, "all"),  # :314-325
+        ("no filters", [B], [], [[[1, 2, 3]]], dflt, "all"),  # :370-379
+        ("empty build side", [B], [0], [], dflt, [("none",)]),  # :381-389
+        ("min max when too many positions", [B], [0], [[seq(0, 101)]], dflt, [("range", 0, 100)]),  # :391-406
+        ("below the distinct limit", [B, B, B], [0, 1, 2], [[seq(0, 101), seq(100, 201), seq(200, 301)]], (101, 10240, 1000000),
+         [("values", seq(0, 101)), ("values", seq(100, 201)), ("values", seq(200, 301))]),  # :408-429
+        ("min max when too many distinct", [B, B], [0, 1], [[seq(0, 101), [200] * 101]], dflt, [("range", 0, 100), ("range", 200, 200)]),  # :431-447 (COLOR channel left out)
+        ("min max with nulls", [B, B], [0, 1], [[[None] * 100, seq(200, 300)]], (99, 10240, 1000000), [("none",), ("range", 200, 299)]),  # :449-462 shape
+        ("too many bytes", [V], [0], [[[text]]], (100, 10240, 100), [("range", text, text)]),  # :464-483
+        ("too many bytes, two columns", [V, V], [0, 1], [[[ta], [tb]]], (100, 10240, 100), [("range", ta, ta), ("range", tb, tb)]),  # :485-507
+        ("multiple large pages", [B], [0], [[seq(50, 151)], [seq(0, 101)], [seq(100, 201)]], dflt, [("range", 0, 200)]),  # :509-526
+        ("deduplication", [B], [0], [[[7] * 1000], [[None] * 1000]], dflt, [("values", [7])]),  # :528-542
+        ("min max limit, single page", [B], [0], [[seq(0, 201)]], (100, 10240, 200), "all"),  # :544-555
+        ("min max limit, multiple pages", [B], [0], [[seq(0, 101)], [seq(0, 101)]], (100, 10240, 201), "all"),  # :557-570
+    ]
+
+
+def dynamic_filter_pages(types, pages):
+    make = {abi.BIGINT: Block.bigint, abi.INTEGER: Block.integer, abi.DOUBLE: Block.double, abi.BOOLEAN: Block.boolean}
+    out = []
+    for cols in pages:
+        blocks = []
+        for t, col in zip(types, cols):
+            if t == abi.VARCHAR:
+                blocks.append(Block.varchar(col))
+            else:
+                nulls = [v is None for v in col]
+                blocks.append(make[t]([0 if v is None else v for v in col], nulls if any(nulls) else None))
+        out.append(Page(blocks, len(cols[0])))
+    return out
+
+
+@pytest.mark.parametrize("kat", dynamic_filter_kats(), ids=lambda k: k[0])
+def test_dynamic_filter_source_kats(oracle, kat):
+    name, types, channels, pages, (max_distinct, max_bytes, row_limit), expected = kat
+    op = oracle.DynamicFilterSource(types, channels, max_distinct, max_bytes, row_limit)
+    for p in dynamic_filter_pages(types, pages):
+        assert op.add_page(p) is p  # verifyPassthrough
+    op.finish()
+    got = "all" if op.predicate == [] else op.predicate
+    assert got == expected
