@@ -56,6 +56,8 @@ struct FpSpec {
     std::vector<OwnedExpr> proj;
     int output_mem = PA_MEM_HOST;
     std::vector<bool> used_channel;
+    // the selection comes from outside (dictionary-aware filter): pa_fp_scatter reads sel4, the filter is not evaluated
+    bool filter_external = false;
 };
 
 struct FpKernelInfo {
@@ -106,7 +108,7 @@ FpKernelInfo generate_fp(const FpSpec& s, const std::vector<ChannelLayout>& layo
 
     // filter: bool pa_sel(args, row...)
     src << "__device__ __forceinline__ bool pa_sel(const PaFpArgs& a" << params << ")\n{\n";
-    if (s.has_filter) {
+    if (s.has_filter && !s.filter_external) {
         RowCodegen gen(layout, "a.err");
         std::ostringstream body;
         GenValue f = gen.emit(s.filter, body);
@@ -212,6 +214,25 @@ public:
         if (d->max_output_page_bytes > 0) merge_max_bytes_ = d->max_output_page_bytes;
         PA_REQUIRE(merge_max_bytes_ >= merge_min_bytes_, PA_ERR_INVALID_ARGUMENT, "maxPageSizeInBytes must be greater or equal than minPageSizeInBytes");
         merging_ = merge_min_bytes_ > 0 || merge_min_rows_ > 0;
+        // DictionaryAwarePageFilter (PageFunctionCompiler wraps a filter over a single input channel in it): two more
+        // kernel families -- the filter alone, run over a dictionary, and the projections under a selection made elsewhere
+        if (spec_.has_filter) {
+            std::set<int32_t> fc;
+            spec_.filter.collect_channels(&fc);
+            if (fc.size() == 1) {
+                dict_channel_ = *fc.begin();
+                dict_spec_ = spec_;
+                dict_spec_.proj.clear();
+                dict_spec_.used_channel.assign(spec_.n_in, false);
+                dict_spec_.used_channel[dict_channel_] = true;
+                ext_spec_ = spec_;
+                ext_spec_.filter_external = true;
+                std::set<int32_t> used;
+                for (const auto& e : ext_spec_.proj) e.collect_channels(&used);
+                ext_spec_.used_channel.assign(spec_.n_in, false);
+                for (int32_t c : used) ext_spec_.used_channel[c] = true;
+            }
+        }
     }
     ~FilterProjectOperator() override { (void)hipStreamSynchronize(stream_.get()); }
     hipStream_t private_stream() override { return stream_.owned() ? stream_.get() : nullptr; }
@@ -226,33 +247,21 @@ public:
         PA_REQUIRE(page->channel_count == spec_.n_in, PA_ERR_INVALID_ARGUMENT, "page channel count does not match the operator's input types");
         if (page->position_count == 0) return;  // PageProcessor.java:113-115
         hipStream_t s = stream_.get();
-        in_ = stager_.stage(page, &spec_.used_channel, s);
+        const int64_t n = page->position_count;
+        const int64_t tiles = (n + kTileRows - 1) / kTileRows;
+        // a dictionary / RLE block under a single-channel filter: the filter runs over the dictionary, the rows look it up
+        const bool external = dict_channel_ >= 0 && dictionary_filter(page, n, tiles, s);
+        const FpSpec& sp = external ? ext_spec_ : spec_;
+        in_ = stager_.stage(page, &sp.used_channel, s);
         in_device_ = page->mem == PA_MEM_DEVICE;
-        const int64_t n = in_.n;
-        std::vector<ChannelLayout> layout(spec_.n_in);
+        std::vector<ChannelLayout> layout(sp.n_in);
         std::string sig;
         bool vec = true;
-        for (int c = 0; c < spec_.n_in; c++) {
-            layout[c].type = spec_.used_channel[c] ? in_.cols[c].type : spec_.in_types[c];
-            layout[c].nullable = spec_.used_channel[c] && in_.cols[c].nulls != nullptr;
-            if (spec_.used_channel[c]) {
-                PA_REQUIRE(in_.cols[c].type == spec_.in_types[c], PA_ERR_INVALID_ARGUMENT, "page block type does not match the declared input type");
-                vec = vec && ((uintptr_t)in_.cols[c].values % 16 == 0) && ((uintptr_t)in_.cols[c].offsets % 16 == 0) &&
-                      ((uintptr_t)in_.cols[c].nulls % 4 == 0);
-            }
-            sig += layout[c].nullable ? 'n' : '-';
-        }
-        Compiled& ck = kernel_for(sig, layout);
-        cur_ = &ck;
-        const int64_t tiles = (n + kTileRows - 1) / kTileRows;
         FpArgs a;
         memset(&a, 0, sizeof a);
-        for (int c = 0; c < spec_.n_in; c++) {
-            if (!spec_.used_channel[c]) continue;
-            a.v[c] = in_.cols[c].values;
-            a.o[c] = in_.cols[c].offsets;
-            a.nl[c] = in_.cols[c].nulls;
-        }
+        bind_inputs(sp, in_, &layout, &sig, &vec, &a);
+        Compiled& ck = kernel_for(external ? 2 : 0, sig, layout);
+        cur_ = &ck;
         a.n = n;
         a.vec = vec ? 1 : 0;
         a.err = ctl_;
@@ -279,7 +288,7 @@ public:
             a.tile_offsets = a.tile_counts;  // scanned in place
             void* params[] = {&a};
             timer.begin(s);
-            PA_HIP(hipModuleLaunchKernel(ck.count_fn, (unsigned)tiles, 1, 1, 256, 1, 1, 0, s, params, nullptr));
+            if (!external) PA_HIP(hipModuleLaunchKernel(ck.count_fn, (unsigned)tiles, 1, 1, 256, 1, 1, 0, s, params, nullptr));
             launch_exclusive_scan_i32(a.tile_counts, a.tile_counts, tiles, ctl_ + 1, scan_temp_.ensure(scan_temp_bytes(tiles)), s);
             PA_HIP(hipModuleLaunchKernel(ck.scatter_fn, (unsigned)tiles, 1, 1, 256, 1, 1, 0, s, params, nullptr));
             timer.end(s);
@@ -488,22 +497,101 @@ private:
         hipFunction_t count_fn = nullptr, scatter_fn = nullptr;
     };
 
-    Compiled& kernel_for(const std::string& sig, const std::vector<ChannelLayout>& layout)
+    // variant 0: the operator as described; 1: the filter alone (over a dictionary); 2: the projections under an external selection
+    Compiled& kernel_for(int variant, const std::string& sig, const std::vector<ChannelLayout>& layout)
     {
-        auto it = compiled_.find(sig);
+        const std::string key = std::to_string(variant) + sig;
+        auto it = compiled_.find(key);
         if (it != compiled_.end()) return *it->second;
+        const FpSpec& sp = variant == 0 ? spec_ : (variant == 1 ? dict_spec_ : ext_spec_);
         auto c = std::make_unique<Compiled>();
-        c->info = generate_fp(spec_, layout);
-        if (spec_.has_filter) c->count_fn = jit_get(c->info.source, "pa_fp_count").fn;
-        c->scatter_fn = jit_get(c->info.source, "pa_fp_scatter").fn;
+        c->info = generate_fp(sp, layout);
+        if (sp.has_filter && !sp.filter_external) c->count_fn = jit_get(c->info.source, "pa_fp_count").fn;
+        if (variant != 1) c->scatter_fn = jit_get(c->info.source, "pa_fp_scatter").fn;
         Compiled& ref = *c;
-        compiled_[sig] = std::move(c);
+        compiled_[key] = std::move(c);
         return ref;
     }
 
-    FpSpec spec_;
+    // column pointers, layout signature and alignment of the channels `sp` reads
+    static void bind_inputs(const FpSpec& sp, const DevPage& in, std::vector<ChannelLayout>* layout, std::string* sig, bool* vec, FpArgs* a)
+    {
+        for (int c = 0; c < sp.n_in; c++) {
+            ChannelLayout& l = (*layout)[c];
+            l.type = sp.used_channel[c] ? in.cols[c].type : sp.in_types[c];
+            l.nullable = sp.used_channel[c] && in.cols[c].nulls != nullptr;
+            if (sp.used_channel[c]) {
+                PA_REQUIRE(in.cols[c].type == sp.in_types[c], PA_ERR_INVALID_ARGUMENT, "page block type does not match the declared input type");
+                *vec = *vec && ((uintptr_t)in.cols[c].values % 16 == 0) && ((uintptr_t)in.cols[c].offsets % 16 == 0) &&
+                       ((uintptr_t)in.cols[c].nulls % 4 == 0);
+                a->v[c] = in.cols[c].values;
+                a->o[c] = in.cols[c].offsets;
+                a->nl[c] = in.cols[c].nulls;
+            }
+            *sig += l.nullable ? 'n' : '-';
+        }
+    }
+
+    // DictionaryAwarePageFilter.filter (DictionaryAwarePageFilter.java:57-83): evaluates the filter on the dictionary (or the
+    // RLE value) and maps the verdicts through the ids into sel4_ / tile_counts_ of the page.  False = ordinary processing:
+    // not a dictionary block, a dictionary larger than the page, or the dictionary pass raised an error (:105-111 -- an
+    // entry no row uses may fail; the ordinary pass then reports the error only if a row really hits it).
+    bool dictionary_filter(const pa_page* page, int64_t n, int64_t tiles, hipStream_t s)
+    {
+        const pa_column& col = page->columns[dict_channel_];
+        if ((col.encoding != PA_DICTIONARY && col.encoding != PA_RLE) || col.dictionary == nullptr) return false;
+        const pa_column& dict = *col.dictionary;
+        if (dict.encoding != PA_FLAT && dict.encoding != PA_VARWIDTH) return false;
+        const int64_t dn = col.encoding == PA_RLE ? 1 : col.dictionary_size;
+        if (dn <= 0 || dn > n || (col.encoding == PA_DICTIONARY && col.ids == nullptr)) return false;
+        std::vector<pa_column> cols((size_t)spec_.n_in);
+        cols[dict_channel_] = dict;
+        pa_page dpage{};
+        dpage.position_count = (int32_t)dn;
+        dpage.channel_count = spec_.n_in;
+        dpage.columns = cols.data();
+        dpage.mem = page->mem;
+        DevPage d = dict_stager_.stage(&dpage, &dict_spec_.used_channel, s);
+        std::vector<ChannelLayout> layout(spec_.n_in);
+        std::string sig;
+        bool vec = true;
+        FpArgs a;
+        memset(&a, 0, sizeof a);
+        bind_inputs(dict_spec_, d, &layout, &sig, &vec, &a);
+        Compiled& dk = kernel_for(1, sig, layout);
+        const int64_t dtiles = (dn + kTileRows - 1) / kTileRows;
+        a.n = dn;
+        a.vec = vec ? 1 : 0;
+        a.err = ctl_;
+        a.sel4 = static_cast<uint8_t*>(dict_sel4_.ensure((size_t)(dn + 3) / 4));
+        a.tile_counts = static_cast<int32_t*>(dict_tiles_.ensure((size_t)dtiles * 4));
+        void* params[] = {&a};
+        PA_HIP(hipModuleLaunchKernel(dk.count_fn, (unsigned)dtiles, 1, 1, 256, 1, 1, 0, s, params, nullptr));
+        PA_HIP(hipMemcpyAsync(h_ctl_, ctl_, 4, hipMemcpyDeviceToHost, s));
+        PA_HIP(hipStreamSynchronize(s));
+        if (h_ctl_[0] != 0) {
+            PA_HIP(hipMemsetAsync(ctl_, 0, 4, s));
+            return false;
+        }
+        const int32_t* ids = nullptr;
+        if (col.encoding == PA_DICTIONARY) {
+            if (page->mem == PA_MEM_DEVICE) ids = col.ids;
+            else {
+                int32_t* dev = static_cast<int32_t*>(ids_.ensure((size_t)n * 4));
+                PA_HIP(hipMemcpyAsync(dev, col.ids, (size_t)n * 4, hipMemcpyHostToDevice, s));
+                ids = dev;
+            }
+        }
+        launch_dict_filter_sel(ids, a.sel4, n, static_cast<uint8_t*>(sel4_.ensure((size_t)(n + 3) / 4)),
+                               static_cast<int32_t*>(tile_counts_.ensure((size_t)tiles * 4)), s);
+        return true;
+    }
+
+    FpSpec spec_, dict_spec_, ext_spec_;
+    int dict_channel_ = -1;  // the filter's only input channel, or -1
     Stream stream_;
-    PageStager stager_;
+    PageStager stager_, dict_stager_;
+    DevBuf dict_sel4_, dict_tiles_, ids_;
     std::map<std::string, std::unique_ptr<Compiled>> compiled_;
     Compiled* cur_ = nullptr;
     DevPage in_;

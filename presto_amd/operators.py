@@ -542,11 +542,13 @@ def upload_page(page):
         check(lib().pa_memcpy_h2d(alloc.ptr, arr.ctypes.data, arr.nbytes, None))
         return DeviceBuffer(alloc.ptr, arr.nbytes, alloc)
 
+    def up_block(b):
+        dictionary = up_block(b.dictionary) if b.dictionary is not None else None  # DictionaryBlock / RunLengthEncodedBlock
+        return Block(b.type, b.encoding, b.position_count, values=up(b.values), offsets=up(b.offsets), nulls=up(b.nulls),
+                     ids=up(b.ids), dictionary=dictionary)
+
     for b in page.blocks:
-        if b.encoding not in (abi.FLAT, abi.VARWIDTH):
-            raise NotImplementedError("upload of encoded blocks")
-        blocks.append(Block(b.type, b.encoding, b.position_count, values=up(b.values), offsets=up(b.offsets),
-                            nulls=up(b.nulls)))
+        blocks.append(up_block(b))
     return Page(blocks, page.position_count, abi.MEM_DEVICE)
 
 

@@ -74,6 +74,43 @@ if "agg" in which:
         print("HashAggregation %8d groups: %.3g rows/s (%.1f GB/s of the 16 B/row inputs), %d groups out; wall %.2f ms, fused kernels %.2f ms in %d launches"
               % (groups, rows / dt, rows * 16 / dt / 1e9, run(), dt * 1e3, run.kernel_ms, run.launches))
 
+if "dict" in which:
+    # l_shipmode as a DictionaryBlock over 7 strings (what an ORC / Parquet reader hands over) under
+    # `shipmode = 'MAIL' OR shipmode = 'SHIP'`, projecting another column: the dictionary-aware filter against the same
+    # rows as a plain VariableWidthBlock
+    from presto_amd.expr import constant, or_
+    rows = 1 << 26
+    g = torch.Generator(device="cuda").manual_seed(4)
+    words = [b"REG AIR", b"AIR", b"RAIL", b"SHIP", b"TRUCK", b"MAIL", b"FOB"]
+    ids = torch.randint(0, 7, (rows,), dtype=torch.int32, device="cuda", generator=g)
+    qty = torch.randint(0, 50, (rows,), dtype=torch.int64, device="cuda", generator=g)
+    dbytes = torch.tensor(list(b"".join(words)), dtype=torch.uint8, device="cuda")
+    doffs = torch.tensor(np.cumsum([0] + [len(w) for w in words]), dtype=torch.int32, device="cuda")
+    dictionary = Block(abi.VARCHAR, abi.VARWIDTH, 7, values=DeviceBuffer(dbytes.data_ptr(), dbytes.numel(), dbytes), offsets=DeviceBuffer(doffs.data_ptr(), 32, doffs))
+    dpage = Page([Block(abi.VARCHAR, abi.DICTIONARY, rows, ids=DeviceBuffer(ids.data_ptr(), rows * 4, ids), dictionary=dictionary), dev_block(abi.BIGINT, qty)], rows, abi.MEM_DEVICE)
+    lens = torch.tensor([len(w) for w in words], dtype=torch.int32, device="cuda")[ids.long()]
+    offs = torch.zeros(rows + 1, dtype=torch.int32, device="cuda")
+    offs[1:] = torch.cumsum(lens, 0).to(torch.int32)
+    total = int(offs[-1])
+    pos = torch.arange(total, device="cuda", dtype=torch.int64)
+    row_of = torch.repeat_interleave(torch.arange(rows, device="cuda"), lens.long())
+    flat = dbytes[(doffs.long()[ids.long()][row_of] + (pos - offs.long()[row_of]))].contiguous()
+    fpage = Page([Block(abi.VARCHAR, abi.VARWIDTH, rows, values=DeviceBuffer(flat.data_ptr(), total, flat), offsets=DeviceBuffer(offs.data_ptr(), (rows + 1) * 4, offs)),
+                  dev_block(abi.BIGINT, qty)], rows, abi.MEM_DEVICE)
+    m = field(0, abi.VARCHAR)
+    f = or_(m.eq(constant(b"MAIL", abi.VARCHAR)), m.eq(constant(b"SHIP", abi.VARCHAR)))
+    for name, page in (("DictionaryBlock (dictionary-aware filter)", dpage), ("VariableWidthBlock (row by row)", fpage)):
+        def run():
+            op = FilterAndProjectOperator([abi.VARCHAR, abi.BIGINT], f, [field(1, abi.BIGINT)], output_mem=abi.MEM_DEVICE)
+            op.addInput(page)
+            out = op.getOutput()
+            op.finish()
+            n = out.position_count
+            op.close()
+            return n
+        dt = timeit(run)
+        print("FilterAndProject shipmode IN (MAIL, SHIP), %-42s %.3g rows/s, %d rows out" % (name, rows / dt, run()))
+
 if "vagg" in which:
     # VARCHAR(25) keys ("Customer#%09d" + padding, c_name / s_name shape): interned on the device, then grouped by id
     rows, width = 1 << 25, 24

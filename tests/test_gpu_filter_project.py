@@ -197,6 +197,69 @@ def test_varchar_dictionary_and_rle_inputs(gpu, oracle):
     assert got == sorted(ref.build_result().to_rows(), key=repr) and len(got) == 6
 
 
+def test_dictionary_aware_filter(gpu, oracle):
+    """DictionaryAwarePageFilter (…/operator/project/DictionaryAwarePageFilter.java:57-142): a filter over one channel whose
+    block is a DictionaryBlock / RLE is evaluated on the dictionary and looked up through the ids.  Same rows as the plain
+    filter: filter channel projected or not, NULL entries, RLE (all rows / no row), a dictionary larger than the page
+    (ordinary path), an entry no row uses that would fail the filter expression (:105-111), one that a row does use."""
+    from presto_amd._lib import PrestoAmdError
+    rng = np.random.default_rng(12)
+    n = 50000
+    d = Block.bigint(np.arange(100) * 3 - 50, (np.arange(100) % 17 == 0))
+    ids = rng.integers(0, 100, n).astype(np.int32)
+    other = Block.double(rng.random(n))
+    x, y = field(0, abi.BIGINT), field(1, abi.DOUBLE)
+    types = [abi.BIGINT, abi.DOUBLE]
+    page = Page([Block.dictionary_block(d, ids), other], n)
+    for f in (x > 40, x.between(constant(-20, abi.BIGINT), constant(100, abi.BIGINT)), x > 10 ** 9, x > -10 ** 9):
+        for proj in ([y * constant(3.0, abi.DOUBLE)], [x + 1, y], [x]):
+            op = FilterAndProjectOperator(types, f, proj)
+            rows = [r for p in to_pages(op, [page]) for r in p.to_rows()]
+            assert rows == oracle_rows(oracle, [page], f, proj)
+    # selectedPositions: a range when no or every row passes (PageFilter.java:37-39), a list otherwise
+    op = FilterAndProjectOperator(types, x > 40, [y])
+    op.addInput(page)
+    out = op.getOutput()
+    is_list, pos = op.selectedPositions()
+    assert is_list and pos.tolist() == [i for i, v in enumerate(page.blocks[0].to_pylist()) if v is not None and v > 40]
+    assert out.position_count == len(pos)
+    # RLE filter channel
+    for value, expect in ((Block.bigint([7]), n), (Block.bigint([-7]), 0), (Block.bigint([0], [1]), 0)):
+        p = Page([Block.rle(value, n), other], n)
+        rows = [r for q in to_pages(FilterAndProjectOperator(types, x > 0, [y, x]), [p]) for r in q.to_rows()]
+        assert len(rows) == expect and rows == oracle_rows(oracle, [p], x > 0, [y, x])
+    # dictionary larger than the page: processed row by row
+    small = Page([Block.dictionary_block(d, ids[:30]), Block.double(rng.random(30))], 30)
+    rows = [r for q in to_pages(FilterAndProjectOperator(types, x > 40, [x, y]), [small]) for r in q.to_rows()]
+    assert rows == oracle_rows(oracle, [small], x > 40, [x, y])
+    # an unused entry that fails the expression: the dictionary pass is dropped, the rows decide
+    dz = Block.bigint([0, 1, 2, 5])
+    f = constant(10, abi.BIGINT) / x > 3
+    ok = Page([Block.dictionary_block(dz, rng.integers(1, 4, 1000).astype(np.int32)), Block.double(rng.random(1000))], 1000)
+    rows = [r for q in to_pages(FilterAndProjectOperator(types, f, [x]), [ok]) for r in q.to_rows()]
+    assert rows == oracle_rows(oracle, [ok], f, [x]) and len(rows) > 0
+    bad = Page([Block.dictionary_block(dz, rng.integers(0, 4, 1000).astype(np.int32)), Block.double(rng.random(1000))], 1000)
+    with pytest.raises(PrestoAmdError) as e:
+        to_pages(FilterAndProjectOperator(types, f, [x]), [bad])
+    assert e.value.status == abi.ERR_DIVISION_BY_ZERO
+
+
+def test_dictionary_aware_filter_on_device_pages(gpu, oracle):
+    """The same with the page resident in HBM (ids, dictionary and the other channel are device pointers), VARCHAR dictionary."""
+    from presto_amd.operators import download_page, upload_page
+    rng = np.random.default_rng(13)
+    n = 200000
+    words = [b"AIR", b"MAIL", b"SHIP", None, b"TRUCK", b"REG AIR", b"FOB", b"RAIL"]
+    page = Page([Block.dictionary_block(Block.varchar(words), rng.integers(0, len(words), n).astype(np.int32)), Block.bigint(rng.integers(0, 1000, n))], n)
+    types = [abi.VARCHAR, abi.BIGINT]
+    m = field(0, abi.VARCHAR)
+    f = or_(m.eq(constant(b"MAIL", abi.VARCHAR)), m.eq(constant(b"SHIP", abi.VARCHAR)))
+    for proj in ([field(1, abi.BIGINT) * 2], [m, field(1, abi.BIGINT)]):
+        op = FilterAndProjectOperator(types, f, proj, output_mem=abi.MEM_DEVICE)
+        rows = [r for p in to_pages(op, [upload_page(page)]) for r in download_page(p).to_rows()]
+        assert rows == oracle_rows(oracle, [page], f, proj)
+
+
 # ---- MergePages behind the PageProcessor (a7) ------------------------------------------------------------------------
 def merged_reference(oracle, pages, f, projections, min_bytes, min_rows, max_bytes=0):
     m = oracle.MergePages(min_bytes, min_rows, max_bytes)
