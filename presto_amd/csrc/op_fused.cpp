@@ -124,7 +124,15 @@ struct KernelInfo {
     std::vector<int32_t> word_kind;
     std::vector<std::pair<int, int>> agg_words;  // per aggregate: (count word, value word or -1)
     std::vector<KeyPart> keys;
+    // identity of the state layout (key packing + meaning of every accumulator word): states are only ever merged,
+    // folded or emitted under the layout they were accumulated with
+    std::string layout_id;
 };
+
+// thrown by adopt_layout before anything of the page was launched: the page's signature needs another state layout
+struct LayoutChange {};
+
+void finalize_spec(Spec& s);
 
 Spec make_spec(const pa_fused_aggregation_desc* d)
 {
@@ -186,6 +194,13 @@ Spec make_spec(const pa_fused_aggregation_desc* d)
     }
     s.expected_groups = ag.expected_groups;
     s.output_mem = ag.output_mem;
+    finalize_spec(s);
+    return s;
+}
+
+// channels read, short / interned VARCHAR keys: everything of a Spec that follows from its expressions and aggregates
+void finalize_spec(Spec& s)
+{
     // channels actually read
     std::set<int32_t> used;
     if (s.has_filter) s.filter.collect_channels(&used);
@@ -240,7 +255,6 @@ Spec make_spec(const pa_fused_aggregation_desc* d)
             if (pe.is_input_ref() && pe.node(pe.root).channel == c) pe.nodes[pe.root].type = PA_INTEGER;
         }
     }
-    return s;
 }
 
 // ---- source generation -------------------------------------------------------------------------
@@ -459,6 +473,17 @@ KernelInfo generate(const Spec& s, const std::vector<ChannelLayout>& layout, int
         k.nw = 1;
     }
     for (const auto& w : words) k.word_kind.push_back(w.kind);
+    {
+        std::vector<std::string> names(words.size(), "rows");
+        for (const auto& kv : word_index) names[(size_t)kv.second] = kv.first;
+        std::ostringstream id;
+        for (const KeyPart& kp : k.keys) {
+            id << kp.type << ',' << kp.word << ',' << kp.shift << ',' << kp.bits << ',' << kp.bound << ',' << kp.null_word << ',' << kp.null_shift << ';';
+        }
+        id << '#';
+        for (size_t w = 0; w < words.size(); w++) id << words[w].kind << ':' << names[w] << ';';
+        k.layout_id = id.str();
+    }
     if (variant == V_LDS) {
         PA_REQUIRE((size_t)k.nw * kLdsSlots * 64 * 8 <= 64 * 1024, PA_ERR_NOT_SUPPORTED, "too many accumulator words for the LDS variant");
     }
@@ -799,9 +824,14 @@ uint32_t next_pow2(uint64_t v)
 class FusedAggregationOperator : public pa_operator {
 public:
     explicit FusedAggregationOperator(const pa_fused_aggregation_desc* d)
-        : spec_(make_spec(d)), stream_(d->aggregation.stream ? d->aggregation.stream : d->filter_project.stream)
+        : FusedAggregationOperator(make_spec(d), d->aggregation.stream ? d->aggregation.stream : d->filter_project.stream)
+    {
+    }
+    FusedAggregationOperator(Spec spec, void* stream) : spec_(std::move(spec)), stream_(stream)
     {
         require_device();
+        nullable_seen_.assign(spec_.n_in, false);
+        out_partial_ = spec_.step == PA_STEP_PARTIAL;
         {
             std::ostringstream f;
             for (int c = 0; c < spec_.n_in; c++) f << spec_.in_types[c] << ',' << spec_.in_params[c] << ';';
@@ -843,8 +873,43 @@ public:
         PA_REQUIRE(page != nullptr, PA_ERR_INVALID_ARGUMENT, "page is null");
         PA_REQUIRE(page->channel_count == spec_.n_in, PA_ERR_INVALID_ARGUMENT, "page channel count does not match the operator's input types");
         if (page->position_count == 0) return;
+        if (next_) {
+            next_->add_input(page);
+            return;
+        }
+        try {
+            add_page(page);
+        }
+        catch (const LayoutChange&) {
+            // nullability only grows, so a state sees at most one change per channel; the combiner none at all
+            PA_REQUIRE(!is_combiner_ && generation_ <= spec_.n_in, PA_ERR_DEVICE, "internal: state layout changed more often than channels exist");
+            // a channel turned nullable in a way that needs more count words / NULL flags: this state stays as it is, the
+            // page and everything after it go to a new generation; get_output combines the generations' states
+            next_ = std::make_unique<FusedAggregationOperator>(spec_, stream_.get());
+            next_->nullable_seen_ = nullable_seen_;
+            next_->generation_ = generation_ + 1;
+            next_->add_input(page);
+        }
+    }
+
+    void add_page(const pa_page* page)
+    {
         hipStream_t s = stream_.get();
-        DevPage dp = stager_.stage(page, &spec_.used_channel, s);
+        // interned key channels that arrive as a DictionaryBlock / RLE over strings take the dictionary route: not decoded
+        std::vector<int> dict_keys;
+        std::vector<bool> needed = spec_.used_channel;
+        for (int c = 0; c < spec_.n_in; c++) {
+            if (!spec_.interned[c]) continue;
+            const pa_column& col = page->columns[c];
+            const bool encoded = (col.encoding == PA_DICTIONARY && col.ids != nullptr) || col.encoding == PA_RLE;
+            if (!encoded || col.dictionary == nullptr || col.dictionary->encoding != PA_VARWIDTH) continue;
+            const int64_t dn = col.encoding == PA_RLE ? 1 : col.dictionary_size;
+            if (dn <= 0 || dn > page->position_count) continue;
+            needed[c] = false;
+            dict_keys.push_back(c);
+        }
+        DevPage dp = stager_.stage(page, &needed, s);
+        for (int c : dict_keys) intern_dictionary_key(page, c, dp, s);
         intern_keys(dp, s);
         // layout signature of this page
         std::vector<ChannelLayout> layout(spec_.n_in);
@@ -852,7 +917,10 @@ public:
         bool vec = true;
         for (int c = 0; c < spec_.n_in; c++) {
             layout[c].type = spec_.used_channel[c] ? dp.cols[c].type : spec_.in_types[c];
-            layout[c].nullable = spec_.used_channel[c] && dp.cols[c].nulls != nullptr;
+            // nullability only ever grows: a page without NULLs on a channel that had some runs the nullable kernels with a
+            // null valueIsNull pointer, so the state layout changes at most once per channel
+            if (spec_.used_channel[c] && dp.cols[c].nulls != nullptr) nullable_seen_[c] = true;
+            layout[c].nullable = nullable_seen_[c];
             if (spec_.used_channel[c]) {
                 PA_REQUIRE(dp.cols[c].type == spec_.in_types[c], PA_ERR_INVALID_ARGUMENT, "page block type does not match the declared input type");
                 vec = vec && ((uintptr_t)dp.cols[c].values % 16 == 0) && ((uintptr_t)dp.cols[c].offsets % 16 == 0) &&
@@ -900,6 +968,7 @@ public:
     {
         if (!finishing_ || output_done_) return false;
         output_done_ = true;
+        if (next_) return combine_generations(out);
         build_output();
         if (grouped_ && out_rows_ > 0) decode_interned_keys();
         if (!grouped_ || out_rows_ > 0) {
@@ -907,6 +976,83 @@ public:
             return true;
         }
         return false;  // HashAggregationOperator emits nothing for an empty input (SINGLE step with keys)
+    }
+
+    // The accumulator states of this generation as a PARTIAL-format page in HBM (false: no group).
+    bool emit_states(pa_page* out)
+    {
+        out_partial_ = true;
+        spec_.output_mem = PA_MEM_DEVICE;  // host-assembled blocks are uploaded
+        build_output();
+        if (grouped_ && out_rows_ > 0) decode_interned_keys();
+        if (grouped_ && out_rows_ == 0) return false;
+        publish_output(out_cols_, out_rows_, PA_MEM_DEVICE, stream_.get(), out, out_storage_);
+        return true;
+    }
+
+    // Generations exist because a channel's nullability changed the state layout mid-stream.  Their states are combined the
+    // way the reference combines partial aggregations (InMemoryHashAggregationBuilder with Step.FINAL / INTERMEDIATE input):
+    // every generation emits its states, a FINAL-input operator over [keys, ($hashvalue), states] adds them up and emits
+    // what this operator was asked for (final values, or states again for Step.PARTIAL).
+    bool combine_generations(pa_page* out)
+    {
+        Spec cs = combiner_spec();
+        combiner_ = std::make_unique<FusedAggregationOperator>(std::move(cs), stream_.get());
+        combiner_->out_partial_ = spec_.step == PA_STEP_PARTIAL;
+        // the generations' state pages differ in nullability by construction: the combiner starts from the most general
+        // layout (every channel nullable), so it never splits into generations itself
+        combiner_->nullable_seen_.assign(combiner_->spec_.n_in, true);
+        combiner_->is_combiner_ = true;
+        for (FusedAggregationOperator* g = this; g != nullptr; g = g->next_.get()) {
+            pa_page states{};
+            if (g->emit_states(&states)) combiner_->add_input(&states);
+        }
+        combiner_->finish();
+        return combiner_->get_output(out);
+    }
+
+    Spec combiner_spec() const
+    {
+        Spec c;
+        c.step = PA_STEP_FINAL;
+        c.output_mem = spec_.output_mem;
+        c.expected_groups = spec_.expected_groups;
+        auto add_channel = [&](int32_t type, int32_t param) {
+            c.in_types.push_back(type);
+            c.in_params.push_back(param);
+            OwnedExpr e;
+            pa_expr_node node{};
+            node.kind = PA_EXPR_INPUT_REF;
+            node.type = type;
+            node.channel = c.n_in;
+            e.nodes.push_back(node);
+            e.strings.emplace_back();
+            e.root = 0;
+            c.proj.push_back(std::move(e));
+            return c.n_in++;
+        };
+        for (size_t gi = 0; gi < spec_.group_proj.size(); gi++) {
+            const OwnedExpr& pe = spec_.proj[spec_.group_proj[gi]];
+            const int ch = pe.is_input_ref() ? pe.node(pe.root).channel : -1;
+            const bool interned = ch >= 0 && spec_.interned[ch];
+            c.group_proj.push_back(add_channel(interned ? (int32_t)PA_VARCHAR : pe.root_type(), ch >= 0 ? spec_.in_params[ch] : 0));
+        }
+        c.hash_channel = spec_.hash_channel >= 0 && !spec_.group_proj.empty() ? add_channel(PA_BIGINT, 0) : -1;
+        for (const pa_aggregate& ag : spec_.aggs) {
+            pa_aggregate f = ag;
+            f.mask_channel = -1;
+            f.input_channel = add_channel(PA_BIGINT, 0);  // count state
+            if (ag.fn != PA_AGG_COUNT && ag.fn != PA_AGG_COUNT_STAR) {
+                const int value_proj = spec_.step == PA_STEP_FINAL ? ag.input_channel + 1 : ag.input_channel;
+                int32_t t = spec_.proj[value_proj].root_type();
+                if (ag.fn == PA_AGG_AVG || (ag.fn == PA_AGG_SUM && t == PA_DOUBLE)) t = PA_DOUBLE;  // sum state: DOUBLE, or BIGINT for integer sums
+                else if (ag.fn == PA_AGG_SUM) t = PA_BIGINT;
+                add_channel(t, 0);
+            }
+            c.aggs.push_back(f);
+        }
+        finalize_spec(c);
+        return c;
     }
 
     int64_t memory_bytes() override
@@ -976,12 +1122,12 @@ private:
         if (!layout_fixed_) {
             nw_ = c.info.nw;
             w_ = c.info.w;
+            layout_id_ = c.info.layout_id;
             layout_fixed_ = true;
         }
-        // every signature of one operator must yield the same state layout: nullable inputs add count
-        // words / null flags, and states of different layouts cannot be merged
-        PA_REQUIRE(c.info.nw == nw_ && c.info.w == w_, PA_ERR_NOT_SUPPORTED,
-                   "pages of one operator changed nullability in a way that changes the accumulator layout");
+        // every signature of one state must yield the same layout: a channel that turns nullable adds count words / NULL
+        // flags, and states of different layouts cannot be merged word by word -- the page starts the next generation
+        if (c.info.layout_id != layout_id_) throw LayoutChange{};
     }
 
     // replicas wanted for a table of g groups: enough distinct accumulator addresses (>= ~2^17) for the atomics of a
@@ -1352,6 +1498,7 @@ private:
     void build_output();
     bool emit_on_device(const KernelInfo& ki, int64_t groups);
     void intern_keys(DevPage& dp, hipStream_t s);
+    void intern_dictionary_key(const pa_page* page, int c, DevPage& dp, hipStream_t s);
     void decode_interned_keys();
     // channel of group key gi when that channel is interned, else -1
     int interned_channel(int gi) const
@@ -1369,6 +1516,13 @@ private:
     std::string plan_fingerprint_;
     bool grouped_ = false, finishing_ = false, output_done_ = false, layout_fixed_ = false;
     int mode_ = V_GLOBAL, cus_ = 256, nw_ = 0, w_ = 0;
+    std::string layout_id_;
+    std::vector<bool> nullable_seen_;  // per channel: some page so far carried a valueIsNull array
+    bool out_partial_ = false;         // the output is the accumulator states (Step.PARTIAL, or a generation to be combined)
+    int generation_ = 0;
+    bool is_combiner_ = false;
+    std::unique_ptr<FusedAggregationOperator> next_;      // later generation: every page from the layout change on
+    std::unique_ptr<FusedAggregationOperator> combiner_;  // FINAL-input operator over the generations' states
     DevBuf ctl_buf_;
     PinnedBuf h_ctl_buf_, h_table_;
     int32_t* ctl_ = nullptr;
@@ -1393,6 +1547,8 @@ private:
     std::vector<pa_column> out_storage_;
     int32_t out_rows_ = 0;
     std::vector<std::unique_ptr<StringInterner>> interners_;  // per input channel, for Spec::interned channels
+    PageStager dict_stager_;
+    std::vector<DevBuf> dict_key_bufs_;  // per interned channel: uploaded ids, key ids, key NULL flags of a dictionary page
 };
 
 // VARCHAR group keys without a short bound: the page's strings become ids of the channel's dictionary, and the kernels
@@ -1402,6 +1558,7 @@ void FusedAggregationOperator::intern_keys(DevPage& dp, hipStream_t s)
     for (int c = 0; c < spec_.n_in; c++) {
         if (!spec_.interned[c]) continue;
         DevColumn& col = dp.cols[c];
+        if (col.type == PA_INTEGER && !col.varwidth && col.values != nullptr) continue;  // took the dictionary route
         PA_REQUIRE(col.type == PA_VARCHAR && col.varwidth && col.offsets != nullptr, PA_ERR_INVALID_ARGUMENT,
                    "page block type does not match the declared input type");
         if (interners_.empty()) interners_.resize(spec_.n_in);
@@ -1412,6 +1569,56 @@ void FusedAggregationOperator::intern_keys(DevPage& dp, hipStream_t s)
         col.values = ids;
         col.offsets = nullptr;
     }
+}
+
+// The dictionary fast path of MultiChannelGroupByHash (MultiChannelGroupByHash.java:465-512: group ids are computed once per
+// dictionary entry and looked up through the ids): the dictionary's strings are interned -- a handful of entries instead of
+// every row -- and the rows' keys are a gather of those dictionary ids.  Works across pages with different dictionaries,
+// since the ids are the operator's own.
+void FusedAggregationOperator::intern_dictionary_key(const pa_page* page, int c, DevPage& dp, hipStream_t s)
+{
+    const pa_column& col = page->columns[c];
+    const int64_t n = page->position_count;
+    const int64_t dn = col.encoding == PA_RLE ? 1 : col.dictionary_size;
+    std::vector<pa_column> cols((size_t)spec_.n_in);
+    cols[c] = *col.dictionary;
+    pa_page dpage{};
+    dpage.position_count = (int32_t)dn;
+    dpage.channel_count = spec_.n_in;
+    dpage.columns = cols.data();
+    dpage.mem = page->mem;
+    std::vector<bool> only(spec_.n_in, false);
+    only[c] = true;
+    DevPage d = dict_stager_.stage(&dpage, &only, s);
+    const DevColumn& dcol = d.cols[c];
+    PA_REQUIRE(dcol.type == PA_VARCHAR && dcol.varwidth && dcol.offsets != nullptr, PA_ERR_INVALID_ARGUMENT,
+               "page block type does not match the declared input type");
+    if (interners_.empty()) interners_.resize(spec_.n_in);
+    if (!interners_[c]) interners_[c] = std::make_unique<StringInterner>();
+    const int32_t* dict_ids = interners_[c]->intern(dcol.values, dcol.offsets, dcol.nulls, dn, s);
+    if (dict_key_bufs_.empty()) dict_key_bufs_.resize((size_t)spec_.n_in * 3);
+    DevBuf& ids_buf = dict_key_bufs_[(size_t)c * 3], &out_buf = dict_key_bufs_[(size_t)c * 3 + 1], &nulls_buf = dict_key_bufs_[(size_t)c * 3 + 2];
+    const int32_t* ids = nullptr;
+    if (col.encoding == PA_DICTIONARY && page->mem == PA_MEM_DEVICE) ids = col.ids;
+    else {
+        int32_t* dev = static_cast<int32_t*>(ids_buf.ensure((size_t)n * 4));
+        if (col.encoding == PA_RLE) PA_HIP(hipMemsetAsync(dev, 0, (size_t)n * 4, s));
+        else PA_HIP(hipMemcpyAsync(dev, col.ids, (size_t)n * 4, hipMemcpyHostToDevice, s));
+        ids = dev;
+    }
+    int32_t* out = static_cast<int32_t*>(out_buf.ensure((size_t)n * 4));
+    launch_gather_flat(dict_ids, 4, ids, n, out, s);
+    uint8_t* out_nulls = nullptr;
+    if (dcol.nulls) {
+        out_nulls = static_cast<uint8_t*>(nulls_buf.ensure((size_t)n));
+        launch_gather_nulls(dcol.nulls, ids, n, out_nulls, s);
+    }
+    DevColumn& k = dp.cols[c];
+    k.type = PA_INTEGER;
+    k.varwidth = false;
+    k.values = out;
+    k.offsets = nullptr;
+    k.nulls = out_nulls;
 }
 
 // The id key columns of the assembled output back to VariableWidthBlocks.
@@ -1455,7 +1662,7 @@ bool FusedAggregationOperator::emit_on_device(const KernelInfo& ki, int64_t grou
     constexpr int64_t kMinGroups = 4096;
     const int nkeys = (int)spec_.group_proj.size();
     const bool has_hash = nkeys > 0 && spec_.hash_channel >= 0;
-    const bool partial = spec_.step == PA_STEP_PARTIAL;
+    const bool partial = out_partial_;
     if (groups < kMinGroups || groups > INT32_MAX) return false;
     for (int gi = 0; gi < nkeys; gi++) {
         if (ki.keys[gi].type == PA_VARCHAR) return false;
@@ -1628,7 +1835,7 @@ void FusedAggregationOperator::build_output()
 
     const int nkeys = (int)spec_.group_proj.size();
     const bool has_hash = nkeys > 0 && spec_.hash_channel >= 0;
-    const bool partial = spec_.step == PA_STEP_PARTIAL;
+    const bool partial = out_partial_;
     int agg_cols = 0;
     for (const auto& ag : spec_.aggs) agg_cols += (partial && ag.fn != PA_AGG_COUNT && ag.fn != PA_AGG_COUNT_STAR) ? 2 : 1;
     const int ncols = nkeys + (has_hash ? 1 : 0) + agg_cols;

@@ -96,7 +96,8 @@ void emit_vector_loads(const RowInputs& s, const std::vector<ChannelLayout>& lay
                 throw Error(PA_ERR_NOT_SUPPORTED, "column type not supported on device");
         }
         if (layout[c].nullable) {
-            o << "        u32 N" << C << " = ((const u32*)a.nl[" << C << "])[q];\n";
+            // a page without a valueIsNull array on a channel that had one earlier passes a null pointer
+            o << "        u32 N" << C << " = a.nl[" << C << "] ? ((const u32*)a.nl[" << C << "])[q] : 0u;\n";
             for (int r = 0; r < 4; r++) args[r] += ", ((N" + C + " >> " + std::to_string(8 * r) + ") & 0xffu) != 0u";
         }
     }
@@ -124,7 +125,7 @@ std::string scalar_args(const RowInputs& s, const std::vector<ChannelLayout>& la
                 break;
             default: throw Error(PA_ERR_NOT_SUPPORTED, "column type not supported on device");
         }
-        if (layout[c].nullable) a += ", a.nl[" + C + "][r] != 0";
+        if (layout[c].nullable) a += ", (a.nl[" + C + "] != nullptr && a.nl[" + C + "][r] != 0)";
     }
     return a;
 }

@@ -271,3 +271,45 @@ def bits_of(rows):
     for r in rows:
         out.append(tuple(("nan" if v != v else struct.pack("<d", v)) if isinstance(v, float) else v for v in r))
     return out
+
+
+@pytest.mark.parametrize("groups", [0, 6, 300, 5000, 200000])
+@pytest.mark.parametrize("step", ["single", "partial"])
+def test_nullability_changes_between_pages(gpu, oracle, groups, step):
+    """valueIsNull arrays come and go from page to page (LongArrayBlock.java:37-41: null when the block has no NULLs).  A key or
+    an aggregate input that turns nullable needs NULL flags / its own count word: the operator keeps the states collected so
+    far as they are, continues in a new generation and combines the generations' states at the end like partial
+    aggregations.  Page order here: no NULLs anywhere -> NULLs in the second key -> none -> NULLs in an aggregate input and
+    the mask -> NULLs in the first key -> none."""
+    rng = np.random.default_rng(groups + 17)
+    rows = 60000
+
+    def page(null_k1, null_k2, null_x, null_m):
+        def nulls(on):
+            return (rng.random(rows) < 0.07) if on else None
+        g = max(groups, 1)
+        return Page([Block.boolean(rng.random(rows) < 0.5, nulls(null_k1)), Block.integer(rng.integers(0, g, rows), nulls(null_k2)),
+                     Block.double(rng.random(rows) * 10, nulls(null_x)), Block.bigint(rng.integers(-50, 50, rows), nulls(null_x)),
+                     Block.boolean(rng.random(rows) < 0.8, nulls(null_m))], rows)
+
+    pages = [page(0, 0, 0, 0), page(0, 1, 0, 0), page(0, 0, 0, 0), page(0, 0, 1, 1), page(1, 0, 0, 0), page(0, 0, 0, 0)]
+    types = [abi.BOOLEAN, abi.INTEGER, abi.DOUBLE, abi.BIGINT, abi.BOOLEAN]
+    aggs = [(abi.AGG_COUNT_STAR, -1, None), (abi.AGG_COUNT, 2, abi.DOUBLE), (abi.AGG_SUM, 2, abi.DOUBLE), (abi.AGG_AVG, 3, abi.BIGINT),
+            (abi.AGG_SUM, 3, abi.BIGINT), (abi.AGG_MIN, 2, abi.DOUBLE), (abi.AGG_MAX, 3, abi.BIGINT), (abi.AGG_SUM, 3, abi.BIGINT, 4),
+            (abi.AGG_COUNT_STAR, -1, None, 4)]
+    keys = [0, 1] if groups else []
+    ref = oracle.HashAggregation(types, keys, aggs)
+    for p in pages:
+        ref.add_page(p)
+    expected = ref.build_result().to_rows()
+    make = (lambda **kw: HashAggregationOperator(types, keys, aggs, expected_groups=max(groups, 1), **kw)) if groups else \
+        (lambda **kw: AggregationOperator(types, aggs, **kw))
+    if step == "single":
+        got = [r for p in to_pages(make(), pages) for r in p.to_rows()]
+    else:
+        from presto_amd.exchange import partial_layout
+        ptypes, faggs = partial_layout([abi.BOOLEAN, abi.INTEGER] if groups else [], aggs)
+        partial_pages = to_pages(make(step=abi.STEP_PARTIAL), pages[:4]) + to_pages(make(step=abi.STEP_PARTIAL), pages[4:])
+        final = HashAggregationOperator(ptypes, [0, 1], faggs, step=abi.STEP_FINAL) if groups else AggregationOperator(ptypes, faggs, step=abi.STEP_FINAL)
+        got = [r for p in to_pages(final, partial_pages) for r in p.to_rows()]
+    rows_equal_ignore_order(got, expected, rel=1e-9)

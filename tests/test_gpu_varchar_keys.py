@@ -150,3 +150,32 @@ def test_device_resident_output(gpu, oracle):
     ref = oracle.HashAggregation(types, [0], aggs)
     ref.add_page(page)
     assert_same(got, ref.build_result().to_rows())
+
+
+@pytest.mark.parametrize("device", [False, True])
+def test_dictionary_blocks_as_long_keys(gpu, oracle, device):
+    """MultiChannelGroupByHash's dictionary path (…/MultiChannelGroupByHash.java:465-512): key pages that arrive as
+    DictionaryBlock / RLE over strings -- a different dictionary per page, NULL entries, unused entries, then a plain
+    VariableWidthBlock page with overlapping strings -- group exactly like their decoded form."""
+    from presto_amd.operators import upload_page
+    rng = np.random.default_rng(21)
+    base = [("part-%05d-%s" % (i, "q" * (i % 29))).encode() for i in range(400)]
+    pages = []
+    for k in range(3):
+        n = 60000 + 1000 * k
+        entries = [base[i] for i in rng.choice(400, 150, replace=False)] + [None]
+        d = Block.varchar(entries)
+        ids = rng.integers(0, len(entries) - (k == 1), n).astype(np.int32)  # page 1 never uses its NULL entry
+        pages.append(Page([Block.dictionary_block(d, ids), Block.bigint(rng.integers(0, 100, n))], n))
+    pages.append(Page([Block.rle(Block.varchar([base[7]]), 5000), Block.bigint(rng.integers(0, 100, 5000))], 5000))
+    pages.append(Page([Block.rle(Block.varchar([None]), 300), Block.bigint(rng.integers(0, 100, 300))], 300))
+    plain = [base[i] for i in rng.integers(0, 400, 20000)]
+    pages.append(Page([Block.varchar(plain), Block.bigint(rng.integers(0, 100, 20000))], 20000))
+    types = [abi.VARCHAR, abi.BIGINT]
+    aggs = [(abi.AGG_COUNT_STAR, -1, None), (abi.AGG_SUM, 1, abi.BIGINT), (abi.AGG_COUNT, 0, abi.VARCHAR)]
+    op = HashAggregationOperator(types, [0], aggs)
+    got = [r for p in to_pages(op, [upload_page(p) for p in pages] if device else pages) for r in p.to_rows()]
+    ref = oracle.HashAggregation(types, [0], aggs)
+    for p in pages:
+        ref.add_page(p)
+    assert_same(got, ref.build_result().to_rows())
