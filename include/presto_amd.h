@@ -255,7 +255,8 @@ typedef struct pa_lookup_join_desc {
     int32_t output_mem;
     void* stream;
     int32_t join_type;                   /* pa_join_type */
-    int32_t reserved;
+    int32_t output_single_match;         /* LookupJoinOperatorFactory.outputSingleMatch (DefaultPageJoiner.java:276-278): at
+                                          * most one output row per probe row -- the first position of its chain */
 } pa_lookup_join_desc;
 
 /* TopNOperator.createOperatorFactory (TopNOperator.java:43-90): keep the n best rows under (sort_channels, sort_orders)

@@ -373,7 +373,7 @@ inline std::unique_ptr<Operator> createHashBuilderOperator(LookupSourceFactory& 
 // OperatorFactories.innerJoin / probeOuterJoin / lookupOuterJoin / fullOuterJoin: joinType = pa_join_type
 inline std::unique_ptr<Operator> createLookupJoinOperator(LookupSourceFactory& bridge, const std::vector<int32_t>& probeTypes,
                                                           const std::vector<int32_t>& probeJoinChannels, const std::vector<int32_t>& probeOutputChannels,
-                                                          int32_t joinType = PA_JOIN_INNER)
+                                                          int32_t joinType = PA_JOIN_INNER, bool outputSingleMatch = false)
 {
     pa_lookup_join_desc d{};
     d.probe_channel_count = (int32_t)probeTypes.size();
@@ -385,6 +385,7 @@ inline std::unique_ptr<Operator> createLookupJoinOperator(LookupSourceFactory& b
     d.probe_output_channels = probeOutputChannels.data();
     d.output_mem = PA_MEM_HOST;
     d.join_type = joinType;
+    d.output_single_match = outputSingleMatch ? 1 : 0;
     pa_operator* h = nullptr;
     check(pa_lookup_join_create(&d, bridge.handle(), &h));
     return std::make_unique<Operator>(h);

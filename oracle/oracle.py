@@ -265,7 +265,7 @@ def make_hash_builder_desc(input_types, join_channels, output_channels, hash_cha
 
 
 def make_lookup_join_desc(probe_types, probe_join_channels, probe_output_channels, probe_hash_channel=-1,
-                          output_mem=abi.MEM_HOST, stream=None, join_type=abi.JOIN_INNER):
+                          output_mem=abi.MEM_HOST, stream=None, join_type=abi.JOIN_INNER, output_single_match=False):
     d = abi.pa_lookup_join_desc()
     types = abi.int32_array(probe_types)
     jc = abi.int32_array(probe_join_channels)
@@ -280,6 +280,7 @@ def make_lookup_join_desc(probe_types, probe_join_channels, probe_output_channel
     d.output_mem = output_mem
     d.stream = stream
     d.join_type = join_type
+    d.output_single_match = 1 if output_single_match else 0
     return d, [types, jc, oc]
 
 
@@ -305,10 +306,12 @@ class HashJoin:
         lib().orc_join_tables(self._h, C.byref(hs), key.ctypes.data, links.ctypes.data)
         return key, links[:lib().orc_join_build_positions(self._h)]
 
-    def probe(self, page, probe_types, probe_join_channels, probe_output_channels, probe_hash_channel=-1, join_type=abi.JOIN_INNER):
+    def probe(self, page, probe_types, probe_join_channels, probe_output_channels, probe_hash_channel=-1, join_type=abi.JOIN_INNER,
+              output_single_match=False):
         """Returns (output Page, probe indices, build positions) in the reference's emission order; build position -1 =
         the NULL-extended row of a probe-outer join."""
-        d, keep = make_lookup_join_desc(probe_types, probe_join_channels, probe_output_channels, probe_hash_channel, join_type=join_type)
+        d, keep = make_lookup_join_desc(probe_types, probe_join_channels, probe_output_channels, probe_hash_channel, join_type=join_type,
+                                        output_single_match=output_single_match)
         cpage, k2 = page.to_c()
         out = abi.pa_page()
         pi = C.POINTER(C.c_int32)()

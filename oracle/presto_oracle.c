@@ -1769,6 +1769,9 @@ int32_t orc_join_probe(const orc_join* j, const pa_lookup_join_desc* d, const pa
             if (track) {
                 ((orc_join*)j)->visited[join_position] = 1; /* OuterLookupSource.appendTo -> positionVisited */
             }
+            if (d->output_single_match) {
+                break; /* DefaultPageJoiner.java:276-278: joinPosition = -1 once the probe row produced a row */
+            }
             join_position = j->position_links[join_position]; /* ArrayPositionLinks.next */
         }
     }

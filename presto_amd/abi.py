@@ -246,7 +246,7 @@ class pa_lookup_join_desc(C.Structure):
         ("output_mem", C.c_int32),
         ("stream", C.c_void_p),
         ("join_type", C.c_int32),
-        ("reserved", C.c_int32),
+        ("output_single_match", C.c_int32),
     ]
 
 

@@ -181,8 +181,9 @@ __global__ __launch_bounds__(256) void k_join_probe_count(JoinKeys build, JoinKe
         }
         head[r] = h;
         i32 c = 0;
-        for (i32 j = h; j != -1; j = links[j]) c++;
-        counts[r] = (c == 0 && probe_outer) ? 1 : c;  // DefaultPageJoiner.outerJoinCurrentPosition: one NULL-extended row
+        if (probe_outer & 2) c = h != -1 ? 1 : 0;  // outputSingleMatch: the head of the chain only
+        else for (i32 j = h; j != -1; j = links[j]) c++;
+        counts[r] = (c == 0 && (probe_outer & 1)) ? 1 : c;  // DefaultPageJoiner.outerJoinCurrentPosition: one NULL-extended row
     }
 }
 
@@ -194,7 +195,7 @@ __global__ __launch_bounds__(256) void k_join_probe_emit(const i32* __restrict__
         const i32 r = (i32)i;
         i32 o = offsets[r];
         const i32 h = head[r];
-        if (h == -1 && probe_outer) {  // LookupJoinPageBuilder.appendNullForBuild
+        if (h == -1 && (probe_outer & 1)) {  // LookupJoinPageBuilder.appendNullForBuild
             probe_idx[o] = r;
             build_pos[o] = -1;
             continue;
@@ -204,6 +205,7 @@ __global__ __launch_bounds__(256) void k_join_probe_emit(const i32* __restrict__
             build_pos[o] = j;
             if (visited) visited[j] = 1;  // OuterLookupSource.appendTo -> positionVisited (same value from every writer)
             o++;
+            if (probe_outer & 2) break;  // outputSingleMatch (DefaultPageJoiner.java:276-278)
         }
     }
 }
@@ -220,11 +222,11 @@ void launch_join_tag_slots(const int32_t* key, int64_t hash_size, const int64_t*
     PA_HIP(hipGetLastError());
 }
 void launch_join_probe_count(const JoinKeys& build, const JoinKeys& probe, const int64_t* probe_hash, int32_t n_probe, const uint64_t* tagged,
-                             uint32_t mask, const int32_t* links, int32_t* head, int32_t* counts, bool probe_outer, hipStream_t s)
+                             uint32_t mask, const int32_t* links, int32_t* head, int32_t* counts, int flags, hipStream_t s)
 {
     if (n_probe <= 0) return;
     hipLaunchKernelGGL(k_join_probe_count, grid_for(n_probe), 256, 0, s, build, probe, (const i64*)probe_hash, n_probe, (const u64*)tagged, mask,
-                       links, head, counts, probe_outer ? 1 : 0);
+                       links, head, counts, flags);
     PA_HIP(hipGetLastError());
 }
 void launch_join_unvisited_flag(const uint8_t* visited, int64_t n, int32_t* partition, hipStream_t s)
@@ -234,11 +236,10 @@ void launch_join_unvisited_flag(const uint8_t* visited, int64_t n, int32_t* part
     PA_HIP(hipGetLastError());
 }
 void launch_join_probe_emit(const int32_t* head, const int32_t* offsets, int32_t n_probe, const int32_t* links, int32_t* probe_idx,
-                            int32_t* build_pos, bool probe_outer, uint8_t* visited, hipStream_t s)
+                            int32_t* build_pos, int flags, uint8_t* visited, hipStream_t s)
 {
     if (n_probe <= 0) return;
-    hipLaunchKernelGGL(k_join_probe_emit, grid_for(n_probe), 256, 0, s, head, offsets, n_probe, links, probe_idx, build_pos, probe_outer ? 1 : 0,
-                       visited);
+    hipLaunchKernelGGL(k_join_probe_emit, grid_for(n_probe), 256, 0, s, head, offsets, n_probe, links, probe_idx, build_pos, flags, visited);
     PA_HIP(hipGetLastError());
 }
 

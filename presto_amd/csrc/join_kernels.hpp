@@ -26,11 +26,11 @@ void launch_join_build(const JoinKeys& build, const int64_t* raw_hash, int32_t n
 // PagesHash.getAddressIndex + chain length per probe row (…/PagesHash.java:158-170, JoinProbe.java:87-117)
 void launch_join_tag_slots(const int32_t* key, int64_t hash_size, const int64_t* raw_hash, uint64_t* tagged, hipStream_t s);
 void launch_join_probe_count(const JoinKeys& build, const JoinKeys& probe, const int64_t* probe_hash, int32_t n_probe, const uint64_t* tagged,
-                             uint32_t mask, const int32_t* links, int32_t* head, int32_t* counts, bool probe_outer, hipStream_t s);
+                             uint32_t mask, const int32_t* links, int32_t* head, int32_t* counts, int flags, hipStream_t s);  // flags: 1 probe-outer, 2 outputSingleMatch
 void launch_join_unvisited_flag(const uint8_t* visited, int64_t n, int32_t* partition, hipStream_t s);
 // DefaultPageJoiner.joinCurrentPosition: (probe position, build position) pairs in emission order
 void launch_join_probe_emit(const int32_t* head, const int32_t* offsets, int32_t n_probe, const int32_t* links, int32_t* probe_idx,
-                            int32_t* build_pos, bool probe_outer, uint8_t* visited, hipStream_t s);
+                            int32_t* build_pos, int flags, uint8_t* visited, hipStream_t s);
 void launch_fill_i32(int32_t* dst, int32_t value, int64_t n, hipStream_t s);
 void launch_rebase_offsets(const int32_t* in, int32_t in_base, int32_t out_base, int64_t n_plus_1, int32_t* out, hipStream_t s);
 

@@ -254,6 +254,7 @@ public:
         PA_REQUIRE(d->join_type >= PA_JOIN_INNER && d->join_type <= PA_JOIN_FULL_OUTER, PA_ERR_INVALID_ARGUMENT, "unknown join type");
         probe_outer_ = d->join_type == PA_JOIN_PROBE_OUTER || d->join_type == PA_JOIN_FULL_OUTER;
         track_visited_ = d->join_type == PA_JOIN_LOOKUP_OUTER || d->join_type == PA_JOIN_FULL_OUTER;
+        probe_flags_ = (probe_outer_ ? 1 : 0) | (d->output_single_match ? 2 : 0);
         needed_.assign(n_probe_channels_, false);
         for (int c : join_channels_) needed_[c] = true;
         for (int c : output_channels_) needed_[c] = true;
@@ -311,7 +312,7 @@ public:
         int32_t* head = static_cast<int32_t*>(head_.ensure((size_t)n * 4));
         int32_t* counts = static_cast<int32_t*>(counts_.ensure((size_t)n * 4));
         timer.begin(s);
-        launch_join_probe_count(ls_->build_keys(), pk, probe_hash, n, ls_->tagged.as<uint64_t>(), ls_->mask, ls_->links.as<int32_t>(), head, counts, probe_outer_, s);
+        launch_join_probe_count(ls_->build_keys(), pk, probe_hash, n, ls_->tagged.as<uint64_t>(), ls_->mask, ls_->links.as<int32_t>(), head, counts, probe_flags_, s);
         launch_exclusive_scan_i32(counts, counts, n, ctl_, scan_temp_.ensure(scan_temp_bytes(n)), s);
         timer.end(s);
         PA_HIP(hipMemcpyAsync(h_ctl_, ctl_, 4, hipMemcpyDeviceToHost, s));
@@ -330,7 +331,7 @@ public:
         const int32_t n = in_.n;
         int32_t* probe_idx = static_cast<int32_t*>(probe_idx_.ensure((size_t)total * 4));
         int32_t* build_pos = static_cast<int32_t*>(build_pos_.ensure((size_t)total * 4));
-        launch_join_probe_emit(head_.as<int32_t>(), counts_.as<int32_t>(), n, ls_->links.as<int32_t>(), probe_idx, build_pos, probe_outer_,
+        launch_join_probe_emit(head_.as<int32_t>(), counts_.as<int32_t>(), n, ls_->links.as<int32_t>(), probe_idx, build_pos, probe_flags_,
                                track_visited_ ? ls_->visited.as<uint8_t>() : nullptr, s);
         // LookupJoinPageBuilder.build: probe output channels by probe index ++ build output channels by build position
         size_t oc = 0;
@@ -406,6 +407,7 @@ private:
     int32_t* h_ctl_ = nullptr;
     int32_t last_matches_ = 0;
     bool finishing_ = false, pending_ = false, probe_outer_ = false, track_visited_ = false;
+    int probe_flags_ = 0;
     std::vector<OutColumn> out_cols_;
     std::vector<pa_column> out_storage_;
 };

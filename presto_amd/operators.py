@@ -424,7 +424,7 @@ def LookupOuterOperator(bridge, probe_types, probe_output_channels, join_type=ab
 
 
 def LookupJoinOperator(bridge, probe_types, probe_join_channels, probe_output_channels, probe_hash_channel=-1,
-                       output_mem=abi.MEM_HOST, stream=None, join_type=abi.JOIN_INNER):
+                       output_mem=abi.MEM_HOST, stream=None, join_type=abi.JOIN_INNER, output_single_match=False):
     """OperatorFactories.innerJoin / probeOuterJoin / lookupOuterJoin / fullOuterJoin (…/operator/OperatorFactories.java:27-84)
     -> LookupJoinOperator; join_type = abi.JOIN_*."""
     d = abi.pa_lookup_join_desc()
@@ -441,6 +441,7 @@ def LookupJoinOperator(bridge, probe_types, probe_join_channels, probe_output_ch
     d.output_mem = output_mem
     d.stream = stream
     d.join_type = join_type
+    d.output_single_match = 1 if output_single_match else 0
     h = C.c_void_p()
     check(lib().pa_lookup_join_create(C.byref(d), bridge._h, C.byref(h)))
     return Operator(h, [types, jc, oc, bridge])

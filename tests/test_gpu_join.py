@@ -202,3 +202,42 @@ def test_outer_joins_match_oracle(gpu, oracle, join_type, device_output):
     assert got[2] == exp[2]
     if exp[2] is not None:
         assert len(exp[2]) > 100
+
+
+@pytest.mark.parametrize("join_type", [abi.JOIN_INNER, abi.JOIN_PROBE_OUTER, abi.JOIN_FULL_OUTER])
+def test_output_single_match(gpu, oracle, join_type):
+    """LookupJoinOperatorFactory.outputSingleMatch (DefaultPageJoiner.java:276-278; the semi-join-like shape the planner
+    asks for when only the existence of a match matters): one output row per probe row -- the first position of its chain
+    (the chain head is the highest build position, ArrayPositionLinks), NULL-extended rows of the outer joins as usual,
+    and only the emitted build row counts as visited for the lookup-outer side."""
+    from presto_amd.operators import LookupOuterOperator
+    rng = np.random.default_rng(31)
+    types = [abi.BIGINT, abi.BIGINT]
+    build = [Page([Block.bigint(rng.integers(0, 300, 2000), rng.random(2000) < 0.05), Block.bigint(np.arange(2000) + 2000 * k)], 2000) for k in range(3)]
+    probe = [Page([Block.bigint(rng.integers(0, 600, 5000), rng.random(5000) < 0.05), Block.bigint(np.arange(5000))], 5000) for _ in range(2)]
+    bridge = LookupSourceFactory()
+    to_pages(HashBuilderOperator(bridge, types, [0], [0, 1]), build)
+    join = LookupJoinOperator(bridge, types, [0], [0, 1], join_type=join_type, output_single_match=True)
+    got = [r for p in to_pages(join, probe) for r in p.to_rows()]
+    ref = oracle.HashJoin(types, [0], [0, 1])
+    for p in build:
+        ref.add_build_page(p)
+    ref.build()
+    expected = [r for p in probe for r in ref.probe(p, types, [0], [0, 1], join_type=join_type, output_single_match=True)[0].to_rows()]
+    assert got == expected
+    plain = [r for p in probe for r in ref.probe(p, types, [0], [0, 1], join_type=abi.JOIN_INNER)[0].to_rows()]
+    assert len(plain) > 2 * len([r for r in got if r[2] is not None])  # the build side holds ~20 rows per key
+    if join_type == abi.JOIN_FULL_OUTER:
+        outer = [r for p in to_pages(LookupOuterOperator(bridge, types, [0, 1], join_type=join_type), []) for r in p.to_rows()]
+        assert sorted(outer, key=repr) == sorted(ref.outer(types, [0, 1]).to_rows(), key=repr) and len(outer) > 3000
+
+
+def test_inner_join_with_output_single_match_kat(gpu, oracle):
+    """TestHashJoinOperator.testInnerJoinWithOutputSingleMatch (…/operator/join/TestHashJoinOperator.java:733-767):
+    build a, a, b; probe a, b, c -> (a, a), (b, b)"""
+    types = [abi.VARCHAR]
+    bridge = LookupSourceFactory()
+    to_pages(HashBuilderOperator(bridge, types, [0], [0]), [Page([Block.varchar([b"a", b"a", b"b"])], 3)])
+    join = LookupJoinOperator(bridge, types, [0], [0], output_single_match=True)
+    got = [r for p in to_pages(join, [Page([Block.varchar([b"a", b"b", b"c"])], 3)]) for r in p.to_rows()]
+    assert got == [(b"a", b"a"), (b"b", b"b")]

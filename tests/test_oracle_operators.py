@@ -387,3 +387,13 @@ def test_dynamic_filter_source_kats(oracle, kat):
     op.finish()
     got = "all" if op.predicate == [] else op.predicate
     assert got == expected
+
+
+def test_join_output_single_match_kat(oracle):
+    """TestHashJoinOperator.testInnerJoinWithOutputSingleMatch (…/operator/join/TestHashJoinOperator.java:733-767):
+    build a, a, b; probe a, b, c -> (a, a), (b, b)"""
+    j = oracle.HashJoin([abi.VARCHAR], [0], [0])
+    j.add_build_page(Page([Block.varchar([b"a", b"a", b"b"])], 3))
+    j.build()
+    out, pi, bi = j.probe(Page([Block.varchar([b"a", b"b", b"c"])], 3), [abi.VARCHAR], [0], [0], output_single_match=True)
+    assert out.to_rows() == [(b"a", b"a"), (b"b", b"b")] and pi.tolist() == [0, 1]
