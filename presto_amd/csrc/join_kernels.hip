@@ -187,7 +187,7 @@ __global__ __launch_bounds__(256) void k_join_probe_count(JoinKeys build, JoinKe
     }
 }
 
-__global__ __launch_bounds__(256) void k_join_probe_emit(const i32* __restrict__ head, const i32* __restrict__ offsets, i32 n_probe,
+__global__ __launch_bounds__(256) void k_join_probe_emit(const i32* __restrict__ head, const i32* __restrict__ offsets, i32 n_probe, i32 total,
                                                          const i32* __restrict__ links, i32* __restrict__ probe_idx, i32* __restrict__ build_pos,
                                                          int probe_outer, u8* __restrict__ visited)
 {
@@ -195,20 +195,105 @@ __global__ __launch_bounds__(256) void k_join_probe_emit(const i32* __restrict__
         const i32 r = (i32)i;
         i32 o = offsets[r];
         const i32 h = head[r];
-        if (h == -1 && (probe_outer & 1)) {  // LookupJoinPageBuilder.appendNullForBuild
-            probe_idx[o] = r;
-            build_pos[o] = -1;
+        if (h == -1) {
+            if (probe_outer & 1) {  // LookupJoinPageBuilder.appendNullForBuild
+                probe_idx[o] = r;
+                build_pos[o] = -1;
+            }
             continue;
         }
-        for (i32 j = h; j != -1; j = links[j]) {
-            probe_idx[o] = r;
-            build_pos[o] = j;
+        // the count pass knows how many rows this probe row emits (1 under outputSingleMatch, DefaultPageJoiner.java:276-278):
+        // the chain is followed only while more are due, so a unique key never touches positionLinks
+        const i32 cnt = ((r + 1 < n_probe) ? offsets[r + 1] : total) - o;
+        i32 j = h;
+        for (i32 k = 0; k < cnt; k++) {
+            probe_idx[o + k] = r;
+            build_pos[o + k] = j;
             if (visited) visited[j] = 1;  // OuterLookupSource.appendTo -> positionVisited (same value from every writer)
-            o++;
-            if (probe_outer & 2) break;  // outputSingleMatch (DefaultPageJoiner.java:276-278)
+            if (k + 1 < cnt) j = links[j];
         }
     }
 }
+
+__device__ __forceinline__ u64 join_key_bits(const JoinCol& c, i32 r)
+{
+    return c.type == PA_BIGINT ? (u64)((const i64*)c.values)[r] : (u64)(i64)((const i32*)c.values)[r];  // INTEGER / DATE sign-extended
+}
+
+// The probe-side table is the lookup structure only -- PagesHash.key[] (the reference's layout, fill 0.75) stays what the
+// build made.  It has its own size (load <= 1/2: an unsuccessful linear probe visits ~2.5 slots instead of ~8.5 at 0.75,
+// and most probe rows of a selective join are unsuccessful) and is filled from the occupied slots of key[]: one entry per
+// distinct key, so inserting needs no key comparison.
+__global__ __launch_bounds__(256) void k_join_key_slots_clear(JoinKeySlot* __restrict__ slots, i64 size)
+{
+    for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < size; i += (i64)gridDim.x * 256) {
+        JoinKeySlot s;
+        s.key = 0ULL;
+        s.head = -1;
+        s.next = -1;
+        slots[i] = s;
+    }
+}
+__global__ __launch_bounds__(256) void k_join_key_slots(const i32* __restrict__ key, i64 hash_size, JoinCol build_key, const i64* __restrict__ raw_hash,
+                                                        const i32* __restrict__ links, JoinKeySlot* slots, u32 mask)
+{
+    for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < hash_size; i += (i64)gridDim.x * 256) {
+        const i32 p = key[i];
+        if (p == -1) continue;
+        u32 pos = (u32)pa_murmur3_fmix((u64)raw_hash[p]) & mask;
+        while (atomicCAS(&slots[pos].head, -1, p) != -1) pos = (pos + 1) & mask;  // load <= 1/2: a free slot exists
+        slots[pos].key = join_key_bits(build_key, p);
+        slots[pos].next = links[p];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_join_probe_count_keyed(JoinCol probe_key, const i64* __restrict__ probe_hash, i32 n_probe,
+                                                                const JoinKeySlot* __restrict__ slots, u32 mask, const i32* __restrict__ links,
+                                                                i32* __restrict__ head, i32* __restrict__ counts, int flags)
+{
+    for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < n_probe; i += (i64)gridDim.x * 256) {
+        const i32 r = (i32)i;
+        i32 h = -1, nxt = -1;
+        if (!jcol_is_null(probe_key, r)) {  // JoinProbe.java:89-91
+            const u64 v = join_key_bits(probe_key, r);
+            const i64 raw = probe_hash ? probe_hash[r] : pa_hash_bigint((i64)v);  // 31 * 0 + hash(value): one channel
+            // linear probing, fetched a 64-byte line (4 slots) at a time: the wave waits for its longest probe sequence, and a
+            // sequence of k slots costs ceil(k / 4) memory round trips instead of k
+            u32 pos = (u32)pa_murmur3_fmix((u64)raw) & mask;
+            const uint4* lines = (const uint4*)slots;
+            bool done = false;
+            for (u32 seen = 0; !done && seen <= mask;) {
+                const u32 base = pos & ~3u, first = pos & 3u;
+                uint4 q[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) q[k] = lines[base + k];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    if (done || (u32)k < first) continue;
+                    const i32 cur = (i32)q[k].z;
+                    if (cur == -1) done = true;
+                    else if ((((u64)q[k].y << 32) | (u64)q[k].x) == v) {
+                        h = cur;
+                        nxt = (i32)q[k].w;
+                        done = true;
+                    }
+                }
+                seen += 4u - first;
+                pos = (base + 4u) & mask;
+            }
+        }
+        head[r] = h;
+        i32 c = 0;
+        if (h != -1) {
+            c = 1;
+            if (!(flags & 2)) {
+                for (i32 j = nxt; j != -1; j = links[j]) c++;
+            }
+        }
+        counts[r] = (c == 0 && (flags & 1)) ? 1 : c;  // DefaultPageJoiner.outerJoinCurrentPosition: one NULL-extended row
+    }
+}
+
 
 // partition 0 = build positions never visited (the rows LookupOuterOperator emits), 1 = visited
 __global__ __launch_bounds__(256) void k_join_unvisited_flag(const u8* __restrict__ visited, i64 n, i32* __restrict__ partition)
@@ -235,11 +320,26 @@ void launch_join_unvisited_flag(const uint8_t* visited, int64_t n, int32_t* part
     hipLaunchKernelGGL(k_join_unvisited_flag, grid_for(n), 256, 0, s, visited, (i64)n, partition);
     PA_HIP(hipGetLastError());
 }
-void launch_join_probe_emit(const int32_t* head, const int32_t* offsets, int32_t n_probe, const int32_t* links, int32_t* probe_idx,
+void launch_join_probe_emit(const int32_t* head, const int32_t* offsets, int32_t n_probe, int32_t total, const int32_t* links, int32_t* probe_idx,
                             int32_t* build_pos, int flags, uint8_t* visited, hipStream_t s)
 {
     if (n_probe <= 0) return;
-    hipLaunchKernelGGL(k_join_probe_emit, grid_for(n_probe), 256, 0, s, head, offsets, n_probe, links, probe_idx, build_pos, flags, visited);
+    hipLaunchKernelGGL(k_join_probe_emit, grid_for(n_probe), 256, 0, s, head, offsets, n_probe, total, links, probe_idx, build_pos, flags, visited);
+    PA_HIP(hipGetLastError());
+}
+void launch_join_key_slots(const int32_t* key, int64_t hash_size, const JoinCol& build_key, const int64_t* raw_hash, const int32_t* links,
+                           JoinKeySlot* slots, uint32_t slots_mask, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_join_key_slots_clear, grid_for((int64_t)slots_mask + 1), 256, 0, s, slots, (i64)slots_mask + 1);
+    hipLaunchKernelGGL(k_join_key_slots, grid_for(hash_size), 256, 0, s, key, (i64)hash_size, build_key, (const i64*)raw_hash, links, slots, slots_mask);
+    PA_HIP(hipGetLastError());
+}
+void launch_join_probe_count_keyed(const JoinCol& probe_key, const int64_t* probe_hash, int32_t n_probe, const JoinKeySlot* slots, uint32_t mask,
+                                   const int32_t* links, int32_t* head, int32_t* counts, int flags, hipStream_t s)
+{
+    if (n_probe <= 0) return;
+    hipLaunchKernelGGL(k_join_probe_count_keyed, grid_for(n_probe), 256, 0, s, probe_key, (const i64*)probe_hash, n_probe, slots, mask, links, head,
+                       counts, flags);
     PA_HIP(hipGetLastError());
 }
 

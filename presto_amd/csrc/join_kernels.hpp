@@ -27,9 +27,23 @@ void launch_join_build(const JoinKeys& build, const int64_t* raw_hash, int32_t n
 void launch_join_tag_slots(const int32_t* key, int64_t hash_size, const int64_t* raw_hash, uint64_t* tagged, hipStream_t s);
 void launch_join_probe_count(const JoinKeys& build, const JoinKeys& probe, const int64_t* probe_hash, int32_t n_probe, const uint64_t* tagged,
                              uint32_t mask, const int32_t* links, int32_t* head, int32_t* counts, int flags, hipStream_t s);  // flags: 1 probe-outer, 2 outputSingleMatch
+// Joins on one BIGINT / INTEGER / DATE key: the probe-side table holds the key itself next to the chain head and the head's
+// link (16 B per slot), so a probe row costs ONE random access -- no tag, no visit to the build key column, and no visit to
+// positionLinks unless the key really has duplicates.  probe_hash may be null: the raw hash (AbstractLongType.hash of the
+// value, combined as InterpretedHashGenerator does for one channel) is then computed in the kernel.
+struct JoinKeySlot {
+    uint64_t key;
+    int32_t head;   // build position, -1 = empty slot
+    int32_t next;   // positionLinks[head]
+};
+// slots_mask + 1 = size of the probe-side table: a power of two >= 2 x the distinct keys (the caller uses 2 x build rows)
+void launch_join_key_slots(const int32_t* key, int64_t hash_size, const JoinCol& build_key, const int64_t* raw_hash, const int32_t* links,
+                           JoinKeySlot* slots, uint32_t slots_mask, hipStream_t s);
+void launch_join_probe_count_keyed(const JoinCol& probe_key, const int64_t* probe_hash, int32_t n_probe, const JoinKeySlot* slots, uint32_t mask,
+                                   const int32_t* links, int32_t* head, int32_t* counts, int flags, hipStream_t s);
 void launch_join_unvisited_flag(const uint8_t* visited, int64_t n, int32_t* partition, hipStream_t s);
 // DefaultPageJoiner.joinCurrentPosition: (probe position, build position) pairs in emission order
-void launch_join_probe_emit(const int32_t* head, const int32_t* offsets, int32_t n_probe, const int32_t* links, int32_t* probe_idx,
+void launch_join_probe_emit(const int32_t* head, const int32_t* offsets, int32_t n_probe, int32_t total, const int32_t* links, int32_t* probe_idx,
                             int32_t* build_pos, int flags, uint8_t* visited, hipStream_t s);
 void launch_fill_i32(int32_t* dst, int32_t value, int64_t n, hipStream_t s);
 void launch_rebase_offsets(const int32_t* in, int32_t in_base, int32_t out_base, int64_t n_plus_1, int32_t* out, hipStream_t s);

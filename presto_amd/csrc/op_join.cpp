@@ -37,6 +37,9 @@ struct LookupSourceImpl {
     std::vector<int> join_channels, output_channels;
     int hash_channel = -1;
     DevBuf key, links, raw_hash, slot_of, tagged;
+    DevBuf key_slots;           // JoinKeySlot[hash_size] when the join key is one BIGINT / INTEGER / DATE column (else `tagged`)
+    bool keyed = false;
+    uint32_t probe_mask = 0;    // size - 1 of key_slots
     DevBuf visited;  // OuterPositionTracker.visitedPositions: 1 B per build position, written by LOOKUP_OUTER / FULL_OUTER probes
     uint32_t mask = 0;
     std::atomic<bool> built{false};
@@ -196,8 +199,19 @@ public:
         timer.begin(s);
         launch_join_build(bk, ls_->raw_hash.as<int64_t>(), n, ls_->key.as<int32_t>(), ls_->mask, ls_->slot_of.as<int32_t>(), ls_->links.as<int32_t>(),
                           ctl_, s);
-        launch_join_tag_slots(ls_->key.as<int32_t>(), (int64_t)hash_size, ls_->raw_hash.as<int64_t>(),
-                              static_cast<uint64_t*>(ls_->tagged.ensure((size_t)hash_size * 8)), s);
+        ls_->keyed = bk.ncols == 1 && (bk.col[0].type == PA_BIGINT || bk.col[0].type == PA_INTEGER || bk.col[0].type == PA_DATE);
+        if (ls_->keyed) {
+            uint64_t slots = 1024;
+            while (slots < 2 * (uint64_t)std::max(n, 1)) slots <<= 1;
+            PA_REQUIRE(slots <= (1ULL << 31), PA_ERR_INSUFFICIENT_RESOURCES, "join build side too large");
+            ls_->probe_mask = (uint32_t)(slots - 1);
+            launch_join_key_slots(ls_->key.as<int32_t>(), (int64_t)hash_size, bk.col[0], ls_->raw_hash.as<int64_t>(), ls_->links.as<int32_t>(),
+                                  static_cast<JoinKeySlot*>(ls_->key_slots.ensure((size_t)slots * sizeof(JoinKeySlot))), ls_->probe_mask, s);
+        }
+        else {
+            launch_join_tag_slots(ls_->key.as<int32_t>(), (int64_t)hash_size, ls_->raw_hash.as<int64_t>(),
+                                  static_cast<uint64_t*>(ls_->tagged.ensure((size_t)hash_size * 8)), s);
+        }
         PA_HIP(hipMemsetAsync(ls_->visited.ensure((size_t)std::max(n, 1)), 0, (size_t)std::max(n, 1), s));
         timer.end(s);
         int32_t err = 0;
@@ -212,7 +226,7 @@ public:
     bool is_finished() override { return finishing_; }
     int64_t memory_bytes() override
     {
-        int64_t b = (int64_t)(ls_->key.capacity() + ls_->links.capacity() + ls_->raw_hash.capacity() + ls_->slot_of.capacity() + ls_->tagged.capacity());
+        int64_t b = (int64_t)(ls_->key.capacity() + ls_->links.capacity() + ls_->raw_hash.capacity() + ls_->slot_of.capacity() + ls_->tagged.capacity() + ls_->key_slots.capacity());
         for (const auto& c : ls_->cols) b += (int64_t)(c.values.capacity() + c.offsets.capacity() + c.nulls.capacity());
         return b;
     }
@@ -290,11 +304,11 @@ public:
             pk.col[i].nulls = c.nulls;
             pk.col[i].type = c.type;
         }
-        const int64_t* probe_hash;
+        const int64_t* probe_hash = nullptr;
         if (hash_channel_ >= 0) {
             probe_hash = static_cast<const int64_t*>(in_.cols[hash_channel_].values);
         }
-        else {
+        else if (!ls_->keyed) {
             HashPageArgs ha;
             memset(&ha, 0, sizeof ha);
             for (int i = 0; i < pk.ncols; i++) {
@@ -312,7 +326,14 @@ public:
         int32_t* head = static_cast<int32_t*>(head_.ensure((size_t)n * 4));
         int32_t* counts = static_cast<int32_t*>(counts_.ensure((size_t)n * 4));
         timer.begin(s);
-        launch_join_probe_count(ls_->build_keys(), pk, probe_hash, n, ls_->tagged.as<uint64_t>(), ls_->mask, ls_->links.as<int32_t>(), head, counts, probe_flags_, s);
+        if (ls_->keyed) {  // one integer key: key-in-slot table, raw hash computed in the kernel unless a $hashvalue channel came along
+            launch_join_probe_count_keyed(pk.col[0], probe_hash, n, ls_->key_slots.as<JoinKeySlot>(), ls_->probe_mask, ls_->links.as<int32_t>(), head, counts,
+                                          probe_flags_, s);
+        }
+        else {
+            launch_join_probe_count(ls_->build_keys(), pk, probe_hash, n, ls_->tagged.as<uint64_t>(), ls_->mask, ls_->links.as<int32_t>(), head, counts,
+                                    probe_flags_, s);
+        }
         launch_exclusive_scan_i32(counts, counts, n, ctl_, scan_temp_.ensure(scan_temp_bytes(n)), s);
         timer.end(s);
         PA_HIP(hipMemcpyAsync(h_ctl_, ctl_, 4, hipMemcpyDeviceToHost, s));
@@ -331,7 +352,7 @@ public:
         const int32_t n = in_.n;
         int32_t* probe_idx = static_cast<int32_t*>(probe_idx_.ensure((size_t)total * 4));
         int32_t* build_pos = static_cast<int32_t*>(build_pos_.ensure((size_t)total * 4));
-        launch_join_probe_emit(head_.as<int32_t>(), counts_.as<int32_t>(), n, ls_->links.as<int32_t>(), probe_idx, build_pos, probe_flags_,
+        launch_join_probe_emit(head_.as<int32_t>(), counts_.as<int32_t>(), n, total, ls_->links.as<int32_t>(), probe_idx, build_pos, probe_flags_,
                                track_visited_ ? ls_->visited.as<uint8_t>() : nullptr, s);
         // LookupJoinPageBuilder.build: probe output channels by probe index ++ build output channels by build position
         size_t oc = 0;
