@@ -1449,12 +1449,13 @@ private:
                         uint64_t fell;
                         memcpy(&fell, h_ctl_ + 2, 8);
                         if (fell != 0) PA_HIP(hipMemsetAsync(ctl_ + 2, 0, 8, s));
-                        if (fell > (uint64_t)n / 4) {
-                            mode_ = V_GT;
-                            if (!list && spilled == 0 && offset + n < total) resume_from_ = offset + n;
-                        }
+                        if (fell > (uint64_t)n / 4) mode_ = V_GT;
                     }
-                    if (spilled == 0) break;
+                    if (spilled == 0) {
+                        // (also after replays of spilled rows: the rest of the page must not crawl through the wrong tier)
+                        if (ki.variant == V_LDSH && mode_ == V_GT && !list && offset + n < total) resume_from_ = offset + n;
+                        break;
+                    }
                     PA_HIP(hipMemsetAsync(ctl_ + 6, 0, 4, s));
                     // at least twice the slots (ensure_table doubles its argument)
                     ensure_table(std::max<uint64_t>((uint64_t)gt_cap_ / 2 + 1, groups_upper_ + spilled) + flush_room);
