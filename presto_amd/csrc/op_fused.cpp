@@ -488,13 +488,20 @@ KernelInfo generate(const Spec& s, const std::vector<ChannelLayout>& layout, int
         PA_REQUIRE((size_t)k.nw * kLdsSlots * 64 * 8 <= 64 * 1024, PA_ERR_NOT_SUPPORTED, "too many accumulator words for the LDS variant");
     }
     if (variant == V_LDSH) {
-        // one table per 512-thread workgroup in 64 KB of LDS (two workgroups per CU): tag + key words + accumulator words per slot
+        // one table per workgroup: tag + key words + accumulator words per slot.  A 1024-thread workgroup with 150 of the CU's
+        // 160 KB of LDS (4096 slots for a one-word key and two accumulator words) against two 512-thread workgroups with 62 KB
+        // each, measured over 64 M rows: 300 groups 64 -> 77 G rows/s, 1 K 26 -> 61 G, 2 K 21 -> 45 G (these now fit the
+        // table without the hash-partitioning passes), 20 K 15 -> 18 G, 100 K 13 -> 15 G (fewer, denser partitions)
         const size_t slot_bytes = 8 * (size_t)(1 + std::max(k.w, 1) + k.nw);
-        int lc = 2048;
-        while (lc > 32 && (size_t)lc * slot_bytes > 62 * 1024) lc >>= 1;
-        PA_REQUIRE((size_t)lc * slot_bytes <= 62 * 1024, PA_ERR_NOT_SUPPORTED, "group state too wide for the LDS-table variant");
+        static const size_t budget = [] {
+            const char* e = getenv("PRESTO_AMD_LDSH_KB");
+            return (size_t)(e ? atoi(e) : 150) * 1024;
+        }();
+        int lc = 4096;
+        while (lc > 32 && (size_t)lc * slot_bytes > budget) lc >>= 1;
+        PA_REQUIRE((size_t)lc * slot_bytes <= budget, PA_ERR_NOT_SUPPORTED, "group state too wide for the LDS-table variant");
         k.lc = lc;
-        k.block = 512;
+        k.block = budget > 64 * 1024 ? 1024 : 512;
     }
 
     // ---- assemble the translation unit ----
@@ -1338,7 +1345,7 @@ private:
                 grid = (int)std::min<int64_t>((work + 63) / 64, (int64_t)cus_ * per_cu);
             }
             else if (ki.variant == V_LDSH) {
-                grid = (int)std::min<int64_t>((work + ki.block - 1) / ki.block, (int64_t)cus_ * 2);  // 64 KB of LDS each
+                grid = (int)std::min<int64_t>((work + ki.block - 1) / ki.block, (int64_t)cus_ * (ki.block == 1024 ? 1 : 2));  // LDS per CU: 160 KB
             }
             else {
                 grid = (int)std::min<int64_t>((work + 255) / 256, (int64_t)cus_ * 8);
