@@ -1224,9 +1224,11 @@ private:
     {
         if (!gt_probed_ || getenv("PRESTO_AMD_NO_PARTITIONED")) return false;
         // measured (64 M rows, 16 B/row, uniform keys; steady state per page): 1 K groups 9 -> 26 G rows/s, 8 K 6 -> 18 G,
-        // 100 K 8 -> 11.6 G; beyond ~128 K groups a workgroup's slice holds more groups than its table
+        // 100 K 8 -> 11.6 G; beyond ~400 K groups a workgroup's slice holds more groups than its table takes
         const uint64_t g = groups_upper_;
-        if (g < 256 || g > (1ULL << 17)) return false;
+        // (512 partitions x ~750 groups of a 4096-slot table: measured even with the HBM table at 500 K groups -- 9.9 vs 9.7 G
+        // rows/s -- ahead below -- 300 K: 13.3 vs 9.7 -- and behind above -- 1 M: 6.8 vs 10)
+        if (g < 256 || g > (3ULL << 17)) return false;
         const Compiled* ldsh = nullptr;
         try {
             ldsh = &kernel_for(sig, layout, V_LDSH);
