@@ -218,6 +218,30 @@ static void testJoinAndTopN()
     }
 }
 
+// TestDynamicFilterSourceOperator.testCollectMultipleOperators (:181-207) first operator, then
+// testSingleColumnCollectMinMaxRangeWhenTooManyPositions (:391-406), through the C++ mirror: the pages pass through, the
+// predicate is polled after finish
+static void testDynamicFilterSource()
+{
+    auto op = createDynamicFilterSourceOperator({PA_BIGINT}, {0}, 100, 10 * 1024, 1000000);
+    auto out = runDriver({Page({Block::bigint({1, 2})}), Page({Block::bigint({3, 5})})}, {op.get()});
+    EXPECT(out.size() == 2 && out[0].getPositionCount() == 2 && out[1].getBlock(0).getLong(1) == 5, "dynamic filter: pages must pass through");
+    int32_t isAll = 0;
+    pa_domain domain{};
+    EXPECT(pa_dynamic_filter_poll(op->handle(), &isAll, &domain, 1) == 1 && !isAll, "dynamic filter: predicate ready after finish");
+    EXPECT(domain.kind == PA_DOMAIN_VALUES && domain.value_count == 4, "dynamic filter: 4 distinct values");
+    const int64_t* v = static_cast<const int64_t*>(domain.values.values);
+    EXPECT(domain.value_count == 4 && v[0] == 1 && v[1] == 2 && v[2] == 3 && v[3] == 5, "dynamic filter: values 1, 2, 3, 5");
+
+    std::vector<int64_t> seq;
+    for (int64_t i = 0; i <= 100; i++) seq.push_back(i);
+    auto big = createDynamicFilterSourceOperator({PA_BIGINT}, {0}, 100, 10 * 1024, 1000000);
+    runDriver({Page({Block::bigint(seq)})}, {big.get()});
+    EXPECT(pa_dynamic_filter_poll(big->handle(), &isAll, &domain, 1) == 1 && !isAll && domain.kind == PA_DOMAIN_RANGE, "dynamic filter: range after 101 values");
+    v = static_cast<const int64_t*>(domain.values.values);
+    EXPECT(domain.value_count == 2 && v[0] == 0 && v[1] == 100, "dynamic filter: range [0, 100]");
+}
+
 int main()
 {
     try {
@@ -226,6 +250,7 @@ int main()
         testDivisionByZero();
         testPipeline();
         testJoinAndTopN();
+        testDynamicFilterSource();
         pa_shutdown();
     }
     catch (const std::exception& e) {
