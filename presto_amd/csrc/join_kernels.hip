@@ -146,15 +146,24 @@ void launch_join_build(const JoinKeys& build, const int64_t* raw_hash, int32_t n
     PA_HIP(hipGetLastError());
 }
 
-// Probe-side copy of PagesHash.key[] with the upper half of the mixed hash next to the build position: a probe that
-// meets another key's slot moves on without touching the build rows (the reference's positionToHashes byte filter,
-// PagesHash.java:85-90,182-196, kept inside the slot so that a mismatch costs no second random access).
-__global__ __launch_bounds__(256) void k_join_tag_slots(const i32* __restrict__ key, i64 hash_size, const i64* __restrict__ raw_hash,
-                                                        u64* __restrict__ tagged)
+// Probe-side table for the general case (several key channels, VARCHAR, DOUBLE ...): build position + the upper half of the
+// mixed hash per 8-byte slot, so that a probe that meets another key's slot moves on without touching the build rows (the
+// reference's positionToHashes byte filter, PagesHash.java:85-90,182-196, kept inside the slot).  Like the keyed table it is
+// separate from PagesHash.key[] and has its own size (load <= 1/2), filled from the occupied slots of key[].
+__global__ __launch_bounds__(256) void k_join_tag_slots_clear(u64* __restrict__ tagged, i64 size)
+{
+    for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < size; i += (i64)gridDim.x * 256) tagged[i] = ~0ULL;
+}
+__global__ __launch_bounds__(256) void k_join_tag_slots(const i32* __restrict__ key, i64 hash_size, const i64* __restrict__ raw_hash, u64* tagged,
+                                                        u32 mask)
 {
     for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < hash_size; i += (i64)gridDim.x * 256) {
         const i32 p = key[i];
-        tagged[i] = p == -1 ? ~0ULL : (((u64)pa_murmur3_fmix((u64)raw_hash[p]) & 0xffffffff00000000ULL) | (u64)(u32)p);
+        if (p == -1) continue;
+        const u64 mixed = (u64)pa_murmur3_fmix((u64)raw_hash[p]);
+        const u64 entry = (mixed & 0xffffffff00000000ULL) | (u64)(u32)p;
+        u32 pos = (u32)mixed & mask;
+        while (atomicCAS((unsigned long long*)&tagged[pos], ~0ULL, (unsigned long long)entry) != ~0ULL) pos = (pos + 1) & mask;
     }
 }
 
@@ -166,17 +175,29 @@ __global__ __launch_bounds__(256) void k_join_probe_count(JoinKeys build, JoinKe
         const i32 r = (i32)i;
         i32 h = -1;
         if (!keys_have_null(probe, r)) {  // JoinProbe.java:89-91
+            // linear probing, a 64-byte line (8 slots) per memory round trip
             const u64 mixed = (u64)pa_murmur3_fmix((u64)probe_hash[r]);
             u32 pos = (u32)mixed & mask;
-            for (u32 probes = 0; probes <= mask; probes++) {
-                const u64 t = tagged[pos];
-                const i32 cur = (i32)(u32)t;
-                if (cur == -1) break;
-                if (((t ^ mixed) >> 32) == 0ULL && keys_equal(build, cur, probe, r)) {
-                    h = cur;
-                    break;
+            const ulonglong2* lines = (const ulonglong2*)tagged;
+            bool done = false;
+            for (u32 seen = 0; !done && seen <= mask;) {
+                const u32 base = pos & ~7u, first = pos & 7u;
+                ulonglong2 q[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) q[k] = lines[(base >> 1) + k];
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    if (done || (u32)k < first) continue;
+                    const u64 t = (k & 1) ? q[k >> 1].y : q[k >> 1].x;
+                    const i32 cur = (i32)(u32)t;
+                    if (cur == -1) done = true;
+                    else if (((t ^ mixed) >> 32) == 0ULL && keys_equal(build, cur, probe, r)) {
+                        h = cur;
+                        done = true;
+                    }
                 }
-                pos = (pos + 1) & mask;
+                seen += 8u - first;
+                pos = (base + 8u) & mask;
             }
         }
         head[r] = h;
@@ -301,9 +322,10 @@ __global__ __launch_bounds__(256) void k_join_unvisited_flag(const u8* __restric
     for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < n; i += (i64)gridDim.x * 256) partition[i] = visited[i] ? 1 : 0;
 }
 
-void launch_join_tag_slots(const int32_t* key, int64_t hash_size, const int64_t* raw_hash, uint64_t* tagged, hipStream_t s)
+void launch_join_tag_slots(const int32_t* key, int64_t hash_size, const int64_t* raw_hash, uint64_t* tagged, uint32_t tagged_mask, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_join_tag_slots, grid_for(hash_size), 256, 0, s, key, (i64)hash_size, (const i64*)raw_hash, (u64*)tagged);
+    hipLaunchKernelGGL(k_join_tag_slots_clear, grid_for((int64_t)tagged_mask + 1), 256, 0, s, (u64*)tagged, (i64)tagged_mask + 1);
+    hipLaunchKernelGGL(k_join_tag_slots, grid_for(hash_size), 256, 0, s, key, (i64)hash_size, (const i64*)raw_hash, (u64*)tagged, tagged_mask);
     PA_HIP(hipGetLastError());
 }
 void launch_join_probe_count(const JoinKeys& build, const JoinKeys& probe, const int64_t* probe_hash, int32_t n_probe, const uint64_t* tagged,

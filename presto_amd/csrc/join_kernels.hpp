@@ -24,7 +24,8 @@ struct JoinKeys {
 void launch_join_build(const JoinKeys& build, const int64_t* raw_hash, int32_t n, int32_t* key, uint32_t mask, int32_t* slot_of,
                        int32_t* links, int32_t* err, hipStream_t s);
 // PagesHash.getAddressIndex + chain length per probe row (…/PagesHash.java:158-170, JoinProbe.java:87-117)
-void launch_join_tag_slots(const int32_t* key, int64_t hash_size, const int64_t* raw_hash, uint64_t* tagged, hipStream_t s);
+// tagged_mask + 1 = size of the probe-side table (a power of two >= 2 x build rows, >= 8)
+void launch_join_tag_slots(const int32_t* key, int64_t hash_size, const int64_t* raw_hash, uint64_t* tagged, uint32_t tagged_mask, hipStream_t s);
 void launch_join_probe_count(const JoinKeys& build, const JoinKeys& probe, const int64_t* probe_hash, int32_t n_probe, const uint64_t* tagged,
                              uint32_t mask, const int32_t* links, int32_t* head, int32_t* counts, int flags, hipStream_t s);  // flags: 1 probe-outer, 2 outputSingleMatch
 // Joins on one BIGINT / INTEGER / DATE key: the probe-side table holds the key itself next to the chain head and the head's

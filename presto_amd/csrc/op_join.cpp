@@ -200,17 +200,18 @@ public:
         launch_join_build(bk, ls_->raw_hash.as<int64_t>(), n, ls_->key.as<int32_t>(), ls_->mask, ls_->slot_of.as<int32_t>(), ls_->links.as<int32_t>(),
                           ctl_, s);
         ls_->keyed = bk.ncols == 1 && (bk.col[0].type == PA_BIGINT || bk.col[0].type == PA_INTEGER || bk.col[0].type == PA_DATE);
+        // the probe-side table: its own size (load <= 1/2), whatever PagesHash.key[] -- the reference's layout -- uses
+        uint64_t slots = 1024;
+        while (slots < 2 * (uint64_t)std::max(n, 1)) slots <<= 1;
+        PA_REQUIRE(slots <= (1ULL << 31), PA_ERR_INSUFFICIENT_RESOURCES, "join build side too large");
+        ls_->probe_mask = (uint32_t)(slots - 1);
         if (ls_->keyed) {
-            uint64_t slots = 1024;
-            while (slots < 2 * (uint64_t)std::max(n, 1)) slots <<= 1;
-            PA_REQUIRE(slots <= (1ULL << 31), PA_ERR_INSUFFICIENT_RESOURCES, "join build side too large");
-            ls_->probe_mask = (uint32_t)(slots - 1);
             launch_join_key_slots(ls_->key.as<int32_t>(), (int64_t)hash_size, bk.col[0], ls_->raw_hash.as<int64_t>(), ls_->links.as<int32_t>(),
                                   static_cast<JoinKeySlot*>(ls_->key_slots.ensure((size_t)slots * sizeof(JoinKeySlot))), ls_->probe_mask, s);
         }
         else {
             launch_join_tag_slots(ls_->key.as<int32_t>(), (int64_t)hash_size, ls_->raw_hash.as<int64_t>(),
-                                  static_cast<uint64_t*>(ls_->tagged.ensure((size_t)hash_size * 8)), s);
+                                  static_cast<uint64_t*>(ls_->tagged.ensure((size_t)slots * 8)), ls_->probe_mask, s);
         }
         PA_HIP(hipMemsetAsync(ls_->visited.ensure((size_t)std::max(n, 1)), 0, (size_t)std::max(n, 1), s));
         timer.end(s);
@@ -331,7 +332,7 @@ public:
                                           probe_flags_, s);
         }
         else {
-            launch_join_probe_count(ls_->build_keys(), pk, probe_hash, n, ls_->tagged.as<uint64_t>(), ls_->mask, ls_->links.as<int32_t>(), head, counts,
+            launch_join_probe_count(ls_->build_keys(), pk, probe_hash, n, ls_->tagged.as<uint64_t>(), ls_->probe_mask, ls_->links.as<int32_t>(), head, counts,
                                     probe_flags_, s);
         }
         launch_exclusive_scan_i32(counts, counts, n, ctl_, scan_temp_.ensure(scan_temp_bytes(n)), s);
