@@ -30,7 +30,16 @@ namespace pa {
 namespace {
 
 constexpr int kMaxChannels = 32;
-constexpr int kTileRows = 1024;
+// A workgroup of 256 threads handles kTileQuads x 256 row quads.  More than one quad per thread (fewer, longer workgroups,
+// all loads in flight before the first block scan) was measured SLOWER on MI355X -- page -> page over 2^27 rows, 1 / 2 / 4 / 8
+// quads: Q6 filter 155 / 146 / 147 / 147 G rows/s, Q1 filter (96 % pass) 106 / 92 / 80 / 79 G, Q3 per step 27.8 / 28.5 / 29.1 /
+// 29.0 ms -- so the default stays 1; PRESTO_AMD_FP_QUADS overrides it for experiments.
+static const int kTileQuads = [] {
+    const char* e = getenv("PRESTO_AMD_FP_QUADS");
+    const int q = e ? atoi(e) : 1;
+    return q >= 1 && q <= 8 ? q : 1;
+}();
+static const int kTileRows = 1024 * kTileQuads;
 
 struct FpArgs {  // host mirror of PaFpArgs
     const void* v[kMaxChannels];
@@ -163,35 +172,47 @@ FpKernelInfo generate_fp(const FpSpec& s, const std::vector<ChannelLayout>& layo
         "    const u32 pa_w = blockIdx.x & ~2047u, pa_i = blockIdx.x & 2047u;\n"
         "    const u32 pa_tile = (pa_w + 2048u <= gridDim.x) ? pa_w + ((pa_i & 7u) << 8) + (pa_i >> 3) : blockIdx.x;\n";
 
+    const std::string J = std::to_string(kTileQuads);
     if (s.has_filter) {
         src << "extern \"C\" __global__ __launch_bounds__(256) void pa_fp_count(PaFpArgs a)\n{\n";
         src << prologue.str();
-        src << tile_decl << "    const i64 q = (i64)pa_tile * 256 + threadIdx.x;\n    const i64 row0 = q << 2;\n    u32 bits = 0;\n";
+        src << tile_decl << "    i32 mine = 0;\n";
+        src << "#pragma unroll\n    for (int pa_j = 0; pa_j < " << J << "; pa_j++) {\n";
+        src << "    const i64 q = ((i64)pa_tile * " << J << " + pa_j) * 256 + threadIdx.x;\n    const i64 row0 = q << 2;\n    u32 bits = 0;\n";
         src << "    if (a.vec && row0 + 4 <= a.n) {\n" << vloads.str();
         for (int r = 0; r < 4; r++) src << "        if (pa_sel(a" << vargs[r] << ")) bits |= " << (1 << r) << "u;\n";
         src << "    } else {\n        for (int i = 0; i < 4; i++) {\n            const i64 r = row0 + i;\n"
                "            if (r < a.n) { if (pa_sel(a" << sargs << ")) bits |= 1u << i; }\n        }\n    }\n";
-        src << "    if (row0 < a.n) a.sel4[q] = (u8)bits;\n";
-        src << "    i32 total;\n    (void)pa_block_exclusive_scan_256((i32)__popc(bits), &total);\n";
+        src << "    if (row0 < a.n) a.sel4[q] = (u8)bits;\n    mine += (i32)__popc(bits);\n    }\n";
+        src << "    i32 total;\n    (void)pa_block_exclusive_scan_256(mine, &total);\n";
         src << "    if (threadIdx.x == 0) a.tile_counts[pa_tile] = total;\n}\n\n";
     }
     src << "extern \"C\" __global__ __launch_bounds__(256) void pa_fp_scatter(PaFpArgs a)\n{\n";
     src << prologue.str();
-    src << tile_decl << "    const i64 q = (i64)pa_tile * 256 + threadIdx.x;\n    const i64 row0 = q << 2;\n";
+    src << tile_decl;
     if (s.has_filter) {
-        src << "    const u32 bits = row0 < a.n ? (u32)a.sel4[q] : 0u;\n";
-        src << "    i32 total;\n    i64 rank = (i64)a.tile_offsets[pa_tile] + pa_block_exclusive_scan_256((i32)__popc(bits), &total);\n";
-        src << "    if (bits == 0u) return;\n";
+        // the selection bits of all quads first (one load each), then quad by quad: rank inside the tile by a block scan
+        src << "    u32 allbits[" << J << "];\n#pragma unroll\n    for (int pa_j = 0; pa_j < " << J << "; pa_j++) {\n"
+               "        const i64 q = ((i64)pa_tile * " << J << " + pa_j) * 256 + threadIdx.x;\n"
+               "        allbits[pa_j] = (q << 2) < a.n ? (u32)a.sel4[q] : 0u;\n    }\n";
+        src << "    i64 pa_base = (i64)a.tile_offsets[pa_tile];\n";
+    }
+    src << "#pragma unroll\n    for (int pa_j = 0; pa_j < " << J << "; pa_j++) {\n";
+    src << "    const i64 q = ((i64)pa_tile * " << J << " + pa_j) * 256 + threadIdx.x;\n    const i64 row0 = q << 2;\n";
+    if (s.has_filter) {
+        src << "    const u32 bits = allbits[pa_j];\n";
+        src << "    i32 total;\n    i64 rank = pa_base + pa_block_exclusive_scan_256((i32)__popc(bits), &total);\n    pa_base += total;\n";
+        src << "    if (bits != 0u) {\n";
     }
     else {
-        src << "    if (row0 >= a.n) return;\n    const i64 left = a.n - row0;\n    const u32 bits = left >= 4 ? 15u : ((1u << left) - 1u);\n    i64 rank = row0;\n";
+        src << "    if (row0 < a.n) {\n    const i64 left = a.n - row0;\n    const u32 bits = left >= 4 ? 15u : ((1u << left) - 1u);\n    i64 rank = row0;\n";
     }
     src << "    if (a.vec && row0 + 4 <= a.n) {\n" << vloads.str();
     for (int r = 0; r < 4; r++) {
         src << "        if (bits & " << (1 << r) << "u) { pa_out(a, rank, (i32)(row0 + " << r << ")" << vargs[r] << "); rank++; }\n";
     }
     src << "    } else {\n        for (int i = 0; i < 4; i++) {\n            const i64 r = row0 + i;\n"
-           "            if (r < a.n && (bits & (1u << i))) { pa_out(a, rank, (i32)r" << sargs << "); rank++; }\n        }\n    }\n}\n";
+           "            if (r < a.n && (bits & (1u << i))) { pa_out(a, rank, (i32)r" << sargs << "); rank++; }\n        }\n    }\n    }\n    }\n}\n";
     k.source = src.str();
     return k;
 }
@@ -583,7 +604,7 @@ private:
             }
         }
         launch_dict_filter_sel(ids, a.sel4, n, static_cast<uint8_t*>(sel4_.ensure((size_t)(n + 3) / 4)),
-                               static_cast<int32_t*>(tile_counts_.ensure((size_t)tiles * 4)), s);
+                               static_cast<int32_t*>(tile_counts_.ensure((size_t)tiles * 4)), kTileQuads, s);
         return true;
     }
 

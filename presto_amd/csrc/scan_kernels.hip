@@ -141,21 +141,25 @@ void launch_exclusive_scan_i32(const int32_t* in, int32_t* out, int64_t n, int32
 // ---------------------------------------------------------------------------------------------
 // dictionary-aware filter: selection of the rows from the selection of the dictionary entries
 // ---------------------------------------------------------------------------------------------
+// kFpTileQuads = kTileQuads of op_filter_project.cpp: one workgroup covers that many x 256 row quads
 __global__ __launch_bounds__(256) void k_dict_filter_sel(const i32* __restrict__ ids, const u8* __restrict__ dict_sel4, i64 n, u8* __restrict__ sel4,
-                                                         i32* __restrict__ tile_counts)
+                                                         i32* __restrict__ tile_counts, int kFpTileQuads)
 {
     __shared__ i32 wave_sum[4];
-    const i64 q = (i64)blockIdx.x * 256 + threadIdx.x, row0 = q << 2;
-    u32 bits = 0;
-    for (int i = 0; i < 4; i++) {
-        const i64 r = row0 + i;
-        if (r < n) {
-            const u32 id = ids ? (u32)ids[r] : 0u;
-            if ((dict_sel4[id >> 2] >> (id & 3u)) & 1u) bits |= 1u << i;
+    i32 c = 0;
+    for (int j = 0; j < kFpTileQuads; j++) {
+        const i64 q = ((i64)blockIdx.x * kFpTileQuads + j) * 256 + threadIdx.x, row0 = q << 2;
+        u32 bits = 0;
+        for (int i = 0; i < 4; i++) {
+            const i64 r = row0 + i;
+            if (r < n) {
+                const u32 id = ids ? (u32)ids[r] : 0u;
+                if ((dict_sel4[id >> 2] >> (id & 3u)) & 1u) bits |= 1u << i;
+            }
         }
+        if (row0 < n) sel4[q] = (u8)bits;
+        c += (i32)__popc(bits);
     }
-    if (row0 < n) sel4[q] = (u8)bits;
-    i32 c = (i32)__popc(bits);
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) c += __shfl_xor(c, d, 64);
     if ((threadIdx.x & 63) == 0) wave_sum[threadIdx.x >> 6] = c;
@@ -163,10 +167,11 @@ __global__ __launch_bounds__(256) void k_dict_filter_sel(const i32* __restrict__
     if (threadIdx.x == 0) tile_counts[blockIdx.x] = wave_sum[0] + wave_sum[1] + wave_sum[2] + wave_sum[3];
 }
 
-void launch_dict_filter_sel(const int32_t* ids, const uint8_t* dict_sel4, int64_t n, uint8_t* sel4, int32_t* tile_counts, hipStream_t s)
+void launch_dict_filter_sel(const int32_t* ids, const uint8_t* dict_sel4, int64_t n, uint8_t* sel4, int32_t* tile_counts, int tile_quads, hipStream_t s)
 {
     if (n <= 0) return;
-    hipLaunchKernelGGL(k_dict_filter_sel, (int)((n + 1023) / 1024), 256, 0, s, ids, dict_sel4, (i64)n, sel4, tile_counts);
+    const int64_t tile_rows = 1024 * (int64_t)tile_quads;
+    hipLaunchKernelGGL(k_dict_filter_sel, (int)((n + tile_rows - 1) / tile_rows), 256, 0, s, ids, dict_sel4, (i64)n, sel4, tile_counts, tile_quads);
     PA_HIP(hipGetLastError());
 }
 

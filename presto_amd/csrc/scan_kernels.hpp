@@ -28,7 +28,8 @@ void launch_varwidth_from_ends(const int32_t* ends, int64_t n, int32_t* offsets,
 // DictionaryAwarePageFilter.selectDictionaryPositions (DictionaryAwarePageFilter.java:117-140): the filter's verdict on the
 // dictionary entries (dict_sel4: 4 selection bits per byte, the layout of pa_fp_count) looked up through the ids (null ids =
 // RunLengthEncodedBlock: entry 0 for every row) -> the page's sel4 + selected rows per 1024-row tile
-void launch_dict_filter_sel(const int32_t* ids, const uint8_t* dict_sel4, int64_t n, uint8_t* sel4, int32_t* tile_counts, hipStream_t s);
+// (tile_quads x 1024 rows per tile_counts entry, as the generated kernels of the operator count them)
+void launch_dict_filter_sel(const int32_t* ids, const uint8_t* dict_sel4, int64_t n, uint8_t* sel4, int32_t* tile_counts, int tile_quads, hipStream_t s);
 size_t partition_temp_bytes(int64_t n, int32_t partition_count);
 void launch_partition_positions(const int32_t* partition, int64_t n, int32_t partition_count, int32_t* out_positions,
                                 int64_t* out_counts_dev, void* temp, hipStream_t s);
