@@ -22,7 +22,8 @@ def one(directory, *patterns):
     """First file under `directory` (any depth) matching one of the patterns: rocprofv3 writes CSVs directly, or a
     rocpd database that `rocpd2csv` / `rocpd2summary --format csv` turn into the same tables."""
     for pattern in patterns:
-        hits = sorted(glob.glob(os.path.join(directory, "**", pattern), recursive=True))
+        # (gpurun merges every run's files into the same local directory: take the newest)
+        hits = sorted(glob.glob(os.path.join(directory, "**", pattern), recursive=True), key=os.path.getmtime, reverse=True)
         if hits:
             return hits[0]
     raise SystemExit("no %s under %s" % (" / ".join(patterns), directory))
