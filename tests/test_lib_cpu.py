@@ -101,3 +101,25 @@ def test_unsupported_shapes_report_not_supported():
     assert lib().pa_codegen_compile_fused(C.byref(d), -1) == abi.ERR_NOT_SUPPORTED
     d, keep = fused_aggregation_desc([abi.DOUBLE], None, [field(0, abi.DOUBLE)], [], [(abi.AGG_MAX, 0, abi.DOUBLE)])
     assert lib().pa_codegen_compile_fused(C.byref(d), -1) > 0
+
+
+def test_header_is_plain_c():
+    """The boundary is a C ABI: include/presto_amd.h must compile as C99 (what a JNI shim written in C includes), and a C
+    translation unit that references every declared function must link against libpresto_amd.so."""
+    import subprocess
+    import tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    header = os.path.join(root, "include", "presto_amd.h")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-fsyntax-only", "-x", "c", header], check=True)
+    names = sorted(set(re.findall(r"\b(pa_[a-z0-9_]+)\s*\(", open(header).read())) - {"pa_column"})
+    with tempfile.TemporaryDirectory() as d:
+        src = os.path.join(d, "link_all.c")
+        with open(src, "w") as f:
+            f.write('#include "presto_amd.h"\n#include <stdio.h>\nint main(void) {\n    const void* fns[] = {\n')
+            f.write("".join("        (const void*)%s,\n" % n for n in names))
+            f.write('    };\n    printf("%d\\n", (int)(sizeof fns / sizeof fns[0]));\n    return 0;\n}\n')
+        exe = os.path.join(d, "link_all")
+        lib_dir = os.path.join(root, "presto_amd")
+        subprocess.run(["gcc", "-std=c99", "-I", os.path.join(root, "include"), src, "-L", lib_dir, "-lpresto_amd",
+                        "-Wl,-rpath," + lib_dir, "-Wl,--allow-shlib-undefined", "-o", exe], check=True)
+        assert len(names) > 40
