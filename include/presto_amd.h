@@ -414,6 +414,14 @@ int32_t pa_partition_ids(const int64_t* raw_hash, int32_t position_count, int32_
  * position order inside each partition (PartitioningExchanger.java:59-82), out_counts[partition_count]. */
 int32_t pa_partition_positions(const int32_t* partition, int32_t position_count, int32_t partition_count,
                                int32_t* out_positions, int64_t* out_counts_host, void* stream);
+/* The rows of flat columns physically regrouped by partition id in one pass (an LDS-staged multisplit: coalesced reads AND
+ * writes, where pa_partition_positions + pa_gather_flat pay a cache line per row and column): out_columns[c] holds the
+ * elements of in_columns[c] (elem_bytes[c] = 1, 4 or 8) with partition 0 first, then partition 1 ...; the same permutation
+ * for every column; the order of the rows INSIDE a partition is unspecified -- for consumers that do not care (the
+ * hash-partitioned aggregation); an exchange that must keep the reference's row order uses pa_partition_positions.
+ * All pointers are device pointers; out_counts_host[partition_count]. */
+int32_t pa_partition_columns(const int32_t* partition, int32_t position_count, int32_t partition_count, const void* const* in_columns,
+                             void* const* out_columns, const int32_t* elem_bytes, int32_t column_count, int64_t* out_counts_host, void* stream);
 /* Block.copyPositions for a flat column: dst[i] = src[positions[i]]. */
 int32_t pa_gather_flat(const void* src, int32_t elem_bytes, const int32_t* positions, int32_t count,
                        void* dst, void* stream);

@@ -629,6 +629,31 @@ int32_t pa_partition_positions(const int32_t* partition, int32_t position_count,
     });
 }
 
+int32_t pa_partition_columns(const int32_t* partition, int32_t position_count, int32_t partition_count, const void* const* in_columns,
+                             void* const* out_columns, const int32_t* elem_bytes, int32_t column_count, int64_t* out_counts_host, void* stream)
+{
+    return guarded([&]() -> int32_t {
+        PA_REQUIRE(partition != nullptr && out_counts_host != nullptr && position_count >= 0, PA_ERR_INVALID_ARGUMENT, "null argument");
+        PA_REQUIRE(column_count >= 0 && column_count <= kMsplitMaxCols && (column_count == 0 || (in_columns && out_columns && elem_bytes)),
+                   PA_ERR_INVALID_ARGUMENT, "bad column arguments");
+        require_device();
+        hipStream_t s = (hipStream_t)stream;
+        std::vector<MsplitCol> cols((size_t)column_count);
+        for (int32_t c = 0; c < column_count; c++) {
+            cols[c].in = in_columns[c];
+            cols[c].out = out_columns[c];
+            cols[c].width = elem_bytes[c];
+        }
+        DevBuf temp, counts;
+        temp.ensure(msplit_temp_bytes(position_count, partition_count));
+        counts.ensure((size_t)partition_count * 8);
+        launch_msplit(partition, position_count, partition_count, cols.data(), column_count, counts.as<int64_t>(), temp.ptr(), s);
+        PA_HIP(hipMemcpyAsync(out_counts_host, counts.ptr(), (size_t)partition_count * 8, hipMemcpyDeviceToHost, s));
+        PA_HIP(hipStreamSynchronize(s));
+        return PA_OK;
+    });
+}
+
 // ---- code generation without a device (build(), CPU-side tests) ----
 // Writes the generated translation unit of a fused descriptor into buf (NUL terminated) and its cache
 // key into key[17]; returns the needed buffer size.  variant: -1 default, 0 GLOBAL, 1 LDS, 2 GT.

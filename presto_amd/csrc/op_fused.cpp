@@ -744,7 +744,7 @@ KernelInfo generate(const Spec& s, const std::vector<ChannelLayout>& layout, int
             // the workgroup's LDS table then meets the groups of a few partitions only)
             src << "    if (a.list_blocked) {\n        const i64 per = (a.n_list + gridDim.x - 1) / gridDim.x;\n"
                    "        const i64 b0 = (i64)blockIdx.x * per, b1 = b0 + per < a.n_list ? b0 + per : a.n_list;\n"
-                   "        for (i64 i = b0 + threadIdx.x; i < b1; i += " << B << ") {\n            const i64 r = a.row_list[i];\n            pa_row(a, acc, true, (i32)r"
+                   "        for (i64 i = b0 + threadIdx.x; i < b1; i += " << B << ") {\n            const i64 r = a.list_blocked == 2 ? i : (i64)a.row_list[i];\n            pa_row(a, acc, true, (i32)r"
                 << scalar_args(ri, layout) << ");\n        }\n    } else {\n";
             src << "    for (i64 i = t; i < a.n_list; i += T) {\n        const i64 r = a.row_list[i];\n        pa_row(a, acc, true, (i32)r" << scalar_args(ri, layout)
                 << ");\n    }\n    }\n";
@@ -1226,9 +1226,7 @@ private:
         // measured (64 M rows, 16 B/row, uniform keys; steady state per page): 1 K groups 9 -> 26 G rows/s, 8 K 6 -> 18 G,
         // 100 K 8 -> 11.6 G; beyond ~400 K groups a workgroup's slice holds more groups than its table takes
         const uint64_t g = groups_upper_;
-        // (512 partitions x ~750 groups of a 4096-slot table: measured even with the HBM table at 500 K groups -- 9.9 vs 9.7 G
-        // rows/s -- ahead below -- 300 K: 13.3 vs 9.7 -- and behind above -- 1 M: 6.8 vs 10)
-        if (g < 256 || g > (3ULL << 17)) return false;
+        if (g < 256) return false;
         const Compiled* ldsh = nullptr;
         try {
             ldsh = &kernel_for(sig, layout, V_LDSH);
@@ -1238,6 +1236,10 @@ private:
             return false;
         }
         const uint64_t per = std::max(ldsh->info.lc / 8, 8);
+        // at most 512 partitions (+ 1 for filtered rows), each within a quarter of the workgroup's table
+        // up to half a table per partition (with one workgroup per partition, see list_grid_hint_): 700 K groups 17 vs 10 G rows/s
+        // on the HBM table, 1 M groups even
+        if (g > 512ULL * (uint64_t)(ldsh->info.lc / 2)) return false;
         uint64_t p = next_pow2((g + per - 1) / per);
         *partitions = (int)std::min<uint64_t>(std::max<uint64_t>(p, 2), 1023);  // + 1 partition for filtered rows <= 1024
         if (*partitions == 1023) *partitions = 512;
@@ -1274,8 +1276,48 @@ private:
             const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(((n + 3) / 4 + 255) / 256, (int64_t)cus_ * 8));
             timer.begin(s);
             PA_HIP(hipModuleLaunchKernel(hk.kernel.fn, grid, 1, 1, hk.info.block, 1, 1, 0, s, params, nullptr));
-            int32_t* positions = static_cast<int32_t*>(part_pos_.ensure((size_t)n * 4));
             int64_t* counts = static_cast<int64_t*>(part_counts_.ensure((size_t)(partitions + 1) * 8));
+            // (pays only when a slice of two partitions would overfill the table -- 500 K groups: 15 -> 20 G rows/s; below that
+            // the second round of workgroups costs more than the sparser tables save -- 300 K: 24.7 -> 22.9)
+            list_grid_hint_ = (2 * groups_upper_ / (uint64_t)partitions > (uint64_t)lk.info.lc * 3 / 8) ? partitions : 0;
+            // fixed-width inputs: the used columns themselves are regrouped by partition (LDS-staged multisplit, coalesced both
+            // ways) and the LDS-table kernel reads its slice contiguously; with a position list it pays a cache line per row
+            // and column.  VARCHAR inputs keep the position list.
+            bool reorder = !getenv("PRESTO_AMD_NO_MSPLIT");
+            for (int c = 0; c < spec_.n_in && reorder; c++) reorder = !spec_.used_channel[c] || !dp.cols[c].varwidth;
+            if (reorder) {
+                std::vector<MsplitCol> mc;
+                DevPage rp;
+                rp.cols.resize(spec_.n_in);
+                if (reorder_bufs_.empty()) reorder_bufs_.resize((size_t)spec_.n_in * 2);
+                for (int c = 0; c < spec_.n_in; c++) {
+                    if (!spec_.used_channel[c]) continue;
+                    const DevColumn& col = dp.cols[c];
+                    const int w = type_width(col.type);
+                    DevColumn& out = rp.cols[c];
+                    out.type = col.type;
+                    out.values = reorder_bufs_[(size_t)c * 2].ensure((size_t)n * w);
+                    mc.push_back(MsplitCol{static_cast<const char*>(col.values) + offset * w, const_cast<void*>(out.values), w, 0});
+                    if (col.nulls) {
+                        out.nulls = static_cast<const uint8_t*>(reorder_bufs_[(size_t)c * 2 + 1].ensure((size_t)n));
+                        mc.push_back(MsplitCol{col.nulls + offset, const_cast<uint8_t*>(out.nulls), 1, 0});
+                    }
+                }
+                reorder = mc.size() <= (size_t)kMsplitMaxCols;
+                if (reorder) {
+                    launch_msplit(a.part_ids, n, partitions + 1, mc.data(), (int32_t)mc.size(), counts,
+                                  part_temp_.ensure(msplit_temp_bytes(n, partitions + 1)), s);
+                    timer.end(s, false);
+                    int64_t dropped = 0;
+                    PA_HIP(hipMemcpyAsync(&dropped, counts + partitions, 8, hipMemcpyDeviceToHost, s));
+                    PA_HIP(hipStreamSynchronize(s));
+                    rp.n = (int32_t)(n - dropped);  // the filtered rows are the last partition
+                    RowList list{nullptr, n - dropped, 0, n - dropped};
+                    if (list.count > 0) run_page(lk, rp, false, &list);
+                    continue;
+                }
+            }
+            int32_t* positions = static_cast<int32_t*>(part_pos_.ensure((size_t)n * 4));
             launch_partition_positions(a.part_ids, n, partitions + 1, positions, counts, part_temp_.ensure(partition_temp_bytes(n, partitions + 1)), s);
             timer.end(s, false);
             int64_t dropped = 0;
@@ -1338,7 +1380,7 @@ private:
             if (list) {
                 a.row_list = list->rows;
                 a.n_list = list->count;
-                a.list_blocked = 1;
+                a.list_blocked = list->rows ? 1 : 2;  // 2: rows 0 .. count-1 of (reordered) columns, one contiguous slice per workgroup
                 work = list->count;
             }
             int grid;
@@ -1348,6 +1390,9 @@ private:
             }
             else if (ki.variant == V_LDSH) {
                 grid = (int)std::min<int64_t>((work + ki.block - 1) / ki.block, (int64_t)cus_ * (ki.block == 1024 ? 1 : 2));  // LDS per CU: 160 KB
+                // partition-ordered rows: at least one workgroup per partition, so that a workgroup's table meets the groups of
+                // one partition (not of the two or three its slice would span with a workgroup per CU)
+                if (list && list_grid_hint_ > grid) grid = (int)std::min<int64_t>((work + ki.block - 1) / ki.block, (int64_t)list_grid_hint_);
             }
             else {
                 grid = (int)std::min<int64_t>((work + 255) / 256, (int64_t)cus_ * 8);
@@ -1470,6 +1515,7 @@ private:
                     ensure_table(std::max<uint64_t>((uint64_t)gt_cap_ / 2 + 1, groups_upper_ + spilled) + flush_room);
                     FusedArgs r = a;
                     r.n = 0;
+                    if (r.list_blocked == 2) r.list_blocked = 1;  // the spilled rows are a real list
                     r.row_list = spill_[cur].as<int32_t>();
                     r.n_list = spilled;
                     r.spill_rows = static_cast<int32_t*>(spill_[cur ^ 1].ensure((size_t)spilled * 4));
@@ -1558,6 +1604,8 @@ private:
     int32_t out_rows_ = 0;
     std::vector<std::unique_ptr<StringInterner>> interners_;  // per input channel, for Spec::interned channels
     PageStager dict_stager_;
+    int list_grid_hint_ = 0;
+    std::vector<DevBuf> reorder_bufs_;   // per channel: values, NULL flags of the partition-ordered copy of a chunk
     std::vector<DevBuf> dict_key_bufs_;  // per interned channel: uploaded ids, key ids, key NULL flags of a dictionary page
 };
 

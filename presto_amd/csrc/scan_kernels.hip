@@ -315,6 +315,140 @@ void launch_partition_positions(const int32_t* partition, int64_t n, int32_t par
     PA_HIP(hipGetLastError());
 }
 
+// ---------------------------------------------------------------------------------------------
+// multisplit of columns (see scan_kernels.hpp)
+// ---------------------------------------------------------------------------------------------
+constexpr int kMsThreads = 1024, kMsItems = 8, kMsTile = kMsThreads * kMsItems;
+struct MsplitArgs {
+    const i32* part;
+    i64 n, tiles;
+    const i32* offsets;  // exclusive scan of the (partition, tile) counts, partition-major
+    i32 P, ncols;
+    MsplitCol col[kMsplitMaxCols];
+};
+
+__global__ __launch_bounds__(kMsThreads) void k_msplit_count(const i32* __restrict__ part, i64 n, i32 P, i64 tiles, i32* __restrict__ counts)
+{
+    __shared__ i32 hist[1025];
+    for (int i = threadIdx.x; i < P; i += kMsThreads) hist[i] = 0;
+    __syncthreads();
+    const i64 tile0 = (i64)blockIdx.x * kMsTile;
+#pragma unroll
+    for (int i = 0; i < kMsItems; i++) {
+        const i64 row = tile0 + (i64)i * kMsThreads + threadIdx.x;
+        if (row < n) atomicAdd(&hist[part[row]], 1);
+    }
+    __syncthreads();
+    for (int p = threadIdx.x; p < P; p += kMsThreads) counts[(i64)p * tiles + blockIdx.x] = hist[p];
+}
+
+__global__ __launch_bounds__(kMsThreads) void k_msplit_scatter(MsplitArgs a)
+{
+    __shared__ i32 goff[1025], lstart[1025], cursor[1025];
+    __shared__ i32 wave_sums[16];
+    __shared__ unsigned short lpart[kMsTile];
+    __shared__ u64 buf[kMsTile];
+    const i64 tile0 = (i64)blockIdx.x * kMsTile;
+    const i32 tile_rows = (i32)(a.n - tile0 < (i64)kMsTile ? a.n - tile0 : (i64)kMsTile);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // the tile's rows per partition (from the scanned counts) and where each partition starts, globally and inside the tile
+    i32 mine = 0;
+    if ((i32)threadIdx.x < a.P) {
+        const i64 idx = (i64)threadIdx.x * a.tiles + blockIdx.x;
+        const i32 o = a.offsets[idx];
+        const i32 nx = idx + 1 < (i64)a.P * a.tiles ? a.offsets[idx + 1] : (i32)a.n;
+        goff[threadIdx.x] = o;
+        mine = nx - o;
+    }
+    i32 inc = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const i32 o = __shfl_up(inc, off, 64);
+        if (lane >= off) inc += o;
+    }
+    if (lane == 63) wave_sums[wave] = inc;
+    __syncthreads();
+    i32 base = 0;
+    for (int w = 0; w < wave; w++) base += wave_sums[w];
+    if ((i32)threadIdx.x < a.P) {
+        lstart[threadIdx.x] = base + inc - mine;
+        cursor[threadIdx.x] = 0;
+    }
+    __syncthreads();
+    // every row's place in the tile's partition-sorted order
+    unsigned short li[kMsItems];
+#pragma unroll
+    for (int i = 0; i < kMsItems; i++) {
+        const i64 row = tile0 + (i64)i * kMsThreads + threadIdx.x;
+        li[i] = 0;
+        if (row < a.n) {
+            const i32 p = a.part[row];
+            const i32 at = lstart[p] + atomicAdd(&cursor[p], 1);
+            li[i] = (unsigned short)at;
+            lpart[at] = (unsigned short)p;
+        }
+    }
+    __syncthreads();
+    for (int c = 0; c < a.ncols; c++) {
+        const MsplitCol col = a.col[c];
+#pragma unroll
+        for (int i = 0; i < kMsItems; i++) {
+            const i64 row = tile0 + (i64)i * kMsThreads + threadIdx.x;
+            if (row < a.n) {
+                if (col.width == 8) buf[li[i]] = ((const u64*)col.in)[row];
+                else if (col.width == 4) ((u32*)buf)[li[i]] = ((const u32*)col.in)[row];
+                else ((u8*)buf)[li[i]] = ((const u8*)col.in)[row];
+            }
+        }
+        __syncthreads();
+        for (i32 j = threadIdx.x; j < tile_rows; j += kMsThreads) {
+            const i32 p = lpart[j];
+            const i64 dest = (i64)goff[p] + (j - lstart[p]);
+            if (col.width == 8) ((u64*)col.out)[dest] = buf[j];
+            else if (col.width == 4) ((u32*)col.out)[dest] = ((const u32*)buf)[j];
+            else ((u8*)col.out)[dest] = ((const u8*)buf)[j];
+        }
+        __syncthreads();
+    }
+}
+
+size_t msplit_temp_bytes(int64_t n, int32_t partition_count)
+{
+    const int64_t tiles = (n + kMsTile - 1) / kMsTile;
+    return (size_t)(tiles * partition_count) * 4 + scan_temp_bytes(tiles * partition_count) + 64;
+}
+
+void launch_msplit(const int32_t* partition, int64_t n, int32_t partition_count, const MsplitCol* cols, int32_t ncols, int64_t* out_counts_dev,
+                   void* temp, hipStream_t s)
+{
+    PA_REQUIRE(partition_count >= 1 && partition_count <= 1024, PA_ERR_NOT_SUPPORTED, "1..1024 partitions");
+    PA_REQUIRE(ncols >= 0 && ncols <= kMsplitMaxCols, PA_ERR_NOT_SUPPORTED, "too many columns for one multisplit");
+    if (n <= 0) {
+        PA_HIP(hipMemsetAsync(out_counts_dev, 0, (size_t)partition_count * 8, s));
+        return;
+    }
+    const int64_t tiles = (n + kMsTile - 1) / kMsTile;
+    i32* counts = static_cast<i32*>(temp);
+    void* scan_temp = counts + tiles * partition_count;
+    hipLaunchKernelGGL(k_msplit_count, (int)tiles, kMsThreads, 0, s, partition, (i64)n, partition_count, (i64)tiles, counts);
+    launch_exclusive_scan_i32(counts, counts, tiles * partition_count, nullptr, scan_temp, s);
+    MsplitArgs a;
+    memset(&a, 0, sizeof a);
+    a.part = partition;
+    a.n = n;
+    a.tiles = tiles;
+    a.offsets = counts;
+    a.P = partition_count;
+    a.ncols = ncols;
+    for (int c = 0; c < ncols; c++) {
+        PA_REQUIRE(cols[c].width == 1 || cols[c].width == 4 || cols[c].width == 8, PA_ERR_NOT_SUPPORTED, "multisplit moves 1, 4 or 8 byte elements");
+        a.col[c] = cols[c];
+    }
+    hipLaunchKernelGGL(k_msplit_scatter, (int)tiles, kMsThreads, 0, s, a);
+    hipLaunchKernelGGL(k_partition_totals, 1, 1024, 0, s, (const i32*)counts, (i64)tiles, partition_count, (i64)n, (i64*)out_counts_dev);
+    PA_HIP(hipGetLastError());
+}
+
 __global__ __launch_bounds__(256) void k_offsets_append(const i32* __restrict__ src, i64 count, i32 dst_base, i32* __restrict__ dst, int write_first)
 {
     const i32 first = src[0];

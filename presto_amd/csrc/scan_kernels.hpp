@@ -30,6 +30,20 @@ void launch_varwidth_from_ends(const int32_t* ends, int64_t n, int32_t* offsets,
 // RunLengthEncodedBlock: entry 0 for every row) -> the page's sel4 + selected rows per 1024-row tile
 // (tile_quads x 1024 rows per tile_counts entry, as the generated kernels of the operator count them)
 void launch_dict_filter_sel(const int32_t* ids, const uint8_t* dict_sel4, int64_t n, uint8_t* sel4, int32_t* tile_counts, int tile_quads, hipStream_t s);
+// Multisplit of fixed-width columns: the rows of a chunk physically reordered so that every partition is contiguous (order
+// inside a partition unspecified).  A 1024-thread workgroup takes 8192 consecutive rows, sorts them by partition in LDS and
+// writes every column out in runs -- both the reads and the writes are coalesced, unlike a gather through the position list
+// of launch_partition_positions, which costs a cache line per row and column once the partitions are many.
+constexpr int kMsplitMaxCols = 48;
+struct MsplitCol {
+    const void* in;
+    void* out;
+    int32_t width;  // 1, 4 or 8 bytes
+    int32_t pad;
+};
+size_t msplit_temp_bytes(int64_t n, int32_t partition_count);
+void launch_msplit(const int32_t* partition, int64_t n, int32_t partition_count, const MsplitCol* cols, int32_t ncols, int64_t* out_counts_dev,
+                   void* temp, hipStream_t s);
 size_t partition_temp_bytes(int64_t n, int32_t partition_count);
 void launch_partition_positions(const int32_t* partition, int64_t n, int32_t partition_count, int32_t* out_positions,
                                 int64_t* out_counts_dev, void* temp, hipStream_t s);

@@ -102,3 +102,37 @@ def test_varchar_exchange_on_one_rank_over_rccl(gpu, oracle):
         assert np.array_equal(h, oracle.hash_page(Page([Block.bigint(keys), Block.varchar(names)], n), [1]))
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n,parts", [(1, 1), (1000, 3), (8192, 256), (8193, 257), (300001, 513), (2_000_003, 1024), (1 << 22, 64)])
+def test_partition_columns_multisplit(gpu, n, parts):
+    """pa_partition_columns: every column regrouped by partition with ONE permutation -- a partition's rows are contiguous,
+    complete and the same rows in every column (their order inside the partition is free)."""
+    import ctypes as C
+    import torch
+    from presto_amd._lib import check, lib
+    g = torch.Generator(device="cuda").manual_seed(n)
+    part = torch.randint(0, parts, (n,), dtype=torch.int32, device="cuda", generator=g)
+    if parts > 4:
+        part[part == 2] = 3  # an empty partition
+    rowid = torch.arange(n, dtype=torch.int64, device="cuda")
+    c4 = (rowid * 7 + 1).to(torch.int32)
+    c1 = (rowid % 251).to(torch.uint8)
+    cols = [rowid, c4, c1]
+    outs = [torch.empty_like(c) for c in cols]
+    torch.cuda.synchronize()
+    vp = C.c_void_p
+    ins = (vp * 3)(*[c.data_ptr() for c in cols])
+    ous = (vp * 3)(*[c.data_ptr() for c in outs])
+    widths = (C.c_int32 * 3)(8, 4, 1)
+    counts = np.zeros(parts, dtype=np.int64)
+    check(lib().pa_partition_columns(part.data_ptr(), n, parts, ins, ous, widths, 3, counts.ctypes.data, None))
+    expected = torch.bincount(part.long(), minlength=parts).cpu().numpy()
+    assert counts.tolist() == expected.tolist()
+    ids = outs[0]
+    assert torch.equal(outs[1], (ids * 7 + 1).to(torch.int32)) and torch.equal(outs[2], (ids % 251).to(torch.uint8))  # one permutation
+    assert torch.equal(torch.sort(ids).values, rowid)  # a permutation of the rows
+    bounds = np.concatenate([[0], np.cumsum(counts)])
+    got_part = part[ids.long()] if n else part
+    want = torch.repeat_interleave(torch.arange(parts, device="cuda", dtype=torch.int32), torch.tensor(counts, device="cuda"))
+    assert torch.equal(got_part, want) and bounds[-1] == n
