@@ -111,6 +111,60 @@ if "dict" in which:
         dt = timeit(run)
         print("FilterAndProject shipmode IN (MAIL, SHIP), %-42s %.3g rows/s, %d rows out" % (name, rows / dt, run()))
 
+if "next" in which:
+    # the SURVEY 8(f) operators: TopN, OrderBy, DynamicFilterSource over device pages; the page wire format over PCIe
+    import ctypes as C
+    from presto_amd.operators import DynamicFilterSourceOperator, OrderByOperator, TopNOperator
+    from presto_amd.page import deserialize_page, serialize_page
+    g = torch.Generator(device="cuda").manual_seed(5)
+    rows = 1 << 26
+    v = torch.rand(rows, dtype=torch.float64, device="cuda", generator=g)
+    k = torch.randint(0, 1 << 40, (rows,), dtype=torch.int64, device="cuda", generator=g)
+    page = Page([dev_block(abi.DOUBLE, v), dev_block(abi.BIGINT, k)], rows, abi.MEM_DEVICE)
+    def topn():
+        op = TopNOperator([abi.DOUBLE, abi.BIGINT], 100, [0, 1], [abi.DESC_NULLS_LAST, abi.ASC_NULLS_LAST])
+        op.addInput(page); op.finish(); out = op.getOutput(); op.close(); return out.position_count
+    dt = timeit(topn, reps=3)
+    print("TopN 100 of %d rows (DOUBLE desc, BIGINT): %.3g rows/s (%.2f ms)" % (rows, rows / dt, dt * 1e3))
+    srows = 1 << 24
+    spage = Page([Block(abi.DOUBLE, abi.FLAT, srows, values=DeviceBuffer(v.data_ptr(), srows * 8, v)),
+                  Block(abi.BIGINT, abi.FLAT, srows, values=DeviceBuffer(k.data_ptr(), srows * 8, k))], srows, abi.MEM_DEVICE)
+    def orderby():
+        op = OrderByOperator([abi.DOUBLE, abi.BIGINT], [0, 1], [1], [abi.ASC_NULLS_LAST], output_mem=abi.MEM_DEVICE)
+        op.addInput(spage); op.finish(); out = op.getOutput(); n = out.position_count; op.close(); return n
+    dt = timeit(orderby, reps=3)
+    print("OrderBy %d rows by one BIGINT key, 16 B rows: %.3g rows/s (%.2f ms; 8 stable 8-bit radix passes)" % (srows, srows / dt, dt * 1e3))
+    small = torch.randint(0, 5000, (rows,), dtype=torch.int64, device="cuda", generator=g)
+    dpage = Page([dev_block(abi.BIGINT, small), dev_block(abi.DOUBLE, v)], rows, abi.MEM_DEVICE)
+    def dynf():
+        op = DynamicFilterSourceOperator([abi.BIGINT, abi.DOUBLE], [0], 10000, 1 << 20, 1 << 30)
+        op.addInput(dpage); op.getOutput(); op.finish(); p = op.predicate(); op.close(); return len(p[0][1])
+    dt = timeit(dynf, reps=3)
+    print("DynamicFilterSource %d rows, one BIGINT channel with 5000 distinct values (limit 10000): %.3g rows/s (%.2f ms), %d values collected"
+          % (rows, rows / dt, dt * 1e3, dynf()))
+    wrows = 1 << 22
+    wpage = Page([Block(abi.DOUBLE, abi.FLAT, wrows, values=DeviceBuffer(v.data_ptr(), wrows * 8, v)),
+                  Block(abi.BIGINT, abi.FLAT, wrows, values=DeviceBuffer(k.data_ptr(), wrows * 8, k))], wrows, abi.MEM_DEVICE)
+    from presto_amd._lib import check, lib
+    cpage, keep = wpage.to_c()
+    buf = np.zeros(wrows * 16 + 4096, dtype=np.uint8)
+    size = lib().pa_page_serialize(C.byref(cpage), buf.ctypes.data, buf.nbytes, None)  # warm
+    t0 = time.perf_counter()
+    for _ in range(5):
+        size = lib().pa_page_serialize(C.byref(cpage), buf.ctypes.data, buf.nbytes, None)
+    t1 = time.perf_counter()
+    handles = []
+    for _ in range(5):
+        h = C.c_void_p()
+        check(lib().pa_page_deserialize(buf.ctypes.data, size, None, C.byref(h)))
+        handles.append(h)
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    for h in handles:
+        lib().pa_page_buffer_free(h)
+    print("PagesSerde %d rows x 16 B through the C ABI (pageable host buffer): device page -> wire bytes %.1f GB/s, wire bytes -> device page %.1f GB/s"
+          % (wrows, 5 * size / (t1 - t0) / 1e9, 5 * size / (t2 - t1) / 1e9))
+
 if "vagg" in which:
     # VARCHAR(25) keys ("Customer#%09d" + padding, c_name / s_name shape): interned on the device, then grouped by id
     rows, width = 1 << 25, 24
