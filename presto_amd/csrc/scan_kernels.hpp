@@ -44,6 +44,15 @@ struct MsplitCol {
 size_t msplit_temp_bytes(int64_t n, int32_t partition_count);
 void launch_msplit(const int32_t* partition, int64_t n, int32_t partition_count, const MsplitCol* cols, int32_t ncols, int64_t* out_counts_dev,
                    void* temp, hipStream_t s);
+// One STABLE 8-bit LSD radix pass over (key, payload) pairs held as two columns: the pairs regrouped by digit =
+// (key >> shift) & 255, arrival order kept inside a digit.  Same LDS-staged structure as the multisplit (8192-row tiles,
+// coalesced reads and writes); the rank of a row inside its (tile, digit) is the number of earlier rows of the tile with the
+// same digit (wave ballots + per-wave counts).  OrderBy sorts (key image, row id) pairs with it.
+size_t radix_pass_temp_bytes(int64_t n);
+void launch_radix_pass_stable(const uint64_t* keys_in, const int32_t* payload_in, int64_t n, int shift, uint64_t* keys_out, int32_t* payload_out,
+                              void* temp, hipStream_t s);
+// out[0] = OR of all keys, out[1] = AND of all keys (device memory, 16 bytes): a byte in which they agree is constant
+void launch_key_or_and(const uint64_t* keys, int64_t n, uint64_t* out, hipStream_t s);
 size_t partition_temp_bytes(int64_t n, int32_t partition_count);
 void launch_partition_positions(const int32_t* partition, int64_t n, int32_t partition_count, int32_t* out_positions,
                                 int64_t* out_counts_dev, void* temp, hipStream_t s);
