@@ -452,7 +452,13 @@ KernelInfo generate(const Spec& s, const std::vector<ChannelLayout>& layout, int
             ccond = "(" + cond + " && !" + x.n + ")";
             cntkey = "cnt|" + xkey + "|" + ckey;
         }
-        int cw = word(W_CNT, ccond, "1", cntkey);
+        // sum / min / max only ask "was there any input?" -- and a GROUP exists because a row created it: with a non-null
+        // input and no mask the answer is always yes, so the group needs no count word (one HBM atomic less per row on the
+        // table tier: Q3's sum(revenue) keeps ONE accumulator word).  -1 = "counts as 1" for every consumer of agg_words.
+        // (Step.PARTIAL keeps the real count: its [count, value] state channels are part of the boundary, include/presto_amd.h)
+        const bool implicit_count = s.step == PA_STEP_SINGLE && !s.group_proj.empty() && ag.mask_channel < 0 && !x.nullable() &&
+                                    (ag.fn == PA_AGG_SUM || ag.fn == PA_AGG_MIN || ag.fn == PA_AGG_MAX);
+        int cw = implicit_count ? -1 : word(W_CNT, ccond, "1", cntkey);
         int vw = -1;
         if (ag.fn == PA_AGG_SUM && x.type != PA_DOUBLE) {
             vw = word(W_SUMI, ccond, x.v, "sumi|" + xkey + "|" + ckey);
@@ -2010,7 +2016,8 @@ void FusedAggregationOperator::build_output()
                 cc.type = PA_BIGINT;
                 host_nulls[col].assign(groups ? groups : 1, 0);
                 host_cols[col].resize((size_t)groups * 8);
-                for (int64_t g = 0; g < groups; g++) memcpy(&host_cols[col][(size_t)g * 8], &words[(size_t)g * nw_ + cw], 8);
+                const uint64_t one = 1;
+                for (int64_t g = 0; g < groups; g++) memcpy(&host_cols[col][(size_t)g * 8], cw >= 0 ? &words[(size_t)g * nw_ + cw] : &one, 8);
                 cc.has_nulls = false;
                 col++;
             }
@@ -2025,7 +2032,7 @@ void FusedAggregationOperator::build_output()
             bool any_null = false;
             for (int64_t g = 0; g < groups; g++) {
                 const uint64_t* ww = &words[(size_t)g * nw_];
-                if (ww[cw] == 0) {
+                if (cw >= 0 && ww[cw] == 0) {
                     nulls[g] = 1;
                     any_null = true;
                     continue;
@@ -2050,7 +2057,11 @@ void FusedAggregationOperator::build_output()
                 auto& data = host_cols[col];
                 host_nulls[col].assign(groups ? groups : 1, 0);
                 data.resize((size_t)groups * 8);
-                for (int64_t g = 0; g < groups; g++) memcpy(&data[(size_t)g * 8], &words[(size_t)g * nw_ + (part == 0 ? cw : vw)], 8);
+                const uint64_t one = 1;  // an implicit count (cw == -1) travels as 1: only "zero or not" matters to sum / min / max
+                for (int64_t g = 0; g < groups; g++) {
+                    const int wi = part == 0 ? cw : vw;
+                    memcpy(&data[(size_t)g * 8], wi >= 0 ? &words[(size_t)g * nw_ + wi] : &one, 8);
+                }
                 oc.has_nulls = false;
             }
             continue;
@@ -2067,7 +2078,7 @@ void FusedAggregationOperator::build_output()
         data.resize((size_t)groups * width);
         for (int64_t g = 0; g < groups; g++) {
             const uint64_t* ww = &words[(size_t)g * nw_];
-            int64_t count = (int64_t)ww[cw];
+            int64_t count = cw >= 0 ? (int64_t)ww[cw] : 1;
             uint64_t bits = 0;
             switch (ag.fn) {
                 case PA_AGG_COUNT_STAR:

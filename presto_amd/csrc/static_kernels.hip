@@ -382,14 +382,15 @@ __device__ __forceinline__ void gt_emit_slot(const GtEmitArgs& a, u64 i, u64 g)
                 break;
             }
             case GT_EMIT_HASH: bits = (u64)row_hash; break;
-            case GT_EMIT_STATE: bits = wd[(u64)col.word * a.cap + i]; break;
+            // (a count word of -1 is the implicit count of op_fused.cpp: it counts as 1)
+            case GT_EMIT_STATE: bits = col.word >= 0 ? wd[(u64)col.word * a.cap + i] : 1ULL; break;
             case GT_EMIT_COUNT: bits = wd[(u64)col.cw * a.cap + i]; break;
             case GT_EMIT_SUM:
-                if (wd[(u64)col.cw * a.cap + i] == 0ULL) is_null = true;
+                if (col.cw >= 0 && wd[(u64)col.cw * a.cap + i] == 0ULL) is_null = true;
                 else bits = wd[(u64)col.vw * a.cap + i];
                 break;
             case GT_EMIT_MINMAX: {
-                if (wd[(u64)col.cw * a.cap + i] == 0ULL) is_null = true;
+                if (col.cw >= 0 && wd[(u64)col.cw * a.cap + i] == 0ULL) is_null = true;
                 else {
                     u64 img = wd[(u64)col.vw * a.cap + i];
                     if (col.shift) img = ~img;  // min is kept as the maximum of the complement

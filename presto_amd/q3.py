@@ -139,11 +139,12 @@ RESULT_TYPES = [abi.BIGINT, abi.DATE, abi.INTEGER, abi.DOUBLE, abi.BIGINT]  # or
 
 
 def run(customer_pages, orders_pages, lineitem_pages, stream, group=None, ops=None, device=None, expected_groups=100000,
-        distributed=None, result_mem=abi.MEM_HOST, top_n=0):
+        distributed=None, result_mem=abi.MEM_HOST, top_n=0, with_count=True):
     """Runs the three pipelines on this rank's pages; returns (result pages, counters).  `stream` is the HIP stream
     handle every operator (and the exchange) runs on; result_mem = where the grouped result is left (PA_MEM_DEVICE
     when a device operator consumes it).  top_n > 0 appends the query's TopN (revenue DESC, orderdate ASC): every rank then
-    returns its own top_n rows -- the groups of different ranks are disjoint, so the query result is the top_n of their union."""
+    returns its own top_n rows -- the groups of different ranks are disjoint, so the query result is the top_n of their union.
+    with_count=False runs the query as TPC-H states it (sum(revenue) only); the count(*) column is there for the parity tests."""
     if distributed is None:
         distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
     dev = abi.MEM_DEVICE
@@ -184,14 +185,16 @@ def run(customer_pages, orders_pages, lineitem_pages, stream, group=None, ops=No
     # pipeline 3
     # orderkey is unique on the build side, so its row count bounds the groups (what the planner's stats estimate)
     expected_groups = max(expected_groups, min(b2.positionCount(), 1 << 28))
-    agg = HashAggregationOperator(AGG_TYPES, AGG_GROUP_BY, AGG_AGGREGATES, expected_groups=expected_groups,
+    aggregates = AGG_AGGREGATES if with_count else AGG_AGGREGATES[:1]
+    result_types = RESULT_TYPES if with_count else RESULT_TYPES[:4]
+    agg = HashAggregationOperator(AGG_TYPES, AGG_GROUP_BY, aggregates, expected_groups=expected_groups,
                                   output_mem=dev if top_n else result_mem, stream=s)
     out = Driver(lineitem_pages, [
         FilterAndProjectOperator(tpch.Q3_LINEITEM_TYPES, tpch.q3_lineitem_filter(), tpch.q3_lineitem_projections(), output_mem=dev, stream=s),
         *exchange([abi.BIGINT, abi.DOUBLE], [0]),
         LookupJoinOperator(b2, [abi.BIGINT, abi.DOUBLE], [0], [0, 1], output_mem=dev, stream=s),
         agg,
-        *([TopNOperator(RESULT_TYPES, top_n, [3, 1], [abi.DESC_NULLS_LAST, abi.ASC_NULLS_LAST], output_mem=result_mem, stream=s)] if top_n else [])]).run()
+        *([TopNOperator(result_types, top_n, [3, 1], [abi.DESC_NULLS_LAST, abi.ASC_NULLS_LAST], output_mem=result_mem, stream=s)] if top_n else [])]).run()
     lap("lineitem_pipeline")
     counters["build1_rows"] = b1.positionCount()
     counters["build2_rows"] = b2.positionCount()
