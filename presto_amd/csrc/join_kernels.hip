@@ -268,14 +268,28 @@ __global__ __launch_bounds__(256) void k_join_key_slots(const i32* __restrict__ 
     }
 }
 
+__global__ __launch_bounds__(256) void k_join_key_bitmap(JoinCol build_key, i32 n, i64 min_key, u64 range, u64* __restrict__ bits)
+{
+    for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < n; i += (i64)gridDim.x * 256) {
+        if (jcol_is_null(build_key, (i32)i)) continue;
+        const u64 d = (u64)((i64)join_key_bits(build_key, (i32)i) - min_key);
+        if (d <= range) atomicOr((unsigned long long*)&bits[d >> 6], 1ULL << (d & 63ULL));
+    }
+}
+
 __global__ __launch_bounds__(256) void k_join_probe_count_keyed(JoinCol probe_key, const i64* __restrict__ probe_hash, i32 n_probe,
                                                                 const JoinKeySlot* __restrict__ slots, u32 mask, const i32* __restrict__ links,
-                                                                i32* __restrict__ head, i32* __restrict__ counts, int flags)
+                                                                JoinKeyBitmap bitmap, i32* __restrict__ head, i32* __restrict__ counts, int flags)
 {
     for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < n_probe; i += (i64)gridDim.x * 256) {
         const i32 r = (i32)i;
         i32 h = -1, nxt = -1;
-        if (!jcol_is_null(probe_key, r)) {  // JoinProbe.java:89-91
+        bool may_match = !jcol_is_null(probe_key, r);  // JoinProbe.java:89-91
+        if (may_match && bitmap.bits) {
+            const u64 d = (u64)((i64)join_key_bits(probe_key, r) - bitmap.min_key);
+            may_match = d <= bitmap.range && ((bitmap.bits[d >> 6] >> (d & 63ULL)) & 1ULL) != 0ULL;
+        }
+        if (may_match) {
             const u64 v = join_key_bits(probe_key, r);
             const i64 raw = probe_hash ? probe_hash[r] : pa_hash_bigint((i64)v);  // 31 * 0 + hash(value): one channel
             // linear probing, fetched a 64-byte line (4 slots) at a time: the wave waits for its longest probe sequence, and a
@@ -356,12 +370,19 @@ void launch_join_key_slots(const int32_t* key, int64_t hash_size, const JoinCol&
     hipLaunchKernelGGL(k_join_key_slots, grid_for(hash_size), 256, 0, s, key, (i64)hash_size, build_key, (const i64*)raw_hash, links, slots, slots_mask);
     PA_HIP(hipGetLastError());
 }
+void launch_join_key_bitmap(const JoinCol& build_key, int32_t n, int64_t min_key, uint64_t range, uint64_t* bits, hipStream_t s)
+{
+    PA_HIP(hipMemsetAsync(bits, 0, (size_t)((range >> 6) + 1) * 8, s));
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_join_key_bitmap, grid_for(n), 256, 0, s, build_key, n, (i64)min_key, (u64)range, (u64*)bits);
+    PA_HIP(hipGetLastError());
+}
 void launch_join_probe_count_keyed(const JoinCol& probe_key, const int64_t* probe_hash, int32_t n_probe, const JoinKeySlot* slots, uint32_t mask,
-                                   const int32_t* links, int32_t* head, int32_t* counts, int flags, hipStream_t s)
+                                   const int32_t* links, const JoinKeyBitmap& bitmap, int32_t* head, int32_t* counts, int flags, hipStream_t s)
 {
     if (n_probe <= 0) return;
-    hipLaunchKernelGGL(k_join_probe_count_keyed, grid_for(n_probe), 256, 0, s, probe_key, (const i64*)probe_hash, n_probe, slots, mask, links, head,
-                       counts, flags);
+    hipLaunchKernelGGL(k_join_probe_count_keyed, grid_for(n_probe), 256, 0, s, probe_key, (const i64*)probe_hash, n_probe, slots, mask, links, bitmap,
+                       head, counts, flags);
     PA_HIP(hipGetLastError());
 }
 

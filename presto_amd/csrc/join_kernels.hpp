@@ -40,8 +40,18 @@ struct JoinKeySlot {
 // slots_mask + 1 = size of the probe-side table: a power of two >= 2 x the distinct keys (the caller uses 2 x build rows)
 void launch_join_key_slots(const int32_t* key, int64_t hash_size, const JoinCol& build_key, const int64_t* raw_hash, const int32_t* links,
                            JoinKeySlot* slots, uint32_t slots_mask, hipStream_t s);
+// Existence bitmap over [min key, max key] of the build side (when that range is small enough to be worth it): a probe row
+// whose key has no bit set cannot match and never touches the slot table.  Keys of fact tables are usually dense and the
+// probe side is often clustered by them (lineitem by orderkey), so the bitmap is read almost sequentially, while the slot
+// table is a random access per row -- and most probe rows of a selective join are misses.
+struct JoinKeyBitmap {
+    const uint64_t* bits;   // null = no bitmap
+    int64_t min_key;
+    uint64_t range;         // max - min
+};
+void launch_join_key_bitmap(const JoinCol& build_key, int32_t n, int64_t min_key, uint64_t range, uint64_t* bits, hipStream_t s);
 void launch_join_probe_count_keyed(const JoinCol& probe_key, const int64_t* probe_hash, int32_t n_probe, const JoinKeySlot* slots, uint32_t mask,
-                                   const int32_t* links, int32_t* head, int32_t* counts, int flags, hipStream_t s);
+                                   const int32_t* links, const JoinKeyBitmap& bitmap, int32_t* head, int32_t* counts, int flags, hipStream_t s);
 void launch_join_unvisited_flag(const uint8_t* visited, int64_t n, int32_t* partition, hipStream_t s);
 // DefaultPageJoiner.joinCurrentPosition: (probe position, build position) pairs in emission order
 void launch_join_probe_emit(const int32_t* head, const int32_t* offsets, int32_t n_probe, int32_t total, const int32_t* links, int32_t* probe_idx,

@@ -14,6 +14,7 @@
 #include <atomic>
 #include <mutex>
 
+#include "dynfilter_kernels.hpp"
 #include "join_kernels.hpp"
 #include "operator.hpp"
 #include "scan_kernels.hpp"
@@ -40,6 +41,8 @@ struct LookupSourceImpl {
     DevBuf key_slots;           // JoinKeySlot[hash_size] when the join key is one BIGINT / INTEGER / DATE column (else `tagged`)
     bool keyed = false;
     uint32_t probe_mask = 0;    // size - 1 of key_slots
+    DevBuf key_bits;            // existence bitmap over [key_min, key_min + key_range] (keyed joins with a dense enough key range)
+    JoinKeyBitmap bitmap{nullptr, 0, 0};
     DevBuf visited;  // OuterPositionTracker.visitedPositions: 1 B per build position, written by LOOKUP_OUTER / FULL_OUTER probes
     uint32_t mask = 0;
     std::atomic<bool> built{false};
@@ -205,6 +208,7 @@ public:
         while (slots < 2 * (uint64_t)std::max(n, 1)) slots <<= 1;
         PA_REQUIRE(slots <= (1ULL << 31), PA_ERR_INSUFFICIENT_RESOURCES, "join build side too large");
         ls_->probe_mask = (uint32_t)(slots - 1);
+        if (ls_->keyed && n > 0) build_key_bitmap(bk.col[0], n, s);
         if (ls_->keyed) {
             launch_join_key_slots(ls_->key.as<int32_t>(), (int64_t)hash_size, bk.col[0], ls_->raw_hash.as<int64_t>(), ls_->links.as<int32_t>(),
                                   static_cast<JoinKeySlot*>(ls_->key_slots.ensure((size_t)slots * sizeof(JoinKeySlot))), ls_->probe_mask, s);
@@ -223,11 +227,30 @@ public:
         if (err) throw Error(err, "hash build failed on device");
     }
 
+    // min / max of the build keys (one reduction pass), then -- when the keys are dense enough for the bitmap to be smaller than
+    // the slot table -- one bit per existing key
+    void build_key_bitmap(const JoinCol& key, int32_t n, hipStream_t s)
+    {
+        DevBuf partials, running;
+        int64_t* run = static_cast<int64_t*>(running.ensure(64));
+        PA_HIP(hipMemsetAsync(run, 0, 64, s));
+        launch_df_collect(key.type, key.values, key.nulls, n, nullptr, static_cast<int64_t*>(partials.ensure(df_partials_bytes())), run, s);
+        int64_t h[3];
+        PA_HIP(hipMemcpyAsync(h, run, 24, hipMemcpyDeviceToHost, s));
+        PA_HIP(hipStreamSynchronize(s));
+        if (!h[2]) return;  // every key NULL
+        const uint64_t range = (uint64_t)h[1] - (uint64_t)h[0];
+        if (range >= 64ULL * (uint64_t)n || range >= (1ULL << 36)) return;
+        uint64_t* bits = static_cast<uint64_t*>(ls_->key_bits.ensure((size_t)((range >> 6) + 1) * 8));
+        launch_join_key_bitmap(key, n, h[0], range, bits, s);
+        ls_->bitmap = JoinKeyBitmap{bits, h[0], range};
+    }
+
     bool get_output(pa_page*) override { return false; }
     bool is_finished() override { return finishing_; }
     int64_t memory_bytes() override
     {
-        int64_t b = (int64_t)(ls_->key.capacity() + ls_->links.capacity() + ls_->raw_hash.capacity() + ls_->slot_of.capacity() + ls_->tagged.capacity() + ls_->key_slots.capacity());
+        int64_t b = (int64_t)(ls_->key.capacity() + ls_->links.capacity() + ls_->raw_hash.capacity() + ls_->slot_of.capacity() + ls_->tagged.capacity() + ls_->key_slots.capacity() + ls_->key_bits.capacity());
         for (const auto& c : ls_->cols) b += (int64_t)(c.values.capacity() + c.offsets.capacity() + c.nulls.capacity());
         return b;
     }
@@ -328,7 +351,7 @@ public:
         int32_t* counts = static_cast<int32_t*>(counts_.ensure((size_t)n * 4));
         timer.begin(s);
         if (ls_->keyed) {  // one integer key: key-in-slot table, raw hash computed in the kernel unless a $hashvalue channel came along
-            launch_join_probe_count_keyed(pk.col[0], probe_hash, n, ls_->key_slots.as<JoinKeySlot>(), ls_->probe_mask, ls_->links.as<int32_t>(), head, counts,
+            launch_join_probe_count_keyed(pk.col[0], probe_hash, n, ls_->key_slots.as<JoinKeySlot>(), ls_->probe_mask, ls_->links.as<int32_t>(), ls_->bitmap, head, counts,
                                           probe_flags_, s);
         }
         else {
