@@ -354,6 +354,15 @@ int32_t pa_hash_aggregation_create(const pa_hash_aggregation_desc* desc, pa_oper
 int32_t pa_fused_aggregation_create(const pa_fused_aggregation_desc* desc, pa_operator** out);
 int32_t pa_topn_create(const pa_topn_desc* desc, pa_operator** out);
 int32_t pa_order_by_create(const pa_order_by_desc* desc, pa_operator** out);
+/* The dynamic filter of an INNER (or lookup-outer) join applied where Trino applies it -- in the scan / filter upstream of the
+ * probe (DynamicFilter.getCurrentPredicate consumed by ScanFilterAndProjectOperator's page source): rows of `op` (a
+ * FilterAndProject operator that has not seen a page yet) whose BIGINT / INTEGER / DATE `channel` value equals no build key
+ * of `source` are dropped together with the rows the filter expression drops.  The predicate is the build side's existence
+ * bitmap (exact over its key range), not the reference's value set / min-max Domain: it only ever removes rows the join would
+ * not match, so results are unchanged.  `source` must be built (its HashBuilderOperator finished).  Returns 1 when the filter
+ * is active, 0 when the source offers none (several key channels, non-integer key, keys too sparse) -- the operator then
+ * works as before.  Not for probe-outer / full-outer joins, whose unmatched probe rows are output. */
+int32_t pa_filter_project_set_dynamic_filter(pa_operator* op, int32_t channel, pa_lookup_source* source);
 int32_t pa_dynamic_filter_source_create(const pa_dynamic_filter_source_desc* desc, pa_operator** out);
 /* The dynamicPredicateConsumer call of a DynamicFilterSourceOperator: returns 0 while the consumer has not been called
  * (it is called by finish(), or earlier when the operator gives up collecting), 1 once it has; then *is_all != 0 means

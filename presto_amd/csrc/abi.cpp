@@ -329,6 +329,19 @@ int32_t pa_dynamic_filter_poll(pa_operator* op, int32_t* is_all, pa_domain* doma
         return dynamic_filter_poll(op, is_all, domains, domain_capacity);
     });
 }
+int32_t pa_filter_project_set_dynamic_filter(pa_operator* op, int32_t channel, pa_lookup_source* source)
+{
+    return guarded([&]() -> int32_t {
+        PA_REQUIRE(op != nullptr && source != nullptr, PA_ERR_INVALID_ARGUMENT, "null argument");
+        const uint64_t* bits = nullptr;
+        int64_t min_key = 0;
+        uint64_t range = 0;
+        std::shared_ptr<void> keep;
+        if (!lookup_source_key_bitmap(source, &bits, &min_key, &range, &keep)) return 0;
+        filter_project_set_dynamic_filter(op, channel, bits, min_key, range, std::move(keep));
+        return 1;
+    });
+}
 int32_t pa_order_by_create(const pa_order_by_desc* desc, pa_operator** out)
 {
     return guarded([&]() -> int32_t {

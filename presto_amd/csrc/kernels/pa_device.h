@@ -568,4 +568,13 @@ struct PaFpArgs {
     const i32* tile_offsets;        // exclusive scan of tile_counts
     i32* positions;                 // SelectedPositions.positions (ascending), worst case n entries
     i32* err;
+    const u64* dyn_bits;            // dynamic filter from a join's build side: existence bitmap over [dyn_min, dyn_min + dyn_range]
+    i64 dyn_min;
+    u64 dyn_range;
 };
+// can a probe row with this key match any build row?  (exact inside the bitmap's range; NULL keys never match)
+__device__ __forceinline__ bool pa_dyn_test(const PaFpArgs& a, const i64 key)
+{
+    const u64 d = (u64)(key - a.dyn_min);
+    return d <= a.dyn_range && ((a.dyn_bits[d >> 6] >> (d & 63ULL)) & 1ULL) != 0ULL;
+}

@@ -55,6 +55,9 @@ struct FpArgs {  // host mirror of PaFpArgs
     const int32_t* tile_offsets;
     int32_t* positions;
     int32_t* err;
+    const uint64_t* dyn_bits;
+    int64_t dyn_min;
+    uint64_t dyn_range;
 };
 
 struct FpSpec {
@@ -67,6 +70,8 @@ struct FpSpec {
     std::vector<bool> used_channel;
     // the selection comes from outside (dictionary-aware filter): pa_fp_scatter reads sel4, the filter is not evaluated
     bool filter_external = false;
+    // channel tested against the existence bitmap of a join's build keys (pa_filter_project_set_dynamic_filter), or -1
+    int dyn_channel = -1;
 };
 
 struct FpKernelInfo {
@@ -117,15 +122,20 @@ FpKernelInfo generate_fp(const FpSpec& s, const std::vector<ChannelLayout>& layo
 
     // filter: bool pa_sel(args, row...)
     src << "__device__ __forceinline__ bool pa_sel(const PaFpArgs& a" << params << ")\n{\n";
-    if (s.has_filter && !s.filter_external) {
+    if (s.has_filter && !s.filter_external && s.filter.root >= 0) {
         RowCodegen gen(layout, "a.err");
         std::ostringstream body;
         GenValue f = gen.emit(s.filter, body);
-        src << body.str() << "return " << (f.nullable() ? "(!" + f.n + " && " + f.v + ")" : f.v) << ";\n";  // PageFunctionCompiler.java:539-542
+        src << body.str() << "return " << (f.nullable() ? "(!" + f.n + " && " + f.v + ")" : f.v);  // PageFunctionCompiler.java:539-542
     }
     else {
-        src << "return true;\n";
+        src << "return true";
     }
+    if (s.dyn_channel >= 0 && !s.filter_external) {
+        const std::string C = std::to_string(s.dyn_channel);
+        src << " && " << (layout[s.dyn_channel].nullable ? "!cn" + C + " && " : "") << "pa_dyn_test(a, (i64)c" << C << ")";
+    }
+    src << ";\n";
     src << "}\n";
 
     // projections of one selected row written at output position `rank`
@@ -286,6 +296,9 @@ public:
         a.n = n;
         a.vec = vec ? 1 : 0;
         a.err = ctl_;
+        a.dyn_bits = dyn_bits_;
+        a.dyn_min = dyn_min_;
+        a.dyn_range = dyn_range_;
         need_positions_ = false;
         for (size_t j = 0; j < spec_.proj.size(); j++) {
             OutColumn& oc = out_cols_[j];
@@ -505,6 +518,24 @@ public:
     int64_t memory_bytes() override { return (int64_t)(stager_.bytes() + sel4_.capacity() + positions_.capacity() + tile_counts_.capacity()); }
 
     // SelectedPositions of the last processed page (after its get_output)
+    // The dynamic filter of a join whose probe side this operator feeds (DynamicFilter.getCurrentPredicate as the page source of
+    // ScanFilterAndProjectOperator applies it): rows whose `channel` value matches no build key are dropped with the filter.
+    void set_dynamic_filter(int channel, const uint64_t* bits, int64_t min_key, uint64_t range, std::shared_ptr<void> keep)
+    {
+        PA_REQUIRE(!pending_ && compiled_.empty(), PA_ERR_ILLEGAL_STATE, "a dynamic filter must be set before the first page");
+        PA_REQUIRE(channel >= 0 && channel < spec_.n_in, PA_ERR_INVALID_ARGUMENT, "dynamic filter channel out of range");
+        const int32_t t = spec_.in_types[channel];
+        PA_REQUIRE(t == PA_BIGINT || t == PA_INTEGER || t == PA_DATE, PA_ERR_NOT_SUPPORTED, "dynamic filters apply to BIGINT / INTEGER / DATE channels");
+        spec_.dyn_channel = channel;
+        spec_.has_filter = true;
+        spec_.used_channel[channel] = true;
+        dict_channel_ = -1;  // (the dictionary-aware path evaluates the filter on dictionaries: not combined with a dynamic filter)
+        dyn_bits_ = bits;
+        dyn_min_ = min_key;
+        dyn_range_ = range;
+        dyn_keep_ = std::move(keep);
+    }
+
     void last_positions(const int32_t** dev_positions, int32_t* count, int32_t* is_list) const
     {
         *dev_positions = positions_.as<int32_t>();
@@ -608,6 +639,10 @@ private:
         return true;
     }
 
+    const uint64_t* dyn_bits_ = nullptr;
+    int64_t dyn_min_ = 0;
+    uint64_t dyn_range_ = 0;
+    std::shared_ptr<void> dyn_keep_;  // the lookup source that owns the bitmap
     FpSpec spec_, dict_spec_, ext_spec_;
     int dict_channel_ = -1;  // the filter's only input channel, or -1
     Stream stream_;
@@ -636,6 +671,13 @@ private:
 };
 
 }  // namespace
+
+void filter_project_set_dynamic_filter(pa_operator* op, int channel, const uint64_t* bits, int64_t min_key, uint64_t range, std::shared_ptr<void> keep)
+{
+    auto* fp = dynamic_cast<FilterProjectOperator*>(op);
+    PA_REQUIRE(fp != nullptr, PA_ERR_INVALID_ARGUMENT, "not a FilterAndProject operator");
+    fp->set_dynamic_filter(channel, bits, min_key, range, std::move(keep));
+}
 
 pa_operator* make_filter_project(const pa_filter_project_desc* desc)
 {

@@ -565,6 +565,18 @@ private:
 
 }  // namespace
 
+bool lookup_source_key_bitmap(pa_lookup_source* ls, const uint64_t** bits, int64_t* min_key, uint64_t* range, std::shared_ptr<void>* keep)
+{
+    PA_REQUIRE(ls != nullptr && ls->impl, PA_ERR_INVALID_ARGUMENT, "lookup source is null");
+    PA_REQUIRE(ls->impl->built.load(), PA_ERR_ILLEGAL_STATE, "the lookup source is not built yet");
+    if (!ls->impl->bitmap.bits) return false;
+    *bits = ls->impl->bitmap.bits;
+    *min_key = ls->impl->bitmap.min_key;
+    *range = ls->impl->bitmap.range;
+    *keep = ls->impl;
+    return true;
+}
+
 pa_operator* make_hash_builder(const pa_hash_builder_desc* desc, pa_lookup_source* bridge)
 {
     return new HashBuilderOperator(desc, bridge);

@@ -76,6 +76,11 @@ class Operator:
             return np.zeros(0, np.int32), np.zeros(0, np.int32)
         return (download(DeviceBuffer(p.value, 4 * n), np.int32, n), download(DeviceBuffer(b.value, 4 * n), np.int32, n))
 
+    def setDynamicFilter(self, channel, lookup_source_factory):
+        """FilterAndProject only, before the first page: drop the rows whose `channel` value matches no build key of the (built)
+        join bridge -- the join's dynamic filter applied upstream of the probe.  True when the filter is active."""
+        return bool(check(lib().pa_filter_project_set_dynamic_filter(self._h, channel, lookup_source_factory._h)))
+
     def close(self):
         if self._h:
             lib().pa_op_close(self._h)

@@ -139,12 +139,15 @@ RESULT_TYPES = [abi.BIGINT, abi.DATE, abi.INTEGER, abi.DOUBLE, abi.BIGINT]  # or
 
 
 def run(customer_pages, orders_pages, lineitem_pages, stream, group=None, ops=None, device=None, expected_groups=100000,
-        distributed=None, result_mem=abi.MEM_HOST, top_n=0, with_count=True):
+        distributed=None, result_mem=abi.MEM_HOST, top_n=0, with_count=True, dynamic_filters=True):
     """Runs the three pipelines on this rank's pages; returns (result pages, counters).  `stream` is the HIP stream
     handle every operator (and the exchange) runs on; result_mem = where the grouped result is left (PA_MEM_DEVICE
     when a device operator consumes it).  top_n > 0 appends the query's TopN (revenue DESC, orderdate ASC): every rank then
     returns its own top_n rows -- the groups of different ranks are disjoint, so the query result is the top_n of their union.
-    with_count=False runs the query as TPC-H states it (sum(revenue) only); the count(*) column is there for the parity tests."""
+    with_count=False runs the query as TPC-H states it (sum(revenue) only); the count(*) column is there for the parity tests.
+    dynamic_filters: the filters upstream of the two probes also drop the rows whose join key matches no build key (the joins'
+    dynamic filters, applied where Trino applies them); only without exchange steps -- before an exchange a rank holds
+    rows whose build side lives on another rank."""
     if distributed is None:
         distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
     dev = abi.MEM_DEVICE
@@ -174,9 +177,12 @@ def run(customer_pages, orders_pages, lineitem_pages, stream, group=None, ops=No
     lap("customer_pipeline")
     # pipeline 2
     b2 = LookupSourceFactory()
+    orders_fp = FilterAndProjectOperator(tpch.ORDERS_TYPES, tpch.q3_orders_filter(), [field(i, t) for i, t in enumerate(tpch.ORDERS_TYPES)],
+                                         output_mem=dev, stream=s)
+    if dynamic_filters and not distributed:
+        counters["orders_dynamic_filter"] = orders_fp.setDynamicFilter(1, b1)
     Driver(orders_pages, [
-        FilterAndProjectOperator(tpch.ORDERS_TYPES, tpch.q3_orders_filter(), [field(i, t) for i, t in enumerate(tpch.ORDERS_TYPES)],
-                                 output_mem=dev, stream=s),
+        orders_fp,
         *exchange(tpch.ORDERS_TYPES, [1]),
         LookupJoinOperator(b1, tpch.ORDERS_TYPES, [1], [0, 2, 3], output_mem=dev, stream=s),
         *exchange(ORDERS_JOINED_TYPES, [0]),
@@ -189,8 +195,11 @@ def run(customer_pages, orders_pages, lineitem_pages, stream, group=None, ops=No
     result_types = RESULT_TYPES if with_count else RESULT_TYPES[:4]
     agg = HashAggregationOperator(AGG_TYPES, AGG_GROUP_BY, aggregates, expected_groups=expected_groups,
                                   output_mem=dev if top_n else result_mem, stream=s)
+    lineitem_fp = FilterAndProjectOperator(tpch.Q3_LINEITEM_TYPES, tpch.q3_lineitem_filter(), tpch.q3_lineitem_projections(), output_mem=dev, stream=s)
+    if dynamic_filters and not distributed:
+        counters["lineitem_dynamic_filter"] = lineitem_fp.setDynamicFilter(0, b2)
     out = Driver(lineitem_pages, [
-        FilterAndProjectOperator(tpch.Q3_LINEITEM_TYPES, tpch.q3_lineitem_filter(), tpch.q3_lineitem_projections(), output_mem=dev, stream=s),
+        lineitem_fp,
         *exchange([abi.BIGINT, abi.DOUBLE], [0]),
         LookupJoinOperator(b2, [abi.BIGINT, abi.DOUBLE], [0], [0, 1], output_mem=dev, stream=s),
         agg,

@@ -241,3 +241,58 @@ def test_inner_join_with_output_single_match_kat(gpu, oracle):
     join = LookupJoinOperator(bridge, types, [0], [0], output_single_match=True)
     got = [r for p in to_pages(join, [Page([Block.varchar([b"a", b"b", b"c"])], 3)]) for r in p.to_rows()]
     assert got == [(b"a", b"a"), (b"b", b"b")]
+
+
+@pytest.mark.parametrize("key_type", [abi.BIGINT, abi.INTEGER, abi.DATE])
+def test_dynamic_filter_upstream_of_the_probe(gpu, oracle, key_type):
+    """pa_filter_project_set_dynamic_filter: the FilterAndProject feeding a probe also drops the rows whose key matches no build key
+    (Trino applies a join's dynamic filter in the probe-side scan).  Its output = the plain filter's output restricted to keys
+    that exist on the build side (NULL keys never match) -- and the join over it equals the join over the unfiltered rows."""
+    from presto_amd._lib import PrestoAmdError
+    from presto_amd.expr import field
+    from presto_amd.operators import FilterAndProjectOperator
+    rng = np.random.default_rng(41)
+    mk = {abi.BIGINT: Block.bigint, abi.INTEGER: Block.integer, abi.DATE: Block.date}[key_type]
+    build = [Page([mk(rng.integers(1000, 30000, 4000) * 3, rng.random(4000) < 0.02), Block.bigint(np.arange(4000))], 4000)]
+    n = 120000
+    probe = [Page([mk(rng.integers(0, 100000, n), rng.random(n) < 0.03), Block.double(rng.random(n))], n) for _ in range(2)]
+    types = [key_type, abi.DOUBLE]
+    bridge = LookupSourceFactory()
+    to_pages(HashBuilderOperator(bridge, [key_type, abi.BIGINT], [0], [0, 1]), build)
+    f = field(1, abi.DOUBLE) < 0.6
+    proj = [field(0, key_type), field(1, abi.DOUBLE)]
+    fp = FilterAndProjectOperator(types, f, proj)
+    assert fp.setDynamicFilter(0, bridge) is True
+    got = [r for p in to_pages(fp, probe) for r in p.to_rows()]
+    keys = {v for v in build[0].blocks[0].to_pylist() if v is not None}
+    plain = [r for p in probe for r in oracle.filter_project(p, f, proj).to_rows()]
+    assert got == [r for r in plain if r[0] in keys] and 0 < len(got) < len(plain) // 5
+    # same join result with and without the dynamic filter
+    def join(pages):
+        return [r for p in to_pages(LookupJoinOperator(bridge, types, [0], [0, 1]), pages) for r in p.to_rows()]
+    filtered = to_pages(FilterAndProjectOperator(types, f, proj), probe)
+    fp2 = FilterAndProjectOperator(types, f, proj)
+    fp2.setDynamicFilter(0, bridge)
+    assert join(to_pages(fp2, probe)) == join(filtered)
+    # no filter expression at all: the dynamic filter alone selects
+    fp3 = FilterAndProjectOperator(types, None, proj)
+    fp3.setDynamicFilter(0, bridge)
+    assert [r for p in to_pages(fp3, probe) for r in p.to_rows()] == [r for p in probe for r in p.to_rows() if r[0] in keys]
+    # too late after the first page
+    fp4 = FilterAndProjectOperator(types, f, proj)
+    fp4.addInput(probe[0])
+    fp4.getOutput()
+    with pytest.raises(PrestoAmdError) as e:
+        fp4.setDynamicFilter(0, bridge)
+    assert e.value.status == abi.ERR_ILLEGAL_STATE
+
+
+def test_dynamic_filter_not_offered_for_varchar_keys(gpu):
+    from presto_amd.expr import field
+    from presto_amd.operators import FilterAndProjectOperator
+    bridge = LookupSourceFactory()
+    to_pages(HashBuilderOperator(bridge, [abi.VARCHAR], [0], [0]), [Page([Block.varchar([b"a", b"b"])], 2)])
+    fp = FilterAndProjectOperator([abi.VARCHAR, abi.BIGINT], None, [field(1, abi.BIGINT)])
+    assert fp.setDynamicFilter(1, bridge) is False
+    page = Page([Block.varchar([b"a", b"x", b"b"]), Block.bigint([1, 2, 3])], 3)
+    assert [r for p in to_pages(fp, [page]) for r in p.to_rows()] == [(1,), (2,), (3,)]
