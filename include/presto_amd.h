@@ -363,6 +363,16 @@ int32_t pa_order_by_create(const pa_order_by_desc* desc, pa_operator** out);
  * is active, 0 when the source offers none (several key channels, non-integer key, keys too sparse) -- the operator then
  * works as before.  Not for probe-outer / full-outer joins, whose unmatched probe rows are output. */
 int32_t pa_filter_project_set_dynamic_filter(pa_operator* op, int32_t channel, pa_lookup_source* source);
+/* The same across the ranks of a partitioned join, where every rank built the keys of its own partition and the probe rows
+ * are filtered BEFORE they are exchanged: (1) pa_lookup_source_key_range -> [min, max] of this rank's build keys (returns 0:
+ * no single integer key / no non-NULL key); the ranks agree on the union range; (2) pa_lookup_source_key_bitmap sets, in a
+ * device bitmap of (range >> 6) + 1 words that it clears first, bit (key - min_key) for each of this rank's keys inside
+ * [min_key, min_key + range]; the ranks OR their bitmaps (all-gather + OR: RCCL has no bitwise reduction);
+ * (3) pa_filter_project_set_dynamic_filter_bitmap installs the combined bitmap, which the caller keeps alive as long as the
+ * operator lives.  presto_amd/q3.py does this with torch.distributed. */
+int32_t pa_lookup_source_key_range(pa_lookup_source* source, int64_t* min_key, int64_t* max_key);
+int32_t pa_lookup_source_key_bitmap(pa_lookup_source* source, int64_t min_key, uint64_t range, uint64_t* bits, void* stream);
+int32_t pa_filter_project_set_dynamic_filter_bitmap(pa_operator* op, int32_t channel, const uint64_t* bits, int64_t min_key, uint64_t range);
 int32_t pa_dynamic_filter_source_create(const pa_dynamic_filter_source_desc* desc, pa_operator** out);
 /* The dynamicPredicateConsumer call of a DynamicFilterSourceOperator: returns 0 while the consumer has not been called
  * (it is called by finish(), or earlier when the operator gives up collecting), 1 once it has; then *is_all != 0 means

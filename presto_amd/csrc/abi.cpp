@@ -342,6 +342,28 @@ int32_t pa_filter_project_set_dynamic_filter(pa_operator* op, int32_t channel, p
         return 1;
     });
 }
+int32_t pa_lookup_source_key_range(pa_lookup_source* source, int64_t* min_key, int64_t* max_key)
+{
+    return guarded([&]() -> int32_t {
+        PA_REQUIRE(source != nullptr && min_key != nullptr && max_key != nullptr, PA_ERR_INVALID_ARGUMENT, "null argument");
+        return lookup_source_key_range(source, min_key, max_key) ? 1 : 0;
+    });
+}
+int32_t pa_lookup_source_key_bitmap(pa_lookup_source* source, int64_t min_key, uint64_t range, uint64_t* bits, void* stream)
+{
+    return guarded([&]() -> int32_t {
+        lookup_source_fill_bitmap(source, min_key, range, bits, (hipStream_t)stream);
+        return PA_OK;
+    });
+}
+int32_t pa_filter_project_set_dynamic_filter_bitmap(pa_operator* op, int32_t channel, const uint64_t* bits, int64_t min_key, uint64_t range)
+{
+    return guarded([&]() -> int32_t {
+        PA_REQUIRE(op != nullptr && bits != nullptr, PA_ERR_INVALID_ARGUMENT, "null argument");
+        filter_project_set_dynamic_filter(op, channel, bits, min_key, range, nullptr);
+        return PA_OK;
+    });
+}
 int32_t pa_order_by_create(const pa_order_by_desc* desc, pa_operator** out)
 {
     return guarded([&]() -> int32_t {

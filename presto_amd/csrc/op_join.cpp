@@ -43,6 +43,8 @@ struct LookupSourceImpl {
     uint32_t probe_mask = 0;    // size - 1 of key_slots
     DevBuf key_bits;            // existence bitmap over [key_min, key_min + key_range] (keyed joins with a dense enough key range)
     JoinKeyBitmap bitmap{nullptr, 0, 0};
+    bool key_range_valid = false;  // keyed join with at least one non-NULL build key: [key_min, key_max]
+    int64_t key_min = 0, key_max = 0;
     DevBuf visited;  // OuterPositionTracker.visitedPositions: 1 B per build position, written by LOOKUP_OUTER / FULL_OUTER probes
     uint32_t mask = 0;
     std::atomic<bool> built{false};
@@ -239,6 +241,9 @@ public:
         PA_HIP(hipMemcpyAsync(h, run, 24, hipMemcpyDeviceToHost, s));
         PA_HIP(hipStreamSynchronize(s));
         if (!h[2]) return;  // every key NULL
+        ls_->key_range_valid = true;
+        ls_->key_min = h[0];
+        ls_->key_max = h[1];
         const uint64_t range = (uint64_t)h[1] - (uint64_t)h[0];
         if (range >= 64ULL * (uint64_t)n || range >= (1ULL << 36)) return;
         uint64_t* bits = static_cast<uint64_t*>(ls_->key_bits.ensure((size_t)((range >> 6) + 1) * 8));
@@ -575,6 +580,25 @@ bool lookup_source_key_bitmap(pa_lookup_source* ls, const uint64_t** bits, int64
     *range = ls->impl->bitmap.range;
     *keep = ls->impl;
     return true;
+}
+
+// For a dynamic filter that spans the ranks of a partitioned join (every rank holds the build keys of its partition): the
+// local key range, and the local keys as bits of a caller-provided bitmap over a common range.
+bool lookup_source_key_range(pa_lookup_source* ls, int64_t* min_key, int64_t* max_key)
+{
+    PA_REQUIRE(ls != nullptr && ls->impl, PA_ERR_INVALID_ARGUMENT, "lookup source is null");
+    PA_REQUIRE(ls->impl->built.load(), PA_ERR_ILLEGAL_STATE, "the lookup source is not built yet");
+    if (!ls->impl->keyed || !ls->impl->key_range_valid) return false;
+    *min_key = ls->impl->key_min;
+    *max_key = ls->impl->key_max;
+    return true;
+}
+void lookup_source_fill_bitmap(pa_lookup_source* ls, int64_t min_key, uint64_t range, uint64_t* bits, hipStream_t s)
+{
+    PA_REQUIRE(ls != nullptr && ls->impl && bits != nullptr, PA_ERR_INVALID_ARGUMENT, "null argument");
+    PA_REQUIRE(ls->impl->built.load() && ls->impl->keyed, PA_ERR_ILLEGAL_STATE, "needs a built lookup source with one integer join key");
+    const JoinKeys bk = ls->impl->build_keys();
+    launch_join_key_bitmap(bk.col[0], ls->impl->n, min_key, range, bits, s);
 }
 
 pa_operator* make_hash_builder(const pa_hash_builder_desc* desc, pa_lookup_source* bridge)

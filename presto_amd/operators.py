@@ -81,6 +81,11 @@ class Operator:
         join bridge -- the join's dynamic filter applied upstream of the probe.  True when the filter is active."""
         return bool(check(lib().pa_filter_project_set_dynamic_filter(self._h, channel, lookup_source_factory._h)))
 
+    def setDynamicFilterBitmap(self, channel, bits_ptr, min_key, key_range, keep=None):
+        """The same with a bitmap combined over the ranks of a partitioned join (`keep` = whatever owns the bitmap)."""
+        check(lib().pa_filter_project_set_dynamic_filter_bitmap(self._h, channel, bits_ptr, min_key, key_range))
+        self._dyn_keep = keep
+
     def close(self):
         if self._h:
             lib().pa_op_close(self._h)
@@ -361,6 +366,17 @@ class LookupSourceFactory:
         check(lib().pa_lookup_source_tables(self._h, C.byref(key), C.byref(hs), C.byref(links), C.byref(n)))
         return (download(DeviceBuffer(key.value, 4 * hs.value), np.int32, hs.value),
                 download(DeviceBuffer(links.value, 4 * n.value), np.int32, n.value))
+
+    def keyRange(self):
+        """(min, max) of this rank's build keys, or None (no single integer join key / no non-NULL key)."""
+        lo, hi = C.c_int64(), C.c_int64()
+        if not check(lib().pa_lookup_source_key_range(self._h, C.byref(lo), C.byref(hi))):
+            return None
+        return lo.value, hi.value
+
+    def fillKeyBitmap(self, min_key, key_range, bits_ptr, stream=None):
+        """Sets bit (key - min_key) of the device bitmap at bits_ptr ((key_range >> 6) + 1 words, cleared first) for every build key."""
+        check(lib().pa_lookup_source_key_bitmap(self._h, min_key, key_range, bits_ptr, stream))
 
     def positionCount(self):
         """Build positions of the published lookup source (LookupSource.getJoinPositionCount)."""

@@ -146,8 +146,8 @@ def run(customer_pages, orders_pages, lineitem_pages, stream, group=None, ops=No
     returns its own top_n rows -- the groups of different ranks are disjoint, so the query result is the top_n of their union.
     with_count=False runs the query as TPC-H states it (sum(revenue) only); the count(*) column is there for the parity tests.
     dynamic_filters: the filters upstream of the two probes also drop the rows whose join key matches no build key (the joins'
-    dynamic filters, applied where Trino applies them); only without exchange steps -- before an exchange a rank holds
-    rows whose build side lives on another rank."""
+    dynamic filters, applied where Trino applies them); with exchange steps the filter is the OR of every rank's build-key
+    bitmap, so that rows are dropped before they are exchanged."""
     if distributed is None:
         distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
     dev = abi.MEM_DEVICE
@@ -159,6 +159,45 @@ def run(customer_pages, orders_pages, lineitem_pages, stream, group=None, ops=No
     import time
     from ._lib import check, lib
     counters = {}
+
+    def dynamic_filter(fp, channel, bridge, name):
+        """Installs the join's dynamic filter in the FilterAndProject upstream of its probe.  With exchange steps the filter
+        runs BEFORE the exchange, so it must know the build keys of every rank: the ranks agree on the key range, each sets the
+        bits of its partition's keys, the bitmaps are all-gathered and OR-ed (RCCL has no bitwise reduction)."""
+        if not dynamic_filters:
+            return
+        if not distributed:
+            counters[name] = fp.setDynamicFilter(channel, bridge)
+            return
+        import torch
+        dev_t = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+        local = bridge.keyRange()
+        big = (1 << 62)
+        ends = torch.tensor([local[0] if local else big, -local[1] if local else big], dtype=torch.int64, device=dev_t)
+        dist.all_reduce(ends, op=dist.ReduceOp.MIN, group=group)
+        lo, hi = int(ends[0]), -int(ends[1])
+        rows = torch.tensor([bridge.positionCount()], dtype=torch.int64, device=dev_t)
+        dist.all_reduce(rows, group=group)
+        key_range = hi - lo
+        if lo == big or key_range < 0 or key_range >= 64 * max(int(rows[0]), 1) or key_range >= (1 << 36):
+            counters[name] = False  # no keys anywhere, or too sparse for a bitmap to pay
+            return
+        words = (key_range >> 6) + 1
+        world = dist.get_world_size(group)
+        mine = torch.zeros(words, dtype=torch.int64, device=dev_t)
+        torch.cuda.synchronize()
+        if local:
+            bridge.fillKeyBitmap(lo, key_range, mine.data_ptr(), s)
+        check(lib().pa_stream_synchronize(s))
+        gathered = torch.empty(world * words, dtype=torch.int64, device=dev_t)
+        dist.all_gather_into_tensor(gathered, mine, group=group)
+        bits = gathered.view(world, words)[0].clone()
+        for r in range(1, world):
+            bits |= gathered.view(world, words)[r]
+        torch.cuda.synchronize()
+        fp.setDynamicFilterBitmap(channel, bits.data_ptr(), lo, key_range, keep=bits)
+        counters[name] = True
+
     t0 = time.perf_counter()
 
     def lap(name):  # wall time of a pipeline incl. its device work (the next pipeline needs its lookup source anyway)
@@ -179,8 +218,7 @@ def run(customer_pages, orders_pages, lineitem_pages, stream, group=None, ops=No
     b2 = LookupSourceFactory()
     orders_fp = FilterAndProjectOperator(tpch.ORDERS_TYPES, tpch.q3_orders_filter(), [field(i, t) for i, t in enumerate(tpch.ORDERS_TYPES)],
                                          output_mem=dev, stream=s)
-    if dynamic_filters and not distributed:
-        counters["orders_dynamic_filter"] = orders_fp.setDynamicFilter(1, b1)
+    dynamic_filter(orders_fp, 1, b1, "orders_dynamic_filter")
     Driver(orders_pages, [
         orders_fp,
         *exchange(tpch.ORDERS_TYPES, [1]),
@@ -196,8 +234,7 @@ def run(customer_pages, orders_pages, lineitem_pages, stream, group=None, ops=No
     agg = HashAggregationOperator(AGG_TYPES, AGG_GROUP_BY, aggregates, expected_groups=expected_groups,
                                   output_mem=dev if top_n else result_mem, stream=s)
     lineitem_fp = FilterAndProjectOperator(tpch.Q3_LINEITEM_TYPES, tpch.q3_lineitem_filter(), tpch.q3_lineitem_projections(), output_mem=dev, stream=s)
-    if dynamic_filters and not distributed:
-        counters["lineitem_dynamic_filter"] = lineitem_fp.setDynamicFilter(0, b2)
+    dynamic_filter(lineitem_fp, 0, b2, "lineitem_dynamic_filter")
     out = Driver(lineitem_pages, [
         lineitem_fp,
         *exchange([abi.BIGINT, abi.DOUBLE], [0]),

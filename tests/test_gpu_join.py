@@ -296,3 +296,38 @@ def test_dynamic_filter_not_offered_for_varchar_keys(gpu):
     assert fp.setDynamicFilter(1, bridge) is False
     page = Page([Block.varchar([b"a", b"x", b"b"]), Block.bigint([1, 2, 3])], 3)
     assert [r for p in to_pages(fp, [page]) for r in p.to_rows()] == [(1,), (2,), (3,)]
+
+
+def test_dynamic_filter_combined_over_partitions(gpu, oracle):
+    """The cross-rank form (presto_amd/q3.py with exchange steps): every rank holds one partition of the build keys; the ranks
+    agree on the union key range, each fills its bits (pa_lookup_source_key_bitmap), the bitmaps are OR-ed and installed with
+    pa_filter_project_set_dynamic_filter_bitmap.  Two lookup sources on one GPU stand in for two ranks."""
+    import torch
+    from presto_amd.expr import field
+    from presto_amd.operators import FilterAndProjectOperator
+    rng = np.random.default_rng(43)
+    keys = rng.choice(np.arange(5000, 90000), 6000, replace=False)
+    parts = [keys[keys % 2 == 0], keys[keys % 2 == 1]]
+    bridges = []
+    for part in parts:
+        b = LookupSourceFactory()
+        to_pages(HashBuilderOperator(b, [abi.BIGINT], [0], [0]), [Page([Block.bigint(part)], len(part))])
+        bridges.append(b)
+    ranges = [b.keyRange() for b in bridges]
+    assert ranges[0] == (int(parts[0].min()), int(parts[0].max()))
+    lo, hi = min(r[0] for r in ranges), max(r[1] for r in ranges)
+    words = ((hi - lo) >> 6) + 1
+    maps = [torch.full((words,), -1, dtype=torch.int64, device="cuda") for _ in bridges]  # the call clears them
+    torch.cuda.synchronize()
+    for b, m in zip(bridges, maps):
+        b.fillKeyBitmap(lo, hi - lo, m.data_ptr())
+    gpu.check(gpu.lib().pa_stream_synchronize(None))
+    both = maps[0] | maps[1]
+    torch.cuda.synchronize()
+    n = 200000
+    probe = Page([Block.bigint(rng.integers(0, 100000, n), rng.random(n) < 0.02), Block.double(rng.random(n))], n)
+    fp = FilterAndProjectOperator([abi.BIGINT, abi.DOUBLE], None, [field(0, abi.BIGINT), field(1, abi.DOUBLE)])
+    fp.setDynamicFilterBitmap(0, both.data_ptr(), lo, hi - lo, keep=both)
+    got = [r for p in to_pages(fp, [probe]) for r in p.to_rows()]
+    want = set(int(k) for k in keys)
+    assert got == [r for r in probe.to_rows() if r[0] in want] and len(got) > 5000
