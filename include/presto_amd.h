@@ -371,6 +371,8 @@ int32_t pa_filter_project_set_dynamic_filter(pa_operator* op, int32_t channel, p
  * (3) pa_filter_project_set_dynamic_filter_bitmap installs the combined bitmap, which the caller keeps alive as long as the
  * operator lives.  presto_amd/q3.py does this with torch.distributed. */
 int32_t pa_lookup_source_key_range(pa_lookup_source* source, int64_t* min_key, int64_t* max_key);
+/* LookupSource.getJoinPositionCount of a built source (>= 0), or a negative pa_status. */
+int32_t pa_lookup_source_position_count(pa_lookup_source* source);
 int32_t pa_lookup_source_key_bitmap(pa_lookup_source* source, int64_t min_key, uint64_t range, uint64_t* bits, void* stream);
 int32_t pa_filter_project_set_dynamic_filter_bitmap(pa_operator* op, int32_t channel, const uint64_t* bits, int64_t min_key, uint64_t range);
 int32_t pa_dynamic_filter_source_create(const pa_dynamic_filter_source_desc* desc, pa_operator** out);

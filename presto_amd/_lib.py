@@ -53,6 +53,7 @@ def lib():
     L.pa_hash_builder_create.argtypes = [C.POINTER(abi.pa_hash_builder_desc), vp, C.POINTER(vp)]
     L.pa_lookup_join_create.argtypes = [C.POINTER(abi.pa_lookup_join_desc), vp, C.POINTER(vp)]
     L.pa_filter_project_set_dynamic_filter.argtypes = [vp, C.c_int32, vp]
+    L.pa_lookup_source_position_count.argtypes = [vp]
     L.pa_lookup_source_key_range.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     L.pa_lookup_source_key_bitmap.argtypes = [vp, C.c_int64, C.c_uint64, vp, vp]
     L.pa_filter_project_set_dynamic_filter_bitmap.argtypes = [vp, C.c_int32, vp, C.c_int64, C.c_uint64]

@@ -342,6 +342,10 @@ int32_t pa_filter_project_set_dynamic_filter(pa_operator* op, int32_t channel, p
         return 1;
     });
 }
+int32_t pa_lookup_source_position_count(pa_lookup_source* source)
+{
+    return guarded([&]() -> int32_t { return lookup_source_position_count(source); });
+}
 int32_t pa_lookup_source_key_range(pa_lookup_source* source, int64_t* min_key, int64_t* max_key)
 {
     return guarded([&]() -> int32_t {

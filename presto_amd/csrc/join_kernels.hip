@@ -268,6 +268,88 @@ __global__ __launch_bounds__(256) void k_join_key_slots(const i32* __restrict__ 
     }
 }
 
+// ---- keyed joins: the probe-side table is built directly from the build rows ---------------------------------------------------
+// (PagesHash.key[] -- the reference's layout, only ever read by the parity tests -- is then built on demand.)  Slot protocol:
+// head -1 empty -> -2 claimed (key being written) -> build position; equal keys raise the head with atomicMax, so it ends at
+// the highest position of the key, the head the reference's sequential insertion leaves.  The loop is wave-uniform: a lane
+// that finds a claimed slot looks again in the next round, and the claiming lane (possibly of the same wave) publishes
+// inside its own round.
+constexpr i32 kSlotBusy = -2;
+__global__ __launch_bounds__(256) void k_join_keyed_build(JoinCol build_key, const i64* __restrict__ raw_hash, i32 n, JoinKeySlot* slots, u32 mask,
+                                                          i32* __restrict__ slot_of, i32* err)
+{
+    const i64 padded = ((i64)n + 255) & ~(i64)255;
+    for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < padded; i += (i64)gridDim.x * 256) {
+        const i32 p = (i32)i;
+        bool pending = i < n && !jcol_is_null(build_key, p);  // PagesHash.java:95-97: rows with a NULL key are not inserted
+        if (i < n && !pending) slot_of[p] = -1;
+        const u64 v = pending ? join_key_bits(build_key, p) : 0ULL;
+        const i64 raw = pending ? (raw_hash ? raw_hash[p] : pa_hash_bigint((i64)v)) : 0;
+        u32 pos = (u32)pa_murmur3_fmix((u64)raw) & mask;
+        u32 probes = 0;
+        while (__ballot(pending) != 0ULL) {
+            if (pending) {
+                i32 cur = __hip_atomic_load(&slots[pos].head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (cur == -1) {
+                    cur = atomicCAS(&slots[pos].head, -1, kSlotBusy);
+                    if (cur == -1) {  // claimed: key first, then the position
+                        __hip_atomic_store(&slots[pos].key, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        atomicMax(&slots[pos].head, p);
+                        slot_of[p] = (i32)pos;
+                        pending = false;
+                    }
+                }
+                if (pending && cur >= 0) {
+                    if (__hip_atomic_load(&slots[pos].key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == v) {
+                        atomicMax(&slots[pos].head, p);
+                        slot_of[p] = (i32)pos;
+                        pending = false;
+                    }
+                    else {
+                        pos = (pos + 1) & mask;
+                        if (++probes > mask) {
+                            pa_raise(err, PA_DEV_ERR_RESOURCES);
+                            slot_of[p] = -1;
+                            pending = false;
+                        }
+                    }
+                }
+                // (cur == kSlotBusy, or the CAS lost to a claim: look at the slot again in the next round)
+            }
+        }
+    }
+}
+
+// positionLinks for the keyed table: as k_join_build_links, the head of a row's chain is slots[slot].head
+__global__ __launch_bounds__(256) void k_join_keyed_links(i32 n, const JoinKeySlot* __restrict__ slots, const i32* __restrict__ slot_of, i32* links)
+{
+    for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < n; i += (i64)gridDim.x * 256) {
+        const i32 p = (i32)i;
+        const i32 slot = slot_of[p];
+        if (slot < 0) continue;
+        i32 a = slots[slot].head;
+        if (a == p) continue;
+        for (;;) {
+            i32 nxt = __hip_atomic_load(&links[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (nxt > p) {
+                a = nxt;
+                continue;
+            }
+            __hip_atomic_store(&links[p], nxt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (atomicCAS(&links[a], nxt, p) == nxt) break;
+        }
+    }
+}
+__global__ __launch_bounds__(256) void k_join_keyed_next(JoinKeySlot* __restrict__ slots, i64 size, const i32* __restrict__ links)
+{
+    for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < size; i += (i64)gridDim.x * 256) {
+        const i32 h = slots[i].head;
+        if (h >= 0) slots[i].next = links[h];
+    }
+}
+
 __global__ __launch_bounds__(256) void k_join_key_bitmap(JoinCol build_key, i32 n, i64 min_key, u64 range, u64* __restrict__ bits)
 {
     for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < n; i += (i64)gridDim.x * 256) {
@@ -368,6 +450,18 @@ void launch_join_key_slots(const int32_t* key, int64_t hash_size, const JoinCol&
 {
     hipLaunchKernelGGL(k_join_key_slots_clear, grid_for((int64_t)slots_mask + 1), 256, 0, s, slots, (i64)slots_mask + 1);
     hipLaunchKernelGGL(k_join_key_slots, grid_for(hash_size), 256, 0, s, key, (i64)hash_size, build_key, (const i64*)raw_hash, links, slots, slots_mask);
+    PA_HIP(hipGetLastError());
+}
+void launch_join_keyed_build(const JoinCol& build_key, const int64_t* raw_hash, int32_t n, JoinKeySlot* slots, uint32_t slots_mask, int32_t* slot_of,
+                             int32_t* links, int32_t* err, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_join_key_slots_clear, grid_for((int64_t)slots_mask + 1), 256, 0, s, slots, (i64)slots_mask + 1);
+    if (n > 0) {
+        launch_fill_i32(links, -1, n, s);
+        hipLaunchKernelGGL(k_join_keyed_build, grid_for(n), 256, 0, s, build_key, (const i64*)raw_hash, n, slots, slots_mask, slot_of, err);
+        hipLaunchKernelGGL(k_join_keyed_links, grid_for(n), 256, 0, s, n, (const JoinKeySlot*)slots, (const i32*)slot_of, links);
+        hipLaunchKernelGGL(k_join_keyed_next, grid_for((int64_t)slots_mask + 1), 256, 0, s, slots, (i64)slots_mask + 1, (const i32*)links);
+    }
     PA_HIP(hipGetLastError());
 }
 void launch_join_key_bitmap(const JoinCol& build_key, int32_t n, int64_t min_key, uint64_t range, uint64_t* bits, hipStream_t s)

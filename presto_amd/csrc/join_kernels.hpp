@@ -49,6 +49,9 @@ struct JoinKeyBitmap {
     int64_t min_key;
     uint64_t range;         // max - min
 };
+// The keyed probe-side table and positionLinks straight from the build rows (raw_hash may be null: computed from the key).
+void launch_join_keyed_build(const JoinCol& build_key, const int64_t* raw_hash, int32_t n, JoinKeySlot* slots, uint32_t slots_mask, int32_t* slot_of,
+                             int32_t* links, int32_t* err, hipStream_t s);
 void launch_join_key_bitmap(const JoinCol& build_key, int32_t n, int64_t min_key, uint64_t range, uint64_t* bits, hipStream_t s);
 void launch_join_probe_count_keyed(const JoinCol& probe_key, const int64_t* probe_hash, int32_t n_probe, const JoinKeySlot* slots, uint32_t mask,
                                    const int32_t* links, const JoinKeyBitmap& bitmap, int32_t* head, int32_t* counts, int flags, hipStream_t s);

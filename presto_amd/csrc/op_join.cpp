@@ -43,6 +43,7 @@ struct LookupSourceImpl {
     uint32_t probe_mask = 0;    // size - 1 of key_slots
     DevBuf key_bits;            // existence bitmap over [key_min, key_min + key_range] (keyed joins with a dense enough key range)
     JoinKeyBitmap bitmap{nullptr, 0, 0};
+    bool reference_built = false;  // PagesHash.key[] (the reference's layout) exists; keyed joins build it on demand
     bool key_range_valid = false;  // keyed join with at least one non-NULL build key: [key_min, key_max]
     int64_t key_min = 0, key_max = 0;
     DevBuf visited;  // OuterPositionTracker.visitedPositions: 1 B per build position, written by LOOKUP_OUTER / FULL_OUTER probes
@@ -74,6 +75,29 @@ struct pa_lookup_source {
 
 namespace pa {
 namespace {
+
+// InterpretedHashGenerator over the join channels, or the precomputed $hashvalue channel
+void fill_raw_hash(LookupSourceImpl& ls, const JoinKeys& bk, int32_t n, hipStream_t s)
+{
+    ls.raw_hash.ensure((size_t)std::max(n, 1) * 8);
+    if (n <= 0) return;
+    if (ls.hash_channel >= 0) {
+        PA_HIP(hipMemcpyAsync(ls.raw_hash.ptr(), ls.cols[ls.hash_channel].values.ptr(), (size_t)n * 8, hipMemcpyDeviceToDevice, s));
+        return;
+    }
+    HashPageArgs ha;
+    memset(&ha, 0, sizeof ha);
+    for (int i = 0; i < bk.ncols; i++) {
+        ha.col[i].values = bk.col[i].values;
+        ha.col[i].offsets = bk.col[i].offsets;
+        ha.col[i].nulls = bk.col[i].nulls;
+        ha.col[i].type = bk.col[i].type;
+    }
+    ha.ncols = bk.ncols;
+    ha.n = n;
+    ha.out = ls.raw_hash.as<int64_t>();
+    launch_hash_page(ha, s);
+}
 
 // fastutil HashCommon.arraySize(expected, 0.75f) as used by PagesHash.java:64
 uint32_t array_size(int64_t expected)
@@ -177,45 +201,31 @@ public:
         const int32_t n = ls_->n;
         const uint32_t hash_size = array_size(n);
         ls_->mask = hash_size - 1;
-        ls_->key.ensure((size_t)hash_size * 4);
         ls_->links.ensure((size_t)std::max(n, 1) * 4);
         ls_->slot_of.ensure((size_t)std::max(n, 1) * 4);
-        ls_->raw_hash.ensure((size_t)std::max(n, 1) * 8);
         JoinKeys bk = ls_->build_keys();
-        if (n > 0) {
-            if (ls_->hash_channel >= 0) {
-                PA_HIP(hipMemcpyAsync(ls_->raw_hash.ptr(), ls_->cols[ls_->hash_channel].values.ptr(), (size_t)n * 8, hipMemcpyDeviceToDevice, s));
-            }
-            else {
-                HashPageArgs ha;
-                memset(&ha, 0, sizeof ha);
-                for (int i = 0; i < bk.ncols; i++) {
-                    ha.col[i].values = bk.col[i].values;
-                    ha.col[i].offsets = bk.col[i].offsets;
-                    ha.col[i].nulls = bk.col[i].nulls;
-                    ha.col[i].type = bk.col[i].type;
-                }
-                ha.ncols = bk.ncols;
-                ha.n = n;
-                ha.out = ls_->raw_hash.as<int64_t>();
-                launch_hash_page(ha, s);
-            }
-        }
-        timer.begin(s);
-        launch_join_build(bk, ls_->raw_hash.as<int64_t>(), n, ls_->key.as<int32_t>(), ls_->mask, ls_->slot_of.as<int32_t>(), ls_->links.as<int32_t>(),
-                          ctl_, s);
         ls_->keyed = bk.ncols == 1 && (bk.col[0].type == PA_BIGINT || bk.col[0].type == PA_INTEGER || bk.col[0].type == PA_DATE);
         // the probe-side table: its own size (load <= 1/2), whatever PagesHash.key[] -- the reference's layout -- uses
         uint64_t slots = 1024;
         while (slots < 2 * (uint64_t)std::max(n, 1)) slots <<= 1;
         PA_REQUIRE(slots <= (1ULL << 31), PA_ERR_INSUFFICIENT_RESOURCES, "join build side too large");
         ls_->probe_mask = (uint32_t)(slots - 1);
-        if (ls_->keyed && n > 0) build_key_bitmap(bk.col[0], n, s);
+        timer.begin(s);
         if (ls_->keyed) {
-            launch_join_key_slots(ls_->key.as<int32_t>(), (int64_t)hash_size, bk.col[0], ls_->raw_hash.as<int64_t>(), ls_->links.as<int32_t>(),
-                                  static_cast<JoinKeySlot*>(ls_->key_slots.ensure((size_t)slots * sizeof(JoinKeySlot))), ls_->probe_mask, s);
+            // one integer key: the probe-side table is built straight from the build rows; the raw hash comes from the $hashvalue
+            // channel when there is one, else from the key inside the kernel.  PagesHash.key[] is built when somebody asks for it.
+            const int64_t* raw = nullptr;
+            if (ls_->hash_channel >= 0 && n > 0) raw = ls_->cols[ls_->hash_channel].values.as<int64_t>();
+            launch_join_keyed_build(bk.col[0], raw, n, static_cast<JoinKeySlot*>(ls_->key_slots.ensure((size_t)slots * sizeof(JoinKeySlot))),
+                                    ls_->probe_mask, ls_->slot_of.as<int32_t>(), ls_->links.as<int32_t>(), ctl_, s);
+            if (n > 0) build_key_bitmap(bk.col[0], n, s);
         }
         else {
+            compute_raw_hash(bk, n, s);
+            ls_->key.ensure((size_t)hash_size * 4);
+            launch_join_build(bk, ls_->raw_hash.as<int64_t>(), n, ls_->key.as<int32_t>(), ls_->mask, ls_->slot_of.as<int32_t>(), ls_->links.as<int32_t>(),
+                              ctl_, s);
+            ls_->reference_built = true;
             launch_join_tag_slots(ls_->key.as<int32_t>(), (int64_t)hash_size, ls_->raw_hash.as<int64_t>(),
                                   static_cast<uint64_t*>(ls_->tagged.ensure((size_t)slots * 8)), ls_->probe_mask, s);
         }
@@ -228,6 +238,8 @@ public:
         ls_->built.store(true);  // lendPartitionLookupSource: probes may proceed
         if (err) throw Error(err, "hash build failed on device");
     }
+
+    void compute_raw_hash(const JoinKeys& bk, int32_t n, hipStream_t s) { fill_raw_hash(*ls_, bk, n, s); }
 
     // min / max of the build keys (one reduction pass), then -- when the keys are dense enough for the bitmap to be smaller than
     // the slot table -- one bit per existing key
@@ -624,10 +636,33 @@ int32_t lookup_join_last_pairs(pa_operator* op, const int32_t** probe_idx, const
     return PA_OK;
 }
 
+int32_t lookup_source_position_count(pa_lookup_source* ls)
+{
+    PA_REQUIRE(ls != nullptr && ls->impl != nullptr && ls->impl->built.load(), PA_ERR_ILLEGAL_STATE, "lookup source is not built");
+    return ls->impl->n;
+}
+
 // key[] / positionLinks[] of a built lookup source (tests: chain order parity with the reference)
 int32_t lookup_source_tables(pa_lookup_source* ls, const int32_t** key, int32_t* hash_size, const int32_t** links, int32_t* positions)
 {
     PA_REQUIRE(ls != nullptr && ls->impl != nullptr && ls->impl->built.load(), PA_ERR_ILLEGAL_STATE, "lookup source is not built");
+    LookupSourceImpl& impl = *ls->impl;
+    if (!impl.reference_built) {
+        // keyed joins probe their own table; PagesHash.key[] is made here, for whoever wants to compare it with the reference.
+        // The chains are the ones in use: both constructions leave a key's highest position as head and link downwards.
+        const int32_t n = impl.n;
+        const JoinKeys bk = impl.build_keys();
+        DevBuf slot_scratch, link_scratch, err;
+        fill_raw_hash(impl, bk, n, nullptr);
+        impl.key.ensure((size_t)(impl.mask + 1) * 4);
+        int32_t* e = static_cast<int32_t*>(err.ensure(64));
+        PA_HIP(hipMemsetAsync(e, 0, 64, nullptr));
+        launch_join_build(bk, impl.raw_hash.as<int64_t>(), n, impl.key.as<int32_t>(), impl.mask,
+                          static_cast<int32_t*>(slot_scratch.ensure((size_t)std::max(n, 1) * 4)),
+                          static_cast<int32_t*>(link_scratch.ensure((size_t)std::max(n, 1) * 4)), e, nullptr);
+        PA_HIP(hipStreamSynchronize(nullptr));
+        impl.reference_built = true;
+    }
     *key = ls->impl->key.as<int32_t>();
     *hash_size = (int32_t)(ls->impl->mask + 1);
     *links = ls->impl->links.as<int32_t>();

@@ -36,6 +36,7 @@ pa_operator* make_lookup_outer(const pa_lookup_join_desc* desc, pa_lookup_source
 // join-side dynamic filter: the existence bitmap of a built lookup source (false: none -- not built, not a single integer key,
 // or keys too sparse) and its application in a FilterAndProject operator upstream of the probe
 bool lookup_source_key_bitmap(pa_lookup_source* ls, const uint64_t** bits, int64_t* min_key, uint64_t* range, std::shared_ptr<void>* keep);
+int32_t lookup_source_position_count(pa_lookup_source* ls);
 bool lookup_source_key_range(pa_lookup_source* ls, int64_t* min_key, int64_t* max_key);
 void lookup_source_fill_bitmap(pa_lookup_source* ls, int64_t min_key, uint64_t range, uint64_t* bits, hipStream_t s);
 void filter_project_set_dynamic_filter(pa_operator* op, int channel, const uint64_t* bits, int64_t min_key, uint64_t range, std::shared_ptr<void> keep);

@@ -380,9 +380,7 @@ class LookupSourceFactory:
 
     def positionCount(self):
         """Build positions of the published lookup source (LookupSource.getJoinPositionCount)."""
-        key, links, hs, n = C.c_void_p(), C.c_void_p(), C.c_int32(), C.c_int32()
-        check(lib().pa_lookup_source_tables(self._h, C.byref(key), C.byref(hs), C.byref(links), C.byref(n)))
-        return n.value
+        return check(lib().pa_lookup_source_position_count(self._h))
 
     def destroy(self):
         if self._h:
