@@ -443,6 +443,10 @@ int32_t pa_partition_positions(const int32_t* partition, int32_t position_count,
  * All pointers are device pointers; out_counts_host[partition_count]. */
 int32_t pa_partition_columns(const int32_t* partition, int32_t position_count, int32_t partition_count, const void* const* in_columns,
                              void* const* out_columns, const int32_t* elem_bytes, int32_t column_count, int64_t* out_counts_host, void* stream);
+/* The same with ascending row order kept inside every partition (what PartitioningExchanger produces); at most 256 partitions.
+ * The exchange regroups its flat columns with it: one pass instead of pa_partition_positions + a pa_gather_flat per column. */
+int32_t pa_partition_columns_stable(const int32_t* partition, int32_t position_count, int32_t partition_count, const void* const* in_columns,
+                                    void* const* out_columns, const int32_t* elem_bytes, int32_t column_count, int64_t* out_counts_host, void* stream);
 /* Block.copyPositions for a flat column: dst[i] = src[positions[i]]. */
 int32_t pa_gather_flat(const void* src, int32_t elem_bytes, const int32_t* positions, int32_t count,
                        void* dst, void* stream);

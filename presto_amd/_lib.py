@@ -69,6 +69,7 @@ def lib():
     L.pa_hash_page.argtypes = [C.POINTER(abi.pa_page), C.c_int32, C.POINTER(C.c_int32), vp, vp]
     L.pa_partition_ids.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, vp, vp]
     L.pa_partition_positions.argtypes = [vp, C.c_int32, C.c_int32, vp, vp, vp]
+    L.pa_partition_columns_stable.argtypes = [vp, C.c_int32, C.c_int32, C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_int32), C.c_int32, vp, vp]
     L.pa_partition_columns.argtypes = [vp, C.c_int32, C.c_int32, C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_int32), C.c_int32, vp, vp]
     L.pa_gather_flat.argtypes = [vp, C.c_int32, vp, C.c_int32, vp, vp]
     L.pa_tpch_generate.argtypes = [C.c_int32, C.c_double, C.c_int64, C.c_int64, C.c_uint64, vp, vp, vp]

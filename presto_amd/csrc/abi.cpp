@@ -668,8 +668,22 @@ int32_t pa_partition_positions(const int32_t* partition, int32_t position_count,
     });
 }
 
+static int32_t partition_columns(const int32_t* partition, int32_t position_count, int32_t partition_count, const void* const* in_columns,
+                                 void* const* out_columns, const int32_t* elem_bytes, int32_t column_count, int64_t* out_counts_host, void* stream,
+                                 bool stable);
 int32_t pa_partition_columns(const int32_t* partition, int32_t position_count, int32_t partition_count, const void* const* in_columns,
                              void* const* out_columns, const int32_t* elem_bytes, int32_t column_count, int64_t* out_counts_host, void* stream)
+{
+    return partition_columns(partition, position_count, partition_count, in_columns, out_columns, elem_bytes, column_count, out_counts_host, stream, false);
+}
+int32_t pa_partition_columns_stable(const int32_t* partition, int32_t position_count, int32_t partition_count, const void* const* in_columns,
+                                    void* const* out_columns, const int32_t* elem_bytes, int32_t column_count, int64_t* out_counts_host, void* stream)
+{
+    return partition_columns(partition, position_count, partition_count, in_columns, out_columns, elem_bytes, column_count, out_counts_host, stream, true);
+}
+static int32_t partition_columns(const int32_t* partition, int32_t position_count, int32_t partition_count, const void* const* in_columns,
+                                 void* const* out_columns, const int32_t* elem_bytes, int32_t column_count, int64_t* out_counts_host, void* stream,
+                                 bool stable)
 {
     return guarded([&]() -> int32_t {
         PA_REQUIRE(partition != nullptr && out_counts_host != nullptr && position_count >= 0, PA_ERR_INVALID_ARGUMENT, "null argument");
@@ -686,7 +700,7 @@ int32_t pa_partition_columns(const int32_t* partition, int32_t position_count, i
         DevBuf temp, counts;
         temp.ensure(msplit_temp_bytes(position_count, partition_count));
         counts.ensure((size_t)partition_count * 8);
-        launch_msplit(partition, position_count, partition_count, cols.data(), column_count, counts.as<int64_t>(), temp.ptr(), s);
+        launch_msplit(partition, position_count, partition_count, cols.data(), column_count, counts.as<int64_t>(), temp.ptr(), s, stable);
         PA_HIP(hipMemcpyAsync(out_counts_host, counts.ptr(), (size_t)partition_count * 8, hipMemcpyDeviceToHost, s));
         PA_HIP(hipStreamSynchronize(s));
         return PA_OK;

@@ -412,6 +412,103 @@ __global__ __launch_bounds__(kMsThreads) void k_msplit_scatter(MsplitArgs a)
     }
 }
 
+// The stable form (at most 256 partitions): a row's place inside its (tile, partition) is the number of earlier rows of the tile
+// with the same partition -- the rank computation of k_radix_scatter_stable -- so every partition keeps ascending row order,
+// what the exchange needs (PartitioningExchanger appends positions in order).
+__global__ __launch_bounds__(kMsThreads) void k_msplit_scatter_stable(MsplitArgs a)
+{
+    __shared__ i32 goff[256], lstart[256], running[256];
+    __shared__ i32 cnt[16][256], off[16][256];
+    __shared__ i32 wave_sums[16];
+    __shared__ u8 ldigit[kMsTile];
+    __shared__ u64 buf[kMsTile];
+    const i64 tile0 = (i64)blockIdx.x * kMsTile;
+    const i32 tile_rows = (i32)(a.n - tile0 < (i64)kMsTile ? a.n - tile0 : (i64)kMsTile);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    i32 mine = 0;
+    if (threadIdx.x < 256) {
+        goff[threadIdx.x] = 0;
+        running[threadIdx.x] = 0;
+#pragma unroll
+        for (int w = 0; w < 16; w++) cnt[w][threadIdx.x] = 0;
+        if ((i32)threadIdx.x < a.P) {
+            const i64 idx = (i64)threadIdx.x * a.tiles + blockIdx.x;
+            const i32 o = a.offsets[idx];
+            const i32 nx = idx + 1 < (i64)a.P * a.tiles ? a.offsets[idx + 1] : (i32)a.n;
+            goff[threadIdx.x] = o;
+            mine = nx - o;
+        }
+    }
+    i32 inc = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const i32 v = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += v;
+    }
+    if (lane == 63) wave_sums[wave] = inc;
+    __syncthreads();
+    if (threadIdx.x < 256) {
+        i32 base = 0;
+        for (int w = 0; w < wave; w++) base += wave_sums[w];
+        lstart[threadIdx.x] = base + inc - mine;
+    }
+    __syncthreads();
+    unsigned short li[kMsItems];
+    for (int i = 0; i < kMsItems; i++) {
+        const i64 row = tile0 + (i64)i * kMsThreads + threadIdx.x;
+        const bool live = row < a.n;
+        const u32 d = live ? (u32)a.part[row] & 255u : 0u;
+        u64 peers = __ballot(live);
+#pragma unroll
+        for (int bit = 0; bit < 8; bit++) {
+            const u64 b = __ballot(live && ((d >> bit) & 1u));
+            peers &= ((d >> bit) & 1u) ? b : ~b;
+        }
+        const int before = __popcll(peers & ((1ULL << lane) - 1ULL));
+        if (live && before == 0) cnt[wave][d] = (i32)__popcll(peers);
+        __syncthreads();
+        if (threadIdx.x < 256) {
+            i32 acc = running[threadIdx.x];
+#pragma unroll
+            for (int w = 0; w < 16; w++) {
+                const i32 c = cnt[w][threadIdx.x];
+                cnt[w][threadIdx.x] = 0;
+                off[w][threadIdx.x] = acc;
+                acc += c;
+            }
+            running[threadIdx.x] = acc;
+        }
+        __syncthreads();
+        li[i] = 0;
+        if (live) {
+            const i32 at = lstart[d] + off[wave][d] + before;
+            li[i] = (unsigned short)at;
+            ldigit[at] = (u8)d;
+        }
+    }
+    __syncthreads();
+    for (int c = 0; c < a.ncols; c++) {
+        const MsplitCol col = a.col[c];
+        for (int i = 0; i < kMsItems; i++) {
+            const i64 row = tile0 + (i64)i * kMsThreads + threadIdx.x;
+            if (row < a.n) {
+                if (col.width == 8) buf[li[i]] = ((const u64*)col.in)[row];
+                else if (col.width == 4) ((u32*)buf)[li[i]] = ((const u32*)col.in)[row];
+                else ((u8*)buf)[li[i]] = ((const u8*)col.in)[row];
+            }
+        }
+        __syncthreads();
+        for (i32 j = threadIdx.x; j < tile_rows; j += kMsThreads) {
+            const i32 d = ldigit[j];
+            const i64 dest = (i64)goff[d] + (j - lstart[d]);
+            if (col.width == 8) ((u64*)col.out)[dest] = buf[j];
+            else if (col.width == 4) ((u32*)col.out)[dest] = ((const u32*)buf)[j];
+            else ((u8*)col.out)[dest] = ((const u8*)buf)[j];
+        }
+        __syncthreads();
+    }
+}
+
 size_t msplit_temp_bytes(int64_t n, int32_t partition_count)
 {
     const int64_t tiles = (n + kMsTile - 1) / kMsTile;
@@ -419,9 +516,9 @@ size_t msplit_temp_bytes(int64_t n, int32_t partition_count)
 }
 
 void launch_msplit(const int32_t* partition, int64_t n, int32_t partition_count, const MsplitCol* cols, int32_t ncols, int64_t* out_counts_dev,
-                   void* temp, hipStream_t s)
+                   void* temp, hipStream_t s, bool stable)
 {
-    PA_REQUIRE(partition_count >= 1 && partition_count <= 1024, PA_ERR_NOT_SUPPORTED, "1..1024 partitions");
+    PA_REQUIRE(partition_count >= 1 && partition_count <= (stable ? 256 : 1024), PA_ERR_NOT_SUPPORTED, "1..1024 partitions (stable: 1..256)");
     PA_REQUIRE(ncols >= 0 && ncols <= kMsplitMaxCols, PA_ERR_NOT_SUPPORTED, "too many columns for one multisplit");
     if (n <= 0) {
         PA_HIP(hipMemsetAsync(out_counts_dev, 0, (size_t)partition_count * 8, s));
@@ -444,7 +541,8 @@ void launch_msplit(const int32_t* partition, int64_t n, int32_t partition_count,
         PA_REQUIRE(cols[c].width == 1 || cols[c].width == 4 || cols[c].width == 8, PA_ERR_NOT_SUPPORTED, "multisplit moves 1, 4 or 8 byte elements");
         a.col[c] = cols[c];
     }
-    hipLaunchKernelGGL(k_msplit_scatter, (int)tiles, kMsThreads, 0, s, a);
+    if (stable) hipLaunchKernelGGL(k_msplit_scatter_stable, (int)tiles, kMsThreads, 0, s, a);
+    else hipLaunchKernelGGL(k_msplit_scatter, (int)tiles, kMsThreads, 0, s, a);
     hipLaunchKernelGGL(k_partition_totals, 1, 1024, 0, s, (const i32*)counts, (i64)tiles, partition_count, (i64)n, (i64*)out_counts_dev);
     PA_HIP(hipGetLastError());
 }

@@ -42,8 +42,9 @@ struct MsplitCol {
     int32_t pad;
 };
 size_t msplit_temp_bytes(int64_t n, int32_t partition_count);
+// stable = ascending row order inside every partition (at most 256 partitions)
 void launch_msplit(const int32_t* partition, int64_t n, int32_t partition_count, const MsplitCol* cols, int32_t ncols, int64_t* out_counts_dev,
-                   void* temp, hipStream_t s);
+                   void* temp, hipStream_t s, bool stable = false);
 // One STABLE 8-bit LSD radix pass over (key, payload) pairs held as two columns: the pairs regrouped by digit =
 // (key >> shift) & 255, arrival order kept inside a digit.  Same LDS-staged structure as the multisplit (8192-row tiles,
 // coalesced reads and writes); the rank of a row inside its (tile, digit) is the number of earlier rows of the tile with the

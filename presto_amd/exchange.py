@@ -74,6 +74,26 @@ class DeviceOps:
                                                      counts, self._stream()))
         return pos, [int(c) for c in counts]
 
+    def partition_columns(self, partition, partition_count, columns, want_positions):
+        """The flat columns regrouped by partition in one stable multisplit pass (row order kept inside a partition) instead of
+        partition_positions + one gather per column -> (regrouped columns, positions or None, rows per partition).  None when
+        the partition count is beyond the stable kernel's 256."""
+        if partition_count > 256:
+            return None
+        n = partition.numel()
+        cols = list(columns)
+        if want_positions:
+            cols.append(torch.arange(n, dtype=torch.int32, device=partition.device))
+        outs = [torch.empty_like(c) for c in cols]
+        vp = C.c_void_p
+        ins = (vp * max(len(cols), 1))(*[c.data_ptr() for c in cols])
+        ous = (vp * max(len(cols), 1))(*[c.data_ptr() for c in outs])
+        widths = (C.c_int32 * max(len(cols), 1))(*[c.element_size() for c in cols])
+        counts = (C.c_int64 * partition_count)()
+        self._check(self._lib.pa_partition_columns_stable(partition.data_ptr(), n, partition_count, ins, ous, widths, len(cols), counts, self._stream()))
+        positions = outs.pop() if want_positions else None
+        return outs, positions, [int(c) for c in counts]
+
     def gather_varwidth(self, values, offsets, positions):
         """Block.copyPositions for a VARCHAR column -> (bytes, offsets, per-row lengths)."""
         n = positions.numel()
@@ -125,8 +145,22 @@ def exchange_columns(ops, columns, types, hash_channels, group=None, local=None,
         local = (world & (world - 1)) == 0  # LocalPartitionGenerator needs a power of two
     device = (columns[0][0] if isinstance(columns[0], (tuple, list)) else columns[0]).device
     rows = rows_of(columns[0])
+    regrouped = {}
     if rows > 0:
-        positions, send_counts = partition_rows(ops, columns, types, hash_channels, world, local, raw_hash)
+        fast = None
+        if hasattr(ops, "partition_columns"):
+            # device path: all flat columns regrouped by destination in one stable multisplit pass (same row order as the
+            # position list gives); a position list is only made for VARCHAR columns
+            if raw_hash is None:
+                raw_hash = ops.hash_rows(columns, types, hash_channels)
+            part = ops.partition_ids(raw_hash, world, local)
+            flat = [i for i, t in enumerate(types) if t != abi.VARCHAR]
+            fast = ops.partition_columns(part, world, [columns[i] for i in flat], any(t == abi.VARCHAR for t in types))
+        if fast is not None:
+            outs, positions, send_counts = fast
+            regrouped = dict(zip(flat, outs))
+        else:
+            positions, send_counts = partition_rows(ops, columns, types, hash_channels, world, local, raw_hash)
     else:  # a rank with nothing to send still takes part in the collectives
         positions, send_counts = None, [0] * world
     # 8 x 8 count matrix: every rank learns how much it receives from each source
@@ -135,7 +169,7 @@ def exchange_columns(ops, columns, types, hash_channels, group=None, local=None,
     dist.all_to_all_single(rc, sc, group=group)
     recv_counts = [int(x) for x in rc.tolist()]
     received = []
-    for col, t in zip(columns, types):
+    for ci, (col, t) in enumerate(zip(columns, types)):
         if t == abi.VARCHAR:
             values, offsets = col
             if rows > 0:
@@ -159,7 +193,7 @@ def exchange_columns(ops, columns, types, hash_channels, group=None, local=None,
             assert total == sum(recv_byte_counts)
             received.append((recv_bytes, recv_offsets))
             continue
-        send = ops.gather(col, positions) if rows > 0 else col
+        send = (regrouped[ci] if ci in regrouped else ops.gather(col, positions)) if rows > 0 else col
         recv = torch.empty(sum(recv_counts), dtype=col.dtype, device=device)
         dist.all_to_all_single(recv, send, output_split_sizes=recv_counts, input_split_sizes=send_counts, group=group)
         received.append(recv)

@@ -136,3 +136,31 @@ def test_partition_columns_multisplit(gpu, n, parts):
     got_part = part[ids.long()] if n else part
     want = torch.repeat_interleave(torch.arange(parts, device="cuda", dtype=torch.int32), torch.tensor(counts, device="cuda"))
     assert torch.equal(got_part, want) and bounds[-1] == n
+
+
+@pytest.mark.parametrize("n,parts", [(1, 1), (5000, 2), (8193, 8), (300001, 256), (1 << 22, 8)])
+def test_partition_columns_stable(gpu, oracle, n, parts):
+    """pa_partition_columns_stable: the columns regrouped by partition with ascending row order inside every partition -- exactly
+    the gather through pa_partition_positions' position list (the oracle's stable partition)."""
+    import ctypes as C
+    import torch
+    from presto_amd._lib import check, lib
+    g = torch.Generator(device="cuda").manual_seed(n + 1)
+    part = torch.randint(0, parts, (n,), dtype=torch.int32, device="cuda", generator=g)
+    rowid = torch.arange(n, dtype=torch.int32, device="cuda")
+    c8 = torch.randint(-(1 << 60), 1 << 60, (n,), dtype=torch.int64, device="cuda", generator=g)
+    c1 = (rowid % 7).to(torch.uint8)
+    cols = [rowid, c8, c1]
+    outs = [torch.empty_like(c) for c in cols]
+    torch.cuda.synchronize()
+    vp = C.c_void_p
+    ins = (vp * 3)(*[c.data_ptr() for c in cols])
+    ous = (vp * 3)(*[c.data_ptr() for c in outs])
+    widths = (C.c_int32 * 3)(4, 8, 1)
+    counts = np.zeros(parts, dtype=np.int64)
+    check(lib().pa_partition_columns_stable(part.data_ptr(), n, parts, ins, ous, widths, 3, counts.ctypes.data, None))
+    pos, ocounts = oracle.partition_positions(part.cpu().numpy(), parts)
+    assert counts.tolist() == ocounts.tolist()
+    assert outs[0].cpu().numpy().tolist() == pos.tolist()
+    p = torch.from_numpy(pos).cuda().long()
+    assert torch.equal(outs[1], c8[p]) and torch.equal(outs[2], c1[p])
