@@ -138,3 +138,33 @@ def test_far_offset_sample_matches_oracle(lineitem, oracle):
     s, c = q6(lineitem, first, count)
     es, ec = oracle.q6(*[oracle.tpch_column(col, SF, first, count)[0] for col in tpch.Q6_COLUMNS])
     assert c == ec and abs(s - es) <= 1e-9 * abs(es)
+
+
+@pytest.mark.parametrize("groups", [3000, 150000, 5_000_000])
+def test_grouped_aggregation_over_a_full_size_page(gpu, groups):
+    """HashAggregation over ONE 2^28-row page (several 2^26-row chunks inside the operator) at the cardinalities of the LDS-table,
+    the hash-partitioned (multisplit) and the HBM-table tier, against torch: the per-group counts exactly (bincount), the
+    sums exactly too (every value is 0.5, so any summation order gives the same double)."""
+    import torch
+    from presto_amd.operators import HashAggregationOperator, download_page
+    from presto_amd.page import Block, DeviceBuffer, Page
+    n = 1 << 28
+    g = torch.Generator(device="cuda").manual_seed(groups)
+    keys = torch.randint(0, groups, (n,), dtype=torch.int64, device="cuda", generator=g)
+    vals = torch.full((n,), 0.5, dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    page = Page([Block(abi.BIGINT, abi.FLAT, n, values=DeviceBuffer(keys.data_ptr(), n * 8, keys)),
+                 Block(abi.DOUBLE, abi.FLAT, n, values=DeviceBuffer(vals.data_ptr(), n * 8, vals))], n, abi.MEM_DEVICE)
+    op = HashAggregationOperator([abi.BIGINT, abi.DOUBLE], [0], [(abi.AGG_COUNT_STAR, -1, None), (abi.AGG_SUM, 1, abi.DOUBLE)],
+                                 expected_groups=groups, output_mem=abi.MEM_DEVICE)
+    op.addInput(page)
+    op.finish()
+    out = download_page(op.getOutput())
+    op.close()
+    k = np.asarray(out.blocks[0].values)
+    c = np.asarray(out.blocks[1].values)
+    s = np.asarray(out.blocks[2].values)
+    expected = torch.bincount(keys, minlength=groups).cpu().numpy()
+    assert len(k) == int((expected > 0).sum()) and len(np.unique(k)) == len(k)
+    assert np.array_equal(c, expected[k]) and int(c.sum()) == n
+    assert np.array_equal(s, c * 0.5)
