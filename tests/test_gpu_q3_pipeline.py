@@ -117,3 +117,36 @@ def test_q3_with_topn(gpu, oracle):
     for g, e in zip(rows, top):
         assert g[:3] == e[:3] and g[4] == e[4] and abs(g[3] - e[3]) <= 1e-9 * abs(e[3])
     stream.destroy()
+
+
+def test_q3_sf100_independent_paths_agree(gpu):
+    """BASELINE config #4 at full size (765 M input rows), tied to the small-scale oracle parity above through a size-independent
+    property: the TopN result must not depend on the path -- with / without the joins' dynamic filters (rows dropped before
+    the probe vs inside it), with / without the extra count(*) (implicit vs explicit count word), 2^28- vs 2^26-row pages."""
+    from presto_amd import q3
+    sf = 100.0
+    customer, orders, lineitem = _device_tables(sf)
+    stream = DeviceStream()
+
+    def run(page_rows, **kw):
+        out, counters = q3.run(customer.pages(page_rows - page_rows % 20), orders.pages(page_rows), lineitem.pages(page_rows), stream.handle,
+                               distributed=False, top_n=10, **kw)
+        return [r for p in out for r in p.to_rows()], counters
+
+    base, counters = run(1 << 28)
+    assert len(base) == 10 and counters["lineitem_dynamic_filter"] is True and counters["build2_rows"] > 10_000_000
+    revenue = [r[3] for r in base]
+    assert revenue == sorted(revenue, reverse=True)
+    plain, counters2 = run(1 << 28, dynamic_filters=False)
+    assert "lineitem_dynamic_filter" not in counters2
+
+    def same(a, b, cols):
+        assert len(a) == len(b)
+        for x, y in zip(a, b):
+            assert x[:3] == y[:3] and all(abs(x[c] - y[c]) <= 1e-9 * abs(y[c]) for c in cols), (x, y)
+
+    same(base, plain, [3])
+    assert [r[4] for r in base] == [r[4] for r in plain]  # count(*) per group, exactly
+    same(run(1 << 28, with_count=False)[0], base, [3])
+    same(run(1 << 26)[0], base, [3])
+    stream.destroy()
