@@ -570,11 +570,15 @@ KernelInfo generate(const Spec& s, const std::vector<ChannelLayout>& layout, int
         src << "struct PaAcc { int unused; };\n";
     }
     else {
-        src << "struct PaAcc { PaGtView tv; PaGtCtr gt; };\n";
+        // pending run of the thread: consecutive selected rows with equal keys are combined before they touch the table
+        src << "struct PaAcc { PaGtView tv; PaGtCtr gt; i32 pn; i32 prow; u64 pk[PA_KW];";
+        for (int w = 0; w < k.nw; w++) src << " bool pu" << w << "; " << (words[w].kind == W_SUMF ? "double" : (words[w].kind == W_MAXU ? "u64" : "i64")) << " px" << w << ";";
+        src << " };\n";
     }
     if (variant == V_GT || variant == V_LDSH) {
         // accumulation of one row into the workgroup's LDS table / the HBM table
-        src << "__device__ __forceinline__ void pa_acc(const PaFusedArgs& a, PaAcc& acc, const bool sel, const i32 row, const u64 (&key)[PA_KW]";
+        src << "__device__ __forceinline__ void " << (variant == V_GT ? "pa_acc_now" : "pa_acc")
+            << "(const PaFusedArgs& a, PaAcc& acc, const bool sel, const i32 row, " << (variant == V_GT ? "const i32 nrows, " : "") << "const u64 (&key)[PA_KW]";
         for (int w = 0; w < k.nw; w++) src << ", const bool u" << w << ", const " << (words[w].kind == W_SUMF ? "double" : (words[w].kind == W_MAXU ? "u64" : "i64")) << " x" << w;
         src << ")\n{\n";
         src << "if (sel) {\n  const u32 h = pa_key_hash(key, PA_KW);\n";
@@ -610,10 +614,41 @@ KernelInfo generate(const Spec& s, const std::vector<ChannelLayout>& layout, int
             else src << "    if (u" << w << ") pa_gt_add_u64(acc.tv.words, " << idx << ", (u64)x" << w << ");\n";
         }
         // no room for this row's group: spill the row; the host rehashes and replays the spilled rows
-        src << "  } else {\n    a.spill_rows[atomicAdd(a.spill_count, 1u)] = row;\n  }\n";
+        if (variant == V_GT) {
+            src << "  } else {\n    const u32 sb = atomicAdd(a.spill_count, (u32)nrows);\n    for (i32 i = 0; i < nrows; i++) a.spill_rows[sb + (u32)i] = row + i;\n  }\n";
+        }
+        else {
+            src << "  } else {\n    a.spill_rows[atomicAdd(a.spill_count, 1u)] = row;\n  }\n";
+        }
         if (variant == V_LDSH) src << "  }\n";
         src << "}\n";
         src << "}\n\n";
+        if (variant == V_GT) {
+            // Run combining.  A thread of the vector loop walks 4 consecutive rows; when their keys repeat (clustered inputs: a
+            // fact table joined on its own key order) the rows are combined in registers and reach the table once -- one probe and
+            // one atomic per word for the run.  pa_flush ends the pending run; the loops call it after every quad (every row
+            // in the scalar / list loops), so a run is always a range of consecutive rows, which is what a spill records.
+            src << "__device__ __forceinline__ void pa_flush(const PaFusedArgs& a, PaAcc& acc, const bool doit)\n{\n"
+                   "  pa_acc_now(a, acc, doit && acc.pn > 0, acc.prow, acc.pn, acc.pk";
+            for (int w = 0; w < k.nw; w++) src << ", acc.pu" << w << ", acc.px" << w;
+            src << ");\n  if (doit) acc.pn = 0;\n}\n";
+            src << "__device__ __forceinline__ void pa_acc(const PaFusedArgs& a, PaAcc& acc, const bool sel, const i32 row, const u64 (&key)[PA_KW]";
+            for (int w = 0; w < k.nw; w++) src << ", const bool u" << w << ", const " << (words[w].kind == W_SUMF ? "double" : (words[w].kind == W_MAXU ? "u64" : "i64")) << " x" << w;
+            src << ")\n{\n  bool same = sel && acc.pn > 0;\n#pragma unroll\n  for (int w = 0; w < PA_KW; w++) same = same && key[w] == acc.pk[w];\n"
+                   "  pa_flush(a, acc, !same);\n  if (sel) {\n    if (acc.pn == 0) {\n#pragma unroll\n      for (int w = 0; w < PA_KW; w++) acc.pk[w] = key[w];\n"
+                   "      acc.prow = row;\n      acc.pn = 1;\n";
+            for (int w = 0; w < k.nw; w++) src << "      acc.pu" << w << " = u" << w << "; acc.px" << w << " = x" << w << ";\n";
+            src << "    } else {\n      acc.pn = row - acc.prow + 1;\n";
+            for (int w = 0; w < k.nw; w++) {
+                const std::string P = "acc.px" + std::to_string(w), U = "acc.pu" + std::to_string(w), X = "x" + std::to_string(w);
+                std::string comb;
+                if (words[w].kind == W_SUMF || words[w].kind == W_CNT) comb = P + " + " + X;
+                else if (words[w].kind == W_SUMI) comb = "pa_add_exact(" + P + ", " + X + ", a.err)";
+                else comb = "(" + X + " > " + P + " ? " + X + " : " + P + ")";
+                src << "      if (u" << w << ") { " << P << " = " << U << " ? " << comb << " : " << X << "; " << U << " = true; }\n";
+            }
+            src << "    }\n  }\n}\n\n";
+        }
     }
     src << "__device__ __forceinline__ void pa_row(const PaFusedArgs& a, PaAcc& acc, const bool live, const i32 row" << row_params(ri, layout) << ")\n{\n";
     src << body.str();
@@ -712,8 +747,10 @@ KernelInfo generate(const Spec& s, const std::vector<ChannelLayout>& layout, int
             src << "    PaAcc acc; acc.unused = 0;\n";
         }
         else {
-            src << "    PaAcc acc; acc.tv = pa_gt_view(a, PA_KW, PA_NW); acc.gt = pa_gt_ctr_init(acc.tv.count, true, a.gt_rep_mask + 1u);\n";
+            src << "    PaAcc acc; acc.tv = pa_gt_view(a, PA_KW, PA_NW); acc.gt = pa_gt_ctr_init(acc.tv.count, true, a.gt_rep_mask + 1u); acc.pn = 0;\n";
         }
+        // V_GT: the pending run of every thread ends after a quad of consecutive rows / after every row of the other loops
+        const std::string flush = variant == V_GT ? " pa_flush(a, acc, true);" : "";
         if (mode != 2) emit_prologue(ri, layout, src);
         if (variant == V_GLOBAL) {
             // XCD-aware block -> tile mapping: consecutive workgroup ids go round-robin to the 8 XCDs, so give the
@@ -742,8 +779,8 @@ KernelInfo generate(const Spec& s, const std::vector<ChannelLayout>& layout, int
             src << "    for (i64 q = t; q < nq; q += T) {\n";
             emit_vector_loads(ri, layout, src, args);
             for (int r = 0; r < 4; r++) src << "        pa_row(a, acc, true, (i32)(4 * q + " << r << ")" << args[r] << ");\n";
-            src << "    }\n";
-            src << "    for (i64 r = (nq << 2) + t; r < a.n; r += T) {\n        pa_row(a, acc, true, (i32)r" << scalar_args(ri, layout) << ");\n    }\n";
+            src << "       " << flush << "\n    }\n";
+            src << "    for (i64 r = (nq << 2) + t; r < a.n; r += T) {\n        pa_row(a, acc, true, (i32)r" << scalar_args(ri, layout) << ");" << flush << "\n    }\n";
         }
         if (variant == V_GT || variant == V_LDSH) {
             // rows given by a list: grid-stride (spill replays), or one contiguous slice per workgroup (partition-ordered lists:
@@ -751,9 +788,9 @@ KernelInfo generate(const Spec& s, const std::vector<ChannelLayout>& layout, int
             src << "    if (a.list_blocked) {\n        const i64 per = (a.n_list + gridDim.x - 1) / gridDim.x;\n"
                    "        const i64 b0 = (i64)blockIdx.x * per, b1 = b0 + per < a.n_list ? b0 + per : a.n_list;\n"
                    "        for (i64 i = b0 + threadIdx.x; i < b1; i += " << B << ") {\n            const i64 r = a.list_blocked == 2 ? i : (i64)a.row_list[i];\n            pa_row(a, acc, true, (i32)r"
-                << scalar_args(ri, layout) << ");\n        }\n    } else {\n";
+                << scalar_args(ri, layout) << ");" << flush << "\n        }\n    } else {\n";
             src << "    for (i64 i = t; i < a.n_list; i += T) {\n        const i64 r = a.row_list[i];\n        pa_row(a, acc, true, (i32)r" << scalar_args(ri, layout)
-                << ");\n    }\n    }\n";
+                << ");" << flush << "\n    }\n    }\n";
         }
         if (variant == V_LDSH) {
             // the workgroup's table -> HBM table: one upsert and PA_NW atomics per group and workgroup
