@@ -2,6 +2,8 @@
 nullable BOOLEAN, DOUBLE with -0.0 / NaN, short VARCHAR with a declared length bound, longer VARCHAR, interned text), random aggregates
 (count(*), count, sum, avg, min, max; masks; nullable inputs), cardinalities from a handful to tens of thousands -- so the
 key packing (bit fields, two-word strings, NULL flags) and every tier of the aggregation see shapes nobody wrote by hand."""
+import os
+
 import numpy as np
 import pytest
 
@@ -36,7 +38,7 @@ def key_column(rng, kind, n, card):
     return abi.VARCHAR, Block.varchar([WORDS_LONG[i] for i in rng.integers(0, len(WORDS_LONG), n)]), 0
 
 
-@pytest.mark.parametrize("seed", list(range(24)))
+@pytest.mark.parametrize("seed", list(range(int(os.environ.get("PA_FUZZ_SEEDS", "24")))))  # PA_FUZZ_SEEDS=N: a longer one-off run
 def test_random_group_by_shapes(gpu, oracle, seed):
     rng = np.random.default_rng(7000 + seed)
     kinds = ["bigint", "integer", "date", "boolean", "double", "short", "long", "text"]

@@ -3,6 +3,8 @@ in tests/test_oracle_operators.py::dynamic_filter_kats) and against the oracle o
 the fall-back to min / max, giving up, NULL / NaN / -0.0 handling, VARCHAR channels, pass-through of the pages."""
 import math
 
+import os
+
 import numpy as np
 import pytest
 
@@ -71,7 +73,7 @@ def test_predicate_is_not_ready_before_finish_unless_given_up(gpu):
     assert op.predicate() == "all"
 
 
-@pytest.mark.parametrize("seed", list(range(16)))
+@pytest.mark.parametrize("seed", list(range(int(os.environ.get("PA_FUZZ_SEEDS", "16")))))  # PA_FUZZ_SEEDS=N: a longer one-off run
 def test_random_build_sides_against_oracle(gpu, oracle, seed):
     rng = np.random.default_rng(900 + seed)
     kinds = [abi.BIGINT, abi.INTEGER, abi.DATE, abi.DOUBLE, abi.BOOLEAN, abi.VARCHAR]

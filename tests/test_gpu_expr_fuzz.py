@@ -2,6 +2,8 @@
 (AND / OR / NOT / IF / COALESCE / BETWEEN / IN / IS NULL), exact BIGINT / INTEGER arithmetic with its error cases
 (NUMERIC_VALUE_OUT_OF_RANGE, DIVISION_BY_ZERO -- also the ones a short-circuit must NOT raise), DOUBLE arithmetic compared
 as raw bits (no fused multiply-add), casts, comparisons across nullable columns.  Seeded: the same trees every run."""
+import os
+
 import numpy as np
 import pytest
 
@@ -93,7 +95,7 @@ def raw_bits(rows):
     return [tuple(struct.pack("<d", v) if isinstance(v, float) and v == v else ("nan" if isinstance(v, float) else v) for v in r) for r in rows]
 
 
-@pytest.mark.parametrize("seed", list(range(40)))
+@pytest.mark.parametrize("seed", list(range(int(os.environ.get("PA_FUZZ_SEEDS", "40")))))  # PA_FUZZ_SEEDS=N: a longer one-off run
 def test_random_expression_trees(gpu, oracle, seed):
     rng = np.random.default_rng(1000 + seed)
     g = Gen(rng)
