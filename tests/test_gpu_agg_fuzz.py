@@ -96,3 +96,53 @@ def test_random_group_by_shapes(gpu, oracle, seed):
                 assert gv != gv, (k, g[k], er)
             else:
                 assert gv == ev, (k, g[k], er)
+
+
+@pytest.mark.parametrize("seed", list(range(int(os.environ.get("PA_FUZZ_SEEDS", "16")))))
+def test_random_page_sequences(gpu, oracle, seed):
+    """Sequences of pages whose shape changes from page to page: valueIsNull arrays that come and go per column (state layout
+    generations, implicit count words), keys in runs / sorted (run combining on the table tier), the VARCHAR key as a plain,
+    dictionary or RLE block (dictionary route of the interned keys), tiny and large pages -- against the oracle."""
+    rng = np.random.default_rng(9100 + seed)
+    card = int([4, 300, 6000, 90000][seed % 4])
+    clustered = bool(rng.integers(0, 2))
+    text = [b"item-%06d-%s" % (i, b"w" * (i % 21)) for i in range(min(card, 5000))]
+    pages = []
+    for _ in range(int(rng.integers(2, 6))):
+        n = int(rng.choice([3, 70, 5000, 120000]))
+        k = rng.integers(0, card, n)
+        if clustered:
+            k = np.sort(k)
+        def nulls(p=0.06):
+            return (rng.random(n) < p) if rng.random() < 0.4 else None
+        tk = k % len(text)
+        form = int(rng.integers(0, 3))
+        if form == 0:
+            tblock = Block.varchar([None if (rng.random() < 0.02) else text[i] for i in tk])
+        elif form == 1:
+            tblock = Block.dictionary_block(Block.varchar(text + [None]), np.where(rng.random(n) < 0.02, len(text), tk).astype(np.int32))
+        else:
+            tblock = Block.rle(Block.varchar([text[int(tk[0])]]), n)
+        pages.append(Page([Block.bigint(k * 13 - 7, nulls()), tblock, Block.double(rng.random(n) * 8, nulls()), Block.bigint(rng.integers(-99, 99, n), nulls()),
+                           Block.boolean(rng.random(n) < 0.75, nulls())], n))
+    types = [abi.BIGINT, abi.VARCHAR, abi.DOUBLE, abi.BIGINT, abi.BOOLEAN]
+    keys = [[0], [1], [0, 1]][seed % 3]
+    pool = [(abi.AGG_COUNT_STAR, -1, None), (abi.AGG_SUM, 2, abi.DOUBLE), (abi.AGG_SUM, 3, abi.BIGINT), (abi.AGG_MIN, 2, abi.DOUBLE), (abi.AGG_MAX, 3, abi.BIGINT),
+            (abi.AGG_AVG, 2, abi.DOUBLE), (abi.AGG_COUNT, 3, abi.BIGINT), (abi.AGG_SUM, 2, abi.DOUBLE, 4)]
+    aggs = [pool[i] for i in sorted(rng.choice(len(pool), int(rng.integers(1, 5)), replace=False))]
+    op = HashAggregationOperator(types, keys, aggs, expected_groups=card)
+    got = [r for p in to_pages(op, pages) for r in p.to_rows()]
+    ref = oracle.HashAggregation(types, keys, aggs)
+    for p in pages:
+        ref.add_page(p)
+    expected = ref.build_result().to_rows()
+    nk = len(keys)
+    assert len(got) == len(expected)
+    g, e = {r[:nk]: r for r in got}, {r[:nk]: r for r in expected}
+    assert len(g) == len(got) and set(g) == set(e)
+    for kk, er in e.items():
+        for gv, ev in zip(g[kk][nk:], er[nk:]):
+            if isinstance(ev, float):
+                assert gv == ev or abs(gv - ev) <= 1e-9 * max(abs(gv), abs(ev)), (kk, g[kk], er)
+            else:
+                assert gv == ev, (kk, g[kk], er)
