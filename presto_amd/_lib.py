@@ -10,7 +10,7 @@ import os
 from . import abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpresto_amd.so")
+LIB_PATH = os.environ.get("PRESTO_AMD_LIB") or os.path.join(_HERE, "libpresto_amd.so")  # PRESTO_AMD_LIB: A/B runs against another build
 _LIB = None
 
 

@@ -33,7 +33,10 @@ constexpr int kMaxChannels = 32;
 // A workgroup of 256 threads handles kTileQuads x 256 row quads.  More than one quad per thread (fewer, longer workgroups,
 // all loads in flight before the first block scan) was measured SLOWER on MI355X -- page -> page over 2^27 rows, 1 / 2 / 4 / 8
 // quads: Q6 filter 155 / 146 / 147 / 147 G rows/s, Q1 filter (96 % pass) 106 / 92 / 80 / 79 G, Q3 per step 27.8 / 28.5 / 29.1 /
-// 29.0 ms -- so the default stays 1; PRESTO_AMD_FP_QUADS overrides it for experiments.
+// 29.0 ms -- so the default stays 1; PRESTO_AMD_FP_QUADS overrides it for experiments.  Also measured and dropped: counting and
+// ranking per WAVE (256 rows) with shuffles only, no block-wide scan and no barrier in either kernel -- same box, same run:
+// Q6 filter 149 vs 152 G rows/s, Q1 filter 97 vs 100 G, Q3 even; the four times longer count array and its scan cost more
+// than the two barriers per tile.
 static const int kTileQuads = [] {
     const char* e = getenv("PRESTO_AMD_FP_QUADS");
     const int q = e ? atoi(e) : 1;
