@@ -14,12 +14,10 @@ namespace {
 // 8-byte word w of a string (zero padded behind its end): the unit strings are stored and compared in
 __device__ __forceinline__ u64 string_word(const u8* p, i32 len, i32 w)
 {
-    u64 v = 0;
     const i32 base = 8 * w;
-#pragma unroll
-    for (int b = 0; b < 8; b++) {
-        if (base + b < len) v |= (u64)p[base + b] << (8 * b);
-    }
+    if (base + 8 <= len) return pa_rd64(p + base);  // one unaligned load
+    u64 v = 0;
+    for (int b = 0; base + b < len; b++) v |= (u64)p[base + b] << (8 * b);
     return v;
 }
 

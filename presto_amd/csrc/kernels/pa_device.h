@@ -58,16 +58,18 @@ __device__ __forceinline__ i64 pa_combine_hash(i64 prev, i64 v) { return (i64)(3
 
 __device__ __forceinline__ u64 pa_xxh_round(u64 acc, u64 in) { return pa_rotl64(acc + in * PA_P2, 31) * PA_P1; }
 __device__ __forceinline__ u64 pa_xxh_merge(u64 h, u64 v) { return (h ^ pa_xxh_round(0, v)) * PA_P1 + PA_P4; }
+// little-endian words of a byte string at any alignment: one unaligned global load each (gfx950 allows them), not 8 / 4 byte loads
 __device__ __forceinline__ u64 pa_rd64(const u8* p)
 {
-    u64 v = 0;
-#pragma unroll
-    for (int i = 0; i < 8; i++) v |= (u64)p[i] << (8 * i);
+    u64 v;
+    __builtin_memcpy(&v, p, 8);
     return v;
 }
 __device__ __forceinline__ u32 pa_rd32(const u8* p)
 {
-    return (u32)p[0] | ((u32)p[1] << 8) | ((u32)p[2] << 16) | ((u32)p[3] << 24);
+    u32 v;
+    __builtin_memcpy(&v, p, 4);
+    return v;
 }
 __device__ __forceinline__ u64 pa_xxh_avalanche(u64 h)
 {
@@ -135,7 +137,10 @@ __device__ __forceinline__ u64 pa_xxh64_long(u64 v)
 __device__ inline bool pa_str_eq(const u8* a, i32 alen, const u8* b, i32 blen)
 {
     if (alen != blen) return false;
-    for (i32 i = 0; i < alen; i++)
+    i32 i = 0;
+    for (; i + 8 <= alen; i += 8)
+        if (pa_rd64(a + i) != pa_rd64(b + i)) return false;
+    for (; i < alen; i++)
         if (a[i] != b[i]) return false;
     return true;
 }
