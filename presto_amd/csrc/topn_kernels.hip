@@ -83,6 +83,42 @@ __global__ __launch_bounds__(1024) void k_topn_hist_reduce(const u32* __restrict
     if (q == 0) out[bin] = part[0][bin] + part[1][bin] + part[2][bin] + part[3][bin];
 }
 
+// the keys that carry the selected prefix, compacted (order irrelevant: the later passes only histogram them).  A workgroup
+// owns one contiguous chunk: it counts its matches, reserves their room with ONE atomic (many atomics on one counter
+// retire at ~0.15 M/s on this part: a per-wave reservation made this kernel 9 ms for 64 M keys), then walks the chunk again.
+__global__ __launch_bounds__(256) void k_topn_compact(const u64* __restrict__ keys, i64 n, u64 prefix, int shift, u64* __restrict__ out,
+                                                      u32* __restrict__ counter)
+{
+    __shared__ u32 wave_count[4];
+    __shared__ u32 block_base;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const i64 per = ((n + gridDim.x - 1) / gridDim.x + 255) & ~(i64)255;
+    const i64 c0 = (i64)blockIdx.x * per, c1 = c0 + per < n ? c0 + per : n;
+    u32 mine = 0;
+    for (i64 i = c0 + threadIdx.x; i < c1; i += 256) mine += ((keys[i] >> shift) == prefix) ? 1u : 0u;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) mine += (u32)__shfl_xor((int)mine, d, 64);
+    if (lane == 0) wave_count[wave] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const u32 total = wave_count[0] + wave_count[1] + wave_count[2] + wave_count[3];
+        block_base = total ? atomicAdd(counter, total) : 0u;
+    }
+    __syncthreads();
+    // second walk: a wave's matches go behind the matches of the earlier waves' whole chunks shares -- order is free, so every wave
+    // simply takes its own counted share: base + sum of the earlier waves' counts + running offset inside the wave
+    u32 at = block_base;
+    for (int w = 0; w < wave; w++) at += wave_count[w];
+    for (i64 i0 = c0 + (i64)wave * 64; i0 < c1; i0 += 256) {
+        const i64 i = i0 + lane;
+        const u64 k = i < c1 ? keys[i] : 0ULL;
+        const bool keep = i < c1 && (k >> shift) == prefix;
+        const u64 m = __ballot(keep);
+        if (keep) out[at + (u32)__popcll(m & ((1ULL << lane) - 1ULL))] = k;
+        at += (u32)__popcll(m);
+    }
+}
+
 __global__ __launch_bounds__(256) void k_topn_flag(const u64* __restrict__ keys, i64 n, u64 threshold, i32* __restrict__ partition)
 {
     for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < n; i += (i64)gridDim.x * 256) partition[i] = keys[i] <= threshold ? 0 : 1;
@@ -107,11 +143,19 @@ uint64_t topn_select_kth(const uint64_t* keys, int64_t n, int64_t k, void* temp,
     PA_REQUIRE(k >= 1 && k <= n, PA_ERR_INVALID_ARGUMENT, "selection rank out of range");
     u32* slab = static_cast<u32*>(temp);
     u32* total = slab + (size_t)kHistGrid * 256;
-    const int grid = (int)std::min<int64_t>(kHistGrid, std::max<int64_t>(1, (n + 255) / 256));
+    // MSB radix selection.  After a pass only the keys with the selected digit matter: once they are few they are compacted,
+    // and the remaining passes histogram thousands of keys instead of walking all n again (64 M DOUBLE keys: 8 full passes
+    // became one full pass, one compaction and seven trivial ones).
+    DevBuf cand[2], counter_buf;
+    u32* counter = static_cast<u32*>(counter_buf.ensure(64));
+    const u64* cur = reinterpret_cast<const u64*>(keys);
+    int64_t cur_n = n;
+    int which = 0;
     uint64_t prefix = 0;
     int64_t remaining = k;
     for (int shift = 56; shift >= 0; shift -= 8) {
-        hipLaunchKernelGGL(k_topn_hist, grid, 256, 0, s, (const u64*)keys, (i64)n, (u64)prefix, shift, shift == 56 ? 1 : 0, slab);
+        const int grid = (int)std::min<int64_t>(kHistGrid, std::max<int64_t>(1, (cur_n + 255) / 256));
+        hipLaunchKernelGGL(k_topn_hist, grid, 256, 0, s, cur, (i64)cur_n, (u64)prefix, shift, shift == 56 ? 1 : 0, slab);  // (compacted candidates only share the prefix of their compaction: keep checking)
         hipLaunchKernelGGL(k_topn_hist_reduce, 1, 1024, 0, s, (const u32*)slab, grid, total);
         PA_HIP(hipGetLastError());
         PA_HIP(hipMemcpyAsync(host_hist, total, 256 * 4, hipMemcpyDeviceToHost, s));
@@ -127,7 +171,18 @@ uint64_t topn_select_kth(const uint64_t* keys, int64_t n, int64_t k, void* temp,
         }
         remaining -= before;
         prefix = (prefix << 8) | (uint64_t)digit;
+        const int64_t next_n = (int64_t)host_hist[digit];
+        if (shift > 0 && next_n * 4 <= cur_n && cur_n > 4096) {
+            u64* out = static_cast<u64*>(cand[which].ensure((size_t)std::max<int64_t>(next_n, 1) * 8));
+            PA_HIP(hipMemsetAsync(counter, 0, 4, s));
+            hipLaunchKernelGGL(k_topn_compact, (int)std::min<int64_t>(1024, std::max<int64_t>(1, (cur_n + 4095) / 4096)), 256, 0, s, cur, (i64)cur_n, (u64)prefix, shift, out, counter);
+            PA_HIP(hipGetLastError());
+            cur = out;
+            cur_n = next_n;
+            which ^= 1;
+        }
     }
+    PA_HIP(hipStreamSynchronize(s));  // the candidate buffers go back to the pool
     return prefix;
 }
 
