@@ -135,7 +135,12 @@ __global__ __launch_bounds__(256) void k_intern_bytes(InternTable t, const i32* 
         const u8* src = (const u8*)(t.arena + t.id_off[id]);
         u8* dst = out_bytes + out_offsets[r];
         const i32 len = (i32)t.id_len[id];
-        for (i32 b = 0; b < len; b++) dst[b] = src[b];
+        i32 b = 0;
+        for (; b + 8 <= len; b += 8) {  // the arena is 8-byte aligned; the destination need not be
+            const u64 w = *(const u64*)(src + b);
+            __builtin_memcpy(dst + b, &w, 8);
+        }
+        for (; b < len; b++) dst[b] = src[b];
     }
 }
 

@@ -195,7 +195,13 @@ __global__ __launch_bounds__(256) void k_varwidth_copy(const i32* __restrict__ p
         i32 len = (p < 0 || (nulls && nulls[p])) ? 0 : offsets[p + 1] - offsets[p];
         const u8* src = bytes + (p < 0 ? 0 : offsets[p]);
         u8* dst = out_bytes + out_offsets[i];
-        for (i32 b = 0; b < len; b++) dst[b] = src[b];
+        i32 b = 0;
+        for (; b + 8 <= len; b += 8) {  // unaligned 8-byte moves (gfx950 allows them), then the tail
+            u64 w;
+            __builtin_memcpy(&w, src + b, 8);
+            __builtin_memcpy(dst + b, &w, 8);
+        }
+        for (; b < len; b++) dst[b] = src[b];
         if (i == count - 1) out_offsets[count] = *total;
     }
 }
