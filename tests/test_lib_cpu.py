@@ -70,11 +70,12 @@ def test_q6_q1_kernels_generate_and_compile_for_gfx950():
     assert lib().pa_codegen_compile_fused(C.byref(d6), -1) > 1000
     d1, k1 = fused_aggregation_desc(tpch.Q1_TYPES, tpch.q1_filter(), tpch.q1_projections(), tpch.Q1_GROUP_BY, tpch.Q1_AGGREGATES,
                                     type_params=tpch.Q1_TYPE_PARAMS)
-    for variant in (1, 2):
+    for variant in (1, 2, 3, 4):  # register/LDS table, HBM table (with run combining), workgroup LDS table (150 KB), partition-id pass
         src, key = fused_source(d1, variant)
         assert "#define PA_KW 1\n" in src  # both VARCHAR(1) keys share one packed word
         assert "#define PA_NW 6\n" in src  # 5 sums + 1 shared count for the 8 aggregates
         assert lib().pa_codegen_compile_fused(C.byref(d1), variant) > 1000, lib().pa_last_error()
+    assert "pa_flush(a, acc, true)" in fused_source(d1, 2)[0] and "pa_lt_upsert" in fused_source(d1, 3)[0]
 
 
 def test_expression_forms_compile():
