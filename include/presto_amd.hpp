@@ -256,6 +256,9 @@ public:
         h_ = nullptr;
     }
     pa_operator* handle() { return h_; }
+    // FilterAndProject only, before the first page: the dynamic filter of the (built) join this operator feeds -- rows whose
+    // `channel` value matches no build key are dropped with the filter; true when the source offers one
+    bool setDynamicFilter(int32_t channel, pa_lookup_source* source) { return check(pa_filter_project_set_dynamic_filter(h_, channel, source)) == 1; }
 
 private:
     pa_operator* h_;

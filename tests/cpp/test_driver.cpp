@@ -207,6 +207,23 @@ static void testJoinAndTopN()
         EXPECT(out[0].getBlock(1).getLong(i) == 1000 + k && out[0].getBlock(2).getLong(i) == 2000 + k, "join-1 probe columns row %d", i);
         EXPECT(out[0].getBlock(4).getLong(i) == 30 + (k - 20) && out[0].getBlock(5).getLong(i) == 40 + (k - 20), "join-1 build columns row %d", i);
     }
+    // the join's dynamic filter in the FilterAndProject upstream of the probe: the same 10 rows reach the join (a BIGINT key:
+    // the VARCHAR key of join-1 offers no bitmap), and the join result is unchanged
+    {
+        LookupSourceFactory byNumber;
+        auto b = createHashBuilderOperator(byNumber, types, {1}, {0, 1, 2});
+        runDriver({sequencePage3(10, 20, 30, 40)}, {b.get()});
+        auto fp = createFilterAndProjectOperator(types, nullptr, {field(0, PA_VARCHAR), field(1, PA_BIGINT), field(2, PA_BIGINT)});
+        EXPECT(fp->setDynamicFilter(1, byNumber.handle()), "dynamic filter: a BIGINT key offers a bitmap");
+        auto j = createLookupJoinOperator(byNumber, types, {1}, {0, 1, 2});
+        auto filtered = runDriver({sequencePage3(1000, 0, 0, 2000)}, {fp.get()});
+        EXPECT(filtered.size() == 1 && filtered[0].getPositionCount() == 10, "dynamic filter: 10 of 1000 probe rows have a build partner");
+        auto joined2 = runDriver(filtered, {j.get()});
+        EXPECT(joined2.size() == 1 && joined2[0].getPositionCount() == 10 && joined2[0].getBlock(1).getLong(0) == 30 && joined2[0].getBlock(4).getLong(9) == 39,
+               "dynamic filter: join over the filtered rows");
+        auto fpv = createFilterAndProjectOperator(types, nullptr, {field(0, PA_VARCHAR)});
+        EXPECT(!fpv->setDynamicFilter(0, bridge.handle()), "dynamic filter: none for a VARCHAR key");
+    }
     // testProbeOuterJoin (:850-894): 15 probe rows @20: 10 matches, then 5 rows with NULL build columns
     auto outer = createLookupJoinOperator(bridge, types, {0}, {0, 1, 2}, PA_JOIN_PROBE_OUTER);
     auto rows = runDriver({sequencePage3(15, 20, 1020, 2020)}, {outer.get()});
