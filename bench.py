@@ -1,17 +1,24 @@
 #!/usr/bin/env python3
-"""bench.py -- rows/s through the operator pipeline, TPC-H Q1 + Q6 over device-resident lineitem pages.
+"""bench.py -- rows/s through the operator pipeline, TPC-H Q1 + Q6 over device-resident lineitem pages (the headline),
+with TPC-H Q3 (two hash joins + grouped sum, exchange steps between the ranks when N > 1) timed beside it.
 
-One step = one Q6 pass (scan-filter-project -> global SUM) plus one Q1 pass (scan-filter-project ->
-hash aggregation on (returnflag, linestatus), 8 aggregates) over the rank's lineitem shard, each through a
-fresh fused operator driven with the Operator protocol (addInput per page, finish, getOutput).
-Weak scaling: every rank holds `--sf` worth of lineitem rows (its slice of the SF x N table); the path
-shards by row range and needs no data-path collective, the final 4-group / 1-row partials
-are not merged across ranks inside the timed region.
+Headline step = one Q6 pass (scan-filter-project -> global SUM) plus one Q1 pass (scan-filter-project -> hash
+aggregation on (returnflag, linestatus), 8 aggregates) over the rank's lineitem shard, each through a fresh fused
+operator driven with the Operator protocol (addInput per page, finish, getOutput).  Weak scaling: every rank holds
+`--sf` worth of lineitem rows (its slice of the SF x N table); the path shards by row range and needs no data-path
+collective, the final 4-group / 1-row partials are not merged across ranks inside the timed region.
+
+The `q3` object of the line is its own timed region (W warm-up + K steps between barriers, max over ranks): the three
+Driver pipelines of presto_amd/q3.py over the rank's slices of customer / orders / lineitem.  With N > 1 every build
+and probe side is hash-partitioned on its join key and shuffled between the ranks (RCCL over xGMI) -- BASELINE config #4.
 
 Prints ONE JSON line on rank 0 (see the contract in the task description), including
   roofline     for the dominant kernel (the Q1 fused kernel; Q6's is reported next to it), measured with
                HIP events on the operator's stream around every launch in the timed region;
-  cpu_baseline the oracle's hand-written-twin pipelines timed on the host cores on a bounded sample.
+  cpu_baseline the oracle's hand-written-twin pipelines timed on the host cores on a bounded sample;
+  q3           ms/step, input rows/s, per-pipeline ms, achieved HBM GB/s against the algorithmic bytes of SURVEY 8d,
+               exchange bytes and GB/s over xGMI when N > 1;
+  h2d          the Q6 pipeline fed with PA_MEM_HOST pages (what a JNI shim hands over): PCIe-inclusive rows/s, N = 1 only.
 """
 import argparse
 import json
@@ -25,31 +32,43 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured streaming)
+PCIE_PEAK_GBS = 63.0   # MI355X_MICROARCH.md: PCIe Gen5 x16 host link
 
 
-def parse_args():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--sf", type=float, default=100.0, help="TPC-H scale factor of the lineitem shard per GPU")
+    ap.add_argument("--sf", type=float, default=100.0, help="TPC-H scale factor of the shard per GPU")
     ap.add_argument("--page-rows", type=int, default=1 << 28, help="rows per device-resident page")
     ap.add_argument("--cpu-rows", type=int, default=16_000_000, help="rows of the CPU-baseline sample (0 = skip)")
-    ap.add_argument("--queries", default="q1,q6")
+    ap.add_argument("--queries", default="q1,q6", help="headline queries")
+    ap.add_argument("--q3", type=int, default=1, help="1 = also time the Q3 pipelines (the `q3` object), 0 = skip")
+    ap.add_argument("--q3-sf", type=float, default=0.0, help="scale factor per GPU of the Q3 tables (0 = --sf)")
+    ap.add_argument("--h2d-rows", type=int, default=1 << 25, help="rows of the host-page (PCIe-inclusive) Q6 leg, N = 1 only (0 = skip)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend; 'gloo' only to rehearse the multi-rank "
                     "control flow with several ranks on one GPU (RCCL refuses two ranks on one device)")
-    return ap.parse_args()
+    return ap.parse_args(argv)
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def cpu_baseline(sf, rows):
     """Oracle twins of the two pipelines (HandTpchQuery6 / HandTpchQuery1 shape) on a sample of the same
     synthetic workload: one Driver thread each first, then T threads over disjoint row ranges."""
-    import numpy as np
     from oracle import oracle as O
     from presto_amd import abi, tpch
     O.build()
     threads = max(1, min(len(os.sched_getaffinity(0)), 64))
-    cols = {}
     union = sorted(set(tpch.Q1_COLUMNS + tpch.Q6_COLUMNS))
 
     def gen(lo, hi, out):
@@ -91,22 +110,233 @@ def cpu_baseline(sf, rows):
     one = 2 * rows / (t6_1 + t1_1)
     many = 2 * rows / (t6_t + t1_t)
     return {
-        "value": many, "unit": "rows/s", "cores": threads, "kind": "port",
-        "sample": "%d lineitem rows (SF%g generator), Q6+Q1 hand-written-twin pipelines of the oracle; "
-                  "1 thread: %.3g rows/s (q6 %.3g, q1 %.3g); %d threads over disjoint row ranges: q6 %.3g, q1 %.3g rows/s"
-                  % (rows, sf, one, rows / t6_1, rows / t1_1, threads, rows / t6_t, rows / t1_t),
+        "value": many, "unit": "rows/s", "cores": threads, "kind": "port", "cpu_model": cpu_model(),
+        "host_threads_available": len(os.sched_getaffinity(0)),
+        "one_thread": {"value": one, "q6": rows / t6_1, "q1": rows / t1_1, "unit": "rows/s"},
+        "all_threads": {"value": many, "q6": rows / t6_t, "q1": rows / t1_t, "threads": threads, "unit": "rows/s"},
+        "sample": "%d lineitem rows (SF%g generator), Q6+Q1 hand-written-twin pipelines of the oracle (C, -O2, scalar); "
+                  "1 thread = one reference Driver; %d threads over disjoint row ranges = task_concurrency Drivers; "
+                  "`value` is the %d-thread figure" % (rows, sf, threads, threads),
     }
 
 
-def main():
-    args = parse_args()
+class DeviceWorkload:
+    """The product path: device-resident synthetic tables, operators through the C ABI (presto_amd.operators)."""
+
+    def __init__(self, args, rank, world, device):
+        import torch
+        from presto_amd import _lib, abi, tpch
+        from presto_amd.operators import FusedAggregationOperatorFactory
+        self.args, self.rank, self.world = args, rank, world
+        self.torch, self.abi, self.tpch = torch, abi, tpch
+        _lib.init(device)
+        # the communicator of the Q3 exchange steps: RCCL, one rank per GPU (gloo rehearsals with ranks sharing a GPU: the
+        # library's host transport, the two collectives then run over torch.distributed)
+        self.comm = None
+        if world > 1 and args.q3:
+            from presto_amd.exchange import Comm
+            self.comm = Comm.rccl() if args.backend == "nccl" else Comm.host()
+        self.rows = tpch.lineitem_rows(args.sf)
+        self.queries = [q for q in args.queries.split(",") if q]
+        q3_sf = args.q3_sf or args.sf
+        self.q3_on = bool(args.q3)
+        self.q3_sf = q3_sf
+        columns = set((tpch.Q1_COLUMNS if "q1" in self.queries else []) + (tpch.Q6_COLUMNS if "q6" in self.queries else []))
+        share_lineitem = self.q3_on and q3_sf == args.sf
+        if share_lineitem:
+            columns |= set(tpch.Q3_LINEITEM_COLUMNS)
+        self._keep = []
+
+        def allocator(nbytes):
+            t = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+            self._keep.append(t)
+            return t
+
+        # this rank's slice of the SF x world tables, generated on device
+        self.table = tpch.DeviceColumns(sorted(columns), args.sf * world, self.rows, allocator=allocator, first_row=rank * self.rows)
+        self.q6_pages = self._pages_of(self.table, tpch.Q6_COLUMNS, args.page_rows) if "q6" in self.queries else []
+        self.q1_pages = self._pages_of(self.table, tpch.Q1_COLUMNS, args.page_rows) if "q1" in self.queries else []
+        self.ktime = {"q6": [0.0, 0], "q1": [0.0, 0]}
+        self.results = {}
+        # the planner's part, once per query plan: OperatorFactory objects holding the serialised descriptors
+        # (LocalExecutionPlanner builds the factories; every Driver then calls createOperator)
+        self.factories = {
+            "q6": FusedAggregationOperatorFactory(tpch.Q6_TYPES, tpch.q6_filter(), tpch.q6_projections(), [], tpch.Q6_AGGREGATES),
+            "q1": FusedAggregationOperatorFactory(tpch.Q1_TYPES, tpch.q1_filter(), tpch.q1_projections(), tpch.Q1_GROUP_BY,
+                                                  tpch.Q1_AGGREGATES, type_params=tpch.Q1_TYPE_PARAMS),
+        }
+        if self.q3_on:
+            nc, no, nl = tpch.customer_rows(q3_sf), tpch.orders_rows(q3_sf), tpch.lineitem_rows(q3_sf)
+            self.q3_rows = (nc, no, nl)
+            total = q3_sf * world
+            self.customer = tpch.DeviceColumns(tpch.CUSTOMER_COLUMNS, total, nc, allocator=allocator, first_row=rank * nc)
+            self.orders = tpch.DeviceColumns(tpch.ORDERS_COLUMNS, total, no, allocator=allocator, first_row=rank * no)
+            self.q3_lineitem = self.table if share_lineitem else tpch.DeviceColumns(
+                tpch.Q3_LINEITEM_COLUMNS, total, nl, allocator=allocator, first_row=rank * nl)
+            pr = args.page_rows
+            self.q3_pages = (self._pages_of(self.customer, tpch.CUSTOMER_COLUMNS, max(20, pr - pr % 20)),
+                             self._pages_of(self.orders, tpch.ORDERS_COLUMNS, pr),
+                             self._pages_of(self.q3_lineitem, tpch.Q3_LINEITEM_COLUMNS, pr))
+            self.q3_stream = _lib.DeviceStream()
+            self.q3_counters = {}
+        torch.cuda.synchronize()
+
+    def _pages_of(self, table, cols, page_rows):
+        sub = self.tpch.DeviceColumns.__new__(self.tpch.DeviceColumns)
+        sub.columns = cols
+        sub.rows = table.rows
+        sub._bufs = table._bufs
+        pages = list(sub.pages(page_rows))
+        for p in pages:
+            p.to_c()  # the C view of a page is what the JNI shim is handed: built once, outside the timed region
+        return pages
+
+    def synchronize(self):
+        self.torch.cuda.synchronize()
+
+    # ---- headline ----
+    def run_query(self, name, timed):
+        op = self.factories[name].createOperator()  # a fresh operator per pass: operators are single-use
+        for p in (self.q6_pages if name == "q6" else self.q1_pages):
+            op.addInput(p)
+        op.finish()
+        out = op.getOutput()
+        self.results[name] = out.to_rows()
+        ms, n = op.kernelTime()  # also during warm-up: the first event query of a process pays a one-off cost
+        if timed:
+            self.ktime[name][0] += ms
+            self.ktime[name][1] += n
+        op.close()
+
+    def step(self, timed):
+        for q in self.queries:
+            self.run_query(q, timed)
+
+    def rows_per_step(self):
+        return self.rows * len(self.queries)
+
+    def roofline(self, name, steps, pmc):
+        tpch = self.tpch
+        bytes_per_row = {"q1": tpch.Q1_BYTES_PER_ROW, "q6": tpch.Q6_BYTES_PER_ROW}[name]
+        pages = self.q1_pages if name == "q1" else self.q6_pages
+        ms, n = self.ktime[name]
+        if n == 0:
+            return None
+        # algorithmic bytes of the timed region / summed duration of the operator's kernel launches; n counts the
+        # launches of the dominant kernel `pa_fused` only (a page whose row count is not a multiple of 256 adds one
+        # <256-row `pa_fused_tail` launch: its ~10 us are in `ms`, it is not a launch of the dominant kernel)
+        total_bytes = sum(p.position_count for p in pages) * bytes_per_row * steps
+        achieved = total_bytes / (ms / 1e3) / 1e9
+        traffic = pmc.get({"q1": "q1_lds", "q6": "q6_global"}[name], {}).get("hbm_bytes_per_launch")
+        return {"bound": "hbm", "kernel": "pa_fused (%s)" % name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE x2 on gfx950), average per launch" if pmc else None,
+                "avg_launch_ms": ms / n, "launches": n, "algorithmic_bytes_per_launch": total_bytes / n}
+
+    def workload_name(self):
+        a = self.args
+        return ("TPC-H SF%g %s fused scan-filter-project-aggregate over device-resident lineitem pages, %d rows per GPU, %d-row pages"
+                % (a.sf, "+".join(q.upper() for q in self.queries), self.rows, a.page_rows))
+
+    # ---- Q3 ----
+    def q3_step(self):
+        from presto_amd import q3
+        out, counters = q3.run(self.q3_pages[0], self.q3_pages[1], self.q3_pages[2], self.q3_stream.handle, comm=self.comm,
+                               distributed=self.world > 1, result_mem=self.abi.MEM_HOST, top_n=10, with_count=False)
+        self.q3_counters = counters
+        self.results["q3"] = [r for p in out for r in p.to_rows()]
+
+    def q3_input_rows(self):
+        return sum(self.q3_rows)
+
+    def q3_algorithmic_bytes(self):
+        # SURVEY 8d: customer 21 B/row, orders 24 B/row, lineitem 28 B/row (columns read once by the scans)
+        nc, no, nl = self.q3_rows
+        return nc * 21 + no * 24 + nl * 28
+
+    # ---- host pages ----
+    def h2d(self, rows):
+        """Q6 over PA_MEM_HOST pages (pageable numpy buffers, 4 Mi-row pages): the rate an unmodified Driver sees when its
+        pages start on the host.  Bounded by the host link (28 B/row over PCIe), not by the kernel."""
+        from presto_amd.operators import FusedAggregationOperator, download_page
+        tpch = self.tpch
+        rows = min(rows, self.rows)
+        sub = self._pages_of(self.table, tpch.Q6_COLUMNS, rows)[0]
+        host = download_page(sub)
+        page_rows = 1 << 22
+        pages = [host.get_region(i, min(page_rows, rows - i)) for i in range(0, rows, page_rows)]
+        best = None
+        for _ in range(3):
+            op = FusedAggregationOperator(tpch.Q6_TYPES, tpch.q6_filter(), tpch.q6_projections(), [], tpch.Q6_AGGREGATES)
+            t0 = time.perf_counter()
+            for p in pages:
+                op.addInput(p)
+            op.finish()
+            op.getOutput()
+            dt = time.perf_counter() - t0
+            op.close()
+            best = dt if best is None else min(best, dt)
+        gbs = rows * tpch.Q6_BYTES_PER_ROW / best / 1e9
+        return {"value": rows / best, "unit": "rows/s", "GBps": gbs, "peak_GBps": PCIE_PEAK_GBS, "frac": gbs / PCIE_PEAK_GBS,
+                "workload": "Q6 fused pipeline over %d rows handed over as PA_MEM_HOST pages of %d rows (pageable host buffers)" % (rows, page_rows)}
+
+    def close(self):
+        if self.q3_on:
+            self.q3_stream.destroy()
+        if self.comm is not None:
+            self.comm.destroy()
+
+
+def timed_region(workload, dist, world, backend, fn, steps, warmup):
+    """W untimed + K timed calls of fn between barrier + device synchronisation on both sides; MAX over the ranks."""
+    import gc
+    import torch
+    for _ in range(warmup):
+        fn(False)
+    # a full collection over torch's import graph takes tens of ms: keep the cyclic GC out of the timed region
+    gc.collect()
+    gc.freeze()
+    gc.disable()
+    workload.synchronize()
+    if world > 1:
+        dist.barrier()
+    workload.synchronize()
+    t0 = time.perf_counter()
+    step_times = []
+    for _ in range(steps):
+        ts0 = time.perf_counter()
+        fn(True)
+        step_times.append(time.perf_counter() - ts0)
+    workload.synchronize()
+    if world > 1:
+        dist.barrier()
+    workload.synchronize()
+    elapsed = time.perf_counter() - t0
+    gc.enable()
+    gc.unfreeze()
+    if os.environ.get("BENCH_DEBUG"):
+        print("step ms:", ["%.2f" % (x * 1e3) for x in step_times], file=sys.stderr)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return elapsed
+
+
+def main(argv=None, workload_factory=None, out=None):
+    """workload_factory(args, rank, world, device) -> workload: tests rehearse the multi-rank control flow (barriers, the
+    max-over-ranks clock, the exchange rounds of Q3, the JSON line) on CPU ranks with a checker workload; the default is
+    the device workload."""
+    args = parse_args(argv)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch
     import torch.distributed as dist
-    device = local_rank if args.backend == "nccl" else local_rank % max(torch.cuda.device_count(), 1)
-    torch.cuda.set_device(device)
+    device = None
+    if workload_factory is None:
+        device = local_rank if args.backend == "nccl" else local_rank % max(torch.cuda.device_count(), 1)
+        torch.cuda.set_device(device)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.backend == "nccl":
@@ -114,94 +344,38 @@ def main():
         else:
             dist.init_process_group(args.backend)
 
-    from presto_amd import _lib, abi, tpch
-    from presto_amd.operators import FusedAggregationOperatorFactory
-    _lib.init(device)
+    workload = (workload_factory or DeviceWorkload)(args, rank, world, device)
 
-    rows = tpch.lineitem_rows(args.sf)
-    queries = args.queries.split(",")
-    columns = sorted(set((tpch.Q1_COLUMNS if "q1" in queries else []) + (tpch.Q6_COLUMNS if "q6" in queries else [])))
-    keep = []
+    elapsed = timed_region(workload, dist, world, args.backend, workload.step, args.steps, args.warmup)
+    value = workload.rows_per_step() * args.steps * world / elapsed
 
-    def allocator(nbytes):
-        t = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
-        keep.append(t)
-        return t
-
-    # this rank's slice of the SF x world lineitem table, generated on device
-    table = tpch.DeviceColumns(columns, args.sf * world, rows, allocator=allocator, first_row=rank * rows)
-    torch.cuda.synchronize()
-
-    def pages_of(cols):
-        sub = tpch.DeviceColumns.__new__(tpch.DeviceColumns)
-        sub.columns = cols
-        sub.rows = table.rows
-        sub._bufs = table._bufs
-        return list(sub.pages(args.page_rows))
-
-    q6_pages = pages_of(tpch.Q6_COLUMNS) if "q6" in queries else []
-    q1_pages = pages_of(tpch.Q1_COLUMNS) if "q1" in queries else []
-    ktime = {"q6": [0.0, 0], "q1": [0.0, 0]}
-    results = {}
-
-    # the planner's part, once per query plan: OperatorFactory objects holding the serialised descriptors
-    # (LocalExecutionPlanner builds the factories; every Driver then calls createOperator)
-    factories = {
-        "q6": FusedAggregationOperatorFactory(tpch.Q6_TYPES, tpch.q6_filter(), tpch.q6_projections(), [], tpch.Q6_AGGREGATES),
-        "q1": FusedAggregationOperatorFactory(tpch.Q1_TYPES, tpch.q1_filter(), tpch.q1_projections(), tpch.Q1_GROUP_BY,
-                                              tpch.Q1_AGGREGATES, type_params=tpch.Q1_TYPE_PARAMS),
-    }
-
-    def run_query(name, timed):
-        op = factories[name].createOperator()  # a fresh operator per pass: operators are single-use
-        pages = q6_pages if name == "q6" else q1_pages
-        for p in pages:
-            op.addInput(p)
-        op.finish()
-        out = op.getOutput()
-        results[name] = out.to_rows()
-        ms, n = op.kernelTime()  # also during warm-up: the first event query of a process pays a one-off cost
-        if timed:
-            ktime[name][0] += ms
-            ktime[name][1] += n
-        op.close()
-
-    def step(timed):
-        for q in queries:
-            run_query(q, timed)
-
-    for _ in range(args.warmup):
-        step(False)
-    # a full collection over torch's import graph takes tens of ms: keep the cyclic GC out of the timed region
-    import gc
-    gc.collect()
-    gc.freeze()
-    gc.disable()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    step_times = []
-    for _ in range(args.steps):
-        ts0 = time.perf_counter()
-        step(True)
-        step_times.append(time.perf_counter() - ts0)
-    te = time.perf_counter()
-    torch.cuda.synchronize()
-    if os.environ.get("BENCH_DEBUG"):
-        print("step ms:", ["%.2f" % (x * 1e3) for x in step_times], "final sync ms: %.2f" % ((time.perf_counter() - te) * 1e3), file=sys.stderr)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    rows_per_step = rows * len(queries)
-    value = rows_per_step * args.steps * world / elapsed
+    q3 = None
+    if getattr(workload, "q3_on", False):
+        try:
+            q3_elapsed = timed_region(workload, dist, world, args.backend, lambda timed: workload.q3_step(), args.steps, max(1, min(args.warmup, 2)))
+            c = dict(workload.q3_counters)
+            rows_in = workload.q3_input_rows()
+            ms = q3_elapsed / args.steps * 1e3
+            alg = workload.q3_algorithmic_bytes()
+            q3 = {"metric": "input rows/s through the TPC-H Q3 operator pipelines (customer + orders + lineitem rows entering the three scans)",
+                  "value": rows_in * world * args.steps / q3_elapsed, "unit": "rows/s", "ms_per_step": ms, "steps": args.steps,
+                  "scale_factor_per_gpu": workload.q3_sf, "input_rows_per_gpu": rows_in,
+                  "stage_ms_rank0": {k: v for k, v in c.items() if k.endswith("_pipeline_ms")},
+                  "rank0": {k: v for k, v in c.items() if not k.endswith("_pipeline_ms")},
+                  "roofline": {"bound": "hbm", "scope": "whole step (all kernels of the three pipelines)", "achieved": alg / (ms / 1e3) / 1e9,
+                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / (ms / 1e3) / 1e9 / HBM_PEAK_GBS,
+                               "algorithmic_bytes_per_step": alg},
+                  "exchange": "none (one rank)"}
+            if world > 1:
+                sent, t_ms = c.get("exchange_bytes_remote", 0), c.get("exchange_transfer_ms", 0.0)
+                q3["exchange"] = {"what": "4 hash-partitioned exchanges per step (customer keys, orders, orders JOIN customer, lineitem), each one "
+                                          "count all-gather + one grouped ncclSend/ncclRecv all-to-all; dynamic-filter bitmaps combined by all-reduce",
+                                  "transport": "RCCL over xGMI" if args.backend == "nccl" else "host transport over " + args.backend,
+                                  "rank0_bytes_to_other_ranks_per_step": sent, "rank0_all_to_all_ms_per_step": t_ms,
+                                  "xgmi_GBps": (sent / (t_ms / 1e3) / 1e9) if t_ms > 0 else None,
+                                  "note": "xgmi_GBps = rank 0's payload bytes sent to the other ranks / device time of its all-to-alls (HIP events)"}
+        except Exception as e:  # the headline must survive a failing side leg
+            q3 = {"error": "%s: %s" % (type(e).__name__, e)}
 
     # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command (profiles/pmc_traffic.json,
     # written by scripts/summarize_profile.py); only valid for the default workload shape they were collected on
@@ -210,42 +384,35 @@ def main():
     if os.path.exists(pmc_path) and args.sf == 100.0 and args.page_rows == 1 << 28:
         pmc = json.load(open(pmc_path)).get("kernels", {})
 
-    def roof(name, bytes_per_row, pages):
-        ms, n = ktime[name]
-        if n == 0:
-            return None
-        # algorithmic bytes of the timed region / summed duration of the operator's kernel launches; n counts the
-        # launches of the dominant kernel `pa_fused` only (a page whose row count is not a multiple of 256 adds one
-        # <256-row `pa_fused_tail` launch: its ~10 us are in `ms`, it is not a launch of the dominant kernel)
-        total_bytes = sum(p.position_count for p in pages) * bytes_per_row * args.steps
-        achieved = total_bytes / (ms / 1e3) / 1e9
-        traffic = pmc.get({"q1": "q1_lds", "q6": "q6_global"}[name], {}).get("hbm_bytes_per_launch")
-        return {"bound": "hbm", "kernel": "pa_fused (%s)" % name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE x2 on gfx950), average per launch" if pmc else None,
-                "avg_launch_ms": ms / n, "launches": n, "algorithmic_bytes_per_launch": total_bytes / n}
-
     if rank == 0:
+        queries = workload.queries
         line = {
             "metric": "rows/s through operator pipeline, TPC-H Q1+Q6 SF100, 1/2/4/8 GPUs vs CPU ref",
             "value": value, "unit": "rows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "TPC-H SF%g %s fused scan-filter-project-aggregate over device-resident lineitem pages, "
-                                   "%d rows per GPU, %d-row pages" % (args.sf, "+".join(q.upper() for q in queries), rows,
-                                                                        args.page_rows),
-                       "scale_factor_per_gpu": args.sf, "rows_per_gpu": rows, "page_rows": args.page_rows,
-                       "queries": queries, "parallelism": "row-range shards, %d rank(s), no data-path collective" % world},
+            "config": {"workload": workload.workload_name(),
+                       "scale_factor_per_gpu": args.sf, "rows_per_gpu": workload.rows, "page_rows": args.page_rows,
+                       "queries": queries, "parallelism": "row-range shards, %d rank(s), no data-path collective in Q1/Q6; "
+                                                          "Q3 (the `q3` object) shuffles its join sides between the ranks" % world},
         }
-        r1 = roof("q1", tpch.Q1_BYTES_PER_ROW, q1_pages) if "q1" in queries else None
-        r6 = roof("q6", tpch.Q6_BYTES_PER_ROW, q6_pages) if "q6" in queries else None
+        r1 = workload.roofline("q1", args.steps, pmc) if "q1" in queries else None
+        r6 = workload.roofline("q6", args.steps, pmc) if "q6" in queries else None
         line["roofline"] = r1 or r6
         if r1 and r6:
             line["roofline_q6"] = r6
-        line["results"] = {k: [[x.decode() if isinstance(x, bytes) else x for x in r] for r in v] for k, v in results.items()}
+        if q3 is not None:
+            line["q3"] = q3
+        line["results"] = {k: [[x.decode() if isinstance(x, bytes) else x for x in r] for r in v] for k, v in workload.results.items()}
+        if world == 1 and args.h2d_rows > 0 and hasattr(workload, "h2d"):
+            try:
+                line["h2d"] = workload.h2d(args.h2d_rows)
+            except Exception as e:
+                line["h2d"] = {"error": "%s: %s" % (type(e).__name__, e)}
         if world == 1 and args.cpu_rows > 0:
             line["cpu_baseline"] = cpu_baseline(args.sf, args.cpu_rows)
-        print(json.dumps(line), flush=True)
+        print(json.dumps(line), file=out or sys.stdout, flush=True)
+    workload.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

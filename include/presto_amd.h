@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PA_ABI_VERSION 4
+#define PA_ABI_VERSION 5
 
 /* ---- status codes (negative = error).  Mapped by the JNI shim onto TrinoException
  *      StandardErrorCode (trino-spi/.../StandardErrorCode.java). ---- */
@@ -81,12 +81,21 @@ typedef struct pa_column {
 } pa_column;
 
 /* One Page: Block[] + positionCount (Page.java:33-60). */
+typedef enum pa_page_flags {
+    /* The page's buffers stay valid and unchanged until the operator it is given to is closed -- the contract of the
+     * reference, where a Page is immutable and kept alive by whoever references it (SURVEY 8b "Ownership"): pages over pinned
+     * / HBM buffers the host keeps for the query, row ranges of a resident table.  NOT set on the pages a device operator
+     * returns from pa_op_get_output (valid until the next call on that operator).  An operator may defer its work on a
+     * stable page past the return of pa_op_add_input: consecutive small stable pages that continue each other in memory
+     * are processed as one range, without a copy. */
+    PA_PAGE_STABLE = 1
+} pa_page_flags;
 typedef struct pa_page {
     int32_t position_count;
     int32_t channel_count;
     pa_column* columns;
     int32_t mem;                        /* pa_mem: where every pointer of every column lives */
-    int32_t reserved;
+    int32_t flags;                      /* pa_page_flags */
 } pa_page;
 
 /* ---- RowExpression tree, flattened (TM/sql/relational package) ---- */
@@ -450,6 +459,73 @@ int32_t pa_partition_columns_stable(const int32_t* partition, int32_t position_c
 /* Block.copyPositions for a flat column: dst[i] = src[positions[i]]. */
 int32_t pa_gather_flat(const void* src, int32_t elem_bytes, const int32_t* positions, int32_t count,
                        void* dst, void* stream);
+
+/* ---- hash-partitioned exchange between the ranks (one per GPU) of a node: RCCL over xGMI ----
+ * Replaces, for GPU-resident pages, the reference's page shuffle between the stages of a distributed join / aggregation:
+ *   producer side  PartitionedOutputOperator.PagePartitioner.partitionPage (TM/operator/PartitionedOutputOperator.java:411-431),
+ *                  local twin PartitioningExchanger.accept (TM/operator/exchange/PartitioningExchanger.java:59-82);
+ *   routing rule   HashGenerator.getPartition (TM/operator/HashGenerator.java:24-35) /
+ *                  LocalPartitionGenerator.getPartition (TM/operator/exchange/LocalPartitionGenerator.java:45-65);
+ *   consumer side  ExchangeOperator.getOutput (TM/operator/ExchangeOperator.java) fed by the ExchangeClient.
+ * The reference serialises pages and pulls them over HTTP; here the rows of every destination are kept as raw column
+ * segments in HBM and travel in ONE variable all-to-all (a grouped ncclSend / ncclRecv per peer) when the producing
+ * pipeline of every rank has finished -- a bulk exchange sized for 288 GB of HBM: every rank takes part in exactly one
+ * count all-gather and one all-to-all per exchange, whatever its page count, so the collective order is the program order
+ * on every rank.  NULLs travel (1 B / row per nullable column), VARCHAR travels as per-row lengths + bytes.
+ * Row order at the consumer = (source rank, source position), what draining the producers in rank order gives. */
+typedef struct pa_comm pa_comm;          /* communicator: rank, world, transport */
+typedef struct pa_exchange pa_exchange;  /* the OutputBuffer + ExchangeClient pair of one exchange on this rank */
+#define PA_COMM_ID_BYTES 128
+/* ncclGetUniqueId: called on one rank; the host ships the 128 bytes to the others (the coordinator's job in Trino). */
+int32_t pa_comm_unique_id(void* id_out);
+/* ncclCommInitRank on the calling thread's device (collective over the ranks). */
+int32_t pa_comm_create(const void* unique_id, int32_t rank, int32_t world, pa_comm** out);
+/* The same exchange with the two collectives done by the host: several ranks sharing one GPU (RCCL refuses that; the
+ * multi-rank tests on a one-GPU box use it over gloo) or a host that moves the bytes itself.  Callbacks return 0 or a
+ * negative pa_status; all buffers are host memory. */
+typedef struct pa_host_transport {
+    void* ctx;
+    /* every rank contributes count int64 values, recv gets world * count in rank order */
+    int32_t (*all_gather_i64)(void* ctx, const int64_t* send, int64_t* recv, int32_t count);
+    /* rank p is sent send[send_offsets[p] .. + send_bytes[p]) and its bytes arrive at recv + recv_offsets[p] */
+    int32_t (*all_to_all_v)(void* ctx, const void* send, const int64_t* send_offsets, const int64_t* send_bytes, void* recv,
+                            const int64_t* recv_offsets, const int64_t* recv_bytes);
+} pa_host_transport;
+int32_t pa_comm_create_host(const pa_host_transport* transport, int32_t rank, int32_t world, pa_comm** out);
+int32_t pa_comm_destroy(pa_comm* comm);
+int32_t pa_comm_rank(pa_comm* comm);
+int32_t pa_comm_world(pa_comm* comm);
+/* Small host-side reductions between the ranks (blocking): op 0 = SUM, 1 = MIN, 2 = MAX; values in place. */
+int32_t pa_comm_all_reduce_i64(pa_comm* comm, int64_t* values, int32_t count, int32_t op, void* stream);
+
+typedef struct pa_exchange_desc {
+    int32_t channel_count;
+    const int32_t* types;                /* pa_type per channel */
+    int32_t partition_channel_count;
+    const int32_t* partition_channels;   /* rawHash = InterpretedHashGenerator over these (ignored with hash_channel >= 0) */
+    int32_t hash_channel;                /* precomputed $hashvalue BIGINT channel or -1 */
+    int32_t partition_rule;              /* 0 = (rawHash & MAX_LONG) % world (remote exchange), 1 = LocalPartitionGenerator
+                                          * (world must be a power of two), -1 = 1 when world is a power of two, else 0 */
+    int32_t sink_count;                  /* PartitionedOutput operators that feed it (Drivers of the producing pipeline); 0 = 1 */
+    int32_t reserved;
+} pa_exchange_desc;
+int32_t pa_exchange_create(const pa_exchange_desc* desc, pa_comm* comm, pa_exchange** out);
+int32_t pa_exchange_destroy(pa_exchange* exchange);
+/* The sink of the producing pipeline (Operator protocol: needs input until finish, never has output). */
+int32_t pa_partitioned_output_create(pa_exchange* exchange, void* stream, pa_operator** out);
+/* The source of the consuming pipeline: never needs input; is blocked while a sink of this rank is unfinished; its first
+ * get_output afterwards performs the collective (every rank must get there) and returns the received rows as one page. */
+int32_t pa_exchange_source_create(pa_exchange* exchange, int32_t output_mem, void* stream, pa_operator** out);
+/* rows this rank sent / received, payload bytes sent to OTHER ranks, and the device time of the all-to-all (ms). */
+int32_t pa_exchange_stats(pa_exchange* exchange, int64_t* rows_sent, int64_t* rows_received, int64_t* bytes_sent_remote, double* transfer_ms);
+/* The dynamic filter of a partitioned join, agreed between the ranks (steps (1)-(2) of the comment above
+ * pa_lookup_source_key_range, done natively): the ranks take the union key range (MIN / MAX reductions), each sets the
+ * bits of its partition's build keys, and the bitmaps are combined with one SUM all-reduce (every key lives on exactly one
+ * rank after a build partitioned on the join key -- partitioned_by_key != 0 -- so the set bits are disjoint and SUM == OR;
+ * with partitioned_by_key == 0 the bitmaps are all-gathered and OR-ed by a kernel).  Returns 1 and the device bitmap
+ * ((range >> 6) + 1 words, owned by the lookup source) / 0 when no filter is possible (no integer key, keys too sparse). */
+int32_t pa_lookup_source_shared_key_bitmap(pa_lookup_source* source, pa_comm* comm, int32_t partitioned_by_key, void* stream,
+                                           const uint64_t** bits, int64_t* min_key, uint64_t* range);
 
 /* ---- page wire format (PagesSerde, uncompressed / unencrypted / no checksum) ----
  * pa_page_serialize writes the SerializedPage frame (PagesSerdeUtil.java:66-74: positionCount int, markers byte = 0,

@@ -107,7 +107,7 @@ public:
         out->channel_count = (int32_t)blocks.size();
         out->columns = cols.data();
         out->mem = PA_MEM_HOST;
-        out->reserved = 0;
+        out->flags = 0;
     }
     // copies a PA_MEM_HOST pa_page returned by pa_op_get_output
     static Page fromNative(const pa_page& p)

@@ -92,6 +92,19 @@ def lib():
     L.pa_page_deserialize.argtypes = [vp, C.c_int64, vp, C.POINTER(vp)]
     L.pa_page_buffer_page.argtypes = [vp, C.POINTER(abi.pa_page)]
     L.pa_page_buffer_free.argtypes = [vp]
+    L.pa_comm_unique_id.argtypes = [vp]
+    L.pa_comm_create.argtypes = [vp, C.c_int32, C.c_int32, C.POINTER(vp)]
+    L.pa_comm_create_host.argtypes = [C.POINTER(abi.pa_host_transport), C.c_int32, C.c_int32, C.POINTER(vp)]
+    L.pa_comm_destroy.argtypes = [vp]
+    L.pa_comm_rank.argtypes = [vp]
+    L.pa_comm_world.argtypes = [vp]
+    L.pa_comm_all_reduce_i64.argtypes = [vp, C.POINTER(C.c_int64), C.c_int32, C.c_int32, vp]
+    L.pa_exchange_create.argtypes = [C.POINTER(abi.pa_exchange_desc), vp, C.POINTER(vp)]
+    L.pa_exchange_destroy.argtypes = [vp]
+    L.pa_partitioned_output_create.argtypes = [vp, vp, C.POINTER(vp)]
+    L.pa_exchange_source_create.argtypes = [vp, C.c_int32, vp, C.POINTER(vp)]
+    L.pa_exchange_stats.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_double)]
+    L.pa_lookup_source_shared_key_bitmap.argtypes = [vp, vp, C.c_int32, vp, C.POINTER(vp), C.POINTER(C.c_int64), C.POINTER(C.c_uint64)]
     if L.pa_abi_version() != abi.ABI_VERSION:
         raise ImportError("libpresto_amd.so ABI version %d != %d" % (L.pa_abi_version(), abi.ABI_VERSION))
     _LIB = L

@@ -5,7 +5,7 @@ test-only oracle binding (oracle/oracle.py), exactly as both C sides share the h
 """
 import ctypes as C
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 # pa_status
 OK = 0
@@ -78,8 +78,11 @@ class pa_page(C.Structure):
         ("channel_count", C.c_int32),
         ("columns", C.POINTER(pa_column)),
         ("mem", C.c_int32),
-        ("reserved", C.c_int32),
+        ("flags", C.c_int32),
     ]
+
+
+PAGE_STABLE = 1
 
 
 class pa_expr_node(C.Structure):
@@ -249,6 +252,31 @@ class pa_lookup_join_desc(C.Structure):
         ("output_single_match", C.c_int32),
     ]
 
+
+class pa_exchange_desc(C.Structure):
+    _fields_ = [
+        ("channel_count", C.c_int32),
+        ("types", C.POINTER(C.c_int32)),
+        ("partition_channel_count", C.c_int32),
+        ("partition_channels", C.POINTER(C.c_int32)),
+        ("hash_channel", C.c_int32),
+        ("partition_rule", C.c_int32),
+        ("sink_count", C.c_int32),
+        ("reserved", C.c_int32),
+    ]
+
+
+COMM_ID_BYTES = 128
+ALL_GATHER_I64 = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_int32)
+ALL_TO_ALL_V = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_void_p,
+                           C.POINTER(C.c_int64), C.POINTER(C.c_int64))
+
+
+class pa_host_transport(C.Structure):
+    _fields_ = [("ctx", C.c_void_p), ("all_gather_i64", ALL_GATHER_I64), ("all_to_all_v", ALL_TO_ALL_V)]
+
+
+COMM_SUM, COMM_MIN, COMM_MAX = 0, 1, 2
 
 JOIN_INNER, JOIN_PROBE_OUTER, JOIN_LOOKUP_OUTER, JOIN_FULL_OUTER = 0, 1, 2, 3  # LookupJoinOperators.JoinType
 

@@ -2,6 +2,9 @@
 // exception -> status translation, and dispatch to the operator objects.  No arithmetic lives here.
 #include <mutex>
 
+#include <atomic>
+
+#include "comm.hpp"
 #include "exprgen.hpp"
 #include "jit.hpp"
 #include "operator.hpp"
@@ -55,10 +58,43 @@ int device_cu_count()
     return g_cu_count > 0 ? g_cu_count : 256;
 }
 
+// The device pa_init chose, process-wide: Trino's Driver / TaskExecutor threads never call pa_init themselves, and a HIP
+// thread that has not chosen a device works on device 0.  Every C-ABI entry binds a thread that has no binding of its own
+// to it; operator handles carry their device and rebind per call (OpScope).
+static std::atomic<int> g_default_device{-1};
+static thread_local bool t_device_bound = false;
+
+static void bind_default_device()
+{
+    if (t_device_bound) return;
+    const int d = g_default_device.load(std::memory_order_relaxed);
+    if (d >= 0) {
+        (void)hipSetDevice(d);
+        t_device_bound = true;
+    }
+}
+
+// An operator call: the thread works on the operator's device, and HBM blocks the operator releases meanwhile are tagged with
+// its stream (pool.cpp).
+struct OpScope {
+    explicit OpScope(pa_operator* op)
+    {
+        if (op->device >= 0) {
+            int cur = -1;
+            if (hipGetDevice(&cur) != hipSuccess || cur != op->device) (void)hipSetDevice(op->device);
+            t_device_bound = true;
+        }
+        prev_ = pool_scope_stream(op->main_stream());
+    }
+    ~OpScope() { (void)pool_scope_stream(prev_); }
+    hipStream_t prev_;
+};
+
 template <typename F>
 static int32_t guarded(F&& f)
 {
     try {
+        bind_default_device();
         return f();
     }
     catch (const Error& e) {
@@ -107,6 +143,8 @@ int32_t pa_init(int32_t device)
         if (device >= 0) {
             PA_REQUIRE(device < count, PA_ERR_INVALID_ARGUMENT, "device ordinal out of range");
             PA_HIP(hipSetDevice(device));
+            t_device_bound = true;
+            g_default_device.store(device, std::memory_order_relaxed);
         }
         require_device();
         return PA_OK;
@@ -194,7 +232,11 @@ int32_t pa_stream_create(void** stream)
 int32_t pa_stream_destroy(void* stream)
 {
     return guarded([&]() -> int32_t {
-        if (stream) PA_HIP(hipStreamDestroy((hipStream_t)stream));
+        if (stream) {
+            PA_HIP(hipStreamSynchronize((hipStream_t)stream));
+            pool_forget_stream((hipStream_t)stream);
+            PA_HIP(hipStreamDestroy((hipStream_t)stream));
+        }
         return PA_OK;
     });
 }
@@ -402,6 +444,108 @@ int32_t pa_lookup_outer_create(const pa_lookup_join_desc* desc, pa_lookup_source
     });
 }
 
+// ---- partitioned exchange ----
+int32_t pa_comm_unique_id(void* id_out)
+{
+    return guarded([&]() -> int32_t {
+        PA_REQUIRE(id_out != nullptr, PA_ERR_INVALID_ARGUMENT, "null argument");
+        comm_unique_id(id_out);
+        return PA_OK;
+    });
+}
+int32_t pa_comm_create(const void* unique_id, int32_t rank, int32_t world, pa_comm** out)
+{
+    return guarded([&]() -> int32_t {
+        PA_REQUIRE(out != nullptr, PA_ERR_INVALID_ARGUMENT, "null argument");
+        *out = comm_create_rccl(unique_id, rank, world);
+        return PA_OK;
+    });
+}
+int32_t pa_comm_create_host(const pa_host_transport* transport, int32_t rank, int32_t world, pa_comm** out)
+{
+    return guarded([&]() -> int32_t {
+        PA_REQUIRE(out != nullptr, PA_ERR_INVALID_ARGUMENT, "null argument");
+        *out = comm_create_host(transport, rank, world);
+        return PA_OK;
+    });
+}
+int32_t pa_comm_destroy(pa_comm* comm)
+{
+    return guarded([&]() -> int32_t {
+        delete comm;
+        return PA_OK;
+    });
+}
+int32_t pa_comm_rank(pa_comm* comm)
+{
+    return guarded([&]() -> int32_t {
+        PA_REQUIRE(comm != nullptr, PA_ERR_INVALID_ARGUMENT, "null argument");
+        return comm->rank;
+    });
+}
+int32_t pa_comm_world(pa_comm* comm)
+{
+    return guarded([&]() -> int32_t {
+        PA_REQUIRE(comm != nullptr, PA_ERR_INVALID_ARGUMENT, "null argument");
+        return comm->world;
+    });
+}
+int32_t pa_comm_all_reduce_i64(pa_comm* comm, int64_t* values, int32_t count, int32_t op, void* stream)
+{
+    return guarded([&]() -> int32_t {
+        PA_REQUIRE(comm != nullptr && values != nullptr && count > 0 && op >= 0 && op <= 2, PA_ERR_INVALID_ARGUMENT, "bad arguments");
+        comm_all_reduce_i64(comm, values, count, op, (hipStream_t)stream);
+        return PA_OK;
+    });
+}
+int32_t pa_exchange_create(const pa_exchange_desc* desc, pa_comm* comm, pa_exchange** out)
+{
+    return guarded([&]() -> int32_t {
+        PA_REQUIRE(out != nullptr, PA_ERR_INVALID_ARGUMENT, "null argument");
+        *out = exchange_new(desc, comm);
+        return PA_OK;
+    });
+}
+int32_t pa_exchange_destroy(pa_exchange* exchange)
+{
+    return guarded([&]() -> int32_t {
+        exchange_delete(exchange);
+        return PA_OK;
+    });
+}
+int32_t pa_partitioned_output_create(pa_exchange* exchange, void* stream, pa_operator** out)
+{
+    return guarded([&]() -> int32_t {
+        PA_REQUIRE(out != nullptr, PA_ERR_INVALID_ARGUMENT, "null argument");
+        *out = make_partitioned_output(exchange, stream);
+        return PA_OK;
+    });
+}
+int32_t pa_exchange_source_create(pa_exchange* exchange, int32_t output_mem, void* stream, pa_operator** out)
+{
+    return guarded([&]() -> int32_t {
+        PA_REQUIRE(out != nullptr, PA_ERR_INVALID_ARGUMENT, "null argument");
+        *out = make_exchange_source(exchange, output_mem, stream);
+        return PA_OK;
+    });
+}
+int32_t pa_exchange_stats(pa_exchange* exchange, int64_t* rows_sent, int64_t* rows_received, int64_t* bytes_sent_remote, double* transfer_ms)
+{
+    return guarded([&]() -> int32_t {
+        PA_REQUIRE(exchange != nullptr, PA_ERR_INVALID_ARGUMENT, "null argument");
+        exchange_stats(exchange, rows_sent, rows_received, bytes_sent_remote, transfer_ms);
+        return PA_OK;
+    });
+}
+int32_t pa_lookup_source_shared_key_bitmap(pa_lookup_source* source, pa_comm* comm, int32_t partitioned_by_key, void* stream,
+                                           const uint64_t** bits, int64_t* min_key, uint64_t* range)
+{
+    return guarded([&]() -> int32_t {
+        PA_REQUIRE(source && comm && bits && min_key && range, PA_ERR_INVALID_ARGUMENT, "null argument");
+        return lookup_source_shared_bitmap(source, comm, partitioned_by_key != 0, (hipStream_t)stream, bits, min_key, range) ? 1 : 0;
+    });
+}
+
 // ---- page wire format ----
 int64_t pa_page_serialize(const pa_page* page, void* out_host, int64_t capacity, void* stream)
 {
@@ -441,6 +585,7 @@ int32_t pa_op_needs_input(pa_operator* op)
 {
     return guarded([&]() -> int32_t {
         PA_REQUIRE(op != nullptr, PA_ERR_INVALID_ARGUMENT, "operator is null");
+        OpScope scope(op);
         return op->needs_input() ? 1 : 0;
     });
 }
@@ -448,6 +593,7 @@ int32_t pa_op_add_input(pa_operator* op, const pa_page* page)
 {
     return guarded([&]() -> int32_t {
         PA_REQUIRE(op != nullptr, PA_ERR_INVALID_ARGUMENT, "operator is null");
+        OpScope scope(op);
         PA_REQUIRE(op->needs_input(), PA_ERR_ILLEGAL_STATE, "Operator does not need input");
         op->add_input(page);
         return PA_OK;
@@ -457,6 +603,7 @@ int32_t pa_op_get_output(pa_operator* op, pa_page* out)
 {
     return guarded([&]() -> int32_t {
         PA_REQUIRE(op != nullptr && out != nullptr, PA_ERR_INVALID_ARGUMENT, "null argument");
+        OpScope scope(op);
         if (!op->get_output(out)) return 0;
         if (out->mem == PA_MEM_DEVICE) {
             if (hipStream_t s = op->private_stream()) PA_HIP(hipStreamSynchronize(s));
@@ -468,6 +615,7 @@ int32_t pa_op_finish(pa_operator* op)
 {
     return guarded([&]() -> int32_t {
         PA_REQUIRE(op != nullptr, PA_ERR_INVALID_ARGUMENT, "operator is null");
+        OpScope scope(op);
         op->finish();
         return PA_OK;
     });
@@ -476,6 +624,7 @@ int32_t pa_op_is_finished(pa_operator* op)
 {
     return guarded([&]() -> int32_t {
         PA_REQUIRE(op != nullptr, PA_ERR_INVALID_ARGUMENT, "operator is null");
+        OpScope scope(op);
         return op->is_finished() ? 1 : 0;
     });
 }
@@ -483,6 +632,7 @@ int32_t pa_op_is_blocked(pa_operator* op)
 {
     return guarded([&]() -> int32_t {
         PA_REQUIRE(op != nullptr, PA_ERR_INVALID_ARGUMENT, "operator is null");
+        OpScope scope(op);
         return op->is_blocked() ? 1 : 0;
     });
 }
@@ -491,6 +641,7 @@ int64_t pa_op_memory_bytes(pa_operator* op)
     int64_t bytes = 0;
     int32_t rc = guarded([&]() -> int32_t {
         PA_REQUIRE(op != nullptr, PA_ERR_INVALID_ARGUMENT, "operator is null");
+        OpScope scope(op);
         bytes = op->memory_bytes();
         return PA_OK;
     });
@@ -500,6 +651,7 @@ int32_t pa_op_close(pa_operator* op)
 {
     return guarded([&]() -> int32_t {
         if (op) {
+            OpScope scope(op);
             op->close();
             delete op;
         }
@@ -510,6 +662,7 @@ int32_t pa_op_kernel_time(pa_operator* op, double* total_ms, int64_t* launches)
 {
     return guarded([&]() -> int32_t {
         PA_REQUIRE(op != nullptr, PA_ERR_INVALID_ARGUMENT, "operator is null");
+        OpScope scope(op);
         op->timer.drain();
         if (total_ms) *total_ms = op->timer.total_ms();
         if (launches) *launches = op->timer.launches();

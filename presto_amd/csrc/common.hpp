@@ -57,6 +57,11 @@ void* pool_device_alloc(size_t bytes, size_t* granted);
 void pool_device_free(void* ptr, size_t granted);
 void* pool_pinned_alloc(size_t bytes, size_t* granted);
 void pool_pinned_free(void* ptr, size_t granted);
+// Stream of the operator call the thread is in (set by the C-ABI wrappers): blocks released meanwhile are tagged with it and
+// handed to another stream only once it has drained; returns the previous value.  pool_forget_stream: the stream is about to
+// be destroyed (the caller has synchronised it).
+hipStream_t pool_scope_stream(hipStream_t s);
+void pool_forget_stream(hipStream_t s);
 hipStream_t pool_stream_acquire();
 void pool_stream_release(hipStream_t s);
 

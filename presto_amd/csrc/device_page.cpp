@@ -216,7 +216,7 @@ void publish_output(std::vector<OutColumn>& cols, int32_t n, int32_t mem, hipStr
     out->channel_count = (int32_t)cols.size();
     out->columns = storage.data();
     out->mem = mem;
-    out->reserved = 0;
+    out->flags = 0;
 }
 
 }  // namespace pa

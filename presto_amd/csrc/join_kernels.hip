@@ -480,4 +480,21 @@ void launch_join_probe_count_keyed(const JoinCol& probe_key, const int64_t* prob
     PA_HIP(hipGetLastError());
 }
 
+__global__ __launch_bounds__(256) void k_sum_i32_i64(const i32* __restrict__ v, i64 n, unsigned long long* __restrict__ out)
+{
+    i64 acc = 0;
+    for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < n; i += (i64)gridDim.x * 256) acc += v[i];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    if ((threadIdx.x & 63) == 0 && acc != 0) atomicAdd(out, (unsigned long long)acc);  // one atomic per wave: a few thousand in all
+}
+void launch_sum_i32_i64(const int32_t* v, int64_t n, int64_t* out, hipStream_t s)
+{
+    PA_HIP(hipMemsetAsync(out, 0, 8, s));
+    if (n <= 0) return;
+    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((n + 255) / 256, 1024));
+    hipLaunchKernelGGL(k_sum_i32_i64, grid, 256, 0, s, v, (i64)n, reinterpret_cast<unsigned long long*>(out));
+    PA_HIP(hipGetLastError());
+}
+
 }  // namespace pa

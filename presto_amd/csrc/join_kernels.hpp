@@ -62,4 +62,7 @@ void launch_join_probe_emit(const int32_t* head, const int32_t* offsets, int32_t
 void launch_fill_i32(int32_t* dst, int32_t value, int64_t n, hipStream_t s);
 void launch_rebase_offsets(const int32_t* in, int32_t in_base, int32_t out_base, int64_t n_plus_1, int32_t* out, hipStream_t s);
 
+// *out = sum of v[0..n) in 64 bits (out: device memory, 8-byte aligned)
+void launch_sum_i32_i64(const int32_t* v, int64_t n, int64_t* out, hipStream_t s);
+
 }  // namespace pa

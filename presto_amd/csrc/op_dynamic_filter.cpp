@@ -121,6 +121,7 @@ public:
     }
     ~DynamicFilterSourceOperator() override { (void)hipStreamSynchronize(stream_.get()); }
     hipStream_t private_stream() override { return stream_.owned() ? stream_.get() : nullptr; }
+    hipStream_t main_stream() override { return stream_.get(); }
 
     bool needs_input() override { return !has_current_ && !finished_; }
 

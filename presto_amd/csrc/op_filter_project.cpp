@@ -270,6 +270,7 @@ public:
     }
     ~FilterProjectOperator() override { (void)hipStreamSynchronize(stream_.get()); }
     hipStream_t private_stream() override { return stream_.owned() ? stream_.get() : nullptr; }
+    hipStream_t main_stream() override { return stream_.get(); }
 
     bool needs_input() override { return !finishing_ && !pending_ && !big_queued_; }
 

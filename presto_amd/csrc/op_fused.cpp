@@ -19,11 +19,13 @@
 // All are HBM-read bound: algorithmic bytes per row = sum of the widths of the referenced columns.
 #include <algorithm>
 #include <cmath>
+#include <deque>
 #include <map>
 #include <memory>
 #include <mutex>
 #include <sstream>
 
+#include "exchange_kernels.hpp"
 #include "exprgen.hpp"
 #include "host_hash.hpp"
 #include "jit.hpp"
@@ -900,8 +902,8 @@ public:
         cus_ = device_cu_count();
         ctl_ = static_cast<int32_t*>(ctl_buf_.ensure(64));  // [0] err  [1] gt_count  [2..3] overflow rows
         PA_HIP(hipMemsetAsync(ctl_, 0, 64, stream_.get()));
-        h_ctl_ = static_cast<int32_t*>(h_ctl_buf_.ensure(64));
-        memset(h_ctl_, 0, 64);
+        h_ctl_ = static_cast<int32_t*>(h_ctl_buf_.ensure(256));  // [0..15] control block, [16..31] one copy per slab of the LDS variant
+        memset(h_ctl_, 0, 256);
     }
     ~FusedAggregationOperator() override
     {
@@ -914,8 +916,27 @@ public:
         }
     }
     hipStream_t private_stream() override { return stream_.owned() ? stream_.get() : nullptr; }
+    hipStream_t main_stream() override { return stream_.get(); }
 
-    bool needs_input() override { return !finishing_; }
+    // ---- Operator protocol with device work in flight -------------------------------------------------------------------
+    // add_input only enqueues.  Small pages are gathered first (see "small pages" below); the fused launches of the few-groups
+    // variant are confirmed one launch late (its overflow word decides whether a launch must be redone on the next tier), so
+    // the host is one launch ahead of the device and never waits inside add_input for a stable page.  needs_input() turns
+    // false -- and is_blocked() true -- while two launches are unconfirmed (Operator.isBlocked, Operator.java:69-80): the
+    // Driver polls, as it does for a future, instead of parking a thread in the native call.
+    bool needs_input() override
+    {
+        if (finishing_) return false;
+        if (next_) return next_->needs_input();
+        poll_inflight();
+        return inflight_.size() < kMaxInflight;
+    }
+    bool is_blocked() override
+    {
+        if (next_) return next_->is_blocked();
+        poll_inflight();
+        return inflight_.size() >= kMaxInflight;
+    }
 
     void add_input(const pa_page* page) override
     {
@@ -927,6 +948,16 @@ public:
             next_->add_input(page);
             return;
         }
+        if (gather_small_page(page)) return;
+        flush_pending();
+        process_page(page, (page->flags & PA_PAGE_STABLE) != 0 && page->mem == PA_MEM_DEVICE);
+    }
+
+    // One page (or gathered range of pages) through the kernels; `retained`: its buffers stay valid until the operator has
+    // confirmed the launches, so they may be confirmed late.
+    void process_page(const pa_page* page, bool retained)
+    {
+        retained_ = retained;
         try {
             add_page(page);
         }
@@ -935,11 +966,168 @@ public:
             PA_REQUIRE(!is_combiner_ && generation_ <= spec_.n_in, PA_ERR_DEVICE, "internal: state layout changed more often than channels exist");
             // a channel turned nullable in a way that needs more count words / NULL flags: this state stays as it is, the
             // page and everything after it go to a new generation; get_output combines the generations' states
+            confirm_all();
             next_ = std::make_unique<FusedAggregationOperator>(spec_, stream_.get());
             next_->nullable_seen_ = nullable_seen_;
             next_->generation_ = generation_ + 1;
-            next_->add_input(page);
+            next_->process_page(page, retained);
         }
+        retained_ = false;
+    }
+
+    // ---- small pages ----------------------------------------------------------------------------------------------------
+    // An unmodified Driver hands over pages of <= 1 MB / 8192 rows (PageProcessor.java:56-58); one launch per such page
+    // would leave the device idle between launches.  Two ways out, both keeping add_input a plain enqueue:
+    //  * consecutive STABLE device pages that continue each other in memory (row ranges of resident columns: Page.getRegion
+    //    views, pages over one pinned / HBM staging area) are merged into one range -- no copy, only pointer compares -- and
+    //    launched once the range holds kGatherRows rows (or at finish);
+    //  * other small pages with fixed-width used channels are copied behind each other into one of two arenas (one H2D copy
+    //    per column for host pages; one segment-copy launch per page for device pages, whose buffers may be recycled by their
+    //    producer after add_input returns) and the arena is launched when it is full.
+    static constexpr int64_t kSmallPageRows = (int64_t)1 << 21;
+    static int64_t gather_rows()
+    {
+        const char* e = getenv("PRESTO_AMD_GATHER_ROWS");  // tests and sweeps move the launch threshold
+        return e ? std::max<int64_t>(strtoll(e, nullptr, 10), 1) : (int64_t)1 << 26;
+    }
+    static constexpr int64_t kArenaRows = (int64_t)1 << 22;
+
+    bool channel_plain(const pa_column& col, int c) const
+    {
+        if (col.encoding == PA_FLAT) return col.type == spec_.in_types[c] || spec_.interned[c];
+        return col.encoding == PA_VARWIDTH;
+    }
+
+    // true: the page was taken (merged into the pending range / copied into the arena)
+    bool gather_small_page(const pa_page* page)
+    {
+        const int64_t n = page->position_count;
+        const bool stable_dev = (page->flags & PA_PAGE_STABLE) != 0 && page->mem == PA_MEM_DEVICE;
+        if (run_.rows > 0) {
+            // does the page continue the pending range?
+            bool cont = stable_dev && run_.rows + n <= ((int64_t)1 << 30);
+            for (int c = 0; c < spec_.n_in && cont; c++) {
+                if (!spec_.used_channel[c]) continue;
+                const pa_column& a = run_.cols[c];
+                const pa_column& b = page->columns[c];
+                cont = a.encoding == b.encoding && a.type == b.type && (a.nulls == nullptr) == (b.nulls == nullptr);
+                if (!cont) break;
+                if (a.nulls) cont = b.nulls == a.nulls + run_.rows;
+                if (a.encoding == PA_FLAT) {
+                    cont = cont && b.values == static_cast<const char*>(a.values) + run_.rows * type_width(a.type);
+                }
+                else {
+                    cont = cont && b.values == a.values && b.offsets == a.offsets + run_.rows;
+                }
+            }
+            if (cont) {
+                run_.rows += n;
+                if (run_.rows >= gather_rows()) flush_pending();
+                return true;
+            }
+            flush_pending();
+        }
+        if (n >= kSmallPageRows) return false;
+        bool plain = true, flat = true;
+        for (int c = 0; c < spec_.n_in && plain; c++) {
+            if (!spec_.used_channel[c]) continue;
+            plain = channel_plain(page->columns[c], c) && !spec_.interned[c];
+            flat = flat && page->columns[c].encoding == PA_FLAT;
+        }
+        if (!plain) return false;
+        if (stable_dev) {
+            flush_pending();
+            run_.rows = n;
+            run_.cols.assign(page->columns, page->columns + page->channel_count);
+            return true;
+        }
+        if (!flat) return false;
+        append_to_arena(page);
+        return true;
+    }
+
+    void append_to_arena(const pa_page* page)
+    {
+        hipStream_t s = stream_.get();
+        const int64_t n = page->position_count;
+        Arena& a = arena_[arena_cur_];
+        // the nullability of the arena's channels is fixed by its first page: a page that differs starts the next arena
+        bool fits = a.rows + n <= kArenaRows;
+        for (int c = 0; c < spec_.n_in && fits && a.rows > 0; c++) {
+            if (spec_.used_channel[c]) fits = a.nullable[c] == (page->columns[c].nulls != nullptr);
+        }
+        if (!fits) {
+            flush_pending();
+            return append_to_arena(page);
+        }
+        if (a.rows == 0) {
+            a.nullable.assign(spec_.n_in, false);
+            a.values.resize(spec_.n_in);
+            a.nulls.resize(spec_.n_in);
+            for (int c = 0; c < spec_.n_in; c++) {
+                if (!spec_.used_channel[c]) continue;
+                a.nullable[c] = page->columns[c].nulls != nullptr;
+                a.values[c].ensure((size_t)kArenaRows * type_width(spec_.in_types[c]));
+                if (a.nullable[c]) a.nulls[c].ensure((size_t)kArenaRows);
+            }
+        }
+        CopySeg segs[2 * kMaxChannels];
+        int m = 0;
+        for (int c = 0; c < spec_.n_in; c++) {
+            if (!spec_.used_channel[c]) continue;
+            const pa_column& col = page->columns[c];
+            PA_REQUIRE(col.type == spec_.in_types[c], PA_ERR_INVALID_ARGUMENT, "page block type does not match the declared input type");
+            PA_REQUIRE(col.values != nullptr, PA_ERR_INVALID_ARGUMENT, "block values is null");
+            const int w = type_width(col.type);
+            char* dv = a.values[c].as<char>() + a.rows * w;
+            if (page->mem == PA_MEM_DEVICE) {
+                segs[m++] = CopySeg{col.values, dv, n * w, 0};
+                if (col.nulls) segs[m++] = CopySeg{col.nulls, a.nulls[c].as<char>() + a.rows, n, 0};
+            }
+            else {
+                PA_HIP(hipMemcpyAsync(dv, col.values, (size_t)n * w, hipMemcpyHostToDevice, s));
+                if (col.nulls) PA_HIP(hipMemcpyAsync(a.nulls[c].as<char>() + a.rows, col.nulls, (size_t)n, hipMemcpyHostToDevice, s));
+            }
+        }
+        if (m > 0) launch_copy_segments_inline(segs, m, s);
+        a.rows += n;
+        if (a.rows >= kArenaRows) flush_pending();
+    }
+
+    // launches whatever is pending: the merged range of stable pages, or the current arena
+    void flush_pending()
+    {
+        if (run_.rows > 0) {
+            pa_page sp{};
+            sp.position_count = (int32_t)run_.rows;
+            sp.channel_count = spec_.n_in;
+            sp.columns = run_.cols.data();
+            sp.mem = PA_MEM_DEVICE;
+            sp.flags = PA_PAGE_STABLE;
+            run_.rows = 0;
+            process_page(&sp, true);
+            return;
+        }
+        Arena& a = arena_[arena_cur_];
+        if (a.rows == 0) return;
+        std::vector<pa_column> cols((size_t)spec_.n_in);
+        for (int c = 0; c < spec_.n_in; c++) {
+            cols[c].type = spec_.in_types[c];
+            cols[c].encoding = PA_FLAT;
+            if (!spec_.used_channel[c]) continue;
+            cols[c].values = a.values[c].ptr();
+            cols[c].nulls = a.nullable[c] ? a.nulls[c].as<uint8_t>() : nullptr;
+        }
+        pa_page sp{};
+        sp.position_count = (int32_t)a.rows;
+        sp.channel_count = spec_.n_in;
+        sp.columns = cols.data();
+        sp.mem = PA_MEM_DEVICE;
+        a.rows = 0;
+        arena_cur_ ^= 1;
+        // the arena is this operator's own: its rows stay put until the launches on it are confirmed -- the other arena
+        // takes the next pages, and is only written again after this one's launches were confirmed (kMaxInflight = 2)
+        process_page(&sp, true);
     }
 
     void add_page(const pa_page* page)
@@ -978,8 +1166,16 @@ public:
             }
             sig += layout[c].nullable ? 'n' : '-';
         }
-        int64_t start_row = 0;
+        run_tiers(sig, layout, dp, vec, 0);
+    }
+
+    // rows [start_row, dp.n) of a staged page through the tier mode_ names, moving on to the next tier when it gives up
+    void run_tiers(const std::string& sig, const std::vector<ChannelLayout>& layout, const DevPage& dp, bool vec, int64_t start_row)
+    {
         for (;;) {
+            // launches of the few-groups variant still unconfirmed while another tier takes over: settle them first (their
+            // merges write the table the other tiers resize and replicate)
+            if (mode_ != V_LDS && !inflight_.empty()) confirm_all();
             int partitions = 0;
             if (mode_ == V_GT && partitioned_wanted(sig, layout, &partitions)) {
                 run_page_partitioned(sig, layout, dp, vec, partitions, start_row);
@@ -998,11 +1194,14 @@ public:
             }
             const Compiled& ck = *compiled;
             resume_from_ = -1;
+            cur_sig_ = &sig;
+            cur_layout_ = &layout;
             if (run_page(ck, dp, vec, nullptr, start_row)) break;
             if (resume_from_ >= 0) {
-                // the LDS-table variant found, on the first rows of the page, that most rows miss its table: the rows from
-                // resume_from_ on go to the tier mode_ now names (hash-partitioned or plain HBM table)
+                // the rows before resume_from_ are done (or launched and waiting for their confirmation); the rest of the page
+                // goes to the tier mode_ now names
                 start_row = resume_from_;
+                if (start_row >= dp.n) break;
                 continue;
             }
             // the page held more groups than the wave's register table: redo it (and every later page) with the
@@ -1011,13 +1210,20 @@ public:
         }
     }
 
-    void finish() override { finishing_ = true; }
+    void finish() override
+    {
+        if (finishing_) return;
+        if (next_) next_->flush_pending();
+        else flush_pending();
+        finishing_ = true;
+    }
     bool is_finished() override { return finishing_ && output_done_; }
 
     bool get_output(pa_page* out) override
     {
         if (!finishing_ || output_done_) return false;
         output_done_ = true;
+        confirm_all();
         if (next_) return combine_generations(out);
         build_output();
         if (grouped_ && out_rows_ > 0) decode_interned_keys();
@@ -1031,6 +1237,8 @@ public:
     // The accumulator states of this generation as a PARTIAL-format page in HBM (false: no group).
     bool emit_states(pa_page* out)
     {
+        flush_pending();
+        confirm_all();
         out_partial_ = true;
         spec_.output_mem = PA_MEM_DEVICE;  // host-assembled blocks are uploaded
         build_output();
@@ -1470,6 +1678,12 @@ private:
                         PA_HIP(hipEventCreateWithFlags(&ev_merge_[i], hipEventDisableTiming));
                     }
                 }
+                // slab b, its overflow word and ev_main_[b] belong to launch k-2 until that one is confirmed
+                while (inflight_.size() >= kMaxInflight) confirm_oldest();
+                if (mode_ != V_LDS) {  // a confirmation moved the operator to the next tier: the rows from here on go there
+                    resume_from_ = offset;
+                    return false;
+                }
                 // slab b was last read by the merge of page k-2
                 if (merge_pending_[b]) PA_HIP(hipStreamWaitEvent(s, ev_merge_[b], 0));
                 a.slab = static_cast<uint64_t*>(lds_slab_[b].ensure((size_t)grid * ki.c * (1 + ki.w + ki.nw) * 8));
@@ -1514,7 +1728,7 @@ private:
                 // stream, overlapped with the next page's fused kernel; the host only waits for the fused kernel
                 // and the control block (error word, group count, overflow counters).
                 const int b = lds_page_ & 1;
-                PA_HIP(hipMemcpyAsync(h_ctl_, ctl_, 32, hipMemcpyDeviceToHost, s));
+                PA_HIP(hipMemcpyAsync(h_ctl_lds(b), ctl_, 32, hipMemcpyDeviceToHost, s));
                 PA_HIP(hipEventRecord(ev_main_[b], s));
                 PA_HIP(hipStreamWaitEvent(merge_stream_, ev_main_[b], 0));
                 launch_merge_lds_slab(a.slab, grid, ki.c, ki.w, ki.nw, ck.kinds.as<int32_t>(), a.gt_tag, a.gt_keys, a.gt_words, a.gt_mask,
@@ -1522,18 +1736,26 @@ private:
                                       static_cast<int32_t*>(entry_slot_[b].ensure((size_t)grid * ki.c * 4)), merge_stream_);
                 PA_HIP(hipEventRecord(ev_merge_[b], merge_stream_));
                 merge_pending_[b] = true;
-                PA_HIP(hipEventSynchronize(ev_main_[b]));
-                uint64_t overflow;
-                memcpy(&overflow, h_ctl_ + 2 + 2 * b, 8);
-                if (overflow != 0) {
-                    drain_merges();
-                    PA_HIP(hipMemsetAsync(ctl_ + 2 + 2 * b, 0, 8, s));
+                lds_page_++;
+                // The launch is confirmed later: its overflow word says whether a wave met more groups than its register table
+                // holds -- the merge then skipped itself and the rows are redone on the next tier.  The host only ever waits
+                // for a launch when the page cannot be read again later (not retained), or for the first launch of all, whose
+                // outcome decides the tier of everything that follows.
+                Inflight f;
+                f.b = b;
+                f.dp = dp;
+                f.dp.n = (int32_t)(offset + n);
+                f.vec = vec;
+                f.offset = offset;
+                f.sig = *cur_sig_;
+                f.layout = *cur_layout_;
+                inflight_.push_back(std::move(f));
+                if (!retained_ || !lds_probed_) confirm_all();
+                else poll_inflight();
+                if (mode_ != V_LDS) {
+                    resume_from_ = offset + n;
                     return false;
                 }
-                raise_if(h_ctl_[0]);
-                groups_upper_ = (uint64_t)h_ctl_[1];  // groups merged so far (the in-flight merges are bounded above)
-                lds_page_++;
-                lds_probed_ = true;
             }
             else {
                 // replay loop: grow the table until every row of the launch found room for its group
@@ -1580,9 +1802,59 @@ private:
                 }
             }
             offset += n;
-            if (resume_from_ >= 0) return false;  // the rest of the page goes to another tier (see add_input)
+            if (resume_from_ >= 0) return false;  // the rest of the page goes to another tier (see run_tiers)
         }
         return true;
+    }
+
+    // ---- late confirmation of the few-groups launches ------------------------------------------------------------------
+    struct Inflight {
+        int b = 0;            // slab / overflow word / event pair of the launch
+        DevPage dp;           // the page, cut at the end of the launched rows
+        bool vec = false;
+        int64_t offset = 0;   // first row of the launch
+        std::string sig;
+        std::vector<ChannelLayout> layout;
+    };
+    static constexpr size_t kMaxInflight = 2;
+    int32_t* h_ctl_lds(int b) const { return h_ctl_ + 16 + 8 * b; }
+
+    // confirms the launches whose kernel has finished, without waiting
+    void poll_inflight()
+    {
+        while (!inflight_.empty() && hipEventQuery(ev_main_[inflight_.front().b]) == hipSuccess) confirm_oldest();
+        (void)hipGetLastError();  // hipErrorNotReady is not an error here
+    }
+    void confirm_all()
+    {
+        while (!inflight_.empty()) confirm_oldest();
+    }
+    void confirm_oldest()
+    {
+        Inflight f = std::move(inflight_.front());
+        inflight_.pop_front();
+        PA_HIP(hipEventSynchronize(ev_main_[f.b]));
+        const int32_t* hc = h_ctl_lds(f.b);
+        uint64_t overflow;
+        memcpy(&overflow, hc + 2 + 2 * f.b, 8);
+        raise_if(hc[0]);
+        if (overflow == 0) {
+            groups_upper_ = std::max<uint64_t>(groups_upper_, (uint64_t)hc[1]);  // groups merged so far (in-flight merges are bounded above)
+            lds_probed_ = true;
+            return;
+        }
+        // more groups than the wave's register table: the launch's merge skipped itself; its rows -- and every later page --
+        // go to the workgroup-level LDS table, which itself hands rows it has no room for to the HBM table
+        hipStream_t s = stream_.get();
+        drain_merges();
+        PA_HIP(hipMemsetAsync(ctl_ + 2 + 2 * f.b, 0, 8, s));
+        if (mode_ == V_LDS) mode_ = V_LDSH;
+        const int64_t saved = resume_from_;
+        const bool saved_retained = retained_;
+        retained_ = false;
+        run_tiers(f.sig, f.layout, f.dp, f.vec, f.offset);
+        retained_ = saved_retained;
+        resume_from_ = saved;
     }
 
     static void raise_if(int32_t code)
@@ -1638,6 +1910,21 @@ private:
     uint64_t groups_sum_ = 0;
     bool gt_probed_ = false, lds_probed_ = false;
     int64_t resume_from_ = -1;
+    bool retained_ = false;               // the page being processed stays readable until its launches are confirmed
+    std::deque<Inflight> inflight_;       // few-groups launches not confirmed yet (at most kMaxInflight)
+    const std::string* cur_sig_ = nullptr;                  // signature / layout of the page run_page works on
+    const std::vector<ChannelLayout>* cur_layout_ = nullptr;
+    // small pages (see gather_small_page)
+    struct Run {
+        int64_t rows = 0;
+        std::vector<pa_column> cols;      // first page of the range: every later page continues these buffers
+    } run_;
+    struct Arena {
+        int64_t rows = 0;
+        std::vector<bool> nullable;
+        std::vector<DevBuf> values, nulls;
+    } arena_[2];
+    int arena_cur_ = 0;
     const int32_t* kinds_dev_ = nullptr;
     hipStream_t merge_stream_ = nullptr;
     hipEvent_t ev_main_[2] = {nullptr, nullptr}, ev_merge_[2] = {nullptr, nullptr};

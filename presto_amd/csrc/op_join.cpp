@@ -14,7 +14,9 @@
 #include <atomic>
 #include <mutex>
 
+#include "comm.hpp"
 #include "dynfilter_kernels.hpp"
+#include "exchange_kernels.hpp"
 #include "join_kernels.hpp"
 #include "operator.hpp"
 #include "scan_kernels.hpp"
@@ -46,6 +48,7 @@ struct LookupSourceImpl {
     bool reference_built = false;  // PagesHash.key[] (the reference's layout) exists; keyed joins build it on demand
     bool key_range_valid = false;  // keyed join with at least one non-NULL build key: [key_min, key_max]
     int64_t key_min = 0, key_max = 0;
+    DevBuf shared_bits;  // the bitmap of pa_lookup_source_shared_key_bitmap (union key range of all ranks)
     DevBuf visited;  // OuterPositionTracker.visitedPositions: 1 B per build position, written by LOOKUP_OUTER / FULL_OUTER probes
     uint32_t mask = 0;
     std::atomic<bool> built{false};
@@ -112,6 +115,7 @@ uint32_t array_size(int64_t expected)
 
 class HashBuilderOperator : public pa_operator {
 public:
+    hipStream_t main_stream() override { return stream_.get(); }
     HashBuilderOperator(const pa_hash_builder_desc* d, pa_lookup_source* bridge) : stream_(d->stream)
     {
         PA_REQUIRE(d != nullptr, PA_ERR_INVALID_ARGUMENT, "descriptor is null");
@@ -320,6 +324,7 @@ public:
     }
     ~LookupJoinOperator() override { (void)hipStreamSynchronize(stream_.get()); }
     hipStream_t private_stream() override { return stream_.owned() ? stream_.get() : nullptr; }
+    hipStream_t main_stream() override { return stream_.get(); }
 
     // LookupJoinOperator.needsInput: only once the lookup source is ready, one probe page at a time
     bool needs_input() override { return !finishing_ && !pending_ && ls_->built.load(); }
@@ -375,31 +380,71 @@ public:
             launch_join_probe_count(ls_->build_keys(), pk, probe_hash, n, ls_->tagged.as<uint64_t>(), ls_->probe_mask, ls_->links.as<int32_t>(), head, counts,
                                     probe_flags_, s);
         }
-        launch_exclusive_scan_i32(counts, counts, n, ctl_, scan_temp_.ensure(scan_temp_bytes(n)), s);
+        // the matches of the page, in 64 bits: a skewed key or a high fan-out can put more than 2^31 of them behind one page
+        launch_sum_i32_i64(counts, n, reinterpret_cast<int64_t*>(ctl_ + 4), s);
         timer.end(s);
-        PA_HIP(hipMemcpyAsync(h_ctl_, ctl_, 4, hipMemcpyDeviceToHost, s));
+        PA_HIP(hipMemcpyAsync(h_ctl_ + 4, ctl_ + 4, 8, hipMemcpyDeviceToHost, s));
         pending_ = true;
+        range_lo_ = 0;
+        remaining_ = -1;
+    }
+
+    // At most this many output rows per page: the reference's LookupJoinPageBuilder flushes bounded pages (1 MB / 8192 rows);
+    // here a probe page whose matches exceed the bound comes out as several pages, each the join of a row range of the page.
+    static int64_t max_output_rows()
+    {
+        const char* e = getenv("PRESTO_AMD_JOIN_MAX_OUTPUT_ROWS");  // tests exercise the splitting with a small bound
+        return e ? std::max<int64_t>(strtoll(e, nullptr, 10), 1) : (int64_t)1 << 30;
     }
 
     bool get_output(pa_page* out) override
     {
         if (!pending_) return false;
-        pending_ = false;
         hipStream_t s = stream_.get();
-        PA_HIP(hipStreamSynchronize(s));
-        const int32_t total = h_ctl_[0];
-        last_matches_ = total;
-        if (total == 0) return false;
         const int32_t n = in_.n;
+        if (remaining_ < 0) {
+            PA_HIP(hipStreamSynchronize(s));
+            memcpy(&remaining_, h_ctl_ + 4, 8);
+        }
+        int32_t lo = range_lo_, hi = n;
+        int64_t sum = remaining_;
+        for (;;) {
+            if (sum == 0 && hi == n) {  // nothing (more) to emit
+                pending_ = false;
+                last_matches_ = 0;
+                return false;
+            }
+            while (sum > max_output_rows()) {
+                PA_REQUIRE(hi - lo > 1, PA_ERR_INSUFFICIENT_RESOURCES, "one probe row has more matches than an output page may hold (2^30)");
+                hi = lo + (hi - lo) / 2;
+                launch_sum_i32_i64(counts_.as<int32_t>() + lo, hi - lo, reinterpret_cast<int64_t*>(ctl_ + 4), s);
+                PA_HIP(hipMemcpyAsync(h_ctl_ + 4, ctl_ + 4, 8, hipMemcpyDeviceToHost, s));
+                PA_HIP(hipStreamSynchronize(s));
+                memcpy(&sum, h_ctl_ + 4, 8);
+            }
+            if (sum > 0) break;
+            // an empty leading range: move on
+            lo = hi;
+            hi = n;
+            sum = remaining_;
+        }
+        const int32_t rows = hi - lo;
+        const int32_t total = (int32_t)sum;
+        int32_t* offsets = counts_.as<int32_t>() + lo;
+        launch_exclusive_scan_i32(offsets, offsets, rows, nullptr, scan_temp_.ensure(scan_temp_bytes(rows)), s);
+        last_matches_ = total;
         int32_t* probe_idx = static_cast<int32_t*>(probe_idx_.ensure((size_t)total * 4));
         int32_t* build_pos = static_cast<int32_t*>(build_pos_.ensure((size_t)total * 4));
-        launch_join_probe_emit(head_.as<int32_t>(), counts_.as<int32_t>(), n, total, ls_->links.as<int32_t>(), probe_idx, build_pos, probe_flags_,
+        launch_join_probe_emit(head_.as<int32_t>() + lo, offsets, rows, total, ls_->links.as<int32_t>(), probe_idx, build_pos, probe_flags_,
                                track_visited_ ? ls_->visited.as<uint8_t>() : nullptr, s);
-        // LookupJoinPageBuilder.build: probe output channels by probe index ++ build output channels by build position
+        // LookupJoinPageBuilder.build: probe output channels by probe index (relative to the range) ++ build output channels
+        // by build position
         size_t oc = 0;
         for (int c : output_channels_) {
             const DevColumn& src = in_.cols[c];
-            gather_column(src.type, src.varwidth, src.values, src.offsets, src.nulls, probe_idx, total, out_cols_[oc++], s);
+            const void* values = src.varwidth ? src.values : static_cast<const char*>(src.values) + (size_t)lo * type_width(src.type);
+            gather_column(src.type, src.varwidth, values, src.offsets ? src.offsets + lo : nullptr, src.nulls ? src.nulls + lo : nullptr, probe_idx, total,
+                          out_cols_[oc++], s);
         }
         for (int c : ls_->output_channels) {
             const BuildColumn& src = ls_->cols[c];
@@ -407,6 +452,9 @@ public:
                           build_pos, total, out_cols_[oc++], s, probe_outer_);
         }
         publish_output(out_cols_, total, output_mem_, s, out, out_storage_);
+        range_lo_ = hi;
+        remaining_ -= sum;
+        pending_ = hi < n && remaining_ > 0;
         return true;
     }
 
@@ -434,9 +482,14 @@ private:
         if (varwidth) {
             int32_t* lens = static_cast<int32_t*>(oc.offsets.ensure((size_t)(count + 1) * 4));
             launch_varwidth_lengths(positions, count, offsets, nulls, lens, s);
+            launch_sum_i32_i64(lens, count, reinterpret_cast<int64_t*>(ctl_ + 6), s);
             launch_exclusive_scan_i32(lens, lens, count, ctl_ + 2, scan_temp_.ensure(scan_temp_bytes(count)), s);
             PA_HIP(hipMemcpyAsync(h_ctl_ + 2, ctl_ + 2, 4, hipMemcpyDeviceToHost, s));
+            PA_HIP(hipMemcpyAsync(h_ctl_ + 6, ctl_ + 6, 8, hipMemcpyDeviceToHost, s));
             PA_HIP(hipStreamSynchronize(s));
+            int64_t bytes64;
+            memcpy(&bytes64, h_ctl_ + 6, 8);
+            PA_REQUIRE(bytes64 < ((int64_t)1 << 31), PA_ERR_INSUFFICIENT_RESOURCES, "a join output page holds more than 2 GiB of VARCHAR bytes");
             int32_t bytes = h_ctl_[2];
             uint8_t* dst = static_cast<uint8_t*>(oc.values.ensure((size_t)(bytes > 0 ? bytes : 1)));
             launch_varwidth_copy(positions, count, offsets, static_cast<const uint8_t*>(values), nulls, lens, dst, ctl_ + 2, s);
@@ -468,6 +521,8 @@ private:
     int32_t* ctl_ = nullptr;
     int32_t* h_ctl_ = nullptr;
     int32_t last_matches_ = 0;
+    int32_t range_lo_ = 0;     // first probe row not joined yet (a probe page may come out as several pages)
+    int64_t remaining_ = -1;   // matches of the rows from range_lo_ on (-1: not read back yet)
     bool finishing_ = false, pending_ = false, probe_outer_ = false, track_visited_ = false;
     int probe_flags_ = 0;
     std::vector<OutColumn> out_cols_;
@@ -498,6 +553,7 @@ public:
     }
     ~LookupOuterOperator() override { (void)hipStreamSynchronize(stream_.get()); }
     hipStream_t private_stream() override { return stream_.owned() ? stream_.get() : nullptr; }
+    hipStream_t main_stream() override { return stream_.get(); }
 
     bool needs_input() override { return false; }  // LookupOuterOperator.java:135-138
     void add_input(const pa_page*) override { throw Error(PA_ERR_ILLEGAL_STATE, "LookupOuterOperator does not take input"); }
@@ -611,6 +667,58 @@ void lookup_source_fill_bitmap(pa_lookup_source* ls, int64_t min_key, uint64_t r
     PA_REQUIRE(ls->impl->built.load() && ls->impl->keyed, PA_ERR_ILLEGAL_STATE, "needs a built lookup source with one integer join key");
     const JoinKeys bk = ls->impl->build_keys();
     launch_join_key_bitmap(bk.col[0], ls->impl->n, min_key, range, bits, s);
+}
+
+// The dynamic filter of a partitioned join: every rank holds the build keys of its own partition, and the probe side is
+// filtered BEFORE it is exchanged, so the filter must know every rank's keys.  Collective over the ranks of `comm`.
+bool lookup_source_shared_bitmap(pa_lookup_source* ls, pa_comm* comm, bool partitioned_by_key, hipStream_t s, const uint64_t** bits, int64_t* min_key,
+                                 uint64_t* range)
+{
+    PA_REQUIRE(ls != nullptr && ls->impl, PA_ERR_INVALID_ARGUMENT, "lookup source is null");
+    LookupSourceImpl& impl = *ls->impl;
+    PA_REQUIRE(impl.built.load(), PA_ERR_ILLEGAL_STATE, "the lookup source is not built yet");
+    const int64_t big = (int64_t)1 << 62;
+    const bool has = impl.keyed && impl.key_range_valid;
+    // [min key, -max key, "this rank cannot take part"] -> MIN / MIN / MAX; rows -> SUM
+    int64_t ends[2] = {has ? impl.key_min : big, has ? -impl.key_max : big};
+    int64_t flags[1] = {impl.keyed ? 0 : 1};
+    int64_t rows[1] = {impl.n};
+    comm_all_reduce_i64(comm, ends, 2, COMM_MIN, s);
+    comm_all_reduce_i64(comm, flags, 1, COMM_MAX, s);
+    comm_all_reduce_i64(comm, rows, 1, COMM_SUM, s);
+    if (flags[0] != 0 || ends[0] == big) return false;  // not one integer key everywhere, or no key anywhere
+    const int64_t lo = ends[0], hi = -ends[1];
+    const uint64_t r = (uint64_t)(hi - lo);
+    // a bitmap pays while it is no larger than the keys themselves (the rule of the single-rank filter) and stays below 8 GiB
+    if (hi < lo || r >= 64ULL * (uint64_t)std::max<int64_t>(rows[0], 1) || r >= (1ULL << 36)) return false;
+    const int64_t words = (int64_t)(r >> 6) + 1;
+    uint64_t* b = static_cast<uint64_t*>(impl.shared_bits.ensure((size_t)words * 8));
+    if (has) {
+        const JoinKeys bk = impl.build_keys();
+        launch_join_key_bitmap(bk.col[0], impl.n, lo, r, b, s);
+    }
+    else PA_HIP(hipMemsetAsync(b, 0, (size_t)words * 8, s));
+    if (comm->world > 1) {
+        if (partitioned_by_key) {
+            // every key lives on exactly one rank: the ranks' set bits are disjoint, SUM == OR (RCCL has no bitwise reduction)
+            comm_all_reduce_sum_u64(comm, b, words, s);
+        }
+        else {
+            DevBuf all;
+            const int W = comm->world;
+            uint64_t* g = static_cast<uint64_t*>(all.ensure((size_t)words * 8 * W));
+            std::vector<int64_t> soff((size_t)W, 0), sb((size_t)W, words * 8), roff((size_t)W), rb((size_t)W, words * 8);
+            for (int p = 0; p < W; p++) roff[p] = (int64_t)p * words * 8;
+            comm_all_to_all_v(comm, b, soff.data(), sb.data(), g, roff.data(), rb.data(), s);
+            launch_or_words(b, g, words, W, s);
+            PA_HIP(hipStreamSynchronize(s));  // `all` goes back to the pool
+        }
+    }
+    PA_HIP(hipStreamSynchronize(s));
+    *bits = b;
+    *min_key = lo;
+    *range = r;
+    return true;
 }
 
 pa_operator* make_hash_builder(const pa_hash_builder_desc* desc, pa_lookup_source* bridge)

@@ -63,6 +63,7 @@ public:
     }
     ~OrderByOperator() override { (void)hipStreamSynchronize(stream_.get()); }
     hipStream_t private_stream() override { return stream_.owned() ? stream_.get() : nullptr; }
+    hipStream_t main_stream() override { return stream_.get(); }
 
     bool needs_input() override { return !finishing_; }
 

@@ -21,6 +21,13 @@ struct pa_operator {
     // the operator's stream when the library owns it (desc.stream == NULL), else nullptr: nobody outside can order work
     // against an owned stream, so device output pages are completed before pa_op_get_output returns them
     virtual hipStream_t private_stream() { return nullptr; }
+    // the stream the operator enqueues its work on: pooled HBM blocks released inside one of its calls are tagged with it and
+    // re-granted to another stream only once this one has drained (pool.cpp)
+    virtual hipStream_t main_stream() { return nullptr; }
+    // HIP device the operator was created on: every C-ABI entry rebinds the calling thread to it (Trino's Driver threads never
+    // call pa_init; a handle created on one thread may be driven and closed on others)
+    int device = -1;
+    pa_operator() { if (hipGetDevice(&device) != hipSuccess) device = -1; }
     pa::KernelTimer timer;
 };
 
@@ -42,6 +49,16 @@ void lookup_source_fill_bitmap(pa_lookup_source* ls, int64_t min_key, uint64_t r
 void filter_project_set_dynamic_filter(pa_operator* op, int channel, const uint64_t* bits, int64_t min_key, uint64_t range, std::shared_ptr<void> keep);
 pa_operator* make_dynamic_filter_source(const pa_dynamic_filter_source_desc* desc);
 int32_t dynamic_filter_poll(pa_operator* op, int32_t* is_all, pa_domain* domains, int32_t capacity);
+
+// partitioned exchange (op_exchange.cpp)
+pa_exchange* exchange_new(const pa_exchange_desc* desc, pa_comm* comm);
+void exchange_delete(pa_exchange* ex);
+void exchange_stats(pa_exchange* ex, int64_t* rows_sent, int64_t* rows_received, int64_t* bytes_remote, double* transfer_ms);
+pa_operator* make_partitioned_output(pa_exchange* ex, void* stream);
+pa_operator* make_exchange_source(pa_exchange* ex, int32_t output_mem, void* stream);
+// the build-side existence bitmap of a partitioned join over the union key range of all ranks (op_join.cpp)
+bool lookup_source_shared_bitmap(pa_lookup_source* ls, pa_comm* comm, bool partitioned_by_key, hipStream_t s, const uint64_t** bits, int64_t* min_key,
+                                 uint64_t* range);
 
 // page wire format (page_serde.cpp)
 int64_t serialize_page(const pa_page* page, void* out_host, int64_t capacity, hipStream_t s);

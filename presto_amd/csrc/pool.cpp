@@ -12,10 +12,18 @@
 namespace pa {
 namespace {
 
+// A cached HBM block and the stream that may still be working on it: blocks are released in the middle of a pipeline (a
+// staging arena that grows, a table that is rehashed) while kernels enqueued earlier still read them.  A request made on
+// the same stream may take the block at once (stream order), any other stream only once that stream has drained.
+struct DeviceBlock {
+    void* ptr;
+    hipStream_t last;  // nullptr: released by code that had synchronised (or outside any operator call)
+};
+
 struct Pools {
     std::mutex mu;
     // key: (device, size class)
-    std::multimap<std::pair<int, size_t>, void*> device_free;
+    std::multimap<std::pair<int, size_t>, DeviceBlock> device_free;
     std::multimap<size_t, void*> pinned_free;
     std::multimap<int, hipStream_t> stream_free;
     size_t device_cached = 0, pinned_cached = 0;
@@ -48,7 +56,26 @@ size_t max_cached_device()
 }
 constexpr size_t kMaxCachedPinned = 1ULL << 30;
 
+thread_local hipStream_t t_scope_stream = nullptr;
+
 }  // namespace
+
+hipStream_t pool_scope_stream(hipStream_t s)
+{
+    hipStream_t prev = t_scope_stream;
+    t_scope_stream = s;
+    return prev;
+}
+
+void pool_forget_stream(hipStream_t s)
+{
+    if (!s) return;
+    Pools& p = pools();
+    std::lock_guard<std::mutex> lock(p.mu);
+    for (auto& kv : p.device_free) {
+        if (kv.second.last == s) kv.second.last = nullptr;
+    }
+}
 
 void* pool_device_alloc(size_t bytes, size_t* granted)
 {
@@ -58,14 +85,19 @@ void* pool_device_alloc(size_t bytes, size_t* granted)
     {
         Pools& p = pools();
         std::lock_guard<std::mutex> lock(p.mu);
-        auto it = p.device_free.find({dev, c});
-        if (it != p.device_free.end()) {
-            void* ptr = it->second;
+        auto range = p.device_free.equal_range({dev, c});
+        for (auto it = range.first; it != range.second; ++it) {
+            hipStream_t last = it->second.last;
+            // hipStreamQuery: hipErrorNotReady while work is pending; anything else (idle, or a stream its owner destroyed,
+            // which waits for its work) means the block is quiescent
+            if (last != nullptr && last != t_scope_stream && hipStreamQuery(last) == hipErrorNotReady) continue;
+            void* ptr = it->second.ptr;
             p.device_free.erase(it);
             p.device_cached -= c;
             *granted = c;
             return ptr;
         }
+        (void)hipGetLastError();
     }
     void* ptr = nullptr;
     hipError_t e = hipMalloc(&ptr, c);
@@ -78,7 +110,7 @@ void* pool_device_alloc(size_t bytes, size_t* granted)
             std::lock_guard<std::mutex> lock(p.mu);
             for (auto it = p.device_free.begin(); it != p.device_free.end();) {
                 if (it->first.first == dev) {
-                    cached.push_back(it->second);
+                    cached.push_back(it->second.ptr);
                     p.device_cached -= it->first.second;
                     it = p.device_free.erase(it);
                 }
@@ -103,7 +135,7 @@ void pool_device_free(void* ptr, size_t granted)
     {
         std::lock_guard<std::mutex> lock(p.mu);
         if (p.device_cached + granted <= max_cached_device()) {
-            p.device_free.emplace(std::make_pair(dev, granted), ptr);
+            p.device_free.emplace(std::make_pair(dev, granted), DeviceBlock{ptr, t_scope_stream});
             p.device_cached += granted;
             return;
         }
@@ -173,6 +205,7 @@ void pool_stream_release(hipStream_t s)
     if (hipGetDevice(&dev) != hipSuccess) return;
     // everything enqueued by the previous owner must be done before its buffers are recycled
     (void)hipStreamSynchronize(s);
+    pool_forget_stream(s);
     Pools& p = pools();
     std::lock_guard<std::mutex> lock(p.mu);
     p.stream_free.emplace(dev, s);

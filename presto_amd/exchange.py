@@ -1,4 +1,4 @@
-"""Hash-partitioned exchange between the GPUs of one node: the RCCL counterpart of the reference's page shuffle.
+"""Hash-partitioned exchange between the GPUs of one node -- ctypes caller of the native exchange (op_exchange.cpp, comm.cpp).
 
 Reference: rows are routed by
     partition = (int) XxHash64.hash(Long.reverse(rawHash)) & (P - 1)     local exchange / PartitionedLookupSource
@@ -9,195 +9,202 @@ Reference: rows are routed by
                  core/trino-main/src/main/java/io/trino/operator/PartitionedOutputOperator.java:411-431)
 with rawHash = InterpretedHashGenerator over the partition channels, appended per partition in ascending position
 order (core/trino-main/src/main/java/io/trino/operator/exchange/PartitioningExchanger.java:59-82), then serialised
-and pulled over HTTP.  Here: one rank per GPU, P = world size; the per-row work (hash, partition id, stable
-partition, gather into per-destination send buffers) runs in HIP kernels behind the C ABI, and the transfer is one
-all-to-all per column over xGMI (torch.distributed `nccl` == RCCL): raw column bytes, no serialisation, no
-compression.  Row order inside what a rank receives = (source rank, source position), i.e. what a consumer that
-drains the producers in rank order would see.
+and pulled over HTTP.  Here: one rank per GPU, P = world size.  Everything on the data path is behind the C ABI
+(include/presto_amd.h, "hash-partitioned exchange"): the PartitionedOutput sink regroups every page by destination on
+the device, the exchange source runs ONE count all-gather and ONE variable all-to-all (grouped ncclSend / ncclRecv, RCCL
+over xGMI) per exchange and hands the received rows out as one page.  This module only creates the handles:
 
-The `ops` object supplies the per-row kernels so that the exchange logic can be exercised on CPU ranks (gloo) in
-the tests with a checker implementation; the product implementation is DeviceOps.
+  Comm          pa_comm: the RCCL communicator (the 128-byte unique id travels through torch.distributed here; in Trino the
+                coordinator would ship it), or the host transport, whose two collectives this module does over
+                torch.distributed (gloo) -- several ranks sharing one GPU in the tests
+  Exchange      pa_exchange: the OutputBuffer + ExchangeClient pair of one exchange on this rank
+  ExchangeOperator   sink + source behind one Operator, for a Driver pipeline that contains the exchange step
 """
 import ctypes as C
 
-import torch
-import torch.distributed as dist
-
 from . import abi
-from .page import Block, DeviceBuffer, Page
-
-_TORCH_DTYPE = {abi.BIGINT: torch.int64, abi.INTEGER: torch.int32, abi.DATE: torch.int32, abi.DOUBLE: torch.float64,
-                abi.BOOLEAN: torch.uint8}
+from ._lib import check, lib
+from .page import Block, Page
 
 
-class DeviceOps:
-    """Per-row exchange kernels on this rank's GPU through libpresto_amd.so; columns are torch CUDA tensors."""
+class Comm:
+    """pa_comm.  Comm.rccl(group) / Comm.host(group) are collective over the ranks of the torch.distributed group."""
 
-    def __init__(self):
-        from ._lib import check, lib
-        self._check, self._lib = check, lib()
+    def __init__(self, handle, rank, world, keep=None):
+        self._h, self.rank, self.world, self._keep = handle, rank, world, keep
 
     @staticmethod
-    def _stream():
-        return torch.cuda.current_stream().cuda_stream or None
+    def single():
+        """World of one rank (RCCL with itself): the exchange path on one GPU."""
+        ident = (C.c_uint8 * abi.COMM_ID_BYTES)()
+        check(lib().pa_comm_unique_id(ident))
+        h = C.c_void_p()
+        check(lib().pa_comm_create(ident, 0, 1, C.byref(h)))
+        return Comm(h, 0, 1)
 
     @staticmethod
-    def _page(columns, types):
-        n = rows_of(columns[0]) if columns else 0
-        blocks = []
-        for c, t in zip(columns, types):
-            if t == abi.VARCHAR:  # (bytes uint8, offsets int32[n + 1])
-                v, o = c
-                blocks.append(Block(t, abi.VARWIDTH, n, values=DeviceBuffer(v.data_ptr(), v.numel(), v), offsets=DeviceBuffer(o.data_ptr(), o.numel() * 4, o)))
-            else:
-                blocks.append(Block(t, abi.FLAT, n, values=DeviceBuffer(c.data_ptr(), c.numel() * c.element_size(), c)))
-        return Page(blocks, n, abi.MEM_DEVICE)
+    def rccl(group=None):
+        import torch.distributed as dist
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        ident = (C.c_uint8 * abi.COMM_ID_BYTES)()
+        if rank == 0:
+            check(lib().pa_comm_unique_id(ident))
+        box = [bytes(ident)]
+        dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        ident = (C.c_uint8 * abi.COMM_ID_BYTES).from_buffer_copy(box[0])
+        h = C.c_void_p()
+        check(lib().pa_comm_create(ident, rank, world, C.byref(h)))
+        return Comm(h, rank, world)
 
-    def hash_rows(self, columns, types, channels):
-        page = self._page(columns, types)
-        cpage, keep = page.to_c()
-        out = torch.empty(page.position_count, dtype=torch.int64, device=columns[0].device)
-        ch = abi.int32_array(channels)
-        self._check(self._lib.pa_hash_page(C.byref(cpage), len(channels), ch, out.data_ptr(), self._stream()))
-        return out
+    @staticmethod
+    def host(group=None):
+        """The two collectives done here, over torch.distributed on host tensors (gloo): pa_host_transport."""
+        import numpy as np
+        import torch
+        import torch.distributed as dist
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
 
-    def partition_ids(self, raw_hash, partition_count, local):
-        out = torch.empty(raw_hash.numel(), dtype=torch.int32, device=raw_hash.device)
-        self._check(self._lib.pa_partition_ids(raw_hash.data_ptr(), raw_hash.numel(), partition_count, 1 if local else 0,
-                                               out.data_ptr(), self._stream()))
-        return out
+        def all_gather(ctx, send, recv, count):
+            try:
+                s = torch.from_numpy(np.ctypeslib.as_array(send, shape=(count,)).copy())
+                out = torch.empty(world * count, dtype=torch.int64)
+                dist.all_gather_into_tensor(out, s, group=group)
+                np.ctypeslib.as_array(recv, shape=(world * count,))[:] = out.numpy()
+                return 0
+            except Exception:  # never let an exception cross the C boundary
+                import traceback
+                traceback.print_exc()
+                return abi.ERR_DEVICE
 
-    def partition_positions(self, partition, partition_count):
-        pos = torch.empty(partition.numel(), dtype=torch.int32, device=partition.device)
-        counts = (C.c_int64 * partition_count)()
-        self._check(self._lib.pa_partition_positions(partition.data_ptr(), partition.numel(), partition_count, pos.data_ptr(),
-                                                     counts, self._stream()))
-        return pos, [int(c) for c in counts]
+        def all_to_all(ctx, send, soff, sbytes, recv, roff, rbytes):
+            try:
+                so = [int(soff[i]) for i in range(world)]
+                sb = [int(sbytes[i]) for i in range(world)]
+                ro = [int(roff[i]) for i in range(world)]
+                rb = [int(rbytes[i]) for i in range(world)]
+                stotal = max([o + b for o, b in zip(so, sb)] + [0])
+                rtotal = max([o + b for o, b in zip(ro, rb)] + [0])
+                src = np.ctypeslib.as_array(C.cast(send, C.POINTER(C.c_uint8)), shape=(max(stotal, 1),))
+                dst = np.ctypeslib.as_array(C.cast(recv, C.POINTER(C.c_uint8)), shape=(max(rtotal, 1),))
+                # the blobs of consecutive peers are contiguous, but go by the offsets all the same
+                s = torch.from_numpy(np.concatenate([src[o:o + b] for o, b in zip(so, sb)]) if stotal else np.zeros(0, np.uint8))
+                out = torch.empty(sum(rb), dtype=torch.uint8)
+                dist.all_to_all_single(out, s, output_split_sizes=rb, input_split_sizes=sb, group=group)
+                o = out.numpy()
+                at = 0
+                for off, b in zip(ro, rb):
+                    dst[off:off + b] = o[at:at + b]
+                    at += b
+                return 0
+            except Exception:
+                import traceback
+                traceback.print_exc()
+                return abi.ERR_DEVICE
 
-    def partition_columns(self, partition, partition_count, columns, want_positions):
-        """The flat columns regrouped by partition in one stable multisplit pass (row order kept inside a partition) instead of
-        partition_positions + one gather per column -> (regrouped columns, positions or None, rows per partition).  None when
-        the partition count is beyond the stable kernel's 256."""
-        if partition_count > 256:
-            return None
-        n = partition.numel()
-        cols = list(columns)
-        if want_positions:
-            cols.append(torch.arange(n, dtype=torch.int32, device=partition.device))
-        outs = [torch.empty_like(c) for c in cols]
-        vp = C.c_void_p
-        ins = (vp * max(len(cols), 1))(*[c.data_ptr() for c in cols])
-        ous = (vp * max(len(cols), 1))(*[c.data_ptr() for c in outs])
-        widths = (C.c_int32 * max(len(cols), 1))(*[c.element_size() for c in cols])
-        counts = (C.c_int64 * partition_count)()
-        self._check(self._lib.pa_partition_columns_stable(partition.data_ptr(), n, partition_count, ins, ous, widths, len(cols), counts, self._stream()))
-        positions = outs.pop() if want_positions else None
-        return outs, positions, [int(c) for c in counts]
+        t = abi.pa_host_transport()
+        t.ctx = None
+        t.all_gather_i64 = abi.ALL_GATHER_I64(all_gather)
+        t.all_to_all_v = abi.ALL_TO_ALL_V(all_to_all)
+        h = C.c_void_p()
+        check(lib().pa_comm_create_host(C.byref(t), rank, world, C.byref(h)))
+        return Comm(h, rank, world, keep=t)
 
-    def gather_varwidth(self, values, offsets, positions):
-        """Block.copyPositions for a VARCHAR column -> (bytes, offsets, per-row lengths)."""
-        n = positions.numel()
-        lengths = torch.empty(n, dtype=torch.int32, device=values.device)
-        out_offsets = torch.empty(n + 1, dtype=torch.int32, device=values.device)
-        total = C.c_int64()
-        self._check(self._lib.pa_varwidth_gather_offsets(offsets.data_ptr(), positions.data_ptr(), n, lengths.data_ptr(), out_offsets.data_ptr(),
-                                                         C.byref(total), self._stream()))
-        out = torch.empty(max(total.value, 1), dtype=torch.uint8, device=values.device)
-        self._check(self._lib.pa_varwidth_gather_bytes(values.data_ptr(), offsets.data_ptr(), positions.data_ptr(), n, out_offsets.data_ptr(),
-                                                       out.data_ptr(), self._stream()))
-        return out[:total.value], out_offsets, lengths
+    def allReduce(self, values, op=abi.COMM_SUM, stream=None):
+        arr = (C.c_int64 * len(values))(*[int(v) for v in values])
+        check(lib().pa_comm_all_reduce_i64(self._h, arr, len(values), op, stream))
+        return [int(v) for v in arr]
 
-    def offsets_from_lengths(self, lengths):
-        n = lengths.numel()
-        out = torch.empty(n + 1, dtype=torch.int32, device=lengths.device)
-        total = C.c_int64()
-        self._check(self._lib.pa_offsets_from_lengths(lengths.data_ptr() if n else None, n, out.data_ptr(), C.byref(total), self._stream()))
-        return out, total.value
-
-    def gather(self, column, positions):
-        out = torch.empty(positions.numel(), dtype=column.dtype, device=column.device)
-        self._check(self._lib.pa_gather_flat(column.data_ptr(), column.element_size(), positions.data_ptr(), positions.numel(),
-                                             out.data_ptr(), self._stream()))
-        return out
+    def destroy(self):
+        if self._h:
+            lib().pa_comm_destroy(self._h)
+            self._h = None
 
 
-def rows_of(column):
-    """rows of a column: a 1-D tensor, or (bytes, offsets[n + 1]) for VARCHAR"""
-    return int(column[1].shape[0]) - 1 if isinstance(column, (tuple, list)) else int(column.shape[0])
+class Exchange:
+    """pa_exchange: one hash-partitioned exchange on this rank (what sits between a PartitionedOutputOperator and the
+    ExchangeOperator of the consuming pipeline)."""
+
+    def __init__(self, comm, types, partition_channels, hash_channel=-1, partition_rule=-1, sink_count=1):
+        d = abi.pa_exchange_desc()
+        t = abi.int32_array(types)
+        pc = abi.int32_array(partition_channels)
+        d.channel_count = len(types)
+        d.types = C.cast(t, C.POINTER(C.c_int32))
+        d.partition_channel_count = len(partition_channels)
+        d.partition_channels = C.cast(pc, C.POINTER(C.c_int32))
+        d.hash_channel = hash_channel
+        d.partition_rule = partition_rule
+        d.sink_count = sink_count
+        h = C.c_void_p()
+        check(lib().pa_exchange_create(C.byref(d), comm._h, C.byref(h)))
+        self._h, self.comm, self.types = h, comm, list(types)
+
+    def stats(self):
+        """(rows sent, rows received, payload bytes sent to other ranks, device ms of the all-to-all)"""
+        a, b, c, ms = C.c_int64(), C.c_int64(), C.c_int64(), C.c_double()
+        check(lib().pa_exchange_stats(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(ms)))
+        return a.value, b.value, c.value, ms.value
+
+    def destroy(self):
+        if self._h:
+            lib().pa_exchange_destroy(self._h)
+            self._h = None
 
 
-def partition_rows(ops, columns, types, hash_channels, partition_count, local=True, raw_hash=None):
-    """Returns (positions grouped by partition, rows per partition)."""
-    if raw_hash is None:
-        raw_hash = ops.hash_rows(columns, types, hash_channels)
-    part = ops.partition_ids(raw_hash, partition_count, local)
-    return ops.partition_positions(part, partition_count)
+def PartitionedOutputOperator(exchange, stream=None):
+    """The sink of the producing pipeline (PartitionedOutputOperator.java:411-431)."""
+    from .operators import Operator
+    h = C.c_void_p()
+    check(lib().pa_partitioned_output_create(exchange._h, stream, C.byref(h)))
+    return Operator(h, [exchange])
 
 
-def exchange_columns(ops, columns, types, hash_channels, group=None, local=None, raw_hash=None):
-    """All-to-all of the rows of `columns` by the hash of `hash_channels`.  A column is a 1-D tensor, or for VARCHAR the pair
-    (bytes uint8, offsets int32[n + 1]): its rows travel as per-row lengths (split by rows) plus the bytes (split by the byte
-    totals of the destinations), and the receiver rebuilds the offsets with a scan.
+def ExchangeSourceOperator(exchange, output_mem=abi.MEM_DEVICE, stream=None):
+    """The source of the consuming pipeline (ExchangeOperator.java)."""
+    from .operators import Operator
+    h = C.c_void_p()
+    check(lib().pa_exchange_source_create(exchange._h, output_mem, stream, C.byref(h)))
+    return Operator(h, [exchange])
 
-    Returns (received columns, rows received from every source rank)."""
-    world = dist.get_world_size(group)
-    if local is None:
-        local = (world & (world - 1)) == 0  # LocalPartitionGenerator needs a power of two
-    device = (columns[0][0] if isinstance(columns[0], (tuple, list)) else columns[0]).device
-    rows = rows_of(columns[0])
-    regrouped = {}
-    if rows > 0:
-        fast = None
-        if hasattr(ops, "partition_columns"):
-            # device path: all flat columns regrouped by destination in one stable multisplit pass (same row order as the
-            # position list gives); a position list is only made for VARCHAR columns
-            if raw_hash is None:
-                raw_hash = ops.hash_rows(columns, types, hash_channels)
-            part = ops.partition_ids(raw_hash, world, local)
-            flat = [i for i, t in enumerate(types) if t != abi.VARCHAR]
-            fast = ops.partition_columns(part, world, [columns[i] for i in flat], any(t == abi.VARCHAR for t in types))
-        if fast is not None:
-            outs, positions, send_counts = fast
-            regrouped = dict(zip(flat, outs))
-        else:
-            positions, send_counts = partition_rows(ops, columns, types, hash_channels, world, local, raw_hash)
-    else:  # a rank with nothing to send still takes part in the collectives
-        positions, send_counts = None, [0] * world
-    # 8 x 8 count matrix: every rank learns how much it receives from each source
-    sc = torch.tensor(send_counts, dtype=torch.int64, device=device)
-    rc = torch.empty(world, dtype=torch.int64, device=device)
-    dist.all_to_all_single(rc, sc, group=group)
-    recv_counts = [int(x) for x in rc.tolist()]
-    received = []
-    for ci, (col, t) in enumerate(zip(columns, types)):
-        if t == abi.VARCHAR:
-            values, offsets = col
-            if rows > 0:
-                send_bytes, send_offsets, send_lengths = ops.gather_varwidth(values, offsets, positions)
-                bounds = torch.tensor([0] + list(torch.tensor(send_counts).cumsum(0).tolist()), dtype=torch.int64, device=device)
-                ends = send_offsets.index_select(0, bounds).tolist()  # byte offset at every destination boundary
-                send_byte_counts = [int(ends[i + 1] - ends[i]) for i in range(world)]
-            else:
-                send_bytes = torch.empty(0, dtype=torch.uint8, device=device)
-                send_lengths = torch.empty(0, dtype=torch.int32, device=device)
-                send_byte_counts = [0] * world
-            sb = torch.tensor(send_byte_counts, dtype=torch.int64, device=device)
-            rb = torch.empty(world, dtype=torch.int64, device=device)
-            dist.all_to_all_single(rb, sb, group=group)
-            recv_byte_counts = [int(x) for x in rb.tolist()]
-            recv_lengths = torch.empty(sum(recv_counts), dtype=torch.int32, device=device)
-            dist.all_to_all_single(recv_lengths, send_lengths, output_split_sizes=recv_counts, input_split_sizes=send_counts, group=group)
-            recv_bytes = torch.empty(sum(recv_byte_counts), dtype=torch.uint8, device=device)
-            dist.all_to_all_single(recv_bytes, send_bytes.contiguous(), output_split_sizes=recv_byte_counts, input_split_sizes=send_byte_counts, group=group)
-            recv_offsets, total = ops.offsets_from_lengths(recv_lengths)
-            assert total == sum(recv_byte_counts)
-            received.append((recv_bytes, recv_offsets))
-            continue
-        send = (regrouped[ci] if ci in regrouped else ops.gather(col, positions)) if rows > 0 else col
-        recv = torch.empty(sum(recv_counts), dtype=col.dtype, device=device)
-        dist.all_to_all_single(recv, send, output_split_sizes=recv_counts, input_split_sizes=send_counts, group=group)
-        received.append(recv)
-    return received, recv_counts
+
+class ExchangeOperator:
+    """One exchange step inside a Driver pipeline: pages added go to the PartitionedOutput sink; finish() finishes the
+    sink, after which getOutput pulls the exchange source -- the collective: every rank's Driver gets here once per
+    exchange, in program order -- and returns the rows this rank received as one device page."""
+
+    def __init__(self, comm, types, partition_channels, stream=None, output_mem=abi.MEM_DEVICE, hash_channel=-1):
+        self.exchange = Exchange(comm, types, partition_channels, hash_channel=hash_channel)
+        self.sink = PartitionedOutputOperator(self.exchange, stream)
+        self.source = ExchangeSourceOperator(self.exchange, output_mem, stream)
+        self._finishing = False
+
+    def needsInput(self):
+        return not self._finishing
+
+    def addInput(self, page):
+        self.sink.addInput(page)
+
+    def finish(self):
+        if not self._finishing:
+            self._finishing = True
+            self.sink.finish()
+
+    def getOutput(self):
+        return self.source.getOutput() if self._finishing else None
+
+    def isFinished(self):
+        return self._finishing and self.source.isFinished()
+
+    def isBlocked(self):
+        return False
+
+    def stats(self):
+        return self.exchange.stats()
+
+    def close(self):
+        self.sink.close()
+        self.source.close()
+        self.exchange.destroy()
 
 
 # ---- partial -> final aggregation across ranks --------------------------------------------------------------------
@@ -229,6 +236,7 @@ def merge_partial_aggregations(partial_page, make_final_operator, group=None, ds
     Step.FINAL on one; the reference ships the partial pages through its exchange).  `partial_page` is this rank's
     host Page of intermediate states (or None when the rank produced no group); the pages are tiny (Q1: 4 rows), so
     they travel as objects.  Returns the final host Page on rank `dst`, None elsewhere."""
+    import torch.distributed as dist
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     payload = None

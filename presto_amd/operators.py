@@ -28,8 +28,17 @@ class Operator:
 
     def addInput(self, page):
         cpage, keep = page.to_c()
-        check(lib().pa_op_add_input(self._h, C.byref(cpage)))
+        L = lib()
+        # Driver.java:355-457 only hands a page over when needsInput(); while the operator reports isBlocked (device work in
+        # flight, its queue full) the Driver would yield and poll -- so does this
+        while not L.pa_op_needs_input(self._h) and L.pa_op_is_blocked(self._h) > 0:
+            pass
+        check(L.pa_op_add_input(self._h, C.byref(cpage)))
         self._last_input = keep  # Pages may be retained by the operator until its work is done
+        if page.stable:  # PA_PAGE_STABLE: the operator may still read the page until it is closed
+            if not hasattr(self, "_stable_inputs"):
+                self._stable_inputs = []
+            self._stable_inputs.append(page)
 
     def getOutput(self):
         """Returns a host Page (copy) for PA_MEM_HOST operators, a device Page view otherwise, or None."""
@@ -377,6 +386,15 @@ class LookupSourceFactory:
     def fillKeyBitmap(self, min_key, key_range, bits_ptr, stream=None):
         """Sets bit (key - min_key) of the device bitmap at bits_ptr ((key_range >> 6) + 1 words, cleared first) for every build key."""
         check(lib().pa_lookup_source_key_bitmap(self._h, min_key, key_range, bits_ptr, stream))
+
+    def sharedKeyBitmap(self, comm, partitioned_by_key=True, stream=None):
+        """Collective over the ranks of `comm`: the existence bitmap of every rank's build keys over their union key range ->
+        (device pointer, min key, range), or None when no filter is possible (pa_lookup_source_shared_key_bitmap)."""
+        bits, lo, rng = C.c_void_p(), C.c_int64(), C.c_uint64()
+        if not check(lib().pa_lookup_source_shared_key_bitmap(self._h, comm._h, 1 if partitioned_by_key else 0, stream, C.byref(bits),
+                                                              C.byref(lo), C.byref(rng))):
+            return None
+        return bits.value, lo.value, rng.value
 
     def positionCount(self):
         """Build positions of the published lookup source (LookupSource.getJoinPositionCount)."""

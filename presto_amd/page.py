@@ -158,7 +158,10 @@ class Block:
 
 
 class Page:
-    def __init__(self, blocks, position_count=None, mem=abi.MEM_HOST):
+    def __init__(self, blocks, position_count=None, mem=abi.MEM_HOST, stable=False):
+        """stable: the buffers outlive the operator the page is given to (PA_PAGE_STABLE) -- true of a Java Page, which is
+        immutable and kept alive by its references; here of pages over buffers the caller keeps for the whole query."""
+        self.stable = stable
         self.blocks = list(blocks)
         if position_count is None:
             position_count = self.blocks[0].position_count if self.blocks else 0
@@ -172,7 +175,10 @@ class Page:
         return len(self.blocks)
 
     def to_c(self):
-        """Returns (pa_page, keepalive list)."""
+        """Returns (pa_page, keepalive list).  A Page is immutable (Page.java:33), so the C view is built once."""
+        cached = getattr(self, "_c", None)
+        if cached is not None:
+            return cached
         keep = []
         cols = (abi.pa_column * max(len(self.blocks), 1))()
         for i, b in enumerate(self.blocks):
@@ -182,8 +188,10 @@ class Page:
         page.channel_count = len(self.blocks)
         page.columns = C.cast(cols, C.POINTER(abi.pa_column))
         page.mem = self.mem
+        page.flags = abi.PAGE_STABLE if self.stable else 0
         keep.append(cols)
-        return page, keep
+        self._c = (page, keep)
+        return self._c
 
     def to_rows(self):
         cols = [b.to_pylist() for b in self.blocks]

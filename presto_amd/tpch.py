@@ -113,7 +113,7 @@ class DeviceColumns:
                 w = abi.TYPE_WIDTH[t]
                 blocks.append(Block(t, abi.FLAT, row_count,
                                     values=DeviceBuffer(_ptr_of(values) + w * first_row, w * row_count, values)))
-        return Page(blocks, row_count, abi.MEM_DEVICE)
+        return Page(blocks, row_count, abi.MEM_DEVICE, stable=True)  # the table outlives the operators that read it
 
     def pages(self, page_rows):
         page_rows = max(4, page_rows - page_rows % 4)  # keeps every page 16-byte aligned

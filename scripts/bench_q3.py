@@ -35,7 +35,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
-    if world > 1 or args.force_exchange:
+    if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29541")
         kw = {"device_id": torch.device("cuda", local)} if args.backend == "nccl" else {}
@@ -49,10 +49,14 @@ def main():
     lineitem = tpch.DeviceColumns(tpch.Q3_LINEITEM_COLUMNS, total_sf, nl, first_row=rank * nl)
     stream = _lib.DeviceStream()
     distributed = world > 1 or args.force_exchange
+    comm = None
+    if distributed:
+        from presto_amd.exchange import Comm
+        comm = Comm.single() if world == 1 else (Comm.rccl() if args.backend == "nccl" else Comm.host())
 
     def step():
         out, counters = q3.run(customer.pages(args.page_rows - args.page_rows % 20), orders.pages(args.page_rows),
-                               lineitem.pages(args.page_rows), stream.handle, distributed=distributed,
+                               lineitem.pages(args.page_rows), stream.handle, comm=comm, distributed=distributed,
                                result_mem=abi.MEM_HOST if args.top_n else abi.MEM_DEVICE, top_n=args.top_n,
                                with_count=args.with_count)
         groups = sum(p.position_count for p in out)

@@ -1,9 +1,12 @@
-"""world_size-2 gloo test of the exchange logic (presto_amd/exchange.py) on CPU ranks.
+"""world_size > 1 gloo tests of the sharded paths on CPU ranks.
 
-The per-row kernels are supplied by the oracle here (checker implementation of the `ops` interface); what is under
-test is the sharded path itself: partition -> count exchange -> all-to-all per column -> per-rank build/probe,
-which must reproduce the single-process join as a multiset and keep every key on exactly one rank
-(PartitionedLookupSource semantics, …/operator/join/PartitionedLookupSource.java:143-152)."""
+No GPU here, so the per-row work is the oracle's and the exchange is the stand-in of tests/gloo_standin.py (same contract as
+the native exchange: routing by the reference's partition rules, (source rank, source position) order, one collective per
+exchange whatever the page counts).  Under test: the sharded paths themselves -- partitioned join = single-process join as
+a multiset with every key on exactly one rank (PartitionedLookupSource semantics,
+…/operator/join/PartitionedLookupSource.java:143-152), PARTIAL -> FINAL aggregation across ranks, and bench.py's
+multi-rank control flow (world size 8)."""
+import json
 import os
 import socket
 import sys
@@ -15,45 +18,6 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-
-
-class OracleOps:
-    """CPU checker implementation of the exchange `ops` interface."""
-
-    def __init__(self):
-        from oracle import oracle as O
-        self.O = O
-
-    def _page(self, columns, types):
-        from presto_amd import abi
-        from presto_amd.exchange import rows_of
-        from presto_amd.page import Block, Page
-        blocks = [Block.varwidth(c[0].numpy(), c[1].numpy()) if t == abi.VARCHAR else Block.flat(t, c.numpy()) for c, t in zip(columns, types)]
-        return Page(blocks, rows_of(columns[0]))
-
-    def hash_rows(self, columns, types, channels):
-        return torch.from_numpy(self.O.hash_page(self._page(columns, types), channels))
-
-    def partition_ids(self, raw_hash, partition_count, local):
-        return torch.from_numpy(self.O.partition_ids(raw_hash.numpy(), partition_count, local))
-
-    def partition_positions(self, partition, partition_count):
-        pos, counts = self.O.partition_positions(partition.numpy(), partition_count)
-        return torch.from_numpy(pos), [int(c) for c in counts]
-
-    def gather(self, column, positions):
-        return column[positions.long()]
-
-    def gather_varwidth(self, values, offsets, positions):
-        v, o, p = values.numpy(), offsets.numpy().astype(np.int64), positions.numpy().astype(np.int64)
-        lengths = (o[p + 1] - o[p]).astype(np.int32)
-        out_off = np.concatenate([[0], np.cumsum(lengths)]).astype(np.int32)
-        out = np.concatenate([v[o[i]:o[i + 1]] for i in p]) if len(p) else np.zeros(0, np.uint8)
-        return torch.from_numpy(np.ascontiguousarray(out.astype(np.uint8))), torch.from_numpy(out_off), torch.from_numpy(lengths)
-
-    def offsets_from_lengths(self, lengths):
-        out = np.concatenate([[0], np.cumsum(lengths.numpy().astype(np.int64))]).astype(np.int32)
-        return torch.from_numpy(out), int(out[-1])
 
 
 def make_tables(seed):
@@ -74,25 +38,39 @@ def oracle_join_rows(O, build, btypes, probe, ptypes):
     return out.to_rows()
 
 
-def worker(rank, world, port, result_queue):
+def init(rank, world, port):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
+
+
+def shuffle(O, pages, types, channels):
+    """pages through one exchange; returns (received page or None, the operator)"""
+    from tests.gloo_standin import StandinExchangeOperator
+    ex = StandinExchangeOperator(O, types, channels)
+    for p in pages:
+        ex.addInput(p)
+    ex.finish()
+    return ex.getOutput(), ex
+
+
+def worker(rank, world, port, result_queue):
+    init(rank, world, port)
     from oracle import oracle as O
-    from presto_amd.exchange import exchange_columns
-    ops = OracleOps()
+    from presto_amd.page import Block, Page
     build, btypes, probe, ptypes = make_tables(1234)
+
     # every rank starts with a contiguous row range of both tables (the scan shards by row range)
-    def shard(cols):
+    def shard(cols, types):
         n = len(cols[0])
         lo, hi = n * rank // world, n * (rank + 1) // world
-        return [torch.from_numpy(np.ascontiguousarray(c[lo:hi])) for c in cols]
-    b_recv, b_counts = exchange_columns(ops, shard(build), btypes, [0])
-    p_recv, p_counts = exchange_columns(ops, shard(probe), ptypes, [0])
-    rows = oracle_join_rows(O, [c.numpy() for c in b_recv], btypes, [c.numpy() for c in p_recv], ptypes)
-    keys = sorted(set(b_recv[0].tolist()))
-    result_queue.put((rank, rows, keys, b_counts, p_counts))
+        return Page([Block.flat(t, np.ascontiguousarray(c[lo:hi])) for c, t in zip(cols, types)], hi - lo)
+    b_recv, bx = shuffle(O, [shard(build, btypes)], btypes, [0])
+    p_recv, px = shuffle(O, [shard(probe, ptypes)], ptypes, [0])
+    rows = oracle_join_rows(O, [b.values for b in b_recv.blocks], btypes, [b.values for b in p_recv.blocks], ptypes)
+    keys = sorted(set(b_recv.blocks[0].values.tolist()))
+    result_queue.put((rank, rows, keys, bx.rows_received, px.rows_received))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -115,10 +93,7 @@ class OracleFinalOperator:
 
 
 def agg_worker(rank, world, port, result_queue):
-    sys.path.insert(0, ROOT)
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    init(rank, world, port)
     from oracle import oracle as O
     from presto_amd import abi
     from presto_amd.exchange import merge_partial_aggregations, partial_layout
@@ -174,17 +149,21 @@ def free_port():
     return port
 
 
-def test_partitioned_join_over_two_gloo_ranks(oracle):
-    world = 2
+def run_ranks(target, world, timeout=180):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = free_port()
-    procs = [ctx.Process(target=worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=target, args=(r, world, port, q)) for r in range(world)]
     [p.start() for p in procs]
-    results = [q.get(timeout=120) for _ in range(world)]
+    results = [q.get(timeout=timeout) for _ in range(world)]
     [p.join(timeout=60) for p in procs]
     assert all(p.exitcode == 0 for p in procs)
-    results.sort()
+    return sorted(results, key=lambda r: r[0])
+
+
+def test_partitioned_join_over_two_gloo_ranks(oracle):
+    world = 2
+    results = run_ranks(worker, world)
     build, btypes, probe, ptypes = make_tables(1234)
     expected = oracle_join_rows(oracle, build, btypes, probe, ptypes)
     got = [r for _, rows, _, _, _ in results for r in rows]
@@ -197,61 +176,9 @@ def test_partitioned_join_over_two_gloo_ranks(oracle):
     h = oracle.hash_page(Page([Block.bigint(allkeys)], len(allkeys)), [0])
     part = oracle.partition_ids(h, world, local=True)
     assert set(allkeys[part == 0].tolist()) == k0 and set(allkeys[part == 1].tolist()) == k1
-    # counts are consistent: what rank r received from s is what s sent to r
-    assert sum(results[0][3]) + sum(results[1][3]) == len(build[0])
-    assert sum(results[0][4]) + sum(results[1][4]) == len(probe[0])
-
-
-class CollectOperator:
-    """Sink with the Operator protocol: keeps the pages it is given."""
-
-    def __init__(self):
-        self.pages, self._finished = [], False
-
-    def needsInput(self):
-        return not self._finished
-
-    def addInput(self, page):
-        self.pages.append(page)
-
-    def getOutput(self):
-        return None
-
-    def finish(self):
-        self._finished = True
-
-    def isFinished(self):
-        return self._finished
-
-
-def exchange_operator_worker(rank, world, port, result_queue):
-    sys.path.insert(0, ROOT)
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    from presto_amd import abi
-    from presto_amd.operators import Driver
-    from presto_amd.q3 import ExchangeOperator, page_of, tensor_of
-    keys, vals = exchange_operator_table()
-    # uneven page counts: rank 0 feeds three pages, rank 1 one page -- rank 1 must keep answering rank 0's rounds
-    n = len(keys)
-    bounds = [0, n // 4, n // 2, 3 * n // 4] if rank == 0 else [3 * n // 4, n]
-    if rank == 0:
-        ranges = list(zip(bounds[:-1], bounds[1:]))
-    else:
-        ranges = [(bounds[0], bounds[1])]
-    types = [abi.BIGINT, abi.DOUBLE]
-    pages = [page_of([torch.from_numpy(np.ascontiguousarray(keys[lo:hi])), torch.from_numpy(np.ascontiguousarray(vals[lo:hi]))], types)
-             for lo, hi in ranges]
-    ex = ExchangeOperator(types, [0], None, ops=OracleOps(), device=torch.device("cpu"))
-    sink = CollectOperator()
-    Driver(pages, [ex, sink]).run()
-    cpu = torch.device("cpu")
-    got_keys = np.concatenate([tensor_of(p.blocks[0], cpu).numpy() for p in sink.pages]) if sink.pages else np.zeros(0, np.int64)
-    got_vals = np.concatenate([tensor_of(p.blocks[1], cpu).numpy() for p in sink.pages]) if sink.pages else np.zeros(0)
-    result_queue.put((rank, got_keys.tolist(), got_vals.tolist(), ex.rows_sent, ex.rows_received, len(sink.pages)))
-    dist.barrier()
-    dist.destroy_process_group()
+    # every row arrives exactly once
+    assert results[0][3] + results[1][3] == len(build[0])
+    assert results[0][4] + results[1][4] == len(probe[0])
 
 
 def exchange_operator_table():
@@ -259,79 +186,123 @@ def exchange_operator_table():
     return rng.integers(0, 10 ** 6, 4000).astype(np.int64), rng.random(4000)
 
 
-def test_exchange_operator_with_uneven_page_counts(oracle):
-    """ExchangeOperator (the exchange step of the multi-GPU Q3 pipelines): collective rounds stay matched when the
-    ranks feed different numbers of pages; every row arrives exactly once, on the rank its key hashes to."""
-    from presto_amd.page import Block, Page
-    world = 2
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = free_port()
-    procs = [ctx.Process(target=exchange_operator_worker, args=(r, world, port, q)) for r in range(world)]
-    [p.start() for p in procs]
-    results = sorted(q.get(timeout=120) for _ in range(world))
-    [p.join(timeout=60) for p in procs]
-    assert all(p.exitcode == 0 for p in procs)
-    keys, vals = exchange_operator_table()
-    h = oracle.hash_page(Page([Block.bigint(keys)], len(keys)), [0])
-    part = oracle.partition_ids(h, world, local=True)
-    for rank, got_keys, got_vals, sent, received, pages in results:
-        mine = part == rank
-        assert sorted(zip(got_keys, got_vals)) == sorted(zip(keys[mine].tolist(), vals[mine].tolist()))
-        assert received == int(mine.sum())
-        assert pages == 3  # one output page per collective round (rank 0 fed three pages)
-    assert results[0][3] == 3000 and results[1][3] == 1000
-
-
-def varchar_worker(rank, world, port, result_queue):
-    sys.path.insert(0, ROOT)
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+def exchange_operator_worker(rank, world, port, result_queue):
+    init(rank, world, port)
+    from oracle import oracle as O
     from presto_amd import abi
-    from presto_amd.exchange import exchange_columns
-    from presto_amd.page import Block
-    keys, names = varchar_table()
+    from presto_amd.page import Block, Page
+    keys, vals = exchange_operator_table()
+    # uneven page counts: rank 0 feeds three pages, rank 1 one page, rank 2 none at all
     n = len(keys)
-    lo, hi = (0, n // 3) if rank == 0 else (n // 3, n)   # uneven shards
-    b = Block.varchar(names[lo:hi])
-    cols = [torch.from_numpy(np.ascontiguousarray(keys[lo:hi])), (torch.from_numpy(b.values.copy()), torch.from_numpy(b.offsets.copy()))]
-    recv, counts = exchange_columns(OracleOps(), cols, [abi.BIGINT, abi.VARCHAR], [1])   # partitioned BY THE STRING
-    rk = recv[0].numpy().tolist()
-    rb, ro = recv[1][0].numpy().tobytes(), recv[1][1].numpy().tolist()
-    rows = [(rk[i], rb[ro[i]:ro[i + 1]]) for i in range(len(rk))]
-    result_queue.put((rank, rows, counts))
+    ranges = {0: [(0, n // 4), (n // 4, n // 2), (n // 2, 3 * n // 4)], 1: [(3 * n // 4, n)], 2: []}[rank]
+    types = [abi.BIGINT, abi.DOUBLE]
+    pages = [Page([Block.bigint(keys[lo:hi]), Block.double(vals[lo:hi])], hi - lo) for lo, hi in ranges]
+    out, ex = shuffle(O, pages, types, [0])
+    got = [] if out is None else out.to_rows()
+    result_queue.put((rank, got, ex.rows_sent, ex.rows_received))
     dist.barrier()
     dist.destroy_process_group()
+
+
+def test_exchange_with_uneven_page_counts(oracle):
+    """One collective per exchange whatever the page counts (3 / 1 / 0 pages on the three ranks; the remote partition rule,
+    three is no power of two): every row arrives exactly once, on the rank its key hashes to, ordered by (source rank,
+    source position)."""
+    from presto_amd.page import Block, Page
+    world = 3
+    results = run_ranks(exchange_operator_worker, world)
+    keys, vals = exchange_operator_table()
+    h = oracle.hash_page(Page([Block.bigint(keys)], len(keys)), [0])
+    part = oracle.partition_ids(h, world, local=False)
+    for rank, got, sent, received in results:
+        mine = part == rank
+        assert got == list(zip(keys[mine].tolist(), vals[mine].tolist()))   # global row order = (source rank, source position) here
+        assert received == int(mine.sum())
+    assert [r[2] for r in results] == [3000, 1000, 0]
 
 
 def varchar_table():
     rng = np.random.default_rng(21)
     words = [b"", b"a", b"BUILDING", b"AUTOMOBILE", b"0123456789abcdefghijklmnopqrstuvwxyz", b"\xc3\xa9", b"zz"]
     n = 3001
-    return rng.integers(0, 10 ** 6, n).astype(np.int64), [words[i] + str(int(j)).encode() for i, j in zip(rng.integers(0, len(words), n), rng.integers(0, 50, n))]
+    names = [words[i] + str(int(j)).encode() for i, j in zip(rng.integers(0, len(words), n), rng.integers(0, 50, n))]
+    names = [None if k % 17 == 0 else s for k, s in enumerate(names)]   # NULLs travel too
+    return rng.integers(0, 10 ** 6, n).astype(np.int64), names
 
 
-def test_varchar_columns_travel_through_the_exchange(oracle):
-    """VARCHAR columns (and a VARCHAR partitioning key): per-row lengths split by rows, bytes split by the byte totals of
-    the destinations, offsets rebuilt by the receiver; every row arrives once, on the rank its string hashes to."""
+def varchar_worker(rank, world, port, result_queue):
+    init(rank, world, port)
+    from oracle import oracle as O
+    from presto_amd import abi
+    from presto_amd.page import Block, Page
+    keys, names = varchar_table()
+    n = len(keys)
+    lo, hi = (0, n // 3) if rank == 0 else (n // 3, n)   # uneven shards
+    page = Page([Block.bigint(keys[lo:hi]), Block.varchar(names[lo:hi])], hi - lo)
+    out, ex = shuffle(O, [page], [abi.BIGINT, abi.VARCHAR], [1])   # partitioned BY THE STRING
+    result_queue.put((rank, out.to_rows(), ex.rows_received))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_varchar_columns_and_nulls_travel_through_the_exchange(oracle):
     from presto_amd.page import Block, Page
     world = 2
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = free_port()
-    procs = [ctx.Process(target=varchar_worker, args=(r, world, port, q)) for r in range(world)]
-    [p.start() for p in procs]
-    results = sorted(q.get(timeout=120) for _ in range(world))
-    [p.join(timeout=60) for p in procs]
-    assert all(p.exitcode == 0 for p in procs)
+    results = run_ranks(varchar_worker, world)
     keys, names = varchar_table()
     h = oracle.hash_page(Page([Block.varchar(names)], len(names)), [0])
     part = oracle.partition_ids(h, world, local=True)
-    for rank, rows, counts in results:
+    for rank, rows, received in results:
         mine = [(int(k), nm) for k, nm, p in zip(keys, names, part) if p == rank]
-        assert sorted(rows) == sorted(mine) and len(rows) == sum(counts)
-        # source-rank order, then source position: rank 0's rows first, each run in ascending source position
-        split = counts[0]
-        first = [(int(k), nm) for k, nm, p in zip(keys[:len(keys) // 3], names[:len(keys) // 3], part[:len(keys) // 3]) if p == rank]
-        assert rows[:split] == first
+        assert rows == mine and received == len(mine)
+    assert any(nm is None for _, rows, _ in results for _, nm in rows)
+
+
+# ---- bench.py on 8 CPU ranks ------------------------------------------------------------------------------------------------
+def bench_worker(rank, world, port, result_queue):
+    sys.path.insert(0, ROOT)
+    os.environ.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "RANK": str(rank), "LOCAL_RANK": str(rank), "WORLD_SIZE": str(world)})
+    import io
+    import bench
+    from tests.rehearsal_workload import RehearsalWorkload
+    seen = {}
+
+    def factory(args, r, w, device):
+        seen["w"] = RehearsalWorkload(args, r, w, device)
+        return seen["w"]
+
+    out = io.StringIO()
+    bench.main(["--gpus", str(world), "--steps", "2", "--warmup", "1", "--sf", "0.002", "--cpu-rows", "0", "--backend", "gloo"],
+               workload_factory=factory, out=out)
+    result_queue.put((rank, out.getvalue(), seen["w"].results.get("q3")))
+
+
+def test_bench_control_flow_on_eight_gloo_ranks(oracle):
+    """bench.py --gpus 8 --backend gloo with the checker workload: one JSON line from rank 0 only, whole-job value over the
+    max-over-ranks clock, a `q3` object whose exchange steps ran between 8 ranks -- and the union of the ranks' Q3 top-10
+    rows holds the single-process top 10."""
+    from presto_amd import abi, tpch
+    from tests.rehearsal_workload import host_table
+    from tests.test_gpu_q3_pipeline import oracle_q3
+    world, sf = 8, 0.002
+    results = run_ranks(bench_worker, world, timeout=300)
+    lines = [r[1] for r in results]
+    assert all(l == "" for l in lines[1:]) and lines[0].count("\n") == 1
+    line = json.loads(lines[0])
+    rows = tpch.lineitem_rows(sf)
+    assert line["n_gpus"] == world and line["scaling"] == "weak" and line["steps"] == 2 and line["unit"] == "rows/s"
+    assert abs(line["value"] - 2 * rows * 2 * world / (line["ms_per_step"] * 2 / 1e3)) <= 1e-6 * line["value"]
+    assert "error" not in line["q3"] and line["q3"]["value"] > 0 and line["q3"]["input_rows_per_gpu"] == sum(
+        (tpch.customer_rows(sf), tpch.orders_rows(sf), tpch.lineitem_rows(sf)))
+    # Q3 parity of the sharded run: global top 10 = top 10 of the union of the ranks' (disjoint) groups
+    total = sf * world
+    grouped, _, _ = oracle_q3(oracle, host_table(tpch.CUSTOMER_COLUMNS, total, 0, tpch.customer_rows(sf) * world),
+                              host_table(tpch.ORDERS_COLUMNS, total, 0, tpch.orders_rows(sf) * world),
+                              host_table(tpch.Q3_LINEITEM_COLUMNS, total, 0, tpch.lineitem_rows(sf) * world))
+    expected = sorted(grouped, key=lambda r: (-r[3], r[1]))[:10]
+    union = [tuple(r) for _, _, q3 in results for r in (q3 or [])]
+    keys = [r[0] for r in union]
+    assert len(keys) == len(set(keys))   # an orderkey lives on one rank
+    got = sorted(union, key=lambda r: (-r[3], r[1]))[:10]
+    assert len(expected) == 10 and [g[:3] for g in got] == [e[:3] for e in expected]
+    assert all(abs(g[3] - e[3]) <= 1e-9 * abs(e[3]) for g, e in zip(got, expected))

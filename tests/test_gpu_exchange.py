@@ -1,5 +1,5 @@
-"""GPU parity of the exchange kernels (row hash, partition id, stable partition, gather) against the oracle, and the
-full exchange path on one rank over RCCL (a 1-rank all-to-all is a self copy: every row must come back, grouped)."""
+"""GPU parity of the exchange kernels (row hash, partition id, stable partition, multisplit) against the oracle, and the native
+exchange (pa_exchange_*): on one rank over RCCL, and between several ranks sharing the GPU through the host transport."""
 import os
 
 import numpy as np
@@ -40,68 +40,171 @@ def test_hash_page_all_types_bit_exact(gpu, oracle):
 
 @pytest.mark.parametrize("partitions,local", [(2, True), (8, True), (64, True), (8, False), (7, False), (3, False)])
 def test_partition_ids_and_stable_positions(gpu, oracle, partitions, local):
-    from presto_amd.exchange import DeviceOps
+    from presto_amd._lib import check, lib
     rng = np.random.default_rng(4)
     n = 123457
     raw = rng.integers(-2 ** 63, 2 ** 63 - 1, n, dtype=np.int64)
-    ops = DeviceOps()
-    part = ops.partition_ids(torch.from_numpy(raw).cuda(), partitions, local)
+    d_raw = torch.from_numpy(raw).cuda()
+    part = torch.empty(n, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    check(lib().pa_partition_ids(d_raw.data_ptr(), n, partitions, 1 if local else 0, part.data_ptr(), None))
     expected = oracle.partition_ids(raw, partitions, local)
+    check(lib().pa_stream_synchronize(None))
     assert np.array_equal(part.cpu().numpy(), expected)
-    pos, counts = ops.partition_positions(part, partitions)
+    pos = torch.empty(n, dtype=torch.int32, device="cuda")
+    counts = np.zeros(partitions, dtype=np.int64)
+    check(lib().pa_partition_positions(part.data_ptr(), n, partitions, pos.data_ptr(), counts.ctypes.data, None))
     epos, ecounts = oracle.partition_positions(expected, partitions)
-    assert counts == ecounts.tolist()
+    assert counts.tolist() == ecounts.tolist()
     assert np.array_equal(pos.cpu().numpy(), epos)  # ascending positions inside every partition
 
 
-def test_exchange_on_one_rank_over_rccl(gpu, oracle):
-    import torch.distributed as dist
-    from presto_amd.exchange import DeviceOps, exchange_columns
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29531")
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
-    try:
-        rng = np.random.default_rng(6)
-        n = 50001
-        keys = rng.integers(0, 10 ** 9, n).astype(np.int64)
-        vals = rng.random(n)
-        cols = [torch.from_numpy(keys).cuda(), torch.from_numpy(vals).cuda()]
-        recv, counts = exchange_columns(DeviceOps(), cols, [abi.BIGINT, abi.DOUBLE], [0])
-        torch.cuda.synchronize()
-        assert counts == [n]
-        assert np.array_equal(recv[0].cpu().numpy(), keys) and np.array_equal(recv[1].cpu().numpy(), vals)
-    finally:
-        dist.destroy_process_group()
-
-
-def test_varchar_exchange_on_one_rank_over_rccl(gpu, oracle):
-    """VARCHAR column + VARCHAR partitioning key through the device ops and a one-rank RCCL group (self copy): rows come back
-    grouped by partition, strings intact."""
-    import torch.distributed as dist
-    from presto_amd.exchange import DeviceOps, exchange_columns
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29537")
-    torch.zeros(1, device="cuda")
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
-    try:
-        rng = np.random.default_rng(9)
-        n = 40001
-        words = [b"", b"a", b"BUILDING", b"0123456789abcdefghijklmnopqrstuvwxyz", b"zz"]
+# ---- the native exchange (pa_exchange_*): PartitionedOutput sink -> one all-to-all -> exchange source ----
+def exchange_pages(seed, n_pages, rows, nulls_from_page=1):
+    """Pages of (BIGINT key, DOUBLE, VARCHAR, INTEGER): NULLs appear from page `nulls_from_page` on (a channel that turns
+    nullable after rows were already buffered), the VARCHAR holds empty and long strings."""
+    rng = np.random.default_rng(seed)
+    words = [b"", b"a", b"BUILDING", b"0123456789abcdefghijklmnopqrstuvwxyz", b"\xc3\xa9", b"zz"]
+    pages = []
+    for k in range(n_pages):
+        n = rows + 17 * k
+        with_nulls = k >= nulls_from_page
         names = [words[i] + str(int(j)).encode() for i, j in zip(rng.integers(0, len(words), n), rng.integers(0, 1000, n))]
-        b = Block.varchar(names)
-        keys = rng.integers(0, 10 ** 9, n).astype(np.int64)
-        cols = [torch.from_numpy(keys).cuda(), (torch.from_numpy(b.values.copy()).cuda(), torch.from_numpy(b.offsets.copy()).cuda())]
-        recv, counts = exchange_columns(DeviceOps(), cols, [abi.BIGINT, abi.VARCHAR], [1])
-        torch.cuda.synchronize()
-        assert counts == [n]
-        rb, ro = recv[1][0].cpu().numpy().tobytes(), recv[1][1].cpu().numpy().tolist()
-        got = [(int(k), rb[ro[i]:ro[i + 1]]) for i, k in enumerate(recv[0].cpu().numpy().tolist())]
-        assert got == list(zip(keys.tolist(), names))   # one partition: the stable order is the input order
-        # the row hash of the string column equals the oracle's (what routes the rows)
-        h = DeviceOps().hash_rows(cols, [abi.BIGINT, abi.VARCHAR], [1]).cpu().numpy()
-        assert np.array_equal(h, oracle.hash_page(Page([Block.bigint(keys), Block.varchar(names)], n), [1]))
+        if with_nulls:
+            names = [None if rng.random() < 0.1 else s for s in names]
+        pages.append(Page([
+            Block.bigint(rng.integers(0, 10 ** 9, n), (rng.random(n) < 0.05) if with_nulls else None),
+            Block.double(rng.random(n)),
+            Block.varchar(names),
+            Block.integer(rng.integers(-1000, 1000, n), (rng.random(n) < 0.2) if (with_nulls and k % 2 == 1) else None),
+        ], n))
+    return pages
+
+
+EX_TYPES = [abi.BIGINT, abi.DOUBLE, abi.VARCHAR, abi.INTEGER]
+
+
+def run_exchange(comm, pages, channels, device_pages, output_mem=abi.MEM_HOST):
+    from presto_amd.exchange import ExchangeOperator
+    from presto_amd.operators import download_page
+    ex = ExchangeOperator(comm, EX_TYPES, channels, output_mem=output_mem)
+    keep = []
+    for p in pages:
+        if device_pages:
+            p = upload_page(p)
+            keep.append(p)
+        assert ex.needsInput() and ex.getOutput() is None
+        ex.addInput(p)
+    ex.finish()
+    out = ex.getOutput()
+    assert ex.isFinished() and ex.getOutput() is None
+    stats = ex.stats()
+    rows = [] if out is None else (out if output_mem == abi.MEM_HOST else download_page(out)).to_rows()
+    ex.close()
+    return rows, stats
+
+
+def expected_for_rank(oracle, pages_by_rank, channels, world, rank, local):
+    """What `rank` must receive: the rows its partition id names, by (source rank, page, position)."""
+    rows = []
+    for src in range(world):
+        for p in pages_by_rank[src]:
+            part = oracle.partition_ids(oracle.hash_page(p, channels), world, local)
+            rows += [r for r, d in zip(p.to_rows(), part.tolist()) if d == rank]
+    return rows
+
+
+@pytest.mark.parametrize("device_pages,output_mem", [(False, abi.MEM_HOST), (True, abi.MEM_DEVICE)])
+@pytest.mark.parametrize("channels", [[0], [2], [0, 2, 3]])
+def test_native_exchange_on_one_rank_over_rccl(gpu, oracle, channels, device_pages, output_mem):
+    """World of one rank: the count all-gather and the grouped ncclSend / ncclRecv run over RCCL against the rank itself, so
+    every row must come back, in page order (one partition: the stable regrouping is the identity)."""
+    from presto_amd.exchange import Comm
+    comm = Comm.single()
+    try:
+        pages = exchange_pages(11, 4, 20011)
+        rows, (sent, received, remote, ms) = run_exchange(comm, pages, channels, device_pages, output_mem)
+        assert rows == [r for p in pages for r in p.to_rows()]
+        assert sent == received == len(rows) and remote == 0 and ms >= 0
+        assert any(r[0] is None for r in rows) and any(r[2] is None for r in rows) and any(r[3] is None for r in rows)
+        # nothing to send at all: no output page, finished all the same
+        rows, stats = run_exchange(comm, [], channels, device_pages, output_mem)
+        assert rows == [] and stats[0] == 0
     finally:
+        comm.destroy()
+
+
+def test_comm_all_reduce_on_one_rank(gpu):
+    from presto_amd.exchange import Comm
+    comm = Comm.single()
+    try:
+        assert comm.allReduce([5, -7], abi.COMM_MIN) == [5, -7] and comm.allReduce([3], abi.COMM_SUM) == [3]
+    finally:
+        comm.destroy()
+
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def shared_gpu_worker(rank, world, port, q):
+    """One of `world` processes sharing the one GPU: native exchange with the host transport over gloo."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from presto_amd import _lib
+    from presto_amd.exchange import Comm
+    _lib.init(0)
+    comm = Comm.host()
+    try:
+        pages = exchange_pages(100 + rank, [3, 1, 0][rank % 3], 5003, nulls_from_page=1 if rank == 0 else 99)
+        out = {}
+        for name, channels in (("key", [0]), ("string", [2])):
+            out[name] = run_exchange(comm, pages, channels, device_pages=(rank % 2 == 0))
+        out["reduce"] = (comm.allReduce([rank + 1, 10 - rank], abi.COMM_MIN), comm.allReduce([rank + 1], abi.COMM_SUM), comm.allReduce([rank], abi.COMM_MAX))
+        q.put((rank, out))
+        dist.barrier()
+    finally:
+        comm.destroy()
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_native_exchange_between_ranks_sharing_the_gpu(gpu, oracle, world):
+    """The multi-rank logic of the native exchange (count matrix, blob layouts, per-source unpacking, NULL flags that only some
+    ranks carry, ranks with 3 / 1 / 0 pages, power-of-two and other world sizes) with `world` processes on the one GPU of the
+    box: RCCL refuses several ranks on one device, so the two collectives go through the library's host transport over gloo.
+    Every rank must receive exactly the rows its partition id names, ordered by (source rank, source position)."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=shared_gpu_worker, args=(r, world, port, q)) for r in range(world)]
+    [p.start() for p in procs]
+    results = dict(q.get(timeout=300) for _ in range(world))
+    [p.join(timeout=120) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    pages_by_rank = [exchange_pages(100 + r, [3, 1, 0][r % 3], 5003, nulls_from_page=1 if r == 0 else 99) for r in range(world)]
+    local = (world & (world - 1)) == 0
+    total = sum(p.position_count for ps in pages_by_rank for p in ps)
+    for name, channels in (("key", [0]), ("string", [2])):
+        got_total = 0
+        for r in range(world):
+            rows, (sent, received, remote, ms) = results[r][name]
+            assert rows == expected_for_rank(oracle, pages_by_rank, channels, world, r, local), (name, r)
+            assert received == len(rows) and sent == sum(p.position_count for p in pages_by_rank[r])
+            got_total += len(rows)
+        assert got_total == total
+    for r in range(world):
+        assert results[r]["reduce"] == ([1, 10 - (world - 1)], [world * (world + 1) // 2], [world - 1])
 
 
 @pytest.mark.parametrize("n,parts", [(1, 1), (1000, 3), (8192, 256), (8193, 257), (300001, 513), (2_000_003, 1024), (1 << 22, 64)])

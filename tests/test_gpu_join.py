@@ -331,3 +331,30 @@ def test_dynamic_filter_combined_over_partitions(gpu, oracle):
     got = [r for p in to_pages(fp, [probe]) for r in p.to_rows()]
     want = set(int(k) for k in keys)
     assert got == [r for r in probe.to_rows() if r[0] in want] and len(got) > 5000
+
+
+@pytest.mark.parametrize("join_type", [abi.JOIN_INNER, abi.JOIN_PROBE_OUTER])
+def test_probe_page_with_more_matches_than_one_output_page_holds(gpu, oracle, monkeypatch, join_type):
+    """LookupJoinPageBuilder bounds its output pages (LookupJoinPageBuilder.java:51-56); the device operator joins a whole probe
+    page at once, so a probe page whose matches exceed the bound of an output page (2^30 rows; the match total is kept in 64
+    bits) comes out as several pages, each the join of a row range of the probe page.  With the bound lowered to 700 rows: same
+    rows, same order as the oracle, more than one page, VARCHAR and NULL-extended columns included."""
+    monkeypatch.setenv("PRESTO_AMD_JOIN_MAX_OUTPUT_ROWS", "700")
+    rng = np.random.default_rng(17)
+    nb, npr = 4000, 3001
+    bkeys = rng.integers(0, 300, nb)     # ~13 build rows per key
+    build = Page([Block.bigint(bkeys), Block.varchar([b"b%d" % i for i in range(nb)])], nb)
+    pkeys = rng.integers(-50, 350, npr)
+    pkeys[100:1500] = 1000               # a long stretch without any match
+    probe = Page([Block.bigint(pkeys, rng.random(npr) < 0.03), Block.varchar([b"p%d" % i if i % 7 else None for i in range(npr)])], npr)
+    btypes = ptypes = [abi.BIGINT, abi.VARCHAR]
+    bridge = LookupSourceFactory()
+    to_pages(HashBuilderOperator(bridge, btypes, [0], [1, 0]), [build])
+    join = LookupJoinOperator(bridge, ptypes, [0], [1, 0], join_type=join_type)
+    pages = to_pages(join, [probe])
+    j = oracle.HashJoin(btypes, [0], [1, 0])
+    j.add_build_page(build)
+    j.build()
+    expected, _, _ = j.probe(probe, ptypes, [0], [1, 0], join_type=join_type)
+    assert len(pages) > 5 and all(0 < p.position_count <= 700 for p in pages)
+    assert [r for p in pages for r in p.to_rows()] == expected.to_rows()

@@ -71,31 +71,93 @@ def test_q3_pipeline_matches_oracle(gpu, oracle, sf, page_rows):
 
 
 def test_q3_with_exchange_steps_on_one_rank_over_rccl(gpu, oracle):
-    """The multi-GPU form of the pipelines (an ExchangeOperator before every build and probe) with a one-rank RCCL
-    group: every all-to-all is a self copy, so the result must equal the oracle's, and every row must come back."""
-    import os
-    import torch
-    import torch.distributed as dist
+    """The multi-GPU form of the pipelines (an exchange before every build and probe, shared dynamic-filter bitmaps) with a
+    one-rank RCCL communicator: every all-to-all is a self copy, so the result must equal the oracle's, and every row must
+    come back."""
     from presto_amd import q3
+    from presto_amd.exchange import Comm
     sf, page_rows = 0.05, 1 << 16
     expected, exp_orders, exp_joined = _expected(oracle, sf)
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29533")
-    torch.zeros(1, device="cuda")  # initialise torch's view of the device before the process group asks for it
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    comm = Comm.single()
     try:
         stream = DeviceStream()
         customer, orders, lineitem = _device_tables(sf)
         out, counters = q3.run(customer.pages(page_rows - page_rows % 20), orders.pages(page_rows), lineitem.pages(page_rows),
-                               stream.handle, distributed=True)
-        torch.cuda.synchronize()
+                               stream.handle, comm=comm, distributed=True)
         rows = [r for p in out for r in p.to_rows()]
         rows_equal_ignore_order(rows, expected, rel=1e-9)
         assert counters["build2_rows"] == exp_orders
         assert sum(r[4] for r in rows) == exp_joined
+        assert counters["orders_dynamic_filter"] is True and counters["lineitem_dynamic_filter"] is True
+        assert counters["exchange_rows_sent"] == counters["exchange_rows_received"] > 0 and counters["exchange_bytes_remote"] == 0
         stream.destroy()
     finally:
+        comm.destroy()
+
+
+def q3_shared_gpu_worker(rank, world, port, sf, page_rows, q):
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from presto_amd import _lib, q3
+    from presto_amd.exchange import Comm
+    _lib.init(0)
+    comm = Comm.host()
+    try:
+        nc, no, nl = tpch.customer_rows(sf), tpch.orders_rows(sf), tpch.lineitem_rows(sf)
+        total = sf * world
+        # rank r holds rows [r n, (r + 1) n) of the SF x world tables, as bench.py lays them out
+        customer = tpch.DeviceColumns(tpch.CUSTOMER_COLUMNS, total, nc, first_row=rank * nc)
+        orders = tpch.DeviceColumns(tpch.ORDERS_COLUMNS, total, no, first_row=rank * no)
+        lineitem = tpch.DeviceColumns(tpch.Q3_LINEITEM_COLUMNS, total, nl, first_row=rank * nl)
+        stream = DeviceStream()
+        pr = page_rows * (rank + 1)   # different page counts per rank
+        out, counters = q3.run(customer.pages(pr - pr % 20), orders.pages(pr), lineitem.pages(pr), stream.handle, comm=comm)
+        q.put((rank, [r for p in out for r in p.to_rows()], counters))
+        dist.barrier()
+        stream.destroy()
+    finally:
+        comm.destroy()
         dist.destroy_process_group()
+
+
+def test_q3_between_ranks_sharing_the_gpu(gpu, oracle):
+    """BASELINE config #4's shape with 2 ranks: each holds a row range of the three tables, every join side is hash-partitioned
+    and exchanged natively (host transport over gloo: the ranks share the box's one GPU), the dynamic filters are the union
+    of both ranks' build keys.  The union of the ranks' grouped results must be the single-process oracle result, every group
+    on exactly one rank."""
+    import socket
+    import torch.multiprocessing as mp
+    world, sf, page_rows = 2, 0.03, 1 << 15
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=q3_shared_gpu_worker, args=(r, world, port, sf, page_rows, q)) for r in range(world)]
+    [p.start() for p in procs]
+    results = dict((r[0], r[1:]) for r in (q.get(timeout=300) for _ in range(world)))
+    [p.join(timeout=120) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    nc, no, nl = tpch.customer_rows(sf) * world, tpch.orders_rows(sf) * world, tpch.lineitem_rows(sf) * world
+    total = sf * world
+    expected, exp_orders, exp_joined = oracle_q3(oracle, host_table(oracle, tpch.CUSTOMER_COLUMNS, total, nc),
+                                                 host_table(oracle, tpch.ORDERS_COLUMNS, total, no),
+                                                 host_table(oracle, tpch.Q3_LINEITEM_COLUMNS, total, nl))
+    rows = results[0][0] + results[1][0]
+    assert len(results[0][0]) > 0 and len(results[1][0]) > 0
+    rows_equal_ignore_order(rows, expected, rel=1e-9)
+    assert not ({r[0] for r in results[0][0]} & {r[0] for r in results[1][0]})   # an orderkey (group) lives on one rank
+    assert results[0][1]["build2_rows"] + results[1][1]["build2_rows"] == exp_orders
+    for r in range(world):
+        c = results[r][1]
+        assert c["orders_dynamic_filter"] is True and c["lineitem_dynamic_filter"] is True and c["exchange_bytes_remote"] > 0
+    assert sum(results[r][1]["exchange_rows_sent"] for r in range(world)) == sum(results[r][1]["exchange_rows_received"] for r in range(world))
 
 
 def test_q3_with_topn(gpu, oracle):

@@ -1,0 +1,154 @@
+"""Small pages through the fused aggregation operator (what an unmodified Driver delivers: <= 1 MB / 8192 rows,
+PageProcessor.java:56-58): consecutive PA_PAGE_STABLE device pages that continue each other in memory are processed as one
+range without a copy, other small pages are gathered in the operator's arenas, and the launches of the few-groups tier are
+confirmed late (needsInput / isBlocked instead of a wait inside addInput).  None of it may change a result: every case is
+compared with the oracle and with the same rows handed over as one page."""
+import numpy as np
+import pytest
+
+from presto_amd import abi, tpch
+from presto_amd.operators import FusedAggregationOperator, HashAggregationOperator, to_pages, upload_page
+from presto_amd.page import Block, DeviceBuffer, Page
+
+pytestmark = pytest.mark.gpu
+
+
+def stable_regions(dev_page, bounds):
+    """Page.getRegion views of a device page, flagged PA_PAGE_STABLE (the test keeps dev_page alive past the operator)."""
+    out = []
+    for lo, hi in zip(bounds[:-1], bounds[1:]):
+        n = hi - lo
+        blocks = []
+        for b in dev_page.blocks:
+            nulls = DeviceBuffer(b.nulls.ptr + lo, n, b.nulls) if b.nulls is not None else None
+            if b.encoding == abi.VARWIDTH:
+                blocks.append(Block(b.type, abi.VARWIDTH, n, values=b.values, offsets=DeviceBuffer(b.offsets.ptr + 4 * lo, 4 * (n + 1), b.offsets), nulls=nulls))
+            else:
+                w = abi.TYPE_WIDTH[b.type]
+                blocks.append(Block(b.type, abi.FLAT, n, values=DeviceBuffer(b.values.ptr + w * lo, w * n, b.values), nulls=nulls))
+        out.append(Page(blocks, n, abi.MEM_DEVICE, stable=True))
+    return out
+
+
+def bounds_of(n, page_rows):
+    return list(range(0, n, page_rows)) + [n]
+
+
+def q6_host(oracle, sf, n):
+    cols = [oracle.tpch_column(c, sf, 0, n)[0] for c in tpch.Q6_COLUMNS]
+    page = Page([Block.flat(t, c) for t, c in zip(tpch.Q6_TYPES, cols)], n)
+    return page, oracle.q6(*cols)
+
+
+def run_q6(pages, extra=()):
+    op = FusedAggregationOperator(tpch.Q6_TYPES, tpch.q6_filter(), tpch.q6_projections(), [],
+                                  tpch.Q6_AGGREGATES + [(abi.AGG_COUNT_STAR, -1, None)])
+    (revenue, count), = to_pages(op, pages)[0].to_rows()
+    op.close()
+    return revenue, count
+
+
+@pytest.mark.parametrize("page_rows", [8192, 4096 + 4, 65536])
+def test_q6_over_small_pages_every_route(gpu, oracle, monkeypatch, page_rows):
+    n, sf = 600_011, 0.1
+    host, (ref_sum, ref_count) = q6_host(oracle, sf, n)
+    dev = upload_page(host)
+    bounds = bounds_of(n, page_rows)
+    routes = {
+        "stable ranges, one launch at finish": stable_regions(dev, bounds),
+        "device pages of their own (arena, segment copies)": [upload_page(host.get_region(lo, hi - lo)) for lo, hi in zip(bounds[:-1], bounds[1:])][:40]
+        + stable_regions(dev, [bounds[40], n] if len(bounds) > 41 else [n, n])[:1],
+        "host pages (arena, H2D copies)": [host.get_region(lo, hi - lo) for lo, hi in zip(bounds[:-1], bounds[1:])],
+    }
+    for name, pages in routes.items():
+        pages = [p for p in pages if p.position_count > 0]
+        assert sum(p.position_count for p in pages) == n, name
+        revenue, count = run_q6(pages)
+        assert count == ref_count, name
+        assert abs(revenue - ref_sum) <= 1e-9 * abs(ref_sum), name
+    # a launch threshold below the page size: every stable page is launched on its own (range of one page)
+    monkeypatch.setenv("PRESTO_AMD_GATHER_ROWS", "1000")
+    revenue, count = run_q6(stable_regions(dev, bounds))
+    assert count == ref_count and abs(revenue - ref_sum) <= 1e-9 * abs(ref_sum)
+    # ranges broken by a gap: pages 0, 2, 4 ... then 1, 3, 5 ...
+    monkeypatch.setenv("PRESTO_AMD_GATHER_ROWS", str(1 << 26))
+    regs = stable_regions(dev, bounds)
+    revenue, count = run_q6(regs[0::2] + regs[1::2])
+    assert count == ref_count and abs(revenue - ref_sum) <= 1e-9 * abs(ref_sum)
+
+
+@pytest.mark.parametrize("page_rows", [8192, 100_000])
+def test_q1_over_small_stable_pages(gpu, oracle, page_rows):
+    """VARCHAR(1) keys + the few-groups tier: stable ranges are merged (the shared byte array + consecutive offsets continue
+    each other), the launches confirmed late."""
+    n, sf = 1_300_003, 0.25
+    cols = [oracle.tpch_column(c, sf, 0, n) for c in tpch.Q1_COLUMNS]
+    args = [cols[0][0], cols[0][1], cols[1][0], cols[1][1]] + [c[0] for c in cols[2:]]
+    expected = sorted(oracle.q1(args))
+    dev = tpch.DeviceColumns(tpch.Q1_COLUMNS, sf, n)
+    for pages in (list(dev.pages(page_rows)), [dev.page(0, n)]):
+        op = FusedAggregationOperator(tpch.Q1_TYPES, tpch.q1_filter(), tpch.q1_projections(), tpch.Q1_GROUP_BY, tpch.Q1_AGGREGATES,
+                                      type_params=tpch.Q1_TYPE_PARAMS)
+        rows = sorted(r for p in to_pages(op, pages) for r in p.to_rows())
+        op.close()
+        assert len(rows) == len(expected) == 4
+        for a, e in zip(rows, expected):
+            assert a[:2] == e[:2] and a[-1] == e[-1]
+            assert np.allclose(a[2:-1], e[2:-1], rtol=1e-9, atol=0)
+
+
+def test_more_groups_appear_after_the_first_launches(gpu, oracle, monkeypatch):
+    """The few-groups tier is confirmed one launch late for retained pages: rows that overflow its register table AFTER the
+    first (probe) launch was confirmed must be redone on the next tier exactly once -- no row lost, none counted twice."""
+    monkeypatch.setenv("PRESTO_AMD_GATHER_ROWS", str(1 << 18))
+    rng = np.random.default_rng(3)
+    n = (1 << 21) + 12345
+    keys = rng.integers(0, 4, n).astype(np.int64)
+    keys[(1 << 20) + (1 << 19):] = rng.integers(0, 40, n - (1 << 20) - (1 << 19))   # 40 groups from row 1.5 M on
+    vals = rng.integers(-1000, 1000, n).astype(np.int64)
+    host = Page([Block.bigint(keys), Block.bigint(vals)], n)
+    aggs = [(abi.AGG_SUM, 1, abi.BIGINT), (abi.AGG_COUNT_STAR, -1, None), (abi.AGG_MAX, 1, abi.BIGINT)]
+    ref = oracle.HashAggregation([abi.BIGINT, abi.BIGINT], [0], aggs)
+    ref.add_page(host)
+    expected = sorted(ref.build_result().to_rows())
+    dev = upload_page(host)
+    for page_rows in (8192, 1 << 19, n):
+        op = HashAggregationOperator([abi.BIGINT, abi.BIGINT], [0], aggs, expected_groups=8)
+        blocked = 0
+        pages = stable_regions(dev, bounds_of(n, page_rows))
+        for p in pages:
+            while not op.needsInput():
+                assert op.isBlocked()   # only ever refuses input because launches are unconfirmed
+                blocked += 1
+            op.addInput(p)
+        op.finish()
+        rows = []
+        while not op.isFinished():
+            out = op.getOutput()
+            if out is not None:
+                rows += out.to_rows()
+        op.close()
+        assert sorted(rows) == expected, page_rows
+
+
+def test_nullability_changes_between_small_pages(gpu, oracle):
+    """Arena pages fix the nullability of their channels with the first page: a page that differs starts the next arena (and,
+    where the state layout changes, the next generation)."""
+    rng = np.random.default_rng(8)
+    pages, keys_all = [], []
+    for k in range(30):
+        n = 3000 + k
+        nulls = (rng.random(n) < 0.2) if k % 3 == 1 else None
+        pages.append(Page([Block.bigint(rng.integers(0, 5, n)), Block.double(rng.random(n), nulls)], n))
+    aggs = [(abi.AGG_SUM, 1, abi.DOUBLE), (abi.AGG_COUNT, 1, abi.DOUBLE), (abi.AGG_COUNT_STAR, -1, None)]
+    ref = oracle.HashAggregation([abi.BIGINT, abi.DOUBLE], [0], aggs)
+    for p in pages:
+        ref.add_page(p)
+    expected = sorted(ref.build_result().to_rows())
+    for device in (False, True):
+        op = HashAggregationOperator([abi.BIGINT, abi.DOUBLE], [0], aggs)
+        rows = sorted(r for p in to_pages(op, [upload_page(p) if device else p for p in pages]) for r in p.to_rows())
+        op.close()
+        assert len(rows) == len(expected)
+        for a, e in zip(rows, expected):
+            assert a[0] == e[0] and a[2:] == e[2:] and abs(a[1] - e[1]) <= 1e-12 * abs(e[1])
