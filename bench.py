@@ -42,6 +42,9 @@ def parse_args(argv=None):
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--sf", type=float, default=100.0, help="TPC-H scale factor of the shard per GPU")
     ap.add_argument("--page-rows", type=int, default=1 << 28, help="rows per device-resident page")
+    ap.add_argument("--page-order", default="table", choices=["table", "shuffled"],
+                    help="table: pages arrive in table order (consecutive pages continue each other in memory); shuffled: in a "
+                         "seeded random order, so that no page continues its predecessor (page-size sweeps)")
     ap.add_argument("--cpu-rows", type=int, default=16_000_000, help="rows of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--queries", default="q1,q6", help="headline queries")
     ap.add_argument("--q3", type=int, default=1, help="1 = also time the Q3 pipelines (the `q3` object), 0 = skip")
@@ -187,6 +190,9 @@ class DeviceWorkload:
         sub.rows = table.rows
         sub._bufs = table._bufs
         pages = list(sub.pages(page_rows))
+        if self.args.page_order == "shuffled":
+            import random
+            random.Random(0x5EED).shuffle(pages)
         for p in pages:
             p.to_c()  # the C view of a page is what the JNI shim is handed: built once, outside the timed region
         return pages
@@ -393,6 +399,7 @@ def main(argv=None, workload_factory=None, out=None):
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": workload.workload_name(),
                        "scale_factor_per_gpu": args.sf, "rows_per_gpu": workload.rows, "page_rows": args.page_rows,
+                       "page_order": args.page_order,
                        "queries": queries, "parallelism": "row-range shards, %d rank(s), no data-path collective in Q1/Q6; "
                                                           "Q3 (the `q3` object) shuffles its join sides between the ranks" % world},
         }

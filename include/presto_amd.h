@@ -88,7 +88,11 @@ typedef enum pa_page_flags {
      * returns from pa_op_get_output (valid until the next call on that operator).  An operator may defer its work on a
      * stable page past the return of pa_op_add_input: consecutive small stable pages that continue each other in memory
      * are processed as one range, without a copy. */
-    PA_PAGE_STABLE = 1
+    PA_PAGE_STABLE = 1,
+    /* PA_MEM_HOST pages only: every buffer of the page is pinned host memory (pa_host_malloc_pinned, or registered with the
+     * HIP runtime), so the device can read it directly: small pages are then gathered by one copy kernel instead of one
+     * hipMemcpyAsync per block array -- and, when the page is also PA_PAGE_STABLE, by one launch per few thousand pages. */
+    PA_PAGE_PINNED = 2
 } pa_page_flags;
 typedef struct pa_page {
     int32_t position_count;
@@ -356,8 +360,30 @@ int32_t pa_stream_synchronize(void* stream);
 int32_t pa_stream_create(void** stream);
 int32_t pa_stream_destroy(void* stream);
 
+/* ConnectorPageSource as the library sees it (ScanFilterAndProjectOperator pulls pages instead of being handed them).
+ * next_page: ConnectorPageSource.getNextPage -- fills *page (position count, channel count, pa_mem, columns) and returns 1,
+ * or returns 0 when the source is finished (isFinished), or a negative pa_status.  A column whose `values` and `dictionary`
+ * are both NULL is a LazyBlock that has not been loaded; load_block (LazyBlock.getLoadedBlock) fills it for one channel of
+ * the page returned last, returning >= 0 or a negative pa_status.  The page and every loaded block stay valid until the next
+ * next_page / close.  close: ConnectorPageSource.close, called once. */
+typedef struct pa_page_source {
+    void* ctx;
+    int32_t (*next_page)(void* ctx, pa_page* page);
+    int64_t (*load_block)(void* ctx, int32_t channel, pa_column* column);
+    void (*close)(void* ctx);
+} pa_page_source;
+
 /* ---- operator factories ---- */
 int32_t pa_filter_project_create(const pa_filter_project_desc* desc, pa_operator** out);
+/* ScanFilterAndProjectOperator (ScanFilterAndProjectOperator.java:67-114, 357-400): a source operator (never needs input)
+ * over a page source, PageProcessor and MergePages as in pa_filter_project_create.  Lazy blocks are loaded by need
+ * (PageProcessor.java:307-347): the filter's channels first; the other channels of the projections only for a page in which
+ * the filter selected a position; channels no expression reads never. */
+int32_t pa_scan_filter_project_create(const pa_filter_project_desc* desc, const pa_page_source* source, pa_operator** out);
+/* OperatorContext accounting of a scan operator: positions pulled from the source, bytes of the blocks that were loaded
+ * (Block.getSizeInBytes, ScanFilterAndProjectOperator.recordMaterializedBytes :391), blocks loaded, and blocks of the
+ * projections left unloaded because no position survived the filter. */
+int32_t pa_scan_stats(pa_operator* op, int64_t* processed_positions, int64_t* materialized_bytes, int64_t* blocks_loaded, int64_t* blocks_skipped);
 int32_t pa_aggregation_create(const pa_aggregation_desc* desc, pa_operator** out);
 int32_t pa_hash_aggregation_create(const pa_hash_aggregation_desc* desc, pa_operator** out);
 int32_t pa_fused_aggregation_create(const pa_fused_aggregation_desc* desc, pa_operator** out);

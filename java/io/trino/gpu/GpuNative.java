@@ -1,0 +1,60 @@
+/*
+ * The native methods of jni/presto_amd_jni.c, one per entry of include/presto_amd.h.  Not compiled in the authoring image
+ * (no JDK there); the C side is kept in step with the header by tests/test_lib_cpu.py.
+ */
+package io.trino.gpu;
+
+import java.nio.ByteBuffer;
+
+final class GpuNative
+{
+    static {
+        System.loadLibrary("presto_amd_jni"); // links libpresto_amd.so
+        if (abiVersion() != 5) {
+            throw new IllegalStateException("libpresto_amd.so ABI version " + abiVersion() + " != 5");
+        }
+    }
+
+    private GpuNative() {}
+
+    static native int abiVersion();
+    static native void init(int device);
+    static native int deviceCount();
+    static native ByteBuffer hostMallocPinned(long bytes);
+    static native void hostFreePinned(ByteBuffer buffer);
+
+    static native long newExpression(int root, int[] kinds, int[] ops, int[] types, int[] channels, int[] isNull, int[] nargs, int[] firstArg,
+            long[] longs, double[] doubles, byte[][] strings, int[] args);
+    static native void freeExpression(long expression);
+
+    static native long createFilterProject(int[] inputTypes, int[] typeParams, long filter, long[] projections, long minOutputPageBytes,
+            int minOutputPageRows, int outputMem);
+    static native long createHashAggregation(int[] inputTypes, int[] typeParams, int[] groupByChannels, int hashChannel, int step, int[] aggFns,
+            int[] aggInputs, int[] aggMasks, int[] aggInputTypes, int expectedGroups, int outputMem);
+    static native long createLookupSource();
+    static native void destroyLookupSource(long lookupSource);
+    static native long createHashBuilder(long bridge, int[] inputTypes, int[] joinChannels, int hashChannel, int[] outputChannels, int expectedPositions);
+    static native long createLookupJoin(long bridge, int[] probeTypes, int[] probeJoinChannels, int probeHashChannel, int[] probeOutputChannels,
+            int joinType, boolean outputSingleMatch, boolean outer, int outputMem);
+    static native long createTopN(int[] inputTypes, int count, int[] sortChannels, int[] sortOrders, int outputMem);
+    static native boolean setDynamicFilter(long filterProjectOperator, int channel, long lookupSource);
+
+    static native void commUniqueId(byte[] out128);
+    static native long commCreate(byte[] id128, int rank, int world);
+    static native void commDestroy(long comm);
+    static native long exchangeCreate(long comm, int[] types, int[] partitionChannels, int hashChannel, int sinkCount);
+    static native void exchangeDestroy(long exchange);
+    static native long createPartitionedOutput(long exchange);
+    static native long createExchangeSource(long exchange, int outputMem);
+
+    static native boolean needsInput(long operator);
+    static native boolean isBlocked(long operator);
+    static native boolean isFinished(long operator);
+    static native void finish(long operator);
+    static native void close(long operator);
+    static native long memoryBytes(long operator);
+    static native void addInput(long operator, int positions, int channels, int[] types, int[] encodings, long[] valueOffsets, long[] offsetOffsets,
+            long[] nullOffsets, long[] idOffsets, int[] dictionaryChannel, int[] dictionarySize, ByteBuffer pinned, boolean stable);
+    static native long[] getOutput(long operator);
+    static native ByteBuffer wrapAddress(long address, long bytes);
+}

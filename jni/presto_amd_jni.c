@@ -1,0 +1,419 @@
+/* presto_amd_jni.c -- the JNI shim between io.trino.gpu.* (java/io/trino/gpu) and libpresto_amd.so (include/presto_amd.h).
+ *
+ *   gcc -shared -fPIC -I$JAVA_HOME/include -I$JAVA_HOME/include/linux -Iinclude jni/presto_amd_jni.c \
+ *       -Lpresto_amd -lpresto_amd -o libpresto_amd_jni.so
+ *
+ * One native method per C-ABI entry; nothing is computed here.  The image this repository is written in has no JDK, so
+ * the file is not built there: tests/test_lib_cpu.py compiles it with -fsyntax-only against jni/stub/jni.h, which keeps it
+ * in step with include/presto_amd.h (a renamed entry point or a changed descriptor field fails that test).
+ *
+ * Data crosses as the reference's blocks lay it out (SURVEY 8b "Ownership"): the Java side copies long[] / int[] / byte[] /
+ * Slice bytes / boolean[] valueIsNull of every Block into ONE pinned direct ByteBuffer (allocated by hostMallocPinned
+ * below, pooled by PinnedPagePool) and passes per-channel offsets into it; JVM heap arrays are movable and never reach the
+ * device side.  A buffer stays untouched until the operator has read it: pages are flagged PA_PAGE_STABLE only when the
+ * pool keeps the buffer until the operator is closed. */
+#include <jni.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "presto_amd.h"
+
+#define MAX_CHANNELS 64
+
+static void throw_native(JNIEnv* env, int32_t status)
+{
+    /* GpuNativeException(int status, String message) maps pa_status onto io.trino.spi.StandardErrorCode:
+     * NUMERIC_VALUE_OUT_OF_RANGE, DIVISION_BY_ZERO, GENERIC_INSUFFICIENT_RESOURCES, NOT_SUPPORTED, GENERIC_INTERNAL_ERROR */
+    jclass cls = (*env)->FindClass(env, "io/trino/gpu/GpuNativeException");
+    jmethodID ctor = (*env)->GetMethodID(env, cls, "<init>", "(ILjava/lang/String;)V");
+    jstring msg = (*env)->NewStringUTF(env, pa_last_error());
+    (*env)->Throw(env, (jthrowable)(*env)->NewObject(env, cls, ctor, (jint)status, msg));
+}
+static void throw_message(JNIEnv* env, int32_t status, const char* message)
+{
+    jclass cls = (*env)->FindClass(env, "io/trino/gpu/GpuNativeException");
+    jmethodID ctor = (*env)->GetMethodID(env, cls, "<init>", "(ILjava/lang/String;)V");
+    (*env)->Throw(env, (jthrowable)(*env)->NewObject(env, cls, ctor, (jint)status, (*env)->NewStringUTF(env, message)));
+}
+#define CHECK(rc) do { if ((rc) < 0) throw_native(env, (rc)); } while (0)
+
+/* ---- library ---- */
+JNIEXPORT jint JNICALL Java_io_trino_gpu_GpuNative_abiVersion(JNIEnv* env, jclass c) { return pa_abi_version(); }
+JNIEXPORT void JNICALL Java_io_trino_gpu_GpuNative_init(JNIEnv* env, jclass c, jint device) { CHECK(pa_init(device)); }
+JNIEXPORT jint JNICALL Java_io_trino_gpu_GpuNative_deviceCount(JNIEnv* env, jclass c) { return pa_device_count(); }
+JNIEXPORT jobject JNICALL Java_io_trino_gpu_GpuNative_hostMallocPinned(JNIEnv* env, jclass c, jlong bytes)
+{
+    void* p = 0;
+    int32_t rc = pa_host_malloc_pinned(&p, bytes);
+    if (rc < 0) { throw_native(env, rc); return 0; }
+    return (*env)->NewDirectByteBuffer(env, p, bytes);
+}
+JNIEXPORT void JNICALL Java_io_trino_gpu_GpuNative_hostFreePinned(JNIEnv* env, jclass c, jobject buffer)
+{
+    CHECK(pa_host_free_pinned((*env)->GetDirectBufferAddress(env, buffer)));
+}
+
+/* ---- RowExpression trees: RowExpressionSerializer walks the tree children-first and hands over the flat arrays ---- */
+typedef struct native_expr {
+    pa_expr expr;
+    pa_expr_node* nodes;
+    int32_t* args;
+    char** strings;
+    int32_t count;
+} native_expr;
+
+JNIEXPORT jlong JNICALL Java_io_trino_gpu_GpuNative_newExpression(JNIEnv* env, jclass c, jint root, jintArray kinds, jintArray ops, jintArray types,
+        jintArray channels, jintArray isNull, jintArray nargs, jintArray firstArg, jlongArray longs, jdoubleArray doubles, jobjectArray strings, jintArray args)
+{
+    const jsize n = (*env)->GetArrayLength(env, kinds), na = (*env)->GetArrayLength(env, args);
+    native_expr* e = (native_expr*)calloc(1, sizeof(native_expr));
+    e->nodes = (pa_expr_node*)calloc((size_t)(n > 0 ? n : 1), sizeof(pa_expr_node));
+    e->args = (int32_t*)calloc((size_t)(na > 0 ? na : 1), sizeof(int32_t));
+    e->strings = (char**)calloc((size_t)(n > 0 ? n : 1), sizeof(char*));
+    e->count = n;
+    jint* k = (*env)->GetIntArrayElements(env, kinds, 0);
+    jint* o = (*env)->GetIntArrayElements(env, ops, 0);
+    jint* t = (*env)->GetIntArrayElements(env, types, 0);
+    jint* ch = (*env)->GetIntArrayElements(env, channels, 0);
+    jint* nl = (*env)->GetIntArrayElements(env, isNull, 0);
+    jint* na_ = (*env)->GetIntArrayElements(env, nargs, 0);
+    jint* fa = (*env)->GetIntArrayElements(env, firstArg, 0);
+    jlong* lv = (*env)->GetLongArrayElements(env, longs, 0);
+    jdouble* dv = (*env)->GetDoubleArrayElements(env, doubles, 0);
+    jint* av = (*env)->GetIntArrayElements(env, args, 0);
+    for (jsize i = 0; i < n; i++) {
+        pa_expr_node* nd = &e->nodes[i];
+        nd->kind = k[i]; nd->op = o[i]; nd->type = t[i]; nd->channel = ch[i]; nd->is_null = nl[i];
+        nd->nargs = na_[i]; nd->first_arg = fa[i]; nd->i64 = lv[i]; nd->f64 = dv[i];
+        jbyteArray s = (jbyteArray)(*env)->GetObjectArrayElement(env, strings, i);   /* VARCHAR constants: UTF-8 bytes, else null */
+        if (s) {
+            const jsize len = (*env)->GetArrayLength(env, s);
+            jbyte* b = (*env)->GetByteArrayElements(env, s, 0);
+            e->strings[i] = (char*)malloc((size_t)(len > 0 ? len : 1));
+            memcpy(e->strings[i], b, (size_t)len);
+            (*env)->ReleaseByteArrayElements(env, s, b, JNI_ABORT);
+            nd->str = e->strings[i];
+            nd->str_len = len;
+        }
+    }
+    for (jsize i = 0; i < na; i++) e->args[i] = av[i];
+    (*env)->ReleaseIntArrayElements(env, kinds, k, JNI_ABORT);
+    (*env)->ReleaseIntArrayElements(env, ops, o, JNI_ABORT);
+    (*env)->ReleaseIntArrayElements(env, types, t, JNI_ABORT);
+    (*env)->ReleaseIntArrayElements(env, channels, ch, JNI_ABORT);
+    (*env)->ReleaseIntArrayElements(env, isNull, nl, JNI_ABORT);
+    (*env)->ReleaseIntArrayElements(env, nargs, na_, JNI_ABORT);
+    (*env)->ReleaseIntArrayElements(env, firstArg, fa, JNI_ABORT);
+    (*env)->ReleaseLongArrayElements(env, longs, lv, JNI_ABORT);
+    (*env)->ReleaseDoubleArrayElements(env, doubles, dv, JNI_ABORT);
+    (*env)->ReleaseIntArrayElements(env, args, av, JNI_ABORT);
+    e->expr.node_count = n;
+    e->expr.root = root;
+    e->expr.nodes = e->nodes;
+    e->expr.arg_count = na;
+    e->expr.args = e->args;
+    return (jlong)(intptr_t)e;
+}
+JNIEXPORT void JNICALL Java_io_trino_gpu_GpuNative_freeExpression(JNIEnv* env, jclass c, jlong h)
+{
+    native_expr* e = (native_expr*)(intptr_t)h;
+    if (!e) return;
+    for (int32_t i = 0; i < e->count; i++) free(e->strings[i]);
+    free(e->strings); free(e->args); free(e->nodes); free(e);
+}
+
+/* copies a Java int[] into a malloc'ed int32_t[] (descriptor arrays only have to live for the create call) */
+static int32_t* ints_of(JNIEnv* env, jintArray a, jsize* n)
+{
+    *n = a ? (*env)->GetArrayLength(env, a) : 0;
+    int32_t* out = (int32_t*)calloc((size_t)(*n > 0 ? *n : 1), sizeof(int32_t));
+    if (a) {
+        jint* v = (*env)->GetIntArrayElements(env, a, 0);
+        memcpy(out, v, (size_t)*n * sizeof(int32_t));
+        (*env)->ReleaseIntArrayElements(env, a, v, JNI_ABORT);
+    }
+    return out;
+}
+
+/* ---- operator factories (OperatorFactory.createOperator) ---- */
+JNIEXPORT jlong JNICALL Java_io_trino_gpu_GpuNative_createFilterProject(JNIEnv* env, jclass c, jintArray inputTypes, jintArray typeParams, jlong filter,
+        jlongArray projections, jlong minOutputPageBytes, jint minOutputPageRows, jint outputMem)
+{
+    jsize n, np_, nproj = (*env)->GetArrayLength(env, projections);
+    pa_filter_project_desc d;
+    memset(&d, 0, sizeof d);
+    int32_t* types = ints_of(env, inputTypes, &n);
+    int32_t* params = ints_of(env, typeParams, &np_);
+    pa_expr* pe = (pa_expr*)calloc((size_t)(nproj > 0 ? nproj : 1), sizeof(pa_expr));
+    jlong* ph = (*env)->GetLongArrayElements(env, projections, 0);
+    for (jsize i = 0; i < nproj; i++) pe[i] = ((native_expr*)(intptr_t)ph[i])->expr;
+    (*env)->ReleaseLongArrayElements(env, projections, ph, JNI_ABORT);
+    d.input_channel_count = n;
+    d.input_types = types;
+    d.input_type_params = np_ == n ? params : 0;
+    d.filter = filter ? &((native_expr*)(intptr_t)filter)->expr : 0;
+    d.projection_count = nproj;
+    d.projections = pe;
+    d.output_mem = outputMem;
+    d.min_output_page_bytes = minOutputPageBytes;      /* FilterAndProjectOperator's MergePages thresholds */
+    d.min_output_page_rows = minOutputPageRows;
+    pa_operator* op = 0;
+    int32_t rc = pa_filter_project_create(&d, &op);
+    free(pe); free(params); free(types);
+    if (rc < 0) { throw_native(env, rc); return 0; }
+    return (jlong)(intptr_t)op;
+}
+
+static void fill_aggregates(JNIEnv* env, jintArray fns, jintArray inputs, jintArray masks, jintArray inputTypes, pa_aggregate** out, jsize* count)
+{
+    jsize n1, n2, n3, n4;
+    int32_t *f = ints_of(env, fns, &n1), *in = ints_of(env, inputs, &n2), *m = ints_of(env, masks, &n3), *t = ints_of(env, inputTypes, &n4);
+    *out = (pa_aggregate*)calloc((size_t)(n1 > 0 ? n1 : 1), sizeof(pa_aggregate));
+    for (jsize i = 0; i < n1; i++) { (*out)[i].fn = f[i]; (*out)[i].input_channel = in[i]; (*out)[i].mask_channel = m[i]; (*out)[i].input_type = t[i]; }
+    *count = n1;
+    free(f); free(in); free(m); free(t);
+}
+
+JNIEXPORT jlong JNICALL Java_io_trino_gpu_GpuNative_createHashAggregation(JNIEnv* env, jclass c, jintArray inputTypes, jintArray typeParams,
+        jintArray groupByChannels, jint hashChannel, jint step, jintArray aggFns, jintArray aggInputs, jintArray aggMasks, jintArray aggInputTypes,
+        jint expectedGroups, jint outputMem)
+{
+    jsize n, np_, ng, na;
+    pa_hash_aggregation_desc d;
+    memset(&d, 0, sizeof d);
+    int32_t *types = ints_of(env, inputTypes, &n), *params = ints_of(env, typeParams, &np_), *gb = ints_of(env, groupByChannels, &ng);
+    pa_aggregate* aggs;
+    fill_aggregates(env, aggFns, aggInputs, aggMasks, aggInputTypes, &aggs, &na);
+    d.input_channel_count = n; d.input_types = types; d.input_type_params = np_ == n ? params : 0;
+    d.group_by_count = ng; d.group_by_channels = gb; d.hash_channel = hashChannel; d.step = step;
+    d.aggregate_count = na; d.aggregates = aggs; d.expected_groups = expectedGroups; d.output_mem = outputMem;
+    pa_operator* op = 0;
+    int32_t rc = pa_hash_aggregation_create(&d, &op);   /* group_by_count == 0: AggregationOperator */
+    free(aggs); free(gb); free(params); free(types);
+    if (rc < 0) { throw_native(env, rc); return 0; }
+    return (jlong)(intptr_t)op;
+}
+
+JNIEXPORT jlong JNICALL Java_io_trino_gpu_GpuNative_createLookupSource(JNIEnv* env, jclass c)
+{
+    pa_lookup_source* ls = 0;
+    int32_t rc = pa_lookup_source_create(&ls);
+    if (rc < 0) { throw_native(env, rc); return 0; }
+    return (jlong)(intptr_t)ls;
+}
+JNIEXPORT void JNICALL Java_io_trino_gpu_GpuNative_destroyLookupSource(JNIEnv* env, jclass c, jlong h) { CHECK(pa_lookup_source_destroy((pa_lookup_source*)(intptr_t)h)); }
+
+JNIEXPORT jlong JNICALL Java_io_trino_gpu_GpuNative_createHashBuilder(JNIEnv* env, jclass c, jlong bridge, jintArray inputTypes, jintArray joinChannels,
+        jint hashChannel, jintArray outputChannels, jint expectedPositions)
+{
+    jsize n, nj, no;
+    pa_hash_builder_desc d;
+    memset(&d, 0, sizeof d);
+    int32_t *types = ints_of(env, inputTypes, &n), *jc = ints_of(env, joinChannels, &nj), *oc = ints_of(env, outputChannels, &no);
+    d.input_channel_count = n; d.input_types = types; d.join_channel_count = nj; d.join_channels = jc; d.hash_channel = hashChannel;
+    d.output_channel_count = no; d.output_channels = oc; d.expected_positions = expectedPositions;
+    pa_operator* op = 0;
+    int32_t rc = pa_hash_builder_create(&d, (pa_lookup_source*)(intptr_t)bridge, &op);
+    free(oc); free(jc); free(types);
+    if (rc < 0) { throw_native(env, rc); return 0; }
+    return (jlong)(intptr_t)op;
+}
+
+/* OperatorFactories.innerJoin / probeOuterJoin / lookupOuterJoin / fullOuterJoin: joinType = pa_join_type; outer = 1 creates the
+ * LookupOuterOperator of the same bridge */
+JNIEXPORT jlong JNICALL Java_io_trino_gpu_GpuNative_createLookupJoin(JNIEnv* env, jclass c, jlong bridge, jintArray probeTypes, jintArray probeJoinChannels,
+        jint probeHashChannel, jintArray probeOutputChannels, jint joinType, jboolean outputSingleMatch, jboolean outer, jint outputMem)
+{
+    jsize n, nj, no;
+    pa_lookup_join_desc d;
+    memset(&d, 0, sizeof d);
+    int32_t *types = ints_of(env, probeTypes, &n), *jc = ints_of(env, probeJoinChannels, &nj), *oc = ints_of(env, probeOutputChannels, &no);
+    d.probe_channel_count = n; d.probe_types = types; d.join_channel_count = nj; d.probe_join_channels = jc; d.probe_hash_channel = probeHashChannel;
+    d.probe_output_channel_count = no; d.probe_output_channels = oc; d.output_mem = outputMem; d.join_type = joinType;
+    d.output_single_match = outputSingleMatch ? 1 : 0;
+    pa_operator* op = 0;
+    int32_t rc = outer ? pa_lookup_outer_create(&d, (pa_lookup_source*)(intptr_t)bridge, &op) : pa_lookup_join_create(&d, (pa_lookup_source*)(intptr_t)bridge, &op);
+    free(oc); free(jc); free(types);
+    if (rc < 0) { throw_native(env, rc); return 0; }
+    return (jlong)(intptr_t)op;
+}
+
+JNIEXPORT jlong JNICALL Java_io_trino_gpu_GpuNative_createTopN(JNIEnv* env, jclass c, jintArray inputTypes, jint count, jintArray sortChannels, jintArray sortOrders, jint outputMem)
+{
+    jsize n, ns, no;
+    pa_topn_desc d;
+    memset(&d, 0, sizeof d);
+    int32_t *types = ints_of(env, inputTypes, &n), *sc = ints_of(env, sortChannels, &ns), *so = ints_of(env, sortOrders, &no);
+    d.input_channel_count = n; d.input_types = types; d.n = count; d.sort_channel_count = ns; d.sort_channels = sc; d.sort_orders = so; d.output_mem = outputMem;
+    pa_operator* op = 0;
+    int32_t rc = pa_topn_create(&d, &op);
+    free(so); free(sc); free(types);
+    if (rc < 0) { throw_native(env, rc); return 0; }
+    return (jlong)(intptr_t)op;
+}
+
+/* The dynamic filter of an inner join, installed by the probe-side ScanFilterAndProject's factory once the build is done. */
+JNIEXPORT jboolean JNICALL Java_io_trino_gpu_GpuNative_setDynamicFilter(JNIEnv* env, jclass c, jlong fpOperator, jint channel, jlong lookupSource)
+{
+    int32_t rc = pa_filter_project_set_dynamic_filter((pa_operator*)(intptr_t)fpOperator, channel, (pa_lookup_source*)(intptr_t)lookupSource);
+    CHECK(rc);
+    return rc == 1;
+}
+
+/* ---- exchange between the GPUs of a node (one JVM worker per GPU): the coordinator ships the 128-byte id ---- */
+JNIEXPORT void JNICALL Java_io_trino_gpu_GpuNative_commUniqueId(JNIEnv* env, jclass c, jbyteArray out)
+{
+    jbyte* b = (*env)->GetByteArrayElements(env, out, 0);
+    int32_t rc = pa_comm_unique_id(b);
+    (*env)->ReleaseByteArrayElements(env, out, b, 0);
+    CHECK(rc);
+}
+JNIEXPORT jlong JNICALL Java_io_trino_gpu_GpuNative_commCreate(JNIEnv* env, jclass c, jbyteArray id, jint rank, jint world)
+{
+    pa_comm* comm = 0;
+    jbyte* b = (*env)->GetByteArrayElements(env, id, 0);
+    int32_t rc = pa_comm_create(b, rank, world, &comm);
+    (*env)->ReleaseByteArrayElements(env, id, b, JNI_ABORT);
+    if (rc < 0) { throw_native(env, rc); return 0; }
+    return (jlong)(intptr_t)comm;
+}
+JNIEXPORT void JNICALL Java_io_trino_gpu_GpuNative_commDestroy(JNIEnv* env, jclass c, jlong comm) { CHECK(pa_comm_destroy((pa_comm*)(intptr_t)comm)); }
+JNIEXPORT jlong JNICALL Java_io_trino_gpu_GpuNative_exchangeCreate(JNIEnv* env, jclass c, jlong comm, jintArray types, jintArray partitionChannels, jint hashChannel, jint sinkCount)
+{
+    jsize n, np_;
+    pa_exchange_desc d;
+    memset(&d, 0, sizeof d);
+    int32_t *t = ints_of(env, types, &n), *pc = ints_of(env, partitionChannels, &np_);
+    d.channel_count = n; d.types = t; d.partition_channel_count = np_; d.partition_channels = pc; d.hash_channel = hashChannel;
+    d.partition_rule = -1; d.sink_count = sinkCount;
+    pa_exchange* ex = 0;
+    int32_t rc = pa_exchange_create(&d, (pa_comm*)(intptr_t)comm, &ex);
+    free(pc); free(t);
+    if (rc < 0) { throw_native(env, rc); return 0; }
+    return (jlong)(intptr_t)ex;
+}
+JNIEXPORT void JNICALL Java_io_trino_gpu_GpuNative_exchangeDestroy(JNIEnv* env, jclass c, jlong ex) { CHECK(pa_exchange_destroy((pa_exchange*)(intptr_t)ex)); }
+JNIEXPORT jlong JNICALL Java_io_trino_gpu_GpuNative_createPartitionedOutput(JNIEnv* env, jclass c, jlong ex)
+{
+    pa_operator* op = 0;
+    int32_t rc = pa_partitioned_output_create((pa_exchange*)(intptr_t)ex, 0, &op);
+    if (rc < 0) { throw_native(env, rc); return 0; }
+    return (jlong)(intptr_t)op;
+}
+JNIEXPORT jlong JNICALL Java_io_trino_gpu_GpuNative_createExchangeSource(JNIEnv* env, jclass c, jlong ex, jint outputMem)
+{
+    pa_operator* op = 0;
+    int32_t rc = pa_exchange_source_create((pa_exchange*)(intptr_t)ex, outputMem, 0, &op);
+    if (rc < 0) { throw_native(env, rc); return 0; }
+    return (jlong)(intptr_t)op;
+}
+
+/* ---- Operator protocol (Operator.java:21-103) ---- */
+JNIEXPORT jboolean JNICALL Java_io_trino_gpu_GpuNative_needsInput(JNIEnv* env, jclass c, jlong h)
+{
+    int32_t rc = pa_op_needs_input((pa_operator*)(intptr_t)h);
+    CHECK(rc);
+    return rc == 1;
+}
+JNIEXPORT jboolean JNICALL Java_io_trino_gpu_GpuNative_isBlocked(JNIEnv* env, jclass c, jlong h)
+{
+    int32_t rc = pa_op_is_blocked((pa_operator*)(intptr_t)h);
+    CHECK(rc);
+    return rc == 1;
+}
+JNIEXPORT jboolean JNICALL Java_io_trino_gpu_GpuNative_isFinished(JNIEnv* env, jclass c, jlong h)
+{
+    int32_t rc = pa_op_is_finished((pa_operator*)(intptr_t)h);
+    CHECK(rc);
+    return rc == 1;
+}
+JNIEXPORT void JNICALL Java_io_trino_gpu_GpuNative_finish(JNIEnv* env, jclass c, jlong h) { CHECK(pa_op_finish((pa_operator*)(intptr_t)h)); }
+JNIEXPORT void JNICALL Java_io_trino_gpu_GpuNative_close(JNIEnv* env, jclass c, jlong h) { CHECK(pa_op_close((pa_operator*)(intptr_t)h)); }
+JNIEXPORT jlong JNICALL Java_io_trino_gpu_GpuNative_memoryBytes(JNIEnv* env, jclass c, jlong h) { return pa_op_memory_bytes((pa_operator*)(intptr_t)h); }
+
+/* addInput: block arrays at offsets inside one pinned direct ByteBuffer.  Per channel: type, encoding (FLAT / VARWIDTH /
+ * DICTIONARY / RLE), and byte offsets of values / offsets / nulls / ids (-1 = absent); a DICTIONARY / RLE channel names its
+ * dictionary as one more "channel" behind the page's own (dictionaryChannel[i], -1 = none) with dictionarySize positions. */
+JNIEXPORT void JNICALL Java_io_trino_gpu_GpuNative_addInput(JNIEnv* env, jclass c, jlong h, jint positions, jint channels, jintArray types,
+        jintArray encodings, jlongArray valueOffsets, jlongArray offsetOffsets, jlongArray nullOffsets, jlongArray idOffsets, jintArray dictionaryChannel,
+        jintArray dictionarySize, jobject pinned, jboolean stable)
+{
+    char* base = (char*)(*env)->GetDirectBufferAddress(env, pinned);
+    const jsize total = (*env)->GetArrayLength(env, types);   /* page channels + dictionaries */
+    if (total > MAX_CHANNELS || channels > total) { throw_message(env, PA_ERR_INVALID_ARGUMENT, "page with more than 64 blocks (dictionaries included)"); return; }
+    pa_column cols[MAX_CHANNELS];
+    jint* t = (*env)->GetIntArrayElements(env, types, 0);
+    jint* e = (*env)->GetIntArrayElements(env, encodings, 0);
+    jlong* v = (*env)->GetLongArrayElements(env, valueOffsets, 0);
+    jlong* o = (*env)->GetLongArrayElements(env, offsetOffsets, 0);
+    jlong* n = (*env)->GetLongArrayElements(env, nullOffsets, 0);
+    jlong* ids = (*env)->GetLongArrayElements(env, idOffsets, 0);
+    jint* dc = (*env)->GetIntArrayElements(env, dictionaryChannel, 0);
+    jint* ds = (*env)->GetIntArrayElements(env, dictionarySize, 0);
+    for (jsize i = 0; i < total; i++) {
+        pa_column col;
+        memset(&col, 0, sizeof col);
+        col.type = t[i];
+        col.encoding = e[i];
+        col.values = v[i] >= 0 ? base + v[i] : 0;
+        col.offsets = o[i] >= 0 ? (const int32_t*)(base + o[i]) : 0;
+        col.nulls = n[i] >= 0 ? (const uint8_t*)(base + n[i]) : 0;      /* boolean[] valueIsNull, 1 B / position */
+        col.ids = ids[i] >= 0 ? (const int32_t*)(base + ids[i]) : 0;
+        col.dictionary = dc[i] >= 0 ? &cols[dc[i]] : 0;
+        col.dictionary_size = ds[i];
+        cols[i] = col;
+    }
+    pa_page page;
+    memset(&page, 0, sizeof page);
+    page.position_count = positions;
+    page.channel_count = channels;
+    page.columns = cols;
+    page.mem = PA_MEM_HOST;
+    page.flags = stable ? PA_PAGE_STABLE : 0;
+    int32_t rc = pa_op_add_input((pa_operator*)(intptr_t)h, &page);
+    (*env)->ReleaseIntArrayElements(env, types, t, JNI_ABORT);
+    (*env)->ReleaseIntArrayElements(env, encodings, e, JNI_ABORT);
+    (*env)->ReleaseLongArrayElements(env, valueOffsets, v, JNI_ABORT);
+    (*env)->ReleaseLongArrayElements(env, offsetOffsets, o, JNI_ABORT);
+    (*env)->ReleaseLongArrayElements(env, nullOffsets, n, JNI_ABORT);
+    (*env)->ReleaseLongArrayElements(env, idOffsets, ids, JNI_ABORT);
+    (*env)->ReleaseIntArrayElements(env, dictionaryChannel, dc, JNI_ABORT);
+    (*env)->ReleaseIntArrayElements(env, dictionarySize, ds, JNI_ABORT);
+    CHECK(rc);
+}
+
+/* getOutput: returns null when the operator has no page, else long[2 + 6 * channels]:
+ *   [0] positionCount  [1] channelCount  then per channel: type, values address, values bytes, offsets address, nulls address, 0
+ * The addresses are the operator's pinned output buffers (PA_MEM_HOST operators), valid until the next call on the handle;
+ * GpuOperator wraps them (NewDirectByteBuffer on the Java side through wrapAddress) and copies them into fresh long[] /
+ * int[] / byte[] for new LongArrayBlock(n, Optional.ofNullable(valueIsNull), values) etc. */
+JNIEXPORT jlongArray JNICALL Java_io_trino_gpu_GpuNative_getOutput(JNIEnv* env, jclass c, jlong h)
+{
+    pa_page out;
+    memset(&out, 0, sizeof out);
+    int32_t rc = pa_op_get_output((pa_operator*)(intptr_t)h, &out);
+    if (rc < 0) { throw_native(env, rc); return 0; }
+    if (rc == 0) return 0;
+    const jsize len = 2 + 6 * out.channel_count;
+    jlong* v = (jlong*)calloc((size_t)len, sizeof(jlong));
+    v[0] = out.position_count;
+    v[1] = out.channel_count;
+    for (int32_t i = 0; i < out.channel_count; i++) {
+        const pa_column* col = &out.columns[i];
+        jlong* r = v + 2 + 6 * i;
+        r[0] = col->type;
+        r[1] = (jlong)(intptr_t)col->values;
+        if (col->encoding == PA_VARWIDTH) r[2] = out.position_count > 0 ? col->offsets[out.position_count] : 0;
+        else r[2] = (jlong)out.position_count * (col->type == PA_BOOLEAN ? 1 : ((col->type == PA_INTEGER || col->type == PA_DATE) ? 4 : 8));
+        r[3] = (jlong)(intptr_t)col->offsets;
+        r[4] = (jlong)(intptr_t)col->nulls;
+    }
+    jlongArray result = (*env)->NewLongArray(env, len);
+    (*env)->SetLongArrayRegion(env, result, 0, len, v);
+    free(v);
+    return result;
+}
+JNIEXPORT jobject JNICALL Java_io_trino_gpu_GpuNative_wrapAddress(JNIEnv* env, jclass c, jlong address, jlong bytes)
+{
+    return (*env)->NewDirectByteBuffer(env, (void*)(intptr_t)address, bytes);
+}

@@ -45,6 +45,8 @@ def lib():
     L.pa_stream_create.argtypes = [C.POINTER(vp)]
     L.pa_stream_destroy.argtypes = [vp]
     L.pa_filter_project_create.argtypes = [C.POINTER(abi.pa_filter_project_desc), C.POINTER(vp)]
+    L.pa_scan_filter_project_create.argtypes = [C.POINTER(abi.pa_filter_project_desc), C.POINTER(abi.pa_page_source), C.POINTER(vp)]
+    L.pa_scan_stats.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     L.pa_aggregation_create.argtypes = [C.POINTER(abi.pa_aggregation_desc), C.POINTER(vp)]
     L.pa_hash_aggregation_create.argtypes = [C.POINTER(abi.pa_hash_aggregation_desc), C.POINTER(vp)]
     L.pa_fused_aggregation_create.argtypes = [C.POINTER(abi.pa_fused_aggregation_desc), C.POINTER(vp)]

@@ -83,6 +83,7 @@ class pa_page(C.Structure):
 
 
 PAGE_STABLE = 1
+PAGE_PINNED = 2
 
 
 class pa_expr_node(C.Structure):
@@ -264,6 +265,15 @@ class pa_exchange_desc(C.Structure):
         ("sink_count", C.c_int32),
         ("reserved", C.c_int32),
     ]
+
+
+NEXT_PAGE = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.POINTER(pa_page))
+LOAD_BLOCK = C.CFUNCTYPE(C.c_int64, C.c_void_p, C.c_int32, C.POINTER(pa_column))
+CLOSE_SOURCE = C.CFUNCTYPE(None, C.c_void_p)
+
+
+class pa_page_source(C.Structure):
+    _fields_ = [("ctx", C.c_void_p), ("next_page", NEXT_PAGE), ("load_block", LOAD_BLOCK), ("close", CLOSE_SOURCE)]
 
 
 COMM_ID_BYTES = 128

@@ -319,6 +319,23 @@ int32_t pa_filter_project_create(const pa_filter_project_desc* desc, pa_operator
     });
 }
 
+int32_t pa_scan_filter_project_create(const pa_filter_project_desc* desc, const pa_page_source* source, pa_operator** out)
+{
+    return guarded([&]() -> int32_t {
+        PA_REQUIRE(out != nullptr, PA_ERR_INVALID_ARGUMENT, "out is null");
+        *out = make_scan_filter_project(desc, source);
+        return PA_OK;
+    });
+}
+int32_t pa_scan_stats(pa_operator* op, int64_t* processed_positions, int64_t* materialized_bytes, int64_t* blocks_loaded, int64_t* blocks_skipped)
+{
+    return guarded([&]() -> int32_t {
+        PA_REQUIRE(op != nullptr, PA_ERR_INVALID_ARGUMENT, "operator is null");
+        scan_stats(op, processed_positions, materialized_bytes, blocks_loaded, blocks_skipped);
+        return PA_OK;
+    });
+}
+
 int32_t pa_lookup_source_create(pa_lookup_source** out)
 {
     return guarded([&]() -> int32_t {

@@ -48,6 +48,11 @@ __device__ __forceinline__ void copy_chunk(const CopySeg* segs, int nseg)
         return;
     }
     const char* src = static_cast<const char*>(sg.src) + off;
+    if (sg.add_i32 != 0) {
+        const int64_t v = len >> 2;
+        for (int64_t i = threadIdx.x; i < v; i += kCopyThreads) reinterpret_cast<int32_t*>(dst)[i] = reinterpret_cast<const int32_t*>(src)[i] + sg.add_i32;
+        return;
+    }
     if (((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src)) & 15) == 0) {
         const int64_t v = len >> 4;
         for (int64_t i = threadIdx.x; i < v; i += kCopyThreads) reinterpret_cast<uint4*>(dst)[i] = reinterpret_cast<const uint4*>(src)[i];

@@ -12,6 +12,9 @@ struct CopySeg {
     void* dst;
     int64_t bytes;
     int64_t first_chunk;  // filled by launch_copy_segments
+    int32_t add_i32 = 0;  // != 0: the segment is int32 elements (4-byte aligned) and this is added to each while it is copied
+                          // (the offsets of a VariableWidthBlock appended behind other blocks' bytes)
+    int32_t pad = 0;
 };
 // device-side table size for n segments
 size_t copy_segments_table_bytes(size_t n);

@@ -911,6 +911,7 @@ public:
         (void)hipStreamSynchronize(stream_.get());
         if (merge_stream_) pool_stream_release(merge_stream_);  // synchronises it
         for (int b = 0; b < 2; b++) {
+            if (arena_[b].table_event) (void)hipEventDestroy(arena_[b].table_event);
             if (ev_main_[b]) (void)hipEventDestroy(ev_main_[b]);
             if (ev_merge_[b]) (void)hipEventDestroy(ev_merge_[b]);
         }
@@ -950,6 +951,10 @@ public:
         }
         if (gather_small_page(page)) return;
         flush_pending();
+        if (next_) {  // the flush met a layout change and started the next generation: the page belongs there
+            next_->add_input(page);
+            return;
+        }
         process_page(page, (page->flags & PA_PAGE_STABLE) != 0 && page->mem == PA_MEM_DEVICE);
     }
 
@@ -957,6 +962,10 @@ public:
     // confirmed the launches, so they may be confirmed late.
     void process_page(const pa_page* page, bool retained)
     {
+        if (next_) {  // a later generation takes every page (its layout is the more general one)
+            next_->process_page(page, retained);
+            return;
+        }
         retained_ = retained;
         try {
             add_page(page);
@@ -1025,9 +1034,9 @@ public:
                 if (run_.rows >= gather_rows()) flush_pending();
                 return true;
             }
-            flush_pending();
+            retire_run();
+            if (next_) return false;  // (add_input hands the page to the generation a flush started)
         }
-        if (n >= kSmallPageRows) return false;
         bool plain = true, flat = true;
         for (int c = 0; c < spec_.n_in && plain; c++) {
             if (!spec_.used_channel[c]) continue;
@@ -1035,15 +1044,54 @@ public:
             flat = flat && page->columns[c].encoding == PA_FLAT;
         }
         if (!plain) return false;
-        if (stable_dev) {
-            flush_pending();
+        if (stable_dev && n < gather_rows()) {
+            // a range starts here: whatever its size, the next page may continue it
             run_.rows = n;
+            run_.flat = flat;
             run_.cols.assign(page->columns, page->columns + page->channel_count);
             return true;
         }
-        if (!flat) return false;
+        if (n >= kSmallPageRows) return false;
+        // VariableWidthBlocks join the arena when their offsets can be read here (host pages): the bytes are appended and the
+        // offsets rebased on the way; a device page's first offset is not known to the host
+        if (!flat && page->mem != PA_MEM_HOST) return false;
         append_to_arena(page);
         return true;
+    }
+
+    // The pending range ends (the next page does not continue it): a small one joins the arena -- one segment-copy launch --
+    // instead of getting a fused launch and its merges of its own; a large one is launched as it is.
+    void retire_run()
+    {
+        if (run_.rows == 0) return;
+        if (run_.rows >= kSmallPageRows || !run_.flat) {
+            flush_run();
+            return;
+        }
+        pa_page sp{};
+        sp.position_count = (int32_t)run_.rows;
+        sp.channel_count = spec_.n_in;
+        sp.columns = run_.cols.data();
+        sp.mem = PA_MEM_DEVICE;
+        sp.flags = PA_PAGE_STABLE;  // its copy can wait for the arena's launch
+        run_.rows = 0;
+        append_to_arena(&sp);
+    }
+
+    void flush_run()
+    {
+        if (run_.rows == 0) return;
+        pa_page sp{};
+        sp.position_count = (int32_t)run_.rows;
+        sp.channel_count = spec_.n_in;
+        sp.columns = run_.cols.data();
+        sp.mem = PA_MEM_DEVICE;
+        sp.flags = PA_PAGE_STABLE;
+        run_.rows = 0;
+        std::vector<pa_column> cols;
+        cols.swap(run_.cols);  // (process_page may come back here through a generation change)
+        sp.columns = cols.data();
+        process_page(&sp, true);
     }
 
     void append_to_arena(const pa_page* page)
@@ -1052,70 +1100,128 @@ public:
         const int64_t n = page->position_count;
         Arena& a = arena_[arena_cur_];
         // the nullability of the arena's channels is fixed by its first page: a page that differs starts the next arena
-        bool fits = a.rows + n <= kArenaRows;
+        bool fits = a.rows + n <= kArenaRows && a.segs.size() + 3 * (size_t)spec_.n_in <= kArenaMaxSegs;
         for (int c = 0; c < spec_.n_in && fits && a.rows > 0; c++) {
-            if (spec_.used_channel[c]) fits = a.nullable[c] == (page->columns[c].nulls != nullptr);
+            if (!spec_.used_channel[c]) continue;
+            const pa_column& col = page->columns[c];
+            fits = a.nullable[c] == (col.nulls != nullptr);
+            // a VARCHAR channel's byte buffer never moves while copies into it are pending
+            if (fits && col.encoding == PA_VARWIDTH && col.offsets != nullptr) {
+                fits = a.bytes[c] + ((int64_t)col.offsets[n] - col.offsets[0]) <= (int64_t)a.values[c].capacity();
+            }
         }
         if (!fits) {
             flush_pending();
+            if (next_) return next_->add_input(page);  // the flush started the next generation
             return append_to_arena(page);
         }
+        const bool host = page->mem == PA_MEM_HOST;
+        const bool readable = !host || (page->flags & PA_PAGE_PINNED) != 0;  // the device can read the page's buffers itself
+        const bool defer = readable && (page->flags & PA_PAGE_STABLE) != 0;   // ... and they stay: copy at the arena's launch
         if (a.rows == 0) {
             a.nullable.assign(spec_.n_in, false);
             a.values.resize(spec_.n_in);
             a.nulls.resize(spec_.n_in);
+            a.offsets.resize(spec_.n_in);
+            a.bytes.assign(spec_.n_in, 0);
             for (int c = 0; c < spec_.n_in; c++) {
                 if (!spec_.used_channel[c]) continue;
                 a.nullable[c] = page->columns[c].nulls != nullptr;
-                a.values[c].ensure((size_t)kArenaRows * type_width(spec_.in_types[c]));
+                if (spec_.in_types[c] != PA_VARCHAR) a.values[c].ensure((size_t)kArenaRows * type_width(spec_.in_types[c]));
                 if (a.nullable[c]) a.nulls[c].ensure((size_t)kArenaRows);
             }
         }
-        CopySeg segs[2 * kMaxChannels];
+        CopySeg now[3 * kMaxChannels];
         int m = 0;
+        auto seg = [&](const void* src, void* dst, int64_t bytes, int32_t add = 0) {
+            CopySeg sg{src, dst, bytes, 0};
+            sg.add_i32 = add;
+            if (defer) a.segs.push_back(sg);
+            else now[m++] = sg;
+        };
         for (int c = 0; c < spec_.n_in; c++) {
             if (!spec_.used_channel[c]) continue;
             const pa_column& col = page->columns[c];
             PA_REQUIRE(col.type == spec_.in_types[c], PA_ERR_INVALID_ARGUMENT, "page block type does not match the declared input type");
             PA_REQUIRE(col.values != nullptr, PA_ERR_INVALID_ARGUMENT, "block values is null");
+            if (col.nulls) {
+                char* dn = a.nulls[c].as<char>() + a.rows;
+                if (readable) seg(col.nulls, dn, n);
+                else PA_HIP(hipMemcpyAsync(dn, col.nulls, (size_t)n, hipMemcpyHostToDevice, s));
+            }
+            if (col.encoding == PA_VARWIDTH) {
+                // host page: the offsets are readable here.  bytes behind the arena's bytes, offsets rebased by (cursor - first)
+                PA_REQUIRE(col.offsets != nullptr, PA_ERR_INVALID_ARGUMENT, "VARWIDTH block without offsets");
+                const int64_t first = col.offsets[0], len = (int64_t)col.offsets[n] - first;
+                PA_REQUIRE(len >= 0 && a.bytes[c] + len < ((int64_t)1 << 31), PA_ERR_INVALID_ARGUMENT, "bad VARWIDTH offsets");
+                int32_t* doff = static_cast<int32_t*>(a.offsets[c].ensure((size_t)(kArenaRows + 1) * 4)) + a.rows;
+                if (a.rows == 0) {
+                    // sized by the channel's declared bound (VARCHAR(n)), or for this page with room to spare; a later page
+                    // that does not fit starts the next arena (see `fits`)
+                    const int64_t bound = spec_.in_params[c] > 0 ? std::min<int64_t>(spec_.in_params[c], 64) : 0;
+                    a.values[c].ensure((size_t)std::max<int64_t>({bound * kArenaRows, 4 * len, (int64_t)1 << 20}));
+                }
+                char* dv = a.values[c].as<char>() + a.bytes[c];
+                const int32_t delta = (int32_t)(a.bytes[c] - first);
+                if (readable) {
+                    seg(static_cast<const char*>(col.values) + first, dv, len);
+                    // (n + 1 entries: the first one rewrites the previous page's end with the same value)
+                    if (delta != 0) seg(col.offsets, doff, (n + 1) * 4, delta);
+                    else seg(col.offsets, doff, (n + 1) * 4);
+                }
+                else {
+                    if (len) PA_HIP(hipMemcpyAsync(dv, static_cast<const char*>(col.values) + first, (size_t)len, hipMemcpyHostToDevice, s));
+                    PA_HIP(hipMemcpyAsync(doff, col.offsets, (size_t)(n + 1) * 4, hipMemcpyHostToDevice, s));
+                    if (delta != 0) {
+                        CopySeg sg{doff, doff, (n + 1) * 4, 0};
+                        sg.add_i32 = delta;
+                        now[m++] = sg;  // in place, behind the copy in stream order
+                    }
+                }
+                a.bytes[c] += len;
+                continue;
+            }
             const int w = type_width(col.type);
             char* dv = a.values[c].as<char>() + a.rows * w;
-            if (page->mem == PA_MEM_DEVICE) {
-                segs[m++] = CopySeg{col.values, dv, n * w, 0};
-                if (col.nulls) segs[m++] = CopySeg{col.nulls, a.nulls[c].as<char>() + a.rows, n, 0};
-            }
-            else {
-                PA_HIP(hipMemcpyAsync(dv, col.values, (size_t)n * w, hipMemcpyHostToDevice, s));
-                if (col.nulls) PA_HIP(hipMemcpyAsync(a.nulls[c].as<char>() + a.rows, col.nulls, (size_t)n, hipMemcpyHostToDevice, s));
-            }
+            if (readable) seg(col.values, dv, n * w);
+            else PA_HIP(hipMemcpyAsync(dv, col.values, (size_t)n * w, hipMemcpyHostToDevice, s));
         }
-        if (m > 0) launch_copy_segments_inline(segs, m, s);
+        if (m > 0) launch_copy_segments_inline(now, m, s);
         a.rows += n;
         if (a.rows >= kArenaRows) flush_pending();
     }
 
-    // launches whatever is pending: the merged range of stable pages, or the current arena
+    // launches whatever is pending: the merged range of stable pages and the current arena
     void flush_pending()
     {
-        if (run_.rows > 0) {
-            pa_page sp{};
-            sp.position_count = (int32_t)run_.rows;
-            sp.channel_count = spec_.n_in;
-            sp.columns = run_.cols.data();
-            sp.mem = PA_MEM_DEVICE;
-            sp.flags = PA_PAGE_STABLE;
-            run_.rows = 0;
-            process_page(&sp, true);
-            return;
-        }
+        if (next_) next_->flush_pending();
+        flush_arena();
+        flush_run();
+    }
+
+    void flush_arena()
+    {
         Arena& a = arena_[arena_cur_];
         if (a.rows == 0) return;
+        hipStream_t s = stream_.get();
+        if (!a.segs.empty()) {
+            // the copies of the stable pages gathered in this arena, in one launch.  The staging table is written by the host:
+            // the copy of its previous use must have left it
+            if (a.table_used) PA_HIP(hipEventSynchronize(a.table_event));
+            else PA_HIP(hipEventCreateWithFlags(&a.table_event, hipEventDisableTiming));
+            a.table_used = true;
+            launch_copy_segments(a.segs.data(), a.segs.size(), a.h_table.ensure(copy_segments_table_bytes(a.segs.size())),
+                                 a.d_table.ensure(copy_segments_table_bytes(a.segs.size())), s);
+            PA_HIP(hipEventRecord(a.table_event, s));
+            a.segs.clear();
+        }
         std::vector<pa_column> cols((size_t)spec_.n_in);
         for (int c = 0; c < spec_.n_in; c++) {
             cols[c].type = spec_.in_types[c];
-            cols[c].encoding = PA_FLAT;
+            cols[c].encoding = spec_.in_types[c] == PA_VARCHAR ? PA_VARWIDTH : PA_FLAT;
             if (!spec_.used_channel[c]) continue;
             cols[c].values = a.values[c].ptr();
+            cols[c].offsets = spec_.in_types[c] == PA_VARCHAR ? a.offsets[c].as<int32_t>() : nullptr;
             cols[c].nulls = a.nullable[c] ? a.nulls[c].as<uint8_t>() : nullptr;
         }
         pa_page sp{};
@@ -1213,8 +1319,7 @@ public:
     void finish() override
     {
         if (finishing_) return;
-        if (next_) next_->flush_pending();
-        else flush_pending();
+        flush_pending();
         finishing_ = true;
     }
     bool is_finished() override { return finishing_ && output_done_; }
@@ -1493,10 +1598,16 @@ private:
         // (beyond that the HBM table takes the rows as they come: running ITS kernel over partition-ordered rows, for the
         // locality of the table slice, was measured slower -- 3 M groups 7.2 vs 9.5 G rows/s, 10 M 6.1 vs 7.8: the atomics are
         // bound in the L2 atomic units, not by where the table lines live)
-        if (g > 512ULL * (uint64_t)(ldsh->info.lc / 2)) return false;
+        // The multisplit takes up to 4096 partitions in one pass (2048 + 1 for the filtered rows here): at 2048 a tile of 8192
+        // rows leaves runs of ~4 rows per partition, which the L2 still combines into full lines (the write cursors of all
+        // partitions and columns together are a few hundred KB), and a partition of a 2^26-row chunk is one workgroup's slice.
+        static const uint64_t max_parts = [] {
+            const char* e = getenv("PRESTO_AMD_MAX_PARTITIONS");
+            return (uint64_t)(e ? std::max(atoi(e), 2) : 2048);
+        }();
+        if (g > max_parts * (uint64_t)(ldsh->info.lc / 2)) return false;
         uint64_t p = next_pow2((g + per - 1) / per);
-        *partitions = (int)std::min<uint64_t>(std::max<uint64_t>(p, 2), 1023);  // + 1 partition for filtered rows <= 1024
-        if (*partitions == 1023) *partitions = 512;
+        *partitions = (int)std::min<uint64_t>(std::max<uint64_t>(p, 2), max_parts);
         return true;
     }
 
@@ -1917,12 +2028,20 @@ private:
     // small pages (see gather_small_page)
     struct Run {
         int64_t rows = 0;
+        bool flat = true;                 // every used channel is FLAT (a small range can join the arena)
         std::vector<pa_column> cols;      // first page of the range: every later page continues these buffers
     } run_;
+    static constexpr size_t kArenaMaxSegs = 16384;
     struct Arena {
         int64_t rows = 0;
         std::vector<bool> nullable;
-        std::vector<DevBuf> values, nulls;
+        std::vector<DevBuf> values, nulls, offsets;   // per channel; VARCHAR: values = bytes, offsets = rows + 1 entries
+        std::vector<int64_t> bytes;                   // VARCHAR bytes used
+        std::vector<CopySeg> segs;                    // copies of stable, device-readable pages, done at the arena's launch
+        PinnedBuf h_table;
+        DevBuf d_table;
+        hipEvent_t table_event = nullptr;
+        bool table_used = false;
     } arena_[2];
     int arena_cur_ = 0;
     const int32_t* kinds_dev_ = nullptr;

@@ -35,6 +35,8 @@ namespace pa {
 
 pa_operator* make_fused_aggregation(const pa_fused_aggregation_desc* desc);
 pa_operator* make_filter_project(const pa_filter_project_desc* desc);
+pa_operator* make_scan_filter_project(const pa_filter_project_desc* desc, const pa_page_source* source);
+void scan_stats(pa_operator* op, int64_t* rows, int64_t* bytes, int64_t* loaded, int64_t* skipped);
 pa_operator* make_hash_builder(const pa_hash_builder_desc* desc, pa_lookup_source* bridge);
 pa_operator* make_lookup_join(const pa_lookup_join_desc* desc, pa_lookup_source* bridge);
 pa_operator* make_topn(const pa_topn_desc* desc);

@@ -289,8 +289,7 @@ __global__ __launch_bounds__(256) void k_partition_scatter(const i32* __restrict
 
 __global__ void k_partition_totals(const i32* __restrict__ offsets, i64 tiles, i32 P, i64 n, i64* __restrict__ out_counts)
 {
-    int p = threadIdx.x;
-    if (p < P) {
+    for (int p = threadIdx.x; p < P; p += blockDim.x) {
         i64 start = offsets[(i64)p * tiles];
         i64 end = (p + 1 < P) ? (i64)offsets[(i64)(p + 1) * tiles] : n;
         out_counts[p] = end - start;
@@ -333,9 +332,10 @@ struct MsplitArgs {
     MsplitCol col[kMsplitMaxCols];
 };
 
+constexpr int kMsMaxParts = 4096;  // unstable form; the stable form takes 256
 __global__ __launch_bounds__(kMsThreads) void k_msplit_count(const i32* __restrict__ part, i64 n, i32 P, i64 tiles, i32* __restrict__ counts)
 {
-    __shared__ i32 hist[1025];
+    __shared__ i32 hist[kMsMaxParts + 1];
     for (int i = threadIdx.x; i < P; i += kMsThreads) hist[i] = 0;
     __syncthreads();
     const i64 tile0 = (i64)blockIdx.x * kMsTile;
@@ -350,21 +350,28 @@ __global__ __launch_bounds__(kMsThreads) void k_msplit_count(const i32* __restri
 
 __global__ __launch_bounds__(kMsThreads) void k_msplit_scatter(MsplitArgs a)
 {
-    __shared__ i32 goff[1025], lstart[1025], cursor[1025];
+    __shared__ i32 goff[kMsMaxParts + 1], lstart[kMsMaxParts + 1], cursor[kMsMaxParts + 1];
     __shared__ i32 wave_sums[16];
     __shared__ unsigned short lpart[kMsTile];
     __shared__ u64 buf[kMsTile];
     const i64 tile0 = (i64)blockIdx.x * kMsTile;
     const i32 tile_rows = (i32)(a.n - tile0 < (i64)kMsTile ? a.n - tile0 : (i64)kMsTile);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    // the tile's rows per partition (from the scanned counts) and where each partition starts, globally and inside the tile
+    // the tile's rows per partition (from the scanned counts) and where each partition starts, globally and inside the tile;
+    // a thread owns PER consecutive partitions (up to 4 x 1024 threads = 4096 partitions)
+    const int PER = (a.P + kMsThreads - 1) / kMsThreads;
+    i32 cnt[4] = {0, 0, 0, 0};
     i32 mine = 0;
-    if ((i32)threadIdx.x < a.P) {
-        const i64 idx = (i64)threadIdx.x * a.tiles + blockIdx.x;
-        const i32 o = a.offsets[idx];
-        const i32 nx = idx + 1 < (i64)a.P * a.tiles ? a.offsets[idx + 1] : (i32)a.n;
-        goff[threadIdx.x] = o;
-        mine = nx - o;
+    for (int j = 0; j < PER; j++) {
+        const i32 p = (i32)threadIdx.x * PER + j;
+        if (p < a.P) {
+            const i64 idx = (i64)p * a.tiles + blockIdx.x;
+            const i32 o = a.offsets[idx];
+            const i32 nx = idx + 1 < (i64)a.P * a.tiles ? a.offsets[idx + 1] : (i32)a.n;
+            goff[p] = o;
+            cnt[j] = nx - o;
+            mine += nx - o;
+        }
     }
     i32 inc = mine;
 #pragma unroll
@@ -376,9 +383,14 @@ __global__ __launch_bounds__(kMsThreads) void k_msplit_scatter(MsplitArgs a)
     __syncthreads();
     i32 base = 0;
     for (int w = 0; w < wave; w++) base += wave_sums[w];
-    if ((i32)threadIdx.x < a.P) {
-        lstart[threadIdx.x] = base + inc - mine;
-        cursor[threadIdx.x] = 0;
+    i32 run = base + inc - mine;
+    for (int j = 0; j < PER; j++) {
+        const i32 p = (i32)threadIdx.x * PER + j;
+        if (p < a.P) {
+            lstart[p] = run;
+            cursor[p] = 0;
+            run += cnt[j];
+        }
     }
     __syncthreads();
     // every row's place in the tile's partition-sorted order
@@ -524,7 +536,7 @@ size_t msplit_temp_bytes(int64_t n, int32_t partition_count)
 void launch_msplit(const int32_t* partition, int64_t n, int32_t partition_count, const MsplitCol* cols, int32_t ncols, int64_t* out_counts_dev,
                    void* temp, hipStream_t s, bool stable)
 {
-    PA_REQUIRE(partition_count >= 1 && partition_count <= (stable ? 256 : 1024), PA_ERR_NOT_SUPPORTED, "1..1024 partitions (stable: 1..256)");
+    PA_REQUIRE(partition_count >= 1 && partition_count <= (stable ? 256 : kMsMaxParts), PA_ERR_NOT_SUPPORTED, "1..4096 partitions (stable: 1..256)");
     PA_REQUIRE(ncols >= 0 && ncols <= kMsplitMaxCols, PA_ERR_NOT_SUPPORTED, "too many columns for one multisplit");
     if (n <= 0) {
         PA_HIP(hipMemsetAsync(out_counts_dev, 0, (size_t)partition_count * 8, s));

@@ -210,6 +210,98 @@ def FilterAndProjectOperator(input_types, filter_expr, projections, output_mem=a
     return Operator(h, keep)
 
 
+class LazyBlock:
+    """LazyBlock (core/trino-spi/src/main/java/io/trino/spi/block/LazyBlock.java): a block whose loader runs on first use."""
+
+    def __init__(self, position_count, loader):
+        self.position_count = position_count
+        self.loader = loader
+        self.loaded = None
+
+    def getLoadedBlock(self):
+        if self.loaded is None:
+            self.loaded = self.loader()
+            assert self.loaded.position_count == self.position_count
+        return self.loaded
+
+
+class ScanFilterAndProjectOperator(Operator):
+    """ScanFilterAndProjectOperator (…/operator/ScanFilterAndProjectOperator.java:67-114): a source operator over a
+    ConnectorPageSource -- here any object with getNextPage() -> Page | None (None = finished; blocks may be LazyBlocks) and
+    an optional close().  The native operator pulls pages through pa_page_source and loads lazy blocks by need."""
+
+    def __init__(self, page_source, input_types, filter_expr, projections, output_mem=abi.MEM_HOST, stream=None, type_params=None,
+                 min_output_page_size=0, min_output_page_row_count=0):
+        d, keep = _filter_project_desc(input_types, filter_expr, projections, output_mem, stream, type_params)
+        d.min_output_page_bytes = int(min_output_page_size)
+        d.min_output_page_rows = int(min_output_page_row_count)
+        self._source = page_source
+        self._types = list(input_types)
+        self._current = None     # (page, c columns array, keepalive)
+        self.errors = []
+
+        def next_page(ctx, out):
+            try:
+                page = page_source.getNextPage()
+                if page is None:
+                    return 0
+                cols = (abi.pa_column * max(len(page.blocks), 1))()
+                keepalive = []
+                for i, b in enumerate(page.blocks):
+                    if isinstance(b, LazyBlock) and b.loaded is None:
+                        cols[i].type = self._types[i]
+                        cols[i].encoding = abi.VARWIDTH if self._types[i] == abi.VARCHAR else abi.FLAT
+                    else:
+                        (b.loaded if isinstance(b, LazyBlock) else b).fill_c(cols[i], keepalive)
+                out[0].position_count = page.position_count
+                out[0].channel_count = len(page.blocks)
+                out[0].columns = C.cast(cols, C.POINTER(abi.pa_column))
+                out[0].mem = page.mem
+                out[0].flags = 0
+                self._current = (page, cols, keepalive)
+                return 1
+            except Exception as e:  # never let an exception cross the C boundary
+                self.errors.append(e)
+                return abi.ERR_DEVICE
+
+        def load_block(ctx, channel, out):
+            try:
+                page, cols, keepalive = self._current
+                block = page.blocks[channel].getLoadedBlock()
+                block.fill_c(out[0], keepalive)
+                return 0
+            except Exception as e:
+                self.errors.append(e)
+                return abi.ERR_DEVICE
+
+        def close(ctx):
+            if hasattr(page_source, "close"):
+                page_source.close()
+
+        src = abi.pa_page_source()
+        src.ctx = None
+        src.next_page = abi.NEXT_PAGE(next_page)
+        src.load_block = abi.LOAD_BLOCK(load_block)
+        src.close = abi.CLOSE_SOURCE(close)
+        h = C.c_void_p()
+        check(lib().pa_scan_filter_project_create(C.byref(d), C.byref(src), C.byref(h)))
+        super().__init__(h, [keep, src])
+
+    def getOutput(self):
+        try:
+            return super().getOutput()
+        except Exception:
+            if self.errors:
+                raise self.errors[-1]   # the page source's own exception, as the reference would surface it
+            raise
+
+    def stats(self):
+        """(positions pulled, bytes of the blocks loaded, blocks loaded, projection blocks left unloaded)"""
+        v = [C.c_int64() for _ in range(4)]
+        check(lib().pa_scan_stats(self._h, *[C.byref(x) for x in v]))
+        return tuple(x.value for x in v)
+
+
 def AggregationOperator(input_types, aggregates, output_mem=abi.MEM_HOST, stream=None, step=abi.STEP_SINGLE):
     """AggregationOperator.AggregationOperatorFactory (…/operator/AggregationOperator.java:40-95)."""
     d = abi.pa_aggregation_desc()
@@ -514,6 +606,18 @@ def to_pages(operator, input_pages):
             out.append(page)
     assert operator.isFinished(), "operator did not finish"
     return out
+
+
+def source_to_pages(operator, limit=1 << 22):
+    """OperatorAssertion.toPages for a SourceOperator (no input pages): pull getOutput until isFinished."""
+    out = []
+    for _ in range(limit):
+        if operator.isFinished():
+            return out
+        page = operator.getOutput()
+        if page is not None and page.position_count > 0:
+            out.append(page)
+    raise RuntimeError("source operator did not finish")
 
 
 class Driver:

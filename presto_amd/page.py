@@ -158,10 +158,12 @@ class Block:
 
 
 class Page:
-    def __init__(self, blocks, position_count=None, mem=abi.MEM_HOST, stable=False):
+    def __init__(self, blocks, position_count=None, mem=abi.MEM_HOST, stable=False, pinned=False):
         """stable: the buffers outlive the operator the page is given to (PA_PAGE_STABLE) -- true of a Java Page, which is
-        immutable and kept alive by its references; here of pages over buffers the caller keeps for the whole query."""
+        immutable and kept alive by its references; here of pages over buffers the caller keeps for the whole query.
+        pinned: a host page whose buffers are pinned host memory (PA_PAGE_PINNED)."""
         self.stable = stable
+        self.pinned = pinned
         self.blocks = list(blocks)
         if position_count is None:
             position_count = self.blocks[0].position_count if self.blocks else 0
@@ -188,7 +190,7 @@ class Page:
         page.channel_count = len(self.blocks)
         page.columns = C.cast(cols, C.POINTER(abi.pa_column))
         page.mem = self.mem
-        page.flags = abi.PAGE_STABLE if self.stable else 0
+        page.flags = (abi.PAGE_STABLE if self.stable else 0) | (abi.PAGE_PINNED if self.pinned else 0)
         keep.append(cols)
         self._c = (page, keep)
         return self._c

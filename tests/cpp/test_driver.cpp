@@ -1,7 +1,8 @@
 // C++ driver test: runs the reference's operator known-answer cases through include/presto_amd.hpp (the C++ host
 // mirror) on the GPU, and checks them against the oracle (liboracle.so) on the same pages.
-//   fp-1   TestFilterAndProjectOperator.test   core/trino-main/src/test/java/io/trino/operator/TestFilterAndProjectOperator.java:71-112
-//   hagg   TestHashAggregationOperator (count/sum/avg over grouped sequence pages), :150-215
+//   fp-1   TestFilterAndProjectOperator.test   core/trino-main/src/test/java/io/trino/operator/TestFilterAndProjectOperator.java:78-124
+//   hagg-1 TestHashAggregationOperator.testHashAggregation   core/trino-main/src/test/java/io/trino/operator/TestHashAggregationOperator.java:160-219
+//   join-1 TestHashJoinOperator.testInnerJoin   core/trino-main/src/test/java/io/trino/operator/join/TestHashJoinOperator.java:192-229
 // plus a two-operator Driver pipeline FilterAndProject -> HashAggregation (Driver.java:355-457 call order).
 // Built by __graft_entry__.build(); executed by tests/test_gpu_cpp_driver.py.  Exit code 0 = all cases pass.
 #include <cmath>
@@ -35,13 +36,12 @@ static Page sequencePage(int32_t length, int64_t start)
     return Page({Block::varchar(s), Block::bigint(v)});
 }
 
-static Expr between(Expr value, Expr lo, Expr hi) { return specialForm(PA_FORM_BETWEEN, PA_BOOLEAN, {value, lo, hi}); }
-
-// fp-1: filter field1 BETWEEN 10 AND 19, projections (field0, field1 + 5) over sequence pages of 100 rows
+// fp-1, the reference's literal expressions (TestFilterAndProjectOperator.java:86-96): filter LESS_THAN_OR_EQUAL(field1, 9),
+// projections (field0, ADD(field1, 5)) over the sequence page (100, 0, 0) -- here handed over twice -> rows ("0", 5) .. ("9", 14)
 static void testFilterAndProject()
 {
     std::vector<int32_t> types = {PA_VARCHAR, PA_BIGINT};
-    Expr filter = between(field(1, PA_BIGINT), constantLong(10), constantLong(19));
+    Expr filter = call(PA_OP_LESS_THAN_OR_EQUAL, PA_BOOLEAN, {field(1, PA_BIGINT), constantLong(9)});
     std::vector<Expr> projections = {field(0, PA_VARCHAR), call(PA_OP_ADD, PA_BIGINT, {field(1, PA_BIGINT), constantLong(5)})};
     auto op = createFilterAndProjectOperator(types, filter, projections);
     std::vector<Page> input = {sequencePage(100, 0), sequencePage(100, 0)};
@@ -49,7 +49,7 @@ static void testFilterAndProject()
     int64_t rows = 0;
     for (const auto& p : out) {
         for (int32_t i = 0; i < p.getPositionCount(); i++, rows++) {
-            int64_t expect = 10 + (rows % 10);
+            int64_t expect = rows % 10;
             EXPECT(p.getBlock(0).getSlice(i) == std::to_string(expect), "fp-1 row %ld varchar %s", (long)rows, p.getBlock(0).getSlice(i).c_str());
             EXPECT(p.getBlock(1).getLong(i) == expect + 5, "fp-1 row %ld bigint %ld", (long)rows, (long)p.getBlock(1).getLong(i));
         }
@@ -175,6 +175,48 @@ static void testPipeline()
     }
 }
 
+// hagg-1: TestHashAggregationOperator.testHashAggregation (:160-219), the columns the device path covers: 3 sequence pages of
+// 40 000 rows (VARCHAR @100, VARCHAR @0 = the group key, VARCHAR @100000/200000/300000, BIGINT @0, BOOLEAN), aggregates
+// count(*), sum(bigint), avg(bigint), count(varchar), count(boolean) -> per key str(i): 3, 3 i, (double) i, 3, 3; the result
+// comes out in more than one page only on the reference (1 MB pages); compared ignoring order, as the reference does.
+static void testHashAggregationKat()
+{
+    const int32_t n = 40000;
+    std::vector<Page> input;
+    for (int p = 0; p < 3; p++) {
+        std::vector<std::string> a, key, c;
+        std::vector<int64_t> v;
+        std::vector<uint8_t> b;
+        for (int32_t i = 0; i < n; i++) {
+            a.push_back(std::to_string(100 + i));
+            key.push_back(std::to_string(i));
+            c.push_back(std::to_string(100000 * (p + 1) + i));
+            v.push_back(i);
+            b.push_back((uint8_t)((500 + i) % 2 == 0));  // SequencePageBuilder: BOOLEAN = (start + i) % 2 == 0
+        }
+        input.push_back(Page({Block::varchar(a), Block::varchar(key), Block::varchar(c), Block::bigint(v), Block::flat<uint8_t>(PA_BOOLEAN, b)}));
+    }
+    std::vector<int32_t> types = {PA_VARCHAR, PA_VARCHAR, PA_VARCHAR, PA_BIGINT, PA_BOOLEAN};
+    std::vector<pa_aggregate> aggs = {{PA_AGG_COUNT_STAR, -1, -1, PA_BIGINT}, {PA_AGG_SUM, 3, -1, PA_BIGINT}, {PA_AGG_AVG, 3, -1, PA_BIGINT},
+                                      {PA_AGG_COUNT, 0, -1, PA_VARCHAR}, {PA_AGG_COUNT, 4, -1, PA_BOOLEAN}};
+    auto agg = createHashAggregationOperator(types, {1}, aggs);
+    auto out = runDriver(input, {agg.get()});
+    std::map<std::string, int> seen;
+    int64_t rows = 0;
+    for (const auto& p : out) {
+        for (int32_t i = 0; i < p.getPositionCount(); i++, rows++) {
+            const std::string k = p.getBlock(0).getSlice(i);
+            const int64_t v = atoll(k.c_str());
+            EXPECT(seen[k]++ == 0, "hagg-1 duplicate key %s", k.c_str());
+            EXPECT(p.getBlock(1).getLong(i) == 3 && p.getBlock(2).getLong(i) == 3 * v && p.getBlock(3).getDouble(i) == (double)v &&
+                       p.getBlock(4).getLong(i) == 3 && p.getBlock(5).getLong(i) == 3,
+                   "hagg-1 key %s: %ld %ld %g %ld %ld", k.c_str(), (long)p.getBlock(1).getLong(i), (long)p.getBlock(2).getLong(i),
+                   p.getBlock(3).getDouble(i), (long)p.getBlock(4).getLong(i), (long)p.getBlock(5).getLong(i));
+        }
+    }
+    EXPECT(rows == n && (int64_t)seen.size() == n, "hagg-1 expected %d groups, got %ld", n, (long)rows);
+}
+
 // join-1: TestHashJoinOperator.testInnerJoin (core/trino-main/src/test/java/io/trino/operator/join/TestHashJoinOperator.java:192-229):
 // build (VARCHAR, BIGINT, BIGINT) sequence 10 rows @20,30,40; probe sequence 1000 rows @0,1000,2000; key channel 0.  Then the
 // same build probed with a probe-outer join, and a TopN over the join output (TestTopNOperator-style ordering).
@@ -266,6 +308,7 @@ int main()
         testFilterAndProject();
         testDivisionByZero();
         testPipeline();
+        testHashAggregationKat();
         testJoinAndTopN();
         testDynamicFilterSource();
         pa_shutdown();

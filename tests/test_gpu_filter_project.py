@@ -33,8 +33,8 @@ def bits(rows):
 
 
 def test_fp1_filter_and_project_kat(gpu, oracle):
-    """TestFilterAndProjectOperator.test (…/TestFilterAndProjectOperator.java:80-124): (VARCHAR,BIGINT) seq 0..99,
-    filter c1 <= 9 (BETWEEN 10 AND 19 on +10 in the original), project c0, c1 + 5."""
+    """TestFilterAndProjectOperator.test (…/TestFilterAndProjectOperator.java:78-124), the reference's literal expressions:
+    (VARCHAR, BIGINT) sequence page (100, 0, 0), filter LESS_THAN_OR_EQUAL(c1, 9), projections c0 and ADD(c1, 5)."""
     page = sequence_page(100, [(abi.VARCHAR, 0), (abi.BIGINT, 0)])
     f = field(1, abi.BIGINT) <= 9
     proj = [field(0, abi.VARCHAR), field(1, abi.BIGINT) + 5]

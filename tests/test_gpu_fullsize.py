@@ -37,7 +37,9 @@ def sub_pages(table, columns, first, count, page_rows=1 << 26):
 
 def run(op, pages):
     for p in pages:
-        assert op.needsInput()
+        while not op.needsInput():
+            # device work in flight: the Driver polls (Operator.isBlocked), as here; the launch may finish between the two calls
+            assert op.isBlocked() or op.needsInput()
         op.addInput(p)
     op.finish()
     out = op.getOutput()
@@ -168,3 +170,48 @@ def test_grouped_aggregation_over_a_full_size_page(gpu, groups):
     assert len(k) == int((expected > 0).sum()) and len(np.unique(k)) == len(k)
     assert np.array_equal(c, expected[k]) and int(c.sum()) == n
     assert np.array_equal(s, c * 0.5)
+
+
+# ---- BASELINE config #5's lineitem on one GPU: SF300, 1.80 G rows, 82.8 GB of Q1 / Q6 columns --------------------------------
+@pytest.fixture(scope="module")
+def lineitem300(gpu):
+    cols = sorted(set(tpch.Q1_COLUMNS + tpch.Q6_COLUMNS))
+    return tpch.DeviceColumns(cols, 300.0, tpch.lineitem_rows(300.0))
+
+
+def test_sf300_q6_q1_linearity_page_size_invariance_and_far_offset(lineitem300, oracle):
+    """The same size-independent properties at SF300 (row offsets beyond 2^30, 7 pages of 2^28 rows): linearity over disjoint
+    ranges, page-size invariance (2^28- vs 2^22-row pages, i.e. merged ranges vs many launches), bitwise reproducibility, and
+    a sample at the far end of the table row by row against the oracle."""
+    t = lineitem300
+    n = t.rows
+    assert n == 1_800_364_500
+    total, count = q6(t, 0, n, page_rows=1 << 28)
+    assert q6(t, 0, n, page_rows=1 << 28) == (total, count)
+    cuts = [0, (n // 5) - (n // 5) % 4, (1 << 30) + 4, n - 100_000_004, n]
+    parts = [q6(t, a, b - a, page_rows=1 << 27) for a, b in zip(cuts, cuts[1:])]
+    assert sum(c for _, c in parts) == count and close(sum(s for s, _ in parts), total)
+    s2, c2 = q6(t, 0, n, page_rows=1 << 22)
+    assert c2 == count and close(s2, total)
+    assert 0.015 < count / n < 0.025
+    whole = q1(t, 0, n, page_rows=1 << 28)
+    assert [r[:2] for r in whole] == [(b"A", b"F"), (b"N", b"F"), (b"N", b"O"), (b"R", b"F")]
+    half = (1 << 30) + 8
+    a, b = q1(t, 0, half, page_rows=1 << 27), q1(t, half, n - half, page_rows=1 << 24)
+    for w, x, y in zip(whole, a, b):
+        assert w[9] == x[9] + y[9]
+        assert all(close(w[k], x[k] + y[k]) for k in (2, 3, 4, 5))
+    assert sum(w[9] for w in whole) > 0.955 * n
+    # far end of the table against the oracle (generator rows depend on (seed, column, row, scale) only)
+    first, cnt = n - 300_003, 300_003
+    cols = [oracle.tpch_column(c, 300.0, first, cnt) for c in tpch.Q1_COLUMNS]
+    args = [cols[0][0], cols[0][1], cols[1][0], cols[1][1]] + [c[0] for c in cols[2:]]
+    expected = sorted(oracle.q1(args))
+    rows = q1(t, first, cnt)
+    assert len(rows) == len(expected)
+    for r, e in zip(rows, expected):
+        assert r[:2] == e[:2] and r[9] == e[9]
+        assert all(abs(x - y) <= 1e-9 * abs(y) for x, y in zip(r[2:9], e[2:9]))
+    s, c = q6(t, first, cnt)
+    es, ec = oracle.q6(*[oracle.tpch_column(col, 300.0, first, cnt)[0] for col in tpch.Q6_COLUMNS])
+    assert c == ec and abs(s - es) <= 1e-9 * abs(es)

@@ -124,3 +124,22 @@ def test_header_is_plain_c():
         subprocess.run(["gcc", "-std=c99", "-I", os.path.join(root, "include"), src, "-L", lib_dir, "-lpresto_amd",
                         "-Wl,-rpath," + lib_dir, "-Wl,--allow-shlib-undefined", "-o", exe], check=True)
         assert len(names) > 40
+
+
+def test_jni_shim_compiles_against_the_header_and_matches_the_java_natives():
+    """The JVM side (jni/presto_amd_jni.c, java/io/trino/gpu/*.java) cannot be built in this image (no JDK); what can drift
+    silently is the shim against include/presto_amd.h and the Java `native` declarations against the shim's exports.  The C
+    file is compiled (-fsyntax-only) against a stand-in jni.h holding the JNI types and the functions it uses, and the two
+    lists of native methods are compared."""
+    import re
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    shim = os.path.join(root, "jni", "presto_amd_jni.c")
+    subprocess.check_call(["gcc", "-fsyntax-only", "-Wall", "-Werror", "-I" + os.path.join(root, "jni", "stub"), "-I" + os.path.join(root, "include"), shim])
+    exported = set(re.findall(r"Java_io_trino_gpu_GpuNative_(\w+)\(", open(shim).read()))
+    declared = set(re.findall(r"static native [\w\[\]]+ (\w+)\(", open(os.path.join(root, "java", "io", "trino", "gpu", "GpuNative.java")).read()))
+    assert exported == declared and len(declared) > 25
+    # every C-ABI entry the shim calls is declared in the header (the compile above proves it) and exported by the library
+    from presto_amd._lib import lib
+    for sym in set(re.findall(r"\b(pa_[a-z0-9_]+)\(", open(shim).read())):
+        getattr(lib(), sym)

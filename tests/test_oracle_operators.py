@@ -10,9 +10,10 @@ from presto_amd.page import Block, Page, sequence_page
 
 
 def test_fp1_filter_and_project(oracle):
-    """TestFilterAndProjectOperator.test (…/operator/TestFilterAndProjectOperator.java:80-124)"""
+    """TestFilterAndProjectOperator.test (…/operator/TestFilterAndProjectOperator.java:78-124), the reference's literal
+    expressions: filter LESS_THAN_OR_EQUAL(field 1, 9), projections field 0 and ADD(field 1, 5)"""
     page = sequence_page(100, [(abi.VARCHAR, 0), (abi.BIGINT, 0)])
-    out = oracle.filter_project(page, field(1, abi.BIGINT).between(0, 9), [field(0, abi.VARCHAR), field(1, abi.BIGINT) + 5])
+    out = oracle.filter_project(page, field(1, abi.BIGINT) <= 9, [field(0, abi.VARCHAR), field(1, abi.BIGINT) + 5])
     assert out.to_rows() == [(str(i).encode(), i + 5) for i in range(10)]
 
 
