@@ -51,14 +51,18 @@ typedef enum pa_type {
     PA_DATE = 2,     /* IntArrayBlock, 4 B, days since 1970-01-01 */
     PA_DOUBLE = 3,   /* LongArrayBlock holding doubleToLongBits, 8 B */
     PA_BOOLEAN = 4,  /* ByteArrayBlock, 1 B */
-    PA_VARCHAR = 5   /* VariableWidthBlock: bytes + int32 offsets[positionCount+1] */
+    PA_VARCHAR = 5,  /* VariableWidthBlock: bytes + int32 offsets[positionCount+1] */
+    PA_ROW = 6       /* RowBlock of the fields' types (only as the intermediate state of an aggregate, PA_STATES_REFERENCE) */
 } pa_type;
 
 typedef enum pa_encoding {
     PA_FLAT = 0,        /* values[] (+array_offset), optional nulls[] */
     PA_VARWIDTH = 1,    /* values = bytes, offsets[positionCount+1] (already shifted by array_offset) */
     PA_DICTIONARY = 2,  /* ids[positionCount] into *dictionary */
-    PA_RLE = 3          /* *dictionary holds exactly one position, repeated positionCount times */
+    PA_RLE = 3,         /* *dictionary holds exactly one position, repeated positionCount times */
+    PA_ROW_FIELDS = 4   /* RowBlock (core/trino-spi/.../block/RowBlock.java): `dictionary` points at an ARRAY of dictionary_size
+                         * field blocks of positionCount positions each, `nulls` is rowIsNull (fields of a NULL row hold any
+                         * value); type == PA_ROW */
 } pa_encoding;
 
 typedef enum pa_mem {
@@ -165,6 +169,11 @@ typedef struct pa_aggregate {
 } pa_aggregate;
 
 typedef enum pa_agg_step { PA_STEP_SINGLE = 0, PA_STEP_PARTIAL = 1, PA_STEP_FINAL = 2 } pa_agg_step;
+/* How intermediate states cross the boundary (see the comment above pa_aggregation_desc). */
+typedef enum pa_state_format {
+    PA_STATES_FLAT = 0,      /* plain channels: [count] / [count, sum] / [count, value] */
+    PA_STATES_REFERENCE = 1  /* one channel per aggregate, typed as the reference's AccumulatorStateSerializer types it */
+} pa_state_format;
 
 /* ---- operator descriptors (what the planner hands to an OperatorFactory) ---- */
 
@@ -197,7 +206,21 @@ typedef struct pa_filter_project_desc {
  *   min(x), max(x)      ->  [count BIGINT, value of x's type, NULL while count = 0]   (BIGINT / INTEGER / DATE / DOUBLE / BOOLEAN)
  * PARTIAL emits keys, ($hashvalue), then these channels; FINAL takes them as input: pa_aggregate.input_channel names
  * the aggregate's count channel (the sum channel follows it), input_type the type of the sum, and it combines with the
- * @CombineFunction of the aggregate (DoubleSumAggregation.java:47-52 etc.). */
+ * @CombineFunction of the aggregate (DoubleSumAggregation.java:47-52 etc.).
+ *
+ * pa_hash_aggregation_desc.state_format = PA_STATES_REFERENCE switches both ends to the reference's own intermediate types, ONE
+ * channel per aggregate, so that a GPU PARTIAL step can feed a Java FINAL step across a real exchange and the reverse.  The
+ * types are what the generated AccumulatorStateSerializers produce (StateCompiler.java:127-185: one field -> that field's
+ * type; several -> an anonymous ROW of the fields sorted by name, :586-625):
+ *   count(*), count(x)     LongState                      BIGINT
+ *   sum(DOUBLE)            LongDoubleState (+ TwoNullableValueState)   ROW(first BIGINT = count, firstNull BOOLEAN, second DOUBLE = sum, secondNull BOOLEAN)
+ *   sum(BIGINT / INTEGER)  LongLongState   (+ TwoNullableValueState)   ROW(first BIGINT = count, firstNull BOOLEAN, second BIGINT = sum, secondNull BOOLEAN)
+ *                          (DoubleSumAggregation / LongSumAggregation never touch the two null flags: they keep their initial
+ *                          value true, and are ignored on input)
+ *   avg(x)                 LongAndDoubleState             ROW(double DOUBLE = sum, long BIGINT = count)
+ *   min(x), max(x)         NullableLongState / NullableDoubleState / NullableBooleanState with their hand-written serializers:
+ *                          BIGINT (also for INTEGER and DATE inputs: their Java type is long) / DOUBLE / BOOLEAN, NULL = no value
+ * With this format a FINAL step's pa_aggregate.input_channel names the aggregate's single state channel. */
 
 /* AggregationOperator (AggregationOperator.java:40-140): global aggregates. */
 typedef struct pa_aggregation_desc {
@@ -208,6 +231,8 @@ typedef struct pa_aggregation_desc {
     int32_t step;                        /* pa_agg_step */
     int32_t output_mem;
     void* stream;
+    int32_t state_format;                /* a pa_state_format value: PARTIAL output / FINAL input */
+    int32_t reserved;
 } pa_aggregation_desc;
 
 /* HashAggregationOperatorFactory (HashAggregationOperator.java:120-202). */
@@ -224,6 +249,16 @@ typedef struct pa_hash_aggregation_desc {
     int32_t expected_groups;
     int32_t output_mem;
     void* stream;
+    /* Step.PARTIAL only: maxPartialMemory (HashAggregationOperatorFactory, HashAggregationOperator.java:120-202; 16 MB by
+     * default in the reference).  Once the aggregation holds more than this the operator is "full"
+     * (InMemoryHashAggregationBuilder.updateIsFull, :208-215): needs_input turns false, get_output emits the partial result
+     * and the operator starts over with an empty table (HashAggregationOperator.java:372, 431, 501) -- a partial operator may
+     * emit a key more than once.  0 = never flush early.  The size counted is the groups' key and state bytes; the reference
+     * counts GroupByHash.getEstimatedSize(), a JVM-layout figure. */
+    int64_t max_partial_memory;
+    /* pa_state_format of the intermediate states a PARTIAL step emits / a FINAL step takes */
+    int32_t state_format;
+    int32_t reserved;
 } pa_hash_aggregation_desc;
 
 /* Fused pipeline: [Scan]FilterAndProject -> (Hash)AggregationOperator collapsed into one device
@@ -354,6 +389,13 @@ int32_t pa_host_free_pinned(void* ptr);
 int32_t pa_memcpy_h2d(void* dst, const void* src, int64_t bytes, void* stream);
 int32_t pa_memcpy_d2h(void* dst, const void* src, int64_t bytes, void* stream);
 int32_t pa_stream_synchronize(void* stream);
+/* The process's HBM budget for operator memory (the reference's memory pool, seen from the device): with a limit set, an
+ * allocation that would exceed it fails with PA_ERR_INSUFFICIENT_RESOURCES -- except that an aggregation operator given a
+ * PA_PAGE_STABLE page puts the page aside and reports pa_op_is_blocked() == 1 (needs_input 0) until other operators have
+ * released enough (Operator.isBlocked on the memory future, Operator.java:69-80; HashAggregationOperator.java:435-438).
+ * 0 = no limit.  pa_memory_stats: bytes held by operators, bytes cached for reuse, the limit. */
+int32_t pa_memory_set_limit(int64_t bytes);
+int32_t pa_memory_stats(int64_t* in_use, int64_t* cached, int64_t* limit);
 /* One HIP stream per Driver: operators chained through PA_MEM_DEVICE pages must be created with the same
  * desc.stream (stream order is what makes a producer's buffer reuse safe), as a Driver runs its operators on
  * one thread (Driver.java:284,317,357). */
@@ -565,6 +607,14 @@ int32_t pa_lookup_source_shared_key_bitmap(pa_lookup_source* source, pa_comm* co
 typedef struct pa_page_buffer pa_page_buffer;
 int64_t pa_page_serialize(const pa_page* page, void* out_host, int64_t capacity, void* stream);
 int32_t pa_page_deserialize(const void* bytes_host, int64_t size, void* stream, pa_page_buffer** out);
+/* The same frame with the payload as one LZ4 block and PageCodecMarker.COMPRESSED set, when that shrinks it to <= 0.8 of its
+ * size -- PagesSerde.serialize with a compressor (PagesSerde.java:74-95, MINIMUM_COMPRESSION_RATIO); otherwise the frame of
+ * pa_page_serialize.  pa_page_deserialize[_typed] read both (ENCRYPTED frames: PA_ERR_NOT_SUPPORTED). */
+int64_t pa_page_serialize_lz4(const pa_page* page, void* out_host, int64_t capacity, void* stream);
+/* pa_page_deserialize with the consumer's declared channel types: LONG_ARRAY blocks come back as BIGINT or DOUBLE, INT_ARRAY
+ * as INTEGER or DATE, as expected_types says; a block whose encoding cannot carry the declared type is refused. */
+int32_t pa_page_deserialize_typed(const void* bytes_host, int64_t size, const int32_t* expected_types, int32_t channel_count, void* stream,
+                                  pa_page_buffer** out);
 int32_t pa_page_buffer_page(pa_page_buffer* buffer, pa_page* out);
 int32_t pa_page_buffer_free(pa_page_buffer* buffer);
 

@@ -11,7 +11,7 @@ import numpy as np
 
 from presto_amd import abi
 from presto_amd.expr import serialize, serialize_many
-from presto_amd.page import Page, page_from_c
+from presto_amd.page import Block, Page, page_from_c
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
@@ -690,3 +690,170 @@ def deserialize_page(data):
         blocks.append(Block(t, abi.FLAT, n, values=values, nulls=nulls))
     assert pos == len(data)
     return Page(blocks, n)
+
+
+# ---- intermediate states in the reference's serialized form -----------------------------------------------------------------
+# The C restatement keeps Step.PARTIAL / FINAL states as plain channels ([count] / [count, value], presto_amd.h).  The
+# reference serialises ONE block per aggregate, typed by the aggregate's AccumulatorStateSerializer
+# (core/trino-main/src/main/java/io/trino/operator/aggregation/state/StateCompiler.java:127-185; fields of a generated
+# serializer sorted by name, :586-625):
+#   count            LongState                               -> BIGINT
+#   sum(DOUBLE)      LongDoubleState + TwoNullableValueState -> ROW(first BIGINT, firstNull BOOLEAN, second DOUBLE, secondNull BOOLEAN)
+#   sum(BIGINT)      LongLongState + TwoNullableValueState   -> ROW(first BIGINT, firstNull BOOLEAN, second BIGINT, secondNull BOOLEAN)
+#                    (…/aggregation/DoubleSumAggregation.java:33-63 / LongSumAggregation.java:34-64 never set the two null
+#                    flags: they keep TwoNullableValueState's initial value true, minmaxby/TwoNullableValueState.java)
+#   avg              LongAndDoubleState                      -> ROW(double DOUBLE, long BIGINT)   (…/state/LongAndDoubleState.java)
+#   min / max        NullableLongState / NullableDoubleState / NullableBooleanState with their own serializers
+#                    (…/state/NullableLongStateSerializer.java: BIGINT, NULL when state.isNull()) -- a long for INTEGER / DATE too
+def states_to_reference(page, leading, aggregates):
+    """Flat PARTIAL output page -> the reference's form.  aggregates: (fn, input channel, input type[, mask])."""
+    blocks = list(page.blocks[:leading])
+    n = page.position_count
+    at = leading
+    for a in aggregates:
+        fn, in_type = a[0], a[2]
+        cnt = page.blocks[at]
+        if fn in (abi.AGG_COUNT, abi.AGG_COUNT_STAR):
+            blocks.append(cnt)
+            at += 1
+            continue
+        val = page.blocks[at + 1]
+        at += 2
+        true = Block.boolean(np.ones(n, dtype=np.uint8))
+        if fn == abi.AGG_SUM:
+            blocks.append(Block.row([Block.bigint(cnt.values), true, Block.flat(val.type, val.values), true]))
+        elif fn == abi.AGG_AVG:
+            blocks.append(Block.row([Block.double(val.values), Block.bigint(cnt.values)]))
+        else:
+            if in_type in (abi.INTEGER, abi.DATE):
+                val = Block.flat(abi.BIGINT, np.asarray(val.values).astype(np.int64), val.nulls)
+            blocks.append(val)
+    return Page(blocks, n)
+
+
+def states_from_reference(page, leading, aggregates):
+    """The reverse: the reference's form -> the flat channels a Step.FINAL restatement takes."""
+    blocks = list(page.blocks[:leading])
+    n = page.position_count
+    for k, a in enumerate(aggregates):
+        fn, in_type = a[0], a[2]
+        b = page.blocks[leading + k]
+        if fn in (abi.AGG_COUNT, abi.AGG_COUNT_STAR):
+            blocks.append(b)
+        elif fn == abi.AGG_SUM:
+            blocks += [b.fields[0], b.fields[2]]
+        elif fn == abi.AGG_AVG:
+            blocks += [b.fields[1], b.fields[0]]
+        else:
+            nulls = np.zeros(n, dtype=np.uint8) if b.nulls is None else np.asarray(b.nulls)
+            blocks.append(Block.bigint((nulls == 0).astype(np.int64)))
+            if in_type in (abi.INTEGER, abi.DATE):
+                b = Block.flat(in_type, np.asarray(b.values).astype(np.int32), b.nulls)
+            blocks.append(b)
+    return Page(blocks, n)
+
+
+# ---- LZ4 block format (PagesSerde's compressor: io.airlift:aircompressor Lz4Compressor / Lz4Decompressor, un-vendored) ------
+# Restated from the public LZ4 block-format description, independently of presto_amd/csrc/page_serde.cpp; pure Python, for
+# test-sized inputs.  A block is a run of sequences: token (literal length << 4 | match length - 4), literal-length extension
+# bytes (255 ... < 255) when the nibble is 15, the literals, a 2-byte little-endian match offset, match-length extension bytes
+# when the nibble is 15; the last sequence stops after its literals.
+def lz4_decompress(data, uncompressed_size):
+    data = bytes(data)
+    out = bytearray()
+    i = 0
+    while i < len(data):
+        token = data[i]
+        i += 1
+        lit = token >> 4
+        if lit == 15:
+            while True:
+                b = data[i]
+                i += 1
+                lit += b
+                if b != 255:
+                    break
+        out += data[i:i + lit]
+        i += lit
+        if i >= len(data):
+            break
+        offset = data[i] | (data[i + 1] << 8)
+        i += 2
+        assert 0 < offset <= len(out), "bad match offset"
+        ml = token & 15
+        if ml == 15:
+            while True:
+                b = data[i]
+                i += 1
+                ml += b
+                if b != 255:
+                    break
+        ml += 4
+        for _ in range(ml):   # overlapping copy: byte by byte
+            out.append(out[-offset])
+    assert len(out) == uncompressed_size, (len(out), uncompressed_size)
+    return bytes(out)
+
+
+def lz4_compress(data):
+    """A greedy encoder of the same format (another encoder than the library's: the decoder must not depend on whose output it reads)."""
+    data = bytes(data)
+    n = len(data)
+    out = bytearray()
+
+    def emit(lit, match_len, offset):
+        token_at = len(out)
+        out.append(0)
+        ll = len(lit)
+        if ll >= 15:
+            out[token_at] = 15 << 4
+            rest = ll - 15
+            while rest >= 255:
+                out.append(255)
+                rest -= 255
+            out.append(rest)
+        else:
+            out[token_at] = ll << 4
+        out.extend(lit)
+        if match_len == 0:
+            return
+        out.append(offset & 255)
+        out.append(offset >> 8)
+        m = match_len - 4
+        if m >= 15:
+            out[token_at] |= 15
+            rest = m - 15
+            while rest >= 255:
+                out.append(255)
+                rest -= 255
+            out.append(rest)
+        else:
+            out[token_at] |= m
+
+    anchor = i = 0
+    last = {}
+    while n >= 13 and i < n - 12:
+        key = data[i:i + 4]
+        cand = last.get(key)
+        last[key] = i
+        if cand is None or i - cand > 65535:
+            i += 1
+            continue
+        j = i + 4
+        while j < n - 5 and data[j] == data[cand + (j - i)]:
+            j += 1
+        emit(data[anchor:i], j - i, i - cand)
+        i = anchor = j
+    emit(data[anchor:], 0, 0)
+    return bytes(out)
+
+
+def compress_frame(frame):
+    """An uncompressed SerializedPage frame -> the COMPRESSED one a Java worker with a compressor would send (if it pays)."""
+    import struct
+    positions, markers, uncompressed, size = struct.unpack_from("<ibii", frame, 0)
+    assert markers == 0 and uncompressed == size
+    packed = lz4_compress(frame[13:])
+    if len(packed) / max(uncompressed, 1) > 0.8:   # PagesSerde.java:84 MINIMUM_COMPRESSION_RATIO
+        return frame
+    return struct.pack("<ibii", positions, 1, uncompressed, len(packed)) + packed

@@ -42,6 +42,8 @@ def lib():
     L.pa_memcpy_h2d.argtypes = [vp, vp, C.c_int64, vp]
     L.pa_memcpy_d2h.argtypes = [vp, vp, C.c_int64, vp]
     L.pa_stream_synchronize.argtypes = [vp]
+    L.pa_memory_set_limit.argtypes = [C.c_int64]
+    L.pa_memory_stats.argtypes = [C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     L.pa_stream_create.argtypes = [C.POINTER(vp)]
     L.pa_stream_destroy.argtypes = [vp]
     L.pa_filter_project_create.argtypes = [C.POINTER(abi.pa_filter_project_desc), C.POINTER(vp)]
@@ -92,6 +94,9 @@ def lib():
     L.pa_page_serialize.argtypes = [C.POINTER(abi.pa_page), vp, C.c_int64, vp]
     L.pa_page_serialize.restype = C.c_int64
     L.pa_page_deserialize.argtypes = [vp, C.c_int64, vp, C.POINTER(vp)]
+    L.pa_page_serialize_lz4.argtypes = [C.POINTER(abi.pa_page), vp, C.c_int64, vp]
+    L.pa_page_serialize_lz4.restype = C.c_int64
+    L.pa_page_deserialize_typed.argtypes = [vp, C.c_int64, C.POINTER(C.c_int32), C.c_int32, vp, C.POINTER(vp)]
     L.pa_page_buffer_page.argtypes = [vp, C.POINTER(abi.pa_page)]
     L.pa_page_buffer_free.argtypes = [vp]
     L.pa_comm_unique_id.argtypes = [vp]

@@ -26,12 +26,12 @@ STATUS_NAMES = {
 }
 
 # pa_type
-BIGINT, INTEGER, DATE, DOUBLE, BOOLEAN, VARCHAR = range(6)
-TYPE_NAMES = ["BIGINT", "INTEGER", "DATE", "DOUBLE", "BOOLEAN", "VARCHAR"]
-TYPE_WIDTH = {BIGINT: 8, INTEGER: 4, DATE: 4, DOUBLE: 8, BOOLEAN: 1, VARCHAR: 0}
+BIGINT, INTEGER, DATE, DOUBLE, BOOLEAN, VARCHAR, ROW = range(7)
+TYPE_NAMES = ["BIGINT", "INTEGER", "DATE", "DOUBLE", "BOOLEAN", "VARCHAR", "ROW"]
+TYPE_WIDTH = {BIGINT: 8, INTEGER: 4, DATE: 4, DOUBLE: 8, BOOLEAN: 1, VARCHAR: 0, ROW: 0}
 
 # pa_encoding
-FLAT, VARWIDTH, DICTIONARY, RLE = range(4)
+FLAT, VARWIDTH, DICTIONARY, RLE, ROW_FIELDS = range(5)
 # pa_mem
 MEM_HOST, MEM_DEVICE = 0, 1
 # pa_expr_kind
@@ -197,6 +197,8 @@ class pa_aggregation_desc(C.Structure):
         ("step", C.c_int32),
         ("output_mem", C.c_int32),
         ("stream", C.c_void_p),
+        ("state_format", C.c_int32),
+        ("reserved", C.c_int32),
     ]
 
 
@@ -214,7 +216,13 @@ class pa_hash_aggregation_desc(C.Structure):
         ("expected_groups", C.c_int32),
         ("output_mem", C.c_int32),
         ("stream", C.c_void_p),
+        ("max_partial_memory", C.c_int64),
+        ("state_format", C.c_int32),
+        ("reserved", C.c_int32),
     ]
+
+
+STATES_FLAT, STATES_REFERENCE = 0, 1
 
 
 class pa_fused_aggregation_desc(C.Structure):

@@ -218,6 +218,22 @@ int32_t pa_stream_synchronize(void* stream)
     });
 }
 
+int32_t pa_memory_set_limit(int64_t bytes)
+{
+    return guarded([&]() -> int32_t {
+        PA_REQUIRE(bytes >= 0, PA_ERR_INVALID_ARGUMENT, "negative limit");
+        pool_set_limit(bytes);
+        return PA_OK;
+    });
+}
+int32_t pa_memory_stats(int64_t* in_use, int64_t* cached, int64_t* limit)
+{
+    return guarded([&]() -> int32_t {
+        pool_stats(in_use, cached, limit);
+        return PA_OK;
+    });
+}
+
 int32_t pa_stream_create(void** stream)
 {
     return guarded([&]() -> int32_t {
@@ -253,9 +269,20 @@ int32_t pa_fused_aggregation_create(const pa_fused_aggregation_desc* desc, pa_op
 
 // AggregationOperator / HashAggregationOperator on their own = the fused operator with an empty filter
 // and identity projections over the input channels.
+static pa_operator* plain_aggregation(const pa_hash_aggregation_desc* agg);
 static int32_t create_plain_aggregation(const pa_hash_aggregation_desc* agg, pa_operator** out)
 {
     PA_REQUIRE(agg != nullptr && out != nullptr, PA_ERR_INVALID_ARGUMENT, "null argument");
+    if (agg->state_format == PA_STATES_REFERENCE && agg->step != PA_STEP_SINGLE) {
+        *out = make_aggregation_with_reference_states(agg, &plain_aggregation);
+        return PA_OK;
+    }
+    PA_REQUIRE(agg->state_format == PA_STATES_FLAT || agg->state_format == PA_STATES_REFERENCE, PA_ERR_INVALID_ARGUMENT, "unknown state format");
+    *out = plain_aggregation(agg);
+    return PA_OK;
+}
+static pa_operator* plain_aggregation(const pa_hash_aggregation_desc* agg)
+{
     int n = agg->input_channel_count;
     PA_REQUIRE(n > 0, PA_ERR_INVALID_ARGUMENT, "aggregation needs input channels");
     std::vector<pa_expr_node> nodes(n);
@@ -282,8 +309,8 @@ static int32_t create_plain_aggregation(const pa_hash_aggregation_desc* agg, pa_
     d.filter_project.output_mem = agg->output_mem;
     d.filter_project.stream = agg->stream;
     d.aggregation = *agg;
-    *out = make_fused_aggregation(&d);
-    return PA_OK;
+    d.aggregation.state_format = PA_STATES_FLAT;
+    return make_fused_aggregation(&d);
 }
 
 int32_t pa_hash_aggregation_create(const pa_hash_aggregation_desc* desc, pa_operator** out)
@@ -306,6 +333,7 @@ int32_t pa_aggregation_create(const pa_aggregation_desc* desc, pa_operator** out
         h.aggregates = desc->aggregates;
         h.output_mem = desc->output_mem;
         h.stream = desc->stream;
+        h.state_format = desc->state_format;
         return create_plain_aggregation(&h, out);
     });
 }
@@ -568,16 +596,34 @@ int64_t pa_page_serialize(const pa_page* page, void* out_host, int64_t capacity,
 {
     int64_t written = 0;
     int32_t rc = guarded([&]() -> int32_t {
-        written = serialize_page(page, out_host, capacity, static_cast<hipStream_t>(stream));
+        written = serialize_page(page, out_host, capacity, static_cast<hipStream_t>(stream), false);
         return PA_OK;
     });
     return rc < 0 ? (int64_t)rc : written;
+}
+int64_t pa_page_serialize_lz4(const pa_page* page, void* out_host, int64_t capacity, void* stream)
+{
+    int64_t written = 0;
+    int32_t rc = guarded([&]() -> int32_t {
+        written = serialize_page(page, out_host, capacity, static_cast<hipStream_t>(stream), true);
+        return PA_OK;
+    });
+    return rc < 0 ? (int64_t)rc : written;
+}
+int32_t pa_page_deserialize_typed(const void* bytes_host, int64_t size, const int32_t* expected_types, int32_t channel_count, void* stream,
+                                  pa_page_buffer** out)
+{
+    return guarded([&]() -> int32_t {
+        PA_REQUIRE(out != nullptr && expected_types != nullptr, PA_ERR_INVALID_ARGUMENT, "null argument");
+        *out = deserialize_page(bytes_host, size, static_cast<hipStream_t>(stream), expected_types, channel_count);
+        return PA_OK;
+    });
 }
 int32_t pa_page_deserialize(const void* bytes_host, int64_t size, void* stream, pa_page_buffer** out)
 {
     return guarded([&]() -> int32_t {
         PA_REQUIRE(out != nullptr, PA_ERR_INVALID_ARGUMENT, "null argument");
-        *out = deserialize_page(bytes_host, size, static_cast<hipStream_t>(stream));
+        *out = deserialize_page(bytes_host, size, static_cast<hipStream_t>(stream), nullptr, 0);
         return PA_OK;
     });
 }

@@ -52,6 +52,17 @@ inline int type_width(int32_t t)
     }
 }
 
+// Thrown by pool_device_alloc when the HBM budget (pa_memory_set_limit) does not cover the request: the counterpart of a memory
+// reservation the reference's memory pool cannot grant right now (OperatorContext.isWaitingForMemory, Operator.java:69-80) --
+// an operator that can put its page aside reports is_blocked until other operators have released memory.
+struct PoolExhausted : Error {
+    size_t bytes;
+    explicit PoolExhausted(size_t b) : Error(PA_ERR_INSUFFICIENT_RESOURCES, "HBM budget of the process exhausted (pa_memory_set_limit)"), bytes(b) {}
+};
+void pool_set_limit(int64_t bytes);              // 0 = unlimited
+bool pool_has_room(size_t bytes);                 // would a request of this size be granted now?
+void pool_stats(int64_t* in_use, int64_t* cached, int64_t* limit);
+
 // size-class caches (pool.cpp)
 void* pool_device_alloc(size_t bytes, size_t* granted);
 void pool_device_free(void* ptr, size_t granted);
@@ -208,7 +219,9 @@ public:
             }
         }
         PA_HIP(hipEventRecord(pairs_[next_].first, s));
+        begun_++;
     }
+    uint64_t begun() const { return begun_; }  // timed launches started so far
     // dominant = false: the time still counts, the launch does not (e.g. the few-row tail launch of a page)
     void end(hipStream_t s, bool dominant = true)
     {
@@ -235,6 +248,7 @@ private:
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pairs_;
     std::vector<char> minor_;
     size_t next_ = 0;
+    uint64_t begun_ = 0;
     double total_ms_ = 0;
     int64_t launches_ = 0;
 };

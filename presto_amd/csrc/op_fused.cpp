@@ -109,6 +109,7 @@ struct Spec {
     int hash_channel = -1;
     std::vector<pa_aggregate> aggs;
     int expected_groups = 0;
+    int64_t max_partial_memory = 0;
     int step = PA_STEP_SINGLE;
     int output_mem = PA_MEM_HOST;
     std::vector<bool> used_channel;
@@ -195,6 +196,8 @@ Spec make_spec(const pa_fused_aggregation_desc* d)
         s.aggs.push_back(a);
     }
     s.expected_groups = ag.expected_groups;
+    PA_REQUIRE(ag.max_partial_memory >= 0, PA_ERR_INVALID_ARGUMENT, "maxPartialMemory must not be negative");
+    s.max_partial_memory = ag.step == PA_STEP_PARTIAL ? ag.max_partial_memory : 0;
     s.output_mem = ag.output_mem;
     finalize_spec(s);
     return s;
@@ -928,15 +931,57 @@ public:
     bool needs_input() override
     {
         if (finishing_) return false;
+        if (!retry_parked()) return false;
         if (next_) return next_->needs_input();
         poll_inflight();
         return inflight_.size() < kMaxInflight;
     }
     bool is_blocked() override
     {
+        if (!retry_parked()) return true;  // waiting for HBM (Operator.isBlocked on a memory future, Operator.java:69-80)
         if (next_) return next_->is_blocked();
         poll_inflight();
         return inflight_.size() >= kMaxInflight;
+    }
+
+    // A stable page the HBM budget had no room for is put aside whole (HashAggregationOperator's unfinishedWork,
+    // HashAggregationOperator.java:435-438, 476-484) and taken up again once the pool can grant the request that failed.
+    // true: nothing is parked (any more)
+    bool retry_parked()
+    {
+        if (!parked_) return true;
+        if (!pool_has_room(parked_need_)) return false;
+        parked_ = false;
+        pa_page page = parked_page_;
+        page.columns = parked_cols_.data();
+        take_page(&page);
+        return !parked_;
+    }
+
+    void take_page(const pa_page* page)
+    {
+        const uint64_t launched = timer.begun();
+        try {
+            if (next_) {
+                next_->add_input(page);
+                return;
+            }
+            if (gather_small_page(page)) return;
+            flush_pending();
+            if (next_) {  // the flush met a layout change and started the next generation: the page belongs there
+                next_->add_input(page);
+                return;
+            }
+            process_page(page, (page->flags & PA_PAGE_STABLE) != 0 && page->mem == PA_MEM_DEVICE);
+        }
+        catch (const PoolExhausted& e) {
+            // only a page that can be read again later, and of which nothing has been launched, can wait
+            if ((page->flags & PA_PAGE_STABLE) == 0 || timer.begun() != launched || is_combiner_) throw;
+            parked_page_ = *page;
+            parked_cols_.assign(page->columns, page->columns + page->channel_count);
+            parked_need_ = e.bytes;
+            parked_ = true;
+        }
     }
 
     void add_input(const pa_page* page) override
@@ -945,17 +990,8 @@ public:
         PA_REQUIRE(page != nullptr, PA_ERR_INVALID_ARGUMENT, "page is null");
         PA_REQUIRE(page->channel_count == spec_.n_in, PA_ERR_INVALID_ARGUMENT, "page channel count does not match the operator's input types");
         if (page->position_count == 0) return;
-        if (next_) {
-            next_->add_input(page);
-            return;
-        }
-        if (gather_small_page(page)) return;
-        flush_pending();
-        if (next_) {  // the flush met a layout change and started the next generation: the page belongs there
-            next_->add_input(page);
-            return;
-        }
-        process_page(page, (page->flags & PA_PAGE_STABLE) != 0 && page->mem == PA_MEM_DEVICE);
+        PA_REQUIRE(!parked_, PA_ERR_ILLEGAL_STATE, "Operator has unfinished work");  // HashAggregationOperator.java:384
+        take_page(page);
     }
 
     // One page (or gathered range of pages) through the kernels; `retained`: its buffers stay valid until the operator has
@@ -1319,6 +1355,7 @@ public:
     void finish() override
     {
         if (finishing_) return;
+        PA_REQUIRE(retry_parked(), PA_ERR_INSUFFICIENT_RESOURCES, "finish while a page is still waiting for HBM: the pool's budget does not cover the aggregation");
         flush_pending();
         finishing_ = true;
     }
@@ -1422,6 +1459,22 @@ public:
     {
         return (int64_t)(stager_.bytes() + slab_.capacity() + gt_tag_.capacity() + gt_keys_.capacity() + gt_words_.capacity() + state_.capacity());
     }
+
+    // What isFull() compares with maxPartialMemory: the groups known so far x the bytes of a group's key and state words (and
+    // its table slot), over all generations.  Launches still unconfirmed are not counted yet.
+    int64_t group_bytes()
+    {
+        // rows gathered but not launched, or launched but not confirmed, count as one group each (an upper bound: an early
+        // flush of a partial aggregation only costs repeated keys)
+        int64_t pending = run_.rows + arena_[arena_cur_].rows;
+        for (const Inflight& f : inflight_) pending += f.dp.n - f.offset;
+        const int64_t slot = 8 * (1 + std::max(w_, 1) + std::max(nw_, 1));
+        int64_t b = ((int64_t)std::max(groups_upper_, groups_sum_) + pending) * slot;
+        if (next_) b += next_->group_bytes();
+        return b;
+    }
+    const Spec& spec() const { return spec_; }
+    void* stream_handle() { return stream_.get(); }
 
 private:
     // One code object + word-kind table per (plan fingerprint, column-layout signature, variant, device), shared by every
@@ -2022,6 +2075,10 @@ private:
     bool gt_probed_ = false, lds_probed_ = false;
     int64_t resume_from_ = -1;
     bool retained_ = false;               // the page being processed stays readable until its launches are confirmed
+    bool parked_ = false;                 // a stable page waits for HBM (see retry_parked)
+    pa_page parked_page_{};
+    std::vector<pa_column> parked_cols_;
+    size_t parked_need_ = 0;
     std::deque<Inflight> inflight_;       // few-groups launches not confirmed yet (at most kMaxInflight)
     const std::string* cur_sig_ = nullptr;                  // signature / layout of the page run_page works on
     const std::vector<ChannelLayout>* cur_layout_ = nullptr;
@@ -2587,9 +2644,62 @@ void FusedAggregationOperator::build_output()
 
 }  // namespace
 
+// Step.PARTIAL with maxPartialMemory: HashAggregationOperator's flush state machine (HashAggregationOperator.java:366-378,
+// 476-513) around the aggregation.  "Full" -> no input is taken; get_output builds the partial result of what was
+// aggregated so far (closeAggregationBuilder, :532-543) and the next page starts an empty aggregation -- here a fresh
+// FusedAggregationOperator over the same plan (its kernels are cached per plan, its buffers pooled); the one that emitted stays
+// alive until the next call, as its output page does.
+class PartialFlushingAggregationOperator : public pa_operator {
+public:
+    explicit PartialFlushingAggregationOperator(const pa_fused_aggregation_desc* d) : cur_(std::make_unique<FusedAggregationOperator>(d)) {}
+    hipStream_t private_stream() override { return cur_->private_stream(); }
+    hipStream_t main_stream() override { return cur_->main_stream(); }
+    bool needs_input() override { return !finishing_ && !full_ && cur_->needs_input(); }
+    bool is_blocked() override { return !full_ && cur_->is_blocked(); }
+    void add_input(const pa_page* page) override
+    {
+        PA_REQUIRE(!finishing_, PA_ERR_ILLEGAL_STATE, "Operator is already finishing");
+        PA_REQUIRE(!full_, PA_ERR_ILLEGAL_STATE, "Aggregation buffer is full");  // HashAggregationOperator.java:425
+        emitted_.reset();
+        cur_->add_input(page);
+        full_ = cur_->group_bytes() > cur_->spec().max_partial_memory;  // InMemoryHashAggregationBuilder.updateIsFull
+    }
+    bool get_output(pa_page* out) override
+    {
+        if (finishing_) return cur_->get_output(out);
+        if (!full_) return false;  // only flush when finishing or full (:497-499)
+        cur_->finish();
+        const bool any = cur_->get_output(out);
+        if (hipStream_t own = cur_->private_stream()) PA_HIP(hipStreamSynchronize(own));  // the page of an operator about to be parked
+        Spec spec = cur_->spec();
+        void* stream = cur_->stream_handle();
+        flushes_++;
+        emitted_ = std::move(cur_);
+        cur_ = std::make_unique<FusedAggregationOperator>(std::move(spec), emitted_->private_stream() ? nullptr : stream);
+        full_ = false;
+        return any;
+    }
+    void finish() override
+    {
+        if (finishing_) return;
+        finishing_ = true;
+        cur_->finish();
+    }
+    bool is_finished() override { return finishing_ && cur_->is_finished(); }
+    int64_t memory_bytes() override { return cur_->memory_bytes() + (emitted_ ? emitted_->memory_bytes() : 0); }
+
+private:
+    std::unique_ptr<FusedAggregationOperator> cur_, emitted_;
+    bool finishing_ = false, full_ = false;
+    int64_t flushes_ = 0;
+};
+
 pa_operator* make_fused_aggregation(const pa_fused_aggregation_desc* desc)
 {
     PA_REQUIRE(desc != nullptr, PA_ERR_INVALID_ARGUMENT, "descriptor is null");
+    if (desc->aggregation.step == PA_STEP_PARTIAL && desc->aggregation.max_partial_memory > 0 && desc->aggregation.group_by_count > 0) {
+        return new PartialFlushingAggregationOperator(desc);
+    }
     return new FusedAggregationOperator(desc);
 }
 

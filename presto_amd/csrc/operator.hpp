@@ -52,6 +52,9 @@ void filter_project_set_dynamic_filter(pa_operator* op, int channel, const uint6
 pa_operator* make_dynamic_filter_source(const pa_dynamic_filter_source_desc* desc);
 int32_t dynamic_filter_poll(pa_operator* op, int32_t* is_all, pa_domain* domains, int32_t capacity);
 
+// (Hash)AggregationOperator over plain channels with the reference's intermediate-state format at its PARTIAL output / FINAL
+// input: the flat-format operator `make_flat` builds, inside an adapter (op_states.cpp)
+pa_operator* make_aggregation_with_reference_states(const pa_hash_aggregation_desc* agg, pa_operator* (*make_flat)(const pa_hash_aggregation_desc*));
 // partitioned exchange (op_exchange.cpp)
 pa_exchange* exchange_new(const pa_exchange_desc* desc, pa_comm* comm);
 void exchange_delete(pa_exchange* ex);
@@ -63,8 +66,8 @@ bool lookup_source_shared_bitmap(pa_lookup_source* ls, pa_comm* comm, bool parti
                                  uint64_t* range);
 
 // page wire format (page_serde.cpp)
-int64_t serialize_page(const pa_page* page, void* out_host, int64_t capacity, hipStream_t s);
-pa_page_buffer* deserialize_page(const void* bytes, int64_t size, hipStream_t s);
+int64_t serialize_page(const pa_page* page, void* out_host, int64_t capacity, hipStream_t s, bool compress);
+pa_page_buffer* deserialize_page(const void* bytes, int64_t size, hipStream_t s, const int32_t* expected_types, int32_t expected_count);
 void page_buffer_page(pa_page_buffer* buffer, pa_page* out);
 void page_buffer_free(pa_page_buffer* buffer);
 

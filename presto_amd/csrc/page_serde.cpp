@@ -9,7 +9,12 @@
 //                          NULL array, else nonNullCount int + the non-null values only
 //     VARIABLE_WIDTH       VariableWidthBlockEncoding.java:37-58: positionCount int, the END offset of every position (ints),
 //                          nulls as bits, totalLength int, the bytes
-// Uncompressed, unencrypted, no checksum (markers = 0): LZ4 / AES / XXH64 framing stay with the Java PagesSerde.
+// Markers (PageCodecMarker.java:27-30): COMPRESSED = the payload is one LZ4 block (PagesSerde.java:74-95: kept only when it
+// shrinks the payload to <= 0.8 of its size); ENCRYPTED (the spill cipher) stays with the Java PagesSerde.  The LZ4 block codec
+// below is written from the public block-format description (token = literal length << 4 | match length - 4, 255-extension
+// bytes, 2-byte little-endian offsets, last 5 bytes literal, last match starting >= 12 bytes before the end): any decoder of the
+// format -- airlift's Lz4Decompressor on the Java side -- reads what it writes, and it reads any encoder's output.  It runs on
+// the host: the frame is host memory on its way to / from the network.
 // Device side: null bytes <-> bits, compaction / re-expansion of the non-null values (stable partition + gather / scatter),
 // offset re-basing; the host only writes the handful of header ints and moves each segment with one copy.
 #include <cstring>
@@ -45,6 +50,114 @@ struct Writer {
     uint8_t* reserve(int64_t n) { need(n); uint8_t* p = base + pos; pos += n; return p; }
 };
 
+// ---- LZ4 block format ----
+int64_t lz4_max_compressed(int64_t n) { return n + n / 255 + 16; }
+
+int64_t lz4_compress(const uint8_t* src, int64_t n, uint8_t* dst, int64_t cap)
+{
+    const uint8_t* const end = src + n;
+    uint8_t* op = dst;
+    uint8_t* const oend = dst + cap;
+    const uint8_t* anchor = src;
+    auto emit = [&](const uint8_t* lit, int64_t lit_len, int64_t match_len, int offset) -> bool {
+        if (op + 1 + lit_len + lit_len / 255 + 8 + match_len / 255 > oend) return false;
+        uint8_t* token = op++;
+        int64_t l = lit_len;
+        if (l >= 15) {
+            *token = 15 << 4;
+            for (l -= 15; l >= 255; l -= 255) *op++ = 255;
+            *op++ = (uint8_t)l;
+        }
+        else *token = (uint8_t)(l << 4);
+        memcpy(op, lit, (size_t)lit_len);
+        op += lit_len;
+        if (match_len == 0) return true;  // final literals
+        *op++ = (uint8_t)(offset & 255);
+        *op++ = (uint8_t)(offset >> 8);
+        int64_t m = match_len - 4;
+        if (m >= 15) {
+            *token |= 15;
+            for (m -= 15; m >= 255; m -= 255) *op++ = 255;
+            *op++ = (uint8_t)m;
+        }
+        else *token |= (uint8_t)m;
+        return true;
+    };
+    if (n >= 13) {
+        std::vector<int32_t> table(1 << 14, -1);
+        const uint8_t* ip = src;
+        const uint8_t* const mflimit = end - 12;   // a match may not start later
+        const uint8_t* const matchlimit = end - 5; // ... nor reach into the last 5 bytes
+        while (ip < mflimit) {
+            uint32_t v;
+            memcpy(&v, ip, 4);
+            const uint32_t h = (v * 2654435761u) >> 18;
+            const int32_t cand = table[h];
+            table[h] = (int32_t)(ip - src);
+            uint32_t cv = 0;
+            if (cand >= 0) memcpy(&cv, src + cand, 4);
+            if (cand < 0 || cv != v || (ip - src) - cand > 65535) {
+                ip++;
+                continue;
+            }
+            const uint8_t* m = src + cand;
+            const uint8_t* p = ip + 4;
+            const uint8_t* q = m + 4;
+            while (p < matchlimit && *p == *q) { p++; q++; }
+            if (!emit(anchor, ip - anchor, p - ip, (int)(ip - m))) return -1;
+            ip = p;
+            anchor = ip;
+        }
+    }
+    if (!emit(anchor, end - anchor, 0, 0)) return -1;
+    return op - dst;
+}
+
+// returns the decompressed size, or -1 for a malformed block / one that does not fit dst
+int64_t lz4_decompress(const uint8_t* src, int64_t n, uint8_t* dst, int64_t cap)
+{
+    const uint8_t* ip = src;
+    const uint8_t* const iend = src + n;
+    uint8_t* op = dst;
+    uint8_t* const oend = dst + cap;
+    while (ip < iend) {
+        const uint8_t token = *ip++;
+        int64_t lit = token >> 4;
+        if (lit == 15) {
+            uint8_t b;
+            do {
+                if (ip >= iend) return -1;
+                b = *ip++;
+                lit += b;
+            } while (b == 255);
+        }
+        if (lit > iend - ip || lit > oend - op) return -1;
+        memcpy(op, ip, (size_t)lit);
+        ip += lit;
+        op += lit;
+        if (ip >= iend) break;  // the last sequence has literals only
+        if (iend - ip < 2) return -1;
+        const int offset = ip[0] | (ip[1] << 8);
+        ip += 2;
+        if (offset == 0 || offset > op - dst) return -1;
+        int64_t ml = token & 15;
+        if (ml == 15) {
+            uint8_t b;
+            do {
+                if (ip >= iend) return -1;
+                b = *ip++;
+                ml += b;
+            } while (b == 255);
+        }
+        ml += 4;
+        if (ml > oend - op) return -1;
+        const uint8_t* m = op - offset;
+        for (int64_t i = 0; i < ml; i++) op[i] = m[i];  // overlapping copies replicate (offset < length)
+        op += ml;
+    }
+    return op - dst;
+}
+
 struct Reader {
     const uint8_t* base;
     int64_t size;
@@ -57,7 +170,7 @@ struct Reader {
 
 }  // namespace
 
-int64_t serialize_page(const pa_page* page, void* out_host, int64_t capacity, hipStream_t s)
+int64_t serialize_page(const pa_page* page, void* out_host, int64_t capacity, hipStream_t s, bool compress)
 {
     PA_REQUIRE(page != nullptr && out_host != nullptr, PA_ERR_INVALID_ARGUMENT, "null argument");
     require_device();
@@ -128,6 +241,18 @@ int64_t serialize_page(const pa_page* page, void* out_host, int64_t capacity, hi
     const int32_t payload = (int32_t)(w.pos - payload_start);
     memcpy(sizes, &payload, 4);      // uncompressedSizeInBytes
     memcpy(sizes + 4, &payload, 4);  // sizeInBytes of the (uncompressed) slice that follows
+    if (compress && payload > 0) {
+        // PagesSerde.serialize (PagesSerde.java:74-95): compress the payload, keep the result only at <= 0.8 of its size
+        std::vector<uint8_t> packed((size_t)lz4_max_compressed(payload));
+        const int64_t c = lz4_compress(w.base + payload_start, payload, packed.data(), (int64_t)packed.size());
+        if (c > 0 && (double)c / payload <= 0.8) {
+            memcpy(w.base + payload_start, packed.data(), (size_t)c);
+            w.base[4] = 1;  // PageCodecMarker.COMPRESSED
+            const int32_t size = (int32_t)c;
+            memcpy(sizes + 4, &size, 4);
+            return payload_start + c;
+        }
+    }
     return w.pos;
 }
 
@@ -146,18 +271,30 @@ struct pa_page_buffer {
 
 namespace pa {
 
-pa_page_buffer* deserialize_page(const void* bytes, int64_t size, hipStream_t s)
+pa_page_buffer* deserialize_page(const void* bytes, int64_t size, hipStream_t s, const int32_t* expected_types, int32_t expected_count)
 {
     PA_REQUIRE(bytes != nullptr, PA_ERR_INVALID_ARGUMENT, "null argument");
     require_device();
-    Reader r{static_cast<const uint8_t*>(bytes), size};
-    const int32_t n = r.i32();
-    const uint8_t markers = r.u8();
-    PA_REQUIRE(markers == 0, PA_ERR_NOT_SUPPORTED, "compressed / encrypted / checksummed pages are decoded by the Java PagesSerde");
-    const int32_t uncompressed = r.i32(), length = r.i32();
-    PA_REQUIRE(n >= 0 && uncompressed == length && r.pos + length <= size, PA_ERR_INVALID_ARGUMENT, "bad SerializedPage header");
+    Reader frame{static_cast<const uint8_t*>(bytes), size};
+    const int32_t n = frame.i32();
+    const uint8_t markers = frame.u8();
+    PA_REQUIRE((markers & ~1) == 0, PA_ERR_NOT_SUPPORTED, "encrypted pages are decoded by the Java PagesSerde (the spill cipher lives there)");
+    const int32_t uncompressed = frame.i32(), length = frame.i32();
+    PA_REQUIRE(n >= 0 && uncompressed >= 0 && length >= 0 && frame.pos + length <= size, PA_ERR_INVALID_ARGUMENT, "bad SerializedPage header");
+    // the payload, and nothing behind it: every read below is confined to [payload, payload + length) of THIS frame -- the
+    // bytes come from another worker
+    std::vector<uint8_t> inflated;
+    Reader r{frame.base + frame.pos, length};
+    if (markers & 1) {  // PageCodecMarker.COMPRESSED (PagesSerde.java:139-156)
+        inflated.resize((size_t)std::max(uncompressed, 1));
+        PA_REQUIRE(lz4_decompress(frame.base + frame.pos, length, inflated.data(), uncompressed) == uncompressed, PA_ERR_INVALID_ARGUMENT,
+                   "compressed page does not inflate to its uncompressed size");
+        r = Reader{inflated.data(), uncompressed};
+    }
+    else PA_REQUIRE(uncompressed == length, PA_ERR_INVALID_ARGUMENT, "bad SerializedPage header");
     const int32_t channels = r.i32();
     PA_REQUIRE(channels >= 0 && channels <= 4096, PA_ERR_INVALID_ARGUMENT, "bad channel count");
+    PA_REQUIRE(expected_types == nullptr || expected_count == channels, PA_ERR_INVALID_ARGUMENT, "page has a different number of channels than the declared types");
     auto out = std::make_unique<pa_page_buffer>();
     PageBuffer& pb = out->impl;
     pb.cols.resize((size_t)channels);
@@ -171,10 +308,25 @@ pa_page_buffer* deserialize_page(const void* bytes, int64_t size, hipStream_t s)
         PA_REQUIRE(positions == n, PA_ERR_INVALID_ARGUMENT, "block position count differs from the page's");
         const uint8_t* ends_bytes = nullptr;
         int width = 0;
-        if (name == "LONG_ARRAY") { oc.type = PA_BIGINT; width = 8; }        // the declared column type tells BIGINT from DOUBLE
-        else if (name == "INT_ARRAY") { oc.type = PA_INTEGER; width = 4; }
-        else if (name == "BYTE_ARRAY") { oc.type = PA_BOOLEAN; width = 1; }
+        // the wire carries encodings, not types: the consumer's declared types tell DOUBLE from BIGINT and DATE from INTEGER
+        const int32_t want = expected_types ? expected_types[c] : -1;
+        if (name == "LONG_ARRAY") {
+            PA_REQUIRE(want < 0 || want == PA_BIGINT || want == PA_DOUBLE, PA_ERR_INVALID_ARGUMENT, "LONG_ARRAY block for a channel declared otherwise");
+            oc.type = want == PA_DOUBLE ? PA_DOUBLE : PA_BIGINT;
+            width = 8;
+        }
+        else if (name == "INT_ARRAY") {
+            PA_REQUIRE(want < 0 || want == PA_INTEGER || want == PA_DATE, PA_ERR_INVALID_ARGUMENT, "INT_ARRAY block for a channel declared otherwise");
+            oc.type = want == PA_DATE ? PA_DATE : PA_INTEGER;
+            width = 4;
+        }
+        else if (name == "BYTE_ARRAY") {
+            PA_REQUIRE(want < 0 || want == PA_BOOLEAN, PA_ERR_INVALID_ARGUMENT, "BYTE_ARRAY block for a channel declared otherwise");
+            oc.type = PA_BOOLEAN;
+            width = 1;
+        }
         else if (name == "VARIABLE_WIDTH") {
+            PA_REQUIRE(want < 0 || want == PA_VARCHAR, PA_ERR_INVALID_ARGUMENT, "VARIABLE_WIDTH block for a channel declared otherwise");
             oc.type = PA_VARCHAR;
             oc.varwidth = true;
             ends_bytes = r.take((int64_t)n * 4);
@@ -194,6 +346,18 @@ pa_page_buffer* deserialize_page(const void* bytes, int64_t size, hipStream_t s)
             launch_varwidth_from_ends(stage_ends.as<int32_t>(), n, offs, s);
             const int32_t total = r.i32();
             PA_REQUIRE(total >= 0, PA_ERR_INVALID_ARGUMENT, "negative VARCHAR length");
+            {
+                // the end offsets index the bytes that follow: non-negative, ascending, the last one the total -- every
+                // downstream varwidth kernel trusts them
+                int32_t prev = 0;
+                for (int32_t i = 0; i < n; i++) {
+                    int32_t e;
+                    memcpy(&e, ends_bytes + (size_t)i * 4, 4);
+                    PA_REQUIRE(e >= prev && e <= total, PA_ERR_INVALID_ARGUMENT, "VARIABLE_WIDTH end offsets are not ascending within the block's bytes");
+                    prev = e;
+                }
+                PA_REQUIRE(n == 0 || prev == total, PA_ERR_INVALID_ARGUMENT, "VARIABLE_WIDTH end offsets do not end at the block's byte count");
+            }
             oc.values.ensure((size_t)(total > 0 ? total : 1));
             if (total > 0) PA_HIP(hipMemcpyAsync(oc.values.ptr(), r.take(total), (size_t)total, hipMemcpyHostToDevice, s));
             PA_HIP(hipStreamSynchronize(s));  // stage_ends is reused

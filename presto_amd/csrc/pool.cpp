@@ -2,6 +2,7 @@
 // hipStreamCreate cost 0.1-several ms each; an operator instance lives for one query, so without reuse
 // the allocator would dominate short queries (a fresh operator per query is the reference's model too:
 // OperatorFactory.createOperator, …/operator/OperatorFactory.java:18-50).
+#include <algorithm>
 #include <cstdlib>
 #include <map>
 #include <mutex>
@@ -27,6 +28,8 @@ struct Pools {
     std::multimap<size_t, void*> pinned_free;
     std::multimap<int, hipStream_t> stream_free;
     size_t device_cached = 0, pinned_cached = 0;
+    size_t device_in_use = 0;   // HBM handed out and not returned yet
+    size_t device_limit = 0;    // 0 = none: budget for device_in_use (pa_memory_set_limit)
 };
 Pools& pools()
 {
@@ -60,6 +63,29 @@ thread_local hipStream_t t_scope_stream = nullptr;
 
 }  // namespace
 
+void pool_set_limit(int64_t bytes)
+{
+    Pools& p = pools();
+    std::lock_guard<std::mutex> lock(p.mu);
+    p.device_limit = bytes > 0 ? (size_t)bytes : 0;
+}
+
+bool pool_has_room(size_t bytes)
+{
+    Pools& p = pools();
+    std::lock_guard<std::mutex> lock(p.mu);
+    return p.device_limit == 0 || p.device_in_use + size_class(bytes) <= p.device_limit;
+}
+
+void pool_stats(int64_t* in_use, int64_t* cached, int64_t* limit)
+{
+    Pools& p = pools();
+    std::lock_guard<std::mutex> lock(p.mu);
+    if (in_use) *in_use = (int64_t)p.device_in_use;
+    if (cached) *cached = (int64_t)p.device_cached;
+    if (limit) *limit = (int64_t)p.device_limit;
+}
+
 hipStream_t pool_scope_stream(hipStream_t s)
 {
     hipStream_t prev = t_scope_stream;
@@ -85,6 +111,8 @@ void* pool_device_alloc(size_t bytes, size_t* granted)
     {
         Pools& p = pools();
         std::lock_guard<std::mutex> lock(p.mu);
+        if (p.device_limit != 0 && p.device_in_use + c > p.device_limit) throw PoolExhausted(c);
+        p.device_in_use += c;  // (given back below if the driver itself has nothing left)
         auto range = p.device_free.equal_range({dev, c});
         for (auto it = range.first; it != range.second; ++it) {
             hipStream_t last = it->second.last;
@@ -121,6 +149,11 @@ void* pool_device_alloc(size_t bytes, size_t* granted)
         for (void* q : cached) (void)hipFree(q);
         e = hipMalloc(&ptr, c);
     }
+    if (e != hipSuccess) {
+        Pools& p = pools();
+        std::lock_guard<std::mutex> lock(p.mu);
+        p.device_in_use -= c;
+    }
     PA_HIP(e);
     *granted = c;
     return ptr;
@@ -134,6 +167,7 @@ void pool_device_free(void* ptr, size_t granted)
     Pools& p = pools();
     {
         std::lock_guard<std::mutex> lock(p.mu);
+        p.device_in_use -= std::min(p.device_in_use, granted);
         if (p.device_cached + granted <= max_cached_device()) {
             p.device_free.emplace(std::make_pair(dev, granted), DeviceBlock{ptr, t_scope_stream});
             p.device_cached += granted;

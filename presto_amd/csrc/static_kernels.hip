@@ -612,4 +612,36 @@ void launch_tpch(int32_t column, double sf, int64_t first_row, int64_t n, uint64
     PA_HIP(hipGetLastError());
 }
 
+// ---- reference-format aggregation states (op_states.cpp) ----
+__global__ __launch_bounds__(256) void k_widen_i32_i64(const i32* __restrict__ in, i64 n, i64* __restrict__ out)
+{
+    for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < n; i += (i64)gridDim.x * 256) out[i] = (i64)in[i];
+}
+__global__ __launch_bounds__(256) void k_narrow_i64_i32(const i64* __restrict__ in, i64 n, i32* __restrict__ out)
+{
+    for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < n; i += (i64)gridDim.x * 256) out[i] = (i32)in[i];
+}
+__global__ __launch_bounds__(256) void k_count_from_nulls(const u8* __restrict__ nulls, i64 n, i64* __restrict__ out)
+{
+    for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < n; i += (i64)gridDim.x * 256) out[i] = (nulls && nulls[i]) ? 0 : 1;
+}
+void launch_widen_i32_i64(const int32_t* in, int64_t n, int64_t* out, hipStream_t s)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_widen_i32_i64, grid_for(n, 256), 256, 0, s, in, (i64)n, (i64*)out);
+    PA_HIP(hipGetLastError());
+}
+void launch_narrow_i64_i32(const int64_t* in, int64_t n, int32_t* out, hipStream_t s)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_narrow_i64_i32, grid_for(n, 256), 256, 0, s, (const i64*)in, (i64)n, out);
+    PA_HIP(hipGetLastError());
+}
+void launch_count_from_nulls(const uint8_t* nulls, int64_t n, int64_t* out, hipStream_t s)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_count_from_nulls, grid_for(n, 256), 256, 0, s, nulls, (i64)n, (i64*)out);
+    PA_HIP(hipGetLastError());
+}
+
 }  // namespace pa

@@ -114,6 +114,11 @@ def device_page_from_c(cpage, owner=None):
         col = cpage.columns[i]
         w = abi.TYPE_WIDTH[col.type]
         nulls = DeviceBuffer(col.nulls, n, owner) if col.nulls else None
+        if col.encoding == abi.ROW_FIELDS:
+            sub = abi.pa_page()
+            sub.position_count, sub.channel_count, sub.columns, sub.mem = n, col.dictionary_size, col.dictionary, abi.MEM_DEVICE
+            blocks.append(Block(abi.ROW, abi.ROW_FIELDS, n, nulls=nulls, fields=device_page_from_c(sub, owner).blocks))
+            continue
         if col.encoding == abi.VARWIDTH:
             blocks.append(Block(col.type, abi.VARWIDTH, n, values=DeviceBuffer(col.values, 0, owner),
                                 offsets=DeviceBuffer(col.offsets, 4 * (n + 1), owner), nulls=nulls))
@@ -158,7 +163,7 @@ def _aggregates(aggregates):
 
 
 def _hash_agg_desc(input_types, group_by_channels, aggregates, hash_channel, expected_groups, output_mem, stream,
-                   type_params=None, step=abi.STEP_SINGLE):
+                   type_params=None, step=abi.STEP_SINGLE, max_partial_memory=0, state_format=abi.STATES_FLAT):
     keep = []
     d = abi.pa_hash_aggregation_desc()
     types = abi.int32_array(input_types)
@@ -179,16 +184,19 @@ def _hash_agg_desc(input_types, group_by_channels, aggregates, hash_channel, exp
     d.expected_groups = expected_groups
     d.output_mem = output_mem
     d.stream = stream
+    d.max_partial_memory = int(max_partial_memory)
+    d.state_format = state_format
     keep += [types, gb, aggs]
     return d, keep
 
 
 def fused_aggregation_desc(input_types, filter_expr, projections, group_by_channels, aggregates, hash_channel=-1,
-                           expected_groups=10000, output_mem=abi.MEM_HOST, stream=None, type_params=None, step=abi.STEP_SINGLE):
+                           expected_groups=10000, output_mem=abi.MEM_HOST, stream=None, type_params=None, step=abi.STEP_SINGLE,
+                           max_partial_memory=0, state_format=abi.STATES_FLAT):
     """aggregates: list of (fn, projection index, input type[, mask projection index])."""
     fp, k1 = _filter_project_desc(input_types, filter_expr, projections, output_mem, stream, type_params)
     ag, k2 = _hash_agg_desc([p.type for p in projections], group_by_channels, aggregates, hash_channel, expected_groups,
-                            output_mem, stream, None, step)
+                            output_mem, stream, None, step, max_partial_memory, state_format)
     d = abi.pa_fused_aggregation_desc()
     d.filter_project = fp
     d.aggregation = ag
@@ -302,7 +310,7 @@ class ScanFilterAndProjectOperator(Operator):
         return tuple(x.value for x in v)
 
 
-def AggregationOperator(input_types, aggregates, output_mem=abi.MEM_HOST, stream=None, step=abi.STEP_SINGLE):
+def AggregationOperator(input_types, aggregates, output_mem=abi.MEM_HOST, stream=None, step=abi.STEP_SINGLE, state_format=abi.STATES_FLAT):
     """AggregationOperator.AggregationOperatorFactory (…/operator/AggregationOperator.java:40-95)."""
     d = abi.pa_aggregation_desc()
     types = abi.int32_array(input_types)
@@ -314,16 +322,19 @@ def AggregationOperator(input_types, aggregates, output_mem=abi.MEM_HOST, stream
     d.step = step
     d.output_mem = output_mem
     d.stream = stream
+    d.state_format = state_format
     h = C.c_void_p()
     check(lib().pa_aggregation_create(C.byref(d), C.byref(h)))
     return Operator(h, [types, aggs])
 
 
 def HashAggregationOperator(input_types, group_by_channels, aggregates, hash_channel=-1, expected_groups=10000,
-                            output_mem=abi.MEM_HOST, stream=None, type_params=None, step=abi.STEP_SINGLE):
-    """HashAggregationOperatorFactory (…/operator/HashAggregationOperator.java:120-202)."""
+                            output_mem=abi.MEM_HOST, stream=None, type_params=None, step=abi.STEP_SINGLE, max_partial_memory=0,
+                            state_format=abi.STATES_FLAT):
+    """HashAggregationOperatorFactory (…/operator/HashAggregationOperator.java:120-202); max_partial_memory = maxPartialMemory
+    in bytes (Step.PARTIAL: flush when the aggregation is "full"), state_format = abi.STATES_FLAT / STATES_REFERENCE."""
     d, keep = _hash_agg_desc(input_types, group_by_channels, aggregates, hash_channel, expected_groups, output_mem, stream,
-                             type_params, step)
+                             type_params, step, max_partial_memory, state_format)
     h = C.c_void_p()
     check(lib().pa_hash_aggregation_create(C.byref(d), C.byref(h)))
     return Operator(h, keep)
@@ -685,6 +696,8 @@ def upload_page(page):
         return DeviceBuffer(alloc.ptr, arr.nbytes, alloc)
 
     def up_block(b):
+        if b.encoding == abi.ROW_FIELDS:
+            return Block(abi.ROW, abi.ROW_FIELDS, b.position_count, nulls=up(b.nulls), fields=[up_block(f) for f in b.fields])
         dictionary = up_block(b.dictionary) if b.dictionary is not None else None  # DictionaryBlock / RunLengthEncodedBlock
         return Block(b.type, b.encoding, b.position_count, values=up(b.values), offsets=up(b.offsets), nulls=up(b.nulls),
                      ids=up(b.ids), dictionary=dictionary)
@@ -708,6 +721,9 @@ def download_page(page):
     blocks = []
     for b in page.blocks:
         nulls = download(b.nulls, np.uint8, n) if b.nulls is not None else None
+        if b.encoding == abi.ROW_FIELDS:
+            blocks.append(Block.row(download_page(Page(b.fields, n, abi.MEM_DEVICE)).blocks, nulls))
+            continue
         if b.encoding == abi.VARWIDTH:
             off = download(b.offsets, np.int32, n + 1)
             total = int(off[n]) if n else 0

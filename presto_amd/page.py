@@ -40,7 +40,8 @@ def _ptr(buf):
 
 class Block:
     def __init__(self, type_, encoding, position_count, values=None, offsets=None, nulls=None, ids=None,
-                 dictionary=None):
+                 dictionary=None, fields=None):
+        self.fields = fields  # RowBlock: the field blocks (encoding ROW_FIELDS)
         self.type = type_
         self.encoding = encoding
         self.position_count = int(position_count)
@@ -109,6 +110,13 @@ class Block:
                      nulls=nulls)
 
     @staticmethod
+    def row(fields, nulls=None):
+        """RowBlock.fromFieldBlocks (core/trino-spi/src/main/java/io/trino/spi/block/RowBlock.java)"""
+        n = fields[0].position_count
+        assert all(f.position_count == n for f in fields)
+        return Block(abi.ROW, abi.ROW_FIELDS, n, nulls=nulls, fields=list(fields))
+
+    @staticmethod
     def dictionary_block(dictionary, ids):
         ids = np.ascontiguousarray(np.asarray(ids, dtype=np.int32))
         return Block(dictionary.type, abi.DICTIONARY, len(ids), ids=ids, dictionary=dictionary)
@@ -126,6 +134,10 @@ class Block:
             return [d[i] for i in self.ids.tolist()]
         if self.encoding == abi.RLE:
             return self.dictionary.to_pylist() * self.position_count
+        if self.encoding == abi.ROW_FIELDS:
+            cols = [f.to_pylist() for f in self.fields]
+            rows = [tuple(c[i] for c in cols) for i in range(self.position_count)]
+            return [None if (self.nulls is not None and self.nulls[i]) else r for i, r in enumerate(rows)]
         n = self.position_count
         nulls = self.nulls
         if self.type == abi.VARCHAR:
@@ -148,6 +160,13 @@ class Block:
         col.nulls = _ptr(self.nulls)
         col.ids = _ptr(self.ids)
         col.dictionary_size = 0
+        if self.fields is not None:
+            arr = (abi.pa_column * len(self.fields))()
+            for i, f in enumerate(self.fields):
+                f.fill_c(arr[i], keep)
+            keep.append(arr)
+            col.dictionary = C.cast(arr, C.POINTER(abi.pa_column))
+            col.dictionary_size = len(self.fields)
         if self.dictionary is not None:
             d = abi.pa_column()
             self.dictionary.fill_c(d, keep)
@@ -220,6 +239,17 @@ def page_from_c(cpage, copy=True):
     blocks = []
     for i in range(cpage.channel_count):
         col = cpage.columns[i]
+        if col.encoding == abi.ROW_FIELDS:
+            sub = abi.pa_page()
+            sub.position_count = n
+            sub.channel_count = col.dictionary_size
+            sub.columns = col.dictionary
+            sub.mem = abi.MEM_HOST
+            rn = None
+            if col.nulls:
+                rn = np.ctypeslib.as_array(C.cast(col.nulls, C.POINTER(C.c_uint8)), shape=(max(n, 1),))[:n].copy()
+            blocks.append(Block.row(page_from_c(sub, copy).blocks, rn))
+            continue
         nulls = None
         if col.nulls:
             nulls = np.ctypeslib.as_array(C.cast(col.nulls, C.POINTER(C.c_uint8)), shape=(max(n, 1),))[:n]
@@ -267,8 +297,9 @@ def sequence_page(length, columns):
 
 
 # ---- wire format (PagesSerde) through the C ABI ------------------------------------------------------------------------
-def serialize_page(page, stream=None):
-    """SerializedPage bytes (frame + payload, uncompressed) of a host or device Page: pa_page_serialize."""
+def serialize_page(page, stream=None, compress=False):
+    """SerializedPage bytes (frame + payload) of a host or device Page: pa_page_serialize, or pa_page_serialize_lz4 (payload as
+    one LZ4 block when that pays, PagesSerde.java:74-95)."""
     from ._lib import check, lib
     cpage, keep = page.to_c()
     n = page.position_count
@@ -276,7 +307,7 @@ def serialize_page(page, stream=None):
                    for b in page.blocks)
     for _ in range(8):
         buf = (C.c_uint8 * cap)()
-        rc = lib().pa_page_serialize(C.byref(cpage), buf, cap, stream)
+        rc = (lib().pa_page_serialize_lz4 if compress else lib().pa_page_serialize)(C.byref(cpage), buf, cap, stream)
         if rc == abi.ERR_INSUFFICIENT_RESOURCES:
             cap *= 4  # device VARCHAR bytes are only known to the library
             continue
@@ -297,14 +328,17 @@ class _PageBuffer:
             pass
 
 
-def deserialize_page(data, stream=None):
+def deserialize_page(data, stream=None, types=None):
     """PA_MEM_DEVICE Page from SerializedPage bytes: pa_page_deserialize (DOUBLE / DATE columns come back as BIGINT / INTEGER
-    blocks of the same bits: the wire format carries encodings, not types)."""
+    blocks of the same bits: the wire format carries encodings, not types), or with `types` pa_page_deserialize_typed."""
     from ._lib import check, lib
     from .operators import device_page_from_c
     raw = (C.c_uint8 * max(len(data), 1)).from_buffer_copy(bytes(data) if data else b"\0")
     h = C.c_void_p()
-    check(lib().pa_page_deserialize(raw, len(data), stream, C.byref(h)))
+    if types is None:
+        check(lib().pa_page_deserialize(raw, len(data), stream, C.byref(h)))
+    else:
+        check(lib().pa_page_deserialize_typed(raw, len(data), abi.int32_array(types), len(types), stream, C.byref(h)))
     owner = _PageBuffer(h)
     cpage = abi.pa_page()
     check(lib().pa_page_buffer_page(h, C.byref(cpage)))

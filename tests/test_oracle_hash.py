@@ -102,3 +102,17 @@ def test_row_hash_and_partitions(oracle):
     assert oracle.partition_ids(h, 5, local=False).tolist() == [(x & 0x7fffffffffffffff) % 5 for x in exp]
     pos, counts = oracle.partition_positions(np.array([1, 0, 1, 2, 0, 1], dtype=np.int32), 4)
     assert pos.tolist() == [1, 4, 0, 2, 5, 3] and counts.tolist() == [2, 3, 1, 0]
+
+
+def test_lz4_block_format_hand_computed(oracle):
+    """The LZ4 block codec of the oracle (PagesSerde's compressor is the un-vendored io.airlift:aircompressor; parity is
+    pinned by the public block format): a block written by hand -- one literal 'a', a match of 14 at offset 1 (the overlapping
+    copy replicates the byte), then the mandatory 5 closing literals -- inflates to 20 x 'a'; and the encoder's output, whatever
+    its choices, round-trips."""
+    block = bytes([0x1A, 0x61, 0x01, 0x00, 0x50]) + b"aaaaa"
+    assert oracle.lz4_decompress(block, 20) == b"a" * 20
+    # literal-length extension: 15 + 255 + 3 = 273 literals, no match
+    block = bytes([0xF0, 0xFF, 0x03]) + bytes(range(256)) + bytes(range(17))
+    assert oracle.lz4_decompress(block, 273) == bytes(range(256)) + bytes(range(17))
+    for data in (b"", b"x", b"0123456789ab", b"abcd" * 100, bytes(range(256)) * 3, b"\0" * 5000):
+        assert oracle.lz4_decompress(oracle.lz4_compress(data), len(data)) == data
