@@ -313,6 +313,15 @@ struct PaFusedArgs {
     i32* part_ids;                    // hash-partitioning pass: partition of every row of the launch
     i32 list_blocked;                 // row_list is cut into one contiguous slice per workgroup (partition-ordered lists)
     i32 pad3;
+    // Partition-owned tables (LDSP variant): workgroup p aggregates the rows [part_first[p], part_first[p + 1]) of the
+    // partition-ordered columns into an LDS table it LOADS from and STORES to sub_*[p] -- the groups of partition p live nowhere
+    // else, so neither the row loop nor the hand-over to HBM needs an atomic on HBM.  Layout per partition: PA_LC tags,
+    // PA_LC x PA_KW key words, PA_LC x PA_NW accumulator words (slot-major), one group count.
+    u64* sub_tag;
+    u64* sub_keys;
+    u64* sub_words;
+    i32* sub_count;
+    const i64* part_first;
 };
 
 // the replica of the group table this workgroup works on

@@ -47,6 +47,7 @@ void launch_gt_fold(const uint64_t* old_tag, const uint64_t* old_keys, const uin
                     int nw, const int32_t* kinds_dev, uint64_t* tag, uint64_t* keys, uint64_t* words, uint32_t mask, uint32_t new_reps,
                     int32_t* count0, int32_t* rep_count, int32_t* err, hipStream_t s);
 
+void launch_exclusive_prefix_i64(const int64_t* in, int32_t n, int64_t* out, hipStream_t s);
 void launch_gt_compact(const uint64_t* tag, const uint64_t* keys, const uint64_t* words, uint32_t cap, int w, int nw, uint64_t* out_keys,
                        uint64_t* out_words, uint32_t* counter, hipStream_t s);
 
@@ -81,9 +82,15 @@ struct FusedArgs {
     int32_t* part_ids;
     int32_t list_blocked;
     int32_t pad3;
+    uint64_t* sub_tag;
+    uint64_t* sub_keys;
+    uint64_t* sub_words;
+    int32_t* sub_count;
+    const int64_t* part_first;
 };
 
-enum Variant { V_GLOBAL = 0, V_LDS = 1, V_GT = 2, V_LDSH = 3, V_HASH = 4 };
+// V_LDSP: the LDS-table variant with partition-owned tables (see PaFusedArgs::sub_tag)
+enum Variant { V_GLOBAL = 0, V_LDS = 1, V_GT = 2, V_LDSH = 3, V_HASH = 4, V_LDSP = 5 };
 enum WordKind { W_CNT = 0, W_SUMF = 1, W_SUMI = 2, W_MAXU = 3 };
 
 constexpr int kLdsSlots = 8;  // C of the LDS variant: 8 groups x NW words x 64 lanes x 8 B of LDS per wave
@@ -498,7 +505,7 @@ KernelInfo generate(const Spec& s, const std::vector<ChannelLayout>& layout, int
     if (variant == V_LDS) {
         PA_REQUIRE((size_t)k.nw * kLdsSlots * 64 * 8 <= 64 * 1024, PA_ERR_NOT_SUPPORTED, "too many accumulator words for the LDS variant");
     }
-    if (variant == V_LDSH) {
+    if (variant == V_LDSH || variant == V_LDSP) {
         // one table per workgroup: tag + key words + accumulator words per slot.  A 1024-thread workgroup with 150 of the CU's
         // 160 KB of LDS (4096 slots for a one-word key and two accumulator words) against two 512-thread workgroups with 62 KB
         // each, measured over 64 M rows: 300 groups 64 -> 77 G rows/s, 1 K 26 -> 61 G, 2 K 21 -> 45 G (these now fit the
@@ -529,7 +536,7 @@ KernelInfo generate(const Spec& s, const std::vector<ChannelLayout>& layout, int
         src << "__shared__ u64 pa_accw[PA_NW * PA_C * 64];\n";
         src << "struct PaAcc { u64 tk[PA_C][PA_KW]; int tcount; u32 lane; };\n";
     }
-    else if (variant == V_LDSH) {
+    else if (variant == V_LDSH || variant == V_LDSP) {
         // Medium cardinality: the workgroup aggregates into an open-addressing table in LDS (ds_cmpst / ds_add: no HBM
         // atomics in the row loop -- atomics of many rows on a few HBM addresses retire at ~16 M/s per address on this
         // part), and adds its table to the HBM table once, at the end of the kernel.  A row whose group finds no room
@@ -538,7 +545,9 @@ KernelInfo generate(const Spec& s, const std::vector<ChannelLayout>& layout, int
         while ((1 << lc_bits) < k.lc) lc_bits++;
         // the LDS table is indexed by the TOP bits of the 32-bit key hash: the low bits choose the partition (hash-partitioned
         // path) and the HBM-table slot, so rows of one partition would otherwise share their home slots
-        src << "#define PA_LC " << k.lc << "\n#define PA_LC_SHIFT " << (32 - lc_bits) << "\n";
+        // rows whose group finds the table this full go to the HBM table: half of it when the table is the workgroup's own for one
+        // launch (its groups are flushed into HBM, which must have room), three quarters when it is a partition's table for good
+        src << "#define PA_LC " << k.lc << "\n#define PA_LC_SHIFT " << (32 - lc_bits) << "\n#define PA_LT_LIMIT " << (variant == V_LDSP ? "(PA_LC * 3 / 4)" : "(PA_LC / 2)") << "\n";
         src << "__shared__ u64 pa_lt_tag[PA_LC];\n__shared__ u64 pa_lt_key[PA_LC * PA_KW];\n__shared__ u64 pa_lt_acc[PA_LC * PA_NW];\n"
                "__shared__ i32 pa_lt_count;\n";
         src << "struct PaAcc { PaGtView tv; PaGtCtr gt; PaGtCtr flush; i64 fell; };\n";
@@ -551,7 +560,7 @@ KernelInfo generate(const Spec& s, const std::vector<ChannelLayout>& layout, int
                "            const u64 t = __hip_atomic_load(&pa_lt_tag[i], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);\n"
                "            bool advance = false;\n"
                "            if (t == 0ULL) {\n"
-               "                if (__hip_atomic_load(&pa_lt_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= PA_LC / 2) result = -1;\n"
+               "                if (__hip_atomic_load(&pa_lt_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= PA_LT_LIMIT) result = -1;\n"
                "                else {\n"
                "                    u64 expected = 0ULL;\n"
                "                    if (__hip_atomic_compare_exchange_strong(&pa_lt_tag[i], &expected, busy, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {\n"
@@ -580,14 +589,15 @@ KernelInfo generate(const Spec& s, const std::vector<ChannelLayout>& layout, int
         for (int w = 0; w < k.nw; w++) src << " bool pu" << w << "; " << (words[w].kind == W_SUMF ? "double" : (words[w].kind == W_MAXU ? "u64" : "i64")) << " px" << w << ";";
         src << " };\n";
     }
-    if (variant == V_GT || variant == V_LDSH) {
+    const bool lds_table = variant == V_LDSH || variant == V_LDSP;
+    if (variant == V_GT || lds_table) {
         // accumulation of one row into the workgroup's LDS table / the HBM table
         src << "__device__ __forceinline__ void " << (variant == V_GT ? "pa_acc_now" : "pa_acc")
             << "(const PaFusedArgs& a, PaAcc& acc, const bool sel, const i32 row, " << (variant == V_GT ? "const i32 nrows, " : "") << "const u64 (&key)[PA_KW]";
         for (int w = 0; w < k.nw; w++) src << ", const bool u" << w << ", const " << (words[w].kind == W_SUMF ? "double" : (words[w].kind == W_MAXU ? "u64" : "i64")) << " x" << w;
         src << ")\n{\n";
         src << "if (sel) {\n  const u32 h = pa_key_hash(key, PA_KW);\n";
-        if (variant == V_LDSH) {
+        if (lds_table) {
             src << "  const int ls = pa_lt_upsert(h, key);\n  if (ls >= 0) {\n";
             for (int w = 0; w < k.nw; w++) {
                 std::string idx = "pa_lt_acc[ls * PA_NW + " + std::to_string(w) + "]";
@@ -625,7 +635,7 @@ KernelInfo generate(const Spec& s, const std::vector<ChannelLayout>& layout, int
         else {
             src << "  } else {\n    a.spill_rows[atomicAdd(a.spill_count, 1u)] = row;\n  }\n";
         }
-        if (variant == V_LDSH) src << "  }\n";
+        if (lds_table) src << "  }\n";
         src << "}\n";
         src << "}\n\n";
         if (variant == V_GT) {
@@ -741,6 +751,19 @@ KernelInfo generate(const Spec& s, const std::vector<ChannelLayout>& layout, int
             src << "    PaAcc acc; acc.tcount = 0; acc.lane = threadIdx.x;\n";
             src << "#pragma unroll\n    for (int s = 0; s < PA_C; s++) {\n#pragma unroll\n        for (int w = 0; w < PA_KW; w++) acc.tk[s][w] = 0ULL;\n    }\n";
         }
+        else if (variant == V_LDSP) {
+            // the partition's table comes from HBM as the last launch left it (zeroes at first) ...
+            src << "    const u64 sp = (u64)blockIdx.x * PA_LC;\n";
+            src << "    for (int i = threadIdx.x; i < PA_LC; i += " << B << ") pa_lt_tag[i] = a.sub_tag[sp + i];\n";
+            src << "    for (int i = threadIdx.x; i < PA_LC * PA_KW; i += " << B << ") pa_lt_key[i] = a.sub_keys[sp * PA_KW + i];\n";
+            // (accumulator words are word-major in HBM, [word][slot over all partitions] -- the layout of the HBM group table, so
+            // that the partitions' tables can be emitted, or folded, as one table of gridDim.x * PA_LC slots)
+            src << "    const u64 ts = (u64)gridDim.x * PA_LC;\n";
+            src << "    for (int i = threadIdx.x; i < PA_LC * PA_NW; i += " << B << ") { const int w = i / PA_LC, sl = i % PA_LC; pa_lt_acc[sl * PA_NW + w] = a.sub_words[(u64)w * ts + sp + sl]; }\n";
+            src << "    if (threadIdx.x == 0) pa_lt_count = a.sub_count[blockIdx.x];\n    __syncthreads();\n";
+            src << "    PaAcc acc; acc.tv = pa_gt_view(a, PA_KW, PA_NW); acc.gt = pa_gt_ctr_init(acc.tv.count, true, a.gt_rep_mask + 1u);\n"
+                   "    acc.flush = pa_gt_ctr_init(acc.tv.count, false); acc.fell = 0;\n";
+        }
         else if (variant == V_LDSH) {
             src << "    for (int i = threadIdx.x; i < PA_LC; i += " << B << ") pa_lt_tag[i] = 0ULL;\n";
             src << "    for (int i = threadIdx.x; i < PA_LC * PA_NW; i += " << B << ") pa_lt_acc[i] = 0ULL;\n";
@@ -787,6 +810,18 @@ KernelInfo generate(const Spec& s, const std::vector<ChannelLayout>& layout, int
             src << "       " << flush << "\n    }\n";
             src << "    for (i64 r = (nq << 2) + t; r < a.n; r += T) {\n        pa_row(a, acc, true, (i32)r" << scalar_args(ri, layout) << ");" << flush << "\n    }\n";
         }
+        if (variant == V_LDSP) {
+            // ... the workgroup walks the rows of its partition (the columns are partition-ordered) ...
+            src << "    {\n        const i64 b0 = a.part_first[blockIdx.x], b1 = a.part_first[blockIdx.x + 1];\n"
+                   "        for (i64 r = b0 + threadIdx.x; r < b1; r += " << B << ") {\n            pa_row(a, acc, true, (i32)r" << scalar_args(ri, layout) << ");\n        }\n    }\n";
+            // ... and the table goes back (plain coalesced stores: nobody else touches this partition)
+            src << "    __syncthreads();\n";
+            src << "    for (int i = threadIdx.x; i < PA_LC; i += " << B << ") a.sub_tag[sp + i] = pa_lt_tag[i];\n";
+            src << "    for (int i = threadIdx.x; i < PA_LC * PA_KW; i += " << B << ") a.sub_keys[sp * PA_KW + i] = pa_lt_key[i];\n";
+            src << "    for (int i = threadIdx.x; i < PA_LC * PA_NW; i += " << B << ") { const int w = i / PA_LC, sl = i % PA_LC; a.sub_words[(u64)w * ts + sp + sl] = pa_lt_acc[sl * PA_NW + w]; }\n";
+            src << "    if (threadIdx.x == 0) a.sub_count[blockIdx.x] = pa_lt_count;\n";
+            src << "    { const i64 f = pa_wave_sum_i64(acc.fell); if ((threadIdx.x & 63) == 0 && f != 0) atomicAdd((unsigned long long*)a.overflow_rows, (unsigned long long)f); }\n";
+        }
         if (variant == V_GT || variant == V_LDSH) {
             // rows given by a list: grid-stride (spill replays), or one contiguous slice per workgroup (partition-ordered lists:
             // the workgroup's LDS table then meets the groups of a few partitions only)
@@ -815,7 +850,7 @@ KernelInfo generate(const Spec& s, const std::vector<ChannelLayout>& layout, int
             src << "    }\n    pa_gt_ctr_flush(acc.flush, acc.tv.count);\n";
             src << "    { const i64 f = pa_wave_sum_i64(acc.fell); if ((threadIdx.x & 63) == 0 && f != 0) atomicAdd((unsigned long long*)a.overflow_rows, (unsigned long long)f); }\n";
         }
-        if (variant == V_GT || variant == V_LDSH) src << "    pa_gt_ctr_flush(acc.gt, acc.tv.count);\n";
+        if (variant == V_GT || lds_table) src << "    pa_gt_ctr_flush(acc.gt, acc.tv.count);\n";
         if (variant == V_GLOBAL) {
             src << "    __shared__ u64 red[" << (B / 64) << " * PA_NW];\n    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;\n";
             for (int w = 0; w < k.nw; w++) {
@@ -1631,11 +1666,24 @@ private:
     // per workgroup -- the atomics per row move from HBM (~20 G/s for the whole chip) into LDS.
     bool partitioned_wanted(const std::string& sig, const std::vector<ChannelLayout>& layout, int* partitions)
     {
-        if (!gt_probed_ || getenv("PRESTO_AMD_NO_PARTITIONED")) return false;
+        if (getenv("PRESTO_AMD_NO_PARTITIONED")) return false;
+        if (sub_parts_ > 0) {  // partition-owned tables exist: every later page is cut the same way
+            *partitions = sub_parts_;
+            return true;
+        }
+        static const uint64_t ldsp_from = [] {
+            const char* e = getenv("PRESTO_AMD_LDSP_FROM");
+            return (uint64_t)(e ? atoll(e) : 200000);
+        }();
+        const uint64_t expected = (uint64_t)std::max(spec_.expected_groups, 0);
+        // nothing measured yet: only the planner's estimate can name the tier -- when it says "many groups", start with the
+        // partition-owned tables at once (a probe launch on the HBM table would leave its groups there, to be folded later)
+        if (!gt_probed_ && (expected < ldsp_from || is_combiner_)) return false;
         // measured (64 M rows, 16 B/row, uniform keys; steady state per page): 1 K groups 9 -> 26 G rows/s, 8 K 6 -> 18 G,
         // 100 K 8 -> 11.6 G; beyond ~400 K groups a workgroup's slice holds more groups than its table takes
         const uint64_t g = groups_upper_;
-        if (g < 256) return false;
+        const uint64_t g_est = std::max(g, expected);
+        if (g_est < 256) return false;
         const Compiled* ldsh = nullptr;
         try {
             ldsh = &kernel_for(sig, layout, V_LDSH);
@@ -1644,6 +1692,18 @@ private:
             if (e.code != PA_ERR_NOT_SUPPORTED) throw;
             return false;
         }
+        // Many groups: partition-owned tables (V_LDSP).  With the workgroup's table flushed into the HBM table after every
+        // launch, a launch costs one HBM upsert per (group, launch) -- at 3 M groups and 2^24-row pages as many atomics as
+        // rows / 5, and the tier stays bound by them (9 G rows/s).  A table that belongs to ONE partition for good is loaded
+        // from and stored to HBM with plain coalesced accesses instead.  Partitions sized for ~0.4 of a table (they may fill to
+        // 3/4 before rows fall through to the HBM table), from what the probe saw or the planner expects, whichever is more.
+        if (g_est >= ldsp_from && g_est <= 2048ULL * (uint64_t)ldsh->info.lc * 3 / 4) {
+            uint64_t p = next_pow2((uint64_t)((double)g_est / (0.4 * ldsh->info.lc)) + 1);
+            *partitions = (int)std::min<uint64_t>(std::max<uint64_t>(p, 64), 2048);
+            want_ldsp_ = true;
+            return true;
+        }
+        if (!gt_probed_ || g < 256) return false;
         const uint64_t per = std::max(ldsh->info.lc / 8, 8);
         // at most 512 partitions (+ 1 for filtered rows), each within a quarter of the workgroup's table
         // up to half a table per partition (with one workgroup per partition, see list_grid_hint_): 700 K groups 17 vs 10 G rows/s
@@ -1651,12 +1711,12 @@ private:
         // (beyond that the HBM table takes the rows as they come: running ITS kernel over partition-ordered rows, for the
         // locality of the table slice, was measured slower -- 3 M groups 7.2 vs 9.5 G rows/s, 10 M 6.1 vs 7.8: the atomics are
         // bound in the L2 atomic units, not by where the table lines live)
-        // The multisplit takes up to 4096 partitions in one pass (2048 + 1 for the filtered rows here): at 2048 a tile of 8192
-        // rows leaves runs of ~4 rows per partition, which the L2 still combines into full lines (the write cursors of all
-        // partitions and columns together are a few hundred KB), and a partition of a 2^26-row chunk is one workgroup's slice.
+        // (The multisplit takes up to 4096 partitions in one pass, but more than 512 here was measured slower: with the table
+        // flushed into HBM after every launch, 2048 partitions of a 2^24-row page are 8 K-row slices whose table set-up and
+        // flush outweigh the rows -- 700 K groups 17.6 -> 11.8 G rows/s; the partition-owned tables above take over instead.)
         static const uint64_t max_parts = [] {
             const char* e = getenv("PRESTO_AMD_MAX_PARTITIONS");
-            return (uint64_t)(e ? std::max(atoi(e), 2) : 2048);
+            return (uint64_t)(e ? std::max(atoi(e), 2) : 512);
         }();
         if (g > max_parts * (uint64_t)(ldsh->info.lc / 2)) return false;
         uint64_t p = next_pow2((g + per - 1) / per);
@@ -1672,7 +1732,31 @@ private:
         // them contiguously was measured slower at every cardinality -- 8 K groups 14.8 vs 17.9 G rows/s, 100 K 10.5 vs 11.6 --
         // than letting the LDS-table kernel gather the page rows of its slice, and was removed.)
         const Compiled& hk = kernel_for(sig, layout, V_HASH);
-        const Compiled& lk = kernel_for(sig, layout, V_LDSH);
+        bool ldsp = want_ldsp_ || sub_parts_ > 0;
+        // (needs the reordered columns: fixed-width inputs, few enough for one multisplit)
+        int moved = 0;
+        for (int c = 0; c < spec_.n_in && ldsp; c++) {
+            if (!spec_.used_channel[c]) continue;
+            ldsp = !dp.cols[c].varwidth;
+            moved += 1 + (dp.cols[c].nulls ? 1 : 0);
+        }
+        ldsp = ldsp && moved <= kMsplitMaxCols && !getenv("PRESTO_AMD_NO_MSPLIT");
+        if (!ldsp && sub_parts_ == 0) want_ldsp_ = false;
+        if (!ldsp) partitions = std::min(partitions, 2048);
+        const Compiled& lk = kernel_for(sig, layout, ldsp ? V_LDSP : V_LDSH);
+        cur_sig_ = &sig;
+        cur_layout_ = &layout;
+        if (ldsp && sub_parts_ == 0) {
+            // the partitions' tables, all empty
+            sub_parts_ = partitions;
+            const size_t slots = (size_t)partitions * lk.info.lc;
+            PA_HIP(hipMemsetAsync(sub_tag_.ensure(slots * 8), 0, slots * 8, s));
+            sub_keys_.ensure(slots * 8 * std::max(lk.info.w, 1));
+            PA_HIP(hipMemsetAsync(sub_words_.ensure(slots * 8 * lk.info.nw), 0, slots * 8 * lk.info.nw, s));
+            PA_HIP(hipMemsetAsync(sub_count_.ensure((size_t)partitions * 4), 0, (size_t)partitions * 4, s));
+            sub_lc_ = lk.info.lc;
+        }
+        if (ldsp) partitions = sub_parts_;
         const int64_t chunk = (int64_t)1 << 26;
         for (int64_t offset = start_row; offset < dp.n; offset += chunk) {
             const int64_t n = std::min(chunk, dp.n - offset);
@@ -1725,6 +1809,15 @@ private:
                 if (reorder) {
                     launch_msplit(a.part_ids, n, partitions + 1, mc.data(), (int32_t)mc.size(), counts,
                                   part_temp_.ensure(msplit_temp_bytes(n, partitions + 1)), s);
+                    if (ldsp) {
+                        // the kernel finds its rows through the partition boundaries on the device: the host does not need them
+                        launch_exclusive_prefix_i64(counts, partitions + 1, static_cast<int64_t*>(part_first_.ensure((size_t)(partitions + 2) * 8)), s);
+                        timer.end(s, false);
+                        rp.n = (int32_t)n;
+                        RowList list{nullptr, n, 0, n};
+                        run_page(lk, rp, false, &list);
+                        continue;
+                    }
                     timer.end(s, false);
                     int64_t dropped = 0;
                     PA_HIP(hipMemcpyAsync(&dropped, counts + partitions, 8, hipMemcpyDeviceToHost, s));
@@ -1766,14 +1859,15 @@ private:
         int64_t offset = list ? list->first_row : start_row;
         const int64_t total = list ? list->first_row + list->chunk_rows : dp.n;
         // the HBM-table variant bounds the groups one launch can add so that the table can be sized first
-        const int64_t chunk = (ki.variant == V_GT || ki.variant == V_LDSH) ? (int64_t)1 << 26 : total;
+        const bool table_tier = ki.variant == V_GT || ki.variant == V_LDSH || ki.variant == V_LDSP;
+        const int64_t chunk = table_tier ? (int64_t)1 << 26 : total;
         // LDS variant: head = leading multiple of 256 rows through the vector kernel, tail = the rest through the scalar one
         const int64_t lds_head = (ki.variant == V_LDS && vec) ? (total & ~(int64_t)255) : 0;
         while (offset < total) {
             int64_t n = std::min(chunk, total - offset);
             // the first launch on the HBM table is a short one: it tells how many groups there are, which decides the
             // number of table replicas for the rest
-            if ((ki.variant == V_GT || ki.variant == V_LDSH) && !gt_probed_ && !list) n = std::min<int64_t>(n, (int64_t)1 << 22);
+            if (table_tier && !gt_probed_ && !list) n = std::min<int64_t>(n, (int64_t)1 << 22);
             bool use_tail = false;
             if (ki.variant == V_LDS) {
                 if (offset < lds_head) {
@@ -1806,6 +1900,9 @@ private:
                 int per_cu = std::max(1, std::min(16, (int)(160 * 1024 / ((size_t)ki.nw * ki.c * 64 * 8 + 512))));
                 grid = (int)std::min<int64_t>((work + 63) / 64, (int64_t)cus_ * per_cu);
             }
+            else if (ki.variant == V_LDSP) {
+                grid = sub_parts_;  // one workgroup per partition, whatever the page holds
+            }
             else if (ki.variant == V_LDSH) {
                 grid = (int)std::min<int64_t>((work + ki.block - 1) / ki.block, (int64_t)cus_ * (ki.block == 1024 ? 1 : 2));  // LDS per CU: 160 KB
                 // partition-ordered rows: at least one workgroup per partition, so that a workgroup's table meets the groups of
@@ -1818,7 +1915,8 @@ private:
             grid = std::max(grid, 1);
             // V_LDSH: every workgroup adds up to lc / 2 groups of its LDS table at the end of the launch, and must find room
             uint32_t reps = 1;
-            if (ki.variant == V_GT || ki.variant == V_LDSH) {
+            if (ki.variant == V_LDSP) reps = gt_rep_;  // the HBM table only takes the rows that fall through
+            else if (ki.variant == V_GT || ki.variant == V_LDSH) {
                 const uint32_t want = desired_replicas(gt_probed_ ? groups_upper_ : std::max<uint64_t>(groups_upper_, (uint64_t)std::max(spec_.expected_groups, 1)));
                 // change the layout only when it pays: much more replication needed, or far too much held
                 reps = (want >= 2 * gt_rep_ || want * 4 <= gt_rep_) ? want : gt_rep_;
@@ -1860,7 +1958,8 @@ private:
                 // sized by the groups seen so far, not by the rows: rows whose new group does not fit are spilled and
                 // replayed after a rehash (see below)
                 // (ensure_table doubles its argument: the table is kept at most half full)
-                const uint64_t expected = (uint64_t)std::max(spec_.expected_groups, 0);
+                // (partition-owned tables: the HBM table only takes what falls through -- no need to size it for the estimate)
+                const uint64_t expected = ki.variant == V_LDSP ? 0 : (uint64_t)std::max(spec_.expected_groups, 0);
                 ensure_table(std::max<uint64_t>({(uint64_t)16384 / reps, groups_upper_ + groups_upper_ / 4, expected}) + flush_room, reps);
                 if (gt_rep_ != reps) {  // the memory bound reduced the replicas
                     flush_room = room_for_flush(gt_rep_);
@@ -1878,7 +1977,17 @@ private:
             a.gt_words = gt_words_.as<uint64_t>();
             a.gt_mask = gt_cap_ ? gt_cap_ - 1 : 0;
             a.gt_max_fill = ki.variant == V_LDS ? (int32_t)(gt_cap_ - gt_cap_ / 4) : (int32_t)(gt_cap_ / 2 - flush_room);
-            a.gt_rep_mask = (ki.variant == V_GT || ki.variant == V_LDSH) ? gt_rep_ - 1 : 0;
+            a.gt_rep_mask = table_tier ? gt_rep_ - 1 : 0;
+            if (ki.variant == V_LDSP) {
+                a.sub_tag = sub_tag_.as<uint64_t>();
+                a.sub_keys = sub_keys_.as<uint64_t>();
+                a.sub_words = sub_words_.as<uint64_t>();
+                a.sub_count = sub_count_.as<int32_t>();
+                a.part_first = part_first_.as<int64_t>();
+                a.row_list = nullptr;
+                a.n_list = 0;
+                a.list_blocked = 0;
+            }
             a.gt_rep_count = rep_count_.as<int32_t>();
             void* params[] = {&a};
             timer.begin(s);
@@ -1927,8 +2036,15 @@ private:
                 for (;;) {
                     read_group_counts(s);
                     raise_if(h_ctl_[0]);
+                    const bool first_probe = !gt_probed_;
                     gt_probed_ = true;
                     const uint32_t spilled = (uint32_t)h_ctl_[6];
+                    if (ki.variant == V_LDSP) {
+                        uint64_t fell;
+                        memcpy(&fell, h_ctl_ + 2, 8);
+                        if (fell != 0) PA_HIP(hipMemsetAsync(ctl_ + 2, 0, 8, s));
+                        sub_fell_ += fell;
+                    }
                     if (ki.variant == V_LDSH) {
                         // rows that found no room in the workgroups' LDS tables: when they are a large part of the
                         // page, the cardinality is beyond this variant and later pages go to the HBM table directly
@@ -1940,6 +2056,12 @@ private:
                     if (spilled == 0) {
                         // (also after replays of spilled rows: the rest of the page must not crawl through the wrong tier)
                         if (ki.variant == V_LDSH && mode_ == V_GT && !list && offset + n < total) resume_from_ = offset + n;
+                        // the probe launch on the HBM table has told the cardinality: when it calls for the hash-partitioned
+                        // tiers, the rest of this page already goes there
+                        if (ki.variant == V_GT && first_probe && !list && offset + n < total && mode_ == V_GT) {
+                            int p = 0;
+                            if (partitioned_wanted(*cur_sig_, *cur_layout_, &p)) resume_from_ = offset + n;
+                        }
                         break;
                     }
                     PA_HIP(hipMemsetAsync(ctl_ + 6, 0, 4, s));
@@ -1958,9 +2080,11 @@ private:
                     r.gt_max_fill = (int32_t)(gt_cap_ / 2 - flush_room);
                     void* rparams[] = {&r};
                     // (never more workgroups than the launch the table was sized for: V_LDSH flushes per workgroup)
-                    int rgrid = (int)std::max<int64_t>(1, std::min<int64_t>(((int64_t)spilled + ki.block - 1) / ki.block, (int64_t)grid));
+                    // partition-owned tables: the spilled rows are a list over all partitions -- they go to the HBM table, through its kernel
+                    const Compiled& rk = ki.variant == V_LDSP ? kernel_for(*cur_sig_, *cur_layout_, V_GT) : ck;
+                    int rgrid = (int)std::max<int64_t>(1, std::min<int64_t>(((int64_t)spilled + rk.info.block - 1) / rk.info.block, (int64_t)grid));
                     timer.begin(s);
-                    PA_HIP(hipModuleLaunchKernel(ck.kernel.fn, rgrid, 1, 1, ki.block, 1, 1, 0, s, rparams, nullptr));
+                    PA_HIP(hipModuleLaunchKernel(rk.kernel.fn, rgrid, 1, 1, rk.info.block, 1, 1, 0, s, rparams, nullptr));
                     timer.end(s);
                     cur ^= 1;
                 }
@@ -2075,6 +2199,11 @@ private:
     bool gt_probed_ = false, lds_probed_ = false;
     int64_t resume_from_ = -1;
     bool retained_ = false;               // the page being processed stays readable until its launches are confirmed
+    // partition-owned tables (V_LDSP)
+    int sub_parts_ = 0, sub_lc_ = 0;
+    bool want_ldsp_ = false;
+    uint64_t sub_fell_ = 0;               // rows that fell through to the HBM table (their partition's table was full)
+    DevBuf sub_tag_, sub_keys_, sub_words_, sub_count_, part_first_;
     bool parked_ = false;                 // a stable page waits for HBM (see retry_parked)
     pa_page parked_page_{};
     std::vector<pa_column> parked_cols_;
@@ -2359,6 +2488,41 @@ void FusedAggregationOperator::build_output()
     PA_HIP(hipMemcpyAsync(h_ctl_, ctl_, 32, hipMemcpyDeviceToHost, s));
     PA_HIP(hipStreamSynchronize(s));
     raise_if(h_ctl_[0]);
+    if (grouped_ && sub_parts_ > 0) {
+        // Partition-owned tables.  Their HBM form IS a group table of sub_parts_ * lc slots (same arrays, same layouts; only the
+        // probe sequence differs, and nothing probes any more).  When the HBM table proper holds no group -- nothing fell
+        // through, no other tier ran -- they simply become the table; else their groups are folded into it, one upsert per group.
+        std::vector<int32_t> per_part((size_t)sub_parts_);
+        PA_HIP(hipMemcpyAsync(per_part.data(), sub_count_.ptr(), (size_t)sub_parts_ * 4, hipMemcpyDeviceToHost, s));
+        read_group_counts(s);
+        uint64_t total = 0;
+        for (int32_t c : per_part) total += (uint64_t)c;
+        const uint32_t sub_cap = (uint32_t)sub_parts_ * (uint32_t)sub_lc_;
+        if (groups_sum_ == 0) {
+            gt_tag_ = std::move(sub_tag_);
+            gt_keys_ = std::move(sub_keys_);
+            gt_words_ = std::move(sub_words_);
+            gt_cap_ = sub_cap;
+            gt_rep_ = 1;
+            const int32_t count = (int32_t)total;
+            PA_HIP(hipMemcpyAsync(ctl_ + 1, &count, 4, hipMemcpyHostToDevice, s));
+            PA_HIP(hipStreamSynchronize(s));
+            h_ctl_[1] = count;
+            groups_upper_ = groups_sum_ = total;
+        }
+        else {
+            ensure_table(groups_sum_ + total + 1024, 1);
+            launch_gt_fold(sub_tag_.as<uint64_t>(), sub_keys_.as<uint64_t>(), sub_words_.as<uint64_t>(), sub_cap, 1, std::max(w_, 1), nw_, kinds_dev_,
+                           gt_tag_.as<uint64_t>(), gt_keys_.as<uint64_t>(), gt_words_.as<uint64_t>(), gt_cap_ - 1, 1, ctl_ + 1, rep_count_.as<int32_t>(), ctl_, s);
+            PA_HIP(hipMemcpyAsync(h_ctl_, ctl_, 32, hipMemcpyDeviceToHost, s));
+            PA_HIP(hipStreamSynchronize(s));
+            raise_if(h_ctl_[0]);
+            sub_tag_.release();
+            sub_keys_.release();
+            sub_words_.release();
+        }
+        sub_parts_ = 0;
+    }
     std::vector<uint64_t> keys, words;
     int64_t groups = 0;
     if (!grouped_) {

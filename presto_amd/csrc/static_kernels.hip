@@ -612,6 +612,41 @@ void launch_tpch(int32_t column, double sf, int64_t first_row, int64_t n, uint64
     PA_HIP(hipGetLastError());
 }
 
+// ---- partition-owned tables of the fused aggregation (V_LDSP) ----
+// out[i] = in[0] + ... + in[i - 1] for i in [0, n]  (n <= 4097: the partitions of one multisplit)
+__global__ __launch_bounds__(1024) void k_exclusive_prefix_i64(const i64* __restrict__ in, i32 n, i64* __restrict__ out)
+{
+    __shared__ i64 part[1024];
+    // thread t owns the elements [t * 5, t * 5 + 5): 1024 x 5 >= 4097
+    i64 local[5];
+    i64 sum = 0;
+    for (int j = 0; j < 5; j++) {
+        const int i = (int)threadIdx.x * 5 + j;
+        local[j] = sum;
+        if (i < n) sum += in[i];
+    }
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        i64 v = 0;
+        if ((int)threadIdx.x >= off) v = part[threadIdx.x - off];
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    const i64 base = part[threadIdx.x] - sum;
+    for (int j = 0; j < 5; j++) {
+        const int i = (int)threadIdx.x * 5 + j;
+        if (i <= n) out[i] = base + local[j];
+    }
+}
+void launch_exclusive_prefix_i64(const int64_t* in, int32_t n, int64_t* out, hipStream_t s)
+{
+    PA_REQUIRE(n >= 0 && n <= 5119, PA_ERR_NOT_SUPPORTED, "prefix of at most 5119 values");
+    hipLaunchKernelGGL(k_exclusive_prefix_i64, 1, 1024, 0, s, (const i64*)in, n, (i64*)out);
+    PA_HIP(hipGetLastError());
+}
+
 // ---- reference-format aggregation states (op_states.cpp) ----
 __global__ __launch_bounds__(256) void k_widen_i32_i64(const i32* __restrict__ in, i64 n, i64* __restrict__ out)
 {

@@ -57,7 +57,8 @@ if "agg" in which:
         keys = torch.randint(0, groups, (rows,), dtype=torch.int64, device="cuda", generator=g)
         page = Page([dev_block(abi.BIGINT, keys), dev_block(abi.DOUBLE, vals)], rows, abi.MEM_DEVICE)
         sub = [Page([Block(abi.BIGINT, abi.FLAT, 1 << 24, values=DeviceBuffer(keys.data_ptr() + 8 * i, 8 << 24, keys)),
-                     Block(abi.DOUBLE, abi.FLAT, 1 << 24, values=DeviceBuffer(vals.data_ptr() + 8 * i, 8 << 24, vals))], 1 << 24, abi.MEM_DEVICE)
+                     Block(abi.DOUBLE, abi.FLAT, 1 << 24, values=DeviceBuffer(vals.data_ptr() + 8 * i, 8 << 24, vals))], 1 << 24, abi.MEM_DEVICE,
+                    stable=os.environ.get("AGG_STABLE", "1") == "1")   # row ranges of resident tensors: PA_PAGE_STABLE (AGG_STABLE=0: pages of their own)
                for i in range(0, rows, 1 << 24)]
         def run():
             op = HashAggregationOperator([abi.BIGINT, abi.DOUBLE], [0], [(abi.AGG_SUM, 1, abi.DOUBLE), (abi.AGG_COUNT_STAR, -1, None)],

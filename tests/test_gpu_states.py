@@ -164,11 +164,12 @@ def test_operator_blocks_on_the_hbm_budget_and_resumes(gpu, oracle, monkeypatch)
     in_use = C.c_int64()
     check(lib().pa_memory_stats(C.byref(in_use), None, None))
     try:
-        # room for ONE table of 4 M expected groups (2 x 4 M slots x 24 B ~ 200 MB) next to what is already held
-        check(lib().pa_memory_set_limit(in_use.value + (320 << 20)))
-        first = HashAggregationOperator([abi.BIGINT, abi.BIGINT], [0], aggs, expected_groups=4_000_000)
+        # room for ONE HBM table of 8 M expected groups (16 M slots x 24 B ~ 400 MB; beyond the partition-owned tier's range, so
+        # the table is allocated with the first page) next to what is already held
+        check(lib().pa_memory_set_limit(in_use.value + (640 << 20)))
+        first = HashAggregationOperator([abi.BIGINT, abi.BIGINT], [0], aggs, expected_groups=8_000_000)
         first.addInput(page)
-        second = HashAggregationOperator([abi.BIGINT, abi.BIGINT], [0], aggs, expected_groups=4_000_000)
+        second = HashAggregationOperator([abi.BIGINT, abi.BIGINT], [0], aggs, expected_groups=8_000_000)
         assert second.needsInput()
         check(lib().pa_op_add_input(second._h, C.byref(page.to_c()[0])))   # taken, but put aside: no HBM for its table
         assert second.isBlocked() and not second.needsInput()
