@@ -369,7 +369,7 @@ JNIEXPORT void JNICALL Java_io_trino_gpu_GpuNative_addInput(JNIEnv* env, jclass 
     page.channel_count = channels;
     page.columns = cols;
     page.mem = PA_MEM_HOST;
-    page.flags = stable ? PA_PAGE_STABLE : 0;
+    page.flags = stable ? (PA_PAGE_STABLE | PA_PAGE_PINNED) : 0;   /* the slab is pa_host_malloc_pinned memory: the device reads it in place */
     int32_t rc = pa_op_add_input((pa_operator*)(intptr_t)h, &page);
     (*env)->ReleaseIntArrayElements(env, types, t, JNI_ABORT);
     (*env)->ReleaseIntArrayElements(env, encodings, e, JNI_ABORT);

@@ -2,7 +2,7 @@
 # Collects, on the GPU box, everything profiles/ is made of (run through gpurun from the repo root):
 #   1. kernel trace + stats of `python3 bench.py`          -> gpurun_out/r_trace   (+ the bench line of that run)
 #   2. FETCH_SIZE and WRITE_SIZE counter passes (separate) -> gpurun_out/r_fetch, gpurun_out/r_write
-#   3. the default `python3 bench.py` (with cpu_baseline)  -> gpurun_out/r_bench_default.json
+#   3. the default `python3 bench.py` (with q3, h2d, cpu_baseline) -> gpurun_out/r_bench_default.json
 #   4. kernel trace + stats of scripts/bench_q3.py         -> gpurun_out/r_q3 (+ its line)
 # scripts/summarize_profile.py then writes profiles/<tag>_*.  Counter passes never combine --pmc with API traces.
 set -e -o pipefail
@@ -10,11 +10,11 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 rm -rf $O/r_trace $O/r_fetch $O/r_write $O/r_q3
-timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d $O/r_trace -- python3 $R/bench.py --steps 5 --warmup 2 --cpu-rows 0 > $O/r_trace_bench.json 2> $O/r_trace.err
+timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d $O/r_trace -- python3 $R/bench.py --steps 5 --warmup 2 --cpu-rows 0 --q3 0 --h2d-rows 0 > $O/r_trace_bench.json 2> $O/r_trace.err
 echo "trace done"
-timeout -k 10 240 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/r_fetch -- python3 $R/bench.py --steps 3 --warmup 1 --cpu-rows 0 > $O/r_fetch.json 2> $O/r_fetch.err
+timeout -k 10 240 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/r_fetch -- python3 $R/bench.py --steps 3 --warmup 1 --cpu-rows 0 --q3 0 --h2d-rows 0 > $O/r_fetch.json 2> $O/r_fetch.err
 echo "fetch done"
-timeout -k 10 240 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/r_write -- python3 $R/bench.py --steps 3 --warmup 1 --cpu-rows 0 > $O/r_write.json 2> $O/r_write.err
+timeout -k 10 240 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/r_write -- python3 $R/bench.py --steps 3 --warmup 1 --cpu-rows 0 --q3 0 --h2d-rows 0 > $O/r_write.json 2> $O/r_write.err
 echo "write done"
 cd $R
 timeout -k 10 300 python3 bench.py > $O/r_bench_default.json 2> $O/r_bench_default.err

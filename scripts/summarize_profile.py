@@ -72,7 +72,7 @@ for k in dur:
         "hbm_bytes_per_launch": (2.0 * fetch_kib + write_kib) * 1024.0,
         "correction": "FETCH_SIZE x2 (gfx950 wide streaming reads), WRITE_SIZE x1; KiB -> bytes",
     }
-json.dump({"tag": tag, "command": "python3 bench.py --steps N --warmup W --cpu-rows 0 (SF100, 2^28-row pages)", "kernels": traffic},
+json.dump({"tag": tag, "command": "python3 bench.py --steps N --warmup W --cpu-rows 0 --q3 0 --h2d-rows 0 (SF100, 2^28-row pages)", "kernels": traffic},
           open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)
 
 with open(os.path.join(out, tag + "_summary.md"), "w") as f:
