@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PA_ABI_VERSION 5
+#define PA_ABI_VERSION 6
 
 /* ---- status codes (negative = error).  Mapped by the JNI shim onto TrinoException
  *      StandardErrorCode (trino-spi/.../StandardErrorCode.java). ---- */
@@ -307,6 +307,23 @@ typedef struct pa_lookup_join_desc {
                                           * most one output row per probe row -- the first position of its chain */
 } pa_lookup_join_desc;
 
+/* Fused pipeline: [Scan]FilterAndProject -> LookupJoinOperator -> (Hash)AggregationOperator, the probe side of a join whose
+ * output is only ever aggregated (TPC-H Q3's lineitem pipeline; LocalExecutionPlanner chains exactly these three operator
+ * factories in one Driver).  Semantically the composition of the three descriptors: the join's probe page is the projection
+ * output (join.probe_* index the projections), the aggregation's input page is the join's output page = [probe output channels,
+ * build output channels] (LookupJoinPageBuilder.java:76-139).  When the lookup source has one BIGINT / INTEGER / DATE key and no
+ * duplicate keys (known once the build side has finished), filter, probe (JoinProbe.java:87-117, DefaultPageJoiner.java:236-320)
+ * and accumulation run as ONE generated kernel: no compacted probe page, no position lists, no join output page; if in
+ * addition every group key is the join key or a build column (and the join key is among them), the group IS the build row and
+ * the accumulators are indexed by build position.  In every other case the operator runs the three device operators behind
+ * each other internally -- same results either way (summation order of DOUBLE sums aside, as for any device aggregation).
+ * join.join_type must be PA_JOIN_INNER; join.output_mem and filter_project.output_mem are ignored. */
+typedef struct pa_fused_join_aggregation_desc {
+    pa_filter_project_desc filter_project;
+    pa_lookup_join_desc join;
+    pa_hash_aggregation_desc aggregation;   /* input_* fields describe the join's output page */
+} pa_fused_join_aggregation_desc;
+
 /* TopNOperator.createOperatorFactory (TopNOperator.java:43-90): keep the n best rows under (sort_channels, sort_orders)
  * and emit them, ordered, as one page after finish.  Ties between fully equal sort keys come out in arrival order (the
  * reference leaves their order unspecified). */
@@ -429,6 +446,8 @@ int32_t pa_scan_stats(pa_operator* op, int64_t* processed_positions, int64_t* ma
 int32_t pa_aggregation_create(const pa_aggregation_desc* desc, pa_operator** out);
 int32_t pa_hash_aggregation_create(const pa_hash_aggregation_desc* desc, pa_operator** out);
 int32_t pa_fused_aggregation_create(const pa_fused_aggregation_desc* desc, pa_operator** out);
+/* `bridge` must already have its build operator (as for pa_lookup_join_create); pa_op_is_blocked is 1 until the build finished. */
+int32_t pa_fused_join_aggregation_create(const pa_fused_join_aggregation_desc* desc, pa_lookup_source* bridge, pa_operator** out);
 int32_t pa_topn_create(const pa_topn_desc* desc, pa_operator** out);
 int32_t pa_order_by_create(const pa_order_by_desc* desc, pa_operator** out);
 /* The dynamic filter of an INNER (or lookup-outer) join applied where Trino applies it -- in the scan / filter upstream of the
@@ -647,6 +666,10 @@ int32_t pa_tpch_generate(int32_t column, double scale_factor, int64_t first_row,
  * variant: -1 default, 0 GLOBAL (no keys), 1 LDS (few groups), 2 GT (HBM table). */
 int64_t pa_codegen_fused(const pa_fused_aggregation_desc* desc, int32_t variant, char* buf, int64_t buf_size, char* key);
 int64_t pa_codegen_compile_fused(const pa_fused_aggregation_desc* desc, int32_t variant);
+/* the one-kernel form of a fused join-aggregation over a lookup source shaped as `build` describes (variant: -1 default,
+ * 0 GLOBAL, 1 LDS, 2 GT, 3 LDS table per workgroup, 6 BROW = accumulators indexed by build position) */
+int64_t pa_codegen_fused_join(const pa_fused_join_aggregation_desc* desc, const pa_hash_builder_desc* build, int32_t variant, char* buf, int64_t buf_size);
+int64_t pa_codegen_compile_fused_join(const pa_fused_join_aggregation_desc* desc, const pa_hash_builder_desc* build, int32_t variant);
 int64_t pa_codegen_filter_project(const pa_filter_project_desc* desc, char* buf, int64_t buf_size, char* key);
 int64_t pa_codegen_compile_filter_project(const pa_filter_project_desc* desc);
 

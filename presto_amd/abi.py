@@ -5,7 +5,7 @@ test-only oracle binding (oracle/oracle.py), exactly as both C sides share the h
 """
 import ctypes as C
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 # pa_status
 OK = 0
@@ -259,6 +259,14 @@ class pa_lookup_join_desc(C.Structure):
         ("stream", C.c_void_p),
         ("join_type", C.c_int32),
         ("output_single_match", C.c_int32),
+    ]
+
+
+class pa_fused_join_aggregation_desc(C.Structure):
+    _fields_ = [
+        ("filter_project", pa_filter_project_desc),
+        ("join", pa_lookup_join_desc),
+        ("aggregation", pa_hash_aggregation_desc),
     ]
 
 

@@ -318,6 +318,15 @@ int32_t pa_hash_aggregation_create(const pa_hash_aggregation_desc* desc, pa_oper
     return guarded([&]() -> int32_t { return create_plain_aggregation(desc, out); });
 }
 
+int32_t pa_fused_join_aggregation_create(const pa_fused_join_aggregation_desc* desc, pa_lookup_source* bridge, pa_operator** out)
+{
+    return guarded([&]() -> int32_t {
+        PA_REQUIRE(desc != nullptr && out != nullptr && bridge != nullptr, PA_ERR_INVALID_ARGUMENT, "null argument");
+        *out = make_fused_join_aggregation(desc, bridge);
+        return PA_OK;
+    });
+}
+
 int32_t pa_aggregation_create(const pa_aggregation_desc* desc, pa_operator** out)
 {
     return guarded([&]() -> int32_t {
@@ -726,9 +735,10 @@ int32_t pa_op_kernel_time(pa_operator* op, double* total_ms, int64_t* launches)
     return guarded([&]() -> int32_t {
         PA_REQUIRE(op != nullptr, PA_ERR_INVALID_ARGUMENT, "operator is null");
         OpScope scope(op);
-        op->timer.drain();
-        if (total_ms) *total_ms = op->timer.total_ms();
-        if (launches) *launches = op->timer.launches();
+        pa::KernelTimer& timer = op->kernel_timer();
+        timer.drain();
+        if (total_ms) *total_ms = timer.total_ms();
+        if (launches) *launches = timer.launches();
         return PA_OK;
     });
 }
@@ -958,6 +968,29 @@ int64_t pa_codegen_compile_fused(const pa_fused_aggregation_desc* desc, int32_t 
     return rc < 0 ? rc : size;
 }
 
+int64_t pa_codegen_fused_join(const pa_fused_join_aggregation_desc* desc, const pa_hash_builder_desc* build, int32_t variant, char* buf, int64_t buf_size)
+{
+    int64_t need = 0;
+    int32_t rc = guarded([&]() -> int32_t {
+        std::string entry;
+        std::string tu = jit_translation_unit(fused_join_source_for_desc(desc, build, variant, &entry));
+        need = (int64_t)tu.size() + 1;
+        if (buf && buf_size >= need) memcpy(buf, tu.c_str(), (size_t)need);
+        return PA_OK;
+    });
+    return rc < 0 ? rc : need;
+}
+int64_t pa_codegen_compile_fused_join(const pa_fused_join_aggregation_desc* desc, const pa_hash_builder_desc* build, int32_t variant)
+{
+    int64_t size = 0;
+    int32_t rc = guarded([&]() -> int32_t {
+        std::string entry;
+        size = (int64_t)jit_compile_only(fused_join_source_for_desc(desc, build, variant, &entry)).size();
+        return PA_OK;
+    });
+    return rc < 0 ? rc : size;
+}
+
 int64_t pa_codegen_filter_project(const pa_filter_project_desc* desc, char* buf, int64_t buf_size, char* key)
 {
     int64_t need = 0;
@@ -989,3 +1022,12 @@ int64_t pa_codegen_compile_filter_project(const pa_filter_project_desc* desc)
 }
 
 }  // extern "C"
+
+namespace pa {
+pa_operator* make_hash_aggregation(const pa_hash_aggregation_desc* desc)
+{
+    pa_operator* op = nullptr;
+    create_plain_aggregation(desc, &op);
+    return op;
+}
+}  // namespace pa

@@ -302,6 +302,7 @@ __global__ __launch_bounds__(256) void k_join_keyed_build(JoinCol build_key, con
                 }
                 if (pending && cur >= 0) {
                     if (__hip_atomic_load(&slots[pos].key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == v) {
+                        err[1] = 1;  // the key has a second row: positionLinks chains exist (idempotent plain store)
                         atomicMax(&slots[pos].head, p);
                         slot_of[p] = (i32)pos;
                         pending = false;

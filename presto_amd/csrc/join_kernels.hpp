@@ -50,6 +50,7 @@ struct JoinKeyBitmap {
     uint64_t range;         // max - min
 };
 // The keyed probe-side table and positionLinks straight from the build rows (raw_hash may be null: computed from the key).
+// err[0] = device error word, err[1] = set to 1 when some key occurs on more than one row.
 void launch_join_keyed_build(const JoinCol& build_key, const int64_t* raw_hash, int32_t n, JoinKeySlot* slots, uint32_t slots_mask, int32_t* slot_of,
                              int32_t* links, int32_t* err, hipStream_t s);
 void launch_join_key_bitmap(const JoinCol& build_key, int32_t n, int64_t min_key, uint64_t range, uint64_t* bits, hipStream_t s);

@@ -280,6 +280,7 @@ __device__ __forceinline__ u32 pa_mix32(u64 k)
 // Group tables.  Keys are packed into W 64-bit words (exprgen); equality is word equality.
 // ---------------------------------------------------------------------------------------------
 #define PA_MAX_CHANNELS 32
+#define PA_MAX_BUILD_CHANNELS 8
 
 // Kernel argument block of the fused scan-filter-project-aggregate kernels (op_fused.cpp keeps the
 // host mirror `FusedArgs` in sync).
@@ -322,7 +323,113 @@ struct PaFusedArgs {
     u64* sub_words;
     i32* sub_count;
     const i64* part_first;
+    // Probe stage (fused FilterAndProject -> LookupJoin -> aggregation over a lookup source with ONE integer key and no
+    // duplicate keys): the keyed probe-side table of join_kernels.hpp (16 B slots: key, head, next), the build side's key
+    // existence bitmap (null = none) and the build columns the aggregation reads, indexed by build position.
+    const void* jslots;
+    const u64* jbits;
+    i64 jmin;
+    u64 jrange;
+    u32 jmask;
+    i32 jrows;                        // build positions (the build-row table of the BROW variant has this many slots)
+    const void* bv[PA_MAX_BUILD_CHANNELS];
+    const u8* bn[PA_MAX_BUILD_CHANNELS];
 };
+
+// JoinProbe.getCurrentJoinPosition for a keyed lookup source without duplicate keys (…/operator/join/JoinProbe.java:87-117,
+// PagesHash.getAddressIndex, PagesHash.java:158-170): the build position of key `v`, or -1.  Same walk as
+// k_join_probe_count_keyed (join_kernels.hip): bitmap first -- most probe rows of a selective join miss, and a clustered probe
+// side reads the bitmap almost sequentially -- then linear probing over 64-byte lines of four slots.
+__device__ __forceinline__ i32 pa_join_probe_from(const PaFusedArgs& a, const u64 v, u32 pos)
+{
+    const pa_u32x4* lines = (const pa_u32x4*)a.jslots;
+    for (u32 seen = 0; seen <= a.jmask;) {
+        const u32 base = pos & ~3u, first = pos & 3u;
+        pa_u32x4 q[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) q[k] = lines[base + k];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if ((u32)k < first) continue;
+            const i32 cur = (i32)q[k].z;
+            if (cur == -1) return -1;
+            if ((((u64)q[k].y << 32) | (u64)q[k].x) == v) return cur;
+        }
+        seen += 4u - first;
+        pos = (base + 4u) & a.jmask;
+    }
+    return -1;
+}
+__device__ __forceinline__ u32 pa_join_home(const PaFusedArgs& a, const u64 v) { return (u32)pa_murmur3_fmix((u64)pa_hash_bigint((i64)v)) & a.jmask; }
+__device__ __forceinline__ i32 pa_join_probe_keyed(const PaFusedArgs& a, const u64 v)
+{
+    if (a.jbits) {
+        const u64 d = (u64)((i64)v - a.jmin);
+        if (d > a.jrange || ((a.jbits[d >> 6] >> (d & 63ULL)) & 1ULL) == 0ULL) return -1;
+    }
+    return pa_join_probe_from(a, v, pa_join_home(a, v));
+}
+// The same for the four consecutive rows a thread of the vector loops holds, stage by stage: the four bitmap words, then the four
+// pairs of slots, are loaded back to back and waited for once.  Row by row, a row costs two to three DEPENDENT trips to HBM
+// (bitmap word, slot, then the columns only matches read), and a wave of the row loop is then bound by latency, not bandwidth:
+// Q3's lineitem pages ran at 1.7 ms per 2^28 rows that way, three times the time of the filter alone.  A key equal to its
+// predecessor's (a probe side clustered by the key) reuses the predecessor's answer.  s[r]: row r probes; k[r]: its key.
+__device__ __forceinline__ void pa_join_probe4(const PaFusedArgs& a, const bool (&s)[4], const u64 (&k)[4], i32 (&jb)[4])
+{
+    bool dup[4], need[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        dup[r] = r > 0 && s[r] && s[r - 1] && k[r] == k[r - 1];
+        need[r] = s[r] && !dup[r];
+    }
+    if (a.jbits) {
+        u64 d[4], w[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            d[r] = (u64)((i64)k[r] - a.jmin);
+            need[r] = need[r] && d[r] <= a.jrange;
+            w[r] = 0ULL;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            if (need[r]) w[r] = a.jbits[d[r] >> 6];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; r++) need[r] = need[r] && ((w[r] >> (d[r] & 63ULL)) & 1ULL) != 0ULL;
+    }
+    const pa_u32x4* slots = (const pa_u32x4*)a.jslots;
+    u32 pos[4];
+    pa_u32x4 s0[4], s1[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        pos[r] = pa_join_home(a, k[r]);
+        s0[r] = pa_u32x4{0u, 0u, 0xffffffffu, 0u};
+        s1[r] = s0[r];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        if (need[r]) {
+            s0[r] = slots[pos[r]];
+            s1[r] = slots[(pos[r] + 1u) & a.jmask];
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        i32 res = -1;
+        if (need[r] && (i32)s0[r].z != -1) {
+            if ((((u64)s0[r].y << 32) | (u64)s0[r].x) == k[r]) res = (i32)s0[r].z;
+            else if ((i32)s1[r].z != -1) {
+                if ((((u64)s1[r].y << 32) | (u64)s1[r].x) == k[r]) res = (i32)s1[r].z;
+                else res = pa_join_probe_from(a, k[r], (pos[r] + 2u) & a.jmask);  // a probe sequence longer than two slots
+            }
+        }
+        jb[r] = res;
+    }
+#pragma unroll
+    for (int r = 1; r < 4; r++) {
+        if (dup[r]) jb[r] = jb[r - 1];
+    }
+}
 
 // the replica of the group table this workgroup works on
 struct PaGtView {

@@ -16,7 +16,16 @@
 //   LDS     <= C groups: one wave per workgroup, wave-private LDS key table and lane-private LDS
 //           accumulators (no atomics, no barriers), per-wave partial tables in a slab -> merge kernel.
 //   GT      any cardinality: open-addressing table in HBM, agent-scope atomics.
+//   BROW    probe stage only (below): the group IS the build row -- accumulators indexed by build position, no hashing.
 // All are HBM-read bound: algorithmic bytes per row = sum of the widths of the referenced columns.
+//
+// Probe stage (pa_fused_join_aggregation_desc): FilterAndProjectOperator -> LookupJoinOperator (INNER) -> (Hash)AggregationOperator
+// as ONE pass -- filter, key-bitmap test, keyed probe (JoinProbe.getCurrentJoinPosition, JoinProbe.java:87-117;
+// DefaultPageJoiner.joinCurrentPosition, DefaultPageJoiner.java:236-320) and accumulation in the generated row function; no
+// compacted probe page, no (probe, build) position lists, no gathered join output.  Taken when the lookup source has one integer
+// key and no duplicate keys (each probe row then has at most one match); op_fused_join.cpp runs the three operators one after
+// the other otherwise.  The channels of the join's output page become projections: probe outputs are the FilterAndProject
+// projections, build outputs are "virtual" input channels n_in + v read from the lookup source's columns at the build position.
 #include <algorithm>
 #include <cmath>
 #include <deque>
@@ -29,6 +38,7 @@
 #include "exprgen.hpp"
 #include "host_hash.hpp"
 #include "jit.hpp"
+#include "join_source.hpp"
 #include "operator.hpp"
 #include "rowgen.hpp"
 #include "scan_kernels.hpp"
@@ -48,12 +58,15 @@ void launch_gt_fold(const uint64_t* old_tag, const uint64_t* old_keys, const uin
                     int32_t* count0, int32_t* rep_count, int32_t* err, hipStream_t s);
 
 void launch_exclusive_prefix_i64(const int64_t* in, int32_t n, int64_t* out, hipStream_t s);
+void launch_count_nonzero_u64(const uint64_t* v, int64_t n, int64_t stride, uint64_t empty, int64_t* out, hipStream_t s);
+void launch_fill_u64(uint64_t* dst, uint64_t value, int64_t n, hipStream_t s);
 void launch_gt_compact(const uint64_t* tag, const uint64_t* keys, const uint64_t* words, uint32_t cap, int w, int nw, uint64_t* out_keys,
-                       uint64_t* out_words, uint32_t* counter, hipStream_t s);
+                       uint64_t* out_words, uint32_t* counter, hipStream_t s, const GtStrides* strides = nullptr);
 
 namespace {
 
 constexpr int kMaxChannels = 32;  // PA_MAX_CHANNELS in pa_device.h
+constexpr int kMaxBuildChannels = 8;  // PA_MAX_BUILD_CHANNELS
 
 // host mirror of PaFusedArgs (pa_device.h)
 struct FusedArgs {
@@ -87,10 +100,19 @@ struct FusedArgs {
     uint64_t* sub_words;
     int32_t* sub_count;
     const int64_t* part_first;
+    const void* jslots;
+    const uint64_t* jbits;
+    int64_t jmin;
+    uint64_t jrange;
+    uint32_t jmask;
+    int32_t jrows;
+    const void* bv[kMaxBuildChannels];
+    const uint8_t* bn[kMaxBuildChannels];
 };
 
 // V_LDSP: the LDS-table variant with partition-owned tables (see PaFusedArgs::sub_tag)
-enum Variant { V_GLOBAL = 0, V_LDS = 1, V_GT = 2, V_LDSH = 3, V_HASH = 4, V_LDSP = 5 };
+// V_BROW: probe stage whose group keys are functions of the build row: the table slot is the build position
+enum Variant { V_GLOBAL = 0, V_LDS = 1, V_GT = 2, V_LDSH = 3, V_HASH = 4, V_LDSP = 5, V_BROW = 6 };
 enum WordKind { W_CNT = 0, W_SUMF = 1, W_SUMI = 2, W_MAXU = 3 };
 
 constexpr int kLdsSlots = 8;  // C of the LDS variant: 8 groups x NW words x 64 lanes x 8 B of LDS per wave
@@ -106,7 +128,23 @@ struct KeyPart {
     int null_shift = 0;
 };
 
+// The probe stage between the projections and the aggregation (see the head of the file).
+struct JoinStage {
+    std::shared_ptr<LookupSourceImpl> ls;
+    int key_proj = -1;                 // projection that is the probe join key
+    std::vector<int> build_cols;       // virtual channel n_in + v reads ls->cols[build_cols[v]] at the build position
+    std::vector<int32_t> build_types;
+    // per group key: the projection to take it from when the slot is the build position (build columns only: the probe join key
+    // is replaced by the build key column, equal on every match); empty = the group keys do not determine / are not determined
+    // by the build row, no BROW variant
+    std::vector<int> brow_group_proj;
+};
+
 struct Spec {
+    std::shared_ptr<JoinStage> join;   // null: no probe stage
+    // per channel: read inside the selected-rows block only (probe stage: everything the filter and the probe key do not need
+    // is loaded for the rows that found a match, not for the whole page)
+    std::vector<bool> lazy_channel;
     int n_in = 0;
     std::vector<int32_t> in_types, in_params;
     bool has_filter = false;
@@ -131,6 +169,10 @@ struct KernelInfo {
     int variant = V_GLOBAL;
     int nw = 0, w = 0, c = 0, block = 256;
     int lc = 0;  // V_LDSH: slots of the workgroup's LDS table
+    // V_BROW: the accumulator word every row of a group updates -- "this build row has a group" is read off it (its value differs
+    // from occ_empty), and the kernel stores no tags -- or -1: tags are stored
+    int occ_word = -1;
+    uint64_t occ_empty = 0;
     std::vector<int32_t> word_kind;
     std::vector<std::pair<int, int>> agg_words;  // per aggregate: (count word, value word or -1)
     std::vector<KeyPart> keys;
@@ -144,10 +186,24 @@ struct LayoutChange {};
 
 void finalize_spec(Spec& s);
 
-Spec make_spec(const pa_fused_aggregation_desc* d)
+OwnedExpr input_ref_expr(int32_t channel, int32_t type)
 {
-    const pa_filter_project_desc& fp = d->filter_project;
-    const pa_hash_aggregation_desc& ag = d->aggregation;
+    OwnedExpr e;
+    pa_expr_node node{};
+    node.kind = PA_EXPR_INPUT_REF;
+    node.type = type;
+    node.channel = channel;
+    e.nodes.push_back(node);
+    e.strings.emplace_back();
+    e.root = 0;
+    return e;
+}
+
+// jd / bridge: the probe stage between the projections and the aggregation (null: none); the aggregation's channels then index
+// the join's output page = [probe output channels, build output channels] (LookupJoinPageBuilder.java:76-139)
+Spec make_spec(const pa_filter_project_desc& fp, const pa_hash_aggregation_desc& ag, const pa_lookup_join_desc* jd = nullptr,
+               pa_lookup_source* bridge = nullptr)
+{
     Spec s;
     PA_REQUIRE(fp.input_channel_count > 0 && fp.input_channel_count <= kMaxChannels, PA_ERR_NOT_SUPPORTED,
                "fused aggregation supports 1..32 input channels");
@@ -161,21 +217,102 @@ Spec make_spec(const pa_fused_aggregation_desc* d)
         PA_REQUIRE(s.filter.root_type() == PA_BOOLEAN, PA_ERR_INVALID_ARGUMENT, "filter must be BOOLEAN");
     }
     for (int32_t j = 0; j < fp.projection_count; j++) s.proj.push_back(OwnedExpr::copy(fp.projections[j]));
-    PA_REQUIRE(ag.input_channel_count == fp.projection_count, PA_ERR_INVALID_ARGUMENT,
-               "aggregation input channels must be the projection outputs");
+    // channel of the aggregation's input page -> projection
+    std::vector<int> to_proj;
+    if (!jd) {
+        for (int32_t j = 0; j < fp.projection_count; j++) to_proj.push_back(j);
+    }
+    else {
+        PA_REQUIRE(bridge != nullptr && bridge->impl != nullptr, PA_ERR_ILLEGAL_STATE, "lookup source has no build operator yet");
+        PA_REQUIRE(ag.step == PA_STEP_SINGLE || ag.step == PA_STEP_PARTIAL, PA_ERR_NOT_SUPPORTED, "an aggregation over a join output is SINGLE or PARTIAL");
+        PA_REQUIRE(jd->join_type == PA_JOIN_INNER, PA_ERR_NOT_SUPPORTED, "the fused probe is an inner join");
+        auto js = std::make_shared<JoinStage>();
+        js->ls = bridge->impl;
+        const LookupSourceImpl& ls = *js->ls;
+        PA_REQUIRE(jd->probe_channel_count == fp.projection_count, PA_ERR_INVALID_ARGUMENT, "the probe page is the projection output");
+        PA_REQUIRE(jd->join_channel_count == 1 && ls.join_channels.size() == 1, PA_ERR_NOT_SUPPORTED, "the fused probe takes one join key");
+        const int kc = jd->probe_join_channels[0];
+        PA_REQUIRE(kc >= 0 && kc < fp.projection_count, PA_ERR_INVALID_ARGUMENT, "probe join channel out of range");
+        const int build_key_col = ls.join_channels[0];
+        const int32_t kt = s.proj[kc].root_type();
+        PA_REQUIRE(kt == PA_BIGINT || kt == PA_INTEGER || kt == PA_DATE, PA_ERR_NOT_SUPPORTED, "the fused probe takes a BIGINT / INTEGER / DATE key");
+        PA_REQUIRE(kt == ls.cols[build_key_col].type, PA_ERR_INVALID_ARGUMENT, "probe / build join key types differ");
+        js->key_proj = kc;
+        // virtual channels are made for the build columns the aggregation reads
+        std::set<int> read;
+        for (int32_t g = 0; g < ag.group_by_count; g++) read.insert(ag.group_by_channels[g]);
+        for (int32_t k = 0; k < ag.aggregate_count; k++) {
+            if (ag.aggregates[k].fn != PA_AGG_COUNT_STAR) read.insert(ag.aggregates[k].input_channel);
+            if (ag.aggregates[k].mask_channel >= 0) read.insert(ag.aggregates[k].mask_channel);
+        }
+        std::map<int, int> proj_of_build_col;
+        auto build_proj = [&](int col) {
+            auto it = proj_of_build_col.find(col);
+            if (it != proj_of_build_col.end()) return it->second;
+            const int32_t t = ls.cols[col].type;
+            PA_REQUIRE(t != PA_VARCHAR, PA_ERR_NOT_SUPPORTED, "VARCHAR build columns are not read by the fused probe");
+            PA_REQUIRE((int)js->build_cols.size() < kMaxBuildChannels, PA_ERR_NOT_SUPPORTED, "the fused probe reads at most 8 build columns");
+            const int v = (int)js->build_cols.size();
+            js->build_cols.push_back(col);
+            js->build_types.push_back(t);
+            s.proj.push_back(input_ref_expr(s.n_in + v, t));
+            return proj_of_build_col[col] = (int)s.proj.size() - 1;
+        };
+        std::vector<int> build_col_of;  // per channel of the joined page: the build column, or -1 for a probe output
+        for (int32_t i = 0; i < jd->probe_output_channel_count; i++) {
+            const int c = jd->probe_output_channels[i];
+            PA_REQUIRE(c >= 0 && c < fp.projection_count, PA_ERR_INVALID_ARGUMENT, "probe output channel out of range");
+            to_proj.push_back(c);
+            build_col_of.push_back(-1);
+        }
+        for (int col : ls.output_channels) {
+            const int j = (int)to_proj.size();
+            to_proj.push_back(read.count(j) ? build_proj(col) : -1);
+            build_col_of.push_back(col);
+        }
+        // build-row tables: every group key is the join key or a build output, and the join key is among them (without it,
+        // two build rows could hold the same group)
+        bool eligible = ag.group_by_count > 0, has_key = false;
+        std::vector<int> brow;
+        for (int32_t g = 0; g < ag.group_by_count && eligible; g++) {
+            const int ch = ag.group_by_channels[g];
+            if (ch < 0 || ch >= (int)to_proj.size()) break;  // refused below
+            if (build_col_of[ch] >= 0) {
+                brow.push_back(to_proj[ch]);
+                has_key = has_key || build_col_of[ch] == build_key_col;
+            }
+            else if (to_proj[ch] == kc) {
+                brow.push_back(-2);  // the build key column: made a virtual channel below, when the variant is possible at all
+                has_key = true;
+            }
+            else eligible = false;
+        }
+        if (eligible && has_key && (int)brow.size() == ag.group_by_count) {
+            for (int& j : brow) {
+                if (j == -2) j = build_proj(build_key_col);
+            }
+            js->brow_group_proj = brow;
+        }
+        s.join = js;
+    }
+    PA_REQUIRE(ag.input_channel_count == (int32_t)to_proj.size(), PA_ERR_INVALID_ARGUMENT,
+               jd ? "aggregation input channels must be the join output" : "aggregation input channels must be the projection outputs");
+    const int32_t n_agg_in = (int32_t)to_proj.size();
     PA_REQUIRE(ag.step == PA_STEP_SINGLE || ag.step == PA_STEP_PARTIAL || ag.step == PA_STEP_FINAL, PA_ERR_INVALID_ARGUMENT, "unknown aggregation step");
     s.step = ag.step;
     for (int32_t g = 0; g < ag.group_by_count; g++) {
         int ch = ag.group_by_channels[g];
-        PA_REQUIRE(ch >= 0 && ch < fp.projection_count, PA_ERR_INVALID_ARGUMENT, "group-by channel out of range");
-        s.group_proj.push_back(ch);
+        PA_REQUIRE(ch >= 0 && ch < n_agg_in, PA_ERR_INVALID_ARGUMENT, "group-by channel out of range");
+        s.group_proj.push_back(to_proj[ch]);
     }
     s.hash_channel = ag.hash_channel;
     for (int32_t k = 0; k < ag.aggregate_count; k++) {
         pa_aggregate a = ag.aggregates[k];
-        PA_REQUIRE(a.fn == PA_AGG_COUNT_STAR || (a.input_channel >= 0 && a.input_channel < fp.projection_count), PA_ERR_INVALID_ARGUMENT,
+        PA_REQUIRE(a.fn == PA_AGG_COUNT_STAR || (a.input_channel >= 0 && a.input_channel < n_agg_in), PA_ERR_INVALID_ARGUMENT,
                    "aggregate input channel out of range");
-        PA_REQUIRE(a.mask_channel < fp.projection_count, PA_ERR_INVALID_ARGUMENT, "aggregate mask channel out of range");
+        PA_REQUIRE(a.mask_channel < n_agg_in, PA_ERR_INVALID_ARGUMENT, "aggregate mask channel out of range");
+        if (a.fn != PA_AGG_COUNT_STAR) a.input_channel = to_proj[a.input_channel];
+        if (a.mask_channel >= 0) a.mask_channel = to_proj[a.mask_channel];
         if (a.fn == PA_AGG_MIN || a.fn == PA_AGG_MAX) {
             PA_REQUIRE(a.input_type != PA_VARCHAR, PA_ERR_NOT_SUPPORTED, "min/max over VARCHAR are not on the device path yet");
         }
@@ -209,6 +346,7 @@ Spec make_spec(const pa_fused_aggregation_desc* d)
     finalize_spec(s);
     return s;
 }
+Spec make_spec(const pa_fused_aggregation_desc* d) { return make_spec(d->filter_project, d->aggregation); }
 
 // channels read, short / interned VARCHAR keys: everything of a Spec that follows from its expressions and aggregates
 void finalize_spec(Spec& s)
@@ -217,6 +355,10 @@ void finalize_spec(Spec& s)
     std::set<int32_t> used;
     if (s.has_filter) s.filter.collect_channels(&used);
     std::set<int> used_proj(s.group_proj.begin(), s.group_proj.end());
+    if (s.join) {
+        used_proj.insert(s.join->key_proj);
+        used_proj.insert(s.join->brow_group_proj.begin(), s.join->brow_group_proj.end());
+    }
     for (const auto& a : s.aggs) {
         if (a.fn != PA_AGG_COUNT_STAR || s.step == PA_STEP_FINAL) used_proj.insert(a.input_channel);
         if (s.step == PA_STEP_FINAL && a.fn != PA_AGG_COUNT && a.fn != PA_AGG_COUNT_STAR) used_proj.insert(a.input_channel + 1);  // the value state
@@ -224,9 +366,18 @@ void finalize_spec(Spec& s)
     }
     for (int j : used_proj) s.proj[j].collect_channels(&used);
     s.used_channel.assign(s.n_in, false);
+    const int n_virtual = s.join ? (int)s.join->build_cols.size() : 0;
     for (int32_t c : used) {
-        PA_REQUIRE(c >= 0 && c < s.n_in, PA_ERR_INVALID_ARGUMENT, "expression references a channel outside the page");
-        s.used_channel[c] = true;
+        PA_REQUIRE(c >= 0 && c < s.n_in + n_virtual, PA_ERR_INVALID_ARGUMENT, "expression references a channel outside the page");
+        if (c < s.n_in) s.used_channel[c] = true;
+    }
+    s.lazy_channel.assign(s.n_in, false);
+    if (s.join) {
+        // the filter and the probe key run for every row; what only the aggregation reads is loaded for the matches
+        std::set<int32_t> eager;
+        if (s.has_filter) s.filter.collect_channels(&eager);
+        s.proj[s.join->key_proj].collect_channels(&eager);
+        for (int c = 0; c < s.n_in; c++) s.lazy_channel[c] = s.used_channel[c] && !eager.count(c);
     }
     s.short_bound.assign(s.n_in, 0);
     s.interned.assign(s.n_in, false);
@@ -267,6 +418,9 @@ void finalize_spec(Spec& s)
             if (pe.is_input_ref() && pe.node(pe.root).channel == c) pe.nodes[pe.root].type = PA_INTEGER;
         }
     }
+    for (int c = 0; c < s.n_in; c++) {
+        if (s.interned[c] || s.in_types[c] == PA_VARCHAR) s.lazy_channel[c] = false;  // strings are handed to the row function whole
+    }
 }
 
 // ---- source generation -------------------------------------------------------------------------
@@ -297,12 +451,26 @@ KernelInfo generate(const Spec& s, const std::vector<ChannelLayout>& layout, int
     k.block = variant == V_LDS ? 64 : 256;
     k.c = variant == V_LDS ? kLdsSlots : 0;
 
+    PA_REQUIRE(variant != V_BROW || (s.join && !s.join->brow_group_proj.empty()), PA_ERR_NOT_SUPPORTED, "no build-row variant for this plan");
+    PA_REQUIRE(!s.join || (variant != V_HASH && variant != V_LDSP), PA_ERR_NOT_SUPPORTED, "no hash-partitioned variants behind a probe stage");
     RowInputs ri;
     ri.n_in = s.n_in;
     ri.used = s.used_channel;
+    for (int c = 0; c < s.n_in; c++) ri.used[c] = s.used_channel[c] && !s.lazy_channel[c];
     ri.short_bound = s.short_bound;
     std::ostringstream body;  // inside pa_row
-    RowCodegen gen(layout, "a.err");
+    // the page's channels, then the build columns of the probe stage as channels n_in + v (`layout` may already hold them:
+    // their nullability is the lookup source's)
+    std::vector<ChannelLayout> ext(layout.begin(), layout.begin() + s.n_in);
+    if (s.join) {
+        for (size_t v = 0; v < s.join->build_cols.size(); v++) {
+            ChannelLayout cl;
+            cl.type = s.join->build_types[v];
+            cl.nullable = (size_t)s.n_in + v < layout.size() ? layout[(size_t)s.n_in + v].nullable : true;
+            ext.push_back(cl);
+        }
+    }
+    RowCodegen gen(ext, "a.err");
 
     // 1. filter
     std::string sel = "true";
@@ -310,7 +478,21 @@ KernelInfo generate(const Spec& s, const std::vector<ChannelLayout>& layout, int
         GenValue f = gen.emit(s.filter, body);
         sel = f.nullable() ? "(!" + f.n + " && " + f.v + ")" : f.v;  // PageFunctionCompiler.java:539-542
     }
-    body << "const bool sel = live && " << sel << ";\n";
+    std::ostringstream pre;  // probe stage: body of pa_pre (filter, then the probe key of the rows it keeps)
+    if (s.join) {
+        // 1b. rows the filter keeps look their key up; a NULL key matches nothing (JoinProbe.java:89-91)
+        pre << body.str() << "sel0 = live && " << sel << ";\njk = 0ULL;\nif (sel0) {\n";
+        GenValue pk = gen.emit(s.proj[s.join->key_proj], pre);
+        if (pk.nullable()) pre << "if (" << pk.n << ") sel0 = false; else ";
+        pre << "jk = (u64)(i64)" << pk.v << ";\n}\n";
+        body.str("");
+        // what follows (pa_post) runs per row with `jb`, the build position of the match -- the lookup source has no duplicate
+        // keys, so it is the only one -- or -1
+        body << "const bool sel = jb >= 0;\n";
+    }
+    else {
+        body << "const bool sel = live && " << sel << ";\n";
+    }
 
     // 2. projections used downstream, evaluated once, only for selected rows
     std::ostringstream inner;
@@ -328,9 +510,22 @@ KernelInfo generate(const Spec& s, const std::vector<ChannelLayout>& layout, int
         if ((int)word_terms.size() <= word) word_terms.resize(word + 1);
         word_terms[word].push_back(term);
     };
-    for (size_t gi = 0; gi < s.group_proj.size(); gi++) {
-        const GenValue& kv = proj_value(s.group_proj[gi]);
-        const OwnedExpr& pe = s.proj[s.group_proj[gi]];
+    // BROW: the key words are not computed per row -- the slot is the build position -- but once per group, by pa_brow_keys, from
+    // the build columns alone
+    const bool brow = variant == V_BROW;
+    const std::vector<int>& gp = brow ? s.join->brow_group_proj : s.group_proj;
+    std::ostringstream key_os;
+    std::map<int, GenValue> kpv;
+    auto key_value = [&](int j) -> const GenValue& {
+        if (!brow) return proj_value(j);
+        auto it = kpv.find(j);
+        if (it == kpv.end()) it = kpv.emplace(j, gen.emit(s.proj[j], key_os)).first;
+        return it->second;
+    };
+    std::ostringstream& kinner = brow ? key_os : inner;
+    for (size_t gi = 0; gi < gp.size(); gi++) {
+        const GenValue& kv = key_value(gp[gi]);
+        const OwnedExpr& pe = s.proj[gp[gi]];
         KeyPart part;
         part.type = kv.type;
         std::string value;  // u64 expression already confined to `bits` bits
@@ -356,7 +551,7 @@ KernelInfo generate(const Spec& s, const std::vector<ChannelLayout>& layout, int
                 break;
             case PA_VARCHAR: {
                 int ch = pe.is_input_ref() ? pe.node(pe.root).channel : -1;
-                if (ch >= 0 && s.short_bound[ch] > 0) {
+                if (ch >= 0 && ch < s.n_in && s.short_bound[ch] > 0) {
                     part.bound = s.short_bound[ch];
                     part.bits = 8 * part.bound + 4;
                     value = "(cs" + std::to_string(ch) + " | ((u64)" + kv.len + " << " + std::to_string(8 * part.bound) + "))";
@@ -377,13 +572,13 @@ KernelInfo generate(const Spec& s, const std::vector<ChannelLayout>& layout, int
             int w2 = packer.place(64, &sh);
             PA_REQUIRE(w2 == part.word + 1, PA_ERR_NOT_SUPPORTED, "internal: long VARCHAR key words not adjacent");
             std::string id = "ks" + std::to_string(gi);
-            inner << "u64 " << id << "a = 0, " << id << "b = 0;\n";
-            inner << "if (" << (kv.nullable() ? "!" + kv.n : "true") << ") {\n";
-            inner << "  if (" << kv.len << " > 15) pa_raise(a.err, -3);\n";
-            inner << "  for (i32 b = 0; b < " << kv.len << " && b < 15; b++) {\n";
-            inner << "    if (b < 8) " << id << "a |= (u64)" << kv.v << "[b] << (8 * b); else " << id << "b |= (u64)" << kv.v
+            kinner << "u64 " << id << "a = 0, " << id << "b = 0;\n";
+            kinner << "if (" << (kv.nullable() ? "!" + kv.n : "true") << ") {\n";
+            kinner << "  if (" << kv.len << " > 15) pa_raise(a.err, -3);\n";
+            kinner << "  for (i32 b = 0; b < " << kv.len << " && b < 15; b++) {\n";
+            kinner << "    if (b < 8) " << id << "a |= (u64)" << kv.v << "[b] << (8 * b); else " << id << "b |= (u64)" << kv.v
                   << "[b] << (8 * (b - 8));\n  }\n";
-            inner << "  " << id << "b |= (u64)" << kv.len << " << 56;\n}\n";
+            kinner << "  " << id << "b |= (u64)" << kv.len << " << 56;\n}\n";
             add_term(part.word, id + "a");
             add_term(part.word + 1, id + "b");
         }
@@ -491,6 +686,17 @@ KernelInfo generate(const Spec& s, const std::vector<ChannelLayout>& layout, int
         k.nw = 1;
     }
     for (const auto& w : words) k.word_kind.push_back(w.kind);
+    if (variant == V_BROW) {
+        // a word every row of a group updates tells whether the build row has a group: a count is then > 0; a DOUBLE sum that
+        // starts at -0.0 and only ever takes values canonicalised by + 0.0 (x + 0.0 is x, except that -0.0 becomes +0.0) is then
+        // anything but -0.0 -- and equals what the reference computes, whose sum starts at +0.0 (0.0 + -0.0 = 0.0)
+        for (size_t w = 0; w < words.size() && k.occ_word < 0; w++) {
+            if (words[w].cond != "true" || (words[w].kind != W_CNT && words[w].kind != W_SUMF)) continue;
+            k.occ_word = (int)w;
+            k.occ_empty = words[w].kind == W_SUMF ? 0x8000000000000000ULL : 0ULL;
+        }
+        if (getenv("PRESTO_AMD_BROW_TAGS")) k.occ_word = -1;  // (test switch: the tag-storing form)
+    }
     {
         std::vector<std::string> names(words.size(), "rows");
         for (const auto& kv : word_index) names[(size_t)kv.second] = kv.first;
@@ -524,7 +730,9 @@ KernelInfo generate(const Spec& s, const std::vector<ChannelLayout>& layout, int
 
     // ---- assemble the translation unit ----
     std::ostringstream src;
-    src << "#define PA_NW " << k.nw << "\n#define PA_KW " << (k.w > 0 ? k.w : 1) << "\n#define PA_C " << (k.c > 0 ? k.c : 1) << "\n";
+    // (BROW: the row loop's "key" is the build position, one word; PA_TW = key words of the table, written by pa_brow_keys)
+    src << "#define PA_NW " << k.nw << "\n#define PA_KW " << (brow ? 1 : (k.w > 0 ? k.w : 1)) << "\n#define PA_TW " << (k.w > 0 ? k.w : 1) << "\n#define PA_C "
+        << (k.c > 0 ? k.c : 1) << "\n";
     if (variant == V_GLOBAL) {
         src << "struct PaAcc {";
         for (int w = 0; w < k.nw; w++) src << (words[w].kind == W_SUMF ? " double" : (words[w].kind == W_MAXU ? " u64" : " i64")) << " w" << w << ";";
@@ -583,6 +791,86 @@ KernelInfo generate(const Spec& s, const std::vector<ChannelLayout>& layout, int
         // partition order, a contiguous slice per workgroup, so that a workgroup's LDS table meets a few partitions' groups only.
         src << "struct PaAcc { int unused; };\n";
     }
+    else if (brow) {
+        // Build-row table.  Every scattered store / atomic INSTRUCTION of a wave costs the CU on the order of 100 ns whatever the
+        // number of active lanes (measured on Q3's lineitem pages: a flush wherever a thread's key changes -- up to five divergent
+        // tag-store + atomic sequences per quad -- 1.77 ms per 2^28-row page; one sequence per quad 1.15 ms).  So the rows of a quad
+        // are only NOTED (slot r of the thread: build position, flags, values; a row continuing its predecessor's build position
+        // takes that one's values over), and at the end of the quad the wave's noted rows -- a dozen of its 256 when 5 % match --
+        // are compacted through LDS and go out together: one tag store and one atomic per accumulator word for up to 64 of them.
+        // The slot is the build position: nothing to search, nothing to claim.  The tag only says "this build row has a group"
+        // -- a plain store into its own array: every writer stores the same value, so the XCD L2s need not agree on the line before
+        // the kernel ends; the key words are written once per group by pa_brow_keys.  (One record [tag, words] per build position
+        // instead of word-major arrays was 3 x slower: the memory-side atomics of neighbouring build rows share 64-byte requests
+        // only while the words of a kind lie side by side.)
+        auto wtype = [&](int w) { return std::string(words[w].kind == W_SUMF ? "double" : (words[w].kind == W_MAXU ? "u64" : "i64")); };
+        src << "struct PaAcc { PaGtView tv; PaGtCtr gt; bool ev[4]; u32 eg[4];";
+        for (int w = 0; w < k.nw; w++) src << " bool eu" << w << "[4]; " << wtype(w) << " ex" << w << "[4];";
+        src << " };\n";
+        // ... and they do not go out at once: a wave whose tag store and atomics are in flight cannot see the data of ANY later
+        // load before they have retired (vmcnt counts in order), and under load that took ~8 us per quad (0.96 ms of the 1.95 ms a
+        // 2^28-row page cost).  The noted rows are appended to a buffer of the wave in LDS instead, and the buffer is drained when
+        // it is full -- one such wait per ~10 quads.
+        const int waves = 4;  // 256 threads
+        const int cap = 128;  // entries per wave
+        src << "#define PA_BCAP " << cap << "u\n";
+        src << "__shared__ u32 pa_sg[" << waves << "][PA_BCAP];\n__shared__ u32 pa_su[" << waves << "][PA_BCAP];\n__shared__ u64 pa_sx[" << waves
+            << "][PA_NW][PA_BCAP];\n__shared__ u32 pa_sfill[" << waves << "];\n";
+        src << "#define PA_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, \"wavefront\"); __builtin_amdgcn_wave_barrier(); "
+               "__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, \"wavefront\"); } while (0)\n";
+        // noting row `slot` of the quad (a literal at every call site: the arrays stay in registers)
+        src << "__device__ __forceinline__ void pa_acc(const PaFusedArgs& a, PaAcc& acc, const int slot, const bool sel, const u64 (&key)[PA_KW]";
+        for (int w = 0; w < k.nw; w++) src << ", const bool u" << w << ", const " << wtype(w) << " x" << w;
+        src << ")\n{\n  acc.ev[slot] = sel;\n  acc.eg[slot] = (u32)key[0];\n";
+        for (int w = 0; w < k.nw; w++) src << "  acc.eu" << w << "[slot] = u" << w << "; acc.ex" << w << "[slot] = x" << w << ";\n";
+        src << "  if (slot > 0 && sel && acc.ev[slot > 0 ? slot - 1 : 0] && acc.eg[slot > 0 ? slot - 1 : 0] == acc.eg[slot]) {\n    const int p = slot > 0 ? slot - 1 : 0;\n";
+        for (int w = 0; w < k.nw; w++) {
+            const std::string P = "acc.ex" + std::to_string(w) + "[p]", X = "acc.ex" + std::to_string(w) + "[slot]";
+            std::string comb;
+            if (words[w].kind == W_SUMF || words[w].kind == W_CNT) comb = P + " + " + X;
+            else if (words[w].kind == W_SUMI) comb = "pa_add_exact(" + P + ", " + X + ", a.err)";
+            else comb = "(" + X + " > " + P + " ? " + X + " : " + P + ")";
+            src << "    if (acc.eu" << w << "[p]) { " << X << " = acc.eu" << w << "[slot] ? " << comb << " : " << P << "; acc.eu" << w << "[slot] = true; }\n";
+        }
+        src << "    acc.ev[p] = false;\n  }\n}\n";
+        // the buffered rows of the wave -> table; the issuing lanes are the ACTIVE ones, by rank (lanes that have left the row
+        // loop contribute nothing and issue nothing)
+        src << "__device__ __forceinline__ void pa_drain(const PaFusedArgs& a, PaAcc& acc, const u32 fill)\n{\n"
+               "  const u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;\n"
+               "  const u64 act = __ballot(true);\n  const u32 nact = (u32)__popcll(act), rank = (u32)__popcll(act & ((1ULL << lane) - 1ULL));\n"
+               "  const u64 cap = (u64)a.gt_mask + 1ULL;\n"
+               "  for (u32 i = rank; i < fill; i += nact) {\n    const u64 g = pa_sg[wave][i];\n    const u32 f = pa_su[wave][i];\n"
+            << (k.occ_word < 0 ? "    acc.tv.tag[g] = 3ULL;\n" : "");
+        for (int w = 0; w < k.nw; w++) {
+            const std::string W = std::to_string(w), idx = W + "ULL * cap + g", v = "pa_sx[wave][" + W + "][i]";
+            src << "    if (f & " << (1u << w) << "u) ";
+            if (words[w].kind == W_SUMF) src << "pa_gt_add_f64(acc.tv.words, " << idx << ", __longlong_as_double((i64)" << v << ")" << (w == k.occ_word ? " + 0.0" : "") << ");\n";
+            else if (words[w].kind == W_SUMI) src << "pa_gt_add_i64_exact(acc.tv.words, " << idx << ", (i64)" << v << ", a.err);\n";
+            else if (words[w].kind == W_MAXU) src << "pa_gt_max_u64(acc.tv.words, " << idx << ", " << v << ");\n";
+            else src << "pa_gt_add_u64(acc.tv.words, " << idx << ", " << v << ");\n";
+        }
+        src << "  }\n  PA_WAVE_SYNC();\n}\n";
+        // end of a quad: the wave's noted rows are appended (positions by ballot, slot by slot), draining whenever the buffer is full
+        src << "__device__ __forceinline__ void pa_flush(const PaFusedArgs& a, PaAcc& acc, const bool)\n{\n"
+               "  const u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;\n  const u64 below = (1ULL << lane) - 1ULL;\n"
+               "  u64 m[4];\n  u32 first[4], total = 0;\n"
+               "#pragma unroll\n  for (int e = 0; e < 4; e++) { m[e] = __ballot(acc.ev[e]); first[e] = total; total += (u32)__popcll(m[e]); }\n"
+               "  if (total == 0u) return;\n"
+               "  u32 fill = pa_sfill[wave];\n"
+               "  for (u32 base = 0; base < total;) {\n    const u32 room = PA_BCAP - fill, take = total - base < room ? total - base : room;\n"
+               "#pragma unroll\n    for (int e = 0; e < 4; e++) {\n      const u32 idx = first[e] + (u32)__popcll(m[e] & below) - base;\n"
+               "      if (acc.ev[e] && idx < take) {\n        const u32 at = fill + idx;\n        pa_sg[wave][at] = acc.eg[e];\n        u32 f = 0;\n";
+        for (int w = 0; w < k.nw; w++) {
+            const std::string W = std::to_string(w);
+            src << "        if (acc.eu" << W << "[e]) f |= " << (1u << w) << "u;\n        pa_sx[wave][" << W << "][at] = "
+                << (words[w].kind == W_SUMF ? "(u64)__double_as_longlong(acc.ex" + W + "[e])" : "(u64)acc.ex" + W + "[e]") << ";\n";
+        }
+        src << "        pa_su[wave][at] = f;\n      }\n    }\n"
+               "    fill += take;\n    base += take;\n    PA_WAVE_SYNC();\n"
+               "    if (fill == PA_BCAP) { pa_drain(a, acc, fill); fill = 0u; }\n  }\n"
+               "  pa_sfill[wave] = fill;\n  PA_WAVE_SYNC();\n"
+               "#pragma unroll\n  for (int e = 0; e < 4; e++) acc.ev[e] = false;\n}\n\n";
+    }
     else {
         // pending run of the thread: consecutive selected rows with equal keys are combined before they touch the table
         src << "struct PaAcc { PaGtView tv; PaGtCtr gt; i32 pn; i32 prow; u64 pk[PA_KW];";
@@ -590,55 +878,58 @@ KernelInfo generate(const Spec& s, const std::vector<ChannelLayout>& layout, int
         src << " };\n";
     }
     const bool lds_table = variant == V_LDSH || variant == V_LDSP;
-    if (variant == V_GT || lds_table) {
+    const bool gt_like = variant == V_GT;  // a thread-private pending run in front of the table
+    if (gt_like || lds_table) {
         // accumulation of one row into the workgroup's LDS table / the HBM table
-        src << "__device__ __forceinline__ void " << (variant == V_GT ? "pa_acc_now" : "pa_acc")
-            << "(const PaFusedArgs& a, PaAcc& acc, const bool sel, const i32 row, " << (variant == V_GT ? "const i32 nrows, " : "") << "const u64 (&key)[PA_KW]";
+        src << "__device__ __forceinline__ void " << (gt_like ? "pa_acc_now" : "pa_acc")
+            << "(const PaFusedArgs& a, PaAcc& acc, const bool sel, const i32 row, " << (gt_like ? "const i32 nrows, " : "") << "const u64 (&key)[PA_KW]";
         for (int w = 0; w < k.nw; w++) src << ", const bool u" << w << ", const " << (words[w].kind == W_SUMF ? "double" : (words[w].kind == W_MAXU ? "u64" : "i64")) << " x" << w;
         src << ")\n{\n";
-        src << "if (sel) {\n  const u32 h = pa_key_hash(key, PA_KW);\n";
-        if (lds_table) {
-            src << "  const int ls = pa_lt_upsert(h, key);\n  if (ls >= 0) {\n";
-            for (int w = 0; w < k.nw; w++) {
-                std::string idx = "pa_lt_acc[ls * PA_NW + " + std::to_string(w) + "]";
-                if (words[w].kind == W_SUMF) {
-                    src << "    if (u" << w << ") __hip_atomic_fetch_add((double*)&" << idx << ", x" << w << ", __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);\n";
+        {
+            src << "if (sel) {\n  const u32 h = pa_key_hash(key, PA_KW);\n";
+            if (lds_table) {
+                src << "  const int ls = pa_lt_upsert(h, key);\n  if (ls >= 0) {\n";
+                for (int w = 0; w < k.nw; w++) {
+                    std::string idx = "pa_lt_acc[ls * PA_NW + " + std::to_string(w) + "]";
+                    if (words[w].kind == W_SUMF) {
+                        src << "    if (u" << w << ") __hip_atomic_fetch_add((double*)&" << idx << ", x" << w << ", __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);\n";
+                    }
+                    else if (words[w].kind == W_SUMI) {
+                        src << "    if (u" << w << ") { i64 o = (i64)__hip_atomic_fetch_add(&" << idx << ", (u64)x" << w
+                            << ", __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); i64 r; if (__builtin_add_overflow(o, x" << w
+                            << ", &r)) pa_raise(a.err, PA_DEV_ERR_OUT_OF_RANGE); }\n";
+                    }
+                    else if (words[w].kind == W_MAXU) {
+                        src << "    if (u" << w << ") __hip_atomic_fetch_max(&" << idx << ", x" << w << ", __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);\n";
+                    }
+                    else {
+                        src << "    if (u" << w << ") __hip_atomic_fetch_add(&" << idx << ", " << ("(u64)x" + std::to_string(w))
+                            << ", __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);\n";
+                    }
                 }
-                else if (words[w].kind == W_SUMI) {
-                    src << "    if (u" << w << ") { i64 o = (i64)__hip_atomic_fetch_add(&" << idx << ", (u64)x" << w
-                        << ", __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); i64 r; if (__builtin_add_overflow(o, x" << w
-                        << ", &r)) pa_raise(a.err, PA_DEV_ERR_OUT_OF_RANGE); }\n";
-                }
-                else if (words[w].kind == W_MAXU) {
-                    src << "    if (u" << w << ") __hip_atomic_fetch_max(&" << idx << ", x" << w << ", __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);\n";
-                }
-                else {
-                    src << "    if (u" << w << ") __hip_atomic_fetch_add(&" << idx << ", " << ("(u64)x" + std::to_string(w))
-                        << ", __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);\n";
-                }
+                src << "  } else {\n  acc.fell++;\n";
             }
-            src << "  } else {\n  acc.fell++;\n";
+            src << "  int g = pa_gt_upsert<PA_KW>(acc.tv.tag, acc.tv.keys, a.gt_mask, h, key, acc.gt, a.gt_max_fill, a.err);\n";
+            src << "  if (g >= 0) {\n    const u64 cap = (u64)a.gt_mask + 1ULL;\n";
+            for (int w = 0; w < k.nw; w++) {
+                std::string idx = std::to_string(w) + "ULL * cap + (u64)g";
+                if (words[w].kind == W_SUMF) src << "    if (u" << w << ") pa_gt_add_f64(acc.tv.words, " << idx << ", x" << w << ");\n";
+                else if (words[w].kind == W_SUMI) src << "    if (u" << w << ") pa_gt_add_i64_exact(acc.tv.words, " << idx << ", x" << w << ", a.err);\n";
+                else if (words[w].kind == W_MAXU) src << "    if (u" << w << ") pa_gt_max_u64(acc.tv.words, " << idx << ", x" << w << ");\n";
+                else src << "    if (u" << w << ") pa_gt_add_u64(acc.tv.words, " << idx << ", (u64)x" << w << ");\n";
+            }
+            // no room for this row's group: spill the row; the host rehashes and replays the spilled rows
+            if (variant == V_GT) {
+                src << "  } else {\n    const u32 sb = atomicAdd(a.spill_count, (u32)nrows);\n    for (i32 i = 0; i < nrows; i++) a.spill_rows[sb + (u32)i] = row + i;\n  }\n";
+            }
+            else {
+                src << "  } else {\n    a.spill_rows[atomicAdd(a.spill_count, 1u)] = row;\n  }\n";
+            }
+            if (lds_table) src << "  }\n";
+            src << "}\n";
+            src << "}\n\n";
         }
-        src << "  int g = pa_gt_upsert<PA_KW>(acc.tv.tag, acc.tv.keys, a.gt_mask, h, key, acc.gt, a.gt_max_fill, a.err);\n";
-        src << "  if (g >= 0) {\n    const u64 cap = (u64)a.gt_mask + 1ULL;\n";
-        for (int w = 0; w < k.nw; w++) {
-            std::string idx = std::to_string(w) + "ULL * cap + (u64)g";
-            if (words[w].kind == W_SUMF) src << "    if (u" << w << ") pa_gt_add_f64(acc.tv.words, " << idx << ", x" << w << ");\n";
-            else if (words[w].kind == W_SUMI) src << "    if (u" << w << ") pa_gt_add_i64_exact(acc.tv.words, " << idx << ", x" << w << ", a.err);\n";
-            else if (words[w].kind == W_MAXU) src << "    if (u" << w << ") pa_gt_max_u64(acc.tv.words, " << idx << ", x" << w << ");\n";
-            else src << "    if (u" << w << ") pa_gt_add_u64(acc.tv.words, " << idx << ", (u64)x" << w << ");\n";
-        }
-        // no room for this row's group: spill the row; the host rehashes and replays the spilled rows
-        if (variant == V_GT) {
-            src << "  } else {\n    const u32 sb = atomicAdd(a.spill_count, (u32)nrows);\n    for (i32 i = 0; i < nrows; i++) a.spill_rows[sb + (u32)i] = row + i;\n  }\n";
-        }
-        else {
-            src << "  } else {\n    a.spill_rows[atomicAdd(a.spill_count, 1u)] = row;\n  }\n";
-        }
-        if (lds_table) src << "  }\n";
-        src << "}\n";
-        src << "}\n\n";
-        if (variant == V_GT) {
+        if (gt_like) {
             // Run combining.  A thread of the vector loop walks 4 consecutive rows; when their keys repeat (clustered inputs: a
             // fact table joined on its own key order) the rows are combined in registers and reach the table once -- one probe and
             // one atomic per word for the run.  pa_flush ends the pending run; the loops call it after every quad (every row
@@ -665,19 +956,88 @@ KernelInfo generate(const Spec& s, const std::vector<ChannelLayout>& layout, int
             src << "    }\n  }\n}\n\n";
         }
     }
-    src << "__device__ __forceinline__ void pa_row(const PaFusedArgs& a, PaAcc& acc, const bool live, const i32 row" << row_params(ri, layout) << ")\n{\n";
+    // probe stage: the build columns at the match (channels n_in + v), and the page's channels only the aggregation reads
+    std::ostringstream build_loads;
+    if (s.join) {
+        for (size_t v = 0; v < s.join->build_cols.size(); v++) {
+            const std::string id = std::to_string(s.n_in + (int)v), V = std::to_string(v);
+            const int32_t t = s.join->build_types[v];
+            const std::string ct = RowCodegen::ctype(t);
+            build_loads << "const " << ct << " c" << id << " = ";
+            if (t == PA_BIGINT) build_loads << "((const i64*)a.bv[" << V << "])[jb];\n";
+            else if (t == PA_INTEGER || t == PA_DATE) build_loads << "(i64)((const i32*)a.bv[" << V << "])[jb];\n";
+            else if (t == PA_DOUBLE) build_loads << "((const double*)a.bv[" << V << "])[jb];\n";
+            else if (t == PA_BOOLEAN) build_loads << "((const u8*)a.bv[" << V << "])[jb] != 0;\n";
+            else throw Error(PA_ERR_NOT_SUPPORTED, "build column type not read by the fused probe");
+            if (ext[(size_t)s.n_in + v].nullable) build_loads << "const bool cn" << id << " = a.bn[" << V << "] != nullptr && a.bn[" << V << "][jb] != 0;\n";
+        }
+    }
+    // loads of the lazy channels of one row into the variables c<C><suffix> (cn<C><suffix>)
+    auto lazy_assign = [&](const std::string& suffix, const std::string& row) {
+        std::ostringstream o;
+        for (int c = 0; c < s.n_in && s.join; c++) {
+            if (!s.lazy_channel[c]) continue;
+            const std::string C = std::to_string(c);
+            const int32_t t = layout[c].type;
+            o << "c" << C << suffix << " = ";
+            if (t == PA_BIGINT) o << "((const i64*)a.v[" << C << "])[" << row << "]; ";
+            else if (t == PA_INTEGER || t == PA_DATE) o << "(i64)((const i32*)a.v[" << C << "])[" << row << "]; ";
+            else if (t == PA_DOUBLE) o << "((const double*)a.v[" << C << "])[" << row << "]; ";
+            else if (t == PA_BOOLEAN) o << "((const u8*)a.v[" << C << "])[" << row << "] != 0; ";
+            else throw Error(PA_ERR_NOT_SUPPORTED, "column type not supported on device");
+            if (layout[c].nullable) o << "cn" << C << suffix << " = a.nl[" << C << "] != nullptr && a.nl[" << C << "][" << row << "] != 0; ";
+        }
+        return o.str();
+    };
+    // probe stage: pa_pre (filter + key) and pa_post (everything behind the probe) are separate functions, so that the vector loops
+    // can probe the four rows of a quad together (pa_join_probe4); pa_row, their row-by-row composition, serves the scalar loops
+    std::string lazy_params, lazy_names;
+    auto lazy_declare = [&](const std::string& suffix) {
+        std::string d;
+        for (int c = 0; c < s.n_in && s.join; c++) {
+            if (!s.lazy_channel[c]) continue;
+            const std::string C = std::to_string(c);
+            d += RowCodegen::ctype(layout[c].type) + " c" + C + suffix + " = 0; ";
+            if (layout[c].nullable) d += "bool cn" + C + suffix + " = false; ";
+        }
+        return d;
+    };
+    if (s.join) {
+        for (int c = 0; c < s.n_in; c++) {
+            if (!s.lazy_channel[c]) continue;
+            const std::string C = std::to_string(c), ct = RowCodegen::ctype(layout[c].type);
+            lazy_params += ", const " + ct + " c" + C;
+            lazy_names += ", c" + C;
+            if (layout[c].nullable) {
+                lazy_params += ", const bool cn" + C;
+                lazy_names += ", cn" + C;
+            }
+        }
+        src << "__device__ __forceinline__ void pa_pre(const PaFusedArgs& a, const bool live, const i32 row" << row_params(ri, layout)
+            << ", bool& sel0, u64& jk)\n{\n" << pre.str() << "}\n\n";
+        src << "__device__ __forceinline__ void pa_post(const PaFusedArgs& a, PaAcc& acc, const int slot, const i32 row, const i32 jb" << row_params(ri, layout)
+            << lazy_params << ")\n{\n";
+    }
+    else {
+        src << "__device__ __forceinline__ void pa_row(const PaFusedArgs& a, PaAcc& acc, const bool live, const i32 row" << row_params(ri, layout) << ")\n{\n";
+    }
     src << body.str();
     // values needed after the selected-only block are declared up front
     for (int w = 0; w < k.nw; w++) {
         src << "bool u" << w << " = false; " << (words[w].kind == W_SUMF ? "double" : (words[w].kind == W_MAXU ? "u64" : "i64")) << " x" << w << " = 0;\n";
     }
     if (k.w > 0) src << "u64 key[PA_KW];\n#pragma unroll\nfor (int i = 0; i < PA_KW; i++) key[i] = 0;\n";
-    src << "if (sel) {\n" << inner.str();
+    src << "if (sel) {\n" << build_loads.str() << inner.str();
     for (int w = 0; w < k.nw; w++) src << "u" << w << " = " << words[w].cond << "; x" << w << " = " << words[w].val << ";\n";
-    for (int i = 0; i < k.w; i++) {
-        src << "key[" << i << "] = ";
-        for (size_t t = 0; t < word_terms[i].size(); t++) src << (t ? " | " : "") << word_terms[i][t];
-        src << ";\n";
+    if (brow) {
+        src << "key[0] = (u64)(u32)jb;\n";
+    }
+    else {
+        for (int i = 0; i < k.w; i++) {
+            src << "key[" << i << "] = ";
+            for (size_t t = 0; t < word_terms[i].size(); t++) src << (t ? " | " : "") << word_terms[i][t];
+            src << ";\n";
+        }
     }
     src << "}\n";
     if (variant == V_HASH) {
@@ -725,12 +1085,24 @@ KernelInfo generate(const Spec& s, const std::vector<ChannelLayout>& layout, int
         // one overflow counter would serialise the useless pass on a single address: 3 ms instead of 0.25 ms per 64 M rows.)
         src << "  }\n}\n";
     }
+    else if (brow) {
+        src << "pa_acc(a, acc, slot, sel, key";
+        for (int w = 0; w < k.nw; w++) src << ", u" << w << ", x" << w;
+        src << ");\n";
+    }
     else {
         src << "pa_acc(a, acc, sel, row, key";
         for (int w = 0; w < k.nw; w++) src << ", u" << w << ", x" << w;
         src << ");\n";
     }
     src << "}\n\n";
+    if (s.join) {
+        src << "__device__ __forceinline__ void pa_row(const PaFusedArgs& a, PaAcc& acc, const bool live, const i32 row" << row_params(ri, layout) << ")\n{\n"
+            << "bool sel0; u64 jk;\npa_pre(a, live, row" << row_param_names(ri, layout) << ", sel0, jk);\n"
+            << "i32 jb = -1;\nif (sel0) jb = pa_join_probe_keyed(a, jk);\n"
+            << lazy_declare("") << "\nif (jb >= 0) { " << lazy_assign("", "row") << "}\n"
+            << "pa_post(a, acc, 0, row, jb" << row_param_names(ri, layout) << lazy_names << ");\n}\n\n";
+    }
 
     // kernels.  mode 0: one kernel walks the page (GLOBAL / GT).  LDS variant: the wave's key table is wave-uniform
     // state, so every lane must take part in every pa_row call; the host splits the page and `pa_fused` (mode 1) takes the
@@ -739,6 +1111,33 @@ KernelInfo generate(const Spec& s, const std::vector<ChannelLayout>& layout, int
     // wave-uniform trip count, finished lanes riding along with live == false on a clamped row.  Two entry points keep the
     // tail's code out of the hot loop's register allocation.
     const int B = k.block;
+    // the four rows 4q .. 4q + 3 of a thread of the vector loops
+    auto emit_quad = [&](const std::string (&args)[4]) {
+        if (!s.join) {
+            for (int r = 0; r < 4; r++) src << "        pa_row(a, acc, true, (i32)(4 * q + " << r << ")" << args[r] << ");\n";
+            return;
+        }
+        // probe stage: filter and key of the four rows, ONE staged probe for all of them, the lazy channels of the matches
+        // (again four loads in flight), then the rows one by one
+        src << "        bool js[4]; u64 jk[4]; i32 jb[4];\n";
+        for (int r = 0; r < 4; r++) src << "        pa_pre(a, true, (i32)(4 * q + " << r << ")" << args[r] << ", js[" << r << "], jk[" << r << "]);\n";
+        src << "        pa_join_probe4(a, js, jk, jb);\n";
+        for (int r = 0; r < 4; r++) src << "        " << lazy_declare("_" + std::to_string(r)) << "\n";
+        for (int r = 0; r < 4; r++) {
+            const std::string R = std::to_string(r);
+            src << "        if (jb[" << R << "] >= 0) { " << lazy_assign("_" + R, "4 * q + " + R) << "}\n";
+        }
+        for (int r = 0; r < 4; r++) {
+            const std::string R = std::to_string(r);
+            std::string names;
+            for (int c = 0; c < s.n_in; c++) {
+                if (!s.lazy_channel[c]) continue;
+                names += ", c" + std::to_string(c) + "_" + R;
+                if (layout[c].nullable) names += ", cn" + std::to_string(c) + "_" + R;
+            }
+            src << "        pa_post(a, acc, " << R << ", (i32)(4 * q + " << R << "), jb[" << R << "]" << args[r] << names << ");\n";
+        }
+    };
     auto emit_kernel = [&](const char* name, int mode) {
         src << "extern \"C\" __global__ __launch_bounds__(" << B << ") void " << name << "(PaFusedArgs a)\n{\n";
         if (variant == V_GLOBAL) {
@@ -774,11 +1173,16 @@ KernelInfo generate(const Spec& s, const std::vector<ChannelLayout>& layout, int
         else if (variant == V_HASH) {
             src << "    PaAcc acc; acc.unused = 0;\n";
         }
+        else if (brow) {
+            src << "    PaAcc acc; acc.tv = pa_gt_view(a, PA_KW, PA_NW); acc.gt = pa_gt_ctr_init(acc.tv.count, true, a.gt_rep_mask + 1u);\n"
+                   "#pragma unroll\n    for (int e = 0; e < 4; e++) acc.ev[e] = false;\n"
+                   "    if ((threadIdx.x & 63u) == 0u) pa_sfill[threadIdx.x >> 6] = 0u;\n    PA_WAVE_SYNC();\n";
+        }
         else {
             src << "    PaAcc acc; acc.tv = pa_gt_view(a, PA_KW, PA_NW); acc.gt = pa_gt_ctr_init(acc.tv.count, true, a.gt_rep_mask + 1u); acc.pn = 0;\n";
         }
         // V_GT: the pending run of every thread ends after a quad of consecutive rows / after every row of the other loops
-        const std::string flush = variant == V_GT ? " pa_flush(a, acc, true);" : "";
+        const std::string flush = gt_like || brow ? " pa_flush(a, acc, true);" : "";
         if (mode != 2) emit_prologue(ri, layout, src);
         if (variant == V_GLOBAL) {
             // XCD-aware block -> tile mapping: consecutive workgroup ids go round-robin to the 8 XCDs, so give the
@@ -795,7 +1199,7 @@ KernelInfo generate(const Spec& s, const std::vector<ChannelLayout>& layout, int
             src << "    const i64 nq = a.n >> 2;  // the host passes a multiple of 256 rows\n";
             src << "    for (i64 q = t; q < nq; q += T) {\n";
             emit_vector_loads(ri, layout, src, args);
-            for (int r = 0; r < 4; r++) src << "        pa_row(a, acc, true, (i32)(4 * q + " << r << ")" << args[r] << ");\n";
+            emit_quad(args);
             src << "    }\n";
         }
         else if (mode == 2) {
@@ -804,9 +1208,21 @@ KernelInfo generate(const Spec& s, const std::vector<ChannelLayout>& layout, int
         }
         else {
             src << "    const i64 nq = a.vec ? (a.n >> 2) : 0;\n";
-            src << "    for (i64 q = t; q < nq; q += T) {\n";
+            if (brow) {
+                // every wave walks ONE contiguous range of the page (its loads stay coalesced: 64 lanes x 16 B per instruction).
+                // When the probe side is clustered by the join key, the rows a wave notes then belong to neighbouring build rows,
+                // and a drained buffer reaches the table as a few dense 64-byte requests -- tags as whole lines, eight adds per atomic
+                // request -- instead of one read-modify-write in HBM per group
+                src << "    const i64 gw = (i64)blockIdx.x * " << (B / 64) << " + (threadIdx.x >> 6), nwv = (i64)gridDim.x * " << (B / 64) << ";\n"
+                       "    const i64 per = (((nq + nwv - 1) / nwv) + 63) & ~(i64)63;\n"
+                       "    const i64 q1 = (gw + 1) * per < nq ? (gw + 1) * per : nq;\n"
+                       "    for (i64 q = gw * per + (threadIdx.x & 63); q < q1; q += 64) {\n";
+            }
+            else {
+                src << "    for (i64 q = t; q < nq; q += T) {\n";
+            }
             emit_vector_loads(ri, layout, src, args);
-            for (int r = 0; r < 4; r++) src << "        pa_row(a, acc, true, (i32)(4 * q + " << r << ")" << args[r] << ");\n";
+            emit_quad(args);
             src << "       " << flush << "\n    }\n";
             src << "    for (i64 r = (nq << 2) + t; r < a.n; r += T) {\n        pa_row(a, acc, true, (i32)r" << scalar_args(ri, layout) << ");" << flush << "\n    }\n";
         }
@@ -850,7 +1266,8 @@ KernelInfo generate(const Spec& s, const std::vector<ChannelLayout>& layout, int
             src << "    }\n    pa_gt_ctr_flush(acc.flush, acc.tv.count);\n";
             src << "    { const i64 f = pa_wave_sum_i64(acc.fell); if ((threadIdx.x & 63) == 0 && f != 0) atomicAdd((unsigned long long*)a.overflow_rows, (unsigned long long)f); }\n";
         }
-        if (variant == V_GT || lds_table) src << "    pa_gt_ctr_flush(acc.gt, acc.tv.count);\n";
+        if (brow) src << "    pa_drain(a, acc, pa_sfill[threadIdx.x >> 6]);\n";  // (all lanes are back together behind the row loops)
+        if (gt_like || brow || lds_table) src << "    pa_gt_ctr_flush(acc.gt, acc.tv.count);\n";
         if (variant == V_GLOBAL) {
             src << "    __shared__ u64 red[" << (B / 64) << " * PA_NW];\n    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;\n";
             for (int w = 0; w < k.nw; w++) {
@@ -898,6 +1315,23 @@ KernelInfo generate(const Spec& s, const std::vector<ChannelLayout>& layout, int
     else {
         emit_kernel("pa_fused", 0);
     }
+    if (brow) {
+        // key words of the groups, once per group: build row b has a group when its tag is set; its key is a function of the
+        // build columns (the probe join key equals the build key column on every match)
+        src << "extern \"C\" __global__ __launch_bounds__(256) void pa_brow_keys(PaFusedArgs a)\n{\n"
+               "    const i64 cap = (i64)a.gt_mask + 1;\n"
+               "    for (i64 b = (i64)blockIdx.x * 256 + threadIdx.x; b < cap; b += (i64)gridDim.x * 256) {\n"
+            << (k.occ_word < 0 ? std::string("        if (a.gt_tag[b] == 0ULL) continue;\n")
+                               : "        if (a.gt_words[" + std::to_string(k.occ_word) + "ULL * (u64)cap + (u64)b] == " + std::to_string(k.occ_empty) + "ULL) continue;\n")
+            << "        const i32 jb = (i32)b;\n";
+        src << build_loads.str() << key_os.str();
+        for (int i = 0; i < k.w; i++) {
+            src << "        a.gt_keys[(u64)b * PA_TW + " << i << "] = ";
+            for (size_t t = 0; t < word_terms[i].size(); t++) src << (t ? " | " : "") << word_terms[i][t];
+            src << ";\n";
+        }
+        src << "    }\n}\n\n";
+    }
     k.source = src.str();
     return k;
 }
@@ -931,6 +1365,12 @@ public:
             for (int g : spec_.group_proj) f << g << ',';
             f << '|' << spec_.hash_channel << '|' << spec_.step << '|';
             for (const auto& a : spec_.aggs) f << a.fn << ',' << a.input_channel << ',' << a.mask_channel << ',' << a.input_type << ';';
+            if (spec_.join) {
+                f << "|join:" << spec_.join->key_proj << ':';
+                for (int32_t t : spec_.join->build_types) f << t << ',';
+                f << ':';
+                for (int j : spec_.join->brow_group_proj) f << j << ',';
+            }
             plan_fingerprint_ = f.str();
         }
         grouped_ = !spec_.group_proj.empty();
@@ -963,9 +1403,14 @@ public:
     // the host is one launch ahead of the device and never waits inside add_input for a stable page.  needs_input() turns
     // false -- and is_blocked() true -- while two launches are unconfirmed (Operator.isBlocked, Operator.java:69-80): the
     // Driver polls, as it does for a future, instead of parking a thread in the native call.
+    // probe stage: no page is taken before the build side has published its lookup source (LookupJoinOperator.needsInput /
+    // isBlocked on the lookup source future, LookupJoinOperator.java:63, 100)
+    bool lookup_source_ready() const { return !spec_.join || spec_.join->ls->built.load(); }
+
     bool needs_input() override
     {
         if (finishing_) return false;
+        if (!lookup_source_ready()) return false;
         if (!retry_parked()) return false;
         if (next_) return next_->needs_input();
         poll_inflight();
@@ -973,6 +1418,7 @@ public:
     }
     bool is_blocked() override
     {
+        if (!lookup_source_ready()) return !finishing_;
         if (!retry_parked()) return true;  // waiting for HBM (Operator.isBlocked on a memory future, Operator.java:69-80)
         if (next_) return next_->is_blocked();
         poll_inflight();
@@ -1323,6 +1769,15 @@ public:
             needed[c] = false;
             dict_keys.push_back(c);
         }
+        if (spec_.join && !join_checked_) {
+            const LookupSourceImpl& ls = *spec_.join->ls;
+            PA_REQUIRE(ls.built.load(), PA_ERR_ILLEGAL_STATE, "probe page before the lookup source was built");
+            if (int32_t e = ls.error.load()) throw Error(e, "hash build failed on device");
+            PA_REQUIRE(ls.keyed && !ls.has_duplicates, PA_ERR_ILLEGAL_STATE, "internal: fused probe over a lookup source with duplicate keys");
+            join_checked_ = true;
+            // the group is the build row whenever the plan allows it: no hashing, no key compares, no spills
+            if (grouped_ && !spec_.join->brow_group_proj.empty() && !getenv("PRESTO_AMD_NO_BROW")) mode_ = V_BROW;
+        }
         DevPage dp = stager_.stage(page, &needed, s);
         for (int c : dict_keys) intern_dictionary_key(page, c, dp, s);
         intern_keys(dp, s);
@@ -1342,6 +1797,15 @@ public:
                       ((uintptr_t)dp.cols[c].nulls % 4 == 0);
             }
             sig += layout[c].nullable ? 'n' : '-';
+        }
+        if (spec_.join) {  // the build columns as channels n_in + v: their nullability is the lookup source's, fixed since the build
+            for (size_t v = 0; v < spec_.join->build_cols.size(); v++) {
+                ChannelLayout cl;
+                cl.type = spec_.join->build_types[v];
+                cl.nullable = spec_.join->ls->cols[spec_.join->build_cols[v]].has_nulls;
+                layout.push_back(cl);
+                sig += cl.nullable ? 'N' : '_';
+            }
         }
         run_tiers(sig, layout, dp, vec, 0);
     }
@@ -1468,7 +1932,8 @@ public:
         };
         for (size_t gi = 0; gi < spec_.group_proj.size(); gi++) {
             const OwnedExpr& pe = spec_.proj[spec_.group_proj[gi]];
-            const int ch = pe.is_input_ref() ? pe.node(pe.root).channel : -1;
+            int ch = pe.is_input_ref() ? pe.node(pe.root).channel : -1;
+            if (ch >= spec_.n_in) ch = -1;  // a build column of the probe stage: not a channel of the page
             const bool interned = ch >= 0 && spec_.interned[ch];
             c.group_proj.push_back(add_channel(interned ? (int32_t)PA_VARCHAR : pe.root_type(), ch >= 0 ? spec_.in_params[ch] : 0));
         }
@@ -1554,6 +2019,7 @@ private:
         c->info = generate(spec_, layout, variant);
         c->kernel = jit_get(c->info.source, c->info.entry);
         if (variant == V_LDS) c->tail_kernel = jit_get(c->info.source, "pa_fused_tail");
+        if (variant == V_BROW) c->tail_kernel = jit_get(c->info.source, "pa_brow_keys");
         c->kinds.ensure(sizeof(int32_t) * c->info.word_kind.size());
         PA_HIP(hipMemcpyAsync(c->kinds.ptr(), c->info.word_kind.data(), sizeof(int32_t) * c->info.word_kind.size(), hipMemcpyHostToDevice, stream_.get()));
         PA_HIP(hipStreamSynchronize(stream_.get()));
@@ -1667,6 +2133,7 @@ private:
     bool partitioned_wanted(const std::string& sig, const std::vector<ChannelLayout>& layout, int* partitions)
     {
         if (getenv("PRESTO_AMD_NO_PARTITIONED")) return false;
+        if (spec_.join) return false;  // a row's partition would need its probe: the row function runs once per row behind a probe stage
         if (sub_parts_ > 0) {  // partition-owned tables exist: every later page is cut the same way
             *partitions = sub_parts_;
             return true;
@@ -1839,6 +2306,86 @@ private:
         }
     }
 
+    // where the group table keeps its tags / accumulator words (static_kernels.hpp, GtStrides)
+    const uint64_t* table_tags() const
+    {
+        return build_rows_table_ && brow_occ_word_ >= 0 ? gt_words_.as<uint64_t>() + (size_t)brow_occ_word_ * gt_cap_ : gt_tag_.as<uint64_t>();
+    }
+    const uint64_t* table_words() const { return gt_words_.as<uint64_t>(); }
+    GtStrides table_strides() const { return GtStrides{1u, gt_cap_, 1u, 0u, build_rows_table_ && brow_occ_word_ >= 0 ? brow_occ_empty_ : 0ULL}; }
+
+    void fill_join_args(FusedArgs& a) const
+    {
+        const JoinStage& js = *spec_.join;
+        const LookupSourceImpl& ls = *js.ls;
+        a.jslots = ls.key_slots.ptr();
+        a.jmask = ls.probe_mask;
+        a.jbits = ls.bitmap.bits;
+        a.jmin = ls.bitmap.min_key;
+        a.jrange = ls.bitmap.range;
+        a.jrows = ls.n;
+        for (size_t v = 0; v < js.build_cols.size(); v++) {
+            const BuildColumn& bc = ls.cols[js.build_cols[v]];
+            a.bv[v] = bc.values.ptr();
+            a.bn[v] = bc.has_nulls ? bc.nulls.as<uint8_t>() : nullptr;
+        }
+    }
+
+    // BROW: accumulators indexed by build position.  The table has one slot per build row -- it never fills, nothing spills,
+    // nothing needs confirming: launches are enqueued and forgotten (the error word is read at finish).
+    bool run_page_build_rows(const Compiled& ck, const DevPage& dp, FusedArgs a, int64_t start_row)
+    {
+        hipStream_t s = stream_.get();
+        const KernelInfo& ki = ck.info;
+        const uint32_t slots = (uint32_t)std::max(spec_.join->ls->n, 1);
+        if (gt_cap_ == 0) {
+            brow_occ_word_ = ki.occ_word;
+            brow_occ_empty_ = ki.occ_empty;
+            gt_keys_.ensure((size_t)slots * 8 * std::max(w_, 1));
+            gt_words_.ensure((size_t)slots * 8 * nw_);
+            rep_count_.ensure(128 * 4);
+            PA_HIP(hipMemsetAsync(gt_words_.ptr(), 0, (size_t)slots * 8 * nw_, s));
+            if (brow_occ_word_ < 0) {
+                gt_tag_.ensure((size_t)slots * 8);
+                PA_HIP(hipMemsetAsync(gt_tag_.ptr(), 0, (size_t)slots * 8, s));
+            }
+            else if (brow_occ_empty_ != 0) {
+                launch_fill_u64(gt_words_.as<uint64_t>() + (size_t)brow_occ_word_ * slots, brow_occ_empty_, (int64_t)slots, s);
+            }
+            PA_HIP(hipMemsetAsync(rep_count_.ptr(), 0, 128 * 4, s));
+            gt_cap_ = slots;
+            gt_rep_ = 1;
+            build_rows_table_ = true;
+        }
+        PA_REQUIRE(build_rows_table_ && gt_cap_ == slots && brow_occ_word_ == ki.occ_word, PA_ERR_DEVICE, "internal: build-row table mixed with another table");
+        a.gt_tag = gt_tag_.as<uint64_t>();
+        a.gt_keys = gt_keys_.as<uint64_t>();
+        a.gt_words = gt_words_.as<uint64_t>();
+        a.gt_mask = gt_cap_ - 1;  // capacity - 1 (no mask: the slot is the build position)
+        a.gt_max_fill = INT32_MAX;
+        a.gt_rep_mask = 0;
+        a.gt_rep_count = rep_count_.as<int32_t>();
+        const int64_t n = dp.n - start_row;
+        if (n <= 0) return true;
+        if (start_row > 0) {
+            for (int c = 0; c < spec_.n_in; c++) {
+                if (!spec_.used_channel[c]) continue;
+                const DevColumn& col = dp.cols[c];
+                if (col.varwidth) a.o[c] = col.offsets + start_row;
+                else a.v[c] = static_cast<const char*>(col.values) + start_row * type_width(col.type);
+                if (col.nulls) a.nl[c] = col.nulls + start_row;
+            }
+        }
+        a.n = n;
+        const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(((n + 3) / 4 + 255) / 256, (int64_t)cus_ * 8));
+        void* params[] = {&a};
+        timer.begin(s);
+        PA_HIP(hipModuleLaunchKernel(ck.kernel.fn, grid, 1, 1, ki.block, 1, 1, 0, s, params, nullptr));
+        timer.end(s);
+        brow_keys_ = &ck;
+        return true;
+    }
+
     // returns false when the LDS variant overflowed and the page must be redone with the HBM table
     bool run_page(const Compiled& ck, const DevPage& dp, bool vec, const RowList* list = nullptr, int64_t start_row = 0)
     {
@@ -1856,6 +2403,8 @@ private:
         a.err = ctl_;
         a.gt_count = ctl_ + 1;
         a.overflow_rows = reinterpret_cast<uint64_t*>(ctl_ + 2);
+        if (spec_.join) fill_join_args(a);
+        if (ki.variant == V_BROW) return run_page_build_rows(ck, dp, a, start_row);
         int64_t offset = list ? list->first_row : start_row;
         const int64_t total = list ? list->first_row + list->chunk_rows : dp.n;
         // the HBM-table variant bounds the groups one launch can add so that the table can be sized first
@@ -2168,7 +2717,7 @@ private:
         const OwnedExpr& pe = spec_.proj[spec_.group_proj[gi]];
         if (!pe.is_input_ref()) return -1;
         const int c = pe.node(pe.root).channel;
-        return spec_.interned[c] ? c : -1;
+        return c < spec_.n_in && spec_.interned[c] ? c : -1;  // (channels >= n_in: build columns of the probe stage)
     }
 
     Spec spec_;
@@ -2197,6 +2746,12 @@ private:
     uint32_t gt_rep_ = 1;
     uint64_t groups_sum_ = 0;
     bool gt_probed_ = false, lds_probed_ = false;
+    bool join_checked_ = false;  // probe stage: the lookup source was looked at (first page)
+    bool build_rows_table_ = false;  // the group table is indexed by build position (BROW)
+    const Compiled* brow_keys_ = nullptr;  // its pa_brow_keys kernel
+    DevBuf brow_count_;
+    int brow_occ_word_ = -1;       // KernelInfo::occ_word / occ_empty of the table
+    uint64_t brow_occ_empty_ = 0;
     int64_t resume_from_ = -1;
     bool retained_ = false;               // the page being processed stays readable until its launches are confirmed
     // partition-owned tables (V_LDSP)
@@ -2441,9 +2996,10 @@ bool FusedAggregationOperator::emit_on_device(const KernelInfo& ki, int64_t grou
         a.col[c].values = oc.values.ensure((size_t)groups * a.col[c].width);
         a.col[c].nulls = nullable[c] ? static_cast<uint8_t*>(oc.nulls.ensure((size_t)groups)) : nullptr;
     }
-    a.tag = gt_tag_.as<uint64_t>();
+    a.tag = table_tags();
     a.keys = gt_keys_.as<uint64_t>();
-    a.words = gt_words_.as<uint64_t>();
+    a.words = table_words();
+    a.st = table_strides();
     a.cap = gt_cap_;
     a.W = std::max(w_, 1);
     a.NW = nw_;
@@ -2539,6 +3095,29 @@ void FusedAggregationOperator::build_output()
             PA_HIP(hipStreamSynchronize(s));
             raise_if(h_ctl_[0]);
         }
+        if (build_rows_table_) {
+            // build-row table: no kernel counted its groups, and its key words are still to be written -- once per group, from
+            // the build columns (pa_brow_keys)
+            int64_t* cnt = static_cast<int64_t*>(brow_count_.ensure(8));
+            launch_count_nonzero_u64(table_tags(), (int64_t)gt_cap_, (int64_t)table_strides().tag, table_strides().empty, cnt, s);
+            FusedArgs a;
+            memset(&a, 0, sizeof a);
+            fill_join_args(a);
+            a.err = ctl_;
+            a.gt_tag = gt_tag_.as<uint64_t>();
+            a.gt_keys = gt_keys_.as<uint64_t>();
+            a.gt_words = gt_words_.as<uint64_t>();
+            a.gt_mask = gt_cap_ - 1;
+            void* params[] = {&a};
+            const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(((int64_t)gt_cap_ + 255) / 256, (int64_t)cus_ * 8));
+            PA_HIP(hipModuleLaunchKernel(brow_keys_->tail_kernel.fn, grid, 1, 1, 256, 1, 1, 0, s, params, nullptr));
+            int64_t found = 0;
+            PA_HIP(hipMemcpyAsync(&found, cnt, 8, hipMemcpyDeviceToHost, s));
+            PA_HIP(hipMemcpyAsync(h_ctl_, ctl_, 32, hipMemcpyDeviceToHost, s));
+            PA_HIP(hipStreamSynchronize(s));
+            raise_if(h_ctl_[0]);
+            h_ctl_[1] = (int32_t)found;
+        }
         groups = h_ctl_[1];
         if (emit_on_device(ki, groups)) return;
         if (groups > 0) {
@@ -2546,8 +3125,9 @@ void FusedAggregationOperator::build_output()
             dense_keys_.ensure((size_t)groups * kw * 8);
             dense_words_.ensure((size_t)groups * nw_ * 8);
             PA_HIP(hipMemsetAsync(ctl_ + 7, 0, 4, s));
-            launch_gt_compact(gt_tag_.as<uint64_t>(), gt_keys_.as<uint64_t>(), gt_words_.as<uint64_t>(), gt_cap_, kw, nw_,
-                              dense_keys_.as<uint64_t>(), dense_words_.as<uint64_t>(), reinterpret_cast<uint32_t*>(ctl_ + 7), s);
+            const GtStrides st = table_strides();
+            launch_gt_compact(table_tags(), gt_keys_.as<uint64_t>(), table_words(), gt_cap_, kw, nw_, dense_keys_.as<uint64_t>(),
+                              dense_words_.as<uint64_t>(), reinterpret_cast<uint32_t*>(ctl_ + 7), s, &st);
             uint8_t* land = static_cast<uint8_t*>(h_table_.ensure((size_t)groups * (kw + nw_) * 8));
             PA_HIP(hipMemcpyAsync(land, dense_keys_.ptr(), (size_t)groups * kw * 8, hipMemcpyDeviceToHost, s));
             PA_HIP(hipMemcpyAsync(land + (size_t)groups * kw * 8, dense_words_.ptr(), (size_t)groups * nw_ * 8, hipMemcpyDeviceToHost, s));
@@ -2865,6 +3445,45 @@ pa_operator* make_fused_aggregation(const pa_fused_aggregation_desc* desc)
         return new PartialFlushingAggregationOperator(desc);
     }
     return new FusedAggregationOperator(desc);
+}
+
+pa_operator* make_fused_probe_aggregation(const pa_fused_join_aggregation_desc* desc, pa_lookup_source* bridge)
+{
+    PA_REQUIRE(desc != nullptr && bridge != nullptr, PA_ERR_INVALID_ARGUMENT, "null argument");
+    void* stream = desc->aggregation.stream ? desc->aggregation.stream : (desc->join.stream ? desc->join.stream : desc->filter_project.stream);
+    return new FusedAggregationOperator(make_spec(desc->filter_project, desc->aggregation, &desc->join, bridge), stream);
+}
+
+// the probe-stage kernels of a descriptor over a lookup source shaped like `build` (no device needed: nothing is allocated)
+std::string fused_join_source_for_desc(const pa_fused_join_aggregation_desc* desc, const pa_hash_builder_desc* build, int variant, std::string* entry)
+{
+    PA_REQUIRE(desc != nullptr && build != nullptr, PA_ERR_INVALID_ARGUMENT, "descriptor is null");
+    pa_lookup_source bridge;
+    bridge.impl = std::make_shared<LookupSourceImpl>();
+    LookupSourceImpl& ls = *bridge.impl;
+    PA_REQUIRE(build->input_channel_count > 0 && build->input_channel_count <= 32, PA_ERR_NOT_SUPPORTED, "1..32 build channels");
+    ls.cols.resize(build->input_channel_count);
+    for (int c = 0; c < build->input_channel_count; c++) ls.cols[c].type = build->input_types[c];
+    for (int i = 0; i < build->join_channel_count; i++) {
+        PA_REQUIRE(build->join_channels[i] >= 0 && build->join_channels[i] < build->input_channel_count, PA_ERR_INVALID_ARGUMENT, "join channel out of range");
+        ls.join_channels.push_back(build->join_channels[i]);
+    }
+    for (int i = 0; i < build->output_channel_count; i++) {
+        PA_REQUIRE(build->output_channels[i] >= 0 && build->output_channels[i] < build->input_channel_count, PA_ERR_INVALID_ARGUMENT, "output channel out of range");
+        ls.output_channels.push_back(build->output_channels[i]);
+    }
+    Spec s = make_spec(desc->filter_project, desc->aggregation, &desc->join, &bridge);
+    std::vector<ChannelLayout> layout(s.n_in);
+    for (int c = 0; c < s.n_in; c++) layout[c].type = s.in_types[c];
+    for (int32_t t : s.join->build_types) {
+        ChannelLayout cl;
+        cl.type = t;
+        layout.push_back(cl);
+    }
+    if (variant < 0) variant = s.group_proj.empty() ? V_GLOBAL : (s.join->brow_group_proj.empty() ? V_GT : V_BROW);
+    KernelInfo k = generate(s, layout, variant);
+    if (entry) *entry = k.entry;
+    return k.source;
 }
 
 std::string fused_source_for_desc(const pa_fused_aggregation_desc* desc, int variant, std::string* entry)

@@ -18,63 +18,10 @@
 #include "dynfilter_kernels.hpp"
 #include "exchange_kernels.hpp"
 #include "join_kernels.hpp"
+#include "join_source.hpp"
 #include "operator.hpp"
 #include "scan_kernels.hpp"
 #include "static_kernels.hpp"
-
-namespace pa {
-
-struct BuildColumn {
-    int32_t type = PA_BIGINT;
-    bool varwidth = false;
-    DevBuf values, offsets, nulls;
-    bool has_nulls = false;
-    int64_t bytes = 0;  // VARWIDTH: bytes used
-};
-
-// The lookup source shared between the build operator and its probe operators
-// (LookupSourceFactory / JoinBridge; PartitionedLookupSourceFactory.java:179-206).
-struct LookupSourceImpl {
-    std::vector<BuildColumn> cols;
-    int32_t n = 0;
-    std::vector<int> join_channels, output_channels;
-    int hash_channel = -1;
-    DevBuf key, links, raw_hash, slot_of, tagged;
-    DevBuf key_slots;           // JoinKeySlot[hash_size] when the join key is one BIGINT / INTEGER / DATE column (else `tagged`)
-    bool keyed = false;
-    uint32_t probe_mask = 0;    // size - 1 of key_slots
-    DevBuf key_bits;            // existence bitmap over [key_min, key_min + key_range] (keyed joins with a dense enough key range)
-    JoinKeyBitmap bitmap{nullptr, 0, 0};
-    bool reference_built = false;  // PagesHash.key[] (the reference's layout) exists; keyed joins build it on demand
-    bool key_range_valid = false;  // keyed join with at least one non-NULL build key: [key_min, key_max]
-    int64_t key_min = 0, key_max = 0;
-    DevBuf shared_bits;  // the bitmap of pa_lookup_source_shared_key_bitmap (union key range of all ranks)
-    DevBuf visited;  // OuterPositionTracker.visitedPositions: 1 B per build position, written by LOOKUP_OUTER / FULL_OUTER probes
-    uint32_t mask = 0;
-    std::atomic<bool> built{false};
-    std::atomic<int32_t> error{0};
-
-    JoinKeys build_keys() const
-    {
-        JoinKeys k;
-        memset(&k, 0, sizeof k);
-        k.ncols = (int32_t)join_channels.size();
-        for (int i = 0; i < k.ncols; i++) {
-            const BuildColumn& c = cols[join_channels[i]];
-            k.col[i].values = c.values.ptr();
-            k.col[i].offsets = c.offsets.as<int32_t>();
-            k.col[i].nulls = c.has_nulls ? c.nulls.as<uint8_t>() : nullptr;
-            k.col[i].type = c.type;
-        }
-        return k;
-    }
-};
-
-}  // namespace pa
-
-struct pa_lookup_source {
-    std::shared_ptr<pa::LookupSourceImpl> impl;
-};
 
 namespace pa {
 namespace {
@@ -235,9 +182,11 @@ public:
         }
         PA_HIP(hipMemsetAsync(ls_->visited.ensure((size_t)std::max(n, 1)), 0, (size_t)std::max(n, 1), s));
         timer.end(s);
-        int32_t err = 0;
-        PA_HIP(hipMemcpyAsync(&err, ctl_, 4, hipMemcpyDeviceToHost, s));
+        int32_t ctl[2] = {0, 0};
+        PA_HIP(hipMemcpyAsync(ctl, ctl_, 8, hipMemcpyDeviceToHost, s));
         PA_HIP(hipStreamSynchronize(s));
+        const int32_t err = ctl[0];
+        ls_->has_duplicates = !ls_->keyed || ctl[1] != 0;
         ls_->error.store(err);
         ls_->built.store(true);  // lendPartitionLookupSource: probes may proceed
         if (err) throw Error(err, "hash build failed on device");

@@ -29,11 +29,21 @@ struct pa_operator {
     int device = -1;
     pa_operator() { if (hipGetDevice(&device) != hipSuccess) device = -1; }
     pa::KernelTimer timer;
+    // the stopwatch pa_op_kernel_time reads (an operator made of operators names the one of its dominant kernel)
+    virtual pa::KernelTimer& kernel_timer() { return timer; }
 };
 
 namespace pa {
 
 pa_operator* make_fused_aggregation(const pa_fused_aggregation_desc* desc);
+// (Hash)AggregationOperator over plain channels (abi.cpp: the fused operator with identity projections, or the reference-state adapter)
+pa_operator* make_hash_aggregation(const pa_hash_aggregation_desc* desc);
+// FilterAndProject -> LookupJoin -> aggregation (op_fused_join.cpp); make_fused_probe_aggregation is its one-kernel form
+// (op_fused.cpp), valid only for keyed lookup sources without duplicate keys -- probe_source_is_unique, once built
+pa_operator* make_fused_join_aggregation(const pa_fused_join_aggregation_desc* desc, pa_lookup_source* bridge);
+pa_operator* make_fused_probe_aggregation(const pa_fused_join_aggregation_desc* desc, pa_lookup_source* bridge);
+bool lookup_source_built(pa_lookup_source* ls);
+bool lookup_source_unique_keyed(pa_lookup_source* ls);
 pa_operator* make_filter_project(const pa_filter_project_desc* desc);
 pa_operator* make_scan_filter_project(const pa_filter_project_desc* desc, const pa_page_source* source);
 void scan_stats(pa_operator* op, int64_t* rows, int64_t* bytes, int64_t* loaded, int64_t* skipped);
@@ -74,6 +84,7 @@ void page_buffer_free(pa_page_buffer* buffer);
 // code-object source for a fused descriptor under the "no nulls, aligned" layout; used by build() to
 // pre-compile the TPC-H shapes and by the CPU-side codegen tests
 std::string fused_source_for_desc(const pa_fused_aggregation_desc* desc, int variant, std::string* entry);
+std::string fused_join_source_for_desc(const pa_fused_join_aggregation_desc* desc, const pa_hash_builder_desc* build, int variant, std::string* entry);
 std::string filter_project_source_for_desc(const pa_filter_project_desc* desc, std::string* entry);
 
 }  // namespace pa

@@ -18,6 +18,20 @@ std::string row_params(const RowInputs& s, const std::vector<ChannelLayout>& lay
     return p.str();
 }
 
+// the same parameters by name only (", c0, ..."): forwarding from one generated function to another
+std::string row_param_names(const RowInputs& s, const std::vector<ChannelLayout>& layout)
+{
+    std::ostringstream p;
+    for (int c = 0; c < s.n_in; c++) {
+        if (!s.used[c]) continue;
+        p << ", c" << c;
+        if (layout[c].type == PA_VARCHAR) p << ", cl" << c;
+        if (s.short_bound[c] > 0) p << ", cs" << c;
+        if (layout[c].nullable) p << ", cn" << c;
+    }
+    return p.str();
+}
+
 // Kernel prologue: wave-uniform facts about the page used by the speculative VARCHAR(1) path.
 void emit_prologue(const RowInputs& s, const std::vector<ChannelLayout>& layout, std::ostringstream& o)
 {

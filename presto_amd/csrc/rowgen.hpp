@@ -17,6 +17,7 @@ struct RowInputs {
 
 // ", type c0, ..." parameter list of the per-row function
 std::string row_params(const RowInputs& s, const std::vector<ChannelLayout>& layout);
+std::string row_param_names(const RowInputs& s, const std::vector<ChannelLayout>& layout);
 // wave-uniform per-page values the vector loads rely on (emit once, before the loops)
 void emit_prologue(const RowInputs& s, const std::vector<ChannelLayout>& layout, std::ostringstream& o);
 // vector loads of row quad q (into `o`) and the 4 argument lists of the per-row calls

@@ -38,11 +38,20 @@ struct GtEmitCol {
     uint8_t* nulls;              // may be null when the column cannot hold NULLs
     const uint64_t* dict_hash;   // KEY of an interned VARCHAR channel: per id the hash of the string ($hashvalue), else null
 };
+// how a group table lays out its tags and accumulator words, in 8-byte words: tag of slot i at tag[i * tag], word w of slot i at
+// words[w * word + i * slot].  The hashed tables are word-major ({1, capacity, 1}); a build-row table keeps one record
+// [tag, word 0, ...] per build position ({1 + NW, 1, 1 + NW} with words = tag + 1)
+struct GtStrides {
+    uint32_t tag, word, slot;
+    uint32_t pad;
+    uint64_t empty;  // tag value of a slot without a group (0 for real tags; a build-row table may read an accumulator word as its tag)
+};
 constexpr int GT_EMIT_MAX_COLS = 32;
 struct GtEmitArgs {
     const uint64_t* tag;
     const uint64_t* keys;
     const uint64_t* words;
+    GtStrides st;
     uint32_t cap;
     int32_t W, NW, ncols;
     uint32_t* counter;

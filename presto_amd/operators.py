@@ -515,9 +515,7 @@ class LookupSourceFactory:
             pass
 
 
-def HashBuilderOperator(bridge, input_types, join_channels, output_channels, hash_channel=-1, expected_positions=0,
-                        stream=None):
-    """HashBuilderOperator.HashBuilderOperatorFactory (…/operator/join/HashBuilderOperator.java:56-180)."""
+def hash_builder_desc(input_types, join_channels, output_channels, hash_channel=-1, expected_positions=0, stream=None):
     d = abi.pa_hash_builder_desc()
     types = abi.int32_array(input_types)
     jc = abi.int32_array(join_channels)
@@ -531,9 +529,41 @@ def HashBuilderOperator(bridge, input_types, join_channels, output_channels, has
     d.output_channels = C.cast(oc, C.POINTER(C.c_int32))
     d.expected_positions = expected_positions
     d.stream = stream
+    return d, [types, jc, oc]
+
+
+def HashBuilderOperator(bridge, input_types, join_channels, output_channels, hash_channel=-1, expected_positions=0,
+                        stream=None):
+    """HashBuilderOperator.HashBuilderOperatorFactory (…/operator/join/HashBuilderOperator.java:56-180)."""
+    d, keep = hash_builder_desc(input_types, join_channels, output_channels, hash_channel, expected_positions, stream)
     h = C.c_void_p()
     check(lib().pa_hash_builder_create(C.byref(d), bridge._h, C.byref(h)))
-    return Operator(h, [types, jc, oc, bridge])
+    return Operator(h, keep + [bridge])
+
+
+def fused_join_aggregation_desc(input_types, filter_expr, projections, probe_join_channels, probe_output_channels, joined_types,
+                                group_by_channels, aggregates, hash_channel=-1, expected_groups=10000, output_mem=abi.MEM_HOST, stream=None,
+                                type_params=None, step=abi.STEP_SINGLE):
+    """pa_fused_join_aggregation_desc: FilterAndProject(input_types; filter, projections) -> LookupJoin(probe page = the
+    projections; probe_join_channels / probe_output_channels index them) -> (Hash)Aggregation over the join's output page
+    (joined_types = [probe outputs, build outputs]; group_by_channels / aggregates index it)."""
+    d = abi.pa_fused_join_aggregation_desc()
+    fp, k1 = _filter_project_desc(input_types, filter_expr, projections, abi.MEM_DEVICE, stream, type_params)
+    jd, k2 = _lookup_join_desc([p.type for p in projections], probe_join_channels, probe_output_channels, -1, abi.MEM_DEVICE, stream, abi.JOIN_INNER)
+    ag, k3 = _hash_agg_desc(joined_types, group_by_channels, aggregates, hash_channel, expected_groups, output_mem, stream, None, step)
+    d.filter_project, d.join, d.aggregation = fp, jd, ag
+    return d, [k1, k2, k3]
+
+
+def FusedJoinAggregationOperator(bridge, input_types, filter_expr, projections, probe_join_channels, probe_output_channels, joined_types,
+                                 group_by_channels, aggregates, **kw):
+    """[Scan]FilterAndProject -> LookupJoin (INNER) -> (Hash)Aggregation behind one handle (pa_fused_join_aggregation_create): one
+    generated kernel when the lookup source has a single integer key without duplicates, the three device operators otherwise."""
+    d, keep = fused_join_aggregation_desc(input_types, filter_expr, projections, probe_join_channels, probe_output_channels, joined_types,
+                                          group_by_channels, aggregates, **kw)
+    h = C.c_void_p()
+    check(lib().pa_fused_join_aggregation_create(C.byref(d), bridge._h, C.byref(h)))
+    return Operator(h, [keep, bridge])
 
 
 def _lookup_join_desc(probe_types, probe_join_channels, probe_output_channels, probe_hash_channel, output_mem, stream, join_type):

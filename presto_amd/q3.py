@@ -21,8 +21,8 @@ producing side of the rank has finished."""
 from . import abi, tpch
 from .exchange import ExchangeOperator
 from .expr import field
-from .operators import (Driver, FilterAndProjectOperator, HashAggregationOperator, HashBuilderOperator, LookupJoinOperator,
-                        LookupSourceFactory, TopNOperator)
+from .operators import (Driver, FilterAndProjectOperator, FusedJoinAggregationOperator, HashAggregationOperator, HashBuilderOperator,
+                        LookupJoinOperator, LookupSourceFactory, TopNOperator)
 
 
 AGG_TYPES = [abi.BIGINT, abi.DOUBLE, abi.DATE, abi.INTEGER]       # lineitem JOIN orders: orderkey, revenue, orderdate, shippriority
@@ -33,7 +33,7 @@ RESULT_TYPES = [abi.BIGINT, abi.DATE, abi.INTEGER, abi.DOUBLE, abi.BIGINT]  # or
 
 
 def run(customer_pages, orders_pages, lineitem_pages, stream, comm=None, expected_groups=100000, distributed=None,
-        result_mem=abi.MEM_HOST, top_n=0, with_count=True, dynamic_filters=True):
+        result_mem=abi.MEM_HOST, top_n=0, with_count=True, dynamic_filters=True, fused_probe=True):
     """Runs the three pipelines on this rank's pages; returns (result pages, counters).  `stream` is the HIP stream
     handle every operator (and the exchange) runs on; `comm` the presto_amd.exchange.Comm of the ranks (None: one rank, no
     exchange steps; distributed=True with a one-rank comm still runs them); result_mem = where the grouped result is left
@@ -42,7 +42,11 @@ def run(customer_pages, orders_pages, lineitem_pages, stream, comm=None, expecte
     of their union.  with_count=False runs the query as TPC-H states it (sum(revenue) only); the count(*) column is there for
     the parity tests.  dynamic_filters: the filters upstream of the two probes also drop the rows whose join key matches no
     build key (the joins' dynamic filters, applied where Trino applies them); with exchange steps the filter is the union of
-    every rank's build-key bitmap (pa_lookup_source_shared_key_bitmap), so that rows are dropped before they are exchanged."""
+    every rank's build-key bitmap (pa_lookup_source_shared_key_bitmap), so that rows are dropped before they are exchanged.
+    fused_probe: the lineitem pipeline's FilterAndProject -> LookupJoin -> HashAggregation run behind one handle
+    (pa_fused_join_aggregation_create: one generated kernel over the lineitem pages -- orderkey is unique on the build side);
+    with exchange steps the filter stays in front of the exchange and the fused operator takes the exchanged pages.
+    False: the three operators on their own (the independent path of the parity tests)."""
     if distributed is None:
         distributed = comm is not None and comm.world > 1
     if distributed and comm is None:
@@ -111,16 +115,26 @@ def run(customer_pages, orders_pages, lineitem_pages, stream, comm=None, expecte
     expected_groups = max(expected_groups, min(b2.positionCount(), 1 << 28))
     aggregates = AGG_AGGREGATES if with_count else AGG_AGGREGATES[:1]
     result_types = RESULT_TYPES if with_count else RESULT_TYPES[:4]
-    agg = HashAggregationOperator(AGG_TYPES, AGG_GROUP_BY, aggregates, expected_groups=expected_groups,
-                                  output_mem=dev if top_n else result_mem, stream=s)
-    lineitem_fp = FilterAndProjectOperator(tpch.Q3_LINEITEM_TYPES, tpch.q3_lineitem_filter(), tpch.q3_lineitem_projections(), output_mem=dev, stream=s)
-    dynamic_filter(lineitem_fp, 0, b2, "lineitem_dynamic_filter")
-    out = Driver(lineitem_pages, [
-        lineitem_fp,
-        *exchange([abi.BIGINT, abi.DOUBLE], [0]),
-        LookupJoinOperator(b2, [abi.BIGINT, abi.DOUBLE], [0], [0, 1], output_mem=dev, stream=s),
-        agg,
-        *([TopNOperator(result_types, top_n, [3, 1], [abi.DESC_NULLS_LAST, abi.ASC_NULLS_LAST], output_mem=result_mem, stream=s)] if top_n else [])]).run()
+    agg_mem = dev if top_n else result_mem
+    top = [TopNOperator(result_types, top_n, [3, 1], [abi.DESC_NULLS_LAST, abi.ASC_NULLS_LAST], output_mem=result_mem, stream=s)] if top_n else []
+    if fused_probe and not distributed:
+        # (the join's dynamic filter is the fused kernel's own bitmap test)
+        if dynamic_filters:
+            counters["lineitem_dynamic_filter"] = "fused"
+        head = [FusedJoinAggregationOperator(b2, tpch.Q3_LINEITEM_TYPES, tpch.q3_lineitem_filter(), tpch.q3_lineitem_projections(), [0], [0, 1],
+                                             AGG_TYPES, AGG_GROUP_BY, aggregates, expected_groups=expected_groups, output_mem=agg_mem, stream=s)]
+    else:
+        lineitem_fp = FilterAndProjectOperator(tpch.Q3_LINEITEM_TYPES, tpch.q3_lineitem_filter(), tpch.q3_lineitem_projections(), output_mem=dev, stream=s)
+        dynamic_filter(lineitem_fp, 0, b2, "lineitem_dynamic_filter")
+        exchanged = [abi.BIGINT, abi.DOUBLE]
+        if fused_probe:
+            tail = [FusedJoinAggregationOperator(b2, exchanged, None, [field(0, abi.BIGINT), field(1, abi.DOUBLE)], [0], [0, 1], AGG_TYPES, AGG_GROUP_BY,
+                                                 aggregates, expected_groups=expected_groups, output_mem=agg_mem, stream=s)]
+        else:
+            tail = [LookupJoinOperator(b2, exchanged, [0], [0, 1], output_mem=dev, stream=s),
+                    HashAggregationOperator(AGG_TYPES, AGG_GROUP_BY, aggregates, expected_groups=expected_groups, output_mem=agg_mem, stream=s)]
+        head = [lineitem_fp, *exchange(exchanged, [0]), *tail]
+    out = Driver(lineitem_pages, head + top).run()
     lap("lineitem_pipeline")
     counters["build1_rows"] = b1.positionCount()
     counters["build2_rows"] = b2.positionCount()

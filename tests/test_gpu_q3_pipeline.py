@@ -54,14 +54,17 @@ def _expected(oracle, sf):
                      host_table(oracle, tpch.Q3_LINEITEM_COLUMNS, sf, nl))
 
 
+@pytest.mark.parametrize("fused_probe", [True, False])
 @pytest.mark.parametrize("sf,page_rows", [(0.02, 1 << 14), (0.1, 1 << 17)])
-def test_q3_pipeline_matches_oracle(gpu, oracle, sf, page_rows):
+def test_q3_pipeline_matches_oracle(gpu, oracle, sf, page_rows, fused_probe):
+    """fused_probe: the lineitem pipeline as one generated kernel (filter, bitmap test, probe, accumulate by build row) / as the
+    three operators FilterAndProject -> LookupJoin -> HashAggregation."""
     from presto_amd import q3
     expected, exp_orders, exp_joined = _expected(oracle, sf)
     stream = DeviceStream()
     customer, orders, lineitem = _device_tables(sf)
     out, counters = q3.run(customer.pages(page_rows - page_rows % 20), orders.pages(page_rows), lineitem.pages(page_rows), stream.handle,
-                           distributed=False)
+                           distributed=False, fused_probe=fused_probe)
     rows = [r for p in out for r in p.to_rows()]
     assert len(expected) > 100
     rows_equal_ignore_order(rows, expected, rel=1e-9)
@@ -184,7 +187,8 @@ def test_q3_with_topn(gpu, oracle):
 def test_q3_sf100_independent_paths_agree(gpu):
     """BASELINE config #4 at full size (765 M input rows), tied to the small-scale oracle parity above through a size-independent
     property: the TopN result must not depend on the path -- with / without the joins' dynamic filters (rows dropped before
-    the probe vs inside it), with / without the extra count(*) (implicit vs explicit count word), 2^28- vs 2^26-row pages."""
+    the probe vs inside it), with / without the extra count(*) (implicit vs explicit count word), 2^28- vs 2^26-row pages,
+    fused probe kernel with build-row accumulators vs FilterAndProject -> LookupJoin -> HashAggregation with a hashed table."""
     from presto_amd import q3
     sf = 100.0
     customer, orders, lineitem = _device_tables(sf)
@@ -196,7 +200,7 @@ def test_q3_sf100_independent_paths_agree(gpu):
         return [r for p in out for r in p.to_rows()], counters
 
     base, counters = run(1 << 28)
-    assert len(base) == 10 and counters["lineitem_dynamic_filter"] is True and counters["build2_rows"] > 10_000_000
+    assert len(base) == 10 and counters["lineitem_dynamic_filter"] == "fused" and counters["build2_rows"] > 10_000_000
     revenue = [r[3] for r in base]
     assert revenue == sorted(revenue, reverse=True)
     plain, counters2 = run(1 << 28, dynamic_filters=False)
@@ -211,4 +215,9 @@ def test_q3_sf100_independent_paths_agree(gpu):
     assert [r[4] for r in base] == [r[4] for r in plain]  # count(*) per group, exactly
     same(run(1 << 28, with_count=False)[0], base, [3])
     same(run(1 << 26)[0], base, [3])
+    # the lineitem pipeline as one generated kernel (above) vs as three operators with a hashed group table
+    unfused, counters3 = run(1 << 28, fused_probe=False)
+    assert counters3["lineitem_dynamic_filter"] is True
+    same(unfused, base, [3])
+    assert [r[4] for r in base] == [r[4] for r in unfused]
     stream.destroy()

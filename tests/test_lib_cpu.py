@@ -78,6 +78,51 @@ def test_q6_q1_kernels_generate_and_compile_for_gfx950():
     assert "pa_flush(a, acc, true)" in fused_source(d1, 2)[0] and "pa_lt_upsert" in fused_source(d1, 3)[0]
 
 
+def fused_join_source(desc, build, variant=-1):
+    L = lib()
+    need = L.pa_codegen_fused_join(C.byref(desc), C.byref(build), variant, None, 0)
+    assert need > 0, L.pa_last_error()
+    buf = C.create_string_buffer(need)
+    L.pa_codegen_fused_join(C.byref(desc), C.byref(build), variant, buf, need)
+    return buf.value.decode()
+
+
+def test_q3_probe_stage_kernels_generate_and_compile_for_gfx950():
+    """FilterAndProject -> LookupJoin -> HashAggregation of Q3's lineitem pipeline as one kernel: the build side is
+    (orderkey, orderdate, shippriority) keyed by orderkey; the group keys are the join key and two build columns, so the
+    accumulators can be indexed by build position (variant 6); the hashed table (2) and the LDS tables (1, 3) take the same rows."""
+    from presto_amd import q3
+    from presto_amd.operators import fused_join_aggregation_desc, hash_builder_desc
+    build, kb = hash_builder_desc(q3.ORDERS_JOINED_TYPES, [0], [1, 2])
+    d, keep = fused_join_aggregation_desc(tpch.Q3_LINEITEM_TYPES, tpch.q3_lineitem_filter(), tpch.q3_lineitem_projections(), [0], [0, 1],
+                                          q3.AGG_TYPES, q3.AGG_GROUP_BY, q3.AGG_AGGREGATES)
+    src = fused_join_source(d, build)  # default: the build-row table
+    assert "pa_brow_keys" in src and "pa_join_probe_keyed(a, " in src and "#define PA_KW 1\n" in src and "#define PA_TW 2\n" in src
+    # the vector loop probes the four rows of a quad together, between pa_pre (filter + key) and pa_post (accumulate)
+    assert "pa_join_probe4(a, js, jk, jb);" in src and src.count("pa_pre(a, true, (i32)(4 * q + ") == 4
+    # extendedprice and discount are read for the matches only: filter and key take shipdate and orderkey
+    pre_fn = src[src.index("void pa_pre("):]
+    assert pre_fn[:pre_fn.index(")")].endswith("const i32 row, i64 c0, i64 c3, bool& sel0, u64& jk")
+    assert "if (jb[2] >= 0) { c1_2 = ((const double*)a.v[1])[4 * q + 2]; c2_2 = ((const double*)a.v[2])[4 * q + 2]; }" in src
+    for variant in (6, 2, 1, 3):
+        assert lib().pa_codegen_compile_fused_join(C.byref(d), C.byref(build), variant) > 1000, lib().pa_last_error()
+    assert "pa_brow_keys" not in fused_join_source(d, build, 2)
+    # a global aggregate behind the probe
+    d0, k0 = fused_join_aggregation_desc(tpch.Q3_LINEITEM_TYPES, tpch.q3_lineitem_filter(), tpch.q3_lineitem_projections(), [0], [0, 1],
+                                         q3.AGG_TYPES, [], [(abi.AGG_SUM, 1, abi.DOUBLE), (abi.AGG_MAX, 2, abi.DATE)])
+    assert lib().pa_codegen_compile_fused_join(C.byref(d0), C.byref(build), -1) > 1000, lib().pa_last_error()
+    # group keys that do not name the build row (revenue is a probe column): only the hashed variants exist
+    d2, k2 = fused_join_aggregation_desc(tpch.Q3_LINEITEM_TYPES, tpch.q3_lineitem_filter(), tpch.q3_lineitem_projections(), [0], [0, 1],
+                                         q3.AGG_TYPES, [2, 3], [(abi.AGG_SUM, 1, abi.DOUBLE)])
+    assert lib().pa_codegen_compile_fused_join(C.byref(d2), C.byref(build), 6) == abi.ERR_NOT_SUPPORTED
+    assert lib().pa_codegen_compile_fused_join(C.byref(d2), C.byref(build), 2) > 1000, lib().pa_last_error()
+    # a VARCHAR key is no keyed lookup source
+    bad, kb2 = hash_builder_desc([abi.VARCHAR, abi.DATE], [0], [1])
+    dv, kv = fused_join_aggregation_desc([abi.VARCHAR], None, [field(0, abi.VARCHAR)], [0], [0], [abi.VARCHAR, abi.DATE], [1],
+                                         [(abi.AGG_COUNT_STAR, -1, None)])
+    assert lib().pa_codegen_compile_fused_join(C.byref(dv), C.byref(bad), -1) == abi.ERR_NOT_SUPPORTED
+
+
 def test_expression_forms_compile():
     types = [abi.BIGINT, abi.DOUBLE, abi.BOOLEAN, abi.INTEGER, abi.VARCHAR, abi.DATE]
     a, b, c, d, s, t = (field(i, ty) for i, ty in enumerate(types))
