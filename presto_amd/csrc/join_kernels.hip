@@ -274,6 +274,10 @@ __global__ __launch_bounds__(256) void k_join_key_slots(const i32* __restrict__ 
 // the highest position of the key, the head the reference's sequential insertion leaves.  The loop is wave-uniform: a lane
 // that finds a claimed slot looks again in the next round, and the claiming lane (possibly of the same wave) publishes
 // inside its own round.
+// (Measured, 14.6 M unique keys into 2^25 slots: 1.5 ms -- ~30 G table accesses per second, the rate at which HBM opens rows for
+// scattered memory-side operations, whatever their kind: claiming through a 64-bit CAS on the key word plus atomicMax on the head,
+// two operations per row and no waiting, took 1.77 ms; dropping the load in front of the CAS 1.62 ms.  Only a build that writes
+// every table line once -- rows partitioned by hash first, tables assembled in LDS -- gets below that.)
 constexpr i32 kSlotBusy = -2;
 __global__ __launch_bounds__(256) void k_join_keyed_build(JoinCol build_key, const i64* __restrict__ raw_hash, i32 n, JoinKeySlot* slots, u32 mask,
                                                           i32* __restrict__ slot_of, i32* err)
@@ -322,6 +326,82 @@ __global__ __launch_bounds__(256) void k_join_keyed_build(JoinCol build_key, con
     }
 }
 
+// ---- partitioned build of the keyed table --------------------------------------------------------------------------------------
+// Large build sides.  The rows are first regrouped (scan_kernels' multisplit: coalesced reads and writes) by the PARTITION of
+// their home slot -- the table is cut into partitions of kJoinPartSlots consecutive slots, and linear probing wraps around inside a
+// partition -- then one workgroup per partition assembles its slots in LDS and writes them out once, as whole lines.  No table
+// access ever goes to HBM alone: the build streams (keys twice, the table once) instead of opening a DRAM row per operation.
+// Rows with a NULL key travel with row position -1 and are not inserted.
+__global__ __launch_bounds__(256) void k_join_part_ids(JoinCol build_key, i32 n, u32 mask, i32* __restrict__ part, u64* __restrict__ keybits,
+                                                       i32* __restrict__ rowpos)
+{
+    for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < n; i += (i64)gridDim.x * 256) {
+        const i32 p = (i32)i;
+        const bool null = jcol_is_null(build_key, p);
+        const u64 v = null ? 0ULL : join_key_bits(build_key, p);
+        const u32 home = (u32)pa_murmur3_fmix((u64)pa_hash_bigint((i64)v)) & mask;
+        part[p] = null ? (i32)((u32)p & (mask >> kJoinPartSlotsLog2)) : (i32)(home >> kJoinPartSlotsLog2);  // (NULL rows: spread, any partition)
+        keybits[p] = v;
+        rowpos[p] = null ? -1 : p;
+    }
+}
+// err[1]: some key has several rows; err[2]: a partition holds more rows than its slots take (the caller builds the table the
+// other way in both cases: chains need slot_of, which this build does not produce)
+__global__ __launch_bounds__(1024) void k_join_part_build(const u64* __restrict__ keys, const i32* __restrict__ rows, const i64* __restrict__ first, u32 mask,
+                                                          JoinKeySlot* __restrict__ slots, i32* err)
+{
+    __shared__ JoinKeySlot tab[kJoinPartSlots];
+    constexpr u32 lmask = kJoinPartSlots - 1;
+    for (int i = threadIdx.x; i < kJoinPartSlots; i += 1024) {
+        JoinKeySlot e;
+        e.key = 0ULL;
+        e.head = -1;
+        e.next = -1;
+        tab[i] = e;
+    }
+    __syncthreads();
+    const i64 b0 = first[blockIdx.x], b1 = first[blockIdx.x + 1];
+    if (b1 - b0 > (i64)(kJoinPartSlots - kJoinPartSlots / 8)) {
+        if (threadIdx.x == 0) err[2] = 1;
+    }
+    else {
+        const i64 padded = b0 + ((b1 - b0 + 1023) & ~(i64)1023);
+        for (i64 i = b0 + threadIdx.x; i < padded; i += 1024) {
+            const i32 p = i < b1 ? rows[i] : -1;
+            bool pending = p >= 0;
+            const u64 v = i < b1 ? keys[i] : 0ULL;
+            u32 pos = (u32)pa_murmur3_fmix((u64)pa_hash_bigint((i64)v)) & lmask;   // (home & lmask: the partition is the slot's upper bits)
+            while (__ballot(pending) != 0ULL) {  // same claim / publish protocol as k_join_keyed_build, on LDS
+                if (pending) {
+                    i32 cur = __hip_atomic_load(&tab[pos].head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (cur == -1) {
+                        i32 expected = -1;
+                        if (__hip_atomic_compare_exchange_strong(&tab[pos].head, &expected, kSlotBusy, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
+                            __hip_atomic_store(&tab[pos].key, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            __hip_atomic_store(&tab[pos].head, p, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            pending = false;
+                        }
+                        cur = kSlotBusy;  // (lost the claim: look again)
+                    }
+                    if (pending && cur >= 0) {
+                        (void)__hip_atomic_load(&tab[pos].head, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        if (__hip_atomic_load(&tab[pos].key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == v) {
+                            err[1] = 1;
+                            __hip_atomic_fetch_max(&tab[pos].head, p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            pending = false;
+                        }
+                        else pos = (pos + 1) & lmask;  // (load <= 7/8: an empty slot exists)
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const uint4* src = (const uint4*)tab;
+    uint4* dst = (uint4*)(slots + (u64)blockIdx.x * kJoinPartSlots);
+    for (int i = threadIdx.x; i < kJoinPartSlots; i += 1024) dst[i] = src[i];
+}
+
 // positionLinks for the keyed table: as k_join_build_links, the head of a row's chain is slots[slot].head
 __global__ __launch_bounds__(256) void k_join_keyed_links(i32 n, const JoinKeySlot* __restrict__ slots, const i32* __restrict__ slot_of, i32* links)
 {
@@ -361,7 +441,7 @@ __global__ __launch_bounds__(256) void k_join_key_bitmap(JoinCol build_key, i32 
 }
 
 __global__ __launch_bounds__(256) void k_join_probe_count_keyed(JoinCol probe_key, const i64* __restrict__ probe_hash, i32 n_probe,
-                                                                const JoinKeySlot* __restrict__ slots, u32 mask, const i32* __restrict__ links,
+                                                                const JoinKeySlot* __restrict__ slots, u32 mask, u32 wrap, const i32* __restrict__ links,
                                                                 JoinKeyBitmap bitmap, i32* __restrict__ head, i32* __restrict__ counts, int flags)
 {
     for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < n_probe; i += (i64)gridDim.x * 256) {
@@ -380,7 +460,7 @@ __global__ __launch_bounds__(256) void k_join_probe_count_keyed(JoinCol probe_ke
             u32 pos = (u32)pa_murmur3_fmix((u64)raw) & mask;
             const uint4* lines = (const uint4*)slots;
             bool done = false;
-            for (u32 seen = 0; !done && seen <= mask;) {
+            for (u32 seen = 0; !done && seen <= wrap;) {  // (wrap: the probe sequence stays inside the slot's partition)
                 const u32 base = pos & ~3u, first = pos & 3u;
                 uint4 q[4];
 #pragma unroll
@@ -397,7 +477,7 @@ __global__ __launch_bounds__(256) void k_join_probe_count_keyed(JoinCol probe_ke
                     }
                 }
                 seen += 4u - first;
-                pos = (base + 4u) & mask;
+                pos = (pos & ~wrap) | ((base + 4u) & wrap);
             }
         }
         head[r] = h;
@@ -460,9 +540,26 @@ void launch_join_keyed_build(const JoinCol& build_key, const int64_t* raw_hash, 
     if (n > 0) {
         launch_fill_i32(links, -1, n, s);
         hipLaunchKernelGGL(k_join_keyed_build, grid_for(n), 256, 0, s, build_key, (const i64*)raw_hash, n, slots, slots_mask, slot_of, err);
-        hipLaunchKernelGGL(k_join_keyed_links, grid_for(n), 256, 0, s, n, (const JoinKeySlot*)slots, (const i32*)slot_of, links);
-        hipLaunchKernelGGL(k_join_keyed_next, grid_for((int64_t)slots_mask + 1), 256, 0, s, slots, (i64)slots_mask + 1, (const i32*)links);
     }
+    PA_HIP(hipGetLastError());
+}
+void launch_join_part_ids(const JoinCol& build_key, int32_t n, uint32_t slots_mask, int32_t* part, uint64_t* keybits, int32_t* rowpos, hipStream_t s)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_join_part_ids, grid_for(n), 256, 0, s, build_key, n, slots_mask, part, (u64*)keybits, rowpos);
+    PA_HIP(hipGetLastError());
+}
+void launch_join_part_build(const uint64_t* keys, const int32_t* rows, const int64_t* first, int32_t partitions, uint32_t slots_mask, JoinKeySlot* slots,
+                            int32_t* err, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_join_part_build, partitions, 1024, 0, s, (const u64*)keys, rows, (const i64*)first, slots_mask, slots, err);
+    PA_HIP(hipGetLastError());
+}
+void launch_join_keyed_links(int32_t n, JoinKeySlot* slots, uint32_t slots_mask, const int32_t* slot_of, int32_t* links, hipStream_t s)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_join_keyed_links, grid_for(n), 256, 0, s, n, (const JoinKeySlot*)slots, (const i32*)slot_of, links);
+    hipLaunchKernelGGL(k_join_keyed_next, grid_for((int64_t)slots_mask + 1), 256, 0, s, slots, (i64)slots_mask + 1, (const i32*)links);
     PA_HIP(hipGetLastError());
 }
 void launch_join_key_bitmap(const JoinCol& build_key, int32_t n, int64_t min_key, uint64_t range, uint64_t* bits, hipStream_t s)
@@ -473,10 +570,10 @@ void launch_join_key_bitmap(const JoinCol& build_key, int32_t n, int64_t min_key
     PA_HIP(hipGetLastError());
 }
 void launch_join_probe_count_keyed(const JoinCol& probe_key, const int64_t* probe_hash, int32_t n_probe, const JoinKeySlot* slots, uint32_t mask,
-                                   const int32_t* links, const JoinKeyBitmap& bitmap, int32_t* head, int32_t* counts, int flags, hipStream_t s)
+                                   uint32_t wrap, const int32_t* links, const JoinKeyBitmap& bitmap, int32_t* head, int32_t* counts, int flags, hipStream_t s)
 {
     if (n_probe <= 0) return;
-    hipLaunchKernelGGL(k_join_probe_count_keyed, grid_for(n_probe), 256, 0, s, probe_key, (const i64*)probe_hash, n_probe, slots, mask, links, bitmap,
+    hipLaunchKernelGGL(k_join_probe_count_keyed, grid_for(n_probe), 256, 0, s, probe_key, (const i64*)probe_hash, n_probe, slots, mask, wrap, links, bitmap,
                        head, counts, flags);
     PA_HIP(hipGetLastError());
 }

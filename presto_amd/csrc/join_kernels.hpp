@@ -49,13 +49,27 @@ struct JoinKeyBitmap {
     int64_t min_key;
     uint64_t range;         // max - min
 };
-// The keyed probe-side table and positionLinks straight from the build rows (raw_hash may be null: computed from the key).
+// The keyed probe-side table straight from the build rows (raw_hash may be null: computed from the key); links are left at -1.
 // err[0] = device error word, err[1] = set to 1 when some key occurs on more than one row.
 void launch_join_keyed_build(const JoinCol& build_key, const int64_t* raw_hash, int32_t n, JoinKeySlot* slots, uint32_t slots_mask, int32_t* slot_of,
                              int32_t* links, int32_t* err, hipStream_t s);
+// Partitioned build (join_kernels.hip): partition = home slot >> kJoinPartSlotsLog2; part / keybits / rowpos: n entries each, to be
+// regrouped by partition (launch_msplit) before launch_join_part_build, which takes first[p] = offset of partition p's rows
+// (partitions + 1 entries).  err[1] / err[2]: duplicate keys / an overfull partition -- the caller then builds with
+// launch_join_keyed_build instead.
+constexpr int kJoinPartSlotsLog2 = 13;
+constexpr int kJoinPartSlots = 1 << kJoinPartSlotsLog2;  // 8192 slots = 128 KB of LDS
+void launch_join_part_ids(const JoinCol& build_key, int32_t n, uint32_t slots_mask, int32_t* part, uint64_t* keybits, int32_t* rowpos, hipStream_t s);
+void launch_join_part_build(const uint64_t* keys, const int32_t* rows, const int64_t* first, int32_t partitions, uint32_t slots_mask, JoinKeySlot* slots,
+                            int32_t* err, hipStream_t s);
+// positionLinks and the slots' `next` fields: only needed when some key has several rows (err[1] of the build; every link and
+// every `next` is -1 otherwise, which is what the build leaves)
+void launch_join_keyed_links(int32_t n, JoinKeySlot* slots, uint32_t slots_mask, const int32_t* slot_of, int32_t* links, hipStream_t s);
 void launch_join_key_bitmap(const JoinCol& build_key, int32_t n, int64_t min_key, uint64_t range, uint64_t* bits, hipStream_t s);
+// wrap = mask, or kJoinPartSlots - 1 for a table built in partitions (the probe sequence of a key then stays inside the
+// kJoinPartSlots-slot partition of its home slot)
 void launch_join_probe_count_keyed(const JoinCol& probe_key, const int64_t* probe_hash, int32_t n_probe, const JoinKeySlot* slots, uint32_t mask,
-                                   const int32_t* links, const JoinKeyBitmap& bitmap, int32_t* head, int32_t* counts, int flags, hipStream_t s);
+                                   uint32_t wrap, const int32_t* links, const JoinKeyBitmap& bitmap, int32_t* head, int32_t* counts, int flags, hipStream_t s);
 void launch_join_unvisited_flag(const uint8_t* visited, int64_t n, int32_t* partition, hipStream_t s);
 // DefaultPageJoiner.joinCurrentPosition: (probe position, build position) pairs in emission order
 void launch_join_probe_emit(const int32_t* head, const int32_t* offsets, int32_t n_probe, int32_t total, const int32_t* links, int32_t* probe_idx,

@@ -32,6 +32,7 @@ struct LookupSourceImpl {
     DevBuf key_slots;           // JoinKeySlot[hash_size] when the join key is one BIGINT / INTEGER / DATE column (else `tagged`)
     bool keyed = false;
     uint32_t probe_mask = 0;    // size - 1 of key_slots
+    uint32_t probe_wrap = 0;    // probe sequences wrap inside (slot & ~probe_wrap): probe_mask, or kJoinPartSlots - 1 after a partitioned build
     DevBuf key_bits;            // existence bitmap over [key_min, key_min + key_range] (keyed joins with a dense enough key range)
     JoinKeyBitmap bitmap{nullptr, 0, 0};
     bool reference_built = false;  // PagesHash.key[] (the reference's layout) exists; keyed joins build it on demand

@@ -332,6 +332,8 @@ struct PaFusedArgs {
     u64 jrange;
     u32 jmask;
     i32 jrows;                        // build positions (the build-row table of the BROW variant has this many slots)
+    u32 jwrap;                        // probe sequences wrap inside (pos & ~jwrap): jmask, or the partition size - 1 of a partitioned build
+    u32 jpad;
     const void* bv[PA_MAX_BUILD_CHANNELS];
     const u8* bn[PA_MAX_BUILD_CHANNELS];
 };
@@ -343,7 +345,7 @@ struct PaFusedArgs {
 __device__ __forceinline__ i32 pa_join_probe_from(const PaFusedArgs& a, const u64 v, u32 pos)
 {
     const pa_u32x4* lines = (const pa_u32x4*)a.jslots;
-    for (u32 seen = 0; seen <= a.jmask;) {
+    for (u32 seen = 0; seen <= a.jwrap;) {
         const u32 base = pos & ~3u, first = pos & 3u;
         pa_u32x4 q[4];
 #pragma unroll
@@ -356,7 +358,7 @@ __device__ __forceinline__ i32 pa_join_probe_from(const PaFusedArgs& a, const u6
             if ((((u64)q[k].y << 32) | (u64)q[k].x) == v) return cur;
         }
         seen += 4u - first;
-        pos = (base + 4u) & a.jmask;
+        pos = (pos & ~a.jwrap) | ((base + 4u) & a.jwrap);
     }
     return -1;
 }
@@ -410,7 +412,7 @@ __device__ __forceinline__ void pa_join_probe4(const PaFusedArgs& a, const bool 
     for (int r = 0; r < 4; r++) {
         if (need[r]) {
             s0[r] = slots[pos[r]];
-            s1[r] = slots[(pos[r] + 1u) & a.jmask];
+            s1[r] = slots[(pos[r] & ~a.jwrap) | ((pos[r] + 1u) & a.jwrap)];
         }
     }
 #pragma unroll
@@ -420,7 +422,7 @@ __device__ __forceinline__ void pa_join_probe4(const PaFusedArgs& a, const bool 
             if ((((u64)s0[r].y << 32) | (u64)s0[r].x) == k[r]) res = (i32)s0[r].z;
             else if ((i32)s1[r].z != -1) {
                 if ((((u64)s1[r].y << 32) | (u64)s1[r].x) == k[r]) res = (i32)s1[r].z;
-                else res = pa_join_probe_from(a, k[r], (pos[r] + 2u) & a.jmask);  // a probe sequence longer than two slots
+                else res = pa_join_probe_from(a, k[r], (pos[r] & ~a.jwrap) | ((pos[r] + 2u) & a.jwrap));  // a probe sequence longer than two slots
             }
         }
         jb[r] = res;

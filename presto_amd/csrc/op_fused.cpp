@@ -106,6 +106,8 @@ struct FusedArgs {
     uint64_t jrange;
     uint32_t jmask;
     int32_t jrows;
+    uint32_t jwrap;
+    uint32_t jpad;
     const void* bv[kMaxBuildChannels];
     const uint8_t* bn[kMaxBuildChannels];
 };
@@ -2320,6 +2322,7 @@ private:
         const LookupSourceImpl& ls = *js.ls;
         a.jslots = ls.key_slots.ptr();
         a.jmask = ls.probe_mask;
+        a.jwrap = ls.probe_wrap;
         a.jbits = ls.bitmap.bits;
         a.jmin = ls.bitmap.min_key;
         a.jrange = ls.bitmap.range;

@@ -167,9 +167,29 @@ public:
             // channel when there is one, else from the key inside the kernel.  PagesHash.key[] is built when somebody asks for it.
             const int64_t* raw = nullptr;
             if (ls_->hash_channel >= 0 && n > 0) raw = ls_->cols[ls_->hash_channel].values.as<int64_t>();
-            launch_join_keyed_build(bk.col[0], raw, n, static_cast<JoinKeySlot*>(ls_->key_slots.ensure((size_t)slots * sizeof(JoinKeySlot))),
-                                    ls_->probe_mask, ls_->slot_of.as<int32_t>(), ls_->links.as<int32_t>(), ctl_, s);
+            JoinKeySlot* table = static_cast<JoinKeySlot*>(ls_->key_slots.ensure((size_t)slots * sizeof(JoinKeySlot)));
+            ls_->probe_wrap = ls_->probe_mask;
+            bool done = false;
+            // large build sides: rows regrouped by the partition of their home slot, tables assembled in LDS and written once
+            // (join_kernels.hip).  It leaves no slot_of, so chains (duplicate keys) -- and partitions too full, which a decent hash
+            // does not produce -- are built the other way
+            const int64_t partitions = (int64_t)slots >> kJoinPartSlotsLog2;
+            if (n >= (1 << 20) && partitions >= 2 && partitions <= 4096 && !getenv("PRESTO_AMD_NO_PARTITIONED_BUILD")) {
+                done = partitioned_build(bk.col[0], n, table, (int32_t)partitions, s);
+                if (done) ls_->probe_wrap = (uint32_t)kJoinPartSlots - 1u;
+            }
+            int32_t dups = 0;
+            if (!done) {
+                PA_HIP(hipMemsetAsync(ctl_ + 1, 0, 8, s));
+                launch_join_keyed_build(bk.col[0], raw, n, table, ls_->probe_mask, ls_->slot_of.as<int32_t>(), ls_->links.as<int32_t>(), ctl_, s);
+                // (the key range read-back below waits for the stream anyway: the duplicate flag rides along)
+                PA_HIP(hipMemcpyAsync(&dups, ctl_ + 1, 4, hipMemcpyDeviceToHost, s));
+            }
             if (n > 0) build_key_bitmap(bk.col[0], n, s);
+            else PA_HIP(hipStreamSynchronize(s));
+            // chains exist only when some key has several rows: two passes over the rows and the table that unique keys -- the build
+            // side of a primary-key join -- do without
+            if (dups) launch_join_keyed_links(n, table, ls_->probe_mask, ls_->slot_of.as<int32_t>(), ls_->links.as<int32_t>(), s);
         }
         else {
             compute_raw_hash(bk, n, s);
@@ -190,6 +210,36 @@ public:
         ls_->error.store(err);
         ls_->built.store(true);  // lendPartitionLookupSource: probes may proceed
         if (err) throw Error(err, "hash build failed on device");
+    }
+
+    // true: `table` holds the keyed probe-side table, built partition by partition (links stay -1: no key has several rows)
+    bool partitioned_build(const JoinCol& key, int32_t n, JoinKeySlot* table, int32_t partitions, hipStream_t s)
+    {
+        DevBuf part, keys_in, keys_out, rows_in, rows_out, counts, first, temp;
+        int32_t* pid = static_cast<int32_t*>(part.ensure((size_t)n * 4));
+        uint64_t* kin = static_cast<uint64_t*>(keys_in.ensure((size_t)n * 8));
+        int32_t* rin = static_cast<int32_t*>(rows_in.ensure((size_t)n * 4));
+        launch_join_part_ids(key, n, ls_->probe_mask, pid, kin, rin, s);
+        MsplitCol cols[2];
+        memset(cols, 0, sizeof cols);
+        cols[0].in = kin;
+        cols[0].out = keys_out.ensure((size_t)n * 8);
+        cols[0].width = 8;
+        cols[1].in = rin;
+        cols[1].out = rows_out.ensure((size_t)n * 4);
+        cols[1].width = 4;
+        int64_t* cnt = static_cast<int64_t*>(counts.ensure((size_t)(partitions + 1) * 8));
+        PA_HIP(hipMemsetAsync(cnt, 0, (size_t)(partitions + 1) * 8, s));
+        launch_msplit(pid, n, partitions, cols, 2, cnt, temp.ensure(msplit_temp_bytes(n, partitions)), s);
+        int64_t* fst = static_cast<int64_t*>(first.ensure((size_t)(partitions + 1) * 8));
+        launch_exclusive_prefix_i64(cnt, partitions, fst, s);  // fst[p] = first row of partition p, fst[partitions] = n
+        PA_HIP(hipMemsetAsync(ctl_ + 1, 0, 8, s));
+        launch_join_part_build(keys_out.as<uint64_t>(), rows_out.as<int32_t>(), fst, partitions, ls_->probe_mask, table, ctl_, s);
+        launch_fill_i32(ls_->links.as<int32_t>(), -1, n, s);
+        int32_t flags[2] = {0, 0};
+        PA_HIP(hipMemcpyAsync(flags, ctl_ + 1, 8, hipMemcpyDeviceToHost, s));
+        PA_HIP(hipStreamSynchronize(s));  // (the temporaries above return to the pool)
+        return flags[0] == 0 && flags[1] == 0;
     }
 
     void compute_raw_hash(const JoinKeys& bk, int32_t n, hipStream_t s) { fill_raw_hash(*ls_, bk, n, s); }
@@ -322,7 +372,7 @@ public:
         int32_t* counts = static_cast<int32_t*>(counts_.ensure((size_t)n * 4));
         timer.begin(s);
         if (ls_->keyed) {  // one integer key: key-in-slot table, raw hash computed in the kernel unless a $hashvalue channel came along
-            launch_join_probe_count_keyed(pk.col[0], probe_hash, n, ls_->key_slots.as<JoinKeySlot>(), ls_->probe_mask, ls_->links.as<int32_t>(), ls_->bitmap, head, counts,
+            launch_join_probe_count_keyed(pk.col[0], probe_hash, n, ls_->key_slots.as<JoinKeySlot>(), ls_->probe_mask, ls_->probe_wrap, ls_->links.as<int32_t>(), ls_->bitmap, head, counts,
                                           probe_flags_, s);
         }
         else {

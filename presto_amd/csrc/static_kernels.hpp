@@ -59,5 +59,7 @@ struct GtEmitArgs {
     GtEmitCol col[GT_EMIT_MAX_COLS];
 };
 void launch_gt_emit(const GtEmitArgs& args, hipStream_t s);
+// out[i] = in[0] + ... + in[i - 1] for i in [0, n], n <= 5119 (static_kernels.hip)
+void launch_exclusive_prefix_i64(const int64_t* in, int32_t n, int64_t* out, hipStream_t s);
 
 }  // namespace pa

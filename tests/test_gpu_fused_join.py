@@ -193,6 +193,21 @@ def test_sum_of_negative_zeros_is_positive_zero(gpu, oracle):
     assert len(zeros) == 11 and all(r[2] == 0.0 and np.signbit(r[2]) == False for r in zeros)
 
 
+def test_fused_probe_of_long_min_value(gpu, oracle):
+    """Long.MIN_VALUE as a join key (10 % of the probe rows): no key value may double as an "empty slot" mark."""
+    rng = np.random.default_rng(14)
+    low = -2 ** 63
+    bkeys = np.concatenate([np.arange(100, 1100), [low]]).astype(np.int64)
+    build = [build_page(rng, bkeys[rng.permutation(len(bkeys))], nullable=False)]
+    n = 4000
+    key = np.where(rng.random(n) < 0.1, low, rng.integers(0, 1500, n)).astype(np.int64)
+    probe = [Page([Block.bigint(key), Block.double(rng.random(n)), Block.integer(rng.integers(0, 9, n)), Block.date(np.full(n, 9300, dtype=np.int32))], n)]
+    aggs = [(abi.AGG_SUM, 1, abi.DOUBLE), (abi.AGG_COUNT_STAR, -1, None)]
+    expected, jt = oracle_rows(oracle, probe, build, [1, 2], [0, 1, 2, 3], [0, 4, 5], aggs)
+    assert any(r[0] == low and r[4] > 300 for r in expected)
+    rows_equal_ignore_order(fused_rows(probe, build, [1, 2], [0, 1, 2, 3], jt, [0, 4, 5], aggs), expected, rel=1e-9)
+
+
 def test_refused_shapes(gpu):
     from presto_amd._lib import PrestoAmdError
     bridge = LookupSourceFactory()

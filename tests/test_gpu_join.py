@@ -86,6 +86,59 @@ def test_duplicates_nulls_and_chain_order(gpu, oracle, hashed):
     assert len(key) == len(okey) and sorted(key[key >= 0].tolist()) == sorted(okey[okey >= 0].tolist())
 
 
+@pytest.mark.parametrize("duplicates", [False, True])
+def test_extreme_key_values(gpu, oracle, duplicates):
+    """Extreme key values (Long.MIN_VALUE, -1, 0, Long.MAX_VALUE) on both sides of a keyed join, with and without chains: no key
+    value may double as an "empty slot" mark."""
+    rng = np.random.default_rng(21)
+    low = -2 ** 63
+    bkeys = np.concatenate([rng.permutation(5000)[:3000], [low] * (3 if duplicates else 1), [0, -1, 2 ** 63 - 1]]).astype(np.int64)
+    if duplicates:
+        bkeys = np.concatenate([bkeys, [7, 7, 2 ** 63 - 1]]).astype(np.int64)
+    order = rng.permutation(len(bkeys))
+    bkeys = bkeys[order]
+    nb = len(bkeys)
+    build = [Page([Block.bigint(bkeys), Block.integer(np.arange(nb))], nb)]
+    pkeys = np.concatenate([rng.integers(-10, 5010, 4000), [low, low, 0, -1, 2 ** 63 - 1, low + 1]]).astype(np.int64)
+    pkeys = pkeys[rng.permutation(len(pkeys))]
+    probe = [Page([Block.bigint(pkeys), Block.integer(np.arange(len(pkeys)))], len(pkeys))]
+    types = [abi.BIGINT, abi.INTEGER]
+    rows, pairs, _ = gpu_join(build, types, [0], [1], probe, types, [0], [0, 1])
+    orows, opairs, _ = oracle_join(oracle, build, types, [0], [1], probe, types, [0], [0, 1])
+    assert rows == orows and sum(1 for r in rows if r[0] == low) == (6 if duplicates else 2)
+    for (gp, gb), (op_, ob) in zip(pairs, opairs):
+        assert np.array_equal(gp, op_) and np.array_equal(gb, ob)
+
+
+@pytest.mark.parametrize("key_type,duplicates", [(abi.BIGINT, False), (abi.INTEGER, False), (abi.BIGINT, True)])
+def test_large_build_side_is_built_in_partitions(gpu, oracle, key_type, duplicates, monkeypatch):
+    """>= 2^20 build rows with one integer key: the probe-side table is assembled partition by partition in LDS (rows regrouped by
+    the partition of their home slot; probe sequences wrap inside a partition).  Same rows, same (probe, build) pairs as the oracle
+    -- and as the table built slot by slot with atomics in HBM, which duplicate keys still get."""
+    rng = np.random.default_rng(31)
+    nb, npr = (1 << 20) + 12345, 300000
+    if key_type == abi.BIGINT:
+        keys = rng.permutation(3 * nb)[:nb].astype(np.int64) * 977 - 10 ** 9
+    else:
+        keys = (rng.permutation(3 * nb)[:nb] - nb).astype(np.int32)
+    if duplicates:
+        keys[rng.integers(0, nb, 1000)] = keys[rng.integers(0, nb, 1000)]
+    kb = Block.bigint if key_type == abi.BIGINT else Block.integer
+    build = [Page([kb(keys, rng.random(nb) < 0.01), Block.integer(np.arange(nb))], nb)]
+    pk = np.where(rng.random(npr) < 0.6, keys[rng.integers(0, nb, npr)], rng.integers(-2 ** 31, 2 ** 31 - 1, npr)).astype(keys.dtype)
+    probe = [Page([kb(pk, rng.random(npr) < 0.02), Block.integer(np.arange(npr))], npr)]
+    types = [key_type, abi.INTEGER]
+    orows, opairs, _ = oracle_join(oracle, build, types, [0], [1], probe, types, [0], [0, 1])
+    assert len(orows) > 100000
+    for switch in (None, "1"):
+        if switch:
+            monkeypatch.setenv("PRESTO_AMD_NO_PARTITIONED_BUILD", switch)
+        rows, pairs, _ = gpu_join(build, types, [0], [1], probe, types, [0], [0, 1])
+        assert rows == orows
+        for (gp, gb), (op_, ob) in zip(pairs, opairs):
+            assert np.array_equal(gp, op_) and np.array_equal(gb, ob)
+
+
 def test_multi_channel_keys_with_varchar_and_double(gpu, oracle):
     rng = np.random.default_rng(9)
     nb, npr = 4001, 9001
