@@ -305,6 +305,13 @@ typedef struct pa_lookup_join_desc {
     int32_t join_type;                   /* pa_join_type */
     int32_t output_single_match;         /* LookupJoinOperatorFactory.outputSingleMatch (DefaultPageJoiner.java:276-278): at
                                           * most one output row per probe row -- the first position of its chain */
+    /* JoinFilterFunction (JoinFilterFunctionCompiler.java; JoinHash.isJoinPositionEligible, JoinHash.java:116-120): a BOOLEAN
+     * expression over one (build row, probe row) pair, or NULL.  Its channels are numbered as the compiled filter numbers its
+     * blocks: [0, B) = the channels of the build page (pa_hash_builder_desc.input_types), [B, B + probe_channel_count) = the probe
+     * page's.  A position of a probe row's chain is joined only if the filter is TRUE for it (NULL counts as false); a probe row
+     * none of whose positions is eligible is unmatched (probe-outer joins emit it NULL-extended; lookup-outer joins do not mark
+     * the build rows visited); output_single_match keeps the first ELIGIBLE position (DefaultPageJoiner.java:266-292). */
+    const pa_expr* filter;
 } pa_lookup_join_desc;
 
 /* Fused pipeline: [Scan]FilterAndProject -> LookupJoinOperator -> (Hash)AggregationOperator, the probe side of a join whose

@@ -373,12 +373,16 @@ inline std::unique_ptr<Operator> createHashBuilderOperator(LookupSourceFactory& 
     return std::make_unique<Operator>(h);
 }
 
-// OperatorFactories.innerJoin / probeOuterJoin / lookupOuterJoin / fullOuterJoin: joinType = pa_join_type
+// OperatorFactories.innerJoin / probeOuterJoin / lookupOuterJoin / fullOuterJoin: joinType = pa_join_type; filter = the join's
+// JoinFilterFunction over [build page channels, probe page channels], or null
 inline std::unique_ptr<Operator> createLookupJoinOperator(LookupSourceFactory& bridge, const std::vector<int32_t>& probeTypes,
                                                           const std::vector<int32_t>& probeJoinChannels, const std::vector<int32_t>& probeOutputChannels,
-                                                          int32_t joinType = PA_JOIN_INNER, bool outputSingleMatch = false)
+                                                          int32_t joinType = PA_JOIN_INNER, bool outputSingleMatch = false, const Expr& filter = nullptr)
 {
+    std::unique_ptr<SerializedExpression> f;
+    if (filter) f = std::make_unique<SerializedExpression>(filter);
     pa_lookup_join_desc d{};
+    d.filter = f ? f->get() : nullptr;
     d.probe_channel_count = (int32_t)probeTypes.size();
     d.probe_types = probeTypes.data();
     d.join_channel_count = (int32_t)probeJoinChannels.size();

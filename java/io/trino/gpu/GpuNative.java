@@ -35,7 +35,7 @@ final class GpuNative
     static native void destroyLookupSource(long lookupSource);
     static native long createHashBuilder(long bridge, int[] inputTypes, int[] joinChannels, int hashChannel, int[] outputChannels, int expectedPositions);
     static native long createLookupJoin(long bridge, int[] probeTypes, int[] probeJoinChannels, int probeHashChannel, int[] probeOutputChannels,
-            int joinType, boolean outputSingleMatch, boolean outer, int outputMem);
+            int joinType, boolean outputSingleMatch, boolean outer, int outputMem, long filterExpression);
     static native long createTopN(int[] inputTypes, int count, int[] sortChannels, int[] sortOrders, int outputMem);
     static native boolean setDynamicFilter(long filterProjectOperator, int channel, long lookupSource);
 

@@ -23,8 +23,12 @@ import java.util.stream.IntStream;
  *   newOptionalBinder(binder, OperatorFactories.class).setBinding().to(GpuOperatorFactories.class)
  * (core/trino-main/src/main/java/io/trino/server/ServerMainModule.java:303 declares the default, TrinoOperatorFactories).
  * The JoinBridgeManager identifies the join: the build side's GpuHashBuilder factory registers its pa_lookup_source under the
- * same manager (GpuJoinBridges), the probe factories created here look it up.  A join the device path does not cover (filter
- * function, unsupported key type -> PA_ERR_NOT_SUPPORTED) falls back to the reference factories.
+ * same manager (GpuJoinBridges), the probe factories created here look it up.  The reference hands the join's filter function to
+ * the BUILD side (LocalExecutionPlanner.createLookupSourceFactory -> HashBuilderOperatorFactory's JoinFilterFunctionFactory); the
+ * device HashBuilder factory serialises that RowExpression (build channels first, then probe channels: JoinFilterFunctionCompiler's
+ * numbering) and registers it next to the bridge (FILTERS), pa_lookup_join_desc.filter takes it.  A join the device path does not
+ * cover (a filter expression RowExpressionSerializer cannot express, an unsupported key type -> PA_ERR_NOT_SUPPORTED) falls back
+ * to the reference factories.
  */
 public final class GpuOperatorFactories
         implements OperatorFactories
@@ -34,6 +38,8 @@ public final class GpuOperatorFactories
     private final OperatorFactories fallback = new TrinoOperatorFactories();
     /** pa_lookup_source* per join bridge; filled by the device HashBuilder factory of the same join. */
     static final Map<JoinBridgeManager<?>, Long> BRIDGES = new ConcurrentHashMap<>();
+    /** newExpression handle of the join's filter function, for joins that have one and whose filter the serialiser covers. */
+    static final Map<JoinBridgeManager<?>, Long> FILTERS = new ConcurrentHashMap<>();
 
     @Override
     public OperatorFactory innerJoin(int operatorId, PlanNodeId planNodeId, JoinBridgeManager<? extends LookupSourceFactory> lookupSourceFactory,
@@ -42,11 +48,12 @@ public final class GpuOperatorFactories
             PartitioningSpillerFactory partitioningSpillerFactory, BlockTypeOperators blockTypeOperators)
     {
         Long bridge = BRIDGES.get(lookupSourceFactory);
-        if (hasFilter || bridge == null) {   // JoinFilterFunction is evaluated by pa_lookup_join_desc.filter only for the supported subset
+        if (bridge == null || (hasFilter && !FILTERS.containsKey(lookupSourceFactory))) {
             return fallback.innerJoin(operatorId, planNodeId, lookupSourceFactory, outputSingleMatch, waitForBuild, hasFilter, probeTypes, probeJoinChannel,
                     probeHashChannel, probeOutputChannels, totalOperatorsCount, partitioningSpillerFactory, blockTypeOperators);
         }
-        return lookupJoin(operatorId, planNodeId, bridge, INNER, outputSingleMatch, probeTypes, probeJoinChannel, probeHashChannel, probeOutputChannels);
+        return lookupJoin(operatorId, planNodeId, bridge, INNER, outputSingleMatch, probeTypes, probeJoinChannel, probeHashChannel, probeOutputChannels,
+                hasFilter ? FILTERS.get(lookupSourceFactory) : 0L);
     }
 
     @Override
@@ -56,11 +63,12 @@ public final class GpuOperatorFactories
             BlockTypeOperators blockTypeOperators)
     {
         Long bridge = BRIDGES.get(lookupSourceFactory);
-        if (hasFilter || bridge == null) {
+        if (bridge == null || (hasFilter && !FILTERS.containsKey(lookupSourceFactory))) {
             return fallback.probeOuterJoin(operatorId, planNodeId, lookupSourceFactory, outputSingleMatch, hasFilter, probeTypes, probeJoinChannel,
                     probeHashChannel, probeOutputChannels, totalOperatorsCount, partitioningSpillerFactory, blockTypeOperators);
         }
-        return lookupJoin(operatorId, planNodeId, bridge, PROBE_OUTER, outputSingleMatch, probeTypes, probeJoinChannel, probeHashChannel, probeOutputChannels);
+        return lookupJoin(operatorId, planNodeId, bridge, PROBE_OUTER, outputSingleMatch, probeTypes, probeJoinChannel, probeHashChannel, probeOutputChannels,
+                hasFilter ? FILTERS.get(lookupSourceFactory) : 0L);
     }
 
     @Override
@@ -70,12 +78,13 @@ public final class GpuOperatorFactories
             BlockTypeOperators blockTypeOperators)
     {
         Long bridge = BRIDGES.get(lookupSourceFactory);
-        if (hasFilter || bridge == null) {
+        if (bridge == null || (hasFilter && !FILTERS.containsKey(lookupSourceFactory))) {
             return fallback.lookupOuterJoin(operatorId, planNodeId, lookupSourceFactory, waitForBuild, hasFilter, probeTypes, probeJoinChannel,
                     probeHashChannel, probeOutputChannels, totalOperatorsCount, partitioningSpillerFactory, blockTypeOperators);
         }
         // the outer operator of the same bridge (LookupJoinOperatorFactory.createOuterOperatorFactory) is createLookupJoin(..., outer = true)
-        return lookupJoin(operatorId, planNodeId, bridge, LOOKUP_OUTER, false, probeTypes, probeJoinChannel, probeHashChannel, probeOutputChannels);
+        return lookupJoin(operatorId, planNodeId, bridge, LOOKUP_OUTER, false, probeTypes, probeJoinChannel, probeHashChannel, probeOutputChannels,
+                hasFilter ? FILTERS.get(lookupSourceFactory) : 0L);
     }
 
     @Override
@@ -84,15 +93,16 @@ public final class GpuOperatorFactories
             OptionalInt totalOperatorsCount, PartitioningSpillerFactory partitioningSpillerFactory, BlockTypeOperators blockTypeOperators)
     {
         Long bridge = BRIDGES.get(lookupSourceFactory);
-        if (hasFilter || bridge == null) {
+        if (bridge == null || (hasFilter && !FILTERS.containsKey(lookupSourceFactory))) {
             return fallback.fullOuterJoin(operatorId, planNodeId, lookupSourceFactory, hasFilter, probeTypes, probeJoinChannel, probeHashChannel,
                     probeOutputChannels, totalOperatorsCount, partitioningSpillerFactory, blockTypeOperators);
         }
-        return lookupJoin(operatorId, planNodeId, bridge, FULL_OUTER, false, probeTypes, probeJoinChannel, probeHashChannel, probeOutputChannels);
+        return lookupJoin(operatorId, planNodeId, bridge, FULL_OUTER, false, probeTypes, probeJoinChannel, probeHashChannel, probeOutputChannels,
+                hasFilter ? FILTERS.get(lookupSourceFactory) : 0L);
     }
 
     private static OperatorFactory lookupJoin(int operatorId, PlanNodeId planNodeId, long bridge, int joinType, boolean outputSingleMatch, List<Type> probeTypes,
-            List<Integer> probeJoinChannel, OptionalInt probeHashChannel, Optional<List<Integer>> probeOutputChannels)
+            List<Integer> probeJoinChannel, OptionalInt probeHashChannel, Optional<List<Integer>> probeOutputChannels, long filterExpression)
     {
         int[] types = probeTypes.stream().mapToInt(RowExpressionSerializer::typeOf).toArray();
         int[] joinChannels = probeJoinChannel.stream().mapToInt(Integer::intValue).toArray();
@@ -104,6 +114,6 @@ public final class GpuOperatorFactories
             outputTypes.add(probeTypes.get(c));
         }
         return new GpuOperatorFactory(operatorId, planNodeId, "GpuLookupJoinOperator", probeTypes, outputTypes,
-                () -> GpuNative.createLookupJoin(bridge, types, joinChannels, probeHashChannel.orElse(-1), outputChannels, joinType, outputSingleMatch, false, 0));
+                () -> GpuNative.createLookupJoin(bridge, types, joinChannels, probeHashChannel.orElse(-1), outputChannels, joinType, outputSingleMatch, false, 0, filterExpression));
     }
 }

@@ -220,9 +220,10 @@ JNIEXPORT jlong JNICALL Java_io_trino_gpu_GpuNative_createHashBuilder(JNIEnv* en
 }
 
 /* OperatorFactories.innerJoin / probeOuterJoin / lookupOuterJoin / fullOuterJoin: joinType = pa_join_type; outer = 1 creates the
- * LookupOuterOperator of the same bridge */
+ * LookupOuterOperator of the same bridge; filter = a newExpression handle over [build channels, probe channels] (the
+ * JoinFilterFunction the planner compiled for this join, JoinFilterFunctionCompiler.java) or 0 */
 JNIEXPORT jlong JNICALL Java_io_trino_gpu_GpuNative_createLookupJoin(JNIEnv* env, jclass c, jlong bridge, jintArray probeTypes, jintArray probeJoinChannels,
-        jint probeHashChannel, jintArray probeOutputChannels, jint joinType, jboolean outputSingleMatch, jboolean outer, jint outputMem)
+        jint probeHashChannel, jintArray probeOutputChannels, jint joinType, jboolean outputSingleMatch, jboolean outer, jint outputMem, jlong filter)
 {
     jsize n, nj, no;
     pa_lookup_join_desc d;
@@ -231,6 +232,7 @@ JNIEXPORT jlong JNICALL Java_io_trino_gpu_GpuNative_createLookupJoin(JNIEnv* env
     d.probe_channel_count = n; d.probe_types = types; d.join_channel_count = nj; d.probe_join_channels = jc; d.probe_hash_channel = probeHashChannel;
     d.probe_output_channel_count = no; d.probe_output_channels = oc; d.output_mem = outputMem; d.join_type = joinType;
     d.output_single_match = outputSingleMatch ? 1 : 0;
+    d.filter = filter ? &((native_expr*)(intptr_t)filter)->expr : 0;
     pa_operator* op = 0;
     int32_t rc = outer ? pa_lookup_outer_create(&d, (pa_lookup_source*)(intptr_t)bridge, &op) : pa_lookup_join_create(&d, (pa_lookup_source*)(intptr_t)bridge, &op);
     free(oc); free(jc); free(types);

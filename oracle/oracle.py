@@ -346,6 +346,51 @@ class HashJoin:
         self.close()
 
 
+def join_with_filter(build_pages, build_types, join_channels, build_output_channels, probe_page, probe_types, probe_join_channels,
+                     probe_output_channels, filter_expr, join_type=abi.JOIN_INNER, output_single_match=False):
+    """LookupJoinOperator with a JoinFilterFunction, restated over this module's pieces: the candidates of every probe row are the
+    positions of its chain in chain order (HashJoin.probe: PagesHash.getAddressIndex + ArrayPositionLinks); a candidate is joined
+    when the filter -- an expression over [build page channels, probe page channels], JoinFilterFunctionCompiler's numbering --
+    is TRUE for the pair (JoinHash.isJoinPositionEligible, JoinHash.java:116-120); DefaultPageJoiner.joinCurrentPosition
+    (DefaultPageJoiner.java:266-292) stops at the first eligible position under outputSingleMatch, and a probe row that produced
+    no row is emitted NULL-extended by a probe-outer join (outerJoinCurrentPosition, :296-303).
+    Returns (output rows, [(probe position, build position or -1)], visited build positions)."""
+    nb, npr = len(build_types), len(probe_types)
+    j = HashJoin(build_types, join_channels, list(range(nb)))
+    for p in build_pages:
+        j.add_build_page(p)
+    j.build()
+    cand, pi, bi = j.probe(probe_page, probe_types, probe_join_channels, list(range(npr)))
+    eligible = set()
+    if cand.position_count:
+        pairs = Page(cand.blocks[npr:] + cand.blocks[:npr], cand.position_count)   # [build channels, probe channels]
+        is_list, sel = filter_positions(pairs, filter_expr)
+        eligible = set(int(i) for i in sel) if is_list else set(range(int(sel)))
+    cand_rows = cand.to_rows()
+    by_row = {}
+    for i, p in enumerate(pi):
+        by_row.setdefault(int(p), []).append(i)
+    probe_rows = probe_page.to_rows()
+    rows, out_pairs, visited = [], [], set()
+    outer = join_type in (abi.JOIN_PROBE_OUTER, abi.JOIN_FULL_OUTER)
+    for r in range(probe_page.position_count):
+        produced = False
+        for i in by_row.get(r, []):
+            if i not in eligible:
+                continue
+            produced = True
+            c = cand_rows[i]
+            rows.append(tuple(c[ch] for ch in probe_output_channels) + tuple(c[npr + ch] for ch in build_output_channels))
+            out_pairs.append((r, int(bi[i])))
+            visited.add(int(bi[i]))
+            if output_single_match:
+                break
+        if not produced and outer:
+            rows.append(tuple(probe_rows[r][ch] for ch in probe_output_channels) + (None,) * len(build_output_channels))
+            out_pairs.append((r, -1))
+    return rows, out_pairs, visited
+
+
 # ---- synthetic TPC-H ---------------------------------------------------------------------------------
 def tpch_column(column, scale_factor, first_row, row_count, seed=0x5EED0000):
     """Returns (values ndarray, offsets ndarray | None)."""

@@ -259,6 +259,7 @@ class pa_lookup_join_desc(C.Structure):
         ("stream", C.c_void_p),
         ("join_type", C.c_int32),
         ("output_single_match", C.c_int32),
+        ("filter", C.POINTER(pa_expr)),
     ]
 
 

@@ -578,6 +578,100 @@ void launch_join_probe_count_keyed(const JoinCol& probe_key, const int64_t* prob
     PA_HIP(hipGetLastError());
 }
 
+// ---- JoinFilterFunction (JoinHash.isJoinPositionEligible, JoinHash.java:116-120; DefaultPageJoiner.joinCurrentPosition, :266-292) ----
+// The candidates of a probe page -- every (probe row, build position of its chain), in emission order -- have been through the
+// filter; `eligible` holds the indices of those it kept, ascending.  The kernels below turn them into the output pairs.
+// keep[i] = 1 for the first eligible candidate of every probe row (outputSingleMatch), else 0
+__global__ __launch_bounds__(256) void k_jf_first_of_row(const i32* __restrict__ eligible, i32 ne, const i32* __restrict__ cand_probe, i32* __restrict__ keep)
+{
+    for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < ne; i += (i64)gridDim.x * 256) {
+        keep[i] = (i == 0 || cand_probe[eligible[i]] != cand_probe[eligible[i - 1]]) ? 1 : 0;
+    }
+}
+// eligible[i] -> out[pos[i]] for the kept ones (pos = exclusive scan of keep)
+__global__ __launch_bounds__(256) void k_jf_compact(const i32* __restrict__ eligible, i32 ne, const i32* __restrict__ keep_scan, i32 kept, i32* __restrict__ out)
+{
+    for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < ne; i += (i64)gridDim.x * 256) {
+        const i32 at = keep_scan[i], next = i + 1 < ne ? keep_scan[i + 1] : kept;
+        if (next != at) out[at] = eligible[i];
+    }
+}
+// eligible candidates per probe row
+__global__ __launch_bounds__(256) void k_jf_count_rows(const i32* __restrict__ eligible, i32 ne, const i32* __restrict__ cand_probe, i32* __restrict__ per_row)
+{
+    for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < ne; i += (i64)gridDim.x * 256) atomicAdd(&per_row[cand_probe[eligible[i]]], 1);
+}
+// probe-outer: a probe row without an eligible match comes out once, NULL-extended (DefaultPageJoiner.outerJoinCurrentPosition,
+// :296-303).  first[r] = exclusive scan of per_row (index of the row's first eligible candidate in `eligible`), at[r] = exclusive
+// scan of max(per_row, 1) (the row's first output position)
+__global__ __launch_bounds__(256) void k_jf_outer_rows(const i32* __restrict__ per_row, const i32* __restrict__ at, i32 rows, i32* __restrict__ out_probe,
+                                                       i32* __restrict__ out_build)
+{
+    for (i64 r = (i64)blockIdx.x * 256 + threadIdx.x; r < rows; r += (i64)gridDim.x * 256) {
+        if (per_row[r] == 0) {
+            out_probe[at[r]] = (i32)r;
+            out_build[at[r]] = -1;
+        }
+    }
+}
+__global__ __launch_bounds__(256) void k_jf_outer_matches(const i32* __restrict__ eligible, i32 ne, const i32* __restrict__ cand_probe, const i32* __restrict__ cand_build,
+                                                          const i32* __restrict__ first, const i32* __restrict__ at, i32* __restrict__ out_probe,
+                                                          i32* __restrict__ out_build)
+{
+    for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < ne; i += (i64)gridDim.x * 256) {
+        const i32 c = eligible[i], r = cand_probe[c];
+        const i32 o = at[r] + ((i32)i - first[r]);
+        out_probe[o] = r;
+        out_build[o] = cand_build[c];
+    }
+}
+__global__ __launch_bounds__(256) void k_jf_max1(const i32* __restrict__ in, i64 n, i32* __restrict__ out)
+{
+    for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < n; i += (i64)gridDim.x * 256) out[i] = in[i] > 0 ? in[i] : 1;
+}
+__global__ __launch_bounds__(256) void k_jf_mark_visited(const i32* __restrict__ build_pos, i64 n, u8* __restrict__ visited)
+{
+    for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < n; i += (i64)gridDim.x * 256) {
+        if (build_pos[i] >= 0) visited[build_pos[i]] = 1;
+    }
+}
+void launch_jf_first_of_row(const int32_t* eligible, int32_t ne, const int32_t* cand_probe, int32_t* keep, hipStream_t s)
+{
+    if (ne <= 0) return;
+    hipLaunchKernelGGL(k_jf_first_of_row, grid_for(ne), 256, 0, s, eligible, ne, cand_probe, keep);
+    PA_HIP(hipGetLastError());
+}
+void launch_jf_compact(const int32_t* eligible, int32_t ne, const int32_t* keep_scan, int32_t kept, int32_t* out, hipStream_t s)
+{
+    if (ne <= 0) return;
+    hipLaunchKernelGGL(k_jf_compact, grid_for(ne), 256, 0, s, eligible, ne, keep_scan, kept, out);
+    PA_HIP(hipGetLastError());
+}
+void launch_jf_count_rows(const int32_t* eligible, int32_t ne, const int32_t* cand_probe, int32_t* per_row, hipStream_t s)
+{
+    if (ne <= 0) return;
+    hipLaunchKernelGGL(k_jf_count_rows, grid_for(ne), 256, 0, s, eligible, ne, cand_probe, per_row);
+    PA_HIP(hipGetLastError());
+}
+void launch_jf_outer(const int32_t* eligible, int32_t ne, const int32_t* cand_probe, const int32_t* cand_build, const int32_t* per_row, const int32_t* first,
+                     const int32_t* at, int32_t rows, int32_t* out_probe, int32_t* out_build, hipStream_t s)
+{
+    if (rows > 0) hipLaunchKernelGGL(k_jf_outer_rows, grid_for(rows), 256, 0, s, per_row, at, rows, out_probe, out_build);
+    if (ne > 0) hipLaunchKernelGGL(k_jf_outer_matches, grid_for(ne), 256, 0, s, eligible, ne, cand_probe, cand_build, first, at, out_probe, out_build);
+    PA_HIP(hipGetLastError());
+}
+void launch_jf_max1(const int32_t* in, int64_t n, int32_t* out, hipStream_t s)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_jf_max1, grid_for(n), 256, 0, s, in, (i64)n, out);
+    PA_HIP(hipGetLastError());
+}
+void launch_jf_mark_visited(const int32_t* build_pos, int64_t n, uint8_t* visited, hipStream_t s)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_jf_mark_visited, grid_for(n), 256, 0, s, build_pos, (i64)n, visited);
+    PA_HIP(hipGetLastError());
+}
 __global__ __launch_bounds__(256) void k_sum_i32_i64(const i32* __restrict__ v, i64 n, unsigned long long* __restrict__ out)
 {
     i64 acc = 0;

@@ -77,6 +77,15 @@ void launch_join_probe_emit(const int32_t* head, const int32_t* offsets, int32_t
 void launch_fill_i32(int32_t* dst, int32_t value, int64_t n, hipStream_t s);
 void launch_rebase_offsets(const int32_t* in, int32_t in_base, int32_t out_base, int64_t n_plus_1, int32_t* out, hipStream_t s);
 
+// JoinFilterFunction: from the indices of the candidates the filter kept (`eligible`, ascending = emission order) to output pairs
+void launch_jf_first_of_row(const int32_t* eligible, int32_t ne, const int32_t* cand_probe, int32_t* keep, hipStream_t s);
+void launch_jf_compact(const int32_t* eligible, int32_t ne, const int32_t* keep_scan, int32_t kept, int32_t* out, hipStream_t s);
+void launch_jf_count_rows(const int32_t* eligible, int32_t ne, const int32_t* cand_probe, int32_t* per_row, hipStream_t s);
+void launch_jf_outer(const int32_t* eligible, int32_t ne, const int32_t* cand_probe, const int32_t* cand_build, const int32_t* per_row, const int32_t* first,
+                     const int32_t* at, int32_t rows, int32_t* out_probe, int32_t* out_build, hipStream_t s);
+void launch_jf_max1(const int32_t* in, int64_t n, int32_t* out, hipStream_t s);
+void launch_jf_mark_visited(const int32_t* build_pos, int64_t n, uint8_t* visited, hipStream_t s);
+
 // *out = sum of v[0..n) in 64 bits (out: device memory, 8-byte aligned)
 void launch_sum_i32_i64(const int32_t* v, int64_t n, int64_t* out, hipStream_t s);
 

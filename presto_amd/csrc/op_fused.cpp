@@ -228,6 +228,7 @@ Spec make_spec(const pa_filter_project_desc& fp, const pa_hash_aggregation_desc&
         PA_REQUIRE(bridge != nullptr && bridge->impl != nullptr, PA_ERR_ILLEGAL_STATE, "lookup source has no build operator yet");
         PA_REQUIRE(ag.step == PA_STEP_SINGLE || ag.step == PA_STEP_PARTIAL, PA_ERR_NOT_SUPPORTED, "an aggregation over a join output is SINGLE or PARTIAL");
         PA_REQUIRE(jd->join_type == PA_JOIN_INNER, PA_ERR_NOT_SUPPORTED, "the fused probe is an inner join");
+        PA_REQUIRE(jd->filter == nullptr, PA_ERR_NOT_SUPPORTED, "a join filter function runs in the LookupJoinOperator, not in the fused probe");
         auto js = std::make_shared<JoinStage>();
         js->ls = bridge->impl;
         const LookupSourceImpl& ls = *js->ls;

@@ -16,6 +16,7 @@
 
 #include "comm.hpp"
 #include "dynfilter_kernels.hpp"
+#include "exprgen.hpp"
 #include "exchange_kernels.hpp"
 #include "join_kernels.hpp"
 #include "join_source.hpp"
@@ -316,6 +317,7 @@ public:
         needed_.assign(n_probe_channels_, false);
         for (int c : join_channels_) needed_[c] = true;
         for (int c : output_channels_) needed_[c] = true;
+        if (d->filter) setup_filter(*d->filter, d->output_single_match != 0);
         if (hash_channel_ >= 0) needed_[hash_channel_] = true;
         ctl_ = static_cast<int32_t*>(ctl_buf_.ensure(64));
         h_ctl_ = static_cast<int32_t*>(h_ctl_buf_.ensure(64));
@@ -435,22 +437,36 @@ public:
         int32_t* probe_idx = static_cast<int32_t*>(probe_idx_.ensure((size_t)total * 4));
         int32_t* build_pos = static_cast<int32_t*>(build_pos_.ensure((size_t)total * 4));
         launch_join_probe_emit(head_.as<int32_t>() + lo, offsets, rows, total, ls_->links.as<int32_t>(), probe_idx, build_pos, probe_flags_,
-                               track_visited_ ? ls_->visited.as<uint8_t>() : nullptr, s);
+                               track_visited_ && !filter_ ? ls_->visited.as<uint8_t>() : nullptr, s);
+        int32_t total_out = total;
+        if (filter_) {
+            // the pairs so far are the CANDIDATES: every position of every probe row's chain; the filter decides which are joined
+            total_out = apply_filter(lo, rows, total, probe_idx, build_pos, s);
+            probe_idx = filtered_probe_.as<int32_t>();
+            build_pos = filtered_build_.as<int32_t>();
+            last_matches_ = total_out;
+            if (total_out == 0) {  // nothing of this range survives: on to the next range (or done)
+                range_lo_ = hi;
+                remaining_ -= sum;
+                pending_ = hi < n && remaining_ > 0;
+                return pending_ ? get_output(out) : false;
+            }
+        }
         // LookupJoinPageBuilder.build: probe output channels by probe index (relative to the range) ++ build output channels
         // by build position
         size_t oc = 0;
         for (int c : output_channels_) {
             const DevColumn& src = in_.cols[c];
             const void* values = src.varwidth ? src.values : static_cast<const char*>(src.values) + (size_t)lo * type_width(src.type);
-            gather_column(src.type, src.varwidth, values, src.offsets ? src.offsets + lo : nullptr, src.nulls ? src.nulls + lo : nullptr, probe_idx, total,
+            gather_column(src.type, src.varwidth, values, src.offsets ? src.offsets + lo : nullptr, src.nulls ? src.nulls + lo : nullptr, probe_idx, total_out,
                           out_cols_[oc++], s);
         }
         for (int c : ls_->output_channels) {
             const BuildColumn& src = ls_->cols[c];
             gather_column(src.type, src.varwidth, src.values.ptr(), src.offsets.as<int32_t>(), src.has_nulls ? src.nulls.as<uint8_t>() : nullptr,
-                          build_pos, total, out_cols_[oc++], s, probe_outer_);
+                          build_pos, total_out, out_cols_[oc++], s, probe_outer_);
         }
-        publish_output(out_cols_, total, output_mem_, s, out, out_storage_);
+        publish_output(out_cols_, total_out, output_mem_, s, out, out_storage_);
         range_lo_ = hi;
         remaining_ -= sum;
         pending_ = hi < n && remaining_ > 0;
@@ -463,9 +479,141 @@ public:
 
     void last_pairs(const int32_t** probe_idx, const int32_t** build_pos, int32_t* count) const
     {
-        *probe_idx = probe_idx_.as<int32_t>();
-        *build_pos = build_pos_.as<int32_t>();
+        *probe_idx = filter_ ? filtered_probe_.as<int32_t>() : probe_idx_.as<int32_t>();
+        *build_pos = filter_ ? filtered_build_.as<int32_t>() : build_pos_.as<int32_t>();
         *count = last_matches_;
+    }
+
+    // ---- JoinFilterFunction ----------------------------------------------------------------------------------------------
+    // The filter is an ordinary RowExpression over a (build row, probe row) pair (JoinFilterFunctionCompiler.java numbers the build
+    // page's channels first, then the probe page's).  It runs as a FilterAndProject operator of this library over the PAIR PAGE of
+    // a probe page's candidates -- the channels the filter reads, gathered by build position / probe position, plus the
+    // candidates' own indices, which is all it projects: what comes out are the indices of the eligible candidates, in order.
+    void setup_filter(const pa_expr& f, bool single_match)
+    {
+        OwnedExpr e = OwnedExpr::copy(f);
+        PA_REQUIRE(e.root_type() == PA_BOOLEAN, PA_ERR_INVALID_ARGUMENT, "join filter must be BOOLEAN");
+        const int nb = (int)ls_->cols.size();
+        std::set<int32_t> used;
+        e.collect_channels(&used);
+        for (int32_t c : used) PA_REQUIRE(c >= 0 && c < nb + n_probe_channels_, PA_ERR_INVALID_ARGUMENT, "join filter references a channel outside the build and probe pages");
+        filter_types_.clear();
+        for (int c = 0; c < nb; c++) filter_types_.push_back(ls_->cols[c].type);
+        for (int c = 0; c < n_probe_channels_; c++) filter_types_.push_back(probe_types_[c]);
+        filter_types_.push_back(PA_INTEGER);  // the candidate's index
+        filter_used_.assign(filter_types_.size(), false);
+        for (int32_t c : used) {
+            filter_used_[c] = true;
+            if (c >= nb) needed_[c - nb] = true;  // probe channels the filter reads are staged like the output channels
+        }
+        pa_expr_node idx{};
+        idx.kind = PA_EXPR_INPUT_REF;
+        idx.type = PA_INTEGER;
+        idx.channel = nb + n_probe_channels_;
+        pa_expr projection{};
+        projection.node_count = 1;
+        projection.root = 0;
+        projection.nodes = &idx;
+        pa_filter_project_desc fp{};
+        fp.input_channel_count = (int32_t)filter_types_.size();
+        fp.input_types = filter_types_.data();
+        fp.filter = &f;
+        fp.projection_count = 1;
+        fp.projections = &projection;
+        fp.output_mem = PA_MEM_DEVICE;
+        fp.stream = stream_.get();
+        filter_.reset(make_filter_project(&fp));
+        filter_single_match_ = single_match;
+        // candidates are emitted unfiltered: every position of every chain, no NULL-extended rows
+        probe_flags_ = 0;
+        pair_cols_.resize(filter_types_.size());
+    }
+
+    // candidates (probe_idx, build_pos)[0 .. total) of the probe rows [lo, lo + rows) -> filtered_probe_ / filtered_build_; returns their count
+    int32_t apply_filter(int32_t lo, int32_t rows, int32_t total, const int32_t* cand_probe, const int32_t* cand_build, hipStream_t s)
+    {
+        const int nb = (int)ls_->cols.size();
+        std::vector<pa_column> cols(filter_types_.size());
+        for (size_t c = 0; c < cols.size(); c++) {
+            memset(&cols[c], 0, sizeof(pa_column));
+            cols[c].type = filter_types_[c];
+            cols[c].encoding = filter_types_[c] == PA_VARCHAR ? PA_VARWIDTH : PA_FLAT;
+            if (!filter_used_[c] && (int)c != nb + n_probe_channels_) continue;
+            OutColumn& oc = pair_cols_[c];
+            if ((int)c < nb) {
+                const BuildColumn& src = ls_->cols[c];
+                gather_column(src.type, src.varwidth, src.values.ptr(), src.offsets.as<int32_t>(), src.has_nulls ? src.nulls.as<uint8_t>() : nullptr, cand_build, total, oc, s);
+            }
+            else if ((int)c < nb + n_probe_channels_) {
+                const DevColumn& src = in_.cols[c - nb];
+                const void* values = src.varwidth ? src.values : static_cast<const char*>(src.values) + (size_t)lo * type_width(src.type);
+                gather_column(src.type, src.varwidth, values, src.offsets ? src.offsets + lo : nullptr, src.nulls ? src.nulls + lo : nullptr, cand_probe, total, oc, s);
+            }
+            else {
+                oc.type = PA_INTEGER;
+                oc.varwidth = false;
+                oc.has_nulls = false;
+                launch_iota_i32(static_cast<int32_t*>(oc.values.ensure((size_t)total * 4)), total, s);
+            }
+            cols[c].values = oc.values.ptr();
+            cols[c].offsets = oc.varwidth ? oc.offsets.as<int32_t>() : nullptr;
+            cols[c].nulls = oc.has_nulls ? oc.nulls.as<uint8_t>() : nullptr;
+        }
+        pa_page pairs{};
+        pairs.position_count = total;
+        pairs.channel_count = (int32_t)cols.size();
+        pairs.columns = cols.data();
+        pairs.mem = PA_MEM_DEVICE;
+        filter_->add_input(&pairs);
+        pa_page kept{};
+        int32_t ne = 0;
+        const int32_t* eligible = nullptr;
+        if (filter_->get_output(&kept)) {
+            ne = kept.position_count;
+            eligible = static_cast<const int32_t*>(kept.columns[0].values);
+        }
+        // outputSingleMatch: the first eligible position of a row only (DefaultPageJoiner.java:276-278)
+        if (filter_single_match_ && ne > 0) {
+            int32_t* keep = static_cast<int32_t*>(jf_keep_.ensure((size_t)(ne + 1) * 4));
+            launch_jf_first_of_row(eligible, ne, cand_probe, keep, s);
+            launch_exclusive_scan_i32(keep, keep, ne, ctl_ + 8, scan_temp_.ensure(scan_temp_bytes(ne)), s);
+            PA_HIP(hipMemcpyAsync(h_ctl_ + 8, ctl_ + 8, 4, hipMemcpyDeviceToHost, s));
+            PA_HIP(hipStreamSynchronize(s));
+            const int32_t kept_n = h_ctl_[8];
+            int32_t* firsts = static_cast<int32_t*>(jf_first_.ensure((size_t)std::max(kept_n, 1) * 4));
+            launch_jf_compact(eligible, ne, keep, kept_n, firsts, s);
+            eligible = firsts;
+            ne = kept_n;
+        }
+        int32_t out_n = ne;
+        if (!probe_outer_) {
+            int32_t* op = static_cast<int32_t*>(filtered_probe_.ensure((size_t)std::max(ne, 1) * 4));
+            int32_t* ob = static_cast<int32_t*>(filtered_build_.ensure((size_t)std::max(ne, 1) * 4));
+            if (ne > 0) {
+                launch_gather_flat(cand_probe, 4, eligible, ne, op, s);
+                launch_gather_flat(cand_build, 4, eligible, ne, ob, s);
+            }
+        }
+        else {
+            // a row without an eligible position comes out once, NULL-extended, in its place (DefaultPageJoiner.java:296-303)
+            int32_t* per_row = static_cast<int32_t*>(jf_rows_.ensure((size_t)(rows + 1) * 4 * 3));
+            int32_t* first = per_row + (rows + 1);
+            int32_t* at = first + (rows + 1);
+            PA_HIP(hipMemsetAsync(per_row, 0, (size_t)(rows + 1) * 4, s));
+            launch_jf_count_rows(eligible, ne, cand_probe, per_row, s);
+            launch_exclusive_scan_i32(per_row, first, rows, nullptr, scan_temp_.ensure(scan_temp_bytes(rows)), s);
+            launch_jf_max1(per_row, rows, at, s);
+            launch_exclusive_scan_i32(at, at, rows, ctl_ + 8, scan_temp_.ensure(scan_temp_bytes(rows)), s);
+            PA_HIP(hipMemcpyAsync(h_ctl_ + 8, ctl_ + 8, 4, hipMemcpyDeviceToHost, s));
+            PA_HIP(hipStreamSynchronize(s));
+            out_n = h_ctl_[8];
+            int32_t* op = static_cast<int32_t*>(filtered_probe_.ensure((size_t)std::max(out_n, 1) * 4));
+            int32_t* ob = static_cast<int32_t*>(filtered_build_.ensure((size_t)std::max(out_n, 1) * 4));
+            launch_jf_outer(eligible, ne, cand_probe, cand_build, per_row, first, at, rows, op, ob, s);
+        }
+        // OuterPositionTracker: only joined build rows count as visited
+        if (track_visited_ && out_n > 0) launch_jf_mark_visited(filtered_build_.as<int32_t>(), out_n, ls_->visited.as<uint8_t>(), s);
+        return out_n;
     }
 
 private:
@@ -516,6 +664,13 @@ private:
     int hash_channel_ = -1, output_mem_ = PA_MEM_HOST;
     DevPage in_;
     DevBuf ctl_buf_, hash_, head_, counts_, probe_idx_, build_pos_, scan_temp_;
+    // JoinFilterFunction
+    std::unique_ptr<pa_operator> filter_;
+    bool filter_single_match_ = false;
+    std::vector<int32_t> filter_types_;
+    std::vector<bool> filter_used_;
+    std::vector<OutColumn> pair_cols_;
+    DevBuf filtered_probe_, filtered_build_, jf_keep_, jf_first_, jf_rows_;
     PinnedBuf h_ctl_buf_;
     int32_t* ctl_ = nullptr;
     int32_t* h_ctl_ = nullptr;

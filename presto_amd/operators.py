@@ -594,9 +594,10 @@ def LookupOuterOperator(bridge, probe_types, probe_output_channels, join_type=ab
 
 
 def LookupJoinOperator(bridge, probe_types, probe_join_channels, probe_output_channels, probe_hash_channel=-1,
-                       output_mem=abi.MEM_HOST, stream=None, join_type=abi.JOIN_INNER, output_single_match=False):
+                       output_mem=abi.MEM_HOST, stream=None, join_type=abi.JOIN_INNER, output_single_match=False, filter=None):
     """OperatorFactories.innerJoin / probeOuterJoin / lookupOuterJoin / fullOuterJoin (…/operator/OperatorFactories.java:27-84)
-    -> LookupJoinOperator; join_type = abi.JOIN_*."""
+    -> LookupJoinOperator; join_type = abi.JOIN_*.  filter = the JoinFilterFunction as an expression over [build page channels,
+    probe page channels] (JoinFilterFunctionCompiler's numbering), or None."""
     d = abi.pa_lookup_join_desc()
     types = abi.int32_array(probe_types)
     jc = abi.int32_array(probe_join_channels)
@@ -612,9 +613,14 @@ def LookupJoinOperator(bridge, probe_types, probe_join_channels, probe_output_ch
     d.stream = stream
     d.join_type = join_type
     d.output_single_match = 1 if output_single_match else 0
+    keep = [types, jc, oc, bridge]
+    if filter is not None:
+        f, kf = serialize(filter)
+        d.filter = C.pointer(f)
+        keep += [f, kf]
     h = C.c_void_p()
     check(lib().pa_lookup_join_create(C.byref(d), bridge._h, C.byref(h)))
-    return Operator(h, [types, jc, oc, bridge])
+    return Operator(h, keep)
 
 
 # ---- driver loop ---------------------------------------------------------------------------------------

@@ -411,3 +411,64 @@ def test_probe_page_with_more_matches_than_one_output_page_holds(gpu, oracle, mo
     expected, _, _ = j.probe(probe, ptypes, [0], [1, 0], join_type=join_type)
     assert len(pages) > 5 and all(0 < p.position_count <= 700 for p in pages)
     assert [r for p in pages for r in p.to_rows()] == expected.to_rows()
+
+
+# ---- JoinFilterFunction ------------------------------------------------------------------------------------------------------
+def _filter_case(rng, nb=3000, npr=5000, keys=400):
+    build = Page([Block.bigint(rng.integers(0, keys, nb), rng.random(nb) < 0.03), Block.integer(rng.integers(0, 100, nb), rng.random(nb) < 0.1),
+                  Block.varchar([[b"a", b"bb", b"ccc", None][i] for i in rng.integers(0, 4, nb)]), Block.double(rng.random(nb))], nb)
+    probe = Page([Block.integer(rng.integers(0, 100, npr), rng.random(npr) < 0.1), Block.bigint(rng.integers(-20, keys + 50, npr), rng.random(npr) < 0.03),
+                  Block.varchar([[b"a", b"bb", b"zz"][i] for i in rng.integers(0, 3, npr)])], npr)
+    return build, [abi.BIGINT, abi.INTEGER, abi.VARCHAR, abi.DOUBLE], probe, [abi.INTEGER, abi.BIGINT, abi.VARCHAR]
+
+
+@pytest.mark.parametrize("join_type", [abi.JOIN_INNER, abi.JOIN_PROBE_OUTER])
+@pytest.mark.parametrize("single_match", [False, True])
+@pytest.mark.parametrize("which", ["less", "strings", "never", "always"])
+def test_join_filter_function(gpu, oracle, join_type, single_match, which):
+    """build.key = probe.key AND <filter over the pair>: eligible positions only, in chain order; the first eligible one under
+    outputSingleMatch; NULL-extended probe rows when none is eligible (probe-outer); a NULL filter result is not a match.
+    Filter channels: 0..3 = build (key, quantity, tag, weight), 4..6 = probe (quantity, key, tag)."""
+    from presto_amd.expr import and_, constant, field
+    rng = np.random.default_rng(40 + len(which))
+    build, btypes, probe, ptypes = _filter_case(rng)
+    flt = {"less": field(1, abi.INTEGER) < field(4, abi.INTEGER),                                   # build.quantity < probe.quantity (NULLs on both sides)
+           "strings": and_(field(2, abi.VARCHAR).eq(field(6, abi.VARCHAR)), field(3, abi.DOUBLE) > constant(0.25, abi.DOUBLE)),
+           "never": field(0, abi.BIGINT) > field(5, abi.BIGINT),                                  # contradicts the equi-condition
+           "always": field(0, abi.BIGINT).eq(field(5, abi.BIGINT))}[which]
+    expected, epairs, _ = oracle.join_with_filter([build], btypes, [0], [1, 2], probe, ptypes, [1], [0, 1, 2], flt, join_type, single_match)
+    bridge = LookupSourceFactory()
+    to_pages(HashBuilderOperator(bridge, btypes, [0], [1, 2]), [build.get_region(0, 1000), build.get_region(1000, 2000)])
+    join = LookupJoinOperator(bridge, ptypes, [1], [0, 1, 2], join_type=join_type, output_single_match=single_match, filter=flt)
+    rows, pairs = [], []
+    for page, base in ((probe.get_region(0, 2000), 0), (probe.get_region(2000, 3000), 2000)):
+        join.addInput(page)
+        out = join.getOutput()
+        if out is not None:
+            rows += out.to_rows()
+            gp, gb = join.matchPairs()
+            pairs += [(int(p) + base, int(b)) for p, b in zip(gp, gb)]
+    assert rows == expected and pairs == epairs
+    if which == "never":
+        assert len(rows) == (probe.position_count if join_type == abi.JOIN_PROBE_OUTER else 0)
+    else:
+        assert len(rows) > 500
+
+
+def test_join_filter_decides_which_build_rows_a_full_outer_join_has_visited(gpu, oracle):
+    from presto_amd.expr import field
+    from presto_amd.operators import LookupOuterOperator
+    rng = np.random.default_rng(77)
+    build, btypes, probe, ptypes = _filter_case(rng, nb=800, npr=1500, keys=300)
+    flt = field(1, abi.INTEGER) < field(4, abi.INTEGER)
+    expected, _, visited = oracle.join_with_filter([build], btypes, [0], [0, 1], probe, ptypes, [1], [0, 1], flt, abi.JOIN_FULL_OUTER)
+    bridge = LookupSourceFactory()
+    to_pages(HashBuilderOperator(bridge, btypes, [0], [0, 1]), [build])
+    join = LookupJoinOperator(bridge, ptypes, [1], [0, 1], join_type=abi.JOIN_FULL_OUTER, filter=flt)
+    outer = LookupOuterOperator(bridge, ptypes, [0, 1], join_type=abi.JOIN_FULL_OUTER)
+    rows = [r for p in to_pages(join, [probe]) for r in p.to_rows()]
+    assert rows == expected
+    unvisited = [r for p in to_pages(outer, []) for r in p.to_rows()]
+    brows = build.to_rows()
+    assert 0 < len(unvisited) < 800
+    assert unvisited == [(None, None, brows[b][0], brows[b][1]) for b in range(800) if b not in visited]
