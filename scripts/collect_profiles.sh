@@ -22,3 +22,12 @@ echo "default bench done"
 cd /tmp
 timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d $O/r_q3 -- python3 $R/scripts/bench_q3.py --steps 5 --warmup 1 > $O/r_q3_bench.json 2> $O/r_q3.err
 echo "q3 done"
+cd $R
+python3 scripts/kernel_timeline.py $O/r_q3 pa_fp_count 2 > $O/r_q3_timeline.txt
+cd /tmp
+# HBM bytes of Q3's kernels (counter pass of its own)
+rm -rf $O/r_q3_fetch
+timeout -k 10 240 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/r_q3_fetch -- python3 $R/scripts/bench_q3.py --steps 2 --warmup 1 > $O/r_q3_fetch.json 2> $O/r_q3_fetch.err
+cd $R
+python3 scripts/pmc_by_kernel.py $O/r_q3_fetch > $O/r_q3_fetch.txt
+echo "q3 counters done"
