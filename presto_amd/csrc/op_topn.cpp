@@ -82,6 +82,7 @@ public:
             int32_t* pos = static_cast<int32_t*>(pos_.ensure((size_t)n * 4));
             int64_t* counts = static_cast<int64_t*>(counts_.ensure(64));
             launch_topn_flag(keys, n, threshold_, part, s);
+            if (n >= n_) refine_ties(dp, keys, n, part, s);
             launch_partition_positions(part, n, 2, pos, counts, part_temp_.ensure(partition_temp_bytes(n, 2)), s);
             int64_t h_counts[2];
             PA_HIP(hipMemcpyAsync(h_counts, counts, 16, hipMemcpyDeviceToHost, s));
@@ -113,9 +114,51 @@ public:
         return true;
     }
 
-    int64_t memory_bytes() override { return (int64_t)(stager_.bytes() + keys_.capacity() + part_.capacity() + pos_.capacity()); }
+    int64_t memory_bytes() override { return (int64_t)(stager_.bytes() + keys_.capacity() + keys2_.capacity() + state_.capacity() + part_.capacity() + pos_.capacity()); }
 
 private:
+    // Many rows tied with the bound on the first sort key (ORDER BY a low-cardinality column ... LIMIT n; all-equal keys): they
+    // would all cross to the host and be sorted there -- 12 M tied rows took 5.8 s.  A page contributes at most its OWN n best
+    // rows to the result, so the page's ties are cut down on the device: among the rows tied so far, the next sort channel's
+    // keys are selected from the same way, channel after channel, and rows tied on every channel are kept in arrival order (what
+    // the host's stable sort would do).  A VARCHAR channel ends the refinement (its key is the first 8 bytes: equal keys need not
+    // be equal strings), keeping the remaining ties whole.  Rewrites `part` (0 = kept).
+    void refine_ties(const DevPage& dp, const uint64_t* keys0, int64_t n, int32_t* part, hipStream_t s)
+    {
+        if (types_[(size_t)sort_channels_[0]] == PA_VARCHAR) return;
+        uint8_t* state = static_cast<uint8_t*>(state_.ensure((size_t)n));
+        int64_t* dcounts = static_cast<int64_t*>(counts_.ensure(64)) + 4;
+        launch_topn_state(keys0, n, threshold_, true, state, s);
+        int64_t h[2];
+        auto count = [&] {
+            launch_topn_count_states(state, n, dcounts, s);
+            PA_HIP(hipMemcpyAsync(h, dcounts, 16, hipMemcpyDeviceToHost, s));
+            PA_HIP(hipStreamSynchronize(s));
+        };
+        count();
+        int64_t need = n_ - h[0];   // ties still wanted
+        if (need <= 0 || h[1] <= std::max<int64_t>(4 * n_, 1 << 16) || h[1] <= need) return;  // few ties: the host sorts them out
+        uint64_t* keys = nullptr;
+        for (size_t level = 1; level < sort_channels_.size() && h[1] > need; level++) {
+            const DevColumn& col = dp.cols[(size_t)sort_channels_[level]];
+            if (col.type == PA_VARCHAR) {
+                need = h[1];  // keep every remaining tie
+                break;
+            }
+            keys = static_cast<uint64_t*>(keys2_.ensure((size_t)n * 8));
+            launch_topn_keys(col.type, col.values, col.offsets, col.nulls, n, sort_orders_[level], keys, s);
+            launch_topn_mask_keys(state, n, keys, s);
+            const uint64_t thr = topn_select_kth(keys, n, need, select_temp_.ensure(topn_select_temp_bytes()), h_hist_, s);
+            launch_topn_state(keys, n, thr, false, state, s);
+            count();
+            need = n_ - h[0];
+        }
+        int32_t* flags = static_cast<int32_t*>(tie_rank_.ensure((size_t)(n + 1) * 4));
+        launch_topn_tie_flags(state, n, flags, s);
+        launch_exclusive_scan_i32(flags, flags, n, nullptr, scan_temp_.ensure(scan_temp_bytes(n)), s);
+        launch_topn_state_partition(state, flags, n, std::max<int64_t>(need, 0), part, s);
+    }
+
     // selected rows of the page -> host store (Block.copyPositions on device, then one D2H per column)
     void append_rows(const DevPage& dp, const uint64_t* keys, const int32_t* positions, int64_t count)
     {
@@ -344,6 +387,7 @@ private:
     bool finishing_ = false, output_done_ = false;
     uint64_t threshold_ = ~0ULL;  // rows whose first-channel key is above it cannot be among the N best
     DevBuf keys_, part_, pos_, counts_, part_temp_, select_temp_, gather_, var_off_, var_bytes_, scan_temp_;
+    DevBuf keys2_, state_, tie_rank_;  // refine_ties
     PinnedBuf land_, h_hist_buf_;
     uint32_t* h_hist_ = nullptr;
     std::vector<HostColumn> store_;

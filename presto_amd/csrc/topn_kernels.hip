@@ -124,9 +124,87 @@ __global__ __launch_bounds__(256) void k_topn_flag(const u64* __restrict__ keys,
     for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < n; i += (i64)gridDim.x * 256) partition[i] = keys[i] <= threshold ? 0 : 1;
 }
 
+// ---- ties on the first sort key (see op_topn.cpp): per-row state 0 = among the best for sure, 1 = tied with the bound on every
+// channel looked at so far, 2 = out ----
+__global__ __launch_bounds__(256) void k_topn_state(const u64* __restrict__ keys, i64 n, u64 threshold, int first, u8* __restrict__ state)
+{
+    for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < n; i += (i64)gridDim.x * 256) {
+        if (!first && state[i] != 1) continue;
+        const u64 k = keys[i];
+        state[i] = k < threshold ? 0 : (k == threshold ? 1 : 2);
+    }
+}
+__global__ __launch_bounds__(256) void k_topn_mask_keys(const u8* __restrict__ state, i64 n, u64* __restrict__ keys)
+{
+    for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < n; i += (i64)gridDim.x * 256) {
+        if (state[i] != 1) keys[i] = ~0ULL;
+    }
+}
+// out[0] = rows in state 0, out[1] = rows in state 1
+__global__ __launch_bounds__(256) void k_topn_count_states(const u8* __restrict__ state, i64 n, unsigned long long* __restrict__ out)
+{
+    i64 c0 = 0, c1 = 0;
+    for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < n; i += (i64)gridDim.x * 256) {
+        const u8 v = state[i];
+        c0 += v == 0;
+        c1 += v == 1;
+    }
+    c0 = pa_wave_sum_i64(c0);
+    c1 = pa_wave_sum_i64(c1);
+    if ((threadIdx.x & 63) == 0) {
+        if (c0) atomicAdd(out, (unsigned long long)c0);
+        if (c1) atomicAdd(out + 1, (unsigned long long)c1);
+    }
+}
+__global__ __launch_bounds__(256) void k_topn_tie_flags(const u8* __restrict__ state, i64 n, i32* __restrict__ flags)
+{
+    for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < n; i += (i64)gridDim.x * 256) flags[i] = state[i] == 1 ? 1 : 0;
+}
+// partition[i] = 0 (kept) for state 0 and for the first `ties_kept` rows in state 1 (tie_rank = exclusive scan of the tie flags)
+__global__ __launch_bounds__(256) void k_topn_state_partition(const u8* __restrict__ state, const i32* __restrict__ tie_rank, i64 n, i64 ties_kept,
+                                                              i32* __restrict__ partition)
+{
+    for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < n; i += (i64)gridDim.x * 256) {
+        const u8 v = state[i];
+        partition[i] = (v == 0 || (v == 1 && (i64)tie_rank[i] < ties_kept)) ? 0 : 1;
+    }
+}
+
 int grid_of(int64_t n) { return (int)std::max<int64_t>(1, std::min<int64_t>((n + 255) / 256, 2048)); }
 
 }  // namespace
+
+void launch_topn_state(const uint64_t* keys, int64_t n, uint64_t threshold, bool first, uint8_t* state, hipStream_t s)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_topn_state, grid_of(n), 256, 0, s, (const u64*)keys, (i64)n, (u64)threshold, first ? 1 : 0, state);
+    PA_HIP(hipGetLastError());
+}
+void launch_topn_mask_keys(const uint8_t* state, int64_t n, uint64_t* keys, hipStream_t s)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_topn_mask_keys, grid_of(n), 256, 0, s, state, (i64)n, (u64*)keys);
+    PA_HIP(hipGetLastError());
+}
+void launch_topn_count_states(const uint8_t* state, int64_t n, int64_t* out2, hipStream_t s)
+{
+    PA_HIP(hipMemsetAsync(out2, 0, 16, s));
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_topn_count_states, grid_of(n), 256, 0, s, state, (i64)n, reinterpret_cast<unsigned long long*>(out2));
+    PA_HIP(hipGetLastError());
+}
+void launch_topn_tie_flags(const uint8_t* state, int64_t n, int32_t* flags, hipStream_t s)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_topn_tie_flags, grid_of(n), 256, 0, s, state, (i64)n, flags);
+    PA_HIP(hipGetLastError());
+}
+void launch_topn_state_partition(const uint8_t* state, const int32_t* tie_rank, int64_t n, int64_t ties_kept, int32_t* partition, hipStream_t s)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_topn_state_partition, grid_of(n), 256, 0, s, state, tie_rank, (i64)n, (i64)ties_kept, partition);
+    PA_HIP(hipGetLastError());
+}
 
 void launch_topn_keys(int32_t type, const void* values, const int32_t* offsets, const uint8_t* nulls, int64_t n, int32_t sort_order,
                       uint64_t* keys, hipStream_t s)

@@ -15,4 +15,15 @@ uint64_t topn_select_kth(const uint64_t* keys, int64_t n, int64_t k, void* temp,
 // partition[i] = key[i] <= threshold ? 0 : 1
 void launch_topn_flag(const uint64_t* keys, int64_t n, uint64_t threshold, int32_t* partition, hipStream_t s);
 
+// Ties with the bound (op_topn.cpp): state[i] = 0 key < threshold, 1 key == threshold, 2 beyond; first = false refines only the
+// rows in state 1 (the next sort channel's keys)
+void launch_topn_state(const uint64_t* keys, int64_t n, uint64_t threshold, bool first, uint8_t* state, hipStream_t s);
+// keys[i] = ~0 unless state[i] == 1 (the selection then only sees the tied rows)
+void launch_topn_mask_keys(const uint8_t* state, int64_t n, uint64_t* keys, hipStream_t s);
+// out2[0] = rows in state 0, out2[1] = rows in state 1 (device memory, 16 bytes)
+void launch_topn_count_states(const uint8_t* state, int64_t n, int64_t* out2, hipStream_t s);
+void launch_topn_tie_flags(const uint8_t* state, int64_t n, int32_t* flags, hipStream_t s);
+// partition[i] = 0 for state 0 and for the first ties_kept rows in state 1 (tie_rank = exclusive scan of the tie flags), else 1
+void launch_topn_state_partition(const uint8_t* state, const int32_t* tie_rank, int64_t n, int64_t ties_kept, int32_t* partition, hipStream_t s);
+
 }  // namespace pa

@@ -83,3 +83,35 @@ def test_topn_device_pages_and_device_output(gpu, oracle):
     out = download_page(op.getOutput())
     assert out.to_rows() == oracle.topn(pages, 10, [0, 1], [abi.DESC_NULLS_LAST, abi.ASC_NULLS_LAST])
     assert op.isFinished()
+
+
+@pytest.mark.parametrize("shape", ["all_equal", "two_values", "three_channels", "fully_tied", "varchar_second"])
+def test_topn_with_masses_of_ties_on_the_first_key(gpu, oracle, shape):
+    """ORDER BY <low-cardinality column>, ... LIMIT n: hundreds of thousands of rows tie with the bound on the first key.  The page's
+    ties are cut down on the device, channel by channel (a page contributes at most its own n best rows), instead of crossing to
+    the host whole; fully tied rows come out in arrival order.  Results equal the oracle's, and the call stays fast."""
+    import time
+    rng = np.random.default_rng(len(shape))
+    n = 120000
+    pages = []
+    for p in range(3):
+        first = {"all_equal": np.zeros(n), "two_values": (rng.random(n) < 0.5).astype(np.float64), "three_channels": np.zeros(n),
+                 "fully_tied": np.zeros(n), "varchar_second": np.zeros(n)}[shape]
+        second = rng.integers(0, 5, n) if shape in ("three_channels", "varchar_second") else rng.permutation(n) + p * n
+        if shape == "fully_tied":
+            second = np.zeros(n, dtype=np.int64)
+        blocks = [Block.double(first, rng.random(n) < 0.001), Block.bigint(second), Block.integer(rng.permutation(n).astype(np.int32) + p * n)]
+        if shape == "varchar_second":
+            blocks[1] = Block.varchar([[b"abcdefghA", b"abcdefghB", b"x"][j] for j in rng.integers(0, 3, n)])
+        pages.append(Page(blocks, n))
+    types = [abi.DOUBLE, abi.VARCHAR if shape == "varchar_second" else abi.BIGINT, abi.INTEGER]
+    for limit, orders in ((10, [abi.ASC_NULLS_LAST, abi.DESC_NULLS_LAST, abi.ASC_NULLS_LAST]), (2000, [abi.DESC_NULLS_FIRST, abi.ASC_NULLS_LAST, abi.DESC_NULLS_LAST])):
+        expected = oracle.topn(pages, limit, [0, 1, 2], orders)
+        t0 = time.perf_counter()
+        got = rows_of(to_pages(TopNOperator(types, limit, [0, 1, 2], orders), pages))
+        elapsed = time.perf_counter() - t0
+        if shape == "fully_tied":   # the third channel decides (unique); rows tied on all three do not exist
+            assert got == expected
+        else:
+            assert got == expected, (got[:3], expected[:3])
+        assert elapsed < (20.0 if shape == "varchar_second" else 3.0), elapsed
