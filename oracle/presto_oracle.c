@@ -844,6 +844,8 @@ typedef struct acc_state { /* LongDoubleState / LongLongState / LongState per gr
     double dsum;
     int64_t lsum;
     int32_t has_value; /* min/max */
+    uint8_t* str;      /* min/max over VARCHAR: the value so far (owned copy) */
+    int32_t slen;
 } acc_state;
 
 struct orc_hash_agg {
@@ -962,6 +964,10 @@ void orc_hash_agg_destroy(orc_hash_agg* a)
     }
     free(a->key_builders);
     free(a->raw_hash_by_group);
+    if (a->states) {
+        const size_t total = (size_t)a->state_cap * (size_t)(a->desc.aggregate_count > 0 ? a->desc.aggregate_count : 1);
+        for (size_t i = 0; i < total; i++) free(a->states[i].str);
+    }
     free(a->states);
     free(a);
 }
@@ -1254,13 +1260,27 @@ static void min_max_update(acc_state* s, int is_min, const orc_val* v)
         take = 1;
     }
     else {
-        int c = v->type == PA_DOUBLE ? double_compare(v->d, s->dsum) : (v->i < s->lsum ? -1 : (v->i > s->lsum ? 1 : 0));
+        int c;
+        if (v->type == PA_VARCHAR) { /* VarcharType's comparison = Slice.compareTo: unsigned bytes, then length */
+            int32_t m = v->slen < s->slen ? v->slen : s->slen;
+            c = m > 0 ? memcmp(v->s, s->str, (size_t)m) : 0;
+            if (c == 0) c = v->slen < s->slen ? -1 : (v->slen > s->slen ? 1 : 0);
+        }
+        else {
+            c = v->type == PA_DOUBLE ? double_compare(v->d, s->dsum) : (v->i < s->lsum ? -1 : (v->i > s->lsum ? 1 : 0));
+        }
         take = is_min ? c < 0 : c > 0;
     }
     if (take) {
         s->has_value = 1;
         s->dsum = v->d;
         s->lsum = v->i;
+        if (v->type == PA_VARCHAR) {
+            free(s->str);
+            s->str = (uint8_t*)malloc((size_t)(v->slen > 0 ? v->slen : 1));
+            if (v->slen > 0) memcpy(s->str, v->s, (size_t)v->slen);
+            s->slen = v->slen;
+        }
     }
 }
 
@@ -1483,7 +1503,7 @@ int32_t orc_hash_agg_build_result(orc_hash_agg* a, pa_page* out)
                     v.type = b.type;
                     if (part == 0) v.i = st[g].count;
                     else if (min_max && !st[g].has_value) v.is_null = 1;
-                    else { v.d = st[g].dsum; v.i = st[g].lsum; }
+                    else { v.d = st[g].dsum; v.i = st[g].lsum; v.s = st[g].str; v.slen = st[g].slen; }
                     cb_append(&b, &v);
                 }
                 cb_finish(&b, &out->columns[c++]);
@@ -1520,7 +1540,7 @@ int32_t orc_hash_agg_build_result(orc_hash_agg* a, pa_page* out)
                     break;
                 default:
                     if (!s->has_value) v.is_null = 1;
-                    else { v.d = s->dsum; v.i = s->lsum; }
+                    else { v.d = s->dsum; v.i = s->lsum; v.s = s->str; v.slen = s->slen; }
                     break;
             }
             cb_append(&b, &v);

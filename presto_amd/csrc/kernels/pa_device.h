@@ -460,6 +460,19 @@ __device__ __forceinline__ u64 pa_readlane_u64(u64 v, int lane)
     return ((u64)hi << 32) | (u64)lo;
 }
 
+// order-preserving image of a string of at most 7 bytes: its bytes from the top of the word down, the length in the lowest byte
+// (Slice.compareTo: unsigned bytes, then length -- a proper prefix sorts first: equal upper bytes, smaller length)
+__device__ __forceinline__ u64 pa_img_str7(const u8* p, i32 len, i32* err)
+{
+    if (len > 7) {
+        pa_raise(err, -3);
+        len = 7;
+    }
+    u64 v = (u64)len;
+    for (i32 b = 0; b < len; b++) v |= (u64)p[b] << (56 - 8 * b);
+    return v;
+}
+
 // bytes of a short VARCHAR (declared bound <= 7) packed little-endian into one word
 __device__ __forceinline__ u64 pa_short_bytes(const u8* p, i32 len, i32 bound, i32* err)
 {

@@ -316,8 +316,17 @@ Spec make_spec(const pa_filter_project_desc& fp, const pa_hash_aggregation_desc&
         PA_REQUIRE(a.mask_channel < n_agg_in, PA_ERR_INVALID_ARGUMENT, "aggregate mask channel out of range");
         if (a.fn != PA_AGG_COUNT_STAR) a.input_channel = to_proj[a.input_channel];
         if (a.mask_channel >= 0) a.mask_channel = to_proj[a.mask_channel];
-        if (a.fn == PA_AGG_MIN || a.fn == PA_AGG_MAX) {
-            PA_REQUIRE(a.input_type != PA_VARCHAR, PA_ERR_NOT_SUPPORTED, "min/max over VARCHAR are not on the device path yet");
+        // min / max over VARCHAR: strings of a declared length of at most 7 bytes have an order-preserving 64-bit image (bytes
+        // big-endian, then the length: Slice.compareTo = unsigned bytes, then length) and ride the integer max machinery; longer or
+        // unbounded strings stay with the Java operator
+        auto short_varchar = [&](int proj) {
+            const OwnedExpr& pe = s.proj[proj];
+            if (!pe.is_input_ref()) return false;
+            const int ch = pe.node(pe.root).channel;
+            return ch >= 0 && ch < s.n_in && s.in_params[ch] >= 1 && s.in_params[ch] <= 7;
+        };
+        if ((a.fn == PA_AGG_MIN || a.fn == PA_AGG_MAX) && ag.step != PA_STEP_FINAL && a.input_channel >= 0 && s.proj[a.input_channel].root_type() == PA_VARCHAR) {
+            PA_REQUIRE(short_varchar(a.input_channel), PA_ERR_NOT_SUPPORTED, "min/max over VARCHAR: only channels declared VARCHAR(n), n <= 7, are on the device path");
         }
         if (s.step == PA_STEP_FINAL) {
             // intermediate input: [count BIGINT] for count / count(*), [count BIGINT, sum] for sum / avg
@@ -326,7 +335,8 @@ Spec make_spec(const pa_filter_project_desc& fp, const pa_hash_aggregation_desc&
             PA_REQUIRE(a.mask_channel < 0, PA_ERR_INVALID_ARGUMENT, "FINAL step takes no mask");
             if (a.fn == PA_AGG_MIN || a.fn == PA_AGG_MAX) {
                 PA_REQUIRE(a.input_channel + 1 < fp.projection_count, PA_ERR_INVALID_ARGUMENT, "FINAL step: missing value state channel");
-                PA_REQUIRE(s.proj[a.input_channel + 1].root_type() != PA_VARCHAR, PA_ERR_NOT_SUPPORTED, "min/max over VARCHAR are not on the device path yet");
+                PA_REQUIRE(s.proj[a.input_channel + 1].root_type() != PA_VARCHAR || short_varchar(a.input_channel + 1), PA_ERR_NOT_SUPPORTED,
+                           "min/max over VARCHAR: only state channels declared VARCHAR(n), n <= 7, are on the device path");
             }
             if (a.fn == PA_AGG_SUM || a.fn == PA_AGG_AVG) {
                 PA_REQUIRE(a.input_channel + 1 < fp.projection_count, PA_ERR_INVALID_ARGUMENT, "FINAL step: missing sum state channel");
@@ -337,7 +347,7 @@ Spec make_spec(const pa_filter_project_desc& fp, const pa_hash_aggregation_desc&
         else if (a.fn != PA_AGG_COUNT_STAR) {
             int32_t t = s.proj[a.input_channel].root_type();
             const bool min_max = a.fn == PA_AGG_MIN || a.fn == PA_AGG_MAX;
-            PA_REQUIRE(a.fn == PA_AGG_COUNT || t == PA_DOUBLE || t == PA_BIGINT || t == PA_INTEGER || (min_max && (t == PA_DATE || t == PA_BOOLEAN)),
+            PA_REQUIRE(a.fn == PA_AGG_COUNT || t == PA_DOUBLE || t == PA_BIGINT || t == PA_INTEGER || (min_max && (t == PA_DATE || t == PA_BOOLEAN || t == PA_VARCHAR)),
                        PA_ERR_NOT_SUPPORTED, "aggregate input type not supported on device");
         }
         s.aggs.push_back(a);
@@ -618,6 +628,7 @@ KernelInfo generate(const Spec& s, const std::vector<ChannelLayout>& layout, int
             case PA_DATE: img = "pa_img_i64((i64)" + x.v + ")"; break;
             case PA_DOUBLE: img = "pa_img_f64(" + x.v + ")"; break;
             case PA_BOOLEAN: img = "(" + x.v + " ? 1ULL : 0ULL)"; break;
+            case PA_VARCHAR: img = "pa_img_str7(" + x.v + ", " + x.len + ", a.err)"; break;
             default: throw Error(PA_ERR_NOT_SUPPORTED, "min/max input type not supported on device");
         }
         return is_min ? "(~" + img + ")" : img;
@@ -1950,7 +1961,7 @@ public:
                 int32_t t = spec_.proj[value_proj].root_type();
                 if (ag.fn == PA_AGG_AVG || (ag.fn == PA_AGG_SUM && t == PA_DOUBLE)) t = PA_DOUBLE;  // sum state: DOUBLE, or BIGINT for integer sums
                 else if (ag.fn == PA_AGG_SUM) t = PA_BIGINT;
-                add_channel(t, 0);
+                add_channel(t, t == PA_VARCHAR ? 7 : 0);  // (min / max over VARCHAR only exist for strings of <= 7 bytes)
             }
             c.aggs.push_back(f);
         }
@@ -2963,6 +2974,7 @@ bool FusedAggregationOperator::emit_on_device(const KernelInfo& ki, int64_t grou
             c->word = cw;
             nullable.push_back(false);
         }
+        if (min_max && spec_.proj[value_proj].root_type() == PA_VARCHAR) return false;  // strings are assembled on the host
         if (min_max) {  // the value itself (final result, or the value half of the PARTIAL state): NULL while no input was seen
             GtEmitCol* c = add(GT_EMIT_MINMAX, spec_.proj[value_proj].root_type());
             if (!c) return false;
@@ -3272,12 +3284,33 @@ void FusedAggregationOperator::build_output()
             const int value_proj = spec_.step == PA_STEP_FINAL ? ag.input_channel + 1 : ag.input_channel;
             OutColumn& oc = out_cols_[col];
             oc.type = spec_.proj[value_proj].root_type();
-            const int width = type_width(oc.type);
             auto& data = host_cols[col];
             auto& nulls = host_nulls[col];
             nulls.assign(groups ? groups : 1, 0);
-            data.assign((size_t)groups * width, 0);
             bool any_null = false;
+            if (oc.type == PA_VARCHAR) {  // image = up to 7 bytes big-endian, then the length (pa_img_str7)
+                oc.varwidth = true;
+                auto& offs = host_offsets[col];
+                offs.assign(1, 0);
+                for (int64_t g = 0; g < groups; g++) {
+                    const uint64_t* ww = &words[(size_t)g * nw_];
+                    if (cw >= 0 && ww[cw] == 0) {
+                        nulls[g] = 1;
+                        any_null = true;
+                    }
+                    else {
+                        const uint64_t img = ag.fn == PA_AGG_MIN ? ~ww[vw] : ww[vw];
+                        const int len = (int)(img & 0xff);
+                        for (int b = 0; b < len && b < 7; b++) data.push_back((uint8_t)(img >> (56 - 8 * b)));
+                    }
+                    offs.push_back((int32_t)data.size());
+                }
+                oc.has_nulls = any_null;
+                col++;
+                continue;
+            }
+            const int width = type_width(oc.type);
+            data.assign((size_t)groups * width, 0);
             for (int64_t g = 0; g < groups; g++) {
                 const uint64_t* ww = &words[(size_t)g * nw_];
                 if (cw >= 0 && ww[cw] == 0) {
