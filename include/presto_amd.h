@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PA_ABI_VERSION 6
+#define PA_ABI_VERSION 7
 
 /* ---- status codes (negative = error).  Mapped by the JNI shim onto TrinoException
  *      StandardErrorCode (trino-spi/.../StandardErrorCode.java). ---- */
@@ -52,7 +52,10 @@ typedef enum pa_type {
     PA_DOUBLE = 3,   /* LongArrayBlock holding doubleToLongBits, 8 B */
     PA_BOOLEAN = 4,  /* ByteArrayBlock, 1 B */
     PA_VARCHAR = 5,  /* VariableWidthBlock: bytes + int32 offsets[positionCount+1] */
-    PA_ROW = 6       /* RowBlock of the fields' types (only as the intermediate state of an aggregate, PA_STATES_REFERENCE) */
+    PA_ROW = 6,      /* RowBlock of the fields' types (only as the intermediate state of an aggregate, PA_STATES_REFERENCE) */
+    PA_REAL = 7      /* IntArrayBlock holding floatToRawIntBits, 4 B (RealType.java).  Expressions (arithmetic, comparisons, casts
+                      * from / to DOUBLE and from the integer types), sum / avg / min / max / count inputs, and payload channels of
+                      * joins, exchanges and TopN; not a group, join, sort or partition key (PA_ERR_NOT_SUPPORTED) */
 } pa_type;
 
 typedef enum pa_encoding {
@@ -138,7 +141,7 @@ typedef struct pa_expr_node {
     int32_t first_arg;  /* index of first child id in pa_expr.args */
     int32_t str_len;    /* CONSTANT VARCHAR */
     int64_t i64;        /* CONSTANT BIGINT/INTEGER/DATE/BOOLEAN */
-    double f64;         /* CONSTANT DOUBLE */
+    double f64;          /* CONSTANT of type DOUBLE, or REAL (the float value, widened) */
     const char* str;    /* CONSTANT VARCHAR bytes (not NUL terminated) */
 } pa_expr_node;
 

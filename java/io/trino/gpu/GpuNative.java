@@ -10,8 +10,8 @@ final class GpuNative
 {
     static {
         System.loadLibrary("presto_amd_jni"); // links libpresto_amd.so
-        if (abiVersion() != 5) {
-            throw new IllegalStateException("libpresto_amd.so ABI version " + abiVersion() + " != 5");
+        if (abiVersion() != 7) {
+            throw new IllegalStateException("libpresto_amd.so ABI version " + abiVersion() + " != 7");
         }
     }
 

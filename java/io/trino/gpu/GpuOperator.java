@@ -119,7 +119,8 @@ public final class GpuOperator
                     break;
                 }
                 case RowExpressionSerializer.PA_INTEGER:
-                case RowExpressionSerializer.PA_DATE: {
+                case RowExpressionSerializer.PA_DATE:
+                case RowExpressionSerializer.PA_REAL: {        // RealType stores floatToRawIntBits in an IntArrayBlock
                     int[] v = new int[positions];
                     values.asIntBuffer().get(v);
                     blocks[c] = new IntArrayBlock(positions, Optional.ofNullable(valueIsNull), v);

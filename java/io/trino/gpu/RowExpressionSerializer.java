@@ -39,7 +39,7 @@ final class RowExpressionSerializer
     }
 
     // pa_type / pa_expr_kind / pa_call_op / pa_special_form ordinals
-    static final int PA_BIGINT = 0, PA_INTEGER = 1, PA_DATE = 2, PA_DOUBLE = 3, PA_BOOLEAN = 4, PA_VARCHAR = 5;
+    static final int PA_BIGINT = 0, PA_INTEGER = 1, PA_DATE = 2, PA_DOUBLE = 3, PA_BOOLEAN = 4, PA_VARCHAR = 5, PA_REAL = 7;
     private static final int INPUT_REF = 0, CONSTANT = 1, CALL = 2, SPECIAL = 3;
 
     private final List<int[]> nodes = new ArrayList<>();      // kind, op, type, channel, isNull, nargs, firstArg
@@ -84,6 +84,9 @@ final class RowExpressionSerializer
         }
         if (type.equals(BOOLEAN)) {
             return PA_BOOLEAN;
+        }
+        if (type.equals(io.trino.spi.type.RealType.REAL)) {
+            return PA_REAL;
         }
         if (type instanceof io.trino.spi.type.VarcharType) {
             return PA_VARCHAR;
@@ -167,6 +170,8 @@ final class RowExpressionSerializer
         }
         switch (typeOf(type)) {
             case PA_DOUBLE: return add(CONSTANT, 0, type, 0, false, List.of(), 0, (Double) value, null);
+            // a REAL literal is a Long holding floatToRawIntBits (RealType's Java type); the native side takes the value widened
+            case PA_REAL: return add(CONSTANT, 0, type, 0, false, List.of(), 0, Float.intBitsToFloat(((Number) value).intValue()), null);
             case PA_BOOLEAN: return add(CONSTANT, 0, type, 0, false, List.of(), (Boolean) value ? 1 : 0, 0, null);
             case PA_VARCHAR: return add(CONSTANT, 0, type, 0, false, List.of(), 0, 0, ((Slice) value).getBytes());
             default: return add(CONSTANT, 0, type, 0, false, List.of(), ((Number) value).longValue(), 0, null);

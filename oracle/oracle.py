@@ -646,7 +646,8 @@ class DynamicFilterSource:
 
 # ---- page wire format -------------------------------------------------------------------------------------------------
 _ENCODING = {abi.BIGINT: (b"LONG_ARRAY", "<i8"), abi.DOUBLE: (b"LONG_ARRAY", "<f8"), abi.INTEGER: (b"INT_ARRAY", "<i4"), abi.DATE: (b"INT_ARRAY", "<i4"),
-             abi.BOOLEAN: (b"BYTE_ARRAY", "u1"), abi.VARCHAR: (b"VARIABLE_WIDTH", None)}
+             abi.BOOLEAN: (b"BYTE_ARRAY", "u1"), abi.VARCHAR: (b"VARIABLE_WIDTH", None),
+             abi.REAL: (b"INT_ARRAY", "<f4")}   # RealType: floatToRawIntBits in an IntArrayBlock
 
 
 def serialize_page(page):

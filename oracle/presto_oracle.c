@@ -171,6 +171,8 @@ typedef struct orc_val {
 } orc_val;
 
 static inline int type_is_int(int32_t t) { return t == PA_BIGINT || t == PA_INTEGER || t == PA_DATE; }
+/* DOUBLE, and REAL: a REAL value travels in orc_val.d as the double it converts to exactly (RealOperators.castToDouble) */
+static inline int type_is_fp(int32_t t) { return t == PA_DOUBLE || t == PA_REAL; }
 
 /* resolve Dictionary / RLE wrappers (SPI/block/DictionaryBlock.java, RunLengthEncodedBlock.java) */
 static inline const pa_column* resolve(const pa_column* c, int32_t* pos)
@@ -213,6 +215,9 @@ static inline orc_val col_get(const pa_column* c, int32_t pos)
             break;
         case PA_DOUBLE:
             v.d = ((const double*)c->values)[pos];
+            break;
+        case PA_REAL: /* IntArrayBlock of floatToRawIntBits (SPI/type/RealType.java) */
+            v.d = (double)((const float*)c->values)[pos];
             break;
         case PA_BOOLEAN:
             v.i = ((const uint8_t*)c->values)[pos] != 0;
@@ -364,8 +369,9 @@ static orc_val eval_compare(eval_ctx* cx, int32_t op, const orc_val* a, const or
         return null_of(PA_BOOLEAN);
     }
     int lt, eq;
-    if (a->type == PA_DOUBLE) {
-        /* TM/type/DoubleOperators: plain IEEE comparisons (NaN compares false, -0 == +0) */
+    if (type_is_fp(a->type)) {
+        /* TM/type/DoubleOperators, RealOperators: plain IEEE comparisons (NaN compares false, -0 == +0); float comparisons are the
+         * comparisons of the widened values */
         lt = a->d < b->d;
         eq = a->d == b->d;
         switch (op) {
@@ -405,6 +411,20 @@ static orc_val eval_arith(eval_ctx* cx, int32_t op, int32_t type, const orc_val*
     orc_val r;
     memset(&r, 0, sizeof r);
     r.type = type;
+    if (type == PA_REAL) { /* TM/type/RealOperators.java:55-95: Java float arithmetic */
+        const float x = (float)a->d, y = b ? (float)b->d : 0.0f;
+        float z;
+        switch (op) {
+            case PA_OP_ADD: z = x + y; break;
+            case PA_OP_SUBTRACT: z = x - y; break;
+            case PA_OP_MULTIPLY: z = x * y; break;
+            case PA_OP_DIVIDE: z = x / y; break;
+            case PA_OP_MODULUS: z = fmodf(x, y); break;
+            default: z = -x; break;
+        }
+        r.d = (double)z;
+        return r;
+    }
     if (type == PA_DOUBLE) { /* TM/type/DoubleOperators.java:59-110 */
         switch (op) {
             case PA_OP_ADD: r.d = a->d + b->d; break;
@@ -463,7 +483,7 @@ static orc_val eval_node(eval_ctx* cx, int32_t id)
             v.type = n->type;
             v.is_null = n->is_null;
             v.i = n->i64;
-            v.d = n->f64;
+            v.d = n->type == PA_REAL ? (double)(float)n->f64 : n->f64;
             v.s = (const uint8_t*)n->str;
             v.slen = n->str_len;
             return v;
@@ -495,6 +515,15 @@ static orc_val eval_node(eval_ctx* cx, int32_t id)
                 r.type = n->type;
                 if (n->type == PA_DOUBLE && type_is_int(a.type)) {
                     r.d = (double)a.i; /* BigintOperators.castToDouble */
+                }
+                else if (n->type == PA_DOUBLE && a.type == PA_REAL) {
+                    r.d = a.d; /* RealOperators.castToDouble (:164-169) */
+                }
+                else if (n->type == PA_REAL && a.type == PA_DOUBLE) {
+                    r.d = (double)(float)a.d; /* DoubleOperators.castToReal: (float) value */
+                }
+                else if (n->type == PA_REAL && type_is_int(a.type)) {
+                    r.d = (double)(float)a.i; /* BigintOperators / IntegerOperators.castToReal: (float) value */
                 }
                 else if (n->type == PA_BIGINT && type_is_int(a.type)) {
                     r.i = a.i;
@@ -659,6 +688,7 @@ static int32_t type_width(int32_t t)
             return 8;
         case PA_INTEGER:
         case PA_DATE:
+        case PA_REAL:
             return 4;
         case PA_BOOLEAN:
             return 1;
@@ -721,6 +751,9 @@ static void cb_append(col_builder* b, const orc_val* v)
             break;
         case PA_DOUBLE:
             ((double*)b->values)[i] = v->is_null ? 0.0 : v->d;
+            break;
+        case PA_REAL:
+            ((float*)b->values)[i] = v->is_null ? 0.0f : (float)v->d;
             break;
         case PA_BOOLEAN:
             b->values[i] = v->is_null ? 0 : (uint8_t)(v->i != 0);
@@ -1060,6 +1093,7 @@ static orc_val builder_get(const col_builder* b, int32_t pos)
         case PA_INTEGER:
         case PA_DATE: v.i = ((int32_t*)b->values)[pos]; break;
         case PA_DOUBLE: v.d = ((double*)b->values)[pos]; break;
+        case PA_REAL: v.d = (double)((float*)b->values)[pos]; break;
         case PA_BOOLEAN: v.i = b->values[pos]; break;
         case PA_VARCHAR:
             v.s = b->values + b->offsets[pos];
@@ -1267,7 +1301,7 @@ static void min_max_update(acc_state* s, int is_min, const orc_val* v)
             if (c == 0) c = v->slen < s->slen ? -1 : (v->slen > s->slen ? 1 : 0);
         }
         else {
-            c = v->type == PA_DOUBLE ? double_compare(v->d, s->dsum) : (v->i < s->lsum ? -1 : (v->i > s->lsum ? 1 : 0));
+            c = type_is_fp(v->type) ? double_compare(v->d, s->dsum) : (v->i < s->lsum ? -1 : (v->i > s->lsum ? 1 : 0));
         }
         take = is_min ? c < 0 : c > 0;
     }
@@ -1347,7 +1381,8 @@ static void accumulate(orc_hash_agg* a, int32_t k, const pa_page* page, const in
                 break;
             case PA_AGG_SUM:
                 s->count++;
-                if (v.type == PA_DOUBLE) { /* DoubleSumAggregation.java:33-38 */
+                if (type_is_fp(v.type)) { /* DoubleSumAggregation.java:33-38; RealSumAggregation.java:36-41: the REAL sum's state is a
+                                           * double, every input widened */
                     s->dsum = s->dsum + v.d;
                 }
                 else { /* LongSumAggregation.java:37-42 -> BigintOperators.add (Math.addExact) */
@@ -1361,7 +1396,7 @@ static void accumulate(orc_hash_agg* a, int32_t k, const pa_page* page, const in
                 break;
             case PA_AGG_AVG: /* AverageAggregations.java:34-46 */
                 s->count++;
-                s->dsum = s->dsum + (v.type == PA_DOUBLE ? v.d : (double)v.i);
+                s->dsum = s->dsum + (type_is_fp(v.type) ? v.d : (double)v.i); /* (RealAverageAggregation.input: double sum of widened floats) */
                 break;
             case PA_AGG_MIN:
             case PA_AGG_MAX:
@@ -1491,7 +1526,7 @@ int32_t orc_hash_agg_build_result(orc_hash_agg* a, pa_page* out)
         const acc_state* st = a->states + (size_t)k * a->state_cap;
         if (partial) {
             /* Step.PARTIAL: the states themselves, flattened: [count BIGINT] (+ [sum DOUBLE | BIGINT]) */
-            int value_double = ag->fn == PA_AGG_AVG || ag->input_type == PA_DOUBLE;
+            int value_double = ag->fn == PA_AGG_AVG || type_is_fp(ag->input_type); /* REAL sums / averages: NullableDoubleState / DoubleState */
             int min_max = ag->fn == PA_AGG_MIN || ag->fn == PA_AGG_MAX;
             for (int part = 0; part < ((ag->fn == PA_AGG_COUNT || ag->fn == PA_AGG_COUNT_STAR) ? 1 : 2); part++) {
                 col_builder b;
@@ -1514,8 +1549,8 @@ int32_t orc_hash_agg_build_result(orc_hash_agg* a, pa_page* out)
         switch (ag->fn) {
             case PA_AGG_COUNT_STAR:
             case PA_AGG_COUNT: out_type = PA_BIGINT; break;
-            case PA_AGG_AVG: out_type = PA_DOUBLE; break;
-            default: out_type = ag->input_type == PA_DOUBLE ? PA_DOUBLE : ag->input_type; break;
+            case PA_AGG_AVG: out_type = ag->input_type == PA_REAL ? PA_REAL : PA_DOUBLE; break; /* RealAverageAggregation.output writes a REAL */
+            default: out_type = ag->input_type; break;
         }
         col_builder b;
         cb_init(&b, out_type, groups);
@@ -1531,11 +1566,12 @@ int32_t orc_hash_agg_build_result(orc_hash_agg* a, pa_page* out)
                     break;
                 case PA_AGG_SUM:
                     if (s->count == 0) v.is_null = 1;
-                    else if (out_type == PA_DOUBLE) v.d = s->dsum;
+                    else if (type_is_fp(out_type)) v.d = out_type == PA_REAL ? (double)(float)s->dsum : s->dsum; /* RealSumAggregation.output: (float) sum */
                     else v.i = s->lsum;
                     break;
                 case PA_AGG_AVG:
                     if (s->count == 0) v.is_null = 1;
+                    else if (out_type == PA_REAL) v.d = (double)(float)(s->dsum / (double)s->count); /* RealAverageAggregation.java:150-158 */
                     else v.d = s->dsum / (double)s->count;
                     break;
                 default:

@@ -5,7 +5,7 @@ test-only oracle binding (oracle/oracle.py), exactly as both C sides share the h
 """
 import ctypes as C
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 # pa_status
 OK = 0
@@ -26,9 +26,9 @@ STATUS_NAMES = {
 }
 
 # pa_type
-BIGINT, INTEGER, DATE, DOUBLE, BOOLEAN, VARCHAR, ROW = range(7)
+BIGINT, INTEGER, DATE, DOUBLE, BOOLEAN, VARCHAR, ROW, REAL = range(8)
 TYPE_NAMES = ["BIGINT", "INTEGER", "DATE", "DOUBLE", "BOOLEAN", "VARCHAR", "ROW"]
-TYPE_WIDTH = {BIGINT: 8, INTEGER: 4, DATE: 4, DOUBLE: 8, BOOLEAN: 1, VARCHAR: 0, ROW: 0}
+TYPE_WIDTH = {BIGINT: 8, INTEGER: 4, DATE: 4, DOUBLE: 8, BOOLEAN: 1, VARCHAR: 0, ROW: 0, REAL: 4}
 
 # pa_encoding
 FLAT, VARWIDTH, DICTIONARY, RLE, ROW_FIELDS = range(5)

@@ -44,6 +44,7 @@ inline int type_width(int32_t t)
             return 8;
         case PA_INTEGER:
         case PA_DATE:
+        case PA_REAL:
             return 4;
         case PA_BOOLEAN:
             return 1;

@@ -90,6 +90,8 @@ std::string RowCodegen::ctype(int32_t type)
     switch (type) {
         case PA_DOUBLE:
             return "double";
+        case PA_REAL:
+            return "float";
         case PA_BOOLEAN:
             return "bool";
         case PA_VARCHAR:
@@ -158,6 +160,8 @@ GenValue RowCodegen::emit_compare(int32_t op, const GenValue& a, const GenValue&
     }
     bool ad = a.type == PA_DOUBLE, bd = b.type == PA_DOUBLE;
     PA_REQUIRE(ad == bd, PA_ERR_NOT_SUPPORTED, "comparison between DOUBLE and non-DOUBLE needs an explicit CAST");
+    // RealOperators' comparisons are Java float comparisons (RealOperators.java: intBitsToFloat(left) < intBitsToFloat(right) ...)
+    PA_REQUIRE((a.type == PA_REAL) == (b.type == PA_REAL), PA_ERR_NOT_SUPPORTED, "comparison between REAL and non-REAL needs an explicit CAST");
     out << "bool " << r.v << " = (" << a.v << " " << s << " " << b.v << ");\n";
     return r;
 }
@@ -183,6 +187,9 @@ GenValue RowCodegen::emit_node(const OwnedExpr& e, int32_t id, std::ostringstrea
             switch (n.type) {
                 case PA_DOUBLE:
                     r.v = n.is_null ? "0.0" : double_literal(n.f64);
+                    break;
+                case PA_REAL:  // the constant travels in f64 (every float is exactly a double)
+                    r.v = n.is_null ? "0.0f" : "((float)" + double_literal((double)(float)n.f64) + ")";
                     break;
                 case PA_BOOLEAN:
                     r.v = (!n.is_null && n.i64) ? "true" : "false";
@@ -219,6 +226,10 @@ GenValue RowCodegen::emit_node(const OwnedExpr& e, int32_t id, std::ostringstrea
                 GenValue x = emit_node(e, a[0], out);
                 r.n = x.n;
                 if (n.type == PA_DOUBLE && is_int_type(x.type)) r.v = "((double)" + x.v + ")";
+                // RealOperators.castToDouble (:164-169), DoubleOperators.castToReal, BigintOperators / IntegerOperators.castToReal: Java
+                // widening / narrowing primitive conversions = the C conversions (round to nearest even)
+                else if (n.type == PA_DOUBLE && x.type == PA_REAL) r.v = "((double)" + x.v + ")";
+                else if (n.type == PA_REAL && (x.type == PA_DOUBLE || is_int_type(x.type))) r.v = "((float)" + x.v + ")";
                 else if (n.type == PA_BIGINT && is_int_type(x.type)) r.v = x.v;
                 else if (n.type == x.type) { r.v = x.v; r.len = x.len; }
                 else throw Error(PA_ERR_NOT_SUPPORTED, "CAST not supported on device");
@@ -232,6 +243,7 @@ GenValue RowCodegen::emit_node(const OwnedExpr& e, int32_t id, std::ostringstrea
                 y = emit_node(e, a[1], out);
                 PA_REQUIRE((x.type == PA_DOUBLE) == (y.type == PA_DOUBLE), PA_ERR_NOT_SUPPORTED,
                            "mixed DOUBLE / integer arithmetic needs an explicit CAST");
+                PA_REQUIRE((x.type == PA_REAL) == (y.type == PA_REAL), PA_ERR_NOT_SUPPORTED, "mixed REAL / other arithmetic needs an explicit CAST");
             }
             else {
                 y.n = "false";
@@ -249,6 +261,21 @@ GenValue RowCodegen::emit_node(const OwnedExpr& e, int32_t id, std::ostringstrea
                     case PA_OP_DIVIDE: out << x.v << " / " << y.v; break;
                     case PA_OP_MODULUS: out << "fmod(" << x.v << ", " << y.v << ")"; break;
                     default: out << "-(" << x.v << ")"; break;  // (a negative literal operand would read as `--`)
+                }
+                out << ";\n";
+                return r;
+            }
+            if (n.type == PA_REAL) {
+                PA_REQUIRE(x.type == PA_REAL, PA_ERR_NOT_SUPPORTED, "REAL arithmetic on non-REAL operands");
+                // RealOperators.java:55-95: Java float arithmetic (IEEE single, no contraction); % is fmodf
+                out << "float " << r.v << " = ";
+                switch (n.op) {
+                    case PA_OP_ADD: out << x.v << " + " << y.v; break;
+                    case PA_OP_SUBTRACT: out << x.v << " - " << y.v; break;
+                    case PA_OP_MULTIPLY: out << x.v << " * " << y.v; break;
+                    case PA_OP_DIVIDE: out << x.v << " / " << y.v; break;
+                    case PA_OP_MODULUS: out << "fmodf(" << x.v << ", " << y.v << ")"; break;
+                    default: out << "-(" << x.v << ")"; break;
                 }
                 out << ";\n";
                 return r;
@@ -379,7 +406,7 @@ GenValue RowCodegen::emit_node(const OwnedExpr& e, int32_t id, std::ostringstrea
                 case PA_FORM_COALESCE: {
                     PA_REQUIRE(n.type != PA_VARCHAR, PA_ERR_NOT_SUPPORTED, "VARCHAR-valued COALESCE not supported on device");
                     std::string v = fresh("t"), nn = fresh("n");
-                    out << ctype(n.type) << " " << v << " = " << (n.type == PA_DOUBLE ? "0.0" : (n.type == PA_BOOLEAN ? "false" : "0LL"))
+                    out << ctype(n.type) << " " << v << " = " << (n.type == PA_DOUBLE ? "0.0" : (n.type == PA_REAL ? "0.0f" : (n.type == PA_BOOLEAN ? "false" : "0LL")))
                         << "; bool " << nn << " = true;\n";
                     for (int32_t k = 0; k < n.nargs; k++) {
                         out << "if (" << nn << ") {\n";

@@ -20,6 +20,7 @@ typedef unsigned char u8;
 
 typedef i32 pa_i32x4 __attribute__((ext_vector_type(4)));
 typedef double pa_f64x2 __attribute__((ext_vector_type(2)));
+typedef float pa_f32x4 __attribute__((ext_vector_type(4)));
 typedef i64 pa_i64x2 __attribute__((ext_vector_type(2)));
 typedef u32 pa_u32x4 __attribute__((ext_vector_type(4)));
 

@@ -90,6 +90,7 @@ public:
             FilterChannel ch;
             ch.index = d->filter_channels[i];
             PA_REQUIRE(ch.index >= 0 && ch.index < (int)types_.size(), PA_ERR_INVALID_ARGUMENT, "filter channel out of range");
+            PA_REQUIRE(types_[(size_t)ch.index] != PA_REAL, PA_ERR_NOT_SUPPORTED, "REAL dynamic-filter channels are not on the device path");
             ch.type = types_[ch.index];
             needed_[ch.index] = true;
             // :188 -- orderable and not floating point

@@ -161,6 +161,7 @@ FpKernelInfo generate_fp(const FpSpec& s, const std::vector<ChannelLayout>& layo
                 case PA_INTEGER:
                 case PA_DATE: ct = "i32"; val = "(i32)" + val; break;
                 case PA_DOUBLE: ct = "double"; break;
+                case PA_REAL: ct = "float"; break;
                 case PA_BOOLEAN: ct = "u8"; val = "(" + val + " ? (u8)1 : (u8)0)"; break;
                 default: throw Error(PA_ERR_NOT_SUPPORTED, "projection type not supported on device");
             }

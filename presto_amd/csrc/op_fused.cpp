@@ -347,7 +347,7 @@ Spec make_spec(const pa_filter_project_desc& fp, const pa_hash_aggregation_desc&
         else if (a.fn != PA_AGG_COUNT_STAR) {
             int32_t t = s.proj[a.input_channel].root_type();
             const bool min_max = a.fn == PA_AGG_MIN || a.fn == PA_AGG_MAX;
-            PA_REQUIRE(a.fn == PA_AGG_COUNT || t == PA_DOUBLE || t == PA_BIGINT || t == PA_INTEGER || (min_max && (t == PA_DATE || t == PA_BOOLEAN || t == PA_VARCHAR)),
+            PA_REQUIRE(a.fn == PA_AGG_COUNT || t == PA_DOUBLE || t == PA_REAL || t == PA_BIGINT || t == PA_INTEGER || (min_max && (t == PA_DATE || t == PA_BOOLEAN || t == PA_VARCHAR)),
                        PA_ERR_NOT_SUPPORTED, "aggregate input type not supported on device");
         }
         s.aggs.push_back(a);
@@ -627,6 +627,7 @@ KernelInfo generate(const Spec& s, const std::vector<ChannelLayout>& layout, int
             case PA_INTEGER:
             case PA_DATE: img = "pa_img_i64((i64)" + x.v + ")"; break;
             case PA_DOUBLE: img = "pa_img_f64(" + x.v + ")"; break;
+            case PA_REAL: img = "pa_img_f64((double)" + x.v + ")"; break;  // (float order = order of the widened values)
             case PA_BOOLEAN: img = "(" + x.v + " ? 1ULL : 0ULL)"; break;
             case PA_VARCHAR: img = "pa_img_str7(" + x.v + ", " + x.len + ", a.err)"; break;
             default: throw Error(PA_ERR_NOT_SUPPORTED, "min/max input type not supported on device");
@@ -681,7 +682,9 @@ KernelInfo generate(const Spec& s, const std::vector<ChannelLayout>& layout, int
                                     (ag.fn == PA_AGG_SUM || ag.fn == PA_AGG_MIN || ag.fn == PA_AGG_MAX);
         int cw = implicit_count ? -1 : word(W_CNT, ccond, "1", cntkey);
         int vw = -1;
-        if (ag.fn == PA_AGG_SUM && x.type != PA_DOUBLE) {
+        // (REAL inputs: RealSumAggregation / RealAverageAggregation keep a DOUBLE sum of the widened floats -- the same accumulator
+        // words as for DOUBLE; the output functions narrow the result)
+        if (ag.fn == PA_AGG_SUM && x.type != PA_DOUBLE && x.type != PA_REAL) {
             vw = word(W_SUMI, ccond, x.v, "sumi|" + xkey + "|" + ckey);
         }
         else if (ag.fn == PA_AGG_SUM || ag.fn == PA_AGG_AVG) {
@@ -2994,7 +2997,9 @@ bool FusedAggregationOperator::emit_on_device(const KernelInfo& ki, int64_t grou
             continue;
         }
         const bool as_double = ag.fn == PA_AGG_AVG || (ag.fn == PA_AGG_SUM && value_is_double);
-        const int type = as_double ? PA_DOUBLE : ((ag.fn == PA_AGG_SUM) ? spec_.proj[value_proj].root_type() : PA_BIGINT);
+        // sum / avg over REAL narrow their DOUBLE state on output (RealSumAggregation.output, RealAverageAggregation.output)
+        const bool real_out = as_double && (ag.input_type == PA_REAL || spec_.proj[value_proj].root_type() == PA_REAL);
+        const int type = real_out ? PA_REAL : (as_double ? PA_DOUBLE : ((ag.fn == PA_AGG_SUM) ? spec_.proj[value_proj].root_type() : PA_BIGINT));
         const int kind = ag.fn == PA_AGG_SUM ? GT_EMIT_SUM : (ag.fn == PA_AGG_AVG ? GT_EMIT_AVG : GT_EMIT_COUNT);
         if (ag.fn != PA_AGG_SUM && ag.fn != PA_AGG_AVG && ag.fn != PA_AGG_COUNT && ag.fn != PA_AGG_COUNT_STAR) return false;
         GtEmitCol* c = add(kind, type);
@@ -3320,9 +3325,16 @@ void FusedAggregationOperator::build_output()
                 }
                 uint64_t img = ag.fn == PA_AGG_MIN ? ~ww[vw] : ww[vw];
                 uint64_t bits;
-                if (oc.type == PA_DOUBLE) bits = (img >> 63) ? (img & 0x7fffffffffffffffULL) : ~img;
+                if (oc.type == PA_DOUBLE || oc.type == PA_REAL) bits = (img >> 63) ? (img & 0x7fffffffffffffffULL) : ~img;
                 else if (oc.type == PA_BOOLEAN) bits = img;
                 else bits = img ^ 0x8000000000000000ULL;
+                if (oc.type == PA_REAL) {  // the image is the widened value's
+                    double d;
+                    memcpy(&d, &bits, 8);
+                    const float f = (float)d;
+                    memcpy(&data[(size_t)g * width], &f, 4);
+                    continue;
+                }
                 memcpy(&data[(size_t)g * width], &bits, (size_t)width);  // little endian: the low bytes are the narrower value
             }
             oc.has_nulls = any_null;
@@ -3350,7 +3362,8 @@ void FusedAggregationOperator::build_output()
         OutColumn& oc = out_cols_[col];
         bool as_double = ag.fn == PA_AGG_AVG || (ag.fn == PA_AGG_SUM && value_is_double);
         const int value_proj = spec_.step == PA_STEP_FINAL ? ag.input_channel + 1 : ag.input_channel;
-        oc.type = as_double ? PA_DOUBLE : ((ag.fn == PA_AGG_SUM) ? spec_.proj[value_proj].root_type() : PA_BIGINT);
+        const bool real_out = as_double && (ag.input_type == PA_REAL || spec_.proj[value_proj].root_type() == PA_REAL);
+        oc.type = real_out ? PA_REAL : (as_double ? PA_DOUBLE : ((ag.fn == PA_AGG_SUM) ? spec_.proj[value_proj].root_type() : PA_BIGINT));
         auto& data = host_cols[col];
         auto& nulls = host_nulls[col];
         nulls.assign(groups ? groups : 1, 0);
@@ -3383,6 +3396,12 @@ void FusedAggregationOperator::build_output()
                     break;
             }
             if (width == 8) memcpy(&data[(size_t)g * 8], &bits, 8);
+            else if (real_out) {  // (float) of the DOUBLE sum / average
+                double d;
+                memcpy(&d, &bits, 8);
+                const float f = (float)d;
+                memcpy(&data[(size_t)g * 4], &f, 4);
+            }
             else {
                 int32_t v = (int32_t)(int64_t)bits;
                 memcpy(&data[(size_t)g * 4], &v, 4);

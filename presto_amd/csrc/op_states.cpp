@@ -248,6 +248,11 @@ pa_operator* make_aggregation_with_reference_states(const pa_hash_aggregation_de
     std::vector<int32_t> types;
     std::vector<int32_t> group_by;
     std::vector<pa_aggregate> aggs(agg->aggregates, agg->aggregates + agg->aggregate_count);
+    for (const pa_aggregate& a : aggs) {
+        // (RealSumAggregation keeps a NullableDoubleState, RealAverageAggregation a LongState + DoubleState pair: other serialized
+        // forms than the DOUBLE aggregates' -- not translated here)
+        PA_REQUIRE(a.input_type != PA_REAL, PA_ERR_NOT_SUPPORTED, "reference-format states of aggregates over REAL are not on the device path");
+    }
     if (agg->step == PA_STEP_PARTIAL) {
         // input is raw rows: nothing to translate; the shapes come from the aggregates' input types
         for (const pa_aggregate& a : aggs) {

@@ -32,7 +32,8 @@ const char* encoding_name(int32_t type)
         case PA_BIGINT:
         case PA_DOUBLE: return "LONG_ARRAY";   // DoubleType stores doubleToLongBits in a LongArrayBlock (DoubleType.java:98-108)
         case PA_INTEGER:
-        case PA_DATE: return "INT_ARRAY";
+        case PA_DATE:
+        case PA_REAL: return "INT_ARRAY";      // RealType stores floatToRawIntBits in an IntArrayBlock (RealType.java)
         case PA_BOOLEAN: return "BYTE_ARRAY";
         case PA_VARCHAR: return "VARIABLE_WIDTH";
         default: throw Error(PA_ERR_NOT_SUPPORTED, "block type has no wire encoding here");
@@ -316,8 +317,8 @@ pa_page_buffer* deserialize_page(const void* bytes, int64_t size, hipStream_t s,
             width = 8;
         }
         else if (name == "INT_ARRAY") {
-            PA_REQUIRE(want < 0 || want == PA_INTEGER || want == PA_DATE, PA_ERR_INVALID_ARGUMENT, "INT_ARRAY block for a channel declared otherwise");
-            oc.type = want == PA_DATE ? PA_DATE : PA_INTEGER;
+            PA_REQUIRE(want < 0 || want == PA_INTEGER || want == PA_DATE || want == PA_REAL, PA_ERR_INVALID_ARGUMENT, "INT_ARRAY block for a channel declared otherwise");
+            oc.type = want == PA_DATE ? PA_DATE : (want == PA_REAL ? PA_REAL : PA_INTEGER);
             width = 4;
         }
         else if (name == "BYTE_ARRAY") {

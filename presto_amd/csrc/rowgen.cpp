@@ -69,6 +69,10 @@ void emit_vector_loads(const RowInputs& s, const std::vector<ChannelLayout>& lay
                 o << "        pa_i32x4 A" << C << " = ((const pa_i32x4*)a.v[" << C << "])[q];\n";
                 for (int r = 0; r < 4; r++) args[r] += ", (i64)A" + C + "." + xyzw[r];
                 break;
+            case PA_REAL:
+                o << "        pa_f32x4 A" << C << " = ((const pa_f32x4*)a.v[" << C << "])[q];\n";
+                for (int r = 0; r < 4; r++) args[r] += ", A" + C + "." + xyzw[r];
+                break;
             case PA_BOOLEAN:
                 o << "        u32 A" << C << " = ((const u32*)a.v[" << C << "])[q];\n";
                 for (int r = 0; r < 4; r++) args[r] += ", ((A" + C + " >> " + std::to_string(8 * r) + ") & 0xffu) != 0u";
@@ -129,6 +133,7 @@ std::string scalar_args(const RowInputs& s, const std::vector<ChannelLayout>& la
             case PA_DOUBLE: a += ", ((const double*)a.v[" + C + "])[r]"; break;
             case PA_INTEGER:
             case PA_DATE: a += ", (i64)((const i32*)a.v[" + C + "])[r]"; break;
+            case PA_REAL: a += ", ((const float*)a.v[" + C + "])[r]"; break;
             case PA_BOOLEAN: a += ", ((const u8*)a.v[" + C + "])[r] != 0"; break;
             case PA_VARCHAR:
                 a += ", (const u8*)a.v[" + C + "] + a.o[" + C + "][r], a.o[" + C + "][r + 1] - a.o[" + C + "][r]";

@@ -417,7 +417,10 @@ __device__ __forceinline__ void gt_emit_slot(const GtEmitArgs& a, u64 i, u64 g)
             case GT_EMIT_COUNT: bits = wd[(u64)col.cw * a.st.word + i * a.st.slot]; break;
             case GT_EMIT_SUM:
                 if (col.cw >= 0 && wd[(u64)col.cw * a.st.word + i * a.st.slot] == 0ULL) is_null = true;
-                else bits = wd[(u64)col.vw * a.st.word + i * a.st.slot];
+                else {
+                    bits = wd[(u64)col.vw * a.st.word + i * a.st.slot];
+                    if (col.type == PA_REAL) bits = (u64)__float_as_uint((float)__longlong_as_double((i64)bits));  // RealSumAggregation.output: (float) sum
+                }
                 break;
             case GT_EMIT_MINMAX: {
                 if (col.cw >= 0 && wd[(u64)col.cw * a.st.word + i * a.st.slot] == 0ULL) is_null = true;
@@ -425,6 +428,7 @@ __device__ __forceinline__ void gt_emit_slot(const GtEmitArgs& a, u64 i, u64 g)
                     u64 img = wd[(u64)col.vw * a.st.word + i * a.st.slot];
                     if (col.shift) img = ~img;  // min is kept as the maximum of the complement
                     if (col.type == PA_DOUBLE) bits = pa_unimg_f64_bits(img);
+                    else if (col.type == PA_REAL) bits = (u64)__float_as_uint((float)__longlong_as_double((i64)pa_unimg_f64_bits(img)));
                     else if (col.type == PA_BOOLEAN) bits = img;
                     else bits = (u64)pa_unimg_i64(img);
                 }
@@ -435,7 +439,7 @@ __device__ __forceinline__ void gt_emit_slot(const GtEmitArgs& a, u64 i, u64 g)
                 if (count == 0) is_null = true;
                 else {
                     double avg = __longlong_as_double((i64)wd[(u64)col.vw * a.st.word + i * a.st.slot]) / (double)count;
-                    bits = (u64)__double_as_longlong(avg);
+                    bits = col.type == PA_REAL ? (u64)__float_as_uint((float)avg) : (u64)__double_as_longlong(avg);
                 }
                 break;
             }

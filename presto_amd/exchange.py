@@ -220,9 +220,10 @@ def partial_layout(key_types, aggregates):
         first = len(types)
         types.append(abi.BIGINT)
         if fn in (abi.AGG_SUM, abi.AGG_AVG):
-            value_type = abi.DOUBLE if (fn == abi.AGG_AVG or in_type == abi.DOUBLE) else abi.BIGINT
+            value_type = abi.DOUBLE if (fn == abi.AGG_AVG or in_type in (abi.DOUBLE, abi.REAL)) else abi.BIGINT
             types.append(value_type)
-            final.append((fn, first, value_type))
+            # (sum / avg over REAL: a DOUBLE state; the FINAL step narrows its result, so it keeps the input type)
+            final.append((fn, first, abi.REAL if in_type == abi.REAL else value_type))
         elif fn in (abi.AGG_MIN, abi.AGG_MAX):
             types.append(in_type)  # [count, value of the input type]
             final.append((fn, first, in_type))

@@ -100,7 +100,7 @@ def serialize(expr):
         n.first_arg = len(args)
         args.extend(child_ids)
         if e.kind == abi.EXPR_CONSTANT and not e.is_null:
-            if e.type == abi.DOUBLE:
+            if e.type in (abi.DOUBLE, abi.REAL):  # a REAL constant travels as the double it converts to exactly
                 n.f64 = float(e.value)
             elif e.type == abi.VARCHAR:
                 buf = C.create_string_buffer(bytes(e.value), max(len(e.value), 1))

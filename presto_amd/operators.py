@@ -767,6 +767,6 @@ def download_page(page):
             blocks.append(Block(b.type, abi.VARWIDTH, n, values=vals, offsets=off, nulls=nulls))
         else:
             dt = {abi.BIGINT: np.int64, abi.INTEGER: np.int32, abi.DATE: np.int32, abi.DOUBLE: np.float64,
-                  abi.BOOLEAN: np.uint8}[b.type]
+                  abi.BOOLEAN: np.uint8, abi.REAL: np.float32}[b.type]
             blocks.append(Block(b.type, abi.FLAT, n, values=download(b.values, dt, n), nulls=nulls))
     return Page(blocks, n, abi.MEM_HOST)

@@ -13,7 +13,7 @@ import numpy as np
 from . import abi
 
 _NP_DTYPE = {abi.BIGINT: np.int64, abi.INTEGER: np.int32, abi.DATE: np.int32, abi.DOUBLE: np.float64,
-             abi.BOOLEAN: np.uint8}
+             abi.BOOLEAN: np.uint8, abi.REAL: np.float32}
 
 
 class DeviceBuffer:
@@ -77,6 +77,11 @@ class Block:
     @staticmethod
     def double(values, nulls=None):
         return Block.flat(abi.DOUBLE, values, nulls)
+
+    @staticmethod
+    def real(values, nulls=None):
+        """RealType: IEEE single values (the IntArrayBlock of their raw bits); to_pylist gives them as Python floats."""
+        return Block.flat(abi.REAL, values, nulls)
 
     @staticmethod
     def boolean(values, nulls=None):

@@ -173,6 +173,13 @@ def test_header_is_plain_c():
         assert len(names) > 40
 
 
+def test_java_side_expects_this_abi_version():
+    """GpuNative.java checks pa_abi_version against the version it was written for: keep the two in step."""
+    import re
+    text = open(os.path.join(ROOT, "java", "io", "trino", "gpu", "GpuNative.java")).read()
+    assert [int(v) for v in re.findall(r"abiVersion\(\) != (\d+)", text)] == [abi.ABI_VERSION]
+
+
 def test_jni_shim_compiles_against_the_header_and_matches_the_java_natives():
     """The JVM side (jni/presto_amd_jni.c, java/io/trino/gpu/*.java) cannot be built in this image (no JDK); what can drift
     silently is the shim against include/presto_amd.h and the Java `native` declarations against the shim's exports.  The C

@@ -398,3 +398,30 @@ def test_join_output_single_match_kat(oracle):
     j.build()
     out, pi, bi = j.probe(Page([Block.varchar([b"a", b"b", b"c"])], 3), [abi.VARCHAR], [0], [0], output_single_match=True)
     assert out.to_rows() == [(b"a", b"a"), (b"b", b"b")] and pi.tolist() == [0, 1]
+
+
+def test_real_type_hand_computed(oracle):
+    """RealType / RealOperators / RealSumAggregation / RealAverageAggregation restated: values are IEEE singles, arithmetic is Java
+    float arithmetic (0.1f + 0.2f = 0.3f rounded in single precision, 1e8f + 1f = 1e8f), sums accumulate the widened values in
+    double and narrow on output, avg = (float)(double sum / count).  Expected values computed with numpy float32 / float64."""
+    import numpy as np
+    from presto_amd.expr import constant, field
+    from presto_amd.page import Block, Page
+    F = np.float32
+    page = Page([Block.real([F(0.1), F(1e8), F(3.0), F(-2.5)], [0, 0, 1, 0]), Block.real([F(0.2), F(1.0), F(1.0), F(4.0)])], 4)
+    a, b = field(0, abi.REAL), field(1, abi.REAL)
+    out = oracle.filter_project(page, b < constant(3.5, abi.REAL), [a + b, a * b, a / b, a % b, -a, a.cast(abi.DOUBLE), constant(16777217, abi.BIGINT).cast(abi.REAL)])
+    assert out.to_rows() == [
+        (float(F(0.1) + F(0.2)), float(F(0.1) * F(0.2)), float(F(0.1) / F(0.2)), float(np.fmod(F(0.1), F(0.2))), float(-F(0.1)), float(F(0.1)), 16777216.0),
+        (100000000.0, 100000000.0, 100000000.0, 0.0, -100000000.0, 100000000.0, 16777216.0),
+        (None, None, None, None, None, None, 16777216.0)]
+    assert [blk.type for blk in out.blocks] == [abi.REAL] * 5 + [abi.DOUBLE, abi.REAL]
+    agg = oracle.HashAggregation([abi.REAL, abi.REAL], [], [(abi.AGG_SUM, 0, abi.REAL), (abi.AGG_AVG, 1, abi.REAL), (abi.AGG_MIN, 0, abi.REAL), (abi.AGG_MAX, 0, abi.REAL),
+                                                            (abi.AGG_COUNT, 0, abi.REAL)])
+    agg.add_page(page)
+    dsum = float(F(0.1)) + 1e8 + float(F(-2.5))                       # the double state of RealSumAggregation
+    davg = (float(F(0.2)) + 1.0 + 1.0 + 4.0) / 4
+    assert agg.build_result().to_rows() == [(float(F(dsum)), float(F(davg)), -2.5, 100000000.0, 3)]
+    # the wire format carries the raw bits as INT_ARRAY
+    frame = oracle.serialize_page(page)
+    assert b"INT_ARRAY" in frame and oracle.deserialize_page(frame).position_count == 4
