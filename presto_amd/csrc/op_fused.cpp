@@ -29,6 +29,7 @@
 #include <algorithm>
 #include <cmath>
 #include <deque>
+#include <functional>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -852,20 +853,56 @@ KernelInfo generate(const Spec& s, const std::vector<ChannelLayout>& layout, int
         src << "    acc.ev[p] = false;\n  }\n}\n";
         // the buffered rows of the wave -> table; the issuing lanes are the ACTIVE ones, by rank (lanes that have left the row
         // loop contribute nothing and issue nothing)
+        // A drain goes out SORTED by build position, one entry per build row: the wave sorts (build position, entry) keys in LDS
+        // (bitonic, 28 steps for 128 keys), the first entry of every run of equal positions takes its followers' values along,
+        // and only those leaders touch the table.  Memory-side atomics of one instruction share 64-byte requests when their
+        // addresses are neighbours -- and never when two lanes name the same address (an order whose rows two lanes hold).
+        auto emit_issue = [&](const std::string& ind, const std::string& g, const std::string& f, const std::function<std::string(int)>& val) {
+            if (k.occ_word < 0) src << ind << "acc.tv.tag[" << g << "] = 3ULL;\n";
+            for (int w = 0; w < k.nw; w++) {
+                const std::string W = std::to_string(w), idx = W + "ULL * cap + " + g, v = val(w);
+                src << ind << "if (" << f << " & " << (1u << w) << "u) ";
+                if (words[w].kind == W_SUMF) src << "pa_gt_add_f64(acc.tv.words, " << idx << ", __longlong_as_double((i64)" << v << ")" << (w == k.occ_word ? " + 0.0" : "") << ");\n";
+                else if (words[w].kind == W_SUMI) src << "pa_gt_add_i64_exact(acc.tv.words, " << idx << ", (i64)" << v << ", a.err);\n";
+                else if (words[w].kind == W_MAXU) src << "pa_gt_max_u64(acc.tv.words, " << idx << ", " << v << ");\n";
+                else src << "pa_gt_add_u64(acc.tv.words, " << idx << ", " << v << ");\n";
+            }
+        };
+        src << "__shared__ u64 pa_sk[" << waves << "][PA_BCAP];\n";
         src << "__device__ __forceinline__ void pa_drain(const PaFusedArgs& a, PaAcc& acc, const u32 fill)\n{\n"
                "  const u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;\n"
                "  const u64 act = __ballot(true);\n  const u32 nact = (u32)__popcll(act), rank = (u32)__popcll(act & ((1ULL << lane) - 1ULL));\n"
                "  const u64 cap = (u64)a.gt_mask + 1ULL;\n"
-               "  for (u32 i = rank; i < fill; i += nact) {\n    const u64 g = pa_sg[wave][i];\n    const u32 f = pa_su[wave][i];\n"
-            << (k.occ_word < 0 ? "    acc.tv.tag[g] = 3ULL;\n" : "");
+               "  if (fill == 0u) return;\n"
+               "  if (nact == 64u) {\n"
+               "    u64* sk = pa_sk[wave];\n"
+               "    for (u32 i = lane; i < PA_BCAP; i += 64u) sk[i] = i < fill ? (((u64)pa_sg[wave][i] << 32) | (u64)i) : ~0ULL;\n"
+               "    PA_WAVE_SYNC();\n"
+               "    for (u32 kk = 2u; kk <= PA_BCAP; kk <<= 1) {\n      for (u32 j = kk >> 1; j > 0u; j >>= 1) {\n"
+               "#pragma unroll\n        for (u32 h = 0; h < PA_BCAP / 64u; h++) {\n          const u32 i = lane + 64u * h, p = i ^ j;\n"
+               "          if (p > i) {\n            const u64 x = sk[i], y = sk[p];\n            if ((x > y) == ((i & kk) == 0u)) { sk[i] = y; sk[p] = x; }\n          }\n        }\n"
+               "        PA_WAVE_SYNC();\n      }\n    }\n"
+               "    for (u32 p = lane; p < fill; p += 64u) {\n      const u64 kx = sk[p];\n      const u32 gk = (u32)(kx >> 32);\n"
+               "      if (p > 0u && (u32)(sk[p - 1u] >> 32) == gk) continue;  // a follower: its leader takes it along\n"
+               "      u32 f = 0u;\n";
+        for (int w = 0; w < k.nw; w++) src << "      u64 v" << w << " = 0ULL;\n";
+        src << "      for (u32 q = p; q < fill; q++) {\n        const u64 kq = sk[q];\n        if ((u32)(kq >> 32) != gk) break;\n"
+               "        const u32 e = (u32)kq, fe = pa_su[wave][e];\n";
         for (int w = 0; w < k.nw; w++) {
-            const std::string W = std::to_string(w), idx = W + "ULL * cap + g", v = "pa_sx[wave][" + W + "][i]";
-            src << "    if (f & " << (1u << w) << "u) ";
-            if (words[w].kind == W_SUMF) src << "pa_gt_add_f64(acc.tv.words, " << idx << ", __longlong_as_double((i64)" << v << ")" << (w == k.occ_word ? " + 0.0" : "") << ");\n";
-            else if (words[w].kind == W_SUMI) src << "pa_gt_add_i64_exact(acc.tv.words, " << idx << ", (i64)" << v << ", a.err);\n";
-            else if (words[w].kind == W_MAXU) src << "pa_gt_max_u64(acc.tv.words, " << idx << ", " << v << ");\n";
-            else src << "pa_gt_add_u64(acc.tv.words, " << idx << ", " << v << ");\n";
+            const std::string W = std::to_string(w), V = "v" + W, X = "pa_sx[wave][" + W + "][e]", bit = std::to_string(1u << w) + "u";
+            std::string comb;
+            if (words[w].kind == W_SUMF) comb = "(u64)__double_as_longlong(__longlong_as_double((i64)" + V + ") + __longlong_as_double((i64)" + X + "))";
+            else if (words[w].kind == W_SUMI) comb = "(u64)pa_add_exact((i64)" + V + ", (i64)" + X + ", a.err)";
+            else if (words[w].kind == W_MAXU) comb = "(" + X + " > " + V + " ? " + X + " : " + V + ")";
+            else comb = V + " + " + X;
+            src << "        if (fe & " << bit << ") " << V << " = (f & " << bit << ") ? " << comb << " : " << X << ";\n";
         }
+        src << "        f |= fe;\n      }\n      const u64 g = (u64)gk;\n";
+        emit_issue("      ", "g", "f", [](int w) { return "v" + std::to_string(w); });
+        src << "    }\n    PA_WAVE_SYNC();\n    return;\n  }\n"
+               // (some lanes have left the row loop: the last wave of the grid) entry by entry, the issuing lanes by rank
+               "  for (u32 i = rank; i < fill; i += nact) {\n    const u64 g = pa_sg[wave][i];\n    const u32 f = pa_su[wave][i];\n";
+        emit_issue("    ", "g", "f", [](int w) { return "pa_sx[wave][" + std::to_string(w) + "][i]"; });
         src << "  }\n  PA_WAVE_SYNC();\n}\n";
         // end of a quad: the wave's noted rows are appended (positions by ballot, slot by slot), draining whenever the buffer is full
         src << "__device__ __forceinline__ void pa_flush(const PaFusedArgs& a, PaAcc& acc, const bool)\n{\n"
