@@ -1374,17 +1374,19 @@ KernelInfo generate(const Spec& s, const std::vector<ChannelLayout>& layout, int
         // build columns (the probe join key equals the build key column on every match)
         src << "extern \"C\" __global__ __launch_bounds__(256) void pa_brow_keys(PaFusedArgs a)\n{\n"
                "    const i64 cap = (i64)a.gt_mask + 1;\n"
+               "    i64 found = 0;\n"
                "    for (i64 b = (i64)blockIdx.x * 256 + threadIdx.x; b < cap; b += (i64)gridDim.x * 256) {\n"
             << (k.occ_word < 0 ? std::string("        if (a.gt_tag[b] == 0ULL) continue;\n")
                                : "        if (a.gt_words[" + std::to_string(k.occ_word) + "ULL * (u64)cap + (u64)b] == " + std::to_string(k.occ_empty) + "ULL) continue;\n")
-            << "        const i32 jb = (i32)b;\n";
+            << "        found++;\n        const i32 jb = (i32)b;\n";
         src << build_loads.str() << key_os.str();
         for (int i = 0; i < k.w; i++) {
             src << "        a.gt_keys[(u64)b * PA_TW + " << i << "] = ";
             for (size_t t = 0; t < word_terms[i].size(); t++) src << (t ? " | " : "") << word_terms[i][t];
             src << ";\n";
         }
-        src << "    }\n}\n\n";
+        // (the groups are counted on the way: one atomic per wave on the table's group counter)
+        src << "    }\n    found = pa_wave_sum_i64(found);\n    if ((threadIdx.x & 63) == 0 && found != 0) atomicAdd(a.gt_count, (i32)found);\n}\n\n";
     }
     k.source = src.str();
     return k;
@@ -2804,7 +2806,6 @@ private:
     bool join_checked_ = false;  // probe stage: the lookup source was looked at (first page)
     bool build_rows_table_ = false;  // the group table is indexed by build position (BROW)
     const Compiled* brow_keys_ = nullptr;  // its pa_brow_keys kernel
-    DevBuf brow_count_;
     int brow_occ_word_ = -1;       // KernelInfo::occ_word / occ_empty of the table
     uint64_t brow_occ_empty_ = 0;
     int64_t resume_from_ = -1;
@@ -3156,12 +3157,12 @@ void FusedAggregationOperator::build_output()
         if (build_rows_table_) {
             // build-row table: no kernel counted its groups, and its key words are still to be written -- once per group, from
             // the build columns (pa_brow_keys)
-            int64_t* cnt = static_cast<int64_t*>(brow_count_.ensure(8));
-            launch_count_nonzero_u64(table_tags(), (int64_t)gt_cap_, (int64_t)table_strides().tag, table_strides().empty, cnt, s);
             FusedArgs a;
             memset(&a, 0, sizeof a);
             fill_join_args(a);
             a.err = ctl_;
+            a.gt_count = ctl_ + 1;
+            PA_HIP(hipMemsetAsync(ctl_ + 1, 0, 4, s));
             a.gt_tag = gt_tag_.as<uint64_t>();
             a.gt_keys = gt_keys_.as<uint64_t>();
             a.gt_words = gt_words_.as<uint64_t>();
@@ -3169,12 +3170,9 @@ void FusedAggregationOperator::build_output()
             void* params[] = {&a};
             const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(((int64_t)gt_cap_ + 255) / 256, (int64_t)cus_ * 8));
             PA_HIP(hipModuleLaunchKernel(brow_keys_->tail_kernel.fn, grid, 1, 1, 256, 1, 1, 0, s, params, nullptr));
-            int64_t found = 0;
-            PA_HIP(hipMemcpyAsync(&found, cnt, 8, hipMemcpyDeviceToHost, s));
             PA_HIP(hipMemcpyAsync(h_ctl_, ctl_, 32, hipMemcpyDeviceToHost, s));
             PA_HIP(hipStreamSynchronize(s));
             raise_if(h_ctl_[0]);
-            h_ctl_[1] = (int32_t)found;
         }
         groups = h_ctl_[1];
         if (emit_on_device(ki, groups)) return;

@@ -139,6 +139,40 @@ def test_large_build_side_is_built_in_partitions(gpu, oracle, key_type, duplicat
             assert np.array_equal(gp, op_) and np.array_equal(gb, ob)
 
 
+def test_partitioned_build_with_an_overfull_partition_falls_back(gpu, oracle):
+    """Keys chosen so that more of them have their home slot in ONE 8192-slot partition than the partition may hold: the build
+    notices (no slot is dropped, nothing overflows the LDS table) and assembles the table slot by slot instead."""
+    P1, P2 = np.uint64(0x9E3779B185EBCA87), np.uint64(0xC2B2AE3D27D4EB4F)
+
+    def home(keys, mask):   # AbstractLongType.hash + fastutil murmurHash3 (pa_hash_bigint, pa_murmur3_fmix)
+        with np.errstate(over="ignore"):
+            h = keys.astype(np.uint64) * P2
+            h = ((h << np.uint64(31)) | (h >> np.uint64(33))) * P1
+            h ^= h >> np.uint64(33)
+            h *= np.uint64(0xff51afd7ed558ccd)
+            h ^= h >> np.uint64(33)
+            h *= np.uint64(0xc4ceb9fe1a85ec53)
+            h ^= h >> np.uint64(33)
+        return h & np.uint64(mask)
+
+    nb = (1 << 20) + 5000
+    slots = 1 << 22                                   # the probe-side table of nb rows: >= 2 nb slots, a power of two
+    cand = np.arange(1, 6_000_000, dtype=np.int64)
+    in_first = cand[home(cand, slots - 1) < np.uint64(8192)]
+    assert len(in_first) > 7800                        # > 7/8 of a partition's 8192 slots
+    rest = cand[home(cand, slots - 1) >= np.uint64(8192)][: nb - len(in_first)]
+    keys = np.concatenate([in_first, rest])
+    rng = np.random.default_rng(2)
+    keys = keys[rng.permutation(len(keys))]
+    build = [Page([Block.bigint(keys), Block.integer(np.arange(len(keys)))], len(keys))]
+    pk = np.concatenate([in_first[:5000], rng.integers(1, 7_000_000, 100000)]).astype(np.int64)
+    probe = [Page([Block.bigint(pk), Block.integer(np.arange(len(pk)))], len(pk))]
+    types = [abi.BIGINT, abi.INTEGER]
+    rows, pairs, _ = gpu_join(build, types, [0], [1], probe, types, [0], [0, 1])
+    orows, opairs, _ = oracle_join(oracle, build, types, [0], [1], probe, types, [0], [0, 1])
+    assert rows == orows and len(rows) > 5000
+
+
 def test_multi_channel_keys_with_varchar_and_double(gpu, oracle):
     rng = np.random.default_rng(9)
     nb, npr = 4001, 9001
