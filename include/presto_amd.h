@@ -334,6 +334,19 @@ typedef struct pa_fused_join_aggregation_desc {
     pa_hash_aggregation_desc aggregation;   /* input_* fields describe the join's output page */
 } pa_fused_join_aggregation_desc;
 
+/* Fused pipeline: [Scan]FilterAndProject -> LookupJoinOperator, the probe side of a join whose output feeds further operators (TPC-H
+ * Q3's orders pipeline: orders JOIN customer -> the next build side).  Semantically the composition of the two descriptors (the
+ * join's probe page is the projection output); under the same condition as pa_fused_join_aggregation_desc -- one BIGINT / INTEGER /
+ * DATE key, no duplicate keys on the build side -- filter and probe select the rows in one pass over the page, and the second pass
+ * writes the join's output page [probe output channels, build output channels] directly: no FilterAndProject page, no position
+ * lists, no gathers.  In every other case the handle runs the two device operators behind each other.  Output rows come in probe
+ * order either way.  join.join_type must be PA_JOIN_INNER, join.filter NULL; filter_project.output_mem is ignored, join.output_mem
+ * is where the output page lives; the MergePages thresholds of filter_project apply to the joined output. */
+typedef struct pa_fused_join_desc {
+    pa_filter_project_desc filter_project;
+    pa_lookup_join_desc join;
+} pa_fused_join_desc;
+
 /* TopNOperator.createOperatorFactory (TopNOperator.java:43-90): keep the n best rows under (sort_channels, sort_orders)
  * and emit them, ordered, as one page after finish.  Ties between fully equal sort keys come out in arrival order (the
  * reference leaves their order unspecified). */
@@ -458,6 +471,7 @@ int32_t pa_hash_aggregation_create(const pa_hash_aggregation_desc* desc, pa_oper
 int32_t pa_fused_aggregation_create(const pa_fused_aggregation_desc* desc, pa_operator** out);
 /* `bridge` must already have its build operator (as for pa_lookup_join_create); pa_op_is_blocked is 1 until the build finished. */
 int32_t pa_fused_join_aggregation_create(const pa_fused_join_aggregation_desc* desc, pa_lookup_source* bridge, pa_operator** out);
+int32_t pa_fused_join_create(const pa_fused_join_desc* desc, pa_lookup_source* bridge, pa_operator** out);
 int32_t pa_topn_create(const pa_topn_desc* desc, pa_operator** out);
 int32_t pa_order_by_create(const pa_order_by_desc* desc, pa_operator** out);
 /* The dynamic filter of an INNER (or lookup-outer) join applied where Trino applies it -- in the scan / filter upstream of the

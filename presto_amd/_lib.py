@@ -57,6 +57,7 @@ def lib():
     L.pa_hash_builder_create.argtypes = [C.POINTER(abi.pa_hash_builder_desc), vp, C.POINTER(vp)]
     L.pa_lookup_join_create.argtypes = [C.POINTER(abi.pa_lookup_join_desc), vp, C.POINTER(vp)]
     L.pa_fused_join_aggregation_create.argtypes = [C.POINTER(abi.pa_fused_join_aggregation_desc), vp, C.POINTER(vp)]
+    L.pa_fused_join_create.argtypes = [C.POINTER(abi.pa_fused_join_desc), vp, C.POINTER(vp)]
     L.pa_codegen_fused_join.argtypes = [C.POINTER(abi.pa_fused_join_aggregation_desc), C.POINTER(abi.pa_hash_builder_desc), C.c_int32, C.c_char_p, C.c_int64]
     L.pa_codegen_fused_join.restype = C.c_int64
     L.pa_codegen_compile_fused_join.argtypes = [C.POINTER(abi.pa_fused_join_aggregation_desc), C.POINTER(abi.pa_hash_builder_desc), C.c_int32]

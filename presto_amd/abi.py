@@ -263,6 +263,13 @@ class pa_lookup_join_desc(C.Structure):
     ]
 
 
+class pa_fused_join_desc(C.Structure):
+    _fields_ = [
+        ("filter_project", pa_filter_project_desc),
+        ("join", pa_lookup_join_desc),
+    ]
+
+
 class pa_fused_join_aggregation_desc(C.Structure):
     _fields_ = [
         ("filter_project", pa_filter_project_desc),

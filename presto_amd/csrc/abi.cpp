@@ -318,6 +318,15 @@ int32_t pa_hash_aggregation_create(const pa_hash_aggregation_desc* desc, pa_oper
     return guarded([&]() -> int32_t { return create_plain_aggregation(desc, out); });
 }
 
+int32_t pa_fused_join_create(const pa_fused_join_desc* desc, pa_lookup_source* bridge, pa_operator** out)
+{
+    return guarded([&]() -> int32_t {
+        PA_REQUIRE(desc != nullptr && out != nullptr && bridge != nullptr, PA_ERR_INVALID_ARGUMENT, "null argument");
+        *out = make_fused_join(desc, bridge);
+        return PA_OK;
+    });
+}
+
 int32_t pa_fused_join_aggregation_create(const pa_fused_join_aggregation_desc* desc, pa_lookup_source* bridge, pa_operator** out)
 {
     return guarded([&]() -> int32_t {

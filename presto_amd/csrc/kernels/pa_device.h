@@ -343,7 +343,9 @@ struct PaFusedArgs {
 // PagesHash.getAddressIndex, PagesHash.java:158-170): the build position of key `v`, or -1.  Same walk as
 // k_join_probe_count_keyed (join_kernels.hip): bitmap first -- most probe rows of a selective join miss, and a clustered probe
 // side reads the bitmap almost sequentially -- then linear probing over 64-byte lines of four slots.
-__device__ __forceinline__ i32 pa_join_probe_from(const PaFusedArgs& a, const u64 v, u32 pos)
+// (A = PaFusedArgs or PaFpArgs: both carry the probe-side table as jslots / jmask / jwrap / jbits / jmin / jrange)
+template <class A>
+__device__ __forceinline__ i32 pa_join_probe_from(const A& a, const u64 v, u32 pos)
 {
     const pa_u32x4* lines = (const pa_u32x4*)a.jslots;
     for (u32 seen = 0; seen <= a.jwrap;) {
@@ -363,8 +365,10 @@ __device__ __forceinline__ i32 pa_join_probe_from(const PaFusedArgs& a, const u6
     }
     return -1;
 }
-__device__ __forceinline__ u32 pa_join_home(const PaFusedArgs& a, const u64 v) { return (u32)pa_murmur3_fmix((u64)pa_hash_bigint((i64)v)) & a.jmask; }
-__device__ __forceinline__ i32 pa_join_probe_keyed(const PaFusedArgs& a, const u64 v)
+template <class A>
+__device__ __forceinline__ u32 pa_join_home(const A& a, const u64 v) { return (u32)pa_murmur3_fmix((u64)pa_hash_bigint((i64)v)) & a.jmask; }
+template <class A>
+__device__ __forceinline__ i32 pa_join_probe_keyed(const A& a, const u64 v)
 {
     if (a.jbits) {
         const u64 d = (u64)((i64)v - a.jmin);
@@ -377,7 +381,8 @@ __device__ __forceinline__ i32 pa_join_probe_keyed(const PaFusedArgs& a, const u
 // (bitmap word, slot, then the columns only matches read), and a wave of the row loop is then bound by latency, not bandwidth:
 // Q3's lineitem pages ran at 1.7 ms per 2^28 rows that way, three times the time of the filter alone.  A key equal to its
 // predecessor's (a probe side clustered by the key) reuses the predecessor's answer.  s[r]: row r probes; k[r]: its key.
-__device__ __forceinline__ void pa_join_probe4(const PaFusedArgs& a, const bool (&s)[4], const u64 (&k)[4], i32 (&jb)[4])
+template <class A>
+__device__ __forceinline__ void pa_join_probe4(const A& a, const bool (&s)[4], const u64 (&k)[4], i32 (&jb)[4])
 {
     bool dup[4], need[4];
 #pragma unroll
@@ -708,6 +713,16 @@ struct PaFpArgs {
     const u64* dyn_bits;            // dynamic filter from a join's build side: existence bitmap over [dyn_min, dyn_min + dyn_range]
     i64 dyn_min;
     u64 dyn_range;
+    // probe stage (FilterAndProject -> LookupJoin in one pass, op_filter_project.cpp): the keyed probe-side table, its key bitmap,
+    // and the build columns the output carries, as in PaFusedArgs
+    const void* jslots;
+    const u64* jbits;
+    i64 jmin;
+    u64 jrange;
+    u32 jmask;
+    u32 jwrap;
+    const void* bv[PA_MAX_BUILD_CHANNELS];
+    const u8* bn[PA_MAX_BUILD_CHANNELS];
 };
 // can a probe row with this key match any build row?  (exact inside the bitmap's range; NULL keys never match)
 __device__ __forceinline__ bool pa_dyn_test(const PaFpArgs& a, const i64 key)

@@ -22,6 +22,7 @@
 
 #include "exprgen.hpp"
 #include "jit.hpp"
+#include "join_source.hpp"
 #include "operator.hpp"
 #include "rowgen.hpp"
 #include "scan_kernels.hpp"
@@ -30,6 +31,7 @@ namespace pa {
 namespace {
 
 constexpr int kMaxChannels = 32;
+constexpr int kMaxBuildChannels = 8;  // PA_MAX_BUILD_CHANNELS
 // A workgroup of 256 threads handles kTileQuads x 256 row quads.  More than one quad per thread (fewer, longer workgroups,
 // all loads in flight before the first block scan) was measured SLOWER on MI355X -- page -> page over 2^27 rows, 1 / 2 / 4 / 8
 // quads: Q6 filter 155 / 146 / 147 / 147 G rows/s, Q1 filter (96 % pass) 106 / 92 / 80 / 79 G, Q3 per step 27.8 / 28.5 / 29.1 /
@@ -61,9 +63,29 @@ struct FpArgs {  // host mirror of PaFpArgs
     const uint64_t* dyn_bits;
     int64_t dyn_min;
     uint64_t dyn_range;
+    const void* jslots;
+    const uint64_t* jbits;
+    int64_t jmin;
+    uint64_t jrange;
+    uint32_t jmask;
+    uint32_t jwrap;
+    const void* bv[kMaxBuildChannels];
+    const uint8_t* bn[kMaxBuildChannels];
+};
+
+// Probe stage (FilterAndProject -> LookupJoin (INNER) in one pass; pa_fused_join_create): a row is selected when the filter keeps it
+// AND its key finds a build row -- the lookup source has one integer key without duplicates, so at most one -- and the output page
+// is [probe output channels (projections), build output channels]: the build columns are "virtual" channels n_in + v of the
+// generated code, read at the build position (as in op_fused.cpp's probe stage).
+struct FpJoin {
+    std::shared_ptr<LookupSourceImpl> ls;
+    OwnedExpr key;                  // the probe join key (a projection of the FilterAndProject)
+    std::vector<int> build_cols;    // virtual channel n_in + v = ls->cols[build_cols[v]]
+    std::vector<int32_t> build_types;
 };
 
 struct FpSpec {
+    std::shared_ptr<FpJoin> join;
     int n_in = 0;
     std::vector<int32_t> in_types;
     bool has_filter = false;
@@ -113,8 +135,73 @@ FpSpec make_fp_spec(const pa_filter_project_desc* d)
     return s;
 }
 
-FpKernelInfo generate_fp(const FpSpec& s, const std::vector<ChannelLayout>& layout)
+// FilterAndProject(fp) -> LookupJoin(jd over `bridge`): the output page's projections are the probe output channels of the
+// FilterAndProject's projections, then the build output channels
+FpSpec make_fp_join_spec(const pa_filter_project_desc* fp, const pa_lookup_join_desc* jd, pa_lookup_source* bridge)
 {
+    PA_REQUIRE(fp != nullptr && jd != nullptr && bridge != nullptr && bridge->impl != nullptr, PA_ERR_INVALID_ARGUMENT, "null argument");
+    FpSpec base = make_fp_spec(fp);
+    PA_REQUIRE(jd->join_type == PA_JOIN_INNER && jd->filter == nullptr, PA_ERR_NOT_SUPPORTED, "the fused probe is an inner join without a filter function");
+    auto js = std::make_shared<FpJoin>();
+    js->ls = bridge->impl;
+    const LookupSourceImpl& ls = *js->ls;
+    PA_REQUIRE(jd->probe_channel_count == (int32_t)base.proj.size(), PA_ERR_INVALID_ARGUMENT, "the probe page is the projection output");
+    PA_REQUIRE(jd->join_channel_count == 1 && ls.join_channels.size() == 1, PA_ERR_NOT_SUPPORTED, "the fused probe takes one join key");
+    const int kc = jd->probe_join_channels[0];
+    PA_REQUIRE(kc >= 0 && kc < (int)base.proj.size(), PA_ERR_INVALID_ARGUMENT, "probe join channel out of range");
+    const int32_t kt = base.proj[(size_t)kc].root_type();
+    PA_REQUIRE(kt == PA_BIGINT || kt == PA_INTEGER || kt == PA_DATE, PA_ERR_NOT_SUPPORTED, "the fused probe takes a BIGINT / INTEGER / DATE key");
+    PA_REQUIRE(kt == ls.cols[(size_t)ls.join_channels[0]].type, PA_ERR_INVALID_ARGUMENT, "probe / build join key types differ");
+    js->key = base.proj[(size_t)kc];
+    FpSpec s = base;
+    s.proj.clear();
+    for (int32_t i = 0; i < jd->probe_output_channel_count; i++) {
+        const int c = jd->probe_output_channels[i];
+        PA_REQUIRE(c >= 0 && c < (int)base.proj.size(), PA_ERR_INVALID_ARGUMENT, "probe output channel out of range");
+        s.proj.push_back(base.proj[(size_t)c]);
+    }
+    for (int col : ls.output_channels) {
+        const int32_t t = ls.cols[(size_t)col].type;
+        PA_REQUIRE(t != PA_VARCHAR, PA_ERR_NOT_SUPPORTED, "VARCHAR build columns are not carried by the fused probe");
+        PA_REQUIRE((int)js->build_cols.size() < kMaxBuildChannels, PA_ERR_NOT_SUPPORTED, "the fused probe carries at most 8 build columns");
+        OwnedExpr e;
+        pa_expr_node node{};
+        node.kind = PA_EXPR_INPUT_REF;
+        node.type = t;
+        node.channel = s.n_in + (int)js->build_cols.size();
+        e.nodes.push_back(node);
+        e.strings.emplace_back();
+        e.root = 0;
+        s.proj.push_back(std::move(e));
+        js->build_cols.push_back(col);
+        js->build_types.push_back(t);
+    }
+    PA_REQUIRE(s.proj.size() <= (size_t)kMaxChannels, PA_ERR_NOT_SUPPORTED, "at most 32 output channels");
+    s.has_filter = true;  // the probe selects
+    s.join = js;
+    std::set<int32_t> used;
+    if (s.filter.root >= 0 && fp->filter != nullptr) s.filter.collect_channels(&used);
+    js->key.collect_channels(&used);
+    for (const auto& e : s.proj) e.collect_channels(&used);
+    s.used_channel.assign(s.n_in, false);
+    for (int32_t c : used) {
+        if (c < s.n_in) s.used_channel[(size_t)c] = true;
+    }
+    return s;
+}
+
+FpKernelInfo generate_fp(const FpSpec& s, const std::vector<ChannelLayout>& layout_in)
+{
+    // (probe stage: the build columns as channels n_in + v; the caller may have appended them already, with their nullability)
+    std::vector<ChannelLayout> layout(layout_in.begin(), layout_in.begin() + s.n_in);
+    if (s.join) {
+        for (size_t v = 0; v < s.join->build_cols.size(); v++) {
+            ChannelLayout cl;
+            cl.type = s.join->build_types[v];
+            cl.nullable = (size_t)s.n_in + v < layout_in.size() ? layout_in[(size_t)s.n_in + v].nullable : true;
+            layout.push_back(cl);
+        }
+    }
     FpKernelInfo k;
     RowInputs ri;
     ri.n_in = s.n_in;
@@ -129,21 +216,53 @@ FpKernelInfo generate_fp(const FpSpec& s, const std::vector<ChannelLayout>& layo
         RowCodegen gen(layout, "a.err");
         std::ostringstream body;
         GenValue f = gen.emit(s.filter, body);
-        src << body.str() << "return " << (f.nullable() ? "(!" + f.n + " && " + f.v + ")" : f.v);  // PageFunctionCompiler.java:539-542
+        src << body.str() << "const bool keep = " << (f.nullable() ? "(!" + f.n + " && " + f.v + ")" : f.v);  // PageFunctionCompiler.java:539-542
     }
     else {
-        src << "return true";
+        src << "const bool keep = true";
     }
     if (s.dyn_channel >= 0 && !s.filter_external) {
         const std::string C = std::to_string(s.dyn_channel);
         src << " && " << (layout[s.dyn_channel].nullable ? "!cn" + C + " && " : "") << "pa_dyn_test(a, (i64)c" << C << ")";
     }
     src << ";\n";
+    // probe stage: a kept row is selected when its key finds a build row (a NULL key matches nothing, JoinProbe.java:89-91); the key's
+    // bitmap is tested first, inside pa_join_probe_keyed
+    std::ostringstream key_code;
+    std::string key_expr;
+    if (s.join && !s.filter_external) {
+        RowCodegen gen(layout, "a.err");
+        GenValue kv = gen.emit(s.join->key, key_code);
+        key_expr = "(u64)(i64)" + kv.v;
+        src << "if (!keep) return false;\n" << key_code.str();
+        if (kv.nullable()) src << "if (" << kv.n << ") return false;\n";
+        src << "return pa_join_probe_keyed(a, " << key_expr << ") >= 0;\n";
+    }
+    else {
+        src << "return keep;\n";
+    }
     src << "}\n";
 
     // projections of one selected row written at output position `rank`
     src << "__device__ __forceinline__ void pa_out(const PaFpArgs& a, i64 rank, i32 row" << params << ")\n{\n";
     src << "if (a.positions) a.positions[rank] = row;\n";
+    if (s.join) {
+        // the selected row's build position once more (one row in ten is selected: cheaper than carrying 4 B per row between the
+        // two kernels), then the build columns of the output at that position
+        src << "i32 jb;\n{\n" << key_code.str() << "jb = pa_join_probe_keyed(a, " << key_expr << ");\n}\n";
+        for (size_t v = 0; v < s.join->build_cols.size(); v++) {
+            const std::string id = std::to_string(s.n_in + (int)v), V = std::to_string(v);
+            const int32_t t = s.join->build_types[v];
+            src << "const " << RowCodegen::ctype(t) << " c" << id << " = ";
+            if (t == PA_BIGINT) src << "((const i64*)a.bv[" << V << "])[jb];\n";
+            else if (t == PA_INTEGER || t == PA_DATE) src << "(i64)((const i32*)a.bv[" << V << "])[jb];\n";
+            else if (t == PA_DOUBLE) src << "((const double*)a.bv[" << V << "])[jb];\n";
+            else if (t == PA_REAL) src << "((const float*)a.bv[" << V << "])[jb];\n";
+            else if (t == PA_BOOLEAN) src << "((const u8*)a.bv[" << V << "])[jb] != 0;\n";
+            else throw Error(PA_ERR_NOT_SUPPORTED, "build column type not carried by the fused probe");
+            if (layout[(size_t)s.n_in + v].nullable) src << "const bool cn" << id << " = a.bn[" << V << "] != nullptr && a.bn[" << V << "][jb] != 0;\n";
+        }
+    }
     {
         RowCodegen gen(layout, "a.err");
         std::ostringstream body;
@@ -233,7 +352,9 @@ FpKernelInfo generate_fp(const FpSpec& s, const std::vector<ChannelLayout>& layo
 
 class FilterProjectOperator : public pa_operator {
 public:
-    explicit FilterProjectOperator(const pa_filter_project_desc* d) : spec_(make_fp_spec(d)), stream_(d->stream)
+    explicit FilterProjectOperator(const pa_filter_project_desc* d) : FilterProjectOperator(d, make_fp_spec(d)) {}
+    // the probe-stage form: FilterAndProject -> LookupJoin (make_fp_join_spec)
+    FilterProjectOperator(const pa_filter_project_desc* d, FpSpec spec) : spec_(std::move(spec)), stream_(d->stream)
     {
         require_device();
         ctl_ = static_cast<int32_t*>(ctl_buf_.ensure(64));  // [0] err [1] selected count
@@ -251,7 +372,7 @@ public:
         merging_ = merge_min_bytes_ > 0 || merge_min_rows_ > 0;
         // DictionaryAwarePageFilter (PageFunctionCompiler wraps a filter over a single input channel in it): two more
         // kernel families -- the filter alone, run over a dictionary, and the projections under a selection made elsewhere
-        if (spec_.has_filter) {
+        if (spec_.has_filter && !spec_.join && spec_.filter.root >= 0) {
             std::set<int32_t> fc;
             spec_.filter.collect_channels(&fc);
             if (fc.size() == 1) {
@@ -273,7 +394,10 @@ public:
     hipStream_t private_stream() override { return stream_.owned() ? stream_.get() : nullptr; }
     hipStream_t main_stream() override { return stream_.get(); }
 
-    bool needs_input() override { return !finishing_ && !pending_ && !big_queued_; }
+    // probe stage: no page before the build side has published its lookup source (LookupJoinOperator.java:63, 100)
+    bool lookup_source_ready() const { return !spec_.join || spec_.join->ls->built.load(); }
+    bool needs_input() override { return !finishing_ && !pending_ && !big_queued_ && lookup_source_ready(); }
+    bool is_blocked() override { return !finishing_ && !lookup_source_ready(); }
 
     void add_input(const pa_page* page) override
     {
@@ -296,6 +420,28 @@ public:
         FpArgs a;
         memset(&a, 0, sizeof a);
         bind_inputs(sp, in_, &layout, &sig, &vec, &a);
+        if (spec_.join) {
+            const LookupSourceImpl& ls = *spec_.join->ls;
+            PA_REQUIRE(ls.built.load(), PA_ERR_ILLEGAL_STATE, "probe page before the lookup source was built");
+            if (int32_t e = ls.error.load()) throw Error(e, "hash build failed on device");
+            PA_REQUIRE(ls.keyed && !ls.has_duplicates, PA_ERR_ILLEGAL_STATE, "internal: fused probe over a lookup source with duplicate keys");
+            a.jslots = ls.key_slots.ptr();
+            a.jmask = ls.probe_mask;
+            a.jwrap = ls.probe_wrap;
+            a.jbits = ls.bitmap.bits;
+            a.jmin = ls.bitmap.min_key;
+            a.jrange = ls.bitmap.range;
+            for (size_t v = 0; v < spec_.join->build_cols.size(); v++) {
+                const BuildColumn& bc = ls.cols[(size_t)spec_.join->build_cols[v]];
+                a.bv[v] = bc.values.ptr();
+                a.bn[v] = bc.has_nulls ? bc.nulls.as<uint8_t>() : nullptr;
+                ChannelLayout cl;
+                cl.type = spec_.join->build_types[v];
+                cl.nullable = bc.has_nulls;
+                layout.push_back(cl);
+                sig += cl.nullable ? 'N' : '_';
+            }
+        }
         Compiled& ck = kernel_for(external ? 2 : 0, sig, layout);
         cur_ = &ck;
         a.n = n;
@@ -400,7 +546,7 @@ public:
         for (size_t j = 0; j < spec_.proj.size(); j++) {
             OutColumn& oc = out_cols_[j];
             const OwnedExpr& e = spec_.proj[j];
-            const bool identity = e.is_input_ref();
+            const bool identity = e.is_input_ref() && e.node(e.root).channel < spec_.n_in;  // (not a build column of the probe stage)
             if (identity && count == n) {
                 // positionsRange(0, n): InputPageProjection returns block.getRegion -> zero copy
                 const DevColumn& src = in_.cols[e.node(e.root).channel];
@@ -519,7 +665,6 @@ public:
 
     void finish() override { finishing_ = true; }
     bool is_finished() override { return finishing_ && !pending_ && !big_queued_ && m_rows_ == 0; }
-    bool is_blocked() override { return false; }
     int64_t memory_bytes() override { return (int64_t)(stager_.bytes() + sel4_.capacity() + positions_.capacity() + tile_counts_.capacity()); }
 
     // SelectedPositions of the last processed page (after its get_output)
@@ -687,6 +832,12 @@ void filter_project_set_dynamic_filter(pa_operator* op, int channel, const uint6
 pa_operator* make_filter_project(const pa_filter_project_desc* desc)
 {
     return new FilterProjectOperator(desc);
+}
+
+pa_operator* make_filter_project_probe(const pa_filter_project_desc* fp, const pa_lookup_join_desc* join, pa_lookup_source* bridge)
+{
+    PA_REQUIRE(fp != nullptr, PA_ERR_INVALID_ARGUMENT, "descriptor is null");
+    return new FilterProjectOperator(fp, make_fp_join_spec(fp, join, bridge));
 }
 
 std::string filter_project_source_for_desc(const pa_filter_project_desc* desc, std::string* entry)

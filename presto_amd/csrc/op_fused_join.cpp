@@ -1,15 +1,17 @@
-// op_fused_join.cpp -- FilterAndProjectOperator -> LookupJoinOperator -> (Hash)AggregationOperator behind one operator handle
-// (pa_fused_join_aggregation_desc).
+// op_fused_join.cpp -- FilterAndProjectOperator -> LookupJoinOperator [-> (Hash)AggregationOperator] behind one operator handle
+// (pa_fused_join_aggregation_desc, pa_fused_join_desc).
 //
 // The reference runs the three operators of such a pipeline in one Driver (LocalExecutionPlanner.visitAggregation over
 // visitJoin's probe side; Driver.processInternal moves pages between neighbours, Driver.java:355-457).  Two executions of the
 // same composition live behind this handle, chosen when the build side has published its lookup source:
-//   * one generated kernel (op_fused.cpp, "probe stage") when the lookup source has one integer key and no duplicate keys;
-//   * the three device operators behind each other, pages moved between them the way Driver.processInternal does, in every
+//   * one generated kernel (op_fused.cpp, "probe stage"; for the join without an aggregation behind it: the FilterAndProject kernels
+//     with the probe inside, op_filter_project.cpp) when the lookup source has one integer key and no duplicate keys;
+//   * the device operators behind each other, pages moved between them the way Driver.processInternal does, in every
 //     other case (duplicate keys -- a probe row then has several matches --, several join keys, other key types).
 // Both are created up front (creation does no device work to speak of), so that everything a descriptor can get wrong is
 // reported by the factory call, and the one not taken is dropped with the first page.
 #include <memory>
+#include <vector>
 
 #include "join_source.hpp"
 #include "operator.hpp"
@@ -26,6 +28,32 @@ namespace {
 
 class FusedJoinAggregationOperator : public pa_operator {
 public:
+    // FilterAndProject -> LookupJoin (no aggregation behind it)
+    FusedJoinAggregationOperator(const pa_fused_join_desc* d, pa_lookup_source* bridge) : bridge_(*bridge)
+    {
+        PA_REQUIRE(bridge->impl != nullptr, PA_ERR_ILLEGAL_STATE, "lookup source has no build operator yet");
+        PA_REQUIRE(d->join.join_type == PA_JOIN_INNER && d->join.filter == nullptr, PA_ERR_NOT_SUPPORTED, "the fused join is an inner join without a filter function");
+        void* stream = d->join.stream ? d->join.stream : d->filter_project.stream;
+        pa_filter_project_desc fp = d->filter_project;
+        fp.output_mem = PA_MEM_DEVICE;
+        fp.stream = stream;
+        fp.min_output_page_bytes = fp.min_output_page_rows = fp.max_output_page_bytes = 0;  // (MergePages sits behind the join)
+        pa_lookup_join_desc join = d->join;
+        join.stream = stream;
+        chain_.emplace_back(make_filter_project(&fp));
+        chain_.emplace_back(make_lookup_join(&join, bridge));
+        try {
+            pa_filter_project_desc one = d->filter_project;
+            one.output_mem = d->join.output_mem;
+            one.stream = stream;
+            fused_.reset(make_filter_project_probe(&one, &d->join, bridge));
+        }
+        catch (const Error& e) {
+            if (e.code != PA_ERR_NOT_SUPPORTED) throw;
+        }
+        stream_ = chain_.back()->main_stream();
+        finish_sent_.assign(chain_.size(), false);
+    }
     FusedJoinAggregationOperator(const pa_fused_join_aggregation_desc* d, pa_lookup_source* bridge) : bridge_(*bridge)
     {
         PA_REQUIRE(bridge->impl != nullptr, PA_ERR_ILLEGAL_STATE, "lookup source has no build operator yet");
@@ -40,9 +68,9 @@ public:
         join.stream = stream;
         pa_hash_aggregation_desc agg = d->aggregation;
         agg.stream = stream;
-        chain_[0].reset(make_filter_project(&fp));
-        chain_[1].reset(make_lookup_join(&join, bridge));
-        chain_[2].reset(make_hash_aggregation(&agg));
+        chain_.emplace_back(make_filter_project(&fp));
+        chain_.emplace_back(make_lookup_join(&join, bridge));
+        chain_.emplace_back(make_hash_aggregation(&agg));
         try {
             pa_fused_join_aggregation_desc f = *d;
             f.aggregation.stream = stream;
@@ -51,10 +79,11 @@ public:
         catch (const Error& e) {
             if (e.code != PA_ERR_NOT_SUPPORTED) throw;  // shapes the one-kernel form does not cover run as the chain
         }
-        stream_ = chain_[2]->main_stream();
+        stream_ = chain_.back()->main_stream();
+        finish_sent_.assign(chain_.size(), false);
     }
     hipStream_t main_stream() override { return stream_; }
-    hipStream_t private_stream() override { return active() ? active()->private_stream() : chain_[2]->private_stream(); }
+    hipStream_t private_stream() override { return active() ? active()->private_stream() : chain_.back()->private_stream(); }
 
     bool needs_input() override
     {
@@ -96,9 +125,9 @@ public:
     {
         if (fused_) return fused_->get_output(out);
         pump();
-        return chain_[2]->get_output(out);
+        return chain_.back()->get_output(out);
     }
-    bool is_finished() override { return fused_ ? fused_->is_finished() : chain_[2]->is_finished(); }
+    bool is_finished() override { return fused_ ? fused_->is_finished() : chain_.back()->is_finished(); }
     int64_t memory_bytes() override
     {
         if (fused_) return fused_->memory_bytes();
@@ -106,7 +135,7 @@ public:
         for (auto& op : chain_) b += op ? op->memory_bytes() : 0;
         return b;
     }
-    KernelTimer& kernel_timer() override { return fused_ ? fused_->kernel_timer() : (chain_[2] ? chain_[2]->kernel_timer() : timer); }
+    KernelTimer& kernel_timer() override { return fused_ ? fused_->kernel_timer() : (!chain_.empty() && chain_.back() ? chain_.back()->kernel_timer() : timer); }
     // which execution runs (tests, DESIGN's measurements): 1 = one kernel, 2 = operator chain, 0 = not decided yet
     int execution() const { return !chosen_ ? 0 : (fused_ ? 1 : 2); }
 
@@ -119,9 +148,7 @@ private:
         if (chosen_) return true;
         if (!lookup_source_built(&bridge_)) return false;
         if (fused_ && !lookup_source_unique_keyed(&bridge_)) fused_.reset();
-        if (fused_) {
-            for (auto& op : chain_) op.reset();
-        }
+        if (fused_) chain_.clear();
         chosen_ = true;
         return true;
     }
@@ -131,7 +158,7 @@ private:
     {
         for (bool moved = true; moved;) {
             moved = false;
-            for (int i = 0; i < 2; i++) {
+            for (size_t i = 0; i + 1 < chain_.size(); i++) {
                 pa_operator* cur = chain_[i].get();
                 pa_operator* next = chain_[i + 1].get();
                 if (!cur->is_finished() && next->needs_input()) {
@@ -152,14 +179,20 @@ private:
     }
 
     pa_lookup_source bridge_;
-    std::unique_ptr<pa_operator> chain_[3];
+    std::vector<std::unique_ptr<pa_operator>> chain_;
     std::unique_ptr<pa_operator> fused_;
     hipStream_t stream_ = nullptr;
     bool chosen_ = false, finishing_ = false;
-    bool finish_sent_[3] = {false, false, false};
+    std::vector<bool> finish_sent_;
 };
 
 }  // namespace
+
+pa_operator* make_fused_join(const pa_fused_join_desc* desc, pa_lookup_source* bridge)
+{
+    PA_REQUIRE(desc != nullptr && bridge != nullptr, PA_ERR_INVALID_ARGUMENT, "null argument");
+    return new FusedJoinAggregationOperator(desc, bridge);
+}
 
 pa_operator* make_fused_join_aggregation(const pa_fused_join_aggregation_desc* desc, pa_lookup_source* bridge)
 {

@@ -42,6 +42,10 @@ pa_operator* make_hash_aggregation(const pa_hash_aggregation_desc* desc);
 // (op_fused.cpp), valid only for keyed lookup sources without duplicate keys -- probe_source_is_unique, once built
 pa_operator* make_fused_join_aggregation(const pa_fused_join_aggregation_desc* desc, pa_lookup_source* bridge);
 pa_operator* make_fused_probe_aggregation(const pa_fused_join_aggregation_desc* desc, pa_lookup_source* bridge);
+// FilterAndProject -> LookupJoin (op_fused_join.cpp); make_filter_project_probe is its one-pass form (op_filter_project.cpp), valid
+// under the same condition
+pa_operator* make_fused_join(const pa_fused_join_desc* desc, pa_lookup_source* bridge);
+pa_operator* make_filter_project_probe(const pa_filter_project_desc* fp, const pa_lookup_join_desc* join, pa_lookup_source* bridge);
 bool lookup_source_built(pa_lookup_source* ls);
 bool lookup_source_unique_keyed(pa_lookup_source* ls);
 pa_operator* make_filter_project(const pa_filter_project_desc* desc);

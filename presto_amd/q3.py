@@ -21,7 +21,7 @@ producing side of the rank has finished."""
 from . import abi, tpch
 from .exchange import ExchangeOperator
 from .expr import field
-from .operators import (Driver, FilterAndProjectOperator, FusedJoinAggregationOperator, HashAggregationOperator, HashBuilderOperator,
+from .operators import (Driver, FilterAndProjectOperator, FusedJoinAggregationOperator, FusedJoinOperator, HashAggregationOperator, HashBuilderOperator,
                         LookupJoinOperator, LookupSourceFactory, TopNOperator)
 
 
@@ -43,7 +43,8 @@ def run(customer_pages, orders_pages, lineitem_pages, stream, comm=None, expecte
     the parity tests.  dynamic_filters: the filters upstream of the two probes also drop the rows whose join key matches no
     build key (the joins' dynamic filters, applied where Trino applies them); with exchange steps the filter is the union of
     every rank's build-key bitmap (pa_lookup_source_shared_key_bitmap), so that rows are dropped before they are exchanged.
-    fused_probe: the lineitem pipeline's FilterAndProject -> LookupJoin -> HashAggregation run behind one handle
+    fused_probe: the orders pipeline's FilterAndProject -> LookupJoin run behind one handle (pa_fused_join_create), and
+    the lineitem pipeline's FilterAndProject -> LookupJoin -> HashAggregation run behind one handle
     (pa_fused_join_aggregation_create: one generated kernel over the lineitem pages -- orderkey is unique on the build side);
     with exchange steps the filter stays in front of the exchange and the fused operator takes the exchanged pages.
     False: the three operators on their own (the independent path of the parity tests)."""
@@ -100,13 +101,19 @@ def run(customer_pages, orders_pages, lineitem_pages, stream, comm=None, expecte
     lap("customer_pipeline")
     # pipeline 2
     b2 = LookupSourceFactory()
-    orders_fp = FilterAndProjectOperator(tpch.ORDERS_TYPES, tpch.q3_orders_filter(), [field(i, t) for i, t in enumerate(tpch.ORDERS_TYPES)],
-                                         output_mem=dev, stream=s)
-    dynamic_filter(orders_fp, 1, b1, "orders_dynamic_filter")
+    orders_projections = [field(i, t) for i, t in enumerate(tpch.ORDERS_TYPES)]
+    if fused_probe and not distributed:
+        # FilterAndProject -> LookupJoin as one operator: custkey is unique on the build side (the join's dynamic filter is the
+        # fused kernels' own bitmap test)
+        if dynamic_filters:
+            counters["orders_dynamic_filter"] = "fused"
+        orders_head = [FusedJoinOperator(b1, tpch.ORDERS_TYPES, tpch.q3_orders_filter(), orders_projections, [1], [0, 2, 3], output_mem=dev, stream=s)]
+    else:
+        orders_fp = FilterAndProjectOperator(tpch.ORDERS_TYPES, tpch.q3_orders_filter(), orders_projections, output_mem=dev, stream=s)
+        dynamic_filter(orders_fp, 1, b1, "orders_dynamic_filter")
+        orders_head = [orders_fp, *exchange(tpch.ORDERS_TYPES, [1]), LookupJoinOperator(b1, tpch.ORDERS_TYPES, [1], [0, 2, 3], output_mem=dev, stream=s)]
     Driver(orders_pages, [
-        orders_fp,
-        *exchange(tpch.ORDERS_TYPES, [1]),
-        LookupJoinOperator(b1, tpch.ORDERS_TYPES, [1], [0, 2, 3], output_mem=dev, stream=s),
+        *orders_head,
         *exchange(ORDERS_JOINED_TYPES, [0]),
         HashBuilderOperator(b2, ORDERS_JOINED_TYPES, [0], [1, 2], stream=s)]).run()
     lap("orders_pipeline")

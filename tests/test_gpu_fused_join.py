@@ -217,3 +217,100 @@ def test_refused_shapes(gpu):
     with pytest.raises(PrestoAmdError):   # probe / build key types differ
         FusedJoinAggregationOperator(bridge, PROBE_TYPES, FILTER, PROJECTIONS, [2], [0, 1], [abi.BIGINT, abi.DOUBLE, abi.DATE], [0], [(abi.AGG_COUNT_STAR, -1, None)])
     builder.close()
+
+
+# ---- FilterAndProject -> LookupJoin behind one handle (pa_fused_join_create) ------------------------------------------------
+def joined_rows_oracle(oracle, probe, build, build_out, probe_out, flt=FILTER):
+    j = oracle.HashJoin(BUILD_TYPES, [0], build_out)
+    for p in build:
+        j.add_build_page(p)
+    j.build()
+    rows = []
+    for p in probe:
+        fp = oracle.filter_project(p, flt, PROJECTIONS)
+        if fp is None or fp.position_count == 0:
+            continue
+        rows += j.probe(fp, PROJECTED, [0], probe_out)[0].to_rows()
+    return rows
+
+
+def joined_rows_device(probe, build, build_out, probe_out, flt=FILTER, output_mem=abi.MEM_HOST):
+    from presto_amd.operators import FusedJoinOperator, download_page
+    bridge = LookupSourceFactory()
+    builder = HashBuilderOperator(bridge, BUILD_TYPES, [0], build_out)
+    op = FusedJoinOperator(bridge, PROBE_TYPES, flt, PROJECTIONS, [0], probe_out, output_mem=output_mem)
+    assert not op.needsInput() and op.isBlocked()
+    Driver(build, [builder]).run()
+    assert op.needsInput() and not op.isBlocked()
+    if output_mem != abi.MEM_DEVICE:
+        return [r for p in to_pages(op, probe) for r in p.to_rows()]
+    rows = []   # device output buffers belong to the operator until its next call: read every page at once
+    for p in probe:
+        op.addInput(p)
+        out = op.getOutput()
+        if out is not None:
+            rows += download_page(out).to_rows()
+    op.finish()
+    assert op.getOutput() is None and op.isFinished()
+    return rows
+
+
+@pytest.mark.parametrize("n", [1, 1000, 70000])
+@pytest.mark.parametrize("duplicates", [False, True])
+def test_fused_join_rows_and_order(gpu, oracle, n, duplicates):
+    """FilterAndProject -> LookupJoin: the same rows in the same (probe) order as the oracle's two operators -- through the
+    one-pass form (unique build keys) and through the operator chain (duplicate keys: matches of a row in chain order)."""
+    rng = np.random.default_rng(n + duplicates)
+    key_range = max(4 * n // 3, 8)
+    keys = rng.integers(0, key_range, max(key_range // 2, 1)) if duplicates else rng.permutation(key_range)[: max(key_range // 2, 1)]
+    build = [build_page(rng, keys)]
+    probe = probe_pages(rng, 3, n, key_range, clustered=(n == 70000))
+    for probe_out, build_out in (([0, 1, 2, 3], [1, 2, 3, 4]), ([3, 1], [2]), ([0], [])):
+        expected = joined_rows_oracle(oracle, probe, build, build_out, probe_out)
+        assert joined_rows_device(probe, build, build_out, probe_out) == expected
+    assert joined_rows_device(probe, build, [1, 3], [0, 2], output_mem=abi.MEM_DEVICE) == joined_rows_oracle(oracle, probe, build, [1, 3], [0, 2])
+
+
+def test_fused_join_every_row_and_no_row(gpu, oracle):
+    """Every probe row selected (identity projections of a fully selected page are views of the input; the build columns are still
+    computed), no filter at all, and a probe side without a single match."""
+    rng = np.random.default_rng(9)
+    n = 5000
+    build = [build_page(rng, np.arange(n), nullable=False)]
+    probe = [Page([Block.bigint(rng.permutation(n)), Block.double(rng.random(n)), Block.integer(rng.integers(0, 9, n)), Block.date(np.full(n, 9300, dtype=np.int32))], n)]
+    idp = [field(0, abi.BIGINT), field(1, abi.DOUBLE), field(2, abi.INTEGER), field(3, abi.DATE)]
+    from presto_amd.operators import FusedJoinOperator
+    for flt in (None, FILTER):
+        bridge = LookupSourceFactory()
+        Driver(build, [HashBuilderOperator(bridge, BUILD_TYPES, [0], [1, 2])]).run()
+        rows = [r for p in to_pages(FusedJoinOperator(bridge, PROBE_TYPES, flt, idp, [0], [0, 1, 2, 3]), probe) for r in p.to_rows()]
+        j = oracle.HashJoin(BUILD_TYPES, [0], [1, 2])
+        j.add_build_page(build[0])
+        j.build()
+        assert rows == j.probe(probe[0], PROBE_TYPES, [0], [0, 1, 2, 3])[0].to_rows() and len(rows) == n
+    none = [Page([Block.bigint(np.arange(n) + 10 * n), Block.double(rng.random(n)), Block.integer(np.zeros(n, dtype=np.int32)), Block.date(np.full(n, 9300, dtype=np.int32))], n)]
+    assert joined_rows_device(none, build, [1], [0, 1]) == []
+
+
+def test_fused_join_with_varchar_probe_channels(gpu, oracle):
+    from presto_amd.operators import FusedJoinOperator
+    rng = np.random.default_rng(10)
+    n = 20000
+    words = [b"", b"a", b"BUILDING", b"0123456789abcdefghij", None]
+    types = [abi.BIGINT, abi.VARCHAR, abi.DOUBLE]
+    probe = [Page([Block.bigint(rng.integers(0, 3000, n), rng.random(n) < 0.03), Block.varchar([words[i] for i in rng.integers(0, len(words), n)]), Block.double(rng.random(n))], n)
+             for _ in range(2)]
+    build = [build_page(rng, rng.permutation(3000)[:1500])]
+    proj = [field(0, abi.BIGINT), field(1, abi.VARCHAR), field(2, abi.DOUBLE) * constant(3.0, abi.DOUBLE)]
+    flt = field(2, abi.DOUBLE) < constant(0.8, abi.DOUBLE)
+    bridge = LookupSourceFactory()
+    Driver(build, [HashBuilderOperator(bridge, BUILD_TYPES, [0], [1, 4])]).run()
+    rows = [r for p in to_pages(FusedJoinOperator(bridge, types, flt, proj, [0], [1, 2, 0]), probe) for r in p.to_rows()]
+    j = oracle.HashJoin(BUILD_TYPES, [0], [1, 4])
+    j.add_build_page(build[0])
+    j.build()
+    expected = []
+    for p in probe:
+        fp = oracle.filter_project(p, flt, proj)
+        expected += j.probe(fp, types, [0], [1, 2, 0])[0].to_rows()
+    assert rows == expected and len(rows) > 5000
