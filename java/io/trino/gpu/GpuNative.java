@@ -36,6 +36,10 @@ final class GpuNative
     static native long createHashBuilder(long bridge, int[] inputTypes, int[] joinChannels, int hashChannel, int[] outputChannels, int expectedPositions);
     static native long createLookupJoin(long bridge, int[] probeTypes, int[] probeJoinChannels, int probeHashChannel, int[] probeOutputChannels,
             int joinType, boolean outputSingleMatch, boolean outer, int outputMem, long filterExpression);
+    /** FilterAndProject -> LookupJoin [-> aggregation] of one pipeline behind one handle (aggFns == null: no aggregation). */
+    static native long createFusedJoin(long bridge, int[] inputTypes, int[] typeParams, long filter, long[] projections, int[] projectionTypes,
+            int[] probeJoinChannels, int[] probeOutputChannels, int[] joinedTypes, int[] groupByChannels, int step, int[] aggFns, int[] aggInputs,
+            int[] aggMasks, int[] aggInputTypes, int expectedGroups, int outputMem);
     static native long createTopN(int[] inputTypes, int count, int[] sortChannels, int[] sortOrders, int outputMem);
     static native boolean setDynamicFilter(long filterProjectOperator, int channel, long lookupSource);
 

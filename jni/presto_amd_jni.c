@@ -240,6 +240,49 @@ JNIEXPORT jlong JNICALL Java_io_trino_gpu_GpuNative_createLookupJoin(JNIEnv* env
     return (jlong)(intptr_t)op;
 }
 
+/* FilterAndProject -> LookupJoin (INNER, no filter function) [-> (Hash)Aggregation] of one pipeline behind one handle:
+ * pa_fused_join_create (aggFns == null) / pa_fused_join_aggregation_create.  The probe page is the projection output; joinedTypes =
+ * types of the join's output page [probe output channels, build output channels] (the aggregation's input). */
+JNIEXPORT jlong JNICALL Java_io_trino_gpu_GpuNative_createFusedJoin(JNIEnv* env, jclass c, jlong bridge, jintArray inputTypes, jintArray typeParams, jlong filter,
+        jlongArray projections, jintArray projectionTypes, jintArray probeJoinChannels, jintArray probeOutputChannels, jintArray joinedTypes,
+        jintArray groupByChannels, jint step, jintArray aggFns, jintArray aggInputs, jintArray aggMasks, jintArray aggInputTypes, jint expectedGroups, jint outputMem)
+{
+    jsize n, np_, npt, nj, no, njt, ng, na = 0, nproj = (*env)->GetArrayLength(env, projections);
+    pa_fused_join_aggregation_desc d;
+    memset(&d, 0, sizeof d);
+    int32_t *types = ints_of(env, inputTypes, &n), *params = ints_of(env, typeParams, &np_), *ptypes = ints_of(env, projectionTypes, &npt);
+    int32_t *jc = ints_of(env, probeJoinChannels, &nj), *oc = ints_of(env, probeOutputChannels, &no), *jt = ints_of(env, joinedTypes, &njt);
+    int32_t* gb = ints_of(env, groupByChannels, &ng);
+    pa_aggregate* aggs = 0;
+    if (aggFns) fill_aggregates(env, aggFns, aggInputs, aggMasks, aggInputTypes, &aggs, &na);
+    pa_expr* pe = (pa_expr*)calloc((size_t)(nproj > 0 ? nproj : 1), sizeof(pa_expr));
+    jlong* ph = (*env)->GetLongArrayElements(env, projections, 0);
+    for (jsize i = 0; i < nproj; i++) pe[i] = ((native_expr*)(intptr_t)ph[i])->expr;
+    (*env)->ReleaseLongArrayElements(env, projections, ph, JNI_ABORT);
+    d.filter_project.input_channel_count = n; d.filter_project.input_types = types; d.filter_project.input_type_params = np_ == n ? params : 0;
+    d.filter_project.filter = filter ? &((native_expr*)(intptr_t)filter)->expr : 0;
+    d.filter_project.projection_count = nproj; d.filter_project.projections = pe; d.filter_project.output_mem = PA_MEM_DEVICE;
+    d.join.probe_channel_count = npt; d.join.probe_types = ptypes; d.join.join_channel_count = nj; d.join.probe_join_channels = jc;
+    d.join.probe_hash_channel = -1; d.join.probe_output_channel_count = no; d.join.probe_output_channels = oc; d.join.join_type = PA_JOIN_INNER;
+    d.join.output_mem = aggFns ? PA_MEM_DEVICE : outputMem;
+    d.aggregation.input_channel_count = njt; d.aggregation.input_types = jt; d.aggregation.group_by_count = ng; d.aggregation.group_by_channels = gb;
+    d.aggregation.hash_channel = -1; d.aggregation.step = step; d.aggregation.aggregate_count = na; d.aggregation.aggregates = aggs;
+    d.aggregation.expected_groups = expectedGroups; d.aggregation.output_mem = outputMem;
+    pa_operator* op = 0;
+    int32_t rc;
+    if (aggFns) rc = pa_fused_join_aggregation_create(&d, (pa_lookup_source*)(intptr_t)bridge, &op);
+    else {
+        pa_fused_join_desc j;
+        memset(&j, 0, sizeof j);
+        j.filter_project = d.filter_project;
+        j.join = d.join;
+        rc = pa_fused_join_create(&j, (pa_lookup_source*)(intptr_t)bridge, &op);
+    }
+    free(pe); free(aggs); free(gb); free(jt); free(oc); free(jc); free(ptypes); free(params); free(types);
+    if (rc < 0) { throw_native(env, rc); return 0; }
+    return (jlong)(intptr_t)op;
+}
+
 JNIEXPORT jlong JNICALL Java_io_trino_gpu_GpuNative_createTopN(JNIEnv* env, jclass c, jintArray inputTypes, jint count, jintArray sortChannels, jintArray sortOrders, jint outputMem)
 {
     jsize n, ns, no;
