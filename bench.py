@@ -18,7 +18,9 @@ Prints ONE JSON line on rank 0 (see the contract in the task description), inclu
   cpu_baseline the oracle's hand-written-twin pipelines timed on the host cores on a bounded sample;
   q3           ms/step, input rows/s, per-pipeline ms, achieved HBM GB/s against the algorithmic bytes of SURVEY 8d,
                exchange bytes and GB/s over xGMI when N > 1;
-  h2d          the Q6 pipeline fed with PA_MEM_HOST pages (what a JNI shim hands over): PCIe-inclusive rows/s, N = 1 only.
+  h2d          the Q6 pipeline fed with PA_MEM_HOST pages (what a JNI shim hands over): PCIe-inclusive rows/s, N = 1 only;
+  sf300        BASELINE config #5's tables on the one GPU (1.80 G lineitem rows, 82.8 GB of Q1 / Q6 columns, plus the Q3
+               tables): Q1+Q6 rows/s and Q3 ms/step over a few steps, N = 1 only (the SF100 tables are released first).
 """
 import argparse
 import json
@@ -49,7 +51,10 @@ def parse_args(argv=None):
     ap.add_argument("--queries", default="q1,q6", help="headline queries")
     ap.add_argument("--q3", type=int, default=1, help="1 = also time the Q3 pipelines (the `q3` object), 0 = skip")
     ap.add_argument("--q3-sf", type=float, default=0.0, help="scale factor per GPU of the Q3 tables (0 = --sf)")
+    ap.add_argument("--q3-timeout", type=int, default=300, help="N > 1: seconds after which the line is printed without the Q3 leg (0 = wait for ever)")
     ap.add_argument("--h2d-rows", type=int, default=1 << 25, help="rows of the host-page (PCIe-inclusive) Q6 leg, N = 1 only (0 = skip)")
+    ap.add_argument("--sf300", type=int, default=1, help="1 = also run BASELINE config #5's tables (SF300: 1.80 G lineitem rows, 82.8 GB of "
+                    "Q1 / Q6 columns + the Q3 tables) on this one GPU for a few steps (the `sf300` object), N = 1 only; 0 = skip")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend; 'gloo' only to rehearse the multi-rank "
                     "control flow with several ranks on one GPU (RCCL refuses two ranks on one device)")
     return ap.parse_args(argv)
@@ -329,6 +334,38 @@ def timed_region(workload, dist, world, backend, fn, steps, warmup):
     return elapsed
 
 
+def sf300_leg(args, dist, device, steps=3):
+    """BASELINE config #5's tables on one GPU: Q1+Q6 over 1.80 G lineitem rows (82.8 GB of columns) and Q3 over the SF300
+    customer / orders / lineitem tables, `steps` timed steps each after one warm-up step.  The SF100 tables of the headline
+    are released first (the caller closed that workload)."""
+    import copy
+    import gc
+    import torch
+    gc.collect()
+    torch.cuda.empty_cache()
+    a = copy.copy(args)
+    a.sf, a.q3_sf, a.h2d_rows = 300.0, 0.0, 0
+    t0 = time.perf_counter()
+    w = DeviceWorkload(a, 0, 1, device)
+    gen_s = time.perf_counter() - t0
+    try:
+        elapsed = timed_region(w, dist, 1, args.backend, w.step, steps, 1)
+        out = {"workload": w.workload_name(), "value": w.rows_per_step() * steps / elapsed, "unit": "rows/s", "steps": steps,
+               "ms_per_step": elapsed / steps * 1e3, "table_generation_s": gen_s,
+               "hbm_bytes_resident": sum(t.numel() for t in w._keep),
+               "results": {k: [[x.decode() if isinstance(x, bytes) else x for x in r] for r in v] for k, v in w.results.items()}}
+        r1, r6 = w.roofline("q1", steps, {}), w.roofline("q6", steps, {})
+        out["roofline_frac"] = {"q1": r1 and r1["frac"], "q6": r6 and r6["frac"]}
+        if w.q3_on:
+            q3_elapsed = timed_region(w, dist, 1, args.backend, lambda timed: w.q3_step(), steps, 1)
+            out["q3"] = {"ms_per_step": q3_elapsed / steps * 1e3, "value": w.q3_input_rows() * steps / q3_elapsed, "unit": "rows/s",
+                         "input_rows": w.q3_input_rows(), "result": [[x.decode() if isinstance(x, bytes) else x for x in r] for r in w.results["q3"]],
+                         "stage_ms": {k: v for k, v in w.q3_counters.items() if k.endswith("_pipeline_ms")}}
+        return out
+    finally:
+        w.close()
+
+
 def main(argv=None, workload_factory=None, out=None):
     """workload_factory(args, rank, world, device) -> workload: tests rehearse the multi-rank control flow (barriers, the
     max-over-ranks clock, the exchange rounds of Q3, the JSON line) on CPU ranks with a checker workload; the default is
@@ -355,6 +392,71 @@ def main(argv=None, workload_factory=None, out=None):
     elapsed = timed_region(workload, dist, world, args.backend, workload.step, args.steps, args.warmup)
     value = workload.rows_per_step() * args.steps * world / elapsed
 
+    # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command (profiles/pmc_traffic.json,
+    # written by scripts/summarize_profile.py); only valid for the default workload shape they were collected on
+    pmc = {}
+    pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(pmc_path) and args.sf == 100.0 and args.page_rows == 1 << 28:
+        pmc = json.load(open(pmc_path)).get("kernels", {})
+
+    emitted = False
+
+    def emit(q3, side_legs=True):
+        nonlocal workload, emitted
+        if rank != 0 or emitted:
+            return
+        emitted = True
+        queries = workload.queries
+        line = {
+            "metric": "rows/s through operator pipeline, TPC-H Q1+Q6 SF100, 1/2/4/8 GPUs vs CPU ref",
+            "value": value, "unit": "rows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": workload.workload_name(),
+                       "scale_factor_per_gpu": args.sf, "rows_per_gpu": workload.rows, "page_rows": args.page_rows,
+                       "page_order": args.page_order,
+                       "queries": queries, "parallelism": "row-range shards, %d rank(s), no data-path collective in Q1/Q6; "
+                                                          "Q3 (the `q3` object) shuffles its join sides between the ranks" % world},
+        }
+        r1 = workload.roofline("q1", args.steps, pmc) if "q1" in queries else None
+        r6 = workload.roofline("q6", args.steps, pmc) if "q6" in queries else None
+        line["roofline"] = r1 or r6
+        if r1 and r6:
+            line["roofline_q6"] = r6
+        if q3 is not None:
+            line["q3"] = q3
+        line["results"] = {k: [[x.decode() if isinstance(x, bytes) else x for x in r] for r in v] for k, v in workload.results.items()}
+        if side_legs and world == 1 and args.h2d_rows > 0 and hasattr(workload, "h2d"):
+            try:
+                line["h2d"] = workload.h2d(args.h2d_rows)
+            except Exception as e:
+                line["h2d"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        if side_legs and world == 1 and args.sf300 and args.sf == 100.0 and workload_factory is None:
+            try:
+                workload.close()
+                workload = None
+                line["sf300"] = sf300_leg(args, dist, device)
+            except Exception as e:
+                line["sf300"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        if side_legs and world == 1 and args.cpu_rows > 0:
+            line["cpu_baseline"] = cpu_baseline(args.sf, args.cpu_rows)
+        print(json.dumps(line), file=out or sys.stdout, flush=True)
+
+    # N > 1: the Q3 leg runs collectives; a rank that fails inside one would leave the others waiting for ever.  The headline was
+    # measured above: if the leg does not come back within --q3-timeout seconds, rank 0 prints the line without it and every
+    # rank leaves.
+    watchdog = None
+    if world > 1 and getattr(workload, "q3_on", False) and args.q3_timeout > 0:
+        import threading
+
+        def bail():
+            try:
+                emit({"error": "the Q3 leg did not finish within %d s on %d ranks" % (args.q3_timeout, world)}, side_legs=False)
+            finally:
+                os._exit(0)
+        watchdog = threading.Timer(args.q3_timeout, bail)
+        watchdog.daemon = True
+        watchdog.start()
     q3 = None
     if getattr(workload, "q3_on", False):
         try:
@@ -392,46 +494,13 @@ def main(argv=None, workload_factory=None, out=None):
                                   "note": "xgmi_GBps = rank 0's payload bytes sent to the other ranks / device time of its all-to-alls (HIP events)"}
         except Exception as e:  # the headline must survive a failing side leg
             q3 = {"error": "%s: %s" % (type(e).__name__, e)}
-
-    # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command (profiles/pmc_traffic.json,
-    # written by scripts/summarize_profile.py); only valid for the default workload shape they were collected on
-    pmc = {}
-    pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(pmc_path) and args.sf == 100.0 and args.page_rows == 1 << 28:
-        pmc = json.load(open(pmc_path)).get("kernels", {})
-
-    if rank == 0:
-        queries = workload.queries
-        line = {
-            "metric": "rows/s through operator pipeline, TPC-H Q1+Q6 SF100, 1/2/4/8 GPUs vs CPU ref",
-            "value": value, "unit": "rows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
-            "config": {"workload": workload.workload_name(),
-                       "scale_factor_per_gpu": args.sf, "rows_per_gpu": workload.rows, "page_rows": args.page_rows,
-                       "page_order": args.page_order,
-                       "queries": queries, "parallelism": "row-range shards, %d rank(s), no data-path collective in Q1/Q6; "
-                                                          "Q3 (the `q3` object) shuffles its join sides between the ranks" % world},
-        }
-        r1 = workload.roofline("q1", args.steps, pmc) if "q1" in queries else None
-        r6 = workload.roofline("q6", args.steps, pmc) if "q6" in queries else None
-        line["roofline"] = r1 or r6
-        if r1 and r6:
-            line["roofline_q6"] = r6
-        if q3 is not None:
-            line["q3"] = q3
-        line["results"] = {k: [[x.decode() if isinstance(x, bytes) else x for x in r] for r in v] for k, v in workload.results.items()}
-        if world == 1 and args.h2d_rows > 0 and hasattr(workload, "h2d"):
-            try:
-                line["h2d"] = workload.h2d(args.h2d_rows)
-            except Exception as e:
-                line["h2d"] = {"error": "%s: %s" % (type(e).__name__, e)}
-        if world == 1 and args.cpu_rows > 0:
-            line["cpu_baseline"] = cpu_baseline(args.sf, args.cpu_rows)
-        print(json.dumps(line), file=out or sys.stdout, flush=True)
-    workload.close()
+    emit(q3)
+    if workload is not None:
+        workload.close()
     if world > 1:
-        dist.barrier()
+        dist.barrier()  # (still under the watchdog: a rank whose Q3 leg failed arrives here while the others wait inside a collective)
+        if watchdog is not None:
+            watchdog.cancel()
         dist.destroy_process_group()
 
 

@@ -306,3 +306,37 @@ def test_bench_control_flow_on_eight_gloo_ranks(oracle):
     got = sorted(union, key=lambda r: (-r[3], r[1]))[:10]
     assert len(expected) == 10 and [g[:3] for g in got] == [e[:3] for e in expected]
     assert all(abs(g[3] - e[3]) <= 1e-9 * abs(e[3]) for g, e in zip(got, expected))
+
+
+def bench_worker_one_rank_fails(rank, world, port, path):
+    sys.path.insert(0, ROOT)
+    os.environ.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "RANK": str(rank), "LOCAL_RANK": str(rank), "WORLD_SIZE": str(world)})
+    import bench
+    from tests.rehearsal_workload import RehearsalWorkload
+
+    class FailsOnRankOne(RehearsalWorkload):
+        def q3_step(self):
+            if self.rank == 1:
+                raise RuntimeError("rank 1 gives up before its first exchange")
+            return super().q3_step()
+
+    with open("%s.%d" % (path, rank), "w") as out:
+        bench.main(["--gpus", str(world), "--steps", "1", "--warmup", "1", "--sf", "0.002", "--cpu-rows", "0", "--backend", "gloo",
+                    "--q3-timeout", "8"], workload_factory=FailsOnRankOne, out=out)
+
+
+def test_bench_line_survives_a_rank_failing_inside_q3(oracle, tmp_path):
+    """One rank raising inside the Q3 leg leaves the others inside a collective: after --q3-timeout the headline line is
+    printed by rank 0 without the Q3 numbers and every rank leaves with exit code 0."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    port = free_port()
+    path = str(tmp_path / "line")
+    procs = [ctx.Process(target=bench_worker_one_rank_fails, args=(r, world, port, path)) for r in range(world)]
+    [p.start() for p in procs]
+    [p.join(timeout=120) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    text = open(path + ".0").read()
+    assert text.count("\n") == 1 and open(path + ".1").read() == ""
+    line = json.loads(text)
+    assert line["n_gpus"] == world and line["value"] > 0 and "error" in line["q3"]
