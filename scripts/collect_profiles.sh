@@ -10,14 +10,14 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 rm -rf $O/r_trace $O/r_fetch $O/r_write $O/r_q3
-timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d $O/r_trace -- python3 $R/bench.py --steps 5 --warmup 2 --cpu-rows 0 --q3 0 --h2d-rows 0 > $O/r_trace_bench.json 2> $O/r_trace.err
+timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d $O/r_trace -- python3 $R/bench.py --steps 5 --warmup 2 --cpu-rows 0 --q3 0 --h2d-rows 0 --sf300 0 > $O/r_trace_bench.json 2> $O/r_trace.err
 echo "trace done"
-timeout -k 10 240 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/r_fetch -- python3 $R/bench.py --steps 3 --warmup 1 --cpu-rows 0 --q3 0 --h2d-rows 0 > $O/r_fetch.json 2> $O/r_fetch.err
+timeout -k 10 240 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/r_fetch -- python3 $R/bench.py --steps 3 --warmup 1 --cpu-rows 0 --q3 0 --h2d-rows 0 --sf300 0 > $O/r_fetch.json 2> $O/r_fetch.err
 echo "fetch done"
-timeout -k 10 240 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/r_write -- python3 $R/bench.py --steps 3 --warmup 1 --cpu-rows 0 --q3 0 --h2d-rows 0 > $O/r_write.json 2> $O/r_write.err
+timeout -k 10 240 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/r_write -- python3 $R/bench.py --steps 3 --warmup 1 --cpu-rows 0 --q3 0 --h2d-rows 0 --sf300 0 > $O/r_write.json 2> $O/r_write.err
 echo "write done"
 cd $R
-timeout -k 10 300 python3 bench.py > $O/r_bench_default.json 2> $O/r_bench_default.err
+timeout -k 10 540 python3 bench.py > $O/r_bench_default.json 2> $O/r_bench_default.err
 echo "default bench done"
 cd /tmp
 timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d $O/r_q3 -- python3 $R/scripts/bench_q3.py --steps 5 --warmup 1 > $O/r_q3_bench.json 2> $O/r_q3.err
