@@ -694,6 +694,9 @@ int64_t pa_codegen_compile_fused(const pa_fused_aggregation_desc* desc, int32_t 
  * 0 GLOBAL, 1 LDS, 2 GT, 3 LDS table per workgroup, 6 BROW = accumulators indexed by build position) */
 int64_t pa_codegen_fused_join(const pa_fused_join_aggregation_desc* desc, const pa_hash_builder_desc* build, int32_t variant, char* buf, int64_t buf_size);
 int64_t pa_codegen_compile_fused_join(const pa_fused_join_aggregation_desc* desc, const pa_hash_builder_desc* build, int32_t variant);
+/* the FilterAndProject kernels with the probe inside: what pa_fused_join_create runs over a lookup source with unique keys */
+int64_t pa_codegen_fused_join_probe(const pa_fused_join_desc* desc, const pa_hash_builder_desc* build, char* buf, int64_t buf_size);
+int64_t pa_codegen_compile_fused_join_probe(const pa_fused_join_desc* desc, const pa_hash_builder_desc* build);
 int64_t pa_codegen_filter_project(const pa_filter_project_desc* desc, char* buf, int64_t buf_size, char* key);
 int64_t pa_codegen_compile_filter_project(const pa_filter_project_desc* desc);
 

@@ -62,6 +62,10 @@ def lib():
     L.pa_codegen_fused_join.restype = C.c_int64
     L.pa_codegen_compile_fused_join.argtypes = [C.POINTER(abi.pa_fused_join_aggregation_desc), C.POINTER(abi.pa_hash_builder_desc), C.c_int32]
     L.pa_codegen_compile_fused_join.restype = C.c_int64
+    L.pa_codegen_fused_join_probe.argtypes = [C.POINTER(abi.pa_fused_join_desc), C.POINTER(abi.pa_hash_builder_desc), C.c_char_p, C.c_int64]
+    L.pa_codegen_fused_join_probe.restype = C.c_int64
+    L.pa_codegen_compile_fused_join_probe.argtypes = [C.POINTER(abi.pa_fused_join_desc), C.POINTER(abi.pa_hash_builder_desc)]
+    L.pa_codegen_compile_fused_join_probe.restype = C.c_int64
     L.pa_filter_project_set_dynamic_filter.argtypes = [vp, C.c_int32, vp]
     L.pa_lookup_source_position_count.argtypes = [vp]
     L.pa_lookup_source_key_range.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]

@@ -1001,6 +1001,27 @@ int64_t pa_codegen_compile_fused_join(const pa_fused_join_aggregation_desc* desc
     return rc < 0 ? rc : size;
 }
 
+int64_t pa_codegen_fused_join_probe(const pa_fused_join_desc* desc, const pa_hash_builder_desc* build, char* buf, int64_t buf_size)
+{
+    int64_t need = 0;
+    int32_t rc = guarded([&]() -> int32_t {
+        std::string tu = jit_translation_unit(filter_project_probe_source_for_desc(desc, build));
+        need = (int64_t)tu.size() + 1;
+        if (buf && buf_size >= need) memcpy(buf, tu.c_str(), (size_t)need);
+        return PA_OK;
+    });
+    return rc < 0 ? rc : need;
+}
+int64_t pa_codegen_compile_fused_join_probe(const pa_fused_join_desc* desc, const pa_hash_builder_desc* build)
+{
+    int64_t size = 0;
+    int32_t rc = guarded([&]() -> int32_t {
+        size = (int64_t)jit_compile_only(filter_project_probe_source_for_desc(desc, build)).size();
+        return PA_OK;
+    });
+    return rc < 0 ? rc : size;
+}
+
 int64_t pa_codegen_filter_project(const pa_filter_project_desc* desc, char* buf, int64_t buf_size, char* key)
 {
     int64_t need = 0;

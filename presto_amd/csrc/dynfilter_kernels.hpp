@@ -9,7 +9,7 @@ namespace pa {
 // Distinct values of one fixed-width channel as canonical 64-bit keys: open addressing, one CAS per probe, no payload.
 // A slot holds kDfEmpty or a key; the key that equals kDfEmpty itself is tracked by a flag.
 constexpr uint64_t kDfEmpty = 0x8000000000000001ULL;
-constexpr int kDfBlocks = 256;  // grid of the collect kernel: bounds the inserts still in flight when the limit is reached
+constexpr int kDfBlocks = 1024;  // grid of the collect kernel: bounds the inserts still in flight when the limit is reached
 struct DfSet {
     uint64_t* keys;       // [cap]
     uint32_t cap_mask;

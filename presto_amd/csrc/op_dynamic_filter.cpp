@@ -16,6 +16,7 @@
 #include "operator.hpp"
 
 namespace pa {
+void launch_fill_u64(uint64_t* dst, uint64_t value, int64_t n, hipStream_t s);  // static_kernels.hip
 
 void launch_iota_i32(int32_t* dst, int64_t n, hipStream_t s);  // topn_kernels.hip
 
@@ -108,9 +109,7 @@ public:
                 ch.set.cap_mask = (uint32_t)(cap - 1);
                 ch.set.limit = (uint32_t)max_distinct_;
                 ch.set.counters = static_cast<uint32_t*>(ch.counters.ensure(64));
-                std::vector<uint64_t> fill(cap, kDfEmpty);
-                PA_HIP(hipMemcpyAsync(ch.set.keys, fill.data(), cap * 8, hipMemcpyHostToDevice, s));
-                PA_HIP(hipStreamSynchronize(s));
+                launch_fill_u64(ch.set.keys, kDfEmpty, (int64_t)cap, s);
                 PA_HIP(hipMemsetAsync(ch.set.counters, 0, 64, s));
                 PA_HIP(hipMemsetAsync(ch.running.ensure(64), 0, 64, s));
             }

@@ -3545,13 +3545,11 @@ pa_operator* make_fused_probe_aggregation(const pa_fused_join_aggregation_desc* 
     return new FusedAggregationOperator(make_spec(desc->filter_project, desc->aggregation, &desc->join, bridge), stream);
 }
 
-// the probe-stage kernels of a descriptor over a lookup source shaped like `build` (no device needed: nothing is allocated)
-std::string fused_join_source_for_desc(const pa_fused_join_aggregation_desc* desc, const pa_hash_builder_desc* build, int variant, std::string* entry)
+// a lookup source with the channels of `build` and nothing built: what the code generators need to know of the build side
+void lookup_source_shape_for_desc(const pa_hash_builder_desc* build, pa_lookup_source* bridge)
 {
-    PA_REQUIRE(desc != nullptr && build != nullptr, PA_ERR_INVALID_ARGUMENT, "descriptor is null");
-    pa_lookup_source bridge;
-    bridge.impl = std::make_shared<LookupSourceImpl>();
-    LookupSourceImpl& ls = *bridge.impl;
+    bridge->impl = std::make_shared<LookupSourceImpl>();
+    LookupSourceImpl& ls = *bridge->impl;
     PA_REQUIRE(build->input_channel_count > 0 && build->input_channel_count <= 32, PA_ERR_NOT_SUPPORTED, "1..32 build channels");
     ls.cols.resize(build->input_channel_count);
     for (int c = 0; c < build->input_channel_count; c++) ls.cols[c].type = build->input_types[c];
@@ -3563,6 +3561,14 @@ std::string fused_join_source_for_desc(const pa_fused_join_aggregation_desc* des
         PA_REQUIRE(build->output_channels[i] >= 0 && build->output_channels[i] < build->input_channel_count, PA_ERR_INVALID_ARGUMENT, "output channel out of range");
         ls.output_channels.push_back(build->output_channels[i]);
     }
+}
+
+// the probe-stage kernels of a descriptor over a lookup source shaped like `build` (no device needed: nothing is allocated)
+std::string fused_join_source_for_desc(const pa_fused_join_aggregation_desc* desc, const pa_hash_builder_desc* build, int variant, std::string* entry)
+{
+    PA_REQUIRE(desc != nullptr && build != nullptr, PA_ERR_INVALID_ARGUMENT, "descriptor is null");
+    pa_lookup_source bridge;
+    lookup_source_shape_for_desc(build, &bridge);
     Spec s = make_spec(desc->filter_project, desc->aggregation, &desc->join, &bridge);
     std::vector<ChannelLayout> layout(s.n_in);
     for (int c = 0; c < s.n_in; c++) layout[c].type = s.in_types[c];

@@ -546,13 +546,19 @@ def FusedJoinOperator(bridge, input_types, filter_expr, projections, probe_join_
     """[Scan]FilterAndProject -> LookupJoin (INNER) behind one handle (pa_fused_join_create): filter, probe and the join's output page
     [probe output channels, build output channels] in two passes over the page when the lookup source has a single integer key
     without duplicates; the two device operators otherwise."""
+    d, keep = fused_join_desc(input_types, filter_expr, projections, probe_join_channels, probe_output_channels, output_mem, stream, type_params)
+    h = C.c_void_p()
+    check(lib().pa_fused_join_create(C.byref(d), bridge._h, C.byref(h)))
+    return Operator(h, [keep, bridge])
+
+
+def fused_join_desc(input_types, filter_expr, projections, probe_join_channels, probe_output_channels, output_mem=abi.MEM_HOST, stream=None,
+                    type_params=None):
     d = abi.pa_fused_join_desc()
     fp, k1 = _filter_project_desc(input_types, filter_expr, projections, abi.MEM_DEVICE, stream, type_params)
     jd, k2 = _lookup_join_desc([p.type for p in projections], probe_join_channels, probe_output_channels, -1, output_mem, stream, abi.JOIN_INNER)
     d.filter_project, d.join = fp, jd
-    h = C.c_void_p()
-    check(lib().pa_fused_join_create(C.byref(d), bridge._h, C.byref(h)))
-    return Operator(h, [k1, k2, bridge])
+    return d, [k1, k2]
 
 
 def fused_join_aggregation_desc(input_types, filter_expr, projections, probe_join_channels, probe_output_channels, joined_types,

@@ -197,3 +197,30 @@ def test_jni_shim_compiles_against_the_header_and_matches_the_java_natives():
     from presto_amd._lib import lib
     for sym in set(re.findall(r"\b(pa_[a-z0-9_]+)\(", open(shim).read())):
         getattr(lib(), sym)
+
+
+def test_q3_orders_probe_inside_filter_and_project_generates_and_compiles_for_gfx950():
+    """FilterAndProject -> LookupJoin of Q3's orders pipeline (pa_fused_join_desc): the probe runs inside the FilterAndProject
+    kernels, the four rows of a quad side by side in both passes."""
+    from presto_amd import q3
+    from presto_amd.expr import field
+    from presto_amd.operators import fused_join_desc, hash_builder_desc
+    build, kb = hash_builder_desc([abi.BIGINT], [0], [])
+    projections = [field(i, t) for i, t in enumerate(tpch.ORDERS_TYPES)]
+    d, keep = fused_join_desc(tpch.ORDERS_TYPES, tpch.q3_orders_filter(), projections, [1], [0, 2, 3], output_mem=abi.MEM_DEVICE)
+    L = lib()
+    need = L.pa_codegen_fused_join_probe(C.byref(d), C.byref(build), None, 0)
+    assert need > 0, L.pa_last_error()
+    buf = C.create_string_buffer(need)
+    L.pa_codegen_fused_join_probe(C.byref(d), C.byref(build), buf, need)
+    src = buf.value.decode()
+    count = src[src.index("void pa_fp_count("):src.index("void pa_fp_scatter(")]
+    scatter = src[src.index("void pa_fp_scatter("):]
+    assert count.count("pa_keep(a, pa_k[") == 4 and "pa_join_probe4(a, pa_s, pa_k, pa_jb);" in count
+    assert scatter.count("pa_key_of(a") >= 4 and "pa_join_probe4(a, pa_s, pa_k, pa_jb);" in scatter and "pa_jb[3]" in scatter
+    assert L.pa_codegen_compile_fused_join_probe(C.byref(d), C.byref(build)) > 1000, L.pa_last_error()
+    # a build side that carries columns: they become output channels read at the build position
+    build2, kb2 = hash_builder_desc(q3.ORDERS_JOINED_TYPES, [0], [1, 2])
+    lp = [field(i, t) for i, t in enumerate(tpch.Q3_LINEITEM_TYPES)]
+    d2, keep2 = fused_join_desc(tpch.Q3_LINEITEM_TYPES, tpch.q3_lineitem_filter(), lp, [0], [0, 1, 2], output_mem=abi.MEM_DEVICE)
+    assert L.pa_codegen_compile_fused_join_probe(C.byref(d2), C.byref(build2)) > 1000, L.pa_last_error()
