@@ -439,6 +439,44 @@ __device__ __forceinline__ void pa_join_probe4(const A& a, const bool (&s)[4], c
     }
 }
 
+// Does the key find a build row at all?  The key bitmap holds exactly the non-NULL keys of the build side (every one sets its bit,
+// the range is their min .. max), so where it exists it IS the answer and the slot table is not touched: a join whose output carries
+// no build column -- and the counting pass of any join -- needs no build position.
+template <class A>
+__device__ __forceinline__ bool pa_join_exists_keyed(const A& a, const u64 v)
+{
+    if (a.jbits) {
+        const u64 d = (u64)((i64)v - a.jmin);
+        return d <= a.jrange && ((a.jbits[d >> 6] >> (d & 63ULL)) & 1ULL) != 0ULL;
+    }
+    return pa_join_probe_from(a, v, pa_join_home(a, v)) >= 0;
+}
+template <class A>
+__device__ __forceinline__ void pa_join_exists4(const A& a, const bool (&s)[4], const u64 (&k)[4], bool (&hit)[4])
+{
+    if (a.jbits) {
+        u64 d[4], w[4];
+        bool need[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            d[r] = (u64)((i64)k[r] - a.jmin);
+            need[r] = s[r] && d[r] <= a.jrange;
+            w[r] = 0ULL;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            if (need[r]) w[r] = a.jbits[d[r] >> 6];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; r++) hit[r] = need[r] && ((w[r] >> (d[r] & 63ULL)) & 1ULL) != 0ULL;
+        return;
+    }
+    i32 jb[4];
+    pa_join_probe4(a, s, k, jb);
+#pragma unroll
+    for (int r = 0; r < 4; r++) hit[r] = jb[r] >= 0;
+}
+
 // the replica of the group table this workgroup works on
 struct PaGtView {
     u64* tag;

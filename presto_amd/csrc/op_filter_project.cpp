@@ -259,7 +259,7 @@ FpKernelInfo generate_fp(const FpSpec& s, const std::vector<ChannelLayout>& layo
     const std::string names = row_param_names(ri, layout);
     if (probing) {
         src << "__device__ __forceinline__ bool pa_sel(const PaFpArgs& a" << params << ")\n{\nu64 pa_key;\n"
-            << "if (!pa_keep(a, pa_key" << names << ")) return false;\nreturn pa_join_probe_keyed(a, pa_key) >= 0;\n}\n";
+            << "if (!pa_keep(a, pa_key" << names << ")) return false;\nreturn pa_join_exists_keyed(a, pa_key);\n}\n";
     }
     if (s.join) {
         // a selected row's key once more (pa_fp_scatter: one row in ten is selected -- cheaper than carrying 4 B per row between the
@@ -336,10 +336,10 @@ FpKernelInfo generate_fp(const FpSpec& s, const std::vector<ChannelLayout>& layo
         src << "    const i64 q = ((i64)pa_tile * " << J << " + pa_j) * 256 + threadIdx.x;\n    const i64 row0 = q << 2;\n    u32 bits = 0;\n";
         src << "    if (a.vec && row0 + 4 <= a.n) {\n" << vloads.str();
         if (probing) {
-            src << "        bool pa_s[4]; u64 pa_k[4]; i32 pa_jb[4];\n";
+            src << "        bool pa_s[4], pa_hit[4]; u64 pa_k[4];\n";
             for (int r = 0; r < 4; r++) src << "        pa_s[" << r << "] = pa_keep(a, pa_k[" << r << "]" << vargs[r] << ");\n";
-            src << "        pa_join_probe4(a, pa_s, pa_k, pa_jb);\n";
-            for (int r = 0; r < 4; r++) src << "        if (pa_jb[" << r << "] >= 0) bits |= " << (1 << r) << "u;\n";
+            src << "        pa_join_exists4(a, pa_s, pa_k, pa_hit);\n";
+            for (int r = 0; r < 4; r++) src << "        if (pa_hit[" << r << "]) bits |= " << (1 << r) << "u;\n";
         }
         else {
             for (int r = 0; r < 4; r++) src << "        if (pa_sel(a" << vargs[r] << ")) bits |= " << (1 << r) << "u;\n";
@@ -371,7 +371,9 @@ FpKernelInfo generate_fp(const FpSpec& s, const std::vector<ChannelLayout>& layo
         src << "    if (row0 < a.n) {\n    const i64 left = a.n - row0;\n    const u32 bits = left >= 4 ? 15u : ((1u << left) - 1u);\n    i64 rank = row0;\n";
     }
     src << "    if (a.vec && row0 + 4 <= a.n) {\n" << vloads.str();
-    if (s.join) {
+    const bool carries = s.join && !s.join->build_cols.empty();  // (no build column in the output: the selected rows are the join's output)
+    if (s.join && !carries) src << "        const i32 pa_jb[4] = {-1, -1, -1, -1};\n";
+    if (carries) {
         src << "        bool pa_s[4]; u64 pa_k[4]; i32 pa_jb[4];\n";
         for (int r = 0; r < 4; r++) {
             src << "        pa_s[" << r << "] = (bits & " << (1 << r) << "u) != 0u;\n        pa_k[" << r << "] = pa_s[" << r << "] ? pa_key_of(a" << vargs[r] << ") : 0ULL;\n";
@@ -382,7 +384,7 @@ FpKernelInfo generate_fp(const FpSpec& s, const std::vector<ChannelLayout>& layo
         src << "        if (bits & " << (1 << r) << "u) { pa_out(a, rank, (i32)(row0 + " << r << ")" << (s.join ? ", pa_jb[" + std::to_string(r) + "]" : std::string()) << vargs[r] << "); rank++; }\n";
     }
     src << "    } else {\n        for (int i = 0; i < 4; i++) {\n            const i64 r = row0 + i;\n"
-           "            if (r < a.n && (bits & (1u << i))) { pa_out(a, rank, (i32)r" << (s.join ? ", pa_join_probe_keyed(a, pa_key_of(a" + sargs + "))" : std::string()) << sargs << "); rank++; }\n        }\n    }\n    }\n    }\n}\n";
+           "            if (r < a.n && (bits & (1u << i))) { pa_out(a, rank, (i32)r" << (carries ? ", pa_join_probe_keyed(a, pa_key_of(a" + sargs + "))" : (s.join ? std::string(", -1") : std::string())) << sargs << "); rank++; }\n        }\n    }\n    }\n    }\n}\n";
     k.source = src.str();
     return k;
 }

@@ -216,11 +216,19 @@ def test_q3_orders_probe_inside_filter_and_project_generates_and_compiles_for_gf
     src = buf.value.decode()
     count = src[src.index("void pa_fp_count("):src.index("void pa_fp_scatter(")]
     scatter = src[src.index("void pa_fp_scatter("):]
-    assert count.count("pa_keep(a, pa_k[") == 4 and "pa_join_probe4(a, pa_s, pa_k, pa_jb);" in count
-    assert scatter.count("pa_key_of(a") >= 4 and "pa_join_probe4(a, pa_s, pa_k, pa_jb);" in scatter and "pa_jb[3]" in scatter
+    # the counting pass asks whether a key exists (the key bitmap is exact: the slot table is only read where there is none)
+    assert count.count("pa_keep(a, pa_k[") == 4 and "pa_join_exists4(a, pa_s, pa_k, pa_hit);" in count
+    # no build column in the output: the second pass does not probe at all
+    assert "pa_join_probe4(" not in scatter and "pa_key_of(a" not in scatter
     assert L.pa_codegen_compile_fused_join_probe(C.byref(d), C.byref(build)) > 1000, L.pa_last_error()
     # a build side that carries columns: they become output channels read at the build position
     build2, kb2 = hash_builder_desc(q3.ORDERS_JOINED_TYPES, [0], [1, 2])
     lp = [field(i, t) for i, t in enumerate(tpch.Q3_LINEITEM_TYPES)]
     d2, keep2 = fused_join_desc(tpch.Q3_LINEITEM_TYPES, tpch.q3_lineitem_filter(), lp, [0], [0, 1, 2], output_mem=abi.MEM_DEVICE)
+    need = L.pa_codegen_fused_join_probe(C.byref(d2), C.byref(build2), None, 0)
+    buf = C.create_string_buffer(need)
+    L.pa_codegen_fused_join_probe(C.byref(d2), C.byref(build2), buf, need)
+    scatter2 = buf.value.decode()
+    scatter2 = scatter2[scatter2.index("void pa_fp_scatter("):]
+    assert scatter2.count("pa_key_of(a") >= 4 and "pa_join_probe4(a, pa_s, pa_k, pa_jb);" in scatter2 and "pa_jb[3]" in scatter2
     assert L.pa_codegen_compile_fused_join_probe(C.byref(d2), C.byref(build2)) > 1000, L.pa_last_error()
