@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 
 #include "join_kernels.hpp"
+#include "scan_kernels.hpp"
 #include "kernels/pa_device.h"
 
 namespace pa {
@@ -458,14 +459,56 @@ __global__ __launch_bounds__(256) void k_join_key_bitmap(JoinCol build_key, i32 
     }
 }
 
+// ---- key rank index (join_kernels.hpp) ----
+__global__ __launch_bounds__(256) void k_join_rank_counts(const u64* __restrict__ bits, i64 nwords, i32* __restrict__ counts)
+{
+    for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < nwords; i += (i64)gridDim.x * 256) counts[i] = (i32)__popcll(bits[i]);
+}
+__global__ __launch_bounds__(256) void k_join_rank_zip(const u64* __restrict__ bits, const i32* __restrict__ below, i64 nwords, JoinRankWord* __restrict__ words)
+{
+    for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < nwords; i += (i64)gridDim.x * 256) {
+        const u64 b = bits[i];
+        ((uint4*)words)[i] = uint4{(u32)b, (u32)(b >> 32), (u32)below[i], 0u};
+    }
+}
+__device__ __forceinline__ i32 join_rank_of(const JoinRankWord* __restrict__ words, const u64 d)
+{
+    const uint4 w = ((const uint4*)words)[d >> 6];
+    const u64 bits = ((u64)w.y << 32) | (u64)w.x;
+    const u32 b = (u32)(d & 63ULL);
+    if (((bits >> b) & 1ULL) == 0ULL) return -1;
+    return (i32)w.z + (i32)__popcll(bits & ((1ULL << b) - 1ULL));
+}
+__global__ __launch_bounds__(256) void k_join_rank_rows(JoinCol build_key, i32 n, const JoinRankWord* __restrict__ words, i64 min_key, i32* __restrict__ rows,
+                                                        i32* __restrict__ unordered)
+{
+    bool off = false;
+    for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < n; i += (i64)gridDim.x * 256) {
+        const i32 r = join_rank_of(words, (u64)((i64)join_key_bits(build_key, (i32)i) - min_key));  // (every build key has its bit)
+        if (r >= 0) rows[r] = (i32)i;
+        off = off || r != (i32)i;
+    }
+    if (__ballot(off) != 0ULL && (threadIdx.x & 63) == 0) *unordered = 1;
+}
+
 __global__ __launch_bounds__(256) void k_join_probe_count_keyed(JoinCol probe_key, const i64* __restrict__ probe_hash, i32 n_probe,
                                                                 const JoinKeySlot* __restrict__ slots, u32 mask, u32 wrap, const i32* __restrict__ links,
-                                                                JoinKeyBitmap bitmap, i32* __restrict__ head, i32* __restrict__ counts, int flags)
+                                                                JoinKeyBitmap bitmap, JoinRankIndex rank, i32* __restrict__ head, i32* __restrict__ counts, int flags)
 {
     for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < n_probe; i += (i64)gridDim.x * 256) {
         const i32 r = (i32)i;
         i32 h = -1, nxt = -1;
         bool may_match = !jcol_is_null(probe_key, r);  // JoinProbe.java:89-91
+        if (rank.words) {  // (no duplicate keys: the key's rank names its only build row)
+            if (may_match) {
+                const u64 d = (u64)((i64)join_key_bits(probe_key, r) - rank.min_key);
+                if (d <= rank.range) {
+                    h = join_rank_of(rank.words, d);
+                    if (h >= 0 && rank.rows) h = rank.rows[h];
+                }
+            }
+            may_match = false;
+        }
         if (may_match && bitmap.bits) {
             const u64 d = (u64)((i64)join_key_bits(probe_key, r) - bitmap.min_key);
             may_match = d <= bitmap.range && ((bitmap.bits[d >> 6] >> (d & 63ULL)) & 1ULL) != 0ULL;
@@ -587,12 +630,27 @@ void launch_join_key_bitmap(const JoinCol& build_key, int32_t n, int64_t min_key
     hipLaunchKernelGGL(k_join_key_bitmap, grid_for(n), 256, 0, s, build_key, n, (i64)min_key, (u64)range, (u64*)bits);
     PA_HIP(hipGetLastError());
 }
+void launch_join_rank_words(const uint64_t* bits, int64_t nwords, JoinRankWord* words, int32_t* counts, void* temp, int32_t* total_out, hipStream_t s)
+{
+    if (nwords <= 0) return;
+    hipLaunchKernelGGL(k_join_rank_counts, grid_for(nwords), 256, 0, s, (const u64*)bits, (i64)nwords, counts);
+    launch_exclusive_scan_i32(counts, counts, nwords, total_out, temp, s);
+    hipLaunchKernelGGL(k_join_rank_zip, grid_for(nwords), 256, 0, s, (const u64*)bits, (const i32*)counts, (i64)nwords, words);
+    PA_HIP(hipGetLastError());
+}
+void launch_join_rank_rows(const JoinCol& build_key, int32_t n, const JoinRankWord* words, int64_t min_key, int32_t* rows, int32_t* unordered, hipStream_t s)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_join_rank_rows, grid_for(n), 256, 0, s, build_key, n, words, (i64)min_key, rows, unordered);
+    PA_HIP(hipGetLastError());
+}
 void launch_join_probe_count_keyed(const JoinCol& probe_key, const int64_t* probe_hash, int32_t n_probe, const JoinKeySlot* slots, uint32_t mask,
-                                   uint32_t wrap, const int32_t* links, const JoinKeyBitmap& bitmap, int32_t* head, int32_t* counts, int flags, hipStream_t s)
+                                   uint32_t wrap, const int32_t* links, const JoinKeyBitmap& bitmap, const JoinRankIndex& rank, int32_t* head, int32_t* counts,
+                                   int flags, hipStream_t s)
 {
     if (n_probe <= 0) return;
     hipLaunchKernelGGL(k_join_probe_count_keyed, grid_for(n_probe), 256, 0, s, probe_key, (const i64*)probe_hash, n_probe, slots, mask, wrap, links, bitmap,
-                       head, counts, flags);
+                       rank, head, counts, flags);
     PA_HIP(hipGetLastError());
 }
 

@@ -66,10 +66,32 @@ void launch_join_part_build(const uint64_t* keys, const int32_t* rows, const int
 // every `next` is -1 otherwise, which is what the build leaves)
 void launch_join_keyed_links(int32_t n, JoinKeySlot* slots, uint32_t slots_mask, const int32_t* slot_of, int32_t* links, hipStream_t s);
 void launch_join_key_bitmap(const JoinCol& build_key, int32_t n, int64_t min_key, uint64_t range, uint64_t* bits, hipStream_t s);
+// Key rank index: the bitmap's words, each with the number of build keys below it.  Over a build side WITHOUT duplicate keys the rank
+// of a key among the build keys -- below + popcount(bits under the key's bit) -- names its build row: directly when the rows arrived
+// in key order (rows == null), through rows[rank] otherwise.  One 16-byte load answers a probe (does the key exist, and where), where
+// the slot table takes the bitmap word plus one or two 64-byte lines at a random place; and nothing has to be hashed, regrouped or
+// inserted to build it.
+struct JoinRankWord {
+    uint64_t bits;
+    uint32_t below;
+    uint32_t pad;
+};
+struct JoinRankIndex {
+    const JoinRankWord* words;  // null = none
+    const int32_t* rows;        // rank -> build position, or null when rank == build position
+    int64_t min_key;
+    uint64_t range;
+};
+// words[i] = {bits[i], number of set bits in bits[0 .. i)}; *total_out (device) = number of set bits = distinct build keys.
+// counts: nwords int32 of scratch; temp: scan_temp_bytes(nwords)
+void launch_join_rank_words(const uint64_t* bits, int64_t nwords, JoinRankWord* words, int32_t* counts, void* temp, int32_t* total_out, hipStream_t s);
+// rows[rank(key of build row i)] = i for all rows (no NULL keys); *unordered (device, zeroed by the caller) = 1 when some rank != i
+void launch_join_rank_rows(const JoinCol& build_key, int32_t n, const JoinRankWord* words, int64_t min_key, int32_t* rows, int32_t* unordered, hipStream_t s);
 // wrap = mask, or kJoinPartSlots - 1 for a table built in partitions (the probe sequence of a key then stays inside the
 // kJoinPartSlots-slot partition of its home slot)
 void launch_join_probe_count_keyed(const JoinCol& probe_key, const int64_t* probe_hash, int32_t n_probe, const JoinKeySlot* slots, uint32_t mask,
-                                   uint32_t wrap, const int32_t* links, const JoinKeyBitmap& bitmap, int32_t* head, int32_t* counts, int flags, hipStream_t s);
+                                   uint32_t wrap, const int32_t* links, const JoinKeyBitmap& bitmap, const JoinRankIndex& rank, int32_t* head, int32_t* counts,
+                                   int flags, hipStream_t s);
 void launch_join_unvisited_flag(const uint8_t* visited, int64_t n, int32_t* partition, hipStream_t s);
 // DefaultPageJoiner.joinCurrentPosition: (probe position, build position) pairs in emission order
 void launch_join_probe_emit(const int32_t* head, const int32_t* offsets, int32_t n_probe, int32_t total, const int32_t* links, int32_t* probe_idx,

@@ -35,6 +35,10 @@ struct LookupSourceImpl {
     uint32_t probe_wrap = 0;    // probe sequences wrap inside (slot & ~probe_wrap): probe_mask, or kJoinPartSlots - 1 after a partitioned build
     DevBuf key_bits;            // existence bitmap over [key_min, key_min + key_range] (keyed joins with a dense enough key range)
     JoinKeyBitmap bitmap{nullptr, 0, 0};
+    // key rank index (join_kernels.hpp): built instead of key_slots over a keyed build side with a bitmap, no NULL key and no duplicate
+    // key -- every probe (LookupJoinOperator's, the fused ones) then goes through it and key_slots stays empty
+    DevBuf rank_words, rank_rows;
+    JoinRankIndex rank{nullptr, nullptr, 0, 0};
     bool reference_built = false;  // PagesHash.key[] (the reference's layout) exists; keyed joins build it on demand
     bool key_range_valid = false;  // keyed join with at least one non-NULL build key: [key_min, key_max]
     int64_t key_min = 0, key_max = 0;

@@ -337,6 +337,10 @@ struct PaFusedArgs {
     u32 jpad;
     const void* bv[PA_MAX_BUILD_CHANNELS];
     const u8* bn[PA_MAX_BUILD_CHANNELS];
+    // key rank index (join_kernels.hpp JoinRankIndex; null = none, the slot table answers): 16-byte words {64 key bits, build keys
+    // below the word} over [jmin, jmin + jrange], and rank -> build position (null: the rank is the position)
+    const pa_u32x4* jrank;
+    const i32* jrank_rows;
 };
 
 // JoinProbe.getCurrentJoinPosition for a keyed lookup source without duplicate keys (…/operator/join/JoinProbe.java:87-117,
@@ -367,9 +371,23 @@ __device__ __forceinline__ i32 pa_join_probe_from(const A& a, const u64 v, u32 p
 }
 template <class A>
 __device__ __forceinline__ u32 pa_join_home(const A& a, const u64 v) { return (u32)pa_murmur3_fmix((u64)pa_hash_bigint((i64)v)) & a.jmask; }
+// rank of the key at distance d from the bitmap's first key, from its rank word; -1 = not a build key
+__device__ __forceinline__ i32 pa_join_rank(const pa_u32x4 w, const u64 d)
+{
+    const u64 bits = ((u64)w.y << 32) | (u64)w.x;
+    const u32 b = (u32)(d & 63ULL);
+    if (((bits >> b) & 1ULL) == 0ULL) return -1;
+    return (i32)w.z + (i32)__popcll(bits & ((1ULL << b) - 1ULL));
+}
 template <class A>
 __device__ __forceinline__ i32 pa_join_probe_keyed(const A& a, const u64 v)
 {
+    if (a.jrank) {  // the key's rank among the build keys names its build row (no duplicate keys)
+        const u64 d = (u64)((i64)v - a.jmin);
+        if (d > a.jrange) return -1;
+        const i32 r = pa_join_rank(a.jrank[d >> 6], d);
+        return (r >= 0 && a.jrank_rows) ? a.jrank_rows[r] : r;
+    }
     if (a.jbits) {
         const u64 d = (u64)((i64)v - a.jmin);
         if (d > a.jrange || ((a.jbits[d >> 6] >> (d & 63ULL)) & 1ULL) == 0ULL) return -1;
@@ -389,6 +407,34 @@ __device__ __forceinline__ void pa_join_probe4(const A& a, const bool (&s)[4], c
     for (int r = 0; r < 4; r++) {
         dup[r] = r > 0 && s[r] && s[r - 1] && k[r] == k[r - 1];
         need[r] = s[r] && !dup[r];
+    }
+    if (a.jrank) {  // one 16-byte load per row: does the key exist, and its rank = its build row
+        u64 d[4];
+        pa_u32x4 w[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            d[r] = (u64)((i64)k[r] - a.jmin);
+            need[r] = need[r] && d[r] <= a.jrange;
+            w[r] = pa_u32x4{0u, 0u, 0u, 0u};
+        }
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            if (need[r]) w[r] = a.jrank[d[r] >> 6];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; r++) jb[r] = need[r] ? pa_join_rank(w[r], d[r]) : -1;
+        if (a.jrank_rows) {
+            i32 p[4];
+#pragma unroll
+            for (int r = 0; r < 4; r++) p[r] = jb[r] >= 0 ? a.jrank_rows[jb[r]] : -1;
+#pragma unroll
+            for (int r = 0; r < 4; r++) jb[r] = p[r];
+        }
+#pragma unroll
+        for (int r = 1; r < 4; r++) {
+            if (dup[r]) jb[r] = jb[r - 1];
+        }
+        return;
     }
     if (a.jbits) {
         u64 d[4], w[4];
@@ -761,6 +807,8 @@ struct PaFpArgs {
     u32 jwrap;
     const void* bv[PA_MAX_BUILD_CHANNELS];
     const u8* bn[PA_MAX_BUILD_CHANNELS];
+    const pa_u32x4* jrank;          // key rank index, as in PaFusedArgs
+    const i32* jrank_rows;
 };
 // can a probe row with this key match any build row?  (exact inside the bitmap's range; NULL keys never match)
 __device__ __forceinline__ bool pa_dyn_test(const PaFpArgs& a, const i64 key)

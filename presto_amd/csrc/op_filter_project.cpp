@@ -77,6 +77,8 @@ struct FpArgs {  // host mirror of PaFpArgs
     uint32_t jwrap;
     const void* bv[kMaxBuildChannels];
     const uint8_t* bn[kMaxBuildChannels];
+    const void* jrank;
+    const int32_t* jrank_rows;
 };
 
 // Probe stage (FilterAndProject -> LookupJoin (INNER) in one pass; pa_fused_join_create): a row is selected when the filter keeps it
@@ -470,6 +472,8 @@ public:
             a.jbits = ls.bitmap.bits;
             a.jmin = ls.bitmap.min_key;
             a.jrange = ls.bitmap.range;
+            a.jrank = ls.rank.words;
+            a.jrank_rows = ls.rank.rows;
             for (size_t v = 0; v < spec_.join->build_cols.size(); v++) {
                 const BuildColumn& bc = ls.cols[(size_t)spec_.join->build_cols[v]];
                 a.bv[v] = bc.values.ptr();

@@ -111,6 +111,8 @@ struct FusedArgs {
     uint32_t jpad;
     const void* bv[kMaxBuildChannels];
     const uint8_t* bn[kMaxBuildChannels];
+    const void* jrank;
+    const int32_t* jrank_rows;
 };
 
 // V_LDSP: the LDS-table variant with partition-owned tables (see PaFusedArgs::sub_tag)
@@ -2380,6 +2382,8 @@ private:
         a.jbits = ls.bitmap.bits;
         a.jmin = ls.bitmap.min_key;
         a.jrange = ls.bitmap.range;
+        a.jrank = ls.rank.words;
+        a.jrank_rows = ls.rank.rows;
         a.jrows = ls.n;
         for (size_t v = 0; v < js.build_cols.size(); v++) {
             const BuildColumn& bc = ls.cols[js.build_cols[v]];

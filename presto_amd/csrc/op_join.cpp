@@ -163,35 +163,19 @@ public:
         while (slots < 2 * (uint64_t)std::max(n, 1)) slots <<= 1;
         PA_REQUIRE(slots <= (1ULL << 31), PA_ERR_INSUFFICIENT_RESOURCES, "join build side too large");
         ls_->probe_mask = (uint32_t)(slots - 1);
+        bool keyed_dups = false;
         timer.begin(s);
         if (ls_->keyed) {
-            // one integer key: the probe-side table is built straight from the build rows; the raw hash comes from the $hashvalue
-            // channel when there is one, else from the key inside the kernel.  PagesHash.key[] is built when somebody asks for it.
-            const int64_t* raw = nullptr;
-            if (ls_->hash_channel >= 0 && n > 0) raw = ls_->cols[ls_->hash_channel].values.as<int64_t>();
-            JoinKeySlot* table = static_cast<JoinKeySlot*>(ls_->key_slots.ensure((size_t)slots * sizeof(JoinKeySlot)));
-            ls_->probe_wrap = ls_->probe_mask;
-            bool done = false;
-            // large build sides: rows regrouped by the partition of their home slot, tables assembled in LDS and written once
-            // (join_kernels.hip).  It leaves no slot_of, so chains (duplicate keys) -- and partitions too full, which a decent hash
-            // does not produce -- are built the other way
-            const int64_t partitions = (int64_t)slots >> kJoinPartSlotsLog2;
-            if (n >= (1 << 20) && partitions >= 2 && partitions <= 4096 && !getenv("PRESTO_AMD_NO_PARTITIONED_BUILD")) {
-                done = partitioned_build(bk.col[0], n, table, (int32_t)partitions, s);
-                if (done) ls_->probe_wrap = (uint32_t)kJoinPartSlots - 1u;
-            }
-            int32_t dups = 0;
-            if (!done) {
-                PA_HIP(hipMemsetAsync(ctl_ + 1, 0, 8, s));
-                launch_join_keyed_build(bk.col[0], raw, n, table, ls_->probe_mask, ls_->slot_of.as<int32_t>(), ls_->links.as<int32_t>(), ctl_, s);
-                // (the key range read-back below waits for the stream anyway: the duplicate flag rides along)
-                PA_HIP(hipMemcpyAsync(&dups, ctl_ + 1, 4, hipMemcpyDeviceToHost, s));
-            }
+            // one integer key.  Key range and bitmap first: over a dense enough key range without NULL or duplicate keys the key rank
+            // index is the whole lookup structure and no table is built
             if (n > 0) build_key_bitmap(bk.col[0], n, s);
             else PA_HIP(hipStreamSynchronize(s));
+            int32_t dups = 0;
+            if (!build_rank_index(bk.col[0], n, s)) dups = build_key_slots(bk.col[0], n, slots, s);
             // chains exist only when some key has several rows: two passes over the rows and the table that unique keys -- the build
             // side of a primary-key join -- do without
-            if (dups) launch_join_keyed_links(n, table, ls_->probe_mask, ls_->slot_of.as<int32_t>(), ls_->links.as<int32_t>(), s);
+            if (dups) launch_join_keyed_links(n, ls_->key_slots.as<JoinKeySlot>(), ls_->probe_mask, ls_->slot_of.as<int32_t>(), ls_->links.as<int32_t>(), s);
+            keyed_dups = dups != 0;
         }
         else {
             compute_raw_hash(bk, n, s);
@@ -208,10 +192,64 @@ public:
         PA_HIP(hipMemcpyAsync(ctl, ctl_, 8, hipMemcpyDeviceToHost, s));
         PA_HIP(hipStreamSynchronize(s));
         const int32_t err = ctl[0];
-        ls_->has_duplicates = !ls_->keyed || ctl[1] != 0;
+        ls_->has_duplicates = !ls_->keyed || keyed_dups;
         ls_->error.store(err);
         ls_->built.store(true);  // lendPartitionLookupSource: probes may proceed
         if (err) throw Error(err, "hash build failed on device");
+    }
+
+    // The probe-side table straight from the build rows (the raw hash from the $hashvalue channel when there is one, else from the
+    // key inside the kernel); PagesHash.key[] is built when somebody asks for it.  Returns whether some key has several rows.
+    int32_t build_key_slots(const JoinCol& key, int32_t n, uint64_t slots, hipStream_t s)
+    {
+        const int64_t* raw = nullptr;
+        if (ls_->hash_channel >= 0 && n > 0) raw = ls_->cols[ls_->hash_channel].values.as<int64_t>();
+        JoinKeySlot* table = static_cast<JoinKeySlot*>(ls_->key_slots.ensure((size_t)slots * sizeof(JoinKeySlot)));
+        ls_->probe_wrap = ls_->probe_mask;
+        // large build sides: rows regrouped by the partition of their home slot, tables assembled in LDS and written once
+        // (join_kernels.hip).  It leaves no slot_of, so chains (duplicate keys) -- and partitions too full, which a decent hash
+        // does not produce -- are built the other way
+        const int64_t partitions = (int64_t)slots >> kJoinPartSlotsLog2;
+        if (n >= (1 << 20) && partitions >= 2 && partitions <= 4096 && !getenv("PRESTO_AMD_NO_PARTITIONED_BUILD")) {
+            if (partitioned_build(key, n, table, (int32_t)partitions, s)) {
+                ls_->probe_wrap = (uint32_t)kJoinPartSlots - 1u;
+                return 0;
+            }
+        }
+        int32_t dups = 0;
+        PA_HIP(hipMemsetAsync(ctl_ + 1, 0, 8, s));
+        launch_join_keyed_build(key, raw, n, table, ls_->probe_mask, ls_->slot_of.as<int32_t>(), ls_->links.as<int32_t>(), ctl_, s);
+        PA_HIP(hipMemcpyAsync(&dups, ctl_ + 1, 4, hipMemcpyDeviceToHost, s));
+        PA_HIP(hipStreamSynchronize(s));
+        return dups;
+    }
+
+    // The key rank index (join_kernels.hpp) from the key bitmap; false = the build side does not qualify (no bitmap, NULL keys,
+    // duplicate keys) and the slot table is built.  PRESTO_AMD_NO_RANK_INDEX=1 turns it off (A/B runs, tests of the table builds).
+    bool build_rank_index(const JoinCol& key, int32_t n, hipStream_t s)
+    {
+        if (ls_->bitmap.bits == nullptr || key.nulls != nullptr || n <= 0 || getenv("PRESTO_AMD_NO_RANK_INDEX")) return false;
+        const int64_t nwords = (int64_t)(ls_->bitmap.range >> 6) + 1;
+        DevBuf counts, temp;
+        JoinRankWord* words = static_cast<JoinRankWord*>(ls_->rank_words.ensure((size_t)nwords * sizeof(JoinRankWord)));
+        PA_HIP(hipMemsetAsync(ctl_ + 4, 0, 8, s));
+        launch_join_rank_words(ls_->bitmap.bits, nwords, words, static_cast<int32_t*>(counts.ensure((size_t)nwords * 4)), temp.ensure(scan_temp_bytes(nwords)),
+                               ctl_ + 4, s);
+        // (rows of duplicate keys overwrite each other below: the index is dropped then)
+        int32_t* rows = static_cast<int32_t*>(ls_->rank_rows.ensure((size_t)n * 4));
+        launch_join_rank_rows(key, n, words, ls_->bitmap.min_key, rows, ctl_ + 5, s);
+        int32_t h[2] = {0, 0};  // distinct keys, some row not at its rank
+        PA_HIP(hipMemcpyAsync(h, ctl_ + 4, 8, hipMemcpyDeviceToHost, s));
+        PA_HIP(hipStreamSynchronize(s));
+        if (h[0] != n) {  // some key on several rows
+            ls_->rank_words.release();
+            ls_->rank_rows.release();
+            return false;
+        }
+        if (!h[1]) ls_->rank_rows.release();  // build rows in key order: rank == build position
+        ls_->rank = JoinRankIndex{words, h[1] ? rows : nullptr, ls_->bitmap.min_key, ls_->bitmap.range};
+        launch_fill_i32(ls_->links.as<int32_t>(), -1, n, s);
+        return true;
     }
 
     // true: `table` holds the keyed probe-side table, built partition by partition (links stay -1: no key has several rows)
@@ -272,7 +310,7 @@ public:
     bool is_finished() override { return finishing_; }
     int64_t memory_bytes() override
     {
-        int64_t b = (int64_t)(ls_->key.capacity() + ls_->links.capacity() + ls_->raw_hash.capacity() + ls_->slot_of.capacity() + ls_->tagged.capacity() + ls_->key_slots.capacity() + ls_->key_bits.capacity());
+        int64_t b = (int64_t)(ls_->key.capacity() + ls_->links.capacity() + ls_->raw_hash.capacity() + ls_->slot_of.capacity() + ls_->tagged.capacity() + ls_->key_slots.capacity() + ls_->key_bits.capacity() + ls_->rank_words.capacity() + ls_->rank_rows.capacity());
         for (const auto& c : ls_->cols) b += (int64_t)(c.values.capacity() + c.offsets.capacity() + c.nulls.capacity());
         return b;
     }
@@ -375,7 +413,7 @@ public:
         int32_t* counts = static_cast<int32_t*>(counts_.ensure((size_t)n * 4));
         timer.begin(s);
         if (ls_->keyed) {  // one integer key: key-in-slot table, raw hash computed in the kernel unless a $hashvalue channel came along
-            launch_join_probe_count_keyed(pk.col[0], probe_hash, n, ls_->key_slots.as<JoinKeySlot>(), ls_->probe_mask, ls_->probe_wrap, ls_->links.as<int32_t>(), ls_->bitmap, head, counts,
+            launch_join_probe_count_keyed(pk.col[0], probe_hash, n, ls_->key_slots.as<JoinKeySlot>(), ls_->probe_mask, ls_->probe_wrap, ls_->links.as<int32_t>(), ls_->bitmap, ls_->rank, head, counts,
                                           probe_flags_, s);
         }
         else {

@@ -28,10 +28,11 @@ def probe_pages(rng, pages, n, key_range, null_keys=True, clustered=False):
     return out
 
 
-def build_page(rng, keys, nullable=True):
+def build_page(rng, keys, nullable=True, null_keys=None):
     n = len(keys)
     nulls = (lambda p: rng.random(n) < p) if nullable else (lambda p: None)
-    return Page([Block.bigint(keys, nulls(0.02)), Block.date(rng.integers(8000, 8100, n), nulls(0.2)), Block.integer(rng.integers(0, 3, n)),
+    key_nulls = nulls(0.02) if null_keys is None or null_keys else None
+    return Page([Block.bigint(keys, key_nulls), Block.date(rng.integers(8000, 8100, n), nulls(0.2)), Block.integer(rng.integers(0, 3, n)),
                  Block.double(rng.random(n), nulls(0.1)), Block.boolean(rng.random(n) < 0.5)], n)
 
 
@@ -84,13 +85,18 @@ AGGS = [(abi.AGG_SUM, 1, abi.DOUBLE), (abi.AGG_COUNT_STAR, -1, None), (abi.AGG_S
 
 @pytest.mark.parametrize("case", ["build_rows", "hashed", "few_groups", "global"])
 @pytest.mark.parametrize("n", [1, 777, 70000])
-def test_fused_probe_matches_oracle(gpu, oracle, case, n):
+@pytest.mark.parametrize("lookup", ["table", "rank", "rank, rows in key order"])
+def test_fused_probe_matches_oracle(gpu, oracle, case, n, lookup):
     """Unique build keys: the one-kernel execution.  build_rows: group by (probe key, build date, build priority) -- the group is
     the build row; hashed: group by (probe day, build priority); few_groups: group by the build priority alone; global: no keys.
-    NULL probe keys and NULL build keys match nothing; NULL build values are group key values."""
+    NULL probe keys and NULL build keys match nothing; NULL build values are group key values.  lookup: NULL build keys leave the
+    lookup to the slot table, without them the key rank index answers (build rows shuffled, or arriving in key order)."""
     rng = np.random.default_rng(n + len(case))
     key_range = max(4 * n // 3, 8)
-    build = [build_page(rng, rng.permutation(key_range)[: max(key_range // 2, 1)])]
+    keys = rng.permutation(key_range)[: max(key_range // 2, 1)]
+    if lookup == "rank, rows in key order":
+        keys = np.sort(keys)
+    build = [build_page(rng, keys, null_keys=(lookup == "table"))]
     probe = probe_pages(rng, 3, n, key_range, clustered=(n == 70000))
     probe_out, build_out = [0, 1, 2, 3], [1, 2, 3]          # joined page: key, amount, quantity, day, date, priority, weight
     group_by = {"build_rows": [0, 4, 5], "hashed": [3, 5], "few_groups": [5], "global": []}[case]
@@ -256,14 +262,14 @@ def joined_rows_device(probe, build, build_out, probe_out, flt=FILTER, output_me
 
 
 @pytest.mark.parametrize("n", [1, 1000, 70000])
-@pytest.mark.parametrize("duplicates", [False, True])
-def test_fused_join_rows_and_order(gpu, oracle, n, duplicates):
+@pytest.mark.parametrize("duplicates,null_keys", [(False, True), (True, True), (False, False)])
+def test_fused_join_rows_and_order(gpu, oracle, n, duplicates, null_keys):
     """FilterAndProject -> LookupJoin: the same rows in the same (probe) order as the oracle's two operators -- through the
     one-pass form (unique build keys) and through the operator chain (duplicate keys: matches of a row in chain order)."""
     rng = np.random.default_rng(n + duplicates)
     key_range = max(4 * n // 3, 8)
     keys = rng.integers(0, key_range, max(key_range // 2, 1)) if duplicates else rng.permutation(key_range)[: max(key_range // 2, 1)]
-    build = [build_page(rng, keys)]
+    build = [build_page(rng, keys, null_keys=null_keys)]   # (no NULL and no duplicate key: the key rank index instead of the table)
     probe = probe_pages(rng, 3, n, key_range, clustered=(n == 70000))
     for probe_out, build_out in (([0, 1, 2, 3], [1, 2, 3, 4]), ([3, 1], [2]), ([0], [])):
         expected = joined_rows_oracle(oracle, probe, build, build_out, probe_out)

@@ -139,7 +139,7 @@ def test_large_build_side_is_built_in_partitions(gpu, oracle, key_type, duplicat
             assert np.array_equal(gp, op_) and np.array_equal(gb, ob)
 
 
-def test_partitioned_build_with_an_overfull_partition_falls_back(gpu, oracle):
+def test_partitioned_build_with_an_overfull_partition_falls_back(gpu, oracle, monkeypatch):
     """Keys chosen so that more of them have their home slot in ONE 8192-slot partition than the partition may hold: the build
     notices (no slot is dropped, nothing overflows the LDS table) and assembles the table slot by slot instead."""
     P1, P2 = np.uint64(0x9E3779B185EBCA87), np.uint64(0xC2B2AE3D27D4EB4F)
@@ -155,6 +155,7 @@ def test_partitioned_build_with_an_overfull_partition_falls_back(gpu, oracle):
             h ^= h >> np.uint64(33)
         return h & np.uint64(mask)
 
+    monkeypatch.setenv("PRESTO_AMD_NO_RANK_INDEX", "1")  # (dense unique keys: the rank index would stand in for the table)
     nb = (1 << 20) + 5000
     slots = 1 << 22                                   # the probe-side table of nb rows: >= 2 nb slots, a power of two
     cand = np.arange(1, 6_000_000, dtype=np.int64)
@@ -171,6 +172,63 @@ def test_partitioned_build_with_an_overfull_partition_falls_back(gpu, oracle):
     rows, pairs, _ = gpu_join(build, types, [0], [1], probe, types, [0], [0, 1])
     orows, opairs, _ = oracle_join(oracle, build, types, [0], [1], probe, types, [0], [0, 1])
     assert rows == orows and len(rows) > 5000
+
+
+@pytest.mark.parametrize("key_type", [abi.BIGINT, abi.INTEGER, abi.DATE])
+@pytest.mark.parametrize("order", ["key order", "shuffled", "descending"])
+@pytest.mark.parametrize("nb", [1, 777, 300_001])
+def test_unique_dense_keys_are_looked_up_by_rank(gpu, oracle, key_type, order, nb, monkeypatch):
+    """A build side with one integer key, no NULL and no duplicate key over a dense enough range is looked up through the key rank
+    index (bitmap words with running counts; the rank of a key names its build row, directly when the rows came in key order) and no
+    table is built.  Same rows and (probe, build) pairs as the oracle and as the table (PRESTO_AMD_NO_RANK_INDEX=1)."""
+    rng = np.random.default_rng(nb + len(order))
+    dtype = np.int64 if key_type == abi.BIGINT else np.int32
+    base = -5_000_000_000 if key_type == abi.BIGINT else -1000
+    keys = (np.sort(rng.permutation(4 * nb + 100)[:nb]) * 3 + base).astype(dtype)   # unique, sparse (x3), 64 words and more
+    if order == "shuffled":
+        keys = keys[rng.permutation(nb)]
+    elif order == "descending":
+        keys = keys[::-1].copy()
+    kb = {abi.BIGINT: Block.bigint, abi.INTEGER: Block.integer, abi.DATE: Block.date}[key_type]
+    build = Page([kb(keys), Block.double(rng.random(nb)), Block.integer(np.arange(nb))], nb)
+    bpages = [build] if nb < 1000 else [build.get_region(0, 1000), build.get_region(1000, nb - 1000)]
+    npr = 50_000
+    pk = np.where(rng.random(npr) < 0.5, keys[rng.integers(0, nb, npr)], (rng.integers(-200, 12 * nb + 500, npr) + base)).astype(dtype)
+    pk[:4] = [keys.min(), keys.max(), keys.min() - 1, keys.max() + 1]
+    probe = [Page([kb(pk, rng.random(npr) < 0.03), Block.integer(np.arange(npr))], npr)]
+    btypes, ptypes = [key_type, abi.DOUBLE, abi.INTEGER], [key_type, abi.INTEGER]
+    orows, opairs, _ = oracle_join(oracle, bpages, btypes, [0], [1, 2], probe, ptypes, [0], [0, 1])
+    assert len(orows) > npr // 3
+    for switch in (None, "1"):
+        if switch:
+            monkeypatch.setenv("PRESTO_AMD_NO_RANK_INDEX", switch)
+        rows, pairs, _ = gpu_join(bpages, btypes, [0], [1, 2], probe, ptypes, [0], [0, 1])
+        assert rows == orows
+        for (gp, gb), (op_, ob) in zip(pairs, opairs):
+            assert np.array_equal(gp, op_) and np.array_equal(gb, ob)
+
+
+@pytest.mark.parametrize("spoiler", ["duplicate key", "null key"])
+def test_rank_index_is_not_used_with_duplicate_or_null_keys(gpu, oracle, spoiler):
+    """One duplicate key or one NULL key among dense keys: the build falls back to the table; chains and NULL rules as ever."""
+    rng = np.random.default_rng(8)
+    nb, npr = 20_000, 30_000
+    keys = (rng.permutation(3 * nb)[:nb]).astype(np.int64)
+    nulls = np.zeros(nb, dtype=bool)
+    if spoiler == "duplicate key":
+        keys[nb - 1] = keys[0]
+    else:
+        nulls[nb // 2] = True
+    build = [Page([Block.bigint(keys, nulls if nulls.any() else None), Block.integer(np.arange(nb))], nb)]
+    pk = rng.integers(-5, 3 * nb + 5, npr).astype(np.int64)
+    pk[:2] = [keys[0], keys[nb // 2]]
+    probe = [Page([Block.bigint(pk), Block.integer(np.arange(npr))], npr)]
+    types = [abi.BIGINT, abi.INTEGER]
+    rows, pairs, _ = gpu_join(build, types, [0], [1], probe, types, [0], [0, 1])
+    orows, opairs, _ = oracle_join(oracle, build, types, [0], [1], probe, types, [0], [0, 1])
+    assert rows == orows and len(rows) > 5000
+    for (gp, gb), (op_, ob) in zip(pairs, opairs):
+        assert np.array_equal(gp, op_) and np.array_equal(gb, ob)
 
 
 def test_multi_channel_keys_with_varchar_and_double(gpu, oracle):
