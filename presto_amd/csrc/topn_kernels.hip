@@ -119,6 +119,46 @@ __global__ __launch_bounds__(256) void k_topn_compact(const u64* __restrict__ ke
     }
 }
 
+// The remaining digits of the selection over a few candidates (compacted: at most kSelectSmall keys) in ONE workgroup: digit by
+// digit histogram in LDS, the digit that holds the wanted rank, next digit -- no launch, read-back and host step per digit (six such
+// rounds cost 0.19 ms of Q3's TopN, most of it launch gaps).  out[0] = the selected key.
+constexpr int64_t kSelectSmall = 1 << 18;
+__global__ __launch_bounds__(1024) void k_topn_select_small(const u64* __restrict__ keys, i64 n, u64 prefix, int shift, i64 remaining, u64* __restrict__ out)
+{
+    __shared__ u32 hist[256];
+    __shared__ u64 s_prefix;
+    __shared__ i64 s_remaining;
+    if (threadIdx.x == 0) {
+        s_prefix = prefix;
+        s_remaining = remaining;
+    }
+    for (; shift >= 0; shift -= 8) {
+        if (threadIdx.x < 256) hist[threadIdx.x] = 0;
+        __syncthreads();
+        const u64 pf = s_prefix;
+        for (i64 i = threadIdx.x; i < n; i += 1024) {
+            const u64 k = keys[i];
+            if (shift == 56 || (k >> (shift + 8)) == pf) atomicAdd(&hist[(k >> shift) & 255ULL], 1u);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int digit = 255;
+            i64 before = 0;
+            for (int d = 0; d < 256; d++) {
+                if (before + (i64)hist[d] >= s_remaining) {
+                    digit = d;
+                    break;
+                }
+                before += (i64)hist[d];
+            }
+            s_remaining -= before;
+            s_prefix = (pf << 8) | (u64)digit;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = s_prefix;
+}
+
 __global__ __launch_bounds__(256) void k_topn_flag(const u64* __restrict__ keys, i64 n, u64 threshold, i32* __restrict__ partition)
 {
     for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < n; i += (i64)gridDim.x * 256) partition[i] = keys[i] <= threshold ? 0 : 1;
@@ -232,6 +272,15 @@ uint64_t topn_select_kth(const uint64_t* keys, int64_t n, int64_t k, void* temp,
     uint64_t prefix = 0;
     int64_t remaining = k;
     for (int shift = 56; shift >= 0; shift -= 8) {
+        if (cur_n <= kSelectSmall) {  // few candidates (a compaction's worth, or a small page): the remaining digits in one launch
+            u64* result = reinterpret_cast<u64*>(counter + 2);
+            hipLaunchKernelGGL(k_topn_select_small, 1, 1024, 0, s, cur, (i64)cur_n, (u64)prefix, shift, (i64)remaining, result);
+            PA_HIP(hipGetLastError());
+            PA_HIP(hipMemcpyAsync(host_hist, result, 8, hipMemcpyDeviceToHost, s));
+            PA_HIP(hipStreamSynchronize(s));
+            memcpy(&prefix, host_hist, 8);
+            break;
+        }
         const int grid = (int)std::min<int64_t>(kHistGrid, std::max<int64_t>(1, (cur_n + 255) / 256));
         hipLaunchKernelGGL(k_topn_hist, grid, 256, 0, s, cur, (i64)cur_n, (u64)prefix, shift, shift == 56 ? 1 : 0, slab);  // (compacted candidates only share the prefix of their compaction: keep checking)
         hipLaunchKernelGGL(k_topn_hist_reduce, 1, 1024, 0, s, (const u32*)slab, grid, total);
