@@ -163,19 +163,22 @@ public:
         while (slots < 2 * (uint64_t)std::max(n, 1)) slots <<= 1;
         PA_REQUIRE(slots <= (1ULL << 31), PA_ERR_INSUFFICIENT_RESOURCES, "join build side too large");
         ls_->probe_mask = (uint32_t)(slots - 1);
-        bool keyed_dups = false;
-        timer.begin(s);
-        if (ls_->keyed) {
-            // one integer key.  Key range and bitmap first: over a dense enough key range without NULL or duplicate keys the key rank
-            // index is the whole lookup structure and no table is built
-            if (n > 0) build_key_bitmap(bk.col[0], n, s);
-            else PA_HIP(hipStreamSynchronize(s));
-            int32_t dups = 0;
-            if (!build_rank_index(bk.col[0], n, s)) dups = build_key_slots(bk.col[0], n, slots, s);
+        bool keyed_dups = false, rank_pending = false;
+        auto build_table = [&] {
+            const int32_t dups = build_key_slots(bk.col[0], n, slots, s);
             // chains exist only when some key has several rows: two passes over the rows and the table that unique keys -- the build
             // side of a primary-key join -- do without
             if (dups) launch_join_keyed_links(n, ls_->key_slots.as<JoinKeySlot>(), ls_->probe_mask, ls_->slot_of.as<int32_t>(), ls_->links.as<int32_t>(), s);
             keyed_dups = dups != 0;
+        };
+        timer.begin(s);
+        if (ls_->keyed) {
+            // one integer key.  Key range and bitmap first: over a dense enough key range without NULL or duplicate keys the key rank
+            // index is the whole lookup structure and no table is built (whether it holds is read back with the error word below)
+            if (n > 0) build_key_bitmap(bk.col[0], n, s);
+            else PA_HIP(hipStreamSynchronize(s));
+            rank_pending = start_rank_index(bk.col[0], n, s);
+            if (!rank_pending) build_table();
         }
         else {
             compute_raw_hash(bk, n, s);
@@ -188,9 +191,16 @@ public:
         }
         PA_HIP(hipMemsetAsync(ls_->visited.ensure((size_t)std::max(n, 1)), 0, (size_t)std::max(n, 1), s));
         timer.end(s);
-        int32_t ctl[2] = {0, 0};
-        PA_HIP(hipMemcpyAsync(ctl, ctl_, 8, hipMemcpyDeviceToHost, s));
+        int32_t ctl[6] = {0, 0, 0, 0, 0, 0};  // [0] error word, [4] distinct build keys, [5] some build row not at its key's rank
+        PA_HIP(hipMemcpyAsync(ctl, ctl_, sizeof ctl, hipMemcpyDeviceToHost, s));
         PA_HIP(hipStreamSynchronize(s));
+        if (rank_pending && !finish_rank_index(n, ctl[4], ctl[5] != 0)) {
+            timer.begin(s);
+            build_table();
+            timer.end(s);
+            PA_HIP(hipMemcpyAsync(ctl, ctl_, 4, hipMemcpyDeviceToHost, s));
+            PA_HIP(hipStreamSynchronize(s));
+        }
         const int32_t err = ctl[0];
         ls_->has_duplicates = !ls_->keyed || keyed_dups;
         ls_->error.store(err);
@@ -224,31 +234,33 @@ public:
         return dups;
     }
 
-    // The key rank index (join_kernels.hpp) from the key bitmap; false = the build side does not qualify (no bitmap, NULL keys,
-    // duplicate keys) and the slot table is built.  PRESTO_AMD_NO_RANK_INDEX=1 turns it off (A/B runs, tests of the table builds).
-    bool build_rank_index(const JoinCol& key, int32_t n, hipStream_t s)
+    // The key rank index (join_kernels.hpp) from the key bitmap: enqueues its construction; false = the build side does not qualify up
+    // front (no bitmap, NULL keys).  Whether it holds -- no key on several rows -- shows in ctl_[4] (distinct keys) once the stream has
+    // drained: finish_rank_index.  PRESTO_AMD_NO_RANK_INDEX=1 turns it off (A/B runs, tests of the table builds).
+    bool start_rank_index(const JoinCol& key, int32_t n, hipStream_t s)
     {
         if (ls_->bitmap.bits == nullptr || key.nulls != nullptr || n <= 0 || getenv("PRESTO_AMD_NO_RANK_INDEX")) return false;
         const int64_t nwords = (int64_t)(ls_->bitmap.range >> 6) + 1;
-        DevBuf counts, temp;
         JoinRankWord* words = static_cast<JoinRankWord*>(ls_->rank_words.ensure((size_t)nwords * sizeof(JoinRankWord)));
         PA_HIP(hipMemsetAsync(ctl_ + 4, 0, 8, s));
-        launch_join_rank_words(ls_->bitmap.bits, nwords, words, static_cast<int32_t*>(counts.ensure((size_t)nwords * 4)), temp.ensure(scan_temp_bytes(nwords)),
-                               ctl_ + 4, s);
-        // (rows of duplicate keys overwrite each other below: the index is dropped then)
-        int32_t* rows = static_cast<int32_t*>(ls_->rank_rows.ensure((size_t)n * 4));
-        launch_join_rank_rows(key, n, words, ls_->bitmap.min_key, rows, ctl_ + 5, s);
-        int32_t h[2] = {0, 0};  // distinct keys, some row not at its rank
-        PA_HIP(hipMemcpyAsync(h, ctl_ + 4, 8, hipMemcpyDeviceToHost, s));
-        PA_HIP(hipStreamSynchronize(s));
-        if (h[0] != n) {  // some key on several rows
+        launch_join_rank_words(ls_->bitmap.bits, nwords, words, static_cast<int32_t*>(rank_counts_.ensure((size_t)nwords * 4)),
+                               rank_temp_.ensure(scan_temp_bytes(nwords)), ctl_ + 4, s);
+        // (rows of duplicate keys overwrite each other here: the index is dropped then)
+        launch_join_rank_rows(key, n, words, ls_->bitmap.min_key, static_cast<int32_t*>(ls_->rank_rows.ensure((size_t)n * 4)), ctl_ + 5, s);
+        launch_fill_i32(ls_->links.as<int32_t>(), -1, n, s);
+        return true;
+    }
+    bool finish_rank_index(int32_t n, int32_t distinct, bool unordered)
+    {
+        rank_counts_.release();
+        rank_temp_.release();
+        if (distinct != n) {  // some key on several rows
             ls_->rank_words.release();
             ls_->rank_rows.release();
             return false;
         }
-        if (!h[1]) ls_->rank_rows.release();  // build rows in key order: rank == build position
-        ls_->rank = JoinRankIndex{words, h[1] ? rows : nullptr, ls_->bitmap.min_key, ls_->bitmap.range};
-        launch_fill_i32(ls_->links.as<int32_t>(), -1, n, s);
+        if (!unordered) ls_->rank_rows.release();  // build rows in key order: rank == build position
+        ls_->rank = JoinRankIndex{ls_->rank_words.as<JoinRankWord>(), unordered ? ls_->rank_rows.as<int32_t>() : nullptr, ls_->bitmap.min_key, ls_->bitmap.range};
         return true;
     }
 
@@ -319,7 +331,7 @@ private:
     Stream stream_;
     PageStager stager_;
     std::shared_ptr<LookupSourceImpl> ls_;
-    DevBuf ctl_buf_;
+    DevBuf ctl_buf_, rank_counts_, rank_temp_;
     int32_t* ctl_ = nullptr;
     int64_t expected_ = 0;
     bool finishing_ = false;

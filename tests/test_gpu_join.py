@@ -324,14 +324,16 @@ def test_probe_outer_join_kats(gpu, oracle):
 
 @pytest.mark.parametrize("join_type", [abi.JOIN_PROBE_OUTER, abi.JOIN_LOOKUP_OUTER, abi.JOIN_FULL_OUTER])
 @pytest.mark.parametrize("device_output", [False, True])
-def test_outer_joins_match_oracle(gpu, oracle, join_type, device_output):
+@pytest.mark.parametrize("unique_keys", [False, True])
+def test_outer_joins_match_oracle(gpu, oracle, join_type, device_output, unique_keys):
     """Duplicates, NULL keys on both sides, several probe pages (the visited marks accumulate), nullable / VARCHAR build
-    payload: output rows and their order, (probe, build) pairs and the LookupOuterOperator's rows equal the oracle's."""
+    payload: output rows and their order, (probe, build) pairs and the LookupOuterOperator's rows equal the oracle's.
+    unique_keys: no duplicate and no NULL build key -- the lookup goes through the key rank index instead of the table."""
     rng = np.random.default_rng(100 + join_type)
     nb = 5000
     words = [b"", b"x", b"payload", None, b"0123456789abcdef"]
-    bk = rng.integers(0, 3000, nb).astype(np.int64)
-    build = [Page([Block.bigint(bk, rng.random(nb) < 0.03), Block.varchar([words[i] for i in rng.integers(0, len(words), nb)]),
+    bk = rng.permutation(6000)[:nb].astype(np.int64) if unique_keys else rng.integers(0, 3000, nb).astype(np.int64)
+    build = [Page([Block.bigint(bk, None if unique_keys else rng.random(nb) < 0.03), Block.varchar([words[i] for i in rng.integers(0, len(words), nb)]),
                    Block.double(rng.random(nb), rng.random(nb) < 0.1), Block.integer(np.arange(nb, dtype=np.int32))], nb)]
     btypes = [abi.BIGINT, abi.VARCHAR, abi.DOUBLE, abi.INTEGER]
     probes = []
