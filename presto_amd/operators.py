@@ -209,13 +209,17 @@ def FilterAndProjectOperator(input_types, filter_expr, projections, output_mem=a
     """FilterAndProjectOperator.createOperatorFactory (…/operator/FilterAndProjectOperator.java:73-178) with
     PageProcessor(Optional<PageFilter>, List<PageProjection>); minOutputPageSize / minOutputPageRowCount configure
     the MergePages step behind it (0, 0 = every page passes through, as in the reference's operator tests)."""
+    return FilterAndProjectOperatorFactory(input_types, filter_expr, projections, output_mem, stream, type_params, min_output_page_size,
+                                           min_output_page_row_count, max_output_page_size).createOperator()
+
+
+def FilterAndProjectOperatorFactory(input_types, filter_expr, projections, output_mem=abi.MEM_HOST, stream=None,
+                                    type_params=None, min_output_page_size=0, min_output_page_row_count=0, max_output_page_size=0):
     d, keep = _filter_project_desc(input_types, filter_expr, projections, output_mem, stream, type_params)
     d.min_output_page_bytes = int(min_output_page_size)
     d.min_output_page_rows = int(min_output_page_row_count)
     d.max_output_page_bytes = int(max_output_page_size)
-    h = C.c_void_p()
-    check(lib().pa_filter_project_create(C.byref(d), C.byref(h)))
-    return Operator(h, keep)
+    return OperatorFactory(lib().pa_filter_project_create, d, keep)
 
 
 class LazyBlock:
@@ -354,6 +358,16 @@ class OperatorFactory:
         return Operator(h, self._keep)
 
 
+class JoinOperatorFactory(OperatorFactory):
+    """The factories of a join's operators (HashBuilderOperatorFactory, LookupJoinOperatorFactory and the fused forms) share a
+    JoinBridge; here the LookupSourceFactory of the Driver's query comes with createOperator."""
+
+    def createOperator(self, bridge):
+        h = C.c_void_p()
+        check(self._create(C.byref(self._desc), bridge._h, C.byref(h)))
+        return Operator(h, [self._keep, bridge])
+
+
 def FusedAggregationOperatorFactory(input_types, filter_expr, projections, group_by_channels, aggregates, **kw):
     d, keep = fused_aggregation_desc(input_types, filter_expr, projections, group_by_channels, aggregates, **kw)
     return OperatorFactory(lib().pa_fused_aggregation_create, d, keep)
@@ -366,6 +380,10 @@ def FusedAggregationOperator(input_types, filter_expr, projections, group_by_cha
 
 def TopNOperator(input_types, n, sort_channels, sort_orders, output_mem=abi.MEM_HOST, stream=None):
     """TopNOperator.createOperatorFactory (…/operator/TopNOperator.java:43-90)."""
+    return TopNOperatorFactory(input_types, n, sort_channels, sort_orders, output_mem, stream).createOperator()
+
+
+def TopNOperatorFactory(input_types, n, sort_channels, sort_orders, output_mem=abi.MEM_HOST, stream=None):
     d = abi.pa_topn_desc()
     types = abi.int32_array(input_types)
     sc = abi.int32_array(sort_channels)
@@ -378,9 +396,7 @@ def TopNOperator(input_types, n, sort_channels, sort_orders, output_mem=abi.MEM_
     d.sort_orders = C.cast(so, C.POINTER(C.c_int32))
     d.output_mem = output_mem
     d.stream = stream
-    h = C.c_void_p()
-    check(lib().pa_topn_create(C.byref(d), C.byref(h)))
-    return Operator(h, [types, sc, so])
+    return OperatorFactory(lib().pa_topn_create, d, [types, sc, so])
 
 
 def OrderByOperator(input_types, output_channels, sort_channels, sort_orders, output_mem=abi.MEM_HOST, stream=None):
@@ -535,10 +551,12 @@ def hash_builder_desc(input_types, join_channels, output_channels, hash_channel=
 def HashBuilderOperator(bridge, input_types, join_channels, output_channels, hash_channel=-1, expected_positions=0,
                         stream=None):
     """HashBuilderOperator.HashBuilderOperatorFactory (…/operator/join/HashBuilderOperator.java:56-180)."""
+    return HashBuilderOperatorFactory(input_types, join_channels, output_channels, hash_channel, expected_positions, stream).createOperator(bridge)
+
+
+def HashBuilderOperatorFactory(input_types, join_channels, output_channels, hash_channel=-1, expected_positions=0, stream=None):
     d, keep = hash_builder_desc(input_types, join_channels, output_channels, hash_channel, expected_positions, stream)
-    h = C.c_void_p()
-    check(lib().pa_hash_builder_create(C.byref(d), bridge._h, C.byref(h)))
-    return Operator(h, keep + [bridge])
+    return JoinOperatorFactory(lib().pa_hash_builder_create, d, keep)
 
 
 def FusedJoinOperator(bridge, input_types, filter_expr, projections, probe_join_channels, probe_output_channels, output_mem=abi.MEM_HOST,
@@ -546,10 +564,14 @@ def FusedJoinOperator(bridge, input_types, filter_expr, projections, probe_join_
     """[Scan]FilterAndProject -> LookupJoin (INNER) behind one handle (pa_fused_join_create): filter, probe and the join's output page
     [probe output channels, build output channels] in two passes over the page when the lookup source has a single integer key
     without duplicates; the two device operators otherwise."""
+    return FusedJoinOperatorFactory(input_types, filter_expr, projections, probe_join_channels, probe_output_channels, output_mem, stream,
+                                    type_params).createOperator(bridge)
+
+
+def FusedJoinOperatorFactory(input_types, filter_expr, projections, probe_join_channels, probe_output_channels, output_mem=abi.MEM_HOST,
+                             stream=None, type_params=None):
     d, keep = fused_join_desc(input_types, filter_expr, projections, probe_join_channels, probe_output_channels, output_mem, stream, type_params)
-    h = C.c_void_p()
-    check(lib().pa_fused_join_create(C.byref(d), bridge._h, C.byref(h)))
-    return Operator(h, [keep, bridge])
+    return JoinOperatorFactory(lib().pa_fused_join_create, d, keep)
 
 
 def fused_join_desc(input_types, filter_expr, projections, probe_join_channels, probe_output_channels, output_mem=abi.MEM_HOST, stream=None,
@@ -579,11 +601,15 @@ def FusedJoinAggregationOperator(bridge, input_types, filter_expr, projections, 
                                  group_by_channels, aggregates, **kw):
     """[Scan]FilterAndProject -> LookupJoin (INNER) -> (Hash)Aggregation behind one handle (pa_fused_join_aggregation_create): one
     generated kernel when the lookup source has a single integer key without duplicates, the three device operators otherwise."""
+    return FusedJoinAggregationOperatorFactory(input_types, filter_expr, projections, probe_join_channels, probe_output_channels, joined_types,
+                                               group_by_channels, aggregates, **kw).createOperator(bridge)
+
+
+def FusedJoinAggregationOperatorFactory(input_types, filter_expr, projections, probe_join_channels, probe_output_channels, joined_types,
+                                        group_by_channels, aggregates, **kw):
     d, keep = fused_join_aggregation_desc(input_types, filter_expr, projections, probe_join_channels, probe_output_channels, joined_types,
                                           group_by_channels, aggregates, **kw)
-    h = C.c_void_p()
-    check(lib().pa_fused_join_aggregation_create(C.byref(d), bridge._h, C.byref(h)))
-    return Operator(h, [keep, bridge])
+    return JoinOperatorFactory(lib().pa_fused_join_aggregation_create, d, keep)
 
 
 def _lookup_join_desc(probe_types, probe_join_channels, probe_output_channels, probe_hash_channel, output_mem, stream, join_type):

@@ -21,8 +21,9 @@ producing side of the rank has finished."""
 from . import abi, tpch
 from .exchange import ExchangeOperator
 from .expr import field
-from .operators import (Driver, FilterAndProjectOperator, FusedJoinAggregationOperator, FusedJoinOperator, HashAggregationOperator, HashBuilderOperator,
-                        LookupJoinOperator, LookupSourceFactory, TopNOperator)
+from .operators import (Driver, FilterAndProjectOperator, FilterAndProjectOperatorFactory, FusedJoinAggregationOperator,
+                        FusedJoinAggregationOperatorFactory, FusedJoinOperatorFactory, HashAggregationOperator,
+                        HashBuilderOperatorFactory, LookupJoinOperator, LookupSourceFactory, TopNOperatorFactory)
 
 
 AGG_TYPES = [abi.BIGINT, abi.DOUBLE, abi.DATE, abi.INTEGER]       # lineitem JOIN orders: orderkey, revenue, orderdate, shippriority
@@ -30,6 +31,20 @@ AGG_GROUP_BY = [0, 2, 3]
 AGG_AGGREGATES = [(abi.AGG_SUM, 1, abi.DOUBLE), (abi.AGG_COUNT_STAR, -1, None)]
 ORDERS_JOINED_TYPES = [abi.BIGINT, abi.DATE, abi.INTEGER]           # orders JOIN customer: orderkey, orderdate, shippriority
 RESULT_TYPES = [abi.BIGINT, abi.DATE, abi.INTEGER, abi.DOUBLE, abi.BIGINT]  # orderkey, orderdate, shippriority, revenue, count
+
+
+# The planner's part of the one-rank plan with fused probes (LocalExecutionPlanner: OperatorFactory objects, made once per plan and
+# stream; a Driver then only calls createOperator): the serialised descriptors of the operators the three pipelines create.
+_FACTORIES = {}
+
+
+def _factory(key, make):
+    f = _FACTORIES.get(key)
+    if f is None:
+        if len(_FACTORIES) > 64:
+            _FACTORIES.clear()
+        f = _FACTORIES[key] = make()
+    return f
 
 
 def run(customer_pages, orders_pages, lineitem_pages, stream, comm=None, expected_groups=100000, distributed=None,
@@ -95,27 +110,30 @@ def run(customer_pages, orders_pages, lineitem_pages, stream, comm=None, expecte
     # pipeline 1
     b1 = LookupSourceFactory()
     Driver(customer_pages, [
-        FilterAndProjectOperator(tpch.CUSTOMER_TYPES, tpch.q3_customer_filter(), [field(0, abi.BIGINT)], output_mem=dev, stream=s),
+        _factory(("customer", s), lambda: FilterAndProjectOperatorFactory(tpch.CUSTOMER_TYPES, tpch.q3_customer_filter(), [field(0, abi.BIGINT)],
+                                                                          output_mem=dev, stream=s)).createOperator(),
         *exchange([abi.BIGINT], [0]),
-        HashBuilderOperator(b1, [abi.BIGINT], [0], [], stream=s)]).run()
+        _factory(("build1", s), lambda: HashBuilderOperatorFactory([abi.BIGINT], [0], [], stream=s)).createOperator(b1)]).run()
     lap("customer_pipeline")
     # pipeline 2
     b2 = LookupSourceFactory()
-    orders_projections = [field(i, t) for i, t in enumerate(tpch.ORDERS_TYPES)]
     if fused_probe and not distributed:
         # FilterAndProject -> LookupJoin as one operator: custkey is unique on the build side (the join's dynamic filter is the
         # fused kernels' own bitmap test)
         if dynamic_filters:
             counters["orders_dynamic_filter"] = "fused"
-        orders_head = [FusedJoinOperator(b1, tpch.ORDERS_TYPES, tpch.q3_orders_filter(), orders_projections, [1], [0, 2, 3], output_mem=dev, stream=s)]
+        orders_head = [_factory(("orders", s), lambda: FusedJoinOperatorFactory(
+            tpch.ORDERS_TYPES, tpch.q3_orders_filter(), [field(i, t) for i, t in enumerate(tpch.ORDERS_TYPES)], [1], [0, 2, 3], output_mem=dev,
+            stream=s)).createOperator(b1)]
     else:
+        orders_projections = [field(i, t) for i, t in enumerate(tpch.ORDERS_TYPES)]
         orders_fp = FilterAndProjectOperator(tpch.ORDERS_TYPES, tpch.q3_orders_filter(), orders_projections, output_mem=dev, stream=s)
         dynamic_filter(orders_fp, 1, b1, "orders_dynamic_filter")
         orders_head = [orders_fp, *exchange(tpch.ORDERS_TYPES, [1]), LookupJoinOperator(b1, tpch.ORDERS_TYPES, [1], [0, 2, 3], output_mem=dev, stream=s)]
     Driver(orders_pages, [
         *orders_head,
         *exchange(ORDERS_JOINED_TYPES, [0]),
-        HashBuilderOperator(b2, ORDERS_JOINED_TYPES, [0], [1, 2], stream=s)]).run()
+        _factory(("build2", s), lambda: HashBuilderOperatorFactory(ORDERS_JOINED_TYPES, [0], [1, 2], stream=s)).createOperator(b2)]).run()
     lap("orders_pipeline")
     # pipeline 3
     # orderkey is unique on the build side, so its row count bounds the groups (what the planner's stats estimate)
@@ -123,13 +141,15 @@ def run(customer_pages, orders_pages, lineitem_pages, stream, comm=None, expecte
     aggregates = AGG_AGGREGATES if with_count else AGG_AGGREGATES[:1]
     result_types = RESULT_TYPES if with_count else RESULT_TYPES[:4]
     agg_mem = dev if top_n else result_mem
-    top = [TopNOperator(result_types, top_n, [3, 1], [abi.DESC_NULLS_LAST, abi.ASC_NULLS_LAST], output_mem=result_mem, stream=s)] if top_n else []
+    top = [_factory(("top", s, top_n, with_count, result_mem), lambda: TopNOperatorFactory(
+        result_types, top_n, [3, 1], [abi.DESC_NULLS_LAST, abi.ASC_NULLS_LAST], output_mem=result_mem, stream=s)).createOperator()] if top_n else []
     if fused_probe and not distributed:
         # (the join's dynamic filter is the fused kernel's own bitmap test)
         if dynamic_filters:
             counters["lineitem_dynamic_filter"] = "fused"
-        head = [FusedJoinAggregationOperator(b2, tpch.Q3_LINEITEM_TYPES, tpch.q3_lineitem_filter(), tpch.q3_lineitem_projections(), [0], [0, 1],
-                                             AGG_TYPES, AGG_GROUP_BY, aggregates, expected_groups=expected_groups, output_mem=agg_mem, stream=s)]
+        head = [_factory(("lineitem", s, with_count, expected_groups, agg_mem), lambda: FusedJoinAggregationOperatorFactory(
+            tpch.Q3_LINEITEM_TYPES, tpch.q3_lineitem_filter(), tpch.q3_lineitem_projections(), [0], [0, 1], AGG_TYPES, AGG_GROUP_BY, aggregates,
+            expected_groups=expected_groups, output_mem=agg_mem, stream=s)).createOperator(b2)]
     else:
         lineitem_fp = FilterAndProjectOperator(tpch.Q3_LINEITEM_TYPES, tpch.q3_lineitem_filter(), tpch.q3_lineitem_projections(), output_mem=dev, stream=s)
         dynamic_filter(lineitem_fp, 0, b2, "lineitem_dynamic_filter")
