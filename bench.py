@@ -371,6 +371,12 @@ def main(argv=None, workload_factory=None, out=None):
     max-over-ranks clock, the exchange rounds of Q3, the JSON line) on CPU ranks with a checker workload; the default is
     the device workload."""
     args = parse_args(argv)
+    # ONE JSON line on stdout: whatever libraries print there while the bench runs (RCCL greets with its version) goes to stderr
+    line_fd = None
+    if out is None:
+        sys.stdout.flush()
+        line_fd = os.dup(1)
+        os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -440,7 +446,11 @@ def main(argv=None, workload_factory=None, out=None):
                 line["sf300"] = {"error": "%s: %s" % (type(e).__name__, e)}
         if side_legs and world == 1 and args.cpu_rows > 0:
             line["cpu_baseline"] = cpu_baseline(args.sf, args.cpu_rows)
-        print(json.dumps(line), file=out or sys.stdout, flush=True)
+        if out is not None:
+            print(json.dumps(line), file=out, flush=True)
+        else:
+            sys.stdout.flush()
+            os.write(line_fd, (json.dumps(line) + "\n").encode())
 
     # N > 1: the Q3 leg runs collectives; a rank that fails inside one would leave the others waiting for ever.  The headline was
     # measured above: if the leg does not come back within --q3-timeout seconds, rank 0 prints the line without it and every
@@ -502,6 +512,10 @@ def main(argv=None, workload_factory=None, out=None):
         if watchdog is not None:
             watchdog.cancel()
         dist.destroy_process_group()
+    if line_fd is not None:
+        sys.stdout.flush()
+        os.dup2(line_fd, 1)
+        os.close(line_fd)
 
 
 if __name__ == "__main__":

@@ -26,6 +26,8 @@ def main():
     ap.add_argument("--backend", default="nccl")
     ap.add_argument("--force-exchange", action="store_true", help="run the exchange steps even with one rank")
     ap.add_argument("--with-count", action="store_true", help="also compute count(*) per group (the parity tests' extra column; TPC-H Q3 itself has sum(revenue) only)")
+    ap.add_argument("--unfused", action="store_true", help="FilterAndProject, LookupJoin and HashAggregation as operators of their own "
+                    "(what a plan without the fused descriptors runs)")
     ap.add_argument("--top-n", type=int, default=10, help="the query's ORDER BY revenue DESC, orderdate LIMIT n (0 = stop at the grouped result)")
     args = ap.parse_args()
 
@@ -58,7 +60,7 @@ def main():
         out, counters = q3.run(customer.pages(args.page_rows - args.page_rows % 20), orders.pages(args.page_rows),
                                lineitem.pages(args.page_rows), stream.handle, comm=comm, distributed=distributed,
                                result_mem=abi.MEM_HOST if args.top_n else abi.MEM_DEVICE, top_n=args.top_n,
-                               with_count=args.with_count)
+                               with_count=args.with_count, fused_probe=not args.unfused)
         groups = sum(p.position_count for p in out)
         return groups, counters
 
