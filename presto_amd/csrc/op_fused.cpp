@@ -2768,7 +2768,7 @@ private:
     }
 
     void build_output();
-    bool emit_on_device(const KernelInfo& ki, int64_t groups);
+    bool emit_on_device(const KernelInfo& ki, int64_t groups, bool keys_from_build_columns = false);
     void intern_keys(DevPage& dp, hipStream_t s);
     void intern_dictionary_key(const pa_page* page, int c, DevPage& dp, hipStream_t s);
     void decode_interned_keys();
@@ -2968,7 +2968,10 @@ void FusedAggregationOperator::decode_interned_keys()
 
 // Large grouped results (Q3: millions of groups) never visit the host: k_gt_emit compacts the table and writes the output
 // blocks in one pass.  Small results and VARCHAR keys take the host assembly of build_output below.
-bool FusedAggregationOperator::emit_on_device(const KernelInfo& ki, int64_t groups)
+// keys_from_build_columns (build-row table): the group of slot p is build row p and its keys are build columns, so they are copied
+// from there -- no packed key words (pa_brow_keys is not run) and no group count beforehand: `groups` is then the table's capacity,
+// an upper bound, and the emit kernel's counter says how many there were.
+bool FusedAggregationOperator::emit_on_device(const KernelInfo& ki, int64_t groups, bool keys_from_build_columns)
 {
     constexpr int64_t kMinGroups = 4096;
     const int nkeys = (int)spec_.group_proj.size();
@@ -2978,6 +2981,7 @@ bool FusedAggregationOperator::emit_on_device(const KernelInfo& ki, int64_t grou
     for (int gi = 0; gi < nkeys; gi++) {
         if (ki.keys[gi].type == PA_VARCHAR) return false;
     }
+    if (keys_from_build_columns && (has_hash || !spec_.join || spec_.join->brow_group_proj.size() != (size_t)nkeys)) return false;
     GtEmitArgs a{};
     int n = 0;
     auto add = [&](int kind, int type) -> GtEmitCol* {
@@ -2992,6 +2996,18 @@ bool FusedAggregationOperator::emit_on_device(const KernelInfo& ki, int64_t grou
     std::vector<bool> nullable;
     for (int gi = 0; gi < nkeys; gi++) {
         const KeyPart& kp = ki.keys[gi];
+        if (keys_from_build_columns) {
+            const OwnedExpr& pe = spec_.proj[(size_t)spec_.join->brow_group_proj[(size_t)gi]];
+            const int v = pe.is_input_ref() ? pe.node(pe.root).channel - spec_.n_in : -1;
+            if (v < 0 || v >= (int)spec_.join->build_cols.size()) return false;
+            const BuildColumn& bc = spec_.join->ls->cols[(size_t)spec_.join->build_cols[(size_t)v]];
+            GtEmitCol* c = add(GT_EMIT_COLUMN, kp.type);
+            if (!c || bc.varwidth || type_width(bc.type) != c->width) return false;
+            c->src = bc.values.ptr();
+            c->src_nulls = bc.has_nulls ? bc.nulls.as<uint8_t>() : nullptr;
+            nullable.push_back(bc.has_nulls);
+            continue;
+        }
         GtEmitCol* c = add(GT_EMIT_KEY, kp.type);
         if (!c) return false;
         c->word = kp.word;
@@ -3076,6 +3092,7 @@ bool FusedAggregationOperator::emit_on_device(const KernelInfo& ki, int64_t grou
     PA_HIP(hipMemcpyAsync(flags, a.null_flags, sizeof(flags), hipMemcpyDeviceToHost, s));
     PA_HIP(hipMemcpyAsync(h_ctl_, ctl_, 32, hipMemcpyDeviceToHost, s));
     PA_HIP(hipStreamSynchronize(s));
+    if (keys_from_build_columns) groups = (int64_t)(uint32_t)h_ctl_[7];
     PA_REQUIRE((int64_t)(uint32_t)h_ctl_[7] == groups, PA_ERR_DEVICE, "group table and group count disagree");
     for (int c = 0; c < n; c++) out_cols_[c].has_nulls = flags[c] != 0;
     out_rows_ = (int32_t)groups;
@@ -3158,6 +3175,8 @@ void FusedAggregationOperator::build_output()
             PA_HIP(hipStreamSynchronize(s));
             raise_if(h_ctl_[0]);
         }
+        // build-row table of some size: the output blocks straight from the accumulators and the build columns
+        if (build_rows_table_ && (int64_t)gt_cap_ >= (1 << 14) && emit_on_device(ki, (int64_t)gt_cap_, true)) return;
         if (build_rows_table_) {
             // build-row table: no kernel counted its groups, and its key words are still to be written -- once per group, from
             // the build columns (pa_brow_keys)

@@ -411,6 +411,19 @@ __device__ __forceinline__ void gt_emit_slot(const GtEmitArgs& a, u64 i, u64 g)
                 row_hash = pa_combine_hash(row_hash, h);
                 break;
             }
+            case GT_EMIT_COLUMN: {  // group key read where it lives (slot = build position); DOUBLE in the group key's canonical form
+                is_null = col.src_nulls != nullptr && col.src_nulls[i] != 0;
+                if (!is_null) {
+                    if (col.width == 8) bits = ((const u64*)col.src)[i];
+                    else if (col.width == 4) bits = (u64)((const u32*)col.src)[i];
+                    else bits = ((const u8*)col.src)[i] != 0 ? 1ULL : 0ULL;
+                    if (col.type == PA_DOUBLE) {
+                        const double v = __longlong_as_double((i64)bits);
+                        bits = v == 0.0 ? 0ULL : (v != v ? 0x7ff8000000000000ULL : bits);
+                    }
+                }
+                break;
+            }
             case GT_EMIT_HASH: bits = (u64)row_hash; break;
             // (a count word of -1 is the implicit count of op_fused.cpp: it counts as 1)
             case GT_EMIT_STATE: bits = col.word >= 0 ? wd[(u64)col.word * a.st.word + i * a.st.slot] : 1ULL; break;

@@ -27,7 +27,8 @@ void launch_tpch(int32_t column, double sf, int64_t first_row, int64_t n, uint64
 // Grouped output assembled on device (InMemoryHashAggregationBuilder.buildResult): one pass over the table slots
 // compacts the occupied ones (one counter atomic per wave) and writes every output block -- unpacked key columns,
 // $hashvalue, final aggregate values or PARTIAL states -- directly.
-enum GtEmitKind { GT_EMIT_KEY = 0, GT_EMIT_HASH = 1, GT_EMIT_COUNT = 2, GT_EMIT_SUM = 3, GT_EMIT_AVG = 4, GT_EMIT_STATE = 5, GT_EMIT_MINMAX = 6 };
+enum GtEmitKind { GT_EMIT_KEY = 0, GT_EMIT_HASH = 1, GT_EMIT_COUNT = 2, GT_EMIT_SUM = 3, GT_EMIT_AVG = 4, GT_EMIT_STATE = 5, GT_EMIT_MINMAX = 6,
+                  GT_EMIT_COLUMN = 7 };  // COLUMN: the key is element [slot] of a column (a build-row table's keys are build columns)
 struct GtEmitCol {
     int32_t kind, type;          // GtEmitKind, pa_type of the output block
     int32_t word, shift, bits;   // KEY: packed position; STATE: accumulator word; MINMAX: shift = 1 for min
@@ -37,6 +38,8 @@ struct GtEmitCol {
     void* values;
     uint8_t* nulls;              // may be null when the column cannot hold NULLs
     const uint64_t* dict_hash;   // KEY of an interned VARCHAR channel: per id the hash of the string ($hashvalue), else null
+    const void* src;             // COLUMN: the column's values (element width = width) and NULL flags (may be null)
+    const uint8_t* src_nulls;
 };
 // how a group table lays out its tags and accumulator words, in 8-byte words: tag of slot i at tag[i * tag], word w of slot i at
 // words[w * word + i * slot].  The hashed tables are word-major ({1, capacity, 1}); a build-row table keeps one record
