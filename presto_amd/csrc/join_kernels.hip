@@ -750,17 +750,22 @@ void launch_jf_mark_visited(const int32_t* build_pos, int64_t n, uint8_t* visite
 }
 __global__ __launch_bounds__(256) void k_sum_i32_i64(const i32* __restrict__ v, i64 n, unsigned long long* __restrict__ out)
 {
+    __shared__ i64 part[4];
     i64 acc = 0;
     for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < n; i += (i64)gridDim.x * 256) acc += v[i];
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
-    if ((threadIdx.x & 63) == 0 && acc != 0) atomicAdd(out, (unsigned long long)acc);  // one atomic per wave: a few thousand in all
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    // one atomic per workgroup: atomics on ONE address retire at about 10 ns each on this part (they execute at the memory side), so
+    // the 4096 of a one-per-wave reduction were 40 of this kernel's 65 us over 13 M counts
+    if (threadIdx.x == 0 && (acc = part[0] + part[1] + part[2] + part[3]) != 0) atomicAdd(out, (unsigned long long)acc);
 }
 void launch_sum_i32_i64(const int32_t* v, int64_t n, int64_t* out, hipStream_t s)
 {
     PA_HIP(hipMemsetAsync(out, 0, 8, s));
     if (n <= 0) return;
-    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((n + 255) / 256, 1024));
+    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((n + 255) / 256, 512));
     hipLaunchKernelGGL(k_sum_i32_i64, grid, 256, 0, s, v, (i64)n, reinterpret_cast<unsigned long long*>(out));
     PA_HIP(hipGetLastError());
 }

@@ -59,7 +59,6 @@ void launch_gt_fold(const uint64_t* old_tag, const uint64_t* old_keys, const uin
                     int32_t* count0, int32_t* rep_count, int32_t* err, hipStream_t s);
 
 void launch_exclusive_prefix_i64(const int64_t* in, int32_t n, int64_t* out, hipStream_t s);
-void launch_count_nonzero_u64(const uint64_t* v, int64_t n, int64_t stride, uint64_t empty, int64_t* out, hipStream_t s);
 void launch_fill_u64(uint64_t* dst, uint64_t value, int64_t n, hipStream_t s);
 void launch_gt_compact(const uint64_t* tag, const uint64_t* keys, const uint64_t* words, uint32_t cap, int w, int nw, uint64_t* out_keys,
                        uint64_t* out_words, uint32_t* counter, hipStream_t s, const GtStrides* strides = nullptr);

@@ -329,23 +329,6 @@ void launch_gt_fold(const uint64_t* old_tag, const uint64_t* old_keys, const uin
     PA_HIP(hipGetLastError());
 }
 
-// *out = number of words other than `empty` among v[0], v[stride], .. (n of them): occupied slots of a table whose group count no kernel kept (build-row tables)
-__global__ __launch_bounds__(256) void k_count_nonzero_u64(const u64* __restrict__ v, i64 n, i64 stride, u64 empty, unsigned long long* __restrict__ out)
-{
-    i64 acc = 0;
-    for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < n; i += (i64)gridDim.x * 256) acc += v[i * stride] != empty ? 1 : 0;
-    acc = pa_wave_sum_i64(acc);
-    if ((threadIdx.x & 63) == 0 && acc != 0) atomicAdd(out, (unsigned long long)acc);  // one atomic per wave
-}
-void launch_count_nonzero_u64(const uint64_t* v, int64_t n, int64_t stride, uint64_t empty, int64_t* out, hipStream_t s)
-{
-    PA_HIP(hipMemsetAsync(out, 0, 8, s));
-    if (n <= 0) return;
-    hipLaunchKernelGGL(k_count_nonzero_u64, (int)std::max<int64_t>(1, std::min<int64_t>((n + 255) / 256, 2048)), 256, 0, s, (const u64*)v, (i64)n,
-                       (i64)stride, (u64)empty, reinterpret_cast<unsigned long long*>(out));
-    PA_HIP(hipGetLastError());
-}
-
 __global__ __launch_bounds__(256) void k_fill_u64(u64* __restrict__ dst, u64 v, i64 n)
 {
     for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < n; i += (i64)gridDim.x * 256) dst[i] = v;
