@@ -14,9 +14,9 @@ from presto_amd.page import Block, Page
 pytestmark = pytest.mark.gpu
 
 
-def key_block(rng, t, n, card, sparse, null_share):
+def key_block(rng, t, n, card, sparse, null_share, values=None):
     nulls = (rng.random(n) < null_share) if null_share else None
-    v = rng.integers(0, card, n)
+    v = rng.integers(0, card, n) if values is None else values
     if t == abi.BIGINT:
         return Block.bigint(v * (1 << 33 if sparse else 3) - 11, nulls)
     if t == abi.INTEGER:
@@ -43,11 +43,27 @@ def test_random_joins(gpu, oracle, seed):
     types = key_types + [abi.BIGINT]
     join_ch = list(range(nkeys))
 
-    def pages(count, rows_choice, null_share):
+    # one integer key, now and then without duplicate or NULL build keys (in key order or not): dense enough, such a build side is
+    # looked up through the key rank index instead of the table
+    unique = nkeys == 1 and key_types[0] in (abi.BIGINT, abi.INTEGER, abi.DATE) and card >= 4000 and bool(rng.integers(0, 3) == 0)
+    pool = rng.permutation(card)
+    if unique and rng.integers(0, 2):
+        pool = np.sort(pool[: card // 2])
+    taken = 0
+
+    def pages(count, rows_choice, null_share, build_side=False):
+        nonlocal taken
         out = []
         for _ in range(count):
             n = int(rng.choice(rows_choice))
-            blocks = [key_block(rng, t, n, card, sparse, null_share if rng.random() < 0.6 else 0) for t in key_types]
+            values = None
+            if unique and build_side:
+                n = min(n, len(pool) - taken)
+                if n == 0:
+                    continue
+                values = pool[taken:taken + n]
+                taken += n
+            blocks = [key_block(rng, t, n, card, sparse, 0 if values is not None else (null_share if rng.random() < 0.6 else 0), values) for t in key_types]
             p = Page(blocks + [Block.bigint(rng.integers(0, 1 << 40, n))], n)
             if hashed:
                 p = Page(p.blocks + [Block.bigint(oracle.hash_page(p, join_ch))], n)
@@ -55,7 +71,7 @@ def test_random_joins(gpu, oracle, seed):
         return out
 
     # (few distinct keys = long chains: keep the pages small there, the output has build x probe / card rows)
-    build = pages(int(rng.integers(1, 4)), [1, 40, 300] if card < 100 else [1, 40, 3000, 20000], 0.05)
+    build = pages(int(rng.integers(1, 4)), [1, 40, 300] if card < 100 else [1, 40, 3000, 20000], 0.05, build_side=True)
     probe = pages(int(rng.integers(1, 4)), [1, 60, 2000] if card < 100 else [1, 60, 5000, 50000], 0.05)
     ptypes = types + ([abi.BIGINT] if hashed else [])
     hc = len(types) if hashed else -1
