@@ -9,7 +9,7 @@
 //   pipeline 2  orders:   FilterAndProject(orderdate < 1995-03-15) -> LookupJoin(b1)   -> HashBuilder(b2; key orderkey)   [pa_fused_join_create]
 //   pipeline 3  lineitem: FilterAndProject(shipdate > 1995-03-15; revenue) -> LookupJoin(b2) -> HashAggregation(orderkey, orderdate,
 //               shippriority; sum(revenue)) [pa_fused_join_aggregation_create] -> TopN(10; revenue DESC, orderdate ASC)
-// Prints one JSON line: ms per step, input rows/s, per-pipeline ms and the ten result rows.  Build: g++ -O2 -std=c++17 -I include scripts/q3_native.cpp -L presto_amd -lpresto_amd -Wl,-rpath,'$ORIGIN/../presto_amd' -Wl,--allow-shlib-undefined -o scripts/q3_native
+// Prints one JSON line: ms per step, input rows/s, per-pipeline ms and the ten result rows.  Built by __graft_entry__.build_native_q3().
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>

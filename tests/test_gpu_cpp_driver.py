@@ -31,3 +31,27 @@ def test_cpp_driver_refuses_without_device():
     r = subprocess.run([_exe()], capture_output=True, text=True, timeout=60)
     assert r.returncode == 2
     assert "no CPU fallback" in r.stderr
+
+
+@pytest.mark.gpu
+def test_native_q3_equals_the_python_driven_pipelines():
+    """scripts/q3_native.cpp (C++ Driver loop over the C ABI, descriptors built in C++) and presto_amd/q3.py over the same
+    synthetic SF1 tables: the same ten rows, bit for bit."""
+    import json
+
+    import __graft_entry__
+    from presto_amd import _lib, abi, q3, tpch
+    exe = __graft_entry__.build_native_q3()
+    r = subprocess.run([exe, "--sf", "1", "--steps", "1", "--warmup", "0"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    native = json.loads(r.stdout.strip().splitlines()[-1])
+    assert native["input_rows"] == tpch.customer_rows(1) + tpch.orders_rows(1) + tpch.lineitem_rows(1)
+    customer = tpch.DeviceColumns(tpch.CUSTOMER_COLUMNS, 1, tpch.customer_rows(1))
+    orders = tpch.DeviceColumns(tpch.ORDERS_COLUMNS, 1, tpch.orders_rows(1))
+    lineitem = tpch.DeviceColumns(tpch.Q3_LINEITEM_COLUMNS, 1, tpch.lineitem_rows(1))
+    stream = _lib.DeviceStream()
+    out, _ = q3.run(customer.pages(1 << 28), orders.pages(1 << 28), lineitem.pages(1 << 28), stream.handle, result_mem=abi.MEM_HOST, top_n=10,
+                    with_count=False)
+    rows = [list(r) for p in out for r in p.to_rows()]
+    stream.destroy()
+    assert len(rows) == 10 and [[int(a), int(b), int(c), float(d)] for a, b, c, d in rows] == native["result"]
