@@ -513,7 +513,7 @@ def topn(pages, n, sort_channels, sort_orders):
     types = [b.type for b in pages[0].blocks] if pages else []
 
     def value_cmp(t, a, b):
-        if t == abi.DOUBLE:
+        if t in (abi.DOUBLE, abi.REAL):  # (RealType's comparison is Float.compare: the same order on the widened values)
             def image(d):
                 bits = 0x7ff8000000000000 if math.isnan(d) else struct.unpack("<Q", struct.pack("<d", d))[0]
                 return (~bits) & 0xFFFFFFFFFFFFFFFF if bits >> 63 else bits | 0x8000000000000000

@@ -246,6 +246,18 @@ static int64_t val_hash(const orc_val* v)
             return orc_hash_integer((int32_t)v->i);
         case PA_DOUBLE:
             return orc_hash_double(v->d);
+        case PA_REAL: { /* SPI/type/RealType.java:107-115: AbstractLongType.hash(floatToIntBits(v == 0 ? 0 : v)) */
+            float f = (float)v->d;
+            uint32_t bits;
+            if (f == 0.0f) {
+                f = 0.0f;
+            }
+            memcpy(&bits, &f, 4);
+            if (f != f) {
+                bits = 0x7fc00000u; /* floatToIntBits: one NaN */
+            }
+            return orc_hash_bigint((int64_t)(int32_t)bits);
+        }
         case PA_BOOLEAN:
             return orc_hash_boolean((int32_t)v->i);
         case PA_VARCHAR:
@@ -1114,6 +1126,7 @@ static int not_distinct(const orc_val* a, const orc_val* b)
     }
     switch (a->type) {
         case PA_DOUBLE:
+        case PA_REAL: /* SPI/type/RealType.java:127-140: the same rule on floats (the values travel widened, exactly) */
             if (a->d != a->d && b->d != b->d) {
                 return 1;
             }
@@ -1676,7 +1689,9 @@ static int64_t join_build_hash(const orc_join* j, int32_t pos)
 static int equals_ignore_nulls(const orc_val* a, const orc_val* b)
 {
     switch (a->type) {
-        case PA_DOUBLE: return a->d == b->d;
+        case PA_DOUBLE:
+        case PA_REAL: /* SPI/type/RealType.java:101-105 */
+            return a->d == b->d;
         case PA_VARCHAR: return a->slen == b->slen && (a->slen == 0 || memcmp(a->s, b->s, (size_t)a->slen) == 0);
         default: return a->i == b->i;
     }

@@ -767,7 +767,7 @@ int32_t pa_hash_page(const pa_page* page, int32_t channel_count, const int32_t* 
             PA_REQUIRE(c >= 0 && c < page->channel_count, PA_ERR_INVALID_ARGUMENT, "hash channel out of range");
             const pa_column& col = page->columns[c];
             PA_REQUIRE(col.encoding == PA_FLAT || col.encoding == PA_VARWIDTH, PA_ERR_NOT_SUPPORTED, "hash of an encoded block");
-            PA_REQUIRE(col.type != PA_REAL && col.type != PA_ROW, PA_ERR_NOT_SUPPORTED, "hash of a REAL / ROW channel is not on the device path");
+            PA_REQUIRE(col.type != PA_ROW, PA_ERR_NOT_SUPPORTED, "hash of a ROW channel is not on the device path");
             a.col[i].values = col.values;
             a.col[i].offsets = col.offsets;
             a.col[i].nulls = col.nulls;

@@ -32,6 +32,7 @@ __device__ __forceinline__ bool jcol_equal(const JoinCol& a, i32 ra, const JoinC
         case PA_INTEGER:
         case PA_DATE: return ((const i32*)a.values)[ra] == ((const i32*)b.values)[rb];
         case PA_DOUBLE: return ((const double*)a.values)[ra] == ((const double*)b.values)[rb];
+        case PA_REAL: return ((const float*)a.values)[ra] == ((const float*)b.values)[rb];  // RealType.equalOperator: NaN matches nothing
         case PA_BOOLEAN: return (((const u8*)a.values)[ra] != 0) == (((const u8*)b.values)[rb] != 0);
         case PA_VARCHAR: {
             i32 oa = a.offsets[ra], ob = b.offsets[rb];

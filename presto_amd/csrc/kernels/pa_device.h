@@ -44,6 +44,10 @@ __device__ __forceinline__ i64 pa_hash_double(double v)
     i64 bits = (v != v) ? 0x7ff8000000000000LL : __double_as_longlong(v);
     return pa_hash_bigint(bits);
 }
+// RealType.hashCodeOperator (core/trino-spi/.../type/RealType.java:107-115): hash(floatToIntBits(v == 0 ? 0 : v)); the canonical bits
+// (+0 for both zeros, one NaN) are also what a REAL group key is compared by (IS NOT DISTINCT FROM, RealType.java:127-140)
+__device__ __forceinline__ u32 pa_real_key_bits(float v) { return v == 0.0f ? 0u : ((v != v) ? 0x7fc00000u : __float_as_uint(v)); }
+__device__ __forceinline__ i64 pa_hash_real(float v) { return pa_hash_bigint((i64)(i32)pa_real_key_bits(v)); }
 // fastutil HashCommon.murmurHash3 == PagesHash.getHashPosition mix (…/operator/join/PagesHash.java:225-241)
 __device__ __forceinline__ u64 pa_murmur3_fmix(u64 h)
 {

@@ -530,7 +530,6 @@ pa_exchange* exchange_new(const pa_exchange_desc* d, pa_comm* comm)
                    "1..16 partition channels (or a hash channel)");
         for (int i = 0; i < d->partition_channel_count; i++) {
             PA_REQUIRE(d->partition_channels[i] >= 0 && d->partition_channels[i] < d->channel_count, PA_ERR_INVALID_ARGUMENT, "partition channel out of range");
-            PA_REQUIRE(d->types[d->partition_channels[i]] != PA_REAL, PA_ERR_NOT_SUPPORTED, "REAL partition keys are not on the device path");
             ex->partition_channels.push_back(d->partition_channels[i]);
         }
     }

@@ -554,6 +554,10 @@ KernelInfo generate(const Spec& s, const std::vector<ChannelLayout>& layout, int
                 part.bits = 32;
                 value = "(u64)(u32)(i32)" + kv.v;
                 break;
+            case PA_REAL:
+                part.bits = 32;  // the key's canonical bits: -0 == +0, NaN == NaN (RealType.java:127-140), hashed as RealType hashes them
+                value = "(u64)pa_real_key_bits(" + kv.v + ")";
+                break;
             case PA_BOOLEAN:
                 part.bits = 1;
                 value = "(" + kv.v + " ? 1ULL : 0ULL)";
@@ -3272,7 +3276,8 @@ void FusedAggregationOperator::build_output()
                     break;
                 }
                 case PA_INTEGER:
-                case PA_DATE: {
+                case PA_DATE:
+                case PA_REAL: {  // (REAL: the canonical float bits, hashed like the int they are -- RealType.hashCodeOperator)
                     int32_t v = is_null ? 0 : (int32_t)(uint32_t)w0;
                     data.insert(data.end(), (uint8_t*)&v, (uint8_t*)&v + 4);
                     if (!is_null) h = (ic >= 0 && (size_t)(uint32_t)v < dict_hash.size()) ? (int64_t)dict_hash[(uint32_t)v] : host_hash_bigint((int64_t)v);

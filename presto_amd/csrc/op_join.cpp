@@ -78,7 +78,6 @@ public:
         }
         for (int i = 0; i < d->join_channel_count; i++) {
             PA_REQUIRE(d->join_channels[i] >= 0 && d->join_channels[i] < d->input_channel_count, PA_ERR_INVALID_ARGUMENT, "join channel out of range");
-            PA_REQUIRE(d->input_types[d->join_channels[i]] != PA_REAL, PA_ERR_NOT_SUPPORTED, "REAL join keys are not on the device path");
             ls_->join_channels.push_back(d->join_channels[i]);
         }
         for (int i = 0; i < d->output_channel_count; i++) {

@@ -49,7 +49,6 @@ public:
         for (int c : output_channels_) PA_REQUIRE(c >= 0 && c < (int)types_.size(), PA_ERR_INVALID_ARGUMENT, "output channel out of range");
         for (size_t i = 0; i < sort_channels_.size(); i++) {
             PA_REQUIRE(sort_channels_[i] >= 0 && sort_channels_[i] < (int)types_.size(), PA_ERR_INVALID_ARGUMENT, "sort channel out of range");
-            PA_REQUIRE(types_[(size_t)sort_channels_[i]] != PA_REAL, PA_ERR_NOT_SUPPORTED, "REAL sort keys are not on the device path");
             PA_REQUIRE(sort_orders_[i] >= 0 && sort_orders_[i] <= 3, PA_ERR_INVALID_ARGUMENT, "unknown sort order");
         }
         output_mem_ = d->output_mem;

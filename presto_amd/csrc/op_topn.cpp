@@ -40,7 +40,6 @@ public:
         sort_orders_.assign(d->sort_orders, d->sort_orders + d->sort_channel_count);
         for (size_t i = 0; i < sort_channels_.size(); i++) {
             PA_REQUIRE(sort_channels_[i] >= 0 && sort_channels_[i] < (int)types_.size(), PA_ERR_INVALID_ARGUMENT, "sort channel out of range");
-            PA_REQUIRE(types_[(size_t)sort_channels_[i]] != PA_REAL, PA_ERR_NOT_SUPPORTED, "REAL sort keys are not on the device path");
             PA_REQUIRE(sort_orders_[i] >= 0 && sort_orders_[i] <= 3, PA_ERR_INVALID_ARGUMENT, "unknown sort order");
         }
         n_ = d->n;
@@ -343,6 +342,19 @@ private:
                 auto image = [&](int64_t r) {
                     double d;
                     memcpy(&d, &hc.values[(size_t)r * 8], 8);
+                    uint64_t bits;
+                    if (d != d) bits = 0x7ff8000000000000ULL;
+                    else memcpy(&bits, &d, 8);
+                    return (bits >> 63) ? ~bits : (bits | 0x8000000000000000ULL);
+                };
+                const uint64_t x = image(a), y = image(b);
+                return x < y ? -1 : (x > y ? 1 : 0);
+            }
+            case PA_REAL: {  // Float.compare (RealType.comparisonOperator): the order of the widened values' images
+                auto image = [&](int64_t r) {
+                    float f;
+                    memcpy(&f, &hc.values[(size_t)r * 4], 4);
+                    const double d = (double)f;
                     uint64_t bits;
                     if (d != d) bits = 0x7ff8000000000000ULL;
                     else memcpy(&bits, &d, 8);

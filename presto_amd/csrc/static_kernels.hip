@@ -384,6 +384,7 @@ __device__ __forceinline__ void gt_emit_slot(const GtEmitArgs& a, u64 i, u64 g)
                         case PA_BIGINT: bits = w0; h = pa_hash_bigint((i64)w0); break;
                         case PA_INTEGER:
                         case PA_DATE:
+                        case PA_REAL:  // canonical float bits, hashed as the int they are (RealType.hashCodeOperator)
                             bits = (u64)(u32)w0;
                             h = col.dict_hash ? (i64)col.dict_hash[(u32)w0] : pa_hash_bigint((i64)(i32)(u32)w0);
                             break;
@@ -404,6 +405,7 @@ __device__ __forceinline__ void gt_emit_slot(const GtEmitArgs& a, u64 i, u64 g)
                         const double v = __longlong_as_double((i64)bits);
                         bits = v == 0.0 ? 0ULL : (v != v ? 0x7ff8000000000000ULL : bits);
                     }
+                    else if (col.type == PA_REAL) bits = (u64)pa_real_key_bits(__uint_as_float((u32)bits));
                 }
                 break;
             }
@@ -522,6 +524,7 @@ __global__ __launch_bounds__(256) void k_hash_page(HashPageArgs a)
                     case PA_INTEGER:
                     case PA_DATE: h = pa_hash_bigint((i64)((const i32*)col.values)[r]); break;
                     case PA_DOUBLE: h = pa_hash_double(((const double*)col.values)[r]); break;
+                    case PA_REAL: h = pa_hash_real(((const float*)col.values)[r]); break;
                     case PA_BOOLEAN: h = (i64)pa_xxh64_long(((const u8*)col.values)[r] ? 1ULL : 0ULL); break;
                     case PA_VARCHAR: {
                         i32 o = col.offsets[r];

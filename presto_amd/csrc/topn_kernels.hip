@@ -42,6 +42,13 @@ __global__ __launch_bounds__(256) void k_topn_keys(i32 type, const void* __restr
                     img = (b >> 63) ? ~b : (b | 0x8000000000000000ULL);
                     break;
                 }
+                case PA_REAL: {
+                    // Float.compare order (RealType.comparisonOperator) = Double.compare order of the widened values
+                    const double d = (double)((const float*)values)[i];
+                    u64 b = d != d ? 0x7ff8000000000000ULL : (u64)__double_as_longlong(d);
+                    img = (b >> 63) ? ~b : (b | 0x8000000000000000ULL);
+                    break;
+                }
                 case PA_VARCHAR: {
                     // Slice.compareTo = unsigned bytes, shorter first: the first 8 bytes big-endian are a monotone image
                     const i32 o = offsets[i], len = offsets[i + 1] - o;

@@ -133,15 +133,115 @@ def test_real_fused_filter_and_payload_channels(gpu, oracle):
     same_rows(back.to_rows(), pages[0].to_rows())
 
 
-def test_real_keys_are_refused(gpu):
-    from presto_amd._lib import PrestoAmdError
+def key_pool(rng, distinct):
+    return np.concatenate([(rng.standard_normal(distinct) * 50).astype(F32), np.array([0.0, -0.0, np.nan, np.inf, -np.inf, 1e-42, -1e-42], dtype=F32)])
+
+
+def key_page(rng, n, distinct, nulls=True, pool=None):
+    """a REAL key channel with both zeros, NaN, +-Inf, denormals and NULLs among `distinct` ordinary values, and two payload channels"""
+    if pool is None:
+        pool = key_pool(rng, distinct)
+    k = pool[rng.integers(0, len(pool), n)]
+    return Page([Block.real(k, rng.random(n) < 0.04 if nulls else None), Block.bigint(rng.integers(-50, 50, n)), Block.double(rng.random(n))], n)
+
+
+KEY_TYPES = [abi.REAL, abi.BIGINT, abi.DOUBLE]
+
+
+def norm(rows):  # NaN != NaN, and the key of the zero group may come out with either sign
+    return sorted((tuple("nan" if isinstance(v, float) and v != v else (0.0 if isinstance(v, float) and v == 0 else v) for v in r) for r in rows), key=repr)
+
+
+@pytest.mark.parametrize("distinct,n", [(3, 2000), (500, 60000), (40000, 300000)])
+def test_group_by_a_real_key(gpu, oracle, distinct, n):
+    """REAL group keys: -0 and +0 are one group, NaN is one group (IS NOT DISTINCT FROM, RealType.java:127-140), NULL is a group;
+    every tier (few groups in registers / LDS, many in the HBM table).  Sums of integers and counts exact, the DOUBLE sum to 1e-9."""
+    rng = np.random.default_rng(distinct)
+    pool = key_pool(rng, distinct)
+    pages = [key_page(rng, n, distinct, pool=pool), key_page(rng, n // 3 + 1, distinct, pool=pool)]
+    aggs = [(abi.AGG_COUNT_STAR, -1, None), (abi.AGG_SUM, 1, abi.BIGINT), (abi.AGG_SUM, 2, abi.DOUBLE), (abi.AGG_MIN, 1, abi.BIGINT)]
+    ref = oracle.HashAggregation(KEY_TYPES, [0], aggs)
+    for p in pages:
+        ref.add_page(p)
+    expected = norm(ref.build_result().to_rows())
+    got = norm([r for p in to_pages(HashAggregationOperator(KEY_TYPES, [0], aggs, expected_groups=distinct + 8), pages) for r in p.to_rows()])
+    assert len(got) == len(expected)
+    for g, e in zip(got, expected):
+        assert g[:3] == e[:3] and g[4] == e[4] and abs(g[3] - e[3]) <= 1e-9 * max(abs(e[3]), 1.0)
+    # the two-column key (REAL, BIGINT) through the fused operator
+    fused = FusedAggregationOperator(KEY_TYPES, None, [field(0, abi.REAL), field(1, abi.BIGINT), field(2, abi.DOUBLE)], [0, 1], [(abi.AGG_COUNT_STAR, -1, None)])
+    ref2 = oracle.HashAggregation(KEY_TYPES, [0, 1], [(abi.AGG_COUNT_STAR, -1, None)])
+    for p in pages:
+        ref2.add_page(p)
+    assert norm([r for p in to_pages(fused, pages) for r in p.to_rows()]) == norm(ref2.build_result().to_rows())
+
+
+@pytest.mark.parametrize("join_type", [abi.JOIN_INNER, abi.JOIN_PROBE_OUTER, abi.JOIN_FULL_OUTER])
+def test_join_on_a_real_key(gpu, oracle, join_type):
+    """REAL join keys: RealType.equalOperator is ==, so NaN matches nothing and -0 matches +0 (their hash is the same);
+    rows, order and chains as the oracle's PagesHash."""
+    rng = np.random.default_rng(41 + join_type)
+    pool = key_pool(rng, 400)   # (both sides draw from the same values: chains of ~7 build rows per key)
+    build, probe = [key_page(rng, 3000, 400, pool=pool)], [key_page(rng, 5000, 400, pool=pool), key_page(rng, 1, 400, pool=pool)]
+    bridge = LookupSourceFactory()
+    to_pages(HashBuilderOperator(bridge, KEY_TYPES, [0], [0, 1]), build)
+    join = LookupJoinOperator(bridge, KEY_TYPES, [0], [0, 2], join_type=join_type)
+    got = [r for p in to_pages(join, probe) for r in p.to_rows()]
+    ref = oracle.HashJoin(KEY_TYPES, [0], [0, 1])
+    ref.add_build_page(build[0])
+    ref.build()
+    expected = [r for p in probe for r in ref.probe(p, KEY_TYPES, [0], [0, 2], join_type=join_type)[0].to_rows()]
+
+    def nn(rows):
+        return [tuple("nan" if isinstance(v, float) and v != v else v for v in r) for r in rows]
+    assert nn(got) == nn(expected) and len(got) > 20000
+
+
+def test_sort_by_a_real_key(gpu, oracle):
+    """TopN and OrderBy by a REAL channel: Float.compare order (-Inf < .. < -0.0 < 0.0 < .. < Inf < NaN), NULL placement, both
+    directions, a second key breaking ties."""
     from presto_amd.operators import OrderByOperator
-    cases = [lambda: HashAggregationOperator([abi.REAL], [0], [(abi.AGG_COUNT_STAR, -1, None)]),
-             lambda: HashBuilderOperator(LookupSourceFactory(), [abi.REAL], [0], []),
-             lambda: TopNOperator([abi.REAL], 5, [0], [abi.ASC_NULLS_LAST]),
-             lambda: OrderByOperator([abi.REAL], [0], [0], [abi.ASC_NULLS_LAST])]
-    for make in cases:
-        with pytest.raises(PrestoAmdError) as e:
-            op = make()
-            to_pages(op, [Page([Block.real([1.0, 2.0])], 2)])
-        assert e.value.status == abi.ERR_NOT_SUPPORTED
+    rng = np.random.default_rng(77)
+    pages = [key_page(rng, 20000, 300), key_page(rng, 777, 300)]
+    for order in (abi.ASC_NULLS_LAST, abi.DESC_NULLS_FIRST, abi.ASC_NULLS_FIRST, abi.DESC_NULLS_LAST):
+        expected = oracle.topn(pages, 200, [0, 1], [order, abi.ASC_NULLS_LAST])
+        got = [r for p in to_pages(TopNOperator(KEY_TYPES, 200, [0, 1], [order, abi.ASC_NULLS_LAST]), pages) for r in p.to_rows()]
+
+        def keys(rows):   # rows tied on both keys may come in either order
+            return [tuple("nan" if isinstance(v, float) and v != v else (repr(v) if isinstance(v, float) else v) for v in r[:2]) for r in rows]
+        assert keys(got) == keys(expected)
+        ordered = [r for p in to_pages(OrderByOperator(KEY_TYPES, [0, 1], [0, 1], [order, abi.ASC_NULLS_LAST]), pages) for r in p.to_rows()]
+        assert keys(ordered) == keys(oracle.order_by(pages, [0, 1], [0, 1], [order, abi.ASC_NULLS_LAST]))
+
+
+def test_hash_of_a_real_channel(gpu, oracle):
+    """$hashvalue over a REAL channel: AbstractLongType.hash(floatToIntBits(v)) with +0 for both zeros and one NaN -- what routes a row
+    through a partitioned exchange."""
+    import ctypes as C
+
+    from presto_amd._lib import DeviceAllocation, check, lib
+    from presto_amd.operators import DeviceBuffer, download, upload_page
+
+    def hash_page(page, channels):
+        cpage, keep = upload_page(page).to_c()
+        buf = DeviceAllocation(8 * page.position_count)
+        check(lib().pa_hash_page(C.byref(cpage), len(channels), abi.int32_array(channels), buf.ptr, None))
+        check(lib().pa_stream_synchronize(None))
+        return download(DeviceBuffer(buf.ptr, 8 * page.position_count), np.int64, page.position_count)
+
+    rng = np.random.default_rng(5)
+    page = key_page(rng, 5000, 100)
+    assert np.array_equal(hash_page(page, [0]), oracle.hash_page(page, [0]))
+    assert np.array_equal(hash_page(page, [1, 0]), oracle.hash_page(page, [1, 0]))
+    zeros = Page([Block.real(np.array([0.0, -0.0], dtype=F32))], 2)
+    h = hash_page(zeros, [0])
+    assert h[0] == h[1]
+
+
+def test_real_dynamic_filter_channels_are_refused(gpu):
+    from presto_amd._lib import PrestoAmdError
+    from presto_amd.operators import DynamicFilterSourceOperator
+    with pytest.raises(PrestoAmdError) as e:
+        op = DynamicFilterSourceOperator([abi.REAL], [0], 100, 1 << 20, 100)
+        to_pages(op, [Page([Block.real([1.0, 2.0])], 2)])
+    assert e.value.status == abi.ERR_NOT_SUPPORTED

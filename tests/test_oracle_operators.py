@@ -425,3 +425,38 @@ def test_real_type_hand_computed(oracle):
     # the wire format carries the raw bits as INT_ARRAY
     frame = oracle.serialize_page(page)
     assert b"INT_ARRAY" in frame and oracle.deserialize_page(frame).position_count == 4
+
+
+def test_real_keys_hand_computed(oracle):
+    """RealType as a key (core/trino-spi/.../type/RealType.java:101-140): hash = AbstractLongType.hash(floatToIntBits(v == 0 ? 0 : v)) --
+    computed here from the constants of AbstractLongType.java:126-130, independently of the oracle's C --, -0 and +0 one group, NaN
+    one group, NaN joins nothing, Float.compare order."""
+    import struct
+    M = (1 << 64) - 1
+
+    def long_hash(v):  # rotateLeft(v * 0xC2B2AE3D27D4EB4F, 31) * 0x9E3779B185EBCA87
+        x = (v * 0xC2B2AE3D27D4EB4F) & M
+        x = ((x << 31) | (x >> 33)) & M
+        x = (x * 0x9E3779B185EBCA87) & M
+        return x - (1 << 64) if x >> 63 else x
+
+    def real_hash(f):
+        bits = struct.unpack("<i", struct.pack("<f", 0.0 if f == 0 else f))[0] if f == f else 0x7fc00000
+        return long_hash(bits & M if bits >= 0 else (bits + (1 << 64)))
+
+    values = np.array([1.0, -2.5, 0.0, -0.0, np.nan, np.inf, 1e-42], dtype=np.float32)
+    page = Page([Block.real(values), Block.bigint(np.arange(len(values)))], len(values))
+    # row hash of one channel = 31 * 0 + hash(value)
+    assert list(oracle.hash_page(page, [0])) == [real_hash(float(v)) for v in values]
+    assert real_hash(0.0) == real_hash(-0.0)
+    agg = oracle.HashAggregation([abi.REAL, abi.BIGINT], [0], [(abi.AGG_COUNT_STAR, -1, None)])
+    agg.add_page(Page([Block.real(np.array([0.0, -0.0, np.nan, np.nan, 1.0, 1.0, 1.0], dtype=np.float32)), Block.bigint(np.zeros(7, dtype=np.int64))], 7))
+    counts = sorted(r[1] for r in agg.build_result().to_rows())
+    assert counts == [2, 2, 3]
+    join = oracle.HashJoin([abi.REAL, abi.BIGINT], [0], [1])
+    join.add_build_page(Page([Block.real(np.array([0.0, np.nan, 2.0], dtype=np.float32)), Block.bigint(np.array([10, 11, 12]))], 3))
+    join.build()
+    out, _, _ = join.probe(Page([Block.real(np.array([-0.0, np.nan, 2.0, 3.0], dtype=np.float32)), Block.bigint(np.arange(4))], 4), [abi.REAL, abi.BIGINT], [0], [1])
+    assert out.to_rows() == [(0, 10), (2, 12)]          # -0 = +0; NaN = nothing
+    rows = oracle.topn([Page([Block.real(np.array([np.nan, 0.0, -0.0, -np.inf, 5.0], dtype=np.float32))], 5)], 5, [0], [abi.ASC_NULLS_LAST])
+    assert [repr(r[0]) for r in rows] == ["-inf", "-0.0", "0.0", "5.0", "nan"]
