@@ -1930,7 +1930,7 @@ public:
         build_output();
         if (grouped_ && out_rows_ > 0) decode_interned_keys();
         if (!grouped_ || out_rows_ > 0) {
-            publish_output(out_cols_, out_rows_, spec_.output_mem, stream_.get(), out, out_storage_);
+            publish_output(out_cols_, out_rows_, spec_.output_mem, stream_.get(), stream_.owned(), out, out_storage_);
             return true;
         }
         return false;  // HashAggregationOperator emits nothing for an empty input (SINGLE step with keys)
@@ -1946,7 +1946,7 @@ public:
         build_output();
         if (grouped_ && out_rows_ > 0) decode_interned_keys();
         if (grouped_ && out_rows_ == 0) return false;
-        publish_output(out_cols_, out_rows_, PA_MEM_DEVICE, stream_.get(), out, out_storage_);
+        publish_output(out_cols_, out_rows_, PA_MEM_DEVICE, stream_.get(), stream_.owned(), out, out_storage_);
         return true;
     }
 

@@ -516,7 +516,7 @@ public:
             gather_column(src.type, src.varwidth, src.values.ptr(), src.offsets.as<int32_t>(), src.has_nulls ? src.nulls.as<uint8_t>() : nullptr,
                           build_pos, total_out, out_cols_[oc++], s, probe_outer_);
         }
-        publish_output(out_cols_, total_out, output_mem_, s, out, out_storage_);
+        publish_output(out_cols_, total_out, output_mem_, s, stream_.owned(), out, out_storage_);
         range_lo_ = hi;
         remaining_ -= sum;
         pending_ = hi < n && remaining_ > 0;
@@ -822,7 +822,7 @@ public:
             }
             if (nulls) launch_gather_nulls(nulls, pos, count, static_cast<uint8_t*>(o.nulls.ensure((size_t)count)), s);
         }
-        publish_output(out_cols_, count, output_mem_, s, out, out_storage_);
+        publish_output(out_cols_, count, output_mem_, s, stream_.owned(), out, out_storage_);
         return true;
     }
 
