@@ -515,6 +515,10 @@ int32_t pa_lookup_outer_create(const pa_lookup_join_desc* desc, pa_lookup_source
 
 /* ---- Operator protocol (Operator.java:21-103; call order Driver.java:355-457) ---- */
 int32_t pa_op_needs_input(pa_operator* op);                 /* 1 / 0 */
+/* The page's buffers must stay valid until the call returns -- and, for pages flagged PA_PAGE_STABLE, until the operator is closed.
+ * A PA_MEM_DEVICE page without that flag (what another operator's pa_op_get_output returned) is read in stream order: an operator
+ * on the caller-provided desc.stream may still have work on it enqueued there when the call returns -- the producer, on the same
+ * stream, is ordered behind it --, an operator on a stream of the library's own has finished with it. */
 int32_t pa_op_add_input(pa_operator* op, const pa_page* page);
 /* Returns 1 and fills *out when a page is available, 0 when none.  The page's buffers are owned by
  * the operator (or, for zero-copy identity projections, are the caller's own input buffers) and stay valid

@@ -677,6 +677,12 @@ int32_t pa_op_add_input(pa_operator* op, const pa_page* page)
         OpScope scope(op);
         PA_REQUIRE(op->needs_input(), PA_ERR_ILLEGAL_STATE, "Operator does not need input");
         op->add_input(page);
+        // A device page some operator returned is that operator's again with its next call.  Work this operator has enqueued on the
+        // page is ordered before that call when both run on the caller's stream; on a stream of the operator's own nothing orders it
+        // (an aggregation copies a small page into its arena with a kernel of its own stream and returns), so that stream is drained.
+        if (page != nullptr && page->mem == PA_MEM_DEVICE && (page->flags & PA_PAGE_STABLE) == 0) {
+            if (hipStream_t s = op->private_stream()) PA_HIP(hipStreamSynchronize(s));
+        }
         return PA_OK;
     });
 }

@@ -163,11 +163,11 @@ DevPage PageStager::stage(const pa_page* page, const std::vector<bool>* needed, 
     return out;
 }
 
-void publish_output(std::vector<OutColumn>& cols, int32_t n, int32_t mem, hipStream_t stream, bool stream_owned, pa_page* out,
+void publish_output(std::vector<OutColumn>& cols, int32_t n, int32_t mem, hipStream_t stream, pa_page* out,
                     std::vector<pa_column>& storage)
 {
     storage.assign(cols.size() ? cols.size() : 1, pa_column{});
-    bool need_sync = mem == PA_MEM_DEVICE && stream_owned;
+    bool need_sync = false;
     for (size_t c = 0; c < cols.size(); c++) {
         OutColumn& o = cols[c];
         pa_column& p = storage[c];

@@ -58,10 +58,7 @@ struct OutColumn {
 
 // Fills `out` (whose `columns` array has room for cols.size() entries) from device columns; for
 // PA_MEM_HOST copies the first `n` positions to pinned memory and synchronises the stream.
-// A PA_MEM_DEVICE page leaves in stream order: on a stream the caller passed in the descriptor the next operator is expected to
-// run on that stream too (a Driver's pipeline shares one) and nothing waits; on a stream of the operator's own
-// (`stream_owned`) nobody else can order work behind the kernels still writing the page, so the stream is drained first.
-void publish_output(std::vector<OutColumn>& cols, int32_t n, int32_t mem, hipStream_t stream, bool stream_owned, pa_page* out,
+void publish_output(std::vector<OutColumn>& cols, int32_t n, int32_t mem, hipStream_t stream, pa_page* out,
                     std::vector<pa_column>& storage);
 
 // static kernels used by staging (static_kernels.hip)

@@ -271,8 +271,11 @@ __device__ __forceinline__ u32 pa_wave_prefix(bool pred, u32* total)
 }
 
 // packed-key hashing for the group tables (any good mix; not part of results parity)
+// (the halves are folded AFTER a 64-bit multiply: folding the key's own halves made every pair of packed keys (a, b), (a ^ d, b ^ d)
+// collide in all 32 bits -- (day, priority) = (9172, 1) and (9173, 0) -- and equal hashes are equal tags in the tables)
 __device__ __forceinline__ u32 pa_mix32(u64 k)
 {
+    k *= 0x9E3779B97F4A7C15ULL;
     u32 x = (u32)k ^ (u32)(k >> 32);
     x *= 0x9E3779B1u;
     x ^= x >> 15;
@@ -591,6 +594,7 @@ __device__ __forceinline__ u64 pa_short_bytes(const u8* p, i32 len, i32 bound, i
 // grid): loads and atomics on ONE address from every insert retire at well under 1 G/s on this part and used to bound
 // launches that create millions of groups.  The estimate only decides when rows start to be spilled; a probe-length
 // bound backs it up, and the exact count is known to the host after every launch.
+#define PA_GT_KEY_CLEAR 0xA5A5A5A5A5A5A5A5ULL  // what hipMemset(0xA5) leaves in the key words of a new table
 struct PaGtCtr {
     i32 base;   // groups in the table when the kernel started
     i32 scale;  // waves in the grid
@@ -620,9 +624,14 @@ __device__ __forceinline__ int pa_gt_upsert_n(u64* tag, u64* keys, u32 mask, u32
     int result = -2;  // -2 = still searching, -1 = no room, >= 0 = slot
     // Fast path for groups that already exist (the common case once a table is warm): ordinary cached loads.
     // Tags only ever go empty -> busy -> ready and key words are written once, before the tag turns ready, so a
-    // (possibly stale) cached view can at worst miss a group that exists -- never match a wrong one.  Hot groups
+    // (possibly stale) cached view can at worst miss a group that exists -- never match a wrong one -- PROVIDED the key words
+    // of an unclaimed slot cannot look like a key: the key arrays are cleared to PA_GT_KEY_CLEAR when a table is made (a
+    // recycled block holds the keys of its previous life: a stale line then matched a key whose hash collided with the
+    // slot's new owner, and its rows went to that group), and a key that IS the clear pattern skips this path.  Hot groups
     // are then served from L1/L2 instead of hammering one memory channel with device-scope loads.
-    {
+    bool clear_pattern = true;
+    for (int w = 0; w < W; w++) clear_pattern = clear_pattern && k[w] == PA_GT_KEY_CLEAR;
+    if (!clear_pattern) {
         u32 j = i;
         for (int probe = 0; probe < 8; probe++) {
             const u64 t = tag[j];

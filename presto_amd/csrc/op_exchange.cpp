@@ -288,7 +288,7 @@ public:
         done_ = true;
         const int64_t rows = transfer();
         if (rows == 0) return false;
-        publish_output(out_cols_, (int32_t)rows, output_mem_, stream_.get(), stream_.owned(), out, out_storage_);
+        publish_output(out_cols_, (int32_t)rows, output_mem_, stream_.get(), out, out_storage_);
         return true;
     }
 

@@ -537,21 +537,21 @@ public:
         hipStream_t s = stream_.get();
         if (big_queued_) {  // :114-119 the big page that followed a flush
             big_queued_ = false;
-            publish_output(out_cols_, big_count_, spec_.output_mem, s, stream_.owned(), out, out_storage_);
+            publish_output(out_cols_, big_count_, spec_.output_mem, s, out, out_storage_);
             return true;
         }
         if (pending_) {
             int32_t count = 0;
             const bool have = process_pending(&count);
             if (have && !merging_) {
-                publish_output(out_cols_, count, spec_.output_mem, s, stream_.owned(), out, out_storage_);
+                publish_output(out_cols_, count, spec_.output_mem, s, out, out_storage_);
                 return true;
             }
             if (have) {
                 const int64_t bytes = page_size_in_bytes(count);
                 if (count >= merge_min_rows_ || bytes >= merge_min_bytes_) {  // :128
                     if (m_rows_ == 0) {
-                        publish_output(out_cols_, count, spec_.output_mem, s, stream_.owned(), out, out_storage_);
+                        publish_output(out_cols_, count, spec_.output_mem, s, out, out_storage_);
                         return true;
                     }
                     big_queued_ = true;  // :133-138
@@ -698,7 +698,7 @@ public:
             mc.is_view = false;
             mc.host_ready = false;
         }
-        publish_output(merge_cols_, n, spec_.output_mem, stream_.get(), stream_.owned(), out, merge_storage_);
+        publish_output(merge_cols_, n, spec_.output_mem, stream_.get(), out, merge_storage_);
         m_rows_ = 0;
         m_size_ = 0;
         for (auto& mc : merge_cols_) mc.has_nulls = false;  // the pointers of the published page are already taken

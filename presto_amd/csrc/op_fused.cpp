@@ -1930,7 +1930,7 @@ public:
         build_output();
         if (grouped_ && out_rows_ > 0) decode_interned_keys();
         if (!grouped_ || out_rows_ > 0) {
-            publish_output(out_cols_, out_rows_, spec_.output_mem, stream_.get(), stream_.owned(), out, out_storage_);
+            publish_output(out_cols_, out_rows_, spec_.output_mem, stream_.get(), out, out_storage_);
             return true;
         }
         return false;  // HashAggregationOperator emits nothing for an empty input (SINGLE step with keys)
@@ -1946,7 +1946,7 @@ public:
         build_output();
         if (grouped_ && out_rows_ > 0) decode_interned_keys();
         if (grouped_ && out_rows_ == 0) return false;
-        publish_output(out_cols_, out_rows_, PA_MEM_DEVICE, stream_.get(), stream_.owned(), out, out_storage_);
+        publish_output(out_cols_, out_rows_, PA_MEM_DEVICE, stream_.get(), out, out_storage_);
         return true;
     }
 
@@ -2138,6 +2138,8 @@ private:
         words.ensure(slots * 8 * nw_);
         rc.ensure(128 * 4);
         PA_HIP(hipMemsetAsync(tag.ptr(), 0, slots * 8, s));
+        // (PA_GT_KEY_CLEAR: no slot's key words may look like a key before the slot is claimed -- see pa_gt_upsert_n's fast path)
+        PA_HIP(hipMemsetAsync(keys.ptr(), 0xA5, slots * 8 * std::max(w_, 1), s));
         PA_HIP(hipMemsetAsync(words.ptr(), 0, slots * 8 * nw_, s));
         PA_HIP(hipMemsetAsync(rc.ptr(), 0, 128 * 4, s));
         if (gt_cap_ > 0) {

@@ -389,6 +389,8 @@ public:
         if (page->position_count == 0) return;
         hipStream_t s = stream_.get();
         in_ = stager_.stage(page, &needed_, s);
+        // (a device page some operator upstream returned: its buffers are that operator's again with its next call)
+        in_volatile_ = page->mem == PA_MEM_DEVICE && (page->flags & PA_PAGE_STABLE) == 0;
         const int32_t n = in_.n;
         JoinKeys pk;
         memset(&pk, 0, sizeof pk);
@@ -456,6 +458,9 @@ public:
         if (remaining_ < 0) {
             PA_HIP(hipStreamSynchronize(s));
             memcpy(&remaining_, h_ctl_ + 4, 8);
+            // more matches than one output page holds: the page is joined range by range over several get_output calls, and the
+            // operator upstream may be given its next page in between -- the probe channels still to be read are kept
+            if (remaining_ > max_output_rows() && in_volatile_) keep_input(s);
         }
         int32_t lo = range_lo_, hi = n;
         int64_t sum = remaining_;
@@ -516,11 +521,49 @@ public:
             gather_column(src.type, src.varwidth, src.values.ptr(), src.offsets.as<int32_t>(), src.has_nulls ? src.nulls.as<uint8_t>() : nullptr,
                           build_pos, total_out, out_cols_[oc++], s, probe_outer_);
         }
-        publish_output(out_cols_, total_out, output_mem_, s, stream_.owned(), out, out_storage_);
+        publish_output(out_cols_, total_out, output_mem_, s, out, out_storage_);
         range_lo_ = hi;
         remaining_ -= sum;
         pending_ = hi < n && remaining_ > 0;
         return true;
+    }
+
+    // private copies of the probe page's channels this operator reads (in_ is repointed to them)
+    void keep_input(hipStream_t s)
+    {
+        const int64_t n = in_.n;
+        kept_.resize(in_.cols.size() * 3);
+        for (size_t c = 0; c < in_.cols.size(); c++) {
+            if (!needed_[c]) continue;
+            DevColumn& col = in_.cols[c];
+            if (col.values == nullptr) continue;
+            if (col.varwidth) {
+                int32_t ends[2] = {0, 0};
+                PA_HIP(hipMemcpyAsync(&ends[0], col.offsets, 4, hipMemcpyDeviceToHost, s));
+                PA_HIP(hipMemcpyAsync(&ends[1], col.offsets + n, 4, hipMemcpyDeviceToHost, s));
+                PA_HIP(hipStreamSynchronize(s));
+                const size_t bytes = (size_t)(ends[1] - ends[0]);
+                char* v = static_cast<char*>(kept_[3 * c].ensure(bytes ? bytes : 1));
+                if (bytes) PA_HIP(hipMemcpyAsync(v, static_cast<const char*>(col.values) + ends[0], bytes, hipMemcpyDeviceToDevice, s));
+                int32_t* o = static_cast<int32_t*>(kept_[3 * c + 1].ensure((size_t)(n + 1) * 4));
+                PA_HIP(hipMemcpyAsync(o, col.offsets, (size_t)(n + 1) * 4, hipMemcpyDeviceToDevice, s));
+                col.values = v - ends[0];  // (the offsets stay absolute)
+                col.offsets = o;
+            }
+            else {
+                const size_t bytes = (size_t)n * type_width(col.type);
+                void* v = kept_[3 * c].ensure(bytes ? bytes : 1);
+                if (bytes) PA_HIP(hipMemcpyAsync(v, col.values, bytes, hipMemcpyDeviceToDevice, s));
+                col.values = v;
+            }
+            if (col.nulls) {
+                uint8_t* nl = static_cast<uint8_t*>(kept_[3 * c + 2].ensure((size_t)n));
+                PA_HIP(hipMemcpyAsync(nl, col.nulls, (size_t)n, hipMemcpyDeviceToDevice, s));
+                col.nulls = nl;
+            }
+        }
+        PA_HIP(hipStreamSynchronize(s));
+        in_volatile_ = false;
     }
 
     void finish() override { finishing_ = true; }
@@ -713,6 +756,8 @@ private:
     std::vector<bool> needed_;
     int hash_channel_ = -1, output_mem_ = PA_MEM_HOST;
     DevPage in_;
+    bool in_volatile_ = false;
+    std::vector<DevBuf> kept_;  // keep_input: per channel values, offsets, NULL flags
     DevBuf ctl_buf_, hash_, head_, counts_, probe_idx_, build_pos_, scan_temp_;
     // JoinFilterFunction
     std::unique_ptr<pa_operator> filter_;
@@ -822,7 +867,7 @@ public:
             }
             if (nulls) launch_gather_nulls(nulls, pos, count, static_cast<uint8_t*>(o.nulls.ensure((size_t)count)), s);
         }
-        publish_output(out_cols_, count, output_mem_, s, stream_.owned(), out, out_storage_);
+        publish_output(out_cols_, count, output_mem_, s, out, out_storage_);
         return true;
     }
 

@@ -213,7 +213,7 @@ public:
             }
             if (nulls) launch_gather_nulls(nulls, perm, n, static_cast<uint8_t*>(oc.nulls.ensure((size_t)n)), s);
         }
-        publish_output(out_cols_, (int32_t)n, output_mem_, s, stream_.owned(), out, out_storage_);
+        publish_output(out_cols_, (int32_t)n, output_mem_, s, out, out_storage_);
         return true;
     }
 

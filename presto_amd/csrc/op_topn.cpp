@@ -110,7 +110,7 @@ public:
         std::stable_sort(order.begin(), order.end(), [&](int64_t a, int64_t b) { return compare_rows(a, b) < 0; });
         const int64_t m = std::min<int64_t>(rows, n_);
         build_output(order, m);
-        publish_output(out_cols_, (int32_t)m, output_mem_, stream_.get(), stream_.owned(), out, out_storage_);
+        publish_output(out_cols_, (int32_t)m, output_mem_, stream_.get(), out, out_storage_);
         return true;
     }
 

@@ -391,7 +391,7 @@ pa_page_buffer* deserialize_page(const void* bytes, int64_t size, hipStream_t s,
         }
     }
     PA_HIP(hipStreamSynchronize(s));
-    publish_output(pb.cols, n, PA_MEM_DEVICE, s, false, &pb.page, pb.storage);
+    publish_output(pb.cols, n, PA_MEM_DEVICE, s, &pb.page, pb.storage);
     return out.release();
 }
 

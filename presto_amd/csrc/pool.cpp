@@ -123,6 +123,17 @@ void* pool_device_alloc(size_t bytes, size_t* granted)
             p.device_free.erase(it);
             p.device_cached -= c;
             *granted = c;
+            // PRESTO_AMD_POOL_SCRUB=<byte>: a recycled block is overwritten before it is handed out -- shows code that relies on
+            // what a previous owner left behind (debugging aid; the scrub waits for the device)
+            static const int scrub = [] {
+                const char* e = getenv("PRESTO_AMD_POOL_SCRUB");
+                return e ? (int)strtol(e, nullptr, 0) & 0xff : -1;
+            }();
+            if (scrub >= 0) {
+                (void)hipDeviceSynchronize();
+                (void)hipMemset(ptr, scrub, c);
+                (void)hipDeviceSynchronize();
+            }
             return ptr;
         }
         (void)hipGetLastError();

@@ -313,3 +313,25 @@ def test_nullability_changes_between_pages(gpu, oracle, groups, step):
         final = HashAggregationOperator(ptypes, [0, 1], faggs, step=abi.STEP_FINAL) if groups else AggregationOperator(ptypes, faggs, step=abi.STEP_FINAL)
         got = [r for p in to_pages(final, partial_pages) for r in p.to_rows()]
     rows_equal_ignore_order(got, expected, rel=1e-9)
+
+
+def test_group_tables_on_recycled_memory(gpu, oracle):
+    """The same aggregation forty times in a row: every operator's group table lives in blocks the previous one gave back to the pool,
+    still holding ITS keys.  Keys whose packed halves XOR to the same value -- (day, priority) = (9172, 1) and (9173, 0) -- used to
+    collide in all 32 hash bits, and a cached look at an unclaimed slot's leftover key words then sent rows to the colliding key's
+    group, about once in sixty runs: the key arrays are cleared when a table is made, and the hash mixes before it folds."""
+    rng = np.random.default_rng(606)
+    n = 75000
+    page = Page([Block.date(rng.integers(9100, 9400, n)), Block.integer(rng.integers(0, 3, n)), Block.double(rng.random(n) * 100),
+                 Block.integer(rng.integers(-50, 50, n))], n)
+    types = [abi.DATE, abi.INTEGER, abi.DOUBLE, abi.INTEGER]
+    aggs = [(abi.AGG_COUNT_STAR, -1, None), (abi.AGG_SUM, 3, abi.INTEGER), (abi.AGG_SUM, 2, abi.DOUBLE)]
+    ref = oracle.HashAggregation(types, [0, 1], aggs)
+    ref.add_page(page)
+    expected = sorted(ref.build_result().to_rows())
+    dev = upload_page(page)
+    for _ in range(40):
+        got = sorted(r for p in to_pages(HashAggregationOperator(types, [0, 1], aggs), [dev]) for r in p.to_rows())
+        assert len(got) == len(expected)
+        for g, e in zip(got, expected):
+            assert g[:4] == e[:4] and abs(g[4] - e[4]) <= 1e-9 * abs(e[4])

@@ -507,6 +507,35 @@ def test_probe_page_with_more_matches_than_one_output_page_holds(gpu, oracle, mo
     assert [r for p in pages for r in p.to_rows()] == expected.to_rows()
 
 
+def test_split_probe_page_behind_a_device_operator(gpu, oracle, monkeypatch):
+    """The probe pages come from a FilterAndProject on the device, whose output buffers are its own again as soon as it is given the
+    next page -- which a Driver does while the join still emits the ranges of the page before.  The join keeps the probe channels
+    of a page it has to emit range by range: same rows as over host pages."""
+    from presto_amd.expr import field
+    from presto_amd.operators import Driver, FilterAndProjectOperator
+    monkeypatch.setenv("PRESTO_AMD_JOIN_MAX_OUTPUT_ROWS", "500")
+    rng = np.random.default_rng(23)
+    nb = 3000
+    build = Page([Block.bigint(rng.integers(0, 200, nb)), Block.integer(np.arange(nb))], nb)
+    probes = []
+    for i in range(4):
+        n = 2000 + i
+        probes.append(Page([Block.bigint(rng.integers(-20, 230, n), rng.random(n) < 0.03), Block.varchar([b"p%d_%d" % (i, r) if r % 5 else None for r in range(n)]),
+                            Block.integer(np.arange(n) + 10000 * i)], n))
+    btypes, ptypes = [abi.BIGINT, abi.INTEGER], [abi.BIGINT, abi.VARCHAR, abi.INTEGER]
+    bridge = LookupSourceFactory()
+    to_pages(HashBuilderOperator(bridge, btypes, [0], [1]), [build])
+    fp = FilterAndProjectOperator(ptypes, field(2, abi.INTEGER) >= 0, [field(0, abi.BIGINT), field(1, abi.VARCHAR), field(2, abi.INTEGER)], output_mem=abi.MEM_DEVICE)
+    join = LookupJoinOperator(bridge, ptypes, [0], [1, 2, 0])
+    pages = Driver(probes, [fp, join]).run()
+    j = oracle.HashJoin(btypes, [0], [1])
+    j.add_build_page(build)
+    j.build()
+    expected = [r for p in probes for r in j.probe(p, ptypes, [0], [1, 2, 0])[0].to_rows()]
+    assert len(pages) > 20 and all(0 < p.position_count <= 500 for p in pages)
+    assert [r for p in pages for r in p.to_rows()] == expected
+
+
 # ---- JoinFilterFunction ------------------------------------------------------------------------------------------------------
 def _filter_case(rng, nb=3000, npr=5000, keys=400):
     build = Page([Block.bigint(rng.integers(0, keys, nb), rng.random(nb) < 0.03), Block.integer(rng.integers(0, 100, nb), rng.random(nb) < 0.1),
