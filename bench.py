@@ -491,10 +491,13 @@ def main(argv=None, workload_factory=None, out=None):
                 # and reads price and discount for the matching rows only, so its HBM traffic is below the algorithmic figure
                 k_ms, k_n = c["lineitem_fused_kernel_ms"], c["lineitem_fused_launches"]
                 k_alg = workload.q3_rows[2] * 28
-                q3["roofline_dominant"] = {"bound": "hbm", "kernel": "pa_fused, probe stage (lineitem: filter -> bitmap -> probe -> accumulate by build row)",
+                q3["roofline_dominant"] = {"bound": "hbm", "kernel": "pa_fused, probe stage (lineitem: filter -> key rank index -> accumulate by build row)",
                                            "achieved": k_alg / (k_ms / 1e3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                            "frac": k_alg / (k_ms / 1e3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_step": k_alg,
-                                           "kernel_ms_per_step": k_ms, "launches_per_step": k_n, "traffic": None}
+                                           "kernel_ms_per_step": k_ms, "launches_per_step": k_n,
+                                           "traffic": pmc.get("q3_probe", {}).get("hbm_bytes_per_launch"),
+                                           "traffic_source": "profiles/pmc_traffic.json q3_probe: rocprofv3 --pmc FETCH_SIZE pass of scripts/bench_q3.py, x2 on gfx950, "
+                                                             "average per launch (reads; the table updates are memory-side atomics)" if "q3_probe" in pmc else None}
             if world > 1:
                 sent, t_ms = c.get("exchange_bytes_remote", 0), c.get("exchange_transfer_ms", 0.0)
                 q3["exchange"] = {"what": "4 hash-partitioned exchanges per step (customer keys, orders, orders JOIN customer, lineitem), each one "

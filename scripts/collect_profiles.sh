@@ -4,7 +4,7 @@
 #   2. FETCH_SIZE and WRITE_SIZE counter passes (separate) -> gpurun_out/r_fetch, gpurun_out/r_write
 #   3. the default `python3 bench.py` (with q3, h2d, cpu_baseline) -> gpurun_out/r_bench_default.json
 #   4. kernel trace + stats of scripts/bench_q3.py         -> gpurun_out/r_q3 (+ its line)
-# scripts/summarize_profile.py then writes profiles/<tag>_*.  Counter passes never combine --pmc with API traces.
+# scripts/summarize_profile.py <tag> r_trace r_fetch r_write r_trace_bench.json r_q3_fetch.txt then writes profiles/<tag>_*.  Counter passes never combine --pmc with API traces.
 set -e -o pipefail
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out

@@ -13,6 +13,7 @@ import sys
 
 tag, trace_dir, fetch_dir, write_dir = sys.argv[1:5]
 bench_json = sys.argv[5] if len(sys.argv) > 5 else None
+q3_fetch_txt = sys.argv[6] if len(sys.argv) > 6 else None  # scripts/pmc_by_kernel.py output of the Q3 FETCH_SIZE pass
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = os.path.join(root, "profiles")
 os.makedirs(out, exist_ok=True)
@@ -72,6 +73,16 @@ for k in dur:
         "hbm_bytes_per_launch": (2.0 * fetch_kib + write_kib) * 1024.0,
         "correction": "FETCH_SIZE x2 (gfx950 wide streaming reads), WRITE_SIZE x1; KiB -> bytes",
     }
+if q3_fetch_txt and os.path.exists(q3_fetch_txt):
+    # the fused probe kernel of Q3's lineitem pipeline (launches of `pa_fused` in scripts/bench_q3.py): reads only -- its writes are
+    # memory-side atomics into the build-row table, not counted by WRITE_SIZE
+    for line in open(q3_fetch_txt):
+        parts = line.split()
+        if parts and parts[0] == "pa_fused" and "FETCH_SIZE" in parts:
+            kib = float(parts[parts.index("avg") + 1])
+            traffic["q3_probe"] = {"fetch_size_kib_raw": kib, "launches": int(parts[parts.index("over") + 1]),
+                                   "hbm_bytes_per_launch": 2.0 * kib * 1024.0,
+                                   "correction": "FETCH_SIZE x2 (gfx950 wide streaming reads); KiB -> bytes; command: python3 scripts/bench_q3.py (SF100)"}
 json.dump({"tag": tag, "command": "python3 bench.py --steps N --warmup W --cpu-rows 0 --q3 0 --h2d-rows 0 (SF100, 2^28-row pages)", "kernels": traffic},
           open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)
 
