@@ -57,7 +57,31 @@ def parse_args(argv=None):
                     "Q1 / Q6 columns + the Q3 tables) on this one GPU for a few steps (the `sf300` object), N = 1 only; 0 = skip")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend; 'gloo' only to rehearse the multi-rank "
                     "control flow with several ranks on one GPU (RCCL refuses two ranks on one device)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="what `value` measures at N > 1.  weak: every rank holds --sf worth of rows (its slice of the SF x N table); "
+                         "strong: the ranks split the ONE --sf table by row range (the metric's 'SF100 at 1/2/4/8 GPUs').  The other "
+                         "mode is timed beside it and reported as an object of that name (--other-scaling 0 skips it)")
+    ap.add_argument("--other-scaling", type=int, default=1)
+    ap.add_argument("--workload", default="device", help="'device' = the product path; 'module:Class' = a checker workload with the same "
+                    "surface (tests/rehearsal_workload.py: the oracle's operators on CPU ranks, to rehearse the multi-rank control flow)")
     return ap.parse_args(argv)
+
+
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` with N > 1 and no torchrun environment: this process becomes the launcher -- it starts N ranks as
+    fresh child processes (torch.distributed.run, one per GPU, rendezvous on 127.0.0.1) BEFORE anything here has touched the GPU or
+    imported torch, waits for them and leaves with their exit code.  The ranks inherit stdout: rank 0's JSON line is the output."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("OMP_NUM_THREADS", "8")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
 
 
 def cpu_model():
@@ -132,24 +156,38 @@ def cpu_baseline(sf, rows):
 class DeviceWorkload:
     """The product path: device-resident synthetic tables, operators through the C ABI (presto_amd.operators)."""
 
-    def __init__(self, args, rank, world, device):
+    def __init__(self, args, rank, world, device, scaling=None, with_q3=None):
         import torch
         from presto_amd import _lib, abi, tpch
         from presto_amd.operators import FusedAggregationOperatorFactory
         self.args, self.rank, self.world = args, rank, world
         self.torch, self.abi, self.tpch = torch, abi, tpch
+        self.scaling = scaling or args.scaling
         _lib.init(device)
+        self.queries = [q for q in args.queries.split(",") if q]
+        q3_sf = args.q3_sf or args.sf
+        self.q3_on = bool(args.q3) if with_q3 is None else with_q3
+        self.q3_sf = q3_sf
         # the communicator of the Q3 exchange steps: RCCL, one rank per GPU (gloo rehearsals with ranks sharing a GPU: the
         # library's host transport, the two collectives then run over torch.distributed)
         self.comm = None
-        if world > 1 and args.q3:
+        if world > 1 and self.q3_on:
             from presto_amd.exchange import Comm
             self.comm = Comm.rccl() if args.backend == "nccl" else Comm.host()
-        self.rows = tpch.lineitem_rows(args.sf)
-        self.queries = [q for q in args.queries.split(",") if q]
-        q3_sf = args.q3_sf or args.sf
-        self.q3_on = bool(args.q3)
-        self.q3_sf = q3_sf
+
+        # Row-range shards (SURVEY 8e).  weak: rank r holds rows [r n, (r + 1) n) of the SF x world table, n = rows of one SF table;
+        # strong: the ranks split the ONE SF table, rank r holds rows [N r / W, N (r + 1) / W) (boundaries on multiples of `multiple`).
+        def shard(rows_of, sf, multiple=4):
+            if self.scaling == "weak" or world == 1:
+                n = rows_of(sf)
+                return sf * world, rank * n, n
+            n = rows_of(sf)
+            lo = n * rank // world // multiple * multiple
+            hi = n if rank == world - 1 else n * (rank + 1) // world // multiple * multiple
+            return sf, lo, hi - lo
+
+        total_sf, first, self.rows = shard(tpch.lineitem_rows, args.sf)
+        self.job_rows = tpch.lineitem_rows(args.sf) * (world if self.scaling == "weak" else 1)  # lineitem rows of the whole job
         columns = set((tpch.Q1_COLUMNS if "q1" in self.queries else []) + (tpch.Q6_COLUMNS if "q6" in self.queries else []))
         share_lineitem = self.q3_on and q3_sf == args.sf
         if share_lineitem:
@@ -161,27 +199,44 @@ class DeviceWorkload:
             self._keep.append(t)
             return t
 
-        # this rank's slice of the SF x world tables, generated on device
-        self.table = tpch.DeviceColumns(sorted(columns), args.sf * world, self.rows, allocator=allocator, first_row=rank * self.rows)
+        # this rank's slice of the table, generated on device
+        self.table = tpch.DeviceColumns(sorted(columns), total_sf, self.rows, allocator=allocator, first_row=first)
         self.q6_pages = self._pages_of(self.table, tpch.Q6_COLUMNS, args.page_rows) if "q6" in self.queries else []
         self.q1_pages = self._pages_of(self.table, tpch.Q1_COLUMNS, args.page_rows) if "q1" in self.queries else []
         self.ktime = {"q6": [0.0, 0], "q1": [0.0, 0]}
         self.results = {}
         # the planner's part, once per query plan: OperatorFactory objects holding the serialised descriptors
-        # (LocalExecutionPlanner builds the factories; every Driver then calls createOperator)
+        # (LocalExecutionPlanner builds the factories; every Driver then calls createOperator).  With more than one rank the
+        # aggregations run as Step.PARTIAL on every rank and Step.FINAL on rank 0 (HashAggregationOperator.java:390), the
+        # ranks' intermediate pages combined in rank order -- inside the step.
+        step = abi.STEP_PARTIAL if world > 1 else abi.STEP_SINGLE
         self.factories = {
-            "q6": FusedAggregationOperatorFactory(tpch.Q6_TYPES, tpch.q6_filter(), tpch.q6_projections(), [], tpch.Q6_AGGREGATES),
+            "q6": FusedAggregationOperatorFactory(tpch.Q6_TYPES, tpch.q6_filter(), tpch.q6_projections(), [], tpch.Q6_AGGREGATES, step=step),
             "q1": FusedAggregationOperatorFactory(tpch.Q1_TYPES, tpch.q1_filter(), tpch.q1_projections(), tpch.Q1_GROUP_BY,
-                                                  tpch.Q1_AGGREGATES, type_params=tpch.Q1_TYPE_PARAMS),
+                                                  tpch.Q1_AGGREGATES, type_params=tpch.Q1_TYPE_PARAMS, step=step),
         }
+        self.merger = None
+        if world > 1:
+            from presto_amd.exchange import PartialStateMerger, partial_layout
+            from presto_amd.operators import AggregationOperator, HashAggregationOperator
+            self.merger = PartialStateMerger(device="cuda" if args.backend == "nccl" else None)
+            t6, f6 = partial_layout([], tpch.Q6_AGGREGATES)
+            t1, f1 = partial_layout([abi.VARCHAR, abi.VARCHAR], tpch.Q1_AGGREGATES)
+            self.final_operators = {
+                "q6": lambda: AggregationOperator(t6, f6, step=abi.STEP_FINAL),
+                "q1": lambda: HashAggregationOperator(t1, [0, 1], f1, step=abi.STEP_FINAL, type_params=[1, 1] + [0] * (len(t1) - 2)),
+            }
         if self.q3_on:
-            nc, no, nl = tpch.customer_rows(q3_sf), tpch.orders_rows(q3_sf), tpch.lineitem_rows(q3_sf)
+            self.q3_rows_job = tuple(f(q3_sf) * (world if self.scaling == "weak" else 1)
+                                     for f in (tpch.customer_rows, tpch.orders_rows, tpch.lineitem_rows))
+            ct, cf, nc = shard(tpch.customer_rows, q3_sf, 20)
+            ot, of, no = shard(tpch.orders_rows, q3_sf)
+            lt, lf, nl = shard(tpch.lineitem_rows, q3_sf)
             self.q3_rows = (nc, no, nl)
-            total = q3_sf * world
-            self.customer = tpch.DeviceColumns(tpch.CUSTOMER_COLUMNS, total, nc, allocator=allocator, first_row=rank * nc)
-            self.orders = tpch.DeviceColumns(tpch.ORDERS_COLUMNS, total, no, allocator=allocator, first_row=rank * no)
+            self.customer = tpch.DeviceColumns(tpch.CUSTOMER_COLUMNS, ct, nc, allocator=allocator, first_row=cf)
+            self.orders = tpch.DeviceColumns(tpch.ORDERS_COLUMNS, ot, no, allocator=allocator, first_row=of)
             self.q3_lineitem = self.table if share_lineitem else tpch.DeviceColumns(
-                tpch.Q3_LINEITEM_COLUMNS, total, nl, allocator=allocator, first_row=rank * nl)
+                tpch.Q3_LINEITEM_COLUMNS, lt, nl, allocator=allocator, first_row=lf)
             pr = args.page_rows
             self.q3_pages = (self._pages_of(self.customer, tpch.CUSTOMER_COLUMNS, max(20, pr - pr % 20)),
                              self._pages_of(self.orders, tpch.ORDERS_COLUMNS, pr),
@@ -213,7 +268,10 @@ class DeviceWorkload:
             op.addInput(p)
         op.finish()
         out = op.getOutput()
-        self.results[name] = out.to_rows()
+        if self.world > 1:
+            self.partials[name] = out   # this rank's intermediate states (a host page of a few rows)
+        else:
+            self.results[name] = out.to_rows()
         ms, n = op.kernelTime()  # also during warm-up: the first event query of a process pays a one-off cost
         if timed:
             self.ktime[name][0] += ms
@@ -221,11 +279,22 @@ class DeviceWorkload:
         op.close()
 
     def step(self, timed):
+        self.partials = {}
         for q in self.queries:
             self.run_query(q, timed)
+        if self.world > 1:
+            # PARTIAL -> FINAL across the ranks, inside the step: one small all-gather, the FINAL operators on rank 0
+            final = self.merger.merge(self.partials, self.final_operators)
+            if final is not None:
+                self.results.update({q: ([] if p is None else p.to_rows()) for q, p in final.items()})
 
     def rows_per_step(self):
+        """lineitem rows entering the first operators of one step, on THIS rank"""
         return self.rows * len(self.queries)
+
+    def job_rows_per_step(self):
+        """... on all ranks together"""
+        return self.job_rows * len(self.queries)
 
     def roofline(self, name, steps, pmc):
         tpch = self.tpch
@@ -247,6 +316,10 @@ class DeviceWorkload:
 
     def workload_name(self):
         a = self.args
+        if self.world > 1 and self.scaling == "strong":
+            return ("TPC-H SF%g %s fused scan-filter-project-aggregate over device-resident lineitem pages, the %d rows of the table split by row "
+                    "range over %d GPUs, PARTIAL -> FINAL merge inside the step, %d-row pages"
+                    % (a.sf, "+".join(q.upper() for q in self.queries), self.job_rows, self.world, a.page_rows))
         return ("TPC-H SF%g %s fused scan-filter-project-aggregate over device-resident lineitem pages, %d rows per GPU, %d-row pages"
                 % (a.sf, "+".join(q.upper() for q in self.queries), self.rows, a.page_rows))
 
@@ -260,6 +333,9 @@ class DeviceWorkload:
 
     def q3_input_rows(self):
         return sum(self.q3_rows)
+
+    def q3_job_input_rows(self):
+        return sum(self.q3_rows_job)
 
     def q3_algorithmic_bytes(self):
         # customer 21 B/row, orders 24 B/row, lineitem 28 B/row (columns read once by the scans)
@@ -367,11 +443,73 @@ def sf300_leg(args, dist, device, steps=3):
         w.close()
 
 
+def load_workload_class(spec):
+    if spec == "device":
+        return DeviceWorkload
+    import importlib
+    mod, _, cls = spec.partition(":")
+    return getattr(importlib.import_module(mod), cls)
+
+
+def q3_line_object(args, workload, world, q3_elapsed, pmc):
+    c = dict(workload.q3_counters)
+    rows_in = workload.q3_input_rows()
+    job_rows = workload.q3_job_input_rows() if hasattr(workload, "q3_job_input_rows") else rows_in * world
+    ms = q3_elapsed / args.steps * 1e3
+    alg = workload.q3_algorithmic_bytes()
+    q3 = {"metric": "input rows/s through the TPC-H Q3 operator pipelines (customer + orders + lineitem rows entering the three scans)",
+          "value": job_rows * args.steps / q3_elapsed, "unit": "rows/s", "ms_per_step": ms, "steps": args.steps,
+          "scaling": getattr(workload, "scaling", "weak"),
+          "scale_factor_per_gpu": workload.q3_sf if getattr(workload, "scaling", "weak") == "weak" else workload.q3_sf / world,
+          "input_rows_per_gpu": rows_in,
+          "stage_ms_rank0": {k: v for k, v in c.items() if k.endswith("_pipeline_ms")},
+          "rank0": {k: v for k, v in c.items() if not k.endswith("_pipeline_ms")},
+          "roofline": {"bound": "hbm", "scope": "whole step (all kernels of the three pipelines)", "achieved": alg / (ms / 1e3) / 1e9,
+                       "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / (ms / 1e3) / 1e9 / HBM_PEAK_GBS,
+                       "algorithmic_bytes_per_step": alg},
+          "exchange": "none (one rank)"}
+    if "lineitem_fused_kernel_ms" in c and c["lineitem_fused_kernel_ms"] > 0:
+        # the dominant kernel of Q3: lineitem's filter -> probe -> aggregate as one generated kernel; algorithmic bytes =
+        # the 28 B/row of SURVEY 8d (orderkey 8, extendedprice 8, discount 8, shipdate 4) -- the kernel itself streams 12 B/row
+        # and reads price and discount for the matching rows only, so its HBM traffic is below the algorithmic figure
+        k_ms, k_n = c["lineitem_fused_kernel_ms"], c["lineitem_fused_launches"]
+        k_alg = workload.q3_rows[2] * 28
+        q3["roofline_dominant"] = {"bound": "hbm", "kernel": "pa_fused, probe stage (lineitem: filter -> key rank index -> accumulate by build row)",
+                                   "achieved": k_alg / (k_ms / 1e3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                   "frac": k_alg / (k_ms / 1e3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_step": k_alg,
+                                   "kernel_ms_per_step": k_ms, "launches_per_step": k_n,
+                                   "traffic": pmc.get("q3_probe", {}).get("hbm_bytes_per_launch"),
+                                   "traffic_source": "profiles/pmc_traffic.json q3_probe: rocprofv3 --pmc FETCH_SIZE pass of scripts/bench_q3.py, x2 on gfx950, "
+                                                     "average per launch (reads; the table updates are memory-side atomics)" if "q3_probe" in pmc else None}
+    if world > 1:
+        sent, t_ms = c.get("exchange_bytes_remote", 0), c.get("exchange_transfer_ms", 0.0)
+        q3["exchange"] = {"what": "4 hash-partitioned exchanges per step (customer keys, orders, orders JOIN customer, lineitem), each one "
+                                  "count all-gather + one grouped ncclSend/ncclRecv all-to-all; dynamic-filter bitmaps combined by all-reduce; "
+                                  "all partitions of a build side arrive before any probe (PartitionedLookupSourceFactory.java:179-206)",
+                          "transport": "RCCL over xGMI" if args.backend == "nccl" else "host transport over " + args.backend,
+                          "rank0_bytes_to_other_ranks_per_step": sent, "rank0_all_to_all_ms_per_step": t_ms,
+                          "xgmi_GBps": (sent / (t_ms / 1e3) / 1e9) if t_ms > 0 else None,
+                          "note": "xgmi_GBps = rank 0's payload bytes sent to the other ranks / device time of its all-to-alls (HIP events)"}
+    return q3
+
+
+Q3_FAILED_EXIT_CODE = 3   # the line was printed, but a rank failed inside the Q3 leg (or the leg timed out)
+
+
 def main(argv=None, workload_factory=None, out=None):
     """workload_factory(args, rank, world, device) -> workload: tests rehearse the multi-rank control flow (barriers, the
     max-over-ranks clock, the exchange rounds of Q3, the JSON line) on CPU ranks with a checker workload; the default is
-    the device workload."""
+    the device workload (--workload names another one for subprocess runs).  Returns the process exit code."""
+    argv = list(sys.argv[1:] if argv is None else argv)
     args = parse_args(argv)
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        return launch_ranks(args, argv)   # nothing here has touched the GPU (torch is not even imported yet)
+    world = int(env_world or "1")
+    if world != args.gpus:
+        print("bench.py: --gpus %d but WORLD_SIZE=%d: start it as `python bench.py --gpus N` (it launches its own ranks) or under "
+              "torch.distributed.run with --nproc-per-node equal to --gpus" % (args.gpus, world), file=sys.stderr)
+        return 2
     # ONE JSON line on stdout: whatever libraries print there while the bench runs (RCCL greets with its version) goes to stderr
     line_fd = None
     if out is None:
@@ -380,11 +518,12 @@ def main(argv=None, workload_factory=None, out=None):
         os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch
     import torch.distributed as dist
     device = None
-    if workload_factory is None:
+    make_workload = workload_factory or load_workload_class(args.workload)
+    on_device = make_workload is DeviceWorkload
+    if on_device:
         device = local_rank if args.backend == "nccl" else local_rank % max(torch.cuda.device_count(), 1)
         torch.cuda.set_device(device)
     if world > 1:
@@ -394,21 +533,26 @@ def main(argv=None, workload_factory=None, out=None):
         else:
             dist.init_process_group(args.backend)
 
-    workload = (workload_factory or DeviceWorkload)(args, rank, world, device)
+    workload = make_workload(args, rank, world, device)
+    scaling = getattr(workload, "scaling", "weak")
+
+    def job_rows(w):
+        return w.job_rows_per_step() if hasattr(w, "job_rows_per_step") else w.rows_per_step() * world
 
     elapsed = timed_region(workload, dist, world, args.backend, workload.step, args.steps, args.warmup)
-    value = workload.rows_per_step() * args.steps * world / elapsed
+    value = job_rows(workload) * args.steps / elapsed
 
     # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command (profiles/pmc_traffic.json,
     # written by scripts/summarize_profile.py); only valid for the default workload shape they were collected on
     pmc = {}
     pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(pmc_path) and args.sf == 100.0 and args.page_rows == 1 << 28:
+    if os.path.exists(pmc_path) and args.sf == 100.0 and args.page_rows == 1 << 28 and (world == 1 or scaling == "weak"):
         pmc = json.load(open(pmc_path)).get("kernels", {})
 
     emitted = False
+    exit_code = 0
 
-    def emit(q3, side_legs=True):
+    def emit(q3, other, side_legs=True):
         nonlocal workload, emitted
         if rank != 0 or emitted:
             return
@@ -417,19 +561,23 @@ def main(argv=None, workload_factory=None, out=None):
         line = {
             "metric": "rows/s through operator pipeline, TPC-H Q1+Q6 SF100, 1/2/4/8 GPUs vs CPU ref",
             "value": value, "unit": "rows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": workload.workload_name(),
-                       "scale_factor_per_gpu": args.sf, "rows_per_gpu": workload.rows, "page_rows": args.page_rows,
+                       "scale_factor_per_gpu": args.sf if scaling == "weak" else args.sf / world, "scale_factor_job": args.sf * (world if scaling == "weak" else 1),
+                       "rows_per_gpu": workload.rows, "page_rows": args.page_rows,
                        "page_order": args.page_order,
-                       "queries": queries, "parallelism": "row-range shards, %d rank(s), no data-path collective in Q1/Q6; "
-                                                          "Q3 (the `q3` object) shuffles its join sides between the ranks" % world},
+                       "queries": queries, "parallelism": "row-range shards, %d rank(s), no data-path collective in Q1/Q6%s; "
+                                                          "Q3 (the `q3` object) shuffles its join sides between the ranks"
+                                                          % (world, "" if world == 1 else " (Step.PARTIAL per rank, one small all-gather, Step.FINAL on rank 0, inside the step)")},
         }
         r1 = workload.roofline("q1", args.steps, pmc) if "q1" in queries else None
         r6 = workload.roofline("q6", args.steps, pmc) if "q6" in queries else None
         line["roofline"] = r1 or r6
         if r1 and r6:
             line["roofline_q6"] = r6
+        if other is not None:
+            line[other["scaling"]] = other
         if q3 is not None:
             line["q3"] = q3
         line["results"] = {k: [[x.decode() if isinstance(x, bytes) else x for x in r] for r in v] for k, v in workload.results.items()}
@@ -438,7 +586,7 @@ def main(argv=None, workload_factory=None, out=None):
                 line["h2d"] = workload.h2d(args.h2d_rows)
             except Exception as e:
                 line["h2d"] = {"error": "%s: %s" % (type(e).__name__, e)}
-        if side_legs and world == 1 and args.sf300 and args.sf == 100.0 and workload_factory is None:
+        if side_legs and world == 1 and args.sf300 and args.sf == 100.0 and on_device:
             try:
                 workload.close()
                 workload = None
@@ -453,18 +601,40 @@ def main(argv=None, workload_factory=None, out=None):
             sys.stdout.flush()
             os.write(line_fd, (json.dumps(line) + "\n").encode())
 
+    # the other scaling mode, timed beside the headline (Q1 + Q6 only; its tables are generated now and released afterwards)
+    other = None
+    if world > 1 and args.other_scaling:
+        other_mode = "strong" if scaling == "weak" else "weak"
+        try:
+            import inspect
+            kw = {"scaling": other_mode, "with_q3": False} if "scaling" in inspect.signature(make_workload).parameters else None
+            if kw is not None:
+                w2 = make_workload(args, rank, world, device, **kw)
+                try:
+                    e2 = timed_region(w2, dist, world, args.backend, w2.step, args.steps, args.warmup)
+                    other = {"scaling": other_mode, "value": job_rows(w2) * args.steps / e2, "unit": "rows/s", "ms_per_step": e2 / args.steps * 1e3,
+                             "steps": args.steps, "rows_per_gpu_rank0": w2.rows, "job_rows": job_rows(w2) // max(len(w2.queries), 1),
+                             "workload": w2.workload_name(),
+                             "results": {k: [[x.decode() if isinstance(x, bytes) else x for x in r] for r in v] for k, v in w2.results.items()}}
+                    ro = w2.roofline("q1", args.steps, {}) if "q1" in w2.queries else None
+                    if ro:
+                        other["roofline_frac_q1_rank0"] = ro["frac"]
+                finally:
+                    w2.close()
+                    del w2
+        except Exception as e:
+            other = {"scaling": other_mode, "error": "%s: %s" % (type(e).__name__, e)}
+
     # N > 1: the Q3 leg runs collectives; a rank that fails inside one would leave the others waiting for ever.  The headline was
     # measured above: if the leg does not come back within --q3-timeout seconds, rank 0 prints the line without it and every
-    # rank leaves.
+    # rank leaves -- with a non-zero exit code: the line is there, the run is not clean.
     watchdog = None
     if world > 1 and getattr(workload, "q3_on", False) and args.q3_timeout > 0:
-        import threading
-
         def bail():
             try:
-                emit({"error": "the Q3 leg did not finish within %d s on %d ranks" % (args.q3_timeout, world)}, side_legs=False)
+                emit({"error": "the Q3 leg did not finish within %d s on %d ranks" % (args.q3_timeout, world)}, other, side_legs=False)
             finally:
-                os._exit(0)
+                os._exit(Q3_FAILED_EXIT_CODE)
         watchdog = threading.Timer(args.q3_timeout, bail)
         watchdog.daemon = True
         watchdog.start()
@@ -472,43 +642,11 @@ def main(argv=None, workload_factory=None, out=None):
     if getattr(workload, "q3_on", False):
         try:
             q3_elapsed = timed_region(workload, dist, world, args.backend, lambda timed: workload.q3_step(), args.steps, max(1, min(args.warmup, 2)))
-            c = dict(workload.q3_counters)
-            rows_in = workload.q3_input_rows()
-            ms = q3_elapsed / args.steps * 1e3
-            alg = workload.q3_algorithmic_bytes()
-            q3 = {"metric": "input rows/s through the TPC-H Q3 operator pipelines (customer + orders + lineitem rows entering the three scans)",
-                  "value": rows_in * world * args.steps / q3_elapsed, "unit": "rows/s", "ms_per_step": ms, "steps": args.steps,
-                  "scale_factor_per_gpu": workload.q3_sf, "input_rows_per_gpu": rows_in,
-                  "stage_ms_rank0": {k: v for k, v in c.items() if k.endswith("_pipeline_ms")},
-                  "rank0": {k: v for k, v in c.items() if not k.endswith("_pipeline_ms")},
-                  "roofline": {"bound": "hbm", "scope": "whole step (all kernels of the three pipelines)", "achieved": alg / (ms / 1e3) / 1e9,
-                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / (ms / 1e3) / 1e9 / HBM_PEAK_GBS,
-                               "algorithmic_bytes_per_step": alg},
-                  "exchange": "none (one rank)"}
-            if "lineitem_fused_kernel_ms" in c and c["lineitem_fused_kernel_ms"] > 0:
-                # the dominant kernel of Q3: lineitem's filter -> probe -> aggregate as one generated kernel; algorithmic bytes =
-                # the 28 B/row of SURVEY 8d (orderkey 8, extendedprice 8, discount 8, shipdate 4) -- the kernel itself streams 12 B/row
-                # and reads price and discount for the matching rows only, so its HBM traffic is below the algorithmic figure
-                k_ms, k_n = c["lineitem_fused_kernel_ms"], c["lineitem_fused_launches"]
-                k_alg = workload.q3_rows[2] * 28
-                q3["roofline_dominant"] = {"bound": "hbm", "kernel": "pa_fused, probe stage (lineitem: filter -> key rank index -> accumulate by build row)",
-                                           "achieved": k_alg / (k_ms / 1e3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                           "frac": k_alg / (k_ms / 1e3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_step": k_alg,
-                                           "kernel_ms_per_step": k_ms, "launches_per_step": k_n,
-                                           "traffic": pmc.get("q3_probe", {}).get("hbm_bytes_per_launch"),
-                                           "traffic_source": "profiles/pmc_traffic.json q3_probe: rocprofv3 --pmc FETCH_SIZE pass of scripts/bench_q3.py, x2 on gfx950, "
-                                                             "average per launch (reads; the table updates are memory-side atomics)" if "q3_probe" in pmc else None}
-            if world > 1:
-                sent, t_ms = c.get("exchange_bytes_remote", 0), c.get("exchange_transfer_ms", 0.0)
-                q3["exchange"] = {"what": "4 hash-partitioned exchanges per step (customer keys, orders, orders JOIN customer, lineitem), each one "
-                                          "count all-gather + one grouped ncclSend/ncclRecv all-to-all; dynamic-filter bitmaps combined by all-reduce",
-                                  "transport": "RCCL over xGMI" if args.backend == "nccl" else "host transport over " + args.backend,
-                                  "rank0_bytes_to_other_ranks_per_step": sent, "rank0_all_to_all_ms_per_step": t_ms,
-                                  "xgmi_GBps": (sent / (t_ms / 1e3) / 1e9) if t_ms > 0 else None,
-                                  "note": "xgmi_GBps = rank 0's payload bytes sent to the other ranks / device time of its all-to-alls (HIP events)"}
+            q3 = q3_line_object(args, workload, world, q3_elapsed, pmc)
         except Exception as e:  # the headline must survive a failing side leg
             q3 = {"error": "%s: %s" % (type(e).__name__, e)}
-    emit(q3)
+            exit_code = Q3_FAILED_EXIT_CODE
+    emit(q3, other)
     if workload is not None:
         workload.close()
     if world > 1:
@@ -520,7 +658,8 @@ def main(argv=None, workload_factory=None, out=None):
         sys.stdout.flush()
         os.dup2(line_fd, 1)
         os.close(line_fd)
+    return exit_code
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

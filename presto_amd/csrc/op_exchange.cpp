@@ -56,6 +56,9 @@ struct pa_exchange {
     std::vector<bool> nullable;     // per channel: some page carried a valueIsNull array
     int sinks_created = 0, sinks_finished = 0;
     bool transferred = false;
+    // stream of the sink that appended last (under mu): another sink drains it before it touches the destinations' buffers --
+    // reserve_keep copies and recycles them on the caller's stream, and the previous appender's copy kernel may still write there
+    hipStream_t last_appender = nullptr;
     // statistics
     int64_t rows_sent = 0, rows_received = 0, bytes_remote = 0;
     double transfer_ms = 0;
@@ -85,6 +88,7 @@ public:
         finishing_ = true;
         PA_HIP(hipStreamSynchronize(stream_.get()));  // the appended runs are complete before the source packs them
         std::lock_guard<std::mutex> lock(ex_->mu);
+        if (ex_->last_appender == stream_.get()) ex_->last_appender = nullptr;  // (drained above; the stream may go away with the sink)
         ex_->sinks_finished++;
     }
     int64_t memory_bytes() override { return (int64_t)stager_.bytes(); }
@@ -201,6 +205,8 @@ public:
         }
         // ---- append the runs to the destinations' buffers ----
         std::lock_guard<std::mutex> lock(ex_->mu);
+        if (ex_->last_appender != nullptr && ex_->last_appender != s) PA_HIP(hipStreamSynchronize(ex_->last_appender));
+        ex_->last_appender = s;
         std::vector<CopySeg> segs;
         for (int c = 0; c < C; c++) {
             if (dp.cols[c].nulls && !ex_->nullable[c]) {

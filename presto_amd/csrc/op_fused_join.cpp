@@ -33,7 +33,7 @@ public:
     {
         PA_REQUIRE(bridge->impl != nullptr, PA_ERR_ILLEGAL_STATE, "lookup source has no build operator yet");
         PA_REQUIRE(d->join.join_type == PA_JOIN_INNER && d->join.filter == nullptr, PA_ERR_NOT_SUPPORTED, "the fused join is an inner join without a filter function");
-        void* stream = d->join.stream ? d->join.stream : d->filter_project.stream;
+        void* stream = shared_stream(d->join.stream ? d->join.stream : d->filter_project.stream);
         pa_filter_project_desc fp = d->filter_project;
         fp.output_mem = PA_MEM_DEVICE;
         fp.stream = stream;
@@ -58,7 +58,7 @@ public:
     {
         PA_REQUIRE(bridge->impl != nullptr, PA_ERR_ILLEGAL_STATE, "lookup source has no build operator yet");
         PA_REQUIRE(d->join.join_type == PA_JOIN_INNER, PA_ERR_NOT_SUPPORTED, "the fused join-aggregation is an inner join");
-        void* stream = d->aggregation.stream ? d->aggregation.stream : (d->join.stream ? d->join.stream : d->filter_project.stream);
+        void* stream = shared_stream(d->aggregation.stream ? d->aggregation.stream : (d->join.stream ? d->join.stream : d->filter_project.stream));
         // the chain: intermediate pages stay in HBM, everything on one stream
         pa_filter_project_desc fp = d->filter_project;
         fp.output_mem = PA_MEM_DEVICE;
@@ -82,8 +82,18 @@ public:
         stream_ = chain_.back()->main_stream();
         finish_sent_.assign(chain_.size(), false);
     }
+    ~FusedJoinAggregationOperator() override
+    {
+        // the members run on own_stream_: they go first, the stream (drained) after them
+        if (own_stream_) (void)hipStreamSynchronize(own_stream_->get());
+        fused_.reset();
+        chain_.clear();
+    }
     hipStream_t main_stream() override { return stream_; }
-    hipStream_t private_stream() override { return active() ? active()->private_stream() : chain_.back()->private_stream(); }
+    // every member runs on ONE stream: the caller's, or -- when no descriptor names one -- a stream this handle owns.  (Members
+    // with pooled streams of their own would hand device pages to each other inside pump() with nothing ordering the streams:
+    // only the C-ABI wrappers drain a private stream when a device page changes hands.)
+    hipStream_t private_stream() override { return own_stream_ ? own_stream_->get() : nullptr; }
 
     bool needs_input() override
     {
@@ -140,7 +150,12 @@ public:
     int execution() const { return !chosen_ ? 0 : (fused_ ? 1 : 2); }
 
 private:
-    pa_operator* active() { return fused_ ? fused_.get() : nullptr; }
+    void* shared_stream(void* given)
+    {
+        if (given) return given;
+        own_stream_ = std::make_unique<Stream>(nullptr);
+        return own_stream_->get();
+    }
 
     // true once the lookup source is there and the execution is fixed
     bool choose()
@@ -179,6 +194,7 @@ private:
     }
 
     pa_lookup_source bridge_;
+    std::unique_ptr<Stream> own_stream_;
     std::vector<std::unique_ptr<pa_operator>> chain_;
     std::unique_ptr<pa_operator> fused_;
     hipStream_t stream_ = nullptr;

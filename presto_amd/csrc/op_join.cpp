@@ -219,7 +219,9 @@ public:
         // (join_kernels.hip).  It leaves no slot_of, so chains (duplicate keys) -- and partitions too full, which a decent hash
         // does not produce -- are built the other way
         const int64_t partitions = (int64_t)slots >> kJoinPartSlotsLog2;
-        if (n >= (1 << 20) && partitions >= 2 && partitions <= 4096 && !getenv("PRESTO_AMD_NO_PARTITIONED_BUILD")) {
+        // (not with a $hashvalue channel: the partitioned build places rows by the hash it computes from the key itself, the
+        // probe by the channel's value -- the two must be the same function)
+        if (raw == nullptr && n >= (1 << 20) && partitions >= 2 && partitions <= 4096 && !getenv("PRESTO_AMD_NO_PARTITIONED_BUILD")) {
             if (partitioned_build(key, n, table, (int32_t)partitions, s)) {
                 ls_->probe_wrap = (uint32_t)kJoinPartSlots - 1u;
                 return 0;

@@ -22,9 +22,8 @@ namespace {
 
 class ScanFilterProjectOperator : public pa_operator {
 public:
-    ScanFilterProjectOperator(const pa_filter_project_desc* d, const pa_page_source* source) : stream_(d->stream)
+    ScanFilterProjectOperator(const pa_filter_project_desc* d, const pa_page_source* source) : stream_(checked(d, source)->stream)
     {
-        PA_REQUIRE(d != nullptr && source != nullptr && source->next_page != nullptr, PA_ERR_INVALID_ARGUMENT, "page source without next_page");
         source_ = *source;
         n_in_ = d->input_channel_count;
         types_.assign(d->input_types, d->input_types + n_in_);
@@ -58,6 +57,11 @@ public:
             count.stream = stream_.get();
             count_.reset(make_filter_project(&count));
         }
+    }
+    static const pa_filter_project_desc* checked(const pa_filter_project_desc* d, const pa_page_source* source)
+    {
+        PA_REQUIRE(d != nullptr && source != nullptr && source->next_page != nullptr, PA_ERR_INVALID_ARGUMENT, "page source without next_page");
+        return d;
     }
     ~ScanFilterProjectOperator() override
     {

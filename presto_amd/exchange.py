@@ -261,3 +261,68 @@ def merge_partial_aggregations(partial_page, make_final_operator, group=None, ds
         op.addInput(Page(blocks, len(cols[0][1]) if cols else 0))
     op.finish()
     return op.getOutput()
+
+
+class PartialStateMerger:
+    """The FINAL step of row-range-sharded aggregations, for a step loop: ONE fixed-size all-gather per call carries the Step.PARTIAL
+    pages of several aggregations (Q1: 4 rows, Q6: 1 row per rank), the FINAL operators run on rank `dst` over the ranks' pages
+    in rank order -- a fixed combine order (HashAggregationOperator.java:390 Step.PARTIAL -> Step.FINAL;
+    DoubleSumAggregation.java:47-52 combine).  Same result as merge_partial_aggregations; the buffers are made once."""
+
+    CAPACITY = 1 << 15   # bytes per rank and call
+
+    def __init__(self, group=None, dst=0, device=None):
+        import torch
+        import torch.distributed as dist
+        self.dist, self.group, self.dst = dist, group, dst
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        self.device = device   # "cuda" tensors for the nccl backend, None (host) for gloo
+        self.send = torch.zeros(self.CAPACITY, dtype=torch.uint8, device=device or "cpu")
+        self.recv = torch.zeros(self.CAPACITY * self.world, dtype=torch.uint8, device=device or "cpu")
+        self.stage = torch.zeros(self.CAPACITY, dtype=torch.uint8).pin_memory() if device else self.send
+
+    def merge(self, partial_pages, make_final_operator):
+        """partial_pages: {name: host Page | None} on every rank (same names everywhere); make_final_operator: {name: () -> Operator};
+        returns {name: final host Page | None} on rank dst, None elsewhere.  Collective."""
+        import pickle
+        import numpy as np
+        import torch
+        payload = {}
+        for name, page in partial_pages.items():
+            payload[name] = None if page is None or page.position_count == 0 else [(b.type, b.to_pylist()) for b in page.blocks]
+        blob = pickle.dumps(payload, protocol=pickle.HIGHEST_PROTOCOL)
+        if len(blob) + 8 > self.CAPACITY:
+            raise ValueError("partial aggregation states of %d bytes: not a few-groups result, use an exchange" % len(blob))
+        head = np.frombuffer(np.int64(len(blob)).tobytes() + blob, dtype=np.uint8)
+        self.stage[:len(head)] = torch.from_numpy(head.copy())
+        if self.device:
+            self.send.copy_(self.stage, non_blocking=True)
+        self.dist.all_gather_into_tensor(self.recv, self.send, group=self.group)
+        if self.rank != self.dst:
+            return None
+        got = self.recv.cpu().numpy()
+        out = {}
+        per_rank = []
+        for r in range(self.world):
+            chunk = got[r * self.CAPACITY:(r + 1) * self.CAPACITY]
+            n = int(np.frombuffer(chunk[:8].tobytes(), dtype=np.int64)[0])
+            per_rank.append(pickle.loads(chunk[8:8 + n].tobytes()))
+        for name in partial_pages:
+            op = make_final_operator[name]()
+            for payload in per_rank:   # rank order
+                cols = payload[name]
+                if cols is None:
+                    continue
+                blocks = []
+                for t, values in cols:
+                    if t == abi.VARCHAR:
+                        blocks.append(Block.varchar(values))
+                    else:
+                        nulls = [v is None for v in values]
+                        blocks.append(Block.flat(t, [0 if v is None else v for v in values], nulls if any(nulls) else None))
+                op.addInput(Page(blocks, len(cols[0][1])))
+            op.finish()
+            out[name] = op.getOutput()
+            if hasattr(op, "close"):
+                op.close()
+        return out

@@ -29,45 +29,94 @@ def empty_page(types):
     return Page([Block.varchar([]) if t == abi.VARCHAR else Block.flat(t, []) for t in types], 0)
 
 
+class OracleFinalOperator:
+    """Operator-protocol adapter over the oracle's Step.FINAL aggregation."""
+
+    def __init__(self, types, group_by, aggregates):
+        self.agg = O.HashAggregation(types, group_by, aggregates, step=abi.STEP_FINAL)
+
+    def addInput(self, page):
+        self.agg.add_page(page)
+
+    def finish(self):
+        pass
+
+    def getOutput(self):
+        return self.agg.build_result()
+
+
 class RehearsalWorkload:
-    def __init__(self, args, rank, world, device):
+    def __init__(self, args, rank, world, device, scaling=None, with_q3=None):
         O.build()
         self.args, self.rank, self.world = args, rank, world
+        self.scaling = scaling or getattr(args, "scaling", "weak")
         self.queries = ["q1", "q6"]
-        self.rows = tpch.lineitem_rows(args.sf)
-        self.total_sf = args.sf * world
         self.results = {}
-        self.q3_on = bool(args.q3)
+        self.q3_on = bool(args.q3) if with_q3 is None else with_q3
         self.q3_sf = args.q3_sf or args.sf
         self.q3_counters = {}
-        first = rank * self.rows
-        self.q6_cols = [O.tpch_column(c, self.total_sf, first, self.rows)[0] for c in tpch.Q6_COLUMNS]
-        cols = [O.tpch_column(c, self.total_sf, first, self.rows) for c in tpch.Q1_COLUMNS]
-        self.q1_args = [cols[0][0], cols[0][1], cols[1][0], cols[1][1]] + [c[0] for c in cols[2:]]
+
+        def shard(rows_of, sf, multiple=4):   # bench.DeviceWorkload's row-range shards
+            n = rows_of(sf)
+            if self.scaling == "weak" or world == 1:
+                return sf * world, rank * n, n
+            lo = n * rank // world // multiple * multiple
+            hi = n if rank == world - 1 else n * (rank + 1) // world // multiple * multiple
+            return sf, lo, hi - lo
+
+        self.total_sf, first, self.rows = shard(tpch.lineitem_rows, args.sf)
+        self.job_rows = tpch.lineitem_rows(args.sf) * (world if self.scaling == "weak" else 1)
+        self.q6_page = host_table(tpch.Q6_COLUMNS, self.total_sf, first, self.rows)
+        self.q1_page = host_table(tpch.Q1_COLUMNS, self.total_sf, first, self.rows)
+        self.merger = None
+        if world > 1:
+            from presto_amd.exchange import PartialStateMerger, partial_layout
+            self.merger = PartialStateMerger()
+            t6, f6 = partial_layout([], tpch.Q6_AGGREGATES)
+            t1, f1 = partial_layout([abi.VARCHAR, abi.VARCHAR], tpch.Q1_AGGREGATES)
+            self.final_operators = {"q6": lambda: OracleFinalOperator(t6, [], f6), "q1": lambda: OracleFinalOperator(t1, [0, 1], f1)}
         if self.q3_on:
             sf = self.q3_sf
-            nc, no, nl = tpch.customer_rows(sf), tpch.orders_rows(sf), tpch.lineitem_rows(sf)
+            self.q3_rows_job = tuple(f(sf) * (world if self.scaling == "weak" else 1) for f in (tpch.customer_rows, tpch.orders_rows, tpch.lineitem_rows))
+            ct, cf, nc = shard(tpch.customer_rows, sf, 20)
+            ot, of, no = shard(tpch.orders_rows, sf)
+            lt, lf, nl = shard(tpch.lineitem_rows, sf)
             self.q3_rows = (nc, no, nl)
-            t = sf * world
-            self.customer = host_table(tpch.CUSTOMER_COLUMNS, t, rank * nc, nc)
-            self.orders = host_table(tpch.ORDERS_COLUMNS, t, rank * no, no)
-            self.lineitem = host_table(tpch.Q3_LINEITEM_COLUMNS, t, rank * nl, nl)
+            self.customer = host_table(tpch.CUSTOMER_COLUMNS, ct, cf, nc)
+            self.orders = host_table(tpch.ORDERS_COLUMNS, ot, of, no)
+            self.lineitem = host_table(tpch.Q3_LINEITEM_COLUMNS, lt, lf, nl)
 
     def synchronize(self):
         pass
 
+    def _aggregate(self, page, filter_expr, projections, group_by, aggregates, step):
+        agg = O.HashAggregation([p.type for p in projections], group_by, aggregates, step=step)
+        if page.position_count:
+            selected = O.filter_project(page, filter_expr, projections)
+            if selected is not None and selected.position_count:
+                agg.add_page(selected)
+        return agg.build_result()
+
     def step(self, timed):
-        self.results["q6"] = [O.q6(*self.q6_cols)]
-        self.results["q1"] = O.q1(self.q1_args)
+        step = abi.STEP_PARTIAL if self.world > 1 else abi.STEP_SINGLE
+        out = {"q6": self._aggregate(self.q6_page, tpch.q6_filter(), tpch.q6_projections(), [], tpch.Q6_AGGREGATES, step),
+               "q1": self._aggregate(self.q1_page, tpch.q1_filter(), tpch.q1_projections(), tpch.Q1_GROUP_BY, tpch.Q1_AGGREGATES, step)}
+        if self.world > 1:
+            out = self.merger.merge(out, self.final_operators)
+        if out is not None:
+            self.results.update({q: ([] if p is None else p.to_rows()) for q, p in out.items()})
 
     def rows_per_step(self):
         return 2 * self.rows
+
+    def job_rows_per_step(self):
+        return 2 * self.job_rows
 
     def roofline(self, name, steps, pmc):
         return None
 
     def workload_name(self):
-        return "rehearsal: oracle operators on CPU ranks, SF%g per rank" % self.args.sf
+        return "rehearsal: oracle operators on CPU ranks, SF%g, %s scaling" % (self.args.sf, self.scaling)
 
     def q3_step(self):
         """presto_amd/q3.py's three pipelines with the oracle's operators and the stand-in exchange."""
@@ -99,6 +148,9 @@ class RehearsalWorkload:
 
     def q3_input_rows(self):
         return sum(self.q3_rows)
+
+    def q3_job_input_rows(self):
+        return sum(self.q3_rows_job)
 
     def q3_algorithmic_bytes(self):
         nc, no, nl = self.q3_rows

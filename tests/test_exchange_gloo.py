@@ -321,13 +321,14 @@ def bench_worker_one_rank_fails(rank, world, port, path):
             return super().q3_step()
 
     with open("%s.%d" % (path, rank), "w") as out:
-        bench.main(["--gpus", str(world), "--steps", "1", "--warmup", "1", "--sf", "0.002", "--cpu-rows", "0", "--backend", "gloo",
-                    "--q3-timeout", "8"], workload_factory=FailsOnRankOne, out=out)
+        sys.exit(bench.main(["--gpus", str(world), "--steps", "1", "--warmup", "1", "--sf", "0.002", "--cpu-rows", "0", "--backend", "gloo",
+                             "--q3-timeout", "8", "--other-scaling", "0"], workload_factory=FailsOnRankOne, out=out))
 
 
 def test_bench_line_survives_a_rank_failing_inside_q3(oracle, tmp_path):
     """One rank raising inside the Q3 leg leaves the others inside a collective: after --q3-timeout the headline line is
-    printed by rank 0 without the Q3 numbers and every rank leaves with exit code 0."""
+    printed by rank 0 without the Q3 numbers and every rank leaves -- with a non-zero exit code: the line is there, the run was
+    not clean."""
     world = 2
     ctx = mp.get_context("spawn")
     port = free_port()
@@ -335,8 +336,75 @@ def test_bench_line_survives_a_rank_failing_inside_q3(oracle, tmp_path):
     procs = [ctx.Process(target=bench_worker_one_rank_fails, args=(r, world, port, path)) for r in range(world)]
     [p.start() for p in procs]
     [p.join(timeout=120) for p in procs]
-    assert all(p.exitcode == 0 for p in procs)
+    import bench
+    assert all(p.exitcode == bench.Q3_FAILED_EXIT_CODE for p in procs)
     text = open(path + ".0").read()
     assert text.count("\n") == 1 and open(path + ".1").read() == ""
     line = json.loads(text)
     assert line["n_gpus"] == world and line["value"] > 0 and "error" in line["q3"]
+
+
+# ---- bench.py as the driver starts it: a plain subprocess, no torchrun, no environment -----------------------------------
+def run_bench(argv, env_extra=None, timeout=600):
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                          timeout=timeout, cwd=ROOT)
+
+
+def oracle_q1_q6(oracle, sf, rows):
+    from presto_amd import tpch
+    q6_cols = [oracle.tpch_column(c, sf, 0, rows)[0] for c in tpch.Q6_COLUMNS]
+    cols = [oracle.tpch_column(c, sf, 0, rows) for c in tpch.Q1_COLUMNS]
+    q1 = oracle.q1([cols[0][0], cols[0][1], cols[1][0], cols[1][1]] + [c[0] for c in cols[2:]])
+    return oracle.q6(*q6_cols)[0], sorted(q1)
+
+
+def check_q1_q6(results, q6_sum, q1_rows):
+    assert abs(results["q6"][0][0] - q6_sum) <= 1e-9 * abs(q6_sum)
+    got = sorted((r[0].encode(), r[1].encode(), *r[2:]) for r in results["q1"])
+    assert len(got) == len(q1_rows)
+    for g, e in zip(got, q1_rows):
+        assert g[:2] == e[:2] and g[-1] == e[-1]
+        assert all(abs(a - b) <= 1e-9 * abs(b) for a, b in zip(g[2:-1], e[2:-1]))
+
+
+def test_bench_launches_its_own_ranks(oracle):
+    """`python bench.py --gpus 8` with no torchrun environment starts 8 ranks itself (before anything touches a GPU), prints ONE
+    line with n_gpus 8, the weak headline and the `strong` object (the ONE SF table split by row range), both with the
+    PARTIAL -> FINAL merge inside the step: the merged results are those of one process over the whole tables."""
+    from presto_amd import tpch
+    world, sf = 8, 0.002
+    r = run_bench(["--gpus", str(world), "--backend", "gloo", "--workload", "tests.rehearsal_workload:RehearsalWorkload", "--sf", str(sf),
+                   "--steps", "2", "--warmup", "1", "--cpu-rows", "0"])
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    text = r.stdout.decode()
+    assert text.count("\n") == 1
+    line = json.loads(text)
+    assert line["n_gpus"] == world and line["scaling"] == "weak" and line["strong"]["scaling"] == "strong"
+    rows = tpch.lineitem_rows(sf)
+    assert abs(line["value"] - 2 * rows * world * 2 / (line["ms_per_step"] * 2 / 1e3)) <= 1e-6 * line["value"]
+    assert line["strong"]["job_rows"] == rows
+    assert abs(line["strong"]["value"] - 2 * rows * 2 / (line["strong"]["ms_per_step"] * 2 / 1e3)) <= 1e-6 * line["strong"]["value"]
+    assert "error" not in line["q3"] and line["q3"]["exchange"]["transport"].startswith("host transport")
+    check_q1_q6(line["results"], *oracle_q1_q6(oracle, sf * world, rows * world))   # weak: the SF x 8 table
+    check_q1_q6(line["strong"]["results"], *oracle_q1_q6(oracle, sf, rows))          # strong: the SF table
+
+
+def test_bench_strong_headline_on_two_ranks(oracle):
+    from presto_amd import tpch
+    sf = 0.002
+    r = run_bench(["--gpus", "2", "--backend", "gloo", "--workload", "tests.rehearsal_workload:RehearsalWorkload", "--sf", str(sf), "--steps", "1",
+                   "--warmup", "1", "--cpu-rows", "0", "--scaling", "strong", "--q3", "0"])
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    line = json.loads(r.stdout.decode())
+    assert line["scaling"] == "strong" and line["weak"]["scaling"] == "weak" and line["n_gpus"] == 2
+    check_q1_q6(line["results"], *oracle_q1_q6(oracle, sf, tpch.lineitem_rows(sf)))
+    check_q1_q6(line["weak"]["results"], *oracle_q1_q6(oracle, sf * 2, tpch.lineitem_rows(sf) * 2))
+
+
+def test_bench_refuses_a_world_size_that_is_not_gpus():
+    r = run_bench(["--gpus", "4", "--backend", "gloo", "--workload", "tests.rehearsal_workload:RehearsalWorkload", "--sf", "0.002"],
+                  env_extra={"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29999"}, timeout=120)
+    assert r.returncode == 2 and r.stdout == b"" and b"WORLD_SIZE" in r.stderr

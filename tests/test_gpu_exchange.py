@@ -267,3 +267,50 @@ def test_partition_columns_stable(gpu, oracle, n, parts):
     assert outs[0].cpu().numpy().tolist() == pos.tolist()
     p = torch.from_numpy(pos).cuda().long()
     assert torch.equal(outs[1], c8[p]) and torch.equal(outs[2], c1[p])
+
+
+def test_two_sinks_on_two_driver_threads(gpu, oracle):
+    """pa_exchange_desc.sink_count = 2: two PartitionedOutput operators, each on a Driver thread and a stream of its own, append to
+    the same destination buffers (growing them: reserve_keep copies and recycles a buffer the other sink's copy kernel may still
+    be writing to unless the appends are ordered).  Every row arrives once; per sink, in page order."""
+    import threading
+    from presto_amd.exchange import Comm, Exchange, ExchangeSourceOperator, PartitionedOutputOperator
+    comm = Comm.single()
+    try:
+        for attempt in range(3):
+            ex = Exchange(comm, EX_TYPES, [0], sink_count=2)
+            sinks = [PartitionedOutputOperator(ex), PartitionedOutputOperator(ex)]
+            source = ExchangeSourceOperator(ex, abi.MEM_HOST)
+            pages = [exchange_pages(100 + attempt, 12, 30011, nulls_from_page=3), exchange_pages(200 + attempt, 12, 25013, nulls_from_page=5)]
+            errors = []
+
+            def drive(sink, mine):
+                try:
+                    for p in mine:
+                        sink.addInput(p)
+                    sink.finish()
+                except Exception as e:  # surfaces in the main thread
+                    errors.append(e)
+            assert source.isBlocked()
+            threads = [threading.Thread(target=drive, args=(s_, p_)) for s_, p_ in zip(sinks, pages)]
+            [t.start() for t in threads]
+            [t.join() for t in threads]
+            assert not errors, errors
+            out = source.getOutput()
+            rows = out.to_rows()
+            expected = [[r for p in mine for r in p.to_rows()] for mine in pages]
+            assert len(rows) == len(expected[0]) + len(expected[1])
+            key = lambda r: tuple((x is None, x) for x in r)
+            assert sorted(rows, key=key) == sorted(expected[0] + expected[1], key=key)
+            # per sink the rows keep their order: the rows of sink k, as a subsequence of the output
+            for mine in expected:
+                want = set(map(key, mine))
+                got = [r for r in rows if key(r) in want]
+                if len(want) == len(mine) and not (want & set(map(key, expected[1] if mine is expected[0] else expected[0]))):
+                    assert got == mine
+            for s_ in sinks:
+                s_.close()
+            source.close()
+            ex.destroy()
+    finally:
+        comm.destroy()

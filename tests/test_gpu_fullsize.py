@@ -215,3 +215,66 @@ def test_sf300_q6_q1_linearity_page_size_invariance_and_far_offset(lineitem300, 
     s, c = q6(t, first, cnt)
     es, ec = oracle.q6(*[oracle.tpch_column(col, 300.0, first, cnt)[0] for col in tpch.Q6_COLUMNS])
     assert c == ec and abs(s - es) <= 1e-9 * abs(es)
+
+
+# ---- BASELINE config #2: TPC-H SF10 Q6 scan-filter-project on one GPU, exactly 59 986 052 rows ----------------------------------
+def test_sf10_q6_config_2(gpu, oracle):
+    """Page -> device, HIP predicate + wavefront compaction, DOUBLE SUM reduce over the 59 986 052 lineitem rows of SF10:
+    fused operator == FilterAndProject (positions list, compaction) -> Aggregation chain, exactly in the count and to 1e-12 in the
+    sum; linearity over disjoint ranges; bitwise reproducibility; and three samples (front, middle, far end) row by row against
+    the oracle."""
+    n = 59_986_052
+    t = tpch.DeviceColumns(tpch.Q6_COLUMNS, 10.0, n)
+    total, count = q6(t, 0, n)
+    assert q6(t, 0, n) == (total, count)
+    assert 0.015 < count / n < 0.025
+    cuts = [0, 20_000_000, 20_000_004, 41_234_568, n]
+    parts = [q6(t, a, b - a, page_rows=1 << 23) for a, b in zip(cuts, cuts[1:])]
+    assert sum(c for _, c in parts) == count and close(sum(s for s, _ in parts), total)
+    # the unfused chain: FilterAndProject emits the compacted revenue column, the aggregation adds it up
+    fp = FilterAndProjectOperator(tpch.Q6_TYPES, tpch.q6_filter(), tpch.q6_projections(), output_mem=abi.MEM_DEVICE)
+    agg = AggregationOperator([abi.DOUBLE], [(abi.AGG_SUM, 0, abi.DOUBLE), (abi.AGG_COUNT_STAR, -1, None)])
+    for p in sub_pages(t, tpch.Q6_COLUMNS, 0, n, 1 << 25):
+        fp.addInput(p)
+        out = fp.getOutput()
+        if out is not None:
+            agg.addInput(out)
+    fp.finish()
+    agg.finish()
+    (s, c), = agg.getOutput().to_rows()
+    assert c == count and close(s, total)
+    for first, cnt in ((0, 250_001), (30_000_000, 250_003), (n - 250_002, 250_002)):
+        gs, gc = q6(t, first, cnt)
+        es, ec = oracle.q6(*[oracle.tpch_column(col, 10.0, first, cnt)[0] for col in tpch.Q6_COLUMNS])
+        assert gc == ec and abs(gs - es) <= 1e-9 * abs(es)
+
+
+# ---- BASELINE config #1's shape: TPC-H tiny Q6 (60 175 lineitem rows), the whole table against the oracle -------------------------
+def test_tiny_q6_config_1(gpu, oracle):
+    """lineitem scan -> filter -> SUM over the 60 175 rows of TPC-H tiny (SF0.01): the device result against the oracle's
+    hand-written twin (HandTpchQuery6.java:95-141) over the whole table, the selected positions bit-exact, through 8192-row host
+    pages (what TpchQueryRunner's Driver delivers) and as one device page."""
+    from presto_amd.operators import to_pages
+    from presto_amd.page import Block, Page
+    n, sf = 60_175, 0.01
+    cols = [oracle.tpch_column(c, sf, 0, n)[0] for c in tpch.Q6_COLUMNS]
+    es, ec = oracle.q6(*cols)
+    assert ec > 500
+    host = Page([Block.flat(t, c) for t, c in zip(tpch.Q6_TYPES, cols)], n)
+    pages = [host.get_region(i, min(8192, n - i)) for i in range(0, n, 8192)]
+    aggs = tpch.Q6_AGGREGATES + [(abi.AGG_COUNT_STAR, -1, None)]
+    op = FusedAggregationOperator(tpch.Q6_TYPES, tpch.q6_filter(), tpch.q6_projections(), [], aggs)
+    (s, c), = to_pages(op, pages)[0].to_rows()
+    assert c == ec and abs(s - es) <= 1e-9 * abs(es)
+    dev = tpch.DeviceColumns(tpch.Q6_COLUMNS, sf, n)
+    s2, c2 = q6(dev, 0, n)
+    assert c2 == ec and abs(s2 - es) <= 1e-9 * abs(es)
+    # row selection bit-exact: positions of the filter over the whole table
+    fp = FilterAndProjectOperator(tpch.Q6_TYPES, tpch.q6_filter(), tpch.q6_projections(), output_mem=abi.MEM_DEVICE)
+    fp.addInput(dev.page(0, n))
+    out = fp.getOutput()
+    is_list, pos = fp.selectedPositions()
+    oracle_is_list, expected = oracle.filter_positions(host, tpch.q6_filter())
+    assert is_list and oracle_is_list and np.array_equal(pos, expected) and out.position_count == ec
+    projected = np.asarray(download_page(out).blocks[0].values)
+    assert np.array_equal(projected.view(np.int64), (cols[3][expected] * cols[1][expected]).view(np.int64))   # raw bits

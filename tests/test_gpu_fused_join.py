@@ -320,3 +320,20 @@ def test_fused_join_with_varchar_probe_channels(gpu, oracle):
         fp = oracle.filter_project(p, flt, proj)
         expected += j.probe(fp, types, [0], [1, 2, 0])[0].to_rows()
     assert rows == expected and len(rows) > 5000
+
+
+def test_operator_chain_on_an_owned_stream_with_a_large_duplicate_build_side(gpu, oracle):
+    """No stream in any descriptor (the JNI default) and a build side with duplicate keys: the handle runs FilterAndProject ->
+    LookupJoin -> HashAggregation behind each other, device pages handed over inside the handle -- on ONE stream the handle owns
+    (members with pooled streams of their own would race: nothing orders two private streams).  Large pages, so that a page's
+    gather kernels are still running when the next operator takes it."""
+    rng = np.random.default_rng(77)
+    nb = 200_000
+    build = [build_page(rng, rng.integers(0, 150_000, nb), nullable=False)]
+    probe = probe_pages(rng, 6, 300_000, 160_000, null_keys=False)
+    aggs = [(abi.AGG_SUM, 1, abi.DOUBLE), (abi.AGG_COUNT_STAR, -1, None), (abi.AGG_SUM, 2, abi.INTEGER)]
+    expected, joined_types = oracle_rows(oracle, probe, build, [1, 2], [0, 1, 2, 3], [0], aggs)
+    assert sum(r[2] for r in expected) > 1_000_000
+    for _ in range(3):
+        rows = fused_rows(probe, build, [1, 2], [0, 1, 2, 3], joined_types, [0], aggs, expected_groups=200_000)
+        rows_equal_ignore_order(rows, expected, rel=1e-9)

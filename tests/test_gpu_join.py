@@ -595,3 +595,29 @@ def test_join_filter_decides_which_build_rows_a_full_outer_join_has_visited(gpu,
     brows = build.to_rows()
     assert 0 < len(unvisited) < 800
     assert unvisited == [(None, None, brows[b][0], brows[b][1]) for b in range(800) if b not in visited]
+
+
+def test_large_build_side_with_a_hash_channel(gpu, oracle):
+    """>= 2^20 build rows AND a $hashvalue channel on both sides: build and probe must place / look for a key by the same hash --
+    the channel's -- so the partitioned build (which hashes the key itself) is not taken.  The channel carries the reference's
+    hash here; a second run carries another function of the key, which only stays consistent if both sides use the channel."""
+    rng = np.random.default_rng(41)
+    nb, npr = (1 << 20) + 777, 200_000
+    keys = rng.permutation(2 * nb)[:nb].astype(np.int64) * 31 - 5
+    pk = np.where(rng.random(npr) < 0.7, keys[rng.integers(0, nb, npr)], rng.integers(-10 ** 9, 10 ** 9, npr)).astype(np.int64)
+    types = [abi.BIGINT, abi.INTEGER, abi.BIGINT]
+
+    def pages(hash_of):
+        b = [Page([Block.bigint(keys), Block.integer(np.arange(nb)), Block.bigint(hash_of(keys))], nb)]
+        p = [Page([Block.bigint(pk), Block.integer(np.arange(npr)), Block.bigint(hash_of(pk))], npr)]
+        return b, p
+
+    ref_hash = lambda k: oracle.hash_page(Page([Block.bigint(k)], len(k)), [0])
+    other_hash = lambda k: (k * np.int64(0x9E3779B97F4A7C15 - (1 << 64))) ^ (k >> np.int64(7))
+    for hash_of in (ref_hash, other_hash):
+        build, probe = pages(hash_of)
+        rows, pairs, _ = gpu_join(build, types, [0], [1], probe, types, [0], [0, 1], build_hash=2, probe_hash=2)
+        orows, opairs, _ = oracle_join(oracle, build, types, [0], [1], probe, types, [0], [0, 1], build_hash=2, probe_hash=2)
+        assert len(orows) > 100_000 and rows == orows
+        for (gp, gb), (op_, ob) in zip(pairs, opairs):
+            assert np.array_equal(gp, op_) and np.array_equal(gb, ob)

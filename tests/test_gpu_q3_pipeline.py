@@ -184,14 +184,17 @@ def test_q3_with_topn(gpu, oracle):
     stream.destroy()
 
 
-def test_q3_sf100_independent_paths_agree(gpu):
-    """BASELINE config #4 at full size (765 M input rows), tied to the small-scale oracle parity above through a size-independent
-    property: the TopN result must not depend on the path -- with / without the joins' dynamic filters (rows dropped before
-    the probe vs inside it), with / without the extra count(*) (implicit vs explicit count word), 2^28- vs 2^26-row pages,
-    fused probe kernel with build-row accumulators vs FilterAndProject -> LookupJoin -> HashAggregation with a hashed table."""
+@pytest.mark.parametrize("sf", [100.0, 300.0])
+def test_q3_full_size_independent_paths_agree(gpu, sf):
+    """BASELINE config #4 at full size (SF100: 765 M input rows) and config #5's Q3 leg (SF300: 2.3 G input rows on the one GPU,
+    lineitem row offsets beyond 2^30 and byte offsets beyond 2^32), tied to the small-scale oracle parity above through a
+    size-independent property: the TopN result must not depend on the path -- with / without the joins' dynamic filters (rows
+    dropped before the probe vs inside it), with / without the extra count(*) (implicit vs explicit count word), 2^28- vs
+    2^26-row pages, fused probe kernel with build-row accumulators vs FilterAndProject -> LookupJoin -> HashAggregation with a
+    hashed table."""
     from presto_amd import q3
-    sf = 100.0
     customer, orders, lineitem = _device_tables(sf)
+    assert lineitem.rows == int(6001215 * sf)
     stream = DeviceStream()
 
     def run(page_rows, **kw):
@@ -200,7 +203,7 @@ def test_q3_sf100_independent_paths_agree(gpu):
         return [r for p in out for r in p.to_rows()], counters
 
     base, counters = run(1 << 28)
-    assert len(base) == 10 and counters["lineitem_dynamic_filter"] == "fused" and counters["build2_rows"] > 10_000_000
+    assert len(base) == 10 and counters["lineitem_dynamic_filter"] == "fused" and counters["build2_rows"] > 100_000 * sf
     revenue = [r[3] for r in base]
     assert revenue == sorted(revenue, reverse=True)
     plain, counters2 = run(1 << 28, dynamic_filters=False)

@@ -460,3 +460,30 @@ def test_real_keys_hand_computed(oracle):
     assert out.to_rows() == [(0, 10), (2, 12)]          # -0 = +0; NaN = nothing
     rows = oracle.topn([Page([Block.real(np.array([np.nan, 0.0, -0.0, -np.inf, 5.0], dtype=np.float32))], 5)], 5, [0], [abi.ASC_NULLS_LAST])
     assert [repr(r[0]) for r in rows] == ["-inf", "-0.0", "0.0", "5.0", "nan"]
+
+
+def test_tiny_q6_config_1_on_the_cpu_operators(oracle):
+    """BASELINE config #1 (TPC-H tiny Q6, lineitem scan -> filter -> SUM on the CPU operators; plumbing, no GPU): over the
+    60 175 lineitem rows of SF0.01 the oracle's hand-written twin of the pipeline (HandTpchQuery6.java:95-141) and the oracle's
+    operator composition FilterAndProject -> Aggregation (what TpchQueryRunner's Driver runs) give the same count and -- both
+    adding left to right -- bit-identical sums, through 8192-row pages as the Driver delivers them."""
+    import numpy as np
+    from presto_amd import abi, tpch
+    from presto_amd.page import Block, Page
+    n, sf = 60_175, 0.01
+    cols = [oracle.tpch_column(c, sf, 0, n)[0] for c in tpch.Q6_COLUMNS]
+    twin_sum, twin_count = oracle.q6(*cols)
+    host = Page([Block.flat(t, c) for t, c in zip(tpch.Q6_TYPES, cols)], n)
+    agg = oracle.HashAggregation([abi.DOUBLE], [], [(abi.AGG_SUM, 0, abi.DOUBLE), (abi.AGG_COUNT_STAR, -1, None)])
+    selected = 0
+    for i in range(0, n, 8192):
+        out = oracle.filter_project(host.get_region(i, min(8192, n - i)), tpch.q6_filter(), tpch.q6_projections())
+        if out is not None and out.position_count:
+            selected += out.position_count
+            agg.add_page(out)
+    (s, c), = agg.build_result().to_rows()
+    assert c == twin_count == selected and 500 < c < 2000
+    assert np.float64(s).view(np.int64) == np.float64(twin_sum).view(np.int64)
+    # and against numpy over the whole table (independent of both)
+    m = (cols[0] >= 8766) & (cols[0] < 9131) & (cols[1] >= 0.05) & (cols[1] <= 0.07) & (cols[2] < 24.0)
+    assert int(m.sum()) == c and abs(float((cols[3][m] * cols[1][m]).sum()) - s) <= 1e-12 * s
