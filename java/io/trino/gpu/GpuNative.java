@@ -31,6 +31,9 @@ final class GpuNative
             int minOutputPageRows, int outputMem);
     static native long createHashAggregation(int[] inputTypes, int[] typeParams, int[] groupByChannels, int hashChannel, int step, int[] aggFns,
             int[] aggInputs, int[] aggMasks, int[] aggInputTypes, int expectedGroups, int outputMem);
+    /** [Scan]FilterAndProject -> (Hash)Aggregation of one pipeline as one device pass; aggregate channels index the projections. */
+    static native long createFusedAggregation(int[] inputTypes, int[] typeParams, long filter, long[] projections, int[] projectionTypes,
+            int[] groupByChannels, int step, int[] aggFns, int[] aggInputs, int[] aggMasks, int[] aggInputTypes, int expectedGroups, int outputMem);
     static native long createLookupSource();
     static native void destroyLookupSource(long lookupSource);
     static native long createHashBuilder(long bridge, int[] inputTypes, int[] joinChannels, int hashChannel, int[] outputChannels, int expectedPositions);

@@ -194,6 +194,37 @@ JNIEXPORT jlong JNICALL Java_io_trino_gpu_GpuNative_createHashAggregation(JNIEnv
     return (jlong)(intptr_t)op;
 }
 
+/* [Scan]FilterAndProject -> (Hash)Aggregation of one pipeline as ONE device pass (pa_fused_aggregation_create): the planner hook
+ * collapses the two neighbouring operator factories when both are on the device.  Aggregate channels index the projections. */
+JNIEXPORT jlong JNICALL Java_io_trino_gpu_GpuNative_createFusedAggregation(JNIEnv* env, jclass c, jintArray inputTypes, jintArray typeParams, jlong filter,
+        jlongArray projections, jintArray projectionTypes, jintArray groupByChannels, jint step, jintArray aggFns, jintArray aggInputs, jintArray aggMasks,
+        jintArray aggInputTypes, jint expectedGroups, jint outputMem)
+{
+    jsize n, np_, npt, ng, na, nproj = (*env)->GetArrayLength(env, projections);
+    pa_fused_aggregation_desc d;
+    memset(&d, 0, sizeof d);
+    int32_t *types = ints_of(env, inputTypes, &n), *params = ints_of(env, typeParams, &np_), *ptypes = ints_of(env, projectionTypes, &npt);
+    int32_t* gb = ints_of(env, groupByChannels, &ng);
+    pa_aggregate* aggs;
+    fill_aggregates(env, aggFns, aggInputs, aggMasks, aggInputTypes, &aggs, &na);
+    pa_expr* pe = (pa_expr*)calloc((size_t)(nproj > 0 ? nproj : 1), sizeof(pa_expr));
+    jlong* ph = (*env)->GetLongArrayElements(env, projections, 0);
+    for (jsize i = 0; i < nproj; i++) pe[i] = ((native_expr*)(intptr_t)ph[i])->expr;
+    (*env)->ReleaseLongArrayElements(env, projections, ph, JNI_ABORT);
+    d.filter_project.input_channel_count = n; d.filter_project.input_types = types; d.filter_project.input_type_params = np_ == n ? params : 0;
+    d.filter_project.filter = filter ? &((native_expr*)(intptr_t)filter)->expr : 0;
+    d.filter_project.projection_count = nproj; d.filter_project.projections = pe; d.filter_project.output_mem = outputMem;
+    d.aggregation.input_channel_count = npt; d.aggregation.input_types = ptypes; d.aggregation.group_by_count = ng; d.aggregation.group_by_channels = gb;
+    d.aggregation.hash_channel = -1; d.aggregation.step = step; d.aggregation.aggregate_count = na; d.aggregation.aggregates = aggs;
+    d.aggregation.expected_groups = expectedGroups; d.aggregation.output_mem = outputMem;
+    pa_operator* op = 0;
+    int32_t rc = npt == nproj ? pa_fused_aggregation_create(&d, &op) : PA_ERR_INVALID_ARGUMENT;
+    free(pe); free(aggs); free(gb); free(ptypes); free(params); free(types);
+    if (rc == PA_ERR_INVALID_ARGUMENT && npt != nproj) { throw_message(env, rc, "one projection type per projection"); return 0; }
+    if (rc < 0) { throw_native(env, rc); return 0; }
+    return (jlong)(intptr_t)op;
+}
+
 JNIEXPORT jlong JNICALL Java_io_trino_gpu_GpuNative_createLookupSource(JNIEnv* env, jclass c)
 {
     pa_lookup_source* ls = 0;
@@ -432,6 +463,15 @@ JNIEXPORT void JNICALL Java_io_trino_gpu_GpuNative_addInput(JNIEnv* env, jclass 
  * The addresses are the operator's pinned output buffers (PA_MEM_HOST operators), valid until the next call on the handle;
  * GpuOperator wraps them (NewDirectByteBuffer on the Java side through wrapAddress) and copies them into fresh long[] /
  * int[] / byte[] for new LongArrayBlock(n, Optional.ofNullable(valueIsNull), values) etc. */
+static int64_t value_width(int32_t type)   /* bytes per position of a flat block (common.hpp type_width) */
+{
+    switch (type) {
+        case PA_BIGINT: case PA_DOUBLE: return 8;
+        case PA_INTEGER: case PA_DATE: case PA_REAL: return 4;
+        case PA_BOOLEAN: return 1;
+        default: return 0;
+    }
+}
 JNIEXPORT jlongArray JNICALL Java_io_trino_gpu_GpuNative_getOutput(JNIEnv* env, jclass c, jlong h)
 {
     pa_page out;
@@ -439,6 +479,10 @@ JNIEXPORT jlongArray JNICALL Java_io_trino_gpu_GpuNative_getOutput(JNIEnv* env, 
     int32_t rc = pa_op_get_output((pa_operator*)(intptr_t)h, &out);
     if (rc < 0) { throw_native(env, rc); return 0; }
     if (rc == 0) return 0;
+    if (out.mem != PA_MEM_HOST) {   /* the addresses below are read by the JVM: a device page has nothing to wrap */
+        throw_message(env, PA_ERR_ILLEGAL_STATE, "getOutput: the operator was created with PA_MEM_DEVICE output");
+        return 0;
+    }
     const jsize len = 2 + 6 * out.channel_count;
     jlong* v = (jlong*)calloc((size_t)len, sizeof(jlong));
     v[0] = out.position_count;
@@ -449,7 +493,7 @@ JNIEXPORT jlongArray JNICALL Java_io_trino_gpu_GpuNative_getOutput(JNIEnv* env, 
         r[0] = col->type;
         r[1] = (jlong)(intptr_t)col->values;
         if (col->encoding == PA_VARWIDTH) r[2] = out.position_count > 0 ? col->offsets[out.position_count] : 0;
-        else r[2] = (jlong)out.position_count * (col->type == PA_BOOLEAN ? 1 : ((col->type == PA_INTEGER || col->type == PA_DATE) ? 4 : 8));
+        else r[2] = (jlong)out.position_count * value_width(col->type);
         r[3] = (jlong)(intptr_t)col->offsets;
         r[4] = (jlong)(intptr_t)col->nulls;
     }
