@@ -62,6 +62,9 @@ def parse_args(argv=None):
                          "strong: the ranks split the ONE --sf table by row range (the metric's 'SF100 at 1/2/4/8 GPUs').  The other "
                          "mode is timed beside it and reported as an object of that name (--other-scaling 0 skips it)")
     ap.add_argument("--other-scaling", type=int, default=1)
+    ap.add_argument("--operators", type=int, default=1, help="1 = also run the operator benchmarks (the `operators` object: hash aggregation at "
+                    "several cardinalities, hash join build / probe, OrderBy, TopN -- the reference's micro-benchmark shapes -- each beside its oracle twin "
+                    "on the host), N = 1 only; 0 = skip")
     ap.add_argument("--workload", default="device", help="'device' = the product path; 'module:Class' = a checker workload with the same "
                     "surface (tests/rehearsal_workload.py: the oracle's operators on CPU ranks, to rehearse the multi-rank control flow)")
     return ap.parse_args(argv)
@@ -94,63 +97,120 @@ def cpu_model():
     return "unknown"
 
 
-def cpu_baseline(sf, rows):
-    """Oracle twins of the two pipelines (HandTpchQuery6 / HandTpchQuery1 shape) on a sample of the same
-    synthetic workload: one Driver thread each first, then T threads over disjoint row ranges."""
+def physical_cores():
+    """Distinct (physical id, core id) pairs of /proc/cpuinfo among the CPUs this process may run on (hyper-thread siblings
+    count once); falls back to the affinity count."""
+    allowed = os.sched_getaffinity(0)
+    cores, cpu, phys = set(), None, 0
+    try:
+        for line in open("/proc/cpuinfo"):
+            key, _, value = line.partition(":")
+            key = key.strip()
+            if key == "processor":
+                cpu = int(value)
+            elif key == "physical id":
+                phys = int(value)
+            elif key == "core id" and cpu in allowed:
+                cores.add((phys, int(value)))
+    except (OSError, ValueError):
+        pass
+    return len(cores) or len(allowed)
+
+
+def cpu_baseline(sf, rows, one_thread_rows=8_000_000, warmups=3, runs=10):
+    """Oracle twins of the two pipelines (HandTpchQuery6 / HandTpchQuery1 shape) on a sample of the same synthetic workload, as
+    BASELINE.md section 2 asks: one Driver thread, and T threads over disjoint row ranges with T = all physical cores; `warmups`
+    warm-up passes + `runs` measured passes each, median and min (AbstractOperatorBenchmark.java:305-334: rows / wall seconds).
+    The T-thread passes walk the whole sample, the one-thread passes its first `one_thread_rows` rows."""
     from oracle import oracle as O
     from presto_amd import abi, tpch
     O.build()
-    threads = max(1, min(len(os.sched_getaffinity(0)), 64))
+    threads = max(1, physical_cores())
     union = sorted(set(tpch.Q1_COLUMNS + tpch.Q6_COLUMNS))
 
     def gen(lo, hi, out):
         for c in union:
             out[c] = O.tpch_column(c, sf, lo, hi - lo)
 
-    # generate the sample in parallel slices (generation is not timed)
+    # the sample in `threads` slices, generated in parallel (generation is not timed); the one-thread sample in front of them
+    one_rows = min(one_thread_rows, rows)
     bounds = [rows * i // threads for i in range(threads + 1)]
     parts = [dict() for _ in range(threads)]
+    head = {}
     ts = [threading.Thread(target=gen, args=(bounds[i], bounds[i + 1], parts[i])) for i in range(threads)]
+    ts.append(threading.Thread(target=gen, args=(0, one_rows, head)))
     [t.start() for t in ts]
     [t.join() for t in ts]
 
-    def q6_args(p):
-        return [p[c][0] for c in tpch.Q6_COLUMNS]
+    def q6(p):
+        return O.q6(*[p[c][0] for c in tpch.Q6_COLUMNS])
 
-    def q1_args(p):
+    def q1(p):
         rf, ls = p[abi.L_RETURNFLAG], p[abi.L_LINESTATUS]
-        return [rf[0], rf[1], ls[0], ls[1]] + [p[c][0] for c in tpch.Q1_COLUMNS[2:]]
+        return O.q1([rf[0], rf[1], ls[0], ls[1]] + [p[c][0] for c in tpch.Q1_COLUMNS[2:]])
 
-    def run_all(fn, nthreads):
-        res = [None] * nthreads
-        # nthreads == 1: one Driver walks every slice; else slice i on thread i
-        if nthreads == 1:
-            t0 = time.perf_counter()
-            for i in range(threads):
-                fn(parts[i])
-            return time.perf_counter() - t0
-        ts = [threading.Thread(target=lambda i=i: res.__setitem__(i, fn(parts[i]))) for i in range(nthreads)]
+    def one(fn):
+        t0 = time.perf_counter()
+        fn(head)
+        return time.perf_counter() - t0
+
+    def many(fn):
+        ts = [threading.Thread(target=fn, args=(parts[i],)) for i in range(threads)]
         t0 = time.perf_counter()
         [t.start() for t in ts]
         [t.join() for t in ts]
         return time.perf_counter() - t0
 
-    t6_1 = run_all(lambda p: O.q6(*q6_args(p)), 1)
-    t1_1 = run_all(lambda p: O.q1(q1_args(p)), 1)
-    # (the T-thread passes are short: the best of three keeps thread start-up noise out)
-    t6_t = min(run_all(lambda p: O.q6(*q6_args(p)), threads) for _ in range(3))
-    t1_t = min(run_all(lambda p: O.q1(q1_args(p)), threads) for _ in range(3))
-    one = 2 * rows / (t6_1 + t1_1)
-    many = 2 * rows / (t6_t + t1_t)
+    def measure(run, fn):
+        for _ in range(warmups):
+            run(fn)
+        t = sorted(run(fn) for _ in range(runs))
+        return t[len(t) // 2], t[0]
+
+    (m6_1, b6_1), (m1_1, b1_1) = measure(one, q6), measure(one, q1)
+    (m6_t, b6_t), (m1_t, b1_t) = measure(many, q6), measure(many, q1)
+    one_v, many_v = 2 * one_rows / (m6_1 + m1_1), 2 * rows / (m6_t + m1_t)
     return {
-        "value": many, "unit": "rows/s", "cores": threads, "kind": "port", "cpu_model": cpu_model(),
-        "host_threads_available": len(os.sched_getaffinity(0)),
-        "one_thread": {"value": one, "q6": rows / t6_1, "q1": rows / t1_1, "unit": "rows/s"},
-        "all_threads": {"value": many, "q6": rows / t6_t, "q1": rows / t1_t, "threads": threads, "unit": "rows/s"},
-        "sample": "%d lineitem rows (SF%g generator), Q6+Q1 hand-written-twin pipelines of the oracle (C, -O2, scalar); "
-                  "1 thread = one reference Driver; %d threads over disjoint row ranges = task_concurrency Drivers; "
-                  "`value` is the %d-thread figure" % (rows, sf, threads, threads),
+        "value": many_v, "unit": "rows/s", "cores": threads, "kind": "port", "cpu_model": cpu_model(),
+        "host_threads_available": len(os.sched_getaffinity(0)), "physical_cores": threads, "warmups": warmups, "runs": runs,
+        "one_thread": {"value": one_v, "best": 2 * one_rows / (b6_1 + b1_1), "q6": one_rows / m6_1, "q1": one_rows / m1_1, "rows": one_rows, "unit": "rows/s"},
+        "all_threads": {"value": many_v, "best": 2 * rows / (b6_t + b1_t), "q6": rows / m6_t, "q1": rows / m1_t, "threads": threads, "rows": rows, "unit": "rows/s"},
+        "sample": "%d lineitem rows (SF%g generator), Q6+Q1 hand-written-twin pipelines of the oracle (C, -O2, scalar); 1 thread = one reference "
+                  "Driver over the first %d rows; %d threads (one per physical core) over disjoint row ranges = task_concurrency Drivers; %d warm-up + "
+                  "%d measured passes each, `value` = rows / median wall time of the %d-thread passes (`best`: / min)"
+                  % (rows, sf, one_rows, threads, warmups, runs, threads),
     }
+
+
+def q3_cpu_baseline(sf=1.0, warmups=1, runs=3):
+    """The oracle's composition of the Q3 operators (oracle.q3: FilterAndProject, HashBuilder / LookupJoin twice, HashAggregation, TopN)
+    on one thread over SF`sf` tables of the same generator: input rows / median wall time."""
+    from oracle import oracle as O
+    from presto_amd import abi, tpch
+    from presto_amd.page import Block, Page
+    O.build()
+
+    def table(columns, n):
+        blocks = []
+        for c in columns:
+            v, o = O.tpch_column(c, sf, 0, n)
+            t = abi.TPCH_COLUMN_TYPE[c]
+            blocks.append(Block.varwidth(v, o) if t == abi.VARCHAR else Block.flat(t, v))
+        return Page(blocks, n)
+    nc, no, nl = tpch.customer_rows(sf), tpch.orders_rows(sf), tpch.lineitem_rows(sf)
+    customer, orders, lineitem = table(tpch.CUSTOMER_COLUMNS, nc), table(tpch.ORDERS_COLUMNS, no), table(tpch.Q3_LINEITEM_COLUMNS, nl)
+    ts = []
+    for i in range(warmups + runs):
+        t0 = time.perf_counter()
+        O.q3(customer, orders, lineitem, top_n=10)
+        if i >= warmups:
+            ts.append(time.perf_counter() - t0)
+    ts.sort()
+    rows = nc + no + nl
+    return {"value": rows / ts[len(ts) // 2], "best": rows / ts[0], "unit": "rows/s", "cores": 1, "kind": "port", "cpu_model": cpu_model(),
+            "warmups": warmups, "runs": runs,
+            "sample": "TPC-H SF%g tables of the same generator (%d + %d + %d rows), the oracle's Q3 operator composition incl. TopN on one thread "
+                      "(one reference Driver per pipeline)" % (sf, nc, no, nl)}
 
 
 class DeviceWorkload:
@@ -593,8 +653,25 @@ def main(argv=None, workload_factory=None, out=None):
                 line["sf300"] = sf300_leg(args, dist, device)
             except Exception as e:
                 line["sf300"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        if side_legs and world == 1 and args.operators and on_device:
+            try:
+                if workload is not None:
+                    workload.close()
+                    workload = None
+                import gc
+                gc.collect()
+                torch.cuda.empty_cache()
+                import bench_ops
+                line["operators"] = bench_ops.run(cpu=args.cpu_rows > 0)
+            except Exception as e:
+                line["operators"] = {"error": "%s: %s" % (type(e).__name__, e)}
         if side_legs and world == 1 and args.cpu_rows > 0:
             line["cpu_baseline"] = cpu_baseline(args.sf, args.cpu_rows)
+            if isinstance(line.get("q3"), dict) and "error" not in line["q3"]:
+                try:
+                    line["q3"]["cpu_baseline"] = q3_cpu_baseline()
+                except Exception as e:
+                    line["q3"]["cpu_baseline"] = {"error": "%s: %s" % (type(e).__name__, e)}
         if out is not None:
             print(json.dumps(line), file=out, flush=True)
         else:

@@ -76,6 +76,8 @@ def lib():
         L.orc_q6.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_double),
                              C.POINTER(C.c_int64)]
         L.orc_q1_add.argtypes = [C.c_void_p] + [C.c_void_p] * 9 + [C.c_int64]
+        L.orc_sort_positions_bigint.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
+        L.orc_topn_double_desc_bigint_asc.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]
         _LIB = L
     return _LIB
 
@@ -431,6 +433,37 @@ def q1(columns, chunks=1):
 
 
 # ---- MergePages ---------------------------------------------------------------------------------------------------
+def q3(customer, orders, lineitem, top_n=0):
+    """TPC-H Q3 as the composition of the oracle's operators (the plan of presto_amd/q3.py: customer -> filter -> HashBuilder;
+    orders -> filter -> LookupJoin -> HashBuilder; lineitem -> filter / project -> LookupJoin -> HashAggregation(orderkey, orderdate,
+    shippriority; sum(revenue), count(*)) [-> TopN(revenue DESC, orderdate ASC)]) over host pages: (rows, orders rows joined,
+    lineitem rows joined).  The parity tests' checker and bench.py's q3.cpu_baseline."""
+    from presto_amd import tpch
+    from presto_amd.expr import field
+    c = filter_project(customer, tpch.q3_customer_filter(), [field(0, abi.BIGINT)])
+    j1 = HashJoin([abi.BIGINT], [0], [])
+    if c is not None:
+        j1.add_build_page(c)
+    j1.build()
+    o = filter_project(orders, tpch.q3_orders_filter(), [field(i, t) for i, t in enumerate(tpch.ORDERS_TYPES)])
+    oc, _, _ = j1.probe(o, tpch.ORDERS_TYPES, [1], [0, 2, 3])
+    j2 = HashJoin([abi.BIGINT, abi.DATE, abi.INTEGER], [0], [1, 2])
+    j2.add_build_page(oc)
+    j2.build()
+    l = filter_project(lineitem, tpch.q3_lineitem_filter(), tpch.q3_lineitem_projections())
+    joined, _, _ = j2.probe(l, [abi.BIGINT, abi.DOUBLE], [0], [0, 1])
+    agg = HashAggregation([abi.BIGINT, abi.DOUBLE, abi.DATE, abi.INTEGER], [0, 2, 3], [(abi.AGG_SUM, 1, abi.DOUBLE), (abi.AGG_COUNT_STAR, -1, None)],
+                          expected_groups=100000)
+    agg.add_page(joined)
+    grouped = agg.build_result()
+    if top_n:
+        # ORDER BY revenue DESC, o_orderdate LIMIT n: the C heap (TopNProcessor) over the grouped columns
+        cols = [np.asarray(b.values) for b in grouped.blocks]   # BIGINT, DATE, INTEGER, DOUBLE, BIGINT: flat, no NULLs
+        keep = topn_positions_double_desc_bigint_asc(cols[3], cols[1].astype(np.int64), top_n)
+        return [tuple(c[i].item() for c in cols) for i in keep.tolist()], oc.position_count, joined.position_count
+    return grouped.to_rows(), oc.position_count, joined.position_count
+
+
 def block_size_in_bytes(block):
     """Block.getSizeInBytes of the flat block kinds: LongArrayBlock / IntArrayBlock / ByteArrayBlock
     (core/trino-spi/src/main/java/io/trino/spi/block/LongArrayBlock.java:55-57: (value width + 1) * positions) and
@@ -547,6 +580,24 @@ def order_by(pages, output_channels, sort_channels, sort_orders):
     """OrderByOperator (core/trino-main/src/main/java/io/trino/operator/OrderByOperator.java:45-330): PagesIndex.sort with the same
     comparator as TopN (SimplePagesIndexComparator / SortOrder.compareBlockValue), every row kept; output channels only."""
     return [tuple(r[c] for c in output_channels) for r in topn(pages, None, sort_channels, sort_orders)]
+
+
+def sort_positions_bigint(keys):
+    """PagesIndex.sort over row positions by one BIGINT key ascending (PagesIndexOrdering.quickSort restated in C): the
+    positions in output order.  Not stable, like the reference's."""
+    keys = np.ascontiguousarray(keys, dtype=np.int64)
+    pos = np.arange(len(keys), dtype=np.int32)
+    _check(lib().orc_sort_positions_bigint(keys.ctypes.data, len(keys), pos.ctypes.data))
+    return pos
+
+
+def topn_positions_double_desc_bigint_asc(values, keys, limit):
+    """TopNProcessor's bounded heap under (DOUBLE DESC, BIGINT ASC) in C: positions of the kept rows, best first."""
+    values = np.ascontiguousarray(values, dtype=np.float64)
+    keys = np.ascontiguousarray(keys, dtype=np.int64)
+    out = np.zeros(max(limit, 1), dtype=np.int32)
+    n = _check(lib().orc_topn_double_desc_bigint_asc(values.ctypes.data, keys.ctypes.data, len(values), limit, out.ctypes.data))
+    return out[:n]
 
 
 # ---- dynamic filter source -----------------------------------------------------------------------------------------

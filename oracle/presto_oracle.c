@@ -2157,3 +2157,171 @@ int32_t orc_q1_add(orc_hash_agg* agg, const uint8_t* returnflag, const int32_t* 
     }
     return 0;
 }
+
+/* =====================================================================================
+ * OrderByOperator / TopNOperator over flat columns: the CPU twins bench.py times beside the device operators (the
+ * Python restatements of oracle.py -- oracle.order_by, oracle.topn -- are the parity checkers for small pages; these
+ * follow the same reference code at a speed worth timing).
+ *
+ * orc_sort_positions_bigint: PagesIndex.sort (core/trino-main/src/main/java/io/trino/operator/PagesIndex.java:386-396) ->
+ *   PagesIndexOrdering.quickSort (…/operator/PagesIndexOrdering.java:52-142; forked from fastutil: insertion sort below
+ *   SMALL = 7, median of 3 above, pseudo-median of 9 above MEDIUM = 40, the "moving target" fat partition) over the row
+ *   addresses, compared through one BIGINT sort channel (SimplePagesIndexComparator -> SortOrder.compareBlockValue,
+ *   ASC_NULLS_LAST, no NULLs).  positions[] must hold 0..n-1 on entry (the arrival order); sorted on return.
+ * ===================================================================================== */
+typedef struct {
+    const int64_t* keys;
+    int32_t* pos;
+} sort_ctx;
+
+static inline int sort_cmp(const sort_ctx* c, int32_t i, int32_t j)
+{
+    const int64_t a = c->keys[c->pos[i]], b = c->keys[c->pos[j]];
+    return a < b ? -1 : (a > b ? 1 : 0);
+}
+static inline void sort_swap(const sort_ctx* c, int32_t i, int32_t j)
+{
+    const int32_t t = c->pos[i];
+    c->pos[i] = c->pos[j];
+    c->pos[j] = t;
+}
+static int32_t sort_median3(const sort_ctx* c, int32_t a, int32_t b, int32_t d)
+{
+    const int ab = sort_cmp(c, a, b), ac = sort_cmp(c, a, d), bc = sort_cmp(c, b, d);
+    return ab < 0 ? (bc < 0 ? b : ac < 0 ? d : a) : (bc > 0 ? b : ac > 0 ? d : a);
+}
+static void sort_vector_swap(const sort_ctx* c, int32_t from, int32_t l, int32_t s)
+{
+    for (int32_t i = 0; i < s; i++, from++, l++) sort_swap(c, from, l);
+}
+static void sort_quick(const sort_ctx* x, int32_t from, int32_t to)
+{
+    enum { SMALL = 7, MEDIUM = 40 };
+    const int32_t len = to - from;
+    if (len < SMALL) {
+        for (int32_t i = from; i < to; i++) {
+            for (int32_t j = i; j > from && sort_cmp(x, j - 1, j) > 0; j--) sort_swap(x, j, j - 1);
+        }
+        return;
+    }
+    int32_t m = from + len / 2;
+    if (len > SMALL) {
+        int32_t l = from, n = to - 1;
+        if (len > MEDIUM) {
+            const int32_t s = len / 8;
+            l = sort_median3(x, l, l + s, l + 2 * s);
+            m = sort_median3(x, m - s, m, m + s);
+            n = sort_median3(x, n - 2 * s, n - s, n);
+        }
+        m = sort_median3(x, l, m, n);
+    }
+    int32_t a = from, b = a, c = to - 1, d = c;
+    for (;;) {
+        int comparison;
+        while (b <= c && (comparison = sort_cmp(x, b, m)) <= 0) {
+            if (comparison == 0) {
+                if (a == m) m = b;
+                else if (b == m) m = a;
+                sort_swap(x, a++, b);
+            }
+            b++;
+        }
+        while (c >= b && (comparison = sort_cmp(x, c, m)) >= 0) {
+            if (comparison == 0) {
+                if (c == m) m = d;
+                else if (d == m) m = c;
+                sort_swap(x, c, d--);
+            }
+            c--;
+        }
+        if (b > c) break;
+        if (b == m) m = d;
+        else if (c == m) m = c;
+        sort_swap(x, b++, c--);
+    }
+    int32_t s, n = to;
+    s = a - from < b - a ? a - from : b - a;
+    sort_vector_swap(x, from, b - s, s);
+    s = d - c < n - d - 1 ? d - c : n - d - 1;
+    sort_vector_swap(x, b, n - s, s);
+    if ((s = b - a) > 1) sort_quick(x, from, from + s);
+    if ((s = d - c) > 1) sort_quick(x, n - s, n);
+}
+int32_t orc_sort_positions_bigint(const int64_t* keys, int32_t n, int32_t* positions)
+{
+    if (n < 0 || (n > 0 && (!keys || !positions))) return fail(PA_ERR_INVALID_ARGUMENT, "orc_sort_positions_bigint: null argument");
+    sort_ctx c = {keys, positions};
+    sort_quick(&c, 0, n);
+    return 0;
+}
+
+/* orc_topn_double_desc_bigint_asc: TopNProcessor (…/operator/TopNProcessor.java:35-110) with one group: the `limit` first rows
+ * under (channel 0 DOUBLE DESC_NULLS_LAST, channel 1 BIGINT ASC_NULLS_LAST) -- Q3's ORDER BY revenue DESC, o_orderdate --, kept
+ * in a binary heap whose root is the WORST kept row: a new row enters only when it precedes the root (GroupedTopNBuilder's
+ * RowHeap discipline).  DOUBLE order is Double.compare.  out_positions: the kept rows, best first. */
+static inline int dbl_compare(double a, double b)   /* Double.compare: -0.0 < 0.0, NaN greatest and equal to itself */
+{
+    if (a < b) return -1;
+    if (a > b) return 1;
+    int64_t x, y;
+    memcpy(&x, &a, 8);
+    memcpy(&y, &b, 8);
+    if (a != a) x = 0x7ff8000000000000LL;
+    if (b != b) y = 0x7ff8000000000000LL;
+    return x == y ? 0 : (x < y ? -1 : 1);
+}
+typedef struct {
+    const double* v;
+    const int64_t* k;
+} topn_ctx;
+static inline int topn_cmp(const topn_ctx* c, int32_t i, int32_t j)   /* < 0: row i precedes row j in the output order */
+{
+    const int d = dbl_compare(c->v[i], c->v[j]);
+    if (d != 0) return -d;
+    return c->k[i] < c->k[j] ? -1 : (c->k[i] > c->k[j] ? 1 : 0);
+}
+static int topn_qsort_cmp_ctx_set;
+static const topn_ctx* topn_qsort_ctx;
+static int topn_qsort_cmp(const void* a, const void* b)
+{
+    const int c = topn_cmp(topn_qsort_ctx, *(const int32_t*)a, *(const int32_t*)b);
+    return c != 0 ? c : (*(const int32_t*)a < *(const int32_t*)b ? -1 : 1);
+}
+int32_t orc_topn_double_desc_bigint_asc(const double* values, const int64_t* keys, int64_t n, int32_t limit, int32_t* out_positions)
+{
+    if (limit < 0 || n < 0 || n > 0x7fffffffLL) return fail(PA_ERR_INVALID_ARGUMENT, "orc_topn: bad sizes");
+    if (limit == 0 || n == 0) return 0;
+    topn_ctx c = {values, keys};
+    int32_t* heap = (int32_t*)malloc(sizeof(int32_t) * (size_t)limit);
+    int32_t size = 0;
+    for (int32_t r = 0; r < (int32_t)n; r++) {
+        if (size < limit) {
+            int32_t i = size++;
+            heap[i] = r;
+            while (i > 0) {   /* sift up: a parent must not precede its children (max-heap on the output order) */
+                const int32_t p = (i - 1) / 2;
+                if (topn_cmp(&c, heap[p], heap[i]) >= 0) break;
+                const int32_t t = heap[p]; heap[p] = heap[i]; heap[i] = t;
+                i = p;
+            }
+        }
+        else if (topn_cmp(&c, r, heap[0]) < 0) {
+            heap[0] = r;
+            int32_t i = 0;
+            for (;;) {
+                int32_t l = 2 * i + 1, rr = l + 1, w = i;
+                if (l < size && topn_cmp(&c, heap[l], heap[w]) > 0) w = l;
+                if (rr < size && topn_cmp(&c, heap[rr], heap[w]) > 0) w = rr;
+                if (w == i) break;
+                const int32_t t = heap[w]; heap[w] = heap[i]; heap[i] = t;
+                i = w;
+            }
+        }
+    }
+    (void)topn_qsort_cmp_ctx_set;
+    topn_qsort_ctx = &c;
+    qsort(heap, (size_t)size, sizeof(int32_t), topn_qsort_cmp);
+    memcpy(out_positions, heap, sizeof(int32_t) * (size_t)size);
+    free(heap);
+    return size;
+}

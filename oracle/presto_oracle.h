@@ -97,6 +97,12 @@ int32_t orc_q1_add(orc_hash_agg* agg, const uint8_t* returnflag, const int32_t* 
                    const int32_t* ls_offsets, const double* quantity, const double* extendedprice, const double* discount,
                    const double* tax, const int32_t* shipdate, int64_t n);
 
+/* ---- OrderBy / TopN over flat columns, at a speed worth timing (bench.py's CPU twins; oracle.py's order_by / topn are the
+ *      parity checkers): PagesIndexOrdering.quickSort over row positions by one BIGINT key; TopNProcessor's bounded heap under
+ *      (DOUBLE DESC, BIGINT ASC).  orc_topn returns the number of rows kept. ---- */
+int32_t orc_sort_positions_bigint(const int64_t* keys, int32_t n, int32_t* positions);
+int32_t orc_topn_double_desc_bigint_asc(const double* values, const int64_t* keys, int64_t n, int32_t limit, int32_t* out_positions);
+
 #ifdef __cplusplus
 }
 #endif

@@ -41,3 +41,19 @@ def test_bench_one_rank_default_shape_small(gpu, oracle):
     check_q1_q6(line["results"], *oracle_q1_q6(oracle, sf, rows))
     assert "error" not in line["q3"] and line["q3"]["exchange"] == "none (one rank)"
     assert line["cpu_baseline"]["value"] > 0 and line["h2d"]["value"] > 0
+    assert line["cpu_baseline"]["cores"] == line["cpu_baseline"]["physical_cores"] >= 1 and line["cpu_baseline"]["runs"] >= 10
+    assert line["q3"]["cpu_baseline"]["value"] > 0
+    ops = line["operators"]
+    assert "error" not in ops, ops
+    assert [e["groups"] for e in ops["hash_agg"]] == [3_000_000, 4, 1000, 100_000, 3_000_000] and ops["hash_agg"][0]["rows"] == 10_000_000
+    for e in ops["hash_agg"]:
+        assert e["groups_out"] <= e["groups"] and e["value"] > 0 and 0 < e["frac"] < 1 and e["cpu"]["value"] > 0
+    assert len(ops["hash_join"]) == 8
+    for e in ops["hash_join"]:
+        assert e["build"]["value"] > 0 and e["probe"]["value"] > 0 and e["probe"]["cpu"]["value"] > 0
+    # the reference's probe pages: every row matches at rate 1 (x1 build rows), about a tenth at 0.1, five build rows per match at x5
+    by_case = {e["case"]: e for e in ops["hash_join"]}
+    assert by_case["8 M build rows x1, 1.4 M probe rows, match rate 1"]["probe"]["matches"] == 1_400_000
+    assert 120_000 < by_case["8 M build rows x1, 1.4 M probe rows, match rate 0.1"]["probe"]["matches"] < 160_000
+    assert 6_900_000 < by_case["8 M build rows x5, 1.4 M probe rows, match rate 1"]["probe"]["matches"] < 7_100_000
+    assert ops["order_by"]["value"] > 0 and ops["topn"]["value"] > 0 and ops["topn"]["cpu"]["value"] > 0

@@ -25,21 +25,7 @@ def host_table(oracle, columns, sf, n):
 
 
 def oracle_q3(oracle, customer, orders, lineitem):
-    c = oracle.filter_project(customer, tpch.q3_customer_filter(), [field(0, abi.BIGINT)])
-    j1 = oracle.HashJoin([abi.BIGINT], [0], [])
-    j1.add_build_page(c)
-    j1.build()
-    o = oracle.filter_project(orders, tpch.q3_orders_filter(), [field(i, t) for i, t in enumerate(tpch.ORDERS_TYPES)])
-    oc, _, _ = j1.probe(o, tpch.ORDERS_TYPES, [1], [0, 2, 3])
-    j2 = oracle.HashJoin([abi.BIGINT, abi.DATE, abi.INTEGER], [0], [1, 2])
-    j2.add_build_page(oc)
-    j2.build()
-    l = oracle.filter_project(lineitem, tpch.q3_lineitem_filter(), tpch.q3_lineitem_projections())
-    joined, _, _ = j2.probe(l, [abi.BIGINT, abi.DOUBLE], [0], [0, 1])
-    agg = oracle.HashAggregation([abi.BIGINT, abi.DOUBLE, abi.DATE, abi.INTEGER], [0, 2, 3], [(abi.AGG_SUM, 1, abi.DOUBLE), (abi.AGG_COUNT_STAR, -1, None)],
-                                 expected_groups=100000)
-    agg.add_page(joined)
-    return agg.build_result().to_rows(), oc.position_count, joined.position_count
+    return oracle.q3(customer, orders, lineitem)
 
 
 def _device_tables(sf):

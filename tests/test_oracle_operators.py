@@ -487,3 +487,30 @@ def test_tiny_q6_config_1_on_the_cpu_operators(oracle):
     # and against numpy over the whole table (independent of both)
     m = (cols[0] >= 8766) & (cols[0] < 9131) & (cols[1] >= 0.05) & (cols[1] <= 0.07) & (cols[2] < 24.0)
     assert int(m.sum()) == c and abs(float((cols[3][m] * cols[1][m]).sum()) - s) <= 1e-12 * s
+
+
+def test_c_sort_and_topn_twins_agree_with_the_python_restatements(oracle):
+    """The timing-grade C twins of OrderBy / TopN (bench.py's CPU legs) against the Python restatements that are the parity
+    checkers, and against numpy: PagesIndexOrdering.quickSort by one BIGINT key sorts and keeps every row once; TopNProcessor's
+    heap under (DOUBLE DESC, BIGINT ASC) keeps the same rows in the same order, ties on both channels included."""
+    import numpy as np
+    from presto_amd import abi
+    from presto_amd.page import Block, Page
+    rng = np.random.default_rng(12)
+    for n, hi in ((0, 5), (1, 5), (6, 3), (7, 3), (41, 10), (100_000, 1000), (100_000, 1 << 40)):
+        k = rng.integers(-hi, hi, n)
+        p = oracle.sort_positions_bigint(k)
+        assert np.array_equal(k[p], np.sort(k)) and np.array_equal(np.sort(p), np.arange(n))
+    k = np.arange(50_000)[::-1].copy()           # descending input, and all-equal keys
+    assert np.array_equal(oracle.sort_positions_bigint(k), np.arange(50_000)[::-1])
+    assert sorted(oracle.sort_positions_bigint(np.zeros(1000, np.int64)).tolist()) == list(range(1000))
+    v = rng.random(5000)
+    v[::7] = 0.5
+    v[3], v[4], v[5] = -0.0, 0.0, np.nan
+    kk = rng.integers(0, 50, 5000)
+    for limit in (1, 10, 100, 5000, 6000):
+        got = oracle.topn_positions_double_desc_bigint_asc(v, kk, limit)
+        ref = oracle.topn([Page([Block.double(v), Block.bigint(kk)], 5000)], limit, [0, 1], [abi.DESC_NULLS_LAST, abi.ASC_NULLS_LAST])
+        assert len(got) == min(limit, 5000)
+        for i, r in zip(got, ref):
+            assert (np.float64(v[i]).view(np.int64) == np.float64(r[0]).view(np.int64) or (np.isnan(v[i]) and np.isnan(r[0]))) and kk[i] == r[1]
