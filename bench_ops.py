@@ -7,7 +7,7 @@ kind) through the device operators, each with the oracle's twin of the same oper
   hash_join  HashBuilderOperator + LookupJoinOperator on one BIGINT key:
              8 M build rows (every key once / five times), 1.4 M probe rows at match rate 0.1 / 1 / 2
                                       core/trino-main/src/test/java/io/trino/operator/join/BenchmarkHashBuildAndJoinOperators.java:103-110,192-199,260-303
-             15 M unique random build keys, 2^26 random probe keys (half of them match); the same with x5 duplicate build keys
+             15 M unique random build keys, 2^26 random probe keys (one in eight matches); the same with about five build rows per key
   order_by   OrderByOperator, 2^24 rows x 16 B by one BIGINT key        topn   TopNOperator, 100 of 2^26 rows (DOUBLE desc, BIGINT)
 
 Device figures: W warm-ups + K measured runs, median and min of the wall time of a whole operator life (create, addInput of
@@ -193,10 +193,10 @@ def run(cpu=True):
     nb = 15_000_000
     unique = (torch.randperm(nb, device="cuda", generator=g).to(torch.int64) * 4).contiguous()
     pkeys = torch.randint(0, nb * 8, (1 << 26,), dtype=torch.int64, device="cuda", generator=g)
-    join_case("15 M unique random build keys, 2^26 random probe keys (50 % match)", unique, pkeys, None, 4_000_000)
+    join_case("15 M unique random build keys, 2^26 random probe keys (one in eight matches)", unique, pkeys, None, 4_000_000)
     dup = (torch.randint(0, nb // 5, (nb,), dtype=torch.int64, device="cuda", generator=g) * 4).contiguous()
     pkeys5 = torch.randint(0, nb // 5 * 8, (1 << 26,), dtype=torch.int64, device="cuda", generator=g)
-    join_case("15 M random build keys, about 5 rows per key, 2^26 random probe keys (50 % match, 5 matches each)", dup, pkeys5, None, 2_000_000)
+    join_case("15 M random build keys, about 5 rows per key, 2^26 random probe keys (one in eight matches, about 5 rows each)", dup, pkeys5, None, 2_000_000)
     del unique, dup, pkeys, pkeys5
 
     # ---- OrderBy / TopN ----

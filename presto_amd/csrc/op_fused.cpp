@@ -812,7 +812,9 @@ KernelInfo generate(const Spec& s, const std::vector<ChannelLayout>& layout, int
         // Hash-partitioning pass in front of the LDS-table variant at medium cardinality (hundreds to ~10^5 groups): it only
         // computes every row's partition = hash(key) mod P (P + 1 for rows the filter drops).  The rows are then taken in
         // partition order, a contiguous slice per workgroup, so that a workgroup's LDS table meets a few partitions' groups only.
-        src << "struct PaAcc { int unused; };\n";
+        // (round 3) ... and histograms every 8192-row tile on the way (the tiles of the multisplit behind it, scan_kernels.hpp): the
+        // multisplit's own counting pass read the ids a second time
+        src << "struct PaAcc { int unused; };\n__shared__ i32 pa_hist[4097];\n";
     }
     else if (brow) {
         // Build-row table.  Every scattered store / atomic INSTRUCTION of a wave costs the CU on the order of 100 ns whatever the
@@ -830,15 +832,21 @@ KernelInfo generate(const Spec& s, const std::vector<ChannelLayout>& layout, int
         src << "struct PaAcc { PaGtView tv; PaGtCtr gt; bool ev[4]; u32 eg[4];";
         for (int w = 0; w < k.nw; w++) src << " bool eu" << w << "[4]; " << wtype(w) << " ex" << w << "[4];";
         src << " };\n";
-        // ... and they do not go out at once: a wave whose tag store and atomics are in flight cannot see the data of ANY later
-        // load before they have retired (vmcnt counts in order), and under load that took ~8 us per quad (0.96 ms of the 1.95 ms a
-        // 2^28-row page cost).  The noted rows are appended to a buffer of the wave in LDS instead, and the buffer is drained when
-        // it is full -- one such wait per ~10 quads.
-        const int waves = 4;  // 256 threads
-        const int cap = 128;  // entries per wave
-        src << "#define PA_BCAP " << cap << "u\n";
-        src << "__shared__ u32 pa_sg[" << waves << "][PA_BCAP];\n__shared__ u32 pa_su[" << waves << "][PA_BCAP];\n__shared__ u64 pa_sx[" << waves
-            << "][PA_NW][PA_BCAP];\n__shared__ u32 pa_sfill[" << waves << "];\n";
+        // ... and they do not go out one by one (round 3).  Every wave walks ONE contiguous row range of the page, so when the probe
+        // side is clustered by the join key -- a fact table ordered by the key of its dimension, lineitem by orderkey -- the build
+        // positions a wave meets rise with its rows.  The wave keeps a WINDOW of PA_WIN consecutive build positions in LDS
+        // (accumulator words + one touched bit per position): a noted row inside the window is an LDS atomic (ds_add_f64 / ds_add_u64
+        // / ds_max_u64) -- no HBM traffic, no waiting --, a row beyond it first flushes the window and moves it there.  A flush
+        // hands the touched positions to the table 64 consecutive positions per instruction: the memory-side atomics of one
+        // instruction share a 64-byte request when their addresses are neighbours, so eight build rows go out per request where the
+        // sorted drains of round 2 (128 noted rows, bitonic sort, one atomic per distinct position) reached about two -- and the
+        // sort is gone.  Windows of different waves overlap only where their row ranges meet, and the flush is atomic, so nothing
+        // here depends on the clustering for correctness: rows in no particular order move the window at most PA_WIN_MOVES times
+        // per quad and then go to the table directly, one atomic each.
+        int win = 256;
+        while (win > 64 && (size_t)win * 8 * (size_t)k.nw * 4 > 48 * 1024) win >>= 1;
+        src << "#define PA_WIN " << win << "u\n#define PA_WIN_MOVES 2\n";
+        src << "__shared__ u64 pa_win[4][PA_NW][PA_WIN];\n__shared__ u64 pa_wtouch[4][PA_WIN / 64u];\n__shared__ u32 pa_sfill[4];\n__shared__ u32 pa_wbase[4];\n";
         src << "#define PA_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, \"wavefront\"); __builtin_amdgcn_wave_barrier(); "
                "__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, \"wavefront\"); } while (0)\n";
         // noting row `slot` of the quad (a literal at every call site: the arrays stay in registers)
@@ -856,79 +864,70 @@ KernelInfo generate(const Spec& s, const std::vector<ChannelLayout>& layout, int
             src << "    if (acc.eu" << w << "[p]) { " << X << " = acc.eu" << w << "[slot] ? " << comb << " : " << P << "; acc.eu" << w << "[slot] = true; }\n";
         }
         src << "    acc.ev[p] = false;\n  }\n}\n";
-        // the buffered rows of the wave -> table; the issuing lanes are the ACTIVE ones, by rank (lanes that have left the row
-        // loop contribute nothing and issue nothing)
-        // A drain goes out SORTED by build position, one entry per build row: the wave sorts (build position, entry) keys in LDS
-        // (bitonic, 28 steps for 128 keys), the first entry of every run of equal positions takes its followers' values along,
-        // and only those leaders touch the table.  Memory-side atomics of one instruction share 64-byte requests when their
-        // addresses are neighbours -- and never when two lanes name the same address (an order whose rows two lanes hold).
-        auto emit_issue = [&](const std::string& ind, const std::string& g, const std::string& f, const std::function<std::string(int)>& val) {
+        // one value for build position g -> table (the direct route, and the window's flush)
+        auto emit_issue = [&](const std::string& ind, const std::string& g, const std::function<std::string(int)>& cond, const std::function<std::string(int)>& val) {
             if (k.occ_word < 0) src << ind << "acc.tv.tag[" << g << "] = 3ULL;\n";
             for (int w = 0; w < k.nw; w++) {
-                const std::string W = std::to_string(w), idx = W + "ULL * cap + " + g, v = val(w);
-                src << ind << "if (" << f << " & " << (1u << w) << "u) ";
-                if (words[w].kind == W_SUMF) src << "pa_gt_add_f64(acc.tv.words, " << idx << ", __longlong_as_double((i64)" << v << ")" << (w == k.occ_word ? " + 0.0" : "") << ");\n";
-                else if (words[w].kind == W_SUMI) src << "pa_gt_add_i64_exact(acc.tv.words, " << idx << ", (i64)" << v << ", a.err);\n";
+                const std::string W = std::to_string(w), idx = W + "ULL * cap + " + g, v = val(w), c = cond(w);
+                src << ind << (c.empty() ? std::string() : "if (" + c + ") ");
+                if (words[w].kind == W_SUMF) src << "pa_gt_add_f64(acc.tv.words, " << idx << ", " << v << (w == k.occ_word ? " + 0.0" : "") << ");\n";
+                else if (words[w].kind == W_SUMI) src << "pa_gt_add_i64_exact(acc.tv.words, " << idx << ", " << v << ", a.err);\n";
                 else if (words[w].kind == W_MAXU) src << "pa_gt_max_u64(acc.tv.words, " << idx << ", " << v << ");\n";
-                else src << "pa_gt_add_u64(acc.tv.words, " << idx << ", " << v << ");\n";
+                else src << "pa_gt_add_u64(acc.tv.words, " << idx << ", (u64)" << v << ");\n";
             }
         };
-        src << "__shared__ u64 pa_sk[" << waves << "][PA_BCAP];\n";
-        src << "__device__ __forceinline__ void pa_drain(const PaFusedArgs& a, PaAcc& acc, const u32 fill)\n{\n"
-               "  const u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;\n"
+        // the window -> table: lane l takes positions base + 64 k + l; only touched positions issue (and are reset)
+        // (the issuing lanes are the ACTIVE ones, by rank: lanes that have left the row loop issue nothing, and the window is
+        // complete all the same)
+        src << "__device__ __forceinline__ void pa_window_flush(const PaFusedArgs& a, PaAcc& acc)\n{\n"
+               "  const u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;\n  const u64 cap = (u64)a.gt_mask + 1ULL;\n"
                "  const u64 act = __ballot(true);\n  const u32 nact = (u32)__popcll(act), rank = (u32)__popcll(act & ((1ULL << lane) - 1ULL));\n"
-               "  const u64 cap = (u64)a.gt_mask + 1ULL;\n"
-               "  if (fill == 0u) return;\n"
-               "  if (nact == 64u) {\n"
-               "    u64* sk = pa_sk[wave];\n"
-               "    for (u32 i = lane; i < PA_BCAP; i += 64u) sk[i] = i < fill ? (((u64)pa_sg[wave][i] << 32) | (u64)i) : ~0ULL;\n"
-               "    PA_WAVE_SYNC();\n"
-               "    for (u32 kk = 2u; kk <= PA_BCAP; kk <<= 1) {\n      for (u32 j = kk >> 1; j > 0u; j >>= 1) {\n"
-               "#pragma unroll\n        for (u32 h = 0; h < PA_BCAP / 64u; h++) {\n          const u32 i = lane + 64u * h, p = i ^ j;\n"
-               "          if (p > i) {\n            const u64 x = sk[i], y = sk[p];\n            if ((x > y) == ((i & kk) == 0u)) { sk[i] = y; sk[p] = x; }\n          }\n        }\n"
-               "        PA_WAVE_SYNC();\n      }\n    }\n"
-               "    for (u32 p = lane; p < fill; p += 64u) {\n      const u64 kx = sk[p];\n      const u32 gk = (u32)(kx >> 32);\n"
-               "      if (p > 0u && (u32)(sk[p - 1u] >> 32) == gk) continue;  // a follower: its leader takes it along\n"
-               "      u32 f = 0u;\n";
-        for (int w = 0; w < k.nw; w++) src << "      u64 v" << w << " = 0ULL;\n";
-        src << "      for (u32 q = p; q < fill; q++) {\n        const u64 kq = sk[q];\n        if ((u32)(kq >> 32) != gk) break;\n"
-               "        const u32 e = (u32)kq, fe = pa_su[wave][e];\n";
-        for (int w = 0; w < k.nw; w++) {
-            const std::string W = std::to_string(w), V = "v" + W, X = "pa_sx[wave][" + W + "][e]", bit = std::to_string(1u << w) + "u";
-            std::string comb;
-            if (words[w].kind == W_SUMF) comb = "(u64)__double_as_longlong(__longlong_as_double((i64)" + V + ") + __longlong_as_double((i64)" + X + "))";
-            else if (words[w].kind == W_SUMI) comb = "(u64)pa_add_exact((i64)" + V + ", (i64)" + X + ", a.err)";
-            else if (words[w].kind == W_MAXU) comb = "(" + X + " > " + V + " ? " + X + " : " + V + ")";
-            else comb = V + " + " + X;
-            src << "        if (fe & " << bit << ") " << V << " = (f & " << bit << ") ? " << comb << " : " << X << ";\n";
-        }
-        src << "        f |= fe;\n      }\n      const u64 g = (u64)gk;\n";
-        emit_issue("      ", "g", "f", [](int w) { return "v" + std::to_string(w); });
-        src << "    }\n    PA_WAVE_SYNC();\n    return;\n  }\n"
-               // (some lanes have left the row loop: the last wave of the grid) entry by entry, the issuing lanes by rank
-               "  for (u32 i = rank; i < fill; i += nact) {\n    const u64 g = pa_sg[wave][i];\n    const u32 f = pa_su[wave][i];\n";
-        emit_issue("    ", "g", "f", [](int w) { return "pa_sx[wave][" + std::to_string(w) + "][i]"; });
-        src << "  }\n  PA_WAVE_SYNC();\n}\n";
-        // end of a quad: the wave's noted rows are appended (positions by ballot, slot by slot), draining whenever the buffer is full
+               "  PA_WAVE_SYNC();\n"
+               "  const u32 wbase = pa_wbase[wave];  // (in LDS: a lane that was not active when the window moved must see where it is)\n"
+               "  for (u32 at = rank; at < PA_WIN; at += nact) {\n    const u64 touch = pa_wtouch[wave][at >> 6];\n"
+               "    if ((touch >> (at & 63u)) & 1ULL) {\n      const u64 g = (u64)wbase + at;\n";
+        emit_issue("      ", "g", [](int) { return std::string(); }, [&](int w) {
+            const std::string X = "pa_win[wave][" + std::to_string(w) + "][at]";
+            return words[w].kind == W_SUMF ? "__longlong_as_double((i64)" + X + ")" : (words[w].kind == W_MAXU ? X : "(i64)" + X);
+        });
+        for (int w = 0; w < k.nw; w++) src << "      pa_win[wave][" << w << "][at] = 0ULL;\n";
+        src << "    }\n  }\n  PA_WAVE_SYNC();\n  for (u32 i = rank; i < PA_WIN / 64u; i += nact) pa_wtouch[wave][i] = 0ULL;\n  PA_WAVE_SYNC();\n}\n";
+        src << "__device__ __forceinline__ void pa_drain(const PaFusedArgs& a, PaAcc& acc, const u32)\n{\n  pa_window_flush(a, acc);\n}\n";
+        // end of a quad: the wave's noted rows go into the window, which moves on when they lie beyond it
         src << "__device__ __forceinline__ void pa_flush(const PaFusedArgs& a, PaAcc& acc, const bool)\n{\n"
-               "  const u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;\n  const u64 below = (1ULL << lane) - 1ULL;\n"
-               "  u64 m[4];\n  u32 first[4], total = 0;\n"
-               "#pragma unroll\n  for (int e = 0; e < 4; e++) { m[e] = __ballot(acc.ev[e]); first[e] = total; total += (u32)__popcll(m[e]); }\n"
-               "  if (total == 0u) return;\n"
-               "  u32 fill = pa_sfill[wave];\n"
-               "  for (u32 base = 0; base < total;) {\n    const u32 room = PA_BCAP - fill, take = total - base < room ? total - base : room;\n"
-               "#pragma unroll\n    for (int e = 0; e < 4; e++) {\n      const u32 idx = first[e] + (u32)__popcll(m[e] & below) - base;\n"
-               "      if (acc.ev[e] && idx < take) {\n        const u32 at = fill + idx;\n        pa_sg[wave][at] = acc.eg[e];\n        u32 f = 0;\n";
+               "  const u32 wave = threadIdx.x >> 6;\n  const u64 cap = (u64)a.gt_mask + 1ULL;\n"
+               "  if (__ballot(acc.ev[0] || acc.ev[1] || acc.ev[2] || acc.ev[3]) == 0ULL) return;\n"
+               "  u32 wbase = pa_wbase[wave];\n"
+               "  for (int moves = 0;; moves++) {\n"
+               "#pragma unroll\n    for (int e = 0; e < 4; e++) {\n      const u32 at = acc.eg[e] - wbase;\n      if (acc.ev[e] && at < PA_WIN) {\n";
         for (int w = 0; w < k.nw; w++) {
-            const std::string W = std::to_string(w);
-            src << "        if (acc.eu" << W << "[e]) f |= " << (1u << w) << "u;\n        pa_sx[wave][" << W << "][at] = "
-                << (words[w].kind == W_SUMF ? "(u64)__double_as_longlong(acc.ex" + W + "[e])" : "(u64)acc.ex" + W + "[e]") << ";\n";
+            const std::string W = std::to_string(w), L = "pa_win[wave][" + W + "][at]", X = "acc.ex" + W + "[e]";
+            src << "        if (acc.eu" << W << "[e]) ";
+            if (words[w].kind == W_SUMF) src << "__hip_atomic_fetch_add((double*)&" << L << ", " << X << ", __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);\n";
+            else if (words[w].kind == W_SUMI) {
+                src << "{ const i64 o = (i64)__hip_atomic_fetch_add(&" << L << ", (u64)" << X << ", __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); i64 r; "
+                       "if (__builtin_add_overflow(o, " << X << ", &r)) pa_raise(a.err, PA_DEV_ERR_OUT_OF_RANGE); }\n";
+            }
+            else if (words[w].kind == W_MAXU) src << "__hip_atomic_fetch_max(&" << L << ", " << X << ", __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);\n";
+            else src << "__hip_atomic_fetch_add(&" << L << ", (u64)" << X << ", __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);\n";
         }
-        src << "        pa_su[wave][at] = f;\n      }\n    }\n"
-               "    fill += take;\n    base += take;\n    PA_WAVE_SYNC();\n"
-               "    if (fill == PA_BCAP) { pa_drain(a, acc, fill); fill = 0u; }\n  }\n"
-               "  pa_sfill[wave] = fill;\n  PA_WAVE_SYNC();\n"
-               "#pragma unroll\n  for (int e = 0; e < 4; e++) acc.ev[e] = false;\n}\n\n";
+        src << "        __hip_atomic_fetch_or(&pa_wtouch[wave][at >> 6], 1ULL << (at & 63u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);\n"
+               "        acc.ev[e] = false;\n      }\n    }\n"
+               "    const bool left = acc.ev[0] || acc.ev[1] || acc.ev[2] || acc.ev[3];\n"
+               "    if (__ballot(left) == 0ULL) break;\n"
+               "    if (moves >= PA_WIN_MOVES) {\n"
+               // rows in no particular order: the rest of the quad goes to the table directly
+               "#pragma unroll\n      for (int e = 0; e < 4; e++) {\n        if (!acc.ev[e]) continue;\n        const u64 g = (u64)acc.eg[e];\n";
+        emit_issue("        ", "g", [](int w) { return "acc.eu" + std::to_string(w) + "[e]"; }, [&](int w) { return "acc.ex" + std::to_string(w) + "[e]"; });
+        src << "        acc.ev[e] = false;\n      }\n      break;\n    }\n"
+               // the window moves to the smallest position still waiting (down to a 64-byte line of the table's word arrays)
+               // (through LDS: a shuffle would read the registers of lanes that have left the loop)
+               "    u32 gmin = 0xffffffffu;\n"
+               "#pragma unroll\n    for (int e = 0; e < 4; e++) { if (acc.ev[e] && acc.eg[e] < gmin) gmin = acc.eg[e]; }\n"
+               "    pa_sfill[wave] = 0xffffffffu;\n    PA_WAVE_SYNC();\n"
+               "    if (left) __hip_atomic_fetch_min(&pa_sfill[wave], gmin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);\n"
+               "    PA_WAVE_SYNC();\n    gmin = pa_sfill[wave];\n"
+               "    pa_window_flush(a, acc);\n    wbase = gmin & ~7u;\n    pa_wbase[wave] = wbase;\n    PA_WAVE_SYNC();\n  }\n}\n\n";
     }
     else {
         // pending run of the thread: consecutive selected rows with equal keys are combined before they touch the table
@@ -1100,7 +1099,8 @@ KernelInfo generate(const Spec& s, const std::vector<ChannelLayout>& layout, int
     }
     src << "}\n";
     if (variant == V_HASH) {
-        src << "if (live) a.part_ids[row] = sel ? (i32)(pa_key_hash(key, PA_KW) & a.part_mask) : (i32)(a.part_mask + 1u);\n";
+        src << "if (live) { const i32 pid = sel ? (i32)(pa_key_hash(key, PA_KW) & a.part_mask) : (i32)(a.part_mask + 1u); a.part_ids[row] = pid; "
+               "__hip_atomic_fetch_add(&pa_hist[pid], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }\n";
     }
     else if (variant == V_GLOBAL) {
         src << "if (sel) {\n";
@@ -1235,6 +1235,9 @@ KernelInfo generate(const Spec& s, const std::vector<ChannelLayout>& layout, int
         else if (brow) {
             src << "    PaAcc acc; acc.tv = pa_gt_view(a, PA_KW, PA_NW); acc.gt = pa_gt_ctr_init(acc.tv.count, true, a.gt_rep_mask + 1u);\n"
                    "#pragma unroll\n    for (int e = 0; e < 4; e++) acc.ev[e] = false;\n"
+                   "    if ((threadIdx.x & 63u) == 0u) pa_wbase[threadIdx.x >> 6] = 0u;\n"
+                   "    for (u32 i = threadIdx.x & 63u; i < PA_NW * PA_WIN; i += 64u) (&pa_win[threadIdx.x >> 6][0][0])[i] = 0ULL;\n"
+                   "    if ((threadIdx.x & 63u) < PA_WIN / 64u) pa_wtouch[threadIdx.x >> 6][threadIdx.x & 63u] = 0ULL;\n"
                    "    if ((threadIdx.x & 63u) == 0u) pa_sfill[threadIdx.x >> 6] = 0u;\n    PA_WAVE_SYNC();\n";
         }
         else {
@@ -1264,6 +1267,23 @@ KernelInfo generate(const Spec& s, const std::vector<ChannelLayout>& layout, int
         else if (mode == 2) {
             src << "    for (i64 rb = (i64)blockIdx.x * 64; rb < a.n; rb += T) {\n        const bool live = rb + threadIdx.x < a.n;\n"
                    "        const i64 r = live ? rb + threadIdx.x : a.n - 1;\n        pa_row(a, acc, live, (i32)r" << scalar_args(ri, layout) << ");\n    }\n";
+        }
+        else if (variant == V_HASH) {
+            // tile by tile (a.sub_count: the tile x partition counts of the multisplit, tile-major)
+            src << "    const i64 nq = a.vec ? (a.n >> 2) : 0;\n    const i64 tiles = (a.n + " << (kMsplitTileRows - 1) << ") / " << kMsplitTileRows << ";\n"
+                   "    const i32 hp = (i32)a.part_mask + 2;\n"
+                   "    for (i64 tile = blockIdx.x; tile < tiles; tile += gridDim.x) {\n"
+                   "      for (i32 i = threadIdx.x; i < hp; i += " << B << ") pa_hist[i] = 0;\n      __syncthreads();\n"
+                   "      const i64 r0 = tile * " << kMsplitTileRows << ", r1 = r0 + " << kMsplitTileRows << " < a.n ? r0 + " << kMsplitTileRows << " : a.n;\n"
+                   "      const i64 q1 = (r1 >> 2) < nq ? (r1 >> 2) : nq;\n"
+                   "      for (i64 q = (r0 >> 2) + threadIdx.x; q < q1; q += " << B << ") {\n";
+            emit_vector_loads(ri, layout, src, args);
+            emit_quad(args);
+            src << "      }\n"
+                   "      for (i64 r = ((q1 << 2) > r0 ? (q1 << 2) : r0) + threadIdx.x; r < r1; r += " << B << ") {\n        pa_row(a, acc, true, (i32)r" << scalar_args(ri, layout) << ");\n      }\n"
+                   "      __syncthreads();\n"
+                   "      for (i32 i = threadIdx.x; i < hp; i += " << B << ") a.sub_count[tile * hp + i] = pa_hist[i];\n      __syncthreads();\n"
+                   "    }\n";
         }
         else {
             src << "    const i64 nq = a.vec ? (a.n >> 2) : 0;\n";
@@ -2304,8 +2324,11 @@ private:
             a.err = ctl_;
             a.part_ids = static_cast<int32_t*>(part_ids_.ensure((size_t)n * 4));
             a.part_mask = (uint32_t)partitions - 1;
+            // the partition pass leaves the multisplit's tile x partition counts behind (tile-major, in the multisplit's scratch)
+            void* ms_temp = part_temp_.ensure(std::max(msplit_temp_bytes(n, partitions + 1), partition_temp_bytes(n, partitions + 1)));
+            a.sub_count = msplit_counts(ms_temp);
             void* params[] = {&a};
-            const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(((n + 3) / 4 + 255) / 256, (int64_t)cus_ * 8));
+            const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(msplit_tiles(n), (int64_t)cus_ * 8));
             timer.begin(s);
             PA_HIP(hipModuleLaunchKernel(hk.kernel.fn, grid, 1, 1, hk.info.block, 1, 1, 0, s, params, nullptr));
             int64_t* counts = static_cast<int64_t*>(part_counts_.ensure((size_t)(partitions + 1) * 8));
@@ -2337,8 +2360,7 @@ private:
                 }
                 reorder = mc.size() <= (size_t)kMsplitMaxCols;
                 if (reorder) {
-                    launch_msplit(a.part_ids, n, partitions + 1, mc.data(), (int32_t)mc.size(), counts,
-                                  part_temp_.ensure(msplit_temp_bytes(n, partitions + 1)), s);
+                    launch_msplit(a.part_ids, n, partitions + 1, mc.data(), (int32_t)mc.size(), counts, ms_temp, s, false, true);
                     if (ldsp) {
                         // the kernel finds its rows through the partition boundaries on the device: the host does not need them
                         launch_exclusive_prefix_i64(counts, partitions + 1, static_cast<int64_t*>(part_first_.ensure((size_t)(partitions + 2) * 8)), s);
@@ -2359,7 +2381,7 @@ private:
                 }
             }
             int32_t* positions = static_cast<int32_t*>(part_pos_.ensure((size_t)n * 4));
-            launch_partition_positions(a.part_ids, n, partitions + 1, positions, counts, part_temp_.ensure(partition_temp_bytes(n, partitions + 1)), s);
+            launch_partition_positions(a.part_ids, n, partitions + 1, positions, counts, ms_temp, s);
             timer.end(s, false);
             int64_t dropped = 0;
             PA_HIP(hipMemcpyAsync(&dropped, counts + partitions, 8, hipMemcpyDeviceToHost, s));

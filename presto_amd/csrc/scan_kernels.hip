@@ -411,48 +411,75 @@ struct MsplitArgs {
 };
 
 constexpr int kMsMaxParts = 4096;  // unstable form; the stable form takes 256
-template <int ITEMS, int MAXP>
-__global__ __launch_bounds__(kMsThreads) void k_msplit_count(const i32* __restrict__ part, i64 n, i32 P, i64 tiles, i32* __restrict__ counts)
+
+// ---- the unstable form (round 3) ---------------------------------------------------------------------------------------------
+// Counts are TILE-major (counts[tile][partition]): a tile's workgroup writes and later reads its P values as one coalesced run --
+// with the partition-major layout every (tile, partition) count was a 64-byte line request of its own, as many requests per tile
+// as the tile's data (2049 partitions: 4098 strided loads per scatter tile next to 2560 data lines).  The offsets are the
+// column-wise exclusive scan of that matrix plus the partitions' bases: three small kernels, coalesced across the partitions.
+// The scatter ranks a tile's rows with returning LDS atomics on its own histogram (so it needs no counts, only where each
+// partition's run of this tile starts) and has the ids and the first columns in registers before the first barrier: one HBM round
+// trip per tile instead of one per column.
+template <int MAXP>
+__global__ __launch_bounds__(kMsThreads) void k_msplit_count_tm(const i32* __restrict__ part, i64 n, i32 P, i32* __restrict__ counts)
 {
-    static_assert(ITEMS == kMsItems, "tile = kMsTile rows");
     __shared__ i32 hist[MAXP + 1];
     for (int i = threadIdx.x; i < P; i += kMsThreads) hist[i] = 0;
     __syncthreads();
     const i64 tile0 = (i64)blockIdx.x * kMsTile;
+    i32 pid[kMsItems];
 #pragma unroll
     for (int i = 0; i < kMsItems; i++) {
         const i64 row = tile0 + (i64)i * kMsThreads + threadIdx.x;
-        if (row < n) atomicAdd(&hist[part[row]], 1);
+        pid[i] = row < n ? part[row] : -1;
+    }
+#pragma unroll
+    for (int i = 0; i < kMsItems; i++) {
+        if (pid[i] >= 0) atomicAdd(&hist[pid[i]], 1);
     }
     __syncthreads();
-    for (int p = threadIdx.x; p < P; p += kMsThreads) counts[(i64)p * tiles + blockIdx.x] = hist[p];
+    for (int p = threadIdx.x; p < P; p += kMsThreads) counts[(i64)blockIdx.x * P + p] = hist[p];
 }
 
-template <int ITEMS, int MAXP>
-__global__ __launch_bounds__(kMsThreads) void k_msplit_scatter(MsplitArgs a)
+constexpr int kMsChunkTiles = 64;  // tiles per chunk of the column-wise scan
+// per (chunk of tiles, partition): the rows of the chunk's tiles
+__global__ __launch_bounds__(256) void k_msplit_chunk_sums(const i32* __restrict__ counts, i64 tiles, i32 P, i32* __restrict__ chunk_sums)
 {
-    static_assert(ITEMS == kMsItems, "tile = kMsTile rows");
-    __shared__ i32 goff[MAXP + 1], lstart[MAXP + 1], cursor[MAXP + 1];
+    const i32 p = (i32)(blockIdx.x * 256 + threadIdx.x);
+    if (p >= P) return;
+    const i64 t0 = (i64)blockIdx.y * kMsChunkTiles, t1 = t0 + kMsChunkTiles < tiles ? t0 + kMsChunkTiles : tiles;
+    i32 sum = 0;
+    for (i64 t = t0; t < t1; t++) sum += counts[t * P + p];
+    chunk_sums[(i64)blockIdx.y * P + p] = sum;
+}
+// per partition: the exclusive scan over the chunks (in place) and the partition's total
+__global__ __launch_bounds__(256) void k_msplit_chunk_scan(i32* __restrict__ chunk_sums, i64 chunks, i32 P, i32* __restrict__ totals, i64* __restrict__ out_counts)
+{
+    const i32 p = (i32)(blockIdx.x * 256 + threadIdx.x);
+    if (p >= P) return;
+    i32 run = 0;
+#pragma unroll 8
+    for (i64 c = 0; c < chunks; c++) {
+        const i32 v = chunk_sums[c * P + p];
+        chunk_sums[c * P + p] = run;
+        run += v;
+    }
+    totals[p] = run;
+    if (out_counts) out_counts[p] = run;
+}
+// one workgroup: exclusive scan of the partitions' totals -> where each partition starts in the output
+__global__ __launch_bounds__(kMsThreads) void k_msplit_part_base(const i32* __restrict__ totals, i32 P, i32* __restrict__ base)
+{
     __shared__ i32 wave_sums[16];
-    __shared__ unsigned short lpart[kMsTile];
-    __shared__ u64 buf[kMsTile];
-    const i64 tile0 = (i64)blockIdx.x * kMsTile;
-    const i32 tile_rows = (i32)(a.n - tile0 < (i64)kMsTile ? a.n - tile0 : (i64)kMsTile);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    // the tile's rows per partition (from the scanned counts) and where each partition starts, globally and inside the tile;
-    // a thread owns PER consecutive partitions (up to 4 x 1024 threads = 4096 partitions)
-    const int PER = (a.P + kMsThreads - 1) / kMsThreads;
-    i32 cnt[4] = {0, 0, 0, 0};
+    const int PER = (P + kMsThreads - 1) / kMsThreads;
+    i32 t[4] = {0, 0, 0, 0};
     i32 mine = 0;
     for (int j = 0; j < PER; j++) {
         const i32 p = (i32)threadIdx.x * PER + j;
-        if (p < a.P) {
-            const i64 idx = (i64)p * a.tiles + blockIdx.x;
-            const i32 o = a.offsets[idx];
-            const i32 nx = idx + 1 < (i64)a.P * a.tiles ? a.offsets[idx + 1] : (i32)a.n;
-            goff[p] = o;
-            cnt[j] = nx - o;
-            mine += nx - o;
+        if (p < P) {
+            t[j] = totals[p];
+            mine += t[j];
         }
     }
     i32 inc = mine;
@@ -463,38 +490,138 @@ __global__ __launch_bounds__(kMsThreads) void k_msplit_scatter(MsplitArgs a)
     }
     if (lane == 63) wave_sums[wave] = inc;
     __syncthreads();
-    i32 base = 0;
-    for (int w = 0; w < wave; w++) base += wave_sums[w];
-    i32 run = base + inc - mine;
+    i32 run = inc - mine;
+    for (int w = 0; w < wave; w++) run += wave_sums[w];
+    for (int j = 0; j < PER; j++) {
+        const i32 p = (i32)threadIdx.x * PER + j;
+        if (p < P) {
+            base[p] = run;
+            run += t[j];
+        }
+    }
+}
+// counts[tile][p] -> where the tile's rows of partition p start in the output
+__global__ __launch_bounds__(256) void k_msplit_offsets(i32* __restrict__ counts, i64 tiles, i32 P, const i32* __restrict__ chunk_base, const i32* __restrict__ base)
+{
+    const i32 p = (i32)(blockIdx.x * 256 + threadIdx.x);
+    if (p >= P) return;
+    const i64 t0 = (i64)blockIdx.y * kMsChunkTiles, t1 = t0 + kMsChunkTiles < tiles ? t0 + kMsChunkTiles : tiles;
+    i32 run = base[p] + chunk_base[(i64)blockIdx.y * P + p];
+#pragma unroll 8
+    for (i64 t = t0; t < t1; t++) {
+        const i32 v = counts[t * P + p];
+        counts[t * P + p] = run;
+        run += v;
+    }
+}
+
+constexpr int kMsRegCols = 3;  // columns whose tile values are loaded before the first barrier
+template <int MAXP>
+__global__ __launch_bounds__(kMsThreads) void k_msplit_scatter_tm(MsplitArgs a)
+{
+    __shared__ i32 goff[MAXP + 1], lstart[MAXP + 1];
+    __shared__ i32 wave_sums[16];
+    __shared__ unsigned short lpart[kMsTile];
+    __shared__ u64 buf[kMsTile];
+    // Consecutive workgroup ids go round-robin to the 8 XCDs: give the workgroups of one XCD CONSECUTIVE tiles.  The runs two
+    // neighbouring tiles write for a partition are neighbours in the output (a run of a 2048-way split is ~4 rows, half a 64-byte
+    // line): tiles in flight on one XCD then complete each other's lines in that XCD's L2 before they are written back.
+    const i64 tile = (gridDim.x & 7u) == 0u ? (i64)(blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3) : (i64)blockIdx.x;
+    const i64 tile0 = tile * kMsTile;
+    const i32 tile_rows = (i32)(a.n - tile0 < (i64)kMsTile ? a.n - tile0 : (i64)kMsTile);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // everything the tile reads from HBM, issued together: the ids, the first columns, the tile's offsets
+    i32 pid[kMsItems];
+    u64 val[kMsRegCols][kMsItems];
+#pragma unroll
+    for (int i = 0; i < kMsItems; i++) {
+        const i64 row = tile0 + (i64)i * kMsThreads + threadIdx.x;
+        pid[i] = row < a.n ? a.part[row] : -1;
+    }
+#pragma unroll
+    for (int c = 0; c < kMsRegCols; c++) {
+        if (c < a.ncols) {
+            const MsplitCol col = a.col[c];
+#pragma unroll
+            for (int i = 0; i < kMsItems; i++) {
+                const i64 row = tile0 + (i64)i * kMsThreads + threadIdx.x;
+                u64 v = 0;
+                if (row < a.n) {
+                    if (col.width == 8) v = ((const u64*)col.in)[row];
+                    else if (col.width == 4) v = ((const u32*)col.in)[row];
+                    else v = ((const u8*)col.in)[row];
+                }
+                val[c][i] = v;
+            }
+        }
+    }
+    for (int p = threadIdx.x; p < a.P; p += kMsThreads) {
+        goff[p] = a.offsets[tile * a.P + p];
+        lstart[p] = 0;
+    }
+    __syncthreads();
+    // rank of every row inside its (tile, partition); lstart counts meanwhile
+    unsigned short li[kMsItems];
+#pragma unroll
+    for (int i = 0; i < kMsItems; i++) li[i] = pid[i] >= 0 ? (unsigned short)atomicAdd(&lstart[pid[i]], 1) : (unsigned short)0;
+    __syncthreads();
+    // counts -> where each partition starts inside the tile-sorted order; a thread owns PER consecutive partitions
+    const int PER = (a.P + kMsThreads - 1) / kMsThreads;
+    i32 cnt[4] = {0, 0, 0, 0};
+    i32 mine = 0;
+    for (int j = 0; j < PER; j++) {
+        const i32 p = (i32)threadIdx.x * PER + j;
+        if (p < a.P) {
+            cnt[j] = lstart[p];
+            mine += cnt[j];
+        }
+    }
+    i32 inc = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const i32 o = __shfl_up(inc, off, 64);
+        if (lane >= off) inc += o;
+    }
+    if (lane == 63) wave_sums[wave] = inc;
+    __syncthreads();
+    i32 run = inc - mine;
+    for (int w = 0; w < wave; w++) run += wave_sums[w];
     for (int j = 0; j < PER; j++) {
         const i32 p = (i32)threadIdx.x * PER + j;
         if (p < a.P) {
             lstart[p] = run;
-            cursor[p] = 0;
             run += cnt[j];
         }
     }
     __syncthreads();
-    // every row's place in the tile's partition-sorted order
-    unsigned short li[kMsItems];
 #pragma unroll
     for (int i = 0; i < kMsItems; i++) {
-        const i64 row = tile0 + (i64)i * kMsThreads + threadIdx.x;
-        li[i] = 0;
-        if (row < a.n) {
-            const i32 p = a.part[row];
-            const i32 at = lstart[p] + atomicAdd(&cursor[p], 1);
-            li[i] = (unsigned short)at;
-            lpart[at] = (unsigned short)p;
+        if (pid[i] >= 0) {
+            li[i] = (unsigned short)(lstart[pid[i]] + li[i]);
+            lpart[li[i]] = (unsigned short)pid[i];
         }
     }
     __syncthreads();
     for (int c = 0; c < a.ncols; c++) {
         const MsplitCol col = a.col[c];
+        if (c < kMsRegCols) {
 #pragma unroll
-        for (int i = 0; i < kMsItems; i++) {
-            const i64 row = tile0 + (i64)i * kMsThreads + threadIdx.x;
-            if (row < a.n) {
+            for (int i = 0; i < kMsItems; i++) {
+                if (pid[i] < 0) continue;
+                // (c < kMsRegCols is uniform: the compiler keeps val in registers only when the index is a literal)
+                u64 v = 0;
+#pragma unroll
+                for (int cc = 0; cc < kMsRegCols; cc++) v = cc == c ? val[cc][i] : v;
+                if (col.width == 8) buf[li[i]] = v;
+                else if (col.width == 4) ((u32*)buf)[li[i]] = (u32)v;
+                else ((u8*)buf)[li[i]] = (u8)v;
+            }
+        }
+        else {
+#pragma unroll
+            for (int i = 0; i < kMsItems; i++) {
+                const i64 row = tile0 + (i64)i * kMsThreads + threadIdx.x;
+                if (pid[i] < 0) continue;
                 if (col.width == 8) buf[li[i]] = ((const u64*)col.in)[row];
                 else if (col.width == 4) ((u32*)buf)[li[i]] = ((const u32*)col.in)[row];
                 else ((u8*)buf)[li[i]] = ((const u8*)col.in)[row];
@@ -510,6 +637,22 @@ __global__ __launch_bounds__(kMsThreads) void k_msplit_scatter(MsplitArgs a)
         }
         __syncthreads();
     }
+}
+
+// partition-major counts of the stable form (at most 256 partitions)
+__global__ __launch_bounds__(kMsThreads) void k_msplit_count_pm(const i32* __restrict__ part, i64 n, i32 P, i64 tiles, i32* __restrict__ counts)
+{
+    __shared__ i32 hist[256];
+    if (threadIdx.x < 256) hist[threadIdx.x] = 0;
+    __syncthreads();
+    const i64 tile0 = (i64)blockIdx.x * kMsTile;
+#pragma unroll
+    for (int i = 0; i < kMsItems; i++) {
+        const i64 row = tile0 + (i64)i * kMsThreads + threadIdx.x;
+        if (row < n) atomicAdd(&hist[part[row]], 1);
+    }
+    __syncthreads();
+    for (int p = threadIdx.x; p < P; p += kMsThreads) counts[(i64)p * tiles + blockIdx.x] = hist[p];
 }
 
 // The stable form (at most 256 partitions): a row's place inside its (tile, partition) is the number of earlier rows of the tile
@@ -612,27 +755,25 @@ __global__ __launch_bounds__(kMsThreads) void k_msplit_scatter_stable(MsplitArgs
 size_t msplit_temp_bytes(int64_t n, int32_t partition_count)
 {
     const int64_t tiles = (n + kMsTile - 1) / kMsTile;
-    return (size_t)(tiles * partition_count) * 4 + scan_temp_bytes(tiles * partition_count) + 64;
+    const int64_t chunks = (tiles + kMsChunkTiles - 1) / kMsChunkTiles;
+    // (the stable form scans the whole matrix; the unstable one keeps per-chunk sums behind it)
+    return (size_t)(tiles * partition_count) * 4 + std::max(scan_temp_bytes(tiles * partition_count), (size_t)((chunks + 2) * partition_count) * 4) + 64;
 }
+int64_t msplit_tiles(int64_t n) { return (n + kMsTile - 1) / kMsTile; }
+int32_t* msplit_counts(void* temp) { return static_cast<i32*>(temp); }
 
 void launch_msplit(const int32_t* partition, int64_t n, int32_t partition_count, const MsplitCol* cols, int32_t ncols, int64_t* out_counts_dev,
-                   void* temp, hipStream_t s, bool stable)
+                   void* temp, hipStream_t s, bool stable, bool counts_ready)
 {
     PA_REQUIRE(partition_count >= 1 && partition_count <= (stable ? 256 : kMsMaxParts), PA_ERR_NOT_SUPPORTED, "1..4096 partitions (stable: 1..256)");
     PA_REQUIRE(ncols >= 0 && ncols <= kMsplitMaxCols, PA_ERR_NOT_SUPPORTED, "too many columns for one multisplit");
+    PA_REQUIRE(!(stable && counts_ready), PA_ERR_INVALID_ARGUMENT, "internal: precomputed counts are tile-major, the stable form's are not");
     if (n <= 0) {
         PA_HIP(hipMemsetAsync(out_counts_dev, 0, (size_t)partition_count * 8, s));
         return;
     }
-    // Up to 1024 partitions the per-partition LDS arrays are a quarter the size (3 M groups / 64 M rows through the partition-owned
-    // tables: 23.8 -> 25.4 G rows/s).  Measured and dropped: tiles of 4 rows per thread, three workgroups to a CU instead of one but
-    // runs half as long per partition -- 24.6 G.
     const int64_t tiles = (n + kMsTile - 1) / kMsTile;
     i32* counts = static_cast<i32*>(temp);
-    void* scan_temp = counts + tiles * partition_count;
-    if (partition_count > 1024) hipLaunchKernelGGL((k_msplit_count<kMsItems, kMsMaxParts>), (int)tiles, kMsThreads, 0, s, partition, (i64)n, partition_count, (i64)tiles, counts);
-    else hipLaunchKernelGGL((k_msplit_count<kMsItems, 1024>), (int)tiles, kMsThreads, 0, s, partition, (i64)n, partition_count, (i64)tiles, counts);
-    launch_exclusive_scan_i32(counts, counts, tiles * partition_count, nullptr, scan_temp, s);
     MsplitArgs a;
     memset(&a, 0, sizeof a);
     a.part = partition;
@@ -645,10 +786,32 @@ void launch_msplit(const int32_t* partition, int64_t n, int32_t partition_count,
         PA_REQUIRE(cols[c].width == 1 || cols[c].width == 4 || cols[c].width == 8, PA_ERR_NOT_SUPPORTED, "multisplit moves 1, 4 or 8 byte elements");
         a.col[c] = cols[c];
     }
-    if (stable) hipLaunchKernelGGL(k_msplit_scatter_stable, (int)tiles, kMsThreads, 0, s, a);
-    else if (partition_count > 1024) hipLaunchKernelGGL((k_msplit_scatter<kMsItems, kMsMaxParts>), (int)tiles, kMsThreads, 0, s, a);
-    else hipLaunchKernelGGL((k_msplit_scatter<kMsItems, 1024>), (int)tiles, kMsThreads, 0, s, a);
-    hipLaunchKernelGGL(k_partition_totals, 1, 1024, 0, s, (const i32*)counts, (i64)tiles, partition_count, (i64)n, (i64*)out_counts_dev);
+    if (stable) {
+        void* scan_temp = counts + tiles * partition_count;
+        hipLaunchKernelGGL(k_msplit_count_pm, (int)tiles, kMsThreads, 0, s, partition, (i64)n, partition_count, (i64)tiles, counts);
+        launch_exclusive_scan_i32(counts, counts, tiles * partition_count, nullptr, scan_temp, s);
+        hipLaunchKernelGGL(k_msplit_scatter_stable, (int)tiles, kMsThreads, 0, s, a);
+        hipLaunchKernelGGL(k_partition_totals, 1, 1024, 0, s, (const i32*)counts, (i64)tiles, partition_count, (i64)n, (i64*)out_counts_dev);
+        PA_HIP(hipGetLastError());
+        return;
+    }
+    // Up to 1024 partitions the per-partition LDS arrays are a quarter the size
+    const bool big = partition_count > 1024;
+    if (!counts_ready) {
+        if (big) hipLaunchKernelGGL((k_msplit_count_tm<kMsMaxParts>), (int)tiles, kMsThreads, 0, s, partition, (i64)n, partition_count, counts);
+        else hipLaunchKernelGGL((k_msplit_count_tm<1024>), (int)tiles, kMsThreads, 0, s, partition, (i64)n, partition_count, counts);
+    }
+    const int64_t chunks = (tiles + kMsChunkTiles - 1) / kMsChunkTiles;
+    i32* chunk_sums = counts + tiles * partition_count;
+    const dim3 grid((unsigned)((partition_count + 255) / 256), (unsigned)chunks);
+    hipLaunchKernelGGL(k_msplit_chunk_sums, grid, 256, 0, s, (const i32*)counts, (i64)tiles, partition_count, chunk_sums);
+    i32* totals = chunk_sums + chunks * partition_count;
+    i32* base = totals + partition_count;
+    hipLaunchKernelGGL(k_msplit_chunk_scan, (partition_count + 255) / 256, 256, 0, s, chunk_sums, (i64)chunks, partition_count, totals, (i64*)out_counts_dev);
+    hipLaunchKernelGGL(k_msplit_part_base, 1, kMsThreads, 0, s, (const i32*)totals, partition_count, base);
+    hipLaunchKernelGGL(k_msplit_offsets, grid, 256, 0, s, counts, (i64)tiles, partition_count, (const i32*)chunk_sums, (const i32*)base);
+    if (big) hipLaunchKernelGGL((k_msplit_scatter_tm<kMsMaxParts>), (int)tiles, kMsThreads, 0, s, a);
+    else hipLaunchKernelGGL((k_msplit_scatter_tm<1024>), (int)tiles, kMsThreads, 0, s, a);
     PA_HIP(hipGetLastError());
 }
 

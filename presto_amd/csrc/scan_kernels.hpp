@@ -43,8 +43,14 @@ struct MsplitCol {
 };
 size_t msplit_temp_bytes(int64_t n, int32_t partition_count);
 // stable = ascending row order inside every partition (at most 256 partitions)
+// counts_ready (unstable form only): the tile x partition counts are already in `temp` -- msplit_counts(temp)[tile * P + p] for the
+// msplit_tiles(n) tiles of 8192 consecutive rows -- written by whoever made the partition ids (the generated partition pass of
+// the fused aggregation histograms its tiles while it writes the ids), so the ids are not read a second time
 void launch_msplit(const int32_t* partition, int64_t n, int32_t partition_count, const MsplitCol* cols, int32_t ncols, int64_t* out_counts_dev,
-                   void* temp, hipStream_t s, bool stable = false);
+                   void* temp, hipStream_t s, bool stable = false, bool counts_ready = false);
+int64_t msplit_tiles(int64_t n);
+int32_t* msplit_counts(void* temp);
+constexpr int kMsplitTileRows = 8192;
 // One STABLE 8-bit LSD radix pass over (key, payload) pairs held as two columns: the pairs regrouped by digit =
 // (key >> shift) & 255, arrival order kept inside a digit.  Same LDS-staged structure as the multisplit (8192-row tiles,
 // coalesced reads and writes); the rank of a row inside its (tile, digit) is the number of earlier rows of the tile with the
