@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PA_ABI_VERSION 7
+#define PA_ABI_VERSION 8
 
 /* ---- status codes (negative = error).  Mapped by the JNI shim onto TrinoException
  *      StandardErrorCode (trino-spi/.../StandardErrorCode.java). ---- */
@@ -58,7 +58,23 @@ typedef enum pa_type {
                       * group / join / sort / partition keys with RealType's operators (hash of floatToIntBits with +0 for both zeros,
                       * == for joins, IS NOT DISTINCT for groups, Float.compare order; RealType.java:101-160).  Not a dynamic-filter
                       * channel and not an aggregate input in PA_STATES_REFERENCE (PA_ERR_NOT_SUPPORTED) */
+    PA_DECIMAL = 8,  /* ShortDecimalType (core/trino-spi/.../type/ShortDecimalType.java): DECIMAL(p, s), p <= 18 -- a LongArrayBlock of
+                      * unscaled values, 8 B.  Precision and scale travel as the channel's type parameter PA_DECIMAL_PARAM(p, s)
+                      * (pa_*_desc.input_type_params) and, for expression nodes, in pa_expr_node.type_param.  Expressions: + - *
+                      * (DecimalOperators.java: operands rescaled to the result scale the planner derived; a result of more than 18
+                      * digits is a PA_LONG_DECIMAL value), comparisons / BETWEEN / IN between operands of one type, negation, CAST
+                      * from INTEGER / BIGINT / a decimal of smaller scale.  Aggregates: sum (-> DECIMAL(38, s), DecimalSumAggregation),
+                      * avg (-> the input type, DecimalAverageAggregation: sum / count rounded half up), min / max / count.  Group /
+                      * join / sort / partition key: as the long it is (ShortDecimalType: hash code = the value, == and < of longs) */
+    PA_LONG_DECIMAL = 9 /* LongDecimalType (.../type/LongDecimalType.java, UnscaledDecimal128Arithmetic.java): DECIMAL(p, s), 18 < p <= 38 --
+                      * 16 B per position, little endian: the low 64 bits of the magnitude, then the high 63 bits with the SIGN in the
+                      * top bit (sign-magnitude, as the reference's Slice holds it).  On the device path: a value inside expressions
+                      * (products and sums of short decimals), the result of sum / avg over decimals, the sum half of their PARTIAL
+                      * state, an input of sum / avg / count.  Not a key, not a comparison operand (PA_ERR_NOT_SUPPORTED) */
 } pa_type;
+#define PA_DECIMAL_PARAM(precision, scale) (((precision) << 8) | (scale))
+#define PA_DECIMAL_PRECISION(param) (((param) >> 8) & 0xff)
+#define PA_DECIMAL_SCALE(param) ((param) & 0xff)
 
 typedef enum pa_encoding {
     PA_FLAT = 0,        /* values[] (+array_offset), optional nulls[] */
@@ -141,8 +157,12 @@ typedef struct pa_expr_node {
     int32_t is_null;    /* CONSTANT: typed NULL */
     int32_t nargs;
     int32_t first_arg;  /* index of first child id in pa_expr.args */
-    int32_t str_len;    /* CONSTANT VARCHAR */
-    int64_t i64;        /* CONSTANT BIGINT/INTEGER/DATE/BOOLEAN */
+    union {
+        int32_t str_len;    /* CONSTANT VARCHAR */
+        int32_t type_param; /* nodes of type PA_DECIMAL / PA_LONG_DECIMAL: PA_DECIMAL_PARAM(precision, scale) of the node's type */
+    };
+    int64_t i64;        /* CONSTANT BIGINT/INTEGER/DATE/BOOLEAN; CONSTANT PA_DECIMAL: the unscaled value; CONSTANT PA_LONG_DECIMAL: its low
+                         * 64 bits (two's complement), the high 64 bits in the bits of f64 */
     double f64;          /* CONSTANT of type DOUBLE, or REAL (the float value, widened) */
     const char* str;    /* CONSTANT VARCHAR bytes (not NUL terminated) */
 } pa_expr_node;

@@ -10,8 +10,8 @@ final class GpuNative
 {
     static {
         System.loadLibrary("presto_amd_jni"); // links libpresto_amd.so
-        if (abiVersion() != 7) {
-            throw new IllegalStateException("libpresto_amd.so ABI version " + abiVersion() + " != 7");
+        if (abiVersion() != 8) {
+            throw new IllegalStateException("libpresto_amd.so ABI version " + abiVersion() + " != 8");
         }
     }
 
@@ -23,8 +23,8 @@ final class GpuNative
     static native ByteBuffer hostMallocPinned(long bytes);
     static native void hostFreePinned(ByteBuffer buffer);
 
-    static native long newExpression(int root, int[] kinds, int[] ops, int[] types, int[] channels, int[] isNull, int[] nargs, int[] firstArg,
-            long[] longs, double[] doubles, byte[][] strings, int[] args);
+    static native long newExpression(int root, int[] kinds, int[] ops, int[] types, int[] typeParams, int[] channels, int[] isNull, int[] nargs,
+            int[] firstArg, long[] longs, double[] doubles, byte[][] strings, int[] args);
     static native void freeExpression(long expression);
 
     static native long createFilterProject(int[] inputTypes, int[] typeParams, long filter, long[] projections, long minOutputPageBytes,

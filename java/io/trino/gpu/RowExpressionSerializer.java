@@ -39,10 +39,10 @@ final class RowExpressionSerializer
     }
 
     // pa_type / pa_expr_kind / pa_call_op / pa_special_form ordinals
-    static final int PA_BIGINT = 0, PA_INTEGER = 1, PA_DATE = 2, PA_DOUBLE = 3, PA_BOOLEAN = 4, PA_VARCHAR = 5, PA_REAL = 7;
+    static final int PA_BIGINT = 0, PA_INTEGER = 1, PA_DATE = 2, PA_DOUBLE = 3, PA_BOOLEAN = 4, PA_VARCHAR = 5, PA_REAL = 7, PA_DECIMAL = 8, PA_LONG_DECIMAL = 9;
     private static final int INPUT_REF = 0, CONSTANT = 1, CALL = 2, SPECIAL = 3;
 
-    private final List<int[]> nodes = new ArrayList<>();      // kind, op, type, channel, isNull, nargs, firstArg
+    private final List<int[]> nodes = new ArrayList<>();      // kind, op, type, typeParam, channel, isNull, nargs, firstArg
     private final List<Long> longs = new ArrayList<>();
     private final List<Double> doubles = new ArrayList<>();
     private final List<byte[]> strings = new ArrayList<>();
@@ -54,17 +54,17 @@ final class RowExpressionSerializer
         RowExpressionSerializer s = new RowExpressionSerializer();
         int root = expression.accept(s, null);
         int n = s.nodes.size();
-        int[][] columns = new int[7][n];
+        int[][] columns = new int[8][n];
         long[] longs = new long[n];
         double[] doubles = new double[n];
         for (int i = 0; i < n; i++) {
-            for (int f = 0; f < 7; f++) {
+            for (int f = 0; f < 8; f++) {
                 columns[f][i] = s.nodes.get(i)[f];
             }
             longs[i] = s.longs.get(i);
             doubles[i] = s.doubles.get(i);
         }
-        return GpuNative.newExpression(root, columns[0], columns[1], columns[2], columns[3], columns[4], columns[5], columns[6], longs, doubles,
+        return GpuNative.newExpression(root, columns[0], columns[1], columns[2], columns[3], columns[4], columns[5], columns[6], columns[7], longs, doubles,
                 s.strings.toArray(new byte[0][]), s.args.stream().mapToInt(Integer::intValue).toArray());
     }
 
@@ -91,12 +91,25 @@ final class RowExpressionSerializer
         if (type instanceof io.trino.spi.type.VarcharType) {
             return PA_VARCHAR;
         }
+        if (type instanceof io.trino.spi.type.DecimalType) {
+            return ((io.trino.spi.type.DecimalType) type).isShort() ? PA_DECIMAL : PA_LONG_DECIMAL;
+        }
         throw new UnsupportedOnDevice("type " + type);
+    }
+
+    /** PA_DECIMAL_PARAM(precision, scale) for DECIMAL types, else 0. */
+    static int typeParamOf(Type type)
+    {
+        if (type instanceof io.trino.spi.type.DecimalType) {
+            io.trino.spi.type.DecimalType decimal = (io.trino.spi.type.DecimalType) type;
+            return (decimal.getPrecision() << 8) | decimal.getScale();
+        }
+        return 0;
     }
 
     private int add(int kind, int op, Type type, int channel, boolean isNull, List<Integer> children, long longValue, double doubleValue, byte[] string)
     {
-        nodes.add(new int[] {kind, op, typeOf(type), channel, isNull ? 1 : 0, children.size(), args.size()});
+        nodes.add(new int[] {kind, op, typeOf(type), typeParamOf(type), channel, isNull ? 1 : 0, children.size(), args.size()});
         args.addAll(children);
         longs.add(longValue);
         doubles.add(doubleValue);
@@ -174,6 +187,11 @@ final class RowExpressionSerializer
             case PA_REAL: return add(CONSTANT, 0, type, 0, false, List.of(), 0, Float.intBitsToFloat(((Number) value).intValue()), null);
             case PA_BOOLEAN: return add(CONSTANT, 0, type, 0, false, List.of(), (Boolean) value ? 1 : 0, 0, null);
             case PA_VARCHAR: return add(CONSTANT, 0, type, 0, false, List.of(), 0, 0, ((Slice) value).getBytes());
+            case PA_LONG_DECIMAL: {
+                // a long decimal literal is a Slice in UnscaledDecimal128Arithmetic's layout: it travels as its two's complement halves
+                java.math.BigInteger unscaled = io.trino.spi.type.Decimals.decodeUnscaledValue((Slice) value);
+                return add(CONSTANT, 0, type, 0, false, List.of(), unscaled.longValue(), Double.longBitsToDouble(unscaled.shiftRight(64).longValue()), null);
+            }
             default: return add(CONSTANT, 0, type, 0, false, List.of(), ((Number) value).longValue(), 0, null);
         }
     }

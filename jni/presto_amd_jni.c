@@ -62,8 +62,11 @@ typedef struct native_expr {
     int32_t count;
 } native_expr;
 
+/* typeParams: per node PA_DECIMAL_PARAM(precision, scale) for nodes of a DECIMAL type, else 0 (a long decimal constant carries its low
+ * 64 bits in longs[i] and its high 64 bits as the bit pattern of doubles[i]) */
 JNIEXPORT jlong JNICALL Java_io_trino_gpu_GpuNative_newExpression(JNIEnv* env, jclass c, jint root, jintArray kinds, jintArray ops, jintArray types,
-        jintArray channels, jintArray isNull, jintArray nargs, jintArray firstArg, jlongArray longs, jdoubleArray doubles, jobjectArray strings, jintArray args)
+        jintArray typeParams, jintArray channels, jintArray isNull, jintArray nargs, jintArray firstArg, jlongArray longs, jdoubleArray doubles,
+        jobjectArray strings, jintArray args)
 {
     const jsize n = (*env)->GetArrayLength(env, kinds), na = (*env)->GetArrayLength(env, args);
     native_expr* e = (native_expr*)calloc(1, sizeof(native_expr));
@@ -74,6 +77,7 @@ JNIEXPORT jlong JNICALL Java_io_trino_gpu_GpuNative_newExpression(JNIEnv* env, j
     jint* k = (*env)->GetIntArrayElements(env, kinds, 0);
     jint* o = (*env)->GetIntArrayElements(env, ops, 0);
     jint* t = (*env)->GetIntArrayElements(env, types, 0);
+    jint* tp = (*env)->GetIntArrayElements(env, typeParams, 0);
     jint* ch = (*env)->GetIntArrayElements(env, channels, 0);
     jint* nl = (*env)->GetIntArrayElements(env, isNull, 0);
     jint* na_ = (*env)->GetIntArrayElements(env, nargs, 0);
@@ -85,6 +89,7 @@ JNIEXPORT jlong JNICALL Java_io_trino_gpu_GpuNative_newExpression(JNIEnv* env, j
         pa_expr_node* nd = &e->nodes[i];
         nd->kind = k[i]; nd->op = o[i]; nd->type = t[i]; nd->channel = ch[i]; nd->is_null = nl[i];
         nd->nargs = na_[i]; nd->first_arg = fa[i]; nd->i64 = lv[i]; nd->f64 = dv[i];
+        if (t[i] == PA_DECIMAL || t[i] == PA_LONG_DECIMAL) nd->type_param = tp[i];
         jbyteArray s = (jbyteArray)(*env)->GetObjectArrayElement(env, strings, i);   /* VARCHAR constants: UTF-8 bytes, else null */
         if (s) {
             const jsize len = (*env)->GetArrayLength(env, s);
@@ -100,6 +105,7 @@ JNIEXPORT jlong JNICALL Java_io_trino_gpu_GpuNative_newExpression(JNIEnv* env, j
     (*env)->ReleaseIntArrayElements(env, kinds, k, JNI_ABORT);
     (*env)->ReleaseIntArrayElements(env, ops, o, JNI_ABORT);
     (*env)->ReleaseIntArrayElements(env, types, t, JNI_ABORT);
+    (*env)->ReleaseIntArrayElements(env, typeParams, tp, JNI_ABORT);
     (*env)->ReleaseIntArrayElements(env, channels, ch, JNI_ABORT);
     (*env)->ReleaseIntArrayElements(env, isNull, nl, JNI_ABORT);
     (*env)->ReleaseIntArrayElements(env, nargs, na_, JNI_ABORT);
@@ -466,7 +472,8 @@ JNIEXPORT void JNICALL Java_io_trino_gpu_GpuNative_addInput(JNIEnv* env, jclass 
 static int64_t value_width(int32_t type)   /* bytes per position of a flat block (common.hpp type_width) */
 {
     switch (type) {
-        case PA_BIGINT: case PA_DOUBLE: return 8;
+        case PA_BIGINT: case PA_DOUBLE: case PA_DECIMAL: return 8;
+        case PA_LONG_DECIMAL: return 16;
         case PA_INTEGER: case PA_DATE: case PA_REAL: return 4;
         case PA_BOOLEAN: return 1;
         default: return 0;

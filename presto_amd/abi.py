@@ -5,7 +5,7 @@ test-only oracle binding (oracle/oracle.py), exactly as both C sides share the h
 """
 import ctypes as C
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 # pa_status
 OK = 0
@@ -26,9 +26,37 @@ STATUS_NAMES = {
 }
 
 # pa_type
-BIGINT, INTEGER, DATE, DOUBLE, BOOLEAN, VARCHAR, ROW, REAL = range(8)
-TYPE_NAMES = ["BIGINT", "INTEGER", "DATE", "DOUBLE", "BOOLEAN", "VARCHAR", "ROW"]
-TYPE_WIDTH = {BIGINT: 8, INTEGER: 4, DATE: 4, DOUBLE: 8, BOOLEAN: 1, VARCHAR: 0, ROW: 0, REAL: 4}
+BIGINT, INTEGER, DATE, DOUBLE, BOOLEAN, VARCHAR, ROW, REAL, DECIMAL, LONG_DECIMAL = range(10)
+TYPE_NAMES = ["BIGINT", "INTEGER", "DATE", "DOUBLE", "BOOLEAN", "VARCHAR", "ROW", "REAL", "DECIMAL", "LONG_DECIMAL"]
+TYPE_WIDTH = {BIGINT: 8, INTEGER: 4, DATE: 4, DOUBLE: 8, BOOLEAN: 1, VARCHAR: 0, ROW: 0, REAL: 4, DECIMAL: 8, LONG_DECIMAL: 16}
+
+
+class DecimalType(int):
+    """DECIMAL(precision, scale) as a pa_type value that knows its parameters: compares and hashes as PA_DECIMAL (precision <= 18,
+    ShortDecimalType) or PA_LONG_DECIMAL (LongDecimalType), `param` is PA_DECIMAL_PARAM(precision, scale)."""
+
+    def __new__(cls, precision, scale):
+        if not (1 <= precision <= 38 and 0 <= scale <= precision):
+            raise ValueError("DECIMAL(%d, %d)" % (precision, scale))
+        self = super().__new__(cls, DECIMAL if precision <= 18 else LONG_DECIMAL)
+        self.precision, self.scale = precision, scale
+        return self
+
+    @property
+    def param(self):
+        return (self.precision << 8) | self.scale
+
+    def __repr__(self):
+        return "DECIMAL(%d, %d)" % (self.precision, self.scale)
+
+
+def decimal(precision, scale):
+    return DecimalType(precision, scale)
+
+
+def type_param(t):
+    """The type parameter a descriptor carries for type t (0 for the types that have none)."""
+    return t.param if isinstance(t, DecimalType) else 0
 
 # pa_encoding
 FLAT, VARWIDTH, DICTIONARY, RLE, ROW_FIELDS = range(5)

@@ -1212,13 +1212,20 @@ KernelInfo generate(const Spec& s, const std::vector<ChannelLayout>& layout, int
         else if (variant == V_LDSP) {
             // the partition's table comes from HBM as the last launch left it (zeroes at first) ...
             src << "    const u64 sp = (u64)blockIdx.x * PA_LC;\n";
-            src << "    for (int i = threadIdx.x; i < PA_LC; i += " << B << ") pa_lt_tag[i] = a.sub_tag[sp + i];\n";
-            src << "    for (int i = threadIdx.x; i < PA_LC * PA_KW; i += " << B << ") pa_lt_key[i] = a.sub_keys[sp * PA_KW + i];\n";
             // (accumulator words are word-major in HBM, [word][slot over all partitions] -- the layout of the HBM group table, so
             // that the partitions' tables can be emitted, or folded, as one table of gridDim.x * PA_LC slots)
             src << "    const u64 ts = (u64)gridDim.x * PA_LC;\n";
-            src << "    for (int i = threadIdx.x; i < PA_LC * PA_NW; i += " << B << ") { const int w = i / PA_LC, sl = i % PA_LC; pa_lt_acc[sl * PA_NW + w] = a.sub_words[(u64)w * ts + sp + sl]; }\n";
-            src << "    if (threadIdx.x == 0) pa_lt_count = a.sub_count[blockIdx.x];\n    __syncthreads();\n";
+            // a.pad3: the first launch on these tables -- they are empty by definition, nothing to load (and the host cleared nothing)
+            src << "    if (a.pad3) {\n";
+            src << "      for (int i = threadIdx.x; i < PA_LC; i += " << B << ") pa_lt_tag[i] = 0ULL;\n";
+            src << "      for (int i = threadIdx.x; i < PA_LC * PA_NW; i += " << B << ") pa_lt_acc[i] = 0ULL;\n";
+            src << "      if (threadIdx.x == 0) pa_lt_count = 0;\n";
+            src << "    } else {\n";
+            src << "      for (int i = threadIdx.x; i < PA_LC; i += " << B << ") pa_lt_tag[i] = a.sub_tag[sp + i];\n";
+            src << "      for (int i = threadIdx.x; i < PA_LC * PA_KW; i += " << B << ") pa_lt_key[i] = a.sub_keys[sp * PA_KW + i];\n";
+            src << "      for (int i = threadIdx.x; i < PA_LC * PA_NW; i += " << B << ") { const int w = i / PA_LC, sl = i % PA_LC; pa_lt_acc[sl * PA_NW + w] = a.sub_words[(u64)w * ts + sp + sl]; }\n";
+            src << "      if (threadIdx.x == 0) pa_lt_count = a.sub_count[blockIdx.x];\n";
+            src << "    }\n    __syncthreads();\n";
             src << "    PaAcc acc; acc.tv = pa_gt_view(a, PA_KW, PA_NW); acc.gt = pa_gt_ctr_init(acc.tv.count, true, a.gt_rep_mask + 1u);\n"
                    "    acc.flush = pa_gt_ctr_init(acc.tv.count, false); acc.fell = 0;\n";
         }
@@ -2300,11 +2307,13 @@ private:
             // the partitions' tables, all empty
             sub_parts_ = partitions;
             const size_t slots = (size_t)partitions * lk.info.lc;
-            PA_HIP(hipMemsetAsync(sub_tag_.ensure(slots * 8), 0, slots * 8, s));
+            // (not cleared: the first launch starts every partition's table from zeroes in LDS and stores all of them)
+            sub_tag_.ensure(slots * 8);
             sub_keys_.ensure(slots * 8 * std::max(lk.info.w, 1));
-            PA_HIP(hipMemsetAsync(sub_words_.ensure(slots * 8 * lk.info.nw), 0, slots * 8 * lk.info.nw, s));
-            PA_HIP(hipMemsetAsync(sub_count_.ensure((size_t)partitions * 4), 0, (size_t)partitions * 4, s));
+            sub_words_.ensure(slots * 8 * lk.info.nw);
+            sub_count_.ensure((size_t)partitions * 4);
             sub_lc_ = lk.info.lc;
+            sub_fresh_ = true;
         }
         if (ldsp) partitions = sub_parts_;
         const int64_t chunk = (int64_t)1 << 26;
@@ -2624,6 +2633,8 @@ private:
                 a.row_list = nullptr;
                 a.n_list = 0;
                 a.list_blocked = 0;
+                a.pad3 = sub_fresh_ ? 1 : 0;
+                sub_fresh_ = false;
             }
             a.gt_rep_count = rep_count_.as<int32_t>();
             void* params[] = {&a};
@@ -2846,6 +2857,7 @@ private:
     bool want_ldsp_ = false;
     uint64_t sub_fell_ = 0;               // rows that fell through to the HBM table (their partition's table was full)
     DevBuf sub_tag_, sub_keys_, sub_words_, sub_count_, part_first_;
+    bool sub_fresh_ = false;       // the partitions' tables exist but no launch has written them yet
     bool parked_ = false;                 // a stable page waits for HBM (see retry_parked)
     pa_page parked_page_{};
     std::vector<pa_column> parked_cols_;
@@ -3167,10 +3179,9 @@ void FusedAggregationOperator::build_output()
             gt_words_ = std::move(sub_words_);
             gt_cap_ = sub_cap;
             gt_rep_ = 1;
-            const int32_t count = (int32_t)total;
-            PA_HIP(hipMemcpyAsync(ctl_ + 1, &count, 4, hipMemcpyHostToDevice, s));
-            PA_HIP(hipStreamSynchronize(s));
-            h_ctl_[1] = count;
+            // (the count goes to the device from the pinned control block: no wait)
+            h_ctl_[1] = (int32_t)total;
+            PA_HIP(hipMemcpyAsync(ctl_ + 1, h_ctl_ + 1, 4, hipMemcpyHostToDevice, s));
             groups_upper_ = groups_sum_ = total;
         }
         else {

@@ -40,8 +40,6 @@ public:
         fp.min_output_page_bytes = fp.min_output_page_rows = fp.max_output_page_bytes = 0;  // (MergePages sits behind the join)
         pa_lookup_join_desc join = d->join;
         join.stream = stream;
-        chain_.emplace_back(make_filter_project(&fp));
-        chain_.emplace_back(make_lookup_join(&join, bridge));
         try {
             pa_filter_project_desc one = d->filter_project;
             one.output_mem = d->join.output_mem;
@@ -51,7 +49,12 @@ public:
         catch (const Error& e) {
             if (e.code != PA_ERR_NOT_SUPPORTED) throw;
         }
-        stream_ = chain_.back()->main_stream();
+        // (a lookup source that is already built has told which execution runs: the other one is not even made)
+        if (!(fused_ && lookup_source_unique_keyed(bridge))) {
+            chain_.emplace_back(make_filter_project(&fp));
+            chain_.emplace_back(make_lookup_join(&join, bridge));
+        }
+        stream_ = static_cast<hipStream_t>(stream);
         finish_sent_.assign(chain_.size(), false);
     }
     FusedJoinAggregationOperator(const pa_fused_join_aggregation_desc* d, pa_lookup_source* bridge) : bridge_(*bridge)
@@ -68,9 +71,6 @@ public:
         join.stream = stream;
         pa_hash_aggregation_desc agg = d->aggregation;
         agg.stream = stream;
-        chain_.emplace_back(make_filter_project(&fp));
-        chain_.emplace_back(make_lookup_join(&join, bridge));
-        chain_.emplace_back(make_hash_aggregation(&agg));
         try {
             pa_fused_join_aggregation_desc f = *d;
             f.aggregation.stream = stream;
@@ -79,7 +79,12 @@ public:
         catch (const Error& e) {
             if (e.code != PA_ERR_NOT_SUPPORTED) throw;  // shapes the one-kernel form does not cover run as the chain
         }
-        stream_ = chain_.back()->main_stream();
+        if (!(fused_ && lookup_source_unique_keyed(bridge))) {
+            chain_.emplace_back(make_filter_project(&fp));
+            chain_.emplace_back(make_lookup_join(&join, bridge));
+            chain_.emplace_back(make_hash_aggregation(&agg));
+        }
+        stream_ = static_cast<hipStream_t>(stream);
         finish_sent_.assign(chain_.size(), false);
     }
     ~FusedJoinAggregationOperator() override

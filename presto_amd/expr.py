@@ -26,6 +26,8 @@ class RowExpression:
     # sugar so tests read like SQL
     def _bin(self, op, other, type_=None):
         other = _lift(other, self.type)
+        if type_ is None and isinstance(self.type, abi.DecimalType) and isinstance(other.type, abi.DecimalType):
+            type_ = decimal_result_type(op, self.type, other.type)
         return call(op, type_ if type_ is not None else self.type, self, other)
 
     def __add__(self, o): return self._bin(abi.OP_ADD, o)
@@ -47,6 +49,18 @@ class RowExpression:
     def between(self, lo, hi): return special(abi.FORM_BETWEEN, abi.BOOLEAN, self, _lift(lo, self.type), _lift(hi, self.type))
     def isin(self, *values): return special(abi.FORM_IN, abi.BOOLEAN, self, *[_lift(v, self.type) for v in values])
     def cast(self, type_): return call(abi.OP_CAST, type_, self)
+
+
+def decimal_result_type(op, a, b):
+    """The result type the reference's signatures derive for decimal arithmetic (core/trino-main/src/main/java/io/trino/type/
+    DecimalOperators.java:76-84 add / subtract: precision min(38, max(p1 - s1, p2 - s2) + max(s1, s2) + 1), scale max(s1, s2);
+    :243-249 multiply: precision min(38, p1 + p2), scale s1 + s2)."""
+    if op in (abi.OP_ADD, abi.OP_SUBTRACT):
+        scale = max(a.scale, b.scale)
+        return abi.decimal(min(38, max(a.precision - a.scale, b.precision - b.scale) + scale + 1), scale)
+    if op == abi.OP_MULTIPLY:
+        return abi.decimal(min(38, a.precision + b.precision), a.scale + b.scale)
+    raise ValueError("decimal operator %d is not on the device path" % op)
 
 
 def _lift(v, type_):
@@ -109,8 +123,14 @@ def serialize(expr):
                 n.str_len = len(e.value)
             elif e.type == abi.BOOLEAN:
                 n.i64 = 1 if e.value else 0
+            elif e.type == abi.LONG_DECIMAL:   # two's complement halves of the unscaled value: low in i64, high in the bits of f64
+                v = int(e.value) & ((1 << 128) - 1)
+                n.i64 = C.c_int64(v & 0xFFFFFFFFFFFFFFFF).value
+                n.f64 = C.cast(C.pointer(C.c_uint64(v >> 64)), C.POINTER(C.c_double))[0]
             else:
                 n.i64 = int(e.value)
+        if isinstance(e.type, abi.DecimalType):
+            n.str_len = e.type.param
         nodes.append(n)
         return len(nodes) - 1
 

@@ -13,7 +13,24 @@ import numpy as np
 from . import abi
 
 _NP_DTYPE = {abi.BIGINT: np.int64, abi.INTEGER: np.int32, abi.DATE: np.int32, abi.DOUBLE: np.float64,
-             abi.BOOLEAN: np.uint8, abi.REAL: np.float32}
+             abi.BOOLEAN: np.uint8, abi.REAL: np.float32, abi.DECIMAL: np.int64}
+
+# LongDecimalType: 16 B per position -- the low 64 bits of the magnitude, then the high 63 bits with the sign in the top bit
+# (UnscaledDecimal128Arithmetic.java: SIGN_LONG_MASK); held as an (n, 2) array of uint64
+_SIGN = 1 << 63
+
+
+def long_decimal_words(value):
+    """unscaled Python int -> (low, high) words of the reference's layout"""
+    mag = -value if value < 0 else value
+    if mag >> 127:
+        raise OverflowError("unscaled value beyond 127 bits")
+    return mag & 0xFFFFFFFFFFFFFFFF, (mag >> 64) | (_SIGN if value < 0 else 0)
+
+
+def long_decimal_value(low, high):
+    mag = ((int(high) & (_SIGN - 1)) << 64) | int(low)
+    return -mag if int(high) & _SIGN else mag
 
 
 class DeviceBuffer:
@@ -61,6 +78,28 @@ class Block:
             if not nl.any():
                 nl = None  # LongArrayBlock: valueIsNull == null when mayHaveNull is false
         return Block(type_, abi.FLAT, len(arr), values=arr, nulls=nl)
+
+    @staticmethod
+    def decimal(values, nulls=None):
+        """ShortDecimalType block: unscaled values (LongArrayBlock)."""
+        return Block.flat(abi.DECIMAL, values, nulls)
+
+    @staticmethod
+    def long_decimal(values, nulls=None):
+        """LongDecimalType block from unscaled Python ints (None = NULL)."""
+        values = list(values)
+        if nulls is None and any(v is None for v in values):
+            nulls = [v is None for v in values]
+        arr = np.zeros((len(values), 2), dtype=np.uint64)
+        for i, v in enumerate(values):
+            if v is not None:
+                arr[i, 0], arr[i, 1] = long_decimal_words(int(v))
+        nl = None
+        if nulls is not None:
+            nl = np.ascontiguousarray(np.asarray(nulls, dtype=np.uint8))
+            if not nl.any():
+                nl = None
+        return Block(abi.LONG_DECIMAL, abi.FLAT, len(values), values=np.ascontiguousarray(arr), nulls=nl)
 
     @staticmethod
     def bigint(values, nulls=None):
@@ -149,6 +188,8 @@ class Block:
             raw = self.values.tobytes()
             off = self.offsets.tolist()
             out = [raw[off[i]:off[i + 1]] for i in range(n)]
+        elif self.type == abi.LONG_DECIMAL:
+            out = [long_decimal_value(lo, hi) for lo, hi in self.values[:n].tolist()]
         else:
             out = self.values[:n].tolist()
             if self.type == abi.BOOLEAN:
@@ -269,6 +310,11 @@ def page_from_c(cpage, copy=True):
             else:
                 vals = np.zeros(1, dtype=np.uint8)
             blocks.append(Block(col.type, abi.VARWIDTH, n, values=vals, offsets=off, nulls=nulls))
+        elif col.encoding == abi.FLAT and col.type == abi.LONG_DECIMAL:
+            vals = np.zeros((n, 2), dtype=np.uint64)
+            if n > 0:
+                vals = np.ctypeslib.as_array(C.cast(col.values, C.POINTER(C.c_uint64)), shape=(n, 2)).copy()
+            blocks.append(Block(col.type, abi.FLAT, n, values=vals, nulls=nulls))
         elif col.encoding == abi.FLAT:
             dt = np.dtype(_NP_DTYPE[col.type])
             if n > 0:

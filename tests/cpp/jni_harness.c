@@ -30,8 +30,8 @@ jint Java_io_trino_gpu_GpuNative_abiVersion(JNIEnv*, jclass);
 void Java_io_trino_gpu_GpuNative_init(JNIEnv*, jclass, jint);
 jobject Java_io_trino_gpu_GpuNative_hostMallocPinned(JNIEnv*, jclass, jlong);
 void Java_io_trino_gpu_GpuNative_hostFreePinned(JNIEnv*, jclass, jobject);
-jlong Java_io_trino_gpu_GpuNative_newExpression(JNIEnv*, jclass, jint, jintArray, jintArray, jintArray, jintArray, jintArray, jintArray, jintArray, jlongArray,
-                                                jdoubleArray, jobjectArray, jintArray);
+jlong Java_io_trino_gpu_GpuNative_newExpression(JNIEnv*, jclass, jint, jintArray, jintArray, jintArray, jintArray, jintArray, jintArray, jintArray, jintArray,
+                                                jlongArray, jdoubleArray, jobjectArray, jintArray);
 void Java_io_trino_gpu_GpuNative_freeExpression(JNIEnv*, jclass, jlong);
 jlong Java_io_trino_gpu_GpuNative_createFilterProject(JNIEnv*, jclass, jintArray, jintArray, jlong, jlongArray, jlong, jint, jint);
 jlong Java_io_trino_gpu_GpuNative_createHashAggregation(JNIEnv*, jclass, jintArray, jintArray, jintArray, jint, jint, jintArray, jintArray, jintArray, jintArray,
@@ -216,7 +216,7 @@ static jint take_exception(char* message, size_t cap)
 /* =========================================== the Java side, in C =========================================== */
 /* RowExpressionSerializer: nodes appended children-first, a node's children named by indices into `args` */
 typedef struct {
-    jint kind[32], op[32], type[32], channel[32], is_null[32], nargs[32], first_arg[32], args[64];
+    jint kind[32], op[32], type[32], type_param[32], channel[32], is_null[32], nargs[32], first_arg[32], args[64];
     jlong i64[32];
     jdouble f64[32];
     jint n, na;
@@ -254,7 +254,8 @@ static jint e_call2(expr_builder* b, jint op, jint type, jint l, jint r)
 static jlong e_finish(expr_builder* b, jint root)
 {
     jobjectArray strings = new_object(K_OBJECTS, b->n, (size_t)b->n * sizeof(jobject));   /* no VARCHAR constants here: all null */
-    jlong h = Java_io_trino_gpu_GpuNative_newExpression(env, 0, root, ints(b->n, b->kind), ints(b->n, b->op), ints(b->n, b->type), ints(b->n, b->channel),
+    jlong h = Java_io_trino_gpu_GpuNative_newExpression(env, 0, root, ints(b->n, b->kind), ints(b->n, b->op), ints(b->n, b->type), ints(b->n, b->type_param),
+                                                        ints(b->n, b->channel),
                                                         ints(b->n, b->is_null), ints(b->n, b->nargs), ints(b->n, b->first_arg), longs(b->n, b->i64),
                                                         doubles(b->n, b->f64), strings, ints(b->na, b->args));
     NO_EXCEPTION("newExpression");
