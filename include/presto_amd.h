@@ -53,7 +53,7 @@ typedef enum pa_type {
     PA_BOOLEAN = 4,  /* ByteArrayBlock, 1 B */
     PA_VARCHAR = 5,  /* VariableWidthBlock: bytes + int32 offsets[positionCount+1] */
     PA_ROW = 6,      /* RowBlock of the fields' types (only as the intermediate state of an aggregate, PA_STATES_REFERENCE) */
-    PA_REAL = 7      /* IntArrayBlock holding floatToRawIntBits, 4 B (RealType.java).  Expressions (arithmetic, comparisons, casts
+    PA_REAL = 7,     /* IntArrayBlock holding floatToRawIntBits, 4 B (RealType.java).  Expressions (arithmetic, comparisons, casts
                       * from / to DOUBLE and from the integer types), sum / avg / min / max / count inputs, payload channels, and
                       * group / join / sort / partition keys with RealType's operators (hash of floatToIntBits with +0 for both zeros,
                       * == for joins, IS NOT DISTINCT for groups, Float.compare order; RealType.java:101-160).  Not a dynamic-filter
