@@ -76,6 +76,7 @@ def lib():
         L.orc_q6.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_double),
                              C.POINTER(C.c_int64)]
         L.orc_q1_add.argtypes = [C.c_void_p] + [C.c_void_p] * 9 + [C.c_int64]
+        L.orc_decimal_state_after.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int64), C.c_void_p, C.c_void_p]
         L.orc_sort_positions_bigint.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
         L.orc_topn_double_desc_bigint_asc.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]
         _LIB = L
@@ -580,6 +581,24 @@ def order_by(pages, output_channels, sort_channels, sort_orders):
     """OrderByOperator (core/trino-main/src/main/java/io/trino/operator/OrderByOperator.java:45-330): PagesIndex.sort with the same
     comparator as TopN (SimplePagesIndexComparator / SortOrder.compareBlockValue), every row kept; output channels only."""
     return [tuple(r[c] for c in output_channels) for r in topn(pages, None, sort_channels, sort_orders)]
+
+
+def decimal_state_after(values, want_average=False):
+    """LongDecimalWithOverflow(AndLong)State after inputLongDecimal of `values` (unscaled Python ints) in order:
+    (overflow, unscaled value of the state's Slice -- its sign bit may be set on a zero magnitude: returned as (negative, magnitude)),
+    and DecimalAverageAggregation.average at scale 0 when asked."""
+    from presto_amd.page import long_decimal_value, long_decimal_words
+    buf = np.zeros((max(len(values), 1), 2), dtype=np.uint64)
+    for i, v in enumerate(values):
+        buf[i, 0], buf[i, 1] = long_decimal_words(int(v))
+    overflow = C.c_int64()
+    state = np.zeros(2, dtype=np.uint64)
+    avg = np.zeros(2, dtype=np.uint64)
+    _check(lib().orc_decimal_state_after(buf.ctypes.data, len(values), C.byref(overflow), state.ctypes.data, avg.ctypes.data if want_average else None))
+    negative = bool(int(state[1]) >> 63)
+    magnitude = ((int(state[1]) & ((1 << 63) - 1)) << 64) | int(state[0])
+    out = (overflow.value, negative, magnitude)
+    return out + (long_decimal_value(avg[0], avg[1]),) if want_average else out
 
 
 def sort_positions_bigint(keys):

@@ -168,7 +168,36 @@ typedef struct orc_val {
     double d;         /* DOUBLE */
     const uint8_t* s; /* VARCHAR */
     int32_t slen;
+    __int128 q;       /* DECIMAL (short and long): the unscaled value */
 } orc_val;
+
+/* ---- DECIMAL: ShortDecimalType (unscaled long) and LongDecimalType (SPI/type/UnscaledDecimal128Arithmetic.java: a 16-byte Slice,
+ *      little endian: the low 64 bits of the magnitude, then the high 63 bits with the sign in bit 63 of the second long) ---- */
+typedef unsigned __int128 u128;
+static inline int type_is_decimal(int32_t t) { return t == PA_DECIMAL || t == PA_LONG_DECIMAL; }
+static inline __int128 ld_read(const void* p)
+{
+    uint64_t lo, hi;
+    memcpy(&lo, p, 8);
+    memcpy(&hi, (const uint8_t*)p + 8, 8);
+    const u128 mag = ((u128)(hi & 0x7fffffffffffffffULL) << 64) | lo;
+    return (hi >> 63) ? -(__int128)mag : (__int128)mag;
+}
+static inline void ld_write(void* p, __int128 v)
+{
+    const u128 mag = v < 0 ? (u128)(-v) : (u128)v;
+    uint64_t lo = (uint64_t)mag, hi = (uint64_t)(mag >> 64) | (v < 0 ? 0x8000000000000000ULL : 0);
+    memcpy(p, &lo, 8);
+    memcpy((uint8_t*)p + 8, &hi, 8);
+}
+static __int128 pow10_128(int k)
+{
+    __int128 r = 1;
+    while (k-- > 0) r *= 10;
+    return r;
+}
+/* UnscaledDecimal128Arithmetic.throwIfOverflows: a magnitude of 10^38 or more is an overflow */
+static inline int ld_overflows(__int128 v) { return v >= pow10_128(38) || v <= -pow10_128(38); }
 
 static inline int type_is_int(int32_t t) { return t == PA_BIGINT || t == PA_INTEGER || t == PA_DATE; }
 /* DOUBLE, and REAL: a REAL value travels in orc_val.d as the double it converts to exactly (RealOperators.castToDouble) */
@@ -226,6 +255,13 @@ static inline orc_val col_get(const pa_column* c, int32_t pos)
             v.s = (const uint8_t*)c->values + c->offsets[pos];
             v.slen = c->offsets[pos + 1] - c->offsets[pos];
             break;
+        case PA_DECIMAL:
+            v.i = ((const int64_t*)c->values)[pos];
+            v.q = v.i;
+            break;
+        case PA_LONG_DECIMAL:
+            v.q = ld_read((const uint8_t*)c->values + 16 * (size_t)pos);
+            break;
         default:
             break;
     }
@@ -262,6 +298,8 @@ static int64_t val_hash(const orc_val* v)
             return orc_hash_boolean((int32_t)v->i);
         case PA_VARCHAR:
             return (int64_t)orc_xxh64(v->s, v->slen, 0);
+        case PA_DECIMAL: /* SPI/type/ShortDecimalType.java:127-131: hashCodeOperator(long value) = value */
+            return v->i;
         default:
             return 0;
     }
@@ -400,6 +438,10 @@ static orc_val eval_compare(eval_ctx* cx, int32_t op, const orc_val* a, const or
         lt = c < 0;
         eq = c == 0;
     }
+    else if (type_is_decimal(a->type)) { /* operands of one decimal type (the planner casts): their unscaled values compare */
+        lt = a->q < b->q;
+        eq = a->q == b->q;
+    }
     else {
         lt = a->i < b->i;
         eq = a->i == b->i;
@@ -479,6 +521,76 @@ static orc_val eval_arith(eval_ctx* cx, int32_t op, int32_t type, const orc_val*
     return r;
 }
 
+/* TM/type/DecimalOperators.java: add / subtract (:86-231) bring both operands to the result scale (the larger of the two) and add
+ * the unscaled values; multiply (:251-330) multiplies them (the result scale is the sum of the scales).  A result type of at most
+ * 18 digits is computed in longs (the derived precision cannot overflow them); a long result throws NUMERIC_VALUE_OUT_OF_RANGE
+ * once its magnitude reaches 10^38 (UnscaledDecimal128Arithmetic.throwIfOverflows) -- a product that does not even fit 128 bits
+ * included.  sa / sb / sr: the scales of the operands and of the result (pa_expr_node.type_param). */
+static orc_val eval_decimal_arith(eval_ctx* cx, int32_t op, int32_t type, const orc_val* a, int sa, const orc_val* b, int sb, int sr)
+{
+    if (a->is_null || (b != NULL && b->is_null)) {
+        return null_of(type);
+    }
+    orc_val r;
+    memset(&r, 0, sizeof r);
+    r.type = type;
+    __int128 x = a->q, y = b ? b->q : 0, z = 0;
+    int ovf = 0;
+    switch (op) {
+        case PA_OP_ADD:
+        case PA_OP_SUBTRACT:
+            ovf |= __builtin_mul_overflow(x, pow10_128(sr - sa), &x);
+            ovf |= __builtin_mul_overflow(y, pow10_128(sr - sb), &y);
+            ovf |= op == PA_OP_ADD ? __builtin_add_overflow(x, y, &z) : __builtin_sub_overflow(x, y, &z);
+            break;
+        case PA_OP_MULTIPLY:
+            ovf = __builtin_mul_overflow(x, y, &z);
+            break;
+        case PA_OP_NEGATE:
+            z = -x;
+            break;
+        default:
+            cx->error = PA_ERR_NOT_SUPPORTED;
+            return r;
+    }
+    if (type == PA_LONG_DECIMAL ? (ovf || ld_overflows(z)) : ovf) {
+        cx->error = PA_ERR_NUMERIC_VALUE_OUT_OF_RANGE;
+        return r;
+    }
+    r.q = z;
+    r.i = (int64_t)z; /* (a short result: the long the reference computed, wrapping as Java's would if the type lied) */
+    if (type == PA_DECIMAL) r.q = r.i;
+    return r;
+}
+
+/* CAST to DECIMAL(p, s): from BIGINT / INTEGER (TM/type/DecimalCasts.java bigintToShortDecimal / bigintToLongDecimal: value * 10^s,
+ * out of range once the magnitude reaches 10^p) and from another DECIMAL (DecimalConversions.java shortToShortCast ... : rescale,
+ * dividing rounds half up -- away from zero --, then the same range check) */
+static orc_val eval_decimal_cast(eval_ctx* cx, int32_t type, int32_t param, const orc_val* a, int sa)
+{
+    orc_val r;
+    memset(&r, 0, sizeof r);
+    r.type = type;
+    const int p = PA_DECIMAL_PRECISION(param), sc = PA_DECIMAL_SCALE(param);
+    __int128 v = type_is_decimal(a->type) ? a->q : (__int128)a->i;
+    int ovf = 0;
+    if (sc >= sa) {
+        ovf = __builtin_mul_overflow(v, pow10_128(sc - sa), &v);
+    }
+    else {
+        const __int128 d = pow10_128(sa - sc), half = d / 2;
+        const __int128 q = v / d, rem = v % d;
+        v = q + (rem >= half ? 1 : (rem <= -half ? -1 : 0));
+    }
+    if (ovf || v >= pow10_128(p) || v <= -pow10_128(p)) {
+        cx->error = PA_ERR_NUMERIC_VALUE_OUT_OF_RANGE;
+        return r;
+    }
+    r.q = v;
+    r.i = (int64_t)v;
+    return r;
+}
+
 static orc_val eval_node(eval_ctx* cx, int32_t id)
 {
     const pa_expr_node* n = &cx->e->nodes[id];
@@ -498,6 +610,14 @@ static orc_val eval_node(eval_ctx* cx, int32_t id)
             v.d = n->type == PA_REAL ? (double)(float)n->f64 : n->f64;
             v.s = (const uint8_t*)n->str;
             v.slen = n->str_len;
+            if (n->type == PA_DECIMAL) {
+                v.q = n->i64;
+            }
+            else if (n->type == PA_LONG_DECIMAL) { /* low 64 bits in i64, high 64 bits in the bits of f64 (two's complement) */
+                uint64_t hi;
+                memcpy(&hi, &n->f64, 8);
+                v.q = (__int128)(((u128)hi << 64) | (uint64_t)n->i64);
+            }
             return v;
         }
         case PA_EXPR_CALL: {
@@ -515,12 +635,19 @@ static orc_val eval_node(eval_ctx* cx, int32_t id)
             }
             if (n->op == PA_OP_NEGATE) {
                 orc_val a = eval_node(cx, args[0]);
+                if (type_is_decimal(n->type)) {
+                    return eval_decimal_arith(cx, n->op, n->type, &a, 0, NULL, 0, 0);
+                }
                 return eval_arith(cx, n->op, n->type, &a, NULL);
             }
             if (n->op == PA_OP_CAST) {
                 orc_val a = eval_node(cx, args[0]);
                 if (a.is_null) {
                     return null_of(n->type);
+                }
+                if (type_is_decimal(n->type) && (type_is_decimal(a.type) || type_is_int(a.type))) {
+                    const pa_expr_node* an = &cx->e->nodes[args[0]];
+                    return eval_decimal_cast(cx, n->type, n->type_param, &a, type_is_decimal(an->type) ? PA_DECIMAL_SCALE(an->type_param) : 0);
                 }
                 orc_val r;
                 memset(&r, 0, sizeof r);
@@ -550,6 +677,10 @@ static orc_val eval_node(eval_ctx* cx, int32_t id)
             }
             orc_val a = eval_node(cx, args[0]);
             orc_val b = eval_node(cx, args[1]);
+            if (type_is_decimal(n->type)) {
+                return eval_decimal_arith(cx, n->op, n->type, &a, PA_DECIMAL_SCALE(cx->e->nodes[args[0]].type_param), &b,
+                                          PA_DECIMAL_SCALE(cx->e->nodes[args[1]].type_param), PA_DECIMAL_SCALE(n->type_param));
+            }
             return eval_arith(cx, n->op, n->type, &a, &b);
         }
         case PA_EXPR_SPECIAL: {
@@ -695,8 +826,11 @@ typedef struct col_builder {
 static int32_t type_width(int32_t t)
 {
     switch (t) {
+        case PA_LONG_DECIMAL:
+            return 16;
         case PA_BIGINT:
         case PA_DOUBLE:
+        case PA_DECIMAL:
             return 8;
         case PA_INTEGER:
         case PA_DATE:
@@ -769,6 +903,12 @@ static void cb_append(col_builder* b, const orc_val* v)
             break;
         case PA_BOOLEAN:
             b->values[i] = v->is_null ? 0 : (uint8_t)(v->i != 0);
+            break;
+        case PA_DECIMAL:
+            ((int64_t*)b->values)[i] = v->is_null ? 0 : (int64_t)v->q;
+            break;
+        case PA_LONG_DECIMAL:
+            ld_write(b->values + 16 * (size_t)i, v->is_null ? 0 : v->q);
             break;
         case PA_VARCHAR: {
             int32_t len = v->is_null ? 0 : v->slen;
@@ -891,7 +1031,103 @@ typedef struct acc_state { /* LongDoubleState / LongLongState / LongState per gr
     int32_t has_value; /* min/max */
     uint8_t* str;      /* min/max over VARCHAR: the value so far (owned copy) */
     int32_t slen;
+    /* LongDecimalWithOverflowState / LongDecimalWithOverflowAndLongState (sum / avg over DECIMAL): the 127-bit sign-magnitude sum as
+     * the reference's Slice holds it (dneg: its sign bit, which zero may carry too) and the overflow counter beside it */
+    u128 dmag;
+    int32_t dneg;
+    int64_t overflow;
 } acc_state;
+
+/* UnscaledDecimal128Arithmetic.addWithOverflow (SPI/type/UnscaledDecimal128Arithmetic.java:354-379) on (sign, 127-bit magnitude)
+ * pairs: equal signs add the magnitudes -- a carry out of bit 126 is the overflow, +1 / -1 by the sign, and the sum keeps its low
+ * 127 bits --; different signs subtract the smaller magnitude from the larger and take its sign; equal magnitudes give +0 */
+static int64_t ld_add_with_overflow(acc_state* s, __int128 x)
+{
+    const int xneg = x < 0;
+    const u128 xmag = xneg ? (u128)(-x) : (u128)x;
+    const u128 limit = (u128)1 << 127;
+    if (s->dneg == xneg) {
+        u128 sum = s->dmag + xmag; /* both < 2^127: no wrap of the 128-bit word */
+        const int64_t ovf = sum >= limit ? 1 : 0;
+        s->dmag = sum & (limit - 1);
+        return xneg ? -ovf : ovf;
+    }
+    if (s->dmag > xmag) {
+        s->dmag -= xmag;
+    }
+    else if (s->dmag < xmag) {
+        s->dmag = xmag - s->dmag;
+        s->dneg = xneg;
+    }
+    else {
+        s->dmag = 0;
+        s->dneg = 0;
+    }
+    return 0;
+}
+/* sum = overflow * 2^127 + (sign, magnitude), divided by count and rounded half up -- away from zero -- at the sum's scale:
+ * DecimalAverageAggregation.average (TM/operator/aggregation/DecimalAverageAggregation.java:214-226; BigDecimal.divide(count, scale,
+ * ROUND_HALF_UP)).  Exact in 192-bit arithmetic on three limbs.  Returns 0 when the quotient does not fit 127 bits. */
+static int ld_average(const acc_state* s, int64_t count, __int128* out)
+{
+    /* total = overflow * 2^127 +- mag as a two's complement number of 192 bits in three 64-bit limbs */
+    uint64_t t[3] = {0, 0, 0};
+    {
+        /* overflow * 2^127: overflow is a small signed count */
+        const __int128 hi = (__int128)s->overflow; /* bits 127.. */
+        /* place hi << 127 */
+        const u128 lowpart = ((u128)(uint64_t)hi << 127); /* contributes bit 127 of limb 1 from bit 0 of hi */
+        t[0] = 0;
+        t[1] = (uint64_t)(lowpart >> 64);
+        t[2] = (uint64_t)((hi >> 1) & (__int128)0xffffffffffffffffULL);
+        /* add the signed magnitude */
+        u128 mag = s->dmag;
+        uint64_t m[3] = {(uint64_t)mag, (uint64_t)(mag >> 64), 0};
+        if (s->dneg) { /* two's complement negate over 192 bits */
+            uint64_t carry = 1;
+            for (int i = 0; i < 3; i++) {
+                uint64_t v = ~m[i] + carry;
+                carry = (carry && v == 0) ? 1 : 0;
+                m[i] = v;
+            }
+        }
+        uint64_t carry = 0;
+        for (int i = 0; i < 3; i++) {
+            u128 sum = (u128)t[i] + m[i] + carry;
+            t[i] = (uint64_t)sum;
+            carry = (uint64_t)(sum >> 64);
+        }
+    }
+    const int neg = (t[2] >> 63) != 0;
+    if (neg) {
+        uint64_t carry = 1;
+        for (int i = 0; i < 3; i++) {
+            uint64_t v = ~t[i] + carry;
+            carry = (carry && v == 0) ? 1 : 0;
+            t[i] = v;
+        }
+    }
+    /* magnitude / count with remainder, limb by limb from the top */
+    const uint64_t d = (uint64_t)count;
+    uint64_t q[3];
+    u128 rem = 0;
+    for (int i = 2; i >= 0; i--) {
+        const u128 cur = (rem << 64) | t[i];
+        q[i] = (uint64_t)(cur / d);
+        rem = cur % d;
+    }
+    if ((u128)rem * 2 >= (u128)d) { /* half up on the magnitude */
+        for (int i = 0; i < 3; i++) {
+            if (++q[i] != 0) break;
+        }
+    }
+    if (q[2] != 0 || (q[1] >> 63)) {
+        return 0;
+    }
+    const u128 mag = ((u128)q[1] << 64) | q[0];
+    *out = neg ? -(__int128)mag : (__int128)mag;
+    return 1;
+}
 
 struct orc_hash_agg {
     pa_hash_aggregation_desc desc;
@@ -1107,6 +1343,7 @@ static orc_val builder_get(const col_builder* b, int32_t pos)
         case PA_DOUBLE: v.d = ((double*)b->values)[pos]; break;
         case PA_REAL: v.d = (double)((float*)b->values)[pos]; break;
         case PA_BOOLEAN: v.i = b->values[pos]; break;
+        case PA_DECIMAL: v.i = ((int64_t*)b->values)[pos]; v.q = v.i; break;
         case PA_VARCHAR:
             v.s = b->values + b->offsets[pos];
             v.slen = b->offsets[pos + 1] - b->offsets[pos];
@@ -1363,6 +1600,10 @@ static void accumulate(orc_hash_agg* a, int32_t k, const pa_page* page, const in
                 if (v.type == PA_DOUBLE) {
                     s->dsum = s->dsum + v.d;
                 }
+                else if (type_is_decimal(v.type)) { /* DecimalSumAggregation.combine / DecimalAverageAggregation.combine (the flat
+                                                      * state carries no overflow count: a partial sum that had one was refused) */
+                    s->overflow += ld_add_with_overflow(s, v.q);
+                }
                 else {
                     int64_t r;
                     if (__builtin_add_overflow(s->lsum, v.i, &r)) {
@@ -1394,7 +1635,10 @@ static void accumulate(orc_hash_agg* a, int32_t k, const pa_page* page, const in
                 break;
             case PA_AGG_SUM:
                 s->count++;
-                if (type_is_fp(v.type)) { /* DoubleSumAggregation.java:33-38; RealSumAggregation.java:36-41: the REAL sum's state is a
+                if (type_is_decimal(v.type)) { /* DecimalSumAggregation.inputShortDecimal / inputLongDecimal (:139-159) */
+                    s->overflow += ld_add_with_overflow(s, v.q);
+                }
+                else if (type_is_fp(v.type)) { /* DoubleSumAggregation.java:33-38; RealSumAggregation.java:36-41: the REAL sum's state is a
                                            * double, every input widened */
                     s->dsum = s->dsum + v.d;
                 }
@@ -1409,6 +1653,10 @@ static void accumulate(orc_hash_agg* a, int32_t k, const pa_page* page, const in
                 break;
             case PA_AGG_AVG: /* AverageAggregations.java:34-46 */
                 s->count++;
+                if (type_is_decimal(v.type)) { /* DecimalAverageAggregation.inputShortDecimal / inputLongDecimal (:153-177) */
+                    s->overflow += ld_add_with_overflow(s, v.q);
+                    break;
+                }
                 s->dsum = s->dsum + (type_is_fp(v.type) ? v.d : (double)v.i); /* (RealAverageAggregation.input: double sum of widened floats) */
                 break;
             case PA_AGG_MIN:
@@ -1541,17 +1789,26 @@ int32_t orc_hash_agg_build_result(orc_hash_agg* a, pa_page* out)
             /* Step.PARTIAL: the states themselves, flattened: [count BIGINT] (+ [sum DOUBLE | BIGINT]) */
             int value_double = ag->fn == PA_AGG_AVG || type_is_fp(ag->input_type); /* REAL sums / averages: NullableDoubleState / DoubleState */
             int min_max = ag->fn == PA_AGG_MIN || ag->fn == PA_AGG_MAX;
+            /* sum / avg over DECIMAL: [count BIGINT, sum DECIMAL(38, s)] -- the flat form of LongDecimalWithOverflow(AndLong)State; a sum
+             * whose overflow counter is not zero, or that reached 10^38, does not fit it (NUMERIC_VALUE_OUT_OF_RANGE) */
+            int decimal_sum = !min_max && type_is_decimal(ag->input_type) && (ag->fn == PA_AGG_SUM || ag->fn == PA_AGG_AVG);
             for (int part = 0; part < ((ag->fn == PA_AGG_COUNT || ag->fn == PA_AGG_COUNT_STAR) ? 1 : 2); part++) {
                 col_builder b;
                 /* min / max: [count BIGINT, value of the input type (NULL while no value was seen)] */
-                cb_init(&b, part == 0 ? PA_BIGINT : (min_max ? ag->input_type : (value_double ? PA_DOUBLE : PA_BIGINT)), groups);
+                cb_init(&b, part == 0 ? PA_BIGINT : (decimal_sum ? PA_LONG_DECIMAL : (min_max ? ag->input_type : (value_double ? PA_DOUBLE : PA_BIGINT))), groups);
                 for (int32_t g = 0; g < groups; g++) {
                     orc_val v;
                     memset(&v, 0, sizeof v);
                     v.type = b.type;
                     if (part == 0) v.i = st[g].count;
                     else if (min_max && !st[g].has_value) v.is_null = 1;
-                    else { v.d = st[g].dsum; v.i = st[g].lsum; v.s = st[g].str; v.slen = st[g].slen; }
+                    else if (decimal_sum) {
+                        v.q = st[g].dneg ? -(__int128)st[g].dmag : (__int128)st[g].dmag;
+                        if (st[g].overflow != 0 || ld_overflows(v.q)) {
+                            a->error = PA_ERR_NUMERIC_VALUE_OUT_OF_RANGE;
+                        }
+                    }
+                    else { v.d = st[g].dsum; v.i = st[g].lsum; v.q = st[g].lsum; v.s = st[g].str; v.slen = st[g].slen; }
                     cb_append(&b, &v);
                 }
                 cb_finish(&b, &out->columns[c++]);
@@ -1562,7 +1819,8 @@ int32_t orc_hash_agg_build_result(orc_hash_agg* a, pa_page* out)
         switch (ag->fn) {
             case PA_AGG_COUNT_STAR:
             case PA_AGG_COUNT: out_type = PA_BIGINT; break;
-            case PA_AGG_AVG: out_type = ag->input_type == PA_REAL ? PA_REAL : PA_DOUBLE; break; /* RealAverageAggregation.output writes a REAL */
+            case PA_AGG_AVG: out_type = ag->input_type == PA_REAL ? PA_REAL : (type_is_decimal(ag->input_type) ? ag->input_type : PA_DOUBLE); break; /* RealAverageAggregation.output writes a REAL; avg(DECIMAL(p, s)) is a DECIMAL(p, s) */
+            case PA_AGG_SUM: out_type = type_is_decimal(ag->input_type) ? PA_LONG_DECIMAL : ag->input_type; break; /* sum(DECIMAL(p, s)) is a DECIMAL(38, s) */
             default: out_type = ag->input_type; break;
         }
         col_builder b;
@@ -1579,22 +1837,36 @@ int32_t orc_hash_agg_build_result(orc_hash_agg* a, pa_page* out)
                     break;
                 case PA_AGG_SUM:
                     if (s->count == 0) v.is_null = 1;
+                    else if (type_is_decimal(ag->input_type)) { /* DecimalSumAggregation.outputLongDecimal (:177-190) */
+                        v.q = s->dneg ? -(__int128)s->dmag : (__int128)s->dmag;
+                        if (s->overflow != 0 || ld_overflows(v.q)) a->error = PA_ERR_NUMERIC_VALUE_OUT_OF_RANGE;
+                    }
                     else if (type_is_fp(out_type)) v.d = out_type == PA_REAL ? (double)(float)s->dsum : s->dsum; /* RealSumAggregation.output: (float) sum */
                     else v.i = s->lsum;
                     break;
                 case PA_AGG_AVG:
                     if (s->count == 0) v.is_null = 1;
+                    else if (type_is_decimal(ag->input_type)) { /* DecimalAverageAggregation.outputShortDecimal / outputLongDecimal */
+                        if (!ld_average(s, s->count, &v.q) || (out_type == PA_DECIMAL && (v.q > INT64_MAX || v.q < INT64_MIN)) ||
+                            (out_type == PA_LONG_DECIMAL && ld_overflows(v.q))) {
+                            a->error = PA_ERR_NUMERIC_VALUE_OUT_OF_RANGE;
+                        }
+                        v.i = (int64_t)v.q;
+                    }
                     else if (out_type == PA_REAL) v.d = (double)(float)(s->dsum / (double)s->count); /* RealAverageAggregation.java:150-158 */
                     else v.d = s->dsum / (double)s->count;
                     break;
                 default:
                     if (!s->has_value) v.is_null = 1;
-                    else { v.d = s->dsum; v.i = s->lsum; v.s = s->str; v.slen = s->slen; }
+                    else { v.d = s->dsum; v.i = s->lsum; v.q = s->lsum; v.s = s->str; v.slen = s->slen; }
                     break;
             }
             cb_append(&b, &v);
         }
         cb_finish(&b, &out->columns[c++]);
+    }
+    if (a->error) {
+        return fail(a->error, "Decimal overflow");
     }
     return 1;
 }
@@ -2324,4 +2596,33 @@ int32_t orc_topn_double_desc_bigint_asc(const double* values, const int64_t* key
     memcpy(out_positions, heap, sizeof(int32_t) * (size_t)size);
     free(heap);
     return size;
+}
+
+/* =====================================================================================
+ * Known-answer hooks of the DECIMAL accumulator states: TestDecimalSumAggregation / TestDecimalAverageAggregation look INSIDE the
+ * state (LongDecimalWithOverflowState.getOverflow / getLongDecimal) after every input, which the operator surface does not show.
+ * values: n long decimals in the reference's 16-byte layout, added in order to an empty state (inputLongDecimal); *overflow, state
+ * (16 bytes) = the state afterwards; *average (16 bytes, when non-NULL) = DecimalAverageAggregation.average at scale 0.
+ * ===================================================================================== */
+int32_t orc_decimal_state_after(const uint8_t* values, int32_t n, int64_t* overflow, uint8_t* state, uint8_t* average)
+{
+    acc_state s;
+    memset(&s, 0, sizeof s);
+    for (int32_t i = 0; i < n; i++) {
+        s.overflow += ld_add_with_overflow(&s, ld_read(values + 16 * (size_t)i));
+        s.count++;
+    }
+    *overflow = s.overflow;
+    /* the Slice itself: magnitude + sign bit (zero may be negative: -2^126 + -2^126 leaves "-0" with one underflow) */
+    uint64_t lo = (uint64_t)s.dmag, hi = (uint64_t)(s.dmag >> 64) | (s.dneg ? 0x8000000000000000ULL : 0);
+    memcpy(state, &lo, 8);
+    memcpy(state + 8, &hi, 8);
+    if (average) {
+        __int128 avg = 0;
+        if (n == 0 || !ld_average(&s, s.count, &avg)) {
+            return fail(PA_ERR_NUMERIC_VALUE_OUT_OF_RANGE, "average does not fit");
+        }
+        ld_write(average, avg);
+    }
+    return 0;
 }

@@ -103,6 +103,10 @@ int32_t orc_q1_add(orc_hash_agg* agg, const uint8_t* returnflag, const int32_t* 
 int32_t orc_sort_positions_bigint(const int64_t* keys, int32_t n, int32_t* positions);
 int32_t orc_topn_double_desc_bigint_asc(const double* values, const int64_t* keys, int64_t n, int32_t limit, int32_t* out_positions);
 
+/* ---- DECIMAL accumulator state after adding n long decimals (16-byte reference layout) in order: the known-answer hook of
+ *      TestDecimalSumAggregation / TestDecimalAverageAggregation, which look inside the state ---- */
+int32_t orc_decimal_state_after(const uint8_t* values, int32_t n, int64_t* overflow, uint8_t* state, uint8_t* average);
+
 #ifdef __cplusplus
 }
 #endif

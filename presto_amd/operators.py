@@ -128,8 +128,16 @@ def device_page_from_c(cpage, owner=None):
 
 
 # ---- descriptors -----------------------------------------------------------------------------------
+def _params_of(input_types, type_params):
+    """DECIMAL channels carry PA_DECIMAL_PARAM(precision, scale) as their type parameter (abi.DecimalType knows it)."""
+    if type_params is None and any(isinstance(t, abi.DecimalType) for t in input_types):
+        return [abi.type_param(t) for t in input_types]
+    return type_params
+
+
 def _filter_project_desc(input_types, filter_expr, projections, output_mem, stream, type_params=None):
     keep = []
+    type_params = _params_of(input_types, type_params)
     d = abi.pa_filter_project_desc()
     types = abi.int32_array(input_types)
     d.input_channel_count = len(input_types)
@@ -165,6 +173,7 @@ def _aggregates(aggregates):
 def _hash_agg_desc(input_types, group_by_channels, aggregates, hash_channel, expected_groups, output_mem, stream,
                    type_params=None, step=abi.STEP_SINGLE, max_partial_memory=0, state_format=abi.STATES_FLAT):
     keep = []
+    type_params = _params_of(input_types, type_params)
     d = abi.pa_hash_aggregation_desc()
     types = abi.int32_array(input_types)
     gb = abi.int32_array(group_by_channels)
