@@ -64,13 +64,16 @@ typedef enum pa_type {
                       * (DecimalOperators.java: operands rescaled to the result scale the planner derived; a result of more than 18
                       * digits is a PA_LONG_DECIMAL value), comparisons / BETWEEN / IN between operands of one type, negation, CAST
                       * from INTEGER / BIGINT / a decimal of smaller scale.  Aggregates: sum (-> DECIMAL(38, s), DecimalSumAggregation),
-                      * avg (-> the input type, DecimalAverageAggregation: sum / count rounded half up), min / max / count.  Group /
-                      * join / sort / partition key: as the long it is (ShortDecimalType: hash code = the value, == and < of longs) */
+                      * avg (-> the input type, DecimalAverageAggregation: sum / count rounded half up), min / max / count.  Group key
+                      * of an aggregation: yes (ShortDecimalType: == of longs; $hashvalue = the value itself).  Join / sort keys and
+                      * payload channels of joins, sorts and exchanges: declare the channel PA_BIGINT -- the same LongArrayBlock, the same
+                      * == and < -- ; as the PARTITION key of an exchange it is not supported (its hash differs from BIGINT's) */
     PA_LONG_DECIMAL = 9 /* LongDecimalType (.../type/LongDecimalType.java, UnscaledDecimal128Arithmetic.java): DECIMAL(p, s), 18 < p <= 38 --
                       * 16 B per position, little endian: the low 64 bits of the magnitude, then the high 63 bits with the SIGN in the
                       * top bit (sign-magnitude, as the reference's Slice holds it).  On the device path: a value inside expressions
                       * (products and sums of short decimals), the result of sum / avg over decimals, the sum half of their PARTIAL
-                      * state, an input of sum / avg / count.  Not a key, not a comparison operand (PA_ERR_NOT_SUPPORTED) */
+                      * state, an input of sum / avg / count, an operand of comparisons with its own type.  Not a key, not a min / max
+                      * input, not divided or rescaled down (PA_ERR_NOT_SUPPORTED) */
 } pa_type;
 #define PA_DECIMAL_PARAM(precision, scale) (((precision) << 8) | (scale))
 #define PA_DECIMAL_PRECISION(param) (((param) >> 8) & 0xff)
@@ -716,6 +719,12 @@ int32_t pa_tpch_generate(int32_t column, double scale_factor, int64_t first_row,
  * variant: -1 default, 0 GLOBAL (no keys), 1 LDS (few groups), 2 GT (HBM table). */
 int64_t pa_codegen_fused(const pa_fused_aggregation_desc* desc, int32_t variant, char* buf, int64_t buf_size, char* key);
 int64_t pa_codegen_compile_fused(const pa_fused_aggregation_desc* desc, int32_t variant);
+/* the same for ANY column-layout signature and every tier: nullable_channels = bit c set when input channel c carries a valueIsNull
+ * array (kernels are generated per signature); variant 0 GLOBAL, 1 LDS (register key table), 2 GT (HBM table), 3 LDSH (LDS table per
+ * workgroup), 4 the hash-partition pass, 5 LDSP (partition-owned LDS tables).  buf may be NULL; compile != 0 also compiles the unit with
+ * hiprtc for gfx950 and returns the code-object size instead of the source size.  PA_ERR_NOT_SUPPORTED: the tier does not take the shape */
+int64_t pa_codegen_fused_layout(const pa_fused_aggregation_desc* desc, int32_t variant, uint64_t nullable_channels, int32_t compile, char* buf,
+                                int64_t buf_size);
 /* the one-kernel form of a fused join-aggregation over a lookup source shaped as `build` describes (variant: -1 default,
  * 0 GLOBAL, 1 LDS, 2 GT, 3 LDS table per workgroup, 6 BROW = accumulators indexed by build position) */
 int64_t pa_codegen_fused_join(const pa_fused_join_aggregation_desc* desc, const pa_hash_builder_desc* build, int32_t variant, char* buf, int64_t buf_size);

@@ -970,6 +970,24 @@ int64_t pa_codegen_fused(const pa_fused_aggregation_desc* desc, int32_t variant,
     return rc < 0 ? rc : need;
 }
 
+int64_t pa_codegen_fused_layout(const pa_fused_aggregation_desc* desc, int32_t variant, uint64_t nullable_channels, int32_t compile, char* buf,
+                                int64_t buf_size)
+{
+    int64_t need = 0;
+    int32_t rc = guarded([&]() -> int32_t {
+        std::string src = fused_source_for_layout(desc, variant, nullable_channels);
+        if (compile) {
+            need = (int64_t)jit_compile_only(src).size();
+            return PA_OK;
+        }
+        std::string tu = jit_translation_unit(src);
+        need = (int64_t)tu.size() + 1;
+        if (buf && buf_size >= need) memcpy(buf, tu.c_str(), (size_t)need);
+        return PA_OK;
+    });
+    return rc < 0 ? rc : need;
+}
+
 // Compiles a fused descriptor's kernel with hiprtc for gfx950 (no device needed); returns the code
 // object size or a negative status.
 int64_t pa_codegen_compile_fused(const pa_fused_aggregation_desc* desc, int32_t variant)

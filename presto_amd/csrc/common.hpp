@@ -39,8 +39,11 @@ void set_last_error(const std::string& msg);
 inline int type_width(int32_t t)
 {
     switch (t) {
+        case PA_LONG_DECIMAL:
+            return 16;
         case PA_BIGINT:
         case PA_DOUBLE:
+        case PA_DECIMAL:
             return 8;
         case PA_INTEGER:
         case PA_DATE:

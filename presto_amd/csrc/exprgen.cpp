@@ -54,6 +54,7 @@ std::string OwnedExpr::fingerprint() const
         const pa_expr_node& n = nodes[id];
         s << n.kind << ':' << n.op << ':' << n.type << ':' << n.channel << ':' << n.is_null << ':' << n.nargs << ':'
           << n.i64 << ':' << double_literal(n.f64) << ':' << strings[id].size() << ':' << strings[id] << ';';
+        if (n.type == PA_DECIMAL || n.type == PA_LONG_DECIMAL) s << 'p' << n.type_param << ';';
         for (int32_t k = 0; k < n.nargs; k++) stack.push_back(args[n.first_arg + k]);
     }
     return s.str();
@@ -96,6 +97,8 @@ std::string RowCodegen::ctype(int32_t type)
             return "bool";
         case PA_VARCHAR:
             return "const u8*";
+        case PA_LONG_DECIMAL:
+            return "i128";
         default:
             return "i64";
     }
@@ -119,11 +122,28 @@ std::string RowCodegen::or_nulls(const std::vector<std::string>& ns)
 }
 
 static bool is_int_type(int32_t t) { return t == PA_BIGINT || t == PA_INTEGER || t == PA_DATE; }
+static bool is_decimal_type(int32_t t) { return t == PA_DECIMAL || t == PA_LONG_DECIMAL; }
+
+// 10^k as an expression of the generated code: an i64 literal up to 10^18, an i128 from its halves beyond
+static std::string pow10_literal(int k, bool wide)
+{
+    unsigned __int128 v = 1;
+    for (int i = 0; i < k; i++) v *= 10;
+    char buf[96];
+    if (!wide && k <= 18) {
+        snprintf(buf, sizeof buf, "%" PRId64 "LL", (int64_t)v);
+        return buf;
+    }
+    snprintf(buf, sizeof buf, "pa_i128_of(0x%" PRIx64 "ULL, 0x%" PRIx64 "ULL)", (uint64_t)(v >> 64), (uint64_t)v);
+    return buf;
+}
 
 bool RowCodegen::can_throw(const OwnedExpr& e, int32_t id) const
 {
     const pa_expr_node& n = e.node(id);
     if (n.kind == PA_EXPR_CALL && is_int_type(n.type) && n.op <= PA_OP_NEGATE) return true;
+    // long decimal arithmetic raises NUMERIC_VALUE_OUT_OF_RANGE at 10^38, casts to a decimal check their precision
+    if (n.kind == PA_EXPR_CALL && ((n.type == PA_LONG_DECIMAL && n.op <= PA_OP_NEGATE) || (is_decimal_type(n.type) && n.op == PA_OP_CAST))) return true;
     const int32_t* a = e.node_args(id);
     for (int32_t k = 0; k < n.nargs; k++) {
         if (can_throw(e, a[k])) return true;
@@ -158,6 +178,13 @@ GenValue RowCodegen::emit_compare(int32_t op, const GenValue& a, const GenValue&
         }
         return r;
     }
+    if (is_decimal_type(a.type) || is_decimal_type(b.type)) {
+        // operands of ONE decimal type (the planner casts them): the unscaled values compare (ShortDecimalType / LongDecimalType operators)
+        PA_REQUIRE(a.type == b.type && PA_DECIMAL_SCALE(a.param) == PA_DECIMAL_SCALE(b.param), PA_ERR_NOT_SUPPORTED,
+                   "comparison between decimals of different types needs an explicit CAST");
+        out << "bool " << r.v << " = (" << a.v << " " << s << " " << b.v << ");\n";
+        return r;
+    }
     bool ad = a.type == PA_DOUBLE, bd = b.type == PA_DOUBLE;
     PA_REQUIRE(ad == bd, PA_ERR_NOT_SUPPORTED, "comparison between DOUBLE and non-DOUBLE needs an explicit CAST");
     // RealOperators' comparisons are Java float comparisons (RealOperators.java: intBitsToFloat(left) < intBitsToFloat(right) ...)
@@ -177,6 +204,9 @@ GenValue RowCodegen::emit_node(const OwnedExpr& e, int32_t id, std::ostringstrea
             PA_REQUIRE(n.channel >= 0 && n.channel < (int32_t)channels_.size(), PA_ERR_INVALID_ARGUMENT, "input channel out of range");
             const ChannelLayout& c = channels_[n.channel];
             r.type = c.type;
+            r.param = is_decimal_type(c.type) ? n.type_param : 0;
+            PA_REQUIRE(!is_decimal_type(c.type) || (n.type == c.type && n.type_param != 0), PA_ERR_INVALID_ARGUMENT,
+                       "a DECIMAL input reference carries its type parameter (precision, scale)");
             r.v = "c" + std::to_string(n.channel);
             if (c.type == PA_VARCHAR) r.len = "cl" + std::to_string(n.channel);
             r.n = c.nullable ? "cn" + std::to_string(n.channel) : "false";
@@ -198,7 +228,17 @@ GenValue RowCodegen::emit_node(const OwnedExpr& e, int32_t id, std::ostringstrea
                     r.v = bytes_literal(e.strings[id]);
                     r.len = std::to_string(e.strings[id].size());
                     break;
+                case PA_LONG_DECIMAL: {  // two's complement halves: low in i64, high in the bits of f64
+                    uint64_t hi = 0;
+                    memcpy(&hi, &n.f64, 8);
+                    char buf[96];
+                    snprintf(buf, sizeof buf, "pa_i128_of(0x%" PRIx64 "ULL, 0x%" PRIx64 "ULL)", n.is_null ? (uint64_t)0 : hi, n.is_null ? (uint64_t)0 : (uint64_t)n.i64);
+                    r.v = buf;
+                    r.param = n.type_param;
+                    break;
+                }
                 default: {
+                    if (n.type == PA_DECIMAL) r.param = n.type_param;
                     char buf[40];
                     int64_t v = n.is_null ? 0 : n.i64;
                     if (v == INT64_MIN) snprintf(buf, sizeof buf, "(-9223372036854775807LL - 1)");
@@ -225,6 +265,26 @@ GenValue RowCodegen::emit_node(const OwnedExpr& e, int32_t id, std::ostringstrea
             if (n.op == PA_OP_CAST) {
                 GenValue x = emit_node(e, a[0], out);
                 r.n = x.n;
+                if (is_decimal_type(n.type) && (is_decimal_type(x.type) || is_int_type(x.type))) {
+                    // DecimalCasts (bigint -> decimal: value * 10^scale) / DecimalConversions (decimal -> decimal: rescale, a division
+                    // rounds half up); out of range once the magnitude reaches 10^precision
+                    const int p = PA_DECIMAL_PRECISION(n.type_param), sc = PA_DECIMAL_SCALE(n.type_param);
+                    const int sx = is_decimal_type(x.type) ? PA_DECIMAL_SCALE(x.param) : 0;
+                    PA_REQUIRE(p >= 1 && p <= 38 && sc <= p, PA_ERR_INVALID_ARGUMENT, "CAST to a DECIMAL without its type parameter");
+                    r.param = n.type_param;
+                    r.v = fresh("t");
+                    const std::string guard = r.nullable() ? "(" + r.n + ") ? (i128)0 : " : "";
+                    std::string wide;
+                    if (sc >= sx) wide = "pa_dec_mul((i128)" + x.v + ", " + pow10_literal(sc - sx, true) + ", " + err_ + ")";
+                    else {
+                        PA_REQUIRE(x.type != PA_LONG_DECIMAL && sx - sc <= 18, PA_ERR_NOT_SUPPORTED, "rescaling a long decimal down is not on the device path");
+                        wide = "(i128)pa_dec_div_round(" + x.v + ", " + pow10_literal(sx - sc, false) + ")";
+                    }
+                    out << "const i128 " << r.v << "w = " << guard << "pa_dec_check_bound(" << wide << ", " << pow10_literal(p, true) << ", " << err_ << ");\n";
+                    if (n.type == PA_DECIMAL) out << "const i64 " << r.v << " = (i64)" << r.v << "w;\n";
+                    else out << "const i128 " << r.v << " = " << r.v << "w;\n";
+                    return r;
+                }
                 if (n.type == PA_DOUBLE && is_int_type(x.type)) r.v = "((double)" + x.v + ")";
                 // RealOperators.castToDouble (:164-169), DoubleOperators.castToReal, BigintOperators / IntegerOperators.castToReal: Java
                 // widening / narrowing primitive conversions = the C conversions (round to nearest even)
@@ -250,6 +310,43 @@ GenValue RowCodegen::emit_node(const OwnedExpr& e, int32_t id, std::ostringstrea
             }
             r.n = or_nulls({x.n, y.n});
             r.v = fresh("t");
+            if (is_decimal_type(n.type)) {
+                // DecimalOperators: add / subtract rescale both operands to the result scale, multiply multiplies the unscaled values;
+                // a result of at most 18 digits is long arithmetic (the derived precision cannot overflow it), a long result raises
+                // NUMERIC_VALUE_OUT_OF_RANGE once its magnitude reaches 10^38
+                PA_REQUIRE(is_decimal_type(x.type) && (n.op == PA_OP_NEGATE || is_decimal_type(y.type)), PA_ERR_NOT_SUPPORTED,
+                           "mixed DECIMAL / other arithmetic needs an explicit CAST");
+                PA_REQUIRE(n.op == PA_OP_ADD || n.op == PA_OP_SUBTRACT || n.op == PA_OP_MULTIPLY || n.op == PA_OP_NEGATE, PA_ERR_NOT_SUPPORTED,
+                           "DECIMAL division / modulus are not on the device path");
+                PA_REQUIRE(n.type_param != 0, PA_ERR_INVALID_ARGUMENT, "a DECIMAL expression node carries its type parameter (precision, scale)");
+                r.param = n.type_param;
+                const int sr = PA_DECIMAL_SCALE(n.type_param), sx = PA_DECIMAL_SCALE(x.param), sy = PA_DECIMAL_SCALE(y.param);
+                const bool wide = n.type == PA_LONG_DECIMAL;
+                const std::string T = wide ? "i128" : "i64";
+                const std::string guard = r.nullable() ? "(" + r.n + ") ? (" + T + ")0 : " : "";
+                std::string val;
+                if (n.op == PA_OP_NEGATE) val = "-(" + x.v + ")";
+                else if (n.op == PA_OP_MULTIPLY) {
+                    PA_REQUIRE(sr == sx + sy, PA_ERR_INVALID_ARGUMENT, "DECIMAL multiply: the result scale is the sum of the operand scales");
+                    val = wide ? "pa_dec_check38(pa_dec_mul((i128)" + x.v + ", (i128)" + y.v + ", " + err_ + "), " + err_ + ")" : "(" + x.v + " * " + y.v + ")";
+                }
+                else {
+                    PA_REQUIRE(sr >= sx && sr >= sy, PA_ERR_INVALID_ARGUMENT, "DECIMAL add / subtract: the result scale is the larger operand scale");
+                    if (wide) {
+                        const std::string xs = sr == sx ? "(i128)" + x.v : "pa_dec_mul((i128)" + x.v + ", " + pow10_literal(sr - sx, true) + ", " + err_ + ")";
+                        const std::string ys = sr == sy ? "(i128)" + y.v : "pa_dec_mul((i128)" + y.v + ", " + pow10_literal(sr - sy, true) + ", " + err_ + ")";
+                        val = std::string("pa_dec_check38(") + (n.op == PA_OP_ADD ? "pa_dec_add(" : "pa_dec_sub(") + xs + ", " + ys + ", " + err_ + "), " + err_ + ")";
+                    }
+                    else {
+                        PA_REQUIRE(x.type == PA_DECIMAL && y.type == PA_DECIMAL, PA_ERR_INVALID_ARGUMENT, "a short DECIMAL result has short operands");
+                        const std::string xs = sr == sx ? x.v : "(" + x.v + " * " + pow10_literal(sr - sx, false) + ")";
+                        const std::string ys = sr == sy ? y.v : "(" + y.v + " * " + pow10_literal(sr - sy, false) + ")";
+                        val = "(" + xs + (n.op == PA_OP_ADD ? " + " : " - ") + ys + ")";
+                    }
+                }
+                out << "const " << T << " " << r.v << " = " << guard << val << ";\n";
+                return r;
+            }
             if (n.type == PA_DOUBLE) {
                 PA_REQUIRE(x.type == PA_DOUBLE, PA_ERR_NOT_SUPPORTED, "DOUBLE arithmetic on non-DOUBLE operands");
                 // DoubleOperators.java:59-110; kept as separate statements, compiled with -ffp-contract=off
@@ -401,6 +498,7 @@ GenValue RowCodegen::emit_node(const OwnedExpr& e, int32_t id, std::ostringstrea
                     out << v << " = " << y.v << "; " << nn << " = " << y.n << ";\n}\n";
                     r.v = v;
                     r.n = nn;
+                    r.param = is_decimal_type(n.type) ? n.type_param : 0;
                     return r;
                 }
                 case PA_FORM_COALESCE: {
@@ -415,6 +513,7 @@ GenValue RowCodegen::emit_node(const OwnedExpr& e, int32_t id, std::ostringstrea
                     }
                     r.v = v;
                     r.n = nn;
+                    r.param = is_decimal_type(n.type) ? n.type_param : 0;
                     return r;
                 }
                 case PA_FORM_IN: {

@@ -44,6 +44,7 @@ struct GenValue {
     std::string len;   // VARCHAR only
     std::string n;     // "false" when statically non-null
     int32_t type = PA_BIGINT;
+    int32_t param = 0;  // DECIMAL types: PA_DECIMAL_PARAM(precision, scale) of the value's type
     bool nullable() const { return n != "false"; }
 };
 

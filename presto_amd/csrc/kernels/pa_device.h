@@ -766,6 +766,85 @@ __device__ __forceinline__ void pa_gt_add_i64_exact(u64* words, u64 idx, i64 v, 
 }
 
 // ---------------------------------------------------------------------------------------------
+// DECIMAL (ShortDecimalType: an unscaled i64; LongDecimalType: 16 bytes, the low 64 bits of the magnitude then the high 63
+// bits with the sign in the top bit -- UnscaledDecimal128Arithmetic.java).  Inside expressions a long decimal is a two's
+// complement i128; no 128-bit division happens on the device.
+// ---------------------------------------------------------------------------------------------
+typedef __int128 i128;
+typedef unsigned __int128 u128;
+__device__ __forceinline__ i128 pa_i128_of(u64 hi, u64 lo) { return (i128)(((u128)hi << 64) | (u128)lo); }
+__device__ __forceinline__ i128 pa_ld_from(i64 lo, i64 hi)   // the block's two longs -> value
+{
+    const u128 mag = ((u128)((u64)hi & 0x7fffffffffffffffULL) << 64) | (u128)(u64)lo;
+    return hi < 0 ? -(i128)mag : (i128)mag;
+}
+__device__ __forceinline__ i128 pa_ld_read(const u64* p) { return pa_ld_from((i64)p[0], (i64)p[1]); }
+__device__ __forceinline__ void pa_ld_write(u64* p, i128 v)
+{
+    const u128 mag = v < 0 ? (u128)(-v) : (u128)v;
+    p[0] = (u64)mag;
+    p[1] = (u64)(mag >> 64) | (v < 0 ? 0x8000000000000000ULL : 0ULL);
+}
+// 10^38 = 0x4B3B4CA85A86C47A_098A224000000000
+__device__ __forceinline__ i128 pa_ten38() { return pa_i128_of(0x4B3B4CA85A86C47AULL, 0x098A224000000000ULL); }
+// UnscaledDecimal128Arithmetic.throwIfOverflows: a magnitude of 10^38 or more
+__device__ __forceinline__ i128 pa_dec_check38(i128 v, i32* err)
+{
+    if (v >= pa_ten38() || v <= -pa_ten38()) pa_raise(err, PA_DEV_ERR_OUT_OF_RANGE);
+    return v;
+}
+// |v| < bound (10^precision) or NUMERIC_VALUE_OUT_OF_RANGE: casts to DECIMAL(p, s)
+__device__ __forceinline__ i128 pa_dec_check_bound(i128 v, i128 bound, i32* err)
+{
+    if (v >= bound || v <= -bound) pa_raise(err, PA_DEV_ERR_OUT_OF_RANGE);
+    return v;
+}
+// a * b, NUMERIC_VALUE_OUT_OF_RANGE when the product does not fit 127 bits (the caller then checks 10^38): 64-bit limbs, no
+// compiler-rt (__muloti4 does not exist on the device)
+__device__ __forceinline__ i128 pa_dec_mul(i128 a, i128 b, i32* err)
+{
+    const bool neg = (a < 0) != (b < 0);
+    const u128 x = a < 0 ? (u128)(-a) : (u128)a, y = b < 0 ? (u128)(-b) : (u128)b;
+    const u64 x0 = (u64)x, x1 = (u64)(x >> 64), y0 = (u64)y, y1 = (u64)(y >> 64);
+    bool ovf = x1 != 0 && y1 != 0;
+    const u128 low = (u128)x0 * y0;
+    const u128 c1 = (u128)x1 * y0, c2 = (u128)x0 * y1;
+    ovf = ovf || (c1 >> 64) != 0 || (c2 >> 64) != 0;
+    const u128 cross = (u128)(u64)c1 + (u128)(u64)c2 + (low >> 64);
+    ovf = ovf || (cross >> 63) != 0;
+    const u128 mag = (cross << 64) | (u128)(u64)low;
+    if (ovf) pa_raise(err, PA_DEV_ERR_OUT_OF_RANGE);
+    return neg ? -(i128)mag : (i128)mag;
+}
+__device__ __forceinline__ i128 pa_dec_add(i128 a, i128 b, i32* err)
+{
+    i128 r;
+    if (__builtin_add_overflow(a, b, &r)) pa_raise(err, PA_DEV_ERR_OUT_OF_RANGE);
+    return r;
+}
+__device__ __forceinline__ i128 pa_dec_sub(i128 a, i128 b, i32* err)
+{
+    i128 r;
+    if (__builtin_sub_overflow(a, b, &r)) pa_raise(err, PA_DEV_ERR_OUT_OF_RANGE);
+    return r;
+}
+// x / d rounded half up (away from zero), d > 0: rescaling a SHORT decimal to a smaller scale (DecimalConversions)
+__device__ __forceinline__ i64 pa_dec_div_round(i64 x, i64 d)
+{
+    const i64 q = x / d, r = x % d, half = d / 2;
+    return q + (r >= half && d > 1 ? 1 : (r <= -half && d > 1 ? -1 : 0));
+}
+// Limb k of a decimal value for the sum accumulators: 30 bits per limb, the top limb signed.  A sum of decimals is kept as
+// independent i64 sums of the limbs (every word of a group's state is then an ordinary integer sum: merges, folds, replicas and
+// PARTIAL states treat it like any other), exact for 2^33 rows per group; the value is put together again at output.
+#define PA_DEC_LIMB_BITS 30
+__device__ __forceinline__ i64 pa_dec_limb(i128 v, int k, int last)
+{
+    const i128 s = v >> (PA_DEC_LIMB_BITS * k);
+    return k == last ? (i64)s : (i64)((u64)s & ((1ULL << PA_DEC_LIMB_BITS) - 1ULL));
+}
+
+// ---------------------------------------------------------------------------------------------
 // workgroup (256 threads) exclusive scan of small per-thread counts: wave shuffles + LDS
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ i32 pa_block_exclusive_scan_256(i32 v, i32* total)

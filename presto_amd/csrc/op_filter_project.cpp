@@ -299,8 +299,15 @@ FpKernelInfo generate_fp(const FpSpec& s, const std::vector<ChannelLayout>& layo
             GenValue v = gen.emit(e, body);
             const char* ct = nullptr;
             std::string val = v.v;
+            if (e.root_type() == PA_LONG_DECIMAL) {  // 16 bytes per position in the reference's layout; NULL rows store zero
+                body << "pa_ld_write((u64*)a.out_v[" << j << "] + 2 * (i64)rank, " << (v.nullable() ? "(" + v.n + ") ? (i128)0 : " : "") << val << ");\n";
+                if (v.nullable()) body << "a.out_nl[" << j << "][rank] = (" << v.n << ") ? (u8)1 : (u8)0;\n";
+                k.proj_nullable.push_back(v.nullable());
+                continue;
+            }
             switch (e.root_type()) {
-                case PA_BIGINT: ct = "i64"; break;
+                case PA_BIGINT:
+                case PA_DECIMAL: ct = "i64"; break;
                 case PA_INTEGER:
                 case PA_DATE: ct = "i32"; val = "(i32)" + val; break;
                 case PA_DOUBLE: ct = "double"; break;

@@ -35,6 +35,7 @@
 #include <mutex>
 #include <sstream>
 
+#include "decimal_host.hpp"
 #include "exchange_kernels.hpp"
 #include "exprgen.hpp"
 #include "host_hash.hpp"
@@ -179,6 +180,9 @@ struct KernelInfo {
     uint64_t occ_empty = 0;
     std::vector<int32_t> word_kind;
     std::vector<std::pair<int, int>> agg_words;  // per aggregate: (count word, value word or -1)
+    // per aggregate: > 0 for sum / avg over a DECIMAL -- the value is kept as that many limb words from agg_words[k].second on
+    // (pa_dec_limb: independent integer sums, put together at output: decimal_host.hpp)
+    std::vector<int> agg_limbs;
     std::vector<KeyPart> keys;
     // identity of the state layout (key packing + meaning of every accumulator word): states are only ever merged,
     // folded or emitted under the layout they were accumulated with
@@ -343,13 +347,17 @@ Spec make_spec(const pa_filter_project_desc& fp, const pa_hash_aggregation_desc&
             if (a.fn == PA_AGG_SUM || a.fn == PA_AGG_AVG) {
                 PA_REQUIRE(a.input_channel + 1 < fp.projection_count, PA_ERR_INVALID_ARGUMENT, "FINAL step: missing sum state channel");
                 int32_t t = s.proj[a.input_channel + 1].root_type();
-                PA_REQUIRE(t == PA_DOUBLE || (a.fn == PA_AGG_SUM && t == PA_BIGINT), PA_ERR_INVALID_ARGUMENT, "FINAL step: bad sum state type");
+                PA_REQUIRE(t == PA_DOUBLE || (a.fn == PA_AGG_SUM && t == PA_BIGINT) || t == PA_LONG_DECIMAL, PA_ERR_INVALID_ARGUMENT, "FINAL step: bad sum state type");
+                // (sum / avg over DECIMAL: the state's sum is a DECIMAL(38, s); pa_aggregate.input_type names the aggregate's RESULT type)
+                PA_REQUIRE(t != PA_LONG_DECIMAL || a.input_type == PA_DECIMAL || a.input_type == PA_LONG_DECIMAL, PA_ERR_INVALID_ARGUMENT,
+                           "FINAL step over a DECIMAL sum state: input_type is the aggregate's result type");
             }
         }
         else if (a.fn != PA_AGG_COUNT_STAR) {
             int32_t t = s.proj[a.input_channel].root_type();
             const bool min_max = a.fn == PA_AGG_MIN || a.fn == PA_AGG_MAX;
-            PA_REQUIRE(a.fn == PA_AGG_COUNT || t == PA_DOUBLE || t == PA_REAL || t == PA_BIGINT || t == PA_INTEGER || (min_max && (t == PA_DATE || t == PA_BOOLEAN || t == PA_VARCHAR)),
+            PA_REQUIRE(a.fn == PA_AGG_COUNT || t == PA_DOUBLE || t == PA_REAL || t == PA_BIGINT || t == PA_INTEGER || t == PA_DECIMAL ||
+                           (!min_max && t == PA_LONG_DECIMAL) || (min_max && (t == PA_DATE || t == PA_BOOLEAN || t == PA_VARCHAR)),
                        PA_ERR_NOT_SUPPORTED, "aggregate input type not supported on device");
         }
         s.aggs.push_back(a);
@@ -546,6 +554,7 @@ KernelInfo generate(const Spec& s, const std::vector<ChannelLayout>& layout, int
         std::string value;  // u64 expression already confined to `bits` bits
         switch (kv.type) {
             case PA_BIGINT:
+            case PA_DECIMAL:  // ShortDecimalType: equal values are equal longs
                 part.bits = 64;
                 value = "(u64)" + kv.v;
                 break;
@@ -631,6 +640,7 @@ KernelInfo generate(const Spec& s, const std::vector<ChannelLayout>& layout, int
         switch (x.type) {
             case PA_BIGINT:
             case PA_INTEGER:
+            case PA_DECIMAL:  // ShortDecimalType's comparison is the longs' (one scale)
             case PA_DATE: img = "pa_img_i64((i64)" + x.v + ")"; break;
             case PA_DOUBLE: img = "pa_img_f64(" + x.v + ")"; break;
             case PA_REAL: img = "pa_img_f64((double)" + x.v + ")"; break;  // (float order = order of the widened values)
@@ -652,6 +662,18 @@ KernelInfo generate(const Spec& s, const std::vector<ChannelLayout>& layout, int
             if (ag.fn == PA_AGG_SUM || ag.fn == PA_AGG_AVG) {
                 const GenValue& v = proj_value(ag.input_channel + 1);
                 std::string vcond = v.nullable() ? "(" + ccond + " && !" + v.n + ")" : ccond;
+                if (v.type == PA_LONG_DECIMAL) {  // the sum half of a DECIMAL state: limbs again (combine = add)
+                    const int limbs = decimal_limbs_for_bits(128);
+                    for (int l = 0; l < limbs; l++) {
+                        const int w = word(W_SUMI, vcond, "pa_dec_limb(" + v.v + ", " + std::to_string(l) + ", " + std::to_string(limbs - 1) + ")", "fdec" + std::to_string(l) + "|" + ch);
+                        if (l == 0) vw = w;
+                        PA_REQUIRE(w == vw + l, PA_ERR_NOT_SUPPORTED, "internal: the limb words of a DECIMAL sum are not adjacent");
+                    }
+                    k.agg_words.emplace_back(cw, vw);
+                    k.agg_limbs.resize(k.agg_words.size(), 0);
+                    k.agg_limbs.back() = limbs;
+                    continue;
+                }
                 vw = word(v.type == PA_DOUBLE ? W_SUMF : W_SUMI, vcond, v.v, "fsum|" + ch);
             }
             else if (ag.fn == PA_AGG_MIN || ag.fn == PA_AGG_MAX) {
@@ -688,6 +710,22 @@ KernelInfo generate(const Spec& s, const std::vector<ChannelLayout>& layout, int
                                     (ag.fn == PA_AGG_SUM || ag.fn == PA_AGG_MIN || ag.fn == PA_AGG_MAX);
         int cw = implicit_count ? -1 : word(W_CNT, ccond, "1", cntkey);
         int vw = -1;
+        if ((ag.fn == PA_AGG_SUM || ag.fn == PA_AGG_AVG) && (x.type == PA_DECIMAL || x.type == PA_LONG_DECIMAL)) {
+            // DecimalSumAggregation / DecimalAverageAggregation: the exact sum as limb words, shared between sum(x) and avg(x)
+            // (as many limbs as the TYPE's precision needs: |x| < 10^p by the planner's type derivation; the top limb is signed and
+            // takes whatever is left of a value that breaks it, up to 63 bits)
+            const int limbs = decimal_limbs_for_bits(std::min(x.type == PA_DECIMAL ? 64 : 128, decimal_bits_for_precision(PA_DECIMAL_PRECISION(x.param))));
+            for (int l = 0; l < limbs; l++) {
+                const int w = word(W_SUMI, ccond, "pa_dec_limb((i128)" + x.v + ", " + std::to_string(l) + ", " + std::to_string(limbs - 1) + ")",
+                                   "dec" + std::to_string(l) + "/" + std::to_string(limbs) + "|" + xkey + "|" + ckey);
+                if (l == 0) vw = w;
+                PA_REQUIRE(w == vw + l, PA_ERR_NOT_SUPPORTED, "internal: the limb words of a DECIMAL sum are not adjacent");
+            }
+            k.agg_words.emplace_back(cw, vw);
+            k.agg_limbs.resize(k.agg_words.size(), 0);
+            k.agg_limbs.back() = limbs;
+            continue;
+        }
         // (REAL inputs: RealSumAggregation / RealAverageAggregation keep a DOUBLE sum of the widened floats -- the same accumulator
         // words as for DOUBLE; the output functions narrow the result)
         if (ag.fn == PA_AGG_SUM && x.type != PA_DOUBLE && x.type != PA_REAL) {
@@ -703,6 +741,7 @@ KernelInfo generate(const Spec& s, const std::vector<ChannelLayout>& layout, int
         k.agg_words.emplace_back(cw, vw);
     }
     k.nw = (int)words.size();
+    k.agg_limbs.resize(k.agg_words.size(), 0);
     PA_REQUIRE(k.nw > 0 || k.w > 0, PA_ERR_INVALID_ARGUMENT, "aggregation without aggregates and keys");
     if (k.nw == 0) {  // DISTINCT-style group by without aggregates: keep a row count so the kernels stay uniform
         words.push_back({W_CNT, "true", "1"});
@@ -3018,7 +3057,12 @@ bool FusedAggregationOperator::emit_on_device(const KernelInfo& ki, int64_t grou
     const bool partial = out_partial_;
     if (groups < kMinGroups || groups > INT32_MAX) return false;
     for (int gi = 0; gi < nkeys; gi++) {
-        if (ki.keys[gi].type == PA_VARCHAR) return false;
+        if (ki.keys[gi].type == PA_VARCHAR || ki.keys[gi].type == PA_DECIMAL) return false;  // (DECIMAL keys: their hash is the value itself)
+    }
+    for (size_t k = 0; k < spec_.aggs.size(); k++) {
+        if (ki.agg_limbs[k] > 0) return false;  // DECIMAL sums are put together on the host (decimal_host.hpp)
+        const int value_proj = spec_.step == PA_STEP_FINAL ? spec_.aggs[k].input_channel + 1 : spec_.aggs[k].input_channel;
+        if (spec_.aggs[k].fn != PA_AGG_COUNT_STAR && spec_.proj[value_proj].root_type() == PA_DECIMAL && (spec_.aggs[k].fn == PA_AGG_MIN || spec_.aggs[k].fn == PA_AGG_MAX)) return false;
     }
     if (keys_from_build_columns && (has_hash || !spec_.join || spec_.join->brow_group_proj.size() != (size_t)nkeys)) return false;
     GtEmitArgs a{};
@@ -3304,10 +3348,11 @@ void FusedAggregationOperator::build_output()
             }
             uint64_t w0 = (kw[kp.word] >> kp.shift) & mask;
             switch (kp.type) {
-                case PA_BIGINT: {
+                case PA_BIGINT:
+                case PA_DECIMAL: {
                     int64_t v = is_null ? 0 : (int64_t)w0;
                     data.insert(data.end(), (uint8_t*)&v, (uint8_t*)&v + 8);
-                    if (!is_null) h = host_hash_bigint(v);
+                    if (!is_null) h = kp.type == PA_DECIMAL ? v : host_hash_bigint(v);  // ShortDecimalType.hashCodeOperator: the value
                     break;
                 }
                 case PA_INTEGER:
@@ -3433,6 +3478,55 @@ void FusedAggregationOperator::build_output()
                     continue;
                 }
                 memcpy(&data[(size_t)g * width], &bits, (size_t)width);  // little endian: the low bytes are the narrower value
+            }
+            oc.has_nulls = any_null;
+            col++;
+            continue;
+        }
+        if (ki.agg_limbs[k] > 0) {
+            // sum / avg over DECIMAL: the limb sums -> the exact total.  SINGLE / FINAL: sum is a DECIMAL(38, s) -- NUMERIC_VALUE_OUT_OF_RANGE
+            // at 10^38 (DecimalSumAggregation.outputLongDecimal) --, avg the total / count rounded half up in the input's type
+            // (DecimalAverageAggregation.average); PARTIAL: [count BIGINT, sum DECIMAL(38, s)]
+            const int limbs = ki.agg_limbs[k];
+            if (partial) {
+                OutColumn& cc = out_cols_[col];
+                cc.type = PA_BIGINT;
+                host_nulls[col].assign(groups ? groups : 1, 0);
+                host_cols[col].resize((size_t)groups * 8);
+                const uint64_t one = 1;
+                for (int64_t g = 0; g < groups; g++) memcpy(&host_cols[col][(size_t)g * 8], cw >= 0 ? &words[(size_t)g * nw_ + cw] : &one, 8);
+                cc.has_nulls = false;
+                col++;
+            }
+            const int value_proj = spec_.step == PA_STEP_FINAL ? ag.input_channel + 1 : ag.input_channel;
+            const int32_t in_type = spec_.step == PA_STEP_FINAL ? ag.input_type : spec_.proj[value_proj].root_type();
+            OutColumn& oc = out_cols_[col];
+            oc.type = (partial || ag.fn == PA_AGG_SUM) ? PA_LONG_DECIMAL : in_type;
+            const int width = type_width(oc.type);
+            auto& data = host_cols[col];
+            auto& nulls = host_nulls[col];
+            nulls.assign(groups ? groups : 1, 0);
+            data.assign((size_t)groups * width, 0);
+            bool any_null = false;
+            for (int64_t g = 0; g < groups; g++) {
+                const uint64_t* ww = &words[(size_t)g * nw_];
+                const int64_t count = cw >= 0 ? (int64_t)ww[cw] : 1;
+                if (count == 0 && !partial) {
+                    nulls[g] = 1;
+                    any_null = true;
+                    continue;
+                }
+                Wide192 total = decimal_total(ww, vw, limbs);
+                if (!partial && ag.fn == PA_AGG_AVG) total = decimal_average(total, count);
+                bool neg = false;
+                unsigned __int128 mag = 0;
+                const unsigned __int128 bound = oc.type == PA_DECIMAL ? ((unsigned __int128)1 << 63) : kTen38;
+                PA_REQUIRE(decimal_fits(total, bound, &neg, &mag), PA_ERR_NUMERIC_VALUE_OUT_OF_RANGE, "Decimal overflow");
+                if (oc.type == PA_DECIMAL) {
+                    const int64_t v = neg ? -(int64_t)(uint64_t)mag : (int64_t)(uint64_t)mag;
+                    memcpy(&data[(size_t)g * 8], &v, 8);
+                }
+                else long_decimal_store(&data[(size_t)g * 16], neg, mag);
             }
             oc.has_nulls = any_null;
             col++;
@@ -3656,6 +3750,20 @@ std::string fused_source_for_desc(const pa_fused_aggregation_desc* desc, int var
     KernelInfo k = generate(s, layout, variant);
     if (entry) *entry = k.entry;
     return k.source;
+}
+
+std::string fused_source_for_layout(const pa_fused_aggregation_desc* desc, int variant, uint64_t nullable_channels)
+{
+    PA_REQUIRE(desc != nullptr, PA_ERR_INVALID_ARGUMENT, "descriptor is null");
+    Spec s = make_spec(desc);
+    std::vector<ChannelLayout> layout(s.n_in);
+    for (int c = 0; c < s.n_in; c++) {
+        layout[c].type = s.in_types[c];
+        layout[c].nullable = c < 64 && ((nullable_channels >> c) & 1ULL) != 0;
+    }
+    PA_REQUIRE(variant >= V_GLOBAL && variant <= V_LDSP, PA_ERR_INVALID_ARGUMENT, "variant out of range");
+    PA_REQUIRE(variant == V_GLOBAL ? s.group_proj.empty() : !s.group_proj.empty(), PA_ERR_INVALID_ARGUMENT, "variant does not match the descriptor");
+    return generate(s, layout, variant).source;
 }
 
 }  // namespace pa

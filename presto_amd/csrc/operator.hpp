@@ -88,6 +88,8 @@ void page_buffer_free(pa_page_buffer* buffer);
 // code-object source for a fused descriptor under the "no nulls, aligned" layout; used by build() to
 // pre-compile the TPC-H shapes and by the CPU-side codegen tests
 std::string fused_source_for_desc(const pa_fused_aggregation_desc* desc, int variant, std::string* entry);
+// ... under any nullability signature (bit c: channel c carries NULL flags) and for every tier
+std::string fused_source_for_layout(const pa_fused_aggregation_desc* desc, int variant, uint64_t nullable_channels);
 void lookup_source_shape_for_desc(const pa_hash_builder_desc* build, pa_lookup_source* bridge);
 std::string filter_project_probe_source_for_desc(const pa_fused_join_desc* desc, const pa_hash_builder_desc* build);
 std::string fused_join_source_for_desc(const pa_fused_join_aggregation_desc* desc, const pa_hash_builder_desc* build, int variant, std::string* entry);

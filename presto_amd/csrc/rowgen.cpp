@@ -55,9 +55,16 @@ void emit_vector_loads(const RowInputs& s, const std::vector<ChannelLayout>& lay
         std::string C = std::to_string(c);
         switch (layout[c].type) {
             case PA_BIGINT:
+            case PA_DECIMAL:  // ShortDecimalType: a LongArrayBlock of unscaled values
                 o << "        pa_i64x2 A" << C << " = ((const pa_i64x2*)a.v[" << C << "])[2 * q], B" << C << " = ((const pa_i64x2*)a.v[" << C
                   << "])[2 * q + 1];\n";
                 for (int r = 0; r < 4; r++) args[r] += ", " + std::string(r < 2 ? "A" : "B") + C + "." + xyzw[r & 1];
+                break;
+            case PA_LONG_DECIMAL:  // 16 bytes per position: one 16-byte load per row
+                for (int r = 0; r < 4; r++) {
+                    o << "        pa_i64x2 L" << C << r << " = ((const pa_i64x2*)a.v[" << C << "])[4 * q + " << r << "];\n";
+                    args[r] += ", pa_ld_from(L" + C + std::to_string(r) + ".x, L" + C + std::to_string(r) + ".y)";
+                }
                 break;
             case PA_DOUBLE:
                 o << "        pa_f64x2 A" << C << " = ((const pa_f64x2*)a.v[" << C << "])[2 * q], B" << C << " = ((const pa_f64x2*)a.v[" << C
@@ -129,7 +136,9 @@ std::string scalar_args(const RowInputs& s, const std::vector<ChannelLayout>& la
         if (!s.used[c]) continue;
         std::string C = std::to_string(c);
         switch (layout[c].type) {
-            case PA_BIGINT: a += ", ((const i64*)a.v[" + C + "])[r]"; break;
+            case PA_BIGINT:
+            case PA_DECIMAL: a += ", ((const i64*)a.v[" + C + "])[r]"; break;
+            case PA_LONG_DECIMAL: a += ", pa_ld_read((const u64*)a.v[" + C + "] + 2 * r)"; break;
             case PA_DOUBLE: a += ", ((const double*)a.v[" + C + "])[r]"; break;
             case PA_INTEGER:
             case PA_DATE: a += ", (i64)((const i32*)a.v[" + C + "])[r]"; break;

@@ -219,7 +219,12 @@ def partial_layout(key_types, aggregates):
         fn, in_type = a[0], a[2]
         first = len(types)
         types.append(abi.BIGINT)
-        if fn in (abi.AGG_SUM, abi.AGG_AVG):
+        if fn in (abi.AGG_SUM, abi.AGG_AVG) and in_type in (abi.DECIMAL, abi.LONG_DECIMAL):
+            # sum / avg over DECIMAL(p, s): [count, sum DECIMAL(38, s)]; the FINAL aggregate's input_type names its RESULT type
+            scale = in_type.scale if isinstance(in_type, abi.DecimalType) else 0
+            types.append(abi.decimal(38, scale))
+            final.append((fn, first, abi.decimal(38, scale) if fn == abi.AGG_SUM else in_type))
+        elif fn in (abi.AGG_SUM, abi.AGG_AVG):
             value_type = abi.DOUBLE if (fn == abi.AGG_AVG or in_type in (abi.DOUBLE, abi.REAL)) else abi.BIGINT
             types.append(value_type)
             # (sum / avg over REAL: a DOUBLE state; the FINAL step narrows its result, so it keeps the input type)

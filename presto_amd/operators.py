@@ -820,8 +820,10 @@ def download_page(page):
             total = int(off[n]) if n else 0
             vals = download(b.values, np.uint8, total) if total else np.zeros(1, np.uint8)
             blocks.append(Block(b.type, abi.VARWIDTH, n, values=vals, offsets=off, nulls=nulls))
+        elif b.type == abi.LONG_DECIMAL:
+            blocks.append(Block(b.type, abi.FLAT, n, values=download(b.values, np.uint64, 2 * n).reshape(n, 2), nulls=nulls))
         else:
             dt = {abi.BIGINT: np.int64, abi.INTEGER: np.int32, abi.DATE: np.int32, abi.DOUBLE: np.float64,
-                  abi.BOOLEAN: np.uint8, abi.REAL: np.float32}[b.type]
+                  abi.BOOLEAN: np.uint8, abi.REAL: np.float32, abi.DECIMAL: np.int64}[b.type]
             blocks.append(Block(b.type, abi.FLAT, n, values=download(b.values, dt, n), nulls=nulls))
     return Page(blocks, n, abi.MEM_HOST)

@@ -170,3 +170,40 @@ def customer_rows(scale_factor):
 
 def orders_rows(scale_factor):
     return int(ORDERS_ROWS_PER_SF * scale_factor)
+
+
+# ---- Q6 / Q1 over DECIMAL(12, 2) money and quantity columns (the types TPC-H gives them; DOUBLE above is what the reference's
+#      tpch connector produces by default, TpchMetadata.java:587-603) -------------------------------------------------------------
+DEC = abi.decimal(12, 2)
+Q6_DECIMAL_TYPES = [abi.DATE, DEC, DEC, DEC]
+Q1_DECIMAL_TYPES = [abi.VARCHAR, abi.VARCHAR, DEC, DEC, DEC, DEC, abi.DATE]
+
+
+def q6_decimal_filter():
+    shipdate, discount, quantity = field(0, abi.DATE), field(1, DEC), field(2, DEC)
+    return and_(shipdate >= constant(8766, abi.DATE), shipdate < constant(9131, abi.DATE),
+                discount >= constant(5, DEC), discount <= constant(7, DEC),        # 0.05, 0.07 as DECIMAL(12, 2)
+                quantity < constant(2400, DEC))                                    # 24
+
+
+def q6_decimal_projections():
+    return [field(3, DEC) * field(1, DEC)]      # extendedprice * discount: DECIMAL(24, 4)
+
+
+def q6_decimal_aggregates():
+    return [(abi.AGG_SUM, 0, q6_decimal_projections()[0].type)]
+
+
+def q1_decimal_projections():
+    rf, ls = field(0, abi.VARCHAR), field(1, abi.VARCHAR)
+    qty, price, disc, tax = (field(c, DEC) for c in (2, 3, 4, 5))
+    one = constant(1, abi.decimal(10, 0))   # the INTEGER literal 1 coerced to DECIMAL(10, 0)
+    disc_price = price * (one - disc)       # DECIMAL(25, 4)
+    charge = disc_price * (one + tax)       # DECIMAL(38, 6)
+    return [rf, ls, qty, price, disc_price, charge, disc]
+
+
+def q1_decimal_aggregates():
+    p = q1_decimal_projections()
+    return [(abi.AGG_SUM, 2, p[2].type), (abi.AGG_SUM, 3, p[3].type), (abi.AGG_SUM, 4, p[4].type), (abi.AGG_SUM, 5, p[5].type),
+            (abi.AGG_AVG, 2, p[2].type), (abi.AGG_AVG, 3, p[3].type), (abi.AGG_AVG, 6, p[6].type), (abi.AGG_COUNT_STAR, -1, None)]
