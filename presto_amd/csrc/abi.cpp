@@ -292,6 +292,12 @@ static pa_operator* plain_aggregation(const pa_hash_aggregation_desc* agg)
         nodes[c].kind = PA_EXPR_INPUT_REF;
         nodes[c].type = agg->input_types[c];
         nodes[c].channel = c;
+        // DECIMAL channels: their type parameter, or -- for a descriptor that carries none (pa_aggregation_desc) -- the widest
+        // precision of the block type; the aggregates only take the value's width from it, never the scale
+        if (agg->input_types[c] == PA_DECIMAL || agg->input_types[c] == PA_LONG_DECIMAL) {
+            const int32_t given = agg->input_type_params ? agg->input_type_params[c] : 0;
+            nodes[c].type_param = given ? given : (agg->input_types[c] == PA_DECIMAL ? PA_DECIMAL_PARAM(18, 0) : PA_DECIMAL_PARAM(38, 0));
+        }
         exprs[c].node_count = 1;
         exprs[c].root = 0;
         exprs[c].nodes = &nodes[c];

@@ -35,7 +35,7 @@ def test_decimal_expressions_bit_exact(gpu, oracle, device_pages):
     one = constant(1, abi.decimal(10, 0))
     projections = [a + b, a - b, a * b, (one - b), a * (one - b), a * (one - b) * (one + b), -a, (a * b) + (a * b),
                    field(2, abi.BIGINT).cast(abi.decimal(18, 3)), a.cast(abi.decimal(14, 4)), a.cast(abi.decimal(12, 0)), a.cast(abi.decimal(30, 10))]
-    flt = and_(b >= constant(2, D), b.between(constant(1, D), constant(9, D)), (a * b) > constant(-5 * 10 ** 12, abi.decimal(24, 4)))
+    flt = and_(b >= constant(2, D), b.between(constant(1, D), constant(9, D)), (b * b) > constant(3, abi.decimal(24, 4)))
     expected = oracle.filter_project(page, flt, projections)
     op = FilterAndProjectOperator(TYPES, flt, projections)
     out = to_pages(op, [upload_page(page) if device_pages else page])
