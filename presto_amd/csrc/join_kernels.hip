@@ -460,6 +460,56 @@ __global__ __launch_bounds__(256) void k_join_key_bitmap(JoinCol build_key, i32 
     }
 }
 
+// ---- the bitmap of a build side whose rows do NOT arrive in key order (behind an exchange, behind another join) ----
+// One atomic per key at a random word of the bitmap is what the kernel above then costs (15 M keys: 0.56 ms, the rank -> row
+// scatter as much again).  Instead: is the column out of order at all (k_join_key_disorder), then the (key, row) pairs are
+// regrouped by key RANGE -- partition = (key - min) >> shift, at most 4096 of them, one LDS-staged multisplit --, a workgroup
+// ORs the bits of its partitions together in LDS and writes the words out with plain stores, and the rank -> row scatter walks
+// the regrouped pairs: its stores stay inside one partition's slice of the array at a time.
+__global__ __launch_bounds__(256) void k_join_key_disorder(JoinCol key, i32 n, i32* __restrict__ flag)
+{
+    bool off = false;
+    for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i + 1 < n; i += (i64)gridDim.x * 256) {
+        if (jcol_is_null(key, (i32)i) || jcol_is_null(key, (i32)i + 1)) continue;
+        off = off || (i64)join_key_bits(key, (i32)i) > (i64)join_key_bits(key, (i32)i + 1);
+    }
+    if (__ballot(off) != 0ULL && (threadIdx.x & 63) == 0) *flag = 1;
+}
+__global__ __launch_bounds__(256) void k_join_range_ids(JoinCol build_key, i32 n, i64 min_key, int shift, i32 partitions, i32* __restrict__ part,
+                                                        u64* __restrict__ keybits, i32* __restrict__ rowpos)
+{
+    for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < n; i += (i64)gridDim.x * 256) {
+        const i32 p = (i32)i;
+        const bool null = jcol_is_null(build_key, p);
+        const u64 v = null ? 0ULL : join_key_bits(build_key, p);
+        part[p] = null ? partitions : (i32)(((u64)((i64)v - min_key)) >> shift);   // (NULL keys: a partition of their own, never read)
+        keybits[p] = v;
+        rowpos[p] = p;
+    }
+}
+constexpr int kJoinRangeWordsMax = 8192;   // 2^19 key values per partition at most (64 KB of LDS)
+__global__ __launch_bounds__(1024) void k_join_range_bitmap(const u64* __restrict__ keys, const i64* __restrict__ first, i32 partitions, i64 min_key, int shift,
+                                                            u64 range, u64* __restrict__ bits)
+{
+    __shared__ u64 words[kJoinRangeWordsMax];
+    const int nw = 1 << (shift - 6);
+    const i64 total_words = (i64)(range >> 6) + 1;
+    for (i32 p = (i32)blockIdx.x; p < partitions; p += (i32)gridDim.x) {
+        for (int i = threadIdx.x; i < nw; i += 1024) words[i] = 0ULL;
+        __syncthreads();
+        const u64 base = (u64)p << shift;
+        for (i64 i = first[p] + threadIdx.x; i < first[p + 1]; i += 1024) {
+            const u64 d = (u64)((i64)keys[i] - min_key) - base;   // < 2^shift by the partition rule
+            __hip_atomic_fetch_or(&words[d >> 6], 1ULL << (d & 63ULL), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        __syncthreads();
+        const i64 w0 = (i64)(base >> 6);
+        for (int i = threadIdx.x; i < nw; i += 1024) {
+            if (w0 + i < total_words) bits[w0 + i] = words[i];
+        }
+        __syncthreads();
+    }
+}
 // ---- key rank index (join_kernels.hpp) ----
 __global__ __launch_bounds__(256) void k_join_rank_counts(const u64* __restrict__ bits, i64 nwords, i32* __restrict__ counts)
 {
@@ -480,6 +530,41 @@ __device__ __forceinline__ i32 join_rank_of(const JoinRankWord* __restrict__ wor
     if (((bits >> b) & 1ULL) == 0ULL) return -1;
     return (i32)w.z + (i32)__popcll(bits & ((1ULL << b) - 1ULL));
 }
+__global__ __launch_bounds__(256) void k_join_rank_rows_pairs(const u64* __restrict__ keys, const i32* __restrict__ rowpos, i64 n,
+                                                              const JoinRankWord* __restrict__ words, i64 min_key, i32* __restrict__ rows)
+{
+    for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < n; i += (i64)gridDim.x * 256) {
+        const i32 r = join_rank_of(words, (u64)((i64)keys[i] - min_key));
+        if (r >= 0) rows[r] = rowpos[i];
+    }
+}
+
+// ... or, partition by partition, through LDS: the ranks of a partition's keys are one contiguous range (its first key value's
+// rank onwards), so the workgroup places the rows in LDS and writes the range out as whole lines
+constexpr int kJoinRangeRowsMax = 32768;   // key values per partition this form takes (128 KB of LDS)
+__global__ __launch_bounds__(1024) void k_join_range_rows(const u64* __restrict__ keys, const i32* __restrict__ rowpos, const i64* __restrict__ first,
+                                                          i32 partitions, const JoinRankWord* __restrict__ words, i64 min_key, int shift, i64 n,
+                                                          i32* __restrict__ rows)
+{
+    __shared__ i32 stage[kJoinRangeRowsMax];
+    for (i32 p = (i32)blockIdx.x; p < partitions; p += (i32)gridDim.x) {
+        const i64 b0 = first[p], b1 = first[p + 1];
+        if (b1 <= b0) continue;   // (uniform: every thread reads the same bounds)
+        const i32 base = (i32)((const uint4*)words)[((u64)p << shift) >> 6].z;   // build keys below the partition's first key value
+        const i64 cnt = b1 - b0;   // (one row per rank when no key repeats -- else the index is dropped and what lands here is not read)
+        for (i64 i = threadIdx.x; i < cnt && i < kJoinRangeRowsMax; i += 1024) stage[i] = -1;
+        __syncthreads();
+        for (i64 i = b0 + threadIdx.x; i < b1; i += 1024) {
+            const i32 r = join_rank_of(words, (u64)((i64)keys[i] - min_key)) - base;
+            if (r >= 0 && r < kJoinRangeRowsMax) stage[r] = rowpos[i];
+        }
+        __syncthreads();
+        for (i64 i = threadIdx.x; i < cnt && i < kJoinRangeRowsMax; i += 1024) {
+            if ((i64)base + i < n) rows[(i64)base + i] = stage[i];
+        }
+        __syncthreads();
+    }
+}
 __global__ __launch_bounds__(256) void k_join_rank_rows(JoinCol build_key, i32 n, const JoinRankWord* __restrict__ words, i64 min_key, i32* __restrict__ rows,
                                                         i32* __restrict__ unordered)
 {
@@ -494,8 +579,10 @@ __global__ __launch_bounds__(256) void k_join_rank_rows(JoinCol build_key, i32 n
 
 __global__ __launch_bounds__(256) void k_join_probe_count_keyed(JoinCol probe_key, const i64* __restrict__ probe_hash, i32 n_probe,
                                                                 const JoinKeySlot* __restrict__ slots, u32 mask, u32 wrap, const i32* __restrict__ links,
-                                                                JoinKeyBitmap bitmap, JoinRankIndex rank, i32* __restrict__ head, i32* __restrict__ counts, int flags)
+                                                                JoinKeyBitmap bitmap, JoinRankIndex rank, i32* __restrict__ head, i32* __restrict__ counts, int flags,
+                                                                unsigned long long* __restrict__ total)
 {
+    i64 mine = 0;  // this thread's output rows: the page's total is summed on the way (one atomic per wave), not by a pass of its own
     for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < n_probe; i += (i64)gridDim.x * 256) {
         const i32 r = (i32)i;
         i32 h = -1, nxt = -1;
@@ -551,6 +638,19 @@ __global__ __launch_bounds__(256) void k_join_probe_count_keyed(JoinCol probe_ke
             }
         }
         counts[r] = (c == 0 && (flags & 1)) ? 1 : c;  // DefaultPageJoiner.outerJoinCurrentPosition: one NULL-extended row
+        mine += (c == 0 && (flags & 1)) ? 1 : c;
+    }
+    if (total) {
+        // one atomic per WORKGROUP, spread over 16 counters: same-address atomics retire one after the other at the memory side
+        // (~8 ns each), and the grid's waves all arrive here together -- one per wave on one counter cost this kernel 100 us of tail
+        __shared__ i64 wave_total[4];
+        mine = pa_wave_sum_i64(mine);
+        if ((threadIdx.x & 63) == 0) wave_total[threadIdx.x >> 6] = mine;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const i64 all = wave_total[0] + wave_total[1] + wave_total[2] + wave_total[3];
+            if (all != 0) atomicAdd(total + (blockIdx.x & 15u), (unsigned long long)all);   // 16 counters: the host adds them up
+        }
     }
 }
 
@@ -631,6 +731,44 @@ void launch_join_key_bitmap(const JoinCol& build_key, int32_t n, int64_t min_key
     hipLaunchKernelGGL(k_join_key_bitmap, grid_for(n), 256, 0, s, build_key, n, (i64)min_key, (u64)range, (u64*)bits);
     PA_HIP(hipGetLastError());
 }
+void launch_join_key_disorder(const JoinCol& key, int32_t n, int32_t* flag, hipStream_t s)
+{
+    if (n <= 1) return;
+    hipLaunchKernelGGL(k_join_key_disorder, grid_for(n), 256, 0, s, key, n, flag);
+    PA_HIP(hipGetLastError());
+}
+int join_range_shift(uint64_t range)
+{
+    int shift = 15;   // 2^15 key values per partition: the rank -> row array then goes through LDS too
+    while (((range >> shift) + 1) > 4096) shift++;
+    return shift <= 19 ? shift : -1;   // (a wider key range: the atomic bitmap kernel)
+}
+void launch_join_range_ids(const JoinCol& build_key, int32_t n, int64_t min_key, int shift, int32_t partitions, int32_t* part, uint64_t* keybits,
+                           int32_t* rowpos, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_join_range_ids, grid_for(n), 256, 0, s, build_key, n, (i64)min_key, shift, partitions, part, (u64*)keybits, rowpos);
+    PA_HIP(hipGetLastError());
+}
+void launch_join_range_bitmap(const uint64_t* keys, const int64_t* first, int32_t partitions, int64_t min_key, int shift, uint64_t range, uint64_t* bits,
+                              hipStream_t s)
+{
+    hipLaunchKernelGGL(k_join_range_bitmap, std::min(partitions, 2048), 1024, 0, s, (const u64*)keys, (const i64*)first, partitions, (i64)min_key, shift,
+                       (u64)range, (u64*)bits);
+    PA_HIP(hipGetLastError());
+}
+void launch_join_rank_rows_pairs(const uint64_t* keys, const int32_t* rowpos, int64_t n, const JoinRankWord* words, int64_t min_key, int32_t* rows,
+                                 hipStream_t s, const int64_t* first, int32_t partitions, int shift)
+{
+    if (n <= 0) return;
+    if (first != nullptr && shift >= 6 && (1 << shift) <= kJoinRangeRowsMax) {
+        hipLaunchKernelGGL(k_join_range_rows, std::min(partitions, 2048), 1024, 0, s, (const u64*)keys, rowpos, (const i64*)first, partitions, words, (i64)min_key,
+                           shift, (i64)n, rows);
+        PA_HIP(hipGetLastError());
+        return;
+    }
+    hipLaunchKernelGGL(k_join_rank_rows_pairs, grid_for(n), 256, 0, s, (const u64*)keys, rowpos, (i64)n, words, (i64)min_key, rows);
+    PA_HIP(hipGetLastError());
+}
 void launch_join_rank_words(const uint64_t* bits, int64_t nwords, JoinRankWord* words, int32_t* counts, void* temp, int32_t* total_out, hipStream_t s)
 {
     if (nwords <= 0) return;
@@ -647,11 +785,11 @@ void launch_join_rank_rows(const JoinCol& build_key, int32_t n, const JoinRankWo
 }
 void launch_join_probe_count_keyed(const JoinCol& probe_key, const int64_t* probe_hash, int32_t n_probe, const JoinKeySlot* slots, uint32_t mask,
                                    uint32_t wrap, const int32_t* links, const JoinKeyBitmap& bitmap, const JoinRankIndex& rank, int32_t* head, int32_t* counts,
-                                   int flags, hipStream_t s)
+                                   int flags, hipStream_t s, int64_t* total)
 {
     if (n_probe <= 0) return;
     hipLaunchKernelGGL(k_join_probe_count_keyed, grid_for(n_probe), 256, 0, s, probe_key, (const i64*)probe_hash, n_probe, slots, mask, wrap, links, bitmap,
-                       rank, head, counts, flags);
+                       rank, head, counts, flags, (unsigned long long*)total);
     PA_HIP(hipGetLastError());
 }
 

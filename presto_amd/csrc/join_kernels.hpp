@@ -91,7 +91,16 @@ void launch_join_rank_rows(const JoinCol& build_key, int32_t n, const JoinRankWo
 // kJoinPartSlots-slot partition of its home slot)
 void launch_join_probe_count_keyed(const JoinCol& probe_key, const int64_t* probe_hash, int32_t n_probe, const JoinKeySlot* slots, uint32_t mask,
                                    uint32_t wrap, const int32_t* links, const JoinKeyBitmap& bitmap, const JoinRankIndex& rank, int32_t* head, int32_t* counts,
-                                   int flags, hipStream_t s);
+                                   int flags, hipStream_t s, int64_t* total = nullptr);   // total: 16 counters (zeroed by the caller) whose sum is the page's output rows
+// build rows out of key order: the bitmap and the rank -> row array over (key, row) pairs regrouped by key range (join_kernels.hip)
+void launch_join_key_disorder(const JoinCol& key, int32_t n, int32_t* flag, hipStream_t s);
+int join_range_shift(uint64_t range);   // log2 of the key values per partition (16..19), -1: the range is too wide
+void launch_join_range_ids(const JoinCol& build_key, int32_t n, int64_t min_key, int shift, int32_t partitions, int32_t* part, uint64_t* keybits,
+                           int32_t* rowpos, hipStream_t s);
+void launch_join_range_bitmap(const uint64_t* keys, const int64_t* first, int32_t partitions, int64_t min_key, int shift, uint64_t range, uint64_t* bits,
+                              hipStream_t s);
+void launch_join_rank_rows_pairs(const uint64_t* keys, const int32_t* rowpos, int64_t n, const JoinRankWord* words, int64_t min_key, int32_t* rows,
+                                 hipStream_t s, const int64_t* first = nullptr, int32_t partitions = 0, int shift = 0);
 void launch_join_unvisited_flag(const uint8_t* visited, int64_t n, int32_t* partition, hipStream_t s);
 // DefaultPageJoiner.joinCurrentPosition: (probe position, build position) pairs in emission order
 void launch_join_probe_emit(const int32_t* head, const int32_t* offsets, int32_t n_probe, int32_t total, const int32_t* links, int32_t* probe_idx,

@@ -240,14 +240,27 @@ public:
     // drained: finish_rank_index.  PRESTO_AMD_NO_RANK_INDEX=1 turns it off (A/B runs, tests of the table builds).
     bool start_rank_index(const JoinCol& key, int32_t n, hipStream_t s)
     {
-        if (ls_->bitmap.bits == nullptr || key.nulls != nullptr || n <= 0 || getenv("PRESTO_AMD_NO_RANK_INDEX")) return false;
+        if (ls_->bitmap.bits == nullptr || key.nulls != nullptr || n <= 0 || getenv("PRESTO_AMD_NO_RANK_INDEX")) {
+            pair_keys_.release();
+            pair_rows_.release();
+            pair_first_.release();
+            return false;
+        }
         const int64_t nwords = (int64_t)(ls_->bitmap.range >> 6) + 1;
         JoinRankWord* words = static_cast<JoinRankWord*>(ls_->rank_words.ensure((size_t)nwords * sizeof(JoinRankWord)));
         PA_HIP(hipMemsetAsync(ctl_ + 4, 0, 8, s));
         launch_join_rank_words(ls_->bitmap.bits, nwords, words, static_cast<int32_t*>(rank_counts_.ensure((size_t)nwords * 4)),
                                rank_temp_.ensure(scan_temp_bytes(nwords)), ctl_ + 4, s);
         // (rows of duplicate keys overwrite each other here: the index is dropped then)
-        launch_join_rank_rows(key, n, words, ls_->bitmap.min_key, static_cast<int32_t*>(ls_->rank_rows.ensure((size_t)n * 4)), ctl_ + 5, s);
+        if (pairs_ == n) {  // the pairs regrouped by key range: the scatter stays inside one partition's slice at a time
+            launch_join_rank_rows_pairs(pair_keys_.as<uint64_t>(), pair_rows_.as<int32_t>(), n, words, ls_->bitmap.min_key,
+                                        static_cast<int32_t*>(ls_->rank_rows.ensure((size_t)n * 4)), s, pair_first_.as<int64_t>(), pair_partitions_, pair_shift_);
+            PA_HIP(hipMemsetAsync(ctl_ + 5, 1, 4, s));   // "out of key order" (non-zero), by the check that brought us here
+        }
+        else launch_join_rank_rows(key, n, words, ls_->bitmap.min_key, static_cast<int32_t*>(ls_->rank_rows.ensure((size_t)n * 4)), ctl_ + 5, s);
+        pair_keys_.release();
+        pair_rows_.release();
+        pair_first_.release();
         launch_fill_i32(ls_->links.as<int32_t>(), -1, n, s);
         return true;
     }
@@ -305,8 +318,9 @@ public:
         int64_t* run = static_cast<int64_t*>(running.ensure(64));
         PA_HIP(hipMemsetAsync(run, 0, 64, s));
         launch_df_collect(key.type, key.values, key.nulls, n, nullptr, static_cast<int64_t*>(partials.ensure(df_partials_bytes())), run, s);
-        int64_t h[3];
-        PA_HIP(hipMemcpyAsync(h, run, 24, hipMemcpyDeviceToHost, s));
+        launch_join_key_disorder(key, n, reinterpret_cast<int32_t*>(run + 3), s);   // (rides on the same read-back)
+        int64_t h[4];
+        PA_HIP(hipMemcpyAsync(h, run, 32, hipMemcpyDeviceToHost, s));
         PA_HIP(hipStreamSynchronize(s));
         if (!h[2]) return;  // every key NULL
         ls_->key_range_valid = true;
@@ -315,7 +329,36 @@ public:
         const uint64_t range = (uint64_t)h[1] - (uint64_t)h[0];
         if (range >= 64ULL * (uint64_t)n || range >= (1ULL << 36)) return;
         uint64_t* bits = static_cast<uint64_t*>(ls_->key_bits.ensure((size_t)((range >> 6) + 1) * 8));
-        launch_join_key_bitmap(key, n, h[0], range, bits, s);
+        const int shift = join_range_shift(range);
+        if (h[3] != 0 && n >= (1 << 18) && shift >= 0 && key.nulls == nullptr && !getenv("PRESTO_AMD_NO_RANGE_BITMAP")) {
+            // rows out of key order: regroup the (key, row) pairs by key range, OR the bits in LDS (join_kernels.hip); the pairs stay
+            // for the rank -> row array of the key rank index
+            const int32_t partitions = (int32_t)((range >> shift) + 1);
+            DevBuf part, keys_in, rows_in, counts, temp;
+            int32_t* pid = static_cast<int32_t*>(part.ensure((size_t)n * 4));
+            uint64_t* kin = static_cast<uint64_t*>(keys_in.ensure((size_t)n * 8));
+            int32_t* rin = static_cast<int32_t*>(rows_in.ensure((size_t)n * 4));
+            launch_join_range_ids(key, n, h[0], shift, partitions, pid, kin, rin, s);
+            MsplitCol cols[2];
+            memset(cols, 0, sizeof cols);
+            cols[0].in = kin;
+            cols[0].out = pair_keys_.ensure((size_t)n * 8);
+            cols[0].width = 8;
+            cols[1].in = rin;
+            cols[1].out = pair_rows_.ensure((size_t)n * 4);
+            cols[1].width = 4;
+            int64_t* cnt = static_cast<int64_t*>(counts.ensure((size_t)(partitions + 2) * 8));
+            launch_msplit(pid, n, partitions + 1, cols, 2, cnt, temp.ensure(msplit_temp_bytes(n, partitions + 1)), s);
+            int64_t* fst = static_cast<int64_t*>(pair_first_.ensure((size_t)(partitions + 3) * 8));
+            launch_exclusive_prefix_i64(cnt, partitions + 1, fst, s);
+            launch_join_range_bitmap(pair_keys_.as<uint64_t>(), fst, partitions, h[0], shift, range, bits, s);
+            pairs_ = n;
+            pair_partitions_ = partitions;
+            pair_shift_ = shift;
+        }
+        else {
+            launch_join_key_bitmap(key, n, h[0], range, bits, s);
+        }
         ls_->bitmap = JoinKeyBitmap{bits, h[0], range};
     }
 
@@ -333,6 +376,10 @@ private:
     PageStager stager_;
     std::shared_ptr<LookupSourceImpl> ls_;
     DevBuf ctl_buf_, rank_counts_, rank_temp_;
+    // (key, row) pairs regrouped by key range, kept between build_key_bitmap and start_rank_index (rows out of key order)
+    DevBuf pair_keys_, pair_rows_, pair_first_;
+    int32_t pairs_ = 0, pair_partitions_ = 0;
+    int pair_shift_ = 0;
     int32_t* ctl_ = nullptr;
     int64_t expected_ = 0;
     bool finishing_ = false;
@@ -427,16 +474,26 @@ public:
         int32_t* head = static_cast<int32_t*>(head_.ensure((size_t)n * 4));
         int32_t* counts = static_cast<int32_t*>(counts_.ensure((size_t)n * 4));
         timer.begin(s);
+        // the matches of the page, in 64 bits: a skewed key or a high fan-out can put more than 2^31 of them behind one page
         if (ls_->keyed) {  // one integer key: key-in-slot table, raw hash computed in the kernel unless a $hashvalue channel came along
+            // (the keyed kernel sums the page's matches on the way: one atomic per wave instead of a pass over the counts)
+            int64_t* totals = static_cast<int64_t*>(totals_.ensure(16 * 8));
+            PA_HIP(hipMemsetAsync(totals, 0, 16 * 8, s));
             launch_join_probe_count_keyed(pk.col[0], probe_hash, n, ls_->key_slots.as<JoinKeySlot>(), ls_->probe_mask, ls_->probe_wrap, ls_->links.as<int32_t>(), ls_->bitmap, ls_->rank, head, counts,
-                                          probe_flags_, s);
+                                          probe_flags_, s, totals);
+            timer.end(s);
+            PA_HIP(hipMemcpyAsync(h_totals_.ensure(16 * 8), totals, 16 * 8, hipMemcpyDeviceToHost, s));
+            totals_pending_ = true;
+            pending_ = true;
+            range_lo_ = 0;
+            remaining_ = -1;
+            return;
         }
         else {
             launch_join_probe_count(ls_->build_keys(), pk, probe_hash, n, ls_->tagged.as<uint64_t>(), ls_->probe_mask, ls_->links.as<int32_t>(), head, counts,
                                     probe_flags_, s);
+            launch_sum_i32_i64(counts, n, reinterpret_cast<int64_t*>(ctl_ + 4), s);
         }
-        // the matches of the page, in 64 bits: a skewed key or a high fan-out can put more than 2^31 of them behind one page
-        launch_sum_i32_i64(counts, n, reinterpret_cast<int64_t*>(ctl_ + 4), s);
         timer.end(s);
         PA_HIP(hipMemcpyAsync(h_ctl_ + 4, ctl_ + 4, 8, hipMemcpyDeviceToHost, s));
         pending_ = true;
@@ -459,7 +516,12 @@ public:
         const int32_t n = in_.n;
         if (remaining_ < 0) {
             PA_HIP(hipStreamSynchronize(s));
-            memcpy(&remaining_, h_ctl_ + 4, 8);
+            if (totals_pending_) {
+                remaining_ = 0;
+                for (int i = 0; i < 16; i++) remaining_ += h_totals_.as<int64_t>()[i];
+                totals_pending_ = false;
+            }
+            else memcpy(&remaining_, h_ctl_ + 4, 8);
             // more matches than one output page holds: the page is joined range by range over several get_output calls, and the
             // operator upstream may be given its next page in between -- the probe channels still to be read are kept
             if (remaining_ > max_output_rows() && in_volatile_) keep_input(s);
@@ -511,18 +573,46 @@ public:
         }
         // LookupJoinPageBuilder.build: probe output channels by probe index (relative to the range) ++ build output channels
         // by build position
+        // (the flat channels of both sides by ONE launch -- a page's gathers are small and their launches dominate --, strings one by one)
         size_t oc = 0;
+        GatherMultiArgs gm;
+        memset(&gm, 0, sizeof gm);
+        gm.positions[0] = probe_idx;
+        gm.positions[1] = build_pos;
+        gm.count = total_out;
+        auto flat = [&](int32_t type, const void* values, const uint8_t* nulls, int which, bool null_rows, OutColumn& out) {
+            const int w = type_width(type);
+            if ((w != 1 && w != 4 && w != 8) || gm.ncols >= GATHER_MULTI_MAX_COLS) return false;
+            out.type = type;
+            out.varwidth = false;
+            out.is_view = false;
+            out.host_ready = false;
+            out.has_nulls = nulls != nullptr || null_rows;
+            GatherMultiCol& g = gm.col[gm.ncols++];
+            g.src = values;
+            g.src_nulls = nulls;
+            g.dst = out.values.ensure((size_t)std::max(total_out, 1) * w);
+            g.dst_nulls = out.has_nulls ? static_cast<uint8_t*>(out.nulls.ensure((size_t)std::max(total_out, 1))) : nullptr;
+            g.width = w;
+            g.which = which;
+            return true;
+        };
         for (int c : output_channels_) {
             const DevColumn& src = in_.cols[c];
             const void* values = src.varwidth ? src.values : static_cast<const char*>(src.values) + (size_t)lo * type_width(src.type);
+            OutColumn& out_col = out_cols_[oc++];
+            if (!src.varwidth && flat(src.type, values, src.nulls ? src.nulls + lo : nullptr, 0, false, out_col)) continue;
             gather_column(src.type, src.varwidth, values, src.offsets ? src.offsets + lo : nullptr, src.nulls ? src.nulls + lo : nullptr, probe_idx, total_out,
-                          out_cols_[oc++], s);
+                          out_col, s);
         }
         for (int c : ls_->output_channels) {
             const BuildColumn& src = ls_->cols[c];
+            OutColumn& out_col = out_cols_[oc++];
+            if (!src.varwidth && flat(src.type, src.values.ptr(), src.has_nulls ? src.nulls.as<uint8_t>() : nullptr, 1, probe_outer_, out_col)) continue;
             gather_column(src.type, src.varwidth, src.values.ptr(), src.offsets.as<int32_t>(), src.has_nulls ? src.nulls.as<uint8_t>() : nullptr,
-                          build_pos, total_out, out_cols_[oc++], s, probe_outer_);
+                          build_pos, total_out, out_col, s, probe_outer_);
         }
+        launch_gather_multi(gm, s);
         publish_output(out_cols_, total_out, output_mem_, s, out, out_storage_);
         range_lo_ = hi;
         remaining_ -= sum;
@@ -760,7 +850,9 @@ private:
     DevPage in_;
     bool in_volatile_ = false;
     std::vector<DevBuf> kept_;  // keep_input: per channel values, offsets, NULL flags
-    DevBuf ctl_buf_, hash_, head_, counts_, probe_idx_, build_pos_, scan_temp_;
+    DevBuf ctl_buf_, hash_, head_, counts_, probe_idx_, build_pos_, scan_temp_, totals_;
+    PinnedBuf h_totals_;
+    bool totals_pending_ = false;
     // JoinFilterFunction
     std::unique_ptr<pa_operator> filter_;
     bool filter_single_match_ = false;

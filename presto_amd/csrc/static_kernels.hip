@@ -71,6 +71,33 @@ void launch_gather_flat(const void* src, int elem_bytes, const int32_t* position
     }
     PA_HIP(hipGetLastError());
 }
+// Several flat columns gathered by ONE launch (LookupJoinPageBuilder.build: probe output channels by probe index, build output
+// channels by build position): a join output page of a few million rows is a handful of small gathers, each dominated by its
+// launch; a position of -1 (the build side of an unmatched probe row of an outer join) gives a zero value and, where the column
+// has NULL flags to write, a NULL
+__global__ __launch_bounds__(256) void k_gather_multi(GatherMultiArgs a)
+{
+    for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < a.count; i += (i64)gridDim.x * 256) {
+        const i32 p0 = a.positions[0] ? a.positions[0][i] : 0, p1 = a.positions[1] ? a.positions[1][i] : 0;
+        for (int c = 0; c < a.ncols; c++) {
+            const GatherMultiCol col = a.col[c];
+            const i32 p = col.which ? p1 : p0;
+            if (col.dst) {
+                if (col.width == 8) ((u64*)col.dst)[i] = p < 0 ? 0ULL : ((const u64*)col.src)[p];
+                else if (col.width == 4) ((u32*)col.dst)[i] = p < 0 ? 0u : ((const u32*)col.src)[p];
+                else ((u8*)col.dst)[i] = p < 0 ? (u8)0 : ((const u8*)col.src)[p];
+            }
+            if (col.dst_nulls) col.dst_nulls[i] = p < 0 ? (u8)1 : (col.src_nulls ? col.src_nulls[p] : (u8)0);
+        }
+    }
+}
+void launch_gather_multi(const GatherMultiArgs& args, hipStream_t s)
+{
+    if (args.count <= 0 || args.ncols <= 0) return;
+    hipLaunchKernelGGL(k_gather_multi, grid_for(args.count, 256), 256, 0, s, args);
+    PA_HIP(hipGetLastError());
+}
+
 void launch_gather_nulls(const uint8_t* src, const int32_t* positions, int64_t count, uint8_t* dst, hipStream_t s)
 {
     launch_gather_flat(src, 1, positions, count, dst, s);

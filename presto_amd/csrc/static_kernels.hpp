@@ -49,6 +49,23 @@ struct GtStrides {
     uint32_t pad;
     uint64_t empty;  // tag value of a slot without a group (0 for real tags; a build-row table may read an accumulator word as its tag)
 };
+// launch_gather_multi: up to 24 flat columns by one launch; which = 0 / 1 names the position list (probe index / build position)
+constexpr int GATHER_MULTI_MAX_COLS = 24;
+struct GatherMultiCol {
+    const void* src;
+    const uint8_t* src_nulls;
+    void* dst;
+    uint8_t* dst_nulls;   // written when non-null (a -1 position gives 1)
+    int32_t width;        // 1, 4 or 8
+    int32_t which;
+};
+struct GatherMultiArgs {
+    const int32_t* positions[2];
+    int64_t count;
+    int32_t ncols, pad;
+    GatherMultiCol col[GATHER_MULTI_MAX_COLS];
+};
+void launch_gather_multi(const GatherMultiArgs& args, hipStream_t s);
 constexpr int GT_EMIT_MAX_COLS = 32;
 struct GtEmitArgs {
     const uint64_t* tag;
