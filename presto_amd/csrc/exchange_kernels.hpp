@@ -25,6 +25,37 @@ void launch_copy_segments(CopySeg* segs, size_t n, void* host_table, void* dev_t
 // The same for at most kInlineSegs segments, the table travelling in the kernel arguments: no staging buffer, one launch.
 constexpr int kInlineSegs = 64;
 void launch_copy_segments_inline(CopySeg* segs, int n, hipStream_t s);
+
+// One VariableWidthBlock of a DEVICE page to be appended behind the bytes an arena channel already holds.  Where the block's
+// bytes start (offsets[0]) and how many there are is known on the device only, so the position they land at comes from a
+// byte cursor kept in HBM: the segment starts at *cursor_in (0 when `fresh`) and leaves the cursor behind its bytes in
+// *cursor_out -- two slots used in turn, so that a launch never reads the slot it writes.  The offsets are copied rebased
+// (offsets[k] - offsets[0] + start), rows + 1 entries: the last one is the next block's first.
+struct VarSeg {
+    const char* values;
+    const int32_t* offsets;
+    char* dst_bytes;        // the arena channel's byte buffer ...
+    int64_t capacity;       // ... and its size: a block that does not fit raises PA_ERR_INVALID_ARGUMENT in *err, nothing is written
+    int32_t* dst_offsets;   // the arena channel's offsets + the arena row the block starts at
+    const int64_t* cursor_in;
+    int64_t* cursor_out;
+    int64_t first_wg;       // filled by the launchers
+    int64_t start;          // filled on the device (k_var_plan): byte position of the block in dst_bytes, -1 = refused
+    int32_t rows;
+    int32_t byte_wgs;       // workgroups the block's bytes are strided over (the host's guess of bytes / 64 KB, at least 1)
+    int32_t first;          // filled on the device: offsets[0]
+    int32_t len;            // filled on the device: offsets[rows] - offsets[0]
+    int32_t slot;           // segments of one arena channel share a slot (< kVarSlots) and are appended in table order
+    int32_t fresh;          // the arena channel is empty: the cursor reads as 0
+};
+constexpr int kVarSlots = 16;
+constexpr int kInlineVarSegs = 16;
+// One page's blocks (n <= kInlineVarSegs, distinct slots), the table travelling in the kernel arguments: one launch.
+void launch_var_append_inline(VarSeg* segs, int n, int32_t* err, hipStream_t s);
+// Many pages' blocks in table order: one planning launch (a workgroup: the cursor positions by prefix sums per slot) and
+// one copy launch.  Tables as for launch_copy_segments (copy_var_table_bytes(n) each).
+size_t copy_var_table_bytes(size_t n);
+void launch_var_append(VarSeg* segs, size_t n, void* host_table, void* dev_table, int32_t* err, hipStream_t s);
 // out[i] = i (topn_kernels.hip)
 void launch_iota_i32(int32_t* out, int64_t n, hipStream_t s);
 // dst[i] |= src[r * words + i] for r in [0, reps)

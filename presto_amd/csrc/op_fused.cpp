@@ -1517,6 +1517,7 @@ public:
         if (merge_stream_) pool_stream_release(merge_stream_);  // synchronises it
         for (int b = 0; b < 2; b++) {
             if (arena_[b].table_event) (void)hipEventDestroy(arena_[b].table_event);
+            if (arena_[b].vtable_event) (void)hipEventDestroy(arena_[b].vtable_event);
             if (ev_main_[b]) (void)hipEventDestroy(ev_main_[b]);
             if (ev_merge_[b]) (void)hipEventDestroy(ev_merge_[b]);
         }
@@ -1696,11 +1697,27 @@ public:
             return true;
         }
         if (n >= kSmallPageRows) return false;
-        // VariableWidthBlocks join the arena when their offsets can be read here (host pages): the bytes are appended and the
-        // offsets rebased on the way; a device page's first offset is not known to the host
-        if (!flat && page->mem != PA_MEM_HOST) return false;
+        // VariableWidthBlocks join the arena too: the bytes are appended and the offsets rebased on the way -- by the host's
+        // arithmetic when the offsets can be read here (host pages), by a byte cursor in HBM for device pages, whose first
+        // offset and byte count only the device knows (launch_var_append)
+        if (!flat && page->mem != PA_MEM_HOST && !device_var_gatherable()) return false;
         append_to_arena(page);
         return true;
+    }
+
+    // A device page's VariableWidthBlocks are appended without the host knowing how many bytes they hold: the arena's byte
+    // buffers are sized for the most the declared types allow -- VARCHAR(n), n code points of at most 4 bytes -- which is kept
+    // to 64 bytes per row (n <= 16); unbounded or longer channels get a launch per page as before.
+    static constexpr int64_t kDeviceVarMaxLength = 16;
+    bool device_var_gatherable() const
+    {
+        int slots = 0;
+        for (int c = 0; c < spec_.n_in; c++) {
+            if (!spec_.used_channel[c] || spec_.in_types[c] != PA_VARCHAR) continue;
+            if (spec_.in_params[c] < 1 || spec_.in_params[c] > kDeviceVarMaxLength) return false;
+            slots++;
+        }
+        return slots <= kInlineVarSegs;
     }
 
     // The pending range ends (the next page does not continue it): a small one joins the arena -- one segment-copy launch --
@@ -1708,7 +1725,7 @@ public:
     void retire_run()
     {
         if (run_.rows == 0) return;
-        if (run_.rows >= kSmallPageRows || !run_.flat) {
+        if (run_.rows >= kSmallPageRows || (!run_.flat && !device_var_gatherable())) {
             flush_run();
             return;
         }
@@ -1744,13 +1761,16 @@ public:
         const int64_t n = page->position_count;
         Arena& a = arena_[arena_cur_];
         // the nullability of the arena's channels is fixed by its first page: a page that differs starts the next arena
-        bool fits = a.rows + n <= kArenaRows && a.segs.size() + 3 * (size_t)spec_.n_in <= kArenaMaxSegs;
+        bool fits = a.rows + n <= kArenaRows && a.segs.size() + 3 * (size_t)spec_.n_in <= kArenaMaxSegs && a.vsegs.size() + (size_t)spec_.n_in <= kArenaMaxSegs;
+        // the byte cursor of a VARCHAR channel is either the host's (a.bytes) or the device's: pages of the other kind start the next arena
+        const bool dev_var = page->mem != PA_MEM_HOST;
         for (int c = 0; c < spec_.n_in && fits && a.rows > 0; c++) {
             if (!spec_.used_channel[c]) continue;
             const pa_column& col = page->columns[c];
             fits = a.nullable[c] == (col.nulls != nullptr);
+            if (fits && col.encoding == PA_VARWIDTH) fits = a.dev_var == dev_var;
             // a VARCHAR channel's byte buffer never moves while copies into it are pending
-            if (fits && col.encoding == PA_VARWIDTH && col.offsets != nullptr) {
+            if (fits && col.encoding == PA_VARWIDTH && col.offsets != nullptr && !dev_var) {
                 fits = a.bytes[c] + ((int64_t)col.offsets[n] - col.offsets[0]) <= (int64_t)a.values[c].capacity();
             }
         }
@@ -1768,6 +1788,8 @@ public:
             a.nulls.resize(spec_.n_in);
             a.offsets.resize(spec_.n_in);
             a.bytes.assign(spec_.n_in, 0);
+            a.dev_var = dev_var;
+            a.var_fresh = true;
             for (int c = 0; c < spec_.n_in; c++) {
                 if (!spec_.used_channel[c]) continue;
                 a.nullable[c] = page->columns[c].nulls != nullptr;
@@ -1776,7 +1798,19 @@ public:
             }
         }
         CopySeg now[3 * kMaxChannels];
-        int m = 0;
+        VarSeg vnow[kInlineVarSegs];
+        int m = 0, vm = 0, slot = 0;
+        // the device cursors of this append: read from one half of a.cursors, left in the other (deferred appends of one
+        // arena launch are planned together: launch_var_append takes the first one's input and the last one's output)
+        int64_t* cur_in = nullptr;
+        int64_t* cur_out = nullptr;
+        if (dev_var) {
+            int64_t* cursors = static_cast<int64_t*>(a.cursors.ensure(2 * kVarSlots * sizeof(int64_t)));
+            const bool pending = defer && !a.vsegs.empty();  // a deferred append continues the pending plan: same halves
+            if (!pending) a.cursor_half ^= 1;
+            cur_in = cursors + (a.cursor_half ^ 1) * kVarSlots;
+            cur_out = cursors + a.cursor_half * kVarSlots;
+        }
         auto seg = [&](const void* src, void* dst, int64_t bytes, int32_t add = 0) {
             CopySeg sg{src, dst, bytes, 0};
             sg.add_i32 = add;
@@ -1792,6 +1826,27 @@ public:
                 char* dn = a.nulls[c].as<char>() + a.rows;
                 if (readable) seg(col.nulls, dn, n);
                 else PA_HIP(hipMemcpyAsync(dn, col.nulls, (size_t)n, hipMemcpyHostToDevice, s));
+            }
+            if (col.encoding == PA_VARWIDTH && dev_var) {
+                // device page: where the block's bytes start and how many there are is only known over there
+                PA_REQUIRE(col.offsets != nullptr, PA_ERR_INVALID_ARGUMENT, "VARWIDTH block without offsets");
+                const int64_t row_bytes = 4 * (int64_t)spec_.in_params[c];
+                if (a.rows == 0) a.values[c].ensure((size_t)(row_bytes * kArenaRows));
+                VarSeg vs{};
+                vs.values = static_cast<const char*>(col.values);
+                vs.offsets = col.offsets;
+                vs.dst_bytes = a.values[c].as<char>();
+                vs.capacity = std::min<int64_t>((int64_t)a.values[c].capacity(), ((int64_t)1 << 31) - 1);
+                vs.dst_offsets = static_cast<int32_t*>(a.offsets[c].ensure((size_t)(kArenaRows + 1) * 4)) + a.rows;
+                vs.cursor_in = cur_in + slot;
+                vs.cursor_out = cur_out + slot;
+                vs.rows = (int32_t)n;
+                vs.byte_wgs = (int32_t)std::min<int64_t>(std::max<int64_t>(n * std::min<int64_t>(row_bytes, 16) >> 16, 1), 64);
+                vs.slot = slot++;
+                vs.fresh = a.var_fresh ? 1 : 0;
+                if (defer) a.vsegs.push_back(vs);
+                else vnow[vm++] = vs;
+                continue;
             }
             if (col.encoding == PA_VARWIDTH) {
                 // host page: the offsets are readable here.  bytes behind the arena's bytes, offsets rebased by (cursor - first)
@@ -1831,6 +1886,12 @@ public:
             else PA_HIP(hipMemcpyAsync(dv, col.values, (size_t)n * w, hipMemcpyHostToDevice, s));
         }
         if (m > 0) launch_copy_segments_inline(now, m, s);
+        if (vm > 0) {
+            // (deferred appends recorded before this page come first: the cursor passes through them)
+            flush_var_segments(a);
+            launch_var_append_inline(vnow, vm, ctl_, s);
+        }
+        if (slot > 0) a.var_fresh = false;
         a.rows += n;
         if (a.rows >= kArenaRows) flush_pending();
     }
@@ -1841,6 +1902,20 @@ public:
         if (next_) next_->flush_pending();
         flush_arena();
         flush_run();
+    }
+
+    // the deferred VariableWidthBlock appends of an arena: one planning launch and one copy launch for all of them
+    template <typename ArenaT> void flush_var_segments(ArenaT& a)
+    {
+        if (a.vsegs.empty()) return;
+        hipStream_t s = stream_.get();
+        if (a.vtable_used) PA_HIP(hipEventSynchronize(a.vtable_event));
+        else PA_HIP(hipEventCreateWithFlags(&a.vtable_event, hipEventDisableTiming));
+        a.vtable_used = true;
+        launch_var_append(a.vsegs.data(), a.vsegs.size(), a.h_vtable.ensure(copy_var_table_bytes(a.vsegs.size())),
+                          a.d_vtable.ensure(copy_var_table_bytes(a.vsegs.size())), ctl_, s);
+        PA_HIP(hipEventRecord(a.vtable_event, s));
+        a.vsegs.clear();
     }
 
     void flush_arena()
@@ -1859,6 +1934,7 @@ public:
             PA_HIP(hipEventRecord(a.table_event, s));
             a.segs.clear();
         }
+        flush_var_segments(a);
         std::vector<pa_column> cols((size_t)spec_.n_in);
         for (int c = 0; c < spec_.n_in; c++) {
             cols[c].type = spec_.in_types[c];
@@ -2840,6 +2916,7 @@ private:
             case PA_ERR_DIVISION_BY_ZERO: throw Error(code, "Division by zero");
             case PA_ERR_INSUFFICIENT_RESOURCES: throw Error(code, "group table capacity exceeded");
             case PA_ERR_NOT_SUPPORTED: throw Error(code, "VARCHAR group key longer than its declared bound / the device key packing supports");
+            case PA_ERR_INVALID_ARGUMENT: throw Error(code, "VARCHAR blocks of device pages hold more bytes than their declared VARCHAR(n) allows");
             default: throw Error(code, "device-side error");
         }
     }
@@ -2921,6 +2998,15 @@ private:
         DevBuf d_table;
         hipEvent_t table_event = nullptr;
         bool table_used = false;
+        // VariableWidthBlocks of device pages (launch_var_append): the byte cursors live in HBM, two halves used in turn
+        bool dev_var = false, var_fresh = true;
+        int cursor_half = 0;
+        DevBuf cursors;
+        std::vector<VarSeg> vsegs;                    // deferred appends (stable pages), done at the arena's launch
+        PinnedBuf h_vtable;
+        DevBuf d_vtable;
+        hipEvent_t vtable_event = nullptr;
+        bool vtable_used = false;
     } arena_[2];
     int arena_cur_ = 0;
     const int32_t* kinds_dev_ = nullptr;

@@ -219,3 +219,90 @@ def test_q1_q6_over_small_host_pages_pageable_and_pinned(gpu, oracle, page_rows)
             assert count == ref_count and abs(revenue - ref_sum) <= 1e-9 * abs(ref_sum), name
     finally:
         pinned.free()
+
+
+def q1_expected(oracle, sf, n):
+    cols = [oracle.tpch_column(c, sf, 0, n) for c in tpch.Q1_COLUMNS]
+    args = [cols[0][0], cols[0][1], cols[1][0], cols[1][1]] + [c[0] for c in cols[2:]]
+    host = Page([Block.varwidth(v, o) if t == abi.VARCHAR else Block.flat(t, v) for (v, o), t in zip(cols, tpch.Q1_TYPES)], n)
+    return host, sorted(oracle.q1(args))
+
+
+@pytest.mark.parametrize("page_rows", [8192, 65536])
+def test_q1_over_small_device_pages_with_varchar_channels(gpu, oracle, page_rows):
+    """Device pages whose VARCHAR blocks start at an offset only the device knows: stable pages that do not continue each
+    other (a shuffled scan) are gathered by one planning + one copy launch per arena, pages with buffers of their own (what a
+    device operator upstream hands over) by one launch each -- a byte cursor in HBM places the bytes and rebases the offsets --
+    instead of a fused launch and its merges per page (PageProcessor.java:56-58 page sizes)."""
+    n, sf = 1_000_003, 0.2
+    host, expected = q1_expected(oracle, sf, n)
+    dev = upload_page(host)
+    bounds = bounds_of(n, page_rows)
+    stable = stable_regions(dev, bounds)
+    order = np.random.default_rng(5).permutation(len(stable))
+    own = [upload_page(host.get_region(lo, hi - lo)) for lo, hi in zip(bounds[:-1], bounds[1:])]
+    routes = {
+        "stable, shuffled": [stable[i] for i in order],
+        "buffers of their own": own,
+        "both kinds and host pages in turn": [(stable[i], own[i], host.get_region(bounds[i], bounds[i + 1] - bounds[i]))[i % 3] for i in order],
+    }
+    for name, pages in routes.items():
+        op = FusedAggregationOperator(tpch.Q1_TYPES, tpch.q1_filter(), tpch.q1_projections(), tpch.Q1_GROUP_BY, tpch.Q1_AGGREGATES,
+                                      type_params=tpch.Q1_TYPE_PARAMS)
+        rows = sorted(r for p in to_pages(op, pages) for r in p.to_rows())
+        _, launches = op.kernelTime()
+        op.close()
+        assert len(rows) == len(expected) == 4, name
+        for a, e in zip(rows, expected):
+            assert a[:2] == e[:2] and a[-1] == e[-1], name
+            assert np.allclose(a[2:-1], e[2:-1], rtol=1e-9, atol=0), name
+        if name != "both kinds and host pages in turn":
+            assert launches <= max(len(pages) // 8, 3), (name, launches, len(pages))
+
+
+def test_ragged_varchar_keys_over_small_device_pages(gpu, oracle):
+    """Strings of 0..12 bytes with NULLs as a group key: blocks whose bytes start anywhere and are not aligned with where they
+    land, pages of 1 to a few thousand rows, some empty."""
+    rng = np.random.default_rng(17)
+    words = [b"", b"a", b"bc", b"\xc3\xa9t\xc3\xa9", b"lineitem", b"twelve bytes", None]
+    sizes = [1, 0, 4097, 3, 2500, 64, 8191, 2, 1000, 777] * 6
+    types = [abi.VARCHAR, abi.BIGINT]
+    aggs = [(abi.AGG_SUM, 1, abi.BIGINT), (abi.AGG_COUNT_STAR, -1, None)]
+    host_pages = []
+    for k, n in enumerate(sizes):
+        keys = [words[i] for i in rng.integers(0, len(words), n)]
+        host_pages.append(Page([Block.varchar(keys), Block.bigint(rng.integers(-50, 50, n))], n))
+    ref = oracle.HashAggregation(types, [0], aggs)
+    for p in host_pages:
+        ref.add_page(p)
+    expected = sorted(ref.build_result().to_rows(), key=repr)
+    own = [upload_page(p) for p in host_pages]
+    # the same pages as regions of one device page (stable), visited out of order
+    total = sum(sizes)
+    merged = Page([Block.varchar([s for p in host_pages for s in p.blocks[0].to_pylist()]),
+                   Block.bigint(np.concatenate([p.blocks[1].values for p in host_pages]))], total)
+    dev = upload_page(merged)
+    stable = stable_regions(dev, [0] + list(np.cumsum(sizes)))
+    order = rng.permutation(len(stable))
+    for name, pages in (("own", own), ("stable", [stable[i] for i in order]), ("mixed", [(own[i], stable[i])[i & 1] for i in order])):
+        op = HashAggregationOperator(types, [0], aggs, type_params=[12, 0])
+        rows = sorted((r for p in to_pages(op, pages) for r in p.to_rows()), key=repr)
+        op.close()
+        assert rows == expected, name
+
+
+def test_varchar_bytes_beyond_the_declared_bound_are_refused(gpu):
+    """The arena of device pages is sized by the declared VARCHAR(n): blocks that hold more than 4 n bytes per row of an arena
+    do not fit -- nothing is written past the buffer, the operator fails with INVALID_ARGUMENT."""
+    from presto_amd import expr as E
+    from presto_amd._lib import PrestoAmdError
+    n = 200_000
+    strings = np.full(n * 120, ord("x"), dtype=np.uint8)
+    offsets = np.arange(n + 1, dtype=np.int32) * 120
+    pages = [upload_page(Page([Block.varwidth(strings, offsets), Block.bigint(np.ones(n, dtype=np.int64))], n)) for _ in range(2)]
+    op = FusedAggregationOperator([abi.VARCHAR, abi.BIGINT], E.field(0, abi.VARCHAR).eq(E.constant("y", abi.VARCHAR)), [E.field(1, abi.BIGINT)], [],
+                                  [(abi.AGG_SUM, 0, abi.BIGINT)], type_params=[1, 0])
+    with pytest.raises(PrestoAmdError) as err:
+        to_pages(op, pages)
+    op.close()
+    assert err.value.status == abi.ERR_INVALID_ARGUMENT
