@@ -8,6 +8,7 @@
 // Output pages are produced in HBM and, for PA_MEM_HOST consumers, landed in pinned host memory.
 #pragma once
 
+#include <memory>
 #include <vector>
 
 #include "common.hpp"
@@ -25,6 +26,9 @@ struct DevColumn {
 struct DevPage {
     int32_t n = 0;
     std::vector<DevColumn> cols;
+    // set: the page is the rows of these ranges, one behind the other (stable device pages that do not continue each other in
+    // memory, handed to ONE launch as a table: op_fused.cpp); n is their total, cols those of the first
+    std::shared_ptr<const std::vector<DevPage>> ranges;
 };
 
 class PageStager {

@@ -348,6 +348,9 @@ struct PaFusedArgs {
     // below the word} over [jmin, jmin + jrange], and rank -> build position (null: the rank is the position)
     const pa_u32x4* jrank;
     const i32* jrank_rows;
+    // pa_fused_ranges: a table of row ranges taken in place (entry layout: op_fused.cpp range_entry_words)
+    const u64* ranges;
+    i64 n_ranges;
 };
 
 // JoinProbe.getCurrentJoinPosition for a keyed lookup source without duplicate keys (…/operator/join/JoinProbe.java:87-117,

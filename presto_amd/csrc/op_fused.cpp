@@ -113,11 +113,17 @@ struct FusedArgs {
     const uint8_t* bn[kMaxBuildChannels];
     const void* jrank;
     const int32_t* jrank_rows;
+    const uint64_t* ranges;
+    int64_t n_ranges;
 };
 
 // V_LDSP: the LDS-table variant with partition-owned tables (see PaFusedArgs::sub_tag)
 // V_BROW: probe stage whose group keys are functions of the build row: the table slot is the build position
-enum Variant { V_GLOBAL = 0, V_LDS = 1, V_GT = 2, V_LDSH = 3, V_HASH = 4, V_LDSP = 5, V_BROW = 6 };
+// V_GLOBAL_R / V_LDS_R: the ungrouped / few-groups kernels over a TABLE of row ranges (stable device pages that do not continue
+// each other in memory, taken in place by one launch: see ranges_)
+enum Variant { V_GLOBAL = 0, V_LDS = 1, V_GT = 2, V_LDSH = 3, V_HASH = 4, V_LDSP = 5, V_BROW = 6, V_GLOBAL_R = 7, V_LDS_R = 8 };
+// rows per entry of a range table: one workgroup takes an entry at a time
+constexpr int64_t kRangeRows = 8192, kRangeRowsLds = 4096;
 enum WordKind { W_CNT = 0, W_SUMF = 1, W_SUMI = 2, W_MAXU = 3 };
 
 constexpr int kLdsSlots = 8;  // C of the LDS variant: 8 groups x NW words x 64 lanes x 8 B of LDS per wave
@@ -172,6 +178,7 @@ struct Spec {
 struct KernelInfo {
     std::string source, entry;
     int variant = V_GLOBAL;
+    bool ranged = false;  // the kernel walks a table of row ranges (V_GLOBAL_R / V_LDS_R; `variant` names the base variant)
     int nw = 0, w = 0, c = 0, block = 256;
     int lc = 0;  // V_LDSH: slots of the workgroup's LDS table
     // V_BROW: the accumulator word every row of a group updates -- "this build row has a group" is read off it (its value differs
@@ -466,11 +473,29 @@ struct KeyPacker {
     }
 };
 
+// Words of a range-table entry, in this order: per used channel its values pointer, its offsets pointer when it is a VARCHAR
+// channel, its NULL flags pointer when the layout calls it nullable; then rows | (vec << 32).
+int range_entry_words(const Spec& s, const std::vector<ChannelLayout>& layout)
+{
+    int words = 1;
+    for (int c = 0; c < s.n_in; c++) {
+        if (!s.used_channel[c]) continue;
+        words += 1 + (layout[c].type == PA_VARCHAR ? 1 : 0) + (layout[c].nullable ? 1 : 0);
+    }
+    return words;
+}
+
 KernelInfo generate(const Spec& s, const std::vector<ChannelLayout>& layout, int variant)
 {
     KernelInfo k;
+    const bool ranged = variant == V_GLOBAL_R || variant == V_LDS_R;
+    if (ranged) {
+        PA_REQUIRE(!s.join, PA_ERR_NOT_SUPPORTED, "no range-table variant behind a probe stage");
+        variant = variant == V_GLOBAL_R ? V_GLOBAL : V_LDS;
+    }
     k.variant = variant;
-    k.entry = "pa_fused";
+    k.ranged = ranged;
+    k.entry = ranged ? "pa_fused_ranges" : "pa_fused";
     k.block = variant == V_LDS ? 64 : 256;
     k.c = variant == V_LDS ? kLdsSlots : 0;
 
@@ -1291,8 +1316,47 @@ KernelInfo generate(const Spec& s, const std::vector<ChannelLayout>& layout, int
         }
         // V_GT: the pending run of every thread ends after a quad of consecutive rows / after every row of the other loops
         const std::string flush = gt_like || brow ? " pa_flush(a, acc, true);" : "";
-        if (mode != 2) emit_prologue(ri, layout, src);
-        if (variant == V_GLOBAL) {
+        if (mode != 2 && mode != 3) emit_prologue(ri, layout, src);
+        if (mode == 3) {
+            // a table of row ranges, one workgroup per entry at a time (entries of one XCD's workgroups next to each other, as below)
+            ColumnNames rn;
+            rn.ranged = true;
+            const int rw = range_entry_words(s, layout);
+            src << "    const u32 bsw = (gridDim.x & 7u) == 0u ? (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x;\n"
+                   "    for (i64 ri = bsw; ri < a.n_ranges; ri += gridDim.x) {\n"
+                   "      const u64* RT = a.ranges + (u64)ri * " << rw << "ULL;\n";
+            int word = 0;
+            for (int c = 0; c < s.n_in; c++) {
+                if (!ri.used[c]) continue;
+                src << "      const void* const RV" << c << " = (const void*)RT[" << word++ << "];\n";
+                if (layout[c].type == PA_VARCHAR) src << "      const i32* const RO" << c << " = (const i32*)RT[" << word++ << "];\n";
+                if (layout[c].nullable) src << "      const u8* const RNL" << c << " = (const u8*)RT[" << word++ << "];\n";
+            }
+            src << "      const i64 RN = (i64)(RT[" << word << "] & 0xffffffffULL);\n"
+                   "      const bool rvec = (RT[" << word << "] >> 32) != 0ULL;\n";
+            {
+                std::ostringstream pro;
+                emit_prologue(ri, layout, pro, rn);
+                src << pro.str();
+            }
+            // whole groups of 64 quads for the wave-level table of the LDS variant (every lane takes part in every row call)
+            if (variant == V_LDS) src << "      const i64 nq = rvec ? (RN >> 8) << 6 : 0;\n";
+            else src << "      const i64 nq = rvec ? RN >> 2 : 0;\n";
+            src << "      for (i64 q = threadIdx.x; q < nq; q += " << B << ") {\n";
+            std::string rargs[4];
+            emit_vector_loads(ri, layout, src, rargs, rn);
+            emit_quad(rargs);
+            src << "      }\n";
+            if (variant == V_LDS) {
+                src << "      for (i64 rb = nq << 2; rb < RN; rb += 64) {\n        const bool live = rb + threadIdx.x < RN;\n"
+                       "        const i64 r = live ? rb + threadIdx.x : RN - 1;\n        pa_row(a, acc, live, (i32)r" << scalar_args(ri, layout, rn) << ");\n      }\n";
+            }
+            else {
+                src << "      for (i64 r = (nq << 2) + threadIdx.x; r < RN; r += " << B << ") {\n        pa_row(a, acc, true, (i32)r" << scalar_args(ri, layout, rn) << ");\n      }\n";
+            }
+            src << "    }\n";
+        }
+        else if (variant == V_GLOBAL) {
             // XCD-aware block -> tile mapping: consecutive workgroup ids go round-robin to the 8 XCDs, so give the
             // workgroups of one XCD consecutive tiles (each XCD's L2 / TLB then walks one contiguous eighth of every grid
             // stride).  Measured on Q6: 0.75 -> 0.79 of the HBM peak; neutral for the one-wave workgroups of the LDS variant.
@@ -1303,7 +1367,10 @@ KernelInfo generate(const Spec& s, const std::vector<ChannelLayout>& layout, int
             src << "    const i64 t = (i64)blockIdx.x * " << B << " + threadIdx.x, T = (i64)gridDim.x * " << B << ";\n";
         }
         std::string args[4];
-        if (mode == 1) {
+        if (mode == 3) {
+            // (the loop above)
+        }
+        else if (mode == 1) {
             src << "    const i64 nq = a.n >> 2;  // the host passes a multiple of 256 rows\n";
             src << "    for (i64 q = t; q < nq; q += T) {\n";
             emit_vector_loads(ri, layout, src, args);
@@ -1433,7 +1500,10 @@ KernelInfo generate(const Spec& s, const std::vector<ChannelLayout>& layout, int
         }
         src << "}\n\n";
     };
-    if (variant == V_LDS) {
+    if (ranged) {
+        emit_kernel("pa_fused_ranges", 3);
+    }
+    else if (variant == V_LDS) {
         emit_kernel("pa_fused", 1);
         emit_kernel("pa_fused_tail", 2);
     }
@@ -1520,6 +1590,9 @@ public:
             if (arena_[b].vtable_event) (void)hipEventDestroy(arena_[b].vtable_event);
             if (ev_main_[b]) (void)hipEventDestroy(ev_main_[b]);
             if (ev_merge_[b]) (void)hipEventDestroy(ev_merge_[b]);
+        }
+        for (RangeTable& t : range_table_) {
+            if (t.event) (void)hipEventDestroy(t.event);
         }
     }
     hipStream_t private_stream() override { return stream_.owned() ? stream_.get() : nullptr; }
@@ -1616,17 +1689,22 @@ public:
             add_page(page);
         }
         catch (const LayoutChange&) {
-            // nullability only grows, so a state sees at most one change per channel; the combiner none at all
-            PA_REQUIRE(!is_combiner_ && generation_ <= spec_.n_in, PA_ERR_DEVICE, "internal: state layout changed more often than channels exist");
-            // a channel turned nullable in a way that needs more count words / NULL flags: this state stays as it is, the
-            // page and everything after it go to a new generation; get_output combines the generations' states
-            confirm_all();
-            next_ = std::make_unique<FusedAggregationOperator>(spec_, stream_.get());
-            next_->nullable_seen_ = nullable_seen_;
-            next_->generation_ = generation_ + 1;
+            start_next_generation();
             next_->process_page(page, retained);
         }
         retained_ = false;
+    }
+
+    void start_next_generation()
+    {
+        // nullability only grows, so a state sees at most one change per channel; the combiner none at all
+        PA_REQUIRE(!is_combiner_ && generation_ <= spec_.n_in, PA_ERR_DEVICE, "internal: state layout changed more often than channels exist");
+        // a channel turned nullable in a way that needs more count words / NULL flags: this state stays as it is, the
+        // page and everything after it go to a new generation; get_output combines the generations' states
+        confirm_all();
+        next_ = std::make_unique<FusedAggregationOperator>(spec_, stream_.get());
+        next_->nullable_seen_ = nullable_seen_;
+        next_->generation_ = generation_ + 1;
     }
 
     // ---- small pages ----------------------------------------------------------------------------------------------------
@@ -1725,6 +1803,32 @@ public:
     void retire_run()
     {
         if (run_.rows == 0) return;
+        if (run_.rows < kSmallPageRows && ranges_possible()) {
+            // the ungrouped / few-groups kernels take such ranges in place, as a table: no copy at all.  (The first launch of
+            // the few-groups tier decides whether it is the right one: nothing is collected before it is confirmed)
+            if (mode_ == V_LDS && !lds_probed_) {
+                flush_run();
+                return;
+            }
+            DevPage r;
+            r.n = (int32_t)run_.rows;
+            r.cols.resize((size_t)spec_.n_in);
+            for (int c = 0; c < spec_.n_in; c++) {
+                if (!spec_.used_channel[c]) continue;
+                const pa_column& col = run_.cols[c];
+                r.cols[c].type = col.type;
+                r.cols[c].varwidth = col.encoding == PA_VARWIDTH;
+                r.cols[c].values = col.values;
+                r.cols[c].offsets = col.offsets;
+                r.cols[c].nulls = col.nulls;
+            }
+            if (!ranges_) ranges_ = std::make_shared<std::vector<DevPage>>();
+            ranges_->push_back(std::move(r));
+            range_rows_ += run_.rows;
+            run_.rows = 0;
+            if (range_rows_ >= std::min<int64_t>(gather_rows(), (int64_t)1 << 30) || ranges_->size() >= kMaxRanges) flush_ranges();
+            return;
+        }
         if (run_.rows >= kSmallPageRows || (!run_.flat && !device_var_gatherable())) {
             flush_run();
             return;
@@ -1737,6 +1841,82 @@ public:
         sp.flags = PA_PAGE_STABLE;  // its copy can wait for the arena's launch
         run_.rows = 0;
         append_to_arena(&sp);
+    }
+
+    // stable device ranges can be handed over as a table when the tier in charge has a kernel for it
+    bool ranges_possible() const
+    {
+        if (spec_.join || getenv("PRESTO_AMD_NO_RANGES")) return false;
+        if (mode_ != V_GLOBAL && mode_ != V_LDS) return false;
+        for (int c = 0; c < spec_.n_in; c++) {
+            if (spec_.used_channel[c] && spec_.interned[c]) return false;
+        }
+        return true;
+    }
+
+    void flush_ranges()
+    {
+        if (!ranges_ || ranges_->empty()) return;
+        std::shared_ptr<const std::vector<DevPage>> set = std::move(ranges_);
+        ranges_.reset();
+        const int64_t rows = range_rows_;
+        range_rows_ = 0;
+        const uint64_t launched = timer.begun();
+        try {
+            process_ranges(set, rows);
+        }
+        catch (const PoolExhausted&) {
+            // nothing of the table was launched: it waits with the page that is being parked (take_page)
+            if (timer.begun() == launched && !next_) {
+                ranges_ = std::make_shared<std::vector<DevPage>>(*set);
+                range_rows_ = rows;
+            }
+            throw;
+        }
+    }
+
+    void process_ranges(const std::shared_ptr<const std::vector<DevPage>>& set, int64_t rows)
+    {
+        if (next_) {
+            next_->process_ranges(set, rows);
+            return;
+        }
+        retained_ = true;
+        try {
+            DevPage dp;
+            dp.n = (int32_t)rows;
+            dp.cols = set->front().cols;
+            dp.ranges = set;
+            std::vector<ChannelLayout> layout(spec_.n_in);
+            std::string sig;
+            for (int c = 0; c < spec_.n_in; c++) {
+                layout[c].type = spec_.in_types[c];
+                if (spec_.used_channel[c]) {
+                    for (const DevPage& r : *set) {
+                        PA_REQUIRE(r.cols[c].type == spec_.in_types[c], PA_ERR_INVALID_ARGUMENT, "page block type does not match the declared input type");
+                        if (r.cols[c].nulls != nullptr) nullable_seen_[c] = true;
+                    }
+                }
+                layout[c].nullable = nullable_seen_[c];
+                sig += layout[c].nullable ? 'n' : '-';
+            }
+            run_tiers(sig, layout, dp, true, 0);
+        }
+        catch (const LayoutChange&) {
+            start_next_generation();
+            next_->process_ranges(set, rows);
+        }
+        retained_ = false;
+    }
+
+    static bool range_aligned(const DevPage& r, const std::vector<bool>& used)
+    {
+        bool vec = true;
+        for (size_t c = 0; c < r.cols.size(); c++) {
+            if (!used[c]) continue;
+            vec = vec && ((uintptr_t)r.cols[c].values % 16 == 0) && ((uintptr_t)r.cols[c].offsets % 16 == 0) && ((uintptr_t)r.cols[c].nulls % 4 == 0);
+        }
+        return vec;
     }
 
     void flush_run()
@@ -1900,6 +2080,9 @@ public:
     void flush_pending()
     {
         if (next_) next_->flush_pending();
+        // a small pending range joins the table of the others; alone, it is launched in place as it is
+        if (ranges_ && !ranges_->empty() && run_.rows > 0 && run_.rows < kSmallPageRows && ranges_possible()) retire_run();
+        flush_ranges();
         flush_arena();
         flush_run();
     }
@@ -2020,6 +2203,11 @@ public:
             // launches of the few-groups variant still unconfirmed while another tier takes over: settle them first (their
             // merges write the table the other tiers resize and replicate)
             if (mode_ != V_LDS && !inflight_.empty()) confirm_all();
+            if (dp.ranges && mode_ != V_GLOBAL && mode_ != V_LDS) {
+                // a table of ranges and a tier without a kernel for tables (the few-groups tier gave up): range by range
+                for (const DevPage& r : *dp.ranges) run_tiers(sig, layout, r, range_aligned(r, spec_.used_channel), 0);
+                break;
+            }
             int partitions = 0;
             if (mode_ == V_GT && partitioned_wanted(sig, layout, &partitions)) {
                 run_page_partitioned(sig, layout, dp, vec, partitions, start_row);
@@ -2027,7 +2215,7 @@ public:
             }
             const Compiled* compiled = nullptr;
             try {
-                compiled = &kernel_for(sig, layout, mode_);
+                compiled = &kernel_for(sig, layout, dp.ranges ? (mode_ == V_GLOBAL ? V_GLOBAL_R : V_LDS_R) : mode_);
             }
             catch (const Error& e) {
                 // the group state may be too wide for the wave's / the workgroup's LDS budget: move on to the next tier
@@ -2599,6 +2787,50 @@ private:
     }
 
     // returns false when the LDS variant overflowed and the page must be redone with the HBM table
+    // The table of a ranged launch (entry layout: range_entry_words): every range cut into entries of at most kRangeRows rows,
+    // each with its own buffer addresses.  Returns the number of entries.
+    int64_t fill_range_table(const KernelInfo& ki, const DevPage& dp, FusedArgs& a, hipStream_t s)
+    {
+        const std::vector<ChannelLayout>& layout = *cur_layout_;
+        const int rw = range_entry_words(spec_, layout);
+        const int64_t per = ki.variant == V_LDS ? kRangeRowsLds : kRangeRows;
+        int64_t entries = 0;
+        for (const DevPage& r : *dp.ranges) entries += (r.n + per - 1) / per;
+        RangeTable& t = range_table_[range_table_next_];
+        range_table_next_ = (range_table_next_ + 1) % 3;
+        // the staging table is written by the host: the copy of its previous use must have left it
+        if (t.used) PA_HIP(hipEventSynchronize(t.event));
+        else PA_HIP(hipEventCreateWithFlags(&t.event, hipEventDisableTiming));
+        t.used = true;
+        const size_t bytes = (size_t)entries * rw * 8;
+        uint64_t* w = static_cast<uint64_t*>(t.host.ensure(bytes));
+        for (const DevPage& r : *dp.ranges) {
+            const uint64_t vec = range_aligned(r, spec_.used_channel) ? 1 : 0;
+            for (int64_t row0 = 0; row0 < r.n; row0 += per) {
+                const int64_t n = std::min<int64_t>(per, r.n - row0);
+                for (int c = 0; c < spec_.n_in; c++) {
+                    if (!spec_.used_channel[c]) continue;
+                    const DevColumn& col = r.cols[c];
+                    if (layout[c].type == PA_VARCHAR) {
+                        *w++ = (uint64_t)(uintptr_t)col.values;
+                        *w++ = (uint64_t)(uintptr_t)(col.offsets + row0);
+                    }
+                    else {
+                        *w++ = (uint64_t)(uintptr_t)(static_cast<const char*>(col.values) + row0 * type_width(col.type));
+                    }
+                    if (layout[c].nullable) *w++ = col.nulls ? (uint64_t)(uintptr_t)(col.nulls + row0) : 0;
+                }
+                *w++ = (uint64_t)n | (vec << 32);
+            }
+        }
+        void* dev = t.dev.ensure(bytes);
+        PA_HIP(hipMemcpyAsync(dev, t.host.ptr(), bytes, hipMemcpyHostToDevice, s));
+        PA_HIP(hipEventRecord(t.event, s));
+        a.ranges = static_cast<const uint64_t*>(dev);
+        a.n_ranges = entries;
+        return entries;
+    }
+
     bool run_page(const Compiled& ck, const DevPage& dp, bool vec, const RowList* list = nullptr, int64_t start_row = 0)
     {
         hipStream_t s = stream_.get();
@@ -2617,13 +2849,20 @@ private:
         a.overflow_rows = reinterpret_cast<uint64_t*>(ctl_ + 2);
         if (spec_.join) fill_join_args(a);
         if (ki.variant == V_BROW) return run_page_build_rows(ck, dp, a, start_row);
+        // a table of ranges: one launch takes all of them, a workgroup per entry at a time
+        int64_t range_entries = 0;
+        if (dp.ranges) {
+            PA_REQUIRE(ki.ranged && !list && start_row == 0, PA_ERR_DEVICE, "internal: range table handed to a kernel that walks one page");
+            range_entries = fill_range_table(ki, dp, a, s);
+        }
         int64_t offset = list ? list->first_row : start_row;
         const int64_t total = list ? list->first_row + list->chunk_rows : dp.n;
         // the HBM-table variant bounds the groups one launch can add so that the table can be sized first
         const bool table_tier = ki.variant == V_GT || ki.variant == V_LDSH || ki.variant == V_LDSP;
         const int64_t chunk = table_tier ? (int64_t)1 << 26 : total;
         // LDS variant: head = leading multiple of 256 rows through the vector kernel, tail = the rest through the scalar one
-        const int64_t lds_head = (ki.variant == V_LDS && vec) ? (total & ~(int64_t)255) : 0;
+        // (a range table has its tails inside: the one kernel takes everything)
+        const int64_t lds_head = dp.ranges ? total : (ki.variant == V_LDS && vec) ? (total & ~(int64_t)255) : 0;
         while (offset < total) {
             int64_t n = std::min(chunk, total - offset);
             // the first launch on the HBM table is a short one: it tells how many groups there are, which decides the
@@ -2635,7 +2874,7 @@ private:
                     n = lds_head - offset;
                     // nothing is known about the cardinality yet: a short first launch decides whether the register-table
                     // variant fits, instead of a whole wasted pass over a large page
-                    if (!lds_probed_ && n > ((int64_t)1 << 22)) n = (int64_t)1 << 20;
+                    if (!lds_probed_ && n > ((int64_t)1 << 22) && !dp.ranges) n = (int64_t)1 << 20;
                 }
                 else use_tail = true;
             }
@@ -2650,6 +2889,7 @@ private:
             }
             a.n = list ? 0 : n;
             int64_t work = use_tail ? n : (n + 3) / 4;
+            if (dp.ranges) work = range_entries * ki.block;  // a workgroup per entry
             if (list) {
                 a.row_list = list->rows;
                 a.n_list = list->count;
@@ -2987,6 +3227,17 @@ private:
         bool flat = true;                 // every used channel is FLAT (a small range can join the arena)
         std::vector<pa_column> cols;      // first page of the range: every later page continues these buffers
     } run_;
+    // stable device ranges waiting to be launched as one table (see retire_run)
+    static constexpr size_t kMaxRanges = 16384;
+    std::shared_ptr<std::vector<DevPage>> ranges_;
+    int64_t range_rows_ = 0;
+    struct RangeTable {
+        PinnedBuf host;
+        DevBuf dev;
+        hipEvent_t event = nullptr;
+        bool used = false;
+    } range_table_[3];
+    int range_table_next_ = 0;
     static constexpr size_t kArenaMaxSegs = 16384;
     struct Arena {
         int64_t rows = 0;
@@ -3847,8 +4098,9 @@ std::string fused_source_for_layout(const pa_fused_aggregation_desc* desc, int v
         layout[c].type = s.in_types[c];
         layout[c].nullable = c < 64 && ((nullable_channels >> c) & 1ULL) != 0;
     }
-    PA_REQUIRE(variant >= V_GLOBAL && variant <= V_LDSP, PA_ERR_INVALID_ARGUMENT, "variant out of range");
-    PA_REQUIRE(variant == V_GLOBAL ? s.group_proj.empty() : !s.group_proj.empty(), PA_ERR_INVALID_ARGUMENT, "variant does not match the descriptor");
+    PA_REQUIRE((variant >= V_GLOBAL && variant <= V_LDSP) || variant == V_GLOBAL_R || variant == V_LDS_R, PA_ERR_INVALID_ARGUMENT, "variant out of range");
+    PA_REQUIRE(variant == V_GLOBAL || variant == V_GLOBAL_R ? s.group_proj.empty() : !s.group_proj.empty(), PA_ERR_INVALID_ARGUMENT,
+               "variant does not match the descriptor");
     return generate(s, layout, variant).source;
 }
 

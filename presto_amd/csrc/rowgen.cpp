@@ -33,12 +33,12 @@ std::string row_param_names(const RowInputs& s, const std::vector<ChannelLayout>
 }
 
 // Kernel prologue: wave-uniform facts about the page used by the speculative VARCHAR(1) path.
-void emit_prologue(const RowInputs& s, const std::vector<ChannelLayout>& layout, std::ostringstream& o)
+void emit_prologue(const RowInputs& s, const std::vector<ChannelLayout>& layout, std::ostringstream& o, const ColumnNames& nm)
 {
     for (int c = 0; c < s.n_in; c++) {
         if (!s.used[c] || layout[c].type != PA_VARCHAR || s.short_bound[c] != 1) continue;
-        o << "    const i32 P" << c << " = a.n > 0 ? a.o[" << c << "][0] : 0;\n";
-        o << "    const i64 PB" << c << " = a.n > 0 ? (i64)a.o[" << c << "][a.n] - P" << c << " : 0;\n";
+        o << "    const i32 P" << c << " = " << nm.n() << " > 0 ? " << nm.o(c) << "[0] : 0;\n";
+        o << "    const i64 PB" << c << " = " << nm.n() << " > 0 ? (i64)" << nm.o(c) << "[" << nm.n() << "] - P" << c << " : 0;\n";
     }
 }
 
@@ -46,46 +46,46 @@ void emit_prologue(const RowInputs& s, const std::vector<ChannelLayout>& layout,
 // round trip per step); work that depends on loaded offsets follows.  VARCHAR(1) keys read their 4 bytes
 // speculatively at the position they have when every earlier string of the page is one byte long, and
 // fall back to the offset-dependent path otherwise.
-void emit_vector_loads(const RowInputs& s, const std::vector<ChannelLayout>& layout, std::ostringstream& o, std::string args[4])
+void emit_vector_loads(const RowInputs& s, const std::vector<ChannelLayout>& layout, std::ostringstream& o, std::string args[4], const ColumnNames& nm)
 {
     static const char* xyzw[4] = {"x", "y", "z", "w"};
     std::ostringstream post;
     for (int c = 0; c < s.n_in; c++) {
         if (!s.used[c]) continue;
-        std::string C = std::to_string(c);
+        const std::string C = std::to_string(c), V = nm.v(c), O = nm.o(c), NL = nm.nl(c);
         switch (layout[c].type) {
             case PA_BIGINT:
             case PA_DECIMAL:  // ShortDecimalType: a LongArrayBlock of unscaled values
-                o << "        pa_i64x2 A" << C << " = ((const pa_i64x2*)a.v[" << C << "])[2 * q], B" << C << " = ((const pa_i64x2*)a.v[" << C
-                  << "])[2 * q + 1];\n";
+                o << "        pa_i64x2 A" << C << " = ((const pa_i64x2*)" << V << ")[2 * q], B" << C << " = ((const pa_i64x2*)" << V
+                  << ")[2 * q + 1];\n";
                 for (int r = 0; r < 4; r++) args[r] += ", " + std::string(r < 2 ? "A" : "B") + C + "." + xyzw[r & 1];
                 break;
             case PA_LONG_DECIMAL:  // 16 bytes per position: one 16-byte load per row
                 for (int r = 0; r < 4; r++) {
-                    o << "        pa_i64x2 L" << C << r << " = ((const pa_i64x2*)a.v[" << C << "])[4 * q + " << r << "];\n";
+                    o << "        pa_i64x2 L" << C << r << " = ((const pa_i64x2*)" << V << ")[4 * q + " << r << "];\n";
                     args[r] += ", pa_ld_from(L" + C + std::to_string(r) + ".x, L" + C + std::to_string(r) + ".y)";
                 }
                 break;
             case PA_DOUBLE:
-                o << "        pa_f64x2 A" << C << " = ((const pa_f64x2*)a.v[" << C << "])[2 * q], B" << C << " = ((const pa_f64x2*)a.v[" << C
-                  << "])[2 * q + 1];\n";
+                o << "        pa_f64x2 A" << C << " = ((const pa_f64x2*)" << V << ")[2 * q], B" << C << " = ((const pa_f64x2*)" << V
+                  << ")[2 * q + 1];\n";
                 for (int r = 0; r < 4; r++) args[r] += ", " + std::string(r < 2 ? "A" : "B") + C + "." + xyzw[r & 1];
                 break;
             case PA_INTEGER:
             case PA_DATE:
-                o << "        pa_i32x4 A" << C << " = ((const pa_i32x4*)a.v[" << C << "])[q];\n";
+                o << "        pa_i32x4 A" << C << " = ((const pa_i32x4*)" << V << ")[q];\n";
                 for (int r = 0; r < 4; r++) args[r] += ", (i64)A" + C + "." + xyzw[r];
                 break;
             case PA_REAL:
-                o << "        pa_f32x4 A" << C << " = ((const pa_f32x4*)a.v[" << C << "])[q];\n";
+                o << "        pa_f32x4 A" << C << " = ((const pa_f32x4*)" << V << ")[q];\n";
                 for (int r = 0; r < 4; r++) args[r] += ", A" + C + "." + xyzw[r];
                 break;
             case PA_BOOLEAN:
-                o << "        u32 A" << C << " = ((const u32*)a.v[" << C << "])[q];\n";
+                o << "        u32 A" << C << " = ((const u32*)" << V << ")[q];\n";
                 for (int r = 0; r < 4; r++) args[r] += ", ((A" + C + " >> " + std::to_string(8 * r) + ") & 0xffu) != 0u";
                 break;
             case PA_VARCHAR: {
-                o << "        pa_i32x4 O" << C << " = ((const pa_i32x4*)a.o[" << C << "])[q]; i32 E" << C << " = a.o[" << C << "][4 * q + 4];\n";
+                o << "        pa_i32x4 O" << C << " = ((const pa_i32x4*)" << O << ")[q]; i32 E" << C << " = " << O << "[4 * q + 4];\n";
                 std::string lo[4], len[4];
                 for (int r = 0; r < 4; r++) {
                     lo[r] = "O" + C + "." + xyzw[r];
@@ -94,10 +94,10 @@ void emit_vector_loads(const RowInputs& s, const std::vector<ChannelLayout>& lay
                 if (s.short_bound[c] > 0) {
                     post << "        u64 S" << C << "0, S" << C << "1, S" << C << "2, S" << C << "3;\n";
                     if (s.short_bound[c] == 1) {
-                        o << "        u32 K" << C << " = 0u; if (4 * q + 4 <= PB" << C << ") __builtin_memcpy(&K" << C << ", (const u8*)a.v[" << C
-                          << "] + P" << C << " + 4 * q, 4);\n";
+                        o << "        u32 K" << C << " = 0u; if (4 * q + 4 <= PB" << C << ") __builtin_memcpy(&K" << C << ", (const u8*)" << V
+                          << " + P" << C << " + 4 * q, 4);\n";
                         post << "        if (E" << C << " - " << lo[0] << " == 4) {\n            u32 pk = K" << C << ";\n            if (" << lo[0]
-                             << " != P" << C << " + (i32)(4 * q) || 4 * q + 4 > PB" << C << ") __builtin_memcpy(&pk, (const u8*)a.v[" << C << "] + "
+                             << " != P" << C << " + (i32)(4 * q) || 4 * q + 4 > PB" << C << ") __builtin_memcpy(&pk, (const u8*)" << V << " + "
                              << lo[0] << ", 4);\n";
                         for (int r = 0; r < 4; r++) post << "            S" << C << r << " = (pk >> " << 8 * r << ") & 0xffu;\n";
                         post << "        } else {\n";
@@ -106,13 +106,13 @@ void emit_vector_loads(const RowInputs& s, const std::vector<ChannelLayout>& lay
                         post << "        {\n";
                     }
                     for (int r = 0; r < 4; r++) {
-                        post << "            S" << C << r << " = pa_short_bytes((const u8*)a.v[" << C << "] + " << lo[r] << ", " << len[r] << ", "
+                        post << "            S" << C << r << " = pa_short_bytes((const u8*)" << V << " + " << lo[r] << ", " << len[r] << ", "
                              << s.short_bound[c] << ", a.err);\n";
                     }
                     post << "        }\n";
                 }
                 for (int r = 0; r < 4; r++) {
-                    args[r] += ", (const u8*)a.v[" + C + "] + " + lo[r] + ", " + len[r];
+                    args[r] += ", (const u8*)" + V + " + " + lo[r] + ", " + len[r];
                     if (s.short_bound[c] > 0) args[r] += ", S" + C + std::to_string(r);
                 }
                 break;
@@ -122,38 +122,38 @@ void emit_vector_loads(const RowInputs& s, const std::vector<ChannelLayout>& lay
         }
         if (layout[c].nullable) {
             // a page without a valueIsNull array on a channel that had one earlier passes a null pointer
-            o << "        u32 N" << C << " = a.nl[" << C << "] ? ((const u32*)a.nl[" << C << "])[q] : 0u;\n";
+            o << "        u32 N" << C << " = " << NL << " ? ((const u32*)" << NL << ")[q] : 0u;\n";
             for (int r = 0; r < 4; r++) args[r] += ", ((N" + C + " >> " + std::to_string(8 * r) + ") & 0xffu) != 0u";
         }
     }
     o << post.str();
 }
 
-std::string scalar_args(const RowInputs& s, const std::vector<ChannelLayout>& layout)
+std::string scalar_args(const RowInputs& s, const std::vector<ChannelLayout>& layout, const ColumnNames& nm)
 {
     std::string a;
     for (int c = 0; c < s.n_in; c++) {
         if (!s.used[c]) continue;
-        std::string C = std::to_string(c);
+        const std::string C = std::to_string(c), V = nm.v(c), O = nm.o(c), NL = nm.nl(c);
         switch (layout[c].type) {
             case PA_BIGINT:
-            case PA_DECIMAL: a += ", ((const i64*)a.v[" + C + "])[r]"; break;
-            case PA_LONG_DECIMAL: a += ", pa_ld_read((const u64*)a.v[" + C + "] + 2 * r)"; break;
-            case PA_DOUBLE: a += ", ((const double*)a.v[" + C + "])[r]"; break;
+            case PA_DECIMAL: a += ", ((const i64*)" + V + ")[r]"; break;
+            case PA_LONG_DECIMAL: a += ", pa_ld_read((const u64*)" + V + " + 2 * r)"; break;
+            case PA_DOUBLE: a += ", ((const double*)" + V + ")[r]"; break;
             case PA_INTEGER:
-            case PA_DATE: a += ", (i64)((const i32*)a.v[" + C + "])[r]"; break;
-            case PA_REAL: a += ", ((const float*)a.v[" + C + "])[r]"; break;
-            case PA_BOOLEAN: a += ", ((const u8*)a.v[" + C + "])[r] != 0"; break;
+            case PA_DATE: a += ", (i64)((const i32*)" + V + ")[r]"; break;
+            case PA_REAL: a += ", ((const float*)" + V + ")[r]"; break;
+            case PA_BOOLEAN: a += ", ((const u8*)" + V + ")[r] != 0"; break;
             case PA_VARCHAR:
-                a += ", (const u8*)a.v[" + C + "] + a.o[" + C + "][r], a.o[" + C + "][r + 1] - a.o[" + C + "][r]";
+                a += ", (const u8*)" + V + " + " + O + "[r], " + O + "[r + 1] - " + O + "[r]";
                 if (s.short_bound[c] > 0) {
-                    a += ", pa_short_bytes((const u8*)a.v[" + C + "] + a.o[" + C + "][r], a.o[" + C + "][r + 1] - a.o[" + C + "][r], " +
+                    a += ", pa_short_bytes((const u8*)" + V + " + " + O + "[r], " + O + "[r + 1] - " + O + "[r], " +
                          std::to_string(s.short_bound[c]) + ", a.err)";
                 }
                 break;
             default: throw Error(PA_ERR_NOT_SUPPORTED, "column type not supported on device");
         }
-        if (layout[c].nullable) a += ", (a.nl[" + C + "] != nullptr && a.nl[" + C + "][r] != 0)";
+        if (layout[c].nullable) a += ", (" + NL + " != nullptr && " + NL + "[r] != 0)";
     }
     return a;
 }

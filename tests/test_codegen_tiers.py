@@ -14,8 +14,8 @@ from presto_amd._lib import lib
 from presto_amd.expr import and_, constant, field
 from presto_amd.operators import fused_aggregation_desc, fused_join_aggregation_desc, hash_builder_desc
 
-V_GLOBAL, V_LDS, V_GT, V_LDSH, V_HASH, V_LDSP, V_BROW = range(7)
-TIER_NAMES = ["global", "lds", "gt", "ldsh", "hash", "ldsp", "brow"]
+V_GLOBAL, V_LDS, V_GT, V_LDSH, V_HASH, V_LDSP, V_BROW, V_GLOBAL_R, V_LDS_R = range(9)
+TIER_NAMES = ["global", "lds", "gt", "ldsh", "hash", "ldsp", "brow", "global_ranges", "lds_ranges"]
 D = abi.decimal(12, 2)
 
 
@@ -55,6 +55,7 @@ def cells(full):
         n = len(shape[0])
         for mask in ([0, (1 << n) - 1] if full else [0, 0b10 if n > 1 else 1]):
             out.append((name, V_GLOBAL, mask))
+            out.append((name, V_GLOBAL_R, mask))   # the same kernel over a table of row ranges
     for name, shape in shapes().items():
         n = len(shape[0])
         masks = [0, (1 << n) - 1, 0b01, 0b10] if full else [0, (1 << n) - 1]
@@ -63,6 +64,8 @@ def cells(full):
                 if not full and variant in (V_HASH, V_LDSP) and mask:
                     continue
                 out.append((name, variant, mask))
+        for mask in masks[:2]:
+            out.append((name, V_LDS_R, mask))
     return out
 
 

@@ -228,12 +228,16 @@ def q1_expected(oracle, sf, n):
     return host, sorted(oracle.q1(args))
 
 
+@pytest.mark.parametrize("in_place", [True, False])
 @pytest.mark.parametrize("page_rows", [8192, 65536])
-def test_q1_over_small_device_pages_with_varchar_channels(gpu, oracle, page_rows):
+def test_q1_over_small_device_pages_with_varchar_channels(gpu, oracle, monkeypatch, page_rows, in_place):
     """Device pages whose VARCHAR blocks start at an offset only the device knows: stable pages that do not continue each
     other (a shuffled scan) are gathered by one planning + one copy launch per arena, pages with buffers of their own (what a
     device operator upstream hands over) by one launch each -- a byte cursor in HBM places the bytes and rebases the offsets --
-    instead of a fused launch and its merges per page (PageProcessor.java:56-58 page sizes)."""
+    instead of a fused launch and its merges per page (PageProcessor.java:56-58 page sizes).  in_place: the few-groups tier takes
+    the stable pages as a TABLE of row ranges, without any copy (the default); otherwise they are gathered like the others."""
+    if not in_place:
+        monkeypatch.setenv("PRESTO_AMD_NO_RANGES", "1")
     n, sf = 1_000_003, 0.2
     host, expected = q1_expected(oracle, sf, n)
     dev = upload_page(host)
@@ -306,3 +310,66 @@ def test_varchar_bytes_beyond_the_declared_bound_are_refused(gpu):
         to_pages(op, pages)
     op.close()
     assert err.value.status == abi.ERR_INVALID_ARGUMENT
+
+
+@pytest.mark.parametrize("page_rows", [8192, 4096 + 4, 65536])
+def test_row_range_tables_ungrouped_and_few_groups(gpu, oracle, monkeypatch, page_rows):
+    """Stable device pages that do not continue each other are taken in place as a table of row ranges by ONE launch of the
+    ungrouped (Q6) / few-groups (Q1-like) kernels: ragged range sizes, unaligned ranges (scalar rows), NULL flags that appear in
+    some ranges only, a launch threshold that cuts the table several times."""
+    monkeypatch.setenv("PRESTO_AMD_GATHER_ROWS", str(1 << 18))
+    n, sf = 700_001, 0.1
+    host, (ref_sum, ref_count) = q6_host(oracle, sf, n)
+    dev = upload_page(host)
+    bounds = bounds_of(n, page_rows)
+    regs = stable_regions(dev, bounds)
+    order = np.random.default_rng(9).permutation(len(regs))
+    revenue, count = run_q6([regs[i] for i in order])
+    assert count == ref_count and abs(revenue - ref_sum) <= 1e-9 * abs(ref_sum)
+    # few groups, BIGINT key, a nullable DOUBLE channel whose NULL flags exist in every third range only
+    rng = np.random.default_rng(10)
+    keys = rng.integers(0, 6, n).astype(np.int64)
+    vals = rng.random(n)
+    nulls = rng.random(n) < 0.1
+    aggs = [(abi.AGG_SUM, 1, abi.DOUBLE), (abi.AGG_COUNT, 1, abi.DOUBLE), (abi.AGG_COUNT_STAR, -1, None), (abi.AGG_MIN, 1, abi.DOUBLE)]
+    with_nulls = upload_page(Page([Block.bigint(keys), Block.double(vals, nulls)], n))
+    pages, ref = [], oracle.HashAggregation([abi.BIGINT, abi.DOUBLE], [0], aggs)
+    for i, (lo, hi) in enumerate(zip(bounds[:-1], bounds[1:])):
+        reg = stable_regions(with_nulls, [lo, hi])[0]
+        has = i % 3 == 0
+        if not has:
+            reg = Page([reg.blocks[0], Block(abi.DOUBLE, abi.FLAT, hi - lo, values=reg.blocks[1].values)], hi - lo, abi.MEM_DEVICE, stable=True)
+        pages.append(reg)
+        ref.add_page(Page([Block.bigint(keys[lo:hi]), Block.double(vals[lo:hi], nulls[lo:hi] if has else None)], hi - lo))
+    expected = sorted(ref.build_result().to_rows())
+    op = HashAggregationOperator([abi.BIGINT, abi.DOUBLE], [0], aggs, expected_groups=8)
+    rows = sorted(r for p in to_pages(op, [pages[i] for i in order]) for r in p.to_rows())
+    _, launches = op.kernelTime()
+    op.close()
+    assert launches <= 2 + n // (1 << 18) + 2, launches
+    assert len(rows) == len(expected)
+    for a, e in zip(rows, expected):
+        assert a[0] == e[0] and a[2:4] == e[2:4] and a[4] == e[4] and abs(a[1] - e[1]) <= 1e-9 * abs(e[1])
+
+
+def test_row_range_table_when_the_few_groups_tier_gives_up(gpu, oracle, monkeypatch):
+    """A table of ranges whose rows hold more groups than the wave-level tables: the launch is redone range by range on the next
+    tier, and later ranges are gathered the old way -- no row lost, none counted twice."""
+    monkeypatch.setenv("PRESTO_AMD_GATHER_ROWS", str(1 << 17))
+    rng = np.random.default_rng(12)
+    n = 500_000
+    keys = rng.integers(0, 4, n).astype(np.int64)
+    keys[300_000:] = rng.integers(0, 5000, n - 300_000)
+    vals = rng.integers(-1000, 1000, n).astype(np.int64)
+    aggs = [(abi.AGG_SUM, 1, abi.BIGINT), (abi.AGG_COUNT_STAR, -1, None), (abi.AGG_MAX, 1, abi.BIGINT)]
+    host = Page([Block.bigint(keys), Block.bigint(vals)], n)
+    ref = oracle.HashAggregation([abi.BIGINT, abi.BIGINT], [0], aggs)
+    ref.add_page(host)
+    expected = sorted(ref.build_result().to_rows())
+    dev = upload_page(host)
+    regs = stable_regions(dev, bounds_of(n, 8192))
+    # every other page first, then the rest: no page continues its predecessor, the many-groups rows arrive mid-way
+    op = HashAggregationOperator([abi.BIGINT, abi.BIGINT], [0], aggs, expected_groups=8)
+    rows = sorted(r for p in to_pages(op, regs[0::2] + regs[1::2]) for r in p.to_rows())
+    op.close()
+    assert rows == expected
