@@ -1,5 +1,7 @@
 // abi.cpp -- the extern "C" surface declared in include/presto_amd.h.  Thin: argument checks, the
 // exception -> status translation, and dispatch to the operator objects.  No arithmetic lives here.
+#include <chrono>
+#include <mutex>
 #include <mutex>
 
 #include <atomic>
@@ -90,9 +92,47 @@ struct OpScope {
     hipStream_t prev_;
 };
 
+// PRESTO_AMD_HOST_TRACE=<file>: wall-clock start and duration of every C-ABI call, appended to <file> when the process ends
+// (start us since the first call, duration us, entry point) -- the host side of a kernel timeline (scripts/kernel_timeline.py)
+struct HostTrace {
+    struct Rec {
+        double start_us, us;
+        const char* name;
+    };
+    std::vector<Rec> recs;
+    std::mutex mu;
+    const char* path = getenv("PRESTO_AMD_HOST_TRACE");
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    ~HostTrace()
+    {
+        if (!path || recs.empty()) return;
+        if (FILE* f = fopen(path, "a")) {
+            for (const Rec& r : recs) fprintf(f, "%12.1f %9.1f %s\n", r.start_us, r.us, r.name);
+            fclose(f);
+        }
+    }
+};
+static HostTrace g_host_trace;
+struct HostTraceScope {
+    const char* name;
+    std::chrono::steady_clock::time_point t;
+    explicit HostTraceScope(const char* n) : name(n)
+    {
+        if (g_host_trace.path) t = std::chrono::steady_clock::now();
+    }
+    ~HostTraceScope()
+    {
+        if (!g_host_trace.path) return;
+        const auto e = std::chrono::steady_clock::now();
+        std::lock_guard<std::mutex> lock(g_host_trace.mu);
+        g_host_trace.recs.push_back({std::chrono::duration<double, std::micro>(t - g_host_trace.t0).count(), std::chrono::duration<double, std::micro>(e - t).count(), name});
+    }
+};
+
 template <typename F>
-static int32_t guarded(F&& f)
+static int32_t guarded(F&& f, const char* entry = __builtin_FUNCTION())
 {
+    HostTraceScope trace(entry);
     try {
         bind_default_device();
         return f();

@@ -73,9 +73,24 @@ void FusedGen::ldsp_kernel_begin()
 
 void FusedGen::ldsp_partition_loop()
 {
-    // ... the workgroup walks the rows of its partition (the columns are partition-ordered) ...
+    // ... the workgroup walks the rows of its partition (the columns are partition-ordered), four rows per thread and step with
+    // their loads issued together: a partition is a few dozen rows per thread, and a row's way through the LDS table (tag, key
+    // compare, atomics) would otherwise wait for one HBM round trip per row (rows beyond the partition ride along, not live)
     src << "    {\n        const i64 b0 = a.part_first[blockIdx.x], b1 = a.part_first[blockIdx.x + 1];\n"
-           "        for (i64 r = b0 + threadIdx.x; r < b1; r += " << B << ") {\n            pa_row(a, acc, true, (i32)r" << scalar_args(ri, layout) << ");\n        }\n    }\n";
+           "        for (i64 r0 = b0 + threadIdx.x; r0 < b1; r0 += " << 4 * B << ") {\n";
+    std::string rows[4];
+    for (int u = 0; u < 4; u++) {
+        const std::string U = std::to_string(u);
+        if (u > 0) src << "            const bool v" << U << " = r0 + " << u * B << " < b1; const i64 r" << U << " = v" << U << " ? r0 + " << u * B << " : r0;\n";
+        std::ostringstream decl;
+        rows[u] = scalar_loads(ri, layout, "r" + U, "_" + U, decl);
+        src << "            " << decl.str() << "\n";
+    }
+    for (int u = 0; u < 4; u++) {
+        const std::string U = std::to_string(u);
+        src << "            pa_row(a, acc, " << (u == 0 ? std::string("true") : "v" + U) << ", (i32)r" << U << rows[u] << ");\n";
+    }
+    src << "        }\n    }\n";
     // ... and the table goes back (plain coalesced stores: nobody else touches this partition)
     src << "    __syncthreads();\n";
     src << "    for (int i = threadIdx.x; i < PA_LC; i += " << B << ") a.sub_tag[sp + i] = pa_lt_tag[i];\n";

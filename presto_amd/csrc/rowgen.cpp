@@ -129,6 +129,37 @@ void emit_vector_loads(const RowInputs& s, const std::vector<ChannelLayout>& lay
     o << post.str();
 }
 
+std::string scalar_loads(const RowInputs& s, const std::vector<ChannelLayout>& layout, const std::string& row, const std::string& suffix, std::ostringstream& decl,
+                         const ColumnNames& nm)
+{
+    std::string a;
+    for (int c = 0; c < s.n_in; c++) {
+        if (!s.used[c]) continue;
+        const std::string C = std::to_string(c), V = nm.v(c), O = nm.o(c), NL = nm.nl(c), L = "l" + C + suffix;
+        switch (layout[c].type) {
+            case PA_BIGINT:
+            case PA_DECIMAL: decl << "const i64 " << L << " = ((const i64*)" << V << ")[" << row << "]; "; a += ", " + L; break;
+            case PA_LONG_DECIMAL: decl << "const i128 " << L << " = pa_ld_read((const u64*)" << V << " + 2 * (" << row << ")); "; a += ", " + L; break;
+            case PA_DOUBLE: decl << "const double " << L << " = ((const double*)" << V << ")[" << row << "]; "; a += ", " + L; break;
+            case PA_INTEGER:
+            case PA_DATE: decl << "const i64 " << L << " = (i64)((const i32*)" << V << ")[" << row << "]; "; a += ", " + L; break;
+            case PA_REAL: decl << "const float " << L << " = ((const float*)" << V << ")[" << row << "]; "; a += ", " + L; break;
+            case PA_BOOLEAN: decl << "const bool " << L << " = ((const u8*)" << V << ")[" << row << "] != 0; "; a += ", " + L; break;
+            case PA_VARCHAR:
+                decl << "const i32 " << L << "o = " << O << "[" << row << "], " << L << "e = " << O << "[(" << row << ") + 1]; ";
+                a += ", (const u8*)" + V + " + " + L + "o, " + L + "e - " + L + "o";
+                if (s.short_bound[c] > 0) a += ", pa_short_bytes((const u8*)" + V + " + " + L + "o, " + L + "e - " + L + "o, " + std::to_string(s.short_bound[c]) + ", a.err)";
+                break;
+            default: throw Error(PA_ERR_NOT_SUPPORTED, "column type not supported on device");
+        }
+        if (layout[c].nullable) {
+            decl << "const bool ln" << C << suffix << " = " << NL << " != nullptr && " << NL << "[" << row << "] != 0; ";
+            a += ", ln" + C + suffix;
+        }
+    }
+    return a;
+}
+
 std::string scalar_args(const RowInputs& s, const std::vector<ChannelLayout>& layout, const ColumnNames& nm)
 {
     std::string a;

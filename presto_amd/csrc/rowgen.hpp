@@ -33,6 +33,10 @@ void emit_prologue(const RowInputs& s, const std::vector<ChannelLayout>& layout,
 // vector loads of row quad q (into `o`) and the 4 argument lists of the per-row calls
 void emit_vector_loads(const RowInputs& s, const std::vector<ChannelLayout>& layout, std::ostringstream& o, std::string args[4],
                        const ColumnNames& names = ColumnNames());
+// the same with the loads of the row's values named: declarations of locals <name><suffix> go to `decl` (so that the loads of several
+// rows can be issued before the first row is worked on), the returned argument list names them
+std::string scalar_loads(const RowInputs& s, const std::vector<ChannelLayout>& layout, const std::string& row, const std::string& suffix,
+                         std::ostringstream& decl, const ColumnNames& names = ColumnNames());
 // argument list of the scalar (row r) call
 std::string scalar_args(const RowInputs& s, const std::vector<ChannelLayout>& layout, const ColumnNames& names = ColumnNames());
 

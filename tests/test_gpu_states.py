@@ -152,6 +152,7 @@ def test_operator_blocks_on_the_hbm_budget_and_resumes(gpu, oracle, monkeypatch)
     from presto_amd._lib import check, lib
     from tests.test_gpu_small_pages import stable_regions
     monkeypatch.setenv("PRESTO_AMD_GATHER_ROWS", "1")   # no gathering: a page is launched (and its table allocated) as it arrives
+    monkeypatch.setenv("PRESTO_AMD_NO_PARTITIONED", "1")  # the HBM-table tier alone: one table, sized once by the planner's estimate
     rng = np.random.default_rng(2)
     n = 2_300_003                                        # above the small-page bound, so it is not copied into an arena either
     host = Page([Block.bigint(rng.integers(0, 300_000, n)), Block.bigint(rng.integers(-5, 5, n))], n)
