@@ -9,6 +9,7 @@
 // exact multi-channel comparison (all sort channels, NULL placement, ties in arrival order) at the end.  Rows tied with
 // the N-th on the first key are kept, so the result is exact; the reference leaves the order of fully tied rows open.
 #include <algorithm>
+#include <cmath>
 #include <cstring>
 #include <numeric>
 
@@ -70,8 +71,13 @@ public:
         const int64_t n = dp.n;
         for (size_t c = 0; c < types_.size(); c++) PA_REQUIRE(dp.cols[c].type == types_[c], PA_ERR_INVALID_ARGUMENT, "page block type does not match the declared input type");
         const DevColumn& first = dp.cols[sort_channels_[0]];
-        uint64_t* keys = static_cast<uint64_t*>(keys_.ensure((size_t)n * 8));
         timer.begin(s);
+        if (add_filtered(dp, first, n)) {
+            timer.end(s);
+            return;
+        }
+        // the exact way: a key per row, radix selection of the page's N-th best, ties refined channel by channel
+        uint64_t* keys = static_cast<uint64_t*>(keys_.ensure((size_t)n * 8));
         launch_topn_keys(first.type, first.values, first.offsets, first.nulls, n, sort_orders_[0], keys, s);
         // the N-th best first key of this page alone bounds the N-th best overall
         if (n >= n_) threshold_ = std::min(threshold_, topn_select_kth(keys, n, n_, select_temp_.ensure(topn_select_temp_bytes()), h_hist_, s));
@@ -105,10 +111,15 @@ public:
         output_done_ = true;
         const int64_t rows = (int64_t)store_keys_.size();
         if (rows == 0) return false;
-        std::vector<int64_t> order((size_t)rows);
-        std::iota(order.begin(), order.end(), 0);
-        std::stable_sort(order.begin(), order.end(), [&](int64_t a, int64_t b) { return compare_rows(a, b) < 0; });
-        const int64_t m = std::min<int64_t>(rows, n_);
+        // (rows beyond the bound cannot be among the N best: they need not be compared at all -- the bound is the exact N-th best
+        // first key whenever a page went the sampled way, and a few thousand candidates then shrink to N and its ties)
+        std::vector<int64_t> order;
+        order.reserve((size_t)rows);
+        for (int64_t i = 0; i < rows; i++) {
+            if (store_keys_[(size_t)i] <= threshold_) order.push_back(i);
+        }
+        std::sort(order.begin(), order.end(), [&](int64_t a, int64_t b) { return compare_rows(a, b) < 0; });
+        const int64_t m = std::min<int64_t>((int64_t)order.size(), n_);
         build_output(order, m);
         publish_output(out_cols_, (int32_t)m, output_mem_, stream_.get(), out, out_storage_);
         return true;
@@ -117,6 +128,64 @@ public:
     int64_t memory_bytes() override { return (int64_t)(stager_.bytes() + keys_.capacity() + keys2_.capacity() + state_.capacity() + part_.capacity() + pos_.capacity()); }
 
 private:
+    // The common case in ONE pass over the first sort channel: a bound for the page is drawn from a sample of its rows -- the
+    // order statistic of 2^16 evenly spaced rows that lies above the page's N-th best key with overwhelming probability -- and
+    // the rows not beyond min(that, the bound carried over from earlier pages) are collected as they are met, a few thousand
+    // of 2^26 (the exact way walks the page a dozen times: keys, two histogram passes, compaction, flags, states, partition --
+    // 34 G rows/s for the 100 best of 2^26 rows).  The exact N-th best key of everything kept so far then becomes the next
+    // page's bound.  Whatever the sample cannot vouch for goes the exact way: fewer than N rows under a bound that came from
+    // the sample (the sample was unlucky), or more rows than the sample promised (ties on the first key: refine_ties).
+    // true: the page was taken.
+    bool add_filtered(const DevPage& dp, const DevColumn& first, int64_t n)
+    {
+        if (getenv("PRESTO_AMD_TOPN_EXACT")) return false;
+        hipStream_t s = stream_.get();
+        constexpr int64_t kSample = (int64_t)1 << 16;
+        bool sampled = false;
+        int64_t expect = 0;
+        uint32_t* counter = static_cast<uint32_t*>(counts_.ensure(256)) + 32;  // [count, pad, bound (8 bytes)]
+        uint64_t* device_bound = reinterpret_cast<uint64_t*>(counter + 2);
+        if (n >= n_ && n >= 4 * kSample) {
+            const double j = (double)n_ * (double)kSample / (double)n;
+            const int64_t rank = (int64_t)std::ceil(j + 8.0 + 4.0 * std::sqrt(j));
+            if (rank <= kSample / 8) {
+                launch_topn_sample_bound(first.type, first.values, first.offsets, first.nulls, n, sort_orders_[0], kSample, rank,
+                                         static_cast<uint64_t*>(keys2_.ensure((size_t)kSample * 8)), device_bound, s);
+                sampled = true;
+                expect = rank * (n / kSample + 1);
+            }
+        }
+        if (!sampled && threshold_ == ~0ULL) return false;  // nothing bounds the page
+        const int64_t capacity = std::min<int64_t>(n, sampled ? 2 * expect + kSample : (int64_t)1 << 20);
+        int32_t* positions = static_cast<int32_t*>(pos_.ensure((size_t)capacity * 4));
+        uint64_t* keys = static_cast<uint64_t*>(keys_.ensure((size_t)capacity * 8));
+        launch_topn_filter(first.type, first.values, first.offsets, first.nulls, n, sort_orders_[0], threshold_, sampled ? device_bound : nullptr,
+                           (uint32_t)capacity, positions, keys, counter, s);
+        struct Landed {
+            uint32_t count, pad;
+            uint64_t bound;
+        };
+        Landed* h = reinterpret_cast<Landed*>(h_hist_);
+        PA_HIP(hipMemcpyAsync(h, counter, 16, hipMemcpyDeviceToHost, s));
+        PA_HIP(hipStreamSynchronize(s));
+        const int64_t count = (int64_t)h->count;
+        if (count > capacity) return false;
+        // fewer than N rows are only the whole truth under the carried-over bound (which holds by construction)
+        if (sampled && count < n_ && h->bound < threshold_) return false;
+        if (count == 0) return true;
+        // (the matches were collected as the waves met them: every row takes its arrival number along -- store_seq_ -- and fully
+        // tied rows are put in arrival order by the final comparison, not by the order they are stored in)
+        append_rows(dp, keys, positions, count, true);
+        // the exact N-th best first key of everything kept so far bounds every later page (and what prune keeps)
+        if ((int64_t)store_keys_.size() >= n_) {
+            std::vector<uint64_t> k(store_keys_);
+            std::nth_element(k.begin(), k.begin() + (n_ - 1), k.end());
+            threshold_ = std::min(threshold_, k[(size_t)n_ - 1]);
+        }
+        prune();
+        return true;
+    }
+
     // Many rows tied with the bound on the first sort key (ORDER BY a low-cardinality column ... LIMIT n; all-equal keys): they
     // would all cross to the host and be sorted there -- 12 M tied rows took 5.8 s.  A page contributes at most its OWN n best
     // rows to the result, so the page's ties are cut down on the device: among the rows tied so far, the next sort channel's
@@ -160,7 +229,8 @@ private:
     }
 
     // selected rows of the page -> host store (Block.copyPositions on device, then one D2H per column)
-    void append_rows(const DevPage& dp, const uint64_t* keys, const int32_t* positions, int64_t count)
+    // (keys_compacted: keys[i] belongs to positions[i]; else keys is the page's key array)
+    void append_rows(const DevPage& dp, const uint64_t* keys, const int32_t* positions, int64_t count, bool keys_compacted = false)
     {
         hipStream_t s = stream_.get();
         const int64_t n = dp.n;
@@ -183,6 +253,7 @@ private:
             return pieces.size() - 1;
         };
         const size_t key_piece = reserve((size_t)count * 8);
+        const size_t pos_piece = positions ? reserve((size_t)count * 4) : (size_t)-1;
         std::vector<size_t> null_piece(types_.size(), (size_t)-1), value_piece(types_.size(), (size_t)-1);
         for (size_t c = 0; c < types_.size(); c++) {
             const DevColumn& col = dp.cols[c];
@@ -200,7 +271,9 @@ private:
                 PA_HIP(hipMemcpyAsync(dst, src, pieces[piece].bytes, hipMemcpyDeviceToDevice, s));
             }
         };
-        place(key_piece, keys, 8);
+        if (keys_compacted) PA_HIP(hipMemcpyAsync(side + pieces[key_piece].at, keys, (size_t)count * 8, hipMemcpyDeviceToDevice, s));
+        else place(key_piece, keys, 8);
+        if (positions) PA_HIP(hipMemcpyAsync(side + pieces[pos_piece].at, positions, (size_t)count * 4, hipMemcpyDeviceToDevice, s));
         for (size_t c = 0; c < types_.size(); c++) {
             const DevColumn& col = dp.cols[c];
             if (col.nulls) place(null_piece[c], col.nulls, 0);
@@ -213,6 +286,11 @@ private:
             const size_t old = store_keys_.size();
             store_keys_.resize(old + (size_t)count);
             memcpy(store_keys_.data() + old, landed + pieces[key_piece].at, (size_t)count * 8);
+            // arrival number of every row: (page, position in the page)
+            store_seq_.resize(old + (size_t)count);
+            const int32_t* hp = positions ? reinterpret_cast<const int32_t*>(landed + pieces[pos_piece].at) : nullptr;
+            for (int64_t i = 0; i < count; i++) store_seq_[old + (size_t)i] = (pages_seen_ << 32) | (uint64_t)(uint32_t)(hp ? hp[i] : (int32_t)i);
+            pages_seen_++;
         }
         for (size_t c = 0; c < types_.size(); c++) {
             const DevColumn& col = dp.cols[c];
@@ -266,8 +344,13 @@ private:
         }
         if (keep.size() == rows) return;
         std::vector<uint64_t> nk(keep.size());
-        for (size_t i = 0; i < keep.size(); i++) nk[i] = store_keys_[(size_t)keep[i]];
+        std::vector<uint64_t> ns(keep.size());
+        for (size_t i = 0; i < keep.size(); i++) {
+            nk[i] = store_keys_[(size_t)keep[i]];
+            ns[i] = store_seq_[(size_t)keep[i]];
+        }
         store_keys_.swap(nk);
+        store_seq_.swap(ns);
         for (auto& hc : store_) {
             HostColumn out;
             out.type = hc.type;
@@ -317,7 +400,8 @@ private:
             }
             if (c != 0) return c;
         }
-        return 0;
+        // fully tied rows: arrival order (what a stable sort of the rows as they came would leave)
+        return store_seq_[(size_t)a] < store_seq_[(size_t)b] ? -1 : (store_seq_[(size_t)a] > store_seq_[(size_t)b] ? 1 : 0);
     }
 
     static int compare_values(const HostColumn& hc, int64_t a, int64_t b)
@@ -418,10 +502,12 @@ private:
     uint64_t threshold_ = ~0ULL;  // rows whose first-channel key is above it cannot be among the N best
     DevBuf keys_, part_, pos_, counts_, part_temp_, select_temp_, gather_, var_off_, var_bytes_, scan_temp_;
     DevBuf keys2_, state_, tie_rank_;  // refine_ties
-    PinnedBuf land_, side_land_, h_hist_buf_;
+    PinnedBuf land_, side_land_, h_hist_buf_, found_land_;
     uint32_t* h_hist_ = nullptr;
     std::vector<HostColumn> store_;
     std::vector<uint64_t> store_keys_;
+    std::vector<uint64_t> store_seq_;   // arrival number of every stored row: (page << 32) | position
+    uint64_t pages_seen_ = 0;
     std::vector<OutColumn> out_cols_;
     std::vector<pa_column> out_storage_;
 };

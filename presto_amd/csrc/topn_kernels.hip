@@ -23,44 +23,100 @@ __device__ __forceinline__ u64 order_key(u64 ascending_image, bool is_null, int 
     return descending ? ~ascending_image : ascending_image;
 }
 
+// order-preserving 64-bit image of row i of a sort channel (see topn_kernels.hpp)
+__device__ __forceinline__ u64 row_key(i32 type, const void* __restrict__ values, const i32* __restrict__ offsets, const u8* __restrict__ nulls, i64 i,
+                                       i32 sort_order)
+{
+    const bool is_null = nulls && nulls[i];
+    u64 img = 0;
+    if (!is_null) {
+        switch (type) {
+            case PA_BIGINT: img = (u64)((const i64*)values)[i] ^ 0x8000000000000000ULL; break;
+            case PA_INTEGER:
+            case PA_DATE: img = (u64)(i64)((const i32*)values)[i] ^ 0x8000000000000000ULL; break;
+            case PA_BOOLEAN: img = ((const u8*)values)[i] ? 1ULL : 0ULL; break;
+            case PA_DOUBLE: {
+                // Double.compare order (DoubleType.compareTo): -0.0 < 0.0, NaN above everything, one NaN
+                double d = ((const double*)values)[i];
+                u64 b = d != d ? 0x7ff8000000000000ULL : (u64)__double_as_longlong(d);
+                img = (b >> 63) ? ~b : (b | 0x8000000000000000ULL);
+                break;
+            }
+            case PA_REAL: {
+                // Float.compare order (RealType.comparisonOperator) = Double.compare order of the widened values
+                const double d = (double)((const float*)values)[i];
+                u64 b = d != d ? 0x7ff8000000000000ULL : (u64)__double_as_longlong(d);
+                img = (b >> 63) ? ~b : (b | 0x8000000000000000ULL);
+                break;
+            }
+            case PA_VARCHAR: {
+                // Slice.compareTo = unsigned bytes, shorter first: the first 8 bytes big-endian are a monotone image
+                const i32 o = offsets[i], len = offsets[i + 1] - o;
+                const u8* p = (const u8*)values + o;
+                for (int b = 0; b < 8; b++) img = (img << 8) | (b < len ? (u64)p[b] : 0ULL);
+                break;
+            }
+            default: break;
+        }
+    }
+    return order_key(img, is_null, sort_order);
+}
+
 __global__ __launch_bounds__(256) void k_topn_keys(i32 type, const void* __restrict__ values, const i32* __restrict__ offsets,
                                                    const u8* __restrict__ nulls, i64 n, i32 sort_order, u64* __restrict__ keys)
 {
-    for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < n; i += (i64)gridDim.x * 256) {
-        const bool is_null = nulls && nulls[i];
-        u64 img = 0;
-        if (!is_null) {
-            switch (type) {
-                case PA_BIGINT: img = (u64)((const i64*)values)[i] ^ 0x8000000000000000ULL; break;
-                case PA_INTEGER:
-                case PA_DATE: img = (u64)(i64)((const i32*)values)[i] ^ 0x8000000000000000ULL; break;
-                case PA_BOOLEAN: img = ((const u8*)values)[i] ? 1ULL : 0ULL; break;
-                case PA_DOUBLE: {
-                    // Double.compare order (DoubleType.compareTo): -0.0 < 0.0, NaN above everything, one NaN
-                    double d = ((const double*)values)[i];
-                    u64 b = d != d ? 0x7ff8000000000000ULL : (u64)__double_as_longlong(d);
-                    img = (b >> 63) ? ~b : (b | 0x8000000000000000ULL);
-                    break;
-                }
-                case PA_REAL: {
-                    // Float.compare order (RealType.comparisonOperator) = Double.compare order of the widened values
-                    const double d = (double)((const float*)values)[i];
-                    u64 b = d != d ? 0x7ff8000000000000ULL : (u64)__double_as_longlong(d);
-                    img = (b >> 63) ? ~b : (b | 0x8000000000000000ULL);
-                    break;
-                }
-                case PA_VARCHAR: {
-                    // Slice.compareTo = unsigned bytes, shorter first: the first 8 bytes big-endian are a monotone image
-                    const i32 o = offsets[i], len = offsets[i + 1] - o;
-                    const u8* p = (const u8*)values + o;
-                    for (int b = 0; b < 8; b++) img = (img << 8) | (b < len ? (u64)p[b] : 0ULL);
-                    break;
-                }
-                default: break;
+    for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < n; i += (i64)gridDim.x * 256) keys[i] = row_key(type, values, offsets, nulls, i, sort_order);
+}
+
+// keys of every stride-th row (the sample the bound of a page is drawn from)
+__global__ __launch_bounds__(256) void k_topn_sample_keys(i32 type, const void* __restrict__ values, const i32* __restrict__ offsets,
+                                                          const u8* __restrict__ nulls, i64 stride, i64 count, i32 sort_order, u64* __restrict__ keys)
+{
+    for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < count; i += (i64)gridDim.x * 256) {
+        keys[i] = row_key(type, values, offsets, nulls, i * stride, sort_order);
+    }
+}
+
+// The rows whose key is not beyond the bound -- min(bound, *device_bound) -- in ANY order: positions and keys of the first
+// `capacity` of them, and how many there are in all (counter[0]; the host sees an overflow there).  One pass over the sort
+// channel itself: no key array.  A wave reserves room for its matches with one atomic; matches are few by construction.
+__global__ __launch_bounds__(256) void k_topn_filter(i32 type, const void* __restrict__ values, const i32* __restrict__ offsets, const u8* __restrict__ nulls,
+                                                     i64 n, i32 sort_order, u64 bound, const u64* __restrict__ device_bound, u32 capacity,
+                                                     i32* __restrict__ out_positions, u64* __restrict__ out_keys, u32* __restrict__ counter)
+{
+    const u64 limit = device_bound && *device_bound < bound ? *device_bound : bound;
+    const u32 lane = threadIdx.x & 63u;
+    const i64 step = (i64)gridDim.x * 256;
+    const i64 rounds = (n + step - 1) / step;  // wave-uniform trip count (the ballots below want whole waves)
+    i64 i = (i64)blockIdx.x * 256 + threadIdx.x;
+    for (i64 r = 0; r < rounds; r += 2, i += 2 * step) {
+        // two rows per lane and step: their loads are in flight together
+        const i64 j = i + step;
+        const u64 k0 = i < n ? row_key(type, values, offsets, nulls, i, sort_order) : ~0ULL;
+        const u64 k1 = j < n ? row_key(type, values, offsets, nulls, j, sort_order) : ~0ULL;
+        const bool keep0 = i < n && k0 <= limit, keep1 = j < n && k1 <= limit;
+        const u64 m0 = __ballot(keep0), m1 = __ballot(keep1);
+        if ((m0 | m1) == 0ULL) continue;
+        const u32 c0 = (u32)__popcll(m0), total = c0 + (u32)__popcll(m1);
+        u32 base = 0;
+        if (lane == 0) base = atomicAdd(counter, total);
+        base = (u32)__shfl((int)base, 0, 64);
+        if (keep0) {
+            const u32 at = base + (u32)__popcll(m0 & ((1ULL << lane) - 1ULL));
+            if (at < capacity) {
+                out_positions[at] = (i32)i;
+                out_keys[at] = k0;
             }
         }
-        keys[i] = order_key(img, is_null, sort_order);
+        if (keep1) {
+            const u32 at = base + c0 + (u32)__popcll(m1 & ((1ULL << lane) - 1ULL));
+            if (at < capacity) {
+                out_positions[at] = (i32)j;
+                out_keys[at] = k1;
+            }
+        }
     }
+    if (blockIdx.x == 0 && threadIdx.x == 0) counter[1] = 0u;  // (pads the read-back to 8 bytes)
 }
 
 // digit histogram of the keys that share the already selected prefix; one 256-bin row per workgroup
@@ -133,6 +189,7 @@ constexpr int64_t kSelectSmall = 1 << 18;
 __global__ __launch_bounds__(1024) void k_topn_select_small(const u64* __restrict__ keys, i64 n, u64 prefix, int shift, i64 remaining, u64* __restrict__ out)
 {
     __shared__ u32 hist[256];
+    __shared__ u32 scan[256];
     __shared__ u64 s_prefix;
     __shared__ i64 s_remaining;
     if (threadIdx.x == 0) {
@@ -143,23 +200,43 @@ __global__ __launch_bounds__(1024) void k_topn_select_small(const u64* __restric
         if (threadIdx.x < 256) hist[threadIdx.x] = 0;
         __syncthreads();
         const u64 pf = s_prefix;
-        for (i64 i = threadIdx.x; i < n; i += 1024) {
-            const u64 k = keys[i];
-            if (shift == 56 || (k >> (shift + 8)) == pf) atomicAdd(&hist[(k >> shift) & 255ULL], 1u);
+        // (the leading bytes of a page's keys are mostly the same: when all lanes of a wave hold one digit they add once, together
+        // -- 64 atomics on one LDS address otherwise take their turns)
+        const i64 rounds = (n + 1023) / 1024;
+        for (i64 r = 0; r < rounds; r++) {
+            const i64 i = r * 1024 + threadIdx.x;
+            const u64 k = i < n ? keys[i] : 0ULL;
+            const bool in = i < n && (shift == 56 || (k >> (shift + 8)) == pf);
+            const u32 digit = (u32)((k >> shift) & 255ULL);
+            const u64 members = __ballot(in);
+            if (members == 0ULL) continue;
+            const u32 first = (u32)__shfl((int)digit, __ffsll((long long)members) - 1, 64);
+            if (__ballot(in && digit == first) == members) {
+                if ((threadIdx.x & 63) == (u32)(__ffsll((long long)members) - 1)) atomicAdd(&hist[first], (u32)__popcll(members));
+            }
+            else if (in) atomicAdd(&hist[digit], 1u);
         }
         __syncthreads();
-        if (threadIdx.x == 0) {
-            int digit = 255;
-            i64 before = 0;
-            for (int d = 0; d < 256; d++) {
-                if (before + (i64)hist[d] >= s_remaining) {
-                    digit = d;
-                    break;
-                }
-                before += (i64)hist[d];
+        // the digit that holds the wanted rank: inclusive prefix sums of the 256 bins (one bin per thread of the first four waves), then
+        // the one bin whose sums straddle the rank speaks up (a single thread walking the bins took 25 us per digit)
+        if (threadIdx.x < 256) scan[threadIdx.x] = hist[threadIdx.x];
+        __syncthreads();
+        for (int d = 1; d < 256; d <<= 1) {
+            u32 add = 0;
+            if (threadIdx.x < 256 && (int)threadIdx.x >= d) add = scan[threadIdx.x - d];
+            __syncthreads();
+            if (threadIdx.x < 256) scan[threadIdx.x] += add;
+            __syncthreads();
+        }
+        const i64 want = s_remaining;
+        __syncthreads();
+        if (threadIdx.x < 256) {
+            const i64 incl = (i64)scan[threadIdx.x], before = incl - (i64)hist[threadIdx.x];
+            // (the last bin answers when the rank lies beyond all keys -- it cannot: the callers pass ranks within the key count)
+            if ((before < want && want <= incl) || (threadIdx.x == 255 && want > incl)) {
+                s_remaining = want - before;
+                s_prefix = (pf << 8) | (u64)threadIdx.x;
             }
-            s_remaining -= before;
-            s_prefix = (pf << 8) | (u64)digit;
         }
         __syncthreads();
     }
@@ -258,6 +335,29 @@ void launch_topn_keys(int32_t type, const void* values, const int32_t* offsets, 
 {
     if (n <= 0) return;
     hipLaunchKernelGGL(k_topn_keys, grid_of(n), 256, 0, s, type, values, (const i32*)offsets, (const u8*)nulls, (i64)n, sort_order, (u64*)keys);
+    PA_HIP(hipGetLastError());
+}
+
+void launch_topn_sample_bound(int32_t type, const void* values, const int32_t* offsets, const uint8_t* nulls, int64_t n, int32_t sort_order,
+                              int64_t sample_rows, int64_t rank, uint64_t* sample_keys, uint64_t* bound_out, hipStream_t s)
+{
+    PA_REQUIRE(sample_rows >= 1 && sample_rows <= kSelectSmall && rank >= 1 && rank <= sample_rows && n >= sample_rows, PA_ERR_INVALID_ARGUMENT,
+               "bad TopN sample");
+    const int64_t stride = n / sample_rows;
+    hipLaunchKernelGGL(k_topn_sample_keys, grid_of(sample_rows), 256, 0, s, type, values, (const i32*)offsets, (const u8*)nulls, (i64)stride,
+                       (i64)sample_rows, sort_order, (u64*)sample_keys);
+    hipLaunchKernelGGL(k_topn_select_small, 1, 1024, 0, s, (const u64*)sample_keys, (i64)sample_rows, (u64)0, 56, (i64)rank, (u64*)bound_out);
+    PA_HIP(hipGetLastError());
+}
+
+void launch_topn_filter(int32_t type, const void* values, const int32_t* offsets, const uint8_t* nulls, int64_t n, int32_t sort_order, uint64_t bound,
+                        const uint64_t* device_bound, uint32_t capacity, int32_t* out_positions, uint64_t* out_keys, uint32_t* counter, hipStream_t s)
+{
+    PA_HIP(hipMemsetAsync(counter, 0, 8, s));
+    if (n <= 0) return;
+    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((n + 511) / 512, 4096));
+    hipLaunchKernelGGL(k_topn_filter, grid, 256, 0, s, type, values, (const i32*)offsets, (const u8*)nulls, (i64)n, sort_order, (u64)bound,
+                       (const u64*)device_bound, capacity, out_positions, (u64*)out_keys, counter);
     PA_HIP(hipGetLastError());
 }
 

@@ -9,6 +9,14 @@ namespace pa {
 // key(a) <= key(b) (monotone, not injective: VARCHAR uses its first 8 bytes, NULLs share the extreme value of their side).
 void launch_topn_keys(int32_t type, const void* values, const int32_t* offsets, const uint8_t* nulls, int64_t n, int32_t sort_order,
                       uint64_t* keys, hipStream_t s);
+// A bound for a page drawn from a sample: the keys of `sample_rows` rows (every (n / sample_rows)-th; sample_rows <= 2^18) go to
+// sample_keys, the rank-th smallest of them (1-based) to *bound_out -- both device memory; nothing is waited for.
+void launch_topn_sample_bound(int32_t type, const void* values, const int32_t* offsets, const uint8_t* nulls, int64_t n, int32_t sort_order,
+                              int64_t sample_rows, int64_t rank, uint64_t* sample_keys, uint64_t* bound_out, hipStream_t s);
+// One pass over the sort channel: positions and keys (in no particular order) of the rows whose key is <= min(bound, *device_bound)
+// (device_bound may be null), at most `capacity` of them; counter[0] = how many such rows there are (8 bytes of device memory).
+void launch_topn_filter(int32_t type, const void* values, const int32_t* offsets, const uint8_t* nulls, int64_t n, int32_t sort_order, uint64_t bound,
+                        const uint64_t* device_bound, uint32_t capacity, int32_t* out_positions, uint64_t* out_keys, uint32_t* counter, hipStream_t s);
 // The k-th smallest key (1-based) by MSB radix selection; temp >= topn_select_temp_bytes(); synchronises the stream.
 size_t topn_select_temp_bytes();
 uint64_t topn_select_kth(const uint64_t* keys, int64_t n, int64_t k, void* temp, uint32_t* host_hist_pinned, hipStream_t s);

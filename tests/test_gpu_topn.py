@@ -115,3 +115,44 @@ def test_topn_with_masses_of_ties_on_the_first_key(gpu, oracle, shape):
         else:
             assert got == expected, (got[:3], expected[:3])
         assert elapsed < (20.0 if shape == "varchar_second" else 3.0), elapsed
+
+
+@pytest.mark.parametrize("shape", ["random", "ascending", "descending", "fifty_values", "three_values", "nulls_first"])
+def test_topn_large_pages_take_the_sampled_single_pass(gpu, oracle, shape):
+    """Pages of >= 2^18 rows: the page's bound is drawn from a sample and the candidates are collected in one pass over the first sort
+    channel (op_topn.cpp add_filtered); inputs that get better page after page, ties with the bound (within what the sample
+    promised, and beyond it: the exact way takes over) and NULLs sorting first must all give the oracle's rows in the oracle's
+    order.  (The oracle is handed the rows that can matter -- everything not worse than the 2 N-th best first key, in arrival
+    order -- so that it finishes in seconds.)"""
+    rng = np.random.default_rng(len(shape) + 40)
+    n = 270_001 if shape == "three_values" else 700_001
+    pages = []
+    for p in range(1 if shape == "three_values" else 3):
+        if shape == "random":
+            first = rng.standard_normal(n) * 1e6
+        elif shape == "ascending":      # DESC order below: every page holds better rows than all before it
+            first = np.arange(n, dtype=np.float64) + p * n
+        elif shape == "descending":
+            first = -(np.arange(n, dtype=np.float64) + p * n)
+        elif shape == "fifty_values":
+            first = rng.integers(0, 50, n).astype(np.float64)
+        elif shape == "three_values":
+            first = rng.integers(0, 3, n).astype(np.float64)
+        else:
+            first = rng.random(n)
+        nulls = (rng.random(n) < (0.01 if shape == "nulls_first" else 0.001))
+        pages.append(Page([Block.double(first, nulls), Block.bigint(rng.permutation(n) + p * n)], n))
+    types = [abi.DOUBLE, abi.BIGINT]
+    nulls_first = shape == "nulls_first"
+    orders = [abi.DESC_NULLS_FIRST if nulls_first else abi.DESC_NULLS_LAST, abi.ASC_NULLS_LAST]
+    first_all = np.concatenate([p.blocks[0].values for p in pages])
+    nulls_all = np.concatenate([p.blocks[0].nulls for p in pages])
+    second_all = np.concatenate([p.blocks[1].values for p in pages])
+    score = np.where(nulls_all != 0, np.inf if nulls_first else -np.inf, first_all)
+    for limit in (100, 20_000):
+        cut = np.partition(score, len(score) - 2 * limit)[len(score) - 2 * limit]
+        keep = score >= cut
+        relevant = Page([Block.double(first_all[keep], nulls_all[keep] != 0), Block.bigint(second_all[keep])], int(keep.sum()))
+        expected = oracle.topn([relevant], limit, [0, 1], orders)
+        got = rows_of(to_pages(TopNOperator(types, limit, [0, 1], orders), pages))
+        assert got == expected, (shape, limit, got[:3], expected[:3])
