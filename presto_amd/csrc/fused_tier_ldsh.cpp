@@ -108,7 +108,10 @@ void FusedGen::ldsh_kernel_end()
 {
     // the workgroup's table -> HBM table: one upsert and PA_NW atomics per group and workgroup
     src << "    __syncthreads();\n    const u64 cap = (u64)a.gt_mask + 1ULL;\n";
-    src << "    for (int sl = threadIdx.x; sl < PA_LC; sl += " << B << ") {\n        if (pa_lt_tag[sl] == 0ULL) continue;\n"
+    // (every workgroup starts somewhere else in its table: a group sits at the same place in all of them -- the slot is a function
+    // of the key's hash -- and 256 workgroups flushing slot after slot in step would meet on one HBM address after the other)
+    src << "    for (int s0 = threadIdx.x; s0 < PA_LC; s0 += " << B << ") {\n        const int sl = (s0 + (int)(blockIdx.x * 1297u)) & (PA_LC - 1);\n"
+           "        if (pa_lt_tag[sl] == 0ULL) continue;\n"
            "        u64 fk[PA_KW];\n#pragma unroll\n        for (int w = 0; w < PA_KW; w++) fk[w] = pa_lt_key[sl * PA_KW + w];\n"
            "        const int g = pa_gt_upsert<PA_KW>(acc.tv.tag, acc.tv.keys, a.gt_mask, pa_key_hash(fk, PA_KW), fk, acc.flush, 0x7fffffff, a.err);\n"
            "        if (g < 0) { pa_raise(a.err, PA_DEV_ERR_RESOURCES); continue; }\n";

@@ -7,7 +7,7 @@ timeout -k 10 400 python -m pytest -x -q -m gpu tests/test_gpu_fused.py tests/te
 tail -3 $O/r3_p10_tests.log
 cd /tmp && export TMPDIR=/tmp
 rm -rf $O/r3_agg_e
-AGG_GROUPS=3000000,1000000,300000,100000,20000,3000 timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d $O/r3_agg_e -- python3 $R/scripts/bench_operators.py agg > $O/r3_agg_e.txt 2> $O/r3_agg_e.err
+AGG_GROUPS=100000,20000,3000,2000,1000,300,64,4 timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d $O/r3_agg_e -- python3 $R/scripts/bench_operators.py agg > $O/r3_agg_e.txt 2> $O/r3_agg_e.err
 cat $O/r3_agg_e.txt
 f=$(ls $O/r3_agg_e/*/*_kernel_stats.csv | head -1)
 head -14 $f | cut -c1-150

@@ -94,7 +94,8 @@ with open(os.path.join(out, tag + "_summary.md"), "w") as f:
         f.write("| `%s` | %s | %.3f | %.1f | %s |\n" % (r["Name"][:70], r["Calls"], int(r["TotalDurationNs"]) / 1e6, float(r["AverageNs"]) / 1e3, r["Percentage"]))
     f.write("\n## fused kernels (per launch = one 2^28-row page (the last page of the table is shorter))\n\n| kernel | launches | avg ms | FETCH_SIZE KiB (raw) | WRITE_SIZE KiB | HBM bytes / launch (corrected) |\n|---|---|---|---|---|---|\n")
     for k, t in traffic.items():
-        f.write("| pa_fused %s | %d | %.4f | %.0f | %.1f | %.4g |\n" % (k, t["launches"], t["avg_launch_ms"], t["fetch_size_kib_raw"], t["write_size_kib"], t["hbm_bytes_per_launch"]))
+        f.write("| pa_fused %s | %d | %.4f | %.0f | %.1f | %.4g |\n" % (k, t["launches"], t.get("avg_launch_ms", float("nan")), t["fetch_size_kib_raw"], t.get("write_size_kib", 0.0),
+                                                                        t["hbm_bytes_per_launch"]))
     if bench_json and os.path.exists(bench_json):
         f.write("\n## bench.py line of the traced run\n\n```\n%s\n```\n" % open(bench_json).read().strip())
 print(json.dumps(traffic, indent=1))
