@@ -347,12 +347,25 @@ __global__ __launch_bounds__(256) void k_join_part_ids(JoinCol build_key, i32 n,
         rowpos[p] = null ? -1 : p;
     }
 }
-// err[1]: some key has several rows; err[2]: a partition holds more rows than its slots take (the caller builds the table the
-// other way in both cases: chains need slot_of, which this build does not produce)
+// err[1]: some key has several rows (their chains are built here too, see below); err[2]: a partition holds more rows than its
+// slots take, or a key has more rows than the chain rounds below are good for -- the caller then builds the table the other way.
+//
+// Chains (ArrayPositionLinks, ArrayPositionLinks.java:45-50: the rows of a key from the highest position down).  A partition's
+// rows sit in the registers of its workgroup -- seven per thread -- so a chain is put together in rounds, in LDS: the slot's head
+// is the highest position (an atomic max while the rows are inserted); in every round each row not yet on its chain offers its
+// position to the current tail's link (another atomic max), the one whose offer stands has become the new tail.  Rounds = the
+// longest chain of the partition; no row reads another row's position from HBM, and the links leave the workgroup as one store
+// per row.  (The table-wide way -- a lock-free sorted-list insertion through HBM, k_join_keyed_links -- took 1.9 ms for 8 M rows
+// with five rows per key.)
+constexpr int kJoinPartRowsMax = kJoinPartSlots - kJoinPartSlots / 8;  // rows of a partition (load <= 7/8)
+constexpr int kJoinPartRowsPerThread = (kJoinPartRowsMax + 1023) / 1024;
+constexpr int kJoinPartChainRounds = 256;
 __global__ __launch_bounds__(1024) void k_join_part_build(const u64* __restrict__ keys, const i32* __restrict__ rows, const i64* __restrict__ first, u32 mask,
-                                                          JoinKeySlot* __restrict__ slots, i32* err)
+                                                          JoinKeySlot* __restrict__ slots, i32* __restrict__ links, i32* err)
 {
     __shared__ JoinKeySlot tab[kJoinPartSlots];
+    __shared__ i32 lnext[kJoinPartRowsMax];  // chain link of local row li, as a build position (-1: none)
+    __shared__ int any_dup, more;
     constexpr u32 lmask = kJoinPartSlots - 1;
     for (int i = threadIdx.x; i < kJoinPartSlots; i += 1024) {
         JoinKeySlot e;
@@ -361,14 +374,21 @@ __global__ __launch_bounds__(1024) void k_join_part_build(const u64* __restrict_
         e.next = -1;
         tab[i] = e;
     }
+    if (threadIdx.x == 0) any_dup = 0;
     __syncthreads();
     const i64 b0 = first[blockIdx.x], b1 = first[blockIdx.x + 1];
-    if (b1 - b0 > (i64)(kJoinPartSlots - kJoinPartSlots / 8)) {
+    i32 my_p[kJoinPartRowsPerThread];
+    u32 my_slot[kJoinPartRowsPerThread];
+#pragma unroll
+    for (int r = 0; r < kJoinPartRowsPerThread; r++) my_p[r] = -1;
+    if (b1 - b0 > (i64)kJoinPartRowsMax) {
         if (threadIdx.x == 0) err[2] = 1;
     }
     else {
-        const i64 padded = b0 + ((b1 - b0 + 1023) & ~(i64)1023);
-        for (i64 i = b0 + threadIdx.x; i < padded; i += 1024) {
+#pragma unroll
+        for (int r = 0; r < kJoinPartRowsPerThread; r++) {
+            const i64 i = b0 + (i64)r * 1024 + threadIdx.x;
+            if (b0 + (i64)r * 1024 >= b1) break;  // (uniform: whole rounds of 1024 rows)
             const i32 p = i < b1 ? rows[i] : -1;
             bool pending = p >= 0;
             const u64 v = i < b1 ? keys[i] : 0ULL;
@@ -388,7 +408,7 @@ __global__ __launch_bounds__(1024) void k_join_part_build(const u64* __restrict_
                     if (pending && cur >= 0) {
                         (void)__hip_atomic_load(&tab[pos].head, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
                         if (__hip_atomic_load(&tab[pos].key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == v) {
-                            err[1] = 1;
+                            any_dup = 1;
                             __hip_atomic_fetch_max(&tab[pos].head, p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                             pending = false;
                         }
@@ -396,9 +416,64 @@ __global__ __launch_bounds__(1024) void k_join_part_build(const u64* __restrict_
                     }
                 }
             }
+            my_p[r] = p;
+            my_slot[r] = pos;
         }
     }
     __syncthreads();
+    if (any_dup) {  // (uniform: LDS flag behind a barrier)
+        if (threadIdx.x == 0) err[1] = 1;
+        bool linked[kJoinPartRowsPerThread];
+        // the head of every chain is known (the slot's maximum): it is the first tail; tab[slot].next names the tail's local row
+#pragma unroll
+        for (int r = 0; r < kJoinPartRowsPerThread; r++) {
+            linked[r] = true;
+            if (my_p[r] < 0) continue;
+            const int li = r * 1024 + (int)threadIdx.x;
+            lnext[li] = -1;
+            linked[r] = tab[my_slot[r]].head == my_p[r];
+            if (linked[r]) tab[my_slot[r]].next = li;
+        }
+        __syncthreads();
+        int round = 0;
+        for (; round < kJoinPartChainRounds; round++) {
+            if (threadIdx.x == 0) more = 0;
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < kJoinPartRowsPerThread; r++) {
+                if (linked[r]) continue;
+                __hip_atomic_fetch_max(&lnext[tab[my_slot[r]].next], my_p[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                more = 1;
+            }
+            __syncthreads();
+            if (!more) break;
+            bool tail_now[kJoinPartRowsPerThread];
+#pragma unroll
+            for (int r = 0; r < kJoinPartRowsPerThread; r++) {
+                tail_now[r] = !linked[r] && lnext[tab[my_slot[r]].next] == my_p[r];
+            }
+            __syncthreads();  // (every row has read its chain's tail before any tail moves)
+#pragma unroll
+            for (int r = 0; r < kJoinPartRowsPerThread; r++) {
+                if (!tail_now[r]) continue;
+                linked[r] = true;
+                tab[my_slot[r]].next = r * 1024 + (int)threadIdx.x;
+            }
+            __syncthreads();
+        }
+        if (round == kJoinPartChainRounds && threadIdx.x == 0) err[2] = 1;  // a key with more rows than that: the caller's other way
+        // the links leave for HBM; the slot keeps its head's link (JoinKeySlot::next)
+#pragma unroll
+        for (int r = 0; r < kJoinPartRowsPerThread; r++) {
+            if (my_p[r] >= 0) links[my_p[r]] = lnext[r * 1024 + (int)threadIdx.x];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < kJoinPartRowsPerThread; r++) {
+            if (my_p[r] >= 0 && tab[my_slot[r]].head == my_p[r]) tab[my_slot[r]].next = lnext[r * 1024 + (int)threadIdx.x];
+        }
+        __syncthreads();
+    }
     const uint4* src = (const uint4*)tab;
     uint4* dst = (uint4*)(slots + (u64)blockIdx.x * kJoinPartSlots);
     for (int i = threadIdx.x; i < kJoinPartSlots; i += 1024) dst[i] = src[i];
@@ -531,8 +606,9 @@ __device__ __forceinline__ i32 join_rank_of(const JoinRankWord* __restrict__ wor
     return (i32)w.z + (i32)__popcll(bits & ((1ULL << b) - 1ULL));
 }
 __global__ __launch_bounds__(256) void k_join_rank_rows_pairs(const u64* __restrict__ keys, const i32* __restrict__ rowpos, i64 n,
-                                                              const JoinRankWord* __restrict__ words, i64 min_key, i32* __restrict__ rows)
+                                                              const JoinRankWord* __restrict__ words, i64 min_key, i32* __restrict__ rows, const i32* __restrict__ distinct)
 {
+    if (distinct && (i64)*distinct != n) return;
     for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < n; i += (i64)gridDim.x * 256) {
         const i32 r = join_rank_of(words, (u64)((i64)keys[i] - min_key));
         if (r >= 0) rows[r] = rowpos[i];
@@ -544,9 +620,10 @@ __global__ __launch_bounds__(256) void k_join_rank_rows_pairs(const u64* __restr
 constexpr int kJoinRangeRowsMax = 32768;   // key values per partition this form takes (128 KB of LDS)
 __global__ __launch_bounds__(1024) void k_join_range_rows(const u64* __restrict__ keys, const i32* __restrict__ rowpos, const i64* __restrict__ first,
                                                           i32 partitions, const JoinRankWord* __restrict__ words, i64 min_key, int shift, i64 n,
-                                                          i32* __restrict__ rows)
+                                                          i32* __restrict__ rows, const i32* __restrict__ distinct)
 {
     __shared__ i32 stage[kJoinRangeRowsMax];
+    if (distinct && (i64)*distinct != n) return;  // some key has several rows: the index will be dropped, nothing to write
     for (i32 p = (i32)blockIdx.x; p < partitions; p += (i32)gridDim.x) {
         const i64 b0 = first[p], b1 = first[p + 1];
         if (b1 <= b0) continue;   // (uniform: every thread reads the same bounds)
@@ -566,8 +643,9 @@ __global__ __launch_bounds__(1024) void k_join_range_rows(const u64* __restrict_
     }
 }
 __global__ __launch_bounds__(256) void k_join_rank_rows(JoinCol build_key, i32 n, const JoinRankWord* __restrict__ words, i64 min_key, i32* __restrict__ rows,
-                                                        i32* __restrict__ unordered)
+                                                        i32* __restrict__ unordered, const i32* __restrict__ distinct)
 {
+    if (distinct && *distinct != n) return;  // some key has several rows: the index will be dropped
     bool off = false;
     for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < n; i += (i64)gridDim.x * 256) {
         const i32 r = join_rank_of(words, (u64)((i64)join_key_bits(build_key, (i32)i) - min_key));  // (every build key has its bit)
@@ -712,9 +790,9 @@ void launch_join_part_ids(const JoinCol& build_key, int32_t n, uint32_t slots_ma
     PA_HIP(hipGetLastError());
 }
 void launch_join_part_build(const uint64_t* keys, const int32_t* rows, const int64_t* first, int32_t partitions, uint32_t slots_mask, JoinKeySlot* slots,
-                            int32_t* err, hipStream_t s)
+                            int32_t* links, int32_t* err, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_join_part_build, partitions, 1024, 0, s, (const u64*)keys, rows, (const i64*)first, slots_mask, slots, err);
+    hipLaunchKernelGGL(k_join_part_build, partitions, 1024, 0, s, (const u64*)keys, rows, (const i64*)first, slots_mask, slots, links, err);
     PA_HIP(hipGetLastError());
 }
 void launch_join_keyed_links(int32_t n, JoinKeySlot* slots, uint32_t slots_mask, const int32_t* slot_of, int32_t* links, hipStream_t s)
@@ -757,16 +835,16 @@ void launch_join_range_bitmap(const uint64_t* keys, const int64_t* first, int32_
     PA_HIP(hipGetLastError());
 }
 void launch_join_rank_rows_pairs(const uint64_t* keys, const int32_t* rowpos, int64_t n, const JoinRankWord* words, int64_t min_key, int32_t* rows,
-                                 hipStream_t s, const int64_t* first, int32_t partitions, int shift)
+                                 hipStream_t s, const int64_t* first, int32_t partitions, int shift, const int32_t* distinct)
 {
     if (n <= 0) return;
     if (first != nullptr && shift >= 6 && (1 << shift) <= kJoinRangeRowsMax) {
         hipLaunchKernelGGL(k_join_range_rows, std::min(partitions, 2048), 1024, 0, s, (const u64*)keys, rowpos, (const i64*)first, partitions, words, (i64)min_key,
-                           shift, (i64)n, rows);
+                           shift, (i64)n, rows, distinct);
         PA_HIP(hipGetLastError());
         return;
     }
-    hipLaunchKernelGGL(k_join_rank_rows_pairs, grid_for(n), 256, 0, s, (const u64*)keys, rowpos, (i64)n, words, (i64)min_key, rows);
+    hipLaunchKernelGGL(k_join_rank_rows_pairs, grid_for(n), 256, 0, s, (const u64*)keys, rowpos, (i64)n, words, (i64)min_key, rows, distinct);
     PA_HIP(hipGetLastError());
 }
 void launch_join_rank_words(const uint64_t* bits, int64_t nwords, JoinRankWord* words, int32_t* counts, void* temp, int32_t* total_out, hipStream_t s)
@@ -777,10 +855,11 @@ void launch_join_rank_words(const uint64_t* bits, int64_t nwords, JoinRankWord* 
     hipLaunchKernelGGL(k_join_rank_zip, grid_for(nwords), 256, 0, s, (const u64*)bits, (const i32*)counts, (i64)nwords, words);
     PA_HIP(hipGetLastError());
 }
-void launch_join_rank_rows(const JoinCol& build_key, int32_t n, const JoinRankWord* words, int64_t min_key, int32_t* rows, int32_t* unordered, hipStream_t s)
+void launch_join_rank_rows(const JoinCol& build_key, int32_t n, const JoinRankWord* words, int64_t min_key, int32_t* rows, int32_t* unordered, hipStream_t s,
+                           const int32_t* distinct)
 {
     if (n <= 0) return;
-    hipLaunchKernelGGL(k_join_rank_rows, grid_for(n), 256, 0, s, build_key, n, words, (i64)min_key, rows, unordered);
+    hipLaunchKernelGGL(k_join_rank_rows, grid_for(n), 256, 0, s, build_key, n, words, (i64)min_key, rows, unordered, distinct);
     PA_HIP(hipGetLastError());
 }
 void launch_join_probe_count_keyed(const JoinCol& probe_key, const int64_t* probe_hash, int32_t n_probe, const JoinKeySlot* slots, uint32_t mask,

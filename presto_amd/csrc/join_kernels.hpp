@@ -55,13 +55,14 @@ void launch_join_keyed_build(const JoinCol& build_key, const int64_t* raw_hash, 
                              int32_t* links, int32_t* err, hipStream_t s);
 // Partitioned build (join_kernels.hip): partition = home slot >> kJoinPartSlotsLog2; part / keybits / rowpos: n entries each, to be
 // regrouped by partition (launch_msplit) before launch_join_part_build, which takes first[p] = offset of partition p's rows
-// (partitions + 1 entries).  err[1] / err[2]: duplicate keys / an overfull partition -- the caller then builds with
-// launch_join_keyed_build instead.
+// (partitions + 1 entries) and writes the chains of keys with several rows into `links` (pre-filled with -1) and the slots' `next`
+// fields itself.  err[1]: some key has several rows; err[2]: an overfull partition, or a key with hundreds of rows -- the caller
+// then builds with launch_join_keyed_build instead.
 constexpr int kJoinPartSlotsLog2 = 13;
 constexpr int kJoinPartSlots = 1 << kJoinPartSlotsLog2;  // 8192 slots = 128 KB of LDS
 void launch_join_part_ids(const JoinCol& build_key, int32_t n, uint32_t slots_mask, int32_t* part, uint64_t* keybits, int32_t* rowpos, hipStream_t s);
 void launch_join_part_build(const uint64_t* keys, const int32_t* rows, const int64_t* first, int32_t partitions, uint32_t slots_mask, JoinKeySlot* slots,
-                            int32_t* err, hipStream_t s);
+                            int32_t* links, int32_t* err, hipStream_t s);
 // positionLinks and the slots' `next` fields: only needed when some key has several rows (err[1] of the build; every link and
 // every `next` is -1 otherwise, which is what the build leaves)
 void launch_join_keyed_links(int32_t n, JoinKeySlot* slots, uint32_t slots_mask, const int32_t* slot_of, int32_t* links, hipStream_t s);
@@ -86,7 +87,9 @@ struct JoinRankIndex {
 // counts: nwords int32 of scratch; temp: scan_temp_bytes(nwords)
 void launch_join_rank_words(const uint64_t* bits, int64_t nwords, JoinRankWord* words, int32_t* counts, void* temp, int32_t* total_out, hipStream_t s);
 // rows[rank(key of build row i)] = i for all rows (no NULL keys); *unordered (device, zeroed by the caller) = 1 when some rank != i
-void launch_join_rank_rows(const JoinCol& build_key, int32_t n, const JoinRankWord* words, int64_t min_key, int32_t* rows, int32_t* unordered, hipStream_t s);
+// (distinct: device word holding the number of distinct build keys, or null -- when it is not n the index cannot hold and the pass does nothing)
+void launch_join_rank_rows(const JoinCol& build_key, int32_t n, const JoinRankWord* words, int64_t min_key, int32_t* rows, int32_t* unordered, hipStream_t s,
+                           const int32_t* distinct = nullptr);
 // wrap = mask, or kJoinPartSlots - 1 for a table built in partitions (the probe sequence of a key then stays inside the
 // kJoinPartSlots-slot partition of its home slot)
 void launch_join_probe_count_keyed(const JoinCol& probe_key, const int64_t* probe_hash, int32_t n_probe, const JoinKeySlot* slots, uint32_t mask,
@@ -100,7 +103,7 @@ void launch_join_range_ids(const JoinCol& build_key, int32_t n, int64_t min_key,
 void launch_join_range_bitmap(const uint64_t* keys, const int64_t* first, int32_t partitions, int64_t min_key, int shift, uint64_t range, uint64_t* bits,
                               hipStream_t s);
 void launch_join_rank_rows_pairs(const uint64_t* keys, const int32_t* rowpos, int64_t n, const JoinRankWord* words, int64_t min_key, int32_t* rows,
-                                 hipStream_t s, const int64_t* first = nullptr, int32_t partitions = 0, int shift = 0);
+                                 hipStream_t s, const int64_t* first = nullptr, int32_t partitions = 0, int shift = 0, const int32_t* distinct = nullptr);
 void launch_join_unvisited_flag(const uint8_t* visited, int64_t n, int32_t* partition, hipStream_t s);
 // DefaultPageJoiner.joinCurrentPosition: (probe position, build position) pairs in emission order
 void launch_join_probe_emit(const int32_t* head, const int32_t* offsets, int32_t n_probe, int32_t total, const int32_t* links, int32_t* probe_idx,

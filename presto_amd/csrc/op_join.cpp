@@ -167,7 +167,7 @@ public:
             const int32_t dups = build_key_slots(bk.col[0], n, slots, s);
             // chains exist only when some key has several rows: two passes over the rows and the table that unique keys -- the build
             // side of a primary-key join -- do without
-            if (dups) launch_join_keyed_links(n, ls_->key_slots.as<JoinKeySlot>(), ls_->probe_mask, ls_->slot_of.as<int32_t>(), ls_->links.as<int32_t>(), s);
+            if (dups && !links_built_) launch_join_keyed_links(n, ls_->key_slots.as<JoinKeySlot>(), ls_->probe_mask, ls_->slot_of.as<int32_t>(), ls_->links.as<int32_t>(), s);
             keyed_dups = dups != 0;
         };
         timer.begin(s);
@@ -222,11 +222,14 @@ public:
         // (not with a $hashvalue channel: the partitioned build places rows by the hash it computes from the key itself, the
         // probe by the channel's value -- the two must be the same function)
         if (raw == nullptr && n >= (1 << 20) && partitions >= 2 && partitions <= 4096 && !getenv("PRESTO_AMD_NO_PARTITIONED_BUILD")) {
-            if (partitioned_build(key, n, table, (int32_t)partitions, s)) {
+            const int built = partitioned_build(key, n, table, (int32_t)partitions, s);
+            if (built) {
                 ls_->probe_wrap = (uint32_t)kJoinPartSlots - 1u;
-                return 0;
+                links_built_ = true;  // (chains of keys with several rows included)
+                return built == 2 ? 1 : 0;
             }
         }
+        links_built_ = false;
         int32_t dups = 0;
         PA_HIP(hipMemsetAsync(ctl_ + 1, 0, 8, s));
         launch_join_keyed_build(key, raw, n, table, ls_->probe_mask, ls_->slot_of.as<int32_t>(), ls_->links.as<int32_t>(), ctl_, s);
@@ -254,10 +257,10 @@ public:
         // (rows of duplicate keys overwrite each other here: the index is dropped then)
         if (pairs_ == n) {  // the pairs regrouped by key range: the scatter stays inside one partition's slice at a time
             launch_join_rank_rows_pairs(pair_keys_.as<uint64_t>(), pair_rows_.as<int32_t>(), n, words, ls_->bitmap.min_key,
-                                        static_cast<int32_t*>(ls_->rank_rows.ensure((size_t)n * 4)), s, pair_first_.as<int64_t>(), pair_partitions_, pair_shift_);
+                                        static_cast<int32_t*>(ls_->rank_rows.ensure((size_t)n * 4)), s, pair_first_.as<int64_t>(), pair_partitions_, pair_shift_, ctl_ + 4);
             PA_HIP(hipMemsetAsync(ctl_ + 5, 1, 4, s));   // "out of key order" (non-zero), by the check that brought us here
         }
-        else launch_join_rank_rows(key, n, words, ls_->bitmap.min_key, static_cast<int32_t*>(ls_->rank_rows.ensure((size_t)n * 4)), ctl_ + 5, s);
+        else launch_join_rank_rows(key, n, words, ls_->bitmap.min_key, static_cast<int32_t*>(ls_->rank_rows.ensure((size_t)n * 4)), ctl_ + 5, s, ctl_ + 4);
         pair_keys_.release();
         pair_rows_.release();
         pair_first_.release();
@@ -278,8 +281,9 @@ public:
         return true;
     }
 
-    // true: `table` holds the keyed probe-side table, built partition by partition (links stay -1: no key has several rows)
-    bool partitioned_build(const JoinCol& key, int32_t n, JoinKeySlot* table, int32_t partitions, hipStream_t s)
+    // != 0: `table` holds the keyed probe-side table, built partition by partition -- 1: no key has several rows (links stay -1),
+    // 2: some do, and their chains (`links`, the slots' `next`) were built in the same pass
+    int partitioned_build(const JoinCol& key, int32_t n, JoinKeySlot* table, int32_t partitions, hipStream_t s)
     {
         DevBuf part, keys_in, keys_out, rows_in, rows_out, counts, first, temp;
         int32_t* pid = static_cast<int32_t*>(part.ensure((size_t)n * 4));
@@ -300,12 +304,13 @@ public:
         int64_t* fst = static_cast<int64_t*>(first.ensure((size_t)(partitions + 1) * 8));
         launch_exclusive_prefix_i64(cnt, partitions, fst, s);  // fst[p] = first row of partition p, fst[partitions] = n
         PA_HIP(hipMemsetAsync(ctl_ + 1, 0, 8, s));
-        launch_join_part_build(keys_out.as<uint64_t>(), rows_out.as<int32_t>(), fst, partitions, ls_->probe_mask, table, ctl_, s);
         launch_fill_i32(ls_->links.as<int32_t>(), -1, n, s);
+        launch_join_part_build(keys_out.as<uint64_t>(), rows_out.as<int32_t>(), fst, partitions, ls_->probe_mask, table, ls_->links.as<int32_t>(), ctl_, s);
         int32_t flags[2] = {0, 0};
         PA_HIP(hipMemcpyAsync(flags, ctl_ + 1, 8, hipMemcpyDeviceToHost, s));
         PA_HIP(hipStreamSynchronize(s));  // (the temporaries above return to the pool)
-        return flags[0] == 0 && flags[1] == 0;
+        if (flags[1] != 0) return 0;
+        return flags[0] != 0 ? 2 : 1;
     }
 
     void compute_raw_hash(const JoinKeys& bk, int32_t n, hipStream_t s) { fill_raw_hash(*ls_, bk, n, s); }
@@ -378,6 +383,7 @@ private:
     DevBuf ctl_buf_, rank_counts_, rank_temp_;
     // (key, row) pairs regrouped by key range, kept between build_key_bitmap and start_rank_index (rows out of key order)
     DevBuf pair_keys_, pair_rows_, pair_first_;
+    bool links_built_ = false;  // the table build left the chains of keys with several rows behind (the partitioned build does)
     int32_t pairs_ = 0, pair_partitions_ = 0;
     int pair_shift_ = 0;
     int32_t* ctl_ = nullptr;

@@ -139,6 +139,31 @@ def test_large_build_side_is_built_in_partitions(gpu, oracle, key_type, duplicat
             assert np.array_equal(gp, op_) and np.array_equal(gb, ob)
 
 
+@pytest.mark.parametrize("shape", ["five_per_key", "one_long_chain", "a_chain_beyond_the_rounds"])
+def test_partitioned_build_links_the_rows_of_a_key(gpu, oracle, shape):
+    """>= 2^20 build rows where keys have several rows: the partitioned build puts the chains together in LDS (round by round: the
+    highest position not yet on the chain becomes the next link) -- positionLinks and emission order equal the oracle's
+    (ArrayPositionLinks.java:45-50: from the highest position down).  A key with more rows than the rounds take sends the build
+    the other way."""
+    rng = np.random.default_rng(len(shape) + 7)
+    nb, npr = (1 << 20) + 4321, 120_000
+    distinct = nb // 5 if shape == "five_per_key" else nb
+    keys = (rng.integers(0, distinct, nb).astype(np.int64) * 7919) - 12345
+    if shape != "five_per_key":
+        heavy = 150 if shape == "one_long_chain" else 400
+        keys[rng.permutation(nb)[:heavy]] = 77_777_777_777
+    build = [Page([Block.bigint(keys, rng.random(nb) < 0.001), Block.integer(np.arange(nb))], nb)]
+    pk = np.where(rng.random(npr) < 0.5, keys[rng.integers(0, nb, npr)], rng.integers(-2 ** 40, 2 ** 40, npr)).astype(np.int64)
+    pk[:3] = 77_777_777_777
+    probe = [Page([Block.bigint(pk), Block.integer(np.arange(npr))], npr)]
+    types = [abi.BIGINT, abi.INTEGER]
+    orows, opairs, _ = oracle_join(oracle, build, types, [0], [1], probe, types, [0], [0, 1])
+    rows, pairs, _ = gpu_join(build, types, [0], [1], probe, types, [0], [0, 1])
+    assert len(orows) > 100_000 and rows == orows
+    for (gp, gb), (op_, ob) in zip(pairs, opairs):
+        assert np.array_equal(gp, op_) and np.array_equal(gb, ob)
+
+
 def test_partitioned_build_with_an_overfull_partition_falls_back(gpu, oracle, monkeypatch):
     """Keys chosen so that more of them have their home slot in ONE 8192-slot partition than the partition may hold: the build
     notices (no slot is dropped, nothing overflows the LDS table) and assembles the table slot by slot instead."""
