@@ -633,7 +633,8 @@ class DynamicFilterSource:
         self.channels = list(filter_channels)
         self.max_distinct, self.max_bytes, self.limit = max_distinct_values, max_filter_size_bytes, min_max_collection_limit
         # :183-203
-        self.min_max_channels = [i for i, t in enumerate(self.types) if min_max_collection_limit > 0 and t != abi.DOUBLE]
+        # ("Skipping DOUBLE and REAL in collectMinMaxValues to avoid dealing with NaN values", :187-188)
+        self.min_max_channels = [i for i, t in enumerate(self.types) if min_max_collection_limit > 0 and t not in (abi.DOUBLE, abi.REAL)]
         self.sets = [dict() for _ in self.types]  # canonical key -> first seen value (TypedSet keeps the first of equal values)
         self.has_null = [False] * len(self.types)
         self.min = [None] * len(self.types) if self.min_max_channels else None
@@ -643,7 +644,7 @@ class DynamicFilterSource:
 
     @staticmethod
     def _key(t, v):
-        if t == abi.DOUBLE:  # IS DISTINCT FROM: NaN equals NaN, -0.0 equals 0.0
+        if t in (abi.DOUBLE, abi.REAL):  # IS DISTINCT FROM: NaN equals NaN, -0.0 equals 0.0
             return "nan" if v != v else (0.0 if v == 0.0 else v)
         return v
 
@@ -680,7 +681,7 @@ class DynamicFilterSource:
             if t == abi.VARCHAR:
                 size_bytes += sum(-(-len(v) // 8) * 8 for v in self.sets[i]) + 4 * n
             else:
-                size_bytes += n * {abi.BIGINT: 8, abi.DOUBLE: 8, abi.INTEGER: 4, abi.DATE: 4, abi.BOOLEAN: 1}[t]
+                size_bytes += n * {abi.BIGINT: 8, abi.DOUBLE: 8, abi.INTEGER: 4, abi.DATE: 4, abi.BOOLEAN: 1, abi.REAL: 4}[t]
             most = max(most, n + (1 if self.has_null[i] else 0))
         if most > self.max_distinct or size_bytes > self.max_bytes:  # handleTooLargePredicate :268-292
             if not self.min_max_channels:
@@ -708,7 +709,7 @@ class DynamicFilterSource:
         out = []
         for t, values in zip(self.types, self.sets):  # convertToDomain :403-418: no NULL, no NaN
             vals = [v for k, v in values.items() if k != "nan"]
-            if t == abi.DOUBLE:
+            if t in (abi.DOUBLE, abi.REAL):
                 vals = [0.0 if v == 0.0 else v for v in vals]  # the device keeps +0.0 for the {-0.0, 0.0} element (DESIGN)
             out.append(("values", sorted(vals)) if vals else ("none",))
         self.predicate = out

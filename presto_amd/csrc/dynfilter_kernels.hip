@@ -18,6 +18,12 @@ __device__ __forceinline__ u64 df_key(int type, const void* values, i64 r)
         case PA_INTEGER:
         case PA_DATE: return (u64)(i64)((const i32*)values)[r];
         case PA_BOOLEAN: return ((const u8*)values)[r] != 0 ? 1ULL : 0ULL;
+        case PA_REAL: {  // the float widened (exactly) to the DOUBLE key: one NaN, +0.0 for both zeros
+            const float f = ((const float*)values)[r];
+            if (f != f) return 0x7ff8000000000000ULL;
+            const u64 b = (u64)__double_as_longlong((double)f);
+            return b == 0x8000000000000000ULL ? 0ULL : b;
+        }
         default: {  // DOUBLE
             const u64 b = ((const u64*)values)[r];
             if ((b & 0x7fffffffffffffffULL) > 0x7ff0000000000000ULL) return 0x7ff8000000000000ULL;

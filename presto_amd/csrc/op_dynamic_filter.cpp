@@ -91,11 +91,10 @@ public:
             FilterChannel ch;
             ch.index = d->filter_channels[i];
             PA_REQUIRE(ch.index >= 0 && ch.index < (int)types_.size(), PA_ERR_INVALID_ARGUMENT, "filter channel out of range");
-            PA_REQUIRE(types_[(size_t)ch.index] != PA_REAL, PA_ERR_NOT_SUPPORTED, "REAL dynamic-filter channels are not on the device path");
             ch.type = types_[ch.index];
             needed_[ch.index] = true;
             // :188 -- orderable and not floating point
-            ch.min_max = d->min_max_collection_limit > 0 && ch.type != PA_DOUBLE;
+            ch.min_max = d->min_max_collection_limit > 0 && ch.type != PA_DOUBLE && ch.type != PA_REAL;
             any_min_max = any_min_max || ch.min_max;
             if (ch.type == PA_VARCHAR) {
                 ch.strings = std::make_unique<StringInterner>();
@@ -292,8 +291,8 @@ private:
         if (m) PA_HIP(hipMemcpyAsync(keys.data(), dev, (size_t)m * 8, hipMemcpyDeviceToHost, s));
         PA_HIP(hipStreamSynchronize(s));
         if (flags[2]) keys.push_back(kDfEmpty);
-        if (ch.type == PA_DOUBLE) {
-            // "join doesn't match rows with NaN values"; the rest in Double.compare order
+        if (ch.type == PA_DOUBLE || ch.type == PA_REAL) {
+            // "join doesn't match rows with NaN values"; the rest in Double.compare order (REAL keys are the widened floats)
             keys.erase(std::remove(keys.begin(), keys.end(), 0x7ff8000000000000ULL), keys.end());
             std::sort(keys.begin(), keys.end(), [](uint64_t a, uint64_t b) {
                 double x, y;
@@ -301,6 +300,16 @@ private:
                 memcpy(&y, &b, 8);
                 return x < y;
             });
+            if (ch.type == PA_REAL) {  // back to the IntArrayBlock's raw float bits
+                for (uint64_t& k : keys) {
+                    double x;
+                    memcpy(&x, &k, 8);
+                    const float f = (float)x;
+                    uint32_t bits;
+                    memcpy(&bits, &f, 4);
+                    k = bits;
+                }
+            }
         }
         else std::sort(keys.begin(), keys.end(), [](uint64_t a, uint64_t b) { return (int64_t)a < (int64_t)b; });
         store_fixed(keys, ch.type, d);

@@ -285,6 +285,7 @@ class PartialStateMerger:
         self.send = torch.zeros(self.CAPACITY, dtype=torch.uint8, device=device or "cpu")
         self.recv = torch.zeros(self.CAPACITY * self.world, dtype=torch.uint8, device=device or "cpu")
         self.stage = torch.zeros(self.CAPACITY, dtype=torch.uint8).pin_memory() if device else self.send
+        self.copied = None
 
     def merge(self, partial_pages, make_final_operator):
         """partial_pages: {name: host Page | None} on every rank (same names everywhere); make_final_operator: {name: () -> Operator};
@@ -299,9 +300,13 @@ class PartialStateMerger:
         if len(blob) + 8 > self.CAPACITY:
             raise ValueError("partial aggregation states of %d bytes: not a few-groups result, use an exchange" % len(blob))
         head = np.frombuffer(np.int64(len(blob)).tobytes() + blob, dtype=np.uint8)
+        if self.device and self.copied is not None:
+            self.copied.synchronize()   # the previous call's copy out of the pinned staging buffer has left it
         self.stage[:len(head)] = torch.from_numpy(head.copy())
         if self.device:
             self.send.copy_(self.stage, non_blocking=True)
+            self.copied = torch.cuda.Event()
+            self.copied.record()
         self.dist.all_gather_into_tensor(self.recv, self.send, group=self.group)
         if self.rank != self.dst:
             return None

@@ -76,7 +76,7 @@ def test_predicate_is_not_ready_before_finish_unless_given_up(gpu):
 @pytest.mark.parametrize("seed", list(range(int(os.environ.get("PA_FUZZ_SEEDS", "16")))))  # PA_FUZZ_SEEDS=N: a longer one-off run
 def test_random_build_sides_against_oracle(gpu, oracle, seed):
     rng = np.random.default_rng(900 + seed)
-    kinds = [abi.BIGINT, abi.INTEGER, abi.DATE, abi.DOUBLE, abi.BOOLEAN, abi.VARCHAR]
+    kinds = [abi.BIGINT, abi.INTEGER, abi.DATE, abi.DOUBLE, abi.BOOLEAN, abi.VARCHAR, abi.REAL]
     nch = int(rng.integers(1, 4))
     types = [kinds[i] for i in rng.integers(0, len(kinds), nch)] + [abi.BIGINT]
     channels = list(range(nch))
@@ -102,6 +102,9 @@ def test_random_build_sides_against_oracle(gpu, oracle, seed):
             elif t == abi.DOUBLE:
                 pool = np.concatenate([rng.standard_normal(card), [0.0, -0.0, np.nan, np.inf, -np.inf]])
                 blocks.append(Block.double(pool[rng.integers(0, len(pool), n)], nulls))
+            elif t == abi.REAL:
+                pool = np.concatenate([rng.standard_normal(card), [0.0, -0.0, np.nan, np.inf, -np.inf]]).astype(np.float32)
+                blocks.append(Block.real(pool[rng.integers(0, len(pool), n)], nulls))
             else:
                 ids = rng.integers(0, card, n)
                 blocks.append(Block.varchar([None if (nulls is not None and nulls[i]) else b"key-%d-%s" % (v, b"z" * (v % 11)) for i, v in enumerate(ids)]))

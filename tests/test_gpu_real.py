@@ -238,10 +238,28 @@ def test_hash_of_a_real_channel(gpu, oracle):
     assert h[0] == h[1]
 
 
-def test_real_dynamic_filter_channels_are_refused(gpu):
-    from presto_amd._lib import PrestoAmdError
+def test_real_dynamic_filter_channels(gpu, oracle):
+    """REAL build-side channels of a DynamicFilterSource (TestDynamicFilterSourceOperator.java:296-312, 327-338): values without
+    NaN, one element for the two zeros, no min / max collection (DynamicFilterSourceOperator.java:187-188)."""
     from presto_amd.operators import DynamicFilterSourceOperator
-    with pytest.raises(PrestoAmdError) as e:
-        op = DynamicFilterSourceOperator([abi.REAL], [0], 100, 1 << 20, 100)
-        to_pages(op, [Page([Block.real([1.0, 2.0])], 2)])
-    assert e.value.status == abi.ERR_NOT_SUPPORTED
+    nan = float("nan")
+    pages = [Page([Block.real([42.0, nan, -0.0, 0.0, 1.5, -3.25, 1.5])], 7), Page([Block.real([7.0, nan], [False, True])], 2)]
+    ref = oracle.DynamicFilterSource([abi.REAL], [0], 100, 1 << 20, 100)
+    for p in pages:
+        ref.add_page(p)
+    ref.finish()
+    op = DynamicFilterSourceOperator([abi.REAL], [0], 100, 1 << 20, 100)
+    for p in pages:
+        op.addInput(p)
+        op.getOutput()
+    op.finish()
+    got = op.predicate()
+    op.close()
+    assert got == ref.predicate == [("values", [-3.25, 0.0, 1.5, 7.0, 42.0])]
+    # more distinct values than the limit and no orderable channel: TupleDomain.all()
+    op = DynamicFilterSourceOperator([abi.REAL], [0], 100, 1 << 20, 1000000)
+    op.addInput(Page([Block.real(np.arange(101, dtype=np.float32))], 101))
+    op.getOutput()
+    op.finish()
+    assert op.predicate() == "all"
+    op.close()

@@ -334,7 +334,7 @@ def dynamic_filter_kats():
     """(name, types, filter channels, pages as column lists, (max distinct, max bytes, min/max row limit), expected)"""
     seq = lambda a, b: list(range(a, b))
     nan = float("nan")
-    B, I, D, BO, V = abi.BIGINT, abi.INTEGER, abi.DOUBLE, abi.BOOLEAN, abi.VARCHAR
+    B, I, D, BO, V, R = abi.BIGINT, abi.INTEGER, abi.DOUBLE, abi.BOOLEAN, abi.VARCHAR, abi.REAL
     dflt = (100, 10240, 1000000)
     text = b"A" * 10241
     ta, tb = b"A" * 5121, b"B" * 5121
@@ -348,6 +348,8 @@ def dynamic_filter_kats():
         ("nulls", [I], [0], [[[1, 2, 3]], [[3, None, 4]], [[4, 5]]], dflt, [("values", [1, 2, 3, 4, 5])]),  # :255-276
         ("double NaN", [D], [0], [[[42.0, nan]]], dflt, [("values", [42.0])]),  # :278-294
         ("too many rows double", [D], [0], [[[float(i) for i in seq(0, 101)]], [[nan] * 101]], dflt, "all"),  # :314-325
+        ("real NaN", [R], [0], [[[42.0, nan]]], dflt, [("values", [42.0])]),  # :296-312
+        ("too many rows real", [R], [0], [[[float(i) for i in seq(0, 101)]], [[nan] * 101]], dflt, "all"),  # :327-338
         ("no filters", [B], [], [[[1, 2, 3]]], dflt, "all"),  # :370-379
         ("empty build side", [B], [0], [], dflt, [("none",)]),  # :381-389
         ("min max when too many positions", [B], [0], [[seq(0, 101)]], dflt, [("range", 0, 100)]),  # :391-406
@@ -365,7 +367,7 @@ def dynamic_filter_kats():
 
 
 def dynamic_filter_pages(types, pages):
-    make = {abi.BIGINT: Block.bigint, abi.INTEGER: Block.integer, abi.DOUBLE: Block.double, abi.BOOLEAN: Block.boolean}
+    make = {abi.BIGINT: Block.bigint, abi.INTEGER: Block.integer, abi.DOUBLE: Block.double, abi.BOOLEAN: Block.boolean, abi.REAL: Block.real}
     out = []
     for cols in pages:
         blocks = []
