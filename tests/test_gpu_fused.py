@@ -225,6 +225,39 @@ def test_hash_aggregation_across_cardinalities(gpu, oracle, groups, pages, rows)
     rows_equal_ignore_order(got, expected, rel=1e-9)
 
 
+@pytest.mark.parametrize("expected_groups", [10000, 3_000_000])
+@pytest.mark.parametrize("shape", ["few_then_many", "many_from_the_start", "many_then_few", "device_pages"])
+def test_tier_hand_overs_at_high_cardinality(gpu, oracle, shape, expected_groups):
+    """Page sequences that cross the tiers at hundreds of thousands of groups: the few-groups tier's first launch giving up
+    (the page restarts on the next tier), the probe launch whose groups are given up when the page goes to the partition-owned
+    tables (its rows are redone there), pages that arrive before / after the tier is known, tables that already hold groups
+    when the cardinality jumps (nothing may be dropped then).  Every row counted exactly once."""
+    from presto_amd.operators import upload_page
+    rng = np.random.default_rng(len(shape) + expected_groups % 7)
+
+    def page(rows, groups, base=0):
+        k = rng.integers(0, groups, rows).astype(np.int64) * 7919 + base
+        return Page([Block.bigint(k), Block.bigint(rng.integers(-100, 100, rows)), Block.double(rng.random(rows))], rows)
+
+    if shape == "few_then_many":
+        pages = [page(300_000, 5), page(2_300_000, 700_000), page(1_200_000, 700_000, 13)]
+    elif shape == "many_then_few":
+        pages = [page(2_500_000, 900_000), page(400_000, 6), page(900_000, 900_000)]
+    else:
+        pages = [page(2_600_000, 800_000), page(1_100_000, 800_000), page(300_001, 250_000, 5)]
+    types = [abi.BIGINT, abi.BIGINT, abi.DOUBLE]
+    aggs = [(abi.AGG_SUM, 1, abi.BIGINT), (abi.AGG_COUNT_STAR, -1, None), (abi.AGG_SUM, 2, abi.DOUBLE), (abi.AGG_MAX, 1, abi.BIGINT)]
+    ref = oracle.HashAggregation(types, [0], aggs)
+    for p in pages:
+        ref.add_page(p)
+    expected = ref.build_result().to_rows()
+    fed = [upload_page(p) for p in pages] if shape == "device_pages" else pages
+    op = HashAggregationOperator(types, [0], aggs, expected_groups=expected_groups)
+    got = [r for p in to_pages(op, fed) for r in p.to_rows()]
+    assert len(expected) > 500_000
+    rows_equal_ignore_order(got, expected, rel=1e-9)
+
+
 @pytest.mark.parametrize("groups,rows", [(0, 30001), (5, 20000), (200, 100003), (5000, 200001), (60000, 200003)])
 def test_min_max_across_variants_and_types(gpu, oracle, groups, rows):
     """min / max (AbstractMinMaxAggregationFunction: the type's COMPARISON operator; Double.compare for DOUBLE, so NaN is the
