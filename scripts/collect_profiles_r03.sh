@@ -34,4 +34,5 @@ rm -f $O/r_sweep_*.jsonl
 for layout in table shuffled separate; do
   timeout -k 10 150 scripts/page_sweep --sf 100 --steps 3 --layout $layout --rows 4194304,1048576,65536,8192 > $O/r_sweep_$layout.jsonl 2> $O/r_sweep_$layout.err || echo "sweep $layout failed"
 done
+timeout -k 10 150 scripts/page_sweep --sf 100 --steps 3 --layout separate --shared-stream --rows 4194304,1048576,65536,8192 > $O/r_sweep_separate_shared.jsonl 2> $O/r_sweep_separate_shared.err || echo "sweep separate (caller's stream) failed"
 echo "sweep done"

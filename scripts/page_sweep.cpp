@@ -1,7 +1,10 @@
 // page_sweep.cpp -- Q1 + Q6 through the C ABI at the page sizes an unmodified Driver delivers, with no Python in the loop:
 // a Driver thread's view (one needsInput + one addInput native call per page, as the JNI shim of INTEGRATION.md makes them).
 //
-//   page_sweep [--sf 100] [--steps 5] [--layout table|shuffled|separate|host] [--rows N,N,...]
+//   page_sweep [--sf 100] [--steps 5] [--layout table|shuffled|separate|host] [--rows N,N,...] [--shared-stream]
+//   --shared-stream  the operators run on a stream the caller made (what a pipeline of device operators does: pages change hands in
+//                    stream order, nobody waits); without it the operator owns its stream and drains it after every page that is
+//                    not PA_PAGE_STABLE, because the caller may recycle the page's buffers once add_input has returned
 //
 //   table     pages are consecutive row ranges of resident columns, PA_PAGE_STABLE, handed over in table order
 //   shuffled  the same pages in a seeded random order: no page continues its predecessor
@@ -213,8 +216,10 @@ int main(int argc, char** argv)
     std::string layout = "table";
     std::vector<int64_t> sizes = {1LL << 28, 1LL << 22, 1LL << 20, 1LL << 16, 8192};
     double max_copy_gb = 4.0;
+    bool shared_stream = false;
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
+        if (a == "--shared-stream") shared_stream = true;
         if (a == "--sf" && i + 1 < argc) sf = atof(argv[++i]);
         else if (a == "--steps" && i + 1 < argc) steps = atoi(argv[++i]);
         else if (a == "--layout" && i + 1 < argc) layout = argv[++i];
@@ -226,6 +231,8 @@ int main(int argc, char** argv)
         }
     }
     check(pa_init(0));
+    void* stream = nullptr;
+    if (shared_stream) check(pa_stream_create(&stream));
     int64_t rows = (int64_t)(kLineitemRowsPerSf * sf);
     const bool host_layout = layout == "host" || layout == "hostcopy";
     const bool bounded = layout == "separate" || host_layout;
@@ -237,6 +244,8 @@ int main(int argc, char** argv)
     std::vector<std::vector<Column>> columns;
     for (const Query& q : queries) {
         factories.push_back(new Factory(q));
+        factories.back()->desc.filter_project.stream = stream;
+        factories.back()->desc.aggregation.stream = stream;
         std::vector<Column> cs;
         for (size_t i = 0; i < q.tpch_columns.size(); i++) cs.push_back(make_column(q.tpch_columns[i], q.types[i], sf, rows));
         columns.push_back(std::move(cs));
@@ -337,10 +346,10 @@ int main(int argc, char** argv)
         }
         const double dt = std::chrono::duration<double>(Clock::now() - t0).count();
         const double rps = 2.0 * rows * steps / dt;
-        printf("{\"layout\": \"%s\", \"page_rows\": %lld, \"pages_per_query\": %zu, \"rows\": %lld, \"steps\": %d, \"ms_per_step\": %.3f, "
+        printf("{\"layout\": \"%s%s\", \"page_rows\": %lld, \"pages_per_query\": %zu, \"rows\": %lld, \"steps\": %d, \"ms_per_step\": %.3f, "
                "\"rows_per_s\": %.4g, \"q6_rows_per_s\": %.4g, \"q1_rows_per_s\": %.4g, \"q6_GBps\": %.1f, \"q1_GBps\": %.1f, "
                "\"needs_input_spins_per_step\": %.1f, \"q6_revenue\": %.6f, \"q1_last_count\": %lld}\n",
-               layout.c_str(), (long long)page_rows, sets[0].pages.size(), (long long)rows, steps, dt / steps * 1e3, rps,
+               layout.c_str(), shared_stream ? ", caller's stream" : "", (long long)page_rows, sets[0].pages.size(), (long long)rows, steps, dt / steps * 1e3, rps,
                rows * steps / per_query_s[0], rows * steps / per_query_s[1], rows * steps / per_query_s[0] * 28 / 1e9,
                rows * steps / per_query_s[1] * 46 / 1e9, (double)spins / steps, v6, (long long)*reinterpret_cast<int64_t*>(&v1));
         fflush(stdout);

@@ -63,7 +63,7 @@ with open(os.path.join(P, "r03_operators.md"), "w") as f:
     f.write(stats_table("r_next"))
 
 rows = []
-for layout in ("table", "shuffled", "separate"):
+for layout in ("table", "shuffled", "separate", "separate_shared"):
     path = os.path.join(O, "r_sweep_%s.jsonl" % layout)
     if os.path.exists(path):
         for line in open(path):
