@@ -92,8 +92,9 @@ struct OpScope {
     hipStream_t prev_;
 };
 
-// PRESTO_AMD_HOST_TRACE=<file>: wall-clock start and duration of every C-ABI call, appended to <file> when the process ends
-// (start us since the first call, duration us, entry point) -- the host side of a kernel timeline (scripts/kernel_timeline.py)
+// PRESTO_AMD_HOST_TRACE=<file>: wall-clock start and duration of every C-ABI call (and of the phases inside an operator that
+// carry a HostTraceScope), appended to <file> when the process ends (start us since the first call, duration us, name) -- the host
+// side of a kernel timeline (scripts/kernel_timeline.py)
 struct HostTrace {
     struct Rec {
         double start_us, us;
@@ -113,21 +114,17 @@ struct HostTrace {
     }
 };
 static HostTrace g_host_trace;
-struct HostTraceScope {
-    const char* name;
-    std::chrono::steady_clock::time_point t;
-    explicit HostTraceScope(const char* n) : name(n)
-    {
-        if (g_host_trace.path) t = std::chrono::steady_clock::now();
-    }
-    ~HostTraceScope()
-    {
-        if (!g_host_trace.path) return;
-        const auto e = std::chrono::steady_clock::now();
-        std::lock_guard<std::mutex> lock(g_host_trace.mu);
-        g_host_trace.recs.push_back({std::chrono::duration<double, std::micro>(t - g_host_trace.t0).count(), std::chrono::duration<double, std::micro>(e - t).count(), name});
-    }
-};
+HostTraceScope::HostTraceScope(const char* n) : name(n), on(g_host_trace.path != nullptr)
+{
+    if (on) t = std::chrono::steady_clock::now();
+}
+HostTraceScope::~HostTraceScope()
+{
+    if (!on) return;
+    const auto e = std::chrono::steady_clock::now();
+    std::lock_guard<std::mutex> lock(g_host_trace.mu);
+    g_host_trace.recs.push_back({std::chrono::duration<double, std::micro>(t - g_host_trace.t0).count(), std::chrono::duration<double, std::micro>(e - t).count(), name});
+}
 
 template <typename F>
 static int32_t guarded(F&& f, const char* entry = __builtin_FUNCTION())

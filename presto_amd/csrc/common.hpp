@@ -3,6 +3,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -259,5 +260,14 @@ private:
 
 int device_cu_count();
 void require_device();
+
+// a phase of host work in the PRESTO_AMD_HOST_TRACE listing (abi.cpp); costs one branch when the trace is off
+struct HostTraceScope {
+    const char* name;
+    bool on;
+    std::chrono::steady_clock::time_point t;
+    explicit HostTraceScope(const char* n);
+    ~HostTraceScope();
+};
 
 }  // namespace pa

@@ -129,7 +129,7 @@ public:
 
 private:
     // The common case in ONE pass over the first sort channel: a bound for the page is drawn from a sample of its rows -- the
-    // order statistic of 2^16 evenly spaced rows that lies above the page's N-th best key with overwhelming probability -- and
+    // order statistic of 2^14 evenly spaced rows that lies above the page's N-th best key with overwhelming probability -- and
     // the rows not beyond min(that, the bound carried over from earlier pages) are collected as they are met, a few thousand
     // of 2^26 (the exact way walks the page a dozen times: keys, two histogram passes, compaction, flags, states, partition --
     // 34 G rows/s for the 100 best of 2^26 rows).  The exact N-th best key of everything kept so far then becomes the next
@@ -140,7 +140,10 @@ private:
     {
         if (getenv("PRESTO_AMD_TOPN_EXACT")) return false;
         hipStream_t s = stream_.get();
-        constexpr int64_t kSample = (int64_t)1 << 16;
+        // 2^14 sample rows (a workgroup's registers hold that many keys: sample and selection are one launch, topn_kernels.hip);
+        // 2^16 for the largest pages, where a four times tighter bound saves more host work on the candidates than the second
+        // launch and its walks over the sample array cost (2^26 rows: 0.45 vs 0.70 ms per page)
+        const int64_t kSample = n >= ((int64_t)1 << 25) ? (int64_t)1 << 16 : (int64_t)1 << 14;
         bool sampled = false;
         int64_t expect = 0;
         uint32_t* counter = static_cast<uint32_t*>(counts_.ensure(256)) + 32;  // [count, pad, bound (8 bytes)]

@@ -243,6 +243,75 @@ __global__ __launch_bounds__(1024) void k_topn_select_small(const u64* __restric
     if (threadIdx.x == 0) out[0] = s_prefix;
 }
 
+// The sample of a page and the selection over it in ONE workgroup: a thread holds its 16 of the (at most) 16 384 sample keys in
+// registers -- every evenly spaced row's key, computed from the column itself -- and the eight digit rounds run over registers and
+// an LDS histogram (walking a 2^16-key sample array in global memory eight times took 132 us of Q3's TopN).  out[0] = the rank-th
+// smallest sample key.
+constexpr int kSampleRegs = 16;
+__global__ __launch_bounds__(1024) void k_topn_sample_select(i32 type, const void* __restrict__ values, const i32* __restrict__ offsets,
+                                                             const u8* __restrict__ nulls, i64 stride, i64 count, i32 sort_order, i64 rank, u64* __restrict__ out)
+{
+    __shared__ u32 hist[256];
+    __shared__ u32 scan[256];
+    __shared__ u64 s_prefix;
+    __shared__ i64 s_remaining;
+    u64 mine[kSampleRegs];
+    u32 have = 0;
+#pragma unroll
+    for (int j = 0; j < kSampleRegs; j++) {
+        const i64 i = (i64)j * 1024 + threadIdx.x;
+        mine[j] = ~0ULL;
+        if (i < count) {
+            mine[j] = row_key(type, values, offsets, nulls, i * stride, sort_order);
+            have |= 1u << j;
+        }
+    }
+    if (threadIdx.x == 0) {
+        s_prefix = 0;
+        s_remaining = rank;
+    }
+    for (int shift = 56; shift >= 0; shift -= 8) {
+        if (threadIdx.x < 256) hist[threadIdx.x] = 0;
+        __syncthreads();
+        const u64 pf = s_prefix;
+#pragma unroll
+        for (int j = 0; j < kSampleRegs; j++) {
+            const u64 k = mine[j];
+            const bool in = ((have >> j) & 1u) && (shift == 56 || (k >> (shift + 8)) == pf);
+            const u32 digit = (u32)((k >> shift) & 255ULL);
+            const u64 members = __ballot(in);
+            if (members == 0ULL) continue;
+            const int leader = __ffsll((long long)members) - 1;
+            const u32 first = (u32)__shfl((int)digit, leader, 64);
+            if (__ballot(in && digit == first) == members) {
+                if ((int)(threadIdx.x & 63) == leader) atomicAdd(&hist[first], (u32)__popcll(members));
+            }
+            else if (in) atomicAdd(&hist[digit], 1u);
+        }
+        __syncthreads();
+        if (threadIdx.x < 256) scan[threadIdx.x] = hist[threadIdx.x];
+        __syncthreads();
+        for (int d = 1; d < 256; d <<= 1) {
+            u32 add = 0;
+            if (threadIdx.x < 256 && (int)threadIdx.x >= d) add = scan[threadIdx.x - d];
+            __syncthreads();
+            if (threadIdx.x < 256) scan[threadIdx.x] += add;
+            __syncthreads();
+        }
+        const i64 want = s_remaining;
+        __syncthreads();
+        if (threadIdx.x < 256) {
+            const i64 incl = (i64)scan[threadIdx.x], before = incl - (i64)hist[threadIdx.x];
+            if ((before < want && want <= incl) || (threadIdx.x == 255 && want > incl)) {
+                s_remaining = want - before;
+                s_prefix = (pf << 8) | (u64)threadIdx.x;
+            }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = s_prefix;
+}
+
 __global__ __launch_bounds__(256) void k_topn_flag(const u64* __restrict__ keys, i64 n, u64 threshold, i32* __restrict__ partition)
 {
     for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < n; i += (i64)gridDim.x * 256) partition[i] = keys[i] <= threshold ? 0 : 1;
@@ -344,6 +413,12 @@ void launch_topn_sample_bound(int32_t type, const void* values, const int32_t* o
     PA_REQUIRE(sample_rows >= 1 && sample_rows <= kSelectSmall && rank >= 1 && rank <= sample_rows && n >= sample_rows, PA_ERR_INVALID_ARGUMENT,
                "bad TopN sample");
     const int64_t stride = n / sample_rows;
+    if (sample_rows <= (int64_t)kSampleRegs * 1024) {  // sample and selection in one workgroup, the keys in registers
+        hipLaunchKernelGGL(k_topn_sample_select, 1, 1024, 0, s, type, values, (const i32*)offsets, (const u8*)nulls, (i64)stride, (i64)sample_rows, sort_order,
+                           (i64)rank, (u64*)bound_out);
+        PA_HIP(hipGetLastError());
+        return;
+    }
     hipLaunchKernelGGL(k_topn_sample_keys, grid_of(sample_rows), 256, 0, s, type, values, (const i32*)offsets, (const u8*)nulls, (i64)stride,
                        (i64)sample_rows, sort_order, (u64*)sample_keys);
     hipLaunchKernelGGL(k_topn_select_small, 1, 1024, 0, s, (const u64*)sample_keys, (i64)sample_rows, (u64)0, 56, (i64)rank, (u64*)bound_out);
