@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PA_ABI_VERSION 8
+#define PA_ABI_VERSION 9
 
 /* ---- status codes (negative = error).  Mapped by the JNI shim onto TrinoException
  *      StandardErrorCode (trino-spi/.../StandardErrorCode.java). ---- */
@@ -508,6 +508,16 @@ int32_t pa_order_by_create(const pa_order_by_desc* desc, pa_operator** out);
  * is active, 0 when the source offers none (several key channels, non-integer key, keys too sparse) -- the operator then
  * works as before.  Not for probe-outer / full-outer joins, whose unmatched probe rows are output. */
 int32_t pa_filter_project_set_dynamic_filter(pa_operator* op, int32_t channel, pa_lookup_source* source);
+/* A planner's note to a (Hash)AggregationOperator (plain, fused, or behind a fused probe; Step.SINGLE / FINAL) whose ONLY consumer is
+ * a TopNOperator(n, sort channels, sort orders) over its output page (LocalExecutionPlanner.visitTopN over visitAggregation -- TPC-H
+ * Q3's ORDER BY revenue DESC, o_orderdate LIMIT 10; sort_channels index the aggregation's OUTPUT channels: group keys, ($hashvalue),
+ * aggregates): groups that cannot be among the TopN's n best rows MAY then be left out of the output.  What is emitted is every group
+ * whose first sort channel is not beyond a bound under which at least n groups lie (ties on that channel included), in no particular
+ * order -- a superset of the n best, thousands of rows where the table holds millions; the TopN downstream does the exact work.
+ * Returns 1 when the operator takes the hint, 0 when it does not (it then emits everything, as without the call).  Without this call
+ * nothing changes.  (The reference has no such fusion: TopNOperator.java:30-160 sees every group.) */
+int32_t pa_aggregation_set_output_topn_hint(pa_operator* op, int64_t n, int32_t sort_channel_count, const int32_t* sort_channels,
+                                            const int32_t* sort_orders);
 /* The same across the ranks of a partitioned join, where every rank built the keys of its own partition and the probe rows
  * are filtered BEFORE they are exchanged: (1) pa_lookup_source_key_range -> [min, max] of this rank's build keys (returns 0:
  * no single integer key / no non-NULL key); the ranks agree on the union range; (2) pa_lookup_source_key_bitmap sets, in a

@@ -259,6 +259,11 @@ public:
     // FilterAndProject only, before the first page: the dynamic filter of the (built) join this operator feeds -- rows whose
     // `channel` value matches no build key are dropped with the filter; true when the source offers one
     bool setDynamicFilter(int32_t channel, pa_lookup_source* source) { return check(pa_filter_project_set_dynamic_filter(h_, channel, source)) == 1; }
+    // aggregation operators whose only consumer is a TopN over their output (pa_aggregation_set_output_topn_hint)
+    bool setOutputTopNHint(int64_t n, const std::vector<int32_t>& sortChannels, const std::vector<int32_t>& sortOrders)
+    {
+        return check(pa_aggregation_set_output_topn_hint(h_, n, (int32_t)sortChannels.size(), sortChannels.data(), sortOrders.data())) == 1;
+    }
 
 private:
     pa_operator* h_;

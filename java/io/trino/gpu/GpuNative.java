@@ -10,8 +10,8 @@ final class GpuNative
 {
     static {
         System.loadLibrary("presto_amd_jni"); // links libpresto_amd.so
-        if (abiVersion() != 8) {
-            throw new IllegalStateException("libpresto_amd.so ABI version " + abiVersion() + " != 8");
+        if (abiVersion() != 9) {
+            throw new IllegalStateException("libpresto_amd.so ABI version " + abiVersion() + " != 9");
         }
     }
 
@@ -45,6 +45,9 @@ final class GpuNative
             int[] aggMasks, int[] aggInputTypes, int expectedGroups, int outputMem);
     static native long createTopN(int[] inputTypes, int count, int[] sortChannels, int[] sortOrders, int outputMem);
     static native boolean setDynamicFilter(long filterProjectOperator, int channel, long lookupSource);
+
+    /** The only consumer of the aggregation's output is TopNOperator(n, sortChannels, sortOrders): groups that cannot be among its n best rows may be left out. */
+    static native boolean setOutputTopNHint(long aggregationOperator, long n, int[] sortChannels, int[] sortOrders);
 
     static native void commUniqueId(byte[] out128);
     static native long commCreate(byte[] id128, int rank, int world);

@@ -342,6 +342,21 @@ JNIEXPORT jboolean JNICALL Java_io_trino_gpu_GpuNative_setDynamicFilter(JNIEnv* 
     return rc == 1;
 }
 
+/* The planner's note that the only consumer of an aggregation's output is a TopN over it (LocalExecutionPlanner.visitTopN over
+ * visitAggregation): groups that cannot be among its n best rows may be left out. */
+JNIEXPORT jboolean JNICALL Java_io_trino_gpu_GpuNative_setOutputTopNHint(JNIEnv* env, jclass c, jlong aggregationOperator, jlong n, jintArray sortChannels,
+                                                                          jintArray sortOrders)
+{
+    jsize count = (*env)->GetArrayLength(env, sortChannels);
+    jint* ch = (*env)->GetIntArrayElements(env, sortChannels, 0);
+    jint* od = (*env)->GetIntArrayElements(env, sortOrders, 0);
+    int32_t rc = pa_aggregation_set_output_topn_hint((pa_operator*)(intptr_t)aggregationOperator, n, (int32_t)count, (const int32_t*)ch, (const int32_t*)od);
+    (*env)->ReleaseIntArrayElements(env, sortChannels, ch, 0);
+    (*env)->ReleaseIntArrayElements(env, sortOrders, od, 0);
+    CHECK(rc);
+    return rc == 1;
+}
+
 /* ---- exchange between the GPUs of a node (one JVM worker per GPU): the coordinator ships the 128-byte id ---- */
 JNIEXPORT void JNICALL Java_io_trino_gpu_GpuNative_commUniqueId(JNIEnv* env, jclass c, jbyteArray out)
 {

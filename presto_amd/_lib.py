@@ -67,6 +67,7 @@ def lib():
     L.pa_codegen_compile_fused_join_probe.argtypes = [C.POINTER(abi.pa_fused_join_desc), C.POINTER(abi.pa_hash_builder_desc)]
     L.pa_codegen_compile_fused_join_probe.restype = C.c_int64
     L.pa_filter_project_set_dynamic_filter.argtypes = [vp, C.c_int32, vp]
+    L.pa_aggregation_set_output_topn_hint.argtypes = [vp, C.c_int64, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     L.pa_lookup_source_position_count.argtypes = [vp]
     L.pa_lookup_source_key_range.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     L.pa_lookup_source_key_bitmap.argtypes = [vp, C.c_int64, C.c_uint64, vp, vp]

@@ -490,6 +490,16 @@ int32_t pa_filter_project_set_dynamic_filter(pa_operator* op, int32_t channel, p
         return 1;
     });
 }
+int32_t pa_aggregation_set_output_topn_hint(pa_operator* op, int64_t n, int32_t sort_channel_count, const int32_t* sort_channels, const int32_t* sort_orders)
+{
+    return guarded([&]() -> int32_t {
+        PA_REQUIRE(op != nullptr && sort_channel_count > 0 && sort_channels != nullptr && sort_orders != nullptr && n > 0, PA_ERR_INVALID_ARGUMENT, "null argument");
+        for (int i = 0; i < sort_channel_count; i++) {
+            PA_REQUIRE(sort_channels[i] >= 0 && sort_orders[i] >= 0 && sort_orders[i] <= 3, PA_ERR_INVALID_ARGUMENT, "bad sort channel / order");
+        }
+        return aggregation_set_output_topn(op, n, sort_channels, sort_orders, sort_channel_count) ? 1 : 0;
+    });
+}
 int32_t pa_lookup_source_position_count(pa_lookup_source* source)
 {
     return guarded([&]() -> int32_t { return lookup_source_position_count(source); });

@@ -143,6 +143,15 @@ public:
         return chain_.back()->get_output(out);
     }
     bool is_finished() override { return fused_ ? fused_->is_finished() : chain_.back()->is_finished(); }
+    // (the one-kernel form and the aggregation at the end of the chain both take it; the hint may arrive before the lookup source
+    // decides which of the two runs, so it goes to both)
+    bool set_output_topn(int64_t n, const int32_t* channels, const int32_t* orders, int32_t count) override
+    {
+        bool taken = false;
+        if (fused_) taken = fused_->set_output_topn(n, channels, orders, count) || taken;
+        if (!chain_.empty() && chain_.back()) taken = chain_.back()->set_output_topn(n, channels, orders, count) || taken;
+        return taken;
+    }
     int64_t memory_bytes() override
     {
         if (fused_) return fused_->memory_bytes();

@@ -24,6 +24,9 @@ struct pa_operator {
     // the stream the operator enqueues its work on: pooled HBM blocks released inside one of its calls are tagged with it and
     // re-granted to another stream only once this one has drained (pool.cpp)
     virtual hipStream_t main_stream() { return nullptr; }
+    // pa_aggregation_set_output_topn_hint: the only consumer of this operator's output is a TopN(n; sort channels / orders over the
+    // output channels); false = the hint is not taken (everything is emitted)
+    virtual bool set_output_topn(int64_t, const int32_t*, const int32_t*, int32_t) { return false; }
     // HIP device the operator was created on: every C-ABI entry rebinds the calling thread to it (Trino's Driver threads never
     // call pa_init; a handle created on one thread may be driven and closed on others)
     int device = -1;
@@ -56,6 +59,9 @@ pa_operator* make_lookup_join(const pa_lookup_join_desc* desc, pa_lookup_source*
 pa_operator* make_topn(const pa_topn_desc* desc);
 pa_operator* make_order_by(const pa_order_by_desc* desc);
 pa_operator* make_lookup_outer(const pa_lookup_join_desc* desc, pa_lookup_source* bridge);
+// the consumer of an aggregation's output is a TopN over it: groups that cannot be among its n best rows may be left out (op_fused.cpp);
+// false: the operator does not take the hint (it emits everything)
+bool aggregation_set_output_topn(pa_operator* op, int64_t n, const int32_t* sort_channels, const int32_t* sort_orders, int32_t count);
 // join-side dynamic filter: the existence bitmap of a built lookup source (false: none -- not built, not a single integer key,
 // or keys too sparse) and its application in a FilterAndProject operator upstream of the probe
 bool lookup_source_key_bitmap(pa_lookup_source* ls, const uint64_t** bits, int64_t* min_key, uint64_t* range, std::shared_ptr<void>* keep);

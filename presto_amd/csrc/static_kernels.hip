@@ -391,6 +391,83 @@ void launch_gt_compact(const uint64_t* tag, const uint64_t* keys, const uint64_t
 // keys -> output blocks, states -> final values, in the pass that compacts the table (see static_kernels.hpp).
 // A workgroup takes 4096 consecutive slots: occupancy bits -> workgroup scan -> ONE counter atomic per tile (atomics
 // on a single address retire at only ~0.25 G/s on this part, so per-wave or per-slot counting would bound the kernel).
+// one output column of the group in slot i: its value bits and NULL flag (KEY columns also feed the row's $hashvalue)
+__device__ __forceinline__ void gt_emit_value(const GtEmitArgs& a, const GtEmitCol& col, u64 i, const u64* kw, const u64* wd, i64& row_hash, u64& bits, bool& is_null)
+{
+    bits = 0;
+    is_null = false;
+    switch (col.kind) {
+        case GT_EMIT_KEY: {
+            is_null = col.null_word >= 0 && ((kw[col.null_word] >> col.null_shift) & 1ULL);
+            const u64 mask = col.bits >= 64 ? ~0ULL : ((1ULL << col.bits) - 1ULL);
+            const u64 w0 = (kw[col.word] >> col.shift) & mask;
+            i64 h = 0;  // NULL hashes to 0
+            if (!is_null) {
+                switch (col.type) {
+                    case PA_BIGINT: bits = w0; h = pa_hash_bigint((i64)w0); break;
+                    case PA_INTEGER:
+                    case PA_DATE:
+                    case PA_REAL:  // canonical float bits, hashed as the int they are (RealType.hashCodeOperator)
+                        bits = (u64)(u32)w0;
+                        h = col.dict_hash ? (i64)col.dict_hash[(u32)w0] : pa_hash_bigint((i64)(i32)(u32)w0);
+                        break;
+                    case PA_BOOLEAN: bits = w0 != 0 ? 1ULL : 0ULL; h = (i64)pa_xxh64_long(bits); break;
+                    default: bits = w0; h = pa_hash_bigint((i64)w0); break;  // DOUBLE: canonical bits
+                }
+            }
+            row_hash = pa_combine_hash(row_hash, h);
+            break;
+        }
+        case GT_EMIT_COLUMN: {  // group key read where it lives (slot = build position); DOUBLE in the group key's canonical form
+            is_null = col.src_nulls != nullptr && col.src_nulls[i] != 0;
+            if (!is_null) {
+                if (col.width == 8) bits = ((const u64*)col.src)[i];
+                else if (col.width == 4) bits = (u64)((const u32*)col.src)[i];
+                else bits = ((const u8*)col.src)[i] != 0 ? 1ULL : 0ULL;
+                if (col.type == PA_DOUBLE) {
+                    const double v = __longlong_as_double((i64)bits);
+                    bits = v == 0.0 ? 0ULL : (v != v ? 0x7ff8000000000000ULL : bits);
+                }
+                else if (col.type == PA_REAL) bits = (u64)pa_real_key_bits(__uint_as_float((u32)bits));
+            }
+            break;
+        }
+        case GT_EMIT_HASH: bits = (u64)row_hash; break;
+        // (a count word of -1 is the implicit count of op_fused.cpp: it counts as 1)
+        case GT_EMIT_STATE: bits = col.word >= 0 ? wd[(u64)col.word * a.st.word + i * a.st.slot] : 1ULL; break;
+        case GT_EMIT_COUNT: bits = wd[(u64)col.cw * a.st.word + i * a.st.slot]; break;
+        case GT_EMIT_SUM:
+            if (col.cw >= 0 && wd[(u64)col.cw * a.st.word + i * a.st.slot] == 0ULL) is_null = true;
+            else {
+                bits = wd[(u64)col.vw * a.st.word + i * a.st.slot];
+                if (col.type == PA_REAL) bits = (u64)__float_as_uint((float)__longlong_as_double((i64)bits));  // RealSumAggregation.output: (float) sum
+            }
+            break;
+        case GT_EMIT_MINMAX: {
+            if (col.cw >= 0 && wd[(u64)col.cw * a.st.word + i * a.st.slot] == 0ULL) is_null = true;
+            else {
+                u64 img = wd[(u64)col.vw * a.st.word + i * a.st.slot];
+                if (col.shift) img = ~img;  // min is kept as the maximum of the complement
+                if (col.type == PA_DOUBLE) bits = pa_unimg_f64_bits(img);
+                else if (col.type == PA_REAL) bits = (u64)__float_as_uint((float)__longlong_as_double((i64)pa_unimg_f64_bits(img)));
+                else if (col.type == PA_BOOLEAN) bits = img;
+                else bits = (u64)pa_unimg_i64(img);
+            }
+            break;
+        }
+        case GT_EMIT_AVG: {
+            const i64 count = (i64)wd[(u64)col.cw * a.st.word + i * a.st.slot];
+            if (count == 0) is_null = true;
+            else {
+                double avg = __longlong_as_double((i64)wd[(u64)col.vw * a.st.word + i * a.st.slot]) / (double)count;
+                bits = col.type == PA_REAL ? (u64)__float_as_uint((float)avg) : (u64)__double_as_longlong(avg);
+            }
+            break;
+        }
+        default: break;
+    }
+}
+
 __device__ __forceinline__ void gt_emit_slot(const GtEmitArgs& a, u64 i, u64 g)
 {
     const u64* kw = (const u64*)a.keys + i * (u64)a.W;
@@ -398,78 +475,9 @@ __device__ __forceinline__ void gt_emit_slot(const GtEmitArgs& a, u64 i, u64 g)
     i64 row_hash = 0;
     for (int c = 0; c < a.ncols; c++) {
         const GtEmitCol& col = a.col[c];
-        u64 bits = 0;
-        bool is_null = false;
-        switch (col.kind) {
-            case GT_EMIT_KEY: {
-                is_null = col.null_word >= 0 && ((kw[col.null_word] >> col.null_shift) & 1ULL);
-                const u64 mask = col.bits >= 64 ? ~0ULL : ((1ULL << col.bits) - 1ULL);
-                const u64 w0 = (kw[col.word] >> col.shift) & mask;
-                i64 h = 0;  // NULL hashes to 0
-                if (!is_null) {
-                    switch (col.type) {
-                        case PA_BIGINT: bits = w0; h = pa_hash_bigint((i64)w0); break;
-                        case PA_INTEGER:
-                        case PA_DATE:
-                        case PA_REAL:  // canonical float bits, hashed as the int they are (RealType.hashCodeOperator)
-                            bits = (u64)(u32)w0;
-                            h = col.dict_hash ? (i64)col.dict_hash[(u32)w0] : pa_hash_bigint((i64)(i32)(u32)w0);
-                            break;
-                        case PA_BOOLEAN: bits = w0 != 0 ? 1ULL : 0ULL; h = (i64)pa_xxh64_long(bits); break;
-                        default: bits = w0; h = pa_hash_bigint((i64)w0); break;  // DOUBLE: canonical bits
-                    }
-                }
-                row_hash = pa_combine_hash(row_hash, h);
-                break;
-            }
-            case GT_EMIT_COLUMN: {  // group key read where it lives (slot = build position); DOUBLE in the group key's canonical form
-                is_null = col.src_nulls != nullptr && col.src_nulls[i] != 0;
-                if (!is_null) {
-                    if (col.width == 8) bits = ((const u64*)col.src)[i];
-                    else if (col.width == 4) bits = (u64)((const u32*)col.src)[i];
-                    else bits = ((const u8*)col.src)[i] != 0 ? 1ULL : 0ULL;
-                    if (col.type == PA_DOUBLE) {
-                        const double v = __longlong_as_double((i64)bits);
-                        bits = v == 0.0 ? 0ULL : (v != v ? 0x7ff8000000000000ULL : bits);
-                    }
-                    else if (col.type == PA_REAL) bits = (u64)pa_real_key_bits(__uint_as_float((u32)bits));
-                }
-                break;
-            }
-            case GT_EMIT_HASH: bits = (u64)row_hash; break;
-            // (a count word of -1 is the implicit count of op_fused.cpp: it counts as 1)
-            case GT_EMIT_STATE: bits = col.word >= 0 ? wd[(u64)col.word * a.st.word + i * a.st.slot] : 1ULL; break;
-            case GT_EMIT_COUNT: bits = wd[(u64)col.cw * a.st.word + i * a.st.slot]; break;
-            case GT_EMIT_SUM:
-                if (col.cw >= 0 && wd[(u64)col.cw * a.st.word + i * a.st.slot] == 0ULL) is_null = true;
-                else {
-                    bits = wd[(u64)col.vw * a.st.word + i * a.st.slot];
-                    if (col.type == PA_REAL) bits = (u64)__float_as_uint((float)__longlong_as_double((i64)bits));  // RealSumAggregation.output: (float) sum
-                }
-                break;
-            case GT_EMIT_MINMAX: {
-                if (col.cw >= 0 && wd[(u64)col.cw * a.st.word + i * a.st.slot] == 0ULL) is_null = true;
-                else {
-                    u64 img = wd[(u64)col.vw * a.st.word + i * a.st.slot];
-                    if (col.shift) img = ~img;  // min is kept as the maximum of the complement
-                    if (col.type == PA_DOUBLE) bits = pa_unimg_f64_bits(img);
-                    else if (col.type == PA_REAL) bits = (u64)__float_as_uint((float)__longlong_as_double((i64)pa_unimg_f64_bits(img)));
-                    else if (col.type == PA_BOOLEAN) bits = img;
-                    else bits = (u64)pa_unimg_i64(img);
-                }
-                break;
-            }
-            case GT_EMIT_AVG: {
-                const i64 count = (i64)wd[(u64)col.cw * a.st.word + i * a.st.slot];
-                if (count == 0) is_null = true;
-                else {
-                    double avg = __longlong_as_double((i64)wd[(u64)col.vw * a.st.word + i * a.st.slot]) / (double)count;
-                    bits = col.type == PA_REAL ? (u64)__float_as_uint((float)avg) : (u64)__double_as_longlong(avg);
-                }
-                break;
-            }
-            default: break;
-        }
+        u64 bits;
+        bool is_null;
+        gt_emit_value(a, col, i, kw, wd, row_hash, bits, is_null);
         if (col.width == 8) ((u64*)col.values)[g] = bits;
         else if (col.width == 4) ((u32*)col.values)[g] = (u32)bits;
         else ((u8*)col.values)[g] = (u8)bits;
@@ -492,13 +500,14 @@ __global__ __launch_bounds__(256) void k_gt_emit(GtEmitArgs a)
     const i64 tiles = (cap + 4095) >> 12;
     const u64* tag = (const u64*)a.tag;
     const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const u64 bound = a.filter_keys ? *a.filter_bound : ~0ULL;  // (a consumer's TopN: groups beyond the bound are left out)
     for (i64 tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
         const i64 first = (tile << 12) + threadIdx.x;
         u32 occ = 0;
 #pragma unroll
         for (int j = 0; j < 16; j++) {
             const i64 i = first + (i64)j * 256;
-            if (i < cap && tag[(u64)i * a.st.tag] != a.st.empty) occ |= 1u << j;
+            if (i < cap && tag[(u64)i * a.st.tag] != a.st.empty && (!a.filter_keys || a.filter_keys[i] <= bound)) occ |= 1u << j;
         }
 #pragma unroll
         for (int j = 0; j < 16; j++) {
@@ -528,6 +537,60 @@ __global__ __launch_bounds__(256) void k_gt_emit(GtEmitArgs a)
         __syncthreads();  // `part` is rewritten by the next tile
     }
 }
+// Order-preserving 64-bit key of a value under a SortOrder (ASC_NULLS_FIRST 0, ASC_NULLS_LAST 1, DESC_NULLS_FIRST 2, DESC_NULLS_LAST 3):
+// a <= b in the requested order implies key(a) <= key(b).  `bits` = the value as an output block holds it (4-byte types in the low
+// half).  Double.compare / Float.compare order: -0.0 < 0.0, one NaN above everything.
+__device__ __forceinline__ u64 pa_sort_key(i32 type, u64 bits, bool is_null, i32 sort_order)
+{
+    const bool descending = sort_order >= 2, nulls_first = (sort_order & 1) == 0;
+    if (is_null) return nulls_first ? 0ULL : ~0ULL;
+    u64 img;
+    switch (type) {
+        case PA_INTEGER:
+        case PA_DATE: img = (u64)(i64)(i32)(u32)bits ^ 0x8000000000000000ULL; break;
+        case PA_BOOLEAN: img = bits != 0ULL ? 1ULL : 0ULL; break;
+        case PA_DOUBLE: {
+            const double d = __longlong_as_double((i64)bits);
+            const u64 b = d != d ? 0x7ff8000000000000ULL : bits;
+            img = (b >> 63) ? ~b : (b | 0x8000000000000000ULL);
+            break;
+        }
+        case PA_REAL: {
+            const double d = (double)__uint_as_float((u32)bits);
+            const u64 b = d != d ? 0x7ff8000000000000ULL : (u64)__double_as_longlong(d);
+            img = (b >> 63) ? ~b : (b | 0x8000000000000000ULL);
+            break;
+        }
+        default: img = bits ^ 0x8000000000000000ULL; break;  // BIGINT, short DECIMAL
+    }
+    return descending ? ~img : img;
+}
+
+// The order-preserving key (topn_kernels.hpp) of output column `column` for every slot of the table; ~0 for slots without a group.
+__global__ __launch_bounds__(256) void k_gt_emit_keys(GtEmitArgs a, int column, int sort_order, u64* __restrict__ keys)
+{
+    const u64* tag = (const u64*)a.tag;
+    const u64* wd = (const u64*)a.words;
+    const GtEmitCol& col = a.col[column];
+    for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < (i64)a.cap; i += (i64)gridDim.x * 256) {
+        u64 key = ~0ULL;
+        if (tag[(u64)i * a.st.tag] != a.st.empty) {
+            const u64* kw = (const u64*)a.keys + (u64)i * (u64)a.W;
+            i64 row_hash = 0;
+            u64 bits;
+            bool is_null;
+            gt_emit_value(a, col, (u64)i, kw, wd, row_hash, bits, is_null);
+            key = pa_sort_key(col.type, bits, is_null, sort_order);
+        }
+        keys[i] = key;
+    }
+}
+void launch_gt_emit_keys(const GtEmitArgs& args, int column, int sort_order, uint64_t* keys, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_gt_emit_keys, grid_for((int64_t)args.cap, 256), 256, 0, s, args, column, sort_order, (u64*)keys);
+    PA_HIP(hipGetLastError());
+}
+
 void launch_gt_emit(const GtEmitArgs& args, hipStream_t s)
 {
     const int64_t tiles = ((int64_t)args.cap + 4095) >> 12;

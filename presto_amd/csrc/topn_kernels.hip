@@ -27,6 +27,7 @@ __device__ __forceinline__ u64 order_key(u64 ascending_image, bool is_null, int 
 __device__ __forceinline__ u64 row_key(i32 type, const void* __restrict__ values, const i32* __restrict__ offsets, const u8* __restrict__ nulls, i64 i,
                                        i32 sort_order)
 {
+    if (type < 0) return ((const u64*)values)[i];  // PA_TOPN_KEYS: the column already holds keys
     const bool is_null = nulls && nulls[i];
     u64 img = 0;
     if (!is_null) {

@@ -90,6 +90,13 @@ class Operator:
         join bridge -- the join's dynamic filter applied upstream of the probe.  True when the filter is active."""
         return bool(check(lib().pa_filter_project_set_dynamic_filter(self._h, channel, lookup_source_factory._h)))
 
+    def setOutputTopNHint(self, n, sort_channels, sort_orders):
+        """(Hash)Aggregation operators whose only consumer is TopNOperator(n, sort_channels, sort_orders) over their output: groups
+        that cannot be among its n best rows may be left out (pa_aggregation_set_output_topn_hint).  True when the hint is taken."""
+        ch, od = abi.int32_array(sort_channels), abi.int32_array(sort_orders)
+        return bool(check(lib().pa_aggregation_set_output_topn_hint(self._h, n, len(sort_channels), C.cast(ch, C.POINTER(C.c_int32)),
+                                                                    C.cast(od, C.POINTER(C.c_int32)))))
+
     def setDynamicFilterBitmap(self, channel, bits_ptr, min_key, key_range, keep=None):
         """The same with a bitmap combined over the ranks of a partitioned join (`keep` = whatever owns the bitmap)."""
         check(lib().pa_filter_project_set_dynamic_filter_bitmap(self._h, channel, bits_ptr, min_key, key_range))

@@ -48,7 +48,7 @@ def _factory(key, make):
 
 
 def run(customer_pages, orders_pages, lineitem_pages, stream, comm=None, expected_groups=100000, distributed=None,
-        result_mem=abi.MEM_HOST, top_n=0, with_count=True, dynamic_filters=True, fused_probe=True):
+        result_mem=abi.MEM_HOST, top_n=0, with_count=True, dynamic_filters=True, fused_probe=True, topn_hint=True):
     """Runs the three pipelines on this rank's pages; returns (result pages, counters).  `stream` is the HIP stream
     handle every operator (and the exchange) runs on; `comm` the presto_amd.exchange.Comm of the ranks (None: one rank, no
     exchange steps; distributed=True with a one-rank comm still runs them); result_mem = where the grouped result is left
@@ -62,7 +62,8 @@ def run(customer_pages, orders_pages, lineitem_pages, stream, comm=None, expecte
     the lineitem pipeline's FilterAndProject -> LookupJoin -> HashAggregation run behind one handle
     (pa_fused_join_aggregation_create: one generated kernel over the lineitem pages -- orderkey is unique on the build side);
     with exchange steps the filter stays in front of the exchange and the fused operator takes the exchanged pages.
-    False: the three operators on their own (the independent path of the parity tests)."""
+    False: the three operators on their own (the independent path of the parity tests).  topn_hint (with top_n): the final
+    aggregation is told that a TopN is its only consumer (pa_aggregation_set_output_topn_hint)."""
     if distributed is None:
         distributed = comm is not None and comm.world > 1
     if distributed and comm is None:
@@ -161,6 +162,11 @@ def run(customer_pages, orders_pages, lineitem_pages, stream, comm=None, expecte
             tail = [LookupJoinOperator(b2, exchanged, [0], [0, 1], output_mem=dev, stream=s),
                     HashAggregationOperator(AGG_TYPES, AGG_GROUP_BY, aggregates, expected_groups=expected_groups, output_mem=agg_mem, stream=s)]
         head = [lineitem_fp, *exchange(exchanged, [0]), *tail]
+    if top_n and topn_hint:
+        # the planner's note (LocalExecutionPlanner.visitTopN over visitAggregation): the aggregation's only consumer is this TopN, so
+        # groups that cannot be among its rows may stay in the table -- thousands of rows leave it instead of millions
+        agg_op = head[0] if (fused_probe and not distributed) else head[-1]
+        counters["topn_hint"] = agg_op.setOutputTopNHint(top_n, [3, 1], [abi.DESC_NULLS_LAST, abi.ASC_NULLS_LAST])
     out = Driver(lineitem_pages, head + top).run()
     lap("lineitem_pipeline")
     if fused_probe and not distributed:

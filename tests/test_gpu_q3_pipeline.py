@@ -202,6 +202,12 @@ def test_q3_full_size_independent_paths_agree(gpu, sf):
 
     same(base, plain, [3])
     assert [r[4] for r in base] == [r[4] for r in plain]  # count(*) per group, exactly
+    # the aggregation told that a TopN is its only consumer (thousands of groups leave the table) vs every group emitted
+    assert counters["topn_hint"] is True
+    every, counters4 = run(1 << 28, topn_hint=False)
+    assert "topn_hint" not in counters4
+    same(every, base, [3])
+    assert [r[4] for r in base] == [r[4] for r in every]
     same(run(1 << 28, with_count=False)[0], base, [3])
     same(run(1 << 26)[0], base, [3])
     # the lineitem pipeline as one generated kernel (above) vs as three operators with a hashed group table

