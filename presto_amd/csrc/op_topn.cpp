@@ -158,7 +158,25 @@ private:
                 expect = rank * (n / kSample + 1);
             }
         }
-        if (!sampled && threshold_ == ~0ULL) return false;  // nothing bounds the page
+        auto tighten = [&] {
+            // the exact N-th best first key of everything kept so far bounds every later page (and what prune keeps)
+            if ((int64_t)store_keys_.size() >= n_) {
+                std::vector<uint64_t> k(store_keys_);
+                std::nth_element(k.begin(), k.begin() + (n_ - 1), k.end());
+                threshold_ = std::min(threshold_, k[(size_t)n_ - 1]);
+            }
+            prune();
+        };
+        if (!sampled && threshold_ == ~0ULL) {
+            if (n > ((int64_t)1 << 14)) return false;  // nothing bounds the page
+            // a small first page (an upstream operator that already cut its output down, Q3's hinted aggregation): every row is a
+            // candidate -- one kernel for the keys, one copy to the host -- instead of a selection over a few thousand rows
+            uint64_t* all = static_cast<uint64_t*>(keys_.ensure((size_t)n * 8));
+            launch_topn_keys(first.type, first.values, first.offsets, first.nulls, n, sort_orders_[0], all, s);
+            append_rows(dp, all, nullptr, n);
+            tighten();
+            return true;
+        }
         const int64_t capacity = std::min<int64_t>(n, sampled ? 2 * expect + kSample : (int64_t)1 << 20);
         int32_t* positions = static_cast<int32_t*>(pos_.ensure((size_t)capacity * 4));
         uint64_t* keys = static_cast<uint64_t*>(keys_.ensure((size_t)capacity * 8));
@@ -179,13 +197,7 @@ private:
         // (the matches were collected as the waves met them: every row takes its arrival number along -- store_seq_ -- and fully
         // tied rows are put in arrival order by the final comparison, not by the order they are stored in)
         append_rows(dp, keys, positions, count, true);
-        // the exact N-th best first key of everything kept so far bounds every later page (and what prune keeps)
-        if ((int64_t)store_keys_.size() >= n_) {
-            std::vector<uint64_t> k(store_keys_);
-            std::nth_element(k.begin(), k.begin() + (n_ - 1), k.end());
-            threshold_ = std::min(threshold_, k[(size_t)n_ - 1]);
-        }
-        prune();
+        tighten();
         return true;
     }
 
