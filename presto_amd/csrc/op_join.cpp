@@ -260,6 +260,11 @@ public:
                                         static_cast<int32_t*>(ls_->rank_rows.ensure((size_t)n * 4)), s, pair_first_.as<int64_t>(), pair_partitions_, pair_shift_, ctl_ + 4);
             PA_HIP(hipMemsetAsync(ctl_ + 5, 1, 4, s));   // "out of key order" (non-zero), by the check that brought us here
         }
+        else if (keys_ascending_) {
+            // no key is smaller than its predecessor (k_join_key_disorder): with no key on two rows -- the condition the index stands
+            // on anyway -- the keys are strictly ascending and the rank of a key IS its row; nothing to write, nothing to check
+            PA_HIP(hipMemsetAsync(ctl_ + 5, 0, 4, s));
+        }
         else launch_join_rank_rows(key, n, words, ls_->bitmap.min_key, static_cast<int32_t*>(ls_->rank_rows.ensure((size_t)n * 4)), ctl_ + 5, s, ctl_ + 4);
         pair_keys_.release();
         pair_rows_.release();
@@ -328,6 +333,7 @@ public:
         PA_HIP(hipMemcpyAsync(h, run, 32, hipMemcpyDeviceToHost, s));
         PA_HIP(hipStreamSynchronize(s));
         if (!h[2]) return;  // every key NULL
+        keys_ascending_ = h[3] == 0;
         ls_->key_range_valid = true;
         ls_->key_min = h[0];
         ls_->key_max = h[1];
@@ -383,6 +389,7 @@ private:
     DevBuf ctl_buf_, rank_counts_, rank_temp_;
     // (key, row) pairs regrouped by key range, kept between build_key_bitmap and start_rank_index (rows out of key order)
     DevBuf pair_keys_, pair_rows_, pair_first_;
+    bool keys_ascending_ = false;  // no build key is smaller than the key of the row before it (build_key_bitmap)
     bool links_built_ = false;  // the table build left the chains of keys with several rows behind (the partitioned build does)
     int32_t pairs_ = 0, pair_partitions_ = 0;
     int pair_shift_ = 0;
