@@ -862,11 +862,79 @@ void launch_join_rank_rows(const JoinCol& build_key, int32_t n, const JoinRankWo
     hipLaunchKernelGGL(k_join_rank_rows, grid_for(n), 256, 0, s, build_key, n, words, (i64)min_key, rows, unordered, distinct);
     PA_HIP(hipGetLastError());
 }
+// The same over a lookup source WITHOUT duplicate keys, four consecutive probe rows per thread and step: their keys, then their
+// bitmap / rank words, then their slots are loaded back to back and waited for once (pa_join_probe4, the probe of the generated
+// fused kernels) -- row by row a wave waits for two to three dependent trips to memory per row and runs at a third of the rate.
+// Every chain is one row long, so a row's count is whether it matched (or 1, for the NULL-extended row of a probe-outer join).
+struct ProbeTable {
+    const void* jslots;
+    const u64* jbits;
+    i64 jmin;
+    u64 jrange;
+    u32 jmask, jwrap;
+    const pa_u32x4* jrank;
+    const i32* jrank_rows;
+};
+__global__ __launch_bounds__(256) void k_join_probe_count_keyed4(JoinCol probe_key, i32 n_probe, ProbeTable t, i32* __restrict__ head, i32* __restrict__ counts,
+                                                                 int flags, unsigned long long* __restrict__ total)
+{
+    i64 mine = 0;
+    const i64 quads = ((i64)n_probe + 3) >> 2;
+    for (i64 q = (i64)blockIdx.x * 256 + threadIdx.x; q < quads; q += (i64)gridDim.x * 256) {
+        bool s[4];
+        u64 k[4];
+        i32 jb[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const i64 i = 4 * q + r;
+            s[r] = i < n_probe && !jcol_is_null(probe_key, (i32)i);  // JoinProbe.java:89-91
+            k[r] = s[r] ? join_key_bits(probe_key, (i32)i) : 0ULL;
+        }
+        pa_join_probe4(t, s, k, jb);
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const i64 i = 4 * q + r;
+            if (i >= n_probe) continue;
+            const i32 h = s[r] ? jb[r] : -1;
+            const i32 c = (h != -1 || (flags & 1)) ? 1 : 0;
+            head[i] = h;
+            counts[i] = c;
+            mine += c;
+        }
+    }
+    if (total) {
+        __shared__ i64 wave_total[4];
+        mine = pa_wave_sum_i64(mine);
+        if ((threadIdx.x & 63) == 0) wave_total[threadIdx.x >> 6] = mine;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const i64 all = wave_total[0] + wave_total[1] + wave_total[2] + wave_total[3];
+            if (all != 0) atomicAdd(total + (blockIdx.x & 15u), (unsigned long long)all);
+        }
+    }
+}
+
 void launch_join_probe_count_keyed(const JoinCol& probe_key, const int64_t* probe_hash, int32_t n_probe, const JoinKeySlot* slots, uint32_t mask,
                                    uint32_t wrap, const int32_t* links, const JoinKeyBitmap& bitmap, const JoinRankIndex& rank, int32_t* head, int32_t* counts,
-                                   int flags, hipStream_t s, int64_t* total)
+                                   int flags, hipStream_t s, int64_t* total, bool unique_keys)
 {
     if (n_probe <= 0) return;
+    // (with a $hashvalue channel the home slot comes from the channel's value: the row-by-row kernel reads it)
+    if (unique_keys && probe_hash == nullptr && (rank.words == nullptr || rank.min_key == bitmap.min_key || bitmap.bits == nullptr)) {
+        ProbeTable t{};
+        t.jslots = slots;
+        t.jbits = rank.words ? nullptr : reinterpret_cast<const u64*>(bitmap.bits);
+        t.jmin = rank.words ? rank.min_key : bitmap.min_key;
+        t.jrange = rank.words ? rank.range : bitmap.range;
+        t.jmask = mask;
+        t.jwrap = wrap;
+        t.jrank = reinterpret_cast<const pa_u32x4*>(rank.words);
+        t.jrank_rows = rank.rows;
+        hipLaunchKernelGGL(k_join_probe_count_keyed4, grid_for(((int64_t)n_probe + 3) / 4), 256, 0, s, probe_key, n_probe, t, head, counts, flags,
+                           (unsigned long long*)total);
+        PA_HIP(hipGetLastError());
+        return;
+    }
     hipLaunchKernelGGL(k_join_probe_count_keyed, grid_for(n_probe), 256, 0, s, probe_key, (const i64*)probe_hash, n_probe, slots, mask, wrap, links, bitmap,
                        rank, head, counts, flags, (unsigned long long*)total);
     PA_HIP(hipGetLastError());

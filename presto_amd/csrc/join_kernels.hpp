@@ -94,7 +94,7 @@ void launch_join_rank_rows(const JoinCol& build_key, int32_t n, const JoinRankWo
 // kJoinPartSlots-slot partition of its home slot)
 void launch_join_probe_count_keyed(const JoinCol& probe_key, const int64_t* probe_hash, int32_t n_probe, const JoinKeySlot* slots, uint32_t mask,
                                    uint32_t wrap, const int32_t* links, const JoinKeyBitmap& bitmap, const JoinRankIndex& rank, int32_t* head, int32_t* counts,
-                                   int flags, hipStream_t s, int64_t* total = nullptr);   // total: 16 counters (zeroed by the caller) whose sum is the page's output rows
+                                   int flags, hipStream_t s, int64_t* total = nullptr, bool unique_keys = false);   // total: 16 counters (zeroed by the caller) whose sum is the page's output rows
 // build rows out of key order: the bitmap and the rank -> row array over (key, row) pairs regrouped by key range (join_kernels.hip)
 void launch_join_key_disorder(const JoinCol& key, int32_t n, int32_t* flag, hipStream_t s);
 int join_range_shift(uint64_t range);   // log2 of the key values per partition (16..19), -1: the range is too wide

@@ -493,7 +493,7 @@ public:
             int64_t* totals = static_cast<int64_t*>(totals_.ensure(16 * 8));
             PA_HIP(hipMemsetAsync(totals, 0, 16 * 8, s));
             launch_join_probe_count_keyed(pk.col[0], probe_hash, n, ls_->key_slots.as<JoinKeySlot>(), ls_->probe_mask, ls_->probe_wrap, ls_->links.as<int32_t>(), ls_->bitmap, ls_->rank, head, counts,
-                                          probe_flags_, s, totals);
+                                          probe_flags_, s, totals, !ls_->has_duplicates);
             timer.end(s);
             PA_HIP(hipMemcpyAsync(h_totals_.ensure(16 * 8), totals, 16 * 8, hipMemcpyDeviceToHost, s));
             totals_pending_ = true;
