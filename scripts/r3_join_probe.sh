@@ -3,8 +3,8 @@ set -e -o pipefail
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out
 cd $R
-timeout -k 10 700 python -m pytest -x -q -m gpu tests/test_gpu_join.py tests/test_gpu_join_fuzz.py tests/test_gpu_fused_join.py tests/test_gpu_q3_pipeline.py --durations=5 > $O/r3_p13_tests.log 2>&1 || { tail -60 $O/r3_p13_tests.log; exit 1; }
-tail -8 $O/r3_p13_tests.log
+timeout -k 10 700 python -m pytest -x -q -m gpu tests/test_gpu_join.py tests/test_gpu_join_fuzz.py tests/test_gpu_fused_join.py tests/test_gpu_q3_pipeline.py --durations=5 > $O/r3_join_tests.log 2>&1 || { tail -60 $O/r3_p13_tests.log; exit 1; }
+tail -8 $O/r3_join_tests.log
 python3 - <<'PY' > $O/r3_join_c.txt 2>&1
 import bench_ops
 out = bench_ops.run(cpu=False)
