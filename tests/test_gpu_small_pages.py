@@ -373,3 +373,43 @@ def test_row_range_table_when_the_few_groups_tier_gives_up(gpu, oracle, monkeypa
     rows = sorted(r for p in to_pages(op, regs[0::2] + regs[1::2]) for r in p.to_rows())
     op.close()
     assert rows == expected
+
+
+@pytest.mark.parametrize("seed", list(range(int(__import__("os").environ.get("PA_FUZZ_SEEDS", "8")))))
+def test_random_mix_of_page_routes(gpu, oracle, monkeypatch, seed):
+    """Pages of random sizes handed over in random order through a random mix of routes -- stable views of one device page (merged
+    when they continue each other, taken as a table of row ranges when they do not), device pages with buffers of their own, plain
+    host pages -- with a launch threshold that cuts the stream several times: a VARCHAR(3) + BIGINT grouped aggregation with NULL keys
+    and NULL values, and an ungrouped one, must give the oracle's result whatever the mix."""
+    rng = np.random.default_rng(4000 + seed)
+    monkeypatch.setenv("PRESTO_AMD_GATHER_ROWS", str(int(rng.choice([1 << 15, 1 << 17, 1 << 26]))))
+    n = int(rng.integers(150_000, 400_000))
+    words = [b"", b"a", b"ab", b"abc", b"zz", None]
+    skeys = [words[i] for i in rng.integers(0, len(words), n)]
+    ikeys = rng.integers(0, int(rng.choice([3, 40])), n).astype(np.int64)
+    vals = rng.random(n) * 10 - 5
+    vnull = rng.random(n) < 0.1
+    host = Page([Block.varchar(skeys), Block.bigint(ikeys), Block.double(vals, vnull)], n)
+    dev = upload_page(host)
+    cuts = sorted(set(int(x) for x in rng.integers(1, n, int(rng.integers(5, 60)))))
+    bounds = [0] + cuts + [n]
+    views = stable_regions(dev, bounds)
+    order = rng.permutation(len(views)) if rng.random() < 0.7 else np.arange(len(views))
+    pages = []
+    for i in order:
+        lo, hi = bounds[i], bounds[i + 1]
+        route = rng.integers(0, 3)
+        pages.append(views[i] if route == 0 else (upload_page(host.get_region(lo, hi - lo)) if route == 1 else host.get_region(lo, hi - lo)))
+    types = [abi.VARCHAR, abi.BIGINT, abi.DOUBLE]
+    aggs = [(abi.AGG_SUM, 2, abi.DOUBLE), (abi.AGG_COUNT, 2, abi.DOUBLE), (abi.AGG_COUNT_STAR, -1, None), (abi.AGG_MAX, 1, abi.BIGINT)]
+    for keys in ([0, 1], []):
+        ref = oracle.HashAggregation(types, keys, aggs)
+        ref.add_page(host)
+        expected = sorted(ref.build_result().to_rows(), key=repr)
+        op = HashAggregationOperator(types, keys, aggs, type_params=[3, 0, 0])
+        got = sorted((r for p in to_pages(op, pages) for r in p.to_rows()), key=repr)
+        op.close()
+        assert len(got) == len(expected)
+        for g, e in zip(got, expected):
+            assert g[:len(keys)] == e[:len(keys)] and g[len(keys) + 1:] == e[len(keys) + 1:], (g, e)
+            assert (g[len(keys)] is None and e[len(keys)] is None) or abs(g[len(keys)] - e[len(keys)]) <= 1e-9 * max(abs(e[len(keys)]), 1.0), (g, e)
