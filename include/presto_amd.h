@@ -231,7 +231,8 @@ typedef struct pa_filter_project_desc {
  * LongDoubleState / LongLongState rows; here they are flattened into plain channels, per aggregate
  *   count(*), count(x)  ->  [count BIGINT]
  *   sum(x), avg(x)      ->  [count BIGINT, sum DOUBLE]   (sum BIGINT for sum over BIGINT/INTEGER)
- *   min(x), max(x)      ->  [count BIGINT, value of x's type, NULL while count = 0]   (BIGINT / INTEGER / DATE / DOUBLE / BOOLEAN)
+ *   min(x), max(x)      ->  [count BIGINT, value of x's type, NULL while count = 0]   (BIGINT / INTEGER / DATE / DOUBLE / REAL / BOOLEAN /
+ *                           short DECIMAL / VARCHAR: the string itself)
  * PARTIAL emits keys, ($hashvalue), then these channels; FINAL takes them as input: pa_aggregate.input_channel names
  * the aggregate's count channel (the sum channel follows it), input_type the type of the sum, and it combines with the
  * @CombineFunction of the aggregate (DoubleSumAggregation.java:47-52 etc.).

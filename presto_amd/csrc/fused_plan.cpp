@@ -136,15 +136,16 @@ Spec make_spec(const pa_filter_project_desc& fp, const pa_hash_aggregation_desc&
         if (a.mask_channel >= 0) a.mask_channel = to_proj[a.mask_channel];
         // min / max over VARCHAR: strings of a declared length of at most 7 bytes have an order-preserving 64-bit image (bytes
         // big-endian, then the length: Slice.compareTo = unsigned bytes, then length) and ride the integer max machinery; longer or
-        // unbounded strings stay with the Java operator
-        auto short_varchar = [&](int proj) {
+        // unbounded strings go through their rank in the channel's dictionary (Spec::ranked, finalize_spec) -- for that the
+        // argument has to be a channel of the page itself, not a computed string
+        auto varchar_channel = [&](int proj) {
             const OwnedExpr& pe = s.proj[proj];
             if (!pe.is_input_ref()) return false;
             const int ch = pe.node(pe.root).channel;
-            return ch >= 0 && ch < s.n_in && s.in_params[ch] >= 1 && s.in_params[ch] <= 7;
+            return ch >= 0 && ch < s.n_in;
         };
         if ((a.fn == PA_AGG_MIN || a.fn == PA_AGG_MAX) && ag.step != PA_STEP_FINAL && a.input_channel >= 0 && s.proj[a.input_channel].root_type() == PA_VARCHAR) {
-            PA_REQUIRE(short_varchar(a.input_channel), PA_ERR_NOT_SUPPORTED, "min/max over VARCHAR: only channels declared VARCHAR(n), n <= 7, are on the device path");
+            PA_REQUIRE(varchar_channel(a.input_channel), PA_ERR_NOT_SUPPORTED, "min/max over VARCHAR: the argument must be an input channel");
         }
         if (s.step == PA_STEP_FINAL) {
             // intermediate input: [count BIGINT] for count / count(*), [count BIGINT, sum] for sum / avg
@@ -153,8 +154,8 @@ Spec make_spec(const pa_filter_project_desc& fp, const pa_hash_aggregation_desc&
             PA_REQUIRE(a.mask_channel < 0, PA_ERR_INVALID_ARGUMENT, "FINAL step takes no mask");
             if (a.fn == PA_AGG_MIN || a.fn == PA_AGG_MAX) {
                 PA_REQUIRE(a.input_channel + 1 < fp.projection_count, PA_ERR_INVALID_ARGUMENT, "FINAL step: missing value state channel");
-                PA_REQUIRE(s.proj[a.input_channel + 1].root_type() != PA_VARCHAR || short_varchar(a.input_channel + 1), PA_ERR_NOT_SUPPORTED,
-                           "min/max over VARCHAR: only state channels declared VARCHAR(n), n <= 7, are on the device path");
+                PA_REQUIRE(s.proj[a.input_channel + 1].root_type() != PA_VARCHAR || varchar_channel(a.input_channel + 1), PA_ERR_NOT_SUPPORTED,
+                           "min/max over VARCHAR: the value state must be an input channel");
             }
             if (a.fn == PA_AGG_SUM || a.fn == PA_AGG_AVG) {
                 PA_REQUIRE(a.input_channel + 1 < fp.projection_count, PA_ERR_INVALID_ARGUMENT, "FINAL step: missing sum state channel");
@@ -246,6 +247,41 @@ void finalize_spec(Spec& s)
                        "VARCHAR group keys longer than 15 bytes that other expressions read are not on the device path");
         }
     }
+    // min / max over VARCHAR channels without a bound of at most 7 bytes: by rank (Spec::ranked).  Nothing else may read the
+    // channel -- a filter, an expression or a group key would need the strings themselves -- except count(), which only looks at
+    // the NULL flag
+    s.ranked.assign(s.n_in, false);
+    for (const pa_aggregate& a : s.aggs) {
+        if (a.fn != PA_AGG_MIN && a.fn != PA_AGG_MAX) continue;
+        const int vp = s.step == PA_STEP_FINAL ? a.input_channel + 1 : a.input_channel;
+        const OwnedExpr& pe = s.proj[vp];
+        if (pe.root_type() != PA_VARCHAR || !pe.is_input_ref()) continue;
+        const int c = pe.node(pe.root).channel;
+        if (c < 0 || c >= s.n_in || (s.in_params[c] >= 1 && s.in_params[c] <= 7)) continue;
+        s.ranked[c] = true;
+    }
+    for (int c = 0; c < s.n_in; c++) {
+        if (!s.ranked[c]) continue;
+        PA_REQUIRE(!s.join, PA_ERR_NOT_SUPPORTED, "min/max over long VARCHAR behind the fused probe is not on the device path");
+        bool only_minmax = !s.interned[c] && !(s.has_filter && [&] { std::set<int32_t> f; s.filter.collect_channels(&f); return f.count(c) != 0; }());
+        for (size_t q = 0; q < s.proj.size() && only_minmax; q++) {
+            std::set<int32_t> ch;
+            s.proj[q].collect_channels(&ch);
+            if (!ch.count(c)) continue;
+            only_minmax = s.proj[q].is_input_ref();
+            for (int j : s.group_proj) only_minmax = only_minmax && j != (int)q;
+            for (const pa_aggregate& a : s.aggs) {
+                if (a.mask_channel == (int32_t)q) only_minmax = false;
+                const int vp = s.step == PA_STEP_FINAL ? a.input_channel + 1 : a.input_channel;
+                if (vp == (int)q && a.fn != PA_AGG_MIN && a.fn != PA_AGG_MAX && a.fn != PA_AGG_COUNT) only_minmax = false;
+            }
+        }
+        PA_REQUIRE(only_minmax, PA_ERR_NOT_SUPPORTED, "min/max over a VARCHAR channel longer than 7 bytes that other expressions read is not on the device path");
+        s.in_types[c] = PA_BIGINT;
+        for (OwnedExpr& pe : s.proj) {
+            if (pe.is_input_ref() && pe.node(pe.root).channel == c) pe.nodes[pe.root].type = PA_BIGINT;
+        }
+    }
     for (int c = 0; c < s.n_in; c++) {
         if (!s.interned[c]) continue;
         s.in_types[c] = PA_INTEGER;
@@ -254,7 +290,7 @@ void finalize_spec(Spec& s)
         }
     }
     for (int c = 0; c < s.n_in; c++) {
-        if (s.interned[c] || s.in_types[c] == PA_VARCHAR) s.lazy_channel[c] = false;  // strings are handed to the row function whole
+        if (s.derived(c) || s.in_types[c] == PA_VARCHAR) s.lazy_channel[c] = false;  // strings are handed to the row function whole
     }
 }
 

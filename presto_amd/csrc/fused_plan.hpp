@@ -122,6 +122,17 @@ struct Spec {
     // per channel: VARCHAR group key of unknown or long (> 15 bytes) bound, replaced by its interned id before the kernels
     // see the page (intern_kernels.hpp); in_types / the projection's type say INTEGER for such a channel
     std::vector<bool> interned;
+    // per channel: VARCHAR argument of min / max without a short bound.  The page's strings are interned and the kernels see a BIGINT
+    // column in their place -- (rank of the string among the dictionary's strings) << 32 | id -- whose integer order is the strings'
+    // order; the operator re-ranks what it accumulated whenever a page brings new strings (op_fused.cpp: rank_values)
+    std::vector<bool> ranked;
+    bool any_ranked() const
+    {
+        for (bool r : ranked) if (r) return true;
+        return false;
+    }
+    // channels the kernels do not read as they arrive
+    bool derived(int c) const { return interned[c] || ranked[c]; }
 };
 
 struct KernelInfo {

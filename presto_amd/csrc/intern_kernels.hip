@@ -173,4 +173,42 @@ void launch_intern_bytes(const InternTable& t, const int32_t* ids, const uint8_t
     PA_HIP(hipGetLastError());
 }
 
+namespace {
+__global__ __launch_bounds__(256) void k_rank_image(const i32* __restrict__ ids, const u8* __restrict__ nulls, const u32* __restrict__ ranks, i64 n,
+                                                    i64* __restrict__ image)
+{
+    for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < n; i += (i64)gridDim.x * 256) {
+        if (nulls && nulls[i]) {
+            image[i] = 0;
+            continue;
+        }
+        const u32 id = (u32)ids[i];
+        image[i] = (i64)(((u64)(ranks[id] + 1u) << 32) | (u64)id);
+    }
+}
+__global__ __launch_bounds__(256) void k_rerank_words(u64* __restrict__ words, i64 n, int is_min, const u32* __restrict__ ranks)
+{
+    for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < n; i += (i64)gridDim.x * 256) {
+        const u64 w = words[i];
+        if (w == 0ULL) continue;
+        const u64 img = is_min ? ~w : w;
+        const u32 id = (u32)(img ^ 0x8000000000000000ULL);
+        const u64 now = ((((u64)(ranks[id] + 1u)) << 32) | (u64)id) ^ 0x8000000000000000ULL;
+        words[i] = is_min ? ~now : now;
+    }
+}
+}  // namespace
+void launch_rank_image(const int32_t* ids, const uint8_t* nulls, const uint32_t* ranks, int64_t n, int64_t* image, hipStream_t s)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_rank_image, grid_of(n), 256, 0, s, ids, nulls, ranks, (i64)n, (i64*)image);
+    PA_HIP(hipGetLastError());
+}
+void launch_rerank_words(uint64_t* words, int64_t n, bool is_min, const uint32_t* ranks, hipStream_t s)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_rerank_words, grid_of(n), 256, 0, s, (u64*)words, (i64)n, is_min ? 1 : 0, ranks);
+    PA_HIP(hipGetLastError());
+}
+
 }  // namespace pa

@@ -2,6 +2,9 @@
 // 32-bit ids that the packed-key machinery of the aggregation handles like an INTEGER column.
 #pragma once
 
+#include <string>
+#include <vector>
+
 #include "common.hpp"
 
 namespace pa {
@@ -29,6 +32,13 @@ void launch_intern_rehash(const uint64_t* old_tag, const uint64_t* old_meta, con
 void launch_intern_lengths(const InternTable& t, const int32_t* ids, const uint8_t* nulls, int64_t n, int32_t* out_lengths, hipStream_t s);
 void launch_intern_bytes(const InternTable& t, const int32_t* ids, const uint8_t* nulls, int64_t n, const int32_t* out_offsets, uint8_t* out_bytes, hipStream_t s);
 
+// min / max over strings by rank (op_fused.cpp: rank_values).  image[i] = (ranks[ids[i]] + 1) << 32 | ids[i] -- a positive BIGINT whose
+// order is the order of the strings, and whose low half names the string; 0 for the rows flagged in `nulls` (may be null)
+void launch_rank_image(const int32_t* ids, const uint8_t* nulls, const uint32_t* ranks, int64_t n, int64_t* image, hipStream_t s);
+// accumulator words holding such images -- as pa_img_i64 leaves them, complemented for min; 0 = no value yet -- brought up to date with
+// new ranks: the id stays, the rank is looked up again
+void launch_rerank_words(uint64_t* words, int64_t n, bool is_min, const uint32_t* ranks, hipStream_t s);
+
 // The dictionary of one channel, owned by the operator that interns it.  Not thread safe (one operator = one driver thread).
 class StringInterner {
 public:
@@ -38,6 +48,8 @@ public:
     void decode(const int32_t* ids, const uint8_t* nulls, int64_t n, DevBuf* values, DevBuf* offsets, hipStream_t s);
     const uint64_t* hashes() const { return id_hash_.as<uint64_t>(); }
     uint32_t size() const { return ids_; }
+    // the strings of the ids from->size() onwards appended to `out` (a copy for the host: ranks, small results)
+    void fetch_strings(uint32_t from, std::vector<std::string>* out, hipStream_t s);
     uint64_t bytes() const { return (uint64_t)words_ * 8; }  // arena in use (strings padded to 8 bytes)
 
 private:

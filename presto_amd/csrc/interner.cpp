@@ -105,4 +105,27 @@ void StringInterner::decode(const int32_t* ids, const uint8_t* nulls, int64_t n,
     launch_intern_bytes(view(), ids, nulls, n, offs, out, s);
 }
 
+void StringInterner::fetch_strings(uint32_t from, std::vector<std::string>* out, hipStream_t s)
+{
+    if (from >= ids_) return;
+    const uint32_t n = ids_ - from;
+    std::vector<uint32_t> off(n), len(n);
+    PA_HIP(hipMemcpyAsync(off.data(), id_off_.as<uint32_t>() + from, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    PA_HIP(hipMemcpyAsync(len.data(), id_len_.as<uint32_t>() + from, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    PA_HIP(hipStreamSynchronize(s));
+    // (the arena is handed out by an atomic cursor: the new ids' strings lie somewhere between the lowest of their offsets and its end)
+    uint32_t lo = words_;
+    for (uint32_t i = 0; i < n; i++) lo = std::min(lo, off[i]);
+    std::vector<uint64_t> words((size_t)(words_ - lo) + 1);
+    if (words_ > lo) {
+        PA_HIP(hipMemcpyAsync(words.data(), arena_.as<uint64_t>() + lo, (size_t)(words_ - lo) * 8, hipMemcpyDeviceToHost, s));
+        PA_HIP(hipStreamSynchronize(s));
+    }
+    out->reserve(out->size() + n);
+    for (uint32_t i = 0; i < n; i++) {
+        PA_REQUIRE(off[i] >= lo && (uint64_t)(off[i] - lo) * 8 + len[i] <= (uint64_t)(words_ - lo) * 8, PA_ERR_DEVICE, "internal: dictionary entry outside the arena");
+        out->emplace_back(reinterpret_cast<const char*>(words.data() + (off[i] - lo)), (size_t)len[i]);
+    }
+}
+
 }  // namespace pa

@@ -227,15 +227,148 @@ def test_min_max_varchar_partial_final(gpu, oracle):
     assert_same(final, expected)
 
 
+def long_strings(rng, count, pool):
+    """`count` strings out of `pool` distinct ones: lengths 0..40, shared prefixes (a proper prefix sorts first), bytes >= 0x80 (unsigned
+    order), some NULL."""
+    stems = [b"", b"a", b"customer#", b"customer#0000", b"\xff\xfe", b"\x80", b"special requests ", b"zz"]
+    words = [None]
+    for i in range(pool):
+        stem = stems[i % len(stems)]
+        words.append(stem + bytes(rng.integers(0, 256, int(rng.integers(0, 41 - len(stem)))).astype(np.uint8)))
+    return [words[i] for i in rng.integers(0, len(words), count)]
+
+
+@pytest.mark.parametrize("device", [False, True])
+@pytest.mark.parametrize("groups", [0, 3, 300, 40000])
+def test_min_max_over_long_varchar(gpu, oracle, groups, device):
+    """min / max over VARCHAR channels without a bound of <= 7 bytes (undeclared, and VARCHAR(40)): the strings travel as ranks in the
+    channel's dictionary.  Every page brings strings the pages before did not hold -- what was accumulated is re-ranked each time --,
+    the last page only repeats known ones.  Slice.compareTo order, NULL inputs skipped, NULL for groups without a value; ungrouped, a
+    few groups, many groups."""
+    from presto_amd.operators import upload_page
+    rng = np.random.default_rng(groups + 77)
+    n = 60000
+    pages = []
+    for k in range(4):
+        a = long_strings(rng, n, 50 if groups == 3 else 5000)
+        b = long_strings(rng, n, 700)
+        key = rng.integers(0, max(groups, 1), n)
+        pages.append(Page([Block.bigint(key), Block.varchar(a), Block.double(rng.random(n)), Block.varchar(b)], n))
+    pages.append(pages[1].get_region(100, 20000))
+    types = [abi.BIGINT, abi.VARCHAR, abi.DOUBLE, abi.VARCHAR]
+    aggs = [(abi.AGG_MIN, 1, abi.VARCHAR), (abi.AGG_MAX, 1, abi.VARCHAR), (abi.AGG_COUNT, 1, abi.VARCHAR), (abi.AGG_SUM, 2, abi.DOUBLE),
+            (abi.AGG_MAX, 3, abi.VARCHAR), (abi.AGG_COUNT_STAR, -1, None)]
+    keys = [0] if groups else []
+    inputs = [upload_page(p) for p in pages] if device else pages
+    op = HashAggregationOperator(types, keys, aggs, type_params=[0, 0, 0, 40], expected_groups=max(groups, 1))
+    got = [r for p in to_pages(op, inputs) for r in p.to_rows()]
+    ref = oracle.HashAggregation(types, keys, aggs)
+    for p in pages:
+        ref.add_page(p)
+    assert_same(got, ref.build_result().to_rows(), nkeys=len(keys))
+
+
+def test_min_max_long_varchar_empty_and_all_null(gpu, oracle):
+    types, aggs = [abi.BIGINT, abi.VARCHAR], [(abi.AGG_MIN, 1, abi.VARCHAR), (abi.AGG_MAX, 1, abi.VARCHAR), (abi.AGG_COUNT_STAR, -1, None)]
+    # no input at all: one row of NULLs for the ungrouped aggregation, no row for the grouped one
+    assert [r for p in to_pages(HashAggregationOperator(types, [], aggs), []) for r in p.to_rows()] == [(None, None, 0)]
+    assert [r for p in to_pages(HashAggregationOperator(types, [0], aggs), []) for r in p.to_rows()] == []
+    # a group whose strings are all NULL, next to one holding the empty string
+    page = Page([Block.bigint([1, 1, 2, 2]), Block.varchar([None, None, b"", b"a much longer string than seven bytes"])], 4)
+    got, expected = run_both(oracle, types, [0], aggs, [page])
+    assert_same(got, expected)
+    assert sorted(got) == [(1, None, None, 2), (2, b"", b"a much longer string than seven bytes", 2)]
+
+
+def test_min_max_long_varchar_partial_final(gpu, oracle):
+    """PARTIAL emits [count, the string itself]; FINAL takes those state pages -- from several PARTIAL operators with dictionaries of
+    their own -- and ranks the state strings in its own dictionary."""
+    rng = np.random.default_rng(8)
+    n = 40000
+    pages = [Page([Block.bigint(rng.integers(0, 500, n)), Block.varchar(long_strings(rng, n, 3000))], n) for _ in range(3)]
+    types, aggs = [abi.BIGINT, abi.VARCHAR], [(abi.AGG_MIN, 1, abi.VARCHAR), (abi.AGG_MAX, 1, abi.VARCHAR)]
+    single, expected = run_both(oracle, types, [0], aggs, pages)
+    assert_same(single, expected)
+    ptypes, faggs = partial_layout([abi.BIGINT], aggs)
+    assert ptypes == [abi.BIGINT, abi.BIGINT, abi.VARCHAR, abi.BIGINT, abi.VARCHAR]
+    partial_pages = []
+    for p in pages:
+        out = to_pages(HashAggregationOperator(types, [0], aggs, step=abi.STEP_PARTIAL), [p])
+        ref = oracle.HashAggregation(types, [0], aggs, step=abi.STEP_PARTIAL)
+        ref.add_page(p)
+        assert sorted(out[0].to_rows(), key=lambda r: r[0]) == sorted(ref.build_result().to_rows(), key=lambda r: r[0])
+        partial_pages += out
+    final = [r for p in to_pages(HashAggregationOperator(ptypes, [0], faggs, step=abi.STEP_FINAL), partial_pages) for r in p.to_rows()]
+    assert_same(final, expected)
+
+
+@pytest.mark.parametrize("groups", [0, 200])
+def test_min_max_long_varchar_page_shapes(gpu, oracle, groups):
+    """The forms a page takes -- VariableWidthBlock without and with NULLs (the second changes the channel's layout: a new generation of
+    the operator's state, combined at the end through the strings themselves), DictionaryBlock and RLE over strings, small device pages,
+    device-resident output -- behind a filter and projections on other channels (the fused ScanFilterAndProject -> aggregation)."""
+    from presto_amd.operators import upload_page
+    rng = np.random.default_rng(groups + 31)
+
+    def strings(n, with_null):
+        v = long_strings(rng, n, 900)
+        return v if with_null else [x if x is not None else b"never null here" for x in v]
+    pages = []
+    for k, n in enumerate((30000, 30000, 2000, 800, 25000)):
+        key, q = rng.integers(0, max(groups, 1), n), rng.integers(0, 50, n)
+        if k == 2:
+            entries = strings(300, True)
+            col = Block.dictionary_block(Block.varchar(entries), rng.integers(0, len(entries), n).astype(np.int32))
+        elif k == 3:
+            col = Block.rle(Block.varchar([b"the one string of this run-length page"]), n)
+        else:
+            col = Block.varchar(strings(n, k >= 1))
+        pages.append(Page([Block.bigint(key), col, Block.bigint(q)], n))
+    types = [abi.BIGINT, abi.VARCHAR, abi.BIGINT]
+    q = field(2, abi.BIGINT)
+    filt = q < constant(40, abi.BIGINT)
+    proj = [field(0, abi.BIGINT), field(1, abi.VARCHAR), q + 1]
+    aggs = [(abi.AGG_MIN, 1, abi.VARCHAR), (abi.AGG_MAX, 1, abi.VARCHAR), (abi.AGG_COUNT, 1, abi.VARCHAR), (abi.AGG_SUM, 2, abi.BIGINT)]
+    keys = [0] if groups else []
+    ref = oracle.HashAggregation(types, keys, aggs)
+    for p in pages:
+        ref.add_page(oracle.filter_project(p, filt, proj))
+    expected = ref.build_result().to_rows()
+    inputs = [pages[0], pages[1], pages[2], pages[3]] + [upload_page(pages[4].get_region(i, min(5000, 25000 - i))) for i in range(0, 25000, 5000)]
+    for mem in (abi.MEM_HOST, abi.MEM_DEVICE):
+        op = FusedAggregationOperator(types, filt, proj, keys, aggs, output_mem=mem)
+        got = [r for p in to_pages(op, inputs) for r in (download_page(p) if mem == abi.MEM_DEVICE else p).to_rows()]
+        assert_same(got, expected, nkeys=len(keys))
+
+
+def test_min_max_long_varchar_partial_flushes(gpu, oracle):
+    """Step.PARTIAL under maxPartialMemory: the operator flushes its groups whenever they pass the budget -- each flush hands the strings
+    out and starts over; the FINAL step over all flushed pages gives the SINGLE result."""
+    rng = np.random.default_rng(12)
+    n = 30000
+    pages = [Page([Block.bigint(rng.integers(0, 3000, n)), Block.varchar(long_strings(rng, n, 2000))], n) for _ in range(5)]
+    types, aggs = [abi.BIGINT, abi.VARCHAR], [(abi.AGG_MIN, 1, abi.VARCHAR), (abi.AGG_MAX, 1, abi.VARCHAR)]
+    ref = oracle.HashAggregation(types, [0], aggs)
+    for p in pages:
+        ref.add_page(p)
+    expected = ref.build_result().to_rows()
+    ptypes, faggs = partial_layout([abi.BIGINT], aggs)
+    partial = HashAggregationOperator(types, [0], aggs, step=abi.STEP_PARTIAL, max_partial_memory=64 << 10)
+    flushed = to_pages(partial, pages)
+    assert len(flushed) >= 3
+    final = [r for p in to_pages(HashAggregationOperator(ptypes, [0], faggs, step=abi.STEP_FINAL), flushed) for r in p.to_rows()]
+    assert_same(final, expected)
+
+
 def test_min_max_varchar_outside_the_device_subset(gpu):
     from presto_amd._lib import PrestoAmdError
-    types, aggs = [abi.BIGINT, abi.VARCHAR], [(abi.AGG_MAX, 1, abi.VARCHAR)]
-    for params in (None, [0, 0], [0, 8]):     # no declared length, or more than 7 bytes: the Java operator keeps the plan node
-        with pytest.raises(PrestoAmdError) as e:
-            HashAggregationOperator(types, [0], aggs, type_params=params)
-        assert e.value.status == abi.ERR_NOT_SUPPORTED
-    # a string longer than the declared length fails the query (as a VARCHAR(n) cast would have upstream)
-    op = HashAggregationOperator(types, [0], aggs, type_params=[0, 7])
+    types = [abi.BIGINT, abi.VARCHAR]
+    # the long string is also the group key, or an expression reads it: the strings themselves would be needed next to their ranks
+    with pytest.raises(PrestoAmdError) as e:
+        HashAggregationOperator([abi.VARCHAR, abi.BIGINT], [0], [(abi.AGG_MAX, 0, abi.VARCHAR)], type_params=[20, 0])
+    assert e.value.status == abi.ERR_NOT_SUPPORTED
+    # a string longer than the declared length of a short channel fails the query (as a VARCHAR(n) cast would have upstream)
+    op = HashAggregationOperator(types, [0], [(abi.AGG_MAX, 1, abi.VARCHAR)], type_params=[0, 7])
     page = Page([Block.bigint([1, 1]), Block.varchar([b"short", b"12345678"])], 2)
     with pytest.raises(PrestoAmdError):
         to_pages(op, [page])

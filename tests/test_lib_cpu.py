@@ -142,9 +142,12 @@ def test_unsupported_shapes_report_not_supported():
     # DOUBLE compared with BIGINT needs the planner's explicit CAST
     fp, keep = _filter_project_desc([abi.DOUBLE, abi.BIGINT], field(0, abi.DOUBLE) > field(1, abi.BIGINT), [], abi.MEM_HOST, None)
     assert lib().pa_codegen_compile_filter_project(C.byref(fp)) == abi.ERR_NOT_SUPPORTED
-    # min / max over VARCHAR: only channels declared VARCHAR(n), n <= 7 (an order-preserving 64-bit image exists)
-    d, keep = fused_aggregation_desc([abi.VARCHAR], None, [field(0, abi.VARCHAR)], [], [(abi.AGG_MAX, 0, abi.VARCHAR)])
+    # min / max over VARCHAR: channels declared VARCHAR(n), n <= 7, through an order-preserving 64-bit image, any other channel through
+    # its strings' ranks -- unless something else (here: the grouping) needs the strings themselves
+    d, keep = fused_aggregation_desc([abi.VARCHAR], None, [field(0, abi.VARCHAR)], [0], [(abi.AGG_MAX, 0, abi.VARCHAR)], type_params=[20])
     assert lib().pa_codegen_compile_fused(C.byref(d), -1) == abi.ERR_NOT_SUPPORTED
+    d, keep = fused_aggregation_desc([abi.VARCHAR], None, [field(0, abi.VARCHAR)], [], [(abi.AGG_MAX, 0, abi.VARCHAR)])
+    assert lib().pa_codegen_compile_fused(C.byref(d), -1) > 0
     d, keep = fused_aggregation_desc([abi.VARCHAR], None, [field(0, abi.VARCHAR)], [], [(abi.AGG_MAX, 0, abi.VARCHAR)], type_params=[7])
     assert lib().pa_codegen_compile_fused(C.byref(d), -1) > 0
     d, keep = fused_aggregation_desc([abi.DOUBLE], None, [field(0, abi.DOUBLE)], [], [(abi.AGG_MAX, 0, abi.DOUBLE)])
