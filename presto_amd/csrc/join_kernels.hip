@@ -537,18 +537,84 @@ __global__ __launch_bounds__(256) void k_join_key_bitmap(JoinCol build_key, i32 
 
 // ---- the bitmap of a build side whose rows do NOT arrive in key order (behind an exchange, behind another join) ----
 // One atomic per key at a random word of the bitmap is what the kernel above then costs (15 M keys: 0.56 ms, the rank -> row
-// scatter as much again).  Instead: is the column out of order at all (k_join_key_disorder), then the (key, row) pairs are
+// scatter as much again).  Instead: is the column out of order at all (k_join_key_stats), then the (key, row) pairs are
 // regrouped by key RANGE -- partition = (key - min) >> shift, at most 4096 of them, one LDS-staged multisplit --, a workgroup
 // ORs the bits of its partitions together in LDS and writes the words out with plain stores, and the rank -> row scatter walks
 // the regrouped pairs: its stores stay inside one partition's slice of the array at a time.
-__global__ __launch_bounds__(256) void k_join_key_disorder(JoinCol key, i32 n, i32* __restrict__ flag)
+// One pass over the build keys for everything the build decides on first: min and max of the non-NULL keys, whether there is one at
+// all, and whether some key is smaller than the key of the row before it.  out[0] = max over the keys of ~image, out[1] = max of image
+// (image = the key with its sign bit flipped: unsigned order = signed order), out[2] = 1 when some key is not NULL, out[3] = 1 when some
+// pair of neighbouring non-NULL keys descends (0 is the identity of all four).
+constexpr int kKeyStatsBlocks = 2048;
+__global__ __launch_bounds__(256) void k_join_key_stats(JoinCol key, i32 n, u64* __restrict__ partials)
 {
-    bool off = false;
-    for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i + 1 < n; i += (i64)gridDim.x * 256) {
-        if (jcol_is_null(key, (i32)i) || jcol_is_null(key, (i32)i + 1)) continue;
-        off = off || (i64)join_key_bits(key, (i32)i) > (i64)join_key_bits(key, (i32)i + 1);
+    __shared__ u64 s_lo[4], s_hi[4];
+    __shared__ int s_flags[4];
+    u64 lo = 0ULL, hi = 0ULL;   // max of ~image / of image
+    bool any = false, off = false;
+    for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < n; i += (i64)gridDim.x * 256) {
+        if (jcol_is_null(key, (i32)i)) continue;
+        const i64 v = (i64)join_key_bits(key, (i32)i);
+        const u64 img = (u64)v ^ 0x8000000000000000ULL;
+        lo = any ? (~img > lo ? ~img : lo) : ~img;
+        hi = any ? (img > hi ? img : hi) : img;
+        any = true;
+        if (i + 1 < n && !jcol_is_null(key, (i32)i + 1)) off = off || v > (i64)join_key_bits(key, (i32)i + 1);
     }
-    if (__ballot(off) != 0ULL && (threadIdx.x & 63) == 0) *flag = 1;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const u64 l2 = (u64)__shfl_xor((unsigned long long)lo, d, 64), h2 = (u64)__shfl_xor((unsigned long long)hi, d, 64);
+        lo = l2 > lo ? l2 : lo;   // (a lane without keys holds 0 in both: the identity of max, and "any" travels on its own)
+        hi = h2 > hi ? h2 : hi;
+    }
+    const int flags = (__ballot(any) != 0ULL ? 1 : 0) | (__ballot(off) != 0ULL ? 2 : 0);
+    if ((threadIdx.x & 63) == 0) {
+        s_lo[threadIdx.x >> 6] = lo;
+        s_hi[threadIdx.x >> 6] = hi;
+        s_flags[threadIdx.x >> 6] = flags;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int f = 0;
+        for (int w = 0; w < 4; w++) {
+            lo = s_lo[w] > lo ? s_lo[w] : lo;
+            hi = s_hi[w] > hi ? s_hi[w] : hi;
+            f |= s_flags[w];
+        }
+        // (one line of partials per workgroup, folded by k_join_key_stats_fold: 4096 atomic maxima on two words took 170 us)
+        u64* p = partials + (u64)blockIdx.x * 4ULL;
+        p[0] = lo;
+        p[1] = hi;
+        p[2] = (u64)(f & 1);
+        p[3] = (u64)((f >> 1) & 1);
+    }
+}
+__global__ __launch_bounds__(256) void k_join_key_stats_fold(const u64* __restrict__ partials, int blocks, u64* __restrict__ out)
+{
+    __shared__ u64 s_v[4][4];
+    u64 v[4] = {0ULL, 0ULL, 0ULL, 0ULL};
+    for (int b = threadIdx.x; b < blocks; b += 256) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const u64 x = partials[(u64)b * 4ULL + k];
+            v[k] = x > v[k] ? x : v[k];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            const u64 o = (u64)__shfl_xor((unsigned long long)v[k], d, 64);
+            v[k] = o > v[k] ? o : v[k];
+        }
+        if ((threadIdx.x & 63) == 0) s_v[threadIdx.x >> 6][k] = v[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        u64 r = 0ULL;
+        for (int w = 0; w < 4; w++) r = s_v[w][threadIdx.x] > r ? s_v[w][threadIdx.x] : r;
+        out[threadIdx.x] = r;
+    }
 }
 __global__ __launch_bounds__(256) void k_join_range_ids(JoinCol build_key, i32 n, i64 min_key, int shift, i32 partitions, i32* __restrict__ part,
                                                         u64* __restrict__ keybits, i32* __restrict__ rowpos)
@@ -586,15 +652,68 @@ __global__ __launch_bounds__(1024) void k_join_range_bitmap(const u64* __restric
     }
 }
 // ---- key rank index (join_kernels.hpp) ----
-__global__ __launch_bounds__(256) void k_join_rank_counts(const u64* __restrict__ bits, i64 nwords, i32* __restrict__ counts)
+// 16 consecutive words per thread, 1024 threads: a workgroup's tile is 16 384 words (2^20 key values).  First the tiles' bit counts,
+// scanned by the caller (573 entries for Q3's 600 M-wide orderkey range: one small launch); then every tile again -- its words ranked
+// inside the workgroup, plus the tile's offset -- writing {bits, bits below} once.  (Five launches before: counts per word, a three-launch
+// scan of them, and the zip -- the count array was written, scanned and read again: 109 us for 9.4 M words, now the two passes below.)
+constexpr int kRankTileThreads = 1024, kRankWordsPerThread = 16, kRankTileWords = kRankTileThreads * kRankWordsPerThread;
+__device__ __forceinline__ i32 rank_thread_words(const u64* __restrict__ bits, i64 nwords, i64 first, u64 (&w)[kRankWordsPerThread])
 {
-    for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < nwords; i += (i64)gridDim.x * 256) counts[i] = (i32)__popcll(bits[i]);
+    i32 c = 0;
+    if (first + kRankWordsPerThread <= nwords) {
+#pragma unroll
+        for (int i = 0; i < kRankWordsPerThread; i += 2) {
+            const ulonglong2 v = *reinterpret_cast<const ulonglong2*>(bits + first + i);   // (first is a multiple of 16: 16-byte aligned)
+            w[i] = v.x;
+            w[i + 1] = v.y;
+        }
+    }
+    else {
+#pragma unroll
+        for (int i = 0; i < kRankWordsPerThread; i++) w[i] = first + i < nwords ? bits[first + i] : 0ULL;
+    }
+#pragma unroll
+    for (int i = 0; i < kRankWordsPerThread; i++) c += (i32)__popcll(w[i]);
+    return c;
 }
-__global__ __launch_bounds__(256) void k_join_rank_zip(const u64* __restrict__ bits, const i32* __restrict__ below, i64 nwords, JoinRankWord* __restrict__ words)
+__global__ __launch_bounds__(kRankTileThreads) void k_join_rank_tile_sums(const u64* __restrict__ bits, i64 nwords, i32* __restrict__ sums)
 {
-    for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < nwords; i += (i64)gridDim.x * 256) {
-        const u64 b = bits[i];
-        ((uint4*)words)[i] = uint4{(u32)b, (u32)(b >> 32), (u32)below[i], 0u};
+    __shared__ i32 s_wave[kRankTileThreads / 64];
+    u64 w[kRankWordsPerThread];
+    i32 c = rank_thread_words(bits, nwords, (i64)blockIdx.x * kRankTileWords + (i64)threadIdx.x * kRankWordsPerThread, w);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) c += __shfl_xor(c, d, 64);
+    if ((threadIdx.x & 63) == 0) s_wave[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        i32 t = 0;
+        for (int i = 0; i < kRankTileThreads / 64; i++) t += s_wave[i];
+        sums[blockIdx.x] = t;
+    }
+}
+__global__ __launch_bounds__(kRankTileThreads) void k_join_rank_tile_zip(const u64* __restrict__ bits, const i32* __restrict__ tile_below, i64 nwords,
+                                                                          JoinRankWord* __restrict__ words)
+{
+    __shared__ i32 s_wave[kRankTileThreads / 64];
+    u64 w[kRankWordsPerThread];
+    const i64 first = (i64)blockIdx.x * kRankTileWords + (i64)threadIdx.x * kRankWordsPerThread;
+    const i32 mine = rank_thread_words(bits, nwords, first, w);
+    // exclusive scan of the threads' counts: inside the wave by shuffles, across the 16 waves through LDS
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    i32 incl = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const i32 o = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += o;
+    }
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    i32 below = tile_below[blockIdx.x] + incl - mine;
+    for (int i = 0; i < wave; i++) below += s_wave[i];
+#pragma unroll
+    for (int i = 0; i < kRankWordsPerThread; i++) {
+        if (first + i < nwords) ((uint4*)words)[first + i] = uint4{(u32)w[i], (u32)(w[i] >> 32), (u32)below, 0u};
+        below += (i32)__popcll(w[i]);
     }
 }
 __device__ __forceinline__ i32 join_rank_of(const JoinRankWord* __restrict__ words, const u64 d)
@@ -809,10 +928,16 @@ void launch_join_key_bitmap(const JoinCol& build_key, int32_t n, int64_t min_key
     hipLaunchKernelGGL(k_join_key_bitmap, grid_for(n), 256, 0, s, build_key, n, (i64)min_key, (u64)range, (u64*)bits);
     PA_HIP(hipGetLastError());
 }
-void launch_join_key_disorder(const JoinCol& key, int32_t n, int32_t* flag, hipStream_t s)
+size_t join_key_stats_temp_bytes() { return (size_t)kKeyStatsBlocks * 32; }
+void launch_join_key_stats(const JoinCol& key, int32_t n, uint64_t* out, void* temp, hipStream_t s)
 {
-    if (n <= 1) return;
-    hipLaunchKernelGGL(k_join_key_disorder, grid_for(n), 256, 0, s, key, n, flag);
+    if (n <= 0) {
+        PA_HIP(hipMemsetAsync(out, 0, 32, s));
+        return;
+    }
+    const int blocks = (int)std::min<int64_t>(((int64_t)n + 255) / 256, kKeyStatsBlocks);
+    hipLaunchKernelGGL(k_join_key_stats, blocks, 256, 0, s, key, n, (u64*)temp);
+    hipLaunchKernelGGL(k_join_key_stats_fold, 1, 256, 0, s, (const u64*)temp, blocks, (u64*)out);
     PA_HIP(hipGetLastError());
 }
 int join_range_shift(uint64_t range)
@@ -847,12 +972,14 @@ void launch_join_rank_rows_pairs(const uint64_t* keys, const int32_t* rowpos, in
     hipLaunchKernelGGL(k_join_rank_rows_pairs, grid_for(n), 256, 0, s, (const u64*)keys, rowpos, (i64)n, words, (i64)min_key, rows, distinct);
     PA_HIP(hipGetLastError());
 }
+int64_t join_rank_tiles(int64_t nwords) { return (nwords + kRankTileWords - 1) / kRankTileWords; }
 void launch_join_rank_words(const uint64_t* bits, int64_t nwords, JoinRankWord* words, int32_t* counts, void* temp, int32_t* total_out, hipStream_t s)
 {
     if (nwords <= 0) return;
-    hipLaunchKernelGGL(k_join_rank_counts, grid_for(nwords), 256, 0, s, (const u64*)bits, (i64)nwords, counts);
-    launch_exclusive_scan_i32(counts, counts, nwords, total_out, temp, s);
-    hipLaunchKernelGGL(k_join_rank_zip, grid_for(nwords), 256, 0, s, (const u64*)bits, (const i32*)counts, (i64)nwords, words);
+    const int64_t tiles = (nwords + kRankTileWords - 1) / kRankTileWords;
+    hipLaunchKernelGGL(k_join_rank_tile_sums, (int)tiles, kRankTileThreads, 0, s, (const u64*)bits, (i64)nwords, counts);
+    launch_exclusive_scan_i32(counts, counts, tiles, total_out, temp, s);
+    hipLaunchKernelGGL(k_join_rank_tile_zip, (int)tiles, kRankTileThreads, 0, s, (const u64*)bits, (const i32*)counts, (i64)nwords, words);
     PA_HIP(hipGetLastError());
 }
 void launch_join_rank_rows(const JoinCol& build_key, int32_t n, const JoinRankWord* words, int64_t min_key, int32_t* rows, int32_t* unordered, hipStream_t s,

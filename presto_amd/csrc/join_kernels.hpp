@@ -84,7 +84,8 @@ struct JoinRankIndex {
     uint64_t range;
 };
 // words[i] = {bits[i], number of set bits in bits[0 .. i)}; *total_out (device) = number of set bits = distinct build keys.
-// counts: nwords int32 of scratch; temp: scan_temp_bytes(nwords)
+// counts: join_rank_tiles(nwords) int32 of scratch; temp: scan_temp_bytes(join_rank_tiles(nwords))
+int64_t join_rank_tiles(int64_t nwords);
 void launch_join_rank_words(const uint64_t* bits, int64_t nwords, JoinRankWord* words, int32_t* counts, void* temp, int32_t* total_out, hipStream_t s);
 // rows[rank(key of build row i)] = i for all rows (no NULL keys); *unordered (device, zeroed by the caller) = 1 when some rank != i
 // (distinct: device word holding the number of distinct build keys, or null -- when it is not n the index cannot hold and the pass does nothing)
@@ -96,7 +97,25 @@ void launch_join_probe_count_keyed(const JoinCol& probe_key, const int64_t* prob
                                    uint32_t wrap, const int32_t* links, const JoinKeyBitmap& bitmap, const JoinRankIndex& rank, int32_t* head, int32_t* counts,
                                    int flags, hipStream_t s, int64_t* total = nullptr, bool unique_keys = false);   // total: 16 counters (zeroed by the caller) whose sum is the page's output rows
 // build rows out of key order: the bitmap and the rank -> row array over (key, row) pairs regrouped by key range (join_kernels.hip)
-void launch_join_key_disorder(const JoinCol& key, int32_t n, int32_t* flag, hipStream_t s);
+// min / max / presence / disorder of the build keys in one pass.  out: 4 x u64, see join_key_stats_decode; temp: join_key_stats_temp_bytes()
+size_t join_key_stats_temp_bytes();
+void launch_join_key_stats(const JoinCol& key, int32_t n, uint64_t* out, void* temp, hipStream_t s);
+struct JoinKeyStats {
+    int64_t min_key = 0, max_key = 0;
+    bool any = false;        // some key is not NULL
+    bool descending = false; // some key is smaller than the key of the row before it
+};
+inline JoinKeyStats join_key_stats_decode(const uint64_t (&h)[4])
+{
+    JoinKeyStats st;
+    st.any = h[2] != 0;
+    st.descending = h[3] != 0;
+    if (st.any) {
+        st.min_key = (int64_t)(~h[0] ^ 0x8000000000000000ULL);
+        st.max_key = (int64_t)(h[1] ^ 0x8000000000000000ULL);
+    }
+    return st;
+}
 int join_range_shift(uint64_t range);   // log2 of the key values per partition (16..19), -1: the range is too wide
 void launch_join_range_ids(const JoinCol& build_key, int32_t n, int64_t min_key, int shift, int32_t partitions, int32_t* part, uint64_t* keybits,
                            int32_t* rowpos, hipStream_t s);

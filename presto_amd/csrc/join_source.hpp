@@ -4,6 +4,9 @@
 //  PagesHash.java:54-126 for what the table holds)
 #pragma once
 
+#include <algorithm>
+#include <mutex>
+
 #include <atomic>
 #include <memory>
 #include <vector>
@@ -43,7 +46,19 @@ struct LookupSourceImpl {
     bool key_range_valid = false;  // keyed join with at least one non-NULL build key: [key_min, key_max]
     int64_t key_min = 0, key_max = 0;
     DevBuf shared_bits;  // the bitmap of pa_lookup_source_shared_key_bitmap (union key range of all ranks)
-    DevBuf visited;  // OuterPositionTracker.visitedPositions: 1 B per build position, written by LOOKUP_OUTER / FULL_OUTER probes
+    // OuterPositionTracker.visitedPositions: 1 B per build position, written by LOOKUP_OUTER / FULL_OUTER probes and read by the
+    // LookupOuterOperator -- created (and cleared) when the first of them asks: an inner or probe-outer join never pays for it
+    DevBuf visited;
+    std::once_flag visited_once;
+    uint8_t* visited_positions(hipStream_t s)
+    {
+        std::call_once(visited_once, [&] {
+            const size_t bytes = (size_t)std::max(n, 1);
+            PA_HIP(hipMemsetAsync(visited.ensure(bytes), 0, bytes, s));
+            PA_HIP(hipStreamSynchronize(s));  // (probe operators on other streams may be the next to touch it)
+        });
+        return visited.as<uint8_t>();
+    }
     uint32_t mask = 0;
     // keyed joins: some key occurs on more than one build row (positionLinks chains exist).  Set before `built`.
     bool has_duplicates = true;

@@ -188,7 +188,6 @@ public:
             launch_join_tag_slots(ls_->key.as<int32_t>(), (int64_t)hash_size, ls_->raw_hash.as<int64_t>(),
                                   static_cast<uint64_t*>(ls_->tagged.ensure((size_t)slots * 8)), ls_->probe_mask, s);
         }
-        PA_HIP(hipMemsetAsync(ls_->visited.ensure((size_t)std::max(n, 1)), 0, (size_t)std::max(n, 1), s));
         timer.end(s);
         int32_t ctl[6] = {0, 0, 0, 0, 0, 0};  // [0] error word, [4] distinct build keys, [5] some build row not at its key's rank
         PA_HIP(hipMemcpyAsync(ctl, ctl_, sizeof ctl, hipMemcpyDeviceToHost, s));
@@ -252,8 +251,9 @@ public:
         const int64_t nwords = (int64_t)(ls_->bitmap.range >> 6) + 1;
         JoinRankWord* words = static_cast<JoinRankWord*>(ls_->rank_words.ensure((size_t)nwords * sizeof(JoinRankWord)));
         PA_HIP(hipMemsetAsync(ctl_ + 4, 0, 8, s));
-        launch_join_rank_words(ls_->bitmap.bits, nwords, words, static_cast<int32_t*>(rank_counts_.ensure((size_t)nwords * 4)),
-                               rank_temp_.ensure(scan_temp_bytes(nwords)), ctl_ + 4, s);
+        const int64_t tiles = join_rank_tiles(nwords);
+        launch_join_rank_words(ls_->bitmap.bits, nwords, words, static_cast<int32_t*>(rank_counts_.ensure((size_t)tiles * 4)),
+                               rank_temp_.ensure(scan_temp_bytes(tiles)), ctl_ + 4, s);
         // (rows of duplicate keys overwrite each other here: the index is dropped then)
         if (pairs_ == n) {  // the pairs regrouped by key range: the scatter stays inside one partition's slice at a time
             launch_join_rank_rows_pairs(pair_keys_.as<uint64_t>(), pair_rows_.as<int32_t>(), n, words, ls_->bitmap.min_key,
@@ -324,19 +324,19 @@ public:
     // the slot table -- one bit per existing key
     void build_key_bitmap(const JoinCol& key, int32_t n, hipStream_t s)
     {
-        DevBuf partials, running;
-        int64_t* run = static_cast<int64_t*>(running.ensure(64));
-        PA_HIP(hipMemsetAsync(run, 0, 64, s));
-        launch_df_collect(key.type, key.values, key.nulls, n, nullptr, static_cast<int64_t*>(partials.ensure(df_partials_bytes())), run, s);
-        launch_join_key_disorder(key, n, reinterpret_cast<int32_t*>(run + 3), s);   // (rides on the same read-back)
-        int64_t h[4];
-        PA_HIP(hipMemcpyAsync(h, run, 32, hipMemcpyDeviceToHost, s));
+        DevBuf running, partials;
+        uint64_t* run = static_cast<uint64_t*>(running.ensure(64));
+        launch_join_key_stats(key, n, run, partials.ensure(join_key_stats_temp_bytes()), s);
+        uint64_t raw[4];
+        PA_HIP(hipMemcpyAsync(raw, run, 32, hipMemcpyDeviceToHost, s));
         PA_HIP(hipStreamSynchronize(s));
-        if (!h[2]) return;  // every key NULL
-        keys_ascending_ = h[3] == 0;
+        const JoinKeyStats st = join_key_stats_decode(raw);
+        if (!st.any) return;  // every key NULL
+        keys_ascending_ = !st.descending;
         ls_->key_range_valid = true;
-        ls_->key_min = h[0];
-        ls_->key_max = h[1];
+        ls_->key_min = st.min_key;
+        ls_->key_max = st.max_key;
+        const int64_t h[4] = {st.min_key, st.max_key, 1, st.descending ? 1 : 0};
         const uint64_t range = (uint64_t)h[1] - (uint64_t)h[0];
         if (range >= 64ULL * (uint64_t)n || range >= (1ULL << 36)) return;
         uint64_t* bits = static_cast<uint64_t*>(ls_->key_bits.ensure((size_t)((range >> 6) + 1) * 8));
@@ -569,7 +569,7 @@ public:
         int32_t* probe_idx = static_cast<int32_t*>(probe_idx_.ensure((size_t)total * 4));
         int32_t* build_pos = static_cast<int32_t*>(build_pos_.ensure((size_t)total * 4));
         launch_join_probe_emit(head_.as<int32_t>() + lo, offsets, rows, total, ls_->links.as<int32_t>(), probe_idx, build_pos, probe_flags_,
-                               track_visited_ && !filter_ ? ls_->visited.as<uint8_t>() : nullptr, s);
+                               track_visited_ && !filter_ ? ls_->visited_positions(s) : nullptr, s);
         int32_t total_out = total;
         if (filter_) {
             // the pairs so far are the CANDIDATES: every position of every probe row's chain; the filter decides which are joined
@@ -810,7 +810,7 @@ public:
             launch_jf_outer(eligible, ne, cand_probe, cand_build, per_row, first, at, rows, op, ob, s);
         }
         // OuterPositionTracker: only joined build rows count as visited
-        if (track_visited_ && out_n > 0) launch_jf_mark_visited(filtered_build_.as<int32_t>(), out_n, ls_->visited.as<uint8_t>(), s);
+        if (track_visited_ && out_n > 0) launch_jf_mark_visited(filtered_build_.as<int32_t>(), out_n, ls_->visited_positions(s), s);
         return out_n;
     }
 
@@ -927,7 +927,7 @@ public:
         int32_t* part = static_cast<int32_t*>(part_.ensure((size_t)n * 4));
         int32_t* pos = static_cast<int32_t*>(pos_.ensure((size_t)n * 4));
         int64_t* counts = static_cast<int64_t*>(counts_.ensure(64));
-        launch_join_unvisited_flag(ls_->visited.as<uint8_t>(), n, part, s);
+        launch_join_unvisited_flag(ls_->visited_positions(s), n, part, s);
         launch_partition_positions(part, n, 2, pos, counts, part_temp_.ensure(partition_temp_bytes(n, 2)), s);
         int64_t h_counts[2];
         PA_HIP(hipMemcpyAsync(h_counts, counts, 16, hipMemcpyDeviceToHost, s));
