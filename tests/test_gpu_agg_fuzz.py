@@ -146,3 +146,67 @@ def test_random_page_sequences(gpu, oracle, seed):
                 assert gv == ev or abs(gv - ev) <= 1e-9 * max(abs(gv), abs(ev)), (kk, g[kk], er)
             else:
                 assert gv == ev, (kk, g[kk], er)
+
+
+@pytest.mark.parametrize("seed", list(range(int(os.environ.get("PA_FUZZ_SEEDS", "12")))))
+def test_random_min_max_over_strings(gpu, oracle, seed):
+    """min / max (masked and not) and count over VARCHAR channels of any length -- by rank in the channel's dictionary --
+    next to sums, under random group keys (none, integers, short and interned strings), page counts and sizes, NULL shares and pools of
+    distinct strings; SINGLE, or PARTIAL per page -> FINAL."""
+    from presto_amd.exchange import partial_layout
+    rng = np.random.default_rng(9100 + seed)
+    kinds = ["bigint", "integer", "short", "text"]
+    nkeys = int(rng.integers(0, 3))
+    chosen = [kinds[i] for i in rng.choice(len(kinds), nkeys, replace=False)]
+    card = int([3, 40, 700, 20000][seed % 4])
+    pool_size = int(rng.choice([5, 300, 20000]))
+    stems = [b"", b"a", b"ab", b"order comment: ", b"\xf0\x9f\x98\x80", b"\x80\x81", b"zzzzzzzzzzzzzzzzzzzzzzzzzzzzzzzz"]
+    words = [stems[i % len(stems)] + bytes(rng.integers(0, 256, int(rng.integers(0, 30))).astype(np.uint8)) for i in range(pool_size)]
+    null_share = float(rng.choice([0.0, 0.05, 0.6]))
+    pages = []
+    types, params = None, None
+    for k in range(int(rng.integers(1, 5))):
+        n = int(rng.integers(1, 50000))
+        blocks, types, params = [], [], []
+        for kind in chosen:
+            t, b, p = key_column(rng, kind, n, card)
+            blocks.append(b)
+            types.append(t)
+            params.append(p)
+        # page k draws from a growing prefix of the pool: later pages bring strings the earlier ones did not hold
+        upto = max(1, pool_size * (k + 1) // 4)
+        strings = [None if z else words[i] for i, z in zip(rng.integers(0, min(upto, pool_size), n), rng.random(n) < (null_share if k != 1 else 0.0))]
+        blocks += [Block.varchar(strings), Block.double(rng.random(n) * 10, rng.random(n) < 0.1), Block.boolean(rng.random(n) < 0.6, rng.random(n) < 0.05)]
+        types += [abi.VARCHAR, abi.DOUBLE, abi.BOOLEAN]
+        params += [int(rng.choice([0, 64])), 0, 0]
+        pages.append(Page(blocks, n))
+    v = nkeys
+    pool = [(abi.AGG_MIN, v, abi.VARCHAR), (abi.AGG_MAX, v, abi.VARCHAR), (abi.AGG_COUNT, v, abi.VARCHAR), (abi.AGG_MAX, v, abi.VARCHAR, v + 2),
+            (abi.AGG_MIN, v, abi.VARCHAR, v + 2), (abi.AGG_SUM, v + 1, abi.DOUBLE), (abi.AGG_COUNT_STAR, -1, None)]
+    picks = sorted(set([int(rng.integers(0, 2))] + [int(i) for i in rng.choice(len(pool), int(rng.integers(1, 5)), replace=False)]))
+    aggs = [pool[i] for i in picks]
+    keys = list(range(nkeys))
+    params[v] = params[v] if nkeys else 0
+    ref = oracle.HashAggregation(types, keys, aggs)
+    for p in pages:
+        ref.add_page(p)
+    expected = ref.build_result().to_rows()
+    masked = any(len(a) > 3 for a in aggs)
+    if seed % 3 == 2 and not masked:
+        ptypes, faggs = partial_layout([types[i] for i in keys], aggs)
+        partials = []
+        for p in pages:
+            partials += to_pages(HashAggregationOperator(types, keys, aggs, step=abi.STEP_PARTIAL, type_params=params), [p])
+        pparams = [params[i] for i in keys] + [0] * (len(ptypes) - nkeys)
+        got = [r for p in to_pages(HashAggregationOperator(ptypes, keys, faggs, step=abi.STEP_FINAL, type_params=pparams), partials) for r in p.to_rows()]
+    else:
+        got = [r for p in to_pages(HashAggregationOperator(types, keys, aggs, type_params=params), pages) for r in p.to_rows()]
+    assert len(got) == len(expected)
+    g, e = {tuple(map(repr, r[:nkeys])): r for r in got}, {tuple(map(repr, r[:nkeys])): r for r in expected}
+    assert len(g) == len(got) and set(g) == set(e)
+    for k, er in e.items():
+        for gv, ev in zip(g[k][nkeys:], er[nkeys:]):
+            if isinstance(ev, float):
+                assert gv == ev or abs(gv - ev) <= 1e-9 * max(abs(gv), abs(ev)), (k, g[k], er)
+            else:
+                assert gv == ev, (k, g[k], er)
