@@ -283,6 +283,8 @@ int main(int argc, char** argv)
             pa_operator* h = nullptr;
             check(pa_fused_join_aggregation_create(&lineitem_desc, b2.handle(), &h));
             Operator agg(h);
+            // (the planner's note that the aggregation's only consumer is this TopN, as presto_amd/q3.py passes it)
+            agg.setOutputTopNHint(top.n, sort_channels, sort_orders);
             pa_operator* t = nullptr;
             check(pa_topn_create(&top, &t));
             Operator topn(t);
