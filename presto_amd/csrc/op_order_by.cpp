@@ -7,13 +7,15 @@
 // (topn_kernels.hip: integers, DATE, BOOLEAN, DOUBLE in Double.compare order; a VARCHAR as its 8-byte chunks, zero padded,
 // with the length as the least significant key -- Slice.compareTo: unsigned bytes, a proper prefix sorts first) plus a
 // one-bit NULL digit above them (SortOrder: NULLS FIRST / LAST, independent of ASC / DESC); channels are processed from the
-// last sort channel to the first, each image in eight 8-bit passes of the stable partition the exchange already uses
-// (digit -> partition id -> positions grouped by digit in arrival order).  Fully tied rows keep arrival order.
+// last sort channel to the first, each image by one stable sort of (image, row id) pairs over the bits in which the images
+// differ (sort_kernels.hip), the NULL digit by the stable partition the exchange already uses.  Fully tied rows keep arrival
+// order.  A first sort channel of integers without NULL rows that is also an output channel is written from the sorted images.
 #include <algorithm>
 #include <cstring>
 
 #include "operator.hpp"
 #include "scan_kernels.hpp"
+#include "sort_kernels.hpp"
 #include "topn_kernels.hpp"
 
 namespace pa {
@@ -130,34 +132,51 @@ public:
         void* temp = part_temp_.ensure(partition_temp_bytes(n, 256));
         launch_iota_i32(perm, n, s);
         timer.begin(s);
+        bool identity = true;  // perm is still 0, 1, 2, ...: the images are in the current order as they are
         auto pass = [&](int partitions) {
             // one stable radix pass: rows grouped by digit, arrival order kept inside a digit; perm' = perm o pos
             launch_partition_positions(digits, n, partitions, pos, counts, temp, s);
             launch_gather_flat(perm, 4, pos, n, next, s);
             std::swap(perm, next);
+            identity = false;
         };
-        // Stable LSD radix sort of (image, row id) PAIRS: the images are brought into the current order once (one gather), then
-        // every 8-bit pass physically regroups the pairs (launch_radix_pass_stable: LDS-staged, coalesced both ways).  Bytes in
-        // which all images agree are skipped (OR / AND of the images: keys below 2^40 need five passes, not eight).  The first
-        // version sorted the permutation alone and fetched every pass's digits through it -- a random 8-byte read per row
-        // and pass: 2^24 rows by a BIGINT key took 6.5 ms.
+        // Stable sort of (image, row id) PAIRS: the images are brought into the current order once (one gather), then the pairs are sorted
+        // by the bits in which the images differ at all (OR / AND of the images: keys below 2^40 are sorted by 40 bits, not 64) --
+        // launch_sort_pairs, sort_kernels.hip.  The first version sorted the permutation alone and fetched every pass's digits through
+        // it (a random 8-byte read per row and pass: 2^24 rows by a BIGINT key 6.5 ms), the second regrouped the pairs in eight LDS-staged
+        // 8-bit passes of its own (count, scan, scatter: 2.3 ms).
         uint64_t* kp[2] = {static_cast<uint64_t*>(pair_keys_[0].ensure((size_t)n * 8)), static_cast<uint64_t*>(pair_keys_[1].ensure((size_t)n * 8))};
-        void* radix_temp = radix_temp_.ensure(radix_pass_temp_bytes(n));
-        uint64_t* or_and = static_cast<uint64_t*>(or_and_.ensure(64));
+        const size_t sort_temp_bytes = sort_pairs_temp_bytes(n);
+        void* sort_temp = radix_temp_.ensure(sort_temp_bytes);
+        uint64_t* or_and = static_cast<uint64_t*>(or_and_.ensure(key_or_and_bytes()));
+        std::vector<uint64_t> h_or_and(key_or_and_bytes() / 8);
+        const uint64_t* sorted_images = nullptr;  // the images of the channel sorted by last, in their sorted order (valid until perm changes again)
         auto sort_by_image = [&]() {
-            launch_gather_flat(keys, 8, perm, n, kp[0], s);
-            launch_key_or_and(kp[0], n, or_and, s);
-            uint64_t h[2];
-            PA_HIP(hipMemcpyAsync(h, or_and, 16, hipMemcpyDeviceToHost, s));
-            PA_HIP(hipStreamSynchronize(s));
-            const uint64_t varying = h[0] ^ h[1];
-            int cur = 0;
-            for (int shift = 0; shift < 64; shift += 8) {
-                if (((varying >> shift) & 255ULL) == 0ULL) continue;
-                launch_radix_pass_stable(kp[cur], perm, n, shift, kp[cur ^ 1], next, radix_temp, s);
-                cur ^= 1;
-                std::swap(perm, next);
+            const uint64_t* in = keys;
+            if (!identity) {
+                launch_gather_flat(keys, 8, perm, n, kp[0], s);
+                in = kp[0];
             }
+            const int blocks = launch_key_or_and(in, n, or_and, s);
+            PA_HIP(hipMemcpyAsync(h_or_and.data(), or_and, (size_t)blocks * 16, hipMemcpyDeviceToHost, s));
+            PA_HIP(hipStreamSynchronize(s));
+            uint64_t h[2] = {0ULL, ~0ULL};
+            for (int b = 0; b < blocks; b++) {
+                h[0] |= h_or_and[2 * (size_t)b];
+                h[1] &= h_or_and[2 * (size_t)b + 1];
+            }
+            const uint64_t varying = h[0] ^ h[1];
+            sorted_images = nullptr;
+            if (varying == 0ULL) return;  // every image the same: the order stays
+            int begin_bit = __builtin_ctzll(varying);
+            const int end_bit = 64 - __builtin_clzll(varying);
+            // (rocPRIM 4.0's merge-sort path for small inputs builds its mask of the bit range with 1 << end_bit: a range that ends at
+            // bit 64 without starting at bit 0 compares nothing -- such ranges are widened to the whole key)
+            if (end_bit == 64) begin_bit = 0;
+            launch_sort_pairs(in, perm, kp[1], next, n, begin_bit, end_bit, sort_temp, sort_temp_bytes, s);
+            std::swap(perm, next);
+            identity = false;
+            sorted_images = kp[1];
         };
         for (int i = (int)sort_channels_.size() - 1; i >= 0; i--) {
             const Accumulated& a = cols_[(size_t)sort_channels_[i]];
@@ -182,9 +201,17 @@ public:
             if (nulls) {
                 launch_sort_null_digits(nulls, perm, n, nulls_first ? 1 : 0, digits, s);
                 pass(2);
+                sorted_images = nullptr;
             }
         }
         timer.end(s);
+        // the first sort channel as an output channel: its sorted images ARE the column (integers without NULL rows), no gather
+        const int first_channel = sort_channels_[0];
+        const bool first_descending = sort_orders_[0] >= 2;
+        {
+            const Accumulated& f = cols_[(size_t)first_channel];
+            if (f.varwidth || f.has_nulls || !(f.type == PA_BIGINT || f.type == PA_INTEGER || f.type == PA_DATE)) sorted_images = nullptr;
+        }
         // output channels in sorted order (PagesIndex.appendTo)
         const std::vector<int>& outs = output_channels_;
         out_cols_.clear();
@@ -206,6 +233,9 @@ public:
                 PA_HIP(hipStreamSynchronize(s));
                 launch_varwidth_copy(perm, n, a.offsets.as<int32_t>(), a.values.as<uint8_t>(), nulls, lens,
                                      static_cast<uint8_t*>(oc.values.ensure((size_t)(h_total > 0 ? h_total : 1))), total, s);
+            }
+            else if (sorted_images != nullptr && outs[j] == first_channel) {
+                launch_topn_values_of_keys(a.type, sorted_images, n, first_descending, oc.values.ensure((size_t)n * type_width(a.type)), s);
             }
             else {
                 const int w = type_width(a.type);

@@ -59,7 +59,9 @@ size_t radix_pass_temp_bytes(int64_t n);
 void launch_radix_pass_stable(const uint64_t* keys_in, const int32_t* payload_in, int64_t n, int shift, uint64_t* keys_out, int32_t* payload_out,
                               void* temp, hipStream_t s);
 // out[0] = OR of all keys, out[1] = AND of all keys (device memory, 16 bytes): a byte in which they agree is constant
-void launch_key_or_and(const uint64_t* keys, int64_t n, uint64_t* out, hipStream_t s);
+// per workgroup b: out[2 b] = OR, out[2 b + 1] = AND of its keys; returns the workgroups launched (out: key_or_and_bytes())
+size_t key_or_and_bytes();
+int launch_key_or_and(const uint64_t* keys, int64_t n, uint64_t* out, hipStream_t s);
 size_t partition_temp_bytes(int64_t n, int32_t partition_count);
 void launch_partition_positions(const int32_t* partition, int64_t n, int32_t partition_count, int32_t* out_positions,
                                 int64_t* out_counts_dev, void* temp, hipStream_t s);

@@ -1,0 +1,14 @@
+// sort_kernels.hpp -- launchers of sort_kernels.hip.
+#pragma once
+
+#include "common.hpp"
+
+namespace pa {
+
+// Stable sort of (key, row) pairs by bits [begin_bit, end_bit) of the keys, ascending.  temp: sort_pairs_temp_bytes(n) bytes; the inputs
+// are left as they are, the outputs must not overlap them.
+size_t sort_pairs_temp_bytes(int64_t n);
+void launch_sort_pairs(const uint64_t* keys_in, const int32_t* rows_in, uint64_t* keys_out, int32_t* rows_out, int64_t n, int begin_bit, int end_bit,
+                       void* temp, size_t temp_bytes, hipStream_t s);
+
+}  // namespace pa

@@ -408,6 +408,25 @@ void launch_topn_keys(int32_t type, const void* values, const int32_t* offsets, 
     PA_HIP(hipGetLastError());
 }
 
+// the values back from their keys (BIGINT / INTEGER / DATE channels without NULL rows: the image is the value with its sign bit flipped,
+// complemented for descending orders)
+__global__ __launch_bounds__(256) void k_topn_values_of_keys(i32 type, const u64* __restrict__ keys, i64 n, int descending, void* __restrict__ values)
+{
+    for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < n; i += (i64)gridDim.x * 256) {
+        const u64 img = descending ? ~keys[i] : keys[i];
+        const i64 v = (i64)(img ^ 0x8000000000000000ULL);
+        if (type == PA_BIGINT) ((i64*)values)[i] = v;
+        else ((i32*)values)[i] = (i32)v;
+    }
+}
+void launch_topn_values_of_keys(int32_t type, const uint64_t* keys, int64_t n, bool descending, void* values, hipStream_t s)
+{
+    if (n <= 0) return;
+    PA_REQUIRE(type == PA_BIGINT || type == PA_INTEGER || type == PA_DATE, PA_ERR_DEVICE, "internal: keys of this type do not give the values back");
+    hipLaunchKernelGGL(k_topn_values_of_keys, grid_of(n), 256, 0, s, type, (const u64*)keys, (i64)n, descending ? 1 : 0, values);
+    PA_HIP(hipGetLastError());
+}
+
 void launch_topn_sample_bound(int32_t type, const void* values, const int32_t* offsets, const uint8_t* nulls, int64_t n, int32_t sort_order,
                               int64_t sample_rows, int64_t rank, uint64_t* sample_keys, uint64_t* bound_out, hipStream_t s)
 {

@@ -134,7 +134,7 @@ if "next" in which:
         op = OrderByOperator([abi.DOUBLE, abi.BIGINT], [0, 1], [1], [abi.ASC_NULLS_LAST], output_mem=abi.MEM_DEVICE)
         op.addInput(spage); op.finish(); out = op.getOutput(); n = out.position_count; op.close(); return n
     dt = timeit(orderby, reps=3)
-    print("OrderBy %d rows by one BIGINT key, 16 B rows: %.3g rows/s (%.2f ms; stable 8-bit radix passes over (image, row id) pairs, constant bytes skipped)" % (srows, srows / dt, dt * 1e3))
+    print("OrderBy %d rows by one BIGINT key, 16 B rows: %.3g rows/s (%.2f ms; stable sort of (image, row id) pairs over the images' varying bits)" % (srows, srows / dt, dt * 1e3))
     small = torch.randint(0, 5000, (rows,), dtype=torch.int64, device="cuda", generator=g)
     dpage = Page([dev_block(abi.BIGINT, small), dev_block(abi.DOUBLE, v)], rows, abi.MEM_DEVICE)
     def dynf():

@@ -72,3 +72,49 @@ def test_order_by_device_pages_and_output(gpu, oracle):
     out = download_page(op.getOutput())
     assert out.to_rows() == oracle.order_by(pages, [1], [0], [abi.DESC_NULLS_LAST])
     assert op.isFinished()
+
+
+@pytest.mark.parametrize("n", [300, 5000, 150_000])
+@pytest.mark.parametrize("kind", ["bigint_wide", "bigint_narrow", "integer", "date"])
+def test_first_sort_channel_as_output_and_every_sort_size(gpu, oracle, n, kind):
+    """The pair sort's regimes (one workgroup, merge sort; the one-sweep radix passes in the test below) over key ranges whose varying bits
+    end at bit 64 (negative and positive keys), lie in the middle of the word, or start at bit 0; the first sort channel -- an integer channel
+    without NULL rows -- is also an output channel, which the operator then writes from the sorted keys instead of gathering it.  A second
+    sort channel breaks ties; the arrival index pins the permutation."""
+    rng = np.random.default_rng(n % 9973 + len(kind))
+    page = Page([sort_keys(rng, kind, n), Block.integer(rng.integers(0, 4, n), rng.random(n) < 0.1), Block.bigint(np.arange(n))], n)
+    types = [page.blocks[0].type, abi.INTEGER, abi.BIGINT]
+    for orders in ([abi.ASC_NULLS_LAST, abi.DESC_NULLS_FIRST], [abi.DESC_NULLS_FIRST, abi.ASC_NULLS_LAST]):
+        expected = oracle.order_by([page], [0, 2, 1], [0, 1], orders)
+        halves = [page.get_region(0, n // 3), page.get_region(n // 3, n - n // 3)]
+        got = rows_of(to_pages(OrderByOperator(types, [0, 2, 1], [0, 1], orders), halves))
+        assert got == expected
+
+
+def sort_keys(rng, kind, n):
+    if kind == "bigint_wide":
+        return Block.bigint(rng.integers(-2 ** 62, 2 ** 62, n))
+    if kind == "bigint_narrow":
+        return Block.bigint((rng.integers(0, 1 << 20, n).astype(np.int64) << 12) + (7 << 40))   # bits 12..31 vary
+    if kind == "integer":
+        return Block.integer(rng.integers(-1000, 1000, n))
+    return Block.date(rng.integers(8000, 8300, n))
+
+
+@pytest.mark.parametrize("kind", ["bigint_wide", "bigint_narrow", "integer"])
+def test_sorts_beyond_a_million_rows(gpu, kind):
+    """Above 2^20 rows the pair sort runs its one-sweep radix passes: checked against numpy's stable sort (the oracle's row-at-a-time
+    quicksort would take a minute here) -- keys in order, ties in arrival order, both directions, the key column written from the keys."""
+    n = 1_300_000
+    rng = np.random.default_rng(len(kind))
+    key = sort_keys(rng, kind, n)
+    page = Page([key, Block.bigint(np.arange(n))], n)
+    types = [key.type, abi.BIGINT]
+    values = np.asarray(key.values).astype(np.int64)
+    for order in (abi.ASC_NULLS_LAST, abi.DESC_NULLS_FIRST):
+        out = to_pages(OrderByOperator(types, [0, 1], [0], [order]), [page.get_region(0, 400_000), page.get_region(400_000, n - 400_000)])
+        got_keys = np.concatenate([np.asarray(p.blocks[0].values).astype(np.int64) for p in out])
+        got_rows = np.concatenate([np.asarray(p.blocks[1].values) for p in out])
+        perm = np.argsort(values if order == abi.ASC_NULLS_LAST else ~values, kind="stable")
+        assert np.array_equal(got_rows, perm)
+        assert np.array_equal(got_keys, values[perm])
