@@ -566,7 +566,14 @@ __global__ __launch_bounds__(256) void k_varchar_max_length(const i32* __restric
     i32 m = 0;
     for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < n; i += (i64)gridDim.x * 256) m = max(m, offsets[i + 1] - offsets[i]);
     for (int off = 32; off >= 1; off >>= 1) m = max(m, __shfl_xor(m, off, 64));
-    if ((threadIdx.x & 63) == 0 && m > 0) atomicMax(out, m);
+    // (one atomic per workgroup of at most 512: same-address atomics retire one after the other at the memory side)
+    __shared__ i32 s_m[4];
+    if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = max(max(s_m[0], s_m[1]), max(s_m[2], s_m[3]));
+        if (m > 0) atomicMax(out, m);
+    }
 }
 }  // namespace
 
@@ -599,7 +606,7 @@ int32_t varchar_max_length(const int32_t* offsets, int64_t n, void* temp_dev_8, 
 {
     int32_t* out = static_cast<int32_t*>(temp_dev_8);
     PA_HIP(hipMemsetAsync(out, 0, 4, s));
-    if (n > 0) hipLaunchKernelGGL(k_varchar_max_length, grid_of(n), 256, 0, s, offsets, (i64)n, out);
+    if (n > 0) hipLaunchKernelGGL(k_varchar_max_length, std::min(grid_of(n), 512), 256, 0, s, offsets, (i64)n, out);
     int32_t h = 0;
     PA_HIP(hipMemcpyAsync(&h, out, 4, hipMemcpyDeviceToHost, s));
     PA_HIP(hipStreamSynchronize(s));

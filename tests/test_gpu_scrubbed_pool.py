@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 SUITES = ["tests/test_gpu_fused.py", "tests/test_gpu_fused_join.py", "tests/test_gpu_join.py", "tests/test_gpu_partial_final.py",
-          "tests/test_gpu_small_pages.py"]
+          "tests/test_gpu_small_pages.py", "tests/test_gpu_varchar_keys.py"]
 
 
 def test_suites_on_a_scrubbed_pool(gpu):
