@@ -1002,35 +1002,52 @@ struct ProbeTable {
     const pa_u32x4* jrank;
     const i32* jrank_rows;
 };
+// tile_totals (may be null): the output rows of every tile of kJoinProbeTileRows probe rows -- with them the pairs are emitted tile by
+// tile (k_join_probe_emit_tiles: ranks inside the workgroup) and the exclusive scan runs over the tiles' totals, a thousandth of the rows
 __global__ __launch_bounds__(256) void k_join_probe_count_keyed4(JoinCol probe_key, i32 n_probe, ProbeTable t, i32* __restrict__ head, i32* __restrict__ counts,
-                                                                 int flags, unsigned long long* __restrict__ total)
+                                                                 int flags, unsigned long long* __restrict__ total, i32* __restrict__ tile_totals)
 {
+    __shared__ i64 wave_total[4];
+    __shared__ i32 wave_tile[4];
     i64 mine = 0;
     const i64 quads = ((i64)n_probe + 3) >> 2;
-    for (i64 q = (i64)blockIdx.x * 256 + threadIdx.x; q < quads; q += (i64)gridDim.x * 256) {
-        bool s[4];
-        u64 k[4];
-        i32 jb[4];
+    const i64 tiles = (quads + 255) >> 8;
+    for (i64 tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        const i64 q = tile * 256 + threadIdx.x;
+        i32 here = 0;
+        if (q < quads) {
+            bool s[4];
+            u64 k[4];
+            i32 jb[4];
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const i64 i = 4 * q + r;
-            s[r] = i < n_probe && !jcol_is_null(probe_key, (i32)i);  // JoinProbe.java:89-91
-            k[r] = s[r] ? join_key_bits(probe_key, (i32)i) : 0ULL;
+            for (int r = 0; r < 4; r++) {
+                const i64 i = 4 * q + r;
+                s[r] = i < n_probe && !jcol_is_null(probe_key, (i32)i);  // JoinProbe.java:89-91
+                k[r] = s[r] ? join_key_bits(probe_key, (i32)i) : 0ULL;
+            }
+            pa_join_probe4(t, s, k, jb);
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const i64 i = 4 * q + r;
+                if (i >= n_probe) continue;
+                const i32 h = s[r] ? jb[r] : -1;
+                const i32 c = (h != -1 || (flags & 1)) ? 1 : 0;
+                head[i] = h;
+                counts[i] = c;
+                here += c;
+            }
         }
-        pa_join_probe4(t, s, k, jb);
+        mine += here;
+        if (tile_totals) {
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const i64 i = 4 * q + r;
-            if (i >= n_probe) continue;
-            const i32 h = s[r] ? jb[r] : -1;
-            const i32 c = (h != -1 || (flags & 1)) ? 1 : 0;
-            head[i] = h;
-            counts[i] = c;
-            mine += c;
+            for (int d = 32; d >= 1; d >>= 1) here += __shfl_xor(here, d, 64);
+            if ((threadIdx.x & 63) == 0) wave_tile[threadIdx.x >> 6] = here;
+            __syncthreads();
+            if (threadIdx.x == 0) tile_totals[tile] = wave_tile[0] + wave_tile[1] + wave_tile[2] + wave_tile[3];
+            __syncthreads();
         }
     }
     if (total) {
-        __shared__ i64 wave_total[4];
         mine = pa_wave_sum_i64(mine);
         if ((threadIdx.x & 63) == 0) wave_total[threadIdx.x >> 6] = mine;
         __syncthreads();
@@ -1040,12 +1057,59 @@ __global__ __launch_bounds__(256) void k_join_probe_count_keyed4(JoinCol probe_k
         }
     }
 }
-
-void launch_join_probe_count_keyed(const JoinCol& probe_key, const int64_t* probe_hash, int32_t n_probe, const JoinKeySlot* slots, uint32_t mask,
-                                   uint32_t wrap, const int32_t* links, const JoinKeyBitmap& bitmap, const JoinRankIndex& rank, int32_t* head, int32_t* counts,
-                                   int flags, hipStream_t s, int64_t* total, bool unique_keys)
+// The pairs of a page whose probe rows emit at most one pair each (no build key on several rows), tile by tile: a row's place is its
+// tile's offset (the scanned tile totals) plus the pairs of the rows before it in the tile.  (Measured and dropped: the same for chains
+// of several build rows -- four consecutive probe rows per thread, each walking its chain: 1.4 M probe rows x 5 matches 0.19 -> 0.34 ms;
+// those pages keep one probe row per thread and the scan over the rows' counts.)
+__global__ __launch_bounds__(256) void k_join_probe_emit_tiles(const i32* __restrict__ head, const i32* __restrict__ tile_offsets, i32 n_probe, int probe_outer,
+                                                               i32* __restrict__ probe_idx, i32* __restrict__ build_pos, u8* __restrict__ visited)
 {
-    if (n_probe <= 0) return;
+    __shared__ i32 wave_sum[4];
+    const i64 quads = ((i64)n_probe + 3) >> 2;
+    const i64 tiles = (quads + 255) >> 8;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (i64 tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        const i64 q = tile * 256 + threadIdx.x;
+        i32 h[4] = {-1, -1, -1, -1};
+        bool out[4] = {false, false, false, false};
+        i32 here = 0;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const i64 i = 4 * q + r;
+            if (i < n_probe) {
+                h[r] = head[i];
+                out[r] = h[r] != -1 || (probe_outer & 1);
+                here += out[r] ? 1 : 0;
+            }
+        }
+        i32 incl = here;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const i32 o = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += o;
+        }
+        if (lane == 63) wave_sum[wave] = incl;
+        __syncthreads();
+        i32 o = tile_offsets[tile] + incl - here;
+        for (int w = 0; w < wave; w++) o += wave_sum[w];
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            if (!out[r]) continue;
+            probe_idx[o] = (i32)(4 * q + r);
+            build_pos[o] = h[r];   // (-1: LookupJoinPageBuilder.appendNullForBuild)
+            if (visited && h[r] >= 0) visited[h[r]] = 1;
+            o++;
+        }
+    }
+}
+
+int64_t join_probe_tiles(int32_t n_probe) { return ((((int64_t)n_probe + 3) >> 2) + 255) >> 8; }
+bool launch_join_probe_count_keyed(const JoinCol& probe_key, const int64_t* probe_hash, int32_t n_probe, const JoinKeySlot* slots, uint32_t mask,
+                                   uint32_t wrap, const int32_t* links, const JoinKeyBitmap& bitmap, const JoinRankIndex& rank, int32_t* head, int32_t* counts,
+                                   int flags, hipStream_t s, int64_t* total, bool unique_keys, int32_t* tile_totals)
+{
+    if (n_probe <= 0) return false;
     // (with a $hashvalue channel the home slot comes from the channel's value: the row-by-row kernel reads it)
     if (unique_keys && probe_hash == nullptr && (rank.words == nullptr || rank.min_key == bitmap.min_key || bitmap.bits == nullptr)) {
         ProbeTable t{};
@@ -1058,12 +1122,20 @@ void launch_join_probe_count_keyed(const JoinCol& probe_key, const int64_t* prob
         t.jrank = reinterpret_cast<const pa_u32x4*>(rank.words);
         t.jrank_rows = rank.rows;
         hipLaunchKernelGGL(k_join_probe_count_keyed4, grid_for(((int64_t)n_probe + 3) / 4), 256, 0, s, probe_key, n_probe, t, head, counts, flags,
-                           (unsigned long long*)total);
+                           (unsigned long long*)total, tile_totals);
         PA_HIP(hipGetLastError());
-        return;
+        return tile_totals != nullptr;
     }
     hipLaunchKernelGGL(k_join_probe_count_keyed, grid_for(n_probe), 256, 0, s, probe_key, (const i64*)probe_hash, n_probe, slots, mask, wrap, links, bitmap,
                        rank, head, counts, flags, (unsigned long long*)total);
+    PA_HIP(hipGetLastError());
+    return false;
+}
+void launch_join_probe_emit_tiles(const int32_t* head, const int32_t* tile_offsets, int32_t n_probe, int flags, int32_t* probe_idx, int32_t* build_pos,
+                                  uint8_t* visited, hipStream_t s)
+{
+    if (n_probe <= 0) return;
+    hipLaunchKernelGGL(k_join_probe_emit_tiles, grid_for(((int64_t)n_probe + 3) / 4), 256, 0, s, head, tile_offsets, n_probe, flags, probe_idx, build_pos, visited);
     PA_HIP(hipGetLastError());
 }
 

@@ -93,9 +93,15 @@ void launch_join_rank_rows(const JoinCol& build_key, int32_t n, const JoinRankWo
                            const int32_t* distinct = nullptr);
 // wrap = mask, or kJoinPartSlots - 1 for a table built in partitions (the probe sequence of a key then stays inside the
 // kJoinPartSlots-slot partition of its home slot)
-void launch_join_probe_count_keyed(const JoinCol& probe_key, const int64_t* probe_hash, int32_t n_probe, const JoinKeySlot* slots, uint32_t mask,
+// tile_totals (optional, join_probe_tiles(n_probe) entries): filled -- the function then returns true -- when the lookup source has no
+// key on several rows and the four-rows-per-step kernel runs: the pairs can then be emitted by launch_join_probe_emit_tiles after an
+// exclusive scan of the tile totals alone
+int64_t join_probe_tiles(int32_t n_probe);
+bool launch_join_probe_count_keyed(const JoinCol& probe_key, const int64_t* probe_hash, int32_t n_probe, const JoinKeySlot* slots, uint32_t mask,
                                    uint32_t wrap, const int32_t* links, const JoinKeyBitmap& bitmap, const JoinRankIndex& rank, int32_t* head, int32_t* counts,
-                                   int flags, hipStream_t s, int64_t* total = nullptr, bool unique_keys = false);   // total: 16 counters (zeroed by the caller) whose sum is the page's output rows
+                                   int flags, hipStream_t s, int64_t* total = nullptr, bool unique_keys = false, int32_t* tile_totals = nullptr);   // total: 16 counters (zeroed by the caller) whose sum is the page's output rows
+void launch_join_probe_emit_tiles(const int32_t* head, const int32_t* tile_offsets, int32_t n_probe, int flags, int32_t* probe_idx, int32_t* build_pos,
+                                  uint8_t* visited, hipStream_t s);
 // build rows out of key order: the bitmap and the rank -> row array over (key, row) pairs regrouped by key range (join_kernels.hip)
 // min / max / presence / disorder of the build keys in one pass.  out: 4 x u64, see join_key_stats_decode; temp: join_key_stats_temp_bytes()
 size_t join_key_stats_temp_bytes();
