@@ -1,4 +1,6 @@
 // exprgen.cpp -- see exprgen.hpp.
+#include <cstring>
+
 #include "exprgen.hpp"
 
 #include <cinttypes>
@@ -52,8 +54,10 @@ std::string OwnedExpr::fingerprint() const
         int32_t id = stack.back();
         stack.pop_back();
         const pa_expr_node& n = nodes[id];
+        uint64_t f64_bits;   // (the raw bits: a long-decimal constant keeps its high half there, and NaN payloads must not collapse)
+        memcpy(&f64_bits, &n.f64, 8);
         s << n.kind << ':' << n.op << ':' << n.type << ':' << n.channel << ':' << n.is_null << ':' << n.nargs << ':'
-          << n.i64 << ':' << double_literal(n.f64) << ':' << strings[id].size() << ':' << strings[id] << ';';
+          << n.i64 << ':' << f64_bits << ':' << strings[id].size() << ':' << strings[id] << ';';
         if (n.type == PA_DECIMAL || n.type == PA_LONG_DECIMAL) s << 'p' << n.type_param << ';';
         for (int32_t k = 0; k < n.nargs; k++) stack.push_back(args[n.first_arg + k]);
     }

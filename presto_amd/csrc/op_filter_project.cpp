@@ -18,6 +18,8 @@
 //                  writes them (and the ascending positions list) compacted
 // Both are HBM-bound: filter columns are read once, projection inputs once, outputs written once.
 #include <map>
+#include <memory>
+#include <mutex>
 #include <sstream>
 
 #include "exprgen.hpp"
@@ -492,7 +494,7 @@ public:
                 sig += cl.nullable ? 'N' : '_';
             }
         }
-        Compiled& ck = kernel_for(external ? 2 : 0, sig, layout);
+        const Compiled& ck = kernel_for(external ? 2 : 0, sig, layout);
         cur_ = &ck;
         a.n = n;
         a.vec = vec ? 1 : 0;
@@ -749,20 +751,68 @@ private:
         hipFunction_t count_fn = nullptr, scatter_fn = nullptr;
     };
 
-    // variant 0: the operator as described; 1: the filter alone (over a dictionary); 2: the projections under an external selection
-    Compiled& kernel_for(int variant, const std::string& sig, const std::vector<ChannelLayout>& layout)
+    // One code object per (plan, column-layout signature, variant, device), shared by every operator instance of the process: an operator
+    // lives for one query (OperatorFactory.createOperator) while the generated code of its plan node does not change -- generating and
+    // hashing the source again for every instance cost 80 us per pipeline of Q3 (as in op_fused.cpp).
+    static std::mutex& shared_mutex()
     {
-        const std::string key = std::to_string(variant) + sig;
+        static std::mutex* m = new std::mutex();
+        return *m;
+    }
+    static std::map<std::string, std::shared_ptr<const Compiled>>& shared_cache()
+    {
+        static auto* c = new std::map<std::string, std::shared_ptr<const Compiled>>();  // leaked: HIP may be gone at exit
+        return *c;
+    }
+    // everything of a spec the generated code depends on (generate_fp)
+    static std::string plan_fingerprint(const FpSpec& sp)
+    {
+        std::ostringstream f;
+        f << sp.n_in << '|';
+        for (int32_t t : sp.in_types) f << t << ',';
+        // (behind a probe stage "has a filter" may mean the probe alone: no expression then)
+        f << '|' << (sp.has_filter ? (sp.filter.root >= 0 ? sp.filter.fingerprint() : std::string("+")) : std::string("-")) << '|' << (sp.filter_external ? 'x' : 'i')
+          << '|' << sp.dyn_channel << '|';
+        for (const OwnedExpr& e : sp.proj) f << e.fingerprint() << '#';
+        f << '|';
+        for (bool u : sp.used_channel) f << (u ? '1' : '0');
+        if (sp.join) {
+            f << "|J" << sp.join->key.fingerprint() << ':';
+            for (size_t v = 0; v < sp.join->build_cols.size(); v++) f << sp.join->build_cols[v] << '/' << sp.join->build_types[v] << ',';
+        }
+        f << "|q" << kTileQuads;
+        return f.str();
+    }
+
+    // variant 0: the operator as described; 1: the filter alone (over a dictionary); 2: the projections under an external selection
+    const Compiled& kernel_for(int variant, const std::string& sig, const std::vector<ChannelLayout>& layout)
+    {
+        const FpSpec& sp = variant == 0 ? spec_ : (variant == 1 ? dict_spec_ : ext_spec_);
+        // (the dynamic filter's channel is set after the operator was made: it is part of the key)
+        const std::string key = std::to_string(variant) + sig + "|" + std::to_string(sp.dyn_channel);
         auto it = compiled_.find(key);
         if (it != compiled_.end()) return *it->second;
-        const FpSpec& sp = variant == 0 ? spec_ : (variant == 1 ? dict_spec_ : ext_spec_);
-        auto c = std::make_unique<Compiled>();
+        int dev = 0;
+        PA_HIP(hipGetDevice(&dev));
+        const std::string shared_key = std::to_string(dev) + "|" + key + "|" + plan_fingerprint(sp);
+        {
+            std::lock_guard<std::mutex> lock(shared_mutex());
+            auto hit = shared_cache().find(shared_key);
+            if (hit != shared_cache().end()) {
+                compiled_[key] = hit->second;
+                return *hit->second;
+            }
+        }
+        auto c = std::make_shared<Compiled>();
         c->info = generate_fp(sp, layout);
         if (sp.has_filter && !sp.filter_external) c->count_fn = jit_get(c->info.source, "pa_fp_count").fn;
         if (variant != 1) c->scatter_fn = jit_get(c->info.source, "pa_fp_scatter").fn;
-        Compiled& ref = *c;
-        compiled_[key] = std::move(c);
-        return ref;
+        {
+            std::lock_guard<std::mutex> lock(shared_mutex());
+            shared_cache()[shared_key] = c;
+        }
+        compiled_[key] = c;
+        return *c;
     }
 
     // column pointers, layout signature and alignment of the channels `sp` reads
@@ -810,7 +860,7 @@ private:
         FpArgs a;
         memset(&a, 0, sizeof a);
         bind_inputs(dict_spec_, d, &layout, &sig, &vec, &a);
-        Compiled& dk = kernel_for(1, sig, layout);
+        const Compiled& dk = kernel_for(1, sig, layout);
         const int64_t dtiles = (dn + kTileRows - 1) / kTileRows;
         a.n = dn;
         a.vec = vec ? 1 : 0;
@@ -848,8 +898,8 @@ private:
     Stream stream_;
     PageStager stager_, dict_stager_;
     DevBuf dict_sel4_, dict_tiles_, ids_;
-    std::map<std::string, std::unique_ptr<Compiled>> compiled_;
-    Compiled* cur_ = nullptr;
+    std::map<std::string, std::shared_ptr<const Compiled>> compiled_;
+    const Compiled* cur_ = nullptr;
     DevPage in_;
     bool in_device_ = false, finishing_ = false, pending_ = false, need_positions_ = false;
     DevBuf ctl_buf_, sel4_, tile_counts_, positions_, scan_temp_;
