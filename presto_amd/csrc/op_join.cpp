@@ -140,8 +140,10 @@ public:
             }
         }
         ls_->n = (int32_t)(n0 + m);
-        // staged host pages live in the stager's arena, which the next add_input overwrites
-        PA_HIP(hipStreamSynchronize(s));
+        // staged host pages live in the stager's arena, which the next add_input overwrites.  (A device page is its producer's again
+        // with that operator's next call: on the caller's stream these copies are ordered before it, a stream of this operator's own
+        // is drained by pa_op_add_input -- abi.cpp.)
+        if (page->mem != PA_MEM_DEVICE) PA_HIP(hipStreamSynchronize(s));
     }
 
     // finishInput -> buildLookupSource -> new PagesHash(...)
