@@ -543,15 +543,16 @@ __global__ __launch_bounds__(256) void k_join_key_bitmap(JoinCol build_key, i32 
 // the regrouped pairs: its stores stay inside one partition's slice of the array at a time.
 // One pass over the build keys for everything the build decides on first: min and max of the non-NULL keys, whether there is one at
 // all, and whether some key is smaller than the key of the row before it.  out[0] = max over the keys of ~image, out[1] = max of image
-// (image = the key with its sign bit flipped: unsigned order = signed order), out[2] = 1 when some key is not NULL, out[3] = 1 when some
-// pair of neighbouring non-NULL keys descends (0 is the identity of all four).
+// (image = the key with its sign bit flipped: unsigned order = signed order), out[2] = 1 when some key is not NULL, out[3] = the number of
+// pairs of neighbouring non-NULL keys that descend (0 is the identity of all four).
 constexpr int kKeyStatsBlocks = 2048;
 __global__ __launch_bounds__(256) void k_join_key_stats(JoinCol key, i32 n, u64* __restrict__ partials)
 {
-    __shared__ u64 s_lo[4], s_hi[4];
+    __shared__ u64 s_lo[4], s_hi[4], s_off[4];
     __shared__ int s_flags[4];
     u64 lo = 0ULL, hi = 0ULL;   // max of ~image / of image
-    bool any = false, off = false;
+    bool any = false;
+    u32 off = 0u;               // neighbouring pairs that descend
     for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < n; i += (i64)gridDim.x * 256) {
         if (jcol_is_null(key, (i32)i)) continue;
         const i64 v = (i64)join_key_bits(key, (i32)i);
@@ -559,7 +560,7 @@ __global__ __launch_bounds__(256) void k_join_key_stats(JoinCol key, i32 n, u64*
         lo = any ? (~img > lo ? ~img : lo) : ~img;
         hi = any ? (img > hi ? img : hi) : img;
         any = true;
-        if (i + 1 < n && !jcol_is_null(key, (i32)i + 1)) off = off || v > (i64)join_key_bits(key, (i32)i + 1);
+        if (i + 1 < n && !jcol_is_null(key, (i32)i + 1) && v > (i64)join_key_bits(key, (i32)i + 1)) off++;
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
@@ -567,10 +568,12 @@ __global__ __launch_bounds__(256) void k_join_key_stats(JoinCol key, i32 n, u64*
         lo = l2 > lo ? l2 : lo;   // (a lane without keys holds 0 in both: the identity of max, and "any" travels on its own)
         hi = h2 > hi ? h2 : hi;
     }
-    const int flags = (__ballot(any) != 0ULL ? 1 : 0) | (__ballot(off) != 0ULL ? 2 : 0);
+    const int flags = __ballot(any) != 0ULL ? 1 : 0;
+    const u64 offs = (u64)pa_wave_sum_i64((i64)off);
     if ((threadIdx.x & 63) == 0) {
         s_lo[threadIdx.x >> 6] = lo;
         s_hi[threadIdx.x >> 6] = hi;
+        s_off[threadIdx.x >> 6] = offs;
         s_flags[threadIdx.x >> 6] = flags;
     }
     __syncthreads();
@@ -586,7 +589,7 @@ __global__ __launch_bounds__(256) void k_join_key_stats(JoinCol key, i32 n, u64*
         p[0] = lo;
         p[1] = hi;
         p[2] = (u64)(f & 1);
-        p[3] = (u64)((f >> 1) & 1);
+        p[3] = s_off[0] + s_off[1] + s_off[2] + s_off[3];
     }
 }
 __global__ __launch_bounds__(256) void k_join_key_stats_fold(const u64* __restrict__ partials, int blocks, u64* __restrict__ out)
@@ -597,7 +600,7 @@ __global__ __launch_bounds__(256) void k_join_key_stats_fold(const u64* __restri
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const u64 x = partials[(u64)b * 4ULL + k];
-            v[k] = x > v[k] ? x : v[k];
+            v[k] = k == 3 ? v[k] + x : (x > v[k] ? x : v[k]);
         }
     }
 #pragma unroll
@@ -605,14 +608,14 @@ __global__ __launch_bounds__(256) void k_join_key_stats_fold(const u64* __restri
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) {
             const u64 o = (u64)__shfl_xor((unsigned long long)v[k], d, 64);
-            v[k] = o > v[k] ? o : v[k];
+            v[k] = k == 3 ? v[k] + o : (o > v[k] ? o : v[k]);
         }
         if ((threadIdx.x & 63) == 0) s_v[threadIdx.x >> 6][k] = v[k];
     }
     __syncthreads();
     if (threadIdx.x < 4) {
         u64 r = 0ULL;
-        for (int w = 0; w < 4; w++) r = s_v[w][threadIdx.x] > r ? s_v[w][threadIdx.x] : r;
+        for (int w = 0; w < 4; w++) r = threadIdx.x == 3 ? r + s_v[w][threadIdx.x] : (s_v[w][threadIdx.x] > r ? s_v[w][threadIdx.x] : r);
         out[threadIdx.x] = r;
     }
 }

@@ -110,12 +110,14 @@ struct JoinKeyStats {
     int64_t min_key = 0, max_key = 0;
     bool any = false;        // some key is not NULL
     bool descending = false; // some key is smaller than the key of the row before it
+    uint64_t descents = 0;   // ... how many
 };
 inline JoinKeyStats join_key_stats_decode(const uint64_t (&h)[4])
 {
     JoinKeyStats st;
     st.any = h[2] != 0;
     st.descending = h[3] != 0;
+    st.descents = h[3];
     if (st.any) {
         st.min_key = (int64_t)(~h[0] ^ 0x8000000000000000ULL);
         st.max_key = (int64_t)(h[1] ^ 0x8000000000000000ULL);

@@ -244,7 +244,7 @@ public:
     // drained: finish_rank_index.  PRESTO_AMD_NO_RANK_INDEX=1 turns it off (A/B runs, tests of the table builds).
     bool start_rank_index(const JoinCol& key, int32_t n, hipStream_t s)
     {
-        if (ls_->bitmap.bits == nullptr || key.nulls != nullptr || n <= 0 || getenv("PRESTO_AMD_NO_RANK_INDEX")) {
+        if (ls_->bitmap.bits == nullptr || key.nulls != nullptr || n <= 0 || duplicates_certain_ || getenv("PRESTO_AMD_NO_RANK_INDEX")) {
             pair_keys_.release();
             pair_rows_.release();
             pair_first_.release();
@@ -343,7 +343,14 @@ public:
         if (range >= 64ULL * (uint64_t)n || range >= (1ULL << 36)) return;
         uint64_t* bits = static_cast<uint64_t*>(ls_->key_bits.ensure((size_t)((range >> 6) + 1) * 8));
         const int shift = join_range_shift(range);
-        if (h[3] != 0 && n >= (1 << 18) && shift >= 0 && key.nulls == nullptr && !getenv("PRESTO_AMD_NO_RANGE_BITMAP")) {
+        // more rows than key values: some key is on several rows for certain, so there will be no rank index and no use for the pairs
+        // regrouped by key range -- the bitmap is small against the rows (its words stay in the L2) and takes the rows' atomics as they
+        // come when they mostly ascend (8 M rows over 1.6 M keys: 0.33 ms of range passes -> 0.04 ms)
+        duplicates_certain_ = range + 1 < (uint64_t)n;
+        // (rows that mostly ascend -- fewer than one descent per four waves: sequences of pages that wrap around -- keep the atomics few:
+        // neighbouring lanes set bits of the same word and combine them first; random rows go through the range passes all the same)
+        const bool atomics_do = duplicates_certain_ && st.descents * 256 < (uint64_t)n;
+        if (h[3] != 0 && n >= (1 << 18) && shift >= 0 && key.nulls == nullptr && !atomics_do && !getenv("PRESTO_AMD_NO_RANGE_BITMAP")) {
             // rows out of key order: regroup the (key, row) pairs by key range, OR the bits in LDS (join_kernels.hip); the pairs stay
             // for the rank -> row array of the key rank index
             const int32_t partitions = (int32_t)((range >> shift) + 1);
@@ -392,6 +399,7 @@ private:
     // (key, row) pairs regrouped by key range, kept between build_key_bitmap and start_rank_index (rows out of key order)
     DevBuf pair_keys_, pair_rows_, pair_first_;
     bool keys_ascending_ = false;  // no build key is smaller than the key of the row before it (build_key_bitmap)
+    bool duplicates_certain_ = false;  // fewer key values between min and max than rows (build_key_bitmap)
     bool links_built_ = false;  // the table build left the chains of keys with several rows behind (the partitioned build does)
     int32_t pairs_ = 0, pair_partitions_ = 0;
     int pair_shift_ = 0;
