@@ -169,6 +169,18 @@ private:
     size_t cap_ = 0;
 };
 
+// A few words from the device for a host decision: through a pinned landing zone of the calling thread, then the wait.  (Into pageable
+// memory -- a variable on the stack -- the runtime stages the copy itself and blocks: 22 us per round trip against 16,
+// scripts/micro/readback.cpp.)
+inline void read_back(void* dst, const void* src_dev, size_t bytes, hipStream_t s)
+{
+    static thread_local PinnedBuf* land = new PinnedBuf();   // (leaked: the pool may be gone when a thread ends)
+    void* p = land->ensure(bytes < 256 ? 256 : bytes);
+    PA_HIP(hipMemcpyAsync(p, src_dev, bytes, hipMemcpyDeviceToHost, s));
+    PA_HIP(hipStreamSynchronize(s));
+    memcpy(dst, p, bytes);
+}
+
 int device_cu_count();
 void require_device();
 

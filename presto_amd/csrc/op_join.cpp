@@ -192,14 +192,12 @@ public:
         }
         timer.end(s);
         int32_t ctl[6] = {0, 0, 0, 0, 0, 0};  // [0] error word, [4] distinct build keys, [5] some build row not at its key's rank
-        PA_HIP(hipMemcpyAsync(ctl, ctl_, sizeof ctl, hipMemcpyDeviceToHost, s));
-        PA_HIP(hipStreamSynchronize(s));
+        read_back(ctl, ctl_, sizeof ctl, s);
         if (rank_pending && !finish_rank_index(n, ctl[4], ctl[5] != 0)) {
             timer.begin(s);
             build_table();
             timer.end(s);
-            PA_HIP(hipMemcpyAsync(ctl, ctl_, 4, hipMemcpyDeviceToHost, s));
-            PA_HIP(hipStreamSynchronize(s));
+            read_back(ctl, ctl_, 4, s);
         }
         const int32_t err = ctl[0];
         ls_->has_duplicates = !ls_->keyed || keyed_dups;
@@ -234,8 +232,7 @@ public:
         int32_t dups = 0;
         PA_HIP(hipMemsetAsync(ctl_ + 1, 0, 8, s));
         launch_join_keyed_build(key, raw, n, table, ls_->probe_mask, ls_->slot_of.as<int32_t>(), ls_->links.as<int32_t>(), ctl_, s);
-        PA_HIP(hipMemcpyAsync(&dups, ctl_ + 1, 4, hipMemcpyDeviceToHost, s));
-        PA_HIP(hipStreamSynchronize(s));
+        read_back(&dups, ctl_ + 1, 4, s);
         return dups;
     }
 
@@ -314,8 +311,7 @@ public:
         launch_fill_i32(ls_->links.as<int32_t>(), -1, n, s);
         launch_join_part_build(keys_out.as<uint64_t>(), rows_out.as<int32_t>(), fst, partitions, ls_->probe_mask, table, ls_->links.as<int32_t>(), ctl_, s);
         int32_t flags[2] = {0, 0};
-        PA_HIP(hipMemcpyAsync(flags, ctl_ + 1, 8, hipMemcpyDeviceToHost, s));
-        PA_HIP(hipStreamSynchronize(s));  // (the temporaries above return to the pool)
+        read_back(flags, ctl_ + 1, 8, s);  // (waits: the temporaries above return to the pool)
         if (flags[1] != 0) return 0;
         return flags[0] != 0 ? 2 : 1;
     }
@@ -330,8 +326,7 @@ public:
         uint64_t* run = static_cast<uint64_t*>(running.ensure(64));
         launch_join_key_stats(key, n, run, partials.ensure(join_key_stats_temp_bytes()), s);
         uint64_t raw[4];
-        PA_HIP(hipMemcpyAsync(raw, run, 32, hipMemcpyDeviceToHost, s));
-        PA_HIP(hipStreamSynchronize(s));
+        read_back(raw, run, 32, s);
         const JoinKeyStats st = join_key_stats_decode(raw);
         if (!st.any) return;  // every key NULL
         keys_ascending_ = !st.descending;

@@ -158,8 +158,7 @@ public:
                 in = kp[0];
             }
             const int blocks = launch_key_or_and(in, n, or_and, s);
-            PA_HIP(hipMemcpyAsync(h_or_and.data(), or_and, (size_t)blocks * 16, hipMemcpyDeviceToHost, s));
-            PA_HIP(hipStreamSynchronize(s));
+            read_back(h_or_and.data(), or_and, (size_t)blocks * 16, s);
             uint64_t h[2] = {0ULL, ~0ULL};
             for (int b = 0; b < blocks; b++) {
                 h[0] |= h_or_and[2 * (size_t)b];

@@ -1,5 +1,6 @@
 // readback.cpp -- what one "device decides, host reads the word, host launches the next kernel" round trip costs on this part.
-//   A  hipMemcpyAsync(D2H, 8 B) + hipStreamSynchronize                (what the operators did in rounds 1-2)
+//   A  hipMemcpyAsync(D2H, 8 B) into pinned memory + hipStreamSynchronize
+//   P  the same into pageable memory (a variable on the stack: the runtime stages the copy and blocks)
 //   B  a one-wave kernel stores the words + a sequence flag into host-coherent pinned memory; the host spins on the flag
 //   C  as B, but the producing kernel itself publishes (no extra launch)
 // Each loop: work kernel (touches `n` elements) -> read back its result word -> next iteration depends on it.
@@ -63,7 +64,7 @@ int main(int argc, char** argv)
     const int grid = (n + 255) / 256;
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto us = [](auto a, auto b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
-    for (int mode = 0; mode < 3; mode++) {
+    for (int mode = -1; mode < 3; mode++) {
         long long check = 0;
         unsigned seq = *flag;
         for (int rep = 0; rep < 2; rep++) {
@@ -72,7 +73,14 @@ int main(int argc, char** argv)
             auto t0 = now();
             int add = 1;
             for (int it = 0; it < iters; it++) {
-                if (mode == 0) {
+                if (mode == -1) {
+                    int pageable[2];
+                    hipLaunchKernelGGL(k_work, dim3(grid), dim3(256), 0, s, in, n, result, add);
+                    CK(hipMemcpyAsync(pageable, result, 8, hipMemcpyDeviceToHost, s));
+                    CK(hipStreamSynchronize(s));
+                    host[0] = pageable[0];
+                }
+                else if (mode == 0) {
                     hipLaunchKernelGGL(k_work, dim3(grid), dim3(256), 0, s, in, n, result, add);
                     CK(hipMemcpyAsync(host, result, 8, hipMemcpyDeviceToHost, s));
                     CK(hipStreamSynchronize(s));
@@ -93,7 +101,7 @@ int main(int argc, char** argv)
             }
             CK(hipStreamSynchronize(s));
             auto t1 = now();
-            if (rep == 1) printf("mode %c  n=%d  %.2f us per round trip (check %lld)\n", "ABC"[mode], n, us(t0, t1) / iters, check);
+            if (rep == 1) printf("mode %c  n=%d  %.2f us per round trip (check %lld)\n", "PABC"[mode + 1], n, us(t0, t1) / iters, check);
         }
     }
     // the bare kernel, back to back, for reference
