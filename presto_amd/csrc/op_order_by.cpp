@@ -20,7 +20,6 @@
 
 namespace pa {
 
-void launch_sort_digits(const uint64_t* keys, const int32_t* perm, int64_t n, int shift, int bits, int32_t* digits, hipStream_t s);
 void launch_sort_null_digits(const uint8_t* nulls, const int32_t* perm, int64_t n, int nulls_first, int32_t* digits, hipStream_t s);
 void launch_varchar_chunk_keys(const void* values, const int32_t* offsets, const uint8_t* nulls, int64_t n, int chunk, int descending,
                                uint64_t* keys, hipStream_t s);

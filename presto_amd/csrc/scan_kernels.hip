@@ -656,7 +656,7 @@ __global__ __launch_bounds__(kMsThreads) void k_msplit_count_pm(const i32* __res
 }
 
 // The stable form (at most 256 partitions): a row's place inside its (tile, partition) is the number of earlier rows of the tile
-// with the same partition -- the rank computation of k_radix_scatter_stable -- so every partition keeps ascending row order,
+// with the same partition -- wave ballots and per-wave counts -- so every partition keeps ascending row order,
 // what the exchange needs (PartitioningExchanger appends positions in order).
 __global__ __launch_bounds__(kMsThreads) void k_msplit_scatter_stable(MsplitArgs a)
 {
@@ -816,118 +816,8 @@ void launch_msplit(const int32_t* partition, int64_t n, int32_t partition_count,
 }
 
 // ---------------------------------------------------------------------------------------------
-// stable radix pass over (key, payload) pairs (see scan_kernels.hpp)
+// OrderBy helpers
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kMsThreads) void k_radix_count(const u64* __restrict__ keys, i64 n, int shift, i64 tiles, i32* __restrict__ counts)
-{
-    __shared__ i32 hist[256];
-    if (threadIdx.x < 256) hist[threadIdx.x] = 0;
-    __syncthreads();
-    const i64 tile0 = (i64)blockIdx.x * kMsTile;
-#pragma unroll
-    for (int i = 0; i < kMsItems; i++) {
-        const i64 row = tile0 + (i64)i * kMsThreads + threadIdx.x;
-        if (row < n) atomicAdd(&hist[(keys[row] >> shift) & 255ULL], 1);
-    }
-    __syncthreads();
-    if (threadIdx.x < 256) counts[(i64)threadIdx.x * tiles + blockIdx.x] = hist[threadIdx.x];
-}
-
-__global__ __launch_bounds__(kMsThreads) void k_radix_scatter_stable(const u64* __restrict__ keys_in, const i32* __restrict__ pay_in, i64 n, int shift, i64 tiles,
-                                                                     const i32* __restrict__ offsets, u64* __restrict__ keys_out, i32* __restrict__ pay_out)
-{
-    __shared__ i32 goff[256], lstart[256], running[256];
-    __shared__ i32 cnt[16][256], off[16][256];
-    __shared__ i32 wave_sums[16];
-    __shared__ u8 ldigit[kMsTile];
-    __shared__ u64 buf[kMsTile];
-    const i64 tile0 = (i64)blockIdx.x * kMsTile;
-    const i32 tile_rows = (i32)(n - tile0 < (i64)kMsTile ? n - tile0 : (i64)kMsTile);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    i32 mine = 0;
-    if (threadIdx.x < 256) {
-        const i64 idx = (i64)threadIdx.x * tiles + blockIdx.x;
-        const i32 o = offsets[idx];
-        const i32 nx = idx + 1 < 256 * tiles ? offsets[idx + 1] : (i32)n;
-        goff[threadIdx.x] = o;
-        mine = nx - o;
-        running[threadIdx.x] = 0;
-#pragma unroll
-        for (int w = 0; w < 16; w++) cnt[w][threadIdx.x] = 0;
-    }
-    i32 inc = mine;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const i32 v = __shfl_up(inc, o, 64);
-        if (lane >= o) inc += v;
-    }
-    if (lane == 63) wave_sums[wave] = inc;
-    __syncthreads();
-    if (threadIdx.x < 256) {
-        i32 base = 0;
-        for (int w = 0; w < wave; w++) base += wave_sums[w];
-        lstart[threadIdx.x] = base + inc - mine;
-    }
-    __syncthreads();
-    u64 key[kMsItems];
-    unsigned short li[kMsItems];
-    for (int i = 0; i < kMsItems; i++) {
-        const i64 row = tile0 + (i64)i * kMsThreads + threadIdx.x;
-        const bool live = row < n;
-        key[i] = live ? keys_in[row] : 0ULL;
-        const u32 d = (u32)(key[i] >> shift) & 255u;
-        // lanes of this wave with the same digit, and how many of them come before this lane
-        u64 peers = __ballot(live);
-#pragma unroll
-        for (int bit = 0; bit < 8; bit++) {
-            const u64 b = __ballot(live && ((d >> bit) & 1u));
-            peers &= ((d >> bit) & 1u) ? b : ~b;
-        }
-        const int before = __popcll(peers & ((1ULL << lane) - 1ULL));
-        if (live && before == 0) cnt[wave][d] = (i32)__popcll(peers);
-        __syncthreads();
-        // per digit: where every wave's rows of this slot start (after the rows of the earlier slots and the earlier waves)
-        if (threadIdx.x < 256) {
-            i32 acc = running[threadIdx.x];
-#pragma unroll
-            for (int w = 0; w < 16; w++) {
-                const i32 c = cnt[w][threadIdx.x];
-                cnt[w][threadIdx.x] = 0;
-                off[w][threadIdx.x] = acc;
-                acc += c;
-            }
-            running[threadIdx.x] = acc;
-        }
-        __syncthreads();
-        li[i] = 0;
-        if (live) {
-            const i32 at = lstart[d] + off[wave][d] + before;
-            li[i] = (unsigned short)at;
-            ldigit[at] = (u8)d;
-        }
-    }
-    __syncthreads();
-    // keys, then payloads, through the staging buffer
-    for (int i = 0; i < kMsItems; i++) {
-        if (tile0 + (i64)i * kMsThreads + threadIdx.x < n) buf[li[i]] = key[i];
-    }
-    __syncthreads();
-    for (i32 j = threadIdx.x; j < tile_rows; j += kMsThreads) {
-        const i32 d = ldigit[j];
-        keys_out[(i64)goff[d] + (j - lstart[d])] = buf[j];
-    }
-    __syncthreads();
-    for (int i = 0; i < kMsItems; i++) {
-        const i64 row = tile0 + (i64)i * kMsThreads + threadIdx.x;
-        if (row < n) ((i32*)buf)[li[i]] = pay_in[row];
-    }
-    __syncthreads();
-    for (i32 j = threadIdx.x; j < tile_rows; j += kMsThreads) {
-        const i32 d = ldigit[j];
-        pay_out[(i64)goff[d] + (j - lstart[d])] = ((const i32*)buf)[j];
-    }
-}
-
 // OR and AND of the keys, one pair per workgroup (out[2 b], out[2 b + 1]); the host folds the pairs it reads back anyway -- a pair of
 // same-address atomics per wave (8192 of them) took 120 us over 2^24 keys, four times the pass itself
 constexpr int kOrAndBlocks = 1024;
@@ -954,26 +844,6 @@ __global__ __launch_bounds__(256) void k_key_or_and(const u64* __restrict__ keys
         out[2 * blockIdx.x] = s_o[0] | s_o[1] | s_o[2] | s_o[3];
         out[2 * blockIdx.x + 1] = s_a[0] & s_a[1] & s_a[2] & s_a[3];
     }
-}
-
-size_t radix_pass_temp_bytes(int64_t n)
-{
-    const int64_t tiles = (n + kMsTile - 1) / kMsTile;
-    return (size_t)(tiles * 256) * 4 + scan_temp_bytes(tiles * 256) + 64;
-}
-
-void launch_radix_pass_stable(const uint64_t* keys_in, const int32_t* payload_in, int64_t n, int shift, uint64_t* keys_out, int32_t* payload_out,
-                              void* temp, hipStream_t s)
-{
-    if (n <= 0) return;
-    const int64_t tiles = (n + kMsTile - 1) / kMsTile;
-    i32* counts = static_cast<i32*>(temp);
-    void* scan_temp = counts + tiles * 256;
-    hipLaunchKernelGGL(k_radix_count, (int)tiles, kMsThreads, 0, s, (const u64*)keys_in, (i64)n, shift, (i64)tiles, counts);
-    launch_exclusive_scan_i32(counts, counts, tiles * 256, nullptr, scan_temp, s);
-    hipLaunchKernelGGL(k_radix_scatter_stable, (int)tiles, kMsThreads, 0, s, (const u64*)keys_in, payload_in, (i64)n, shift, (i64)tiles, (const i32*)counts,
-                       (u64*)keys_out, payload_out);
-    PA_HIP(hipGetLastError());
 }
 
 size_t key_or_and_bytes() { return (size_t)kOrAndBlocks * 16; }

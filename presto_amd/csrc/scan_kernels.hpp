@@ -51,14 +51,7 @@ void launch_msplit(const int32_t* partition, int64_t n, int32_t partition_count,
 int64_t msplit_tiles(int64_t n);
 int32_t* msplit_counts(void* temp);
 constexpr int kMsplitTileRows = 8192;
-// One STABLE 8-bit LSD radix pass over (key, payload) pairs held as two columns: the pairs regrouped by digit =
-// (key >> shift) & 255, arrival order kept inside a digit.  Same LDS-staged structure as the multisplit (8192-row tiles,
-// coalesced reads and writes); the rank of a row inside its (tile, digit) is the number of earlier rows of the tile with the
-// same digit (wave ballots + per-wave counts).  OrderBy sorts (key image, row id) pairs with it.
-size_t radix_pass_temp_bytes(int64_t n);
-void launch_radix_pass_stable(const uint64_t* keys_in, const int32_t* payload_in, int64_t n, int shift, uint64_t* keys_out, int32_t* payload_out,
-                              void* temp, hipStream_t s);
-// out[0] = OR of all keys, out[1] = AND of all keys (device memory, 16 bytes): a byte in which they agree is constant
+// OR and AND of keys: a bit in which they agree is constant (OrderBy leaves such bits out of its sort)
 // per workgroup b: out[2 b] = OR, out[2 b + 1] = AND of its keys; returns the workgroups launched (out: key_or_and_bytes())
 size_t key_or_and_bytes();
 int launch_key_or_and(const uint64_t* keys, int64_t n, uint64_t* out, hipStream_t s);

@@ -524,11 +524,6 @@ void launch_topn_flag(const uint64_t* keys, int64_t n, uint64_t threshold, int32
 
 // ---- OrderByOperator (op_order_by.cpp): digits of a radix pass, taken through the current permutation --------------------
 namespace {
-__global__ __launch_bounds__(256) void k_sort_digits(const u64* __restrict__ keys, const i32* __restrict__ perm, i64 n, int shift, u32 mask,
-                                                     i32* __restrict__ digits)
-{
-    for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < n; i += (i64)gridDim.x * 256) digits[i] = (i32)((keys[perm[i]] >> shift) & mask);
-}
 __global__ __launch_bounds__(256) void k_sort_null_digits(const u8* __restrict__ nulls, const i32* __restrict__ perm, i64 n, int nulls_first,
                                                           i32* __restrict__ digits)
 {
@@ -577,12 +572,6 @@ __global__ __launch_bounds__(256) void k_varchar_max_length(const i32* __restric
 }
 }  // namespace
 
-void launch_sort_digits(const uint64_t* keys, const int32_t* perm, int64_t n, int shift, int bits, int32_t* digits, hipStream_t s)
-{
-    if (n <= 0) return;
-    hipLaunchKernelGGL(k_sort_digits, grid_of(n), 256, 0, s, (const u64*)keys, perm, (i64)n, shift, (u32)((1u << bits) - 1u), digits);
-    PA_HIP(hipGetLastError());
-}
 void launch_sort_null_digits(const uint8_t* nulls, const int32_t* perm, int64_t n, int nulls_first, int32_t* digits, hipStream_t s)
 {
     if (n <= 0) return;
