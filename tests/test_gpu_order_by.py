@@ -1,4 +1,4 @@
-"""OrderByOperator on device (stable LSD radix sort of a row permutation) against the reference's known answers
+"""OrderByOperator on device (stable sorts of (key image, row id) pairs, channel by channel) against the reference's known answers
 (core/trino-main/src/test/java/io/trino/operator/TestOrderByOperator.java:130-232) and the oracle on random pages: every type as sort
 key, all four SortOrders, multi-channel keys, long VARCHAR keys, ties in arrival order."""
 import numpy as np
