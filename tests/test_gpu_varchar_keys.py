@@ -268,6 +268,17 @@ def test_min_max_over_long_varchar(gpu, oracle, groups, device):
     assert_same(got, ref.build_result().to_rows(), nkeys=len(keys))
 
 
+@pytest.mark.parametrize("param", [0, 7])
+def test_min_max_over_strings_reference_kats(gpu, param):
+    """TestVarBinaryMaxAggregation / TestVarBinaryMinAggregation (max / min over VARCHAR values holding the big-endian bytes of an integer
+    sequence) through AbstractTestAggregationFunction's cases, on the device: by rank (undeclared length) and by image (VARCHAR(7))."""
+    from tests.test_oracle_operators import VARBINARY_MINMAX_CASES
+    for name, values, lo, hi in VARBINARY_MINMAX_CASES:
+        op = HashAggregationOperator([abi.VARCHAR], [], [(abi.AGG_MIN, 0, abi.VARCHAR), (abi.AGG_MAX, 0, abi.VARCHAR)], type_params=[param])
+        pages = [Page([Block.varchar(values)], len(values))] if values else []
+        assert [r for p in to_pages(op, pages) for r in p.to_rows()] == [(lo, hi)], name
+
+
 def test_min_max_long_varchar_empty_and_all_null(gpu, oracle):
     types, aggs = [abi.BIGINT, abi.VARCHAR], [(abi.AGG_MIN, 1, abi.VARCHAR), (abi.AGG_MAX, 1, abi.VARCHAR), (abi.AGG_COUNT_STAR, -1, None)]
     # no input at all: one row of NULLs for the ungrouped aggregation, no row for the grouped one

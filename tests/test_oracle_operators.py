@@ -516,3 +516,37 @@ def test_c_sort_and_topn_twins_agree_with_the_python_restatements(oracle):
         assert len(got) == min(limit, 5000)
         for i, r in zip(got, ref):
             assert (np.float64(v[i]).view(np.int64) == np.float64(r[0]).view(np.int64) or (np.isnan(v[i]) and np.isnan(r[0]))) and kk[i] == r[1]
+
+
+def varbinary_sequence(start, length):
+    """TestVarBinaryMaxAggregation.getSequenceBlocks (…/operator/aggregation/TestVarBinaryMaxAggregation.java:33-41): the big-endian four
+    bytes of start .. start + length - 1, aggregated as VARCHAR."""
+    import struct
+    return [struct.pack(">i", i) for i in range(start, start + length)]
+
+
+# AbstractTestAggregationFunction's cases (…/operator/aggregation/AbstractTestAggregationFunction.java:84-140) with the answers
+# TestVarBinaryMaxAggregation / TestVarBinaryMinAggregation.getExpectedValue compute: the natural order of Slices -- unsigned bytes, so
+# the negative integers' 0xff.. images are the largest strings
+VARBINARY_MINMAX_CASES = [
+    ("testNoPositions", [], None, None),
+    ("testSinglePosition", varbinary_sequence(0, 1), b"\x00\x00\x00\x00", b"\x00\x00\x00\x00"),
+    ("testMultiplePositions", varbinary_sequence(0, 5), b"\x00\x00\x00\x00", b"\x00\x00\x00\x04"),
+    ("testAllPositionsNull", [None] * 10, None, None),
+    ("testMixedNullAndNonNullPositions", [v for x in varbinary_sequence(0, 10) for v in (None, x)], b"\x00\x00\x00\x00", b"\x00\x00\x00\x09"),
+    ("testNegativeOnlyValues", varbinary_sequence(-10, 5), b"\xff\xff\xff\xf6", b"\xff\xff\xff\xfa"),
+    ("testPositiveOnlyValues", varbinary_sequence(2, 4), b"\x00\x00\x00\x02", b"\x00\x00\x00\x05"),
+]
+
+
+@pytest.mark.parametrize("case", VARBINARY_MINMAX_CASES, ids=[c[0] for c in VARBINARY_MINMAX_CASES])
+def test_min_max_over_strings_kats(oracle, case):
+    _, values, lo, hi = case
+    agg = oracle.HashAggregation([abi.VARCHAR], [], [(abi.AGG_MIN, 0, abi.VARCHAR), (abi.AGG_MAX, 0, abi.VARCHAR)])
+    if values:
+        agg.add_page(Page([Block.varchar(values)], len(values)))
+    assert agg.build_result().to_rows() == [(lo, hi)]
+    # a value that mixes both signs (not one of the reference's cases): the unsigned order puts -1 on top
+    mixed = oracle.HashAggregation([abi.VARCHAR], [], [(abi.AGG_MIN, 0, abi.VARCHAR), (abi.AGG_MAX, 0, abi.VARCHAR)])
+    mixed.add_page(Page([Block.varchar(varbinary_sequence(-5, 10))], 10))
+    assert mixed.build_result().to_rows() == [(b"\x00\x00\x00\x00", b"\xff\xff\xff\xff")]
