@@ -171,6 +171,41 @@ def test_aggregation_operator_kat(gpu, oracle):
     assert out[0].to_rows() == [(100, 4950, 49.5, 54950.0)]
 
 
+def test_aggregation_function_sequence_kats_on_device(gpu):
+    """The reference's per-function tests (TestCountColumnAggregation, TestLong/DoubleSum/Average/Min/MaxAggregation, TestDateMaxAggregation,
+    TestShortDecimalMaxAggregation) over AbstractTestAggregationFunction's cases (…/aggregation/AbstractTestAggregationFunction.java:84-140),
+    as tests/test_oracle_operators.py::test_aggregation_function_sequence_kats restates them for the oracle -- here through the device's
+    AggregationOperator (ungrouped) and HashAggregationOperator (one group)."""
+    from tests.test_oracle_operators import SEQUENCE_CASES
+    D = abi.decimal(10, 5)
+    for name, start, length, shape in SEQUENCE_CASES:
+        seq = list(range(start, start + length))
+        if shape == "all_null":
+            values, nulls = [0] * 10, [True] * 10
+        elif shape == "alternating":
+            values, nulls = [v for x in seq for v in (0, x)], [n for _ in seq for n in (True, False)]
+        else:
+            values, nulls = seq, [False] * len(seq)
+        n = len(values)
+        nl = np.array(nulls, dtype=bool)
+        blocks = [Block.bigint(np.array(values, dtype=np.int64), nl), Block.double(np.array(values, dtype=np.float64), nl),
+                  Block.date(np.array(values, dtype=np.int32), nl), Block.decimal(np.array(values, dtype=np.int64), nl)]
+        types = [abi.BIGINT, abi.DOUBLE, abi.DATE, D]
+        aggs = [(abi.AGG_COUNT, 0, abi.BIGINT), (abi.AGG_SUM, 0, abi.BIGINT), (abi.AGG_AVG, 0, abi.BIGINT), (abi.AGG_SUM, 1, abi.DOUBLE),
+                (abi.AGG_AVG, 1, abi.DOUBLE), (abi.AGG_MIN, 0, abi.BIGINT), (abi.AGG_MAX, 0, abi.BIGINT), (abi.AGG_MIN, 1, abi.DOUBLE),
+                (abi.AGG_MAX, 1, abi.DOUBLE), (abi.AGG_MAX, 2, abi.DATE), (abi.AGG_MAX, 3, D)]
+        total, lo, hi = sum(seq), start, start + length - 1
+        expected = (0,) + (None,) * 10 if length == 0 else (length, total, float(total) / length, float(total), float(total) / length, lo, hi,
+                                                            float(lo), float(hi), hi, hi)
+        pages = [Page(blocks, n)] if n else []
+        assert [r for p in to_pages(AggregationOperator(types, aggs), pages) for r in p.to_rows()] == [expected], name
+        if n:   # the same values as one group of a grouped aggregation
+            grouped = [Page([Block.bigint(np.full(n, 7, dtype=np.int64))] + blocks, n)]
+            gaggs = [(a[0], a[1] + 1, a[2]) for a in aggs]
+            got = [r for p in to_pages(HashAggregationOperator([abi.BIGINT] + types, [0], gaggs), grouped) for r in p.to_rows()]
+            assert got == [(7,) + expected], name
+
+
 def test_bigint_sum_overflow_raises(gpu):
     from presto_amd._lib import PrestoAmdError
     page = Page([Block.bigint([2 ** 62, 2 ** 62, 5])])

@@ -550,3 +550,43 @@ def test_min_max_over_strings_kats(oracle, case):
     mixed = oracle.HashAggregation([abi.VARCHAR], [], [(abi.AGG_MIN, 0, abi.VARCHAR), (abi.AGG_MAX, 0, abi.VARCHAR)])
     mixed.add_page(Page([Block.varchar(varbinary_sequence(-5, 10))], 10))
     assert mixed.build_result().to_rows() == [(b"\x00\x00\x00\x00", b"\xff\xff\xff\xff")]
+
+
+# The reference's per-function tests over AbstractTestAggregationFunction's cases (…/operator/aggregation/AbstractTestAggregationFunction
+# .java:84-140: getSequenceBlocks(start, length) = the integers start .. start + length - 1 in the function's type):
+# TestCountColumnAggregation (length), TestLongSumAggregation / TestDoubleSumAggregation (the sum, NULL without input),
+# TestLongAverageAggregation / TestDoubleAverageAggregation (sum / length), TestLongMinAggregation / TestLongMaxAggregation /
+# TestDoubleMinAggregation / TestDoubleMaxAggregation / TestDateMaxAggregation / TestShortDecimalMaxAggregation (start, start + length - 1)
+SEQUENCE_CASES = [("testNoPositions", 0, 0, "plain"), ("testSinglePosition", 0, 1, "plain"), ("testMultiplePositions", 0, 5, "plain"),
+                  ("testAllPositionsNull", 0, 0, "all_null"), ("testMixedNullAndNonNullPositions", 0, 10, "alternating"),
+                  ("testNegativeOnlyValues", -10, 5, "plain"), ("testPositiveOnlyValues", 2, 4, "plain")]
+
+
+@pytest.mark.parametrize("case", SEQUENCE_CASES, ids=[c[0] for c in SEQUENCE_CASES])
+def test_aggregation_function_sequence_kats(oracle, case):
+    _, start, length, shape = case
+    seq = list(range(start, start + length))
+    if shape == "all_null":
+        values, nulls = [0] * 10, [True] * 10
+    elif shape == "alternating":   # createAlternatingNullsBlock: a NULL in front of every value
+        values, nulls = [v for x in seq for v in (0, x)], [n for _ in seq for n in (True, False)]
+    else:
+        values, nulls = seq, [False] * len(seq)
+    n = len(values)
+    nl = np.array(nulls, dtype=bool)
+    D = abi.decimal(10, 5)
+    blocks = [Block.bigint(np.array(values, dtype=np.int64), nl), Block.double(np.array(values, dtype=np.float64), nl),
+              Block.date(np.array(values, dtype=np.int32), nl), Block.decimal(np.array(values, dtype=np.int64), nl)]
+    types = [abi.BIGINT, abi.DOUBLE, abi.DATE, D]
+    aggs = [(abi.AGG_COUNT, 0, abi.BIGINT), (abi.AGG_SUM, 0, abi.BIGINT), (abi.AGG_AVG, 0, abi.BIGINT), (abi.AGG_SUM, 1, abi.DOUBLE),
+            (abi.AGG_AVG, 1, abi.DOUBLE), (abi.AGG_MIN, 0, abi.BIGINT), (abi.AGG_MAX, 0, abi.BIGINT), (abi.AGG_MIN, 1, abi.DOUBLE),
+            (abi.AGG_MAX, 1, abi.DOUBLE), (abi.AGG_MAX, 2, abi.DATE), (abi.AGG_MAX, 3, D)]
+    agg = oracle.HashAggregation(types, [], aggs)
+    if n:
+        agg.add_page(Page(blocks, n))
+    (row,) = agg.build_result().to_rows()
+    if length == 0:
+        assert row == (0,) + (None,) * 10
+        return
+    total, lo, hi = sum(seq), start, start + length - 1
+    assert row == (length, total, float(total) / length, float(total), float(total) / length, lo, hi, float(lo), float(hi), hi, hi)
