@@ -590,3 +590,24 @@ def test_aggregation_function_sequence_kats(oracle, case):
         return
     total, lo, hi = sum(seq), start, start + length - 1
     assert row == (length, total, float(total) / length, float(total), float(total) / length, lo, hi, float(lo), float(hi), hi, hi)
+
+
+def test_lookup_join_page_builder_positions(oracle):
+    """TestLookupJoinPageBuilder.testDifferentPositions (…/join/TestLookupJoinPageBuilder.java:85-150) at the operator's level: a probe page
+    of 0 .. 99 against the build page 0 .. 99 -- no probe row joined gives an empty page; every second probe row joined gives probe and
+    build columns 0, 2, 4, ...; every row joined gives both columns 0 .. 99, in probe order."""
+    build = Page([Block.bigint(np.arange(100, dtype=np.int64))], 100)
+    j = oracle.HashJoin([abi.BIGINT], [0], [0])
+    j.add_build_page(build)
+    j.build()
+    # "empty": no probe key exists on the build side
+    out, pi, bi = j.probe(Page([Block.bigint(np.arange(100, dtype=np.int64) + 1000)], 100), [abi.BIGINT], [0], [0], -1)
+    assert out is None or out.position_count == 0
+    # "the probe covers non-sequential positions": odd positions carry keys the build side does not hold
+    keys = np.arange(100, dtype=np.int64)
+    keys[1::2] += 1000
+    out, pi, bi = j.probe(Page([Block.bigint(keys)], 100), [abi.BIGINT], [0], [0], -1)
+    assert out.to_rows() == [(2 * i, 2 * i) for i in range(50)] and pi.tolist() == list(range(0, 100, 2)) and bi.tolist() == list(range(0, 100, 2))
+    # "the probe covers everything"
+    out, pi, bi = j.probe(build, [abi.BIGINT], [0], [0], -1)
+    assert out.to_rows() == [(i, i) for i in range(100)] and pi.tolist() == bi.tolist() == list(range(100))
