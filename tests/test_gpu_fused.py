@@ -173,7 +173,7 @@ def test_aggregation_operator_kat(gpu, oracle):
 
 def test_aggregation_function_sequence_kats_on_device(gpu):
     """The reference's per-function tests (TestCountColumnAggregation, TestLong/DoubleSum/Average/Min/MaxAggregation, TestDateMaxAggregation,
-    TestShortDecimalMaxAggregation) over AbstractTestAggregationFunction's cases (…/aggregation/AbstractTestAggregationFunction.java:84-140),
+    TestShortDecimalMaxAggregation, TestBooleanMax / MinAggregation, TestRealSumAggregation) over AbstractTestAggregationFunction's cases (…/aggregation/AbstractTestAggregationFunction.java:84-140),
     as tests/test_oracle_operators.py::test_aggregation_function_sequence_kats restates them for the oracle -- here through the device's
     AggregationOperator (ungrouped) and HashAggregationOperator (one group)."""
     from tests.test_oracle_operators import SEQUENCE_CASES
@@ -189,14 +189,18 @@ def test_aggregation_function_sequence_kats_on_device(gpu):
         n = len(values)
         nl = np.array(nulls, dtype=bool)
         blocks = [Block.bigint(np.array(values, dtype=np.int64), nl), Block.double(np.array(values, dtype=np.float64), nl),
-                  Block.date(np.array(values, dtype=np.int32), nl), Block.decimal(np.array(values, dtype=np.int64), nl)]
-        types = [abi.BIGINT, abi.DOUBLE, abi.DATE, D]
+                  Block.date(np.array(values, dtype=np.int32), nl), Block.decimal(np.array(values, dtype=np.int64), nl),
+                  Block.boolean(np.array([v % 2 != 0 for v in values], dtype=bool), nl), Block.boolean(np.array([v % 2 == 0 for v in values], dtype=bool), nl),
+                  Block.real(np.array(values, dtype=np.float32), nl)]
+        types = [abi.BIGINT, abi.DOUBLE, abi.DATE, D, abi.BOOLEAN, abi.BOOLEAN, abi.REAL]
         aggs = [(abi.AGG_COUNT, 0, abi.BIGINT), (abi.AGG_SUM, 0, abi.BIGINT), (abi.AGG_AVG, 0, abi.BIGINT), (abi.AGG_SUM, 1, abi.DOUBLE),
                 (abi.AGG_AVG, 1, abi.DOUBLE), (abi.AGG_MIN, 0, abi.BIGINT), (abi.AGG_MAX, 0, abi.BIGINT), (abi.AGG_MIN, 1, abi.DOUBLE),
-                (abi.AGG_MAX, 1, abi.DOUBLE), (abi.AGG_MAX, 2, abi.DATE), (abi.AGG_MAX, 3, D)]
+                (abi.AGG_MAX, 1, abi.DOUBLE), (abi.AGG_MAX, 2, abi.DATE), (abi.AGG_MAX, 3, D), (abi.AGG_MAX, 4, abi.BOOLEAN), (abi.AGG_MIN, 5, abi.BOOLEAN),
+                (abi.AGG_SUM, 6, abi.REAL)]
         total, lo, hi = sum(seq), start, start + length - 1
-        expected = (0,) + (None,) * 10 if length == 0 else (length, total, float(total) / length, float(total), float(total) / length, lo, hi,
-                                                            float(lo), float(hi), hi, hi)
+        bool_max = length > 1 or start % 2 == 1
+        expected = (0,) + (None,) * 13 if length == 0 else (length, total, float(total) / length, float(total), float(total) / length, lo, hi,
+                                                            float(lo), float(hi), hi, hi, bool_max, not bool_max, float(np.float32(total)))
         pages = [Page(blocks, n)] if n else []
         assert [r for p in to_pages(AggregationOperator(types, aggs), pages) for r in p.to_rows()] == [expected], name
         if n:   # the same values as one group of a grouped aggregation

@@ -556,7 +556,8 @@ def test_min_max_over_strings_kats(oracle, case):
 # .java:84-140: getSequenceBlocks(start, length) = the integers start .. start + length - 1 in the function's type):
 # TestCountColumnAggregation (length), TestLongSumAggregation / TestDoubleSumAggregation (the sum, NULL without input),
 # TestLongAverageAggregation / TestDoubleAverageAggregation (sum / length), TestLongMinAggregation / TestLongMaxAggregation /
-# TestDoubleMinAggregation / TestDoubleMaxAggregation / TestDateMaxAggregation / TestShortDecimalMaxAggregation (start, start + length - 1)
+# TestDoubleMinAggregation / TestDoubleMaxAggregation / TestDateMaxAggregation / TestShortDecimalMaxAggregation (start, start + length - 1),
+# TestBooleanMaxAggregation / TestBooleanMinAggregation, TestRealSumAggregation
 SEQUENCE_CASES = [("testNoPositions", 0, 0, "plain"), ("testSinglePosition", 0, 1, "plain"), ("testMultiplePositions", 0, 5, "plain"),
                   ("testAllPositionsNull", 0, 0, "all_null"), ("testMixedNullAndNonNullPositions", 0, 10, "alternating"),
                   ("testNegativeOnlyValues", -10, 5, "plain"), ("testPositiveOnlyValues", 2, 4, "plain")]
@@ -576,20 +577,27 @@ def test_aggregation_function_sequence_kats(oracle, case):
     nl = np.array(nulls, dtype=bool)
     D = abi.decimal(10, 5)
     blocks = [Block.bigint(np.array(values, dtype=np.int64), nl), Block.double(np.array(values, dtype=np.float64), nl),
-              Block.date(np.array(values, dtype=np.int32), nl), Block.decimal(np.array(values, dtype=np.int64), nl)]
-    types = [abi.BIGINT, abi.DOUBLE, abi.DATE, D]
+              Block.date(np.array(values, dtype=np.int32), nl), Block.decimal(np.array(values, dtype=np.int64), nl),
+              Block.boolean(np.array([v % 2 != 0 for v in values], dtype=bool), nl), Block.boolean(np.array([v % 2 == 0 for v in values], dtype=bool), nl),
+              Block.real(np.array(values, dtype=np.float32), nl)]
+    types = [abi.BIGINT, abi.DOUBLE, abi.DATE, D, abi.BOOLEAN, abi.BOOLEAN, abi.REAL]
     aggs = [(abi.AGG_COUNT, 0, abi.BIGINT), (abi.AGG_SUM, 0, abi.BIGINT), (abi.AGG_AVG, 0, abi.BIGINT), (abi.AGG_SUM, 1, abi.DOUBLE),
             (abi.AGG_AVG, 1, abi.DOUBLE), (abi.AGG_MIN, 0, abi.BIGINT), (abi.AGG_MAX, 0, abi.BIGINT), (abi.AGG_MIN, 1, abi.DOUBLE),
-            (abi.AGG_MAX, 1, abi.DOUBLE), (abi.AGG_MAX, 2, abi.DATE), (abi.AGG_MAX, 3, D)]
+            (abi.AGG_MAX, 1, abi.DOUBLE), (abi.AGG_MAX, 2, abi.DATE), (abi.AGG_MAX, 3, D), (abi.AGG_MAX, 4, abi.BOOLEAN), (abi.AGG_MIN, 5, abi.BOOLEAN),
+            (abi.AGG_SUM, 6, abi.REAL)]
     agg = oracle.HashAggregation(types, [], aggs)
     if n:
         agg.add_page(Page(blocks, n))
     (row,) = agg.build_result().to_rows()
     if length == 0:
-        assert row == (0,) + (None,) * 10
+        assert row == (0,) + (None,) * 13
         return
     total, lo, hi = sum(seq), start, start + length - 1
-    assert row == (length, total, float(total) / length, float(total), float(total) / length, lo, hi, float(lo), float(hi), hi, hi)
+    # TestBooleanMaxAggregation (= TestBooleanOrAggregation over false, true, false, ...), TestBooleanMinAggregation (= ...And over true,
+    # false, ...), TestRealSumAggregation (the float sum)
+    bool_max, bool_min = length > 1 or start % 2 == 1, not (length > 1 or start % 2 == 1)
+    assert row == (length, total, float(total) / length, float(total), float(total) / length, lo, hi, float(lo), float(hi), hi, hi,
+                   bool_max, bool_min, float(np.float32(total)))
 
 
 def test_lookup_join_page_builder_positions(oracle):
