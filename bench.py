@@ -4,9 +4,21 @@ with TPC-H Q3 (two hash joins + grouped sum, exchange steps between the ranks wh
 
 Headline step = one Q6 pass (scan-filter-project -> global SUM) plus one Q1 pass (scan-filter-project -> hash
 aggregation on (returnflag, linestatus), 8 aggregates) over the rank's lineitem shard, each through a fresh fused
-operator driven with the Operator protocol (addInput per page, finish, getOutput).  Weak scaling: every rank holds
-`--sf` worth of lineitem rows (its slice of the SF x N table); the path shards by row range and needs no data-path
-collective, the final 4-group / 1-row partials are not merged across ranks inside the timed region.
+operator driven with the Operator protocol (addInput per page, finish, getOutput).  The headline is the metric's own
+scaling mode -- STRONG: the ONE SF100 table split by row range over the N ranks ("SF100 at 1/2/4/8 GPUs"); the weak
+figure (every rank holds `--sf` worth of rows) is timed beside it at N > 1.  The path shards by row range and needs no
+data-path collective for the scans; the ranks' Step.PARTIAL states (4 groups / 1 row) are merged by a
+Step.FINAL operator on rank 0 inside the step.
+
+Processes.  One rank per GPU.  A rank holds ONE ROCm stack: the library's (/opt/rocm: HIP, RCCL).  torch is imported in a
+rank for torch.distributed over gloo only -- the control plane: rendezvous, barriers, the max-over-ranks clock, shipping the
+RCCL unique id -- and its HIP runtime is never initialised (`torch_cuda_initialized` in the detail file is asserted false);
+tables come from pa_device_malloc, every byte of the data plane moves through pa_comm (RCCL over xGMI), and a fresh
+communicator is pre-flighted (checked 1 MB all-to-all + all-reduce + all-gather under a watchdog) before the first step.
+
+Output.  ONE JSON line of at most 4 KB on rank 0's stdout: the contract's keys, `roofline`, `cpu_baseline` and one-number
+summaries of the side legs.  Everything else -- per-stage times, results, operator benchmark entries, samples' descriptions --
+goes to the detail file (`--detail`, default bench_detail.json next to this file) and to stderr.
 
 The `q3` object of the line is its own timed region (W warm-up + K steps between barriers, max over ranks): the three
 Driver pipelines of presto_amd/q3.py over the rank's slices of customer / orders / lineitem.  With N > 1 every build
@@ -55,12 +67,16 @@ def parse_args(argv=None):
     ap.add_argument("--h2d-rows", type=int, default=1 << 25, help="rows of the host-page (PCIe-inclusive) Q6 leg, N = 1 only (0 = skip)")
     ap.add_argument("--sf300", type=int, default=1, help="1 = also run BASELINE config #5's tables (SF300: 1.80 G lineitem rows, 82.8 GB of "
                     "Q1 / Q6 columns + the Q3 tables) on this one GPU for a few steps (the `sf300` object), N = 1 only; 0 = skip")
-    ap.add_argument("--backend", default="nccl", help="torch.distributed backend; 'gloo' only to rehearse the multi-rank "
-                    "control flow with several ranks on one GPU (RCCL refuses two ranks on one device)")
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
-                    help="what `value` measures at N > 1.  weak: every rank holds --sf worth of rows (its slice of the SF x N table); "
-                         "strong: the ranks split the ONE --sf table by row range (the metric's 'SF100 at 1/2/4/8 GPUs').  The other "
+    ap.add_argument("--backend", default="nccl", help="the DATA plane between the ranks: 'nccl' (= 'rccl') the library's RCCL communicator, one "
+                    "rank per GPU; 'gloo' (= 'host') the library's host transport, to rehearse the multi-rank control flow with several ranks "
+                    "on one GPU (RCCL refuses two ranks on one device).  The control plane is torch.distributed over gloo either way")
+    ap.add_argument("--scaling", default="strong", choices=["weak", "strong"],
+                    help="what `value` measures at N > 1.  strong (the metric's 'SF100 at 1/2/4/8 GPUs'): the ranks split the ONE --sf table "
+                         "by row range; weak: every rank holds --sf worth of rows (its slice of the SF x N table).  The other "
                          "mode is timed beside it and reported as an object of that name (--other-scaling 0 skips it)")
+    ap.add_argument("--detail", default=os.path.join(ROOT, "bench_detail.json"), help="where rank 0 writes the full report (the stdout line is its summary)")
+    ap.add_argument("--preflight-timeout", type=int, default=120, help="N > 1: seconds the communicator's creation + pre-flight may take before the rank "
+                    "leaves with exit code 4 instead of waiting inside RCCL for ever")
     ap.add_argument("--other-scaling", type=int, default=1)
     ap.add_argument("--operators", type=int, default=1, help="1 = also run the operator benchmarks (the `operators` object: hash aggregation at "
                     "several cardinalities, hash join build / probe, OrderBy, TopN -- the reference's micro-benchmark shapes -- each beside its oracle twin "
@@ -74,13 +90,10 @@ def launch_ranks(args, argv):
     """`python bench.py --gpus N` with N > 1 and no torchrun environment: this process becomes the launcher -- it starts N ranks as
     fresh child processes (torch.distributed.run, one per GPU, rendezvous on 127.0.0.1) BEFORE anything here has touched the GPU or
     imported torch, waits for them and leaves with their exit code.  The ranks inherit stdout: rank 0's JSON line is the output."""
-    import socket
     import subprocess
-    with socket.socket() as sock:
-        sock.bind(("127.0.0.1", 0))
-        port = sock.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    # --standalone: torchrun picks and owns the rendezvous port itself (two benches started together cannot collide on one)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           os.path.abspath(__file__)] + list(argv)
     env = dict(os.environ)
     env.setdefault("OMP_NUM_THREADS", "8")
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -175,6 +188,8 @@ def cpu_baseline(sf, rows, one_thread_rows=8_000_000, warmups=3, runs=10):
         "host_threads_available": len(os.sched_getaffinity(0)), "physical_cores": threads, "warmups": warmups, "runs": runs,
         "one_thread": {"value": one_v, "best": 2 * one_rows / (b6_1 + b1_1), "q6": one_rows / m6_1, "q1": one_rows / m1_1, "rows": one_rows, "unit": "rows/s"},
         "all_threads": {"value": many_v, "best": 2 * rows / (b6_t + b1_t), "q6": rows / m6_t, "q1": rows / m1_t, "threads": threads, "rows": rows, "unit": "rows/s"},
+        "sample_short": "%d lineitem rows of the SF%g generator through the oracle's Q6+Q1 twins (C -O2, scalar): %d threads over disjoint row ranges, "
+                        "median of %d passes; one_thread = one Driver over the first %d rows" % (rows, sf, threads, runs, one_rows),
         "sample": "%d lineitem rows (SF%g generator), Q6+Q1 hand-written-twin pipelines of the oracle (C, -O2, scalar); 1 thread = one reference "
                   "Driver over the first %d rows; %d threads (one per physical core) over disjoint row ranges = task_concurrency Drivers; %d warm-up + "
                   "%d measured passes each, `value` = rows / median wall time of the %d-thread passes (`best`: / min)"
@@ -216,24 +231,23 @@ def q3_cpu_baseline(sf=1.0, warmups=1, runs=3):
 class DeviceWorkload:
     """The product path: device-resident synthetic tables, operators through the C ABI (presto_amd.operators)."""
 
-    def __init__(self, args, rank, world, device, scaling=None, with_q3=None):
-        import torch
+    def __init__(self, args, rank, world, device, scaling=None, with_q3=None, comm=None):
         from presto_amd import _lib, abi, tpch
         from presto_amd.operators import FusedAggregationOperatorFactory
         self.args, self.rank, self.world = args, rank, world
-        self.torch, self.abi, self.tpch = torch, abi, tpch
+        self._lib, self.abi, self.tpch = _lib, abi, tpch
         self.scaling = scaling or args.scaling
         _lib.init(device)
         self.queries = [q for q in args.queries.split(",") if q]
         q3_sf = args.q3_sf or args.sf
         self.q3_on = bool(args.q3) if with_q3 is None else with_q3
         self.q3_sf = q3_sf
-        # the communicator of the Q3 exchange steps: RCCL, one rank per GPU (gloo rehearsals with ranks sharing a GPU: the
-        # library's host transport, the two collectives then run over torch.distributed)
-        self.comm = None
-        if world > 1 and self.q3_on:
-            from presto_amd.exchange import Comm
-            self.comm = Comm.rccl() if args.backend == "nccl" else Comm.host()
+        # the communicator of the data plane (Q3's exchange steps, the PARTIAL states on their way to the FINAL operator): the
+        # library's RCCL, one rank per GPU (rehearsals with ranks sharing a GPU: its host transport over gloo).  Made once per
+        # process by main() and pre-flighted there; a second workload of the process (the other scaling mode) is handed the same one.
+        self.comm, self.owns_comm = comm, False
+        if world > 1 and comm is None:
+            self.comm, self.owns_comm = make_comm(args), True
 
         # Row-range shards (SURVEY 8e).  weak: rank r holds rows [r n, (r + 1) n) of the SF x world table, n = rows of one SF table;
         # strong: the ranks split the ONE SF table, rank r holds rows [N r / W, N (r + 1) / W) (boundaries on multiples of `multiple`).
@@ -252,18 +266,18 @@ class DeviceWorkload:
         share_lineitem = self.q3_on and q3_sf == args.sf
         if share_lineitem:
             columns |= set(tpch.Q3_LINEITEM_COLUMNS)
-        self._keep = []
+        self.hbm_bytes = 0
 
-        def allocator(nbytes):
-            t = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
-            self._keep.append(t)
-            return t
+        def allocator(nbytes):   # HBM through the C ABI (pa_device_malloc): the rank's one ROCm stack
+            self.hbm_bytes += int(nbytes)
+            return _lib.DeviceAllocation(nbytes)
 
         # this rank's slice of the table, generated on device
         self.table = tpch.DeviceColumns(sorted(columns), total_sf, self.rows, allocator=allocator, first_row=first)
         self.q6_pages = self._pages_of(self.table, tpch.Q6_COLUMNS, args.page_rows) if "q6" in self.queries else []
         self.q1_pages = self._pages_of(self.table, tpch.Q1_COLUMNS, args.page_rows) if "q1" in self.queries else []
         self.ktime = {"q6": [0.0, 0], "q1": [0.0, 0]}
+        self.kname = {}
         self.results = {}
         # the planner's part, once per query plan: OperatorFactory objects holding the serialised descriptors
         # (LocalExecutionPlanner builds the factories; every Driver then calls createOperator).  With more than one rank the
@@ -279,7 +293,7 @@ class DeviceWorkload:
         if world > 1:
             from presto_amd.exchange import PartialStateMerger, partial_layout
             from presto_amd.operators import AggregationOperator, HashAggregationOperator
-            self.merger = PartialStateMerger(device="cuda" if args.backend == "nccl" else None)
+            self.merger = PartialStateMerger(comm=self.comm)
             t6, f6 = partial_layout([], tpch.Q6_AGGREGATES)
             t1, f1 = partial_layout([abi.VARCHAR, abi.VARCHAR], tpch.Q1_AGGREGATES)
             self.final_operators = {
@@ -303,7 +317,7 @@ class DeviceWorkload:
                              self._pages_of(self.q3_lineitem, tpch.Q3_LINEITEM_COLUMNS, pr))
             self.q3_stream = _lib.DeviceStream()
             self.q3_counters = {}
-        torch.cuda.synchronize()
+        _lib.device_synchronize()
 
     def _pages_of(self, table, cols, page_rows):
         sub = self.tpch.DeviceColumns.__new__(self.tpch.DeviceColumns)
@@ -319,7 +333,7 @@ class DeviceWorkload:
         return pages
 
     def synchronize(self):
-        self.torch.cuda.synchronize()
+        self._lib.device_synchronize()
 
     # ---- headline ----
     def run_query(self, name, timed):
@@ -336,6 +350,7 @@ class DeviceWorkload:
         if timed:
             self.ktime[name][0] += ms
             self.ktime[name][1] += n
+            self.kname[name] = op.kernelName()
         op.close()
 
     def step(self, timed):
@@ -363,16 +378,24 @@ class DeviceWorkload:
         ms, n = self.ktime[name]
         if n == 0:
             return None
-        # algorithmic bytes of the timed region / summed duration of the operator's kernel launches; n counts the
-        # launches of the dominant kernel `pa_fused` only (a page whose row count is not a multiple of 256 adds one
-        # <256-row `pa_fused_tail` launch: its ~10 us are in `ms`, it is not a launch of the dominant kernel)
+        # algorithmic bytes of the timed region / summed duration of the operator's kernel launches; n counts the launches of
+        # the dominant kernel only (a page whose row count is not a multiple of 256 adds one <256-row `..._tail` launch: its
+        # ~10 us are in `ms`, it is not a launch of the dominant kernel)
         total_bytes = sum(p.position_count for p in pages) * bytes_per_row * steps
         achieved = total_bytes / (ms / 1e3) / 1e9
-        traffic = pmc.get({"q1": "q1_lds", "q6": "q6_global"}[name], {}).get("hbm_bytes_per_launch")
-        return {"bound": "hbm", "kernel": "pa_fused (%s)" % name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        kernel = self.kname.get(name, "")
+        # HBM bytes per launch from the committed counter passes -- only when they are of THIS kernel (same generated code: the
+        # name carries the code object's key) launched over the same pages (same launches per pass and rows per launch)
+        t = pmc.get(kernel)
+        traffic = None
+        if t and abs(t.get("algorithmic_bytes_per_launch", 0) - total_bytes / n) <= 1e-6 * total_bytes / n:
+            traffic = t.get("hbm_bytes_per_launch")
+        return {"bound": "hbm", "kernel": kernel, "query": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE x2 on gfx950), average per launch" if pmc else None,
-                "avg_launch_ms": ms / n, "launches": n, "algorithmic_bytes_per_launch": total_bytes / n}
+                "traffic_source": "profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --operators 0 --sf300 0 --q3 0 "
+                                  "--h2d-rows 0 --cpu-rows 0`, launches of this kernel name only, FETCH_SIZE x2 on gfx950, average per launch" if traffic else None,
+                "avg_launch_ms": ms / n, "launches": n, "algorithmic_bytes_per_launch": total_bytes / n,
+                "rows_per_launch": sum(p.position_count for p in pages) * steps / n}
 
     def workload_name(self):
         a = self.args
@@ -431,17 +454,58 @@ class DeviceWorkload:
     def close(self):
         if self.q3_on:
             self.q3_stream.destroy()
-        if self.comm is not None:
+        if self.comm is not None and self.owns_comm:
             self.comm.destroy()
+        self.comm = None
+        # the tables go back to the library's pool (DeviceAllocation.free): the next leg's tables reuse the HBM
+        for t in ("table", "customer", "orders", "q3_lineitem"):
+            cols = getattr(self, t, None)
+            if cols is not None:
+                for values, offsets in cols._bufs.values():
+                    for b in (values, offsets):
+                        if b is not None and hasattr(b, "free"):
+                            b.free()
+                setattr(self, t, None)
+        self.q6_pages = self.q1_pages = []
+        self.q3_pages = ()
 
 
-def timed_region(workload, dist, world, backend, fn, steps, warmup):
-    """W untimed + K timed calls of fn between barrier + device synchronisation on both sides; MAX over the ranks."""
+def rccl_transport(args):
+    return args.backend in ("nccl", "rccl")
+
+
+def make_comm(args):
+    """The process's pa_comm, made and pre-flighted under a watchdog: a peer that never arrives leaves ncclCommInitRank (or the first
+    collective) waiting for ever -- after --preflight-timeout seconds this rank leaves with PREFLIGHT_FAILED_EXIT_CODE instead."""
+    from presto_amd.exchange import Comm
+
+    def bail():
+        print("bench.py: the communicator was not up and checked within %d s -- leaving" % args.preflight_timeout, file=sys.stderr, flush=True)
+        os._exit(PREFLIGHT_FAILED_EXIT_CODE)
+    watchdog = None
+    if args.preflight_timeout > 0:
+        watchdog = threading.Timer(args.preflight_timeout, bail)
+        watchdog.daemon = True
+        watchdog.start()
+    try:
+        comm = Comm.rccl() if rccl_transport(args) else Comm.host()
+        comm.preflight(1 << 20)
+    except Exception as e:
+        print("bench.py: communicator pre-flight failed: %s: %s" % (type(e).__name__, e), file=sys.stderr, flush=True)
+        os._exit(PREFLIGHT_FAILED_EXIT_CODE)
+    finally:
+        if watchdog is not None:
+            watchdog.cancel()
+    return comm
+
+
+def timed_region(workload, dist, world, fn, steps, warmup):
+    """W untimed + K timed calls of fn between barrier + device synchronisation on both sides; MAX over the ranks.  The barrier and
+    the MAX run over the control plane (gloo, host tensors); the device synchronisation is the library's (pa_device_synchronize)."""
     import gc
-    import torch
     for _ in range(warmup):
         fn(False)
-    # a full collection over torch's import graph takes tens of ms: keep the cyclic GC out of the timed region
+    # a full collection over a large import graph takes tens of ms: keep the cyclic GC out of the timed region
     gc.collect()
     gc.freeze()
     gc.disable()
@@ -465,38 +529,40 @@ def timed_region(workload, dist, world, backend, fn, steps, warmup):
     if os.environ.get("BENCH_DEBUG"):
         print("step ms:", ["%.2f" % (x * 1e3) for x in step_times], file=sys.stderr)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        import torch
+        t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     return elapsed
 
 
+def printable(rows):
+    return [[x.decode() if isinstance(x, bytes) else x for x in r] for r in rows]
+
+
 def sf300_leg(args, dist, device, steps=3):
     """BASELINE config #5's tables on one GPU: Q1+Q6 over 1.80 G lineitem rows (82.8 GB of columns) and Q3 over the SF300
     customer / orders / lineitem tables, `steps` timed steps each after one warm-up step.  The SF100 tables of the headline
-    are released first (the caller closed that workload)."""
+    are released first (the caller closed that workload: its HBM went back to the library's pool)."""
     import copy
     import gc
-    import torch
     gc.collect()
-    torch.cuda.empty_cache()
     a = copy.copy(args)
     a.sf, a.q3_sf, a.h2d_rows = 300.0, 0.0, 0
     t0 = time.perf_counter()
     w = DeviceWorkload(a, 0, 1, device)
     gen_s = time.perf_counter() - t0
     try:
-        elapsed = timed_region(w, dist, 1, args.backend, w.step, steps, 1)
+        elapsed = timed_region(w, dist, 1, w.step, steps, 1)
         out = {"workload": w.workload_name(), "value": w.rows_per_step() * steps / elapsed, "unit": "rows/s", "steps": steps,
-               "ms_per_step": elapsed / steps * 1e3, "table_generation_s": gen_s,
-               "hbm_bytes_resident": sum(t.numel() for t in w._keep),
-               "results": {k: [[x.decode() if isinstance(x, bytes) else x for x in r] for r in v] for k, v in w.results.items()}}
+               "ms_per_step": elapsed / steps * 1e3, "table_generation_s": gen_s, "hbm_bytes_resident": w.hbm_bytes,
+               "results": {k: printable(v) for k, v in w.results.items()}}
         r1, r6 = w.roofline("q1", steps, {}), w.roofline("q6", steps, {})
         out["roofline_frac"] = {"q1": r1 and r1["frac"], "q6": r6 and r6["frac"]}
         if w.q3_on:
-            q3_elapsed = timed_region(w, dist, 1, args.backend, lambda timed: w.q3_step(), steps, 1)
+            q3_elapsed = timed_region(w, dist, 1, lambda timed: w.q3_step(), steps, 1)
             out["q3"] = {"ms_per_step": q3_elapsed / steps * 1e3, "value": w.q3_input_rows() * steps / q3_elapsed, "unit": "rows/s",
-                         "input_rows": w.q3_input_rows(), "result": [[x.decode() if isinstance(x, bytes) else x for x in r] for r in w.results["q3"]],
+                         "input_rows": w.q3_input_rows(), "result": printable(w.results["q3"]),
                          "stage_ms": {k: v for k, v in w.q3_counters.items() if k.endswith("_pipeline_ms")}}
         return out
     finally:
@@ -534,26 +600,108 @@ def q3_line_object(args, workload, world, q3_elapsed, pmc):
         # and reads price and discount for the matching rows only, so its HBM traffic is below the algorithmic figure
         k_ms, k_n = c["lineitem_fused_kernel_ms"], c["lineitem_fused_launches"]
         k_alg = workload.q3_rows[2] * 28
-        q3["roofline_dominant"] = {"bound": "hbm", "kernel": "pa_fused, probe stage (lineitem: filter -> key rank index -> accumulate by build row)",
+        kernel = c.get("lineitem_fused_kernel", "pa_fused_probe_brow")
+        t = pmc.get(kernel) or {}
+        q3["roofline_dominant"] = {"bound": "hbm", "kernel": kernel, "what": "probe stage (lineitem: filter -> key rank index -> accumulate by build row)",
                                    "achieved": k_alg / (k_ms / 1e3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                    "frac": k_alg / (k_ms / 1e3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_step": k_alg,
                                    "kernel_ms_per_step": k_ms, "launches_per_step": k_n,
-                                   "traffic": pmc.get("q3_probe", {}).get("hbm_bytes_per_launch"),
-                                   "traffic_source": "profiles/pmc_traffic.json q3_probe: rocprofv3 --pmc FETCH_SIZE pass of scripts/bench_q3.py, x2 on gfx950, "
-                                                     "average per launch (reads; the table updates are memory-side atomics)" if "q3_probe" in pmc else None}
+                                   "traffic": t.get("hbm_bytes_per_launch"),
+                                   "note": "the kernel physically reads less than the algorithmic 28 B/row: price and discount only for the matching rows"}
     if world > 1:
         sent, t_ms = c.get("exchange_bytes_remote", 0), c.get("exchange_transfer_ms", 0.0)
         q3["exchange"] = {"what": "4 hash-partitioned exchanges per step (customer keys, orders, orders JOIN customer, lineitem), each one "
                                   "count all-gather + one grouped ncclSend/ncclRecv all-to-all; dynamic-filter bitmaps combined by all-reduce; "
                                   "all partitions of a build side arrive before any probe (PartitionedLookupSourceFactory.java:179-206)",
-                          "transport": "RCCL over xGMI" if args.backend == "nccl" else "host transport over " + args.backend,
+                          "transport": "RCCL over xGMI" if rccl_transport(args) else "host transport over gloo",
                           "rank0_bytes_to_other_ranks_per_step": sent, "rank0_all_to_all_ms_per_step": t_ms,
                           "xgmi_GBps": (sent / (t_ms / 1e3) / 1e9) if t_ms > 0 else None,
                           "note": "xgmi_GBps = rank 0's payload bytes sent to the other ranks / device time of its all-to-alls (HIP events)"}
     return q3
 
 
-Q3_FAILED_EXIT_CODE = 3   # the line was printed, but a rank failed inside the Q3 leg (or the leg timed out)
+def sig(x, digits=6):
+    """numbers of the stdout line: `digits` significant digits (the detail file keeps everything)"""
+    if isinstance(x, bool) or x is None:
+        return x
+    if isinstance(x, float):
+        return float("%.*g" % (digits, x))
+    return x
+
+
+LINE_LIMIT = 4096   # the driver keeps ~8 KB of stdout: the line stays far below
+
+
+def summary_line(detail):
+    """The ONE stdout line: the contract's keys + `roofline` + `cpu_baseline` verbatim (trimmed to their contract fields), one-number
+    summaries of every side leg.  The full objects are in the detail file."""
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")
+    line = {k: sig(detail[k]) for k in keep}
+    c = detail["config"]
+    line["config"] = {k: c[k] for k in ("workload", "scale_factor_job", "rows_per_gpu", "page_rows", "queries", "parallelism") if k in c}
+
+    def roof(r, extra=()):
+        if not r:
+            return None
+        keys = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms", "launches", "algorithmic_bytes_per_launch") + tuple(extra)
+        return {k: sig(r.get(k)) for k in keys}
+    line["roofline"] = roof(detail.get("roofline"))
+    if detail.get("roofline_q6"):
+        line["roofline_q6"] = roof(detail["roofline_q6"])
+    cb = detail.get("cpu_baseline")
+    if cb:
+        line["cpu_baseline"] = {"value": sig(cb["value"]), "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"],
+                                "sample": cb.get("sample_short", cb["sample"][:240]), "one_thread": sig(cb.get("one_thread", {}).get("value"))}
+    for name in ("strong", "weak"):
+        o = detail.get(name)
+        if o:
+            line[name] = {"error": o["error"][:120]} if "error" in o else {"value": sig(o["value"]), "ms_per_step": sig(o["ms_per_step"])}
+    q3 = detail.get("q3")
+    if q3:
+        if "error" in q3:
+            line["q3"] = {"error": q3["error"][:160]}
+        else:
+            line["q3"] = {"value": sig(q3["value"]), "ms_per_step": sig(q3["ms_per_step"]), "frac": sig(q3["roofline"]["frac"]),
+                          "cpu_rows_s": sig((q3.get("cpu_baseline") or {}).get("value"))}
+            if isinstance(q3.get("exchange"), dict):
+                line["q3"]["xgmi_GBps"] = sig(q3["exchange"].get("xgmi_GBps"))
+    h = detail.get("h2d")
+    if h:
+        line["h2d"] = {"error": h["error"][:120]} if "error" in h else {k: sig(h[k]) for k in ("value", "GBps", "frac") if k in h}
+        if "small_pages" in h and "error" not in h["small_pages"]:
+            line["h2d"]["small_pages_GBps"] = sig(h["small_pages"]["GBps"])
+    s3 = detail.get("sf300")
+    if s3:
+        line["sf300"] = {"error": s3["error"][:120]} if "error" in s3 else {"value": sig(s3["value"]), "ms_per_step": sig(s3["ms_per_step"]),
+                                                                           "q3_ms_per_step": sig((s3.get("q3") or {}).get("ms_per_step"))}
+    ops = detail.get("operators")
+    if ops:
+        if "error" in ops:
+            line["operators"] = {"error": ops["error"][:160]}
+        else:
+            o = {}
+            for e in ops.get("hash_agg", []):
+                o["agg_%dr_%dg" % (e["rows"], e["groups"])] = [sig(e["value"], 4), sig(e["frac"], 3)]
+            for i, e in enumerate(ops.get("hash_join", [])):
+                o["join%d_build" % i] = [sig(e["build"]["value"], 4), sig(e["build"]["frac"], 3)]
+                o["join%d_probe" % i] = [sig(e["probe"]["value"], 4), sig(e["probe"]["frac"], 3)]
+            for k in ("order_by", "topn"):
+                if k in ops:
+                    o[k] = [sig(ops[k]["value"], 4), sig(ops[k]["frac"], 3)]
+            line["operators"] = o
+    line["detail"] = os.path.basename(detail.get("detail_path", "bench_detail.json"))
+    text = json.dumps(line, separators=(",", ":"))
+    if len(text) >= LINE_LIMIT:   # never: but a line the driver cannot read is worth nothing -- drop side legs, biggest first
+        for k in ("operators", "sf300", "h2d", "roofline_q6", "strong", "weak", "q3"):
+            line.pop(k, None)
+            text = json.dumps(line, separators=(",", ":"))
+            if len(text) < LINE_LIMIT:
+                break
+    return text
+
+
+Q3_FAILED_EXIT_CODE = 3          # the line was printed, but a rank failed inside the Q3 leg (or the leg timed out)
+PREFLIGHT_FAILED_EXIT_CODE = 4   # the communicator did not come up (or its pre-flight found damaged bytes): nothing was measured
 
 
 def main(argv=None, workload_factory=None, out=None):
@@ -578,36 +726,44 @@ def main(argv=None, workload_factory=None, out=None):
         os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    import torch
-    import torch.distributed as dist
+    dist = None
     device = None
     make_workload = workload_factory or load_workload_class(args.workload)
     on_device = make_workload is DeviceWorkload
-    if on_device:
-        device = local_rank if args.backend == "nccl" else local_rank % max(torch.cuda.device_count(), 1)
-        torch.cuda.set_device(device)
     if world > 1:
+        # the control plane: torch.distributed over gloo, host tensors only.  torch's own HIP runtime stays uninitialised in a
+        # rank -- the GPU belongs to the library's ROCm stack (see the module docstring)
+        import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", device))
-        else:
-            dist.init_process_group(args.backend)
+        dist.init_process_group("gloo")
+    if on_device:
+        from presto_amd._lib import lib
+        n_dev = lib().pa_device_count()
+        if n_dev <= 0:
+            print("bench.py: no gfx950 device (pa_device_count = %d)" % n_dev, file=sys.stderr)
+            return 2
+        # RCCL: one rank per GPU.  Host transport (rehearsal): the ranks share what is there
+        device = local_rank if rccl_transport(args) else local_rank % n_dev
 
     workload = make_workload(args, rank, world, device)
     scaling = getattr(workload, "scaling", "weak")
+    comm = getattr(workload, "comm", None)
 
     def job_rows(w):
         return w.job_rows_per_step() if hasattr(w, "job_rows_per_step") else w.rows_per_step() * world
 
-    elapsed = timed_region(workload, dist, world, args.backend, workload.step, args.steps, args.warmup)
+    elapsed = timed_region(workload, dist, world, workload.step, args.steps, args.warmup)
     value = job_rows(workload) * args.steps / elapsed
 
-    # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command (profiles/pmc_traffic.json,
-    # written by scripts/summarize_profile.py); only valid for the default workload shape they were collected on
+    # HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json, written by
+    # scripts/summarize_profile.py), keyed by kernel name: a kernel whose generated code changed has another name and gets null
     pmc = {}
     pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(pmc_path) and args.sf == 100.0 and args.page_rows == 1 << 28 and (world == 1 or scaling == "weak"):
-        pmc = json.load(open(pmc_path)).get("kernels", {})
+    if os.path.exists(pmc_path) and world == 1:
+        try:
+            pmc = json.load(open(pmc_path)).get("kernels", {})
+        except ValueError:
+            pmc = {}
 
     emitted = False
     exit_code = 0
@@ -618,7 +774,7 @@ def main(argv=None, workload_factory=None, out=None):
             return
         emitted = True
         queries = workload.queries
-        line = {
+        detail = {
             "metric": "rows/s through operator pipeline, TPC-H Q1+Q6 SF100, 1/2/4/8 GPUs vs CPU ref",
             "value": value, "unit": "rows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
@@ -627,32 +783,39 @@ def main(argv=None, workload_factory=None, out=None):
                        "scale_factor_per_gpu": args.sf if scaling == "weak" else args.sf / world, "scale_factor_job": args.sf * (world if scaling == "weak" else 1),
                        "rows_per_gpu": workload.rows, "page_rows": args.page_rows,
                        "page_order": args.page_order,
-                       "queries": queries, "parallelism": "row-range shards, %d rank(s), no data-path collective in Q1/Q6%s; "
-                                                          "Q3 (the `q3` object) shuffles its join sides between the ranks"
-                                                          % (world, "" if world == 1 else " (Step.PARTIAL per rank, one small all-gather, Step.FINAL on rank 0, inside the step)")},
+                       "queries": queries, "parallelism": "row-range shards x%d%s" % (world, "" if world == 1 else ", PARTIAL per rank -> FINAL on rank 0 inside the step"),
+                       "parallelism_note": "no data-path collective in the Q1/Q6 scans; with more than one rank the Step.PARTIAL states travel in one small "
+                                           "all-gather over the library's communicator to the Step.FINAL operators on rank 0, inside the step; Q3 (the `q3` "
+                                           "object) shuffles its join sides between the ranks",
+                       "data_plane": None if world == 1 else ("RCCL (library's /opt/rocm stack)" if rccl_transport(args) else "host transport over gloo (rehearsal)"),
+                       "control_plane": None if world == 1 else "torch.distributed gloo (host tensors)"},
+            "detail_path": args.detail,
         }
+        if "torch" in sys.modules and on_device and world > 1:
+            import torch
+            detail["torch_cuda_initialized"] = bool(torch.cuda.is_initialized())
         r1 = workload.roofline("q1", args.steps, pmc) if "q1" in queries else None
         r6 = workload.roofline("q6", args.steps, pmc) if "q6" in queries else None
-        line["roofline"] = r1 or r6
+        detail["roofline"] = r1 or r6
         if r1 and r6:
-            line["roofline_q6"] = r6
+            detail["roofline_q6"] = r6
         if other is not None:
-            line[other["scaling"]] = other
+            detail[other["scaling"]] = other
         if q3 is not None:
-            line["q3"] = q3
-        line["results"] = {k: [[x.decode() if isinstance(x, bytes) else x for x in r] for r in v] for k, v in workload.results.items()}
+            detail["q3"] = q3
+        detail["results"] = {k: printable(v) for k, v in workload.results.items()}
         if side_legs and world == 1 and args.h2d_rows > 0 and hasattr(workload, "h2d"):
             try:
-                line["h2d"] = workload.h2d(args.h2d_rows)
+                detail["h2d"] = workload.h2d(args.h2d_rows)
             except Exception as e:
-                line["h2d"] = {"error": "%s: %s" % (type(e).__name__, e)}
+                detail["h2d"] = {"error": "%s: %s" % (type(e).__name__, e)}
         if side_legs and world == 1 and args.sf300 and args.sf == 100.0 and on_device:
             try:
                 workload.close()
                 workload = None
-                line["sf300"] = sf300_leg(args, dist, device)
+                detail["sf300"] = sf300_leg(args, dist, device)
             except Exception as e:
-                line["sf300"] = {"error": "%s: %s" % (type(e).__name__, e)}
+                detail["sf300"] = {"error": "%s: %s" % (type(e).__name__, e)}
         if side_legs and world == 1 and args.operators and on_device:
             try:
                 if workload is not None:
@@ -660,23 +823,30 @@ def main(argv=None, workload_factory=None, out=None):
                     workload = None
                 import gc
                 gc.collect()
-                torch.cuda.empty_cache()
                 import bench_ops
-                line["operators"] = bench_ops.run(cpu=args.cpu_rows > 0)
+                detail["operators"] = bench_ops.run(cpu=args.cpu_rows > 0)
             except Exception as e:
-                line["operators"] = {"error": "%s: %s" % (type(e).__name__, e)}
+                detail["operators"] = {"error": "%s: %s" % (type(e).__name__, e)}
         if side_legs and world == 1 and args.cpu_rows > 0:
-            line["cpu_baseline"] = cpu_baseline(args.sf, args.cpu_rows)
-            if isinstance(line.get("q3"), dict) and "error" not in line["q3"]:
+            detail["cpu_baseline"] = cpu_baseline(args.sf, args.cpu_rows)
+            if isinstance(detail.get("q3"), dict) and "error" not in detail["q3"]:
                 try:
-                    line["q3"]["cpu_baseline"] = q3_cpu_baseline()
+                    detail["q3"]["cpu_baseline"] = q3_cpu_baseline()
                 except Exception as e:
-                    line["q3"]["cpu_baseline"] = {"error": "%s: %s" % (type(e).__name__, e)}
+                    detail["q3"]["cpu_baseline"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        text = summary_line(detail)
+        detail["line"] = json.loads(text)
+        try:
+            with open(args.detail, "w") as f:
+                json.dump(detail, f, indent=1)
+        except OSError as e:
+            print("bench.py: could not write %s: %s" % (args.detail, e), file=sys.stderr)
+        print(json.dumps(detail), file=sys.stderr, flush=True)
         if out is not None:
-            print(json.dumps(line), file=out, flush=True)
+            print(text, file=out, flush=True)
         else:
             sys.stdout.flush()
-            os.write(line_fd, (json.dumps(line) + "\n").encode())
+            os.write(line_fd, (text + "\n").encode())
 
     # the other scaling mode, timed beside the headline (Q1 + Q6 only; its tables are generated now and released afterwards)
     other = None
@@ -684,15 +854,17 @@ def main(argv=None, workload_factory=None, out=None):
         other_mode = "strong" if scaling == "weak" else "weak"
         try:
             import inspect
-            kw = {"scaling": other_mode, "with_q3": False} if "scaling" in inspect.signature(make_workload).parameters else None
+            params = inspect.signature(make_workload).parameters
+            kw = {"scaling": other_mode, "with_q3": False} if "scaling" in params else None
             if kw is not None:
+                if "comm" in params:
+                    kw["comm"] = comm
                 w2 = make_workload(args, rank, world, device, **kw)
                 try:
-                    e2 = timed_region(w2, dist, world, args.backend, w2.step, args.steps, args.warmup)
+                    e2 = timed_region(w2, dist, world, w2.step, args.steps, args.warmup)
                     other = {"scaling": other_mode, "value": job_rows(w2) * args.steps / e2, "unit": "rows/s", "ms_per_step": e2 / args.steps * 1e3,
                              "steps": args.steps, "rows_per_gpu_rank0": w2.rows, "job_rows": job_rows(w2) // max(len(w2.queries), 1),
-                             "workload": w2.workload_name(),
-                             "results": {k: [[x.decode() if isinstance(x, bytes) else x for x in r] for r in v] for k, v in w2.results.items()}}
+                             "workload": w2.workload_name(), "results": {k: printable(v) for k, v in w2.results.items()}}
                     ro = w2.roofline("q1", args.steps, {}) if "q1" in w2.queries else None
                     if ro:
                         other["roofline_frac_q1_rank0"] = ro["frac"]
@@ -718,7 +890,7 @@ def main(argv=None, workload_factory=None, out=None):
     q3 = None
     if getattr(workload, "q3_on", False):
         try:
-            q3_elapsed = timed_region(workload, dist, world, args.backend, lambda timed: workload.q3_step(), args.steps, max(1, min(args.warmup, 2)))
+            q3_elapsed = timed_region(workload, dist, world, lambda timed: workload.q3_step(), args.steps, max(1, min(args.warmup, 2)))
             q3 = q3_line_object(args, workload, world, q3_elapsed, pmc)
         except Exception as e:  # the headline must survive a failing side leg
             q3 = {"error": "%s: %s" % (type(e).__name__, e)}
@@ -730,6 +902,11 @@ def main(argv=None, workload_factory=None, out=None):
         dist.barrier()  # (still under the watchdog: a rank whose Q3 leg failed arrives here while the others wait inside a collective)
         if watchdog is not None:
             watchdog.cancel()
+        if on_device and "torch" in sys.modules:
+            import torch
+            if torch.cuda.is_initialized():   # a second ROCm stack came up in this rank: the run is not what it claims to be
+                print("bench.py: torch's HIP runtime was initialised in rank %d" % rank, file=sys.stderr)
+                exit_code = exit_code or 5
         dist.destroy_process_group()
     if line_fd is not None:
         sys.stdout.flush()

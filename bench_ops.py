@@ -14,7 +14,10 @@ Device figures: W warm-ups + K measured runs, median and min of the wall time of
 device-resident pages, finish, getOutput into HBM, close; device drained), rows/s from the median.  `frac` = algorithmic bytes
 (the operator's input columns read once: SURVEY 8d's convention) / median time / 8 TB/s.  CPU figures: the oracle's operator
 (test infrastructure, C, one thread = one reference Driver) on the same pages or on a stated sample of them, one run each --
-they are reported baselines, not targets.  Only bench.py calls this module."""
+they are reported baselines, not targets.  Only bench.py calls this module.
+
+No torch here: the inputs are numpy arrays uploaded through the C ABI (pa_device_malloc + pa_memcpy_h2d) -- the process holds ONE
+ROCm stack, the library's."""
 import time
 
 HBM_PEAK_GBS = 8000.0
@@ -46,10 +49,26 @@ def _cpu(rows, seconds, what):
     return {"value": rows / seconds, "unit": "rows/s", "rows": rows, "seconds": seconds, "cores": 1, "kind": "port", "sample": what}
 
 
+class DeviceArray:
+    """A numpy array and its copy in HBM (the host copy feeds the CPU twin)."""
+
+    def __init__(self, host):
+        import numpy as np
+        from presto_amd._lib import DeviceAllocation, check, lib
+        self.host = np.ascontiguousarray(host)
+        self.alloc = DeviceAllocation(max(self.host.nbytes, 16))
+        check(lib().pa_memcpy_h2d(self.alloc.ptr, self.host.ctypes.data, self.host.nbytes, None))
+
+    def numel(self):
+        return self.host.size
+
+    def free(self):
+        self.alloc.free()
+
+
 def run(cpu=True):
     import numpy as np
-    import torch
-    from presto_amd import abi
+    from presto_amd import _lib, abi
     from presto_amd.operators import (HashAggregationOperator, HashBuilderOperator, LookupJoinOperator, LookupSourceFactory, OrderByOperator,
                                       TopNOperator)
     from presto_amd.page import Block, DeviceBuffer, Page
@@ -58,26 +77,26 @@ def run(cpu=True):
         O.build()
 
     def sync():
-        torch.cuda.synchronize()
+        _lib.device_synchronize()
 
     def dev_block(type_, t, first=0, n=None):
         n = t.numel() - first if n is None else n
-        w = t.element_size()
-        return Block(type_, abi.FLAT, n, values=DeviceBuffer(t.data_ptr() + w * first, w * n, t))
+        w = t.host.itemsize
+        return Block(type_, abi.FLAT, n, values=DeviceBuffer(t.alloc.ptr + w * first, w * n, t))
 
-    def host_page(types, tensors, n):
-        return Page([Block.flat(t, x[:n].cpu().numpy()) for t, x in zip(types, tensors)], n)
+    def host_page(types, arrays, n):
+        return Page([Block.flat(t, x.host[:n]) for t, x in zip(types, arrays)], n)
 
     out = {}
-    g = torch.Generator(device="cuda").manual_seed(1)
+    rng = np.random.default_rng(1)
 
     # ---- HashAggregation ----
     aggs = [(abi.AGG_SUM, 1, abi.DOUBLE), (abi.AGG_COUNT_STAR, -1, None)]
-    vals = torch.rand(1 << 26, dtype=torch.float64, device="cuda", generator=g)
+    vals = DeviceArray(rng.random(1 << 26))
     out["hash_agg"] = []
     for rows, groups, shape in ((10_000_000, 3_000_000, "BenchmarkGroupByHash.java:68-71"), (1 << 26, 4, None), (1 << 26, 1000, None),
                                 (1 << 26, 100_000, None), (1 << 26, 3_000_000, None)):
-        keys = torch.randint(0, groups, (rows,), dtype=torch.int64, device="cuda", generator=g)
+        keys = DeviceArray(rng.integers(0, groups, rows, dtype=np.int64))
         sync()
         chunk = 1 << 24
         pages = [Page([dev_block(abi.BIGINT, keys, i, min(chunk, rows - i)), dev_block(abi.DOUBLE, vals, i, min(chunk, rows - i))],
@@ -104,7 +123,8 @@ def run(cpu=True):
                                                          "(BigintGroupByHash, expectedGroups as on the device)" % n)
             ref.close()
         out["hash_agg"].append(e)
-        del keys, pages
+        del pages
+        keys.free()
 
     # ---- HashBuilder + LookupJoin ----
     types = [abi.BIGINT, abi.BIGINT]
@@ -112,8 +132,8 @@ def run(cpu=True):
 
     def join_case(name, bkeys, pkeys, shape, cpu_probe_rows):
         nb, npr = bkeys.numel(), pkeys.numel()
-        bpay = torch.arange(nb, dtype=torch.int64, device="cuda")
-        ppay = torch.arange(npr, dtype=torch.int64, device="cuda")
+        bpay = DeviceArray(np.arange(nb, dtype=np.int64))
+        ppay = DeviceArray(np.arange(npr, dtype=np.int64))
         sync()
         build = Page([dev_block(abi.BIGINT, bkeys), dev_block(abi.BIGINT, bpay)], nb, abi.MEM_DEVICE, stable=True)
         chunk = 1 << 24
@@ -164,6 +184,8 @@ def run(cpu=True):
             e["probe"]["cpu"] = _cpu(n, t2 - t1, "the first %d probe rows through the oracle's JoinProbe / DefaultPageJoiner" % n)
         state.pop("builder").close()
         state.pop("bridge").destroy()
+        bpay.free()
+        ppay.free()
         out["hash_join"].append(e)
 
     ref = "BenchmarkHashBuildAndJoinOperators.java:103-110,192-199,260-303"
@@ -171,12 +193,12 @@ def run(cpu=True):
         nb = 8_000_000
         max_value = nb // repetition + 40
         # addSequencePage(newRows, ..., (rows + 30) % maxValue, ...) page by page (1024 rows): BIGINT channel 1 = (rows + 30) % maxValue + i
-        i = torch.arange(nb, dtype=torch.int64, device="cuda")
-        bkeys = ((i // 1024 * 1024 + 30) % max_value + i % 1024).contiguous()
+        i = np.arange(nb, dtype=np.int64)
+        bkeys = DeviceArray((i // 1024 * 1024 + 30) % max_value + i % 1024)
         for match_rate in (0.1, 1, 2):
-            rng = np.random.default_rng(42)
+            prng = np.random.default_rng(42)
             remaining, keys = 1_400_000, []
-            rolls = rng.random(1_400_000)
+            rolls = prng.random(1_400_000)
             if match_rate < 1:
                 k = 30 + np.arange(remaining, 0, -1, dtype=np.int64)
                 keys = np.where(rolls > match_rate, -k, k)
@@ -188,21 +210,26 @@ def run(cpu=True):
                 keys = np.repeat(30 + rem, counts[:take])[:remaining]
             else:
                 keys = 30 + np.arange(remaining, 0, -1, dtype=np.int64)
-            pkeys = torch.from_numpy(np.ascontiguousarray(keys, dtype=np.int64)).cuda()
+            pkeys = DeviceArray(np.ascontiguousarray(keys, dtype=np.int64))
             join_case("8 M build rows x%d, 1.4 M probe rows, match rate %g" % (repetition, match_rate), bkeys, pkeys, ref, 1_400_000)
+            pkeys.free()
+        bkeys.free()
     nb = 15_000_000
-    unique = (torch.randperm(nb, device="cuda", generator=g).to(torch.int64) * 4).contiguous()
-    pkeys = torch.randint(0, nb * 8, (1 << 26,), dtype=torch.int64, device="cuda", generator=g)
+    unique = DeviceArray(rng.permutation(nb).astype(np.int64) * 4)
+    pkeys = DeviceArray(rng.integers(0, nb * 8, 1 << 26, dtype=np.int64))
     join_case("15 M unique random build keys, 2^26 random probe keys (one in eight matches)", unique, pkeys, None, 4_000_000)
-    dup = (torch.randint(0, nb // 5, (nb,), dtype=torch.int64, device="cuda", generator=g) * 4).contiguous()
-    pkeys5 = torch.randint(0, nb // 5 * 8, (1 << 26,), dtype=torch.int64, device="cuda", generator=g)
+    unique.free()
+    pkeys.free()
+    dup = DeviceArray(rng.integers(0, nb // 5, nb, dtype=np.int64) * 4)
+    pkeys5 = DeviceArray(rng.integers(0, nb // 5 * 8, 1 << 26, dtype=np.int64))
     join_case("15 M random build keys, about 5 rows per key, 2^26 random probe keys (one in eight matches, about 5 rows each)", dup, pkeys5, None, 2_000_000)
-    del unique, dup, pkeys, pkeys5
+    dup.free()
+    pkeys5.free()
 
     # ---- OrderBy / TopN ----
     rows = 1 << 26
-    v = torch.rand(rows, dtype=torch.float64, device="cuda", generator=g)
-    k = torch.randint(0, 1 << 40, (rows,), dtype=torch.int64, device="cuda", generator=g)
+    v = vals   # 2^26 uniform doubles
+    k = DeviceArray(rng.integers(0, 1 << 40, rows, dtype=np.int64))
     sync()
     srows = 1 << 24
     spage = Page([dev_block(abi.DOUBLE, v, 0, srows), dev_block(abi.BIGINT, k, 0, srows)], srows, abi.MEM_DEVICE)
@@ -217,7 +244,7 @@ def run(cpu=True):
     out["order_by"] = _entry(srows, srows * 16 * 2, med, best, shape="2^24 rows of (DOUBLE, BIGINT) by the BIGINT channel ascending; bytes = rows read + written once")
     if cpu:
         n = 1 << 22
-        kk = k[:n].cpu().numpy()
+        kk = np.ascontiguousarray(k.host[:n])
         t0 = time.perf_counter()
         O.sort_positions_bigint(kk)
         out["order_by"]["cpu"] = _cpu(n, time.perf_counter() - t0, "the first %d rows: PagesIndexOrdering.quickSort over row positions (oracle, C); "
@@ -233,7 +260,7 @@ def run(cpu=True):
     med, best = _timed(topn, sync, warmup=1, runs=5)
     out["topn"] = _entry(rows, rows * 16, med, best, shape="100 of 2^26 rows of (DOUBLE, BIGINT), DOUBLE descending then BIGINT ascending")
     if cpu:
-        vv, kk = v.cpu().numpy(), k.cpu().numpy()
+        vv, kk = v.host, k.host
         t0 = time.perf_counter()
         O.topn_positions_double_desc_bigint_asc(vv, kk, 100)
         out["topn"]["cpu"] = _cpu(rows, time.perf_counter() - t0, "the same page: TopNProcessor's bounded heap (oracle, C)")

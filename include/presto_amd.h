@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PA_ABI_VERSION 9
+#define PA_ABI_VERSION 10
 
 /* ---- status codes (negative = error).  Mapped by the JNI shim onto TrinoException
  *      StandardErrorCode (trino-spi/.../StandardErrorCode.java). ---- */
@@ -455,6 +455,7 @@ int32_t pa_host_free_pinned(void* ptr);
 int32_t pa_memcpy_h2d(void* dst, const void* src, int64_t bytes, void* stream);
 int32_t pa_memcpy_d2h(void* dst, const void* src, int64_t bytes, void* stream);
 int32_t pa_stream_synchronize(void* stream);
+int32_t pa_device_synchronize(void);   /* every stream of the calling thread's device has drained */
 /* The process's HBM budget for operator memory (the reference's memory pool, seen from the device): with a limit set, an
  * allocation that would exceed it fails with PA_ERR_INSUFFICIENT_RESOURCES -- except that an aggregation operator given a
  * PA_PAGE_STABLE page puts the page aside and reports pa_op_is_blocked() == 1 (needs_input 0) until other operators have
@@ -568,6 +569,10 @@ int32_t pa_op_close(pa_operator* op);
 /* Device time (ms) of the kernels the operator launched since creation, measured with HIP events
  * on the operator's stream; *launches = number of timed launches of its dominant kernel. */
 int32_t pa_op_kernel_time(pa_operator* op, double* total_ms, int64_t* launches);
+/* Name of that dominant kernel as a kernel trace (rocprofv3 --kernel-trace) shows it: generated kernels are called
+ * <entry>_<tier>_<first 8 hex digits of the code object's key>, e.g. pa_fused_lds_1f0c9a3e -- one name per plan and page layout.
+ * Empty until the operator has launched it. */
+int32_t pa_op_kernel_name(pa_operator* op, char* buf, int32_t buf_size);
 
 /* (probe position, build position) pairs of the probe page a LookupJoin operator joined last, in emission
  * order (DefaultPageJoiner.java:236-320), valid after its get_output; device pointers. */
@@ -648,6 +653,13 @@ int32_t pa_comm_rank(pa_comm* comm);
 int32_t pa_comm_world(pa_comm* comm);
 /* Small host-side reductions between the ranks (blocking): op 0 = SUM, 1 = MIN, 2 = MAX; values in place. */
 int32_t pa_comm_all_reduce_i64(pa_comm* comm, int64_t* values, int32_t count, int32_t op, void* stream);
+/* Every rank contributes `count` int64 of host memory and receives world * count in rank order (blocking): the Step.PARTIAL
+ * pages of a few-groups aggregation travel this way to the rank of the Step.FINAL operator (a few hundred bytes per rank). */
+int32_t pa_comm_all_gather_i64(pa_comm* comm, const int64_t* send, int64_t* recv, int32_t count, void* stream);
+/* Pre-flight of a fresh communicator (collective): a bytes_per_peer all-to-all, an all-reduce and an all-gather whose results
+ * every rank verifies.  PA_ERR_DEVICE when a byte arrived damaged.  A host runs it under its own watchdog: a transport whose peers
+ * never answer blocks inside RCCL. */
+int32_t pa_comm_preflight(pa_comm* comm, int64_t bytes_per_peer, void* stream);
 
 typedef struct pa_exchange_desc {
     int32_t channel_count;

@@ -10,8 +10,8 @@ final class GpuNative
 {
     static {
         System.loadLibrary("presto_amd_jni"); // links libpresto_amd.so
-        if (abiVersion() != 9) {
-            throw new IllegalStateException("libpresto_amd.so ABI version " + abiVersion() + " != 9");
+        if (abiVersion() != 10) {
+            throw new IllegalStateException("libpresto_amd.so ABI version " + abiVersion() + " != 10");
         }
     }
 

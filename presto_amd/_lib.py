@@ -81,6 +81,7 @@ def lib():
     L.pa_op_memory_bytes.argtypes = [vp]
     L.pa_op_memory_bytes.restype = C.c_int64
     L.pa_op_kernel_time.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+    L.pa_op_kernel_name.argtypes = [vp, C.c_char_p, C.c_int32]
     L.pa_hash_page.argtypes = [C.POINTER(abi.pa_page), C.c_int32, C.POINTER(C.c_int32), vp, vp]
     L.pa_partition_ids.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, vp, vp]
     L.pa_partition_positions.argtypes = [vp, C.c_int32, C.c_int32, vp, vp, vp]
@@ -117,6 +118,8 @@ def lib():
     L.pa_comm_rank.argtypes = [vp]
     L.pa_comm_world.argtypes = [vp]
     L.pa_comm_all_reduce_i64.argtypes = [vp, C.POINTER(C.c_int64), C.c_int32, C.c_int32, vp]
+    L.pa_comm_all_gather_i64.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_int32, vp]
+    L.pa_comm_preflight.argtypes = [vp, C.c_int64, vp]
     L.pa_exchange_create.argtypes = [C.POINTER(abi.pa_exchange_desc), vp, C.POINTER(vp)]
     L.pa_exchange_destroy.argtypes = [vp]
     L.pa_partitioned_output_create.argtypes = [vp, vp, C.POINTER(vp)]
@@ -138,6 +141,10 @@ def check(rc):
 def init(device=-1):
     """pa_init: binds the thread to a gfx950 device, fails loudly when there is none."""
     check(lib().pa_init(device))
+
+
+def device_synchronize():
+    check(lib().pa_device_synchronize())
 
 
 class DeviceAllocation:

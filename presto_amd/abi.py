@@ -5,7 +5,7 @@ test-only oracle binding (oracle/oracle.py), exactly as both C sides share the h
 """
 import ctypes as C
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 # pa_status
 OK = 0

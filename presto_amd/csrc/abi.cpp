@@ -255,6 +255,15 @@ int32_t pa_stream_synchronize(void* stream)
     });
 }
 
+int32_t pa_device_synchronize(void)
+{
+    return guarded([&]() -> int32_t {
+        require_device();
+        PA_HIP(hipDeviceSynchronize());
+        return PA_OK;
+    });
+}
+
 int32_t pa_memory_set_limit(int64_t bytes)
 {
     return guarded([&]() -> int32_t {
@@ -614,6 +623,22 @@ int32_t pa_comm_all_reduce_i64(pa_comm* comm, int64_t* values, int32_t count, in
         return PA_OK;
     });
 }
+int32_t pa_comm_all_gather_i64(pa_comm* comm, const int64_t* send, int64_t* recv, int32_t count, void* stream)
+{
+    return guarded([&]() -> int32_t {
+        PA_REQUIRE(comm != nullptr && send != nullptr && recv != nullptr && count > 0, PA_ERR_INVALID_ARGUMENT, "bad arguments");
+        comm_all_gather_i64(comm, send, recv, count, (hipStream_t)stream);
+        return PA_OK;
+    });
+}
+int32_t pa_comm_preflight(pa_comm* comm, int64_t bytes_per_peer, void* stream)
+{
+    return guarded([&]() -> int32_t {
+        PA_REQUIRE(comm != nullptr, PA_ERR_INVALID_ARGUMENT, "null argument");
+        comm_preflight(comm, bytes_per_peer, (hipStream_t)stream);
+        return PA_OK;
+    });
+}
 int32_t pa_exchange_create(const pa_exchange_desc* desc, pa_comm* comm, pa_exchange** out)
 {
     return guarded([&]() -> int32_t {
@@ -807,6 +832,16 @@ int32_t pa_op_kernel_time(pa_operator* op, double* total_ms, int64_t* launches)
         timer.drain();
         if (total_ms) *total_ms = timer.total_ms();
         if (launches) *launches = timer.launches();
+        return PA_OK;
+    });
+}
+int32_t pa_op_kernel_name(pa_operator* op, char* buf, int32_t buf_size)
+{
+    return guarded([&]() -> int32_t {
+        PA_REQUIRE(op != nullptr && buf != nullptr && buf_size > 0, PA_ERR_INVALID_ARGUMENT, "null argument");
+        OpScope scope(op);
+        const std::string& n = op->kernel_timer().name();
+        snprintf(buf, (size_t)buf_size, "%s", n.c_str());
         return PA_OK;
     });
 }

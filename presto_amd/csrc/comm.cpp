@@ -167,6 +167,67 @@ void comm_all_to_all_v(pa_comm* c, const void* send, const int64_t* send_off, co
     PA_NCCL(ncclGroupEnd());
 }
 
+// Pre-flight of a communicator: a `bytes_per_peer`-byte all-to-all whose every byte names (source rank, destination rank, position),
+// an all-reduce of a device word array and a host-side all-gather, each verified on the receiving side.  A mismatch is
+// PA_ERR_DEVICE with the first offending peer in the message; a transport that never answers is the caller's watchdog's to catch.
+void comm_preflight(pa_comm* c, int64_t bytes_per_peer, hipStream_t s)
+{
+    PA_REQUIRE(bytes_per_peer > 0 && bytes_per_peer % 8 == 0, PA_ERR_INVALID_ARGUMENT, "pre-flight payload must be a positive multiple of 8 bytes");
+    const int W = c->world;
+    const size_t per = (size_t)bytes_per_peer, total = per * (size_t)W;
+    auto pattern = [](int src, int dst, size_t i) { return (uint8_t)(src * 131 + dst * 31 + (int)(i * 2654435761u >> 24) + 7); };
+    PinnedBuf hs, hr;
+    DevBuf ds, dr;
+    uint8_t* a = static_cast<uint8_t*>(hs.ensure(total));
+    uint8_t* b = static_cast<uint8_t*>(hr.ensure(total));
+    for (int p = 0; p < W; p++) {
+        for (size_t i = 0; i < per; i++) a[(size_t)p * per + i] = pattern(c->rank, p, i);
+    }
+    memset(b, 0, total);
+    char* dsp = static_cast<char*>(ds.ensure(total));
+    char* drp = static_cast<char*>(dr.ensure(total));
+    PA_HIP(hipMemcpyAsync(dsp, a, total, hipMemcpyHostToDevice, s));
+    PA_HIP(hipMemsetAsync(drp, 0, total, s));
+    std::vector<int64_t> off((size_t)W), len((size_t)W, (int64_t)per);
+    for (int p = 0; p < W; p++) off[p] = (int64_t)per * p;
+    const int64_t before = c->payload_bytes_remote;
+    comm_all_to_all_v(c, dsp, off.data(), len.data(), drp, off.data(), len.data(), s);
+    PA_HIP(hipMemcpyAsync(b, drp, total, hipMemcpyDeviceToHost, s));
+    PA_HIP(hipStreamSynchronize(s));
+    c->payload_bytes_remote = before;  // (the statistics are the exchanges')
+    for (int p = 0; p < W; p++) {
+        for (size_t i = 0; i < per; i++) {
+            if (b[(size_t)p * per + i] != pattern(p, c->rank, i)) {
+                throw Error(PA_ERR_DEVICE, "communicator pre-flight: all-to-all byte " + std::to_string(i) + " from rank " + std::to_string(p) + " to rank " +
+                                               std::to_string(c->rank) + " arrived damaged");
+            }
+        }
+    }
+    // all-reduce: word i of rank r = (r + 1) * (i + 1); the sum over the ranks = W (W + 1) / 2 * (i + 1)
+    const int64_t words = std::min<int64_t>(bytes_per_peer / 8, 1 << 17);
+    uint64_t* w = reinterpret_cast<uint64_t*>(a);
+    for (int64_t i = 0; i < words; i++) w[i] = (uint64_t)(c->rank + 1) * (uint64_t)(i + 1);
+    PA_HIP(hipMemcpyAsync(dsp, w, (size_t)words * 8, hipMemcpyHostToDevice, s));
+    comm_all_reduce_sum_u64(c, reinterpret_cast<uint64_t*>(dsp), words, s);
+    PA_HIP(hipMemcpyAsync(b, dsp, (size_t)words * 8, hipMemcpyDeviceToHost, s));
+    PA_HIP(hipStreamSynchronize(s));
+    c->payload_bytes_remote = before;
+    const uint64_t* got = reinterpret_cast<const uint64_t*>(b);
+    for (int64_t i = 0; i < words; i++) {
+        if (got[i] != (uint64_t)W * (uint64_t)(W + 1) / 2 * (uint64_t)(i + 1)) {
+            throw Error(PA_ERR_DEVICE, "communicator pre-flight: all-reduce word " + std::to_string(i) + " is wrong on rank " + std::to_string(c->rank));
+        }
+    }
+    int64_t mine[2] = {c->rank, 0x5EED0000LL + c->rank};
+    std::vector<int64_t> all((size_t)2 * W);
+    comm_all_gather_i64(c, mine, all.data(), 2, s);
+    for (int p = 0; p < W; p++) {
+        if (all[(size_t)2 * p] != p || all[(size_t)2 * p + 1] != 0x5EED0000LL + p) {
+            throw Error(PA_ERR_DEVICE, "communicator pre-flight: all-gather slot " + std::to_string(p) + " is wrong on rank " + std::to_string(c->rank));
+        }
+    }
+}
+
 }  // namespace pa
 
 pa_comm::~pa_comm()

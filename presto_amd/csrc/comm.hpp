@@ -42,4 +42,7 @@ void comm_all_reduce_sum_u64(pa_comm* c, uint64_t* dev_words, int64_t words, hip
 void comm_all_to_all_v(pa_comm* c, const void* send, const int64_t* send_off, const int64_t* send_bytes, void* recv, const int64_t* recv_off,
                        const int64_t* recv_bytes, hipStream_t s);
 
+// checked all-to-all + all-reduce + all-gather over the communicator (collective; see comm.cpp)
+void comm_preflight(pa_comm* c, int64_t bytes_per_peer, hipStream_t s);
+
 }  // namespace pa

@@ -260,6 +260,9 @@ public:
     }
     double total_ms() const { return total_ms_; }
     int64_t launches() const { return launches_; }
+    // the dominant kernel's name as a kernel trace shows it (pa_op_kernel_name); set by the operator at its launch
+    void set_name(const std::string& n) { if (name_ != n) name_ = n; }
+    const std::string& name() const { return name_; }
 
 private:
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pairs_;
@@ -268,6 +271,7 @@ private:
     uint64_t begun_ = 0;
     double total_ms_ = 0;
     int64_t launches_ = 0;
+    std::string name_;
 };
 
 int device_cu_count();

@@ -57,7 +57,12 @@ KernelInfo FusedGen::run()
     }
     k.variant = variant;
     k.ranged = ranged;
-    k.entry = ranged ? "pa_fused_ranges" : "pa_fused";
+    // entry names carry the tier (and "probe" behind a probe stage); the translation unit appends the first 8 hex digits of the
+    // code object's key (PA_K, jit.cpp), so that a kernel trace tells the plans apart: pa_fused_lds_<key8>, pa_fused_probe_brow_<key8> ...
+    {
+        static const char* const kTierName[] = {"global", "lds", "gt", "ldsh", "hash", "ldsp", "brow"};
+        k.entry = std::string("pa_fused_") + (s.join ? "probe_" : "") + kTierName[variant] + (ranged ? "_ranges" : "");
+    }
     k.block = variant == V_LDS ? 64 : 256;
     k.c = variant == V_LDS ? kLdsSlots : 0;
 
@@ -105,14 +110,14 @@ KernelInfo FusedGen::run()
     // wave-uniform trip count, finished lanes riding along with live == false on a clamped row.  Two entry points keep the
     // tail's code out of the hot loop's register allocation.
     if (ranged) {
-        emit_kernel("pa_fused_ranges", 3);
+        emit_kernel(k.entry, 3);
     }
     else if (variant == V_LDS) {
-        emit_kernel("pa_fused", 1);
-        emit_kernel("pa_fused_tail", 2);
+        emit_kernel(k.entry, 1);
+        emit_kernel(k.entry + "_tail", 2);
     }
     else {
-        emit_kernel("pa_fused", 0);
+        emit_kernel(k.entry, 0);
     }
     if (brow) brow_keys_kernel();
     k.source = src.str();
@@ -435,9 +440,9 @@ void FusedGen::emit_quad(const std::string (&args)[4])
     for (int r = 0; r < 4; r++) src << "        pa_row(a, acc, true, (i32)(4 * q + " << r << ")" << args[r] << ");\n";
 }
 
-void FusedGen::emit_kernel(const char* name, int mode)
+void FusedGen::emit_kernel(const std::string& name, int mode)
 {
-    src << "extern \"C\" __global__ __launch_bounds__(" << B << ") void " << name << "(PaFusedArgs a)\n{\n";
+    src << "extern \"C\" __global__ __launch_bounds__(" << B << ") void PA_K(" << name << ")(PaFusedArgs a)\n{\n";
     if (variant == V_GLOBAL) global_kernel_begin();
     else if (variant == V_LDS) lds_kernel_begin();
     else if (variant == V_LDSP) ldsp_kernel_begin();

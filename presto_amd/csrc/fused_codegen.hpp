@@ -92,7 +92,7 @@ struct FusedGen {
     void state_layout_id();
     void row_function();
     void emit_quad(const std::string (&args)[4]);
-    void emit_kernel(const char* name, int mode);
+    void emit_kernel(const std::string& name, int mode);
     void ranges_loop();
     void page_loop();
     void table_counter_flush();

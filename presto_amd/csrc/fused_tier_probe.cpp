@@ -289,7 +289,7 @@ void FusedGen::brow_keys_kernel()
 {
     // key words of the groups, once per group: build row b has a group when its tag is set; its key is a function of the
     // build columns (the probe join key equals the build key column on every match)
-    src << "extern \"C\" __global__ __launch_bounds__(256) void pa_brow_keys(PaFusedArgs a)\n{\n"
+    src << "extern \"C\" __global__ __launch_bounds__(256) void PA_K(pa_brow_keys)(PaFusedArgs a)\n{\n"
            "    const i64 cap = (i64)a.gt_mask + 1;\n"
            "    i64 found = 0;\n"
            "    for (i64 b = (i64)blockIdx.x * 256 + threadIdx.x; b < cap; b += (i64)gridDim.x * 256) {\n"

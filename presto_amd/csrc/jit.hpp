@@ -17,6 +17,7 @@ namespace pa {
 struct JitKernel {
     hipModule_t module = nullptr;
     hipFunction_t fn = nullptr;
+    std::string name;  // the kernel's name in the code object: `entry`_<first 8 hex digits of the key> (what a kernel trace shows)
 };
 
 // FNV-1a 64 of the generated source (+ device header + options): the cache key.
@@ -25,7 +26,8 @@ std::string jit_key(const std::string& source);
 // Full translation unit for `source` (device header prepended), as written to prebuilt/<key>.hip.
 std::string jit_translation_unit(const std::string& source);
 
-// Returns the kernel named `entry` of the code object generated from `source`.
+// Returns the kernel `entry` of the code object generated from `source` (the source defines it as PA_K(entry): its name in the
+// code object is entry_<key8>).
 JitKernel jit_get(const std::string& source, const std::string& entry);
 
 // Compile only (no device needed): returns the code object bytes; used by the CPU-side tests and by

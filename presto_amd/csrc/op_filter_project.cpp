@@ -340,7 +340,7 @@ FpKernelInfo generate_fp(const FpSpec& s, const std::vector<ChannelLayout>& layo
 
     const std::string J = std::to_string(kTileQuads);
     if (s.has_filter) {
-        src << "extern \"C\" __global__ __launch_bounds__(256) void pa_fp_count(PaFpArgs a)\n{\n";
+        src << "extern \"C\" __global__ __launch_bounds__(256) void PA_K(pa_fp_count)(PaFpArgs a)\n{\n";
         src << prologue.str();
         src << tile_decl << "    i32 mine = 0;\n";
         src << "#pragma unroll\n    for (int pa_j = 0; pa_j < " << J << "; pa_j++) {\n";
@@ -361,7 +361,7 @@ FpKernelInfo generate_fp(const FpSpec& s, const std::vector<ChannelLayout>& layo
         src << "    i32 total;\n    (void)pa_block_exclusive_scan_256(mine, &total);\n";
         src << "    if (threadIdx.x == 0) a.tile_counts[pa_tile] = total;\n}\n\n";
     }
-    src << "extern \"C\" __global__ __launch_bounds__(256) void pa_fp_scatter(PaFpArgs a)\n{\n";
+    src << "extern \"C\" __global__ __launch_bounds__(256) void PA_K(pa_fp_scatter)(PaFpArgs a)\n{\n";
     src << prologue.str();
     src << tile_decl;
     if (s.has_filter) {
@@ -524,6 +524,7 @@ public:
             a.positions = static_cast<int32_t*>(positions_.ensure((size_t)n * 4));
             a.tile_offsets = a.tile_counts;  // scanned in place
             void* params[] = {&a};
+            timer.set_name(ck.name);
             timer.begin(s);
             if (!external) PA_HIP(hipModuleLaunchKernel(ck.count_fn, (unsigned)tiles, 1, 1, 256, 1, 1, 0, s, params, nullptr));
             launch_exclusive_scan_i32(a.tile_counts, a.tile_counts, tiles, ctl_ + 1, scan_temp_.ensure(scan_temp_bytes(tiles)), s);
@@ -749,6 +750,7 @@ private:
     struct Compiled {
         FpKernelInfo info;
         hipFunction_t count_fn = nullptr, scatter_fn = nullptr;
+        std::string name;  // of the kernel that reads the page first (pa_op_kernel_name)
     };
 
     // One code object per (plan, column-layout signature, variant, device), shared by every operator instance of the process: an operator
@@ -805,8 +807,16 @@ private:
         }
         auto c = std::make_shared<Compiled>();
         c->info = generate_fp(sp, layout);
-        if (sp.has_filter && !sp.filter_external) c->count_fn = jit_get(c->info.source, "pa_fp_count").fn;
-        if (variant != 1) c->scatter_fn = jit_get(c->info.source, "pa_fp_scatter").fn;
+        if (variant != 1) {
+            JitKernel k = jit_get(c->info.source, "pa_fp_scatter");
+            c->scatter_fn = k.fn;
+            c->name = k.name;
+        }
+        if (sp.has_filter && !sp.filter_external) {
+            JitKernel k = jit_get(c->info.source, "pa_fp_count");
+            c->count_fn = k.fn;
+            c->name = k.name;
+        }
         {
             std::lock_guard<std::mutex> lock(shared_mutex());
             shared_cache()[shared_key] = c;

@@ -109,6 +109,10 @@ class Comm:
         check(lib().pa_comm_create_host(C.byref(t), rank, world, C.byref(h)))
         return Comm(h, rank, world, keep=t)
 
+    def preflight(self, bytes_per_peer=1 << 20, stream=None):
+        """pa_comm_preflight: a checked all-to-all + all-reduce + all-gather over the fresh communicator (collective)."""
+        check(lib().pa_comm_preflight(self._h, bytes_per_peer, stream))
+
     def allReduce(self, values, op=abi.COMM_SUM, stream=None):
         arr = (C.c_int64 * len(values))(*[int(v) for v in values])
         check(lib().pa_comm_all_reduce_i64(self._h, arr, len(values), op, stream))
@@ -237,6 +241,29 @@ def partial_layout(key_types, aggregates):
     return types, final
 
 
+def _state_payload(page):
+    """A host Page of intermediate states as (type, type parameter, python values) per channel -- what travels between the ranks."""
+    if page is None or page.position_count == 0:
+        return None
+    params = getattr(page, "type_params", None) or [0] * len(page.blocks)
+    return [(int(b.type), int(params[k]) if k < len(params) else 0, b.to_pylist()) for k, b in enumerate(page.blocks)]
+
+
+def _state_page(cols):
+    """The host Page of a received payload; every channel type of a PARTIAL state (include/presto_amd.h): BIGINT counts, DOUBLE /
+    BIGINT / DECIMAL(38, s) sums (LONG_DECIMAL: two words per value), min / max values of any type, VARCHAR keys."""
+    blocks = []
+    for t, _param, values in cols:
+        if t == abi.VARCHAR:
+            blocks.append(Block.varchar(values))
+        elif t == abi.LONG_DECIMAL:
+            blocks.append(Block.long_decimal(values))      # None = NULL
+        else:
+            nulls = [v is None for v in values]
+            blocks.append(Block.flat(t, [0 if v is None else v for v in values], nulls if any(nulls) else None))
+    return Page(blocks, len(cols[0][2]) if cols else 0)
+
+
 def merge_partial_aggregations(partial_page, make_final_operator, group=None, dst=0):
     """The FINAL step of a row-range-sharded aggregation (HashAggregationOperator Step.PARTIAL on every rank ->
     Step.FINAL on one; the reference ships the partial pages through its exchange).  `partial_page` is this rank's
@@ -245,25 +272,15 @@ def merge_partial_aggregations(partial_page, make_final_operator, group=None, ds
     import torch.distributed as dist
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
-    payload = None
-    if partial_page is not None and partial_page.position_count > 0:
-        payload = [(b.type, b.to_pylist()) for b in partial_page.blocks]
     gathered = [None] * world
-    dist.all_gather_object(gathered, payload, group=group)
+    dist.all_gather_object(gathered, _state_payload(partial_page), group=group)
     if rank != dst:
         return None
     op = make_final_operator()
     for cols in gathered:  # rank order: a fixed combine order
         if cols is None:
             continue
-        blocks = []
-        for t, values in cols:
-            nulls = [v is None for v in values]
-            if t == abi.VARCHAR:
-                blocks.append(Block.varchar(values))
-            else:
-                blocks.append(Block.flat(t, [0 if v is None else v for v in values], nulls))
-        op.addInput(Page(blocks, len(cols[0][1]) if cols else 0))
+        op.addInput(_state_page(cols))
     op.finish()
     return op.getOutput()
 
@@ -272,65 +289,66 @@ class PartialStateMerger:
     """The FINAL step of row-range-sharded aggregations, for a step loop: ONE fixed-size all-gather per call carries the Step.PARTIAL
     pages of several aggregations (Q1: 4 rows, Q6: 1 row per rank), the FINAL operators run on rank `dst` over the ranks' pages
     in rank order -- a fixed combine order (HashAggregationOperator.java:390 Step.PARTIAL -> Step.FINAL;
-    DoubleSumAggregation.java:47-52 combine).  Same result as merge_partial_aggregations; the buffers are made once."""
+    DoubleSumAggregation.java:47-52 combine).  Same result as merge_partial_aggregations; the buffers are made once.
 
-    CAPACITY = 1 << 15   # bytes per rank and call
+    comm: a Comm -- the all-gather runs over the library's communicator (pa_comm_all_gather_i64: RCCL over xGMI, or the host
+    transport); None: over torch.distributed host tensors of `group` (CPU ranks of the tests)."""
 
-    def __init__(self, group=None, dst=0, device=None):
-        import torch
-        import torch.distributed as dist
-        self.dist, self.group, self.dst = dist, group, dst
-        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
-        self.device = device   # "cuda" tensors for the nccl backend, None (host) for gloo
-        self.send = torch.zeros(self.CAPACITY, dtype=torch.uint8, device=device or "cpu")
-        self.recv = torch.zeros(self.CAPACITY * self.world, dtype=torch.uint8, device=device or "cpu")
-        self.stage = torch.zeros(self.CAPACITY, dtype=torch.uint8).pin_memory() if device else self.send
-        self.copied = None
+    CAPACITY = 1 << 13   # bytes per rank and call
+
+    def __init__(self, group=None, dst=0, comm=None):
+        self.group, self.dst, self.comm = group, dst, comm
+        if comm is not None:
+            self.world, self.rank = comm.world, comm.rank
+            words = self.CAPACITY // 8
+            self.send = (C.c_int64 * words)()
+            self.recv = (C.c_int64 * (words * self.world))()
+        else:
+            import torch
+            import torch.distributed as dist
+            self.dist = dist
+            self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+            self.send = torch.zeros(self.CAPACITY, dtype=torch.uint8)
+            self.recv = torch.zeros(self.CAPACITY * self.world, dtype=torch.uint8)
+
+    def _all_gather(self, blob):
+        """blob (bytes, <= CAPACITY) of every rank -> list of CAPACITY-byte chunks in rank order"""
+        if self.comm is not None:
+            C.memmove(self.send, blob, len(blob))
+            check(lib().pa_comm_all_gather_i64(self.comm._h, self.send, self.recv, self.CAPACITY // 8, None))
+            got = bytes(self.recv)
+        else:
+            import numpy as np
+            import torch
+            self.send[:len(blob)] = torch.from_numpy(np.frombuffer(blob, dtype=np.uint8).copy())
+            self.dist.all_gather_into_tensor(self.recv, self.send, group=self.group)
+            got = self.recv.numpy().tobytes()
+        return [got[r * self.CAPACITY:(r + 1) * self.CAPACITY] for r in range(self.world)]
 
     def merge(self, partial_pages, make_final_operator):
         """partial_pages: {name: host Page | None} on every rank (same names everywhere); make_final_operator: {name: () -> Operator};
         returns {name: final host Page | None} on rank dst, None elsewhere.  Collective."""
         import pickle
-        import numpy as np
-        import torch
-        payload = {}
-        for name, page in partial_pages.items():
-            payload[name] = None if page is None or page.position_count == 0 else [(b.type, b.to_pylist()) for b in page.blocks]
+        import struct
+        payload = {name: _state_payload(page) for name, page in partial_pages.items()}
         blob = pickle.dumps(payload, protocol=pickle.HIGHEST_PROTOCOL)
         if len(blob) + 8 > self.CAPACITY:
             raise ValueError("partial aggregation states of %d bytes: not a few-groups result, use an exchange" % len(blob))
-        head = np.frombuffer(np.int64(len(blob)).tobytes() + blob, dtype=np.uint8)
-        if self.device and self.copied is not None:
-            self.copied.synchronize()   # the previous call's copy out of the pinned staging buffer has left it
-        self.stage[:len(head)] = torch.from_numpy(head.copy())
-        if self.device:
-            self.send.copy_(self.stage, non_blocking=True)
-            self.copied = torch.cuda.Event()
-            self.copied.record()
-        self.dist.all_gather_into_tensor(self.recv, self.send, group=self.group)
+        chunks = self._all_gather(struct.pack("<q", len(blob)) + blob)
         if self.rank != self.dst:
             return None
-        got = self.recv.cpu().numpy()
-        out = {}
         per_rank = []
-        for r in range(self.world):
-            chunk = got[r * self.CAPACITY:(r + 1) * self.CAPACITY]
-            n = int(np.frombuffer(chunk[:8].tobytes(), dtype=np.int64)[0])
-            per_rank.append(pickle.loads(chunk[8:8 + n].tobytes()))
+        for chunk in chunks:
+            n = struct.unpack("<q", chunk[:8])[0]
+            per_rank.append(pickle.loads(chunk[8:8 + n]))
+        out = {}
         for name in partial_pages:
             op = make_final_operator[name]()
             for payload in per_rank:   # rank order
                 cols = payload[name]
                 if cols is None:
                     continue
-                blocks = []
-                for t, values in cols:
-                    if t == abi.VARCHAR:
-                        blocks.append(Block.varchar(values))
-                    else:
-                        nulls = [v is None for v in values]
-                        blocks.append(Block.flat(t, [0 if v is None else v for v in values], nulls if any(nulls) else None))
-                op.addInput(Page(blocks, len(cols[0][1])))
+                op.addInput(_state_page(cols))
             op.finish()
             out[name] = op.getOutput()
             if hasattr(op, "close"):

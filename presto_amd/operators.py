@@ -68,6 +68,12 @@ class Operator:
         check(lib().pa_op_kernel_time(self._h, C.byref(ms), C.byref(n)))
         return ms.value, n.value
 
+    def kernelName(self):
+        """Name of that kernel as a kernel trace shows it (pa_fused_<tier>_<key8>); '' before its first launch."""
+        buf = C.create_string_buffer(128)
+        check(lib().pa_op_kernel_name(self._h, buf, 128))
+        return buf.value.decode()
+
     def selectedPositions(self):
         """FilterAndProject only: SelectedPositions of the last page -> (is_list, ndarray | count)."""
         ptr, count, is_list = C.c_void_p(), C.c_int32(), C.c_int32()

@@ -172,6 +172,7 @@ def run(customer_pages, orders_pages, lineitem_pages, stream, comm=None, expecte
     if fused_probe and not distributed:
         # HIP-event time of the fused filter -> probe -> aggregate launches (pa_op_kernel_time of the handle)
         counters["lineitem_fused_kernel_ms"], counters["lineitem_fused_launches"] = head[0].kernelTime()
+        counters["lineitem_fused_kernel"] = head[0].kernelName()
     counters["build1_rows"] = b1.positionCount()
     counters["build2_rows"] = b2.positionCount()
     if exchanges:

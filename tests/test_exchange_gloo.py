@@ -272,12 +272,30 @@ def bench_worker(rank, world, port, result_queue):
         return seen["w"]
 
     out = io.StringIO()
-    bench.main(["--gpus", str(world), "--steps", "2", "--warmup", "1", "--sf", "0.002", "--cpu-rows", "0", "--backend", "gloo"],
-               workload_factory=factory, out=out)
+    detail = os.path.join(os.environ.get("BENCH_TEST_DIR", "/tmp"), "bench_detail_8.json")
+    bench.main(["--gpus", str(world), "--steps", "2", "--warmup", "1", "--sf", "0.002", "--cpu-rows", "0", "--backend", "gloo", "--scaling", "weak",
+                "--detail", detail], workload_factory=factory, out=out)
     result_queue.put((rank, out.getvalue(), seen["w"].results.get("q3")))
 
 
-def test_bench_control_flow_on_eight_gloo_ranks(oracle):
+CONTRACT_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+                 "config", "roofline")
+
+
+def check_line_shape(text):
+    """What the driver needs of the stdout line: ONE line, far below the ~8 KB of stdout it keeps, parseable from its tail, with
+    the contract's keys."""
+    import bench
+    assert text.count("\n") == 1 and text.endswith("\n")
+    assert len(text) < bench.LINE_LIMIT, len(text)
+    line = json.loads(text[-8000:])   # the driver's view: the last 8000 bytes of stdout
+    for k in CONTRACT_KEYS:
+        assert k in line, k
+    assert isinstance(line["config"]["workload"], str) and "model" not in line["config"]
+    return line
+
+
+def test_bench_control_flow_on_eight_gloo_ranks(oracle, tmp_path, monkeypatch):
     """bench.py --gpus 8 --backend gloo with the checker workload: one JSON line from rank 0 only, whole-job value over the
     max-over-ranks clock, a `q3` object whose exchange steps ran between 8 ranks -- and the union of the ranks' Q3 top-10
     rows holds the single-process top 10."""
@@ -285,14 +303,18 @@ def test_bench_control_flow_on_eight_gloo_ranks(oracle):
     from tests.rehearsal_workload import host_table
     from tests.test_gpu_q3_pipeline import oracle_q3
     world, sf = 8, 0.002
+    monkeypatch.setenv("BENCH_TEST_DIR", str(tmp_path))
     results = run_ranks(bench_worker, world, timeout=300)
     lines = [r[1] for r in results]
-    assert all(l == "" for l in lines[1:]) and lines[0].count("\n") == 1
-    line = json.loads(lines[0])
+    assert all(l == "" for l in lines[1:])
+    line = check_line_shape(lines[0])
+    detail = json.load(open(tmp_path / "bench_detail_8.json"))
+    assert detail["line"] == line
     rows = tpch.lineitem_rows(sf)
     assert line["n_gpus"] == world and line["scaling"] == "weak" and line["steps"] == 2 and line["unit"] == "rows/s"
-    assert abs(line["value"] - 2 * rows * 2 * world / (line["ms_per_step"] * 2 / 1e3)) <= 1e-6 * line["value"]
-    assert "error" not in line["q3"] and line["q3"]["value"] > 0 and line["q3"]["input_rows_per_gpu"] == sum(
+    assert abs(detail["value"] - 2 * rows * 2 * world / (detail["ms_per_step"] * 2 / 1e3)) <= 1e-6 * detail["value"]
+    assert abs(line["value"] - detail["value"]) <= 1e-5 * detail["value"]
+    assert "error" not in line["q3"] and line["q3"]["value"] > 0 and detail["q3"]["input_rows_per_gpu"] == sum(
         (tpch.customer_rows(sf), tpch.orders_rows(sf), tpch.lineitem_rows(sf)))
     # Q3 parity of the sharded run: global top 10 = top 10 of the union of the ranks' (disjoint) groups
     total = sf * world
@@ -322,7 +344,7 @@ def bench_worker_one_rank_fails(rank, world, port, path):
 
     with open("%s.%d" % (path, rank), "w") as out:
         sys.exit(bench.main(["--gpus", str(world), "--steps", "1", "--warmup", "1", "--sf", "0.002", "--cpu-rows", "0", "--backend", "gloo",
-                             "--q3-timeout", "8", "--other-scaling", "0"], workload_factory=FailsOnRankOne, out=out))
+                             "--q3-timeout", "8", "--other-scaling", "0", "--detail", path + ".detail"], workload_factory=FailsOnRankOne, out=out))
 
 
 def test_bench_line_survives_a_rank_failing_inside_q3(oracle, tmp_path):
@@ -339,8 +361,8 @@ def test_bench_line_survives_a_rank_failing_inside_q3(oracle, tmp_path):
     import bench
     assert all(p.exitcode == bench.Q3_FAILED_EXIT_CODE for p in procs)
     text = open(path + ".0").read()
-    assert text.count("\n") == 1 and open(path + ".1").read() == ""
-    line = json.loads(text)
+    assert open(path + ".1").read() == ""
+    line = check_line_shape(text)
     assert line["n_gpus"] == world and line["value"] > 0 and "error" in line["q3"]
 
 
@@ -370,38 +392,72 @@ def check_q1_q6(results, q6_sum, q1_rows):
         assert all(abs(a - b) <= 1e-9 * abs(b) for a, b in zip(g[2:-1], e[2:-1]))
 
 
-def test_bench_launches_its_own_ranks(oracle):
+def test_bench_launches_its_own_ranks(oracle, tmp_path):
     """`python bench.py --gpus 8` with no torchrun environment starts 8 ranks itself (before anything touches a GPU), prints ONE
-    line with n_gpus 8, the weak headline and the `strong` object (the ONE SF table split by row range), both with the
-    PARTIAL -> FINAL merge inside the step: the merged results are those of one process over the whole tables."""
+    line with n_gpus 8, the STRONG headline (the metric's mode: the ONE SF table split by row range) and the `weak` object, both with
+    the PARTIAL -> FINAL merge inside the step: the merged results are those of one process over the whole tables."""
     from presto_amd import tpch
     world, sf = 8, 0.002
+    path = str(tmp_path / "detail.json")
     r = run_bench(["--gpus", str(world), "--backend", "gloo", "--workload", "tests.rehearsal_workload:RehearsalWorkload", "--sf", str(sf),
-                   "--steps", "2", "--warmup", "1", "--cpu-rows", "0"])
+                   "--steps", "2", "--warmup", "1", "--cpu-rows", "0", "--detail", path])
     assert r.returncode == 0, r.stderr.decode()[-2000:]
-    text = r.stdout.decode()
-    assert text.count("\n") == 1
-    line = json.loads(text)
-    assert line["n_gpus"] == world and line["scaling"] == "weak" and line["strong"]["scaling"] == "strong"
+    line = check_line_shape(r.stdout.decode())
+    detail = json.load(open(path))
+    assert line["n_gpus"] == world and line["scaling"] == "strong" and detail["weak"]["scaling"] == "weak" and line["weak"]["value"] > 0
     rows = tpch.lineitem_rows(sf)
-    assert abs(line["value"] - 2 * rows * world * 2 / (line["ms_per_step"] * 2 / 1e3)) <= 1e-6 * line["value"]
-    assert line["strong"]["job_rows"] == rows
-    assert abs(line["strong"]["value"] - 2 * rows * 2 / (line["strong"]["ms_per_step"] * 2 / 1e3)) <= 1e-6 * line["strong"]["value"]
-    assert "error" not in line["q3"] and line["q3"]["exchange"]["transport"].startswith("host transport")
-    check_q1_q6(line["results"], *oracle_q1_q6(oracle, sf * world, rows * world))   # weak: the SF x 8 table
-    check_q1_q6(line["strong"]["results"], *oracle_q1_q6(oracle, sf, rows))          # strong: the SF table
+    assert abs(detail["value"] - 2 * rows * 2 / (detail["ms_per_step"] * 2 / 1e3)) <= 1e-6 * detail["value"]
+    assert detail["weak"]["job_rows"] == rows * world
+    assert abs(detail["weak"]["value"] - 2 * rows * world * 2 / (detail["weak"]["ms_per_step"] * 2 / 1e3)) <= 1e-6 * detail["weak"]["value"]
+    assert "error" not in detail["q3"] and detail["q3"]["exchange"]["transport"].startswith("host transport")
+    check_q1_q6(detail["results"], *oracle_q1_q6(oracle, sf, rows))                         # strong: the SF table
+    check_q1_q6(detail["weak"]["results"], *oracle_q1_q6(oracle, sf * world, rows * world))   # weak: the SF x 8 table
 
 
-def test_bench_strong_headline_on_two_ranks(oracle):
+def test_bench_weak_headline_on_two_ranks(oracle, tmp_path):
     from presto_amd import tpch
     sf = 0.002
+    path = str(tmp_path / "detail.json")
     r = run_bench(["--gpus", "2", "--backend", "gloo", "--workload", "tests.rehearsal_workload:RehearsalWorkload", "--sf", str(sf), "--steps", "1",
-                   "--warmup", "1", "--cpu-rows", "0", "--scaling", "strong", "--q3", "0"])
+                   "--warmup", "1", "--cpu-rows", "0", "--scaling", "weak", "--q3", "0", "--detail", path])
     assert r.returncode == 0, r.stderr.decode()[-2000:]
-    line = json.loads(r.stdout.decode())
-    assert line["scaling"] == "strong" and line["weak"]["scaling"] == "weak" and line["n_gpus"] == 2
-    check_q1_q6(line["results"], *oracle_q1_q6(oracle, sf, tpch.lineitem_rows(sf)))
-    check_q1_q6(line["weak"]["results"], *oracle_q1_q6(oracle, sf * 2, tpch.lineitem_rows(sf) * 2))
+    line = check_line_shape(r.stdout.decode())
+    detail = json.load(open(path))
+    assert line["scaling"] == "weak" and detail["strong"]["scaling"] == "strong" and line["n_gpus"] == 2
+    check_q1_q6(detail["results"], *oracle_q1_q6(oracle, sf * 2, tpch.lineitem_rows(sf) * 2))
+    check_q1_q6(detail["strong"]["results"], *oracle_q1_q6(oracle, sf, tpch.lineitem_rows(sf)))
+
+
+def test_summary_line_of_a_full_detail_object_stays_small():
+    """The line bench.py prints is a summary of the detail object: with every side leg present (the shape of a default N = 1 run,
+    operator benchmarks included) it stays below 4 KB and its last 8000 bytes parse."""
+    import bench
+    roof = {"bound": "hbm", "kernel": "pa_fused_lds_0123abcd", "query": "q1", "achieved": 6063.123456789, "peak": 8000.0, "unit": "GB/s", "frac": 0.757890123,
+            "traffic": 7.05e9, "traffic_source": "x" * 300, "avg_launch_ms": 1.138123456, "launches": 80, "algorithmic_bytes_per_launch": 6.9e9,
+            "rows_per_launch": 1.5e8}
+    cpu = {"value": 2.4e8, "unit": "rows/s", "cores": 128, "kind": "port", "sample": "s" * 900, "sample_short": "t" * 200, "one_thread": {"value": 1.87e7}}
+    entry = {"rows": 67108864, "groups": 3000000, "value": 4.1e10, "frac": 0.0831234, "cpu": cpu, "reference_shape": "y" * 80}
+    join = {"case": "c" * 90, "build": dict(entry), "probe": dict(entry)}
+    detail = {"metric": "rows/s through operator pipeline, TPC-H Q1+Q6 SF100, 1/2/4/8 GPUs vs CPU ref", "value": 1.5712345678e11, "unit": "rows/s", "n_gpus": 1,
+              "steps": 20, "warmup": 5, "ms_per_step": 7.64123456, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
+              "data": "synthetic", "config": {"workload": "w" * 200, "scale_factor_job": 100.0, "rows_per_gpu": 600037902, "page_rows": 1 << 28,
+                                              "queries": ["q1", "q6"], "parallelism": "row-range shards x1", "parallelism_note": "n" * 500},
+              "roofline": roof, "roofline_q6": roof, "cpu_baseline": cpu, "results": {"q1": [["A", "F"] + [1.0] * 8] * 4},
+              "q3": {"value": 1.6e11, "ms_per_step": 4.66, "roofline": {"frac": 0.556}, "cpu_baseline": {"value": 1.1e7}, "exchange": "none (one rank)",
+                     "stage_ms_rank0": {"a": 1.0}},
+              "h2d": {"value": 2e9, "GBps": 54.8, "frac": 0.87, "workload": "h" * 200, "small_pages": {"GBps": 31.0}},
+              "sf300": {"value": 1.5e11, "ms_per_step": 23.0, "q3": {"ms_per_step": 14.0}, "results": {"q1": [[1.0] * 10] * 4}},
+              "operators": {"hash_agg": [dict(entry, groups=g) for g in (3000000, 4, 1000, 100000, 3000001)], "hash_join": [join] * 8,
+                            "order_by": entry, "topn": entry},
+              "detail_path": "/somewhere/bench_detail.json"}
+    text = bench.summary_line(detail) + "\n"
+    line = check_line_shape(text)
+    assert line["roofline"]["kernel"] == "pa_fused_lds_0123abcd" and line["roofline"]["frac"] == 0.75789 and line["cpu_baseline"]["cores"] == 128
+    assert len(line["operators"]) == 5 + 16 + 2 and line["q3"]["ms_per_step"] == 4.66 and line["detail"] == "bench_detail.json"
+    # a detail object larger than anything the bench produces still yields a parseable line: side legs are dropped, never the contract
+    detail["operators"]["hash_join"] = [join] * 400
+    line = check_line_shape(bench.summary_line(detail) + "\n")
+    assert "operators" not in line and line["roofline"]["frac"] == 0.75789
 
 
 def test_bench_refuses_a_world_size_that_is_not_gpus():

@@ -6,38 +6,48 @@ import json
 import pytest
 
 from presto_amd import tpch
-from tests.test_exchange_gloo import check_q1_q6, oracle_q1_q6, run_bench
+from tests.test_exchange_gloo import check_line_shape, check_q1_q6, oracle_q1_q6, run_bench
 
 pytestmark = pytest.mark.gpu
 
 
-def test_bench_two_ranks_as_a_plain_subprocess(gpu, oracle):
+def test_bench_two_ranks_as_a_plain_subprocess(gpu, oracle, tmp_path):
+    """Two ranks on the one GPU over the library's host transport.  Inside the ranks torch is the control plane only: its HIP runtime
+    is never initialised (the detail file says so, and a rank that found it initialised leaves with exit code 5)."""
     sf = 0.05
-    r = run_bench(["--gpus", "2", "--backend", "gloo", "--sf", str(sf), "--steps", "2", "--warmup", "1", "--cpu-rows", "0"], timeout=900)
+    path = str(tmp_path / "detail.json")
+    r = run_bench(["--gpus", "2", "--backend", "gloo", "--sf", str(sf), "--steps", "2", "--warmup", "1", "--cpu-rows", "0", "--detail", path], timeout=900)
     assert r.returncode == 0, r.stderr.decode()[-3000:]
-    text = r.stdout.decode()
-    assert text.count("\n") == 1, text[:2000]
-    line = json.loads(text)
+    line = check_line_shape(r.stdout.decode())
+    d = json.load(open(path))
     rows = tpch.lineitem_rows(sf)
-    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["strong"]["scaling"] == "strong"
-    assert line["config"]["rows_per_gpu"] == rows and line["strong"]["job_rows"] == rows
-    assert abs(line["value"] - 2 * rows * 2 * 2 / (line["ms_per_step"] * 2 / 1e3)) <= 1e-6 * line["value"]
-    check_q1_q6(line["results"], *oracle_q1_q6(oracle, sf * 2, rows * 2))
-    check_q1_q6(line["strong"]["results"], *oracle_q1_q6(oracle, sf, rows))
-    q3 = line["q3"]
+    assert d["torch_cuda_initialized"] is False
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and d["weak"]["scaling"] == "weak" and line["weak"]["value"] > 0
+    assert d["weak"]["rows_per_gpu_rank0"] == rows and d["config"]["rows_per_gpu"] == rows // 2 // 4 * 4
+    assert abs(d["value"] - 2 * rows * 2 / (d["ms_per_step"] * 2 / 1e3)) <= 1e-6 * d["value"]
+    check_q1_q6(d["results"], *oracle_q1_q6(oracle, sf, rows))
+    check_q1_q6(d["weak"]["results"], *oracle_q1_q6(oracle, sf * 2, rows * 2))
+    q3 = d["q3"]
     assert "error" not in q3 and q3["exchange"]["rank0_bytes_to_other_ranks_per_step"] > 0 and q3["exchange"]["transport"].startswith("host transport")
-    assert q3["rank0"]["exchange_rows_sent"] > 0 and len(line["results"]["q3"]) == 10
-    assert line["roofline"]["frac"] > 0 and line["roofline"]["launches"] > 0
+    assert q3["rank0"]["exchange_rows_sent"] > 0 and len(d["results"]["q3"]) == 10
+    assert line["roofline"]["frac"] > 0 and line["roofline"]["launches"] > 0 and line["roofline"]["kernel"].startswith("pa_fused_lds_")
 
 
-def test_bench_one_rank_default_shape_small(gpu, oracle):
-    """`--gpus 1`: no launcher, no merge; the line's side objects are all there."""
+def test_bench_one_rank_default_shape_small(gpu, oracle, tmp_path):
+    """`--gpus 1`: no launcher, no merge; the side legs are all in the detail file, their one-number summaries in the line."""
     sf = 0.05
-    r = run_bench(["--gpus", "1", "--sf", str(sf), "--steps", "2", "--warmup", "1", "--cpu-rows", "200000", "--h2d-rows", "100000"], timeout=900)
+    path = str(tmp_path / "detail.json")
+    r = run_bench(["--gpus", "1", "--sf", str(sf), "--steps", "2", "--warmup", "1", "--cpu-rows", "200000", "--h2d-rows", "100000", "--detail", path],
+                  timeout=900)
     assert r.returncode == 0, r.stderr.decode()[-3000:]
-    line = json.loads(r.stdout.decode())
+    summary = check_line_shape(r.stdout.decode())
+    line = json.load(open(path))
+    assert line["line"] == summary
     rows = tpch.lineitem_rows(sf)
-    assert line["n_gpus"] == 1 and "strong" not in line and line["config"]["rows_per_gpu"] == rows
+    assert line["n_gpus"] == 1 and "strong" not in line and "weak" not in line and line["config"]["rows_per_gpu"] == rows
+    assert summary["roofline"]["kernel"].startswith("pa_fused_lds_") and summary["roofline_q6"]["kernel"].startswith("pa_fused_global_")
+    assert summary["cpu_baseline"]["value"] > 0 and summary["cpu_baseline"]["cores"] >= 1 and summary["q3"]["cpu_rows_s"] > 0
+    assert len(summary["operators"]) == 5 + 16 + 2 and all(v[0] > 0 and 0 < v[1] < 1 for v in summary["operators"].values())
     check_q1_q6(line["results"], *oracle_q1_q6(oracle, sf, rows))
     assert "error" not in line["q3"] and line["q3"]["exchange"] == "none (one rank)"
     assert line["cpu_baseline"]["value"] > 0 and line["h2d"]["value"] > 0

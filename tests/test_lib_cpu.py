@@ -217,8 +217,8 @@ def test_q3_orders_probe_inside_filter_and_project_generates_and_compiles_for_gf
     buf = C.create_string_buffer(need)
     L.pa_codegen_fused_join_probe(C.byref(d), C.byref(build), buf, need)
     src = buf.value.decode()
-    count = src[src.index("void pa_fp_count("):src.index("void pa_fp_scatter(")]
-    scatter = src[src.index("void pa_fp_scatter("):]
+    count = src[src.index("void PA_K(pa_fp_count)("):src.index("void PA_K(pa_fp_scatter)(")]
+    scatter = src[src.index("void PA_K(pa_fp_scatter)("):]
     # the counting pass asks whether a key exists (the key bitmap is exact: the slot table is only read where there is none)
     assert count.count("pa_keep(a, pa_k[") == 4 and "pa_join_exists4(a, pa_s, pa_k, pa_hit);" in count
     # no build column in the output: the second pass does not probe at all
@@ -232,6 +232,6 @@ def test_q3_orders_probe_inside_filter_and_project_generates_and_compiles_for_gf
     buf = C.create_string_buffer(need)
     L.pa_codegen_fused_join_probe(C.byref(d2), C.byref(build2), buf, need)
     scatter2 = buf.value.decode()
-    scatter2 = scatter2[scatter2.index("void pa_fp_scatter("):]
+    scatter2 = scatter2[scatter2.index("void PA_K(pa_fp_scatter)("):]
     assert scatter2.count("pa_key_of(a") >= 4 and "pa_join_probe4(a, pa_s, pa_k, pa_jb);" in scatter2 and "pa_jb[3]" in scatter2
     assert L.pa_codegen_compile_fused_join_probe(C.byref(d2), C.byref(build2)) > 1000, L.pa_last_error()
