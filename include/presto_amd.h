@@ -287,7 +287,16 @@ typedef struct pa_hash_aggregation_desc {
     int64_t max_partial_memory;
     /* pa_state_format of the intermediate states a PARTIAL step emits / a FINAL step takes */
     int32_t state_format;
-    int32_t reserved;
+    /* GROUPING SETS with global grouping sets (HashAggregationOperatorFactory's produceDefaultOutput, globalAggregationGroupIds and
+     * groupIdChannel, HashAggregationOperator.java:120-202): when the operator finishes without having been given a page it emits one
+     * row per id of global_aggregation_group_ids -- NULL in every group-by column except the one at index group_id_channel AMONG THE
+     * GROUP-BY COLUMNS (a BIGINT: the id), that row's $hashvalue when hash_channel >= 0 (calculateDefaultOutputHash, :589-600), and
+     * every aggregate's output over no input (count 0, sum / avg / min / max NULL; a PARTIAL step: the empty intermediate states) --
+     * HashAggregationOperator.java:486-492, 545-587.  produce_default_output = 0: such an operator emits nothing. */
+    int32_t produce_default_output;
+    int32_t group_id_channel;                    /* only read when global_aggregation_group_id_count > 0 */
+    int32_t global_aggregation_group_id_count;
+    const int32_t* global_aggregation_group_ids;
 } pa_hash_aggregation_desc;
 
 /* Fused pipeline: [Scan]FilterAndProject -> (Hash)AggregationOperator collapsed into one device

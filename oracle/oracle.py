@@ -50,6 +50,7 @@ def lib():
         L.orc_hash_agg_capacity.argtypes = [C.c_void_p]
         L.orc_hash_agg_contains.argtypes = [C.c_void_p, C.POINTER(abi.pa_page), C.c_int32]
         L.orc_hash_agg_build_result.argtypes = [C.c_void_p, C.POINTER(abi.pa_page)]
+        L.orc_hash_agg_default_output.argtypes = [C.POINTER(abi.pa_hash_aggregation_desc), C.POINTER(abi.pa_page)]
         L.orc_hash_agg_destroy.argtypes = [C.c_void_p]
         L.orc_join_create.restype = C.c_void_p
         L.orc_join_create.argtypes = [C.POINTER(abi.pa_hash_builder_desc)]
@@ -185,7 +186,8 @@ def make_aggregates(aggregates):
 
 
 def make_hash_agg_desc(input_types, group_by_channels, aggregates, hash_channel=-1, expected_groups=10000,
-                       step=abi.STEP_SINGLE, output_mem=abi.MEM_HOST, stream=None):
+                       step=abi.STEP_SINGLE, output_mem=abi.MEM_HOST, stream=None, global_aggregation_group_ids=None, group_id_channel=None,
+                       produce_default_output=False):
     d = abi.pa_hash_aggregation_desc()
     keep = []
     types = abi.int32_array(input_types)
@@ -202,8 +204,111 @@ def make_hash_agg_desc(input_types, group_by_channels, aggregates, hash_channel=
     d.expected_groups = expected_groups
     d.output_mem = output_mem
     d.stream = stream
+    d.produce_default_output = 1 if produce_default_output else 0
+    d.group_id_channel = -1 if group_id_channel is None else group_id_channel
+    if global_aggregation_group_ids:
+        ids = abi.int32_array(global_aggregation_group_ids)
+        d.global_aggregation_group_id_count = len(global_aggregation_group_ids)
+        d.global_aggregation_group_ids = C.cast(ids, C.POINTER(C.c_int32))
+        keep.append(ids)
     keep += [types, gb, aggs]
     return d, keep
+
+
+def page_builder_row_bytes(page):
+    """Bytes every row of `page` adds to a PageBuilder's status (PageBuilderStatus via BlockBuilderStatus.addBytes): fixed-width
+    builders add 1 (the null flag) + the value width per entry (LongArrayBlockBuilder.java / IntArrayBlockBuilder / ByteArrayBlockBuilder:
+    `Byte.BYTES + Long.BYTES` ...), VariableWidthBlockBuilder 1 + 4 + the entry's bytes (entryAdded)."""
+    n = page.position_count
+    total = np.zeros(n, dtype=np.int64)
+    for b in page.blocks:
+        if b.encoding == abi.VARWIDTH:
+            total += 5 + np.diff(np.asarray(b.offsets[:n + 1], dtype=np.int64))
+        elif b.type == abi.LONG_DECIMAL:
+            total += 17
+        else:
+            total += 1 + abi.TYPE_WIDTH[b.type]
+    return total
+
+
+class HashAggregationOperator:
+    """HashAggregationOperator.java:348-543 as the Driver sees it (Operator.java:21-103), over this module's
+    InMemoryHashAggregationBuilder restatement; no spill, no memory revocation.
+      addInput   :380-439   inputProcessed = true; the builder takes the page
+      finish     :366-370
+      getOutput  :455-513   finishing && !inputProcessed && produceDefaultOutput -> getGlobalAggregationOutput (:545-587) and finished;
+                            else buildResult once finishing -- a WorkProcessor of pages cut by the PageBuilder: rows are appended while
+                            !pageBuilder.isFull() (InMemoryHashAggregationBuilder.java:283-298; PageBuilderStatus.DEFAULT_MAX_PAGE_SIZE_IN_BYTES
+                            = 1 MB, PageBuilder.java:116-180)"""
+
+    MAX_PAGE_BYTES = 1024 * 1024
+
+    def __init__(self, input_types, group_by_channels, aggregates, hash_channel=-1, expected_groups=10000, step=abi.STEP_SINGLE,
+                 global_aggregation_group_ids=None, group_id_channel=None, produce_default_output=False):
+        self._args = (input_types, group_by_channels, aggregates, hash_channel, expected_groups, step)
+        self._desc, self._keep = make_hash_agg_desc(input_types, group_by_channels, aggregates, hash_channel, expected_groups, step,
+                                                    global_aggregation_group_ids=global_aggregation_group_ids, group_id_channel=group_id_channel,
+                                                    produce_default_output=produce_default_output)
+        self.produce_default_output = produce_default_output
+        self.builder = None
+        self.input_processed = False
+        self.finishing = False
+        self.finished = False
+        self.output_pages = None
+
+    def needsInput(self):
+        return not self.finishing and self.output_pages is None
+
+    def addInput(self, page):
+        assert self.needsInput()
+        self.input_processed = True
+        if self.builder is None:
+            self.builder = HashAggregation(*self._args)
+        self.builder.add_page(page)
+
+    def finish(self):
+        self.finishing = True
+
+    def isFinished(self):
+        return self.finished
+
+    def getOutput(self):
+        if self.finished:
+            return None
+        if self.output_pages is None:
+            if self.finishing:
+                if not self.input_processed and self.produce_default_output:
+                    self.finished = True
+                    out = abi.pa_page()
+                    _check(lib().orc_hash_agg_default_output(C.byref(self._desc), C.byref(out)))
+                    if out.position_count == 0:
+                        return None
+                    page = page_from_c(out)
+                    lib().orc_free_page(C.byref(out))
+                    return page
+                if self.builder is None:
+                    self.finished = True
+                    return None
+            else:
+                return None   # (Step.PARTIAL's early flush when the builder is full is HashAggregation's caller's business here)
+            result = self.builder.build_result()
+            # buildResult's pages: a row goes into the current page while the PageBuilder is not full
+            sizes = page_builder_row_bytes(result)
+            cuts, at, acc = [], 0, 0
+            for i in range(result.position_count):
+                if acc >= self.MAX_PAGE_BYTES:
+                    cuts.append((at, i - at))
+                    at, acc = i, 0
+                acc += int(sizes[i])
+            if result.position_count > at:
+                cuts.append((at, result.position_count - at))
+            self.output_pages = [result.get_region(o, n) for o, n in cuts]
+        if not self.output_pages:
+            self.builder.close()
+            self.builder = None
+            self.finished = True   # closeAggregationBuilder; with `finishing` the operator is done (:529-531)
+            return None
+        return self.output_pages.pop(0)
 
 
 class HashAggregation:

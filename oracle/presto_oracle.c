@@ -1706,6 +1706,77 @@ int32_t orc_hash_agg_add_page(orc_hash_agg* a, const pa_page* page, int32_t* gro
     return 0;
 }
 
+/* HashAggregationOperator.getGlobalAggregationOutput (TM/operator/HashAggregationOperator.java:545-587) with
+ * calculateDefaultOutputHash (:589-600): the rows an operator with produceDefaultOutput emits when it finishes without having seen
+ * a page (:486-492) -- one per globalAggregationGroupIds entry: NULL in every group-by column except groupIdChannel (the id), the
+ * row's $hashvalue if a hash channel was supplied, then every accumulator's evaluateFinal / evaluateIntermediate over no input (fresh
+ * accumulators: the one row of this file's AggregationOperator restatement over nothing). */
+int32_t orc_hash_agg_default_output(const pa_hash_aggregation_desc* d, pa_page* out)
+{
+    memset(out, 0, sizeof *out);
+    out->mem = PA_MEM_HOST;
+    int32_t n = d->global_aggregation_group_id_count;
+    if (!d->produce_default_output || n <= 0) return 0; /* output.isEmpty() -> null */
+    pa_hash_aggregation_desc g = *d;
+    g.group_by_count = 0;
+    g.group_by_channels = NULL;
+    g.hash_channel = -1;
+    g.produce_default_output = 0;
+    g.global_aggregation_group_id_count = 0;
+    orc_hash_agg* fresh = orc_hash_agg_create(&g);
+    pa_page row;
+    int32_t rc = orc_hash_agg_build_result(fresh, &row);
+    if (rc < 0 || row.position_count != 1) {
+        orc_hash_agg_destroy(fresh);
+        return rc < 0 ? rc : PA_ERR_INVALID_ARGUMENT;
+    }
+    int32_t nkeys = d->group_by_count, has_hash = d->hash_channel >= 0;
+    int32_t ncols = nkeys + has_hash + row.channel_count;
+    out->position_count = n;
+    out->channel_count = ncols;
+    out->columns = (pa_column*)calloc((size_t)ncols, sizeof(pa_column));
+    int32_t c = 0;
+    for (int32_t k = 0; k < nkeys; k++) {
+        col_builder b;
+        cb_init(&b, d->input_types[d->group_by_channels[k]], n);
+        for (int32_t i = 0; i < n; i++) {
+            orc_val v = null_of(b.type);
+            if (k == d->group_id_channel) {
+                v.is_null = 0;
+                v.i = d->global_aggregation_group_ids[i];
+            }
+            cb_append(&b, &v);
+        }
+        cb_finish(&b, &out->columns[c++]);
+    }
+    if (has_hash) {
+        col_builder b;
+        cb_init(&b, PA_BIGINT, n);
+        for (int32_t i = 0; i < n; i++) {
+            int64_t result = 0; /* INITIAL_HASH_VALUE */
+            for (int32_t k = 0; k < nkeys; k++) {
+                result = orc_combine_hash(result, k != d->group_id_channel ? 0 /* NULL_HASH_CODE */ : orc_hash_bigint(d->global_aggregation_group_ids[i]));
+            }
+            orc_val v;
+            memset(&v, 0, sizeof v);
+            v.type = PA_BIGINT;
+            v.i = result;
+            cb_append(&b, &v);
+        }
+        cb_finish(&b, &out->columns[c++]);
+    }
+    for (int32_t a = 0; a < row.channel_count; a++) {
+        col_builder b;
+        cb_init(&b, row.columns[a].type, n);
+        orc_val v = col_get(&row.columns[a], 0);
+        for (int32_t i = 0; i < n; i++) cb_append(&b, &v);
+        cb_finish(&b, &out->columns[c++]);
+    }
+    orc_free_page(&row);
+    orc_hash_agg_destroy(fresh);
+    return 0;
+}
+
 /* InMemoryHashAggregationBuilder.buildResult (…/InMemoryHashAggregationBuilder.java:244-298): group ids
  * 0..n-1 in order; output columns = keys, ($hashvalue), aggregates (toTypes :419-431).  Output
  * functions: DoubleSumAggregation.java:54-63, LongSumAggregation.java:55-64, AverageAggregations.java:

@@ -63,6 +63,9 @@ int32_t orc_hash_agg_contains(const orc_hash_agg* agg, const pa_page* page, int3
 /* buildResult: rows for group id 0..n-1 in order: [keys..., ($hashvalue), aggregates...]. */
 int32_t orc_hash_agg_build_result(orc_hash_agg* agg, pa_page* out);
 void orc_hash_agg_destroy(orc_hash_agg* agg);
+/* HashAggregationOperator.getGlobalAggregationOutput (:545-587): the default rows of the global grouping sets (0 rows when the
+ * descriptor asks for none). */
+int32_t orc_hash_agg_default_output(const pa_hash_aggregation_desc* desc, pa_page* out);
 
 /* ---- hash join ---- */
 typedef struct orc_join orc_join;

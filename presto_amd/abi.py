@@ -246,7 +246,10 @@ class pa_hash_aggregation_desc(C.Structure):
         ("stream", C.c_void_p),
         ("max_partial_memory", C.c_int64),
         ("state_format", C.c_int32),
-        ("reserved", C.c_int32),
+        ("produce_default_output", C.c_int32),
+        ("group_id_channel", C.c_int32),
+        ("global_aggregation_group_id_count", C.c_int32),
+        ("global_aggregation_group_ids", C.POINTER(C.c_int32)),
     ]
 
 

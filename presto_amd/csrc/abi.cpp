@@ -362,7 +362,10 @@ static pa_operator* plain_aggregation(const pa_hash_aggregation_desc* agg)
     d.filter_project.stream = agg->stream;
     d.aggregation = *agg;
     d.aggregation.state_format = PA_STATES_FLAT;
-    return make_fused_aggregation(&d);
+    pa_operator* op = make_fused_aggregation(&d);
+    // produceDefaultOutput (HashAggregationOperator.java:486-492): the rows of the global grouping sets when no input arrives
+    if (agg->produce_default_output && agg->group_by_count > 0) return make_default_output_aggregation(op, agg, &plain_aggregation);
+    return op;
 }
 
 int32_t pa_hash_aggregation_create(const pa_hash_aggregation_desc* desc, pa_operator** out)

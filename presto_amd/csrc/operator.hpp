@@ -75,6 +75,8 @@ int32_t dynamic_filter_poll(pa_operator* op, int32_t* is_all, pa_domain* domains
 // (Hash)AggregationOperator over plain channels with the reference's intermediate-state format at its PARTIAL output / FINAL
 // input: the flat-format operator `make_flat` builds, inside an adapter (op_states.cpp)
 pa_operator* make_aggregation_with_reference_states(const pa_hash_aggregation_desc* agg, pa_operator* (*make_flat)(const pa_hash_aggregation_desc*));
+// HashAggregationOperator's default output rows when no input arrived (op_default_output.cpp): takes ownership of `inner`
+pa_operator* make_default_output_aggregation(pa_operator* inner, const pa_hash_aggregation_desc* desc, pa_operator* (*make_flat)(const pa_hash_aggregation_desc*));
 // partitioned exchange (op_exchange.cpp)
 pa_exchange* exchange_new(const pa_exchange_desc* desc, pa_comm* comm);
 void exchange_delete(pa_exchange* ex);

@@ -242,7 +242,9 @@ __global__ __launch_bounds__(256) void k_merge_lds_words(const u64* __restrict__
             }
             slot = best;
         }
-        for (int w = 0; w < NW; w++) {
+        // blockIdx.y = the accumulator word: the NW passes over the entries run side by side (Q1: 15 words -- one pass's latency
+        // instead of fifteen); each (slot, word) is still reduced by one workgroup in one fixed order
+        for (int w = blockIdx.y; w < NW; w += gridDim.y) {
             const int kind = kinds[w];
             const u64* col = slab + (i64)(1 + W + w) * entries;
             double accf = 0.0;
@@ -299,7 +301,7 @@ void launch_merge_lds_slab(const uint64_t* slab, int waves, int c, int w, int nw
     int64_t entries = (int64_t)waves * c;
     hipLaunchKernelGGL(k_merge_lds_keys, grid_for(entries, 256), 256, 0, s, (const u64*)slab, entries, w, nw, (u64*)gt_tag, (u64*)gt_keys,
                        gt_mask, gt_max_fill, gt_count, err, (const u64*)overflow_rows, entry_slot);
-    hipLaunchKernelGGL(k_merge_lds_words, (gt_mask + 256) / 256, 256, 0, s, (const u64*)slab, entries, w, nw, kinds_dev, (const u64*)gt_tag,
+    hipLaunchKernelGGL(k_merge_lds_words, dim3((gt_mask + 256) / 256, (unsigned)std::max(1, nw), 1), dim3(256, 1, 1), 0, s, (const u64*)slab, entries, w, nw, kinds_dev, (const u64*)gt_tag,
                        (u64*)gt_words, gt_mask + 1, (const i32*)entry_slot, err);
     PA_HIP(hipGetLastError());
 }

@@ -184,7 +184,8 @@ def _aggregates(aggregates):
 
 
 def _hash_agg_desc(input_types, group_by_channels, aggregates, hash_channel, expected_groups, output_mem, stream,
-                   type_params=None, step=abi.STEP_SINGLE, max_partial_memory=0, state_format=abi.STATES_FLAT):
+                   type_params=None, step=abi.STEP_SINGLE, max_partial_memory=0, state_format=abi.STATES_FLAT,
+                   global_aggregation_group_ids=None, group_id_channel=None, produce_default_output=False):
     keep = []
     type_params = _params_of(input_types, type_params)
     d = abi.pa_hash_aggregation_desc()
@@ -208,6 +209,13 @@ def _hash_agg_desc(input_types, group_by_channels, aggregates, hash_channel, exp
     d.stream = stream
     d.max_partial_memory = int(max_partial_memory)
     d.state_format = state_format
+    d.produce_default_output = 1 if produce_default_output else 0
+    d.group_id_channel = -1 if group_id_channel is None else group_id_channel
+    if global_aggregation_group_ids:
+        ids = abi.int32_array(global_aggregation_group_ids)
+        d.global_aggregation_group_id_count = len(global_aggregation_group_ids)
+        d.global_aggregation_group_ids = C.cast(ids, C.POINTER(C.c_int32))
+        keep.append(ids)
     keep += [types, gb, aggs]
     return d, keep
 
@@ -356,11 +364,14 @@ def AggregationOperator(input_types, aggregates, output_mem=abi.MEM_HOST, stream
 
 def HashAggregationOperator(input_types, group_by_channels, aggregates, hash_channel=-1, expected_groups=10000,
                             output_mem=abi.MEM_HOST, stream=None, type_params=None, step=abi.STEP_SINGLE, max_partial_memory=0,
-                            state_format=abi.STATES_FLAT):
+                            state_format=abi.STATES_FLAT, global_aggregation_group_ids=None, group_id_channel=None, produce_default_output=False):
     """HashAggregationOperatorFactory (…/operator/HashAggregationOperator.java:120-202); max_partial_memory = maxPartialMemory
-    in bytes (Step.PARTIAL: flush when the aggregation is "full"), state_format = abi.STATES_FLAT / STATES_REFERENCE."""
+    in bytes (Step.PARTIAL: flush when the aggregation is "full"), state_format = abi.STATES_FLAT / STATES_REFERENCE;
+    global_aggregation_group_ids / group_id_channel (an index among the group-by columns) / produce_default_output: the default rows
+    of the global grouping sets when no page arrives (:486-492, 545-587)."""
     d, keep = _hash_agg_desc(input_types, group_by_channels, aggregates, hash_channel, expected_groups, output_mem, stream,
-                             type_params, step, max_partial_memory, state_format)
+                             type_params, step, max_partial_memory, state_format, global_aggregation_group_ids, group_id_channel,
+                             produce_default_output)
     h = C.c_void_p()
     check(lib().pa_hash_aggregation_create(C.byref(d), C.byref(h)))
     return Operator(h, keep)

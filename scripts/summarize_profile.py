@@ -99,7 +99,7 @@ with open(os.path.join(out, tag + "_summary.md"), "w") as f:
     f.write("Three runs of the same command: `rocprofv3 --kernel-trace --stats`, then `--pmc FETCH_SIZE --kernel-trace` and `--pmc WRITE_SIZE "
             "--kernel-trace` (counter passes never combined with API traces).  `%s_kernel_stats.csv` is rocprofv3's own statistics file of the "
             "first run.\n\n" % tag)
-    f.write("## kernel stats (all kernels of the traced run)\n\n| kernel | calls | total ms | avg us | %% |\n|---|---|---|---|---|\n")
+    f.write("## kernel stats (all kernels of the traced run)\n\n| kernel | calls | total ms | avg us | % |\n|---|---|---|---|---|\n")
     for r in stats:
         f.write("| `%s` | %d | %.3f | %.1f | %.2f |\n" % (r["Name"][:70], r["Calls"], r["TotalDurationNs"] / 1e6, r["AverageNs"] / 1e3, r["Percentage"]))
     f.write("\n## generated kernels: roofline from the trace alone\n\n"

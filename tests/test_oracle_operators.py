@@ -73,29 +73,160 @@ def test_agg_empty_input_default_row(oracle):
     assert agg.build_result().to_rows() == [(0, None, None)]
 
 
-@pytest.mark.parametrize("hashed", [False, True])
-def test_hagg1_hash_aggregation(oracle, hashed):
-    """TestHashAggregationOperator.testHashAggregation (…/TestHashAggregationOperator.java:160-219): 3 pages x 40 000
-    rows keyed by VARCHAR seq; per key count(*) 3, sum(bigint) 3i, avg i, count(varchar) 3"""
-    pages = [sequence_page(40000, [(abi.VARCHAR, 0), (abi.BIGINT, 0)]) for _ in range(3)]
-    types = [abi.VARCHAR, abi.BIGINT]
+def hagg1_input(oracle, hashed, rows=40000):
+    """rowPagesBuilder(hashEnabled, hashChannels = [1], VARCHAR, VARCHAR, VARCHAR, BIGINT, BOOLEAN) with three
+    addSequencePage(rows, 100, 0, {1,2,3}00_000, 0, 500) pages (TestHashAggregationOperator.java:172-177); hashEnabled appends the
+    $hashvalue of the hash channels as a last channel (RowPagesBuilder.java)."""
+    types = [abi.VARCHAR, abi.VARCHAR, abi.VARCHAR, abi.BIGINT, abi.BOOLEAN]
+    pages = [sequence_page(rows, [(abi.VARCHAR, 100), (abi.VARCHAR, 0), (abi.VARCHAR, start), (abi.BIGINT, 0), (abi.BOOLEAN, 500)])
+             for start in (100_000, 200_000, 300_000)]
     hc = -1
     if hashed:
-        pages = [Page(p.blocks + [Block.bigint(oracle.hash_page(p, [0]))], 40000) for p in pages]
-        types, hc = types + [abi.BIGINT], 2
-    agg = oracle.HashAggregation(types, [0], [(abi.AGG_COUNT_STAR, -1, None), (abi.AGG_SUM, 1, abi.BIGINT), (abi.AGG_AVG, 1, abi.BIGINT),
-                                              (abi.AGG_COUNT, 0, abi.VARCHAR)], hash_channel=hc, expected_groups=100000)
-    for p in pages:
-        agg.add_page(p)
-    rows = agg.build_result().to_rows()
-    assert len(rows) == 40000
-    # group ids are first-seen ordinals, so the result is already in key order here
-    for i, r in enumerate(rows):
+        pages = [Page(p.blocks + [Block.bigint(oracle.hash_page(p, [1]))], rows) for p in pages]
+        types, hc = types + [abi.BIGINT], 5
+    return types, pages, hc
+
+
+# COUNT, LONG_SUM(3), LONG_AVERAGE(3), max(varchar @2), count(varchar @0), count(boolean @4): TestHashAggregationOperator.java:186-191
+HAGG1_AGGREGATES = [(abi.AGG_COUNT_STAR, -1, None), (abi.AGG_SUM, 3, abi.BIGINT), (abi.AGG_AVG, 3, abi.BIGINT), (abi.AGG_MAX, 2, abi.VARCHAR),
+                    (abi.AGG_COUNT, 0, abi.VARCHAR), (abi.AGG_COUNT, 4, abi.BOOLEAN)]
+
+
+def check_hagg1_rows(oracle, rows, hashed, n=40000):
+    """expectedBuilder.row(Integer.toString(i), 3L, 3L * i, (double) i, Integer.toString(300_000 + i), 3L, 3L), compared ignoring order
+    (assertPagesEqualIgnoreOrder, the $hashvalue column dropped: TestHashAggregationOperator.java:205-216)"""
+    assert len(rows) == n
+    seen = set()
+    for r in rows:
         key, rest = r[0], r[1:]
+        i = int(key)
         if hashed:
             assert rest[0] == oracle.combine_hash(0, oracle._s64(oracle.xxh64(key)))
             rest = rest[1:]
-        assert key == str(i).encode() and rest == (3, 3 * i, float(i), 3)
+        assert key == str(i).encode() and rest == (3, 3 * i, float(i), str(300_000 + i).encode(), 3, 3), r
+        seen.add(i)
+    assert seen == set(range(n))
+
+
+def drive(op, pages):
+    """toPages (OperatorAssertion.java): the Driver's loop -- needsInput / addInput per page, finish, getOutput until finished."""
+    out = []
+    for p in pages:
+        assert op.needsInput()
+        op.addInput(p)
+        o = op.getOutput()
+        if o is not None:
+            out.append(o)
+    op.finish()
+    for _ in range(1000):
+        if op.isFinished():
+            break
+        o = op.getOutput()
+        if o is not None and o.position_count:
+            out.append(o)
+    assert op.isFinished()
+    return out
+
+
+@pytest.mark.parametrize("hashed", [False, True])
+def test_hagg1_hash_aggregation(oracle, hashed):
+    """TestHashAggregationOperator.testHashAggregation (…/TestHashAggregationOperator.java:160-219): 3 pages x 40 000 rows keyed by a
+    VARCHAR sequence, all six aggregates; more than one output page (:213)."""
+    types, pages, hc = hagg1_input(oracle, hashed)
+    op = oracle.HashAggregationOperator(types, [1], HAGG1_AGGREGATES, hash_channel=hc, expected_groups=100_000)
+    out = drive(op, pages)
+    assert len(out) > 1   # "Expected more than one output page"
+    check_hagg1_rows(oracle, [r for p in out for r in p.to_rows()], hashed)
+
+
+# testHashAggregationWithGlobals (…/TestHashAggregationOperator.java:221-272).  The reference builds its factory with group-by TYPES
+# (VARCHAR, BIGINT) over channels (1, 2) of a (VARCHAR, VARCHAR, VARCHAR, BIGINT, BIGINT, BOOLEAN) page layout -- no page ever flows, so
+# the mismatch of channel 2 never shows.  Here the key types come from the channels: channel 2 is declared BIGINT and max(varchar) reads a
+# VARCHAR channel of its own (6); the operator sees what the reference's sees: keys (VARCHAR, BIGINT), group id in key column 1, ids 42, 49.
+GLOBALS_TYPES = [abi.VARCHAR, abi.VARCHAR, abi.BIGINT, abi.BIGINT, abi.BIGINT, abi.BOOLEAN, abi.VARCHAR]
+GLOBALS_AGGREGATES = [(abi.AGG_COUNT_STAR, -1, None), (abi.AGG_MIN, 4, abi.BIGINT), (abi.AGG_AVG, 4, abi.BIGINT), (abi.AGG_MAX, 6, abi.VARCHAR),
+                      (abi.AGG_COUNT, 0, abi.VARCHAR), (abi.AGG_COUNT, 5, abi.BOOLEAN)]
+GLOBALS_EXPECTED = [(None, 42, 0, None, None, None, 0, 0), (None, 49, 0, None, None, None, 0, 0)]
+
+
+def globals_hash(oracle, group_id):
+    """calculateDefaultOutputHash (HashAggregationOperator.java:589-600) over (NULL, id)"""
+    return oracle.combine_hash(oracle.combine_hash(0, 0), oracle.hash_bigint(group_id))
+
+
+@pytest.mark.parametrize("hashed", [False, True])
+def test_hash_aggregation_with_globals(oracle, hashed):
+    types, hc = (GLOBALS_TYPES + [abi.BIGINT], 7) if hashed else (GLOBALS_TYPES, -1)
+    op = oracle.HashAggregationOperator(types, [1, 2], GLOBALS_AGGREGATES, hash_channel=hc, expected_groups=100_000,
+                                        global_aggregation_group_ids=[42, 49], group_id_channel=1, produce_default_output=True)
+    out = drive(op, [])
+    rows = [r for p in out for r in p.to_rows()]
+    if hashed:
+        assert [r[2] for r in rows] == [globals_hash(oracle, 42), globals_hash(oracle, 49)]
+        rows = [r[:2] + r[3:] for r in rows]
+    assert rows == GLOBALS_EXPECTED
+    # with input the default rows are not produced (inputProcessed, :386, 488); without produceDefaultOutput nothing is emitted at all
+    op = oracle.HashAggregationOperator(GLOBALS_TYPES, [1, 2], GLOBALS_AGGREGATES, global_aggregation_group_ids=[42, 49], group_id_channel=1,
+                                        produce_default_output=True)
+    page = Page([Block.varchar(["a"]), Block.varchar(["k"]), Block.bigint([7]), Block.bigint([1]), Block.bigint([5]), Block.boolean([True]),
+                 Block.varchar(["z"])], 1)
+    assert [r for p in drive(op, [page]) for r in p.to_rows()] == [(b"k", 7, 1, 5, 5.0, b"z", 1, 1)]
+    op = oracle.HashAggregationOperator(GLOBALS_TYPES, [1, 2], GLOBALS_AGGREGATES, global_aggregation_group_ids=[42, 49], group_id_channel=1)
+    assert drive(op, []) == []
+    # a PARTIAL step emits the empty intermediate states (evaluateIntermediate, :576-578): [count 0] / [count 0, value NULL or 0]
+    op = oracle.HashAggregationOperator(GLOBALS_TYPES, [1, 2], GLOBALS_AGGREGATES, step=abi.STEP_PARTIAL, global_aggregation_group_ids=[42],
+                                        group_id_channel=1, produce_default_output=True)
+    (row,), = [p.to_rows() for p in drive(op, [])]
+    assert row[:2] == (None, 42) and row[2] == 0 and row[3:5] == (0, None) and row[5] == 0 and row[7:9] == (0, None) and row[9:] == (0, 0)
+
+
+def hash_builder_resize_pages(oracle, hashed):
+    """testHashBuilderResize's input (…/TestHashAggregationOperator.java:360-399): addSequencePage(10, 100), one row holding a
+    200 000-byte string of zero bytes (larger than MAX_BLOCK_SIZE_IN_BYTES), addSequencePage(10, 100)"""
+    big = Page([Block.varchar([b"\0" * 200_000])], 1)
+    pages = [sequence_page(10, [(abi.VARCHAR, 100)]), big, sequence_page(10, [(abi.VARCHAR, 100)])]
+    types, hc = [abi.VARCHAR], -1
+    if hashed:
+        pages = [Page(p.blocks + [Block.bigint(oracle.hash_page(p, [0]))], p.position_count) for p in pages]
+        types, hc = types + [abi.BIGINT], 1
+    return types, pages, hc
+
+
+def check_hash_builder_resize_rows(rows, hashed):
+    got = sorted((r[0], r[-1]) for r in rows)
+    assert got == sorted([(str(100 + i).encode(), 2) for i in range(10)] + [(b"\0" * 200_000, 1)])
+
+
+@pytest.mark.parametrize("hashed", [False, True])
+def test_hash_builder_resize(oracle, hashed):
+    """The reference asserts only that the operator gets through (toPages); the rows are checked here as well."""
+    types, pages, hc = hash_builder_resize_pages(oracle, hashed)
+    op = oracle.HashAggregationOperator(types, [0], [(abi.AGG_COUNT_STAR, -1, None)], hash_channel=hc, expected_groups=100_000)
+    check_hash_builder_resize_rows([r for p in drive(op, pages) for r in p.to_rows()], hashed)
+
+
+MULTI_SLICE_POSITIONS = int(1.5 * 1024 * 1024 / 32)   # testMultiSliceAggregationOutput: 1.5 x DEFAULT_MAX_PAGE_SIZE_IN_BYTES / fixedWidthSize
+
+
+def multi_slice_input(oracle, hashed):
+    page = sequence_page(MULTI_SLICE_POSITIONS, [(abi.BIGINT, 0), (abi.BIGINT, 0)])
+    types, hc = [abi.BIGINT, abi.BIGINT], -1
+    if hashed:
+        page = Page(page.blocks + [Block.bigint(oracle.hash_page(page, [1]))], page.position_count)
+        types, hc = types + [abi.BIGINT], 2
+    return types, [page], hc
+
+
+@pytest.mark.parametrize("hashed", [False, True])
+def test_multi_slice_aggregation_output(oracle, hashed):
+    """TestHashAggregationOperator.testMultiSliceAggregationOutput (…/TestHashAggregationOperator.java:477-510): 49 152 BIGINT groups,
+    count + avg -> the result leaves as TWO pages (the PageBuilder fills at 1 MB)."""
+    types, pages, hc = multi_slice_input(oracle, hashed)
+    op = oracle.HashAggregationOperator(types, [1], [(abi.AGG_COUNT_STAR, -1, None), (abi.AGG_AVG, 1, abi.BIGINT)], hash_channel=hc, expected_groups=100_000)
+    out = drive(op, pages)
+    assert len(out) == 2
+    rows = [r for p in out for r in p.to_rows()]
+    assert [(r[0], r[-2], r[-1]) for r in rows] == [(i, 1, float(i)) for i in range(MULTI_SLICE_POSITIONS)]
 
 
 def test_gbh1_group_ids_are_first_seen_ordinals(oracle):
