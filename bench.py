@@ -284,10 +284,15 @@ class DeviceWorkload:
         # aggregations run as Step.PARTIAL on every rank and Step.FINAL on rank 0 (HashAggregationOperator.java:390), the
         # ranks' intermediate pages combined in rank order -- inside the step.
         step = abi.STEP_PARTIAL if world > 1 else abi.STEP_SINGLE
+        # the two pipelines of a step are two Drivers of one task on ONE stream of the task's (what desc.stream is for): their
+        # kernels run one after the other -- so that a kernel's HIP-event time is its own -- while the host work of one pipeline
+        # (descriptor, launch, result read-back) overlaps the other's kernels
+        self.stream = _lib.DeviceStream()
         self.factories = {
-            "q6": FusedAggregationOperatorFactory(tpch.Q6_TYPES, tpch.q6_filter(), tpch.q6_projections(), [], tpch.Q6_AGGREGATES, step=step),
+            "q6": FusedAggregationOperatorFactory(tpch.Q6_TYPES, tpch.q6_filter(), tpch.q6_projections(), [], tpch.Q6_AGGREGATES, step=step,
+                                                  stream=self.stream.handle),
             "q1": FusedAggregationOperatorFactory(tpch.Q1_TYPES, tpch.q1_filter(), tpch.q1_projections(), tpch.Q1_GROUP_BY,
-                                                  tpch.Q1_AGGREGATES, type_params=tpch.Q1_TYPE_PARAMS, step=step),
+                                                  tpch.Q1_AGGREGATES, type_params=tpch.Q1_TYPE_PARAMS, step=step, stream=self.stream.handle),
         }
         self.merger = None
         if world > 1:
@@ -336,27 +341,31 @@ class DeviceWorkload:
         self._lib.device_synchronize()
 
     # ---- headline ----
-    def run_query(self, name, timed):
-        op = self.factories[name].createOperator()  # a fresh operator per pass: operators are single-use
-        for p in (self.q6_pages if name == "q6" else self.q1_pages):
-            op.addInput(p)
-        op.finish()
-        out = op.getOutput()
-        if self.world > 1:
-            self.partials[name] = out   # this rank's intermediate states (a host page of a few rows)
-        else:
-            self.results[name] = out.to_rows()
-        ms, n = op.kernelTime()  # also during warm-up: the first event query of a process pays a one-off cost
-        if timed:
-            self.ktime[name][0] += ms
-            self.ktime[name][1] += n
-            self.kname[name] = op.kernelName()
-        op.close()
-
     def step(self, timed):
+        """One pass of every query: each pipeline through a fresh operator (operators are single-use) driven with the Operator protocol
+        -- addInput per page, finish, getOutput.  The Drivers of the step's pipelines are interleaved the way the task executor
+        interleaves them: every pipeline's pages are handed over first, then the results are collected."""
+        ops = []
+        for name in self.queries:
+            op = self.factories[name].createOperator()
+            for p in (self.q6_pages if name == "q6" else self.q1_pages):
+                op.addInput(p)
+            op.finish()
+            ops.append((name, op))
         self.partials = {}
-        for q in self.queries:
-            self.run_query(q, timed)
+        for name, op in ops:
+            out = op.getOutput()
+            if self.world > 1:
+                self.partials[name] = out   # this rank's intermediate states (a host page of a few rows)
+            else:
+                self.results[name] = out.to_rows()
+            ms, n = op.kernelTime()  # also during warm-up: the first event query of a process pays a one-off cost
+            if timed:
+                self.ktime[name][0] += ms
+                self.ktime[name][1] += n
+                if name not in self.kname:
+                    self.kname[name] = op.kernelName()
+            op.close()
         if self.world > 1:
             # PARTIAL -> FINAL across the ranks, inside the step: one small all-gather, the FINAL operators on rank 0
             final = self.merger.merge(self.partials, self.final_operators)
@@ -452,6 +461,9 @@ class DeviceWorkload:
                 "workload": "Q6 fused pipeline over %d rows handed over as PA_MEM_HOST pages of %d rows (pageable host buffers)" % (rows, page_rows)}
 
     def close(self):
+        if getattr(self, "stream", None) is not None:
+            self.stream.destroy()
+            self.stream = None
         if self.q3_on:
             self.q3_stream.destroy()
         if self.comm is not None and self.owns_comm:

@@ -120,7 +120,16 @@ typedef enum pa_page_flags {
     /* PA_MEM_HOST pages only: every buffer of the page is pinned host memory (pa_host_malloc_pinned, or registered with the
      * HIP runtime), so the device can read it directly: small pages are then gathered by one copy kernel instead of one
      * hipMemcpyAsync per block array -- and, when the page is also PA_PAGE_STABLE, by one launch per few thousand pages. */
-    PA_PAGE_PINNED = 2
+    PA_PAGE_PINNED = 2,
+    /* The page's owner keeps its buffers valid and unchanged until the operator calls page.release(page.release_ctx) -- the C-ABI form of
+     * what a reference does for a Java Page (immutable, alive while referenced): a JNI staging slot of PinnedPagePool, the output
+     * buffers of an upstream device operator that hands them over.  The operator calls release exactly once per page, on the
+     * thread of a later call on the same handle (add_input / needs_input / finish / get_output) or of its close, when nothing
+     * reads the page any more; an operator that does not hold on to pages is given the page as a plain one and the library calls
+     * release before pa_op_add_input returns.  Until its release such a page is treated like a PA_PAGE_STABLE one: small pages
+     * are merged into ranges, listed in range tables or copied by ONE gather launch per few thousand pages -- no launch and no wait
+     * per page.  release must not call back into the library. */
+    PA_PAGE_RETAINED = 4
 } pa_page_flags;
 typedef struct pa_page {
     int32_t position_count;
@@ -128,6 +137,8 @@ typedef struct pa_page {
     pa_column* columns;
     int32_t mem;                        /* pa_mem: where every pointer of every column lives */
     int32_t flags;                      /* pa_page_flags */
+    void (*release)(void* ctx);         /* PA_PAGE_RETAINED only */
+    void* release_ctx;
 } pa_page;
 
 /* ---- RowExpression tree, flattened (TM/sql/relational package) ---- */

@@ -293,8 +293,12 @@ inline std::unique_ptr<Operator> createFilterAndProjectOperator(const std::vecto
     return std::make_unique<Operator>(h);
 }
 
+// HashAggregationOperatorFactory (HashAggregationOperator.java:120-202); globalAggregationGroupIds / groupIdChannel (an index among the
+// group-by columns) / produceDefaultOutput: the default rows of the global grouping sets when no page arrives (:486-492, 545-587)
 inline std::unique_ptr<Operator> createHashAggregationOperator(const std::vector<int32_t>& inputTypes, const std::vector<int32_t>& groupByChannels,
-                                                               const std::vector<pa_aggregate>& aggregates, int32_t step = PA_STEP_SINGLE)
+                                                               const std::vector<pa_aggregate>& aggregates, int32_t step = PA_STEP_SINGLE,
+                                                               const std::vector<int32_t>& globalAggregationGroupIds = {}, int32_t groupIdChannel = -1,
+                                                               bool produceDefaultOutput = false)
 {
     pa_hash_aggregation_desc d{};
     d.input_channel_count = (int32_t)inputTypes.size();
@@ -307,6 +311,10 @@ inline std::unique_ptr<Operator> createHashAggregationOperator(const std::vector
     d.aggregates = aggregates.data();
     d.expected_groups = 10000;
     d.output_mem = PA_MEM_HOST;
+    d.produce_default_output = produceDefaultOutput ? 1 : 0;
+    d.group_id_channel = groupIdChannel;
+    d.global_aggregation_group_id_count = (int32_t)globalAggregationGroupIds.size();
+    d.global_aggregation_group_ids = globalAggregationGroupIds.data();
     pa_operator* h = nullptr;
     check(pa_hash_aggregation_create(&d, &h));
     return std::make_unique<Operator>(h);

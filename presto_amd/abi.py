@@ -107,11 +107,15 @@ class pa_page(C.Structure):
         ("columns", C.POINTER(pa_column)),
         ("mem", C.c_int32),
         ("flags", C.c_int32),
+        ("release", C.c_void_p),       # PAGE_RELEASE function pointer (PAGE_RETAINED only)
+        ("release_ctx", C.c_void_p),
     ]
 
 
+PAGE_RELEASE = C.CFUNCTYPE(None, C.c_void_p)
 PAGE_STABLE = 1
 PAGE_PINNED = 2
+PAGE_RETAINED = 4
 
 
 class pa_expr_node(C.Structure):

@@ -757,6 +757,36 @@ int32_t pa_op_add_input(pa_operator* op, const pa_page* page)
         PA_REQUIRE(op != nullptr, PA_ERR_INVALID_ARGUMENT, "operator is null");
         OpScope scope(op);
         PA_REQUIRE(op->needs_input(), PA_ERR_ILLEGAL_STATE, "Operator does not need input");
+        const bool retained = page != nullptr && (page->flags & PA_PAGE_RETAINED) != 0 && page->release != nullptr;
+        if (retained && op->takes_retained()) {
+            op->add_input(page);  // the operator owns the release from here on (it is called even when this call throws: at close at the latest)
+            return PA_OK;
+        }
+        if (retained) {
+            // an operator that does not hold on to pages: the page is taken as a plain one and handed back when the call returns
+            pa_page plain = *page;
+            plain.flags &= ~PA_PAGE_RETAINED;
+            struct Releaser {
+                const pa_page* p;
+                ~Releaser() { p->release(p->release_ctx); }
+            };
+            try {
+                op->add_input(&plain);
+                // device buffers and pinned host buffers are read by the device itself: the reads the operator enqueued must have run
+                // (pageable host buffers were staged by the runtime before hipMemcpyAsync returned)
+                if (plain.mem == PA_MEM_DEVICE || (plain.flags & PA_PAGE_PINNED) != 0) {
+                    hipStream_t m = op->main_stream() ? op->main_stream() : op->private_stream();
+                    if (m) PA_HIP(hipStreamSynchronize(m));
+                    else PA_HIP(hipDeviceSynchronize());
+                }
+            }
+            catch (...) {
+                Releaser r{page};
+                throw;
+            }
+            Releaser r{page};
+            return PA_OK;
+        }
         op->add_input(page);
         // A device page some operator returned is that operator's again with its next call.  Work this operator has enqueued on the
         // page is ordered before that call when both run on the caller's stream; on a stream of the operator's own nothing orders it

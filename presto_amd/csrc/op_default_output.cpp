@@ -60,6 +60,7 @@ public:
     }
     hipStream_t private_stream() override { return inner_->private_stream(); }
     hipStream_t main_stream() override { return inner_->main_stream(); }
+    bool takes_retained() override { return inner_->takes_retained(); }
     bool needs_input() override { return inner_->needs_input(); }
     bool is_blocked() override { return inner_->is_blocked(); }
     int64_t memory_bytes() override { return inner_->memory_bytes(); }

@@ -24,6 +24,10 @@ struct pa_operator {
     // the stream the operator enqueues its work on: pooled HBM blocks released inside one of its calls are tagged with it and
     // re-granted to another stream only once this one has drained (pool.cpp)
     virtual hipStream_t main_stream() { return nullptr; }
+    // PA_PAGE_RETAINED pages: true = the operator keeps reading such a page after add_input returns and calls its release itself, once
+    // nothing reads it any more (and, at the latest, when it is destroyed); false = pa_op_add_input releases the page when the call
+    // returns, after the operator's own stream has drained
+    virtual bool takes_retained() { return false; }
     // pa_aggregation_set_output_topn_hint: the only consumer of this operator's output is a TopN(n; sort channels / orders over the
     // output channels); false = the hint is not taken (everything is emitted)
     virtual bool set_output_topn(int64_t, const int32_t*, const int32_t*, int32_t) { return false; }

@@ -249,6 +249,15 @@ def _state_payload(page):
     return [(int(b.type), int(params[k]) if k < len(params) else 0, b.to_pylist()) for k, b in enumerate(page.blocks)]
 
 
+def _concat_payloads(payloads):
+    """The ranks' payloads of one aggregation behind each other, in rank order: ONE page for the FINAL operator (its combine order
+    is the rows' order: rank 0's states first)."""
+    payloads = [p for p in payloads if p is not None]
+    if not payloads:
+        return None
+    return [(t, param, [v for p in payloads for v in p[k][2]]) for k, (t, param, _values) in enumerate(payloads[0])]
+
+
 def _state_page(cols):
     """The host Page of a received payload; every channel type of a PARTIAL state (include/presto_amd.h): BIGINT counts, DOUBLE /
     BIGINT / DECIMAL(38, s) sums (LONG_DECIMAL: two words per value), min / max values of any type, VARCHAR keys."""
@@ -344,10 +353,8 @@ class PartialStateMerger:
         out = {}
         for name in partial_pages:
             op = make_final_operator[name]()
-            for payload in per_rank:   # rank order
-                cols = payload[name]
-                if cols is None:
-                    continue
+            cols = _concat_payloads([payload[name] for payload in per_rank])   # rank order
+            if cols is not None:
                 op.addInput(_state_page(cols))
             op.finish()
             out[name] = op.getOutput()

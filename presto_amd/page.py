@@ -223,12 +223,15 @@ class Block:
 
 
 class Page:
-    def __init__(self, blocks, position_count=None, mem=abi.MEM_HOST, stable=False, pinned=False):
+    def __init__(self, blocks, position_count=None, mem=abi.MEM_HOST, stable=False, pinned=False, on_release=None):
         """stable: the buffers outlive the operator the page is given to (PA_PAGE_STABLE) -- true of a Java Page, which is
         immutable and kept alive by its references; here of pages over buffers the caller keeps for the whole query.
-        pinned: a host page whose buffers are pinned host memory (PA_PAGE_PINNED)."""
+        pinned: a host page whose buffers are pinned host memory (PA_PAGE_PINNED).
+        on_release: a callable -- the page is handed over as PA_PAGE_RETAINED: its buffers stay valid until the operator calls it
+        (once, from inside a later call on the operator, or its close)."""
         self.stable = stable
         self.pinned = pinned
+        self.on_release = on_release
         self.blocks = list(blocks)
         if position_count is None:
             position_count = self.blocks[0].position_count if self.blocks else 0
@@ -256,6 +259,19 @@ class Page:
         page.columns = C.cast(cols, C.POINTER(abi.pa_column))
         page.mem = self.mem
         page.flags = (abi.PAGE_STABLE if self.stable else 0) | (abi.PAGE_PINNED if self.pinned else 0)
+        if self.on_release is not None:
+            callback = self.on_release
+
+            def release(ctx):
+                try:
+                    callback()
+                except Exception:  # never let an exception cross the C boundary
+                    import traceback
+                    traceback.print_exc()
+            fn = abi.PAGE_RELEASE(release)
+            page.flags |= abi.PAGE_RETAINED
+            page.release = C.cast(fn, C.c_void_p)
+            keep.append(fn)
         keep.append(cols)
         self._c = (page, keep)
         return self._c

@@ -1,7 +1,7 @@
 // page_sweep.cpp -- Q1 + Q6 through the C ABI at the page sizes an unmodified Driver delivers, with no Python in the loop:
 // a Driver thread's view (one needsInput + one addInput native call per page, as the JNI shim of INTEGRATION.md makes them).
 //
-//   page_sweep [--sf 100] [--steps 5] [--layout table|shuffled|separate|host] [--rows N,N,...] [--shared-stream]
+//   page_sweep [--sf 100] [--steps 5] [--layout table|shuffled|separate|retained|host] [--rows N,N,...] [--shared-stream]
 //   --shared-stream  the operators run on a stream the caller made (what a pipeline of device operators does: pages change hands in
 //                    stream order, nobody waits); without it the operator owns its stream and drains it after every page that is
 //                    not PA_PAGE_STABLE, because the caller may recycle the page's buffers once add_input has returned
@@ -10,6 +10,9 @@
 //   shuffled  the same pages in a seeded random order: no page continues its predecessor
 //   separate  every page's columns were copied to buffers of their own (not stable: what a device operator upstream hands
 //             over); bounded to --max-separate-gb of copies
+//   retained  the same separate buffers, handed over as PA_PAGE_RETAINED with a release callback: the producer (an upstream device
+//             operator handing its output buffers over, the staging pool of the JNI shim) keeps a page's buffers until the operator
+//             says it has read them -- the sweep counts the releases: every page exactly once per pass, none missing at close
 //   host      PA_MEM_HOST pages in pinned memory kept until the operator is closed (what the JNI shim's PinnedPagePool stages:
 //             PA_PAGE_STABLE | PA_PAGE_PINNED), bounded sample
 //   hostcopy  the same buffers without the flags: the library copies every block array with hipMemcpyAsync
@@ -183,11 +186,31 @@ struct Factory {
     pa_fused_aggregation_desc desc;
 };
 
+// retained layout: what the producer's release callback does here -- count (a staging pool would put the slot back on its free list)
+struct ReleaseCounter {
+    std::vector<int32_t> per_page;
+    int64_t total = 0;
+};
+struct ReleaseCtx {
+    ReleaseCounter* counter;
+    size_t page;
+};
+static void on_release(void* ctx)
+{
+    ReleaseCtx* c = static_cast<ReleaseCtx*>(ctx);
+    c->counter->per_page[c->page]++;
+    c->counter->total++;
+}
+
 // one pass of a query over its pages with the Driver's call protocol (Driver.java:355-457); returns the spins spent waiting
-static int64_t run_pass(Factory& f, const std::vector<pa_page>& pages, double* first_value)
+static int64_t run_pass(Factory& f, const std::vector<pa_page>& pages, double* first_value, ReleaseCounter* releases = nullptr)
 {
     pa_operator* op = f.create();
     int64_t spins = 0;
+    if (releases) {
+        releases->per_page.assign(pages.size(), 0);
+        releases->total = 0;
+    }
     for (const pa_page& p : pages) {
         while (check(pa_op_needs_input(op)) == 0) {
             // the Driver would yield on isBlocked's future; this thread has nothing else to do
@@ -206,6 +229,11 @@ static int64_t run_pass(Factory& f, const std::vector<pa_page>& pages, double* f
         }
     }
     check(pa_op_close(op));
+    if (releases) {
+        for (size_t i = 0; i < pages.size(); i++) {
+            if (releases->per_page[i] != 1) throw std::runtime_error("retained page " + std::to_string(i) + " released " + std::to_string(releases->per_page[i]) + " times");
+        }
+    }
     return spins;
 }
 
@@ -235,7 +263,8 @@ int main(int argc, char** argv)
     if (shared_stream) check(pa_stream_create(&stream));
     int64_t rows = (int64_t)(kLineitemRowsPerSf * sf);
     const bool host_layout = layout == "host" || layout == "hostcopy";
-    const bool bounded = layout == "separate" || host_layout;
+    const bool retained = layout == "retained";
+    const bool bounded = layout == "separate" || retained || host_layout;
     if (bounded) rows = std::min<int64_t>(rows, (int64_t)(max_copy_gb * 1e9 / 46));
     std::vector<Query> queries = {q6(), q1()};
     // resident columns (the union of both queries' channels is generated once per query here: they share nothing but HBM)
@@ -254,6 +283,8 @@ int main(int argc, char** argv)
     for (int64_t page_rows : sizes) {
         std::vector<PageSet> sets;
         std::vector<std::vector<void*>> owned_dev, owned_host;
+        std::vector<ReleaseCounter> counters(queries.size());
+        std::vector<std::vector<ReleaseCtx>> release_ctx(queries.size());
         for (size_t qi = 0; qi < queries.size(); qi++) {
             PageSet ps = table_pages(columns[qi], rows, page_rows, layout == "table" || layout == "shuffled");
             if (layout == "shuffled") {
@@ -321,7 +352,15 @@ int main(int argc, char** argv)
                         }
                     }
                     ps.pages[pi].mem = host_layout ? PA_MEM_HOST : PA_MEM_DEVICE;
-                    ps.pages[pi].flags = layout == "host" ? (PA_PAGE_STABLE | PA_PAGE_PINNED) : 0;
+                    ps.pages[pi].flags = layout == "host" ? (PA_PAGE_STABLE | PA_PAGE_PINNED) : (retained ? PA_PAGE_RETAINED : 0);
+                }
+                if (retained) {
+                    release_ctx[qi].resize(ps.pages.size());
+                    for (size_t pi = 0; pi < ps.pages.size(); pi++) {
+                        release_ctx[qi][pi] = ReleaseCtx{&counters[qi], pi};
+                        ps.pages[pi].release = &on_release;
+                        ps.pages[pi].release_ctx = &release_ctx[qi][pi];
+                    }
                 }
             }
             sets.push_back(std::move(ps));
@@ -333,14 +372,14 @@ int main(int argc, char** argv)
         }
         double v6 = 0, v1 = 0;
         int64_t spins = 0;
-        for (size_t qi = 0; qi < queries.size(); qi++) run_pass(*factories[qi], sets[qi].pages, nullptr);  // warm-up (JIT cache, pools)
+        for (size_t qi = 0; qi < queries.size(); qi++) run_pass(*factories[qi], sets[qi].pages, nullptr, retained ? &counters[qi] : nullptr);  // warm-up (JIT cache, pools)
         check(pa_stream_synchronize(nullptr));
         const auto t0 = Clock::now();
         double per_query_s[2] = {0, 0};
         for (int s = 0; s < steps; s++) {
             for (size_t qi = 0; qi < queries.size(); qi++) {
                 const auto q0 = Clock::now();
-                spins += run_pass(*factories[qi], sets[qi].pages, qi == 0 ? &v6 : &v1);
+                spins += run_pass(*factories[qi], sets[qi].pages, qi == 0 ? &v6 : &v1, retained ? &counters[qi] : nullptr);
                 per_query_s[qi] += std::chrono::duration<double>(Clock::now() - q0).count();
             }
         }

@@ -175,10 +175,10 @@ static void testPipeline()
     }
 }
 
-// hagg-1: TestHashAggregationOperator.testHashAggregation (:160-219), the columns the device path covers: 3 sequence pages of
-// 40 000 rows (VARCHAR @100, VARCHAR @0 = the group key, VARCHAR @100000/200000/300000, BIGINT @0, BOOLEAN), aggregates
-// count(*), sum(bigint), avg(bigint), count(varchar), count(boolean) -> per key str(i): 3, 3 i, (double) i, 3, 3; the result
-// comes out in more than one page only on the reference (1 MB pages); compared ignoring order, as the reference does.
+// hagg-1: TestHashAggregationOperator.testHashAggregation (:160-219): 3 sequence pages of 40 000 rows (VARCHAR @100, VARCHAR @0 =
+// the group key, VARCHAR @100000/200000/300000, BIGINT @0, BOOLEAN @500), the test's six aggregates count(*), sum(bigint),
+// avg(bigint), max(varchar), count(varchar), count(boolean) -> per key str(i): 3, 3 i, (double) i, str(300000 + i), 3, 3; the
+// result comes out in more than one page only on the reference (1 MB pages); compared ignoring order, as the reference does.
 static void testHashAggregationKat()
 {
     const int32_t n = 40000;
@@ -198,7 +198,7 @@ static void testHashAggregationKat()
     }
     std::vector<int32_t> types = {PA_VARCHAR, PA_VARCHAR, PA_VARCHAR, PA_BIGINT, PA_BOOLEAN};
     std::vector<pa_aggregate> aggs = {{PA_AGG_COUNT_STAR, -1, -1, PA_BIGINT}, {PA_AGG_SUM, 3, -1, PA_BIGINT}, {PA_AGG_AVG, 3, -1, PA_BIGINT},
-                                      {PA_AGG_COUNT, 0, -1, PA_VARCHAR}, {PA_AGG_COUNT, 4, -1, PA_BOOLEAN}};
+                                      {PA_AGG_MAX, 2, -1, PA_VARCHAR}, {PA_AGG_COUNT, 0, -1, PA_VARCHAR}, {PA_AGG_COUNT, 4, -1, PA_BOOLEAN}};
     auto agg = createHashAggregationOperator(types, {1}, aggs);
     auto out = runDriver(input, {agg.get()});
     std::map<std::string, int> seen;
@@ -209,12 +209,50 @@ static void testHashAggregationKat()
             const int64_t v = atoll(k.c_str());
             EXPECT(seen[k]++ == 0, "hagg-1 duplicate key %s", k.c_str());
             EXPECT(p.getBlock(1).getLong(i) == 3 && p.getBlock(2).getLong(i) == 3 * v && p.getBlock(3).getDouble(i) == (double)v &&
-                       p.getBlock(4).getLong(i) == 3 && p.getBlock(5).getLong(i) == 3,
-                   "hagg-1 key %s: %ld %ld %g %ld %ld", k.c_str(), (long)p.getBlock(1).getLong(i), (long)p.getBlock(2).getLong(i),
-                   p.getBlock(3).getDouble(i), (long)p.getBlock(4).getLong(i), (long)p.getBlock(5).getLong(i));
+                       p.getBlock(4).getSlice(i) == std::to_string(300000 + v) && p.getBlock(5).getLong(i) == 3 && p.getBlock(6).getLong(i) == 3,
+                   "hagg-1 key %s: %ld %ld %g %s %ld %ld", k.c_str(), (long)p.getBlock(1).getLong(i), (long)p.getBlock(2).getLong(i),
+                   p.getBlock(3).getDouble(i), p.getBlock(4).getSlice(i).c_str(), (long)p.getBlock(5).getLong(i), (long)p.getBlock(6).getLong(i));
         }
     }
     EXPECT(rows == n && (int64_t)seen.size() == n, "hagg-1 expected %d groups, got %ld", n, (long)rows);
+}
+
+// testHashAggregationWithGlobals (TestHashAggregationOperator.java:221-272): no input page, globalAggregationGroupIds (42, 49),
+// groupIdChannel 1 among the keys (VARCHAR, BIGINT), produceDefaultOutput -> rows (NULL, 42, 0, NULL, NULL, NULL, 0, 0) and
+// (NULL, 49, ...).  Channel layout as in tests/test_oracle_operators.py (the reference's factory is given the key TYPES apart from
+// the channels; here they come from the channels).
+static void testHashAggregationWithGlobals()
+{
+    std::vector<int32_t> types = {PA_VARCHAR, PA_VARCHAR, PA_BIGINT, PA_BIGINT, PA_BIGINT, PA_BOOLEAN, PA_VARCHAR};
+    std::vector<pa_aggregate> aggs = {{PA_AGG_COUNT_STAR, -1, -1, PA_BIGINT}, {PA_AGG_MIN, 4, -1, PA_BIGINT}, {PA_AGG_AVG, 4, -1, PA_BIGINT},
+                                      {PA_AGG_MAX, 6, -1, PA_VARCHAR}, {PA_AGG_COUNT, 0, -1, PA_VARCHAR}, {PA_AGG_COUNT, 5, -1, PA_BOOLEAN}};
+    auto agg = createHashAggregationOperator(types, {1, 2}, aggs, PA_STEP_SINGLE, {42, 49}, 1, true);
+    auto out = runDriver({}, {agg.get()});
+    EXPECT(out.size() == 1 && out[0].getPositionCount() == 2 && out[0].getChannelCount() == 8, "globals: %zu pages", out.size());
+    if (out.size() != 1 || out[0].getPositionCount() != 2) return;
+    const Page& p = out[0];
+    for (int32_t i = 0; i < 2; i++) {
+        EXPECT(p.getBlock(0).isNull(i) && !p.getBlock(1).isNull(i) && p.getBlock(1).getLong(i) == (i == 0 ? 42 : 49), "globals row %d keys", i);
+        EXPECT(p.getBlock(2).getLong(i) == 0 && p.getBlock(3).isNull(i) && p.getBlock(4).isNull(i) && p.getBlock(5).isNull(i) &&
+                   p.getBlock(6).getLong(i) == 0 && p.getBlock(7).getLong(i) == 0, "globals row %d aggregates", i);
+    }
+    // the oracle's twin agrees
+    pa_hash_aggregation_desc d{};
+    std::vector<int32_t> gb = {1, 2}, ids = {42, 49};
+    d.input_channel_count = (int32_t)types.size();
+    d.input_types = types.data();
+    d.group_by_count = 2;
+    d.group_by_channels = gb.data();
+    d.hash_channel = -1;
+    d.aggregate_count = (int32_t)aggs.size();
+    d.aggregates = aggs.data();
+    d.produce_default_output = 1;
+    d.group_id_channel = 1;
+    d.global_aggregation_group_id_count = 2;
+    d.global_aggregation_group_ids = ids.data();
+    pa_page ref{};
+    EXPECT(orc_hash_agg_default_output(&d, &ref) >= 0 && ref.position_count == 2 && ref.channel_count == 8, "oracle default output");
+    orc_free_page(&ref);
 }
 
 // join-1: TestHashJoinOperator.testInnerJoin (core/trino-main/src/test/java/io/trino/operator/join/TestHashJoinOperator.java:192-229):
@@ -309,6 +347,7 @@ int main()
         testDivisionByZero();
         testPipeline();
         testHashAggregationKat();
+        testHashAggregationWithGlobals();
         testJoinAndTopN();
         testDynamicFilterSource();
         pa_shutdown();

@@ -413,3 +413,75 @@ def test_random_mix_of_page_routes(gpu, oracle, monkeypatch, seed):
         for g, e in zip(got, expected):
             assert g[:len(keys)] == e[:len(keys)] and g[len(keys) + 1:] == e[len(keys) + 1:], (g, e)
             assert (g[len(keys)] is None and e[len(keys)] is None) or abs(g[len(keys)] - e[len(keys)]) <= 1e-9 * max(abs(e[len(keys)]), 1.0), (g, e)
+
+
+# ---- PA_PAGE_RETAINED: pages kept by their owner until the operator releases them -----------------------------------------------
+def retained_pages(host, bounds, released, scribble=True):
+    """Every row range of `host` uploaded to buffers of its own and handed over as a retained page.  The release callback does what a
+    staging pool's would -- it takes the buffers back: here it overwrites them with garbage, so an operator that releases a page
+    before its last read of it computes a wrong result."""
+    from presto_amd._lib import check, lib
+    pages = []
+    for i, (lo, hi) in enumerate(zip(bounds[:-1], bounds[1:])):
+        dev = upload_page(host.get_region(lo, hi - lo))
+
+        def on_release(i=i, dev=dev):
+            released.append(i)
+            if scribble:
+                for b in dev.blocks:
+                    for buf in (b.values, b.offsets):
+                        if buf is not None and buf.nbytes:
+                            junk = np.full(buf.nbytes, 0x7F, dtype=np.uint8)
+                            check(lib().pa_memcpy_h2d(buf.ptr, junk.ctypes.data, buf.nbytes, None))
+        pages.append(Page(dev.blocks, dev.position_count, abi.MEM_DEVICE, on_release=on_release))
+    return pages
+
+
+@pytest.mark.parametrize("page_rows", [8192, 65536, 1 << 22])
+def test_retained_pages_are_released_once_and_only_after_their_last_read(gpu, oracle, monkeypatch, page_rows):
+    n, sf = 1_300_003, 0.25
+    host6, (ref_sum, ref_count) = q6_host(oracle, sf, n)
+    bounds = bounds_of(n, page_rows)
+    for gather in (None, "20000"):   # one table of ranges at finish / a launch (and a round of releases) every few pages
+        if gather:
+            monkeypatch.setenv("PRESTO_AMD_GATHER_ROWS", gather)
+        released = []
+        pages = retained_pages(host6, bounds, released)
+        revenue, count = run_q6(pages)
+        assert count == ref_count and abs(revenue - ref_sum) <= 1e-9 * abs(ref_sum)
+        assert sorted(released) == list(range(len(pages)))     # every page, exactly once (the operator is closed)
+    monkeypatch.delenv("PRESTO_AMD_GATHER_ROWS", raising=False)
+    # Q1: VARCHAR channels, the few-groups tier with its late confirmation
+    cols = [oracle.tpch_column(c, sf, 0, n) for c in tpch.Q1_COLUMNS]
+    host1 = Page([Block.varwidth(*c) if t == abi.VARCHAR else Block.flat(t, c[0]) for t, c in zip(tpch.Q1_TYPES, cols)], n)
+    expected = sorted(oracle.q1([cols[0][0], cols[0][1], cols[1][0], cols[1][1]] + [c[0] for c in cols[2:]]))
+    released = []
+    pages = retained_pages(host1, bounds, released)
+    op = FusedAggregationOperator(tpch.Q1_TYPES, tpch.q1_filter(), tpch.q1_projections(), tpch.Q1_GROUP_BY, tpch.Q1_AGGREGATES, type_params=tpch.Q1_TYPE_PARAMS)
+    rows = sorted(r for p in to_pages(op, pages) for r in p.to_rows())
+    op.close()
+    assert sorted(released) == list(range(len(pages)))
+    assert len(rows) == len(expected)
+    for a, e in zip(rows, expected):
+        assert a[:2] == e[:2] and a[-1] == e[-1] and np.allclose(a[2:-1], e[2:-1], rtol=1e-9, atol=0)
+
+
+def test_retained_pages_through_operators_that_do_not_hold_pages(gpu, oracle):
+    """An operator without retention (here: HashAggregation over a high-cardinality key handed over as dictionary blocks, and a
+    FilterAndProject) gets the page as a plain one; the library releases it before add_input returns."""
+    from presto_amd.expr import field
+    from presto_amd.operators import FilterAndProjectOperator
+    released = []
+    host = Page([Block.bigint(np.arange(50_000) % 977), Block.double(np.arange(50_000, dtype=np.float64))], 50_000)
+    pages = retained_pages(host, bounds_of(50_000, 7_000), released, scribble=False)
+    op = FilterAndProjectOperator([abi.BIGINT, abi.DOUBLE], field(0, abi.BIGINT) < 10, [field(0, abi.BIGINT), field(1, abi.DOUBLE)])
+    seen = 0
+    for i, p in enumerate(pages):
+        assert op.needsInput()
+        op.addInput(p)
+        assert released == list(range(i + 1))   # handed back when the call returned
+        out = op.getOutput()
+        seen += out.position_count if out is not None else 0
+    op.finish()
+    op.close()
+    assert seen == int((np.arange(50_000) % 977 < 10).sum())
