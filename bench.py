@@ -10,11 +10,14 @@ figure (every rank holds `--sf` worth of rows) is timed beside it at N > 1.  The
 data-path collective for the scans; the ranks' Step.PARTIAL states (4 groups / 1 row) are merged by a
 Step.FINAL operator on rank 0 inside the step.
 
-Processes.  One rank per GPU.  A rank holds ONE ROCm stack: the library's (/opt/rocm: HIP, RCCL).  torch is imported in a
-rank for torch.distributed over gloo only -- the control plane: rendezvous, barriers, the max-over-ranks clock, shipping the
-RCCL unique id -- and its HIP runtime is never initialised (`torch_cuda_initialized` in the detail file is asserted false);
-tables come from pa_device_malloc, every byte of the data plane moves through pa_comm (RCCL over xGMI), and a fresh
-communicator is pre-flighted (checked 1 MB all-to-all + all-reduce + all-gather under a watchdog) before the first step.
+Processes.  One rank per GPU.  A rank holds ONE ROCm stack: the library's (/opt/rocm: HIP, RCCL, hiprtc).  A rank of the device
+workload never imports torch -- `import torch` puts the wheel's own libamdhip64 / librccl / libhiprtc into the global symbol scope
+and a library loaded afterwards binds to THOSE (presto_amd/control.py) -- `torch_imported` in the detail file is asserted false.
+The control plane (rendezvous, barriers around the timed region, the max-over-ranks clock, shipping the RCCL unique id) is a local
+socket between the ranks of the node (presto_amd/control.py, named after the launcher's MASTER_ADDR / MASTER_PORT); tables come from
+pa_device_malloc, every byte of the data plane moves through pa_comm (RCCL over xGMI), and a fresh communicator is pre-flighted
+(checked 1 MB all-to-all + all-reduce + all-gather under a watchdog) before the first step.  (Checker workloads of the CPU tests
+bring torch.distributed themselves: for them the control plane is the gloo group.)
 
 Output.  ONE JSON line of at most 4 KB on rank 0's stdout: the contract's keys, `roofline`, `cpu_baseline` and one-number
 summaries of the side legs.  Everything else -- per-stage times, results, operator benchmark entries, samples' descriptions --
@@ -68,8 +71,8 @@ def parse_args(argv=None):
     ap.add_argument("--sf300", type=int, default=1, help="1 = also run BASELINE config #5's tables (SF300: 1.80 G lineitem rows, 82.8 GB of "
                     "Q1 / Q6 columns + the Q3 tables) on this one GPU for a few steps (the `sf300` object), N = 1 only; 0 = skip")
     ap.add_argument("--backend", default="nccl", help="the DATA plane between the ranks: 'nccl' (= 'rccl') the library's RCCL communicator, one "
-                    "rank per GPU; 'gloo' (= 'host') the library's host transport, to rehearse the multi-rank control flow with several ranks "
-                    "on one GPU (RCCL refuses two ranks on one device).  The control plane is torch.distributed over gloo either way")
+                    "rank per GPU; 'gloo' (= 'host') the library's host transport over the control plane, to rehearse the multi-rank control "
+                    "flow with several ranks on one GPU (RCCL refuses two ranks on one device)")
     ap.add_argument("--scaling", default="strong", choices=["weak", "strong"],
                     help="what `value` measures at N > 1.  strong (the metric's 'SF100 at 1/2/4/8 GPUs'): the ranks split the ONE --sf table "
                          "by row range; weak: every rank holds --sf worth of rows (its slice of the SF x N table).  The other "
@@ -486,6 +489,9 @@ def rccl_transport(args):
     return args.backend in ("nccl", "rccl")
 
 
+CONTROL = None   # the process's control plane (main() makes it)
+
+
 def make_comm(args):
     """The process's pa_comm, made and pre-flighted under a watchdog: a peer that never arrives leaves ncclCommInitRank (or the first
     collective) waiting for ever -- after --preflight-timeout seconds this rank leaves with PREFLIGHT_FAILED_EXIT_CODE instead."""
@@ -500,7 +506,7 @@ def make_comm(args):
         watchdog.daemon = True
         watchdog.start()
     try:
-        comm = Comm.rccl() if rccl_transport(args) else Comm.host()
+        comm = Comm.rccl(CONTROL) if rccl_transport(args) else Comm.host(CONTROL)
         comm.preflight(1 << 20)
     except Exception as e:
         print("bench.py: communicator pre-flight failed: %s: %s" % (type(e).__name__, e), file=sys.stderr, flush=True)
@@ -513,7 +519,7 @@ def make_comm(args):
 
 def timed_region(workload, dist, world, fn, steps, warmup):
     """W untimed + K timed calls of fn between barrier + device synchronisation on both sides; MAX over the ranks.  The barrier and
-    the MAX run over the control plane (gloo, host tensors); the device synchronisation is the library's (pa_device_synchronize)."""
+    the MAX run over the control plane (`dist`); the device synchronisation is the library's (pa_device_synchronize)."""
     import gc
     for _ in range(warmup):
         fn(False)
@@ -541,10 +547,7 @@ def timed_region(workload, dist, world, fn, steps, warmup):
     if os.environ.get("BENCH_DEBUG"):
         print("step ms:", ["%.2f" % (x * 1e3) for x in step_times], file=sys.stderr)
     if world > 1:
-        import torch
-        t = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed = float(dist.all_reduce_max(elapsed))
     return elapsed
 
 
@@ -738,16 +741,26 @@ def main(argv=None, workload_factory=None, out=None):
         os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    global CONTROL
     dist = None
     device = None
     make_workload = workload_factory or load_workload_class(args.workload)
     on_device = make_workload is DeviceWorkload
+    torch_group = False
     if world > 1:
-        # the control plane: torch.distributed over gloo, host tensors only.  torch's own HIP runtime stays uninitialised in a
-        # rank -- the GPU belongs to the library's ROCm stack (see the module docstring)
-        import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("gloo")
+        if on_device:
+            # the control plane of device ranks: a local socket, no torch in the process (see the module docstring)
+            from presto_amd.control import ControlPlane
+            dist = ControlPlane(rank, world, timeout=max(args.preflight_timeout, 60))
+        else:
+            # checker workloads run the oracle's operators on CPU ranks and exchange over torch.distributed themselves
+            import torch.distributed as torch_dist
+            from presto_amd.control import TorchControlPlane
+            torch_dist.init_process_group("gloo")
+            torch_group = True
+            dist = TorchControlPlane()
+        CONTROL = dist
     if on_device:
         from presto_amd._lib import lib
         n_dev = lib().pa_device_count()
@@ -800,12 +813,12 @@ def main(argv=None, workload_factory=None, out=None):
                                            "all-gather over the library's communicator to the Step.FINAL operators on rank 0, inside the step; Q3 (the `q3` "
                                            "object) shuffles its join sides between the ranks",
                        "data_plane": None if world == 1 else ("RCCL (library's /opt/rocm stack)" if rccl_transport(args) else "host transport over gloo (rehearsal)"),
-                       "control_plane": None if world == 1 else "torch.distributed gloo (host tensors)"},
+                       "control_plane": None if world == 1 else ("local socket between the ranks (presto_amd/control.py), no torch in the process" if on_device
+                                                                   else "torch.distributed gloo (checker workload)")},
             "detail_path": args.detail,
         }
-        if "torch" in sys.modules and on_device and world > 1:
-            import torch
-            detail["torch_cuda_initialized"] = bool(torch.cuda.is_initialized())
+        if on_device:
+            detail["torch_imported"] = "torch" in sys.modules   # (bench_ops and the legs of this file bring none)
         r1 = workload.roofline("q1", args.steps, pmc) if "q1" in queries else None
         r6 = workload.roofline("q6", args.steps, pmc) if "q6" in queries else None
         detail["roofline"] = r1 or r6
@@ -914,12 +927,13 @@ def main(argv=None, workload_factory=None, out=None):
         dist.barrier()  # (still under the watchdog: a rank whose Q3 leg failed arrives here while the others wait inside a collective)
         if watchdog is not None:
             watchdog.cancel()
-        if on_device and "torch" in sys.modules:
-            import torch
-            if torch.cuda.is_initialized():   # a second ROCm stack came up in this rank: the run is not what it claims to be
-                print("bench.py: torch's HIP runtime was initialised in rank %d" % rank, file=sys.stderr)
-                exit_code = exit_code or 5
-        dist.destroy_process_group()
+        if on_device and "torch" in sys.modules:   # a second ROCm stack in this rank: the run is not what it claims to be
+            print("bench.py: torch was imported in rank %d" % rank, file=sys.stderr)
+            exit_code = exit_code or 5
+        dist.close()
+        if torch_group:
+            import torch.distributed as torch_dist
+            torch_dist.destroy_process_group()
     if line_fd is not None:
         sys.stdout.flush()
         os.dup2(line_fd, 1)

@@ -2492,7 +2492,7 @@ int32_t orc_q1_add(orc_hash_agg* agg, const uint8_t* returnflag, const int32_t* 
             cols[2 + c].encoding = PA_FLAT;
             cols[2 + c].values = d[c];
         }
-        pa_page page = {m, 7, cols, PA_MEM_HOST, 0};
+        pa_page page = {m, 7, cols, PA_MEM_HOST, 0, NULL, NULL};
         int32_t rc = orc_hash_agg_add_page(agg, &page, NULL);
         if (rc < 0) {
             return rc;

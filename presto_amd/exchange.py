@@ -14,9 +14,9 @@ and pulled over HTTP.  Here: one rank per GPU, P = world size.  Everything on th
 the device, the exchange source runs ONE count all-gather and ONE variable all-to-all (grouped ncclSend / ncclRecv, RCCL
 over xGMI) per exchange and hands the received rows out as one page.  This module only creates the handles:
 
-  Comm          pa_comm: the RCCL communicator (the 128-byte unique id travels through torch.distributed here; in Trino the
-                coordinator would ship it), or the host transport, whose two collectives this module does over
-                torch.distributed (gloo) -- several ranks sharing one GPU in the tests
+  Comm          pa_comm: the RCCL communicator (the 128-byte unique id travels through the control plane -- presto_amd/control.py, or a
+                torch.distributed group in the CPU tests; in Trino the coordinator would ship it), or the host transport, whose two
+                collectives this module does over the control plane -- several ranks sharing one GPU in the tests
   Exchange      pa_exchange: the OutputBuffer + ExchangeClient pair of one exchange on this rank
   ExchangeOperator   sink + source behind one Operator, for a Driver pipeline that contains the exchange step
 """
@@ -43,33 +43,35 @@ class Comm:
         return Comm(h, 0, 1)
 
     @staticmethod
-    def rccl(group=None):
-        import torch.distributed as dist
-        rank, world = dist.get_rank(group), dist.get_world_size(group)
+    def rccl(control=None, group=None):
+        """ncclCommInitRank over the ranks of `control` (presto_amd.control.ControlPlane: the torch-free control plane of bench.py's
+        ranks) or, without one, of the torch.distributed group.  Collective."""
+        if control is None:
+            from .control import TorchControlPlane
+            control = TorchControlPlane(group)
         ident = (C.c_uint8 * abi.COMM_ID_BYTES)()
-        if rank == 0:
+        if control.rank == 0:
             check(lib().pa_comm_unique_id(ident))
-        box = [bytes(ident)]
-        dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
-        ident = (C.c_uint8 * abi.COMM_ID_BYTES).from_buffer_copy(box[0])
+        ident = (C.c_uint8 * abi.COMM_ID_BYTES).from_buffer_copy(control.broadcast(bytes(ident), src=0))
         h = C.c_void_p()
-        check(lib().pa_comm_create(ident, rank, world, C.byref(h)))
-        return Comm(h, rank, world)
+        check(lib().pa_comm_create(ident, control.rank, control.world, C.byref(h)))
+        return Comm(h, control.rank, control.world)
 
     @staticmethod
-    def host(group=None):
-        """The two collectives done here, over torch.distributed on host tensors (gloo): pa_host_transport."""
+    def host(control=None, group=None):
+        """The two collectives done by the host, over the control plane (pa_host_transport): several ranks sharing one GPU in the
+        tests -- RCCL refuses that -- not a data path."""
         import numpy as np
-        import torch
-        import torch.distributed as dist
-        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        if control is None:
+            from .control import TorchControlPlane
+            control = TorchControlPlane(group)
+        rank, world = control.rank, control.world
 
         def all_gather(ctx, send, recv, count):
             try:
-                s = torch.from_numpy(np.ctypeslib.as_array(send, shape=(count,)).copy())
-                out = torch.empty(world * count, dtype=torch.int64)
-                dist.all_gather_into_tensor(out, s, group=group)
-                np.ctypeslib.as_array(recv, shape=(world * count,))[:] = out.numpy()
+                mine = np.ctypeslib.as_array(send, shape=(count,)).tobytes()
+                got = control.all_gather(mine)
+                np.ctypeslib.as_array(recv, shape=(world * count,))[:] = np.frombuffer(b"".join(got), dtype=np.int64)
                 return 0
             except Exception:  # never let an exception cross the C boundary
                 import traceback
@@ -86,15 +88,11 @@ class Comm:
                 rtotal = max([o + b for o, b in zip(ro, rb)] + [0])
                 src = np.ctypeslib.as_array(C.cast(send, C.POINTER(C.c_uint8)), shape=(max(stotal, 1),))
                 dst = np.ctypeslib.as_array(C.cast(recv, C.POINTER(C.c_uint8)), shape=(max(rtotal, 1),))
-                # the blobs of consecutive peers are contiguous, but go by the offsets all the same
-                s = torch.from_numpy(np.concatenate([src[o:o + b] for o, b in zip(so, sb)]) if stotal else np.zeros(0, np.uint8))
-                out = torch.empty(sum(rb), dtype=torch.uint8)
-                dist.all_to_all_single(out, s, output_split_sizes=rb, input_split_sizes=sb, group=group)
-                o = out.numpy()
-                at = 0
-                for off, b in zip(ro, rb):
-                    dst[off:off + b] = o[at:at + b]
-                    at += b
+                got = control.all_to_all([src[o:o + b].tobytes() for o, b in zip(so, sb)])
+                for off, b, blob in zip(ro, rb, got):
+                    if len(blob) != b:
+                        raise ValueError("all_to_all_v: %d bytes arrived where %d were announced" % (len(blob), b))
+                    dst[off:off + b] = np.frombuffer(blob, dtype=np.uint8)
                 return 0
             except Exception:
                 import traceback

@@ -12,8 +12,8 @@ pytestmark = pytest.mark.gpu
 
 
 def test_bench_two_ranks_as_a_plain_subprocess(gpu, oracle, tmp_path):
-    """Two ranks on the one GPU over the library's host transport.  Inside the ranks torch is the control plane only: its HIP runtime
-    is never initialised (the detail file says so, and a rank that found it initialised leaves with exit code 5)."""
+    """Two ranks on the one GPU over the library's host transport.  The ranks never import torch (the detail file says so, and a rank
+    that finds it imported leaves with exit code 5): control plane = presto_amd/control.py, one ROCm stack per process."""
     sf = 0.05
     path = str(tmp_path / "detail.json")
     r = run_bench(["--gpus", "2", "--backend", "gloo", "--sf", str(sf), "--steps", "2", "--warmup", "1", "--cpu-rows", "0", "--detail", path], timeout=900)
@@ -21,7 +21,7 @@ def test_bench_two_ranks_as_a_plain_subprocess(gpu, oracle, tmp_path):
     line = check_line_shape(r.stdout.decode())
     d = json.load(open(path))
     rows = tpch.lineitem_rows(sf)
-    assert d["torch_cuda_initialized"] is False
+    assert d["torch_imported"] is False and d["config"]["control_plane"].startswith("local socket")
     assert line["n_gpus"] == 2 and line["scaling"] == "strong" and d["weak"]["scaling"] == "weak" and line["weak"]["value"] > 0
     assert d["weak"]["rows_per_gpu_rank0"] == rows and d["config"]["rows_per_gpu"] == rows // 2 // 4 * 4
     assert abs(d["value"] - 2 * rows * 2 / (d["ms_per_step"] * 2 / 1e3)) <= 1e-6 * d["value"]
