@@ -91,7 +91,7 @@ public final class GpuOperator
         Page loaded = page.getLoadedPage();                  // LazyBlock -> loaded (PageProcessor.java:341-343)
         PinnedPagePool.StagedPage s = staging.stage(loaded); // long[] / int[] / byte[] / Slice bytes + offsets + valueIsNull
         GpuNative.addInput(handle, s.positions, s.channels, s.types, s.encodings, s.valueOffsets, s.offsetOffsets, s.nullOffsets, s.idOffsets,
-                s.dictionaryChannel, s.dictionarySize, s.buffer, s.stable);
+                s.dictionaryChannel, s.dictionarySize, s.buffer, s.stable ? 1 : 0, 0L);
         operatorContext.recordProcessedInput(page.getSizeInBytes(), page.getPositionCount());
     }
 

@@ -41,12 +41,13 @@ final class PinnedPagePool
 
     private static final int SLAB_BYTES = 4 << 20;
     private final List<Type> types;
-    private final List<ByteBuffer> slabs = new ArrayList<>();
+    private final List<ByteBuffer> slabs;
     private ByteBuffer current;
 
     PinnedPagePool(List<Type> types)
     {
         this.types = types;
+        this.slabs = new ArrayList<>();
     }
 
     StagedPage stage(Page page)
@@ -178,6 +179,51 @@ final class PinnedPagePool
             slabs.add(current);
         }
         return current;
+    }
+
+    /**
+     * A page of a page source: the blocks that are loaded are staged as stage() does; an unloaded LazyBlock gets its type and encoding
+     * only (the native side asks for it through GpuPageSource.loadBlock when an expression needs it).  The slab of a scan's page is
+     * reused for the next page: the native operator has consumed a page when it asks for the next one.
+     */
+    StagedPage stageLoadedBlocks(Page page)
+    {
+        Block[] blocks = new Block[page.getChannelCount()];
+        for (int c = 0; c < blocks.length; c++) {
+            Block b = page.getBlock(c);
+            boolean loaded = !(b instanceof io.trino.spi.block.LazyBlock) || b.isLoaded();
+            // an unloaded block is staged as an empty block of its channel's kind: positions are the page's, arrays absent
+            blocks[c] = loaded ? b.getLoadedBlock() : types.get(c).createBlockBuilder(null, 0).build();
+        }
+        if (current != null) {
+            current.clear();          // (the previous page of this source was consumed)
+        }
+        StagedPage s = stage(new Page(page.getPositionCount(), blocks));
+        s.stable = false;
+        return s;
+    }
+
+    /** One block staged on its own (a LazyBlock the native side asked for): the addresses of [values, offsets, nulls], 0 = absent. */
+    long[] stageBlock(int channel, Block loaded)
+    {
+        List<Type> saved = new ArrayList<>(types);
+        StagedPage s = new PinnedPagePool(java.util.Collections.singletonList(saved.get(channel)), this).stage(new Page(loaded.getPositionCount(), loaded));
+        long base = GpuNative.bufferAddress(s.buffer);
+        return new long[] {s.valueOffsets[0] >= 0 ? base + s.valueOffsets[0] : 0, s.offsetOffsets[0] >= 0 ? base + s.offsetOffsets[0] : 0,
+                s.nullOffsets[0] >= 0 ? base + s.nullOffsets[0] : 0};
+    }
+
+    /** A view of `parent` for one channel: stages into the parent's slabs (they are released with the parent). */
+    private PinnedPagePool(List<Type> types, PinnedPagePool parent)
+    {
+        this.types = types;
+        this.slabs = parent.slabs;
+        this.current = parent.current;
+    }
+
+    void close()
+    {
+        releaseAll();
     }
 
     void releaseAll()

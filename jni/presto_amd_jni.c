@@ -22,6 +22,7 @@
 
 static void throw_native(JNIEnv* env, int32_t status)
 {
+    if ((*env)->ExceptionCheck(env)) return;   /* a Java exception raised inside a page-source callback is the one that propagates */
     /* GpuNativeException(int status, String message) maps pa_status onto io.trino.spi.StandardErrorCode:
      * NUMERIC_VALUE_OUT_OF_RANGE, DIVISION_BY_ZERO, GENERIC_INSUFFICIENT_RESOURCES, NOT_SUPPORTED, GENERIC_INTERNAL_ERROR */
     jclass cls = (*env)->FindClass(env, "io/trino/gpu/GpuNativeException");
@@ -180,24 +181,266 @@ static void fill_aggregates(JNIEnv* env, jintArray fns, jintArray inputs, jintAr
     free(f); free(in); free(m); free(t);
 }
 
+/* HashAggregationOperatorFactory's arguments (HashAggregationOperator.java:120-202): globalAggregationGroupIds (may be null), groupIdChannel
+ * (an index among the group-by columns, -1 = Optional.empty()), produceDefaultOutput, maxPartialMemory in bytes (0 = no early flush),
+ * stateFormat = pa_state_format of a PARTIAL step's output / a FINAL step's input. */
 JNIEXPORT jlong JNICALL Java_io_trino_gpu_GpuNative_createHashAggregation(JNIEnv* env, jclass c, jintArray inputTypes, jintArray typeParams,
-        jintArray groupByChannels, jint hashChannel, jint step, jintArray aggFns, jintArray aggInputs, jintArray aggMasks, jintArray aggInputTypes,
-        jint expectedGroups, jint outputMem)
+        jintArray groupByChannels, jintArray globalAggregationGroupIds, jint hashChannel, jint groupIdChannel, jint step, jboolean produceDefaultOutput,
+        jintArray aggFns, jintArray aggInputs, jintArray aggMasks, jintArray aggInputTypes, jint expectedGroups, jlong maxPartialMemory, jint stateFormat,
+        jint outputMem)
 {
-    jsize n, np_, ng, na;
+    jsize n, np_, ng, na, nids;
     pa_hash_aggregation_desc d;
     memset(&d, 0, sizeof d);
     int32_t *types = ints_of(env, inputTypes, &n), *params = ints_of(env, typeParams, &np_), *gb = ints_of(env, groupByChannels, &ng);
+    int32_t* ids = ints_of(env, globalAggregationGroupIds, &nids);
     pa_aggregate* aggs;
     fill_aggregates(env, aggFns, aggInputs, aggMasks, aggInputTypes, &aggs, &na);
     d.input_channel_count = n; d.input_types = types; d.input_type_params = np_ == n ? params : 0;
     d.group_by_count = ng; d.group_by_channels = gb; d.hash_channel = hashChannel; d.step = step;
     d.aggregate_count = na; d.aggregates = aggs; d.expected_groups = expectedGroups; d.output_mem = outputMem;
+    d.max_partial_memory = maxPartialMemory; d.state_format = stateFormat;
+    d.produce_default_output = produceDefaultOutput ? 1 : 0; d.group_id_channel = groupIdChannel;
+    d.global_aggregation_group_id_count = nids; d.global_aggregation_group_ids = ids;
     pa_operator* op = 0;
     int32_t rc = pa_hash_aggregation_create(&d, &op);   /* group_by_count == 0: AggregationOperator */
-    free(aggs); free(gb); free(params); free(types);
+    free(aggs); free(ids); free(gb); free(params); free(types);
     if (rc < 0) { throw_native(env, rc); return 0; }
     return (jlong)(intptr_t)op;
+}
+
+/* AggregationOperator.AggregationOperatorFactory (AggregationOperator.java:40-140; LocalExecutionPlanner.java:3389): ungrouped aggregates */
+JNIEXPORT jlong JNICALL Java_io_trino_gpu_GpuNative_createAggregation(JNIEnv* env, jclass c, jintArray inputTypes, jint step, jintArray aggFns, jintArray aggInputs,
+        jintArray aggMasks, jintArray aggInputTypes, jint stateFormat, jint outputMem)
+{
+    jsize n, na;
+    pa_aggregation_desc d;
+    memset(&d, 0, sizeof d);
+    int32_t* types = ints_of(env, inputTypes, &n);
+    pa_aggregate* aggs;
+    fill_aggregates(env, aggFns, aggInputs, aggMasks, aggInputTypes, &aggs, &na);
+    d.input_channel_count = n; d.input_types = types; d.aggregate_count = na; d.aggregates = aggs; d.step = step; d.output_mem = outputMem;
+    d.state_format = stateFormat;
+    pa_operator* op = 0;
+    int32_t rc = pa_aggregation_create(&d, &op);
+    free(aggs); free(types);
+    if (rc < 0) { throw_native(env, rc); return 0; }
+    return (jlong)(intptr_t)op;
+}
+
+/* OrderByOperator.OrderByOperatorFactory (OrderByOperator.java:45-120) */
+JNIEXPORT jlong JNICALL Java_io_trino_gpu_GpuNative_createOrderBy(JNIEnv* env, jclass c, jintArray inputTypes, jintArray outputChannels, jintArray sortChannels,
+        jintArray sortOrders, jint outputMem)
+{
+    jsize n, no, ns, nso;
+    pa_order_by_desc d;
+    memset(&d, 0, sizeof d);
+    int32_t *types = ints_of(env, inputTypes, &n), *oc = ints_of(env, outputChannels, &no), *sc = ints_of(env, sortChannels, &ns), *so = ints_of(env, sortOrders, &nso);
+    d.input_channel_count = n; d.input_types = types; d.output_channel_count = no; d.output_channels = oc; d.sort_channel_count = ns; d.sort_channels = sc;
+    d.sort_orders = so; d.output_mem = outputMem;
+    pa_operator* op = 0;
+    int32_t rc = ns == nso ? pa_order_by_create(&d, &op) : PA_ERR_INVALID_ARGUMENT;
+    free(so); free(sc); free(oc); free(types);
+    if (rc == PA_ERR_INVALID_ARGUMENT && ns != nso) { throw_message(env, rc, "one sort order per sort channel"); return 0; }
+    if (rc < 0) { throw_native(env, rc); return 0; }
+    return (jlong)(intptr_t)op;
+}
+
+/* DynamicFilterSourceOperator.DynamicFilterSourceOperatorFactory (DynamicFilterSourceOperator.java:74-139; LocalExecutionPlanner.java:2536-2539) */
+JNIEXPORT jlong JNICALL Java_io_trino_gpu_GpuNative_createDynamicFilterSource(JNIEnv* env, jclass c, jintArray inputTypes, jintArray filterChannels,
+        jint maxDistinctValues, jint minMaxCollectionLimit, jlong maxFilterSizeBytes)
+{
+    jsize n, nf;
+    pa_dynamic_filter_source_desc d;
+    memset(&d, 0, sizeof d);
+    int32_t *types = ints_of(env, inputTypes, &n), *fc = ints_of(env, filterChannels, &nf);
+    d.input_channel_count = n; d.input_types = types; d.filter_channel_count = nf; d.filter_channels = fc; d.max_distinct_values = maxDistinctValues;
+    d.min_max_collection_limit = minMaxCollectionLimit; d.max_filter_size_bytes = maxFilterSizeBytes;
+    pa_operator* op = 0;
+    int32_t rc = pa_dynamic_filter_source_create(&d, &op);
+    free(fc); free(types);
+    if (rc < 0) { throw_native(env, rc); return 0; }
+    return (jlong)(intptr_t)op;
+}
+/* The TupleDomain handed to dynamicPredicateConsumer once the operator has finished: null while it is not ready, else
+ * long[1 + 6 * channels]: [0] isAll (TupleDomain.all(): nothing was collected), then per filter channel: kind (pa_domain_kind), valueCount,
+ * type, values address, values bytes, offsets address (VARCHAR) -- host memory of the operator, valid until it is closed. */
+static int64_t value_width(int32_t type);
+JNIEXPORT jlongArray JNICALL Java_io_trino_gpu_GpuNative_dynamicFilterPoll(JNIEnv* env, jclass c, jlong h, jint channels)
+{
+    if (channels < 0 || channels > MAX_CHANNELS) { throw_message(env, PA_ERR_INVALID_ARGUMENT, "bad filter channel count"); return 0; }
+    pa_domain domains[MAX_CHANNELS];
+    memset(domains, 0, sizeof domains);
+    int32_t is_all = 0;
+    int32_t rc = pa_dynamic_filter_poll((pa_operator*)(intptr_t)h, &is_all, domains, channels);
+    if (rc < 0) { throw_native(env, rc); return 0; }
+    if (rc == 0) return 0;
+    const jsize len = 1 + 6 * channels;
+    jlong* v = (jlong*)calloc((size_t)len, sizeof(jlong));
+    v[0] = is_all;
+    for (jint i = 0; i < channels; i++) {
+        jlong* r = v + 1 + 6 * i;
+        const pa_column* col = &domains[i].values;
+        r[0] = domains[i].kind; r[1] = domains[i].value_count; r[2] = col->type; r[3] = (jlong)(intptr_t)col->values;
+        r[4] = col->encoding == PA_VARWIDTH ? (domains[i].value_count > 0 && col->offsets ? col->offsets[domains[i].value_count] : 0)
+                                             : (jlong)domains[i].value_count * value_width(col->type);
+        r[5] = (jlong)(intptr_t)col->offsets;
+    }
+    jlongArray result = (*env)->NewLongArray(env, len);
+    (*env)->SetLongArrayRegion(env, result, 0, len, v);
+    free(v);
+    return result;
+}
+
+/* The worker's HBM budget for operator memory (the memory pool as the device sees it) and its use: long[3] = in use, cached, limit */
+JNIEXPORT void JNICALL Java_io_trino_gpu_GpuNative_memorySetLimit(JNIEnv* env, jclass c, jlong bytes) { CHECK(pa_memory_set_limit(bytes)); }
+JNIEXPORT jlongArray JNICALL Java_io_trino_gpu_GpuNative_memoryStats(JNIEnv* env, jclass c)
+{
+    int64_t v[3] = {0, 0, 0};
+    int32_t rc = pa_memory_stats(&v[0], &v[1], &v[2]);
+    if (rc < 0) { throw_native(env, rc); return 0; }
+    jlong j[3] = {v[0], v[1], v[2]};
+    jlongArray result = (*env)->NewLongArray(env, 3);
+    (*env)->SetLongArrayRegion(env, result, 0, 3, j);
+    return result;
+}
+
+/* ---- ScanFilterAndProjectOperator: the ConnectorPageSource stays on the Java side, the native operator pulls pages through it ----
+ * pageSource: an io.trino.gpu.GpuPageSource (java/io/trino/gpu/GpuPageSource.java), whose three methods are called back from inside
+ * getOutput, on the Driver's thread:
+ *   long[] nextPage()        ConnectorPageSource.getNextPage staged into the source's pinned slab; null = finished, else
+ *                            [positions, channels, slab address, then per channel: type, encoding, values offset, offsets offset,
+ *                             nulls offset, loaded] -- offsets inside the slab, -1 = absent; loaded = 0: a LazyBlock not loaded yet
+ *   long[] loadBlock(int c)  LazyBlock.getLoadedBlock of channel c of that page, staged (possibly into another slab): the ADDRESSES of
+ *                            [values, offsets, nulls], 0 = absent
+ *   void close()             ConnectorPageSource.close
+ * A Java exception thrown by one of them stays pending and surfaces when the native returns (the operator reports PA_ERR_DEVICE). */
+typedef struct scan_source {
+    JavaVM* vm;
+    jobject source;              /* global reference */
+    jmethodID next_page, load_block, close;
+    pa_column cols[MAX_CHANNELS];
+    char* base;
+} scan_source;
+static JNIEnv* scan_env(scan_source* s)
+{
+    JNIEnv* env = 0;
+    return (*s->vm)->GetEnv(s->vm, (void**)&env, JNI_VERSION_1_8) == JNI_OK ? env : 0;
+}
+static int32_t scan_next_page(void* ctx, pa_page* page)
+{
+    scan_source* s = (scan_source*)ctx;
+    JNIEnv* env = scan_env(s);
+    if (!env) return PA_ERR_DEVICE;
+    jlongArray a = (jlongArray)(*env)->CallObjectMethod(env, s->source, s->next_page);
+    if ((*env)->ExceptionCheck(env)) return PA_ERR_DEVICE;
+    if (!a) return 0;
+    const jsize len = (*env)->GetArrayLength(env, a);
+    jlong* v = (*env)->GetLongArrayElements(env, a, 0);
+    int32_t rc = 1;
+    const jlong channels = len >= 3 ? v[1] : -1;
+    if (channels < 0 || channels > MAX_CHANNELS || len != 3 + 6 * channels) rc = PA_ERR_INVALID_ARGUMENT;
+    else {
+        s->base = (char*)(intptr_t)v[2];
+        memset(s->cols, 0, sizeof s->cols);
+        for (jlong i = 0; i < channels; i++) {
+            const jlong* r = v + 3 + 6 * i;
+            pa_column* col = &s->cols[i];
+            col->type = (int32_t)r[0];
+            col->encoding = (int32_t)r[1];
+            if (r[5]) {   /* loaded; else values and dictionary stay NULL: a LazyBlock (include/presto_amd.h, pa_page_source) */
+                col->values = r[2] >= 0 ? s->base + r[2] : 0;
+                col->offsets = r[3] >= 0 ? (const int32_t*)(s->base + r[3]) : 0;
+                col->nulls = r[4] >= 0 ? (const uint8_t*)(s->base + r[4]) : 0;
+            }
+        }
+        memset(page, 0, sizeof *page);
+        page->position_count = (int32_t)v[0];
+        page->channel_count = (int32_t)channels;
+        page->columns = s->cols;
+        page->mem = PA_MEM_HOST;
+    }
+    (*env)->ReleaseLongArrayElements(env, a, v, JNI_ABORT);
+    return rc;
+}
+static int64_t scan_load_block(void* ctx, int32_t channel, pa_column* column)
+{
+    scan_source* s = (scan_source*)ctx;
+    JNIEnv* env = scan_env(s);
+    if (!env) return PA_ERR_DEVICE;
+    jlongArray a = (jlongArray)(*env)->CallObjectMethod(env, s->source, s->load_block, (jint)channel);
+    if ((*env)->ExceptionCheck(env) || !a) return PA_ERR_DEVICE;
+    jlong* v = (*env)->GetLongArrayElements(env, a, 0);
+    const int ok = (*env)->GetArrayLength(env, a) == 3 && channel >= 0 && channel < MAX_CHANNELS;
+    if (ok) {
+        *column = s->cols[channel];   /* type and encoding as nextPage announced them */
+        column->values = (const void*)(intptr_t)v[0];
+        column->offsets = (const int32_t*)(intptr_t)v[1];
+        column->nulls = (const uint8_t*)(intptr_t)v[2];
+    }
+    (*env)->ReleaseLongArrayElements(env, a, v, JNI_ABORT);
+    return ok && column->values ? 0 : PA_ERR_INVALID_ARGUMENT;
+}
+static void scan_close(void* ctx)
+{
+    scan_source* s = (scan_source*)ctx;
+    JNIEnv* env = scan_env(s);
+    if (env) {
+        (*env)->CallVoidMethod(env, s->source, s->close);
+        (*env)->DeleteGlobalRef(env, s->source);
+    }
+    free(s);
+}
+JNIEXPORT jlong JNICALL Java_io_trino_gpu_GpuNative_createScanFilterProject(JNIEnv* env, jclass c, jobject pageSource, jintArray inputTypes, jintArray typeParams,
+        jlong filter, jlongArray projections, jlong minOutputPageBytes, jint minOutputPageRows, jint outputMem)
+{
+    jsize n, np_, nproj = (*env)->GetArrayLength(env, projections);
+    pa_filter_project_desc d;
+    memset(&d, 0, sizeof d);
+    scan_source* s = (scan_source*)calloc(1, sizeof(scan_source));
+    (*env)->GetJavaVM(env, &s->vm);
+    jclass cls = (*env)->GetObjectClass(env, pageSource);
+    s->next_page = (*env)->GetMethodID(env, cls, "nextPage", "()[J");
+    s->load_block = (*env)->GetMethodID(env, cls, "loadBlock", "(I)[J");
+    s->close = (*env)->GetMethodID(env, cls, "close", "()V");
+    if (!s->next_page || !s->load_block || !s->close) {
+        free(s);
+        throw_message(env, PA_ERR_INVALID_ARGUMENT, "pageSource must be an io.trino.gpu.GpuPageSource");
+        return 0;
+    }
+    s->source = (*env)->NewGlobalRef(env, pageSource);
+    int32_t* types = ints_of(env, inputTypes, &n);
+    int32_t* params = ints_of(env, typeParams, &np_);
+    pa_expr* pe = (pa_expr*)calloc((size_t)(nproj > 0 ? nproj : 1), sizeof(pa_expr));
+    jlong* ph = (*env)->GetLongArrayElements(env, projections, 0);
+    for (jsize i = 0; i < nproj; i++) pe[i] = ((native_expr*)(intptr_t)ph[i])->expr;
+    (*env)->ReleaseLongArrayElements(env, projections, ph, JNI_ABORT);
+    d.input_channel_count = n; d.input_types = types; d.input_type_params = np_ == n ? params : 0;
+    d.filter = filter ? &((native_expr*)(intptr_t)filter)->expr : 0;
+    d.projection_count = nproj; d.projections = pe; d.output_mem = outputMem;
+    d.min_output_page_bytes = minOutputPageBytes; d.min_output_page_rows = minOutputPageRows;
+    pa_page_source src = {s, scan_next_page, scan_load_block, scan_close};
+    pa_operator* op = 0;
+    int32_t rc = pa_scan_filter_project_create(&d, &src, &op);
+    free(pe); free(params); free(types);
+    if (rc < 0) {   /* the operator was not made: the source is still ours */
+        (*env)->DeleteGlobalRef(env, s->source);
+        free(s);
+        throw_native(env, rc);
+        return 0;
+    }
+    return (jlong)(intptr_t)op;
+}
+/* ScanFilterAndProjectOperator's statistics: long[4] = processed positions, materialised bytes, lazy blocks loaded, lazy blocks never loaded */
+JNIEXPORT jlongArray JNICALL Java_io_trino_gpu_GpuNative_scanStats(JNIEnv* env, jclass c, jlong h)
+{
+    int64_t v[4] = {0, 0, 0, 0};
+    int32_t rc = pa_scan_stats((pa_operator*)(intptr_t)h, &v[0], &v[1], &v[2], &v[3]);
+    if (rc < 0) { throw_native(env, rc); return 0; }
+    jlong j[4] = {v[0], v[1], v[2], v[3]};
+    jlongArray result = (*env)->NewLongArray(env, 4);
+    (*env)->SetLongArrayRegion(env, result, 0, 4, j);
+    return result;
 }
 
 /* [Scan]FilterAndProject -> (Hash)Aggregation of one pipeline as ONE device pass (pa_fused_aggregation_create): the planner hook
@@ -428,12 +671,41 @@ JNIEXPORT void JNICALL Java_io_trino_gpu_GpuNative_finish(JNIEnv* env, jclass c,
 JNIEXPORT void JNICALL Java_io_trino_gpu_GpuNative_close(JNIEnv* env, jclass c, jlong h) { CHECK(pa_op_close((pa_operator*)(intptr_t)h)); }
 JNIEXPORT jlong JNICALL Java_io_trino_gpu_GpuNative_memoryBytes(JNIEnv* env, jclass c, jlong h) { return pa_op_memory_bytes((pa_operator*)(intptr_t)h); }
 
+/* Released PA_PAGE_RETAINED pages: the operator's release callback may run on any Driver thread, inside any later native call on the
+ * operator's handle; it must not call back into the library (or the JVM): the token is queued and PinnedPagePool collects it. */
+static struct { int64_t* tokens; int32_t count, capacity; volatile int lock; } released = {0, 0, 0, 0};
+static void released_lock(void) { while (__sync_lock_test_and_set(&released.lock, 1)) {} }
+static void released_unlock(void) { __sync_lock_release(&released.lock); }
+static void released_token(void* ctx)
+{
+    released_lock();
+    if (released.count == released.capacity) {
+        released.capacity = released.capacity ? 2 * released.capacity : 256;
+        released.tokens = (int64_t*)realloc(released.tokens, (size_t)released.capacity * sizeof(int64_t));
+    }
+    released.tokens[released.count++] = (int64_t)(intptr_t)ctx;
+    released_unlock();
+}
+/* moves up to out.length released tokens into `out`; returns how many */
+JNIEXPORT jint JNICALL Java_io_trino_gpu_GpuNative_drainReleased(JNIEnv* env, jclass c, jlongArray out)
+{
+    const jsize cap = (*env)->GetArrayLength(env, out);
+    jlong* v = (*env)->GetLongArrayElements(env, out, 0);
+    released_lock();
+    const int32_t n = released.count < cap ? released.count : cap;
+    for (int32_t i = 0; i < n; i++) v[i] = released.tokens[released.count - n + i];
+    released.count -= n;
+    released_unlock();
+    (*env)->ReleaseLongArrayElements(env, out, v, 0);
+    return n;
+}
+
 /* addInput: block arrays at offsets inside one pinned direct ByteBuffer.  Per channel: type, encoding (FLAT / VARWIDTH /
  * DICTIONARY / RLE), and byte offsets of values / offsets / nulls / ids (-1 = absent); a DICTIONARY / RLE channel names its
  * dictionary as one more "channel" behind the page's own (dictionaryChannel[i], -1 = none) with dictionarySize positions. */
 JNIEXPORT void JNICALL Java_io_trino_gpu_GpuNative_addInput(JNIEnv* env, jclass c, jlong h, jint positions, jint channels, jintArray types,
         jintArray encodings, jlongArray valueOffsets, jlongArray offsetOffsets, jlongArray nullOffsets, jlongArray idOffsets, jintArray dictionaryChannel,
-        jintArray dictionarySize, jobject pinned, jboolean stable)
+        jintArray dictionarySize, jobject pinned, jint retention, jlong releaseToken)
 {
     char* base = (char*)(*env)->GetDirectBufferAddress(env, pinned);
     const jsize total = (*env)->GetArrayLength(env, types);   /* page channels + dictionaries */
@@ -466,7 +738,14 @@ JNIEXPORT void JNICALL Java_io_trino_gpu_GpuNative_addInput(JNIEnv* env, jclass 
     page.channel_count = channels;
     page.columns = cols;
     page.mem = PA_MEM_HOST;
-    page.flags = stable ? (PA_PAGE_STABLE | PA_PAGE_PINNED) : 0;   /* the slab is pa_host_malloc_pinned memory: the device reads it in place */
+    /* retention (PinnedPagePool): 0 = the slab may be reused when this call returns; 1 = it is kept until the operator is closed
+     * (PA_PAGE_STABLE); 2 = it is kept until the operator releases the page (PA_PAGE_RETAINED): releaseToken then shows up in
+     * drainReleased and the pool puts the slab back on its free list.  The slab is pa_host_malloc_pinned memory: the device reads it in place. */
+    page.flags = retention == 1 ? (PA_PAGE_STABLE | PA_PAGE_PINNED) : retention == 2 ? (PA_PAGE_RETAINED | PA_PAGE_PINNED) : 0;
+    if (retention == 2) {
+        page.release = &released_token;
+        page.release_ctx = (void*)(intptr_t)releaseToken;
+    }
     int32_t rc = pa_op_add_input((pa_operator*)(intptr_t)h, &page);
     (*env)->ReleaseIntArrayElements(env, types, t, JNI_ABORT);
     (*env)->ReleaseIntArrayElements(env, encodings, e, JNI_ABORT);
@@ -527,4 +806,44 @@ JNIEXPORT jlongArray JNICALL Java_io_trino_gpu_GpuNative_getOutput(JNIEnv* env, 
 JNIEXPORT jobject JNICALL Java_io_trino_gpu_GpuNative_wrapAddress(JNIEnv* env, jclass c, jlong address, jlong bytes)
 {
     return (*env)->NewDirectByteBuffer(env, (void*)(intptr_t)address, bytes);
+}
+JNIEXPORT jlong JNICALL Java_io_trino_gpu_GpuNative_bufferAddress(JNIEnv* env, jclass c, jobject buffer)
+{
+    return (jlong)(intptr_t)(*env)->GetDirectBufferAddress(env, buffer);
+}
+
+/* ---- page wire format (PagesSerde): exchange pages of CPU workers feed device operators and the reverse, without a Java-side decode ---- */
+/* The page an operator would return next, serialised into `out` (a direct buffer): the SerializedPage frame of PagesSerde.serialize
+ * (LZ4 when compress and it pays).  Returns the frame's size, 0 when the operator has no page; the operator may have been created with
+ * PA_MEM_DEVICE output -- the page never has to exist on the Java heap. */
+JNIEXPORT jlong JNICALL Java_io_trino_gpu_GpuNative_getOutputSerialized(JNIEnv* env, jclass c, jlong h, jobject out, jboolean compress)
+{
+    pa_page page;
+    memset(&page, 0, sizeof page);
+    int32_t rc = pa_op_get_output((pa_operator*)(intptr_t)h, &page);
+    if (rc < 0) { throw_native(env, rc); return 0; }
+    if (rc == 0) return 0;
+    void* dst = (*env)->GetDirectBufferAddress(env, out);
+    const jlong cap = (*env)->GetDirectBufferCapacity(env, out);
+    int64_t size = compress ? pa_page_serialize_lz4(&page, dst, cap, 0) : pa_page_serialize(&page, dst, cap, 0);
+    if (size < 0) { throw_native(env, (int32_t)size); return 0; }
+    return size;
+}
+/* A SerializedPage frame (direct buffer, `size` bytes) decoded into HBM and handed to the operator as its next input page; expectedTypes:
+ * the consumer's declared channel types (LONG_ARRAY blocks become BIGINT or DOUBLE, INT_ARRAY blocks INTEGER or DATE ...). */
+JNIEXPORT void JNICALL Java_io_trino_gpu_GpuNative_addInputSerialized(JNIEnv* env, jclass c, jlong h, jobject bytes, jlong size, jintArray expectedTypes)
+{
+    jsize n;
+    int32_t* types = ints_of(env, expectedTypes, &n);
+    pa_page_buffer* buffer = 0;
+    int32_t rc = pa_page_deserialize_typed((*env)->GetDirectBufferAddress(env, bytes), size, types, n, 0, &buffer);
+    free(types);
+    if (rc < 0) { throw_native(env, rc); return; }
+    pa_page page;
+    memset(&page, 0, sizeof page);
+    rc = pa_page_buffer_page(buffer, &page);
+    if (rc >= 0 && page.position_count > 0) rc = pa_op_add_input((pa_operator*)(intptr_t)h, &page);   /* Driver.java:391: never an empty page */
+    int32_t rc2 = pa_page_buffer_free(buffer);   /* (the operator has read or copied the page: it is not flagged stable) */
+    if (rc < 0) { throw_native(env, rc); return; }
+    CHECK(rc2);
 }

@@ -7,6 +7,8 @@
 #define JNIEXPORT __attribute__((visibility("default")))
 #define JNICALL
 #define JNI_ABORT 2
+#define JNI_OK 0
+#define JNI_VERSION_1_8 0x00010008
 typedef int32_t jint;
 typedef int64_t jlong;
 typedef int8_t jbyte;
@@ -27,6 +29,11 @@ struct _jmethodID;
 typedef struct _jmethodID* jmethodID;
 struct JNINativeInterface_;
 typedef const struct JNINativeInterface_* JNIEnv;
+struct JNIInvokeInterface_;
+typedef const struct JNIInvokeInterface_* JavaVM;
+struct JNIInvokeInterface_ {
+    jint (*GetEnv)(JavaVM*, void**, jint);
+};
 struct JNINativeInterface_ {
     jclass (*FindClass)(JNIEnv*, const char*);
     jmethodID (*GetMethodID)(JNIEnv*, jclass, const char*, const char*);
@@ -49,5 +56,12 @@ struct JNINativeInterface_ {
     jobject (*NewDirectByteBuffer)(JNIEnv*, void*, jlong);
     void* (*GetDirectBufferAddress)(JNIEnv*, jobject);
     jlong (*GetDirectBufferCapacity)(JNIEnv*, jobject);
+    jboolean (*ExceptionCheck)(JNIEnv*);
+    jint (*GetJavaVM)(JNIEnv*, JavaVM**);
+    jclass (*GetObjectClass)(JNIEnv*, jobject);
+    jobject (*NewGlobalRef)(JNIEnv*, jobject);
+    void (*DeleteGlobalRef)(JNIEnv*, jobject);
+    jobject (*CallObjectMethod)(JNIEnv*, jobject, jmethodID, ...);
+    void (*CallVoidMethod)(JNIEnv*, jobject, jmethodID, ...);
 };
 #endif
