@@ -104,3 +104,27 @@ def test_multi_slice_aggregation_output(gpu, oracle, hashed):
     assert sorted((r[0], r[-2], r[-1]) for r in rows) == [(i, 1, float(i)) for i in range(MULTI_SLICE_POSITIONS)]
     if hashed:
         assert all(r[1] == oracle.hash_bigint(r[0]) for r in rows)
+
+
+def test_group_by_hash_append_to(gpu, oracle):
+    """TestGroupByHash.testAppendTo / testAppendToMultipleTuplesPerGroup (…/operator/TestGroupByHash.java:151-200): the keys (and, with a
+    hash channel, their $hashvalue) that appendValuesTo writes per group -- on the device: the output of a HashAggregation without aggregates.
+    VARCHAR "0" .. "99" with precomputed hashes -> 100 rows (value, hash); BIGINT i % 50 over 100 rows -> the 50 values 0 .. 49.  (Group ids are
+    first-seen ordinals on the reference; the device has no group ids to show, rows are compared as a set.)"""
+    from presto_amd.page import sequence_page
+    values = sequence_page(100, [(abi.VARCHAR, 0)])
+    hashes = oracle.hash_page(values, [0])
+    page = Page(values.blocks + [Block.bigint(hashes)], 100)
+    op = HashAggregationOperator([abi.VARCHAR, abi.BIGINT], [0], [], hash_channel=1, expected_groups=100)
+    rows = rows_of(to_pages(op, [page]))
+    op.close()
+    assert sorted(rows) == sorted((str(i).encode(), int(hashes[i])) for i in range(100))
+    ref = oracle.HashAggregation([abi.VARCHAR, abi.BIGINT], [0], [], hash_channel=1, expected_groups=100)
+    ids = ref.add_page(page, want_group_ids=True)
+    assert ids.tolist() == list(range(100)) and ref.build_result().to_rows() == [(str(i).encode(), int(hashes[i])) for i in range(100)]
+    many = Page([Block.bigint([i % 50 for i in range(100)])], 100)
+    many = Page(many.blocks + [Block.bigint(oracle.hash_page(many, [0]))], 100)
+    op = HashAggregationOperator([abi.BIGINT, abi.BIGINT], [0], [], hash_channel=1, expected_groups=100)
+    rows = rows_of(to_pages(op, [many]))
+    op.close()
+    assert sorted(r[0] for r in rows) == list(range(50)) and all(r[1] == oracle.hash_bigint(r[0]) for r in rows)

@@ -646,3 +646,66 @@ def test_large_build_side_with_a_hash_channel(gpu, oracle):
         assert len(orows) > 100_000 and rows == orows
         for (gp, gb), (op_, ob) in zip(pairs, opairs):
             assert np.array_equal(gp, op_) and np.array_equal(gb, ob)
+
+
+def test_lookup_join_page_builder_positions_on_device(gpu, oracle):
+    """TestLookupJoinPageBuilder.testDifferentPositions (…/join/TestLookupJoinPageBuilder.java:85-150) at the operator's level, on the
+    device: a probe page of 0 .. 99 against the build page 0 .. 99 -- (1) no probe row joins: no page; (2) only the last position joins;
+    (3) every position joins once: both columns 0 .. 99 in probe order; (4) every second position joins: 0, 2, 4, ...; (5) every position
+    joins twice (two build rows per key): each probe row twice, build rows in descending build position.  Rows, order and the
+    (probe position, build position) pairs equal the oracle's LookupJoinPageBuilder restatement."""
+    types = [abi.BIGINT]
+    build = [Page([Block.bigint(np.arange(100, dtype=np.int64))], 100)]
+    keys_even = np.arange(100, dtype=np.int64)
+    keys_even[1::2] += 1000
+    keys_last = np.arange(100, dtype=np.int64) + 1000
+    keys_last[99] = 99
+    cases = {
+        "empty": np.arange(100, dtype=np.int64) + 1000,
+        "last position only": keys_last,
+        "every position": np.arange(100, dtype=np.int64),
+        "even positions": keys_even,
+    }
+    for name, keys in cases.items():
+        probe = [Page([Block.bigint(keys)], 100)]
+        rows, pairs, _ = gpu_join(build, types, [0], [0], probe, types, [0], [0])
+        orows, opairs, _ = oracle_join(oracle, build, types, [0], [0], probe, types, [0], [0])
+        assert rows == orows, name
+        assert pairs[0][0].tolist() == opairs[0][0].tolist() and pairs[0][1].tolist() == opairs[0][1].tolist(), name
+    assert cases and oracle_join(oracle, build, types, [0], [0], [Page([Block.bigint(cases["empty"])], 100)], types, [0], [0])[0] == []
+    # (5) each probe position joined twice
+    twice = [Page([Block.bigint(np.concatenate([np.arange(100), np.arange(100)]).astype(np.int64)), Block.bigint(np.arange(200, dtype=np.int64))], 200)]
+    probe = [Page([Block.bigint(np.arange(100, dtype=np.int64))], 100)]
+    rows, pairs, _ = gpu_join(twice, [abi.BIGINT, abi.BIGINT], [0], [1], probe, types, [0], [0])
+    assert rows == [(i, b) for i in range(100) for b in (100 + i, i)]          # descending build position within a probe row
+    orows, opairs, _ = oracle_join(oracle, twice, [abi.BIGINT, abi.BIGINT], [0], [1], probe, types, [0], [0])
+    assert rows == orows and pairs[0][0].tolist() == opairs[0][0].tolist() and pairs[0][1].tolist() == opairs[0][1].tolist()
+
+
+def test_group_by_hash_contains_on_device(gpu, oracle):
+    """TestGroupByHash.testContains / testContainsMultipleColumns (…/operator/TestGroupByHash.java:202-235): membership of a row in the
+    set of keys seen.  GroupByHash.contains is the primitive under the reference's ChannelSet (SetBuilderOperator -> semi join); on the device
+    the set is a lookup source and the question a probe with outputSingleMatch: DOUBLE keys 0 .. 9 contain 3.0 and not 11.0;
+    (DOUBLE, VARCHAR) keys (i, str(i)) contain (3.0, "3") and not (3.0, "4").  -0.0 finds 0.0 and NaN finds NaN (IS NOT DISTINCT keys)."""
+    from presto_amd.operators import LookupJoinOperator as Join
+
+    def contains(build_page, build_types, probe_page):
+        bridge = LookupSourceFactory()
+        to_pages(HashBuilderOperator(bridge, build_types, list(range(len(build_types))), []), [build_page])
+        j = Join(bridge, build_types, list(range(len(build_types))), [0], output_single_match=True)
+        j.addInput(probe_page)
+        out = j.getOutput()
+        j.finish()
+        return 0 if out is None else out.position_count
+
+    keys = Page([Block.double(np.arange(10, dtype=np.float64))], 10)
+    assert contains(keys, [abi.DOUBLE], Page([Block.double([3.0])], 1)) == 1
+    assert contains(keys, [abi.DOUBLE], Page([Block.double([11.0])], 1)) == 0
+    assert contains(keys, [abi.DOUBLE], Page([Block.double([-0.0])], 1)) == 1
+    two = Page([Block.double(np.arange(10, dtype=np.float64)), Block.varchar([str(i) for i in range(10)])], 10)
+    assert contains(two, [abi.DOUBLE, abi.VARCHAR], Page([Block.double([3.0]), Block.varchar(["3"])], 1)) == 1
+    assert contains(two, [abi.DOUBLE, abi.VARCHAR], Page([Block.double([3.0]), Block.varchar(["4"])], 1)) == 0
+    # the oracle's GroupByHash agrees
+    gbh = oracle.HashAggregation([abi.DOUBLE, abi.VARCHAR], [0, 1], [], expected_groups=100)
+    gbh.add_page(two)
+    assert gbh.contains(Page([Block.double([3.0]), Block.varchar(["3"])], 1), 0) and not gbh.contains(Page([Block.double([3.0]), Block.varchar(["4"])], 1), 0)
