@@ -66,7 +66,9 @@ class DeviceArray:
         self.alloc.free()
 
 
-def run(cpu=True):
+def run(cpu=True, only=None):
+    """only: None = everything, else a set of section names out of {'hash_agg', 'hash_join', 'order_by', 'topn'} (profiling runs)"""
+    want = lambda name: only is None or name in only
     import numpy as np
     from presto_amd import _lib, abi
     from presto_amd.operators import (HashAggregationOperator, HashBuilderOperator, LookupJoinOperator, LookupSourceFactory, OrderByOperator,
@@ -94,8 +96,9 @@ def run(cpu=True):
     aggs = [(abi.AGG_SUM, 1, abi.DOUBLE), (abi.AGG_COUNT_STAR, -1, None)]
     vals = DeviceArray(rng.random(1 << 26))
     out["hash_agg"] = []
-    for rows, groups, shape in ((10_000_000, 3_000_000, "BenchmarkGroupByHash.java:68-71"), (1 << 26, 4, None), (1 << 26, 1000, None),
-                                (1 << 26, 100_000, None), (1 << 26, 3_000_000, None)):
+    agg_cases = ((10_000_000, 3_000_000, "BenchmarkGroupByHash.java:68-71"), (1 << 26, 4, None), (1 << 26, 1000, None),
+                 (1 << 26, 100_000, None), (1 << 26, 3_000_000, None))
+    for rows, groups, shape in (agg_cases if want("hash_agg") else ()):
         keys = DeviceArray(rng.integers(0, groups, rows, dtype=np.int64))
         sync()
         chunk = 1 << 24
@@ -189,7 +192,7 @@ def run(cpu=True):
         out["hash_join"].append(e)
 
     ref = "BenchmarkHashBuildAndJoinOperators.java:103-110,192-199,260-303"
-    for repetition in (1, 5):
+    for repetition in ((1, 5) if want("hash_join") else ()):
         nb = 8_000_000
         max_value = nb // repetition + 40
         # addSequencePage(newRows, ..., (rows + 30) % maxValue, ...) page by page (1024 rows): BIGINT channel 1 = (rows + 30) % maxValue + i
@@ -214,17 +217,18 @@ def run(cpu=True):
             join_case("8 M build rows x%d, 1.4 M probe rows, match rate %g" % (repetition, match_rate), bkeys, pkeys, ref, 1_400_000)
             pkeys.free()
         bkeys.free()
-    nb = 15_000_000
-    unique = DeviceArray(rng.permutation(nb).astype(np.int64) * 4)
-    pkeys = DeviceArray(rng.integers(0, nb * 8, 1 << 26, dtype=np.int64))
-    join_case("15 M unique random build keys, 2^26 random probe keys (one in eight matches)", unique, pkeys, None, 4_000_000)
-    unique.free()
-    pkeys.free()
-    dup = DeviceArray(rng.integers(0, nb // 5, nb, dtype=np.int64) * 4)
-    pkeys5 = DeviceArray(rng.integers(0, nb // 5 * 8, 1 << 26, dtype=np.int64))
-    join_case("15 M random build keys, about 5 rows per key, 2^26 random probe keys (one in eight matches, about 5 rows each)", dup, pkeys5, None, 2_000_000)
-    dup.free()
-    pkeys5.free()
+    if want("hash_join"):
+        nb = 15_000_000
+        unique = DeviceArray(rng.permutation(nb).astype(np.int64) * 4)
+        pkeys = DeviceArray(rng.integers(0, nb * 8, 1 << 26, dtype=np.int64))
+        join_case("15 M unique random build keys, 2^26 random probe keys (one in eight matches)", unique, pkeys, None, 4_000_000)
+        unique.free()
+        pkeys.free()
+        dup = DeviceArray(rng.integers(0, nb // 5, nb, dtype=np.int64) * 4)
+        pkeys5 = DeviceArray(rng.integers(0, nb // 5 * 8, 1 << 26, dtype=np.int64))
+        join_case("15 M random build keys, about 5 rows per key, 2^26 random probe keys (one in eight matches, about 5 rows each)", dup, pkeys5, None, 2_000_000)
+        dup.free()
+        pkeys5.free()
 
     # ---- OrderBy / TopN ----
     rows = 1 << 26
@@ -240,9 +244,10 @@ def run(cpu=True):
         op.finish()
         op.getOutput()
         op.close()
-    med, best = _timed(order_by, sync, warmup=1, runs=5)
-    out["order_by"] = _entry(srows, srows * 16 * 2, med, best, shape="2^24 rows of (DOUBLE, BIGINT) by the BIGINT channel ascending; bytes = rows read + written once")
-    if cpu:
+    if want("order_by"):
+        med, best = _timed(order_by, sync, warmup=1, runs=5)
+        out["order_by"] = _entry(srows, srows * 16 * 2, med, best, shape="2^24 rows of (DOUBLE, BIGINT) by the BIGINT channel ascending; bytes = rows read + written once")
+    if cpu and want("order_by"):
         n = 1 << 22
         kk = np.ascontiguousarray(k.host[:n])
         t0 = time.perf_counter()
@@ -257,6 +262,8 @@ def run(cpu=True):
         op.finish()
         op.getOutput()
         op.close()
+    if not want("topn"):
+        return out
     med, best = _timed(topn, sync, warmup=1, runs=5)
     out["topn"] = _entry(rows, rows * 16, med, best, shape="100 of 2^26 rows of (DOUBLE, BIGINT), DOUBLE descending then BIGINT ascending")
     if cpu:

@@ -16,6 +16,7 @@
 #include "operator.hpp"
 #include "scan_kernels.hpp"
 #include "sort_kernels.hpp"
+#include "static_kernels.hpp"
 #include "topn_kernels.hpp"
 
 namespace pa {
@@ -214,6 +215,16 @@ public:
         const std::vector<int>& outs = output_channels_;
         out_cols_.clear();
         out_cols_.resize(outs.size());
+        // the fixed-width channels (and every NULL flag array) are gathered through the permutation by ONE launch: the permutation is
+        // read once, the random reads of all channels are in flight together
+        GatherMultiArgs gm;
+        memset(&gm, 0, sizeof gm);
+        gm.positions[0] = perm;
+        gm.count = n;
+        auto flush_gather = [&] {
+            if (gm.ncols > 0) launch_gather_multi(gm, s);
+            gm.ncols = 0;
+        };
         for (size_t j = 0; j < outs.size(); j++) {
             const Accumulated& a = cols_[(size_t)outs[j]];
             OutColumn& oc = out_cols_[j];
@@ -221,6 +232,10 @@ public:
             oc.varwidth = a.varwidth;
             const uint8_t* nulls = a.has_nulls ? a.nulls.as<uint8_t>() : nullptr;
             oc.has_nulls = nulls != nullptr;
+            if (gm.ncols == GATHER_MULTI_MAX_COLS) flush_gather();
+            GatherMultiCol& gc = gm.col[gm.ncols];
+            memset(&gc, 0, sizeof gc);
+            gc.width = 1;
             if (a.varwidth) {
                 int32_t* lens = static_cast<int32_t*>(oc.offsets.ensure((size_t)(n + 1) * 4));
                 int32_t* total = reinterpret_cast<int32_t*>(counts);
@@ -237,10 +252,20 @@ public:
             }
             else {
                 const int w = type_width(a.type);
-                launch_gather_flat(a.values.ptr(), w, perm, n, oc.values.ensure((size_t)n * w), s);
+                if (w == 1 || w == 4 || w == 8) {
+                    gc.src = a.values.ptr();
+                    gc.dst = oc.values.ensure((size_t)n * w);
+                    gc.width = w;
+                }
+                else launch_gather_flat(a.values.ptr(), w, perm, n, oc.values.ensure((size_t)n * w), s);   // (LONG_DECIMAL: 16 bytes)
             }
-            if (nulls) launch_gather_nulls(nulls, perm, n, static_cast<uint8_t*>(oc.nulls.ensure((size_t)n)), s);
+            if (nulls) {
+                gc.src_nulls = nulls;
+                gc.dst_nulls = static_cast<uint8_t*>(oc.nulls.ensure((size_t)n));
+            }
+            if (gc.dst || gc.dst_nulls) gm.ncols++;
         }
+        flush_gather();
         publish_output(out_cols_, (int32_t)n, output_mem_, s, out, out_storage_);
         return true;
     }

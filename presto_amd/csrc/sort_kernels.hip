@@ -25,6 +25,11 @@ void launch_sort_pairs(const uint64_t* keys_in, const int32_t* rows_in, uint64_t
 {
     if (n <= 0) return;
     PA_REQUIRE(begin_bit >= 0 && end_bit > begin_bit && end_bit <= 64, PA_ERR_DEVICE, "internal: bit range of a pair sort");
+    // the scratch was sized for the whole key (sort_pairs_temp_bytes): rocPRIM does not promise that a narrower bit range needs no more
+    // (its merge-sort and one-sweep paths size differently) -- ask for THIS range and refuse to run short
+    size_t need = 0;
+    PA_HIP(rocprim::radix_sort_pairs(nullptr, need, keys_in, keys_out, rows_in, rows_out, (size_t)n, (unsigned)begin_bit, (unsigned)end_bit, s));
+    PA_REQUIRE(need <= temp_bytes, PA_ERR_DEVICE, "internal: pair sort scratch smaller than this bit range needs");
     PA_HIP(rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, rows_in, rows_out, (size_t)n, (unsigned)begin_bit, (unsigned)end_bit, s));
 }
 
