@@ -24,6 +24,16 @@ def host_table(oracle, columns, sf, n):
     return Page(blocks, n)
 
 
+def host_table_at(oracle, columns, sf, first, n):
+    """rows [first, first + n) of a table of the generator"""
+    blocks = []
+    for c in columns:
+        v, o = oracle.tpch_column(c, sf, first, n)
+        t = abi.TPCH_COLUMN_TYPE[c]
+        blocks.append(Block.varwidth(v, o) if t == abi.VARCHAR else Block.flat(t, v))
+    return Page(blocks, n)
+
+
 def oracle_q3(oracle, customer, orders, lineitem):
     return oracle.q3(customer, orders, lineitem)
 
@@ -215,4 +225,39 @@ def test_q3_full_size_independent_paths_agree(gpu, sf):
     assert counters3["lineitem_dynamic_filter"] is True
     same(unfused, base, [3])
     assert [r[4] for r in base] == [r[4] for r in unfused]
+    stream.destroy()
+
+
+def test_q3_sf100_far_offset_sample_matches_oracle(gpu, oracle):
+    """BASELINE config #4 at full size against the ORACLE, on a sample far into the tables: the generator is regular -- 7 orders own 28
+    consecutive lineitem rows, order row o has orderkey sparse(o) -- so the orders [o0, o0 + m) and their lineitem rows
+    [4 o0, 4 (o0 + m)) form a closed slice of the join graph once every customer is known.  The oracle's Q3 composition over (the whole
+    SF100 customer table, that orders slice, that lineitem slice) must give exactly the groups the device's full-size run (765 M input
+    rows, every group emitted) holds for those orderkeys: keys, dates, priorities and count(*) bit-exact, sum(revenue) to 1e-9."""
+    import numpy as np
+    from presto_amd import q3
+    sf = 100.0
+    customer, orders, lineitem = _device_tables(sf)
+    stream = DeviceStream()
+    out, counters = q3.run(customer.pages(1 << 28), orders.pages(1 << 28), lineitem.pages(1 << 28), stream.handle, distributed=False, top_n=0)
+    cols = [np.concatenate([np.asarray(p.blocks[c].values)[:p.position_count] for p in out]) for c in range(5)]
+    assert len(cols[0]) == len(np.unique(cols[0])) > 1_000_000 * 10   # one group per joined orderkey
+    checked = 0
+    for o0, m in ((7 * 15_000_000, 7 * 20_000), (7 * 21_428_000, 7 * 5_000)):   # order rows 105 M .. and the table's last orders
+        m = min(m, tpch.orders_rows(sf) - o0)
+        # (the table's last order owns every lineitem row behind 4 x orders: the slice then runs to the end of lineitem)
+        l_rows = (tpch.lineitem_rows(sf) if o0 + m == tpch.orders_rows(sf) else 4 * (o0 + m)) - 4 * o0
+        ref_rows, _, _ = oracle.q3(host_table(oracle, tpch.CUSTOMER_COLUMNS, sf, tpch.customer_rows(sf)),
+                                   host_table_at(oracle, tpch.ORDERS_COLUMNS, sf, o0, m), host_table_at(oracle, tpch.Q3_LINEITEM_COLUMNS, sf, 4 * o0, l_rows))
+        expected = {r[0]: r for r in ref_rows}
+        lo = min(expected) if expected else 0
+        hi = max(expected) if expected else 0
+        sel = np.nonzero((cols[0] >= lo) & (cols[0] <= hi))[0]
+        got = {int(cols[0][i]): tuple(c[i].item() for c in cols) for i in sel.tolist()}
+        assert len(expected) > m // 20 and set(got) == set(expected)
+        for k, e in expected.items():
+            g = got[k]
+            assert g[:3] == e[:3] and g[4] == e[4] and abs(g[3] - e[3]) <= 1e-9 * abs(e[3]), (g, e)
+        checked += len(expected)
+    assert checked > 5_000
     stream.destroy()
