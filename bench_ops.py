@@ -138,7 +138,10 @@ def run(cpu=True, only=None):
         bpay = DeviceArray(np.arange(nb, dtype=np.int64))
         ppay = DeviceArray(np.arange(npr, dtype=np.int64))
         sync()
-        build = Page([dev_block(abi.BIGINT, bkeys), dev_block(abi.BIGINT, bpay)], nb, abi.MEM_DEVICE, stable=True)
+        # the build side arrives as ONE page whose owner keeps it alive until the lookup source lets go of it (PA_PAGE_RETAINED: what a
+        # reference does for a Java Page in PagesIndex) -- the build columns are the page's block arrays, nothing is copied
+        released = []
+        build = Page([dev_block(abi.BIGINT, bkeys), dev_block(abi.BIGINT, bpay)], nb, abi.MEM_DEVICE, on_release=lambda: released.append(1))
         chunk = 1 << 24
         probes = [Page([dev_block(abi.BIGINT, pkeys, i, min(chunk, npr - i)), dev_block(abi.BIGINT, ppay, i, min(chunk, npr - i))],
                        min(chunk, npr - i), abi.MEM_DEVICE, stable=True) for i in range(0, npr, chunk)]

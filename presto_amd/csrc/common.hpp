@@ -87,13 +87,23 @@ public:
     DevBuf() = default;
     DevBuf(const DevBuf&) = delete;
     DevBuf& operator=(const DevBuf&) = delete;
-    DevBuf(DevBuf&& o) noexcept : p_(o.p_), cap_(o.cap_) { o.p_ = nullptr; o.cap_ = 0; }
+    DevBuf(DevBuf&& o) noexcept : p_(o.p_), cap_(o.cap_), borrowed_(o.borrowed_) { o.p_ = nullptr; o.cap_ = 0; o.borrowed_ = false; }
     DevBuf& operator=(DevBuf&& o) noexcept
     {
-        if (this != &o) { release(); p_ = o.p_; cap_ = o.cap_; o.p_ = nullptr; o.cap_ = 0; }
+        if (this != &o) { release(); p_ = o.p_; cap_ = o.cap_; borrowed_ = o.borrowed_; o.p_ = nullptr; o.cap_ = 0; o.borrowed_ = false; }
         return *this;
     }
     ~DevBuf() { release(); }
+    // `bytes` of somebody else's HBM, read in place (a retained page's block array): never freed here; growing past it moves the
+    // contents into an allocation of the buffer's own (reserve_keep)
+    void borrow(const void* p, size_t bytes)
+    {
+        release();
+        p_ = const_cast<void*>(p);
+        cap_ = bytes;
+        borrowed_ = true;
+    }
+    bool borrowed() const { return borrowed_; }
     void* ensure(size_t bytes)
     {
         if (bytes > cap_) {
@@ -120,9 +130,10 @@ public:
     }
     void release()
     {
-        if (p_) pool_device_free(p_, cap_);
+        if (p_ && !borrowed_) pool_device_free(p_, cap_);
         p_ = nullptr;
         cap_ = 0;
+        borrowed_ = false;
     }
     void* ptr() const { return p_; }
     template <typename T> T* as() const { return static_cast<T*>(p_); }
@@ -131,6 +142,7 @@ public:
 private:
     void* p_ = nullptr;
     size_t cap_ = 0;
+    bool borrowed_ = false;
 };
 
 // Growable pinned host allocation (D2H landing zone / H2D staging).

@@ -27,6 +27,17 @@ struct BuildColumn {
 // The lookup source shared between the build operator and its probe operators
 // (LookupSourceFactory / JoinBridge; PartitionedLookupSourceFactory.java:179-206).
 struct LookupSourceImpl {
+    // PA_PAGE_RETAINED build pages whose block arrays the build columns read in place: released when the lookup source goes
+    // (the last probe operator or the bridge, whichever holds it longest)
+    struct Release {
+        void (*fn)(void*);
+        void* ctx;
+    };
+    std::vector<Release> releases;
+    ~LookupSourceImpl()
+    {
+        for (const Release& r : releases) r.fn(r.ctx);
+    }
     std::vector<BuildColumn> cols;
     int32_t n = 0;
     std::vector<int> join_channels, output_channels;

@@ -77,7 +77,8 @@ void launch_gather_flat(const void* src, int elem_bytes, const int32_t* position
 // has NULL flags to write, a NULL
 __global__ __launch_bounds__(256) void k_gather_multi(GatherMultiArgs a)
 {
-    for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < a.count; i += (i64)gridDim.x * 256) {
+    const i64 count = a.count_dev ? (i64)*a.count_dev : a.count;
+    for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < count; i += (i64)gridDim.x * 256) {
         const i32 p0 = a.positions[0] ? a.positions[0][i] : 0, p1 = a.positions[1] ? a.positions[1][i] : 0;
         for (int c = 0; c < a.ncols; c++) {
             const GatherMultiCol col = a.col[c];

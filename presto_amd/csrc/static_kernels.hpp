@@ -61,7 +61,8 @@ struct GatherMultiCol {
 };
 struct GatherMultiArgs {
     const int32_t* positions[2];
-    int64_t count;
+    int64_t count;             // rows to gather -- or, with count_dev, the most there can be (the grid is sized for it)
+    const int32_t* count_dev;  // non-null: the row count is read on the device (a join's match total that the host has not seen yet)
     int32_t ncols, pad;
     GatherMultiCol col[GATHER_MULTI_MAX_COLS];
 };

@@ -33,6 +33,7 @@ class Operator:
         # flight, its queue full) the Driver would yield and poll -- so does this
         while not L.pa_op_needs_input(self._h) and L.pa_op_is_blocked(self._h) > 0:
             pass
+        page.retain_until_released()   # (PA_PAGE_RETAINED pages: kept until the native side calls their release)
         check(L.pa_op_add_input(self._h, C.byref(cpage)))
         self._last_input = keep  # Pages may be retained by the operator until its work is done
         if page.stable:  # PA_PAGE_STABLE: the operator may still read the page until it is closed

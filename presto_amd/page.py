@@ -222,6 +222,9 @@ class Block:
         keep.append(self)
 
 
+_RETAINED = {}   # id(Page) -> [Page, releases still to come]: retained pages the native side has not let go of yet
+
+
 class Page:
     def __init__(self, blocks, position_count=None, mem=abi.MEM_HOST, stable=False, pinned=False, on_release=None):
         """stable: the buffers outlive the operator the page is given to (PA_PAGE_STABLE) -- true of a Java Page, which is
@@ -261,9 +264,17 @@ class Page:
         page.flags = (abi.PAGE_STABLE if self.stable else 0) | (abi.PAGE_PINNED if self.pinned else 0)
         if self.on_release is not None:
             callback = self.on_release
+            me = self
 
             def release(ctx):
                 try:
+                    # the operator (or the lookup source it built) is done with the page: the hand-over that kept this Page object and
+                    # its buffers alive ends (retain_until_released)
+                    held = _RETAINED.get(id(me))
+                    if held is not None:
+                        held[1] -= 1
+                        if held[1] <= 0:
+                            del _RETAINED[id(me)]
                     callback()
                 except Exception:  # never let an exception cross the C boundary
                     import traceback
@@ -275,6 +286,15 @@ class Page:
         keep.append(cols)
         self._c = (page, keep)
         return self._c
+
+    def retain_until_released(self):
+        """Called when the page is handed to an operator as PA_PAGE_RETAINED: the native side will call the page's release thunk some
+        time later -- from another operator's call, or when a lookup source is destroyed -- so the Page (its buffers' owners and the
+        ctypes thunk) must outlive the Python references to it.  One count per hand-over."""
+        if self.on_release is None:
+            return
+        held = _RETAINED.setdefault(id(self), [self, 0])
+        held[1] += 1
 
     def to_rows(self):
         cols = [b.to_pylist() for b in self.blocks]

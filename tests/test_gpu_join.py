@@ -709,3 +709,59 @@ def test_group_by_hash_contains_on_device(gpu, oracle):
     gbh = oracle.HashAggregation([abi.DOUBLE, abi.VARCHAR], [0, 1], [], expected_groups=100)
     gbh.add_page(two)
     assert gbh.contains(Page([Block.double([3.0]), Block.varchar(["3"])], 1), 0) and not gbh.contains(Page([Block.double([3.0]), Block.varchar(["4"])], 1), 0)
+
+
+def test_retained_build_page_is_read_in_place_until_the_lookup_source_goes(gpu, oracle):
+    """A build side that arrives as one PA_PAGE_RETAINED device page is not copied: the build columns are the page's block arrays
+    (PagesIndex holds on to the Page's blocks the same way) and the page is released when the lookup source is destroyed -- not before:
+    the test overwrites the buffers in the release callback, a probe after an early release would join garbage.  A second build page
+    moves the borrowed arrays into the builder's own; a retained page that had to be copied is handed back at once."""
+    from presto_amd._lib import check, lib
+    from presto_amd.operators import upload_page
+    rng = np.random.default_rng(11)
+    nb, npr = 20_000, 50_000
+    bhost = Page([Block.bigint(rng.permutation(nb).astype(np.int64) * 3), Block.double(rng.random(nb))], nb)
+    phost = Page([Block.bigint(rng.integers(0, 3 * nb, npr).astype(np.int64)), Block.integer(np.arange(npr))], npr)
+    btypes, ptypes = [abi.BIGINT, abi.DOUBLE], [abi.BIGINT, abi.INTEGER]
+    orows, _, _ = oracle_join(oracle, [bhost], btypes, [0], [1], [phost], ptypes, [0], [0, 1])
+
+    def retained(host, released, tag):
+        dev = upload_page(host)
+
+        def on_release():
+            released.append(tag)
+            for b in dev.blocks:
+                junk = np.full(b.values.nbytes, 0x5A, dtype=np.uint8)
+                check(lib().pa_memcpy_h2d(b.values.ptr, junk.ctypes.data, b.values.nbytes, None))
+        return Page(dev.blocks, dev.position_count, abi.MEM_DEVICE, on_release=on_release)
+
+    released = []
+    bridge = LookupSourceFactory()
+    builder = HashBuilderOperator(bridge, btypes, [0], [1])
+    to_pages(builder, [retained(bhost, released, "build")])
+    builder.close()
+    assert released == []                                  # the lookup source reads the page where it is
+    for _ in range(2):                                     # two probe operators of the same bridge
+        join = LookupJoinOperator(bridge, ptypes, [0], [0, 1])
+        join.addInput(phost)
+        assert join.getOutput().to_rows() == orows
+        join.finish()
+        join.close()
+    assert released == []
+    bridge.destroy()
+    assert released == ["build"]
+    # two pages: the first is borrowed, the second makes the builder take copies; a retained second page is released right away
+    released = []
+    half = nb // 2
+    bridge = LookupSourceFactory()
+    builder = HashBuilderOperator(bridge, btypes, [0], [1])
+    to_pages(builder, [retained(bhost.get_region(0, half), released, "first"), retained(bhost.get_region(half, nb - half), released, "second")])
+    assert released == ["second"]
+    join = LookupJoinOperator(bridge, ptypes, [0], [0, 1])
+    join.addInput(phost)
+    assert join.getOutput().to_rows() == orows
+    join.finish()
+    join.close()
+    builder.close()
+    bridge.destroy()
+    assert sorted(released) == ["first", "second"]
