@@ -236,6 +236,12 @@ typedef struct pa_filter_project_desc {
     int64_t min_output_page_bytes;
     int32_t min_output_page_rows;
     int32_t max_output_page_bytes;
+    /* Non-zero (PA_MEM_DEVICE output only): an output page whose blocks are all the operator's own buffers (no zero-copy view of the
+     * input) is handed over -- flagged PA_PAGE_RETAINED, its release frees the buffers -- instead of being lent until the operator's next
+     * call: the consumer may keep reading it (a HashBuilder reads a retained build page in place: the join's build side is not copied);
+     * the operator takes fresh buffers for its next page.  Whoever takes such a page owes it exactly one release call. */
+    int32_t output_handover;
+    int32_t reserved;
 } pa_filter_project_desc;
 
 /* Intermediate states of Step.PARTIAL / Step.FINAL (AggregationNode.Step): the reference serialises LongState /

@@ -167,6 +167,8 @@ class pa_filter_project_desc(C.Structure):
         ("min_output_page_bytes", C.c_int64),
         ("min_output_page_rows", C.c_int32),
         ("max_output_page_bytes", C.c_int32),
+        ("output_handover", C.c_int32),
+        ("reserved", C.c_int32),
     ]
 
 

@@ -102,6 +102,7 @@ struct FpSpec {
     OwnedExpr filter;
     std::vector<OwnedExpr> proj;
     int output_mem = PA_MEM_HOST;
+    bool output_handover = false;  // pa_filter_project_desc.output_handover
     std::vector<bool> used_channel;
     // the selection comes from outside (dictionary-aware filter): pa_fp_scatter reads sel4, the filter is not evaluated
     bool filter_external = false;
@@ -134,6 +135,7 @@ FpSpec make_fp_spec(const pa_filter_project_desc* d)
                    "VARCHAR projections other than plain input references are not on the device path");
     }
     s.output_mem = d->output_mem;
+    s.output_handover = d->output_handover != 0 && d->output_mem == PA_MEM_DEVICE;
     std::set<int32_t> used;
     if (s.has_filter) s.filter.collect_channels(&used);
     for (const auto& e : s.proj) e.collect_channels(&used);
@@ -555,6 +557,7 @@ public:
             const bool have = process_pending(&count);
             if (have && !merging_) {
                 publish_output(out_cols_, count, spec_.output_mem, s, out, out_storage_);
+                if (spec_.output_handover) hand_over(out);
                 return true;
             }
             if (have) {
@@ -574,6 +577,27 @@ public:
         }
         if (finishing_ && m_rows_ > 0) return flush_merged(out);  // :121-124
         return false;
+    }
+
+    // pa_filter_project_desc.output_handover: the page's buffers leave the operator with the page (released by whoever took it)
+    struct HandedOver {
+        std::vector<DevBuf> bufs;
+    };
+    void hand_over(pa_page* out)
+    {
+        if (out->mem != PA_MEM_DEVICE) return;
+        for (const OutColumn& oc : out_cols_) {
+            if (oc.is_view) return;  // a zero-copy view of the input page is the input page's owner's to keep alive: lent as before
+        }
+        auto* h = new HandedOver;
+        for (OutColumn& oc : out_cols_) {
+            h->bufs.push_back(std::move(oc.values));
+            h->bufs.push_back(std::move(oc.offsets));
+            h->bufs.push_back(std::move(oc.nulls));
+        }
+        out->flags |= PA_PAGE_RETAINED;
+        out->release = [](void* ctx) { delete static_cast<HandedOver*>(ctx); };
+        out->release_ctx = h;
     }
 
     // the PageProcessor part: fills out_cols_ for the page added last; false when no row was selected

@@ -38,6 +38,7 @@ public:
         fp.output_mem = PA_MEM_DEVICE;
         fp.stream = stream;
         fp.min_output_page_bytes = fp.min_output_page_rows = fp.max_output_page_bytes = 0;  // (MergePages sits behind the join)
+        fp.output_handover = 0;  // (inside the chain the page goes to the join in stream order; the hand-over is the one-pass form's)
         pa_lookup_join_desc join = d->join;
         join.stream = stream;
         try {

@@ -138,7 +138,11 @@ def device_page_from_c(cpage, owner=None):
                                 offsets=DeviceBuffer(col.offsets, 4 * (n + 1), owner), nulls=nulls))
         else:
             blocks.append(Block(col.type, abi.FLAT, n, values=DeviceBuffer(col.values, w * n, owner), nulls=nulls))
-    return Page(blocks, n, abi.MEM_DEVICE)
+    page = Page(blocks, n, abi.MEM_DEVICE)
+    if cpage.flags & abi.PAGE_RETAINED and cpage.release:
+        # a page that was handed over (pa_filter_project_desc.output_handover): its release travels with it to the operator that takes it
+        page.native_release = (cpage.release, cpage.release_ctx)
+    return page
 
 
 # ---- descriptors -----------------------------------------------------------------------------------
@@ -149,7 +153,7 @@ def _params_of(input_types, type_params):
     return type_params
 
 
-def _filter_project_desc(input_types, filter_expr, projections, output_mem, stream, type_params=None):
+def _filter_project_desc(input_types, filter_expr, projections, output_mem, stream, type_params=None, output_handover=False):
     keep = []
     type_params = _params_of(input_types, type_params)
     d = abi.pa_filter_project_desc()
@@ -171,6 +175,7 @@ def _filter_project_desc(input_types, filter_expr, projections, output_mem, stre
     d.projections = C.cast(arr, C.POINTER(abi.pa_expr))
     d.output_mem = output_mem
     d.stream = stream
+    d.output_handover = 1 if output_handover else 0
     return d, keep
 
 
@@ -245,8 +250,11 @@ def FilterAndProjectOperator(input_types, filter_expr, projections, output_mem=a
 
 
 def FilterAndProjectOperatorFactory(input_types, filter_expr, projections, output_mem=abi.MEM_HOST, stream=None,
-                                    type_params=None, min_output_page_size=0, min_output_page_row_count=0, max_output_page_size=0):
-    d, keep = _filter_project_desc(input_types, filter_expr, projections, output_mem, stream, type_params)
+                                    type_params=None, min_output_page_size=0, min_output_page_row_count=0, max_output_page_size=0,
+                                    output_handover=False):
+    """output_handover: device output pages leave with their buffers (PA_PAGE_RETAINED, released by the operator that takes them) --
+    what feeds a HashBuilder, which then reads the build side in place."""
+    d, keep = _filter_project_desc(input_types, filter_expr, projections, output_mem, stream, type_params, output_handover)
     d.min_output_page_bytes = int(min_output_page_size)
     d.min_output_page_rows = int(min_output_page_row_count)
     d.max_output_page_bytes = int(max_output_page_size)
@@ -603,15 +611,16 @@ def FusedJoinOperator(bridge, input_types, filter_expr, projections, probe_join_
 
 
 def FusedJoinOperatorFactory(input_types, filter_expr, projections, probe_join_channels, probe_output_channels, output_mem=abi.MEM_HOST,
-                             stream=None, type_params=None):
-    d, keep = fused_join_desc(input_types, filter_expr, projections, probe_join_channels, probe_output_channels, output_mem, stream, type_params)
+                             stream=None, type_params=None, output_handover=False):
+    d, keep = fused_join_desc(input_types, filter_expr, projections, probe_join_channels, probe_output_channels, output_mem, stream, type_params,
+                              output_handover)
     return JoinOperatorFactory(lib().pa_fused_join_create, d, keep)
 
 
 def fused_join_desc(input_types, filter_expr, projections, probe_join_channels, probe_output_channels, output_mem=abi.MEM_HOST, stream=None,
-                    type_params=None):
+                    type_params=None, output_handover=False):
     d = abi.pa_fused_join_desc()
-    fp, k1 = _filter_project_desc(input_types, filter_expr, projections, abi.MEM_DEVICE, stream, type_params)
+    fp, k1 = _filter_project_desc(input_types, filter_expr, projections, abi.MEM_DEVICE, stream, type_params, output_handover)
     jd, k2 = _lookup_join_desc([p.type for p in projections], probe_join_channels, probe_output_channels, -1, output_mem, stream, abi.JOIN_INNER)
     d.filter_project, d.join = fp, jd
     return d, [k1, k2]

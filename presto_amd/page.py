@@ -235,6 +235,7 @@ class Page:
         self.stable = stable
         self.pinned = pinned
         self.on_release = on_release
+        self.native_release = None   # (function pointer, ctx) of a page an operator handed over (device_page_from_c)
         self.blocks = list(blocks)
         if position_count is None:
             position_count = self.blocks[0].position_count if self.blocks else 0
@@ -262,6 +263,9 @@ class Page:
         page.columns = C.cast(cols, C.POINTER(abi.pa_column))
         page.mem = self.mem
         page.flags = (abi.PAGE_STABLE if self.stable else 0) | (abi.PAGE_PINNED if self.pinned else 0)
+        if self.native_release is not None:   # handed over by its producer: the operator that takes the page owes the release
+            page.flags |= abi.PAGE_RETAINED
+            page.release, page.release_ctx = self.native_release
         if self.on_release is not None:
             callback = self.on_release
             me = self
@@ -287,7 +291,20 @@ class Page:
         self._c = (page, keep)
         return self._c
 
+    def __del__(self):
+        # a handed-over page nobody took: its buffers go back now
+        rel = getattr(self, "native_release", None)
+        if rel is not None and not getattr(self, "_taken", False):
+            try:
+                abi.PAGE_RELEASE(rel[0])(rel[1])
+            except Exception:
+                pass
+
     def retain_until_released(self):
+        if self.native_release is not None:
+            if getattr(self, "_taken", False):
+                raise ValueError("a handed-over page can be given to ONE operator")
+            self._taken = True
         """Called when the page is handed to an operator as PA_PAGE_RETAINED: the native side will call the page's release thunk some
         time later -- from another operator's call, or when a lookup source is destroyed -- so the Page (its buffers' owners and the
         ctypes thunk) must outlive the Python references to it.  One count per hand-over."""

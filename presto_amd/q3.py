@@ -111,8 +111,9 @@ def run(customer_pages, orders_pages, lineitem_pages, stream, comm=None, expecte
     # pipeline 1
     b1 = LookupSourceFactory()
     Driver(customer_pages, [
+        # (the pages that feed a HashBuilder are handed over with their buffers: the build side is read where the filter wrote it)
         _factory(("customer", s), lambda: FilterAndProjectOperatorFactory(tpch.CUSTOMER_TYPES, tpch.q3_customer_filter(), [field(0, abi.BIGINT)],
-                                                                          output_mem=dev, stream=s)).createOperator(),
+                                                                          output_mem=dev, stream=s, output_handover=True)).createOperator(),
         *exchange([abi.BIGINT], [0]),
         _factory(("build1", s), lambda: HashBuilderOperatorFactory([abi.BIGINT], [0], [], stream=s)).createOperator(b1)]).run()
     lap("customer_pipeline")
@@ -125,7 +126,7 @@ def run(customer_pages, orders_pages, lineitem_pages, stream, comm=None, expecte
             counters["orders_dynamic_filter"] = "fused"
         orders_head = [_factory(("orders", s), lambda: FusedJoinOperatorFactory(
             tpch.ORDERS_TYPES, tpch.q3_orders_filter(), [field(i, t) for i, t in enumerate(tpch.ORDERS_TYPES)], [1], [0, 2, 3], output_mem=dev,
-            stream=s)).createOperator(b1)]
+            stream=s, output_handover=True)).createOperator(b1)]
     else:
         orders_projections = [field(i, t) for i, t in enumerate(tpch.ORDERS_TYPES)]
         orders_fp = FilterAndProjectOperator(tpch.ORDERS_TYPES, tpch.q3_orders_filter(), orders_projections, output_mem=dev, stream=s)
