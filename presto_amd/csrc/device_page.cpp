@@ -12,9 +12,175 @@ void* PageStager::arena(size_t index, size_t bytes)
 
 size_t PageStager::bytes() const
 {
-    size_t total = 0;
+    size_t total = packed_dev_[0].capacity() + packed_dev_[1].capacity();
     for (const auto& b : bufs_) total += b.capacity();
     return total;
+}
+
+PageStager::~PageStager()
+{
+    for (Packed& p : packed_) {
+        if (p.done) {
+            if (p.pending) (void)hipEventSynchronize(p.done);   // the pinned block goes back to the pool: not under a running copy
+            (void)hipEventDestroy(p.done);
+        }
+    }
+}
+
+// The packed path of small host pages (kPackedLimit).  false: the page does not qualify (an encoded block, too large), nothing done.
+bool PageStager::stage_packed(const pa_page* page, const std::vector<bool>* needed, hipStream_t stream, DevPage& out)
+{
+    const int64_t n = page->position_count;
+    struct Piece { const void* src; size_t bytes; size_t at; };
+    Piece pieces[3 * 64];
+    if (page->channel_count > 64) return false;
+    size_t count = 0, total = 0;
+    auto add = [&](const void* src, size_t bytes) -> size_t {
+        size_t at = total;
+        pieces[count++] = Piece{src, bytes, at};
+        total += (bytes + 255) & ~(size_t)255;
+        return at;
+    };
+    // first pass: every block qualifies, and the layout
+    for (int32_t c = 0; c < page->channel_count; c++) {
+        const pa_column& col = page->columns[c];
+        if (needed && (c >= (int32_t)needed->size() || !(*needed)[c])) continue;
+        if (col.encoding == PA_FLAT) {
+            int w = type_width(col.type);
+            if (w <= 0 || (col.values == nullptr && n > 0)) return false;   // the general path reports it
+        }
+        else if (col.encoding == PA_VARWIDTH) {
+            if (col.type != PA_VARCHAR || col.offsets == nullptr) return false;
+        }
+        else return false;
+    }
+    size_t bytes = 0;
+    for (int32_t c = 0; c < page->channel_count; c++) {
+        const pa_column& col = page->columns[c];
+        if (needed && (c >= (int32_t)needed->size() || !(*needed)[c])) continue;
+        bytes += col.encoding == PA_FLAT ? (size_t)n * type_width(col.type) : (size_t)(n + 1) * 4 + (size_t)col.offsets[n];
+        bytes += col.nulls ? (size_t)n : 0;
+    }
+    if (bytes == 0 || bytes > kPackedLimit) return false;
+    const size_t turn = packed_at_++ & 1;
+    Packed& slot = packed_[turn];
+    if (slot.done == nullptr) PA_HIP(hipEventCreateWithFlags(&slot.done, hipEventDisableTiming));
+    if (slot.pending) PA_HIP(hipEventSynchronize(slot.done));   // two pages back: done long ago
+    slot.pending = false;
+    out.n = page->position_count;
+    out.cols.assign(page->channel_count, DevColumn{});
+    struct Where { size_t values = 0, offsets = 0, nulls = 0; bool has_nulls = false; };
+    std::vector<Where> where(page->channel_count);
+    for (int32_t c = 0; c < page->channel_count; c++) {
+        const pa_column& col = page->columns[c];
+        out.cols[c].type = col.type;
+        if (needed && (c >= (int32_t)needed->size() || !(*needed)[c])) continue;
+        Where& w = where[c];
+        if (col.encoding == PA_FLAT) w.values = add(col.values, (size_t)n * type_width(col.type));
+        else {
+            w.offsets = add(col.offsets, (size_t)(n + 1) * 4);
+            w.values = add(col.values, (size_t)col.offsets[n]);
+        }
+        if (col.nulls) {
+            w.nulls = add(col.nulls, (size_t)n);
+            w.has_nulls = true;
+        }
+    }
+    uint8_t* host = static_cast<uint8_t*>(slot.host.ensure(total));
+    for (size_t i = 0; i < count; i++)
+        if (pieces[i].bytes) memcpy(host + pieces[i].at, pieces[i].src, pieces[i].bytes);
+    uint8_t* dev = static_cast<uint8_t*>(packed_dev_[turn].ensure(total));
+    PA_HIP(hipMemcpyAsync(dev, host, total, hipMemcpyHostToDevice, stream));
+    PA_HIP(hipEventRecord(slot.done, stream));
+    slot.pending = true;
+    for (int32_t c = 0; c < page->channel_count; c++) {
+        const pa_column& col = page->columns[c];
+        if (needed && (c >= (int32_t)needed->size() || !(*needed)[c])) continue;
+        DevColumn& d = out.cols[c];
+        const Where& w = where[c];
+        d.values = dev + w.values;
+        if (col.encoding == PA_VARWIDTH) {
+            d.varwidth = true;
+            d.offsets = reinterpret_cast<const int32_t*>(dev + w.offsets);
+        }
+        d.nulls = w.has_nulls ? dev + w.nulls : nullptr;
+    }
+    return true;
+}
+
+PinnedPageCopy::~PinnedPageCopy()
+{
+    for (Slot& p : slots_) {
+        if (p.done) {
+            if (p.pending) (void)hipEventSynchronize(p.done);   // the pinned block goes back to the pool: not under a running read
+            (void)hipEventDestroy(p.done);
+        }
+    }
+}
+
+const pa_page* PinnedPageCopy::copy(const pa_page* page, const std::vector<bool>* needed)
+{
+    const int64_t n = page->position_count;
+    if (n <= 0 || page->mem != PA_MEM_HOST) return nullptr;
+    auto skip = [&](int32_t c) { return needed && (c >= (int32_t)needed->size() || !(*needed)[c]); };
+    auto pad = [](size_t bytes) { return (bytes + 255) & ~(size_t)255; };
+    size_t total = 0;
+    for (int32_t c = 0; c < page->channel_count; c++) {
+        const pa_column& col = page->columns[c];
+        if (skip(c)) continue;
+        if (col.encoding == PA_FLAT) {
+            const int w = type_width(col.type);
+            if (w <= 0 || col.values == nullptr) return nullptr;   // (the general path reports it)
+            total += pad((size_t)n * w);
+        }
+        else if (col.encoding == PA_VARWIDTH) {
+            if (col.type != PA_VARCHAR || col.offsets == nullptr || col.offsets[n] < 0 || (col.offsets[n] > 0 && col.values == nullptr)) return nullptr;
+            total += pad((size_t)(n + 1) * 4) + pad((size_t)col.offsets[n]);
+        }
+        else return nullptr;
+        if (col.nulls) total += pad((size_t)n);
+        if (total > PageStager::kPackedLimit) return nullptr;
+    }
+    if (total == 0) return nullptr;
+    Slot& slot = slots_[at_++ & 1];
+    if (slot.done == nullptr) PA_HIP(hipEventCreateWithFlags(&slot.done, hipEventDisableTiming));
+    if (slot.pending) PA_HIP(hipEventSynchronize(slot.done));   // two pages back
+    slot.pending = false;
+    char* base = static_cast<char*>(slot.host.ensure(total));
+    size_t at = 0;
+    auto put = [&](const void* src, size_t bytes) -> const void* {
+        char* dst = base + at;
+        if (bytes) memcpy(dst, src, bytes);
+        at += pad(bytes);
+        return dst;
+    };
+    slot.cols.assign(page->columns, page->columns + page->channel_count);
+    for (int32_t c = 0; c < page->channel_count; c++) {
+        if (skip(c)) continue;
+        const pa_column& col = page->columns[c];
+        pa_column& out = slot.cols[c];
+        if (col.encoding == PA_FLAT) out.values = put(col.values, (size_t)n * type_width(col.type));
+        else {
+            out.offsets = static_cast<const int32_t*>(put(col.offsets, (size_t)(n + 1) * 4));
+            out.values = put(col.values, (size_t)col.offsets[n]);   // from byte 0: the offsets stay what they are
+        }
+        if (col.nulls) out.nulls = static_cast<const uint8_t*>(put(col.nulls, (size_t)n));
+    }
+    slot.page = *page;
+    slot.page.columns = slot.cols.data();
+    slot.page.flags = PA_PAGE_PINNED;
+    slot.page.release = nullptr;
+    slot.page.release_ctx = nullptr;
+    cur_ = &slot;
+    return &slot.page;
+}
+
+void PinnedPageCopy::used(hipStream_t stream)
+{
+    if (cur_ == nullptr) return;
+    PA_HIP(hipEventRecord(cur_->done, stream));
+    cur_->pending = true;
+    cur_ = nullptr;
 }
 
 static const void* to_device(const void* src, size_t bytes, bool is_device, void* dst, hipStream_t stream)
@@ -33,6 +199,7 @@ DevPage PageStager::stage(const pa_page* page, const std::vector<bool>* needed, 
     const bool dev = page->mem == PA_MEM_DEVICE;
     const int64_t n = page->position_count;
     DevPage out;
+    if (!dev && n > 0 && stage_packed(page, needed, stream, out)) return out;
     out.n = page->position_count;
     out.cols.resize(page->channel_count);
     next_ = 0;

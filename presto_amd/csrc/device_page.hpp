@@ -33,14 +33,60 @@ struct DevPage {
 
 class PageStager {
 public:
+    PageStager() = default;
+    PageStager(const PageStager&) = delete;
+    PageStager& operator=(const PageStager&) = delete;
+    ~PageStager();
     // `needed` (may be null) limits staging to the channels an operator actually reads.
     DevPage stage(const pa_page* page, const std::vector<bool>* needed, hipStream_t stream);
     size_t bytes() const;
 
+    // A host page of FLAT / VARWIDTH blocks up to this many bytes travels as ONE copy: its arrays are laid behind each other in a
+    // pinned block and land in one HBM allocation (an enqueued copy costs ~4 us whatever its size: the 19 arrays of a 4-row page of
+    // Q1's PARTIAL states were 85 us of staging, one copy is 6).
+    static constexpr size_t kPackedLimit = 256 << 10;
+
 private:
     void* arena(size_t index, size_t bytes);
+    bool stage_packed(const pa_page* page, const std::vector<bool>* needed, hipStream_t stream, DevPage& out);
     std::vector<DevBuf> bufs_;
     size_t next_ = 0;
+    // the pinned blocks of the packed path: two, taken in turn; `done` = the copy out of the block has been executed
+    struct Packed {
+        PinnedBuf host;
+        hipEvent_t done = nullptr;
+        bool pending = false;
+    };
+    Packed packed_[2];
+    DevBuf packed_dev_[2];
+    size_t packed_at_ = 0;
+};
+
+// A small pageable host page laid into pinned memory, so that ONE launch (or copy) can read all its arrays: an enqueued copy costs
+// ~4 us whatever its size, and a page of Q1's PARTIAL states has 19 arrays of 4 rows.  Two pinned blocks taken in turn: the page of
+// a call stays valid until the call after the next.
+class PinnedPageCopy {
+public:
+    PinnedPageCopy() = default;
+    PinnedPageCopy(const PinnedPageCopy&) = delete;
+    PinnedPageCopy& operator=(const PinnedPageCopy&) = delete;
+    ~PinnedPageCopy();
+    // The same page with every needed FLAT / VARWIDTH array in pinned memory (flags = PA_PAGE_PINNED), or nullptr when the page does
+    // not qualify (encoded blocks, more than PageStager::kPackedLimit bytes, no rows).  After enqueueing what reads it: used(stream).
+    const pa_page* copy(const pa_page* page, const std::vector<bool>* needed);
+    void used(hipStream_t stream);
+
+private:
+    struct Slot {
+        PinnedBuf host;
+        hipEvent_t done = nullptr;
+        bool pending = false;
+        std::vector<pa_column> cols;
+        pa_page page{};
+    };
+    Slot slots_[2];
+    size_t at_ = 0;
+    Slot* cur_ = nullptr;
 };
 
 // One output Block under construction in HBM.

@@ -288,11 +288,35 @@ def test_ragged_varchar_keys_over_small_device_pages(gpu, oracle):
     dev = upload_page(merged)
     stable = stable_regions(dev, [0] + list(np.cumsum(sizes)))
     order = rng.permutation(len(stable))
-    for name, pages in (("own", own), ("stable", [stable[i] for i in order]), ("mixed", [(own[i], stable[i])[i & 1] for i in order])):
+    # ... and as pageable host pages: laid into pinned memory, one copy launch per page (PinnedPageCopy)
+    for name, pages in (("own", own), ("stable", [stable[i] for i in order]), ("mixed", [(own[i], stable[i])[i & 1] for i in order]),
+                        ("host", host_pages), ("host and device in turn", [(host_pages[i], own[i], stable[i])[i % 3] for i in range(len(own))])):
         op = HashAggregationOperator(types, [0], aggs, type_params=[12, 0])
         rows = sorted((r for p in to_pages(op, pages) for r in p.to_rows()), key=repr)
         op.close()
         assert rows == expected, name
+
+
+def test_pageable_host_pages_either_side_of_the_one_copy_limit(gpu, oracle):
+    """Pageable host pages up to 256 KB of block arrays go through pinned memory as one copy launch, larger ones array by array
+    (device_page.hpp PinnedPageCopy, PageStager::kPackedLimit): pages of both kinds in turn, nullable channels, exact sums."""
+    rng = np.random.default_rng(23)
+    types = [abi.BIGINT, abi.BIGINT, abi.INTEGER]
+    aggs = [(abi.AGG_SUM, 1, abi.BIGINT), (abi.AGG_COUNT, 1, abi.BIGINT), (abi.AGG_MAX, 2, abi.INTEGER), (abi.AGG_COUNT_STAR, -1, None)]
+    sizes = [12_000, 13_200, 1, 12_900, 40_000, 12_901, 5, 12_483, 12_484, 3000] * 3   # 256 KB = 12 483 rows of 8 + 8 + 4 + 1 bytes
+    pages = []
+    for n in sizes:
+        nulls = rng.random(n) < 0.1
+        pages.append(Page([Block.bigint(rng.integers(0, 7, n)), Block.flat(abi.BIGINT, rng.integers(-10**12, 10**12, n), nulls),
+                           Block.flat(abi.INTEGER, rng.integers(-2**31, 2**31 - 1, n).astype(np.int32))], n))
+    ref = oracle.HashAggregation(types, [0], aggs)
+    for p in pages:
+        ref.add_page(p)
+    expected = sorted(ref.build_result().to_rows())
+    op = HashAggregationOperator(types, [0], aggs)
+    rows = sorted(r for p in to_pages(op, pages) for r in p.to_rows())
+    op.close()
+    assert rows == expected
 
 
 def test_varchar_bytes_beyond_the_declared_bound_are_refused(gpu):
