@@ -43,21 +43,27 @@ void launch_rerank_words(uint64_t* words, int64_t n, bool is_min, const uint32_t
 class StringInterner {
 public:
     // VARCHAR column of a staged page -> its ids (n x i32 on the device, valid until the next call); NULL rows get id 0
-    const int32_t* intern(const void* values, const int32_t* offsets, const uint8_t* nulls, int64_t n, hipStream_t s);
+    // bytes_hint >= 0: an upper bound of the column's bytes the caller knows (a page gathered from host pages), which saves the
+    // round trip for offsets[0] / offsets[n].  The dictionary's counters come back behind the launch without a wait: whoever
+    // needs them next (size(), the next intern) waits then -- by which time the stream has usually passed the copy.
+    const int32_t* intern(const void* values, const int32_t* offsets, const uint8_t* nulls, int64_t n, hipStream_t s, int64_t bytes_hint = -1);
     // ids -> VariableWidthBlock arrays (offsets: n + 1 entries); rows flagged in `nulls` (may be null) become empty
     void decode(const int32_t* ids, const uint8_t* nulls, int64_t n, DevBuf* values, DevBuf* offsets, hipStream_t s);
     const uint64_t* hashes() const { return id_hash_.as<uint64_t>(); }
-    uint32_t size() const { return ids_; }
+    uint32_t size() { settle(); return ids_; }
     // the strings of the ids from->size() onwards appended to `out` (a copy for the host: ranks, small results)
     void fetch_strings(uint32_t from, std::vector<std::string>* out, hipStream_t s);
-    uint64_t bytes() const { return (uint64_t)words_ * 8; }  // arena in use (strings padded to 8 bytes)
+    uint64_t bytes() const { return (uint64_t)words_ * 8; }  // arena in use (strings padded to 8 bytes), as of the last settled page
 
 private:
     InternTable view() const;
     void reserve(int64_t rows, int64_t bytes, hipStream_t s);
+    void settle();   // ids_ / words_ as the last launch left them
     DevBuf tag_, meta_, off_, id_off_, id_len_, id_hash_, arena_, counters_, ids_out_;
-    PinnedBuf h_;
+    PinnedBuf h_, h_fetch_;
     uint32_t cap_ = 0, ids_ = 0, words_ = 0;
+    bool pending_ = false;             // the counters' copy of the last launch is in pending_stream_, not looked at yet
+    hipStream_t pending_stream_ = nullptr;
 };
 
 }  // namespace pa

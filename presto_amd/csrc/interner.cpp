@@ -61,29 +61,45 @@ void StringInterner::reserve(int64_t rows, int64_t bytes, hipStream_t s)
     arena_.reserve_keep((size_t)need_words * 8, (size_t)words_ * 8, s);
 }
 
-const int32_t* StringInterner::intern(const void* values, const int32_t* offsets, const uint8_t* nulls, int64_t n, hipStream_t s)
+void StringInterner::settle()
 {
+    if (!pending_) return;
+    PA_HIP(hipStreamSynchronize(pending_stream_));
+    const uint32_t* h = h_.as<uint32_t>();
+    ids_ = h[0];
+    words_ = h[1];
+    pending_ = false;
+}
+
+const int32_t* StringInterner::intern(const void* values, const int32_t* offsets, const uint8_t* nulls, int64_t n, hipStream_t s, int64_t bytes_hint)
+{
+    settle();
     int32_t* ids = static_cast<int32_t*>(ids_out_.ensure((size_t)std::max<int64_t>(n, 1) * 4));
     uint32_t* h = static_cast<uint32_t*>(h_.ensure(64));
     for (int64_t at = 0; at < n; at += kSliceRows) {
         const int64_t rows = std::min(kSliceRows, n - at);
-        int32_t* hb = reinterpret_cast<int32_t*>(h + 4);
-        PA_HIP(hipMemcpyAsync(hb, offsets + at, 4, hipMemcpyDeviceToHost, s));
-        PA_HIP(hipMemcpyAsync(hb + 1, offsets + at + rows, 4, hipMemcpyDeviceToHost, s));
-        PA_HIP(hipStreamSynchronize(s));
-        PA_REQUIRE(hb[1] >= hb[0], PA_ERR_INVALID_ARGUMENT, "VARCHAR offsets are not ascending");
-        reserve(rows, (int64_t)hb[1] - hb[0], s);
+        int64_t bytes = bytes_hint;
+        if (bytes < 0) {
+            int32_t* hb = reinterpret_cast<int32_t*>(h + 4);
+            PA_HIP(hipMemcpyAsync(hb, offsets + at, 4, hipMemcpyDeviceToHost, s));
+            PA_HIP(hipMemcpyAsync(hb + 1, offsets + at + rows, 4, hipMemcpyDeviceToHost, s));
+            PA_HIP(hipStreamSynchronize(s));
+            PA_REQUIRE(hb[1] >= hb[0], PA_ERR_INVALID_ARGUMENT, "VARCHAR offsets are not ascending");
+            bytes = (int64_t)hb[1] - hb[0];
+        }
+        reserve(rows, bytes, s);
         launch_intern(view(), values, offsets + at, nulls ? nulls + at : nullptr, rows, ids + at, s);
         PA_HIP(hipMemcpyAsync(h, counters_.ptr(), 8, hipMemcpyDeviceToHost, s));
-        PA_HIP(hipStreamSynchronize(s));
-        ids_ = h[0];
-        words_ = h[1];
+        pending_ = true;
+        pending_stream_ = s;
+        if (at + rows < n) settle();   // the next slice's reservation starts from these
     }
     return ids;
 }
 
 void StringInterner::decode(const int32_t* ids, const uint8_t* nulls, int64_t n, DevBuf* values, DevBuf* offsets, hipStream_t s)
 {
+    settle();
     int32_t* offs = static_cast<int32_t*>(offsets->ensure((size_t)(n + 1) * 4));
     if (n == 0) {
         PA_HIP(hipMemsetAsync(offs, 0, 4, s));
@@ -107,24 +123,36 @@ void StringInterner::decode(const int32_t* ids, const uint8_t* nulls, int64_t n,
 
 void StringInterner::fetch_strings(uint32_t from, std::vector<std::string>* out, hipStream_t s)
 {
+    settle();
     if (from >= ids_) return;
     const uint32_t n = ids_ - from;
-    std::vector<uint32_t> off(n), len(n);
-    PA_HIP(hipMemcpyAsync(off.data(), id_off_.as<uint32_t>() + from, (size_t)n * 4, hipMemcpyDeviceToHost, s));
-    PA_HIP(hipMemcpyAsync(len.data(), id_len_.as<uint32_t>() + from, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    // a small dictionary (the keys of a FINAL step, a handful of flags): offsets, lengths and the whole arena in one round trip
+    const bool whole = (uint64_t)words_ * 8 <= (64u << 10);
+    uint32_t* land = static_cast<uint32_t*>(h_fetch_.ensure((size_t)n * 8 + (whole ? (size_t)words_ * 8 : 0) + 8));
+    uint32_t* off = land;
+    uint32_t* len = land + n;
+    PA_HIP(hipMemcpyAsync(off, id_off_.as<uint32_t>() + from, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    PA_HIP(hipMemcpyAsync(len, id_len_.as<uint32_t>() + from, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    if (whole && words_) PA_HIP(hipMemcpyAsync(land + 2 * (size_t)n, arena_.ptr(), (size_t)words_ * 8, hipMemcpyDeviceToHost, s));
     PA_HIP(hipStreamSynchronize(s));
     // (the arena is handed out by an atomic cursor: the new ids' strings lie somewhere between the lowest of their offsets and its end)
-    uint32_t lo = words_;
-    for (uint32_t i = 0; i < n; i++) lo = std::min(lo, off[i]);
-    std::vector<uint64_t> words((size_t)(words_ - lo) + 1);
-    if (words_ > lo) {
-        PA_HIP(hipMemcpyAsync(words.data(), arena_.as<uint64_t>() + lo, (size_t)(words_ - lo) * 8, hipMemcpyDeviceToHost, s));
-        PA_HIP(hipStreamSynchronize(s));
+    uint32_t lo = 0;
+    std::vector<uint64_t> fetched;
+    const uint64_t* words = reinterpret_cast<const uint64_t*>(land + 2 * (size_t)n);
+    if (!whole) {
+        lo = words_;
+        for (uint32_t i = 0; i < n; i++) lo = std::min(lo, off[i]);
+        fetched.resize((size_t)(words_ - lo) + 1);
+        if (words_ > lo) {
+            PA_HIP(hipMemcpyAsync(fetched.data(), arena_.as<uint64_t>() + lo, (size_t)(words_ - lo) * 8, hipMemcpyDeviceToHost, s));
+            PA_HIP(hipStreamSynchronize(s));
+        }
+        words = fetched.data();
     }
     out->reserve(out->size() + n);
     for (uint32_t i = 0; i < n; i++) {
         PA_REQUIRE(off[i] >= lo && (uint64_t)(off[i] - lo) * 8 + len[i] <= (uint64_t)(words_ - lo) * 8, PA_ERR_DEVICE, "internal: dictionary entry outside the arena");
-        out->emplace_back(reinterpret_cast<const char*>(words.data() + (off[i] - lo)), (size_t)len[i]);
+        out->emplace_back(reinterpret_cast<const char*>(words + (off[i] - lo)), (size_t)len[i]);
     }
 }
 
