@@ -172,7 +172,8 @@ public:
             // (rocPRIM 4.0's merge-sort path for small inputs builds its mask of the bit range with 1 << end_bit: a range that ends at
             // bit 64 without starting at bit 0 compares nothing -- such ranges are widened to the whole key)
             if (end_bit == 64) begin_bit = 0;
-            launch_sort_pairs(in, perm, kp[1], next, n, begin_bit, end_bit, sort_temp, sort_temp_bytes, s);
+            const int path = launch_sort_pairs(in, perm, kp[1], next, n, begin_bit, end_bit, sort_temp, sort_temp_bytes, s);
+            timer.set_name(path == PA_SORT_LIBRARY ? "rocprim_radix_sort_pairs" : "pa_sort_buckets");   // (pa_op_kernel_name: which sort the last image took)
             std::swap(perm, next);
             identity = false;
             sorted_images = kp[1];

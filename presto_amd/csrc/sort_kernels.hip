@@ -1,9 +1,22 @@
 // sort_kernels.hip -- the pair sort under OrderByOperator's passes: (64-bit key image, row id) pairs by a range of the image's bits, stable.
-// rocPRIM's device radix sort (one-sweep passes: every pass reads and writes the pairs once) is the library primitive for exactly this
-// and replaces the operator's own LDS-staged 8-bit passes (count + scan + scatter: the pairs were read twice per pass) -- 2^24 pairs by
-// 64 bits 2.3 ms -> see DESIGN.md section 6.  What the sort is asked to do stays the operator's: order-preserving images per sort channel
-// and direction, 8-byte chunks + length for VARCHAR, the NULL placement as a digit of its own, constant bits left out (op_order_by.cpp;
-// PagesIndex.sort / PagesIndexOrdering.quickSort, core/trino-main/src/main/java/io/trino/operator/PagesIndex.java:418-426).
+// (PagesIndex.sort / PagesIndexOrdering.quickSort, core/trino-main/src/main/java/io/trino/operator/PagesIndex.java:418-426: the
+// reference quick-sorts row addresses with a comparator; what the sort is asked to do here -- order-preserving images per sort channel and
+// direction, 8-byte chunks + length for VARCHAR, the NULL placement as a digit of its own, constant bits left out -- is op_order_by.cpp's.)
+//
+// Most-significant bits first, and the pairs cross HBM three times instead of once per 8-bit digit:
+//   1. two stable partition passes by the top T = bits1 + bits2 bits of the range (at most 7 bits each): a count launch (keys only), a
+//      scan of the tile x digit matrix, and a scatter launch whose 4096-row tiles rank their rows with wave ballots (a row's place in its
+//      (tile, digit) run = earlier rows of the tile with the same digit), stage the tile in LDS in digit order and write every run
+//      as one contiguous piece.  The second pass works inside the first pass's buckets (tiles never straddle a bucket).
+//      T is chosen so that a final bucket holds ~1024 pairs (n / 2^T); bits the range does not have are not partitioned by.
+//   2. one launch that sorts every final bucket in LDS by the remaining bits: stable 7-bit passes over at most kCap = 2048 pairs, the
+//      same ballot ranking, ping-pong between two LDS copies; the bucket is read once and written once, in place of its final rows.
+// 2^24 pairs by 40 bits: 5 one-sweep passes of the library sort read and write the pairs 5 times (24 B per pair and pass); this reads
+// 8 + 24 + 8 + 24 + 24 and writes 12 + 12 + 12 bytes per pair.
+// Buckets are bit prefixes, so this is for keys that spread over their varying bits (row ids, hashes, uniform integers: what OR / AND
+// of the images leaves).  When a final bucket would not fit in LDS (skewed keys: exponent bits of doubles, few hot values in a wide
+// range) or the input is beyond 27 M pairs, rocPRIM's device radix sort does the whole job instead -- decided from the bucket sizes, which
+// are known on the device before the last pass; the partition passes already done are then wasted (0.2 ms at 2^24 pairs).
 #include <cstring>
 
 #include <rocprim/device/device_radix_sort.hpp>
@@ -12,25 +25,574 @@
 
 namespace pa {
 
-size_t sort_pairs_temp_bytes(int64_t n)
+namespace {
+
+using u64 = unsigned long long;
+using u32 = unsigned int;
+using i32 = int;
+using i64 = long long;
+
+constexpr int kTile = 4096;       // rows of a partition tile: 4 waves x 16 rounds of 64
+constexpr int kPartBits = 7;      // digit of a partition pass (cnt[4][128]: the kernel's LDS stays under 53 KB -> 3 workgroups per CU)
+constexpr int kCap = 2048;        // pairs of a final bucket the LDS sort takes
+constexpr int kSortBits = 7;      // digit of an LDS pass
+constexpr int kMaxTopBits = 2 * kPartBits;
+constexpr i64 kFastMaxRows = 27000000;   // 2^14 buckets of <= 1650 pairs on average: six sigma of a uniform spread stay under kCap
+
+struct SortCtl {
+    i32 max_bucket;   // largest final bucket
+    i32 tiles_b;      // tiles of the second partition pass
+    i32 pad[14];
+};
+
+__device__ __forceinline__ i32 wave_inclusive_scan(i32 v, int lane)
+{
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const i32 u = __shfl_up(v, o, 64);
+        if (lane >= o) v += u;
+    }
+    return v;
+}
+
+// rows of this lane's digit among the live lanes of the wave: `peers` = their lanes, returns how many of them come before this lane.
+// One ballot per bit of the digit; a lane keeps the lanes whose bit equals its own: peers &= ~(ballot ^ s) with s = the lane's bit
+// spread over a word (0 or ~0).
+template <int BITS>
+__device__ __forceinline__ int wave_digit_peers_n(u32 d, bool live, int lane, u64* peers_out)
+{
+    const u64 all = __ballot(live);
+    u32 lo = (u32)all, hi = (u32)(all >> 32);
+#pragma unroll
+    for (int b = 0; b < BITS; b++) {
+        const i32 s = __builtin_amdgcn_sbfe((i32)d, b, 1);   // 0 or -1
+        const u64 bal = __ballot(s != 0);
+        lo &= ~((u32)bal ^ (u32)s);
+        hi &= ~((u32)(bal >> 32) ^ (u32)s);
+    }
+    *peers_out = ((u64)hi << 32) | lo;
+    return (int)__builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0u));
+}
+
+__device__ __forceinline__ int wave_digit_peers(u32 d, bool live, int bits, int lane, u64* peers_out)
+{
+    switch (bits) {   // (uniform: the digit's width is a launch parameter)
+        case 1: return wave_digit_peers_n<1>(d, live, lane, peers_out);
+        case 2: return wave_digit_peers_n<2>(d, live, lane, peers_out);
+        case 3: return wave_digit_peers_n<3>(d, live, lane, peers_out);
+        case 4: return wave_digit_peers_n<4>(d, live, lane, peers_out);
+        case 5: return wave_digit_peers_n<5>(d, live, lane, peers_out);
+        case 6: return wave_digit_peers_n<6>(d, live, lane, peers_out);
+        default: return wave_digit_peers_n<7>(d, live, lane, peers_out);
+    }
+}
+
+// digit counts of every tile: counts[digit * tiles_cap + tile].  Tiles: 4096 consecutive rows of the input (tile_start == nullptr), or
+// the rows the plan kernel listed (second pass: tiles inside the first pass's buckets; workgroups past *ntiles_dev leave).
+__global__ __launch_bounds__(256) void k_sort_count(const u64* __restrict__ keys, i64 n, const i32* __restrict__ tile_start, const i32* __restrict__ tile_rows,
+                                                    const i32* __restrict__ ntiles_dev, i32 tiles_cap, int shift, int bits, i32* __restrict__ counts)
+{
+    __shared__ i32 hist[1 << kPartBits];
+    const i32 tile = (i32)blockIdx.x;
+    if (ntiles_dev != nullptr && tile >= *ntiles_dev) return;
+    if (threadIdx.x < (1u << kPartBits)) hist[threadIdx.x] = 0;
+    __syncthreads();
+    const i64 start = tile_start ? (i64)tile_start[tile] : (i64)tile * kTile;
+    const i32 rows = tile_rows ? tile_rows[tile] : (i32)(n - start < (i64)kTile ? n - start : (i64)kTile);
+    const u32 mask = (1u << bits) - 1u;
+#pragma unroll
+    for (int i = 0; i < kTile / 256; i++) {
+        const i32 idx = i * 256 + (i32)threadIdx.x;
+        if (idx < rows) atomicAdd(&hist[(u32)(keys[start + idx] >> shift) & mask], 1);
+    }
+    __syncthreads();
+    if (threadIdx.x < (1u << bits)) counts[(i64)threadIdx.x * tiles_cap + tile] = hist[threadIdx.x];
+}
+
+// counts[digit][tile] -> rows of the digit in earlier tiles of the same bucket (exclusive, in place); totals[bucket * nd + digit] = rows of
+// the digit in the bucket.  One workgroup per (digit, bucket), a run of consecutive tiles per thread.  bucket_tile_base == nullptr: one
+// bucket of `tiles` tiles.
+__global__ __launch_bounds__(256) void k_sort_scan_tiles(i32* __restrict__ counts, i32 tiles_cap, const i32* __restrict__ bucket_tile_base, i32 tiles, i32 nd,
+                                                         i32* __restrict__ totals)
+{
+    __shared__ i32 wave_sums[4];
+    const i32 d = (i32)blockIdx.x, b = (i32)blockIdx.y;
+    const int lane = (int)threadIdx.x & 63, wave = (int)threadIdx.x >> 6;
+    const i32 t0 = bucket_tile_base ? bucket_tile_base[b] : 0;
+    const i32 t1 = bucket_tile_base ? bucket_tile_base[b + 1] : tiles;
+    i32* row = counts + (i64)d * tiles_cap;
+    const i32 per = (t1 - t0 + 255) / 256;
+    const i32 lo = t0 + (i32)threadIdx.x * per < t1 ? t0 + (i32)threadIdx.x * per : t1;
+    const i32 hi = lo + per < t1 ? lo + per : t1;
+    i32 sum = 0;
+    for (i32 t = lo; t < hi; t++) sum += row[t];
+    const i32 inc = wave_inclusive_scan(sum, lane);
+    if (lane == 63) wave_sums[wave] = inc;
+    __syncthreads();
+    i32 before = 0, all = 0;
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        if (w < wave) before += wave_sums[w];
+        all += wave_sums[w];
+    }
+    i32 run = before + inc - sum;
+    for (i32 t = lo; t < hi; t++) {
+        const i32 v = row[t];
+        row[t] = run;
+        run += v;
+    }
+    if (threadIdx.x == 0) totals[(i64)b * nd + d] = all;
+}
+
+// offs[0..m] = exclusive prefix sums of totals[0..m), *max_out = the largest of them.  One workgroup, a run of entries per thread.
+__global__ __launch_bounds__(256) void k_sort_offsets(const i32* __restrict__ totals, i32 m, i32* __restrict__ offs, i32* __restrict__ max_out)
+{
+    __shared__ i32 wave_sums[4];
+    __shared__ i32 wave_max[4];
+    const int lane = (int)threadIdx.x & 63, wave = (int)threadIdx.x >> 6;
+    const i32 per = (m + 255) / 256;
+    const i32 lo = (i32)threadIdx.x * per < m ? (i32)threadIdx.x * per : m;
+    const i32 hi = lo + per < m ? lo + per : m;
+    i32 sum = 0, mx = 0;
+    for (i32 i = lo; i < hi; i++) {
+        const i32 v = totals[i];
+        sum += v;
+        mx = v > mx ? v : mx;
+    }
+    const i32 inc = wave_inclusive_scan(sum, lane);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const i32 u = __shfl_xor(mx, o, 64);
+        mx = u > mx ? u : mx;
+    }
+    if (lane == 63) wave_sums[wave] = inc;
+    if (lane == 0) wave_max[wave] = mx;
+    __syncthreads();
+    i32 before = 0, all = 0;
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        if (w < wave) before += wave_sums[w];
+        all += wave_sums[w];
+    }
+    i32 run = before + inc - sum;
+    for (i32 i = lo; i < hi; i++) {
+        offs[i] = run;
+        run += totals[i];
+    }
+    if (threadIdx.x == 0) {
+        offs[m] = all;
+        if (max_out != nullptr) {
+            i32 best = wave_max[0];
+            for (int w = 1; w < 4; w++) best = wave_max[w] > best ? wave_max[w] : best;
+            *max_out = best;
+        }
+    }
+}
+
+// The tiles of the second partition pass: every bucket of the first pass (offs[b] .. offs[b + 1]) cut into pieces of kTile rows.
+// One workgroup, one thread per bucket (nb <= 128).
+__global__ __launch_bounds__(256) void k_sort_plan_tiles(const i32* __restrict__ offs, i32 nb, i32* __restrict__ bucket_tile_base, i32* __restrict__ tile_start,
+                                                         i32* __restrict__ tile_rows, i32* __restrict__ tile_bucket, i32* __restrict__ tiles_out)
+{
+    __shared__ i32 wave_sums[4];
+    const int lane = (int)threadIdx.x & 63, wave = (int)threadIdx.x >> 6;
+    const i32 b = (i32)threadIdx.x;
+    const i32 first = b < nb ? offs[b] : 0;
+    const i32 size = b < nb ? offs[b + 1] - first : 0;
+    const i32 nt = (size + kTile - 1) / kTile;
+    const i32 inc = wave_inclusive_scan(nt, lane);
+    if (lane == 63) wave_sums[wave] = inc;
+    __syncthreads();
+    i32 before = 0, all = 0;
+    for (int w = 0; w < 4; w++) {
+        if (w < wave) before += wave_sums[w];
+        all += wave_sums[w];
+    }
+    const i32 tb = before + inc - nt;
+    if (b < nb) bucket_tile_base[b] = tb;
+    if (b == 0) {
+        bucket_tile_base[nb] = all;
+        *tiles_out = all;
+    }
+    for (i32 k = 0; k < nt; k++) {
+        tile_start[tb + k] = first + k * kTile;
+        tile_rows[tb + k] = size - k * kTile < kTile ? size - k * kTile : kTile;
+        tile_bucket[tb + k] = b;
+    }
+}
+
+// One stable partition pass over a tile: the tile's rows go to out[base[bucket * nd + d] + offs[d * tiles_cap + tile] + (place of the row
+// among the tile's rows of digit d)].  Wave w of the workgroup takes rows [1024 w, 1024 (w + 1)) of the tile in 16 rounds of 64 consecutive
+// rows, so "earlier in the tile" = earlier wave, then earlier round, then lower lane.
+__global__ __launch_bounds__(256) void k_sort_partition(const u64* __restrict__ kin, const i32* __restrict__ rin, u64* __restrict__ kout, i32* __restrict__ rout, i64 n,
+                                                        const i32* __restrict__ tile_start, const i32* __restrict__ tile_rows, const i32* __restrict__ tile_bucket,
+                                                        const i32* __restrict__ ntiles_dev, i32 tiles_cap, int shift, int bits, const i32* __restrict__ offs,
+                                                        const i32* __restrict__ base)
+{
+    constexpr int kRounds = kTile / 256;
+    __shared__ u64 skey[kTile];
+    __shared__ i32 srow[kTile];
+    __shared__ i32 cnt[4][1 << kPartBits];
+    __shared__ i32 lstart[1 << kPartBits], goff[1 << kPartBits];
+    __shared__ i32 wave_sums[4];
+    const i32 tile = (i32)blockIdx.x;
+    if (ntiles_dev != nullptr && tile >= *ntiles_dev) return;
+    const int lane = (int)threadIdx.x & 63, wave = (int)threadIdx.x >> 6;
+    const i64 start = tile_start ? (i64)tile_start[tile] : (i64)tile * kTile;
+    const i32 rows = tile_rows ? tile_rows[tile] : (i32)(n - start < (i64)kTile ? n - start : (i64)kTile);
+    const i32 bucket = tile_bucket ? tile_bucket[tile] : 0;
+    const i32 nd = 1 << bits;
+    const u32 mask = (u32)nd - 1u;
+    if ((i32)threadIdx.x < nd) {
+#pragma unroll
+        for (int w = 0; w < 4; w++) cnt[w][threadIdx.x] = 0;
+    }
+    u64 key[kRounds];
+    i32 row[kRounds];
+    i32 lr[kRounds];
+#pragma unroll
+    for (int r = 0; r < kRounds; r++) {
+        const i32 idx = wave * (kTile / 4) + r * 64 + lane;
+        const bool live = idx < rows;
+        key[r] = live ? kin[start + idx] : 0ULL;
+        row[r] = live ? rin[start + idx] : 0;
+    }
+    __syncthreads();
+    // the wave's count of every digit grows round by round: the first lane of a digit's rows in a round adds them and gets the count of
+    // the rounds before (LDS executes a wave's atomics in order); the adds of all rounds are in flight together, their results are
+    // handed to the other lanes of the group afterwards
+    i32 prior[kRounds];
+    int leader[kRounds];
+#pragma unroll
+    for (int r = 0; r < kRounds; r++) {
+        const i32 idx = wave * (kTile / 4) + r * 64 + lane;
+        const bool live = idx < rows;
+        const u32 d = (u32)(key[r] >> shift) & mask;
+        u64 peers;
+        const int before = wave_digit_peers(d, live, bits, lane, &peers);
+        lr[r] = before;
+        leader[r] = live ? __ffsll((long long)peers) - 1 : lane;
+        prior[r] = 0;
+        if (live && before == 0) prior[r] = __hip_atomic_fetch_add(&cnt[wave][d], (i32)__popcll(peers), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+#pragma unroll
+    for (int r = 0; r < kRounds; r++) lr[r] += __shfl(prior[r], leader[r], 64);
+    __syncthreads();
+    {
+        i32 total = 0;
+        if ((i32)threadIdx.x < nd) {
+#pragma unroll
+            for (int w = 0; w < 4; w++) {
+                const i32 c = cnt[w][threadIdx.x];
+                cnt[w][threadIdx.x] = total;
+                total += c;
+            }
+        }
+        const i32 inc = wave_inclusive_scan(total, lane);
+        if (lane == 63) wave_sums[wave] = inc;
+        __syncthreads();
+        i32 before = 0;
+        for (int w = 0; w < wave; w++) before += wave_sums[w];
+        if ((i32)threadIdx.x < nd) {
+            lstart[threadIdx.x] = before + inc - total;
+            goff[threadIdx.x] = base[(i64)bucket * nd + threadIdx.x] + offs[(i64)threadIdx.x * tiles_cap + tile];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < kRounds; r++) {
+        const i32 idx = wave * (kTile / 4) + r * 64 + lane;
+        if (idx < rows) {
+            const u32 d = (u32)(key[r] >> shift) & mask;
+            const i32 p = lstart[d] + cnt[wave][d] + lr[r];
+            skey[p] = key[r];
+            srow[p] = row[r];
+        }
+    }
+    __syncthreads();
+    for (i32 j = (i32)threadIdx.x; j < rows; j += 256) {
+        const u64 k = skey[j];
+        const u32 d = (u32)(k >> shift) & mask;
+        const i64 dest = (i64)goff[d] + (j - lstart[d]);
+        kout[dest] = k;
+        rout[dest] = srow[j];
+    }
+}
+
+// Every final bucket sorted in LDS by bits [begin_bit, begin_bit + rest_bits) of its keys: `passes` stable passes of `bits_per` bits.
+// Bucket b = rows offs[b] .. offs[b + 1] of the input (offs == nullptr: the one bucket of rows 0 .. n_single); at most kCap rows each
+// (the host checked).  The sorted bucket lands at the same rows of the output.
+// A pass: every wave takes consecutive rows (the same number of 64-row rounds each), ranks them like the partition pass, and the rows go to
+// their places IN the one LDS copy -- every row sits in a register of its thread between the barrier that ends the reads and the writes.
+// The first pass takes its rows from HBM directly.  26.5 KB of LDS: six workgroups per CU.
+__global__ __launch_bounds__(256) void k_sort_buckets(const u64* __restrict__ kin, const i32* __restrict__ rin, u64* __restrict__ kout, i32* __restrict__ rout,
+                                                      const i32* __restrict__ offs, i32 n_single, int begin_bit, int rest_bits, int passes, int bits_per)
+{
+    constexpr int kRounds = kCap / 256;
+    __shared__ u64 kbuf[kCap];
+    __shared__ i32 rbuf[kCap];
+    __shared__ i32 cnt[2][4][1 << kSortBits];
+    __shared__ i32 dstart[1 << kSortBits];
+    const i32 bucket = (i32)blockIdx.x;
+    const i32 start = offs ? offs[bucket] : 0;
+    const i32 count = offs ? offs[bucket + 1] - start : n_single;
+    if (count <= 0) return;
+    const int lane = (int)threadIdx.x & 63, wave = (int)threadIdx.x >> 6;
+    const i32 chunk = ((count + 255) / 256) * 64;
+    const int rounds = chunk / 64;
+    u64 key[kRounds];
+    i32 row[kRounds];
+#pragma unroll
+    for (int r = 0; r < kRounds; r++) {
+        const i32 idx = wave * chunk + r * 64 + lane;
+        const bool live = r < rounds && idx < count;
+        key[r] = live ? kin[(i64)start + idx] : 0ULL;
+        row[r] = live ? rin[(i64)start + idx] : 0;
+    }
+    if (threadIdx.x < (1u << kSortBits)) {
+#pragma unroll
+        for (int w = 0; w < 4; w++) cnt[0][w][threadIdx.x] = 0;
+    }
+    for (int p = 0; p < passes; p++) {
+        const int lo = begin_bit + p * bits_per;
+        const int bits = (begin_bit + rest_bits - lo) < bits_per ? (begin_bit + rest_bits - lo) : bits_per;
+        const u32 mask = (1u << bits) - 1u;
+        i32(*c)[1 << kSortBits] = cnt[p & 1];
+        __syncthreads();   // the counters are zero; the previous pass's rows are in their places
+        if (p > 0) {
+#pragma unroll
+            for (int r = 0; r < kRounds; r++) {
+                const i32 idx = wave * chunk + r * 64 + lane;
+                if (r < rounds && idx < count) {
+                    key[r] = kbuf[idx];
+                    row[r] = rbuf[idx];
+                }
+            }
+        }
+        i32 lr[kRounds], prior[kRounds];
+        int leader[kRounds];
+#pragma unroll
+        for (int r = 0; r < kRounds; r++) {
+            lr[r] = 0;
+            prior[r] = 0;
+            leader[r] = lane;
+            if (r < rounds) {
+                const i32 idx = wave * chunk + r * 64 + lane;
+                const bool live = idx < count;
+                const u32 d = (u32)(key[r] >> lo) & mask;
+                u64 peers;
+                const int before = wave_digit_peers(d, live, bits, lane, &peers);
+                lr[r] = before;
+                if (live) leader[r] = __ffsll((long long)peers) - 1;
+                if (live && before == 0) prior[r] = __hip_atomic_fetch_add(&c[wave][d], (i32)__popcll(peers), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < kRounds; r++) {
+            if (r < rounds) lr[r] += __shfl(prior[r], leader[r], 64);
+        }
+        __syncthreads();   // every wave has counted, and has read its rows of the LDS copy
+        if (wave == 0) {
+            // two digits per lane: counts of the waves -> rows of the digit in the waves before; start of the digit's rows in the bucket
+            i32 t0 = 0, t1 = 0;
+#pragma unroll
+            for (int w = 0; w < 4; w++) {
+                const i32 c0 = c[w][2 * lane], c1 = c[w][2 * lane + 1];
+                c[w][2 * lane] = t0;
+                c[w][2 * lane + 1] = t1;
+                t0 += c0;
+                t1 += c1;
+            }
+            const i32 inc = wave_inclusive_scan(t0 + t1, lane);
+            dstart[2 * lane] = inc - t0 - t1;
+            dstart[2 * lane + 1] = inc - t1;
+        }
+        else if (wave == 1) {
+            // the other set of counters for the next pass
+            i32(*z)[1 << kSortBits] = cnt[(p + 1) & 1];
+#pragma unroll
+            for (int w = 0; w < 4; w++) {
+                z[w][2 * lane] = 0;
+                z[w][2 * lane + 1] = 0;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < kRounds; r++) {
+            const i32 idx = wave * chunk + r * 64 + lane;
+            if (r < rounds && idx < count) {
+                const u32 d = (u32)(key[r] >> lo) & mask;
+                const i32 at = dstart[d] + c[wave][d] + lr[r];
+                kbuf[at] = key[r];
+                rbuf[at] = row[r];
+            }
+        }
+    }
+    __syncthreads();
+    for (i32 j = (i32)threadIdx.x; j < count; j += 256) {
+        kout[(i64)start + j] = kbuf[j];
+        rout[(i64)start + j] = rbuf[j];
+    }
+}
+
+struct FastLayout {
+    size_t keys = 0, rows = 0, counts_a = 0, totals_a = 0, offs_a = 0, bucket_tiles = 0, tile_start = 0, tile_rows = 0, tile_bucket = 0, counts_b = 0, totals_b = 0,
+           offs_b = 0, ctl = 0, end = 0;
+    i64 tiles_a = 0, tiles_cap_b = 0;
+};
+
+FastLayout fast_layout(int64_t n)
+{
+    FastLayout l;
+    l.tiles_a = (n + kTile - 1) / kTile;
+    l.tiles_cap_b = l.tiles_a + (1 << kPartBits);
+    size_t at = 0;
+    auto take = [&at](size_t bytes) {
+        const size_t here = at;
+        at += (bytes + 255) & ~(size_t)255;
+        return here;
+    };
+    l.keys = take((size_t)n * 8);
+    l.rows = take((size_t)n * 4);
+    l.counts_a = take((size_t)l.tiles_a * (1 << kPartBits) * 4);
+    l.totals_a = take((size_t)(1 << kPartBits) * 4);
+    l.offs_a = take((size_t)((1 << kPartBits) + 1) * 4);
+    l.bucket_tiles = take((size_t)((1 << kPartBits) + 1) * 4);
+    l.tile_start = take((size_t)l.tiles_cap_b * 4);
+    l.tile_rows = take((size_t)l.tiles_cap_b * 4);
+    l.tile_bucket = take((size_t)l.tiles_cap_b * 4);
+    l.counts_b = take((size_t)l.tiles_cap_b * (1 << kPartBits) * 4);
+    l.totals_b = take((size_t)(1 << kMaxTopBits) * 4);
+    l.offs_b = take((size_t)((1 << kMaxTopBits) + 1) * 4);
+    l.ctl = take(sizeof(SortCtl));
+    l.end = at;
+    return l;
+}
+
+size_t library_temp_bytes(int64_t n)
 {
     size_t bytes = 0;
     PA_HIP(rocprim::radix_sort_pairs(nullptr, bytes, (const uint64_t*)nullptr, (uint64_t*)nullptr, (const int32_t*)nullptr, (int32_t*)nullptr,
                                      (size_t)std::max<int64_t>(n, 1), 0u, 64u, (hipStream_t) nullptr));
-    return bytes + 256;
+    return bytes;
 }
 
-void launch_sort_pairs(const uint64_t* keys_in, const int32_t* rows_in, uint64_t* keys_out, int32_t* rows_out, int64_t n, int begin_bit, int end_bit,
-                       void* temp, size_t temp_bytes, hipStream_t s)
+void library_sort(const uint64_t* keys_in, const int32_t* rows_in, uint64_t* keys_out, int32_t* rows_out, int64_t n, int begin_bit, int end_bit, void* temp,
+                  size_t temp_bytes, hipStream_t s)
 {
-    if (n <= 0) return;
-    PA_REQUIRE(begin_bit >= 0 && end_bit > begin_bit && end_bit <= 64, PA_ERR_DEVICE, "internal: bit range of a pair sort");
     // the scratch was sized for the whole key (sort_pairs_temp_bytes): rocPRIM does not promise that a narrower bit range needs no more
     // (its merge-sort and one-sweep paths size differently) -- ask for THIS range and refuse to run short
     size_t need = 0;
     PA_HIP(rocprim::radix_sort_pairs(nullptr, need, keys_in, keys_out, rows_in, rows_out, (size_t)n, (unsigned)begin_bit, (unsigned)end_bit, s));
     PA_REQUIRE(need <= temp_bytes, PA_ERR_DEVICE, "internal: pair sort scratch smaller than this bit range needs");
     PA_HIP(rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, rows_in, rows_out, (size_t)n, (unsigned)begin_bit, (unsigned)end_bit, s));
+}
+
+int ceil_log2(int64_t v)
+{
+    int b = 0;
+    while (((int64_t)1 << b) < v) b++;
+    return b;
+}
+
+}  // namespace
+
+size_t sort_pairs_temp_bytes(int64_t n)
+{
+    n = std::max<int64_t>(n, 1);
+    const size_t fast = n <= kFastMaxRows ? fast_layout(n).end : 0;
+    return std::max(library_temp_bytes(n), fast) + 256;
+}
+
+int launch_sort_pairs(const uint64_t* keys_in, const int32_t* rows_in, uint64_t* keys_out, int32_t* rows_out, int64_t n, int begin_bit, int end_bit, void* temp,
+                      size_t temp_bytes, hipStream_t s)
+{
+    if (n <= 0) return PA_SORT_NONE;
+    PA_REQUIRE(begin_bit >= 0 && end_bit > begin_bit && end_bit <= 64, PA_ERR_DEVICE, "internal: bit range of a pair sort");
+    static const bool library_only = getenv("PRESTO_AMD_SORT_LIBRARY") != nullptr;
+    if (library_only || n > kFastMaxRows) {
+        library_sort(keys_in, rows_in, keys_out, rows_out, n, begin_bit, end_bit, temp, temp_bytes, s);
+        return PA_SORT_LIBRARY;
+    }
+    const int width = end_bit - begin_bit;
+    const u64* kin = reinterpret_cast<const u64*>(keys_in);
+    u64* kout = reinterpret_cast<u64*>(keys_out);
+    auto lds_passes = [](int rest, int* bits_per) {
+        const int passes = (rest + kSortBits - 1) / kSortBits;
+        *bits_per = passes ? (rest + passes - 1) / passes : 0;
+        return passes;
+    };
+    if (n <= kCap) {  // one bucket: the LDS sort alone
+        int bits_per = 0;
+        const int passes = lds_passes(width, &bits_per);
+        hipLaunchKernelGGL(k_sort_buckets, 1, 256, 0, s, kin, rows_in, kout, rows_out, (const i32*)nullptr, (i32)n, begin_bit, width, passes, bits_per);
+        PA_HIP(hipGetLastError());
+        return PA_SORT_BUCKETS;
+    }
+    const FastLayout l = fast_layout(n);
+    PA_REQUIRE(l.end <= temp_bytes, PA_ERR_DEVICE, "internal: pair sort scratch smaller than the partition passes need");
+    char* t = static_cast<char*>(temp);
+    u64* tkeys = reinterpret_cast<u64*>(t + l.keys);
+    i32* trows = reinterpret_cast<i32*>(t + l.rows);
+    i32* counts_a = reinterpret_cast<i32*>(t + l.counts_a);
+    i32* totals_a = reinterpret_cast<i32*>(t + l.totals_a);
+    i32* offs_a = reinterpret_cast<i32*>(t + l.offs_a);
+    i32* bucket_tiles = reinterpret_cast<i32*>(t + l.bucket_tiles);
+    i32* tile_start = reinterpret_cast<i32*>(t + l.tile_start);
+    i32* tile_rows = reinterpret_cast<i32*>(t + l.tile_rows);
+    i32* tile_bucket = reinterpret_cast<i32*>(t + l.tile_bucket);
+    i32* counts_b = reinterpret_cast<i32*>(t + l.counts_b);
+    i32* totals_b = reinterpret_cast<i32*>(t + l.totals_b);
+    i32* offs_b = reinterpret_cast<i32*>(t + l.offs_b);
+    SortCtl* ctl = reinterpret_cast<SortCtl*>(t + l.ctl);
+
+    // ~1024 pairs per final bucket, at most 14 bits of partitioning, never more than the range has
+    const int top = std::min(width, std::min(kMaxTopBits, std::max(1, ceil_log2((n + 1023) / 1024))));
+    const int bits1 = std::min(top, kPartBits), bits2 = top - bits1, rest = width - top;
+    const i32 nd1 = 1 << bits1, nd2 = 1 << bits2;
+    const i32 tiles_a = (i32)l.tiles_a, cap_b = (i32)l.tiles_cap_b;
+    // where the passes land: the last one (partition or LDS sort) in the output, the ones before alternate with the scratch pairs
+    const bool two = bits2 > 0, sorting = rest > 0;
+    const int moves = 1 + (two ? 1 : 0) + (sorting ? 1 : 0);
+    u64* dst1_k = (moves % 2) ? kout : tkeys;   // (1 move: output; 2: scratch, output; 3: output, scratch, output)
+    i32* dst1_r = (moves % 2) ? rows_out : trows;
+    u64* dst2_k = (moves % 2) ? tkeys : kout;
+    i32* dst2_r = (moves % 2) ? trows : rows_out;
+
+    const int shift1 = end_bit - bits1, shift2 = end_bit - top;
+    hipLaunchKernelGGL(k_sort_count, tiles_a, 256, 0, s, kin, (i64)n, (const i32*)nullptr, (const i32*)nullptr, (const i32*)nullptr, tiles_a, shift1, bits1, counts_a);
+    hipLaunchKernelGGL(k_sort_scan_tiles, dim3(nd1, 1), 256, 0, s, counts_a, tiles_a, (const i32*)nullptr, tiles_a, nd1, totals_a);
+    hipLaunchKernelGGL(k_sort_offsets, 1, 256, 0, s, (const i32*)totals_a, nd1, offs_a, &ctl->max_bucket);
+    if (two) hipLaunchKernelGGL(k_sort_plan_tiles, 1, 256, 0, s, (const i32*)offs_a, nd1, bucket_tiles, tile_start, tile_rows, tile_bucket, &ctl->tiles_b);
+    hipLaunchKernelGGL(k_sort_partition, tiles_a, 256, 0, s, kin, rows_in, dst1_k, dst1_r, (i64)n, (const i32*)nullptr, (const i32*)nullptr, (const i32*)nullptr,
+                       (const i32*)nullptr, tiles_a, shift1, bits1, (const i32*)counts_a, (const i32*)offs_a);
+    const i32* final_offs = offs_a;
+    const u64* last_k = dst1_k;
+    const i32* last_r = dst1_r;
+    if (two) {
+        hipLaunchKernelGGL(k_sort_count, cap_b, 256, 0, s, (const u64*)dst1_k, (i64)n, (const i32*)tile_start, (const i32*)tile_rows, (const i32*)&ctl->tiles_b, cap_b, shift2,
+                           bits2, counts_b);
+        hipLaunchKernelGGL(k_sort_scan_tiles, dim3(nd2, nd1), 256, 0, s, counts_b, cap_b, (const i32*)bucket_tiles, 0, nd2, totals_b);
+        hipLaunchKernelGGL(k_sort_offsets, 1, 256, 0, s, (const i32*)totals_b, nd1 * nd2, offs_b, &ctl->max_bucket);
+        hipLaunchKernelGGL(k_sort_partition, cap_b, 256, 0, s, (const u64*)dst1_k, (const i32*)dst1_r, dst2_k, dst2_r, (i64)n, (const i32*)tile_start, (const i32*)tile_rows,
+                           (const i32*)tile_bucket, (const i32*)&ctl->tiles_b, cap_b, shift2, bits2, (const i32*)counts_b, (const i32*)offs_b);
+        final_offs = offs_b;
+        last_k = dst2_k;
+        last_r = dst2_r;
+    }
+    PA_HIP(hipGetLastError());
+    if (!sorting) return PA_SORT_BUCKETS;   // the range had no more bits than the partition passes took: done, nothing to wait for
+    i32 max_bucket = 0;
+    read_back(&max_bucket, &ctl->max_bucket, 4, s);
+    if (max_bucket > kCap) {  // keys crowd in a few bit prefixes: the library's passes over the whole range, from the untouched input
+        library_sort(keys_in, rows_in, keys_out, rows_out, n, begin_bit, end_bit, temp, temp_bytes, s);
+        return PA_SORT_LIBRARY;
+    }
+    int bits_per = 0;
+    const int passes = lds_passes(rest, &bits_per);
+    hipLaunchKernelGGL(k_sort_buckets, nd1 * nd2, 256, 0, s, last_k, last_r, kout, rows_out, final_offs, 0, begin_bit, rest, passes, bits_per);
+    PA_HIP(hipGetLastError());
+    return PA_SORT_BUCKETS;
 }
 
 }  // namespace pa

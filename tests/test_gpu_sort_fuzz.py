@@ -57,3 +57,71 @@ def test_random_sorts(gpu, oracle, seed):
     n = int(rng.choice([1, 7, 100, total + 5]))
     top = [r for p in to_pages(TopNOperator(types, n, sort_channels, orders), pages) for r in p.to_rows()]
     assert norm(top) == norm(oracle.topn(pages, n, sort_channels, orders))
+
+
+def _sorted_rows(keys, descending=False):
+    """(key, arrival index) rows in PagesIndexOrdering's order for one BIGINT channel: by key, ties in arrival order."""
+    order = np.argsort(-keys if descending else keys, kind="stable")
+    return keys[order], order
+
+
+def _expected_sort(keys):
+    """Which sort launch_sort_pairs takes for these BIGINT keys (sort_kernels.hip's plan, restated): images = keys with the sign bit
+    flipped, sorted over the bits in which they differ; ~1024 pairs per bucket of the top bits, at most 14; a bucket beyond 2048 pairs
+    with bits left to sort by -> the library."""
+    n = len(keys)
+    img = keys.astype(np.uint64) ^ np.uint64(1 << 63)
+    varying = int(np.bitwise_or.reduce(img)) ^ int(np.bitwise_and.reduce(img))
+    begin, end = (varying & -varying).bit_length() - 1, varying.bit_length()
+    if end == 64:
+        begin = 0
+    width = end - begin
+    if n <= 2048:
+        return "pa_sort_buckets"
+    top = min(width, 14, max(1, int(np.ceil(np.log2((n + 1023) // 1024)))))
+    if width == top:
+        return "pa_sort_buckets"
+    buckets = (img >> np.uint64(end - top)) & np.uint64((1 << top) - 1)
+    return "rocprim_radix_sort_pairs" if np.bincount(buckets.astype(np.int64)).max() > 2048 else "pa_sort_buckets"
+
+
+SORT_SIZES = [1, 2, 63, 2048, 2049, 4095, 4097, 10_000, 262_147, (1 << 20) + 5, 3_000_001]
+
+
+@pytest.mark.parametrize("n", SORT_SIZES)
+@pytest.mark.parametrize("spread", ["40 bits", "63 bits", "5 bits", "14 bits", "wide with duplicates", "hot prefix", "one outlier"])
+def test_pair_sort_paths(gpu, n, spread):
+    """The pair sort under OrderBy (sort_kernels.hip) at the sizes where its plan changes -- one LDS bucket (<= 2048 pairs), one or two
+    partition passes, tiles that end inside a bucket -- and over key spreads that take each of its routes: uniform keys (partition passes
+    + LDS bucket sort), ranges no wider than the partition passes (no LDS sort), keys crowded under one bit prefix (the library sort
+    takes over after the bucket sizes are known).  Expected: numpy's stable sort of (key, arrival index)."""
+    rng = np.random.default_rng(n * 31 + len(spread))
+    if spread == "40 bits":
+        keys = rng.integers(0, 1 << 40, n, dtype=np.int64)
+    elif spread == "63 bits":
+        keys = rng.integers(-(1 << 62), 1 << 62, n, dtype=np.int64)
+    elif spread == "5 bits":
+        keys = rng.integers(0, 32, n, dtype=np.int64)
+    elif spread == "14 bits":
+        keys = rng.integers(0, 1 << 14, n, dtype=np.int64) * 8 + 3
+    elif spread == "wide with duplicates":
+        keys = rng.integers(0, 1 << 40, max(n // 16, 1), dtype=np.int64)[rng.integers(0, max(n // 16, 1), n)]
+    elif spread == "hot prefix":
+        keys = rng.integers(0, 1 << 20, n, dtype=np.int64)
+        keys[rng.random(n) < 0.02] += 1 << 50     # the varying range is 51 bits wide, nearly every key sits under one prefix of it
+    else:
+        keys = np.full(n, 7, dtype=np.int64)
+        keys[n // 2] = 1 << 45
+    descending = n % 2 == 1
+    page = Page([Block.bigint(keys), Block.integer(np.arange(n, dtype=np.int32))], n)
+    op = OrderByOperator([abi.BIGINT, abi.INTEGER], [0, 1], [0], [abi.DESC_NULLS_LAST if descending else abi.ASC_NULLS_LAST])
+    out = to_pages(op, [page])
+    name = op.kernelName()
+    op.close()
+    got_keys = np.concatenate([p.blocks[0].values for p in out])
+    got_rows = np.concatenate([p.blocks[1].values for p in out])
+    want_keys, want_rows = _sorted_rows(keys, descending)
+    assert np.array_equal(got_keys, want_keys)
+    assert np.array_equal(got_rows, want_rows.astype(np.int32))
+    if len(np.unique(keys)) > 1:
+        assert name == _expected_sort(keys), (name, n, spread)
