@@ -130,12 +130,18 @@ public:
         int64_t* counts = static_cast<int64_t*>(counts_.ensure(256 * 8));
         uint64_t* keys = static_cast<uint64_t*>(keys_.ensure((size_t)n * 8));
         void* temp = part_temp_.ensure(partition_temp_bytes(n, 256));
-        launch_iota_i32(perm, n, s);
         timer.begin(s);
-        bool identity = true;  // perm is still 0, 1, 2, ...: the images are in the current order as they are
+        bool identity = true;  // the permutation is still 0, 1, 2, ...: the images are in the current order as they are, and perm is not
+                               // written yet (the first sort takes the row ids as implied; whoever else needs them writes them first)
+        bool written = false;
+        auto materialize = [&] {
+            if (identity && !written) launch_iota_i32(perm, n, s);
+            written = true;
+        };
         auto pass = [&](int partitions) {
             // one stable radix pass: rows grouped by digit, arrival order kept inside a digit; perm' = perm o pos
             launch_partition_positions(digits, n, partitions, pos, counts, temp, s);
+            materialize();
             launch_gather_flat(perm, 4, pos, n, next, s);
             std::swap(perm, next);
             identity = false;
@@ -172,7 +178,7 @@ public:
             // (rocPRIM 4.0's merge-sort path for small inputs builds its mask of the bit range with 1 << end_bit: a range that ends at
             // bit 64 without starting at bit 0 compares nothing -- such ranges are widened to the whole key)
             if (end_bit == 64) begin_bit = 0;
-            const int path = launch_sort_pairs(in, perm, kp[1], next, n, begin_bit, end_bit, sort_temp, sort_temp_bytes, s);
+            const int path = launch_sort_pairs(in, identity ? nullptr : perm, pos, kp[1], next, n, begin_bit, end_bit, sort_temp, sort_temp_bytes, s);
             timer.set_name(path == PA_SORT_LIBRARY ? "rocprim_radix_sort_pairs" : "pa_sort_buckets");   // (pa_op_kernel_name: which sort the last image took)
             std::swap(perm, next);
             identity = false;
@@ -199,11 +205,13 @@ public:
                 sort_by_image();
             }
             if (nulls) {
+                materialize();
                 launch_sort_null_digits(nulls, perm, n, nulls_first ? 1 : 0, digits, s);
                 pass(2);
                 sorted_images = nullptr;
             }
         }
+        materialize();   // (no sort ran: every image the same)
         timer.end(s);
         // the first sort channel as an output channel: its sorted images ARE the column (integers without NULL rows), no gather
         const int first_channel = sort_channels_[0];

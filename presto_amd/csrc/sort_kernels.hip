@@ -110,31 +110,36 @@ __global__ __launch_bounds__(256) void k_sort_count(const u64* __restrict__ keys
 }
 
 // counts[digit][tile] -> rows of the digit in earlier tiles of the same bucket (exclusive, in place); totals[bucket * nd + digit] = rows of
-// the digit in the bucket.  One workgroup per (digit, bucket), a run of consecutive tiles per thread.  bucket_tile_base == nullptr: one
-// bucket of `tiles` tiles.
+// the digit in the bucket.  One workgroup per (digit, bucket) -- 256 threads for the one bucket of the first pass, one wave for the second
+// pass's buckets of a few dozen tiles -- and a run of consecutive tiles per thread.  bucket_tile_base == nullptr: one bucket of `tiles` tiles.
 __global__ __launch_bounds__(256) void k_sort_scan_tiles(i32* __restrict__ counts, i32 tiles_cap, const i32* __restrict__ bucket_tile_base, i32 tiles, i32 nd,
                                                          i32* __restrict__ totals)
 {
     __shared__ i32 wave_sums[4];
     const i32 d = (i32)blockIdx.x, b = (i32)blockIdx.y;
     const int lane = (int)threadIdx.x & 63, wave = (int)threadIdx.x >> 6;
+    const i32 threads = (i32)blockDim.x;
     const i32 t0 = bucket_tile_base ? bucket_tile_base[b] : 0;
     const i32 t1 = bucket_tile_base ? bucket_tile_base[b + 1] : tiles;
     i32* row = counts + (i64)d * tiles_cap;
-    const i32 per = (t1 - t0 + 255) / 256;
+    const i32 per = (t1 - t0 + threads - 1) / threads;
     const i32 lo = t0 + (i32)threadIdx.x * per < t1 ? t0 + (i32)threadIdx.x * per : t1;
     const i32 hi = lo + per < t1 ? lo + per : t1;
     i32 sum = 0;
     for (i32 t = lo; t < hi; t++) sum += row[t];
     const i32 inc = wave_inclusive_scan(sum, lane);
-    if (lane == 63) wave_sums[wave] = inc;
-    __syncthreads();
-    i32 before = 0, all = 0;
+    i32 before = 0, all = inc;
+    if (threads > 64) {
+        if (lane == 63) wave_sums[wave] = inc;
+        __syncthreads();
+        all = 0;
 #pragma unroll
-    for (int w = 0; w < 4; w++) {
-        if (w < wave) before += wave_sums[w];
-        all += wave_sums[w];
+        for (int w = 0; w < 4; w++) {
+            if (w < wave) before += wave_sums[w];
+            all += wave_sums[w];
+        }
     }
+    else all = __shfl(inc, 63, 64);
     i32 run = before + inc - sum;
     for (i32 t = lo; t < hi; t++) {
         const i32 v = row[t];
@@ -144,20 +149,27 @@ __global__ __launch_bounds__(256) void k_sort_scan_tiles(i32* __restrict__ count
     if (threadIdx.x == 0) totals[(i64)b * nd + d] = all;
 }
 
-// offs[0..m] = exclusive prefix sums of totals[0..m), *max_out = the largest of them.  One workgroup, a run of entries per thread.
-__global__ __launch_bounds__(256) void k_sort_offsets(const i32* __restrict__ totals, i32 m, i32* __restrict__ offs, i32* __restrict__ max_out)
+// offs[0..m] = exclusive prefix sums of totals[0..m), *max_out = the largest of them.  One workgroup of 1024, a run of at most kOffsPer
+// entries per thread (m <= 2^14), held in registers between the two sweeps.
+constexpr int kOffsPer = (1 << kMaxTopBits) / 1024;
+__global__ __launch_bounds__(1024) void k_sort_offsets(const i32* __restrict__ totals, i32 m, i32* __restrict__ offs, i32* __restrict__ max_out)
 {
-    __shared__ i32 wave_sums[4];
-    __shared__ i32 wave_max[4];
+    __shared__ i32 wave_sums[16];
+    __shared__ i32 wave_max[16];
     const int lane = (int)threadIdx.x & 63, wave = (int)threadIdx.x >> 6;
-    const i32 per = (m + 255) / 256;
-    const i32 lo = (i32)threadIdx.x * per < m ? (i32)threadIdx.x * per : m;
-    const i32 hi = lo + per < m ? lo + per : m;
+    const i32 per = (m + 1023) / 1024;
+    const i32 lo = (i32)threadIdx.x * per;
+    i32 vals[kOffsPer];
     i32 sum = 0, mx = 0;
-    for (i32 i = lo; i < hi; i++) {
-        const i32 v = totals[i];
-        sum += v;
-        mx = v > mx ? v : mx;
+#pragma unroll
+    for (int k = 0; k < kOffsPer; k++) {
+        const i32 i = lo + k;
+        vals[k] = (k < per && i < m) ? totals[i] : 0;
+    }
+#pragma unroll
+    for (int k = 0; k < kOffsPer; k++) {
+        sum += vals[k];
+        mx = vals[k] > mx ? vals[k] : mx;
     }
     const i32 inc = wave_inclusive_scan(sum, lane);
 #pragma unroll
@@ -170,20 +182,22 @@ __global__ __launch_bounds__(256) void k_sort_offsets(const i32* __restrict__ to
     __syncthreads();
     i32 before = 0, all = 0;
 #pragma unroll
-    for (int w = 0; w < 4; w++) {
+    for (int w = 0; w < 16; w++) {
         if (w < wave) before += wave_sums[w];
         all += wave_sums[w];
     }
     i32 run = before + inc - sum;
-    for (i32 i = lo; i < hi; i++) {
-        offs[i] = run;
-        run += totals[i];
+#pragma unroll
+    for (int k = 0; k < kOffsPer; k++) {
+        const i32 i = lo + k;
+        if (k < per && i < m) offs[i] = run;
+        run += vals[k];
     }
     if (threadIdx.x == 0) {
         offs[m] = all;
         if (max_out != nullptr) {
             i32 best = wave_max[0];
-            for (int w = 1; w < 4; w++) best = wave_max[w] > best ? wave_max[w] : best;
+            for (int w = 1; w < 16; w++) best = wave_max[w] > best ? wave_max[w] : best;
             *max_out = best;
         }
     }
@@ -255,7 +269,7 @@ __global__ __launch_bounds__(256) void k_sort_partition(const u64* __restrict__ 
         const i32 idx = wave * (kTile / 4) + r * 64 + lane;
         const bool live = idx < rows;
         key[r] = live ? kin[start + idx] : 0ULL;
-        row[r] = live ? rin[start + idx] : 0;
+        row[r] = live ? (rin ? rin[start + idx] : (i32)(start + idx)) : 0;
     }
     __syncthreads();
     // the wave's count of every digit grows round by round: the first lane of a digit's rows in a round adds them and gets the count of
@@ -347,7 +361,7 @@ __global__ __launch_bounds__(256) void k_sort_buckets(const u64* __restrict__ ki
         const i32 idx = wave * chunk + r * 64 + lane;
         const bool live = r < rounds && idx < count;
         key[r] = live ? kin[(i64)start + idx] : 0ULL;
-        row[r] = live ? rin[(i64)start + idx] : 0;
+        row[r] = live ? (rin ? rin[(i64)start + idx] : start + idx) : 0;
     }
     if (threadIdx.x < (1u << kSortBits)) {
 #pragma unroll
@@ -435,6 +449,12 @@ __global__ __launch_bounds__(256) void k_sort_buckets(const u64* __restrict__ ki
     }
 }
 
+__global__ __launch_bounds__(256) void k_sort_iota(i32* __restrict__ rows, i64 n)
+{
+    const i64 i = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) rows[i] = (i32)i;
+}
+
 struct FastLayout {
     size_t keys = 0, rows = 0, counts_a = 0, totals_a = 0, offs_a = 0, bucket_tiles = 0, tile_start = 0, tile_rows = 0, tile_bucket = 0, counts_b = 0, totals_b = 0,
            offs_b = 0, ctl = 0, end = 0;
@@ -477,9 +497,14 @@ size_t library_temp_bytes(int64_t n)
     return bytes;
 }
 
-void library_sort(const uint64_t* keys_in, const int32_t* rows_in, uint64_t* keys_out, int32_t* rows_out, int64_t n, int begin_bit, int end_bit, void* temp,
-                  size_t temp_bytes, hipStream_t s)
+void library_sort(const uint64_t* keys_in, const int32_t* rows_in, int32_t* rows_scratch, uint64_t* keys_out, int32_t* rows_out, int64_t n, int begin_bit,
+                  int end_bit, void* temp, size_t temp_bytes, hipStream_t s)
 {
+    if (rows_in == nullptr) {  // rows 0, 1, 2, ... were implied: the library wants them in memory
+        PA_REQUIRE(rows_scratch != nullptr, PA_ERR_DEVICE, "internal: pair sort without row ids and without room for them");
+        hipLaunchKernelGGL(k_sort_iota, (int)((n + 255) / 256), 256, 0, s, rows_scratch, (i64)n);
+        rows_in = rows_scratch;
+    }
     // the scratch was sized for the whole key (sort_pairs_temp_bytes): rocPRIM does not promise that a narrower bit range needs no more
     // (its merge-sort and one-sweep paths size differently) -- ask for THIS range and refuse to run short
     size_t need = 0;
@@ -504,14 +529,14 @@ size_t sort_pairs_temp_bytes(int64_t n)
     return std::max(library_temp_bytes(n), fast) + 256;
 }
 
-int launch_sort_pairs(const uint64_t* keys_in, const int32_t* rows_in, uint64_t* keys_out, int32_t* rows_out, int64_t n, int begin_bit, int end_bit, void* temp,
-                      size_t temp_bytes, hipStream_t s)
+int launch_sort_pairs(const uint64_t* keys_in, const int32_t* rows_in, int32_t* rows_scratch, uint64_t* keys_out, int32_t* rows_out, int64_t n, int begin_bit,
+                      int end_bit, void* temp, size_t temp_bytes, hipStream_t s)
 {
     if (n <= 0) return PA_SORT_NONE;
     PA_REQUIRE(begin_bit >= 0 && end_bit > begin_bit && end_bit <= 64, PA_ERR_DEVICE, "internal: bit range of a pair sort");
     static const bool library_only = getenv("PRESTO_AMD_SORT_LIBRARY") != nullptr;
     if (library_only || n > kFastMaxRows) {
-        library_sort(keys_in, rows_in, keys_out, rows_out, n, begin_bit, end_bit, temp, temp_bytes, s);
+        library_sort(keys_in, rows_in, rows_scratch, keys_out, rows_out, n, begin_bit, end_bit, temp, temp_bytes, s);
         return PA_SORT_LIBRARY;
     }
     const int width = end_bit - begin_bit;
@@ -562,7 +587,7 @@ int launch_sort_pairs(const uint64_t* keys_in, const int32_t* rows_in, uint64_t*
     const int shift1 = end_bit - bits1, shift2 = end_bit - top;
     hipLaunchKernelGGL(k_sort_count, tiles_a, 256, 0, s, kin, (i64)n, (const i32*)nullptr, (const i32*)nullptr, (const i32*)nullptr, tiles_a, shift1, bits1, counts_a);
     hipLaunchKernelGGL(k_sort_scan_tiles, dim3(nd1, 1), 256, 0, s, counts_a, tiles_a, (const i32*)nullptr, tiles_a, nd1, totals_a);
-    hipLaunchKernelGGL(k_sort_offsets, 1, 256, 0, s, (const i32*)totals_a, nd1, offs_a, &ctl->max_bucket);
+    hipLaunchKernelGGL(k_sort_offsets, 1, 1024, 0, s, (const i32*)totals_a, nd1, offs_a, &ctl->max_bucket);
     if (two) hipLaunchKernelGGL(k_sort_plan_tiles, 1, 256, 0, s, (const i32*)offs_a, nd1, bucket_tiles, tile_start, tile_rows, tile_bucket, &ctl->tiles_b);
     hipLaunchKernelGGL(k_sort_partition, tiles_a, 256, 0, s, kin, rows_in, dst1_k, dst1_r, (i64)n, (const i32*)nullptr, (const i32*)nullptr, (const i32*)nullptr,
                        (const i32*)nullptr, tiles_a, shift1, bits1, (const i32*)counts_a, (const i32*)offs_a);
@@ -572,8 +597,8 @@ int launch_sort_pairs(const uint64_t* keys_in, const int32_t* rows_in, uint64_t*
     if (two) {
         hipLaunchKernelGGL(k_sort_count, cap_b, 256, 0, s, (const u64*)dst1_k, (i64)n, (const i32*)tile_start, (const i32*)tile_rows, (const i32*)&ctl->tiles_b, cap_b, shift2,
                            bits2, counts_b);
-        hipLaunchKernelGGL(k_sort_scan_tiles, dim3(nd2, nd1), 256, 0, s, counts_b, cap_b, (const i32*)bucket_tiles, 0, nd2, totals_b);
-        hipLaunchKernelGGL(k_sort_offsets, 1, 256, 0, s, (const i32*)totals_b, nd1 * nd2, offs_b, &ctl->max_bucket);
+        hipLaunchKernelGGL(k_sort_scan_tiles, dim3(nd2, nd1), 64, 0, s, counts_b, cap_b, (const i32*)bucket_tiles, 0, nd2, totals_b);
+        hipLaunchKernelGGL(k_sort_offsets, 1, 1024, 0, s, (const i32*)totals_b, nd1 * nd2, offs_b, &ctl->max_bucket);
         hipLaunchKernelGGL(k_sort_partition, cap_b, 256, 0, s, (const u64*)dst1_k, (const i32*)dst1_r, dst2_k, dst2_r, (i64)n, (const i32*)tile_start, (const i32*)tile_rows,
                            (const i32*)tile_bucket, (const i32*)&ctl->tiles_b, cap_b, shift2, bits2, (const i32*)counts_b, (const i32*)offs_b);
         final_offs = offs_b;
@@ -585,7 +610,7 @@ int launch_sort_pairs(const uint64_t* keys_in, const int32_t* rows_in, uint64_t*
     i32 max_bucket = 0;
     read_back(&max_bucket, &ctl->max_bucket, 4, s);
     if (max_bucket > kCap) {  // keys crowd in a few bit prefixes: the library's passes over the whole range, from the untouched input
-        library_sort(keys_in, rows_in, keys_out, rows_out, n, begin_bit, end_bit, temp, temp_bytes, s);
+        library_sort(keys_in, rows_in, rows_scratch, keys_out, rows_out, n, begin_bit, end_bit, temp, temp_bytes, s);
         return PA_SORT_LIBRARY;
     }
     int bits_per = 0;
