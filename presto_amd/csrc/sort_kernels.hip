@@ -55,6 +55,15 @@ __device__ __forceinline__ i32 wave_inclusive_scan(i32 v, int lane)
     return v;
 }
 
+// bits [shift, shift + width) of a key as a 32-bit digit (width <= 8).  The shift is the same for every lane: one 32-bit funnel shift
+// instead of a 64-bit shift (quarter rate)
+__device__ __forceinline__ u32 key_digit(u64 key, int shift, u32 mask)
+{
+    const u32 lo = (u32)key, hi = (u32)(key >> 32);
+    const u32 v = shift >= 32 ? hi >> (shift - 32) : __builtin_amdgcn_alignbit(hi, lo, (u32)shift);
+    return v & mask;
+}
+
 // rows of this lane's digit among the live lanes of the wave: `peers` = their lanes, returns how many of them come before this lane.
 // One ballot per bit of the digit; a lane keeps the lanes whose bit equals its own: peers &= ~(ballot ^ s) with s = the lane's bit
 // spread over a word (0 or ~0).
@@ -103,7 +112,7 @@ __global__ __launch_bounds__(256) void k_sort_count(const u64* __restrict__ keys
 #pragma unroll
     for (int i = 0; i < kTile / 256; i++) {
         const i32 idx = i * 256 + (i32)threadIdx.x;
-        if (idx < rows) atomicAdd(&hist[(u32)(keys[start + idx] >> shift) & mask], 1);
+        if (idx < rows) atomicAdd(&hist[key_digit(keys[start + idx], shift, mask)], 1);
     }
     __syncthreads();
     if (threadIdx.x < (1u << bits)) counts[(i64)threadIdx.x * tiles_cap + tile] = hist[threadIdx.x];
@@ -281,7 +290,7 @@ __global__ __launch_bounds__(256) void k_sort_partition(const u64* __restrict__ 
     for (int r = 0; r < kRounds; r++) {
         const i32 idx = wave * (kTile / 4) + r * 64 + lane;
         const bool live = idx < rows;
-        const u32 d = (u32)(key[r] >> shift) & mask;
+        const u32 d = key_digit(key[r], shift, mask);
         u64 peers;
         const int before = wave_digit_peers(d, live, bits, lane, &peers);
         lr[r] = before;
@@ -317,7 +326,7 @@ __global__ __launch_bounds__(256) void k_sort_partition(const u64* __restrict__ 
     for (int r = 0; r < kRounds; r++) {
         const i32 idx = wave * (kTile / 4) + r * 64 + lane;
         if (idx < rows) {
-            const u32 d = (u32)(key[r] >> shift) & mask;
+            const u32 d = key_digit(key[r], shift, mask);
             const i32 p = lstart[d] + cnt[wave][d] + lr[r];
             skey[p] = key[r];
             srow[p] = row[r];
@@ -326,7 +335,7 @@ __global__ __launch_bounds__(256) void k_sort_partition(const u64* __restrict__ 
     __syncthreads();
     for (i32 j = (i32)threadIdx.x; j < rows; j += 256) {
         const u64 k = skey[j];
-        const u32 d = (u32)(k >> shift) & mask;
+        const u32 d = key_digit(k, shift, mask);
         const i64 dest = (i64)goff[d] + (j - lstart[d]);
         kout[dest] = k;
         rout[dest] = srow[j];
@@ -393,7 +402,7 @@ __global__ __launch_bounds__(256) void k_sort_buckets(const u64* __restrict__ ki
             if (r < rounds) {
                 const i32 idx = wave * chunk + r * 64 + lane;
                 const bool live = idx < count;
-                const u32 d = (u32)(key[r] >> lo) & mask;
+                const u32 d = key_digit(key[r], lo, mask);
                 u64 peers;
                 const int before = wave_digit_peers(d, live, bits, lane, &peers);
                 lr[r] = before;
@@ -435,7 +444,7 @@ __global__ __launch_bounds__(256) void k_sort_buckets(const u64* __restrict__ ki
         for (int r = 0; r < kRounds; r++) {
             const i32 idx = wave * chunk + r * 64 + lane;
             if (r < rounds && idx < count) {
-                const u32 d = (u32)(key[r] >> lo) & mask;
+                const u32 d = key_digit(key[r], lo, mask);
                 const i32 at = dstart[d] + c[wave][d] + lr[r];
                 kbuf[at] = key[r];
                 rbuf[at] = row[r];
