@@ -51,18 +51,46 @@ def generated(name):
     return name.startswith("pa_fused_") or name.startswith("pa_fp_") or name.startswith("pa_brow_keys")
 
 
-def counters(directory, counter):
+def counters(directory, counter, per_pass=None):
+    """{kernel name: (average counter value per launch, launches)}.  per_pass: {name: launches of the kernel per pass over the table} --
+    the first (launches mod that) launches of the kernel are left out: the first operator of a plan cuts a 2^20-row probe launch off its
+    first page (op_fused.cpp, the few-groups tier's verdict), a launch the timed passes of the bench line do not have."""
     rows = list(csv.DictReader(open(one(directory, "*counter_collection*.csv"))))
     acc = collections.defaultdict(list)
     for r in rows:
         if r["Counter_Name"] == counter and generated(r["Kernel_Name"]):
-            acc[r["Kernel_Name"]].append(float(r["Counter_Value"]))
-    return {k: (sum(v) / len(v), len(v)) for k, v in acc.items()}
+            acc[r["Kernel_Name"]].append((int(r["Start_Timestamp"]), float(r["Counter_Value"])))
+    out = {}
+    for k, v in acc.items():
+        v.sort()
+        extra = len(v) % per_pass[k] if per_pass and per_pass.get(k) else 0
+        vals = [x for _, x in v[extra:]]
+        out[k] = (sum(vals) / len(vals), len(vals))
+    return out
 
 
-fetch, write = counters(fetch_dir, "FETCH_SIZE"), counters(write_dir, "WRITE_SIZE")
+def trace_durations(directory, per_pass):
+    """{kernel name: (average duration ns, launches)} from the kernel trace, over the same launch population as `counters`"""
+    rows = list(csv.DictReader(open(one(directory, "*_kernel_trace.csv"))))
+    acc = collections.defaultdict(list)
+    for r in rows:
+        if generated(r["Kernel_Name"]):
+            acc[r["Kernel_Name"]].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
+    out = {}
+    for k, v in acc.items():
+        v.sort()
+        extra = len(v) % per_pass[k] if per_pass.get(k) else 0
+        vals = [x for _, x in v[extra:]]
+        out[k] = (sum(vals) / len(vals), len(vals))
+    return out
+
+
 detail = json.load(open(detail_json)) if detail_json and os.path.exists(detail_json) else {}
 roofs = {r["kernel"]: r for r in (detail.get("roofline"), detail.get("roofline_q6")) if r}
+steps = (detail.get("line") or detail).get("steps") or 0
+per_pass = {name: int(round(r["launches"] / steps)) for name, r in roofs.items() if steps}
+fetch, write = counters(fetch_dir, "FETCH_SIZE", per_pass), counters(write_dir, "WRITE_SIZE", per_pass)
+traced = trace_durations(trace_dir, per_pass)
 
 kernels = {}
 for r in stats:
@@ -71,7 +99,8 @@ for r in stats:
         continue
     f, fl = fetch.get(name, (0.0, 0))
     w, wl = write.get(name, (0.0, 0))
-    k = {"launches_traced": r["Calls"], "avg_launch_ms": r["AverageNs"] / 1e6, "fetch_size_kib_raw": f, "fetch_launches": fl,
+    avg_ns, calls = traced.get(name, (r["AverageNs"], r["Calls"]))
+    k = {"launches_traced": calls, "launches_in_stats_file": r["Calls"], "avg_launch_ms": avg_ns / 1e6, "fetch_size_kib_raw": f, "fetch_launches": fl,
          "write_size_kib": w, "write_launches": wl, "hbm_bytes_per_launch": (2.0 * f + w) * 1024.0,
          "correction": "FETCH_SIZE x2 (gfx950 wide streaming reads), WRITE_SIZE x1; KiB -> bytes"}
     if name in roofs:
@@ -103,9 +132,12 @@ with open(os.path.join(out, tag + "_summary.md"), "w") as f:
     for r in stats:
         f.write("| `%s` | %d | %.3f | %.1f | %.2f |\n" % (r["Name"][:70], r["Calls"], r["TotalDurationNs"] / 1e6, r["AverageNs"] / 1e3, r["Percentage"]))
     f.write("\n## generated kernels: roofline from the trace alone\n\n"
-            "`achieved` = algorithmic bytes per launch / average launch duration of the kernel's row in `%s_kernel_stats.csv`; algorithmic bytes per launch = "
-            "rows per launch x bytes per row (SURVEY 8d: Q1 46 B/row, Q6 28 B/row), rows per launch = 600 037 902 rows of SF100 lineitem / launches per "
-            "pass (warm-up passes launch the same pages, so the average over all calls is the average of the timed ones).  `frac` = achieved / 8000 GB/s.\n\n"
+            "`achieved` = algorithmic bytes per launch / average launch duration of the kernel in the kernel trace behind `%s_kernel_stats.csv`; algorithmic "
+            "bytes per launch = rows per launch x bytes per row (SURVEY 8d: Q1 46 B/row, Q6 28 B/row), rows per launch = 600 037 902 rows of SF100 lineitem / "
+            "launches per pass (warm-up passes launch the same pages, so the average over the calls is the average of the timed ones).  A kernel whose call "
+            "count is not a multiple of its launches per pass had probe launches in its first pass (the few-groups tier cuts 2^20 rows off the first page of "
+            "the first operator of a plan): the first (calls mod launches per pass) launches are left out of the averages, durations and counters alike, and "
+            "`calls` below is what remains (the statistics file's own average includes them).  `frac` = achieved / 8000 GB/s.\n\n"
             "| kernel | calls | avg ms (trace) | rows / launch | algorithmic bytes / launch | achieved GB/s | frac | bench line: avg ms | frac | FETCH_SIZE KiB raw | "
             "WRITE_SIZE KiB | HBM bytes / launch (corrected) | traffic / algorithmic |\n|---|---|---|---|---|---|---|---|---|---|---|---|---|\n" % tag)
     for name, k in kernels.items():
