@@ -63,21 +63,119 @@ public:
             cols_[c].varwidth = types_[c] == PA_VARCHAR;
         }
     }
-    ~OrderByOperator() override { (void)hipStreamSynchronize(stream_.get()); }
+    ~OrderByOperator() override
+    {
+        (void)hipStreamSynchronize(stream_.get());
+        for (Held& h : held_) {
+            if (h.release) h.release(h.release_ctx);
+        }
+    }
     hipStream_t private_stream() override { return stream_.owned() ? stream_.get() : nullptr; }
     hipStream_t main_stream() override { return stream_.get(); }
 
     bool needs_input() override { return !finishing_; }
 
+    bool takes_retained() override { return true; }
+
+    // PagesIndex.addPage keeps the Page; so does this for device pages that stay where they are (PA_PAGE_STABLE, PA_PAGE_RETAINED) and
+    // hold only flat fixed-width blocks in the needed channels: they are listed, not copied.  One such page alone is sorted in place; several
+    // are laid behind each other when the input ends (the same copies, later).  Every other page is copied when it arrives -- its
+    // buffers are the caller's again when add_input returns -- after the pages listed before it.
     void add_input(const pa_page* page) override
     {
         PA_REQUIRE(!finishing_, PA_ERR_ILLEGAL_STATE, "Operator is already finishing");
         PA_REQUIRE(page != nullptr && page->channel_count == (int32_t)types_.size(), PA_ERR_INVALID_ARGUMENT, "page does not match the operator's input types");
-        if (page->position_count == 0) return;
+        const bool retained = (page->flags & PA_PAGE_RETAINED) != 0 && page->release != nullptr;
+        if (page->position_count == 0) {
+            if (retained) page->release(page->release_ctx);
+            return;
+        }
+        const int64_t m = page->position_count;
+        if (rows_ + m > INT32_MAX) {
+            if (retained) page->release(page->release_ctx);   // (nothing of it was read)
+            throw Error(PA_ERR_INSUFFICIENT_RESOURCES, "too many rows for one sort");
+        }
+        if (page->mem == PA_MEM_DEVICE && (retained || (page->flags & PA_PAGE_STABLE) != 0) && holdable(page)) {
+            Held h;
+            h.rows = m;
+            h.cols.assign(page->columns, page->columns + page->channel_count);
+            if (retained) {
+                h.release = page->release;
+                h.release_ctx = page->release_ctx;
+            }
+            held_.push_back(std::move(h));
+            rows_ += m;
+            return;
+        }
+        // (a retained page that is copied goes back to its owner when the copies have run -- also when a check below throws)
+        struct ReleaseAtExit {
+            const pa_page* p;
+            bool on;
+            hipStream_t s;
+            ~ReleaseAtExit()
+            {
+                if (!on) return;
+                (void)hipStreamSynchronize(s);
+                p->release(p->release_ctx);
+            }
+        } release_at_exit{page, retained, stream_.get()};
+        flush_held();
         hipStream_t s = stream_.get();
         DevPage dp = stager_.stage(page, &needed_, s);
+        append(dp);
+        PA_HIP(hipStreamSynchronize(s));  // the stager's buffers are reused by the next page
+    }
+
+    bool holdable(const pa_page* page) const
+    {
+        for (size_t c = 0; c < types_.size(); c++) {
+            if (!needed_[c]) continue;
+            const pa_column& in = page->columns[c];
+            if (in.encoding != PA_FLAT || in.type != types_[c] || in.values == nullptr || type_width(in.type) <= 0) return false;
+        }
+        return true;
+    }
+
+    // the listed pages behind the rows copied so far, in arrival order; their owners get them back
+    void flush_held()
+    {
+        if (held_.empty()) return;
+        hipStream_t s = stream_.get();
+        const int64_t total = rows_;
+        int64_t listed = 0;
+        for (const Held& h : held_) listed += h.rows;
+        rows_ = total - listed;   // (append counts them again)
+        std::vector<Held> held;
+        held.swap(held_);
+        struct ReleaseAll {
+            std::vector<Held>& held;
+            hipStream_t s;
+            ~ReleaseAll()
+            {
+                (void)hipStreamSynchronize(s);
+                for (Held& h : held) {
+                    if (h.release) h.release(h.release_ctx);
+                }
+            }
+        } release_all{held, s};
+        for (const Held& h : held) {
+            DevPage dp;
+            dp.n = (int32_t)h.rows;
+            dp.cols.resize(types_.size());
+            for (size_t c = 0; c < types_.size(); c++) {
+                dp.cols[c].type = types_[c];
+                if (!needed_[c]) continue;
+                dp.cols[c].values = h.cols[c].values;
+                dp.cols[c].nulls = h.cols[c].nulls;
+            }
+            append(dp);
+        }
+    }
+
+    void append(const DevPage& dp)
+    {
+        hipStream_t s = stream_.get();
         const int64_t m = dp.n;
-        PA_REQUIRE(rows_ + m <= INT32_MAX, PA_ERR_INSUFFICIENT_RESOURCES, "too many rows for one sort");
         for (size_t c = 0; c < types_.size(); c++) {
             if (!needed_[c]) continue;
             const DevColumn& in = dp.cols[c];
@@ -109,7 +207,6 @@ public:
                 a.has_nulls = true;
             }
         }
-        PA_HIP(hipStreamSynchronize(s));  // the stager's buffers are reused by the next page
         rows_ += m;
     }
 
@@ -122,6 +219,19 @@ public:
         output_done_ = true;
         if (rows_ == 0) return false;
         hipStream_t s = stream_.get();
+        if (held_.size() == 1 && held_[0].rows == rows_) {
+            // the one page of the input, still where its owner put it: its block arrays ARE the columns (released when the operator goes)
+            for (size_t c = 0; c < types_.size(); c++) {
+                if (!needed_[c]) continue;
+                const pa_column& in = held_[0].cols[c];
+                cols_[c].values.borrow(in.values, (size_t)rows_ * type_width(types_[c]));
+                if (in.nulls) {
+                    cols_[c].nulls.borrow(in.nulls, (size_t)rows_);
+                    cols_[c].has_nulls = true;
+                }
+            }
+        }
+        else flush_held();
         const int64_t n = rows_;
         int32_t* perm = static_cast<int32_t*>(perm_[0].ensure((size_t)n * 4));
         int32_t* next = static_cast<int32_t*>(perm_[1].ensure((size_t)n * 4));
@@ -293,6 +403,14 @@ private:
     std::vector<int> output_channels_, sort_channels_;
     std::vector<bool> needed_;
     std::vector<Accumulated> cols_;
+    // device pages listed instead of copied (add_input)
+    struct Held {
+        int64_t rows = 0;
+        std::vector<pa_column> cols;
+        void (*release)(void*) = nullptr;
+        void* release_ctx = nullptr;
+    };
+    std::vector<Held> held_;
     int64_t rows_ = 0;
     int32_t output_mem_ = PA_MEM_HOST;
     bool finishing_ = false, output_done_ = false;

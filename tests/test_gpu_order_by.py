@@ -118,3 +118,46 @@ def test_sorts_beyond_a_million_rows(gpu, kind):
         perm = np.argsort(values if order == abi.ASC_NULLS_LAST else ~values, kind="stable")
         assert np.array_equal(got_rows, perm)
         assert np.array_equal(got_keys, values[perm])
+
+
+@pytest.mark.parametrize("mix", ["one stable", "one retained", "several retained", "retained then host then stable", "retained with a VARCHAR channel"])
+def test_device_pages_that_stay_are_kept_not_copied(gpu, oracle, mix):
+    """PagesIndex.addPage keeps the Page (PagesIndex.java:150-170).  Device pages flagged PA_PAGE_STABLE / PA_PAGE_RETAINED with flat
+    fixed-width blocks are listed by the operator instead of copied: one alone is sorted where it lies, several are laid behind each other
+    when the input ends, a plain page in between forces the listed ones to be copied first (arrival order).  Retained pages are released
+    exactly once, never before their last read (the release overwrites the buffers), at close at the latest."""
+    from tests.test_gpu_small_pages import retained_pages
+    rng = np.random.default_rng(len(mix))
+    n = 50_000
+    nulls = rng.random(n) < 0.05
+    blocks = [Block.bigint(rng.integers(-1000, 1000, n)), Block.flat(abi.DOUBLE, rng.standard_normal(n), nulls), Block.integer(np.arange(n, dtype=np.int32))]
+    types = [abi.BIGINT, abi.DOUBLE, abi.INTEGER]
+    if mix == "retained with a VARCHAR channel":
+        blocks.append(Block.varchar([b"k%d" % (i % 7) for i in range(n)]))
+        types.append(abi.VARCHAR)
+    host = Page(blocks, n)
+    released = []
+    if mix == "one stable":
+        dev = upload_page(host)
+        pages = [Page(dev.blocks, n, abi.MEM_DEVICE, stable=True)]
+        keep = dev
+    elif mix in ("one retained", "retained with a VARCHAR channel"):
+        pages = retained_pages(host, [0, n], released)
+    elif mix == "several retained":
+        pages = retained_pages(host, [0, 7, 20_000, 20_001, n], released)
+    else:
+        first = retained_pages(host.get_region(0, 10_000), [0, 10_000], released)
+        dev = upload_page(host.get_region(30_000, n - 30_000))
+        pages = [first[0], host.get_region(10_000, 20_000), Page(dev.blocks, n - 30_000, abi.MEM_DEVICE, stable=True)]
+        keep = dev
+    outs = list(range(len(types)))
+    op = OrderByOperator(types, outs, [0, 1], [abi.DESC_NULLS_LAST, abi.ASC_NULLS_FIRST])
+    got = [row for p in to_pages(op, pages) for row in p.to_rows()]
+    want = oracle.order_by([host], outs, [0, 1], [abi.DESC_NULLS_LAST, abi.ASC_NULLS_FIRST])
+    op.close()
+
+    def norm(rows):
+        return [tuple(repr(v) if isinstance(v, float) else v for v in r) for r in rows]
+    assert norm(got) == norm(want)
+    handed = sum(1 for p in pages if getattr(p, "on_release", None) is not None)
+    assert sorted(released) == sorted(set(released)) and len(released) == handed, (released, handed)
