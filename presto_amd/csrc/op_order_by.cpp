@@ -267,13 +267,14 @@ public:
         uint64_t* or_and = static_cast<uint64_t*>(or_and_.ensure(key_or_and_bytes()));
         std::vector<uint64_t> h_or_and(key_or_and_bytes() / 8);
         const uint64_t* sorted_images = nullptr;  // the images of the channel sorted by last, in their sorted order (valid until perm changes again)
-        auto sort_by_image = [&]() {
+        // pairs: OR / AND of the images already in or_and (the image kernel left them there), 0 = still to be computed
+        auto sort_by_image = [&](int pairs) {
             const uint64_t* in = keys;
             if (!identity) {
                 launch_gather_flat(keys, 8, perm, n, kp[0], s);
                 in = kp[0];
             }
-            const int blocks = launch_key_or_and(in, n, or_and, s);
+            const int blocks = pairs > 0 ? pairs : launch_key_or_and(in, n, or_and, s);
             read_back(h_or_and.data(), or_and, (size_t)blocks * 16, s);
             uint64_t h[2] = {0ULL, ~0ULL};
             for (int b = 0; b < blocks; b++) {
@@ -305,14 +306,14 @@ public:
                 const int chunks = (max_len + 7) / 8;
                 for (int chunk = chunks; chunk >= 0; chunk--) {
                     launch_varchar_chunk_keys(a.values.ptr(), a.offsets.as<int32_t>(), nulls, n, chunk == chunks ? -1 : chunk, descending ? 1 : 0, keys, s);
-                    sort_by_image();
+                    sort_by_image(0);
                 }
             }
             else {
                 // value image; NULL rows get one constant image (they keep arrival order among themselves) and their place
                 // relative to the values is decided by the separate NULL digit below
-                launch_topn_keys(a.type, a.values.ptr(), nullptr, nulls, n, descending ? PA_DESC_NULLS_LAST : PA_ASC_NULLS_LAST, keys, s);
-                sort_by_image();
+                const int pairs = launch_topn_keys_or_and(a.type, a.values.ptr(), nullptr, nulls, n, descending ? PA_DESC_NULLS_LAST : PA_ASC_NULLS_LAST, keys, or_and, s);
+                sort_by_image(pairs);
             }
             if (nulls) {
                 materialize();

@@ -69,6 +69,36 @@ __global__ __launch_bounds__(256) void k_topn_keys(i32 type, const void* __restr
     for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < n; i += (i64)gridDim.x * 256) keys[i] = row_key(type, values, offsets, nulls, i, sort_order);
 }
 
+// the same, and OR / AND of the keys per workgroup (out[2 b], out[2 b + 1]; at most kKeysOrAndBlocks workgroups): OrderBy sorts by the
+// bits in which the images differ, and finds them out without another pass over the images
+constexpr int kKeysOrAndBlocks = 1024;
+__global__ __launch_bounds__(256) void k_topn_keys_or_and(i32 type, const void* __restrict__ values, const i32* __restrict__ offsets,
+                                                          const u8* __restrict__ nulls, i64 n, i32 sort_order, u64* __restrict__ keys, u64* __restrict__ out)
+{
+    __shared__ u64 s_o[4], s_a[4];
+    u64 o = 0ULL, a = ~0ULL;
+    for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < n; i += (i64)gridDim.x * 256) {
+        const u64 k = row_key(type, values, offsets, nulls, i, sort_order);
+        keys[i] = k;
+        o |= k;
+        a &= k;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        o |= (u64)__shfl_xor((long long)o, d, 64);
+        a &= (u64)__shfl_xor((long long)a, d, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        s_o[threadIdx.x >> 6] = o;
+        s_a[threadIdx.x >> 6] = a;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        out[2 * blockIdx.x] = s_o[0] | s_o[1] | s_o[2] | s_o[3];
+        out[2 * blockIdx.x + 1] = s_a[0] & s_a[1] & s_a[2] & s_a[3];
+    }
+}
+
 // keys of every stride-th row (the sample the bound of a page is drawn from)
 __global__ __launch_bounds__(256) void k_topn_sample_keys(i32 type, const void* __restrict__ values, const i32* __restrict__ offsets,
                                                           const u8* __restrict__ nulls, i64 stride, i64 count, i32 sort_order, u64* __restrict__ keys)
@@ -406,6 +436,16 @@ void launch_topn_keys(int32_t type, const void* values, const int32_t* offsets, 
     if (n <= 0) return;
     hipLaunchKernelGGL(k_topn_keys, grid_of(n), 256, 0, s, type, values, (const i32*)offsets, (const u8*)nulls, (i64)n, sort_order, (u64*)keys);
     PA_HIP(hipGetLastError());
+}
+
+int launch_topn_keys_or_and(int32_t type, const void* values, const int32_t* offsets, const uint8_t* nulls, int64_t n, int32_t sort_order, uint64_t* keys,
+                            uint64_t* or_and, hipStream_t s)
+{
+    if (n <= 0) return 0;
+    const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((n + 255) / 256, kKeysOrAndBlocks));
+    hipLaunchKernelGGL(k_topn_keys_or_and, blocks, 256, 0, s, type, values, (const i32*)offsets, (const u8*)nulls, (i64)n, sort_order, (u64*)keys, (u64*)or_and);
+    PA_HIP(hipGetLastError());
+    return blocks;
 }
 
 // the values back from their keys (BIGINT / INTEGER / DATE channels without NULL rows: the image is the value with its sign bit flipped,

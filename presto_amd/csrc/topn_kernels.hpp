@@ -9,6 +9,9 @@ namespace pa {
 // key(a) <= key(b) (monotone, not injective: VARCHAR uses its first 8 bytes, NULLs share the extreme value of their side).
 void launch_topn_keys(int32_t type, const void* values, const int32_t* offsets, const uint8_t* nulls, int64_t n, int32_t sort_order,
                       uint64_t* keys, hipStream_t s);
+// ... and OR / AND of the keys, one pair per workgroup in or_and (key_or_and_bytes() bytes); returns the number of pairs
+int launch_topn_keys_or_and(int32_t type, const void* values, const int32_t* offsets, const uint8_t* nulls, int64_t n, int32_t sort_order, uint64_t* keys,
+                            uint64_t* or_and, hipStream_t s);
 // BIGINT / INTEGER / DATE values back from keys made without NULL rows (an OrderBy whose first sort channel is also an output channel
 // writes that column from the sorted keys: a sequential pass instead of a gather)
 void launch_topn_values_of_keys(int32_t type, const uint64_t* keys, int64_t n, bool descending, void* values, hipStream_t s);
