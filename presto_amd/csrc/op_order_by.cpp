@@ -262,13 +262,38 @@ public:
         // it (a random 8-byte read per row and pass: 2^24 rows by a BIGINT key 6.5 ms), the second regrouped the pairs in eight LDS-staged
         // 8-bit passes of its own (count, scan, scatter: 2.3 ms).
         uint64_t* kp[2] = {static_cast<uint64_t*>(pair_keys_[0].ensure((size_t)n * 8)), static_cast<uint64_t*>(pair_keys_[1].ensure((size_t)n * 8))};
-        const size_t sort_temp_bytes = sort_pairs_temp_bytes(n);
+        // Output channels that can ride along with the pairs of the LAST sort (the first sort channel's) instead of being gathered by the
+        // sorted row ids afterwards: flat 4- / 8-byte channels without NULL rows, when that sort starts from the identity permutation (one
+        // sort channel, or the channels behind it all constant) and no NULL digit follows it.  payload_of[j] = its slot, or -1.
+        const std::vector<int>& outs = output_channels_;
+        std::vector<int> payload_of(outs.size(), -1);
+        SortPayload payload;
+        memset(&payload, 0, sizeof payload);
+        {
+            const Accumulated& f = cols_[(size_t)sort_channels_[0]];
+            const bool images_serve = !f.varwidth && !f.has_nulls && (f.type == PA_BIGINT || f.type == PA_INTEGER || f.type == PA_DATE);
+            if (!f.varwidth && !f.has_nulls && !getenv("PRESTO_AMD_SORT_NO_PAYLOAD")) {
+                for (size_t j = 0; j < outs.size() && payload.count < PA_SORT_MAX_PAYLOAD; j++) {
+                    const Accumulated& a = cols_[(size_t)outs[j]];
+                    const int w = a.varwidth ? 0 : type_width(a.type);
+                    if (a.has_nulls || (w != 4 && w != 8)) continue;
+                    if (outs[j] == sort_channels_[0] && images_serve) continue;   // (written from the sorted images)
+                    payload_of[j] = payload.count;
+                    payload.in[payload.count] = a.values.ptr();
+                    payload.out[payload.count] = payload_out_[payload.count].ensure((size_t)n * w);
+                    payload.width[payload.count] = w;
+                    payload.count++;
+                }
+            }
+        }
+        bool payload_moved = false;
+        const size_t sort_temp_bytes = sort_pairs_temp_bytes(n, payload.count);
         void* sort_temp = radix_temp_.ensure(sort_temp_bytes);
         uint64_t* or_and = static_cast<uint64_t*>(or_and_.ensure(key_or_and_bytes()));
         std::vector<uint64_t> h_or_and(key_or_and_bytes() / 8);
         const uint64_t* sorted_images = nullptr;  // the images of the channel sorted by last, in their sorted order (valid until perm changes again)
         // pairs: OR / AND of the images already in or_and (the image kernel left them there), 0 = still to be computed
-        auto sort_by_image = [&](int pairs) {
+        auto sort_by_image = [&](int pairs, bool last) {
             const uint64_t* in = keys;
             if (!identity) {
                 launch_gather_flat(keys, 8, perm, n, kp[0], s);
@@ -289,7 +314,10 @@ public:
             // (rocPRIM 4.0's merge-sort path for small inputs builds its mask of the bit range with 1 << end_bit: a range that ends at
             // bit 64 without starting at bit 0 compares nothing -- such ranges are widened to the whole key)
             if (end_bit == 64) begin_bit = 0;
-            const int path = launch_sort_pairs(in, identity ? nullptr : perm, pos, kp[1], next, n, begin_bit, end_bit, sort_temp, sort_temp_bytes, s);
+            const bool carry = last && identity && payload.count > 0;
+            const int path = launch_sort_pairs(in, identity ? nullptr : perm, pos, kp[1], next, n, begin_bit, end_bit, sort_temp, sort_temp_bytes, s,
+                                               carry ? &payload : nullptr);
+            payload_moved = carry && path == PA_SORT_BUCKETS;
             timer.set_name(path == PA_SORT_LIBRARY ? "rocprim_radix_sort_pairs" : "pa_sort_buckets");   // (pa_op_kernel_name: which sort the last image took)
             std::swap(perm, next);
             identity = false;
@@ -306,14 +334,14 @@ public:
                 const int chunks = (max_len + 7) / 8;
                 for (int chunk = chunks; chunk >= 0; chunk--) {
                     launch_varchar_chunk_keys(a.values.ptr(), a.offsets.as<int32_t>(), nulls, n, chunk == chunks ? -1 : chunk, descending ? 1 : 0, keys, s);
-                    sort_by_image(0);
+                    sort_by_image(0, false);
                 }
             }
             else {
                 // value image; NULL rows get one constant image (they keep arrival order among themselves) and their place
                 // relative to the values is decided by the separate NULL digit below
                 const int pairs = launch_topn_keys_or_and(a.type, a.values.ptr(), nullptr, nulls, n, descending ? PA_DESC_NULLS_LAST : PA_ASC_NULLS_LAST, keys, or_and, s);
-                sort_by_image(pairs);
+                sort_by_image(pairs, i == 0 && nulls == nullptr);
             }
             if (nulls) {
                 materialize();
@@ -332,7 +360,6 @@ public:
             if (f.varwidth || f.has_nulls || !(f.type == PA_BIGINT || f.type == PA_INTEGER || f.type == PA_DATE)) sorted_images = nullptr;
         }
         // output channels in sorted order (PagesIndex.appendTo)
-        const std::vector<int>& outs = output_channels_;
         out_cols_.clear();
         out_cols_.resize(outs.size());
         // the fixed-width channels (and every NULL flag array) are gathered through the permutation by ONE launch: the permutation is
@@ -366,6 +393,9 @@ public:
                 PA_HIP(hipStreamSynchronize(s));
                 launch_varwidth_copy(perm, n, a.offsets.as<int32_t>(), a.values.as<uint8_t>(), nulls, lens,
                                      static_cast<uint8_t*>(oc.values.ensure((size_t)(h_total > 0 ? h_total : 1))), total, s);
+            }
+            else if (payload_moved && payload_of[j] >= 0) {
+                oc.values = std::move(payload_out_[payload_of[j]]);   // the sort brought the channel along
             }
             else if (sorted_images != nullptr && outs[j] == first_channel) {
                 launch_topn_values_of_keys(a.type, sorted_images, n, first_descending, oc.values.ensure((size_t)n * type_width(a.type)), s);
@@ -415,6 +445,7 @@ private:
     int64_t rows_ = 0;
     int32_t output_mem_ = PA_MEM_HOST;
     bool finishing_ = false, output_done_ = false;
+    DevBuf payload_out_[PA_SORT_MAX_PAYLOAD];
     DevBuf perm_[2], digits_, pos_, counts_, keys_, part_temp_, scan_temp_, pair_keys_[2], radix_temp_, or_and_;
     std::vector<OutColumn> out_cols_;
     std::vector<pa_column> out_storage_;

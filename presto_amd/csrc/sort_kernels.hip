@@ -39,6 +39,14 @@ constexpr int kSortBits = 7;      // digit of an LDS pass
 constexpr int kMaxTopBits = 2 * kPartBits;
 constexpr i64 kFastMaxRows = 27000000;   // 2^14 buckets of <= 1650 pairs on average: six sigma of a uniform spread stay under kCap
 
+// columns that ride along with the pairs (OrderBy's output channels): moved by every pass to the rows their pairs go to
+struct PayloadDev {
+    const void* in[PA_SORT_MAX_PAYLOAD];
+    void* out[PA_SORT_MAX_PAYLOAD];
+    int width[PA_SORT_MAX_PAYLOAD];   // 4 or 8 bytes
+    int n;
+};
+
 struct SortCtl {
     i32 max_bucket;   // largest final bucket
     i32 tiles_b;      // tiles of the second partition pass
@@ -250,7 +258,7 @@ __global__ __launch_bounds__(256) void k_sort_plan_tiles(const i32* __restrict__
 __global__ __launch_bounds__(256) void k_sort_partition(const u64* __restrict__ kin, const i32* __restrict__ rin, u64* __restrict__ kout, i32* __restrict__ rout, i64 n,
                                                         const i32* __restrict__ tile_start, const i32* __restrict__ tile_rows, const i32* __restrict__ tile_bucket,
                                                         const i32* __restrict__ ntiles_dev, i32 tiles_cap, int shift, int bits, const i32* __restrict__ offs,
-                                                        const i32* __restrict__ base)
+                                                        const i32* __restrict__ base, PayloadDev pl)
 {
     constexpr int kRounds = kTile / 256;
     __shared__ u64 skey[kTile];
@@ -328,17 +336,57 @@ __global__ __launch_bounds__(256) void k_sort_partition(const u64* __restrict__ 
         if (idx < rows) {
             const u32 d = key_digit(key[r], shift, mask);
             const i32 p = lstart[d] + cnt[wave][d] + lr[r];
+            lr[r] = p;   // (the row's place in the staged tile: the payload columns go the same way)
             skey[p] = key[r];
             srow[p] = row[r];
         }
     }
     __syncthreads();
-    for (i32 j = (i32)threadIdx.x; j < rows; j += 256) {
-        const u64 k = skey[j];
-        const u32 d = key_digit(k, shift, mask);
-        const i64 dest = (i64)goff[d] + (j - lstart[d]);
-        kout[dest] = k;
-        rout[dest] = srow[j];
+    i32 dest[kRounds];   // where staged row threadIdx.x + 256 i goes
+#pragma unroll
+    for (int i = 0; i < kRounds; i++) {
+        const i32 j = (i32)threadIdx.x + 256 * i;
+        dest[i] = 0;
+        if (j < rows) {
+            const u64 k = skey[j];
+            const u32 d = key_digit(k, shift, mask);
+            dest[i] = goff[d] + (j - lstart[d]);
+            kout[dest[i]] = k;
+            rout[dest[i]] = srow[j];
+        }
+    }
+    for (int c = 0; c < pl.n; c++) {
+        __syncthreads();   // the staged keys / rows (or the column before) have been written out
+        if (pl.width[c] == 8) {
+            const u64* pin = static_cast<const u64*>(pl.in[c]);
+            u64* pout = static_cast<u64*>(pl.out[c]);
+#pragma unroll
+            for (int r = 0; r < kRounds; r++) {
+                const i32 idx = wave * (kTile / 4) + r * 64 + lane;
+                if (idx < rows) skey[lr[r]] = pin[start + idx];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < kRounds; i++) {
+                const i32 j = (i32)threadIdx.x + 256 * i;
+                if (j < rows) pout[dest[i]] = skey[j];
+            }
+        }
+        else {
+            const u32* pin = static_cast<const u32*>(pl.in[c]);
+            u32* pout = static_cast<u32*>(pl.out[c]);
+#pragma unroll
+            for (int r = 0; r < kRounds; r++) {
+                const i32 idx = wave * (kTile / 4) + r * 64 + lane;
+                if (idx < rows) srow[lr[r]] = (i32)pin[start + idx];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < kRounds; i++) {
+                const i32 j = (i32)threadIdx.x + 256 * i;
+                if (j < rows) pout[dest[i]] = (u32)srow[j];
+            }
+        }
     }
 }
 
@@ -349,7 +397,7 @@ __global__ __launch_bounds__(256) void k_sort_partition(const u64* __restrict__ 
 // their places IN the one LDS copy -- every row sits in a register of its thread between the barrier that ends the reads and the writes.
 // The first pass takes its rows from HBM directly.  26.5 KB of LDS: six workgroups per CU.
 __global__ __launch_bounds__(256) void k_sort_buckets(const u64* __restrict__ kin, const i32* __restrict__ rin, u64* __restrict__ kout, i32* __restrict__ rout,
-                                                      const i32* __restrict__ offs, i32 n_single, int begin_bit, int rest_bits, int passes, int bits_per)
+                                                      const i32* __restrict__ offs, i32 n_single, int begin_bit, int rest_bits, int passes, int bits_per, PayloadDev pl)
 {
     constexpr int kRounds = kCap / 256;
     __shared__ u64 kbuf[kCap];
@@ -370,7 +418,7 @@ __global__ __launch_bounds__(256) void k_sort_buckets(const u64* __restrict__ ki
         const i32 idx = wave * chunk + r * 64 + lane;
         const bool live = r < rounds && idx < count;
         key[r] = live ? kin[(i64)start + idx] : 0ULL;
-        row[r] = live ? (rin ? rin[(i64)start + idx] : start + idx) : 0;
+        row[r] = idx;   // where the pair lies in the input bucket: its row id and its payload are fetched from there at the end
     }
     if (threadIdx.x < (1u << kSortBits)) {
 #pragma unroll
@@ -452,9 +500,15 @@ __global__ __launch_bounds__(256) void k_sort_buckets(const u64* __restrict__ ki
         }
     }
     __syncthreads();
+    // the sorted keys from LDS; row ids and payload columns from the input bucket (a window of <= 2048 rows that was just read)
     for (i32 j = (i32)threadIdx.x; j < count; j += 256) {
+        const i32 from = rbuf[j];
         kout[(i64)start + j] = kbuf[j];
-        rout[(i64)start + j] = rbuf[j];
+        rout[(i64)start + j] = rin ? rin[(i64)start + from] : start + from;
+        for (int c = 0; c < pl.n; c++) {
+            if (pl.width[c] == 8) static_cast<u64*>(pl.out[c])[(i64)start + j] = static_cast<const u64*>(pl.in[c])[(i64)start + from];
+            else static_cast<u32*>(pl.out[c])[(i64)start + j] = static_cast<const u32*>(pl.in[c])[(i64)start + from];
+        }
     }
 }
 
@@ -465,12 +519,13 @@ __global__ __launch_bounds__(256) void k_sort_iota(i32* __restrict__ rows, i64 n
 }
 
 struct FastLayout {
+    size_t payload = 0;   // scratch copies of the payload columns, 8 n bytes each, behind each other
     size_t keys = 0, rows = 0, counts_a = 0, totals_a = 0, offs_a = 0, bucket_tiles = 0, tile_start = 0, tile_rows = 0, tile_bucket = 0, counts_b = 0, totals_b = 0,
            offs_b = 0, ctl = 0, end = 0;
     i64 tiles_a = 0, tiles_cap_b = 0;
 };
 
-FastLayout fast_layout(int64_t n)
+FastLayout fast_layout(int64_t n, int payload_columns)
 {
     FastLayout l;
     l.tiles_a = (n + kTile - 1) / kTile;
@@ -494,6 +549,8 @@ FastLayout fast_layout(int64_t n)
     l.totals_b = take((size_t)(1 << kMaxTopBits) * 4);
     l.offs_b = take((size_t)((1 << kMaxTopBits) + 1) * 4);
     l.ctl = take(sizeof(SortCtl));
+    l.payload = at;
+    for (int c = 0; c < payload_columns; c++) take((size_t)n * 8);
     l.end = at;
     return l;
 }
@@ -531,16 +588,32 @@ int ceil_log2(int64_t v)
 
 }  // namespace
 
-size_t sort_pairs_temp_bytes(int64_t n)
+size_t sort_pairs_temp_bytes(int64_t n, int payload_columns)
 {
     n = std::max<int64_t>(n, 1);
-    const size_t fast = n <= kFastMaxRows ? fast_layout(n).end : 0;
+    const size_t fast = n <= kFastMaxRows ? fast_layout(n, payload_columns).end : 0;
     return std::max(library_temp_bytes(n), fast) + 256;
 }
 
 int launch_sort_pairs(const uint64_t* keys_in, const int32_t* rows_in, int32_t* rows_scratch, uint64_t* keys_out, int32_t* rows_out, int64_t n, int begin_bit,
-                      int end_bit, void* temp, size_t temp_bytes, hipStream_t s)
+                      int end_bit, void* temp, size_t temp_bytes, hipStream_t s, const SortPayload* payload)
 {
+    const int pcols = payload ? payload->count : 0;
+    PA_REQUIRE(pcols >= 0 && pcols <= PA_SORT_MAX_PAYLOAD, PA_ERR_DEVICE, "internal: payload columns of a pair sort");
+    for (int c = 0; c < pcols; c++) PA_REQUIRE(payload->width[c] == 4 || payload->width[c] == 8, PA_ERR_DEVICE, "internal: payload width of a pair sort");
+    // the payload columns of one pass: from the caller's arrays / the output / the scratch copies to the next of them
+    auto stage = [&](int from, int to) {   // 0 = the caller's input, 1 = the caller's output, 2 = scratch
+        PayloadDev d;
+        memset(&d, 0, sizeof d);
+        d.n = pcols;
+        for (int c = 0; c < pcols; c++) {
+            char* scratch = static_cast<char*>(temp) + fast_layout(n, pcols).payload + (size_t)c * (((size_t)n * 8 + 255) & ~(size_t)255);
+            d.in[c] = from == 0 ? payload->in[c] : (from == 1 ? payload->out[c] : scratch);
+            d.out[c] = to == 1 ? payload->out[c] : scratch;
+            d.width[c] = payload->width[c];
+        }
+        return d;
+    };
     if (n <= 0) return PA_SORT_NONE;
     PA_REQUIRE(begin_bit >= 0 && end_bit > begin_bit && end_bit <= 64, PA_ERR_DEVICE, "internal: bit range of a pair sort");
     static const bool library_only = getenv("PRESTO_AMD_SORT_LIBRARY") != nullptr;
@@ -559,11 +632,11 @@ int launch_sort_pairs(const uint64_t* keys_in, const int32_t* rows_in, int32_t* 
     if (n <= kCap) {  // one bucket: the LDS sort alone
         int bits_per = 0;
         const int passes = lds_passes(width, &bits_per);
-        hipLaunchKernelGGL(k_sort_buckets, 1, 256, 0, s, kin, rows_in, kout, rows_out, (const i32*)nullptr, (i32)n, begin_bit, width, passes, bits_per);
+        hipLaunchKernelGGL(k_sort_buckets, 1, 256, 0, s, kin, rows_in, kout, rows_out, (const i32*)nullptr, (i32)n, begin_bit, width, passes, bits_per, stage(0, 1));
         PA_HIP(hipGetLastError());
         return PA_SORT_BUCKETS;
     }
-    const FastLayout l = fast_layout(n);
+    const FastLayout l = fast_layout(n, pcols);
     PA_REQUIRE(l.end <= temp_bytes, PA_ERR_DEVICE, "internal: pair sort scratch smaller than the partition passes need");
     char* t = static_cast<char*>(temp);
     u64* tkeys = reinterpret_cast<u64*>(t + l.keys);
@@ -598,8 +671,9 @@ int launch_sort_pairs(const uint64_t* keys_in, const int32_t* rows_in, int32_t* 
     hipLaunchKernelGGL(k_sort_scan_tiles, dim3(nd1, 1), 256, 0, s, counts_a, tiles_a, (const i32*)nullptr, tiles_a, nd1, totals_a);
     hipLaunchKernelGGL(k_sort_offsets, 1, 1024, 0, s, (const i32*)totals_a, nd1, offs_a, &ctl->max_bucket);
     if (two) hipLaunchKernelGGL(k_sort_plan_tiles, 1, 256, 0, s, (const i32*)offs_a, nd1, bucket_tiles, tile_start, tile_rows, tile_bucket, &ctl->tiles_b);
+    const int place1 = (moves % 2) ? 1 : 2, place2 = (moves % 2) ? 2 : 1;   // where the first / second pass leave their rows (as dst1 / dst2)
     hipLaunchKernelGGL(k_sort_partition, tiles_a, 256, 0, s, kin, rows_in, dst1_k, dst1_r, (i64)n, (const i32*)nullptr, (const i32*)nullptr, (const i32*)nullptr,
-                       (const i32*)nullptr, tiles_a, shift1, bits1, (const i32*)counts_a, (const i32*)offs_a);
+                       (const i32*)nullptr, tiles_a, shift1, bits1, (const i32*)counts_a, (const i32*)offs_a, stage(0, place1));
     const i32* final_offs = offs_a;
     const u64* last_k = dst1_k;
     const i32* last_r = dst1_r;
@@ -609,11 +683,12 @@ int launch_sort_pairs(const uint64_t* keys_in, const int32_t* rows_in, int32_t* 
         hipLaunchKernelGGL(k_sort_scan_tiles, dim3(nd2, nd1), 64, 0, s, counts_b, cap_b, (const i32*)bucket_tiles, 0, nd2, totals_b);
         hipLaunchKernelGGL(k_sort_offsets, 1, 1024, 0, s, (const i32*)totals_b, nd1 * nd2, offs_b, &ctl->max_bucket);
         hipLaunchKernelGGL(k_sort_partition, cap_b, 256, 0, s, (const u64*)dst1_k, (const i32*)dst1_r, dst2_k, dst2_r, (i64)n, (const i32*)tile_start, (const i32*)tile_rows,
-                           (const i32*)tile_bucket, (const i32*)&ctl->tiles_b, cap_b, shift2, bits2, (const i32*)counts_b, (const i32*)offs_b);
+                           (const i32*)tile_bucket, (const i32*)&ctl->tiles_b, cap_b, shift2, bits2, (const i32*)counts_b, (const i32*)offs_b, stage(place1, place2));
         final_offs = offs_b;
         last_k = dst2_k;
         last_r = dst2_r;
     }
+    const int last_place = two ? place2 : place1;
     PA_HIP(hipGetLastError());
     if (!sorting) return PA_SORT_BUCKETS;   // the range had no more bits than the partition passes took: done, nothing to wait for
     i32 max_bucket = 0;
@@ -624,7 +699,7 @@ int launch_sort_pairs(const uint64_t* keys_in, const int32_t* rows_in, int32_t* 
     }
     int bits_per = 0;
     const int passes = lds_passes(rest, &bits_per);
-    hipLaunchKernelGGL(k_sort_buckets, nd1 * nd2, 256, 0, s, last_k, last_r, kout, rows_out, final_offs, 0, begin_bit, rest, passes, bits_per);
+    hipLaunchKernelGGL(k_sort_buckets, nd1 * nd2, 256, 0, s, last_k, last_r, kout, rows_out, final_offs, 0, begin_bit, rest, passes, bits_per, stage(last_place, 1));
     PA_HIP(hipGetLastError());
     return PA_SORT_BUCKETS;
 }

@@ -113,8 +113,10 @@ def test_pair_sort_paths(gpu, n, spread):
         keys = np.full(n, 7, dtype=np.int64)
         keys[n // 2] = 1 << 45
     descending = n % 2 == 1
-    page = Page([Block.bigint(keys), Block.integer(np.arange(n, dtype=np.int32))], n)
-    op = OrderByOperator([abi.BIGINT, abi.INTEGER], [0, 1], [0], [abi.DESC_NULLS_LAST if descending else abi.ASC_NULLS_LAST])
+    # (the INTEGER and DOUBLE channels ride along with the pairs -- 4- and 8-byte payload columns of the sort -- when the hand-written
+    # sort runs, and are gathered by the sorted row ids when the library's does)
+    page = Page([Block.bigint(keys), Block.integer(np.arange(n, dtype=np.int32)), Block.double(np.arange(n) * 0.5)], n)
+    op = OrderByOperator([abi.BIGINT, abi.INTEGER, abi.DOUBLE], [0, 1, 2], [0], [abi.DESC_NULLS_LAST if descending else abi.ASC_NULLS_LAST])
     out = to_pages(op, [page])
     name = op.kernelName()
     op.close()
@@ -123,5 +125,6 @@ def test_pair_sort_paths(gpu, n, spread):
     want_keys, want_rows = _sorted_rows(keys, descending)
     assert np.array_equal(got_keys, want_keys)
     assert np.array_equal(got_rows, want_rows.astype(np.int32))
+    assert np.array_equal(np.concatenate([p.blocks[2].values for p in out]), want_rows * 0.5)
     if len(np.unique(keys)) > 1:
         assert name == _expected_sort(keys), (name, n, spread)
