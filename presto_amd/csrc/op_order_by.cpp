@@ -293,7 +293,8 @@ public:
         std::vector<uint64_t> h_or_and(key_or_and_bytes() / 8);
         const uint64_t* sorted_images = nullptr;  // the images of the channel sorted by last, in their sorted order (valid until perm changes again)
         // pairs: OR / AND of the images already in or_and (the image kernel left them there), 0 = still to be computed
-        auto sort_by_image = [&](int pairs, bool last) {
+        // crowded: images of doubles (exponent bits) or text crowd under few bit prefixes -- the sort takes its bucket bounds from a sample
+        auto sort_by_image = [&](int pairs, bool last, bool crowded) {
             const uint64_t* in = keys;
             if (!identity) {
                 launch_gather_flat(keys, 8, perm, n, kp[0], s);
@@ -316,7 +317,7 @@ public:
             if (end_bit == 64) begin_bit = 0;
             const bool carry = last && identity && payload.count > 0;
             const int path = launch_sort_pairs(in, identity ? nullptr : perm, pos, kp[1], next, n, begin_bit, end_bit, sort_temp, sort_temp_bytes, s,
-                                               carry ? &payload : nullptr);
+                                               carry ? &payload : nullptr, crowded ? PA_SORT_HINT_CROWDED : PA_SORT_HINT_SPREAD);
             payload_moved = carry && path == PA_SORT_BUCKETS;
             timer.set_name(path == PA_SORT_LIBRARY ? "rocprim_radix_sort_pairs" : "pa_sort_buckets");   // (pa_op_kernel_name: which sort the last image took)
             std::swap(perm, next);
@@ -334,14 +335,14 @@ public:
                 const int chunks = (max_len + 7) / 8;
                 for (int chunk = chunks; chunk >= 0; chunk--) {
                     launch_varchar_chunk_keys(a.values.ptr(), a.offsets.as<int32_t>(), nulls, n, chunk == chunks ? -1 : chunk, descending ? 1 : 0, keys, s);
-                    sort_by_image(0, false);
+                    sort_by_image(0, false, chunk != chunks);   // (the length key spreads; the byte chunks do not)
                 }
             }
             else {
                 // value image; NULL rows get one constant image (they keep arrival order among themselves) and their place
                 // relative to the values is decided by the separate NULL digit below
                 const int pairs = launch_topn_keys_or_and(a.type, a.values.ptr(), nullptr, nulls, n, descending ? PA_DESC_NULLS_LAST : PA_ASC_NULLS_LAST, keys, or_and, s);
-                sort_by_image(pairs, i == 0 && nulls == nullptr);
+                sort_by_image(pairs, i == 0 && nulls == nullptr, a.type == PA_DOUBLE || a.type == PA_REAL);
             }
             if (nulls) {
                 materialize();

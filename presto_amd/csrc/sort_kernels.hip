@@ -47,6 +47,14 @@ struct PayloadDev {
     int n;
 };
 
+// Bucket bounds from a sorted sample of the keys instead of bit prefixes (keys that crowd under a few prefixes: doubles, text): bucket
+// (b, t) of a pass with nd digits = keys in [sorted[(b * nd + t) * stride], sorted[(b * nd + t + 1) * stride]); sorted == nullptr: the digit
+// is bits of the key.
+struct Splitters {
+    const u64* sorted;
+    i32 stride;
+};
+
 struct SortCtl {
     i32 max_bucket;   // largest final bucket
     i32 tiles_b;      // tiles of the second partition pass
@@ -70,6 +78,21 @@ __device__ __forceinline__ u32 key_digit(u64 key, int shift, u32 mask)
     const u32 lo = (u32)key, hi = (u32)(key >> 32);
     const u32 v = shift >= 32 ? hi >> (shift - 32) : __builtin_amdgcn_alignbit(hi, lo, (u32)shift);
     return v & mask;
+}
+
+// the bounds of bucket `bucket`'s digits in LDS: spl[t] = lower bound of digit t (spl[0] = 0: everything below the first bound)
+__device__ __forceinline__ void load_splitters(u64* spl, const Splitters& sp, i32 bucket, i32 nd)
+{
+    if ((i32)threadIdx.x < nd) spl[threadIdx.x] = threadIdx.x == 0 ? 0ULL : sp.sorted[((i64)bucket * nd + (i64)threadIdx.x) * sp.stride];
+}
+// digit of a key = number of bounds (beyond spl[0]) that are <= key; nd = 1 << bits of them in spl
+__device__ __forceinline__ u32 splitter_digit(const u64* spl, int bits, u64 key)
+{
+    u32 pos = 0;
+    for (int step = bits > 0 ? 1 << (bits - 1) : 0; step > 0; step >>= 1) {
+        if (spl[pos + step] <= key) pos += (u32)step;
+    }
+    return pos;
 }
 
 // rows of this lane's digit among the live lanes of the wave: `peers` = their lanes, returns how many of them come before this lane.
@@ -107,12 +130,15 @@ __device__ __forceinline__ int wave_digit_peers(u32 d, bool live, int bits, int 
 // digit counts of every tile: counts[digit * tiles_cap + tile].  Tiles: 4096 consecutive rows of the input (tile_start == nullptr), or
 // the rows the plan kernel listed (second pass: tiles inside the first pass's buckets; workgroups past *ntiles_dev leave).
 __global__ __launch_bounds__(256) void k_sort_count(const u64* __restrict__ keys, i64 n, const i32* __restrict__ tile_start, const i32* __restrict__ tile_rows,
-                                                    const i32* __restrict__ ntiles_dev, i32 tiles_cap, int shift, int bits, i32* __restrict__ counts)
+                                                    const i32* __restrict__ tile_bucket, const i32* __restrict__ ntiles_dev, i32 tiles_cap, int shift, int bits,
+                                                    i32* __restrict__ counts, Splitters sp)
 {
     __shared__ i32 hist[1 << kPartBits];
+    __shared__ u64 spl[1 << kPartBits];
     const i32 tile = (i32)blockIdx.x;
     if (ntiles_dev != nullptr && tile >= *ntiles_dev) return;
     if (threadIdx.x < (1u << kPartBits)) hist[threadIdx.x] = 0;
+    if (sp.sorted) load_splitters(spl, sp, tile_bucket ? tile_bucket[tile] : 0, 1 << bits);
     __syncthreads();
     const i64 start = tile_start ? (i64)tile_start[tile] : (i64)tile * kTile;
     const i32 rows = tile_rows ? tile_rows[tile] : (i32)(n - start < (i64)kTile ? n - start : (i64)kTile);
@@ -120,7 +146,10 @@ __global__ __launch_bounds__(256) void k_sort_count(const u64* __restrict__ keys
 #pragma unroll
     for (int i = 0; i < kTile / 256; i++) {
         const i32 idx = i * 256 + (i32)threadIdx.x;
-        if (idx < rows) atomicAdd(&hist[key_digit(keys[start + idx], shift, mask)], 1);
+        if (idx < rows) {
+            const u64 k = keys[start + idx];
+            atomicAdd(&hist[sp.sorted ? splitter_digit(spl, bits, k) : key_digit(k, shift, mask)], 1);
+        }
     }
     __syncthreads();
     if (threadIdx.x < (1u << bits)) counts[(i64)threadIdx.x * tiles_cap + tile] = hist[threadIdx.x];
@@ -258,13 +287,14 @@ __global__ __launch_bounds__(256) void k_sort_plan_tiles(const i32* __restrict__
 __global__ __launch_bounds__(256) void k_sort_partition(const u64* __restrict__ kin, const i32* __restrict__ rin, u64* __restrict__ kout, i32* __restrict__ rout, i64 n,
                                                         const i32* __restrict__ tile_start, const i32* __restrict__ tile_rows, const i32* __restrict__ tile_bucket,
                                                         const i32* __restrict__ ntiles_dev, i32 tiles_cap, int shift, int bits, const i32* __restrict__ offs,
-                                                        const i32* __restrict__ base, PayloadDev pl)
+                                                        const i32* __restrict__ base, PayloadDev pl, Splitters sp)
 {
     constexpr int kRounds = kTile / 256;
     __shared__ u64 skey[kTile];
     __shared__ i32 srow[kTile];
     __shared__ i32 cnt[4][1 << kPartBits];
     __shared__ i32 lstart[1 << kPartBits], goff[1 << kPartBits];
+    __shared__ u64 spl[1 << kPartBits];
     __shared__ i32 wave_sums[4];
     const i32 tile = (i32)blockIdx.x;
     if (ntiles_dev != nullptr && tile >= *ntiles_dev) return;
@@ -278,9 +308,11 @@ __global__ __launch_bounds__(256) void k_sort_partition(const u64* __restrict__ 
 #pragma unroll
         for (int w = 0; w < 4; w++) cnt[w][threadIdx.x] = 0;
     }
+    if (sp.sorted) load_splitters(spl, sp, bucket, nd);
     u64 key[kRounds];
     i32 row[kRounds];
     i32 lr[kRounds];
+    u32 dg[kRounds];
 #pragma unroll
     for (int r = 0; r < kRounds; r++) {
         const i32 idx = wave * (kTile / 4) + r * 64 + lane;
@@ -298,7 +330,8 @@ __global__ __launch_bounds__(256) void k_sort_partition(const u64* __restrict__ 
     for (int r = 0; r < kRounds; r++) {
         const i32 idx = wave * (kTile / 4) + r * 64 + lane;
         const bool live = idx < rows;
-        const u32 d = key_digit(key[r], shift, mask);
+        const u32 d = live ? (sp.sorted ? splitter_digit(spl, bits, key[r]) : key_digit(key[r], shift, mask)) : 0u;
+        dg[r] = d;
         u64 peers;
         const int before = wave_digit_peers(d, live, bits, lane, &peers);
         lr[r] = before;
@@ -334,7 +367,7 @@ __global__ __launch_bounds__(256) void k_sort_partition(const u64* __restrict__ 
     for (int r = 0; r < kRounds; r++) {
         const i32 idx = wave * (kTile / 4) + r * 64 + lane;
         if (idx < rows) {
-            const u32 d = key_digit(key[r], shift, mask);
+            const u32 d = dg[r];
             const i32 p = lstart[d] + cnt[wave][d] + lr[r];
             lr[r] = p;   // (the row's place in the staged tile: the payload columns go the same way)
             skey[p] = key[r];
@@ -349,7 +382,14 @@ __global__ __launch_bounds__(256) void k_sort_partition(const u64* __restrict__ 
         dest[i] = 0;
         if (j < rows) {
             const u64 k = skey[j];
-            const u32 d = key_digit(k, shift, mask);
+            u32 d;
+            if (sp.sorted) {  // the digit whose rows of the staged tile hold position j (the last one that starts at or before j)
+                d = 0;
+                for (int step = nd >> 1; step > 0; step >>= 1) {
+                    if (lstart[d + step] <= j) d += (u32)step;
+                }
+            }
+            else d = key_digit(k, shift, mask);
             dest[i] = goff[d] + (j - lstart[d]);
             kout[dest[i]] = k;
             rout[dest[i]] = srow[j];
@@ -397,7 +437,8 @@ __global__ __launch_bounds__(256) void k_sort_partition(const u64* __restrict__ 
 // their places IN the one LDS copy -- every row sits in a register of its thread between the barrier that ends the reads and the writes.
 // The first pass takes its rows from HBM directly.  26.5 KB of LDS: six workgroups per CU.
 __global__ __launch_bounds__(256) void k_sort_buckets(const u64* __restrict__ kin, const i32* __restrict__ rin, u64* __restrict__ kout, i32* __restrict__ rout,
-                                                      const i32* __restrict__ offs, i32 n_single, int begin_bit, int rest_bits, int passes, int bits_per, PayloadDev pl)
+                                                      const i32* __restrict__ offs, i32 n_single, int begin_bit, int rest_bits, int passes, int bits_per, PayloadDev pl,
+                                                      Splitters sp, i32 buckets)
 {
     constexpr int kRounds = kCap / 256;
     __shared__ u64 kbuf[kCap];
@@ -407,7 +448,30 @@ __global__ __launch_bounds__(256) void k_sort_buckets(const u64* __restrict__ ki
     const i32 bucket = (i32)blockIdx.x;
     const i32 start = offs ? offs[bucket] : 0;
     const i32 count = offs ? offs[bucket + 1] - start : n_single;
-    if (count <= 0) return;
+    if (count <= 0 || count > kCap) return;   // (a bucket beyond the LDS copy: the host has seen it and sorts everything another way)
+    if (sp.sorted) {
+        // bounds from a sorted sample: the bucket's keys lie between two of them, so the bits above the highest one in which the bounds
+        // differ are the same in all of them (rest_bits = the whole range here: the bounds say what is left of it)
+        const u64 lo = bucket > 0 ? sp.sorted[(i64)bucket * sp.stride] : 0ULL;
+        const u64 hi = bucket + 1 < buckets ? sp.sorted[(i64)(bucket + 1) * sp.stride] : ~0ULL;
+        const u64 x = lo ^ hi;
+        const int top = x ? 64 - __builtin_clzll(x) : 0;
+        const int end = top < begin_bit + rest_bits ? top : begin_bit + rest_bits;
+        rest_bits = end > begin_bit ? end - begin_bit : 0;
+        passes = (rest_bits + kSortBits - 1) / kSortBits;
+        bits_per = passes ? (rest_bits + passes - 1) / passes : 0;
+    }
+    if (passes == 0) {  // every key of the bucket the same in the bits that count: the rows stay as the partition passes left them
+        for (i32 j = (i32)threadIdx.x; j < count; j += 256) {
+            kout[(i64)start + j] = kin[(i64)start + j];
+            rout[(i64)start + j] = rin ? rin[(i64)start + j] : start + j;
+            for (int c = 0; c < pl.n; c++) {
+                if (pl.width[c] == 8) static_cast<u64*>(pl.out[c])[(i64)start + j] = static_cast<const u64*>(pl.in[c])[(i64)start + j];
+                else static_cast<u32*>(pl.out[c])[(i64)start + j] = static_cast<const u32*>(pl.in[c])[(i64)start + j];
+            }
+        }
+        return;
+    }
     const int lane = (int)threadIdx.x & 63, wave = (int)threadIdx.x >> 6;
     const i32 chunk = ((count + 255) / 256) * 64;
     const int rounds = chunk / 64;
@@ -512,14 +576,39 @@ __global__ __launch_bounds__(256) void k_sort_buckets(const u64* __restrict__ ki
     }
 }
 
+// every stride-th key, from the middle of its stretch
+__global__ __launch_bounds__(256) void k_sort_sample(const u64* __restrict__ keys, i64 stride, i32 m, u64* __restrict__ sample)
+{
+    const i32 i = (i32)(blockIdx.x * 256 + threadIdx.x);
+    if (i < m) sample[i] = keys[(i64)i * stride + (stride >> 1)];
+}
+
 __global__ __launch_bounds__(256) void k_sort_iota(i32* __restrict__ rows, i64 n)
 {
     const i64 i = (i64)blockIdx.x * 256 + threadIdx.x;
     if (i < n) rows[i] = (i32)i;
 }
 
+constexpr int kOversample = 16;                                  // sample keys per final bucket (splitter mode)
+constexpr int64_t kSampleMax = (int64_t)(1 << kMaxTopBits) * kOversample;
+// A bucket between two sampled bounds holds n / buckets rows on average and a Gamma(16)-distributed multiple of 1/16 of that: at 512 rows on
+// average the 2048 of the LDS copy are 64 / 16 -- never reached (10^-14 per bucket); at 1024 on average they are 32 / 16: one bucket in 2000.
+constexpr int64_t kSampledMeanRows = 512;
+constexpr int64_t kSampledMaxRows = (int64_t)(1 << kMaxTopBits) * 600;   // beyond: the library sort
+
+size_t sample_sort_temp_bytes()
+{
+    static const size_t bytes = [] {
+        size_t b = 0;
+        PA_HIP(rocprim::radix_sort_keys(nullptr, b, (const uint64_t*)nullptr, (uint64_t*)nullptr, (size_t)kSampleMax, 0u, 64u, (hipStream_t) nullptr));
+        return b;
+    }();
+    return bytes;
+}
+
 struct FastLayout {
     size_t payload = 0;   // scratch copies of the payload columns, 8 n bytes each, behind each other
+    size_t sample_in = 0, sample_sorted = 0, sample_temp = 0, sample_temp_bytes = 0;   // splitter mode: the sample, sorted, the library's scratch
     size_t keys = 0, rows = 0, counts_a = 0, totals_a = 0, offs_a = 0, bucket_tiles = 0, tile_start = 0, tile_rows = 0, tile_bucket = 0, counts_b = 0, totals_b = 0,
            offs_b = 0, ctl = 0, end = 0;
     i64 tiles_a = 0, tiles_cap_b = 0;
@@ -549,6 +638,10 @@ FastLayout fast_layout(int64_t n, int payload_columns)
     l.totals_b = take((size_t)(1 << kMaxTopBits) * 4);
     l.offs_b = take((size_t)((1 << kMaxTopBits) + 1) * 4);
     l.ctl = take(sizeof(SortCtl));
+    l.sample_in = take((size_t)kSampleMax * 8);
+    l.sample_sorted = take((size_t)kSampleMax * 8);
+    l.sample_temp_bytes = sample_sort_temp_bytes();
+    l.sample_temp = take(l.sample_temp_bytes);
     l.payload = at;
     for (int c = 0; c < payload_columns; c++) take((size_t)n * 8);
     l.end = at;
@@ -596,7 +689,7 @@ size_t sort_pairs_temp_bytes(int64_t n, int payload_columns)
 }
 
 int launch_sort_pairs(const uint64_t* keys_in, const int32_t* rows_in, int32_t* rows_scratch, uint64_t* keys_out, int32_t* rows_out, int64_t n, int begin_bit,
-                      int end_bit, void* temp, size_t temp_bytes, hipStream_t s, const SortPayload* payload)
+                      int end_bit, void* temp, size_t temp_bytes, hipStream_t s, const SortPayload* payload, int hint)
 {
     const int pcols = payload ? payload->count : 0;
     PA_REQUIRE(pcols >= 0 && pcols <= PA_SORT_MAX_PAYLOAD, PA_ERR_DEVICE, "internal: payload columns of a pair sort");
@@ -617,7 +710,8 @@ int launch_sort_pairs(const uint64_t* keys_in, const int32_t* rows_in, int32_t* 
     if (n <= 0) return PA_SORT_NONE;
     PA_REQUIRE(begin_bit >= 0 && end_bit > begin_bit && end_bit <= 64, PA_ERR_DEVICE, "internal: bit range of a pair sort");
     static const bool library_only = getenv("PRESTO_AMD_SORT_LIBRARY") != nullptr;
-    if (library_only || n > kFastMaxRows) {
+    const bool by_sample = hint == PA_SORT_HINT_CROWDED && n > kCap;
+    if (library_only || n > kFastMaxRows || (by_sample && n > kSampledMaxRows)) {
         library_sort(keys_in, rows_in, rows_scratch, keys_out, rows_out, n, begin_bit, end_bit, temp, temp_bytes, s);
         return PA_SORT_LIBRARY;
     }
@@ -629,10 +723,11 @@ int launch_sort_pairs(const uint64_t* keys_in, const int32_t* rows_in, int32_t* 
         *bits_per = passes ? (rest + passes - 1) / passes : 0;
         return passes;
     };
+    const Splitters none{nullptr, 0};
     if (n <= kCap) {  // one bucket: the LDS sort alone
         int bits_per = 0;
         const int passes = lds_passes(width, &bits_per);
-        hipLaunchKernelGGL(k_sort_buckets, 1, 256, 0, s, kin, rows_in, kout, rows_out, (const i32*)nullptr, (i32)n, begin_bit, width, passes, bits_per, stage(0, 1));
+        hipLaunchKernelGGL(k_sort_buckets, 1, 256, 0, s, kin, rows_in, kout, rows_out, (const i32*)nullptr, (i32)n, begin_bit, width, passes, bits_per, stage(0, 1), none, 1);
         PA_HIP(hipGetLastError());
         return PA_SORT_BUCKETS;
     }
@@ -654,10 +749,29 @@ int launch_sort_pairs(const uint64_t* keys_in, const int32_t* rows_in, int32_t* 
     SortCtl* ctl = reinterpret_cast<SortCtl*>(t + l.ctl);
 
     // ~1024 pairs per final bucket, at most 14 bits of partitioning, never more than the range has
-    const int top = std::min(width, std::min(kMaxTopBits, std::max(1, ceil_log2((n + 1023) / 1024))));
-    const int bits1 = std::min(top, kPartBits), bits2 = top - bits1, rest = width - top;
+    // (bounded by a sample: ~512 per bucket -- the buckets differ in size)
+    const int64_t mean = by_sample ? kSampledMeanRows : 1024;
+    const int top = std::min(width, std::min(kMaxTopBits, std::max(1, ceil_log2((n + mean - 1) / mean))));
+    const int bits1 = std::min(top, kPartBits), bits2 = top - bits1;
+    const int rest = by_sample ? width : width - top;   // (by sample: what is left of the range differs bucket by bucket, the bounds tell)
     const i32 nd1 = 1 << bits1, nd2 = 1 << bits2;
     const i32 tiles_a = (i32)l.tiles_a, cap_b = (i32)l.tiles_cap_b;
+    // bucket bounds from a sample: every (n / m)-th key, sorted by the library (2^18 keys at most); final bucket i starts at sorted[16 i]
+    Splitters sp1 = none, sp2 = none, sp_final = none;
+    if (by_sample) {
+        const i32 m = nd1 * nd2 * kOversample;
+        u64* sample = reinterpret_cast<u64*>(t + l.sample_in);
+        u64* sorted = reinterpret_cast<u64*>(t + l.sample_sorted);
+        hipLaunchKernelGGL(k_sort_sample, (m + 255) / 256, 256, 0, s, kin, (i64)(n / m), m, sample);
+        size_t need = 0;
+        PA_HIP(rocprim::radix_sort_keys(nullptr, need, (const uint64_t*)sample, (uint64_t*)sorted, (size_t)m, (unsigned)begin_bit, (unsigned)end_bit, s));
+        PA_REQUIRE(need <= l.sample_temp_bytes, PA_ERR_DEVICE, "internal: sample sort scratch smaller than this bit range needs");
+        size_t have = l.sample_temp_bytes;
+        PA_HIP(rocprim::radix_sort_keys(t + l.sample_temp, have, (const uint64_t*)sample, (uint64_t*)sorted, (size_t)m, (unsigned)begin_bit, (unsigned)end_bit, s));
+        sp1 = Splitters{sorted, nd2 * kOversample};
+        sp2 = Splitters{sorted, kOversample};
+        sp_final = sp2;
+    }
     // where the passes land: the last one (partition or LDS sort) in the output, the ones before alternate with the scratch pairs
     const bool two = bits2 > 0, sorting = rest > 0;
     const int moves = 1 + (two ? 1 : 0) + (sorting ? 1 : 0);
@@ -667,23 +781,24 @@ int launch_sort_pairs(const uint64_t* keys_in, const int32_t* rows_in, int32_t* 
     i32* dst2_r = (moves % 2) ? trows : rows_out;
 
     const int shift1 = end_bit - bits1, shift2 = end_bit - top;
-    hipLaunchKernelGGL(k_sort_count, tiles_a, 256, 0, s, kin, (i64)n, (const i32*)nullptr, (const i32*)nullptr, (const i32*)nullptr, tiles_a, shift1, bits1, counts_a);
+    hipLaunchKernelGGL(k_sort_count, tiles_a, 256, 0, s, kin, (i64)n, (const i32*)nullptr, (const i32*)nullptr, (const i32*)nullptr, (const i32*)nullptr, tiles_a, shift1,
+                       bits1, counts_a, sp1);
     hipLaunchKernelGGL(k_sort_scan_tiles, dim3(nd1, 1), 256, 0, s, counts_a, tiles_a, (const i32*)nullptr, tiles_a, nd1, totals_a);
     hipLaunchKernelGGL(k_sort_offsets, 1, 1024, 0, s, (const i32*)totals_a, nd1, offs_a, &ctl->max_bucket);
     if (two) hipLaunchKernelGGL(k_sort_plan_tiles, 1, 256, 0, s, (const i32*)offs_a, nd1, bucket_tiles, tile_start, tile_rows, tile_bucket, &ctl->tiles_b);
     const int place1 = (moves % 2) ? 1 : 2, place2 = (moves % 2) ? 2 : 1;   // where the first / second pass leave their rows (as dst1 / dst2)
     hipLaunchKernelGGL(k_sort_partition, tiles_a, 256, 0, s, kin, rows_in, dst1_k, dst1_r, (i64)n, (const i32*)nullptr, (const i32*)nullptr, (const i32*)nullptr,
-                       (const i32*)nullptr, tiles_a, shift1, bits1, (const i32*)counts_a, (const i32*)offs_a, stage(0, place1));
+                       (const i32*)nullptr, tiles_a, shift1, bits1, (const i32*)counts_a, (const i32*)offs_a, stage(0, place1), sp1);
     const i32* final_offs = offs_a;
     const u64* last_k = dst1_k;
     const i32* last_r = dst1_r;
     if (two) {
-        hipLaunchKernelGGL(k_sort_count, cap_b, 256, 0, s, (const u64*)dst1_k, (i64)n, (const i32*)tile_start, (const i32*)tile_rows, (const i32*)&ctl->tiles_b, cap_b, shift2,
-                           bits2, counts_b);
+        hipLaunchKernelGGL(k_sort_count, cap_b, 256, 0, s, (const u64*)dst1_k, (i64)n, (const i32*)tile_start, (const i32*)tile_rows, (const i32*)tile_bucket,
+                           (const i32*)&ctl->tiles_b, cap_b, shift2, bits2, counts_b, sp2);
         hipLaunchKernelGGL(k_sort_scan_tiles, dim3(nd2, nd1), 64, 0, s, counts_b, cap_b, (const i32*)bucket_tiles, 0, nd2, totals_b);
         hipLaunchKernelGGL(k_sort_offsets, 1, 1024, 0, s, (const i32*)totals_b, nd1 * nd2, offs_b, &ctl->max_bucket);
         hipLaunchKernelGGL(k_sort_partition, cap_b, 256, 0, s, (const u64*)dst1_k, (const i32*)dst1_r, dst2_k, dst2_r, (i64)n, (const i32*)tile_start, (const i32*)tile_rows,
-                           (const i32*)tile_bucket, (const i32*)&ctl->tiles_b, cap_b, shift2, bits2, (const i32*)counts_b, (const i32*)offs_b, stage(place1, place2));
+                           (const i32*)tile_bucket, (const i32*)&ctl->tiles_b, cap_b, shift2, bits2, (const i32*)counts_b, (const i32*)offs_b, stage(place1, place2), sp2);
         final_offs = offs_b;
         last_k = dst2_k;
         last_r = dst2_r;
@@ -693,13 +808,16 @@ int launch_sort_pairs(const uint64_t* keys_in, const int32_t* rows_in, int32_t* 
     if (!sorting) return PA_SORT_BUCKETS;   // the range had no more bits than the partition passes took: done, nothing to wait for
     i32 max_bucket = 0;
     read_back(&max_bucket, &ctl->max_bucket, 4, s);
-    if (max_bucket > kCap) {  // keys crowd in a few bit prefixes: the library's passes over the whole range, from the untouched input
+    if (max_bucket > kCap) {
+        // keys crowd in a few bit prefixes -- or, bounded by a sample, one key value fills more than a bucket: the library's passes over the
+        // whole range, from the untouched input
         library_sort(keys_in, rows_in, rows_scratch, keys_out, rows_out, n, begin_bit, end_bit, temp, temp_bytes, s);
         return PA_SORT_LIBRARY;
     }
     int bits_per = 0;
     const int passes = lds_passes(rest, &bits_per);
-    hipLaunchKernelGGL(k_sort_buckets, nd1 * nd2, 256, 0, s, last_k, last_r, kout, rows_out, final_offs, 0, begin_bit, rest, passes, bits_per, stage(last_place, 1));
+    hipLaunchKernelGGL(k_sort_buckets, nd1 * nd2, 256, 0, s, last_k, last_r, kout, rows_out, final_offs, 0, begin_bit, rest, passes, bits_per, stage(last_place, 1),
+                       sp_final, nd1 * nd2);
     PA_HIP(hipGetLastError());
     return PA_SORT_BUCKETS;
 }

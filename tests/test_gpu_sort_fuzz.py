@@ -128,3 +128,49 @@ def test_pair_sort_paths(gpu, n, spread):
     assert np.array_equal(np.concatenate([p.blocks[2].values for p in out]), want_rows * 0.5)
     if len(np.unique(keys)) > 1:
         assert name == _expected_sort(keys), (name, n, spread)
+
+
+@pytest.mark.parametrize("n", [3_001, 262_144, 1_000_003, 5_000_000, 10_000_000])
+@pytest.mark.parametrize("spread", ["uniform [0, 1)", "normal", "exponential", "signed, huge range", "specials", "few values", "REAL uniform"])
+def test_pair_sort_by_sampled_bounds(gpu, n, spread):
+    """DOUBLE / REAL sort keys: their images crowd under a few bit prefixes (the exponent), so the pair sort takes its bucket bounds from a
+    sorted sample of the keys (sort_kernels.hip, PA_SORT_HINT_CROWDED; 16 sampled keys per bucket of ~512 rows, up to 9.8 M rows); values
+    that fill more than a bucket (few distinct values) send it to the library sort.  Expected: numpy's stable sort by the key in Double.compare order, ties in arrival order;
+    an INTEGER and a BIGINT channel ride along."""
+    rng = np.random.default_rng(n % 1000 + len(spread))
+    real = spread.startswith("REAL")
+    if spread in ("uniform [0, 1)", "REAL uniform"):
+        keys = rng.random(n)
+    elif spread == "normal":
+        keys = rng.standard_normal(n) * 1e6
+    elif spread == "exponential":
+        keys = rng.exponential(1e-3, n)
+    elif spread == "signed, huge range":
+        keys = rng.standard_normal(n) * 10.0 ** rng.integers(-200, 200, n)
+    elif spread == "specials":
+        keys = rng.standard_normal(n)
+        keys[rng.integers(0, n, n // 50)] = rng.choice([0.0, -0.0, np.inf, -np.inf, np.nan], n // 50)
+    else:
+        keys = rng.integers(0, 7, n).astype(np.float64) * 1.5
+    if real:
+        keys = keys.astype(np.float32)
+    descending = n % 2 == 0
+    t = abi.REAL if real else abi.DOUBLE
+    page = Page([Block.flat(t, keys), Block.integer(np.arange(n, dtype=np.int32)), Block.bigint(np.arange(n, dtype=np.int64) * 3)], n)
+    op = OrderByOperator([t, abi.INTEGER, abi.BIGINT], [0, 1, 2], [0], [abi.DESC_NULLS_LAST if descending else abi.ASC_NULLS_LAST])
+    out = to_pages(op, [page])
+    name = op.kernelName()
+    op.close()
+    # Double.compare order as an integer image: -0.0 < 0.0, one NaN above everything
+    wide = keys.astype(np.float64)
+    bits = np.where(np.isnan(wide), np.float64(np.nan), wide).view(np.int64).copy()
+    bits[np.isnan(wide)] = 0x7ff8000000000000
+    image = np.where(bits < 0, ~bits, bits | np.int64(-2**63)).view(np.uint64)
+    order = np.argsort(~image if descending else image, kind="stable")
+    got_rows = np.concatenate([p.blocks[1].values for p in out])
+    assert np.array_equal(got_rows, order.astype(np.int32))
+    assert np.array_equal(np.concatenate([p.blocks[2].values for p in out]), order.astype(np.int64) * 3)
+    got_keys = np.concatenate([p.blocks[0].values for p in out])
+    assert np.array_equal(got_keys.view(np.uint32 if real else np.uint64), keys[order].view(np.uint32 if real else np.uint64))
+    crowded = (spread == "few values" and n // 7 > 2048) or (spread == "specials" and n // 50 // 5 > 2048)   # (a value that fills more than the LDS copy)
+    assert name == ("rocprim_radix_sort_pairs" if crowded or n > 9_830_400 else "pa_sort_buckets"), (name, n, spread)
