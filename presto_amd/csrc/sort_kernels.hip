@@ -47,12 +47,19 @@ struct PayloadDev {
     int n;
 };
 
-// Bucket bounds from a sorted sample of the keys instead of bit prefixes (keys that crowd under a few prefixes: doubles, text): bucket
-// (b, t) of a pass with nd digits = keys in [sorted[(b * nd + t) * stride], sorted[(b * nd + t + 1) * stride]); sorted == nullptr: the digit
-// is bits of the key.
+// Bucket bounds from sorted samples of the keys instead of bit prefixes (keys that crowd under a few prefixes: doubles, text).  A pass
+// over bucket b (the whole input: b = 0) with nd digits has kSamplePer sampled keys of that bucket, sorted, at sorted[b * kSamplePer ..]:
+// digit t starts at sorted[b * kSamplePer + t * (kSamplePer / nd)].  sorted == nullptr: the digit is bits of the key.
+constexpr int kSamplePer = 2048;   // sampled keys per partitioned range (= one LDS bucket sort): >= 16 per digit
 struct Splitters {
     const u64* sorted;
-    i32 stride;
+};
+// ... and of the final buckets (b, t) for the LDS sort, which takes the bits its bucket's bounds leave open: first-pass bounds s1 (one
+// range), second-pass bounds s2 (one range per first-pass bucket; null when there was one pass)
+struct FinalBounds {
+    const u64* s1;
+    const u64* s2;
+    i32 nd1, nd2;
 };
 
 struct SortCtl {
@@ -83,7 +90,7 @@ __device__ __forceinline__ u32 key_digit(u64 key, int shift, u32 mask)
 // the bounds of bucket `bucket`'s digits in LDS: spl[t] = lower bound of digit t (spl[0] = 0: everything below the first bound)
 __device__ __forceinline__ void load_splitters(u64* spl, const Splitters& sp, i32 bucket, i32 nd)
 {
-    if ((i32)threadIdx.x < nd) spl[threadIdx.x] = threadIdx.x == 0 ? 0ULL : sp.sorted[((i64)bucket * nd + (i64)threadIdx.x) * sp.stride];
+    if ((i32)threadIdx.x < nd) spl[threadIdx.x] = threadIdx.x == 0 ? 0ULL : sp.sorted[(i64)bucket * kSamplePer + (i64)threadIdx.x * (kSamplePer / nd)];
 }
 // digit of a key = number of bounds (beyond spl[0]) that are <= key; nd = 1 << bits of them in spl
 __device__ __forceinline__ u32 splitter_digit(const u64* spl, int bits, u64 key)
@@ -438,7 +445,7 @@ __global__ __launch_bounds__(256) void k_sort_partition(const u64* __restrict__ 
 // The first pass takes its rows from HBM directly.  26.5 KB of LDS: six workgroups per CU.
 __global__ __launch_bounds__(256) void k_sort_buckets(const u64* __restrict__ kin, const i32* __restrict__ rin, u64* __restrict__ kout, i32* __restrict__ rout,
                                                       const i32* __restrict__ offs, i32 n_single, int begin_bit, int rest_bits, int passes, int bits_per, PayloadDev pl,
-                                                      Splitters sp, i32 buckets)
+                                                      FinalBounds fb)
 {
     constexpr int kRounds = kCap / 256;
     __shared__ u64 kbuf[kCap];
@@ -446,14 +453,18 @@ __global__ __launch_bounds__(256) void k_sort_buckets(const u64* __restrict__ ki
     __shared__ i32 cnt[2][4][1 << kSortBits];
     __shared__ i32 dstart[1 << kSortBits];
     const i32 bucket = (i32)blockIdx.x;
-    const i32 start = offs ? offs[bucket] : 0;
+    const i32 start = offs ? offs[bucket] : bucket * n_single;   // (no offsets: buckets of n_single rows each, one behind the other)
     const i32 count = offs ? offs[bucket + 1] - start : n_single;
     if (count <= 0 || count > kCap) return;   // (a bucket beyond the LDS copy: the host has seen it and sorts everything another way)
-    if (sp.sorted) {
-        // bounds from a sorted sample: the bucket's keys lie between two of them, so the bits above the highest one in which the bounds
+    if (fb.s1) {
+        // bounds from sorted samples: the bucket's keys lie between two of them, so the bits above the highest one in which the bounds
         // differ are the same in all of them (rest_bits = the whole range here: the bounds say what is left of it)
-        const u64 lo = bucket > 0 ? sp.sorted[(i64)bucket * sp.stride] : 0ULL;
-        const u64 hi = bucket + 1 < buckets ? sp.sorted[(i64)(bucket + 1) * sp.stride] : ~0ULL;
+        const i32 b = bucket / fb.nd2, tt = bucket - b * fb.nd2;
+        const i32 step1 = kSamplePer / fb.nd1, step2 = kSamplePer / fb.nd2;
+        const u64 lo1 = b > 0 ? fb.s1[(i64)b * step1] : 0ULL;
+        const u64 hi1 = b + 1 < fb.nd1 ? fb.s1[(i64)(b + 1) * step1] : ~0ULL;
+        const u64 lo = (fb.s2 && tt > 0) ? fb.s2[(i64)b * kSamplePer + (i64)tt * step2] : lo1;
+        const u64 hi = (fb.s2 && tt + 1 < fb.nd2) ? fb.s2[(i64)b * kSamplePer + (i64)(tt + 1) * step2] : hi1;
         const u64 x = lo ^ hi;
         const int top = x ? 64 - __builtin_clzll(x) : 0;
         const int end = top < begin_bit + rest_bits ? top : begin_bit + rest_bits;
@@ -576,11 +587,14 @@ __global__ __launch_bounds__(256) void k_sort_buckets(const u64* __restrict__ ki
     }
 }
 
-// every stride-th key, from the middle of its stretch
-__global__ __launch_bounds__(256) void k_sort_sample(const u64* __restrict__ keys, i64 stride, i32 m, u64* __restrict__ sample)
+// kSamplePer keys of every bucket (offs == nullptr: of the one range 0 .. n), evenly spaced: sample[b * kSamplePer + i]
+__global__ __launch_bounds__(256) void k_sort_sample(const u64* __restrict__ keys, const i32* __restrict__ offs, i64 n, u64* __restrict__ sample)
 {
+    const i32 b = (i32)blockIdx.y;
     const i32 i = (i32)(blockIdx.x * 256 + threadIdx.x);
-    if (i < m) sample[i] = keys[(i64)i * stride + (stride >> 1)];
+    const i64 first = offs ? (i64)offs[b] : 0;
+    const i64 size = offs ? (i64)offs[b + 1] - first : n;
+    if (i < kSamplePer) sample[(i64)b * kSamplePer + i] = size > 0 ? keys[first + (size * i + (size >> 1)) / kSamplePer] : 0ULL;
 }
 
 __global__ __launch_bounds__(256) void k_sort_iota(i32* __restrict__ rows, i64 n)
@@ -589,26 +603,16 @@ __global__ __launch_bounds__(256) void k_sort_iota(i32* __restrict__ rows, i64 n
     if (i < n) rows[i] = (i32)i;
 }
 
-constexpr int kOversample = 16;                                  // sample keys per final bucket (splitter mode)
-constexpr int64_t kSampleMax = (int64_t)(1 << kMaxTopBits) * kOversample;
-// A bucket between two sampled bounds holds n / buckets rows on average and a Gamma(16)-distributed multiple of 1/16 of that: at 512 rows on
-// average the 2048 of the LDS copy are 64 / 16 -- never reached (10^-14 per bucket); at 1024 on average they are 32 / 16: one bucket in 2000.
+constexpr int64_t kSampleMax = (int64_t)(1 << kPartBits) * kSamplePer;   // the second pass's samples: one range per first-pass bucket
+// A bucket between two sampled bounds (every 16th key of a sorted sample, at least) holds n / buckets rows on average and a
+// Gamma(16)-distributed multiple of 1/16 of that: at 512 rows on average the 2048 of the LDS copy are 64 / 16 -- never reached (10^-14 per
+// bucket); at 1024 on average they are 32 / 16: one bucket in 2000.
 constexpr int64_t kSampledMeanRows = 512;
 constexpr int64_t kSampledMaxRows = (int64_t)(1 << kMaxTopBits) * 600;   // beyond: the library sort
 
-size_t sample_sort_temp_bytes()
-{
-    static const size_t bytes = [] {
-        size_t b = 0;
-        PA_HIP(rocprim::radix_sort_keys(nullptr, b, (const uint64_t*)nullptr, (uint64_t*)nullptr, (size_t)kSampleMax, 0u, 64u, (hipStream_t) nullptr));
-        return b;
-    }();
-    return bytes;
-}
-
 struct FastLayout {
     size_t payload = 0;   // scratch copies of the payload columns, 8 n bytes each, behind each other
-    size_t sample_in = 0, sample_sorted = 0, sample_temp = 0, sample_temp_bytes = 0;   // splitter mode: the sample, sorted, the library's scratch
+    size_t sample_in = 0, sample1 = 0, sample2 = 0, sample_rows = 0;   // bounds from samples: as drawn, sorted (first pass, second pass), row ids nobody reads
     size_t keys = 0, rows = 0, counts_a = 0, totals_a = 0, offs_a = 0, bucket_tiles = 0, tile_start = 0, tile_rows = 0, tile_bucket = 0, counts_b = 0, totals_b = 0,
            offs_b = 0, ctl = 0, end = 0;
     i64 tiles_a = 0, tiles_cap_b = 0;
@@ -639,9 +643,9 @@ FastLayout fast_layout(int64_t n, int payload_columns)
     l.offs_b = take((size_t)((1 << kMaxTopBits) + 1) * 4);
     l.ctl = take(sizeof(SortCtl));
     l.sample_in = take((size_t)kSampleMax * 8);
-    l.sample_sorted = take((size_t)kSampleMax * 8);
-    l.sample_temp_bytes = sample_sort_temp_bytes();
-    l.sample_temp = take(l.sample_temp_bytes);
+    l.sample1 = take((size_t)kSamplePer * 8);
+    l.sample2 = take((size_t)kSampleMax * 8);
+    l.sample_rows = take((size_t)kSampleMax * 4);
     l.payload = at;
     for (int c = 0; c < payload_columns; c++) take((size_t)n * 8);
     l.end = at;
@@ -723,11 +727,12 @@ int launch_sort_pairs(const uint64_t* keys_in, const int32_t* rows_in, int32_t* 
         *bits_per = passes ? (rest + passes - 1) / passes : 0;
         return passes;
     };
-    const Splitters none{nullptr, 0};
+    const Splitters none{nullptr};
     if (n <= kCap) {  // one bucket: the LDS sort alone
         int bits_per = 0;
         const int passes = lds_passes(width, &bits_per);
-        hipLaunchKernelGGL(k_sort_buckets, 1, 256, 0, s, kin, rows_in, kout, rows_out, (const i32*)nullptr, (i32)n, begin_bit, width, passes, bits_per, stage(0, 1), none, 1);
+        hipLaunchKernelGGL(k_sort_buckets, 1, 256, 0, s, kin, rows_in, kout, rows_out, (const i32*)nullptr, (i32)n, begin_bit, width, passes, bits_per, stage(0, 1),
+                           FinalBounds{nullptr, nullptr, 1, 1});
         PA_HIP(hipGetLastError());
         return PA_SORT_BUCKETS;
     }
@@ -756,21 +761,27 @@ int launch_sort_pairs(const uint64_t* keys_in, const int32_t* rows_in, int32_t* 
     const int rest = by_sample ? width : width - top;   // (by sample: what is left of the range differs bucket by bucket, the bounds tell)
     const i32 nd1 = 1 << bits1, nd2 = 1 << bits2;
     const i32 tiles_a = (i32)l.tiles_a, cap_b = (i32)l.tiles_cap_b;
-    // bucket bounds from a sample: every (n / m)-th key, sorted by the library (2^18 keys at most); final bucket i starts at sorted[16 i]
-    Splitters sp1 = none, sp2 = none, sp_final = none;
+    // bucket bounds from samples: 2048 evenly spaced keys of the input now, 2048 of every first-pass bucket once the first pass has placed
+    // them; each sample is sorted by the LDS bucket sort itself (one workgroup per sample, the whole bit range)
+    Splitters sp1 = none, sp2 = none;
+    FinalBounds fb{nullptr, nullptr, nd1, nd2};
+    u64* sample = reinterpret_cast<u64*>(t + l.sample_in);
+    u64* sorted1 = reinterpret_cast<u64*>(t + l.sample1);
+    u64* sorted2 = reinterpret_cast<u64*>(t + l.sample2);
+    i32* sample_rows = reinterpret_cast<i32*>(t + l.sample_rows);
+    auto sort_samples = [&](const u64* keys, const i32* offs, i32 ranges, u64* sorted) {
+        hipLaunchKernelGGL(k_sort_sample, dim3(kSamplePer / 256, ranges), 256, 0, s, keys, offs, (i64)n, sample);
+        int per = 0;
+        const int p = lds_passes(width, &per);
+        PayloadDev nothing;
+        memset(&nothing, 0, sizeof nothing);
+        hipLaunchKernelGGL(k_sort_buckets, ranges, 256, 0, s, (const u64*)sample, (const i32*)nullptr, sorted, sample_rows, (const i32*)nullptr, (i32)kSamplePer, begin_bit,
+                           width, p, per, nothing, FinalBounds{nullptr, nullptr, 1, 1});
+    };
     if (by_sample) {
-        const i32 m = nd1 * nd2 * kOversample;
-        u64* sample = reinterpret_cast<u64*>(t + l.sample_in);
-        u64* sorted = reinterpret_cast<u64*>(t + l.sample_sorted);
-        hipLaunchKernelGGL(k_sort_sample, (m + 255) / 256, 256, 0, s, kin, (i64)(n / m), m, sample);
-        size_t need = 0;
-        PA_HIP(rocprim::radix_sort_keys(nullptr, need, (const uint64_t*)sample, (uint64_t*)sorted, (size_t)m, (unsigned)begin_bit, (unsigned)end_bit, s));
-        PA_REQUIRE(need <= l.sample_temp_bytes, PA_ERR_DEVICE, "internal: sample sort scratch smaller than this bit range needs");
-        size_t have = l.sample_temp_bytes;
-        PA_HIP(rocprim::radix_sort_keys(t + l.sample_temp, have, (const uint64_t*)sample, (uint64_t*)sorted, (size_t)m, (unsigned)begin_bit, (unsigned)end_bit, s));
-        sp1 = Splitters{sorted, nd2 * kOversample};
-        sp2 = Splitters{sorted, kOversample};
-        sp_final = sp2;
+        sort_samples(kin, nullptr, 1, sorted1);
+        sp1 = Splitters{sorted1};
+        fb.s1 = sorted1;
     }
     // where the passes land: the last one (partition or LDS sort) in the output, the ones before alternate with the scratch pairs
     const bool two = bits2 > 0, sorting = rest > 0;
@@ -793,6 +804,11 @@ int launch_sort_pairs(const uint64_t* keys_in, const int32_t* rows_in, int32_t* 
     const u64* last_k = dst1_k;
     const i32* last_r = dst1_r;
     if (two) {
+        if (by_sample) {
+            sort_samples(dst1_k, offs_a, nd1, sorted2);
+            sp2 = Splitters{sorted2};
+            fb.s2 = sorted2;
+        }
         hipLaunchKernelGGL(k_sort_count, cap_b, 256, 0, s, (const u64*)dst1_k, (i64)n, (const i32*)tile_start, (const i32*)tile_rows, (const i32*)tile_bucket,
                            (const i32*)&ctl->tiles_b, cap_b, shift2, bits2, counts_b, sp2);
         hipLaunchKernelGGL(k_sort_scan_tiles, dim3(nd2, nd1), 64, 0, s, counts_b, cap_b, (const i32*)bucket_tiles, 0, nd2, totals_b);
@@ -817,7 +833,7 @@ int launch_sort_pairs(const uint64_t* keys_in, const int32_t* rows_in, int32_t* 
     int bits_per = 0;
     const int passes = lds_passes(rest, &bits_per);
     hipLaunchKernelGGL(k_sort_buckets, nd1 * nd2, 256, 0, s, last_k, last_r, kout, rows_out, final_offs, 0, begin_bit, rest, passes, bits_per, stage(last_place, 1),
-                       sp_final, nd1 * nd2);
+                       fb);
     PA_HIP(hipGetLastError());
     return PA_SORT_BUCKETS;
 }
