@@ -13,10 +13,15 @@
 //      same ballot ranking, ping-pong between two LDS copies; the bucket is read once and written once, in place of its final rows.
 // 2^24 pairs by 40 bits: 5 one-sweep passes of the library sort read and write the pairs 5 times (24 B per pair and pass); this reads
 // 8 + 24 + 8 + 24 + 24 and writes 12 + 12 + 12 bytes per pair.
-// Buckets are bit prefixes, so this is for keys that spread over their varying bits (row ids, hashes, uniform integers: what OR / AND
-// of the images leaves).  When a final bucket would not fit in LDS (skewed keys: exponent bits of doubles, few hot values in a wide
-// range) or the input is beyond 27 M pairs, rocPRIM's device radix sort does the whole job instead -- decided from the bucket sizes, which
-// are known on the device before the last pass; the partition passes already done are then wasted (0.2 ms at 2^24 pairs).
+// Bucket bounds: bit prefixes for keys that spread over their varying bits (row ids, hashes, uniform integers: what OR / AND of the images
+// leaves); for keys that crowd under few prefixes (images of doubles: the exponent; text) the caller says so and the bounds are every 16th
+// key (at least) of sorted samples -- 2048 keys of the input, then 2048 of every first-pass bucket, each sample sorted by the bucket-sort
+// kernel itself --, a digit is the number of bounds <= key, and a final bucket's LDS sort takes the bits in which its bounds differ.
+// Payload: up to four 4- / 8-byte columns ride along with the pairs (OrderBy's output channels): staged through the same LDS tile by the
+// partition passes, fetched from the bucket's window by the LDS sort -- sequential passes instead of a random gather by the sorted rows.
+// When a final bucket would not fit in LDS (prefix mode: crowded keys after all; sampled mode: one value filling a bucket) or the input is
+// beyond 27 M pairs (9.8 M by samples), rocPRIM's device radix sort does the whole job instead -- decided from the bucket sizes, which are
+// known on the device before the last pass; the partition passes already done are then wasted (0.2 ms at 2^24 pairs).
 #include <cstring>
 
 #include <rocprim/device/device_radix_sort.hpp>
