@@ -442,7 +442,11 @@ void FusedGen::emit_quad(const std::string (&args)[4])
 
 void FusedGen::emit_kernel(const std::string& name, int mode)
 {
-    src << "extern \"C\" __global__ __launch_bounds__(" << B << ") void PA_K(" << name << ")(PaFusedArgs a)\n{\n";
+    std::string occupancy;
+    if (brow) {  // (measurement switch: ask the register allocator for this many waves per SIMD)
+        if (const char* e = getenv("PRESTO_AMD_BROW_WAVES")) occupancy = " __attribute__((amdgpu_waves_per_eu(" + std::to_string(atoi(e)) + ")))";
+    }
+    src << "extern \"C\" __global__ __launch_bounds__(" << B << ")" << occupancy << " void PA_K(" << name << ")(PaFusedArgs a)\n{\n";
     if (variant == V_GLOBAL) global_kernel_begin();
     else if (variant == V_LDS) lds_kernel_begin();
     else if (variant == V_LDSP) ldsp_kernel_begin();
@@ -524,7 +528,24 @@ void FusedGen::page_loop()
 {
     std::string args[4];
     src << "    const i64 nq = a.vec ? (a.n >> 2) : 0;\n";
+    const std::string tail_rows = "    for (i64 r = (nq << 2) + t; r < a.n; r += T) {\n        pa_row(a, acc, true, (i32)r" + scalar_args(ri, layout) + ");" + flush + "\n    }\n";
+    bool two_loops = false;
     if (brow) {
+        int level = 3;
+        if (const char* e = getenv("PRESTO_AMD_BROW_PIPE")) level = atoi(e);  // (measurement switch: 0 = one quad at a time)
+        std::vector<VectorVar> vars;
+        const bool can = level > 0 && s.join && vector_load_vars(ri, layout, vars);
+        if (can && level < 3) {
+            brow_pipelined_loop(level);
+            src << tail_rows;
+            return;
+        }
+        if (can) {  // the software pipeline works on the key rank index; a lookup source without one takes the plain loop
+            src << "    if (a.jrank) {\n";
+            brow_pipelined_loop(level);
+            src << "    } else {\n";
+            two_loops = true;
+        }
         brow_wave_loop_head();
     }
     else {
@@ -533,7 +554,8 @@ void FusedGen::page_loop()
     emit_vector_loads(ri, layout, src, args);
     emit_quad(args);
     src << "       " << flush << "\n    }\n";
-    src << "    for (i64 r = (nq << 2) + t; r < a.n; r += T) {\n        pa_row(a, acc, true, (i32)r" << scalar_args(ri, layout) << ");" << flush << "\n    }\n";
+    if (two_loops) src << "    }\n";
+    src << tail_rows;
 }
 
 void FusedGen::table_counter_flush()

@@ -149,6 +149,7 @@ struct FusedGen {
     void brow_accumulate_row();
     void brow_kernel_begin();
     void brow_wave_loop_head();
+    bool brow_pipelined_loop(int level);
     void brow_kernel_end();
     void brow_keys_kernel();
 };

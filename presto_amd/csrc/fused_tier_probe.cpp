@@ -280,6 +280,108 @@ void FusedGen::brow_wave_loop_head()
            "    for (i64 q = gw * per + (threadIdx.x & 63); q < q1; q += 64) {\n";
 }
 
+// The BROW page loop as a software pipeline (round 4).  One iteration of the plain loop is a chain of dependent round trips -- the
+// quad's columns (HBM), the rank words of its keys (L2), the lazy channels of its matches (HBM again: a few scattered lines per wave
+// and iteration, but some lane matches in every iteration), the window in LDS -- and at four waves per SIMD the chain, not the
+// bandwidth, was the kernel's time: waves waited 77 % of their cycles (SQ_WAIT_ANY / SQ_WAVE_CYCLES) at 3.1 TB/s on Q3's lineitem pages.
+// Here a lane has four quads in flight, one per stage, and an iteration runs the stages youngest data last:
+//   S3  accumulates quad i - 2 (pa_post, pa_flush) -- its lazy channels were asked for an iteration ago;
+//   S2  reads the rank words of quad i - 1 (asked for an iteration ago) and asks for the lazy channels of its matches;
+//   S1  takes the columns of quad i (asked for an iteration ago), filters, and asks for the rank words of its keys;
+//   S0  asks for the columns of quad i + 1.
+// Every load in the loop is unconditional (a row without a match reads the lazy channels of the range's first row, a row that does
+// not probe reads rank word 0 -- one hot line each): loads come back in issue order and the compiler counts them, so each stage waits
+// for exactly what was issued an iteration ago and leaves the younger loads in flight.  Quads beyond the range are loaded from its
+// last quad and take part as rows the filter drops, so the loop has no prologue or epilogue: it just runs two iterations longer.
+// `level` 1: only the columns of the next quad are loaded ahead (the rows are accumulated in their own iteration).
+bool FusedGen::brow_pipelined_loop(int level)
+{
+    std::vector<VectorVar> vars;
+    if (!s.join || !vector_load_vars(ri, layout, vars)) return false;
+    auto lazy_vars = [&]() {
+        std::vector<std::string> names;
+        for (int c = 0; c < s.n_in; c++) {
+            if (!s.lazy_channel[c]) continue;
+            names.push_back("c" + std::to_string(c));
+            if (layout[c].nullable) names.push_back("cn" + std::to_string(c));
+        }
+        return names;
+    };
+    auto lazy_names_of = [&](const std::string& suffix) {
+        std::string names;
+        for (const std::string& n : lazy_vars()) names += ", " + n + suffix;
+        return names;
+    };
+    src << "    const i64 gw = (i64)blockIdx.x * " << (B / 64) << " + (threadIdx.x >> 6), nwv = (i64)gridDim.x * " << (B / 64) << ";\n"
+           "    const i64 per = (((nq + nwv - 1) / nwv) + 63) & ~(i64)63;\n"
+           "    const i64 q1 = (gw + 1) * per < nq ? (gw + 1) * per : nq;\n"
+           "    if (gw * per < q1) {\n"   // (wave-uniform)
+           "      i64 q = gw * per + (threadIdx.x & 63);\n"
+           "      const i64 qf = q < q1 ? q : q1 - 1;\n";
+    for (const VectorVar& v : vars) src << "      " << v.type << " n" << v.name << " = " << v.load("qf") << ";\n";
+    if (level < 3) {
+        src << "      for (; q < q1; q += 64) {\n";
+        for (const VectorVar& v : vars) src << "        const " << v.type << " " << v.name << " = n" << v.name << ";\n";
+        src << "        bool js[4]; u64 jk[4]; i32 jb[4];\n";
+        for (int r = 0; r < 4; r++) {
+            src << "        pa_pre(a, true, (i32)(4 * q + " << r << ")" << vector_var_args(ri, layout, "", r) << ", js[" << r << "], jk[" << r << "]);\n";
+        }
+        src << "        {\n          const i64 qn = q + 64 < q1 ? q + 64 : q;\n";
+        for (const VectorVar& v : vars) src << "          n" << v.name << " = " << v.load("qn") << ";\n";
+        src << "        }\n        pa_join_probe4(a, js, jk, jb);\n";
+        for (int r = 0; r < 4; r++) src << "        " << lazy_declare("_" + std::to_string(r)) << "\n";
+        for (int r = 0; r < 4; r++) {
+            const std::string R = std::to_string(r);
+            src << "        if (jb[" << R << "] >= 0) { " << lazy_assign("_" + R, "4 * q + " + R) << "}\n";
+        }
+        for (int r = 0; r < 4; r++) {
+            const std::string R = std::to_string(r);
+            src << "        pa_post(a, acc, " << R << ", (i32)(4 * q + " << R << "), jb[" << R << "]" << vector_var_args(ri, layout, "", r) << lazy_names_of("_" + R) << ");\n";
+        }
+        src << "        pa_flush(a, acc, true);\n      }\n    }\n";
+        return true;
+    }
+    // state between the stages: d = the quad whose rank words are in flight, p = the quad whose lazy channels are
+    src << "      const i64 n_it = (q1 - gw * per + 63) >> 6;\n"
+           "      const i64 rs = 4 * (gw * per);\n"   // (the row whose lazy channels stand in for rows without a match)
+           "      bool djs[4] = {false, false, false, false}; u64 djk[4] = {0ULL, 0ULL, 0ULL, 0ULL};\n"
+           "      PaRank4 dw; dw.lo = pa_u32x4{0u, 0u, 0u, 0u}; dw.hi = dw.lo; dw.below = dw.lo;\n"
+           "      i64 dq = qf, pq = qf; i32 pjb0 = -1, pjb1 = -1, pjb2 = -1, pjb3 = -1;\n";
+    for (const VectorVar& v : vars) src << "      " << v.type << " d" << v.name << " = n" << v.name << ", p" << v.name << " = n" << v.name << ";\n";
+    for (int r = 0; r < 4; r++) src << "      " << lazy_declare("_p" + std::to_string(r)) << "\n";
+    src << "      for (i64 it = 0; it < n_it + 2; it++, q += 64) {\n";
+    // S3
+    for (int r = 0; r < 4; r++) {
+        const std::string R = std::to_string(r);
+        src << "        pa_post(a, acc, " << R << ", (i32)(4 * pq + " << R << "), pjb" << R << vector_var_args(ri, layout, "p", r) << lazy_names_of("_p" + R) << ");\n";
+    }
+    src << "        pa_flush(a, acc, true);\n";
+    // S2
+    src << "        {\n          i32 jb[4];\n          pa_join_rank4_read(a, djs, djk, dw, jb);\n"
+           "          pjb0 = jb[0]; pjb1 = jb[1]; pjb2 = jb[2]; pjb3 = jb[3]; pq = dq;\n";
+    for (const VectorVar& v : vars) src << "          p" << v.name << " = d" << v.name << ";\n";
+    for (int r = 0; r < 4; r++) {
+        const std::string R = std::to_string(r);
+        src << "          " << lazy_assign("_p" + R, "(pjb" + R + " >= 0 ? 4 * pq + " + R + " : rs)") << "\n";
+    }
+    src << "        }\n";
+    // S1
+    src << "        {\n";
+    for (const VectorVar& v : vars) src << "          const " << v.type << " " << v.name << " = n" << v.name << ";\n";
+    src << "          const bool live = q < q1;\n";
+    for (int r = 0; r < 4; r++) {
+        src << "          pa_pre(a, live, (i32)(4 * q + " << r << ")" << vector_var_args(ri, layout, "", r) << ", djs[" << r << "], djk[" << r << "]);\n";
+    }
+    src << "          pa_join_rank4_issue(a, djs, djk, dw);\n          dq = live ? q : qf;\n";
+    for (const VectorVar& v : vars) src << "          d" << v.name << " = " << v.name << ";\n";
+    src << "        }\n";
+    // S0
+    src << "        {\n          const i64 qn = q + 64 < q1 ? q + 64 : q1 - 1;\n";
+    for (const VectorVar& v : vars) src << "          n" << v.name << " = " << v.load("qn") << ";\n";
+    src << "        }\n      }\n    }\n";
+    return true;
+}
+
 void FusedGen::brow_kernel_end()
 {
     src << "    pa_drain(a, acc, pa_sfill[threadIdx.x >> 6]);\n";  // (all lanes are back together behind the row loops)

@@ -404,6 +404,49 @@ __device__ __forceinline__ i32 pa_join_probe_keyed(const A& a, const u64 v)
     }
     return pa_join_probe_from(a, v, pa_join_home(a, v));
 }
+// The key rank index in two halves, for row loops that keep several quads in flight: pa_join_rank4_issue asks for the rank words of
+// the four keys and pa_join_rank4_read, an iteration later, turns them into build positions.  The loads are UNCONDITIONAL (a row that
+// does not probe reads word 0): a load inside a divergent branch may or may not have been issued, so the compiler could no longer count
+// how many younger loads may stay in flight when it waits for an older one, and would wait for all of them.
+struct PaRank4 {
+    pa_u32x4 lo, hi, below;   // per row of the quad: the 64 key bits of the word and the build keys below it
+                              // (vectors, not arrays: the words live in registers across the loop's back edge)
+};
+template <class A>
+__device__ __forceinline__ void pa_join_rank4_issue(const A& a, const bool (&s)[4], const u64 (&k)[4], PaRank4& w)
+{
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const bool dup = r > 0 && s[r] && s[r - 1] && k[r] == k[r - 1];
+        const u64 d = (u64)((i64)k[r] - a.jmin);
+        const u32* p = (const u32*)&a.jrank[(s[r] && !dup && d <= a.jrange) ? d >> 6 : 0ULL];
+        w.lo[r] = p[0];
+        w.hi[r] = p[1];
+        w.below[r] = p[2];
+    }
+}
+template <class A>
+__device__ __forceinline__ void pa_join_rank4_read(const A& a, const bool (&s)[4], const u64 (&k)[4], const PaRank4& w, i32 (&jb)[4])
+{
+    bool dup[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        dup[r] = r > 0 && s[r] && s[r - 1] && k[r] == k[r - 1];
+        const u64 d = (u64)((i64)k[r] - a.jmin);
+        jb[r] = (s[r] && !dup[r] && d <= a.jrange) ? pa_join_rank(pa_u32x4{w.lo[r], w.hi[r], w.below[r], 0u}, d) : -1;
+    }
+    if (a.jrank_rows) {
+        i32 p[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) p[r] = jb[r] >= 0 ? a.jrank_rows[jb[r]] : -1;
+#pragma unroll
+        for (int r = 0; r < 4; r++) jb[r] = p[r];
+    }
+#pragma unroll
+    for (int r = 1; r < 4; r++) {
+        if (dup[r]) jb[r] = jb[r - 1];
+    }
+}
 // The same for the four consecutive rows a thread of the vector loops holds, stage by stage: the four bitmap words, then the four
 // pairs of slots, are loaded back to back and waited for once.  Row by row, a row costs two to three DEPENDENT trips to HBM
 // (bitmap word, slot, then the columns only matches read), and a wave of the row loop is then bound by latency, not bandwidth:

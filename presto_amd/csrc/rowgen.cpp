@@ -129,6 +129,63 @@ void emit_vector_loads(const RowInputs& s, const std::vector<ChannelLayout>& lay
     o << post.str();
 }
 
+std::string VectorVar::load(const std::string& q) const
+{
+    const std::string idx = per_quad == 2 ? "2 * (" + q + ")" + (half ? " + 1" : "") : "(" + q + ")";
+    const std::string ld = "((const " + type + "*)" + array + ")[" + idx + "]";
+    return maybe_null ? "(" + array + " ? " + ld + " : 0u)" : ld;
+}
+
+bool vector_load_vars(const RowInputs& s, const std::vector<ChannelLayout>& layout, std::vector<VectorVar>& vars, const ColumnNames& nm)
+{
+    vars.clear();
+    for (int c = 0; c < s.n_in; c++) {
+        if (!s.used[c]) continue;
+        const std::string C = std::to_string(c);
+        switch (layout[c].type) {
+            case PA_BIGINT:
+            case PA_DECIMAL:
+                vars.push_back(VectorVar{"pa_i64x2", "A" + C, nm.v(c), 2, 0, false});
+                vars.push_back(VectorVar{"pa_i64x2", "B" + C, nm.v(c), 2, 1, false});
+                break;
+            case PA_DOUBLE:
+                vars.push_back(VectorVar{"pa_f64x2", "A" + C, nm.v(c), 2, 0, false});
+                vars.push_back(VectorVar{"pa_f64x2", "B" + C, nm.v(c), 2, 1, false});
+                break;
+            case PA_INTEGER:
+            case PA_DATE: vars.push_back(VectorVar{"pa_i32x4", "A" + C, nm.v(c), 1, 0, false}); break;
+            case PA_REAL: vars.push_back(VectorVar{"pa_f32x4", "A" + C, nm.v(c), 1, 0, false}); break;
+            case PA_BOOLEAN: vars.push_back(VectorVar{"u32", "A" + C, nm.v(c), 1, 0, false}); break;
+            default: return false;
+        }
+        if (layout[c].nullable) vars.push_back(VectorVar{"u32", "N" + C, nm.nl(c), 1, 0, true});
+    }
+    return true;
+}
+
+// (the argument list emit_vector_loads builds for row r of the quad, over variables with a prefix)
+std::string vector_var_args(const RowInputs& s, const std::vector<ChannelLayout>& layout, const std::string& P, int r)
+{
+    static const char* xyzw[4] = {"x", "y", "z", "w"};
+    std::string a;
+    for (int c = 0; c < s.n_in; c++) {
+        if (!s.used[c]) continue;
+        const std::string C = std::to_string(c);
+        switch (layout[c].type) {
+            case PA_BIGINT:
+            case PA_DECIMAL:
+            case PA_DOUBLE: a += ", " + P + std::string(r < 2 ? "A" : "B") + C + "." + xyzw[r & 1]; break;
+            case PA_INTEGER:
+            case PA_DATE: a += ", (i64)" + P + "A" + C + "." + xyzw[r]; break;
+            case PA_REAL: a += ", " + P + "A" + C + "." + xyzw[r]; break;
+            case PA_BOOLEAN: a += ", ((" + P + "A" + C + " >> " + std::to_string(8 * r) + ") & 0xffu) != 0u"; break;
+            default: throw Error(PA_ERR_NOT_SUPPORTED, "column type not supported on device");
+        }
+        if (layout[c].nullable) a += ", ((" + P + "N" + C + " >> " + std::to_string(8 * r) + ") & 0xffu) != 0u";
+    }
+    return a;
+}
+
 std::string scalar_loads(const RowInputs& s, const std::vector<ChannelLayout>& layout, const std::string& row, const std::string& suffix, std::ostringstream& decl,
                          const ColumnNames& nm)
 {

@@ -33,6 +33,18 @@ void emit_prologue(const RowInputs& s, const std::vector<ChannelLayout>& layout,
 // vector loads of row quad q (into `o`) and the 4 argument lists of the per-row calls
 void emit_vector_loads(const RowInputs& s, const std::vector<ChannelLayout>& layout, std::ostringstream& o, std::string args[4],
                        const ColumnNames& names = ColumnNames());
+// The vector loads of a quad as a list of variables (type, name, the load of quad `q` as an expression) and the argument lists over
+// variables named <prefix><name>, for loops that keep several quads in flight (the next one being loaded, the current one, the one
+// whose rows are still to be accumulated).  false: some used channel does not load that simply (VARCHAR, long DECIMAL).
+struct VectorVar {
+    std::string type, name, array;   // load of quad q: ((const type*)array)[index(q)], guarded when the array may be null
+    int per_quad;                    // 2: the variable holds half a quad (index 2 q + half), 1: the whole quad
+    int half;
+    bool maybe_null;                 // (a valueIsNull array that a page may leave out)
+    std::string load(const std::string& q) const;
+};
+bool vector_load_vars(const RowInputs& s, const std::vector<ChannelLayout>& layout, std::vector<VectorVar>& vars, const ColumnNames& names = ColumnNames());
+std::string vector_var_args(const RowInputs& s, const std::vector<ChannelLayout>& layout, const std::string& prefix, int r);
 // the same with the loads of the row's values named: declarations of locals <name><suffix> go to `decl` (so that the loads of several
 // rows can be issued before the first row is worked on), the returned argument list names them
 std::string scalar_loads(const RowInputs& s, const std::vector<ChannelLayout>& layout, const std::string& row, const std::string& suffix,
