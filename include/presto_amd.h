@@ -73,7 +73,11 @@ typedef enum pa_type {
                       * top bit (sign-magnitude, as the reference's Slice holds it).  On the device path: a value inside expressions
                       * (products and sums of short decimals), the result of sum / avg over decimals, the sum half of their PARTIAL
                       * state, an input of sum / avg / count, an operand of comparisons with its own type.  Not a key, not a min / max
-                      * input, not divided or rescaled down (PA_ERR_NOT_SUPPORTED) */
+                      * input, not divided or rescaled down (PA_ERR_NOT_SUPPORTED).  Overflow: the reference's
+                      * LongDecimalWithOverflow(AndLong)State carries an overflow counter through Step.PARTIAL, so a partial sum may pass
+                      * 10^38 and come back (and avg over such sums is legal, DecimalAverageAggregation.average); the device state has no
+                      * such counter and raises NUMERIC_VALUE_OUT_OF_RANGE as soon as a partial sum leaves +-10^38: the planner keeps
+                      * sum / avg over DECIMAL(38, s) inputs whose partial sums can get there on the reference operator */
 } pa_type;
 #define PA_DECIMAL_PARAM(precision, scale) (((precision) << 8) | (scale))
 #define PA_DECIMAL_PRECISION(param) (((param) >> 8) & 0xff)

@@ -210,11 +210,13 @@ int main(int argc, char** argv)
     };
     auto cmp = [](int32_t op, Expr a, Expr b) { return call(op, PA_BOOLEAN, {a, b}); };
     FilterProject customer_fp({PA_BIGINT, PA_VARCHAR}, cmp(PA_OP_EQUAL, field(1, PA_VARCHAR), varchar("BUILDING")), {field(0, PA_BIGINT)}, stream);
+    customer_fp.desc.output_handover = 1;  // (the build sides leave their FilterAndProject with their buffers: the HashBuilders read them in place)
     HashBuilder build1({PA_BIGINT}, {0}, {}, stream);
     const std::vector<int32_t> orders_types = {PA_BIGINT, PA_BIGINT, PA_DATE, PA_INTEGER};
     FilterProject orders_fp(orders_types, cmp(PA_OP_LESS_THAN, field(2, PA_DATE), constantLong(9204, PA_DATE)),
                             {field(0, PA_BIGINT), field(1, PA_BIGINT), field(2, PA_DATE), field(3, PA_INTEGER)}, stream);
     LookupJoin orders_join(orders_types, {1}, {0, 2, 3}, stream);
+    orders_fp.desc.output_handover = 1;
     pa_fused_join_desc orders_desc{};
     orders_desc.filter_project = orders_fp.desc;
     orders_desc.join = orders_join.desc;

@@ -337,3 +337,23 @@ def test_operator_chain_on_an_owned_stream_with_a_large_duplicate_build_side(gpu
     for _ in range(3):
         rows = fused_rows(probe, build, [1, 2], [0, 1, 2, 3], joined_types, [0], aggs, expected_groups=200_000)
         rows_equal_ignore_order(rows, expected, rel=1e-9)
+
+
+@pytest.mark.parametrize("n", [3, 255, 1021, 262147])
+@pytest.mark.parametrize("clustered", [True, False])
+def test_pipelined_probe_loop_equals_the_plain_loop(gpu, oracle, n, clustered, monkeypatch):
+    """The build-row tier's page loop as a software pipeline (four quads in flight per lane, the default over a key rank index) against
+    the plain loop (PRESTO_AMD_BROW_PIPE=0) and the loop that only loads the next quad's columns ahead (=1), on pages whose row counts
+    leave partial quads, partial waves and ranges shorter than the pipeline is deep -- and against the oracle."""
+    rng = np.random.default_rng(n)
+    key_range = max(2 * n, 64)
+    keys = np.sort(rng.permutation(key_range)[: key_range // 2])
+    build = [build_page(rng, keys, null_keys=False)]
+    probe = probe_pages(rng, 3, n, key_range, clustered=clustered)
+    group_by, aggs = [0, 4, 5], AGGS
+    expected, jt = oracle_rows(oracle, probe, build, [1, 2], [0, 1, 2, 3], group_by, aggs)
+    for level in (None, "0", "1"):
+        if level is not None:
+            monkeypatch.setenv("PRESTO_AMD_BROW_PIPE", level)
+        rows = fused_rows(probe, build, [1, 2], [0, 1, 2, 3], jt, group_by, aggs, expected_groups=len(keys))
+        rows_equal_ignore_order(rows, expected, rel=1e-9)
