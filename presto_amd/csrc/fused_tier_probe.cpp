@@ -2,7 +2,8 @@
 // (JoinProbe.getCurrentJoinPosition, JoinProbe.java:87-117; DefaultPageJoiner.joinCurrentPosition, DefaultPageJoiner.java:236-320)
 // in front of any tier -- pa_pre (filter + probe key), the keyed probe (four per quad: pa_join_probe4), pa_post (build columns at
 // the match, lazy channels, accumulation) -- and BROW, the tier whose group IS the build row: accumulators indexed by build
-// position, no hashing, a per-wave window of build positions in LDS in front of the table.
+// position, no hashing, a per-wave window of build positions in LDS in front of the table.  BROW's page loop over a key rank index is
+// a four-stage software pipeline (brow_pipelined_loop): columns, rank words, lazy channels and accumulation of four quads in flight.
 #include "decimal_host.hpp"
 #include "fused_codegen.hpp"
 #include "scan_kernels.hpp"
