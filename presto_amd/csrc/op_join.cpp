@@ -215,8 +215,26 @@ public:
             const int32_t dups = build_key_slots(bk.col[0], n, slots, s);
             // chains exist only when some key has several rows: two passes over the rows and the table that unique keys -- the build
             // side of a primary-key join -- do without
-            if (dups && !links_built_) launch_join_keyed_links(n, ls_->key_slots.as<JoinKeySlot>(), ls_->probe_mask, ls_->slot_of.as<int32_t>(), ls_->links.as<int32_t>(), s);
-            keyed_dups = dups != 0;
+            if (dups > 0 && !links_built_) launch_join_keyed_links(n, ls_->key_slots.as<JoinKeySlot>(), ls_->probe_mask, ls_->slot_of.as<int32_t>(), ls_->links.as<int32_t>(), s);
+            keyed_dups = dups > 0;   // (-1: a partitioned build is in flight, settle_partitioned_build reads its verdict)
+        };
+        // The partitioned build leaves its verdict in the control words the read-back below fetches anyway -- [1] some key has
+        // several rows, [2] a partition too full or a chain too long: the table the other way -- so it costs no round trip of its
+        // own; its temporaries live until then.
+        auto settle_partitioned_build = [&](int32_t* ctl) {
+            if (!part_pending_) return;
+            part_pending_ = false;
+            part_temps_.clear();  // (the stream has drained)
+            if (ctl[2] != 0) {
+                ls_->probe_wrap = ls_->probe_mask;
+                const int32_t dups = build_key_slots_plain(bk.col[0], n, ls_->key_slots.as<JoinKeySlot>(), s);
+                if (dups) launch_join_keyed_links(n, ls_->key_slots.as<JoinKeySlot>(), ls_->probe_mask, ls_->slot_of.as<int32_t>(), ls_->links.as<int32_t>(), s);
+                keyed_dups = dups != 0;
+                int32_t again[1] = {0};
+                read_back(again, ctl_, 4, s);
+                ctl[0] = again[0];
+            }
+            else keyed_dups = ctl[1] != 0;
         };
         timer.begin(s);
         if (ls_->keyed) {
@@ -239,11 +257,13 @@ public:
         timer.end(s);
         int32_t ctl[6] = {0, 0, 0, 0, 0, 0};  // [0] error word, [4] distinct build keys, [5] some build row not at its key's rank
         read_back(ctl, ctl_, sizeof ctl, s);
+        settle_partitioned_build(ctl);
         if (rank_pending && !finish_rank_index(n, ctl[4], ctl[5] != 0)) {
             timer.begin(s);
             build_table();
             timer.end(s);
-            read_back(ctl, ctl_, 4, s);
+            read_back(ctl, ctl_, 12, s);
+            settle_partitioned_build(ctl);
         }
         const int32_t err = ctl[0];
         ls_->has_duplicates = !ls_->keyed || keyed_dups;
@@ -267,13 +287,18 @@ public:
         // (not with a $hashvalue channel: the partitioned build places rows by the hash it computes from the key itself, the
         // probe by the channel's value -- the two must be the same function)
         if (raw == nullptr && n >= (1 << 20) && partitions >= 2 && partitions <= 4096 && !getenv("PRESTO_AMD_NO_PARTITIONED_BUILD")) {
-            const int built = partitioned_build(key, n, table, (int32_t)partitions, s);
-            if (built) {
-                ls_->probe_wrap = (uint32_t)kJoinPartSlots - 1u;
-                links_built_ = true;  // (chains of keys with several rows included)
-                return built == 2 ? 1 : 0;
-            }
+            partitioned_build(key, n, table, (int32_t)partitions, s);
+            ls_->probe_wrap = (uint32_t)kJoinPartSlots - 1u;
+            links_built_ = true;  // (chains of keys with several rows included)
+            return -1;            // the verdict travels with the caller's read-back of the control words
         }
+        return build_key_slots_plain(key, n, table, s);
+    }
+    // slot by slot, straight from the build rows; returns whether some key has several rows (one round trip)
+    int32_t build_key_slots_plain(const JoinCol& key, int32_t n, JoinKeySlot* table, hipStream_t s)
+    {
+        const int64_t* raw = nullptr;
+        if (ls_->hash_channel >= 0 && n > 0) raw = ls_->cols[ls_->hash_channel].values.as<int64_t>();
         links_built_ = false;
         int32_t dups = 0;
         PA_HIP(hipMemsetAsync(ctl_ + 1, 0, 8, s));
@@ -331,11 +356,14 @@ public:
         return true;
     }
 
-    // != 0: `table` holds the keyed probe-side table, built partition by partition -- 1: no key has several rows (links stay -1),
-    // 2: some do, and their chains (`links`, the slots' `next`) were built in the same pass
-    int partitioned_build(const JoinCol& key, int32_t n, JoinKeySlot* table, int32_t partitions, hipStream_t s)
+    // Enqueues the keyed probe-side table built partition by partition.  ctl_[1] != 0: some key has several rows -- their chains
+    // (`links`, the slots' `next`) were built in the same pass (otherwise links stay -1); ctl_[2] != 0: not built (see the kernel)
+    void partitioned_build(const JoinCol& key, int32_t n, JoinKeySlot* table, int32_t partitions, hipStream_t s)
     {
-        DevBuf part, keys_in, keys_out, rows_in, rows_out, counts, first, temp;
+        part_temps_.clear();
+        part_temps_.resize(8);
+        DevBuf &part = part_temps_[0], &keys_in = part_temps_[1], &keys_out = part_temps_[2], &rows_in = part_temps_[3], &rows_out = part_temps_[4],
+               &counts = part_temps_[5], &first = part_temps_[6], &temp = part_temps_[7];
         int32_t* pid = static_cast<int32_t*>(part.ensure((size_t)n * 4));
         uint64_t* kin = static_cast<uint64_t*>(keys_in.ensure((size_t)n * 8));
         int32_t* rin = static_cast<int32_t*>(rows_in.ensure((size_t)n * 4));
@@ -356,10 +384,7 @@ public:
         PA_HIP(hipMemsetAsync(ctl_ + 1, 0, 8, s));
         launch_fill_i32(ls_->links.as<int32_t>(), -1, n, s);
         launch_join_part_build(keys_out.as<uint64_t>(), rows_out.as<int32_t>(), fst, partitions, ls_->probe_mask, table, ls_->links.as<int32_t>(), ctl_, s);
-        int32_t flags[2] = {0, 0};
-        read_back(flags, ctl_ + 1, 8, s);  // (waits: the temporaries above return to the pool)
-        if (flags[1] != 0) return 0;
-        return flags[0] != 0 ? 2 : 1;
+        part_pending_ = true;  // ctl_[1]: some key has several rows; ctl_[2]: start over the other way (finish() reads both)
     }
 
     void compute_raw_hash(const JoinKeys& bk, int32_t n, hipStream_t s) { fill_raw_hash(*ls_, bk, n, s); }
@@ -442,6 +467,8 @@ private:
     bool keys_ascending_ = false;  // no build key is smaller than the key of the row before it (build_key_bitmap)
     bool duplicates_certain_ = false;  // fewer key values between min and max than rows (build_key_bitmap)
     bool links_built_ = false;  // the table build left the chains of keys with several rows behind (the partitioned build does)
+    bool part_pending_ = false; // a partitioned build is in flight: its verdict is in ctl_[1..2]
+    std::vector<DevBuf> part_temps_;  // its temporaries, released once the stream has drained
     int32_t pairs_ = 0, pair_partitions_ = 0;
     int pair_shift_ = 0;
     int32_t* ctl_ = nullptr;
