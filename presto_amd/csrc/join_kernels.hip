@@ -375,23 +375,31 @@ __global__ __launch_bounds__(1024) void k_join_part_build(const u64* __restrict_
         tab[i] = e;
     }
     if (threadIdx.x == 0) any_dup = 0;
-    __syncthreads();
     const i64 b0 = first[blockIdx.x], b1 = first[blockIdx.x + 1];
     i32 my_p[kJoinPartRowsPerThread];
+    u64 my_v[kJoinPartRowsPerThread];
     u32 my_slot[kJoinPartRowsPerThread];
+    // the partition's rows first, all rounds of loads in flight together (while the table above is being cleared): round by round,
+    // a workgroup -- the only one its CU holds, the table takes the LDS -- paid seven HBM round trips one after the other
+    const bool fits = b1 - b0 <= (i64)kJoinPartRowsMax;
 #pragma unroll
-    for (int r = 0; r < kJoinPartRowsPerThread; r++) my_p[r] = -1;
-    if (b1 - b0 > (i64)kJoinPartRowsMax) {
+    for (int r = 0; r < kJoinPartRowsPerThread; r++) {
+        const i64 i = b0 + (i64)r * 1024 + threadIdx.x;
+        const bool in = fits && i < b1;
+        my_p[r] = in ? rows[i] : -1;
+        my_v[r] = in ? keys[i] : 0ULL;
+    }
+    __syncthreads();
+    if (!fits) {
         if (threadIdx.x == 0) err[2] = 1;
     }
     else {
 #pragma unroll
         for (int r = 0; r < kJoinPartRowsPerThread; r++) {
-            const i64 i = b0 + (i64)r * 1024 + threadIdx.x;
             if (b0 + (i64)r * 1024 >= b1) break;  // (uniform: whole rounds of 1024 rows)
-            const i32 p = i < b1 ? rows[i] : -1;
+            const i32 p = my_p[r];
             bool pending = p >= 0;
-            const u64 v = i < b1 ? keys[i] : 0ULL;
+            const u64 v = my_v[r];
             u32 pos = (u32)pa_murmur3_fmix((u64)pa_hash_bigint((i64)v)) & lmask;   // (home & lmask: the partition is the slot's upper bits)
             while (__ballot(pending) != 0ULL) {  // same claim / publish protocol as k_join_keyed_build, on LDS
                 if (pending) {
@@ -416,7 +424,6 @@ __global__ __launch_bounds__(1024) void k_join_part_build(const u64* __restrict_
                     }
                 }
             }
-            my_p[r] = p;
             my_slot[r] = pos;
         }
     }
