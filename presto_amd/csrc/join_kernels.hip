@@ -253,7 +253,7 @@ __global__ __launch_bounds__(256) void k_join_key_slots_clear(JoinKeySlot* __res
         JoinKeySlot s;
         s.key = 0ULL;
         s.head = -1;
-        s.next = -1;
+        s.count = 0;
         slots[i] = s;
     }
 }
@@ -266,7 +266,9 @@ __global__ __launch_bounds__(256) void k_join_key_slots(const i32* __restrict__ 
         u32 pos = (u32)pa_murmur3_fmix((u64)raw_hash[p]) & mask;
         while (atomicCAS(&slots[pos].head, -1, p) != -1) pos = (pos + 1) & mask;  // load <= 1/2: a free slot exists
         slots[pos].key = join_key_bits(build_key, p);
-        slots[pos].next = links[p];
+        i32 c = 1;
+        for (i32 j = links[p]; j != -1; j = links[j]) c++;
+        slots[pos].count = c;
     }
 }
 
@@ -371,7 +373,7 @@ __global__ __launch_bounds__(1024) void k_join_part_build(const u64* __restrict_
         JoinKeySlot e;
         e.key = 0ULL;
         e.head = -1;
-        e.next = -1;
+        e.count = 0;
         tab[i] = e;
     }
     if (threadIdx.x == 0) any_dup = 0;
@@ -408,6 +410,7 @@ __global__ __launch_bounds__(1024) void k_join_part_build(const u64* __restrict_
                         i32 expected = -1;
                         if (__hip_atomic_compare_exchange_strong(&tab[pos].head, &expected, kSlotBusy, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
                             __hip_atomic_store(&tab[pos].key, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            tab[pos].count = 1;  // (a partition without a key on several rows leaves as it is now)
                             __hip_atomic_store(&tab[pos].head, p, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
                             pending = false;
                         }
@@ -431,15 +434,18 @@ __global__ __launch_bounds__(1024) void k_join_part_build(const u64* __restrict_
     if (any_dup) {  // (uniform: LDS flag behind a barrier)
         if (threadIdx.x == 0) err[1] = 1;
         bool linked[kJoinPartRowsPerThread];
-        // the head of every chain is known (the slot's maximum): it is the first tail; tab[slot].next names the tail's local row
+        int depth[kJoinPartRowsPerThread];  // place of the row on its chain: 0 = the head
+        // the head of every chain is known (the slot's maximum): it is the first tail; while the chains are put together
+        // tab[slot].count names the tail's local row (the chain lengths are written when they are done)
 #pragma unroll
         for (int r = 0; r < kJoinPartRowsPerThread; r++) {
             linked[r] = true;
+            depth[r] = 0;
             if (my_p[r] < 0) continue;
             const int li = r * 1024 + (int)threadIdx.x;
             lnext[li] = -1;
             linked[r] = tab[my_slot[r]].head == my_p[r];
-            if (linked[r]) tab[my_slot[r]].next = li;
+            if (linked[r]) tab[my_slot[r]].count = li;
         }
         __syncthreads();
         int round = 0;
@@ -449,7 +455,7 @@ __global__ __launch_bounds__(1024) void k_join_part_build(const u64* __restrict_
 #pragma unroll
             for (int r = 0; r < kJoinPartRowsPerThread; r++) {
                 if (linked[r]) continue;
-                __hip_atomic_fetch_max(&lnext[tab[my_slot[r]].next], my_p[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_max(&lnext[tab[my_slot[r]].count], my_p[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 more = 1;
             }
             __syncthreads();
@@ -457,19 +463,20 @@ __global__ __launch_bounds__(1024) void k_join_part_build(const u64* __restrict_
             bool tail_now[kJoinPartRowsPerThread];
 #pragma unroll
             for (int r = 0; r < kJoinPartRowsPerThread; r++) {
-                tail_now[r] = !linked[r] && lnext[tab[my_slot[r]].next] == my_p[r];
+                tail_now[r] = !linked[r] && lnext[tab[my_slot[r]].count] == my_p[r];
             }
             __syncthreads();  // (every row has read its chain's tail before any tail moves)
 #pragma unroll
             for (int r = 0; r < kJoinPartRowsPerThread; r++) {
                 if (!tail_now[r]) continue;
                 linked[r] = true;
-                tab[my_slot[r]].next = r * 1024 + (int)threadIdx.x;
+                depth[r] = round + 1;
+                tab[my_slot[r]].count = r * 1024 + (int)threadIdx.x;
             }
             __syncthreads();
         }
         if (round == kJoinPartChainRounds && threadIdx.x == 0) err[2] = 1;  // a key with more rows than that: the caller's other way
-        // the links leave for HBM; the slot keeps its head's link (JoinKeySlot::next)
+        // the links leave for HBM; the slot gets its chain's length (JoinKeySlot::count): the place of its last row + 1
 #pragma unroll
         for (int r = 0; r < kJoinPartRowsPerThread; r++) {
             if (my_p[r] >= 0) links[my_p[r]] = lnext[r * 1024 + (int)threadIdx.x];
@@ -477,7 +484,12 @@ __global__ __launch_bounds__(1024) void k_join_part_build(const u64* __restrict_
         __syncthreads();
 #pragma unroll
         for (int r = 0; r < kJoinPartRowsPerThread; r++) {
-            if (my_p[r] >= 0 && tab[my_slot[r]].head == my_p[r]) tab[my_slot[r]].next = lnext[r * 1024 + (int)threadIdx.x];
+            if (my_p[r] >= 0 && depth[r] == 0) tab[my_slot[r]].count = 1;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < kJoinPartRowsPerThread; r++) {
+            if (my_p[r] >= 0 && depth[r] > 0) __hip_atomic_fetch_max(&tab[my_slot[r]].count, depth[r] + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         __syncthreads();
     }
@@ -511,7 +523,10 @@ __global__ __launch_bounds__(256) void k_join_keyed_next(JoinKeySlot* __restrict
 {
     for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < size; i += (i64)gridDim.x * 256) {
         const i32 h = slots[i].head;
-        if (h >= 0) slots[i].next = links[h];
+        if (h < 0) continue;
+        i32 c = 1;
+        for (i32 j = links[h]; j != -1; j = links[j]) c++;
+        slots[i].count = c;
     }
 }
 
@@ -792,7 +807,7 @@ __global__ __launch_bounds__(256) void k_join_probe_count_keyed(JoinCol probe_ke
     i64 mine = 0;  // this thread's output rows: the page's total is summed on the way (one atomic per wave), not by a pass of its own
     for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < n_probe; i += (i64)gridDim.x * 256) {
         const i32 r = (i32)i;
-        i32 h = -1, nxt = -1;
+        i32 h = -1, rows_of_key = 0;
         bool may_match = !jcol_is_null(probe_key, r);  // JoinProbe.java:89-91
         if (rank.words) {  // (no duplicate keys: the key's rank names its only build row)
             if (may_match) {
@@ -828,7 +843,7 @@ __global__ __launch_bounds__(256) void k_join_probe_count_keyed(JoinCol probe_ke
                     if (cur == -1) done = true;
                     else if ((((u64)q[k].y << 32) | (u64)q[k].x) == v) {
                         h = cur;
-                        nxt = (i32)q[k].w;
+                        rows_of_key = (i32)q[k].w;
                         done = true;
                     }
                 }
@@ -838,12 +853,7 @@ __global__ __launch_bounds__(256) void k_join_probe_count_keyed(JoinCol probe_ke
         }
         head[r] = h;
         i32 c = 0;
-        if (h != -1) {
-            c = 1;
-            if (!(flags & 2)) {
-                for (i32 j = nxt; j != -1; j = links[j]) c++;
-            }
-        }
+        if (h != -1) c = (flags & 2) ? 1 : (rank.words ? 1 : rows_of_key);  // (the slot knows its chain's length: no walk here)
         counts[r] = (c == 0 && (flags & 1)) ? 1 : c;  // DefaultPageJoiner.outerJoinCurrentPosition: one NULL-extended row
         mine += (c == 0 && (flags & 1)) ? 1 : c;
     }
@@ -1014,6 +1024,9 @@ struct ProbeTable {
 };
 // tile_totals (may be null): the output rows of every tile of kJoinProbeTileRows probe rows -- with them the pairs are emitted tile by
 // tile (k_join_probe_emit_tiles: ranks inside the workgroup) and the exclusive scan runs over the tiles' totals, a thousandth of the rows
+// kChains: keys may have several build rows -- the slot names the chain's length (JoinKeySlot::count), so counting still costs one
+// slot per probe row and no step along positionLinks (flags & 2, outputSingleMatch: one output row per matching probe row)
+template <bool kChains>
 __global__ __launch_bounds__(256) void k_join_probe_count_keyed4(JoinCol probe_key, i32 n_probe, ProbeTable t, i32* __restrict__ head, i32* __restrict__ counts,
                                                                  int flags, unsigned long long* __restrict__ total, i32* __restrict__ tile_totals)
 {
@@ -1028,20 +1041,20 @@ __global__ __launch_bounds__(256) void k_join_probe_count_keyed4(JoinCol probe_k
         if (q < quads) {
             bool s[4];
             u64 k[4];
-            i32 jb[4];
+            i32 jb[4], jc[4];
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 const i64 i = 4 * q + r;
                 s[r] = i < n_probe && !jcol_is_null(probe_key, (i32)i);  // JoinProbe.java:89-91
                 k[r] = s[r] ? join_key_bits(probe_key, (i32)i) : 0ULL;
             }
-            pa_join_probe4(t, s, k, jb);
+            pa_join_probe4x<kChains>(t, s, k, jb, jc);
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 const i64 i = 4 * q + r;
                 if (i >= n_probe) continue;
                 const i32 h = s[r] ? jb[r] : -1;
-                const i32 c = (h != -1 || (flags & 1)) ? 1 : 0;
+                const i32 c = h != -1 ? ((kChains && !(flags & 2)) ? jc[r] : 1) : ((flags & 1) ? 1 : 0);
                 head[i] = h;
                 counts[i] = c;
                 here += c;
@@ -1121,7 +1134,7 @@ bool launch_join_probe_count_keyed(const JoinCol& probe_key, const int64_t* prob
 {
     if (n_probe <= 0) return false;
     // (with a $hashvalue channel the home slot comes from the channel's value: the row-by-row kernel reads it)
-    if (unique_keys && probe_hash == nullptr && (rank.words == nullptr || rank.min_key == bitmap.min_key || bitmap.bits == nullptr)) {
+    if (probe_hash == nullptr && (rank.words == nullptr || rank.min_key == bitmap.min_key || bitmap.bits == nullptr)) {
         ProbeTable t{};
         t.jslots = slots;
         t.jbits = rank.words ? nullptr : reinterpret_cast<const u64*>(bitmap.bits);
@@ -1131,10 +1144,16 @@ bool launch_join_probe_count_keyed(const JoinCol& probe_key, const int64_t* prob
         t.jwrap = wrap;
         t.jrank = reinterpret_cast<const pa_u32x4*>(rank.words);
         t.jrank_rows = rank.rows;
-        hipLaunchKernelGGL(k_join_probe_count_keyed4, grid_for(((int64_t)n_probe + 3) / 4), 256, 0, s, probe_key, n_probe, t, head, counts, flags,
-                           (unsigned long long*)total, tile_totals);
+        if (unique_keys) {
+            hipLaunchKernelGGL(k_join_probe_count_keyed4<false>, grid_for(((int64_t)n_probe + 3) / 4), 256, 0, s, probe_key, n_probe, t, head, counts, flags,
+                               (unsigned long long*)total, tile_totals);
+        }
+        else {  // (the tiles' totals belong to the emission of one-row chains: not here)
+            hipLaunchKernelGGL(k_join_probe_count_keyed4<true>, grid_for(((int64_t)n_probe + 3) / 4), 256, 0, s, probe_key, n_probe, t, head, counts, flags,
+                               (unsigned long long*)total, (i32*)nullptr);
+        }
         PA_HIP(hipGetLastError());
-        return tile_totals != nullptr;
+        return unique_keys && tile_totals != nullptr;
     }
     hipLaunchKernelGGL(k_join_probe_count_keyed, grid_for(n_probe), 256, 0, s, probe_key, (const i64*)probe_hash, n_probe, slots, mask, wrap, links, bitmap,
                        rank, head, counts, flags, (unsigned long long*)total);

@@ -28,14 +28,15 @@ void launch_join_build(const JoinKeys& build, const int64_t* raw_hash, int32_t n
 void launch_join_tag_slots(const int32_t* key, int64_t hash_size, const int64_t* raw_hash, uint64_t* tagged, uint32_t tagged_mask, hipStream_t s);
 void launch_join_probe_count(const JoinKeys& build, const JoinKeys& probe, const int64_t* probe_hash, int32_t n_probe, const uint64_t* tagged,
                              uint32_t mask, const int32_t* links, int32_t* head, int32_t* counts, int flags, hipStream_t s);  // flags: 1 probe-outer, 2 outputSingleMatch
-// Joins on one BIGINT / INTEGER / DATE key: the probe-side table holds the key itself next to the chain head and the head's
-// link (16 B per slot), so a probe row costs ONE random access -- no tag, no visit to the build key column, and no visit to
+// Joins on one BIGINT / INTEGER / DATE key: the probe-side table holds the key itself next to the chain head and the chain's
+// length (16 B per slot), so a probe row costs ONE random access -- no tag, no visit to the build key column, and no visit to
 // positionLinks unless the key really has duplicates.  probe_hash may be null: the raw hash (AbstractLongType.hash of the
 // value, combined as InterpretedHashGenerator does for one channel) is then computed in the kernel.
 struct JoinKeySlot {
     uint64_t key;
     int32_t head;   // build position, -1 = empty slot
-    int32_t next;   // positionLinks[head]
+    int32_t count;  // rows of the key = entries of the chain head -> positionLinks[head] -> ...: a probe row knows how many output rows
+                    // it gets without walking the chain (until round 4 the slot held positionLinks[head] and the counting pass walked)
 };
 // slots_mask + 1 = size of the probe-side table: a power of two >= 2 x the distinct keys (the caller uses 2 x build rows)
 void launch_join_key_slots(const int32_t* key, int64_t hash_size, const JoinCol& build_key, const int64_t* raw_hash, const int32_t* links,

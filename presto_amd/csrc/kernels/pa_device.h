@@ -358,8 +358,9 @@ struct PaFusedArgs {
 // k_join_probe_count_keyed (join_kernels.hip): bitmap first -- most probe rows of a selective join miss, and a clustered probe
 // side reads the bitmap almost sequentially -- then linear probing over 64-byte lines of four slots.
 // (A = PaFusedArgs or PaFpArgs: both carry the probe-side table as jslots / jmask / jwrap / jbits / jmin / jrange)
+// (rows_of_key: the rows of the key on the build side -- the slot's chain length, join_kernels.hpp JoinKeySlot::count -- when found)
 template <class A>
-__device__ __forceinline__ i32 pa_join_probe_from(const A& a, const u64 v, u32 pos)
+__device__ __forceinline__ i32 pa_join_probe_from(const A& a, const u64 v, u32 pos, i32* rows_of_key = nullptr)
 {
     const pa_u32x4* lines = (const pa_u32x4*)a.jslots;
     for (u32 seen = 0; seen <= a.jwrap;) {
@@ -372,7 +373,10 @@ __device__ __forceinline__ i32 pa_join_probe_from(const A& a, const u64 v, u32 p
             if ((u32)k < first) continue;
             const i32 cur = (i32)q[k].z;
             if (cur == -1) return -1;
-            if ((((u64)q[k].y << 32) | (u64)q[k].x) == v) return cur;
+            if ((((u64)q[k].y << 32) | (u64)q[k].x) == v) {
+                if (rows_of_key) *rows_of_key = (i32)q[k].w;
+                return cur;
+            }
         }
         seen += 4u - first;
         pos = (pos & ~a.jwrap) | ((base + 4u) & a.jwrap);
@@ -452,8 +456,9 @@ __device__ __forceinline__ void pa_join_rank4_read(const A& a, const bool (&s)[4
 // (bitmap word, slot, then the columns only matches read), and a wave of the row loop is then bound by latency, not bandwidth:
 // Q3's lineitem pages ran at 1.7 ms per 2^28 rows that way, three times the time of the filter alone.  A key equal to its
 // predecessor's (a probe side clustered by the key) reuses the predecessor's answer.  s[r]: row r probes; k[r]: its key.
-template <class A>
-__device__ __forceinline__ void pa_join_probe4(const A& a, const bool (&s)[4], const u64 (&k)[4], i32 (&jb)[4])
+// kCount: jc[r] = the rows of the key on the build side (1 over a key rank index: it stands on unique keys), 0 without a match
+template <bool kCount, class A>
+__device__ __forceinline__ void pa_join_probe4x(const A& a, const bool (&s)[4], const u64 (&k)[4], i32 (&jb)[4], i32 (&jc)[4])
 {
     bool dup[4], need[4];
 #pragma unroll
@@ -486,6 +491,10 @@ __device__ __forceinline__ void pa_join_probe4(const A& a, const bool (&s)[4], c
 #pragma unroll
         for (int r = 1; r < 4; r++) {
             if (dup[r]) jb[r] = jb[r - 1];
+        }
+        if (kCount) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) jc[r] = jb[r] >= 0 ? 1 : 0;
         }
         return;
     }
@@ -522,20 +531,36 @@ __device__ __forceinline__ void pa_join_probe4(const A& a, const bool (&s)[4], c
     }
 #pragma unroll
     for (int r = 0; r < 4; r++) {
-        i32 res = -1;
+        i32 res = -1, rows = 0;
         if (need[r] && (i32)s0[r].z != -1) {
-            if ((((u64)s0[r].y << 32) | (u64)s0[r].x) == k[r]) res = (i32)s0[r].z;
+            if ((((u64)s0[r].y << 32) | (u64)s0[r].x) == k[r]) {
+                res = (i32)s0[r].z;
+                rows = (i32)s0[r].w;
+            }
             else if ((i32)s1[r].z != -1) {
-                if ((((u64)s1[r].y << 32) | (u64)s1[r].x) == k[r]) res = (i32)s1[r].z;
-                else res = pa_join_probe_from(a, k[r], (pos[r] & ~a.jwrap) | ((pos[r] + 2u) & a.jwrap));  // a probe sequence longer than two slots
+                if ((((u64)s1[r].y << 32) | (u64)s1[r].x) == k[r]) {
+                    res = (i32)s1[r].z;
+                    rows = (i32)s1[r].w;
+                }
+                else res = pa_join_probe_from(a, k[r], (pos[r] & ~a.jwrap) | ((pos[r] + 2u) & a.jwrap), kCount ? &rows : nullptr);  // a probe sequence longer than two slots
             }
         }
         jb[r] = res;
+        if (kCount) jc[r] = res >= 0 ? rows : 0;
     }
 #pragma unroll
     for (int r = 1; r < 4; r++) {
-        if (dup[r]) jb[r] = jb[r - 1];
+        if (dup[r]) {
+            jb[r] = jb[r - 1];
+            if (kCount) jc[r] = jc[r - 1];
+        }
     }
+}
+template <class A>
+__device__ __forceinline__ void pa_join_probe4(const A& a, const bool (&s)[4], const u64 (&k)[4], i32 (&jb)[4])
+{
+    i32 unused[4];
+    pa_join_probe4x<false>(a, s, k, jb, unused);
 }
 
 // Does the key find a build row at all?  The key bitmap holds exactly the non-NULL keys of the build side (every one sets its bit,
