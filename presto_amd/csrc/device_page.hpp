@@ -27,7 +27,7 @@ struct DevPage {
     int32_t n = 0;
     std::vector<DevColumn> cols;
     // set: the page is the rows of these ranges, one behind the other (stable device pages that do not continue each other in
-    // memory, handed to ONE launch as a table: op_fused.cpp); n is their total, cols those of the first
+    // memory, handed to ONE launch as a table: op_fused.hpp); n is their total, cols those of the first
     std::shared_ptr<const std::vector<DevPage>> ranges;
 };
 

@@ -1,5 +1,5 @@
 // fused_plan.hpp -- what the fused scan-filter-project(-probe)-aggregate operator is asked to do, in the form its code generator
-// (fused_codegen.cpp + one fused_tier_*.cpp per kernel tier) and its host side (op_fused.cpp) share: the plan (Spec), the kernel
+// (fused_codegen.cpp + one fused_tier_*.cpp per kernel tier) and its host side (op_fused.hpp) share: the plan (Spec), the kernel
 // argument block's host mirror (FusedArgs), the tiers (Variant) and what a generated kernel tells the host about itself (KernelInfo).
 #pragma once
 
@@ -124,7 +124,7 @@ struct Spec {
     std::vector<bool> interned;
     // per channel: VARCHAR argument of min / max without a short bound.  The page's strings are interned and the kernels see a BIGINT
     // column in their place -- (rank of the string among the dictionary's strings) << 32 | id -- whose integer order is the strings'
-    // order; the operator re-ranks what it accumulated whenever a page brings new strings (op_fused.cpp: rank_values)
+    // order; the operator re-ranks what it accumulated whenever a page brings new strings (op_fused_intern.cpp: rank_values)
     std::vector<bool> ranked;
     bool any_ranked() const
     {

@@ -32,7 +32,7 @@ void launch_intern_rehash(const uint64_t* old_tag, const uint64_t* old_meta, con
 void launch_intern_lengths(const InternTable& t, const int32_t* ids, const uint8_t* nulls, int64_t n, int32_t* out_lengths, hipStream_t s);
 void launch_intern_bytes(const InternTable& t, const int32_t* ids, const uint8_t* nulls, int64_t n, const int32_t* out_offsets, uint8_t* out_bytes, hipStream_t s);
 
-// min / max over strings by rank (op_fused.cpp: rank_values).  image[i] = (ranks[ids[i]] + 1) << 32 | ids[i] -- a positive BIGINT whose
+// min / max over strings by rank (op_fused_intern.cpp: rank_values).  image[i] = (ranks[ids[i]] + 1) << 32 | ids[i] -- a positive BIGINT whose
 // order is the order of the strings, and whose low half names the string; 0 for the rows flagged in `nulls` (may be null)
 void launch_rank_image(const int32_t* ids, const uint8_t* nulls, const uint32_t* ranks, int64_t n, int64_t* image, hipStream_t s);
 // accumulator words holding such images -- as pa_img_i64 leaves them, complemented for min; 0 = no value yet -- brought up to date with

@@ -1,5 +1,5 @@
 // join_source.hpp -- the lookup source a build operator publishes and its probe-side operators read (op_join.cpp builds it;
-// LookupJoinOperator and the fused probe of op_fused.cpp read it).
+// LookupJoinOperator and the fused probe of op_fused.hpp read it).
 // (LookupSourceFactory / JoinBridge: core/trino-main/src/main/java/io/trino/operator/join/PartitionedLookupSourceFactory.java:179-206;
 //  PagesHash.java:54-126 for what the table holds)
 #pragma once

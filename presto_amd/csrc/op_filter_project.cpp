@@ -86,7 +86,7 @@ struct FpArgs {  // host mirror of PaFpArgs
 // Probe stage (FilterAndProject -> LookupJoin (INNER) in one pass; pa_fused_join_create): a row is selected when the filter keeps it
 // AND its key finds a build row -- the lookup source has one integer key without duplicates, so at most one -- and the output page
 // is [probe output channels (projections), build output channels]: the build columns are "virtual" channels n_in + v of the
-// generated code, read at the build position (as in op_fused.cpp's probe stage).
+// generated code, read at the build position (as in op_fused.hpp's probe stage).
 struct FpJoin {
     std::shared_ptr<LookupSourceImpl> ls;
     OwnedExpr key;                  // the probe join key (a projection of the FilterAndProject)
@@ -779,7 +779,7 @@ private:
 
     // One code object per (plan, column-layout signature, variant, device), shared by every operator instance of the process: an operator
     // lives for one query (OperatorFactory.createOperator) while the generated code of its plan node does not change -- generating and
-    // hashing the source again for every instance cost 80 us per pipeline of Q3 (as in op_fused.cpp).
+    // hashing the source again for every instance cost 80 us per pipeline of Q3 (as in op_fused.hpp).
     static std::mutex& shared_mutex()
     {
         static std::mutex* m = new std::mutex();

@@ -46,7 +46,7 @@ pa_operator* make_fused_aggregation(const pa_fused_aggregation_desc* desc);
 // (Hash)AggregationOperator over plain channels (abi.cpp: the fused operator with identity projections, or the reference-state adapter)
 pa_operator* make_hash_aggregation(const pa_hash_aggregation_desc* desc);
 // FilterAndProject -> LookupJoin -> aggregation (op_fused_join.cpp); make_fused_probe_aggregation is its one-kernel form
-// (op_fused.cpp), valid only for keyed lookup sources without duplicate keys -- probe_source_is_unique, once built
+// (op_fused.hpp), valid only for keyed lookup sources without duplicate keys -- probe_source_is_unique, once built
 pa_operator* make_fused_join_aggregation(const pa_fused_join_aggregation_desc* desc, pa_lookup_source* bridge);
 pa_operator* make_fused_probe_aggregation(const pa_fused_join_aggregation_desc* desc, pa_lookup_source* bridge);
 // FilterAndProject -> LookupJoin (op_fused_join.cpp); make_filter_project_probe is its one-pass form (op_filter_project.cpp), valid
@@ -63,7 +63,7 @@ pa_operator* make_lookup_join(const pa_lookup_join_desc* desc, pa_lookup_source*
 pa_operator* make_topn(const pa_topn_desc* desc);
 pa_operator* make_order_by(const pa_order_by_desc* desc);
 pa_operator* make_lookup_outer(const pa_lookup_join_desc* desc, pa_lookup_source* bridge);
-// the consumer of an aggregation's output is a TopN over it: groups that cannot be among its n best rows may be left out (op_fused.cpp);
+// the consumer of an aggregation's output is a TopN over it: groups that cannot be among its n best rows may be left out (op_fused.hpp);
 // false: the operator does not take the hint (it emits everything)
 bool aggregation_set_output_topn(pa_operator* op, int64_t n, const int32_t* sort_channels, const int32_t* sort_orders, int32_t count);
 // join-side dynamic filter: the existence bitmap of a built lookup source (false: none -- not built, not a single integer key,

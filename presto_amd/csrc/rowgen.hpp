@@ -16,7 +16,7 @@ struct RowInputs {
 };
 
 // How the generated loops name a page's buffers: the kernel argument block (a.v[c], a.o[c], a.nl[c], a.n), or -- `ranged` --
-// locals of the loop over a table of row ranges (RV<c>, RO<c>, RNL<c>, RN; op_fused.cpp, the pa_fused_ranges kernels).
+// locals of the loop over a table of row ranges (RV<c>, RO<c>, RNL<c>, RN; op_fused.hpp, the pa_fused_ranges kernels).
 struct ColumnNames {
     bool ranged = false;
     std::string v(int c) const { return ranged ? "RV" + std::to_string(c) : "a.v[" + std::to_string(c) + "]"; }
