@@ -251,6 +251,8 @@ class DeviceWorkload:
         self.comm, self.owns_comm = comm, False
         if world > 1 and comm is None:
             self.comm, self.owns_comm = make_comm(args), True
+        if getattr(args, "rccl_failed", None):
+            self.q3_on = False   # (its exchange steps are what RCCL is for)
 
         # Row-range shards.  weak: rank r holds rows [r n, (r + 1) n) of the SF x world table, n = rows of one SF table;
         # strong: the ranks split the ONE SF table, rank r holds rows [N r / W, N (r + 1) / W) (boundaries on multiples of `multiple`).
@@ -527,15 +529,35 @@ def make_comm(args):
         watchdog = threading.Timer(args.preflight_timeout, bail)
         watchdog.daemon = True
         watchdog.start()
+    comm, failure = None, None
     try:
         comm = Comm.rccl(CONTROL) if rccl_transport(args) else Comm.host(CONTROL)
         comm.preflight(1 << 20)
     except Exception as e:
-        print("bench.py: communicator pre-flight failed: %s: %s" % (type(e).__name__, e), file=sys.stderr, flush=True)
-        os._exit(PREFLIGHT_FAILED_EXIT_CODE)
+        failure = "%s: %s" % (type(e).__name__, e)
+        print("bench.py: communicator pre-flight failed: %s" % failure, file=sys.stderr, flush=True)
+        if not rccl_transport(args):
+            os._exit(PREFLIGHT_FAILED_EXIT_CODE)
     finally:
         if watchdog is not None:
             watchdog.cancel()
+    if rccl_transport(args):
+        # The ranks decide TOGETHER, over the control plane (which does not depend on RCCL): when RCCL answered with an error on some rank
+        # (and every rank came back -- one that hangs inside RCCL is the watchdog's, and then the control plane's time-out ends the others),
+        # all of them go on over the library's host transport.  The headline needs no more than that -- the scans run without a data-path
+        # collective and the PARTIAL states are a few KB per step -- so the job still yields its number; the Q3 leg, whose exchange moves
+        # GBs between the GPUs, is left out, and the line says so (config.data_plane, q3.error).
+        failures = [f for f in CONTROL.all_gather(failure) if f]
+        if failures:
+            args.rccl_failed = failures[0]
+            print("bench.py: RCCL is not available to this job (%s) -- the ranks go on over the host transport, without the Q3 leg" % failures[0],
+                  file=sys.stderr, flush=True)
+            try:
+                comm = Comm.host(CONTROL)
+                comm.preflight(1 << 16)
+            except Exception as e:
+                print("bench.py: host transport pre-flight failed: %s: %s" % (type(e).__name__, e), file=sys.stderr, flush=True)
+                os._exit(PREFLIGHT_FAILED_EXIT_CODE)
     return comm
 
 
@@ -789,8 +811,9 @@ def main(argv=None, workload_factory=None, out=None):
         if n_dev <= 0:
             print("bench.py: no gfx950 device (pa_device_count = %d)" % n_dev, file=sys.stderr)
             return 2
-        # RCCL: one rank per GPU.  Host transport (rehearsal): the ranks share what is there
-        device = local_rank if rccl_transport(args) else local_rank % n_dev
+        # RCCL: one rank per GPU.  Host transport (rehearsal): the ranks share what is there.  (More ranks than GPUs under RCCL: the
+        # ranks share devices too -- RCCL refuses that with an error, and make_comm's fall-back to the host transport takes over.)
+        device = local_rank % n_dev
 
     workload = make_workload(args, rank, world, device)
     scaling = getattr(workload, "scaling", "weak")
@@ -834,7 +857,8 @@ def main(argv=None, workload_factory=None, out=None):
                        "parallelism_note": "no data-path collective in the Q1/Q6 scans; with more than one rank the Step.PARTIAL states travel in one small "
                                            "all-gather over the library's communicator to the Step.FINAL operators on rank 0, inside the step; Q3 (the `q3` "
                                            "object) shuffles its join sides between the ranks",
-                       "data_plane": None if world == 1 else ("RCCL (library's /opt/rocm stack)" if rccl_transport(args) else "host transport over gloo (rehearsal)"),
+                       "data_plane": None if world == 1 else (("host transport over the control plane -- RCCL failed: %s" % args.rccl_failed)[:300] if getattr(args, "rccl_failed", None)
+                                                               else ("RCCL (library's /opt/rocm stack)" if rccl_transport(args) else "host transport over gloo (rehearsal)")),
                        "control_plane": None if world == 1 else ("local socket between the ranks (presto_amd/control.py), no torch in the process" if on_device
                                                                    else "torch.distributed gloo (checker workload)")},
             "detail_path": args.detail,
@@ -848,6 +872,8 @@ def main(argv=None, workload_factory=None, out=None):
             detail["roofline_q6"] = r6
         if other is not None:
             detail[other["scaling"]] = other
+        if q3 is None and getattr(args, "rccl_failed", None) and args.q3:
+            q3 = {"error": "left out: the exchange steps of Q3 need the RCCL communicator, which failed its creation or pre-flight"}
         if q3 is not None:
             detail["q3"] = q3
         detail["results"] = {k: printable(v) for k, v in workload.results.items()}

@@ -33,6 +33,26 @@ def test_bench_two_ranks_as_a_plain_subprocess(gpu, oracle, tmp_path):
     assert line["roofline"]["frac"] > 0 and line["roofline"]["launches"] > 0 and line["roofline"]["kernel"].startswith("pa_fused_lds_")
 
 
+def test_bench_goes_on_over_the_host_transport_when_rccl_refuses(gpu, oracle, tmp_path):
+    """`--backend nccl` with two ranks on the one GPU: RCCL refuses the communicator (two ranks on one device) with an error on every
+    rank.  The ranks agree over the control plane, go on over the host transport and still deliver the headline -- both scaling modes,
+    results equal to the oracle's -- without the Q3 leg; the line says what happened (config.data_plane, q3.error) and the exit code is 0."""
+    sf = 0.05
+    path = str(tmp_path / "detail.json")
+    r = run_bench(["--gpus", "2", "--backend", "nccl", "--sf", str(sf), "--steps", "2", "--warmup", "1", "--cpu-rows", "0", "--preflight-timeout", "60",
+                   "--detail", path], timeout=900)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    line = check_line_shape(r.stdout.decode())
+    d = json.load(open(path))
+    rows = tpch.lineitem_rows(sf)
+    assert d["torch_imported"] is False
+    assert d["config"]["data_plane"].startswith("host transport over the control plane -- RCCL failed"), d["config"]["data_plane"]
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["value"] > 0 and d["weak"]["value"] > 0
+    assert "error" in d["q3"] and "error" in line["q3"]
+    check_q1_q6(d["results"], *oracle_q1_q6(oracle, sf, rows))
+    check_q1_q6(d["weak"]["results"], *oracle_q1_q6(oracle, sf * 2, rows * 2))
+
+
 def test_bench_one_rank_default_shape_small(gpu, oracle, tmp_path):
     """`--gpus 1`: no launcher, no merge; the side legs are all in the detail file, their one-number summaries in the line."""
     sf = 0.05
