@@ -225,8 +225,22 @@ def q3_cpu_baseline(sf=1.0, warmups=1, runs=3):
             ts.append(time.perf_counter() - t0)
     ts.sort()
     rows = nc + no + nl
+    # ... and on T threads (T = the physical cores): T instances of the same plan side by side over the same read-only tables -- what T
+    # tasks of the reference would do with T copies of the work (no exchange between them: an upper bound for a partitioned join)
+    threads = max(1, physical_cores())
+
+    def many():
+        workers = [threading.Thread(target=O.q3, args=(customer, orders, lineitem), kwargs={"top_n": 10}) for _ in range(threads)]
+        t0 = time.perf_counter()
+        [w.start() for w in workers]
+        [w.join() for w in workers]
+        return time.perf_counter() - t0
+    many()
+    tm = sorted(many() for _ in range(runs))
     return {"value": rows / ts[len(ts) // 2], "best": rows / ts[0], "unit": "rows/s", "cores": 1, "kind": "port", "cpu_model": cpu_model(),
             "warmups": warmups, "runs": runs,
+            "all_threads": {"value": threads * rows / tm[len(tm) // 2], "best": threads * rows / tm[0], "threads": threads, "unit": "rows/s",
+                            "sample": "%d instances of the same composition side by side, one per physical core, over the same tables" % threads},
             "sample": "TPC-H SF%g tables of the same generator (%d + %d + %d rows), the oracle's Q3 operator composition incl. TopN on one thread "
                       "(one reference Driver per pipeline)" % (sf, nc, no, nl)}
 
@@ -721,7 +735,8 @@ def summary_line(detail):
             line["q3"] = {"error": q3["error"][:160]}
         else:
             line["q3"] = {"value": sig(q3["value"]), "ms_per_step": sig(q3["ms_per_step"]), "frac": sig(q3["roofline"]["frac"]),
-                          "cpu_rows_s": sig((q3.get("cpu_baseline") or {}).get("value"))}
+                          "cpu_rows_s": sig((q3.get("cpu_baseline") or {}).get("value")),
+                          "cpu_rows_s_all_cores": sig(((q3.get("cpu_baseline") or {}).get("all_threads") or {}).get("value"))}
             if isinstance(q3.get("exchange"), dict):
                 line["q3"]["xgmi_GBps"] = sig(q3["exchange"].get("xgmi_GBps"))
     h = detail.get("h2d")
