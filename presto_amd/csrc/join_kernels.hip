@@ -300,7 +300,8 @@ __global__ __launch_bounds__(256) void k_join_keyed_build(JoinCol build_key, con
                 i32 cur = __hip_atomic_load(&slots[pos].head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (cur == -1) {
                     cur = atomicCAS(&slots[pos].head, -1, kSlotBusy);
-                    if (cur == -1) {  // claimed: key first, then the position
+                    if (cur == -1) {  // claimed: key (and the chain's length while no second row shows: k_join_keyed_next counts then) first, then the position
+                        __hip_atomic_store(&slots[pos].count, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         __hip_atomic_store(&slots[pos].key, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                         atomicMax(&slots[pos].head, p);
@@ -853,7 +854,7 @@ __global__ __launch_bounds__(256) void k_join_probe_count_keyed(JoinCol probe_ke
         }
         head[r] = h;
         i32 c = 0;
-        if (h != -1) c = (flags & 2) ? 1 : (rank.words ? 1 : rows_of_key);  // (the slot knows its chain's length: no walk here)
+        if (h != -1) c = ((flags & 2) || rank.words || rows_of_key < 1) ? 1 : rows_of_key;  // (the slot knows its chain's length: no walk here)
         counts[r] = (c == 0 && (flags & 1)) ? 1 : c;  // DefaultPageJoiner.outerJoinCurrentPosition: one NULL-extended row
         mine += (c == 0 && (flags & 1)) ? 1 : c;
     }
@@ -1054,7 +1055,7 @@ __global__ __launch_bounds__(256) void k_join_probe_count_keyed4(JoinCol probe_k
                 const i64 i = 4 * q + r;
                 if (i >= n_probe) continue;
                 const i32 h = s[r] ? jb[r] : -1;
-                const i32 c = h != -1 ? ((kChains && !(flags & 2)) ? jc[r] : 1) : ((flags & 1) ? 1 : 0);
+                const i32 c = h != -1 ? ((kChains && !(flags & 2) && jc[r] > 1) ? jc[r] : 1) : ((flags & 1) ? 1 : 0);
                 head[i] = h;
                 counts[i] = c;
                 here += c;

@@ -765,3 +765,27 @@ def test_retained_build_page_is_read_in_place_until_the_lookup_source_goes(gpu, 
     builder.close()
     bridge.destroy()
     assert sorted(released) == ["first", "second"]
+
+
+@pytest.mark.parametrize("duplicates", [False, True])
+def test_keyed_table_with_a_hash_channel_and_no_rank_index(gpu, oracle, duplicates):
+    """One integer key, a $hashvalue channel on both sides and a NULL build key (no key rank index): the probe reads the slot table row by
+    row and takes a match's output rows from the slot's chain length -- 1 for a key on one build row, set when the slot is claimed (a build
+    without duplicate keys never runs the pass that counts the chains: round 4's first version emitted nothing here)."""
+    rng = np.random.default_rng(77)
+    nb, npr = 3000, 20_000
+    keys = (rng.permutation(3 * nb)[:nb] * 7 - 100).astype(np.int64)
+    if duplicates:
+        keys[nb // 2:] = keys[: nb - nb // 2]
+    nulls = np.zeros(nb, dtype=bool)
+    nulls[5] = True
+    pk = np.where(rng.random(npr) < 0.6, keys[rng.integers(0, nb, npr)], rng.integers(-500, 25 * nb, npr)).astype(np.int64)
+    types = [abi.BIGINT, abi.INTEGER, abi.BIGINT]
+    h = lambda k: oracle.hash_page(Page([Block.bigint(k)], len(k)), [0])
+    build = [Page([Block.bigint(keys, nulls), Block.integer(np.arange(nb)), Block.bigint(h(keys))], nb)]
+    probe = [Page([Block.bigint(pk), Block.integer(np.arange(npr)), Block.bigint(h(pk))], npr)]
+    rows, pairs, _ = gpu_join(build, types, [0], [1], probe, types, [0], [0, 1], build_hash=2, probe_hash=2)
+    orows, opairs, _ = oracle_join(oracle, build, types, [0], [1], probe, types, [0], [0, 1], build_hash=2, probe_hash=2)
+    assert len(orows) > npr // 3 and rows == orows
+    for (gp, gb), (op_, ob) in zip(pairs, opairs):
+        assert np.array_equal(gp, op_) and np.array_equal(gb, ob)

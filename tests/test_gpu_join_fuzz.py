@@ -29,7 +29,7 @@ def key_block(rng, t, n, card, sparse, null_share, values=None):
     return Block.varchar([None if (nulls is not None and nulls[i]) else b"k%05d%s" % (x, b"_" * (x % 9)) for i, x in enumerate(v)])
 
 
-@pytest.mark.parametrize("seed", list(range(int(os.environ.get("PA_FUZZ_SEEDS", "24")))))
+@pytest.mark.parametrize("seed", list(range(int(os.environ.get("PA_FUZZ_SEEDS", "64")))))
 def test_random_joins(gpu, oracle, seed):
     rng = np.random.default_rng(5200 + seed)
     kinds = [abi.BIGINT, abi.INTEGER, abi.DATE, abi.DOUBLE, abi.VARCHAR]
