@@ -357,3 +357,26 @@ def test_pipelined_probe_loop_equals_the_plain_loop(gpu, oracle, n, clustered, m
             monkeypatch.setenv("PRESTO_AMD_BROW_PIPE", level)
         rows = fused_rows(probe, build, [1, 2], [0, 1, 2, 3], jt, group_by, aggs, expected_groups=len(keys))
         rows_equal_ignore_order(rows, expected, rel=1e-9)
+
+
+@pytest.mark.parametrize("seed", list(range(int(__import__("os").environ.get("PA_FUZZ_SEEDS", "16")))))
+def test_random_fused_probes_over_a_key_rank_index(gpu, oracle, seed):
+    """Seeded shapes of the one-kernel execution over a lookup source with a key rank index (the pipelined page loop of the build-row
+    tier, and the other tiers' quad loops): page sizes that leave partial quads and waves, clustered or not, several pages, group keys
+    that make the group the build row or not, aggregates with lazy (probe-side) and build-side inputs."""
+    rng = np.random.default_rng(9100 + seed)
+    n = int(rng.choice([1, 2, 5, 63, 64, 257, 1023, 4099, 30011, 131075]))
+    pages = int(rng.integers(1, 4))
+    clustered = bool(rng.integers(0, 2))
+    key_range = max(int(n * rng.choice([0.5, 1.5, 4.0])), 8)
+    keys = rng.permutation(key_range)[: max(key_range // 2, 1)]
+    if rng.integers(0, 2):
+        keys = np.sort(keys)
+    build = [build_page(rng, keys, null_keys=False)]
+    probe = probe_pages(rng, pages, n, key_range, null_keys=bool(rng.integers(0, 2)), clustered=clustered)
+    group_by = [[0, 4, 5], [3, 5], [5], []][int(rng.integers(0, 4))]
+    aggs = AGGS + ([(abi.AGG_SUM, 6, abi.DOUBLE)] if rng.integers(0, 2) else [])
+    probe_out, build_out = [0, 1, 2, 3], [1, 2, 3]
+    expected, jt = oracle_rows(oracle, probe, build, build_out, probe_out, group_by, aggs)
+    rows = fused_rows(probe, build, build_out, probe_out, jt, group_by, aggs, expected_groups=max(len(keys), 16))
+    rows_equal_ignore_order(rows, expected, rel=1e-9)
