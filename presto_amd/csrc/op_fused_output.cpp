@@ -144,12 +144,16 @@ bool FusedAggregationOperator::emit_on_device(const KernelInfo& ki, int64_t grou
         const double j = (double)topn_hint_.n * (double)kSample / (double)cap;
         const int64_t rank = (int64_t)std::ceil(j + 8.0 + 4.0 * std::sqrt(j));
         if (c0 >= 0 && c0 < n && a.col[c0].kind != GT_EMIT_HASH && cap >= 4 * kSample && rank <= kSample / 8) {
-            uint64_t* keys = static_cast<uint64_t*>(topn_keys.ensure((size_t)cap * 8 + 64));
-            uint64_t* bound = keys + cap;
-            launch_gt_emit_keys(a, c0, topn_hint_.orders[0], keys, s);
-            launch_topn_sample_bound(PA_TOPN_KEYS, keys, nullptr, nullptr, cap, 1, kSample, rank, nullptr, bound, s);
-            a.filter_keys = keys;
+            // (the keys of the kSample sampled slots only -- slot j * (cap / kSample), the sample launch_topn_sample_bound would draw from
+            // keys of every slot -- and k_gt_emit computes a slot's key again from the words it reads anyway: until round 4 the keys
+            // of all `cap` slots were written out and read back twice, 0.35 GB for Q3's 14.6 M build rows)
+            uint64_t* keys = static_cast<uint64_t*>(topn_keys.ensure((size_t)kSample * 8 + 64));
+            uint64_t* bound = keys + kSample;
+            launch_gt_emit_keys_strided(a, c0, topn_hint_.orders[0], cap / kSample, kSample, keys, s);
+            launch_topn_sample_bound(PA_TOPN_KEYS, keys, nullptr, nullptr, kSample, 1, kSample, rank, nullptr, bound, s);
             a.filter_bound = bound;
+            a.filter_col = c0;
+            a.filter_order = topn_hint_.orders[0];
             bounded = true;
         }
     }
@@ -162,7 +166,6 @@ bool FusedAggregationOperator::emit_on_device(const KernelInfo& ki, int64_t grou
         read_back(flags, a.null_flags, sizeof(flags), s);   // (one wait for both)
         if (!bounded || (int64_t)(uint32_t)h_ctl_[7] >= topn_hint_.n) break;
         bounded = false;
-        a.filter_keys = nullptr;
         a.filter_bound = nullptr;
     }
     if (keys_from_build_columns || bounded) groups = (int64_t)(uint32_t)h_ctl_[7];

@@ -491,6 +491,19 @@ __device__ __forceinline__ void gt_emit_slot(const GtEmitArgs& a, u64 i, u64 g)
     }
 }
 
+__device__ __forceinline__ u64 pa_sort_key(i32 type, u64 bits, bool is_null, i32 sort_order);
+// the order-preserving key of output column `column` of the group in slot i
+__device__ __forceinline__ u64 gt_emit_sort_key(const GtEmitArgs& a, int column, i32 sort_order, u64 i)
+{
+    const GtEmitCol& col = a.col[column];
+    const u64* kw = (const u64*)a.keys + i * (u64)a.W;
+    i64 row_hash = 0;
+    u64 bits;
+    bool is_null;
+    gt_emit_value(a, col, i, kw, (const u64*)a.words, row_hash, bits, is_null);
+    return pa_sort_key(col.type, bits, is_null, sort_order);
+}
+
 __global__ __launch_bounds__(256) void k_gt_emit(GtEmitArgs a)
 {
     // Output positions are handed out so that one store instruction of a wave writes CONSECUTIVE rows of every output block:
@@ -503,14 +516,15 @@ __global__ __launch_bounds__(256) void k_gt_emit(GtEmitArgs a)
     const i64 tiles = (cap + 4095) >> 12;
     const u64* tag = (const u64*)a.tag;
     const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    const u64 bound = a.filter_keys ? *a.filter_bound : ~0ULL;  // (a consumer's TopN: groups beyond the bound are left out)
+    const bool filtered = a.filter_bound != nullptr;  // (a consumer's TopN: groups beyond the bound are left out)
+    const u64 bound = filtered ? *a.filter_bound : ~0ULL;
     for (i64 tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
         const i64 first = (tile << 12) + threadIdx.x;
         u32 occ = 0;
 #pragma unroll
         for (int j = 0; j < 16; j++) {
             const i64 i = first + (i64)j * 256;
-            if (i < cap && tag[(u64)i * a.st.tag] != a.st.empty && (!a.filter_keys || a.filter_keys[i] <= bound)) occ |= 1u << j;
+            if (i < cap && tag[(u64)i * a.st.tag] != a.st.empty && (!filtered || gt_emit_sort_key(a, a.filter_col, a.filter_order, (u64)i) <= bound)) occ |= 1u << j;
         }
 #pragma unroll
         for (int j = 0; j < 16; j++) {
@@ -587,6 +601,19 @@ __global__ __launch_bounds__(256) void k_gt_emit_keys(GtEmitArgs a, int column, 
         }
         keys[i] = key;
     }
+}
+__global__ __launch_bounds__(256) void k_gt_emit_keys_strided(GtEmitArgs a, int column, int sort_order, i64 stride, i64 count, u64* __restrict__ keys)
+{
+    const u64* tag = (const u64*)a.tag;
+    for (i64 j = (i64)blockIdx.x * 256 + threadIdx.x; j < count; j += (i64)gridDim.x * 256) {
+        const i64 i = j * stride;
+        keys[j] = tag[(u64)i * a.st.tag] != a.st.empty ? gt_emit_sort_key(a, column, sort_order, (u64)i) : ~0ULL;
+    }
+}
+void launch_gt_emit_keys_strided(const GtEmitArgs& args, int column, int sort_order, int64_t stride, int64_t count, uint64_t* keys, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_gt_emit_keys_strided, grid_for(count, 256), 256, 0, s, args, column, sort_order, (i64)stride, (i64)count, (u64*)keys);
+    PA_HIP(hipGetLastError());
 }
 void launch_gt_emit_keys(const GtEmitArgs& args, int column, int sort_order, uint64_t* keys, hipStream_t s)
 {

@@ -77,15 +77,18 @@ struct GtEmitArgs {
     int32_t W, NW, ncols;
     uint32_t* counter;
     uint32_t* null_flags;        // [ncols]: set to 1 when the column wrote a NULL
-    // set: only the groups whose filter_keys[slot] <= *filter_bound are emitted (the consumer is a TopN: launch_gt_emit_keys)
-    const uint64_t* filter_keys;
+    // filter_bound set: only the groups whose order-preserving key of output column filter_col under filter_order (launch_gt_emit_keys'
+    // key, computed from the table on the way) is <= *filter_bound are emitted -- the consumer is a TopN
     const uint64_t* filter_bound;
+    int32_t filter_col, filter_order;
     GtEmitCol col[GT_EMIT_MAX_COLS];
 };
 void launch_gt_emit(const GtEmitArgs& args, hipStream_t s);
 // keys[slot] = the order-preserving 64-bit key (as TopN's, topn_kernels.hpp) of output column `column` under `sort_order`, ~0 for
 // slots without a group; kinds KEY / COLUMN / STATE / COUNT / SUM / AVG / MINMAX
 void launch_gt_emit_keys(const GtEmitArgs& args, int column, int sort_order, uint64_t* keys, hipStream_t s);
+// the same for `count` evenly spaced slots only: keys[j] = the key of slot j * stride (the sample a TopN bound is drawn from)
+void launch_gt_emit_keys_strided(const GtEmitArgs& args, int column, int sort_order, int64_t stride, int64_t count, uint64_t* keys, hipStream_t s);
 // out[i] = in[0] + ... + in[i - 1] for i in [0, n], n <= 5119 (static_kernels.hip)
 void launch_exclusive_prefix_i64(const int64_t* in, int32_t n, int64_t* out, hipStream_t s);
 
