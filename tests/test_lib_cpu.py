@@ -235,3 +235,26 @@ def test_q3_orders_probe_inside_filter_and_project_generates_and_compiles_for_gf
     scatter2 = scatter2[scatter2.index("void PA_K(pa_fp_scatter)("):]
     assert scatter2.count("pa_key_of(a") >= 4 and "pa_join_probe4(a, pa_s, pa_k, pa_jb);" in scatter2 and "pa_jb[3]" in scatter2
     assert L.pa_codegen_compile_fused_join_probe(C.byref(d2), C.byref(build2)) > 1000, L.pa_last_error()
+
+
+def test_committed_counter_passes_are_of_the_kernels_the_bench_runs():
+    """profiles/pmc_traffic.json is keyed by kernel NAME (tier + the first 8 hex digits of the code object's key), and bench.py quotes
+    `roofline.traffic` only for a kernel of that name.  A change of the generated source (pa_device.h, the generator, the expression
+    printer) gives the kernels new names and the line `traffic: null`: this test says so -- as a warning, the line stays valid -- so
+    that the counter passes (scripts/collect_profiles.sh + scripts/summarize_profile.py) are collected again."""
+    import json
+    import os
+    import warnings
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "pmc_traffic.json")
+    if not os.path.exists(path):
+        pytest.skip("no committed counter passes")
+    names = set(json.load(open(path)).get("kernels", {}))
+    d6, k6 = fused_aggregation_desc(tpch.Q6_TYPES, tpch.q6_filter(), tpch.q6_projections(), [], tpch.Q6_AGGREGATES)
+    d1, k1 = fused_aggregation_desc(tpch.Q1_TYPES, tpch.q1_filter(), tpch.q1_projections(), tpch.Q1_GROUP_BY, tpch.Q1_AGGREGATES,
+                                    type_params=tpch.Q1_TYPE_PARAMS)
+    expected = {"pa_fused_global_" + fused_source(d6, 0)[1][:8], "pa_fused_lds_" + fused_source(d1, 1)[1][:8]}
+    missing = expected - names
+    if missing:
+        warnings.warn("profiles/pmc_traffic.json holds no counter pass of %s: bench.py will print roofline.traffic = null until "
+                      "scripts/collect_profiles.sh has been run again" % sorted(missing))
+    assert all(len(n.rsplit("_", 1)[1]) == 8 for n in expected)
