@@ -348,13 +348,18 @@ class PartialStateMerger:
         for chunk in chunks:
             n = struct.unpack("<q", chunk[:8])[0]
             per_rank.append(pickle.loads(chunk[8:8 + n]))
-        out = {}
+        # every FINAL operator is given its page before the first result is asked for: the operators work on streams of their own,
+        # so the launch chains of Q6's and Q1's FINAL steps overlap instead of following each other
+        ops = {}
         for name in partial_pages:
             op = make_final_operator[name]()
             cols = _concat_payloads([payload[name] for payload in per_rank])   # rank order
             if cols is not None:
                 op.addInput(_state_page(cols))
             op.finish()
+            ops[name] = op
+        out = {}
+        for name, op in ops.items():
             out[name] = op.getOutput()
             if hasattr(op, "close"):
                 op.close()
