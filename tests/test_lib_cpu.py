@@ -123,6 +123,30 @@ def test_q3_probe_stage_kernels_generate_and_compile_for_gfx950():
     assert lib().pa_codegen_compile_fused_join(C.byref(dv), C.byref(bad), -1) == abi.ERR_NOT_SUPPORTED
 
 
+def test_q3_probe_kernel_page_loops_generate_and_compile_for_gfx950(monkeypatch):
+    """The build-row tier's page loop in its three forms: the four-stage software pipeline over a key rank index (the default, beside the
+    plain loop for lookup sources without one), the plain loop alone (PRESTO_AMD_BROW_PIPE=0) and the loop that loads only the next quad's
+    columns ahead (=1).  In the pipeline every load is unconditional: no `if (jb` in front of a lazy channel's load."""
+    from presto_amd import q3
+    from presto_amd.operators import fused_join_aggregation_desc, hash_builder_desc
+    build, kb = hash_builder_desc(q3.ORDERS_JOINED_TYPES, [0], [1, 2])
+    d, keep = fused_join_aggregation_desc(tpch.Q3_LINEITEM_TYPES, tpch.q3_lineitem_filter(), tpch.q3_lineitem_projections(), [0], [0, 1],
+                                          q3.AGG_TYPES, q3.AGG_GROUP_BY, q3.AGG_AGGREGATES)
+    src = fused_join_source(d, build, 6)
+    assert "if (a.jrank) {" in src and "pa_join_rank4_issue(a, djs, djk, dw);" in src and "pa_join_rank4_read(a, djs, djk, dw, jb);" in src
+    kernel = src[src.index("void PA_K(pa_fused_probe_brow)("):]
+    piped = kernel[kernel.index("if (a.jrank) {"):kernel.index("    } else {\n")]
+    assert "(pjb0 >= 0 ? 4 * pq + 0 : rs)" in piped and "if (jb" not in piped and "it < n_it + 2" in piped
+    sources = {src}
+    for level in ("0", "1"):
+        monkeypatch.setenv("PRESTO_AMD_BROW_PIPE", level)
+        s = fused_join_source(d, build, 6)
+        assert "pa_join_rank4_issue" not in s[s.index("void PA_K(pa_fused_probe_brow)("):]
+        assert lib().pa_codegen_compile_fused_join(C.byref(d), C.byref(build), 6) > 1000, lib().pa_last_error()
+        sources.add(s)
+    assert len(sources) == 3
+
+
 def test_expression_forms_compile():
     types = [abi.BIGINT, abi.DOUBLE, abi.BOOLEAN, abi.INTEGER, abi.VARCHAR, abi.DATE]
     a, b, c, d, s, t = (field(i, ty) for i, ty in enumerate(types))
